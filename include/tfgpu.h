@@ -1,0 +1,279 @@
+/*
+ * tfgpu.h — C ABI of the MI355X-native columnar transform stage for Transferia.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of
+ * its own (it is 100 % Go); the entry points below are what a cgo shim that
+ * implements the reference's plugin interfaces would bind:
+ *
+ *   abstract.Transformer{Type,Description,Suitable,ResultSchema,Apply}
+ *       /root/reference/pkg/abstract/transformer.go:32-38
+ *   transformer.Register / transformer.New (config arrives as JSON-remapped map)
+ *       /root/reference/pkg/transformer/registry.go:34-47
+ *   parsers.Parser{Do,DoBatch}            pkg/parsers/abstract.go:35-38
+ *   serializer.BatchSerializer            pkg/serializer/interface.go:11-26
+ *   s3 CSVReader.Read / parseCSVRows      pkg/providers/s3/reader/registry/csv/reader_csv.go:85-247
+ *   httpuploader.MarshalCItoJSON          pkg/providers/clickhouse/httpuploader/marshal.go:82-125
+ *
+ * Conventions
+ *   - every function returns a tfgpu_status (0 = ok) unless stated otherwise;
+ *     tfgpu_last_error() returns a thread-local human-readable message.
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary.
+ *   - plans are immutable after creation and safe for concurrent use
+ *     (transformation.Push calls Apply from one goroutine per table,
+ *     pkg/transformer/transformation.go:131-135).
+ *   - the library never retains caller pointers after a call returns.
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry
+ *     point fails with TFGPU_ERR_DEVICE.
+ */
+#ifndef TFGPU_H
+#define TFGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFGPU_ABI_VERSION 1
+
+typedef enum tfgpu_status {
+  TFGPU_OK = 0,
+  TFGPU_ERR_INVALID = 1,     /* bad argument / malformed batch                 */
+  TFGPU_ERR_CONFIG = 2,      /* transformer config rejected (factory error)    */
+  TFGPU_ERR_UNSUPPORTED = 3, /* valid in the reference, not device-resident    */
+  TFGPU_ERR_DEVICE = 4,      /* HIP error / no gfx950 device                   */
+  TFGPU_ERR_NOMEM = 5,
+  TFGPU_ERR_UNKNOWN_TYPE = 6 /* transformer type not registered                */
+} tfgpu_status;
+
+/* ColSchema.DataType — the YT type names the reference uses as strings
+ * (pkg/abstract/typesystem/schema.go:49-69).
+ * NB: "string" is arbitrary bytes (ytschema.TypeBytes), "utf8" is text. */
+typedef enum tfgpu_dtype {
+  TFGPU_T_INVALID = 0,
+  TFGPU_T_INT8 = 1, TFGPU_T_INT16, TFGPU_T_INT32, TFGPU_T_INT64,
+  TFGPU_T_UINT8, TFGPU_T_UINT16, TFGPU_T_UINT32, TFGPU_T_UINT64,
+  TFGPU_T_FLOAT32,   /* "float"     */
+  TFGPU_T_FLOAT64,   /* "double"    */
+  TFGPU_T_BOOLEAN,   /* "boolean"   */
+  TFGPU_T_BYTES,     /* "string"    */
+  TFGPU_T_UTF8,      /* "utf8"      */
+  TFGPU_T_DATE,      /* "date"      */
+  TFGPU_T_DATETIME,  /* "datetime"  */
+  TFGPU_T_TIMESTAMP, /* "timestamp" */
+  TFGPU_T_INTERVAL,  /* "interval"  */
+  TFGPU_T_ANY,       /* "any"       */
+  TFGPU_T__COUNT
+} tfgpu_dtype;
+
+/* Physical representation of a column = the Go dynamic type of the boxed
+ * ColumnValues it was fanned out from.  The reference dispatches on the
+ * dynamic type in many places (filter_rows.go:180-365, to_string.go:145-171),
+ * so it is part of the data, separate from the schema DataType. */
+typedef enum tfgpu_repr {
+  TFGPU_R_INVALID = 0,
+  TFGPU_R_INT8 = 1, TFGPU_R_INT16, TFGPU_R_INT32, TFGPU_R_INT64,
+  TFGPU_R_UINT8, TFGPU_R_UINT16, TFGPU_R_UINT32, TFGPU_R_UINT64,
+  TFGPU_R_FLOAT32, TFGPU_R_FLOAT64,
+  TFGPU_R_BOOL,     /* 1 byte per value, 0/1                                  */
+  TFGPU_R_STRING,   /* Go string      : offsets[nrows+1] (u32) + data         */
+  TFGPU_R_BYTES,    /* Go []byte      : offsets + data                        */
+  TFGPU_R_JSONNUM,  /* json.Number    : offsets + data (decimal text)         */
+  TFGPU_R_JSON,     /* any            : offsets + data (json.Marshal text)    */
+  TFGPU_R_TIME,     /* time.Time (UTC): values = i64 unix seconds,
+                                        nanos  = i32 nanoseconds or NULL (=0) */
+  TFGPU_R_DURATION, /* time.Duration  : values = i64 nanoseconds              */
+  TFGPU_R__COUNT
+} tfgpu_repr;
+
+/* ChangeItem.Kind (pkg/abstract/changeitem/kind.go:5-44), row-level subset.
+ * filter_rows treats "Insert"/"insert" etc. as equal (filter_rows.go:92-96). */
+typedef enum tfgpu_kind {
+  TFGPU_K_INSERT = 0, TFGPU_K_UPDATE = 1, TFGPU_K_DELETE = 2,
+  TFGPU_K_OTHER = 3 /* any non-row kind: passes through every row kernel */
+} tfgpu_kind;
+
+enum { TFGPU_MEM_HOST = 0, TFGPU_MEM_DEVICE = 1 };
+
+enum { TFGPU_COL_KEY = 1u /* ColSchema.PrimaryKey */, TFGPU_COL_REQUIRED = 2u };
+
+/* One ColSchema (pkg/abstract/changeitem/col_schema.go:14-29). */
+typedef struct tfgpu_colschema {
+  const char *name;          /* ColumnName                                    */
+  int32_t dtype;             /* tfgpu_dtype                                   */
+  uint32_t flags;            /* TFGPU_COL_*                                   */
+  const char *path;          /* ColSchema.Path (CSV: decimal column index)    */
+  const char *original_type; /* ColSchema.OriginalType or NULL                */
+} tfgpu_colschema;
+
+typedef struct tfgpu_schema {
+  int32_t ncols;
+  tfgpu_colschema *cols;
+} tfgpu_schema;
+
+/* One column of a batch: ColumnNames[i] + all rows' ColumnValues[i]. */
+typedef struct tfgpu_column {
+  const char *name;
+  int32_t dtype;      /* schema DataType looked up BY NAME       */
+  int32_t repr;       /* tfgpu_repr                                           */
+  void *values;       /* fixed-width reprs: nrows elements; else NULL         */
+  uint32_t *offsets;  /* var-width reprs: nrows+1 offsets into data           */
+  uint8_t *data;      /* var-width payload                                    */
+  uint64_t data_len;  /* bytes in data                                        */
+  int32_t *nanos;     /* TFGPU_R_TIME only; NULL = all zero                   */
+  uint8_t *validity;  /* bitmap, bit i (LSB first) = 1 if value i != nil;
+                         NULL = no nil values                                 */
+} tfgpu_column;
+
+/* A batch = one contiguous same-table, same-schema run of ChangeItems, which
+ * is exactly what transformation.do hands to Apply (transformation.go:252-257). */
+typedef struct tfgpu_batch {
+  int64_t nrows;
+  int32_t ncols;
+  tfgpu_column *cols;
+  const char *table_ns;   /* ChangeItem.Schema */
+  const char *table_name; /* ChangeItem.Table  */
+  uint8_t *kind;          /* tfgpu_kind per row; NULL = all insert            */
+  int32_t *src_row;       /* outputs: index of the input row each output row
+                             came from (the fan-in key for row meta);
+                             NULL on input = identity                         */
+  uint32_t *part_id;      /* outputs of sharder_transformer: PartID = itoa()  */
+  int32_t mem;            /* TFGPU_MEM_HOST / TFGPU_MEM_DEVICE                */
+} tfgpu_batch;
+
+/* Per-row failure, the C image of abstract.TransformerError
+ * (pkg/abstract/transformer.go:40-48): the row is omitted from the output. */
+typedef enum tfgpu_rowerr {
+  TFGPU_ROW_OK = 0,
+  TFGPU_ROW_UNSUPPORTED_KIND = 1,  /* filter_rows.go:103-107 (fatal)          */
+  TFGPU_ROW_COLUMN_NOT_FOUND = 2,  /* filter_rows.go:149-154 (fatal)          */
+  TFGPU_ROW_INT_OVERFLOW = 3,      /* filter_rows/util.go:65-68               */
+  TFGPU_ROW_TYPE_PAIR = 4,         /* "Unsupported type pair" filter_rows:364 */
+  TFGPU_ROW_MISSING_CELL = 5,      /* reader_csv.go:303-316                   */
+  TFGPU_ROW_CAST = 6,              /* strictify cast error                    */
+  TFGPU_ROW_RANGE = 7,             /* StrictifyRangeError                     */
+  TFGPU_ROW_QUOTE = 8,             /* csv: element is a single quote char     */
+  TFGPU_ROW_DOUBLE_QUOTE = 9,      /* csv: errDoubleQuotesDisabled            */
+  TFGPU_ROW_QUOTING_DISABLED = 10, /* csv: errQuotingDisabled                 */
+  TFGPU_ROW_HOST_FALLBACK = 11     /* value form not handled on device (free-
+                                      form dates …): caller must run this row
+                                      through the stock Go path               */
+} tfgpu_rowerr;
+
+typedef struct tfgpu_row_error {
+  int64_t row;      /* index into the INPUT batch / line number for parsers   */
+  int32_t code;     /* tfgpu_rowerr                                           */
+  int32_t step;     /* index of the plan in the chain that raised it          */
+  int32_t column;   /* column index the error refers to, or -1                */
+} tfgpu_row_error;
+
+typedef struct tfgpu_plan tfgpu_plan;     /* one transformer instance         */
+typedef struct tfgpu_dbatch tfgpu_dbatch; /* a batch resident in HBM          */
+typedef struct tfgpu_dbuf tfgpu_dbuf;     /* a byte buffer resident in HBM    */
+
+/* ---- library ----------------------------------------------------------- */
+int tfgpu_abi_version(void);
+const char *tfgpu_last_error(void);
+/* Bind the calling process to HIP device `device` (one process per GPU).    */
+int tfgpu_init(int device);
+int tfgpu_shutdown(void);
+int tfgpu_device_count(int *out);
+int tfgpu_synchronize(void);
+/* The HIP stream every kernel of this library is launched on (hipStream_t). */
+void *tfgpu_stream(void);
+
+/* Pinned staging memory (hipHostMalloc) for double-buffered H2D/D2H.        */
+int tfgpu_host_alloc(size_t bytes, void **out);
+int tfgpu_host_free(void *p);
+
+/* ---- transformers: abstract.Transformer -------------------------------- */
+/* transformer.New(type, cfg…) — pkg/transformer/registry.go:36-47.
+ * `type_name` is the YAML key ("mask_field", "filter_rows", "rename_tables",
+ * "filter_columns", "skip_events", "convert_to_string", "convert_to_datetime",
+ * "sharder_transformer"); `config_json` is the same JSON object the Go
+ * factory receives.                                                         */
+int tfgpu_plan_create(const char *type_name, const char *config_json, tfgpu_plan **out);
+void tfgpu_plan_destroy(tfgpu_plan *plan);
+const char *tfgpu_plan_type(const tfgpu_plan *plan);                /* Type()        */
+int tfgpu_plan_description(const tfgpu_plan *plan, char *buf, size_t cap); /* Description() */
+/* Suitable(table, schema): *out = 1/0.                                      */
+int tfgpu_plan_suitable(const tfgpu_plan *plan, const char *table_ns, const char *table_name,
+                        const tfgpu_schema *schema, int *out);
+/* ResultSchema(schema): *out is library-owned, free with tfgpu_schema_free.  */
+int tfgpu_plan_result_schema(const tfgpu_plan *plan, const tfgpu_schema *in, tfgpu_schema **out);
+void tfgpu_schema_free(tfgpu_schema *s);
+
+/* Number of registered transformer types and their names.                   */
+int tfgpu_registry_count(void);
+const char *tfgpu_registry_name(int i);
+
+/* ---- batches ------------------------------------------------------------ */
+int tfgpu_batch_upload(const tfgpu_batch *host, tfgpu_dbatch **out);
+/* Borrowed view with DEVICE pointers (valid until tfgpu_dbatch_free).       */
+int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *view);
+/* Copy into caller-allocated host buffers sized from the view.              */
+int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *host_out);
+void tfgpu_dbatch_free(tfgpu_dbatch *b);
+
+/* Apply(items) for a chain of plans, the loop of transformation.do
+ * (pkg/transformer/transformation.go:252-274), entirely in HBM.
+ * `errs` (optional) receives up to `errs_cap` row errors; *nerrs the total.  */
+int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tfgpu_dbatch **out,
+                tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+
+/* ---- CSV ingest: pkg/csv.Reader + s3 CSVReader.doParse ------------------ */
+typedef struct tfgpu_csv_options {
+  /* pkg/csv/reader.go:43-54, defaults from NewReader (reader.go:337-350)    */
+  uint8_t delimiter;        /* ','  */
+  uint8_t quote_char;       /* '"'  ; 0 = quoting disabled                   */
+  uint8_t escape_char;      /* '\\' ; 0 = none                               */
+  uint8_t double_quote;     /* 1                                             */
+  uint8_t newlines_in_value;/* 0                                             */
+  /* reader_csv.go additionalReaderOptions                                   */
+  uint8_t include_missing_columns;
+  uint8_t strings_can_be_null;
+  uint8_t quoted_strings_can_be_null;
+  int32_t n_null_values;  const char *const *null_values;
+  int32_t n_true_values;  const char *const *true_values;
+  int32_t n_false_values; const char *const *false_values;
+  int32_t n_timestamp_parsers; const char *const *timestamp_parsers; /* Go layouts */
+  const char *decimal_point; /* "" or NULL = '.'                             */
+  int64_t skip_rows;         /* lines dropped before parsing starts          */
+} tfgpu_csv_options;
+void tfgpu_csv_options_default(tfgpu_csv_options *o);
+
+/* Parse `len` bytes of CSV into a device batch typed by `schema` (column i
+ * reads CSV field atoi(schema.cols[i].path)), then Strictify.  *consumed is
+ * the offset of the first unconsumed byte (a trailing line without '\n' is
+ * left for the next chunk, reader.go:158-168).                              */
+int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes,
+                    uint64_t len, int mem, tfgpu_dbatch **out, uint64_t *consumed,
+                    tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+
+/* ---- serialize ---------------------------------------------------------- */
+enum {
+  TFGPU_FMT_CH_JSON_EACH_ROW = 1, /* httpuploader.MarshalCItoJSON             */
+  TFGPU_FMT_JSON = 2,             /* pkg/serializer/json.go (sorted keys)     */
+  TFGPU_FMT_CSV = 3               /* pkg/serializer/csv.go                    */
+};
+int tfgpu_serialize(int format, const tfgpu_dbatch *b, tfgpu_dbuf **out);
+int tfgpu_dbuf_size(const tfgpu_dbuf *b, uint64_t *out);
+void *tfgpu_dbuf_ptr(const tfgpu_dbuf *b); /* device pointer */
+int tfgpu_dbuf_download(const tfgpu_dbuf *b, void *host, uint64_t cap);
+void tfgpu_dbuf_free(tfgpu_dbuf *b);
+/* Upload raw bytes (e.g. a CSV chunk) so a parse can start HBM-resident.    */
+int tfgpu_dbuf_upload(const void *host, uint64_t len, tfgpu_dbuf **out);
+
+/* ---- profiling hooks (bench.py / rocprof cross-check) ------------------- */
+/* Per-kernel accumulated device time measured with HIP events on the library
+ * stream.  Enable, run, then read back name/launches/total_ms.              */
+int tfgpu_prof_enable(int on);
+int tfgpu_prof_reset(void);
+int tfgpu_prof_count(void);
+int tfgpu_prof_get(int i, const char **name, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFGPU_H */

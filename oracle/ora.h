@@ -1,0 +1,176 @@
+/*
+ * oracle/ora.h — CPU restatement of the reference's transform/serialize hot
+ * path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (transferia_amd/, libtfgpu.so) never does.
+ *
+ * The reference is Go and cannot be built here (no Go toolchain, ~330
+ * un-vendored modules), so this is a restatement in plain C11 that keeps the
+ * reference's data model — a batch is an array of row structs, each holding
+ * an array of boxed, individually heap-allocated values (ChangeItem /
+ * ColumnValues []interface{}, pkg/abstract/changeitem/change_item.go:27-80)
+ * — and its scalar, per-row algorithms.  Every function cites the reference
+ * file:line it follows.  Parity is pinned by the reference's own golden
+ * vectors (tests/golden/, extracted by tools/extract_golden.py).
+ */
+#ifndef ORA_H
+#define ORA_H
+#include <stddef.h>
+#include <stdint.h>
+#include "../include/tfgpu.h" /* shared enums + the columnar struct used for test I/O */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- boxed values (Go interface{} payloads) ---- */
+typedef enum {
+  OV_NIL = 0,
+  OV_I8, OV_I16, OV_I32, OV_I64, OV_U8, OV_U16, OV_U32, OV_U64,
+  OV_F32, OV_F64, OV_BOOL,
+  OV_STRING, OV_BYTES, OV_JSONNUM, OV_JSON,
+  OV_TIME, OV_DURATION
+} ora_vkind;
+
+typedef struct ora_value {
+  int kind;
+  union {
+    int64_t i;
+    uint64_t u;
+    double f64;
+    float f32;
+    int b;
+    struct { int64_t sec; int32_t nsec; } t;
+  } v;
+  char *s;      /* heap payload for STRING/BYTES/JSONNUM/JSON */
+  size_t slen;
+} ora_value;
+
+typedef struct ora_colschema {
+  char *name;
+  int dtype;          /* tfgpu_dtype */
+  int key;
+  char *path;
+  char *original_type;
+} ora_colschema;
+
+typedef struct ora_schema {
+  int ncols;
+  ora_colschema *cols;
+  int refs;
+} ora_schema;
+
+typedef struct ora_names { int n; char **names; int refs; } ora_names;
+
+/* ChangeItem (row-level subset that the path reads or writes) */
+typedef struct ora_item {
+  int kind;            /* tfgpu_kind */
+  char *ns;            /* Schema */
+  char *table;         /* Table  */
+  char *part_id;       /* PartID */
+  ora_names *names;    /* ColumnNames (shared, write-once) */
+  int nvalues;
+  ora_value *values;   /* ColumnValues */
+  ora_schema *schema;  /* TableSchema (shared pointer, replaced not mutated) */
+  int64_t src_row;     /* index in the original input batch */
+} ora_item;
+
+typedef struct ora_error { int64_t row; int code; char *msg; } ora_error;
+
+typedef struct ora_batch {
+  int64_t n, cap;
+  ora_item *items;
+  int64_t nerr, errcap;
+  ora_error *errs;
+} ora_batch;
+
+/* ---- memory / construction ---- */
+ora_batch *ora_batch_new(void);
+void ora_batch_free(ora_batch *b);
+void ora_value_free(ora_value *v);
+ora_value ora_value_clone(const ora_value *v);
+ora_schema *ora_schema_from(const tfgpu_schema *s);
+void ora_schema_unref(ora_schema *s);
+ora_item *ora_batch_push(ora_batch *b); /* zeroed item */
+void ora_batch_add_error(ora_batch *b, int64_t row, int code, const char *msg);
+void ora_item_clear(ora_item *it);
+
+/* columnar <-> row conversion (test I/O only; not timed) */
+ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema);
+/* Allocates a host tfgpu_batch with malloc; all rows must share column layout. */
+tfgpu_batch *ora_to_columns(const ora_batch *b);
+void ora_columns_free(tfgpu_batch *cb);
+tfgpu_schema *ora_batch_schema(const ora_batch *b); /* schema of first row, malloc'd */
+void ora_tschema_free(tfgpu_schema *s);
+
+/* ---- Go stdlib behaviours restated (strconv/fmt/time) ---- */
+size_t ora_fmt_int(char *dst, int64_t v);
+size_t ora_fmt_uint(char *dst, uint64_t v);
+/* strconv.FormatFloat(f, fmt, -1, bits), fmt in {'g'(=fmt %v), 'f'} */
+size_t ora_fmt_float(char *dst, double f, char fmt, int bits);
+size_t ora_fmt_date(char *dst, int64_t sec);               /* time.DateOnly, UTC */
+size_t ora_fmt_rfc3339nano(char *dst, int64_t sec, int32_t nsec); /* UTC */
+size_t ora_fmt_time_string(char *dst, int64_t sec, int32_t nsec); /* Time.String(), UTC */
+size_t ora_fmt_duration(char *dst, int64_t ns);            /* Duration.String() */
+/* strconv.ParseInt(s, base, bits): 0 ok, 1 syntax error, 2 range error */
+int ora_parse_int(const char *s, size_t n, int base, int bits, int64_t *out);
+int ora_parse_uint(const char *s, size_t n, int base, int bits, uint64_t *out);
+int ora_parse_float(const char *s, size_t n, int bits, double *out); /* strconv.ParseFloat */
+int ora_parse_bool(const char *s, size_t n, int *out);     /* strconv.ParseBool */
+/* time.Parse(layout, s) for the layouts used on the path; returns 0 on success */
+int ora_time_parse(const char *layout, const char *s, size_t n, int64_t *sec, int32_t *nsec);
+void ora_civil_from_days(int64_t z, int64_t *y, int *m, int *d);
+int64_t ora_days_from_civil(int64_t y, int m, int d);
+
+/* ---- hashes ---- */
+void ora_sha256(const void *data, size_t n, uint8_t out[32]);
+void ora_hmac_sha256(const void *key, size_t klen, const void *msg, size_t mlen, uint8_t out[32]);
+uint32_t ora_crc32_ieee(const void *data, size_t n);
+uint32_t ora_fnv1a32(const void *data, size_t n);
+
+/* ---- a5: SerializeToString (to_string.go:145-178) ---- */
+/* returns malloc'd string, *len set */
+char *ora_serialize_to_string(const ora_value *v, int dtype, size_t *len);
+
+/* ---- transformers: Apply(type, config_json) ---- */
+typedef struct ora_transformer ora_transformer;
+ora_transformer *ora_transformer_new(const char *type_name, const char *config_json, char *err, size_t errcap);
+void ora_transformer_free(ora_transformer *t);
+int ora_transformer_suitable(const ora_transformer *t, const char *ns, const char *table, const tfgpu_schema *s);
+tfgpu_schema *ora_transformer_result_schema(const ora_transformer *t, const tfgpu_schema *s);
+/* Consumes `in` rows (ownership moves like AsyncPush), returns new batch with
+ * Transformed rows and Errors. */
+ora_batch *ora_transformer_apply(const ora_transformer *t, ora_batch *in);
+
+/* filter grammar (library/go/yandex/cloud/filter) exposed for tests:
+ * returns number of terms or -1 and fills err */
+int ora_filter_parse_check(const char *expr, char *err, size_t errcap);
+
+/* ---- CSV: pkg/csv.Reader + s3 CSVReader ---- */
+/* csv.Reader.ReadAll over a buffer; returns fields as a flat malloc'd table.
+ * out_rows[i] = number of fields of line i (or -1 for a nil line), fields in
+ * order in out_fields (each malloc'd, NUL-terminated, with length array).     */
+typedef struct ora_csv_table {
+  int64_t nlines;
+  int32_t *nfields;    /* -1: ReadLine returned (nil,nil) */
+  int32_t *line_err;   /* tfgpu_rowerr for that line, 0 ok */
+  int64_t ntotal;
+  char **fields;
+  size_t *lens;
+  uint64_t consumed;
+} ora_csv_table;
+ora_csv_table *ora_csv_read_all(const tfgpu_csv_options *o, const void *bytes, uint64_t len);
+void ora_csv_table_free(ora_csv_table *t);
+/* parseCSVRows + doParse (constructCI + Strictify) → batch of typed rows */
+ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema, const char *ns,
+                         const char *table, const void *bytes, uint64_t len, uint64_t *consumed);
+
+/* ---- serializers ---- */
+/* format = TFGPU_FMT_*; returns malloc'd bytes */
+char *ora_serialize(int format, const ora_batch *b, uint64_t *len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,247 @@
+"""ctypes wrapper over oracle/liboracle.so — the CPU restatement of the reference.
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(),
+bench.py's cpu_baseline leg.  The product package (transferia_amd/) must never
+import this module; tests/test_layout.py enforces that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import subprocess
+import time
+
+import numpy as np
+
+from transferia_amd import abi
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_DIR, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", _DIR, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_DIR, "liboracle.so")
+    if not os.path.exists(so):
+        build()
+    L = C.CDLL(so)
+    P = C.c_void_p
+    L.ora_from_columns.restype = P
+    L.ora_from_columns.argtypes = [C.POINTER(abi.CBatch), C.POINTER(abi.CSchema)]
+    L.ora_to_columns.restype = C.POINTER(abi.CBatch)
+    L.ora_to_columns.argtypes = [P]
+    L.ora_columns_free.argtypes = [C.POINTER(abi.CBatch)]
+    L.ora_batch_schema.restype = C.POINTER(abi.CSchema)
+    L.ora_batch_schema.argtypes = [P]
+    L.ora_tschema_free.argtypes = [C.POINTER(abi.CSchema)]
+    L.ora_batch_free.argtypes = [P]
+    L.ora_transformer_new.restype = P
+    L.ora_transformer_new.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.ora_transformer_free.argtypes = [P]
+    L.ora_transformer_suitable.restype = C.c_int
+    L.ora_transformer_suitable.argtypes = [P, C.c_char_p, C.c_char_p, C.POINTER(abi.CSchema)]
+    L.ora_transformer_result_schema.restype = C.POINTER(abi.CSchema)
+    L.ora_transformer_result_schema.argtypes = [P, C.POINTER(abi.CSchema)]
+    L.ora_transformer_apply.restype = P
+    L.ora_transformer_apply.argtypes = [P, P]
+    L.ora_filter_parse_check.restype = C.c_int
+    L.ora_filter_parse_check.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.ora_csv_parse.restype = P
+    L.ora_csv_parse.argtypes = [C.POINTER(abi.CCsvOptions), C.POINTER(abi.CSchema), C.c_char_p, C.c_char_p, C.c_void_p,
+                                C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ora_csv_read_all.restype = P
+    L.ora_csv_read_all.argtypes = [C.POINTER(abi.CCsvOptions), C.c_void_p, C.c_uint64]
+    L.ora_csv_table_free.argtypes = [P]
+    L.ora_serialize.restype = P
+    L.ora_serialize.argtypes = [C.c_int, P, C.POINTER(C.c_uint64)]
+    L.ora_hmac_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
+    L.ora_crc32_ieee.restype = C.c_uint32
+    L.ora_crc32_ieee.argtypes = [C.c_char_p, C.c_size_t]
+    L.ora_fnv1a32.restype = C.c_uint32
+    L.ora_fnv1a32.argtypes = [C.c_char_p, C.c_size_t]
+    L.ora_fmt_float.restype = C.c_size_t
+    L.ora_fmt_float.argtypes = [C.c_char_p, C.c_double, C.c_char, C.c_int]
+    L.ora_fmt_duration.restype = C.c_size_t
+    L.ora_fmt_duration.argtypes = [C.c_char_p, C.c_int64]
+    L.ora_parse_int.restype = C.c_int
+    L.ora_parse_int.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    L.ora_time_parse.restype = C.c_int
+    L.ora_time_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.free = C.CDLL(None).free
+    L.free.argtypes = [C.c_void_p]
+    _LIB = L
+    return L
+
+
+class _BatchErr:
+    pass
+
+
+def _errors_of(L, bptr):
+    """Read ora_batch.errs (row, code, msg)."""
+    class OraError(C.Structure):
+        _fields_ = [("row", C.c_int64), ("code", C.c_int), ("msg", C.c_char_p)]
+
+    class OraBatch(C.Structure):
+        _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("items", C.c_void_p), ("nerr", C.c_int64), ("errcap", C.c_int64),
+                    ("errs", C.POINTER(OraError))]
+    ob = OraBatch.from_address(bptr)
+    return [(int(ob.errs[i].row), int(ob.errs[i].code), (ob.errs[i].msg or b"").decode()) for i in range(ob.nerr)]
+
+
+class Result:
+    def __init__(self, batch: abi.Batch, schema: abi.Schema, errors, seconds: float):
+        self.batch, self.schema, self.errors, self.seconds = batch, schema, errors, seconds
+
+
+def _finish(L, out_ptr, seconds):
+    errs = _errors_of(L, out_ptr)
+    cb = L.ora_to_columns(out_ptr)
+    batch = abi.batch_from_c(cb.contents)
+    cs = L.ora_batch_schema(out_ptr)
+    schema = abi.Schema.from_c(cs.contents)
+    L.ora_tschema_free(cs)
+    L.ora_columns_free(cb)
+    L.ora_batch_free(out_ptr)
+    return Result(batch, schema, errs, seconds)
+
+
+class Transformer:
+    """abstract.Transformer over the oracle (pkg/abstract/transformer.go:32-38)."""
+
+    def __init__(self, type_name: str, config):
+        L = lib()
+        err = C.create_string_buffer(512)
+        cfg = config if isinstance(config, str) else json.dumps(config)
+        self._h = L.ora_transformer_new(type_name.encode(), cfg.encode(), err, 512)
+        if not self._h:
+            raise ValueError(err.value.decode() or "transformer construction failed")
+        self.type_name = type_name
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ora_transformer_free(self._h)
+            self._h = None
+
+    def suitable(self, ns: str, table: str, schema: abi.Schema) -> bool:
+        cs = schema.to_c()
+        return bool(lib().ora_transformer_suitable(self._h, ns.encode(), table.encode(), C.byref(cs)))
+
+    def result_schema(self, schema: abi.Schema) -> abi.Schema:
+        L = lib()
+        cs = schema.to_c()
+        out = L.ora_transformer_result_schema(self._h, C.byref(cs))
+        s = abi.Schema.from_c(out.contents)
+        L.ora_tschema_free(out)
+        return s
+
+    def apply(self, batch: abi.Batch, schema: abi.Schema) -> Result:
+        return apply_chain([self], batch, schema)
+
+
+def apply_chain(transformers, batch: abi.Batch, schema: abi.Schema) -> Result:
+    """Row-model Apply chain; only the Apply calls are timed (boxing the test
+    input into rows and unboxing the result are test I/O)."""
+    L = lib()
+    cb, cs = batch.to_c(), schema.to_c()
+    cur = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    t0 = time.perf_counter()
+    for t in transformers:
+        cur = L.ora_transformer_apply(t._h, cur)
+    dt = time.perf_counter() - t0
+    return _finish(L, cur, dt)
+
+
+def filter_parse_check(expr: str):
+    err = C.create_string_buffer(256)
+    n = lib().ora_filter_parse_check(expr.encode("utf-8"), err, 256)
+    return n, err.value.decode()
+
+
+def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data: bytes, ns="", table="") -> Result:
+    L = lib()
+    cs = schema.to_c()
+    consumed = C.c_uint64(0)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    t0 = time.perf_counter()
+    out = L.ora_csv_parse(C.byref(opts), C.byref(cs), ns.encode(), table.encode(), buf.ctypes.data if len(buf) else None, len(buf), C.byref(consumed))
+    dt = time.perf_counter() - t0
+    r = _finish(L, out, dt)
+    r.consumed = int(consumed.value)
+    if r.batch.nrows == 0 and not r.batch.cols:
+        r.schema = schema
+    return r
+
+
+class _CsvTable(C.Structure):
+    _fields_ = [("nlines", C.c_int64), ("nfields", C.POINTER(C.c_int32)), ("line_err", C.POINTER(C.c_int32)), ("ntotal", C.c_int64),
+                ("fields", C.POINTER(C.c_void_p)), ("lens", C.POINTER(C.c_size_t)), ("consumed", C.c_uint64)]
+
+
+def csv_read_all(opts: abi.CCsvOptions, data: bytes):
+    """csv.Reader.ReadAll → (lines: list[list[bytes] | None], errs: list[int], consumed)."""
+    L = lib()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    p = L.ora_csv_read_all(C.byref(opts), buf.ctypes.data if len(buf) else None, len(buf))
+    t = _CsvTable.from_address(p)
+    lines, errs, k = [], [], 0
+    for i in range(t.nlines):
+        nf = t.nfields[i]
+        errs.append(int(t.line_err[i]))
+        if nf < 0:
+            lines.append(None)
+            continue
+        row = []
+        for _ in range(nf):
+            row.append(C.string_at(t.fields[k], t.lens[k]))
+            k += 1
+        lines.append(row)
+    consumed = int(t.consumed)
+    L.ora_csv_table_free(p)
+    return lines, errs, consumed
+
+
+def hmac_sha256_hex(key: bytes, msg: bytes) -> str:
+    out = C.create_string_buffer(32)
+    lib().ora_hmac_sha256(key, len(key), msg, len(msg), out)
+    return out.raw.hex()
+
+
+def crc32(data: bytes) -> int:
+    return int(lib().ora_crc32_ieee(data, len(data)))
+
+
+def fmt_float(f: float, fmt: str = "g", bits: int = 64) -> str:
+    buf = C.create_string_buffer(400)
+    n = lib().ora_fmt_float(buf, f, fmt.encode(), bits)
+    return buf.raw[:n].decode()
+
+
+def fmt_duration(ns: int) -> str:
+    buf = C.create_string_buffer(64)
+    n = lib().ora_fmt_duration(buf, ns)
+    return buf.raw[:n].decode("utf-8")
+
+
+def parse_int(s: str, base: int = 0, bits: int = 64):
+    out = C.c_int64(0)
+    b = s.encode()
+    rc = lib().ora_parse_int(b, len(b), base, bits, C.byref(out))
+    return rc, int(out.value)
+
+
+def time_parse(layout: str, s: str):
+    sec, ns = C.c_int64(0), C.c_int32(0)
+    b = s.encode()
+    rc = lib().ora_time_parse(layout.encode(), b, len(b), C.byref(sec), C.byref(ns))
+    return None if rc else (int(sec.value), int(ns.value))

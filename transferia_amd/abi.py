@@ -1,0 +1,420 @@
+"""ctypes image of include/tfgpu.h plus numpy-side batch containers.
+
+This module only describes memory layout; it performs no computation and is
+shared by the product binding (transferia_amd.lib) and the test oracle
+wrapper (oracle/oracle.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import datetime as _dt
+import re
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+# ---- enums (keep in sync with include/tfgpu.h) ---------------------------
+DTYPES = ["invalid", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float", "double",
+          "boolean", "string", "utf8", "date", "datetime", "timestamp", "interval", "any"]
+DTYPE_ID = {n: i for i, n in enumerate(DTYPES)}
+
+R_INT8, R_INT16, R_INT32, R_INT64, R_UINT8, R_UINT16, R_UINT32, R_UINT64, R_FLOAT32, R_FLOAT64, R_BOOL, \
+    R_STRING, R_BYTES, R_JSONNUM, R_JSON, R_TIME, R_DURATION = range(1, 18)
+REPR_NAMES = ["invalid", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float32", "float64",
+              "bool", "string", "bytes", "jsonnum", "json", "time", "duration"]
+REPR_NP = {R_INT8: np.int8, R_INT16: np.int16, R_INT32: np.int32, R_INT64: np.int64, R_UINT8: np.uint8,
+           R_UINT16: np.uint16, R_UINT32: np.uint32, R_UINT64: np.uint64, R_FLOAT32: np.float32,
+           R_FLOAT64: np.float64, R_BOOL: np.uint8, R_TIME: np.int64, R_DURATION: np.int64}
+VAR_REPRS = (R_STRING, R_BYTES, R_JSONNUM, R_JSON)
+
+K_INSERT, K_UPDATE, K_DELETE, K_OTHER = 0, 1, 2, 3
+KIND_ID = {"insert": 0, "Insert": 0, "update": 1, "Update": 1, "delete": 2, "Delete": 2}
+
+MEM_HOST, MEM_DEVICE = 0, 1
+COL_KEY = 1
+
+ROWERR = {0: "OK", 1: "UNSUPPORTED_KIND", 2: "COLUMN_NOT_FOUND", 3: "INT_OVERFLOW", 4: "TYPE_PAIR", 5: "MISSING_CELL",
+          6: "CAST", 7: "RANGE", 8: "QUOTE", 9: "DOUBLE_QUOTE", 10: "QUOTING_DISABLED", 11: "HOST_FALLBACK"}
+ROWERR_ID = {v: k for k, v in ROWERR.items()}
+
+FMT_CH_JSON_EACH_ROW, FMT_JSON, FMT_CSV = 1, 2, 3
+
+
+# ---- C structs -----------------------------------------------------------
+class CColSchema(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("flags", C.c_uint32), ("path", C.c_char_p),
+                ("original_type", C.c_char_p)]
+
+
+class CSchema(C.Structure):
+    _fields_ = [("ncols", C.c_int32), ("cols", C.POINTER(CColSchema))]
+
+
+class CColumn(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("repr", C.c_int32), ("values", C.c_void_p),
+                ("offsets", C.c_void_p), ("data", C.c_void_p), ("data_len", C.c_uint64), ("nanos", C.c_void_p),
+                ("validity", C.c_void_p)]
+
+
+class CBatch(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int32), ("cols", C.POINTER(CColumn)), ("table_ns", C.c_char_p),
+                ("table_name", C.c_char_p), ("kind", C.c_void_p), ("src_row", C.c_void_p), ("part_id", C.c_void_p),
+                ("mem", C.c_int32)]
+
+
+class CRowError(C.Structure):
+    _fields_ = [("row", C.c_int64), ("code", C.c_int32), ("step", C.c_int32), ("column", C.c_int32)]
+
+
+class CCsvOptions(C.Structure):
+    _fields_ = [("delimiter", C.c_uint8), ("quote_char", C.c_uint8), ("escape_char", C.c_uint8),
+                ("double_quote", C.c_uint8), ("newlines_in_value", C.c_uint8), ("include_missing_columns", C.c_uint8),
+                ("strings_can_be_null", C.c_uint8), ("quoted_strings_can_be_null", C.c_uint8),
+                ("n_null_values", C.c_int32), ("null_values", C.POINTER(C.c_char_p)),
+                ("n_true_values", C.c_int32), ("true_values", C.POINTER(C.c_char_p)),
+                ("n_false_values", C.c_int32), ("false_values", C.POINTER(C.c_char_p)),
+                ("n_timestamp_parsers", C.c_int32), ("timestamp_parsers", C.POINTER(C.c_char_p)),
+                ("decimal_point", C.c_char_p), ("skip_rows", C.c_int64)]
+
+
+def _b(s) -> bytes:
+    return s if isinstance(s, bytes) else str(s).encode("utf-8")
+
+
+# ---- python-side containers ------------------------------------------------
+@dataclass
+class ColSchema:
+    name: str
+    dtype: str
+    key: bool = False
+    path: str = ""
+    original_type: str = ""
+
+
+@dataclass
+class Schema:
+    cols: List[ColSchema]
+
+    @staticmethod
+    def of(spec: Sequence) -> "Schema":
+        out = []
+        for i, c in enumerate(spec):
+            if isinstance(c, ColSchema):
+                out.append(c)
+            else:
+                c = list(c)
+                out.append(ColSchema(c[0], c[1], bool(c[2]) if len(c) > 2 else False, c[3] if len(c) > 3 else "",
+                                     c[4] if len(c) > 4 else ""))
+        return Schema(out)
+
+    def dtype_of(self, name: str) -> str:
+        for c in self.cols:
+            if c.name == name:
+                return c.dtype
+        return "invalid"
+
+    def to_c(self):
+        arr = (CColSchema * max(len(self.cols), 1))()
+        keep = []
+        for i, c in enumerate(self.cols):
+            n, p, o = _b(c.name), _b(c.path), _b(c.original_type)
+            keep += [n, p, o]
+            arr[i].name, arr[i].dtype, arr[i].flags, arr[i].path, arr[i].original_type = n, DTYPE_ID[c.dtype], (COL_KEY if c.key else 0), p, o
+        s = CSchema(len(self.cols), arr)
+        s._keep = (arr, keep)
+        return s
+
+    @staticmethod
+    def from_c(cs: CSchema) -> "Schema":
+        out = []
+        for i in range(cs.ncols):
+            c = cs.cols[i]
+            out.append(ColSchema(c.name.decode("utf-8"), DTYPES[c.dtype], bool(c.flags & COL_KEY),
+                                 (c.path or b"").decode(), (c.original_type or b"").decode()))
+        return Schema(out)
+
+    def triples(self):
+        return [[c.name, c.dtype, c.key] for c in self.cols]
+
+
+@dataclass
+class Column:
+    name: str
+    dtype: str
+    repr: int
+    values: Optional[np.ndarray] = None   # fixed width
+    offsets: Optional[np.ndarray] = None  # uint32[n+1]
+    data: Optional[np.ndarray] = None     # uint8
+    nanos: Optional[np.ndarray] = None    # int32
+    validity: Optional[np.ndarray] = None  # bool[n] (python side), bitmap on the C side
+
+    def nrows(self) -> int:
+        return int(len(self.offsets) - 1) if self.repr in VAR_REPRS else int(len(self.values))
+
+    def is_valid(self, i: int) -> bool:
+        return True if self.validity is None else bool(self.validity[i])
+
+    def get_bytes(self, i: int) -> bytes:
+        return bytes(self.data[int(self.offsets[i]):int(self.offsets[i + 1])])
+
+    def pyvalue(self, i: int):
+        """Go-typed python value [gotype, v] for row i (test convenience)."""
+        if not self.is_valid(i):
+            return ["nil", None]
+        r = self.repr
+        if r in VAR_REPRS:
+            b = self.get_bytes(i)
+            return [{R_STRING: "string", R_BYTES: "bytes", R_JSONNUM: "jsonnum", R_JSON: "json"}[r], b]
+        if r == R_TIME:
+            return ["time", (int(self.values[i]), int(self.nanos[i]) if self.nanos is not None else 0)]
+        if r == R_DURATION:
+            return ["duration", int(self.values[i])]
+        if r == R_BOOL:
+            return ["bool", bool(self.values[i])]
+        if r in (R_FLOAT32, R_FLOAT64):
+            return [REPR_NAMES[r], float(self.values[i])]
+        return [REPR_NAMES[r], int(self.values[i])]
+
+
+def pack_validity(v: Optional[np.ndarray], n: int) -> Optional[np.ndarray]:
+    if v is None:
+        return None
+    return np.packbits(np.asarray(v, dtype=bool), bitorder="little")
+
+
+def unpack_validity(bits: np.ndarray, n: int) -> np.ndarray:
+    return np.unpackbits(bits, bitorder="little")[:n].astype(bool)
+
+
+@dataclass
+class Batch:
+    cols: List[Column]
+    nrows: int
+    table_ns: str = ""
+    table_name: str = ""
+    kind: Optional[np.ndarray] = None     # uint8
+    src_row: Optional[np.ndarray] = None  # int32
+    part_id: Optional[np.ndarray] = None  # uint32
+
+    def col(self, name: str) -> Column:
+        for c in self.cols:
+            if c.name == name:
+                return c
+        raise KeyError(name)
+
+    def to_c(self) -> CBatch:
+        arr = (CColumn * max(len(self.cols), 1))()
+        keep = []
+        for i, c in enumerate(self.cols):
+            nm = _b(c.name)
+            keep.append(nm)
+            arr[i].name, arr[i].dtype, arr[i].repr = nm, DTYPE_ID[c.dtype], c.repr
+            if c.repr in VAR_REPRS:
+                off = np.ascontiguousarray(c.offsets, dtype=np.uint32)
+                dat = np.ascontiguousarray(c.data if c.data is not None and len(c.data) else np.zeros(1, np.uint8), dtype=np.uint8)
+                keep += [off, dat]
+                arr[i].offsets, arr[i].data, arr[i].data_len = off.ctypes.data, dat.ctypes.data, int(off[-1]) if len(off) else 0
+            else:
+                vals = np.ascontiguousarray(c.values, dtype=REPR_NP[c.repr])
+                if len(vals) == 0:
+                    vals = np.zeros(1, REPR_NP[c.repr])
+                keep.append(vals)
+                arr[i].values = vals.ctypes.data
+                if c.nanos is not None:
+                    nn = np.ascontiguousarray(c.nanos, dtype=np.int32)
+                    keep.append(nn)
+                    arr[i].nanos = nn.ctypes.data
+            if c.validity is not None:
+                bm = pack_validity(c.validity, self.nrows)
+                if len(bm) == 0:
+                    bm = np.zeros(1, np.uint8)
+                keep.append(bm)
+                arr[i].validity = bm.ctypes.data
+        cb = CBatch()
+        cb.nrows, cb.ncols, cb.cols = self.nrows, len(self.cols), arr
+        ns, tn = _b(self.table_ns), _b(self.table_name)
+        keep += [ns, tn]
+        cb.table_ns, cb.table_name, cb.mem = ns, tn, MEM_HOST
+        if self.kind is not None:
+            k = np.ascontiguousarray(self.kind, dtype=np.uint8)
+            keep.append(k)
+            cb.kind = k.ctypes.data if len(k) else None
+        if self.src_row is not None:
+            s = np.ascontiguousarray(self.src_row, dtype=np.int32)
+            keep.append(s)
+            cb.src_row = s.ctypes.data if len(s) else None
+        cb._keep = (arr, keep)
+        return cb
+
+
+def _np_from_ptr(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+def batch_from_c(cb: CBatch) -> Batch:
+    """Copy a HOST-memory tfgpu_batch into numpy-owned storage."""
+    n = int(cb.nrows)
+    cols = []
+    for i in range(cb.ncols):
+        c = cb.cols[i]
+        col = Column((c.name or b"").decode("utf-8"), DTYPES[c.dtype], int(c.repr))
+        if c.repr in VAR_REPRS:
+            col.offsets = _np_from_ptr(c.offsets, n + 1, np.uint32) if n or c.offsets else np.zeros(1, np.uint32)
+            if len(col.offsets) == 0:
+                col.offsets = np.zeros(1, np.uint32)
+            col.data = _np_from_ptr(c.data, int(col.offsets[-1]), np.uint8)
+        else:
+            col.values = _np_from_ptr(c.values, n, REPR_NP[c.repr])
+            if c.repr == R_TIME and c.nanos:
+                col.nanos = _np_from_ptr(c.nanos, n, np.int32)
+        if c.validity:
+            col.validity = unpack_validity(_np_from_ptr(c.validity, (n + 7) // 8, np.uint8), n)
+        cols.append(col)
+    b = Batch(cols, n, (cb.table_ns or b"").decode(), (cb.table_name or b"").decode())
+    if cb.kind:
+        b.kind = _np_from_ptr(cb.kind, n, np.uint8)
+    if cb.src_row:
+        b.src_row = _np_from_ptr(cb.src_row, n, np.int32)
+    if cb.part_id:
+        b.part_id = _np_from_ptr(cb.part_id, n, np.uint32)
+    return b
+
+
+# ---- building batches from Go-typed python values (tests, host mirror) ----
+_GOTYPE_REPR = {"int8": R_INT8, "int16": R_INT16, "int32": R_INT32, "int64": R_INT64, "int": R_INT64,
+                "uint8": R_UINT8, "uint16": R_UINT16, "uint32": R_UINT32, "uint64": R_UINT64, "uint": R_UINT64,
+                "float32": R_FLOAT32, "float64": R_FLOAT64, "bool": R_BOOL, "string": R_STRING, "bytes": R_BYTES,
+                "bytes-utf8": R_BYTES, "jsonnum": R_JSONNUM, "json": R_JSON, "time": R_TIME, "duration": R_DURATION}
+
+_RFC = re.compile(r"^(-?\d{4,})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)(?:\.(\d+))?(Z|[+-]\d\d:\d\d)$")
+
+
+def days_from_civil(y: int, m: int, d: int) -> int:
+    y -= m <= 2
+    era = y // 400  # python floor division
+    yoe = y - era * 400
+    doy = (153 * (m - 3 if m > 2 else m + 9) + 2) // 5 + d - 1
+    doe = yoe * 365 + yoe // 4 - yoe // 100 + doy
+    return era * 146097 + doe - 719468
+
+
+def parse_rfc3339(s: str):
+    """RFC3339Nano text (any year, any numeric zone) → (unix seconds, nanoseconds)."""
+    m = _RFC.match(s)
+    if not m:
+        raise ValueError("bad time " + s)
+    y, mo, d, h, mi, se = (int(m.group(i)) for i in range(1, 7))
+    frac = (m.group(7) or "")[:9].ljust(9, "0")
+    z = m.group(8)
+    off = 0 if z == "Z" else (1 if z[0] == "+" else -1) * (int(z[1:3]) * 3600 + int(z[4:6]) * 60)
+    return days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + se - off, int(frac)
+
+
+def _to_bytes(gotype: str, v) -> bytes:
+    if isinstance(v, (bytes, bytearray)):
+        return bytes(v)
+    if isinstance(v, list):
+        return bytes(v)
+    if gotype == "bytes":
+        return v.encode("latin-1")
+    return v.encode("utf-8")
+
+
+def column_from_values(name: str, dtype: str, vals: Sequence) -> Column:
+    """vals: list of [gotype, value]; all non-nil entries must share a gotype."""
+    n = len(vals)
+    gts = {g for g, _ in vals if g != "nil"}
+    if len(gts) > 1:
+        raise ValueError(f"column {name}: mixed Go types {gts}")
+    gt = next(iter(gts)) if gts else "string"
+    r = _GOTYPE_REPR[gt]
+    valid = np.array([g != "nil" for g, _ in vals], dtype=bool)
+    col = Column(name, dtype, r, validity=None if valid.all() else valid)
+    if r in VAR_REPRS:
+        parts = [(_to_bytes(g, v) if g != "nil" else b"") for g, v in vals]
+        off = np.zeros(n + 1, np.uint32)
+        if n:
+            off[1:] = np.cumsum([len(p) for p in parts])
+        col.offsets = off
+        col.data = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    elif r == R_TIME:
+        secs, nanos = np.zeros(n, np.int64), np.zeros(n, np.int32)
+        for i, (g, v) in enumerate(vals):
+            if g == "nil":
+                continue
+            s, ns = parse_rfc3339(v) if isinstance(v, str) else v
+            secs[i], nanos[i] = s, ns
+        col.values, col.nanos = secs, nanos
+    else:
+        arr = np.zeros(n, REPR_NP[r])
+        for i, (g, v) in enumerate(vals):
+            if g != "nil":
+                arr[i] = v
+        col.values = arr
+    return col
+
+
+def batch_from_rows(schema: Schema, names: Sequence[str], rows: Sequence[Sequence], ns="", table="", kinds=None) -> Batch:
+    cols = [column_from_values(nm, schema.dtype_of(nm), [r[i] for r in rows]) for i, nm in enumerate(names)]
+    b = Batch(cols, len(rows), ns, table)
+    if kinds is not None:
+        b.kind = np.array([KIND_ID.get(k, K_OTHER) for k in kinds], dtype=np.uint8)
+    return b
+
+
+def norm_value(v):
+    """Canonical comparable form of a [gotype, value] pair."""
+    g, x = v
+    if g == "nil":
+        return ("nil", None)
+    if g in ("int", "int64"):
+        return ("int64", int(x))
+    if g in ("uint", "uint64"):
+        return ("uint64", int(x))
+    if g in ("string", "bytes", "bytes-utf8", "jsonnum", "json"):
+        return ({"bytes-utf8": "bytes"}.get(g, g), _to_bytes(g, x))
+    if g == "time":
+        return ("time", tuple(parse_rfc3339(x)) if isinstance(x, str) else tuple(x))
+    if g == "float32":
+        return ("float32", float(np.float32(x)))
+    if g == "float64":
+        return ("float64", float(x))
+    if g == "bool":
+        return ("bool", bool(x))
+    return (g, int(x))
+
+
+def batch_rows(b: Batch):
+    return [[norm_value(c.pyvalue(i)) for c in b.cols] for i in range(b.nrows)]
+
+
+def csv_options(delimiter=",", quote_char='"', escape_char="\\", double_quote=1, newlines_in_value=0,
+                include_missing_columns=0, strings_can_be_null=0, quoted_strings_can_be_null=0, null_values=(),
+                true_values=(), false_values=(), timestamp_parsers=(), decimal_point="", skip_rows=0) -> CCsvOptions:
+    o = CCsvOptions()
+
+    def ch(x):
+        return 0 if x in (0, None, "") else (x if isinstance(x, int) else ord(x))
+    o.delimiter, o.quote_char, o.escape_char = ch(delimiter), ch(quote_char), ch(escape_char)
+    o.double_quote, o.newlines_in_value = int(double_quote), int(newlines_in_value)
+    o.include_missing_columns, o.strings_can_be_null = int(include_missing_columns), int(strings_can_be_null)
+    o.quoted_strings_can_be_null = int(quoted_strings_can_be_null)
+    keep = []
+
+    def lst(vals):
+        arr = (C.c_char_p * max(len(vals), 1))(*[_b(v) for v in vals])
+        keep.append(arr)
+        return len(vals), arr
+    o.n_null_values, o.null_values = lst(list(null_values))
+    o.n_true_values, o.true_values = lst(list(true_values))
+    o.n_false_values, o.false_values = lst(list(false_values))
+    o.n_timestamp_parsers, o.timestamp_parsers = lst(list(timestamp_parsers))
+    dp = _b(decimal_point)
+    keep.append(dp)
+    o.decimal_point, o.skip_rows = dp, int(skip_rows)
+    o._keep = keep
+    return o
