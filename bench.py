@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — ClickBench-hits CSV parse → mask(ClientIP) + filter(EventDate) → devnull.
+
+The workload is BASELINE.json configs[1] ("ClickBench hits-1M CSV parse →
+mask(ip)+filter(EventDate) → devnull, 1×MI355X").  One *step* is one pass of
+that hot path over one HBM-resident batch of 2^20 synthetic hits rows per GPU.
+Rows shard by range across ranks with no data-path collective (weak scaling:
+every rank parses its own 2^20-row batch); torch.distributed is used only for
+the barrier and the max-over-ranks timing.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CHAIN = [
+    ("mask_field", {"maskFunctionHash": {"userDefinedSalt": "clickbench-salt"}, "columns": ["clientip"]}),
+    ("filter_rows", {"filter": "eventdate >= 2013-07-15"}),
+]
+
+
+def stage_shard(lib, workload, row0, nrows, chunk_rows=1 << 15):
+    """Generate rows [row0,row0+nrows) chunk by chunk into one reused host buffer and
+    assemble the CSV (header + rows) in HBM.  Returns (DeviceBuffer, nbytes)."""
+    hs = workload.HitsStream(chunk_rows=chunk_rows)
+    sizes, r = [], row0
+    while r < row0 + nrows:  # first pass: sizes only (the generator is deterministic)
+        k = min(chunk_rows, row0 + nrows - r)
+        sizes.append((r, k, hs.chunk(r, k)[1]))
+        r += k
+    total = len(hs.header) + sum(s[2] for s in sizes)
+    dbuf = lib.DeviceBuffer.alloc(total)
+    hdr = np.frombuffer(hs.header, dtype=np.uint8).copy()
+    dbuf.write(0, hdr, len(hdr))
+    off = len(hdr)
+    for (r, k, n) in sizes:
+        buf, n2 = hs.chunk(r, k)
+        assert n2 == n
+        dbuf.write(off, buf, n)
+        off += n
+    return dbuf, total, hs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU per step")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 16, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--prof-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from transferia_amd import lib, workload
+    lib.init(local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    schema = workload.hits_schema()
+    opts = workload.hits_csv_options()
+    plans = [lib.Transformer(t, c) for t, c in CHAIN]
+
+    # ---- stage this rank's shard in HBM (untimed) ----
+    row0 = rank * args.rows
+    dbuf, csv_bytes, hs = stage_shard(lib, workload, row0, args.rows)
+
+    state = {}
+
+    def step(keep=False):
+        db, consumed, errs = lib.csv_parse(opts, schema, dbuf)
+        res = lib.apply_chain(plans, db)
+        if keep:
+            state["parsed_rows"] = db.nrows
+            state["parsed_bytes"] = db.payload_bytes()
+            v = db.view()
+            fixed = 0
+            str_bytes = 0
+            for i in range(v.ncols):
+                c = v.cols[i]
+                if c.repr in (12, 13, 14, 15):
+                    str_bytes += int(c.data_len)
+                else:
+                    fixed += int(v.nrows) * (np.dtype(lib.abi.REPR_NP[c.repr]).itemsize + (4 if c.nanos else 0))
+            state["fixed_bytes"], state["str_bytes"] = fixed, str_bytes
+            state["out_rows"] = res.transformed.nrows
+            state["out_bytes"] = res.transformed.payload_bytes()
+            state["errors"] = len(errs) + len(res.errors)
+            state["consumed"] = consumed
+        res.transformed.free()
+        db.free()  # devnull sink
+
+    for _ in range(args.warmup):
+        step()
+    step(keep=True)  # one extra untimed pass to record sizes
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel device time, HIP events on the library stream (separate, untimed pass) ----
+    lib.prof_reset()
+    lib.prof_enable(True)
+    for _ in range(max(args.prof_steps, 1)):
+        step()
+    lib.prof_enable(False)
+    prof = lib.prof_get()
+    lib.prof_reset()
+
+    rows, fixed_b, str_b = state["parsed_rows"], state["fixed_bytes"], state["str_bytes"]
+    sel = state["out_rows"] / max(rows, 1)
+    # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"; SURVEY.md §8d per-row figures × rows per launch)
+    alg = {
+        "csv_count_newlines": csv_bytes,
+        "csv_line_index": csv_bytes + 4 * rows,
+        "csv_parse_rows": csv_bytes + fixed_b,            # read every input byte once, write every fixed-width value once
+        "csv_copy_strings": 2 * str_b,                    # string payload: one read + one write
+        "scan_u32_segments": 12 * rows * 28,
+        "mask_hmac_sha256": 72 * rows,                    # 4 B in + 64 B hex + 4 B offset per value
+        "filter_rows_eval": int((8 + 4 + 0.125) * rows),  # time value + keep flag
+        "compact_gather": int((1 + sel) * state["parsed_bytes"]),
+        "scan_u32": 12 * rows,
+    }
+    kernels = {}
+    for name, launches, ms in prof:
+        if launches:
+            kernels[name] = {"launches_per_step": launches / max(args.prof_steps, 1), "avg_ms": ms / launches,
+                             "ms_per_step": ms / max(args.prof_steps, 1)}
+    dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if kernels else None
+    roofline = None
+    if dom:
+        per_launch = alg.get(dom, 0) / max(kernels[dom]["launches_per_step"], 1)
+        achieved = per_launch / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 if per_launch else 0.0
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(per_launch),
+                    "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+    for k, v in kernels.items():
+        b = alg.get(k)
+        if b:
+            v["alg_gb_s"] = round(b / max(v["launches_per_step"], 1) / (v["avg_ms"] * 1e-3) / 1e9, 2)
+        v["avg_ms"], v["ms_per_step"] = round(v["avg_ms"], 4), round(v["ms_per_step"], 4)
+
+    # ---- CPU baseline: the oracle (C restatement of the Go reference), rank 0, N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_rows > 0:
+        from oracle import oracle as ora
+        sample = workload.hits_csv(args.cpu_rows)
+        ochain = [ora.Transformer(t, c) for t, c in CHAIN]
+        r1 = ora.csv_parse(opts, schema, sample, "", "")
+        r2 = ora.apply_chain(ochain, r1.batch, r1.schema)
+        secs = r1.seconds + r2.seconds
+        cpu = {"value": round(args.cpu_rows / secs, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{args.cpu_rows} rows of the same synthetic hits CSV: oracle csv parse+strictify ({r1.seconds:.2f}s) + mask+filter ({r2.seconds:.2f}s), "
+                         "single thread = the reference's shape for one table (transformation.go:131-135)",
+               "note": "C restatement of the Go reference (row-oriented boxed values), not the Go binary"}
+
+    if rank == 0:
+        total_rows = rows * world * args.steps
+        value = total_rows / dt
+        out = {
+            "metric": "ChangeItems/sec through CSV parse -> mask(ClientIP)+filter(EventDate) -> devnull, ClickBench hits",
+            "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "ClickBench hits-1M CSV parse -> mask(ip)+filter(EventDate) -> devnull (BASELINE.json configs[1])",
+                       "rows_per_gpu_per_step": rows, "csv_bytes_per_gpu_per_step": csv_bytes, "columns": len(schema.cols),
+                       "chain": [t for t, _ in CHAIN], "filter_selectivity": round(sel, 4), "parallelism": f"row-range shard x{world}, no collective"},
+            "gib_per_s_csv_in": round(csv_bytes * world * args.steps / dt / 2**30, 3),
+            "gib_per_s_deepsizeof": round((state["parsed_bytes"] + 16 * len(schema.cols) * rows) * world * args.steps / dt / 2**30, 3),
+            "rows_out_per_step": state["out_rows"], "row_errors": state["errors"],
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

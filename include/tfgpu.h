@@ -264,6 +264,10 @@ int tfgpu_dbuf_download(const tfgpu_dbuf *b, void *host, uint64_t cap);
 void tfgpu_dbuf_free(tfgpu_dbuf *b);
 /* Upload raw bytes (e.g. a CSV chunk) so a parse can start HBM-resident.    */
 int tfgpu_dbuf_upload(const void *host, uint64_t len, tfgpu_dbuf **out);
+/* Allocate `len` bytes in HBM and fill them piecewise from a (pinned) staging
+ * buffer: the H2D half of the double-buffered pull loop (parsequeue.go:57-154). */
+int tfgpu_dbuf_alloc(uint64_t len, tfgpu_dbuf **out);
+int tfgpu_dbuf_write(tfgpu_dbuf *b, uint64_t offset, const void *host, uint64_t len);
 
 /* ---- profiling hooks (bench.py / rocprof cross-check) ------------------- */
 /* Per-kernel accumulated device time measured with HIP events on the library

@@ -1,0 +1,134 @@
+"""Parity of the HIP CSV ingest (tfgpu_csv_parse: csv.Reader + constructCI +
+Strictify on device) with the oracle.  Through the C ABI; needs an MI355X."""
+import numpy as np
+import pytest
+
+from transferia_amd import abi, workload
+from util import golden
+from test_gpu_transformers import assert_batches_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+def compare(tf, oracle, opts_kw, schema, data: bytes, ctx=""):
+    opts = abi.csv_options(**opts_kw)
+    ref = oracle.csv_parse(opts, schema, data, "ns", "t")
+    db, consumed, errs = tf.csv_parse(opts, schema, data)
+    out = db.download()
+    assert consumed == ref.consumed, ctx
+    gpu_err = sorted((e[0], e[1]) for e in errs)
+    ref_err = sorted((e[0], abi.ROWERR[e[1]]) for e in ref.errors)
+    hf = {e[0] for e in gpu_err if e[1] == "HOST_FALLBACK"}
+    if hf:
+        # rows the device hands back to the host path: everything else must still agree
+        gpu_err = [e for e in gpu_err if e[0] not in hf]
+        ref_err = [e for e in ref_err if e[0] not in hf]
+        keep = ~np.isin(ref.batch.src_row, list(hf))
+        assert np.array_equal(out.src_row if out.src_row is not None else np.arange(out.nrows), ref.batch.src_row[keep]), ctx
+    else:
+        if ref.batch.nrows == 0:
+            assert out.nrows == 0, ctx
+        else:
+            assert_batches_equal(out, ref.batch, ctx)
+            src = out.src_row if out.src_row is not None else np.arange(out.nrows, dtype=np.int32)
+            assert np.array_equal(src, ref.batch.src_row), ctx
+    assert gpu_err == ref_err, ctx
+    return out, errs
+
+
+S4 = abi.Schema.of([["a", "int32", True, "0"], ["b", "utf8", False, "1"], ["c", "int64", False, "2"], ["d", "utf8", False, "3"]])
+
+
+def test_reference_reader_cases(tf, oracle):
+    """pkg/csv/reader_test.go inputs through the typed path (all-utf8 schema)."""
+    g = golden("csv_reader.json")
+    for case in g["cases"]:
+        o = dict(case["opts"])
+        if o.get("newlines_in_value") or o.get("quote_char", '"') in (0, None) or "input_latin1" in case:
+            continue  # documented UNSUPPORTED on device this round
+        data = case["input"].encode("utf-8")
+        nf = max((len(r) for r in case.get("expect", [[0] * 8])), default=8)
+        schema = abi.Schema.of([[f"f{i}", "utf8", False, str(i)] for i in range(nf)])
+        o["include_missing_columns"] = 1
+        compare(tf, oracle, o, schema, data, case["name"])
+
+
+def test_unsupported_options_fail_loudly(tf):
+    for kw in [dict(newlines_in_value=1), dict(quote_char=0), dict(timestamp_parsers=["2006-01-02"]), dict(decimal_point=",")]:
+        with pytest.raises(tf.TfgpuError) as ei:
+            tf.csv_parse(abi.csv_options(**kw), S4, b"1,a,2,b\n")
+        assert ei.value.code == tf.ERR_UNSUPPORTED
+
+
+EDGE_LINES = [
+    b"1,a,2,b\n", b" 1 , a , 2 , b \n", b"1,\"a,b\",2,\"c\"\"d\"\n", b"\n", b"\r\n", b"x\n", b"1\n", b",,,\n", b"1,a,2\n",
+    b"1,a,2,b,extra,more\n", b"08,a,2,b\n", b"0x1F,a,0b101,b\n", b"1_000,a,0x_1,b\n", b"12.00,a,5.0,b\n", b"12.5,a,5,b\n", b"-0,a,+7,b\n",
+    b"2147483647,a,9223372036854775807,b\n", b"2147483648,a,1,b\n", b"-2147483649,a,1,b\n", b"1,a,9223372036854775808,b\n",
+    b"1,a,-9223372036854775808,b\n", b"1,a,-9223372036854775809,b\n", b"\"1\",\"a\",\"2\",\"b\"\n", b"\"1,a,2,b\n", b"1,a\\,2,b\n",
+    b"1,\"a\\\",2,b\"\n", b"1,\"a\\\\\",2,b\n", b"1,\",2,b\n", b"1,\"\",2,\"\"\"\"\n", b"1,\"\"\"\",2,b\n", b"1,\xc2\xa0a\xe2\x80\x83,2,\xe3\x80\x80b\n",
+    b"1,\xd0\xb9\xd1\x86\xd1\x83,2,\xf0\x9f\x98\x80\n", b"1,a\tb,2,\x0bc\x0c\n", b"1,a,2,b\r\n", b"  \n", b"1,a,2,b,\n", b"0,a,0o17,b\n",
+    b"1,a,0X1f,B\n", b"1,'a',2,'b'\n", b"1,a,__1,b\n", b"1,a,1__0,b\n", b"1,a,0_7,b\n", b"+,a,1,b\n", b"1,a,.0,b\n", b"1.,a,1,b\n", b"1,a,00.000,b\n",
+]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(include_missing_columns=1), dict(delimiter=";"), dict(escape_char=0),
+                                dict(double_quote=0), dict(quote_char="'"), dict(strings_can_be_null=1, null_values=["", "a", "1"]),
+                                dict(quoted_strings_can_be_null=1, null_values=["a", "NULL", "2"])])
+def test_edge_lines(tf, oracle, kw):
+    data = b"".join(EDGE_LINES)
+    if kw.get("delimiter") == ";":
+        data = data.replace(b",", b";")
+    compare(tf, oracle, kw, S4, data + b"trailing,no,newline", str(kw))
+    # each line on its own too (first/last line handling)
+    for ln in EDGE_LINES[:12]:
+        compare(tf, oracle, kw, S4, ln, str(kw) + repr(ln))
+    compare(tf, oracle, kw, S4, b"", "empty")
+    compare(tf, oracle, kw, S4, b"no newline at all", "no-nl")
+
+
+def test_typed_columns(tf, oracle):
+    schema = abi.Schema.of([["i8", "int8", False, "0"], ["u8", "uint8", False, "1"], ["u64", "uint64", False, "2"], ["b", "boolean", False, "3"],
+                            ["d", "date", False, "4"], ["dt", "datetime", False, "5"], ["ts", "timestamp", False, "6"], ["f", "double", False, "7"],
+                            ["by", "string", False, "8"], ["any", "any", False, "9"], ["dup", "utf8", False, "0"], ["neg", "int16", False, "-1"]])
+    lines = [
+        b"1,2,3,true,2013-07-15,2013-07-15 10:47:34,1374100000,1.5,bytes,x\n",
+        b"-128,255,18446744073709551615,F,0001-01-01,2013-07-15T10:47:34Z,2013-07-15 10:47:34.123456789,-1e5,,\n",
+        b"127,0,0,1,9999-12-31,2013-07-15T10:47:34+03:00,-5,inf,\"q\"\"q\",\"a,b\"\n",
+        b"128,1,1,t,2013-07-15,2013-07-15,0,nan,a,b\n", b"1,256,1,t,2013-07-15,2013-07-15,0,1,a,b\n", b"1,-1,1,t,2013-07-15,2013-07-15,0,1,a,b\n",
+        b"1,1,-1,t,2013-07-15,2013-07-15,0,1,a,b\n", b"1,1,1,yes,2013-07-15,2013-07-15,0,1,a,b\n", b"1,1,1,TRUE,2013-02-30,2013-07-15,0,1,a,b\n",
+        b"1,1,1,False,2013-13-01,2013-07-15,0,1,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15 24:00:00,0,1,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15 9:05:06,0,1,a,b\n",
+        b"1,1,1,0,2013-07-15,15 Jul 2013,0,1,a,b\n", b"1,1,1,0,13-07-15,2013-07-15,0,1,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15,x,1,a,b\n",
+        b"1,1,1,0,2013-07-15,2013-07-15,0,1.,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15,0,.5,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15,0,+5,a,b\n",
+        b"1,1,1,0,2013-07-15,2013-07-15,0,1e,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15,0,abc,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15,0,0x10,a,b\n",
+        b"1,1,1,0,2013-07-15,2013-07-15T10:47:34.5,2013-07-15T00:00:00.000000001Z,1,a,b\n", b"1,1,1,0,2013-07-15,2013-07-15 10:47:34 +0300,0,1,a,b\n",
+    ]
+    for kw in [dict(), dict(include_missing_columns=1), dict(true_values=["yes"], false_values=["t"], strings_can_be_null=1, null_values=["TRUE"])]:
+        compare(tf, oracle, kw, schema, b"".join(lines), "typed " + str(kw))
+
+
+@pytest.mark.parametrize("n", [1, 257, 5000])
+def test_hits_small(tf, oracle, n):
+    schema = workload.hits_schema()
+    data = workload.hits_csv(n)
+    out, errs = compare(tf, oracle, dict(skip_rows=1), schema, data, f"hits {n}")
+    assert out.nrows == n and not errs
+    # a chunk cut in the middle of a line leaves the tail unconsumed
+    compare(tf, oracle, dict(skip_rows=1), schema, data[: len(data) - 7], f"hits-cut {n}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_bytes(tf, oracle, seed):
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"0123456789,,,,\"\"\\ \t\n\n\nabc-+._xX\xc2\xa0\r'", dtype=np.uint8)
+    data = rng.choice(alphabet, 200_000).tobytes()
+    schema = abi.Schema.of([["a", "int32", True, "0"], ["b", "utf8", False, "1"], ["c", "int16", False, "2"], ["d", "string", False, "4"],
+                            ["e", "double", False, "3"], ["g", "timestamp", False, "2"]])
+    for kw in [dict(include_missing_columns=1), dict(), dict(include_missing_columns=1, escape_char=0), dict(include_missing_columns=1, double_quote=0)]:
+        compare(tf, oracle, kw, schema, data, f"random {seed} {kw}")

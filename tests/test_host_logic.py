@@ -1,0 +1,95 @@
+"""Host-side logic of the product (plan factories, Suitable, ResultSchema,
+Description, filter grammar) against the oracle and the reference's golden
+vectors.  No GPU needed: these paths never launch a kernel."""
+import pytest
+
+from transferia_amd import abi, lib
+from util import golden, item_to_batch
+
+
+def schema_of(item):
+    return item_to_batch(item)[1]
+
+
+@pytest.mark.parametrize("name,tname", [("sharder.json", "sharder_transformer"), ("to_string.json", "convert_to_string"),
+                                        ("to_datetime.json", "convert_to_datetime")])
+def test_suitable_matrix(name, tname):
+    for case in golden(name)["cases"]:
+        t = lib.Transformer(tname, case["config"])
+        assert t.type() == tname
+        assert t.suitable(case["item"]["ns"], case["item"]["table"], schema_of(case["item"])) == case["suitable"]
+        if case["suitable"] and "expect_types" in case:
+            assert [c.dtype for c in t.result_schema(schema_of(case["item"])).cols] == case["expect_types"]
+
+
+def test_mask_result_schema():
+    g = golden("mask.json")
+    t = lib.Transformer("mask_field", g["config"])
+    for case in g["cases"]:
+        s = schema_of(case["item"])
+        assert t.suitable(case["item"]["ns"], case["item"]["table"], s)
+        assert [[c.name, c.dtype, c.key, c.original_type] for c in t.result_schema(s).cols] == case["expect_schema"]
+    assert t.description().startswith("Hash table columns: columns: column1,column2,column3,column4")
+
+
+def test_filter_rows_suitable_and_parse_errors(oracle):
+    g = golden("filter_rows.json")
+    for bad in g["unparseable"] + ["a = ", "a IN 5", "a = (1,2)", "a > NULL", "a IN (1, 'x')", "a IN ((1))", "= 1", "a == 1", "a = 1 OR b = 2",
+                                   "a = 1 AND", "a IN (TRUE, FALSE)", "a = 2013-13-45", "a = 99999999999999999999"]:
+        with pytest.raises(lib.TfgpuError) as ei:
+            lib.Transformer("filter_rows", {"filter": bad})
+        assert ei.value.code == lib.ERR_CONFIG, bad
+        with pytest.raises(ValueError):
+            oracle.Transformer("filter_rows", {"filter": bad})
+    for ok in ["", "a=1", "a  NOT   IN  ( 1 ,2 )", "a in (1)", "a = nil", "A.b_c ~ 'x' and d !~ \"y\"", "a = 2013-07-15T10:00Z", "a=2013-07-15T10:00:01.5+03:00",
+               "a >= -5 AND a <= +7.25", "a = 'it\\'s'", "a = true AND b = FALSE"]:
+        lib.Transformer("filter_rows", {"filter": ok})
+        oracle.Transformer("filter_rows", {"filter": ok})
+    with pytest.raises(lib.TfgpuError):
+        lib.Transformer("filter_rows", {"filter": "a=1", "filters": ["b=2"]})
+    for case in g["cases"]:
+        t = lib.Transformer("filter_rows", case["config"])
+        s = schema_of(case)
+        assert t.suitable(case["ns"], case["table"], s) == case["suitable"], case["name"]
+        assert t.result_schema(s).triples() == s.triples()
+
+
+def test_product_and_oracle_agree_on_host_logic(oracle):
+    schema = abi.Schema.of([["id", "int64", True], ["name", "utf8", False], ["ip", "int32", False], ["ts", "timestamp", False],
+                            ["u", "uint32", False], ["blob", "string", False]])
+    cases = [
+        ("mask_field", {"columns": ["ip", "zzz"], "maskFunctionHash": {"userDefinedSalt": "x"}, "tables": {"includeTables": ["^db\\.t$"]}}),
+        ("mask_field", {"columns": [], "maskFunctionHash": {"userDefinedSalt": "x"}}),
+        ("filter_columns", {"columns": {"includeColumns": ["^i"]}}),
+        ("filter_columns", {"columns": {"excludeColumns": ["^id$"]}}),
+        ("filter_columns", {"columns": {"excludeColumns": ["^name$"]}, "tables": {"excludeTables": ["other"]}}),
+        ("convert_to_string", {"columns": {"includeColumns": ["ts|ip"]}, "convert_to_bytes": True}),
+        ("convert_to_datetime", {"columns": {"includeColumns": [".*"]}}),
+        ("convert_to_datetime", {}),
+        ("sharder_transformer", {"shardsCount": "16", "columns": {"excludeColumns": ["blob"]}}),
+        ("skip_events", {"events": ["delete"], "tables": {"includeTables": ["\"db\"\\.\"t\""]}}),
+        ("rename_tables", {"renameTables": [{"originalName": {"nameSpace": "db", "name": "t"}, "newName": {"nameSpace": "", "name": "t2"}}]}),
+        ("filter_rows", {"filter": "ip > 5 AND name ~ 'a'"}),
+        ("filter_rows", {"filter": "blob > 5"}),
+        ("filter_rows", {"filter": "nope = 1"}),
+    ]
+    for tname, cfg in cases:
+        a, b = lib.Transformer(tname, cfg), oracle.Transformer(tname, cfg)
+        for ns, tbl in [("db", "t"), ("db", "other"), ("", "t"), ("db", "__wal")]:
+            assert a.suitable(ns, tbl, schema) == b.suitable(ns, tbl, schema), (tname, cfg, ns, tbl)
+        assert a.result_schema(schema).triples() == b.result_schema(schema).triples(), (tname, cfg)
+    with pytest.raises(lib.TfgpuError):
+        lib.Transformer("sharder_transformer", {"shardsCount": "abc"})
+    with pytest.raises(lib.TfgpuError):
+        lib.Transformer("mask_field", "{not json")
+    with pytest.raises(lib.TfgpuError):
+        lib.Transformer("filter_columns", {"columns": {"includeColumns": ["("]}})
+
+
+def test_workload_generator_is_row_addressable():
+    from transferia_amd import workload
+    whole = workload.hits_csv(300, header=False)
+    parts = b"".join(workload.hits_csv(100, row0=r, header=False) for r in (0, 100, 200))
+    assert whole == parts
+    assert len(workload.hits_columns()) == 105
+    assert whole.count(b"\n") == 300

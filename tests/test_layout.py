@@ -1,0 +1,75 @@
+"""The oracle is test infrastructure: nothing in the product package may
+import, load or link it, and the product must not contain a CPU fallback."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "transferia_amd")
+
+
+def product_files():
+    for d, _, files in os.walk(PKG):
+        if os.path.basename(d) in ("build", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                yield os.path.join(d, f)
+
+
+def test_product_never_touches_oracle():
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|liboracle|oracle/|ora_[a-z_]+\()")
+    bad = []
+    for p in product_files():
+        src = open(p, encoding="utf-8").read()
+        for m in pat.finditer(src):
+            line = src[: m.start()].count("\n") + 1
+            bad.append(f"{os.path.relpath(p, ROOT)}:{line}: {m.group(0)}")
+    assert not bad, bad
+
+
+def test_libtfgpu_does_not_link_oracle():
+    so = os.path.join(PKG, "libtfgpu.so")
+    if not os.path.exists(so):
+        return
+    out = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert " ora_" not in syms
+
+
+def test_only_allowed_importers_of_oracle():
+    allowed_dirs = {"tests", "oracle"}
+    allowed_files = {"bench.py", "__graft_entry__.py"}
+    offenders = []
+    for d, _, files in os.walk(ROOT):
+        rel = os.path.relpath(d, ROOT)
+        top = rel.split(os.sep)[0]
+        if top in (".git", "gpurun_out", "profiles") or "__pycache__" in rel:
+            continue
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            p = os.path.join(d, f)
+            src = open(p, encoding="utf-8").read()
+            if re.search(r"^\s*(from oracle|import oracle)", src, re.M):
+                if top in allowed_dirs or (rel == "." and f in allowed_files):
+                    continue
+                offenders.append(os.path.relpath(p, ROOT))
+    assert not offenders, offenders
+
+
+def test_no_reference_path_at_runtime():
+    """/root/reference does not exist on the GPU box: only tools/ may mention it."""
+    bad = []
+    for d, _, files in os.walk(ROOT):
+        rel = os.path.relpath(d, ROOT)
+        top = rel.split(os.sep)[0]
+        if top in (".git", "gpurun_out", "tools") or "__pycache__" in rel:
+            continue
+        for f in files:
+            if f.endswith(".py") and f != "test_layout.py":
+                src = open(os.path.join(d, f), encoding="utf-8").read()
+                if re.search(r"open\([^)]*/root/reference|REF\s*=\s*\"/root/reference", src):
+                    bad.append(os.path.join(rel, f))
+    assert not bad, bad

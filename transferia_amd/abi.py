@@ -1,8 +1,8 @@
 """ctypes image of include/tfgpu.h plus numpy-side batch containers.
 
-This module only describes memory layout; it performs no computation and is
-shared by the product binding (transferia_amd.lib) and the test oracle
-wrapper (oracle/oracle.py).
+This module only describes memory layout and performs no computation; the
+product binding (transferia_amd.lib) and the test harness both build their
+batches through it.
 """
 from __future__ import annotations
 

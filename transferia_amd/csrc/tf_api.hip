@@ -1,0 +1,126 @@
+// tf_api.hip — the transformer half of the C ABI (include/tfgpu.h): plan
+// lifecycle, Suitable / ResultSchema, and Apply over a chain of plans.
+#include "tf_plan.hpp"
+
+using namespace tf;
+
+#define TF_API_BEGIN try {
+#define TF_API_END                                                        \
+  }                                                                       \
+  catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }       \
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+
+// blank-import list of the reference: pkg/transformer/registry/registry.go:3-20
+// (device-resident subset; see DESIGN.md for what stays on the host)
+static const char *REGISTRY[] = {"mask_field", "rename_tables", "filter_columns", "skip_events", "filter_rows",
+                                 "convert_to_string", "convert_to_datetime", "sharder_transformer"};
+
+static char *dup_cstr(const std::string &s) {
+  char *r = (char *)std::malloc(s.size() + 1);
+  std::memcpy(r, s.c_str(), s.size() + 1);
+  return r;
+}
+
+extern "C" {
+
+int tfgpu_registry_count(void) { return (int)(sizeof REGISTRY / sizeof *REGISTRY); }
+const char *tfgpu_registry_name(int i) { return (i >= 0 && i < tfgpu_registry_count()) ? REGISTRY[i] : nullptr; }
+
+int tfgpu_plan_create(const char *type_name, const char *config_json, tfgpu_plan **out) {
+  TF_API_BEGIN
+  if (!type_name || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_plan_create: null argument");
+  *out = make_plan(type_name, config_json ? config_json : "{}").release();
+  return TFGPU_OK;
+  TF_API_END
+}
+void tfgpu_plan_destroy(tfgpu_plan *p) { delete p; }
+const char *tfgpu_plan_type(const tfgpu_plan *p) { return p ? p->type_name.c_str() : nullptr; }
+
+int tfgpu_plan_description(const tfgpu_plan *p, char *buf, size_t cap) {
+  TF_API_BEGIN
+  if (!p || !buf || !cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_plan_description: null argument");
+  std::string d = plan_description(*p);
+  size_t n = std::min(cap - 1, d.size());
+  std::memcpy(buf, d.data(), n); buf[n] = 0;
+  return TFGPU_OK;
+  TF_API_END
+}
+
+int tfgpu_plan_suitable(const tfgpu_plan *p, const char *ns, const char *name, const tfgpu_schema *s, int *out) {
+  TF_API_BEGIN
+  if (!p || !s || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_plan_suitable: null argument");
+  *out = plan_suitable(*p, ns ? ns : "", name ? name : "", *s) ? 1 : 0;
+  return TFGPU_OK;
+  TF_API_END
+}
+
+int tfgpu_plan_result_schema(const tfgpu_plan *p, const tfgpu_schema *in, tfgpu_schema **out) {
+  TF_API_BEGIN
+  if (!p || !in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_plan_result_schema: null argument");
+  auto *s = (tfgpu_schema *)std::calloc(1, sizeof(tfgpu_schema));
+  s->cols = (tfgpu_colschema *)std::calloc((size_t)std::max(in->ncols, 1), sizeof(tfgpu_colschema));
+  for (int i = 0; i < in->ncols; i++) {
+    const tfgpu_colschema &c = in->cols[i];
+    std::string name = c.name ? c.name : "";
+    int dtype = c.dtype;
+    std::string orig = c.original_type ? c.original_type : "";
+    switch (p->kind) {
+      case PK_MASK:  // hmac_hasher.go:35-46
+        if (p->mask_has(name)) { dtype = TFGPU_T_UTF8; orig = ""; }
+        break;
+      case PK_TO_STRING:  // to_string.go:114-127
+        if (p->columns.match(name)) dtype = p->to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8;
+        break;
+      case PK_TO_DATETIME:  // to_datetime.go:125-133
+        if (p->columns.match(name) && (dtype == TFGPU_T_INT32 || dtype == TFGPU_T_UINT32)) dtype = TFGPU_T_DATETIME;
+        break;
+      case PK_FILTER_COLUMNS:  // filter_columns_transformer.go:228-239
+        if (!p->columns.match(name)) continue;
+        break;
+      default: break;  // rename, skip_events, filter_rows, sharder: schema unchanged
+    }
+    tfgpu_colschema &o = s->cols[s->ncols++];
+    o.name = dup_cstr(name); o.dtype = dtype; o.flags = c.flags;
+    o.path = dup_cstr(c.path ? c.path : ""); o.original_type = dup_cstr(orig);
+  }
+  *out = s;
+  return TFGPU_OK;
+  TF_API_END
+}
+
+void tfgpu_schema_free(tfgpu_schema *s) {
+  if (!s) return;
+  for (int i = 0; i < s->ncols; i++) { std::free((void *)s->cols[i].name); std::free((void *)s->cols[i].path); std::free((void *)s->cols[i].original_type); }
+  std::free(s->cols); std::free(s);
+}
+
+int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tfgpu_dbatch **out, tfgpu_row_error *errs,
+                int64_t errs_cap, int64_t *nerrs) {
+  TF_API_BEGIN
+  if (!in || !out || (nplans > 0 && !plans)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_apply: null argument");
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  ApplyCtx ax;
+  std::unique_ptr<tfgpu_dbatch> cur = std::make_unique<tfgpu_dbatch>(*in);
+  // transformation.do (transformation.go:252-274): toApply = t.Apply(toApply).Transformed
+  for (int i = 0; i < nplans; i++) {
+    ax.step = i;
+    size_t before = ax.errs.size();
+    std::unique_ptr<tfgpu_dbatch> next = apply_plan(*plans[i], *cur, ax);
+    // errors are reported against rows of the ORIGINAL input batch
+    if (ax.errs.size() > before && cur->src_row) {
+      std::vector<int32_t> sr((size_t)cur->nrows);
+      d2h(sr.data(), cur->src_row->p, sr.size() * 4);
+      tf::sync();
+      for (size_t k = before; k < ax.errs.size(); k++) ax.errs[k].row = sr[(size_t)ax.errs[k].row];
+    }
+    cur = std::move(next);
+  }
+  if (nerrs) *nerrs = (int64_t)ax.errs.size();
+  if (errs) for (int64_t k = 0; k < errs_cap && k < (int64_t)ax.errs.size(); k++) errs[k] = ax.errs[(size_t)k];
+  *out = cur.release();
+  return TFGPU_OK;
+  TF_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// tf_common.hpp — internal (non-ABI) types of libtfgpu: context, HBM buffers,
+// device batches, error plumbing and the per-kernel event profiler.
+// gfx950 / CDNA4 only; there is no CPU path in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tfgpu.h"
+
+namespace tf {
+
+// ---- error plumbing -------------------------------------------------------
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const std::string &m);
+int fail(int code, const std::string &m);  // sets last error, returns code
+
+#define TF_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess)                                                                        \
+      throw ::tf::Error(TFGPU_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+  } while (0)
+
+// ---- context: one process ↔ one GPU ↔ one stream --------------------------
+struct ProfEntry {
+  std::string name;
+  int64_t launches = 0;
+  double total_ms = 0;
+};
+
+struct Context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipMemPool_t pool = nullptr;
+  bool prof_on = false;
+  std::vector<ProfEntry> prof;
+  struct Pending { int idx; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  std::mutex mu;  // serialises API calls that enqueue on the stream
+  int num_cus = 256;
+
+  hipEvent_t get_event();
+  void prof_begin(const char *name, Pending &p);
+  void prof_end(Pending &p);
+  void prof_flush();
+};
+Context &ctx();  // throws TFGPU_ERR_DEVICE if tfgpu_init has not succeeded
+
+// RAII marker: times everything enqueued between ctor and dtor under `name`.
+struct KernelTimer {
+  Context::Pending p{-1, nullptr, nullptr};
+  bool on;
+  explicit KernelTimer(const char *name) : on(ctx().prof_on) { if (on) ctx().prof_begin(name, p); }
+  ~KernelTimer() { if (on) ctx().prof_end(p); }
+};
+
+// ---- HBM buffers (stream-ordered pool) -------------------------------------
+struct DevMem {
+  void *p = nullptr;
+  size_t bytes = 0;
+  explicit DevMem(size_t n);
+  ~DevMem();
+  DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
+};
+using Buf = std::shared_ptr<DevMem>;
+Buf dalloc(size_t bytes);              // uninitialised
+Buf dalloc_zero(size_t bytes);
+template <class T> inline T *ptr(const Buf &b) { return b ? reinterpret_cast<T *>(b->p) : nullptr; }
+
+void h2d(void *dst, const void *src, size_t n);
+void d2h(void *dst, const void *src, size_t n);
+void d2d(void *dst, const void *src, size_t n);
+void sync();
+
+// ---- device batches --------------------------------------------------------
+inline bool repr_is_var(int r) { return r == TFGPU_R_STRING || r == TFGPU_R_BYTES || r == TFGPU_R_JSONNUM || r == TFGPU_R_JSON; }
+inline size_t repr_width(int r) {
+  switch (r) {
+    case TFGPU_R_INT8: case TFGPU_R_UINT8: case TFGPU_R_BOOL: return 1;
+    case TFGPU_R_INT16: case TFGPU_R_UINT16: return 2;
+    case TFGPU_R_INT32: case TFGPU_R_UINT32: case TFGPU_R_FLOAT32: return 4;
+    case TFGPU_R_INT64: case TFGPU_R_UINT64: case TFGPU_R_FLOAT64: case TFGPU_R_TIME: case TFGPU_R_DURATION: return 8;
+    default: return 0;
+  }
+}
+
+struct DColumn {
+  std::string name;
+  int dtype = TFGPU_T_INVALID;
+  int repr = TFGPU_R_INVALID;
+  Buf values, offsets, data, nanos, validity;
+  uint64_t data_len = 0;
+};
+
+}  // namespace tf
+
+struct tfgpu_dbatch {
+  int64_t nrows = 0;
+  std::vector<tf::DColumn> cols;
+  std::string ns, table;
+  tf::Buf kind, src_row, part_id;
+};
+
+struct tfgpu_dbuf {
+  tf::Buf mem;
+  uint64_t size = 0;
+};
+
+namespace tf {
+
+// ---- shared device primitives (tf_scan.hip) --------------------------------
+// out[i] = sum(in[0..i)), i in [0, n]; out has n+1 entries when `with_total`.
+// in/out may alias.  All on ctx().stream.
+void exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, bool with_total);
+// Segmented variant for `nseg` equally-long arrays laid out back to back
+// (used for the string columns of a batch): each segment scanned on its own.
+void exclusive_scan_u32_segments(uint32_t *inout, int64_t seg_len, int nseg, int64_t seg_stride);
+
+}  // namespace tf

@@ -1,0 +1,793 @@
+// tf_csv.hip — CSV ingest on device: pkg/csv.Reader (reader.go:89-324) +
+// s3 CSVReader.doParse (reader_csv.go:233-341, 345-452) + strictify.Strictify
+// (strictify.go:18-181), producing typed Arrow-style columns in HBM without
+// ever materialising ChangeItems.
+//
+// Pipeline (all on the library stream):
+//   1. csv_count_newlines   : '\n' per 16 KiB tile                (reads B_csv)
+//   2. scan + csv_line_index: row_start[] of every complete line  (reads B_csv)
+//   3. csv_parse_rows       : one lane per row, wave-uniform loop over field
+//                             index; splitString state machine over an 8-byte
+//                             register window, typed parse of the fields the
+//                             schema maps, coalesced column-major stores;
+//                             string columns record (start,len)   (reads B_csv, writes B_fixed)
+//   4. segmented scan of string lengths → Arrow offsets
+//   5. csv_copy_strings     : unquote / ""-collapse copy           (reads ~B_str, writes B_str)
+// Rows that fail (missing cell, cast, range, quote errors) are compacted out
+// and reported as tfgpu_row_error, mirroring how parseCSVRows drops them.
+//
+// HBM-bound byte kernel: algorithmic traffic B_csv + B_bin per row.
+#include <algorithm>
+
+#include "tf_devfmt.hpp"
+#include "tf_plan.hpp"
+
+namespace tf {
+
+std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  // tf_transform.hip
+
+// ---------------------------------------------------------------------------
+// line index
+// ---------------------------------------------------------------------------
+static constexpr int NL_THREADS = 256;
+static constexpr int NL_ITERS = 4;
+static constexpr int NL_TILE = NL_THREADS * 16 * NL_ITERS;  // 16 KiB per workgroup
+
+__device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
+  // bit i set iff byte i of the 16-byte chunk is '\n'
+  uint32_t m = 0;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t x = w[k] ^ 0x0A0A0A0Au;
+    uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;  // 0x80 where the byte is zero (exact for the lowest hit, see below)
+    // the borrow trick can flag a byte that follows a true zero byte; verify each byte
+    uint32_t b0 = ((x & 0xFFu) == 0), b1 = ((x & 0xFF00u) == 0), b2 = ((x & 0xFF0000u) == 0), b3 = ((x & 0xFF000000u) == 0);
+    (void)z;
+    m |= (b0 | b1 << 1 | b2 << 2 | b3 << 3) << (4 * k);
+  }
+  return m;
+}
+
+__device__ __forceinline__ uint4 load16_guard(const uint8_t *base, uint64_t pos, uint64_t len) {
+  // buffers handed to the kernels are padded to a multiple of 16 bytes past `len`
+  uint4 v = *reinterpret_cast<const uint4 *>(base + pos);
+  if (pos + 16 > len) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < 16; i++) if (pos + i >= len) w[i >> 2] &= ~(0xFFu << (8 * (i & 3)));
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(NL_THREADS) csv_count_newlines(const uint8_t *__restrict__ data, uint64_t len, uint32_t *__restrict__ tile_counts) {
+  __shared__ uint32_t red[NL_THREADS / 64];
+  uint64_t tile = (uint64_t)blockIdx.x * NL_TILE;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int it = 0; it < NL_ITERS; it++) {
+    uint64_t pos = tile + ((uint64_t)it * NL_THREADS + threadIdx.x) * 16;
+    if (pos < len) cnt += __popc(nl_mask16(load16_guard(data, pos, len)));
+  }
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(NL_THREADS) csv_line_index(const uint8_t *__restrict__ data, uint64_t len, const uint32_t *__restrict__ tile_base,
+                                                            uint32_t *__restrict__ row_start /* [nlines+1], row_start[0] preset */) {
+  __shared__ uint32_t wsum[NL_THREADS / 64];
+  uint64_t tile = (uint64_t)blockIdx.x * NL_TILE;
+  uint32_t base = tile_base[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int it = 0; it < NL_ITERS; it++) {
+    uint64_t pos = tile + ((uint64_t)it * NL_THREADS + threadIdx.x) * 16;
+    uint32_t m = pos < len ? nl_mask16(load16_guard(data, pos, len)) : 0;
+    uint32_t c = __popc(m), inc = c;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (int i = 0; i < NL_THREADS / 64; i++) { uint32_t s = wsum[i]; if (i < wv) wbase += s; tot += s; }
+    __syncthreads();
+    uint32_t k = base + wbase + inc - c;
+    while (m) { int b = __ffs(m) - 1; m &= m - 1; row_start[++k] = (uint32_t)(pos + b + 1); }
+    base += tot;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// byte readers
+// ---------------------------------------------------------------------------
+// Sequential reader over HBM with an 8-byte register window.
+struct MemBytes {
+  const uint8_t *base;  // 8-byte aligned buffer start
+  uint64_t win; uint64_t widx;
+  __device__ __forceinline__ explicit MemBytes(const uint8_t *b) : base(b), win(0), widx(~0ull) {}
+  __device__ __forceinline__ uint32_t at(uint64_t pos) {
+    uint64_t i = pos >> 3;
+    if (i != widx) { win = reinterpret_cast<const uint64_t *>(base)[i]; widx = i; }
+    return (uint32_t)(win >> ((pos & 7) * 8)) & 0xFFu;
+  }
+};
+// A field view: absolute [start, start+n) through a MemBytes reader.
+struct Field {
+  MemBytes *m; uint64_t start; uint32_t n;
+  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return m->at(start + i); }
+};
+
+// unicode.IsSpace over UTF-8 at s[i..): width of the space rune or 0
+__device__ __forceinline__ uint32_t space_prefix(const Field &f, uint32_t i, uint32_t end) {
+  uint32_t c = f[i];
+  if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+  if (c < 0xC2) return 0;
+  uint32_t r = end - i;
+  if (c == 0xC2 && r >= 2) { uint32_t d = f[i + 1]; return (d == 0x85 || d == 0xA0) ? 2 : 0; }
+  if (r >= 3 && (c == 0xE1 || c == 0xE2 || c == 0xE3)) {
+    uint32_t d = f[i + 1], e = f[i + 2];
+    if (c == 0xE1) return (d == 0x9A && e == 0x80) ? 3 : 0;
+    if (c == 0xE3) return (d == 0x80 && e == 0x80) ? 3 : 0;
+    if (d == 0x80 && ((e >= 0x80 && e <= 0x8A) || e == 0xA8 || e == 0xA9 || e == 0xAF)) return 3;
+    if (d == 0x81 && e == 0x9F) return 3;
+  }
+  return 0;
+}
+__device__ __forceinline__ uint32_t space_suffix(const Field &f, uint32_t a, uint32_t b) {
+  uint32_t c = f[b - 1];
+  if (c == ' ' || (c >= 9 && c <= 13)) return 1;
+  if (c < 0x80) return 0;
+  if (b - a >= 2 && f[b - 2] == 0xC2 && (c == 0x85 || c == 0xA0)) return 2;
+  if (b - a >= 3 && space_prefix(f, b - 3, b) == 3) return 3;
+  return 0;
+}
+
+struct CsvOpts {
+  uint8_t delim, quote, escape, double_quote, include_missing, strings_can_be_null, quoted_strings_can_be_null, pad;
+  int32_t n_null, n_true, n_false;
+  const uint32_t *list_off;  // offsets of null|true|false values, concatenated, into list_data
+  const uint8_t *list_data;
+};
+
+// sanitizeElement reader.go:273-324: TrimSpace, unquote, count ""-pairs.
+// Returns tfgpu_rowerr (0 ok).  Content = [a, b) within the field; npairs = doubled quotes inside.
+__device__ __forceinline__ int sanitize(const CsvOpts &o, const Field &f, uint32_t &a, uint32_t &b, uint32_t &npairs) {
+  a = 0; b = f.n; npairs = 0;
+  uint32_t k;
+  while (a < b && (k = space_prefix(f, a, b)) > 0) a += k;
+  while (a < b && (k = space_suffix(f, a, b)) > 0) b -= k;
+  if (o.quote == 0) return 0;
+  if (b - a >= 1) {
+    if (b - a == 1 && f[a] == o.quote) return TFGPU_ROW_QUOTE;
+    if (f[a] == o.quote && f[b - 1] == o.quote) { a++; b--; }
+  }
+  for (uint32_t i = a; i + 1 < b;) {
+    if (f[i] == o.quote && f[i + 1] == o.quote) { npairs++; i += 2; } else i++;
+  }
+  if (!o.double_quote && npairs) return TFGPU_ROW_DOUBLE_QUOTE;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// typed parsers over a Field range [a,b)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_(uint32_t c) { return c | 0x20u; }
+__device__ __forceinline__ bool dg(uint32_t c) { return c >= '0' && c <= '9'; }
+
+// strconv/atoi.go underscoreOK over s = f[a..b)
+__device__ bool underscore_ok(const Field &f, uint32_t a, uint32_t b) {
+  uint32_t saw = '^';
+  uint32_t i = a;
+  if (b - i >= 1 && (f[i] == '-' || f[i] == '+')) i++;
+  bool hex = false;
+  if (b - i >= 2 && f[i] == '0' && (lower_(f[i + 1]) == 'b' || lower_(f[i + 1]) == 'o' || lower_(f[i + 1]) == 'x')) { hex = lower_(f[i + 1]) == 'x'; i += 2; saw = '0'; }
+  for (; i < b; i++) {
+    uint32_t c = f[i];
+    if (dg(c) || (hex && lower_(c) >= 'a' && lower_(c) <= 'f')) { saw = '0'; continue; }
+    if (c == '_') { if (saw != '0') return false; saw = '_'; continue; }
+    if (saw == '_') return false;
+    saw = '!';
+  }
+  return saw != '_';
+}
+
+// strconv.ParseUint(s, base 0 or 10, 64): 0 ok, 1 syntax, 2 range
+__device__ int parse_uint64(const Field &f, uint32_t a, uint32_t b, bool base0, uint64_t *out) {
+  *out = 0;
+  if (a >= b) return 1;
+  uint32_t s0 = a;
+  uint32_t base = 10;
+  if (base0 && f[a] == '0') {
+    uint32_t n = b - a;
+    uint32_t c1 = n >= 3 ? lower_(f[a + 1]) : 0;
+    if (c1 == 'b') { base = 2; a += 2; } else if (c1 == 'o') { base = 8; a += 2; } else if (c1 == 'x') { base = 16; a += 2; } else { base = 8; a += 1; }
+  }
+  const uint64_t cutoff = 0xFFFFFFFFFFFFFFFFull / base + 1;
+  bool underscores = false;
+  uint64_t v = 0;
+  for (uint32_t i = a; i < b; i++) {
+    uint32_t c = f[i], d;
+    if (c == '_' && base0) { underscores = true; continue; }
+    else if (dg(c)) d = c - '0';
+    else if (lower_(c) >= 'a' && lower_(c) <= 'z') d = lower_(c) - 'a' + 10;
+    else return 1;
+    if (d >= base) return 1;
+    if (v >= cutoff) { *out = ~0ull; return 2; }
+    v *= base;
+    uint64_t v1 = v + d;
+    if (v1 < v) { *out = ~0ull; return 2; }
+    v = v1;
+  }
+  if (underscores && !underscore_ok(f, s0, b)) return 1;
+  *out = v;
+  return 0;
+}
+// strconv.ParseInt(s, base, 64)
+__device__ int parse_int64(const Field &f, uint32_t a, uint32_t b, bool base0, int64_t *out) {
+  *out = 0;
+  if (a >= b) return 1;
+  bool neg = false;
+  if (f[a] == '+') a++; else if (f[a] == '-') { neg = true; a++; }
+  uint64_t un;
+  int rc = parse_uint64(f, a, b, base0, &un);
+  if (rc == 1) return 1;
+  const uint64_t cutoff = 1ull << 63;
+  if (!neg && un >= cutoff) { *out = (int64_t)(cutoff - 1); return 2; }
+  if (neg && un > cutoff) { *out = (int64_t)cutoff; return 2; }
+  if (rc == 2) return 2;
+  *out = neg ? (int64_t)(0 - un) : (int64_t)un;
+  return 0;
+}
+// spf13/cast trimZeroDecimal: "12.00" → "12"
+__device__ __forceinline__ uint32_t trim_zero_decimal(const Field &f, uint32_t a, uint32_t b) {
+  bool found_zero = false;
+  for (uint32_t i = b; i > a; i--) {
+    uint32_t c = f[i - 1];
+    if (c == '.') { if (found_zero) return i - 1; }
+    else if (c == '0') found_zero = true;
+    else return b;
+  }
+  return b;
+}
+
+__device__ __forceinline__ bool field_equals(const Field &f, uint32_t a, uint32_t b, const uint8_t *s, uint32_t n) {
+  if (b - a != n) return false;
+  for (uint32_t i = 0; i < n; i++) if (f[a + i] != s[i]) return false;
+  return true;
+}
+__device__ __forceinline__ bool in_list(const CsvOpts &o, int first, int count, const Field &f, uint32_t a, uint32_t b) {
+  for (int i = 0; i < count; i++) {
+    uint32_t s = o.list_off[first + i], e = o.list_off[first + i + 1];
+    if (field_equals(f, a, b, o.list_data + s, e - s)) return true;
+  }
+  return false;
+}
+// strconv.ParseBool
+__device__ __forceinline__ int parse_bool(const Field &f, uint32_t a, uint32_t b, int *out) {
+  uint32_t n = b - a;
+  if (n == 1) { uint32_t c = f[a]; if (c == '1' || c == 't' || c == 'T') { *out = 1; return 0; } if (c == '0' || c == 'f' || c == 'F') { *out = 0; return 0; } return 1; }
+  if (n == 4) {
+    uint32_t c0 = f[a], c1 = f[a + 1], c2 = f[a + 2], c3 = f[a + 3];
+    if ((c0 == 'T' && c1 == 'R' && c2 == 'U' && c3 == 'E') || ((c0 == 't' || c0 == 'T') && c1 == 'r' && c2 == 'u' && c3 == 'e')) { *out = 1; return 0; }
+    return 1;
+  }
+  if (n == 5) {
+    uint32_t c0 = f[a], c1 = f[a + 1], c2 = f[a + 2], c3 = f[a + 3], c4 = f[a + 4];
+    if ((c0 == 'F' && c1 == 'A' && c2 == 'L' && c3 == 'S' && c4 == 'E') || ((c0 == 'f' || c0 == 'F') && c1 == 'a' && c2 == 'l' && c3 == 's' && c4 == 'e')) { *out = 0; return 0; }
+    return 1;
+  }
+  return 1;
+}
+
+// cast.StringToDate (spf13/cast v1.7.1 timeFormats) for the fixed numeric shapes:
+//   2006-01-02 | 2006-01-02T15:04:05[.frac][Z07:00] | 2006-01-02 15:04:05[.frac]
+// returns 0 ok, TFGPU_ROW_CAST if the shape is one of these but the value is
+// invalid, TFGPU_ROW_HOST_FALLBACK if the text has another shape.
+__device__ int parse_datetime(const Field &f, uint32_t a, uint32_t b, int64_t *sec, int32_t *nsec) {
+  uint32_t n = b - a;
+  if (n < 10) return TFGPU_ROW_HOST_FALLBACK;
+  for (int i = 0; i < 10; i++) {
+    uint32_t c = f[a + i];
+    if (i == 4 || i == 7) { if (c != '-') return TFGPU_ROW_HOST_FALLBACK; } else if (!dg(c)) return TFGPU_ROW_HOST_FALLBACK;
+  }
+  int64_t y = (f[a] - '0') * 1000 + (f[a + 1] - '0') * 100 + (f[a + 2] - '0') * 10 + (f[a + 3] - '0');
+  int mo = (f[a + 5] - '0') * 10 + (f[a + 6] - '0'), d = (f[a + 8] - '0') * 10 + (f[a + 9] - '0');
+  int h = 0, mi = 0, se = 0; int64_t ns = 0; int off = 0;
+  if (n > 10) {
+    uint32_t sep = f[a + 10];
+    if (sep != 'T' && sep != ' ') return TFGPU_ROW_HOST_FALLBACK;
+    uint32_t k = a + 11;
+    // stdHour "15" takes one or two digits; minutes/seconds are fixed two digits
+    if (k >= b || !dg(f[k])) return TFGPU_ROW_HOST_FALLBACK;
+    h = f[k] - '0'; k++;
+    if (k < b && dg(f[k])) { h = h * 10 + (f[k] - '0'); k++; }
+    if (k + 6 > b || f[k] != ':' || !dg(f[k + 1]) || !dg(f[k + 2]) || f[k + 3] != ':' || !dg(f[k + 4]) || !dg(f[k + 5])) return TFGPU_ROW_HOST_FALLBACK;
+    mi = (f[k + 1] - '0') * 10 + (f[k + 2] - '0'); se = (f[k + 4] - '0') * 10 + (f[k + 5] - '0');
+    k += 6;
+    if (k + 1 < b && (f[k] == '.' || f[k] == ',') && dg(f[k + 1])) {
+      k++; int nd = 0;
+      while (k < b && dg(f[k])) { if (nd < 9) { ns = ns * 10 + (f[k] - '0'); nd++; } k++; }
+      while (nd < 9) { ns *= 10; nd++; }
+    }
+    if (k < b) {
+      if (sep != 'T') return TFGPU_ROW_HOST_FALLBACK;  // "… 15:04:05 -0700", "…Z07:00" after a space: host path
+      if (f[k] == 'Z' && k + 1 == b) k++;
+      else if ((f[k] == '+' || f[k] == '-') && k + 6 == b && dg(f[k + 1]) && dg(f[k + 2]) && f[k + 3] == ':' && dg(f[k + 4]) && dg(f[k + 5])) {
+        int hh = (f[k + 1] - '0') * 10 + (f[k + 2] - '0'), mm = (f[k + 4] - '0') * 10 + (f[k + 5] - '0');
+        if (hh > 24 || mm > 60) return TFGPU_ROW_CAST;
+        off = (f[k] == '-' ? -1 : 1) * (hh * 3600 + mm * 60);
+        k += 6;
+      } else return TFGPU_ROW_HOST_FALLBACK;
+    }
+  }
+  if (mo < 1 || mo > 12 || d < 1 || d > dev::days_in_month(mo, y) || h > 23 || mi > 59 || se > 59) return TFGPU_ROW_CAST;
+  *sec = dev::days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + se - off;
+  *nsec = (int32_t)ns;
+  return 0;
+}
+
+// castx.ToJSONNumberE acceptance (fastfloat.Parse grammar or ParseInt base 10)
+__device__ bool json_number_ok(const Field &f, uint32_t a, uint32_t b) {
+  if (a >= b) return false;
+  uint32_t p = a;
+  if (f[p] == '-' || f[p] == '+') p++;
+  uint32_t d0 = p; while (p < b && dg(f[p])) p++;
+  uint32_t nd = p - d0; bool ok = true;
+  if (p < b && f[p] == '.') { p++; uint32_t f0 = p; while (p < b && dg(f[p])) p++; if (p == f0) nd = 0; else nd += p - f0; }
+  if (nd > 0 && p < b && (f[p] == 'e' || f[p] == 'E')) { p++; if (p < b && (f[p] == '-' || f[p] == '+')) p++; uint32_t x0 = p; while (p < b && dg(f[p])) p++; if (p == x0) ok = false; }
+  if (ok && nd > 0 && p == b) return true;
+  // inf / infinity / nan, case-insensitive
+  uint32_t q = a; if (f[q] == '-' || f[q] == '+') q++;
+  uint32_t n = b - q;
+  auto ci = [&](const char *s, uint32_t sl) { if (n != sl) return false; for (uint32_t i = 0; i < sl; i++) if (lower_(f[q + i]) != (uint32_t)s[i]) return false; return true; };
+  return ci("inf", 3) || ci("infinity", 8) || ci("nan", 3);
+}
+
+// ---------------------------------------------------------------------------
+// row parse kernel
+// ---------------------------------------------------------------------------
+enum CsvKind : int32_t { CK_INT, CK_UINT, CK_STR, CK_JSONNUM, CK_DATE, CK_TIMESTAMP, CK_BOOL, CK_F32, CK_DEFAULT, CK_INTERVAL };
+
+struct CsvCol {
+  int32_t field;      // CSV field index (ColSchema.Path); <0 → DefaultValue
+  int32_t kind;       // CsvKind
+  int32_t width;      // bytes of the fixed-width output element
+  int32_t next;       // next column reading the same field, or -1
+  int64_t lo; uint64_t hi;  // strictify range limits
+  void *values;       // fixed-width output
+  int32_t *nanos;
+  uint32_t *lens;     // string columns: lens[r] = content length (Arrow offsets after the scan)
+  uint32_t *fstart;   // string columns: absolute start of the content | bit31 = has doubled quotes
+};
+
+struct CsvParams {
+  const uint8_t *data;
+  const uint32_t *row_start;  // already shifted by skip_rows
+  int64_t nrows;
+  CsvOpts o;
+  const CsvCol *cols;
+  int32_t ncols;
+  const int32_t *field_first;  // first column index per CSV field, -1 = unused
+  int32_t nfields_used;        // max mapped field index + 1
+  uint8_t *err;                // per row tfgpu_rowerr
+  int32_t *err_col;
+  uint32_t *nerr;
+};
+
+__device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v) {
+  switch (c.width) {
+    case 1: ((int8_t *)c.values)[r] = (int8_t)v; break;
+    case 2: ((int16_t *)c.values)[r] = (int16_t)v; break;
+    case 4: ((int32_t *)c.values)[r] = (int32_t)v; break;
+    default: ((int64_t *)c.values)[r] = v;
+  }
+}
+
+// DefaultValue(col) (pkg/abstract/change_item_builders.go:88-109) after Strictify
+__device__ __forceinline__ void store_default(const CsvCol &c, int64_t r) {
+  switch (c.kind) {
+    case CK_STR: case CK_JSONNUM: c.lens[r] = (c.kind == CK_JSONNUM) ? 1u : 0u; c.fstart[r] = 0x7FFFFFFFu; break;  // "" / json "0"
+    case CK_DATE: case CK_TIMESTAMP: ((int64_t *)c.values)[r] = 0; if (c.nanos) c.nanos[r] = 0; break;
+    case CK_BOOL: ((uint8_t *)c.values)[r] = 0; break;
+    case CK_F32: ((float *)c.values)[r] = 0.f; break;
+    default: store_int(c, r, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have_row = r < p.nrows;
+  uint64_t pos = have_row ? p.row_start[r] : 0;
+  const uint64_t end = have_row ? p.row_start[r + 1] : 0;  // one past '\n'
+  const uint64_t row0 = pos;
+  MemBytes scan(p.data), fld(p.data);
+  const CsvOpts &o = p.o;
+  int err = 0, err_col = -1;
+  // a line that is just "\n" makes ReadLine return (nil, nil): zero fields (reader.go:146-150)
+  const bool nil_line = have_row && (end - pos) <= 1;
+  bool active = have_row && !nil_line;
+  bool in_quotes = false; uint32_t prev = 0xFFFFFFFFu;
+  int32_t nfields = 0;          // fields produced so far by this lane
+  bool seen_delim = false;
+  for (int32_t f = 0;; f++) {
+    // ---- splitString (reader.go:220-271): advance to the end of field f ----
+    uint64_t fs = pos, fe = pos; bool last = false;
+    if (active) {
+      while (true) {
+        if (pos >= end) { last = true; fe = end; break; }
+        uint32_t ch = scan.at(pos);
+        if (o.escape != 0 && prev == o.escape && in_quotes) { prev = ch; pos++; continue; }
+        if (o.quote != 0 && ch == o.quote) { in_quotes = !in_quotes; prev = ch; pos++; continue; }
+        if (ch == o.delim && !in_quotes) { fe = pos; pos++; seen_delim = true; prev = ch; break; }
+        prev = ch; pos++;
+      }
+      // lastElement := line[lastDelimPosition+1:] with lastDelimPosition == 0 when the
+      // line holds no delimiter: the first byte of the line is dropped (reader.go:263)
+      if (last && !seen_delim) fs = row0 + 1 <= end ? row0 + 1 : end;
+    }
+    const bool has_field = active;
+    if (!__any(has_field) && f >= p.nfields_used) break;
+    // ---- sanitizeElement on every field, mapped or not (errors abort the line) ----
+    Field fv{&fld, fs, (uint32_t)(fe - fs)};
+    uint32_t a = 0, b = 0, npairs = 0;
+    const int32_t first_col = f < p.nfields_used ? p.field_first[f] : -1;
+    if (has_field && !err) {
+      int e = sanitize(o, fv, a, b, npairs);
+      if (e) { err = e; err_col = first_col; }
+      nfields = f + 1;
+    }
+    // ---- constructCI + getCorrespondingValue + Strictify for the mapped columns ----
+    for (int32_t ci = first_col; ci >= 0; ci = p.cols[ci].next) {
+      const CsvCol &c = p.cols[ci];
+      if (!have_row || err) continue;
+      if (!has_field) {  // index >= len(row) (reader_csv.go:303-316)
+        if (o.include_missing) store_default(c, r); else { err = TFGPU_ROW_MISSING_CELL; err_col = ci; }
+        continue;
+      }
+      switch (c.kind) {
+        case CK_INT: case CK_UINT: {
+          // parseNullValues (reader_csv.go:384-401) then cast.ToIntNE(string) + range check
+          bool isnull = false;
+          if (o.quoted_strings_can_be_null) {
+            uint32_t ta = a, tb = b;
+            if (tb > ta && ((fv[ta] == '"' && fv[tb - 1] == '"') || (fv[ta] == '\'' && fv[tb - 1] == '\''))) { ta++; tb = tb > ta ? tb - 1 : ta; }
+            isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, ta, tb);
+          } else if (o.strings_can_be_null) isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
+          if (isnull) { store_default(c, r); break; }
+          if (npairs) { err = TFGPU_ROW_CAST; err_col = ci; break; }  // a '"' survives in the text: not a number
+          uint32_t tb = trim_zero_decimal(fv, a, b);
+          if (c.kind == CK_INT || c.hi != ~0ull) {
+            int64_t v; int rc = parse_int64(fv, a, tb, true, &v);
+            if (rc) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+            if (c.kind == CK_UINT) {
+              if (v < 0) { err = TFGPU_ROW_CAST; err_col = ci; break; }  // errNegativeNotAllowed
+              if ((uint64_t)v > c.hi) { err = TFGPU_ROW_RANGE; err_col = ci; break; }
+            } else if (v < c.lo || v > (int64_t)c.hi) { err = TFGPU_ROW_RANGE; err_col = ci; break; }
+            store_int(c, r, v);
+          } else {  // uint64: cast.ToUint64E parses with ParseUint
+            uint64_t v; int rc = parse_uint64(fv, a, tb, true, &v);
+            if (rc) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+            ((uint64_t *)c.values)[r] = v;
+          }
+          break;
+        }
+        case CK_STR: case CK_JSONNUM: {
+          bool isnull = false;
+          if (c.kind == CK_STR) {
+            if (o.quoted_strings_can_be_null) {
+              uint32_t ta = a, tb = b;
+              if (tb > ta && ((fv[ta] == '"' && fv[tb - 1] == '"') || (fv[ta] == '\'' && fv[tb - 1] == '\''))) { ta++; tb = tb > ta ? tb - 1 : ta; }
+              isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, ta, tb);
+            } else if (o.strings_can_be_null) isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
+          }
+          if (isnull) { c.lens[r] = 0; c.fstart[r] = 0x7FFFFFFFu; break; }
+          if (c.kind == CK_JSONNUM && (npairs || !json_number_ok(fv, a, b))) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          c.lens[r] = (b - a) - npairs;
+          c.fstart[r] = (uint32_t)(fs + a) | (npairs ? 0x80000000u : 0u);
+          break;
+        }
+        case CK_DATE: case CK_TIMESTAMP: {
+          if (npairs) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          int64_t sec = 0; int32_t ns = 0; int rc;
+          if (c.kind == CK_TIMESTAMP && parse_int64(fv, a, b, false, &sec) == 0) rc = 0;  // parseTimestampValue :419-426
+          else rc = parse_datetime(fv, a, b, &sec, &ns);
+          if (rc) { err = rc; err_col = ci; break; }
+          ((int64_t *)c.values)[r] = sec;
+          c.nanos[r] = ns;
+          break;
+        }
+        case CK_BOOL: {  // parseBooleanValue :431-452 then cast.ToBoolE
+          int v = 0;
+          if (npairs) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          if (o.strings_can_be_null && in_list(o, 0, o.n_null, fv, a, b)) v = 0;
+          else if (in_list(o, o.n_null, o.n_true, fv, a, b)) v = 1;
+          else if (in_list(o, o.n_null + o.n_true, o.n_false, fv, a, b)) v = 0;
+          else if (parse_bool(fv, a, b, &v)) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          ((uint8_t *)c.values)[r] = (uint8_t)v;
+          break;
+        }
+        default:  // CK_F32 (strconv.ParseFloat 32-bit rounding), CK_INTERVAL: host path
+          err = TFGPU_ROW_HOST_FALLBACK; err_col = ci;
+      }
+    }
+    if (last) active = false;
+  }
+  if (!have_row) return;
+  // columns whose field index lies beyond every field this line produced, and nil lines
+  if (!err) {
+    for (int32_t ci = 0; ci < p.ncols; ci++) {
+      const CsvCol &c = p.cols[ci];
+      if (c.field < 0) { store_default(c, r); continue; }
+      if (c.field >= nfields) {
+        if (c.field < p.nfields_used && !nil_line) continue;  // handled in the loop above
+        if (o.include_missing) store_default(c, r); else { err = TFGPU_ROW_MISSING_CELL; err_col = ci; break; }
+      }
+    }
+  }
+  p.err[r] = (uint8_t)err;
+  if (err) { p.err_col[r] = err_col; atomicAdd(p.nerr, 1u); }
+}
+
+// rows that failed contribute no string bytes
+__global__ void csv_zero_err_lens(const uint8_t *err, int64_t nrows, const CsvCol *cols, int32_t ncols) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows || !err[r]) return;
+  for (int32_t ci = 0; ci < ncols; ci++) if (cols[ci].lens) cols[ci].lens[r] = 0;
+}
+
+struct CopyCol { const uint32_t *offsets; const uint32_t *fstart; uint8_t *out; int32_t is_jsonnum; };
+struct CopyParams { const uint8_t *data; int64_t nrows; const CopyCol *cols; int32_t ncols; uint8_t quote; };
+
+// lane = row, wave-uniform loop over string columns.  8-byte words where the
+// destination is aligned, byte stores for head/tail and for ""-collapse.
+__global__ void __launch_bounds__(256) csv_copy_strings(CopyParams p) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  MemBytes src(p.data);
+  for (int32_t ci = 0; ci < p.ncols; ci++) {
+    const CopyCol &c = p.cols[ci];
+    uint32_t o0 = c.offsets[r], n = c.offsets[r + 1] - o0;
+    if (!n) continue;
+    uint32_t fsv = c.fstart[r];
+    uint8_t *dst = c.out + o0;
+    if ((fsv & 0x7FFFFFFFu) == 0x7FFFFFFFu) { if (c.is_jsonnum) dst[0] = '0'; continue; }  // DefaultValue of a double is json.Number("0")
+    uint64_t s = fsv & 0x7FFFFFFFu;
+    if (fsv & 0x80000000u) {  // collapse doubled quotes: "" → "
+      uint32_t w = 0;
+      while (w < n) {
+        uint32_t ch = src.at(s);
+        if (ch == p.quote && src.at(s + 1) == p.quote) { dst[w++] = '"'; s += 2; }
+        else { dst[w++] = (uint8_t)ch; s++; }
+      }
+      continue;
+    }
+    uint32_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 7)) { dst[i] = (uint8_t)src.at(s + i); i++; }
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) w |= (uint64_t)src.at(s + i + k) << (8 * k);
+      *reinterpret_cast<uint64_t *>(dst + i) = w;
+    }
+    for (; i < n; i++) dst[i] = (uint8_t)src.at(s + i);
+  }
+}
+
+__global__ void csv_shift_rows(const uint32_t *row_start, int64_t n, uint32_t *out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) out[i] = row_start[i];
+}
+
+}  // namespace tf
+
+using namespace tf;
+
+#define TF_API_BEGIN try {
+#define TF_API_END                                                        \
+  }                                                                       \
+  catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }       \
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+
+extern "C" void tfgpu_csv_options_default(tfgpu_csv_options *o) {  // csv.NewReader reader.go:337-350
+  std::memset(o, 0, sizeof *o);
+  o->delimiter = ','; o->quote_char = '"'; o->escape_char = '\\'; o->double_quote = 1;
+}
+
+static inline unsigned blocks_for(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
+
+extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes, uint64_t len, int mem,
+                               tfgpu_dbatch **out, uint64_t *consumed, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
+  TF_API_BEGIN
+  if (!opts || !schema || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_csv_parse: null argument");
+  if (len >= 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_csv_parse: chunk must be < 2 GiB (the reference reads 20 MiB chunks, chunk_reader.go:12)");
+  // validDelimiter reader.go:326-328
+  if (opts->delimiter == 0 || opts->delimiter == '\r' || opts->delimiter == '\n' || opts->delimiter >= 0x80)
+    return tf::fail(TFGPU_ERR_CONFIG, "csv: invalid delimiter");
+  if (opts->newlines_in_value && opts->quote_char)
+    return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: NewlinesInValue (multi-line quoted fields) is not device-resident yet");
+  if (opts->n_timestamp_parsers > 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: user TimestampParsers layouts are not device-resident yet");
+  if (opts->decimal_point && opts->decimal_point[0]) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: DecimalPoint is not device-resident yet");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  hipStream_t st = cx.stream;
+
+  // ---- input in HBM, padded so 16-byte loads never run off the allocation ----
+  Buf staged;
+  const uint8_t *data;
+  if (mem == TFGPU_MEM_HOST) {
+    staged = dalloc(len + 64);
+    h2d(staged->p, bytes, len);
+    TF_HIP(hipMemsetAsync((char *)staged->p + len, 0, 64, st));
+    data = ptr<uint8_t>(staged);
+  } else {
+    data = (const uint8_t *)bytes;  // tfgpu_dbuf_upload pads its buffers the same way
+    if (reinterpret_cast<uintptr_t>(data) & 15) return tf::fail(TFGPU_ERR_INVALID, "csv: device buffer must be 16-byte aligned");
+  }
+
+  // ---- 1/2: line index ----
+  int64_t ntiles = (int64_t)((len + NL_TILE - 1) / NL_TILE);
+  Buf tile_counts = dalloc((size_t)(ntiles + 1) * 4);
+  uint32_t nlines = 0;
+  if (ntiles) {
+    { KernelTimer t("csv_count_newlines"); csv_count_newlines<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts)); }
+    exclusive_scan_u32(ptr<uint32_t>(tile_counts), ptr<uint32_t>(tile_counts), ntiles, true);
+    d2h(&nlines, ptr<uint32_t>(tile_counts) + ntiles, 4);
+    tf::sync();
+  }
+  Buf row_start = dalloc_zero((size_t)(nlines + 2) * 4);
+  if (nlines) { KernelTimer t("csv_line_index"); csv_line_index<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ptr<uint32_t>(row_start)); }
+  int64_t skip = std::min<int64_t>(std::max<int64_t>(opts->skip_rows, 0), nlines);
+  int64_t nrows = (int64_t)nlines - skip;
+  const uint32_t *rs = ptr<uint32_t>(row_start) + skip;
+
+  // ---- column plan ----
+  int ncols = schema->ncols;
+  std::vector<CsvCol> cols((size_t)ncols);
+  auto db = std::make_unique<tfgpu_dbatch>();
+  db->nrows = nrows;
+  int nstr = 0;
+  for (int i = 0; i < ncols; i++) {
+    int k = schema->cols[i].dtype;
+    if (k == TFGPU_T_UTF8 || k == TFGPU_T_BYTES || k == TFGPU_T_ANY || k == TFGPU_T_FLOAT64) nstr++;
+  }
+  int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
+  Buf lens_all = dalloc((size_t)std::max(nstr, 1) * (size_t)seg_stride * 4 + 16);
+  Buf fstart_all = dalloc((size_t)std::max(nstr, 1) * (size_t)std::max<int64_t>(nrows, 1) * 4);
+  int max_field = -1;
+  int si = 0;
+  std::vector<int> str_col_index;
+  for (int i = 0; i < ncols; i++) {
+    const tfgpu_colschema &sc = schema->cols[i];
+    CsvCol &c = cols[(size_t)i];
+    std::memset(&c, 0, sizeof c);
+    const char *path = sc.path ? sc.path : "";
+    char *endp = nullptr;
+    long idx = std::strtol(path, &endp, 10);
+    if (endp == path || *endp) return tf::fail(TFGPU_ERR_CONFIG, std::string("csv: column ") + (sc.name ? sc.name : "") + ": ColSchema.Path is not an integer (strconv.Atoi)");
+    c.field = (int32_t)idx; c.next = -1;
+    DColumn d;
+    d.name = sc.name ? sc.name : ""; d.dtype = sc.dtype;
+    switch (sc.dtype) {
+      case TFGPU_T_INT8: c.kind = CK_INT; c.width = 1; c.lo = INT8_MIN; c.hi = INT8_MAX; d.repr = TFGPU_R_INT8; break;
+      case TFGPU_T_INT16: c.kind = CK_INT; c.width = 2; c.lo = INT16_MIN; c.hi = INT16_MAX; d.repr = TFGPU_R_INT16; break;
+      case TFGPU_T_INT32: c.kind = CK_INT; c.width = 4; c.lo = INT32_MIN; c.hi = INT32_MAX; d.repr = TFGPU_R_INT32; break;
+      case TFGPU_T_INT64: c.kind = CK_INT; c.width = 8; c.lo = INT64_MIN; c.hi = INT64_MAX; d.repr = TFGPU_R_INT64; break;
+      case TFGPU_T_UINT8: c.kind = CK_UINT; c.width = 1; c.hi = UINT8_MAX; d.repr = TFGPU_R_UINT8; break;
+      case TFGPU_T_UINT16: c.kind = CK_UINT; c.width = 2; c.hi = UINT16_MAX; d.repr = TFGPU_R_UINT16; break;
+      case TFGPU_T_UINT32: c.kind = CK_UINT; c.width = 4; c.hi = UINT32_MAX; d.repr = TFGPU_R_UINT32; break;
+      case TFGPU_T_UINT64: c.kind = CK_UINT; c.width = 8; c.hi = ~0ull; d.repr = TFGPU_R_UINT64; break;
+      case TFGPU_T_BOOLEAN: c.kind = CK_BOOL; c.width = 1; d.repr = TFGPU_R_BOOL; break;
+      case TFGPU_T_DATE: case TFGPU_T_DATETIME: c.kind = CK_DATE; c.width = 8; d.repr = TFGPU_R_TIME; break;
+      case TFGPU_T_TIMESTAMP: c.kind = CK_TIMESTAMP; c.width = 8; d.repr = TFGPU_R_TIME; break;
+      case TFGPU_T_FLOAT32: c.kind = CK_F32; c.width = 4; d.repr = TFGPU_R_FLOAT32; break;
+      case TFGPU_T_FLOAT64: c.kind = CK_JSONNUM; d.repr = TFGPU_R_JSONNUM; break;  // strictify: float64 → json.Number text
+      case TFGPU_T_UTF8: case TFGPU_T_ANY: c.kind = CK_STR; d.repr = TFGPU_R_STRING; break;
+      case TFGPU_T_BYTES: c.kind = CK_STR; d.repr = TFGPU_R_BYTES; break;
+      case TFGPU_T_INTERVAL: c.kind = CK_INTERVAL; c.width = 8; d.repr = TFGPU_R_DURATION; break;
+      default: return tf::fail(TFGPU_ERR_CONFIG, "csv: cannot strictify value of unknown type");
+    }
+    if (c.kind == CK_STR || c.kind == CK_JSONNUM) {
+      c.lens = ptr<uint32_t>(lens_all) + (int64_t)si * seg_stride;
+      c.fstart = ptr<uint32_t>(fstart_all) + (int64_t)si * std::max<int64_t>(nrows, 1);
+      str_col_index.push_back(i);
+      si++;
+    } else {
+      d.values = dalloc((size_t)std::max<int64_t>(nrows, 1) * (size_t)c.width);
+      c.values = d.values->p;
+      if (d.repr == TFGPU_R_TIME) { d.nanos = dalloc((size_t)std::max<int64_t>(nrows, 1) * 4); c.nanos = ptr<int32_t>(d.nanos); }
+    }
+    if (c.field > max_field) max_field = c.field;
+    db->cols.push_back(std::move(d));
+  }
+  std::vector<int32_t> field_first((size_t)std::max(max_field + 1, 1), -1);
+  for (int i = ncols - 1; i >= 0; i--) {
+    int f = cols[(size_t)i].field;
+    if (f < 0) continue;
+    cols[(size_t)i].next = field_first[(size_t)f];
+    field_first[(size_t)f] = i;
+  }
+  // null / true / false value lists
+  std::vector<uint32_t> loff{0}; std::string ldata;
+  auto add_list = [&](int n, const char *const *v) { for (int i = 0; i < n; i++) { ldata += v[i] ? v[i] : ""; loff.push_back((uint32_t)ldata.size()); } };
+  add_list(opts->n_null_values, opts->null_values); add_list(opts->n_true_values, opts->true_values); add_list(opts->n_false_values, opts->false_values);
+  auto up = [&](const void *src, size_t bytes) { Buf b = dalloc(bytes + 16); if (bytes) h2d(b->p, src, bytes); return b; };
+  Buf bcols = up(cols.data(), cols.size() * sizeof(CsvCol)), bff = up(field_first.data(), field_first.size() * 4);
+  Buf bloff = up(loff.data(), loff.size() * 4), bldata = up(ldata.data(), ldata.size());
+  Buf err = dalloc((size_t)nrows + 16), err_col = dalloc((size_t)nrows * 4 + 16), nerr = dalloc_zero(4);
+
+  CsvParams pp;
+  pp.data = data; pp.row_start = rs; pp.nrows = nrows;
+  pp.o.delim = opts->delimiter; pp.o.quote = opts->quote_char; pp.o.escape = opts->escape_char; pp.o.double_quote = opts->double_quote;
+  pp.o.include_missing = opts->include_missing_columns; pp.o.strings_can_be_null = opts->strings_can_be_null;
+  pp.o.quoted_strings_can_be_null = opts->quoted_strings_can_be_null; pp.o.pad = 0;
+  pp.o.n_null = opts->n_null_values; pp.o.n_true = opts->n_true_values; pp.o.n_false = opts->n_false_values;
+  pp.o.list_off = ptr<uint32_t>(bloff); pp.o.list_data = ptr<uint8_t>(bldata);
+  pp.cols = ptr<CsvCol>(bcols); pp.ncols = ncols; pp.field_first = ptr<int32_t>(bff); pp.nfields_used = max_field + 1;
+  pp.err = ptr<uint8_t>(err); pp.err_col = ptr<int32_t>(err_col); pp.nerr = ptr<uint32_t>(nerr);
+
+  // QuoteChar == 0 and the data holds '"' → errQuotingDisabled for that line (reader.go:182-184):
+  // the state machine cannot see it (quote disabled), so treat '"' as an error marker via the quote path
+  if (opts->quote_char == 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: QuoteChar=0 (quoting disabled) is not device-resident yet");
+
+  if (nrows) {
+    KernelTimer t("csv_parse_rows");
+    csv_parse_rows<<<blocks_for(nrows, 256), 256, 0, st>>>(pp);
+  }
+  if (nrows && nstr) {
+    csv_zero_err_lens<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint8_t>(err), nrows, ptr<CsvCol>(bcols), ncols);
+    exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, nstr, seg_stride);
+  } else if (nstr) {
+    TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)nstr * (size_t)seg_stride * 4, st));
+  }
+  // ---- one read-back: error count + string totals ----
+  uint32_t hnerr = 0;
+  std::vector<uint32_t> totals((size_t)std::max(nstr, 1), 0);
+  d2h(&hnerr, nerr->p, 4);
+  for (int s = 0; s < nstr; s++) d2h(&totals[(size_t)s], ptr<uint32_t>(lens_all) + (int64_t)s * seg_stride + nrows, 4);
+  tf::sync();
+
+  // ---- string payloads ----
+  std::vector<CopyCol> cc;
+  for (int s = 0; s < nstr; s++) {
+    DColumn &d = db->cols[(size_t)str_col_index[(size_t)s]];
+    d.data_len = totals[(size_t)s];
+    d.data = dalloc(d.data_len + 8);
+    d.offsets = dalloc((size_t)(nrows + 1) * 4);
+    d2d(d.offsets->p, ptr<uint32_t>(lens_all) + (int64_t)s * seg_stride, (size_t)(nrows + 1) * 4);
+    cc.push_back(CopyCol{ptr<uint32_t>(d.offsets), cols[(size_t)str_col_index[(size_t)s]].fstart, ptr<uint8_t>(d.data), d.repr == TFGPU_R_JSONNUM ? 1 : 0});
+  }
+  Buf bcc = up(cc.data(), cc.size() * sizeof(CopyCol));
+  if (nrows && nstr) {
+    CopyParams cp{data, nrows, ptr<CopyCol>(bcc), nstr, opts->quote_char};
+    KernelTimer t("csv_copy_strings");
+    csv_copy_strings<<<blocks_for(nrows, 256), 256, 0, st>>>(cp);
+  }
+
+  // ---- consumed: one past the last '\n' (an unterminated tail is left for the next chunk) ----
+  uint32_t last = 0;
+  d2h(&last, ptr<uint32_t>(row_start) + nlines, 4);
+  std::unique_ptr<tfgpu_dbatch> result;
+  int64_t ne = 0;
+  if (hnerr) {
+    std::vector<uint8_t> he((size_t)nrows); std::vector<int32_t> hc((size_t)nrows);
+    d2h(he.data(), err->p, (size_t)nrows); d2h(hc.data(), err_col->p, (size_t)nrows * 4);
+    tf::sync();
+    Buf keep = dalloc((size_t)(nrows + 1) * 4);
+    std::vector<uint32_t> hk((size_t)nrows + 1, 0);
+    for (int64_t r = 0; r < nrows; r++) {
+      hk[(size_t)r] = he[(size_t)r] ? 0u : 1u;
+      if (he[(size_t)r]) { if (errs && ne < errs_cap) errs[ne] = tfgpu_row_error{r, he[(size_t)r], 0, hc[(size_t)r]}; ne++; }
+    }
+    h2d(keep->p, hk.data(), hk.size() * 4);
+    result = compact_rows(*db, keep);
+  } else {
+    tf::sync();
+    result = std::move(db);
+  }
+  if (consumed) *consumed = last;
+  if (nerrs) *nerrs = ne;
+  *out = result.release();
+  return TFGPU_OK;
+  TF_API_END
+}

@@ -1,0 +1,102 @@
+// tf_plan.hpp — host-side transformer plans: the C++ image of the reference's
+// transformer structs, built from the same JSON configs the Go factories take
+// (pkg/transformer/registry.go:34-47).  Immutable after construction, so a plan
+// can be used from any number of threads (transformation.go:131-135).
+#pragma once
+#include <array>
+#include <map>
+#include <memory>
+#include <regex>
+#include <string>
+#include <vector>
+
+#include "tf_common.hpp"
+
+namespace tf {
+
+// ---- tiny JSON reader (configs only) ---------------------------------------
+struct Json {
+  enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
+  bool b = false;
+  double num = 0;
+  std::string str;
+  std::vector<Json> arr;
+  std::vector<std::pair<std::string, Json>> obj;
+  const Json *get(const std::string &key) const;  // case-insensitive fallback like encoding/json
+  std::string s(const std::string &key, const std::string &dflt = "") const;
+  bool flag(const std::string &key, bool dflt = false) const;
+  std::vector<std::string> strings(const std::string &key) const;
+  static Json parse(const std::string &text);  // throws Error(TFGPU_ERR_CONFIG)
+};
+
+// ---- filter.Filter (pkg/transformer/registry/filter/filter.go:19-74) --------
+struct NameFilter {
+  std::vector<std::string> include_src, exclude_src;
+  std::vector<std::regex> include, exclude;
+  void init(const std::vector<std::string> &inc, const std::vector<std::string> &exc);
+  bool match(const std::string &v) const;
+  bool empty() const { return include_src.empty() && exclude_src.empty(); }
+  // MatchAnyTableNameVariant (transformer_common.go:9-33)
+  bool match_table(const std::string &ns, const std::string &name) const;
+};
+
+// ---- filter_rows predicate (library/go/yandex/cloud/filter) ------------------
+enum FOp : int32_t { F_EQ, F_NE, F_LT, F_LE, F_GT, F_GE, F_IN, F_NOTIN, F_MATCH, F_NOTMATCH };
+enum FVal : int32_t { FV_STRING, FV_TIME, FV_BOOL, FV_FLOAT, FV_INT, FV_NULL, FV_BADLIST };
+
+struct FTerm {
+  std::string attr;
+  int32_t op = F_EQ;
+  int32_t vtype = FV_INT;  // element type for lists
+  bool is_list = false;
+  std::vector<int64_t> ints;      // FV_INT / FV_BOOL(0,1) / FV_TIME (unix micro)
+  std::vector<double> floats;     // FV_FLOAT
+  std::vector<std::string> strs;  // FV_STRING
+};
+struct FExpr { std::vector<FTerm> terms; };
+std::vector<FTerm> parse_filter(const std::string &src);  // throws Error(TFGPU_ERR_CONFIG)
+
+}  // namespace tf
+
+enum PlanKind { PK_MASK, PK_RENAME, PK_FILTER_COLUMNS, PK_SKIP_EVENTS, PK_FILTER_ROWS, PK_TO_STRING, PK_TO_DATETIME, PK_SHARDER };
+
+struct tfgpu_plan {
+  int kind = PK_MASK;
+  std::string type_name;
+  tf::NameFilter tables, columns;
+  // mask_field
+  std::string salt;
+  std::vector<std::string> mask_cols;
+  uint32_t ipad_state[8], opad_state[8];  // SHA-256 midstates after the key block
+  // rename_tables
+  std::vector<std::array<std::string, 4>> renames;  // from_ns, from_name, to_ns, to_name
+  // skip_events
+  bool skip[4] = {false, false, false, false};
+  // filter_rows
+  std::vector<tf::FExpr> exprs;
+  // convert_to_string
+  bool to_bytes = false, skip_utc = false;
+  // sharder_transformer
+  int64_t shards = 1;
+  bool is_random = false;
+
+  bool mask_has(const std::string &n) const {
+    for (auto &c : mask_cols) if (c == n) return true;
+    return false;
+  }
+};
+
+namespace tf {
+std::unique_ptr<tfgpu_plan> make_plan(const std::string &type_name, const std::string &config_json);
+bool plan_suitable(const tfgpu_plan &p, const std::string &ns, const std::string &name, const tfgpu_schema &s);
+std::string plan_description(const tfgpu_plan &p);
+bool is_system_table(const std::string &name);
+void sha256_midstate(const uint8_t block[64], uint32_t out[8]);
+
+// Apply one plan to a device batch (tf_transform.hip). `errs` collects row errors.
+struct ApplyCtx {
+  std::vector<tfgpu_row_error> errs;
+  int step = 0;
+};
+std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax);
+}  // namespace tf

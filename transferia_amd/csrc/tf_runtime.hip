@@ -1,0 +1,330 @@
+// tf_runtime.hip — context, HBM pool, profiler and the batch/buffer half of the
+// C ABI (include/tfgpu.h).  One process drives one MI355X through one HIP
+// stream; device memory comes from a stream-ordered pool whose release
+// threshold is unlimited, so steady-state batches never hit hipMalloc.
+#include <algorithm>
+#include <cstdlib>
+
+#include "tf_common.hpp"
+
+namespace tf {
+
+static thread_local std::string g_last_error;
+static std::unique_ptr<Context> g_ctx;
+static std::mutex g_init_mu;
+
+void set_last_error(const std::string &m) { g_last_error = m; }
+int fail(int code, const std::string &m) { g_last_error = m; return code; }
+
+Context &ctx() {
+  if (!g_ctx) throw Error(TFGPU_ERR_DEVICE, "tfgpu_init() has not been called (or no gfx950 device): no CPU fallback exists");
+  return *g_ctx;
+}
+
+hipEvent_t Context::get_event() {
+  if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+  hipEvent_t e;
+  TF_HIP(hipEventCreate(&e));
+  return e;
+}
+void Context::prof_begin(const char *name, Pending &p) {
+  int idx = -1;
+  for (size_t i = 0; i < prof.size(); i++) if (prof[i].name == name) { idx = (int)i; break; }
+  if (idx < 0) { prof.push_back(ProfEntry{name, 0, 0}); idx = (int)prof.size() - 1; }
+  p.idx = idx; p.a = get_event(); p.b = get_event();
+  TF_HIP(hipEventRecord(p.a, stream));
+}
+void Context::prof_end(Pending &p) {
+  hipEventRecord(p.b, stream);
+  pending.push_back(p);
+  if (pending.size() > 4096) prof_flush();
+}
+void Context::prof_flush() {
+  if (pending.empty()) return;
+  hipStreamSynchronize(stream);
+  for (auto &p : pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof[p.idx].launches++; prof[p.idx].total_ms += ms; }
+    free_events.push_back(p.a); free_events.push_back(p.b);
+  }
+  pending.clear();
+}
+
+DevMem::DevMem(size_t n) : bytes(n) {
+  Context &c = ctx();
+  size_t a = n ? n : 16;
+  hipError_t e = hipMallocAsync(&p, a, c.stream);
+  if (e != hipSuccess) throw Error(TFGPU_ERR_NOMEM, std::string("hipMallocAsync(") + std::to_string(a) + "): " + hipGetErrorString(e));
+}
+DevMem::~DevMem() {
+  if (p && g_ctx) hipFreeAsync(p, g_ctx->stream);
+}
+Buf dalloc(size_t bytes) { return std::make_shared<DevMem>(bytes); }
+Buf dalloc_zero(size_t bytes) {
+  Buf b = dalloc(bytes);
+  if (bytes) TF_HIP(hipMemsetAsync(b->p, 0, bytes, ctx().stream));
+  return b;
+}
+void h2d(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx().stream)); }
+void d2h(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, ctx().stream)); }
+void d2d(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, ctx().stream)); }
+void sync() { TF_HIP(hipStreamSynchronize(ctx().stream)); }
+
+}  // namespace tf
+
+using namespace tf;
+
+#define TF_API_BEGIN try {
+#define TF_API_END                                                        \
+  }                                                                       \
+  catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }       \
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+
+extern "C" {
+
+int tfgpu_abi_version(void) { return TFGPU_ABI_VERSION; }
+const char *tfgpu_last_error(void) { return g_last_error.c_str(); }
+
+int tfgpu_device_count(int *out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *out = 0; return tf::fail(TFGPU_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  *out = n;
+  return TFGPU_OK;
+}
+
+int tfgpu_init(int device) {
+  TF_API_BEGIN
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (g_ctx) {
+    if (g_ctx->device == device) return TFGPU_OK;
+    return tf::fail(TFGPU_ERR_INVALID, "tfgpu_init: process already bound to another device (one process per GPU)");
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return tf::fail(TFGPU_ERR_DEVICE, "no HIP device visible; this library has no CPU fallback");
+  if (device < 0 || device >= n) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_init: device index out of range");
+  TF_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  TF_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return tf::fail(TFGPU_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  auto c = std::make_unique<Context>();
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount;
+  TF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  TF_HIP(hipDeviceGetDefaultMemPool(&c->pool, device));
+  uint64_t thr = UINT64_MAX;
+  TF_HIP(hipMemPoolSetAttribute(c->pool, hipMemPoolAttrReleaseThreshold, &thr));
+  g_ctx = std::move(c);
+  return TFGPU_OK;
+  TF_API_END
+}
+
+int tfgpu_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (!g_ctx) return TFGPU_OK;
+  hipStreamSynchronize(g_ctx->stream);
+  for (auto &p : g_ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : g_ctx->free_events) hipEventDestroy(e);
+  hipStreamDestroy(g_ctx->stream);
+  g_ctx.reset();
+  return TFGPU_OK;
+}
+
+int tfgpu_synchronize(void) {
+  TF_API_BEGIN
+  tf::sync();
+  return TFGPU_OK;
+  TF_API_END
+}
+
+void *tfgpu_stream(void) { return g_ctx ? (void *)g_ctx->stream : nullptr; }
+
+int tfgpu_host_alloc(size_t bytes, void **out) {
+  TF_API_BEGIN
+  ctx();
+  TF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_host_free(void *p) {
+  TF_API_BEGIN
+  if (p) TF_HIP(hipHostFree(p));
+  return TFGPU_OK;
+  TF_API_END
+}
+
+// ---- batches ---------------------------------------------------------------
+static Buf upload(const void *src, size_t n) {
+  if (!src) return nullptr;
+  Buf b = dalloc(n);
+  h2d(b->p, src, n);
+  return b;
+}
+
+int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
+  TF_API_BEGIN
+  if (!h || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_batch_upload: null argument");
+  if (h->mem != TFGPU_MEM_HOST) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_batch_upload: batch is not in host memory");
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  auto b = std::make_unique<tfgpu_dbatch>();
+  b->nrows = h->nrows;
+  b->ns = h->table_ns ? h->table_ns : "";
+  b->table = h->table_name ? h->table_name : "";
+  size_t n = (size_t)h->nrows;
+  for (int i = 0; i < h->ncols; i++) {
+    const tfgpu_column &c = h->cols[i];
+    DColumn d;
+    d.name = c.name ? c.name : "";
+    d.dtype = c.dtype; d.repr = c.repr;
+    if (c.repr <= TFGPU_R_INVALID || c.repr >= TFGPU_R__COUNT) return tf::fail(TFGPU_ERR_INVALID, "column " + d.name + ": bad repr");
+    if (repr_is_var(c.repr)) {
+      if (!c.offsets) return tf::fail(TFGPU_ERR_INVALID, "column " + d.name + ": var-width column without offsets");
+      d.offsets = upload(c.offsets, (n + 1) * 4);
+      d.data_len = c.offsets[n];
+      d.data = dalloc(d.data_len);
+      h2d(d.data->p, c.data, d.data_len);
+    } else {
+      if (!c.values && n) return tf::fail(TFGPU_ERR_INVALID, "column " + d.name + ": fixed-width column without values");
+      d.values = upload(c.values, n * repr_width(c.repr));
+      if (c.repr == TFGPU_R_TIME && c.nanos) d.nanos = upload(c.nanos, n * 4);
+    }
+    if (c.validity) d.validity = upload(c.validity, (n + 7) / 8);
+    b->cols.push_back(std::move(d));
+  }
+  if (h->kind) b->kind = upload(h->kind, n);
+  if (h->src_row) b->src_row = upload(h->src_row, n * 4);
+  tf::sync();  // caller may release its buffers as soon as we return
+  *out = b.release();
+  return TFGPU_OK;
+  TF_API_END
+}
+
+// Views hand out pointers into per-dbatch scratch arrays.
+struct ViewStore { std::vector<tfgpu_column> cols; };
+static thread_local ViewStore g_view;
+
+int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
+  TF_API_BEGIN
+  if (!b || !v) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_view: null argument");
+  g_view.cols.assign(b->cols.size(), tfgpu_column{});
+  for (size_t i = 0; i < b->cols.size(); i++) {
+    const DColumn &d = b->cols[i];
+    tfgpu_column &c = g_view.cols[i];
+    c.name = d.name.c_str(); c.dtype = d.dtype; c.repr = d.repr;
+    c.values = d.values ? d.values->p : nullptr;
+    c.offsets = ptr<uint32_t>(d.offsets); c.data = ptr<uint8_t>(d.data); c.data_len = d.data_len;
+    c.nanos = ptr<int32_t>(d.nanos); c.validity = ptr<uint8_t>(d.validity);
+  }
+  v->nrows = b->nrows; v->ncols = (int32_t)b->cols.size(); v->cols = g_view.cols.data();
+  v->table_ns = b->ns.c_str(); v->table_name = b->table.c_str();
+  v->kind = ptr<uint8_t>(b->kind); v->src_row = ptr<int32_t>(b->src_row); v->part_id = ptr<uint32_t>(b->part_id);
+  v->mem = TFGPU_MEM_DEVICE;
+  return TFGPU_OK;
+  TF_API_END
+}
+
+int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
+  TF_API_BEGIN
+  if (!b || !h) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: null argument");
+  if (h->ncols != (int32_t)b->cols.size() || h->nrows != b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: shape mismatch");
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  size_t n = (size_t)b->nrows;
+  for (size_t i = 0; i < b->cols.size(); i++) {
+    const DColumn &d = b->cols[i];
+    tfgpu_column &c = h->cols[i];
+    if (repr_is_var(d.repr)) {
+      if (c.offsets && d.offsets) d2h(c.offsets, d.offsets->p, (n + 1) * 4);
+      if (c.data && d.data) d2h(c.data, d.data->p, d.data_len);
+    } else {
+      if (c.values && d.values) d2h(c.values, d.values->p, n * repr_width(d.repr));
+      if (c.nanos && d.nanos) d2h(c.nanos, d.nanos->p, n * 4);
+    }
+    if (c.validity && d.validity) d2h(c.validity, d.validity->p, (n + 7) / 8);
+  }
+  if (h->kind && b->kind) d2h(h->kind, b->kind->p, n);
+  if (h->src_row && b->src_row) d2h(h->src_row, b->src_row->p, n * 4);
+  if (h->part_id && b->part_id) d2h(h->part_id, b->part_id->p, n * 4);
+  tf::sync();
+  return TFGPU_OK;
+  TF_API_END
+}
+
+void tfgpu_dbatch_free(tfgpu_dbatch *b) { delete b; }
+
+// ---- raw byte buffers --------------------------------------------------------
+int tfgpu_dbuf_upload(const void *host, uint64_t len, tfgpu_dbuf **out) {
+  TF_API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  auto b = std::make_unique<tfgpu_dbuf>();
+  b->size = len;
+  b->mem = dalloc(len + 64);  // tail padding lets kernels issue whole 16-byte loads
+  h2d(b->mem->p, host, len);
+  TF_HIP(hipMemsetAsync((char *)b->mem->p + len, 0, 64, ctx().stream));
+  tf::sync();
+  *out = b.release();
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_dbuf_alloc(uint64_t len, tfgpu_dbuf **out) {
+  TF_API_BEGIN
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  auto b = std::make_unique<tfgpu_dbuf>();
+  b->size = len;
+  b->mem = dalloc(len + 64);
+  TF_HIP(hipMemsetAsync((char *)b->mem->p + len, 0, 64, ctx().stream));
+  *out = b.release();
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_dbuf_write(tfgpu_dbuf *b, uint64_t offset, const void *host, uint64_t len) {
+  TF_API_BEGIN
+  if (!b || offset + len > b->size) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbuf_write: out of range");
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  h2d((char *)b->mem->p + offset, host, len);
+  tf::sync();  // the staging buffer is reusable on return
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_dbuf_size(const tfgpu_dbuf *b, uint64_t *out) { *out = b ? b->size : 0; return TFGPU_OK; }
+void *tfgpu_dbuf_ptr(const tfgpu_dbuf *b) { return b && b->mem ? b->mem->p : nullptr; }
+int tfgpu_dbuf_download(const tfgpu_dbuf *b, void *host, uint64_t cap) {
+  TF_API_BEGIN
+  if (!b) return tf::fail(TFGPU_ERR_INVALID, "null dbuf");
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  d2h(host, b->mem->p, std::min<uint64_t>(cap, b->size));
+  tf::sync();
+  return TFGPU_OK;
+  TF_API_END
+}
+void tfgpu_dbuf_free(tfgpu_dbuf *b) { delete b; }
+
+// ---- profiler ---------------------------------------------------------------
+int tfgpu_prof_enable(int on) {
+  TF_API_BEGIN
+  ctx().prof_flush();
+  ctx().prof_on = on != 0;
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_prof_reset(void) {
+  TF_API_BEGIN
+  ctx().prof_flush();
+  ctx().prof.clear();
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_prof_count(void) {
+  if (!g_ctx) return 0;
+  g_ctx->prof_flush();
+  return (int)g_ctx->prof.size();
+}
+int tfgpu_prof_get(int i, const char **name, int64_t *launches, double *total_ms) {
+  if (!g_ctx || i < 0 || i >= (int)g_ctx->prof.size()) return TFGPU_ERR_INVALID;
+  *name = g_ctx->prof[i].name.c_str(); *launches = g_ctx->prof[i].launches; *total_ms = g_ctx->prof[i].total_ms;
+  return TFGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// tf_scan.hip — exclusive prefix sums over uint32 arrays (row counts, string
+// lengths → Arrow offsets, selection vectors).  Reduce-then-scan with 4096
+// elements per 256-thread workgroup: every element is read twice and written
+// once, all accesses 16 B/lane coalesced.  HBM-bound: 12 B/element.
+#include "tf_common.hpp"
+
+namespace tf {
+
+static constexpr int SCAN_THREADS = 256;
+static constexpr int SCAN_ITEMS = 16;
+static constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread across a 256-thread block.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total, uint32_t *lds /*>=4*/) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = wave_incl_scan(v);
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_THREADS / 64; i++) { uint32_t s = lds[i]; if (i < w) base += s; tot += s; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// seg = blockIdx.y; arrays of nseg segments, each seg_stride elements apart.
+__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ sums,
+                                                                  int64_t n, int64_t seg_stride, int64_t nblocks) {
+  __shared__ uint32_t lds[4];
+  const uint32_t *src = in + (int64_t)blockIdx.y * seg_stride;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t s = 0;
+  if (base + SCAN_ITEMS <= n && ((reinterpret_cast<uintptr_t>(src + base) & 15) == 0)) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) { uint4 v = p[i]; s += v.x + v.y + v.z + v.w; }
+  } else {
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) s += src[base + i];
+  }
+  uint32_t tot;
+  block_excl_scan(s, &tot, lds);
+  if (threadIdx.x == 0) sums[(int64_t)blockIdx.y * nblocks + blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                                 const uint32_t *__restrict__ block_base, int64_t n,
+                                                                 int64_t seg_stride, int64_t nblocks, int write_total) {
+  __shared__ uint32_t lds[4];
+  const uint32_t *src = in + (int64_t)blockIdx.y * seg_stride;
+  uint32_t *dst = out + (int64_t)blockIdx.y * seg_stride;
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  bool fast = base + SCAN_ITEMS <= n && ((reinterpret_cast<uintptr_t>(src + base) & 15) == 0);
+  if (fast) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(src + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) { uint4 q = p[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) v[i] = (base + i < n) ? src[base + i] : 0;
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
+  uint32_t tot;
+  uint32_t ex = block_excl_scan(s, &tot, lds) + (block_base ? block_base[(int64_t)blockIdx.y * nblocks + blockIdx.x] : 0);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) { uint32_t t = v[i]; v[i] = ex; ex += t; }
+  if (fast) {
+    uint4 *p = reinterpret_cast<uint4 *>(dst + base);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS / 4; i++) p[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) dst[base + i] = v[i];
+  }
+  // the element one past the end receives the grand total (Arrow offsets[n])
+  if (write_total && base <= n - 1 && n - 1 < base + SCAN_ITEMS) dst[n] = ex;
+}
+
+static void scan_impl(const uint32_t *in, uint32_t *out, int64_t n, int64_t seg_stride, int nseg, bool with_total) {
+  if (n <= 0) {
+    if (with_total) for (int s = 0; s < nseg; s++) TF_HIP(hipMemsetAsync(out + (int64_t)s * seg_stride, 0, 4, ctx().stream));
+    return;
+  }
+  hipStream_t st = ctx().stream;
+  int64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+  dim3 grid((unsigned)nblocks, (unsigned)nseg);
+  if (nblocks == 1) {
+    scan_apply_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, out, nullptr, n, seg_stride, 1, with_total ? 1 : 0);
+    return;
+  }
+  Buf sums = dalloc((size_t)nblocks * nseg * 4 + 4);
+  scan_reduce_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, ptr<uint32_t>(sums), n, seg_stride, nblocks);
+  scan_impl(ptr<uint32_t>(sums), ptr<uint32_t>(sums), nblocks, nblocks, nseg, false);
+  scan_apply_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, out, ptr<uint32_t>(sums), n, seg_stride, nblocks, with_total ? 1 : 0);
+}
+
+void exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, bool with_total) {
+  KernelTimer t("scan_u32");
+  scan_impl(in, out, n, 0, 1, with_total);
+}
+
+// Each segment is (seg_len + 1) entries long, segments seg_stride (>= seg_len+1,
+// a multiple of 4 keeps the 16-byte path) apart; entry 0 of the input is ignored
+// by construction: callers store length[r] at index r and receive offsets at
+// index r, with the total at index seg_len.
+void exclusive_scan_u32_segments(uint32_t *inout, int64_t seg_len, int nseg, int64_t seg_stride) {
+  if (nseg <= 0) return;
+  KernelTimer t("scan_u32_segments");
+  scan_impl(inout, inout, seg_len, seg_stride, nseg, true);
+}
+
+}  // namespace tf

@@ -1,0 +1,782 @@
+// tf_transform.hip — device kernels behind abstract.Transformer.Apply for the
+// row transformers of SURVEY.md §8a (a4–a13), plus the apply dispatcher.
+//
+// All kernels are byte/row kernels: one lane per row, column-major (Arrow)
+// buffers so that neighbouring lanes touch neighbouring addresses.  None of
+// them is a contraction, so there is no MFMA here; mask is INT32-ALU bound
+// (2–3 SHA-256 compressions per value), everything else is HBM bound.
+#include <algorithm>
+
+#include "tf_devfmt.hpp"
+#include "tf_plan.hpp"
+
+namespace tf {
+
+// ---- device view of a column ------------------------------------------------
+struct DCol {
+  const void *values;
+  const uint32_t *offsets;
+  const uint8_t *data;
+  const int32_t *nanos;
+  const uint8_t *validity;
+  int32_t repr;
+  int32_t dtype;
+};
+static DCol dcol_of(const DColumn &c) {
+  DCol d;
+  d.values = c.values ? c.values->p : nullptr;
+  d.offsets = ptr<uint32_t>(c.offsets);
+  d.data = ptr<uint8_t>(c.data);
+  d.nanos = ptr<int32_t>(c.nanos);
+  d.validity = ptr<uint8_t>(c.validity);
+  d.repr = c.repr; d.dtype = c.dtype;
+  return d;
+}
+__device__ __forceinline__ bool is_valid(const DCol &c, int64_t r) { return !c.validity || ((c.validity[r >> 3] >> (r & 7)) & 1); }
+
+static inline unsigned grid_for(int64_t n, int threads) {
+  int64_t b = (n + threads - 1) / threads;
+  return (unsigned)std::max<int64_t>(1, b);
+}
+
+// ============================================================================
+// SerializeToString on device (to_string.go:145-178).  Formats value r of
+// column c into `buf` (>= 64 bytes) unless the value is var-width text, in
+// which case *ext points at the bytes in HBM.  Returns the length.
+// ============================================================================
+__device__ __forceinline__ int serialize_small(const DCol &c, int64_t r, uint8_t *buf, const uint8_t **ext) {
+  *ext = nullptr;
+  if (!is_valid(c, r)) { buf[0] = '<'; buf[1] = 'n'; buf[2] = 'i'; buf[3] = 'l'; buf[4] = '>'; return 5; }
+  switch (c.repr) {
+    case TFGPU_R_INT8: return dev::fmt_i64(buf, ((const int8_t *)c.values)[r]);
+    case TFGPU_R_INT16: return dev::fmt_i64(buf, ((const int16_t *)c.values)[r]);
+    case TFGPU_R_INT32: return dev::fmt_i64(buf, ((const int32_t *)c.values)[r]);
+    case TFGPU_R_INT64: return dev::fmt_i64(buf, ((const int64_t *)c.values)[r]);
+    case TFGPU_R_UINT8: return dev::fmt_u64(buf, ((const uint8_t *)c.values)[r]);
+    case TFGPU_R_UINT16: return dev::fmt_u64(buf, ((const uint16_t *)c.values)[r]);
+    case TFGPU_R_UINT32: return dev::fmt_u64(buf, ((const uint32_t *)c.values)[r]);
+    case TFGPU_R_UINT64: return dev::fmt_u64(buf, ((const uint64_t *)c.values)[r]);
+    case TFGPU_R_BOOL:
+      if (((const uint8_t *)c.values)[r]) { buf[0] = 't'; buf[1] = 'r'; buf[2] = 'u'; buf[3] = 'e'; return 4; }
+      buf[0] = 'f'; buf[1] = 'a'; buf[2] = 'l'; buf[3] = 's'; buf[4] = 'e'; return 5;
+    case TFGPU_R_TIME: {
+      int64_t s = ((const int64_t *)c.values)[r];
+      int32_t ns = c.nanos ? c.nanos[r] : 0;
+      if (c.dtype == TFGPU_T_DATE) return dev::fmt_date(buf, s);
+      if (c.dtype == TFGPU_T_DATETIME || c.dtype == TFGPU_T_TIMESTAMP) return dev::fmt_rfc3339nano(buf, s, ns);
+      return dev::fmt_time_string(buf, s, ns);
+    }
+    case TFGPU_R_DURATION: return dev::fmt_duration(buf, ((const int64_t *)c.values)[r]);
+    case TFGPU_R_STRING: case TFGPU_R_JSONNUM: case TFGPU_R_JSON: case TFGPU_R_BYTES: {
+      uint32_t a = c.offsets[r], b = c.offsets[r + 1];
+      *ext = c.data + a;
+      return (int)(b - a);
+    }
+  }
+  return 0;
+}
+// Host-side check: can serialize_small reproduce SerializeToString for this column?
+static void require_serializable(const DColumn &c, const char *what) {
+  if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64)
+    throw Error(TFGPU_ERR_UNSUPPORTED, std::string(what) + ": column " + c.name + " holds Go floats; shortest-float formatting is not device-resident yet");
+  if (c.repr == TFGPU_R_BYTES && c.dtype != TFGPU_T_BYTES)
+    throw Error(TFGPU_ERR_UNSUPPORTED, std::string(what) + ": column " + c.name + " holds []byte under a non-\"string\" DataType (%v prints a byte list)");
+  if (c.repr == TFGPU_R_STRING && c.dtype == TFGPU_T_ANY)
+    throw Error(TFGPU_ERR_UNSUPPORTED, std::string(what) + ": column " + c.name + " is `any` holding Go strings (json.Marshal quoting)");
+}
+
+// ============================================================================
+// a4  mask_field: hex(HMAC_SHA256(salt, SerializeToString(v))) — hmac_hasher.go:29-33
+// ============================================================================
+__constant__ uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
+
+__device__ __forceinline__ void sha256_compress(uint32_t st[8], uint32_t w[16]) {
+  uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll
+  for (int i = 0; i < 64; i++) {
+    if (i >= 16) {
+      uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+      uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+      uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+      w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+    }
+    uint32_t t1 = h + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + w[i & 15];
+    uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+
+struct MaskParams {
+  DCol col;
+  uint32_t ipad[8], opad[8];
+  int64_t nrows;
+  uint8_t *out;  // nrows * 64 hex bytes
+};
+
+__global__ void __launch_bounds__(256) mask_hmac_kernel(MaskParams p) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  uint8_t buf[64];
+  const uint8_t *ext;
+  int len = serialize_small(p.col, r, buf, &ext);
+  uint32_t st[8], w[16];
+#pragma unroll
+  for (int i = 0; i < 8; i++) st[i] = p.ipad[i];
+  // inner hash: the ipad block is already absorbed; stream the message
+  int off = 0;
+  uint64_t bits = (uint64_t)(64 + len) * 8;
+  bool pad_done = false, len_done = false;
+  while (!len_done) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    int take = len - off; if (take > 64) take = 64; if (take < 0) take = 0;
+    for (int i = 0; i < take; i++) {
+      uint32_t b = ext ? ext[off + i] : buf[off + i];
+      w[i >> 2] |= b << (24 - 8 * (i & 3));
+    }
+    off += take;
+    if (take < 64 && !pad_done) { w[take >> 2] |= 0x80u << (24 - 8 * (take & 3)); pad_done = true; if (take < 56) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; len_done = true; } }
+    else if (pad_done) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; len_done = true; }
+    sha256_compress(st, w);
+  }
+  // outer hash: opad block absorbed; message = 32-byte inner digest
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = st[i];
+  w[8] = 0x80000000u;
+#pragma unroll
+  for (int i = 9; i < 15; i++) w[i] = 0;
+  w[15] = (64 + 32) * 8;
+  uint32_t so[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) so[i] = p.opad[i];
+  sha256_compress(so, w);
+  // hex.EncodeToString: 64 lower-case hex chars, stored as 4 x 16 bytes
+  uint4 *dst = reinterpret_cast<uint4 *>(p.out + r * 64);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // 2 bytes of digest → 4 hex chars (little-endian packing of the output bytes)
+      uint32_t word = so[q * 2 + (k >> 1)];
+      uint32_t half = (k & 1) ? (word & 0xFFFF) : (word >> 16);
+      uint32_t n0 = (half >> 12) & 15, n1 = (half >> 8) & 15, n2 = (half >> 4) & 15, n3 = half & 15;
+      auto hx = [](uint32_t n) { return n + (n < 10 ? '0' : 'a' - 10); };
+      o[k] = hx(n0) | hx(n1) << 8 | hx(n2) << 16 | hx(n3) << 24;
+    }
+    dst[q] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ void fill_offsets_stride_kernel(uint32_t *off, int64_t n, uint32_t stride) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) off[i] = (uint32_t)(i * stride);
+}
+
+static std::unique_ptr<tfgpu_dbatch> shallow_copy(const tfgpu_dbatch &in) { return std::make_unique<tfgpu_dbatch>(in); }
+
+static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu_dbatch &in) {
+  auto out = shallow_copy(in);
+  hipStream_t st = ctx().stream;
+  for (auto &c : out->cols) {
+    if (!p.mask_has(c.name)) continue;
+    require_serializable(c, "mask_field");
+    int64_t n = in.nrows;
+    if ((uint64_t)n * 64 > 0xFFFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "mask_field: batch too large for 32-bit offsets; split the batch by rows");
+    DColumn o;
+    o.name = c.name; o.dtype = TFGPU_T_UTF8; o.repr = TFGPU_R_STRING;
+    o.data_len = (uint64_t)n * 64;
+    o.data = dalloc(o.data_len);
+    o.offsets = dalloc((size_t)(n + 1) * 4);
+    MaskParams mp;
+    mp.col = dcol_of(c);
+    std::memcpy(mp.ipad, p.ipad_state, sizeof mp.ipad);
+    std::memcpy(mp.opad, p.opad_state, sizeof mp.opad);
+    mp.nrows = n; mp.out = ptr<uint8_t>(o.data);
+    {
+      KernelTimer t("mask_hmac_sha256");
+      if (n) mask_hmac_kernel<<<grid_for(n, 256), 256, 0, st>>>(mp);
+    }
+    fill_offsets_stride_kernel<<<grid_for(n + 1, 256), 256, 0, st>>>(ptr<uint32_t>(o.offsets), n, 64);
+    c = std::move(o);
+  }
+  return out;
+}
+
+// ============================================================================
+// a11  filter_rows — filter_rows.go:99-365
+// ============================================================================
+struct DTerm {
+  int32_t col;      // batch column index, -1 = not present in ColumnNames
+  int32_t op, vtype, is_list;
+  int32_t nvals;
+  int32_t ioff;     // into ints / floats
+  int32_t soff;     // into str_off (nvals+1 entries) for FV_STRING
+};
+struct FilterParams {
+  const DCol *cols;
+  int32_t ncols;
+  const DTerm *terms;
+  const int32_t *expr_start;  // nexpr+1
+  int32_t nexpr;
+  const int64_t *ints;
+  const double *floats;
+  const uint32_t *str_off;
+  const uint8_t *str_data;
+  const uint8_t *kind;
+  int64_t nrows;
+  uint32_t *keep;   // 0/1 per row
+  uint8_t *err;     // tfgpu_rowerr per row
+  int32_t *err_term;
+  uint32_t *nerr;   // global counter
+};
+
+__device__ __forceinline__ int cmp_op_i(int64_t a, int64_t b, int op) {
+  switch (op) { case F_EQ: return a == b; case F_NE: return a != b; case F_LT: return a < b; case F_LE: return a <= b; case F_GT: return a > b; case F_GE: return a >= b; }
+  return -1;
+}
+__device__ __forceinline__ int cmp_op_f(double a, double b, int op) {
+  switch (op) { case F_EQ: return a == b; case F_NE: return a != b; case F_LT: return a < b; case F_LE: return a <= b; case F_GT: return a > b; case F_GE: return a >= b; }
+  return -1;
+}
+__device__ __forceinline__ int bytes_compare(const uint8_t *a, uint32_t an, const uint8_t *b, uint32_t bn) {
+  uint32_t m = an < bn ? an : bn;
+  for (uint32_t i = 0; i < m; i++) { if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1; }
+  return an < bn ? -1 : an > bn ? 1 : 0;
+}
+__device__ __forceinline__ bool bytes_contains(const uint8_t *h, uint32_t hn, const uint8_t *n, uint32_t nn) {
+  if (nn == 0) return true;
+  if (nn > hn) return false;
+  for (uint32_t i = 0; i + nn <= hn; i++) {
+    uint32_t k = 0;
+    while (k < nn && h[i + k] == n[k]) k++;
+    if (k == nn) return true;
+  }
+  return false;
+}
+
+// time.Parse over the layouts of stringToTime (filter_rows/util.go:15-39) that
+// are fixed-shape numeric: "2006-01-02", "2006-01-02 15:04:05", "2006-01-02T15:04:05",
+// RFC3339 / RFC3339Nano.  Returns 1 ok, 0 = does not look like any of them
+// (the row is then handed back to the host path).
+__device__ __forceinline__ bool is_dg(uint8_t c) { return c >= '0' && c <= '9'; }
+__device__ int parse_time_subset(const uint8_t *s, uint32_t n, int64_t *sec, int32_t *nsec) {
+  if (n < 10) return 0;
+  if (!(is_dg(s[0]) && is_dg(s[1]) && is_dg(s[2]) && is_dg(s[3]) && s[4] == '-' && is_dg(s[5]) && is_dg(s[6]) && s[7] == '-' && is_dg(s[8]) && is_dg(s[9]))) return 0;
+  int64_t y = (s[0] - '0') * 1000 + (s[1] - '0') * 100 + (s[2] - '0') * 10 + (s[3] - '0');
+  int mo = (s[5] - '0') * 10 + (s[6] - '0'), d = (s[8] - '0') * 10 + (s[9] - '0');
+  int h = 0, mi = 0, se = 0; int64_t ns = 0; int off = 0;
+  uint32_t k = 10;
+  if (n > 10) {
+    if (!(s[10] == 'T' || s[10] == ' ')) return 0;
+    bool tform = s[10] == 'T';
+    if (n < 19) return 0;
+    if (!(is_dg(s[11]) && is_dg(s[12]) && s[13] == ':' && is_dg(s[14]) && is_dg(s[15]) && s[16] == ':' && is_dg(s[17]) && is_dg(s[18]))) return 0;
+    h = (s[11] - '0') * 10 + (s[12] - '0'); mi = (s[14] - '0') * 10 + (s[15] - '0'); se = (s[17] - '0') * 10 + (s[18] - '0');
+    k = 19;
+    if (k + 1 < n && (s[k] == '.' || s[k] == ',') && is_dg(s[k + 1])) {
+      k++; int nd = 0;
+      while (k < n && is_dg(s[k])) { if (nd < 9) { ns = ns * 10 + (s[k] - '0'); nd++; } k++; }
+      while (nd < 9) { ns *= 10; nd++; }
+    }
+    if (k < n) {
+      if (!tform) return 0;  // "2006-01-02 15:04:05 -0700 MST" etc: host path
+      if (s[k] == 'Z') k++;
+      else if ((s[k] == '+' || s[k] == '-') && k + 6 <= n && is_dg(s[k + 1]) && is_dg(s[k + 2]) && s[k + 3] == ':' && is_dg(s[k + 4]) && is_dg(s[k + 5])) {
+        int hh = (s[k + 1] - '0') * 10 + (s[k + 2] - '0'), mm = (s[k + 4] - '0') * 10 + (s[k + 5] - '0');
+        if (hh > 24 || mm > 60) return 0;
+        off = (s[k] == '-' ? -1 : 1) * (hh * 3600 + mm * 60);
+        k += 6;
+      } else return 0;
+      if (k != n) return 0;
+    }
+  }
+  if (mo < 1 || mo > 12 || d < 1 || d > dev::days_in_month(mo, y) || h > 23 || mi > 59 || se > 59) return 0;
+  *sec = dev::days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + se - off;
+  *nsec = (int32_t)ns;
+  return 1;
+}
+
+// matchValue (filter_rows.go:180-365).  Returns 1/0, or -(tfgpu_rowerr).
+__device__ int match_value(const FilterParams &p, const DTerm &t, int64_t r) {
+  const DCol &c = p.cols[t.col];
+  const bool valid = is_valid(c, r);
+  const bool is_set = t.op == F_IN || t.op == F_NOTIN;
+  bool isInt1 = false, isFloat1 = false, maybeFloat = false;
+  int64_t int1 = 0; double float1 = 0;
+  if (valid) {
+    switch (c.repr) {  // toInt64E util.go:42-82, then cast.ToFloat64E
+      case TFGPU_R_INT8: int1 = ((const int8_t *)c.values)[r]; isInt1 = true; break;
+      case TFGPU_R_INT16: int1 = ((const int16_t *)c.values)[r]; isInt1 = true; break;
+      case TFGPU_R_INT32: int1 = ((const int32_t *)c.values)[r]; isInt1 = true; break;
+      case TFGPU_R_INT64: int1 = ((const int64_t *)c.values)[r]; isInt1 = true; break;
+      case TFGPU_R_UINT8: int1 = ((const uint8_t *)c.values)[r]; isInt1 = true; break;
+      case TFGPU_R_UINT16: int1 = ((const uint16_t *)c.values)[r]; isInt1 = true; break;
+      case TFGPU_R_UINT32: int1 = ((const uint32_t *)c.values)[r]; isInt1 = true; break;
+      case TFGPU_R_UINT64: { uint64_t u = ((const uint64_t *)c.values)[r]; if (u > 0x7FFFFFFFFFFFFFFFull) return -TFGPU_ROW_INT_OVERFLOW; int1 = (int64_t)u; isInt1 = true; break; }
+      case TFGPU_R_FLOAT32: float1 = ((const float *)c.values)[r]; isFloat1 = true; break;
+      case TFGPU_R_FLOAT64: float1 = ((const double *)c.values)[r]; isFloat1 = true; break;
+      case TFGPU_R_BOOL: float1 = ((const uint8_t *)c.values)[r] ? 1.0 : 0.0; isFloat1 = true; break;
+      case TFGPU_R_STRING: case TFGPU_R_JSONNUM: maybeFloat = true; break;  // strconv.ParseFloat of text
+    }
+  } else { float1 = 0; isFloat1 = true; }  // cast.ToFloat64E(nil) == 0
+  int res;
+  switch (t.vtype) {
+    case FV_INT:
+      if (isInt1) {
+        if (is_set) { bool f = false; for (int i = 0; i < t.nvals; i++) f = f || p.ints[t.ioff + i] == int1; return t.op == F_IN ? f : !f; }
+        res = cmp_op_i(int1, p.ints[t.ioff], t.op); return res < 0 ? -TFGPU_ROW_TYPE_PAIR : res;
+      }
+      if (maybeFloat) return -TFGPU_ROW_HOST_FALLBACK;
+      if (isFloat1) {
+        if (is_set) {
+          if (trunc(float1) == float1) { int64_t iv = (int64_t)float1; bool f = false; for (int i = 0; i < t.nvals; i++) f = f || p.ints[t.ioff + i] == iv; return t.op == F_IN ? f : !f; }
+          return 0;
+        }
+        res = cmp_op_f(float1, (double)p.ints[t.ioff], t.op); return res < 0 ? -TFGPU_ROW_TYPE_PAIR : res;
+      }
+      break;
+    case FV_FLOAT:
+      if (maybeFloat && !isInt1) return -TFGPU_ROW_HOST_FALLBACK;
+      if (isInt1 || isFloat1) {
+        double a = isInt1 ? (double)int1 : float1;
+        if (is_set) { bool f = false; for (int i = 0; i < t.nvals; i++) f = f || p.floats[t.ioff + i] == a; return t.op == F_IN ? f : !f; }
+        res = cmp_op_f(a, p.floats[t.ioff], t.op); return res < 0 ? -TFGPU_ROW_TYPE_PAIR : res;
+      }
+      break;
+    case FV_BOOL:
+      if (valid && c.repr == TFGPU_R_BOOL) {
+        res = cmp_op_i(((const uint8_t *)c.values)[r] ? 1 : 0, p.ints[t.ioff], t.op); return res < 0 ? -TFGPU_ROW_TYPE_PAIR : res;
+      }
+      break;
+    case FV_STRING:
+      if (valid && (c.repr == TFGPU_R_BYTES || c.repr == TFGPU_R_STRING)) {
+        const uint8_t *a = c.data + c.offsets[r]; uint32_t an = c.offsets[r + 1] - c.offsets[r];
+        const uint32_t *so = p.str_off + t.soff;
+        if (t.op == F_MATCH || t.op == F_NOTMATCH) { bool m = bytes_contains(a, an, p.str_data + so[0], so[1] - so[0]); return t.op == F_MATCH ? m : !m; }
+        if (is_set) {
+          bool f = false;
+          for (int i = 0; i < t.nvals; i++) { uint32_t bn = so[i + 1] - so[i]; if (bn == an && bytes_compare(a, an, p.str_data + so[i], bn) == 0) f = true; }
+          return t.op == F_IN ? f : !f;
+        }
+        int cr = bytes_compare(a, an, p.str_data + so[0], so[1] - so[0]);
+        res = cmp_op_i(cr, 0, t.op); return res < 0 ? -TFGPU_ROW_TYPE_PAIR : res;
+      }
+      break;
+    case FV_TIME: {
+      int64_t us1 = 0; bool have = false;
+      if (valid && c.repr == TFGPU_R_TIME) { us1 = ((const int64_t *)c.values)[r] * 1000000 + (c.nanos ? c.nanos[r] : 0) / 1000; have = true; }
+      else if (valid && c.repr == TFGPU_R_STRING) {
+        int64_t s; int32_t ns;
+        if (!parse_time_subset(c.data + c.offsets[r], c.offsets[r + 1] - c.offsets[r], &s, &ns)) return -TFGPU_ROW_HOST_FALLBACK;
+        us1 = s * 1000000 + ns / 1000; have = true;
+      }
+      if (have) {
+        if (is_set) { bool f = false; for (int i = 0; i < t.nvals; i++) f = f || p.ints[t.ioff + i] == us1; return t.op == F_IN ? f : !f; }
+        res = cmp_op_i(us1, p.ints[t.ioff], t.op); return res < 0 ? -TFGPU_ROW_TYPE_PAIR : res;
+      }
+      break;
+    }
+    case FV_NULL:
+      if (t.op == F_EQ) return !valid;
+      if (t.op == F_NE) return valid;
+      break;
+  }
+  return -TFGPU_ROW_TYPE_PAIR;
+}
+
+__global__ void __launch_bounds__(256) filter_eval_kernel(FilterParams p) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  int kind = p.kind ? p.kind[r] : TFGPU_K_INSERT;
+  uint32_t keep = 0; int err = 0, eterm = -1;
+  if (kind == TFGPU_K_UPDATE || kind == TFGPU_K_DELETE) err = TFGPU_ROW_UNSUPPORTED_KIND;  // :103-107
+  else if (kind != TFGPU_K_INSERT || p.nexpr < 0) keep = 1;                              // :110-113 (nexpr<0: table not matched)
+  else {
+    for (int e = 0; e < p.nexpr && !keep && !err; e++) {  // matchItem :132-143
+      bool ok = true;
+      for (int k = p.expr_start[e]; k < p.expr_start[e + 1] && ok && !err; k++) {  // matchExpression :145-178
+        const DTerm &t = p.terms[k];
+        if (p.ncols == 0) continue;  // a row without columns never enters the name loop
+        if (t.col < 0) { err = TFGPU_ROW_COLUMN_NOT_FOUND; eterm = k; break; }
+        int m = match_value(p, t, r);
+        if (m < 0) { err = -m; eterm = k; } else if (!m) ok = false;
+      }
+      if (!err && ok) keep = 1;
+    }
+  }
+  p.keep[r] = err ? 0 : keep;
+  p.err[r] = (uint8_t)err;
+  if (err) { p.err_term[r] = eterm; atomicAdd(p.nerr, 1u); }
+}
+
+// ============================================================================
+// compaction: keep flags → selection vector → gather of every column
+// ============================================================================
+__global__ void __launch_bounds__(256) build_selection_kernel(const uint32_t *__restrict__ keep_scan, int64_t n, int32_t *__restrict__ sel) {
+  // keep_scan[i] = exclusive prefix of keep; row i kept iff keep_scan[i+1] != keep_scan[i]
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t a = keep_scan[i], b = keep_scan[i + 1];
+  if (a != b) sel[a] = (int32_t)i;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gather_fixed_kernel(const T *__restrict__ in, const int32_t *__restrict__ sel, int64_t m, T *__restrict__ out) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < m) out[k] = in[sel[k]];
+}
+__global__ void __launch_bounds__(256) gather_srcrow_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ sel, int64_t m, int32_t *__restrict__ out) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < m) out[k] = in ? in[sel[k]] : sel[k];
+}
+__global__ void __launch_bounds__(256) gather_bitmap_kernel(const uint8_t *__restrict__ in, const int32_t *__restrict__ sel, int64_t m, uint8_t *__restrict__ out) {
+  // one thread per output byte (8 rows)
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * 8 >= m) return;
+  uint32_t v = 0;
+  for (int j = 0; j < 8; j++) { int64_t k = b * 8 + j; if (k < m) { int32_t s = sel[k]; v |= ((in[s >> 3] >> (s & 7)) & 1u) << j; } }
+  out[b] = (uint8_t)v;
+}
+__global__ void __launch_bounds__(256) gather_len_kernel(const uint32_t *__restrict__ off, const int32_t *__restrict__ sel, int64_t m, uint32_t *__restrict__ len_out) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < m) { int32_t s = sel[k]; len_out[k] = off[s + 1] - off[s]; }
+}
+// One wave per 64 output rows; each row's bytes are copied by the whole wave
+// when long, by one lane when short.
+__global__ void __launch_bounds__(256) gather_bytes_kernel(const uint32_t *__restrict__ in_off, const uint8_t *__restrict__ in_data,
+                                                          const int32_t *__restrict__ sel, const uint32_t *__restrict__ out_off, int64_t m,
+                                                          uint8_t *__restrict__ out_data) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  int32_t s = sel[k];
+  uint32_t a = in_off[s], n = in_off[s + 1] - a, o = out_off[k];
+  const uint8_t *src = in_data + a; uint8_t *dst = out_data + o;
+  for (uint32_t i = 0; i < n; i++) dst[i] = src[i];
+}
+
+// Gather all columns of `in` through `sel` (m output rows).
+static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const Buf &sel, int64_t m) {
+  auto out = std::make_unique<tfgpu_dbatch>();
+  out->nrows = m; out->ns = in.ns; out->table = in.table;
+  hipStream_t st = ctx().stream;
+  const int32_t *sp = ptr<int32_t>(sel);
+  unsigned g = grid_for(m, 256);
+  KernelTimer t("compact_gather");
+  for (auto &c : in.cols) {
+    DColumn o;
+    o.name = c.name; o.dtype = c.dtype; o.repr = c.repr;
+    if (repr_is_var(c.repr)) {
+      o.offsets = dalloc((size_t)(m + 1) * 4);
+      if (m) gather_len_kernel<<<g, 256, 0, st>>>(ptr<uint32_t>(c.offsets), sp, m, ptr<uint32_t>(o.offsets));
+      exclusive_scan_u32(ptr<uint32_t>(o.offsets), ptr<uint32_t>(o.offsets), m, true);
+      // total is only known on the device; size the payload by the source (upper bound)
+      o.data = dalloc(c.data_len);
+      if (m) gather_bytes_kernel<<<g, 256, 0, st>>>(ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.data), sp, ptr<uint32_t>(o.offsets), m, ptr<uint8_t>(o.data));
+      o.data_len = c.data_len;  // fixed up below after one read-back
+    } else {
+      size_t w = repr_width(c.repr);
+      o.values = dalloc((size_t)m * w);
+      if (m) switch (w) {
+        case 1: gather_fixed_kernel<uint8_t><<<g, 256, 0, st>>>(ptr<uint8_t>(c.values), sp, m, ptr<uint8_t>(o.values)); break;
+        case 2: gather_fixed_kernel<uint16_t><<<g, 256, 0, st>>>(ptr<uint16_t>(c.values), sp, m, ptr<uint16_t>(o.values)); break;
+        case 4: gather_fixed_kernel<uint32_t><<<g, 256, 0, st>>>(ptr<uint32_t>(c.values), sp, m, ptr<uint32_t>(o.values)); break;
+        case 8: gather_fixed_kernel<uint64_t><<<g, 256, 0, st>>>(ptr<uint64_t>(c.values), sp, m, ptr<uint64_t>(o.values)); break;
+      }
+      if (c.nanos) { o.nanos = dalloc((size_t)m * 4); if (m) gather_fixed_kernel<uint32_t><<<g, 256, 0, st>>>(ptr<uint32_t>(c.nanos), sp, m, ptr<uint32_t>(o.nanos)); }
+    }
+    if (c.validity) { o.validity = dalloc((size_t)(m + 7) / 8 + 1); if (m) gather_bitmap_kernel<<<grid_for((m + 7) / 8, 256), 256, 0, st>>>(ptr<uint8_t>(c.validity), sp, m, ptr<uint8_t>(o.validity)); }
+    out->cols.push_back(std::move(o));
+  }
+  if (in.kind) { out->kind = dalloc((size_t)m); if (m) gather_fixed_kernel<uint8_t><<<g, 256, 0, st>>>(ptr<uint8_t>(in.kind), sp, m, ptr<uint8_t>(out->kind)); }
+  if (in.part_id) { out->part_id = dalloc((size_t)m * 4); if (m) gather_fixed_kernel<uint32_t><<<g, 256, 0, st>>>(ptr<uint32_t>(in.part_id), sp, m, ptr<uint32_t>(out->part_id)); }
+  out->src_row = dalloc((size_t)m * 4);
+  if (m) gather_srcrow_kernel<<<g, 256, 0, st>>>(ptr<int32_t>(in.src_row), sp, m, ptr<int32_t>(out->src_row));
+  // one read-back for all var-width totals
+  std::vector<uint32_t> totals(out->cols.size(), 0);
+  bool any = false;
+  for (size_t i = 0; i < out->cols.size(); i++)
+    if (repr_is_var(out->cols[i].repr)) { d2h(&totals[i], ptr<uint32_t>(out->cols[i].offsets) + m, 4); any = true; }
+  if (any) { sync(); for (size_t i = 0; i < out->cols.size(); i++) if (repr_is_var(out->cols[i].repr)) out->cols[i].data_len = totals[i]; }
+  return out;
+}
+
+// keep flags (uint32 0/1, n+1 slots) → compacted batch; identity if all kept
+static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /* n+1 u32 */) {
+  int64_t n = in.nrows;
+  exclusive_scan_u32(ptr<uint32_t>(keep), ptr<uint32_t>(keep), n, true);
+  uint32_t m = 0;
+  d2h(&m, ptr<uint32_t>(keep) + n, 4);
+  sync();
+  if ((int64_t)m == n) return shallow_copy(in);
+  Buf sel = dalloc((size_t)m * 4 + 4);
+  if (n) build_selection_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint32_t>(keep), n, ptr<int32_t>(sel));
+  return gather_batch(in, sel, m);
+}
+
+std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep) { return compact(in, keep); }
+
+static void collect_row_errors(const Buf &err, const Buf &err_term, int64_t n, ApplyCtx &ax) {
+  std::vector<uint8_t> he((size_t)n);
+  std::vector<int32_t> ht((size_t)n);
+  d2h(he.data(), err->p, (size_t)n);
+  if (err_term) d2h(ht.data(), err_term->p, (size_t)n * 4);
+  sync();
+  for (int64_t r = 0; r < n; r++) if (he[(size_t)r]) ax.errs.push_back(tfgpu_row_error{r, he[(size_t)r], ax.step, err_term ? ht[(size_t)r] : -1});
+}
+
+static std::unique_ptr<tfgpu_dbatch> apply_filter_rows(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {
+  // pass-through conditions that hold for the whole batch (one table per batch)
+  if (!p.tables.match_table(in.ns, in.table) || is_system_table(in.table)) {
+    // impossible kinds still raise errors before the table check (filter_rows.go:103-113)
+    if (!in.kind) return shallow_copy(in);
+  }
+  bool table_applies = p.tables.match_table(in.ns, in.table) && !is_system_table(in.table);
+  int64_t n = in.nrows;
+  hipStream_t st = ctx().stream;
+  // device program
+  std::vector<DTerm> terms; std::vector<int32_t> expr_start{0};
+  std::vector<int64_t> ints; std::vector<double> floats; std::vector<uint32_t> soff; std::string sdata;
+  if (table_applies) {
+    for (auto &e : p.exprs) {
+      for (auto &t : e.terms) {
+        DTerm d{};
+        d.col = -1;
+        for (size_t i = 0; i < in.cols.size(); i++) if (in.cols[i].name == t.attr) { d.col = (int32_t)i; break; }
+        d.op = t.op; d.vtype = t.vtype; d.is_list = t.is_list;
+        switch (t.vtype) {
+          case FV_FLOAT: d.nvals = (int32_t)t.floats.size(); d.ioff = (int32_t)floats.size(); floats.insert(floats.end(), t.floats.begin(), t.floats.end()); break;
+          case FV_STRING:
+            d.nvals = (int32_t)t.strs.size(); d.soff = (int32_t)soff.size();
+            for (auto &s : t.strs) { soff.push_back((uint32_t)sdata.size()); sdata += s; }
+            soff.push_back((uint32_t)sdata.size());
+            break;
+          default: d.nvals = (int32_t)t.ints.size(); d.ioff = (int32_t)ints.size(); ints.insert(ints.end(), t.ints.begin(), t.ints.end());
+        }
+        terms.push_back(d);
+      }
+      expr_start.push_back((int32_t)terms.size());
+    }
+  }
+  std::vector<DCol> cols;
+  for (auto &c : in.cols) cols.push_back(dcol_of(c));
+  auto up = [&](const void *src, size_t bytes) { Buf b = dalloc(bytes + 16); if (bytes) h2d(b->p, src, bytes); return b; };
+  Buf bcols = up(cols.data(), cols.size() * sizeof(DCol)), bterms = up(terms.data(), terms.size() * sizeof(DTerm));
+  Buf bexpr = up(expr_start.data(), expr_start.size() * 4), bints = up(ints.data(), ints.size() * 8), bfl = up(floats.data(), floats.size() * 8);
+  Buf bsoff = up(soff.data(), soff.size() * 4), bsd = up(sdata.data(), sdata.size());
+  Buf keep = dalloc((size_t)(n + 1) * 4), err = dalloc((size_t)n + 1), eterm = dalloc((size_t)n * 4 + 4), nerr = dalloc_zero(4);
+  FilterParams fp;
+  fp.cols = ptr<DCol>(bcols); fp.ncols = (int32_t)cols.size(); fp.terms = ptr<DTerm>(bterms); fp.expr_start = ptr<int32_t>(bexpr);
+  fp.nexpr = table_applies ? (int32_t)p.exprs.size() : 0;
+  fp.ints = ptr<int64_t>(bints); fp.floats = ptr<double>(bfl); fp.str_off = ptr<uint32_t>(bsoff); fp.str_data = ptr<uint8_t>(bsd);
+  fp.kind = ptr<uint8_t>(in.kind); fp.nrows = n; fp.keep = ptr<uint32_t>(keep); fp.err = ptr<uint8_t>(err); fp.err_term = ptr<int32_t>(eterm); fp.nerr = ptr<uint32_t>(nerr);
+  if (!table_applies) {
+    // only the kind check applies: emulate with zero expressions and keep-all for inserts
+    fp.nexpr = -1;
+  }
+  {
+    KernelTimer t("filter_rows_eval");
+    if (n) filter_eval_kernel<<<grid_for(n, 256), 256, 0, st>>>(fp);
+  }
+  uint32_t hn = 0;
+  d2h(&hn, nerr->p, 4);
+  auto out = compact(in, keep);  // syncs
+  if (hn) collect_row_errors(err, eterm, n, ax);
+  return out;
+}
+
+// ============================================================================
+// a10 skip_events — skip_events.go:52-62
+// ============================================================================
+__global__ void kind_keep_kernel(const uint8_t *kind, int64_t n, uint32_t skip_mask, uint32_t *keep) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) keep[r] = ((skip_mask >> kind[r]) & 1u) ? 0u : 1u;
+}
+static std::unique_ptr<tfgpu_dbatch> apply_skip_events(const tfgpu_plan &p, const tfgpu_dbatch &in) {
+  uint32_t mask = (p.skip[0] ? 1u : 0) | (p.skip[1] ? 2u : 0) | (p.skip[2] ? 4u : 0);
+  int64_t n = in.nrows;
+  if (!in.kind) {  // all rows are inserts
+    if (!(mask & 1u)) return shallow_copy(in);
+    Buf sel = dalloc(4);
+    return gather_batch(in, sel, 0);
+  }
+  Buf keep = dalloc((size_t)(n + 1) * 4);
+  if (n) kind_keep_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), n, mask, ptr<uint32_t>(keep));
+  return compact(in, keep);
+}
+
+// ============================================================================
+// a6 convert_to_string — to_string.go:58-97
+// ============================================================================
+__global__ void __launch_bounds__(256) tostring_len_kernel(DCol c, int64_t n, uint32_t *len) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint8_t buf[64]; const uint8_t *ext;
+  len[r] = (uint32_t)serialize_small(c, r, buf, &ext);
+}
+__global__ void __launch_bounds__(256) tostring_write_kernel(DCol c, int64_t n, const uint32_t *off, uint8_t *data) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint8_t buf[64]; const uint8_t *ext;
+  int len = serialize_small(c, r, buf, &ext);
+  uint8_t *dst = data + off[r];
+  if (ext) for (int i = 0; i < len; i++) dst[i] = ext[i];
+  else for (int i = 0; i < len; i++) dst[i] = buf[i];
+}
+
+static DColumn column_to_string(const DColumn &c, int64_t n, bool to_bytes, int max_len_hint) {
+  hipStream_t st = ctx().stream;
+  DColumn o;
+  o.name = c.name; o.dtype = to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8; o.repr = to_bytes ? TFGPU_R_BYTES : TFGPU_R_STRING;
+  o.offsets = dalloc((size_t)(n + 1) * 4);
+  DCol dc = dcol_of(c);
+  KernelTimer t("to_string");
+  if (n) tostring_len_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets));
+  exclusive_scan_u32(ptr<uint32_t>(o.offsets), ptr<uint32_t>(o.offsets), n, true);
+  uint64_t cap = repr_is_var(c.repr) ? c.data_len + (uint64_t)n * 5 : (uint64_t)n * (uint64_t)max_len_hint;
+  o.data = dalloc(cap);
+  if (n) tostring_write_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data));
+  uint32_t tot = 0;
+  d2h(&tot, ptr<uint32_t>(o.offsets) + n, 4);
+  sync();
+  o.data_len = tot;
+  return o;
+}
+
+static std::unique_ptr<tfgpu_dbatch> apply_to_string(const tfgpu_plan &p, const tfgpu_dbatch &in) {
+  if (p.skip_utc) {
+    for (auto &c : in.cols) if (p.columns.match(c.name) && c.repr == TFGPU_R_TIME)
+      throw Error(TFGPU_ERR_UNSUPPORTED, "convert_to_string skip_utc_conversion=true needs per-value time zones, which the columnar batch does not carry");
+  }
+  auto out = shallow_copy(in);
+  for (auto &c : out->cols) {
+    if (!p.columns.match(c.name)) continue;
+    require_serializable(c, "convert_to_string");
+    // already text with identical bytes: only the type tag changes
+    if (repr_is_var(c.repr) && !c.validity) { c.dtype = p.to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8; c.repr = p.to_bytes ? TFGPU_R_BYTES : TFGPU_R_STRING; continue; }
+    c = column_to_string(c, in.nrows, p.to_bytes, 64);
+  }
+  return out;
+}
+
+// ============================================================================
+// a7 convert_to_datetime — to_datetime.go:89-149
+// ============================================================================
+template <typename T>
+__global__ void todatetime_kernel(const T *in, int64_t n, int64_t *out) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = (int64_t)in[r];
+}
+static std::unique_ptr<tfgpu_dbatch> apply_to_datetime(const tfgpu_plan &p, const tfgpu_dbatch &in) {
+  auto out = shallow_copy(in);
+  int64_t n = in.nrows;
+  for (auto &c : out->cols) {
+    if (!(p.columns.match(c.name) && (c.dtype == TFGPU_T_INT32 || c.dtype == TFGPU_T_UINT32))) continue;
+    DColumn o;
+    o.name = c.name; o.dtype = TFGPU_T_DATETIME; o.repr = TFGPU_R_TIME;
+    o.values = dalloc_zero((size_t)n * 8);  // SerializeToDateTime falls back to time.Unix(0,0) on a type mismatch
+    KernelTimer t("to_datetime");
+    if (n && c.dtype == TFGPU_T_INT32 && c.repr == TFGPU_R_INT32) todatetime_kernel<int32_t><<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<int32_t>(c.values), n, ptr<int64_t>(o.values));
+    else if (n && c.dtype == TFGPU_T_UINT32 && c.repr == TFGPU_R_UINT32) todatetime_kernel<uint32_t><<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint32_t>(c.values), n, ptr<int64_t>(o.values));
+    // nil values also become time.Unix(0,0): the value.(int32) assertion fails
+    c = std::move(o);
+  }
+  return out;
+}
+
+// ============================================================================
+// a13 sharder_transformer — sharder.go:130-145 (CRC32-IEEE of '.'-joined strings)
+// ============================================================================
+__device__ __forceinline__ uint32_t crc32_update(uint32_t crc, uint8_t b, const uint32_t *tab) { return tab[(crc ^ b) & 0xFF] ^ (crc >> 8); }
+
+struct SharderParams {
+  const DCol *cols;   // in schema order, already resolved (repr==0 → missing → "<nil>")
+  int32_t ncols;
+  int64_t nrows;
+  uint32_t shards;
+  uint32_t *part_id;
+};
+__global__ void __launch_bounds__(256) sharder_kernel(SharderParams p) {
+  __shared__ uint32_t tab[256];
+  {  // build the IEEE table (reflected 0xEDB88320) once per block
+    uint32_t c = threadIdx.x;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+    tab[threadIdx.x] = c;
+  }
+  __syncthreads();
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  uint32_t crc = 0xFFFFFFFFu;
+  for (int i = 0; i < p.ncols; i++) {
+    if (i) crc = crc32_update(crc, '.', tab);
+    uint8_t buf[64]; const uint8_t *ext = nullptr; int len;
+    if (p.cols[i].repr == 0) { buf[0] = '<'; buf[1] = 'n'; buf[2] = 'i'; buf[3] = 'l'; buf[4] = '>'; len = 5; }
+    else len = serialize_small(p.cols[i], r, buf, &ext);
+    if (ext) for (int k = 0; k < len; k++) crc = crc32_update(crc, ext[k], tab);
+    else for (int k = 0; k < len; k++) crc = crc32_update(crc, buf[k], tab);
+  }
+  p.part_id[r] = (crc ^ 0xFFFFFFFFu) % p.shards;
+}
+
+static std::unique_ptr<tfgpu_dbatch> apply_sharder(const tfgpu_plan &p, const tfgpu_dbatch &in, const tfgpu_schema *schema_order) {
+  auto out = shallow_copy(in);
+  int64_t n = in.nrows;
+  // Columns are visited in TableSchema order; without a separate schema the
+  // batch column order stands in for it (they coincide for every source that
+  // builds ColumnNames from the schema).
+  std::vector<DCol> cols;
+  for (auto &c : in.cols) {
+    if (!p.columns.match(c.name)) continue;
+    require_serializable(c, "sharder_transformer");
+    cols.push_back(dcol_of(c));
+  }
+  (void)schema_order;
+  Buf bc = dalloc(cols.size() * sizeof(DCol) + 16);
+  h2d(bc->p, cols.data(), cols.size() * sizeof(DCol));
+  out->part_id = dalloc((size_t)n * 4 + 4);
+  SharderParams sp{ptr<DCol>(bc), (int32_t)cols.size(), n, (uint32_t)p.shards, ptr<uint32_t>(out->part_id)};
+  KernelTimer t("sharder_crc32");
+  if (n) sharder_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(sp);
+  sync();  // cols vector must outlive the H2D copy
+  return out;
+}
+
+// ============================================================================
+// metadata-only transformers
+// ============================================================================
+static std::unique_ptr<tfgpu_dbatch> apply_rename(const tfgpu_plan &p, const tfgpu_dbatch &in) {  // rename.go:46-61
+  auto out = shallow_copy(in);
+  for (auto &r : p.renames) if (r[0] == in.ns && r[1] == in.table) { out->ns = r[2]; out->table = r[3]; break; }
+  return out;
+}
+static std::unique_ptr<tfgpu_dbatch> apply_filter_columns(const tfgpu_plan &p, const tfgpu_dbatch &in) {  // filter_columns_transformer.go:51-79
+  auto out = shallow_copy(in);
+  out->cols.clear();
+  for (auto &c : in.cols) if (p.columns.match(c.name)) out->cols.push_back(c);
+  return out;
+}
+
+std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {
+  switch (p.kind) {
+    case PK_MASK: return apply_mask(p, in);
+    case PK_RENAME: return apply_rename(p, in);
+    case PK_FILTER_COLUMNS: return apply_filter_columns(p, in);
+    case PK_SKIP_EVENTS: return apply_skip_events(p, in);
+    case PK_FILTER_ROWS: return apply_filter_rows(p, in, ax);
+    case PK_TO_STRING: return apply_to_string(p, in);
+    case PK_TO_DATETIME: return apply_to_datetime(p, in);
+    case PK_SHARDER: return apply_sharder(p, in, nullptr);
+  }
+  throw Error(TFGPU_ERR_INVALID, "unknown plan kind");
+}
+
+}  // namespace tf

@@ -1,0 +1,386 @@
+"""ctypes binding of transferia_amd/libtfgpu.so (the C ABI in include/tfgpu.h)
+and a thin host mirror of the reference's plugin interface.
+
+The mirror keeps the reference's names and argument meaning
+(abstract.Transformer: Type / Description / Suitable / ResultSchema / Apply —
+pkg/abstract/transformer.go:32-38) so tests read like the reference's tests.
+Nothing here computes: every call lands in a HIP kernel.  There is no CPU
+fallback; if the library or a gfx950 device is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libtfgpu.so")
+_lib = None
+
+EXPORTS = [
+    "tfgpu_abi_version", "tfgpu_last_error", "tfgpu_init", "tfgpu_shutdown", "tfgpu_device_count", "tfgpu_synchronize",
+    "tfgpu_stream", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
+    "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
+    "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
+    "tfgpu_apply", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
+    "tfgpu_prof_get",
+]
+
+
+class TfgpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"tfgpu error {code}: {msg}")
+        self.code = code
+
+
+ERR_INVALID, ERR_CONFIG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NOMEM, ERR_UNKNOWN_TYPE = 1, 2, 3, 4, 5, 6
+
+
+def load():
+    """Load libtfgpu.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIBPATH):
+        raise RuntimeError(f"{_LIBPATH} is missing: run `python -m transferia_amd.build` (hipcc, gfx950). "
+                           "transferia_amd has no CPU implementation.")
+    L = C.CDLL(_LIBPATH)
+    P = C.c_void_p
+    L.tfgpu_last_error.restype = C.c_char_p
+    L.tfgpu_stream.restype = P
+    L.tfgpu_plan_type.restype = C.c_char_p
+    L.tfgpu_plan_type.argtypes = [P]
+    L.tfgpu_registry_name.restype = C.c_char_p
+    L.tfgpu_registry_name.argtypes = [C.c_int]
+    L.tfgpu_init.argtypes = [C.c_int]
+    L.tfgpu_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.tfgpu_host_alloc.argtypes = [C.c_size_t, C.POINTER(P)]
+    L.tfgpu_host_free.argtypes = [P]
+    L.tfgpu_plan_create.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(P)]
+    L.tfgpu_plan_destroy.argtypes = [P]
+    L.tfgpu_plan_destroy.restype = None
+    L.tfgpu_plan_description.argtypes = [P, C.c_char_p, C.c_size_t]
+    L.tfgpu_plan_suitable.argtypes = [P, C.c_char_p, C.c_char_p, C.POINTER(abi.CSchema), C.POINTER(C.c_int)]
+    L.tfgpu_plan_result_schema.argtypes = [P, C.POINTER(abi.CSchema), C.POINTER(C.POINTER(abi.CSchema))]
+    L.tfgpu_schema_free.argtypes = [C.POINTER(abi.CSchema)]
+    L.tfgpu_schema_free.restype = None
+    L.tfgpu_batch_upload.argtypes = [C.POINTER(abi.CBatch), C.POINTER(P)]
+    L.tfgpu_dbatch_view.argtypes = [P, C.POINTER(abi.CBatch)]
+    L.tfgpu_dbatch_download.argtypes = [P, C.POINTER(abi.CBatch)]
+    L.tfgpu_dbatch_free.argtypes = [P]
+    L.tfgpu_dbatch_free.restype = None
+    L.tfgpu_apply.argtypes = [C.POINTER(P), C.c_int, P, C.POINTER(P), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_csv_options_default.argtypes = [C.POINTER(abi.CCsvOptions)]
+    L.tfgpu_csv_options_default.restype = None
+    L.tfgpu_csv_parse.argtypes = [C.POINTER(abi.CCsvOptions), C.POINTER(abi.CSchema), P, C.c_uint64, C.c_int, C.POINTER(P),
+                                  C.POINTER(C.c_uint64), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_serialize.argtypes = [C.c_int, P, C.POINTER(P)]
+    L.tfgpu_dbuf_size.argtypes = [P, C.POINTER(C.c_uint64)]
+    L.tfgpu_dbuf_ptr.argtypes = [P]
+    L.tfgpu_dbuf_ptr.restype = P
+    L.tfgpu_dbuf_download.argtypes = [P, P, C.c_uint64]
+    L.tfgpu_dbuf_free.argtypes = [P]
+    L.tfgpu_dbuf_free.restype = None
+    L.tfgpu_dbuf_upload.argtypes = [P, C.c_uint64, C.POINTER(P)]
+    L.tfgpu_dbuf_alloc.argtypes = [C.c_uint64, C.POINTER(P)]
+    L.tfgpu_dbuf_write.argtypes = [P, C.c_uint64, P, C.c_uint64]
+    L.tfgpu_prof_enable.argtypes = [C.c_int]
+    L.tfgpu_prof_get.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise TfgpuError(rc, (load().tfgpu_last_error() or b"").decode("utf-8", "replace"))
+
+
+_initialised = None
+
+
+def init(device: Optional[int] = None) -> int:
+    """Bind this process to one GPU (LOCAL_RANK by default): one process per GPU."""
+    global _initialised
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _initialised is not None:
+        return _initialised
+    _check(load().tfgpu_init(device))
+    _initialised = device
+    return device
+
+
+def synchronize():
+    _check(load().tfgpu_synchronize())
+
+
+def registry() -> List[str]:
+    L = load()
+    return [L.tfgpu_registry_name(i).decode() for i in range(L.tfgpu_registry_count())]
+
+
+# ---- device-resident containers ---------------------------------------------
+class DeviceBatch:
+    """A []ChangeItem run (one table, one schema) fanned out into HBM columns."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def upload(batch: abi.Batch) -> "DeviceBatch":
+        init()
+        cb = batch.to_c()
+        h = C.c_void_p()
+        _check(load().tfgpu_batch_upload(C.byref(cb), C.byref(h)))
+        return DeviceBatch(h)
+
+    def view(self) -> abi.CBatch:
+        v = abi.CBatch()
+        _check(load().tfgpu_dbatch_view(self._h, C.byref(v)))
+        return v
+
+    @property
+    def nrows(self) -> int:
+        return int(self.view().nrows)
+
+    def column_names(self) -> List[str]:
+        v = self.view()
+        return [v.cols[i].name.decode() for i in range(v.ncols)]
+
+    def payload_bytes(self) -> int:
+        """Bytes of column payload resident in HBM (values + offsets + data)."""
+        v = self.view()
+        n, tot = int(v.nrows), 0
+        for i in range(v.ncols):
+            c = v.cols[i]
+            if c.repr in abi.VAR_REPRS:
+                tot += (n + 1) * 4 + int(c.data_len)
+            else:
+                tot += n * np.dtype(abi.REPR_NP[c.repr]).itemsize + (n * 4 if c.nanos else 0)
+        return tot
+
+    def download(self) -> abi.Batch:
+        v = self.view()
+        n = int(v.nrows)
+        cols, carr, keep = [], (abi.CColumn * max(v.ncols, 1))(), []
+        for i in range(v.ncols):
+            c = v.cols[i]
+            col = abi.Column(c.name.decode(), abi.DTYPES[c.dtype], int(c.repr))
+            carr[i].name, carr[i].dtype, carr[i].repr = c.name, c.dtype, c.repr
+            if c.repr in abi.VAR_REPRS:
+                col.offsets = np.zeros(n + 1, np.uint32)
+                col.data = np.zeros(max(int(c.data_len), 1), np.uint8)
+                carr[i].offsets, carr[i].data, carr[i].data_len = col.offsets.ctypes.data, col.data.ctypes.data, c.data_len
+            else:
+                col.values = np.zeros(max(n, 1), abi.REPR_NP[c.repr])
+                carr[i].values = col.values.ctypes.data
+                if c.nanos:
+                    col.nanos = np.zeros(max(n, 1), np.int32)
+                    carr[i].nanos = col.nanos.ctypes.data
+            if c.validity:
+                bm = np.zeros((n + 7) // 8 + 1, np.uint8)
+                keep.append(bm)
+                carr[i].validity = bm.ctypes.data
+                col._bm = bm
+            cols.append(col)
+        hb = abi.CBatch()
+        hb.nrows, hb.ncols, hb.cols, hb.mem = n, v.ncols, carr, abi.MEM_HOST
+        kind = src = part = None
+        if v.kind:
+            kind = np.zeros(max(n, 1), np.uint8); hb.kind = kind.ctypes.data
+        if v.src_row:
+            src = np.zeros(max(n, 1), np.int32); hb.src_row = src.ctypes.data
+        if v.part_id:
+            part = np.zeros(max(n, 1), np.uint32); hb.part_id = part.ctypes.data
+        _check(load().tfgpu_dbatch_download(self._h, C.byref(hb)))
+        for col in cols:
+            if col.repr in abi.VAR_REPRS:
+                col.data = col.data[: int(col.offsets[-1])]
+            else:
+                col.values = col.values[:n]
+                if col.nanos is not None:
+                    col.nanos = col.nanos[:n]
+            if hasattr(col, "_bm"):
+                col.validity = abi.unpack_validity(col._bm, n)
+        b = abi.Batch(cols, n, (v.table_ns or b"").decode(), (v.table_name or b"").decode())
+        b.kind = kind[:n] if kind is not None else None
+        b.src_row = src[:n] if src is not None else None
+        b.part_id = part[:n] if part is not None else None
+        return b
+
+    def free(self):
+        if self._h:
+            load().tfgpu_dbatch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def upload(data: bytes) -> "DeviceBuffer":
+        init()
+        buf = np.frombuffer(data, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(load().tfgpu_dbuf_upload(buf.ctypes.data if len(buf) else None, len(buf), C.byref(h)))
+        return DeviceBuffer(h)
+
+    @staticmethod
+    def alloc(nbytes: int) -> "DeviceBuffer":
+        init()
+        h = C.c_void_p()
+        _check(load().tfgpu_dbuf_alloc(nbytes, C.byref(h)))
+        return DeviceBuffer(h)
+
+    def write(self, offset: int, arr: np.ndarray, nbytes: int):
+        _check(load().tfgpu_dbuf_write(self._h, offset, arr.ctypes.data, nbytes))
+
+    @property
+    def size(self) -> int:
+        n = C.c_uint64(0)
+        load().tfgpu_dbuf_size(self._h, C.byref(n))
+        return int(n.value)
+
+    @property
+    def ptr(self) -> int:
+        return int(load().tfgpu_dbuf_ptr(self._h) or 0)
+
+    def download(self) -> bytes:
+        n = self.size
+        out = np.zeros(max(n, 1), np.uint8)
+        _check(load().tfgpu_dbuf_download(self._h, out.ctypes.data, n))
+        return out[:n].tobytes()
+
+    def free(self):
+        if self._h:
+            load().tfgpu_dbuf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class TransformerResult:
+    """abstract.TransformerResult: Transformed rows + per-row Errors."""
+
+    def __init__(self, transformed: DeviceBatch, errors):
+        self.transformed = transformed
+        self.errors = errors  # list of (row, code_name, step, column)
+
+
+class Transformer:
+    """abstract.Transformer backed by a tfgpu_plan."""
+
+    def __init__(self, type_name: str, config):
+        cfg = config if isinstance(config, str) else json.dumps(config)
+        h = C.c_void_p()
+        _check(load().tfgpu_plan_create(type_name.encode(), cfg.encode("utf-8"), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().tfgpu_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def type(self) -> str:
+        return load().tfgpu_plan_type(self._h).decode()
+
+    def description(self) -> str:
+        buf = C.create_string_buffer(1024)
+        _check(load().tfgpu_plan_description(self._h, buf, 1024))
+        return buf.value.decode()
+
+    def suitable(self, ns: str, table: str, schema: abi.Schema) -> bool:
+        cs, out = schema.to_c(), C.c_int(0)
+        _check(load().tfgpu_plan_suitable(self._h, ns.encode(), table.encode(), C.byref(cs), C.byref(out)))
+        return bool(out.value)
+
+    def result_schema(self, schema: abi.Schema) -> abi.Schema:
+        cs = schema.to_c()
+        out = C.POINTER(abi.CSchema)()
+        _check(load().tfgpu_plan_result_schema(self._h, C.byref(cs), C.byref(out)))
+        s = abi.Schema.from_c(out.contents)
+        load().tfgpu_schema_free(out)
+        return s
+
+    def apply(self, batch: DeviceBatch) -> TransformerResult:
+        return apply_chain([self], batch)
+
+
+def apply_chain(transformers: Sequence[Transformer], batch: DeviceBatch, max_errors: int = 1 << 16) -> TransformerResult:
+    """The Apply loop of transformation.do (pkg/transformer/transformation.go:252-274) in HBM."""
+    init()
+    n = len(transformers)
+    arr = (C.c_void_p * max(n, 1))(*[t._h for t in transformers])
+    out = C.c_void_p()
+    errs = (abi.CRowError * max_errors)()
+    nerr = C.c_int64(0)
+    _check(load().tfgpu_apply(arr, n, batch._h, C.byref(out), errs, max_errors, C.byref(nerr)))
+    el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
+          for i in range(min(int(nerr.value), max_errors))]
+    return TransformerResult(DeviceBatch(out), el)
+
+
+def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int = 1 << 16):
+    """s3 CSVReader.parseCSVRows + Strictify on device.  `data` is bytes or a DeviceBuffer.
+    Returns (DeviceBatch, consumed_bytes, errors)."""
+    init()
+    L = load()
+    cs = schema.to_c()
+    out, consumed, nerr = C.c_void_p(), C.c_uint64(0), C.c_int64(0)
+    errs = (abi.CRowError * max_errors)()
+    if isinstance(data, DeviceBuffer):
+        _check(L.tfgpu_csv_parse(C.byref(opts), C.byref(cs), data.ptr, data.size, abi.MEM_DEVICE, C.byref(out), C.byref(consumed), errs,
+                                 max_errors, C.byref(nerr)))
+    else:
+        buf = np.frombuffer(data, dtype=np.uint8)
+        _check(L.tfgpu_csv_parse(C.byref(opts), C.byref(cs), buf.ctypes.data if len(buf) else None, len(buf), abi.MEM_HOST, C.byref(out),
+                                 C.byref(consumed), errs, max_errors, C.byref(nerr)))
+    el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
+          for i in range(min(int(nerr.value), max_errors))]
+    return DeviceBatch(out), int(consumed.value), el
+
+
+def serialize(fmt: int, batch: DeviceBatch) -> DeviceBuffer:
+    init()
+    out = C.c_void_p()
+    _check(load().tfgpu_serialize(fmt, batch._h, C.byref(out)))
+    return DeviceBuffer(out)
+
+
+def prof_enable(on: bool):
+    _check(load().tfgpu_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    _check(load().tfgpu_prof_reset())
+
+
+def prof_get():
+    """[(kernel name, launches, total_ms)] measured with HIP events on the library stream."""
+    L = load()
+    out = []
+    for i in range(L.tfgpu_prof_count()):
+        name, n, ms = C.c_char_p(), C.c_int64(0), C.c_double(0)
+        L.tfgpu_prof_get(i, C.byref(name), C.byref(n), C.byref(ms))
+        out.append((name.value.decode(), int(n.value), float(ms.value)))
+    return out
