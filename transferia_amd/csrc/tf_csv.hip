@@ -402,7 +402,10 @@ __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
   const uint64_t row0 = pos;
   MemBytes scan(p.data), fld(p.data);
   const CsvOpts &o = p.o;
-  int err = 0, err_col = -1;
+  // Error precedence of the reference for one line: ReadLine errors (first field in
+  // line order, reader.go:273-324) > constructCI missing cell (first column in schema
+  // order, reader_csv.go:303-316) > Strictify cast/range (first column in schema order).
+  int rerr = 0, rerr_col = -1, miss_col = 0x7FFFFFFF, cerr = 0, cerr_col = 0x7FFFFFFF;
   // a line that is just "\n" makes ReadLine return (nil, nil): zero fields (reader.go:146-150)
   const bool nil_line = have_row && (end - pos) <= 1;
   bool active = have_row && !nil_line;
@@ -431,17 +434,18 @@ __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
     Field fv{&fld, fs, (uint32_t)(fe - fs)};
     uint32_t a = 0, b = 0, npairs = 0;
     const int32_t first_col = f < p.nfields_used ? p.field_first[f] : -1;
-    if (has_field && !err) {
+    if (has_field) {
       int e = sanitize(o, fv, a, b, npairs);
-      if (e) { err = e; err_col = first_col; }
+      if (e && !rerr) { rerr = e; rerr_col = first_col; }
       nfields = f + 1;
     }
     // ---- constructCI + getCorrespondingValue + Strictify for the mapped columns ----
     for (int32_t ci = first_col; ci >= 0; ci = p.cols[ci].next) {
       const CsvCol &c = p.cols[ci];
-      if (!have_row || err) continue;
+      if (!have_row || rerr) continue;
+      int err = 0;
       if (!has_field) {  // index >= len(row) (reader_csv.go:303-316)
-        if (o.include_missing) store_default(c, r); else { err = TFGPU_ROW_MISSING_CELL; err_col = ci; }
+        if (o.include_missing) store_default(c, r); else if (ci < miss_col) miss_col = ci;
         continue;
       }
       switch (c.kind) {
@@ -454,19 +458,19 @@ __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
             isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, ta, tb);
           } else if (o.strings_can_be_null) isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
           if (isnull) { store_default(c, r); break; }
-          if (npairs) { err = TFGPU_ROW_CAST; err_col = ci; break; }  // a '"' survives in the text: not a number
+          if (npairs) { err = TFGPU_ROW_CAST; break; }  // a '"' survives in the text: not a number
           uint32_t tb = trim_zero_decimal(fv, a, b);
           if (c.kind == CK_INT || c.hi != ~0ull) {
             int64_t v; int rc = parse_int64(fv, a, tb, true, &v);
-            if (rc) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+            if (rc) { err = TFGPU_ROW_CAST; break; }
             if (c.kind == CK_UINT) {
-              if (v < 0) { err = TFGPU_ROW_CAST; err_col = ci; break; }  // errNegativeNotAllowed
-              if ((uint64_t)v > c.hi) { err = TFGPU_ROW_RANGE; err_col = ci; break; }
-            } else if (v < c.lo || v > (int64_t)c.hi) { err = TFGPU_ROW_RANGE; err_col = ci; break; }
+              if (v < 0) { err = TFGPU_ROW_CAST; break; }  // errNegativeNotAllowed
+              if ((uint64_t)v > c.hi) { err = TFGPU_ROW_RANGE; break; }
+            } else if (v < c.lo || v > (int64_t)c.hi) { err = TFGPU_ROW_RANGE; break; }
             store_int(c, r, v);
           } else {  // uint64: cast.ToUint64E parses with ParseUint
             uint64_t v; int rc = parse_uint64(fv, a, tb, true, &v);
-            if (rc) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+            if (rc) { err = TFGPU_ROW_CAST; break; }
             ((uint64_t *)c.values)[r] = v;
           }
           break;
@@ -481,49 +485,53 @@ __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
             } else if (o.strings_can_be_null) isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
           }
           if (isnull) { c.lens[r] = 0; c.fstart[r] = 0x7FFFFFFFu; break; }
-          if (c.kind == CK_JSONNUM && (npairs || !json_number_ok(fv, a, b))) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          if (c.kind == CK_JSONNUM && (npairs || !json_number_ok(fv, a, b))) { err = TFGPU_ROW_CAST; break; }
           c.lens[r] = (b - a) - npairs;
           c.fstart[r] = (uint32_t)(fs + a) | (npairs ? 0x80000000u : 0u);
           break;
         }
         case CK_DATE: case CK_TIMESTAMP: {
-          if (npairs) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          if (npairs) { err = TFGPU_ROW_CAST; break; }
           int64_t sec = 0; int32_t ns = 0; int rc;
           if (c.kind == CK_TIMESTAMP && parse_int64(fv, a, b, false, &sec) == 0) rc = 0;  // parseTimestampValue :419-426
           else rc = parse_datetime(fv, a, b, &sec, &ns);
-          if (rc) { err = rc; err_col = ci; break; }
+          if (rc) { err = rc; break; }
           ((int64_t *)c.values)[r] = sec;
           c.nanos[r] = ns;
           break;
         }
         case CK_BOOL: {  // parseBooleanValue :431-452 then cast.ToBoolE
           int v = 0;
-          if (npairs) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          if (npairs) { err = TFGPU_ROW_CAST; break; }
           if (o.strings_can_be_null && in_list(o, 0, o.n_null, fv, a, b)) v = 0;
           else if (in_list(o, o.n_null, o.n_true, fv, a, b)) v = 1;
           else if (in_list(o, o.n_null + o.n_true, o.n_false, fv, a, b)) v = 0;
-          else if (parse_bool(fv, a, b, &v)) { err = TFGPU_ROW_CAST; err_col = ci; break; }
+          else if (parse_bool(fv, a, b, &v)) { err = TFGPU_ROW_CAST; break; }
           ((uint8_t *)c.values)[r] = (uint8_t)v;
           break;
         }
         default:  // CK_F32 (strconv.ParseFloat 32-bit rounding), CK_INTERVAL: host path
-          err = TFGPU_ROW_HOST_FALLBACK; err_col = ci;
+          err = TFGPU_ROW_HOST_FALLBACK;
       }
+      if (err && ci < cerr_col) { cerr = err; cerr_col = ci; }
     }
     if (last) active = false;
   }
   if (!have_row) return;
   // columns whose field index lies beyond every field this line produced, and nil lines
-  if (!err) {
+  if (!rerr) {
     for (int32_t ci = 0; ci < p.ncols; ci++) {
       const CsvCol &c = p.cols[ci];
       if (c.field < 0) { store_default(c, r); continue; }
       if (c.field >= nfields) {
         if (c.field < p.nfields_used && !nil_line) continue;  // handled in the loop above
-        if (o.include_missing) store_default(c, r); else { err = TFGPU_ROW_MISSING_CELL; err_col = ci; break; }
+        if (o.include_missing) store_default(c, r); else { if (ci < miss_col) miss_col = ci; break; }
       }
     }
   }
+  int err = rerr, err_col = rerr_col;
+  if (!err && miss_col != 0x7FFFFFFF) { err = TFGPU_ROW_MISSING_CELL; err_col = miss_col; }
+  if (!err && cerr) { err = cerr; err_col = cerr_col; }
   p.err[r] = (uint8_t)err;
   if (err) { p.err_col[r] = err_col; atomicAdd(p.nerr, 1u); }
 }

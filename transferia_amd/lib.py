@@ -210,7 +210,8 @@ class DeviceBatch:
                 col.validity = abi.unpack_validity(col._bm, n)
         b = abi.Batch(cols, n, (v.table_ns or b"").decode(), (v.table_name or b"").decode())
         b.kind = kind[:n] if kind is not None else None
-        b.src_row = src[:n] if src is not None else None
+        # src_row NULL = identity (include/tfgpu.h): no row was dropped or reordered
+        b.src_row = src[:n] if src is not None else np.arange(n, dtype=np.int32)
         b.part_id = part[:n] if part is not None else None
         return b
 
