@@ -152,6 +152,7 @@ def main():
         "csv_count_newlines": csv_bytes,
         "csv_line_index": csv_bytes + 4 * rows,
         "csv_parse_rows": csv_bytes + fixed_b,            # read every input byte once, write every fixed-width value once
+        "csv_parse_tiles": csv_bytes + fixed_b,           # same work, tile-cooperative kernel
         "csv_copy_strings": 2 * str_b,                    # string payload: one read + one write
         "scan_u32_segments": 12 * rows * 28,
         "mask_hmac_sha256": 72 * rows,                    # 4 B in + 64 B hex + 4 B offset per value

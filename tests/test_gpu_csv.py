@@ -20,7 +20,7 @@ def tf():
 def compare(tf, oracle, opts_kw, schema, data: bytes, ctx=""):
     opts = abi.csv_options(**opts_kw)
     ref = oracle.csv_parse(opts, schema, data, "ns", "t")
-    db, consumed, errs = tf.csv_parse(opts, schema, data)
+    db, consumed, errs = tf.csv_parse(opts, schema, data, max_errors=1 << 18)
     out = db.download()
     assert consumed == ref.consumed, ctx
     gpu_err = sorted((e[0], e[1]) for e in errs)
@@ -132,3 +132,53 @@ def test_random_bytes(tf, oracle, seed):
                             ["e", "double", False, "3"], ["g", "timestamp", False, "2"]])
     for kw in [dict(include_missing_columns=1), dict(), dict(include_missing_columns=1, escape_char=0), dict(include_missing_columns=1, double_quote=0)]:
         compare(tf, oracle, kw, schema, data, f"random {seed} {kw}")
+
+
+def test_tile_path_shapes(tf, oracle):
+    """Inputs that stress the tile path's windows: lines longer than the LDS look-behind (per-row
+    hand-off), lines spanning several tiles, more fields / lines per tile than one pass indexes."""
+    rng = np.random.default_rng(11)
+    kw = dict(include_missing_columns=1)
+
+    def row(n_fields, width):
+        return b",".join(b"%d" % rng.integers(0, 10 ** width) for _ in range(n_fields)) + b"\n"
+
+    normal = b"".join(b"%d,s%d,%d,\"q,%d\"\n" % (i, i, i * 7, i) for i in range(3000))
+    long9k = b"5,\"" + b"x" * 9000 + b"\",6,y\n"            # longer than the 8 KiB look-behind
+    long40k = b"7,\"" + b"ab" * 20000 + b"\",8,\"z\"\"z\"\n"  # spans three 16 KiB tiles
+    wide = b"9," + b"," * 7000 + b"\n"                        # more fields than one pass indexes
+    tiny = b"1\n" * 30000                                     # thousands of lines per tile
+    empties = b",,,\n" * 20000                                # field ends at every byte
+    blank = b"\n" * 20000                                     # nil lines only
+    for name, data in [
+        ("long-first", long9k + normal), ("long-mid", normal + long9k + normal + long40k + normal),
+        ("long-only", long40k), ("long-last", normal + long40k), ("wide", normal + wide + normal + wide + wide + normal),
+        ("tiny", tiny), ("empties", empties + normal), ("blank", blank + normal + blank),
+        ("mix", tiny + long9k + empties + wide + normal + blank + long40k + b"tail without newline"),
+    ]:
+        compare(tf, oracle, kw, S4, data, name)
+        compare(tf, oracle, dict(), S4, data, name + " strict")
+    # a header to skip, sitting in a long line
+    compare(tf, oracle, dict(skip_rows=1, include_missing_columns=1), S4, long9k + normal, "skip-long")
+    compare(tf, oracle, dict(skip_rows=3, include_missing_columns=1), S4, normal, "skip3")
+
+
+def test_unmapped_fields_are_still_sanitized(tf, oracle):
+    """sanitizeElement runs on every field of a line, also those no column reads (reader.go:240-266)."""
+    schema = abi.Schema.of([["a", "int32", True, "0"], ["d", "utf8", False, "3"]])
+    lines = [b"1,x,y,z\n", b"2,\",y,z\n", b"3,x,y,z,\"\n", b"4,x,\"a\"\"b\",z\n", b"5\n", b"6,x,y\n", b"7,x,y,z,w,v,\"\n"] * 50
+    for kw in [dict(), dict(include_missing_columns=1), dict(double_quote=0)]:
+        compare(tf, oracle, kw, schema, b"".join(lines), "unmapped " + str(kw))
+
+
+def test_row_path_equals_tile_path():
+    """TFGPU_CSV_ROWPATH=1 routes whole chunks through the per-row kernel; both must match the oracle."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TFGPU_CSV_ROWPATH="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_csv.py", "-m", "gpu", "-q", "-x", "-k",
+                        "edge_lines or typed_columns or random_bytes or tile_path_shapes or unmapped"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

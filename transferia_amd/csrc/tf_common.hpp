@@ -9,6 +9,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <unordered_map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -39,10 +40,24 @@ struct ProfEntry {
   double total_ms = 0;
 };
 
+struct BlockCache {
+  std::mutex mu;
+  std::unordered_map<size_t, std::vector<void *>> free_;
+  size_t cached = 0;
+  void *get(size_t cls);
+  void put(void *p, size_t cls);
+  void trim();
+};
+
 struct Context {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipMemPool_t pool = nullptr;
+  BlockCache blocks;
+  // pinned ring for small host<->device tables and read-backs
+  void *pin_base = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
+  void *pin(size_t bytes);
+  template <class T> T *pin_n(size_t n) { return reinterpret_cast<T *>(pin(n * sizeof(T))); }
   bool prof_on = false;
   std::vector<ProfEntry> prof;
   struct Pending { int idx; hipEvent_t a, b; };
@@ -69,18 +84,26 @@ struct KernelTimer {
 // ---- HBM buffers (stream-ordered pool) -------------------------------------
 struct DevMem {
   void *p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0, cls = 0;
+  std::shared_ptr<DevMem> parent;  // set for views into a larger block (see subbuf)
   explicit DevMem(size_t n);
+  DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n);
   ~DevMem();
   DevMem(const DevMem &) = delete;
   DevMem &operator=(const DevMem &) = delete;
 };
 using Buf = std::shared_ptr<DevMem>;
 Buf dalloc(size_t bytes);              // uninitialised
+Buf subbuf(const Buf &owner, size_t off, size_t bytes);  // view sharing ownership of `owner`
 Buf dalloc_zero(size_t bytes);
 template <class T> inline T *ptr(const Buf &b) { return b ? reinterpret_cast<T *>(b->p) : nullptr; }
 
 void h2d(void *dst, const void *src, size_t n);
+void h2d_small(void *dst, const void *src, size_t n);  // via the pinned arena: truly async
+Buf upload_small(const void *src, size_t n);
+// n uint32 words read back into the pinned arena; valid after the next sync()
+const uint32_t *d2h_u32(const void *dev, size_t n = 1);
+struct PinScope { PinScope() {} };  // (the pinned arena is a ring; nothing to do per call)
 void d2h(void *dst, const void *src, size_t n);
 void d2d(void *dst, const void *src, size_t n);
 void sync();

@@ -111,14 +111,29 @@ struct MemBytes {
     return (uint32_t)(win >> ((pos & 7) * 8)) & 0xFFu;
   }
 };
-// A field view: absolute [start, start+n) through a MemBytes reader.
+// A field view: absolute [start, start+n) through a MemBytes reader (HBM, slow path).
 struct Field {
   MemBytes *m; uint64_t start; uint32_t n;
   __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return m->at(start + i); }
 };
+// The same over a tile staged in LDS (fast path): one aligned ds_read_b64 per 8 bytes walked.
+struct LdsBytes {
+  const uint8_t *base;  // 8-byte aligned LDS tile
+  uint64_t win; uint32_t widx;
+  __device__ __forceinline__ explicit LdsBytes(const uint8_t *b) : base(b), win(0), widx(~0u) {}
+  __device__ __forceinline__ uint32_t at(uint32_t pos) {
+    uint32_t i = pos >> 3;
+    if (i != widx) { win = reinterpret_cast<const uint64_t *>(base)[i]; widx = i; }
+    return (uint32_t)(win >> ((pos & 7) * 8)) & 0xFFu;
+  }
+};
+struct LField {
+  LdsBytes *m; uint32_t start; uint32_t n;
+  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return m->at(start + i); }
+};
 
 // unicode.IsSpace over UTF-8 at s[i..): width of the space rune or 0
-__device__ __forceinline__ uint32_t space_prefix(const Field &f, uint32_t i, uint32_t end) {
+template <class F> __device__ __forceinline__ uint32_t space_prefix(const F &f, uint32_t i, uint32_t end) {
   uint32_t c = f[i];
   if (c == ' ' || (c >= 9 && c <= 13)) return 1;
   if (c < 0xC2) return 0;
@@ -133,7 +148,7 @@ __device__ __forceinline__ uint32_t space_prefix(const Field &f, uint32_t i, uin
   }
   return 0;
 }
-__device__ __forceinline__ uint32_t space_suffix(const Field &f, uint32_t a, uint32_t b) {
+template <class F> __device__ __forceinline__ uint32_t space_suffix(const F &f, uint32_t a, uint32_t b) {
   uint32_t c = f[b - 1];
   if (c == ' ' || (c >= 9 && c <= 13)) return 1;
   if (c < 0x80) return 0;
@@ -151,7 +166,23 @@ struct CsvOpts {
 
 // sanitizeElement reader.go:273-324: TrimSpace, unquote, count ""-pairs.
 // Returns tfgpu_rowerr (0 ok).  Content = [a, b) within the field; npairs = doubled quotes inside.
-__device__ __forceinline__ int sanitize(const CsvOpts &o, const Field &f, uint32_t &a, uint32_t &b, uint32_t &npairs) {
+// any quote-character bit set in tile positions [lo, hi)?
+__device__ __forceinline__ bool any_quote(const uint32_t *qmask, uint32_t lo, uint32_t hi) {
+  if (lo >= hi) return false;
+  const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+  for (uint32_t w = w0; w <= w1; w++) {
+    uint32_t m = qmask[w];
+    if (w == w0) m &= ~0u << (lo & 31);
+    if (w == w1) m &= ~0u >> (31 - ((hi - 1) & 31));
+    if (m) return true;
+  }
+  return false;
+}
+
+// `qmask` (tile path) = bitmap of quote characters of the staged tile, `qbase` = tile position of f[0]:
+// a field without inner quote characters cannot hold doubled quotes, so the byte loop is skipped.
+template <class F> __device__ __forceinline__ int sanitize(const CsvOpts &o, const F &f, uint32_t &a, uint32_t &b, uint32_t &npairs,
+                                                           const uint32_t *qmask = nullptr, uint32_t qbase = 0) {
   a = 0; b = f.n; npairs = 0;
   uint32_t k;
   while (a < b && (k = space_prefix(f, a, b)) > 0) a += k;
@@ -161,6 +192,7 @@ __device__ __forceinline__ int sanitize(const CsvOpts &o, const Field &f, uint32
     if (b - a == 1 && f[a] == o.quote) return TFGPU_ROW_QUOTE;
     if (f[a] == o.quote && f[b - 1] == o.quote) { a++; b--; }
   }
+  if (qmask && !any_quote(qmask, qbase + a, qbase + b)) return 0;
   for (uint32_t i = a; i + 1 < b;) {
     if (f[i] == o.quote && f[i + 1] == o.quote) { npairs++; i += 2; } else i++;
   }
@@ -175,7 +207,7 @@ __device__ __forceinline__ uint32_t lower_(uint32_t c) { return c | 0x20u; }
 __device__ __forceinline__ bool dg(uint32_t c) { return c >= '0' && c <= '9'; }
 
 // strconv/atoi.go underscoreOK over s = f[a..b)
-__device__ bool underscore_ok(const Field &f, uint32_t a, uint32_t b) {
+template <class F> __device__ bool underscore_ok(const F &f, uint32_t a, uint32_t b) {
   uint32_t saw = '^';
   uint32_t i = a;
   if (b - i >= 1 && (f[i] == '-' || f[i] == '+')) i++;
@@ -192,7 +224,7 @@ __device__ bool underscore_ok(const Field &f, uint32_t a, uint32_t b) {
 }
 
 // strconv.ParseUint(s, base 0 or 10, 64): 0 ok, 1 syntax, 2 range
-__device__ int parse_uint64(const Field &f, uint32_t a, uint32_t b, bool base0, uint64_t *out) {
+template <class F> __device__ int parse_uint64(const F &f, uint32_t a, uint32_t b, bool base0, uint64_t *out) {
   *out = 0;
   if (a >= b) return 1;
   uint32_t s0 = a;
@@ -223,7 +255,7 @@ __device__ int parse_uint64(const Field &f, uint32_t a, uint32_t b, bool base0, 
   return 0;
 }
 // strconv.ParseInt(s, base, 64)
-__device__ int parse_int64(const Field &f, uint32_t a, uint32_t b, bool base0, int64_t *out) {
+template <class F> __device__ int parse_int64(const F &f, uint32_t a, uint32_t b, bool base0, int64_t *out) {
   *out = 0;
   if (a >= b) return 1;
   bool neg = false;
@@ -239,7 +271,7 @@ __device__ int parse_int64(const Field &f, uint32_t a, uint32_t b, bool base0, i
   return 0;
 }
 // spf13/cast trimZeroDecimal: "12.00" → "12"
-__device__ __forceinline__ uint32_t trim_zero_decimal(const Field &f, uint32_t a, uint32_t b) {
+template <class F> __device__ __forceinline__ uint32_t trim_zero_decimal(const F &f, uint32_t a, uint32_t b) {
   bool found_zero = false;
   for (uint32_t i = b; i > a; i--) {
     uint32_t c = f[i - 1];
@@ -250,12 +282,12 @@ __device__ __forceinline__ uint32_t trim_zero_decimal(const Field &f, uint32_t a
   return b;
 }
 
-__device__ __forceinline__ bool field_equals(const Field &f, uint32_t a, uint32_t b, const uint8_t *s, uint32_t n) {
+template <class F> __device__ __forceinline__ bool field_equals(const F &f, uint32_t a, uint32_t b, const uint8_t *s, uint32_t n) {
   if (b - a != n) return false;
   for (uint32_t i = 0; i < n; i++) if (f[a + i] != s[i]) return false;
   return true;
 }
-__device__ __forceinline__ bool in_list(const CsvOpts &o, int first, int count, const Field &f, uint32_t a, uint32_t b) {
+template <class F> __device__ __forceinline__ bool in_list(const CsvOpts &o, int first, int count, const F &f, uint32_t a, uint32_t b) {
   for (int i = 0; i < count; i++) {
     uint32_t s = o.list_off[first + i], e = o.list_off[first + i + 1];
     if (field_equals(f, a, b, o.list_data + s, e - s)) return true;
@@ -263,7 +295,7 @@ __device__ __forceinline__ bool in_list(const CsvOpts &o, int first, int count, 
   return false;
 }
 // strconv.ParseBool
-__device__ __forceinline__ int parse_bool(const Field &f, uint32_t a, uint32_t b, int *out) {
+template <class F> __device__ __forceinline__ int parse_bool(const F &f, uint32_t a, uint32_t b, int *out) {
   uint32_t n = b - a;
   if (n == 1) { uint32_t c = f[a]; if (c == '1' || c == 't' || c == 'T') { *out = 1; return 0; } if (c == '0' || c == 'f' || c == 'F') { *out = 0; return 0; } return 1; }
   if (n == 4) {
@@ -283,7 +315,7 @@ __device__ __forceinline__ int parse_bool(const Field &f, uint32_t a, uint32_t b
 //   2006-01-02 | 2006-01-02T15:04:05[.frac][Z07:00] | 2006-01-02 15:04:05[.frac]
 // returns 0 ok, TFGPU_ROW_CAST if the shape is one of these but the value is
 // invalid, TFGPU_ROW_HOST_FALLBACK if the text has another shape.
-__device__ int parse_datetime(const Field &f, uint32_t a, uint32_t b, int64_t *sec, int32_t *nsec) {
+template <class F> __device__ int parse_datetime(const F &f, uint32_t a, uint32_t b, int64_t *sec, int32_t *nsec) {
   uint32_t n = b - a;
   if (n < 10) return TFGPU_ROW_HOST_FALLBACK;
   for (int i = 0; i < 10; i++) {
@@ -327,7 +359,7 @@ __device__ int parse_datetime(const Field &f, uint32_t a, uint32_t b, int64_t *s
 }
 
 // castx.ToJSONNumberE acceptance (fastfloat.Parse grammar or ParseInt base 10)
-__device__ bool json_number_ok(const Field &f, uint32_t a, uint32_t b) {
+template <class F> __device__ bool json_number_ok(const F &f, uint32_t a, uint32_t b) {
   if (a >= b) return false;
   uint32_t p = a;
   if (f[p] == '-' || f[p] == '+') p++;
@@ -344,7 +376,7 @@ __device__ bool json_number_ok(const Field &f, uint32_t a, uint32_t b) {
 }
 
 // ---------------------------------------------------------------------------
-// row parse kernel
+// cell parse: constructCI / getCorrespondingValue / Strictify for ONE mapped column
 // ---------------------------------------------------------------------------
 enum CsvKind : int32_t { CK_INT, CK_UINT, CK_STR, CK_JSONNUM, CK_DATE, CK_TIMESTAMP, CK_BOOL, CK_F32, CK_DEFAULT, CK_INTERVAL };
 
@@ -362,16 +394,27 @@ struct CsvCol {
 
 struct CsvParams {
   const uint8_t *data;
-  const uint32_t *row_start;  // already shifted by skip_rows
+  uint64_t len;
+  const uint32_t *row_start;  // slow path: already shifted by skip_rows
   int64_t nrows;
   CsvOpts o;
   const CsvCol *cols;
   int32_t ncols;
   const int32_t *field_first;  // first column index per CSV field, -1 = unused
   int32_t nfields_used;        // max mapped field index + 1
+  int32_t has_unmapped;        // some field index < nfields_used feeds no column
+  const int32_t *col_order;    // columns sorted by (kind, width): neighbouring lanes run one code path
   uint8_t *err;                // per row tfgpu_rowerr
   int32_t *err_col;
   uint32_t *nerr;
+  // tile path
+  const uint32_t *tile_base;   // exclusive scan of newlines per CT_T-byte tile, [ntiles+1]
+  int64_t ntiles;
+  int64_t skip_rows;
+  uint32_t *slow_n;            // rows the tile path hands to the per-row path
+  uint32_t *slow_row;          //   line index (before skip_rows)
+  uint32_t *slow_end;          //   position of the terminating '\n'
+  uint32_t *last_end;          // max over lines of (position of '\n') + 1
 };
 
 __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v) {
@@ -394,11 +437,81 @@ __device__ __forceinline__ void store_default(const CsvCol &c, int64_t r) {
   }
 }
 
-__global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool have_row = r < p.nrows;
-  uint64_t pos = have_row ? p.row_start[r] : 0;
-  const uint64_t end = have_row ? p.row_start[r + 1] : 0;  // one past '\n'
+template <class F>
+__device__ __forceinline__ bool cell_is_null(const CsvOpts &o, const F &fv, uint32_t a, uint32_t b, uint32_t npairs) {
+  // parseNullValues (reader_csv.go:384-401)
+  if (o.quoted_strings_can_be_null) {
+    uint32_t ta = a, tb = b;
+    if (tb > ta && ((fv[ta] == '"' && fv[tb - 1] == '"') || (fv[ta] == '\'' && fv[tb - 1] == '\''))) { ta++; tb = tb > ta ? tb - 1 : ta; }
+    return npairs == 0 && in_list(o, 0, o.n_null, fv, ta, tb);
+  }
+  if (o.strings_can_be_null) return npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
+  return false;
+}
+
+// One sanitized field [a,b) of `fv` (npairs doubled quotes inside) → column c, row r.
+// `abs_start` is the absolute byte offset of fv[0] in the CSV buffer.  Returns tfgpu_rowerr.
+template <class F>
+__device__ int parse_cell(const CsvOpts &o, const CsvCol &c, int64_t r, const F &fv, uint32_t a, uint32_t b, uint32_t npairs, uint64_t abs_start) {
+  switch (c.kind) {
+    case CK_INT: case CK_UINT: {
+      // parseNullValues then cast.ToIntNE(string) + range check
+      if (cell_is_null(o, fv, a, b, npairs)) { store_default(c, r); return 0; }
+      if (npairs) return TFGPU_ROW_CAST;  // a '"' survives in the text: not a number
+      uint32_t tb = trim_zero_decimal(fv, a, b);
+      if (c.kind == CK_INT || c.hi != ~0ull) {
+        int64_t v; int rc = parse_int64(fv, a, tb, true, &v);
+        if (rc) return TFGPU_ROW_CAST;
+        if (c.kind == CK_UINT) {
+          if (v < 0) return TFGPU_ROW_CAST;  // errNegativeNotAllowed
+          if ((uint64_t)v > c.hi) return TFGPU_ROW_RANGE;
+        } else if (v < c.lo || v > (int64_t)c.hi) return TFGPU_ROW_RANGE;
+        store_int(c, r, v);
+      } else {  // uint64: cast.ToUint64E parses with ParseUint
+        uint64_t v; int rc = parse_uint64(fv, a, tb, true, &v);
+        if (rc) return TFGPU_ROW_CAST;
+        ((uint64_t *)c.values)[r] = v;
+      }
+      return 0;
+    }
+    case CK_STR: case CK_JSONNUM: {
+      if (c.kind == CK_STR && cell_is_null(o, fv, a, b, npairs)) { c.lens[r] = 0; c.fstart[r] = 0x7FFFFFFFu; return 0; }
+      if (c.kind == CK_JSONNUM && (npairs || !json_number_ok(fv, a, b))) return TFGPU_ROW_CAST;
+      c.lens[r] = (b - a) - npairs;
+      c.fstart[r] = (uint32_t)(abs_start + a) | (npairs ? 0x80000000u : 0u);
+      return 0;
+    }
+    case CK_DATE: case CK_TIMESTAMP: {
+      if (npairs) return TFGPU_ROW_CAST;
+      int64_t sec = 0; int32_t ns = 0; int rc;
+      if (c.kind == CK_TIMESTAMP && parse_int64(fv, a, b, false, &sec) == 0) rc = 0;  // parseTimestampValue :419-426
+      else rc = parse_datetime(fv, a, b, &sec, &ns);
+      if (rc) return rc;
+      ((int64_t *)c.values)[r] = sec;
+      c.nanos[r] = ns;
+      return 0;
+    }
+    case CK_BOOL: {  // parseBooleanValue :431-452 then cast.ToBoolE
+      int v = 0;
+      if (npairs) return TFGPU_ROW_CAST;
+      if (o.strings_can_be_null && in_list(o, 0, o.n_null, fv, a, b)) v = 0;
+      else if (in_list(o, o.n_null, o.n_true, fv, a, b)) v = 1;
+      else if (in_list(o, o.n_null + o.n_true, o.n_false, fv, a, b)) v = 0;
+      else if (parse_bool(fv, a, b, &v)) return TFGPU_ROW_CAST;
+      ((uint8_t *)c.values)[r] = (uint8_t)v;
+      return 0;
+    }
+    default:  // CK_F32 (strconv.ParseFloat 32-bit rounding), CK_INTERVAL: host path
+      return TFGPU_ROW_HOST_FALLBACK;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// per-row path: one lane per line, bytes straight from HBM.  Used for the lines
+// the tile path cannot stage (longer than its look-behind window) and, with
+// TFGPU_CSV_ROWPATH=1, for whole chunks (parity cross-check of the two paths).
+// ---------------------------------------------------------------------------
+__device__ void parse_line_hbm(const CsvParams &p, const bool have_row, const int64_t r, uint64_t pos, const uint64_t end /* one past '\n' */) {
   const uint64_t row0 = pos;
   MemBytes scan(p.data), fld(p.data);
   const CsvOpts &o = p.o;
@@ -443,76 +556,11 @@ __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
     for (int32_t ci = first_col; ci >= 0; ci = p.cols[ci].next) {
       const CsvCol &c = p.cols[ci];
       if (!have_row || rerr) continue;
-      int err = 0;
       if (!has_field) {  // index >= len(row) (reader_csv.go:303-316)
         if (o.include_missing) store_default(c, r); else if (ci < miss_col) miss_col = ci;
         continue;
       }
-      switch (c.kind) {
-        case CK_INT: case CK_UINT: {
-          // parseNullValues (reader_csv.go:384-401) then cast.ToIntNE(string) + range check
-          bool isnull = false;
-          if (o.quoted_strings_can_be_null) {
-            uint32_t ta = a, tb = b;
-            if (tb > ta && ((fv[ta] == '"' && fv[tb - 1] == '"') || (fv[ta] == '\'' && fv[tb - 1] == '\''))) { ta++; tb = tb > ta ? tb - 1 : ta; }
-            isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, ta, tb);
-          } else if (o.strings_can_be_null) isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
-          if (isnull) { store_default(c, r); break; }
-          if (npairs) { err = TFGPU_ROW_CAST; break; }  // a '"' survives in the text: not a number
-          uint32_t tb = trim_zero_decimal(fv, a, b);
-          if (c.kind == CK_INT || c.hi != ~0ull) {
-            int64_t v; int rc = parse_int64(fv, a, tb, true, &v);
-            if (rc) { err = TFGPU_ROW_CAST; break; }
-            if (c.kind == CK_UINT) {
-              if (v < 0) { err = TFGPU_ROW_CAST; break; }  // errNegativeNotAllowed
-              if ((uint64_t)v > c.hi) { err = TFGPU_ROW_RANGE; break; }
-            } else if (v < c.lo || v > (int64_t)c.hi) { err = TFGPU_ROW_RANGE; break; }
-            store_int(c, r, v);
-          } else {  // uint64: cast.ToUint64E parses with ParseUint
-            uint64_t v; int rc = parse_uint64(fv, a, tb, true, &v);
-            if (rc) { err = TFGPU_ROW_CAST; break; }
-            ((uint64_t *)c.values)[r] = v;
-          }
-          break;
-        }
-        case CK_STR: case CK_JSONNUM: {
-          bool isnull = false;
-          if (c.kind == CK_STR) {
-            if (o.quoted_strings_can_be_null) {
-              uint32_t ta = a, tb = b;
-              if (tb > ta && ((fv[ta] == '"' && fv[tb - 1] == '"') || (fv[ta] == '\'' && fv[tb - 1] == '\''))) { ta++; tb = tb > ta ? tb - 1 : ta; }
-              isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, ta, tb);
-            } else if (o.strings_can_be_null) isnull = npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
-          }
-          if (isnull) { c.lens[r] = 0; c.fstart[r] = 0x7FFFFFFFu; break; }
-          if (c.kind == CK_JSONNUM && (npairs || !json_number_ok(fv, a, b))) { err = TFGPU_ROW_CAST; break; }
-          c.lens[r] = (b - a) - npairs;
-          c.fstart[r] = (uint32_t)(fs + a) | (npairs ? 0x80000000u : 0u);
-          break;
-        }
-        case CK_DATE: case CK_TIMESTAMP: {
-          if (npairs) { err = TFGPU_ROW_CAST; break; }
-          int64_t sec = 0; int32_t ns = 0; int rc;
-          if (c.kind == CK_TIMESTAMP && parse_int64(fv, a, b, false, &sec) == 0) rc = 0;  // parseTimestampValue :419-426
-          else rc = parse_datetime(fv, a, b, &sec, &ns);
-          if (rc) { err = rc; break; }
-          ((int64_t *)c.values)[r] = sec;
-          c.nanos[r] = ns;
-          break;
-        }
-        case CK_BOOL: {  // parseBooleanValue :431-452 then cast.ToBoolE
-          int v = 0;
-          if (npairs) { err = TFGPU_ROW_CAST; break; }
-          if (o.strings_can_be_null && in_list(o, 0, o.n_null, fv, a, b)) v = 0;
-          else if (in_list(o, o.n_null, o.n_true, fv, a, b)) v = 1;
-          else if (in_list(o, o.n_null + o.n_true, o.n_false, fv, a, b)) v = 0;
-          else if (parse_bool(fv, a, b, &v)) { err = TFGPU_ROW_CAST; break; }
-          ((uint8_t *)c.values)[r] = (uint8_t)v;
-          break;
-        }
-        default:  // CK_F32 (strconv.ParseFloat 32-bit rounding), CK_INTERVAL: host path
-          err = TFGPU_ROW_HOST_FALLBACK;
-      }
+      int err = parse_cell(o, c, r, fv, a, b, npairs, fs);
       if (err && ci < cerr_col) { cerr = err; cerr_col = ci; }
     }
     if (last) active = false;
@@ -534,6 +582,315 @@ __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
   if (!err && cerr) { err = cerr; err_col = cerr_col; }
   p.err[r] = (uint8_t)err;
   if (err) { p.err_col[r] = err_col; atomicAdd(p.nerr, 1u); }
+}
+
+__global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool have_row = r < p.nrows;
+  parse_line_hbm(p, have_row, r, have_row ? p.row_start[r] : 0, have_row ? p.row_start[r + 1] : 0);
+}
+
+// lines listed by the tile path: only the '\n' position is known; walk back to the line start
+__global__ void __launch_bounds__(64) csv_parse_listed(CsvParams p) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = *p.slow_n;
+  if ((uint64_t)blockIdx.x * blockDim.x >= n) return;  // whole wave idle
+  const int64_t line = i < n ? (int64_t)p.slow_row[i] : -1;
+  const bool have_row = i < n && line >= p.skip_rows;
+  uint64_t end = 0, pos = 0;
+  if (have_row) {
+    end = (uint64_t)p.slow_end[i] + 1;
+    pos = end - 1;
+    MemBytes back(p.data);
+    while (pos > 0 && back.at(pos - 1) != '\n') pos--;
+  }
+  parse_line_hbm(p, have_row, line - p.skip_rows, pos, end);
+}
+
+// ---------------------------------------------------------------------------
+// tile path.  One 256-thread workgroup owns the lines whose '\n' falls into one
+// CT_T-byte tile of the input.  It stages the tile plus a CT_SPILL-byte
+// look-behind window in LDS with coalesced 16-byte loads, classifies every byte
+// once (quote state = a prefix scan over per-byte {identity, toggle, set, clear}
+// functions — splitString's state machine is a composition of those), turns the
+// field ends into an LDS index, and then parses (column, line) cells with one
+// lane per cell, lines fastest, so every column store is coalesced and every
+// wave runs one column type.
+// ---------------------------------------------------------------------------
+static constexpr int CT_THREADS = 512;
+static constexpr int CT_T = NL_TILE;            // bytes whose '\n' this workgroup owns
+static constexpr int CT_SPILL = 8192;           // look-behind: longest line staged in LDS
+static constexpr int CT_BYTES = CT_T + CT_SPILL;
+static constexpr int CT_CPT = CT_BYTES / 16 / CT_THREADS;  // 16-byte chunks per thread (blocked)
+static constexpr int CT_FCAP = 4096;            // field ends indexed per pass
+static constexpr int CT_RCAP = 256;             // lines per pass
+static_assert(CT_CPT * 16 * CT_THREADS == CT_BYTES, "tile must divide evenly");
+static_assert(CT_BYTES <= 32768, "positions are 15-bit");
+
+// quote-state functions on one bit: bit0 = f(0), bit1 = f(1); identity = 0b10
+__device__ __forceinline__ uint32_t qf_compose(uint32_t first, uint32_t then) {
+  return ((then >> (first & 1)) & 1u) | (((then >> ((first >> 1) & 1)) & 1u) << 1);
+}
+
+__global__ void __launch_bounds__(CT_THREADS) csv_parse_tiles(CsvParams p) {
+  __shared__ __attribute__((aligned(16))) uint8_t sb[CT_BYTES + 16];
+  __shared__ uint16_t fpos[CT_FCAP];   // field-end position | bit15 = it is the line's '\n'
+  __shared__ uint16_t rowend[CT_RCAP]; // ordinal of each line's last field
+  __shared__ uint32_t e_read[CT_RCAP], e_miss[CT_RCAP], e_cast[CT_RCAP];
+  __shared__ uint32_t qmask[CT_BYTES / 32];  // bitmap of quote characters
+  __shared__ uint32_t wtmp[CT_THREADS / 64];
+  __shared__ uint32_t wmax[CT_THREADS / 64];
+
+  // XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
+  const int64_t per_xcd = (p.ntiles + 7) / 8;
+  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const uint32_t line0 = p.tile_base[tile];
+  const uint32_t nlines = p.tile_base[tile + 1] - line0;
+  if (nlines == 0) return;  // no line ends here (inside a very long line)
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const CsvOpts &o = p.o;
+  const int64_t g0 = tile * CT_T - CT_SPILL;  // absolute offset of sb[0]
+
+  // ---- stage: coalesced 16 B/lane ----
+#pragma unroll
+  for (int it = 0; it < CT_CPT; it++) {
+    int chunk = it * CT_THREADS + tid;
+    int64_t gp = g0 + (int64_t)chunk * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gp >= 0 && (uint64_t)gp < p.len) v = *reinterpret_cast<const uint4 *>(p.data + gp);  // buffer is zero-padded past len
+    *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
+  }
+  __syncthreads();
+
+  // ---- classify: thread t walks bytes [96t, 96t+96) under both entry states ----
+  const int base_chunk = tid * CT_CPT;
+  uint32_t fe01[CT_CPT];      // field-end delimiters if the thread starts outside (lo16) / inside (hi16) quotes
+  uint32_t nlm[CT_CPT];       // '\n' mask
+  uint32_t st = 2u;           // function of this thread's bytes (starts as identity)
+  int last_lb_nl = -1;        // last '\n' inside the look-behind window
+  {
+    bool prev_esc = false;
+    if (o.escape != 0 && base_chunk > 0) prev_esc = sb[base_chunk * 16 - 1] == o.escape;
+#pragma unroll
+    for (int q = 0; q < CT_CPT; q++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sb + (base_chunk + q) * 16);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t f0 = 0, f1 = 0, nl = 0, qm = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const bool isq = c == o.quote;  // quote != 0 on this path
+        qm |= (isq ? 1u : 0u) << i;
+        if (c == '\n') { st = 0u; nl |= 1u << i; }
+        else if (isq) st = prev_esc ? 3u : (st ^ 3u);
+        else if (c == o.delim) { f0 |= ((~st) & 1u) << i; f1 |= ((~st >> 1) & 1u) << i; }
+        prev_esc = o.escape != 0 && c == o.escape;
+      }
+      fe01[q] = f0 | (f1 << 16);
+      nlm[q] = nl;
+      reinterpret_cast<uint16_t *>(qmask)[base_chunk + q] = (uint16_t)qm;
+      const int cpos = (base_chunk + q) * 16;
+      if (nl && cpos < CT_SPILL) last_lb_nl = cpos + 31 - __clz((int)nl);
+    }
+  }
+  // ---- block scan of the quote functions + max of the look-behind '\n' ----
+  uint32_t inc = st;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc = qf_compose(t, inc);
+  }
+  int mx = last_lb_nl;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+  if (lane == 63) wtmp[wv] = inc;
+  if (lane == 0) wmax[wv] = (uint32_t)(mx + 1);
+  __syncthreads();
+  uint32_t pre = 2u;
+  for (int i = 0; i < wv; i++) pre = qf_compose(pre, wtmp[i]);
+  uint32_t lane_ex = __shfl_up(inc, 1, 64);
+  if (lane == 0) lane_ex = 2u;
+  const uint32_t s_in = qf_compose(pre, lane_ex) & 1u;  // quote state entering this thread's bytes
+  int frs = 0;                                          // first byte of the first line ending in this tile
+  for (int i = 0; i < CT_THREADS / 64; i++) frs = max(frs, (int)wmax[i]);
+  bool first_long = false;
+  if (frs == 0) {
+    if (g0 <= 0) frs = (int)(-g0);  // the buffer starts inside the window: line 0 starts at absolute 0
+    else first_long = true;         // the first line started before the window: per-row path
+  }
+  __syncthreads();
+
+  // ---- select the hypothesis, drop what precedes the first line, count ----
+  uint32_t fe[CT_CPT];  // field ends: unquoted delimiters and '\n'
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int q = 0; q < CT_CPT; q++) {
+    const int cpos = (base_chunk + q) * 16;
+    uint32_t m = ((s_in ? (fe01[q] >> 16) : fe01[q]) & 0xFFFFu) | nlm[q];
+    uint32_t keep = 0xFFFFu;
+    if (cpos + 16 <= frs) keep = 0; else if (cpos < frs) keep = 0xFFFFu & ~((1u << (frs - cpos)) - 1u);
+    fe[q] = m & keep; nlm[q] &= keep;  // look-behind '\n's all precede frs
+    cnt += __popc(fe[q]) | (__popc(nlm[q]) << 16);
+  }
+  uint32_t cinc = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(cinc, d, 64);
+    if (lane >= d) cinc += t;
+  }
+  if (lane == 63) wtmp[wv] = cinc;
+  __syncthreads();
+  uint32_t cpre = 0, ctot = 0;
+  for (int i = 0; i < CT_THREADS / 64; i++) { uint32_t x = wtmp[i]; if (i < wv) cpre += x; ctot += x; }
+  const uint32_t cex = cpre + cinc - cnt;
+  const uint32_t k_thread = cex & 0xFFFFu, j_thread = cex >> 16;  // ordinal / line of this thread's first field end
+  const uint32_t nl_tot = ctot >> 16;                             // == nlines by construction
+  __syncthreads();
+
+  // ---- passes over the lines of this tile ----
+  uint32_t jb = 0, kb = 0;
+  uint32_t bstart = (uint32_t)frs;  // first byte of line jb
+  while (jb < nl_tot) {
+    // pass 1: ordinal of each line's '\n' for lines [jb, jb+CT_RCAP)
+    {
+      uint32_t k = k_thread, j = j_thread;
+#pragma unroll
+      for (int q = 0; q < CT_CPT; q++) {
+        uint32_t m = nlm[q];
+        while (m) {
+          const int b = __ffs((int)m) - 1; m &= m - 1;
+          const uint32_t kk = k + __popc(fe[q] & ((1u << b) - 1u));
+          if (j >= jb && j < jb + CT_RCAP) rowend[j - jb] = (uint16_t)kk;
+          j++;
+        }
+        k += __popc(fe[q]);
+      }
+    }
+    __syncthreads();
+    const uint32_t nwin = min((uint32_t)CT_RCAP, nl_tot - jb);
+    // lines that fit the field index: rowend is increasing, count entries below the cap
+    uint32_t nr = 0;
+    {
+      uint32_t lo = 0, hi = nwin;  // first index whose last field does not fit
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)rowend[mid] - kb < (uint32_t)CT_FCAP) lo = mid + 1; else hi = mid; }
+      nr = lo;
+    }
+    const bool skip_first = (jb == 0 && first_long) || nr == 0;  // line handled by the per-row path
+    if (skip_first) nr = 1;
+    const uint32_t kend = rowend[nr - 1];
+    // pass 2: positions of the field ends [kb, kend]
+    if (!skip_first) {
+      uint32_t k = k_thread;
+#pragma unroll
+      for (int q = 0; q < CT_CPT; q++) {
+        uint32_t m = fe[q];
+        const int cpos = (base_chunk + q) * 16;
+        while (m) {
+          const int b = __ffs((int)m) - 1; m &= m - 1;
+          if (k >= kb && k <= kend) fpos[k - kb] = (uint16_t)((cpos + b) | (((nlm[q] >> b) & 1u) << 15));
+          k++;
+        }
+      }
+    }
+    for (uint32_t i = tid; i < nr; i += CT_THREADS) { e_read[i] = 0xFFFFFFFFu; e_miss[i] = 0xFFFFFFFFu; e_cast[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+
+    uint32_t next_bstart;
+    if (skip_first) {
+      // find the '\n' of this one line: it is the field end kend; only its owner knows the position
+      uint32_t k = k_thread;
+#pragma unroll
+      for (int q = 0; q < CT_CPT; q++) {
+        uint32_t m = fe[q];
+        const int cpos = (base_chunk + q) * 16;
+        while (m) {
+          const int b = __ffs((int)m) - 1; m &= m - 1;
+          if (k == kend) {
+            fpos[0] = (uint16_t)(cpos + b);
+            uint32_t slot = atomicAdd(p.slow_n, 1u);
+            p.slow_row[slot] = line0 + jb;
+            p.slow_end[slot] = (uint32_t)(g0 + cpos + b);
+          }
+          k++;
+        }
+      }
+      __syncthreads();
+      next_bstart = (uint32_t)fpos[0] + 1;
+    } else {
+      // ---- cells: item = column * nr + line, lines fastest ----
+      const uint32_t total = (uint32_t)p.ncols * nr;
+      LdsBytes rd(sb);
+      for (uint32_t it = tid; it < total; it += CT_THREADS) {
+        const uint32_t oi = it / nr, jj = it - oi * nr;
+        const uint32_t ci = (uint32_t)p.col_order[oi];
+        const int64_t r = (int64_t)line0 + jb + jj - p.skip_rows;
+        if (r < 0) continue;  // header lines
+        const CsvCol &c = p.cols[ci];
+        const uint32_t k0 = jj ? (uint32_t)rowend[jj - 1] + 1 : kb, ke = rowend[jj];
+        const uint32_t row_start = jj ? (uint32_t)(fpos[k0 - 1 - kb] & 0x7FFFu) + 1 : bstart;
+        const uint32_t nl_pos = fpos[ke - kb] & 0x7FFFu;
+        const uint32_t nf = (nl_pos == row_start) ? 0u : ke - k0 + 1;  // "\n" alone: ReadLine returns (nil, nil)
+        if (c.field < 0) { store_default(c, r); continue; }
+        if ((uint32_t)c.field >= nf) {
+          if (o.include_missing) store_default(c, r); else atomicMin(&e_miss[jj], ci);
+          continue;
+        }
+        const uint32_t k = k0 + (uint32_t)c.field;
+        uint32_t fs = c.field ? (uint32_t)(fpos[k - 1 - kb] & 0x7FFFu) + 1 : row_start;
+        const uint32_t fend = fpos[k - kb] & 0x7FFFu;
+        if (nf == 1) fs = row_start + 1;  // no delimiter in the line: line[lastDelimPosition+1:] drops byte 0 (reader.go:263)
+        LField fv{&rd, fs, fend - fs};
+        uint32_t a = 0, b = 0, npairs = 0;
+        int e = sanitize(o, fv, a, b, npairs, qmask, fs);
+        if (e) { atomicMin(&e_read[jj], ((uint32_t)c.field << 8) | (uint32_t)e); continue; }
+        e = parse_cell(o, c, r, fv, a, b, npairs, (uint64_t)(g0 + fs));
+        if (e) atomicMin(&e_cast[jj], (ci << 8) | (uint32_t)e);
+      }
+      // ---- sanitizeElement also runs on fields no column reads ----
+      if (p.has_unmapped || (kend - kb + 1) != nr * (uint32_t)p.nfields_used) {
+        for (uint32_t kk = tid; kk <= kend - kb; kk += CT_THREADS) {
+          uint32_t lo = 0, hi = nr - 1;  // line of ordinal kb+kk
+          while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)rowend[mid] < kb + kk) lo = mid + 1; else hi = mid; }
+          const uint32_t jj = lo;
+          if ((int64_t)line0 + jb + jj - p.skip_rows < 0) continue;
+          const uint32_t k0 = jj ? (uint32_t)rowend[jj - 1] + 1 : kb, ke = rowend[jj];
+          const uint32_t f = kb + kk - k0;
+          if (f < (uint32_t)p.nfields_used && p.field_first[f] >= 0) continue;  // done by its column
+          const uint32_t row_start = jj ? (uint32_t)(fpos[k0 - 1 - kb] & 0x7FFFu) + 1 : bstart;
+          const uint32_t nl_pos = fpos[ke - kb] & 0x7FFFu;
+          if (nl_pos == row_start) continue;
+          uint32_t fs = f ? (uint32_t)(fpos[kk - 1] & 0x7FFFu) + 1 : row_start;
+          if (ke == k0) fs = row_start + 1;
+          LField fv{&rd, fs, (uint32_t)(fpos[kk] & 0x7FFFu) - fs};
+          uint32_t a, b, npairs;
+          int e = sanitize(o, fv, a, b, npairs, qmask, fs);
+          if (e) atomicMin(&e_read[jj], (f << 8) | (uint32_t)e);
+        }
+      }
+      __syncthreads();
+      // ---- per line: ReadLine error > missing cell > strictify error ----
+      for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
+        const int64_t r = (int64_t)line0 + jb + jj - p.skip_rows;
+        if (r < 0) continue;
+        int err = 0, err_col = -1;
+        if (e_read[jj] != 0xFFFFFFFFu) {
+          err = (int)(e_read[jj] & 0xFFu);
+          uint32_t f = e_read[jj] >> 8;
+          err_col = f < (uint32_t)p.nfields_used ? p.field_first[f] : -1;
+        } else if (e_miss[jj] != 0xFFFFFFFFu) { err = TFGPU_ROW_MISSING_CELL; err_col = (int)e_miss[jj]; }
+        else if (e_cast[jj] != 0xFFFFFFFFu) { err = (int)(e_cast[jj] & 0xFFu); err_col = (int)(e_cast[jj] >> 8); }
+        p.err[r] = (uint8_t)err;
+        if (err) { p.err_col[r] = err_col; atomicAdd(p.nerr, 1u); }
+      }
+      next_bstart = (uint32_t)(fpos[kend - kb] & 0x7FFFu) + 1;
+    }
+    __syncthreads();
+    bstart = next_bstart;
+    jb += nr; kb = kend + 1;
+  }
+  if (tid == 0) atomicMax(p.last_end, (uint32_t)(g0 + bstart));  // one past the last '\n' this tile owns
 }
 
 // rows that failed contribute no string bytes
@@ -581,6 +938,18 @@ __global__ void __launch_bounds__(256) csv_copy_strings(CopyParams p) {
   }
 }
 
+// one contiguous summary for a single read-back: [nerr, consumed, total bytes of each string column]
+__global__ void csv_collect(const uint32_t *nerr, const uint32_t *last, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, uint32_t *out) {
+  int i = threadIdx.x;
+  if (i == 0) out[0] = *nerr;
+  if (i == 1) out[1] = *last;
+  for (int s = i; s < nstr; s += blockDim.x) out[2 + s] = lens_all[(int64_t)s * seg_stride + nrows];
+}
+__global__ void csv_keep_from_err(const uint8_t *err, int64_t n, uint32_t *keep) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) keep[r] = err[r] ? 0u : 1u;
+}
+
 __global__ void csv_shift_rows(const uint32_t *row_start, int64_t n, uint32_t *out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n) out[i] = row_start[i];
@@ -618,6 +987,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   if (opts->decimal_point && opts->decimal_point[0]) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: DecimalPoint is not device-resident yet");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
+  PinScope pin_scope;
   hipStream_t st = cx.stream;
 
   // ---- input in HBM, padded so 16-byte loads never run off the allocation ----
@@ -640,14 +1010,21 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   if (ntiles) {
     { KernelTimer t("csv_count_newlines"); csv_count_newlines<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts)); }
     exclusive_scan_u32(ptr<uint32_t>(tile_counts), ptr<uint32_t>(tile_counts), ntiles, true);
-    d2h(&nlines, ptr<uint32_t>(tile_counts) + ntiles, 4);
+    const uint32_t *h = d2h_u32(ptr<uint32_t>(tile_counts) + ntiles);
     tf::sync();
+    nlines = *h;
   }
-  Buf row_start = dalloc_zero((size_t)(nlines + 2) * 4);
-  if (nlines) { KernelTimer t("csv_line_index"); csv_line_index<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ptr<uint32_t>(row_start)); }
+  // TFGPU_CSV_ROWPATH=1 forces the per-row path for whole chunks (the tile path's parity cross-check)
+  static const bool force_rowpath = [] { const char *e = std::getenv("TFGPU_CSV_ROWPATH"); return e && e[0] == '1'; }();
+  const bool rowpath = force_rowpath || opts->escape_char == '\n' || opts->escape_char >= 0x80 || opts->quote_char >= 0x80;
+  Buf row_start;
+  if (rowpath) {
+    row_start = dalloc_zero((size_t)(nlines + 2) * 4);
+    if (nlines) { KernelTimer t("csv_line_index"); csv_line_index<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ptr<uint32_t>(row_start)); }
+  }
   int64_t skip = std::min<int64_t>(std::max<int64_t>(opts->skip_rows, 0), nlines);
   int64_t nrows = (int64_t)nlines - skip;
-  const uint32_t *rs = ptr<uint32_t>(row_start) + skip;
+  const uint32_t *rs = rowpath ? ptr<uint32_t>(row_start) + skip : nullptr;
 
   // ---- column plan ----
   int ncols = schema->ncols;
@@ -719,13 +1096,20 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   std::vector<uint32_t> loff{0}; std::string ldata;
   auto add_list = [&](int n, const char *const *v) { for (int i = 0; i < n; i++) { ldata += v[i] ? v[i] : ""; loff.push_back((uint32_t)ldata.size()); } };
   add_list(opts->n_null_values, opts->null_values); add_list(opts->n_true_values, opts->true_values); add_list(opts->n_false_values, opts->false_values);
-  auto up = [&](const void *src, size_t bytes) { Buf b = dalloc(bytes + 16); if (bytes) h2d(b->p, src, bytes); return b; };
+  auto up = [&](const void *src, size_t bytes) { return upload_small(src, bytes); };
   Buf bcols = up(cols.data(), cols.size() * sizeof(CsvCol)), bff = up(field_first.data(), field_first.size() * 4);
   Buf bloff = up(loff.data(), loff.size() * 4), bldata = up(ldata.data(), ldata.size());
   Buf err = dalloc((size_t)nrows + 16), err_col = dalloc((size_t)nrows * 4 + 16), nerr = dalloc_zero(4);
 
+  // lines the tile path hands to the per-row path (at most one per tile per pass) + consumed offset
+  const int64_t slow_cap = 5 * ntiles + 8;  // <= 1 long first line + CT_BYTES/CT_FCAP over-wide lines per tile
+  Buf slow = dalloc_zero((size_t)(2 * slow_cap + 2) * 4);
   CsvParams pp;
-  pp.data = data; pp.row_start = rs; pp.nrows = nrows;
+  std::memset(&pp, 0, sizeof pp);
+  pp.data = data; pp.len = len; pp.row_start = rs; pp.nrows = nrows;
+  pp.tile_base = ptr<uint32_t>(tile_counts); pp.ntiles = ntiles; pp.skip_rows = skip;
+  pp.slow_n = ptr<uint32_t>(slow); pp.last_end = ptr<uint32_t>(slow) + 1;
+  pp.slow_row = ptr<uint32_t>(slow) + 2; pp.slow_end = ptr<uint32_t>(slow) + 2 + slow_cap;
   pp.o.delim = opts->delimiter; pp.o.quote = opts->quote_char; pp.o.escape = opts->escape_char; pp.o.double_quote = opts->double_quote;
   pp.o.include_missing = opts->include_missing_columns; pp.o.strings_can_be_null = opts->strings_can_be_null;
   pp.o.quoted_strings_can_be_null = opts->quoted_strings_can_be_null; pp.o.pad = 0;
@@ -733,14 +1117,29 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.o.list_off = ptr<uint32_t>(bloff); pp.o.list_data = ptr<uint8_t>(bldata);
   pp.cols = ptr<CsvCol>(bcols); pp.ncols = ncols; pp.field_first = ptr<int32_t>(bff); pp.nfields_used = max_field + 1;
   pp.err = ptr<uint8_t>(err); pp.err_col = ptr<int32_t>(err_col); pp.nerr = ptr<uint32_t>(nerr);
+  pp.has_unmapped = 0;
+  for (int f = 0; f <= max_field; f++) if (field_first[(size_t)f] < 0) pp.has_unmapped = 1;
+  std::vector<int32_t> order((size_t)ncols);
+  for (int i = 0; i < ncols; i++) order[(size_t)i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    const CsvCol &a = cols[(size_t)x], &b = cols[(size_t)y];
+    return a.kind != b.kind ? a.kind < b.kind : a.width < b.width;
+  });
+  Buf border = up(order.data(), order.size() * 4);
+  pp.col_order = ptr<int32_t>(border);
 
   // QuoteChar == 0 and the data holds '"' → errQuotingDisabled for that line (reader.go:182-184):
   // the state machine cannot see it (quote disabled), so treat '"' as an error marker via the quote path
   if (opts->quote_char == 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: QuoteChar=0 (quoting disabled) is not device-resident yet");
 
-  if (nrows) {
+  if (nrows && rowpath) {
     KernelTimer t("csv_parse_rows");
     csv_parse_rows<<<blocks_for(nrows, 256), 256, 0, st>>>(pp);
+  } else if (nlines) {
+    // header lines are parsed by nobody: err[] of the data rows is written by exactly one of the two kernels
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    { KernelTimer t("csv_parse_tiles"); csv_parse_tiles<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
+    { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<blocks_for(slow_cap, 64), 64, 0, st>>>(pp); }
   }
   if (nrows && nstr) {
     csv_zero_err_lens<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint8_t>(err), nrows, ptr<CsvCol>(bcols), ncols);
@@ -748,21 +1147,21 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   } else if (nstr) {
     TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)nstr * (size_t)seg_stride * 4, st));
   }
-  // ---- one read-back: error count + string totals ----
-  uint32_t hnerr = 0;
-  std::vector<uint32_t> totals((size_t)std::max(nstr, 1), 0);
-  d2h(&hnerr, nerr->p, 4);
-  for (int s = 0; s < nstr; s++) d2h(&totals[(size_t)s], ptr<uint32_t>(lens_all) + (int64_t)s * seg_stride + nrows, 4);
+  // ---- one read-back: error count, consumed offset, string totals ----
+  Buf summary = dalloc((size_t)(nstr + 2) * 4);
+  csv_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), rowpath ? ptr<uint32_t>(row_start) + nlines : pp.last_end, ptr<uint32_t>(lens_all),
+                                seg_stride, nrows, nstr, ptr<uint32_t>(summary));
+  const uint32_t *hsum = d2h_u32(summary->p, (size_t)nstr + 2);
   tf::sync();
+  const uint32_t hnerr = hsum[0], last = hsum[1];
 
-  // ---- string payloads ----
+  // ---- string payloads: offsets are views into the scanned lens array ----
   std::vector<CopyCol> cc;
   for (int s = 0; s < nstr; s++) {
     DColumn &d = db->cols[(size_t)str_col_index[(size_t)s]];
-    d.data_len = totals[(size_t)s];
+    d.data_len = hsum[2 + s];
     d.data = dalloc(d.data_len + 8);
-    d.offsets = dalloc((size_t)(nrows + 1) * 4);
-    d2d(d.offsets->p, ptr<uint32_t>(lens_all) + (int64_t)s * seg_stride, (size_t)(nrows + 1) * 4);
+    d.offsets = subbuf(lens_all, (size_t)s * (size_t)seg_stride * 4, (size_t)(nrows + 1) * 4);
     cc.push_back(CopyCol{ptr<uint32_t>(d.offsets), cols[(size_t)str_col_index[(size_t)s]].fstart, ptr<uint8_t>(d.data), d.repr == TFGPU_R_JSONNUM ? 1 : 0});
   }
   Buf bcc = up(cc.data(), cc.size() * sizeof(CopyCol));
@@ -772,25 +1171,18 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     csv_copy_strings<<<blocks_for(nrows, 256), 256, 0, st>>>(cp);
   }
 
-  // ---- consumed: one past the last '\n' (an unterminated tail is left for the next chunk) ----
-  uint32_t last = 0;
-  d2h(&last, ptr<uint32_t>(row_start) + nlines, 4);
   std::unique_ptr<tfgpu_dbatch> result;
   int64_t ne = 0;
-  if (hnerr) {
+  if (hnerr) {  // failed lines are dropped from the batch and reported (parseCSVRows :205-218)
     std::vector<uint8_t> he((size_t)nrows); std::vector<int32_t> hc((size_t)nrows);
     d2h(he.data(), err->p, (size_t)nrows); d2h(hc.data(), err_col->p, (size_t)nrows * 4);
-    tf::sync();
     Buf keep = dalloc((size_t)(nrows + 1) * 4);
-    std::vector<uint32_t> hk((size_t)nrows + 1, 0);
-    for (int64_t r = 0; r < nrows; r++) {
-      hk[(size_t)r] = he[(size_t)r] ? 0u : 1u;
+    csv_keep_from_err<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint8_t>(err), nrows, ptr<uint32_t>(keep));
+    tf::sync();
+    for (int64_t r = 0; r < nrows; r++)
       if (he[(size_t)r]) { if (errs && ne < errs_cap) errs[ne] = tfgpu_row_error{r, he[(size_t)r], 0, hc[(size_t)r]}; ne++; }
-    }
-    h2d(keep->p, hk.data(), hk.size() * 4);
     result = compact_rows(*db, keep);
   } else {
-    tf::sync();
     result = std::move(db);
   }
   if (consumed) *consumed = last;

@@ -50,14 +50,69 @@ void Context::prof_flush() {
   pending.clear();
 }
 
+// ---- HBM block cache ---------------------------------------------------------
+// Every buffer of the library lives on ONE stream, so a block handed back by the
+// host can be re-issued at once: whatever is enqueued next runs after the work
+// that still reads it.  Blocks are binned in 8 size classes per octave (<= 12.5 %
+// slack) and never returned to the driver while the context lives — the HIP pool
+// (hipMallocAsync/hipFreeAsync) cost 40-80 us per call here (profiles/r01c), more
+// than most kernels of the path.
+static inline size_t size_class(size_t n) {
+  if (n <= 256) return 256;
+  int hi = 63 - __builtin_clzll((unsigned long long)n);  // floor(log2 n)
+  size_t step = (size_t)1 << (hi > 3 ? hi - 3 : 0);
+  return (n + step - 1) & ~(step - 1);
+}
+void *BlockCache::get(size_t cls) {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = free_.find(cls);
+    if (it != free_.end() && !it->second.empty()) { void *p = it->second.back(); it->second.pop_back(); cached -= cls; return p; }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, cls);
+  if (e != hipSuccess) {  // give everything cached back to the driver and retry once
+    (void)hipGetLastError();
+    trim();
+    e = hipMalloc(&p, cls);
+  }
+  if (e != hipSuccess) throw Error(TFGPU_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(cls) + "): " + hipGetErrorString(e));
+  return p;
+}
+void BlockCache::put(void *p, size_t cls) {
+  std::lock_guard<std::mutex> lk(mu);
+  free_[cls].push_back(p);
+  cached += cls;
+}
+void BlockCache::trim() {
+  std::lock_guard<std::mutex> lk(mu);
+  hipDeviceSynchronize();
+  for (auto &kv : free_) for (void *p : kv.second) hipFree(p);
+  free_.clear();
+  cached = 0;
+}
+
 DevMem::DevMem(size_t n) : bytes(n) {
   Context &c = ctx();
-  size_t a = n ? n : 16;
-  hipError_t e = hipMallocAsync(&p, a, c.stream);
-  if (e != hipSuccess) throw Error(TFGPU_ERR_NOMEM, std::string("hipMallocAsync(") + std::to_string(a) + "): " + hipGetErrorString(e));
+  cls = size_class(n ? n : 16);
+  p = c.blocks.get(cls);
 }
+DevMem::DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n) : p((char *)owner->p + off), bytes(n), cls(0), parent(std::move(owner)) {}
 DevMem::~DevMem() {
-  if (p && g_ctx) hipFreeAsync(p, g_ctx->stream);
+  if (parent) return;  // a view: the owner returns the block
+  if (p && g_ctx) g_ctx->blocks.put(p, cls);
+}
+Buf subbuf(const Buf &owner, size_t off, size_t bytes) { return std::make_shared<DevMem>(owner, off, bytes); }
+
+// Ring: slots are handed out in order and recycled only after a stream sync at wrap-around, so a
+// pending async copy never sees its pinned source (or a read-back its destination) reused.
+void *Context::pin(size_t bytes) {
+  size_t a = (bytes + 63) & ~(size_t)63;
+  if (a > pin_cap) return nullptr;
+  if (pin_off + a > pin_cap) { hipStreamSynchronize(stream); pin_off = 0; }
+  void *r = (char *)pin_base + pin_off;
+  pin_off += a;
+  return r;
 }
 Buf dalloc(size_t bytes) { return std::make_shared<DevMem>(bytes); }
 Buf dalloc_zero(size_t bytes) {
@@ -66,6 +121,26 @@ Buf dalloc_zero(size_t bytes) {
   return b;
 }
 void h2d(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx().stream)); }
+// small host tables (plans, column descriptors): bounce through the pinned arena so the copy is
+// asynchronous and the caller's vector may die right after the call
+void h2d_small(void *dst, const void *src, size_t n) {
+  if (!n) return;
+  void *st = ctx().pin(n);
+  if (!st) { TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, ctx().stream)); TF_HIP(hipStreamSynchronize(ctx().stream)); return; }
+  std::memcpy(st, src, n);
+  TF_HIP(hipMemcpyAsync(dst, st, n, hipMemcpyHostToDevice, ctx().stream));
+}
+const uint32_t *d2h_u32(const void *dev, size_t n) {
+  uint32_t *h = ctx().pin_n<uint32_t>(n ? n : 1);
+  if (!h) throw Error(TFGPU_ERR_NOMEM, "pinned read-back arena exhausted");
+  d2h(h, dev, n * 4);
+  return h;
+}
+Buf upload_small(const void *src, size_t n) {
+  Buf b = dalloc(n + 16);
+  h2d_small(b->p, src, n);
+  return b;
+}
 void d2h(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, ctx().stream)); }
 void d2d(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, ctx().stream)); }
 void sync() { TF_HIP(hipStreamSynchronize(ctx().stream)); }
@@ -114,9 +189,8 @@ int tfgpu_init(int device) {
   c->device = device;
   c->num_cus = prop.multiProcessorCount;
   TF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  TF_HIP(hipDeviceGetDefaultMemPool(&c->pool, device));
-  uint64_t thr = UINT64_MAX;
-  TF_HIP(hipMemPoolSetAttribute(c->pool, hipMemPoolAttrReleaseThreshold, &thr));
+  c->pin_cap = 8u << 20;
+  TF_HIP(hipHostMalloc(&c->pin_base, c->pin_cap, hipHostMallocDefault));
   g_ctx = std::move(c);
   return TFGPU_OK;
   TF_API_END
@@ -128,6 +202,8 @@ int tfgpu_shutdown(void) {
   hipStreamSynchronize(g_ctx->stream);
   for (auto &p : g_ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : g_ctx->free_events) hipEventDestroy(e);
+  g_ctx->blocks.trim();
+  if (g_ctx->pin_base) hipHostFree(g_ctx->pin_base);
   hipStreamDestroy(g_ctx->stream);
   g_ctx.reset();
   return TFGPU_OK;

@@ -430,14 +430,22 @@ __global__ void __launch_bounds__(256) build_selection_kernel(const uint32_t *__
   if (a != b) sel[a] = (int32_t)i;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) gather_fixed_kernel(const T *__restrict__ in, const int32_t *__restrict__ sel, int64_t m, T *__restrict__ out) {
+// All fixed-width arrays of a batch (values, nanos, kind, part_id, src_row) in ONE launch: lane = output
+// row, wave-uniform loop over the arrays, so every store is coalesced and the selection vector is read once.
+struct GFix { const void *in; void *out; int32_t width; int32_t pad; };
+__global__ void __launch_bounds__(256) gather_fixed_all(const GFix *__restrict__ a, int na, const int32_t *__restrict__ sel, int64_t m) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < m) out[k] = in[sel[k]];
-}
-__global__ void __launch_bounds__(256) gather_srcrow_kernel(const int32_t *__restrict__ in, const int32_t *__restrict__ sel, int64_t m, int32_t *__restrict__ out) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < m) out[k] = in ? in[sel[k]] : sel[k];
+  if (k >= m) return;
+  const int32_t s = sel[k];
+  for (int i = 0; i < na; i++) {
+    const GFix g = a[i];
+    switch (g.width) {
+      case 1: ((uint8_t *)g.out)[k] = ((const uint8_t *)g.in)[s]; break;
+      case 2: ((uint16_t *)g.out)[k] = ((const uint16_t *)g.in)[s]; break;
+      case 4: ((uint32_t *)g.out)[k] = g.in ? ((const uint32_t *)g.in)[s] : (uint32_t)s; break;  // in == NULL: identity src_row
+      default: ((uint64_t *)g.out)[k] = ((const uint64_t *)g.in)[s];
+    }
+  }
 }
 __global__ void __launch_bounds__(256) gather_bitmap_kernel(const uint8_t *__restrict__ in, const int32_t *__restrict__ sel, int64_t m, uint8_t *__restrict__ out) {
   // one thread per output byte (8 rows)
@@ -447,21 +455,34 @@ __global__ void __launch_bounds__(256) gather_bitmap_kernel(const uint8_t *__res
   for (int j = 0; j < 8; j++) { int64_t k = b * 8 + j; if (k < m) { int32_t s = sel[k]; v |= ((in[s >> 3] >> (s & 7)) & 1u) << j; } }
   out[b] = (uint8_t)v;
 }
-__global__ void __launch_bounds__(256) gather_len_kernel(const uint32_t *__restrict__ off, const int32_t *__restrict__ sel, int64_t m, uint32_t *__restrict__ len_out) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < m) { int32_t s = sel[k]; len_out[k] = off[s + 1] - off[s]; }
-}
-// One wave per 64 output rows; each row's bytes are copied by the whole wave
-// when long, by one lane when short.
-__global__ void __launch_bounds__(256) gather_bytes_kernel(const uint32_t *__restrict__ in_off, const uint8_t *__restrict__ in_data,
-                                                          const int32_t *__restrict__ sel, const uint32_t *__restrict__ out_off, int64_t m,
-                                                          uint8_t *__restrict__ out_data) {
+// Var-width columns: lengths of all columns in one launch (segmented layout, then one segmented scan),
+// payload bytes of all columns in one launch.
+struct GVar { const uint32_t *in_off; const uint8_t *in_data; uint32_t *out_off; uint8_t *out_data; };
+__global__ void __launch_bounds__(256) gather_len_all(const GVar *__restrict__ v, int nv, const int32_t *__restrict__ sel, int64_t m) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
-  int32_t s = sel[k];
-  uint32_t a = in_off[s], n = in_off[s + 1] - a, o = out_off[k];
-  const uint8_t *src = in_data + a; uint8_t *dst = out_data + o;
-  for (uint32_t i = 0; i < n; i++) dst[i] = src[i];
+  const int32_t s = sel[k];
+  for (int i = 0; i < nv; i++) { const uint32_t *off = v[i].in_off; v[i].out_off[k] = off[s + 1] - off[s]; }
+}
+__global__ void __launch_bounds__(256) gather_bytes_all(const GVar *__restrict__ v, int nv, const int32_t *__restrict__ sel, int64_t m) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const int32_t s = sel[k];
+  for (int i = 0; i < nv; i++) {
+    const GVar g = v[i];
+    const uint32_t a = g.in_off[s], n = g.in_off[s + 1] - a, o = g.out_off[k];
+    const uint8_t *src = g.in_data + a; uint8_t *dst = g.out_data + o;
+    uint32_t j = 0;
+    // 8-byte moves when source and destination are co-aligned, bytes otherwise
+    if (((reinterpret_cast<uintptr_t>(src) ^ reinterpret_cast<uintptr_t>(dst)) & 7) == 0) {
+      while (j < n && (reinterpret_cast<uintptr_t>(dst + j) & 7)) { dst[j] = src[j]; j++; }
+      for (; j + 8 <= n; j += 8) *reinterpret_cast<uint64_t *>(dst + j) = *reinterpret_cast<const uint64_t *>(src + j);
+    }
+    for (; j < n; j++) dst[j] = src[j];
+  }
+}
+__global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int64_t m, int nv, uint32_t *out) {
+  for (int s = threadIdx.x; s < nv; s += blockDim.x) out[s] = lens_all[(int64_t)s * seg_stride + m];
 }
 
 // Gather all columns of `in` through `sel` (m output rows).
@@ -472,41 +493,48 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   const int32_t *sp = ptr<int32_t>(sel);
   unsigned g = grid_for(m, 256);
   KernelTimer t("compact_gather");
+  std::vector<GFix> fx; std::vector<GVar> vr; std::vector<size_t> var_cols;
+  int nvar = 0;
+  for (auto &c : in.cols) if (repr_is_var(c.repr)) nvar++;
+  const int64_t seg_stride = ((m + 1 + 3) / 4) * 4;
+  Buf lens_all = nvar ? dalloc((size_t)nvar * (size_t)seg_stride * 4 + 16) : nullptr;
   for (auto &c : in.cols) {
     DColumn o;
     o.name = c.name; o.dtype = c.dtype; o.repr = c.repr;
     if (repr_is_var(c.repr)) {
-      o.offsets = dalloc((size_t)(m + 1) * 4);
-      if (m) gather_len_kernel<<<g, 256, 0, st>>>(ptr<uint32_t>(c.offsets), sp, m, ptr<uint32_t>(o.offsets));
-      exclusive_scan_u32(ptr<uint32_t>(o.offsets), ptr<uint32_t>(o.offsets), m, true);
-      // total is only known on the device; size the payload by the source (upper bound)
-      o.data = dalloc(c.data_len);
-      if (m) gather_bytes_kernel<<<g, 256, 0, st>>>(ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.data), sp, ptr<uint32_t>(o.offsets), m, ptr<uint8_t>(o.data));
-      o.data_len = c.data_len;  // fixed up below after one read-back
+      size_t si = vr.size();
+      o.offsets = subbuf(lens_all, si * (size_t)seg_stride * 4, (size_t)(m + 1) * 4);
+      o.data = dalloc(c.data_len + 8);  // the source size bounds the kept payload; exact length read back below
+      o.data_len = c.data_len;
+      vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.data), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data)});
+      var_cols.push_back(out->cols.size());
     } else {
       size_t w = repr_width(c.repr);
       o.values = dalloc((size_t)m * w);
-      if (m) switch (w) {
-        case 1: gather_fixed_kernel<uint8_t><<<g, 256, 0, st>>>(ptr<uint8_t>(c.values), sp, m, ptr<uint8_t>(o.values)); break;
-        case 2: gather_fixed_kernel<uint16_t><<<g, 256, 0, st>>>(ptr<uint16_t>(c.values), sp, m, ptr<uint16_t>(o.values)); break;
-        case 4: gather_fixed_kernel<uint32_t><<<g, 256, 0, st>>>(ptr<uint32_t>(c.values), sp, m, ptr<uint32_t>(o.values)); break;
-        case 8: gather_fixed_kernel<uint64_t><<<g, 256, 0, st>>>(ptr<uint64_t>(c.values), sp, m, ptr<uint64_t>(o.values)); break;
-      }
-      if (c.nanos) { o.nanos = dalloc((size_t)m * 4); if (m) gather_fixed_kernel<uint32_t><<<g, 256, 0, st>>>(ptr<uint32_t>(c.nanos), sp, m, ptr<uint32_t>(o.nanos)); }
+      fx.push_back(GFix{c.values->p, o.values->p, (int32_t)w, 0});
+      if (c.nanos) { o.nanos = dalloc((size_t)m * 4); fx.push_back(GFix{c.nanos->p, o.nanos->p, 4, 0}); }
     }
     if (c.validity) { o.validity = dalloc((size_t)(m + 7) / 8 + 1); if (m) gather_bitmap_kernel<<<grid_for((m + 7) / 8, 256), 256, 0, st>>>(ptr<uint8_t>(c.validity), sp, m, ptr<uint8_t>(o.validity)); }
     out->cols.push_back(std::move(o));
   }
-  if (in.kind) { out->kind = dalloc((size_t)m); if (m) gather_fixed_kernel<uint8_t><<<g, 256, 0, st>>>(ptr<uint8_t>(in.kind), sp, m, ptr<uint8_t>(out->kind)); }
-  if (in.part_id) { out->part_id = dalloc((size_t)m * 4); if (m) gather_fixed_kernel<uint32_t><<<g, 256, 0, st>>>(ptr<uint32_t>(in.part_id), sp, m, ptr<uint32_t>(out->part_id)); }
+  if (in.kind) { out->kind = dalloc((size_t)m); fx.push_back(GFix{in.kind->p, out->kind->p, 1, 0}); }
+  if (in.part_id) { out->part_id = dalloc((size_t)m * 4); fx.push_back(GFix{in.part_id->p, out->part_id->p, 4, 0}); }
   out->src_row = dalloc((size_t)m * 4);
-  if (m) gather_srcrow_kernel<<<g, 256, 0, st>>>(ptr<int32_t>(in.src_row), sp, m, ptr<int32_t>(out->src_row));
-  // one read-back for all var-width totals
-  std::vector<uint32_t> totals(out->cols.size(), 0);
-  bool any = false;
-  for (size_t i = 0; i < out->cols.size(); i++)
-    if (repr_is_var(out->cols[i].repr)) { d2h(&totals[i], ptr<uint32_t>(out->cols[i].offsets) + m, 4); any = true; }
-  if (any) { sync(); for (size_t i = 0; i < out->cols.size(); i++) if (repr_is_var(out->cols[i].repr)) out->cols[i].data_len = totals[i]; }
+  if (in.src_row) fx.push_back(GFix{in.src_row->p, out->src_row->p, 4, 0});
+  else fx.push_back(GFix{nullptr, out->src_row->p, 4, 0});
+  Buf bfx = upload_small(fx.data(), fx.size() * sizeof(GFix));
+  if (m) gather_fixed_all<<<g, 256, 0, st>>>(ptr<GFix>(bfx), (int)fx.size(), sp, m);
+  if (nvar) {
+    Buf bvr = upload_small(vr.data(), vr.size() * sizeof(GVar));
+    if (m) gather_len_all<<<g, 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
+    exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), m, nvar, seg_stride);
+    if (m) gather_bytes_all<<<g, 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
+    Buf tot = dalloc((size_t)nvar * 4);
+    collect_totals<<<1, 64, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, m, nvar, ptr<uint32_t>(tot));
+    const uint32_t *h = d2h_u32(tot->p, (size_t)nvar);
+    sync();
+    for (int i = 0; i < nvar; i++) out->cols[var_cols[(size_t)i]].data_len = h[i];
+  }
   return out;
 }
 
@@ -514,9 +542,9 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
 static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /* n+1 u32 */) {
   int64_t n = in.nrows;
   exclusive_scan_u32(ptr<uint32_t>(keep), ptr<uint32_t>(keep), n, true);
-  uint32_t m = 0;
-  d2h(&m, ptr<uint32_t>(keep) + n, 4);
+  const uint32_t *hm = d2h_u32(ptr<uint32_t>(keep) + n);
   sync();
+  const uint32_t m = *hm;
   if ((int64_t)m == n) return shallow_copy(in);
   Buf sel = dalloc((size_t)m * 4 + 4);
   if (n) build_selection_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint32_t>(keep), n, ptr<int32_t>(sel));
@@ -569,7 +597,7 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_rows(const tfgpu_plan &p, cons
   }
   std::vector<DCol> cols;
   for (auto &c : in.cols) cols.push_back(dcol_of(c));
-  auto up = [&](const void *src, size_t bytes) { Buf b = dalloc(bytes + 16); if (bytes) h2d(b->p, src, bytes); return b; };
+  auto up = [&](const void *src, size_t bytes) { return upload_small(src, bytes); };
   Buf bcols = up(cols.data(), cols.size() * sizeof(DCol)), bterms = up(terms.data(), terms.size() * sizeof(DTerm));
   Buf bexpr = up(expr_start.data(), expr_start.size() * 4), bints = up(ints.data(), ints.size() * 8), bfl = up(floats.data(), floats.size() * 8);
   Buf bsoff = up(soff.data(), soff.size() * 4), bsd = up(sdata.data(), sdata.size());
@@ -587,10 +615,9 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_rows(const tfgpu_plan &p, cons
     KernelTimer t("filter_rows_eval");
     if (n) filter_eval_kernel<<<grid_for(n, 256), 256, 0, st>>>(fp);
   }
-  uint32_t hn = 0;
-  d2h(&hn, nerr->p, 4);
+  const uint32_t *hn = d2h_u32(nerr->p);
   auto out = compact(in, keep);  // syncs
-  if (hn) collect_row_errors(err, eterm, n, ax);
+  if (*hn) collect_row_errors(err, eterm, n, ax);
   return out;
 }
 
@@ -645,10 +672,9 @@ static DColumn column_to_string(const DColumn &c, int64_t n, bool to_bytes, int 
   uint64_t cap = repr_is_var(c.repr) ? c.data_len + (uint64_t)n * 5 : (uint64_t)n * (uint64_t)max_len_hint;
   o.data = dalloc(cap);
   if (n) tostring_write_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data));
-  uint32_t tot = 0;
-  d2h(&tot, ptr<uint32_t>(o.offsets) + n, 4);
+  const uint32_t *tot = d2h_u32(ptr<uint32_t>(o.offsets) + n);
   sync();
-  o.data_len = tot;
+  o.data_len = *tot;
   return o;
 }
 
@@ -740,13 +766,11 @@ static std::unique_ptr<tfgpu_dbatch> apply_sharder(const tfgpu_plan &p, const tf
     cols.push_back(dcol_of(c));
   }
   (void)schema_order;
-  Buf bc = dalloc(cols.size() * sizeof(DCol) + 16);
-  h2d(bc->p, cols.data(), cols.size() * sizeof(DCol));
+  Buf bc = upload_small(cols.data(), cols.size() * sizeof(DCol));
   out->part_id = dalloc((size_t)n * 4 + 4);
   SharderParams sp{ptr<DCol>(bc), (int32_t)cols.size(), n, (uint32_t)p.shards, ptr<uint32_t>(out->part_id)};
   KernelTimer t("sharder_crc32");
   if (n) sharder_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(sp);
-  sync();  // cols vector must outlive the H2D copy
   return out;
 }
 
