@@ -392,6 +392,17 @@ struct CsvCol {
   uint32_t *fstart;   // string columns: absolute start of the content | bit31 = has doubled quotes
 };
 
+// Compact column descriptor of the tile path, staged in LDS in (kind, width) order.
+struct TCol {
+  void *p0;        // fixed-width: values        | text: lens
+  void *p1;        // time: nanos                | text: fstart
+  int16_t field;   // CSV field index, <0 = DefaultValue
+  uint8_t kind;    // CsvKind
+  uint8_t width;
+  int32_t ci;      // index in the schema (error reporting, precedence)
+};
+static_assert(sizeof(TCol) == 24, "TCol is staged as three 8-byte words");
+
 struct CsvParams {
   const uint8_t *data;
   uint64_t len;
@@ -403,7 +414,8 @@ struct CsvParams {
   const int32_t *field_first;  // first column index per CSV field, -1 = unused
   int32_t nfields_used;        // max mapped field index + 1
   int32_t has_unmapped;        // some field index < nfields_used feeds no column
-  const int32_t *col_order;    // columns sorted by (kind, width): neighbouring lanes run one code path
+  const TCol *tcols;           // columns sorted by (kind, width): neighbouring lanes run one code path
+  int32_t null_checks;         // strings_can_be_null || quoted_strings_can_be_null
   uint8_t *err;                // per row tfgpu_rowerr
   int32_t *err_col;
   uint32_t *nerr;
@@ -415,6 +427,7 @@ struct CsvParams {
   uint32_t *slow_row;          //   line index (before skip_rows)
   uint32_t *slow_end;          //   position of the terminating '\n'
   uint32_t *last_end;          // max over lines of (position of '\n') + 1
+  int32_t ablate;              // TFGPU_CSV_ABLATE=n (profiling only): leave the kernel after phase n; results are NOT valid
 };
 
 __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v) {
@@ -592,19 +605,20 @@ __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
 
 // lines listed by the tile path: only the '\n' position is known; walk back to the line start
 __global__ void __launch_bounds__(64) csv_parse_listed(CsvParams p) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = *p.slow_n;
-  if ((uint64_t)blockIdx.x * blockDim.x >= n) return;  // whole wave idle
-  const int64_t line = i < n ? (int64_t)p.slow_row[i] : -1;
-  const bool have_row = i < n && line >= p.skip_rows;
-  uint64_t end = 0, pos = 0;
-  if (have_row) {
-    end = (uint64_t)p.slow_end[i] + 1;
-    pos = end - 1;
-    MemBytes back(p.data);
-    while (pos > 0 && back.at(pos - 1) != '\n') pos--;
+  for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n; base += (uint64_t)gridDim.x * 64) {  // wave-uniform loop
+    const uint64_t i = base + threadIdx.x;
+    const int64_t line = i < n ? (int64_t)p.slow_row[i] : -1;
+    const bool have_row = i < n && line >= p.skip_rows;
+    uint64_t end = 0, pos = 0;
+    if (have_row) {
+      end = (uint64_t)p.slow_end[i] + 1;
+      pos = end - 1;
+      MemBytes back(p.data);
+      while (pos > 0 && back.at(pos - 1) != '\n') pos--;
+    }
+    parse_line_hbm(p, have_row, line - p.skip_rows, pos, end);
   }
-  parse_line_hbm(p, have_row, line - p.skip_rows, pos, end);
 }
 
 // ---------------------------------------------------------------------------
@@ -624,20 +638,99 @@ static constexpr int CT_BYTES = CT_T + CT_SPILL;
 static constexpr int CT_CPT = CT_BYTES / 16 / CT_THREADS;  // 16-byte chunks per thread (blocked)
 static constexpr int CT_FCAP = 4096;            // field ends indexed per pass
 static constexpr int CT_RCAP = 256;             // lines per pass
+static constexpr int CT_LCOLS = 192;            // column descriptors staged in LDS (more: read from HBM)
 static_assert(CT_CPT * 16 * CT_THREADS == CT_BYTES, "tile must divide evenly");
 static_assert(CT_BYTES <= 32768, "positions are 15-bit");
+
+// ---- fast-path helpers of the tile kernel -----------------------------------
+// Is the rune that STARTS at tile position `a` (first byte c) possibly a unicode.IsSpace rune / the quote?
+__device__ __forceinline__ bool starts_plain(const uint8_t *sb, uint32_t a, uint32_t end, uint32_t c, uint32_t quote) {
+  if (c < 0x80) return c > 0x20 && c != 0x7F && c != quote;
+  if (c != 0xC2 && c != 0xE1 && c != 0xE2 && c != 0xE3) return true;
+  const uint32_t d = a + 1 < end ? sb[a + 1] : 0u, e = a + 2 < end ? sb[a + 2] : 0u;
+  if (c == 0xC2) return !(d == 0x85 || d == 0xA0);
+  if (c == 0xE1) return !(d == 0x9A && e == 0x80);
+  if (c == 0xE3) return !(d == 0x80 && e == 0x80);
+  return !((d == 0x80 && ((e >= 0x80 && e <= 0x8A) || e == 0xA8 || e == 0xA9 || e == 0xAF)) || (d == 0x81 && e == 0x9F));
+}
+// Is the rune that ENDS at tile position b-1 (last byte c) possibly a space / the quote?
+__device__ __forceinline__ bool ends_plain(const uint8_t *sb, uint32_t a, uint32_t b, uint32_t c, uint32_t quote) {
+  if (c < 0x80) return c > 0x20 && c != 0x7F && c != quote;
+  if (c >= 0xC0) return true;  // a lead byte at the end: malformed, never a space
+  const uint32_t d = b - a >= 2 ? sb[b - 2] : 0u, e = b - a >= 3 ? sb[b - 3] : 0u;
+  if (d == 0xC2) return !(c == 0x85 || c == 0xA0);
+  if (e == 0xE1) return !(d == 0x9A && c == 0x80);
+  if (e == 0xE3) return !(d == 0x80 && c == 0x80);
+  if (e == 0xE2) return !((d == 0x80 && ((c >= 0x80 && c <= 0x8A) || c == 0xA8 || c == 0xA9 || c == 0xAF)) || (d == 0x81 && c == 0x9F));
+  return true;
+}
+// swapToSingleQuotes (reader.go:307-320) replaces non-overlapping "" left to right: per run of L quote
+// characters that is floor(L/2) pairs.  Walks only the set bits of the tile's quote bitmap in [lo, hi).
+__device__ __forceinline__ uint32_t count_quote_pairs(const uint32_t *qmask, uint32_t lo, uint32_t hi) {
+  if (lo >= hi) return 0;
+  uint32_t pairs = 0, prev = 0xFFFFFFF0u;
+  bool open = false;
+  const uint32_t w0 = lo >> 5, w1 = (hi - 1) >> 5;
+  for (uint32_t w = w0; w <= w1; w++) {
+    uint32_t m = qmask[w];
+    if (w == w0) m &= ~0u << (lo & 31);
+    if (w == w1) m &= ~0u >> (31 - ((hi - 1) & 31));
+    while (m) {
+      const uint32_t pos = (w << 5) + (uint32_t)(__ffs((int)m) - 1);
+      m &= m - 1;
+      if (open && pos == prev + 1) { pairs++; open = false; } else open = true;
+      prev = pos;
+    }
+  }
+  return pairs;
+}
+// n decimal digits starting at byte i0 of the 24-byte little-endian window (b0,b1,b2); false if a non-digit shows up
+__device__ __forceinline__ bool digits_u64(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t i0, uint32_t n, uint64_t *out) {
+  bool ok = true;
+  uint32_t lo = 0;  // first 9 digits accumulate in 32 bits
+  uint64_t v = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t d = ((uint32_t)(b0 >> (8 * i)) & 0xFFu) - '0';
+    if ((uint32_t)i >= i0 && (uint32_t)i < n) { ok = ok && d <= 9u; lo = lo * 10 + d; }
+  }
+  v = lo;
+  if (__any(n > 8)) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint32_t d = ((uint32_t)(b1 >> (8 * i)) & 0xFFu) - '0';
+      if ((uint32_t)(8 + i) < n) { ok = ok && d <= 9u; v = v * 10 + d; }
+    }
+    if (__any(n > 16)) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t d = ((uint32_t)(b2 >> (8 * i)) & 0xFFu) - '0';
+        if ((uint32_t)(16 + i) < n) { ok = ok && d <= 9u; v = v * 10 + d; }
+      }
+    }
+  }
+  *out = v;
+  return ok;
+}
+__device__ __forceinline__ uint32_t two_digits(uint64_t w, int byte, bool *ok) {
+  const uint32_t a = ((uint32_t)(w >> (8 * byte)) & 0xFFu) - '0', b = ((uint32_t)(w >> (8 * byte + 8)) & 0xFFu) - '0';
+  *ok = *ok && a <= 9u && b <= 9u;
+  return a * 10 + b;
+}
 
 // quote-state functions on one bit: bit0 = f(0), bit1 = f(1); identity = 0b10
 __device__ __forceinline__ uint32_t qf_compose(uint32_t first, uint32_t then) {
   return ((then >> (first & 1)) & 1u) | (((then >> ((first >> 1) & 1)) & 1u) << 1);
 }
 
-__global__ void __launch_bounds__(CT_THREADS) csv_parse_tiles(CsvParams p) {
+__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
   __shared__ __attribute__((aligned(16))) uint8_t sb[CT_BYTES + 16];
   __shared__ uint16_t fpos[CT_FCAP];   // field-end position | bit15 = it is the line's '\n'
   __shared__ uint16_t rowend[CT_RCAP]; // ordinal of each line's last field
-  __shared__ uint32_t e_read[CT_RCAP], e_miss[CT_RCAP], e_cast[CT_RCAP];
+  __shared__ uint32_t slowf[CT_RCAP];  // line needs the per-row path (anything but a plain cell in it)
   __shared__ uint32_t qmask[CT_BYTES / 32];  // bitmap of quote characters
+  __shared__ uint64_t rinfo[CT_RCAP];        // per line: first ordinal - kb | fields << 16 | first byte << 32
+  __shared__ uint64_t tcol_lds[CT_LCOLS * 3];
   __shared__ uint32_t wtmp[CT_THREADS / 64];
   __shared__ uint32_t wmax[CT_THREADS / 64];
 
@@ -662,7 +755,10 @@ __global__ void __launch_bounds__(CT_THREADS) csv_parse_tiles(CsvParams p) {
     if (gp >= 0 && (uint64_t)gp < p.len) v = *reinterpret_cast<const uint4 *>(p.data + gp);  // buffer is zero-padded past len
     *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
   }
+  const bool cols_in_lds = p.ncols <= CT_LCOLS;
+  if (cols_in_lds) for (int i = tid; i < p.ncols * 3; i += CT_THREADS) tcol_lds[i] = reinterpret_cast<const uint64_t *>(p.tcols)[i];
   __syncthreads();
+  if (p.ablate == 1) return;
 
   // ---- classify: thread t walks bytes [96t, 96t+96) under both entry states ----
   const int base_chunk = tid * CT_CPT;
@@ -695,6 +791,7 @@ __global__ void __launch_bounds__(CT_THREADS) csv_parse_tiles(CsvParams p) {
       if (nl && cpos < CT_SPILL) last_lb_nl = cpos + 31 - __clz((int)nl);
     }
   }
+  if (p.ablate == 2) { if (st == 77u + fe01[0] + nlm[1]) p.err[0] = 1; return; }
   // ---- block scan of the quote functions + max of the look-behind '\n' ----
   uint32_t inc = st;
 #pragma unroll
@@ -794,8 +891,9 @@ __global__ void __launch_bounds__(CT_THREADS) csv_parse_tiles(CsvParams p) {
         }
       }
     }
-    for (uint32_t i = tid; i < nr; i += CT_THREADS) { e_read[i] = 0xFFFFFFFFu; e_miss[i] = 0xFFFFFFFFu; e_cast[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = tid; i < nr; i += CT_THREADS) slowf[i] = 0;
     __syncthreads();
+    if (p.ablate == 3) { if (fpos[tid] == 0xFFFF && rowend[0] == 0xFFFF) p.err[0] = 1; return; }
 
     uint32_t next_bstart;
     if (skip_first) {
@@ -819,70 +917,154 @@ __global__ void __launch_bounds__(CT_THREADS) csv_parse_tiles(CsvParams p) {
       __syncthreads();
       next_bstart = (uint32_t)fpos[0] + 1;
     } else {
-      // ---- cells: item = column * nr + line, lines fastest ----
-      const uint32_t total = (uint32_t)p.ncols * nr;
-      LdsBytes rd(sb);
-      for (uint32_t it = tid; it < total; it += CT_THREADS) {
-        const uint32_t oi = it / nr, jj = it - oi * nr;
-        const uint32_t ci = (uint32_t)p.col_order[oi];
-        const int64_t r = (int64_t)line0 + jb + jj - p.skip_rows;
-        if (r < 0) continue;  // header lines
-        const CsvCol &c = p.cols[ci];
+      // ---- per-line info, once per pass ----
+      for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
         const uint32_t k0 = jj ? (uint32_t)rowend[jj - 1] + 1 : kb, ke = rowend[jj];
         const uint32_t row_start = jj ? (uint32_t)(fpos[k0 - 1 - kb] & 0x7FFFu) + 1 : bstart;
         const uint32_t nl_pos = fpos[ke - kb] & 0x7FFFu;
         const uint32_t nf = (nl_pos == row_start) ? 0u : ke - k0 + 1;  // "\n" alone: ReadLine returns (nil, nil)
-        if (c.field < 0) { store_default(c, r); continue; }
-        if ((uint32_t)c.field >= nf) {
-          if (o.include_missing) store_default(c, r); else atomicMin(&e_miss[jj], ci);
+        rinfo[jj] = (uint64_t)(k0 - kb) | ((uint64_t)nf << 16) | ((uint64_t)row_start << 32);
+      }
+      __syncthreads();
+      // ---- cells: item = column * nr + line, lines fastest.  Only PLAIN cells are decided here:
+      //      nothing to trim, no quote characters inside, canonical decimal / date shapes.  Any other
+      //      cell flags its line, and flagged lines are re-read whole by the per-row path, which carries
+      //      the complete reference logic (and every error case). ----
+      const uint32_t total = (uint32_t)p.ncols * nr;
+      const uint32_t inv_nr = nr > 1 ? 0xFFFFFFFFu / nr + 1 : 0;  // it / nr == umulhi(it, inv_nr) while it * nr < 2^32 (it < ncols * 256)
+      for (uint32_t it = tid; it < total; it += CT_THREADS) {
+        uint32_t oi = nr > 1 ? __umulhi(it, inv_nr) : it;
+        uint32_t jj = it - oi * nr;
+        if (jj >= nr) { oi++; jj -= nr; }  // guard the rounding of the reciprocal
+        const int64_t r = (int64_t)line0 + jb + jj - p.skip_rows;
+        if (r < 0) continue;  // header lines
+        TCol tc;
+        if (cols_in_lds) { const uint64_t *q = tcol_lds + oi * 3; tc.p0 = (void *)q[0]; tc.p1 = (void *)q[1]; uint64_t m = q[2]; tc.field = (int16_t)m; tc.kind = (uint8_t)(m >> 16); tc.width = (uint8_t)(m >> 24); tc.ci = (int32_t)(m >> 32); }
+        else tc = p.tcols[oi];
+        const uint64_t ri = rinfo[jj];
+        const uint32_t k0r = (uint32_t)ri & 0xFFFFu, nf = (uint32_t)(ri >> 16) & 0xFFFFu, row_start = (uint32_t)(ri >> 32);
+        if (tc.field < 0 || (uint32_t)tc.field >= nf) {
+          if (tc.field < 0 || o.include_missing) {
+            CsvCol c{}; c.kind = tc.kind; c.width = tc.width; c.values = tc.p0; c.nanos = (int32_t *)tc.p1; c.lens = (uint32_t *)tc.p0; c.fstart = (uint32_t *)tc.p1;
+            store_default(c, r);
+          } else slowf[jj] = 1;  // missing cell: an error of this line
           continue;
         }
-        const uint32_t k = k0 + (uint32_t)c.field;
-        uint32_t fs = c.field ? (uint32_t)(fpos[k - 1 - kb] & 0x7FFFu) + 1 : row_start;
-        const uint32_t fend = fpos[k - kb] & 0x7FFFu;
+        const uint32_t kr = k0r + (uint32_t)tc.field;
+        uint32_t fs = tc.field ? (uint32_t)(fpos[kr - 1] & 0x7FFFu) + 1 : row_start;
+        const uint32_t fend = fpos[kr] & 0x7FFFu;
         if (nf == 1) fs = row_start + 1;  // no delimiter in the line: line[lastDelimPosition+1:] drops byte 0 (reader.go:263)
-        LField fv{&rd, fs, fend - fs};
-        uint32_t a = 0, b = 0, npairs = 0;
-        int e = sanitize(o, fv, a, b, npairs, qmask, fs);
-        if (e) { atomicMin(&e_read[jj], ((uint32_t)c.field << 8) | (uint32_t)e); continue; }
-        e = parse_cell(o, c, r, fv, a, b, npairs, (uint64_t)(g0 + fs));
-        if (e) atomicMin(&e_cast[jj], (ci << 8) | (uint32_t)e);
+        const uint32_t n = fend - fs;
+        if (p.ablate == 6) { if (n == 0x7FFF) p.err[0] = 1; continue; }
+        bool done = false;
+        if (n == 0) {
+          if (tc.kind == CK_STR) { ((uint32_t *)tc.p0)[r] = 0; ((uint32_t *)tc.p1)[r] = (uint32_t)(g0 + fs); done = true; }
+        } else {
+          // bytes [fs, fs+24) little-endian; the tile is padded, so the aligned words past the field exist
+          const uint32_t sh = (fs & 7u) * 8;
+          const uint64_t *w = reinterpret_cast<const uint64_t *>(sb + (fs & ~7u));
+          const uint64_t w0 = w[0], w1 = w[1];
+          const uint64_t b0 = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+          const uint32_t c_first = (uint32_t)b0 & 0xFFu, c_last = sb[fend - 1];
+          if (tc.kind == CK_STR) {
+            // nothing to trim: either enclosed in quotes ("…": unquote) or plain at both ends
+            uint32_t a = fs, b = fend;
+            bool ok = false;
+            if (c_first == o.quote && c_last == o.quote && n >= 2) { a++; b--; ok = true; }
+            else ok = c_first != o.quote && c_last != o.quote && starts_plain(sb, fs, fend, c_first, o.quote) && ends_plain(sb, fs, fend, c_last, o.quote);
+            if (ok) {
+              const uint32_t npairs = any_quote(qmask, a, b) ? count_quote_pairs(qmask, a, b) : 0u;
+              if (!(npairs && !o.double_quote)) {  // errDoubleQuotesDisabled: per-row path
+                ((uint32_t *)tc.p0)[r] = (b - a) - npairs;
+                ((uint32_t *)tc.p1)[r] = (uint32_t)(g0 + a) | (npairs ? 0x80000000u : 0u);
+                done = true;
+              }
+            }
+          } else if (tc.kind == CK_INT || tc.kind == CK_UINT) {
+            // [+-]?(0|[1-9][0-9]*) — base prefixes, '_', ".00", spaces, quotes: per-row path
+            if (n <= 20) {
+              const bool neg = c_first == '-';
+              const uint32_t i0 = (c_first == '-' || c_first == '+') ? 1u : 0u;
+              const uint32_t nd = n - i0;
+              bool ok = nd >= 1 && nd <= 19 && !(nd > 1 && ((uint32_t)(b0 >> (8 * i0)) & 0xFFu) == '0');
+              if (tc.kind == CK_UINT && tc.width == 8 && i0) ok = false;  // ParseUint takes no sign
+              uint64_t b1 = 0, b2 = 0;
+              if (__any(n > 8)) { const uint64_t w2 = w[2]; b1 = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1; if (__any(n > 16)) { const uint64_t w3 = w[3]; b2 = sh ? (w2 >> sh) | (w3 << (64 - sh)) : w2; } }
+              uint64_t v;
+              ok = digits_u64(b0, b1, b2, i0, n, &v) && ok;
+              const int bits = tc.width * 8;
+              if (tc.kind == CK_INT) ok = ok && v <= (neg ? (1ull << (bits - 1)) : (1ull << (bits - 1)) - 1);
+              else ok = ok && !(neg && v != 0) && (tc.width == 8 || v <= (1ull << bits) - 1);
+              if (ok && p.ablate != 5) {
+                const int64_t sv = neg ? (int64_t)(0 - v) : (int64_t)v;
+                switch (tc.width) {
+                  case 1: ((int8_t *)tc.p0)[r] = (int8_t)sv; break;
+                  case 2: ((int16_t *)tc.p0)[r] = (int16_t)sv; break;
+                  case 4: ((int32_t *)tc.p0)[r] = (int32_t)sv; break;
+                  default: ((int64_t *)tc.p0)[r] = sv;
+                }
+              }
+              done = ok;
+            }
+          } else if (tc.kind == CK_DATE || tc.kind == CK_TIMESTAMP) {
+            // 2006-01-02 | 2006-01-02[ T]15:04:05 (cast.StringToDate layouts); a timestamp column also takes
+            // plain decimal seconds (parseTimestampValue, reader_csv.go:419-426)
+            const uint64_t w2 = w[2], w3 = w[3];
+            const uint64_t b1 = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1, b2 = sh ? (w2 >> sh) | (w3 << (64 - sh)) : w2;
+            const uint32_t i0 = (c_first == '-' || c_first == '+') ? 1u : 0u;
+            uint64_t v = 0;
+            if (tc.kind == CK_TIMESTAMP && n - i0 >= 1 && n - i0 <= 18 && digits_u64(b0, b1, b2, i0, n, &v)) {
+              // ParseInt(s, 10, 64): leading zeros are fine in base 10
+              ((int64_t *)tc.p0)[r] = c_first == '-' ? -(int64_t)v : (int64_t)v; ((int32_t *)tc.p1)[r] = 0; done = true;
+            } else if (n == 10 || n == 19) {
+              bool ok = true;
+              const uint32_t y = two_digits(b0, 0, &ok) * 100 + two_digits(b0, 2, &ok);
+              const uint32_t mo = two_digits(b0, 5, &ok), d = two_digits(b1, 0, &ok);
+              ok = ok && (((uint32_t)(b0 >> 32) & 0xFFu) == '-') && (((uint32_t)(b0 >> 56) & 0xFFu) == '-');
+              uint32_t h = 0, mi = 0, se = 0;
+              if (n == 19) {
+                const uint32_t sep = (uint32_t)(b1 >> 16) & 0xFFu;
+                ok = ok && (sep == ' ' || sep == 'T') && (((uint32_t)(b1 >> 40) & 0xFFu) == ':') && (((uint32_t)b2 & 0xFFu) == ':');
+                h = two_digits(b1, 3, &ok); mi = two_digits(b1, 6, &ok); se = two_digits(b2, 1, &ok);
+              }
+              ok = ok && mo >= 1 && mo <= 12 && d >= 1 && d <= (uint32_t)dev::days_in_month((int)mo, (int64_t)y) && h <= 23 && mi <= 59 && se <= 59;
+              if (ok) {
+                ((int64_t *)tc.p0)[r] = dev::days_from_civil((int64_t)y, (int)mo, (int)d) * 86400 + h * 3600 + mi * 60 + se;
+                ((int32_t *)tc.p1)[r] = 0;
+                done = true;
+              }
+            }
+          }
+        }
+        if (!done) slowf[jj] = 1;
       }
-      // ---- sanitizeElement also runs on fields no column reads ----
+      // ---- sanitizeElement also runs on fields no column reads: anything but a plain field flags the line ----
       if (p.has_unmapped || (kend - kb + 1) != nr * (uint32_t)p.nfields_used) {
         for (uint32_t kk = tid; kk <= kend - kb; kk += CT_THREADS) {
           uint32_t lo = 0, hi = nr - 1;  // line of ordinal kb+kk
           while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)rowend[mid] < kb + kk) lo = mid + 1; else hi = mid; }
           const uint32_t jj = lo;
           if ((int64_t)line0 + jb + jj - p.skip_rows < 0) continue;
-          const uint32_t k0 = jj ? (uint32_t)rowend[jj - 1] + 1 : kb, ke = rowend[jj];
-          const uint32_t f = kb + kk - k0;
-          if (f < (uint32_t)p.nfields_used && p.field_first[f] >= 0) continue;  // done by its column
-          const uint32_t row_start = jj ? (uint32_t)(fpos[k0 - 1 - kb] & 0x7FFFu) + 1 : bstart;
-          const uint32_t nl_pos = fpos[ke - kb] & 0x7FFFu;
-          if (nl_pos == row_start) continue;
+          const uint64_t ri = rinfo[jj];
+          const uint32_t k0r = (uint32_t)ri & 0xFFFFu, nf = (uint32_t)(ri >> 16) & 0xFFFFu, row_start = (uint32_t)(ri >> 32);
+          const uint32_t f = kk - k0r;
+          if (nf == 0 || (f < (uint32_t)p.nfields_used && p.field_first[f] >= 0)) continue;  // nil line / judged by its column
           uint32_t fs = f ? (uint32_t)(fpos[kk - 1] & 0x7FFFu) + 1 : row_start;
-          if (ke == k0) fs = row_start + 1;
-          LField fv{&rd, fs, (uint32_t)(fpos[kk] & 0x7FFFu) - fs};
-          uint32_t a, b, npairs;
-          int e = sanitize(o, fv, a, b, npairs, qmask, fs);
-          if (e) atomicMin(&e_read[jj], (f << 8) | (uint32_t)e);
+          if (nf == 1) fs = row_start + 1;
+          const uint32_t fend = fpos[kk] & 0x7FFFu;
+          if (fend > fs && !(starts_plain(sb, fs, fend, sb[fs], o.quote) && ends_plain(sb, fs, fend, sb[fend - 1], o.quote) && !any_quote(qmask, fs, fend))) slowf[jj] = 1;
         }
       }
       __syncthreads();
-      // ---- per line: ReadLine error > missing cell > strictify error ----
+      // ---- per line: clean, or handed to the per-row path ----
       for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
         const int64_t r = (int64_t)line0 + jb + jj - p.skip_rows;
         if (r < 0) continue;
-        int err = 0, err_col = -1;
-        if (e_read[jj] != 0xFFFFFFFFu) {
-          err = (int)(e_read[jj] & 0xFFu);
-          uint32_t f = e_read[jj] >> 8;
-          err_col = f < (uint32_t)p.nfields_used ? p.field_first[f] : -1;
-        } else if (e_miss[jj] != 0xFFFFFFFFu) { err = TFGPU_ROW_MISSING_CELL; err_col = (int)e_miss[jj]; }
-        else if (e_cast[jj] != 0xFFFFFFFFu) { err = (int)(e_cast[jj] & 0xFFu); err_col = (int)(e_cast[jj] >> 8); }
-        p.err[r] = (uint8_t)err;
-        if (err) { p.err_col[r] = err_col; atomicAdd(p.nerr, 1u); }
+        if (slowf[jj] || p.null_checks) {
+          const uint32_t slot = atomicAdd(p.slow_n, 1u);
+          p.slow_row[slot] = line0 + jb + jj;
+          p.slow_end[slot] = (uint32_t)(g0 + (fpos[rowend[jj] - kb] & 0x7FFFu));
+        } else p.err[r] = 0;
       }
       next_bstart = (uint32_t)(fpos[kend - kb] & 0x7FFFu) + 1;
     }
@@ -1102,8 +1284,9 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   Buf err = dalloc((size_t)nrows + 16), err_col = dalloc((size_t)nrows * 4 + 16), nerr = dalloc_zero(4);
 
   // lines the tile path hands to the per-row path (at most one per tile per pass) + consumed offset
-  const int64_t slow_cap = 5 * ntiles + 8;  // <= 1 long first line + CT_BYTES/CT_FCAP over-wide lines per tile
-  Buf slow = dalloc_zero((size_t)(2 * slow_cap + 2) * 4);
+  const int64_t slow_cap = (int64_t)nlines + 5 * ntiles + 8;  // every line at most once, plus long / over-wide ones per tile
+  Buf slow = dalloc((size_t)(2 * slow_cap + 2) * 4);
+  TF_HIP(hipMemsetAsync(slow->p, 0, 8, st));
   CsvParams pp;
   std::memset(&pp, 0, sizeof pp);
   pp.data = data; pp.len = len; pp.row_start = rs; pp.nrows = nrows;
@@ -1117,6 +1300,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.o.list_off = ptr<uint32_t>(bloff); pp.o.list_data = ptr<uint8_t>(bldata);
   pp.cols = ptr<CsvCol>(bcols); pp.ncols = ncols; pp.field_first = ptr<int32_t>(bff); pp.nfields_used = max_field + 1;
   pp.err = ptr<uint8_t>(err); pp.err_col = ptr<int32_t>(err_col); pp.nerr = ptr<uint32_t>(nerr);
+  static const int ablate = [] { const char *e = std::getenv("TFGPU_CSV_ABLATE"); return e ? std::atoi(e) : 0; }();
+  pp.ablate = ablate;
   pp.has_unmapped = 0;
   for (int f = 0; f <= max_field; f++) if (field_first[(size_t)f] < 0) pp.has_unmapped = 1;
   std::vector<int32_t> order((size_t)ncols);
@@ -1125,8 +1310,18 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     const CsvCol &a = cols[(size_t)x], &b = cols[(size_t)y];
     return a.kind != b.kind ? a.kind < b.kind : a.width < b.width;
   });
-  Buf border = up(order.data(), order.size() * 4);
-  pp.col_order = ptr<int32_t>(border);
+  std::vector<TCol> tcols((size_t)ncols);
+  for (int i = 0; i < ncols; i++) {
+    const CsvCol &c = cols[(size_t)order[(size_t)i]];
+    TCol &t = tcols[(size_t)i];
+    const bool text = c.kind == CK_STR || c.kind == CK_JSONNUM;
+    t.p0 = text ? (void *)c.lens : c.values; t.p1 = text ? (void *)c.fstart : (void *)c.nanos;
+    if (c.field > 32767) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: ColSchema.Path above 32767");
+    t.field = (int16_t)c.field; t.kind = (uint8_t)c.kind; t.width = (uint8_t)c.width; t.ci = order[(size_t)i];
+  }
+  Buf btcols = up(tcols.data(), tcols.size() * sizeof(TCol));
+  pp.tcols = ptr<TCol>(btcols);
+  pp.null_checks = (opts->strings_can_be_null || opts->quoted_strings_can_be_null) ? 1 : 0;
 
   // QuoteChar == 0 and the data holds '"' → errQuotingDisabled for that line (reader.go:182-184):
   // the state machine cannot see it (quote disabled), so treat '"' as an error marker via the quote path
@@ -1139,7 +1334,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     // header lines are parsed by nobody: err[] of the data rows is written by exactly one of the two kernels
     const int64_t per_xcd = (ntiles + 7) / 8;
     { KernelTimer t("csv_parse_tiles"); csv_parse_tiles<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
-    { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<blocks_for(slow_cap, 64), 64, 0, st>>>(pp); }
+    { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 8192), 64, 0, st>>>(pp); }
   }
   if (nrows && nstr) {
     csv_zero_err_lens<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint8_t>(err), nrows, ptr<CsvCol>(bcols), ncols);
