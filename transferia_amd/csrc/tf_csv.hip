@@ -1120,6 +1120,75 @@ __global__ void __launch_bounds__(256) csv_copy_strings(CopyParams p) {
   }
 }
 
+// Tile version of csv_copy_strings: the workgroup that owns a tile's lines stages the same bytes in LDS
+// (coalesced) and moves every string cell of those lines to its final Arrow position; item = column * lines
+// + line, so neighbouring lanes write neighbouring destination bytes.
+struct CopyTileParams {
+  const uint8_t *data; uint64_t len;
+  const uint32_t *tile_base; int64_t ntiles; int64_t skip_rows;
+  const CopyCol *cols; int32_t ncols; uint8_t quote;
+};
+__global__ void __launch_bounds__(CT_THREADS) csv_copy_tiles(CopyTileParams p) {
+  __shared__ __attribute__((aligned(16))) uint8_t sb[CT_BYTES + 16];
+  const int64_t per_xcd = (p.ntiles + 7) / 8;
+  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const uint32_t line0 = p.tile_base[tile];
+  const uint32_t nlines = p.tile_base[tile + 1] - line0;
+  if (nlines == 0) return;
+  const int tid = threadIdx.x;
+  const int64_t g0 = tile * CT_T - CT_SPILL;
+#pragma unroll
+  for (int it = 0; it < CT_CPT; it++) {
+    int chunk = it * CT_THREADS + tid;
+    int64_t gp = g0 + (int64_t)chunk * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gp >= 0 && (uint64_t)gp < p.len) v = *reinterpret_cast<const uint4 *>(p.data + gp);
+    *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
+  }
+  __syncthreads();
+  const uint32_t total = (uint32_t)p.ncols * nlines;
+  for (uint32_t it = tid; it < total; it += CT_THREADS) {
+    const uint32_t ci = it / nlines, jj = it - ci * nlines;
+    const int64_t r = (int64_t)line0 + jj - p.skip_rows;
+    if (r < 0) continue;
+    const CopyCol c = p.cols[ci];
+    const uint32_t o0 = c.offsets[r], n = c.offsets[r + 1] - o0;
+    if (!n) continue;
+    const uint32_t fsv = c.fstart[r];
+    uint8_t *dst = c.out + o0;
+    if ((fsv & 0x7FFFFFFFu) == 0x7FFFFFFFu) { if (c.is_jsonnum) dst[0] = '0'; continue; }  // DefaultValue of a double is json.Number("0")
+    const int64_t loc = (int64_t)(fsv & 0x7FFFFFFFu) - g0;
+    if (loc < 0) {  // a line longer than the window (parsed by the per-row path): bytes straight from HBM
+      MemBytes src(p.data);
+      uint64_t sp = fsv & 0x7FFFFFFFu;
+      if (fsv & 0x80000000u) { uint32_t w = 0; while (w < n) { uint32_t ch = src.at(sp); if (ch == p.quote && src.at(sp + 1) == p.quote) { dst[w++] = '"'; sp += 2; } else { dst[w++] = (uint8_t)ch; sp++; } } }
+      else for (uint32_t i = 0; i < n; i++) dst[i] = (uint8_t)src.at(sp + i);
+      continue;
+    }
+    uint32_t sp = (uint32_t)loc;
+    if (fsv & 0x80000000u) {  // collapse doubled quotes: "" → "
+      uint32_t w = 0;
+      while (w < n) { const uint32_t ch = sb[sp]; if (ch == p.quote && sb[sp + 1] == p.quote) { dst[w++] = '"'; sp += 2; } else { dst[w++] = (uint8_t)ch; sp++; } }
+      continue;
+    }
+    uint32_t i = 0;
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 7)) { dst[i] = sb[sp + i]; i++; }
+    if (i + 8 <= n) {
+      // destination is 8-byte aligned from here: funnel two aligned LDS words into each stored word
+      const uint32_t s0 = sp + i, sh = (s0 & 7u) * 8;
+      const uint64_t *w = reinterpret_cast<const uint64_t *>(sb + (s0 & ~7u));
+      uint64_t lo = *w++;
+      for (; i + 8 <= n; i += 8) {
+        const uint64_t hi = *w++;
+        *reinterpret_cast<uint64_t *>(dst + i) = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+        lo = hi;
+      }
+    }
+    for (; i < n; i++) dst[i] = sb[sp + i];
+  }
+}
+
 // one contiguous summary for a single read-back: [nerr, consumed, total bytes of each string column]
 __global__ void csv_collect(const uint32_t *nerr, const uint32_t *last, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, uint32_t *out) {
   int i = threadIdx.x;
@@ -1360,10 +1429,15 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     cc.push_back(CopyCol{ptr<uint32_t>(d.offsets), cols[(size_t)str_col_index[(size_t)s]].fstart, ptr<uint8_t>(d.data), d.repr == TFGPU_R_JSONNUM ? 1 : 0});
   }
   Buf bcc = up(cc.data(), cc.size() * sizeof(CopyCol));
-  if (nrows && nstr) {
+  if (nrows && nstr && rowpath) {
     CopyParams cp{data, nrows, ptr<CopyCol>(bcc), nstr, opts->quote_char};
     KernelTimer t("csv_copy_strings");
     csv_copy_strings<<<blocks_for(nrows, 256), 256, 0, st>>>(cp);
+  } else if (nrows && nstr) {
+    CopyTileParams cp{data, len, ptr<uint32_t>(tile_counts), ntiles, skip, ptr<CopyCol>(bcc), nstr, opts->quote_char};
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    KernelTimer t("csv_copy_tiles");
+    csv_copy_tiles<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(cp);
   }
 
   std::unique_ptr<tfgpu_dbatch> result;

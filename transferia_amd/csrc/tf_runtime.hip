@@ -94,7 +94,7 @@ void BlockCache::trim() {
 
 DevMem::DevMem(size_t n) : bytes(n) {
   Context &c = ctx();
-  cls = size_class(n ? n : 16);
+  cls = size_class(n + 16);  // 16 bytes of slack: kernels read whole aligned words around payloads
   p = c.blocks.get(cls);
 }
 DevMem::DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n) : p((char *)owner->p + off), bytes(n), cls(0), parent(std::move(owner)) {}

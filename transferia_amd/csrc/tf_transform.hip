@@ -464,22 +464,31 @@ __global__ void __launch_bounds__(256) gather_len_all(const GVar *__restrict__ v
   const int32_t s = sel[k];
   for (int i = 0; i < nv; i++) { const uint32_t *off = v[i].in_off; v[i].out_off[k] = off[s + 1] - off[s]; }
 }
+// blockIdx.y = column: a wave moves 64 consecutive kept rows of ONE column, so its lanes see similar lengths
+// (whole waves skip the mostly-empty columns) and write one contiguous destination range.  Bodies move as
+// aligned 8-byte stores fed by two aligned 8-byte loads funnelled to the destination's alignment.
 __global__ void __launch_bounds__(256) gather_bytes_all(const GVar *__restrict__ v, int nv, const int32_t *__restrict__ sel, int64_t m) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
+  const GVar g = v[blockIdx.y];
   const int32_t s = sel[k];
-  for (int i = 0; i < nv; i++) {
-    const GVar g = v[i];
-    const uint32_t a = g.in_off[s], n = g.in_off[s + 1] - a, o = g.out_off[k];
-    const uint8_t *src = g.in_data + a; uint8_t *dst = g.out_data + o;
-    uint32_t j = 0;
-    // 8-byte moves when source and destination are co-aligned, bytes otherwise
-    if (((reinterpret_cast<uintptr_t>(src) ^ reinterpret_cast<uintptr_t>(dst)) & 7) == 0) {
-      while (j < n && (reinterpret_cast<uintptr_t>(dst + j) & 7)) { dst[j] = src[j]; j++; }
-      for (; j + 8 <= n; j += 8) *reinterpret_cast<uint64_t *>(dst + j) = *reinterpret_cast<const uint64_t *>(src + j);
+  const uint32_t a = g.in_off[s], n = g.in_off[s + 1] - a;
+  if (!n) return;
+  const uint8_t *src = g.in_data + a; uint8_t *dst = g.out_data + g.out_off[k];
+  uint32_t j = 0;
+  while (j < n && (reinterpret_cast<uintptr_t>(dst + j) & 7)) { dst[j] = src[j]; j++; }
+  if (j + 8 <= n) {
+    const uintptr_t sa = reinterpret_cast<uintptr_t>(src + j);
+    const uint32_t sh = (uint32_t)(sa & 7) * 8;
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(sa & ~(uintptr_t)7);  // every payload block has >= 16 bytes of slack
+    uint64_t lo = *w++;
+    for (; j + 8 <= n; j += 8) {
+      const uint64_t hi = *w++;
+      *reinterpret_cast<uint64_t *>(dst + j) = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+      lo = hi;
     }
-    for (; j < n; j++) dst[j] = src[j];
   }
+  for (; j < n; j++) dst[j] = src[j];
 }
 __global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int64_t m, int nv, uint32_t *out) {
   for (int s = threadIdx.x; s < nv; s += blockDim.x) out[s] = lens_all[(int64_t)s * seg_stride + m];
@@ -528,7 +537,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
     Buf bvr = upload_small(vr.data(), vr.size() * sizeof(GVar));
     if (m) gather_len_all<<<g, 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), m, nvar, seg_stride);
-    if (m) gather_bytes_all<<<g, 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
+    if (m) gather_bytes_all<<<dim3(g, (unsigned)nvar), 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
     Buf tot = dalloc((size_t)nvar * 4);
     collect_totals<<<1, 64, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, m, nvar, ptr<uint32_t>(tot));
     const uint32_t *h = d2h_u32(tot->p, (size_t)nvar);
