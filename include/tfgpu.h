@@ -257,7 +257,29 @@ enum {
   TFGPU_FMT_JSON = 2,             /* pkg/serializer/json.go (sorted keys)     */
   TFGPU_FMT_CSV = 3               /* pkg/serializer/csv.go                    */
 };
+/* Target column of the ClickHouse sink — the fields of columntypes.TypeDescription
+ * (pkg/providers/clickhouse/columntypes) that marshalValue / marshalTime read
+ * (httpuploader/marshal.go:65-80, 140-301).                                 */
+enum {
+  TFGPU_CH_STRING = 1u,     /* colType.IsString                               */
+  TFGPU_CH_DATE = 2u,       /* colType.IsDate                                 */
+  TFGPU_CH_DATETIME64 = 4u, /* colType.IsDateTime64 (+ precision)             */
+  TFGPU_CH_DECIMAL = 8u,    /* colType.IsDecimal                              */
+  TFGPU_CH_ARRAY = 16u      /* colType.IsArray                                */
+};
+typedef struct tfgpu_serialize_options {
+  int32_t add_closing_newline; /* JSONSerializerConfig.AddClosingNewLine (json.go:13-17);
+                                  batch separator "\n" when 0 (batch_factory.go:36-39)    */
+  int32_t any_as_string;       /* AnyAsString                                              */
+  int32_t ncols;               /* CH: entries below, one per batch column; 0 = derive the
+                                  target type from the DataType (clickhouse/typesystem.md) */
+  const uint32_t *ch_flags;    /* TFGPU_CH_*                                               */
+  const uint8_t *ch_precision; /* DateTime64 precision 0..9                                */
+} tfgpu_serialize_options;
+/* batchSerializer.Serialize (pkg/serializer/batch.go:73-117) / one MarshalCItoJSON per row
+ * (marshal.go:82-125).  tfgpu_serialize == tfgpu_serialize_ex with NULL options.          */
 int tfgpu_serialize(int format, const tfgpu_dbatch *b, tfgpu_dbuf **out);
+int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out);
 int tfgpu_dbuf_size(const tfgpu_dbuf *b, uint64_t *out);
 void *tfgpu_dbuf_ptr(const tfgpu_dbuf *b); /* device pointer */
 int tfgpu_dbuf_download(const tfgpu_dbuf *b, void *host, uint64_t cap);

@@ -169,6 +169,7 @@ ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema,
 /* ---- serializers ---- */
 /* format = TFGPU_FMT_*; returns malloc'd bytes */
 char *ora_serialize(int format, const ora_batch *b, uint64_t *len);
+char *ora_serialize_ex(int format, const ora_batch *b, const tfgpu_serialize_options *opts, uint64_t *len);
 
 #ifdef __cplusplus
 }

@@ -1,13 +1,340 @@
 /*
  * oracle/ora_serialize.c — CPU restatement of the sink-side marshalling
  * (SURVEY.md §8a rows a20, a21).  TEST INFRASTRUCTURE ONLY (see ora.h).
+ *
+ *   TFGPU_FMT_CH_JSON_EACH_ROW  pkg/providers/clickhouse/httpuploader/marshal.go:82-419
+ *   TFGPU_FMT_JSON              pkg/serializer/json.go:29-83 + encoding/json (sorted map keys,
+ *                               SetEscapeHTML(false)), batch.go:206-219 (separator "\n")
+ *   TFGPU_FMT_CSV               pkg/serializer/csv.go:22-74, csv_format.go:32-127 + encoding/csv
+ *
+ * Values are the Go dynamic types a strictified ChangeItem carries.  A value form whose
+ * encoding is not restated here makes the whole call return NULL (the HIP side answers
+ * TFGPU_ERR_UNSUPPORTED for the same inputs).
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "ora.h"
 
-char *ora_serialize(int format, const ora_batch *b, uint64_t *len) {
-  (void)format; (void)b;
-  *len = 0;
-  return NULL; /* filled in by the serializer milestone */
+typedef struct { char *p; size_t n, cap; int unsupported; } sbuf;
+static void sb_put(sbuf *b, const void *s, size_t n) {
+  if (b->n + n + 1 > b->cap) { b->cap = (b->n + n + 1) * 2; b->p = (char *)realloc(b->p, b->cap); }
+  memcpy(b->p + b->n, s, n); b->n += n;
 }
+static void sb_c(sbuf *b, char c) { sb_put(b, &c, 1); }
+static void sb_s(sbuf *b, const char *s) { sb_put(b, s, strlen(s)); }
+
+static const char HEXC[] = "0123456789abcdef";
+
+/* writeQuoted (marshal.go:377-419): only ", \ and control bytes are escaped, raw bytes kept */
+static void ch_write_quoted(sbuf *b, const char *s, size_t n) {
+  sb_c(b, '"');
+  for (size_t i = 0; i < n; i++) {
+    unsigned char c = (unsigned char)s[i];
+    if (c >= 0x20 && c != '"' && c != '\\') { sb_c(b, (char)c); continue; }
+    switch (c) {
+      case '"': sb_s(b, "\\\""); break; case '\\': sb_s(b, "\\\\"); break; case '\n': sb_s(b, "\\n"); break;
+      case '\r': sb_s(b, "\\r"); break; case '\t': sb_s(b, "\\t"); break; case '\f': sb_s(b, "\\f"); break; case '\b': sb_s(b, "\\b"); break;
+      default: sb_s(b, "\\u00"); sb_c(b, HEXC[c >> 4]); sb_c(b, HEXC[c & 15]);
+    }
+  }
+  sb_c(b, '"');
+}
+
+/* encoding/json appendString with escapeHTML=false (encode.go): ", \, control bytes, invalid
+ * UTF-8 -> �, U+2028/U+2029 always escaped */
+static void json_string(sbuf *b, const char *s, size_t n, int escape_html) {
+  sb_c(b, '"');
+  size_t i = 0;
+  while (i < n) {
+    unsigned char c = (unsigned char)s[i];
+    if (c < 0x80) {
+      if (c >= 0x20 && c != '"' && c != '\\' && !(escape_html && (c == '<' || c == '>' || c == '&'))) { sb_c(b, (char)c); i++; continue; }
+      switch (c) {
+        case '"': sb_s(b, "\\\""); break; case '\\': sb_s(b, "\\\\"); break; case '\b': sb_s(b, "\\b"); break; case '\f': sb_s(b, "\\f"); break;
+        case '\n': sb_s(b, "\\n"); break; case '\r': sb_s(b, "\\r"); break; case '\t': sb_s(b, "\\t"); break;
+        default: sb_s(b, "\\u00"); sb_c(b, HEXC[c >> 4]); sb_c(b, HEXC[c & 15]);
+      }
+      i++; continue;
+    }
+    /* utf8.DecodeRuneInString */
+    size_t need = 0; unsigned cp = 0; unsigned char lo = 0x80, hi = 0xBF;
+    if (c >= 0xC2 && c <= 0xDF) { need = 1; cp = c & 0x1F; }
+    else if (c >= 0xE0 && c <= 0xEF) { need = 2; cp = c & 0x0F; if (c == 0xE0) lo = 0xA0; if (c == 0xED) hi = 0x9F; }
+    else if (c >= 0xF0 && c <= 0xF4) { need = 3; cp = c & 0x07; if (c == 0xF0) lo = 0x90; if (c == 0xF4) hi = 0x8F; }
+    int ok = need > 0 && i + need < n;  /* all continuation bytes exist */
+    if (ok) {
+      for (size_t k = 1; k <= need; k++) {
+        unsigned char d = (unsigned char)s[i + k];
+        unsigned char l = k == 1 ? lo : 0x80, h = k == 1 ? hi : 0xBF;
+        if (d < l || d > h) { ok = 0; break; }
+        cp = (cp << 6) | (d & 0x3F);
+      }
+    }
+    if (!ok) { sb_s(b, "\\ufffd"); i++; continue; }
+    if (cp == 0x2028 || cp == 0x2029) { sb_s(b, cp == 0x2028 ? "\\u2028" : "\\u2029"); i += need + 1; continue; }
+    sb_put(b, s + i, need + 1); i += need + 1;
+  }
+  sb_c(b, '"');
+}
+
+static void base64_std(sbuf *b, const unsigned char *s, size_t n) {
+  static const char T[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  size_t i = 0;
+  for (; i + 3 <= n; i += 3) { unsigned v = (s[i] << 16) | (s[i + 1] << 8) | s[i + 2]; sb_c(b, T[v >> 18]); sb_c(b, T[(v >> 12) & 63]); sb_c(b, T[(v >> 6) & 63]); sb_c(b, T[v & 63]); }
+  if (n - i == 1) { unsigned v = s[i] << 16; sb_c(b, T[v >> 18]); sb_c(b, T[(v >> 12) & 63]); sb_s(b, "=="); }
+  else if (n - i == 2) { unsigned v = (s[i] << 16) | (s[i + 1] << 8); sb_c(b, T[v >> 18]); sb_c(b, T[(v >> 12) & 63]); sb_c(b, T[(v >> 6) & 63]); sb_c(b, '='); }
+}
+
+static int is_int_kind(int k) { return k >= OV_I8 && k <= OV_U64; }
+static void put_int(sbuf *b, const ora_value *v) {
+  char t[32]; size_t n = (v->kind >= OV_U8 && v->kind <= OV_U64) ? ora_fmt_uint(t, v->v.u) : ora_fmt_int(t, v->v.i);
+  sb_put(b, t, n);
+}
+static void put_float_f(sbuf *b, const ora_value *v) { /* strconv.FormatFloat(f, 'f', -1, bits) */
+  char t[400]; size_t n = v->kind == OV_F32 ? ora_fmt_float(t, (double)v->v.f32, 'f', 32) : ora_fmt_float(t, v->v.f64, 'f', 64);
+  sb_put(b, t, n);
+}
+
+/* strconv.ParseFloat range error for a JSON number literal: +1 / -1 when it overflows to ±Inf */
+static int number_overflows(const char *s, size_t n) {
+  double d; int rc = ora_parse_float(s, n, 64, &d);
+  if (rc == 2) return d < 0 ? -1 : 1;
+  return 0;
+}
+
+static uint32_t default_ch_flags(int dtype, uint8_t *prec) {
+  *prec = 0;
+  switch (dtype) { /* pkg/providers/clickhouse/typesystem.md */
+    case TFGPU_T_BYTES: case TFGPU_T_UTF8: case TFGPU_T_ANY: return TFGPU_CH_STRING;
+    case TFGPU_T_DATE: return TFGPU_CH_DATE;
+    case TFGPU_T_TIMESTAMP: *prec = 9; return TFGPU_CH_DATETIME64;
+    default: return 0;
+  }
+}
+
+static int64_t pow10i(int k) { int64_t r = 1; while (k-- > 0) r *= 10; return r; }
+
+/* marshalValue (marshal.go:140-253) for one non-nil value; returns 1 if the column must be skipped */
+static int ch_value(sbuf *b, const ora_value *v, int dtype, uint32_t fl, uint8_t prec, int any_as_string) {
+  char t[128]; size_t n;
+  if ((fl & TFGPU_CH_DECIMAL) && (v->kind == OV_STRING || v->kind == OV_BYTES)) { sb_put(b, v->s, v->slen); return 0; }
+  switch (dtype) {
+    case TFGPU_T_INT8: case TFGPU_T_INT16: case TFGPU_T_INT32: case TFGPU_T_INT64: case TFGPU_T_UINT8: case TFGPU_T_UINT16:
+    case TFGPU_T_UINT32: case TFGPU_T_UINT64: case TFGPU_T_FLOAT32: case TFGPU_T_FLOAT64: case TFGPU_T_INTERVAL: {
+      /* marshalNumericValue :257-301 */
+      int handled = 1;
+      sbuf tmp = {0};
+      if (is_int_kind(v->kind)) put_int(&tmp, v);
+      else if (v->kind == OV_F32 || v->kind == OV_F64) put_float_f(&tmp, v);
+      else if (v->kind == OV_JSONNUM) {
+        int o = number_overflows(v->s, v->slen);
+        if (o > 0) sb_s(&tmp, "inf"); else if (o < 0) sb_s(&tmp, "-inf"); else sb_put(&tmp, v->s, v->slen);
+      } else handled = 0;
+      if (handled) {
+        if (fl & TFGPU_CH_STRING) sb_c(b, '"');
+        sb_put(b, tmp.p ? tmp.p : "", tmp.n);
+        if (fl & TFGPU_CH_STRING) sb_c(b, '"');
+        free(tmp.p);
+        return 0;
+      }
+      free(tmp.p);
+      break;
+    }
+    case TFGPU_T_BYTES: case TFGPU_T_UTF8:
+      if (v->kind == OV_STRING) { ch_write_quoted(b, v->s, v->slen); return 0; }
+      if (v->kind == OV_BYTES) {
+        if (fl & TFGPU_CH_ARRAY) { sb_c(b, '['); for (size_t i = 0; i < v->slen; i++) { if (i) sb_c(b, ','); n = ora_fmt_uint(t, (unsigned char)v->s[i]); sb_put(b, t, n); } sb_c(b, ']'); }
+        else ch_write_quoted(b, v->s, v->slen);
+        return 0;
+      }
+      break;
+    case TFGPU_T_BOOLEAN:
+      if (v->kind == OV_BOOL) { sb_s(b, v->v.b ? "true" : "false"); return 0; }
+      break;
+    case TFGPU_T_DATE: case TFGPU_T_DATETIME: case TFGPU_T_TIMESTAMP:
+      if (v->kind == OV_TIME) { /* marshalTime :65-80 */
+        if (fl & TFGPU_CH_STRING) { sb_c(b, '"'); n = ora_fmt_time_string(t, v->v.t.sec, v->v.t.nsec); sb_put(b, t, n); sb_c(b, '"'); }
+        else if (fl & TFGPU_CH_DATETIME64) {
+          int64_t full = v->v.t.sec * 1000000000LL + v->v.t.nsec;
+          if (prec > 0 && prec < 9) full = full / pow10i(9 - prec);  /* Go integer division truncates toward zero */
+          n = ora_fmt_int(t, full); sb_put(b, t, n);
+        } else if (fl & TFGPU_CH_DATE) { sb_c(b, '"'); n = ora_fmt_date(t, v->v.t.sec); sb_put(b, t, n); sb_c(b, '"'); }
+        else { n = ora_fmt_int(t, v->v.t.sec); sb_put(b, t, n); }
+        return 0;
+      }
+      break;
+    default: break;
+  }
+  /* marshalGeneric :318-359 */
+  if (v->kind == OV_STRING) { ch_write_quoted(b, v->s, v->slen); return 0; }
+  if (v->kind == OV_BYTES) {
+    if (fl & TFGPU_CH_ARRAY) { sb_c(b, '['); for (size_t i = 0; i < v->slen; i++) { if (i) sb_c(b, ','); n = ora_fmt_uint(t, (unsigned char)v->s[i]); sb_put(b, t, n); } sb_c(b, ']'); }
+    else ch_write_quoted(b, v->s, v->slen);
+    return 0;
+  }
+  /* json.Marshal(v) of the remaining Go types */
+  sbuf r = {0};
+  if (is_int_kind(v->kind)) put_int(&r, v);
+  else if (v->kind == OV_BOOL) sb_s(&r, v->v.b ? "true" : "false");
+  else if (v->kind == OV_JSONNUM) { if (v->slen) sb_put(&r, v->s, v->slen); else sb_c(&r, '0'); }
+  else if (v->kind == OV_JSON) sb_put(&r, v->s, v->slen);
+  else if (v->kind == OV_DURATION) { n = ora_fmt_int(t, v->v.i); sb_put(&r, t, n); }
+  else { free(r.p); b->unsupported = 1; return 0; } /* floats ('g'-style encoding/json), time under a foreign DataType */
+  if (r.n == 4 && !memcmp(r.p, "null", 4)) { free(r.p); return 1; }
+  if (dtype != TFGPU_T_ANY || any_as_string || (fl & TFGPU_CH_STRING)) {
+    /* DOUBLE_MARSHAL: json.Marshal(string(r)) — goccy/go-json escapes HTML like encoding/json */
+    json_string(b, r.p, r.n, 1);
+  } else sb_put(b, r.p, r.n);
+  free(r.p);
+  return 0;
+}
+
+static int dtype_of(const ora_item *it, int i) {
+  /* MarshalCItoJSON looks the ColSchema up by column NAME (gfMap, marshal.go:92-98) */
+  const char *name = it->names && i < it->names->n ? it->names->names[i] : NULL;
+  if (it->schema && name) for (int k = 0; k < it->schema->ncols; k++) if (!strcmp(it->schema->cols[k].name, name)) return it->schema->cols[k].dtype;
+  return TFGPU_T_INVALID;
+}
+static int dtype_by_index(const ora_item *it, int i) {
+  /* the generic serializers pair values with columns[i] (json.go:35-39, csv.go:28-34) */
+  if (it->schema && i < it->schema->ncols) return it->schema->cols[i].dtype;
+  return TFGPU_T_INVALID;
+}
+
+static void ch_row(sbuf *b, const ora_item *it, const tfgpu_serialize_options *o) {
+  sb_c(b, '{');
+  int has = 0;
+  for (int i = 0; i < it->nvalues; i++) {
+    const ora_value *v = &it->values[i];
+    if (v->kind == OV_NIL) continue;
+    const char *name = it->names->names[i];
+    size_t mark = b->n;
+    sb_c(b, '"'); sb_s(b, name); sb_c(b, '"'); sb_c(b, ':');  /* writeColName: the name is NOT escaped */
+    int dt = dtype_of(it, i);
+    uint8_t prec = 0; uint32_t fl;
+    if (o && o->ncols > i && o->ch_flags) { fl = o->ch_flags[i]; prec = o->ch_precision ? o->ch_precision[i] : 0; }
+    else fl = default_ch_flags(dt, &prec);
+    if (ch_value(b, v, dt, fl, prec, o ? o->any_as_string : 0)) { b->n = mark; continue; }
+    sb_c(b, ','); has = 1;
+  }
+  if (has) b->n--;
+  sb_c(b, '}'); sb_c(b, '\n');
+}
+
+/* ---- encoding/json of one value of a strictified row ---- */
+static void json_value(sbuf *b, const ora_value *v, int dtype, int any_as_string) {
+  char t[128]; size_t n;
+  switch (v->kind) {
+    case OV_NIL: sb_s(b, "null"); return;
+    case OV_BOOL: sb_s(b, v->v.b ? "true" : "false"); return;
+    case OV_STRING: json_string(b, v->s, v->slen, 0); return;
+    case OV_BYTES: sb_c(b, '"'); base64_std(b, (const unsigned char *)v->s, v->slen); sb_c(b, '"'); return;
+    case OV_JSONNUM: if (v->slen) sb_put(b, v->s, v->slen); else sb_c(b, '0'); return;
+    case OV_TIME: sb_c(b, '"'); n = ora_fmt_rfc3339nano(t, v->v.t.sec, v->v.t.nsec); sb_put(b, t, n); sb_c(b, '"'); return; /* Time.MarshalJSON */
+    case OV_DURATION: n = ora_fmt_int(t, v->v.i); sb_put(b, t, n); return;
+    case OV_JSON:
+      if (dtype == TFGPU_T_ANY && any_as_string) json_string(b, v->s, v->slen, 0); /* toJsonValue: string(valueData) */
+      else sb_put(b, v->s, v->slen);
+      return;
+    default: break;
+  }
+  if (is_int_kind(v->kind)) { put_int(b, v); return; }
+  b->unsupported = 1; /* float32 / float64: encoding/json's ES6-style float text is not restated */
+}
+
+typedef struct { const char *name; int idx; } keyref;
+static int key_cmp(const void *a, const void *b) { return strcmp(((const keyref *)a)->name, ((const keyref *)b)->name); }
+
+static void json_row(sbuf *b, const ora_item *it, const tfgpu_serialize_options *o) {
+  int n = it->nvalues;
+  keyref *k = (keyref *)malloc(sizeof(keyref) * (size_t)(n ? n : 1));
+  for (int i = 0; i < n; i++) { k[i].name = it->names->names[i]; k[i].idx = i; }
+  qsort(k, (size_t)n, sizeof(keyref), key_cmp);  /* map keys are emitted sorted */
+  sb_c(b, '{');
+  for (int j = 0; j < n; j++) {
+    if (j) sb_c(b, ',');
+    json_string(b, k[j].name, strlen(k[j].name), 0);
+    sb_c(b, ':');
+    json_value(b, &it->values[k[j].idx], dtype_by_index(it, k[j].idx), o ? o->any_as_string : 0);
+  }
+  sb_c(b, '}');
+  free(k);
+}
+
+/* encoding/csv Writer.fieldNeedsQuotes + quoted write (Comma ',', UseCRLF false) */
+static void csv_field(sbuf *b, const char *s, size_t n) {
+  int need = 0;
+  if (n == 0) need = 0;
+  else if (n == 2 && s[0] == '\\' && s[1] == '.') need = 1;
+  else {
+    for (size_t i = 0; i < n; i++) if (s[i] == ',' || s[i] == '"' || s[i] == '\r' || s[i] == '\n') { need = 1; break; }
+    if (!need) { /* unicode.IsSpace(first rune) */
+      unsigned char c = (unsigned char)s[0];
+      if (c == ' ' || (c >= 9 && c <= 13)) need = 1;
+      else if (c == 0xC2 && n >= 2 && ((unsigned char)s[1] == 0x85 || (unsigned char)s[1] == 0xA0)) need = 1;
+      else if (n >= 3 && (c == 0xE1 || c == 0xE2 || c == 0xE3)) {
+        unsigned char d = (unsigned char)s[1], e = (unsigned char)s[2];
+        if (c == 0xE1 && d == 0x9A && e == 0x80) need = 1;
+        if (c == 0xE3 && d == 0x80 && e == 0x80) need = 1;
+        if (c == 0xE2 && ((d == 0x80 && ((e >= 0x80 && e <= 0x8A) || e == 0xA8 || e == 0xA9 || e == 0xAF)) || (d == 0x81 && e == 0x9F))) need = 1;
+      }
+    }
+  }
+  if (!need) { sb_put(b, s, n); return; }
+  sb_c(b, '"');
+  for (size_t i = 0; i < n; i++) { if (s[i] == '"') sb_s(b, "\"\""); else sb_c(b, s[i]); }
+  sb_c(b, '"');
+}
+
+static void csv_row(sbuf *b, const ora_item *it) {
+  for (int i = 0; i < it->nvalues; i++) {
+    if (i) sb_c(b, ',');
+    const ora_value *v = &it->values[i];
+    int dt = dtype_by_index(it, i);
+    sbuf c = {0}; char t[128]; size_t n;
+    if (v->kind == OV_NIL) { /* "" */ }
+    else if (dt == TFGPU_T_BYTES) { if (v->kind == OV_BYTES) base64_std(&c, (const unsigned char *)v->s, v->slen); else b->unsupported = 1; }
+    else if (dt == TFGPU_T_ANY) { /* json.Marshal(value) */
+      if (v->kind == OV_JSON || v->kind == OV_JSONNUM) sb_put(&c, v->s, v->slen);
+      else if (is_int_kind(v->kind)) put_int(&c, v);
+      else if (v->kind == OV_BOOL) sb_s(&c, v->v.b ? "true" : "false");
+      else if (v->kind == OV_STRING) json_string(&c, v->s, v->slen, 1);
+      else b->unsupported = 1;
+    } else switch (v->kind) { /* castx.ToStringE caste.go:57-106 */
+      case OV_STRING: case OV_BYTES: case OV_JSONNUM: sb_put(&c, v->s, v->slen); break;
+      case OV_BOOL: sb_s(&c, v->v.b ? "true" : "false"); break;
+      case OV_F32: case OV_F64: put_float_f(&c, v); break;
+      case OV_TIME: n = ora_fmt_time_string(t, v->v.t.sec, v->v.t.nsec); sb_put(&c, t, n); break; /* fmt.Stringer */
+      case OV_DURATION: n = ora_fmt_duration(t, v->v.i); sb_put(&c, t, n); break;
+      case OV_JSON: b->unsupported = 1; break; /* maps/slices under a non-any type: cast.ToStringE error */
+      default: if (is_int_kind(v->kind)) put_int(&c, v); else b->unsupported = 1;
+    }
+    csv_field(b, c.p ? c.p : "", c.n);
+    free(c.p);
+  }
+  sb_c(b, '\n');
+}
+
+char *ora_serialize_ex(int format, const ora_batch *bt, const tfgpu_serialize_options *o, uint64_t *len) {
+  sbuf b = {0};
+  b.p = (char *)malloc(64); b.cap = 64;
+  for (int64_t r = 0; r < bt->n; r++) {
+    const ora_item *it = &bt->items[r];
+    if (it->kind == TFGPU_K_OTHER) continue; /* !IsRowEvent */
+    switch (format) {
+      case TFGPU_FMT_CH_JSON_EACH_ROW: ch_row(&b, it, o); break;
+      case TFGPU_FMT_JSON:
+        json_row(&b, it, o);
+        if (o && o->add_closing_newline) sb_c(&b, '\n');   /* per item, json.go:66-72; batch separator is nil then */
+        else if (r + 1 < bt->n) sb_c(&b, '\n');            /* separator between items, none after the last */
+        break;
+      case TFGPU_FMT_CSV: csv_row(&b, it); break;
+      default: b.unsupported = 1;
+    }
+  }
+  if (b.unsupported) { free(b.p); *len = 0; return NULL; }
+  *len = b.n;
+  return b.p;
+}
+char *ora_serialize(int format, const ora_batch *b, uint64_t *len) { return ora_serialize_ex(format, b, NULL, len); }

@@ -64,6 +64,8 @@ def lib():
     L.ora_csv_table_free.argtypes = [P]
     L.ora_serialize.restype = P
     L.ora_serialize.argtypes = [C.c_int, P, C.POINTER(C.c_uint64)]
+    L.ora_serialize_ex.restype = P
+    L.ora_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(C.c_uint64)]
     L.ora_hmac_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
     L.ora_crc32_ieee.restype = C.c_uint32
     L.ora_crc32_ieee.argtypes = [C.c_char_p, C.c_size_t]
@@ -160,6 +162,24 @@ def apply_chain(transformers, batch: abi.Batch, schema: abi.Schema) -> Result:
         cur = L.ora_transformer_apply(t._h, cur)
     dt = time.perf_counter() - t0
     return _finish(L, cur, dt)
+
+
+def serialize(fmt: int, batch: abi.Batch, schema: abi.Schema, opts=None):
+    """Serialise a batch the way the reference's sink-side marshallers do; None if a value form is
+    outside what the oracle restates (the HIP side answers ERR_UNSUPPORTED for the same input)."""
+    L = lib()
+    cb, cs = batch.to_c(), schema.to_c()
+    rows = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    n = C.c_uint64(0)
+    t0 = time.perf_counter()
+    p = L.ora_serialize_ex(fmt, rows, C.byref(opts) if opts is not None else None, C.byref(n))
+    serialize.seconds = time.perf_counter() - t0
+    L.ora_batch_free(rows)
+    if not p:
+        return None
+    out = C.string_at(p, n.value)
+    L.free(p)
+    return out
 
 
 def filter_parse_check(expr: str):

@@ -1,0 +1,152 @@
+"""Sink-side marshalling: oracle pinned to the reference's vectors (CPU), HIP
+kernels against the oracle and the same vectors (GPU)."""
+import json
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from util import golden, item_to_batch
+
+FMT = {"ch": abi.FMT_CH_JSON_EACH_ROW, "json": abi.FMT_JSON, "csv": abi.FMT_CSV}
+
+
+def _opts(o):
+    return abi.serialize_options(add_closing_newline=o.get("add_closing_newline", False), any_as_string=o.get("any_as_string", False),
+                                 ch_types=o.get("ch_types"))
+
+
+def _check_case(case, text: bytes):
+    s = text.decode("utf-8", "surrogateescape")
+    if "expect" in case:
+        assert s == case["expect"], case["name"]
+    for frag in case.get("contains", []):
+        assert frag in s, (case["name"], frag, s)
+    if "json_roundtrip" in case:
+        assert json.loads(s) == case["json_roundtrip"], case["name"]
+
+
+def test_oracle_reference_vectors(oracle):
+    for case in golden("serializers.json")["cases"]:
+        b, schema = item_to_batch(case["item"])
+        out = oracle.serialize(FMT[case["format"]], b, schema, _opts(case["opts"]))
+        assert out is not None, case["name"]
+        _check_case(case, out)
+
+
+def test_oracle_escaping_rules(oracle):
+    """encoding/json vs writeQuoted differ exactly where SURVEY §7 says: <>& stay (escapeHTML off),
+    U+2028/9 and invalid UTF-8 are rewritten by encoding/json only, writeQuoted keeps raw bytes."""
+    schema = abi.Schema.of([["s", "utf8", False]])
+    raw = "a<b>& \"\\\n\t\x01\x7f".encode("utf-8") + b"\xfe\xc3"
+    b = abi.batch_from_rows(schema, ["s"], [[["string", raw.decode("latin-1")]]], "", "t")
+    b.cols[0].data = np.frombuffer(raw, np.uint8).copy(); b.cols[0].offsets = np.array([0, len(raw)], np.uint32)
+    js = oracle.serialize(abi.FMT_JSON, b, schema)
+    assert js == b'{"s":"a<b>&\\u2028\\"\\\\\\n\\t\\u0001\x7f\\ufffd\\ufffd"}'
+    ch = oracle.serialize(abi.FMT_CH_JSON_EACH_ROW, b, schema, _opts({"ch_types": [[1, 0]]}))
+    assert ch == b'{"s":"a<b>&\xe2\x80\xa8\\"\\\\\\n\\t\\u0001\x7f\xfe\xc3"}\n'
+    cs = oracle.serialize(abi.FMT_CSV, b, schema)
+    assert cs == b'"a<b>&\xe2\x80\xa8""\\\n\t\x01\x7f\xfe\xc3"\n'
+
+
+def _random_batch(rng, n):
+    from test_gpu_transformers import _random_batch as rb
+    b, schema = rb(rng, n)
+    keep = [c for c in b.cols if c.repr not in (abi.R_FLOAT32, abi.R_FLOAT64)]
+    b = abi.Batch(keep, n, "db", "tbl")
+    # json.Number and pre-marshalled any values
+    nums = [b"0", b"-1.5", b"1e5", b"1E+3000", b"-2e400", b"1.7976931348623157e308", b"1.7976931348623159e308", b"inf", b"", b"123456789012345678901234567890",
+            b"0.000001e315", b"179769313486231580793728971405303415079934132710037826936173778980444968292764750946649017977587207096330286416692887910946555547851940402630657488671505820681908902000708383676273854845817711531764475730270069855571366959622842914819860834936475292719074168444365510704342711559699508093042880177904174497792"]
+    pick = [nums[i] for i in rng.integers(0, len(nums), n)]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in pick])]).astype(np.uint32)
+    b.cols.append(abi.Column("num", "double", abi.R_JSONNUM, offsets=off, data=np.frombuffer(b"".join(pick), np.uint8).copy()))
+    docs = [b"null", b"{\"a\":[1,2,{\"b\":\"<x>\"}]}", b"[]", b"\"s,\\\"q\\\"\"", b"12", b"true"]
+    pick = [docs[i] for i in rng.integers(0, len(docs), n)]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in pick])]).astype(np.uint32)
+    b.cols.append(abi.Column("doc", "any", abi.R_JSON, offsets=off, data=np.frombuffer(b"".join(pick), np.uint8).copy(), validity=rng.random(n) > 0.2))
+    specials = ["", " lead", "a,b", "q\"q", "\\.", "line\nbreak", " nbsp", "plain", " sep", "ctl\x01\x1f", "<&>", "\tx"]
+    pick = [specials[i].encode("utf-8") for i in rng.integers(0, len(specials), n)]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in pick])]).astype(np.uint32)
+    b.cols.append(abi.Column("sp", "utf8", abi.R_STRING, offsets=off, data=np.frombuffer(b"".join(pick), np.uint8).copy()))
+    b.cols.append(abi.Column("anys", "any", abi.R_STRING, offsets=off.copy(), data=np.frombuffer(b"".join(pick), np.uint8).copy()))
+    schema = abi.Schema.of([[c.name, c.dtype, False] for c in b.cols])
+    return b, schema
+
+
+@pytest.mark.parametrize("n", [1, 7, 300])
+def test_oracle_json_rows_parse_back(oracle, n):
+    """Every JSON row the oracle emits is valid JSON holding every column."""
+    rng = np.random.default_rng(n)
+    b, schema = _random_batch(rng, n)
+    b.cols = [c for c in b.cols if c.name != "num"]  # 1E+3000 is not a Python float
+    schema = abi.Schema.of([[c.name, c.dtype, False] for c in b.cols])
+    out = oracle.serialize(abi.FMT_JSON, b, schema)
+    lines = out.decode("utf-8").split("\n")
+    assert len(lines) == n
+    for ln in lines:
+        assert sorted(json.loads(ln).keys()) == sorted(c.name for c in b.cols)
+
+
+# ---------------------------------------------------------------- GPU -------------
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+@pytest.mark.gpu
+def test_gpu_reference_vectors(tf):
+    for case in golden("serializers.json")["cases"]:
+        b, _ = item_to_batch(case["item"])
+        out = tf.serialize(FMT[case["format"]], tf.DeviceBatch.upload(b), _opts(case["opts"])).download()
+        _check_case(case, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 63, 1000, 20011])
+def test_gpu_serializers_match_oracle(tf, oracle, n):
+    rng = np.random.default_rng(100 + n)
+    b, schema = _random_batch(rng, n)
+    db = tf.DeviceBatch.upload(b)
+    variants = [
+        (abi.FMT_JSON, {}), (abi.FMT_JSON, {"add_closing_newline": True}), (abi.FMT_JSON, {"any_as_string": True}),
+        (abi.FMT_CSV, {}), (abi.FMT_CH_JSON_EACH_ROW, {}), (abi.FMT_CH_JSON_EACH_ROW, {"any_as_string": True}),
+        (abi.FMT_CH_JSON_EACH_ROW, {"ch_types": [[(1 << (i % 5)) if i % 3 else 0, i % 10] for i in range(len(b.cols))]}),
+    ]
+    for fmt, o in variants:
+        ref = oracle.serialize(fmt, b, schema, _opts(o))
+        assert ref is not None, (fmt, o)
+        got = tf.serialize(fmt, db, _opts(o)).download()
+        if got != ref:
+            k = next(i for i in range(min(len(got), len(ref))) if got[i] != ref[i]) if got[: len(ref)] != ref[: len(got)] else min(len(got), len(ref))
+            raise AssertionError(f"fmt={fmt} opts={o}: first difference at byte {k}: gpu={got[max(0,k-60):k+60]!r} ref={ref[max(0,k-60):k+60]!r}")
+
+
+@pytest.mark.gpu
+def test_gpu_serialize_unsupported_and_empty(tf, oracle):
+    schema = abi.Schema.of([["f", "double", False]])
+    b = abi.batch_from_rows(schema, ["f"], [[["float64", 1.5]]], "", "t")
+    assert oracle.serialize(abi.FMT_JSON, b, schema) is None
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.serialize(abi.FMT_JSON, tf.DeviceBatch.upload(b))
+    assert ei.value.code == tf.ERR_UNSUPPORTED
+    e = abi.Batch([abi.Column("a", "int32", abi.R_INT32, values=np.zeros(0, np.int32))], 0, "", "t")
+    for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
+        assert tf.serialize(fmt, tf.DeviceBatch.upload(e)).download() == b""
+
+
+@pytest.mark.gpu
+def test_gpu_hits_chain_to_jsoneachrow(tf, oracle):
+    """configs[2] shape: parse -> filter -> ClickHouse JSONEachRow, bytes identical to the oracle."""
+    from transferia_amd import workload
+    schema = workload.hits_schema()
+    data = workload.hits_csv(2000)
+    opts = workload.hits_csv_options()
+    db, _, errs = tf.csv_parse(opts, schema, data)
+    res = tf.apply_chain([tf.Transformer("filter_rows", {"filter": "eventdate >= 2013-07-15"})], db)
+    got = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, res.transformed).download()
+    ref = oracle.csv_parse(opts, schema, data, "", "")
+    ref2 = oracle.apply_chain([oracle.Transformer("filter_rows", {"filter": "eventdate >= 2013-07-15"})], ref.batch, ref.schema)
+    exp = oracle.serialize(abi.FMT_CH_JSON_EACH_ROW, ref2.batch, ref2.schema)
+    assert got == exp and got.count(b"\n") == res.transformed.nrows

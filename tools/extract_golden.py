@@ -365,6 +365,67 @@ def csv_reader():
     write("csv_reader.json", {"source": "pkg/csv/reader_test.go:13-240", "cases": cases})
 
 
+# ---------------------------------------------------------------------------
+# serializers: pkg/serializer/reference/reference_test.go:19-78 (one raw-message item, canon files
+# hold the exact bytes), json_test.go:52-110, httpuploader/marshal_test.go:18-233
+# ---------------------------------------------------------------------------
+def serializers():
+    ref = REF + "/pkg/serializer/reference/canondata/reference.reference.TestSerialize_%s/result"
+
+    def canon_bytes(name):
+        with open(ref % name, "rb") as f:
+            return f.read().decode("utf-8")
+    # abstract.MakeRawMessage([]byte("stub"), "table", time.Time{}, "topic", 42, 42, []byte("data"))
+    # (pkg/abstract/changeitem/mirror.go:23-67): partition is a Go int, meta a nil map (json: null)
+    raw_schema = [["topic", "utf8", True], ["partition", "uint32", True], ["seq_no", "uint64", True], ["write_time", "datetime", True],
+                  ["data", "utf8", False], ["meta", "any", False], ["sequence_key", "string", False]]
+    raw_item = {"ns": "", "table": "table", "schema": raw_schema, "names": [c[0] for c in raw_schema],
+                "values": [["string", "topic"], ["int", 42], ["uint64", 42], ["time", "0001-01-01T00:00:00Z"], ["string", "data"],
+                           ["json", "null"], ["bytes", "stub"]]}
+    cases = [
+        {"name": "TestSerialize/csv:default", "format": "csv", "opts": {}, "item": raw_item, "expect": canon_bytes("csv_default")},
+        {"name": "TestSerialize/json:default", "format": "json", "opts": {}, "item": raw_item, "expect": canon_bytes("json_default")},
+        {"name": "TestSerialize/json:newline", "format": "json", "opts": {"add_closing_newline": True}, "item": raw_item,
+         "expect": canon_bytes("json_newline")},
+    ]
+    # json_test.go:52-110 TestJSONSerializerComplexAsStr (require.Contains fragments)
+    complex_item = {"ns": "", "table": "", "schema": [["id", "int16", False], ["jsonObject", "any", False], ["jsonArray", "any", False], ["nil", "any", False]],
+                    "names": ["id", "jsonObject", "jsonArray", "nil"],
+                    "values": [["int", 1], ["json", "{\"key\":\"value\"}"], ["json", "[1,2,3]"], ["nil", None]]}
+    cases.append({"name": "TestJSONSerializerComplexAsStr/as-string", "format": "json", "opts": {"any_as_string": True}, "item": complex_item,
+                  "contains": ["\"id\":1", "\"jsonObject\":\"{\\\"key\\\":\\\"value\\\"}\"", "\"jsonArray\":\"[1,2,3]\"", "\"nil\":null"]})
+    cases.append({"name": "TestJSONSerializerComplexAsStr/as-is", "format": "json", "opts": {}, "item": complex_item,
+                  "contains": ["\"id\":1", "\"jsonObject\":{\"key\":\"value\"}", "\"jsonArray\":[1,2,3]", "\"nil\":null"]})
+    # httpuploader/marshal_test.go:18-39 TestDatetime64Marshal: time.Date(2020,2,2,10,2,22,123456789,UTC)
+    dt = ["time", "2020-02-02T10:02:22.123456789Z"]
+    for prec, exp in enumerate(["15806377421", "158063774212", "1580637742123", "15806377421234", "158063774212345", "1580637742123456",
+                                "15806377421234567", "158063774212345678", "1580637742123456789"], start=1):
+        cases.append({"name": "TestDatetime64Marshal/DateTime64(%d)" % prec, "format": "ch", "opts": {"ch_types": [[4, prec]]},
+                      "item": {"ns": "", "table": "t", "schema": [["ts", "timestamp", False]], "names": ["ts"], "values": [dt]},
+                      "expect": "{\"ts\":%s}\n" % exp})
+    # marshal_test.go:41-80 TestValidJSON: []byte values under "utf8" round-trip through JSON
+    for i, val in enumerate(["\"[{\\\"foo\\\":0}]\"", "[{\\\"foo\\\":0}]", "\"[{\\\\\\\"foo\\\":0}]"]):
+        cases.append({"name": "TestValidJSON/tc_%d" % i, "format": "ch", "opts": {"ch_types": [[0, 0]]},
+                      "item": {"ns": "", "table": "t", "schema": [["bytes_with_jsons", "utf8", False]], "names": ["bytes_with_jsons"],
+                               "values": [["bytes", val]]}, "json_roundtrip": {"bytes_with_jsons": val}})
+    # marshal_test.go:116-233 TestNullValueMarshal
+    one = [["recipient", "utf8", False]]
+    cases.append({"name": "TestNullValueMarshal/single_null_column", "format": "ch", "opts": {"ch_types": [[0, 0]]},
+                  "item": {"ns": "", "table": "t", "schema": one, "names": ["recipient"], "values": [["nil", None]]}, "expect": "{}\n"})
+    three = [["col1", "utf8", False], ["col2", "utf8", False], ["col3", "utf8", False]]
+    cases.append({"name": "TestNullValueMarshal/multiple_columns_all_null", "format": "ch", "opts": {"ch_types": [[0, 0], [0, 0]]},
+                  "item": {"ns": "", "table": "t", "schema": three[:2], "names": ["col1", "col2"], "values": [["nil", None], ["nil", None]]},
+                  "expect": "{}\n"})
+    cases.append({"name": "TestNullValueMarshal/mixed_null_and_values", "format": "ch", "opts": {"ch_types": [[0, 0]] * 3},
+                  "item": {"ns": "", "table": "t", "schema": three, "names": ["col1", "col2", "col3"],
+                           "values": [["nil", None], ["string", "value2"], ["nil", None]]}, "expect": "{\"col2\":\"value2\"}\n"})
+    # marshal_test.go:235-264 TestJSON: "a\nb" must come out as valid JSON
+    cases.append({"name": "TestJSON", "format": "ch", "opts": {"ch_types": [[0, 0]]},
+                  "item": {"ns": "", "table": "t", "schema": [["data", "utf8", False]], "names": ["data"], "values": [["string", "a\nb"]]},
+                  "expect": "{\"data\":\"a\\nb\"}\n"})
+    write("serializers.json", {"cases": cases})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -378,4 +439,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); hits_schema()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); hits_schema()

@@ -78,6 +78,28 @@ class CCsvOptions(C.Structure):
                 ("decimal_point", C.c_char_p), ("skip_rows", C.c_int64)]
 
 
+class CSerializeOptions(C.Structure):
+    _fields_ = [("add_closing_newline", C.c_int32), ("any_as_string", C.c_int32), ("ncols", C.c_int32),
+                ("ch_flags", C.POINTER(C.c_uint32)), ("ch_precision", C.POINTER(C.c_uint8))]
+
+
+CH_STRING, CH_DATE, CH_DATETIME64, CH_DECIMAL, CH_ARRAY = 1, 2, 4, 8, 16
+
+
+def serialize_options(add_closing_newline=False, any_as_string=False, ch_types=None) -> CSerializeOptions:
+    """ch_types: per batch column (flags, precision) of the ClickHouse target column, or None to
+    derive them from the DataType."""
+    o = CSerializeOptions()
+    o.add_closing_newline, o.any_as_string = int(bool(add_closing_newline)), int(bool(any_as_string))
+    if ch_types:
+        n = len(ch_types)
+        fl = (C.c_uint32 * n)(*[int(t[0]) for t in ch_types])
+        pr = (C.c_uint8 * n)(*[int(t[1]) for t in ch_types])
+        o.ncols, o.ch_flags, o.ch_precision = n, fl, pr
+        o._keep = (fl, pr)
+    return o
+
+
 def _b(s) -> bytes:
     return s if isinstance(s, bytes) else str(s).encode("utf-8")
 

@@ -9,30 +9,9 @@
 
 #include "tf_devfmt.hpp"
 #include "tf_plan.hpp"
+#include "tf_devcol.hpp"
 
 namespace tf {
-
-// ---- device view of a column ------------------------------------------------
-struct DCol {
-  const void *values;
-  const uint32_t *offsets;
-  const uint8_t *data;
-  const int32_t *nanos;
-  const uint8_t *validity;
-  int32_t repr;
-  int32_t dtype;
-};
-static DCol dcol_of(const DColumn &c) {
-  DCol d;
-  d.values = c.values ? c.values->p : nullptr;
-  d.offsets = ptr<uint32_t>(c.offsets);
-  d.data = ptr<uint8_t>(c.data);
-  d.nanos = ptr<int32_t>(c.nanos);
-  d.validity = ptr<uint8_t>(c.validity);
-  d.repr = c.repr; d.dtype = c.dtype;
-  return d;
-}
-__device__ __forceinline__ bool is_valid(const DCol &c, int64_t r) { return !c.validity || ((c.validity[r >> 3] >> (r & 7)) & 1); }
 
 static inline unsigned grid_for(int64_t n, int threads) {
   int64_t b = (n + threads - 1) / threads;

@@ -27,7 +27,7 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -81,6 +81,7 @@ def load():
     L.tfgpu_csv_parse.argtypes = [C.POINTER(abi.CCsvOptions), C.POINTER(abi.CSchema), P, C.c_uint64, C.c_int, C.POINTER(P),
                                   C.POINTER(C.c_uint64), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_serialize.argtypes = [C.c_int, P, C.POINTER(P)]
+    L.tfgpu_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(P)]
     L.tfgpu_dbuf_size.argtypes = [P, C.POINTER(C.c_uint64)]
     L.tfgpu_dbuf_ptr.argtypes = [P]
     L.tfgpu_dbuf_ptr.restype = P
@@ -361,10 +362,14 @@ def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int =
     return DeviceBatch(out), int(consumed.value), el
 
 
-def serialize(fmt: int, batch: DeviceBatch) -> DeviceBuffer:
+def serialize(fmt: int, batch: DeviceBatch, opts: Optional[abi.CSerializeOptions] = None) -> DeviceBuffer:
+    """BatchSerializer.Serialize / MarshalCItoJSON per row, from device columns to device text."""
     init()
     out = C.c_void_p()
-    _check(load().tfgpu_serialize(fmt, batch._h, C.byref(out)))
+    if opts is None:
+        _check(load().tfgpu_serialize(fmt, batch._h, C.byref(out)))
+    else:
+        _check(load().tfgpu_serialize_ex(fmt, batch._h, C.byref(opts), C.byref(out)))
     return DeviceBuffer(out)
 
 
