@@ -156,9 +156,15 @@ typedef enum tfgpu_rowerr {
   TFGPU_ROW_QUOTE = 8,             /* csv: element is a single quote char     */
   TFGPU_ROW_DOUBLE_QUOTE = 9,      /* csv: errDoubleQuotesDisabled            */
   TFGPU_ROW_QUOTING_DISABLED = 10, /* csv: errQuotingDisabled                 */
-  TFGPU_ROW_HOST_FALLBACK = 11     /* value form not handled on device (free-
+  TFGPU_ROW_HOST_FALLBACK = 11,    /* value form not handled on device (free-
                                       form dates …): caller must run this row
                                       through the stock Go path               */
+  TFGPU_ROW_JSON_SYNTAX = 12,      /* generic parser: Unmarshal(line) failed →
+                                      NewUnparsed (generic_parser.go:545-550)  */
+  TFGPU_ROW_PARSE_VAL = 13,        /* ParseVal error on a key/required column →
+                                      newUnparsed (generic_parser.go:363-367)  */
+  TFGPU_ROW_NIL_KEY = 14           /* nil in a key/required column →
+                                      newUnparsed (generic_parser.go:370-372)  */
 } tfgpu_rowerr;
 
 typedef struct tfgpu_row_error {
@@ -250,6 +256,50 @@ void tfgpu_csv_options_default(tfgpu_csv_options *o);
 int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes,
                     uint64_t len, int mem, tfgpu_dbatch **out, uint64_t *consumed,
                     tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+
+/* ---- JSON ingest: parsers/generic GenericParser{Format:"json"} ----------- */
+/* generic.AuxParserOpts (pkg/parsers/generic/generic_parser.go:40-77) as the "json" parser
+ * registry fills them (pkg/parsers/registry/json/parser_json.go:62-86).  Options whose value
+ * forms are not device-resident are rejected with TFGPU_ERR_UNSUPPORTED at call time
+ * (unescape_string_values, unpack_bytes_base64, TimeField, TableSplitter, nested ColSchema.Path). */
+typedef struct tfgpu_json_options {
+  uint8_t add_rest;               /* AddRest: `_rest` column (any)                           */
+  uint8_t add_dedupe_keys;        /* AddDedupeKeys: _timestamp,_partition,_offset,_idx       */
+  uint8_t null_keys_allowed;      /* NullKeysAllowed                                         */
+  uint8_t use_numbers_in_any;     /* UseNumbersInAny                                         */
+  uint8_t unescape_string_values; /* UnescapeStringValues                                    */
+  uint8_t unpack_bytes_base64;    /* UnpackBytesBase64                                       */
+  uint8_t ignore_column_paths;    /* IgnoreColumnPaths                                       */
+  uint8_t mark_dedupe_keys_as_system; /* MarkDedupeKeysAsSystem (json.lb: SkipSystemKeys)     */
+  const char *topic;              /* AuxOpts.Topic → GenericParser.name → ChangeItem.Table   */
+  const char *partition;          /* abstract.Partition.String() of the batch (PartID)       */
+} tfgpu_json_options;
+
+/* parsers.MessageBatch (pkg/parsers/abstract.go): Messages[i].Value concatenated in `bytes`.   */
+typedef struct tfgpu_messages {
+  int64_t nmsg;
+  const uint64_t *start;          /* [nmsg+1] byte offset of each Value; start[nmsg] == len   */
+  const uint64_t *offset;         /* Message.Offset → LSN, `_offset`                          */
+  const int64_t *write_time_ns;   /* Message.WriteTime.UnixNano() → CommitTime, `_timestamp`  */
+} tfgpu_messages;
+
+/* GenericParser.DoBatch (generic_parser.go:406-438) for Format "json": every message is split
+ * into lines (bufio.ScanLines), each non-empty line is one JSON object → one row typed by
+ * `fields` (+ the aux columns the options add, generic_parser.go:99-154).  Lines are numbered
+ * 0.. over the whole batch counting non-empty lines only ("ordinal").  Outputs:
+ *   - *out: parsed rows; src_row[r] = ordinal of the line, part_id[r] = index of its message
+ *     (the shim re-attaches LSN / CommitTime / QueueMessageMeta from it);
+ *   - errs: one entry per line that the reference turns into an `_unparsed` row
+ *     (row = ordinal, step = message index, code = TFGPU_ROW_JSON_SYNTAX / PARSE_VAL / NIL_KEY)
+ *     or that must be re-parsed by the stock Go code (TFGPU_ROW_HOST_FALLBACK);
+ *   - lines whose top-level value is not an object, or is `{}`, yield nothing
+ *     (generic_parser.go:536: len(item) > 0), exactly like the reference.
+ * `msgs` may be NULL: one message spanning the whole buffer, Offset 0, WriteTime 0.          */
+int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_schema *fields, const void *bytes, uint64_t len,
+                     int mem, const tfgpu_messages *msgs, tfgpu_dbatch **out, tfgpu_row_error *errs,
+                     int64_t errs_cap, int64_t *nerrs);
+/* GenericParser.ResultSchema(): fields + aux columns; free with tfgpu_schema_free.            */
+int tfgpu_json_result_schema(const tfgpu_json_options *opts, const tfgpu_schema *fields, tfgpu_schema **out);
 
 /* ---- serialize ---------------------------------------------------------- */
 enum {

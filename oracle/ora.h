@@ -166,6 +166,17 @@ void ora_csv_table_free(ora_csv_table *t);
 ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema, const char *ns,
                          const char *table, const void *bytes, uint64_t len, uint64_t *consumed);
 
+/* ---- a17: generic JSON parser (pkg/parsers/generic/generic_parser.go) — ora_jsonparse.c ---- */
+typedef struct ora_json_lines ora_json_lines; /* per non-empty line: status / code / column / msg / idx / row */
+ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *fields, const void *bytes, uint64_t len,
+                          const tfgpu_messages *msgs, ora_json_lines **lines_out);
+void ora_json_lines_free(ora_json_lines *l);
+tfgpu_schema *ora_json_result_schema(const tfgpu_json_options *o, const tfgpu_schema *fields);
+int ora_batch_value(const ora_batch *b, int64_t row, int col, int *kind, int64_t *i64, double *f64, const char **s, size_t *slen, int32_t *nsec);
+double ora_fastfloat_parse_best_effort(const char *s, size_t n);       /* fastjson/fastfloat v1.6.4 */
+int64_t ora_fastfloat_parse_int64_best_effort(const char *s, size_t n);
+uint64_t ora_fastfloat_parse_uint64_best_effort(const char *s, size_t n);
+
 /* ---- serializers ---- */
 /* format = TFGPU_FMT_*; returns malloc'd bytes */
 char *ora_serialize(int format, const ora_batch *b, uint64_t *len);

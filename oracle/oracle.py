@@ -79,6 +79,16 @@ def lib():
     L.ora_parse_int.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int64)]
     L.ora_time_parse.restype = C.c_int
     L.ora_time_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.ora_json_parse.restype = P
+    L.ora_json_parse.argtypes = [C.POINTER(abi.CJsonOptions), C.POINTER(abi.CSchema), C.c_void_p, C.c_uint64, C.POINTER(abi.CMessages), C.POINTER(P)]
+    L.ora_json_lines_free.argtypes = [P]
+    L.ora_json_result_schema.restype = C.POINTER(abi.CSchema)
+    L.ora_json_result_schema.argtypes = [C.POINTER(abi.CJsonOptions), C.POINTER(abi.CSchema)]
+    L.ora_batch_value.restype = C.c_int
+    L.ora_batch_value.argtypes = [P, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_char_p),
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    L.ora_fastfloat_parse_best_effort.restype = C.c_double
+    L.ora_fastfloat_parse_best_effort.argtypes = [C.c_char_p, C.c_size_t]
     L.free = C.CDLL(None).free
     L.free.argtypes = [C.c_void_p]
     _LIB = L
@@ -265,3 +275,72 @@ def time_parse(layout: str, s: str):
     b = s.encode()
     rc = lib().ora_time_parse(layout.encode(), b, len(b), C.byref(sec), C.byref(ns))
     return None if rc else (int(sec.value), int(ns.value))
+
+
+# ---- a17: generic JSON parser -------------------------------------------------
+JL_ROW, JL_SKIPPED, JL_UNPARSED, JL_UNRESTATED = 0, 1, 2, 3
+_OV_NAMES = ["nil", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float32", "float64", "bool",
+             "string", "bytes", "jsonnum", "json", "time", "duration"]
+
+
+class _JsonLines(C.Structure):
+    _fields_ = [("nlines", C.c_int64), ("status", C.POINTER(C.c_int32)), ("code", C.POINTER(C.c_int32)), ("column", C.POINTER(C.c_int32)),
+                ("msg", C.POINTER(C.c_int32)), ("idx", C.POINTER(C.c_int32)), ("row", C.POINTER(C.c_int64))]
+
+
+class JsonResult:
+    """lines: per non-empty line (status, code, column, msg, idx, row); rows: list of rows of [gotype, value]."""
+
+    def __init__(self):
+        self.lines, self.rows, self.schema, self.seconds, self.nrows = [], [], None, 0.0, 0
+
+
+def _row_values(L, bptr, row, ncols):
+    out = []
+    kind, i64, f64, s, sl, ns = C.c_int(0), C.c_int64(0), C.c_double(0), C.c_char_p(), C.c_size_t(0), C.c_int32(0)
+    for c in range(ncols):
+        L.ora_batch_value(bptr, row, c, C.byref(kind), C.byref(i64), C.byref(f64), C.byref(s), C.byref(sl), C.byref(ns))
+        name = _OV_NAMES[kind.value]
+        if name == "nil":
+            out.append(["nil", None])
+        elif name in ("string", "bytes", "jsonnum", "json"):
+            out.append([name, C.string_at(s, sl.value)])
+        elif name in ("float32", "float64"):
+            out.append([name, f64.value])
+        elif name == "time":
+            out.append(["time", (i64.value, ns.value)])
+        elif name == "bool":
+            out.append(["bool", bool(i64.value)])
+        elif name == "uint64":
+            out.append([name, i64.value & 0xFFFFFFFFFFFFFFFF])
+        else:
+            out.append([name, i64.value])
+    return out
+
+
+def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data: bytes, msgs: abi.CMessages = None, want_rows: bool = True) -> JsonResult:
+    """GenericParser{Format: "json"}.DoBatch over the oracle."""
+    L = lib()
+    cs = fields.to_c()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    lp = C.c_void_p()
+    t0 = time.perf_counter()
+    bptr = L.ora_json_parse(C.byref(opts), C.byref(cs), buf.ctypes.data if len(buf) else None, len(buf), C.byref(msgs) if msgs is not None else None,
+                            C.byref(lp))
+    r = JsonResult()
+    r.seconds = time.perf_counter() - t0
+    jl = _JsonLines.from_address(lp.value)
+    r.lines = [(int(jl.status[i]), int(jl.code[i]), int(jl.column[i]), int(jl.msg[i]), int(jl.idx[i]), int(jl.row[i])) for i in range(jl.nlines)]
+    rs = L.ora_json_result_schema(C.byref(opts), C.byref(cs))
+    r.schema = abi.Schema.from_c(rs.contents)
+    L.ora_tschema_free(rs)
+
+    class OraBatch(C.Structure):
+        _fields_ = [("n", C.c_int64)]
+    n = OraBatch.from_address(bptr).n
+    r.nrows = int(n)
+    if want_rows:
+        r.rows = [_row_values(L, bptr, i, len(r.schema.cols)) for i in range(n)]
+    L.ora_json_lines_free(lp)
+    L.ora_batch_free(bptr)
+    return r

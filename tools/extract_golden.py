@@ -426,6 +426,80 @@ def serializers():
     write("serializers.json", {"cases": cases})
 
 
+
+# ---------------------------------------------------------------------------
+# generic JSON parser (a17)
+#   tests/canon/parser/canon_static_generic_test.go:20-44 + samples/static/generic/{json,mdb}.*
+#   pkg/parsers/generic/parser_test.go:129-231 (TestParserNumberTypes), :233-276 (TestBase64Unpack)
+# ---------------------------------------------------------------------------
+def _canon_value(v):
+    """tests/canon/validator canonized value {type, value} -> [gotype, value]"""
+    t, x = v["type"], v["value"]
+    if t == "nil":
+        return ["nil", None]
+    if t == "time.Time":
+        return ["time", x]
+    if t == "string":
+        return ["string", x]
+    if t == "map[string]interface {}":
+        return ["json", json.dumps(x, separators=(",", ":"), sort_keys=True)]
+    if t in ("uint8", "uint16", "uint32", "uint64", "int8", "int16", "int32", "int64", "float64", "bool"):
+        return [t, x]
+    raise ValueError(t)
+
+
+def json_parser():
+    cases = []
+    base = REF + "/tests/canon/parser"
+    for name in ("json", "mdb"):
+        cfg = json.load(open(f"{base}/samples/static/generic/{name}.config.json"))
+        pc = cfg["ParserConfig"]["json.lb"]
+        sample = open(f"{base}/samples/static/generic/{name}.sample", "rb").read()
+        ext = json.load(open(f"{base}/gotest/canondata/gotest.gotest.TestGenericParsers_{name}_canon_0/extracted"))
+        # ParserConfigJSONLb → GenericParserConfig (pkg/parsers/registry/json/parser_json.go:62-86): AddDedupeKeys = !SkipSystemKeys… for
+        # the Lb flavour dedupe keys are always added (lb.go), AddRest from the config
+        fields = [[f["name"], f["type"], bool(f["key"]), f.get("path", ""), "", bool(f.get("required"))] for f in pc["Fields"]]
+        topic = cfg["GroupTopics"][0]
+        rows = []
+        for it in ext:
+            assert it["ColumnNames"]["value"][:len(fields)] == [f[0] for f in fields]
+            rows.append({"table": it["Table"]["value"], "names": it["ColumnNames"]["value"], "values": [_canon_value(v) for v in it["ColumnValues"]["value"]],
+                         "part": it["PartID"]["value"]})
+        cases.append({"name": "canon_" + name, "ref": f"tests/canon/parser/samples/static/generic/{name}.sample",
+                      "options": {"add_rest": bool(pc["AddRest"]), "add_dedupe_keys": True, "null_keys_allowed": bool(pc["NullKeysAllowed"]),
+                                  "topic": topic, "partition": json.dumps({"partition": 0, "topic": topic}, separators=(",", ":"))},
+                      "fields": fields,
+                      # testcase.MakeDefaultPersqueueReadMessage (tests/canon/parser/testcase/test_case.go:66-76)
+                      "messages": [{"offset": 123, "write_time": "2020-02-02T10:02:20Z", "value_latin1": sample.decode("latin-1")}],
+                      "rows": rows})
+    # TestParserNumberTypes: one line per message, Offset = line index, canon = MarshalJSON of the ChangeItems
+    gdir = REF + "/pkg/parsers/generic"
+    res = json.load(open(gdir + "/gotest/canondata/result.json"))
+    nums = open(gdir + "/test_data/parser_numbers_test.jsonl", "rb").read()
+    nfields = [["id", "int8", False], ["number_field", "int64", False], ["float_field", "double", False], ["obj_field", "any", False], ["array_field", "any", False]]
+    for key, use_numbers in (("UseNumbersFalse", False), ("UseNumbersTrue", True)):
+        items = res["gotest.gotest.TestParserNumberTypes"][key]
+        lines = [ln for ln in nums.split(b"\n")]
+        msgs, rows = [], []
+        for i, ln in enumerate(lines):
+            if ln == b"":
+                continue
+            msgs.append({"offset": i, "write_time": "1970-01-01T00:00:00Z", "value_latin1": ln.decode("latin-1")})
+        for it in items:
+            # canon values went through ChangeItem.MarshalJSON: ints/floats as JSON numbers, any as JSON
+            rows.append({"table": it["table"], "names": it["columnnames"], "marshalled": it["columnvalues"], "part": it["part"]})
+        cases.append({"name": "numbers_" + key, "ref": "pkg/parsers/generic/parser_test.go:129-231",
+                      "options": {"use_numbers_in_any": use_numbers, "topic": "my_topic_name", "partition": '{"partition":0,"topic":""}'},
+                      "fields": nfields, "messages": msgs, "rows": rows})
+    b64 = open(gdir + "/test_data/parse_base64_packed.jsonl", "rb").read()
+    items = res["gotest.gotest.TestBase64Unpack"]
+    msgs = [{"offset": i, "write_time": "1970-01-01T00:00:00Z", "value_latin1": ln.decode("latin-1")} for i, ln in enumerate(b64.split(b"\n")) if ln]
+    cases.append({"name": "base64_unpack", "ref": "pkg/parsers/generic/parser_test.go:233-276",
+                  "options": {"unpack_bytes_base64": True, "topic": "my_topic_name", "partition": '{"partition":0,"topic":""}'},
+                  "fields": [["id", "int8", False], ["stringVal", "utf8", False], ["bytesVal", "string", False]], "messages": msgs,
+                  "rows": [{"table": it["table"], "names": it["columnnames"], "marshalled": it["columnvalues"], "part": it["part"]} for it in items]})
+    write("json_parser.json", {"cases": cases})
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -439,4 +513,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); hits_schema()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema()

@@ -32,10 +32,11 @@ K_INSERT, K_UPDATE, K_DELETE, K_OTHER = 0, 1, 2, 3
 KIND_ID = {"insert": 0, "Insert": 0, "update": 1, "Update": 1, "delete": 2, "Delete": 2}
 
 MEM_HOST, MEM_DEVICE = 0, 1
-COL_KEY = 1
+COL_KEY, COL_REQUIRED = 1, 2
 
 ROWERR = {0: "OK", 1: "UNSUPPORTED_KIND", 2: "COLUMN_NOT_FOUND", 3: "INT_OVERFLOW", 4: "TYPE_PAIR", 5: "MISSING_CELL",
-          6: "CAST", 7: "RANGE", 8: "QUOTE", 9: "DOUBLE_QUOTE", 10: "QUOTING_DISABLED", 11: "HOST_FALLBACK"}
+          6: "CAST", 7: "RANGE", 8: "QUOTE", 9: "DOUBLE_QUOTE", 10: "QUOTING_DISABLED", 11: "HOST_FALLBACK",
+          12: "JSON_SYNTAX", 13: "PARSE_VAL", 14: "NIL_KEY"}
 ROWERR_ID = {v: k for k, v in ROWERR.items()}
 
 FMT_CH_JSON_EACH_ROW, FMT_JSON, FMT_CSV = 1, 2, 3
@@ -78,6 +79,44 @@ class CCsvOptions(C.Structure):
                 ("decimal_point", C.c_char_p), ("skip_rows", C.c_int64)]
 
 
+class CJsonOptions(C.Structure):
+    _fields_ = [("add_rest", C.c_uint8), ("add_dedupe_keys", C.c_uint8), ("null_keys_allowed", C.c_uint8),
+                ("use_numbers_in_any", C.c_uint8), ("unescape_string_values", C.c_uint8), ("unpack_bytes_base64", C.c_uint8),
+                ("ignore_column_paths", C.c_uint8), ("mark_dedupe_keys_as_system", C.c_uint8), ("topic", C.c_char_p), ("partition", C.c_char_p)]
+
+
+class CMessages(C.Structure):
+    _fields_ = [("nmsg", C.c_int64), ("start", C.c_void_p), ("offset", C.c_void_p), ("write_time_ns", C.c_void_p)]
+
+
+def json_options(add_rest=False, add_dedupe_keys=False, null_keys_allowed=False, use_numbers_in_any=False,
+                 unescape_string_values=False, unpack_bytes_base64=False, ignore_column_paths=False, mark_dedupe_keys_as_system=False, topic="",
+                 partition='{"partition":0,"topic":""}') -> CJsonOptions:
+    o = CJsonOptions()
+    o.add_rest, o.add_dedupe_keys, o.null_keys_allowed = int(add_rest), int(add_dedupe_keys), int(null_keys_allowed)
+    o.use_numbers_in_any, o.unescape_string_values = int(use_numbers_in_any), int(unescape_string_values)
+    o.unpack_bytes_base64, o.ignore_column_paths = int(unpack_bytes_base64), int(ignore_column_paths)
+    o.mark_dedupe_keys_as_system = int(mark_dedupe_keys_as_system)
+    t, p = _b(topic), _b(partition)
+    o.topic, o.partition = t, p
+    o._keep = (t, p)
+    return o
+
+
+def messages(values: Sequence[bytes], offsets=None, write_times_ns=None):
+    """parsers.MessageBatch → (concatenated bytes, CMessages).  Values are concatenated as they are."""
+    n = len(values)
+    start = np.zeros(n + 1, np.uint64)
+    if n:
+        start[1:] = np.cumsum([len(v) for v in values])
+    off = np.asarray(offsets if offsets is not None else np.zeros(n), dtype=np.uint64)
+    wt = np.asarray(write_times_ns if write_times_ns is not None else np.zeros(n), dtype=np.int64)
+    m = CMessages()
+    m.nmsg, m.start, m.offset, m.write_time_ns = n, start.ctypes.data, off.ctypes.data, wt.ctypes.data
+    m._keep = (start, off, wt)
+    return b"".join(values), m
+
+
 class CSerializeOptions(C.Structure):
     _fields_ = [("add_closing_newline", C.c_int32), ("any_as_string", C.c_int32), ("ncols", C.c_int32),
                 ("ch_flags", C.POINTER(C.c_uint32)), ("ch_precision", C.POINTER(C.c_uint8))]
@@ -112,6 +151,7 @@ class ColSchema:
     key: bool = False
     path: str = ""
     original_type: str = ""
+    required: bool = False
 
 
 @dataclass
@@ -127,7 +167,7 @@ class Schema:
             else:
                 c = list(c)
                 out.append(ColSchema(c[0], c[1], bool(c[2]) if len(c) > 2 else False, c[3] if len(c) > 3 else "",
-                                     c[4] if len(c) > 4 else ""))
+                                     c[4] if len(c) > 4 else "", bool(c[5]) if len(c) > 5 else False))
         return Schema(out)
 
     def dtype_of(self, name: str) -> str:
@@ -142,7 +182,8 @@ class Schema:
         for i, c in enumerate(self.cols):
             n, p, o = _b(c.name), _b(c.path), _b(c.original_type)
             keep += [n, p, o]
-            arr[i].name, arr[i].dtype, arr[i].flags, arr[i].path, arr[i].original_type = n, DTYPE_ID[c.dtype], (COL_KEY if c.key else 0), p, o
+            arr[i].name, arr[i].dtype, arr[i].path, arr[i].original_type = n, DTYPE_ID[c.dtype], p, o
+            arr[i].flags = (COL_KEY if c.key else 0) | (COL_REQUIRED if c.required else 0)
         s = CSchema(len(self.cols), arr)
         s._keep = (arr, keep)
         return s
@@ -153,7 +194,7 @@ class Schema:
         for i in range(cs.ncols):
             c = cs.cols[i]
             out.append(ColSchema(c.name.decode("utf-8"), DTYPES[c.dtype], bool(c.flags & COL_KEY),
-                                 (c.path or b"").decode(), (c.original_type or b"").decode()))
+                                 (c.path or b"").decode(), (c.original_type or b"").decode(), bool(c.flags & COL_REQUIRED)))
         return Schema(out)
 
     def triples(self):
