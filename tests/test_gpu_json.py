@@ -1,0 +1,340 @@
+"""Parity of the HIP NDJSON ingest (tfgpu_json_parse: GenericParser{Format:"json"} —
+bufio.ScanLines, fastjson grammar, Unmarshal, ParseVal, makeChangeItem's key rules on
+device) with the oracle, through the C ABI; needs an MI355X.
+
+What is compared, per non-empty line (ordinal):
+  - device row            ⇒ the oracle has a fully restated row with identical values;
+  - device `_unparsed`    ⇒ same code (JSON_SYNTAX / PARSE_VAL / NIL_KEY), column and message;
+  - device vanishes       ⇒ the oracle skipped it ({} or not an object);
+  - device HOST_FALLBACK  ⇒ the line is handed to the stock Go code (counted, bounded per test).
+"""
+import json
+import math
+import random
+import struct
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from util import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+def f64_bits(x):
+    return struct.pack("<d", float(x))
+
+
+def expected_json_text(v):
+    """json.Marshal of the Go value an `any` column holds, for the forms the device keeps."""
+    g, x = v
+    if g == "bool":
+        return b"true" if x else b"false"
+    if g == "string":
+        return b'"' + x + b'"'  # the device only keeps strings encoding/json leaves untouched
+    if g in ("jsonnum", "json"):
+        return x
+    raise AssertionError("device kept an `any` value of Go type %s" % g)
+
+
+def compare(tf, oracle, opts, fields, data, msgs=None, ctx="", max_fallback=0):
+    ref = oracle.json_parse(opts, fields, data, msgs)
+    db, errs = tf.json_parse(opts, fields, data, msgs, max_errors=1 << 18)
+    out = db.download()
+    names = [c.name for c in out.cols]
+    assert names == [c.name for c in ref.schema.cols], ctx
+    assert [c.dtype for c in out.cols] == [c.dtype for c in ref.schema.cols], ctx
+    assert names == [c.name for c in tf.json_result_schema(opts, fields).cols], ctx
+    gerr = {e[0]: e for e in errs}
+    assert len(gerr) == len(errs), ctx
+    src = out.src_row if out.src_row is not None else np.arange(out.nrows, dtype=np.int32)
+    row_of = {int(o): i for i, o in enumerate(src)}
+    assert len(row_of) == out.nrows and list(src) == sorted(src), ctx
+    nfb = 0
+    for ordn, (st, code, col, msg, idx, row) in enumerate(ref.lines):
+        where = "%s line %d" % (ctx, ordn)
+        if ordn in gerr:
+            assert ordn not in row_of, where
+            _, gcode, gmsg, gcol = gerr[ordn]
+            if gcode == "HOST_FALLBACK":
+                nfb += 1
+                assert st != oracle.JL_SKIPPED, where
+                continue
+            assert st == oracle.JL_UNPARSED, (where, gcode, st)
+            assert (gcode, gcol, gmsg) == (abi.ROWERR[code], col, msg), where
+            continue
+        if ordn not in row_of:
+            assert st == oracle.JL_SKIPPED, (where, st)
+            continue
+        assert st == oracle.JL_ROW, (where, st)
+        i = row_of[ordn]
+        assert int(out.part_id[i]) == msg, where
+        exp = ref.rows[row]
+        for c, col_ in enumerate(out.cols):
+            got, want = col_.pyvalue(i), exp[c]
+            if want[0] == "nil" or got[0] == "nil":
+                assert got[0] == want[0] == "nil", (where, names[c], got, want)
+            elif col_.repr == abi.R_JSON:
+                assert got[1] == expected_json_text(want), (where, names[c], got, want)
+            elif want[0] == "float64":
+                assert got[0] == "float64" and (f64_bits(got[1]) == f64_bits(want[1]) or (math.isnan(got[1]) and math.isnan(want[1]))), (where, names[c], got, want)
+            else:
+                assert abi.norm_value(got) == abi.norm_value(want), (where, names[c], got, want)
+    assert len(gerr) + out.nrows <= len(ref.lines), ctx
+    assert set(gerr) | set(row_of) <= set(range(len(ref.lines))), ctx
+    assert nfb <= max_fallback, (ctx, "host fallbacks", nfb)
+    return out, errs, nfb
+
+
+def case_inputs(case):
+    o = case["options"]
+    opts = abi.json_options(add_rest=o.get("add_rest", False), add_dedupe_keys=o.get("add_dedupe_keys", False),
+                            null_keys_allowed=o.get("null_keys_allowed", False), use_numbers_in_any=o.get("use_numbers_in_any", False),
+                            unpack_bytes_base64=o.get("unpack_bytes_base64", False), topic=o.get("topic", ""), partition=o.get("partition", ""))
+    fields = abi.Schema.of(case["fields"])
+    vals = [m["value_latin1"].encode("latin-1") for m in case["messages"]]
+    wts = [abi.parse_rfc3339(m["write_time"])[0] * 10**9 for m in case["messages"]]
+    data, msgs = abi.messages(vals, [m["offset"] for m in case["messages"]], wts)
+    return opts, fields, data, msgs
+
+
+@pytest.mark.parametrize("case", golden("json_parser.json")["cases"], ids=lambda c: c["name"])
+def test_reference_parser_canon(tf, oracle, case):
+    """tests/canon/parser {json, mdb} and pkg/parsers/generic canon inputs."""
+    from transferia_amd import lib
+    opts, fields, data, msgs = case_inputs(case)
+    if case["options"].get("unpack_bytes_base64"):
+        with pytest.raises(lib.TfgpuError) as e:
+            tf.json_parse(opts, fields, data, msgs)
+        assert e.value.code == lib.ERR_UNSUPPORTED
+        return
+    # free-form datetime strings, float64 inside `any`, unknown keys under AddRest: host lines
+    compare(tf, oracle, opts, fields, data, msgs, case["name"], max_fallback=len(case["rows"]))
+
+
+EDGE_FIELDS = [["i8", "int8"], ["u16", "uint16"], ["i64", "int64"], ["u64", "uint64"], ["d", "double"], ["b", "boolean"],
+               ["s", "utf8"], ["y", "string"], ["k", "int32", True], ["t", "datetime"], ["a", "any"]]
+
+EDGE_LINES = [
+    b'{"k": 1, "i8": 300, "u16": -1, "i64": 9223372036854775807, "u64": 18446744073709551615, "d": 1.5, "b": true, "s": "x", "y": [1, {"a" : "b\\n"}]}',
+    b'{"k": "0x10", "i8": "12", "u16": "65535", "d": "1e3", "b": "T", "s": 12.50, "y": true}',
+    b'{"k": 1.5}',
+    b'{"k": null}',
+    b'{"k": "zz"}',
+    b'{"i8": "999", "k": 2}',
+    b'{"k": 3,}',
+    b'[1,2]',
+    b'{}',
+    b'  {"k" : 4 , "s" : "a\\u00e9\\ud83d\\ude00\\q" }  ',
+    b'{"k": 5, "k": 6}',
+    b'{"k": 7} x',
+    b'{"k": 1e2}',
+    b'{"k": 8, "d": 123456789012345678901234567890}',
+    b'{"k": 9, "d": 0.000001234e-5, "b": 1, "i64": -9223372036854775808}',
+    # strings: every escape, broken escapes, surrogates
+    b'{"k": 10, "s": "q\\"b\\\\s\\/\\b\\f\\n\\r\\t", "y": "\\u0041\\u00e9\\u20ac\\ud83d\\ude00"}',
+    b'{"k": 11, "s": "\\ud83d", "y": "\\ud83dx\\ude00"}',
+    b'{"k": 12, "s": "\\ud83d\\u0041", "y": "\\udc00\\ud83d"}',
+    b'{"k": 13, "s": "\\u12", "y": "\\uZZZZ"}',
+    b'{"k": 14, "s": "\\x41\\", "y": "tail\\\\"}',
+    b'{"k": 15, "s": "ends with bs\\\\", "y": ""}',
+    b'{"k": 16, "s": "tab\there", "y": "raw \x01 ctrl"}',
+    # numbers through fastfloat
+    b'{"k": 17, "d": -0}', b'{"k": 18, "d": 1.}', b'{"k": 19, "d": .5}', b'{"k": 20, "d": -.5}', b'{"k": 21, "d": 1e}',
+    b'{"k": 22, "d": 1e+}', b'{"k": 23, "d": 1e400}', b'{"k": 24, "d": 1e-400}', b'{"k": 25, "d": inf}', b'{"k": 26, "d": -Infinity}',
+    b'{"k": 27, "d": nan}', b'{"k": 28, "d": NaN}', b'{"k": 29, "d": 123456789012345678}', b'{"k": 30, "d": 1234567890123456789}',
+    b'{"k": 31, "d": 0.1234567890123456}', b'{"k": 32, "d": 0.12345678901234567}', b'{"k": 33, "d": 123.456e2}', b'{"k": 34, "d": 1e308}',
+    b'{"k": 35, "d": 1e-308}', b'{"k": 36, "d": 1-2+3}', b'{"k": 37, "d": -}', b'{"k": 38, "d": +1}', b'{"k": 39, "d": 1e301}',
+    b'{"k": 40, "d": "1.5"}', b'{"k": 41, "d": "1e22"}', b'{"k": 42, "d": "  1"}', b'{"k": 43, "d": "inf"}', b'{"k": 44, "d": "+nan"}',
+    b'{"k": 45, "d": "0x1p-2"}', b'{"k": 46, "d": "1_0"}', b'{"k": 47, "d": "123456789012345678901"}', b'{"k": 48, "d": ""}',
+    b'{"k": 49, "d": "1e"}', b'{"k": 50, "d": ".5"}', b'{"k": 51, "d": "5."}', b'{"k": 52, "d": "1e23"}', b'{"k": 53, "d": "9007199254740993"}',
+    b'{"k": 54, "d": "-0"}', b'{"k": 55, "d": "0.000001"}', b'{"k": 56, "d": "1e-22"}', b'{"k": 57, "d": "1e-23"}', b'{"k": 58, "d": "123456789e30"}',
+    # integers
+    b'{"k": 59, "i8": -129, "u16": 65536, "i64": 12345678901234567890, "u64": 1.0}',
+    b'{"k": 60, "i8": 127, "u16": 65535, "i64": -0, "u64": 18446744073709551616}',
+    b'{"k": 61, "i8": "-128", "u16": "0b101", "i64": "0o17", "u64": "0xFFFFFFFFFFFFFFFF"}',
+    b'{"k": 62, "i8": "1_0", "u16": "0x_f", "i64": "-9223372036854775809", "u64": "-1"}',
+    b'{"k": 63, "i8": "+5", "u16": "+5", "i64": "", "u64": "018"}',
+    b'{"k": 64, "i8": true, "u16": [1], "i64": {"a": 1}, "u64": false}',
+    b'{"k": "2147483647"}', b'{"k": "2147483648"}', b'{"k": 2147483648}', b'{"k": -2147483649}', b'{"k": "-2147483648"}',
+    # booleans
+    b'{"k": 65, "b": false}', b'{"k": 66, "b": "TRUE"}', b'{"k": 67, "b": "tRUE"}', b'{"k": 68, "b": 0}', b'{"k": 69, "b": [true]}', b'{"k": 70, "b": "0"}',
+    # text columns: raw tokens and compacted containers
+    b'{"k": 71, "s": {"a" : [1, 2 , {"b" : "c d"}], "e" : null}, "y": [ ]}',
+    b'{"k": 72, "s": { }, "y": [ [ ], { } ]}',
+    b'{"k": 73, "s": {"a\\"b": 1}, "y": {"plain": {"a\\"b": 1}}}',
+    b'{"k": 74, "s": -1.50e+3, "y": false}',
+    b'{"k": 75, "s": nan, "y": -inf}',
+    # datetime
+    b'{"k": 76, "t": 1600000000}', b'{"k": 77, "t": -5.9}', b'{"k": 78, "t": 1e30}', b'{"k": 79, "t": true}', b'{"k": 80, "t": "2020-01-01"}', b'{"k": 81, "t": null}',
+    b'{"k": 82, "t": [1]}',
+    # any
+    b'{"k": 83, "a": true}', b'{"k": 84, "a": "plain text"}', b'{"k": 85, "a": "  {\\"x\\":1}"}', b'{"k": 86, "a": "<b>"}', b'{"k": 87, "a": 12}',
+    b'{"k": 88, "a": {"z": 1}}', b'{"k": 89, "a": null}', b'{"k": 90, "a": "null"}', b'{"k": 91, "a": "caf\xc3\xa9"}',
+    # grammar
+    b'{"k": 92, "x": [1, 2,]}', b'{"k": 93, "x": [1 2]}', b'{"k": 94, "x": {"a" 1}}', b'{"k": 95, "x": {"a": }}', b'{"k": 96 "x": 1}', b'{"k": 97, x: 1}',
+    b'{"k": 98, "x": tru}', b'{"k": 99, "x": nul}', b'{"k": 100, "x": falsE}', b'{"k": 101, "x": "unterminated}', b'{"k": 102, "x": [}', b'{"k": 103',
+    b'{"k": 104, "x": truex}', b'{"k": 105}}', b'{"k": 106, "x": [[[[[[[[[[1]]]]]]]]]]}', b'"just a string"', b'12', b'null', b'nan', b'   ', b'{"k": 107, "x": ]}',
+    b'{"k\\u0041": 108}', b'{"\\u006b": 109}', b'{"k": 110, "K": 1, "k ": 2}', b'{"": 1, "k": 111}', b'{"k": 112, "x": "\\"}', b'{"k": 113, "x": "\\\\"}',
+    b'{"k":114,"x":1}\r', b'\t{"k":115}\t', b'{"k": 116, "x": I}', b'{"k": 117, "x": +Inf}', b'{"k": 118, "x": -nanx}', b'{"k": 119, "x": --1}',
+]
+
+
+def test_grammar_and_coercion_edge_cases(tf, oracle):
+    fields = abi.Schema.of(EDGE_FIELDS)
+    for use_numbers in (False, True):
+        opts = abi.json_options(topic="some/topic@x", use_numbers_in_any=use_numbers)
+        data = b"\n".join(EDGE_LINES) + b"\n"
+        out, errs, nfb = compare(tf, oracle, opts, fields, data, None, "edge un=%s" % use_numbers, max_fallback=40)
+        assert out.table_name == "some_topic_x"
+        # the device must decide the bulk of these lines itself
+        assert out.nrows >= 95, out.nrows
+
+
+def test_deep_nesting(tf, oracle):
+    fields = abi.Schema.of([["k", "int32", True], ["s", "utf8"]])
+    opts = abi.json_options(topic="t")
+    lines = []
+    for depth in (1, 2, 30, 62, 63, 64, 65, 100, 298, 299, 300, 301, 400):
+        lines.append(b'{"k": %d, "s": ' % depth + b"[" * depth + b"1" + b"]" * depth + b"}")
+        lines.append(b'{"k": %d, "s": ' % depth + b'{"a":' * depth + b"1" + b"}" * depth + b"}")
+        lines.append(b'{"k": %d, "s": ' % depth + b"[" * depth + b"1" + b"]" * (depth - 1) + b"}")
+    compare(tf, oracle, opts, fields, b"\n".join(lines), None, "depth", max_fallback=len(lines))
+
+
+def test_key_and_required_rules(tf, oracle):
+    lines = [b'{"a": 1, "b": 2, "c": 3}', b'{"a": "x", "b": 2, "c": 3}', b'{"a": 1, "b": "x", "c": 3}', b'{"a": 1, "b": 2, "c": "x"}', b'{"b": 2, "c": 3}',
+             b'{"a": 1, "c": 3}', b'{"a": 1, "b": 2}', b'{"a": null, "b": null, "c": null}', b'{"a": "x", "b": "x", "c": "x"}', b'{"c": "x", "b": null, "a": 1}',
+             b'{"z": 1}']
+    data = b"\n".join(lines)
+    for nka in (False, True):
+        for spec in ([["a", "int32", True], ["b", "int32", False, "", "", True], ["c", "int32"]],
+                     [["a", "int32"], ["b", "int32", True], ["c", "int32", False, "", "", True]],
+                     [["a", "int32"], ["b", "int32"], ["c", "int32"]]):
+            opts = abi.json_options(topic="t", null_keys_allowed=nka)
+            compare(tf, oracle, opts, abi.Schema.of(spec), data, None, "rules nka=%s %s" % (nka, spec))
+
+
+def test_paths_duplicates_and_aux_columns(tf, oracle):
+    # two columns reading one key, ColPath different from ColumnName, IgnoreColumnPaths, name clashes with aux columns
+    spec = [["id", "int64", True, "ID"], ["id2", "utf8", False, "ID"], ["name", "utf8", False, "n"], ["_rest", "utf8"], ["_idx", "int32"]]
+    lines = [b'{"ID": 1, "n": "a", "_rest": "r", "_idx": 5}', b'{"ID": 2, "id": 3, "name": "x", "n": "y"}', b'{"ID": 4, "extra": 1}', b'{"id": 5}']
+    vals = [b"\n".join(lines[:2]) + b"\n", b"", lines[2], b"\n\n" + lines[3] + b"\r\n"]
+    data, msgs = abi.messages(vals, [10, 11, 12, 13], [1_600_000_000_123_456_789, 0, -1, 5])
+    for kw in ({}, {"add_rest": True}, {"add_dedupe_keys": True}, {"add_rest": True, "add_dedupe_keys": True, "mark_dedupe_keys_as_system": True},
+               {"ignore_column_paths": True, "add_dedupe_keys": True}):
+        opts = abi.json_options(topic="t", partition='{"partition":3,"topic":"t"}', **kw)
+        compare(tf, oracle, opts, abi.Schema.of(spec), data, msgs, "aux %s" % kw, max_fallback=4)
+
+
+def test_messages_and_scanlines(tf, oracle):
+    fields = abi.Schema.of([["k", "int32", True], ["s", "utf8"]])
+    rng = random.Random(7)
+    vals, k = [], 0
+    for m in range(300):
+        parts = []
+        for _ in range(rng.choice([0, 1, 1, 1, 2, 5])):
+            k += 1
+            parts.append(b'{"k": %d, "s": "m%d"}' % (k, m))
+            parts.append(rng.choice([b"\n", b"\r\n", b"\n\n", b"\r\n\r\n", b"\n\r\n"]))
+        if parts and rng.random() < 0.5:
+            parts.pop()  # last line without a newline
+        if rng.random() < 0.1:
+            parts.insert(0, rng.choice([b"\n", b"\r\n", b"\r", b" \n"]))
+        vals.append(b"".join(parts))
+    data, msgs = abi.messages(vals, list(range(100, 100 + len(vals))), [i * 1_000_000_007 - 5 for i in range(len(vals))])
+    opts = abi.json_options(topic="t", add_dedupe_keys=True, partition='{"partition":1,"topic":"t"}')
+    out, errs, _ = compare(tf, oracle, opts, fields, data, msgs, "messages")
+    assert out.nrows > 300
+    # one message, no trailing newline; empty input; newline-only input
+    compare(tf, oracle, opts, fields, b'{"k": 1}', None, "single")
+    compare(tf, oracle, opts, fields, b"", None, "empty")
+    compare(tf, oracle, opts, fields, b"\n\r\n\n", None, "blank")
+
+
+def rand_json_value(rng, depth=0):
+    t = rng.random()
+    if t < 0.25:
+        return rng.choice([0, 1, -1, 7, 255, 256, 65535, 65536, -32769, 2**31, -2**31 - 1, 2**53 + 1, 2**63 - 1, -2**63, 2**64 - 1, 2**64,
+                           1.5, -0.25, 1e10, 1.25e-7, 123456.789, 0.1, 1e22, 1e23, 3.141592653589793])
+    if t < 0.45:
+        return rng.choice(["", "x", "hello world", "12", "-7", "0x1F", "1e3", "true", "F", "2.50", "né", "tab\t", 'q"q', "back\\slash", "<&>", "€", "\U0001F600",
+                           "  7", "1_000", "9223372036854775808", "0.30000000000000004"])
+    if t < 0.55:
+        return rng.choice([True, False, None])
+    if depth < 3 and t < 0.75:
+        return [rand_json_value(rng, depth + 1) for _ in range(rng.randrange(0, 4))]
+    if depth < 3:
+        return {rng.choice(["a", "b", "c d", "é", 'q"']): rand_json_value(rng, depth + 1) for _ in range(rng.randrange(0, 4))}
+    return 1
+
+
+def mutate(rng, line: bytes) -> bytes:
+    if not line:
+        return line
+    i = rng.randrange(len(line))
+    op = rng.random()
+    if op < 0.4:
+        return line[:i] + line[i + 1:]
+    if op < 0.8:
+        return line[:i] + bytes([rng.choice(b'{}[]",:\\ 0a.-e')]) + line[i:]
+    return line[:i] + bytes([rng.choice(b'{}[]",:\\ 0a.-e')]) + line[i + 1:]
+
+
+def test_random_documents_and_mutations(tf, oracle):
+    rng = random.Random(20260923)
+    keys = ["i8", "u16", "i64", "u64", "d", "b", "s", "y", "k", "t", "a", "zz"]
+    lines = []
+    for n in range(6000):
+        doc = {}
+        for key in rng.sample(keys, rng.randrange(1, len(keys))):
+            doc[key] = rand_json_value(rng)
+        if rng.random() < 0.7:
+            doc["k"] = rng.choice([n, str(n), n % 100])
+        sep = rng.choice([(",", ":"), (", ", ": "), (" , ", " : ")])
+        line = json.dumps(doc, ensure_ascii=rng.random() < 0.5, separators=sep).encode("utf-8")
+        if rng.random() < 0.25:
+            line = mutate(rng, line)
+        if b"\n" in line:
+            continue
+        lines.append(line)
+    fields = abi.Schema.of(EDGE_FIELDS)
+    for kw in ({}, {"use_numbers_in_any": True, "null_keys_allowed": True}):
+        opts = abi.json_options(topic="t", **kw)
+        out, errs, nfb = compare(tf, oracle, opts, fields, b"\n".join(lines), None, "fuzz %s" % kw, max_fallback=len(lines))
+        assert out.nrows > 200 and len(errs) > 200
+
+
+def test_flat_lines_are_device_resident(tf, oracle):
+    """The config-3 shape (flat Kafka JSON, one object per message): no line may go to the host."""
+    rng = random.Random(3)
+    fields = abi.Schema.of([["watchid", "int64", True], ["title", "utf8"], ["eventtime", "datetime"], ["clientip", "int32"], ["counterid", "uint32"],
+                            ["isrefresh", "boolean"], ["ratio", "double"], ["url", "string"]])
+    vals = []
+    for n in range(20000):
+        doc = {"watchid": rng.randrange(-2**63, 2**63), "title": rng.choice(["", "Заголовок", "plain title", 'with "quotes" and \\ and /', "tab\there"]),
+               "eventtime": rng.randrange(1_370_000_000, 1_380_000_000), "clientip": rng.randrange(-2**31, 2**31), "counterid": rng.randrange(0, 2**32),
+               "isrefresh": rng.random() < 0.5, "ratio": rng.choice([0.5, 1.25, 100.0, 3.0e-3, 12345.678, 1e15, 7]), "url": "http://example.com/?q=%d" % n}
+        vals.append(json.dumps(doc, ensure_ascii=rng.random() < 0.5).encode("utf-8"))
+    data, msgs = abi.messages(vals, list(range(len(vals))), [1_700_000_000_000_000_000 + i for i in range(len(vals))])
+    opts = abi.json_options(topic="hits", add_dedupe_keys=True, add_rest=True, partition='{"partition":0,"topic":"hits"}')
+    out, errs, nfb = compare(tf, oracle, opts, fields, data, msgs, "flat", max_fallback=0)
+    assert out.nrows == len(vals) and not errs
+    # the same bytes HBM-resident
+    buf = tf.DeviceBuffer.upload(data)
+    db, errs2 = tf.json_parse(opts, fields, buf, msgs)
+    out2 = db.download()
+    assert out2.nrows == out.nrows and not errs2
+    for a, b in zip(out.cols, out2.cols):
+        if a.repr in abi.VAR_REPRS:
+            assert np.array_equal(a.offsets, b.offsets) and bytes(a.data) == bytes(b.data)
+        else:
+            assert bytes(a.values) == bytes(b.values)

@@ -65,6 +65,7 @@ struct Context {
   std::vector<hipEvent_t> free_events;
   std::mutex mu;  // serialises API calls that enqueue on the stream
   int num_cus = 256;
+  std::shared_ptr<struct DevMem> pow10tab;  // math.Pow10(n), n = -323..308 (tf_json.hip)
 
   hipEvent_t get_event();
   void prof_begin(const char *name, Pending &p);

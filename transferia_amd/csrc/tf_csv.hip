@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "tf_devfmt.hpp"
+#include "tf_devparse.hpp"
 #include "tf_plan.hpp"
 
 namespace tf {
@@ -97,40 +98,6 @@ __global__ void __launch_bounds__(NL_THREADS) csv_line_index(const uint8_t *__re
   }
 }
 
-// ---------------------------------------------------------------------------
-// byte readers
-// ---------------------------------------------------------------------------
-// Sequential reader over HBM with an 8-byte register window.
-struct MemBytes {
-  const uint8_t *base;  // 8-byte aligned buffer start
-  uint64_t win; uint64_t widx;
-  __device__ __forceinline__ explicit MemBytes(const uint8_t *b) : base(b), win(0), widx(~0ull) {}
-  __device__ __forceinline__ uint32_t at(uint64_t pos) {
-    uint64_t i = pos >> 3;
-    if (i != widx) { win = reinterpret_cast<const uint64_t *>(base)[i]; widx = i; }
-    return (uint32_t)(win >> ((pos & 7) * 8)) & 0xFFu;
-  }
-};
-// A field view: absolute [start, start+n) through a MemBytes reader (HBM, slow path).
-struct Field {
-  MemBytes *m; uint64_t start; uint32_t n;
-  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return m->at(start + i); }
-};
-// The same over a tile staged in LDS (fast path): one aligned ds_read_b64 per 8 bytes walked.
-struct LdsBytes {
-  const uint8_t *base;  // 8-byte aligned LDS tile
-  uint64_t win; uint32_t widx;
-  __device__ __forceinline__ explicit LdsBytes(const uint8_t *b) : base(b), win(0), widx(~0u) {}
-  __device__ __forceinline__ uint32_t at(uint32_t pos) {
-    uint32_t i = pos >> 3;
-    if (i != widx) { win = reinterpret_cast<const uint64_t *>(base)[i]; widx = i; }
-    return (uint32_t)(win >> ((pos & 7) * 8)) & 0xFFu;
-  }
-};
-struct LField {
-  LdsBytes *m; uint32_t start; uint32_t n;
-  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return m->at(start + i); }
-};
 
 // unicode.IsSpace over UTF-8 at s[i..): width of the space rune or 0
 template <class F> __device__ __forceinline__ uint32_t space_prefix(const F &f, uint32_t i, uint32_t end) {
@@ -203,73 +170,6 @@ template <class F> __device__ __forceinline__ int sanitize(const CsvOpts &o, con
 // ---------------------------------------------------------------------------
 // typed parsers over a Field range [a,b)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lower_(uint32_t c) { return c | 0x20u; }
-__device__ __forceinline__ bool dg(uint32_t c) { return c >= '0' && c <= '9'; }
-
-// strconv/atoi.go underscoreOK over s = f[a..b)
-template <class F> __device__ bool underscore_ok(const F &f, uint32_t a, uint32_t b) {
-  uint32_t saw = '^';
-  uint32_t i = a;
-  if (b - i >= 1 && (f[i] == '-' || f[i] == '+')) i++;
-  bool hex = false;
-  if (b - i >= 2 && f[i] == '0' && (lower_(f[i + 1]) == 'b' || lower_(f[i + 1]) == 'o' || lower_(f[i + 1]) == 'x')) { hex = lower_(f[i + 1]) == 'x'; i += 2; saw = '0'; }
-  for (; i < b; i++) {
-    uint32_t c = f[i];
-    if (dg(c) || (hex && lower_(c) >= 'a' && lower_(c) <= 'f')) { saw = '0'; continue; }
-    if (c == '_') { if (saw != '0') return false; saw = '_'; continue; }
-    if (saw == '_') return false;
-    saw = '!';
-  }
-  return saw != '_';
-}
-
-// strconv.ParseUint(s, base 0 or 10, 64): 0 ok, 1 syntax, 2 range
-template <class F> __device__ int parse_uint64(const F &f, uint32_t a, uint32_t b, bool base0, uint64_t *out) {
-  *out = 0;
-  if (a >= b) return 1;
-  uint32_t s0 = a;
-  uint32_t base = 10;
-  if (base0 && f[a] == '0') {
-    uint32_t n = b - a;
-    uint32_t c1 = n >= 3 ? lower_(f[a + 1]) : 0;
-    if (c1 == 'b') { base = 2; a += 2; } else if (c1 == 'o') { base = 8; a += 2; } else if (c1 == 'x') { base = 16; a += 2; } else { base = 8; a += 1; }
-  }
-  const uint64_t cutoff = 0xFFFFFFFFFFFFFFFFull / base + 1;
-  bool underscores = false;
-  uint64_t v = 0;
-  for (uint32_t i = a; i < b; i++) {
-    uint32_t c = f[i], d;
-    if (c == '_' && base0) { underscores = true; continue; }
-    else if (dg(c)) d = c - '0';
-    else if (lower_(c) >= 'a' && lower_(c) <= 'z') d = lower_(c) - 'a' + 10;
-    else return 1;
-    if (d >= base) return 1;
-    if (v >= cutoff) { *out = ~0ull; return 2; }
-    v *= base;
-    uint64_t v1 = v + d;
-    if (v1 < v) { *out = ~0ull; return 2; }
-    v = v1;
-  }
-  if (underscores && !underscore_ok(f, s0, b)) return 1;
-  *out = v;
-  return 0;
-}
-// strconv.ParseInt(s, base, 64)
-template <class F> __device__ int parse_int64(const F &f, uint32_t a, uint32_t b, bool base0, int64_t *out) {
-  *out = 0;
-  if (a >= b) return 1;
-  bool neg = false;
-  if (f[a] == '+') a++; else if (f[a] == '-') { neg = true; a++; }
-  uint64_t un;
-  int rc = parse_uint64(f, a, b, base0, &un);
-  if (rc == 1) return 1;
-  const uint64_t cutoff = 1ull << 63;
-  if (!neg && un >= cutoff) { *out = (int64_t)(cutoff - 1); return 2; }
-  if (neg && un > cutoff) { *out = (int64_t)cutoff; return 2; }
-  if (rc == 2) return 2;
-  *out = neg ? (int64_t)(0 - un) : (int64_t)un;
-  return 0;
-}
 // spf13/cast trimZeroDecimal: "12.00" → "12"
 template <class F> __device__ __forceinline__ uint32_t trim_zero_decimal(const F &f, uint32_t a, uint32_t b) {
   bool found_zero = false;
@@ -293,22 +193,6 @@ template <class F> __device__ __forceinline__ bool in_list(const CsvOpts &o, int
     if (field_equals(f, a, b, o.list_data + s, e - s)) return true;
   }
   return false;
-}
-// strconv.ParseBool
-template <class F> __device__ __forceinline__ int parse_bool(const F &f, uint32_t a, uint32_t b, int *out) {
-  uint32_t n = b - a;
-  if (n == 1) { uint32_t c = f[a]; if (c == '1' || c == 't' || c == 'T') { *out = 1; return 0; } if (c == '0' || c == 'f' || c == 'F') { *out = 0; return 0; } return 1; }
-  if (n == 4) {
-    uint32_t c0 = f[a], c1 = f[a + 1], c2 = f[a + 2], c3 = f[a + 3];
-    if ((c0 == 'T' && c1 == 'R' && c2 == 'U' && c3 == 'E') || ((c0 == 't' || c0 == 'T') && c1 == 'r' && c2 == 'u' && c3 == 'e')) { *out = 1; return 0; }
-    return 1;
-  }
-  if (n == 5) {
-    uint32_t c0 = f[a], c1 = f[a + 1], c2 = f[a + 2], c3 = f[a + 3], c4 = f[a + 4];
-    if ((c0 == 'F' && c1 == 'A' && c2 == 'L' && c3 == 'S' && c4 == 'E') || ((c0 == 'f' || c0 == 'F') && c1 == 'a' && c2 == 'l' && c3 == 's' && c4 == 'e')) { *out = 0; return 0; }
-    return 1;
-  }
-  return 1;
 }
 
 // cast.StringToDate (spf13/cast v1.7.1 timeFormats) for the fixed numeric shapes:
@@ -1204,6 +1088,25 @@ __global__ void csv_keep_from_err(const uint8_t *err, int64_t n, uint32_t *keep)
 __global__ void csv_shift_rows(const uint32_t *row_start, int64_t n, uint32_t *out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n) out[i] = row_start[i];
+}
+
+// Shared with the JSON ingest (tf_json.hip): out[0] = 0 and out[k] = offset one past the k-th '\n' of
+// data[0, len) (k = 1..n); returns n.  `data` must be 16-byte aligned and zero-padded past len.
+uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out) {
+  hipStream_t st = ctx().stream;
+  const int64_t ntiles = (int64_t)((len + NL_TILE - 1) / NL_TILE);
+  uint32_t n = 0;
+  Buf tile_counts = dalloc((size_t)(ntiles + 1) * 4);
+  if (ntiles) {
+    { KernelTimer t("csv_count_newlines"); csv_count_newlines<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts)); }
+    exclusive_scan_u32(ptr<uint32_t>(tile_counts), ptr<uint32_t>(tile_counts), ntiles, true);
+    const uint32_t *h = d2h_u32(ptr<uint32_t>(tile_counts) + ntiles);
+    tf::sync();
+    n = *h;
+  }
+  *out = dalloc_zero((size_t)(n + 2) * 4);
+  if (n) { KernelTimer t("csv_line_index"); csv_line_index<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ptr<uint32_t>(*out)); }
+  return n;
 }
 
 }  // namespace tf

@@ -27,7 +27,7 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -80,6 +80,9 @@ def load():
     L.tfgpu_csv_options_default.restype = None
     L.tfgpu_csv_parse.argtypes = [C.POINTER(abi.CCsvOptions), C.POINTER(abi.CSchema), P, C.c_uint64, C.c_int, C.POINTER(P),
                                   C.POINTER(C.c_uint64), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_json_parse.argtypes = [C.POINTER(abi.CJsonOptions), C.POINTER(abi.CSchema), P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages),
+                                   C.POINTER(P), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_json_result_schema.argtypes = [C.POINTER(abi.CJsonOptions), C.POINTER(abi.CSchema), C.POINTER(C.POINTER(abi.CSchema))]
     L.tfgpu_serialize.argtypes = [C.c_int, P, C.POINTER(P)]
     L.tfgpu_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(P)]
     L.tfgpu_dbuf_size.argtypes = [P, C.POINTER(C.c_uint64)]
@@ -360,6 +363,37 @@ def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int =
     el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
           for i in range(min(int(nerr.value), max_errors))]
     return DeviceBatch(out), int(consumed.value), el
+
+
+def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data, msgs: Optional[abi.CMessages] = None, max_errors: int = 1 << 16):
+    """GenericParser{Format: "json"}.DoBatch on device (pkg/parsers/generic/generic_parser.go:406-438).
+    `data` is bytes or a DeviceBuffer holding the concatenated Message.Value bytes.
+    Returns (DeviceBatch, errors); errors = (line ordinal, code name, message index, column)."""
+    init()
+    L = load()
+    cs = fields.to_c()
+    out, nerr = C.c_void_p(), C.c_int64(0)
+    errs = (abi.CRowError * max_errors)()
+    mp = C.byref(msgs) if msgs is not None else None
+    if isinstance(data, DeviceBuffer):
+        _check(L.tfgpu_json_parse(C.byref(opts), C.byref(cs), data.ptr, data.size, abi.MEM_DEVICE, mp, C.byref(out), errs, max_errors, C.byref(nerr)))
+    else:
+        buf = np.frombuffer(data, dtype=np.uint8)
+        _check(L.tfgpu_json_parse(C.byref(opts), C.byref(cs), buf.ctypes.data if len(buf) else None, len(buf), abi.MEM_HOST, mp, C.byref(out), errs,
+                                  max_errors, C.byref(nerr)))
+    el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
+          for i in range(min(int(nerr.value), max_errors))]
+    return DeviceBatch(out), el
+
+
+def json_result_schema(opts: abi.CJsonOptions, fields: abi.Schema) -> abi.Schema:
+    """GenericParser.ResultSchema(): the raw fields plus the aux columns the options add."""
+    cs = fields.to_c()
+    out = C.POINTER(abi.CSchema)()
+    _check(load().tfgpu_json_result_schema(C.byref(opts), C.byref(cs), C.byref(out)))
+    s = abi.Schema.from_c(out.contents)
+    load().tfgpu_schema_free(out)
+    return s
 
 
 def serialize(fmt: int, batch: DeviceBatch, opts: Optional[abi.CSerializeOptions] = None) -> DeviceBuffer:
