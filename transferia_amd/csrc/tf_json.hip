@@ -58,9 +58,8 @@ struct JCol {
 };
 
 // open-addressing table over the top-level keys the parser knows: ColPath (or ColumnName) → column
-struct JSlot { uint32_t hash; int32_t col; uint32_t soff, slen; };  // slen == ~0u: empty
+struct JSlot { uint32_t hash; int32_t col; uint32_t soff, slen; uint32_t aux; };  // slen == ~0u: empty; aux: the key is an aux column's name
 static constexpr int32_t JS_KNOWN = -1;  // a known name no column reads through (p.known, :1203-1210)
-static constexpr int32_t JS_AUX = -2;    // name of an aux column (_rest, _timestamp, …)
 static constexpr int32_t JS_UNKNOWN = -3;
 
 struct JParams {
@@ -70,6 +69,7 @@ struct JParams {
   const JCol *cols; int32_t ncols;
   const JSlot *slots; uint32_t slot_mask; const uint8_t *names;
   const double *pow10;   // math.Pow10(n) at [n + 323]
+  const uint64_t *pow128; // {lo, hi} of 10^e, e = -348..347 (Eisel-Lemire)
   uint8_t *linest;       // JLineSt per line
   uint32_t *line_pos;    // start offset per line (message lookup)
   uint8_t add_rest, use_numbers;
@@ -199,9 +199,11 @@ template <class S> __device__ void compact_walk(MemBytes &rd, const uint64_t s, 
   }
 }
 
-// strconv.ParseFloat(s, 64) restricted to the inputs whose result the exact (Clinger) path of atof64exact
-// decides: 0 ok, 1 syntax error, 3 not decided here (hex floats, '_', > 19 digits, large exponents).
-template <class F> __device__ int parse_float_go(const F &f, uint32_t a, const uint32_t b, const double *p10, double *out) {
+// strconv.ParseFloat(s, 64) as atof64 decides it (strconv/atof.go): special(), readFloat, the exact
+// float path (atof64exact), then Eisel-Lemire — also on mantissa+1 when digits were truncated.  What is left
+// for Go's arbitrary-precision fallback (half-way cases, subnormals) is not decided here.
+// 0 ok, 1 syntax error, 2 range error (*out = ±Inf), 3 not decided (also hex floats and '_').
+template <class F> __device__ int parse_float_go(const F &f, uint32_t a, const uint32_t b, const double *p10, const uint64_t *p128, double *out) {
   uint32_t i = a;
   *out = 0;
   if (i >= b) return 1;
@@ -247,29 +249,45 @@ template <class F> __device__ int parse_float_go(const F &f, uint32_t a, const u
   }
   if (i != b) return 1;
   if (mant == 0) { *out = neg ? -0.0 : 0.0; return 0; }
-  if (trunc || nd > 19 || (mant >> 53)) return 3;
+  // decimal.floatBits: beyond these the slow path answers without looking at the digits
+  if (dp > 310) { *out = neg ? -INFINITY : INFINITY; return 2; }
+  if (dp < -330) { *out = neg ? -0.0 : 0.0; return 0; }
   int exp10 = dp - ndm;
-  double v = (double)mant;
-  if (exp10 > 0 && exp10 <= 15 + 22) {
-    if (exp10 > 22) { v *= p10[323 + exp10 - 22]; exp10 = 22; }
-    if (v > 1e15) return 3;
-    v *= p10[323 + exp10];
-  } else if (exp10 < 0 && exp10 >= -22) {
-    v /= p10[323 - exp10];
-  } else if (exp10 != 0) return 3;
-  *out = neg ? -v : v;
+  // 12300000000000000000e-3 and 123e13 are the same number: without trailing zeros the exact path decides
+  // integers Eisel-Lemire cannot (its 10^-k rows are rounded down), with the same correctly rounded result
+  if (!trunc && (mant >> 52)) while (mant % 10 == 0) { mant /= 10; exp10++; }
+  if (!trunc && !(mant >> 52)) {  // atof64exact
+    double v = (double)mant;
+    bool exact = true;
+    if (exp10 > 0 && exp10 <= 15 + 22) {
+      int e = exp10;
+      if (e > 22) { v *= p10[323 + e - 22]; e = 22; }
+      if (v > 1e15) exact = false; else v *= p10[323 + e];
+    } else if (exp10 < 0 && exp10 >= -22) v /= p10[323 - exp10];
+    else if (exp10 != 0) exact = false;
+    if (exact) { *out = neg ? -v : v; return 0; }
+  }
+  uint64_t bits;
+  if (!eisel_lemire64(mant, exp10, p128, &bits)) return 3;
+  if (trunc) {  // the truncated digits may still matter: confirm with the upper bound
+    uint64_t up;
+    if (!eisel_lemire64(mant + 1, exp10, p128, &up) || up != bits) return 3;
+  }
+  if (neg) bits |= 0x8000000000000000ull;
+  *out = __longlong_as_double((long long)bits);
   return 0;
 }
 
 // f, err := strconv.ParseFloat(s, 64); if err != nil && !math.IsInf(f, 0) → 0 (fastfloat's fallback)
-template <class F> __device__ int strconv_or0(const F &f, uint32_t n, const double *p10, double *out) {
-  const int rc = parse_float_go(f, 0, n, p10, out);
+template <class F> __device__ int strconv_or0(const F &f, uint32_t n, const double *p10, const uint64_t *p128, double *out) {
+  const int rc = parse_float_go(f, 0, n, p10, p128, out);
   if (rc == 1) { *out = 0; return 0; }
+  if (rc == 2) return 0;  // ErrRange with ±Inf is kept
   return rc;
 }
 
 // fastfloat.ParseBestEffort: 0 ok, 3 = needs a correctly rounded ParseFloat this file does not carry
-template <class F> __device__ int ff_best_effort(const F &f, const uint32_t n, const double *p10, double *out) {
+template <class F> __device__ int ff_best_effort(const F &f, const uint32_t n, const double *p10, const uint64_t *p128, double *out) {
   *out = 0;
   if (n == 0) return 0;
   uint32_t i = 0;
@@ -283,7 +301,7 @@ template <class F> __device__ int ff_best_effort(const F &f, const uint32_t n, c
     if (!dg(c)) break;
     d = d * 10 + (c - '0');
     i++;
-    if (i > 18) return strconv_or0(f, n, p10, out);
+    if (i > 18) return strconv_or0(f, n, p10, p128, out);
   }
   if (i <= j && f[i] != '.') {
     uint32_t t = i, tn = n - i;
@@ -304,7 +322,7 @@ template <class F> __device__ int ff_best_effort(const F &f, const uint32_t n, c
       if (!dg(c)) break;
       d = d * 10 + (c - '0');
       i++;
-      if (i - j >= 17) return strconv_or0(f, n, p10, out);
+      if (i - j >= 17) return strconv_or0(f, n, p10, p128, out);
     }
     if (i < k) return 0;
     v = (double)d / p10[323 + (i - k)];
@@ -322,7 +340,7 @@ template <class F> __device__ int ff_best_effort(const F &f, const uint32_t n, c
       if (!dg(c)) break;
       exp = exp * 10 + (int)(c - '0');
       i++;
-      if (exp > 300) return strconv_or0(f, n, p10, out);
+      if (exp > 300) return strconv_or0(f, n, p10, p128, out);
     }
     if (i <= j) return 0;
     if (exp_minus) exp = -exp;
@@ -443,10 +461,10 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
       double v = 0;
       if (vtype == V_STR) {  // strconv.ParseFloat(vv, 64)
         if (sv.bs) return false;
-        const int rc = parse_float_go(str, 0, sv.n, p.pow10, &v);
+        const int rc = parse_float_go(str, 0, sv.n, p.pow10, p.pow128, &v);
         if (rc == 3) return false;
         if (rc) st = JC_ERR;
-      } else if (vtype == V_NUM) { if (ff_best_effort(tok, tok.n, p.pow10, &v)) return false; }
+      } else if (vtype == V_NUM) { if (ff_best_effort(tok, tok.n, p.pow10, p.pow128, &v)) return false; }
       if (st == JC_OK) ((double *)c.values)[r] = v;
       break;
     }
@@ -479,7 +497,7 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
         if (p.use_numbers) { if (parse_int64(tok, 0, tok.n, false, &sec)) st = JC_ERR; }  // json.Number → ParseInt(10, 64)
         else {
           double v;
-          if (ff_best_effort(tok, tok.n, p.pow10, &v)) return false;
+          if (ff_best_effort(tok, tok.n, p.pow10, p.pow128, &v)) return false;
           const double a = fabs(v);
           sec = (a >= 9223372036854775808.0 || a != a) ? INT64_MIN : (int64_t)a;  // int64(math.Abs(f)), amd64 CVTTSD2SQ
         }
@@ -529,10 +547,10 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
             if (sl.hash == k.hash && sl.slen == k.n) {
               bool same = true;
               for (uint32_t i = 0; i < k.n && same; i++) same = aux.at(k.s + i) == p.names[sl.soff + i];
-              if (same) { kcol = sl.col; break; }
+              if (same) { kcol = sl.col; if (sl.aux) fallback = true; break; }  // colTypeMap types it as the aux column (:1218-1225): host
             }
           }
-          if (p.add_rest && (kcol == JS_UNKNOWN || kcol == JS_AUX)) fallback = true;  // `_rest` would not be {}
+          if (p.add_rest && kcol == JS_UNKNOWN) fallback = true;  // `_rest` would not be {}
         }
       } else if (ncont == 2 && vtype == V_OBJ && (k.bs || k.ctrl)) kbad = true;
       JSKIPWS();
@@ -775,8 +793,12 @@ static const double *pow10_table() {
       if (n >= 0) { std::snprintf(a, sizeof a, "1e%d", (n / 32) * 32); std::snprintf(b, sizeof b, "1e%d", n % 32); t[(size_t)(n + 323)] = std::strtod(a, nullptr) * std::strtod(b, nullptr); }
       else { std::snprintf(a, sizeof a, "1e-%d", ((-n) / 32) * 32); std::snprintf(b, sizeof b, "1e%d", (-n) % 32); t[(size_t)(n + 323)] = std::strtod(a, nullptr) / std::strtod(b, nullptr); }
     }
-    cx.pow10tab = dalloc(t.size() * 8);
+    static const uint64_t P128[696][2] = {
+#include "tf_pow10_128.inc"
+    };
+    cx.pow10tab = dalloc(t.size() * 8 + sizeof P128);
     h2d(cx.pow10tab->p, t.data(), t.size() * 8);
+    h2d((char *)cx.pow10tab->p + t.size() * 8, P128, sizeof P128);
     tf::sync();
   }
   return ptr<double>(cx.pow10tab);
@@ -863,7 +885,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   for (int i = 0; i < nraw; i++) {
     const tfgpu_colschema &sc = fields->cols[i];
     const std::string name = sc.name ? sc.name : "", path = (sc.path && sc.path[0]) ? sc.path : name;
-    const std::string &key = opts->ignore_column_paths ? name : path;
+    const std::string &key = path;  // makeChangeItem reads item[key.ColPath()] (:351); IgnoreColumnPaths only re-keys colTypeMap / known
     if (key.find('.') != std::string::npos || key.find('/') != std::string::npos)
       return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: column " + name + ": nested ColSchema.Path (lookupComplex) is not device-resident");
     lookup[(size_t)i] = key;
@@ -888,7 +910,28 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
         return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: column " + name + ": DataType is not device-resident for the generic parser");
     }
   }
-  // key table: ColPath (ColumnName with IgnoreColumnPaths) → first column; names / aux names for `_rest`
+  // Unmarshal types a non-string value by colTypeMap[key] — keyed by ColPath (ColumnName with IgnoreColumnPaths)
+  // over the FINAL schema, the last column winning (:1226-1233) — and every column reading that key then runs
+  // ParseVal on the typed value.  Device cells fuse the two steps, which is only the same thing when the key
+  // is typed with the column's own DataType.
+  {
+    std::vector<std::pair<std::string, int>> col_type;
+    auto put = [&](const std::string &k, int t) { for (auto &e : col_type) if (e.first == k) { e.second = t; return; } col_type.push_back({k, t}); };
+    for (int i = 0; i < nraw; i++) {
+      const tfgpu_colschema &sc = fields->cols[i];
+      const std::string name = sc.name ? sc.name : "";
+      put(opts->ignore_column_paths ? name : ((sc.path && sc.path[0]) ? std::string(sc.path) : name), sc.dtype);
+    }
+    for (auto &a : aux) put(a.name, a.dtype);
+    for (int i = 0; i < nraw; i++) {
+      int t = TFGPU_T_INVALID;
+      for (auto &e : col_type) if (e.first == lookup[(size_t)i]) t = e.second;
+      if (t != fields->cols[i].dtype)
+        return tf::fail(TFGPU_ERR_UNSUPPORTED, std::string("json: column ") + (fields->cols[i].name ? fields->cols[i].name : "") +
+                        ": its key is typed through another column's DataType (shared ColPath, or IgnoreColumnPaths with Path != ColumnName)");
+    }
+  }
+  // key table: ColPath → first column reading it; names / aux names for `_rest`
   std::vector<std::pair<std::string, int32_t>> entries;
   for (int i = nraw - 1; i >= 0; i--) {
     int32_t head = -1;
@@ -905,17 +948,19 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
       add_entry(sc.name ? sc.name : "", JS_KNOWN);
       if (!opts->ignore_column_paths) add_entry((sc.path && sc.path[0]) ? sc.path : (sc.name ? sc.name : ""), JS_KNOWN);
     }
-    for (const char *a : {"_rest", "_timestamp", "_partition", "_offset", "_idx"}) add_entry(a, JS_AUX);
+    for (const char *a : {"_rest", "_timestamp", "_partition", "_offset", "_idx"}) add_entry(a, JS_KNOWN);
   }
   uint32_t nslots = 16;
   while (nslots < entries.size() * 2 + 2) nslots <<= 1;
-  std::vector<JSlot> slots(nslots, JSlot{0, 0, 0, ~0u});
+  std::vector<JSlot> slots(nslots, JSlot{0, 0, 0, ~0u, 0});
   std::string names;
   for (auto &e : entries) {
     const uint32_t h = fnv1a_host(e.first);
     uint32_t s = h & (nslots - 1);
     while (slots[s].slen != ~0u) s = (s + 1) & (nslots - 1);
-    slots[s] = JSlot{h, e.second, (uint32_t)names.size(), (uint32_t)e.first.size()};
+    uint32_t is_aux = 0;
+    if (opts->add_rest) for (const char *a : {"_rest", "_timestamp", "_partition", "_offset", "_idx"}) if (e.first == a) is_aux = 1;
+    slots[s] = JSlot{h, e.second, (uint32_t)names.size(), (uint32_t)e.first.size(), is_aux};
     names += e.first;
   }
 
@@ -1020,7 +1065,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   std::memset(&pp, 0, sizeof pp);
   pp.data = data; pp.seg_start = ptr<uint32_t>(seg_start); pp.seg_len = ptr<uint32_t>(seg_len); pp.seg_ord = ptr<uint32_t>(seg_ord); pp.nseg = nseg;
   pp.cols = ptr<JCol>(bcols); pp.ncols = nraw; pp.slots = ptr<JSlot>(bslots); pp.slot_mask = nslots - 1; pp.names = ptr<uint8_t>(bnames);
-  pp.pow10 = pow10_table(); pp.linest = ptr<uint8_t>(linest); pp.line_pos = ptr<uint32_t>(line_pos);
+  pp.pow10 = pow10_table(); pp.pow128 = reinterpret_cast<const uint64_t *>(pp.pow10 + 632); pp.linest = ptr<uint8_t>(linest); pp.line_pos = ptr<uint32_t>(line_pos);
   pp.add_rest = opts->add_rest; pp.use_numbers = opts->use_numbers_in_any;
   if (nlines) { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp); }
 
