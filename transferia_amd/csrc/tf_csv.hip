@@ -18,9 +18,11 @@
 //
 // HBM-bound byte kernel: algorithmic traffic B_csv + B_bin per row.
 #include <algorithm>
+#include <type_traits>
 
 #include "tf_devfmt.hpp"
 #include "tf_devparse.hpp"
+#include "tf_segcopy.hpp"
 #include "tf_plan.hpp"
 
 namespace tf {
@@ -1004,72 +1006,58 @@ __global__ void __launch_bounds__(256) csv_copy_strings(CopyParams p) {
   }
 }
 
-// Tile version of csv_copy_strings: the workgroup that owns a tile's lines stages the same bytes in LDS
-// (coalesced) and moves every string cell of those lines to its final Arrow position; item = column * lines
-// + line, so neighbouring lanes write neighbouring destination bytes.
-struct CopyTileParams {
-  const uint8_t *data; uint64_t len;
-  const uint32_t *tile_base; int64_t ntiles; int64_t skip_rows;
-  const CopyCol *cols; int32_t ncols; uint8_t quote;
-};
-__global__ void __launch_bounds__(CT_THREADS) csv_copy_tiles(CopyTileParams p) {
-  __shared__ __attribute__((aligned(16))) uint8_t sb[CT_BYTES + 16];
-  const int64_t per_xcd = (p.ntiles + 7) / 8;
-  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (tile >= p.ntiles) return;
-  const uint32_t line0 = p.tile_base[tile];
-  const uint32_t nlines = p.tile_base[tile + 1] - line0;
-  if (nlines == 0) return;
-  const int tid = threadIdx.x;
-  const int64_t g0 = tile * CT_T - CT_SPILL;
-#pragma unroll
-  for (int it = 0; it < CT_CPT; it++) {
-    int chunk = it * CT_THREADS + tid;
-    int64_t gp = g0 + (int64_t)chunk * 16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gp >= 0 && (uint64_t)gp < p.len) v = *reinterpret_cast<const uint4 *>(p.data + gp);
-    *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
+// String payloads, destination-centric (tf_segcopy.hpp): blockIdx.y = string column, blockIdx.x = a run of
+// 256 * RPT rows whose cells are pulled straight out of the CSV in HBM at fstart[row].  Cells that are not a plain
+// byte range (doubled quotes, DefaultValue) are zero-filled here and written by csv_copy_special afterwards.
+__device__ __forceinline__ bool cell_plain(uint32_t fsv) { return !(fsv & 0x80000000u) && fsv != 0x7FFFFFFFu; }
+template <int RPT> __global__ void __launch_bounds__(256) csv_copy_words(CopyParams p) {
+  __shared__ uint32_t doff[256 * RPT + 1];
+  __shared__ uint32_t soff[256 * RPT];
+  const CopyCol c = p.cols[blockIdx.y];
+  auto so = [&](int64_t g) { const uint32_t f = c.fstart[g]; return cell_plain(f) ? f : SEG_NONE; };
+  segcopy_run<RPT>(c.offsets, p.nrows, (int64_t)blockIdx.x * 256 * RPT, p.data, c.out, so, doff, soff);
+}
+// Cells csv_copy_words leaves zero-filled: ""-collapse (swapToSingleQuotes, reader.go:307-320) and the
+// DefaultValue of a double (json.Number "0").  lane = row to find them; every flagged cell is then moved by the
+// whole wave, 64 source bytes per step: a quote is dropped iff an odd number of quotes runs directly before it
+// (non-overlapping pairs, left to right), and the survivors are packed through a ballot prefix count.
+__global__ void __launch_bounds__(256) csv_copy_special(CopyParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const CopyCol c = p.cols[blockIdx.y];
+  uint32_t fsv = 0, o0 = 0, n = 0;
+  bool special = false;
+  if (r < p.nrows) {
+    fsv = c.fstart[r];
+    if (!cell_plain(fsv)) {
+      o0 = c.offsets[r]; n = c.offsets[r + 1] - o0;
+      if (n && (fsv & 0x7FFFFFFFu) == 0x7FFFFFFFu) { if (c.is_jsonnum) c.out[o0] = '0'; }
+      else special = n != 0;
+    }
   }
-  __syncthreads();
-  const uint32_t total = (uint32_t)p.ncols * nlines;
-  for (uint32_t it = tid; it < total; it += CT_THREADS) {
-    const uint32_t ci = it / nlines, jj = it - ci * nlines;
-    const int64_t r = (int64_t)line0 + jj - p.skip_rows;
-    if (r < 0) continue;
-    const CopyCol c = p.cols[ci];
-    const uint32_t o0 = c.offsets[r], n = c.offsets[r + 1] - o0;
-    if (!n) continue;
-    const uint32_t fsv = c.fstart[r];
-    uint8_t *dst = c.out + o0;
-    if ((fsv & 0x7FFFFFFFu) == 0x7FFFFFFFu) { if (c.is_jsonnum) dst[0] = '0'; continue; }  // DefaultValue of a double is json.Number("0")
-    const int64_t loc = (int64_t)(fsv & 0x7FFFFFFFu) - g0;
-    if (loc < 0) {  // a line longer than the window (parsed by the per-row path): bytes straight from HBM
-      MemBytes src(p.data);
-      uint64_t sp = fsv & 0x7FFFFFFFu;
-      if (fsv & 0x80000000u) { uint32_t w = 0; while (w < n) { uint32_t ch = src.at(sp); if (ch == p.quote && src.at(sp + 1) == p.quote) { dst[w++] = '"'; sp += 2; } else { dst[w++] = (uint8_t)ch; sp++; } } }
-      else for (uint32_t i = 0; i < n; i++) dst[i] = (uint8_t)src.at(sp + i);
-      continue;
+  uint64_t todo = __ballot(special);
+  const uint64_t below_me = (1ull << lane) - 1;
+  while (todo) {
+    const int l = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const uint64_t s0 = __shfl(fsv, l, 64) & 0x7FFFFFFFu;
+    const uint32_t on = __shfl(n, l, 64);
+    uint8_t *dst = c.out + __shfl(o0, l, 64);
+    uint32_t produced = 0;
+    bool carry = false;  // the previous step ended on a kept quote still waiting for its pair
+    for (uint64_t sp = s0; produced < on; sp += 64) {
+      const uint32_t ch = p.data[sp + lane];
+      const bool isq = ch == p.quote;
+      const uint64_t Q = __ballot(isq);
+      const uint64_t nonq_below = ~Q & below_me;
+      uint32_t before = nonq_below ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)nonq_below)) - 1u : (uint32_t)lane + (carry ? 1u : 0u);
+      const bool dropped = isq && (before & 1u);
+      const uint64_t K = __ballot(!dropped);
+      const uint32_t idx = produced + (uint32_t)__popcll(K & below_me);
+      if (!dropped && idx < on) dst[idx] = (uint8_t)ch;
+      carry = __shfl((int)(isq && !(before & 1u)), 63, 64) != 0;
+      produced += (uint32_t)__popcll(K);
     }
-    uint32_t sp = (uint32_t)loc;
-    if (fsv & 0x80000000u) {  // collapse doubled quotes: "" → "
-      uint32_t w = 0;
-      while (w < n) { const uint32_t ch = sb[sp]; if (ch == p.quote && sb[sp + 1] == p.quote) { dst[w++] = '"'; sp += 2; } else { dst[w++] = (uint8_t)ch; sp++; } }
-      continue;
-    }
-    uint32_t i = 0;
-    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 7)) { dst[i] = sb[sp + i]; i++; }
-    if (i + 8 <= n) {
-      // destination is 8-byte aligned from here: funnel two aligned LDS words into each stored word
-      const uint32_t s0 = sp + i, sh = (s0 & 7u) * 8;
-      const uint64_t *w = reinterpret_cast<const uint64_t *>(sb + (s0 & ~7u));
-      uint64_t lo = *w++;
-      for (; i + 8 <= n; i += 8) {
-        const uint64_t hi = *w++;
-        *reinterpret_cast<uint64_t *>(dst + i) = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-        lo = hi;
-      }
-    }
-    for (; i < n; i++) dst[i] = sb[sp + i];
   }
 }
 
@@ -1337,10 +1325,16 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     KernelTimer t("csv_copy_strings");
     csv_copy_strings<<<blocks_for(nrows, 256), 256, 0, st>>>(cp);
   } else if (nrows && nstr) {
-    CopyTileParams cp{data, len, ptr<uint32_t>(tile_counts), ntiles, skip, ptr<CopyCol>(bcc), nstr, opts->quote_char};
-    const int64_t per_xcd = (ntiles + 7) / 8;
-    KernelTimer t("csv_copy_tiles");
-    csv_copy_tiles<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(cp);
+    // long cells: short runs of rows, several words per lane; short (mostly empty) cells: long runs, so the fixed
+    // latency of a run is spread over enough bytes
+    std::vector<CopyCol> lng, sht;
+    for (int s = 0; s < nstr; s++) (((uint64_t)hsum[2 + s] >= (uint64_t)nrows * 8) ? lng : sht).push_back(cc[(size_t)s]);
+    Buf blng = up(lng.data(), lng.size() * sizeof(CopyCol)), bsht = up(sht.data(), sht.size() * sizeof(CopyCol));
+    KernelTimer t("csv_copy_words");
+    if (!lng.empty()) { CopyParams cp{data, nrows, ptr<CopyCol>(blng), (int32_t)lng.size(), opts->quote_char}; csv_copy_words<1><<<dim3(blocks_for(nrows, 256), (unsigned)lng.size()), 256, 0, st>>>(cp); }
+    if (!sht.empty()) { CopyParams cp{data, nrows, ptr<CopyCol>(bsht), (int32_t)sht.size(), opts->quote_char}; csv_copy_words<8><<<dim3(blocks_for(nrows, 2048), (unsigned)sht.size()), 256, 0, st>>>(cp); }
+    CopyParams cp{data, nrows, ptr<CopyCol>(bcc), nstr, opts->quote_char};
+    csv_copy_special<<<dim3(blocks_for(nrows, 256), (unsigned)nstr), 256, 0, st>>>(cp);
   }
 
   std::unique_ptr<tfgpu_dbatch> result;

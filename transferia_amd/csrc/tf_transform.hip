@@ -10,6 +10,7 @@
 #include "tf_devfmt.hpp"
 #include "tf_plan.hpp"
 #include "tf_devcol.hpp"
+#include "tf_segcopy.hpp"
 
 namespace tf {
 
@@ -443,31 +444,14 @@ __global__ void __launch_bounds__(256) gather_len_all(const GVar *__restrict__ v
   const int32_t s = sel[k];
   for (int i = 0; i < nv; i++) { const uint32_t *off = v[i].in_off; v[i].out_off[k] = off[s + 1] - off[s]; }
 }
-// blockIdx.y = column: a wave moves 64 consecutive kept rows of ONE column, so its lanes see similar lengths
-// (whole waves skip the mostly-empty columns) and write one contiguous destination range.  Bodies move as
-// aligned 8-byte stores fed by two aligned 8-byte loads funnelled to the destination's alignment.
-__global__ void __launch_bounds__(256) gather_bytes_all(const GVar *__restrict__ v, int nv, const int32_t *__restrict__ sel, int64_t m) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= m) return;
+// Payload bytes of the kept rows, destination-centric (tf_segcopy.hpp): blockIdx.y = column, blockIdx.x = a run of
+// 256 * RPT kept rows, whose cells are contiguous in the output and are fetched through the selection vector.
+template <int RPT> __global__ void __launch_bounds__(256) gather_bytes_all(const GVar *__restrict__ v, const int32_t *__restrict__ sel, int64_t m) {
+  __shared__ uint32_t doff[256 * RPT + 1];
+  __shared__ uint32_t soff[256 * RPT];
   const GVar g = v[blockIdx.y];
-  const int32_t s = sel[k];
-  const uint32_t a = g.in_off[s], n = g.in_off[s + 1] - a;
-  if (!n) return;
-  const uint8_t *src = g.in_data + a; uint8_t *dst = g.out_data + g.out_off[k];
-  uint32_t j = 0;
-  while (j < n && (reinterpret_cast<uintptr_t>(dst + j) & 7)) { dst[j] = src[j]; j++; }
-  if (j + 8 <= n) {
-    const uintptr_t sa = reinterpret_cast<uintptr_t>(src + j);
-    const uint32_t sh = (uint32_t)(sa & 7) * 8;
-    const uint64_t *w = reinterpret_cast<const uint64_t *>(sa & ~(uintptr_t)7);  // every payload block has >= 16 bytes of slack
-    uint64_t lo = *w++;
-    for (; j + 8 <= n; j += 8) {
-      const uint64_t hi = *w++;
-      *reinterpret_cast<uint64_t *>(dst + j) = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-      lo = hi;
-    }
-  }
-  for (; j < n; j++) dst[j] = src[j];
+  auto so = [&](int64_t k) { return g.in_off[sel[k]]; };
+  segcopy_run<RPT>(g.out_off, m, (int64_t)blockIdx.x * 256 * RPT, g.in_data, g.out_data, so, doff, soff);
 }
 __global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int64_t m, int nv, uint32_t *out) {
   for (int s = threadIdx.x; s < nv; s += blockDim.x) out[s] = lens_all[(int64_t)s * seg_stride + m];
@@ -516,7 +500,13 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
     Buf bvr = upload_small(vr.data(), vr.size() * sizeof(GVar));
     if (m) gather_len_all<<<g, 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), m, nvar, seg_stride);
-    if (m) gather_bytes_all<<<dim3(g, (unsigned)nvar), 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
+    if (m) {  // long cells: short runs of rows; short cells: long runs (the fixed latency of a run needs bytes to amortise over)
+      std::vector<GVar> lng, sht;
+      for (size_t i = 0; i < vr.size(); i++) ((in.cols[var_cols[i]].data_len >= (uint64_t)in.nrows * 8) ? lng : sht).push_back(vr[i]);
+      Buf blng = upload_small(lng.data(), lng.size() * sizeof(GVar)), bsht = upload_small(sht.data(), sht.size() * sizeof(GVar));
+      if (!lng.empty()) gather_bytes_all<1><<<dim3(grid_for(m, 256), (unsigned)lng.size()), 256, 0, st>>>(ptr<GVar>(blng), sp, m);
+      if (!sht.empty()) gather_bytes_all<8><<<dim3(grid_for(m, 2048), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
+    }
     Buf tot = dalloc((size_t)nvar * 4);
     collect_totals<<<1, 64, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, m, nvar, ptr<uint32_t>(tot));
     const uint32_t *h = d2h_u32(tot->p, (size_t)nvar);
