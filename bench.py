@@ -155,6 +155,7 @@ def main():
         "csv_parse_tiles": csv_bytes + fixed_b,           # same work, tile-cooperative kernel
         "csv_copy_strings": 2 * str_b,                    # string payload: one read + one write
         "csv_copy_tiles": 2 * str_b,
+        "csv_copy_words": 2 * str_b,
         "scan_u32_segments": 12 * rows * 28,
         "mask_hmac_sha256": 72 * rows,                    # 4 B in + 64 B hex + 4 B offset per value
         "filter_rows_eval": int((8 + 4 + 0.125) * rows),  # time value + keep flag

@@ -33,8 +33,8 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 // line index
 // ---------------------------------------------------------------------------
 static constexpr int NL_THREADS = 256;
-static constexpr int NL_ITERS = 4;
-static constexpr int NL_TILE = NL_THREADS * 16 * NL_ITERS;  // 16 KiB per workgroup
+static constexpr int NL_ITERS = 7;
+static constexpr int NL_TILE = NL_THREADS * 16 * NL_ITERS;  // 28 KiB per workgroup
 
 __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
   // bit i set iff byte i of the 16-byte chunk is '\n'
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(64) csv_parse_listed(CsvParams p) {
 // ---------------------------------------------------------------------------
 static constexpr int CT_THREADS = 512;
 static constexpr int CT_T = NL_TILE;            // bytes whose '\n' this workgroup owns
-static constexpr int CT_SPILL = 8192;           // look-behind: longest line staged in LDS
+static constexpr int CT_SPILL = 4096;           // look-behind: longest line staged in LDS
 static constexpr int CT_BYTES = CT_T + CT_SPILL;
 static constexpr int CT_CPT = CT_BYTES / 16 / CT_THREADS;  // 16-byte chunks per thread (blocked)
 static constexpr int CT_FCAP = 4096;            // field ends indexed per pass
@@ -570,33 +570,50 @@ __device__ __forceinline__ uint32_t count_quote_pairs(const uint32_t *qmask, uin
   }
   return pairs;
 }
-// n decimal digits starting at byte i0 of the 24-byte little-endian window (b0,b1,b2); false if a non-digit shows up
+// Decimal text → integer without a per-digit loop.  `t` holds up to 8 digit VALUES (0..9), one per byte, most
+// significant digit in byte 0, zero-padded at the front: pairs → fours → eight, all in full-rate 24-bit multiplies.
+__device__ __forceinline__ uint32_t four_digits(uint32_t x) {
+  const uint32_t pairs = __umul24(x & 0x00FF00FFu, 10u) + ((x >> 8) & 0x00FF00FFu);  // b0*10+b1 | (b2*10+b3) << 16
+  return __umul24(pairs & 0xFFFFu, 100u) + (pairs >> 16);
+}
+__device__ __forceinline__ uint32_t eight_digits(uint64_t t) { return __umul24(four_digits((uint32_t)t), 10000u) + four_digits((uint32_t)(t >> 32)); }
+// every byte of d (= text ^ '0' per byte) is a digit value
+__device__ __forceinline__ bool all_digits(uint64_t d) { return (((d + 0x7676767676767676ull) | d) & 0x8080808080808080ull) == 0; }
+// n characters at bytes [0, n) of the 24-byte little-endian window (b0,b1,b2); the first i0 (0 or 1) are a sign,
+// the other nd = n - i0 (1..19) must be decimal digits.  false if a non-digit shows up.
 __device__ __forceinline__ bool digits_u64(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t i0, uint32_t n, uint64_t *out) {
-  bool ok = true;
-  uint32_t lo = 0;  // first 9 digits accumulate in 32 bits
-  uint64_t v = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const uint32_t d = ((uint32_t)(b0 >> (8 * i)) & 0xFFu) - '0';
-    if ((uint32_t)i >= i0 && (uint32_t)i < n) { ok = ok && d <= 9u; lo = lo * 10 + d; }
+  const uint64_t K = 0x3030303030303030ull;
+  const bool sane = n > i0 && n - i0 <= 19;
+  const uint32_t nd = sane ? n - i0 : 1u;
+  const uint64_t s0 = i0 ? (b0 >> 8) | (b1 << 56) : b0;
+  if (!__any(nd > 8)) {  // the common case: the whole wave parses short numbers
+    uint64_t d = (s0 ^ K) & (nd >= 8 ? ~0ull : (1ull << (8 * nd)) - 1);
+    const bool ok = all_digits(d);
+    d <<= 8 * (8 - (nd > 8 ? 8 : nd));
+    *out = eight_digits(d);
+    return ok && sane;
   }
-  v = lo;
-  if (__any(n > 8)) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const uint32_t d = ((uint32_t)(b1 >> (8 * i)) & 0xFFu) - '0';
-      if ((uint32_t)(8 + i) < n) { ok = ok && d <= 9u; v = v * 10 + d; }
-    }
-    if (__any(n > 16)) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const uint32_t d = ((uint32_t)(b2 >> (8 * i)) & 0xFFu) - '0';
-        if ((uint32_t)(16 + i) < n) { ok = ok && d <= 9u; v = v * 10 + d; }
-      }
+  const uint64_t s1 = i0 ? (b1 >> 8) | (b2 << 56) : b1, s2 = i0 ? b2 >> 8 : b2;
+  // groups of 8 digits from the right; the leftmost group has g1 = nd - 8 * (groups - 1) digits
+  const uint32_t ng = nd > 16 ? 3u : nd > 8 ? 2u : 1u;
+  const uint32_t g1 = nd - 8 * (ng - 1);  // 1..8
+  uint64_t d1 = (s0 ^ K) & (g1 >= 8 ? ~0ull : (1ull << (8 * g1)) - 1);
+  bool ok = all_digits(d1);
+  d1 <<= 8 * (8 - g1);
+  uint64_t v = eight_digits(d1);
+  if (ng >= 2) {
+    const uint32_t sh = 8 * g1;  // 8..64
+    const uint64_t d2 = (sh == 64 ? s1 : (s0 >> sh) | (s1 << (64 - sh))) ^ K;
+    ok = ok && all_digits(d2);
+    v = v * 100000000ull + eight_digits(d2);
+    if (ng == 3) {
+      const uint64_t d3 = (sh == 64 ? s2 : (s1 >> sh) | (s2 << (64 - sh))) ^ K;
+      ok = ok && all_digits(d3);
+      v = v * 100000000ull + eight_digits(d3);
     }
   }
   *out = v;
-  return ok;
+  return ok && sane;
 }
 __device__ __forceinline__ uint32_t two_digits(uint64_t w, int byte, bool *ok) {
   const uint32_t a = ((uint32_t)(w >> (8 * byte)) & 0xFFu) - '0', b = ((uint32_t)(w >> (8 * byte + 8)) & 0xFFu) - '0';
@@ -619,6 +636,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
   __shared__ uint64_t tcol_lds[CT_LCOLS * 3];
   __shared__ uint32_t wtmp[CT_THREADS / 64];
   __shared__ uint32_t wmax[CT_THREADS / 64];
+  __shared__ uint32_t wcnt[CT_THREADS / 64];
 
   // XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
   const int64_t per_xcd = (p.ntiles + 7) / 8;
@@ -703,7 +721,6 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
     if (g0 <= 0) frs = (int)(-g0);  // the buffer starts inside the window: line 0 starts at absolute 0
     else first_long = true;         // the first line started before the window: per-row path
   }
-  __syncthreads();
 
   // ---- select the hypothesis, drop what precedes the first line, count ----
   uint32_t fe[CT_CPT];  // field ends: unquoted delimiters and '\n'
@@ -723,19 +740,41 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
     uint32_t t = __shfl_up(cinc, d, 64);
     if (lane >= d) cinc += t;
   }
-  if (lane == 63) wtmp[wv] = cinc;
+  if (lane == 63) wcnt[wv] = cinc;
   __syncthreads();
   uint32_t cpre = 0, ctot = 0;
-  for (int i = 0; i < CT_THREADS / 64; i++) { uint32_t x = wtmp[i]; if (i < wv) cpre += x; ctot += x; }
+  for (int i = 0; i < CT_THREADS / 64; i++) { uint32_t x = wcnt[i]; if (i < wv) cpre += x; ctot += x; }
   const uint32_t cex = cpre + cinc - cnt;
   const uint32_t k_thread = cex & 0xFFFFu, j_thread = cex >> 16;  // ordinal / line of this thread's first field end
   const uint32_t nl_tot = ctot >> 16;                             // == nlines by construction
-  __syncthreads();
+  // the usual tile: every field end fits the index and every line the window → one indexing sweep, no search
+  const bool onepass = !first_long && (ctot & 0xFFFFu) <= (uint32_t)CT_FCAP && nl_tot <= (uint32_t)CT_RCAP;
 
   // ---- passes over the lines of this tile ----
   uint32_t jb = 0, kb = 0;
   uint32_t bstart = (uint32_t)frs;  // first byte of line jb
   while (jb < nl_tot) {
+    uint32_t nr = 0, kend = 0;
+    bool skip_first = false;
+    if (onepass) {
+      uint32_t k = k_thread, j = j_thread;
+#pragma unroll
+      for (int q = 0; q < CT_CPT; q++) {
+        uint32_t m = fe[q];
+        const int cpos = (base_chunk + q) * 16;
+        while (m) {
+          const int b = __ffs((int)m) - 1; m &= m - 1;
+          const uint32_t isnl = (nlm[q] >> b) & 1u;
+          fpos[k] = (uint16_t)((cpos + b) | (isnl << 15));
+          if (isnl) rowend[j++] = (uint16_t)k;
+          k++;
+        }
+      }
+      nr = nl_tot;
+      for (uint32_t i = tid; i < nr; i += CT_THREADS) slowf[i] = 0;
+      __syncthreads();
+      kend = rowend[nr - 1];  // field ends past the last '\n' belong to the next tile's first line
+    } else {
     // pass 1: ordinal of each line's '\n' for lines [jb, jb+CT_RCAP)
     {
       uint32_t k = k_thread, j = j_thread;
@@ -754,15 +793,14 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
     __syncthreads();
     const uint32_t nwin = min((uint32_t)CT_RCAP, nl_tot - jb);
     // lines that fit the field index: rowend is increasing, count entries below the cap
-    uint32_t nr = 0;
     {
       uint32_t lo = 0, hi = nwin;  // first index whose last field does not fit
       while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((uint32_t)rowend[mid] - kb < (uint32_t)CT_FCAP) lo = mid + 1; else hi = mid; }
       nr = lo;
     }
-    const bool skip_first = (jb == 0 && first_long) || nr == 0;  // line handled by the per-row path
+    skip_first = (jb == 0 && first_long) || nr == 0;  // line handled by the per-row path
     if (skip_first) nr = 1;
-    const uint32_t kend = rowend[nr - 1];
+    kend = rowend[nr - 1];
     // pass 2: positions of the field ends [kb, kend]
     if (!skip_first) {
       uint32_t k = k_thread;
@@ -779,6 +817,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
     }
     for (uint32_t i = tid; i < nr; i += CT_THREADS) slowf[i] = 0;
     __syncthreads();
+    }
     if (p.ablate == 3) { if (fpos[tid] == 0xFFFF && rowend[0] == 0xFFFF) p.err[0] = 1; return; }
 
     uint32_t next_bstart;
