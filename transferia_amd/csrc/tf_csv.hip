@@ -621,6 +621,20 @@ __device__ __forceinline__ uint32_t two_digits(uint64_t w, int byte, bool *ok) {
   return a * 10 + b;
 }
 
+// 0x80 in every byte of w equal to the byte replicated in pat4 (exact: no borrow between bytes)
+__device__ __forceinline__ uint32_t eq80(uint32_t w, uint32_t pat4) {
+  const uint32_t x = w ^ pat4;
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+// the 0x80 flags of 16 bytes (four words) as a 16-bit mask: v_dot4_u32_u8 with weights 1,2,4,8 sums each word's
+// flags to nibble << 7
+__device__ __forceinline__ uint32_t dense16(uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3) {
+  const uint32_t W = 0x08040201u;
+  const uint32_t d0 = __builtin_amdgcn_udot4(z0, W, 0u, false), d1 = __builtin_amdgcn_udot4(z1, W, 0u, false);
+  const uint32_t d2 = __builtin_amdgcn_udot4(z2, W, 0u, false), d3 = __builtin_amdgcn_udot4(z3, W, 0u, false);
+  return (d0 >> 7) | (d1 >> 3) | (d2 << 1) | (d3 << 5);
+}
+
 // quote-state functions on one bit: bit0 = f(0), bit1 = f(1); identity = 0b10
 __device__ __forceinline__ uint32_t qf_compose(uint32_t first, uint32_t then) {
   return ((then >> (first & 1)) & 1u) | (((then >> ((first >> 1) & 1)) & 1u) << 1);
@@ -671,23 +685,53 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
   uint32_t st = 2u;           // function of this thread's bytes (starts as identity)
   int last_lb_nl = -1;        // last '\n' inside the look-behind window
   {
+    // 16 bytes at a time: per-byte equality flags by SWAR, packed to 16-bit masks with v_dot4, quote parity by
+    // a prefix xor.  Only a chunk where an escape character directly precedes a quote walks its bytes.
+    const uint32_t q4 = o.quote * 0x01010101u, d4 = o.delim * 0x01010101u, e4 = o.escape * 0x01010101u;
     bool prev_esc = false;
     if (o.escape != 0 && base_chunk > 0) prev_esc = sb[base_chunk * 16 - 1] == o.escape;
 #pragma unroll
     for (int q = 0; q < CT_CPT; q++) {
       const uint4 v = *reinterpret_cast<const uint4 *>(sb + (base_chunk + q) * 16);
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-      uint32_t f0 = 0, f1 = 0, nl = 0, qm = 0;
+      const uint32_t qm = dense16(eq80(v.x, q4), eq80(v.y, q4), eq80(v.z, q4), eq80(v.w, q4));
+      const uint32_t dm = dense16(eq80(v.x, d4), eq80(v.y, d4), eq80(v.z, d4), eq80(v.w, d4));
+      const uint32_t nl = dense16(eq80(v.x, 0x0A0A0A0Au), eq80(v.y, 0x0A0A0A0Au), eq80(v.z, 0x0A0A0A0Au), eq80(v.w, 0x0A0A0A0Au));
+      const uint32_t em = o.escape != 0 ? dense16(eq80(v.x, e4), eq80(v.y, e4), eq80(v.z, e4), eq80(v.w, e4)) : 0u;
+      uint32_t f0 = 0, f1 = 0;
+      if ((((em << 1) | (prev_esc ? 1u : 0u)) & qm) != 0) {  // `\"`: splitString's escape rule (reader.go:233-240), byte by byte
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        bool pe = prev_esc;
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-        const bool isq = c == o.quote;  // quote != 0 on this path
-        qm |= (isq ? 1u : 0u) << i;
-        if (c == '\n') { st = 0u; nl |= 1u << i; }
-        else if (isq) st = prev_esc ? 3u : (st ^ 3u);
-        else if (c == o.delim) { f0 |= ((~st) & 1u) << i; f1 |= ((~st >> 1) & 1u) << i; }
-        prev_esc = o.escape != 0 && c == o.escape;
+        for (int i = 0; i < 16; i++) {
+          const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+          if (c == '\n') st = 0u;
+          else if (c == o.quote) st = pe ? 3u : (st ^ 3u);
+          else if (c == o.delim) { f0 |= ((~st) & 1u) << i; f1 |= ((~st >> 1) & 1u) << i; }
+          pe = c == o.escape;
+        }
+      } else {
+        uint32_t px = qm;  // px bit i = parity of the quotes in bytes [0, i]
+        px ^= px << 1; px ^= px << 2; px ^= px << 4; px ^= px << 8;
+        px &= 0xFFFFu;
+        uint32_t s0 = (st & 1u) ? 0xFFFFu : 0u, s1 = (st & 2u) ? 0xFFFFu : 0u;  // in-quotes entering the chunk, per hypothesis
+        if (nl == 0) {
+          f0 = dm & ~(px ^ s0); f1 = dm & ~(px ^ s1);
+          if (__popc(qm) & 1) st ^= 3u;
+        } else {  // every '\n' ends the line and the quote state with it
+          uint32_t m = nl, start = 0, base = 0;
+          while (m) {
+            const uint32_t b = (uint32_t)__ffs((int)m) - 1; m &= m - 1;
+            const uint32_t seg = ((1u << b) - 1u) & ~((1u << start) - 1u);
+            f0 |= dm & ~(px ^ base ^ s0) & seg; f1 |= dm & ~(px ^ base ^ s1) & seg;
+            base = ((px >> b) & 1u) ? 0xFFFFu : 0u; s0 = 0; s1 = 0; start = b + 1;
+          }
+          const uint32_t seg = 0xFFFFu & ~((1u << start) - 1u);
+          const uint32_t t = dm & ~(px ^ base) & seg;
+          f0 |= t; f1 |= t;
+          st = (((px >> 15) ^ base) & 1u) ? 3u : 0u;
+        }
       }
+      prev_esc = (em >> 15) & 1u;
       fe01[q] = f0 | (f1 << 16);
       nlm[q] = nl;
       reinterpret_cast<uint16_t *>(qmask)[base_chunk + q] = (uint16_t)qm;
