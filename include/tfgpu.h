@@ -140,6 +140,11 @@ typedef struct tfgpu_batch {
                              NULL on input = identity                         */
   uint32_t *part_id;      /* outputs of sharder_transformer: PartID = itoa()  */
   int32_t mem;            /* TFGPU_MEM_HOST / TFGPU_MEM_DEVICE                */
+  const tfgpu_schema *schema; /* ChangeItem.TableSchema of the run (columns in schema
+                             order), or NULL = the batch columns in their order.
+                             Transformers that walk the SCHEMA and look values up
+                             by name (sharder.go:134-143) need it when ColumnNames
+                             and TableSchema differ.               */
 } tfgpu_batch;
 
 /* Per-row failure, the C image of abstract.TransformerError

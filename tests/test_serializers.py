@@ -131,6 +131,19 @@ def test_gpu_serialize_unsupported_and_empty(tf, oracle):
     with pytest.raises(tf.TfgpuError) as ei:
         tf.serialize(abi.FMT_JSON, tf.DeviceBatch.upload(b))
     assert ei.value.code == tf.ERR_UNSUPPORTED
+    # strconv.FormatFloat(f, 'f', -1): ClickHouse numeric columns and the CSV serializer render Go floats on device
+    import random
+    import struct
+    rng = random.Random(9)
+    vals = [1.5, -0.0, 0.1, 1e21, 1e-7, 123456789.125, 5e-324, 1.7976931348623157e308] + [struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0] for _ in range(3000)]
+    vals = [v for v in vals if v == v and abs(v) != float("inf")]
+    s2 = abi.Schema.of([["f", "double", False], ["g", "float", False], ["i", "int64", True]])
+    rows = [[["float64", v], ["float32", float(np.float32(rng.uniform(-1e6, 1e6)))], ["int64", k]] for k, v in enumerate(vals)]
+    b2 = abi.batch_from_rows(s2, ["f", "g", "i"], rows, "", "t")
+    for fmt in (abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
+        ref = oracle.serialize(fmt, b2, s2)
+        assert ref is not None
+        assert tf.serialize(fmt, tf.DeviceBatch.upload(b2)).download() == ref
     e = abi.Batch([abi.Column("a", "int32", abi.R_INT32, values=np.zeros(0, np.int32))], 0, "", "t")
     for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
         assert tf.serialize(fmt, tf.DeviceBatch.upload(e)).download() == b""

@@ -24,6 +24,7 @@ def item_to_batch(item):
         b = abi.Batch([], 1, item.get("ns", ""), item.get("table", ""))
     else:
         b = abi.batch_from_rows(schema, item["names"], rows, item.get("ns", ""), item.get("table", ""), item.get("kinds"))
+    b.schema = schema  # the item's TableSchema travels with the batch (ColumnNames may differ from it)
     return b, schema
 
 

@@ -61,7 +61,7 @@ class CColumn(C.Structure):
 class CBatch(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int32), ("cols", C.POINTER(CColumn)), ("table_ns", C.c_char_p),
                 ("table_name", C.c_char_p), ("kind", C.c_void_p), ("src_row", C.c_void_p), ("part_id", C.c_void_p),
-                ("mem", C.c_int32)]
+                ("mem", C.c_int32), ("schema", C.POINTER(CSchema))]
 
 
 class CRowError(C.Structure):
@@ -299,6 +299,10 @@ class Batch:
         ns, tn = _b(self.table_ns), _b(self.table_name)
         keep += [ns, tn]
         cb.table_ns, cb.table_name, cb.mem = ns, tn, MEM_HOST
+        if getattr(self, "schema", None) is not None:  # ChangeItem.TableSchema when it differs from ColumnNames
+            cs = self.schema.to_c()
+            keep.append(cs)
+            cb.schema = C.pointer(cs)
         if self.kind is not None:
             k = np.ascontiguousarray(self.kind, dtype=np.uint8)
             keep.append(k)

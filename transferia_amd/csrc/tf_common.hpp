@@ -134,6 +134,7 @@ struct DColumn {
 struct tfgpu_dbatch {
   int64_t nrows = 0;
   std::vector<tf::DColumn> cols;
+  std::vector<std::pair<std::string, int>> schema;  // TableSchema (name, DataType) in order; empty = same as cols
   std::string ns, table;
   tf::Buf kind, src_row, part_id;
 };

@@ -270,6 +270,7 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
     if (c.validity) d.validity = upload(c.validity, (n + 7) / 8);
     b->cols.push_back(std::move(d));
   }
+  if (h->schema) for (int i = 0; i < h->schema->ncols; i++) b->schema.push_back({h->schema->cols[i].name ? h->schema->cols[i].name : "", h->schema->cols[i].dtype});
   if (h->kind) b->kind = upload(h->kind, n);
   if (h->src_row) b->src_row = upload(h->src_row, n * 4);
   tf::sync();  // caller may release its buffers as soon as we return
@@ -298,6 +299,7 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   v->table_ns = b->ns.c_str(); v->table_name = b->table.c_str();
   v->kind = ptr<uint8_t>(b->kind); v->src_row = ptr<int32_t>(b->src_row); v->part_id = ptr<uint32_t>(b->part_id);
   v->mem = TFGPU_MEM_DEVICE;
+  v->schema = nullptr;
   return TFGPU_OK;
   TF_API_END
 }

@@ -16,6 +16,7 @@
 
 #include "tf_devcol.hpp"
 #include "tf_devfmt.hpp"
+#include "tf_devfloat.hpp"
 
 namespace tf {
 
@@ -111,6 +112,12 @@ template <class S> __device__ void emit_base64(S &s, const uint8_t *p, uint32_t 
 
 template <class S> __device__ __forceinline__ void emit_small(S &s, const uint8_t *t, int n) { for (int i = 0; i < n; i++) s.put(t[i]); }
 
+// strconv.FormatFloat(f, 'f', -1, bits) of a float column's value
+template <class S> __device__ void emit_float_f(S &s, const DCol &c, int64_t r) {
+  if (c.repr == TFGPU_R_FLOAT32) dev::fmt_float(s, (double)((const float *)c.values)[r], 'f', 32);
+  else dev::fmt_float(s, ((const double *)c.values)[r], 'f', 64);
+}
+
 // The integer Go types as decimal text; returns false if the column is not an integer repr.
 template <class S> __device__ bool emit_int(S &s, const DCol &c, int64_t r) {
   uint8_t t[24]; int n;
@@ -199,6 +206,7 @@ template <class S> __device__ bool emit_ch_value(S &s, const SCol &sc, int64_t r
     case TFGPU_T_UINT32: case TFGPU_T_UINT64: case TFGPU_T_FLOAT32: case TFGPU_T_FLOAT64: case TFGPU_T_INTERVAL: {
       const bool q = fl & TFGPU_CH_STRING;
       if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) { if (q) s.put('"'); emit_int(s, c, r); if (q) s.put('"'); return true; }
+      if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { if (q) s.put('"'); emit_float_f(s, c, r); if (q) s.put('"'); return true; }
       if (c.repr == TFGPU_R_JSONNUM) {
         if (q) s.put('"');
         const int o = jsonnum_overflow(vp, vn);
@@ -312,6 +320,7 @@ template <class S> __device__ void emit_csv_field(S &s, const SCol &sc, int64_t 
     case TFGPU_R_BOOL: put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); return;
     case TFGPU_R_TIME: { int n = dev::fmt_time_string(t, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); emit_small(s, t, n); return; }  // fmt.Stringer
     case TFGPU_R_DURATION: { int n = dev::fmt_duration(t, ((const int64_t *)c.values)[r]); emit_small(s, t, n); return; }
+    case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_f(s, c, r); return;
     default: emit_int(s, c, r);
   }
 }
@@ -440,7 +449,14 @@ static void require_supported(int format, const DColumn &c, int any_as_string) {
   auto bad = [&](const char *why) {
     throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_serialize: column " + c.name + ": " + why);
   };
-  if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) bad("Go float values (shortest-float formatting is not device-resident yet)");
+  if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) {
+    // strconv.FormatFloat(f, 'f', -1, bits) is on device: marshalNumericValue (marshal.go:257-301) and castx.ToStringE
+    // (caste.go:57-106).  json.Marshal of a Go float (encoding/json's float text) under other DataTypes stays on the host.
+    const bool numeric = (c.dtype >= TFGPU_T_INT8 && c.dtype <= TFGPU_T_FLOAT64) || c.dtype == TFGPU_T_INTERVAL;
+    if (format == TFGPU_FMT_CH_JSON_EACH_ROW) { if (!numeric) bad("Go float under a non-numeric DataType (generic json.Marshal path)"); }
+    else if (format == TFGPU_FMT_CSV) { if (c.dtype == TFGPU_T_ANY || c.dtype == TFGPU_T_BYTES) bad("Go float under `any` / \"string\""); }
+    else bad("Go float values in the generic JSON serializer (encoding/json float text)");
+  }
   if (format == TFGPU_FMT_CH_JSON_EACH_ROW) {
     const bool temporal = c.dtype == TFGPU_T_DATE || c.dtype == TFGPU_T_DATETIME || c.dtype == TFGPU_T_TIMESTAMP;
     if (c.repr == TFGPU_R_TIME && !temporal) bad("time.Time under a non-temporal DataType (generic JSON fallback)");

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "tf_devfmt.hpp"
+#include "tf_devfloat.hpp"
 #include "tf_plan.hpp"
 #include "tf_devcol.hpp"
 #include "tf_segcopy.hpp"
@@ -47,6 +48,9 @@ __device__ __forceinline__ int serialize_small(const DCol &c, int64_t r, uint8_t
       return dev::fmt_time_string(buf, s, ns);
     }
     case TFGPU_R_DURATION: return dev::fmt_duration(buf, ((const int64_t *)c.values)[r]);
+    // fmt.Sprintf("%v", float): %g with the shortest digits (to_string.go:170), at most 24 bytes
+    case TFGPU_R_FLOAT32: { dev::StoreOut so{buf}; dev::fmt_float(so, (double)((const float *)c.values)[r], 'g', 32); return (int)so.n; }
+    case TFGPU_R_FLOAT64: { dev::StoreOut so{buf}; dev::fmt_float(so, ((const double *)c.values)[r], 'g', 64); return (int)so.n; }
     case TFGPU_R_STRING: case TFGPU_R_JSONNUM: case TFGPU_R_JSON: case TFGPU_R_BYTES: {
       uint32_t a = c.offsets[r], b = c.offsets[r + 1];
       *ext = c.data + a;
@@ -57,8 +61,6 @@ __device__ __forceinline__ int serialize_small(const DCol &c, int64_t r, uint8_t
 }
 // Host-side check: can serialize_small reproduce SerializeToString for this column?
 static void require_serializable(const DColumn &c, const char *what) {
-  if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64)
-    throw Error(TFGPU_ERR_UNSUPPORTED, std::string(what) + ": column " + c.name + " holds Go floats; shortest-float formatting is not device-resident yet");
   if (c.repr == TFGPU_R_BYTES && c.dtype != TFGPU_T_BYTES)
     throw Error(TFGPU_ERR_UNSUPPORTED, std::string(what) + ": column " + c.name + " holds []byte under a non-\"string\" DataType (%v prints a byte list)");
   if (c.repr == TFGPU_R_STRING && c.dtype == TFGPU_T_ANY)
@@ -166,6 +168,7 @@ static std::unique_ptr<tfgpu_dbatch> shallow_copy(const tfgpu_dbatch &in) { retu
 
 static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu_dbatch &in) {
   auto out = shallow_copy(in);
+  for (auto &sc : out->schema) if (p.mask_has(sc.first)) sc.second = TFGPU_T_UTF8;  // hmac_hasher.go:35-46
   hipStream_t st = ctx().stream;
   for (auto &c : out->cols) {
     if (!p.mask_has(c.name)) continue;
@@ -662,6 +665,7 @@ static std::unique_ptr<tfgpu_dbatch> apply_to_string(const tfgpu_plan &p, const 
       throw Error(TFGPU_ERR_UNSUPPORTED, "convert_to_string skip_utc_conversion=true needs per-value time zones, which the columnar batch does not carry");
   }
   auto out = shallow_copy(in);
+  for (auto &sc : out->schema) if (p.columns.match(sc.first)) sc.second = p.to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8;  // to_string.go:114-127
   for (auto &c : out->cols) {
     if (!p.columns.match(c.name)) continue;
     require_serializable(c, "convert_to_string");
@@ -683,6 +687,7 @@ __global__ void todatetime_kernel(const T *in, int64_t n, int64_t *out) {
 static std::unique_ptr<tfgpu_dbatch> apply_to_datetime(const tfgpu_plan &p, const tfgpu_dbatch &in) {
   auto out = shallow_copy(in);
   int64_t n = in.nrows;
+  for (auto &sc : out->schema) if (p.columns.match(sc.first) && (sc.second == TFGPU_T_INT32 || sc.second == TFGPU_T_UINT32)) sc.second = TFGPU_T_DATETIME;  // to_datetime.go:125-133
   for (auto &c : out->cols) {
     if (!(p.columns.match(c.name) && (c.dtype == TFGPU_T_INT32 || c.dtype == TFGPU_T_UINT32))) continue;
     DColumn o;
@@ -738,12 +743,24 @@ static std::unique_ptr<tfgpu_dbatch> apply_sharder(const tfgpu_plan &p, const tf
   // batch column order stands in for it (they coincide for every source that
   // builds ColumnNames from the schema).
   std::vector<DCol> cols;
-  for (auto &c : in.cols) {
-    if (!p.columns.match(c.name)) continue;
-    require_serializable(c, "sharder_transformer");
-    cols.push_back(dcol_of(c));
+  if (in.schema.empty()) {
+    for (auto &c : in.cols) {
+      if (!p.columns.match(c.name)) continue;
+      require_serializable(c, "sharder_transformer");
+      cols.push_back(dcol_of(c));
+    }
+  } else {  // item.TableSchema.Columns() in order, values through AsMap()[name]: a schema column without a value is nil
+    for (auto &sc : in.schema) {
+      if (!p.columns.match(sc.first)) continue;
+      const DColumn *found = nullptr;
+      for (auto &c : in.cols) if (c.name == sc.first) found = &c;  // AsMap: the last duplicate name wins
+      if (!found) { DCol nil{}; nil.repr = 0; nil.dtype = sc.second; cols.push_back(nil); continue; }
+      require_serializable(*found, "sharder_transformer");
+      DCol d = dcol_of(*found);
+      d.dtype = sc.second;
+      cols.push_back(d);
+    }
   }
-  (void)schema_order;
   Buf bc = upload_small(cols.data(), cols.size() * sizeof(DCol));
   out->part_id = dalloc((size_t)n * 4 + 4);
   SharderParams sp{ptr<DCol>(bc), (int32_t)cols.size(), n, (uint32_t)p.shards, ptr<uint32_t>(out->part_id)};
@@ -764,6 +781,8 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_columns(const tfgpu_plan &p, c
   auto out = shallow_copy(in);
   out->cols.clear();
   for (auto &c : in.cols) if (p.columns.match(c.name)) out->cols.push_back(c);
+  out->schema.clear();
+  for (auto &sc : in.schema) if (p.columns.match(sc.first)) out->schema.push_back(sc);
   return out;
 }
 
