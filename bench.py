@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU per step")
     ap.add_argument("--cpu-rows", type=int, default=1 << 16, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--prof-steps", type=int, default=3)
+    ap.add_argument("--lanes", type=int, default=3, help="device lanes (host threads) the steps are spread over: batch N+1 is parsed "
+                    "beside the transform of batch N, the way the parsequeue's workers overlap (1 = strictly serial)")
+    ap.add_argument("--pcie-steps", type=int, default=2, help="extra untimed-for-`value` passes that start from PINNED HOST memory (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,14 +126,74 @@ def main():
         step()
     step(keep=True)  # one extra untimed pass to record sizes
 
+    # ---- the timed region: exactly args.steps steps, spread round-robin over `lanes` host threads, each bound
+    #      to its own device lane (stream + HBM cache) and reading its own HBM-resident copy of the shard ----
+    import threading
+    nl = max(1, min(args.lanes, args.steps, lib.lane_count()))
+    lane_bufs = [dbuf]
+    go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
+    lane_err = []
+
+    def lane_main(k):
+        try:
+            lib.lane_use(k)
+            if k:  # stage this lane's copy of the input (untimed), then warm the lane's caches
+                lane_bufs.append(None)
+            buf = dbuf if k == 0 else stage_shard(lib, workload, row0, args.rows)[0]
+            def lstep():
+                db, consumed, errs = lib.csv_parse(opts, schema, buf)
+                res = lib.apply_chain(plans, db)
+                res.transformed.free()
+                db.free()
+            if k:
+                for _ in range(max(args.warmup, 1)):
+                    lstep()
+            lib.synchronize()
+            go.wait()
+            for i in range(args.steps):
+                if i % nl == k:
+                    lstep()
+            lib.synchronize()
+            done.wait()
+        except Exception as e:  # noqa: BLE001
+            lane_err.append(e)
+            go.abort(); done.abort()
+
+    threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
+    for t in threads:
+        t.start()
     barrier()
     torch.cuda.synchronize()
+    go.wait()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    done.wait()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    for t in threads:
+        t.join()
+    if lane_err:
+        raise lane_err[0]
+    lib.lane_use(0)
+
+    # ---- PCIe-inclusive side measurement (never `value`): the same step starting from pinned host memory ----
+    pcie = None
+    if args.pcie_steps > 0 and rank == 0:
+        host = lib.HostBuffer(dbuf.download())
+        def hstep():
+            db, consumed, errs = lib.csv_parse(opts, schema, host)
+            res = lib.apply_chain(plans, db)
+            res.transformed.free(); db.free()
+        hstep()
+        lib.synchronize()
+        th = time.perf_counter()
+        for _ in range(args.pcie_steps):
+            hstep()
+        lib.synchronize()
+        dth = time.perf_counter() - th
+        pcie = {"rows_per_s": round(args.rows * args.pcie_steps / dth, 1), "gb_per_s_h2d": round(csv_bytes * args.pcie_steps / dth / 1e9, 2),
+                "ms_per_step": round(dth / args.pcie_steps * 1e3, 3), "note": "input in pinned host memory, one lane, H2D inside the step"}
+        host.free()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,7 +272,7 @@ def main():
             "gib_per_s_csv_in": round(csv_bytes * world * args.steps / dt / 2**30, 3),
             "gib_per_s_deepsizeof": round((state["parsed_bytes"] + 16 * len(schema.cols) * rows) * world * args.steps / dt / 2**30, 3),
             "rows_out_per_step": state["out_rows"], "row_errors": state["errors"],
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "lanes": nl, "pcie_inclusive": pcie,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)

@@ -194,6 +194,16 @@ int tfgpu_synchronize(void);
 /* The HIP stream every kernel of this library is launched on (hipStream_t). */
 void *tfgpu_stream(void);
 
+/* Lanes — the device half of the parsequeue (pkg/parsequeue/parsequeue.go:57-154: bounded-parallel
+ * parse, in-order push).  A lane is an independent (HIP stream, HBM block cache, pinned ring) set of the
+ * process's GPU; a host thread (goroutine locked to its OS thread) binds itself to lane k and every call it
+ * makes is enqueued there, so work on different lanes overlaps on the device: H2D of chunk N+1 beside the
+ * kernels of chunk N beside the D2H of chunk N-1.  Lane 0 exists after tfgpu_init and is every thread's
+ * default.  Handles (dbatch, dbuf) must be used and freed on the lane that made them.               */
+int tfgpu_lane_count(void);        /* how many lanes may be used (0 .. count-1)                          */
+int tfgpu_lane_use(int lane);      /* bind the calling thread; creates the lane on first use             */
+int tfgpu_lane_current(void);
+
 /* Pinned staging memory (hipHostMalloc) for double-buffered H2D/D2H.        */
 int tfgpu_host_alloc(size_t bytes, void **out);
 int tfgpu_host_free(void *p);

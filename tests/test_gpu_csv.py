@@ -182,3 +182,33 @@ def test_row_path_equals_tile_path():
                         "edge_lines or typed_columns or random_bytes or tile_path_shapes or unmapped"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_lanes_overlap_and_agree(tf, oracle):
+    """Two host threads on two device lanes (tfgpu_lane_use) parse + transform concurrently; each result is
+    identical to the single-lane result (the parsequeue's parallel workers, parsequeue.go:57-154)."""
+    import threading
+    schema = workload.hits_schema()
+    opts = workload.hits_csv_options()
+    chain = [("mask_field", {"maskFunctionHash": {"userDefinedSalt": "s"}, "columns": ["clientip"]}), ("filter_rows", {"filter": "eventdate >= 2013-07-15"})]
+    datas = [workload.hits_csv(4000), workload.hits_csv(2500)]
+    def run(data):
+        db, consumed, errs = tf.csv_parse(opts, schema, data)
+        res = tf.apply_chain([tf.Transformer(t, c) for t, c in chain], db)
+        return res.transformed.download()
+    base = [run(d) for d in datas]
+    outs, errs = {}, []
+    def worker(k):
+        try:
+            tf.lane_use(k + 1)
+            for _ in range(5):
+                outs[k] = run(datas[k])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for k in range(2):
+        assert_batches_equal(outs[k], base[k], "lane %d" % k)
+    tf.lane_use(0)

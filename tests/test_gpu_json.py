@@ -42,6 +42,13 @@ def expected_json_text(v):
         return b'"' + x + b'"'  # the device only keeps strings encoding/json leaves untouched
     if g in ("jsonnum", "json"):
         return x
+    if g == "float64":  # encoding/json floatEncoder: 'f' unless < 1e-6 or >= 1e21, then 'e' with e-0X → e-X
+        from oracle import oracle as ora
+        a = abs(x)
+        if a != 0 and (a < 1e-6 or a >= 1e21):
+            t = ora.fmt_float(x, "g", 64)
+            return (t[:-2] + t[-1] if t[-4:-1] in ("e-0",) else t).encode()
+        return ora.fmt_float(x, "f", 64).encode()
     raise AssertionError("device kept an `any` value of Go type %s" % g)
 
 

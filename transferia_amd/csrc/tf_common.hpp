@@ -87,6 +87,7 @@ struct DevMem {
   void *p = nullptr;
   size_t bytes = 0, cls = 0;
   std::shared_ptr<DevMem> parent;  // set for views into a larger block (see subbuf)
+  struct BlockCache *owner = nullptr;  // the lane's cache the block returns to
   explicit DevMem(size_t n);
   DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n);
   ~DevMem();

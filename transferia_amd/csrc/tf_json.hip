@@ -31,6 +31,7 @@
 
 #include "tf_common.hpp"
 #include "tf_devfmt.hpp"
+#include "tf_devfloat.hpp"
 #include "tf_devparse.hpp"
 
 namespace tf {
@@ -39,7 +40,7 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out);           // tf_csv.hip
 
 enum JKind : int32_t { JK_INT, JK_UINT, JK_F64, JK_BOOL, JK_TEXT, JK_ANY, JK_DATETIME };
-enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3 };
+enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4 };
 enum JLineSt : uint8_t { JL_ROW = 0, JL_SKIPPED = 1, JL_SYNTAX = 2, JL_FALLBACK = 3 };
 enum JCellSt : uint8_t { JC_NIL = 0, JC_OK = 1, JC_ERR = 2 };
 enum JVal : int32_t { V_NULL, V_STR, V_NUM, V_TRUE, V_FALSE, V_OBJ, V_ARR };
@@ -480,8 +481,17 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
     case JK_ANY:  // stored as json.Marshal(value)
       if (vtype == V_TRUE || vtype == V_FALSE) jtext(c, r, vstart, tok.n, JM_COPY, tok.n);
       else if (vtype == V_NUM) {
-        if (!p.use_numbers || !valid_json_number(tok, tok.n)) return false;  // float64 → shortest-float text: host
-        jtext(c, r, vstart, tok.n, JM_COPY, tok.n);
+        if (p.use_numbers) {  // json.Number: marshalled as its own text, which must be a valid JSON number
+          if (!valid_json_number(tok, tok.n)) return false;
+          jtext(c, r, vstart, tok.n, JM_COPY, tok.n);
+        } else {  // float64 → encoding/json's float text (NaN / ±Inf are a Marshal error: host)
+          double v;
+          if (ff_best_effort(tok, tok.n, p.pow10, p.pow128, &v)) return false;
+          if (v != v || v == INFINITY || v == -INFINITY) return false;
+          dev::CountOut co;
+          dev::fmt_json_float(co, v, 64);
+          jtext(c, r, vstart, tok.n, JM_FLOAT, co.n);
+        }
       } else if (vtype == V_STR) {
         // ParseVal: ReplaceAll(`\\`, `\`) then json.Unmarshal into a map — a map only if the text is an object
         if (!sv.plain) return false;
@@ -758,7 +768,7 @@ __global__ void json_const_text(const uint8_t *text, uint32_t n, int64_t nrows, 
 // text payloads: lane = (column, line) cell
 // ---------------------------------------------------------------------------
 struct JCopyCol { const uint32_t *offsets, *fstart, *meta; uint8_t *out; };
-__global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, const JCopyCol *cols, int64_t nlines) {
+__global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, const JCopyCol *cols, int64_t nlines, const double *pow10, const uint64_t *pow128) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nlines) return;
   const JCopyCol c = cols[blockIdx.y];
@@ -770,6 +780,14 @@ __global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, cons
   MemBytes rd(data);
   if (mode == JM_UNESCAPE) { StoreSink sk{dst}; unescape_walk(rd, s, srclen, sk); return; }
   if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); return; }
+  if (mode == JM_FLOAT) {  // the number token again, as encoding/json prints the float64 it parses to
+    const Field tok{&rd, s, srclen};
+    double v = 0;
+    ff_best_effort(tok, srclen, pow10, pow128, &v);
+    dev::StoreOut so{dst};
+    dev::fmt_json_float(so, v, 64);
+    return;
+  }
   uint32_t w = 0;
   if (mode == JM_QUOTED) dst[w++] = '"';
   for (uint32_t i = 0; i < srclen; i++) dst[w++] = (uint8_t)rd.at(s + i);
@@ -1122,7 +1140,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   if (nlines && nstr) {
     Buf bcc = upload_small(cc.data(), cc.size() * sizeof(JCopyCol));
     KernelTimer t("json_copy_cells");
-    json_copy_cells<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(data, ptr<JCopyCol>(bcc), nlines);
+    json_copy_cells<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(data, ptr<JCopyCol>(bcc), nlines, pp.pow10, pp.pow128);
   }
 
   // ---- dropped lines: `_unparsed` rows / host fallback are reported, skipped lines vanish ----

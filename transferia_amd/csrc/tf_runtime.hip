@@ -10,15 +10,45 @@
 namespace tf {
 
 static thread_local std::string g_last_error;
-static std::unique_ptr<Context> g_ctx;
+// Lanes: independent (stream, HBM block cache, pinned ring, profiler) sets of ONE device.  A host thread binds
+// itself to a lane with tfgpu_lane_use(); calls on different lanes overlap on the GPU — parse of batch N+1 on one
+// lane beside transform / serialize / D2H of batch N on another (the parsequeue's parallel workers,
+// parsequeue.go:57-154, map onto lanes).  Buffers belong to the lane that made them.
+static constexpr int MAX_LANES = 8;
+static std::unique_ptr<Context> g_lanes[MAX_LANES];
+static thread_local int g_lane = 0;
+static int g_device = -1, g_num_cus = 256;
 static std::mutex g_init_mu;
+#define g_ctx g_lanes[0]
 
 void set_last_error(const std::string &m) { g_last_error = m; }
 int fail(int code, const std::string &m) { g_last_error = m; return code; }
 
 Context &ctx() {
   if (!g_ctx) throw Error(TFGPU_ERR_DEVICE, "tfgpu_init() has not been called (or no gfx950 device): no CPU fallback exists");
-  return *g_ctx;
+  Context *c = g_lanes[g_lane].get();
+  if (!c) throw Error(TFGPU_ERR_INVALID, "this thread is bound to a lane that no longer exists");
+  return *c;
+}
+static std::unique_ptr<Context> make_lane() {
+  auto c = std::make_unique<Context>();
+  c->device = g_device;
+  c->num_cus = g_num_cus;
+  TF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->pin_cap = 8u << 20;
+  TF_HIP(hipHostMalloc(&c->pin_base, c->pin_cap, hipHostMallocDefault));
+  return c;
+}
+static void destroy_lane(std::unique_ptr<Context> &c) {
+  if (!c) return;
+  hipStreamSynchronize(c->stream);
+  for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : c->free_events) hipEventDestroy(e);
+  c->pow10tab.reset();
+  c->blocks.trim();
+  if (c->pin_base) hipHostFree(c->pin_base);
+  hipStreamDestroy(c->stream);
+  c.reset();
 }
 
 hipEvent_t Context::get_event() {
@@ -96,11 +126,12 @@ DevMem::DevMem(size_t n) : bytes(n) {
   Context &c = ctx();
   cls = size_class(n + 16);  // 16 bytes of slack: kernels read whole aligned words around payloads
   p = c.blocks.get(cls);
+  owner = &c.blocks;
 }
 DevMem::DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n) : p((char *)owner->p + off), bytes(n), cls(0), parent(std::move(owner)) {}
 DevMem::~DevMem() {
   if (parent) return;  // a view: the owner returns the block
-  if (p && g_ctx) g_ctx->blocks.put(p, cls);
+  if (p && owner && g_ctx) owner->put(p, cls);  // back to the cache of the lane whose stream ordered its use
 }
 Buf subbuf(const Buf &owner, size_t off, size_t bytes) { return std::make_shared<DevMem>(owner, off, bytes); }
 
@@ -185,12 +216,9 @@ int tfgpu_init(int device) {
   TF_HIP(hipGetDeviceProperties(&prop, device));
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return tf::fail(TFGPU_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-  auto c = std::make_unique<Context>();
-  c->device = device;
-  c->num_cus = prop.multiProcessorCount;
-  TF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  c->pin_cap = 8u << 20;
-  TF_HIP(hipHostMalloc(&c->pin_base, c->pin_cap, hipHostMallocDefault));
+  g_device = device;
+  g_num_cus = prop.multiProcessorCount;
+  auto c = make_lane();
   g_ctx = std::move(c);
   return TFGPU_OK;
   TF_API_END
@@ -199,15 +227,24 @@ int tfgpu_init(int device) {
 int tfgpu_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_init_mu);
   if (!g_ctx) return TFGPU_OK;
-  hipStreamSynchronize(g_ctx->stream);
-  for (auto &p : g_ctx->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  for (auto e : g_ctx->free_events) hipEventDestroy(e);
-  g_ctx->blocks.trim();
-  if (g_ctx->pin_base) hipHostFree(g_ctx->pin_base);
-  hipStreamDestroy(g_ctx->stream);
-  g_ctx.reset();
+  for (int i = MAX_LANES - 1; i >= 0; i--) destroy_lane(g_lanes[i]);
+  g_lane = 0;
   return TFGPU_OK;
 }
+
+int tfgpu_lane_count(void) { return MAX_LANES; }
+int tfgpu_lane_use(int lane) {
+  TF_API_BEGIN
+  if (lane < 0 || lane >= MAX_LANES) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_lane_use: lane out of range");
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (!g_ctx) return tf::fail(TFGPU_ERR_DEVICE, "tfgpu_init() has not been called");
+  TF_HIP(hipSetDevice(g_device));  // the HIP device is a per-thread setting
+  if (!g_lanes[lane]) g_lanes[lane] = make_lane();
+  g_lane = lane;
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_lane_current(void) { return g_lane; }
 
 int tfgpu_synchronize(void) {
   TF_API_BEGIN
@@ -216,7 +253,7 @@ int tfgpu_synchronize(void) {
   TF_API_END
 }
 
-void *tfgpu_stream(void) { return g_ctx ? (void *)g_ctx->stream : nullptr; }
+void *tfgpu_stream(void) { return (g_ctx && g_lanes[g_lane]) ? (void *)g_lanes[g_lane]->stream : nullptr; }
 
 int tfgpu_host_alloc(size_t bytes, void **out) {
   TF_API_BEGIN
@@ -395,13 +432,14 @@ int tfgpu_prof_reset(void) {
   TF_API_END
 }
 int tfgpu_prof_count(void) {
-  if (!g_ctx) return 0;
-  g_ctx->prof_flush();
-  return (int)g_ctx->prof.size();
+  if (!g_ctx || !g_lanes[g_lane]) return 0;
+  g_lanes[g_lane]->prof_flush();
+  return (int)g_lanes[g_lane]->prof.size();
 }
 int tfgpu_prof_get(int i, const char **name, int64_t *launches, double *total_ms) {
-  if (!g_ctx || i < 0 || i >= (int)g_ctx->prof.size()) return TFGPU_ERR_INVALID;
-  *name = g_ctx->prof[i].name.c_str(); *launches = g_ctx->prof[i].launches; *total_ms = g_ctx->prof[i].total_ms;
+  Context *c = g_ctx ? g_lanes[g_lane].get() : nullptr;
+  if (!c || i < 0 || i >= (int)c->prof.size()) return TFGPU_ERR_INVALID;
+  *name = c->prof[i].name.c_str(); *launches = c->prof[i].launches; *total_ms = c->prof[i].total_ms;
   return TFGPU_OK;
 }
 

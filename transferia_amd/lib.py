@@ -24,7 +24,7 @@ _lib = None
 
 EXPORTS = [
     "tfgpu_abi_version", "tfgpu_last_error", "tfgpu_init", "tfgpu_shutdown", "tfgpu_device_count", "tfgpu_synchronize",
-    "tfgpu_stream", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
+    "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
@@ -59,6 +59,7 @@ def load():
     L.tfgpu_registry_name.restype = C.c_char_p
     L.tfgpu_registry_name.argtypes = [C.c_int]
     L.tfgpu_init.argtypes = [C.c_int]
+    L.tfgpu_lane_use.argtypes = [C.c_int]
     L.tfgpu_device_count.argtypes = [C.POINTER(C.c_int)]
     L.tfgpu_host_alloc.argtypes = [C.c_size_t, C.POINTER(P)]
     L.tfgpu_host_free.argtypes = [P]
@@ -118,6 +119,17 @@ def init(device: Optional[int] = None) -> int:
     _check(load().tfgpu_init(device))
     _initialised = device
     return device
+
+
+def lane_use(lane: int):
+    """Bind the calling thread to lane `lane` (its own stream / HBM cache / pinned ring): calls made by
+    threads on different lanes overlap on the device, the way the parsequeue's workers overlap."""
+    init()
+    _check(load().tfgpu_lane_use(int(lane)))
+
+
+def lane_count() -> int:
+    return int(load().tfgpu_lane_count())
 
 
 def synchronize():
@@ -281,6 +293,28 @@ class DeviceBuffer:
             pass
 
 
+class HostBuffer:
+    """Pinned (hipHostMalloc) staging memory: the source of a true asynchronous H2D copy."""
+
+    def __init__(self, data: bytes):
+        init()
+        p = C.c_void_p()
+        _check(load().tfgpu_host_alloc(max(len(data), 1), C.byref(p)))
+        self.ptr, self.size = p.value, len(data)
+        C.memmove(self.ptr, data, len(data))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            load().tfgpu_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class TransformerResult:
     """abstract.TransformerResult: Transformed rows + per-row Errors."""
 
@@ -355,6 +389,9 @@ def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int =
     errs = (abi.CRowError * max_errors)()
     if isinstance(data, DeviceBuffer):
         _check(L.tfgpu_csv_parse(C.byref(opts), C.byref(cs), data.ptr, data.size, abi.MEM_DEVICE, C.byref(out), C.byref(consumed), errs,
+                                 max_errors, C.byref(nerr)))
+    elif isinstance(data, HostBuffer):
+        _check(L.tfgpu_csv_parse(C.byref(opts), C.byref(cs), data.ptr, data.size, abi.MEM_HOST, C.byref(out), C.byref(consumed), errs,
                                  max_errors, C.byref(nerr)))
     else:
         buf = np.frombuffer(data, dtype=np.uint8)
