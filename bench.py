@@ -68,33 +68,25 @@ def main():
     ap.add_argument("--pcie-steps", type=int, default=2, help="extra untimed-for-`value` passes that start from PINNED HOST memory (0 = skip)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-
     import torch
-    import torch.distributed as dist
+    from transferia_amd import dist as tdist
+    rank, local_rank, world = tdist.env_rank()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    group = tdist.Group("nccl", torch.device("cuda", local_rank))  # RCCL: barrier + MAX of the wall time only
 
     from transferia_amd import lib, workload
     lib.init(local_rank)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = group.barrier
 
     schema = workload.hits_schema()
     opts = workload.hits_csv_options()
     plans = [lib.Transformer(t, c) for t, c in CHAIN]
 
     # ---- stage this rank's shard in HBM (untimed) ----
-    row0 = rank * args.rows
+    row0, _ = tdist.weak_shard(args.rows, rank)
     dbuf, csv_bytes, hs = stage_shard(lib, workload, row0, args.rows)
 
     state = {}
@@ -194,10 +186,7 @@ def main():
         pcie = {"rows_per_s": round(args.rows * args.pcie_steps / dth, 1), "gb_per_s_h2d": round(csv_bytes * args.pcie_steps / dth / 1e9, 2),
                 "ms_per_step": round(dth / args.pcie_steps * 1e3, 3), "note": "input in pinned host memory, one lane, H2D inside the step"}
         host.free()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = group.max_seconds(dt)
 
     # ---- per-kernel device time, HIP events on the library stream (separate, untimed pass) ----
     lib.prof_reset()
@@ -277,8 +266,7 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":
