@@ -109,6 +109,7 @@ size_t ora_fmt_int(char *dst, int64_t v);
 size_t ora_fmt_uint(char *dst, uint64_t v);
 /* strconv.FormatFloat(f, fmt, -1, bits), fmt in {'g'(=fmt %v), 'f'} */
 size_t ora_fmt_float(char *dst, double f, char fmt, int bits);
+size_t ora_json_float(char *dst, double f, int bits);
 size_t ora_fmt_date(char *dst, int64_t sec);               /* time.DateOnly, UTC */
 size_t ora_fmt_rfc3339nano(char *dst, int64_t sec, int32_t nsec); /* UTC */
 size_t ora_fmt_time_string(char *dst, int64_t sec, int32_t nsec); /* Time.String(), UTC */

@@ -105,6 +105,22 @@ size_t ora_fmt_float(char *dst, double f, char fmt, int bits) {
   return w;
 }
 
+/* encoding/json floatEncoder (encode.go): 'f' unless |f| < 1e-6 or >= 1e21 (compared in float32 for 32-bit values),
+ * then 'e' with a two-digit negative exponent e-0X cleaned to e-X.  NaN / ±Inf are an UnsupportedValueError: returns 0. */
+size_t ora_json_float(char *dst, double f, int bits) {
+  if (isnan(f) || isinf(f)) return 0;
+  double a = fabs(f);
+  int e_form = 0;
+  if (a != 0) {
+    if (bits == 64) e_form = a < 1e-6 || a >= 1e21;
+    else { float af = (float)a; e_form = af < 1e-6f || af >= 1e21f; }
+  }
+  if (!e_form) return ora_fmt_float(dst, f, 'f', bits);
+  size_t n = ora_fmt_float(dst, f, 'g', bits);  /* at these magnitudes %g is in e-form and equals %e with shortest digits */
+  if (n >= 4 && dst[n - 4] == 'e' && dst[n - 3] == '-' && dst[n - 2] == '0') { dst[n - 2] = dst[n - 1]; n--; }
+  return n;
+}
+
 /* ---------------- ParseUint / ParseInt (strconv/atoi.go) ---------------- */
 static int lower_(int c) { return c | ('x' - 'X'); }
 

@@ -180,7 +180,12 @@ static int ch_value(sbuf *b, const ora_value *v, int dtype, uint32_t fl, uint8_t
   else if (v->kind == OV_JSONNUM) { if (v->slen) sb_put(&r, v->s, v->slen); else sb_c(&r, '0'); }
   else if (v->kind == OV_JSON) sb_put(&r, v->s, v->slen);
   else if (v->kind == OV_DURATION) { n = ora_fmt_int(t, v->v.i); sb_put(&r, t, n); }
-  else { free(r.p); b->unsupported = 1; return 0; } /* floats ('g'-style encoding/json), time under a foreign DataType */
+  else if (v->kind == OV_F32 || v->kind == OV_F64) { /* json.Marshal(float): goccy/go-json follows encoding/json's floatEncoder */
+    n = v->kind == OV_F32 ? ora_json_float(t, (double)v->v.f32, 32) : ora_json_float(t, v->v.f64, 64);
+    if (!n) { free(r.p); b->unsupported = 1; return 0; }
+    sb_put(&r, t, n);
+  }
+  else { free(r.p); b->unsupported = 1; return 0; } /* time under a foreign DataType */
   if (r.n == 4 && !memcmp(r.p, "null", 4)) { free(r.p); return 1; }
   if (dtype != TFGPU_T_ANY || any_as_string || (fl & TFGPU_CH_STRING)) {
     /* DOUBLE_MARSHAL: json.Marshal(string(r)) — goccy/go-json escapes HTML like encoding/json */
@@ -240,7 +245,12 @@ static void json_value(sbuf *b, const ora_value *v, int dtype, int any_as_string
     default: break;
   }
   if (is_int_kind(v->kind)) { put_int(b, v); return; }
-  b->unsupported = 1; /* float32 / float64: encoding/json's ES6-style float text is not restated */
+  if (v->kind == OV_F32 || v->kind == OV_F64) { /* floatEncoder; NaN / Inf fail the whole Marshal (UnsupportedValueError) */
+    n = v->kind == OV_F32 ? ora_json_float(t, (double)v->v.f32, 32) : ora_json_float(t, v->v.f64, 64);
+    if (!n) b->unsupported = 1; else sb_put(b, t, n);
+    return;
+  }
+  b->unsupported = 1;
 }
 
 typedef struct { const char *name; int idx; } keyref;

@@ -127,9 +127,11 @@ def test_gpu_serializers_match_oracle(tf, oracle, n):
 def test_gpu_serialize_unsupported_and_empty(tf, oracle):
     schema = abi.Schema.of([["f", "double", False]])
     b = abi.batch_from_rows(schema, ["f"], [[["float64", 1.5]]], "", "t")
-    assert oracle.serialize(abi.FMT_JSON, b, schema) is None
+    assert oracle.serialize(abi.FMT_JSON, b, schema) == tf.serialize(abi.FMT_JSON, tf.DeviceBatch.upload(b)).download() == b'{"f":1.5}'
+    bn = abi.batch_from_rows(schema, ["f"], [[["float64", 1.5]], [["float64", float("nan")]]], "", "t")
+    assert oracle.serialize(abi.FMT_JSON, bn, schema) is None  # json: unsupported value: NaN
     with pytest.raises(tf.TfgpuError) as ei:
-        tf.serialize(abi.FMT_JSON, tf.DeviceBatch.upload(b))
+        tf.serialize(abi.FMT_JSON, tf.DeviceBatch.upload(bn))
     assert ei.value.code == tf.ERR_UNSUPPORTED
     # strconv.FormatFloat(f, 'f', -1): ClickHouse numeric columns and the CSV serializer render Go floats on device
     import random
@@ -140,7 +142,7 @@ def test_gpu_serialize_unsupported_and_empty(tf, oracle):
     s2 = abi.Schema.of([["f", "double", False], ["g", "float", False], ["i", "int64", True]])
     rows = [[["float64", v], ["float32", float(np.float32(rng.uniform(-1e6, 1e6)))], ["int64", k]] for k, v in enumerate(vals)]
     b2 = abi.batch_from_rows(s2, ["f", "g", "i"], rows, "", "t")
-    for fmt in (abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
+    for fmt in (abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW, abi.FMT_JSON):
         ref = oracle.serialize(fmt, b2, s2)
         assert ref is not None
         assert tf.serialize(fmt, tf.DeviceBatch.upload(b2)).download() == ref

@@ -118,6 +118,12 @@ template <class S> __device__ void emit_float_f(S &s, const DCol &c, int64_t r) 
   else dev::fmt_float(s, ((const double *)c.values)[r], 'f', 64);
 }
 
+// json.Marshal(float): encoding/json's floatEncoder
+template <class S> __device__ void emit_float_json(S &s, const DCol &c, int64_t r) {
+  if (c.repr == TFGPU_R_FLOAT32) dev::fmt_json_float(s, (double)((const float *)c.values)[r], 32);
+  else dev::fmt_json_float(s, ((const double *)c.values)[r], 64);
+}
+
 // The integer Go types as decimal text; returns false if the column is not an integer repr.
 template <class S> __device__ bool emit_int(S &s, const DCol &c, int64_t r) {
   uint8_t t[24]; int n;
@@ -254,6 +260,7 @@ template <class S> __device__ bool emit_ch_value(S &s, const SCol &sc, int64_t r
   if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) { if (dbl) s.put('"'); emit_int(s, c, r); if (dbl) s.put('"'); return true; }
   if (c.repr == TFGPU_R_BOOL) { if (dbl) s.put('"'); put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); if (dbl) s.put('"'); return true; }
   if (c.repr == TFGPU_R_DURATION) { if (dbl) s.put('"'); int n = dev::fmt_i64(t, ((const int64_t *)c.values)[r]); emit_small(s, t, n); if (dbl) s.put('"'); return true; }
+  if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { if (dbl) s.put('"'); emit_float_json(s, c, r); if (dbl) s.put('"'); return true; }
   if (c.repr == TFGPU_R_JSONNUM || c.repr == TFGPU_R_JSON) {
     if (c.repr == TFGPU_R_JSONNUM && vn == 0) { if (dbl) s.put('"'); s.put('0'); if (dbl) s.put('"'); return true; }  // json.Number("") encodes as 0
     if (vn == 4 && vp[0] == 'n' && vp[1] == 'u' && vp[2] == 'l' && vp[3] == 'l') return false;  // value is null: skip the column
@@ -281,6 +288,7 @@ template <class S> __device__ void emit_json_value(S &s, const SCol &sc, int64_t
       if (c.dtype == TFGPU_T_ANY && any_as_string) emit_json_string(s, vp, vn, false);
       else put_bytes(s, vp, vn);
       return;
+    case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_json(s, c, r); return;
     default: emit_int(s, c, r);
   }
 }
@@ -450,12 +458,9 @@ static void require_supported(int format, const DColumn &c, int any_as_string) {
     throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_serialize: column " + c.name + ": " + why);
   };
   if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) {
-    // strconv.FormatFloat(f, 'f', -1, bits) is on device: marshalNumericValue (marshal.go:257-301) and castx.ToStringE
-    // (caste.go:57-106).  json.Marshal of a Go float (encoding/json's float text) under other DataTypes stays on the host.
-    const bool numeric = (c.dtype >= TFGPU_T_INT8 && c.dtype <= TFGPU_T_FLOAT64) || c.dtype == TFGPU_T_INTERVAL;
-    if (format == TFGPU_FMT_CH_JSON_EACH_ROW) { if (!numeric) bad("Go float under a non-numeric DataType (generic json.Marshal path)"); }
-    else if (format == TFGPU_FMT_CSV) { if (c.dtype == TFGPU_T_ANY || c.dtype == TFGPU_T_BYTES) bad("Go float under `any` / \"string\""); }
-    else bad("Go float values in the generic JSON serializer (encoding/json float text)");
+    // strconv.FormatFloat(f, 'f', -1, bits): marshalNumericValue (marshal.go:257-301), castx.ToStringE (caste.go:57-106);
+    // json.Marshal(float) = encoding/json's floatEncoder elsewhere (NaN / Inf there fail the whole call: checked on device)
+    if (format == TFGPU_FMT_CSV && (c.dtype == TFGPU_T_ANY || c.dtype == TFGPU_T_BYTES)) bad("Go float under `any` / \"string\" in the CSV serializer");
   }
   if (format == TFGPU_FMT_CH_JSON_EACH_ROW) {
     const bool temporal = c.dtype == TFGPU_T_DATE || c.dtype == TFGPU_T_DATETIME || c.dtype == TFGPU_T_TIMESTAMP;
@@ -466,6 +471,14 @@ static void require_supported(int format, const DColumn &c, int any_as_string) {
     if (c.dtype != TFGPU_T_ANY && c.repr == TFGPU_R_JSON) bad("map/slice value under a scalar DataType");
   }
   (void)any_as_string;
+}
+
+// json.Marshal fails the whole call on NaN / ±Inf (UnsupportedValueError): find them before any text is produced
+__global__ void float_nonfinite_kernel(const void *values, int64_t n, int is32, const uint8_t *validity, uint32_t *flag) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || (validity && !((validity[r >> 3] >> (r & 7)) & 1))) return;
+  const double v = is32 ? (double)((const float *)values)[r] : ((const double *)values)[r];
+  if (v != v || v == INFINITY || v == -INFINITY) *flag = 1;
 }
 
 }  // namespace tf
@@ -484,6 +497,21 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     const int ncols = (int)b->cols.size();
     const int any_as_string = opts ? opts->any_as_string : 0;
     for (auto &c : b->cols) require_supported(format, c, any_as_string);
+    {
+      Buf flag;
+      for (auto &c : b->cols) {
+        if (c.repr != TFGPU_R_FLOAT32 && c.repr != TFGPU_R_FLOAT64) continue;
+        const bool numeric = (c.dtype >= TFGPU_T_INT8 && c.dtype <= TFGPU_T_FLOAT64) || c.dtype == TFGPU_T_INTERVAL;
+        if (format == TFGPU_FMT_CSV || (format == TFGPU_FMT_CH_JSON_EACH_ROW && numeric)) continue;  // FormatFloat prints NaN / +Inf
+        if (!flag) flag = dalloc_zero(4);
+        if (n) float_nonfinite_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(c.values->p, n, c.repr == TFGPU_R_FLOAT32, ptr<uint8_t>(c.validity), ptr<uint32_t>(flag));
+      }
+      if (flag) {
+        const uint32_t *h = d2h_u32(flag->p);
+        tf::sync();
+        if (*h) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_serialize: json: unsupported value: NaN or Inf (json.Marshal fails the batch in the reference)");
+      }
+    }
     if (opts && opts->ncols && opts->ncols != ncols) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize: options describe another column count");
 
     // column order: CH and CSV keep ColumnNames order; encoding/json sorts map keys
