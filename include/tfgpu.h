@@ -230,6 +230,8 @@ int tfgpu_registry_count(void);
 const char *tfgpu_registry_name(int i);
 
 /* ---- batches ------------------------------------------------------------ */
+/* `host->mem` TFGPU_MEM_HOST: pageable or pinned host buffers; TFGPU_MEM_DEVICE: device buffers (copied device-to-device,
+ * e.g. the receive buffers of an all-to-all).  The caller's buffers are free for reuse on return.                    */
 int tfgpu_batch_upload(const tfgpu_batch *host, tfgpu_dbatch **out);
 /* Borrowed view with DEVICE pointers (valid until tfgpu_dbatch_free).       */
 int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *view);
@@ -242,6 +244,13 @@ void tfgpu_dbatch_free(tfgpu_dbatch *b);
  * `errs` (optional) receives up to `errs_cap` row errors; *nerrs the total.  */
 int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tfgpu_dbatch **out,
                 tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+
+/* Hash-partition, local half (BASELINE.json configs[4]: debezium stream → hash-partition → dedup → Kafka sink on 8 GPUs).
+ * Rows are regrouped by part_id — what sharder_transformer wrote: PartID = itoa(CRC32_IEEE(join(SerializeToString(cols), "."))
+ * % shards), sharder.go:130-145 — parts 0..nparts-1 in order, original row order kept inside a part; counts[d] = rows of
+ * part d.  Every column buffer of *out is then laid out for ONE all-to-all (RCCL over xGMI) with split sizes counts[];
+ * the receive side rebuilds a batch from the received device buffers with tfgpu_batch_upload(mem = TFGPU_MEM_DEVICE). */
+int tfgpu_partition(const tfgpu_dbatch *in, int nparts, tfgpu_dbatch **out, int64_t *counts /* [nparts] */);
 
 /* ---- CSV ingest: pkg/csv.Reader + s3 CSVReader.doParse ------------------ */
 typedef struct tfgpu_csv_options {

@@ -71,3 +71,67 @@ def test_two_ranks_over_gloo(tmp_path):
     assert hashlib.sha256(a).hexdigest() == outs[0]["sha"]
     assert outs[0]["len"] + outs[1]["len"] == len(whole)
     assert hashlib.sha256(whole[outs[0]["len"]:]).hexdigest() == outs[1]["sha"]
+
+
+EXCHANGE_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import torch.distributed as dist
+    from transferia_amd import abi, dist as tdist, partition
+    from oracle import oracle as ora
+    g = tdist.Group("gloo")
+    rank, world = g.rank, g.world
+    # every rank owns a contiguous range of a CDC-like table, hashes it to a destination rank with the reference's
+    # sharder (oracle), groups by destination, exchanges
+    schema = abi.Schema.of([["id", "int64", True], ["name", "utf8"], ["ts", "timestamp"], ["opt", "int32"]])
+    n = 500 + 37 * rank
+    lo = 1000 * rank
+    rows = [[["int64", lo + i], ["string", ("name-%d" % (lo + i)) * ((lo + i) % 4)], ["time", (1_600_000_000 + lo + i, (lo + i) % 1000)],
+             ["nil", None] if (lo + i) % 5 == 0 else ["int32", lo + i]] for i in range(n)]
+    b = abi.batch_from_rows(schema, ["id", "name", "ts", "opt"], rows, "db", "t")
+    sh = ora.Transformer("sharder_transformer", {{"shardsCount": str(world), "columns": {{"includeColumns": ["^id$"]}}}})
+    part = sh.apply(b, schema).batch.part_id.astype(np.int64)
+    order = np.argsort(part, kind="stable")
+    grouped = abi.batch_from_rows(schema, ["id", "name", "ts", "opt"], [rows[i] for i in order], "db", "t")
+    grouped.src_row = order.astype(np.int32)
+    counts = [int((part == d).sum()) for d in range(world)]
+    out = partition.exchange_host_batch(dist, grouped, counts)
+    ids = out.col("id").values.tolist()
+    names = [out.col("name").get_bytes(i).decode() for i in range(out.nrows)]
+    opt = [None if not out.col("opt").is_valid(i) else int(out.col("opt").values[i]) for i in range(out.nrows)]
+    nan = out.col("ts").nanos.tolist()
+    print(json.dumps({{"rank": rank, "ids": ids, "names": names, "opt": opt, "nanos": nan, "recv": out.recv_counts, "sent": counts}}))
+    g.close()
+""")
+
+
+def test_hash_partition_exchange_over_gloo(tmp_path, oracle):
+    """configs[4]'s exchange step on CPU: two ranks hash their rows with the reference's sharder, group by destination
+    and run the all-to-all; every row lands on the rank its PartID names, once, in source-rank then original order."""
+    import json
+    import zlib
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "xworker.py"
+    script.write_text(EXCHANGE_WORKER.format(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    all_ids = [list(range(0, 500)), list(range(1000, 1537))]
+    for r, o in enumerate(outs):
+        # destination rule: CRC32_IEEE(SerializeToString(id)) % 2 (sharder.go:130-145)
+        exp = [i for src in all_ids for i in src if zlib.crc32(str(i).encode()) % 2 == r]
+        assert o["ids"] == exp
+        assert o["names"] == [("name-%d" % i) * (i % 4) for i in exp]
+        assert o["opt"] == [None if i % 5 == 0 else i for i in exp]
+        assert o["nanos"] == [i % 1000 for i in exp]
+        assert o["recv"] == [outs[0]["sent"][r], outs[1]["sent"][r]]
+    assert sorted(outs[0]["ids"] + outs[1]["ids"]) == sorted(all_ids[0] + all_ids[1])

@@ -1,6 +1,8 @@
 """Parity of the HIP transformer kernels with the oracle and with the
 reference's golden vectors.  Everything here goes through the C ABI
 (libtfgpu.so); needs a real MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -261,3 +263,63 @@ def test_float_to_string_shortest(tf, oracle):
         out = tf.Transformer("convert_to_string", {}).apply(tf.DeviceBatch.upload(b)).transformed.download()
         for i, v in enumerate(vals):
             assert out.cols[0].get_bytes(i).decode() == oracle.fmt_float(v, "g", bits), (gt, v.hex() if v == v else v)
+
+
+def test_partition_rows_and_device_exchange(tf, oracle):
+    """tfgpu_partition (rows grouped by the sharder's PartID, order kept inside a part) against a stable argsort of the
+    oracle's part ids; then the device half of the hash-partition exchange on a single-rank RCCL group: tensors view
+    the library's HBM buffers, all_to_all_single moves them, tfgpu_batch_upload(mem=DEVICE) rebuilds the batch."""
+    import socket
+    from transferia_amd import workload, partition
+    schema = workload.hits_schema()
+    data = workload.hits_csv(6000)
+    opts = workload.hits_csv_options()
+    cfg = {"shardsCount": "5", "columns": {"includeColumns": ["^watchid$", "^title$", "^eventdate$"]}}
+    db, _, errs = tf.csv_parse(opts, schema, data)
+    sharded = tf.Transformer("sharder_transformer", cfg).apply(db).transformed
+    grouped, counts = tf.partition(sharded, 5)
+    out = grouped.download()
+    ref = oracle.csv_parse(opts, schema, data, "", "")
+    ref2 = oracle.Transformer("sharder_transformer", cfg).apply(ref.batch, ref.schema)
+    part = ref2.batch.part_id.astype(np.int64)
+    order = np.argsort(part, kind="stable")
+    assert counts == [int((part == d).sum()) for d in range(5)] and sum(counts) == 6000 and min(counts) > 0
+    assert np.array_equal(out.src_row, order.astype(np.int32))
+    assert np.array_equal(out.part_id, part[order].astype(np.uint32))
+    for a, b in zip(out.cols, ref2.batch.cols):
+        if a.repr in abi.VAR_REPRS:
+            assert [a.get_bytes(i) for i in range(0, 6000, 7)] == [b.get_bytes(int(order[i])) for i in range(0, 6000, 7)], a.name
+        else:
+            assert np.array_equal(a.values, b.values[order]), a.name
+    with pytest.raises(tf.TfgpuError):
+        tf.partition(sharded, 3)  # part ids 3, 4 fall outside
+    # single-rank RCCL group: the exchange is the identity, every buffer makes the round trip through torch + RCCL.
+    # Own process, torch first (as in bench.py): libtfgpu and torch must share ONE HIP runtime, the one torch loads.
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import socket, sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+        import torch, torch.distributed as dist
+        torch.cuda.set_device(0); torch.cuda.init()
+        from transferia_amd import lib as tf, workload, partition, abi
+        from test_gpu_transformers import assert_batches_equal
+        tf.init(0)
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, world_size=1, rank=0, device_id=torch.device("cuda", 0))
+        schema = workload.hits_schema(); opts = workload.hits_csv_options()
+        db, _, errs = tf.csv_parse(opts, schema, workload.hits_csv(6000))
+        one = tf.Transformer("sharder_transformer", {"shardsCount": "1", "columns": {"includeColumns": ["^watchid$"]}}).apply(db).transformed
+        grouped, counts = tf.partition(one, 1)
+        assert counts == [6000]
+        back, recv = partition.exchange_device_batch(dist, tf, grouped, counts)
+        assert recv == [6000]
+        a, b = back.download(), db.download()
+        assert_batches_equal(a, b, "exchange identity")
+        dist.destroy_process_group()
+        print("EXCHANGE_OK")
+    """ % (root, root))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "EXCHANGE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

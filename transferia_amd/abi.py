@@ -299,6 +299,10 @@ class Batch:
         ns, tn = _b(self.table_ns), _b(self.table_name)
         keep += [ns, tn]
         cb.table_ns, cb.table_name, cb.mem = ns, tn, MEM_HOST
+        if self.part_id is not None:
+            pid = np.ascontiguousarray(self.part_id, dtype=np.uint32)
+            keep.append(pid)
+            cb.part_id = pid.ctypes.data
         if getattr(self, "schema", None) is not None:  # ChangeItem.TableSchema when it differs from ColumnNames
             cs = self.schema.to_c()
             keep.append(cs)

@@ -3,6 +3,7 @@
 #include "tf_plan.hpp"
 
 using namespace tf;
+namespace tf { std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &in, int nparts, int64_t *counts); }
 
 #define TF_API_BEGIN try {
 #define TF_API_END                                                        \
@@ -119,6 +120,15 @@ int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tf
   if (nerrs) *nerrs = (int64_t)ax.errs.size();
   if (errs) for (int64_t k = 0; k < errs_cap && k < (int64_t)ax.errs.size(); k++) errs[k] = ax.errs[(size_t)k];
   *out = cur.release();
+  return TFGPU_OK;
+  TF_API_END
+}
+
+int tfgpu_partition(const tfgpu_dbatch *in, int nparts, tfgpu_dbatch **out, int64_t *counts) {
+  TF_API_BEGIN
+  if (!in || !out || !counts || nparts < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_partition: bad argument");
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  *out = partition_rows(*in, nparts, counts).release();
   return TFGPU_OK;
   TF_API_END
 }

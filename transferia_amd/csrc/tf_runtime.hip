@@ -270,18 +270,21 @@ int tfgpu_host_free(void *p) {
 }
 
 // ---- batches ---------------------------------------------------------------
+static thread_local bool g_upload_from_device = false;
 static Buf upload(const void *src, size_t n) {
   if (!src) return nullptr;
   Buf b = dalloc(n);
-  h2d(b->p, src, n);
+  if (g_upload_from_device) d2d(b->p, src, n); else h2d(b->p, src, n);
   return b;
 }
 
 int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
   TF_API_BEGIN
   if (!h || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_batch_upload: null argument");
-  if (h->mem != TFGPU_MEM_HOST) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_batch_upload: batch is not in host memory");
+  if (h->mem != TFGPU_MEM_HOST && h->mem != TFGPU_MEM_DEVICE) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_batch_upload: bad mem");
   std::lock_guard<std::mutex> lk(ctx().mu);
+  const bool from_dev = h->mem == TFGPU_MEM_DEVICE;
+  struct Flag { Flag(bool v) { g_upload_from_device = v; } ~Flag() { g_upload_from_device = false; } } flag(from_dev);
   auto b = std::make_unique<tfgpu_dbatch>();
   b->nrows = h->nrows;
   b->ns = h->table_ns ? h->table_ns : "";
@@ -296,9 +299,9 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
     if (repr_is_var(c.repr)) {
       if (!c.offsets) return tf::fail(TFGPU_ERR_INVALID, "column " + d.name + ": var-width column without offsets");
       d.offsets = upload(c.offsets, (n + 1) * 4);
-      d.data_len = c.offsets[n];
+      d.data_len = from_dev ? c.data_len : c.offsets[n];  // device offsets cannot be read here: the caller states the length
       d.data = dalloc(d.data_len);
-      h2d(d.data->p, c.data, d.data_len);
+      if (from_dev) d2d(d.data->p, c.data, d.data_len); else h2d(d.data->p, c.data, d.data_len);
     } else {
       if (!c.values && n) return tf::fail(TFGPU_ERR_INVALID, "column " + d.name + ": fixed-width column without values");
       d.values = upload(c.values, n * repr_width(c.repr));
@@ -310,6 +313,7 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
   if (h->schema) for (int i = 0; i < h->schema->ncols; i++) b->schema.push_back({h->schema->cols[i].name ? h->schema->cols[i].name : "", h->schema->cols[i].dtype});
   if (h->kind) b->kind = upload(h->kind, n);
   if (h->src_row) b->src_row = upload(h->src_row, n * 4);
+  if (h->part_id) b->part_id = upload(h->part_id, n * 4);
   tf::sync();  // caller may release its buffers as soon as we return
   *out = b.release();
   return TFGPU_OK;

@@ -463,7 +463,7 @@ __global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int
 // Gather all columns of `in` through `sel` (m output rows).
 static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const Buf &sel, int64_t m) {
   auto out = std::make_unique<tfgpu_dbatch>();
-  out->nrows = m; out->ns = in.ns; out->table = in.table;
+  out->nrows = m; out->ns = in.ns; out->table = in.table; out->schema = in.schema;
   hipStream_t st = ctx().stream;
   const int32_t *sp = ptr<int32_t>(sel);
   unsigned g = grid_for(m, 256);
@@ -784,6 +784,40 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_columns(const tfgpu_plan &p, c
   out->schema.clear();
   for (auto &sc : in.schema) if (p.columns.match(sc.first)) out->schema.push_back(sc);
   return out;
+}
+
+// ============================================================================
+// hash-partition, local half (config 5): rows grouped by PartID, original order kept inside a part
+// ============================================================================
+__global__ void part_keep_kernel(const uint32_t *part_id, int64_t n, uint32_t d, uint32_t *keep) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) keep[r] = part_id[r] == d ? 1u : 0u;
+}
+__global__ void part_scatter_kernel(const uint32_t *keep_scan, int64_t n, uint32_t base, int32_t *sel) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t a = keep_scan[i], b = keep_scan[i + 1];
+  if (a != b) sel[base + a] = (int32_t)i;
+}
+std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &in, int nparts, int64_t *counts) {
+  if (!in.part_id) throw Error(TFGPU_ERR_INVALID, "tfgpu_partition: the batch has no part_id (apply sharder_transformer first)");
+  const int64_t n = in.nrows;
+  hipStream_t st = ctx().stream;
+  Buf sel = dalloc((size_t)n * 4 + 4), keep = dalloc((size_t)(n + 1) * 4);
+  uint32_t base = 0;
+  KernelTimer t("partition_rows");
+  for (int d = 0; d < nparts; d++) {
+    if (n) part_keep_kernel<<<grid_for(n, 256), 256, 0, st>>>(ptr<uint32_t>(in.part_id), n, (uint32_t)d, ptr<uint32_t>(keep));
+    exclusive_scan_u32(ptr<uint32_t>(keep), ptr<uint32_t>(keep), n, true);
+    const uint32_t *h = d2h_u32(ptr<uint32_t>(keep) + n);
+    sync();
+    const uint32_t m = *h;
+    if (n && m) part_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(ptr<uint32_t>(keep), n, base, ptr<int32_t>(sel));
+    counts[d] = m;
+    base += m;
+  }
+  if ((int64_t)base != n) throw Error(TFGPU_ERR_INVALID, "tfgpu_partition: part_id outside [0, nparts)");
+  return gather_batch(in, sel, n);
 }
 
 std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {

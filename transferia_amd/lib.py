@@ -27,7 +27,7 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -77,6 +77,7 @@ def load():
     L.tfgpu_dbatch_free.argtypes = [P]
     L.tfgpu_dbatch_free.restype = None
     L.tfgpu_apply.argtypes = [C.POINTER(P), C.c_int, P, C.POINTER(P), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_partition.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
     L.tfgpu_csv_options_default.argtypes = [C.POINTER(abi.CCsvOptions)]
     L.tfgpu_csv_options_default.restype = None
     L.tfgpu_csv_parse.argtypes = [C.POINTER(abi.CCsvOptions), C.POINTER(abi.CSchema), P, C.c_uint64, C.c_int, C.POINTER(P),
@@ -377,6 +378,16 @@ def apply_chain(transformers: Sequence[Transformer], batch: DeviceBatch, max_err
     el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
           for i in range(min(int(nerr.value), max_errors))]
     return TransformerResult(DeviceBatch(out), el)
+
+
+def partition(batch: DeviceBatch, nparts: int):
+    """Regroup the rows by part_id (sharder_transformer's PartID), parts in order, row order kept inside a part.
+    Returns (DeviceBatch, counts[nparts]): every column buffer is laid out for one all-to-all with those splits."""
+    init()
+    out = C.c_void_p()
+    counts = (C.c_int64 * nparts)()
+    _check(load().tfgpu_partition(batch._h, nparts, C.byref(out), counts))
+    return DeviceBatch(out), [int(c) for c in counts]
 
 
 def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int = 1 << 16):
