@@ -100,7 +100,7 @@ def json_main(args):
     ClickHouse JSONEachRow text, all HBM-resident; the oracle's generic parser on a bounded sample as cpu_baseline."""
     import csv
     import io
-    args.rows = min(args.rows, 1 << 16)
+    args.rows = min(args.rows, 1 << 18)
     args.cpu_rows = min(args.cpu_rows, 1 << 13)
     from transferia_amd import abi, lib, workload
     lib.init(0)

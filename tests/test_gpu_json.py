@@ -384,3 +384,17 @@ def test_flat_lines_are_device_resident(tf, oracle):
             assert np.array_equal(a.offsets, b.offsets) and bytes(a.data) == bytes(b.data)
         else:
             assert bytes(a.values) == bytes(b.values)
+
+
+def test_wave_path_cross_check():
+    """The wave-cooperative parser (TFGPU_JSON_WAVEPATH=1: simdjson-style stage 1 on the scalar unit, members on lanes)
+    and the per-line parser are two independent implementations of the same grammar: the edge-case, fuzz and flat
+    suites must pass under both."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFGPU_JSON_WAVEPATH="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_json.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "edge or random or flat or canon or rules or aux or messages"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]

@@ -665,6 +665,229 @@ __global__ void __launch_bounds__(256) json_parse_lines(JParams p) {
   const uint64_t s = p.seg_start[i];
   parse_json_line(p, (int64_t)p.seg_ord[i], s, s + n);
 }
+// the lines the wave path hands over (nested values, anything it does not fully understand): one lane per line
+__global__ void __launch_bounds__(256) json_parse_listed(JParams p, const uint32_t *slow_n, const uint32_t *slow_seg) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= *slow_n) return;
+  const uint32_t i = slow_seg[k];
+  const uint64_t s = p.seg_start[i];
+  parse_json_line(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i]);
+}
+
+// ---------------------------------------------------------------------------
+// wave path.  One 64-lane wave owns a line.  Stage 1 is simdjson's, on the scalar unit: 64 bytes per step, one
+// byte per lane, every character class a ballot (a 64-bit mask in SGPRs), escaped quotes by the add-carry trick,
+// the in-string mask by a prefix xor — ~50 scalar ops per 64 bytes, shared by the whole wave.  The masks go to
+// LDS; then lane m takes top-level member m: it finds its colon by a rank/select over the colon mask, its key and
+// value by next/previous-bit queries, checks that nothing but whitespace sits in between, and runs the same
+// store_cell as the per-line path.  Only FLAT objects are taken (scalar values, no duplicate keys, <= 128 members,
+// <= JF_MAX bytes); every other line — and every line that does not validate — goes to json_parse_listed, so
+// the wave path never has to classify an error.
+// ---------------------------------------------------------------------------
+static constexpr int JF_MAX = 4096;
+static constexpr int JF_WORDS = JF_MAX / 64;
+static constexpr int JF_WAVES = 4;
+static constexpr int JF_OWN = 512;
+static constexpr uint32_t JF_NONE = 0xFFFFFFFFu;
+struct JFastLds {
+  uint64_t q[JF_WORDS], col[JF_WORDS], com[JF_WORDS], nws[JF_WORDS], bs[JF_WORDS], ctl[JF_WORDS], npl[JF_WORDS], num[JF_WORDS];
+  uint16_t ccol[JF_WORDS + 2], ccom[JF_WORDS + 2];
+  uint32_t owner[JF_OWN];
+};
+__device__ __forceinline__ uint64_t jf_find_escaped(uint64_t bs, uint64_t &carry) {  // bytes escaped by an odd backslash run
+  bs &= ~carry;
+  const uint64_t follows = (bs << 1) | carry;
+  const uint64_t even = 0x5555555555555555ull;
+  const uint64_t odd_starts = bs & ~even & ~follows;
+  const uint64_t sum = odd_starts + bs;
+  carry = sum < bs ? 1ull : 0ull;
+  return (even ^ (sum << 1)) & follows;
+}
+__device__ __forceinline__ uint64_t jf_prefix_xor(uint64_t x) { x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32; return x; }
+// any set bit of m in [a, b)
+__device__ __forceinline__ bool jf_any(const uint64_t *m, uint32_t a, uint32_t b) {
+  if (a >= b) return false;
+  const uint32_t w0 = a >> 6, w1 = (b - 1) >> 6;
+  for (uint32_t w = w0; w <= w1; w++) {
+    uint64_t x = m[w];
+    if (w == w0) x &= ~0ull << (a & 63);
+    if (w == w1) x &= ~0ull >> (63 - ((b - 1) & 63));
+    if (x) return true;
+  }
+  return false;
+}
+__device__ __forceinline__ bool jf_all(const uint64_t *m, uint32_t a, uint32_t b) {  // every bit of [a, b) set
+  if (a >= b) return true;
+  const uint32_t w0 = a >> 6, w1 = (b - 1) >> 6;
+  for (uint32_t w = w0; w <= w1; w++) {
+    uint64_t x = ~m[w];
+    if (w == w0) x &= ~0ull << (a & 63);
+    if (w == w1) x &= ~0ull >> (63 - ((b - 1) & 63));
+    if (x) return false;
+  }
+  return true;
+}
+__device__ __forceinline__ uint32_t jf_next(const uint64_t *m, uint32_t p, uint32_t nw) {  // first set bit at or after p
+  uint32_t w = p >> 6;
+  if (w >= nw) return JF_NONE;
+  uint64_t x = m[w] & (~0ull << (p & 63));
+  while (!x) { if (++w >= nw) return JF_NONE; x = m[w]; }
+  return (w << 6) + (uint32_t)__ffsll((long long)x) - 1;
+}
+__device__ __forceinline__ uint32_t jf_prev(const uint64_t *m, uint32_t p) {  // last set bit strictly below p
+  if (p == 0) return JF_NONE;
+  uint32_t w = (p - 1) >> 6;
+  uint64_t x = m[w] & (~0ull >> (63 - ((p - 1) & 63)));
+  while (!x) { if (w == 0) return JF_NONE; x = m[--w]; }
+  return (w << 6) + 63 - (uint32_t)__clzll((long long)x);
+}
+__device__ __forceinline__ uint32_t jf_select(const uint64_t *m, const uint16_t *c, uint32_t nw, uint32_t j) {  // j-th set bit, c = prefix counts
+  uint32_t lo = 0, hi = nw;  // last word with c[w] <= j
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (c[mid] <= j) lo = mid; else hi = mid; }
+  uint64_t x = m[lo];
+  for (uint32_t k = j - c[lo]; k; k--) x &= x - 1;
+  return (lo << 6) + (uint32_t)__ffsll((long long)x) - 1;
+}
+
+__global__ void __launch_bounds__(256) json_parse_waves(JParams p, uint32_t *slow_n, uint32_t *slow_seg) {
+  __shared__ JFastLds lds_all[JF_WAVES];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  JFastLds &L = lds_all[wv];
+  const int64_t nwaves = (int64_t)gridDim.x * JF_WAVES;
+  uint32_t iter = 0;
+  MemBytes aux(p.data);
+  for (int64_t i = (int64_t)blockIdx.x * JF_WAVES + wv; i < p.nseg; i += nwaves) {
+    const uint32_t n = p.seg_len[i];
+    if (!n) continue;
+    iter++;
+    const uint64_t base = p.seg_start[i];
+    const int64_t r = (int64_t)p.seg_ord[i];
+    bool slow = n > JF_MAX;
+    uint32_t nm = 0, open_pos = JF_NONE, close_pos = JF_NONE;
+    const uint32_t nw = slow ? 0u : (n + 63) >> 6;
+    if (!slow) {
+      uint64_t esc_carry = 0, str_carry = 0;
+      uint32_t ncol = 0, ncom = 0, nopen = 0, nclose = 0, nnws = 0, first_nws = JF_NONE, last_nws = JF_NONE;
+      for (uint32_t k = 0; k < nw; k++) {
+        const uint32_t pos = k * 64 + lane;
+        const uint32_t c = pos < n ? (uint32_t)p.data[base + pos] : 0x20u;
+        uint64_t Q = __ballot(c == '"');
+        const uint64_t B = __ballot(c == '\\');
+        Q &= ~jf_find_escaped(B, esc_carry);
+        const uint64_t instr = jf_prefix_xor(Q) ^ str_carry;  // bit i = inside a string after byte i (opening quote 1, closing quote 0)
+        str_carry = (uint64_t)((int64_t)instr >> 63);
+        const uint64_t outside = ~instr & ~Q;
+        const uint64_t col = __ballot(c == ':') & outside, com = __ballot(c == ',') & outside;
+        const uint64_t opn = __ballot(c == '{' || c == '[') & outside, cls = __ballot(c == '}' || c == ']') & outside;
+        const uint64_t nws = ~__ballot(c == ' ' || c == '\n' || c == '\t' || c == '\r');
+        const uint64_t ctl = __ballot(c < 0x20u);
+        const uint64_t npl = __ballot(c < 0x20u || c > 0x7Fu || c == '\\' || c == '"' || c == '<' || c == '>' || c == '&');
+        const uint64_t num = __ballot((c >= '0' && c <= '9') || c == '.' || c == '-' || c == '+' || c == 'e' || c == 'E');
+        if (lane == 0) {
+          L.q[k] = Q; L.col[k] = col; L.com[k] = com; L.nws[k] = nws; L.bs[k] = B; L.ctl[k] = ctl; L.npl[k] = npl; L.num[k] = num;
+          L.ccol[k] = (uint16_t)ncol; L.ccom[k] = (uint16_t)ncom;
+        }
+        if (opn && !nopen) open_pos = k * 64 + (uint32_t)__ffsll((long long)opn) - 1;
+        if (cls) close_pos = k * 64 + 63 - (uint32_t)__clzll((long long)cls);
+        if (nws) { if (first_nws == JF_NONE) first_nws = k * 64 + (uint32_t)__ffsll((long long)nws) - 1; last_nws = k * 64 + 63 - (uint32_t)__clzll((long long)nws); }
+        ncol += (uint32_t)__popcll(col); ncom += (uint32_t)__popcll(com); nopen += (uint32_t)__popcll(opn); nclose += (uint32_t)__popcll(cls);
+        nnws += (uint32_t)__popcll(nws);
+      }
+      if (lane == 0) { L.ccol[nw] = (uint16_t)ncol; L.ccom[nw] = (uint16_t)ncom; }
+      nm = ncol;
+      // ws* { members } ws* with balanced quotes and no nested container
+      slow = str_carry != 0 || nopen != 1 || nclose != 1 || open_pos != first_nws || close_pos != last_nws;
+      if (!slow) slow = p.data[base + open_pos] != '{' || p.data[base + close_pos] != '}';
+      if (!slow) slow = nm == 0 ? (ncom != 0 || nnws != 2) : (ncom != nm - 1 || nm > 128);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- members: validate all, then store ----
+    uint32_t ks[2], kn[2], vs[2], ve[2];
+    int32_t kcol[2];
+    int vt[2];
+    bool bad = false;
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++) {
+      const uint32_t m = (uint32_t)rd * 64 + (uint32_t)lane;
+      kcol[rd] = JS_UNKNOWN; vt[rd] = -1; ks[rd] = kn[rd] = vs[rd] = ve[rd] = 0;
+      if (slow || m >= nm) continue;
+      const uint32_t pc = jf_select(L.col, L.ccol, nw, m);
+      const uint32_t pprev = m ? jf_select(L.com, L.ccom, nw, m - 1) : open_pos;
+      const uint32_t pnext = m + 1 < nm ? jf_select(L.com, L.ccom, nw, m) : close_pos;
+      const uint32_t q2 = jf_prev(L.q, pc), q1 = q2 != JF_NONE ? jf_prev(L.q, q2) : JF_NONE;
+      if (q1 == JF_NONE || q1 <= pprev || pprev >= pc || pc >= pnext || jf_any(L.nws, pprev + 1, q1) || jf_any(L.nws, q2 + 1, pc)) { bad = true; continue; }
+      const uint32_t v0 = jf_next(L.nws, pc + 1, nw);
+      if (v0 == JF_NONE || v0 >= pnext) { bad = true; continue; }
+      const uint32_t v1 = jf_prev(L.nws, pnext) + 1;  // one past the last byte of the value; > v0
+      const uint32_t c0 = p.data[base + v0];
+      int t;
+      if (c0 == '"') {
+        if (v1 - v0 < 2 || jf_next(L.q, v0 + 1, nw) != v1 - 1) { bad = true; continue; }
+        t = V_STR;
+      } else {
+        if (!jf_all(L.nws, v0, v1) || jf_any(L.q, v0, v1)) { bad = true; continue; }
+        const uint32_t tn = v1 - v0;
+        auto is = [&](const char *w, uint32_t wl) { if (tn != wl) return false; for (uint32_t k = 0; k < wl; k++) if (p.data[base + v0 + k] != (uint8_t)w[k]) return false; return true; };
+        if (c0 == 't') { if (!is("true", 4)) { bad = true; continue; } t = V_TRUE; }
+        else if (c0 == 'f') { if (!is("false", 5)) { bad = true; continue; } t = V_FALSE; }
+        else if (c0 == 'n') { if (!is("null", 4)) { bad = true; continue; } t = V_NULL; }
+        else {  // parseRawNumber: a run of [0-9.+-eE]; a lone sign is "unexpected char"; inf / nan spellings: per-line path
+          if (!jf_all(L.num, v0, v1) || (tn == 1 && (c0 == '-' || c0 == '+'))) { bad = true; continue; }
+          t = V_NUM;
+        }
+      }
+      ks[rd] = q1 + 1; kn[rd] = q2 - q1 - 1; vs[rd] = v0; ve[rd] = v1; vt[rd] = t;
+      if (jf_any(L.bs, ks[rd], q2)) { bad = true; continue; }  // key compared after unescaping: per-line path (→ host)
+      // which column reads this key?
+      uint32_t h = 2166136261u;
+      for (uint32_t k = 0; k < kn[rd]; k++) h = fnv1a(h, aux.at(base + ks[rd] + k));
+      int32_t kc = JS_UNKNOWN;
+      for (uint32_t sl_ = h & p.slot_mask;; sl_ = (sl_ + 1) & p.slot_mask) {
+        const JSlot sl = p.slots[sl_];
+        if (sl.slen == ~0u) break;
+        if (sl.hash == h && sl.slen == kn[rd]) {
+          bool same = true;
+          for (uint32_t k = 0; k < kn[rd] && same; k++) same = aux.at(base + ks[rd] + k) == p.names[sl.soff + k];
+          if (same) { kc = sl.col; if (sl.aux) bad = true; break; }
+        }
+      }
+      if (p.add_rest && kc == JS_UNKNOWN) bad = true;  // `_rest` would not be {}: per-line path (→ host)
+      kcol[rd] = kc;
+      if (kc >= 0) { if (kc >= JF_OWN) bad = true; else L.owner[kc] = (iter << 8) | m; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++)  // a key read twice: "the last one wins" needs the members in order
+      if (kcol[rd] >= 0 && kcol[rd] < JF_OWN && L.owner[kcol[rd]] != ((iter << 8) | ((uint32_t)rd * 64 + (uint32_t)lane))) bad = true;
+    slow = slow || __any(bad);
+    if (slow) {
+      if (lane == 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)i; }
+      continue;
+    }
+    bool fb = false;
+#pragma unroll
+    for (int rd = 0; rd < 2; rd++) {
+      if (vt[rd] < 0) continue;
+      JStr sv{};
+      uint64_t a0 = base + vs[rd], a1 = base + ve[rd];
+      if (vt[rd] == V_STR) {
+        sv.s = a0 + 1; sv.n = ve[rd] - vs[rd] - 2;
+        sv.bs = jf_any(L.bs, vs[rd] + 1, ve[rd] - 1); sv.ctrl = jf_any(L.ctl, vs[rd] + 1, ve[rd] - 1); sv.plain = !jf_any(L.npl, vs[rd] + 1, ve[rd] - 1);
+      }
+      for (int32_t ci = kcol[rd]; ci >= 0; ci = p.cols[ci].next)
+        if (!store_cell(p, p.cols[ci], r, aux, vt[rd], a0, a1, sv, 0, false)) { fb = true; break; }
+    }
+    fb = __any(fb);
+    if (lane == 0) {
+      p.linest[r] = fb ? JL_FALLBACK : (nm ? JL_ROW : JL_SKIPPED);
+      p.line_pos[r] = (uint32_t)base;
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------
 // line boundaries
@@ -888,7 +1111,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
                                 const tfgpu_messages *msgs, tfgpu_dbatch **out, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
   TF_API_BEGIN
   if (!opts || !fields || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_json_parse: null argument");
-  if (len >= 0x0FFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_json_parse: batch must be < 256 MiB of JSON (Bufferer-sized batches are, bufferer.go:117-249)");
+  if (len >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_json_parse: batch must be < 4 GiB of JSON (32-bit cell offsets; Bufferer-sized batches are far below, bufferer.go:117-249)");
   if (opts->unescape_string_values) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: UnescapeStringValues is not device-resident");
   if (opts->unpack_bytes_base64) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: UnpackBytesBase64 is not device-resident");
   Context &cx = ctx();
@@ -1085,7 +1308,21 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   pp.cols = ptr<JCol>(bcols); pp.ncols = nraw; pp.slots = ptr<JSlot>(bslots); pp.slot_mask = nslots - 1; pp.names = ptr<uint8_t>(bnames);
   pp.pow10 = pow10_table(); pp.pow128 = reinterpret_cast<const uint64_t *>(pp.pow10 + 632); pp.linest = ptr<uint8_t>(linest); pp.line_pos = ptr<uint32_t>(line_pos);
   pp.add_rest = opts->add_rest; pp.use_numbers = opts->use_numbers_in_any;
-  if (nlines) { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp); }
+  // The per-line path is the default: 64 lines of one shape run in lockstep, so a wave pays each instruction once per
+  // 64 lines (≈ 23 k wave-instructions per 64 lines of 2.3 KB).  The wave path (TFGPU_JSON_WAVEPATH=1) reads coalesced
+  // and does stage 1 on the scalar unit, but its lanes are MEMBERS of one line — different column kinds side by side —
+  // and the divergent typed parse costs ≈ 20 k wave-instructions per LINE: measured 2× slower at 2^18 hits rows
+  // (13.6 vs 6.7 ms, profiles/r01y_json_paths.txt).  Kept as the parity cross-check of the grammar and as the
+  // starting point for a kind-sorted member phase.
+  static const bool wavepath = [] { const char *e = std::getenv("TFGPU_JSON_WAVEPATH"); return e && e[0] == '1'; }();
+  if (nlines && !wavepath) { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp); }
+  else if (nlines) {
+    Buf slow = dalloc((size_t)(nseg + 1) * 4);
+    TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
+    const unsigned nblk = (unsigned)std::min<int64_t>((nseg + JF_WAVES - 1) / JF_WAVES, (int64_t)cx.num_cus * 8);
+    { KernelTimer t("json_parse_waves"); json_parse_waves<<<nblk, 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+    { KernelTimer t("json_parse_listed"); json_parse_listed<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+  }
 
   // ---- aux columns + row rules ----
   Buf code = dalloc((size_t)nalloc + 16), ecol = dalloc((size_t)nalloc * 4), keep = dalloc((size_t)(nalloc + 1) * 4), nerr = dalloc_zero(4);
