@@ -20,6 +20,19 @@ struct MemBytes {
     if (i != widx) { win = reinterpret_cast<const uint64_t *>(base)[i]; widx = i; }
     return (uint32_t)(win >> ((pos & 7) * 8)) & 0xFFu;
   }
+  // the 8 bytes at [pos, pos + 8), little-endian, for any alignment (buffers are padded past their payload)
+  uint64_t win2 = 0; uint64_t w2idx = ~0ull;
+  __device__ __forceinline__ uint64_t word(uint64_t pos) {
+    const uint64_t i = pos >> 3;
+    const uint32_t sh = (uint32_t)(pos & 7) * 8;
+    if (i != widx) {
+      if (i == w2idx) win = win2; else win = reinterpret_cast<const uint64_t *>(base)[i];
+      widx = i;
+    }
+    if (!sh) return win;
+    if (w2idx != i + 1) { win2 = reinterpret_cast<const uint64_t *>(base)[i + 1]; w2idx = i + 1; }
+    return (win >> sh) | (win2 << (64 - sh));
+  }
 };
 // A field view: absolute [start, start+n) through a MemBytes reader (HBM, slow path).
 struct Field {
@@ -125,6 +138,52 @@ template <class F> __device__ __forceinline__ int parse_bool(const F &f, uint32_
     return 1;
   }
   return 1;
+}
+
+// Decimal text → integer without a per-digit loop.  `t` holds up to 8 digit VALUES (0..9), one per byte, most
+// significant digit in byte 0, zero-padded at the front: pairs → fours → eight, all in full-rate 24-bit multiplies.
+__device__ __forceinline__ uint32_t four_digits(uint32_t x) {
+  const uint32_t pairs = __umul24(x & 0x00FF00FFu, 10u) + ((x >> 8) & 0x00FF00FFu);  // b0*10+b1 | (b2*10+b3) << 16
+  return __umul24(pairs & 0xFFFFu, 100u) + (pairs >> 16);
+}
+__device__ __forceinline__ uint32_t eight_digits(uint64_t t) { return __umul24(four_digits((uint32_t)t), 10000u) + four_digits((uint32_t)(t >> 32)); }
+// every byte of d (= text ^ '0' per byte) is a digit value
+__device__ __forceinline__ bool all_digits(uint64_t d) { return (((d + 0x7676767676767676ull) | d) & 0x8080808080808080ull) == 0; }
+// n characters at bytes [0, n) of the 24-byte little-endian window (b0,b1,b2); the first i0 (0 or 1) are a sign,
+// the other nd = n - i0 (1..19) must be decimal digits.  false if a non-digit shows up.
+__device__ __forceinline__ bool digits_u64(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t i0, uint32_t n, uint64_t *out) {
+  const uint64_t K = 0x3030303030303030ull;
+  const bool sane = n > i0 && n - i0 <= 19;
+  const uint32_t nd = sane ? n - i0 : 1u;
+  const uint64_t s0 = i0 ? (b0 >> 8) | (b1 << 56) : b0;
+  if (!__any(nd > 8)) {  // the common case: the whole wave parses short numbers
+    uint64_t d = (s0 ^ K) & (nd >= 8 ? ~0ull : (1ull << (8 * nd)) - 1);
+    const bool ok = all_digits(d);
+    d <<= 8 * (8 - (nd > 8 ? 8 : nd));
+    *out = eight_digits(d);
+    return ok && sane;
+  }
+  const uint64_t s1 = i0 ? (b1 >> 8) | (b2 << 56) : b1, s2 = i0 ? b2 >> 8 : b2;
+  // groups of 8 digits from the right; the leftmost group has g1 = nd - 8 * (groups - 1) digits
+  const uint32_t ng = nd > 16 ? 3u : nd > 8 ? 2u : 1u;
+  const uint32_t g1 = nd - 8 * (ng - 1);  // 1..8
+  uint64_t d1 = (s0 ^ K) & (g1 >= 8 ? ~0ull : (1ull << (8 * g1)) - 1);
+  bool ok = all_digits(d1);
+  d1 <<= 8 * (8 - g1);
+  uint64_t v = eight_digits(d1);
+  if (ng >= 2) {
+    const uint32_t sh = 8 * g1;  // 8..64
+    const uint64_t d2 = (sh == 64 ? s1 : (s0 >> sh) | (s1 << (64 - sh))) ^ K;
+    ok = ok && all_digits(d2);
+    v = v * 100000000ull + eight_digits(d2);
+    if (ng == 3) {
+      const uint64_t d3 = (sh == 64 ? s2 : (s1 >> sh) | (s2 << (64 - sh))) ^ K;
+      ok = ok && all_digits(d3);
+      v = v * 100000000ull + eight_digits(d3);
+    }
+  }
+  *out = v;
+  return ok && sane;
 }
 
 // strconv.eiselLemire64 (Go strconv/eisel_lemire.go): man * 10^exp10 → the correctly rounded float64 bits,

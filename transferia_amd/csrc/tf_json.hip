@@ -83,25 +83,48 @@ __device__ __forceinline__ uint32_t fnv1a(uint32_t h, uint32_t c) { return (h ^ 
 // ---------------------------------------------------------------------------
 struct JStr { uint64_t s; uint32_t n; uint32_t hash; bool bs, ctrl, plain; };
 
-// parseRawString: `pos` is one past the opening quote; the closing quote is the first '"' preceded by an
-// even number of backslashes.  false: no closing quote.
+// hash of a top-level key for the column table: 8-byte little-endian chunks of the raw key (the last one zero-padded)
+// folded with the length; key_hash_host computes the same over the column paths.
+__device__ __forceinline__ uint32_t key_mix(uint32_t h, uint64_t w) {
+  h = (h ^ (uint32_t)w) * 0x85EBCA6Bu; h = (h ^ (uint32_t)(w >> 32)) * 0xC2B2AE35u;
+  return h ^ (h >> 15);
+}
+__device__ __forceinline__ uint32_t key_finish(uint32_t h, uint32_t n) { return h ^ (n * 0x27D4EB2Fu); }
+
+// parseRawString: `pos` is one past the opening quote; the closing quote is the first '"' preceded by an even
+// number of backslashes, i.e. the first quote met when every backslash swallows the byte after it.  Eight bytes
+// per step: the first quote / backslash of the word by SWAR zero-byte flags (the lowest flag is exact), control
+// and non-ASCII bytes by SWAR range tests over the bytes before it.  false: no closing quote.
 __device__ __forceinline__ bool scan_string(MemBytes &rd, uint64_t &pos, const uint64_t end, JStr &o) {
+  const uint64_t ONES = 0x0101010101010101ull, HI = 0x8080808080808080ull;
   o.s = pos;
-  uint32_t run = 0, h = 2166136261u;
-  bool bs = false, ctrl = false, plain = true;
+  uint32_t h = 0x9E3779B9u;
+  bool bs = false, ctrl = false, hi = false;
   while (pos < end) {
-    const uint32_t c = rd.at(pos);
-    if (c == '"' && !(run & 1u)) {
-      o.n = (uint32_t)(pos - o.s); o.hash = h; o.bs = bs; o.ctrl = ctrl; o.plain = plain;
+    const uint64_t x = rd.word(pos);
+    const uint32_t nb = end - pos < 8 ? (uint32_t)(end - pos) : 8u;
+    const uint64_t xq = x ^ 0x2222222222222222ull, xb = x ^ 0x5C5C5C5C5C5C5C5Cull;
+    uint64_t sp = (((xq - ONES) & ~xq) | ((xb - ONES) & ~xb)) & HI;
+    if (nb < 8) sp &= (1ull << (8 * nb)) - 1;
+    const uint32_t k = sp ? (uint32_t)(__ffsll((long long)sp) - 1) >> 3 : nb;  // bytes before the first quote / backslash
+    if (k) {
+      const uint64_t m = k >= 8 ? ~0ull : (1ull << (8 * k)) - 1;
+      const uint64_t y = (x & m) | (0x3030303030303030ull & ~m);
+      ctrl = ctrl || (((y - 0x2020202020202020ull) & ~y & HI) != 0);
+      hi = hi || (y & HI) != 0;
+      h = key_mix(h, x & m);
+    }
+    pos += k;
+    if (!sp) continue;
+    if (((x >> (8 * k)) & 0xFFu) == '"') {
+      o.n = (uint32_t)(pos - o.s); o.hash = key_finish(h, o.n); o.bs = bs; o.ctrl = ctrl; o.plain = !bs && !ctrl && !hi;
       pos++;
       return true;
     }
-    if (c == '\\') { run++; bs = true; } else run = 0;
-    if (c < 0x20) ctrl = true;
-    // bytes encoding/json would escape or re-validate: keep only printable ASCII without " \ < > &
-    if (c < 0x20 || c > 0x7F || c == '\\' || c == '"' || c == '<' || c == '>' || c == '&') plain = false;
-    h = fnv1a(h, c);
-    pos++;
+    bs = true;  // a backslash: the byte after it can neither end the string nor start another escape
+    if (pos + 1 >= end) { pos = end; return false; }
+    if (rd.at(pos + 1) < 0x20u) ctrl = true;
+    pos += 2;
   }
   return false;
 }
@@ -116,7 +139,9 @@ __device__ __forceinline__ bool scan_number(MemBytes &rd, uint64_t &pos, const u
   uint64_t i = pos;
   for (; i < end; i++) {
     const uint32_t ch = rd.at(i);
-    if ((ch >= '0' && ch <= '9') || ch == '.' || ch == '-' || ch == 'e' || ch == 'E' || ch == '+') continue;
+    // [0-9.+-eE] as one 64-bit table over ch - '+': '+'0 '-'2 '.'3 '0'..'9' 5..14 'E'26 'e'58
+    const uint32_t d = ch - 0x2Bu;
+    if (d < 64u && ((0x0400000004007FEDull >> d) & 1ull)) continue;
     const uint32_t b0 = rd.at(b);
     if (i == b || (i == b + 1 && (b0 == '-' || b0 == '+'))) {
       if (end - i >= 3 && (ci3(rd, i, 'i', 'n', 'f') || ci3(rd, i, 'n', 'a', 'n'))) { pos = i + 3; return true; }
@@ -129,7 +154,16 @@ __device__ __forceinline__ bool scan_number(MemBytes &rd, uint64_t &pos, const u
 }
 
 struct CountSink { uint32_t n = 0; __device__ __forceinline__ void put(uint32_t) { n++; } };
-struct StoreSink { uint8_t *d; uint32_t n = 0; __device__ __forceinline__ void put(uint32_t c) { d[n++] = (uint8_t)c; } };
+// bytes leave eight at a time in one (possibly unaligned) 8-byte store; finish() writes the tail
+struct StoreSink {
+  uint8_t *d; uint32_t n = 0; uint64_t acc = 0;
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  __device__ __forceinline__ void put(uint32_t c) {
+    acc |= (uint64_t)(c & 0xFFu) << (8 * (n & 7));
+    if ((++n & 7) == 0) { reinterpret_cast<U64 *>(d + n - 8)->v = acc; acc = 0; }
+  }
+  __device__ __forceinline__ void finish() { for (uint32_t k = n & ~7u; k < n; k++) { d[k] = (uint8_t)acc; acc >>= 8; } }
+};
 
 template <class S> __device__ __forceinline__ void put_utf8(S &o, uint32_t cp) {  // string(rune(x)); invalid → U+FFFD
   if (cp > 0x10FFFF || (cp >= 0xD800 && cp < 0xE000)) cp = 0xFFFD;
@@ -353,6 +387,13 @@ template <class F> __device__ int ff_best_effort(const F &f, const uint32_t n, c
 // fastfloat.ParseInt64BestEffort
 template <class F> __device__ int64_t ff_int64(const F &f, const uint32_t n) {
   if (n == 0) return 0;
+  if (n <= 18) {  // the whole token in at most three words: sign, then digits only, else 0
+    const uint64_t b0 = f.m->word(f.start), b1 = n > 8 ? f.m->word(f.start + 8) : 0, b2 = n > 16 ? f.m->word(f.start + 16) : 0;
+    const uint32_t i0 = ((uint32_t)b0 & 0xFFu) == '-' ? 1u : 0u;
+    uint64_t v;
+    if (n == i0 || !digits_u64(b0, b1, b2, i0, n, &v)) return 0;
+    return i0 ? -(int64_t)v : (int64_t)v;
+  }
   uint32_t i = 0;
   const bool minus = f[0] == '-';
   if (minus) { i++; if (i >= n) return 0; }
@@ -371,6 +412,11 @@ template <class F> __device__ int64_t ff_int64(const F &f, const uint32_t n) {
 // fastfloat.ParseUint64BestEffort
 template <class F> __device__ uint64_t ff_uint64(const F &f, const uint32_t n) {
   if (n == 0) return 0;
+  if (n <= 18) {
+    const uint64_t b0 = f.m->word(f.start), b1 = n > 8 ? f.m->word(f.start + 8) : 0, b2 = n > 16 ? f.m->word(f.start + 16) : 0;
+    uint64_t v;
+    return digits_u64(b0, b1, b2, 0, n, &v) ? v : 0;
+  }
   uint32_t i = 0;
   uint64_t d = 0;
   while (i < n) {
@@ -494,7 +540,8 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
         }
       } else if (vtype == V_STR) {
         // ParseVal: ReplaceAll(`\\`, `\`) then json.Unmarshal into a map — a map only if the text is an object
-        if (!sv.plain) return false;
+        if (!sv.plain) return false;  // printable ASCII without escapes so far; encoding/json also escapes < > &
+        for (uint32_t q = 0; q < sv.n; q++) { const uint32_t ch = str[q]; if (ch == '<' || ch == '>' || ch == '&') return false; }
         uint32_t i = 0;
         while (i < sv.n && (str[i] == ' ' || str[i] == '\t')) i++;
         if (i < sv.n && (str[i] == '{' || str[i] == 'n')) return false;  // an object, or `null` (Unmarshal succeeds with a nil map)
@@ -555,8 +602,11 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
             const JSlot sl = p.slots[s];
             if (sl.slen == ~0u) break;
             if (sl.hash == k.hash && sl.slen == k.n) {
-              bool same = true;
-              for (uint32_t i = 0; i < k.n && same; i++) same = aux.at(k.s + i) == p.names[sl.soff + i];
+              bool same = true;  // eight bytes per compare: the table's names are zero-padded to whole words
+              for (uint32_t i = 0; i < k.n && same; i += 8) {
+                const uint32_t nb = k.n - i < 8 ? k.n - i : 8u;
+                same = (aux.word(k.s + i) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1)) == *reinterpret_cast<const uint64_t *>(p.names + sl.soff + i);
+              }
               if (same) { kcol = sl.col; if (sl.aux) fallback = true; break; }  // colTypeMap types it as the aux column (:1218-1225): host
             }
           }
@@ -841,15 +891,22 @@ __global__ void __launch_bounds__(256) json_parse_waves(JParams p, uint32_t *slo
       ks[rd] = q1 + 1; kn[rd] = q2 - q1 - 1; vs[rd] = v0; ve[rd] = v1; vt[rd] = t;
       if (jf_any(L.bs, ks[rd], q2)) { bad = true; continue; }  // key compared after unescaping: per-line path (→ host)
       // which column reads this key?
-      uint32_t h = 2166136261u;
-      for (uint32_t k = 0; k < kn[rd]; k++) h = fnv1a(h, aux.at(base + ks[rd] + k));
+      uint32_t h = 0x9E3779B9u;
+      for (uint32_t k = 0; k < kn[rd]; k += 8) {
+        const uint32_t nb = kn[rd] - k < 8 ? kn[rd] - k : 8u;
+        h = key_mix(h, aux.word(base + ks[rd] + k) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1));
+      }
+      h = key_finish(h, kn[rd]);
       int32_t kc = JS_UNKNOWN;
       for (uint32_t sl_ = h & p.slot_mask;; sl_ = (sl_ + 1) & p.slot_mask) {
         const JSlot sl = p.slots[sl_];
         if (sl.slen == ~0u) break;
         if (sl.hash == h && sl.slen == kn[rd]) {
           bool same = true;
-          for (uint32_t k = 0; k < kn[rd] && same; k++) same = aux.at(base + ks[rd] + k) == p.names[sl.soff + k];
+          for (uint32_t k = 0; k < kn[rd] && same; k += 8) {
+            const uint32_t nb = kn[rd] - k < 8 ? kn[rd] - k : 8u;
+            same = (aux.word(base + ks[rd] + k) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1)) == *reinterpret_cast<const uint64_t *>(p.names + sl.soff + k);
+          }
           if (same) { kc = sl.col; if (sl.aux) bad = true; break; }
         }
       }
@@ -1001,8 +1058,8 @@ __global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, cons
   const uint64_t s = c.fstart[r];
   uint8_t *dst = c.out + o0;
   MemBytes rd(data);
-  if (mode == JM_UNESCAPE) { StoreSink sk{dst}; unescape_walk(rd, s, srclen, sk); return; }
-  if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); return; }
+  if (mode == JM_UNESCAPE) { StoreSink sk{dst}; unescape_walk(rd, s, srclen, sk); sk.finish(); return; }
+  if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_FLOAT) {  // the number token again, as encoding/json prints the float64 it parses to
     const Field tok{&rd, s, srclen};
     double v = 0;
@@ -1011,10 +1068,11 @@ __global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, cons
     dev::fmt_json_float(so, v, 64);
     return;
   }
-  uint32_t w = 0;
-  if (mode == JM_QUOTED) dst[w++] = '"';
-  for (uint32_t i = 0; i < srclen; i++) dst[w++] = (uint8_t)rd.at(s + i);
-  if (mode == JM_QUOTED) dst[w++] = '"';
+  StoreSink sk{dst};
+  if (mode == JM_QUOTED) sk.put('"');
+  for (uint32_t i = 0; i < srclen; i++) sk.put(rd.at(s + i));
+  if (mode == JM_QUOTED) sk.put('"');
+  sk.finish();
 }
 
 __global__ void json_collect(const uint32_t *nerr, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, uint32_t *out) {
@@ -1083,7 +1141,16 @@ std::vector<AuxCol> aux_columns(const tfgpu_json_options *o, const tfgpu_schema 
   return aux;
 }
 char *dup_cstr(const std::string &s) { char *r = (char *)std::malloc(s.size() + 1); std::memcpy(r, s.c_str(), s.size() + 1); return r; }
-uint32_t fnv1a_host(const std::string &s) { uint32_t h = 2166136261u; for (unsigned char c : s) h = (h ^ c) * 16777619u; return h; }
+uint32_t key_hash_host(const std::string &s) {  // = scan_string's hash of the same bytes
+  uint32_t h = 0x9E3779B9u;
+  for (size_t k = 0; k < s.size(); k += 8) {
+    uint64_t w = 0;
+    for (size_t i = 0; i < 8 && k + i < s.size(); i++) w |= (uint64_t)(unsigned char)s[k + i] << (8 * i);
+    h = (h ^ (uint32_t)w) * 0x85EBCA6Bu; h = (h ^ (uint32_t)(w >> 32)) * 0xC2B2AE35u;
+    h ^= h >> 15;
+  }
+  return h ^ ((uint32_t)s.size() * 0x27D4EB2Fu);
+}
 }  // namespace
 
 extern "C" int tfgpu_json_result_schema(const tfgpu_json_options *opts, const tfgpu_schema *fields, tfgpu_schema **out) {
@@ -1196,13 +1263,14 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   std::vector<JSlot> slots(nslots, JSlot{0, 0, 0, ~0u, 0});
   std::string names;
   for (auto &e : entries) {
-    const uint32_t h = fnv1a_host(e.first);
+    const uint32_t h = key_hash_host(e.first);
     uint32_t s = h & (nslots - 1);
     while (slots[s].slen != ~0u) s = (s + 1) & (nslots - 1);
     uint32_t is_aux = 0;
     if (opts->add_rest) for (const char *a : {"_rest", "_timestamp", "_partition", "_offset", "_idx"}) if (e.first == a) is_aux = 1;
     slots[s] = JSlot{h, e.second, (uint32_t)names.size(), (uint32_t)e.first.size(), is_aux};
     names += e.first;
+    names.append((8 - names.size() % 8) % 8, '\0');  // whole 8-byte words: the device compares a word at a time
   }
 
   // ---- input in HBM ----

@@ -42,7 +42,20 @@ struct SerParams {
 
 // ---- sinks -----------------------------------------------------------------------
 struct CountSink { uint32_t n = 0; __device__ __forceinline__ void put(uint32_t) { n++; } };
-struct WriteSink { uint8_t *p; __device__ __forceinline__ void put(uint32_t c) { *p++ = (uint8_t)c; } };
+// Bytes gathered eight at a time and stored with ONE (possibly unaligned) 8-byte store: a cell's text lands in the
+// middle of its row, so byte stores would cost one memory transaction per character.
+struct WriteSink {
+  uint8_t *p; uint64_t acc = 0; uint32_t n = 0;
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  __device__ __forceinline__ void put(uint32_t c) {
+    acc |= (uint64_t)(c & 0xFFu) << (8 * n);
+    if (++n == 8) { reinterpret_cast<U64 *>(p)->v = acc; p += 8; acc = 0; n = 0; }
+  }
+  __device__ __forceinline__ void flush() {
+    if (n >= 4) { struct __attribute__((packed, aligned(1))) U32 { uint32_t v; }; reinterpret_cast<U32 *>(p)->v = (uint32_t)acc; p += 4; acc >>= 32; n -= 4; }
+    for (; n; n--) { *p++ = (uint8_t)acc; acc >>= 8; }
+  }
+};
 template <class S> struct CsvQuoteSink {  // doubles '"' (encoding/csv quoted field body)
   S &s;
   __device__ __forceinline__ void put(uint32_t c) { if (c == '"') s.put('"'); s.put(c); }
@@ -398,11 +411,13 @@ __global__ void __launch_bounds__(256) ser_cell_write(SerParams p) {
     if (sc.c.repr == TFGPU_R_JSON || sc.c.repr == TFGPU_R_JSONNUM) { CountSink probe; if (!emit_cell(probe, p, sc, r)) return; }
     WriteSink w{p.out + base};
     emit_cell(w, p, sc, r);
-    *w.p = (p.last_present[r] == ci) ? '}' : ',';
+    w.put((p.last_present[r] == ci) ? '}' : ',');
+    w.flush();
     return;
   }
   WriteSink w{p.out + base};
   emit_cell(w, p, sc, r);
+  w.flush();
 }
 // row frame: '{' and the tail
 __global__ void __launch_bounds__(256) ser_row_frame(SerParams p) {
