@@ -1027,14 +1027,21 @@ __global__ void __launch_bounds__(256) json_finish(JFinish p) {
     p.idx_out[r] = (uint32_t)r - p.seg_ord[p.rank_ms[m]] + 1;  // 1-based index of the line inside its message
   }
 }
-// validity bit = the cell holds a value; one thread per output byte, blockIdx.y = column
-__global__ void __launch_bounds__(256) json_validity(const JCol *cols, int64_t nlines, uint8_t *const *out) {
+// validity bit = the cell holds a value; one thread per output byte, blockIdx.y = column.  has_nil[column] is raised
+// when a KEPT line holds a nil there: columns without one travel without a bitmap (NULL = no nil values).
+__global__ void __launch_bounds__(256) json_validity(const JCol *cols, int64_t nlines, uint8_t *const *out, const uint32_t *keep, uint32_t *has_nil) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b * 8 >= nlines) return;
   const uint8_t *cs = cols[blockIdx.y].cellst;
   uint32_t v = 0;
-  for (int j = 0; j < 8; j++) { const int64_t k = b * 8 + j; if (k < nlines && cs[k] == JC_OK) v |= 1u << j; }
+  bool nil = false;
+  for (int j = 0; j < 8; j++) {
+    const int64_t k = b * 8 + j;
+    if (k >= nlines) break;
+    if (cs[k] == JC_OK) v |= 1u << j; else if (keep[k]) nil = true;
+  }
   out[blockIdx.y][b] = (uint8_t)v;
+  if (nil) has_nil[blockIdx.y] = 1u;
 }
 // constant text columns (`_partition` = PartID, `_rest` = {}): offsets[r] = r * n, data = n bytes repeated
 __global__ void json_const_text(const uint8_t *text, uint32_t n, int64_t nrows, uint32_t *offsets, uint8_t *data) {
@@ -1075,10 +1082,11 @@ __global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, cons
   sk.finish();
 }
 
-__global__ void json_collect(const uint32_t *nerr, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, uint32_t *out) {
+__global__ void json_collect(const uint32_t *nerr, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, const uint32_t *has_nil, int ncols, uint32_t *out) {
   const int i = threadIdx.x;
   if (i == 0) out[0] = *nerr;
   for (int s = i; s < nstr; s += blockDim.x) out[1 + s] = lens_all[(int64_t)s * seg_stride + nrows];
+  for (int c = i; c < ncols; c += blockDim.x) out[1 + nstr + c] = has_nil[c];
 }
 
 // math.Pow10(n), n = -323..308, exactly as Go builds it: pow10postab32[n/32] * pow10tab[n%32] and
@@ -1394,6 +1402,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
 
   // ---- aux columns + row rules ----
   Buf code = dalloc((size_t)nalloc + 16), ecol = dalloc((size_t)nalloc * 4), keep = dalloc((size_t)(nalloc + 1) * 4), nerr = dalloc_zero(4);
+  Buf has_nil = dalloc_zero((size_t)std::max(nraw, 1) * 4);
   db->part_id = dalloc((size_t)nalloc * 4);
   JFinish fp;
   std::memset(&fp, 0, sizeof fp);
@@ -1423,14 +1432,15 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     KernelTimer t("json_finish");
     json_finish<<<jblocks(nlines, 256), 256, 0, st>>>(fp);
     Buf bvp = upload_small(valid_ptrs.data(), valid_ptrs.size() * sizeof(uint8_t *));
-    if (nraw) json_validity<<<dim3(jblocks((nlines + 7) / 8, 256), (unsigned)nraw), 256, 0, st>>>(ptr<JCol>(bcols), nlines, (uint8_t *const *)bvp->p);
+    if (nraw) json_validity<<<dim3(jblocks((nlines + 7) / 8, 256), (unsigned)nraw), 256, 0, st>>>(ptr<JCol>(bcols), nlines, (uint8_t *const *)bvp->p, ptr<uint32_t>(keep), ptr<uint32_t>(has_nil));
   }
   if (nstr) exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nlines, nstr, seg_stride);
-  Buf summary = dalloc((size_t)(nstr + 1) * 4);
-  json_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), ptr<uint32_t>(lens_all), seg_stride, nlines, nstr, ptr<uint32_t>(summary));
-  const uint32_t *hsum = d2h_u32(summary->p, (size_t)nstr + 1);
+  Buf summary = dalloc((size_t)(nstr + nraw + 1) * 4);
+  json_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), ptr<uint32_t>(lens_all), seg_stride, nlines, nstr, ptr<uint32_t>(has_nil), nraw, ptr<uint32_t>(summary));
+  const uint32_t *hsum = d2h_u32(summary->p, (size_t)nstr + nraw + 1);
   tf::sync();
   const uint32_t hnerr = hsum[0];
+  for (int i = 0; i < nraw; i++) if (!hsum[1 + nstr + i]) db->cols[(size_t)i].validity = nullptr;  // no nil among the kept lines
 
   // ---- text payloads ----
   std::vector<JCopyCol> cc;

@@ -430,13 +430,15 @@ __global__ void __launch_bounds__(256) gather_fixed_all(const GFix *__restrict__
     }
   }
 }
-__global__ void __launch_bounds__(256) gather_bitmap_kernel(const uint8_t *__restrict__ in, const int32_t *__restrict__ sel, int64_t m, uint8_t *__restrict__ out) {
-  // one thread per output byte (8 rows)
+// validity bitmaps of all columns in one launch: one thread per output byte (8 rows), blockIdx.y = bitmap
+struct GBit { const uint8_t *in; uint8_t *out; };
+__global__ void __launch_bounds__(256) gather_bitmap_all(const GBit *__restrict__ a, const int32_t *__restrict__ sel, int64_t m) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b * 8 >= m) return;
+  const GBit g = a[blockIdx.y];
   uint32_t v = 0;
-  for (int j = 0; j < 8; j++) { int64_t k = b * 8 + j; if (k < m) { int32_t s = sel[k]; v |= ((in[s >> 3] >> (s & 7)) & 1u) << j; } }
-  out[b] = (uint8_t)v;
+  for (int j = 0; j < 8; j++) { int64_t k = b * 8 + j; if (k < m) { int32_t s = sel[k]; v |= ((g.in[s >> 3] >> (s & 7)) & 1u) << j; } }
+  g.out[b] = (uint8_t)v;
 }
 // Var-width columns: lengths of all columns in one launch (segmented layout, then one segmented scan),
 // payload bytes of all columns in one launch.
@@ -468,7 +470,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   const int32_t *sp = ptr<int32_t>(sel);
   unsigned g = grid_for(m, 256);
   KernelTimer t("compact_gather");
-  std::vector<GFix> fx; std::vector<GVar> vr; std::vector<size_t> var_cols;
+  std::vector<GFix> fx; std::vector<GVar> vr; std::vector<size_t> var_cols; std::vector<GBit> bits;
   int nvar = 0;
   for (auto &c : in.cols) if (repr_is_var(c.repr)) nvar++;
   const int64_t seg_stride = ((m + 1 + 3) / 4) * 4;
@@ -489,7 +491,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       fx.push_back(GFix{c.values->p, o.values->p, (int32_t)w, 0});
       if (c.nanos) { o.nanos = dalloc((size_t)m * 4); fx.push_back(GFix{c.nanos->p, o.nanos->p, 4, 0}); }
     }
-    if (c.validity) { o.validity = dalloc((size_t)(m + 7) / 8 + 1); if (m) gather_bitmap_kernel<<<grid_for((m + 7) / 8, 256), 256, 0, st>>>(ptr<uint8_t>(c.validity), sp, m, ptr<uint8_t>(o.validity)); }
+    if (c.validity) { o.validity = dalloc((size_t)(m + 7) / 8 + 1); bits.push_back(GBit{ptr<uint8_t>(c.validity), ptr<uint8_t>(o.validity)}); }
     out->cols.push_back(std::move(o));
   }
   if (in.kind) { out->kind = dalloc((size_t)m); fx.push_back(GFix{in.kind->p, out->kind->p, 1, 0}); }
@@ -497,6 +499,10 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   out->src_row = dalloc((size_t)m * 4);
   if (in.src_row) fx.push_back(GFix{in.src_row->p, out->src_row->p, 4, 0});
   else fx.push_back(GFix{nullptr, out->src_row->p, 4, 0});
+  if (m && !bits.empty()) {
+    Buf bb = upload_small(bits.data(), bits.size() * sizeof(GBit));
+    gather_bitmap_all<<<dim3(grid_for((m + 7) / 8, 256), (unsigned)bits.size()), 256, 0, st>>>(ptr<GBit>(bb), sp, m);
+  }
   Buf bfx = upload_small(fx.data(), fx.size() * sizeof(GFix));
   if (m) gather_fixed_all<<<g, 256, 0, st>>>(ptr<GFix>(bfx), (int)fx.size(), sp, m);
   if (nvar) {
@@ -637,8 +643,11 @@ __global__ void __launch_bounds__(256) tostring_write_kernel(DCol c, int64_t n, 
   uint8_t buf[64]; const uint8_t *ext;
   int len = serialize_small(c, r, buf, &ext);
   uint8_t *dst = data + off[r];
-  if (ext) for (int i = 0; i < len; i++) dst[i] = ext[i];
-  else for (int i = 0; i < len; i++) dst[i] = buf[i];
+  const uint8_t *src = ext ? ext : buf;
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  int i = 0;
+  for (; i + 8 <= len; i += 8) reinterpret_cast<U64 *>(dst + i)->v = reinterpret_cast<const U64 *>(src + i)->v;  // unaligned 8-byte moves
+  for (; i < len; i++) dst[i] = src[i];
 }
 
 static DColumn column_to_string(const DColumn &c, int64_t n, bool to_bytes, int max_len_hint) {
