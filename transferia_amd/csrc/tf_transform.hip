@@ -458,6 +458,20 @@ template <int RPT> __global__ void __launch_bounds__(256) gather_bytes_all(const
   auto so = [&](int64_t k) { return g.in_off[sel[k]]; };
   segcopy_run<RPT>(g.out_off, m, (int64_t)blockIdx.x * 256 * RPT, g.in_data, g.out_data, so, doff, soff);
 }
+// short, mostly empty cells: cell-centric, lane = kept row, (unaligned) 8-byte words
+__global__ void __launch_bounds__(256) gather_bytes_cells(const GVar *__restrict__ v, const int32_t *__restrict__ sel, int64_t m) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const GVar g = v[blockIdx.y];
+  const uint32_t o0 = g.out_off[k], n = g.out_off[k + 1] - o0;
+  if (!n) return;
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  const uint8_t *src = g.in_data + g.in_off[sel[k]];
+  uint8_t *dst = g.out_data + o0;
+  uint32_t i = 0;
+  for (; i + 8 <= n; i += 8) reinterpret_cast<U64 *>(dst + i)->v = reinterpret_cast<const U64 *>(src + i)->v;
+  if (i < n) { uint64_t x = reinterpret_cast<const U64 *>(src + i)->v; for (; i < n; i++) { dst[i] = (uint8_t)x; x >>= 8; } }
+}
 __global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int64_t m, int nv, uint32_t *out) {
   for (int s = threadIdx.x; s < nv; s += blockDim.x) out[s] = lens_all[(int64_t)s * seg_stride + m];
 }
@@ -514,7 +528,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       for (size_t i = 0; i < vr.size(); i++) ((in.cols[var_cols[i]].data_len >= (uint64_t)in.nrows * 8) ? lng : sht).push_back(vr[i]);
       Buf blng = upload_small(lng.data(), lng.size() * sizeof(GVar)), bsht = upload_small(sht.data(), sht.size() * sizeof(GVar));
       if (!lng.empty()) gather_bytes_all<1><<<dim3(grid_for(m, 256), (unsigned)lng.size()), 256, 0, st>>>(ptr<GVar>(blng), sp, m);
-      if (!sht.empty()) gather_bytes_all<8><<<dim3(grid_for(m, 2048), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
+      if (!sht.empty()) gather_bytes_cells<<<dim3(grid_for(m, 256), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
     }
     Buf tot = dalloc((size_t)nvar * 4);
     collect_totals<<<1, 64, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, m, nvar, ptr<uint32_t>(tot));
