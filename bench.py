@@ -171,8 +171,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU per step")
     ap.add_argument("--cpu-rows", type=int, default=1 << 16, help="rows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--lanes", type=int, default=3, help="device lanes (host threads) the steps are spread over: batch N+1 is parsed "
+    ap.add_argument("--lanes", type=int, default=1, help="device lanes (host threads) the steps are spread over: batch N+1 is parsed "
                     "beside the transform of batch N, the way the parsequeue's workers overlap (1 = strictly serial)")
+    ap.add_argument("--overlap-lanes", type=int, default=3, help="side measurement (never `value`): the same steps spread over this many lanes (0 = skip)")
     ap.add_argument("--pcie-steps", type=int, default=2, help="extra untimed-for-`value` passes that start from PINNED HOST memory (0 = skip)")
     args = ap.parse_args()
     if args.workload == "json":
@@ -231,52 +232,64 @@ def main():
     # ---- the timed region: exactly args.steps steps, spread round-robin over `lanes` host threads, each bound
     #      to its own device lane (stream + HBM cache) and reading its own HBM-resident copy of the shard ----
     import threading
-    nl = max(1, min(args.lanes, args.steps, lib.lane_count()))
-    lane_bufs = [dbuf]
-    go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
-    lane_err = []
 
-    def lane_main(k):
-        try:
-            lib.lane_use(k)
-            if k:  # stage this lane's copy of the input (untimed), then warm the lane's caches
-                lane_bufs.append(None)
-            buf = dbuf if k == 0 else stage_shard(lib, workload, row0, args.rows)[0]
-            def lstep():
-                db, consumed, errs = lib.csv_parse(opts, schema, buf)
-                res = lib.apply_chain(plans, db)
-                res.transformed.free()
-                db.free()
-            if k:
-                for _ in range(max(args.warmup, 1)):
-                    lstep()
-            lib.synchronize()
-            go.wait()
-            for i in range(args.steps):
-                if i % nl == k:
-                    lstep()
-            lib.synchronize()
-            done.wait()
-        except Exception as e:  # noqa: BLE001
-            lane_err.append(e)
-            go.abort(); done.abort()
+    def timed_region(nlanes):
+      nl = max(1, min(nlanes, args.steps, lib.lane_count()))
+      lane_bufs = [dbuf]
+      go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
+      lane_err = []
 
-    threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
-    for t in threads:
-        t.start()
-    barrier()
-    torch.cuda.synchronize()
-    go.wait()
-    t0 = time.perf_counter()
-    done.wait()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    for t in threads:
-        t.join()
-    if lane_err:
-        raise lane_err[0]
-    lib.lane_use(0)
+      def lane_main(k):
+          try:
+              lib.lane_use(k)
+              if k:  # stage this lane's copy of the input (untimed), then warm the lane's caches
+                  lane_bufs.append(None)
+              buf = dbuf if k == 0 else stage_shard(lib, workload, row0, args.rows)[0]
+              def lstep():
+                  db, consumed, errs = lib.csv_parse(opts, schema, buf)
+                  res = lib.apply_chain(plans, db)
+                  res.transformed.free()
+                  db.free()
+              if k:
+                  for _ in range(max(args.warmup, 1)):
+                      lstep()
+              lib.synchronize()
+              go.wait()
+              for i in range(args.steps):
+                  if i % nl == k:
+                      lstep()
+              lib.synchronize()
+              done.wait()
+          except Exception as e:  # noqa: BLE001
+              lane_err.append(e)
+              go.abort(); done.abort()
+
+      threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
+      for t in threads:
+          t.start()
+      barrier()
+      torch.cuda.synchronize()
+      go.wait()
+      t0 = time.perf_counter()
+      done.wait()
+      torch.cuda.synchronize()
+      barrier()
+      dt = time.perf_counter() - t0
+      for t in threads:
+          t.join()
+      if lane_err:
+          raise lane_err[0]
+      lib.lane_use(0)
+      return dt, nl
+
+    dt, nl = timed_region(args.lanes)
+    overlapped = None
+    if args.overlap_lanes > 1 and args.overlap_lanes != args.lanes:
+        dt2, nl2 = timed_region(args.overlap_lanes)
+        dt2 = group.max_seconds(dt2)
+        overlapped = {"lanes": nl2, "rows_per_s": round(args.rows * world * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                      "note": "side measurement, never `value`: the same K steps spread over several device lanes (parse of batch N+1 beside "
+                              "the transform of batch N); kernels of different lanes share the GPU, so per-kernel spans are not comparable"}
 
     # ---- PCIe-inclusive side measurement (never `value`): the same step starting from pinned host memory ----
     pcie = None
@@ -334,8 +347,19 @@ def main():
     if dom:
         per_launch = alg.get(dom, 0) / max(kernels[dom]["launches_per_step"], 1)
         achieved = per_launch / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 if per_launch else 0.0
+        # HBM traffic per launch cannot be read inside this process: it comes from the rocprofv3 --pmc passes whose summary
+        # is committed under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"); null when the
+        # recorded launch shape is not this run's.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get(dom)
+            if t and t["rows_per_launch"] == rows:
+                traffic = t["bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(per_launch),
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch),
                     "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
     for k, v in kernels.items():
         b = alg.get(k)
@@ -371,7 +395,7 @@ def main():
             "gib_per_s_csv_in": round(csv_bytes * world * args.steps / dt / 2**30, 3),
             "gib_per_s_deepsizeof": round((state["parsed_bytes"] + 16 * len(schema.cols) * rows) * world * args.steps / dt / 2**30, 3),
             "rows_out_per_step": state["out_rows"], "row_errors": state["errors"],
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "lanes": nl, "pcie_inclusive": pcie,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "lanes": nl, "overlapped_lanes": overlapped, "pcie_inclusive": pcie,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
