@@ -140,6 +140,13 @@ typedef struct tfgpu_batch {
                              NULL on input = identity                         */
   uint32_t *part_id;      /* outputs of sharder_transformer: PartID = itoa()  */
   int32_t mem;            /* TFGPU_MEM_HOST / TFGPU_MEM_DEVICE                */
+  /* ChangeItem.OldKeys (pkg/abstract/changeitem/old_keys.go:3-7) of Update / Delete rows: one column per
+   * OldKeys.KeyNames entry (name = the key name, values = KeyValues, validity = nil), same row count as the batch.
+   * old_keys_present: bitmap, bit r = len(items[r].OldKeys.KeyValues) > 0; NULL with n_old_keys > 0 = every row.
+   * Only tfgpu_collapse reads them; every row-moving step (filter, partition, …) carries them along.          */
+  int32_t n_old_keys;
+  tfgpu_column *old_keys;
+  uint8_t *old_keys_present;
   const tfgpu_schema *schema; /* ChangeItem.TableSchema of the run (columns in schema
                              order), or NULL = the batch columns in their order.
                              Transformers that walk the SCHEMA and look values up
@@ -244,6 +251,21 @@ void tfgpu_dbatch_free(tfgpu_dbatch *b);
  * `errs` (optional) receives up to `errs_cap` row errors; *nerrs the total.  */
 int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tfgpu_dbatch **out,
                 tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+
+/* abstract.Collapse (pkg/abstract/changeitem/change_item_collapse.go:48-134): the PK-keyed dedup of one batch that
+ * sinks with primary keys run before writing (and clickhouse_local.go:178-210 before the `sql` transformer).  Keys are the
+ * TableSchema's PrimaryKey columns (the batch must carry `schema` with TFGPU_COL_KEY flags); the key of a row is
+ * json.Marshal of its key values in key-name order, taken from OldKeys for Update / Delete rows that have them
+ * (change_item.go:314-358).  Inserts replace, Updates merge into the row filed under their old key (and may re-file it),
+ * Deletes drop it and are kept once per key.  Output order: non-row kinds, then the surviving rows in the order of their
+ * last change, then the deletes (the reference leaves those in map order; here: input order).  src_row of a surviving row
+ * is the row whose Kind / OldKeys / LSN it keeps (the first of its chain); its values are the last writer's.
+ * Batches with fewer than two rows, inserts only, or no key column come back unchanged.
+ * Caller contract (the columnar batch cannot say more): every item shares the batch's ColumnNames — batches mixing
+ * TOAST-style updates with fewer columns take the Go path (compareColumns, :7-35); TFGPU_K_OTHER must not stand for
+ * SynchronizeKind here (InsertsOnly, :37-44, treats that one as an insert).  Keys are compared through 128-bit hashes of
+ * their json.Marshal text.  TFGPU_ERR_UNSUPPORTED: NaN / Inf in a float key column, more than 2^29 rows.             */
+int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out);
 
 /* Hash-partition, local half (BASELINE.json configs[4]: debezium stream → hash-partition → dedup → Kafka sink on 8 GPUs).
  * Rows are regrouped by part_id — what sharder_transformer wrote: PartID = itoa(CRC32_IEEE(join(SerializeToString(cols), "."))

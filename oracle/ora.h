@@ -74,6 +74,10 @@ typedef struct ora_item {
   ora_value *values;   /* ColumnValues */
   ora_schema *schema;  /* TableSchema (shared pointer, replaced not mutated) */
   int64_t src_row;     /* index in the original input batch */
+  /* OldKeys (old_keys.go:3-7): KeyNames (shared) / KeyValues; n_old = len(KeyValues), 0 = none */
+  ora_names *old_names;
+  int n_old;
+  ora_value *old_values;
 } ora_item;
 
 typedef struct ora_error { int64_t row; int code; char *msg; } ora_error;
@@ -181,6 +185,13 @@ uint64_t ora_fastfloat_parse_uint64_best_effort(const char *s, size_t n);
 /* ---- serializers ---- */
 /* format = TFGPU_FMT_*; returns malloc'd bytes */
 char *ora_serialize(int format, const ora_batch *b, uint64_t *len);
+/* ---- a24: abstract.Collapse (change_item_collapse.go:48-134); consumes nothing, returns a new batch ---- */
+ora_batch *ora_collapse(const ora_batch *in);
+ora_batch *ora_batch_from_json(const char *text);  /* row-wise test input (items with differing ColumnNames) */
+int ora_batch_item_info(const ora_batch *b, int64_t row, int *kind, int *nvalues, int *n_old, int64_t *src_row);
+const char *ora_batch_item_name(const ora_batch *b, int64_t row, int col, int old);
+int ora_batch_old_value(const ora_batch *b, int64_t row, int col, int *kind, int64_t *i64, const char **s, size_t *slen);
+int64_t ora_batch_len(const ora_batch *b);
 char *ora_serialize_ex(int format, const ora_batch *b, const tfgpu_serialize_options *opts, uint64_t *len);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@
  * encoding is not restated here makes the whole call return NULL (the HIP side answers
  * TFGPU_ERR_UNSUPPORTED for the same inputs).
  */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -348,3 +349,245 @@ char *ora_serialize_ex(int format, const ora_batch *bt, const tfgpu_serialize_op
   return b.p;
 }
 char *ora_serialize(int format, const ora_batch *b, uint64_t *len) { return ora_serialize_ex(format, b, NULL, len); }
+
+/* ======================================================================================================
+ * a24  abstract.Collapse — pkg/abstract/changeitem/change_item_collapse.go:48-134, with
+ *      OldOrCurrentKeysString / CurrentKeysString (change_item.go:314-358), MakeMapKeys, compareColumns (:7-35).
+ * Go maps are restated as a string-keyed open-addressing table; toDelete, which the reference emits in map
+ * (= unspecified) order, is emitted in the input order of the delete items.
+ * ====================================================================================================== */
+typedef struct { char **keys; int *vals; int cap, n; } smap;  /* vals: >= 0 live, -1 empty, -2 deleted */
+static uint32_t smap_hash(const char *k) { uint32_t h = 2166136261u; for (; *k; k++) h = (h ^ (unsigned char)*k) * 16777619u; return h; }
+static void smap_init(smap *m, int cap) { m->cap = 16; while (m->cap < cap * 4) m->cap <<= 1; m->n = 0; m->keys = (char **)calloc((size_t)m->cap, sizeof(char *)); m->vals = (int *)malloc((size_t)m->cap * sizeof(int)); for (int i = 0; i < m->cap; i++) m->vals[i] = -1; }
+static void smap_free(smap *m) { for (int i = 0; i < m->cap; i++) free(m->keys[i]); free(m->keys); free(m->vals); }
+static int smap_slot(const smap *m, const char *k, int for_insert) {
+  int first_free = -1;
+  for (uint32_t s = smap_hash(k) & (uint32_t)(m->cap - 1);; s = (s + 1) & (uint32_t)(m->cap - 1)) {
+    if (m->vals[s] == -1) return for_insert ? (first_free >= 0 ? first_free : (int)s) : -1;
+    if (m->keys[s] && !strcmp(m->keys[s], k)) { if (m->vals[s] >= 0) return (int)s; if (for_insert && first_free < 0) first_free = (int)s; }
+    else if (m->vals[s] == -2 && for_insert && first_free < 0) first_free = (int)s;
+  }
+}
+static int smap_get(const smap *m, const char *k) { int s = smap_slot(m, k, 0); return s < 0 ? -1 : m->vals[s]; }
+static void smap_set(smap *m, const char *k, int v) { int s = smap_slot(m, k, 1); if (!m->keys[s] || strcmp(m->keys[s], k)) { free(m->keys[s]); m->keys[s] = strdup(k); } m->vals[s] = v; }
+static void smap_del(smap *m, const char *k) { int s = smap_slot(m, k, 0); if (s >= 0) m->vals[s] = -2; }
+
+static int cmp_int(const void *a, const void *b) { int x = *(const int *)a, y = *(const int *)b; return x < y ? -1 : x > y; }
+static int cmp_cstr(const void *a, const void *b) { return strcmp(*(const char *const *)a, *(const char *const *)b); }
+
+/* json.Marshal([]interface{}{…}) of the key values in sorted key-name order; values looked up by name */
+static char *keys_string(char **keynames, int nkeys, char **names, int nnames, const ora_value *values) {
+  sbuf b = {0};
+  sb_c(&b, '[');
+  for (int k = 0; k < nkeys; k++) {
+    if (k) sb_c(&b, ',');
+    const ora_value *v = NULL;
+    for (int i = 0; i < nnames; i++) if (!strcmp(names[i], keynames[k])) v = &values[i];  /* a later duplicate name wins, like the map write */
+    if (!v || v->kind == OV_NIL) sb_s(&b, "null"); else json_value(&b, v, TFGPU_T_INVALID, 0);
+  }
+  sb_c(&b, ']');
+  sb_c(&b, 0);
+  return b.p;
+}
+static char *current_keys_string(const ora_item *c, char **kn, int nk) { return keys_string(kn, nk, c->names ? c->names->names : NULL, c->names ? c->names->n : 0, c->values); }
+static char *old_or_current_keys_string(const ora_item *c, char **kn, int nk) {
+  if ((c->kind == TFGPU_K_UPDATE || c->kind == TFGPU_K_DELETE) && c->n_old > 0) return keys_string(kn, nk, c->old_names->names, c->n_old, c->old_values);
+  return current_keys_string(c, kn, nk);
+}
+static void item_clone(ora_item *d, const ora_item *s) {
+  memset(d, 0, sizeof *d);
+  d->kind = s->kind; d->ns = strdup(s->ns ? s->ns : ""); d->table = strdup(s->table ? s->table : ""); d->part_id = strdup(s->part_id ? s->part_id : "");
+  d->names = s->names; if (d->names) d->names->refs++;
+  d->schema = s->schema; if (d->schema) d->schema->refs++;
+  d->nvalues = s->nvalues; d->values = (ora_value *)calloc((size_t)(s->nvalues ? s->nvalues : 1), sizeof(ora_value));
+  for (int i = 0; i < s->nvalues; i++) d->values[i] = ora_value_clone(&s->values[i]);
+  d->src_row = s->src_row;
+  d->old_names = s->old_names; if (d->old_names) d->old_names->refs++;
+  d->n_old = s->n_old;
+  if (s->n_old) { d->old_values = (ora_value *)calloc((size_t)s->n_old, sizeof(ora_value)); for (int i = 0; i < s->n_old; i++) d->old_values[i] = ora_value_clone(&s->old_values[i]); }
+}
+static void item_set_values_from(ora_item *cur, const ora_item *c) {  /* compareColumns + merge (:86-102) */
+  int same = cur->names == c->names;
+  if (!same && cur->names && c->names && cur->names->n == c->names->n) { same = 1; for (int i = 0; i < c->names->n; i++) if (strcmp(cur->names->names[i], c->names->names[i])) { same = 0; break; } }
+  if (same) {
+    for (int i = 0; i < cur->nvalues; i++) ora_value_free(&cur->values[i]);
+    free(cur->values);
+    cur->nvalues = c->nvalues; cur->values = (ora_value *)calloc((size_t)(c->nvalues ? c->nvalues : 1), sizeof(ora_value));
+    for (int i = 0; i < c->nvalues; i++) cur->values[i] = ora_value_clone(&c->values[i]);
+    return;
+  }
+  /* total = old names, then the new ones not seen; values: old, overwritten by new */
+  int no = cur->names ? cur->names->n : 0, nn = c->names ? c->names->n : 0;
+  ora_names *tot = (ora_names *)calloc(1, sizeof *tot);
+  tot->refs = 1; tot->names = (char **)calloc((size_t)(no + nn + 1), sizeof(char *));
+  for (int i = 0; i < no; i++) tot->names[tot->n++] = strdup(cur->names->names[i]);
+  for (int i = 0; i < nn; i++) { int seen = 0; for (int j = 0; j < no; j++) if (!strcmp(cur->names->names[j], c->names->names[i])) seen = 1; if (!seen) tot->names[tot->n++] = strdup(c->names->names[i]); }
+  ora_value *vals = (ora_value *)calloc((size_t)(tot->n ? tot->n : 1), sizeof(ora_value));
+  for (int t = 0; t < tot->n; t++) {
+    for (int j = 0; j < no; j++) if (!strcmp(cur->names->names[j], tot->names[t])) { ora_value_free(&vals[t]); vals[t] = ora_value_clone(&cur->values[j]); }  /* oldM: last index wins */
+    for (int j = 0; j < nn; j++) if (!strcmp(c->names->names[j], tot->names[t])) { ora_value_free(&vals[t]); vals[t] = ora_value_clone(&c->values[j]); }
+  }
+  for (int i = 0; i < cur->nvalues; i++) ora_value_free(&cur->values[i]);
+  free(cur->values);
+  if (cur->names && --cur->names->refs == 0) { for (int i = 0; i < cur->names->n; i++) free(cur->names->names[i]); free(cur->names->names); free(cur->names); }
+  cur->names = tot; cur->nvalues = tot->n; cur->values = vals;
+}
+
+ora_batch *ora_collapse(const ora_batch *in) {
+  ora_batch *out = ora_batch_new();
+  int passthrough = in->n < 2;
+  if (!passthrough) { passthrough = 1; for (int64_t i = 0; i < in->n; i++) if (in->items[i].kind != TFGPU_K_INSERT) { passthrough = 0; break; } }  /* InsertsOnly */
+  /* keyCols := input[0].MakeMapKeys(): the PrimaryKey columns of its TableSchema */
+  char **kn = NULL; int nk = 0;
+  if (!passthrough && in->items[0].schema) {
+    const ora_schema *sc = in->items[0].schema;
+    kn = (char **)calloc((size_t)(sc->ncols ? sc->ncols : 1), sizeof(char *));
+    for (int i = 0; i < sc->ncols; i++) if (sc->cols[i].key) { int dup = 0; for (int j = 0; j < nk; j++) if (!strcmp(kn[j], sc->cols[i].name)) dup = 1; if (!dup) kn[nk++] = sc->cols[i].name; }
+    qsort(kn, (size_t)nk, sizeof(char *), cmp_cstr);  /* util.MapKeysInOrder */
+  }
+  if (!passthrough && nk == 0) passthrough = 1;
+  if (passthrough) { for (int64_t i = 0; i < in->n; i++) item_clone(ora_batch_push(out), &in->items[i]); free(kn); return out; }
+
+  const int n = (int)in->n;
+  smap rows, to_delete, k2idx;
+  smap_init(&rows, n); smap_init(&to_delete, n); smap_init(&k2idx, n);
+  ora_item *store = (ora_item *)calloc((size_t)n, sizeof(ora_item));      /* the ChangeItem values held by `rows` / `toDelete` (slot = creating row) */
+  char **idx2k = (char **)calloc((size_t)n, sizeof(char *));
+  for (int i = 0; i < n; i++) {
+    const ora_item *c = &in->items[i];
+    char *hashK = old_or_current_keys_string(c, kn, nk);
+    switch (c->kind) {
+      case TFGPU_K_INSERT:
+        smap_del(&to_delete, hashK);
+        item_clone(&store[i], c);
+        smap_set(&rows, hashK, i); smap_set(&k2idx, hashK, i); idx2k[i] = strdup(hashK);
+        break;
+      case TFGPU_K_UPDATE: {
+        smap_del(&to_delete, hashK);
+        int cur = smap_get(&rows, hashK);
+        if (cur < 0) {
+          char *nk_ = current_keys_string(c, kn, nk);
+          item_clone(&store[i], c);
+          smap_set(&rows, nk_, i); smap_set(&k2idx, nk_, i); idx2k[i] = nk_;
+          break;
+        }
+        item_set_values_from(&store[cur], c);
+        char *nk_ = old_or_current_keys_string(&store[cur], kn, nk);
+        if (strcmp(nk_, hashK)) smap_del(&rows, hashK);
+        smap_set(&rows, nk_, cur); smap_set(&k2idx, nk_, i); idx2k[i] = nk_;
+        break;
+      }
+      case TFGPU_K_DELETE: {
+        int cur = smap_get(&rows, hashK);
+        smap_del(&rows, hashK);
+        item_clone(&store[i], c);
+        if (cur >= 0 && store[cur].n_old > 0) {  /* c.OldKeys = current.OldKeys */
+          for (int q = 0; q < store[i].n_old; q++) ora_value_free(&store[i].old_values[q]);
+          free(store[i].old_values);
+          if (store[i].old_names && --store[i].old_names->refs == 0) { for (int q = 0; q < store[i].old_names->n; q++) free(store[i].old_names->names[q]); free(store[i].old_names->names); free(store[i].old_names); }
+          store[i].old_names = store[cur].old_names; store[i].old_names->refs++;
+          store[i].n_old = store[cur].n_old;
+          store[i].old_values = (ora_value *)calloc((size_t)store[cur].n_old, sizeof(ora_value));
+          for (int q = 0; q < store[cur].n_old; q++) store[i].old_values[q] = ora_value_clone(&store[cur].old_values[q]);
+          free(hashK);
+          hashK = old_or_current_keys_string(&store[i], kn, nk);
+        }
+        smap_set(&to_delete, hashK, i);
+        break;
+      }
+      default:
+        item_clone(ora_batch_push(out), c);
+    }
+    free(hashK);
+  }
+  /* rows in the order of hashKToIdx; an entity filed under key k sits in store[rows[k]] */
+  int *order = (int *)malloc((size_t)n * sizeof(int) * 2);
+  int no = 0;
+  for (int s = 0; s < rows.cap; s++) if (rows.vals[s] >= 0) { order[2 * no] = smap_get(&k2idx, rows.keys[s]); order[2 * no + 1] = rows.vals[s]; no++; }
+  qsort(order, (size_t)no, 2 * sizeof(int), cmp_int);
+  for (int a = 0; a < no; a++) item_clone(ora_batch_push(out), &store[order[2 * a + 1]]);
+  /* toDelete: map order in the reference; here by the delete item's position */
+  int nd = 0;
+  for (int s = 0; s < to_delete.cap; s++) if (to_delete.vals[s] >= 0) order[nd++] = to_delete.vals[s];
+  qsort(order, (size_t)nd, sizeof(int), cmp_int);
+  for (int a = 0; a < nd; a++) item_clone(ora_batch_push(out), &store[order[a]]);
+  free(order);
+  for (int i = 0; i < n; i++) { if (store[i].values || store[i].ns) ora_item_clear(&store[i]); free(idx2k[i]); }
+  free(store); free(idx2k); free(kn);
+  smap_free(&rows); smap_free(&to_delete); smap_free(&k2idx);
+  return out;
+}
+
+/* ---- row-wise test I/O for Collapse: items whose ColumnNames differ (TOAST updates) have no columnar form ---- */
+#include "ora_json.h"
+static ora_value value_from_json(const jnode *pair) {  /* ["gotype", value] */
+  ora_value v; memset(&v, 0, sizeof v);
+  if (!pair || pair->type != JN_ARR || pair->n != 2) return v;
+  const char *g = jn_str(pair->kids[0], "nil");
+  const jnode *x = pair->kids[1];
+  if (!strcmp(g, "nil")) return v;
+  if (!strcmp(g, "string") || !strcmp(g, "json")) { v.kind = !strcmp(g, "json") ? OV_JSON : OV_STRING; v.slen = x->slen; v.s = (char *)malloc(x->slen + 1); memcpy(v.s, x->str, x->slen); v.s[x->slen] = 0; return v; }
+  if (!strcmp(g, "bool")) { v.kind = OV_BOOL; v.v.b = jn_bool(x, 0); return v; }
+  if (!strcmp(g, "float64")) { v.kind = OV_F64; v.v.f64 = x->num; return v; }
+  int64_t i = 0; ora_parse_int(x->str, x->slen, 10, 64, &i);  /* JN_NUM keeps its text */
+  if (!strcmp(g, "int") || !strcmp(g, "int64")) { v.kind = OV_I64; v.v.i = i; }
+  else if (!strcmp(g, "int32")) { v.kind = OV_I32; v.v.i = i; }
+  else if (!strcmp(g, "uint64")) { v.kind = OV_U64; v.v.u = (uint64_t)i; }
+  return v;
+}
+static ora_names *names_from_json(const jnode *arr) {
+  ora_names *nm = (ora_names *)calloc(1, sizeof *nm);
+  nm->refs = 1; nm->n = arr ? arr->n : 0; nm->names = (char **)calloc((size_t)(nm->n ? nm->n : 1), sizeof(char *));
+  for (int i = 0; i < nm->n; i++) nm->names[i] = strdup(jn_str(arr->kids[i], ""));
+  return nm;
+}
+/* {"items": [{"kind": "insert|update|delete|other", "keys": ["pk names of its TableSchema"], "names": [...], "values": [["int",1],...],
+ *             "old_names": [...], "old_values": [...]}]} */
+ora_batch *ora_batch_from_json(const char *text) {
+  char err[128];
+  jnode *root = jn_parse(text, err, sizeof err);
+  if (!root) return NULL;
+  ora_batch *b = ora_batch_new();
+  const jnode *items = jn_get(root, "items");
+  for (int i = 0; items && i < items->n; i++) {
+    const jnode *it = items->kids[i];
+    ora_item *o = ora_batch_push(b);
+    const char *k = jn_str(jn_get(it, "kind"), "insert");
+    o->kind = !strcmp(k, "insert") ? TFGPU_K_INSERT : !strcmp(k, "update") ? TFGPU_K_UPDATE : !strcmp(k, "delete") ? TFGPU_K_DELETE : TFGPU_K_OTHER;
+    o->ns = strdup(""); o->table = strdup("t"); o->part_id = strdup("");
+    o->names = names_from_json(jn_get(it, "names"));
+    const jnode *vals = jn_get(it, "values");
+    o->nvalues = o->names->n; o->values = (ora_value *)calloc((size_t)(o->nvalues ? o->nvalues : 1), sizeof(ora_value));
+    for (int c = 0; c < o->nvalues; c++) o->values[c] = value_from_json(vals && c < vals->n ? vals->kids[c] : NULL);
+    const jnode *keys = jn_get(it, "keys");
+    ora_schema *sc = (ora_schema *)calloc(1, sizeof *sc);
+    sc->refs = 1; sc->ncols = keys ? keys->n : 0; sc->cols = (ora_colschema *)calloc((size_t)(sc->ncols ? sc->ncols : 1), sizeof(ora_colschema));
+    for (int c = 0; c < sc->ncols; c++) { sc->cols[c].name = strdup(jn_str(keys->kids[c], "")); sc->cols[c].key = 1; sc->cols[c].path = strdup(""); sc->cols[c].original_type = strdup(""); }
+    o->schema = sc;
+    const jnode *on = jn_get(it, "old_names"), *ov = jn_get(it, "old_values");
+    if (on && on->n) {
+      o->old_names = names_from_json(on);
+      o->n_old = on->n; o->old_values = (ora_value *)calloc((size_t)on->n, sizeof(ora_value));
+      for (int c = 0; c < on->n; c++) o->old_values[c] = value_from_json(ov && c < ov->n ? ov->kids[c] : NULL);
+    }
+    o->src_row = i;
+  }
+  jn_free(root);
+  return b;
+}
+int ora_batch_item_info(const ora_batch *b, int64_t row, int *kind, int *nvalues, int *n_old, int64_t *src_row) {
+  if (row < 0 || row >= b->n) return -1;
+  *kind = b->items[row].kind; *nvalues = b->items[row].nvalues; *n_old = b->items[row].n_old; *src_row = b->items[row].src_row;
+  return 0;
+}
+const char *ora_batch_item_name(const ora_batch *b, int64_t row, int col, int old) {
+  const ora_names *nm = old ? b->items[row].old_names : b->items[row].names;
+  return (nm && col < nm->n) ? nm->names[col] : "";
+}
+int ora_batch_old_value(const ora_batch *b, int64_t row, int col, int *kind, int64_t *i64, const char **s, size_t *slen) {
+  if (row < 0 || row >= b->n || col < 0 || col >= b->items[row].n_old) return -1;
+  const ora_value *v = &b->items[row].old_values[col];
+  *kind = v->kind; *i64 = v->v.i; *s = v->s; *slen = v->slen;
+  return 0;
+}
+int64_t ora_batch_len(const ora_batch *b) { return b->n; }

@@ -49,6 +49,9 @@ void ora_item_clear(ora_item *it) {
   free(it->ns); free(it->table); free(it->part_id);
   names_unref(it->names);
   ora_schema_unref(it->schema);
+  for (int i = 0; i < it->n_old; i++) ora_value_free(&it->old_values[i]);
+  free(it->old_values);
+  names_unref(it->old_names);
   memset(it, 0, sizeof *it);
 }
 
@@ -133,6 +136,12 @@ ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema) {
   ora_names *nm = (ora_names *)calloc(1, sizeof *nm);
   nm->refs = 1; nm->n = cb->ncols; nm->names = (char **)calloc((size_t)(cb->ncols ? cb->ncols : 1), sizeof(char *));
   for (int i = 0; i < cb->ncols; i++) nm->names[i] = dups(cb->cols[i].name);
+  ora_names *onm = NULL;
+  if (cb->n_old_keys > 0) {
+    onm = (ora_names *)calloc(1, sizeof *onm);
+    onm->refs = 1; onm->n = cb->n_old_keys; onm->names = (char **)calloc((size_t)cb->n_old_keys, sizeof(char *));
+    for (int i = 0; i < cb->n_old_keys; i++) onm->names[i] = dups(cb->old_keys[i].name);
+  }
   b->cap = cb->nrows ? cb->nrows : 1;
   b->items = (ora_item *)calloc((size_t)b->cap, sizeof(ora_item));
   for (int64_t r = 0; r < cb->nrows; r++) {
@@ -147,7 +156,14 @@ ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema) {
     it->values = (ora_value *)calloc((size_t)(cb->ncols ? cb->ncols : 1), sizeof(ora_value));
     for (int c = 0; c < cb->ncols; c++) it->values[c] = box(&cb->cols[c], r);
     it->src_row = cb->src_row ? cb->src_row[r] : r;
+    if (onm && valid_at(cb->old_keys_present, r)) {
+      it->old_names = onm; onm->refs++;
+      it->n_old = cb->n_old_keys;
+      it->old_values = (ora_value *)calloc((size_t)cb->n_old_keys, sizeof(ora_value));
+      for (int c = 0; c < cb->n_old_keys; c++) it->old_values[c] = box(&cb->old_keys[c], r);
+    }
   }
+  names_unref(onm);
   names_unref(nm);
   ora_schema_unref(sch);
   return b;
@@ -173,42 +189,27 @@ static size_t repr_width(int r) {
   return 0;
 }
 
-tfgpu_batch *ora_to_columns(const ora_batch *b) {
-  tfgpu_batch *cb = (tfgpu_batch *)calloc(1, sizeof *cb);
-  cb->nrows = b->n; cb->mem = TFGPU_MEM_HOST;
-  cb->kind = (uint8_t *)calloc((size_t)(b->n ? b->n : 1), 1);
-  cb->src_row = (int32_t *)calloc((size_t)(b->n ? b->n : 1), sizeof(int32_t));
-  cb->part_id = (uint32_t *)calloc((size_t)(b->n ? b->n : 1), sizeof(uint32_t));
-  if (b->n == 0) return cb;
-  const ora_item *f = &b->items[0];
-  cb->table_ns = dups(f->ns); cb->table_name = dups(f->table);
-  cb->ncols = f->nvalues;
-  cb->cols = (tfgpu_column *)calloc((size_t)(cb->ncols ? cb->ncols : 1), sizeof(tfgpu_column));
-  for (int64_t r = 0; r < b->n; r++) {
-    cb->kind[r] = (uint8_t)b->items[r].kind;
-    cb->src_row[r] = (int32_t)b->items[r].src_row;
-    const char *p = b->items[r].part_id;
-    cb->part_id[r] = (p && *p >= '0' && *p <= '9') ? (uint32_t)strtoul(p, NULL, 10) : 0;
-  }
-  for (int c = 0; c < cb->ncols; c++) {
-    tfgpu_column *col = &cb->cols[c];
-    col->name = dups(f->names && c < f->names->n ? f->names->names[c] : "");
+#define VAL(it) (old ? ((it)->n_old > c ? &(it)->old_values[c] : &NILV) : &(it)->values[c])
+static const ora_value NILV = {0};
+static void fill_column(tfgpu_column *col, const ora_batch *b, const ora_item *f, const char *name, int c, int old) {
+  {
+    col->name = dups(name);
     /* dtype by name from the row's schema */
     col->dtype = TFGPU_T_INVALID;
     if (f->schema) for (int k = 0; k < f->schema->ncols; k++) if (!strcmp(f->schema->cols[k].name, col->name)) { col->dtype = f->schema->cols[k].dtype; break; }
     int repr = TFGPU_R_INVALID;
-    for (int64_t r = 0; r < b->n && repr == TFGPU_R_INVALID; r++) repr = repr_of(b->items[r].values[c].kind);
+    for (int64_t r = 0; r < b->n && repr == TFGPU_R_INVALID; r++) repr = repr_of((*VAL(&b->items[r])).kind);
     if (repr == TFGPU_R_INVALID) repr = TFGPU_R_STRING; /* all-nil column */
     col->repr = repr;
     col->validity = (uint8_t *)calloc((size_t)((b->n + 7) / 8), 1);
     if (is_var(repr)) {
       col->offsets = (uint32_t *)calloc((size_t)b->n + 1, sizeof(uint32_t));
       uint64_t tot = 0;
-      for (int64_t r = 0; r < b->n; r++) { const ora_value *v = &b->items[r].values[c]; col->offsets[r] = (uint32_t)tot; if (v->kind != OV_NIL) tot += v->slen; }
+      for (int64_t r = 0; r < b->n; r++) { const ora_value *v = &(*VAL(&b->items[r])); col->offsets[r] = (uint32_t)tot; if (v->kind != OV_NIL) tot += v->slen; }
       col->offsets[b->n] = (uint32_t)tot; col->data_len = tot;
       col->data = (uint8_t *)malloc(tot ? tot : 1);
       for (int64_t r = 0; r < b->n; r++) {
-        const ora_value *v = &b->items[r].values[c];
+        const ora_value *v = &(*VAL(&b->items[r]));
         if (v->kind == OV_NIL) continue;
         col->validity[r >> 3] |= (uint8_t)(1u << (r & 7));
         if (v->slen) memcpy(col->data + col->offsets[r], v->s, v->slen);
@@ -218,7 +219,7 @@ tfgpu_batch *ora_to_columns(const ora_batch *b) {
       col->values = calloc((size_t)b->n, w);
       if (repr == TFGPU_R_TIME) col->nanos = (int32_t *)calloc((size_t)b->n, sizeof(int32_t));
       for (int64_t r = 0; r < b->n; r++) {
-        const ora_value *v = &b->items[r].values[c];
+        const ora_value *v = &(*VAL(&b->items[r]));
         if (v->kind == OV_NIL) continue;
         col->validity[r >> 3] |= (uint8_t)(1u << (r & 7));
         switch (repr) {
@@ -238,6 +239,37 @@ tfgpu_batch *ora_to_columns(const ora_batch *b) {
       }
     }
   }
+}
+#undef VAL
+
+tfgpu_batch *ora_to_columns(const ora_batch *b) {
+  tfgpu_batch *cb = (tfgpu_batch *)calloc(1, sizeof *cb);
+  cb->nrows = b->n; cb->mem = TFGPU_MEM_HOST;
+  cb->kind = (uint8_t *)calloc((size_t)(b->n ? b->n : 1), 1);
+  cb->src_row = (int32_t *)calloc((size_t)(b->n ? b->n : 1), sizeof(int32_t));
+  cb->part_id = (uint32_t *)calloc((size_t)(b->n ? b->n : 1), sizeof(uint32_t));
+  if (b->n == 0) return cb;
+  const ora_item *f = &b->items[0];
+  cb->table_ns = dups(f->ns); cb->table_name = dups(f->table);
+  cb->ncols = f->nvalues;
+  cb->cols = (tfgpu_column *)calloc((size_t)(cb->ncols ? cb->ncols : 1), sizeof(tfgpu_column));
+  for (int64_t r = 0; r < b->n; r++) {
+    cb->kind[r] = (uint8_t)b->items[r].kind;
+    cb->src_row[r] = (int32_t)b->items[r].src_row;
+    const char *p = b->items[r].part_id;
+    cb->part_id[r] = (p && *p >= '0' && *p <= '9') ? (uint32_t)strtoul(p, NULL, 10) : 0;
+  }
+  for (int c = 0; c < cb->ncols; c++) fill_column(&cb->cols[c], b, f, f->names && c < f->names->n ? f->names->names[c] : "", c, 0);
+  /* OldKeys: columns by the KeyNames of the first row that has them */
+  const ora_item *fo = NULL;
+  for (int64_t r = 0; r < b->n && !fo; r++) if (b->items[r].n_old > 0) fo = &b->items[r];
+  if (fo) {
+    cb->n_old_keys = fo->n_old;
+    cb->old_keys = (tfgpu_column *)calloc((size_t)fo->n_old, sizeof(tfgpu_column));
+    cb->old_keys_present = (uint8_t *)calloc((size_t)((b->n + 7) / 8), 1);
+    for (int64_t r = 0; r < b->n; r++) if (b->items[r].n_old > 0) cb->old_keys_present[r >> 3] |= (uint8_t)(1u << (r & 7));
+    for (int c = 0; c < fo->n_old; c++) fill_column(&cb->old_keys[c], b, f, fo->old_names->names[c], c, 1);
+  }
   return cb;
 }
 
@@ -247,6 +279,11 @@ void ora_columns_free(tfgpu_batch *cb) {
     tfgpu_column *col = &cb->cols[c];
     free((void *)col->name); free(col->values); free(col->offsets); free(col->data); free(col->nanos); free(col->validity);
   }
+  for (int c = 0; c < cb->n_old_keys; c++) {
+    tfgpu_column *col = &cb->old_keys[c];
+    free((void *)col->name); free(col->values); free(col->offsets); free(col->data); free(col->nanos); free(col->validity);
+  }
+  free(cb->old_keys); free(cb->old_keys_present);
   free(cb->cols); free(cb->kind); free(cb->src_row); free(cb->part_id);
   free((void *)cb->table_ns); free((void *)cb->table_name);
   free(cb);

@@ -89,6 +89,16 @@ def lib():
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     L.ora_fastfloat_parse_best_effort.restype = C.c_double
     L.ora_fastfloat_parse_best_effort.argtypes = [C.c_char_p, C.c_size_t]
+    L.ora_collapse.restype = P
+    L.ora_collapse.argtypes = [P]
+    L.ora_batch_from_json.restype = P
+    L.ora_batch_from_json.argtypes = [C.c_char_p]
+    L.ora_batch_item_info.argtypes = [P, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    L.ora_batch_item_name.restype = C.c_char_p
+    L.ora_batch_item_name.argtypes = [P, C.c_int64, C.c_int, C.c_int]
+    L.ora_batch_old_value.argtypes = [P, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+    L.ora_batch_len.restype = C.c_int64
+    L.ora_batch_len.argtypes = [P]
     L.free = C.CDLL(None).free
     L.free.argtypes = [C.c_void_p]
     _LIB = L
@@ -344,3 +354,40 @@ def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data: bytes, msgs: ab
     L.ora_json_lines_free(lp)
     L.ora_batch_free(bptr)
     return r
+
+
+# ---- a24: abstract.Collapse --------------------------------------------------------------------
+def collapse(batch: abi.Batch, schema: abi.Schema) -> Result:
+    """abstract.Collapse over a columnar batch (uniform ColumnNames); OldKeys ride in batch.old_keys / old_present."""
+    L = lib()
+    cb, cs = batch.to_c(), schema.to_c()
+    cur = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    t0 = time.perf_counter()
+    out = L.ora_collapse(cur)
+    dt = time.perf_counter() - t0
+    L.ora_batch_free(cur)
+    return _finish(L, out, dt)
+
+
+def collapse_rows(items):
+    """abstract.Collapse over row-wise items (dicts: kind, keys, names, values, old_names, old_values — values are
+    [gotype, value] pairs), for inputs whose ColumnNames differ between items.  Returns the result items row-wise."""
+    L = lib()
+    b = L.ora_batch_from_json(json.dumps({"items": items}).encode("utf-8"))
+    out = L.ora_collapse(b)
+    res = []
+    kind, nv, no, src = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+    for r in range(L.ora_batch_len(out)):
+        L.ora_batch_item_info(out, r, C.byref(kind), C.byref(nv), C.byref(no), C.byref(src))
+        names = [L.ora_batch_item_name(out, r, c, 0).decode() for c in range(nv.value)]
+        vals = _row_values(L, out, r, nv.value)
+        olds = []
+        k2, i64, s, sl = C.c_int(0), C.c_int64(0), C.c_char_p(), C.c_size_t(0)
+        for c in range(no.value):
+            L.ora_batch_old_value(out, r, c, C.byref(k2), C.byref(i64), C.byref(s), C.byref(sl))
+            nm = _OV_NAMES[k2.value]
+            olds.append([L.ora_batch_item_name(out, r, c, 1).decode(), [nm, C.string_at(s, sl.value) if nm in ("string", "bytes") else (None if nm == "nil" else i64.value)]])
+        res.append({"kind": ["insert", "update", "delete", "other"][kind.value], "names": names, "values": vals, "old": olds, "src": int(src.value)})
+    L.ora_batch_free(out)
+    L.ora_batch_free(b)
+    return res

@@ -1,0 +1,101 @@
+"""tfgpu_collapse (abstract.Collapse on device) against the oracle, through the C ABI.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from collapse_cases import random_batch, rows_of
+from test_collapse import CASES, SHAPES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as o
+    return o
+
+
+def check(tf, oracle, b, schema, ctx):
+    got = tf.collapse(tf.DeviceBatch.upload(b)).download()
+    ref = oracle.collapse(b, schema).batch
+    assert got.nrows == ref.nrows, ctx
+    assert [c.name for c in got.cols] == [c.name for c in ref.cols], ctx
+    assert rows_of(got) == rows_of(ref), ctx
+    return got
+
+
+def test_reference_cases_uniform_columns(tf, oracle):
+    """TestCollapse cases whose items share one ColumnNames list (the columnar form); the others are the host's."""
+    ran = 0
+    for case in CASES:
+        items = case["items"]
+        if len({tuple(it["names"]) for it in items}) != 1 or not items[0]["names"]:
+            continue
+        if any(v[0] == "json" for it in items for v in it["values"]):
+            continue
+        keys = items[0]["keys"]
+        names = items[0]["names"]
+        gotype = {nm: items[0]["values"][i][0] for i, nm in enumerate(names)}
+        dt = {"int": "int64", "string": "utf8"}
+        schema = abi.Schema([abi.ColSchema(nm, dt[gotype[nm]], nm in keys, "", "") for nm in names])
+        b = abi.batch_from_rows(schema, names, [it["values"] for it in items], "", "t", [it["kind"] for it in items])
+        b.schema = schema
+        onames = next((it["old_names"] for it in items if it.get("old_names")), None)
+        if onames:
+            if any(it.get("old_names", onames) != onames for it in items):
+                continue
+            ogo = {nm: next(it["old_values"][i][0] for it in items if it.get("old_names")) for i, nm in enumerate(onames)}
+            osch = abi.Schema([abi.ColSchema(nm, dt[ogo[nm]], False, "", "") for nm in onames])
+            ob = abi.batch_from_rows(osch, onames, [it.get("old_values") or [["nil", None]] * len(onames) for it in items])
+            b.old_keys, b.old_present = ob.cols, np.array([bool(it.get("old_names")) for it in items])
+        got = check(tf, oracle, b, schema, case["name"])
+        e = case["expect"]
+        assert got.nrows == e["len"], case["name"]
+        for k, kind in e.get("kinds", {}).items():
+            assert ["insert", "update", "delete", "other"][int(got.kind[int(k)])] == kind if got.kind is not None else kind == "insert"
+        ran += 1
+    assert ran >= 6
+
+
+@pytest.mark.parametrize("shape", range(len(SHAPES)))
+def test_random_batches(tf, oracle, shape):
+    for seed in range(4):
+        b, schema = random_batch(1000 * shape + seed, **SHAPES[shape])
+        check(tf, oracle, b, schema, (shape, seed))
+
+
+def test_large_batches(tf, oracle):
+    """A 200k-row CDC batch (30k keys x 6 strings, chains, primary-key changes): thousands of components walked in
+    parallel; then one hot key — a single component, one lane replaying 20k rows in input order."""
+    b, schema = random_batch(99, 200_000, domain=30_000, two_keys=True, nstrs=6)
+    got = check(tf, oracle, b, schema, "large")
+    assert 0 < got.nrows < b.nrows
+    b2, schema2 = random_batch(5, 20_000, domain=1, weights=(1, 6, 2, 0))
+    check(tf, oracle, b2, schema2, "hot key")
+
+
+def test_passthrough_and_errors(tf, oracle):
+    """len < 2, inserts only and no key column come back unchanged (change_item_collapse.go:49-66); a NaN key is refused."""
+    b, schema = random_batch(3, 50, weights=(1, 0, 0, 0))
+    assert rows_of(tf.collapse(tf.DeviceBatch.upload(b)).download()) == rows_of(b)
+    b, schema = random_batch(4, 1)
+    assert tf.collapse(tf.DeviceBatch.upload(b)).download().nrows == 1
+    b, schema = random_batch(5, 50)
+    b.schema = abi.Schema([abi.ColSchema(c.name, c.dtype, False, "", "") for c in schema.cols])
+    assert rows_of(tf.collapse(tf.DeviceBatch.upload(b)).download()) == rows_of(b)
+    sch = abi.Schema([abi.ColSchema("f", "double", True, "", ""), abi.ColSchema("v", "int64", False, "", "")])
+    nb = abi.batch_from_rows(sch, ["f", "v"], [[["float64", 1.5], ["int64", 0]], [["float64", float("nan")], ["int64", 1]]], "", "t", ["insert", "update"])
+    nb.schema = sch
+    with pytest.raises(tf.TfgpuError):
+        tf.collapse(tf.DeviceBatch.upload(nb))
+    ok = abi.batch_from_rows(sch, ["f", "v"], [[["float64", 1.5], ["int64", 0]], [["float64", 1.5], ["int64", 1]], [["float64", -0.0], ["int64", 2]], [["float64", 0.0], ["int64", 3]]],
+                             "", "t", ["insert", "update", "update", "update"])
+    ok.schema = sch
+    check(tf, oracle, ok, sch, "float keys")  # 1.5 merges; -0 and 0 print differently ("-0" / "0"): two keys

@@ -500,6 +500,113 @@ def json_parser():
                   "rows": [{"table": it["table"], "names": it["columnnames"], "marshalled": it["columnvalues"], "part": it["part"]} for it in items]})
     write("json_parser.json", {"cases": cases})
 
+def collapse():
+    """abstract.Collapse cases of TestCollapse (pkg/abstract/changeitem/change_item_test.go:205-964), transcribed as
+    data; expectations are the test's own asserts.  Items: kind, keys (PrimaryKey names of the item's TableSchema),
+    names / values (ColumnNames / ColumnValues), old_names / old_values (OldKeys.KeyNames / KeyValues)."""
+    src = REF + "/pkg/abstract/changeitem/change_item_test.go"
+    lines = open(src, encoding="utf-8").read().split("\n")
+
+    def it(kind, keys, names, values, old=None):
+        d = {"kind": kind, "keys": keys, "names": names, "values": values}
+        if old:
+            d["old_names"], d["old_values"] = old
+        return d
+
+    I = lambda v: ["int", v]
+    S = lambda v: ["string", v]
+    mw = '["бесплатно","борода","игры","порно"]'
+    fio = 'ООО "РостовПромПокрытия"'
+    cid = 51615524
+    cases = []
+
+    def case(line, name, items, expect):
+        assert ('t.Run("%s"' % name) in lines[line - 1], (line, name, lines[line - 1])
+        cases.append({"name": name, "ref": "change_item_test.go:%d" % line, "items": items, "expect": expect})
+
+    case(206, "insert and update primary key",
+         [it("insert", ["id"], ["id"], [I(1)]),
+          it("update", ["id"], ["id"], [I(2)], (["id"], [I(1)])),
+          it("update", ["id"], ["id"], [I(3)], (["id"], [I(2)]))],
+         {"len": 1, "kinds": {"0": "insert"}, "values_equal": {"0": [I(3)]}})
+    case(243, "insert and update primary key sequentially",
+         [it("insert", ["id"], ["id"], [I(1)])] +
+         [it("update", ["id"], ["id"], [I(i + 1)], (["id"], [I(i)])) for i in range(1, 10)],
+         {"len": 1, "kinds": {"0": "insert"}, "values_equal": {"0": [I(10)]}})
+    case(270, "Update Update, Diff toast",
+         [it("update", ["cid"], ["cid", "FIO", "minus_words"], [I(cid), S(fio), S(mw)]),
+          it("update", ["cid"], ["cid", "meaningful_goals"], [I(cid), S('[{"goal_id":"114403594","value":500}]')])],
+         {"len": 1, "kinds": {"0": "update"}, "values_contain": {"0": [S(mw), S('[{"goal_id":"114403594","value":500}]')]},
+          "names_contain": {"0": ["minus_words"]}})
+    mw2 = '["бесплатно","борода","игры","порно","без смс"]'
+    case(313, "Update Update, Diff full",
+         [it("update", ["cid"], ["cid", "FIO", "minus_words"], [I(cid), S(fio), S(mw)],
+             (["cid", "FIO", "minus_words"], [S("51615524"), S(""), S("")])),
+          it("update", ["cid"], ["cid", "FIO", "minus_words"], [I(cid), S(fio), S(mw2)],
+             (["cid", "FIO", "minus_words"], [S("51615524"), S(fio), S(mw)]))],
+         {"len": 1, "kinds": {"0": "update"}, "values_contain": {"0": [S(mw2), S(fio), I(cid)]},
+          "names_contain": {"0": ["minus_words", "FIO", "cid"]}})
+    case(393, "Insert Update, Diff Toast",
+         [it("insert", ["cid"], ["cid", "minus_words", "meaningful_goals"], [I(cid), S(mw), S('[{"value":100}]')]),
+          it("update", ["cid"], ["cid", "meaningful_goals"], [I(cid), S('[{"value":500}]')])],
+         {"len": 1, "kinds": {"0": "insert"}, "values_contain": {"0": [S(mw), S('[{"value":500}]')]},
+          "values_not_contain": {"0": [S('[{"value":100}]')]}, "names_contain": {"0": ["minus_words"]}})
+    case(438, "Insert Update, multiple PK",
+         [it("insert", ["i2", "i1", "i3"], ["i1", "i2", "i3", "t"], [I(11), I(21), I(31), S("test1")]),
+          it("update", ["i1", "i3", "i2"], ["i2", "i1", "i3", "t"], [I(21), I(11), I(31), S("test2")])],
+         {"len": 1, "kinds": {"0": "insert"}, "values_contain": {"0": [I(11), I(21), I(31), S("test2")]}})
+    case(469, "Insert Update, multiple PK, toast",
+         [it("insert", ["i2", "i1"], ["i1", "i2", "t"], [I(11), I(21), S("test1")]),
+          it("update", ["i1", "i2"], ["t"], [S("test2")], (["i2", "i1"], [I(21), I(11)]))],
+         {"len": 1, "kinds": {"0": "insert"}, "values_contain": {"0": [I(11), I(21), S("test2")]}})
+    iud = [it("insert", ["cid"], ["cid", "minus_words", "meaningful_goals"], [I(cid), S(mw), S('[{"value":100}]')]),
+           it("update", ["cid"], ["cid", "meaningful_goals"], [I(cid), S('[{"value":500}]')]),
+           it("delete", ["cid"], ["cid"], [I(cid)])]
+    case(503, "Insert Update Delete", iud, {"len": 1, "kinds": {"0": "delete"}})
+    case(556, "Update primary key and Delete",
+         [it("update", ["cid"], ["cid", "meaningful_goals"], [I(51615525), S('[{"value":500}]')], (["cid"], [I(cid)])),
+          it("delete", ["cid"], [], [], (["cid"], [I(51615525)]))],
+         {"len": 1, "kinds": {"0": "delete"}, "old_value0": {"0": I(cid)}})
+    case(596, "Insert Update Delete Insert",
+         iud + [it("insert", ["cid"], ["cid", "minus_words", "meaningful_goals"], [I(cid), S(mw), S('[{"value":200}]')])],
+         {"len": 1, "kinds": {"0": "insert"}, "values_contain": {"0": [S('[{"value":200}]')]}, "names_contain": {"0": ["minus_words"]}})
+    case(668, "Delete Update (Upsert scenario)",
+         [it("delete", ["cid"], ["cid"], [I(cid)]),
+          it("update", ["cid"], ["cid", "meaningful_goals"], [I(cid), S('[{"value":500}]')])],
+         {"len": 1, "kinds": {"0": "update"}})
+    mw3 = '["платно", "качественный пристойный контент"]'
+    case(704, "Primary key change",
+         [it("insert", ["cid"], ["cid", "minus_words", "meaningful_goals"], [I(cid), S(mw), S('[{"value":100}]')]),
+          it("update", ["cid"], ["cid", "meaningful_goals"], [I(51615525), S('[{"value":500}]')], (["cid"], [I(cid)])),
+          it("insert", ["cid"], ["cid", "minus_words", "meaningful_goals"], [I(51615526), S(mw3), S('[{"value":200}]')])],
+         {"len": 2, "kinds": {"0": "insert", "1": "insert"}, "nvalues": {"0": 3, "1": 3},
+          "col_value": {"0": {"cid": I(51615525), "minus_words": S(mw), "meaningful_goals": S('[{"value":500}]')},
+                        "1": {"cid": I(51615526), "minus_words": S(mw3), "meaningful_goals": S('[{"value":200}]')}}})
+    cu = ["cid", "uniq"]
+    # this reference case runs Collapse twice (changes, changes2): two golden cases
+    case(760, "Bad collapse with extra contstraint",
+         [it("insert", ["cid"], cu, [I(1), S("first_value")]), it("insert", ["cid"], cu, [I(2), S("second_value")])],
+         {"len": 2, "kinds": {"0": "insert"}, "equals_input": True})
+    case(760, "Bad collapse with extra contstraint",
+         [it("update", ["cid"], cu, [I(1), S("temp_value")]), it("update", ["cid"], cu, [I(2), S("first_value")]),
+          it("update", ["cid"], cu, [I(1), S("second_value")])],
+         {"len": 2, "kinds": {"0": "update"}})
+    case(819, "Collapse with no primary keys should be no-op",
+         [it("insert", [], cu, [I(1), S("first_value")]), it("insert", [], cu, [I(2), S("second_value")])],
+         {"len": 2, "equals_input": True})
+    # json.Unmarshal gives []interface{} of map[string]interface{}: json.Marshal renders map keys sorted
+    mkey = '[{"Key":"issueId","Value":"60be59389f7e4745883817d6"},{"Key":"linkField","Value":"parentIssueLinkChain"}]'
+    doc = '{"chain":[{"height":1,"issue":"608999a8a702ca1877a3ddf2"},{"height":2,"issue":"6024fc6b5dc51554943bed7f"},{"height":3,"issue":"6017da0f3ed4d47bd0582d07"}]}'
+    case(842, "Collapse with mongo replication delete->insert records with same pkey",
+         [it("delete", ["_id"], [], [], (["_id"], [["json", mkey]])),
+          it("insert", ["_id"], ["_id", "document"], [["json", mkey], ["json", doc]])],
+         {"len": 1, "equals_item": {"0": 1}})
+    case(933, "update insert",
+         [it("update", ["id"], ["id"], [I(2)], (["id"], [I(1)])), it("insert", ["id"], ["id"], [I(1)])],
+         {"len": 2, "equals_input": True})
+    write("collapse.json", {"source": "pkg/abstract/changeitem/change_item_test.go:205-964 (TestCollapse)", "cases": cases})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -513,4 +620,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse()

@@ -61,7 +61,8 @@ class CColumn(C.Structure):
 class CBatch(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int32), ("cols", C.POINTER(CColumn)), ("table_ns", C.c_char_p),
                 ("table_name", C.c_char_p), ("kind", C.c_void_p), ("src_row", C.c_void_p), ("part_id", C.c_void_p),
-                ("mem", C.c_int32), ("schema", C.POINTER(CSchema))]
+                ("mem", C.c_int32), ("n_old_keys", C.c_int32), ("old_keys", C.POINTER(CColumn)), ("old_keys_present", C.c_void_p),
+                ("schema", C.POINTER(CSchema))]
 
 
 class CRowError(C.Structure):
@@ -267,9 +268,10 @@ class Batch:
         raise KeyError(name)
 
     def to_c(self) -> CBatch:
-        arr = (CColumn * max(len(self.cols), 1))()
+        old = list(getattr(self, "old_keys", None) or [])
+        arr = (CColumn * max(len(self.cols) + len(old), 1))()
         keep = []
-        for i, c in enumerate(self.cols):
+        for i, c in enumerate(list(self.cols) + old):
             nm = _b(c.name)
             keep.append(nm)
             arr[i].name, arr[i].dtype, arr[i].repr = nm, DTYPE_ID[c.dtype], c.repr
@@ -299,6 +301,16 @@ class Batch:
         ns, tn = _b(self.table_ns), _b(self.table_name)
         keep += [ns, tn]
         cb.table_ns, cb.table_name, cb.mem = ns, tn, MEM_HOST
+        if old:  # ChangeItem.OldKeys: columns by KeyNames + which rows carry them
+            cb.n_old_keys = len(old)
+            cb.old_keys = C.cast(C.byref(arr, C.sizeof(CColumn) * len(self.cols)), C.POINTER(CColumn))
+            pres = getattr(self, "old_present", None)
+            if pres is not None:
+                pb = pack_validity(np.asarray(pres, dtype=bool), self.nrows)
+                if len(pb) == 0:
+                    pb = np.zeros(1, np.uint8)
+                keep.append(pb)
+                cb.old_keys_present = pb.ctypes.data
         if self.part_id is not None:
             pid = np.ascontiguousarray(self.part_id, dtype=np.uint32)
             keep.append(pid)
@@ -329,9 +341,12 @@ def _np_from_ptr(ptr, n, dtype):
 def batch_from_c(cb: CBatch) -> Batch:
     """Copy a HOST-memory tfgpu_batch into numpy-owned storage."""
     n = int(cb.nrows)
-    cols = []
-    for i in range(cb.ncols):
-        c = cb.cols[i]
+    cols = [_column_from_c(cb.cols[i], n) for i in range(cb.ncols)]
+    return _batch_from_c_tail(cb, cols, n)
+
+
+def _column_from_c(c, n):
+    if True:
         col = Column((c.name or b"").decode("utf-8"), DTYPES[c.dtype], int(c.repr))
         if c.repr in VAR_REPRS:
             col.offsets = _np_from_ptr(c.offsets, n + 1, np.uint32) if n or c.offsets else np.zeros(1, np.uint32)
@@ -344,8 +359,14 @@ def batch_from_c(cb: CBatch) -> Batch:
                 col.nanos = _np_from_ptr(c.nanos, n, np.int32)
         if c.validity:
             col.validity = unpack_validity(_np_from_ptr(c.validity, (n + 7) // 8, np.uint8), n)
-        cols.append(col)
+        return col
+
+
+def _batch_from_c_tail(cb, cols, n):
     b = Batch(cols, n, (cb.table_ns or b"").decode(), (cb.table_name or b"").decode())
+    if cb.n_old_keys:
+        b.old_keys = [_column_from_c(cb.old_keys[i], n) for i in range(cb.n_old_keys)]
+        b.old_present = unpack_validity(_np_from_ptr(cb.old_keys_present, (n + 7) // 8, np.uint8), n) if cb.old_keys_present else np.ones(n, bool)
     if cb.kind:
         b.kind = _np_from_ptr(cb.kind, n, np.uint8)
     if cb.src_row:

@@ -1,0 +1,321 @@
+// tf_collapse.hip — abstract.Collapse on device (pkg/abstract/changeitem/change_item_collapse.go:48-134).
+//
+// The reference walks the batch once, in order, over three Go maps keyed by a row's key STRING — json.Marshal of its
+// PrimaryKey values in key-name order, taken from OldKeys for an Update / Delete that carries them
+// (OldOrCurrentKeysString / CurrentKeysString, change_item.go:314-358).  Every key string that can ever appear is one of
+// two per row: K_cur(i) (from ColumnValues) and K_old(i) (from OldKeys), because a collapsed row's key is either its
+// first item's OldKeys key or the last writer's current key.  That makes the walk a state machine over at most 2n
+// integer key ids, and rows whose keys never meet are independent:
+//
+//   1. collapse_hash    lane = (row, cur|old): the key string is rendered by the json.Marshal emitter (tf_emit.hpp) into
+//                       a hashing sink — 2 x 64 bits; equal strings <=> equal hashes up to a 2^-128 collision chance.
+//   2. collapse_intern  open-addressing table in HBM (4n..8n slots): a key's id is the slot its hash claims.
+//   3. collapse_link    union-find over key ids: a row ties K_cur(i) to K_old(i).  A component = the keys one chain of
+//                       primary-key changes can reach; everything the reference's maps do for one key stays inside it.
+//   4. radix sort of the rows by component root (rocPRIM, stable: input order survives inside a component).
+//   5. collapse_walk    ONE lane per component replays the reference's switch over its rows in input order; the three
+//                       maps are arrays indexed by key id (rows[k] = (first item m, last writer v), toDelete[k],
+//                       hashKToIdx[k]).  Parallelism = number of components (a batch of n distinct keys: n lanes).
+//   6. flags → one scan → three selection vectors → gathers: result = non-row items, rows by hashKToIdx, deletes.
+//
+// A collapsed row takes Kind / OldKeys / PartID / source position from its first item and ColumnValues from its last
+// writer; a Delete that follows an item with OldKeys inherits those OldKeys (change_item_collapse.go:111-118).  The
+// columnar batch has ONE ColumnNames list, so the compareColumns merge (:7-35, TOAST updates with fewer columns) is the
+// host's: the shim routes batches whose items differ in ColumnNames to the Go path.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+#include "tf_emit.hpp"
+
+namespace tf {
+
+std::unique_ptr<tfgpu_dbatch> gather_rows(const tfgpu_dbatch &in, const Buf &sel, int64_t m);  // tf_transform.hip
+
+static inline unsigned cgrid(int64_t n) { return (unsigned)((n + 255) / 256); }
+static constexpr uint32_t NOKEY = 0xFFFFFFFFu;
+
+// ---- 1. key strings → 128-bit hashes ----------------------------------------------------------------------------
+struct HashSink {
+  uint64_t h1 = 0x243F6A8885A308D3ull, h2 = 0x13198A2E03707344ull, acc = 0, len = 0;
+  uint32_t n = 0;
+  __device__ __forceinline__ void mix(uint64_t w) {
+    h1 = (h1 ^ w) * 0x9E3779B97F4A7C15ull; h1 ^= h1 >> 32;
+    h2 = (((h2 << 31) | (h2 >> 33)) ^ w) * 0xC2B2AE3D27D4EB4Full; h2 ^= h2 >> 29;
+  }
+  __device__ __forceinline__ void put(uint32_t c) {
+    acc |= (uint64_t)(c & 0xFFu) << (8 * n); len++;
+    if (++n == 8) { mix(acc); acc = 0; n = 0; }
+  }
+  __device__ __forceinline__ void finish() {
+    mix(acc); mix(len);
+    h1 ^= h1 >> 33; h1 *= 0xFF51AFD7ED558CCDull; h1 ^= h1 >> 33;
+    h2 ^= h2 >> 33; h2 *= 0xC4CEB9FE1A85EC53ull; h2 ^= h2 >> 33;
+  }
+};
+
+struct KCol { DCol cur, old; int32_t has_cur, has_old; };  // one PrimaryKey name, in sorted-name order
+struct HashParams {
+  const KCol *keys; int32_t nkeys;
+  int64_t n;
+  const uint8_t *old_present; int32_t has_old_keys;  // bitmap (null = every row) / the batch carries OldKeys at all
+  uint64_t *h;        // [2n][2]: (h1 | 1, h2); h1 == 0: the row has no OldKeys
+  uint32_t *badflag;  // a float key that json.Marshal refuses (NaN / Inf)
+};
+__device__ __forceinline__ bool float_bad(const DCol &c, int64_t r) {
+  if (c.repr != TFGPU_R_FLOAT32 && c.repr != TFGPU_R_FLOAT64) return false;
+  if (!is_valid(c, r)) return false;
+  const double v = c.repr == TFGPU_R_FLOAT32 ? (double)((const float *)c.values)[r] : ((const double *)c.values)[r];
+  return v != v || v == INFINITY || v == -INFINITY;
+}
+__global__ void __launch_bounds__(256) collapse_hash(HashParams p) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * p.n) return;
+  const int64_t r = j >> 1;
+  const bool old = j & 1;
+  if (old && (!p.has_old_keys || (p.old_present && !((p.old_present[r >> 3] >> (r & 7)) & 1)))) { p.h[2 * j] = 0; p.h[2 * j + 1] = 0; return; }
+  HashSink s;
+  s.put('[');
+  for (int k = 0; k < p.nkeys; k++) {
+    if (k) s.put(',');
+    const KCol &kc = p.keys[k];
+    const bool has = old ? kc.has_old : kc.has_cur;
+    if (!has) { put_lit(s, "null"); continue; }  // keys[k] = nil: the key column is not among the row's names
+    const DCol &c = old ? kc.old : kc.cur;
+    if (float_bad(c, r)) { *p.badflag = 1; continue; }
+    emit_json_cell(s, c, r, 0, true);
+  }
+  s.put(']');
+  s.finish();
+  p.h[2 * j] = s.h1 | 1ull;
+  p.h[2 * j + 1] = s.h2;
+}
+
+// ---- 2. key ids: the slot a hash claims -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) collapse_intern(const uint64_t *__restrict__ h, int64_t n2, uint32_t *owner, uint32_t mask, uint32_t *__restrict__ keyid) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n2) return;
+  const uint64_t a = h[2 * j], b = h[2 * j + 1];
+  if (a == 0) { keyid[j] = NOKEY; return; }
+  uint32_t slot = (uint32_t)(b ^ (a >> 17)) & mask;
+  for (;;) {
+    uint32_t o = __hip_atomic_load(&owner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o == NOKEY) o = atomicCAS(&owner[slot], NOKEY, (uint32_t)j);
+    if (o == NOKEY || (h[2 * (int64_t)o] == a && h[2 * (int64_t)o + 1] == b)) { keyid[j] = slot; return; }
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ---- 3. components -----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) collapse_init(uint32_t *parent, int32_t *rows_m, int32_t *del_i, uint32_t *owner, int64_t cap) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cap) return;
+  parent[k] = (uint32_t)k; rows_m[k] = -1; del_i[k] = -1; owner[k] = NOKEY;
+}
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
+  for (;;) {
+    const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    x = p;
+  }
+}
+__global__ void __launch_bounds__(256) collapse_link(const uint32_t *__restrict__ keyid, int64_t n, uint32_t *parent) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint32_t a = keyid[2 * r], b = keyid[2 * r + 1];
+  if (b == NOKEY || a == b) return;
+  for (;;) {  // the larger root is hung under the smaller one: roots only ever decrease, no cycles
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const uint32_t t = a; a = b; b = t; }
+    if (atomicCAS(&parent[a], a, b) == a) return;
+  }
+}
+__global__ void __launch_bounds__(256) collapse_roots(const uint32_t *__restrict__ keyid, int64_t n, uint32_t *parent, uint32_t *__restrict__ root, uint32_t *__restrict__ idx) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  root[r] = uf_find(parent, keyid[2 * r]);
+  idx[r] = (uint32_t)r;
+}
+
+// ---- 5. the reference's loop, one lane per component ------------------------------------------------------------
+struct WalkParams {
+  int64_t n;
+  const uint32_t *sroot, *sidx;  // rows sorted by component, input order inside
+  const uint32_t *keyid;         // [2n]: K_cur, K_old (NOKEY = no OldKeys)
+  const uint8_t *kind;
+  int32_t *rows_m, *rows_v, *k2idx, *del_i, *del_o;  // per key id
+  uint32_t *ak;                  // per row: the key the row was filed under
+};
+__global__ void __launch_bounds__(256) collapse_walk(WalkParams p) {
+  const int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q0 >= p.n) return;
+  const uint32_t root = p.sroot[q0];
+  if (q0 > 0 && p.sroot[q0 - 1] == root) return;  // not the first row of its component
+  for (int64_t q = q0; q < p.n && p.sroot[q] == root; q++) {
+    const int32_t i = (int32_t)p.sidx[q];
+    const uint32_t kind = p.kind[i];
+    const uint32_t kc = p.keyid[2 * (int64_t)i], kro = p.keyid[2 * (int64_t)i + 1];
+    // OldOrCurrentKeysString: OldKeys name the row only for an Update / Delete that has them
+    const uint32_t ko = ((kind == TFGPU_K_UPDATE || kind == TFGPU_K_DELETE) && kro != NOKEY) ? kro : kc;
+    if (kind == TFGPU_K_INSERT) {
+      p.del_i[ko] = -1;
+      p.rows_m[ko] = i; p.rows_v[ko] = i; p.k2idx[ko] = i; p.ak[i] = ko;
+    } else if (kind == TFGPU_K_UPDATE) {
+      p.del_i[ko] = -1;
+      const int32_t m = p.rows_m[ko];
+      if (m < 0) {  // nothing to merge into: filed under its CURRENT key
+        p.rows_m[kc] = i; p.rows_v[kc] = i; p.k2idx[kc] = i; p.ak[i] = kc;
+      } else {      // current.ColumnValues = c.ColumnValues; the row keeps the first item's Kind and OldKeys
+        const uint32_t km = p.kind[m], krom = p.keyid[2 * (int64_t)m + 1];
+        const uint32_t newk = ((km == TFGPU_K_UPDATE || km == TFGPU_K_DELETE) && krom != NOKEY) ? krom : kc;
+        if (newk != ko) p.rows_m[ko] = -1;
+        p.rows_m[newk] = m; p.rows_v[newk] = i; p.k2idx[newk] = i; p.ak[i] = newk;
+      }
+    } else if (kind == TFGPU_K_DELETE) {
+      const int32_t m = p.rows_m[ko];
+      p.rows_m[ko] = -1;
+      uint32_t k = ko; int32_t o = i;
+      if (m >= 0) { const uint32_t krom = p.keyid[2 * (int64_t)m + 1]; if (krom != NOKEY) { k = krom; o = m; } }  // c.OldKeys = current.OldKeys
+      p.del_i[k] = i; p.del_o[k] = o; p.ak[i] = k;
+    }
+  }
+}
+
+// ---- 6. result order: non-row items, rows by hashKToIdx, deletes (by position) ----------------------------------
+__global__ void __launch_bounds__(256) collapse_flags(int64_t n, const uint8_t *__restrict__ kind, const uint32_t *__restrict__ ak, const int32_t *__restrict__ rows_m,
+                                                      const int32_t *__restrict__ k2idx, const int32_t *__restrict__ del_i, uint32_t *__restrict__ f) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t kd = kind[i];
+  uint32_t f0 = 0, f1 = 0, f2 = 0;
+  if (kd == TFGPU_K_INSERT || kd == TFGPU_K_UPDATE) { const uint32_t k = ak[i]; f1 = rows_m[k] >= 0 && k2idx[k] == (int32_t)i; }
+  else if (kd == TFGPU_K_DELETE) f2 = del_i[ak[i]] == (int32_t)i;
+  else f0 = 1;
+  f[i] = f0; f[n + i] = f1; f[2 * n + i] = f2;
+}
+__global__ void __launch_bounds__(256) collapse_select(int64_t n, const uint8_t *__restrict__ kind, const uint32_t *__restrict__ ak, const int32_t *__restrict__ rows_m,
+                                                       const int32_t *__restrict__ rows_v, const int32_t *__restrict__ del_o, const uint32_t *__restrict__ pos,
+                                                       int32_t *__restrict__ sel_meta, int32_t *__restrict__ sel_val, int32_t *__restrict__ sel_old) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t kd = kind[i];
+  const int64_t c = (kd == TFGPU_K_INSERT || kd == TFGPU_K_UPDATE) ? 1 : kd == TFGPU_K_DELETE ? 2 : 0;
+  const uint32_t a = pos[c * n + i], b = pos[c * n + i + 1];
+  if (a == b) return;
+  int32_t m = (int32_t)i, v = (int32_t)i, o = (int32_t)i;
+  if (c == 1) { const uint32_t k = ak[i]; m = rows_m[k]; v = rows_v[k]; o = m; }
+  else if (c == 2) o = del_o[ak[i]];
+  sel_meta[a] = m; sel_val[a] = v; sel_old[a] = o;
+}
+__global__ void __launch_bounds__(256) collapse_any_non_insert(const uint8_t *kind, int64_t n, uint32_t *flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && kind[i] != TFGPU_K_INSERT) *flag = 1;
+}
+
+static const DColumn *find_col(const std::vector<DColumn> &cols, const std::string &name) {
+  const DColumn *hit = nullptr;
+  for (auto &c : cols) if (c.name == name) hit = &c;  // a later duplicate wins, like the map write in CurrentKeysString
+  return hit;
+}
+
+std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
+  const int64_t n = in.nrows;
+  hipStream_t st = ctx().stream;
+  auto same = [&] { return std::make_unique<tfgpu_dbatch>(in); };
+  if (n < 2 || !in.kind) return same();  // len(input) < 2; no Kind array = inserts only
+  if (n >= (int64_t)1 << 29) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: more than 2^29 rows in one batch");
+  {  // InsertsOnly
+    Buf flag = dalloc_zero(4);
+    collapse_any_non_insert<<<cgrid(n), 256, 0, st>>>(ptr<uint8_t>(in.kind), n, ptr<uint32_t>(flag));
+    const uint32_t *h = d2h_u32(flag->p);
+    sync();
+    if (!*h) return same();
+  }
+  // keyCols := input[0].MakeMapKeys(), walked in sorted order (util.MapKeysInOrder)
+  std::vector<std::string> names = in.key_names;
+  std::sort(names.begin(), names.end());
+  names.erase(std::unique(names.begin(), names.end()), names.end());
+  if (names.empty()) return same();
+
+  KernelTimer timer("collapse");
+  std::vector<KCol> kc(names.size());
+  for (size_t k = 0; k < names.size(); k++) {
+    std::memset(&kc[k], 0, sizeof(KCol));
+    if (const DColumn *c = find_col(in.cols, names[k])) { kc[k].cur = dcol_of(*c); kc[k].has_cur = 1; }
+    if (const DColumn *c = find_col(in.old_keys, names[k])) { kc[k].old = dcol_of(*c); kc[k].has_old = 1; }
+  }
+  Buf bkc = upload_small(kc.data(), kc.size() * sizeof(KCol));
+  const int64_t n2 = 2 * n;
+  int bits = 4;
+  while (((int64_t)1 << bits) < 4 * n) bits++;  // load factor <= 1/2 even if every row brings two new keys
+  const int64_t cap = (int64_t)1 << bits;
+  Buf hashes = dalloc((size_t)n2 * 16), keyid = dalloc((size_t)n2 * 4), bad = dalloc_zero(4);
+  Buf owner = dalloc((size_t)cap * 4), parent = dalloc((size_t)cap * 4), rows_m = dalloc((size_t)cap * 4), rows_v = dalloc((size_t)cap * 4),
+      k2idx = dalloc((size_t)cap * 4), del_i = dalloc((size_t)cap * 4), del_o = dalloc((size_t)cap * 4);
+  collapse_init<<<cgrid(cap), 256, 0, st>>>(ptr<uint32_t>(parent), ptr<int32_t>(rows_m), ptr<int32_t>(del_i), ptr<uint32_t>(owner), cap);
+  HashParams hp{};
+  hp.keys = ptr<KCol>(bkc); hp.nkeys = (int32_t)kc.size(); hp.n = n;
+  hp.old_present = ptr<uint8_t>(in.old_present); hp.has_old_keys = in.old_keys.empty() ? 0 : 1;
+  hp.h = ptr<uint64_t>(hashes); hp.badflag = ptr<uint32_t>(bad);
+  collapse_hash<<<cgrid(n2), 256, 0, st>>>(hp);
+  collapse_intern<<<cgrid(n2), 256, 0, st>>>(ptr<uint64_t>(hashes), n2, ptr<uint32_t>(owner), (uint32_t)(cap - 1), ptr<uint32_t>(keyid));
+  collapse_link<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent));
+  Buf root = dalloc((size_t)n * 4), idx = dalloc((size_t)n * 4), sroot = dalloc((size_t)n * 4), sidx = dalloc((size_t)n * 4);
+  collapse_roots<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent), ptr<uint32_t>(root), ptr<uint32_t>(idx));
+  {
+    size_t tmp_bytes = 0;
+    TF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ptr<uint32_t>(root), ptr<uint32_t>(sroot), ptr<uint32_t>(idx), ptr<uint32_t>(sidx), (size_t)n, 0u, (unsigned)bits, st));
+    Buf tmp = dalloc(tmp_bytes + 16);
+    TF_HIP(rocprim::radix_sort_pairs(tmp->p, tmp_bytes, ptr<uint32_t>(root), ptr<uint32_t>(sroot), ptr<uint32_t>(idx), ptr<uint32_t>(sidx), (size_t)n, 0u, (unsigned)bits, st));
+  }
+  Buf ak = dalloc((size_t)n * 4);
+  WalkParams wp{};
+  wp.n = n; wp.sroot = ptr<uint32_t>(sroot); wp.sidx = ptr<uint32_t>(sidx); wp.keyid = ptr<uint32_t>(keyid); wp.kind = ptr<uint8_t>(in.kind);
+  wp.rows_m = ptr<int32_t>(rows_m); wp.rows_v = ptr<int32_t>(rows_v); wp.k2idx = ptr<int32_t>(k2idx); wp.del_i = ptr<int32_t>(del_i); wp.del_o = ptr<int32_t>(del_o);
+  wp.ak = ptr<uint32_t>(ak);
+  collapse_walk<<<cgrid(n), 256, 0, st>>>(wp);
+  Buf f = dalloc((size_t)(3 * n + 1) * 4 + 16);
+  collapse_flags<<<cgrid(n), 256, 0, st>>>(n, ptr<uint8_t>(in.kind), ptr<uint32_t>(ak), ptr<int32_t>(rows_m), ptr<int32_t>(k2idx), ptr<int32_t>(del_i), ptr<uint32_t>(f));
+  exclusive_scan_u32(ptr<uint32_t>(f), ptr<uint32_t>(f), 3 * n, true);
+  const uint32_t *hm = d2h_u32(ptr<uint32_t>(f) + 3 * n);
+  const uint32_t *hbad = d2h_u32(bad->p);
+  sync();
+  if (*hbad) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: NaN / Inf in a primary-key column (json.Marshal fails on the key; the reference files every such row under the empty key)");
+  const int64_t m = *hm;
+  Buf sel_meta = dalloc((size_t)m * 4 + 4), sel_val = dalloc((size_t)m * 4 + 4), sel_old = dalloc((size_t)m * 4 + 4);
+  collapse_select<<<cgrid(n), 256, 0, st>>>(n, ptr<uint8_t>(in.kind), ptr<uint32_t>(ak), ptr<int32_t>(rows_m), ptr<int32_t>(rows_v), ptr<int32_t>(del_o), ptr<uint32_t>(f),
+                                            ptr<int32_t>(sel_meta), ptr<int32_t>(sel_val), ptr<int32_t>(sel_old));
+  // ColumnValues from the last writer; Kind / PartID / position from the first item; OldKeys from the first item (or,
+  // for a Delete, from the row it removed)
+  tfgpu_dbatch vals_in = in;
+  vals_in.old_keys.clear(); vals_in.old_present = nullptr; vals_in.kind = nullptr; vals_in.part_id = nullptr; vals_in.src_row = nullptr;
+  auto out = gather_rows(vals_in, sel_val, m);
+  tfgpu_dbatch meta_in;
+  meta_in.nrows = n; meta_in.kind = in.kind; meta_in.part_id = in.part_id; meta_in.src_row = in.src_row;
+  auto meta = gather_rows(meta_in, sel_meta, m);
+  out->kind = meta->kind; out->part_id = meta->part_id; out->src_row = meta->src_row;
+  if (!in.old_keys.empty()) {
+    tfgpu_dbatch old_in;
+    old_in.nrows = n; old_in.old_keys = in.old_keys; old_in.old_present = in.old_present;
+    auto old = gather_rows(old_in, sel_old, m);
+    out->old_keys = std::move(old->old_keys); out->old_present = old->old_present;
+  }
+  out->key_names = in.key_names; out->schema = in.schema; out->ns = in.ns; out->table = in.table;
+  return out;
+}
+
+}  // namespace tf
+
+extern "C" int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out) {
+  try {
+    if (!in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_collapse: null argument");
+    std::lock_guard<std::mutex> lk(tf::ctx().mu);
+    *out = tf::collapse_rows(*in).release();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}

@@ -136,6 +136,9 @@ struct tfgpu_dbatch {
   int64_t nrows = 0;
   std::vector<tf::DColumn> cols;
   std::vector<std::pair<std::string, int>> schema;  // TableSchema (name, DataType) in order; empty = same as cols
+  std::vector<std::string> key_names;               // names of the PrimaryKey columns of that schema (MakeMapKeys)
+  std::vector<tf::DColumn> old_keys;                // OldKeys.KeyValues by KeyNames; empty = no row has OldKeys
+  tf::Buf old_present;                              // bitmap: the row has OldKeys; null with old_keys = every row
   std::string ns, table;
   tf::Buf kind, src_row, part_id;
 };

@@ -1,0 +1,149 @@
+// tf_emit.hpp — Go value text on device: byte sinks and the emitters shared by the serializers (tf_serialize.hip) and by
+// Collapse's key strings (tf_collapse.hip): encoding/json strings, base64, integers, shortest floats.  Every emitter is a
+// template over a sink with put(byte), so the same code counts, writes or hashes.
+#pragma once
+#include "tf_devcol.hpp"
+#include "tf_devfmt.hpp"
+#include "tf_devfloat.hpp"
+
+namespace tf {
+
+// ---- sinks -----------------------------------------------------------------------
+struct CountSink { uint32_t n = 0; __device__ __forceinline__ void put(uint32_t) { n++; } };
+// Bytes gathered eight at a time and stored with ONE (possibly unaligned) 8-byte store: a cell's text lands in the
+// middle of its row, so byte stores would cost one memory transaction per character.
+struct WriteSink {
+  uint8_t *p; uint64_t acc = 0; uint32_t n = 0;
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  __device__ __forceinline__ void put(uint32_t c) {
+    acc |= (uint64_t)(c & 0xFFu) << (8 * n);
+    if (++n == 8) { reinterpret_cast<U64 *>(p)->v = acc; p += 8; acc = 0; n = 0; }
+  }
+  __device__ __forceinline__ void flush() {
+    if (n >= 4) { struct __attribute__((packed, aligned(1))) U32 { uint32_t v; }; reinterpret_cast<U32 *>(p)->v = (uint32_t)acc; p += 4; acc >>= 32; n -= 4; }
+    for (; n; n--) { *p++ = (uint8_t)acc; acc >>= 8; }
+  }
+};
+template <class S> struct CsvQuoteSink {  // doubles '"' (encoding/csv quoted field body)
+  S &s;
+  __device__ __forceinline__ void put(uint32_t c) { if (c == '"') s.put('"'); s.put(c); }
+};
+
+template <class S> __device__ __forceinline__ void put_bytes(S &s, const uint8_t *p, uint32_t n) { for (uint32_t i = 0; i < n; i++) s.put(p[i]); }
+template <class S> __device__ __forceinline__ void put_lit(S &s, const char *p) { while (*p) s.put((uint8_t)*p++); }
+__device__ __forceinline__ uint32_t hexc(uint32_t n) { return n + (n < 10 ? '0' : 'a' - 10); }
+
+// writeQuoted (marshal.go:377-419)
+template <class S> __device__ void emit_ch_quoted(S &s, const uint8_t *p, uint32_t n) {
+  s.put('"');
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = p[i];
+    if (c >= 0x20 && c != '"' && c != '\\') { s.put(c); continue; }
+    s.put('\\');
+    switch (c) {
+      case '"': s.put('"'); break; case '\\': s.put('\\'); break; case '\n': s.put('n'); break; case '\r': s.put('r'); break;
+      case '\t': s.put('t'); break; case '\f': s.put('f'); break; case '\b': s.put('b'); break;
+      default: s.put('u'); s.put('0'); s.put('0'); s.put(hexc(c >> 4)); s.put(hexc(c & 15));
+    }
+  }
+  s.put('"');
+}
+
+// encoding/json appendString: ", \, control bytes, invalid UTF-8 → �, U+2028/9; optional HTML escaping
+template <class S> __device__ void emit_json_string(S &s, const uint8_t *p, uint32_t n, bool html) {
+  s.put('"');
+  uint32_t i = 0;
+  while (i < n) {
+    const uint32_t c = p[i];
+    if (c < 0x80) {
+      if (c >= 0x20 && c != '"' && c != '\\' && !(html && (c == '<' || c == '>' || c == '&'))) { s.put(c); i++; continue; }
+      s.put('\\');
+      switch (c) {
+        case '"': s.put('"'); break; case '\\': s.put('\\'); break; case '\b': s.put('b'); break; case '\f': s.put('f'); break;
+        case '\n': s.put('n'); break; case '\r': s.put('r'); break; case '\t': s.put('t'); break;
+        default: s.put('u'); s.put('0'); s.put('0'); s.put(hexc(c >> 4)); s.put(hexc(c & 15));
+      }
+      i++; continue;
+    }
+    uint32_t need = 0, cp = 0, lo = 0x80, hi = 0xBF;  // utf8.DecodeRune
+    if (c >= 0xC2 && c <= 0xDF) { need = 1; cp = c & 0x1F; }
+    else if (c >= 0xE0 && c <= 0xEF) { need = 2; cp = c & 0x0F; if (c == 0xE0) lo = 0xA0; if (c == 0xED) hi = 0x9F; }
+    else if (c >= 0xF0 && c <= 0xF4) { need = 3; cp = c & 0x07; if (c == 0xF0) lo = 0x90; if (c == 0xF4) hi = 0x8F; }
+    bool ok = need > 0 && i + need < n;
+    if (ok) for (uint32_t k = 1; k <= need; k++) {
+      const uint32_t d = p[i + k], l = k == 1 ? lo : 0x80u, h = k == 1 ? hi : 0xBFu;
+      if (d < l || d > h) { ok = false; break; }
+      cp = (cp << 6) | (d & 0x3F);
+    }
+    if (!ok) { put_lit(s, "\\ufffd"); i++; continue; }
+    if (cp == 0x2028 || cp == 0x2029) { put_lit(s, cp == 0x2028 ? "\\u2028" : "\\u2029"); i += need + 1; continue; }
+    for (uint32_t k = 0; k <= need; k++) s.put(p[i + k]);
+    i += need + 1;
+  }
+  s.put('"');
+}
+
+template <class S> __device__ void emit_base64(S &s, const uint8_t *p, uint32_t n) {  // base64.StdEncoding
+  const char *T = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  uint32_t i = 0;
+  for (; i + 3 <= n; i += 3) { uint32_t v = (p[i] << 16) | (p[i + 1] << 8) | p[i + 2]; s.put(T[v >> 18]); s.put(T[(v >> 12) & 63]); s.put(T[(v >> 6) & 63]); s.put(T[v & 63]); }
+  if (n - i == 1) { uint32_t v = p[i] << 16; s.put(T[v >> 18]); s.put(T[(v >> 12) & 63]); s.put('='); s.put('='); }
+  else if (n - i == 2) { uint32_t v = (p[i] << 16) | (p[i + 1] << 8); s.put(T[v >> 18]); s.put(T[(v >> 12) & 63]); s.put(T[(v >> 6) & 63]); s.put('='); }
+}
+
+template <class S> __device__ __forceinline__ void emit_small(S &s, const uint8_t *t, int n) { for (int i = 0; i < n; i++) s.put(t[i]); }
+
+// strconv.FormatFloat(f, 'f', -1, bits) of a float column's value
+template <class S> __device__ void emit_float_f(S &s, const DCol &c, int64_t r) {
+  if (c.repr == TFGPU_R_FLOAT32) dev::fmt_float(s, (double)((const float *)c.values)[r], 'f', 32);
+  else dev::fmt_float(s, ((const double *)c.values)[r], 'f', 64);
+}
+
+// json.Marshal(float): encoding/json's floatEncoder
+template <class S> __device__ void emit_float_json(S &s, const DCol &c, int64_t r) {
+  if (c.repr == TFGPU_R_FLOAT32) dev::fmt_json_float(s, (double)((const float *)c.values)[r], 32);
+  else dev::fmt_json_float(s, ((const double *)c.values)[r], 64);
+}
+
+// The integer Go types as decimal text; returns false if the column is not an integer repr.
+template <class S> __device__ bool emit_int(S &s, const DCol &c, int64_t r) {
+  uint8_t t[24]; int n;
+  switch (c.repr) {
+    case TFGPU_R_INT8: n = dev::fmt_i64(t, ((const int8_t *)c.values)[r]); break;
+    case TFGPU_R_INT16: n = dev::fmt_i64(t, ((const int16_t *)c.values)[r]); break;
+    case TFGPU_R_INT32: n = dev::fmt_i64(t, ((const int32_t *)c.values)[r]); break;
+    case TFGPU_R_INT64: n = dev::fmt_i64(t, ((const int64_t *)c.values)[r]); break;
+    case TFGPU_R_UINT8: n = dev::fmt_u64(t, ((const uint8_t *)c.values)[r]); break;
+    case TFGPU_R_UINT16: n = dev::fmt_u64(t, ((const uint16_t *)c.values)[r]); break;
+    case TFGPU_R_UINT32: n = dev::fmt_u64(t, ((const uint32_t *)c.values)[r]); break;
+    case TFGPU_R_UINT64: n = dev::fmt_u64(t, ((const uint64_t *)c.values)[r]); break;
+    default: return false;
+  }
+  emit_small(s, t, n);
+  return true;
+}
+
+// json.Marshal of one Go value held in a column cell (the encoding/json serializer's values, and the elements of
+// Collapse's key arrays): nil → null, []byte → base64, time.Time → RFC 3339, json.Number / pre-marshalled `any` verbatim.
+template <class S> __device__ void emit_json_cell(S &s, const DCol &c, int64_t r, int any_as_string, bool html) {
+  if (!is_valid(c, r)) { put_lit(s, "null"); return; }
+  const uint8_t *vp = nullptr; uint32_t vn = 0;
+  if (c.offsets) { vp = c.data + c.offsets[r]; vn = c.offsets[r + 1] - c.offsets[r]; }
+  uint8_t t[64];
+  switch (c.repr) {
+    case TFGPU_R_BOOL: put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); return;
+    case TFGPU_R_STRING: emit_json_string(s, vp, vn, html); return;
+    case TFGPU_R_BYTES: s.put('"'); emit_base64(s, vp, vn); s.put('"'); return;
+    case TFGPU_R_JSONNUM: if (vn) put_bytes(s, vp, vn); else s.put('0'); return;
+    case TFGPU_R_TIME: { s.put('"'); int n = dev::fmt_rfc3339nano(t, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); emit_small(s, t, n); s.put('"'); return; }
+    case TFGPU_R_DURATION: { int n = dev::fmt_i64(t, ((const int64_t *)c.values)[r]); emit_small(s, t, n); return; }
+    case TFGPU_R_JSON:
+      if (c.dtype == TFGPU_T_ANY && any_as_string) emit_json_string(s, vp, vn, html);
+      else put_bytes(s, vp, vn);
+      return;
+    case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_json(s, c, r); return;
+    default: emit_int(s, c, r);
+  }
+}
+
+}  // namespace tf

@@ -290,8 +290,9 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
   b->ns = h->table_ns ? h->table_ns : "";
   b->table = h->table_name ? h->table_name : "";
   size_t n = (size_t)h->nrows;
-  for (int i = 0; i < h->ncols; i++) {
-    const tfgpu_column &c = h->cols[i];
+  for (int i = 0; i < h->ncols + h->n_old_keys; i++) {
+    const bool is_old = i >= h->ncols;
+    const tfgpu_column &c = is_old ? h->old_keys[i - h->ncols] : h->cols[i];
     DColumn d;
     d.name = c.name ? c.name : "";
     d.dtype = c.dtype; d.repr = c.repr;
@@ -308,9 +309,14 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
       if (c.repr == TFGPU_R_TIME && c.nanos) d.nanos = upload(c.nanos, n * 4);
     }
     if (c.validity) d.validity = upload(c.validity, (n + 7) / 8);
-    b->cols.push_back(std::move(d));
+    (is_old ? b->old_keys : b->cols).push_back(std::move(d));
   }
-  if (h->schema) for (int i = 0; i < h->schema->ncols; i++) b->schema.push_back({h->schema->cols[i].name ? h->schema->cols[i].name : "", h->schema->cols[i].dtype});
+  if (h->n_old_keys && h->old_keys_present) b->old_present = upload(h->old_keys_present, (n + 7) / 8);
+  if (h->schema) for (int i = 0; i < h->schema->ncols; i++) {
+    const tfgpu_colschema &sc = h->schema->cols[i];
+    b->schema.push_back({sc.name ? sc.name : "", sc.dtype});
+    if (sc.flags & TFGPU_COL_KEY) b->key_names.push_back(sc.name ? sc.name : "");
+  }
   if (h->kind) b->kind = upload(h->kind, n);
   if (h->src_row) b->src_row = upload(h->src_row, n * 4);
   if (h->part_id) b->part_id = upload(h->part_id, n * 4);
@@ -327,9 +333,9 @@ static thread_local ViewStore g_view;
 int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   TF_API_BEGIN
   if (!b || !v) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_view: null argument");
-  g_view.cols.assign(b->cols.size(), tfgpu_column{});
-  for (size_t i = 0; i < b->cols.size(); i++) {
-    const DColumn &d = b->cols[i];
+  g_view.cols.assign(b->cols.size() + b->old_keys.size(), tfgpu_column{});
+  for (size_t i = 0; i < b->cols.size() + b->old_keys.size(); i++) {
+    const DColumn &d = i < b->cols.size() ? b->cols[i] : b->old_keys[i - b->cols.size()];
     tfgpu_column &c = g_view.cols[i];
     c.name = d.name.c_str(); c.dtype = d.dtype; c.repr = d.repr;
     c.values = d.values ? d.values->p : nullptr;
@@ -341,6 +347,9 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   v->kind = ptr<uint8_t>(b->kind); v->src_row = ptr<int32_t>(b->src_row); v->part_id = ptr<uint32_t>(b->part_id);
   v->mem = TFGPU_MEM_DEVICE;
   v->schema = nullptr;
+  v->n_old_keys = (int32_t)b->old_keys.size();
+  v->old_keys = b->old_keys.empty() ? nullptr : g_view.cols.data() + b->cols.size();
+  v->old_keys_present = ptr<uint8_t>(b->old_present);
   return TFGPU_OK;
   TF_API_END
 }
@@ -349,11 +358,12 @@ int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
   TF_API_BEGIN
   if (!b || !h) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: null argument");
   if (h->ncols != (int32_t)b->cols.size() || h->nrows != b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: shape mismatch");
+  if (h->n_old_keys && h->n_old_keys != (int32_t)b->old_keys.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: old-key shape mismatch");
   std::lock_guard<std::mutex> lk(ctx().mu);
   size_t n = (size_t)b->nrows;
-  for (size_t i = 0; i < b->cols.size(); i++) {
-    const DColumn &d = b->cols[i];
-    tfgpu_column &c = h->cols[i];
+  for (size_t i = 0; i < b->cols.size() + (size_t)h->n_old_keys; i++) {
+    const DColumn &d = i < b->cols.size() ? b->cols[i] : b->old_keys[i - b->cols.size()];
+    tfgpu_column &c = i < b->cols.size() ? h->cols[i] : h->old_keys[i - b->cols.size()];
     if (repr_is_var(d.repr)) {
       if (c.offsets && d.offsets) d2h(c.offsets, d.offsets->p, (n + 1) * 4);
       if (c.data && d.data) d2h(c.data, d.data->p, d.data_len);
@@ -366,6 +376,7 @@ int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
   if (h->kind && b->kind) d2h(h->kind, b->kind->p, n);
   if (h->src_row && b->src_row) d2h(h->src_row, b->src_row->p, n * 4);
   if (h->part_id && b->part_id) d2h(h->part_id, b->part_id->p, n * 4);
+  if (h->old_keys_present && b->old_present) d2h(h->old_keys_present, b->old_present->p, (n + 7) / 8);
   tf::sync();
   return TFGPU_OK;
   TF_API_END

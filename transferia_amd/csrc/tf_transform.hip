@@ -485,11 +485,17 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   unsigned g = grid_for(m, 256);
   KernelTimer t("compact_gather");
   std::vector<GFix> fx; std::vector<GVar> vr; std::vector<size_t> var_cols; std::vector<GBit> bits;
+  // ColumnValues and OldKeys columns move the same way; `all` lists them in that order
+  const size_t ncur = in.cols.size(), nall = ncur + in.old_keys.size();
+  auto col_at = [&](size_t i) -> const DColumn & { return i < ncur ? in.cols[i] : in.old_keys[i - ncur]; };
+  out->cols.reserve(ncur); out->old_keys.reserve(in.old_keys.size());
+  out->key_names = in.key_names;
   int nvar = 0;
-  for (auto &c : in.cols) if (repr_is_var(c.repr)) nvar++;
+  for (size_t i = 0; i < nall; i++) if (repr_is_var(col_at(i).repr)) nvar++;
   const int64_t seg_stride = ((m + 1 + 3) / 4) * 4;
   Buf lens_all = nvar ? dalloc((size_t)nvar * (size_t)seg_stride * 4 + 16) : nullptr;
-  for (auto &c : in.cols) {
+  for (size_t ai = 0; ai < nall; ai++) {
+    const DColumn &c = col_at(ai);
     DColumn o;
     o.name = c.name; o.dtype = c.dtype; o.repr = c.repr;
     if (repr_is_var(c.repr)) {
@@ -498,7 +504,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       o.data = dalloc(c.data_len + 8);  // the source size bounds the kept payload; exact length read back below
       o.data_len = c.data_len;
       vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.data), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data)});
-      var_cols.push_back(out->cols.size());
+      var_cols.push_back(ai);
     } else {
       size_t w = repr_width(c.repr);
       o.values = dalloc((size_t)m * w);
@@ -506,8 +512,10 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       if (c.nanos) { o.nanos = dalloc((size_t)m * 4); fx.push_back(GFix{c.nanos->p, o.nanos->p, 4, 0}); }
     }
     if (c.validity) { o.validity = dalloc((size_t)(m + 7) / 8 + 1); bits.push_back(GBit{ptr<uint8_t>(c.validity), ptr<uint8_t>(o.validity)}); }
-    out->cols.push_back(std::move(o));
+    (ai < ncur ? out->cols : out->old_keys).push_back(std::move(o));
   }
+  auto out_at = [&](size_t i) -> DColumn & { return i < ncur ? out->cols[i] : out->old_keys[i - ncur]; };
+  if (in.old_present) { out->old_present = dalloc((size_t)(m + 7) / 8 + 1); bits.push_back(GBit{ptr<uint8_t>(in.old_present), ptr<uint8_t>(out->old_present)}); }
   if (in.kind) { out->kind = dalloc((size_t)m); fx.push_back(GFix{in.kind->p, out->kind->p, 1, 0}); }
   if (in.part_id) { out->part_id = dalloc((size_t)m * 4); fx.push_back(GFix{in.part_id->p, out->part_id->p, 4, 0}); }
   out->src_row = dalloc((size_t)m * 4);
@@ -525,7 +533,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), m, nvar, seg_stride);
     if (m) {  // long cells: short runs of rows; short cells: long runs (the fixed latency of a run needs bytes to amortise over)
       std::vector<GVar> lng, sht;
-      for (size_t i = 0; i < vr.size(); i++) ((in.cols[var_cols[i]].data_len >= (uint64_t)in.nrows * 8) ? lng : sht).push_back(vr[i]);
+      for (size_t i = 0; i < vr.size(); i++) ((col_at(var_cols[i]).data_len >= (uint64_t)in.nrows * 8) ? lng : sht).push_back(vr[i]);
       Buf blng = upload_small(lng.data(), lng.size() * sizeof(GVar)), bsht = upload_small(sht.data(), sht.size() * sizeof(GVar));
       if (!lng.empty()) gather_bytes_all<1><<<dim3(grid_for(m, 256), (unsigned)lng.size()), 256, 0, st>>>(ptr<GVar>(blng), sp, m);
       if (!sht.empty()) gather_bytes_cells<<<dim3(grid_for(m, 256), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
@@ -534,10 +542,12 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
     collect_totals<<<1, 64, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, m, nvar, ptr<uint32_t>(tot));
     const uint32_t *h = d2h_u32(tot->p, (size_t)nvar);
     sync();
-    for (int i = 0; i < nvar; i++) out->cols[var_cols[(size_t)i]].data_len = h[i];
+    for (int i = 0; i < nvar; i++) out_at(var_cols[(size_t)i]).data_len = h[i];
   }
   return out;
 }
+
+std::unique_ptr<tfgpu_dbatch> gather_rows(const tfgpu_dbatch &in, const Buf &sel, int64_t m) { return gather_batch(in, sel, m); }  // for tf_collapse.hip
 
 // keep flags (uint32 0/1, n+1 slots) → compacted batch; identity if all kept
 static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /* n+1 u32 */) {
@@ -806,6 +816,8 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_columns(const tfgpu_plan &p, c
   for (auto &c : in.cols) if (p.columns.match(c.name)) out->cols.push_back(c);
   out->schema.clear();
   for (auto &sc : in.schema) if (p.columns.match(sc.first)) out->schema.push_back(sc);
+  out->old_keys.clear();  // trimChangeItem also trims OldKeys (filter_columns_transformer.go:187-213)
+  for (auto &c : in.old_keys) if (p.columns.match(c.name)) out->old_keys.push_back(c);
   return out;
 }
 

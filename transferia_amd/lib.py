@@ -27,7 +27,7 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_collapse", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -77,6 +77,7 @@ def load():
     L.tfgpu_dbatch_free.argtypes = [P]
     L.tfgpu_dbatch_free.restype = None
     L.tfgpu_apply.argtypes = [C.POINTER(P), C.c_int, P, C.POINTER(P), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_collapse.argtypes = [P, C.POINTER(P)]
     L.tfgpu_partition.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
     L.tfgpu_csv_options_default.argtypes = [C.POINTER(abi.CCsvOptions)]
     L.tfgpu_csv_options_default.restype = None
@@ -185,9 +186,10 @@ class DeviceBatch:
     def download(self) -> abi.Batch:
         v = self.view()
         n = int(v.nrows)
-        cols, carr, keep = [], (abi.CColumn * max(v.ncols, 1))(), []
-        for i in range(v.ncols):
-            c = v.cols[i]
+        nold = int(v.n_old_keys)
+        cols, carr, keep = [], (abi.CColumn * max(v.ncols + nold, 1))(), []
+        for i in range(v.ncols + nold):
+            c = v.cols[i] if i < v.ncols else v.old_keys[i - v.ncols]
             col = abi.Column(c.name.decode(), abi.DTYPES[c.dtype], int(c.repr))
             carr[i].name, carr[i].dtype, carr[i].repr = c.name, c.dtype, c.repr
             if c.repr in abi.VAR_REPRS:
@@ -208,6 +210,12 @@ class DeviceBatch:
             cols.append(col)
         hb = abi.CBatch()
         hb.nrows, hb.ncols, hb.cols, hb.mem = n, v.ncols, carr, abi.MEM_HOST
+        opres = None
+        if nold:
+            hb.n_old_keys = nold
+            hb.old_keys = C.cast(C.byref(carr, C.sizeof(abi.CColumn) * v.ncols), C.POINTER(abi.CColumn))
+            if v.old_keys_present:
+                opres = np.zeros((n + 7) // 8 + 1, np.uint8); hb.old_keys_present = opres.ctypes.data
         kind = src = part = None
         if v.kind:
             kind = np.zeros(max(n, 1), np.uint8); hb.kind = kind.ctypes.data
@@ -225,7 +233,10 @@ class DeviceBatch:
                     col.nanos = col.nanos[:n]
             if hasattr(col, "_bm"):
                 col.validity = abi.unpack_validity(col._bm, n)
-        b = abi.Batch(cols, n, (v.table_ns or b"").decode(), (v.table_name or b"").decode())
+        b = abi.Batch(cols[: v.ncols], n, (v.table_ns or b"").decode(), (v.table_name or b"").decode())
+        if nold:
+            b.old_keys = cols[v.ncols:]
+            b.old_present = abi.unpack_validity(opres, n) if opres is not None else np.ones(n, bool)
         b.kind = kind[:n] if kind is not None else None
         # src_row NULL = identity (include/tfgpu.h): no row was dropped or reordered
         b.src_row = src[:n] if src is not None else np.arange(n, dtype=np.int32)
@@ -378,6 +389,14 @@ def apply_chain(transformers: Sequence[Transformer], batch: DeviceBatch, max_err
     el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
           for i in range(min(int(nerr.value), max_errors))]
     return TransformerResult(DeviceBatch(out), el)
+
+
+def collapse(batch: DeviceBatch) -> DeviceBatch:
+    """abstract.Collapse (pkg/abstract/changeitem/change_item_collapse.go:48-134) on device."""
+    init()
+    out = C.c_void_p()
+    _check(load().tfgpu_collapse(batch._h, C.byref(out)))
+    return DeviceBatch(out)
 
 
 def partition(batch: DeviceBatch, nparts: int):
