@@ -162,9 +162,57 @@ def json_main(args):
         "row_errors": state["errors"], "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
 
 
+def collapse_main(args):
+    """--workload collapse: abstract.Collapse (the PK-keyed dedup of BASELINE.json configs[4]) as a SIDE benchmark: a CDC
+    slice (workload.cdc_batch) resident in HBM → tfgpu_collapse; the oracle's restatement of the Go maps as cpu_baseline."""
+    from transferia_amd import lib, workload
+    lib.init(0)
+    b, schema = workload.cdc_batch(args.rows)
+    db = lib.DeviceBatch.upload(b)
+    state = {}
+
+    def step(keep=False):
+        out = lib.collapse(db)
+        if keep:
+            state.update(out_rows=out.nrows)
+        out.free()
+
+    for _ in range(args.warmup):
+        step()
+    step(keep=True)
+    lib.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    lib.synchronize()
+    dt = time.perf_counter() - t0
+    lib.prof_reset(); lib.prof_enable(True)
+    for _ in range(3):
+        step()
+    lib.prof_enable(False)
+    kernels = {n: {"launches_per_step": l / 3, "avg_ms": round(ms / l, 4), "ms_per_step": round(ms / 3, 4)} for n, l, ms in lib.prof_get() if l}
+    cpu = None
+    if args.cpu_rows > 0:
+        from oracle import oracle as ora
+        k = min(max(args.cpu_rows, 1 << 18), args.rows)
+        b2, s2 = workload.cdc_batch(k)
+        r1 = ora.collapse(b2, s2)
+        cpu = {"value": round(k / r1.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"a {k}-row slice of the same stream through the oracle's Collapse ({r1.seconds:.2f}s), single thread",
+               "note": "C restatement of the Go reference (json.Marshal key strings, string-keyed maps, boxed values), not the Go binary"}
+    print(json.dumps({
+        "metric": "ChangeItems/sec through abstract.Collapse (PK-keyed dedup of a CDC batch)", "value": round(args.rows * args.steps / dt, 1),
+        "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys, 60% of U/D with OldKeys, 15% of those change the PK) -> Collapse",
+                   "rows_per_step": args.rows, "rows_out_per_step": state["out_rows"]},
+        "roofline": None, "cpu_baseline": cpu, "kernels": kernels}))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["csv", "json"], default="csv", help="csv = BASELINE.json configs[1] (the bench line); json = configs[2] shape, side benchmark")
+    ap.add_argument("--workload", choices=["csv", "json", "collapse"], default="csv",
+                    help="csv = BASELINE.json configs[1] (the bench line); json = configs[2] shape, collapse = configs[4]'s dedup: side benchmarks")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -178,6 +226,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "json":
         return json_main(args)
+    if args.workload == "collapse":
+        return collapse_main(args)
 
     import torch
     from transferia_amd import dist as tdist

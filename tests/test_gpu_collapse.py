@@ -99,3 +99,16 @@ def test_passthrough_and_errors(tf, oracle):
                              "", "t", ["insert", "update", "update", "update"])
     ok.schema = sch
     check(tf, oracle, ok, sch, "float keys")  # 1.5 merges; -0 and 0 print differently ("-0" / "0"): two keys
+
+
+def test_cdc_workload(tf, oracle):
+    """bench.py --workload collapse's stream at 2^18 rows: bit-identical to the oracle, columns compared as arrays."""
+    from transferia_amd import workload
+    from test_gpu_transformers import assert_batches_equal
+    b, schema = workload.cdc_batch(1 << 18)
+    got = tf.collapse(tf.DeviceBatch.upload(b)).download()
+    ref = oracle.collapse(b, schema).batch
+    assert_batches_equal(got, ref, "cdc")
+    assert np.array_equal(got.kind, ref.kind) and np.array_equal(got.src_row, ref.src_row)
+    assert np.array_equal(got.old_present, ref.old_present)
+    assert np.array_equal(got.old_keys[0].values[got.old_present], ref.old_keys[0].values[ref.old_present])

@@ -240,7 +240,6 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   names.erase(std::unique(names.begin(), names.end()), names.end());
   if (names.empty()) return same();
 
-  KernelTimer timer("collapse");
   std::vector<KCol> kc(names.size());
   for (size_t k = 0; k < names.size(); k++) {
     std::memset(&kc[k], 0, sizeof(KCol));
@@ -255,6 +254,7 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   Buf hashes = dalloc((size_t)n2 * 16), keyid = dalloc((size_t)n2 * 4), bad = dalloc_zero(4);
   Buf owner = dalloc((size_t)cap * 4), parent = dalloc((size_t)cap * 4), rows_m = dalloc((size_t)cap * 4), rows_v = dalloc((size_t)cap * 4),
       k2idx = dalloc((size_t)cap * 4), del_i = dalloc((size_t)cap * 4), del_o = dalloc((size_t)cap * 4);
+  std::unique_ptr<KernelTimer> timer = std::make_unique<KernelTimer>("collapse_keys");
   collapse_init<<<cgrid(cap), 256, 0, st>>>(ptr<uint32_t>(parent), ptr<int32_t>(rows_m), ptr<int32_t>(del_i), ptr<uint32_t>(owner), cap);
   HashParams hp{};
   hp.keys = ptr<KCol>(bkc); hp.nkeys = (int32_t)kc.size(); hp.n = n;
@@ -265,29 +265,35 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   collapse_link<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent));
   Buf root = dalloc((size_t)n * 4), idx = dalloc((size_t)n * 4), sroot = dalloc((size_t)n * 4), sidx = dalloc((size_t)n * 4);
   collapse_roots<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent), ptr<uint32_t>(root), ptr<uint32_t>(idx));
+  timer.reset(); timer = std::make_unique<KernelTimer>("collapse_sort");
   {
     size_t tmp_bytes = 0;
     TF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, ptr<uint32_t>(root), ptr<uint32_t>(sroot), ptr<uint32_t>(idx), ptr<uint32_t>(sidx), (size_t)n, 0u, (unsigned)bits, st));
     Buf tmp = dalloc(tmp_bytes + 16);
     TF_HIP(rocprim::radix_sort_pairs(tmp->p, tmp_bytes, ptr<uint32_t>(root), ptr<uint32_t>(sroot), ptr<uint32_t>(idx), ptr<uint32_t>(sidx), (size_t)n, 0u, (unsigned)bits, st));
   }
+  timer.reset(); timer = std::make_unique<KernelTimer>("collapse_walk");
   Buf ak = dalloc((size_t)n * 4);
   WalkParams wp{};
   wp.n = n; wp.sroot = ptr<uint32_t>(sroot); wp.sidx = ptr<uint32_t>(sidx); wp.keyid = ptr<uint32_t>(keyid); wp.kind = ptr<uint8_t>(in.kind);
   wp.rows_m = ptr<int32_t>(rows_m); wp.rows_v = ptr<int32_t>(rows_v); wp.k2idx = ptr<int32_t>(k2idx); wp.del_i = ptr<int32_t>(del_i); wp.del_o = ptr<int32_t>(del_o);
   wp.ak = ptr<uint32_t>(ak);
   collapse_walk<<<cgrid(n), 256, 0, st>>>(wp);
+  timer.reset(); timer = std::make_unique<KernelTimer>("collapse_select");
   Buf f = dalloc((size_t)(3 * n + 1) * 4 + 16);
   collapse_flags<<<cgrid(n), 256, 0, st>>>(n, ptr<uint8_t>(in.kind), ptr<uint32_t>(ak), ptr<int32_t>(rows_m), ptr<int32_t>(k2idx), ptr<int32_t>(del_i), ptr<uint32_t>(f));
   exclusive_scan_u32(ptr<uint32_t>(f), ptr<uint32_t>(f), 3 * n, true);
   const uint32_t *hm = d2h_u32(ptr<uint32_t>(f) + 3 * n);
   const uint32_t *hbad = d2h_u32(bad->p);
+  timer.reset();
   sync();
   if (*hbad) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: NaN / Inf in a primary-key column (json.Marshal fails on the key; the reference files every such row under the empty key)");
   const int64_t m = *hm;
   Buf sel_meta = dalloc((size_t)m * 4 + 4), sel_val = dalloc((size_t)m * 4 + 4), sel_old = dalloc((size_t)m * 4 + 4);
+  timer = std::make_unique<KernelTimer>("collapse_select");
   collapse_select<<<cgrid(n), 256, 0, st>>>(n, ptr<uint8_t>(in.kind), ptr<uint32_t>(ak), ptr<int32_t>(rows_m), ptr<int32_t>(rows_v), ptr<int32_t>(del_o), ptr<uint32_t>(f),
                                             ptr<int32_t>(sel_meta), ptr<int32_t>(sel_val), ptr<int32_t>(sel_old));
+  timer.reset();
   // ColumnValues from the last writer; Kind / PartID / position from the first item; OldKeys from the first item (or,
   // for a Delete, from the row it removed)
   tfgpu_dbatch vals_in = in;

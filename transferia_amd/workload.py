@@ -132,3 +132,30 @@ class HitsStream:
 
 def hits_csv_options(header: bool = True) -> abi.CCsvOptions:
     return abi.csv_options(skip_rows=1 if header else 0)
+
+
+def cdc_batch(nrows: int, keys: int = 0, seed: int = SEED, p_old: float = 0.6, p_pk_change: float = 0.15):
+    """A CDC stream slice for abstract.Collapse (BASELINE.json configs[4]: debezium stream → hash-partition → dedup):
+    (Batch, Schema) of `nrows` row events over `keys` primary keys (default nrows / 4: chains of ~4 events per key),
+    35 % inserts, 45 % updates, 20 % deletes; Update / Delete rows carry OldKeys with probability p_old and
+    p_pk_change of those change the primary key.  Columns: id int64 (PK), ver int64, payload utf8 (24 bytes), ts int64."""
+    rng = np.random.default_rng(seed)
+    keys = keys or max(nrows // 4, 1)
+    schema = abi.Schema([abi.ColSchema("id", "int64", True, "", ""), abi.ColSchema("ver", "int64", False, "", ""),
+                         abi.ColSchema("payload", "utf8", False, "", ""), abi.ColSchema("ts", "int64", False, "", "")])
+    ids = rng.integers(0, keys, size=nrows, dtype=np.int64)
+    kind = rng.choice(np.array([abi.K_INSERT, abi.K_UPDATE, abi.K_DELETE], dtype=np.uint8), size=nrows, p=[0.35, 0.45, 0.20])
+    pay = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)[rng.integers(0, 16, size=(nrows, 24))].reshape(-1)
+    cols = [abi.Column("id", "int64", abi.R_INT64, values=ids), abi.Column("ver", "int64", abi.R_INT64, values=np.arange(nrows, dtype=np.int64)),
+            abi.Column("payload", "utf8", abi.R_STRING, offsets=(np.arange(nrows + 1, dtype=np.uint32) * 24), data=np.ascontiguousarray(pay)),
+            abi.Column("ts", "int64", abi.R_INT64, values=1_700_000_000_000 + np.arange(nrows, dtype=np.int64))]
+    b = abi.Batch(cols, nrows, "public", "events", kind=kind)
+    b.schema = schema
+    present = (kind != abi.K_INSERT) & (rng.random(nrows) < p_old)
+    old = ids.copy()
+    change = present & (rng.random(nrows) < p_pk_change)
+    old[change] = rng.integers(0, keys, size=int(change.sum()), dtype=np.int64)
+    old[~present] = 0
+    b.old_keys = [abi.Column("id", "int64", abi.R_INT64, values=old, validity=present.copy())]
+    b.old_present = present
+    return b, schema
