@@ -267,6 +267,14 @@ int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tf
  * their json.Marshal text.  TFGPU_ERR_UNSUPPORTED: NaN / Inf in a float key column, more than 2^29 rows.             */
 int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out);
 
+/* ChangeItem.KeysChanged (pkg/abstract/changeitem/change_item.go:237-286) for every row: changed[r] = 1 iff row r is an
+ * Update and, for some PrimaryKey column of the TableSchema, reflect.DeepEqual(old value, new value) is false — old from
+ * OldKeys by name (nil when the row has none), new from ColumnValues by name (nil when absent); values of different Go
+ * types are never equal, NaN differs from NaN.  `changed` is a HOST array of nrows bytes.  This is the per-row test of
+ * abstract.SplitUpdatedPKeys (utils.go:75-128): the shim cuts the batch at the flagged rows and turns each of them into
+ * its (Delete by OldKeys, Insert) pair before Collapse (clickhouse_local.go:108, ydb/sink.go:732, yt/sink/sink.go:379). */
+int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed /* [nrows] */, int64_t *nchanged /* optional */);
+
 /* Hash-partition, local half (BASELINE.json configs[4]: debezium stream → hash-partition → dedup → Kafka sink on 8 GPUs).
  * Rows are regrouped by part_id — what sharder_transformer wrote: PartID = itoa(CRC32_IEEE(join(SerializeToString(cols), "."))
  * % shards), sharder.go:130-145 — parts 0..nparts-1 in order, original row order kept inside a part; counts[d] = rows of

@@ -187,6 +187,9 @@ uint64_t ora_fastfloat_parse_uint64_best_effort(const char *s, size_t n);
 char *ora_serialize(int format, const ora_batch *b, uint64_t *len);
 /* ---- a24: abstract.Collapse (change_item_collapse.go:48-134); consumes nothing, returns a new batch ---- */
 ora_batch *ora_collapse(const ora_batch *in);
+int ora_item_keys_changed(const ora_item *c);               /* ChangeItem.KeysChanged, change_item.go:237-286 */
+void ora_keys_changed(const ora_batch *b, uint8_t *out);    /* per item */
+ora_batch *ora_split_updated_pkeys(const ora_batch *in, int64_t **lens_out, int64_t *nlists); /* utils.go:75-128 */
 ora_batch *ora_batch_from_json(const char *text);  /* row-wise test input (items with differing ColumnNames) */
 int ora_batch_item_info(const ora_batch *b, int64_t row, int *kind, int *nvalues, int *n_old, int64_t *src_row);
 const char *ora_batch_item_name(const ora_batch *b, int64_t row, int col, int old);

@@ -518,6 +518,63 @@ ora_batch *ora_collapse(const ora_batch *in) {
   return out;
 }
 
+/* ---- ChangeItem.KeysChanged (change_item.go:237-286) and SplitUpdatedPKeys (utils.go:75-128) ---- */
+static int value_deep_equal(const ora_value *a, const ora_value *b) {  /* reflect.DeepEqual of two boxed scalars */
+  const int an = !a || a->kind == OV_NIL, bn = !b || b->kind == OV_NIL;
+  if (an || bn) return an && bn;
+  if (a->kind != b->kind) return 0;  /* different dynamic types */
+  switch (a->kind) {
+    case OV_STRING: case OV_BYTES: case OV_JSONNUM: case OV_JSON: return a->slen == b->slen && !memcmp(a->s, b->s, a->slen);
+    case OV_F64: return a->v.f64 == b->v.f64;
+    case OV_F32: return a->v.f32 == b->v.f32;
+    case OV_BOOL: return !a->v.b == !b->v.b;
+    case OV_TIME: return a->v.t.sec == b->v.t.sec && a->v.t.nsec == b->v.t.nsec;
+    default: return a->v.u == b->v.u;
+  }
+}
+int ora_item_keys_changed(const ora_item *c) {
+  if (c->kind != TFGPU_K_UPDATE) return 0;
+  /* the len(KeyNames) != len(KeyValues) / len(ColumnNames) != len(ColumnValues) guards cannot fail in this row model */
+  const ora_schema *sc = c->schema;
+  for (int i = 0; sc && i < sc->ncols; i++) {
+    if (!sc->cols[i].key) continue;
+    const ora_value *ov = NULL, *nv = NULL;
+    for (int j = 0; j < c->n_old; j++) if (!strcmp(c->old_names->names[j], sc->cols[i].name)) { ov = &c->old_values[j]; break; }
+    for (int j = 0; c->names && j < c->names->n && j < c->nvalues; j++) if (!strcmp(c->names->names[j], sc->cols[i].name)) { nv = &c->values[j]; break; }
+    if (!value_deep_equal(ov, nv)) return 1;
+  }
+  return 0;
+}
+void ora_keys_changed(const ora_batch *b, uint8_t *out) { for (int64_t i = 0; i < b->n; i++) out[i] = (uint8_t)ora_item_keys_changed(&b->items[i]); }
+/* All sublists back to back in one batch; lens[k] = length of sublist k (caller frees with free()); returns the count */
+ora_batch *ora_split_updated_pkeys(const ora_batch *in, int64_t **lens_out, int64_t *nlists) {
+  ora_batch *out = ora_batch_new();
+  int64_t *lens = (int64_t *)calloc((size_t)(2 * in->n + 2), sizeof(int64_t)), nl = 0, cur = 0;
+  for (int64_t i = 0; i < in->n; i++) {
+    const ora_item *c = &in->items[i];
+    if (!ora_item_keys_changed(c)) { item_clone(ora_batch_push(out), c); cur++; continue; }
+    if (cur > 0) { lens[nl++] = cur; cur = 0; }
+    ora_item *d = ora_batch_push(out);  /* Delete: OldKeys kept, ColumnNames / ColumnValues nil */
+    item_clone(d, c);
+    d->kind = TFGPU_K_DELETE;
+    for (int q = 0; q < d->nvalues; q++) ora_value_free(&d->values[q]);
+    d->nvalues = 0;
+    if (d->names && --d->names->refs == 0) { for (int q = 0; q < d->names->n; q++) free(d->names->names[q]); free(d->names->names); free(d->names); }
+    d->names = (ora_names *)calloc(1, sizeof(ora_names)); d->names->refs = 1; d->names->names = (char **)calloc(1, sizeof(char *));
+    ora_item *n = ora_batch_push(out);  /* Insert: values kept, OldKeys = EmptyOldKeys() */
+    item_clone(n, c);
+    n->kind = TFGPU_K_INSERT;
+    for (int q = 0; q < n->n_old; q++) ora_value_free(&n->old_values[q]);
+    free(n->old_values); n->old_values = NULL; n->n_old = 0;
+    if (n->old_names && --n->old_names->refs == 0) { for (int q = 0; q < n->old_names->n; q++) free(n->old_names->names[q]); free(n->old_names->names); free(n->old_names); }
+    n->old_names = NULL;
+    lens[nl++] = 2;
+  }
+  if (cur > 0) lens[nl++] = cur;
+  *lens_out = lens; *nlists = nl;
+  return out;
+}
+
 /* ---- row-wise test I/O for Collapse: items whose ColumnNames differ (TOAST updates) have no columnar form ---- */
 #include "ora_json.h"
 static ora_value value_from_json(const jnode *pair) {  /* ["gotype", value] */

@@ -99,6 +99,9 @@ def lib():
     L.ora_batch_old_value.argtypes = [P, C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
     L.ora_batch_len.restype = C.c_int64
     L.ora_batch_len.argtypes = [P]
+    L.ora_keys_changed.argtypes = [P, P]
+    L.ora_split_updated_pkeys.restype = P
+    L.ora_split_updated_pkeys.argtypes = [P, C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]
     L.free = C.CDLL(None).free
     L.free.argtypes = [C.c_void_p]
     _LIB = L
@@ -369,12 +372,7 @@ def collapse(batch: abi.Batch, schema: abi.Schema) -> Result:
     return _finish(L, out, dt)
 
 
-def collapse_rows(items):
-    """abstract.Collapse over row-wise items (dicts: kind, keys, names, values, old_names, old_values — values are
-    [gotype, value] pairs), for inputs whose ColumnNames differ between items.  Returns the result items row-wise."""
-    L = lib()
-    b = L.ora_batch_from_json(json.dumps({"items": items}).encode("utf-8"))
-    out = L.ora_collapse(b)
+def _items_of(L, out):
     res = []
     kind, nv, no, src = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
     for r in range(L.ora_batch_len(out)):
@@ -386,8 +384,56 @@ def collapse_rows(items):
         for c in range(no.value):
             L.ora_batch_old_value(out, r, c, C.byref(k2), C.byref(i64), C.byref(s), C.byref(sl))
             nm = _OV_NAMES[k2.value]
-            olds.append([L.ora_batch_item_name(out, r, c, 1).decode(), [nm, C.string_at(s, sl.value) if nm in ("string", "bytes") else (None if nm == "nil" else i64.value)]])
+            olds.append([L.ora_batch_item_name(out, r, c, 1).decode(), [nm, C.string_at(s, sl.value) if nm in ("string", "bytes", "json") else (None if nm == "nil" else i64.value)]])
         res.append({"kind": ["insert", "update", "delete", "other"][kind.value], "names": names, "values": vals, "old": olds, "src": int(src.value)})
+    return res
+
+
+def keys_changed_rows(items):
+    """ChangeItem.KeysChanged of each row-wise item."""
+    L = lib()
+    b = L.ora_batch_from_json(json.dumps({"items": items}).encode("utf-8"))
+    n = L.ora_batch_len(b)
+    buf = (C.c_uint8 * max(n, 1))()
+    L.ora_keys_changed(b, buf)
+    L.ora_batch_free(b)
+    return [bool(buf[i]) for i in range(n)]
+
+
+def keys_changed(batch: abi.Batch, schema: abi.Schema):
+    L = lib()
+    cb, cs = batch.to_c(), schema.to_c()
+    cur = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    buf = (C.c_uint8 * max(batch.nrows, 1))()
+    L.ora_keys_changed(cur, buf)
+    L.ora_batch_free(cur)
+    return np.frombuffer(buf, dtype=np.uint8, count=batch.nrows).astype(bool)
+
+
+def split_updated_pkeys_rows(items):
+    """abstract.SplitUpdatedPKeys over row-wise items: a list of sublists of result items."""
+    L = lib()
+    b = L.ora_batch_from_json(json.dumps({"items": items}).encode("utf-8"))
+    lens, nl = C.POINTER(C.c_int64)(), C.c_int64(0)
+    out = L.ora_split_updated_pkeys(b, C.byref(lens), C.byref(nl))
+    flat = _items_of(L, out)
+    res, a = [], 0
+    for k in range(nl.value):
+        res.append(flat[a:a + lens[k]])
+        a += lens[k]
+    L.free(lens)
+    L.ora_batch_free(out)
+    L.ora_batch_free(b)
+    return res
+
+
+def collapse_rows(items):
+    """abstract.Collapse over row-wise items (dicts: kind, keys, names, values, old_names, old_values — values are
+    [gotype, value] pairs), for inputs whose ColumnNames differ between items.  Returns the result items row-wise."""
+    L = lib()
+    b = L.ora_batch_from_json(json.dumps({"items": items}).encode("utf-8"))
+    out = L.ora_collapse(b)
+    res = _items_of(L, out)
     L.ora_batch_free(out)
     L.ora_batch_free(b)
     return res

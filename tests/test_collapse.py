@@ -96,3 +96,42 @@ def test_columnar_equals_rowwise():
         assert (c[3] is None) == (not r["old"])
         if c[3] is not None:
             assert [tuple(v[1]) for v in r["old"]] == [tuple(x) for x in c[3]]
+
+
+# ---- ChangeItem.KeysChanged / SplitUpdatedPKeys ---------------------------------------------------------------------
+KC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "keys_changed.json"), encoding="utf-8"))
+
+
+def test_keys_changed_reference_cases():
+    items = [c["item"] for c in KC["keys_changed"]]
+    for c in KC["keys_changed"]:
+        assert oracle.keys_changed_rows([c["item"]]) == [c["changed"]], c["ref"]
+    # the second half of every MySQL-ported case: a TableSchema with one more non-key column changes nothing
+    assert len(items) == 14
+
+
+def test_split_updated_pkeys_reference_case():
+    sp = KC["split"]
+    got = oracle.split_updated_pkeys_rows(sp["items"])
+    assert len(got) == len(sp["expected"])
+    for gl, el in zip(got, sp["expected"]):
+        assert len(gl) == len(el)
+        for g, e in zip(gl, el):
+            assert g["kind"] == e["kind"] and g["names"] == e["names"]
+            assert g["values"] == [_norm(v) for v in e["values"]]
+            assert [[n, v] for n, v in g["old"]] == [[n, _norm(v)] for n, v in zip(e.get("old_names", []), e.get("old_values", []))]
+
+
+def test_keys_changed_columnar_equals_rowwise():
+    b, schema = random_batch(11, 80, domain=3, two_keys=True, nstrs=9, null_keys=0.2)
+    items = []
+    for i in range(b.nrows):
+        it = {"kind": ["insert", "update", "delete", "other"][int(b.kind[i])], "keys": ["id", "k2"], "names": [c.name for c in b.cols],
+              "values": [[g, (x.decode("utf-8") if isinstance(x, bytes) else x)] for g, x in (c.pyvalue(i) for c in b.cols)]}
+        if b.old_present[i]:
+            it["old_names"] = [c.name for c in b.old_keys]
+            it["old_values"] = [[g, (x.decode("utf-8") if isinstance(x, bytes) else x)] for g, x in (c.pyvalue(i) for c in b.old_keys)]
+        items.append(it)
+    col = oracle.keys_changed(b, schema)
+    assert list(col) == oracle.keys_changed_rows(items)
+    assert 0 < col.sum() < b.nrows

@@ -112,3 +112,54 @@ def test_cdc_workload(tf, oracle):
     assert np.array_equal(got.kind, ref.kind) and np.array_equal(got.src_row, ref.src_row)
     assert np.array_equal(got.old_present, ref.old_present)
     assert np.array_equal(got.old_keys[0].values[got.old_present], ref.old_keys[0].values[ref.old_present])
+
+
+def _one_item_batch(item):
+    dt = {"int": "int64", "string": "utf8"}
+    names = item["names"]
+    schema = abi.Schema([abi.ColSchema(nm, dt[item["values"][i][0]], nm in item["keys"], "", "") for i, nm in enumerate(names)])
+    b = abi.batch_from_rows(schema, names, [item["values"]], "", "t", [item["kind"]])
+    b.schema = schema
+    if item.get("old_names"):
+        osch = abi.Schema([abi.ColSchema(nm, dt[item["old_values"][i][0]], False, "", "") for i, nm in enumerate(item["old_names"])])
+        b.old_keys = abi.batch_from_rows(osch, item["old_names"], [item["old_values"]]).cols
+        b.old_present = np.array([True])
+    return b, schema
+
+
+def test_keys_changed(tf, oracle):
+    """tfgpu_keys_changed = ChangeItem.KeysChanged: the reference's TestPkeyChange cases, then random batches against
+    the oracle, then the SplitUpdatedPKeys cut plan against the oracle's sublists."""
+    from test_collapse import KC
+    for c in KC["keys_changed"]:
+        b, _ = _one_item_batch(c["item"])
+        assert list(tf.keys_changed(tf.DeviceBatch.upload(b))) == [c["changed"]], c["ref"]
+    for seed, kw in enumerate([dict(n=500, domain=4), dict(n=500, domain=3, two_keys=True, null_keys=0.2), dict(n=300, p_old=0.0),
+                               dict(n=300, two_keys=True, bytes_key=True), dict(n=5000, domain=50, two_keys=True)]):
+        b, schema = random_batch(400 + seed, **kw)
+        db = tf.DeviceBatch.upload(b)
+        want = oracle.keys_changed(b, schema)
+        assert np.array_equal(tf.keys_changed(db), want), kw
+        plan = tf.split_updated_pkeys(db)
+        lens = [p[2] - p[1] if p[0] == "rows" else 2 for p in plan]
+        ref_lens, cur = [], 0
+        for ch in want:  # SplitUpdatedPKeys, utils.go:75-128
+            if ch:
+                if cur:
+                    ref_lens.append(cur)
+                ref_lens.append(2)
+                cur = 0
+            else:
+                cur += 1
+        if cur:
+            ref_lens.append(cur)
+        assert lens == ref_lens
+    # different Go types under one key name are never deeply equal; NaN differs from NaN
+    sch = abi.Schema([abi.ColSchema("f", "double", True, "", "")])
+    fb = abi.batch_from_rows(sch, ["f"], [[["float64", 1.0]], [["float64", float("nan")]], [["float64", 0.0]]], "", "t", ["update"] * 3)
+    fb.schema = sch
+    fb.old_keys = abi.batch_from_rows(sch, ["f"], [[["float64", 1.0]], [["float64", float("nan")]], [["float64", -0.0]]]).cols
+    fb.old_present = np.ones(3, bool)
+    assert list(tf.keys_changed(tf.DeviceBatch.upload(fb))) == [False, True, False]
+    fb.old_keys = abi.batch_from_rows(abi.Schema([abi.ColSchema("f", "int64", True, "", "")]), ["f"], [[["int64", 1]], [["int64", 0]], [["int64", 0]]]).cols
+    assert list(tf.keys_changed(tf.DeviceBatch.upload(fb))) == [True, True, True]

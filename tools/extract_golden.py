@@ -607,6 +607,61 @@ def collapse():
     write("collapse.json", {"source": "pkg/abstract/changeitem/change_item_test.go:205-964 (TestCollapse)", "cases": cases})
 
 
+def keys_changed():
+    """ChangeItem.KeysChanged (TestPkeyChange, change_item_test.go:966-1235) and SplitUpdatedPKeys
+    (TestSplitUnchangedKeys, :1294-1410), transcribed as data with the tests' own expectations."""
+    src = REF + "/pkg/abstract/changeitem/change_item_test.go"
+    lines = open(src, encoding="utf-8").read().split("\n")
+    I = lambda v: ["int", v]
+    S = lambda v: ["string", v]
+
+    def upd(keys, names, values, old=None):
+        d = {"kind": "update", "keys": keys, "names": names, "values": values}
+        if old:
+            d["old_names"], d["old_values"] = old
+        return d
+    cases = []
+
+    def case(line, needle, item, expect):
+        assert needle in lines[line - 1], (line, needle, lines[line - 1])
+        cases.append({"ref": "change_item_test.go:%d" % line, "item": item, "changed": expect})
+    iv = ["id", "value"]
+    for line, vals, exp in [(976, [I(1), S("kek")], False), (987, [I(1), S("lel")], False), (998, [I(2), S("kek")], True), (1009, [I(2), S("lel")], True)]:
+        case(line, "require.", upd(["id"], iv, vals, (iv, [I(1), S("kek")])), exp)
+    n4 = ["id1", "value1", "id2", "value2"]
+    k2 = ["id1", "id2"]
+    case(1036, "require.False", upd(k2, n4, [I(1), S("olel"), I(100), S("okek")], (n4, [I(1), S("lel"), I(100), S("kek")])), False)
+    case(1047, "require.True", upd(k2, n4, [I(1), S("lel"), I(200), S("lel")], (n4, [I(1), S("kek"), I(100), S("lel")])), True)
+    case(1058, "require.True", upd(k2, n4, [I(1), S("lel"), I(200), S("lel")], (k2, [I(1), I(100)])), True)
+    case(1071, "one column - PrimaryKey, changed", upd(["a"], ["a"], [I(1)], (["a"], [I(123)])), True)
+    case(1093, "one column - not a PrimaryKey, changed", upd([], ["a"], [I(1)]), False)
+    ab = ["a", "b"]
+    case(1110, "one 1st changed", upd(ab, ab, [I(1), I(2)], (ab, [I(1), I(3)])), True)
+    case(1135, "one 2nd changed", upd(ab, ab, [I(1), I(2)], (ab, [I(2), I(2)])), True)
+    case(1160, "both changed", upd(ab, ab, [I(1), I(2)], (ab, [I(3), I(4)])), True)
+    case(1185, "both changed", upd(ab, ab, [I(1), I(2)], (ab, [I(1), I(2)])), False)
+    abc = ["a", "b", "c"]
+    case(1210, "not a PrimaryKey changed", upd(ab, abc, [I(1), I(2), I(3)], (abc, [I(1), I(2), I(4)])), False)
+
+    assert "func TestSplitUnchangedKeys" in lines[1293]
+    na = ["name", "address"]
+
+    def it(kind, vals, old=None):
+        d = {"kind": kind, "keys": ["name"], "names": na, "values": [S(v) for v in vals]}
+        if old:
+            d["old_names"], d["old_values"] = na, [S(v) for v in old]
+        return d
+    changes = [it("insert", ["John", "123 Street"]), it("update", ["John", "124 Street"], ["John", "123 Street"]),
+               it("update", ["Susan", "124 Street"], ["John", "124 Street"]), it("insert", ["Ben", "100 Street"]),
+               it("update", ["Ben", "124 Street"], ["Ben", "100 Street"])]
+    expected = [[changes[0], changes[1]],
+                [{"kind": "delete", "keys": ["name"], "names": [], "values": [], "old_names": na, "old_values": [S("John"), S("124 Street")]},
+                 it("insert", ["Susan", "124 Street"])],
+                [changes[3], changes[4]]]
+    write("keys_changed.json", {"source": "pkg/abstract/changeitem/change_item_test.go:966-1235 (TestPkeyChange), :1294-1410 (TestSplitUnchangedKeys)",
+                                "keys_changed": cases, "split": {"ref": "change_item_test.go:1294", "items": changes, "expected": expected}})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -620,4 +675,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed()

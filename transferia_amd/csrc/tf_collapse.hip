@@ -36,6 +36,14 @@ std::unique_ptr<tfgpu_dbatch> gather_rows(const tfgpu_dbatch &in, const Buf &sel
 
 static inline unsigned cgrid(int64_t n) { return (unsigned)((n + 255) / 256); }
 static constexpr uint32_t NOKEY = 0xFFFFFFFFu;
+__device__ __forceinline__ int repr_width_dev(int r) {
+  switch (r) {
+    case TFGPU_R_INT8: case TFGPU_R_UINT8: case TFGPU_R_BOOL: return 1;
+    case TFGPU_R_INT16: case TFGPU_R_UINT16: return 2;
+    case TFGPU_R_INT32: case TFGPU_R_UINT32: case TFGPU_R_FLOAT32: return 4;
+    default: return 8;
+  }
+}
 
 // ---- 1. key strings → 128-bit hashes ----------------------------------------------------------------------------
 struct HashSink {
@@ -215,6 +223,51 @@ __global__ void __launch_bounds__(256) collapse_any_non_insert(const uint8_t *ki
   if (i < n && kind[i] != TFGPU_K_INSERT) *flag = 1;
 }
 
+// ---- ChangeItem.KeysChanged (change_item.go:237-286): reflect.DeepEqual of the old and the new value of every PK column ----
+struct KeysChangedParams { const KCol *keys; int32_t nkeys; int64_t n; const uint8_t *kind, *old_present; int32_t has_old_keys; uint8_t *out; uint32_t *count; };
+__device__ bool cell_deep_equal(const DCol &a, int64_t r, const DCol &b) {  // both non-nil
+  if (a.repr != b.repr) return false;  // different Go dynamic types are never deeply equal
+  if (a.offsets) {
+    const uint32_t a0 = a.offsets[r], an = a.offsets[r + 1] - a0, b0 = b.offsets[r], bn = b.offsets[r + 1] - b0;
+    if (an != bn) return false;
+    for (uint32_t i = 0; i < an; i++) if (a.data[a0 + i] != b.data[b0 + i]) return false;
+    return true;
+  }
+  switch (a.repr) {
+    case TFGPU_R_FLOAT32: return ((const float *)a.values)[r] == ((const float *)b.values)[r];    // NaN != NaN, -0 == 0
+    case TFGPU_R_FLOAT64: return ((const double *)a.values)[r] == ((const double *)b.values)[r];
+    case TFGPU_R_TIME:
+      return ((const int64_t *)a.values)[r] == ((const int64_t *)b.values)[r] && (a.nanos ? a.nanos[r] : 0) == (b.nanos ? b.nanos[r] : 0);
+    default: break;
+  }
+  switch (repr_width_dev(a.repr)) {
+    case 1: return ((const uint8_t *)a.values)[r] == ((const uint8_t *)b.values)[r];
+    case 2: return ((const uint16_t *)a.values)[r] == ((const uint16_t *)b.values)[r];
+    case 4: return ((const uint32_t *)a.values)[r] == ((const uint32_t *)b.values)[r];
+    default: return ((const uint64_t *)a.values)[r] == ((const uint64_t *)b.values)[r];
+  }
+}
+__global__ void __launch_bounds__(256) keys_changed_kernel(KeysChangedParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n) return;
+  bool changed = false;
+  if (p.kind && p.kind[r] == TFGPU_K_UPDATE) {
+    const bool row_has_old = p.has_old_keys && (!p.old_present || ((p.old_present[r >> 3] >> (r & 7)) & 1));
+    for (int k = 0; k < p.nkeys && !changed; k++) {
+      const KCol &kc = p.keys[k];
+      const bool ov = row_has_old && kc.has_old && is_valid(kc.old, r), nv = kc.has_cur && is_valid(kc.cur, r);
+      if (ov != nv) changed = true;
+      else if (ov && !cell_deep_equal(kc.old, r, kc.cur)) changed = true;
+    }
+  }
+  p.out[r] = changed ? 1 : 0;
+  if (changed) atomicAdd(p.count, 1u);
+}
+
+static const DColumn *find_first(const std::vector<DColumn> &cols, const std::string &name) {
+  for (auto &c : cols) if (c.name == name) return &c;  // KeysChanged breaks at the first match
+  return nullptr;
+}
 static const DColumn *find_col(const std::vector<DColumn> &cols, const std::string &name) {
   const DColumn *hit = nullptr;
   for (auto &c : cols) if (c.name == name) hit = &c;  // a later duplicate wins, like the map write in CurrentKeysString
@@ -313,7 +366,44 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   return out;
 }
 
+// flags to a host array; returns how many rows changed their primary key
+int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags) {
+  const int64_t n = in.nrows;
+  if (n == 0) return 0;
+  hipStream_t st = ctx().stream;
+  std::vector<KCol> kc;
+  for (auto &name : in.key_names) {  // TableSchema order; a PK column listed twice is compared twice, harmlessly
+    KCol k; std::memset(&k, 0, sizeof k);
+    if (const DColumn *c = find_first(in.cols, name)) { k.cur = dcol_of(*c); k.has_cur = 1; }
+    if (const DColumn *c = find_first(in.old_keys, name)) { k.old = dcol_of(*c); k.has_old = 1; }
+    kc.push_back(k);
+  }
+  if (kc.empty()) { std::memset(host_flags, 0, (size_t)n); return 0; }  // no PrimaryKey column: nothing can change
+  Buf bkc = upload_small(kc.data(), kc.size() * sizeof(KCol));
+  Buf flags = dalloc((size_t)n + 16), count = dalloc_zero(4);
+  KeysChangedParams p{};
+  p.keys = ptr<KCol>(bkc); p.nkeys = (int32_t)kc.size(); p.n = n; p.kind = ptr<uint8_t>(in.kind); p.old_present = ptr<uint8_t>(in.old_present);
+  p.has_old_keys = in.old_keys.empty() ? 0 : 1; p.out = ptr<uint8_t>(flags); p.count = ptr<uint32_t>(count);
+  { KernelTimer t("keys_changed"); keys_changed_kernel<<<cgrid(n), 256, 0, st>>>(p); }
+  const uint32_t *h = d2h_u32(count->p);
+  d2h(host_flags, flags->p, (size_t)n);
+  sync();
+  return *h;
+}
+
 }  // namespace tf
+
+extern "C" int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed, int64_t *nchanged) {
+  try {
+    if (!in || !changed) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_keys_changed: null argument");
+    std::lock_guard<std::mutex> lk(tf::ctx().mu);
+    const int64_t c = tf::keys_changed_rows(*in, changed);
+    if (nchanged) *nchanged = c;
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
 
 extern "C" int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out) {
   try {

@@ -27,7 +27,7 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_collapse", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -397,6 +397,35 @@ def collapse(batch: DeviceBatch) -> DeviceBatch:
     out = C.c_void_p()
     _check(load().tfgpu_collapse(batch._h, C.byref(out)))
     return DeviceBatch(out)
+
+
+def keys_changed(batch: DeviceBatch) -> np.ndarray:
+    """ChangeItem.KeysChanged (change_item.go:237-286) of every row, as a bool array."""
+    init()
+    flags = np.zeros(max(batch.nrows, 1), dtype=np.uint8)
+    cnt = C.c_int64(0)
+    _check(load().tfgpu_keys_changed(batch._h, flags.ctypes.data_as(C.c_void_p), C.byref(cnt)))
+    out = flags[:batch.nrows].astype(bool)
+    assert int(out.sum()) == cnt.value
+    return out
+
+
+def split_updated_pkeys(batch: DeviceBatch):
+    """abstract.SplitUpdatedPKeys (pkg/abstract/changeitem/utils.go:75-128) as a cut plan over the batch's rows:
+    [("rows", a, b)] for a run of unchanged-key rows [a, b) kept in order, [("pkey_change", i)] for an Update whose
+    primary key changed — the caller turns that one into its pair (Delete carrying the row's OldKeys and no columns,
+    Insert carrying its ColumnValues and empty OldKeys, Counter + 1).  Empty runs are not emitted."""
+    flags = keys_changed(batch)
+    plan, a = [], 0
+    for i in np.flatnonzero(flags):
+        i = int(i)
+        if i > a:
+            plan.append(("rows", a, i))
+        plan.append(("pkey_change", i))
+        a = i + 1
+    if a < batch.nrows:
+        plan.append(("rows", a, batch.nrows))
+    return plan
 
 
 def partition(batch: DeviceBatch, nparts: int):
