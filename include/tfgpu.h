@@ -306,7 +306,13 @@ void tfgpu_csv_options_default(tfgpu_csv_options *o);
 /* Parse `len` bytes of CSV into a device batch typed by `schema` (column i
  * reads CSV field atoi(schema.cols[i].path)), then Strictify.  *consumed is
  * the offset of the first unconsumed byte (a trailing line without '\n' is
- * left for the next chunk, reader.go:158-168).                              */
+ * left for the next chunk, reader.go:158-168).
+ * Text columns of the result are LATE-MATERIALISED: like the Go substrings that alias the chunk they were cut from,
+ * a cell is (length, position in the CSV text) until a consumer needs packed bytes; row filters then pack only the
+ * kept cells, straight from the text.  The library keeps the text alive itself: a host chunk is staged in HBM anyway,
+ * a tfgpu_dbuf is shared (freeing the handle is safe; tfgpu_dbuf_write on a buffer a batch still reads goes to a
+ * private copy).  Any OTHER device pointer (mem = TFGPU_MEM_DEVICE, not a tfgpu_dbuf base) is only trusted for the
+ * duration of the call: the columns are packed before it returns.  TFGPU_CSV_EAGER=1 forces that everywhere.      */
 int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes,
                     uint64_t len, int mem, tfgpu_dbatch **out, uint64_t *consumed,
                     tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);

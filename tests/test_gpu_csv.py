@@ -212,3 +212,46 @@ def test_lanes_overlap_and_agree(tf, oracle):
     for k in range(2):
         assert_batches_equal(outs[k], base[k], "lane %d" % k)
     tf.lane_use(0)
+
+
+def test_late_materialisation(tf, oracle):
+    """Text columns stay (offsets, position in the source text) after the tile path; row compaction packs the kept
+    cells straight from the text.  Checked against the oracle's parse + filter, against the same chain over a batch
+    that was packed first, with the source buffer freed / overwritten while the batch is still lazy."""
+    schema = abi.Schema.of([["a", "int32", True, "0"], ["b", "utf8", False, "1"], ["c", "double", False, "2"], ["d", "utf8", False, "3"], ["e", "utf8", False, "7"]])
+    rng = np.random.default_rng(3)
+    words = ['plain', '"quoted, text"', '"say ""hi"" twice ""x"""', '', '""', '"a longer cell with many bytes to cross several eight-byte words, é and more"', 'x' * 70, '"""";"""']
+    lines = []
+    for i in range(5000):
+        lines.append("%d,%s,%s,%s" % (i, words[int(rng.integers(0, len(words)))], ["1.5", "", "2e3"][int(rng.integers(0, 3))], words[int(rng.integers(0, len(words)))]))
+    data = ("\n".join(lines) + "\n").encode("utf-8")
+    opts = abi.csv_options(include_missing_columns=1)
+    chain = [("filter_rows", {"filter": "a > 10 AND a < 4000"}), ("filter_rows", {"filter": "a != 77"})]
+    ref = oracle.csv_parse(opts, schema, data, "ns", "t")
+    want = oracle.apply_chain([oracle.Transformer(t, c) for t, c in chain], ref.batch, ref.schema).batch
+    plans = [tf.Transformer(t, c) for t, c in chain]
+    # lazy: parse → filter → download
+    db, _, errs = tf.csv_parse(opts, schema, data)
+    assert sorted((e[0], e[1]) for e in errs) == sorted((e[0], abi.ROWERR[e[1]]) for e in ref.errors) and len(errs) > 1000  # "" is no double: those lines are dropped
+    got = tf.apply_chain(plans, db).transformed.download()
+    assert_batches_equal(got, want, "lazy gather")
+    # packed first (download materialises), then the same chain
+    db2, _, _ = tf.csv_parse(opts, schema, data)
+    full = db2.download()
+    assert_batches_equal(full, ref.batch, "materialised")
+    assert_batches_equal(tf.apply_chain(plans, db2).transformed.download(), want, "packed gather")
+    # a predicate on a text column packs just what it reads; the result is the same
+    sfilter = [tf.Transformer("filter_rows", {"filter": "b = \"plain\""})]
+    db3, _, _ = tf.csv_parse(opts, schema, data)
+    want3 = oracle.apply_chain([oracle.Transformer("filter_rows", {"filter": "b = \"plain\""})], ref.batch, ref.schema).batch
+    assert_batches_equal(tf.apply_chain(sfilter, db3).transformed.download(), want3, "string predicate")
+    # the source text outlives its handle: free / overwrite the device buffer while the batch is still unpacked
+    buf = tf.DeviceBuffer.upload(data)
+    db4, _, _ = tf.csv_parse(opts, schema, buf)
+    buf.write(0, np.zeros(4096, np.uint8), 4096)  # copy-on-write: the batch keeps reading the old text
+    buf.free()
+    junk = [tf.DeviceBuffer.upload(b"z" * len(data)) for _ in range(3)]  # recycle the block cache
+    assert_batches_equal(tf.apply_chain(plans, db4).transformed.download(), want, "source freed")
+    assert_batches_equal(db4.download(), ref.batch, "source freed, full")
+    for j in junk:
+        j.free()

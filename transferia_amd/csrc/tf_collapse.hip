@@ -293,6 +293,7 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   names.erase(std::unique(names.begin(), names.end()), names.end());
   if (names.empty()) return same();
 
+  materialize(in);  // key strings read the packed payload
   std::vector<KCol> kc(names.size());
   for (size_t k = 0; k < names.size(); k++) {
     std::memset(&kc[k], 0, sizeof(KCol));
@@ -371,6 +372,7 @@ int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags) {
   const int64_t n = in.nrows;
   if (n == 0) return 0;
   hipStream_t st = ctx().stream;
+  materialize(in);
   std::vector<KCol> kc;
   for (auto &name : in.key_names) {  // TableSchema order; a PK column listed twice is compared twice, harmlessly
     KCol k; std::memset(&k, 0, sizeof k);

@@ -16,6 +16,8 @@
 
 #include "../../include/tfgpu.h"
 
+struct tfgpu_dbatch;
+
 namespace tf {
 
 // ---- error plumbing -------------------------------------------------------
@@ -122,13 +124,32 @@ inline size_t repr_width(int r) {
   }
 }
 
+// Late-materialised text cells (CSV ingest): until a consumer needs the packed Arrow payload, a text column is its
+// offsets (lengths already scanned, data_len known) plus, per row, where the cell sits in the SOURCE text — the columnar
+// form of Go substrings that alias the chunk they were cut from.  Row compaction packs the kept cells straight from
+// the source; everything else calls materialize() first.  `packed` is shared by every copy of the column.
+struct TextView {
+  Buf src;              // the CSV text, kept alive here
+  Buf fstart;           // u32[nrows]: offset of the cell in src | bit 31: collapse doubled quotes; low 31 bits all ones: DefaultValue
+  uint8_t quote = '"';
+  bool jsonnum = false; // DefaultValue of a double is json.Number("0")
+  Buf packed;           // set once by materialize()
+};
 struct DColumn {
   std::string name;
   int dtype = TFGPU_T_INVALID;
   int repr = TFGPU_R_INVALID;
   Buf values, offsets, data, nanos, validity;
   uint64_t data_len = 0;
+  std::shared_ptr<TextView> view;  // non-null while `data` may still be unpacked
+  const Buf &payload() const { return (!data && view) ? view->packed : data; }
+  bool lazy() const { return !data && view && !view->packed; }
 };
+// Packs the lazy text columns of `b` (all of them, or only those listed) from their source text; no-op otherwise.
+void materialize(const struct ::tfgpu_dbatch &b, const std::vector<const DColumn *> *only = nullptr);
+// The library-owned HBM block that starts at `p` (a tfgpu_dbuf), or null for foreign pointers.
+Buf find_device_block(const void *p);
+void register_device_block(const Buf &b);
 
 }  // namespace tf
 

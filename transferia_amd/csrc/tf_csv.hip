@@ -23,6 +23,7 @@
 #include "tf_devfmt.hpp"
 #include "tf_devparse.hpp"
 #include "tf_segcopy.hpp"
+#include "tf_textview.hpp"
 #include "tf_plan.hpp"
 
 namespace tf {
@@ -1047,7 +1048,6 @@ __global__ void __launch_bounds__(256) csv_copy_strings(CopyParams p) {
 // String payloads, destination-centric (tf_segcopy.hpp): blockIdx.y = string column, blockIdx.x = a run of
 // 256 * RPT rows whose cells are pulled straight out of the CSV in HBM at fstart[row].  Cells that are not a plain
 // byte range (doubled quotes, DefaultValue) are zero-filled here and written by csv_copy_special afterwards.
-__device__ __forceinline__ bool cell_plain(uint32_t fsv) { return !(fsv & 0x80000000u) && fsv != 0x7FFFFFFFu; }
 template <int RPT> __global__ void __launch_bounds__(256) csv_copy_words(CopyParams p) {
   __shared__ uint32_t doff[256 * RPT + 1];
   __shared__ uint32_t soff[256 * RPT];
@@ -1084,47 +1084,16 @@ __global__ void __launch_bounds__(256) csv_copy_cells(CopyParams p) {
 }
 
 // Cells csv_copy_words leaves zero-filled: ""-collapse (swapToSingleQuotes, reader.go:307-320) and the
-// DefaultValue of a double (json.Number "0").  lane = row to find them; every flagged cell is then moved by the
-// whole wave, 64 source bytes per step: a quote is dropped iff an odd number of quotes runs directly before it
-// (non-overlapping pairs, left to right), and the survivors are packed through a ballot prefix count.
+// DefaultValue of a double (json.Number "0") — tf_textview.hpp.  lane = row to find them.
 __global__ void __launch_bounds__(256) csv_copy_special(CopyParams p) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
   const CopyCol c = p.cols[blockIdx.y];
   uint32_t fsv = 0, o0 = 0, n = 0;
-  bool special = false;
   if (r < p.nrows) {
     fsv = c.fstart[r];
-    if (!cell_plain(fsv)) {
-      o0 = c.offsets[r]; n = c.offsets[r + 1] - o0;
-      if (n && (fsv & 0x7FFFFFFFu) == 0x7FFFFFFFu) { if (c.is_jsonnum) c.out[o0] = '0'; }
-      else special = n != 0;
-    }
+    if (!cell_plain(fsv)) { o0 = c.offsets[r]; n = c.offsets[r + 1] - o0; }
   }
-  uint64_t todo = __ballot(special);
-  const uint64_t below_me = (1ull << lane) - 1;
-  while (todo) {
-    const int l = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const uint64_t s0 = __shfl(fsv, l, 64) & 0x7FFFFFFFu;
-    const uint32_t on = __shfl(n, l, 64);
-    uint8_t *dst = c.out + __shfl(o0, l, 64);
-    uint32_t produced = 0;
-    bool carry = false;  // the previous step ended on a kept quote still waiting for its pair
-    for (uint64_t sp = s0; produced < on; sp += 64) {
-      const uint32_t ch = p.data[sp + lane];
-      const bool isq = ch == p.quote;
-      const uint64_t Q = __ballot(isq);
-      const uint64_t nonq_below = ~Q & below_me;
-      uint32_t before = nonq_below ? (uint32_t)lane - (63u - (uint32_t)__clzll((long long)nonq_below)) - 1u : (uint32_t)lane + (carry ? 1u : 0u);
-      const bool dropped = isq && (before & 1u);
-      const uint64_t K = __ballot(!dropped);
-      const uint32_t idx = produced + (uint32_t)__popcll(K & below_me);
-      if (!dropped && idx < on) dst[idx] = (uint8_t)ch;
-      carry = __shfl((int)(isq && !(before & 1u)), 63, 64) != 0;
-      produced += (uint32_t)__popcll(K);
-    }
-  }
+  text_copy_special_wave(p.data, p.quote, c.out, c.is_jsonnum != 0, fsv, o0, n, threadIdx.x & 63);
 }
 
 // one contiguous summary for a single read-back: [nerr, consumed, total bytes of each string column]
@@ -1162,6 +1131,45 @@ uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out) {
   if (n) { KernelTimer t("csv_line_index"); csv_line_index<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ptr<uint32_t>(*out)); }
   return n;
 }
+
+// Pack the lazy text columns of a batch.  `text` overrides the source pointer (a caller-owned buffer that is only
+// guaranteed to live for the duration of the parse call).
+static void materialize_cols(const tfgpu_dbatch &b, const std::vector<const DColumn *> *only, const uint8_t *text) {
+  hipStream_t st = ctx().stream;
+  const int64_t nrows = b.nrows;
+  struct Grp { const uint8_t *src; uint8_t quote; std::vector<CopyCol> all, lng, sht; };
+  std::vector<Grp> groups;  // by source text (one, in practice)
+  auto visit = [&](const DColumn &d) {
+    if (!d.lazy()) return;
+    if (only && std::find(only->begin(), only->end(), &d) == only->end()) return;
+    TextView &v = *d.view;
+    const uint8_t *src = text ? text : ptr<uint8_t>(v.src);
+    if (!src) throw Error(TFGPU_ERR_INVALID, "internal: text column " + d.name + " lost its source text");
+    v.packed = dalloc(d.data_len + 8);
+    CopyCol c{ptr<uint32_t>(d.offsets), ptr<uint32_t>(v.fstart), ptr<uint8_t>(v.packed), v.jsonnum ? 1 : 0};
+    Grp *g = nullptr;
+    for (auto &x : groups) if (x.src == src && x.quote == v.quote) g = &x;
+    if (!g) { groups.push_back(Grp{src, v.quote, {}, {}, {}}); g = &groups.back(); }
+    g->all.push_back(c);
+    // long cells: short runs of rows, several words per lane; short (mostly empty) cells: long runs, so the fixed
+    // latency of a run is spread over enough bytes
+    ((d.data_len >= (uint64_t)nrows * 8) ? g->lng : g->sht).push_back(c);
+  };
+  for (auto &d : b.cols) visit(d);
+  for (auto &d : b.old_keys) visit(d);
+  if (!nrows) return;
+  for (auto &g : groups) {
+    Buf ball = upload_small(g.all.data(), g.all.size() * sizeof(CopyCol));
+    Buf blng = upload_small(g.lng.data(), g.lng.size() * sizeof(CopyCol)), bsht = upload_small(g.sht.data(), g.sht.size() * sizeof(CopyCol));
+    KernelTimer t("csv_copy_words");
+    if (!g.lng.empty()) { CopyParams cp{g.src, nrows, ptr<CopyCol>(blng), (int32_t)g.lng.size(), g.quote}; csv_copy_words<1><<<dim3((unsigned)((nrows + 255) / 256), (unsigned)g.lng.size()), 256, 0, st>>>(cp); }
+    if (!g.sht.empty()) { CopyParams cp{g.src, nrows, ptr<CopyCol>(bsht), (int32_t)g.sht.size(), g.quote}; csv_copy_cells<<<dim3((unsigned)((nrows + 255) / 256), (unsigned)((g.sht.size() + CC_GROUP - 1) / CC_GROUP)), 256, 0, st>>>(cp); }
+    CopyParams cp{g.src, nrows, ptr<CopyCol>(ball), (int32_t)g.all.size(), g.quote};
+    csv_copy_special<<<dim3((unsigned)((nrows + 255) / 256), (unsigned)g.all.size()), 256, 0, st>>>(cp);
+  }
+}
+void materialize(const tfgpu_dbatch &b, const std::vector<const DColumn *> *only) { materialize_cols(b, only, nullptr); }
+static void materialize_from(const tfgpu_dbatch &b, const uint8_t *text) { materialize_cols(b, nullptr, text); }
 
 }  // namespace tf
 
@@ -1376,31 +1384,37 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   tf::sync();
   const uint32_t hnerr = hsum[0], last = hsum[1];
 
-  // ---- string payloads: offsets are views into the scanned lens array ----
-  std::vector<CopyCol> cc;
+  // ---- string payloads: offsets are views into the scanned lens array.  The tile path leaves the cells where they
+  //      are: a text column is (offsets, where each cell sits in the source text) until someone needs it packed
+  //      (materialize(), below) — row compaction packs the kept cells straight from the text. ----
+  Buf src_block = staged ? staged : find_device_block(data);  // a foreign device pointer cannot be kept alive: pack now
+  static const bool force_eager = [] { const char *e = std::getenv("TFGPU_CSV_EAGER"); return e && e[0] == '1'; }();
   for (int s = 0; s < nstr; s++) {
     DColumn &d = db->cols[(size_t)str_col_index[(size_t)s]];
     d.data_len = hsum[2 + s];
-    d.data = dalloc(d.data_len + 8);
     d.offsets = subbuf(lens_all, (size_t)s * (size_t)seg_stride * 4, (size_t)(nrows + 1) * 4);
-    cc.push_back(CopyCol{ptr<uint32_t>(d.offsets), cols[(size_t)str_col_index[(size_t)s]].fstart, ptr<uint8_t>(d.data), d.repr == TFGPU_R_JSONNUM ? 1 : 0});
+    if (rowpath) continue;
+    auto v = std::make_shared<TextView>();
+    v->src = src_block ? src_block : nullptr;
+    v->fstart = subbuf(fstart_all, (size_t)s * (size_t)std::max<int64_t>(nrows, 1) * 4, (size_t)std::max<int64_t>(nrows, 1) * 4);
+    v->quote = opts->quote_char; v->jsonnum = d.repr == TFGPU_R_JSONNUM;
+    d.view = std::move(v);
   }
-  Buf bcc = up(cc.data(), cc.size() * sizeof(CopyCol));
-  if (nrows && nstr && rowpath) {
-    CopyParams cp{data, nrows, ptr<CopyCol>(bcc), nstr, opts->quote_char};
-    KernelTimer t("csv_copy_strings");
-    csv_copy_strings<<<blocks_for(nrows, 256), 256, 0, st>>>(cp);
-  } else if (nrows && nstr) {
-    // long cells: short runs of rows, several words per lane; short (mostly empty) cells: long runs, so the fixed
-    // latency of a run is spread over enough bytes
-    std::vector<CopyCol> lng, sht;
-    for (int s = 0; s < nstr; s++) (((uint64_t)hsum[2 + s] >= (uint64_t)nrows * 8) ? lng : sht).push_back(cc[(size_t)s]);
-    Buf blng = up(lng.data(), lng.size() * sizeof(CopyCol)), bsht = up(sht.data(), sht.size() * sizeof(CopyCol));
-    KernelTimer t("csv_copy_words");
-    if (!lng.empty()) { CopyParams cp{data, nrows, ptr<CopyCol>(blng), (int32_t)lng.size(), opts->quote_char}; csv_copy_words<1><<<dim3(blocks_for(nrows, 256), (unsigned)lng.size()), 256, 0, st>>>(cp); }
-    if (!sht.empty()) { CopyParams cp{data, nrows, ptr<CopyCol>(bsht), (int32_t)sht.size(), opts->quote_char}; csv_copy_cells<<<dim3(blocks_for(nrows, 256), (unsigned)((sht.size() + CC_GROUP - 1) / CC_GROUP)), 256, 0, st>>>(cp); }
-    CopyParams cp{data, nrows, ptr<CopyCol>(bcc), nstr, opts->quote_char};
-    csv_copy_special<<<dim3(blocks_for(nrows, 256), (unsigned)nstr), 256, 0, st>>>(cp);
+  if (nstr && rowpath) {
+    std::vector<CopyCol> cc;
+    for (int s = 0; s < nstr; s++) {
+      DColumn &d = db->cols[(size_t)str_col_index[(size_t)s]];
+      d.data = dalloc(d.data_len + 8);
+      cc.push_back(CopyCol{ptr<uint32_t>(d.offsets), cols[(size_t)str_col_index[(size_t)s]].fstart, ptr<uint8_t>(d.data), d.repr == TFGPU_R_JSONNUM ? 1 : 0});
+    }
+    Buf bcc = up(cc.data(), cc.size() * sizeof(CopyCol));
+    if (nrows) {
+      CopyParams cp{data, nrows, ptr<CopyCol>(bcc), nstr, opts->quote_char};
+      KernelTimer t("csv_copy_strings");
+      csv_copy_strings<<<blocks_for(nrows, 256), 256, 0, st>>>(cp);
+    }
+  } else if (nstr && (!src_block || force_eager)) {
+    materialize_from(*db, data);
   }
 
   std::unique_ptr<tfgpu_dbatch> result;

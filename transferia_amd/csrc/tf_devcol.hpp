@@ -19,7 +19,8 @@ static inline DCol dcol_of(const DColumn &c) {
   DCol d;
   d.values = c.values ? c.values->p : nullptr;
   d.offsets = ptr<uint32_t>(c.offsets);
-  d.data = ptr<uint8_t>(c.data);
+  if (c.lazy()) throw Error(TFGPU_ERR_INVALID, "internal: text column " + c.name + " read before materialize()");
+  d.data = ptr<uint8_t>(c.payload());
   d.nanos = ptr<int32_t>(c.nanos);
   d.validity = ptr<uint8_t>(c.validity);
   d.repr = c.repr; d.dtype = c.dtype;

@@ -176,6 +176,24 @@ void d2h(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(ds
 void d2d(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, ctx().stream)); }
 void sync() { TF_HIP(hipStreamSynchronize(ctx().stream)); }
 
+// library-owned blocks handed out as tfgpu_dbuf, by base pointer: a lazy text column keeps its source alive through this
+static std::mutex g_blocks_mu;
+static std::unordered_map<const void *, std::weak_ptr<DevMem>> g_blocks;
+void register_device_block(const Buf &b) {
+  if (!b) return;
+  std::lock_guard<std::mutex> lk(g_blocks_mu);
+  if (g_blocks.size() > 4096) for (auto it = g_blocks.begin(); it != g_blocks.end();) it = it->second.expired() ? g_blocks.erase(it) : std::next(it);
+  g_blocks[b->p] = b;
+}
+Buf find_device_block(const void *p) {
+  std::lock_guard<std::mutex> lk(g_blocks_mu);
+  auto it = g_blocks.find(p);
+  if (it == g_blocks.end()) return nullptr;
+  Buf b = it->second.lock();
+  if (!b || b->p != p) { g_blocks.erase(it); return nullptr; }
+  return b;
+}
+
 }  // namespace tf
 
 using namespace tf;
@@ -333,13 +351,14 @@ static thread_local ViewStore g_view;
 int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   TF_API_BEGIN
   if (!b || !v) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_view: null argument");
+  { std::lock_guard<std::mutex> lk(ctx().mu); materialize(*b); }  // the view exposes packed payload pointers
   g_view.cols.assign(b->cols.size() + b->old_keys.size(), tfgpu_column{});
   for (size_t i = 0; i < b->cols.size() + b->old_keys.size(); i++) {
     const DColumn &d = i < b->cols.size() ? b->cols[i] : b->old_keys[i - b->cols.size()];
     tfgpu_column &c = g_view.cols[i];
     c.name = d.name.c_str(); c.dtype = d.dtype; c.repr = d.repr;
     c.values = d.values ? d.values->p : nullptr;
-    c.offsets = ptr<uint32_t>(d.offsets); c.data = ptr<uint8_t>(d.data); c.data_len = d.data_len;
+    c.offsets = ptr<uint32_t>(d.offsets); c.data = ptr<uint8_t>(d.payload()); c.data_len = d.data_len;
     c.nanos = ptr<int32_t>(d.nanos); c.validity = ptr<uint8_t>(d.validity);
   }
   v->nrows = b->nrows; v->ncols = (int32_t)b->cols.size(); v->cols = g_view.cols.data();
@@ -360,13 +379,14 @@ int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
   if (h->ncols != (int32_t)b->cols.size() || h->nrows != b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: shape mismatch");
   if (h->n_old_keys && h->n_old_keys != (int32_t)b->old_keys.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: old-key shape mismatch");
   std::lock_guard<std::mutex> lk(ctx().mu);
+  materialize(*b);
   size_t n = (size_t)b->nrows;
   for (size_t i = 0; i < b->cols.size() + (size_t)h->n_old_keys; i++) {
     const DColumn &d = i < b->cols.size() ? b->cols[i] : b->old_keys[i - b->cols.size()];
     tfgpu_column &c = i < b->cols.size() ? h->cols[i] : h->old_keys[i - b->cols.size()];
     if (repr_is_var(d.repr)) {
       if (c.offsets && d.offsets) d2h(c.offsets, d.offsets->p, (n + 1) * 4);
-      if (c.data && d.data) d2h(c.data, d.data->p, d.data_len);
+      if (c.data && d.payload()) d2h(c.data, d.payload()->p, d.data_len);
     } else {
       if (c.values && d.values) d2h(c.values, d.values->p, n * repr_width(d.repr));
       if (c.nanos && d.nanos) d2h(c.nanos, d.nanos->p, n * 4);
@@ -394,6 +414,7 @@ int tfgpu_dbuf_upload(const void *host, uint64_t len, tfgpu_dbuf **out) {
   h2d(b->mem->p, host, len);
   TF_HIP(hipMemsetAsync((char *)b->mem->p + len, 0, 64, ctx().stream));
   tf::sync();
+  register_device_block(b->mem);
   *out = b.release();
   return TFGPU_OK;
   TF_API_END
@@ -405,6 +426,7 @@ int tfgpu_dbuf_alloc(uint64_t len, tfgpu_dbuf **out) {
   b->size = len;
   b->mem = dalloc(len + 64);
   TF_HIP(hipMemsetAsync((char *)b->mem->p + len, 0, 64, ctx().stream));
+  register_device_block(b->mem);
   *out = b.release();
   return TFGPU_OK;
   TF_API_END
@@ -413,6 +435,12 @@ int tfgpu_dbuf_write(tfgpu_dbuf *b, uint64_t offset, const void *host, uint64_t 
   TF_API_BEGIN
   if (!b || offset + len > b->size) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbuf_write: out of range");
   std::lock_guard<std::mutex> lk(ctx().mu);
+  if (b->mem.use_count() > 1) {  // a lazy text column still reads this text: write into a private copy
+    Buf fresh = dalloc(b->size + 64);
+    d2d(fresh->p, b->mem->p, b->size + 64);
+    b->mem = fresh;
+    register_device_block(b->mem);
+  }
   h2d((char *)b->mem->p + offset, host, len);
   tf::sync();  // the staging buffer is reusable on return
   return TFGPU_OK;

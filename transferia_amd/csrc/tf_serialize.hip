@@ -376,6 +376,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     const int64_t n = b->nrows;
     const int ncols = (int)b->cols.size();
     const int any_as_string = opts ? opts->any_as_string : 0;
+    materialize(*b);
     for (auto &c : b->cols) require_supported(format, c, any_as_string);
     {
       Buf flag;

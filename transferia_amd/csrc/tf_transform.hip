@@ -12,6 +12,7 @@
 #include "tf_plan.hpp"
 #include "tf_devcol.hpp"
 #include "tf_segcopy.hpp"
+#include "tf_textview.hpp"
 
 namespace tf {
 
@@ -170,6 +171,11 @@ static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu
   auto out = shallow_copy(in);
   for (auto &sc : out->schema) if (p.mask_has(sc.first)) sc.second = TFGPU_T_UTF8;  // hmac_hasher.go:35-46
   hipStream_t st = ctx().stream;
+  {
+    std::vector<const DColumn *> need;
+    for (auto &c : in.cols) if (p.mask_has(c.name)) need.push_back(&c);
+    materialize(in, &need);
+  }
   for (auto &c : out->cols) {
     if (!p.mask_has(c.name)) continue;
     require_serializable(c, "mask_field");
@@ -442,7 +448,9 @@ __global__ void __launch_bounds__(256) gather_bitmap_all(const GBit *__restrict_
 }
 // Var-width columns: lengths of all columns in one launch (segmented layout, then one segmented scan),
 // payload bytes of all columns in one launch.
-struct GVar { const uint32_t *in_off; const uint8_t *in_data; uint32_t *out_off; uint8_t *out_data; };
+// fstart != null: a late-materialised text column (TextView) — in_data is the SOURCE text and a kept cell is fetched from
+// in_data + fstart[row]; cells that are not a plain byte range are left zero-filled for gather_text_special.
+struct GVar { const uint32_t *in_off; const uint8_t *in_data; uint32_t *out_off; uint8_t *out_data; const uint32_t *fstart; uint32_t quote, jsonnum; };
 __global__ void __launch_bounds__(256) gather_len_all(const GVar *__restrict__ v, int nv, const int32_t *__restrict__ sel, int64_t m) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
@@ -455,7 +463,12 @@ template <int RPT> __global__ void __launch_bounds__(256) gather_bytes_all(const
   __shared__ uint32_t doff[256 * RPT + 1];
   __shared__ uint32_t soff[256 * RPT];
   const GVar g = v[blockIdx.y];
-  auto so = [&](int64_t k) { return g.in_off[sel[k]]; };
+  auto so = [&](int64_t k) {
+    const int32_t s = sel[k];
+    if (!g.fstart) return g.in_off[s];
+    const uint32_t f = g.fstart[s];
+    return cell_plain(f) ? f : SEG_NONE;
+  };
   segcopy_run<RPT>(g.out_off, m, (int64_t)blockIdx.x * 256 * RPT, g.in_data, g.out_data, so, doff, soff);
 }
 // short, mostly empty cells: cell-centric, lane = kept row, (unaligned) 8-byte words
@@ -466,11 +479,25 @@ __global__ void __launch_bounds__(256) gather_bytes_cells(const GVar *__restrict
   const uint32_t o0 = g.out_off[k], n = g.out_off[k + 1] - o0;
   if (!n) return;
   struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
-  const uint8_t *src = g.in_data + g.in_off[sel[k]];
+  uint32_t so = 0;
+  if (g.fstart) { so = g.fstart[sel[k]]; if (!cell_plain(so)) return; }  // gather_text_special
+  else so = g.in_off[sel[k]];
+  const uint8_t *src = g.in_data + so;
   uint8_t *dst = g.out_data + o0;
   uint32_t i = 0;
   for (; i + 8 <= n; i += 8) reinterpret_cast<U64 *>(dst + i)->v = reinterpret_cast<const U64 *>(src + i)->v;
   if (i < n) { uint64_t x = reinterpret_cast<const U64 *>(src + i)->v; for (; i < n; i++) { dst[i] = (uint8_t)x; x >>= 8; } }
+}
+// the kept cells of late-materialised columns that need more than a byte copy (doubled quotes, DefaultValue)
+__global__ void __launch_bounds__(256) gather_text_special(const GVar *__restrict__ v, const int32_t *__restrict__ sel, int64_t m) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const GVar g = v[blockIdx.y];
+  uint32_t fsv = 0, o0 = 0, n = 0;
+  if (k < m) {
+    o0 = g.out_off[k]; n = g.out_off[k + 1] - o0;  // coalesced; most cells of a sparse column are empty
+    if (n) { fsv = g.fstart[sel[k]]; if (cell_plain(fsv)) n = 0; }
+  }
+  text_copy_special_wave(g.in_data, g.quote, g.out_data, g.jsonnum != 0, fsv, o0, n, threadIdx.x & 63);
 }
 __global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int64_t m, int nv, uint32_t *out) {
   for (int s = threadIdx.x; s < nv; s += blockDim.x) out[s] = lens_all[(int64_t)s * seg_stride + m];
@@ -503,7 +530,10 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       o.offsets = subbuf(lens_all, si * (size_t)seg_stride * 4, (size_t)(m + 1) * 4);
       o.data = dalloc(c.data_len + 8);  // the source size bounds the kept payload; exact length read back below
       o.data_len = c.data_len;
-      vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.data), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data)});
+      if (c.lazy()) {  // kept cells come straight from the source text
+        if (!c.view->src) throw Error(TFGPU_ERR_INVALID, "internal: text column " + c.name + " lost its source text");
+        vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.view->src), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), ptr<uint32_t>(c.view->fstart), c.view->quote, c.view->jsonnum ? 1u : 0u});
+      } else vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.payload()), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), nullptr, 0, 0});
       var_cols.push_back(ai);
     } else {
       size_t w = repr_width(c.repr);
@@ -537,6 +567,12 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       Buf blng = upload_small(lng.data(), lng.size() * sizeof(GVar)), bsht = upload_small(sht.data(), sht.size() * sizeof(GVar));
       if (!lng.empty()) gather_bytes_all<1><<<dim3(grid_for(m, 256), (unsigned)lng.size()), 256, 0, st>>>(ptr<GVar>(blng), sp, m);
       if (!sht.empty()) gather_bytes_cells<<<dim3(grid_for(m, 256), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
+      std::vector<GVar> lz;
+      for (auto &x : vr) if (x.fstart) lz.push_back(x);
+      if (!lz.empty()) {
+        Buf blz = upload_small(lz.data(), lz.size() * sizeof(GVar));
+        gather_text_special<<<dim3(grid_for(m, 256), (unsigned)lz.size()), 256, 0, st>>>(ptr<GVar>(blz), sp, m);
+      }
     }
     Buf tot = dalloc((size_t)nvar * 4);
     collect_totals<<<1, 64, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, m, nvar, ptr<uint32_t>(tot));
@@ -606,8 +642,16 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_rows(const tfgpu_plan &p, cons
       expr_start.push_back((int32_t)terms.size());
     }
   }
+  {
+    std::vector<const DColumn *> need;
+    for (auto &t : terms) if (t.col >= 0) need.push_back(&in.cols[(size_t)t.col]);
+    materialize(in, &need);
+  }
   std::vector<DCol> cols;
-  for (auto &c : in.cols) cols.push_back(dcol_of(c));
+  for (auto &c : in.cols) {
+    if (c.lazy()) { DColumn shell = c; shell.view = nullptr; cols.push_back(dcol_of(shell)); }  // no term reads it: its payload stays unpacked
+    else cols.push_back(dcol_of(c));
+  }
   auto up = [&](const void *src, size_t bytes) { return upload_small(src, bytes); };
   Buf bcols = up(cols.data(), cols.size() * sizeof(DCol)), bterms = up(terms.data(), terms.size() * sizeof(DTerm));
   Buf bexpr = up(expr_start.data(), expr_start.size() * 4), bints = up(ints.data(), ints.size() * 8), bfl = up(floats.data(), floats.size() * 8);
@@ -679,7 +723,7 @@ static DColumn column_to_string(const DColumn &c, int64_t n, bool to_bytes, int 
   DColumn o;
   o.name = c.name; o.dtype = to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8; o.repr = to_bytes ? TFGPU_R_BYTES : TFGPU_R_STRING;
   o.offsets = dalloc((size_t)(n + 1) * 4);
-  DCol dc = dcol_of(c);
+  DCol dc = dcol_of(c);  // callers materialise text columns first
   KernelTimer t("to_string");
   if (n) tostring_len_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets));
   exclusive_scan_u32(ptr<uint32_t>(o.offsets), ptr<uint32_t>(o.offsets), n, true);
@@ -696,6 +740,11 @@ static std::unique_ptr<tfgpu_dbatch> apply_to_string(const tfgpu_plan &p, const 
   if (p.skip_utc) {
     for (auto &c : in.cols) if (p.columns.match(c.name) && c.repr == TFGPU_R_TIME)
       throw Error(TFGPU_ERR_UNSUPPORTED, "convert_to_string skip_utc_conversion=true needs per-value time zones, which the columnar batch does not carry");
+  }
+  {
+    std::vector<const DColumn *> need;
+    for (auto &c : in.cols) if (p.columns.match(c.name) && c.validity) need.push_back(&c);
+    materialize(in, &need);
   }
   auto out = shallow_copy(in);
   for (auto &sc : out->schema) if (p.columns.match(sc.first)) sc.second = p.to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8;  // to_string.go:114-127
@@ -775,6 +824,11 @@ static std::unique_ptr<tfgpu_dbatch> apply_sharder(const tfgpu_plan &p, const tf
   // Columns are visited in TableSchema order; without a separate schema the
   // batch column order stands in for it (they coincide for every source that
   // builds ColumnNames from the schema).
+  {
+    std::vector<const DColumn *> need;
+    for (auto &c : in.cols) if (p.columns.match(c.name)) need.push_back(&c);
+    materialize(in, &need);
+  }
   std::vector<DCol> cols;
   if (in.schema.empty()) {
     for (auto &c : in.cols) {
