@@ -133,6 +133,7 @@ struct TextView {
   Buf fstart;           // u32[nrows]: offset of the cell in src | bit 31: collapse doubled quotes; low 31 bits all ones: DefaultValue
   uint8_t quote = '"';
   bool jsonnum = false; // DefaultValue of a double is json.Number("0")
+  bool has_special = true;  // some cell is not a plain byte range of src (doubled quotes, DefaultValue text)
   Buf packed;           // set once by materialize()
 };
 struct DColumn {

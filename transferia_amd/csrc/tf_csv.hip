@@ -276,7 +276,7 @@ struct CsvCol {
   void *values;       // fixed-width output
   int32_t *nanos;
   uint32_t *lens;     // string columns: lens[r] = content length (Arrow offsets after the scan)
-  uint32_t *fstart;   // string columns: absolute start of the content | bit31 = has doubled quotes
+  uint32_t *fstart;   // string columns: absolute start of the content | bit31 = has doubled quotes; fstart[-1] = the column has such cells (or DefaultValue text)
 };
 
 // Compact column descriptor of the tile path, staged in LDS in (kind, width) order.
@@ -329,7 +329,7 @@ __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v)
 // DefaultValue(col) (pkg/abstract/change_item_builders.go:88-109) after Strictify
 __device__ __forceinline__ void store_default(const CsvCol &c, int64_t r) {
   switch (c.kind) {
-    case CK_STR: case CK_JSONNUM: c.lens[r] = (c.kind == CK_JSONNUM) ? 1u : 0u; c.fstart[r] = 0x7FFFFFFFu; break;  // "" / json "0"
+    case CK_STR: case CK_JSONNUM: c.lens[r] = (c.kind == CK_JSONNUM) ? 1u : 0u; c.fstart[r] = 0x7FFFFFFFu; if (c.kind == CK_JSONNUM) c.fstart[-1] = 1u; break;  // "" / json "0" (a cell that is no byte range: flag word of the column)
     case CK_DATE: case CK_TIMESTAMP: ((int64_t *)c.values)[r] = 0; if (c.nanos) c.nanos[r] = 0; break;
     case CK_BOOL: ((uint8_t *)c.values)[r] = 0; break;
     case CK_F32: ((float *)c.values)[r] = 0.f; break;
@@ -379,6 +379,7 @@ __device__ int parse_cell(const CsvOpts &o, const CsvCol &c, int64_t r, const F 
       if (c.kind == CK_JSONNUM && (npairs || !json_number_ok(fv, a, b))) return TFGPU_ROW_CAST;
       c.lens[r] = (b - a) - npairs;
       c.fstart[r] = (uint32_t)(abs_start + a) | (npairs ? 0x80000000u : 0u);
+      if (npairs) c.fstart[-1] = 1u;
       return 0;
     }
     case CK_DATE: case CK_TIMESTAMP: {
@@ -902,6 +903,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
               if (!(npairs && !o.double_quote)) {  // errDoubleQuotesDisabled: per-row path
                 ((uint32_t *)tc.p0)[r] = (b - a) - npairs;
                 ((uint32_t *)tc.p1)[r] = (uint32_t)(g0 + a) | (npairs ? 0x80000000u : 0u);
+                if (npairs) ((uint32_t *)tc.p1)[-1] = 1u;  // the column holds cells that are not a plain byte range
                 done = true;
               }
             }
@@ -1007,6 +1009,7 @@ __global__ void csv_zero_err_lens(const uint8_t *err, int64_t nrows, const CsvCo
   for (int32_t ci = 0; ci < ncols; ci++) if (cols[ci].lens) cols[ci].lens[r] = 0;
 }
 
+static constexpr int FS_HDR = 4;  // words in front of a column's fstart array; the last one is its flag word
 struct CopyCol { const uint32_t *offsets; const uint32_t *fstart; uint8_t *out; int32_t is_jsonnum; };
 struct CopyParams { const uint8_t *data; int64_t nrows; const CopyCol *cols; int32_t ncols; uint8_t quote; };
 
@@ -1097,11 +1100,15 @@ __global__ void __launch_bounds__(256) csv_copy_special(CopyParams p) {
 }
 
 // one contiguous summary for a single read-back: [nerr, consumed, total bytes of each string column]
-__global__ void csv_collect(const uint32_t *nerr, const uint32_t *last, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, uint32_t *out) {
+__global__ void csv_collect(const uint32_t *nerr, const uint32_t *last, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, const uint32_t *fstart_all,
+                            int64_t fstride, uint32_t *out) {
   int i = threadIdx.x;
   if (i == 0) out[0] = *nerr;
   if (i == 1) out[1] = *last;
-  for (int s = i; s < nstr; s += blockDim.x) out[2 + s] = lens_all[(int64_t)s * seg_stride + nrows];
+  for (int s = i; s < nstr; s += blockDim.x) { out[2 + s] = lens_all[(int64_t)s * seg_stride + nrows]; out[2 + nstr + s] = fstart_all[(int64_t)s * fstride + FS_HDR - 1]; }
+}
+__global__ void csv_zero_flags(uint32_t *fstart_all, int64_t fstride, int nstr) {
+  for (int s = threadIdx.x; s < nstr; s += blockDim.x) fstart_all[(int64_t)s * fstride + FS_HDR - 1] = 0;
 }
 __global__ void csv_keep_from_err(const uint8_t *err, int64_t n, uint32_t *keep) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1150,7 +1157,7 @@ static void materialize_cols(const tfgpu_dbatch &b, const std::vector<const DCol
     Grp *g = nullptr;
     for (auto &x : groups) if (x.src == src && x.quote == v.quote) g = &x;
     if (!g) { groups.push_back(Grp{src, v.quote, {}, {}, {}}); g = &groups.back(); }
-    g->all.push_back(c);
+    if (v.has_special) g->all.push_back(c);
     // long cells: short runs of rows, several words per lane; short (mostly empty) cells: long runs, so the fixed
     // latency of a run is spread over enough bytes
     ((d.data_len >= (uint64_t)nrows * 8) ? g->lng : g->sht).push_back(c);
@@ -1164,8 +1171,10 @@ static void materialize_cols(const tfgpu_dbatch &b, const std::vector<const DCol
     KernelTimer t("csv_copy_words");
     if (!g.lng.empty()) { CopyParams cp{g.src, nrows, ptr<CopyCol>(blng), (int32_t)g.lng.size(), g.quote}; csv_copy_words<1><<<dim3((unsigned)((nrows + 255) / 256), (unsigned)g.lng.size()), 256, 0, st>>>(cp); }
     if (!g.sht.empty()) { CopyParams cp{g.src, nrows, ptr<CopyCol>(bsht), (int32_t)g.sht.size(), g.quote}; csv_copy_cells<<<dim3((unsigned)((nrows + 255) / 256), (unsigned)((g.sht.size() + CC_GROUP - 1) / CC_GROUP)), 256, 0, st>>>(cp); }
-    CopyParams cp{g.src, nrows, ptr<CopyCol>(ball), (int32_t)g.all.size(), g.quote};
-    csv_copy_special<<<dim3((unsigned)((nrows + 255) / 256), (unsigned)g.all.size()), 256, 0, st>>>(cp);
+    if (!g.all.empty()) {  // only the columns whose cells are not all plain byte ranges
+      CopyParams cp{g.src, nrows, ptr<CopyCol>(ball), (int32_t)g.all.size(), g.quote};
+      csv_copy_special<<<dim3((unsigned)((nrows + 255) / 256), (unsigned)g.all.size()), 256, 0, st>>>(cp);
+    }
   }
 }
 void materialize(const tfgpu_dbatch &b, const std::vector<const DColumn *> *only) { materialize_cols(b, only, nullptr); }
@@ -1254,7 +1263,9 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   }
   int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
   Buf lens_all = dalloc((size_t)std::max(nstr, 1) * (size_t)seg_stride * 4 + 16);
-  Buf fstart_all = dalloc((size_t)std::max(nstr, 1) * (size_t)std::max<int64_t>(nrows, 1) * 4);
+  const int64_t fstride = ((std::max<int64_t>(nrows, 1) + 3) / 4) * 4 + FS_HDR;
+  Buf fstart_all = dalloc((size_t)std::max(nstr, 1) * (size_t)fstride * 4);
+  if (nstr) csv_zero_flags<<<1, 64, 0, st>>>(ptr<uint32_t>(fstart_all), fstride, nstr);
   int max_field = -1;
   int si = 0;
   std::vector<int> str_col_index;
@@ -1290,7 +1301,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     }
     if (c.kind == CK_STR || c.kind == CK_JSONNUM) {
       c.lens = ptr<uint32_t>(lens_all) + (int64_t)si * seg_stride;
-      c.fstart = ptr<uint32_t>(fstart_all) + (int64_t)si * std::max<int64_t>(nrows, 1);
+      c.fstart = ptr<uint32_t>(fstart_all) + (int64_t)si * fstride + FS_HDR;
       str_col_index.push_back(i);
       si++;
     } else {
@@ -1377,10 +1388,10 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)nstr * (size_t)seg_stride * 4, st));
   }
   // ---- one read-back: error count, consumed offset, string totals ----
-  Buf summary = dalloc((size_t)(nstr + 2) * 4);
+  Buf summary = dalloc((size_t)(2 * nstr + 2) * 4);
   csv_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), rowpath ? ptr<uint32_t>(row_start) + nlines : pp.last_end, ptr<uint32_t>(lens_all),
-                                seg_stride, nrows, nstr, ptr<uint32_t>(summary));
-  const uint32_t *hsum = d2h_u32(summary->p, (size_t)nstr + 2);
+                                seg_stride, nrows, nstr, ptr<uint32_t>(fstart_all), fstride, ptr<uint32_t>(summary));
+  const uint32_t *hsum = d2h_u32(summary->p, (size_t)(2 * nstr) + 2);
   tf::sync();
   const uint32_t hnerr = hsum[0], last = hsum[1];
 
@@ -1396,7 +1407,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     if (rowpath) continue;
     auto v = std::make_shared<TextView>();
     v->src = src_block ? src_block : nullptr;
-    v->fstart = subbuf(fstart_all, (size_t)s * (size_t)std::max<int64_t>(nrows, 1) * 4, (size_t)std::max<int64_t>(nrows, 1) * 4);
+    v->fstart = subbuf(fstart_all, ((size_t)s * (size_t)fstride + FS_HDR) * 4, (size_t)std::max<int64_t>(nrows, 1) * 4);
+    v->has_special = hsum[2 + nstr + s] != 0;
     v->quote = opts->quote_char; v->jsonnum = d.repr == TFGPU_R_JSONNUM;
     d.view = std::move(v);
   }

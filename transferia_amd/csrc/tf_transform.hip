@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) gather_bitmap_all(const GBit *__restrict_
 // payload bytes of all columns in one launch.
 // fstart != null: a late-materialised text column (TextView) — in_data is the SOURCE text and a kept cell is fetched from
 // in_data + fstart[row]; cells that are not a plain byte range are left zero-filled for gather_text_special.
-struct GVar { const uint32_t *in_off; const uint8_t *in_data; uint32_t *out_off; uint8_t *out_data; const uint32_t *fstart; uint32_t quote, jsonnum; };
+struct GVar { const uint32_t *in_off; const uint8_t *in_data; uint32_t *out_off; uint8_t *out_data; const uint32_t *fstart; uint32_t quote, jsonnum, has_special; };
 __global__ void __launch_bounds__(256) gather_len_all(const GVar *__restrict__ v, int nv, const int32_t *__restrict__ sel, int64_t m) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
@@ -532,8 +532,8 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       o.data_len = c.data_len;
       if (c.lazy()) {  // kept cells come straight from the source text
         if (!c.view->src) throw Error(TFGPU_ERR_INVALID, "internal: text column " + c.name + " lost its source text");
-        vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.view->src), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), ptr<uint32_t>(c.view->fstart), c.view->quote, c.view->jsonnum ? 1u : 0u});
-      } else vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.payload()), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), nullptr, 0, 0});
+        vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.view->src), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), ptr<uint32_t>(c.view->fstart), c.view->quote, c.view->jsonnum ? 1u : 0u, c.view->has_special ? 1u : 0u});
+      } else vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.payload()), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), nullptr, 0, 0, 0});
       var_cols.push_back(ai);
     } else {
       size_t w = repr_width(c.repr);
@@ -568,7 +568,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       if (!lng.empty()) gather_bytes_all<1><<<dim3(grid_for(m, 256), (unsigned)lng.size()), 256, 0, st>>>(ptr<GVar>(blng), sp, m);
       if (!sht.empty()) gather_bytes_cells<<<dim3(grid_for(m, 256), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
       std::vector<GVar> lz;
-      for (auto &x : vr) if (x.fstart) lz.push_back(x);
+      for (auto &x : vr) if (x.fstart && x.has_special) lz.push_back(x);
       if (!lz.empty()) {
         Buf blz = upload_small(lz.data(), lz.size() * sizeof(GVar));
         gather_text_special<<<dim3(grid_for(m, 256), (unsigned)lz.size()), 256, 0, st>>>(ptr<GVar>(blz), sp, m);
