@@ -401,6 +401,63 @@ int tfgpu_dbuf_upload(const void *host, uint64_t len, tfgpu_dbuf **out);
 int tfgpu_dbuf_alloc(uint64_t len, tfgpu_dbuf **out);
 int tfgpu_dbuf_write(tfgpu_dbuf *b, uint64_t offset, const void *host, uint64_t len);
 
+/* ---- queue serializers: pkg/serializer/queue (the "→ Kafka sink" half of configs[4]) ---- */
+/* ChangeItem fields that are not columns (change_item.go:27-80).  Every array is indexed by the INPUT row of the
+ * pipeline: row r of the batch reads entry src_row[r] (identity when the batch has no src_row) — the fan-in key the
+ * batch carries through every row-moving step.  NULL array = the Go zero value in every row.                        */
+typedef struct tfgpu_row_meta {
+  const uint32_t *id;            /* ChangeItem.ID          "id"                                     */
+  const uint64_t *lsn;           /* ChangeItem.LSN         "nextlsn"                                */
+  const uint64_t *commit_time;   /* ChangeItem.CommitTime  "commitTime"                             */
+  const int64_t *counter;        /* ChangeItem.Counter     "txPosition"                             */
+  const uint32_t *tx_id_offsets; /* ChangeItem.TxID: [n+1] offsets into tx_id_data                  */
+  const uint8_t *tx_id_data;
+  const uint32_t *query_offsets; /* ChangeItem.Query                                                */
+  const uint8_t *query_data;
+  const uint8_t *names_form;     /* 0: ColumnNames / ColumnValues = the batch columns;
+                                    1: ColumnNames == nil   ("columnnames":null, no "columnvalues");
+                                    2: ColumnNames == []    ("columnnames":[],   no "columnvalues")  */
+  int64_t n;                     /* entries in each array (rows of the pipeline input)              */
+  int32_t mem;                   /* TFGPU_MEM_HOST / TFGPU_MEM_DEVICE                               */
+} tfgpu_row_meta;
+
+enum {
+  TFGPU_QFMT_NATIVE = 1, /* NativeSerializer: "[" + ChangeItem.ToJSONString() + "]", batches joined by ","
+                            (native_serializer.go:14-26, native_batcher.go:10-63; MarshalJSON change_item.go:568-616) */
+  TFGPU_QFMT_JSON = 2    /* queue.JSONSerializer: pkg/serializer/json.go per item (UnsupportedItemKinds = update,
+                            delete; AddClosingNewLine / AnyAsString off), batches joined by "\n"
+                            (json_serializer.go:21-59, json_batcher.go:11-66)                                         */
+};
+typedef struct tfgpu_queue_options {
+  int32_t format;              /* TFGPU_QFMT_*                                                       */
+  int32_t batching_enabled;    /* model.Batching.Enabled                                             */
+  int32_t max_change_items;    /* model.Batching.MaxChangeItems, 0 = no limit                        */
+  int64_t max_message_size;    /* model.Batching.MaxMessageSize, 0 = no limit                        */
+  /* NATIVE only: */
+  const char *table_schema_json; /* json.Marshal(TableSchema.Columns()) rendered once by the caller, or NULL =
+                                    rendered from `table_schema` / the batch's schema (TableSchema, TableName,
+                                    Expression = "", FakeKey = false, no Properties)                 */
+  const tfgpu_schema *table_schema;
+  int32_t omit_table_schema;   /* ChangeItem.TableSchema == nil or empty                              */
+  const char *const *old_key_types; /* OldKeys.KeyTypes, one per old-key column, or NULL = omitted    */
+  /* rows are serialised group by group (splitByTablePartID, split.go:5-12): `ngroups` contiguous row runs of
+   * `group_rows[g]` rows each; a batch never spans two groups.  NULL = one group.                    */
+  int32_t ngroups;
+  const int64_t *group_rows;
+  /* ChangeItem.PartID is constant inside a group: one string per group, or NULL = itoa(batch part_id[r]) when the
+   * batch carries part ids (sharder_transformer), "" otherwise.                                       */
+  const char *const *group_part_ids;
+} tfgpu_queue_options;
+
+/* Serializer.Serialize for one table's rows: message VALUES back to back in *values; message m is the bytes
+ * [msg_start[m], msg_start[m+1]) and holds rows [msg_row[m], msg_row[m+1]).  Keys are constant per call and stay with
+ * the caller (Fqtn() when batching is off, nil when on).  msg_start / msg_row have room for `cap`+1 entries; the call
+ * fails with TFGPU_ERR_INVALID if there are more messages (cap = nrows is always enough).
+ * Rows of a non-row kind are TFGPU_ERR_UNSUPPORTED (they travel through the stock serializer); JSON format fails with
+ * TFGPU_ERR_UNSUPPORTED on update / delete rows exactly where the reference returns its "unsupported kind" error.   */
+int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b, const tfgpu_row_meta *meta,
+                          tfgpu_dbuf **values, uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg);
+
 /* ---- profiling hooks (bench.py / rocprof cross-check) ------------------- */
 /* Per-kernel accumulated device time measured with HIP events on the library
  * stream.  Enable, run, then read back name/launches/total_ms.              */

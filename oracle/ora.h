@@ -196,6 +196,10 @@ const char *ora_batch_item_name(const ora_batch *b, int64_t row, int col, int ol
 int ora_batch_old_value(const ora_batch *b, int64_t row, int col, int *kind, int64_t *i64, const char **s, size_t *slen);
 int64_t ora_batch_len(const ora_batch *b);
 char *ora_serialize_ex(int format, const ora_batch *b, const tfgpu_serialize_options *opts, uint64_t *len);
+/* §8f.4 queue serializers (pkg/serializer/queue): message values back to back, NULL = the reference's Serialize
+ * fails (or a value form is outside the restatement).  msg_start / msg_row are malloc'd with *nmsg + 1 entries. */
+char *ora_queue_serialize(const tfgpu_queue_options *o, const ora_batch *b, const tfgpu_row_meta *m, uint64_t *len,
+                          uint64_t **msg_start, int64_t **msg_row, int64_t *nmsg);
 
 #ifdef __cplusplus
 }

@@ -648,3 +648,188 @@ int ora_batch_old_value(const ora_batch *b, int64_t row, int col, int *kind, int
   return 0;
 }
 int64_t ora_batch_len(const ora_batch *b) { return b->n; }
+
+/* ======================================================================================================
+ * §8f.4  queue serializers — pkg/serializer/queue:
+ *   NativeSerializer.serializeOneTableID (native_serializer.go:14-26), BatchNative (native_batcher.go:10-63),
+ *   ChangeItem.ToJSONString / MarshalJSON (change_item.go:452-455, 568-616) under json.Marshal's compact();
+ *   JSONSerializer.serializeOneTableID (json_serializer.go:38-59), BatchJSON (json_batcher.go:11-66) over
+ *   jsonSerializer.Serialize (pkg/serializer/json.go:50-94) with UnsupportedItemKinds = {update, delete}.
+ * Pinned to gotest/canondata TestNativeSerializerTopicName + the batching table of queue/test.go (commonTest).
+ * ====================================================================================================== */
+static const char *DTYPE_NAMES[] = {"", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float", "double",
+                                    "boolean", "string", "utf8", "date", "datetime", "timestamp", "interval", "any"};
+static const char *KIND_NAMES[] = {"insert", "update", "delete"};
+
+/* what json.Marshal's compact(escape=true) does to bytes a Marshaler returned: <, >, & and U+2028/9 become \uXXXX */
+static void put_html_compact(sbuf *b, const char *s, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    unsigned char c = (unsigned char)s[i];
+    if (c == '<' || c == '>' || c == '&') { sb_s(b, "\\u00"); sb_c(b, HEXC[c >> 4]); sb_c(b, HEXC[c & 15]); }
+    else if (c == 0xE2 && i + 2 < n && (unsigned char)s[i + 1] == 0x80 && ((unsigned char)s[i + 2] & 0xFE) == 0xA8) { sb_s(b, "\\u202"); sb_c(b, HEXC[(unsigned char)s[i + 2] & 0xF]); i += 2; }
+    else sb_c(b, (char)c);
+  }
+}
+
+/* encoding/json of one boxed ColumnValues / KeyValues element, escapeHTML on */
+static void native_value(sbuf *b, const ora_value *v) {
+  char t[128]; size_t n;
+  switch (v->kind) {
+    case OV_NIL: sb_s(b, "null"); return;
+    case OV_BOOL: sb_s(b, v->v.b ? "true" : "false"); return;
+    case OV_STRING: json_string(b, v->s, v->slen, 1); return;
+    case OV_BYTES: sb_c(b, '"'); base64_std(b, (const unsigned char *)v->s, v->slen); sb_c(b, '"'); return;
+    case OV_JSONNUM: if (v->slen) sb_put(b, v->s, v->slen); else sb_c(b, '0'); return;
+    case OV_TIME: sb_c(b, '"'); n = ora_fmt_rfc3339nano(t, v->v.t.sec, v->v.t.nsec); sb_put(b, t, n); sb_c(b, '"'); return;
+    case OV_DURATION: n = ora_fmt_int(t, v->v.i); sb_put(b, t, n); return;
+    case OV_JSON: put_html_compact(b, v->s, v->slen); return;
+    case OV_F32: case OV_F64:
+      n = v->kind == OV_F32 ? ora_json_float(t, (double)v->v.f32, 32) : ora_json_float(t, v->v.f64, 64);
+      if (!n) b->unsupported = 1; else sb_put(b, t, n);  /* NaN / Inf: Marshal fails, ToJSONString drops the error */
+      return;
+    default: if (is_int_kind(v->kind)) put_int(b, v); else b->unsupported = 1;
+  }
+}
+
+static void native_string_array(sbuf *b, char *const *names, int n) {
+  sb_c(b, '[');
+  for (int i = 0; i < n; i++) { if (i) sb_c(b, ','); json_string(b, names[i], strlen(names[i]), 1); }
+  sb_c(b, ']');
+}
+
+/* json.Marshal([]ColSchema) — col_schema.go:14-29 field tags; Properties is omitempty */
+static void native_table_schema(sbuf *b, const tfgpu_schema *ts, const ora_schema *os) {
+  int n = ts ? ts->ncols : os->ncols;
+  sb_c(b, '[');
+  for (int i = 0; i < n; i++) {
+    const char *name = ts ? ts->cols[i].name : os->cols[i].name;
+    int dtype = ts ? ts->cols[i].dtype : os->cols[i].dtype;
+    int key = ts ? !!(ts->cols[i].flags & TFGPU_COL_KEY) : os->cols[i].key;
+    int req = ts ? !!(ts->cols[i].flags & TFGPU_COL_REQUIRED) : 0;
+    const char *path = ts ? ts->cols[i].path : os->cols[i].path;
+    const char *ot = ts ? ts->cols[i].original_type : os->cols[i].original_type;
+    if (i) sb_c(b, ',');
+    sb_s(b, "{\"table_schema\":\"\",\"table_name\":\"\",\"path\":"); json_string(b, path ? path : "", path ? strlen(path) : 0, 1);
+    sb_s(b, ",\"name\":"); json_string(b, name ? name : "", name ? strlen(name) : 0, 1);
+    sb_s(b, ",\"type\":"); { const char *tn = dtype > 0 && dtype < TFGPU_T__COUNT ? DTYPE_NAMES[dtype] : ""; json_string(b, tn, strlen(tn), 1); }
+    sb_s(b, ",\"key\":"); sb_s(b, key ? "true" : "false");
+    sb_s(b, ",\"fake_key\":false,\"required\":"); sb_s(b, req ? "true" : "false");
+    sb_s(b, ",\"expression\":\"\",\"original_type\":"); json_string(b, ot ? ot : "", ot ? strlen(ot) : 0, 1);
+    sb_c(b, '}');
+  }
+  sb_c(b, ']');
+}
+
+static void meta_string(sbuf *b, const uint32_t *off, const uint8_t *data, int64_t i) {
+  if (!off) { sb_s(b, "\"\""); return; }
+  json_string(b, (const char *)data + off[i], off[i + 1] - off[i], 1);
+}
+
+/* ChangeItem.ToJSONString(): MarshalJSON's putItem sequence, compacted by json.Marshal */
+static void native_item(sbuf *b, const ora_item *it, const tfgpu_queue_options *o, const tfgpu_row_meta *m, const char *part) {
+  char t[32]; size_t n;
+  const int64_t k = it->src_row;
+  const int form = (m && m->names_form) ? m->names_form[k] : 0;
+  sb_s(b, "{\"id\":"); n = ora_fmt_uint(t, m && m->id ? m->id[k] : 0); sb_put(b, t, n);
+  sb_s(b, ",\"nextlsn\":"); n = ora_fmt_uint(t, m && m->lsn ? m->lsn[k] : 0); sb_put(b, t, n);
+  sb_s(b, ",\"commitTime\":"); n = ora_fmt_uint(t, m && m->commit_time ? m->commit_time[k] : 0); sb_put(b, t, n);
+  sb_s(b, ",\"txPosition\":"); n = ora_fmt_int(t, m && m->counter ? m->counter[k] : 0); sb_put(b, t, n);
+  sb_s(b, ",\"kind\":"); { const char *kn = it->kind >= 0 && it->kind <= 2 ? KIND_NAMES[it->kind] : ""; if (it->kind > 2) b->unsupported = 1; json_string(b, kn, strlen(kn), 1); }
+  sb_s(b, ",\"schema\":"); json_string(b, it->ns, strlen(it->ns), 1);
+  sb_s(b, ",\"table\":"); json_string(b, it->table, strlen(it->table), 1);
+  if (!part) part = it->part_id ? it->part_id : "";
+  sb_s(b, ",\"part\":"); json_string(b, part, strlen(part), 1);
+  sb_s(b, ",\"columnnames\":");
+  if (form == 1) sb_s(b, "null");
+  else if (form == 2) sb_s(b, "[]");
+  else native_string_array(b, it->names ? it->names->names : NULL, it->names ? it->names->n : 0);
+  if (form == 0 && it->nvalues > 0) {  /* len(c.ColumnValues) > 0 */
+    sb_s(b, ",\"columnvalues\":[");
+    for (int i = 0; i < it->nvalues; i++) { if (i) sb_c(b, ','); native_value(b, &it->values[i]); }
+    sb_c(b, ']');
+  }
+  if (!o->omit_table_schema) {
+    if (o->table_schema_json) { sb_s(b, ",\"table_schema\":"); sb_s(b, o->table_schema_json); }
+    else if ((o->table_schema && o->table_schema->ncols > 0) || (!o->table_schema && it->schema && it->schema->ncols > 0)) {
+      sb_s(b, ",\"table_schema\":"); native_table_schema(b, o->table_schema, it->schema);
+    }
+  }
+  sb_s(b, ",\"oldkeys\":{");  /* OldKeysType: every field omitempty (old_keys.go:3-7) */
+  if (it->n_old > 0) {
+    sb_s(b, "\"keynames\":"); native_string_array(b, it->old_names->names, it->old_names->n);
+    if (o->old_key_types) { sb_s(b, ",\"keytypes\":"); native_string_array(b, (char *const *)o->old_key_types, it->n_old); }
+    sb_s(b, ",\"keyvalues\":[");
+    for (int i = 0; i < it->n_old; i++) { if (i) sb_c(b, ','); native_value(b, &it->old_values[i]); }
+    sb_c(b, ']');
+  }
+  sb_c(b, '}');
+  sb_s(b, ",\"tx_id\":"); meta_string(b, m ? m->tx_id_offsets : NULL, m ? m->tx_id_data : NULL, k);
+  sb_s(b, ",\"query\":"); meta_string(b, m ? m->query_offsets : NULL, m ? m->query_data : NULL, k);
+  sb_c(b, '}');
+}
+
+/* one element as the format's batcher sees it: returns 0, or 1 = the reference's Serialize returns an error */
+static int queue_element(sbuf *e, int format, const ora_item *it, const tfgpu_queue_options *o, const tfgpu_row_meta *m, const char *part) {
+  if (format == TFGPU_QFMT_NATIVE) { native_item(e, it, o, m, part); return 0; }
+  if (it->kind == TFGPU_K_OTHER) return 0;                                   /* !IsRowEvent: empty bytes (json.go:51-53) */
+  if (it->kind == TFGPU_K_UPDATE || it->kind == TFGPU_K_DELETE) return 1;    /* UnsupportedItemKinds (json.go:54-56)     */
+  json_row(e, it, NULL);
+  return 0;
+}
+
+typedef struct { uint64_t *start; int64_t *row; int64_t n, cap; } qmsgs;
+static void qm_push(qmsgs *q, uint64_t start, int64_t row) {
+  if (q->n == q->cap) { q->cap = q->cap ? q->cap * 2 : 16; q->start = (uint64_t *)realloc(q->start, sizeof(uint64_t) * (size_t)(q->cap + 1)); q->row = (int64_t *)realloc(q->row, sizeof(int64_t) * (size_t)(q->cap + 1)); }
+  q->start[q->n] = start; q->row[q->n] = row; q->n++;
+}
+
+/* Returns the message values back to back (malloc'd, *len bytes) or NULL when the reference's Serialize fails / a value
+ * form is outside the restatement.  msg_start / msg_row: malloc'd, *nmsg + 1 entries each.                        */
+char *ora_queue_serialize(const tfgpu_queue_options *o, const ora_batch *bt, const tfgpu_row_meta *m, uint64_t *len,
+                          uint64_t **msg_start, int64_t **msg_row, int64_t *nmsg) {
+  sbuf out = {0}; out.p = (char *)malloc(64); out.cap = 64;
+  qmsgs q = {0};
+  const int native = o->format == TFGPU_QFMT_NATIVE;
+  const char *join = native ? "," : "\n";
+  const uint64_t wrap = native ? 2 : 0;  /* "[" "]" */
+  int failed = 0;
+  int64_t g0 = 0;
+  const int ngroups = o->group_rows ? o->ngroups : 1;
+  for (int g = 0; g < ngroups && !failed; g++) {
+    const int64_t gn = o->group_rows ? o->group_rows[g] : bt->n, g1 = g0 + gn;
+    /* serializedElements / lenElements */
+    sbuf *el = (sbuf *)calloc((size_t)(gn ? gn : 1), sizeof(sbuf));
+    for (int64_t i = 0; i < gn; i++) {
+      if (queue_element(&el[i], o->format, &bt->items[g0 + i], o, m, o->group_part_ids ? o->group_part_ids[g] : NULL)) failed = 1;
+      if (el[i].unsupported) { if (native) { el[i].n = 0; out.unsupported = 1; } else failed = 1; }
+    }
+#define EMIT(a, z) do { qm_push(&q, out.n, g0 + (a)); if (native) sb_c(&out, '['); \
+      for (int64_t e_ = (a); e_ < (z); e_++) { if (e_ > (a)) sb_s(&out, join); sb_put(&out, el[e_].p ? el[e_].p : "", el[e_].n); } \
+      if (native) sb_c(&out, ']'); } while (0)
+    if (!failed) {
+      if (!o->batching_enabled) { for (int64_t i = 0; i < gn; i++) EMIT(i, i + 1); }
+      else {
+        int64_t start = 0; uint64_t sum = 0;
+        for (int64_t i = 0; i < gn; i++) {
+          const int64_t num_new = i - start + 1;
+          int violates = 0;
+          if (o->max_message_size != 0 && sum + (uint64_t)(num_new - 1) + el[i].n + wrap > (uint64_t)o->max_message_size) violates = 1;
+          if (o->max_change_items != 0 && num_new > o->max_change_items) violates = 1;
+          if (violates) {
+            if (i - start == 0) { EMIT(start, start + 1); start = i + 1; sum = 0; }
+            else { EMIT(start, i); start = i; sum = el[i].n; }
+          } else sum += el[i].n;
+        }
+        if (start != gn) EMIT(start, gn);
+      }
+    }
+#undef EMIT
+    for (int64_t i = 0; i < gn; i++) free(el[i].p);
+    free(el);
+    g0 = g1;
+  }
+  if (failed || out.unsupported) { free(out.p); free(q.start); free(q.row); *len = 0; *nmsg = 0; *msg_start = NULL; *msg_row = NULL; return NULL; }
+  qm_push(&q, out.n, bt->n); q.n--;
+  *len = out.n; *msg_start = q.start; *msg_row = q.row; *nmsg = q.n;
+  return out.p;
+}

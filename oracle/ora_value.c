@@ -6,6 +6,7 @@
  * TEST INFRASTRUCTURE ONLY (see ora.h).
  */
 #define _GNU_SOURCE
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "ora.h"
@@ -149,7 +150,8 @@ ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema) {
     it->kind = cb->kind ? cb->kind[r] : TFGPU_K_INSERT;
     it->ns = dups(cb->table_ns ? cb->table_ns : "");
     it->table = dups(cb->table_name ? cb->table_name : "");
-    it->part_id = dups("");
+    if (cb->part_id) { char pb[16]; snprintf(pb, sizeof pb, "%u", cb->part_id[r]); it->part_id = dups(pb); }  /* PartID = itoa (sharder.go:145) */
+    else it->part_id = dups("");
     it->names = nm; nm->refs++;
     it->schema = sch; sch->refs++;
     it->nvalues = cb->ncols;

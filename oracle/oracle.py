@@ -66,6 +66,9 @@ def lib():
     L.ora_serialize.argtypes = [C.c_int, P, C.POINTER(C.c_uint64)]
     L.ora_serialize_ex.restype = P
     L.ora_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(C.c_uint64)]
+    L.ora_queue_serialize.restype = P
+    L.ora_queue_serialize.argtypes = [C.POINTER(abi.CQueueOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(C.c_uint64), C.POINTER(P), C.POINTER(P),
+                                      C.POINTER(C.c_int64)]
     L.ora_hmac_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
     L.ora_crc32_ieee.restype = C.c_uint32
     L.ora_crc32_ieee.argtypes = [C.c_char_p, C.c_size_t]
@@ -203,6 +206,29 @@ def serialize(fmt: int, batch: abi.Batch, schema: abi.Schema, opts=None):
     out = C.string_at(p, n.value)
     L.free(p)
     return out
+
+
+def queue_serialize(opts: abi.CQueueOptions, batch: abi.Batch, schema: abi.Schema, meta: abi.CRowMeta = None):
+    """queue.Serializer.Serialize for one table's rows → list of message values (bytes), or None where the reference's
+    Serialize returns an error (or the value form is outside the restatement).  queue_serialize.rows = first row of
+    every message."""
+    L = lib()
+    cb, cs = batch.to_c(), schema.to_c()
+    rows = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    n, nmsg, ps, pr = C.c_uint64(0), C.c_int64(0), C.c_void_p(), C.c_void_p()
+    t0 = time.perf_counter()
+    p = L.ora_queue_serialize(C.byref(opts), rows, C.byref(meta) if meta is not None else None, C.byref(n), C.byref(ps), C.byref(pr), C.byref(nmsg))
+    queue_serialize.seconds = time.perf_counter() - t0
+    L.ora_batch_free(rows)
+    if not p:
+        return None
+    raw = C.string_at(p, n.value)
+    k = int(nmsg.value)
+    st = np.frombuffer(C.string_at(ps.value, 8 * (k + 1)), np.uint64)
+    rw = np.frombuffer(C.string_at(pr.value, 8 * (k + 1)), np.int64)
+    L.free(p); L.free(ps); L.free(pr)
+    queue_serialize.rows = [int(x) for x in rw]
+    return [raw[int(st[i]):int(st[i + 1])] for i in range(k)]
 
 
 def filter_parse_check(expr: str):

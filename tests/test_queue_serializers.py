@@ -1,0 +1,229 @@
+"""Queue serializers (pkg/serializer/queue native / json + their batchers): the oracle against the
+reference's canon (CPU), the HIP path against the oracle and the same canon (GPU)."""
+import json
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from util import golden, item_to_batch
+
+G = golden("queue_serializers.json")
+
+
+def _with_old_keys(b, item):
+    ok = item.get("old_keys")
+    if ok:
+        b.old_keys = [abi.column_from_values(nm, "utf8", [r[i] for r in ok["rows"]]) for i, nm in enumerate(ok["names"])]
+        if "present" in ok:
+            b.old_present = np.array(ok["present"], bool)
+    return b
+
+
+def _meta(m, n):
+    return abi.row_meta(n, ids=m.get("ids"), lsns=m.get("lsns"), commit_times=m.get("commit_times"), counters=m.get("counters"),
+                        tx_ids=m.get("tx_ids"), queries=m.get("queries"), names_form=m.get("names_form"))
+
+
+def _native_topic_name():
+    c = G["native_topic_name"]
+    b, schema = item_to_batch(c["item"])
+    return c, b, schema, _meta(c["meta"], b.nrows), abi.queue_options(abi.QFMT_NATIVE, table_schema=schema)
+
+
+def _marshal_json():
+    c = G["marshal_json"]
+    b, schema = item_to_batch(c["item"])
+    _with_old_keys(b, c["item"])
+    o = abi.queue_options(abi.QFMT_NATIVE, table_schema_json=c["table_schema_json"], old_key_types=c["item"]["old_keys"]["types"],
+                          group_part_ids=[c["meta"]["part"]], group_rows=[b.nrows])
+    return c, b, schema, _meta(c["meta"], b.nrows), o
+
+
+def _batching_cases(fmt):
+    """queue/test.go commonTest: message-size limits are expressed through the element size, as the Go test does."""
+    c = G["batching"]
+    b, schema = item_to_batch(c["item"])
+    for enabled, max_items, size, expected in c["table"]:
+        yield b, schema, enabled, max_items, size, expected
+
+
+def _size(fmt, elem, k, delta):
+    if k == 0:
+        return delta
+    return (2 if fmt == abi.QFMT_NATIVE else 0) + (k - 1) + elem * k + delta   # batchSizer of native_/json_batcher_test.go
+
+
+def _check_batching(serialize, fmt):
+    b, schema = item_to_batch(G["batching"]["item"])
+    one = serialize(abi.queue_options(fmt, table_schema=schema), b, schema)
+    elem = len(one[0]) - (2 if fmt == abi.QFMT_NATIVE else 0)
+    assert len(one) == 5 and all(m == one[0] for m in one)
+    body = one[0][1:-1] if fmt == abi.QFMT_NATIVE else one[0]
+    sep = b"," if fmt == abi.QFMT_NATIVE else b"\n"
+    for enabled, max_items, size, expected in G["batching"]["table"]:
+        o = abi.queue_options(fmt, enabled=enabled, max_change_items=max_items, max_message_size=_size(fmt, elem, *size) if size else 0, table_schema=schema)
+        msgs = serialize(o, b, schema)
+        assert len(msgs) == expected, (fmt, enabled, max_items, size)
+        rows = 0
+        for m in msgs:  # every message is k copies of the element, joined and wrapped
+            inner = m[1:-1] if fmt == abi.QFMT_NATIVE else m
+            k = inner.count(body)
+            assert inner == sep.join([body] * k) and k >= 1
+            if fmt == abi.QFMT_NATIVE:
+                assert m[:1] == b"[" and m[-1:] == b"]"
+            rows += k
+        assert rows == 5
+
+
+# ---------------------------------------------------------------- oracle (CPU) ----
+def test_oracle_native_canon(oracle):
+    c, b, schema, meta, o = _native_topic_name()
+    msgs = oracle.queue_serialize(o, b, schema, meta)
+    assert [m.decode() for m in msgs] == [c["value"]] * 2
+    assert c["key"] == b.table_ns + "_" + b.table_name  # Fqtn(), change_item.go:139-141
+
+
+def test_oracle_marshal_json_canon(oracle):
+    c, b, schema, meta, o = _marshal_json()
+    msgs = oracle.queue_serialize(o, b, schema, meta)
+    assert len(msgs) == 1 and msgs[0].decode() == "[" + c["value"] + "]"
+
+
+def test_oracle_json_canon(oracle):
+    c = G["json_all_types"]
+    b, schema = item_to_batch(c["item"])
+    msgs = oracle.queue_serialize(abi.queue_options(abi.QFMT_JSON), b, schema)
+    assert [m.decode() for m in msgs] == [c["value"]]
+    assert c["key"] == b.table_ns + "_" + b.table_name
+
+
+@pytest.mark.parametrize("fmt", [abi.QFMT_NATIVE, abi.QFMT_JSON])
+def test_oracle_batching_table(oracle, fmt):
+    _check_batching(lambda o, b, s: oracle.queue_serialize(o, b, s), fmt)
+
+
+def test_oracle_native_forms(oracle):
+    """nil / empty ColumnNames, OldKeys on some rows only, HTML escaping, non-row kinds, update/delete in the JSON format."""
+    schema = abi.Schema.of([["k", "int32", True], ["s", "utf8", False]])
+    rows = [[["int32", 1], ["string", "<a&b> "]], [["int32", 2], ["nil", None]], [["int32", 3], ["string", "x"]]]
+    b = abi.batch_from_rows(schema, ["k", "s"], rows, "ns", "t", ["insert", "update", "delete"])
+    b.old_keys = [abi.column_from_values("k", "int32", [["int32", 0], ["int32", 20], ["int32", 30]])]
+    b.old_present = np.array([False, True, True])
+    meta = abi.row_meta(3, ids=[1, 2, 3], names_form=[0, 0, 1], tx_ids=["", "t<1>", ""])
+    msgs = oracle.queue_serialize(abi.queue_options(abi.QFMT_NATIVE, omit_table_schema=True), b, schema, meta)
+    assert msgs[0] == (b'[{"id":1,"nextlsn":0,"commitTime":0,"txPosition":0,"kind":"insert","schema":"ns","table":"t","part":"",'
+                       b'"columnnames":["k","s"],"columnvalues":[1,"\\u003ca\\u0026b\\u003e\\u2028"],"oldkeys":{},"tx_id":"","query":""}]')
+    assert msgs[1] == (b'[{"id":2,"nextlsn":0,"commitTime":0,"txPosition":0,"kind":"update","schema":"ns","table":"t","part":"",'
+                       b'"columnnames":["k","s"],"columnvalues":[2,null],"oldkeys":{"keynames":["k"],"keyvalues":[20]},"tx_id":"t\\u003c1\\u003e","query":""}]')
+    assert msgs[2] == (b'[{"id":3,"nextlsn":0,"commitTime":0,"txPosition":0,"kind":"delete","schema":"ns","table":"t","part":"",'
+                       b'"columnnames":null,"oldkeys":{"keynames":["k"],"keyvalues":[30]},"tx_id":"","query":""}]')
+    for m in msgs:
+        json.loads(m)
+    assert oracle.queue_serialize(abi.queue_options(abi.QFMT_JSON), b, schema) is None  # "JsonSerializer: unsupported kind"
+    b.kind = np.array([abi.K_INSERT, abi.K_OTHER, abi.K_INSERT], np.uint8)
+    js = oracle.queue_serialize(abi.queue_options(abi.QFMT_JSON), b, schema)
+    assert js == [b'{"k":1,"s":"<a&b>\\u2028"}', b"", b'{"k":3,"s":"x"}']  # !IsRowEvent: empty value; SetEscapeHTML(false)
+    assert oracle.queue_serialize(abi.queue_options(abi.QFMT_NATIVE), b, schema) is None  # non-row kinds stay with the stock path
+
+
+def _random_case(rng, n):
+    from test_serializers import _random_batch
+    b, schema = _random_batch(rng, n)
+    b.kind = rng.integers(0, 3, n).astype(np.uint8)
+    b.old_keys = [abi.Column("i64", "int64", abi.R_INT64, values=rng.integers(-9, 9, n).astype(np.int64)),
+                  abi.column_from_values("sk", "utf8", [["string", "k<%d>" % i] if i % 3 else ["nil", None] for i in range(n)])]
+    b.old_present = rng.random(n) < 0.6
+    b.part_id = rng.integers(0, 5, n).astype(np.uint32)  # sharder_transformer ran: PartID = itoa
+    perm = rng.permutation(n).astype(np.int32)  # the batch went through a row-moving step: meta is read through src_row
+    b.src_row = perm
+    meta = abi.row_meta(n, ids=rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), lsns=rng.integers(0, 2**63, n, dtype=np.uint64) * 2 + 1,
+                        commit_times=rng.integers(0, 2**62, n, dtype=np.uint64), counters=rng.integers(-5, 1000, n),
+                        tx_ids=[("tx&%d" % i) if i % 4 == 0 else "" for i in range(n)], queries=[("select '%d' < 2" % i) if i % 7 == 0 else "" for i in range(n)],
+                        names_form=(rng.random(n) < 0.15).astype(np.uint8) * rng.integers(1, 3, n).astype(np.uint8))
+    return b, schema, meta
+
+
+# ---------------------------------------------------------------- GPU -------------
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+def _gpu(tf, o, b, meta=None):
+    r = tf.queue_serialize(o, tf.DeviceBatch.upload(b), meta)
+    return r.messages()
+
+
+@pytest.mark.gpu
+def test_gpu_queue_canon(tf):
+    c, b, schema, meta, o = _native_topic_name()
+    assert [m.decode() for m in _gpu(tf, o, b, meta)] == [c["value"]] * 2
+    c, b, schema, meta, o = _marshal_json()
+    assert [m.decode() for m in _gpu(tf, o, b, meta)] == ["[" + c["value"] + "]"]
+    c = G["json_all_types"]
+    b, schema = item_to_batch(c["item"])
+    assert [m.decode() for m in _gpu(tf, abi.queue_options(abi.QFMT_JSON), b)] == [c["value"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", [abi.QFMT_NATIVE, abi.QFMT_JSON])
+def test_gpu_queue_batching_table(tf, fmt):
+    _check_batching(lambda o, b, s: _gpu(tf, o, b), fmt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 20011])
+def test_gpu_queue_matches_oracle(tf, oracle, n):
+    rng = np.random.default_rng(900 + n)
+    b, schema, meta = _random_case(rng, n)
+    db = tf.DeviceBatch.upload(b)
+    groups = [n] if n < 3 else [n // 3, 0, n - n // 3]
+    variants = [
+        dict(fmt=abi.QFMT_NATIVE, table_schema=schema),
+        dict(fmt=abi.QFMT_NATIVE, omit_table_schema=True, old_key_types=["int64", "utf8"], enabled=True, max_change_items=7),
+        dict(fmt=abi.QFMT_NATIVE, table_schema_json='[{"x":1}]', enabled=True, max_message_size=3000, group_rows=groups, group_part_ids=["p<%d>" % i for i in range(len(groups))]),
+        dict(fmt=abi.QFMT_NATIVE, omit_table_schema=True, enabled=True, max_message_size=1500, max_change_items=3, group_rows=groups),
+    ]
+    for v in variants:
+        o = abi.queue_options(v.pop("fmt"), **v)
+        ref = oracle.queue_serialize(o, b, schema, meta)
+        assert ref is not None
+        res = tf.queue_serialize(o, db, meta)
+        got = res.messages()
+        assert len(got) == len(ref), (v, len(got), len(ref))
+        for i, (x, y) in enumerate(zip(got, ref)):
+            if x != y:
+                k = next((j for j in range(min(len(x), len(y))) if x[j] != y[j]), min(len(x), len(y)))
+                raise AssertionError(f"{v}: message {i} differs at byte {k}: gpu={x[max(0,k-80):k+80]!r} ref={y[max(0,k-80):k+80]!r}")
+        assert list(res.msg_row) == oracle.queue_serialize.rows
+    # JSON format: inserts only (update / delete fail the call like the reference), with a non-row item in the middle
+    b.kind = np.where(rng.random(n) < 0.1, abi.K_OTHER, abi.K_INSERT).astype(np.uint8)
+    db = tf.DeviceBatch.upload(b)
+    for v in (dict(), dict(enabled=True, max_change_items=5), dict(enabled=True, max_message_size=700, group_rows=groups)):
+        o = abi.queue_options(abi.QFMT_JSON, **v)
+        ref = oracle.queue_serialize(o, b, schema)
+        assert ref is not None and tf.queue_serialize(o, db, None).messages() == ref, v
+
+
+@pytest.mark.gpu
+def test_gpu_queue_errors_and_empty(tf, oracle):
+    schema = abi.Schema.of([["k", "int32", True]])
+    b = abi.batch_from_rows(schema, ["k"], [[["int32", 1]], [["int32", 2]]], "", "t", ["insert", "update"])
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.queue_serialize(abi.queue_options(abi.QFMT_JSON), tf.DeviceBatch.upload(b), None)
+    assert ei.value.code == tf.ERR_UNSUPPORTED
+    b.kind = np.array([abi.K_INSERT, abi.K_OTHER], np.uint8)
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.queue_serialize(abi.queue_options(abi.QFMT_NATIVE), tf.DeviceBatch.upload(b), None)
+    assert ei.value.code == tf.ERR_UNSUPPORTED
+    e = abi.Batch([abi.Column("a", "int32", abi.R_INT32, values=np.zeros(0, np.int32))], 0, "", "t")
+    for fmt in (abi.QFMT_NATIVE, abi.QFMT_JSON):
+        assert tf.queue_serialize(abi.queue_options(fmt), tf.DeviceBatch.upload(e), None).messages() == []
+    fs = abi.Schema.of([["f", "double", False]])
+    bn = abi.batch_from_rows(fs, ["f"], [[["float64", 1.5]], [["float64", float("inf")]]], "", "t")
+    assert oracle.queue_serialize(abi.queue_options(abi.QFMT_NATIVE), bn, fs) is None
+    with pytest.raises(tf.TfgpuError):
+        tf.queue_serialize(abi.queue_options(abi.QFMT_NATIVE), tf.DeviceBatch.upload(bn), None)

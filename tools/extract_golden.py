@@ -662,6 +662,59 @@ def keys_changed():
                                 "keys_changed": cases, "split": {"ref": "change_item_test.go:1294", "items": changes, "expected": expected}})
 
 
+# ---------------------------------------------------------------------------
+# queue serializers: pkg/serializer/queue native_serializer_test.go:18-87, json_serializer_test.go:32-141,
+# test.go:36-114 (commonTest table, native_batcher_test.go / json_batcher_test.go sizers),
+# pkg/abstract/changeitem/change_item_test.go:1445-1455 (TestMarshalJSON)
+# ---------------------------------------------------------------------------
+def queue_serializers():
+    q = REF + "/pkg/serializer/queue/gotest/canondata/"
+    res = canon(q + "result.json", "gotest.gotest.TestNativeSerializerTopicName/saveTxOrder-enabled")
+    key = res['""'][0]
+    with open(q + "gotest.gotest.TestNativeSerializerTopicName_saveTxOrder-enabled/extracted") as f:
+        native_value = f.read()
+    with open(q + "gotest.gotest.TestNativeSerializerTopicName_saveTxOrder-disabled/extracted") as f:
+        assert f.read() == native_value
+    # nativeSerializerTestTypicalChangeItem with Table = "table1" (both variables alias one item)
+    native_item = {"ns": "public", "table": "table1", "schema": [["id", "int32", True], ["val", "int32", False]], "names": ["id", "val"],
+                   "original_types": {"id": "pg:integer", "val": "pg:integer"},
+                   "rows": [[["int32", 1], ["int32", -8388605]]] * 2, "kinds": ["insert"] * 2}
+    native_meta = {"ids": [601] * 2, "lsns": [25051056] * 2, "commit_times": [1643660670333075000] * 2, "counters": [0] * 2}
+    jres = canon(q + "result.json", "gotest.gotest.TestJSONSerializerTopicNameAllTypes")
+    with open(q + "gotest.gotest.TestJSONSerializerTopicNameAllTypes/extracted") as f:
+        json_value = f.read()
+    all_schema = [["val_int64", "int64", False], ["val_int32", "int32", False], ["val_int16", "int16", False], ["val_int8", "int8", False],
+                  ["val_uint64", "uint64", False], ["val_uint32", "uint32", False], ["val_uint16", "uint16", False], ["val_uint8", "uint8", False],
+                  ["val_float", "float", False], ["val_double", "double", False], ["val_string", "string", False], ["val_utf8", "utf8", False],
+                  ["val_boolean", "boolean", False], ["val_any", "any", False], ["val_date", "date", False], ["val_datetime", "datetime", False],
+                  ["val_timestamp", "timestamp", False], ["val_interval", "interval", False]]
+    all_vals = [["int64", -1234567899123456789], ["int32", -123456789], ["int16", -12345], ["int8", -123], ["uint64", 123456789123456789],
+                ["uint32", 123456789], ["uint16", 12345], ["uint8", 123], ["float32", 1.23], ["float64", 1.234], ["string", "bla bla bla"],
+                ["string", "utf8 bla bla bla"], ["bool", True], ["json", "{\"123\":123,\"key\":\"val\"}"], ["time", "2021-02-03T00:00:00Z"],
+                ["time", "2021-03-04T05:06:07.000000008Z"], ["duration", 1000000123], ["duration", 1000000321]]
+    json_item = {"ns": "public", "table": "table0", "schema": all_schema, "names": [c[0] for c in all_schema], "rows": [all_vals], "kinds": ["insert"]}
+    # TestMarshalJSON: testChangeItem (change_item_test.go), canon = json.MarshalIndent of the same MarshalJSON bytes
+    with open(REF + "/pkg/abstract/changeitem/gotest/canondata/gotest.gotest.TestMarshalJSON/extracted") as f:
+        mj = json.load(f)
+    marshal_item = {"ns": "schema", "table": "table", "schema": [["a", "utf8", True], ["b", "utf8", True]], "names": ["a", "b"],
+                    "rows": [[["string", "av"], ["string", "bv"]]], "kinds": ["insert"],
+                    "old_keys": {"names": ["a", "b"], "types": ["at", "bt"], "rows": [[["string", "av"], ["string", "bv"]]]}}
+    marshal_meta = {"ids": [100], "lsns": [200], "commit_times": [1961], "counters": [9], "tx_ids": ["tx_id"], "queries": ["query"], "part": "part_id"}
+    # commonTest (test.go:52-114): 5 copies of the master item; size = (k elements fit exactly) + delta
+    master = {"ns": "public", "table": "timmyb32r_test_tm_2174_pg_src2", "schema": [["id", "int32", True], ["val1", "int32", False], ["val2", "int32", False]],
+              "names": ["id", "val1", "val2"], "rows": [[["int32", 4], ["int32", 5], ["int32", 6]]] * 5, "kinds": ["insert"] * 5}
+    table = [  # [enabled, MaxChangeItems, [k, delta] or null, expected #messages]
+        [False, 0, None, 5], [True, 1, None, 5], [True, 2, None, 3], [True, 0, [0, 1], 5], [True, 0, [1, 0], 5], [True, 0, [2, -1], 5],
+        [True, 0, [2, 0], 3], [True, 0, [2, 1], 3], [True, 0, [3, -1], 3], [True, 0, [3, 0], 2], [True, 0, [3, 1], 2],
+        [True, 1, [2, 0], 5], [True, 2, [2, 0], 3], [True, 2, [2, 0], 3], [True, 2, [1, 0], 5]]
+    write("queue_serializers.json", {
+        "native_topic_name": {"item": native_item, "meta": native_meta, "key": key, "value": native_value},
+        "json_all_types": {"item": json_item, "key": jres[0]["Keys"][0], "value": json_value},
+        "marshal_json": {"item": marshal_item, "meta": marshal_meta, "table_schema_json": json.dumps(mj["table_schema"], separators=(",", ":")),
+                         "value": json.dumps(mj, separators=(",", ":"))},
+        "batching": {"item": master, "table": table}})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -675,4 +728,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers()

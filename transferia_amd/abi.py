@@ -140,6 +140,88 @@ def serialize_options(add_closing_newline=False, any_as_string=False, ch_types=N
     return o
 
 
+QFMT_NATIVE, QFMT_JSON = 1, 2
+
+
+class CRowMeta(C.Structure):
+    _fields_ = [("id", C.c_void_p), ("lsn", C.c_void_p), ("commit_time", C.c_void_p), ("counter", C.c_void_p),
+                ("tx_id_offsets", C.c_void_p), ("tx_id_data", C.c_void_p), ("query_offsets", C.c_void_p), ("query_data", C.c_void_p),
+                ("names_form", C.c_void_p), ("n", C.c_int64), ("mem", C.c_int32)]
+
+
+class CQueueOptions(C.Structure):
+    _fields_ = [("format", C.c_int32), ("batching_enabled", C.c_int32), ("max_change_items", C.c_int32), ("max_message_size", C.c_int64),
+                ("table_schema_json", C.c_char_p), ("table_schema", C.POINTER(CSchema)), ("omit_table_schema", C.c_int32),
+                ("old_key_types", C.POINTER(C.c_char_p)), ("ngroups", C.c_int32), ("group_rows", C.c_void_p), ("group_part_ids", C.POINTER(C.c_char_p))]
+
+
+def _var(strings, n):
+    parts = [_b(x) for x in strings]
+    off = np.zeros(n + 1, np.uint32)
+    if n:
+        off[1:] = np.cumsum([len(x) for x in parts])
+    dat = np.frombuffer(b"".join(parts) or b"\0", np.uint8).copy()
+    return off, dat
+
+
+def row_meta(n, ids=None, lsns=None, commit_times=None, counters=None, tx_ids=None, queries=None, names_form=None) -> CRowMeta:
+    """The ChangeItem fields that are not columns, one entry per pipeline INPUT row (HOST memory)."""
+    m = CRowMeta()
+    keep = []
+
+    def arr(v, dt):
+        if v is None:
+            return None
+        a = np.ascontiguousarray(v, dtype=dt)
+        assert len(a) == n
+        keep.append(a)
+        return a.ctypes.data if n else None
+    m.id, m.lsn, m.commit_time, m.counter = arr(ids, np.uint32), arr(lsns, np.uint64), arr(commit_times, np.uint64), arr(counters, np.int64)
+    m.names_form = arr(names_form, np.uint8)
+    if tx_ids is not None:
+        off, dat = _var(tx_ids, n)
+        keep += [off, dat]
+        m.tx_id_offsets, m.tx_id_data = off.ctypes.data, dat.ctypes.data
+    if queries is not None:
+        off, dat = _var(queries, n)
+        keep += [off, dat]
+        m.query_offsets, m.query_data = off.ctypes.data, dat.ctypes.data
+    m.n, m.mem = n, MEM_HOST
+    m._keep = keep
+    return m
+
+
+def queue_options(fmt, enabled=False, max_change_items=0, max_message_size=0, table_schema_json=None, table_schema: "Schema" = None,
+                  omit_table_schema=False, old_key_types=None, group_rows=None, group_part_ids=None) -> CQueueOptions:
+    """model.Batching + what ChangeItem.MarshalJSON needs beyond the batch (queue serializers)."""
+    o = CQueueOptions()
+    o.format, o.batching_enabled, o.max_change_items, o.max_message_size = int(fmt), int(bool(enabled)), int(max_change_items), int(max_message_size)
+    keep = []
+    if table_schema_json is not None:
+        t = _b(table_schema_json)
+        keep.append(t)
+        o.table_schema_json = t
+    if table_schema is not None:
+        cs = table_schema.to_c()
+        keep.append(cs)
+        o.table_schema = C.pointer(cs)
+    o.omit_table_schema = int(bool(omit_table_schema))
+    if old_key_types is not None:
+        a = (C.c_char_p * max(len(old_key_types), 1))(*[_b(x) for x in old_key_types])
+        keep.append(a)
+        o.old_key_types = a
+    if group_rows is not None:
+        g = np.ascontiguousarray(group_rows, dtype=np.int64)
+        keep.append(g)
+        o.ngroups, o.group_rows = len(g), g.ctypes.data
+    if group_part_ids is not None:
+        a = (C.c_char_p * max(len(group_part_ids), 1))(*[_b(x) for x in group_part_ids])
+        keep.append(a)
+        o.group_part_ids = a
+    o._keep = keep
+    return o
+
+
 def _b(s) -> bytes:
     return s if isinstance(s, bytes) else str(s).encode("utf-8")
 

@@ -23,6 +23,27 @@ struct SCol {
   uint32_t pre_off, pre_len;  // key / separator bytes emitted before the value
   uint32_t ch_flags;          // TFGPU_CH_*
   uint32_t prec;              // DateTime64 precision
+  uint32_t kind;              // queue formats: QC_*
+  uint32_t apply;             // queue formats: QA_* (which rows hold this cell)
+};
+// queue formats (tfgpu_queue_serialize): a row is a list of cells — header, constants, values, old-key values, trailer
+enum { QC_VALUE = 0, QC_HEADER = 1, QC_CONST = 2, QC_TRAILER = 3 };
+enum { QA_ALWAYS = 0, QA_NAMES = 1 /* names_form == 0 */, QA_OLD = 2 /* the row has OldKeys */, QA_ROW_EVENT = 3 /* kind != other */ };
+constexpr uint32_t QCONST_INLINE = 64;  // constants up to this many bytes are written by the cell's lane, longer ones by ser_fill_const
+
+struct QueueParams {
+  int32_t qformat;               // 0 = not a queue format, else TFGPU_QFMT_*
+  int32_t has_old;
+  const uint8_t *kind;           // [nrows] or null
+  const int32_t *src_row;        // [nrows] or null
+  const uint32_t *part_id;       // [nrows] or null
+  const uint8_t *old_present;    // bitmap or null
+  const uint32_t *m_id; const uint64_t *m_lsn, *m_commit; const int64_t *m_counter;   // row meta, indexed by src_row
+  const uint32_t *m_tx_off; const uint8_t *m_tx; const uint32_t *m_q_off; const uint8_t *m_q; const uint8_t *m_form;
+  uint32_t hdr_off, hdr_len;     // `,"schema":…,"table":…,"part":` in the blob
+  int32_t ngroups;               // group part ids: rows [gstart[g], gstart[g+1]) carry blob[gpart[g] .. gpart[g+1])
+  const int64_t *gstart; const uint32_t *gpart;
+  const uint8_t *msg_flags;      // [nrows]: bit 0 = first row of its message, bit 1 = last
 };
 
 struct SerParams {
@@ -36,6 +57,7 @@ struct SerParams {
   int32_t *last_present;   // CH: index of the last emitted column per row, -1 = none
   unsigned long long *total64;  // sum of the row lengths (the offsets are 32-bit)
   uint8_t *out;
+  QueueParams q;
 };
 
 // strconv.ParseFloat(s, 64) overflows to ±Inf (err = ErrRange) exactly when |s| >= 2^1024 - 2^970
@@ -211,7 +233,74 @@ template <class S> __device__ void emit_csv_field(S &s, const SCol &sc, int64_t 
   }
 }
 
+// ---- queue formats: ChangeItem.MarshalJSON (change_item.go:568-616) as json.Marshal compacts it, and the queue JSON rows ----
+__device__ __forceinline__ bool q_applies(const SerParams &p, uint32_t apply, int64_t r) {
+  switch (apply) {
+    case QA_NAMES: return !p.q.m_form || p.q.m_form[p.q.src_row ? p.q.src_row[r] : r] == 0;
+    case QA_OLD: return p.q.has_old && (!p.q.old_present || ((p.q.old_present[r >> 3] >> (r & 7)) & 1));
+    case QA_ROW_EVENT: return !p.q.kind || p.q.kind[r] != TFGPU_K_OTHER;
+    default: return true;
+  }
+}
+// bytes a Marshaler returned, as json.Marshal's compact(escapeHTML) leaves them: <, >, & and U+2028/9 become \uXXXX
+template <class S> __device__ void put_html_compact(S &s, const uint8_t *p, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = p[i];
+    if (c == '<' || c == '>' || c == '&') { put_lit(s, "\\u00"); s.put(hexc(c >> 4)); s.put(hexc(c & 15)); }
+    else if (c == 0xE2 && i + 2 < n && p[i + 1] == 0x80 && (p[i + 2] & 0xFE) == 0xA8) { put_lit(s, "\\u202"); s.put(hexc(p[i + 2] & 0xF)); i += 2; }
+    else s.put(c);
+  }
+}
+template <class S> __device__ void emit_meta_string(S &s, const uint32_t *off, const uint8_t *data, int64_t k) {
+  if (!off) { s.put('"'); s.put('"'); return; }
+  emit_json_string(s, data + off[k], off[k + 1] - off[k], true);
+}
+template <class S> __device__ void emit_native_header(S &s, const SerParams &p, int64_t r) {
+  const QueueParams &q = p.q;
+  const int64_t k = q.src_row ? q.src_row[r] : r;
+  uint8_t t[24]; int n;
+  put_lit(s, "{\"id\":"); n = dev::fmt_u64(t, q.m_id ? q.m_id[k] : 0u); emit_small(s, t, n);
+  put_lit(s, ",\"nextlsn\":"); n = dev::fmt_u64(t, q.m_lsn ? q.m_lsn[k] : 0ull); emit_small(s, t, n);
+  put_lit(s, ",\"commitTime\":"); n = dev::fmt_u64(t, q.m_commit ? q.m_commit[k] : 0ull); emit_small(s, t, n);
+  put_lit(s, ",\"txPosition\":"); n = dev::fmt_i64(t, q.m_counter ? q.m_counter[k] : 0ll); emit_small(s, t, n);
+  const uint32_t kd = q.kind ? q.kind[r] : (uint32_t)TFGPU_K_INSERT;
+  put_lit(s, ",\"kind\":\""); put_lit(s, kd == TFGPU_K_INSERT ? "insert" : kd == TFGPU_K_UPDATE ? "update" : "delete"); s.put('"');
+  put_bytes(s, p.blob + q.hdr_off, q.hdr_len);
+  if (q.gpart) {  // PartID of the row's group, already a JSON string
+    int g = 0; while (g + 1 < q.ngroups && r >= q.gstart[g + 1]) g++;
+    put_bytes(s, p.blob + q.gpart[g], q.gpart[g + 1] - q.gpart[g]);
+  } else { s.put('"'); if (q.part_id) { n = dev::fmt_u64(t, q.part_id[r]); emit_small(s, t, n); } s.put('"'); }
+  const uint32_t form = q.m_form ? q.m_form[k] : 0u;
+  if (form == 1) put_lit(s, ",\"columnnames\":null"); else if (form != 0) put_lit(s, ",\"columnnames\":[]");
+}
+template <class S> __device__ void emit_native_trailer(S &s, const SerParams &p, int64_t r) {
+  const QueueParams &q = p.q;
+  const int64_t k = q.src_row ? q.src_row[r] : r;
+  if (q_applies(p, QA_OLD, r)) s.put(']');
+  s.put('}');
+  put_lit(s, ",\"tx_id\":"); emit_meta_string(s, q.m_tx_off, q.m_tx, k);
+  put_lit(s, ",\"query\":"); emit_meta_string(s, q.m_q_off, q.m_q, k);
+  s.put('}');
+}
+template <class S> __device__ bool emit_queue_cell(S &s, const SerParams &p, const SCol &sc, int64_t r) {
+  if (!q_applies(p, sc.apply, r)) return false;
+  switch (sc.kind) {
+    case QC_HEADER: emit_native_header(s, p, r); return true;
+    case QC_TRAILER: emit_native_trailer(s, p, r); return true;
+    case QC_CONST: put_bytes(s, p.blob + sc.pre_off, sc.pre_len); return true;
+    default: break;
+  }
+  put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
+  if (p.q.qformat == TFGPU_QFMT_NATIVE) {  // encoding/json with escapeHTML on; a pre-marshalled `any` passes through compact()
+    const DCol &c = sc.c;
+    if (c.repr == TFGPU_R_JSON && is_valid(c, r)) put_html_compact(s, c.data + c.offsets[r], c.offsets[r + 1] - c.offsets[r]);
+    else emit_json_cell(s, c, r, 0, true);
+  } else emit_json_cell(s, sc.c, r, 0, false);  // serializeQueueItemToJSON: AnyAsString off, SetEscapeHTML(false)
+  return true;
+}
+
 template <class S> __device__ __forceinline__ bool emit_cell(S &s, const SerParams &p, const SCol &sc, int64_t r) {
+  if (p.q.qformat) return emit_queue_cell(s, p, sc, r);
   switch (p.format) {
     case TFGPU_FMT_CH_JSON_EACH_ROW: {
       if (!is_valid(sc.c, r)) return false;  // nil values are omitted (marshal.go:100-102)
@@ -237,6 +326,7 @@ __global__ void __launch_bounds__(256) ser_cell_len(SerParams p) {
   const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= (int64_t)p.ncols * p.nrows) return;
   const int32_t ci = (int32_t)(it / p.nrows); const int64_t r = it - (int64_t)ci * p.nrows;
+  if (p.q.qformat && p.cols[ci].kind == QC_CONST) { p.cell[it] = q_applies(p, p.cols[ci].apply, r) ? p.cols[ci].pre_len : 0u; return; }
   CountSink s;
   const bool present = emit_cell(s, p, p.cols[ci], r);
   uint32_t n = present ? s.n : 0;
@@ -248,6 +338,7 @@ __global__ void __launch_bounds__(256) ser_row_layout(SerParams p) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.nrows) return;
   uint32_t off = (p.format == TFGPU_FMT_CSV) ? 0u : 1u;  // '{'
+  if (p.q.qformat) off = p.q.qformat == TFGPU_QFMT_NATIVE ? 1u : 0u;  // '[' or ',' in front of every native element
   int32_t last = -1;
   for (int32_t c = 0; c < p.ncols; c++) {
     const uint32_t n = p.cell[(int64_t)c * p.nrows + r];
@@ -256,6 +347,7 @@ __global__ void __launch_bounds__(256) ser_row_layout(SerParams p) {
     off += n;
   }
   uint32_t tail;
+  if (p.q.qformat) { p.row_len[r] = off; return; }  // element length (+ lead byte); the message frame is added once the cut plan is known
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW) tail = last < 0 ? 2u : 1u;                       // "}\n" or "\n" (the '}' replaced a ',')
   else if (p.format == TFGPU_FMT_JSON) tail = 1u + ((p.closing_newline || r + 1 < p.nrows) ? 1u : 0u);  // '}' + newline / separator
   else tail = 1u;                                                                                // '\n'
@@ -269,6 +361,7 @@ __global__ void __launch_bounds__(256) ser_cell_write(SerParams p) {
   if (it >= (int64_t)p.ncols * p.nrows) return;
   const int32_t ci = (int32_t)(it / p.nrows); const int64_t r = it - (int64_t)ci * p.nrows;
   const SCol &sc = p.cols[ci];
+  if (p.q.qformat && ((sc.kind == QC_CONST && sc.pre_len > QCONST_INLINE) || !q_applies(p, sc.apply, r))) return;
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW && !is_valid(sc.c, r)) return;
   const uint64_t base = (uint64_t)p.row_len[r] + p.cell[it];
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW) {
@@ -298,16 +391,58 @@ __global__ void __launch_bounds__(256) ser_row_frame(SerParams p) {
   if (nl) row[len - 1] = '\n';
 }
 
+// queue formats: the message frame once the cut plan is known.  Native: "[" before the first element of a message, ","
+// before the others, "]" after the last; JSON: "\n" after every element but the last of its message.
+__global__ void __launch_bounds__(256) ser_queue_tail_len(SerParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  const bool last = p.q.msg_flags[r] & 2;
+  p.row_len[r] += (p.q.qformat == TFGPU_QFMT_NATIVE) ? (last ? 1u : 0u) : (last ? 0u : 1u);
+}
+__global__ void __launch_bounds__(256) ser_queue_frame(SerParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  uint8_t *row = p.out + p.row_len[r];
+  const uint32_t len = p.row_len[r + 1] - p.row_len[r];
+  const uint32_t f = p.q.msg_flags[r];
+  if (p.q.qformat == TFGPU_QFMT_NATIVE) { row[0] = (f & 1) ? '[' : ','; if (f & 2) row[len - 1] = ']'; }
+  else if (!(f & 2)) row[len - 1] = '\n';
+}
+// A long constant cell (column names, table schema) of every row: one workgroup per (row, 4 KiB chunk), 16 bytes per lane,
+// so a wave stores 1 KiB of consecutive bytes per step instead of one lane walking kilobytes.
+__global__ void __launch_bounds__(256) ser_fill_const(SerParams p, int32_t ci, uint32_t chunks) {
+  const int64_t r = blockIdx.x / chunks; const uint32_t ch = blockIdx.x % chunks;
+  const SCol &sc = p.cols[ci];
+  if (!q_applies(p, sc.apply, r)) return;
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  const uint8_t *src = p.blob + sc.pre_off;
+  uint8_t *dst = p.out + (uint64_t)p.row_len[r] + p.cell[(int64_t)ci * p.nrows + r];
+  const uint32_t o = ch * 4096u + threadIdx.x * 16u;
+  if (o >= sc.pre_len) return;
+  if (o + 16u <= sc.pre_len) {
+    const uint64_t a = reinterpret_cast<const U64 *>(src + o)->v, b = reinterpret_cast<const U64 *>(src + o + 8)->v;
+    reinterpret_cast<U64 *>(dst + o)->v = a; reinterpret_cast<U64 *>(dst + o + 8)->v = b;
+  } else for (uint32_t i = o; i < sc.pre_len; i++) dst[i] = src[i];
+}
+// which row kinds occur (bit k = kind k), and whether every src_row indexes the row meta
+__global__ void queue_check_kernel(const uint8_t *kind, const int32_t *src_row, int64_t n, int64_t meta_n, uint32_t *flags) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint32_t f = 1u << (kind ? (kind[r] & 3u) : 0u);
+  if (meta_n >= 0) { const int64_t k = src_row ? src_row[r] : r; if (k < 0 || k >= meta_n) f |= 16u; }
+  if ((f & ~*flags) != 0) atomicOr(flags, f);
+}
+
 static inline unsigned blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + 255) / 256); }
 
 // host-side escaping of a column name the way encoding/json writes a map key (escapeHTML=false)
-static void json_key(std::string &out, const std::string &k) {
+static void json_key(std::string &out, const std::string &k, bool html = false) {
   static const char *hex = "0123456789abcdef";
   out += '"';
   for (size_t i = 0; i < k.size();) {
     unsigned char c = (unsigned char)k[i];
     if (c < 0x80) {
-      if (c >= 0x20 && c != '"' && c != '\\') out += (char)c;
+      if (c >= 0x20 && c != '"' && c != '\\' && !(html && (c == '<' || c == '>' || c == '&'))) out += (char)c;
       else switch (c) {
         case '"': out += "\\\""; break; case '\\': out += "\\\\"; break; case '\b': out += "\\b"; break; case '\f': out += "\\f"; break;
         case '\n': out += "\\n"; break; case '\r': out += "\\r"; break; case '\t': out += "\\t"; break;
@@ -458,3 +593,243 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
 }
 
 extern "C" int tfgpu_serialize(int format, const tfgpu_dbatch *b, tfgpu_dbuf **out) { return tfgpu_serialize_ex(format, b, nullptr, out); }
+
+// ======================================================================================================
+// tfgpu_queue_serialize — pkg/serializer/queue: NativeSerializer / JSONSerializer for one table's rows.
+// Same four passes as tfgpu_serialize_ex over a longer cell list (header, constants, values, old-key values, trailer);
+// between the length pass and the scan the element lengths go to the host once, where BatchNative / BatchJSON's greedy
+// cut (native_batcher.go:10-63, json_batcher.go:11-66) runs over them — it is the reference's own sequential loop over
+// integers — and the cut comes back as one flag byte per row.
+// ======================================================================================================
+namespace tf {
+
+static const char *const QDTYPE_NAMES[] = {"", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float", "double",
+                                           "boolean", "string", "utf8", "date", "datetime", "timestamp", "interval", "any"};
+
+static void json_string_array(std::string &out, const std::vector<std::string> &v) {
+  out += '[';
+  for (size_t i = 0; i < v.size(); i++) { if (i) out += ','; json_key(out, v[i], true); }
+  out += ']';
+}
+// json.Marshal([]ColSchema): col_schema.go:14-29 (Properties omitempty; the fields the ABI schema does not carry are zero)
+static void table_schema_json(std::string &out, const tfgpu_queue_options *o, const tfgpu_dbatch *b) {
+  struct Col { std::string name, path, ot; int dtype; bool key, req; };
+  std::vector<Col> cols;
+  if (o->table_schema) {
+    for (int i = 0; i < o->table_schema->ncols; i++) {
+      const tfgpu_colschema &c = o->table_schema->cols[i];
+      cols.push_back({c.name ? c.name : "", c.path ? c.path : "", c.original_type ? c.original_type : "", c.dtype, (c.flags & TFGPU_COL_KEY) != 0, (c.flags & TFGPU_COL_REQUIRED) != 0});
+    }
+  } else {
+    auto is_key = [&](const std::string &n) { for (auto &k : b->key_names) if (k == n) return true; return false; };
+    if (!b->schema.empty()) for (auto &pr : b->schema) cols.push_back({pr.first, "", "", pr.second, is_key(pr.first), false});
+    else for (auto &c : b->cols) cols.push_back({c.name, "", "", c.dtype, is_key(c.name), false});
+  }
+  if (cols.empty()) return;  // len(c.TableSchema.columns) == 0: the key is omitted
+  out += ",\"table_schema\":[";
+  for (size_t i = 0; i < cols.size(); i++) {
+    const Col &c = cols[i];
+    if (i) out += ',';
+    out += "{\"table_schema\":\"\",\"table_name\":\"\",\"path\":"; json_key(out, c.path, true);
+    out += ",\"name\":"; json_key(out, c.name, true);
+    out += ",\"type\":"; json_key(out, c.dtype > 0 && c.dtype < TFGPU_T__COUNT ? QDTYPE_NAMES[c.dtype] : "", true);
+    out += ",\"key\":"; out += c.key ? "true" : "false";
+    out += ",\"fake_key\":false,\"required\":"; out += c.req ? "true" : "false";
+    out += ",\"expression\":\"\",\"original_type\":"; json_key(out, c.ot, true);
+    out += '}';
+  }
+  out += ']';
+}
+
+// BatchNative / BatchJSON over one group: flags[i] |= 1 first, 2 last of its message
+static void queue_cut_plan(const tfgpu_queue_options *o, const uint32_t *elem_len, int64_t n, uint32_t lead, uint8_t *flags) {
+  if (n == 0) return;
+  if (!o->batching_enabled) { for (int64_t i = 0; i < n; i++) flags[i] = 3; return; }
+  const uint64_t wrap = o->format == TFGPU_QFMT_NATIVE ? 2 : 0;
+  auto emit = [&](int64_t a, int64_t z) { flags[a] |= 1; flags[z - 1] |= 2; };
+  int64_t start = 0; uint64_t sum = 0;
+  for (int64_t i = 0; i < n; i++) {
+    const uint64_t len = elem_len[i] - lead;
+    const int64_t num_new = i - start + 1;
+    bool violates = false;
+    if (o->max_message_size != 0 && sum + (uint64_t)(num_new - 1) + len + wrap > (uint64_t)o->max_message_size) violates = true;
+    if (o->max_change_items != 0 && num_new > o->max_change_items) violates = true;
+    if (violates) {
+      if (i - start == 0) { emit(start, start + 1); start = i + 1; sum = 0; }
+      else { emit(start, i); start = i; sum = len; }
+    } else sum += len;
+  }
+  if (start != n) emit(start, n);
+}
+
+template <class T> static const T *meta_array(const tfgpu_row_meta *m, const T *p, size_t count, std::vector<Buf> &keep) {
+  if (!p) return nullptr;
+  if (m->mem == TFGPU_MEM_DEVICE) return p;
+  Buf d = dalloc(count * sizeof(T) + 16);
+  h2d(d->p, p, count * sizeof(T));
+  keep.push_back(d);
+  return reinterpret_cast<const T *>(d->p);
+}
+
+}  // namespace tf
+
+extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_dbatch *b, const tfgpu_row_meta *meta, tfgpu_dbuf **values,
+                                     uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
+  try {
+    if (!o || !b || !values || !nmsg || (cap > 0 && (!msg_start || !msg_row))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: null argument");
+    if (o->format != TFGPU_QFMT_NATIVE && o->format != TFGPU_QFMT_JSON) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: unknown format");
+    const bool native = o->format == TFGPU_QFMT_NATIVE;
+    Context &cx = ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    hipStream_t st = cx.stream;
+    const int64_t n = b->nrows;
+    const int ncols = (int)b->cols.size(), nold = native ? (int)b->old_keys.size() : 0;
+    // groups: contiguous row runs, each serialised on its own (splitByTablePartID)
+    std::vector<int64_t> gstart{0};
+    if (o->group_rows) { for (int g = 0; g < o->ngroups; g++) { if (o->group_rows[g] < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: negative group size"); gstart.push_back(gstart.back() + o->group_rows[g]); } }
+    else gstart.push_back(n);
+    if (gstart.back() != n) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: group_rows do not add up to the batch's rows");
+    if (meta && meta->n < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: row meta with a negative length");
+    auto res = std::make_unique<tfgpu_dbuf>();
+    if (n == 0) { res->mem = dalloc(64); res->size = 0; *values = res.release(); *nmsg = 0; if (cap >= 0 && msg_start) { msg_start[0] = 0; msg_row[0] = 0; } return TFGPU_OK; }
+    materialize(*b);
+
+    // ---- what must fail the call before any text exists: kinds, meta range, NaN / Inf ----
+    Buf flags = dalloc_zero(8);
+    queue_check_kernel<<<blocks(n), 256, 0, st>>>(ptr<uint8_t>(b->kind), ptr<int32_t>(b->src_row), n, (native && meta) ? meta->n : -1, ptr<uint32_t>(flags));
+    auto nonfinite = [&](const DColumn &c) {
+      if (c.repr != TFGPU_R_FLOAT32 && c.repr != TFGPU_R_FLOAT64) return;
+      float_nonfinite_kernel<<<blocks(n), 256, 0, st>>>(c.values->p, n, c.repr == TFGPU_R_FLOAT32, ptr<uint8_t>(c.validity), ptr<uint32_t>(flags) + 1);
+    };
+    for (auto &c : b->cols) nonfinite(c);
+    for (int k = 0; k < nold; k++) nonfinite(b->old_keys[(size_t)k]);
+    {
+      const uint32_t *h = d2h_u32(flags->p, 2);
+      tf::sync();
+      if (h[0] & 16u) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: src_row outside the row meta");
+      if (native && (h[0] & 8u)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: non-row kinds are serialised by the stock NativeSerializer");
+      if (!native && (h[0] & 6u)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "JsonSerializer: unsupported kind: update / delete (json.go:54-56)");
+      if (h[1]) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: json: unsupported value: NaN or Inf");
+    }
+
+    // ---- the cell list ----
+    std::string blob;
+    std::vector<SCol> sc;
+    auto add = [&](uint32_t kind, uint32_t apply, const std::string &pre, const DColumn *col) {
+      SCol s{};
+      if (col) s.c = dcol_of(*col);
+      s.pre_off = (uint32_t)blob.size(); blob += pre; s.pre_len = (uint32_t)pre.size();
+      s.kind = kind; s.apply = apply;
+      sc.push_back(s);
+    };
+    QueueParams q{};
+    q.qformat = o->format;
+    std::vector<int> order((size_t)ncols);
+    for (int i = 0; i < ncols; i++) order[(size_t)i] = i;
+    if (native) {
+      add(QC_HEADER, QA_ALWAYS, "", nullptr);
+      { std::string t = ",\"schema\":"; json_key(t, b->ns, true); t += ",\"table\":"; json_key(t, b->table, true); t += ",\"part\":"; q.hdr_off = (uint32_t)blob.size(); q.hdr_len = (uint32_t)t.size(); blob += t; }
+      { std::string t = ",\"columnnames\":"; std::vector<std::string> nm; for (auto &c : b->cols) nm.push_back(c.name); json_string_array(t, nm); if (ncols) t += ",\"columnvalues\":["; add(QC_CONST, QA_NAMES, t, nullptr); }
+      for (int j = 0; j < ncols; j++) add(QC_VALUE, QA_NAMES, j ? "," : "", &b->cols[(size_t)j]);
+      if (ncols) add(QC_CONST, QA_NAMES, "]", nullptr);
+      { std::string t; if (!o->omit_table_schema) { if (o->table_schema_json) { t += ",\"table_schema\":"; t += o->table_schema_json; } else table_schema_json(t, o, b); } t += ",\"oldkeys\":{"; add(QC_CONST, QA_ALWAYS, t, nullptr); }
+      for (int k = 0; k < nold; k++) {
+        std::string t;
+        if (k == 0) {
+          std::vector<std::string> nm, ty; for (auto &c : b->old_keys) nm.push_back(c.name);
+          t = "\"keynames\":"; json_string_array(t, nm);
+          if (o->old_key_types) { for (int i = 0; i < nold; i++) ty.push_back(o->old_key_types[i] ? o->old_key_types[i] : ""); t += ",\"keytypes\":"; json_string_array(t, ty); }
+          t += ",\"keyvalues\":[";
+        } else t = ",";
+        add(QC_VALUE, QA_OLD, t, &b->old_keys[(size_t)k]);
+      }
+      add(QC_TRAILER, QA_ALWAYS, "", nullptr);
+    } else {  // one pkg/serializer/json.go row per element: a map, keys sorted; non-row items are empty elements
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->cols[(size_t)x].name < b->cols[(size_t)y].name; });
+      for (int i = 0; i + 1 < ncols; i++) if (b->cols[(size_t)order[(size_t)i]].name == b->cols[(size_t)order[(size_t)i + 1]].name)
+        return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: duplicate column names");
+      add(QC_CONST, QA_ROW_EVENT, "{", nullptr);
+      for (int j = 0; j < ncols; j++) { const DColumn &c = b->cols[(size_t)order[(size_t)j]]; std::string t; if (j) t += ','; json_key(t, c.name); t += ':'; add(QC_VALUE, QA_ROW_EVENT, t, &c); }
+      add(QC_CONST, QA_ROW_EVENT, "}", nullptr);
+    }
+    const int ncell = (int)sc.size();
+
+    // ---- row meta and group part ids ----
+    std::vector<Buf> keep;
+    q.kind = ptr<uint8_t>(b->kind); q.src_row = ptr<int32_t>(b->src_row); q.part_id = ptr<uint32_t>(b->part_id);
+    q.old_present = ptr<uint8_t>(b->old_present); q.has_old = nold > 0;
+    if (native && meta) {
+      const size_t mn = (size_t)meta->n;
+      q.m_id = meta_array(meta, meta->id, mn, keep); q.m_lsn = meta_array(meta, meta->lsn, mn, keep); q.m_commit = meta_array(meta, meta->commit_time, mn, keep);
+      q.m_counter = meta_array(meta, meta->counter, mn, keep); q.m_form = meta_array(meta, meta->names_form, mn, keep);
+      auto var = [&](const uint32_t *off, const uint8_t *data, const uint32_t *&doff, const uint8_t *&ddata) {
+        if (!off) return;
+        if (meta->mem == TFGPU_MEM_DEVICE) { doff = off; ddata = data; return; }
+        doff = meta_array(meta, off, mn + 1, keep);
+        ddata = (data && off[mn]) ? meta_array(meta, data, (size_t)off[mn], keep) : reinterpret_cast<const uint8_t *>(doff);  // all strings empty: never read
+      };
+      var(meta->tx_id_offsets, meta->tx_id_data, q.m_tx_off, q.m_tx);
+      var(meta->query_offsets, meta->query_data, q.m_q_off, q.m_q);
+    }
+    std::vector<uint32_t> gpart;
+    if (native && o->group_part_ids) {
+      for (size_t g = 0; g + 1 < gstart.size(); g++) { gpart.push_back((uint32_t)blob.size()); json_key(blob, o->group_part_ids[g] ? o->group_part_ids[g] : "", true); }
+      gpart.push_back((uint32_t)blob.size());
+      q.ngroups = (int32_t)gstart.size() - 1;
+      Buf a = upload_small(gstart.data(), gstart.size() * sizeof(int64_t)), c = upload_small(gpart.data(), gpart.size() * sizeof(uint32_t));
+      keep.push_back(a); keep.push_back(c);
+      q.gstart = ptr<int64_t>(a); q.gpart = ptr<uint32_t>(c);
+    }
+
+    Buf bsc = upload_small(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_small(blob.data(), blob.size());
+    Buf cell = dalloc((size_t)ncell * (size_t)n * 4), row_len = dalloc((size_t)(n + 1) * 4 + 16), mflags = dalloc((size_t)n + 16);
+    SerParams p{};
+    p.cols = ptr<SCol>(bsc); p.ncols = ncell; p.nrows = n; p.format = TFGPU_FMT_JSON; p.any_as_string = 0; p.closing_newline = 0;
+    p.blob = ptr<uint8_t>(bblob); p.cell = ptr<uint32_t>(cell); p.row_len = ptr<uint32_t>(row_len); p.last_present = nullptr;
+    Buf tot64 = dalloc_zero(8);
+    p.total64 = reinterpret_cast<unsigned long long *>(tot64->p);
+    q.msg_flags = ptr<uint8_t>(mflags);
+    p.q = q;
+    const int64_t ncells = (int64_t)ncell * n;
+    { KernelTimer t("ser_cell_len"); ser_cell_len<<<blocks(ncells), 256, 0, st>>>(p); }
+    { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
+
+    // ---- the cut plan (host: the batchers' sequential greedy loop over the element lengths) ----
+    std::vector<uint32_t> elen((size_t)n);
+    std::vector<uint8_t> hflags((size_t)n, 0);
+    d2h(elen.data(), p.row_len, (size_t)n * 4);
+    tf::sync();
+    const uint32_t lead = native ? 1u : 0u;
+    for (size_t g = 0; g + 1 < gstart.size(); g++) queue_cut_plan(o, elen.data() + gstart[g], gstart[g + 1] - gstart[g], lead, hflags.data() + gstart[g]);
+    int64_t nm = 0; uint64_t total = 0;
+    for (int64_t r = 0; r < n; r++) {
+      if (hflags[(size_t)r] & 1) { if (nm < cap) { msg_start[nm] = total; msg_row[nm] = r; } nm++; }
+      total += elen[(size_t)r] + (native ? ((hflags[(size_t)r] & 2) ? 1u : 0u) : ((hflags[(size_t)r] & 2) ? 0u : 1u));
+    }
+    if (nm > cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: more messages than msg_start / msg_row hold");
+    if (total >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: output exceeds 4 GiB; split the batch by rows");
+    msg_start[nm] = total; msg_row[nm] = n;
+    h2d(mflags->p, hflags.data(), (size_t)n);
+    ser_queue_tail_len<<<blocks(n), 256, 0, st>>>(p);
+    exclusive_scan_u32(p.row_len, p.row_len, n, true);
+    const uint32_t *htot = d2h_u32(p.row_len + n);
+    tf::sync();  // also: hflags / meta staging vectors may die after this
+    if (*htot != (uint32_t)total) return tf::fail(TFGPU_ERR_DEVICE, "tfgpu_queue_serialize: internal: device and host disagree on the output size");
+    res->size = total;
+    res->mem = dalloc(res->size + 64);
+    p.out = ptr<uint8_t>(res->mem);
+    { KernelTimer t("ser_cell_write"); ser_cell_write<<<blocks(ncells), 256, 0, st>>>(p); }
+    for (int ci = 0; ci < ncell; ci++) if (sc[(size_t)ci].kind == QC_CONST && sc[(size_t)ci].pre_len > QCONST_INLINE) {
+      const uint32_t chunks = (sc[(size_t)ci].pre_len + 4095u) / 4096u;
+      KernelTimer t("ser_fill_const");
+      ser_fill_const<<<(unsigned)(n * chunks), 256, 0, st>>>(p, ci, chunks);
+    }
+    { KernelTimer t("ser_queue_frame"); ser_queue_frame<<<blocks(n), 256, 0, st>>>(p); }
+    tf::sync();  // `keep` (row meta staging) is released on return
+    *nmsg = nm;
+    *values = res.release();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}

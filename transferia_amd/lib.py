@@ -27,7 +27,7 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -88,6 +88,7 @@ def load():
     L.tfgpu_json_result_schema.argtypes = [C.POINTER(abi.CJsonOptions), C.POINTER(abi.CSchema), C.POINTER(C.POINTER(abi.CSchema))]
     L.tfgpu_serialize.argtypes = [C.c_int, P, C.POINTER(P)]
     L.tfgpu_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(P)]
+    L.tfgpu_queue_serialize.argtypes = [C.POINTER(abi.CQueueOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(P), P, P, C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_dbuf_size.argtypes = [P, C.POINTER(C.c_uint64)]
     L.tfgpu_dbuf_ptr.argtypes = [P]
     L.tfgpu_dbuf_ptr.restype = P
@@ -501,6 +502,38 @@ def serialize(fmt: int, batch: DeviceBatch, opts: Optional[abi.CSerializeOptions
     else:
         _check(load().tfgpu_serialize_ex(fmt, batch._h, C.byref(opts), C.byref(out)))
     return DeviceBuffer(out)
+
+
+class QueueMessages:
+    """queue.Serializer output for one table's rows: message values back to back in HBM + where each one starts.
+    Keys stay with the caller: Fqtn() (`schema_table`) when batching is off, nil when it is on."""
+
+    def __init__(self, values: DeviceBuffer, msg_start: np.ndarray, msg_row: np.ndarray):
+        self.values, self.msg_start, self.msg_row = values, msg_start, msg_row
+
+    def __len__(self):
+        return len(self.msg_start) - 1
+
+    def messages(self) -> List[bytes]:
+        raw = self.values.download()
+        return [raw[int(self.msg_start[i]):int(self.msg_start[i + 1])] for i in range(len(self))]
+
+
+def queue_serialize(opts: abi.CQueueOptions, batch: DeviceBatch, meta: Optional[abi.CRowMeta] = None) -> QueueMessages:
+    """NativeSerializer / JSONSerializer.Serialize (pkg/serializer/queue) for one table's rows, from device columns."""
+    init()
+    cap = batch.nrows
+    start, row = np.zeros(cap + 1, np.uint64), np.zeros(cap + 1, np.int64)
+    out, n = C.c_void_p(), C.c_int64(0)
+    _check(load().tfgpu_queue_serialize(C.byref(opts), batch._h, C.byref(meta) if meta is not None else None, C.byref(out),
+                                        start.ctypes.data, row.ctypes.data, cap, C.byref(n)))
+    k = int(n.value)
+    return QueueMessages(DeviceBuffer(out), start[:k + 1].copy(), row[:k + 1].copy())
+
+
+def fqtn(ns: str, table: str) -> str:
+    """ChangeItem.Fqtn() (change_item.go:139-141): the Kafka message key of the unbatched queue serializers."""
+    return ns + "_" + table
 
 
 def prof_enable(on: bool):
