@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Builds tools/hipemu/_build/libtfgpu_emu.so: tf_runtime.hip + tf_serialize.hip compiled as plain C++ (g++) against
+tools/hipemu/hip/hip_runtime.h, every `kernel<<<g, b, s, st>>>(args)` rewritten to emu_launch(kernel, g, b, args).
+
+TEST INFRASTRUCTURE ONLY: a way to run the lane-per-item kernels' logic in the GPU-less build container.  Only
+tests/test_hipemu.py loads the result; transferia_amd/ never does (it has no CPU path)."""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+UNITS = ["tf_runtime.hip", "tf_serialize.hip"]  # translation units whose kernels use no LDS / barriers / wave intrinsics
+LAUNCH = re.compile(r"(\b[A-Za-z_][A-Za-z0-9_]*(?:<[^<>;]*>)?)\s*<<<\s*([^;]*?)>>>\s*\(")
+
+
+def _split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    out.append(cur.strip())
+    return out
+
+
+def rewrite(src: str) -> str:
+    def sub(m):
+        cfg = _split_args(m.group(2))
+        return "emu_launch(%s, dim3(%s), dim3(%s), " % (m.group(1), cfg[0], cfg[1])
+    out = LAUNCH.sub(sub, src)
+    assert "<<<" not in out, "unrewritten kernel launch"
+    return out
+
+
+def build() -> str:
+    os.makedirs(OUT, exist_ok=True)
+    so = os.path.join(OUT, "libtfgpu_emu.so")
+    srcs = []
+    for u in UNITS:
+        with open(os.path.join(CSRC, u)) as f:
+            text = rewrite(f.read())
+        text = text.replace(", )", ")")  # kernels without arguments
+        dst = os.path.join(OUT, os.path.splitext(u)[0] + "_emu.cpp")
+        with open(dst, "w") as f:
+            f.write(text)
+        srcs.append(dst)
+    srcs.append(os.path.join(HERE, "emu_stubs.cpp"))
+    obj = os.path.join(OUT, "emu_abi_stubs.o")
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-c", os.path.join(HERE, "emu_abi_stubs.c"), "-o", obj])
+    srcs.append(obj)
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-Wno-unused-result", "-I", HERE, "-I", CSRC, "-o", so, *srcs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-6000:])
+        raise RuntimeError("hipemu build failed")
+    return so
+
+
+if __name__ == "__main__":
+    print(build())
