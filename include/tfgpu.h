@@ -175,8 +175,14 @@ typedef enum tfgpu_rowerr {
                                       NewUnparsed (generic_parser.go:545-550)  */
   TFGPU_ROW_PARSE_VAL = 13,        /* ParseVal error on a key/required column →
                                       newUnparsed (generic_parser.go:363-367)  */
-  TFGPU_ROW_NIL_KEY = 14           /* nil in a key/required column →
+  TFGPU_ROW_NIL_KEY = 14,          /* nil in a key/required column →
                                       newUnparsed (generic_parser.go:370-372)  */
+  TFGPU_ROW_SR_SHORT = 15,         /* confluent SR: message shorter than the 5-byte wire prefix
+                                      (confluentschemaregistry/engine/parser.go:109-112)          */
+  TFGPU_ROW_SR_MAGIC = 16,         /* confluent SR: first byte is not 0 (parser.go:113-116)       */
+  TFGPU_ROW_SR_TYPE = 17,          /* confluent SR json: convertTypes "wrong type" / Number.Int64
+                                      error (utils_json.go:97-128)                                */
+  TFGPU_ROW_SR_REQUIRED = 18       /* confluent SR json: required field absent (utils_json.go:54-56) */
 } tfgpu_rowerr;
 
 typedef struct tfgpu_row_error {
@@ -360,6 +366,47 @@ int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_schema *fields,
                      int64_t errs_cap, int64_t *nerrs);
 /* GenericParser.ResultSchema(): fields + aux columns; free with tfgpu_schema_free.            */
 int tfgpu_json_result_schema(const tfgpu_json_options *opts, const tfgpu_schema *fields, tfgpu_schema **out);
+
+/* ---- Confluent Schema Registry ingest, JSON schemas (configs[2]) ------------------------------ */
+/* ConfluentSrImpl.DoBatch / Do / DoBuf / DoOne (pkg/parsers/registry/confluentschemaregistry/engine/parser.go:108-152):
+ * every Kafka message is a run of FRAMES  0x00 | schema id (BE uint32) | payload,  the payload of a JSON-schema frame
+ * ending at the next 0x00 byte (format_json.go:34-38).  tfgpu_sr_frames lists them — the shim needs the schema ids to
+ * ask the registry (network, stays in Go).  A short message or a wrong magic byte ends its message with an error frame. */
+typedef struct tfgpu_sr_frame {
+  int64_t msg;        /* index of the Kafka message                                                        */
+  uint64_t start;     /* payload offset in the buffer (error frames: where the frame starts)               */
+  uint32_t len;       /* payload bytes (error frames: the rest of the message)                             */
+  uint32_t schema_id;
+  int32_t code;       /* TFGPU_ROW_OK / TFGPU_ROW_SR_SHORT / TFGPU_ROW_SR_MAGIC                            */
+  int32_t index;      /* position of the frame inside its message (QueueMessageMeta.Index)                 */
+} tfgpu_sr_frame;
+int tfgpu_sr_frames(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_sr_frame *frames,
+                    int64_t cap, int64_t *nframes);
+
+/* One property of the JSON schema as jsonPropertyToJSONSchemaRow resolves it (utils_json.go:71-95, types_json.go:25-32):
+ * the `type` (through oneOf), and whether it is required (listed in "required" and no oneOf null).                  */
+enum { TFGPU_SRT_BOOLEAN = 1, TFGPU_SRT_INTEGER = 2, TFGPU_SRT_NUMBER = 3, TFGPU_SRT_STRING = 4, TFGPU_SRT_ANY = 5 };
+typedef struct tfgpu_sr_property { const char *name; int32_t json_type; int32_t required; } tfgpu_sr_property;
+typedef struct tfgpu_sr_json_options {
+  uint32_t schema_id;           /* frames carrying another id are left to another call                      */
+  int32_t nprops;
+  const tfgpu_sr_property *props; /* util.MapKeysInOrder(Properties): sorted by name, unique               */
+  const char *table_ns;         /* BuildJSONTableID(tableNamePolicy, title) (table_name_policy.go:73-92)     */
+  const char *table_name;
+  int32_t is_generate_updates;  /* absent optional fields leave ColumnNames: not columnar → TFGPU_ERR_UNSUPPORTED */
+  int32_t report_frame_errors;  /* also report the SR_SHORT / SR_MAGIC frames (set it in one call per batch) */
+} tfgpu_sr_json_options;
+/* makeChangeItemsFromMessageWithJSON + processPayload + convertTypes (format_json.go:15-67, utils_json.go:27-128) for
+ * every frame of `schema_id`: the payload is decoded like encoding/json's Decoder with UseNumber into a map, and every
+ * property becomes one column — boolean → bool, integer → int64 (json.Number.Int64), number → json.Number (its text),
+ * string → string, anything else → `any` (json.Marshal text of the decoded value).  Rows: one per good frame, Kind
+ * insert, src_row = ordinal of the frame over the whole batch, part_id = index of its message.  errs: one per frame the
+ * reference turns into an `_unparsed` item (row = frame ordinal, step = message index) — after which the rest of that
+ * message is dropped, as DoBuf does — or whose `any` value needs Go's map ordering (TFGPU_ROW_HOST_FALLBACK: an object
+ * whose keys are not already in ascending order).  With several schema ids in one message the shim applies the
+ * "first error ends the message" rule across its calls.                                                              */
+int tfgpu_sr_json_parse(const tfgpu_sr_json_options *opts, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
+                        tfgpu_dbatch **out, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
 /* ---- serialize ---------------------------------------------------------- */
 enum {

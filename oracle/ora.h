@@ -201,6 +201,10 @@ char *ora_serialize_ex(int format, const ora_batch *b, const tfgpu_serialize_opt
 char *ora_queue_serialize(const tfgpu_queue_options *o, const ora_batch *b, const tfgpu_row_meta *m, uint64_t *len,
                           uint64_t **msg_start, int64_t **msg_row, int64_t *nmsg);
 
+/* §8f.1 Confluent Schema Registry parser, JSON schemas (ora_srjson.c) */
+tfgpu_sr_frame *ora_sr_frames(const void *bytes, uint64_t len, const tfgpu_messages *msgs, int64_t *nframes); /* malloc'd */
+ora_batch *ora_sr_json_parse(const tfgpu_sr_json_options *o, const void *bytes, uint64_t len, const tfgpu_messages *msgs, int64_t **msg_of);
+
 #ifdef __cplusplus
 }
 #endif

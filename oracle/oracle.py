@@ -69,6 +69,10 @@ def lib():
     L.ora_queue_serialize.restype = P
     L.ora_queue_serialize.argtypes = [C.POINTER(abi.CQueueOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(C.c_uint64), C.POINTER(P), C.POINTER(P),
                                       C.POINTER(C.c_int64)]
+    L.ora_sr_frames.restype = P
+    L.ora_sr_frames.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(abi.CMessages), C.POINTER(C.c_int64)]
+    L.ora_sr_json_parse.restype = P
+    L.ora_sr_json_parse.argtypes = [C.POINTER(abi.CSrJsonOptions), C.c_void_p, C.c_uint64, C.POINTER(abi.CMessages), C.POINTER(P)]
     L.ora_hmac_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p]
     L.ora_crc32_ieee.restype = C.c_uint32
     L.ora_crc32_ieee.argtypes = [C.c_char_p, C.c_size_t]
@@ -229,6 +233,35 @@ def queue_serialize(opts: abi.CQueueOptions, batch: abi.Batch, schema: abi.Schem
     L.free(p); L.free(ps); L.free(pr)
     queue_serialize.rows = [int(x) for x in rw]
     return [raw[int(st[i]):int(st[i + 1])] for i in range(k)]
+
+
+def sr_frames(data: bytes, msgs: abi.CMessages = None):
+    """ConfluentSrImpl.DoBuf's walk over every message: [(msg, start, len, schema_id, code, index)]."""
+    L = lib()
+    buf = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+    n = C.c_int64(0)
+    p = L.ora_sr_frames(buf.ctypes.data, len(data), C.byref(msgs) if msgs is not None else None, C.byref(n))
+    arr = (abi.CSrFrame * max(int(n.value), 1)).from_address(p)
+    out = [(int(f.msg), int(f.start), int(f.len), int(f.schema_id), int(f.code), int(f.index)) for f in arr[:int(n.value)]]
+    L.free(p)
+    return out
+
+
+def sr_json_parse(opts: abi.CSrJsonOptions, data: bytes, msgs: abi.CMessages = None) -> Result:
+    """Rows of the frames carrying opts.schema_id; .errors = [(frame ordinal, code)]; .batch.src_row = frame ordinals,
+    .batch.part_id = message index of every row."""
+    L = lib()
+    buf = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+    mo = C.c_void_p()
+    t0 = time.perf_counter()
+    out = L.ora_sr_json_parse(C.byref(opts), buf.ctypes.data, len(data), C.byref(msgs) if msgs is not None else None, C.byref(mo))
+    dt = time.perf_counter() - t0
+    n = int(L.ora_batch_len(out))
+    part = np.frombuffer(C.string_at(mo.value, 8 * n), np.int64).astype(np.uint32) if n else np.zeros(0, np.uint32)
+    L.free(mo)
+    res = _finish(L, out, dt)
+    res.batch.part_id = part
+    return res
 
 
 def filter_parse_check(expr: str):

@@ -1,0 +1,200 @@
+"""Confluent Schema Registry parser, JSON schemas (SURVEY §8f.1, configs[2]): the oracle against the reference's canon
+(TestClient) and its own test vectors (CPU); the HIP path against the oracle and the same canon (GPU)."""
+import base64
+import json
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi, confluent_sr
+from util import golden
+
+G = golden("confluent_sr.json")
+MSGS = [base64.b64decode(x) for x in G["messages"]]
+JSON_IDS = sorted(int(k) for k, v in G["schemas"].items() if v["schemaType"] == "JSON")
+
+
+def _batch_items(res, frames):
+    """Rows of one parse result as canon-shaped dicts keyed by frame ordinal."""
+    out = {}
+    b = res.batch if hasattr(res, "batch") else res
+    for r in range(b.nrows):
+        vals = []
+        for c in b.cols:
+            g, v = c.pyvalue(r)
+            if g == "nil":
+                vals.append(None)
+            elif g == "json":
+                vals.append(json.loads(v))
+            elif g == "jsonnum":
+                vals.append(float(v))
+            elif g == "string":
+                vals.append(v.decode("utf-8"))
+            else:
+                vals.append(v)
+        out[int(b.src_row[r])] = {"schema": b.table_ns, "table": b.table_name, "names": [c.name for c in b.cols], "values": vals,
+                                  "lsn": frames[int(b.src_row[r])][0], "dtypes": [c.dtype for c in b.cols]}
+    return out
+
+
+def _check_canon(parse, frames_fn):
+    """TestClient (parser_test.go:76-103): every message through Do, items in message order."""
+    nonempty = [(i, m) for i, m in enumerate(MSGS) if m]  # `if len(data) == 0 { continue }`
+    data, cm = abi.messages([m for _, m in nonempty], offsets=[i for i, _ in nonempty])
+    frames = frames_fn(data, cm)
+    assert len([f for f in frames if f[0] == 0]) == 2  # the first message holds two frames (require.Len(result, 2))
+    lsn_of = [(nonempty[f[0]][0],) for f in frames]
+    got = {}
+    for sid in JSON_IDS:
+        o = confluent_sr.sr_json_options(sid, G["schemas"][str(sid)]["schema"])
+        res = parse(o, data, cm)
+        assert not res.errors, res.errors
+        got.update(_batch_items(res, lsn_of))
+    items = [got[k] for k in sorted(got)]
+    assert len(items) == len(G["items"])
+    for it, exp in zip(items, G["items"]):
+        assert (it["schema"], it["table"], it["lsn"], it["names"]) == (exp["schema"], exp["table"], exp["lsn"], exp["names"])
+        assert it["values"] == exp["values"], (it, exp)
+        assert it["dtypes"] == [c[1] for c in exp["table_schema"]]
+
+
+def test_schema_rows_match_canon():
+    for sid in JSON_IDS:
+        title, rows = confluent_sr.json_schema_rows(G["schemas"][str(sid)]["schema"])
+        ns, tb = confluent_sr.build_json_table_id(title)
+        exp = next(it for it in G["items"] if (it["schema"], it["table"]) == (ns, tb))
+        assert [[n, confluent_sr.SRT_DTYPE[t], r] for n, t, r in rows] == exp["table_schema"]
+    # format_json_test.go:14-65 TestJSONTableNamePolicy
+    assert confluent_sr.build_json_table_id("public.person", confluent_sr.POLICY_DEBEZIUM_STYLE) == ("public", "person")
+    assert confluent_sr.build_json_table_id("public.person", confluent_sr.POLICY_TITLE) == ("", "public.person")
+    assert confluent_sr.build_json_table_id("public.person", manual_table_name="blablabla") == ("", "blablabla")
+    # utils_json_test.go:13-38 TestProcessPayload: required through the "required" list, `connect.type` ignored
+    sv = '{"title":"public.person","type":"object","properties":{"name":{"type":"string"},"id":{"type":"integer","connect.type":"int32"},"email":{"type":"string"}},"required":["name","id"],"additionalProperties":false}'
+    assert confluent_sr.json_schema_rows(sv)[1] == [("email", abi.SRT_STRING, False), ("id", abi.SRT_INTEGER, True), ("name", abi.SRT_STRING, True)]
+
+
+def test_oracle_canon(oracle):
+    _check_canon(oracle.sr_json_parse, oracle.sr_frames)
+
+
+PERSON = '{"title":"public.person","type":"object","properties":{"name":{"type":"string"},"id":{"type":"integer"},"email":{"type":"string"}},"required":["name","id"]}'
+
+
+def test_oracle_process_payload(oracle):
+    """utils_json_test.go TestProcessPayload: 3 names, 3 values; the absent optional field is nil."""
+    o = confluent_sr.sr_json_options(7, PERSON)
+    res = oracle.sr_json_parse(o, b"\0\0\0\0\x07" + b'{"id": 2, "name": "Bob"}')
+    assert abi.batch_rows(res.batch) == [[("nil", None), ("int64", 2), ("string", b"Bob")]] and not res.errors
+    assert (res.batch.table_ns, res.batch.table_name) == ("public", "person")
+
+
+def _vectors():
+    """(payload, expected row or error code) for the PERSON schema + an `any` and a number column."""
+    schema = ('{"title":"a.b","type":"object","properties":{"b":{"type":"boolean"},"i":{"oneOf":[{"type":"null"},{"type":"integer"}]},'
+              '"n":{"type":"number"},"s":{"oneOf":[{"type":"string"},{"type":"null"}]},"x":{"type":"object"},"r":{"type":"integer"}},"required":["r","n","s"]}')
+    E = abi.ROWERR_ID
+    nil = ("nil", None)
+    V = []
+
+    def ok(payload, b=nil, i=nil, n=nil, r=nil, s=nil, x=nil):
+        V.append((payload, [b, i, n, r, s, x]))
+
+    def err(payload, code):
+        V.append((payload, E[code]))
+    ok(b'{"r":1,"n":1.50,"s":"a"}', n=("jsonnum", b"1.50"), r=("int64", 1), s=("string", b"a"))
+    ok(b' \t\r\n{"r":-0,"n":-1e+5,"s":null , "b" : true,"i":null,"x":null}trailing garbage', b=("bool", True), n=("jsonnum", b"-1e+5"), r=("int64", 0))
+    ok(b'{"r":1,"r":2,"n":0,"s":"\\u0041\\n\\/\\ud83d\\ude00\\ud800x\\udc00"}', n=("jsonnum", b"0"), r=("int64", 2),
+       s=("string", "A\n/\U0001F600�x�".encode()))
+    ok(b'{"r":9223372036854775807,"n":1E5,"s":"\xff\xe2\x82"}', n=("jsonnum", b"1E5"), r=("int64", 9223372036854775807), s=("string", "���".encode()))
+    ok(b'{"r":1,"n":1,"s":"","x":{"a":[1,2.50,{"b":"<\\u003e&\xe2\x80\xa8"}],"c":null},"\\u0062":false}', b=("bool", False), n=("jsonnum", b"1"), r=("int64", 1),
+       s=("string", b""), x=("json", b'{"a":[1,2.50,{"b":"\\u003c\\u003e\\u0026\\u2028"}],"c":null}'))
+    ok(b'{"r":1,"n":1,"s":"q","x":[ ]}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"), x=("json", b"[]"))
+    ok(b'{"r":1,"n":1,"s":"q","x":"str"}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"), x=("json", b'"str"'))
+    ok(b'{"r":1,"n":1,"s":"q","x":12.0e1,"zzz":{"deep":[[[{}]]]}}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"), x=("json", b"12.0e1"))
+    err(b'{"n":1,"s":"a"}', "SR_REQUIRED")
+    err(b'null', "SR_REQUIRED")                      # nil map: every lookup misses
+    err(b'{"r":1.0,"n":1,"s":"a"}', "SR_TYPE")       # Number.Int64: strconv.ParseInt syntax error
+    err(b'{"r":9223372036854775808,"n":1,"s":"a"}', "SR_TYPE")
+    err(b'{"r":"1","n":1,"s":"a"}', "SR_TYPE")
+    err(b'{"r":1,"n":"1","s":"a"}', "SR_TYPE")
+    err(b'{"r":1,"n":null,"s":"a"}', "SR_TYPE")      # required → not nullable → nil is a wrong type
+    err(b'{"r":1,"n":1,"s":1}', "SR_TYPE")
+    err(b'{"r":1,"n":1,"s":"a","b":"true"}', "SR_TYPE")
+    err(b'{"r":1,"n":1,"s":"a","i":1e3}', "SR_TYPE")
+    for bad in (b'', b'   ', b'{', b'[1]', b'"s"', b'12', b'nullx', b'{"r":1,"n":01,"s":"a"}', b'{"r":1,"n":1.,"s":"a"}', b'{"r":1,"n":1,"s":"a\x01"}',
+                b'{"r":1,"n":1,"s":"\\x"}', b'{"r":1,"n":1,"s":"\\u12g4"}', b'{"r":1,"n":1,"s":"a",}', b'{"r":1 "n":1}', b"{'r':1}", b'{"r":+1,"n":1,"s":"a"}',
+                b'{"r":1,"n":1e,"s":"a"}', b'{"r":1,"n":-,"s":"a"}', b'{"r":1,"n":1,"s":"a"', b'{"r":1,"n":1,"s":tru}', b'{"r":1,"n":.5,"s":"a"}', b'{r:1}'):
+        err(bad, "JSON_SYNTAX")
+    return schema, V
+
+
+def _check_vectors(parse):
+    schema, V = _vectors()
+    o = confluent_sr.sr_json_options(3, schema)
+    data, cm = abi.messages([b"\0\0\0\0\x03" + p for p, _ in V])
+    res = parse(o, data, cm)
+    rows = {int(res.batch.src_row[r]): row for r, row in enumerate(abi.batch_rows(res.batch))}
+    errs = {int(e[0]): int(e[1]) for e in res.errors}
+    for k, (payload, exp) in enumerate(V):
+        if isinstance(exp, int):
+            assert errs.get(k) == exp and k not in rows, (payload, abi.ROWERR.get(errs.get(k)), rows.get(k))
+        else:
+            assert k not in errs and rows.get(k) == [abi.norm_value(v) for v in exp], (payload, rows.get(k), abi.ROWERR.get(errs.get(k)))
+    assert list(res.batch.part_id) == [k for k in range(len(V)) if k in rows]
+
+
+def test_oracle_vectors(oracle):
+    _check_vectors(oracle.sr_json_parse)
+
+
+def _framing_case():
+    """DoBuf: frames inside one message; an error frame or a failing payload ends its message."""
+    f = lambda sid, p: b"\0" + int(sid).to_bytes(4, "big") + p  # noqa: E731
+    good = b'{"id":1,"name":"n"}'
+    msgs = [
+        f(7, good) + f(7, good) + f(8, b"{}") + f(7, good),   # 4 frames, one of another schema
+        b"",                                                   # no frames
+        b"\0\0\0\7",                                           # shorter than the prefix
+        b"\1\0\0\0\7" + good,                                  # magic byte
+        f(7, good) + f(7, b'{"id":"x"}') + f(7, good),         # the 2nd payload fails: the 3rd frame is never looked at
+        f(7, good) + b"\0\0\7",                                # a good frame, then a short tail
+        f(7, b""),                                             # empty payload: decode error
+        f(7, good + b"  ") + b"\2\0\0\0\7" + good,             # the payload runs to the next 0 byte (trailing bytes after the
+                                                               # object are ignored); that 0 is the next frame's magic: id 0x0000077b
+    ]
+    return msgs
+
+
+def _check_framing(parse, frames_fn):
+    msgs = _framing_case()
+    data, cm = abi.messages(msgs)
+    frames = frames_fn(data, cm)
+    E = abi.ROWERR_ID
+    assert [(f[0], f[3], f[4], f[5]) for f in frames] == [
+        (0, 7, 0, 0), (0, 7, 0, 1), (0, 8, 0, 2), (0, 7, 0, 3), (2, 0, E["SR_SHORT"], 0), (3, 0, E["SR_MAGIC"], 0), (4, 7, 0, 0), (4, 7, 0, 1), (4, 7, 0, 2),
+        (5, 7, 0, 0), (5, 0, E["SR_SHORT"], 1), (6, 7, 0, 0), (7, 7, 0, 0), (7, 0x77B, 0, 1)]
+    for f in frames:
+        if f[4] == 0:
+            assert data[f[1] - 5] == 0 and int.from_bytes(data[f[1] - 4:f[1]], "big") == f[3]
+    o = confluent_sr.sr_json_options(7, PERSON)
+    res = parse(o, data, cm)
+    assert [int(x) for x in res.batch.src_row] == [0, 1, 3, 6, 9, 12]
+    assert [int(x) for x in res.batch.part_id] == [0, 0, 0, 4, 5, 7]
+    assert sorted((int(e[0]), int(e[1])) for e in res.errors) == [(4, E["SR_SHORT"]), (5, E["SR_MAGIC"]), (7, E["SR_TYPE"]), (10, E["SR_SHORT"]),
+                                                                   (11, E["JSON_SYNTAX"])]
+    o2 = confluent_sr.sr_json_options(7, PERSON, report_frame_errors=False)
+    res2 = parse(o2, data, cm)
+    assert sorted((int(e[0]), int(e[1])) for e in res2.errors) == [(7, E["SR_TYPE"]), (11, E["JSON_SYNTAX"])]
+    assert [int(x) for x in res2.batch.src_row] == [0, 1, 3, 6, 9, 12]
+
+
+def test_oracle_framing(oracle):
+    _check_framing(oracle.sr_json_parse, oracle.sr_frames)
+
+
+def test_incorrect_magic_byte(oracle):
+    """parser_test.go:105-133 TestIncorrectMagicByte: every first byte 1..254 yields one `_unparsed` item."""
+    msgs = [bytes([i]) + b"\0\0\0{}" for i in range(1, 255)]
+    data, cm = abi.messages(msgs)
+    res = oracle.sr_json_parse(confluent_sr.sr_json_options(0, PERSON), data, cm)
+    assert res.batch.nrows == 0 and [e[1] for e in res.errors] == [abi.ROWERR_ID["SR_MAGIC"]] * 254

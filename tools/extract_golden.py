@@ -715,6 +715,32 @@ def queue_serializers():
         "batching": {"item": master, "table": table}})
 
 
+# ---------------------------------------------------------------------------
+# Confluent SR parser, JSON schemas: engine/parser_test.go:21-103 (TestClient) over
+# testdata/test_schemas.json + testdata/test_raw_json_messages, canon gotest/canondata/result.json.
+# The canon went through float64 (json.Number values print with 17 digits), so numbers pin to float64 precision.
+# ---------------------------------------------------------------------------
+def confluent_sr():
+    import base64
+    eng = REF + "/pkg/parsers/registry/confluentschemaregistry/engine/"
+    with open(eng + "testdata/test_schemas.json") as f:
+        schemas = json.load(f)
+    # init(): every schema object is re-marshalled; the registry mock serves {"schema": text, "schemaType": ...}
+    schemas = {k: {"schema": v["schema"], "schemaType": v.get("schemaType", "")} for k, v in schemas.items()}
+    with open(eng + "testdata/test_raw_json_messages", "rb") as f:
+        lines = f.read().split(b"\n")
+    items = canon(eng + "gotest/canondata/result.json", "gotest.gotest.TestClient")
+    json_tables = set()
+    for v in schemas.values():
+        if v["schemaType"] == "JSON":
+            ns, tb = json.loads(v["schema"])["title"].split(".", 1)
+            json_tables.add((ns, tb))
+    exp = [{"schema": it["schema"], "table": it["table"], "lsn": it["nextlsn"], "names": it["columnnames"], "values": it["columnvalues"],
+            "table_schema": [[c["name"], c["type"], c["required"]] for c in it["table_schema"]]}
+           for it in items if (it["schema"], it["table"]) in json_tables]
+    write("confluent_sr.json", {"schemas": schemas, "messages": [base64.b64encode(x).decode() for x in lines], "items": exp})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -728,4 +754,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr()

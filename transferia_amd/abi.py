@@ -36,7 +36,7 @@ COL_KEY, COL_REQUIRED = 1, 2
 
 ROWERR = {0: "OK", 1: "UNSUPPORTED_KIND", 2: "COLUMN_NOT_FOUND", 3: "INT_OVERFLOW", 4: "TYPE_PAIR", 5: "MISSING_CELL",
           6: "CAST", 7: "RANGE", 8: "QUOTE", 9: "DOUBLE_QUOTE", 10: "QUOTING_DISABLED", 11: "HOST_FALLBACK",
-          12: "JSON_SYNTAX", 13: "PARSE_VAL", 14: "NIL_KEY"}
+          12: "JSON_SYNTAX", 13: "PARSE_VAL", 14: "NIL_KEY", 15: "SR_SHORT", 16: "SR_MAGIC", 17: "SR_TYPE", 18: "SR_REQUIRED"}
 ROWERR_ID = {v: k for k, v in ROWERR.items()}
 
 FMT_CH_JSON_EACH_ROW, FMT_JSON, FMT_CSV = 1, 2, 3
@@ -137,6 +137,39 @@ def serialize_options(add_closing_newline=False, any_as_string=False, ch_types=N
         pr = (C.c_uint8 * n)(*[int(t[1]) for t in ch_types])
         o.ncols, o.ch_flags, o.ch_precision = n, fl, pr
         o._keep = (fl, pr)
+    return o
+
+
+SRT_BOOLEAN, SRT_INTEGER, SRT_NUMBER, SRT_STRING, SRT_ANY = 1, 2, 3, 4, 5
+
+
+class CSrFrame(C.Structure):
+    _fields_ = [("msg", C.c_int64), ("start", C.c_uint64), ("len", C.c_uint32), ("schema_id", C.c_uint32), ("code", C.c_int32), ("index", C.c_int32)]
+
+
+class CSrProperty(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("json_type", C.c_int32), ("required", C.c_int32)]
+
+
+class CSrJsonOptions(C.Structure):
+    _fields_ = [("schema_id", C.c_uint32), ("nprops", C.c_int32), ("props", C.POINTER(CSrProperty)), ("table_ns", C.c_char_p), ("table_name", C.c_char_p),
+                ("is_generate_updates", C.c_int32), ("report_frame_errors", C.c_int32)]
+
+
+def sr_json_options(schema_id, props, table_ns="", table_name="", is_generate_updates=False, report_frame_errors=True) -> CSrJsonOptions:
+    """props: [(name, SRT_*, required)] sorted by name (util.MapKeysInOrder of the schema's properties)."""
+    o = CSrJsonOptions()
+    arr = (CSrProperty * max(len(props), 1))()
+    keep = [arr]
+    for i, (name, jt, req) in enumerate(props):
+        nb = _b(name)
+        keep.append(nb)
+        arr[i].name, arr[i].json_type, arr[i].required = nb, int(jt), int(bool(req))
+    ns, tn = _b(table_ns), _b(table_name)
+    keep += [ns, tn]
+    o.schema_id, o.nprops, o.props, o.table_ns, o.table_name = int(schema_id), len(props), arr, ns, tn
+    o.is_generate_updates, o.report_frame_errors = int(bool(is_generate_updates)), int(bool(report_frame_errors))
+    o._keep = keep
     return o
 
 
