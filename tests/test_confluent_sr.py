@@ -198,3 +198,118 @@ def test_incorrect_magic_byte(oracle):
     data, cm = abi.messages(msgs)
     res = oracle.sr_json_parse(confluent_sr.sr_json_options(0, PERSON), data, cm)
     assert res.batch.nrows == 0 and [e[1] for e in res.errors] == [abi.ROWERR_ID["SR_MAGIC"]] * 254
+
+
+# ---------------------------------------------------------------- GPU -------------
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+@pytest.mark.gpu
+def test_gpu_canon(tf):
+    _check_canon(tf.sr_json_parse, tf.sr_frames)
+
+
+@pytest.mark.gpu
+def test_gpu_vectors(tf):
+    _check_vectors(tf.sr_json_parse)
+
+
+@pytest.mark.gpu
+def test_gpu_framing(tf):
+    _check_framing(tf.sr_json_parse, tf.sr_frames)
+    msgs = [bytes([i]) + b"\0\0\0{}" for i in range(1, 255)]
+    data, cm = abi.messages(msgs)
+    res = tf.sr_json_parse(confluent_sr.sr_json_options(0, PERSON), data, cm)
+    assert res.batch.nrows == 0 and [e[1] for e in res.errors] == [abi.ROWERR_ID["SR_MAGIC"]] * 254
+    # empty batches
+    data, cm = abi.messages([b"", b""])
+    assert tf.sr_frames(data, cm) == [] and tf.sr_json_parse(confluent_sr.sr_json_options(0, PERSON), data, cm).batch.nrows == 0
+
+
+def _random_payloads(rng, n):
+    """Payloads for one schema drawn from a small grammar: every value kind, escapes, invalid UTF-8, white space,
+    duplicate keys, unknown keys, unsorted objects under `any` (host fallback on the device), type and syntax errors."""
+    schema = ('{"title":"db.t","type":"object","properties":{"an":{"type":"array"},"bo":{"oneOf":[{"type":"null"},{"type":"boolean"}]},'
+              '"in":{"type":"integer"},"nu":{"oneOf":[{"type":"number"},{"type":"null"}]},"ob":{"type":"object"},"st":{"type":"string"},"\u00e9\u4e2d":{"type":"string"}},'
+              '"required":["in","st"]}')
+    strs = ['""', '"a"', '"plain text"', '"\\u00e9\\n\\t\\\\\\/\\""', '"\\ud83d\\ude00"', '"\\ud83dx"', '"\\udc00"', '"<&>\u2028"', '"\u00e9\u4e2d\U0001F600"', '"bad \udcff\udcfe"', '"\\u0000\\u001f"']
+    nums = ["0", "-0", "12", "-9223372036854775808", "9223372036854775807", "9223372036854775808", "1.5", "1e3", "-1.25E-7", "123.2970700287221458280", "1E+400"]
+    anys_ok = ['[]', '{}', '[1, "x", null, true]', '{"a":1,"b":{"c":[{}],"d":"<>"}}', '{"a":"\\u0062","ab":2,"b":3}', '"s"', '1.50', 'true', '[[[[1]]]]', '{ "k" : [ 1 , 2 ] }']
+    anys_fb = ['{"b":1,"a":2}', '{"a":1,"a":2}', '[{"z":1,"y":2}]', '{"a":{"d":1,"c":2}}', '{"\\u0062":1,"a":2}']
+    ws = ["", " ", "\n", "\t  "]
+    out = []
+    for _ in range(n):
+        kind = rng.random()
+        members = []
+        if rng.random() < 0.95:
+            members.append(('"in"', nums[rng.integers(0, 5)] if rng.random() < 0.9 else nums[rng.integers(0, len(nums))]))
+        if rng.random() < 0.95:
+            members.append(('"st"', strs[rng.integers(0, len(strs))] if rng.random() < 0.95 else "12"))
+        if rng.random() < 0.7:
+            members.append(('"nu"', nums[rng.integers(0, len(nums))] if rng.random() < 0.9 else "null"))
+        if rng.random() < 0.5:
+            members.append(('"bo"', ["true", "false", "null", '"true"'][rng.integers(0, 4)]))
+        if rng.random() < 0.6:
+            pool = anys_ok if rng.random() < 0.85 else anys_fb
+            members.append(('"ob"', pool[rng.integers(0, len(pool))]))
+        if rng.random() < 0.4:
+            members.append(('"an"', anys_ok[rng.integers(0, len(anys_ok))]))
+        if rng.random() < 0.3:
+            members.append(('"\u00e9\u4e2d"' if rng.random() < 0.5 else '"\\u00e9\\u4e2d"', strs[rng.integers(0, len(strs))]))
+        if rng.random() < 0.3:
+            members.append(('"unknown"', anys_fb[rng.integers(0, len(anys_fb))]))
+        if rng.random() < 0.15 and members:
+            members.append(members[rng.integers(0, len(members))])  # duplicate key: the last one wins
+        order = rng.permutation(len(members))
+        w = lambda: ws[rng.integers(0, len(ws))]  # noqa: E731
+        body = "{" + ",".join(w() + members[i][0] + w() + ":" + w() + members[i][1] + w() for i in order) + "}"
+        if kind < 0.04:
+            body = body[:-1]
+        elif kind < 0.06:
+            body = body.replace(":", " ", 1)
+        elif kind < 0.08:
+            body = "null"
+        elif kind < 0.10:
+            body = body + " trailing"
+        out.append(w().encode() + body.encode("utf-8", "surrogateescape"))
+    return schema, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 20000])
+def test_gpu_matches_oracle(tf, oracle, n):
+    rng = np.random.default_rng(4000 + n)
+    schema, payloads = _random_payloads(rng, n)
+    frames = [b"\0" + (5 if rng.random() < 0.9 else 6).to_bytes(4, "big") + p for p in payloads]
+    msgs, i = [], 0
+    while i < len(frames):  # 1-3 frames per Kafka message
+        k = int(rng.integers(1, 4))
+        msgs.append(b"".join(frames[i:i + k]))
+        i += k
+    data, cm = abi.messages(msgs, offsets=np.arange(len(msgs)))
+    assert tf.sr_frames(data, cm) == oracle.sr_frames(data, cm)
+    o = confluent_sr.sr_json_options(5, schema)
+    ref = oracle.sr_json_parse(o, data, cm)
+    got = tf.sr_json_parse(o, tf.DeviceBuffer.upload(data) if n == 1000 else data, cm)
+    FB = abi.ROWERR_ID["HOST_FALLBACK"]
+    gerr = {e[0]: e[1] for e in got.errors}
+    rerr = {e[0]: e[1] for e in ref.errors}
+    fallback = {k for k, c in gerr.items() if c == FB}
+    grows = {int(got.batch.src_row[r]): (row, int(got.batch.part_id[r])) for r, row in enumerate(abi.batch_rows(got.batch))}
+    rrows = {int(ref.batch.src_row[r]): (row, int(ref.batch.part_id[r])) for r, row in enumerate(abi.batch_rows(ref.batch))}
+    # a fallback frame ends its message on the device (the shim re-parses that message); every other message must agree
+    fr = oracle.sr_frames(data, cm)
+    dead_msgs = {fr[k][0] for k in fallback}
+    live = [k for k in range(len(fr)) if fr[k][0] not in dead_msgs]
+    assert {k: gerr.get(k) for k in live} == {k: rerr.get(k) for k in live}
+    for k in live:
+        assert grows.get(k) == rrows.get(k), (k, grows.get(k), rrows.get(k))
+    for k in fallback:  # the oracle parsed it: a row whose `any` value needed Go's key ordering
+        assert k in rrows
+    assert set(grows) <= set(rrows)
+    assert n < 1000 or (len(fallback) > 0 and len(grows) > n // 4)
+    assert [c.dtype for c in got.batch.cols] == ["any", "boolean", "int64", "double", "any", "utf8", "utf8"]

@@ -9,7 +9,7 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, bool with_
   if (with_total) out[n] = s;
 }
 void exclusive_scan_u32_segments(uint32_t *inout, int64_t seg_len, int nseg, int64_t seg_stride) {
-  for (int g = 0; g < nseg; g++) exclusive_scan_u32(inout + g * seg_stride, inout + g * seg_stride, seg_len, false);
+  for (int g = 0; g < nseg; g++) exclusive_scan_u32(inout + g * seg_stride, inout + g * seg_stride, seg_len, true);  // total at [seg_len], like tf_scan.hip
 }
 void materialize(const ::tfgpu_dbatch &, const std::vector<const DColumn *> *) {}
 }  // namespace tf

@@ -5,6 +5,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -59,6 +60,18 @@ inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+inline int __mul24(int a, int b) { return ((a << 8) >> 8) * ((b << 8) >> 8); }
+// wave-level intrinsics have no meaning in a lane-at-a-time loop: a kernel that reaches one is not emulable
+[[noreturn]] inline void emu_no_wave_ops(const char *what) { std::fprintf(stderr, "hipemu: %s needs a wavefront; this kernel cannot run under tools/hipemu\n", what); std::abort(); }
+inline int __any(int) { emu_no_wave_ops("__any"); }
+inline int __all(int) { emu_no_wave_ops("__all"); }
+inline unsigned long long __ballot(int) { emu_no_wave_ops("__ballot"); }
+template <class T> inline T __shfl(T, int, int = 64) { emu_no_wave_ops("__shfl"); }
+template <class T> inline T __shfl_up(T, unsigned, int = 64) { emu_no_wave_ops("__shfl_up"); }
+template <class T> inline T __shfl_xor(T, int, int = 64) { emu_no_wave_ops("__shfl_xor"); }
+inline void __syncthreads() { emu_no_wave_ops("__syncthreads"); }
 
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { uint32_t o = *p; *p += v; return o; }

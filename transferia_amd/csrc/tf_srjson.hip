@@ -1,0 +1,686 @@
+// tf_srjson.hip — Confluent Schema Registry ingest, JSON schemas (the source format of configs[2]):
+//
+//   ConfluentSrImpl.DoBatch / Do / DoBuf / DoOne   pkg/parsers/registry/confluentschemaregistry/engine/parser.go:108-152
+//   makeChangeItemsFromMessageWithJSON             engine/format_json.go:15-67
+//   processPayload / convertTypes                  engine/utils_json.go:27-128, types_json.go:25-32
+//   jsonx.NewDefaultDecoder(...).Decode(&map)      encoding/json Decoder + UseNumber (scanner.go, stream.go, decode.go)
+//
+// Messages in, columns out, in lane-per-item passes over HBM-resident bytes:
+//   sr_count_frames / sr_fill_frames   one lane per Kafka message walks its frames (0x00 | BE schema id | payload up to the
+//                                      next 0x00) — DoBuf's loop; a short tail or a wrong magic byte ends the message
+//   sr_parse_frames                    one lane per frame: encoding/json's grammar over the payload with an explicit
+//                                      container stack, top-level keys matched against the sorted property names (last
+//                                      duplicate wins), then processPayload's per-property rules → the frame's fate
+//   sr_message_rule                    one lane per message: the first `_unparsed` frame drops the rest of its message
+//   sr_cell_values                     one lane per (property, row): bool / int64 values, text lengths
+//   sr_cell_text                       one lane per (text column, row): unquoted strings (escapes, surrogate pairs,
+//                                      invalid UTF-8 → U+FFFD), json.Number text, json.Marshal text of `any` values
+// First form of the path: correct and HBM-resident, latency-bound (every lane walks its own payload), like the per-line
+// generic JSON parser before its tile form.  Algorithmic bytes: B_json in + B_bin out per frame.
+#include <algorithm>
+
+#include "tf_common.hpp"
+#include "tf_devparse.hpp"
+
+namespace tf {
+namespace sr {
+
+enum : uint8_t { ST_OK = 0, ST_OTHER = 255, ST_DROPPED = 254 };  // else a tfgpu_rowerr
+enum : uint32_t { VT_ABSENT = 0, VT_NULL, VT_FALSE, VT_TRUE, VT_NUM, VT_STR, VT_ARR, VT_OBJ };
+constexpr int MAX_DEPTH = 128;  // deeper containers (Go allows 10000) go to the host
+
+struct Prop { uint32_t name_off, name_len; int32_t json_type, required; };
+struct Params {
+  const uint8_t *data;
+  const uint32_t *ms; int64_t nmsg;           // message starts [nmsg + 1]
+  uint32_t *fcount;                            // [nmsg + 1] frames per message → first frame of each message
+  tfgpu_sr_frame *frames; int64_t nframes;
+  uint32_t schema_id; int32_t report_frame_errors;
+  const Prop *props; int32_t nprops; const uint8_t *names;
+  uint32_t *vstart, *vlen; uint8_t *vtype;     // [nprops][nframes]: where the property's value sits in the payload
+  uint8_t *status;                             // [nframes]
+  uint32_t *keep;                              // [nframes + 1] → row index
+  uint32_t *row_frame; int64_t nrows;          // [nrows]
+  uint32_t *nerr;
+};
+
+__device__ __forceinline__ bool is_ws(uint32_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+__device__ __forceinline__ int hexv(uint32_t c) { return c >= '0' && c <= '9' ? (int)c - '0' : c >= 'a' && c <= 'f' ? (int)c - 'a' + 10 : c >= 'A' && c <= 'F' ? (int)c - 'A' + 10 : -1; }
+
+// ---- frames: DoBuf / DoOne + the payload end of format_json.go:34-38 --------------------------------------------------
+// Calls emit(frame) for every frame of message m; returns their number.
+template <class F> __device__ uint32_t walk_frames(const Params &p, int64_t m, F emit) {
+  MemBytes rd(p.data);
+  uint64_t a = p.ms[m]; const uint64_t z = p.ms[m + 1];
+  uint32_t k = 0;
+  while (a < z) {
+    tfgpu_sr_frame f; f.msg = m; f.index = (int32_t)k; f.schema_id = 0; f.start = a; f.len = (uint32_t)(z - a);
+    if (z - a < 5) { f.code = TFGPU_ROW_SR_SHORT; emit(k, f); return k + 1; }
+    if (rd.at(a) != 0) { f.code = TFGPU_ROW_SR_MAGIC; emit(k, f); return k + 1; }
+    f.schema_id = (rd.at(a + 1) << 24) | (rd.at(a + 2) << 16) | (rd.at(a + 3) << 8) | rd.at(a + 4);
+    a += 5;
+    uint64_t e = a;
+    while (e < z && rd.at(e) != 0) e++;  // bytes.Index(buf, []byte{0})
+    f.start = a; f.len = (uint32_t)(e - a); f.code = TFGPU_ROW_OK;
+    emit(k, f);
+    k++; a = e;
+  }
+  return k;
+}
+__global__ void __launch_bounds__(256) sr_count_frames(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.nmsg) return;
+  p.fcount[m] = walk_frames(p, m, [](uint32_t, const tfgpu_sr_frame &) {});
+}
+__global__ void __launch_bounds__(256) sr_fill_frames(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.nmsg) return;
+  tfgpu_sr_frame *out = p.frames + p.fcount[m];
+  walk_frames(p, m, [out](uint32_t k, const tfgpu_sr_frame &f) { out[k] = f; });
+}
+
+// ---- encoding/json's grammar (scanner.go) ------------------------------------------------------------------------------
+// String literal at pos (the opening quote): stateInString / stateInStringEsc*.  pos → past the closing quote.
+__device__ bool scan_string(MemBytes &rd, uint32_t &pos, const uint32_t end) {
+  pos++;
+  for (;;) {
+    if (pos >= end) return false;
+    const uint32_t c = rd.at(pos);
+    if (c == '"') { pos++; return true; }
+    if (c < 0x20) return false;
+    if (c != '\\') { pos++; continue; }
+    if (pos + 1 >= end) return false;
+    const uint32_t d = rd.at(pos + 1);
+    pos += 2;
+    if (d == 'u') {
+      if (end - pos < 4) return false;
+      for (int i = 0; i < 4; i++) if (hexv(rd.at(pos + i)) < 0) return false;
+      pos += 4;
+    } else if (!(d == '"' || d == '\\' || d == '/' || d == 'b' || d == 'f' || d == 'n' || d == 'r' || d == 't')) return false;
+  }
+}
+// -?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][+-]?[0-9]+)?
+__device__ bool scan_number(MemBytes &rd, uint32_t &pos, const uint32_t end) {
+  auto dig = [&](uint32_t q) { if (q >= end) return false; const uint32_t c = rd.at(q); return c >= '0' && c <= '9'; };
+  if (pos < end && rd.at(pos) == '-') pos++;
+  if (pos >= end) return false;
+  if (rd.at(pos) == '0') pos++;
+  else if (dig(pos)) { while (dig(pos)) pos++; }
+  else return false;
+  if (pos < end && rd.at(pos) == '.') { pos++; if (!dig(pos)) return false; while (dig(pos)) pos++; }
+  if (pos < end && (rd.at(pos) == 'e' || rd.at(pos) == 'E')) {
+    pos++;
+    if (pos < end && (rd.at(pos) == '+' || rd.at(pos) == '-')) pos++;
+    if (!dig(pos)) return false;
+    while (dig(pos)) pos++;
+  }
+  return true;
+}
+__device__ bool scan_literal(MemBytes &rd, uint32_t &pos, const uint32_t end, uint32_t &vt) {
+  const uint32_t c = rd.at(pos);
+  const char *lit = c == 't' ? "true" : c == 'f' ? "false" : "null";
+  const uint32_t n = c == 'f' ? 5u : 4u;
+  if (end - pos < n) return false;
+  for (uint32_t i = 0; i < n; i++) if (rd.at(pos + i) != (uint8_t)lit[i]) return false;
+  pos += n;
+  vt = c == 't' ? VT_TRUE : c == 'f' ? VT_FALSE : VT_NULL;
+  return true;
+}
+// One value at pos (white space already skipped), containers walked with an explicit stack (bit = 1: object).
+// 0 ok, 1 syntax error, 2 nesting deeper than MAX_DEPTH.
+__device__ int skip_value(MemBytes &rd, uint32_t &pos, const uint32_t end, uint32_t &vt) {
+  uint64_t stk[MAX_DEPTH / 64] = {0, 0};
+  int depth = 0;
+  auto top_is_obj = [&]() { return (stk[(depth - 1) >> 6] >> ((depth - 1) & 63)) & 1; };
+  auto skip_ws = [&]() { while (pos < end && is_ws(rd.at(pos))) pos++; };
+  bool first = true;
+  for (;;) {  // expect a value
+    skip_ws();
+    if (pos >= end) return 1;
+    const uint32_t c = rd.at(pos);
+    uint32_t t = 0;
+    bool opened = false;
+    if (c == '{' || c == '[') {
+      if (depth == MAX_DEPTH) return 2;
+      const uint64_t bit = 1ull << (depth & 63);
+      if (c == '{') stk[depth >> 6] |= bit; else stk[depth >> 6] &= ~bit;
+      depth++; pos++;
+      t = c == '{' ? VT_OBJ : VT_ARR;
+      skip_ws();
+      if (pos >= end) return 1;
+      if (rd.at(pos) == (c == '{' ? '}' : ']')) { pos++; depth--; }
+      else opened = true;
+    } else if (c == '"') { if (!scan_string(rd, pos, end)) return 1; t = VT_STR; }
+    else if (c == '-' || (c >= '0' && c <= '9')) { if (!scan_number(rd, pos, end)) return 1; t = VT_NUM; }
+    else if (c == 't' || c == 'f' || c == 'n') { if (!scan_literal(rd, pos, end, t)) return 1; }
+    else return 1;
+    if (first) { vt = t; first = false; }
+    if (!opened) {
+      // after a value: close containers / move to the next element
+      for (;;) {
+        if (depth == 0) return 0;
+        skip_ws();
+        if (pos >= end) return 1;
+        const uint32_t d = rd.at(pos);
+        if (d == ',') { pos++; break; }
+        if (d == (top_is_obj() ? '}' : ']')) { pos++; depth--; continue; }
+        return 1;
+      }
+    }
+    if (top_is_obj()) {  // a key, then ':'
+      skip_ws();
+      if (pos >= end || rd.at(pos) != '"') return 1;
+      if (!scan_string(rd, pos, end)) return 1;
+      skip_ws();
+      if (pos >= end || rd.at(pos) != ':') return 1;
+      pos++;
+    }
+  }
+}
+
+// ---- decoded strings (decode.go unquote) as rune streams ----------------------------------------------------------------
+// Runes of a validated JSON string body [p, e) (escapes, surrogate pairs, invalid UTF-8 → U+FFFD), or of plain bytes.
+struct RuneIter {
+  MemBytes *rd; const uint8_t *plain; uint32_t p, e;
+  __device__ __forceinline__ uint32_t at(uint32_t q) { return plain ? plain[q] : rd->at(q); }
+  __device__ int next() {
+    if (p >= e) return -1;
+    const uint32_t c = at(p);
+    if (!plain && c == '\\') {
+      const uint32_t d = at(p + 1);
+      p += 2;
+      switch (d) {
+        case 'b': return '\b'; case 'f': return '\f'; case 'n': return '\n'; case 'r': return '\r'; case 't': return '\t';
+        case 'u': {
+          int r = 0;
+          for (int i = 0; i < 4; i++) r = r * 16 + hexv(at(p + i));
+          p += 4;
+          if (r >= 0xD800 && r < 0xE000) {
+            if (r < 0xDC00 && e - p >= 6 && at(p) == '\\' && at(p + 1) == 'u') {
+              int r2 = 0;
+              for (int i = 0; i < 4; i++) r2 = r2 * 16 + hexv(at(p + 2 + i));
+              if (r2 >= 0xDC00 && r2 < 0xE000) { p += 6; return 0x10000 + ((r - 0xD800) << 10) + (r2 - 0xDC00); }
+            }
+            return 0xFFFD;
+          }
+          return r;
+        }
+        default: return (int)d;  // " \ /
+      }
+    }
+    if (c < 0x80) { p++; return (int)c; }
+    uint32_t need = 0, cp = 0, lo = 0x80, hi = 0xBF;  // utf8.DecodeRune
+    if (c >= 0xC2 && c <= 0xDF) { need = 1; cp = c & 0x1F; }
+    else if (c >= 0xE0 && c <= 0xEF) { need = 2; cp = c & 0x0F; if (c == 0xE0) lo = 0xA0; if (c == 0xED) hi = 0x9F; }
+    else if (c >= 0xF0 && c <= 0xF4) { need = 3; cp = c & 0x07; if (c == 0xF0) lo = 0x90; if (c == 0xF4) hi = 0x8F; }
+    bool ok = need > 0 && e - p > need;
+    if (ok) for (uint32_t k = 1; k <= need; k++) {
+      const uint32_t d = at(p + k), l = k == 1 ? lo : 0x80u, h = k == 1 ? hi : 0xBFu;
+      if (d < l || d > h) { ok = false; break; }
+      cp = (cp << 6) | (d & 0x3F);
+    }
+    if (!ok) { p++; return 0xFFFD; }
+    p += need + 1;
+    return (int)cp;
+  }
+};
+// <0, 0, >0: the decoded strings compared the way Go compares strings (UTF-8 bytes order = rune order)
+__device__ int rune_compare(RuneIter a, RuneIter b) {
+  for (;;) {
+    const int x = a.next(), y = b.next();
+    if (x != y) return x < y ? -1 : 1;  // -1 = end sorts first
+    if (x < 0) return 0;
+  }
+}
+struct CountSink { uint32_t n = 0; __device__ __forceinline__ void put(uint32_t) { n++; } };
+struct ByteSink { uint8_t *p; __device__ __forceinline__ void put(uint32_t c) { *p++ = (uint8_t)c; } };
+template <class S> __device__ __forceinline__ void put_utf8(S &o, uint32_t r) {
+  if (r < 0x80) o.put(r);
+  else if (r < 0x800) { o.put(0xC0 | (r >> 6)); o.put(0x80 | (r & 63)); }
+  else if (r < 0x10000) { o.put(0xE0 | (r >> 12)); o.put(0x80 | ((r >> 6) & 63)); o.put(0x80 | (r & 63)); }
+  else { o.put(0xF0 | (r >> 18)); o.put(0x80 | ((r >> 12) & 63)); o.put(0x80 | ((r >> 6) & 63)); o.put(0x80 | (r & 63)); }
+}
+template <class S> __device__ __forceinline__ void put_hex4(S &o, uint32_t r) {
+  const char *H = "0123456789abcdef";
+  o.put('\\'); o.put('u'); o.put(H[(r >> 12) & 15]); o.put(H[(r >> 8) & 15]); o.put(H[(r >> 4) & 15]); o.put(H[r & 15]);
+}
+// the unquoted string: Go string bytes
+template <class S> __device__ void emit_unquoted(S &o, MemBytes &rd, uint32_t start, uint32_t len) {
+  RuneIter it{&rd, nullptr, start + 1, start + len - 1};
+  for (int r; (r = it.next()) >= 0;) put_utf8(o, (uint32_t)r);
+}
+// json.Marshal(string): encoding/json appendString with escapeHTML
+template <class S> __device__ void emit_go_string(S &o, MemBytes &rd, uint32_t start, uint32_t len) {
+  RuneIter it{&rd, nullptr, start + 1, start + len - 1};
+  o.put('"');
+  for (int r; (r = it.next()) >= 0;) {
+    const uint32_t c = (uint32_t)r;
+    if (c < 0x80) {
+      if (c >= 0x20 && c != '"' && c != '\\' && c != '<' && c != '>' && c != '&') { o.put(c); continue; }
+      switch (c) {
+        case '"': o.put('\\'); o.put('"'); break; case '\\': o.put('\\'); o.put('\\'); break; case '\b': o.put('\\'); o.put('b'); break;
+        case '\f': o.put('\\'); o.put('f'); break; case '\n': o.put('\\'); o.put('n'); break; case '\r': o.put('\\'); o.put('r'); break;
+        case '\t': o.put('\\'); o.put('t'); break;
+        default: put_hex4(o, c);
+      }
+    } else if (c == 0x2028 || c == 0x2029) put_hex4(o, c);
+    else put_utf8(o, c);
+  }
+  o.put('"');
+}
+// json.Marshal of a decoded value whose objects already hold their keys in ascending order: the source tokens, strings
+// re-encoded, white space dropped.  (The value was validated by skip_value.)
+template <class S> __device__ void emit_any(S &o, MemBytes &rd, uint32_t start, uint32_t len) {
+  uint32_t pos = start; const uint32_t end = start + len;
+  while (pos < end) {
+    const uint32_t c = rd.at(pos);
+    if (is_ws(c)) { pos++; continue; }
+    if (c == '"') { uint32_t q = pos; scan_string(rd, q, end); emit_go_string(o, rd, pos, q - pos); pos = q; continue; }
+    o.put(c); pos++;
+  }
+}
+// Can emit_any stand for json.Marshal?  Every object's keys must be strictly ascending (Go sorts map keys and a
+// duplicate key keeps only its last value).  The value was validated by skip_value.
+__device__ bool any_keys_sorted(MemBytes &rd, uint32_t start, uint32_t len) {
+  uint32_t prev_s[MAX_DEPTH], prev_n[MAX_DEPTH];  // previous key of every open object (string bodies)
+  uint64_t stk[MAX_DEPTH / 64] = {0, 0};
+  int depth = 0;
+  uint32_t pos = start; const uint32_t end = start + len;
+  bool expect_key = false;
+  while (pos < end) {
+    const uint32_t c = rd.at(pos);
+    if (is_ws(c) || c == ':') { pos++; continue; }
+    if (c == '{' || c == '[') {
+      const uint64_t bit = 1ull << (depth & 63);
+      if (c == '{') { stk[depth >> 6] |= bit; prev_n[depth] = 0xFFFFFFFFu; } else stk[depth >> 6] &= ~bit;
+      depth++; pos++; expect_key = c == '{';
+      continue;
+    }
+    if (c == '}' || c == ']') { depth--; pos++; expect_key = false; continue; }
+    if (c == ',') { pos++; expect_key = depth > 0 && ((stk[(depth - 1) >> 6] >> ((depth - 1) & 63)) & 1); continue; }
+    if (c == '"') {
+      uint32_t q = pos;
+      scan_string(rd, q, end);
+      if (expect_key) {
+        const int d = depth - 1;
+        if (prev_n[d] != 0xFFFFFFFFu) {
+          RuneIter a{&rd, nullptr, prev_s[d], prev_s[d] + prev_n[d]}, b{&rd, nullptr, pos + 1, q - 1};
+          if (rune_compare(a, b) >= 0) return false;
+        }
+        prev_s[d] = pos + 1; prev_n[d] = q - pos - 2;
+        expect_key = false;
+      }
+      pos = q;
+      continue;
+    }
+    pos++;  // number / literal bytes
+  }
+  return true;
+}
+// strconv.ParseInt(text, 10, 64) of a validated JSON number literal: false on a syntax or range error
+__device__ bool number_int64(MemBytes &rd, uint32_t start, uint32_t len, int64_t *out) {
+  uint32_t i = 0; bool neg = false;
+  if (rd.at(start) == '-') { neg = true; i = 1; }
+  uint64_t v = 0;
+  if (i >= len) return false;
+  for (; i < len; i++) {
+    const uint32_t c = rd.at(start + i);
+    if (c < '0' || c > '9') return false;
+    if (v > 1844674407370955161ull) return false;
+    v = v * 10; const uint64_t d = c - '0';
+    if (v > ~0ull - d) return false;
+    v += d;
+  }
+  if (neg) { if (v > 9223372036854775808ull) return false; *out = (int64_t)(0 - v); }
+  else { if (v > 9223372036854775807ull) return false; *out = (int64_t)v; }
+  return true;
+}
+
+// ---- one frame: Decode into a map, then processPayload's rules -----------------------------------------------------------
+__device__ uint32_t parse_frame(const Params &p, const int64_t f) {
+  const tfgpu_sr_frame &fr = p.frames[f];
+  MemBytes rd(p.data);
+  uint32_t pos = (uint32_t)fr.start; const uint32_t end = pos + fr.len;
+  auto skip_ws = [&]() { while (pos < end && is_ws(rd.at(pos))) pos++; };
+  skip_ws();
+  if (pos >= end) return TFGPU_ROW_JSON_SYNTAX;  // io.EOF
+  bool nil_map = false;
+  if (rd.at(pos) == 'n') {  // a top-level null leaves the map nil; a scalar must be followed by white space or the end
+    uint32_t t;
+    if (!scan_literal(rd, pos, end, t) || (pos < end && !is_ws(rd.at(pos)))) return TFGPU_ROW_JSON_SYNTAX;
+    nil_map = true;
+  } else if (rd.at(pos) != '{') return TFGPU_ROW_JSON_SYNTAX;  // syntax error or UnmarshalTypeError: not a map either way
+  if (!nil_map) {
+    pos++;
+    skip_ws();
+    if (pos >= end) return TFGPU_ROW_JSON_SYNTAX;
+    if (rd.at(pos) == '}') pos++;
+    else for (;;) {
+      skip_ws();
+      if (pos >= end || rd.at(pos) != '"') return TFGPU_ROW_JSON_SYNTAX;
+      const uint32_t ks = pos;
+      if (!scan_string(rd, pos, end)) return TFGPU_ROW_JSON_SYNTAX;
+      const uint32_t ke = pos;
+      skip_ws();
+      if (pos >= end || rd.at(pos) != ':') return TFGPU_ROW_JSON_SYNTAX;
+      pos++;
+      skip_ws();
+      const uint32_t vs = pos;
+      uint32_t vt = 0;
+      const int rc = skip_value(rd, pos, end, vt);
+      if (rc == 1) return TFGPU_ROW_JSON_SYNTAX;
+      if (rc == 2) return TFGPU_ROW_HOST_FALLBACK;
+      // m[key] = value: binary search over the sorted property names, the last duplicate wins
+      int lo = 0, hi = p.nprops - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        RuneIter a{&rd, nullptr, ks + 1, ke - 1}, b{nullptr, p.names + p.props[mid].name_off, 0, p.props[mid].name_len};
+        const int c = rune_compare(a, b);
+        if (c == 0) { const int64_t i = (int64_t)mid * p.nframes + f; p.vstart[i] = vs; p.vlen[i] = pos - vs; p.vtype[i] = (uint8_t)vt; break; }
+        if (c < 0) hi = mid - 1; else lo = mid + 1;
+      }
+      skip_ws();
+      if (pos >= end) return TFGPU_ROW_JSON_SYNTAX;
+      const uint32_t d = rd.at(pos);
+      if (d == ',') { pos++; continue; }
+      if (d == '}') { pos++; break; }
+      return TFGPU_ROW_JSON_SYNTAX;
+    }
+  }
+  // processPayload (utils_json.go:45-66), properties in name order: the first failing one names the error
+  bool fallback = false;
+  for (int j = 0; j < p.nprops; j++) {
+    const int64_t i = (int64_t)j * p.nframes + f;
+    const uint32_t vt = p.vtype[i];
+    const Prop &pr = p.props[j];
+    if (vt == VT_ABSENT) { if (pr.required) return TFGPU_ROW_SR_REQUIRED; continue; }
+    if (vt == VT_NULL && !pr.required) continue;
+    switch (pr.json_type) {
+      case TFGPU_SRT_BOOLEAN: if (vt != VT_TRUE && vt != VT_FALSE) return TFGPU_ROW_SR_TYPE; break;
+      case TFGPU_SRT_INTEGER: { int64_t x; if (vt != VT_NUM || !number_int64(rd, p.vstart[i], p.vlen[i], &x)) return TFGPU_ROW_SR_TYPE; break; }
+      case TFGPU_SRT_NUMBER: if (vt != VT_NUM) return TFGPU_ROW_SR_TYPE; break;
+      case TFGPU_SRT_STRING: if (vt != VT_STR) return TFGPU_ROW_SR_TYPE; break;
+      default: if ((vt == VT_OBJ || vt == VT_ARR) && !any_keys_sorted(rd, p.vstart[i], p.vlen[i])) fallback = true;
+    }
+  }
+  return fallback ? (uint32_t)TFGPU_ROW_HOST_FALLBACK : (uint32_t)ST_OK;
+}
+__global__ void __launch_bounds__(128) sr_parse_frames(Params p) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= p.nframes) return;
+  const tfgpu_sr_frame &fr = p.frames[f];
+  uint32_t st;
+  if (fr.code) st = (uint32_t)fr.code;
+  else if (fr.schema_id != p.schema_id) st = ST_OTHER;
+  else st = parse_frame(p, f);
+  p.status[f] = (uint8_t)st;
+}
+// DoBuf: an `_unparsed` item ends its message (doWithSchema returns nil); frames of other schema ids are not ours to judge
+__global__ void __launch_bounds__(256) sr_message_rule(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.nmsg) return;
+  bool dead = false;
+  for (uint32_t f = p.fcount[m]; f < p.fcount[m + 1]; f++) {
+    uint32_t st = p.status[f];
+    if (dead) st = ST_DROPPED;
+    else if (st != ST_OK && st != ST_OTHER) {
+      dead = true;
+      const bool frame_err = st == TFGPU_ROW_SR_SHORT || st == TFGPU_ROW_SR_MAGIC;
+      if (frame_err && !p.report_frame_errors) st = ST_DROPPED; else atomicAdd(p.nerr, 1u);
+    }
+    p.status[f] = (uint8_t)st;
+    p.keep[f] = st == ST_OK ? 1u : 0u;
+  }
+}
+__global__ void __launch_bounds__(256) sr_row_frames(Params p) {
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= p.nframes || p.status[f] != ST_OK) return;
+  p.row_frame[p.keep[f]] = (uint32_t)f;
+}
+
+// ---- cells ------------------------------------------------------------------------------------------------------------
+struct OutCol {
+  int32_t json_type;
+  void *values;        // bool (u8) / int64
+  uint32_t *lens;      // text columns: lengths, then offsets [nrows + 1]
+  uint8_t *data;       // text payload (second pass)
+  uint8_t *valid8;     // one byte per row → packed by sr_pack_validity
+  uint8_t *validity;   // bitmap
+};
+__global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (int64_t)p.nprops * p.nrows) return;
+  const int j = (int)(it / p.nrows); const int64_t r = it - (int64_t)j * p.nrows;
+  const uint32_t f = p.row_frame[r];
+  if (j == 0) { src_row[r] = (int32_t)f; part_id[r] = (uint32_t)p.frames[f].msg; }
+  const OutCol &c = cols[j];
+  const int64_t i = (int64_t)j * p.nframes + f;
+  const uint32_t vt = p.vtype[i], vs = p.vstart[i], vl = p.vlen[i];
+  const bool nil = vt == VT_ABSENT || vt == VT_NULL;
+  c.valid8[r] = nil ? 0 : 1;
+  MemBytes rd(p.data);
+  switch (c.json_type) {
+    case TFGPU_SRT_BOOLEAN: ((uint8_t *)c.values)[r] = vt == VT_TRUE ? 1 : 0; break;
+    case TFGPU_SRT_INTEGER: { int64_t x = 0; if (!nil) number_int64(rd, vs, vl, &x); ((int64_t *)c.values)[r] = x; break; }
+    case TFGPU_SRT_NUMBER: c.lens[r] = nil ? 0u : vl; break;
+    case TFGPU_SRT_STRING: { CountSink s; if (!nil) emit_unquoted(s, rd, vs, vl); c.lens[r] = s.n; break; }
+    default: { CountSink s; if (!nil) emit_any(s, rd, vs, vl); c.lens[r] = s.n; }
+  }
+}
+__global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (int64_t)ntext * p.nrows) return;
+  const int t = (int)(it / p.nrows); const int64_t r = it - (int64_t)t * p.nrows;
+  const int j = text_cols[t];
+  const OutCol &c = cols[j];
+  const uint32_t f = p.row_frame[r];
+  const int64_t i = (int64_t)j * p.nframes + f;
+  const uint32_t vt = p.vtype[i], vs = p.vstart[i], vl = p.vlen[i];
+  if (vt == VT_ABSENT || vt == VT_NULL) return;
+  MemBytes rd(p.data);
+  ByteSink s{c.data + c.lens[r]};
+  if (c.json_type == TFGPU_SRT_NUMBER) { for (uint32_t k = 0; k < vl; k++) s.put(rd.at(vs + k)); }
+  else if (c.json_type == TFGPU_SRT_STRING) emit_unquoted(s, rd, vs, vl);
+  else emit_any(s, rd, vs, vl);
+}
+__global__ void __launch_bounds__(256) sr_pack_validity(const OutCol *cols, int32_t nprops, int64_t nrows) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nb = (nrows + 7) / 8;
+  if (it >= (int64_t)nprops * nb) return;
+  const int j = (int)(it / nb); const int64_t b = it - (int64_t)j * nb;
+  uint32_t v = 0;
+  for (int k = 0; k < 8; k++) { const int64_t r = b * 8 + k; if (r < nrows && cols[j].valid8[r]) v |= 1u << k; }
+  cols[j].validity[b] = (uint8_t)v;
+}
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
+
+// input bytes + message starts in HBM, frames counted and listed; returns the frame count
+struct Staged {
+  Buf bytes, ms, fcount, frames;
+  Params p{};
+  int64_t nframes = 0;
+};
+static void stage_frames(Staged &s, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs) {
+  Context &cx = ctx();
+  hipStream_t st = cx.stream;
+  if (len >= 0xFFFFFFF0ull) throw Error(TFGPU_ERR_UNSUPPORTED, "confluent SR: batch must be < 4 GiB (32-bit offsets)");
+  if (mem == TFGPU_MEM_HOST) {
+    s.bytes = dalloc(len + 64);
+    h2d(s.bytes->p, bytes, len);
+    TF_HIP(hipMemsetAsync((char *)s.bytes->p + len, 0, 64, st));
+    s.p.data = ptr<uint8_t>(s.bytes);
+  } else {
+    s.p.data = (const uint8_t *)bytes;
+    if (reinterpret_cast<uintptr_t>(s.p.data) & 15) throw Error(TFGPU_ERR_INVALID, "confluent SR: device buffer must be 16-byte aligned");
+  }
+  const int64_t nmsg = msgs ? msgs->nmsg : 1;
+  if (nmsg < 0 || (msgs && nmsg > 0 && !msgs->start)) throw Error(TFGPU_ERR_INVALID, "confluent SR: bad message batch");
+  std::vector<uint32_t> ms((size_t)nmsg + 1);
+  if (msgs) {
+    for (int64_t m = 0; m <= nmsg; m++) {
+      if (msgs->start[m] > len || (m && msgs->start[m] < msgs->start[m - 1])) throw Error(TFGPU_ERR_INVALID, "confluent SR: message offsets must be ascending and inside the buffer");
+      ms[(size_t)m] = (uint32_t)msgs->start[m];
+    }
+  } else { ms[0] = 0; ms[1] = (uint32_t)len; }
+  s.ms = dalloc(ms.size() * 4 + 16);
+  h2d(s.ms->p, ms.data(), ms.size() * 4);
+  s.fcount = dalloc_zero((size_t)(nmsg + 1) * 4 + 16);
+  s.p.ms = ptr<uint32_t>(s.ms); s.p.nmsg = nmsg; s.p.fcount = ptr<uint32_t>(s.fcount);
+  if (nmsg) { KernelTimer t("sr_frames"); sr_count_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p); }
+  exclusive_scan_u32(s.p.fcount, s.p.fcount, nmsg, true);
+  const uint32_t *h = d2h_u32(s.p.fcount + nmsg);
+  tf::sync();  // also fences the pageable sources (bytes, ms)
+  s.nframes = *h;
+  s.frames = dalloc((size_t)std::max<int64_t>(s.nframes, 1) * sizeof(tfgpu_sr_frame));
+  s.p.frames = reinterpret_cast<tfgpu_sr_frame *>(s.frames->p); s.p.nframes = s.nframes;
+  if (nmsg && s.nframes) { KernelTimer t("sr_frames"); sr_fill_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p); }
+}
+
+}  // namespace sr
+}  // namespace tf
+
+using namespace tf;
+
+#define TF_API_BEGIN try {
+#define TF_API_END                                                        \
+  }                                                                       \
+  catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }       \
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+
+extern "C" int tfgpu_sr_frames(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_sr_frame *frames, int64_t cap, int64_t *nframes) {
+  TF_API_BEGIN
+  if (!nframes || (len && !bytes)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_frames: null argument");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  sr::Staged s;
+  sr::stage_frames(s, bytes, len, mem, msgs);
+  *nframes = s.nframes;
+  if (s.nframes > cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_frames: more frames than the output holds (see *nframes)");
+  if (s.nframes) { d2h(frames, s.frames->p, (size_t)s.nframes * sizeof(tfgpu_sr_frame)); tf::sync(); }
+  return TFGPU_OK;
+  TF_API_END
+}
+
+extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
+                                   tfgpu_dbatch **out, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
+  TF_API_BEGIN
+  if (!o || !out || (len && !bytes) || (o->nprops && !o->props)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_json_parse: null argument");
+  if (o->is_generate_updates) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR json: isGenerateUpdates drops absent fields from ColumnNames (rows of different shapes): not device-resident");
+  const int np = o->nprops;
+  std::string names;
+  std::vector<sr::Prop> props((size_t)np);
+  for (int j = 0; j < np; j++) {
+    const tfgpu_sr_property &pr = o->props[j];
+    if (!pr.name || pr.json_type < TFGPU_SRT_BOOLEAN || pr.json_type > TFGPU_SRT_ANY) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_json_parse: bad property");
+    if (j && std::string(o->props[j - 1].name) >= pr.name) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_json_parse: properties must be sorted by name and unique (util.MapKeysInOrder)");
+    props[(size_t)j] = sr::Prop{(uint32_t)names.size(), (uint32_t)std::strlen(pr.name), pr.json_type, pr.required ? 1 : 0};
+    names += pr.name;
+  }
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  hipStream_t st = cx.stream;
+  sr::Staged s;
+  sr::stage_frames(s, bytes, len, mem, msgs);
+  sr::Params &p = s.p;
+  const int64_t nf = s.nframes, nfa = std::max<int64_t>(nf, 1);
+  Buf bprops = upload_small(props.data(), std::max<size_t>(props.size(), 1) * sizeof(sr::Prop)), bnames = upload_small(names.data(), names.size());
+  Buf vstart = dalloc((size_t)std::max(np, 1) * (size_t)nfa * 4), vlen = dalloc((size_t)std::max(np, 1) * (size_t)nfa * 4), vtype = dalloc_zero((size_t)std::max(np, 1) * (size_t)nfa + 16);
+  Buf status = dalloc_zero((size_t)nfa + 16), keep = dalloc_zero((size_t)(nfa + 1) * 4 + 16), nerr = dalloc_zero(16);
+  p.schema_id = o->schema_id; p.report_frame_errors = o->report_frame_errors;
+  p.props = ptr<sr::Prop>(bprops); p.nprops = np; p.names = ptr<uint8_t>(bnames);
+  p.vstart = ptr<uint32_t>(vstart); p.vlen = ptr<uint32_t>(vlen); p.vtype = ptr<uint8_t>(vtype);
+  p.status = ptr<uint8_t>(status); p.keep = ptr<uint32_t>(keep); p.nerr = ptr<uint32_t>(nerr);
+  if (nf) {
+    { KernelTimer t("sr_parse_frames"); sr::sr_parse_frames<<<sr::nblk(nf, 128), 128, 0, st>>>(p); }
+    { KernelTimer t("sr_message_rule"); sr::sr_message_rule<<<sr::nblk(p.nmsg, 256), 256, 0, st>>>(p); }
+  }
+  exclusive_scan_u32(p.keep, p.keep, nf, true);
+  const uint32_t *hrows = d2h_u32(p.keep + nf), *hnerr = d2h_u32(p.nerr);
+  tf::sync();
+  const int64_t nrows = *hrows, nra = std::max<int64_t>(nrows, 1);
+  const uint32_t nerr_total = *hnerr;
+
+  auto db = std::make_unique<tfgpu_dbatch>();
+  db->nrows = nrows;
+  db->ns = o->table_ns ? o->table_ns : ""; db->table = o->table_name ? o->table_name : "";
+  db->src_row = dalloc((size_t)nra * 4); db->part_id = dalloc((size_t)nra * 4);
+  Buf row_frame = dalloc((size_t)nra * 4);
+  p.row_frame = ptr<uint32_t>(row_frame); p.nrows = nrows;
+  std::vector<sr::OutCol> oc((size_t)np);
+  std::vector<int32_t> text_cols;
+  const int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
+  int ntext = 0;
+  for (int j = 0; j < np; j++) if (o->props[j].json_type >= TFGPU_SRT_NUMBER) ntext++;
+  Buf lens_all = dalloc_zero((size_t)std::max(ntext, 1) * (size_t)seg_stride * 4 + 16);
+  Buf valid8 = dalloc((size_t)std::max(np, 1) * (size_t)nra);
+  int ti = 0;
+  for (int j = 0; j < np; j++) {
+    const tfgpu_sr_property &pr = o->props[j];
+    DColumn d;
+    d.name = pr.name;
+    sr::OutCol &c = oc[(size_t)j];
+    std::memset(&c, 0, sizeof c);
+    c.json_type = pr.json_type;
+    switch (pr.json_type) {
+      case TFGPU_SRT_BOOLEAN: d.dtype = TFGPU_T_BOOLEAN; d.repr = TFGPU_R_BOOL; d.values = dalloc_zero((size_t)nra); c.values = d.values->p; break;
+      case TFGPU_SRT_INTEGER: d.dtype = TFGPU_T_INT64; d.repr = TFGPU_R_INT64; d.values = dalloc_zero((size_t)nra * 8); c.values = d.values->p; break;
+      case TFGPU_SRT_NUMBER: d.dtype = TFGPU_T_FLOAT64; d.repr = TFGPU_R_JSONNUM; break;
+      case TFGPU_SRT_STRING: d.dtype = TFGPU_T_UTF8; d.repr = TFGPU_R_STRING; break;
+      default: d.dtype = TFGPU_T_ANY; d.repr = TFGPU_R_JSON;
+    }
+    if (pr.json_type >= TFGPU_SRT_NUMBER) {
+      d.offsets = subbuf(lens_all, (size_t)ti * (size_t)seg_stride * 4, (size_t)(nrows + 1) * 4);
+      c.lens = ptr<uint32_t>(d.offsets);
+      text_cols.push_back(j);
+      ti++;
+    }
+    c.valid8 = ptr<uint8_t>(valid8) + (size_t)j * (size_t)nra;
+    d.validity = dalloc_zero((size_t)((nra + 7) / 8) + 8);
+    c.validity = ptr<uint8_t>(d.validity);
+    db->schema.push_back({d.name, d.dtype});
+    db->cols.push_back(std::move(d));
+  }
+  Buf boc = upload_small(oc.data(), std::max<size_t>(oc.size(), 1) * sizeof(sr::OutCol));
+  if (nrows) {
+    sr::sr_row_frames<<<sr::nblk(nf, 256), 256, 0, st>>>(p);
+    if (np) { KernelTimer t("sr_cell_values"); sr::sr_cell_values<<<sr::nblk((int64_t)np * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id)); }
+    if (np) sr::sr_pack_validity<<<sr::nblk((int64_t)np * ((nrows + 7) / 8), 256), 256, 0, st>>>(ptr<sr::OutCol>(boc), np, nrows);
+  }
+  if (np == 0 && nrows) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR json: a schema without properties");
+  if (ntext) {
+    exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);  // offsets in place, the total at [nrows]
+    std::vector<const uint32_t *> tot((size_t)ntext);
+    for (int t = 0; t < ntext; t++) tot[(size_t)t] = d2h_u32(ptr<uint32_t>(lens_all) + (int64_t)t * seg_stride + nrows);
+    tf::sync();
+    for (int t = 0; t < ntext; t++) {
+      DColumn &d = db->cols[(size_t)text_cols[(size_t)t]];
+      d.data_len = *tot[(size_t)t];
+      d.data = dalloc(d.data_len + 8);
+      oc[(size_t)text_cols[(size_t)t]].data = ptr<uint8_t>(d.data);
+    }
+    boc = upload_small(oc.data(), oc.size() * sizeof(sr::OutCol));
+    Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
+    if (nrows) { KernelTimer t("sr_cell_text"); sr::sr_cell_text<<<sr::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext); }
+  }
+  // ---- frames the reference turns into `_unparsed` items / rows for the stock path ----
+  int64_t ne = 0;
+  if (nerr_total) {
+    std::vector<uint8_t> hst((size_t)nf);
+    std::vector<tfgpu_sr_frame> hfr((size_t)nf);
+    d2h(hst.data(), status->p, (size_t)nf); d2h(hfr.data(), s.frames->p, (size_t)nf * sizeof(tfgpu_sr_frame));
+    tf::sync();
+    for (int64_t f = 0; f < nf; f++) {
+      const int c = hst[(size_t)f];
+      if (c == sr::ST_OK || c == sr::ST_OTHER || c == sr::ST_DROPPED) continue;
+      if (errs && ne < errs_cap) errs[ne] = tfgpu_row_error{f, c, (int32_t)hfr[(size_t)f].msg, -1};
+      ne++;
+    }
+  }
+  tf::sync();
+  if (nerrs) *nerrs = ne;
+  *out = db.release();
+  return TFGPU_OK;
+  TF_API_END
+}

@@ -27,7 +27,7 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -86,6 +86,9 @@ def load():
     L.tfgpu_json_parse.argtypes = [C.POINTER(abi.CJsonOptions), C.POINTER(abi.CSchema), P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages),
                                    C.POINTER(P), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_json_result_schema.argtypes = [C.POINTER(abi.CJsonOptions), C.POINTER(abi.CSchema), C.POINTER(C.POINTER(abi.CSchema))]
+    L.tfgpu_sr_frames.argtypes = [P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), C.POINTER(abi.CSrFrame), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_sr_json_parse.argtypes = [C.POINTER(abi.CSrJsonOptions), P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), C.POINTER(P), C.POINTER(abi.CRowError),
+                                      C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_serialize.argtypes = [C.c_int, P, C.POINTER(P)]
     L.tfgpu_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(P)]
     L.tfgpu_queue_serialize.argtypes = [C.POINTER(abi.CQueueOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(P), P, P, C.c_int64, C.POINTER(C.c_int64)]
@@ -481,6 +484,54 @@ def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data, msgs: Optional[
     el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
           for i in range(min(int(nerr.value), max_errors))]
     return DeviceBatch(out), el
+
+
+def _bytes_arg(data):
+    """(pointer, length, mem, keep-alive) of host bytes or a DeviceBuffer."""
+    if isinstance(data, DeviceBuffer):
+        return data.ptr, data.size, abi.MEM_DEVICE, data
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    return buf.ctypes.data, len(data), abi.MEM_HOST, buf
+
+
+def sr_frames(data, msgs: Optional[abi.CMessages] = None):
+    """ConfluentSrImpl.DoBuf's walk over every message: [(msg, start, len, schema_id, code, index)] — the shim asks the
+    registry for the schema ids it finds here."""
+    init()
+    ptr_, n, mem, keep = _bytes_arg(data)
+    cap = max(int(msgs.nmsg) if msgs is not None else 1, 16)
+    while True:
+        arr = (abi.CSrFrame * cap)()
+        nf = C.c_int64(0)
+        rc = load().tfgpu_sr_frames(ptr_, n, mem, C.byref(msgs) if msgs is not None else None, arr, cap, C.byref(nf))
+        if rc != 0 and nf.value > cap:
+            cap = int(nf.value)
+            continue
+        _check(rc)
+        return [(int(f.msg), int(f.start), int(f.len), int(f.schema_id), int(f.code), int(f.index)) for f in arr[:int(nf.value)]]
+
+
+class ParseResult:
+    def __init__(self, batch: "DeviceBatch", errors):
+        self.device_batch, self.errors = batch, errors
+        self._host = None
+
+    @property
+    def batch(self) -> abi.Batch:
+        if self._host is None:
+            self._host = self.device_batch.download()
+        return self._host
+
+
+def sr_json_parse(opts: abi.CSrJsonOptions, data, msgs: Optional[abi.CMessages] = None, max_errors: int = 1 << 16) -> ParseResult:
+    """Confluent SR parser, JSON-schema frames of opts.schema_id → one device batch (rows: src_row = frame ordinal,
+    part_id = message index) + [(frame ordinal, code, message index)] for the frames that become `_unparsed` items."""
+    init()
+    ptr_, n, mem, keep = _bytes_arg(data)
+    errs = (abi.CRowError * max_errors)()
+    ne, out = C.c_int64(0), C.c_void_p()
+    _check(load().tfgpu_sr_json_parse(C.byref(opts), ptr_, n, mem, C.byref(msgs) if msgs is not None else None, C.byref(out), errs, max_errors, C.byref(ne)))
+    return ParseResult(DeviceBatch(out), [(int(errs[i].row), int(errs[i].code), int(errs[i].step)) for i in range(min(int(ne.value), max_errors))])
 
 
 def json_result_schema(opts: abi.CJsonOptions, fields: abi.Schema) -> abi.Schema:
