@@ -162,6 +162,79 @@ def json_main(args):
         "row_errors": state["errors"], "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
 
 
+def sr_main(args):
+    """--workload sr: the Confluent-SR half of BASELINE.json configs[2] / [4] as a SIDE benchmark: Kafka messages in the
+    Schema Registry wire format (0x00 | schema id | one flat hits object, JSON schema of the hits table) → tfgpu_sr_json_parse
+    → queue JSON serializer with batching (the "→ Kafka sink" half), all HBM-resident; the oracle on a bounded sample."""
+    args.rows = min(args.rows, 1 << 18)
+    args.cpu_rows = min(args.cpu_rows, 1 << 13)
+    from transferia_amd import abi, confluent_sr, lib, workload
+    lib.init(0)
+    vals = make_messages(workload, abi, args.rows)
+    rows = len(vals)
+    jt = {"int16": "integer", "int32": "integer", "int64": "integer", "timestamp": "integer"}
+    props = {name: {"type": jt.get(typ, "string")} for name, typ, _ in workload.hits_columns()}
+    schema_text = json.dumps({"type": "object", "title": "default.hits", "properties": props, "required": ["watchid"]})
+    sid = 42
+    frames = [b"\0" + sid.to_bytes(4, "big") + v for v in vals]
+    data, msgs = abi.messages(frames, list(range(rows)), [1_700_000_000_000_000_000 + i for i in range(rows)])
+    opts = confluent_sr.sr_json_options(sid, schema_text)
+    qopts = abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=1 << 20)
+    dbuf = lib.DeviceBuffer.upload(data)
+    state = {}
+
+    def step(keep=False):
+        res = lib.sr_json_parse(opts, dbuf, msgs)
+        out = lib.queue_serialize(qopts, res.device_batch)
+        if keep:
+            state.update(parsed=res.device_batch.nrows, parsed_bytes=res.device_batch.payload_bytes(), out_bytes=out.values.size, messages=len(out), errors=len(res.errors))
+        out.values.free(); res.device_batch.free()
+
+    for _ in range(args.warmup):
+        step()
+    step(keep=True)
+    lib.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    lib.synchronize()
+    dt = time.perf_counter() - t0
+    lib.prof_reset(); lib.prof_enable(True)
+    for _ in range(3):
+        step()
+    lib.prof_enable(False)
+    prof = lib.prof_get()
+    kernels = {n: {"launches_per_step": l / 3, "avg_ms": round(ms / l, 4), "ms_per_step": round(ms / 3, 4)} for n, l, ms in prof if l}
+    alg = {"sr_parse_frames": len(data), "sr_cell_values": len(data) + state["parsed_bytes"], "sr_cell_text": 2 * state["parsed_bytes"],
+           "ser_cell_write": state["parsed_bytes"] + state["out_bytes"], "ser_cell_len": state["parsed_bytes"]}
+    dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
+    roofline = None
+    if dom in alg:
+        ach = alg[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                    "traffic": None, "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"]}
+    cpu = None
+    if args.cpu_rows > 0:
+        from oracle import oracle as ora
+        k = min(args.cpu_rows, rows)
+        d2, m2 = abi.messages(frames[:k], list(range(k)), [0] * k)
+        r1 = ora.sr_json_parse(opts, d2, m2)
+        ora.queue_serialize(qopts, r1.batch, r1.schema)
+        sec = r1.seconds + ora.queue_serialize.seconds
+        cpu = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{k} of the same messages through the oracle's SR JSON parser ({r1.seconds:.2f}s) + queue JSON serializer ({ora.queue_serialize.seconds:.2f}s), single thread",
+               "note": "C restatement of the Go reference (decoded value tree, boxed values per row), not the Go binary"}
+    print(json.dumps({
+        "metric": "ChangeItems/sec through Confluent-SR JSON parse -> queue JSON serializer (batched), ClickBench hits", "value": round(rows * args.steps / dt, 1),
+        "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "Kafka messages in the Schema Registry wire format (one flat hits object each) -> SR JSON parser -> queue JSON serializer, 1 MiB batches "
+                               "(the ingest of BASELINE.json configs[2] and the sink half of configs[4])",
+                   "rows_per_step": rows, "wire_bytes_per_step": len(data), "columns": len(props)},
+        "gib_per_s_wire_in": round(len(data) * args.steps / dt / 2**30, 3), "rows_out_per_step": state["parsed"], "messages_out_per_step": state["messages"],
+        "text_out_bytes_per_step": state["out_bytes"], "row_errors": state["errors"], "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
+
+
 def collapse_main(args):
     """--workload collapse: abstract.Collapse (the PK-keyed dedup of BASELINE.json configs[4]) as a SIDE benchmark: a CDC
     slice (workload.cdc_batch) resident in HBM → tfgpu_collapse; the oracle's restatement of the Go maps as cpu_baseline."""
@@ -211,7 +284,7 @@ def collapse_main(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["csv", "json", "collapse"], default="csv",
+    ap.add_argument("--workload", choices=["csv", "json", "collapse", "sr"], default="csv",
                     help="csv = BASELINE.json configs[1] (the bench line); json = configs[2] shape, collapse = configs[4]'s dedup: side benchmarks")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -228,6 +301,8 @@ def main():
         return json_main(args)
     if args.workload == "collapse":
         return collapse_main(args)
+    if args.workload == "sr":
+        return sr_main(args)
 
     import torch
     from transferia_amd import dist as tdist
