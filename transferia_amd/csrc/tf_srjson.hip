@@ -233,7 +233,18 @@ __device__ int rune_compare(RuneIter a, RuneIter b) {
   }
 }
 struct CountSink { uint32_t n = 0; __device__ __forceinline__ void put(uint32_t) { n++; } };
-struct ByteSink { uint8_t *p; __device__ __forceinline__ void put(uint32_t c) { *p++ = (uint8_t)c; } };
+// Bytes leave eight at a time through one (possibly unaligned) 8-byte store, like tf_emit.hpp's WriteSink.  (A sink that
+// bumps a uint8_t* per byte next to MemBytes' cached window was miscompiled for gfx950 at -O3 — the pointer was clobbered
+// after the first store; tools/hipemu cannot see that, the MI355X run did.)
+struct ByteSink {
+  uint8_t *p; uint64_t acc = 0; uint32_t n = 0;
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  __device__ __forceinline__ void put(uint32_t c) {
+    acc |= (uint64_t)(c & 0xFFu) << (8 * n);
+    if (++n == 8) { reinterpret_cast<U64 *>(p)->v = acc; p += 8; acc = 0; n = 0; }
+  }
+  __device__ __forceinline__ void flush() { for (; n; n--) { *p++ = (uint8_t)acc; acc >>= 8; } }
+};
 template <class S> __device__ __forceinline__ void put_utf8(S &o, uint32_t r) {
   if (r < 0x80) o.put(r);
   else if (r < 0x800) { o.put(0xC0 | (r >> 6)); o.put(0x80 | (r & 63)); }
@@ -482,6 +493,7 @@ __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols
   if (c.json_type == TFGPU_SRT_NUMBER) { for (uint32_t k = 0; k < vl; k++) s.put(rd.at(vs + k)); }
   else if (c.json_type == TFGPU_SRT_STRING) emit_unquoted(s, rd, vs, vl);
   else emit_any(s, rd, vs, vl);
+  s.flush();
 }
 __global__ void __launch_bounds__(256) sr_pack_validity(const OutCol *cols, int32_t nprops, int64_t nrows) {
   const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
