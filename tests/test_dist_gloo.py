@@ -135,3 +135,78 @@ def test_hash_partition_exchange_over_gloo(tmp_path, oracle):
         assert o["nanos"] == [i % 1000 for i in exp]
         assert o["recv"] == [outs[0]["sent"][r], outs[1]["sent"][r]]
     assert sorted(outs[0]["ids"] + outs[1]["ids"]) == sorted(all_ids[0] + all_ids[1])
+
+
+CDC_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    sys.path.insert(0, os.path.join({root!r}, "tests"))
+    import torch.distributed as dist
+    from transferia_amd import abi, dist as tdist, partition, workload
+    from oracle import oracle as ora
+    g = tdist.Group("gloo")
+    rank, world = g.rank, g.world
+    # one CDC stream (OldKeys on most updates / deletes, no PK changes: a key never moves between shards), every rank
+    # owning a contiguous slice of it in stream order
+    N = 4000
+    whole, schema = workload.cdc_batch(N, p_pk_change=0.0)
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    def rows_of(b, idx):
+        out = abi.Batch([], len(idx), b.table_ns, b.table_name)
+        for c in b.cols:
+            if c.repr in abi.VAR_REPRS:
+                parts = [c.get_bytes(int(i)) for i in idx]
+                off = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.uint32)
+                out.cols.append(abi.Column(c.name, c.dtype, c.repr, offsets=off, data=np.frombuffer(b"".join(parts) or b"\\0", np.uint8).copy()))
+            else:
+                out.cols.append(abi.Column(c.name, c.dtype, c.repr, values=c.values[idx].copy()))
+        out.kind = b.kind[idx].copy()
+        k = b.old_keys[0]
+        out.old_keys = [abi.Column(k.name, k.dtype, k.repr, values=k.values[idx].copy(), validity=k.validity[idx].copy())]
+        out.old_present = b.old_present[idx].copy()
+        out.schema = schema
+        return out
+    mine = rows_of(whole, np.arange(lo, hi))
+    sh = ora.Transformer("sharder_transformer", {{"shardsCount": str(world), "columns": {{"includeColumns": ["^id$"]}}}})
+    part = sh.apply(mine, schema).batch.part_id.astype(np.int64)
+    order = np.argsort(part, kind="stable")
+    grouped = rows_of(mine, order)
+    counts = [int((part == d).sum()) for d in range(world)]
+    got = partition.exchange_host_batch(dist, grouped, counts)
+    col = ora.collapse(got, schema).batch
+    rows = sorted((int(col.col("id").values[i]), int(col.col("ver").values[i]), int(col.kind[i]), col.col("payload").get_bytes(i).decode()) for i in range(col.nrows))
+    print(json.dumps({{"rank": rank, "rows": rows, "received": got.nrows, "old_present": int(got.old_present.sum())}}))
+    g.close()
+""")
+
+
+def test_exchange_then_collapse_over_gloo(tmp_path, oracle):
+    """configs[4] end to end on CPU: hash-partition → all-to-all (OldKeys travel with their rows) → Collapse per rank.
+    The union of the per-rank results is the Collapse of the whole stream: rows of one key meet on one rank, in stream order."""
+    import json
+    import zlib
+
+    from transferia_amd import workload
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "cdcworker.py"
+    script.write_text(CDC_WORKER.format(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    whole, schema = workload.cdc_batch(4000, p_pk_change=0.0)
+    ref = oracle.collapse(whole, schema).batch
+    exp = sorted((int(ref.col("id").values[i]), int(ref.col("ver").values[i]), int(ref.kind[i]), ref.col("payload").get_bytes(i).decode()) for i in range(ref.nrows))
+    got = sorted([tuple(r) for o in outs for r in o["rows"]])
+    assert got == exp and len(exp) > 500
+    for r, o in enumerate(outs):  # every row sits on the rank its key hashes to (sharder.go:130-145)
+        assert all(zlib.crc32(str(row[0]).encode()) % 2 == r for row in o["rows"])
+    assert outs[0]["received"] + outs[1]["received"] == 4000
+    assert outs[0]["old_present"] + outs[1]["old_present"] == int(whole.old_present.sum()) > 0

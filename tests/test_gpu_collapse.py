@@ -163,3 +163,53 @@ def test_keys_changed(tf, oracle):
     assert list(tf.keys_changed(tf.DeviceBatch.upload(fb))) == [False, True, False]
     fb.old_keys = abi.batch_from_rows(abi.Schema([abi.ColSchema("f", "int64", True, "", "")]), ["f"], [[["int64", 1]], [["int64", 0]], [["int64", 0]]]).cols
     assert list(tf.keys_changed(tf.DeviceBatch.upload(fb))) == [True, True, True]
+
+
+@pytest.mark.gpu
+def test_configs4_pipeline_single_rank(tf, oracle):
+    """configs[4] on one GPU: sharder → tfgpu_partition → all-to-all over RCCL (world 1: every buffer, OldKeys included,
+    makes the round trip through torch) → tfgpu_collapse → native queue serializer.  The messages are the oracle's for
+    the same stream.  Own process, torch first: libtfgpu and torch must share the HIP runtime torch loads."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import socket, sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+        import numpy as np
+        import torch, torch.distributed as dist
+        torch.cuda.set_device(0); torch.cuda.init()
+        from transferia_amd import lib as tf, workload, partition, abi
+        from oracle import oracle
+        tf.init(0)
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, world_size=1, rank=0, device_id=torch.device("cuda", 0))
+        N = 20000
+        b, schema = workload.cdc_batch(N, p_pk_change=0.0)
+        db = tf.DeviceBatch.upload(b)
+        one = tf.Transformer("sharder_transformer", {"shardsCount": "1", "columns": {"includeColumns": ["^id$"]}}).apply(db).transformed
+        grouped, counts = tf.partition(one, 1)
+        assert counts == [N]
+        back, recv = partition.exchange_device_batch(dist, tf, grouped, counts, schema)
+        assert recv == [N]
+        got = back.download()
+        assert np.array_equal(got.old_present, b.old_present) and np.array_equal(got.old_keys[0].values[b.old_present], b.old_keys[0].values[b.old_present])
+        col = tf.collapse(back)
+        ref = oracle.collapse(b, schema).batch
+        a = col.download()
+        key = lambda x: sorted((int(x.col("id").values[i]), int(x.col("ver").values[i]), int(x.kind[i])) for i in range(x.nrows))
+        assert key(a) == key(ref) and a.nrows < N
+        meta = abi.row_meta(N, ids=np.arange(N) %% 97, lsns=np.arange(N, dtype=np.uint64) + 5, commit_times=np.full(N, 1700000000000000000, np.uint64))
+        o = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 16, table_schema=schema)
+        msgs = tf.queue_serialize(o, col, meta).messages()
+        # the oracle serialises the device's collapsed rows (same order, same src_row → same row meta)
+        a.schema = schema
+        exp = oracle.queue_serialize(o, a, schema, meta)
+        assert msgs == exp and len(msgs) > 10
+        dist.destroy_process_group()
+        print("PIPELINE_OK", a.nrows, len(msgs))
+    """ % (root, root))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PIPELINE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

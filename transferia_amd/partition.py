@@ -47,14 +47,14 @@ def exchange_host_batch(dist, b: abi.Batch, counts: Sequence[int]) -> abi.Batch:
     assert len(counts) == world and sum(counts) == b.nrows
     recv = exchange_counts(dist, counts)
     n_out = sum(recv)
-    cols = []
-    for c in b.cols:
+    bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+
+    def xchg(c):
         o = abi.Column(c.name, c.dtype, c.repr)
         if c.repr in abi.VAR_REPRS:
             lens = np.diff(c.offsets.astype(np.int64)).astype(np.uint32)
             rl = _a2a(dist, torch.from_numpy(lens.view(np.int32)), counts, recv).numpy().view(np.uint32)
             # bytes per destination = sum of the lengths of that run
-            bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
             bsend = [int(c.offsets[bounds[d + 1]]) - int(c.offsets[bounds[d]]) for d in range(world)]
             brecv = exchange_counts(dist, bsend)
             data = np.ascontiguousarray(c.data[: int(c.offsets[-1])], dtype=np.uint8)
@@ -70,18 +70,27 @@ def exchange_host_batch(dist, b: abi.Batch, counts: Sequence[int]) -> abi.Batch:
         if c.validity is not None:
             v = np.ascontiguousarray(c.validity, dtype=np.uint8)
             o.validity = _a2a(dist, torch.from_numpy(v), counts, recv).numpy().astype(bool)
-        cols.append(o)
+        return o
+    cols = [xchg(c) for c in b.cols]
     out = abi.Batch(cols, n_out, b.table_ns, b.table_name)
     if b.kind is not None:
         out.kind = _a2a(dist, torch.from_numpy(np.ascontiguousarray(b.kind, dtype=np.uint8)), counts, recv).numpy()
     if b.src_row is not None:
         out.src_row = _a2a(dist, torch.from_numpy(np.ascontiguousarray(b.src_row, dtype=np.int32)), counts, recv).numpy()
+    old_keys = list(getattr(b, "old_keys", None) or [])
+    if old_keys:  # ChangeItem.OldKeys travel with their rows: Collapse on the receiving rank reads them
+        out.old_keys = [xchg(c) for c in old_keys]
+        pres = getattr(b, "old_present", None)
+        pres = np.ones(b.nrows, np.uint8) if pres is None else np.ascontiguousarray(pres, dtype=np.uint8)
+        out.old_present = _a2a(dist, torch.from_numpy(pres), counts, recv).numpy().astype(bool)
     out.part_id = np.full(n_out, dist.get_rank(), dtype=np.uint32)
     out.recv_counts = recv  # rows received from each source rank, in rank order
+    if getattr(b, "schema", None) is not None:
+        out.schema = b.schema  # TableSchema (PrimaryKey flags): constant per table, never exchanged
     return out
 
 
-def exchange_device_batch(dist, lib, db, counts: Sequence[int]):
+def exchange_device_batch(dist, lib, db, counts: Sequence[int], schema: "abi.Schema" = None):
     """The same exchange with the column buffers left in HBM: torch tensors view the library's device buffers (CUDA
     array interface), RCCL moves them, and the received buffers become a library batch again (device-to-device)."""
     import ctypes as C
@@ -101,11 +110,23 @@ def exchange_device_batch(dist, lib, db, counts: Sequence[int]):
         return torch.as_tensor(_View(ptr, nbytes), device=dev)[: int(nbytes)]
 
     lib.synchronize()  # the partition kernels ran on the library's stream, the collective runs on torch's
-    keep, carr = [], (abi.CColumn * max(v.ncols, 1))()
+    nold = int(v.n_old_keys)
+    keep, carr = [], (abi.CColumn * max(v.ncols + nold, 1))()
     bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    for i in range(v.ncols):
-        c = v.cols[i]
-        carr[i].name, carr[i].dtype, carr[i].repr = c.name, c.dtype, c.repr
+
+    def xchg_bits(ptr):
+        """a bitmap is not byte-aligned per destination: exchange one byte per row, repack"""
+        bits = tensor(ptr, (n_in + 7) // 8)
+        un = ((bits[:, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(-1)[:n_in].contiguous()
+        rb = _a2a(dist, un, counts, recv)
+        pad = torch.zeros((n_out + 7) // 8 * 8, dtype=torch.uint8, device=dev)
+        pad[:n_out] = rb
+        packed = (pad.reshape(-1, 8) << torch.arange(8, device=dev, dtype=torch.uint8)).sum(1).to(torch.uint8)
+        keep.append(packed)
+        return packed.data_ptr()
+
+    def xchg(c, dst):
+        dst.name, dst.dtype, dst.repr = c.name, c.dtype, c.repr
         if c.repr in abi.VAR_REPRS:
             off = tensor(c.offsets, (n_in + 1) * 4).view(torch.int32)
             lens = (off[1:] - off[:-1]).contiguous()
@@ -116,35 +137,41 @@ def exchange_device_batch(dist, lib, db, counts: Sequence[int]):
             rd = _a2a(dist, tensor(c.data, int(c.data_len)), bsend, brecv)
             ro = torch.zeros(n_out + 1, dtype=torch.int32, device=dev)
             ro[1:] = torch.cumsum(rl, 0)
-            keep += [rl, rd, ro]
-            carr[i].offsets, carr[i].data, carr[i].data_len = ro.data_ptr(), rd.data_ptr() if rd.numel() else ro.data_ptr(), int(sum(brecv))
+            keep.extend([rl, rd, ro])
+            dst.offsets, dst.data, dst.data_len = ro.data_ptr(), rd.data_ptr() if rd.numel() else ro.data_ptr(), int(sum(brecv))
         else:
             w = np.dtype(abi.REPR_NP[c.repr]).itemsize
             rv = _a2a(dist, tensor(c.values, n_in * w), counts, recv, w)
             keep.append(rv)
-            carr[i].values = rv.data_ptr()
+            dst.values = rv.data_ptr()
             if c.nanos:
                 rn = _a2a(dist, tensor(c.nanos, n_in * 4), counts, recv, 4)
                 keep.append(rn)
-                carr[i].nanos = rn.data_ptr()
-        if c.validity:  # bitmaps are not byte-aligned per destination: exchange one byte per row, repack
-            bits = tensor(c.validity, (n_in + 7) // 8)
-            un = ((bits[:, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(-1)[:n_in].contiguous()
-            rb = _a2a(dist, un, counts, recv)
-            pad = torch.zeros((n_out + 7) // 8 * 8, dtype=torch.uint8, device=dev)
-            pad[:n_out] = rb
-            packed = (pad.reshape(-1, 8) << torch.arange(8, device=dev, dtype=torch.uint8)).sum(1).to(torch.uint8)
-            keep.append(packed)
-            carr[i].validity = packed.data_ptr()
+                dst.nanos = rn.data_ptr()
+        if c.validity:
+            dst.validity = xchg_bits(c.validity)
+    for i in range(v.ncols):
+        xchg(v.cols[i], carr[i])
+    for k in range(nold):
+        xchg(v.old_keys[k], carr[v.ncols + k])
     hb = abi.CBatch()
     hb.nrows, hb.ncols, hb.cols, hb.mem = n_out, v.ncols, carr, abi.MEM_DEVICE
     hb.table_ns, hb.table_name = v.table_ns, v.table_name
+    if nold:  # ChangeItem.OldKeys travel with their rows: tfgpu_collapse on the receiving rank reads them
+        hb.n_old_keys = nold
+        hb.old_keys = C.cast(C.byref(carr, C.sizeof(abi.CColumn) * v.ncols), C.POINTER(abi.CColumn))
+        if v.old_keys_present:
+            hb.old_keys_present = xchg_bits(v.old_keys_present)
     if v.kind:
         rk = _a2a(dist, tensor(v.kind, n_in), counts, recv)
         keep.append(rk); hb.kind = rk.data_ptr()
     if v.src_row:
         rs = _a2a(dist, tensor(v.src_row, n_in * 4), counts, recv, 4)
         keep.append(rs); hb.src_row = rs.data_ptr()
+    if schema is not None:  # TableSchema (PrimaryKey flags) for tfgpu_collapse on the receiving rank: constant per table
+        cs = schema.to_c()
+        keep.append(cs)
+        hb.schema = C.pointer(cs)
     torch.cuda.synchronize()
     h = C.c_void_p()
     lib._check(lib.load().tfgpu_batch_upload(C.byref(hb), C.byref(h)))
