@@ -339,7 +339,11 @@ typedef struct tfgpu_json_options {
   uint8_t mark_dedupe_keys_as_system; /* MarkDedupeKeysAsSystem (json.lb: SkipSystemKeys)     */
   const char *topic;              /* AuxOpts.Topic → GenericParser.name → ChangeItem.Table   */
   const char *partition;          /* abstract.Partition.String() of the batch (PartID)       */
+  uint8_t format;                 /* GenericParserConfig.Format: TFGPU_JFMT_JSON (0) or TFGPU_JFMT_TSKV — tab-separated
+                                     key=value fields, every value a Go string (generic_parser.go:732-746); with
+                                     unescape_string_values: tryToUnescapeTSKV (:643-670) on text columns         */
 } tfgpu_json_options;
+enum { TFGPU_JFMT_JSON = 0, TFGPU_JFMT_TSKV = 1 };
 
 /* parsers.MessageBatch (pkg/parsers/abstract.go): Messages[i].Value concatenated in `bytes`.   */
 typedef struct tfgpu_messages {

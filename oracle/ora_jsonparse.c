@@ -538,7 +538,7 @@ static ora_value unmarshal_value(const fj_value *v, int dtype, const tfgpu_json_
   if (v->t == FJ_NULL) return r;
   if (v->t == FJ_STR) {
     size_t n; char *s = fj_unescape(v->s, v->n, &n);
-    if (o->unescape_string_values) *unrestated = 1;  /* tryToUnescapeJSON: encoding/json string decoding, not restated */
+    if (o->unescape_string_values && o->format != TFGPU_JFMT_TSKV) *unrestated = 1;  /* tryToUnescapeJSON: encoding/json string decoding, not restated (tskv: already applied) */
     r = val_str(OV_STRING, s, n); free(s);
     return r;
   }
@@ -740,6 +740,57 @@ tfgpu_schema *ora_json_result_schema(const tfgpu_json_options *o, const tfgpu_sc
 
 static const char *col_path(const tfgpu_colschema *c) { return (c->path && c->path[0]) ? c->path : c->name; }
 
+/* ---- GenericParser.Unmarshal, Format "tskv" (:732-746) + tryToUnescapeTSKV (:643-670) ----
+ * strings.Split(line, "\t"), SplitN(field, "=", 2); a field without '=' is skipped; every value is a Go string.  The map
+ * is handed on as a fastjson-shaped object whose keys and string values are JSON-escaped copies (", \ and control bytes),
+ * so that the unescape every consumer below applies gives the raw bytes back.  `buf` owns the copies for the line. */
+static size_t tskv_escape(char *dst, const char *s, size_t n) {
+  static const char H[] = "0123456789abcdef";
+  size_t w = 0;
+  for (size_t i = 0; i < n; i++) {
+    unsigned char c = (unsigned char)s[i];
+    if (c == '"' || c == '\\') { dst[w++] = '\\'; dst[w++] = (char)c; }
+    else if (c < 0x20) { dst[w++] = '\\'; dst[w++] = 'u'; dst[w++] = '0'; dst[w++] = '0'; dst[w++] = H[c >> 4]; dst[w++] = H[c & 15]; }
+    else dst[w++] = (char)c;
+  }
+  return w;
+}
+static size_t tskv_unescape(char *dst, const char *s, size_t n) {  /* the input itself when an escape is broken */
+  size_t w = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (s[i] != '\\') { dst[w++] = s[i]; continue; }
+    if (i == n - 1) { memcpy(dst, s, n); return n; }
+    char c = s[i + 1], out;
+    if (c == '\\') out = '\\'; else if (c == 'n') out = '\n'; else if (c == 'r') out = '\r'; else if (c == 't') out = '\t'; else if (c == '=') out = '=';
+    else { memcpy(dst, s, n); return n; }
+    dst[w++] = out; i++;
+  }
+  return w;
+}
+static fj_value *tskv_object(const char *line, size_t ln, int unescape, char **buf, size_t *cap) {
+  if (*cap < ln * 7 + 16) { *cap = ln * 7 + 16; *buf = (char *)realloc(*buf, *cap); }
+  char *w = *buf, *tmp = *buf + ln * 6 + 8;  /* tmp: ln bytes for the unescaped value */
+  fj_value *root = fj_new(FJ_OBJ);
+  size_t a = 0;
+  while (a <= ln) {
+    const char *t = (const char *)memchr(line + a, '\t', ln - a);
+    const size_t z = t ? (size_t)(t - line) : ln;
+    const char *eq = (const char *)memchr(line + a, '=', z - a);
+    if (eq) {
+      const size_t ke = (size_t)(eq - line);
+      const char *k = w; size_t kl = tskv_escape(w, line + a, ke - a); w += kl;
+      const char *vs = line + ke + 1; size_t vn = z - ke - 1;
+      if (unescape) { vn = tskv_unescape(tmp, vs, vn); vs = tmp; }
+      fj_value *v = fj_new(FJ_STR);
+      v->s = w; v->n = tskv_escape(w, vs, vn); w += v->n;
+      fj_push(root, v, k, kl);
+    }
+    if (!t) break;
+    a = z + 1;
+  }
+  return root;
+}
+
 ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *fields, const void *bytes, uint64_t len,
                           const tfgpu_messages *msgs, ora_json_lines **lines_out) {
   ora_batch *out = ora_batch_new();
@@ -763,6 +814,8 @@ ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *field
   if (!msgs) msgs = &single;
 
   const char *data = (const char *)bytes;
+  const int tskv = o->format == TFGPU_JFMT_TSKV;
+  char *tskv_buf = NULL; size_t tskv_cap = 0;
   for (int64_t m = 0; m < msgs->nmsg; m++) {
     const char *p = data + msgs->start[m], *e = data + msgs->start[m + 1];
     int idx = 0;
@@ -787,7 +840,7 @@ ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *field
       L->status[ord] = ORA_JL_ROW; L->code[ord] = 0; L->column[ord] = -1; L->msg[ord] = (int32_t)m; L->idx[ord] = idx; L->row[ord] = -1;
 
       const char *perr = NULL;
-      fj_value *root = fj_parse(line, ln, &perr);
+      fj_value *root = tskv ? tskv_object(line, ln, o->unescape_string_values, &tskv_buf, &tskv_cap) : fj_parse(line, ln, &perr);
       if (!root) { L->status[ord] = ORA_JL_UNPARSED; L->code[ord] = TFGPU_ROW_JSON_SYNTAX; ora_batch_add_error(out, ord, TFGPU_ROW_JSON_SYNTAX, perr); continue; }
       if (root->t != FJ_OBJ || root->nkids == 0) { L->status[ord] = ORA_JL_SKIPPED; fj_free(root); continue; }
 
@@ -827,7 +880,7 @@ ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *field
           go_json_string(&restb, ks[i].k, ks[i].kl);
           sb_c(&restb, ':');
           const fj_value *kv = root->kids[ks[i].idx];
-          if (kv->t == FJ_STR) { size_t sn; char *s = fj_unescape(kv->s, kv->n, &sn); go_json_string(&restb, s, sn); free(s); if (o->unescape_string_values) unrestated = 1; }
+          if (kv->t == FJ_STR) { size_t sn; char *s = fj_unescape(kv->s, kv->n, &sn); go_json_string(&restb, s, sn); free(s); if (o->unescape_string_values && !tskv) unrestated = 1; }
           else go_marshal_any(&restb, kv, o->use_numbers_in_any);
         }
         sb_c(&restb, '}');
@@ -903,7 +956,7 @@ ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *field
       fj_free(root);
     }
   }
-  free(tname);
+  free(tname); free(tskv_buf);
   /* drop our own references */
   if (--nm->refs == 0) { for (int i = 0; i < nm->n; i++) free(nm->names[i]); free(nm->names); free(nm); }
   ora_schema_unref(sch);

@@ -105,7 +105,8 @@ def case_inputs(case):
     o = case["options"]
     opts = abi.json_options(add_rest=o.get("add_rest", False), add_dedupe_keys=o.get("add_dedupe_keys", False),
                             null_keys_allowed=o.get("null_keys_allowed", False), use_numbers_in_any=o.get("use_numbers_in_any", False),
-                            unpack_bytes_base64=o.get("unpack_bytes_base64", False), topic=o.get("topic", ""), partition=o.get("partition", ""))
+                            unpack_bytes_base64=o.get("unpack_bytes_base64", False), topic=o.get("topic", ""), partition=o.get("partition", ""),
+                            unescape_string_values=o.get("unescape_string_values", False), format=o.get("format", "json"))
     fields = abi.Schema.of(case["fields"])
     vals = [m["value_latin1"].encode("latin-1") for m in case["messages"]]
     wts = [abi.parse_rfc3339(m["write_time"])[0] * 10**9 for m in case["messages"]]
@@ -384,6 +385,61 @@ def test_flat_lines_are_device_resident(tf, oracle):
             assert np.array_equal(a.offsets, b.offsets) and bytes(a.data) == bytes(b.data)
         else:
             assert bytes(a.values) == bytes(b.values)
+
+
+TSKV_LINES = [
+    b"tskv\tk=1\ti8=-5\tu16=65535\ti64=0x10\tu64=18446744073709551615\td=1.5e3\tb=T\ts=plain text\ty=raw \\n \"q\" <&>\ta=word",
+    b"k=2\ts=\ty==\ta=a=b=c",                     # empty value, '=' inside a value (SplitN 2)
+    b"k=3\tk=4",                                    # the last duplicate wins
+    b"tskv\tnofields",                              # no key=value field at all: skipped
+    b"\t\tk=5\t\t",                               # empty fields
+    b"=nokey\tk=6",                                 # empty key
+    b"k=zz",                                         # ParseInt error on the key column → _unparsed
+    b"i8=1",                                         # key column absent → nil key → _unparsed
+    b"k=7\ti8=999\tu16=-1\tb=maybe\td=abc",        # errors on non-key columns → nil
+    b"k=8\tt=1600000000",                           # datetime from a string: dateparse → host
+    b"k=9\ta={\"x\":1}",                            # any: a JSON object in a string → host
+    b"k=10\ts=caf\xc3\xa9 \xff\ta=caf\xc3\xa9",      # non-ASCII bytes: text keeps them, any goes to the host
+    b"k=11\ts=back\\slash\\\ty=\\=\\t",              # backslashes are content when nothing unescapes
+    b"k = 12\tk=12",                                # "k " is another key
+    b"k=13\tunknown=1",
+    b"k=14\r",                                      # ScanLines drops the trailing \r
+]
+
+
+def test_tskv_edge_cases(tf, oracle):
+    fields = abi.Schema.of(EDGE_FIELDS)
+    data = b"\n".join(TSKV_LINES) + b"\n"
+    for opts in (abi.json_options(topic="t", format="tskv"), abi.json_options(topic="t", format="tskv", add_dedupe_keys=True, add_rest=True),
+                 abi.json_options(topic="t", format="tskv", unescape_string_values=True, null_keys_allowed=True)):
+        compare(tf, oracle, opts, fields, data, None, "tskv", max_fallback=6)
+    vals = [TSKV_LINES[0] + b"\n" + TSKV_LINES[1], b"", TSKV_LINES[2] + b"\r\n\r\n" + TSKV_LINES[4]]
+    d2, m2 = abi.messages(vals, [7, 8, 9], [10**18, 0, 5])
+    compare(tf, oracle, abi.json_options(topic="a/b@c", format="tskv", add_dedupe_keys=True), fields, d2, m2, "tskv messages", max_fallback=0)
+
+
+def test_tskv_random_lines(tf, oracle):
+    rng = random.Random(77)
+    fields = abi.Schema.of(EDGE_FIELDS)
+    keys = ["k", "i8", "u16", "i64", "u64", "d", "b", "s", "y", "a", "t", "zz", ""]
+    vals = ["0", "1", "-1", "127", "128", "65535", "0x1F", "1_000", "1e3", "1.25", "-0", "inf", "true", "FALSE", "x", "", "a b", "\\n", "\\", "\\q", "tab\\tend",
+            "=", "a=b", "\"", "<>", "caf\u00e9", "9223372036854775807", "18446744073709551615", "-9223372036854775809", " 1", "1 "]
+    lines = []
+    for _ in range(5000):
+        nf = rng.randint(0, 8)
+        fs = []
+        for _ in range(nf):
+            r = rng.random()
+            if r < 0.1:
+                fs.append(rng.choice(["tskv", "", "novalue"]))
+            else:
+                fs.append(rng.choice(keys) + "=" + rng.choice(vals))
+        if rng.random() < 0.8:
+            fs.append("k=%d" % rng.randint(-5, 10**6))
+        lines.append("\t".join(fs).encode("utf-8"))
+    data = b"\n".join(lines)
+    for opts in (abi.json_options(topic="t", format="tskv"), abi.json_options(topic="t", format="tskv", unescape_string_values=True, add_rest=True)):
+        compare(tf, oracle, opts, fields, data, None, "tskv random", max_fallback=len(lines))
 
 
 def test_wave_path_cross_check():

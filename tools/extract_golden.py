@@ -498,6 +498,14 @@ def json_parser():
                   "options": {"unpack_bytes_base64": True, "topic": "my_topic_name", "partition": '{"partition":0,"topic":""}'},
                   "fields": [["id", "int8", False], ["stringVal", "utf8", False], ["bytesVal", "string", False]], "messages": msgs,
                   "rows": [{"table": it["table"], "names": it["columnnames"], "marshalled": it["columnvalues"], "part": it["part"]} for it in items]})
+    # TestUnescapeTSKV (parser_test.go:323-366): Format "tskv", UnescapeStringValues, one line per message
+    tsk = open(gdir + "/test_data/parser_unescape_test.tskv", "rb").read()
+    items = res["gotest.gotest.TestUnescapeTSKV"]
+    msgs = [{"offset": i, "write_time": "1970-01-01T00:00:00Z", "value_latin1": ln.decode("latin-1")} for i, ln in enumerate(tsk.split(b"\n")) if ln]
+    cases.append({"name": "tskv_unescape", "ref": "pkg/parsers/generic/parser_test.go:323-366",
+                  "options": {"format": "tskv", "unescape_string_values": True, "topic": "my_topic_name", "partition": '{"partition":0,"topic":""}'},
+                  "fields": [["id", "int8", False], ["message", "string", False]], "messages": msgs,
+                  "rows": [{"table": it["table"], "names": it["columnnames"], "marshalled_text": it["columnvalues"], "part": it["part"]} for it in items]})
     write("json_parser.json", {"cases": cases})
 
 def collapse():

@@ -83,7 +83,8 @@ class CCsvOptions(C.Structure):
 class CJsonOptions(C.Structure):
     _fields_ = [("add_rest", C.c_uint8), ("add_dedupe_keys", C.c_uint8), ("null_keys_allowed", C.c_uint8),
                 ("use_numbers_in_any", C.c_uint8), ("unescape_string_values", C.c_uint8), ("unpack_bytes_base64", C.c_uint8),
-                ("ignore_column_paths", C.c_uint8), ("mark_dedupe_keys_as_system", C.c_uint8), ("topic", C.c_char_p), ("partition", C.c_char_p)]
+                ("ignore_column_paths", C.c_uint8), ("mark_dedupe_keys_as_system", C.c_uint8), ("topic", C.c_char_p), ("partition", C.c_char_p),
+                ("format", C.c_uint8)]
 
 
 class CMessages(C.Structure):
@@ -92,8 +93,9 @@ class CMessages(C.Structure):
 
 def json_options(add_rest=False, add_dedupe_keys=False, null_keys_allowed=False, use_numbers_in_any=False,
                  unescape_string_values=False, unpack_bytes_base64=False, ignore_column_paths=False, mark_dedupe_keys_as_system=False, topic="",
-                 partition='{"partition":0,"topic":""}') -> CJsonOptions:
+                 partition='{"partition":0,"topic":""}', format="json") -> CJsonOptions:
     o = CJsonOptions()
+    o.format = {"json": 0, "tskv": 1}[format]
     o.add_rest, o.add_dedupe_keys, o.null_keys_allowed = int(add_rest), int(add_dedupe_keys), int(null_keys_allowed)
     o.use_numbers_in_any, o.unescape_string_values = int(use_numbers_in_any), int(unescape_string_values)
     o.unpack_bytes_base64, o.ignore_column_paths = int(unpack_bytes_base64), int(ignore_column_paths)

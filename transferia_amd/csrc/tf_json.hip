@@ -40,7 +40,7 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out);           // tf_csv.hip
 
 enum JKind : int32_t { JK_INT, JK_UINT, JK_F64, JK_BOOL, JK_TEXT, JK_ANY, JK_DATETIME };
-enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4 };
+enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4, JM_TSKV = 5 };
 enum JLineSt : uint8_t { JL_ROW = 0, JL_SKIPPED = 1, JL_SYNTAX = 2, JL_FALLBACK = 3 };
 enum JCellSt : uint8_t { JC_NIL = 0, JC_OK = 1, JC_ERR = 2 };
 enum JVal : int32_t { V_NULL, V_STR, V_NUM, V_TRUE, V_FALSE, V_OBJ, V_ARR };
@@ -74,6 +74,8 @@ struct JParams {
   uint8_t *linest;       // JLineSt per line
   uint32_t *line_pos;    // start offset per line (message lookup)
   uint8_t add_rest, use_numbers;
+  uint8_t format;        // TFGPU_JFMT_*
+  uint8_t tskv_unescape; // Format tskv + UnescapeStringValues: tryToUnescapeTSKV on the values
 };
 
 __device__ __forceinline__ uint32_t fnv1a(uint32_t h, uint32_t c) { return (h ^ c) * 16777619u; }
@@ -231,6 +233,27 @@ template <class S> __device__ void compact_walk(MemBytes &rd, const uint64_t s, 
       o.put(c);
       if (c == '"') { in_str = true; run = 0; }
     }
+  }
+}
+
+// tryToUnescapeTSKV (generic_parser.go:643-670): \\\\ \\n \\r \\t \\= ; a lone backslash at the end or any other escape
+// leaves the WHOLE input as it is.  tskv_unescaped_len: the output length, or ~0u when the input stays unchanged.
+__device__ uint32_t tskv_unescaped_len(MemBytes &rd, const uint64_t s, const uint32_t n) {
+  uint32_t out = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (rd.at(s + i) != '\\') { out++; continue; }
+    if (i == n - 1) return ~0u;
+    const uint32_t c = rd.at(s + i + 1);
+    if (!(c == '\\' || c == 'n' || c == 'r' || c == 't' || c == '=')) return ~0u;
+    out++; i++;
+  }
+  return out;
+}
+template <class S> __device__ void tskv_walk(MemBytes &rd, const uint64_t s, const uint32_t n, S &o) {  // input already known to be well-formed
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t c = rd.at(s + i);
+    if (c == '\\') { c = rd.at(s + ++i); c = c == 'n' ? '\n' : c == 'r' ? '\r' : c == 't' ? '\t' : c; }
+    o.put(c);
   }
 }
 
@@ -476,6 +499,10 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
     case JK_TEXT:
       if (vtype == V_STR) {  // string(v.GetStringBytes()): unescaped
         if (!sv.bs) jtext(c, r, sv.s, sv.n, JM_COPY, sv.n);
+        else if (p.format == TFGPU_JFMT_TSKV) {  // tryToUnescapeTSKV: unescaped, or the input itself when an escape is broken
+          const uint32_t ul = tskv_unescaped_len(aux, sv.s, sv.n);
+          if (ul == ~0u) jtext(c, r, sv.s, sv.n, JM_COPY, sv.n); else jtext(c, r, sv.s, sv.n, JM_TSKV, ul);
+        }
         else { CountSink cs; unescape_walk(aux, sv.s, sv.n, cs); jtext(c, r, sv.s, sv.n, JM_UNESCAPE, cs.n); }
       } else if (vtype == V_OBJ || vtype == V_ARR) {  // v.String(): MarshalTo with raw strings
         if (kbad) return false;  // an unescaped key that needs strconv.AppendQuote
@@ -707,13 +734,68 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
   p.line_pos[r] = (uint32_t)ls;
 }
 
+// GenericParser.Unmarshal, Format "tskv" (generic_parser.go:732-746): strings.Split(line, "\t"), SplitN(field, "=", 2); a field
+// without '=' is skipped, every value is a Go string (ParseVal's string branch types it), the last duplicate of a key wins.
+// Unmarshal cannot fail here: a line is a row, skipped (no key=value field at all), or handed to the host.
+__device__ void parse_tskv_line(const JParams &p, const int64_t r, const uint64_t ls, const uint64_t le) {
+  MemBytes rd(p.data), aux(p.data);
+  uint64_t pos = ls;
+  uint32_t kids = 0;
+  bool fallback = false;
+  for (;;) {
+    uint64_t fe = pos, eq = ~0ull;
+    bool bs = false, ctrl = false, hi = false, quote = false;
+    while (fe < le) {
+      const uint32_t c = rd.at(fe);
+      if (c == '\t') break;
+      if (eq == ~0ull) { if (c == '=') eq = fe; }
+      else { bs = bs || c == '\\'; ctrl = ctrl || c < 0x20u; hi = hi || c >= 0x80u; quote = quote || c == '"'; }
+      fe++;
+    }
+    if (eq != ~0ull) {
+      kids++;
+      const uint32_t kn = (uint32_t)(eq - pos);
+      uint32_t h = 0x9E3779B9u;
+      for (uint32_t i = 0; i < kn; i += 8) { const uint32_t nb = kn - i < 8 ? kn - i : 8u; h = key_mix(h, aux.word(pos + i) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1)); }
+      h = key_finish(h, kn);
+      int32_t kcol = JS_UNKNOWN;
+      for (uint32_t s = h & p.slot_mask;; s = (s + 1) & p.slot_mask) {
+        const JSlot sl = p.slots[s];
+        if (sl.slen == ~0u) break;
+        if (sl.hash == h && sl.slen == kn) {
+          bool same = true;
+          for (uint32_t i = 0; i < kn && same; i += 8) {
+            const uint32_t nb = kn - i < 8 ? kn - i : 8u;
+            same = (aux.word(pos + i) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1)) == *reinterpret_cast<const uint64_t *>(p.names + sl.soff + i);
+          }
+          if (same) { kcol = sl.col; if (sl.aux) fallback = true; break; }
+        }
+      }
+      if (p.add_rest && kcol == JS_UNKNOWN) fallback = true;  // `_rest` would not be {}
+      if (!fallback && kcol >= 0) {
+        JStr sv;
+        sv.s = eq + 1; sv.n = (uint32_t)(fe - eq - 1); sv.hash = 0;
+        sv.bs = p.tskv_unescape && bs;  // raw bytes ARE the value unless tryToUnescapeTSKV runs
+        sv.ctrl = ctrl; sv.plain = !bs && !ctrl && !hi && !quote;
+        for (int32_t ci = kcol; ci >= 0; ci = p.cols[ci].next)
+          if (!store_cell(p, p.cols[ci], r, aux, V_STR, eq + 1, fe, sv, 0, false)) { fallback = true; break; }
+      }
+    }
+    if (fe >= le) break;
+    pos = fe + 1;
+  }
+  p.linest[r] = fallback ? JL_FALLBACK : kids == 0 ? JL_SKIPPED : JL_ROW;
+  p.line_pos[r] = (uint32_t)ls;
+}
+
 __global__ void __launch_bounds__(256) json_parse_lines(JParams p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.nseg) return;
   const uint32_t n = p.seg_len[i];
   if (!n) return;
   const uint64_t s = p.seg_start[i];
-  parse_json_line(p, (int64_t)p.seg_ord[i], s, s + n);
+  if (p.format == TFGPU_JFMT_TSKV) parse_tskv_line(p, (int64_t)p.seg_ord[i], s, s + n);
+  else parse_json_line(p, (int64_t)p.seg_ord[i], s, s + n);
 }
 // the lines the wave path hands over (nested values, anything it does not fully understand): one lane per line
 __global__ void __launch_bounds__(256) json_parse_listed(JParams p, const uint32_t *slow_n, const uint32_t *slow_seg) {
@@ -1067,6 +1149,7 @@ __global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, cons
   MemBytes rd(data);
   if (mode == JM_UNESCAPE) { StoreSink sk{dst}; unescape_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); sk.finish(); return; }
+  if (mode == JM_TSKV) { StoreSink sk{dst}; tskv_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_FLOAT) {  // the number token again, as encoding/json prints the float64 it parses to
     const Field tok{&rd, s, srclen};
     double v = 0;
@@ -1187,7 +1270,9 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   TF_API_BEGIN
   if (!opts || !fields || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_json_parse: null argument");
   if (len >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_json_parse: batch must be < 4 GiB of JSON (32-bit cell offsets; Bufferer-sized batches are far below, bufferer.go:117-249)");
-  if (opts->unescape_string_values) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: UnescapeStringValues is not device-resident");
+  if (opts->format != TFGPU_JFMT_JSON && opts->format != TFGPU_JFMT_TSKV) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_json_parse: unknown format");
+  const bool tskv = opts->format == TFGPU_JFMT_TSKV;
+  if (opts->unescape_string_values && !tskv) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: UnescapeStringValues (tryToUnescapeJSON) is not device-resident");
   if (opts->unpack_bytes_base64) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: UnpackBytesBase64 is not device-resident");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
@@ -1384,6 +1469,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   pp.cols = ptr<JCol>(bcols); pp.ncols = nraw; pp.slots = ptr<JSlot>(bslots); pp.slot_mask = nslots - 1; pp.names = ptr<uint8_t>(bnames);
   pp.pow10 = pow10_table(); pp.pow128 = reinterpret_cast<const uint64_t *>(pp.pow10 + 632); pp.linest = ptr<uint8_t>(linest); pp.line_pos = ptr<uint32_t>(line_pos);
   pp.add_rest = opts->add_rest; pp.use_numbers = opts->use_numbers_in_any;
+  pp.format = opts->format; pp.tskv_unescape = tskv && opts->unescape_string_values;
   // The per-line path is the default: 64 lines of one shape run in lockstep, so a wave pays each instruction once per
   // 64 lines (≈ 23 k wave-instructions per 64 lines of 2.3 KB).  The wave path (TFGPU_JSON_WAVEPATH=1) reads coalesced
   // and does stage 1 on the scalar unit, but its lanes are MEMBERS of one line — different column kinds side by side —
@@ -1391,7 +1477,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   // (13.6 vs 6.7 ms, profiles/r01y_json_paths.txt).  Kept as the parity cross-check of the grammar and as the
   // starting point for a kind-sorted member phase.
   static const bool wavepath = [] { const char *e = std::getenv("TFGPU_JSON_WAVEPATH"); return e && e[0] == '1'; }();
-  if (nlines && !wavepath) { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp); }
+  if (nlines && (!wavepath || tskv)) { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp); }
   else if (nlines) {
     Buf slow = dalloc((size_t)(nseg + 1) * 4);
     TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
