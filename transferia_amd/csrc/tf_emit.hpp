@@ -9,7 +9,11 @@
 namespace tf {
 
 // ---- sinks -----------------------------------------------------------------------
-struct CountSink { uint32_t n = 0; __device__ __forceinline__ void put(uint32_t) { n++; } };
+struct CountSink {
+  uint32_t n = 0;
+  __device__ __forceinline__ void put(uint32_t) { n++; }
+  __device__ __forceinline__ void put_word(uint64_t, uint32_t k) { n += k; }
+};
 // Bytes gathered eight at a time and stored with ONE (possibly unaligned) 8-byte store: a cell's text lands in the
 // middle of its row, so byte stores would cost one memory transaction per character.
 struct WriteSink {
@@ -18,6 +22,16 @@ struct WriteSink {
   __device__ __forceinline__ void put(uint32_t c) {
     acc |= (uint64_t)(c & 0xFFu) << (8 * n);
     if (++n == 8) { reinterpret_cast<U64 *>(p)->v = acc; p += 8; acc = 0; n = 0; }
+  }
+  // the low k (1..8) bytes of w, the bytes above them zero: one merge instead of k puts
+  __device__ __forceinline__ void put_word(uint64_t w, uint32_t k) {
+    acc |= w << (8 * n);
+    const uint32_t t = n + k;
+    if (t >= 8) {
+      reinterpret_cast<U64 *>(p)->v = acc; p += 8;
+      acc = n ? w >> (8 * (8 - n)) : 0;  // what did not fit (n == 0: everything did)
+      n = t - 8;
+    } else n = t;
   }
   __device__ __forceinline__ void flush() {
     if (n >= 4) { struct __attribute__((packed, aligned(1))) U32 { uint32_t v; }; reinterpret_cast<U32 *>(p)->v = (uint32_t)acc; p += 4; acc >>= 32; n -= 4; }
@@ -29,7 +43,21 @@ template <class S> struct CsvQuoteSink {  // doubles '"' (encoding/csv quoted fi
   __device__ __forceinline__ void put(uint32_t c) { if (c == '"') s.put('"'); s.put(c); }
 };
 
-template <class S> __device__ __forceinline__ void put_bytes(S &s, const uint8_t *p, uint32_t n) { for (uint32_t i = 0; i < n; i++) s.put(p[i]); }
+// s.put_word(w, k) where the sink has one, k puts otherwise (wrapping sinks that look at every byte)
+template <class S> __device__ __forceinline__ auto sink_word(S &s, uint64_t w, uint32_t k, int) -> decltype(s.put_word(w, k), void()) { s.put_word(w, k); }
+template <class S> __device__ __forceinline__ void sink_word(S &s, uint64_t w, uint32_t k, long) { for (uint32_t i = 0; i < k; i++) s.put((uint32_t)(w >> (8 * i)) & 0xFFu); }
+struct __attribute__((packed, aligned(1))) UnalignedU64 { uint64_t v; };
+__device__ __forceinline__ uint64_t load8(const uint8_t *p) { return reinterpret_cast<const UnalignedU64 *>(p)->v; }
+// SWAR byte tests over a 64-bit word (the flags may be inexact only ABOVE a true hit, so "no flag" is exact)
+__device__ __forceinline__ uint64_t swar_has_zero(uint64_t v) { return (v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull; }
+__device__ __forceinline__ uint64_t swar_has(uint64_t w, uint32_t c) { return swar_has_zero(w ^ (0x0101010101010101ull * c)); }
+__device__ __forceinline__ uint64_t swar_has_less(uint64_t w, uint32_t c) { return (w - 0x0101010101010101ull * c) & ~w & 0x8080808080808080ull; }
+
+template <class S> __device__ __forceinline__ void put_bytes(S &s, const uint8_t *p, uint32_t n) {
+  uint32_t i = 0;
+  for (; i + 8 <= n; i += 8) sink_word(s, load8(p + i), 8, 0);
+  if (i < n) { uint64_t w = 0; for (uint32_t k = 0; i + k < n; k++) w |= (uint64_t)p[i + k] << (8 * k); sink_word(s, w, n - i, 0); }
+}
 template <class S> __device__ __forceinline__ void put_lit(S &s, const char *p) { while (*p) s.put((uint8_t)*p++); }
 __device__ __forceinline__ uint32_t hexc(uint32_t n) { return n + (n < 10 ? '0' : 'a' - 10); }
 
@@ -37,6 +65,10 @@ __device__ __forceinline__ uint32_t hexc(uint32_t n) { return n + (n < 10 ? '0' 
 template <class S> __device__ void emit_ch_quoted(S &s, const uint8_t *p, uint32_t n) {
   s.put('"');
   for (uint32_t i = 0; i < n; i++) {
+    if (i + 8 <= n) {  // eight bytes that need no escaping at once
+      const uint64_t w = load8(p + i);
+      if (!(swar_has_less(w, 0x20) | swar_has(w, '"') | swar_has(w, '\\'))) { sink_word(s, w, 8, 0); i += 7; continue; }
+    }
     const uint32_t c = p[i];
     if (c >= 0x20 && c != '"' && c != '\\') { s.put(c); continue; }
     s.put('\\');
@@ -54,6 +86,12 @@ template <class S> __device__ void emit_json_string(S &s, const uint8_t *p, uint
   s.put('"');
   uint32_t i = 0;
   while (i < n) {
+    if (i + 8 <= n) {  // eight printable ASCII bytes that need no escaping at once
+      const uint64_t w = load8(p + i);
+      uint64_t bad = (w & 0x8080808080808080ull) | swar_has_less(w, 0x20) | swar_has(w, '"') | swar_has(w, '\\');
+      if (html) bad |= swar_has(w, '<') | swar_has(w, '>') | swar_has(w, '&');
+      if (!bad) { sink_word(s, w, 8, 0); i += 8; continue; }
+    }
     const uint32_t c = p[i];
     if (c < 0x80) {
       if (c >= 0x20 && c != '"' && c != '\\' && !(html && (c == '<' || c == '>' || c == '&'))) { s.put(c); i++; continue; }
@@ -92,6 +130,13 @@ template <class S> __device__ void emit_base64(S &s, const uint8_t *p, uint32_t 
 }
 
 template <class S> __device__ __forceinline__ void emit_small(S &s, const uint8_t *t, int n) { for (int i = 0; i < n; i++) s.put(t[i]); }
+// decimal text of v < 10^8 built in a register (32-bit arithmetic, no scratch array) and handed over as one word
+template <class S> __device__ __forceinline__ void emit_dec8(S &s, uint32_t v, bool neg) {
+  uint64_t w = 0; uint32_t nd = 0;
+  do { const uint32_t q = v / 10u; w = (w << 8) | ('0' + (v - q * 10u)); v = q; nd++; } while (v);
+  if (neg) s.put('-');
+  sink_word(s, w, nd, 0);
+}
 
 // strconv.FormatFloat(f, 'f', -1, bits) of a float column's value
 template <class S> __device__ void emit_float_f(S &s, const DCol &c, int64_t r) {
@@ -108,6 +153,20 @@ template <class S> __device__ void emit_float_json(S &s, const DCol &c, int64_t 
 // The integer Go types as decimal text; returns false if the column is not an integer repr.
 template <class S> __device__ bool emit_int(S &s, const DCol &c, int64_t r) {
   uint8_t t[24]; int n;
+  {  // the usual case: fewer than nine digits
+    int64_t v; bool is_int = true;
+    switch (c.repr) {
+      case TFGPU_R_INT8: v = ((const int8_t *)c.values)[r]; break;
+      case TFGPU_R_INT16: v = ((const int16_t *)c.values)[r]; break;
+      case TFGPU_R_INT32: v = ((const int32_t *)c.values)[r]; break;
+      case TFGPU_R_INT64: v = ((const int64_t *)c.values)[r]; break;
+      case TFGPU_R_UINT8: v = ((const uint8_t *)c.values)[r]; break;
+      case TFGPU_R_UINT16: v = ((const uint16_t *)c.values)[r]; break;
+      case TFGPU_R_UINT32: v = ((const uint32_t *)c.values)[r]; break;
+      default: is_int = false; v = 0;
+    }
+    if (is_int && v > -100000000ll && v < 100000000ll) { emit_dec8(s, (uint32_t)(v < 0 ? -v : v), v < 0); return true; }
+  }
   switch (c.repr) {
     case TFGPU_R_INT8: n = dev::fmt_i64(t, ((const int8_t *)c.values)[r]); break;
     case TFGPU_R_INT16: n = dev::fmt_i64(t, ((const int16_t *)c.values)[r]); break;

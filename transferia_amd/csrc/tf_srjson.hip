@@ -42,7 +42,9 @@ struct Params {
   uint32_t *keep;                              // [nframes + 1] → row index
   uint32_t *row_frame; int64_t nrows;          // [nrows]
   uint32_t *nerr;
+  uint16_t *guess;                             // [GUESS_N]: property the m-th member of a payload matched last time (a hint, verified)
 };
+constexpr uint32_t GUESS_N = 1024;
 
 __device__ __forceinline__ bool is_ws(uint32_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
 __device__ __forceinline__ int hexv(uint32_t c) { return c >= '0' && c <= '9' ? (int)c - '0' : c >= 'a' && c <= 'f' ? (int)c - 'a' + 10 : c >= 'A' && c <= 'F' ? (int)c - 'A' + 10 : -1; }
@@ -59,8 +61,14 @@ template <class F> __device__ uint32_t walk_frames(const Params &p, int64_t m, F
     if (rd.at(a) != 0) { f.code = TFGPU_ROW_SR_MAGIC; emit(k, f); return k + 1; }
     f.schema_id = (rd.at(a + 1) << 24) | (rd.at(a + 2) << 16) | (rd.at(a + 3) << 8) | rd.at(a + 4);
     a += 5;
-    uint64_t e = a;
-    while (e < z && rd.at(e) != 0) e++;  // bytes.Index(buf, []byte{0})
+    uint64_t e = a;  // bytes.Index(buf, []byte{0}): eight bytes per step (the lowest zero-byte flag of the SWAR test is exact)
+    bool hit = false;
+    while (e + 8 <= z) {
+      const uint64_t w = rd.word(e), t = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;
+      if (t) { e += (uint32_t)(__ffsll((long long)t) - 1) >> 3; hit = true; break; }
+      e += 8;
+    }
+    if (!hit) while (e < z && rd.at(e) != 0) e++;
     f.start = a; f.len = (uint32_t)(e - a); f.code = TFGPU_ROW_OK;
     emit(k, f);
     k++; a = e;
@@ -81,14 +89,17 @@ __global__ void __launch_bounds__(256) sr_fill_frames(Params p) {
 
 // ---- encoding/json's grammar (scanner.go) ------------------------------------------------------------------------------
 // String literal at pos (the opening quote): stateInString / stateInStringEsc*.  pos → past the closing quote.
-__device__ bool scan_string(MemBytes &rd, uint32_t &pos, const uint32_t end) {
+__device__ bool scan_string(MemBytes &rd, uint32_t &pos, const uint32_t end, bool *plain = nullptr) {
   pos++;
+  bool pl = true;  // no escapes, no bytes >= 0x80: the decoded string is the raw body
   for (;;) {
     if (pos >= end) return false;
     const uint32_t c = rd.at(pos);
-    if (c == '"') { pos++; return true; }
+    if (c == '"') { pos++; if (plain) *plain = pl; return true; }
     if (c < 0x20) return false;
+    if (c >= 0x80) pl = false;
     if (c != '\\') { pos++; continue; }
+    pl = false;
     if (pos + 1 >= end) return false;
     const uint32_t d = rd.at(pos + 1);
     pos += 2;
@@ -365,12 +376,14 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
     pos++;
     skip_ws();
     if (pos >= end) return TFGPU_ROW_JSON_SYNTAX;
+    uint32_t member = 0;
     if (rd.at(pos) == '}') pos++;
     else for (;;) {
       skip_ws();
       if (pos >= end || rd.at(pos) != '"') return TFGPU_ROW_JSON_SYNTAX;
       const uint32_t ks = pos;
-      if (!scan_string(rd, pos, end)) return TFGPU_ROW_JSON_SYNTAX;
+      bool kplain = false;
+      if (!scan_string(rd, pos, end, &kplain)) return TFGPU_ROW_JSON_SYNTAX;
       const uint32_t ke = pos;
       skip_ws();
       if (pos >= end || rd.at(pos) != ':') return TFGPU_ROW_JSON_SYNTAX;
@@ -381,15 +394,32 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
       const int rc = skip_value(rd, pos, end, vt);
       if (rc == 1) return TFGPU_ROW_JSON_SYNTAX;
       if (rc == 2) return TFGPU_ROW_HOST_FALLBACK;
-      // m[key] = value: binary search over the sorted property names, the last duplicate wins
-      int lo = 0, hi = p.nprops - 1;
-      while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        RuneIter a{&rd, nullptr, ks + 1, ke - 1}, b{nullptr, p.names + p.props[mid].name_off, 0, p.props[mid].name_len};
-        const int c = rune_compare(a, b);
-        if (c == 0) { const int64_t i = (int64_t)mid * p.nframes + f; p.vstart[i] = vs; p.vlen[i] = pos - vs; p.vtype[i] = (uint8_t)vt; break; }
-        if (c < 0) hi = mid - 1; else lo = mid + 1;
+      // m[key] = value: the last duplicate wins.  Producers write their keys in one order, so the property the m-th
+      // member matched in some other payload is tried first; otherwise binary search over the sorted property names.
+      // A plain key (ASCII, no escapes) is its own decoding and compares as raw bytes; any other key by decoded runes.
+      auto compare_to = [&](int j) -> int {
+        const Prop &pr = p.props[j];
+        if (!kplain) { RuneIter a{&rd, nullptr, ks + 1, ke - 1}, b{nullptr, p.names + pr.name_off, 0, pr.name_len}; return rune_compare(a, b); }
+        const uint32_t kn = ke - ks - 2, m = kn < pr.name_len ? kn : pr.name_len;
+        const uint8_t *nm = p.names + pr.name_off;
+        for (uint32_t q = 0; q < m; q++) { const uint32_t x = rd.at(ks + 1 + q), y = nm[q]; if (x != y) return x < y ? -1 : 1; }
+        return kn == pr.name_len ? 0 : kn < pr.name_len ? -1 : 1;
+      };
+      int found = -1;
+      const uint32_t g = member < GUESS_N ? p.guess[member] : 0xFFFFu;
+      if (g < (uint32_t)p.nprops && compare_to((int)g) == 0) found = (int)g;
+      else {
+        int lo = 0, hi = p.nprops - 1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const int c = compare_to(mid);
+          if (c == 0) { found = mid; break; }
+          if (c < 0) hi = mid - 1; else lo = mid + 1;
+        }
+        if (found >= 0 && member < GUESS_N) p.guess[member] = (uint16_t)found;  // racing writers all store a valid hint
       }
+      if (found >= 0) { const int64_t i = (int64_t)found * p.nframes + f; p.vstart[i] = vs; p.vlen[i] = pos - vs; p.vtype[i] = (uint8_t)vt; }
+      member++;
       skip_ws();
       if (pos >= end) return TFGPU_ROW_JSON_SYNTAX;
       const uint32_t d = rd.at(pos);
@@ -604,6 +634,9 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
   p.props = ptr<sr::Prop>(bprops); p.nprops = np; p.names = ptr<uint8_t>(bnames);
   p.vstart = ptr<uint32_t>(vstart); p.vlen = ptr<uint32_t>(vlen); p.vtype = ptr<uint8_t>(vtype);
   p.status = ptr<uint8_t>(status); p.keep = ptr<uint32_t>(keep); p.nerr = ptr<uint32_t>(nerr);
+  Buf guess = dalloc(sr::GUESS_N * 2 + 16);
+  TF_HIP(hipMemsetAsync(guess->p, 0xFF, sr::GUESS_N * 2, st));
+  p.guess = ptr<uint16_t>(guess);
   if (nf) {
     { KernelTimer t("sr_parse_frames"); sr::sr_parse_frames<<<sr::nblk(nf, 128), 128, 0, st>>>(p); }
     { KernelTimer t("sr_message_rule"); sr::sr_message_rule<<<sr::nblk(p.nmsg, 256), 256, 0, st>>>(p); }
