@@ -160,3 +160,92 @@ def test_collapse_of_key_shards(tf):
     want = np.stack([whole.src_row.astype(np.int64), whole.col("ver").values, whole.kind.astype(np.int64)], axis=1)
     assert got.shape == want.shape
     assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+
+
+# ---- Confluent-SR ingest and the queue serializers at 2^20 frames -------------------------------------------------------
+SR_SCHEMA = ('{"title":"db.events","type":"object","properties":{"a":{"type":"array"},"b":{"oneOf":[{"type":"null"},{"type":"boolean"}]},'
+             '"id":{"type":"integer"},"n":{"type":"number"},"s":{"type":"string"}},"required":["id","s"]}')
+
+
+def _sr_payload(i):
+    return (b'{"id":%d,"s":"row \\"%d\\" <%x>","n":%d.%03d,"b":%s,"a":[%d,"x"]}' % (i, i, i * 2654435761 & 0xFFFFFF, i % 1000, i % 997, (b"true", b"false", b"null")[i % 3], i % 7))
+
+
+@pytest.fixture(scope="module")
+def sr_events(tf):
+    from transferia_amd import confluent_sr
+    frames = [b"\0\0\0\0\x09" + _sr_payload(i) for i in range(N)]
+    msgs, i = [], 0
+    while i < N:  # one or two frames per Kafka message
+        k = 2 if (i // 2) % 5 == 0 and i + 1 < N else 1
+        msgs.append(b"".join(frames[i:i + k]))
+        i += k
+    data, cm = abi.messages(msgs, np.arange(len(msgs)), np.full(len(msgs), 1_700_000_000_000_000_000))
+    o = confluent_sr.sr_json_options(9, SR_SCHEMA)
+    res = tf.sr_json_parse(o, tf.DeviceBuffer.upload(data), cm)
+    return o, data, cm, msgs, res
+
+
+def test_sr_fullsize(tf, oracle, sr_events):
+    """2^20 frames: every frame is a row, in order; sampled messages against the oracle; a message's frames share its index."""
+    o, data, cm, msgs, res = sr_events
+    assert not res.errors and res.device_batch.nrows == N
+    b = res.batch
+    assert np.array_equal(b.src_row, np.arange(N, dtype=np.int32))
+    assert np.array_equal(b.col("id").values, np.arange(N, dtype=np.int64))
+    assert np.all(np.diff(b.part_id.astype(np.int64)) >= 0) and int(b.part_id[-1]) == len(msgs) - 1
+    bv = b.col("b")
+    assert np.array_equal(bv.validity, np.arange(N) % 3 != 2) and np.array_equal(bv.values[bv.validity], (np.arange(N) % 3 == 0)[bv.validity].astype(np.uint8))
+    for lo in (0, 5000, len(msgs) - 3000):  # windows of whole messages through the oracle
+        sub = msgs[lo:lo + 3000]
+        d2, m2 = abi.messages(sub)
+        ref = oracle.sr_json_parse(o, d2, m2)
+        first = int(np.searchsorted(b.part_id, lo))
+        assert not ref.errors
+        for c, rc in zip(b.cols, ref.batch.cols):
+            for k in (0, 1, 17, ref.batch.nrows - 1):
+                assert abi.norm_value(c.pyvalue(first + k)) == abi.norm_value(rc.pyvalue(k)), (c.name, lo, k)
+        assert first + ref.batch.nrows <= N and int(b.col("id").values[first + ref.batch.nrows - 1]) == int(ref.batch.col("id").values[-1])
+
+
+def test_sr_to_queue_json_roundtrip_fullsize(tf, sr_events):
+    """SR parse → queue JSON serializer (1 MiB batches) → the generic JSON parser over the messages = the parsed batch."""
+    o, data, cm, msgs, res = sr_events
+    q = tf.queue_serialize(abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=1 << 20), res.device_batch)
+    sizes = np.diff(q.msg_start.astype(np.int64))
+    assert len(q) > 50 and sizes.max() <= (1 << 20) and int(q.msg_row[-1]) == N and np.all(np.diff(q.msg_row) > 0)
+    raw = q.values.download()
+    assert raw.count(b"\n") == N - len(q)  # rows of one message are joined by "\n", messages lie back to back
+    vals = [raw[int(q.msg_start[i]):int(q.msg_start[i + 1])] for i in range(len(q))]
+    d2, m2 = abi.messages(vals)
+    fields = abi.Schema.of([["a", "utf8"], ["b", "boolean"], ["id", "int64", True], ["n", "utf8"], ["s", "utf8"]])
+    db, errs = tf.json_parse(abi.json_options(topic="t"), fields, d2, m2)
+    assert not errs and db.nrows == N
+    back, b = db.download(), res.batch
+    assert np.array_equal(back.col("id").values, b.col("id").values)
+    for name in ("s", "n", "a"):  # text columns: the same bytes (numbers and arrays as their JSON text)
+        x, y = back.col(name), b.col(name)
+        assert np.array_equal(x.offsets, y.offsets) and np.array_equal(x.data[: int(x.offsets[-1])], y.data[: int(y.offsets[-1])]), name
+    bb, by = back.col("b"), b.col("b")
+    assert np.array_equal(bb.validity if bb.validity is not None else np.ones(N, bool), by.validity)
+    assert np.array_equal(bb.values[by.validity], by.values[by.validity])
+
+
+def test_native_queue_fullsize(tf, sr_events):
+    """2^20 rows through the native serializer: one ChangeItem per row in order, every message a JSON array within its limits."""
+    import json
+    o, data, cm, msgs, res = sr_events
+    meta = abi.row_meta(N, ids=np.arange(N) % 1000, lsns=np.arange(N, dtype=np.uint64) + 10, commit_times=np.full(N, 1_700_000_000_000_000_000, np.uint64))
+    q = tf.queue_serialize(abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_change_items=1000, max_message_size=1 << 19, omit_table_schema=True), res.device_batch, meta)
+    raw = q.values.download()
+    assert raw.count(b'{"id":') == N and int(q.msg_row[-1]) == N
+    rows = np.diff(q.msg_row)
+    assert rows.max() <= 1000 and np.diff(q.msg_start.astype(np.int64)).max() <= (1 << 19)
+    for m in (0, len(q) // 2, len(q) - 1):
+        items = json.loads(raw[int(q.msg_start[m]):int(q.msg_start[m + 1])])
+        r0 = int(q.msg_row[m])
+        assert len(items) == int(rows[m])
+        for k in (0, len(items) - 1):
+            it, i = items[k], r0 + k
+            assert (it["id"], it["nextlsn"], it["kind"], it["schema"], it["table"]) == (i % 1000, i + 10, "insert", "db", "events")
+            assert it["columnnames"] == ["a", "b", "id", "n", "s"] and it["columnvalues"][2] == i and it["columnvalues"][4] == 'row "%d" <%x>' % (i, i * 2654435761 & 0xFFFFFF)
