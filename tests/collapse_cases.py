@@ -3,6 +3,9 @@ device algorithm (transferia_amd/csrc/tf_collapse.hip) over the same inputs."""
 import numpy as np
 
 from transferia_amd import abi
+import os as _os
+
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
 
 KINDS = ["insert", "update", "delete", "other"]
 STRS = [b"", b"a", b"b", b"<x>&", "é".encode(), b"\\u003c", b'"', b"a\x00", "\ufffd".encode(), b"\xff", b"\xfe", b"a\xc3"]  # the last three: invalid UTF-8
@@ -11,7 +14,7 @@ STRS = [b"", b"a", b"b", b"<x>&", "é".encode(), b"\\u003c", b'"', b"a\x00", "\u
 def random_batch(seed, n, domain=8, two_keys=False, p_old=0.6, weights=(3, 4, 2, 1), null_keys=0.0, bytes_key=False, nstrs=len(STRS)):
     """(Batch, Schema).  Keys come from a small domain so rows chain; Update / Delete rows carry OldKeys with
     probability p_old (an Insert never does here); OldKeys also list a non-key name, which Collapse must ignore."""
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(SEED0 + (seed))
     cols = [abi.ColSchema("id", "int64", True, "", ""), abi.ColSchema("v", "int64", False, "", ""), abi.ColSchema("s", "utf8", False, "", "")]
     if two_keys:
         cols.insert(1, abi.ColSchema("k2", "string" if bytes_key else "utf8", True, "", ""))

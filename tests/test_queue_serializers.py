@@ -7,6 +7,9 @@ import pytest
 
 from transferia_amd import abi
 from util import golden, item_to_batch
+import os as _os
+
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
 
 G = golden("queue_serializers.json")
 
@@ -177,7 +180,7 @@ def test_gpu_queue_batching_table(tf, fmt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 65, 1000, 20011])
 def test_gpu_queue_matches_oracle(tf, oracle, n):
-    rng = np.random.default_rng(900 + n)
+    rng = np.random.default_rng(SEED0 + (900 + n))
     b, schema, meta = _random_case(rng, n)
     db = tf.DeviceBatch.upload(b)
     groups = [n] if n < 3 else [n // 3, 0, n - n // 3]

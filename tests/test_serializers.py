@@ -7,6 +7,9 @@ import pytest
 
 from transferia_amd import abi
 from util import golden, item_to_batch
+import os as _os
+
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
 
 FMT = {"ch": abi.FMT_CH_JSON_EACH_ROW, "json": abi.FMT_JSON, "csv": abi.FMT_CSV}
 
@@ -76,7 +79,7 @@ def _random_batch(rng, n):
 @pytest.mark.parametrize("n", [1, 7, 300])
 def test_oracle_json_rows_parse_back(oracle, n):
     """Every JSON row the oracle emits is valid JSON holding every column."""
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(SEED0 + (n))
     b, schema = _random_batch(rng, n)
     b.cols = [c for c in b.cols if c.name != "num"]  # 1E+3000 is not a Python float
     schema = abi.Schema.of([[c.name, c.dtype, False] for c in b.cols])
@@ -106,7 +109,7 @@ def test_gpu_reference_vectors(tf):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 63, 1000, 20011])
 def test_gpu_serializers_match_oracle(tf, oracle, n):
-    rng = np.random.default_rng(100 + n)
+    rng = np.random.default_rng(SEED0 + (100 + n))
     b, schema = _random_batch(rng, n)
     db = tf.DeviceBatch.upload(b)
     variants = [
@@ -136,7 +139,7 @@ def test_gpu_serialize_unsupported_and_empty(tf, oracle):
     # strconv.FormatFloat(f, 'f', -1): ClickHouse numeric columns and the CSV serializer render Go floats on device
     import random
     import struct
-    rng = random.Random(9)
+    rng = random.Random(SEED0 + (9))
     vals = [1.5, -0.0, 0.1, 1e21, 1e-7, 123456789.125, 5e-324, 1.7976931348623157e308] + [struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0] for _ in range(3000)]
     vals = [v for v in vals if v == v and abs(v) != float("inf")]
     s2 = abi.Schema.of([["f", "double", False], ["g", "float", False], ["i", "int64", True]])
