@@ -581,7 +581,8 @@ static ora_value unmarshal_value(const fj_value *v, int dtype, const tfgpu_json_
         default: {  /* map / slice */
           sb b = {0}; g_marshal_unsupported = 0;
           go_marshal_any(&b, v, o->use_numbers_in_any);
-          if (g_marshal_unsupported) *unrestated = 1;
+          /* a datetime column never marshals the container: extractTimeValue rejects any map / slice (:818-886) */
+          if (g_marshal_unsupported && dtype != TFGPU_T_DATETIME) *unrestated = 1;
           r = val_str(OV_JSON, b.p ? b.p : "", b.n); free(b.p);
           return r;
         }

@@ -31,6 +31,8 @@ def run_gpu(tf, type_name, config, batch):
 
 def assert_batches_equal(a: abi.Batch, b: abi.Batch, ctx=""):
     assert a.nrows == b.nrows, ctx
+    if a.nrows == 0 and b.nrows == 0:
+        return  # the oracle's row-to-column conversion has no columns to show for an empty result
     assert [c.name for c in a.cols] == [c.name for c in b.cols], ctx
     for ca, cb in zip(a.cols, b.cols):
         assert ca.repr == cb.repr, (ctx, ca.name, ca.repr, cb.repr)
