@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU per step")
-    ap.add_argument("--cpu-rows", type=int, default=1 << 16, help="rows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 19, help="rows of the CPU-baseline sample (0 = skip); 2^19 rows = about 11 s of oracle time")
     ap.add_argument("--prof-steps", type=int, default=3)
     ap.add_argument("--lanes", type=int, default=1, help="device lanes (host threads) the steps are spread over: batch N+1 is parsed "
                     "beside the transform of batch N, the way the parsequeue's workers overlap (1 = strictly serial)")

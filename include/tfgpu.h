@@ -323,7 +323,7 @@ int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, c
                     uint64_t len, int mem, tfgpu_dbatch **out, uint64_t *consumed,
                     tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
-/* ---- JSON ingest: parsers/generic GenericParser{Format:"json"} ----------- */
+/* ---- JSON / TSKV ingest: parsers/generic GenericParser{Format:"json" | "tskv"} ----------- */
 /* generic.AuxParserOpts (pkg/parsers/generic/generic_parser.go:40-77) as the "json" parser
  * registry fills them (pkg/parsers/registry/json/parser_json.go:62-86).  Options whose value
  * forms are not device-resident are rejected with TFGPU_ERR_UNSUPPORTED at call time
