@@ -75,24 +75,41 @@ template <class F> __device__ uint32_t walk_frames(const Params &p, int64_t m, F
   }
   return k;
 }
-__global__ void __launch_bounds__(256) sr_count_frames(Params p) {
+// The count pass keeps every message's FIRST frame: the usual message holds exactly one, and the fill pass then copies it
+// instead of walking the bytes a second time.
+__global__ void __launch_bounds__(256) sr_count_frames(Params p, tfgpu_sr_frame *first) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= p.nmsg) return;
-  p.fcount[m] = walk_frames(p, m, [](uint32_t, const tfgpu_sr_frame &) {});
+  tfgpu_sr_frame *slot = first + m;
+  p.fcount[m] = walk_frames(p, m, [slot](uint32_t k, const tfgpu_sr_frame &f) { if (k == 0) *slot = f; });
 }
-__global__ void __launch_bounds__(256) sr_fill_frames(Params p) {
+__global__ void __launch_bounds__(256) sr_fill_frames(Params p, const tfgpu_sr_frame *first) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= p.nmsg) return;
-  tfgpu_sr_frame *out = p.frames + p.fcount[m];
+  const uint32_t f0 = p.fcount[m], n = p.fcount[m + 1] - f0;
+  if (n == 0) return;
+  tfgpu_sr_frame *out = p.frames + f0;
+  if (n == 1) { out[0] = first[m]; return; }
   walk_frames(p, m, [out](uint32_t k, const tfgpu_sr_frame &f) { out[k] = f; });
 }
 
 // ---- encoding/json's grammar (scanner.go) ------------------------------------------------------------------------------
 // String literal at pos (the opening quote): stateInString / stateInStringEsc*.  pos → past the closing quote.
 __device__ bool scan_string(MemBytes &rd, uint32_t &pos, const uint32_t end, bool *plain = nullptr) {
+  const uint64_t ONES = 0x0101010101010101ull, HI = 0x8080808080808080ull;
   pos++;
   bool pl = true;  // no escapes, no bytes >= 0x80: the decoded string is the raw body
   for (;;) {
+    // eight bytes per step while nothing in them needs a decision: not '"', not '\\', not a control byte (SWAR flags are
+    // exact up to and including the first hit, so "no flag" is exact)
+    while (pos + 8 <= end) {
+      const uint64_t w = rd.word(pos);
+      const uint64_t xq = w ^ (ONES * '"'), xb = w ^ (ONES * '\\');
+      const uint64_t stop = (((xq - ONES) & ~xq) | ((xb - ONES) & ~xb) | ((w - ONES * 0x20) & ~w)) & HI;
+      if (stop) { const uint32_t k = (uint32_t)(__ffsll((long long)stop) - 1) >> 3; if (k && (w & HI & ((1ull << (8 * k)) - 1))) pl = false; pos += k; break; }
+      if (w & HI) pl = false;
+      pos += 8;
+    }
     if (pos >= end) return false;
     const uint32_t c = rd.at(pos);
     if (c == '"') { pos++; if (plain) *plain = pl; return true; }
@@ -401,8 +418,13 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
         const Prop &pr = p.props[j];
         if (!kplain) { RuneIter a{&rd, nullptr, ks + 1, ke - 1}, b{nullptr, p.names + pr.name_off, 0, pr.name_len}; return rune_compare(a, b); }
         const uint32_t kn = ke - ks - 2, m = kn < pr.name_len ? kn : pr.name_len;
-        const uint8_t *nm = p.names + pr.name_off;
-        for (uint32_t q = 0; q < m; q++) { const uint32_t x = rd.at(ks + 1 + q), y = nm[q]; if (x != y) return x < y ? -1 : 1; }
+        const uint8_t *nm = p.names + pr.name_off;  // 8-byte aligned, zero-padded to whole words
+        for (uint32_t q = 0; q < m; q += 8) {  // eight bytes per compare; the first differing byte decides the order
+          const uint32_t nb = m - q < 8 ? m - q : 8u;
+          const uint64_t mask = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
+          const uint64_t x = rd.word(ks + 1 + q) & mask, y = *reinterpret_cast<const uint64_t *>(nm + q) & mask;
+          if (x != y) { const uint32_t sh = ((uint32_t)(__ffsll((long long)(x ^ y)) - 1) >> 3) * 8; return ((x >> sh) & 0xFF) < ((y >> sh) & 0xFF) ? -1 : 1; }
+        }
         return kn == pr.name_len ? 0 : kn < pr.name_len ? -1 : 1;
       };
       int found = -1;
@@ -539,7 +561,7 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_
 
 // input bytes + message starts in HBM, frames counted and listed; returns the frame count
 struct Staged {
-  Buf bytes, ms, fcount, frames;
+  Buf bytes, ms, fcount, frames, first;
   Params p{};
   int64_t nframes = 0;
 };
@@ -569,14 +591,16 @@ static void stage_frames(Staged &s, const void *bytes, uint64_t len, int mem, co
   h2d(s.ms->p, ms.data(), ms.size() * 4);
   s.fcount = dalloc_zero((size_t)(nmsg + 1) * 4 + 16);
   s.p.ms = ptr<uint32_t>(s.ms); s.p.nmsg = nmsg; s.p.fcount = ptr<uint32_t>(s.fcount);
-  if (nmsg) { KernelTimer t("sr_frames"); sr_count_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p); }
+  s.first = dalloc((size_t)std::max<int64_t>(nmsg, 1) * sizeof(tfgpu_sr_frame));
+  const tfgpu_sr_frame *first = reinterpret_cast<const tfgpu_sr_frame *>(s.first->p);
+  if (nmsg) { KernelTimer t("sr_frames"); sr_count_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p, reinterpret_cast<tfgpu_sr_frame *>(s.first->p)); }
   exclusive_scan_u32(s.p.fcount, s.p.fcount, nmsg, true);
   const uint32_t *h = d2h_u32(s.p.fcount + nmsg);
   tf::sync();  // also fences the pageable sources (bytes, ms)
   s.nframes = *h;
   s.frames = dalloc((size_t)std::max<int64_t>(s.nframes, 1) * sizeof(tfgpu_sr_frame));
   s.p.frames = reinterpret_cast<tfgpu_sr_frame *>(s.frames->p); s.p.nframes = s.nframes;
-  if (nmsg && s.nframes) { KernelTimer t("sr_frames"); sr_fill_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p); }
+  if (nmsg && s.nframes) { KernelTimer t("sr_frames"); sr_fill_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p, first); }
 }
 
 }  // namespace sr
@@ -619,6 +643,7 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     if (j && std::string(o->props[j - 1].name) >= pr.name) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_json_parse: properties must be sorted by name and unique (util.MapKeysInOrder)");
     props[(size_t)j] = sr::Prop{(uint32_t)names.size(), (uint32_t)std::strlen(pr.name), pr.json_type, pr.required ? 1 : 0};
     names += pr.name;
+    names.append((8 - names.size() % 8) % 8, '\0');  // whole 8-byte words: the device compares a word at a time
   }
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
