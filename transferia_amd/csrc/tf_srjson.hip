@@ -26,7 +26,8 @@ namespace tf {
 namespace sr {
 
 enum : uint8_t { ST_OK = 0, ST_OTHER = 255, ST_DROPPED = 254 };  // else a tfgpu_rowerr
-enum : uint32_t { VT_ABSENT = 0, VT_NULL, VT_FALSE, VT_TRUE, VT_NUM, VT_STR, VT_ARR, VT_OBJ };
+enum : uint32_t { VT_ABSENT = 0, VT_NULL, VT_FALSE, VT_TRUE, VT_NUM, VT_STR, VT_ARR, VT_OBJ,
+                  VT_PLAIN = 0x80 /* flag on VT_STR: ASCII without escapes — the decoded string is the raw body */, VT_MASK = 0x7F };
 constexpr int MAX_DEPTH = 128;  // deeper containers (Go allows 10000) go to the host
 
 struct Prop { uint32_t name_off, name_len; int32_t json_type, required; };
@@ -178,7 +179,7 @@ __device__ int skip_value(MemBytes &rd, uint32_t &pos, const uint32_t end, uint3
       if (pos >= end) return 1;
       if (rd.at(pos) == (c == '{' ? '}' : ']')) { pos++; depth--; }
       else opened = true;
-    } else if (c == '"') { if (!scan_string(rd, pos, end)) return 1; t = VT_STR; }
+    } else if (c == '"') { bool pl = false; if (!scan_string(rd, pos, end, &pl)) return 1; t = VT_STR | (pl ? VT_PLAIN : 0u); }
     else if (c == '-' || (c >= '0' && c <= '9')) { if (!scan_number(rd, pos, end)) return 1; t = VT_NUM; }
     else if (c == 't' || c == 'f' || c == 'n') { if (!scan_literal(rd, pos, end, t)) return 1; }
     else return 1;
@@ -270,6 +271,12 @@ struct ByteSink {
   __device__ __forceinline__ void put(uint32_t c) {
     acc |= (uint64_t)(c & 0xFFu) << (8 * n);
     if (++n == 8) { reinterpret_cast<U64 *>(p)->v = acc; p += 8; acc = 0; n = 0; }
+  }
+  // the low k (1..8) bytes of w, the bytes above them zero
+  __device__ __forceinline__ void put_word(uint64_t w, uint32_t k) {
+    acc |= w << (8 * n);
+    const uint32_t t = n + k;
+    if (t >= 8) { reinterpret_cast<U64 *>(p)->v = acc; p += 8; acc = n ? w >> (8 * (8 - n)) : 0; n = t - 8; } else n = t;
   }
   __device__ __forceinline__ void flush() { for (; n; n--) { *p++ = (uint8_t)acc; acc >>= 8; } }
 };
@@ -454,7 +461,7 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
   bool fallback = false;
   for (int j = 0; j < p.nprops; j++) {
     const int64_t i = (int64_t)j * p.nframes + f;
-    const uint32_t vt = p.vtype[i];
+    const uint32_t vt = p.vtype[i] & VT_MASK;
     const Prop &pr = p.props[j];
     if (vt == VT_ABSENT) { if (pr.required) return TFGPU_ROW_SR_REQUIRED; continue; }
     if (vt == VT_NULL && !pr.required) continue;
@@ -518,7 +525,7 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
   if (j == 0) { src_row[r] = (int32_t)f; part_id[r] = (uint32_t)p.frames[f].msg; }
   const OutCol &c = cols[j];
   const int64_t i = (int64_t)j * p.nframes + f;
-  const uint32_t vt = p.vtype[i], vs = p.vstart[i], vl = p.vlen[i];
+  const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
   const bool nil = vt == VT_ABSENT || vt == VT_NULL;
   c.valid8[r] = nil ? 0 : 1;
   MemBytes rd(p.data);
@@ -526,7 +533,11 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
     case TFGPU_SRT_BOOLEAN: ((uint8_t *)c.values)[r] = vt == VT_TRUE ? 1 : 0; break;
     case TFGPU_SRT_INTEGER: { int64_t x = 0; if (!nil) number_int64(rd, vs, vl, &x); ((int64_t *)c.values)[r] = x; break; }
     case TFGPU_SRT_NUMBER: c.lens[r] = nil ? 0u : vl; break;
-    case TFGPU_SRT_STRING: { CountSink s; if (!nil) emit_unquoted(s, rd, vs, vl); c.lens[r] = s.n; break; }
+    case TFGPU_SRT_STRING:
+      if (nil) c.lens[r] = 0;
+      else if (vtr & VT_PLAIN) c.lens[r] = vl - 2;  // nothing to decode
+      else { CountSink s; emit_unquoted(s, rd, vs, vl); c.lens[r] = s.n; }
+      break;
     default: { CountSink s; if (!nil) emit_any(s, rd, vs, vl); c.lens[r] = s.n; }
   }
 }
@@ -538,11 +549,17 @@ __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols
   const OutCol &c = cols[j];
   const uint32_t f = p.row_frame[r];
   const int64_t i = (int64_t)j * p.nframes + f;
-  const uint32_t vt = p.vtype[i], vs = p.vstart[i], vl = p.vlen[i];
+  const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
   if (vt == VT_ABSENT || vt == VT_NULL) return;
   MemBytes rd(p.data);
   ByteSink s{c.data + c.lens[r]};
-  if (c.json_type == TFGPU_SRT_NUMBER) { for (uint32_t k = 0; k < vl; k++) s.put(rd.at(vs + k)); }
+  auto copy_raw = [&](uint32_t a, uint32_t n) {  // eight bytes per step
+    uint32_t k = 0;
+    for (; k + 8 <= n; k += 8) s.put_word(rd.word(a + k), 8);
+    if (k < n) s.put_word(rd.word(a + k) & ((1ull << (8 * (n - k))) - 1), n - k);
+  };
+  if (c.json_type == TFGPU_SRT_NUMBER) copy_raw(vs, vl);
+  else if (c.json_type == TFGPU_SRT_STRING && (vtr & VT_PLAIN)) copy_raw(vs + 1, vl - 2);
   else if (c.json_type == TFGPU_SRT_STRING) emit_unquoted(s, rd, vs, vl);
   else emit_any(s, rd, vs, vl);
   s.flush();
