@@ -112,8 +112,19 @@ def _vectors():
     ok(b'{"r":1,"n":1,"s":"","x":{"a":[1,2.50,{"b":"<\\u003e&\xe2\x80\xa8"}],"c":null},"\\u0062":false}', b=("bool", False), n=("jsonnum", b"1"), r=("int64", 1),
        s=("string", b""), x=("json", b'{"a":[1,2.50,{"b":"\\u003c\\u003e\\u0026\\u2028"}],"c":null}'))
     ok(b'{"r":1,"n":1,"s":"q","x":[ ]}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"), x=("json", b"[]"))
+    # json.Marshal of a map: keys ascending at every level, the last duplicate's value (the sorting emitter on the device)
+    ok(b'{"r":1,"n":1,"s":"q","x":{"b":1,"a":{"z":[{"k":2,"j":1}],"y":"<"},"b":{"d":null,"c":[]},"\\u0061a":0, "A" : [1,{"b":1,"a":2}]}}',
+       n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"),
+       x=("json", b'{"A":[1,{"a":2,"b":1}],"a":{"y":"\\u003c","z":[{"j":1,"k":2}]},"aa":0,"b":{"c":[],"d":null}}'))
+    ok(b'{"r":1,"n":1,"s":"q","x":[{"b":1,"a":2,"b":3},{"\\u00e9":1,"e":2,"\xc3\xa9":3,"z":0}]}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"),
+       x=("json", '[{"a":2,"b":3},{"e":2,"z":0,"é":3}]'.encode()))
     ok(b'{"r":1,"n":1,"s":"q","x":"str"}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"), x=("json", b'"str"'))
     ok(b'{"r":1,"n":1,"s":"q","x":12.0e1,"zzz":{"deep":[[[{}]]]}}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"), x=("json", b"12.0e1"))
+    deep = b"[" * 16 + b'{"b":1,"a":2}' + b"]" * 16   # unsorted keys 17 containers deep: beyond the sorting emitter
+    V.append((b'{"r":1,"n":1,"s":"q","x":' + deep + b'}', ("fallback", [("nil", None), ("nil", None), ("jsonnum", b"1"), ("int64", 1), ("string", b"q"),
+                                                                       ("json", b"[" * 16 + b'{"a":2,"b":1}' + b"]" * 16)])))
+    ok(b'{"r":1,"n":1,"s":"q","x":' + b"[" * 15 + b'{"b":1,"a":2}' + b"]" * 15 + b'}', n=("jsonnum", b"1"), r=("int64", 1), s=("string", b"q"),
+       x=("json", b"[" * 15 + b'{"a":2,"b":1}' + b"]" * 15))
     err(b'{"n":1,"s":"a"}', "SR_REQUIRED")
     err(b'null', "SR_REQUIRED")                      # nil map: every lookup misses
     err(b'{"r":1.0,"n":1,"s":"a"}', "SR_TYPE")       # Number.Int64: strconv.ParseInt syntax error
@@ -138,12 +149,19 @@ def _check_vectors(parse):
     res = parse(o, data, cm)
     rows = {int(res.batch.src_row[r]): row for r, row in enumerate(abi.batch_rows(res.batch))}
     errs = {int(e[0]): int(e[1]) for e in res.errors}
+    FB = abi.ROWERR_ID["HOST_FALLBACK"]
     for k, (payload, exp) in enumerate(V):
+        if isinstance(exp, tuple) and exp[0] == "fallback":  # the oracle has the row; the device may hand the frame to the host
+            if errs.get(k) == FB:
+                assert k not in rows
+                continue
+            exp = exp[1]
         if isinstance(exp, int):
             assert errs.get(k) == exp and k not in rows, (payload, abi.ROWERR.get(errs.get(k)), rows.get(k))
         else:
             assert k not in errs and rows.get(k) == [abi.norm_value(v) for v in exp], (payload, rows.get(k), abi.ROWERR.get(errs.get(k)))
     assert list(res.batch.part_id) == [k for k in range(len(V)) if k in rows]
+    return errs
 
 
 def test_oracle_vectors(oracle):
@@ -218,7 +236,8 @@ def test_gpu_canon(tf):
 
 @pytest.mark.gpu
 def test_gpu_vectors(tf):
-    _check_vectors(tf.sr_json_parse)
+    errs = _check_vectors(tf.sr_json_parse)
+    assert list(errs.values()).count(abi.ROWERR_ID["HOST_FALLBACK"]) == 1  # only the value nested beyond the sorting emitter
 
 
 @pytest.mark.gpu
@@ -231,6 +250,19 @@ def test_gpu_framing(tf):
     # empty batches
     data, cm = abi.messages([b"", b""])
     assert tf.sr_frames(data, cm) == [] and tf.sr_json_parse(confluent_sr.sr_json_options(0, PERSON), data, cm).batch.nrows == 0
+
+
+def _rand_any_text(rng, depth=0):
+    """A JSON value as text: objects with their keys in random order, repeated keys, escaped and non-ASCII keys."""
+    t = rng.random()
+    if depth >= 4 or t < 0.35:
+        return ['1', '-2.50', '"s"', '"<&>"', 'null', 'true', '"\\u00e9"', '1e5', '""'][rng.integers(0, 9)]
+    w = lambda: ["", " ", "\n "][rng.integers(0, 3)]  # noqa: E731
+    if t < 0.6:
+        return "[" + ",".join(w() + _rand_any_text(rng, depth + 1) + w() for _ in range(rng.integers(0, 4))) + "]"
+    keys = ['"a"', '"b"', '"ab"', '"B"', '"\\u0061"', '"\u00e9"', '"\\u00e9"', '"z z"', '"<"', '""', '"a\\"q"']
+    members = [keys[rng.integers(0, len(keys))] + w() + ":" + w() + _rand_any_text(rng, depth + 1) for _ in range(rng.integers(0, 6))]
+    return "{" + ",".join(w() + m + w() for m in members) + "}"
 
 
 def _random_payloads(rng, n):
@@ -257,8 +289,8 @@ def _random_payloads(rng, n):
         if rng.random() < 0.5:
             members.append(('"bo"', ["true", "false", "null", '"true"'][rng.integers(0, 4)]))
         if rng.random() < 0.6:
-            pool = anys_ok if rng.random() < 0.85 else anys_fb
-            members.append(('"ob"', pool[rng.integers(0, len(pool))]))
+            r = rng.random()
+            members.append(('"ob"', anys_ok[rng.integers(0, len(anys_ok))] if r < 0.5 else anys_fb[rng.integers(0, len(anys_fb))] if r < 0.65 else _rand_any_text(rng)))
         if rng.random() < 0.4:
             members.append(('"an"', anys_ok[rng.integers(0, len(anys_ok))]))
         if rng.random() < 0.3:
@@ -314,5 +346,5 @@ def test_gpu_matches_oracle(tf, oracle, n):
     for k in fallback:  # the oracle parsed it: a row whose `any` value needed Go's key ordering
         assert k in rrows
     assert set(grows) <= set(rrows)
-    assert n < 1000 or (len(fallback) > 0 and len(grows) > n // 4)
+    assert not fallback and (n < 1000 or len(grows) > n // 4)  # unsorted `any` objects are sorted on the device
     assert [c.dtype for c in got.batch.cols] == ["any", "boolean", "int64", "double", "any", "utf8", "utf8"]

@@ -27,7 +27,10 @@ namespace sr {
 
 enum : uint8_t { ST_OK = 0, ST_OTHER = 255, ST_DROPPED = 254 };  // else a tfgpu_rowerr
 enum : uint32_t { VT_ABSENT = 0, VT_NULL, VT_FALSE, VT_TRUE, VT_NUM, VT_STR, VT_ARR, VT_OBJ,
-                  VT_PLAIN = 0x80 /* flag on VT_STR: ASCII without escapes — the decoded string is the raw body */, VT_MASK = 0x7F };
+                  VT_PLAIN = 0x80 /* flag on VT_STR: ASCII without escapes — the decoded string is the raw body */,
+                  VT_CANON = 0x40 /* flag on VT_OBJ / VT_ARR under an `any` column: some object's keys are not in ascending
+                                     order (or repeat), json.Marshal text needs the sorting emitter */, VT_MASK = 0x3F };
+constexpr int CANON_DEPTH = 16;  // containers nested deeper than this under an unsorted `any` value go to the host
 constexpr int MAX_DEPTH = 128;  // deeper containers (Go allows 10000) go to the host
 
 struct Prop { uint32_t name_off, name_len; int32_t json_type, required; };
@@ -326,11 +329,13 @@ template <class S> __device__ void emit_any(S &o, MemBytes &rd, uint32_t start, 
   }
 }
 // Can emit_any stand for json.Marshal?  Every object's keys must be strictly ascending (Go sorts map keys and a
-// duplicate key keeps only its last value).  The value was validated by skip_value.
-__device__ bool any_keys_sorted(MemBytes &rd, uint32_t start, uint32_t len) {
+// duplicate key keeps only its last value).  0: yes; 1: no — emit_any_canon sorts; 2: no, and nested deeper than
+// emit_any_canon follows.  The value was validated by skip_value.
+__device__ int any_keys_order(MemBytes &rd, uint32_t start, uint32_t len) {
   uint32_t prev_s[MAX_DEPTH], prev_n[MAX_DEPTH];  // previous key of every open object (string bodies)
   uint64_t stk[MAX_DEPTH / 64] = {0, 0};
-  int depth = 0;
+  int depth = 0, maxdepth = 0;
+  bool sorted = true;
   uint32_t pos = start; const uint32_t end = start + len;
   bool expect_key = false;
   while (pos < end) {
@@ -340,6 +345,7 @@ __device__ bool any_keys_sorted(MemBytes &rd, uint32_t start, uint32_t len) {
       const uint64_t bit = 1ull << (depth & 63);
       if (c == '{') { stk[depth >> 6] |= bit; prev_n[depth] = 0xFFFFFFFFu; } else stk[depth >> 6] &= ~bit;
       depth++; pos++; expect_key = c == '{';
+      if (depth > maxdepth) maxdepth = depth;
       continue;
     }
     if (c == '}' || c == ']') { depth--; pos++; expect_key = false; continue; }
@@ -349,9 +355,9 @@ __device__ bool any_keys_sorted(MemBytes &rd, uint32_t start, uint32_t len) {
       scan_string(rd, q, end);
       if (expect_key) {
         const int d = depth - 1;
-        if (prev_n[d] != 0xFFFFFFFFu) {
+        if (sorted && prev_n[d] != 0xFFFFFFFFu) {
           RuneIter a{&rd, nullptr, prev_s[d], prev_s[d] + prev_n[d]}, b{&rd, nullptr, pos + 1, q - 1};
-          if (rune_compare(a, b) >= 0) return false;
+          if (rune_compare(a, b) >= 0) sorted = false;
         }
         prev_s[d] = pos + 1; prev_n[d] = q - pos - 2;
         expect_key = false;
@@ -361,7 +367,78 @@ __device__ bool any_keys_sorted(MemBytes &rd, uint32_t start, uint32_t len) {
     }
     pos++;  // number / literal bytes
   }
-  return true;
+  return sorted ? 0 : maxdepth <= CANON_DEPTH ? 1 : 2;
+}
+// json.Marshal of a decoded value whose objects hold their keys in any order: what encoding/json does to a
+// map[string]interface{} — keys ascending, the last duplicate's value — without materialising the map.  Every object is
+// emitted by selection: the smallest key greater than the one emitted before, the last occurrence among equals
+// (O(members^2) key compares, no storage per member).  Containers are followed with an explicit stack of CANON_DEPTH frames.
+template <class S> __device__ void emit_any_canon(S &o, MemBytes &rd, uint32_t start, uint32_t len) {
+  struct Frame { uint32_t s, e, cur, prev_n; uint8_t obj, first; };  // array: cur = next element; object: [cur, cur + prev_n) = last key emitted
+  Frame st[CANON_DEPTH];
+  int sp = 0;
+  auto skip_ws = [&](uint32_t &q, uint32_t e) { while (q < e && is_ws(rd.at(q))) q++; };
+  auto begin_value = [&](uint32_t vs, uint32_t ve) {
+    const uint32_t c = rd.at(vs);
+    if (c == '{' || c == '[') {
+      if (sp == CANON_DEPTH) return;  // excluded by any_keys_order
+      Frame &f = st[sp++];
+      f.s = vs; f.e = ve; f.cur = vs + 1; f.prev_n = 0xFFFFFFFFu; f.obj = c == '{'; f.first = 1;
+      o.put(c);
+    } else if (c == '"') emit_go_string(o, rd, vs, ve - vs);
+    else for (uint32_t q = vs; q < ve; q++) o.put(rd.at(q));  // number / literal token
+  };
+  begin_value(start, start + len);
+  while (sp > 0) {
+    Frame &f = st[sp - 1];
+    if (!f.obj) {
+      uint32_t pos = f.cur;
+      skip_ws(pos, f.e);
+      if (rd.at(pos) == ']') { o.put(']'); sp--; continue; }
+      uint32_t q = pos, vt;
+      skip_value(rd, q, f.e, vt);
+      uint32_t nx = q;
+      skip_ws(nx, f.e);
+      if (rd.at(nx) == ',') nx++;
+      f.cur = nx;
+      if (!f.first) o.put(',');
+      f.first = 0;
+      begin_value(pos, q);
+      continue;
+    }
+    // the next key of this object: the smallest one greater than the key emitted last, the last occurrence among equals
+    uint32_t bks = 0, bkn = 0xFFFFFFFFu, bvs = 0, bve = 0;
+    uint32_t pos = f.s + 1;
+    for (;;) {
+      skip_ws(pos, f.e);
+      if (rd.at(pos) == '}') break;
+      const uint32_t ks = pos;
+      scan_string(rd, pos, f.e);
+      const uint32_t ke = pos;
+      skip_ws(pos, f.e);
+      pos++;  // ':'
+      skip_ws(pos, f.e);
+      const uint32_t vs = pos;
+      uint32_t vt;
+      skip_value(rd, pos, f.e, vt);
+      const uint32_t ve = pos;
+      skip_ws(pos, f.e);
+      if (rd.at(pos) == ',') pos++;
+      bool after_prev = true;
+      if (f.prev_n != 0xFFFFFFFFu) { RuneIter a{&rd, nullptr, f.cur, f.cur + f.prev_n}, b{&rd, nullptr, ks + 1, ke - 1}; after_prev = rune_compare(a, b) < 0; }
+      if (!after_prev) continue;
+      bool take = bkn == 0xFFFFFFFFu;
+      if (!take) { RuneIter a{&rd, nullptr, ks + 1, ke - 1}, b{&rd, nullptr, bks, bks + bkn}; take = rune_compare(a, b) <= 0; }  // equal: the later one wins
+      if (take) { bks = ks + 1; bkn = ke - ks - 2; bvs = vs; bve = ve; }
+    }
+    if (bkn == 0xFFFFFFFFu) { o.put('}'); sp--; continue; }
+    if (!f.first) o.put(',');
+    f.first = 0;
+    f.cur = bks; f.prev_n = bkn;
+    emit_go_string(o, rd, bks - 1, bkn + 2);
+    o.put(':');
+    begin_value(bvs, bve);
+  }
 }
 // strconv.ParseInt(text, 10, 64) of a validated JSON number literal: false on a syntax or range error
 __device__ bool number_int64(MemBytes &rd, uint32_t start, uint32_t len, int64_t *out) {
@@ -470,7 +547,12 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
       case TFGPU_SRT_INTEGER: { int64_t x; if (vt != VT_NUM || !number_int64(rd, p.vstart[i], p.vlen[i], &x)) return TFGPU_ROW_SR_TYPE; break; }
       case TFGPU_SRT_NUMBER: if (vt != VT_NUM) return TFGPU_ROW_SR_TYPE; break;
       case TFGPU_SRT_STRING: if (vt != VT_STR) return TFGPU_ROW_SR_TYPE; break;
-      default: if ((vt == VT_OBJ || vt == VT_ARR) && !any_keys_sorted(rd, p.vstart[i], p.vlen[i])) fallback = true;
+      default:
+        if (vt == VT_OBJ || vt == VT_ARR) {
+          const int ord = any_keys_order(rd, p.vstart[i], p.vlen[i]);
+          if (ord == 1) p.vtype[i] = (uint8_t)(vt | VT_CANON);
+          else if (ord == 2) fallback = true;
+        }
     }
   }
   return fallback ? (uint32_t)TFGPU_ROW_HOST_FALLBACK : (uint32_t)ST_OK;
@@ -538,7 +620,7 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
       else if (vtr & VT_PLAIN) c.lens[r] = vl - 2;  // nothing to decode
       else { CountSink s; emit_unquoted(s, rd, vs, vl); c.lens[r] = s.n; }
       break;
-    default: { CountSink s; if (!nil) emit_any(s, rd, vs, vl); c.lens[r] = s.n; }
+    default: { CountSink s; if (!nil) { if (vtr & VT_CANON) emit_any_canon(s, rd, vs, vl); else emit_any(s, rd, vs, vl); } c.lens[r] = s.n; }
   }
 }
 __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
@@ -561,6 +643,7 @@ __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols
   if (c.json_type == TFGPU_SRT_NUMBER) copy_raw(vs, vl);
   else if (c.json_type == TFGPU_SRT_STRING && (vtr & VT_PLAIN)) copy_raw(vs + 1, vl - 2);
   else if (c.json_type == TFGPU_SRT_STRING) emit_unquoted(s, rd, vs, vl);
+  else if (vtr & VT_CANON) emit_any_canon(s, rd, vs, vl);
   else emit_any(s, rd, vs, vl);
   s.flush();
 }
