@@ -406,9 +406,10 @@ typedef struct tfgpu_sr_json_options {
  * string → string, anything else → `any` (json.Marshal text of the decoded value).  Rows: one per good frame, Kind
  * insert, src_row = ordinal of the frame over the whole batch, part_id = index of its message.  errs: one per frame the
  * reference turns into an `_unparsed` item (row = frame ordinal, step = message index) — after which the rest of that
- * message is dropped, as DoBuf does — or whose `any` value needs Go's map ordering (TFGPU_ROW_HOST_FALLBACK: an object
- * whose keys are not already in ascending order).  With several schema ids in one message the shim applies the
- * "first error ends the message" rule across its calls.                                                              */
+ * message is dropped, as DoBuf does.  An `any` value whose objects hold their keys in another order than json.Marshal's
+ * (ascending, the last duplicate wins) is re-emitted sorted on the device; TFGPU_ROW_HOST_FALLBACK is left for such a
+ * value nested deeper than 16 containers and for payloads nested deeper than 128.  With several schema ids in one
+ * message the shim applies the "first error ends the message" rule across its calls.                                */
 int tfgpu_sr_json_parse(const tfgpu_sr_json_options *opts, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
                         tfgpu_dbatch **out, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
