@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-UNITS = ["tf_runtime.hip", "tf_serialize.hip", "tf_srjson.hip"]  # translation units whose kernels use no LDS / barriers / wave intrinsics
+UNITS = ["tf_runtime.hip", "tf_serialize.hip", "tf_srjson.hip", "tf_json.hip"]  # tf_json: the per-line path (its wave path aborts here)  # translation units whose kernels use no LDS / barriers / wave intrinsics
 LAUNCH = re.compile(r"(\b[A-Za-z_][A-Za-z0-9_:]*(?:<[^<>;]*>)?)\s*<<<\s*([^;]*?)>>>\s*\(")
 
 

@@ -15,6 +15,9 @@
 #define __forceinline__ inline
 #define __constant__ static const
 #define __launch_bounds__(...)
+#define __shared__ static  /* one instance per kernel: workgroups run one after another here */
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -65,8 +68,11 @@ inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b &
 inline int __mul24(int a, int b) { return ((a << 8) >> 8) * ((b << 8) >> 8); }
 // wave-level intrinsics have no meaning in a lane-at-a-time loop: a kernel that reaches one is not emulable
 [[noreturn]] inline void emu_no_wave_ops(const char *what) { std::fprintf(stderr, "hipemu: %s needs a wavefront; this kernel cannot run under tools/hipemu\n", what); std::abort(); }
-inline int __any(int) { emu_no_wave_ops("__any"); }
-inline int __all(int) { emu_no_wave_ops("__all"); }
+// __any / __all choose between two per-lane-correct code paths in the emulable kernels (digits_u64: "the whole wave parses
+// short numbers"), so a one-lane wave is a faithful model of them; kernels that really exchange data across lanes reach a
+// ballot / shuffle / barrier below and abort.
+inline int __any(int x) { return x != 0; }
+inline int __all(int x) { return x != 0; }
 inline unsigned long long __ballot(int) { emu_no_wave_ops("__ballot"); }
 template <class T> inline T __shfl(T, int, int = 64) { emu_no_wave_ops("__shfl"); }
 template <class T> inline T __shfl_up(T, unsigned, int = 64) { emu_no_wave_ops("__shfl_up"); }

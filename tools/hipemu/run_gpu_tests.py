@@ -20,6 +20,6 @@ from transferia_amd import lib  # noqa: E402
 lib._LIBPATH = so
 import pytest  # noqa: E402
 
-FILES = ["tests/test_queue_serializers.py", "tests/test_serializers.py", "tests/test_confluent_sr.py"]
-# test_gpu_hits_chain_to_jsoneachrow needs the CSV tile parser (LDS, wave scans): not emulated
-sys.exit(pytest.main(["-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", "not hits_chain", *[os.path.join(ROOT, f) for f in FILES], *sys.argv[1:]]))
+FILES = ["tests/test_queue_serializers.py", "tests/test_serializers.py", "tests/test_confluent_sr.py", "tests/test_gpu_json.py"]
+# test_gpu_hits_chain_to_jsoneachrow needs the CSV tile parser (LDS, wave scans), the JSON wave path wave ballots: not emulated
+sys.exit(pytest.main(["-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", "not hits_chain and not wave_path", *[os.path.join(ROOT, f) for f in FILES], *sys.argv[1:]]))
