@@ -40,7 +40,7 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out);           // tf_csv.hip
 
 enum JKind : int32_t { JK_INT, JK_UINT, JK_F64, JK_BOOL, JK_TEXT, JK_ANY, JK_DATETIME };
-enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4, JM_TSKV = 5 };
+enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4, JM_TSKV = 5, JM_ANYCANON = 6 };
 enum JLineSt : uint8_t { JL_ROW = 0, JL_SKIPPED = 1, JL_SYNTAX = 2, JL_FALLBACK = 3 };
 enum JCellSt : uint8_t { JC_NIL = 0, JC_OK = 1, JC_ERR = 2 };
 enum JVal : int32_t { V_NULL, V_STR, V_NUM, V_TRUE, V_FALSE, V_OBJ, V_ARR };
@@ -470,6 +470,147 @@ template <class F> __device__ bool valid_json_number(const F &f, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------
+// `any` columns holding a container: json.Marshal(wrapIntoEmptyInterface(v, useNumbers)) (generic_parser.go:602-633) —
+// maps with their keys ascending (the last duplicate wins), strings through encoding/json's escaping, numbers as
+// json.Number text or as the float64 fastfloat gives.  Decided on device when every string and key in the value is plain
+// ASCII without escapes, every number is one json.Marshal accepts, and the nesting fits FJ_CANON_DEPTH; else the host.
+// The value was validated by parse_json_line before store_cell sees it.
+// ---------------------------------------------------------------------------
+constexpr int FJ_CANON_DEPTH = 16;
+__device__ __forceinline__ bool fj_ws(uint32_t c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
+// past one validated value at pos (white space in front of it allowed)
+__device__ void fj_skip(MemBytes &rd, uint64_t &pos, const uint64_t end) {
+  while (pos < end && fj_ws(rd.at(pos))) pos++;
+  int depth = 0;
+  while (pos < end) {
+    const uint32_t c = rd.at(pos);
+    if (c == '"') {
+      pos++;
+      while (pos < end) { const uint32_t ch = rd.at(pos); if (ch == '\\') pos += 2; else { pos++; if (ch == '"') break; } }
+      if (depth == 0) return;
+      continue;
+    }
+    if (c == '{' || c == '[') { depth++; pos++; continue; }
+    if (c == '}' || c == ']') { if (depth == 0) return; depth--; pos++; if (depth == 0) return; continue; }
+    if (depth == 0) {  // a number / literal token runs to the next delimiter
+      if (c == ',' || fj_ws(c)) return;
+      pos++;
+      continue;
+    }
+    pos++;
+  }
+}
+__device__ bool fj_any_ok(const JParams &p, MemBytes &rd, const uint64_t vs, const uint64_t ve) {
+  int depth = 0;
+  uint64_t pos = vs;
+  while (pos < ve) {
+    const uint32_t c = rd.at(pos);
+    if (fj_ws(c) || c == ':' || c == ',') { pos++; continue; }
+    if (c == '{' || c == '[') { if (++depth > FJ_CANON_DEPTH) return false; pos++; continue; }
+    if (c == '}' || c == ']') { depth--; pos++; continue; }
+    if (c == '"') {
+      pos++;
+      for (;;) { const uint32_t ch = rd.at(pos); if (ch == '"') break; if (ch == '\\' || ch >= 0x80u) return false; pos++; }
+      pos++;
+      continue;
+    }
+    if (c == 't') { pos += 4; continue; }
+    if (c == 'f') { pos += 5; continue; }
+    if (c == 'n' && pos + 1 < ve && rd.at(pos + 1) == 'u') { pos += 4; continue; }
+    uint64_t q = pos;  // a number token (nan / inf included: json.Marshal refuses them)
+    if (!scan_number(rd, q, ve)) return false;
+    const Field tok{&rd, pos, (uint32_t)(q - pos)};
+    if (p.use_numbers) { if (!valid_json_number(tok, tok.n)) return false; }
+    else { double v; if (ff_best_effort(tok, tok.n, p.pow10, p.pow128, &v) || v != v || v == INFINITY || v == -INFINITY) return false; }
+    pos = q;
+  }
+  return true;
+}
+// encoding/json's string escaping of plain ASCII bytes (escapeHTML on): only control bytes and < > & change
+template <class S> __device__ void fj_go_ascii(S &o, MemBytes &rd, const uint64_t s, const uint32_t n) {
+  const char *H = "0123456789abcdef";
+  o.put('"');
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = rd.at(s + i);
+    if (c >= 0x20 && c != '<' && c != '>' && c != '&') { o.put(c); continue; }
+    o.put('\\');
+    if (c == '\n') o.put('n'); else if (c == '\r') o.put('r'); else if (c == '\t') o.put('t'); else if (c == '\b') o.put('b'); else if (c == '\f') o.put('f');
+    else { o.put('u'); o.put('0'); o.put('0'); o.put(H[c >> 4]); o.put(H[c & 15]); }
+  }
+  o.put('"');
+}
+template <class S> __device__ void fj_emit_any(S &o, const JParams &p, MemBytes &rd, const uint64_t vs, const uint64_t ve) {
+  struct Frame { uint64_t s, e, cur; uint32_t prev_n; uint8_t obj, first; };  // array: cur = next element; object: [cur, cur + prev_n) = last key written
+  Frame st[FJ_CANON_DEPTH];
+  int sp = 0;
+  auto skip_ws = [&](uint64_t &q, uint64_t e) { while (q < e && fj_ws(rd.at(q))) q++; };
+  auto begin_value = [&](uint64_t a, uint64_t b) {
+    const uint32_t c = rd.at(a);
+    if (c == '{' || c == '[') {
+      if (sp == FJ_CANON_DEPTH) return;  // excluded by fj_any_ok
+      Frame &f = st[sp++];
+      f.s = a; f.e = b; f.cur = a + 1; f.prev_n = 0xFFFFFFFFu; f.obj = c == '{'; f.first = 1;
+      o.put(c);
+    } else if (c == '"') fj_go_ascii(o, rd, a + 1, (uint32_t)(b - a - 2));
+    else if (c == 't' || c == 'f' || (c == 'n' && rd.at(a + 1) == 'u') || p.use_numbers) { for (uint64_t q = a; q < b; q++) o.put(rd.at(q)); }
+    else { const Field tok{&rd, a, (uint32_t)(b - a)}; double v = 0; ff_best_effort(tok, tok.n, p.pow10, p.pow128, &v); dev::fmt_json_float(o, v, 64); }
+  };
+  begin_value(vs, ve);
+  while (sp > 0) {
+    Frame &f = st[sp - 1];
+    if (!f.obj) {
+      uint64_t pos = f.cur;
+      skip_ws(pos, f.e);
+      if (rd.at(pos) == ']') { o.put(']'); sp--; continue; }
+      uint64_t q = pos;
+      fj_skip(rd, q, f.e);
+      uint64_t nx = q;
+      skip_ws(nx, f.e);
+      if (rd.at(nx) == ',') nx++;
+      f.cur = nx;
+      if (!f.first) o.put(',');
+      f.first = 0;
+      begin_value(pos, q);
+      continue;
+    }
+    // the next key: the smallest one greater than the key written last, the last occurrence among equals
+    uint64_t bks = 0, bvs = 0, bve = 0; uint32_t bkn = 0xFFFFFFFFu;
+    uint64_t pos = f.s + 1;
+    auto key_cmp = [&](uint64_t a, uint32_t an, uint64_t b, uint32_t bn) -> int {  // plain ASCII bodies: byte order is Go's string order
+      const uint32_t m = an < bn ? an : bn;
+      for (uint32_t i = 0; i < m; i++) { const uint32_t x = rd.at(a + i), y = rd.at(b + i); if (x != y) return x < y ? -1 : 1; }
+      return an == bn ? 0 : an < bn ? -1 : 1;
+    };
+    for (;;) {
+      skip_ws(pos, f.e);
+      if (rd.at(pos) == '}') break;
+      const uint64_t ks = pos + 1;
+      uint64_t q = pos;
+      fj_skip(rd, q, f.e);
+      const uint32_t kn = (uint32_t)(q - pos - 2);
+      pos = q;
+      skip_ws(pos, f.e);
+      pos++;  // ':'
+      skip_ws(pos, f.e);
+      const uint64_t a = pos;
+      fj_skip(rd, pos, f.e);
+      const uint64_t b = pos;
+      skip_ws(pos, f.e);
+      if (rd.at(pos) == ',') pos++;
+      if (f.prev_n != 0xFFFFFFFFu && key_cmp(f.cur, f.prev_n, ks, kn) >= 0) continue;
+      if (bkn == 0xFFFFFFFFu || key_cmp(ks, kn, bks, bkn) <= 0) { bks = ks; bkn = kn; bvs = a; bve = b; }
+    }
+    if (bkn == 0xFFFFFFFFu) { o.put('}'); sp--; continue; }
+    if (!f.first) o.put(',');
+    f.first = 0;
+    f.cur = bks; f.prev_n = bkn;
+    fj_go_ascii(o, rd, bks, bkn);
+    o.put(':');
+    begin_value(bvs, bve);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // one top-level member → the cell of one column (Unmarshal :672-731 then ParseVal :888-1123)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void jstore_int(const JCol &c, int64_t r, int64_t v) {
@@ -573,7 +714,12 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
         while (i < sv.n && (str[i] == ' ' || str[i] == '\t')) i++;
         if (i < sv.n && (str[i] == '{' || str[i] == 'n')) return false;  // an object, or `null` (Unmarshal succeeds with a nil map)
         jtext(c, r, sv.s, sv.n, JM_QUOTED, sv.n + 2);
-      } else return false;  // map / slice: sorted-key re-marshal, host
+      } else {  // map / slice: re-marshalled with sorted keys when every token is one the device decides
+        if (!fj_any_ok(p, aux, vstart, vend)) return false;
+        CountSink cs;
+        fj_emit_any(cs, p, aux, vstart, vend);
+        jtext(c, r, vstart, tok.n, JM_ANYCANON, cs.n);
+      }
       break;
     default:  // JK_DATETIME: extractTimeValue :818-886
       if (vtype == V_NUM) {
@@ -1137,7 +1283,7 @@ __global__ void json_const_text(const uint8_t *text, uint32_t n, int64_t nrows, 
 // text payloads: lane = (column, line) cell
 // ---------------------------------------------------------------------------
 struct JCopyCol { const uint32_t *offsets, *fstart, *meta; uint8_t *out; };
-__global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, const JCopyCol *cols, int64_t nlines, const double *pow10, const uint64_t *pow128) {
+__global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, const JCopyCol *cols, int64_t nlines, const double *pow10, const uint64_t *pow128, int use_numbers) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nlines) return;
   const JCopyCol c = cols[blockIdx.y];
@@ -1150,6 +1296,13 @@ __global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, cons
   if (mode == JM_UNESCAPE) { StoreSink sk{dst}; unescape_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_TSKV) { StoreSink sk{dst}; tskv_walk(rd, s, srclen, sk); sk.finish(); return; }
+  if (mode == JM_ANYCANON) {
+    JParams jp{}; jp.pow10 = pow10; jp.pow128 = pow128; jp.use_numbers = (uint8_t)use_numbers;
+    StoreSink sk{dst};
+    fj_emit_any(sk, jp, rd, s, s + srclen);
+    sk.finish();
+    return;
+  }
   if (mode == JM_FLOAT) {  // the number token again, as encoding/json prints the float64 it parses to
     const Field tok{&rd, s, srclen};
     double v = 0;
@@ -1541,7 +1694,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   if (nlines && nstr) {
     Buf bcc = upload_small(cc.data(), cc.size() * sizeof(JCopyCol));
     KernelTimer t("json_copy_cells");
-    json_copy_cells<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(data, ptr<JCopyCol>(bcc), nlines, pp.pow10, pp.pow128);
+    json_copy_cells<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(data, ptr<JCopyCol>(bcc), nlines, pp.pow10, pp.pow128, (int)pp.use_numbers);
   }
 
   // ---- dropped lines: `_unparsed` rows / host fallback are reported, skipped lines vanish ----
