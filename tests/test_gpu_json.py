@@ -357,7 +357,8 @@ def test_random_documents_and_mutations(tf, oracle):
             continue
         lines.append(line)
     fields = abi.Schema.of(EDGE_FIELDS)
-    for kw in ({}, {"use_numbers_in_any": True, "null_keys_allowed": True}):
+    for kw in ({}, {"use_numbers_in_any": True, "null_keys_allowed": True}, {"add_rest": True, "add_dedupe_keys": True},
+               {"add_rest": True, "use_numbers_in_any": True}):
         opts = abi.json_options(topic="t", **kw)
         out, errs, nfb = compare(tf, oracle, opts, fields, b"\n".join(lines), None, "fuzz %s" % kw, max_fallback=len(lines))
         assert out.nrows > 200 and len(errs) > 200
@@ -443,6 +444,36 @@ def test_tskv_random_lines(tf, oracle):
     data = b"\n".join(lines)
     for opts in (abi.json_options(topic="t", format="tskv"), abi.json_options(topic="t", format="tskv", unescape_string_values=True, add_rest=True)):
         compare(tf, oracle, opts, fields, data, None, "tskv random", max_fallback=len(lines))
+
+
+REST_LINES = [
+    b'{"k": 1, "zz": 1, "aa": "x<y", "mm": null, "b2": [1, {"q": 2, "p": 1}], "cc": 1.50, "dd": true}',
+    b'{"k": 2, "u": 1, "u": 2, "t2": {"b": 1, "a": {"d": 1, "c": 2}, "b": 3}}',          # duplicates: the last one is the map's value
+    b'{"k": 3}',                                                                            # no unknown key: {}
+    b'{"k": 4, "s": "known", "extra": "tab\\there \\"q\\""}',                                 # an escaped string value: host
+    b'{"k": 5, "caf\\u00e9": 1}', b'{"k": 6, "caf\xc3\xa9": 1}',                              # keys that are not plain ASCII: host
+    b'{"k": 7, "n1": 1e400, "n2": 0.1}', b'{"k": 8, "n": nan}',                            # floats json.Marshal refuses (without UseNumbers)
+    b'{"k": 9, ' + b", ".join(b'"x%02d": %d' % (i, i) for i in range(16)) + b'}',           # 16 unknown keys: the most the device sorts
+    b'{"k": 10, ' + b", ".join(b'"x%02d": %d' % (i, i) for i in range(17)) + b'}',          # 17: host
+    b'{"k": 11, "_rest": 1}', b'{"k": 12, "_idx": 5}',                                      # aux names are typed as their columns: host
+    b'{"zz": 1}',                                                                           # key column absent: _unparsed, whatever _rest holds
+    b'{"k": 13, "deep": ' + b"[" * 17 + b"]" * 17 + b'}',                                   # nested beyond the emitter: host
+    b'{"k": 14, "e": "", "o": {}, "a2": [], "neg": -0, "big": 123456789012345678901234567890}',
+]
+
+
+def test_rest_column_on_device(tf, oracle):
+    """AddRest: `_rest` = json.Marshal of the members no column knows.  Device-resident for plain keys and values."""
+    fields = abi.Schema.of(EDGE_FIELDS)
+    data = b"\n".join(REST_LINES)
+    for kw in ({"add_rest": True}, {"add_rest": True, "use_numbers_in_any": True, "add_dedupe_keys": True}):
+        out, errs, nfb = compare(tf, oracle, abi.json_options(topic="t", **kw), fields, data, None, "rest %s" % kw, max_fallback=9)
+        rest = out.col("_rest")
+        got = {int(out.col("k").values[i]): rest.get_bytes(i) for i in range(out.nrows)}
+        assert got[1] == (b'{"aa":"x\\u003cy","b2":[1,{"p":1,"q":2}],"cc":1.50,"dd":true,"mm":null,"zz":1}' if kw.get("use_numbers_in_any")
+                          else b'{"aa":"x\\u003cy","b2":[1,{"p":1,"q":2}],"cc":1.5,"dd":true,"mm":null,"zz":1}')
+        assert got[2] == b'{"t2":{"a":{"c":2,"d":1},"b":3},"u":2}' and got[3] == b"{}"
+        assert 9 in got and 10 not in got and 4 not in got and 5 not in got
 
 
 def test_wave_path_cross_check():

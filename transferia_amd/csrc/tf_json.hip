@@ -40,7 +40,7 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out);           // tf_csv.hip
 
 enum JKind : int32_t { JK_INT, JK_UINT, JK_F64, JK_BOOL, JK_TEXT, JK_ANY, JK_DATETIME };
-enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4, JM_TSKV = 5, JM_ANYCANON = 6 };
+enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4, JM_TSKV = 5, JM_ANYCANON = 6, JM_REST = 7, JM_REST_EMPTY = 8 };
 enum JLineSt : uint8_t { JL_ROW = 0, JL_SKIPPED = 1, JL_SYNTAX = 2, JL_FALLBACK = 3 };
 enum JCellSt : uint8_t { JC_NIL = 0, JC_OK = 1, JC_ERR = 2 };
 enum JVal : int32_t { V_NULL, V_STR, V_NUM, V_TRUE, V_FALSE, V_OBJ, V_ARR };
@@ -74,6 +74,7 @@ struct JParams {
   uint8_t *linest;       // JLineSt per line
   uint32_t *line_pos;    // start offset per line (message lookup)
   uint8_t add_rest, use_numbers;
+  uint32_t *rest_lens, *rest_fstart, *rest_meta;  // `_rest` column (AddRest): text cell per line, null without it
   uint8_t format;        // TFGPU_JFMT_*
   uint8_t tskv_unescape; // Format tskv + UnescapeStringValues: tryToUnescapeTSKV on the values
 };
@@ -740,6 +741,78 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
 }
 
 // ---------------------------------------------------------------------------
+// `_rest` (AddRest, generic_parser.go:323-349): json.Marshal of the map of the top-level members no column knows —
+// p.known = ColumnName and ColPath of the raw fields — each value as Unmarshal left it.  Up to REST_MAX such members with
+// plain ASCII keys and values the `any` emitter decides; else the line goes to the host.  The line was validated.
+// ---------------------------------------------------------------------------
+constexpr int REST_MAX = 16;
+template <class S> __device__ bool rest_emit(S &o, const JParams &p, MemBytes &rd, const uint64_t ls, const uint64_t le) {
+  uint64_t ks[REST_MAX], vs[REST_MAX], ve[REST_MAX]; uint32_t kn[REST_MAX];
+  int n = 0;
+  uint64_t pos = ls;
+  while (pos < le && fj_ws(rd.at(pos))) pos++;
+  pos++;  // '{'
+  for (;;) {
+    while (pos < le && fj_ws(rd.at(pos))) pos++;
+    if (pos >= le || rd.at(pos) == '}') break;
+    pos++;  // '"'
+    JStr k;
+    scan_string(rd, pos, le, k);
+    while (pos < le && fj_ws(rd.at(pos))) pos++;
+    pos++;  // ':'
+    while (pos < le && fj_ws(rd.at(pos))) pos++;
+    const uint64_t a = pos;
+    fj_skip(rd, pos, le);
+    const uint64_t b = pos;
+    while (pos < le && fj_ws(rd.at(pos))) pos++;
+    if (pos < le && rd.at(pos) == ',') pos++;
+    bool known = false;
+    for (uint32_t s = k.hash & p.slot_mask;; s = (s + 1) & p.slot_mask) {
+      const JSlot sl = p.slots[s];
+      if (sl.slen == ~0u) break;
+      if (sl.hash == k.hash && sl.slen == k.n) {
+        bool same = true;
+        for (uint32_t i = 0; i < k.n && same; i += 8) {
+          const uint32_t nb = k.n - i < 8 ? k.n - i : 8u;
+          same = (rd.word(k.s + i) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1)) == *reinterpret_cast<const uint64_t *>(p.names + sl.soff + i);
+        }
+        if (same) { known = true; break; }
+      }
+    }
+    if (known) continue;
+    if (!k.plain || n == REST_MAX) return false;
+    // the value as Unmarshal stores it: a string stays a Go string (plain ASCII only here), anything else through the `any` rules
+    if (rd.at(a) == '"') { for (uint64_t q = a + 1; q + 1 < b; q++) { const uint32_t ch = rd.at(q); if (ch == '\\' || ch >= 0x80u) return false; } }
+    else if (!fj_any_ok(p, rd, a, b)) return false;
+    ks[n] = k.s; kn[n] = k.n; vs[n] = a; ve[n] = b; n++;
+  }
+  auto key_cmp = [&](int x, int y) -> int {
+    const uint32_t m = kn[x] < kn[y] ? kn[x] : kn[y];
+    for (uint32_t i = 0; i < m; i++) { const uint32_t cx = rd.at(ks[x] + i), cy = rd.at(ks[y] + i); if (cx != cy) return cx < cy ? -1 : 1; }
+    return kn[x] == kn[y] ? 0 : kn[x] < kn[y] ? -1 : 1;
+  };
+  // ascending keys by selection (n <= 16); among equal keys the last occurrence is the map's value
+  o.put('{');
+  int prev = -1; bool first = true;
+  for (;;) {
+    int best = -1;
+    for (int i = 0; i < n; i++) {
+      if (prev >= 0 && key_cmp(i, prev) <= 0) continue;
+      if (best < 0 || key_cmp(i, best) <= 0) best = i;
+    }
+    if (best < 0) break;
+    if (!first) o.put(',');
+    first = false;
+    fj_go_ascii(o, rd, ks[best], kn[best]);
+    o.put(':');
+    fj_emit_any(o, p, rd, vs[best], ve[best]);
+    prev = best;
+  }
+  o.put('}');
+  return true;
+}
+
+// ---------------------------------------------------------------------------
 // one line: fastjson Parser.Parse with an explicit container stack; the members of a top-level
 // object are handed to store_cell as they complete
 // ---------------------------------------------------------------------------
@@ -753,6 +826,7 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
   bool root_obj = false, fallback = false, syntax = false, key_next = false;
   uint32_t root_kids = 0;
   int32_t kcol = JS_UNKNOWN;
+  uint32_t nunknown = 0;
   uint64_t vstart = 0;
   int vtype = V_NULL;
   uint32_t clen = 0;
@@ -783,7 +857,7 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
               if (same) { kcol = sl.col; if (sl.aux) fallback = true; break; }  // colTypeMap types it as the aux column (:1218-1225): host
             }
           }
-          if (p.add_rest && kcol == JS_UNKNOWN) fallback = true;  // `_rest` would not be {}
+          if (p.add_rest && kcol == JS_UNKNOWN) nunknown++;  // `_rest` will not be {}
         }
       } else if (ncont == 2 && vtype == V_OBJ && (k.bs || k.ctrl)) kbad = true;
       JSKIPWS();
@@ -876,6 +950,14 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
   if (syntax) st = JL_SYNTAX;              // Unmarshal error → NewUnparsed (:545-550); decided before any fallback,
   else if (fallback) st = JL_FALLBACK;     //   except that a line abandoned for depth is never known to be malformed
   else if (!root_obj || root_kids == 0) st = JL_SKIPPED;  // len(item) == 0 (:536)
+  if (st == JL_ROW && p.rest_lens) {
+    if (nunknown == 0) { p.rest_fstart[r] = (uint32_t)ls; p.rest_meta[r] = (JM_REST_EMPTY << 28); p.rest_lens[r] = 2; }
+    else {
+      CountSink cs;
+      if (!rest_emit(cs, p, aux, ls, le)) st = JL_FALLBACK;
+      else { p.rest_fstart[r] = (uint32_t)ls; p.rest_meta[r] = (uint32_t)(le - ls) | (JM_REST << 28); p.rest_lens[r] = cs.n; }
+    }
+  }
   p.linest[r] = st;
   p.line_pos[r] = (uint32_t)ls;
 }
@@ -931,6 +1013,7 @@ __device__ void parse_tskv_line(const JParams &p, const int64_t r, const uint64_
     pos = fe + 1;
   }
   p.linest[r] = fallback ? JL_FALLBACK : kids == 0 ? JL_SKIPPED : JL_ROW;
+  if (!fallback && kids && p.rest_lens) { p.rest_fstart[r] = (uint32_t)ls; p.rest_meta[r] = (JM_REST_EMPTY << 28); p.rest_lens[r] = 2; }
   p.line_pos[r] = (uint32_t)ls;
 }
 
@@ -1283,7 +1366,8 @@ __global__ void json_const_text(const uint8_t *text, uint32_t n, int64_t nrows, 
 // text payloads: lane = (column, line) cell
 // ---------------------------------------------------------------------------
 struct JCopyCol { const uint32_t *offsets, *fstart, *meta; uint8_t *out; };
-__global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, const JCopyCol *cols, int64_t nlines, const double *pow10, const uint64_t *pow128, int use_numbers) {
+__global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCol *cols, int64_t nlines) {
+  const uint8_t *data = jp.data; const double *pow10 = jp.pow10; const uint64_t *pow128 = jp.pow128;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nlines) return;
   const JCopyCol c = cols[blockIdx.y];
@@ -1296,13 +1380,9 @@ __global__ void __launch_bounds__(256) json_copy_cells(const uint8_t *data, cons
   if (mode == JM_UNESCAPE) { StoreSink sk{dst}; unescape_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_TSKV) { StoreSink sk{dst}; tskv_walk(rd, s, srclen, sk); sk.finish(); return; }
-  if (mode == JM_ANYCANON) {
-    JParams jp{}; jp.pow10 = pow10; jp.pow128 = pow128; jp.use_numbers = (uint8_t)use_numbers;
-    StoreSink sk{dst};
-    fj_emit_any(sk, jp, rd, s, s + srclen);
-    sk.finish();
-    return;
-  }
+  if (mode == JM_ANYCANON) { StoreSink sk{dst}; fj_emit_any(sk, jp, rd, s, s + srclen); sk.finish(); return; }
+  if (mode == JM_REST) { StoreSink sk{dst}; rest_emit(sk, jp, rd, s, s + srclen); sk.finish(); return; }
+  if (mode == JM_REST_EMPTY) { dst[0] = '{'; dst[1] = '}'; return; }
   if (mode == JM_FLOAT) {  // the number token again, as encoding/json prints the float64 it parses to
     const Field tok{&rd, s, srclen};
     double v = 0;
@@ -1575,6 +1655,8 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   }
   int nstr = 0;
   for (auto &c : cols) if (c.kind == JK_TEXT || c.kind == JK_ANY) nstr++;
+  const int rest_seg = opts->add_rest ? nstr++ : -1;  // `_rest` is one more text column (its cells come from the whole line)
+  int rest_col = -1;                                   // its index in db->cols
   const int64_t seg_stride = ((nlines + 1 + 3) / 4) * 4;
   Buf lens_all = dalloc_zero((size_t)std::max(nstr, 1) * (size_t)seg_stride * 4 + 16);
   Buf fstart_all = dalloc((size_t)std::max(nstr, 1) * (size_t)nalloc * 8);  // fstart | meta
@@ -1623,6 +1705,11 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   pp.pow10 = pow10_table(); pp.pow128 = reinterpret_cast<const uint64_t *>(pp.pow10 + 632); pp.linest = ptr<uint8_t>(linest); pp.line_pos = ptr<uint32_t>(line_pos);
   pp.add_rest = opts->add_rest; pp.use_numbers = opts->use_numbers_in_any;
   pp.format = opts->format; pp.tskv_unescape = tskv && opts->unescape_string_values;
+  if (rest_seg >= 0) {
+    pp.rest_lens = ptr<uint32_t>(lens_all) + (int64_t)rest_seg * seg_stride;
+    pp.rest_fstart = ptr<uint32_t>(fstart_all) + (int64_t)rest_seg * 2 * nalloc;
+    pp.rest_meta = pp.rest_fstart + nalloc;
+  }
   // The per-line path is the default: 64 lines of one shape run in lockstep, so a wave pays each instruction once per
   // 64 lines (≈ 23 k wave-instructions per 64 lines of 2.3 KB).  The wave path (TFGPU_JSON_WAVEPATH=1) reads coalesced
   // and does stage 1 on the scalar unit, but its lanes are MEMBERS of one line — different column kinds side by side —
@@ -1653,9 +1740,12 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   for (auto &a : aux) {
     DColumn d;
     d.name = a.name; d.dtype = a.dtype;
-    if (a.dtype == TFGPU_T_ANY || a.dtype == TFGPU_T_BYTES) {  // `_rest` = {} (a line with unknown keys went to the host) / `_partition` = PartID
-      const std::string text = a.dtype == TFGPU_T_ANY ? "{}" : part;
-      d.repr = a.dtype == TFGPU_T_ANY ? TFGPU_R_JSON : TFGPU_R_STRING;
+    if (a.dtype == TFGPU_T_ANY) {  // `_rest`: a text cell per line, written by rest_emit
+      d.repr = TFGPU_R_JSON;
+      rest_col = (int)db->cols.size();
+    } else if (a.dtype == TFGPU_T_BYTES) {  // `_partition` = PartID
+      const std::string text = part;
+      d.repr = TFGPU_R_STRING;
       if ((uint64_t)text.size() * (uint64_t)nalloc >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: `_partition` column exceeds 4 GiB");
       d.offsets = dalloc((size_t)(nalloc + 1) * 4); d.data = dalloc(text.size() * (size_t)nalloc + 8); d.data_len = text.size() * (uint64_t)nlines;
       Buf bt = upload_small(text.data(), text.size());
@@ -1684,17 +1774,18 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   // ---- text payloads ----
   std::vector<JCopyCol> cc;
   for (int s = 0; s < nstr; s++) {
-    DColumn &d = db->cols[(size_t)str_col_index[(size_t)s]];
-    const JCol &c = cols[(size_t)str_col_index[(size_t)s]];
+    const bool is_rest = s == rest_seg;
+    DColumn &d = db->cols[is_rest ? (size_t)rest_col : (size_t)str_col_index[(size_t)s]];
     d.data_len = hsum[1 + s];
     d.data = dalloc(d.data_len + 8);
     d.offsets = subbuf(lens_all, (size_t)s * (size_t)seg_stride * 4, (size_t)(nlines + 1) * 4);
-    cc.push_back(JCopyCol{ptr<uint32_t>(d.offsets), c.fstart, c.meta, ptr<uint8_t>(d.data)});
+    if (is_rest) cc.push_back(JCopyCol{ptr<uint32_t>(d.offsets), pp.rest_fstart, pp.rest_meta, ptr<uint8_t>(d.data)});
+    else { const JCol &c = cols[(size_t)str_col_index[(size_t)s]]; cc.push_back(JCopyCol{ptr<uint32_t>(d.offsets), c.fstart, c.meta, ptr<uint8_t>(d.data)}); }
   }
   if (nlines && nstr) {
     Buf bcc = upload_small(cc.data(), cc.size() * sizeof(JCopyCol));
     KernelTimer t("json_copy_cells");
-    json_copy_cells<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(data, ptr<JCopyCol>(bcc), nlines, pp.pow10, pp.pow128, (int)pp.use_numbers);
+    json_copy_cells<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines);
   }
 
   // ---- dropped lines: `_unparsed` rows / host fallback are reported, skipped lines vanish ----
