@@ -1221,7 +1221,7 @@ __global__ void __launch_bounds__(256) json_parse_waves(JParams p, uint32_t *slo
           if (same) { kc = sl.col; if (sl.aux) bad = true; break; }
         }
       }
-      if (p.add_rest && kc == JS_UNKNOWN) bad = true;  // `_rest` would not be {}: per-line path (→ host)
+      if (p.add_rest && kc == JS_UNKNOWN) bad = true;  // `_rest` will not be {}: the per-line path writes it
       kcol[rd] = kc;
       if (kc >= 0) { if (kc >= JF_OWN) bad = true; else L.owner[kc] = (iter << 8) | m; }
     }
@@ -1253,6 +1253,7 @@ __global__ void __launch_bounds__(256) json_parse_waves(JParams p, uint32_t *slo
     if (lane == 0) {
       p.linest[r] = fb ? JL_FALLBACK : (nm ? JL_ROW : JL_SKIPPED);
       p.line_pos[r] = (uint32_t)base;
+      if (!fb && nm && p.rest_lens) { p.rest_fstart[r] = (uint32_t)base; p.rest_meta[r] = (JM_REST_EMPTY << 28); p.rest_lens[r] = 2; }  // every key was known: {}
     }
   }
 }
