@@ -348,3 +348,41 @@ def test_gpu_matches_oracle(tf, oracle, n):
     assert set(grows) <= set(rrows)
     assert not fallback and (n < 1000 or len(grows) > n // 4)  # unsorted `any` objects are sorted on the device
     assert [c.dtype for c in got.batch.cols] == ["any", "boolean", "int64", "double", "any", "utf8", "utf8"]
+
+
+# ---------------------------------------------------------------- oracle vs an independent JSON implementation ----
+def _py_rand(rng, depth=0):
+    t = rng.random()
+    if depth >= 4 or t < 0.4:
+        return [None, True, False, 0, -1, 12345678901234567890, 1.5, -2.25e-7, 1e300, "", "plain", "<b>&amp;", "tab\t\"q\"\\", "é\u4e2d\U0001F600", "\u2028\u2029\x7f\x01"][int(rng.integers(0, 15))]
+    if t < 0.65:
+        return [_py_rand(rng, depth + 1) for _ in range(int(rng.integers(0, 5)))]
+    keys = ["a", "b", "B", "ab", "", "é", "z z", "<", "\u2028", "k\"q", "\U0001F600"]
+    return {keys[int(rng.integers(0, len(keys)))]: _py_rand(rng, depth + 1) for _ in range(int(rng.integers(0, 6)))}
+
+
+def _go_marshal(v):
+    """json.Marshal of the decoded value, through Python's encoder: sorted keys, no spaces, Go's extra escapes."""
+    t = json.dumps(v, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
+    return t.replace("<", "\\u003c").replace(">", "\\u003e").replace("&", "\\u0026").replace("\u2028", "\\u2028").replace("\u2029", "\\u2029").replace("\x7f", "\x7f")
+
+
+def test_oracle_any_marshal_matches_python_json(oracle):
+    """The oracle's Decoder + json.Marshal restatement against Python's json module on random documents (any key order,
+    escapes or raw UTF-8 in the source): an independent implementation of the same published format."""
+    rng = np.random.default_rng(SEED0 + 424242)
+    schema = '{"title":"a.b","type":"object","properties":{"x":{"type":"object"}}}'
+    docs, payloads = [], []
+    for _ in range(3000):
+        v = _py_rand(rng)
+        src = json.dumps({"pad": 1, "x": v}, ensure_ascii=bool(rng.random() < 0.5), separators=[(",", ":"), (", ", ": "), (" , ", " : ")][int(rng.integers(0, 3))])
+        docs.append(v); payloads.append(src.encode("utf-8"))
+    data, cm = abi.messages([b"\0\0\0\0\x02" + p for p in payloads])
+    res = oracle.sr_json_parse(confluent_sr.sr_json_options(2, schema), data, cm)
+    assert not res.errors and res.batch.nrows == len(docs)
+    col = res.batch.cols[0]
+    for i, v in enumerate(docs):
+        if v is None:
+            assert not col.is_valid(i)
+        else:
+            assert col.get_bytes(i).decode("utf-8") == _go_marshal(v), (i, payloads[i])

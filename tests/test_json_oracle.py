@@ -113,3 +113,28 @@ def test_fastfloat_best_effort(oracle):
                     ("0.0000001", 1e-7), ("123.456e2", 12345.6)]:
         got = L.ora_fastfloat_parse_best_effort(s.encode(), len(s))
         assert got == want and (str(got) == str(want)), s
+
+
+def test_any_and_rest_marshal_match_python_json(oracle):
+    """go_marshal_any / the `_rest` map of the oracle against Python's json module on random valid documents
+    (UseNumbersInAny: numbers keep their text): an independent implementation of the same published format."""
+    import numpy as np
+    from test_confluent_sr import _go_marshal, _py_rand
+    rng = np.random.default_rng(515151)
+    fields = abi.Schema.of([["k", "int32", True], ["a", "any"]])
+    opts = abi.json_options(topic="t", use_numbers_in_any=True, add_rest=True)
+    docs, lines = [], []
+    for n in range(2000):
+        v, extra = _py_rand(rng, 1), {("u%d" % i): _py_rand(rng, 2) for i in range(int(rng.integers(0, 4)))}
+        if not isinstance(v, (dict, list)):
+            v = [v]
+        doc = dict(extra); doc["k"] = n; doc["a"] = v
+        keys = list(doc)
+        rng.shuffle(keys)
+        lines.append(json.dumps({k: doc[k] for k in keys}, ensure_ascii=bool(rng.random() < 0.5)).encode("utf-8"))
+        docs.append((v, extra))
+    r = oracle.json_parse(opts, fields, b"\n".join(lines))
+    assert r.nrows == len(docs) and all(ln[0] == oracle.JL_ROW for ln in r.lines)
+    for (v, extra), row in zip(docs, r.rows):
+        assert row[1][1].decode("utf-8") == _go_marshal(v)
+        assert row[2][1].decode("utf-8") == _go_marshal(extra)
