@@ -73,3 +73,17 @@ def test_no_reference_path_at_runtime():
                 if re.search(r"open\([^)]*/root/reference|REF\s*=\s*\"/root/reference", src):
                     bad.append(os.path.join(rel, f))
     assert not bad, bad
+
+
+def test_product_never_touches_the_emulator():
+    """tools/hipemu is a CPU pre-flight for tests: the product binding knows one library, transferia_amd/libtfgpu.so,
+    has no environment override for it, and nothing in the package mentions the emulator."""
+    bad = []
+    for p in product_files():
+        src = open(p, encoding="utf-8").read()
+        if re.search(r"hipemu|libtfgpu_emu|emu_launch", src):
+            bad.append(os.path.relpath(p, ROOT))
+    assert not bad, bad
+    lib_src = open(os.path.join(PKG, "lib.py"), encoding="utf-8").read()
+    assert re.search(r'_LIBPATH\s*=\s*os\.path\.join\(_HERE,\s*"libtfgpu\.so"\)', lib_src)
+    assert not re.search(r"environ[^\n]*LIB", lib_src)
