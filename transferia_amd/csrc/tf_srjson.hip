@@ -267,7 +267,7 @@ __device__ int rune_compare(RuneIter a, RuneIter b) {
 struct CountSink { uint32_t n = 0; __device__ __forceinline__ void put(uint32_t) { n++; } };
 // Bytes leave eight at a time through one (possibly unaligned) 8-byte store, like tf_emit.hpp's WriteSink.  (A sink that
 // bumps a uint8_t* per byte next to MemBytes' cached window was miscompiled for gfx950 at -O3 — the pointer was clobbered
-// after the first store; tools/hipemu cannot see that, the MI355X run did.)
+// after the first store; a lane-at-a-time CPU run of the kernel cannot see that, the MI355X run did.)
 struct ByteSink {
   uint8_t *p; uint64_t acc = 0; uint32_t n = 0;
   struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
