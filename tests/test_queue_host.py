@@ -1,0 +1,45 @@
+"""Host side of the queue serializers (transferia_amd/queue.py): RawColumnSerializer, message keys, PartID groups —
+pinned to pkg/serializer/queue/raw_column_serializer_test.go:21-245 and split.go."""
+import numpy as np
+
+from transferia_amd import abi, queue
+
+SCHEMA = abi.Schema.of([["extra_column", "int64"], ["test_column", "utf8"], ["other_extra_column", "any"]])
+
+
+def _batch(rows, names=("extra_column", "test_column", "other_extra_column"), schema=SCHEMA):
+    b = abi.batch_from_rows(schema, list(names), rows, "public", "test_table")
+    b.schema = schema
+    return b
+
+
+def test_raw_column_string_and_bytes():
+    # TestRawColumnSerializerString: Go strings
+    b = _batch([[["int64", 1], ["string", "kek"], ["nil", None]], [["int64", 2], ["string", "lel"], ["nil", None]], [["int64", 3], ["string", "wtf"], ["nil", None]]])
+    assert queue.raw_column_messages(b, "test_column") == [b"kek", b"lel", b"wtf"]
+    # TestRawColumnSerializerMissingColumn: the first item has no such column (one batch = one ColumnNames shape here), []byte values
+    b2 = _batch([[["int64", 2], ["bytes", "lel"], ["nil", None]], [["int64", 3], ["bytes", "wtf"], ["nil", None]]])
+    assert queue.raw_column_messages(b2, "test_column") == [b"lel", b"wtf"]
+    assert queue.raw_column_messages(_batch([[["int64", 1], ["nil", None]]], names=("extra_column", "other_extra_column")), "test_column") == []
+    assert queue.raw_column_messages(abi.Batch([], 0, "public", "test_table"), "test_column") == []  # TestRawColumnSerializerEmptyInput
+
+
+def test_raw_column_skips_what_the_reference_skips():
+    # TestRawColumnSerializerUnexpectedType: an int value under a "utf8" column, a column typed int64, a nil value
+    ints = abi.Schema.of([["extra_column", "int64"], ["test_column", "int64"], ["other_extra_column", "any"]])
+    assert queue.raw_column_messages(_batch([[["int64", 1], ["int64", 100500], ["nil", None]]], schema=SCHEMA), "test_column") == []
+    assert queue.raw_column_messages(_batch([[["int64", 2], ["int64", 100500], ["nil", None]]], schema=ints), "test_column") == []
+    b = _batch([[["int64", 1], ["nil", None], ["nil", None]], [["int64", 3], ["string", "wtf"], ["nil", None]]])
+    assert queue.raw_column_messages(b, "test_column") == [b"wtf"]
+    # TestRawColumnSerializerInvalidTableSchema: the TableSchema does not list the column
+    no_col = abi.Schema.of([["extra_column", "int64"], ["other_extra_column", "any"]])
+    assert queue.raw_column_messages(_batch([[["int64", 1], ["string", "kek"], ["nil", None]]]), "test_column", no_col) == []
+
+
+def test_keys_and_part_groups():
+    assert queue.fqtn("public", "table1") == "public_table1"  # TestNativeSerializerTopicName's canon key
+    assert queue.message_keys("public", "t", 2, False) == [b"public_t", b"public_t"] and queue.message_keys("public", "t", 2, True) == [None, None]
+    order, counts, ids = queue.part_groups(np.array([3, 1, 3, 2, 1], np.uint32), 5)
+    assert order.tolist() == [0, 2, 1, 4, 3] and counts == [2, 2, 1] and ids == ["3", "1", "2"]
+    order, counts, ids = queue.part_groups(None, 4)
+    assert order.tolist() == [0, 1, 2, 3] and counts == [4] and ids == [""]

@@ -1,0 +1,64 @@
+"""Host side of the queue serializers (pkg/serializer/queue): what the reference does around the bytes.
+
+`tfgpu_queue_serialize` produces the message VALUES of the native / JSON serializers on the device; this module holds
+the parts that are metadata, the way the shim would do them in Go:
+
+    Serializer.Serialize's message keys          native_serializer.go:24, json_serializer.go:37, *_batcher.go (Key: nil)
+    splitByTablePartID                           split.go:5-12 (rows grouped by ChangeItem.PartID, one group per call)
+    RawColumnSerializer                          raw_column_serializer.go:21-73 (a message per row: one column's bytes)
+
+RawColumnSerializer needs no kernel: its message values ARE the (offsets, data) buffers of the named column, as
+tfgpu_dbatch_view / download expose them.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import abi
+
+
+def fqtn(ns: str, table: str) -> str:
+    """ChangeItem.Fqtn() (change_item.go:139-141)."""
+    return ns + "_" + table
+
+
+def message_keys(ns: str, table: str, nmsg: int, batching_enabled: bool) -> List[Optional[bytes]]:
+    """Keys of the native / JSON serializers' messages: Fqtn() for one-item messages, nil for batched ones."""
+    return [None] * nmsg if batching_enabled else [fqtn(ns, table).encode("utf-8")] * nmsg
+
+
+def part_groups(part_id: Optional[np.ndarray], nrows: int) -> Tuple[np.ndarray, List[int], List[str]]:
+    """splitByTablePartID for one table: (stable row order grouping equal PartIDs, rows per group, PartID text per group).
+    Go maps iterate in no defined order; the groups come out by first appearance."""
+    if part_id is None:
+        return np.arange(nrows), [nrows], [""]
+    _, first, inv = np.unique(part_id, return_index=True, return_inverse=True)
+    rank = np.argsort(np.argsort(first, kind="stable"), kind="stable")  # group number by first appearance
+    g = rank[inv]
+    order = np.argsort(g, kind="stable")
+    counts = np.bincount(g, minlength=len(first)).tolist()
+    ids = [str(int(part_id[np.sort(first)[k]])) for k in range(len(first))]
+    return order, counts, ids
+
+
+def raw_column_messages(batch: abi.Batch, column_name: str, schema: Optional[abi.Schema] = None) -> List[bytes]:
+    """RawColumnSerializer.Serialize for one table / PartID: the value of `column_name` of every row, as bytes; rows the
+    reference skips with a warning (column absent from ColumnNames or from the TableSchema, DataType neither "utf8" nor
+    "string", a value that is not a Go string / []byte — nil included) are skipped here too."""
+    col = next((c for c in batch.cols if c.name == column_name), None)
+    if col is None:
+        return []
+    sch = schema if schema is not None else getattr(batch, "schema", None)
+    dtype = col.dtype
+    if sch is not None:
+        sc = next((c for c in sch.cols if c.name == column_name), None)
+        if sc is None:
+            return []  # "table schema does not contain column"
+        dtype = sc.dtype
+    if dtype not in ("utf8", "string"):
+        return []
+    if col.repr not in (abi.R_STRING, abi.R_BYTES):
+        return []  # "unexpected column value type"
+    return [col.get_bytes(i) for i in range(batch.nrows) if col.is_valid(i)]
