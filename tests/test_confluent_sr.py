@@ -386,3 +386,33 @@ def test_oracle_any_marshal_matches_python_json(oracle):
             assert not col.is_valid(i)
         else:
             assert col.get_bytes(i).decode("utf-8") == _go_marshal(v), (i, payloads[i])
+
+
+# ---------------------------------------------------------------- the parser object (DoBatch over mixed schema ids) ----
+def _check_parser_object(engine):
+    """TestClient through ConfluentSrParser.do_batch: all five JSON schemas and the two protobuf messages in ONE batch."""
+    reg = {int(k): v for k, v in G["schemas"].items()}
+    nonempty = [(i, m) for i, m in enumerate(MSGS) if m]
+    proto = [b"\0\0\0\0\x05" + b"\x08\x01\x12\x03abc", b"\0\0\0\0\x06\x08\x01"]  # protobuf schema ids: the stock parser's frames
+    data, cm = abi.messages([m for _, m in nonempty] + proto, offsets=[i for i, _ in nonempty] + [900, 901])
+    items = confluent_sr.ConfluentSrParser(reg).do_batch(engine, data, cm)
+    rows = [it for it in items if "kind" in it]
+    assert len(rows) == len(G["items"]) and [it["msg"] for it in items if it.get("fallback")] == [len(nonempty), len(nonempty) + 1]
+    for it, exp in zip(rows, G["items"]):
+        assert (it["schema"], it["table"], it["names"], nonempty[it["msg"]][0]) == (exp["schema"], exp["table"], exp["names"], exp["lsn"])
+    assert [it["index"] for it in rows[:3]] == [0, 1, 0]  # the first message holds two frames
+    # a failing frame ends its message across schema ids: frame 1 (schema 0) is bad, frame 2 (schema 3) is never looked at
+    f = lambda sid, p: b"\0" + int(sid).to_bytes(4, "big") + p  # noqa: E731
+    d2, m2 = abi.messages([f(0, b'{"col0_number":1}') + f(0, b'{"col0_number":"x"}') + f(3, b'{"col0_bool":true}'), f(3, b'{"col0_bool":false}'), b"\x07junk"])
+    got = confluent_sr.ConfluentSrParser(reg).do_batch(engine, d2, m2)
+    assert [(x.get("table"), x.get("unparsed"), x["msg"]) for x in got] == [("table_iCMRA", None, 0), (None, abi.ROWERR_ID["SR_TYPE"], 0), ("table_VlgTe", None, 1),
+                                                                         (None, abi.ROWERR_ID["SR_MAGIC"], 2)]
+
+
+def test_oracle_parser_object(oracle):
+    _check_parser_object(oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_parser_object(tf):
+    _check_parser_object(tf)

@@ -82,3 +82,70 @@ def sr_json_options(schema_id: int, schema_text: str, policy: str = POLICY_DEBEZ
 def table_schema(rows) -> abi.Schema:
     """abstract.NewTableSchema(rows) of processPayload: one ColSchema per property."""
     return abi.Schema([abi.ColSchema(n, SRT_DTYPE[t], False, "", "", bool(r)) for n, t, r in rows])
+
+
+class ConfluentSrParser:
+    """ConfluentSrImpl.DoBatch for JSON schemas (engine/parser.go:108-152) over an engine that provides
+    `sr_frames(data, msgs)` and `sr_json_parse(opts, data, msgs)` — transferia_amd.lib on the device (the tests also run it
+    over the oracle).  The registry is a mapping schema id → {"schema": text, "schemaType": "JSON" | ...}: the network
+    client stays with the caller, as it stays in Go.
+
+    do_batch returns the items in the reference's order — message by message, frame by frame — as dicts:
+      {"kind": "insert", "schema", "table", "names", "values": [(gotype, value)], "msg", "index"}   a parsed frame
+      {"unparsed": code, "msg", "index"}                                                            generic.NewUnparsed
+      {"fallback": True, "msg"}                                                  the message goes through the stock parser
+    An `_unparsed` frame ends its message for the frames after it, whatever their schema id (DoBuf stops at the first
+    nil rest); frames of a schema the registry does not know, or of a non-JSON schema, are the stock parser's business.
+    """
+
+    def __init__(self, registry, policy: str = POLICY_DEBEZIUM_STYLE, manual_table_name: str = ""):
+        self.registry, self.policy, self.manual = registry, policy, manual_table_name
+        self._plans = {}
+
+    def _plan(self, sid: int):
+        if sid not in self._plans:
+            ent = self.registry.get(sid) or self.registry.get(str(sid))
+            self._plans[sid] = None if not ent or ent.get("schemaType") != "JSON" else ent["schema"]
+        return self._plans[sid]
+
+    def do_batch(self, engine, data, msgs=None):
+        frames = engine.sr_frames(data, msgs)
+        fate = {}  # frame ordinal → item
+        first = True
+        for sid in sorted({f[3] for f in frames if f[4] == 0}):
+            text = self._plan(sid)
+            if text is None:
+                for k, f in enumerate(frames):
+                    if f[4] == 0 and f[3] == sid:
+                        fate[k] = {"fallback": True, "msg": f[0]}
+                continue
+            opts = sr_json_options(sid, text, self.policy, self.manual, report_frame_errors=first)
+            first = False
+            res = engine.sr_json_parse(opts, data, msgs)
+            b = res.batch
+            for e in res.errors:
+                k, code = int(e[0]), int(e[1])
+                fate[k] = {"fallback": True, "msg": frames[k][0]} if code == abi.ROWERR_ID["HOST_FALLBACK"] else {"unparsed": code, "msg": frames[k][0], "index": frames[k][5]}
+            names = [c.name for c in b.cols]
+            for r in range(b.nrows):
+                k = int(b.src_row[r])
+                fate[k] = {"kind": "insert", "schema": b.table_ns, "table": b.table_name, "names": names, "values": [c.pyvalue(r) for c in b.cols],
+                           "msg": frames[k][0], "index": frames[k][5]}
+        if first:  # no JSON schema in the batch: the frame errors were reported by nobody
+            for k, f in enumerate(frames):
+                if f[4]:
+                    fate[k] = {"unparsed": f[4], "msg": f[0], "index": f[5]}
+        out, dead_msg, host_msgs = [], set(), set()
+        for k, f in enumerate(frames):  # the reference's order; the first `_unparsed` frame of a message ends it
+            it = fate.get(k)
+            if f[0] in dead_msg or f[0] in host_msgs or it is None:
+                continue
+            if it.get("fallback"):
+                host_msgs.add(f[0])
+                out = [x for x in out if x["msg"] != f[0]]  # the whole message is re-parsed by the stock parser
+                out.append({"fallback": True, "msg": f[0]})
+                continue
+            out.append(it)
+            if "unparsed" in it:
+                dead_msg.add(f[0])
+        return out
