@@ -43,3 +43,12 @@ def test_keys_and_part_groups():
     assert order.tolist() == [0, 2, 1, 4, 3] and counts == [2, 2, 1] and ids == ["3", "1", "2"]
     order, counts, ids = queue.part_groups(None, 4)
     assert order.tolist() == [0, 1, 2, 3] and counts == [4] and ids == [""]
+
+
+def test_kafka_hash_partition_known_answers():
+    """TestHashBalancer (vendor_patched/github.com/segmentio/kafka-go/balancer_test.go:10-64), the FNV-1a cases."""
+    assert queue.kafka_hash_partition(None, 3) is None  # nil key: round robin
+    assert queue.kafka_hash_partition(b"blah", 2) == 0
+    assert queue.kafka_hash_partition(b"blah", 3) == 1
+    assert queue.kafka_hash_partition(b"boop", 3) == 2
+    assert queue.kafka_hash_partition(b"20", 16) == 1   # "hash code with MSB set": int32 conversion before the remainder

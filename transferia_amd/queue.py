@@ -62,3 +62,18 @@ def raw_column_messages(batch: abi.Batch, column_name: str, schema: Optional[abi
     if col.repr not in (abi.R_STRING, abi.R_BYTES):
         return []  # "unexpected column value type"
     return [col.get_bytes(i) for i in range(batch.nrows) if col.is_valid(i)]
+
+
+def kafka_hash_partition(key: Optional[bytes], npartitions: int) -> Optional[int]:
+    """kafka-go's Hash balancer (vendor_patched/github.com/segmentio/kafka-go/balancer.go:153-181), the writer the Kafka
+    sink uses: FNV-1a(32) of the key, the hash taken as an int32, Go's truncated remainder, a negative result negated
+    — Sarama's hashPartitioner.  None for a nil key (round robin there).  All messages of one unbatched table share
+    the key Fqtn(), so a table lands in ONE partition; batched messages (nil keys) are spread round robin."""
+    if key is None:
+        return None
+    h = 0x811C9DC5
+    for b in key:
+        h = ((h ^ b) * 0x01000193) & 0xFFFFFFFF
+    v = h - (1 << 32) if h & 0x80000000 else h  # int32(hasher.Sum32())
+    r = abs(v) % npartitions                       # Go's % keeps the dividend's sign; the balancer negates a negative result
+    return r
