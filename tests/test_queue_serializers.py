@@ -230,3 +230,48 @@ def test_gpu_queue_errors_and_empty(tf, oracle):
     assert oracle.queue_serialize(abi.queue_options(abi.QFMT_NATIVE), bn, fs) is None
     with pytest.raises(tf.TfgpuError):
         tf.queue_serialize(abi.queue_options(abi.QFMT_NATIVE), tf.DeviceBatch.upload(bn), None)
+
+
+def test_oracle_native_messages_parse_back(oracle):
+    """Every native message of the oracle is valid JSON whose fields, read back by an independent JSON implementation,
+    are the inputs: key order of MarshalJSON's putItem sequence, values, OldKeys only on the rows that carry them, row meta
+    through src_row."""
+    import base64
+    from collections import OrderedDict
+    n = 300
+    rng = np.random.default_rng(SEED0 + 77)
+    b, schema, meta = _random_case(rng, n)
+    b.cols = [c for c in b.cols if c.name not in ("num",)]  # 1E+3000 is not a Python float
+    schema = abi.Schema.of([[c.name, c.dtype, False] for c in b.cols])
+    ids, lsns = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32), rng.integers(0, 2**63, n, dtype=np.uint64)
+    meta = abi.row_meta(n, ids=ids, lsns=lsns, tx_ids=["tx<%d>" % i for i in range(n)])
+    msgs = oracle.queue_serialize(abi.queue_options(abi.QFMT_NATIVE, table_schema=schema, old_key_types=["int64", "utf8"]), b, schema, meta)
+    assert len(msgs) == n
+    for r, m in enumerate(msgs):
+        (it,) = json.loads(m.decode("utf-8"), object_pairs_hook=OrderedDict)
+        k = int(b.src_row[r])
+        assert list(it)[:9] == ["id", "nextlsn", "commitTime", "txPosition", "kind", "schema", "table", "part", "columnnames"]
+        assert list(it)[-3:] == ["oldkeys", "tx_id", "query"]
+        assert (it["id"], it["nextlsn"], it["tx_id"], it["kind"], it["part"]) == (int(ids[k]), int(lsns[k]), "tx<%d>" % k, ["insert", "update", "delete"][int(b.kind[r])], str(int(b.part_id[r])))
+        assert it["columnnames"] == [c.name for c in b.cols] and len(it["table_schema"]) == len(b.cols)
+        for c, v in zip(b.cols, it["columnvalues"]):
+            g, x = c.pyvalue(r)
+            if g == "nil":
+                assert v is None
+            elif g == "string":
+                assert v == x.decode("utf-8", "replace")
+            elif g == "bytes":
+                assert base64.b64decode(v) == x
+            elif g in ("json", "jsonnum"):
+                assert v == json.loads(x)
+            elif g == "time":
+                assert v.endswith("Z") and abi.parse_rfc3339(v) == (x[0], x[1])
+            elif g == "bool":
+                assert v is x
+            else:
+                assert v == x
+        if b.old_present[r]:
+            assert it["oldkeys"]["keynames"] == ["i64", "sk"] and it["oldkeys"]["keytypes"] == ["int64", "utf8"]
+            assert it["oldkeys"]["keyvalues"][0] == int(b.old_keys[0].values[r])
+        else:
+            assert it["oldkeys"] == {}
