@@ -1,0 +1,51 @@
+"""Static guard on the resources of the perf-critical kernels: hipcc cross-compiles to gfx950 ISA without a GPU, and the
+kernel descriptors in the assembly say how many VGPRs / how much scratch and LDS each kernel takes.  A change that makes
+the tile parser spill, or drops its occupancy below what DESIGN.md §8 records, fails here instead of showing up as a
+slower bench line three steps later."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def kernel_table(src):
+    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", "-", os.path.join(CSRC, src)],
+                         capture_output=True, text=True, timeout=600)
+    assert asm.returncode == 0, asm.stderr[-2000:]
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm.stdout, re.S):
+        body = m.group(2)
+        g = lambda k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))  # noqa: E731
+        out[m.group(1)] = {"vgpr": g("next_free_vgpr"), "scratch": g("private_segment_fixed_size"), "lds": g("group_segment_fixed_size")}
+    return out
+
+
+def find(table, fragment):
+    hits = [v for k, v in table.items() if fragment in k]
+    assert len(hits) == 1, (fragment, list(table))
+    return hits[0]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_tile_parser_resources():
+    t = kernel_table("tf_csv.hip")
+    k = find(t, "csv_parse_tiles")
+    # 512 threads, 6 waves per SIMD: at most 80 VGPRs, nothing in scratch, three workgroups of LDS per CU (160 KB)
+    assert k["scratch"] == 0 and k["vgpr"] <= 80 and k["lds"] * 3 <= 160 * 1024, k
+    assert find(t, "csv_count_newlines")["scratch"] == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_serializer_and_sr_resources():
+    t = kernel_table("tf_serialize.hip")
+    assert find(t, "ser_cell_write")["scratch"] <= 256 and find(t, "ser_cell_len")["scratch"] <= 128  # the float formatter's digit buffer
+    assert find(t, "ser_fill_const")["vgpr"] <= 16
+    t = kernel_table("tf_srjson.hip")
+    # the parse kernel keeps per-depth key spans for the `any` order check in scratch (2 x 128 words) and nothing more
+    assert find(t, "sr_parse_frames")["scratch"] <= 2048 and find(t, "sr_count_frames")["scratch"] == 0
