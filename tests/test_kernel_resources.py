@@ -49,3 +49,17 @@ def test_serializer_and_sr_resources():
     t = kernel_table("tf_srjson.hip")
     # the parse kernel keeps per-depth key spans for the `any` order check in scratch (2 x 128 words) and nothing more
     assert find(t, "sr_parse_frames")["scratch"] <= 2048 and find(t, "sr_count_frames")["scratch"] == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_json_kernels_stay_lean():
+    """The kernels every line / cell runs through do not carry the map emitter (any containers, `_rest`): lines and cells that
+    need it go through json_parse_listed and the second copy launch, which do."""
+    t = kernel_table("tf_json.hip")
+    lines, listed = find(t, "json_parse_lines"), find(t, "json_parse_listed")
+    assert lines["vgpr"] <= 168 and lines["scratch"] <= 320, lines
+    assert listed["vgpr"] > lines["vgpr"]
+    copies = {k: v for k, v in t.items() if "json_copy_cells" in k}
+    assert len(copies) == 2
+    lean = min(copies.values(), key=lambda v: v["vgpr"])
+    assert lean["vgpr"] <= 80 and lean["scratch"] == 0, lean

@@ -627,7 +627,10 @@ __device__ __forceinline__ void jtext(const JCol &c, int64_t r, uint64_t src, ui
 }
 
 // returns false when the value form is not decided on device (the line goes to the host)
-__device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, MemBytes &aux, const int vtype, const uint64_t vstart,
+// 1 stored, 0 the value form is the host's, 2 (HEAVY == false only) the cell needs the map emitter: the line is re-parsed
+// by json_parse_listed, whose kernel carries it — the kernel every line runs through stays lean.
+template <bool HEAVY>
+__device__ int store_cell(const JParams &p, const JCol &c, const int64_t r, MemBytes &aux, const int vtype, const uint64_t vstart,
                            const uint64_t vend, const JStr &sv, const uint32_t clen, const bool kbad) {
   uint8_t st = JC_OK;
   const Field tok{&aux, vstart, (uint32_t)(vend - vstart)};  // raw token of numbers / literals / containers
@@ -716,10 +719,13 @@ __device__ bool store_cell(const JParams &p, const JCol &c, const int64_t r, Mem
         if (i < sv.n && (str[i] == '{' || str[i] == 'n')) return false;  // an object, or `null` (Unmarshal succeeds with a nil map)
         jtext(c, r, sv.s, sv.n, JM_QUOTED, sv.n + 2);
       } else {  // map / slice: re-marshalled with sorted keys when every token is one the device decides
-        if (!fj_any_ok(p, aux, vstart, vend)) return false;
-        CountSink cs;
-        fj_emit_any(cs, p, aux, vstart, vend);
-        jtext(c, r, vstart, tok.n, JM_ANYCANON, cs.n);
+        if constexpr (!HEAVY) return 2;
+        else {
+          if (!fj_any_ok(p, aux, vstart, vend)) return false;
+          CountSink cs;
+          fj_emit_any(cs, p, aux, vstart, vend);
+          jtext(c, r, vstart, tok.n, JM_ANYCANON, cs.n);
+        }
       }
       break;
     default:  // JK_DATETIME: extractTimeValue :818-886
@@ -816,14 +822,17 @@ template <class S> __device__ bool rest_emit(S &o, const JParams &p, MemBytes &r
 // one line: fastjson Parser.Parse with an explicit container stack; the members of a top-level
 // object are handed to store_cell as they complete
 // ---------------------------------------------------------------------------
-__device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_t ls, const uint64_t le) {
+// HEAVY == false: the kernel every line runs through; returns true when the line needs the map emitter (an `any` container,
+// a non-empty `_rest`) and must be re-parsed by the HEAVY form — nothing final has been written for it then.
+template <bool HEAVY>
+__device__ bool parse_json_line(const JParams &p, const int64_t r, const uint64_t ls, const uint64_t le) {
   MemBytes rd(p.data), aux(p.data);
   uint64_t pos = ls;
   const uint64_t end = le;
 #define JSKIPWS() while (pos < end) { const uint32_t w_ = rd.at(pos); if (w_ == ' ' || w_ == '\n' || w_ == '\t' || w_ == '\r') pos++; else break; }
   uint64_t stack = 0;  // bit 0 = innermost container is an object
   int ncont = 0;
-  bool root_obj = false, fallback = false, syntax = false, key_next = false;
+  bool root_obj = false, fallback = false, syntax = false, key_next = false, heavy = false;
   uint32_t root_kids = 0;
   int32_t kcol = JS_UNKNOWN;
   uint32_t nunknown = 0;
@@ -925,9 +934,12 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
       }
       if (ncont == 1) {
         root_kids++;
-        if (root_obj && !fallback) {
-          for (int32_t ci = kcol; ci >= 0; ci = p.cols[ci].next)
-            if (!store_cell(p, p.cols[ci], r, aux, vtype, vstart, pos, sval, clen, kbad)) { fallback = true; break; }
+        if (root_obj && !fallback && !heavy) {
+          for (int32_t ci = kcol; ci >= 0; ci = p.cols[ci].next) {
+            const int rc = store_cell<HEAVY>(p, p.cols[ci], r, aux, vtype, vstart, pos, sval, clen, kbad);
+            if (rc == 0) { fallback = true; break; }
+            if (rc == 2) { heavy = true; break; }
+          }
         }
       }
       JSKIPWS();
@@ -948,10 +960,12 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
 #undef JSKIPWS
   uint8_t st = JL_ROW;
   if (syntax) st = JL_SYNTAX;              // Unmarshal error → NewUnparsed (:545-550); decided before any fallback,
+  else if (heavy) return true;             //   and before the map emitter is asked for
   else if (fallback) st = JL_FALLBACK;     //   except that a line abandoned for depth is never known to be malformed
   else if (!root_obj || root_kids == 0) st = JL_SKIPPED;  // len(item) == 0 (:536)
   if (st == JL_ROW && p.rest_lens) {
     if (nunknown == 0) { p.rest_fstart[r] = (uint32_t)ls; p.rest_meta[r] = (JM_REST_EMPTY << 28); p.rest_lens[r] = 2; }
+    else if constexpr (!HEAVY) return true;
     else {
       CountSink cs;
       if (!rest_emit(cs, p, aux, ls, le)) st = JL_FALLBACK;
@@ -960,6 +974,7 @@ __device__ void parse_json_line(const JParams &p, const int64_t r, const uint64_
   }
   p.linest[r] = st;
   p.line_pos[r] = (uint32_t)ls;
+  return false;
 }
 
 // GenericParser.Unmarshal, Format "tskv" (generic_parser.go:732-746): strings.Split(line, "\t"), SplitN(field, "=", 2); a field
@@ -1006,7 +1021,7 @@ __device__ void parse_tskv_line(const JParams &p, const int64_t r, const uint64_
         sv.bs = p.tskv_unescape && bs;  // raw bytes ARE the value unless tryToUnescapeTSKV runs
         sv.ctrl = ctrl; sv.plain = !bs && !ctrl && !hi && !quote;
         for (int32_t ci = kcol; ci >= 0; ci = p.cols[ci].next)
-          if (!store_cell(p, p.cols[ci], r, aux, V_STR, eq + 1, fe, sv, 0, false)) { fallback = true; break; }
+          if (store_cell<false>(p, p.cols[ci], r, aux, V_STR, eq + 1, fe, sv, 0, false) != 1) { fallback = true; break; }  // strings never need the map emitter
       }
     }
     if (fe >= le) break;
@@ -1017,14 +1032,14 @@ __device__ void parse_tskv_line(const JParams &p, const int64_t r, const uint64_
   p.line_pos[r] = (uint32_t)ls;
 }
 
-__global__ void __launch_bounds__(256) json_parse_lines(JParams p) {
+__global__ void __launch_bounds__(256) json_parse_lines(JParams p, uint32_t *slow_n, uint32_t *slow_seg) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.nseg) return;
   const uint32_t n = p.seg_len[i];
   if (!n) return;
   const uint64_t s = p.seg_start[i];
   if (p.format == TFGPU_JFMT_TSKV) parse_tskv_line(p, (int64_t)p.seg_ord[i], s, s + n);
-  else parse_json_line(p, (int64_t)p.seg_ord[i], s, s + n);
+  else if (parse_json_line<false>(p, (int64_t)p.seg_ord[i], s, s + n)) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)i; }  // → json_parse_listed
 }
 // the lines the wave path hands over (nested values, anything it does not fully understand): one lane per line
 __global__ void __launch_bounds__(256) json_parse_listed(JParams p, const uint32_t *slow_n, const uint32_t *slow_seg) {
@@ -1032,7 +1047,7 @@ __global__ void __launch_bounds__(256) json_parse_listed(JParams p, const uint32
   if (k >= *slow_n) return;
   const uint32_t i = slow_seg[k];
   const uint64_t s = p.seg_start[i];
-  parse_json_line(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i]);
+  parse_json_line<true>(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1247,7 +1262,7 @@ __global__ void __launch_bounds__(256) json_parse_waves(JParams p, uint32_t *slo
         sv.bs = jf_any(L.bs, vs[rd] + 1, ve[rd] - 1); sv.ctrl = jf_any(L.ctl, vs[rd] + 1, ve[rd] - 1); sv.plain = !jf_any(L.npl, vs[rd] + 1, ve[rd] - 1);
       }
       for (int32_t ci = kcol[rd]; ci >= 0; ci = p.cols[ci].next)
-        if (!store_cell(p, p.cols[ci], r, aux, vt[rd], a0, a1, sv, 0, false)) { fb = true; break; }
+        if (store_cell<false>(p, p.cols[ci], r, aux, vt[rd], a0, a1, sv, 0, false) != 1) { fb = true; break; }  // scalars only on this path
     }
     fb = __any(fb);
     if (lane == 0) {
@@ -1367,6 +1382,8 @@ __global__ void json_const_text(const uint8_t *text, uint32_t n, int64_t nrows, 
 // text payloads: lane = (column, line) cell
 // ---------------------------------------------------------------------------
 struct JCopyCol { const uint32_t *offsets, *fstart, *meta; uint8_t *out; };
+// HEAVY == false: every cell but those the map emitter writes; HEAVY == true: only those (a second launch over the same grid)
+template <bool HEAVY>
 __global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCol *cols, int64_t nlines) {
   const uint8_t *data = jp.data; const double *pow10 = jp.pow10; const uint64_t *pow128 = jp.pow128;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1378,11 +1395,16 @@ __global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCo
   const uint64_t s = c.fstart[r];
   uint8_t *dst = c.out + o0;
   MemBytes rd(data);
+  if ((mode == JM_ANYCANON || mode == JM_REST) != HEAVY) return;
+  if constexpr (HEAVY) {
+    StoreSink sk{dst};
+    if (mode == JM_ANYCANON) fj_emit_any(sk, jp, rd, s, s + srclen); else rest_emit(sk, jp, rd, s, s + srclen);
+    sk.finish();
+    return;
+  }
   if (mode == JM_UNESCAPE) { StoreSink sk{dst}; unescape_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_TSKV) { StoreSink sk{dst}; tskv_walk(rd, s, srclen, sk); sk.finish(); return; }
-  if (mode == JM_ANYCANON) { StoreSink sk{dst}; fj_emit_any(sk, jp, rd, s, s + srclen); sk.finish(); return; }
-  if (mode == JM_REST) { StoreSink sk{dst}; rest_emit(sk, jp, rd, s, s + srclen); sk.finish(); return; }
   if (mode == JM_REST_EMPTY) { dst[0] = '{'; dst[1] = '}'; return; }
   if (mode == JM_FLOAT) {  // the number token again, as encoding/json prints the float64 it parses to
     const Field tok{&rd, s, srclen};
@@ -1718,7 +1740,12 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   // (13.6 vs 6.7 ms, profiles/r01y_json_paths.txt).  Kept as the parity cross-check of the grammar and as the
   // starting point for a kind-sorted member phase.
   static const bool wavepath = [] { const char *e = std::getenv("TFGPU_JSON_WAVEPATH"); return e && e[0] == '1'; }();
-  if (nlines && (!wavepath || tskv)) { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp); }
+  if (nlines && (!wavepath || tskv)) {
+    Buf slow = dalloc((size_t)(nseg + 1) * 4);  // lines that need the map emitter: re-parsed by the kernel that carries it
+    TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
+    { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+    if (!tskv) { KernelTimer t("json_parse_listed"); json_parse_listed<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+  }
   else if (nlines) {
     Buf slow = dalloc((size_t)(nseg + 1) * 4);
     TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
@@ -1786,7 +1813,8 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   if (nlines && nstr) {
     Buf bcc = upload_small(cc.data(), cc.size() * sizeof(JCopyCol));
     KernelTimer t("json_copy_cells");
-    json_copy_cells<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines);
+    json_copy_cells<false><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines);
+    json_copy_cells<true><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines);
   }
 
   // ---- dropped lines: `_unparsed` rows / host fallback are reported, skipped lines vanish ----
