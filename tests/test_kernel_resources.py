@@ -49,6 +49,12 @@ def test_serializer_and_sr_resources():
     t = kernel_table("tf_srjson.hip")
     # the parse kernel keeps per-depth key spans for the `any` order check in scratch (2 x 128 words) and nothing more
     assert find(t, "sr_parse_frames")["scratch"] <= 2048 and find(t, "sr_count_frames")["scratch"] == 0
+    # the cell kernels every cell runs through do not carry the sorting emitter's frame stack (its cells have their own launch)
+    for name in ("sr_cell_values", "sr_cell_text"):
+        both = [v for k, v in t.items() if name in k]
+        assert len(both) == 2
+        lean = min(both, key=lambda v: v["scratch"])
+        assert lean["scratch"] == 0 and lean["vgpr"] <= 96, (name, lean)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")

@@ -599,18 +599,28 @@ struct OutCol {
   uint8_t *valid8;     // one byte per row → packed by sr_pack_validity
   uint8_t *validity;   // bitmap
 };
+// CANON == false: every cell but the `any` values that need the sorting emitter; CANON == true: only those (a second launch
+// when the schema has `any` properties) — the kernel every cell runs through does not carry the emitter's frame stack.
+template <bool CANON>
 __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id) {
   const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= (int64_t)p.nprops * p.nrows) return;
   const int j = (int)(it / p.nrows); const int64_t r = it - (int64_t)j * p.nrows;
   const uint32_t f = p.row_frame[r];
-  if (j == 0) { src_row[r] = (int32_t)f; part_id[r] = (uint32_t)p.frames[f].msg; }
   const OutCol &c = cols[j];
   const int64_t i = (int64_t)j * p.nframes + f;
   const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
+  MemBytes rd(p.data);
+  if constexpr (CANON) {
+    if (!(vtr & VT_CANON)) return;
+    CountSink s;
+    emit_any_canon(s, rd, vs, vl);
+    c.lens[r] = s.n;
+    return;
+  }
+  if (j == 0) { src_row[r] = (int32_t)f; part_id[r] = (uint32_t)p.frames[f].msg; }
   const bool nil = vt == VT_ABSENT || vt == VT_NULL;
   c.valid8[r] = nil ? 0 : 1;
-  MemBytes rd(p.data);
   switch (c.json_type) {
     case TFGPU_SRT_BOOLEAN: ((uint8_t *)c.values)[r] = vt == VT_TRUE ? 1 : 0; break;
     case TFGPU_SRT_INTEGER: { int64_t x = 0; if (!nil) number_int64(rd, vs, vl, &x); ((int64_t *)c.values)[r] = x; break; }
@@ -620,9 +630,10 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
       else if (vtr & VT_PLAIN) c.lens[r] = vl - 2;  // nothing to decode
       else { CountSink s; emit_unquoted(s, rd, vs, vl); c.lens[r] = s.n; }
       break;
-    default: { CountSink s; if (!nil) { if (vtr & VT_CANON) emit_any_canon(s, rd, vs, vl); else emit_any(s, rd, vs, vl); } c.lens[r] = s.n; }
+    default: if (!(vtr & VT_CANON)) { CountSink s; if (!nil) emit_any(s, rd, vs, vl); c.lens[r] = s.n; }  // flagged cells: the CANON launch
   }
 }
+template <bool CANON>
 __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
   const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= (int64_t)ntext * p.nrows) return;
@@ -633,8 +644,10 @@ __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols
   const int64_t i = (int64_t)j * p.nframes + f;
   const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
   if (vt == VT_ABSENT || vt == VT_NULL) return;
+  if (((vtr & VT_CANON) != 0) != CANON) return;
   MemBytes rd(p.data);
   ByteSink s{c.data + c.lens[r]};
+  if constexpr (CANON) { emit_any_canon(s, rd, vs, vl); s.flush(); return; }
   auto copy_raw = [&](uint32_t a, uint32_t n) {  // eight bytes per step
     uint32_t k = 0;
     for (; k + 8 <= n; k += 8) s.put_word(rd.word(a + k), 8);
@@ -643,7 +656,6 @@ __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols
   if (c.json_type == TFGPU_SRT_NUMBER) copy_raw(vs, vl);
   else if (c.json_type == TFGPU_SRT_STRING && (vtr & VT_PLAIN)) copy_raw(vs + 1, vl - 2);
   else if (c.json_type == TFGPU_SRT_STRING) emit_unquoted(s, rd, vs, vl);
-  else if (vtr & VT_CANON) emit_any_canon(s, rd, vs, vl);
   else emit_any(s, rd, vs, vl);
   s.flush();
 }
@@ -782,7 +794,8 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
   std::vector<int32_t> text_cols;
   const int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
   int ntext = 0;
-  for (int j = 0; j < np; j++) if (o->props[j].json_type >= TFGPU_SRT_NUMBER) ntext++;
+  bool has_any = false;
+  for (int j = 0; j < np; j++) { if (o->props[j].json_type >= TFGPU_SRT_NUMBER) ntext++; if (o->props[j].json_type == TFGPU_SRT_ANY) has_any = true; }
   Buf lens_all = dalloc_zero((size_t)std::max(ntext, 1) * (size_t)seg_stride * 4 + 16);
   Buf valid8 = dalloc((size_t)std::max(np, 1) * (size_t)nra);
   int ti = 0;
@@ -815,7 +828,11 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
   Buf boc = upload_small(oc.data(), std::max<size_t>(oc.size(), 1) * sizeof(sr::OutCol));
   if (nrows) {
     sr::sr_row_frames<<<sr::nblk(nf, 256), 256, 0, st>>>(p);
-    if (np) { KernelTimer t("sr_cell_values"); sr::sr_cell_values<<<sr::nblk((int64_t)np * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id)); }
+    if (np) {
+      KernelTimer t("sr_cell_values");
+      sr::sr_cell_values<false><<<sr::nblk((int64_t)np * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
+      if (has_any) sr::sr_cell_values<true><<<sr::nblk((int64_t)np * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
+    }
     if (np) sr::sr_pack_validity<<<sr::nblk((int64_t)np * ((nrows + 7) / 8), 256), 256, 0, st>>>(ptr<sr::OutCol>(boc), np, nrows);
   }
   if (np == 0 && nrows) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR json: a schema without properties");
@@ -832,7 +849,11 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     }
     boc = upload_small(oc.data(), oc.size() * sizeof(sr::OutCol));
     Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
-    if (nrows) { KernelTimer t("sr_cell_text"); sr::sr_cell_text<<<sr::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext); }
+    if (nrows) {
+      KernelTimer t("sr_cell_text");
+      sr::sr_cell_text<false><<<sr::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
+      if (has_any) sr::sr_cell_text<true><<<sr::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
+    }
   }
   // ---- frames the reference turns into `_unparsed` items / rows for the stock path ----
   int64_t ne = 0;
