@@ -52,3 +52,33 @@ def test_kafka_hash_partition_known_answers():
     assert queue.kafka_hash_partition(b"blah", 3) == 1
     assert queue.kafka_hash_partition(b"boop", 3) == 2
     assert queue.kafka_hash_partition(b"20", 16) == 1   # "hash code with MSB set": int32 conversion before the remainder
+
+
+# ---------------------------------------------------------------- MirrorSerializer (mirror_serializer_test.go:16-70) ----
+RAW = abi.Schema.of([["topic", "utf8"], ["partition", "uint32"], ["seq_no", "uint64"], ["write_time", "datetime"], ["data", "utf8"], ["meta", "any"],
+                     ["sequence_key", "string"]])
+
+
+def _raw_message(key, data, offset=0):
+    """abstract.MakeRawMessage (changeitem/mirror.go:36-67): the column values of one mirror item."""
+    return [["string", ""], ["int", 0], ["uint64", offset], ["time", "2024-01-01T00:00:00Z"], ["string", data], ["nil", None],
+            ["nil", None] if key is None else ["bytes", key]]
+
+
+def test_mirror_serializer_known_answers():
+    import pytest
+    names = list(queue.RAW_DATA_COLUMNS)
+    one = abi.batch_from_rows(RAW, names, [_raw_message("stub", "aboba123")])
+    assert queue.is_mirror(one) and queue.mirror_messages(one) == [(b"stub", b"aboba123")]  # TestMirrorSerializerTopicName
+    two = abi.batch_from_rows(RAW, names, [_raw_message("sequence_key_1", "aboba1"), _raw_message("sequence_key_2", "aboba2", 1), _raw_message(None, "", 2)])
+    assert queue.mirror_messages(two) == [(b"sequence_key_1", b"aboba1"), (b"sequence_key_2", b"aboba2"), (None, b"")]  # ...GroupsByTopic: one group
+    assert queue.mirror_messages(abi.batch_from_rows(RAW, names, [])) == []  # TestMirrorSerializerEmptyInput
+    # not a mirror item: other names, or the same names in another order (IsMirror compares position by position)
+    with pytest.raises(ValueError):
+        queue.mirror_messages(_batch([[["int64", 1], ["string", "kek"], ["nil", None]]]))
+    swapped = names[:4] + ["meta", "data", "sequence_key"]
+    assert not queue.is_mirror(abi.batch_from_rows(RAW, swapped, [[c for c in _raw_message("k", "v")][:4] + [["nil", None], ["string", "v"], ["bytes", "k"]]]))
+    # GetRawMessageData's default branch: a nil `data`
+    bad = _raw_message("k", "v"); bad[4] = ["nil", None]
+    with pytest.raises(ValueError):
+        queue.mirror_messages(abi.batch_from_rows(RAW, names, [_raw_message("k", "v"), bad]))

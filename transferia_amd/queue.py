@@ -6,6 +6,7 @@ the parts that are metadata, the way the shim would do them in Go:
     Serializer.Serialize's message keys          native_serializer.go:24, json_serializer.go:37, *_batcher.go (Key: nil)
     splitByTablePartID                           split.go:5-12 (rows grouped by ChangeItem.PartID, one group per call)
     RawColumnSerializer                          raw_column_serializer.go:21-73 (a message per row: one column's bytes)
+    MirrorSerializer                             mirror_serializer.go:15-52 (a message per row: `data` → value, `sequence_key` → key)
 
 RawColumnSerializer needs no kernel: its message values ARE the (offsets, data) buffers of the named column, as
 tfgpu_dbatch_view / download expose them.
@@ -62,6 +63,32 @@ def raw_column_messages(batch: abi.Batch, column_name: str, schema: Optional[abi
     if col.repr not in (abi.R_STRING, abi.R_BYTES):
         return []  # "unexpected column value type"
     return [col.get_bytes(i) for i in range(batch.nrows) if col.is_valid(i)]
+
+
+RAW_DATA_COLUMNS = ("topic", "partition", "seq_no", "write_time", "data", "meta", "sequence_key")  # changeitem/mirror.go:23-32
+
+
+def is_mirror(batch: abi.Batch) -> bool:
+    """ChangeItem.IsMirror (change_item.go:385-395): ColumnNames are exactly RawDataColumns, in order."""
+    return tuple(c.name for c in batch.cols) == RAW_DATA_COLUMNS
+
+
+def mirror_messages(batch: abi.Batch) -> List[Tuple[Optional[bytes], bytes]]:
+    """MirrorSerializer.Serialize for one table / PartID: (key, value) per row = (`sequence_key`, `data`) — two column
+    views, no kernel.  Raises ValueError where the reference returns its fatal errors: rows that are not mirror items
+    (mirror_serializer.go:16-18), a `data` value that is neither text nor bytes (mirror.go:78-87; nil included).
+    A nil `sequence_key` is a nil []byte there: the message has no key."""
+    if not is_mirror(batch):
+        raise ValueError("MirrorSerializer should be used only with 'Mirror' changeItems")
+    data, key = batch.cols[RAW_DATA_COLUMNS.index("data")], batch.cols[RAW_DATA_COLUMNS.index("sequence_key")]
+    if data.repr not in (abi.R_STRING, abi.R_BYTES) or key.repr not in (abi.R_STRING, abi.R_BYTES):
+        raise ValueError("unable to get message: unexpected data type, expected string or []byte")
+    out = []
+    for i in range(batch.nrows):
+        if not data.is_valid(i):
+            raise ValueError("unable to get message: unexpected data type: <nil>, expected string or []byte")
+        out.append((key.get_bytes(i) if key.is_valid(i) else None, data.get_bytes(i)))
+    return out
 
 
 def kafka_hash_partition(key: Optional[bytes], npartitions: int) -> Optional[int]:
