@@ -306,6 +306,17 @@ typedef struct tfgpu_csv_options {
   int32_t n_timestamp_parsers; const char *const *timestamp_parsers; /* Go layouts */
   const char *decimal_point; /* "" or NULL = '.'                             */
   int64_t skip_rows;         /* lines dropped before parsing starts          */
+  /* constructCI's system columns (reader_csv.go:275-290; names and types from
+   * s3_reader.AppendSystemColsTableSchema, pkg/providers/s3/reader/util.go:210-215):
+   * a schema column named "__file_name" (utf8) / "__row_index" (uint64) reads no CSV field. */
+  const char *file_name;     /* value of __file_name; NULL = ""                            */
+  uint64_t row_number_base;  /* rowsCounter of the first parsed line (reader_csv.go:98: 1); every
+                              * line read advances it, failed or not (:217-220)            */
+  uint8_t hide_system_cols;  /* config.hideSystemCols: both system columns are nil         */
+  /* csv.Reader.Encoding (reader.go:157-183): NULL = UTF-8 input.  Otherwise the 256 code points
+   * the x/text charmap decoder of that name yields for bytes 0..255 (the shim reads them off
+   * enc.NewDecoder() once); every line is decoded after it was cut at the raw '\n' byte.    */
+  const uint32_t *encoding_table;
 } tfgpu_csv_options;
 void tfgpu_csv_options_default(tfgpu_csv_options *o);
 

@@ -171,6 +171,9 @@ void ora_csv_table_free(ora_csv_table *t);
 ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema, const char *ns,
                          const char *table, const void *bytes, uint64_t len, uint64_t *consumed);
 
+/* getCorrespondingValue alone (reader_csv.go:345-452), for the reference's TestParse*Value tables */
+ora_batch *ora_csv_corresponding_value(const tfgpu_csv_options *o, const char *s, uint64_t n, int dtype);
+
 /* ---- a17: generic JSON parser (pkg/parsers/generic/generic_parser.go) — ora_jsonparse.c ---- */
 typedef struct ora_json_lines ora_json_lines; /* per non-empty line: status / code / column / msg / idx / row */
 ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *fields, const void *bytes, uint64_t len,

@@ -127,6 +127,21 @@ static int complete_quotes(const tfgpu_csv_options *o, const char *s, size_t n) 
 
 /* One ReadLine (reader.go:89-108).  Returns: 0 = got line (fields or nil),
  * 1 = EOF, >1 = tfgpu_rowerr for this line.  *pos advances. */
+/* readAndDecodeLine :157-183: the line is cut at the raw '\n' byte, then decoded by the charmap decoder
+ * (golang.org/x/text/encoding/charmap: one table entry per byte, U+FFFD for an undefined one).  Returns a
+ * malloc'd UTF-8 copy (or NULL when no Encoding is set: the bytes are used as they are). */
+static char *decode_line(const tfgpu_csv_options *o, const char *line, size_t ln, size_t *oln) {
+  if (!o->encoding_table) return NULL;
+  char *d = (char *)malloc(ln * 3 + 1); size_t w = 0;
+  for (size_t i = 0; i < ln; i++) {
+    uint32_t r = o->encoding_table[(unsigned char)line[i]];
+    if (r < 0x80) d[w++] = (char)r;
+    else if (r < 0x800) { d[w++] = (char)(0xC0 | (r >> 6)); d[w++] = (char)(0x80 | (r & 0x3F)); }
+    else { if (r > 0xFFFF) r = 0xFFFD; d[w++] = (char)(0xE0 | (r >> 12)); d[w++] = (char)(0x80 | ((r >> 6) & 0x3F)); d[w++] = (char)(0x80 | (r & 0x3F)); }
+  }
+  *oln = w; return d;
+}
+
 static int read_line(const tfgpu_csv_options *o, const char *buf, uint64_t len, uint64_t *pos, fields *out, int *is_nil) {
   *is_nil = 0;
   if (o->newlines_in_value && o->quote_char != 0) { /* readMultiline :110-137 */
@@ -137,8 +152,11 @@ static int read_line(const tfgpu_csv_options *o, const char *buf, uint64_t len, 
       if (!nl) { free(full); return 1; } /* incomplete last line dropped */
       size_t ln = (size_t)(nl - (buf + *pos)) + 1;
       const char *part = buf + *pos; *pos += ln;
-      if (ln <= 1) continue; /* "\n": skip empty line ("\r" alone cannot occur: lines end in \n) */
+      size_t dl = 0; char *dec = decode_line(o, part, ln, &dl);
+      if (dec) { part = dec; ln = dl; }
+      if (ln <= 1) { free(dec); continue; } /* "\n": skip empty line ("\r" alone cannot occur: lines end in \n) */
       full = (char *)realloc(full, fl + ln + 1); memcpy(full + fl, part, ln); fl += ln;
+      free(dec);
       if (complete_quotes(o, full, fl)) break;
     }
     int rc = split_string(o, full, fl, out);
@@ -150,9 +168,14 @@ static int read_line(const tfgpu_csv_options *o, const char *buf, uint64_t len, 
   if (!nl) return 1;
   size_t ln = (size_t)(nl - (buf + *pos)) + 1;
   const char *line = buf + *pos; *pos += ln;
-  if (o->quote_char == 0 && memchr(line, '"', ln)) return TFGPU_ROW_QUOTING_DISABLED; /* :182-184 */
-  if (ln <= 1) { *is_nil = 1; return 0; } /* readSingleLine :146-150 */
-  return split_string(o, line, ln, out);
+  size_t dl = 0; char *dec = decode_line(o, line, ln, &dl);
+  if (dec) { line = dec; ln = dl; }
+  int rc;
+  if (o->quote_char == 0 && memchr(line, '"', ln)) rc = TFGPU_ROW_QUOTING_DISABLED; /* :182-184 */
+  else if (ln <= 1) { *is_nil = 1; rc = 0; } /* readSingleLine :146-150 */
+  else rc = split_string(o, line, ln, out);
+  free(dec);
+  return rc;
 }
 
 static void fields_free(fields *f) { for (int i = 0; i < f->n; i++) free(f->f[i]); free(f->f); free(f->l); memset(f, 0, sizeof *f); }
@@ -402,6 +425,25 @@ static int strictify_value(ora_value *v, int dtype) {
   return TFGPU_ROW_CAST;
 }
 
+/* s3_reader.SystemColumnNames (pkg/providers/s3/reader/util.go:24-32): 1 = __file_name, 2 = __row_index */
+static int system_col(const char *name) {
+  if (!name) return 0;
+  if (strcmp(name, "__file_name") == 0) return 1;
+  if (strcmp(name, "__row_index") == 0) return 2;
+  return 0;
+}
+
+/* Test hook: getCorrespondingValue alone (before Strictify), as TestParse{Float,Null,Date,Boolean}Value call it
+ * (reader_csv_test.go:281-430).  Returns a one-item batch holding the value. */
+ora_batch *ora_csv_corresponding_value(const tfgpu_csv_options *o, const char *s, uint64_t n, int dtype) {
+  ora_batch *b = ora_batch_new();
+  ora_item *it = ora_batch_push(b);
+  it->kind = TFGPU_K_INSERT; it->ns = dups(""); it->table = dups(""); it->part_id = dups("");
+  it->nvalues = 1; it->values = (ora_value *)calloc(1, sizeof(ora_value));
+  it->values[0] = corresponding_value(o, s, (size_t)n, dtype);
+  return b;
+}
+
 ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema, const char *ns, const char *table,
                          const void *bytes, uint64_t len, uint64_t *consumed) {
   ora_batch *b = ora_batch_new();
@@ -410,7 +452,7 @@ ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema,
   nm->refs = 1; nm->n = schema->ncols; nm->names = (char **)calloc((size_t)(schema->ncols ? schema->ncols : 1), sizeof(char *));
   for (int i = 0; i < schema->ncols; i++) nm->names[i] = dups(schema->cols[i].name);
   int *index = (int *)calloc((size_t)(schema->ncols ? schema->ncols : 1), sizeof(int));
-  for (int i = 0; i < schema->ncols; i++) index[i] = atoi(schema->cols[i].path ? schema->cols[i].path : "0");
+  for (int i = 0; i < schema->ncols; i++) index[i] = system_col(schema->cols[i].name) ? 0 : atoi(schema->cols[i].path ? schema->cols[i].path : "0");
   const char *buf = (const char *)bytes; uint64_t pos = 0;
   int64_t row = 0;
   for (int64_t k = 0; k < o->skip_rows; k++) { /* skipRows: lines consumed with ReadLine */
@@ -426,6 +468,13 @@ ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema,
     int err = 0;
     for (int i = 0; i < schema->ncols && !err; i++) {
       int dt = schema->cols[i].dtype;
+      int sys = system_col(schema->cols[i].name);
+      if (sys) { /* :275-290 */
+        if (o->hide_system_cols) continue; /* nil */
+        if (sys == 1) vals[i] = str_value(o->file_name ? o->file_name : "", o->file_name ? strlen(o->file_name) : 0);
+        else { vals[i].kind = OV_U64; vals[i].v.u = o->row_number_base + (uint64_t)row; }
+        continue;
+      }
       if (index[i] < 0) vals[i] = default_value(dt);
       else if (index[i] >= f.n) { if (o->include_missing_columns) vals[i] = default_value(dt); else err = TFGPU_ROW_MISSING_CELL; }
       else vals[i] = corresponding_value(o, f.f[index[i]], f.l[index[i]], dt);

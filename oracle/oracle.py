@@ -285,6 +285,30 @@ def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data: bytes, ns="", tab
     return r
 
 
+def csv_corresponding_value(opts: abi.CCsvOptions, s: bytes, dtype: str):
+    """CSVReader.getCorrespondingValue(originalValue, col) alone → [gokind, value] (before Strictify)."""
+    L = lib()
+    L.ora_csv_corresponding_value.restype = C.c_void_p
+    L.ora_csv_corresponding_value.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int]
+    bptr = L.ora_csv_corresponding_value(C.addressof(opts), s, len(s), abi.DTYPE_ID[dtype])
+    v = _row_values(L, bptr, 0, 1)[0]
+    L.ora_batch_free(bptr)
+    return v
+
+
+def csv_parse_rows(opts: abi.CCsvOptions, schema: abi.Schema, data: bytes):
+    """parseCSVRows → (rows as [[gokind, value], ...] per parsed line, errors [(row, code)], consumed)."""
+    L = lib()
+    cs = schema.to_c()
+    consumed = C.c_uint64(0)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = L.ora_csv_parse(C.byref(opts), C.byref(cs), b"", b"", buf.ctypes.data if len(buf) else None, len(buf), C.byref(consumed))
+    errs = _errors_of(L, out)
+    rows = [_row_values(L, out, r, len(schema.cols)) for r in range(L.ora_batch_len(out))]
+    L.ora_batch_free(out)
+    return rows, errs, int(consumed.value)
+
+
 class _CsvTable(C.Structure):
     _fields_ = [("nlines", C.c_int64), ("nfields", C.POINTER(C.c_int32)), ("line_err", C.POINTER(C.c_int32)), ("ntotal", C.c_int64),
                 ("fields", C.POINTER(C.c_void_p)), ("lens", C.POINTER(C.c_size_t)), ("consumed", C.c_uint64)]

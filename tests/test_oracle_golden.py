@@ -131,3 +131,66 @@ def test_csv_reader_cases(oracle):
         if "expect_field" in case:
             li, fi, val = case["expect_field"]
             assert lines[li][fi].decode("utf-8") == val
+
+
+def _typed_value(v):
+    """oracle [gokind, value] → the golden's [gotype, value] form."""
+    k, x = v
+    if k in ("string", "bytes", "jsonnum", "json"):
+        return [k, x.decode("utf-8")]
+    if k == "time":
+        import datetime
+        return ["time", (datetime.datetime(1970, 1, 1) + datetime.timedelta(seconds=x[0])).strftime("%Y-%m-%dT%H:%M:%SZ")]
+    return [k, x]
+
+
+def _csv_line(row):
+    """One CSV line that csv.Reader splits back into `row`.  A line without a delimiter loses its first byte
+    (lastElement := line[lastDelimPosition+1:] with lastDelimPosition == 0, pkg/csv/reader.go:263), so a one-field
+    row gets a sacrificial space in front."""
+    return ((" " if len(row) == 1 else "") + ",".join(row) + "\n").encode("utf-8")
+
+
+def test_csv_construct_ci_table(oracle):
+    """TestConstructCI (reader_csv_test.go:168-275) through the oracle's constructCI + Strictify."""
+    g = golden("csv_typed.json")
+    for case in g["construct_ci"]:
+        opts = abi.csv_options(**case["opts"])
+        schema = abi.Schema.of(case["schema"])
+        rows, errs, _ = oracle.csv_parse_rows(opts, schema, _csv_line(case["row"]))
+        if "expect_error" in case:
+            assert not rows and [abi.ROWERR[e[1]] for e in errs] == [case["expect_error"]], case["name"]
+            continue
+        assert not errs, case["name"]
+        assert [_typed_value(v) for v in rows[0]] == case["expect"], case["name"]
+
+
+def test_csv_corresponding_value_tables(oracle):
+    """TestParseFloatValue / TestParseNullValues / TestParseDateValue / TestParseBooleanValue (reader_csv_test.go:273-431)."""
+    g = golden("csv_typed.json")
+    for case in g["corresponding_value"]:
+        opts = abi.csv_options(**case["opts"])
+        got = _typed_value(oracle.csv_corresponding_value(opts, case["in"].encode("utf-8"), case["dtype"]))
+        assert got == case["expect"], (case["fn"], case["line"])
+
+
+def test_csv_s3_canon_rows(oracle):
+    """tests/canon/s3/csv: Go type + value of every cell the sink saw.  The input object is not in the repository, so the
+    lines are rebuilt from the canon's own leading cells; what the canon pins is the typed OUTPUT: strictified values,
+    DefaultValue fill of the missing columns, the system columns."""
+    g = golden("csv_typed.json")
+    for case in g["s3_canon"]:
+        schema = abi.Schema.of(case["schema"])
+        user = [(i, c) for i, c in enumerate(case["schema"]) if not c[0].startswith("__")]
+        width = 1 + max([int(c[3]) for _, c in user if int(c[3]) < 20], default=0)
+        text = b""
+        for row in case["expect_rows"]:
+            cells = ["0"] * width
+            for i, c in user:
+                if int(c[3]) < width:
+                    v = row[i][1]
+                    cells[int(c[3])] = ("true" if v else "false") if isinstance(v, bool) else str(v)
+            text += _csv_line(cells)
+        rows, errs, consumed = oracle.csv_parse_rows(abi.csv_options(**case["opts"]), schema, text)
+        assert not errs and consumed == len(text)
+        assert [[_typed_value(v) for v in r] for r in rows] == case["expect_rows"], case["name"]

@@ -365,6 +365,104 @@ def csv_reader():
     write("csv_reader.json", {"source": "pkg/csv/reader_test.go:13-240", "cases": cases})
 
 
+def csv_typed():
+    """The typed half of the CSV ingest: constructCI / getCorrespondingValue / Strictify.
+
+    pkg/providers/s3/reader/registry/csv/reader_csv_test.go:168-430 (the expected values are literals of the tests,
+    transcribed with their line) and tests/canon/s3/csv/canondata/*/extracted (Go type + value of every cell the
+    validator sink saw; read from the canon files here, never typed)."""
+    T = REF + "/pkg/providers/s3/reader/registry/csv/reader_csv_test.go"
+    with open(T, encoding="utf-8") as f:
+        src = f.read()
+    # guard: the literals transcribed below are still in the test file
+    for lit in ['require.Equal(t, []any{true, ""}, changeItem.ColumnValues)',
+                '"missing row element for column: test-missing-row-column, row elements: 1, columns: 2"',
+                'require.Equal(t, []any{"test_file", uint64(1), true, "this is a test string"}, changeItem.ColumnValues)',
+                'require.Equal(t, []any{nil, nil, true, "this is a test string"}, changeItem.ColumnValues)',
+                'originalValue := "123,456"', 'expected := "123.456"', '"02-Jan-2006",     // dd-Mon-yyyy',
+                'TrueValues:       []string{"true", "yes", "1"}', 'NullValues:             []string{"NULL", "NA"}']:
+        assert lit in src, lit
+    base = [["test-first-column", "boolean", False, "0"], ["test-missing-row-column", "utf8", False, "1"]]
+    sys_cols = [["__file_name", "utf8", True, ""], ["__row_index", "uint64", True, ""]]  # AppendSystemColsTableSchema(cols, true), util.go:210-215
+    construct = [
+        # TestConstructCI, reader_csv_test.go:168-275: row []string given to constructCI directly (one CSV line here)
+        {"name": "missing cols are included", "line": 204, "opts": {"include_missing_columns": 1}, "schema": base, "row": ["true"],
+         "expect": [["bool", True], ["string", ""]]},
+        {"name": "missing cols flag is disabled", "line": 213, "opts": {}, "schema": base, "row": ["true"], "expect_error": "MISSING_CELL",
+         "expect_error_col": "test-missing-row-column"},
+        {"name": "missing cols flag is disabled but all elements present", "line": 221, "opts": {}, "schema": base,
+         "row": ["true", "this is a test string"], "expect": [["bool", True], ["string", "this is a test string"]]},
+        {"name": "schema contains sys cols", "line": 230, "opts": {"file_name": "test_file", "row_number_base": 1}, "schema": sys_cols + base,
+         "row": ["true", "this is a test string"],
+         "expect": [["string", "test_file"], ["uint64", 1], ["bool", True], ["string", "this is a test string"]]},
+        {"name": "hide sys cols", "line": 241, "opts": {"file_name": "test_file", "row_number_base": 1, "hide_system_cols": 1},
+         "schema": sys_cols + base, "row": ["true", "this is a test string"],
+         "expect": [["nil", None], ["nil", None], ["bool", True], ["string", "this is a test string"]]},
+    ]
+    corresponding = [
+        # TestParseFloatValue :273-303 — parseFloatValue returns a string either way
+        {"fn": "parseFloatValue", "line": 278, "opts": {"decimal_point": ","}, "dtype": "double", "in": "123,456", "expect": ["string", "123.456"]},
+        {"fn": "parseFloatValue", "line": 285, "opts": {"decimal_point": "."}, "dtype": "double", "in": "123.456", "expect": ["string", "123.456"]},
+        {"fn": "parseFloatValue", "line": 291, "opts": {"decimal_point": "."}, "dtype": "double", "in": "abc", "expect": ["string", "abc"]},
+        {"fn": "parseFloatValue", "line": 298, "opts": {"decimal_point": ""}, "dtype": "double", "in": "123.456", "expect": ["string", "123.456"]},
+        # TestParseNullValues :305-356 — col is the empty ColSchema: DefaultValue(&col) is nil (change_item_builders.go:88-109, no type matches)
+        {"fn": "parseNullValues", "line": 316, "opts": {"strings_can_be_null": 1, "quoted_strings_can_be_null": 1, "null_values": ["NULL", "NA"]},
+         "dtype": "invalid", "in": "\"NULL\"", "expect": ["nil", None]},
+        {"fn": "parseNullValues", "line": 323, "opts": {"strings_can_be_null": 1, "quoted_strings_can_be_null": 1, "null_values": ["NULL", "NA"]},
+         "dtype": "invalid", "in": "\"notnull\"", "expect": ["string", "\"notnull\""]},
+        {"fn": "parseNullValues", "line": 329, "opts": {"strings_can_be_null": 1, "quoted_strings_can_be_null": 1, "null_values": ["NULL", "NA"]},
+         "dtype": "invalid", "in": "NULL", "expect": ["nil", None]},
+        {"fn": "parseNullValues", "line": 335, "opts": {"strings_can_be_null": 1, "quoted_strings_can_be_null": 1, "null_values": ["NULL", "NA"]},
+         "dtype": "invalid", "in": "notnull", "expect": ["string", "notnull"]},
+        {"fn": "parseNullValues", "line": 343, "opts": {"null_values": ["NULL", "NA"]}, "dtype": "invalid", "in": "\"NULL\"",
+         "expect": ["string", "\"NULL\""]},
+        {"fn": "parseNullValues", "line": 351, "opts": {"strings_can_be_null": 1, "quoted_strings_can_be_null": 1, "null_values": ["NULL", "NA"]},
+         "dtype": "invalid", "in": "notnull", "expect": ["string", "notnull"]},
+        # TestParseDateValue :358-393 — expected = time.Parse(layout, value), written here as RFC3339
+        {"fn": "parseDateValue", "line": 371, "opts": {"timestamp_parsers": ["2006-01-02", "02-Jan-2006", "January 2, 2006"]}, "dtype": "date",
+         "in": "2024-03-22", "expect": ["time", "2024-03-22T00:00:00Z"]},
+        {"fn": "parseDateValue", "line": 377, "opts": {"timestamp_parsers": ["2006-01-02", "02-Jan-2006", "January 2, 2006"]}, "dtype": "date",
+         "in": "22-Mar-2024", "expect": ["time", "2024-03-22T00:00:00Z"]},
+        {"fn": "parseDateValue", "line": 383, "opts": {"timestamp_parsers": ["2006-01-02", "02-Jan-2006", "January 2, 2006"]}, "dtype": "date",
+         "in": "March 22, 2024", "expect": ["time", "2024-03-22T00:00:00Z"]},
+        {"fn": "parseDateValue", "line": 389, "opts": {"timestamp_parsers": ["2006-01-02", "02-Jan-2006", "January 2, 2006"]}, "dtype": "date",
+         "in": "2024/03/22", "expect": ["string", "2024/03/22"]},
+    ]
+    B = {"strings_can_be_null": 1, "null_values": ["NULL", "NA"], "true_values": ["true", "yes", "1"], "false_values": ["false", "no", "0"]}
+    for line, v, e in [(407, "NULL", ["bool", False]), (412, "true", ["bool", True]), (417, "false", ["bool", False]), (422, "TRUE", ["bool", True]),
+                       (427, "random", ["string", "random"])]:  # TestParseBooleanValue :395-431
+        corresponding.append({"fn": "parseBooleanValue", "line": line, "opts": B, "dtype": "boolean", "in": v, "expect": e})
+
+    # S3 canon: what the validator sink received (Go type + value per cell).  The input object (test_csv_all_types/all_types.csv)
+    # lives in the test bucket, not in the repository; the canon pins the OUTPUT — DefaultValue fill of missing columns with
+    # IncludeMissingColumns, the system columns, and the three leading typed cells of every row.
+    canon_cases = []
+    CD = REF + "/tests/canon/s3/csv/canondata/"
+    for d, opts in [("csv.csv.TestNativeS3MissingColumnsAreFilled_canon_0#01", {"include_missing_columns": 1, "hide_system_cols": 1}),
+                    ("csv.csv.TestNativeS3WithProvidedSchemaAndSystemCols_canon_0#01", {})]:
+        with open(CD + d + "/extracted") as f:
+            items = json.load(f)
+        rows, schema = [], None
+        for it in items:
+            names = it["ColumnNames"]["value"]
+            vals = [[v["type"], v["value"]] for v in it["ColumnValues"]["value"]]
+            ts = it["TableSchema"]["value"]
+            sch = [[c["name"], c["type"], bool(c["key"]), c["path"]] for c in ts]
+            assert [c[0] for c in sch] == names
+            schema = schema or sch
+            assert sch == schema
+            rows.append(vals)
+            assert it["Kind"]["value"] == "insert"
+        o = dict(opts)
+        if any(n == "__file_name" for n in names):
+            o["file_name"] = rows[0][names.index("__file_name")][1]
+            o["row_number_base"] = rows[0][names.index("__row_index")][1]
+        canon_cases.append({"name": d, "opts": o, "schema": schema, "expect_rows": rows})
+    write("csv_typed.json", {
+        "source": "pkg/providers/s3/reader/registry/csv/reader_csv_test.go:168-440 + tests/canon/s3/csv/canondata/*/extracted (canon_test.go:188-330)",
+        "construct_ci": construct, "corresponding_value": corresponding, "s3_canon": canon_cases})
+
+
 # ---------------------------------------------------------------------------
 # serializers: pkg/serializer/reference/reference_test.go:19-78 (one raw-message item, canon files
 # hold the exact bytes), json_test.go:52-110, httpuploader/marshal_test.go:18-233
@@ -470,6 +568,25 @@ def json_parser():
                                   "topic": topic, "partition": json.dumps({"partition": 0, "topic": topic}, separators=(",", ":"))},
                       "fields": fields,
                       # testcase.MakeDefaultPersqueueReadMessage (tests/canon/parser/testcase/test_case.go:66-76)
+                      "messages": [{"offset": 123, "write_time": "2020-02-02T10:02:20Z", "value_latin1": sample.decode("latin-1")}],
+                      "rows": rows})
+    # the tskv.lb flavours of the same canon test that need no nested ColSchema.Path and no TimeField (metrika, metrika_complex
+    # read EventValue.* paths; taxi parses its time column through github.com/araddon/dateparse, unpinned: not extracted)
+    for name in ("tskv", "tm-5249"):
+        cfg = json.load(open(f"{base}/samples/static/generic/{name}.config.json"))
+        pc = cfg["ParserConfig"]["tskv.lb"]
+        assert not pc["TimeField"] and not pc["TableSplitter"] and all(not f.get("path") for f in pc["Fields"])
+        sample = open(f"{base}/samples/static/generic/{name}.sample", "rb").read()
+        ext = json.load(open(f"{base}/gotest/canondata/gotest.gotest.TestGenericParsers_{name}_canon_0/extracted"))
+        fields = [[f["name"], f["type"], bool(f["key"]), f.get("path", ""), "", bool(f.get("required"))] for f in pc["Fields"]]
+        topic = cfg["GroupTopics"][0]
+        rows = [{"table": it["Table"]["value"], "names": it["ColumnNames"]["value"], "values": [_canon_value(v) for v in it["ColumnValues"]["value"]],
+                 "part": it["PartID"]["value"]} for it in ext]
+        cases.append({"name": "canon_" + name, "ref": f"tests/canon/parser/samples/static/generic/{name}.sample",
+                      # ParserConfigTSKVLb → GenericParserConfig (pkg/parsers/registry/tskv/parser_tskv.go): Format "tskv"
+                      "options": {"format": "tskv", "add_rest": bool(pc["AddRest"]), "add_dedupe_keys": True, "null_keys_allowed": bool(pc["NullKeysAllowed"]),
+                                  "topic": topic, "partition": json.dumps({"partition": 0, "topic": topic}, separators=(",", ":"))},
+                      "fields": fields,
                       "messages": [{"offset": 123, "write_time": "2020-02-02T10:02:20Z", "value_latin1": sample.decode("latin-1")}],
                       "rows": rows})
     # TestParserNumberTypes: one line per message, Offset = line index, canon = MarshalJSON of the ChangeItems
@@ -762,4 +879,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_typed(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr()

@@ -77,7 +77,9 @@ class CCsvOptions(C.Structure):
                 ("n_true_values", C.c_int32), ("true_values", C.POINTER(C.c_char_p)),
                 ("n_false_values", C.c_int32), ("false_values", C.POINTER(C.c_char_p)),
                 ("n_timestamp_parsers", C.c_int32), ("timestamp_parsers", C.POINTER(C.c_char_p)),
-                ("decimal_point", C.c_char_p), ("skip_rows", C.c_int64)]
+                ("decimal_point", C.c_char_p), ("skip_rows", C.c_int64),
+                ("file_name", C.c_char_p), ("row_number_base", C.c_uint64), ("hide_system_cols", C.c_uint8),
+                ("encoding_table", C.POINTER(C.c_uint32))]
 
 
 class CJsonOptions(C.Structure):
@@ -259,6 +261,35 @@ def queue_options(fmt, enabled=False, max_change_items=0, max_message_size=0, ta
 
 def _b(s) -> bytes:
     return s if isinstance(s, bytes) else str(s).encode("utf-8")
+
+
+# csv.Reader.Encoding names (x/text charmap.All .String(), lower-cased with '-' for ' ' by prepareEncodingName,
+# pkg/csv/reader.go:22-37) -> the Python codec holding the same single-byte table.
+_CHARMAPS = {"ibm-code-page-037": "cp037", "ibm-code-page-437": "cp437", "ibm-code-page-850": "cp850", "ibm-code-page-852": "cp852",
+             "ibm-code-page-855": "cp855", "ibm-code-page-858": "cp858", "ibm-code-page-860": "cp860", "ibm-code-page-862": "cp862",
+             "ibm-code-page-863": "cp863", "ibm-code-page-865": "cp865", "ibm-code-page-866": "cp866", "ibm-code-page-1047": "cp1047",
+             "ibm-code-page-1140": "cp1140", "koi8-r": "koi8_r", "koi8-u": "koi8_u", "macintosh": "mac_roman",
+             "macintosh-cyrillic": "mac_cyrillic", "windows-874": "cp874",
+             **{"iso-8859-%d" % i: "iso8859_%d" % i for i in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16)},
+             **{"windows-%d" % i: "cp%d" % i for i in range(1250, 1259)}}
+
+
+def charmap_table(encoding: str):
+    """The 256 code points tfgpu_csv_options.encoding_table carries.  The Go shim reads them off the reference's own
+    decoder (decoderFactoryByEncoding(name).NewDecoder(), pkg/csv/reader.go:27-37); this host mirror takes them from
+    Python's codec of the same code page.  A byte the code page leaves undefined decodes to U+FFFD as x/text does, except
+    in the windows-125x pages, whose WHATWG tables (x/text's source) pass such bytes through as C1 controls."""
+    name = encoding.lower().replace(" ", "-")
+    if name not in _CHARMAPS:
+        raise ValueError("csv: unknown Encoding %r (not in x/text charmap.All)" % encoding)
+    codec = _CHARMAPS[name]
+    out = []
+    for b in range(256):
+        try:
+            out.append(ord(bytes([b]).decode(codec)))
+        except UnicodeDecodeError:
+            out.append(b if codec.startswith("cp125") else 0xFFFD)
+    return out
 
 
 # ---- python-side containers ------------------------------------------------
@@ -603,7 +634,8 @@ def batch_rows(b: Batch):
 
 def csv_options(delimiter=",", quote_char='"', escape_char="\\", double_quote=1, newlines_in_value=0,
                 include_missing_columns=0, strings_can_be_null=0, quoted_strings_can_be_null=0, null_values=(),
-                true_values=(), false_values=(), timestamp_parsers=(), decimal_point="", skip_rows=0) -> CCsvOptions:
+                true_values=(), false_values=(), timestamp_parsers=(), decimal_point="", skip_rows=0, file_name="",
+                row_number_base=1, hide_system_cols=0, encoding="") -> CCsvOptions:
     o = CCsvOptions()
 
     def ch(x):
@@ -625,5 +657,12 @@ def csv_options(delimiter=",", quote_char='"', escape_char="\\", double_quote=1,
     dp = _b(decimal_point)
     keep.append(dp)
     o.decimal_point, o.skip_rows = dp, int(skip_rows)
+    fn = _b(file_name)
+    keep.append(fn)
+    o.file_name, o.row_number_base, o.hide_system_cols = fn, int(row_number_base), int(hide_system_cols)
+    if encoding:
+        tab = (C.c_uint32 * 256)(*charmap_table(encoding))
+        keep.append(tab)
+        o.encoding_table = tab
     o._keep = keep
     return o
