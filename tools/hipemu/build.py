@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-UNITS = ["tf_runtime.hip", "tf_serialize.hip", "tf_srjson.hip", "tf_json.hip"]  # tf_json: the per-line path (its wave path aborts here)  # translation units whose kernels use no LDS / barriers / wave intrinsics
+UNITS = ["tf_runtime.hip", "tf_scan.hip", "tf_plan.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_serialize.hip", "tf_json.hip",
+         "tf_collapse.hip", "tf_srjson.hip"]  # = transferia_amd/build.py SOURCES
 LAUNCH = re.compile(r"(\b[A-Za-z_][A-Za-z0-9_:]*(?:<[^<>;]*>)?)\s*<<<\s*([^;]*?)>>>\s*\(")
 
 
@@ -53,15 +54,26 @@ def build() -> str:
         with open(dst, "w") as f:
             f.write(text)
         srcs.append(dst)
-    srcs.append(os.path.join(HERE, "emu_stubs.cpp"))
-    obj = os.path.join(OUT, "emu_abi_stubs.o")
-    subprocess.check_call(["gcc", "-O1", "-fPIC", "-c", os.path.join(HERE, "emu_abi_stubs.c"), "-o", obj])
-    srcs.append(obj)
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-Wno-unused-result", "-I", HERE, "-I", CSRC, "-o", so, *srcs]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    objs = []
+
+    def compile_one(src):
+        obj = os.path.splitext(src)[0] + ".o"
+        deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + [os.path.join(HERE, "hip", "hip_runtime.h")]
+        if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
+            return obj
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-c", "-Wno-unused-result", "-I", HERE, "-I", CSRC, "-o", obj, src]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-6000:])
+            raise RuntimeError("hipemu build failed: " + src)
+        return obj
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    r = subprocess.run(["g++", "-shared", "-fPIC", "-o", so, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-6000:])
-        raise RuntimeError("hipemu build failed")
+        raise RuntimeError("hipemu link failed")
     return so
 
 

@@ -18,8 +18,16 @@ so = emu_build.build()
 from transferia_amd import lib  # noqa: E402
 
 lib._LIBPATH = so
+os.environ["TFGPU_TEST_EMU_LIB"] = so
 import pytest  # noqa: E402
 
-FILES = ["tests/test_queue_serializers.py", "tests/test_serializers.py", "tests/test_confluent_sr.py", "tests/test_gpu_json.py"]
-# test_gpu_hits_chain_to_jsoneachrow needs the CSV tile parser (LDS, wave scans), the JSON wave path wave ballots: not emulated
-sys.exit(pytest.main(["-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", "not hits_chain and not wave_path", *[os.path.join(ROOT, f) for f in FILES], *sys.argv[1:]]))
+# everything marked gpu, except what needs the real device: full-size batches (minutes here), RCCL / torch.cuda, the static
+# resource table of the gfx950 build.  Known emulator gap: the experimental JSON wave path (TFGPU_JSON_WAVES=1) parses the
+# subnormal-boundary literal 1e-308 as nil here and correctly on the MI355X.
+K = "not fullsize and not rccl and not resources and not pipeline_single_rank and not exchange and not wave_path_cross"
+args = sys.argv[1:]
+if "-k" in args:
+    i = args.index("-k")
+    K = "(%s) and (%s)" % (K, args[i + 1])
+    del args[i:i + 2]
+sys.exit(pytest.main(["-m", "gpu", "-q", "-p", "no:cacheprovider", "-k", K, os.path.join(ROOT, "tests"), *args]))
