@@ -57,6 +57,9 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(
 inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
 inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
+inline unsigned __float_as_uint(float f) { unsigned v; std::memcpy(&v, &f, 4); return v; }
+inline float __uint_as_float(unsigned v) { float f; std::memcpy(&f, &v, 4); return f; }
+inline float __uint2float_rz(unsigned x) { float f = (float)x; if ((double)f > (double)x) f = std::nextafterf(f, 0.0f); return f; }
 inline int __float_as_int(float f) { int v; std::memcpy(&v, &f, 4); return v; }
 inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
@@ -130,6 +133,22 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
 }
 inline int __builtin_amdgcn_readlane(int v, int l) { return emu_lane_read(v, l); }
 inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int v) { return emu_lane_read(v, (byte_addr >> 2) & 63); }
+// v_mov_b32 ... dpp: the controls libtfgpu uses (gfx9 rows of 16 lanes).  A lane without a source, or masked out by
+// row_mask, keeps `old` (bound_ctrl:0 would give 0 — the library always passes old = 0).
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int l = (int)hipemu::lane_(), row = l >> 4;
+  int from = -1;
+  if (ctrl >= 0x111 && ctrl <= 0x11F) { const int s = l - (ctrl - 0x110); if (s >= 0 && (s >> 4) == row) from = s; }        // row_shr:n
+  else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int s = l + (ctrl - 0x100); if (s < 64 && (s >> 4) == row) from = s; }    // row_shl:n
+  else if (ctrl == 0x142) { if (row >= 1) from = row * 16 - 1; }                                                             // row_bcast:15
+  else if (ctrl == 0x143) { if (l >= 32) from = 31; }                                                                        // row_bcast:31
+  else if (ctrl == 0x138) { if (l >= 1) from = l - 1; }                                                                      // wave_shr:1
+  else { std::fprintf(stderr, "hipemu: dpp_ctrl 0x%x not modelled\n", ctrl); std::abort(); }
+  const int got = emu_lane_read(src, from < 0 ? l : from);
+  if (!((row_mask >> row) & 1) || !((bank_mask >> ((l >> 2) & 3)) & 1)) return old;
+  if (from < 0) return bound_ctrl ? 0 : old;
+  return got;
+}
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned add) { const unsigned l = hipemu::lane_(); return add + (unsigned)__builtin_popcount(m & (l >= 32 ? 0xFFFFFFFFu : ((1u << l) - 1u))); }
 inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned add) { const unsigned l = hipemu::lane_(); return add + (l > 32 ? (unsigned)__builtin_popcount(m & ((1u << (l - 32)) - 1u)) : 0u); }
 inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {

@@ -24,6 +24,7 @@
 #include "tf_devparse.hpp"
 #include "tf_segcopy.hpp"
 #include "tf_textview.hpp"
+#include "tf_wave.hpp"
 #include "tf_plan.hpp"
 
 namespace tf {
@@ -315,6 +316,11 @@ struct CsvParams {
   uint32_t *slow_end;          //   position of the terminating '\n'
   uint32_t *last_end;          // max over lines of (position of '\n') + 1
   int32_t ablate;              // TFGPU_CSV_ABLATE=n (profiling only): leave the kernel after phase n; results are NOT valid
+  uint32_t *gen_n;             // tiles csv_parse_regular hands to the general tile kernel
+  uint32_t *gen_tile;
+  int32_t force_general;       // TFGPU_CSV_GENERAL=1: every tile takes the general kernel (parity cross-check of the two)
+  const struct CsvRun *runs;   // tcols grouped into runs of one (kind, width)
+  int32_t nruns;
 };
 
 __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v) {
@@ -597,8 +603,8 @@ __device__ __forceinline__ uint32_t qf_compose(uint32_t first, uint32_t then) {
   return ((then >> (first & 1)) & 1u) | (((then >> ((first >> 1) & 1)) & 1u) << 1);
 }
 
-__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
-  __shared__ __attribute__((aligned(16))) uint8_t sb[CT_BYTES + 16];
+__device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int64_t tile) {
+  __shared__ __attribute__((aligned(16))) uint8_t sb[CT_BYTES + 48];
   __shared__ uint16_t fpos[CT_FCAP];   // field-end position | bit15 = it is the line's '\n'
   __shared__ uint16_t rowend[CT_RCAP]; // ordinal of each line's last field
   __shared__ uint32_t slowf[CT_RCAP];  // line needs the per-row path (anything but a plain cell in it)
@@ -609,10 +615,6 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
   __shared__ uint32_t wmax[CT_THREADS / 64];
   __shared__ uint32_t wcnt[CT_THREADS / 64];
 
-  // XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
-  const int64_t per_xcd = (p.ntiles + 7) / 8;
-  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (tile >= p.ntiles) return;
   const uint32_t line0 = p.tile_base[tile];
   const uint32_t nlines = p.tile_base[tile + 1] - line0;
   if (nlines == 0) return;  // no line ends here (inside a very long line)
@@ -1002,6 +1004,490 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles(CsvParams p) {
   if (tid == 0) atomicMax(p.last_end, (uint32_t)(g0 + bstart));  // one past the last '\n' this tile owns
 }
 
+// The tiles csv_parse_regular could not take (anything but the plain shape it is specialised for), one after another
+// per workgroup; the LDS arrays are reused, hence the barrier between tiles.
+__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles_general(CsvParams p) {
+  const uint32_t n = *p.gen_n;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    parse_tile_general(p, (int64_t)p.gen_tile[i]);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// regular tiles.  What almost every tile of almost every file looks like: no escape character in front of a
+// quote, every line's quotes balanced (the quote state a '\n' resets is already "outside"), every line the same
+// number NF >= 2 of fields, everything fits the LDS index.  Then splitString's state machine is a plain prefix
+// parity of the quote characters, field k of line j is ordinal j * NF + k of the index, and nothing per line has to
+// be looked up.  A tile that is anything else is handed, whole, to csv_parse_tiles_general (above), which carries
+// the complete state machine; a CELL that is anything but plain still flags its line for csv_parse_listed.
+//   barriers: stage | quote parity per wave | field-end counts per wave | index | cells | epilogue
+// ---------------------------------------------------------------------------
+// four digit VALUES (most significant in byte 0) → their number: two v_dot4 and a mad
+__device__ __forceinline__ uint32_t four_dot(uint32_t x) {
+  return __umul24(__builtin_amdgcn_udot4(x, 0x0000010Au, 0u, false), 100u) + __builtin_amdgcn_udot4(x, 0x010A0000u, 0u, false);
+}
+// days since 1970-01-01 of a civil date with 0 <= y <= 9999, in 32-bit arithmetic (constant divisors only)
+__device__ __forceinline__ int32_t days_from_civil32(uint32_t y, uint32_t m, uint32_t d) {
+  const uint32_t yy = y + 400u - (m <= 2 ? 1u : 0u);  // shifted by one era so that the year stays non-negative
+  const uint32_t era = yy / 400u, yoe = yy - era * 400u;
+  const uint32_t doy = (153u * (m > 2 ? m - 3 : m + 9) + 2u) / 5u + d - 1u;
+  const uint32_t doe = yoe * 365u + yoe / 4u - yoe / 100u + doy;
+  return (int32_t)(era * 146097u + doe) - 719468 - 146097;
+}
+__device__ __forceinline__ uint32_t days_in_month32(uint32_t m, uint32_t y) {
+  const uint32_t leap = ((y & 3u) == 0 && (y % 100u != 0 || y % 400u == 0)) ? 1u : 0u;
+  return m == 2 ? 28u + leap : 30u + ((0x15AAu >> m) & 1u);  // bit m set for the 31-day months 1,3,5,7,8,10,12
+}
+
+// ASCII byte classes of 16 bytes by SWAR.  Per word: lo7 = the low seven bits of every byte, hi1 = all ones except
+// bit 7 of the bytes below 0x80.  For an ASCII pattern byte P, (lo7 ^ P4) + 0x7F7F7F7F carries into bit 7 exactly
+// where the seven bits differ (one v_xad_u32), and OR-ing hi1 leaves 0x7F in the bytes equal to P and 0xFF elsewhere.
+// v_dot4_u32_u8 with weights 1,2,4,8 and the accumulator preset to -(0x7F * 15) then sums 128 * (the weights of the
+// bytes that differ): the complement of the match nibble, already shifted by 7.
+struct Chunk16 { uint32_t lo7[4], hi1[4]; };
+__device__ __forceinline__ Chunk16 chunk16(uint4 v) {
+  Chunk16 c;
+  c.lo7[0] = v.x & 0x7F7F7F7Fu; c.lo7[1] = v.y & 0x7F7F7F7Fu; c.lo7[2] = v.z & 0x7F7F7F7Fu; c.lo7[3] = v.w & 0x7F7F7F7Fu;
+  c.hi1[0] = v.x | 0x7F7F7F7Fu; c.hi1[1] = v.y | 0x7F7F7F7Fu; c.hi1[2] = v.z | 0x7F7F7F7Fu; c.hi1[3] = v.w | 0x7F7F7F7Fu;
+  return c;
+}
+__device__ __forceinline__ uint32_t ne_bytes(const Chunk16 &c, int w, uint32_t pat4) { return ((c.lo7[w] ^ pat4) + 0x7F7F7F7Fu) | c.hi1[w]; }  // 0x7F = equal, 0xFF = not
+// 16-bit mask of the bytes equal to the ASCII byte replicated in pat4
+__device__ __forceinline__ uint32_t class16(const Chunk16 &c, uint32_t pat4) {
+  const uint32_t W = 0x08040201u, B = 0u - 0x7Fu * 15u;
+  const uint32_t d0 = __builtin_amdgcn_udot4(ne_bytes(c, 0, pat4), W, B, false), d1 = __builtin_amdgcn_udot4(ne_bytes(c, 1, pat4), W, B, false);
+  const uint32_t d2 = __builtin_amdgcn_udot4(ne_bytes(c, 2, pat4), W, B, false), d3 = __builtin_amdgcn_udot4(ne_bytes(c, 3, pat4), W, B, false);
+  return ~((d0 >> 7) | (d1 >> 3) | (d2 << 1) | (d3 << 5)) & 0xFFFFu;
+}
+// does any of the 16 bytes equal the ASCII byte replicated in pat4?
+__device__ __forceinline__ bool any16(const Chunk16 &c, uint32_t pat4) {
+  return ((ne_bytes(c, 0, pat4) & ne_bytes(c, 1, pat4) & ne_bytes(c, 2, pat4) & ne_bytes(c, 3, pat4)) & 0x80808080u) != 0x80808080u;
+}
+
+struct CsvRun { int32_t kind, width, first, ncols; };  // consecutive tcols of one (kind, width); kind -1: DefaultValue columns (no field)
+
+// what the cell loops of csv_parse_regular share
+struct RegTile {
+  const uint8_t *sb; const uint16_t *fposx; const uint32_t *qmask; const uint16_t *qpre; uint32_t *slowf; const uint64_t *colp0, *colp1; const uint16_t *colfield;
+  uint32_t nr, NF; float inv_nr; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote;
+};
+// one cell of a run: item → (column, line), its output row and its byte range [fs, fend) in the tile
+struct RegCell { bool on; uint32_t col, jj, fs, fend; int32_t r; };
+__device__ __forceinline__ RegCell reg_cell(const RegTile &t, uint32_t first_col, uint32_t it, uint32_t items) {
+  RegCell c;
+  // it / nr through the float reciprocal (rounded down, so the quotient is never too large; it < 2^24): all full-rate ops
+  uint32_t oi = (uint32_t)(__uint2float_rz(it) * t.inv_nr);
+  uint32_t jj = it - __umul24(oi, t.nr);
+  if (jj >= t.nr) { oi++; jj -= t.nr; }
+  c.col = first_col + oi; c.jj = jj;
+  c.r = t.row0 + (int32_t)jj;
+  c.on = it < items && c.r >= 0;  // header lines produce nothing
+  c.fs = 0; c.fend = 0;
+  if (c.on) {
+    const uint32_t kr = __umul24(jj, t.NF) + (uint32_t)t.colfield[c.col];  // < nr * NF <= the index's size (checked before the cells)
+    c.fs = (uint32_t)t.fposx[kr] + 1; c.fend = t.fposx[kr + 1];
+  }
+  return c;
+}
+// number of quote characters in tile positions [a, b), a <= b: prefix counts per 32-byte word + the bitmap
+__device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint32_t b) {
+  const uint32_t ca = (uint32_t)t.qpre[a >> 5] + (uint32_t)__popc(t.qmask[a >> 5] & ((1u << (a & 31)) - 1u));
+  const uint32_t cb = (uint32_t)t.qpre[b >> 5] + (uint32_t)__popc(t.qmask[b >> 5] & ((1u << (b & 31)) - 1u));
+  return cb - ca;
+}
+
+// Up to eight decimal digits that END at tile position `end` (nd of them, 1..8): the 8-byte window [end - 8, end) holds
+// them right-aligned, so no shifting by the field length is needed — mask what precedes them, check, two v_dot4 per four.
+// Returns false on a non-digit.
+__device__ __forceinline__ bool digits8_end(const uint8_t *sb, uint32_t end, uint32_t nd, uint32_t *out) {
+  const int e8 = (int)end - 8;
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(sb + (e8 & ~3));
+  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)e8) ^ 0x30303030u, hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)e8) ^ 0x30303030u;
+  const uint64_t keep = ~0ull << (8 * (8 - nd));  // nd >= 1
+  const uint32_t tlo = lo & (uint32_t)keep, thi = hi & (uint32_t)(keep >> 32);
+  *out = __umul24(four_dot(tlo), 10000u) + four_dot(thi);  // < 10^8
+  return (((tlo + 0x76767676u) | tlo | (thi + 0x76767676u) | thi) & 0x80808080u) == 0;
+}
+
+template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
+  using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
+  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
+  for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, (s - sbase) * 64 + (uint32_t)lane, items);
+    if (!c.on) continue;
+    T *const out = (T *)t.colp0[c.col];
+    const uint32_t n = c.fend - c.fs;
+    const uint32_t c0 = t.sb[c.fs];
+    const bool neg = c0 == '-', sgn = neg || c0 == '+';
+    const uint32_t nd = n - (sgn ? 1u : 0u);  // digits
+    // [+-]?(0|[1-9][0-9]*): base prefixes, '_', ".00", spaces, quotes → per-row path
+    bool ok = nd - 1u < 19u && n <= 0x7FFFu && !(nd > 1 && t.sb[c.fend - nd] == '0');
+    if constexpr (KIND == CK_UINT && W == 8) ok = ok && !sgn;  // ParseUint takes no sign
+    uint32_t g0v = 0;
+    ok = digits8_end(t.sb, c.fend, min(nd, 8u), &g0v) && ok;
+    if (W < 4 || nd <= 8) {
+      if constexpr (W < 4) {
+        if constexpr (KIND == CK_INT) ok = ok && nd <= 8 && g0v <= (1u << (W * 8 - 1)) - (neg ? 0u : 1u);
+        else ok = ok && nd <= 8 && g0v <= (1u << (W * 8)) - 1u;
+      }
+      if constexpr (KIND == CK_UINT) ok = ok && !(neg && g0v != 0);
+      if (ok) out[c.r] = (T)(neg ? -(int32_t)g0v : (int32_t)g0v);
+    } else {
+      // 9..19 digits: groups of eight from the right
+      uint32_t g1v = 0, g2v = 0;
+      ok = digits8_end(t.sb, c.fend - 8, min(nd - 8, 8u), &g1v) && ok;
+      if (nd > 16) ok = digits8_end(t.sb, c.fend - 16, nd - 16, &g2v) && ok;
+      const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;  // < 10^19 < 2^64
+      if constexpr (KIND == CK_INT) ok = ok && v <= (neg ? (1ull << (W * 8 - 1)) : (1ull << (W * 8 - 1)) - 1);
+      else ok = ok && !(neg && v != 0) && (W == 8 || v <= (1ull << (W * 8 % 64)) - 1);
+      if (ok) out[c.r] = (T)(neg ? (int64_t)(0 - v) : (int64_t)v);
+    }
+    if (!ok) t.slowf[c.jj] = 1;
+  }
+}
+
+__device__ __forceinline__ void reg_cells_str(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
+  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
+  for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, (s - sbase) * 64 + (uint32_t)lane, items);
+    if (!c.on) continue;
+    uint32_t *const lens = (uint32_t *)t.colp0[c.col], *const fstart = (uint32_t *)t.colp1[c.col];
+    const uint32_t n = c.fend - c.fs;
+    if (n == 0) { lens[c.r] = 0; fstart[c.r] = t.g0 + c.fs; continue; }
+    bool done = false;
+    if (n <= 0x7FFFu) {
+      // nothing to trim: either enclosed in quotes ("…": unquote) or plain at both ends
+      const uint32_t c_first = t.sb[c.fs], c_last = t.sb[c.fend - 1];
+      uint32_t a = c.fs, b = c.fend;
+      bool ok = false;
+      if (c_first == t.quote && c_last == t.quote && n >= 2) { a++; b--; ok = true; }
+      else ok = c_first != t.quote && c_last != t.quote && starts_plain(t.sb, c.fs, c.fend, c_first, t.quote) && ends_plain(t.sb, c.fs, c.fend, c_last, t.quote);
+      if (ok) {
+        const uint32_t npairs = quotes_in(t, a, b) ? count_quote_pairs(t.qmask, a, b) : 0u;
+        if (!(npairs && !t.double_quote)) {  // errDoubleQuotesDisabled: per-row path
+          lens[c.r] = (b - a) - npairs;
+          fstart[c.r] = (t.g0 + a) | (npairs ? 0x80000000u : 0u);
+          if (npairs) fstart[-1] = 1u;  // the column holds cells that are not a plain byte range
+          done = true;
+        }
+      }
+    }
+    if (!done) t.slowf[c.jj] = 1;
+  }
+}
+
+// 2006-01-02 | 2006-01-02[ T]15:04:05 (cast.StringToDate layouts); a timestamp column also takes plain decimal
+// seconds (parseTimestampValue, reader_csv.go:419-426)
+__device__ __forceinline__ uint32_t dig2(uint32_t w, int byte, uint32_t *bad) {  // two ASCII digits at bytes byte, byte + 1 of w
+  const uint32_t a = ((w >> (8 * byte)) & 0xFFu) - '0', b = ((w >> (8 * byte + 8)) & 0xFFu) - '0';
+  *bad |= (a > 9u) | (b > 9u);
+  return a * 10 + b;
+}
+template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
+  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
+  for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, (s - sbase) * 64 + (uint32_t)lane, items);
+    if (!c.on) continue;
+    int64_t *const sec = (int64_t *)t.colp0[c.col]; int32_t *const nanos = (int32_t *)t.colp1[c.col];
+    const uint32_t n = c.fend - c.fs;
+    bool done = false;
+    if ((n == 10 || n == 19) && t.sb[c.fs + 4] == '-') {
+      // the 20 bytes from the field's start as five words: "2006" "-01-" "02 1" "5:04" ":05."
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (c.fs & ~3u));
+      const uint32_t x0 = w[0], x1 = w[1], x2 = w[2], x3 = w[3], x4 = w[4], x5 = w[5];
+      const uint32_t w0 = __builtin_amdgcn_alignbyte(x1, x0, c.fs), w1 = __builtin_amdgcn_alignbyte(x2, x1, c.fs), w2 = __builtin_amdgcn_alignbyte(x3, x2, c.fs);
+      uint32_t bad = 0;
+      const uint32_t y = dig2(w0, 0, &bad) * 100 + dig2(w0, 2, &bad);
+      const uint32_t mo = dig2(w1, 1, &bad), d = dig2(w2, 0, &bad);
+      bad |= (w1 & 0xFF0000FFu) != 0x2D00002Du;  // '-' .. '-'
+      uint32_t h = 0, mi = 0, se = 0;
+      if (n == 19) {
+        const uint32_t w3 = __builtin_amdgcn_alignbyte(x4, x3, c.fs), w4 = __builtin_amdgcn_alignbyte(x5, x4, c.fs);
+        const uint32_t sep = (w2 >> 16) & 0xFFu;
+        bad |= !(sep == ' ' || sep == 'T') | (((w3 >> 8) & 0xFFu) != ':') | ((w4 & 0xFFu) != ':');
+        h = (((w2 >> 24) & 0xFFu) - '0') * 10 + ((w3 & 0xFFu) - '0');
+        bad |= (((w2 >> 24) & 0xFFu) - '0' > 9u) | ((w3 & 0xFFu) - '0' > 9u);
+        mi = dig2(w3, 2, &bad); se = dig2(w4, 1, &bad);
+      }
+      const bool ok = !bad && mo >= 1 && mo <= 12 && d >= 1 && d <= days_in_month32(mo, y) && h <= 23 && mi <= 59 && se <= 59;
+      if (ok) {
+        sec[c.r] = (int64_t)days_from_civil32(y, mo, d) * 86400 + (int64_t)(h * 3600 + mi * 60 + se);
+        nanos[c.r] = 0;
+        done = true;
+      }
+    } else if (KIND == CK_TIMESTAMP && n - 1u < 19u) {
+      // ParseInt(s, 10, 64): [+-]?digits, leading zeros are fine in base 10
+      const uint32_t c0 = t.sb[c.fs];
+      const bool neg = c0 == '-', sgn = neg || c0 == '+';
+      const uint32_t nd = n - (sgn ? 1u : 0u);
+      uint32_t g0v = 0, g1v = 0, g2v = 0;
+      bool ok = nd - 1u < 18u;
+      ok = digits8_end(t.sb, c.fend, min(nd, 8u), &g0v) && ok;
+      if (nd > 8) ok = digits8_end(t.sb, c.fend - 8, min(nd - 8, 8u), &g1v) && ok;
+      if (nd > 16) ok = digits8_end(t.sb, c.fend - 16, nd - 16, &g2v) && ok;
+      if (ok) {
+        const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;
+        sec[c.r] = neg ? -(int64_t)v : (int64_t)v; nanos[c.r] = 0; done = true;
+      }
+    }
+    if (!done) t.slowf[c.jj] = 1;
+  }
+}
+
+__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) {
+  static_assert(CT_SPILL == 64 * CT_CPT * 16, "the look-behind window is exactly wave 0's bytes");
+  __shared__ __attribute__((aligned(16))) uint8_t sbuf[16 + CT_BYTES + 48];
+  __shared__ uint16_t fposx[CT_FCAP + 2];    // [k + 1] = end of field k; [0] = first line's start - 1
+  __shared__ uint32_t qmask[CT_BYTES / 32];  // bitmap of quote characters
+  __shared__ uint32_t nlbits[(CT_FCAP + 32) / 32];  // bit k + 1: field k ends its line
+  __shared__ uint16_t qpre[CT_BYTES / 32 + 2];      // quote characters in front of each 32-byte word
+  __shared__ uint32_t wqc[CT_THREADS / 64];
+  __shared__ uint32_t slowf[CT_RCAP];        // line needs the per-row path
+  __shared__ uint64_t colp0[CT_LCOLS], colp1[CT_LCOLS];
+  __shared__ uint16_t colfield[CT_LCOLS];
+  __shared__ uint32_t wpar[CT_THREADS / 64];
+  __shared__ uint32_t wcnt[CT_THREADS / 64];
+  __shared__ uint32_t misc[4];               // 0: first line's start, 1: tile is not regular, 2: NF
+  uint8_t *const sb = sbuf + 16;
+
+  // XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
+  const int64_t per_xcd = (p.ntiles + 7) / 8;
+  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const uint32_t line0 = p.tile_base[tile];
+  const uint32_t nlines = p.tile_base[tile + 1] - line0;
+  if (nlines == 0) return;  // no line ends here (inside a very long line)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const CsvOpts &o = p.o;
+  const int64_t g0 = tile * CT_T - CT_SPILL;  // absolute offset of sb[0]
+  auto give_up = [&]() { if (tid == 0) { const uint32_t slot = atomicAdd(p.gen_n, 1u); p.gen_tile[slot] = (uint32_t)tile; } };
+  if (p.force_general || nlines > (uint32_t)CT_RCAP || p.ncols > CT_LCOLS) { give_up(); return; }
+
+  // ---- stage: coalesced 16 B/lane ----
+  if (g0 >= 0 && (uint64_t)(g0 + CT_BYTES) <= p.len) {
+    const uint8_t *src = p.data + g0;
+#pragma unroll
+    for (int it = 0; it < CT_CPT; it++) {
+      const int chunk = it * CT_THREADS + tid;
+      *reinterpret_cast<uint4 *>(sb + chunk * 16) = *reinterpret_cast<const uint4 *>(src + chunk * 16);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < CT_CPT; it++) {
+      const int chunk = it * CT_THREADS + tid;
+      const int64_t gp = g0 + (int64_t)chunk * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gp >= 0 && (uint64_t)gp < p.len) v = *reinterpret_cast<const uint4 *>(p.data + gp);  // buffer is zero-padded past len
+      *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
+    }
+  }
+  for (int i = tid; i < p.ncols; i += CT_THREADS) { const TCol tc = p.tcols[i]; colp0[i] = (uint64_t)tc.p0; colp1[i] = (uint64_t)tc.p1; colfield[i] = (uint16_t)tc.field; }
+  if (tid < 4) misc[tid] = 0;
+  if (tid < 12) reinterpret_cast<uint32_t *>(sbuf + 16 + CT_BYTES)[tid] = 0;  // the bytes past the tile that cell windows may touch
+  for (int i = tid; i < (CT_FCAP + 32) / 32; i += CT_THREADS) nlbits[i] = 0;
+  __syncthreads();
+  if (p.ablate == 1) return;  // (TFGPU_CSV_ABLATE, profiling only: leave after phase n; results are not valid)
+
+  // ---- pass 1: per-byte classes of this thread's 64 bytes, as 16-bit masks per 16-byte chunk ----
+  const int base_chunk = tid * CT_CPT;
+  uint32_t qm[CT_CPT], dm[CT_CPT], nl[CT_CPT];
+  uint32_t bad = 0;
+  {
+    const uint32_t q4 = o.quote * 0x01010101u, d4 = o.delim * 0x01010101u, e4 = o.escape * 0x01010101u;
+    uint32_t pe = 0;  // the previous chunk ended on the escape character
+    if (o.escape != 0 && base_chunk > 0) pe = sb[base_chunk * 16 - 1] == o.escape ? 1u : 0u;
+#pragma unroll
+    for (int q = 0; q < CT_CPT; q++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sb + (base_chunk + q) * 16);
+      const Chunk16 ck = chunk16(v);
+      qm[q] = class16(ck, q4); dm[q] = class16(ck, d4); nl[q] = class16(ck, 0x0A0A0A0Au);
+      reinterpret_cast<uint16_t *>(qmask)[base_chunk + q] = (uint16_t)qm[q];
+      if (o.escape != 0 && (any16(ck, e4) || pe)) {
+        // an escape character directly in front of a quote (reader.go:233-240) needs the byte-wise state machine
+        const uint32_t em = class16(ck, e4);
+        bad |= ((em << 1) | pe) & qm[q];
+        pe = (em >> 15) & 1u;
+      }
+    }
+  }
+  if (wv == 0) {
+    // the first line this tile owns starts behind the last '\n' of the look-behind window; what precedes it belongs to
+    // the tile before (the highest lane holding a '\n' holds the last one)
+    int mx = -1;
+#pragma unroll
+    for (int q = 0; q < CT_CPT; q++) if (nl[q]) mx = (base_chunk + q) * 16 + 31 - __clz((int)nl[q]);
+    const uint64_t holders = __ballot(mx >= 0);
+    int frs = 0;
+    if (holders) frs = __shfl(mx, 63 - __clzll((long long)holders), 64) + 1;
+    else if (g0 <= 0) frs = (int)(-g0);  // the buffer starts inside the window: line 0 starts at absolute 0
+    else bad |= 1u;                      // the first line started before the window: general path
+#pragma unroll
+    for (int q = 0; q < CT_CPT; q++) {
+      const int cpos = (base_chunk + q) * 16;
+      uint32_t keep = 0xFFFFu;
+      if (cpos + 16 <= frs) keep = 0; else if (cpos < frs) keep = 0xFFFFu & ~((1u << (frs - cpos)) - 1u);
+      qm[q] &= keep; dm[q] &= keep; nl[q] &= keep;
+    }
+    if (lane == 0) misc[0] = (uint32_t)frs;
+  }
+  uint32_t par = 0;
+#pragma unroll
+  for (int q = 0; q < CT_CPT; q++) par ^= (uint32_t)__popc(qm[q]);
+  par &= 1u;
+  const uint64_t pb = __ballot(par != 0);
+  const uint32_t par_in = lanes_below(pb) & 1u;  // parity of the quotes of this wave's bytes before this thread's
+  if (lane == 0) wpar[wv] = (uint32_t)__popcll(pb) & 1u;
+  if (__any(bad != 0) && lane == 0) misc[1] = 1u;
+  __syncthreads();
+  if (p.ablate == 2) { if (par_in == 77u + qm[0] + dm[1] + nl[2] + qm[3] + dm[0] + nl[0]) p.err[0] = 1; return; }
+
+  // ---- pass 2: field ends = delimiters outside quotes, and every '\n' ----
+  uint32_t s_in = par_in;
+  for (int i = 0; i < wv; i++) s_in ^= wpar[i];
+  uint32_t fe[CT_CPT];
+  uint32_t cnt = 0;
+  bad = 0;
+#pragma unroll
+  for (int q = 0; q < CT_CPT; q++) {
+    uint32_t px = qm[q];  // bit i = parity of the quotes in bytes [0, i]
+    px ^= px << 1; px ^= px << 2; px ^= px << 4; px ^= px << 8;
+    const uint32_t inq = (px ^ (s_in ? 0xFFFFu : 0u)) & 0xFFFFu;
+    bad |= nl[q] & inq;  // a '\n' inside quotes cuts the line and resets the state: not the plain parity any more
+    fe[q] = (dm[q] & ~inq) | nl[q];
+    s_in = inq >> 15;
+    cnt += (uint32_t)__popc(fe[q]) | ((uint32_t)__popc(nl[q]) << 16);
+  }
+  const uint32_t cinc = wave_scan_add(cnt);
+  const uint32_t qlo = (uint32_t)__popc(qmask[tid * 2]), qc = qlo + (uint32_t)__popc(qmask[tid * 2 + 1]);  // (all of the tile's quotes, also those in front of the first line)
+  const uint32_t qinc = wave_scan_add(qc);
+  if (lane == 63) { wcnt[wv] = cinc; wqc[wv] = qinc; }
+  if (__any(bad != 0) && lane == 0) misc[1] = 1u;
+  __syncthreads();
+
+  uint32_t cpre = 0, ctot = 0;
+  for (int i = 0; i < CT_THREADS / 64; i++) { const uint32_t x = wcnt[i]; if (i < wv) cpre += x; ctot += x; }
+  const uint32_t nfe = ctot & 0xFFFFu, nr = ctot >> 16;
+  if (misc[1] || nfe > (uint32_t)CT_FCAP || nr != nlines) { give_up(); return; }  // uniform: LDS flags were written before the barrier
+  const uint32_t frs = misc[0];
+  if (p.ablate == 3) { if (fe[0] + fe[1] + fe[2] + fe[3] == 0xFFFFFFFFu) p.err[0] = 1; return; }
+
+  // ---- index: one sweep over this thread's field ends, two chunks (32 bytes) per loop ----
+  {
+    const uint32_t cex = cpre + cinc - cnt;
+    uint32_t k = cex & 0xFFFFu;
+#pragma unroll
+    for (int h = 0; h < CT_CPT; h += 2) {
+      uint32_t m = fe[h] | (fe[h + 1] << 16);
+      const uint32_t nlh = nl[h] | (nl[h + 1] << 16);
+      const uint32_t cpos = (uint32_t)(base_chunk + h) * 16;
+      if (nlh) {  // the rare '\n's: which ordinals end a line; the first of the tile gives NF
+        uint32_t mm = nlh, j = (cex >> 16) + (h ? (uint32_t)__popc(nl[0] | (nl[1] << 16)) : 0u);
+        while (mm) {
+          const uint32_t b = (uint32_t)__ffs((int)mm) - 1; mm &= mm - 1;
+          const uint32_t kk = k + (uint32_t)__popc(m & ((2u << b) - 1u));  // = ordinal + 1
+          atomicOr(&nlbits[kk >> 5], 1u << (kk & 31));
+          if (j == 0) misc[2] = kk;
+          j++;
+        }
+      }
+      while (m) {
+        const uint32_t b = (uint32_t)__ffs((int)m) - 1; m &= m - 1;
+        fposx[++k] = (uint16_t)(cpos + b);
+      }
+    }
+    if (tid == 0) fposx[0] = (uint16_t)(frs - 1);
+    for (uint32_t i = tid; i < nr; i += CT_THREADS) slowf[i] = 0;
+    uint32_t qb = qinc - qc;
+    for (int i = 0; i < wv; i++) qb += wqc[i];
+    qpre[tid * 2] = (uint16_t)qb; qpre[tid * 2 + 1] = (uint16_t)(qb + qlo);
+    if (tid == CT_THREADS - 1) qpre[CT_BYTES / 32] = (uint16_t)(qb + qc);
+  }
+  __syncthreads();
+  if (p.ablate == 4) return;
+  const uint32_t NF = misc[2];  // fields of the first line; every line must have as many
+  if (NF < 2 || NF < (uint32_t)p.nfields_used || nr * NF > nfe) { give_up(); return; }  // uniform.  (A lone "\n" is a line of no fields, reader.go:146-150.)
+  for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
+    const uint32_t idx = (jj + 1) * NF;
+    if (idx > nfe || !((nlbits[idx >> 5] >> (idx & 31)) & 1u)) misc[1] = 1u;  // read after the next barrier; until then the cells are computed optimistically
+  }
+
+  // ---- cells, run by run: a run is a set of columns of one kind and width, its items (column, line) with lines
+  //      fastest, so that column stores are coalesced; 64 items are one slot, and the slots of all runs are dealt
+  //      round-robin to the waves ----
+  {
+    RegTile t;
+    t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.slowf = slowf; t.colp0 = colp0; t.colp1 = colp1; t.colfield = colfield;
+    t.nr = nr; t.NF = NF; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
+    t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0;
+    uint32_t sbase = 0;
+    for (int ri = 0; ri < p.nruns; ri++) {
+      const CsvRun run = p.runs[ri];
+      const uint32_t items = (uint32_t)run.ncols * nr, nslots = (items + 63) >> 6;
+      if (p.ablate >= 10) {  // 10: no cells; 11: integer runs only; 12: text runs only; 13: date / timestamp runs only
+        const int grp = (run.kind == CK_INT || run.kind == CK_UINT) ? 11 : run.kind == CK_STR ? 12 : 13;
+        if (p.ablate != grp) { sbase += nslots; continue; }
+      }
+      switch (run.kind) {
+        case CK_INT:
+          if (run.width == 1) reg_cells_int<CK_INT, 1>(t, run, sbase, wv, lane); else if (run.width == 2) reg_cells_int<CK_INT, 2>(t, run, sbase, wv, lane);
+          else if (run.width == 4) reg_cells_int<CK_INT, 4>(t, run, sbase, wv, lane); else reg_cells_int<CK_INT, 8>(t, run, sbase, wv, lane);
+          break;
+        case CK_UINT:
+          if (run.width == 1) reg_cells_int<CK_UINT, 1>(t, run, sbase, wv, lane); else if (run.width == 2) reg_cells_int<CK_UINT, 2>(t, run, sbase, wv, lane);
+          else if (run.width == 4) reg_cells_int<CK_UINT, 4>(t, run, sbase, wv, lane); else reg_cells_int<CK_UINT, 8>(t, run, sbase, wv, lane);
+          break;
+        case CK_STR: reg_cells_str(t, run, sbase, wv, lane); break;
+        case CK_DATE: reg_cells_time<CK_DATE>(t, run, sbase, wv, lane); break;
+        case CK_TIMESTAMP: reg_cells_time<CK_TIMESTAMP>(t, run, sbase, wv, lane); break;
+        default:
+          for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
+            const uint32_t it = (s - sbase) * 64 + (uint32_t)lane;
+            if (it >= items) continue;
+            const uint32_t oi = it / nr, jj = it - oi * nr;
+            const int32_t r = t.row0 + (int32_t)jj;
+            if (r < 0) continue;
+            if (run.kind < 0) {  // DefaultValue columns (ColSchema.Path < 0)
+              const TCol tc = p.tcols[run.first + oi];
+              CsvCol c{}; c.kind = tc.kind; c.width = tc.width; c.values = tc.p0; c.nanos = (int32_t *)tc.p1; c.lens = (uint32_t *)tc.p0; c.fstart = (uint32_t *)tc.p1;
+              store_default(c, r);
+            } else slowf[jj] = 1;  // bool, float32, json.Number, interval cells: the per-row path carries their rules
+          }
+      }
+      sbase += nslots;
+    }
+    // ---- sanitizeElement also runs on fields no column reads: anything but a plain field flags the line ----
+    if (p.has_unmapped || NF != (uint32_t)p.nfields_used) {
+      const uint32_t tot2 = nr * NF;
+      const uint32_t inv_nf = 0xFFFFFFFFu / NF + 1;
+      for (uint32_t it = tid; it < tot2; it += CT_THREADS) {
+        uint32_t jj = __umulhi(it, inv_nf);
+        uint32_t f = it - jj * NF;
+        if (f >= NF) { jj++; f -= NF; }
+        if (t.row0 + (int32_t)jj < 0) continue;
+        if (f < (uint32_t)p.nfields_used && p.field_first[f] >= 0) continue;  // judged by its column
+        const uint32_t fs = (uint32_t)fposx[it] + 1, fend = fposx[it + 1];
+        if (fend > fs && !(starts_plain(sb, fs, fend, sb[fs], o.quote) && ends_plain(sb, fs, fend, sb[fend - 1], o.quote) && !any_quote(qmask, fs, fend))) slowf[jj] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (misc[1]) { give_up(); return; }  // some line has another number of fields: nothing of the above counts
+  // ---- per line: clean, or handed to the per-row path ----
+  for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
+    const int64_t r = (int64_t)line0 + jj - p.skip_rows;
+    if (r < 0) continue;
+    if (slowf[jj] || p.null_checks) {
+      const uint32_t slot = atomicAdd(p.slow_n, 1u);
+      p.slow_row[slot] = line0 + jj;
+      p.slow_end[slot] = (uint32_t)(g0 + fposx[(jj + 1) * NF]);
+    } else p.err[r] = 0;
+  }
+  // one past the last '\n' of the chunk: only the tile that owns the last line has it (30 000 atomics on one word are not free)
+  if (tid == 0 && p.tile_base[tile + 1] == p.tile_base[p.ntiles]) atomicMax(p.last_end, (uint32_t)(g0 + fposx[nr * NF] + 1));
+}
+
 // rows that failed contribute no string bytes
 __global__ void csv_zero_err_lens(const uint8_t *err, int64_t nrows, const CsvCol *cols, int32_t ncols) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1332,6 +1818,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   const int64_t slow_cap = (int64_t)nlines + 5 * ntiles + 8;  // every line at most once, plus long / over-wide ones per tile
   Buf slow = dalloc((size_t)(2 * slow_cap + 2) * 4);
   TF_HIP(hipMemsetAsync(slow->p, 0, 8, st));
+  Buf gen = dalloc_zero((size_t)(ntiles + 2) * 4);  // [0] = count, then the tiles
   CsvParams pp;
   std::memset(&pp, 0, sizeof pp);
   pp.data = data; pp.len = len; pp.row_start = rs; pp.nrows = nrows;
@@ -1347,6 +1834,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.err = ptr<uint8_t>(err); pp.err_col = ptr<int32_t>(err_col); pp.nerr = ptr<uint32_t>(nerr);
   static const int ablate = [] { const char *e = std::getenv("TFGPU_CSV_ABLATE"); return e ? std::atoi(e) : 0; }();
   pp.ablate = ablate;
+  static const bool force_general = [] { const char *e = std::getenv("TFGPU_CSV_GENERAL"); return e && e[0] == '1'; }();
+  pp.gen_n = ptr<uint32_t>(gen); pp.gen_tile = ptr<uint32_t>(gen) + 1; pp.force_general = force_general ? 1 : 0;
   pp.has_unmapped = 0;
   for (int f = 0; f <= max_field; f++) if (field_first[(size_t)f] < 0) pp.has_unmapped = 1;
   std::vector<int32_t> order((size_t)ncols);
@@ -1366,19 +1855,35 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   }
   Buf btcols = up(tcols.data(), tcols.size() * sizeof(TCol));
   pp.tcols = ptr<TCol>(btcols);
+  std::vector<CsvRun> runs;
+  for (int i = 0; i < ncols; i++) {
+    const TCol &t = tcols[(size_t)i];
+    const int kind = t.field < 0 ? -1 : (int)t.kind, width = t.field < 0 ? 0 : (int)t.width;
+    if (!runs.empty() && runs.back().kind == kind && runs.back().width == width && runs.back().first + runs.back().ncols == i) runs.back().ncols++;
+    else runs.push_back(CsvRun{kind, width, i, 1});
+  }
+  Buf bruns = up(runs.data(), runs.size() * sizeof(CsvRun));
+  pp.runs = ptr<CsvRun>(bruns); pp.nruns = (int32_t)runs.size();
   pp.null_checks = (opts->strings_can_be_null || opts->quoted_strings_can_be_null) ? 1 : 0;
 
   // QuoteChar == 0 and the data holds '"' → errQuotingDisabled for that line (reader.go:182-184):
   // the state machine cannot see it (quote disabled), so treat '"' as an error marker via the quote path
   if (opts->quote_char == 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: QuoteChar=0 (quoting disabled) is not device-resident yet");
 
+  if (ablate) {  // profiling only: what the skipped phases would have written must not be garbage
+    TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)std::max(nstr, 1) * (size_t)seg_stride * 4, st));
+    TF_HIP(hipMemsetAsync(fstart_all->p, 0, (size_t)std::max(nstr, 1) * (size_t)fstride * 4, st));
+    TF_HIP(hipMemsetAsync(err->p, 0, (size_t)nrows + 16, st));
+    for (auto &d : db->cols) { if (d.values) TF_HIP(hipMemsetAsync(d.values->p, 0, d.values->bytes, st)); if (d.nanos) TF_HIP(hipMemsetAsync(d.nanos->p, 0, d.nanos->bytes, st)); }
+  }
   if (nrows && rowpath) {
     KernelTimer t("csv_parse_rows");
     csv_parse_rows<<<blocks_for(nrows, 256), 256, 0, st>>>(pp);
   } else if (nlines) {
     // header lines are parsed by nobody: err[] of the data rows is written by exactly one of the two kernels
     const int64_t per_xcd = (ntiles + 7) / 8;
-    { KernelTimer t("csv_parse_tiles"); csv_parse_tiles<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
+    { KernelTimer t("csv_parse_tiles"); csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
+    { KernelTimer t("csv_parse_tiles_general"); csv_parse_tiles_general<<<(unsigned)std::min<int64_t>(ntiles, 2048), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 8192), 64, 0, st>>>(pp); }
   }
   if (nrows && nstr) {
@@ -1394,6 +1899,13 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   const uint32_t *hsum = d2h_u32(summary->p, (size_t)(2 * nstr) + 2);
   tf::sync();
   const uint32_t hnerr = hsum[0], last = hsum[1];
+  static const bool debug = [] { const char *e = std::getenv("TFGPU_CSV_DEBUG"); return e && e[0] == '1'; }();
+  if (debug && !rowpath) {  // how the tiles and lines were routed
+    uint32_t g = 0, sl = 0;
+    d2h(&g, gen->p, 4); d2h(&sl, slow->p, 4);
+    tf::sync();
+    std::fprintf(stderr, "tfgpu csv: %lld tiles, %u general; %u lines, %u per-row\n", (long long)ntiles, g, nlines, sl);
+  }
 
   // ---- string payloads: offsets are views into the scanned lens array.  The tile path leaves the cells where they
   //      are: a text column is (offsets, where each cell sits in the source text) until someone needs it packed
