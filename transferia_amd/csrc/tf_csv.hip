@@ -1065,11 +1065,13 @@ __device__ __forceinline__ bool any16(const Chunk16 &c, uint32_t pat4) {
   return ((ne_bytes(c, 0, pat4) & ne_bytes(c, 1, pat4) & ne_bytes(c, 2, pat4) & ne_bytes(c, 3, pat4)) & 0x80808080u) != 0x80808080u;
 }
 
+static constexpr int CR_FCAP = 4608;   // field ends the regular kernel indexes per tile (28 KiB of single-digit fields would be 14 000; hits averages 3 800)
+static constexpr int CR_LCOLS = 128;   // columns whose descriptors it stages in LDS
 struct CsvRun { int32_t kind, width, first, ncols; };  // consecutive tcols of one (kind, width); kind -1: DefaultValue columns (no field)
 
 // what the cell loops of csv_parse_regular share
 struct RegTile {
-  const uint8_t *sb; const uint16_t *fposx; const uint32_t *qmask; const uint16_t *qpre; uint32_t *slowf; const uint64_t *colp0, *colp1; const uint16_t *colfield;
+  const uint8_t *sb; const uint16_t *fposx; const uint32_t *qmask; const uint16_t *qpre; uint8_t *slowf; const uint64_t *colp0, *colp1; const uint16_t *colfield;
   uint32_t nr, NF; float inv_nr; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote;
 };
 // one cell of a run: item → (column, line), its output row and its byte range [fs, fend) in the tile
@@ -1239,14 +1241,14 @@ template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile
 __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) {
   static_assert(CT_SPILL == 64 * CT_CPT * 16, "the look-behind window is exactly wave 0's bytes");
   __shared__ __attribute__((aligned(16))) uint8_t sbuf[16 + CT_BYTES + 48];
-  __shared__ uint16_t fposx[CT_FCAP + 2];    // [k + 1] = end of field k; [0] = first line's start - 1
+  __shared__ uint16_t fposx[CR_FCAP + 2];    // [k + 1] = end of field k; [0] = first line's start - 1
   __shared__ uint32_t qmask[CT_BYTES / 32];  // bitmap of quote characters
-  __shared__ uint32_t nlbits[(CT_FCAP + 32) / 32];  // bit k + 1: field k ends its line
+  __shared__ uint32_t nlbits[(CR_FCAP + 32) / 32];  // bit k + 1: field k ends its line
   __shared__ uint16_t qpre[CT_BYTES / 32 + 2];      // quote characters in front of each 32-byte word
   __shared__ uint32_t wqc[CT_THREADS / 64];
-  __shared__ uint32_t slowf[CT_RCAP];        // line needs the per-row path
-  __shared__ uint64_t colp0[CT_LCOLS], colp1[CT_LCOLS];
-  __shared__ uint16_t colfield[CT_LCOLS];
+  __shared__ uint8_t slowf[CT_RCAP];         // line needs the per-row path
+  __shared__ uint64_t colp0[CR_LCOLS], colp1[CR_LCOLS];
+  __shared__ uint16_t colfield[CR_LCOLS];
   __shared__ uint32_t wpar[CT_THREADS / 64];
   __shared__ uint32_t wcnt[CT_THREADS / 64];
   __shared__ uint32_t misc[4];               // 0: first line's start, 1: tile is not regular, 2: NF
@@ -1263,7 +1265,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   const CsvOpts &o = p.o;
   const int64_t g0 = tile * CT_T - CT_SPILL;  // absolute offset of sb[0]
   auto give_up = [&]() { if (tid == 0) { const uint32_t slot = atomicAdd(p.gen_n, 1u); p.gen_tile[slot] = (uint32_t)tile; } };
-  if (p.force_general || nlines > (uint32_t)CT_RCAP || p.ncols > CT_LCOLS) { give_up(); return; }
+  if (p.force_general || nlines > (uint32_t)CT_RCAP || p.ncols > CR_LCOLS) { give_up(); return; }
 
   // ---- stage: coalesced 16 B/lane ----
   if (g0 >= 0 && (uint64_t)(g0 + CT_BYTES) <= p.len) {
@@ -1286,7 +1288,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   for (int i = tid; i < p.ncols; i += CT_THREADS) { const TCol tc = p.tcols[i]; colp0[i] = (uint64_t)tc.p0; colp1[i] = (uint64_t)tc.p1; colfield[i] = (uint16_t)tc.field; }
   if (tid < 4) misc[tid] = 0;
   if (tid < 12) reinterpret_cast<uint32_t *>(sbuf + 16 + CT_BYTES)[tid] = 0;  // the bytes past the tile that cell windows may touch
-  for (int i = tid; i < (CT_FCAP + 32) / 32; i += CT_THREADS) nlbits[i] = 0;
+  for (int i = tid; i < (CR_FCAP + 32) / 32; i += CT_THREADS) nlbits[i] = 0;
   __syncthreads();
   if (p.ablate == 1) return;  // (TFGPU_CSV_ABLATE, profiling only: leave after phase n; results are not valid)
 
@@ -1369,7 +1371,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   uint32_t cpre = 0, ctot = 0;
   for (int i = 0; i < CT_THREADS / 64; i++) { const uint32_t x = wcnt[i]; if (i < wv) cpre += x; ctot += x; }
   const uint32_t nfe = ctot & 0xFFFFu, nr = ctot >> 16;
-  if (misc[1] || nfe > (uint32_t)CT_FCAP || nr != nlines) { give_up(); return; }  // uniform: LDS flags were written before the barrier
+  if (misc[1] || nfe > (uint32_t)CR_FCAP || nr != nlines) { give_up(); return; }  // uniform: LDS flags were written before the barrier
   const uint32_t frs = misc[0];
   if (p.ablate == 3) { if (fe[0] + fe[1] + fe[2] + fe[3] == 0xFFFFFFFFu) p.err[0] = 1; return; }
 

@@ -511,6 +511,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   const int32_t *sp = ptr<int32_t>(sel);
   unsigned g = grid_for(m, 256);
   KernelTimer t("compact_gather");
+  static const bool eager_text = [] { const char *e = std::getenv("TFGPU_CSV_EAGER"); return e && e[0] == '1'; }();
   std::vector<GFix> fx; std::vector<GVar> vr; std::vector<size_t> var_cols; std::vector<GBit> bits;
   // ColumnValues and OldKeys columns move the same way; `all` lists them in that order
   const size_t ncur = in.cols.size(), nall = ncur + in.old_keys.size();
@@ -528,9 +529,21 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
     if (repr_is_var(c.repr)) {
       size_t si = vr.size();
       o.offsets = subbuf(lens_all, si * (size_t)seg_stride * 4, (size_t)(m + 1) * 4);
-      o.data = dalloc(c.data_len + 8);  // the source size bounds the kept payload; exact length read back below
+      if (!c.lazy() || eager_text) o.data = dalloc(c.data_len + 8);  // the source size bounds the kept payload; exact length read back below
       o.data_len = c.data_len;
-      if (c.lazy()) {  // kept cells come straight from the source text
+      if (c.lazy() && !eager_text) {
+        // A kept row keeps pointing INTO the source text, as the kept ChangeItem's Go strings keep aliasing the chunk they
+        // were cut from (filter_rows.go:99-125 appends the item, it copies no string bytes): the compacted column is again
+        // (offsets, position of each cell in the text), packed when — and if — a consumer reads its bytes.
+        if (!c.view->src) throw Error(TFGPU_ERR_INVALID, "internal: text column " + c.name + " lost its source text");
+        auto v = std::make_shared<TextView>();
+        v->src = c.view->src; v->fstart = dalloc((size_t)std::max<int64_t>(m, 1) * 4);
+        v->has_special = c.view->has_special; v->quote = c.view->quote; v->jsonnum = c.view->jsonnum;
+        fx.push_back(GFix{c.view->fstart->p, v->fstart->p, 4, 0});
+        o.view = std::move(v);
+        o.data = nullptr;
+        vr.push_back(GVar{ptr<uint32_t>(c.offsets), nullptr, ptr<uint32_t>(o.offsets), nullptr, nullptr, 0, 0, 0});
+      } else if (c.lazy()) {  // TFGPU_CSV_EAGER=1: kept cells are packed now, straight from the source text
         if (!c.view->src) throw Error(TFGPU_ERR_INVALID, "internal: text column " + c.name + " lost its source text");
         vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.view->src), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), ptr<uint32_t>(c.view->fstart), c.view->quote, c.view->jsonnum ? 1u : 0u, c.view->has_special ? 1u : 0u});
       } else vr.push_back(GVar{ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.payload()), ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), nullptr, 0, 0, 0});
@@ -563,7 +576,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), m, nvar, seg_stride);
     if (m) {  // long cells: short runs of rows; short cells: long runs (the fixed latency of a run needs bytes to amortise over)
       std::vector<GVar> lng, sht;
-      for (size_t i = 0; i < vr.size(); i++) ((col_at(var_cols[i]).data_len >= (uint64_t)in.nrows * 8) ? lng : sht).push_back(vr[i]);
+      for (size_t i = 0; i < vr.size(); i++) if (vr[i].out_data) ((col_at(var_cols[i]).data_len >= (uint64_t)in.nrows * 8) ? lng : sht).push_back(vr[i]);
       Buf blng = upload_small(lng.data(), lng.size() * sizeof(GVar)), bsht = upload_small(sht.data(), sht.size() * sizeof(GVar));
       if (!lng.empty()) gather_bytes_all<1><<<dim3(grid_for(m, 256), (unsigned)lng.size()), 256, 0, st>>>(ptr<GVar>(blng), sp, m);
       if (!sht.empty()) gather_bytes_cells<<<dim3(grid_for(m, 256), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
