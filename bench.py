@@ -1,22 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — ClickBench-hits CSV parse → mask(ClientIP) + filter(EventDate) → devnull.
+"""bench.py — the transform-stage hot path on ClickBench-hits-shaped batches, one MI355X per rank.
 
-The workload is BASELINE.json configs[1] ("ClickBench hits-1M CSV parse →
-mask(ip)+filter(EventDate) → devnull, 1×MI355X").  One *step* is one pass of
-that hot path over one HBM-resident batch of 2^20 synthetic hits rows per GPU.
-Rows shard by range across ranks with no data-path collective (weak scaling:
-every rank parses its own 2^20-row batch); torch.distributed is used only for
-the barrier and the max-over-ranks timing.
+Default workload = BASELINE.json configs[1] ("ClickBench hits-1M CSV parse → mask(ip)+filter(EventDate) → devnull,
+1×MI355X"): one *step* is one pass of that path over one HBM-resident batch of 2^20 synthetic hits rows per GPU.
+Rows shard by range across ranks with no data-path collective (weak scaling: every rank works on its own batch);
+torch.distributed (nccl = RCCL) is used for the barrier and the max-over-ranks timing — and, in configs[4] only,
+for the one real exchange of the path (hash-partition all-to-all).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py [--workload csv|configs2|configs3|configs4|json|sr|collapse] --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" explains every field).  Every workload reports
+`roofline` (dominant kernel: algorithmic bytes per launch ÷ its HIP-event launch time, against the 8 TB/s HBM peak)
+and `cpu_baseline` (the oracle — a C restatement of the Go reference — on a bounded sample of the same input).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,17 +27,24 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+INT32_PEAK_TOPS = 39.3    # 256 CUs x 64 lanes x 2.4 GHz, one 32-bit integer VALU op per lane per clock (same guide)
+# mask_field per value: HMAC-SHA256 with cached ipad / opad midstates = 2 compressions of 64 rounds; a round is
+# Sigma1 (5) + Ch (3) + Sigma0 (5) + Maj (3) + 7 adds, the message schedule sigma0 + sigma1 + 3 adds (13) for 48 of the
+# 64 rounds: ~33 int32 ops per round -> 2 x 64 x 33 = 4224, plus ~180 for the decimal text and the 64 hex characters
+MASK_INT_OPS_PER_VALUE = 4400
 
-CHAIN = [
-    ("mask_field", {"maskFunctionHash": {"userDefinedSalt": "clickbench-salt"}, "columns": ["clientip"]}),
-    ("filter_rows", {"filter": "eventdate >= 2013-07-15"}),
-]
+MASK = ("mask_field", {"maskFunctionHash": {"userDefinedSalt": "clickbench-salt"}, "columns": ["clientip"]})
+CHAIN = [MASK, ("filter_rows", {"filter": "eventdate >= 2013-07-15"})]
+JSON_CHAIN = [MASK, ("filter_rows", {"filter": "regionid >= 40"})]
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# inputs
+# ----------------------------------------------------------------------------------------------------------------
 def stage_shard(lib, workload, row0, nrows, chunk_rows=1 << 15):
-    """Generate rows [row0,row0+nrows) chunk by chunk into one reused host buffer and
-    assemble the CSV (header + rows) in HBM.  Returns (DeviceBuffer, nbytes)."""
+    """Generate rows [row0,row0+nrows) chunk by chunk into one reused host buffer and assemble the CSV (header +
+    rows) in HBM.  Returns (DeviceBuffer, nbytes, stream)."""
     hs = workload.HitsStream(chunk_rows=chunk_rows)
     sizes, r = [], row0
     while r < row0 + nrows:  # first pass: sizes only (the generator is deterministic)
@@ -55,10 +64,6 @@ def stage_shard(lib, workload, row0, nrows, chunk_rows=1 << 15):
     return dbuf, total, hs
 
 
-JSON_CHAIN = [("mask_field", {"maskFunctionHash": {"userDefinedSalt": "clickbench-salt"}, "columns": ["clientip"]}),
-         ("filter_rows", {"filter": "regionid >= 40"})]
-
-
 def json_fields(workload, abi):
     """The hits schema as a generic-parser field list: date → utf8 text, timestamps → datetime (epoch seconds)."""
     out = []
@@ -68,464 +73,766 @@ def json_fields(workload, abi):
     return abi.Schema.of(out)
 
 
-def make_messages(workload, abi, nrows):
+def make_messages(workload, nrows, row0=0):
+    """One flat JSON object per hits row (ints as numbers, timestamps as epoch seconds, the rest as text)."""
+    import calendar
     import csv
+    import datetime
     import io
     cols = workload.hits_columns()
-    data = workload.hits_csv(nrows)
-    vals = []
-    rd = csv.reader(io.StringIO(data.decode("utf-8")))
-    next(rd)  # header
-    for row in rd:
-        doc = {}
-        for (name, typ, _), cell in zip(cols, row):
-            if typ in ("int16", "int32", "int64"):
-                doc[name] = int(cell)
-            elif typ == "timestamp":  # epoch seconds, the form extractTimeValue takes without dateparse
-                if cell.lstrip("-").isdigit():
+    hs = workload.HitsStream(chunk_rows=min(max(nrows, 1), 1 << 15))
+    vals, r = [], row0
+    while r < row0 + nrows:
+        k = min(hs.chunk_rows, row0 + nrows - r)
+        buf, n = hs.chunk(r, k)
+        rd = csv.reader(io.StringIO(bytes(buf[:n]).decode("utf-8")))
+        for row in rd:
+            doc = {}
+            for (name, typ, _), cell in zip(cols, row):
+                if typ in ("int16", "int32", "int64"):
                     doc[name] = int(cell)
+                elif typ == "timestamp":  # epoch seconds, the form extractTimeValue takes without dateparse
+                    if cell.lstrip("-").isdigit():
+                        doc[name] = int(cell)
+                    else:
+                        doc[name] = calendar.timegm(datetime.datetime.strptime(cell[:19].replace("T", " "), "%Y-%m-%d %H:%M:%S").timetuple())
                 else:
-                    import calendar
-                    import datetime
-                    doc[name] = calendar.timegm(datetime.datetime.strptime(cell[:19].replace("T", " "), "%Y-%m-%d %H:%M:%S").timetuple())
-            else:
-                doc[name] = cell
-        vals.append(json.dumps(doc, ensure_ascii=False, separators=(",", ":")).encode("utf-8"))
+                    doc[name] = cell
+            vals.append(json.dumps(doc, ensure_ascii=False, separators=(",", ":")).encode("utf-8"))
+        r += k
     return vals
 
 
-def json_main(args):
-    """--workload json: BASELINE.json configs[2] shape as a SIDE benchmark (the driver's line is the CSV workload):
-    Kafka-style JSON messages (one flat hits object per message) → generic JSON parser on device → mask + filter →
-    ClickHouse JSONEachRow text, all HBM-resident; the oracle's generic parser on a bounded sample as cpu_baseline."""
-    import csv
-    import io
-    args.rows = min(args.rows, 1 << 18)
-    args.cpu_rows = min(args.cpu_rows, 1 << 13)
-    from transferia_amd import abi, lib, workload
-    lib.init(0)
-    fields = json_fields(workload, abi)
-    vals = make_messages(workload, abi, args.rows)
-    rows = len(vals)
-    data, msgs = abi.messages(vals, list(range(rows)), [1_700_000_000_000_000_000 + i for i in range(rows)])
-    opts = abi.json_options(topic="hits", add_dedupe_keys=True, add_rest=True, partition='{"partition":0,"topic":"hits"}')
-    dbuf = lib.DeviceBuffer.upload(data)
-    plans = [lib.Transformer(t, c) for t, c in JSON_CHAIN]
-    state = {}
+def host_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count() or 1, "cpu_model": model}
 
-    def step(keep=False):
-        db, errs = lib.json_parse(opts, fields, dbuf, msgs)
-        res = lib.apply_chain(plans, db)
+
+def run_threads(fn, parts):
+    """fn(part) on one thread per part (the oracle runs inside ctypes calls, which drop the GIL); returns wall seconds."""
+    errs = []
+
+    def w(p):
+        try:
+            fn(p)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=w, args=(p,)) for p in parts]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    if errs:
+        raise errs[0]
+    return dt
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# workloads: setup() stages inputs in HBM (untimed), step() is one pass, alg() the algorithmic bytes per step of each
+# kernel (SURVEY §8d per-row figures x rows), cpu() the oracle on a bounded sample
+# ----------------------------------------------------------------------------------------------------------------
+class Base:
+    metric = ""
+    scaling = "weak"
+
+    def __init__(self, args, env):
+        self.args, self.env, self.state = args, env, {}
+
+    def extra(self):
+        return {}
+
+    def timed(self, steps):
+        """K steps bracketed by barrier + device sync on both sides; returns wall seconds of THIS rank."""
+        e = self.env
+        e.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        e.sync_all()
+        return time.perf_counter() - t0
+
+    def int_roofline(self, kernels):
+        return None
+
+
+class CsvWorkload(Base):
+    """BASELINE.json configs[1]."""
+    metric = "ChangeItems/sec through CSV parse -> mask(ClientIP)+filter(EventDate) -> devnull, ClickBench hits"
+    default_rows = 1 << 20
+
+    def setup(self):
+        e, a = self.env, self.args
+        self.schema = e.workload.hits_schema()
+        self.opts = e.workload.hits_csv_options()
+        self.plans = [e.lib.Transformer(t, c) for t, c in CHAIN]
+        self.row0 = a.rows * e.rank
+        self.dbuf, self.csv_bytes, _ = stage_shard(e.lib, e.workload, self.row0, a.rows)
+        self.nl = 1
+
+    def step(self, keep=False, buf=None):
+        lib = self.env.lib
+        db, consumed, errs = lib.csv_parse(self.opts, self.schema, buf if buf is not None else self.dbuf)
+        res = lib.apply_chain(self.plans, db)
+        if keep:
+            s = self.state
+            s["parsed_rows"], s["parsed_bytes"] = db.nrows, db.payload_bytes()
+            v = db.view()
+            fixed = strb = 0
+            for i in range(v.ncols):
+                c = v.cols[i]
+                if c.repr in (12, 13, 14, 15):
+                    strb += int(c.data_len)
+                else:
+                    fixed += int(v.nrows) * (np.dtype(lib.abi.REPR_NP[c.repr]).itemsize + (4 if c.nanos else 0))
+            s["fixed_bytes"], s["str_bytes"], s["nstr"] = fixed, strb, sum(1 for i in range(v.ncols) if v.cols[i].repr in (12, 13, 14, 15))
+            s["out_rows"], s["out_bytes"] = res.transformed.nrows, res.transformed.payload_bytes()
+            s["errors"] = len(errs) + len(res.errors)
+        res.transformed.free()
+        db.free()  # devnull sink
+
+    def rows(self):
+        return self.state["parsed_rows"]
+
+    # the K timed steps, spread round-robin over `lanes` host threads, each bound to its own device lane (stream + HBM
+    # cache) and reading its own HBM-resident copy of the shard; lanes = 1 is the strictly serial bench line
+    def timed(self, steps, nlanes=None, host_bufs=None):
+        e, a = self.env, self.args
+        nl = max(1, min(nlanes or a.lanes, steps, e.lib.lane_count()))
+        go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
+        lane_err = []
+
+        def lane_main(k):
+            try:
+                e.lib.lane_use(k)
+                if host_bufs is not None:
+                    buf = host_bufs[k]
+                else:
+                    buf = self.dbuf if k == 0 else stage_shard(e.lib, e.workload, self.row0, a.rows)[0]
+                if k or host_bufs is not None:
+                    for _ in range(max(min(a.warmup, 2), 1)):
+                        self.step(buf=buf)
+                e.lib.synchronize()
+                go.wait()
+                for i in range(steps):
+                    if i % nl == k:
+                        self.step(buf=buf)
+                e.lib.synchronize()
+                done.wait()
+            except Exception as ex:  # noqa: BLE001
+                lane_err.append(ex)
+                go.abort(); done.abort()
+
+        threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
+        for t in threads:
+            t.start()
+        e.sync_all()
+        go.wait()
+        t0 = time.perf_counter()
+        done.wait()
+        e.sync_all()
+        dt = time.perf_counter() - t0
+        for t in threads:
+            t.join()
+        if lane_err:
+            raise lane_err[0]
+        e.lib.lane_use(0)
+        self.nl = nl if host_bufs is None and nlanes is None else self.nl
+        return dt
+
+    def alg(self):
+        s = self.state
+        rows, sel = s["parsed_rows"], s["out_rows"] / max(s["parsed_rows"], 1)
+        # compaction: fixed-width values, and for the late-materialised text columns 8 bytes per cell (length + position)
+        gather = int((1 + sel) * (s["fixed_bytes"] + 8 * s["nstr"] * rows))
+        return {"csv_count_newlines": self.csv_bytes, "csv_parse_tiles": self.csv_bytes + s["fixed_bytes"],  # read every input byte once, write every fixed-width value once
+                "csv_parse_rows": self.csv_bytes + s["fixed_bytes"], "csv_copy_words": 2 * s["str_bytes"], "scan_u32_segments": 12 * rows * s["nstr"],
+                "mask_hmac_sha256": 72 * rows,                  # 4 B in + 64 B hex + 4 B offset per value
+                "filter_rows_eval": int((8 + 4 + 0.125) * rows), "compact_gather": gather, "scan_u32": 12 * rows}
+
+    def int_roofline(self, kernels):
+        k = kernels.get("mask_hmac_sha256")
+        if not k:
+            return None
+        ach = MASK_INT_OPS_PER_VALUE * self.state["parsed_rows"] / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
+        return {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s",
+                "frac": round(ach / INT32_PEAK_TOPS, 4), "int_ops_per_value": MASK_INT_OPS_PER_VALUE,
+                "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low"}
+
+    def config(self):
+        s, e = self.state, self.env
+        return {"workload": "ClickBench hits-1M CSV parse -> mask(ip)+filter(EventDate) -> devnull (BASELINE.json configs[1])",
+                "rows_per_gpu_per_step": s["parsed_rows"], "csv_bytes_per_gpu_per_step": self.csv_bytes, "columns": len(self.schema.cols),
+                "chain": [t for t, _ in CHAIN], "filter_selectivity": round(s["out_rows"] / max(s["parsed_rows"], 1), 4),
+                "parallelism": f"row-range shard x{e.world}, no collective"}
+
+    def extra(self):
+        s, e, a = self.state, self.env, self.args
+        out = {"lanes": self.nl}
+        if getattr(self, "dt", None):
+            out["gib_per_s_csv_in"] = round(self.csv_bytes * e.world * a.steps / self.dt / 2**30, 3)
+            out["gib_per_s_deepsizeof"] = round((s["parsed_bytes"] + 16 * len(self.schema.cols) * s["parsed_rows"]) * e.world * a.steps / self.dt / 2**30, 3)
+        return out
+
+    def side_measurements(self):
+        """Never `value`: the same steps over several device lanes, and starting from pinned host memory (PCIe inside)."""
+        e, a = self.env, self.args
+        out = {}
+        k = max(min(a.steps, 60), 3)
+        if a.overlap_lanes > 1 and a.overlap_lanes != a.lanes:
+            dt2 = e.group.max_seconds(self.timed(k, nlanes=a.overlap_lanes))
+            out["overlapped_lanes"] = {"lanes": min(a.overlap_lanes, e.lib.lane_count()), "steps": k, "rows_per_s": round(a.rows * e.world * k / dt2, 1), "ms_per_step": round(dt2 / k * 1e3, 3),
+                                       "note": "the same steps spread over several device lanes (parse of batch N+1 beside the transform of batch N); "
+                                               "kernels of different lanes share the GPU, so per-kernel spans are not comparable"}
+        if a.pcie_steps > 0 and e.rank == 0:
+            raw = self.dbuf.download()
+            res = {}
+            for nl in sorted({1, max(1, min(a.pcie_lanes, e.lib.lane_count()))}):
+                hosts = [e.lib.HostBuffer(raw) for _ in range(nl)]
+                kk = a.pcie_steps * nl
+                dth = self.timed(kk, nlanes=nl, host_bufs=hosts)
+                res[f"lanes_{nl}"] = {"rows_per_s": round(a.rows * kk / dth, 1), "gb_per_s_h2d": round(self.csv_bytes * kk / dth / 1e9, 2), "ms_per_step": round(dth / kk * 1e3, 3)}
+                for h in hosts:
+                    h.free()
+            res["note"] = ("input in pinned host memory (hipHostMalloc), hipMemcpyAsync on each lane's stream inside the step: with several lanes the H2D of "
+                           "one batch runs beside the kernels of another; PCIe Gen5 x16 bounds this at ~55-60 GB/s")
+            out["pcie_inclusive"] = res
+        return out
+
+    def cpu(self):
+        e, a = self.env, self.args
+        from oracle import oracle as ora
+        n1 = a.cpu_rows
+        sample = e.workload.hits_csv(n1)
+        ochain = [ora.Transformer(t, c) for t, c in CHAIN]
+        r1 = ora.csv_parse(self.opts, self.schema, sample, "", "")
+        r2 = ora.apply_chain(ochain, r1.batch, r1.schema)
+        secs = r1.seconds + r2.seconds
+        out = {"value": round(n1 / secs, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{n1} rows of the same synthetic hits CSV: oracle csv parse+strictify ({r1.seconds:.2f}s) + mask+filter ({r2.seconds:.2f}s), "
+                         "single thread = the reference's shape for one table (transformation.go:131-135: one goroutine per table)",
+               "note": "C restatement of the Go reference (row-oriented boxed values), not the Go binary; expect the Go binary to be ~2-3x faster per core "
+                       "(BenchmarkTextFetcher: a 105-column row in ~6 us including parse)"}
+        out.update(host_info())
+        # leg (ii): every host core, the reference's parallelism shape for SEVERAL tables / snapshot parts (one sink pipeline each,
+        # load_snapshot.go:962): independent slices, one oracle pipeline per core
+        nc = out["nproc"]
+        if nc > 1 and a.cpu_all_rows > 0:
+            per = max(a.cpu_all_rows // nc, 1024)
+            slices = [e.workload.hits_csv(per) for _ in range(min(nc, 4))]
+
+            def one(i):
+                c2 = [ora.Transformer(t, c) for t, c in CHAIN]
+                q = ora.csv_parse(self.opts, self.schema, slices[i % len(slices)], "", "")
+                ora.apply_chain(c2, q.batch, q.schema)
+            dt = run_threads(one, list(range(nc)))
+            out["all_cores"] = {"value": round(per * nc / dt, 1), "unit": "rows/s", "cores": nc,
+                                "sample": f"{nc} threads x {per} rows, one parse+mask+filter pipeline per core ({dt:.2f}s wall)"}
+        return out
+
+
+class _Prepared(Base):
+    """Helpers shared by the side workloads: messages staged once, roofline bytes recorded by a keep step."""
+    default_rows = 1 << 18
+
+    def rows(self):
+        return self.n
+
+
+class JsonWorkload(_Prepared):
+    metric = "ChangeItems/sec through Kafka JSON parse -> mask(ClientIP)+filter -> ClickHouse JSONEachRow, ClickBench hits"
+
+    def setup(self):
+        e, a = self.env, self.args
+        abi, lib = e.abi, e.lib
+        self.fields = json_fields(e.workload, abi)
+        self.vals = make_messages(e.workload, a.rows, a.rows * e.rank)
+        self.n = len(self.vals)
+        self.data, self.msgs = abi.messages(self.vals, list(range(self.n)), [1_700_000_000_000_000_000 + i for i in range(self.n)])
+        self.opts = abi.json_options(topic="hits", add_dedupe_keys=True, add_rest=True, partition='{"partition":0,"topic":"hits"}')
+        self.dbuf = lib.DeviceBuffer.upload(self.data)
+        self.plans = [lib.Transformer(t, c) for t, c in JSON_CHAIN]
+
+    def step(self, keep=False):
+        lib, abi = self.env.lib, self.env.abi
+        db, errs = lib.json_parse(self.opts, self.fields, self.dbuf, self.msgs)
+        res = lib.apply_chain(self.plans, db)
         out = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, res.transformed)
         if keep:
-            state.update(parsed=db.nrows, parsed_bytes=db.payload_bytes(), out_rows=res.transformed.nrows, out_bytes=out.size, errors=len(errs) + len(res.errors))
+            self.state.update(parsed_bytes=db.payload_bytes(), out_rows=res.transformed.nrows, out_bytes=out.size, kept_bytes=res.transformed.payload_bytes(),
+                              errors=len(errs) + len(res.errors))
         out.free(); res.transformed.free(); db.free()
 
-    for _ in range(args.warmup):
-        step()
-    step(keep=True)
-    lib.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    lib.synchronize()
-    dt = time.perf_counter() - t0
-    lib.prof_reset(); lib.prof_enable(True)
-    for _ in range(3):
-        step()
-    lib.prof_enable(False)
-    prof = lib.prof_get()
-    kernels = {n: {"launches_per_step": l / 3, "avg_ms": round(ms / l, 4), "ms_per_step": round(ms / 3, 4)} for n, l, ms in prof if l}
-    alg = {"json_parse_lines": len(data) + state["parsed_bytes"], "csv_count_newlines": len(data)}
-    dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
-    roofline = None
-    if dom in alg:
-        ach = alg[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "traffic": None, "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"]}
-    cpu = None
-    if args.cpu_rows > 0:
+    def alg(self):
+        s = self.state
+        return {"json_parse_lines": len(self.data) + s["parsed_bytes"], "csv_count_newlines": len(self.data), "ser_cell_write": s["kept_bytes"] + s["out_bytes"],
+                "ser_cell_len": s["kept_bytes"], "json_copy_cells": 2 * s["parsed_bytes"]}
+
+    def config(self):
+        return {"workload": "Kafka JSON (one flat hits object per message) -> generic parser -> mask+filter -> JSONEachRow (BASELINE.json configs[2] shape, generic-parser flavour)",
+                "rows_per_gpu_per_step": self.n, "json_bytes_per_step": len(self.data), "columns": len(self.fields.cols)}
+
+    def extra(self):
+        s = self.state
+        return {"rows_out_per_step": s["out_rows"], "text_out_bytes_per_step": s["out_bytes"]}
+
+    def cpu(self):
         from oracle import oracle as ora
-        k = min(args.cpu_rows, rows)
-        d2, m2 = abi.messages(vals[:k], list(range(k)), [0] * k)
-        r1 = ora.json_parse(opts, fields, d2, m2, want_rows=False)
-        cpu = {"value": round(k / r1.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+        abi = self.env.abi
+        k = min(self.args.cpu_rows, self.n, 1 << 13)
+        d2, m2 = abi.messages(self.vals[:k], list(range(k)), [0] * k)
+        r1 = ora.json_parse(self.opts, self.fields, d2, m2, want_rows=False)
+        out = {"value": round(k / r1.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
                "sample": f"{k} of the same messages through the oracle's generic JSON parser only ({r1.seconds:.2f}s), single thread",
                "note": "C restatement of the Go reference (fastjson value tree, boxed values per row), not the Go binary"}
-    print(json.dumps({
-        "metric": "ChangeItems/sec through Kafka JSON parse -> mask(ClientIP)+filter -> ClickHouse JSONEachRow, ClickBench hits", "value": round(rows * args.steps / dt, 1),
-        "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "Kafka JSON (one flat hits object per message) -> generic parser -> mask+filter -> JSONEachRow (BASELINE.json configs[2] shape)",
-                   "rows_per_step": rows, "json_bytes_per_step": len(data), "columns": len(fields.cols)},
-        "gib_per_s_json_in": round(len(data) * args.steps / dt / 2**30, 3), "rows_out_per_step": state["out_rows"], "text_out_bytes_per_step": state["out_bytes"],
-        "row_errors": state["errors"], "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
+        out.update(host_info())
+        return out
 
 
-def sr_main(args):
-    """--workload sr: the Confluent-SR half of BASELINE.json configs[2] / [4] as a SIDE benchmark: Kafka messages in the
-    Schema Registry wire format (0x00 | schema id | one flat hits object, JSON schema of the hits table) → tfgpu_sr_json_parse
-    → queue JSON serializer with batching (the "→ Kafka sink" half), all HBM-resident; the oracle on a bounded sample."""
-    args.rows = min(args.rows, 1 << 18)
-    args.cpu_rows = min(args.cpu_rows, 1 << 13)
-    from transferia_amd import abi, confluent_sr, lib, workload
-    lib.init(0)
-    vals = make_messages(workload, abi, args.rows)
-    rows = len(vals)
+def sr_inputs(e, a):
+    """Kafka messages in the Schema Registry wire format: 0x00 | BE schema id | one flat hits object (JSON schema of hits)."""
+    from transferia_amd import confluent_sr
+    vals = make_messages(e.workload, a.rows, a.rows * e.rank)
     jt = {"int16": "integer", "int32": "integer", "int64": "integer", "timestamp": "integer"}
-    props = {name: {"type": jt.get(typ, "string")} for name, typ, _ in workload.hits_columns()}
+    props = {name: {"type": jt.get(typ, "string")} for name, typ, _ in e.workload.hits_columns()}
     schema_text = json.dumps({"type": "object", "title": "default.hits", "properties": props, "required": ["watchid"]})
     sid = 42
     frames = [b"\0" + sid.to_bytes(4, "big") + v for v in vals]
-    data, msgs = abi.messages(frames, list(range(rows)), [1_700_000_000_000_000_000 + i for i in range(rows)])
-    opts = confluent_sr.sr_json_options(sid, schema_text)
-    qopts = abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=1 << 20)
-    dbuf = lib.DeviceBuffer.upload(data)
-    state = {}
+    data, msgs = e.abi.messages(frames, list(range(len(frames))), [1_700_000_000_000_000_000 + i for i in range(len(frames))])
+    return frames, data, msgs, confluent_sr.sr_json_options(sid, schema_text), len(props)
 
-    def step(keep=False):
-        res = lib.sr_json_parse(opts, dbuf, msgs)
-        out = lib.queue_serialize(qopts, res.device_batch)
+
+class SrWorkload(_Prepared):
+    metric = "ChangeItems/sec through Confluent-SR JSON parse -> queue JSON serializer (batched), ClickBench hits"
+
+    def setup(self):
+        e, a = self.env, self.args
+        self.frames, self.data, self.msgs, self.opts, self.ncols = sr_inputs(e, a)
+        self.n = len(self.frames)
+        self.qopts = e.abi.queue_options(e.abi.QFMT_JSON, enabled=True, max_message_size=1 << 20)
+        self.dbuf = e.lib.DeviceBuffer.upload(self.data)
+
+    def step(self, keep=False):
+        lib = self.env.lib
+        res = lib.sr_json_parse(self.opts, self.dbuf, self.msgs)
+        out = lib.queue_serialize(self.qopts, res.device_batch)
         if keep:
-            state.update(parsed=res.device_batch.nrows, parsed_bytes=res.device_batch.payload_bytes(), out_bytes=out.values.size, messages=len(out), errors=len(res.errors))
+            self.state.update(parsed=res.device_batch.nrows, parsed_bytes=res.device_batch.payload_bytes(), out_bytes=out.values.size, messages=len(out), errors=len(res.errors))
         out.values.free(); res.device_batch.free()
 
-    for _ in range(args.warmup):
-        step()
-    step(keep=True)
-    lib.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    lib.synchronize()
-    dt = time.perf_counter() - t0
-    lib.prof_reset(); lib.prof_enable(True)
-    for _ in range(3):
-        step()
-    lib.prof_enable(False)
-    prof = lib.prof_get()
-    kernels = {n: {"launches_per_step": l / 3, "avg_ms": round(ms / l, 4), "ms_per_step": round(ms / 3, 4)} for n, l, ms in prof if l}
-    alg = {"sr_parse_frames": len(data), "sr_cell_values": len(data) + state["parsed_bytes"], "sr_cell_text": 2 * state["parsed_bytes"],
-           "ser_cell_write": state["parsed_bytes"] + state["out_bytes"], "ser_cell_len": state["parsed_bytes"]}
-    dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
-    roofline = None
-    if dom in alg:
-        ach = alg[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "traffic": None, "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"]}
-    cpu = None
-    if args.cpu_rows > 0:
+    def alg(self):
+        s = self.state
+        return {"sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
+                "ser_cell_write": s["parsed_bytes"] + s["out_bytes"], "ser_cell_len": s["parsed_bytes"]}
+
+    def config(self):
+        return {"workload": "Kafka messages in the Schema Registry wire format (one flat hits object each) -> SR JSON parser -> queue JSON serializer, 1 MiB batches "
+                            "(the ingest of BASELINE.json configs[2] and the sink half of configs[4])",
+                "rows_per_gpu_per_step": self.n, "wire_bytes_per_step": len(self.data), "columns": self.ncols}
+
+    def extra(self):
+        s = self.state
+        return {"rows_out_per_step": s["parsed"], "messages_out_per_step": s["messages"], "text_out_bytes_per_step": s["out_bytes"]}
+
+    def cpu(self):
         from oracle import oracle as ora
-        k = min(args.cpu_rows, rows)
-        d2, m2 = abi.messages(frames[:k], list(range(k)), [0] * k)
-        r1 = ora.sr_json_parse(opts, d2, m2)
-        ora.queue_serialize(qopts, r1.batch, r1.schema)
+        abi = self.env.abi
+        k = min(self.args.cpu_rows, self.n, 1 << 13)
+        d2, m2 = abi.messages(self.frames[:k], list(range(k)), [0] * k)
+        r1 = ora.sr_json_parse(self.opts, d2, m2)
+        ora.queue_serialize(self.qopts, r1.batch, r1.schema)
         sec = r1.seconds + ora.queue_serialize.seconds
-        cpu = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+        out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
                "sample": f"{k} of the same messages through the oracle's SR JSON parser ({r1.seconds:.2f}s) + queue JSON serializer ({ora.queue_serialize.seconds:.2f}s), single thread",
                "note": "C restatement of the Go reference (decoded value tree, boxed values per row), not the Go binary"}
-    print(json.dumps({
-        "metric": "ChangeItems/sec through Confluent-SR JSON parse -> queue JSON serializer (batched), ClickBench hits", "value": round(rows * args.steps / dt, 1),
-        "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "Kafka messages in the Schema Registry wire format (one flat hits object each) -> SR JSON parser -> queue JSON serializer, 1 MiB batches "
-                               "(the ingest of BASELINE.json configs[2] and the sink half of configs[4])",
-                   "rows_per_step": rows, "wire_bytes_per_step": len(data), "columns": len(props)},
-        "gib_per_s_wire_in": round(len(data) * args.steps / dt / 2**30, 3), "rows_out_per_step": state["parsed"], "messages_out_per_step": state["messages"],
-        "text_out_bytes_per_step": state["out_bytes"], "row_errors": state["errors"], "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels}))
+        out.update(host_info())
+        return out
 
 
-def collapse_main(args):
-    """--workload collapse: abstract.Collapse (the PK-keyed dedup of BASELINE.json configs[4]) as a SIDE benchmark: a CDC
-    slice (workload.cdc_batch) resident in HBM → tfgpu_collapse; the oracle's restatement of the Go maps as cpu_baseline."""
-    from transferia_amd import lib, workload
-    lib.init(0)
-    b, schema = workload.cdc_batch(args.rows)
-    db = lib.DeviceBatch.upload(b)
-    state = {}
+class Configs2Workload(_Prepared):
+    """BASELINE.json configs[2] as ONE chain: Kafka JSON under a Confluent-SR JSON schema → predicate + casts → ClickHouse
+    JSONEachRow.  The reference's `sql` transformer shells out to clickhouse-local (clickhouse_local.go:97-143); the
+    predicate + cast subset it is asked for here is expressed with the stock transformers that have pinned semantics:
+    filter_rows (predicate), convert_to_string (int64 → text), convert_to_datetime (epoch → datetime; under an SR JSON schema
+    every integer is int64, which that transformer does not take — to_datetime.go:18-21 — so it is in the chain and, exactly as
+    in the reference, not Suitable for this table)."""
+    metric = "ChangeItems/sec through Confluent-SR JSON parse -> filter_rows + convert_to_string (+ convert_to_datetime) -> ClickHouse JSONEachRow, ClickBench hits"
+    CH = [("filter_rows", {"filter": "regionid >= 40"}),
+          ("convert_to_string", {"columns": {"includeColumns": ["^userid$", "^counterid$", "^watchid$"]}, "tables": {}}),
+          ("convert_to_datetime", {"columns": {"includeColumns": ["^eventtime$"]}, "tables": {}})]
 
-    def step(keep=False):
-        out = lib.collapse(db)
+    def setup(self):
+        e, a = self.env, self.args
+        self.frames, self.data, self.msgs, self.opts, self.ncols = sr_inputs(e, a)
+        self.n = len(self.frames)
+        self.dbuf = e.lib.DeviceBuffer.upload(self.data)
+        self.plans = [e.lib.Transformer(t, c) for t, c in self.CH]
+        self.stage = e.lib.Transformation(self.plans)  # transformation.Push: the table plan = the Suitable transformers (transformation.go:46-85)
+
+    def step(self, keep=False):
+        lib, abi = self.env.lib, self.env.abi
+        res = lib.sr_json_parse(self.opts, self.dbuf, self.msgs)
+        db = res.device_batch
+        tr = self.stage.push_run(db)
+        out = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
         if keep:
-            state.update(out_rows=out.nrows)
+            v = db.view()
+            sch = abi.Schema.of([[v.cols[i].name.decode(), abi.DTYPES[v.cols[i].dtype], False] for i in range(v.ncols)])
+            self.state.update(parsed_bytes=db.payload_bytes(), out_rows=tr.transformed.nrows, kept_bytes=tr.transformed.payload_bytes(), out_bytes=out.size,
+                              errors=len(res.errors) + len(tr.errors), table_plan=[self.CH[i][0] for i in self.stage.table_plan((v.table_ns or b"").decode(), (v.table_name or b"").decode(), sch)])
+        for _, eb in tr.error_batches:
+            eb.free()
+        out.free(); tr.transformed.free(); db.free()
+
+    def alg(self):
+        s = self.state
+        return {"sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
+                "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "compact_gather": int(s["parsed_bytes"] + s["kept_bytes"])}
+
+    def config(self):
+        return {"workload": "Kafka JSON (confluent_sr JSON schema, one flat hits object per message) -> predicate (filter_rows) + casts (convert_to_string, convert_to_datetime) "
+                            "-> ClickHouse JSONEachRow (BASELINE.json configs[2])", "rows_per_gpu_per_step": self.n, "wire_bytes_per_step": len(self.data),
+                "columns": self.ncols, "chain": [t for t, _ in self.CH], "table_plan": self.state.get("table_plan")}
+
+    def extra(self):
+        s = self.state
+        return {"rows_out_per_step": s["out_rows"], "text_out_bytes_per_step": s["out_bytes"]}
+
+    def cpu(self):
+        from oracle import oracle as ora
+        abi = self.env.abi
+        k = min(self.args.cpu_rows, self.n, 1 << 13)
+        d2, m2 = abi.messages(self.frames[:k], list(range(k)), [0] * k)
+        r1 = ora.sr_json_parse(self.opts, d2, m2)
+        r2 = ora.apply_chain([ora.Transformer(t, c) for t, c in self.CH], r1.batch, r1.schema)
+        t0 = time.perf_counter()
+        ora.serialize(abi.FMT_CH_JSON_EACH_ROW, r2.batch, r2.schema)
+        ts = time.perf_counter() - t0
+        sec = r1.seconds + r2.seconds + ts
+        out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{k} of the same messages: oracle SR parse ({r1.seconds:.2f}s) + chain ({r2.seconds:.2f}s) + JSONEachRow ({ts:.2f}s), single thread",
+               "note": "C restatement of the Go reference, not the Go binary; the reference parses with GOMAXPROCS goroutines (generic_parser.go:406-438)"}
+        out.update(host_info())
+        return out
+
+
+class Configs3Workload(Base):
+    """BASELINE.json configs[3]: columns delivered as if decoded from Parquet (typed columns resident in HBM; SURVEY §8d allows
+    exactly this) → mask(ClientIP) + sharder-hash(UserID) + casts → ClickHouse JSONEachRow, row-sharded, no collective."""
+    metric = "ChangeItems/sec through mask(ClientIP) + sharder(UserID) + convert_to_string + convert_to_datetime -> ClickHouse JSONEachRow on resident hits columns"
+    default_rows = 1 << 20
+    CH = [MASK, ("sharder_transformer", {"shardsCount": "8", "columns": {"includeColumns": ["^userid$"]}, "tables": {}}),
+          ("convert_to_string", {"columns": {"includeColumns": ["^regionid$", "^counterid$"]}, "tables": {}}),
+          ("convert_to_datetime", {"columns": {"includeColumns": ["^ipnetworkid$"]}, "tables": {}})]
+
+    def setup(self):
+        e, a = self.env, self.args
+        lib = e.lib
+        dbuf, self.csv_bytes, _ = stage_shard(lib, e.workload, a.rows * e.rank, a.rows)
+        db, _, errs = lib.csv_parse(e.workload.hits_csv_options(), e.workload.hits_schema(), dbuf)
+        assert not errs
+        host = db.download()  # packs every column; re-upload = plain resident columns, no reference to the CSV text
+        db.free(); dbuf.free()
+        self.db = lib.DeviceBatch.upload(host)
+        self.n = self.db.nrows
+        self.plans = [lib.Transformer(t, c) for t, c in self.CH]
+
+    def rows(self):
+        return self.n
+
+    def step(self, keep=False):
+        lib, abi = self.env.lib, self.env.abi
+        tr = lib.apply_chain(self.plans, self.db)
+        out = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
+        if keep:
+            self.state.update(in_bytes=self.db.payload_bytes(), out_bytes=out.size, kept_bytes=tr.transformed.payload_bytes(), errors=len(tr.errors))
+        out.free(); tr.transformed.free()
+
+    def alg(self):
+        s = self.state
+        return {"mask_hmac_sha256": 72 * self.n, "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "sharder_crc32": (8 + 4) * self.n,
+                "tostring_write": 2 * 18 * self.n, "todatetime": 12 * self.n}
+
+    def int_roofline(self, kernels):
+        k = kernels.get("mask_hmac_sha256")
+        if not k:
+            return None
+        ach = MASK_INT_OPS_PER_VALUE * self.n / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
+        return {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s", "frac": round(ach / INT32_PEAK_TOPS, 4)}
+
+    def config(self):
+        return {"workload": "hits columns resident in HBM as if decoded from Parquet -> mask + sharder + casts -> ClickHouse JSONEachRow (BASELINE.json configs[3], per-GPU shard)",
+                "rows_per_gpu_per_step": self.n, "columns": 105, "chain": [t for t, _ in self.CH], "parallelism": f"row-range shard x{self.env.world}, no collective"}
+
+    def extra(self):
+        return {"text_out_bytes_per_step": self.state["out_bytes"]}
+
+    def cpu(self):
+        from oracle import oracle as ora
+        e, abi = self.env, self.env.abi
+        k = min(self.args.cpu_rows, self.n, 1 << 16)
+        r1 = ora.csv_parse(e.workload.hits_csv_options(), e.workload.hits_schema(), e.workload.hits_csv(k), "", "")
+        r2 = ora.apply_chain([ora.Transformer(t, c) for t, c in self.CH], r1.batch, r1.schema)
+        t0 = time.perf_counter()
+        ora.serialize(abi.FMT_CH_JSON_EACH_ROW, r2.batch, r2.schema)
+        ts = time.perf_counter() - t0
+        out = {"value": round(k / (r2.seconds + ts), 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{k} rows: oracle chain ({r2.seconds:.2f}s) + JSONEachRow ({ts:.2f}s) on already-typed rows, single thread (one table = one goroutine, transformation.go:131-135)",
+               "note": "C restatement of the Go reference, not the Go binary"}
+        out.update(host_info())
+        return out
+
+
+class Configs4Workload(Base):
+    """BASELINE.json configs[4], from the decoded CDC batch on: hash-partition by key (sharder CRC32 % world → tfgpu_partition →
+    all-to-all over RCCL/xGMI) → Collapse (PK-keyed dedup) → native queue serializer (Kafka-ready messages)."""
+    metric = "ChangeItems/sec through hash-partition (RCCL all-to-all) -> Collapse -> native queue serializer, CDC stream"
+    default_rows = 1 << 20
+
+    def setup(self):
+        e, a = self.env, self.args
+        lib, abi = e.lib, e.abi
+        b, self.schema = e.workload.cdc_batch(a.rows, seed=0x5EED + e.rank)
+        self.n = a.rows
+        self.db = lib.DeviceBatch.upload(b)
+        self.shard = lib.Transformer("sharder_transformer", {"shardsCount": str(e.world), "columns": {"includeColumns": ["^id$"]}, "tables": {}})
+        self.qopts = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 20, table_schema=self.schema)
+        self.meta = abi.row_meta(self.n, ids=np.arange(self.n) % 97, lsns=np.arange(self.n, dtype=np.uint64) + 5, commit_times=np.full(self.n, 1700000000000000000, np.uint64))
+        if e.world > 1 or a.exchange:
+            import torch.distributed as dist
+            if e.world == 1 and not dist.is_initialized():
+                import socket
+                s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=e.device)
+            self.dist = dist
+        else:
+            self.dist = None
+
+    def rows(self):
+        return self.n
+
+    def step(self, keep=False):
+        e = self.env
+        lib = e.lib
+        one = self.shard.apply(self.db).transformed
+        grouped, counts = lib.partition(one, e.world)
+        if self.dist is not None:
+            from transferia_amd import partition
+            back, recv = partition.exchange_device_batch(self.dist, lib, grouped, counts, self.schema)
+            grouped.free()
+        else:
+            back = grouped
+        col = lib.collapse(back)
+        out = lib.queue_serialize(self.qopts, col, self.meta if e.world == 1 else None)
+        if keep:
+            self.state.update(in_bytes=self.db.payload_bytes(), out_rows=col.nrows, out_bytes=out.values.size, messages=len(out))
+        out.values.free(); col.free(); back.free(); one.free()
+
+    def alg(self):
+        s = self.state
+        return {"ser_cell_write": s["in_bytes"] + s["out_bytes"], "compact_gather": 2 * s["in_bytes"], "sharder_crc32": 12 * self.n}
+
+    def config(self):
+        e = self.env
+        return {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys) -> sharder CRC32 % world -> tfgpu_partition -> all-to-all -> Collapse -> "
+                            "native queue serializer (BASELINE.json configs[4] from the decoded batch on)", "rows_per_gpu_per_step": self.n,
+                "exchange": "torch.distributed all_to_all_single over RCCL" if self.dist is not None else "none (1 rank: every row stays)",
+                "parallelism": f"hash-partition x{e.world}"}
+
+    def extra(self):
+        s = self.state
+        return {"rows_out_per_step": s["out_rows"], "messages_out_per_step": s["messages"], "text_out_bytes_per_step": s["out_bytes"]}
+
+    def cpu(self):
+        from oracle import oracle as ora
+        e = self.env
+        k = min(max(self.args.cpu_rows, 1 << 16), self.n, 1 << 18)
+        b2, s2 = e.workload.cdc_batch(k)
+        r1 = ora.collapse(b2, s2)
+        a = r1.batch
+        a.schema = s2
+        meta = e.abi.row_meta(k, ids=np.arange(k) % 97, lsns=np.arange(k, dtype=np.uint64) + 5, commit_times=np.full(k, 1700000000000000000, np.uint64))
+        ora.queue_serialize(self.qopts, a, s2, meta)
+        sec = r1.seconds + ora.queue_serialize.seconds
+        out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"a {k}-row slice of the same stream: oracle Collapse ({r1.seconds:.2f}s) + native serializer ({ora.queue_serialize.seconds:.2f}s), single thread",
+               "note": "C restatement of the Go reference (json.Marshal key strings, string-keyed maps), not the Go binary; context: the reference's own debezium parser "
+                       "benchmark tops out at ~26 k msg/s on 10 cores (multithreadig_test.md)"}
+        out.update(host_info())
+        return out
+
+
+class CollapseWorkload(Base):
+    metric = "ChangeItems/sec through abstract.Collapse (PK-keyed dedup of a CDC batch)"
+    default_rows = 1 << 20
+
+    def setup(self):
+        e, a = self.env, self.args
+        b, self.schema = e.workload.cdc_batch(a.rows)
+        self.n = a.rows
+        self.db = e.lib.DeviceBatch.upload(b)
+
+    def rows(self):
+        return self.n
+
+    def step(self, keep=False):
+        out = self.env.lib.collapse(self.db)
+        if keep:
+            self.state.update(out_rows=out.nrows)
         out.free()
 
-    for _ in range(args.warmup):
-        step()
-    step(keep=True)
-    lib.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    lib.synchronize()
-    dt = time.perf_counter() - t0
-    lib.prof_reset(); lib.prof_enable(True)
-    for _ in range(3):
-        step()
-    lib.prof_enable(False)
-    kernels = {n: {"launches_per_step": l / 3, "avg_ms": round(ms / l, 4), "ms_per_step": round(ms / 3, 4)} for n, l, ms in lib.prof_get() if l}
-    cpu = None
-    if args.cpu_rows > 0:
+    def alg(self):
+        return {}
+
+    def config(self):
+        return {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys, 60% of U/D with OldKeys, 15% of those change the PK) -> Collapse",
+                "rows_per_gpu_per_step": self.n, "rows_out_per_step": self.state["out_rows"]}
+
+    def cpu(self):
         from oracle import oracle as ora
-        k = min(max(args.cpu_rows, 1 << 18), args.rows)
-        b2, s2 = workload.cdc_batch(k)
+        k = min(max(self.args.cpu_rows, 1 << 18), self.n)
+        b2, s2 = self.env.workload.cdc_batch(k)
         r1 = ora.collapse(b2, s2)
-        cpu = {"value": round(k / r1.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+        out = {"value": round(k / r1.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
                "sample": f"a {k}-row slice of the same stream through the oracle's Collapse ({r1.seconds:.2f}s), single thread",
                "note": "C restatement of the Go reference (json.Marshal key strings, string-keyed maps, boxed values), not the Go binary"}
-    print(json.dumps({
-        "metric": "ChangeItems/sec through abstract.Collapse (PK-keyed dedup of a CDC batch)", "value": round(args.rows * args.steps / dt, 1),
-        "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys, 60% of U/D with OldKeys, 15% of those change the PK) -> Collapse",
-                   "rows_per_step": args.rows, "rows_out_per_step": state["out_rows"]},
-        "roofline": None, "cpu_baseline": cpu, "kernels": kernels}))
+        out.update(host_info())
+        return out
+
+
+WORKLOADS = {"csv": CsvWorkload, "json": JsonWorkload, "sr": SrWorkload, "configs2": Configs2Workload, "configs3": Configs3Workload,
+             "configs4": Configs4Workload, "collapse": CollapseWorkload}
+
+
+class Env:
+    pass
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["csv", "json", "collapse", "sr"], default="csv",
-                    help="csv = BASELINE.json configs[1] (the bench line); json = configs[2] shape, collapse = configs[4]'s dedup: side benchmarks")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="csv",
+                    help="csv = BASELINE.json configs[1] (the bench line); configs2/3/4 = the other GPU configs; json / sr / collapse = component benchmarks")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU per step")
-    ap.add_argument("--cpu-rows", type=int, default=1 << 19, help="rows of the CPU-baseline sample (0 = skip); 2^19 rows = about 11 s of oracle time")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: enough for a timed region of >= 1 s)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU per step (default: 2^20 for csv / configs3 / configs4, 2^18 for the message workloads)")
+    ap.add_argument("--cpu-rows", type=int, default=1 << 19, help="rows of the single-thread CPU-baseline sample (0 = skip); 2^19 hits rows = about 11 s of oracle time")
+    ap.add_argument("--cpu-all-rows", type=int, default=1 << 20, help="rows (over all cores) of the all-cores CPU-baseline leg, csv workload (0 = skip)")
     ap.add_argument("--prof-steps", type=int, default=3)
-    ap.add_argument("--lanes", type=int, default=1, help="device lanes (host threads) the steps are spread over: batch N+1 is parsed "
-                    "beside the transform of batch N, the way the parsequeue's workers overlap (1 = strictly serial)")
+    ap.add_argument("--lanes", type=int, default=1, help="device lanes (host threads) the steps are spread over (1 = strictly serial, the bench line)")
     ap.add_argument("--overlap-lanes", type=int, default=3, help="side measurement (never `value`): the same steps spread over this many lanes (0 = skip)")
-    ap.add_argument("--pcie-steps", type=int, default=2, help="extra untimed-for-`value` passes that start from PINNED HOST memory (0 = skip)")
+    ap.add_argument("--pcie-steps", type=int, default=2, help="side measurement (never `value`): passes per lane that start from PINNED HOST memory (0 = skip)")
+    ap.add_argument("--pcie-lanes", type=int, default=3)
+    ap.add_argument("--exchange", type=int, default=1, help="configs4 at 1 rank: 1 = every buffer still makes the RCCL round trip, 0 = skip the collective")
     args = ap.parse_args()
-    if args.workload == "json":
-        return json_main(args)
-    if args.workload == "collapse":
-        return collapse_main(args)
-    if args.workload == "sr":
-        return sr_main(args)
 
-    import torch
-    from transferia_amd import dist as tdist
+    import torch  # first: libtfgpu and torch must share the HIP runtime torch loads
+    from transferia_amd import abi, dist as tdist, lib, workload
     rank, local_rank, world = tdist.env_rank()
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    group = tdist.Group("nccl", torch.device("cuda", local_rank))  # RCCL: barrier + MAX of the wall time only
-
-    from transferia_amd import lib, workload
+    e = Env()
+    e.rank, e.local_rank, e.world = rank, local_rank, world
+    e.device = torch.device("cuda", local_rank)
+    e.group = tdist.Group("nccl", e.device)  # RCCL: barrier + MAX of the wall time (+ the configs4 exchange)
+    e.lib, e.abi, e.workload = lib, abi, workload
     lib.init(local_rank)
 
-    barrier = group.barrier
+    def sync_all():
+        lib.synchronize()
+        e.group.barrier()
+        torch.cuda.synchronize()
+    e.sync_all = sync_all
 
-    schema = workload.hits_schema()
-    opts = workload.hits_csv_options()
-    plans = [lib.Transformer(t, c) for t, c in CHAIN]
-
-    # ---- stage this rank's shard in HBM (untimed) ----
-    row0, _ = tdist.weak_shard(args.rows, rank)
-    dbuf, csv_bytes, hs = stage_shard(lib, workload, row0, args.rows)
-
-    state = {}
-
-    def step(keep=False):
-        db, consumed, errs = lib.csv_parse(opts, schema, dbuf)
-        res = lib.apply_chain(plans, db)
-        if keep:
-            state["parsed_rows"] = db.nrows
-            state["parsed_bytes"] = db.payload_bytes()
-            v = db.view()
-            fixed = 0
-            str_bytes = 0
-            for i in range(v.ncols):
-                c = v.cols[i]
-                if c.repr in (12, 13, 14, 15):
-                    str_bytes += int(c.data_len)
-                else:
-                    fixed += int(v.nrows) * (np.dtype(lib.abi.REPR_NP[c.repr]).itemsize + (4 if c.nanos else 0))
-            state["fixed_bytes"], state["str_bytes"] = fixed, str_bytes
-            state["out_rows"] = res.transformed.nrows
-            state["out_bytes"] = res.transformed.payload_bytes()
-            state["errors"] = len(errs) + len(res.errors)
-            state["consumed"] = consumed
-        res.transformed.free()
-        db.free()  # devnull sink
-
+    W = WORKLOADS[args.workload](args, e)
+    if args.rows <= 0:
+        args.rows = W.default_rows
+    W.setup()
     for _ in range(args.warmup):
-        step()
-    step(keep=True)  # one extra untimed pass to record sizes
-
-    # ---- the timed region: exactly args.steps steps, spread round-robin over `lanes` host threads, each bound
-    #      to its own device lane (stream + HBM cache) and reading its own HBM-resident copy of the shard ----
-    import threading
-
-    def timed_region(nlanes):
-      nl = max(1, min(nlanes, args.steps, lib.lane_count()))
-      lane_bufs = [dbuf]
-      go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
-      lane_err = []
-
-      def lane_main(k):
-          try:
-              lib.lane_use(k)
-              if k:  # stage this lane's copy of the input (untimed), then warm the lane's caches
-                  lane_bufs.append(None)
-              buf = dbuf if k == 0 else stage_shard(lib, workload, row0, args.rows)[0]
-              def lstep():
-                  db, consumed, errs = lib.csv_parse(opts, schema, buf)
-                  res = lib.apply_chain(plans, db)
-                  res.transformed.free()
-                  db.free()
-              if k:
-                  for _ in range(max(args.warmup, 1)):
-                      lstep()
-              lib.synchronize()
-              go.wait()
-              for i in range(args.steps):
-                  if i % nl == k:
-                      lstep()
-              lib.synchronize()
-              done.wait()
-          except Exception as e:  # noqa: BLE001
-              lane_err.append(e)
-              go.abort(); done.abort()
-
-      threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
-      for t in threads:
-          t.start()
-      barrier()
-      torch.cuda.synchronize()
-      go.wait()
-      t0 = time.perf_counter()
-      done.wait()
-      torch.cuda.synchronize()
-      barrier()
-      dt = time.perf_counter() - t0
-      for t in threads:
-          t.join()
-      if lane_err:
-          raise lane_err[0]
-      lib.lane_use(0)
-      return dt, nl
-
-    dt, nl = timed_region(args.lanes)
-    overlapped = None
-    if args.overlap_lanes > 1 and args.overlap_lanes != args.lanes:
-        dt2, nl2 = timed_region(args.overlap_lanes)
-        dt2 = group.max_seconds(dt2)
-        overlapped = {"lanes": nl2, "rows_per_s": round(args.rows * world * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
-                      "note": "side measurement, never `value`: the same K steps spread over several device lanes (parse of batch N+1 beside "
-                              "the transform of batch N); kernels of different lanes share the GPU, so per-kernel spans are not comparable"}
-
-    # ---- PCIe-inclusive side measurement (never `value`): the same step starting from pinned host memory ----
-    pcie = None
-    if args.pcie_steps > 0 and rank == 0:
-        host = lib.HostBuffer(dbuf.download())
-        def hstep():
-            db, consumed, errs = lib.csv_parse(opts, schema, host)
-            res = lib.apply_chain(plans, db)
-            res.transformed.free(); db.free()
-        hstep()
+        W.step()
+    W.step(keep=True)  # one extra untimed pass records sizes
+    if args.steps <= 0:  # a timed region of >= 1 s, so that the driver's 5-s sampler and the region overlap
         lib.synchronize()
-        th = time.perf_counter()
-        for _ in range(args.pcie_steps):
-            hstep()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            W.step()
         lib.synchronize()
-        dth = time.perf_counter() - th
-        pcie = {"rows_per_s": round(args.rows * args.pcie_steps / dth, 1), "gb_per_s_h2d": round(csv_bytes * args.pcie_steps / dth / 1e9, 2),
-                "ms_per_step": round(dth / args.pcie_steps * 1e3, 3), "note": "input in pinned host memory, one lane, H2D inside the step"}
-        host.free()
-    dt = group.max_seconds(dt)
+        per = (time.perf_counter() - t0) / 3
+        args.steps = int(min(max(1.2 / max(per, 1e-6), 20), 2000))
+        if e.group.dist is not None:  # every rank must time the same K
+            t = torch.tensor([args.steps], dtype=torch.int64, device=e.device)
+            e.group.dist.all_reduce(t, op=e.group.dist.ReduceOp.MAX)
+            args.steps = int(t.item())
+
+    dt = e.group.max_seconds(W.timed(args.steps))
+    W.dt = dt
+    side = W.side_measurements() if hasattr(W, "side_measurements") else {}
 
     # ---- per-kernel device time, HIP events on the library stream (separate, untimed pass) ----
-    lib.prof_reset()
-    lib.prof_enable(True)
+    lib.prof_reset(); lib.prof_enable(True)
     for _ in range(max(args.prof_steps, 1)):
-        step()
+        W.step()
     lib.prof_enable(False)
     prof = lib.prof_get()
     lib.prof_reset()
-
-    rows, fixed_b, str_b = state["parsed_rows"], state["fixed_bytes"], state["str_bytes"]
-    sel = state["out_rows"] / max(rows, 1)
-    # ALGORITHMIC bytes per launch (DESIGN.md "Kernels"; SURVEY.md §8d per-row figures × rows per launch)
-    alg = {
-        "csv_count_newlines": csv_bytes,
-        "csv_line_index": csv_bytes + 4 * rows,
-        "csv_parse_rows": csv_bytes + fixed_b,            # read every input byte once, write every fixed-width value once
-        "csv_parse_tiles": csv_bytes + fixed_b,           # same work, tile-cooperative kernel
-        "csv_copy_strings": 2 * str_b,                    # string payload: one read + one write
-        "csv_copy_tiles": 2 * str_b,
-        "csv_copy_words": 2 * str_b,
-        "scan_u32_segments": 12 * rows * 28,
-        "mask_hmac_sha256": 72 * rows,                    # 4 B in + 64 B hex + 4 B offset per value
-        "filter_rows_eval": int((8 + 4 + 0.125) * rows),  # time value + keep flag
-        "compact_gather": int((1 + sel) * state["parsed_bytes"]),
-        "scan_u32": 12 * rows,
-    }
-    kernels = {}
-    for name, launches, ms in prof:
-        if launches:
-            kernels[name] = {"launches_per_step": launches / max(args.prof_steps, 1), "avg_ms": ms / launches,
-                             "ms_per_step": ms / max(args.prof_steps, 1)}
+    ps = max(args.prof_steps, 1)
+    kernels = {n: {"launches_per_step": l / ps, "avg_ms": ms / l, "ms_per_step": ms / ps} for n, l, ms in prof if l}
+    alg = W.alg()
     dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if kernels else None
     roofline = None
-    if dom:
-        per_launch = alg.get(dom, 0) / max(kernels[dom]["launches_per_step"], 1)
-        achieved = per_launch / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 if per_launch else 0.0
-        # HBM traffic per launch cannot be read inside this process: it comes from the rocprofv3 --pmc passes whose summary
-        # is committed under profiles/ (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md "HBM"); null when the
-        # recorded launch shape is not this run's.
+    if dom and alg.get(dom):
+        per_launch = alg[dom] / max(kernels[dom]["launches_per_step"], 1)
+        achieved = per_launch / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        # HBM traffic per launch cannot be read inside this process: it comes from the rocprofv3 --pmc passes whose summary is
+        # committed under profiles/ (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections); null when the recorded launch
+        # shape is not this run's.
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 t = json.load(f).get(dom)
-            if t and t["rows_per_launch"] == rows:
+            if t and t["rows_per_launch"] == W.rows() and t.get("workload", "csv") == args.workload:
                 traffic = t["bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch),
-                    "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+    int_roof = W.int_roofline(kernels)
     for k, v in kernels.items():
         b = alg.get(k)
         if b:
             v["alg_gb_s"] = round(b / max(v["launches_per_step"], 1) / (v["avg_ms"] * 1e-3) / 1e9, 2)
         v["avg_ms"], v["ms_per_step"] = round(v["avg_ms"], 4), round(v["ms_per_step"], 4)
 
-    # ---- CPU baseline: the oracle (C restatement of the Go reference), rank 0, N=1 only ----
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_rows > 0:
-        from oracle import oracle as ora
-        sample = workload.hits_csv(args.cpu_rows)
-        ochain = [ora.Transformer(t, c) for t, c in CHAIN]
-        r1 = ora.csv_parse(opts, schema, sample, "", "")
-        r2 = ora.apply_chain(ochain, r1.batch, r1.schema)
-        secs = r1.seconds + r2.seconds
-        cpu = {"value": round(args.cpu_rows / secs, 1), "unit": "rows/s", "cores": 1, "kind": "port",
-               "sample": f"{args.cpu_rows} rows of the same synthetic hits CSV: oracle csv parse+strictify ({r1.seconds:.2f}s) + mask+filter ({r2.seconds:.2f}s), "
-                         "single thread = the reference's shape for one table (transformation.go:131-135)",
-               "note": "C restatement of the Go reference (row-oriented boxed values), not the Go binary"}
+    cpu = W.cpu() if (rank == 0 and world == 1 and args.cpu_rows > 0) else None  # the oracle, rank 0, N = 1 only
 
     if rank == 0:
-        total_rows = rows * world * args.steps
-        value = total_rows / dt
-        out = {
-            "metric": "ChangeItems/sec through CSV parse -> mask(ClientIP)+filter(EventDate) -> devnull, ClickBench hits",
-            "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "ClickBench hits-1M CSV parse -> mask(ip)+filter(EventDate) -> devnull (BASELINE.json configs[1])",
-                       "rows_per_gpu_per_step": rows, "csv_bytes_per_gpu_per_step": csv_bytes, "columns": len(schema.cols),
-                       "chain": [t for t, _ in CHAIN], "filter_selectivity": round(sel, 4), "parallelism": f"row-range shard x{world}, no collective"},
-            "gib_per_s_csv_in": round(csv_bytes * world * args.steps / dt / 2**30, 3),
-            "gib_per_s_deepsizeof": round((state["parsed_bytes"] + 16 * len(schema.cols) * rows) * world * args.steps / dt / 2**30, 3),
-            "rows_out_per_step": state["out_rows"], "row_errors": state["errors"],
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "lanes": nl, "overlapped_lanes": overlapped, "pcie_inclusive": pcie,
-        }
+        rows = W.rows()
+        value = rows * world * args.steps / dt
+        out = {"metric": W.metric, "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": W.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": W.config()}
+        out.update(W.extra())
+        out["row_errors"] = W.state.get("errors", 0)
+        out["roofline"] = roofline
+        if int_roof:
+            out["int_roofline"] = int_roof
+        out["cpu_baseline"] = cpu
+        out["kernels"] = kernels
+        out.update(side)
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
-    group.close()
+    e.group.close()
 
 
 if __name__ == "__main__":

@@ -258,6 +258,49 @@ void tfgpu_dbatch_free(tfgpu_dbatch *b);
 int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tfgpu_dbatch **out,
                 tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
+/* ---- transformation.Push (pkg/transformer/transformation.go:46-282) -------------------------------------------------
+ * The stage middlewares.Transformation builds from Transfer.TransformationConfigs() + ExtraTransformers
+ * (pkg/middlewares/transformation.go:12-34): `transformers` in that order.  The Go shim cuts a Push into contiguous
+ * same-table, same-schema runs (SplitByTableID, pkg/abstract/changeitem/utils.go:130-136, then the schema-hash cut of
+ * transformation.do :236-251 — it has to anyway, a columnar batch IS such a run) and pushes each run:
+ *   - the table plan = the transformers that are Suitable for (TableID, schema), each judged against the ResultSchema of
+ *     its predecessors (AddTablePlan :46-85), built once per (TableID, schema) under the transformation's mutex and cached
+ *     (preparePlans :93-121); tfgpu_transformation_table_plan returns it (indices into `transformers`);
+ *   - the Apply loop of transformation.do (:252-274);
+ *   - every TransformerError keeps its Input — the item AS THE FAILING TRANSFORMER SAW IT, i.e. after its predecessors:
+ *     error_batches[g] holds the refused rows of the g-th failing transformer (index error_steps[g]) in error order, and
+ *     errs (grouped the same way; row = index in the ORIGINAL run) the reason.  The shim appends the `__transform_error`
+ *     column with Go's own error text and pushes them to the sink or drops them (errorChangeItems / pushErrors :173-235);
+ *   - MiddlewareTransformerStats (:146-155): tfgpu_transformation_get_stats.
+ * Thread-safe: runs of different tables are pushed from different goroutines (:131-135).                              */
+typedef struct tfgpu_transformation tfgpu_transformation;
+typedef struct tfgpu_transformation_stats {
+  int64_t pushes, items_in, items_out;
+  int64_t dropped;      /* sta.Dropped: incoming - transformed                */
+  int64_t errors;       /* sta.Errors                                         */
+  int64_t elapsed_ns;   /* sta.Elapsed, summed                                */
+  int64_t plans_built;  /* AddTablePlan calls (cache misses)                  */
+} tfgpu_transformation_stats;
+int tfgpu_transformation_create(tfgpu_plan *const *transformers, int n, tfgpu_transformation **out); /* plans stay the caller's */
+void tfgpu_transformation_destroy(tfgpu_transformation *t);
+int tfgpu_transformation_table_plan(tfgpu_transformation *t, const char *table_ns, const char *table_name, const tfgpu_schema *schema,
+                                    int32_t *idx, int32_t cap, int32_t *n);
+/* `schema` = the run's TableSchema (NULL: the batch's own TableSchema / columns).                                       */
+int tfgpu_transformation_push(tfgpu_transformation *t, const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_dbatch **transformed,
+                              tfgpu_dbatch **error_batches, int32_t *error_steps, int32_t batches_cap, int32_t *n_error_batches,
+                              tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+int tfgpu_transformation_get_stats(tfgpu_transformation *t, tfgpu_transformation_stats *out);
+/* The same push behind a token: it runs on one of the library's own worker threads, each bound to its own device lane
+ * (stream + HBM cache + pinned ring), after everything the calling thread's lane had enqueued so far.  The parsequeue's
+ * goroutines (pkg/parsequeue/parsequeue.go:57-154) submit parse results and wait for tokens in push order — no goroutine
+ * has to stay locked to an OS thread.  `in` (and the plans) must stay alive until tfgpu_wait returns; a token is waited
+ * for exactly once.  tfgpu_executor_start(n) sizes the pool (default 2 on first use; n < tfgpu_lane_count()).          */
+typedef struct tfgpu_token tfgpu_token;
+int tfgpu_executor_start(int workers);
+int tfgpu_transformation_push_async(tfgpu_transformation *t, const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_token **token);
+int tfgpu_wait(tfgpu_token *token, tfgpu_dbatch **transformed, tfgpu_dbatch **error_batches, int32_t *error_steps, int32_t batches_cap,
+               int32_t *n_error_batches, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+
 /* abstract.Collapse (pkg/abstract/changeitem/change_item_collapse.go:48-134): the PK-keyed dedup of one batch that
  * sinks with primary keys run before writing (and clickhouse_local.go:178-210 before the `sql` transformer).  Keys are the
  * TableSchema's PrimaryKey columns (the batch must carry `schema` with TFGPU_COL_KEY flags); the key of a row is

@@ -48,7 +48,7 @@ def test_struct_sizes():
 def test_registry_lists_reference_type_names():
     # YAML keys of the reference (pkg/transformer/registry/*/): same names, drop-in
     assert set(lib.registry()) == {"mask_field", "rename_tables", "filter_columns", "skip_events", "filter_rows",
-                                   "convert_to_string", "convert_to_datetime", "sharder_transformer"}
+                                   "convert_to_string", "convert_to_datetime", "sharder_transformer", "replace_primary_key"}
 
 
 def _no_gpu():

@@ -69,6 +69,11 @@ class CRowError(C.Structure):
     _fields_ = [("row", C.c_int64), ("code", C.c_int32), ("step", C.c_int32), ("column", C.c_int32)]
 
 
+class CTransformationStats(C.Structure):
+    _fields_ = [("pushes", C.c_int64), ("items_in", C.c_int64), ("items_out", C.c_int64), ("dropped", C.c_int64), ("errors", C.c_int64),
+                ("elapsed_ns", C.c_int64), ("plans_built", C.c_int64)]
+
+
 class CCsvOptions(C.Structure):
     _fields_ = [("delimiter", C.c_uint8), ("quote_char", C.c_uint8), ("escape_char", C.c_uint8),
                 ("double_quote", C.c_uint8), ("newlines_in_value", C.c_uint8), ("include_missing_columns", C.c_uint8),

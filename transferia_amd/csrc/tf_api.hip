@@ -15,13 +15,38 @@ namespace tf { std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &
 // blank-import list of the reference: pkg/transformer/registry/registry.go:3-20
 // (device-resident subset; see DESIGN.md for what stays on the host)
 static const char *REGISTRY[] = {"mask_field", "rename_tables", "filter_columns", "skip_events", "filter_rows",
-                                 "convert_to_string", "convert_to_datetime", "sharder_transformer"};
+                                 "convert_to_string", "convert_to_datetime", "sharder_transformer", "replace_primary_key"};
 
 static char *dup_cstr(const std::string &s) {
   char *r = (char *)std::malloc(s.size() + 1);
   std::memcpy(r, s.c_str(), s.size() + 1);
   return r;
 }
+
+namespace tf {
+void plan_result_columns(const tfgpu_plan &p, std::vector<SchemaCol> &cols) {
+  std::vector<SchemaCol> out;
+  if (p.kind == PK_REPLACE_PK) {  // replace_primary_key.go:108-131
+    if (p.new_keys.size() == 1) { for (auto &c : cols) { if (p.is_new_key(c.name)) c.flags |= TFGPU_COL_KEY; else c.flags &= ~(uint32_t)TFGPU_COL_KEY; } return; }
+    for (auto &k : p.new_keys) for (auto &c : cols) if (c.name == k) { SchemaCol o = c; o.flags |= TFGPU_COL_KEY; out.push_back(o); break; }
+    for (auto &c : cols) if (!p.is_new_key(c.name)) { SchemaCol o = c; o.flags &= ~(uint32_t)TFGPU_COL_KEY; out.push_back(o); }
+    cols.swap(out);
+    return;
+  }
+  for (auto &c : cols) {
+    SchemaCol o = c;
+    switch (p.kind) {
+      case PK_MASK: if (p.mask_has(c.name)) o.dtype = TFGPU_T_UTF8; break;
+      case PK_TO_STRING: if (p.columns.match(c.name)) o.dtype = p.to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8; break;
+      case PK_TO_DATETIME: if (p.columns.match(c.name) && (c.dtype == TFGPU_T_INT32 || c.dtype == TFGPU_T_UINT32)) o.dtype = TFGPU_T_DATETIME; break;
+      case PK_FILTER_COLUMNS: if (!p.columns.match(c.name)) continue; break;
+      default: break;
+    }
+    out.push_back(std::move(o));
+  }
+  cols.swap(out);
+}
+}  // namespace tf
 
 extern "C" {
 
@@ -61,8 +86,19 @@ int tfgpu_plan_result_schema(const tfgpu_plan *p, const tfgpu_schema *in, tfgpu_
   if (!p || !in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_plan_result_schema: null argument");
   auto *s = (tfgpu_schema *)std::calloc(1, sizeof(tfgpu_schema));
   s->cols = (tfgpu_colschema *)std::calloc((size_t)std::max(in->ncols, 1), sizeof(tfgpu_colschema));
-  for (int i = 0; i < in->ncols; i++) {
-    const tfgpu_colschema &c = in->cols[i];
+  std::vector<int> order((size_t)in->ncols);
+  std::vector<uint32_t> flags((size_t)in->ncols);
+  for (int i = 0; i < in->ncols; i++) { order[(size_t)i] = i; flags[(size_t)i] = in->cols[i].flags; }
+  if (p->kind == PK_REPLACE_PK) {  // replace_primary_key.go:108-131: keys first in the configured order (composite), flags rewritten
+    std::vector<SchemaCol> cols;
+    for (int i = 0; i < in->ncols; i++) cols.push_back(SchemaCol{in->cols[i].name ? in->cols[i].name : "", i, in->cols[i].flags});  // dtype slot carries the index
+    plan_result_columns(*p, cols);
+    for (size_t k = 0; k < cols.size(); k++) { order[k] = cols[k].dtype; flags[k] = cols[k].flags; }
+  }
+  for (int oi = 0; oi < in->ncols; oi++) {
+    const int i = order[(size_t)oi];
+    tfgpu_colschema c = in->cols[i];
+    c.flags = flags[(size_t)oi];
     std::string name = c.name ? c.name : "";
     int dtype = c.dtype;
     std::string orig = c.original_type ? c.original_type : "";

@@ -463,6 +463,11 @@ static NameFilter columns_of(const Json &cfg) {
   return f;
 }
 
+static std::string join_keys(const std::vector<std::string> &v) {
+  std::string o;
+  for (size_t i = 0; i < v.size(); i++) { if (i) o += ", "; o += v[i]; }
+  return o;
+}
 std::unique_ptr<tfgpu_plan> make_plan(const std::string &type_name, const std::string &config_json) {
   Json cfg = Json::parse(config_json.empty() ? "{}" : config_json);
   auto p = std::make_unique<tfgpu_plan>();
@@ -538,6 +543,13 @@ std::unique_ptr<tfgpu_plan> make_plan(const std::string &type_name, const std::s
     if (!parse_i64(sc, p->shards)) cfg_error("cannot parse param as int: " + sc);
     if (p->is_random) throw Error(TFGPU_ERR_UNSUPPORTED, "sharder_transformer is_random=true draws from math/rand on the host; not a device transform");
     if (p->shards <= 0 || p->shards > 0xFFFFFFFFll) cfg_error("shardsCount out of range");
+  } else if (type_name == "replace_primary_key") {  // replace_primary_key/replace_primary_key.go:24-27, 134-150
+    p->kind = PK_REPLACE_PK;
+    p->tables = tables_of(cfg); p->columns.init({}, {});
+    p->new_keys = cfg.strings("keys");
+    for (size_t i = 0; i < p->new_keys.size(); i++)
+      for (size_t j = 0; j < i; j++)
+        if (p->new_keys[i] == p->new_keys[j]) cfg_error("Can't use same keys column names twice: " + join_keys(p->new_keys));
   } else {
     throw Error(TFGPU_ERR_UNKNOWN_TYPE, "transformer type not registered: " + type_name);
   }
@@ -589,6 +601,12 @@ bool plan_suitable(const tfgpu_plan &p, const std::string &ns, const std::string
       if (p.columns.empty()) return true;
       for (int i = 0; i < s.ncols; i++) if (p.columns.match(s.cols[i].name)) return true;
       return false;
+    case PK_REPLACE_PK: {  // replace_primary_key.go:104-106: containsAllKeys counts the schema's columns that are new keys
+      if (!p.tables.match_table(ns, name)) return false;
+      size_t hits = 0;
+      for (int i = 0; i < s.ncols; i++) if (p.is_new_key(s.cols[i].name ? s.cols[i].name : "")) hits++;
+      return hits == p.new_keys.size();
+    }
     case PK_TO_DATETIME:  // to_datetime.go:63-76
       if (!p.tables.match_table(ns, name)) return false;
       if (p.columns.empty()) return false;
@@ -623,6 +641,7 @@ std::string plan_description(const tfgpu_plan &p) {
     case PK_TO_DATETIME:
       if (p.columns.empty()) return "Transform to datetime uint32 column values";
       return "Transform to datetime uint32 column values (include: " + trim100(join(p.columns.include_src, "|")) + ", exclude: " + trim100(join(p.columns.exclude_src, "|")) + ")";
+    case PK_REPLACE_PK: return "Replace primary keys to: " + join_keys(p.new_keys) + " ";
     case PK_SHARDER:
       if (p.columns.empty()) return "Transform to shard tables by field values";
       return "Transform to shard tables by field values (include: " + trim100(join(p.columns.include_src, "|")) + ", exclude: " + trim100(join(p.columns.exclude_src, "|")) + ", shards_num: " + std::to_string(p.shards) + ")";

@@ -58,7 +58,7 @@ std::vector<FTerm> parse_filter(const std::string &src);  // throws Error(TFGPU_
 
 }  // namespace tf
 
-enum PlanKind { PK_MASK, PK_RENAME, PK_FILTER_COLUMNS, PK_SKIP_EVENTS, PK_FILTER_ROWS, PK_TO_STRING, PK_TO_DATETIME, PK_SHARDER };
+enum PlanKind { PK_MASK, PK_RENAME, PK_FILTER_COLUMNS, PK_SKIP_EVENTS, PK_FILTER_ROWS, PK_TO_STRING, PK_TO_DATETIME, PK_SHARDER, PK_REPLACE_PK };
 
 struct tfgpu_plan {
   int kind = PK_MASK;
@@ -79,6 +79,12 @@ struct tfgpu_plan {
   // sharder_transformer
   int64_t shards = 1;
   bool is_random = false;
+  // replace_primary_key
+  std::vector<std::string> new_keys;
+  bool is_new_key(const std::string &n) const {
+    for (auto &c : new_keys) if (c == n) return true;
+    return false;
+  }
 
   bool mask_has(const std::string &n) const {
     for (auto &c : mask_cols) if (c == n) return true;
@@ -87,6 +93,10 @@ struct tfgpu_plan {
 };
 
 namespace tf {
+struct SchemaCol { std::string name; int dtype; uint32_t flags; };  // the three ColSchema fields Suitable / ResultSchema read
+// ResultSchema of one transformer over a column list, in place (hmac_hasher.go:35-46, to_string.go:114-127, ...)
+void plan_result_columns(const tfgpu_plan &p, std::vector<SchemaCol> &cols);
+void executor_shutdown();
 std::unique_ptr<tfgpu_plan> make_plan(const std::string &type_name, const std::string &config_json);
 bool plan_suitable(const tfgpu_plan &p, const std::string &ns, const std::string &name, const tfgpu_schema &s);
 std::string plan_description(const tfgpu_plan &p);

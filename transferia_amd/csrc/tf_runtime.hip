@@ -9,6 +9,7 @@
 
 namespace tf {
 
+void executor_shutdown();  // tf_transformation.cpp
 static thread_local std::string g_last_error;
 // Lanes: independent (stream, HBM block cache, pinned ring, profiler) sets of ONE device.  A host thread binds
 // itself to a lane with tfgpu_lane_use(); calls on different lanes overlap on the GPU — parse of batch N+1 on one
@@ -245,6 +246,7 @@ int tfgpu_init(int device) {
 int tfgpu_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_init_mu);
   if (!g_ctx) return TFGPU_OK;
+  executor_shutdown();  // the push workers hold lanes
   for (int i = MAX_LANES - 1; i >= 0; i--) destroy_lane(g_lanes[i]);
   g_lane = 0;
   return TFGPU_OK;
@@ -345,7 +347,7 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
 }
 
 // Views hand out pointers into per-dbatch scratch arrays.
-struct ViewStore { std::vector<tfgpu_column> cols; };
+struct ViewStore { std::vector<tfgpu_column> cols; std::vector<tfgpu_colschema> scols; tfgpu_schema schema; };
 static thread_local ViewStore g_view;
 
 int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
@@ -366,6 +368,16 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   v->kind = ptr<uint8_t>(b->kind); v->src_row = ptr<int32_t>(b->src_row); v->part_id = ptr<uint32_t>(b->part_id);
   v->mem = TFGPU_MEM_DEVICE;
   v->schema = nullptr;
+  if (!b->schema.empty()) {  // the TableSchema, where it is not simply the columns: names, types, PrimaryKey flags
+    g_view.scols.assign(b->schema.size(), tfgpu_colschema{});
+    for (size_t i = 0; i < b->schema.size(); i++) {
+      tfgpu_colschema &sc = g_view.scols[i];
+      sc.name = b->schema[i].first.c_str(); sc.dtype = b->schema[i].second; sc.path = ""; sc.original_type = "";
+      for (auto &k : b->key_names) if (k == b->schema[i].first) sc.flags |= TFGPU_COL_KEY;
+    }
+    g_view.schema.ncols = (int32_t)g_view.scols.size(); g_view.schema.cols = g_view.scols.data();
+    v->schema = &g_view.schema;
+  }
   v->n_old_keys = (int32_t)b->old_keys.size();
   v->old_keys = b->old_keys.empty() ? nullptr : g_view.cols.data() + b->cols.size();
   v->old_keys_present = ptr<uint8_t>(b->old_present);

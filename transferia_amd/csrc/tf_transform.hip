@@ -888,6 +888,41 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_columns(const tfgpu_plan &p, c
   return out;
 }
 
+__global__ void kind_is_kernel(const uint8_t *kind, int64_t n, uint8_t k, uint8_t *bits) {  // one thread per output byte
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * 8 >= n) return;
+  uint32_t v = 0;
+  for (int j = 0; j < 8; j++) { const int64_t r = b * 8 + j; if (r < n && kind[r] == k) v |= 1u << j; }
+  bits[b] = (uint8_t)v;
+}
+// replace_primary_key.go:82-101: the TableSchema is replaced (keys first / flags rewritten); ColumnNames and ColumnValues
+// stay as they are; an Update gets OldKeys = the NEW keys' current values (createOldKeys :51-80).
+static std::unique_ptr<tfgpu_dbatch> apply_replace_pk(const tfgpu_plan &p, const tfgpu_dbatch &in) {
+  auto out = shallow_copy(in);
+  std::vector<SchemaCol> cols;
+  if (!in.schema.empty()) for (auto &c : in.schema) cols.push_back(SchemaCol{c.first, c.second, 0u});
+  else for (auto &c : in.cols) cols.push_back(SchemaCol{c.name, c.dtype, 0u});
+  plan_result_columns(p, cols);
+  out->schema.clear(); out->key_names.clear();
+  for (auto &c : cols) { out->schema.emplace_back(c.name, c.dtype); if (c.flags & TFGPU_COL_KEY) out->key_names.push_back(c.name); }
+  bool has_update = false;
+  if (in.kind && in.nrows) {
+    std::vector<uint8_t> hk((size_t)in.nrows);
+    d2h(hk.data(), in.kind->p, hk.size());
+    sync();
+    for (uint8_t k : hk) if (k == TFGPU_K_UPDATE) { has_update = true; break; }
+  }
+  if (has_update) {
+    if (!in.old_keys.empty()) throw Error(TFGPU_ERR_UNSUPPORTED, "replace_primary_key: a run that mixes Updates with rows that already carry OldKeys of other key names needs per-item KeyNames; not columnar");
+    for (auto &k : p.new_keys)  // key order; a key missing from ColumnNames leaves a nil value in the reference — not modelled
+      for (auto &c : in.cols) if (c.name == k) { out->old_keys.push_back(c); break; }
+    if (out->old_keys.size() != p.new_keys.size()) throw Error(TFGPU_ERR_UNSUPPORTED, "replace_primary_key: a new key is not among the batch's columns");
+    out->old_present = dalloc((size_t)(in.nrows + 7) / 8 + 8);
+    kind_is_kernel<<<grid_for((in.nrows + 7) / 8, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), in.nrows, (uint8_t)TFGPU_K_UPDATE, ptr<uint8_t>(out->old_present));
+  }
+  return out;
+}
+
 // ============================================================================
 // hash-partition, local half (config 5): rows grouped by PartID, original order kept inside a part
 // ============================================================================
@@ -932,6 +967,7 @@ std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch
     case PK_TO_STRING: return apply_to_string(p, in);
     case PK_TO_DATETIME: return apply_to_datetime(p, in);
     case PK_SHARDER: return apply_sharder(p, in, nullptr);
+    case PK_REPLACE_PK: return apply_replace_pk(p, in);
   }
   throw Error(TFGPU_ERR_INVALID, "unknown plan kind");
 }

@@ -27,7 +27,8 @@ EXPORTS = [
     "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
-    "tfgpu_apply", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -77,6 +78,15 @@ def load():
     L.tfgpu_dbatch_free.argtypes = [P]
     L.tfgpu_dbatch_free.restype = None
     L.tfgpu_apply.argtypes = [C.POINTER(P), C.c_int, P, C.POINTER(P), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_transformation_create.argtypes = [C.POINTER(P), C.c_int, C.POINTER(P)]
+    L.tfgpu_transformation_destroy.argtypes = [P]
+    L.tfgpu_transformation_table_plan.argtypes = [P, C.c_char_p, C.c_char_p, C.POINTER(abi.CSchema), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
+    _push_tail = [C.POINTER(P), C.POINTER(P), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_transformation_push.argtypes = [P, P, C.POINTER(abi.CSchema)] + _push_tail
+    L.tfgpu_transformation_get_stats.argtypes = [P, C.POINTER(abi.CTransformationStats)]
+    L.tfgpu_executor_start.argtypes = [C.c_int]
+    L.tfgpu_transformation_push_async.argtypes = [P, P, C.POINTER(abi.CSchema), C.POINTER(P)]
+    L.tfgpu_wait.argtypes = [P] + _push_tail
     L.tfgpu_collapse.argtypes = [P, C.POINTER(P)]
     L.tfgpu_partition.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
     L.tfgpu_csv_options_default.argtypes = [C.POINTER(abi.CCsvOptions)]
@@ -170,6 +180,11 @@ class DeviceBatch:
     @property
     def nrows(self) -> int:
         return int(self.view().nrows)
+
+    def table_schema(self) -> Optional[abi.Schema]:
+        """ChangeItem.TableSchema where the batch carries one of its own, else None (= the columns)."""
+        v = self.view()
+        return abi.Schema.from_c(v.schema.contents) if v.schema else None
 
     def column_names(self) -> List[str]:
         v = self.view()
@@ -393,6 +408,87 @@ def apply_chain(transformers: Sequence[Transformer], batch: DeviceBatch, max_err
     el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
           for i in range(min(int(nerr.value), max_errors))]
     return TransformerResult(DeviceBatch(out), el)
+
+
+class PushResult:
+    """What one run leaves of a transformation.Push: the transformed rows and, per failing transformer, the rows it refused
+    AS IT SAW THEM (TransformerError.Input) with the reasons."""
+
+    def __init__(self, transformed: DeviceBatch, error_batches, errors):
+        self.transformed = transformed
+        self.error_batches = error_batches  # [(index of the transformer, DeviceBatch)]
+        self.errors = errors                # [(row in the original run, code_name, index of the transformer, column)], grouped like error_batches
+
+
+class PushToken:
+    def __init__(self, handle, owner, batch, max_errors):
+        self._h, self._owner, self._batch, self._max = handle, owner, batch, max_errors
+
+    def wait(self) -> PushResult:
+        if self._h is None:
+            raise RuntimeError("a push token is waited for exactly once")
+        h, self._h = self._h, None
+        return self._owner._collect(lambda *a: load().tfgpu_wait(h, *a), self._max)
+
+
+class Transformation:
+    """transformation (pkg/transformer/transformation.go:20-45) behind the C ABI: the transformers in config order
+    (+ ExtraTransformers), the plan cache per (TableID, schema), the Apply loop with error inputs, the stats."""
+
+    def __init__(self, transformers: Sequence[Transformer]):
+        init()
+        self.transformers = list(transformers)  # keeps the plans alive
+        n = len(self.transformers)
+        arr = (C.c_void_p * max(n, 1))(*[t._h for t in self.transformers])
+        h = C.c_void_p()
+        _check(load().tfgpu_transformation_create(arr, n, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if self._h:
+                load().tfgpu_transformation_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def table_plan(self, ns: str, table: str, schema: abi.Schema) -> List[int]:
+        """AddTablePlan: indices of the transformers that are Suitable, each judged against its predecessors' ResultSchema."""
+        cs = schema.to_c()
+        idx, n = (C.c_int32 * max(len(self.transformers), 1))(), C.c_int32(0)
+        _check(load().tfgpu_transformation_table_plan(self._h, ns.encode(), table.encode(), C.byref(cs), idx, len(self.transformers), C.byref(n)))
+        return [int(idx[i]) for i in range(n.value)]
+
+    def _collect(self, call, max_errors):
+        out = C.c_void_p()
+        cap = max(len(self.transformers), 1)
+        eb, es, neb = (C.c_void_p * cap)(), (C.c_int32 * cap)(), C.c_int32(0)
+        errs, nerr = (abi.CRowError * max_errors)(), C.c_int64(0)
+        _check(call(C.byref(out), eb, es, cap, C.byref(neb), errs, max_errors, C.byref(nerr)))
+        el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
+              for i in range(min(int(nerr.value), max_errors))]
+        return PushResult(DeviceBatch(out), [(int(es[g]), DeviceBatch(C.c_void_p(eb[g]))) for g in range(min(neb.value, cap))], el)
+
+    def push_run(self, batch: DeviceBatch, schema: Optional[abi.Schema] = None, max_errors: int = 1 << 16) -> PushResult:
+        """One contiguous same-table, same-schema run through its table plan (transformation.do)."""
+        cs = schema.to_c() if schema is not None else None
+        return self._collect(lambda *a: load().tfgpu_transformation_push(self._h, batch._h, C.byref(cs) if cs is not None else None, *a), max_errors)
+
+    def push_run_async(self, batch: DeviceBatch, schema: Optional[abi.Schema] = None, max_errors: int = 1 << 16) -> PushToken:
+        cs = schema.to_c() if schema is not None else None
+        tok = C.c_void_p()
+        _check(load().tfgpu_transformation_push_async(self._h, batch._h, C.byref(cs) if cs is not None else None, C.byref(tok)))
+        return PushToken(tok, self, batch, max_errors)
+
+    def stats(self) -> dict:
+        st = abi.CTransformationStats()
+        _check(load().tfgpu_transformation_get_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in abi.CTransformationStats._fields_}
+
+
+def executor_start(workers: int):
+    init()
+    _check(load().tfgpu_executor_start(int(workers)))
 
 
 def collapse(batch: DeviceBatch) -> DeviceBatch:
