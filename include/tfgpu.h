@@ -377,6 +377,11 @@ int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, c
                     uint64_t len, int mem, tfgpu_dbatch **out, uint64_t *consumed,
                     tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
+/* csv.Splitter (pkg/csv/splitter.go:37-85): where ConsumeRow cuts a byte stream into CSV entries — at the '\n's outside
+ * double quotes (its three states reduce to the parity of the '"' seen so far).  *row_ends = uint32 offsets one past the
+ * '\n' of every complete entry, in order (a tfgpu_dbuf of *nrows words); what follows the last one is the io.EOF remainder. */
+int tfgpu_csv_split_rows(const void *bytes, uint64_t len, int mem, tfgpu_dbuf **row_ends, int64_t *nrows);
+
 /* ---- JSON / TSKV ingest: parsers/generic GenericParser{Format:"json" | "tskv"} ----------- */
 /* generic.AuxParserOpts (pkg/parsers/generic/generic_parser.go:40-77) as the "json" parser
  * registry fills them (pkg/parsers/registry/json/parser_json.go:62-86).  Options whose value

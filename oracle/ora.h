@@ -171,6 +171,7 @@ void ora_csv_table_free(ora_csv_table *t);
 ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema, const char *ns,
                          const char *table, const void *bytes, uint64_t len, uint64_t *consumed);
 
+int64_t ora_csv_split_rows(const void *bytes, uint64_t len, uint64_t **ends); /* csv.Splitter (pkg/csv/splitter.go) */
 /* getCorrespondingValue alone (reader_csv.go:345-452), for the reference's TestParse*Value tables */
 ora_batch *ora_csv_corresponding_value(const tfgpu_csv_options *o, const char *s, uint64_t n, int dtype);
 

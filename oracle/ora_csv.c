@@ -494,3 +494,25 @@ ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema,
   ora_schema_unref(sch);
   return b;
 }
+
+/* csv.Splitter.ConsumeRow / updateState (pkg/csv/splitter.go:37-85): offsets one past the '\n' that ends each entry.
+ * Returns the number of entries; ends is malloc'd. */
+int64_t ora_csv_split_rows(const void *bytes, uint64_t len, uint64_t **ends) {
+  enum { OUTSIDE, OPEN, CLOSING } st = OUTSIDE;
+  const unsigned char *p = (const unsigned char *)bytes;
+  uint64_t *e = NULL; int64_t n = 0, cap = 0;
+  for (uint64_t i = 0; i < len; i++) {
+    unsigned char c = p[i];
+    switch (st) {
+      case OUTSIDE: if (c == '"') st = OPEN; break;
+      case OPEN: if (c == '"') st = CLOSING; break;
+      case CLOSING: st = c == '"' ? OPEN : OUTSIDE; break;
+    }
+    if (c == '\n' && st == OUTSIDE) { /* ReadSlice returned a whole line and the state is outside: the row is complete */
+      if (n == cap) { cap = cap ? cap * 2 : 64; e = (uint64_t *)realloc(e, sizeof(uint64_t) * (size_t)cap); }
+      e[n++] = i + 1;
+    }
+  }
+  *ends = e;
+  return n;
+}

@@ -238,17 +238,20 @@ int ora_parse_float(const char *s, size_t n, int bits, double *out) {
     if (*p) return 1;
     if (strchr(buf, '_')) { if (!underscore_ok(buf, n)) return 1; /* strip */ char *w = buf; for (char *r = buf; *r; r++) if (*r != '_') *w++ = *r; *w = 0; }
   } else {
+    /* readFloat (strconv/atof.go): '_' may separate digits anywhere in the mantissa and the exponent, provided
+     * underscoreOK(s) holds (atof_test.go: "1_23.50_0_0e+1_2" parses as 1.235e+14) */
     int nd = 0;
-    while (isdigit((unsigned char)*p)) { nd++; p++; }
-    if (*p == '.') { p++; while (isdigit((unsigned char)*p)) { nd++; p++; } }
+    while (isdigit((unsigned char)*p) || *p == '_') { nd += *p != '_'; p++; }
+    if (*p == '.') { p++; while (isdigit((unsigned char)*p) || *p == '_') { nd += *p != '_'; p++; } }
     if (!nd) return 1;
     if (lower_(*p) == 'e') {
       p++;
       if (*p == '+' || *p == '-') p++;
       if (!isdigit((unsigned char)*p)) return 1;
-      while (isdigit((unsigned char)*p)) p++;
+      while (isdigit((unsigned char)*p) || *p == '_') p++;
     }
     if (*p) return 1;
+    if (strchr(buf, '_')) { if (!underscore_ok(buf, n)) return 1; char *w = buf; for (char *r = buf; *r; r++) if (*r != '_') *w++ = *r; *w = 0; }
   }
   if (bits == 32) { float f = strtof(buf, NULL); *out = f; if (isinf(f)) return 2; }
   else { double f = strtod(buf, NULL); *out = f; if (isinf(f)) return 2; }

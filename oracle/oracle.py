@@ -309,6 +309,18 @@ def csv_parse_rows(opts: abi.CCsvOptions, schema: abi.Schema, data: bytes):
     return rows, errs, int(consumed.value)
 
 
+def csv_split_rows(data: bytes):
+    """csv.Splitter: the entries ConsumeRow writes, and the io.EOF remainder."""
+    L = lib()
+    L.ora_csv_split_rows.restype = C.c_int64
+    L.ora_csv_split_rows.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64))]
+    ends = C.POINTER(C.c_uint64)()
+    n = L.ora_csv_split_rows(data, len(data), C.byref(ends))
+    out = [int(ends[i]) for i in range(n)]
+    C.CDLL(None).free(ends)
+    return out
+
+
 class _CsvTable(C.Structure):
     _fields_ = [("nlines", C.c_int64), ("nfields", C.POINTER(C.c_int32)), ("line_err", C.POINTER(C.c_int32)), ("ntotal", C.c_int64),
                 ("fields", C.POINTER(C.c_void_p)), ("lens", C.POINTER(C.c_size_t)), ("consumed", C.c_uint64)]

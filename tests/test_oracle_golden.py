@@ -194,3 +194,12 @@ def test_csv_s3_canon_rows(oracle):
         rows, errs, consumed = oracle.csv_parse_rows(abi.csv_options(**case["opts"]), schema, text)
         assert not errs and consumed == len(text)
         assert [[_typed_value(v) for v in r] for r in rows] == case["expect_rows"], case["name"]
+
+
+def test_csv_splitter_cases(oracle):
+    """csv.Splitter.ConsumeRow (pkg/csv/splitter_test.go): entries and the io.EOF remainder."""
+    for case in golden("csv_splitter.json")["cases"]:
+        data = case["input"].encode()
+        ends = oracle.csv_split_rows(data)
+        rows = [data[a:b].decode() for a, b in zip([0] + ends[:-1], ends)]
+        assert rows == case["rows"] and data[ends[-1] if ends else 0:].decode() == case["eof_rest"], case["name"]

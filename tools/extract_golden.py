@@ -365,6 +365,23 @@ def csv_reader():
     write("csv_reader.json", {"source": "pkg/csv/reader_test.go:13-240", "cases": cases})
 
 
+def csv_splitter():
+    """pkg/csv/splitter_test.go:14-100: the byte streams of the four ConsumeRow tests and the entries they expect (literals of
+    the test; a guard checks they are still in the file)."""
+    with open(REF + "/pkg/csv/splitter_test.go", encoding="utf-8") as f:
+        src = f.read()
+    for lit in ['[]byte("12345678901234567890"),', '[]byte(`"2345"` + "\\n"),', '[]byte(`"23456789012345""89`),', '[]byte(`123456"`),',
+                'require.EqualValues(t, `"23456789012345""89`+"\\n"+`123456"`, builder.String())']:
+        assert lit in src, lit
+    cases = [
+        {"name": "TestScannerBasic", "input": "a\nb", "rows": ["a\n"], "eof_rest": "b"},
+        {"name": "TestScannerBiggerLines", "input": "12345678901234567890\n12345\n", "rows": ["12345678901234567890\n", "12345\n"], "eof_rest": ""},
+        {"name": "TestScannerQuotes", "input": '"234567890123456789"\n"2345"\n', "rows": ['"234567890123456789"\n', '"2345"\n'], "eof_rest": ""},
+        {"name": "TestScannerLineBreaksInsideQuotes", "input": '"23456789012345""89\n123456"', "rows": [], "eof_rest": '"23456789012345""89\n123456"'},
+    ]
+    write("csv_splitter.json", {"source": "pkg/csv/splitter_test.go:14-100", "cases": cases})
+
+
 def csv_typed():
     """The typed half of the CSV ingest: constructCI / getCorrespondingValue / Strictify.
 
@@ -879,4 +896,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_typed(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr()

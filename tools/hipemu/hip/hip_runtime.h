@@ -14,7 +14,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __constant__ static const
+#define __constant__ const
 #define __launch_bounds__(...)
 #define __shared__ static thread_local /* one instance per kernel and host thread: workgroups run one after another */
 #define __builtin_amdgcn_fence(...) ((void)0)

@@ -288,6 +288,11 @@ def charmap_table(encoding: str):
     if name not in _CHARMAPS:
         raise ValueError("csv: unknown Encoding %r (not in x/text charmap.All)" % encoding)
     codec = _CHARMAPS[name]
+    import codecs
+    try:
+        codecs.lookup(codec)
+    except LookupError:
+        raise ValueError("csv: this Python has no table for Encoding %r (%s); pass the 256 code points yourself" % (encoding, codec))
     out = []
     for b in range(256):
         try:

@@ -25,6 +25,8 @@
 #include "tf_segcopy.hpp"
 #include "tf_textview.hpp"
 #include "tf_wave.hpp"
+#include "tf_gotime.hpp"
+#include "tf_f64range.hpp"
 #include "tf_plan.hpp"
 
 namespace tf {
@@ -133,6 +135,11 @@ struct CsvOpts {
   int32_t n_null, n_true, n_false;
   const uint32_t *list_off;  // offsets of null|true|false values, concatenated, into list_data
   const uint8_t *list_data;
+  GtSet user_tp;             // AdditionalReaderOptions.TimestampParsers (Go layouts), compiled
+  GtSet cast_tp;             // spf13/cast StringToDate's layout list, compiled
+  const uint8_t *dp;         // AdditionalReaderOptions.DecimalPoint
+  uint32_t dp_len;
+  uint32_t multiline;        // NewlinesInValue: a row may span physical lines
 };
 
 // sanitizeElement reader.go:273-324: TrimSpace, unquote, count ""-pairs.
@@ -266,7 +273,7 @@ template <class F> __device__ bool json_number_ok(const F &f, uint32_t a, uint32
 // ---------------------------------------------------------------------------
 // cell parse: constructCI / getCorrespondingValue / Strictify for ONE mapped column
 // ---------------------------------------------------------------------------
-enum CsvKind : int32_t { CK_INT, CK_UINT, CK_STR, CK_JSONNUM, CK_DATE, CK_TIMESTAMP, CK_BOOL, CK_F32, CK_DEFAULT, CK_INTERVAL };
+enum CsvKind : int32_t { CK_INT, CK_UINT, CK_STR, CK_JSONNUM, CK_DATE, CK_TIMESTAMP, CK_BOOL, CK_F32, CK_DEFAULT, CK_INTERVAL, CK_SYS /* __file_name / __row_index: filled after the parse */ };
 
 struct CsvCol {
   int32_t field;      // CSV field index (ColSchema.Path); <0 → DefaultValue
@@ -278,7 +285,9 @@ struct CsvCol {
   int32_t *nanos;
   uint32_t *lens;     // string columns: lens[r] = content length (Arrow offsets after the scan)
   uint32_t *fstart;   // string columns: absolute start of the content | bit31 = has doubled quotes; fstart[-1] = the column has such cells (or DefaultValue text)
+  uint32_t *patch;    // float64 columns under DecimalPoint: offset in the cell where the decimal point string becomes '.', or PATCH_NONE
 };
+static constexpr uint32_t PATCH_NONE = 0xFFFFFFFFu;
 
 // Compact column descriptor of the tile path, staged in LDS in (kind, width) order.
 struct TCol {
@@ -295,6 +304,7 @@ struct CsvParams {
   const uint8_t *data;
   uint64_t len;
   const uint32_t *row_start;  // slow path: already shifted by skip_rows
+  const uint32_t *row_end;    // NewlinesInValue: one past the '\n' that completes row r (null: row_start[r + 1])
   int64_t nrows;
   CsvOpts o;
   const CsvCol *cols;
@@ -335,6 +345,7 @@ __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v)
 // DefaultValue(col) (pkg/abstract/change_item_builders.go:88-109) after Strictify
 __device__ __forceinline__ void store_default(const CsvCol &c, int64_t r) {
   switch (c.kind) {
+    case CK_SYS: break;
     case CK_STR: case CK_JSONNUM: c.lens[r] = (c.kind == CK_JSONNUM) ? 1u : 0u; c.fstart[r] = 0x7FFFFFFFu; if (c.kind == CK_JSONNUM) c.fstart[-1] = 1u; break;  // "" / json "0" (a cell that is no byte range: flag word of the column)
     case CK_DATE: case CK_TIMESTAMP: ((int64_t *)c.values)[r] = 0; if (c.nanos) c.nanos[r] = 0; break;
     case CK_BOOL: ((uint8_t *)c.values)[r] = 0; break;
@@ -353,6 +364,38 @@ __device__ __forceinline__ bool cell_is_null(const CsvOpts &o, const F &fv, uint
   }
   if (o.strings_can_be_null) return npairs == 0 && in_list(o, 0, o.n_null, fv, a, b);
   return false;
+}
+
+// strings.Replace(text, DecimalPoint, ".", 1) as a view: the first `k` bytes, a '.', the bytes behind the decimal point string
+template <class F> struct Patched {
+  const F &f; uint32_t a, k, skip;
+  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return i < k ? f[a + i] : i == k ? (uint32_t)'.' : f[a + i + skip - 1]; }
+};
+// strconv.ParseFloat(t[0, n), 64): 0 = err == nil, 1 = an error (syntax or range), 2 = a form left to the host (hexadecimal
+// mantissa, '_' digit separators).  Decimal grammar of readFloat: [+-] digits [. digits] [e [+-] digits], at least one
+// mantissa digit; "inf" / "infinity" (signed) and "nan" (unsigned), any case.
+template <class T> __device__ int parsefloat_err(const T &t, uint32_t n) {
+  if (n == 0) return 1;
+  uint32_t p = 0;
+  if (t[0] == '+' || t[0] == '-') p = 1;
+  const uint32_t w = n - p;
+  auto word = [&](const char *s, uint32_t l) { if (w != l) return false; for (uint32_t i = 0; i < l; i++) if (lower_(t[p + i]) != (uint32_t)s[i]) return false; return true; };
+  if (word("inf", 3) || word("infinity", 8)) return 0;
+  if (p == 0 && word("nan", 3)) return 0;
+  for (uint32_t i = p; i < n; i++) if (t[i] == '_') return 2;
+  if (w >= 2 && t[p] == '0' && lower_(t[p + 1]) == 'x') return 2;
+  uint32_t nd = 0;
+  while (p < n && dg(t[p])) { nd++; p++; }
+  if (p < n && t[p] == '.') { p++; while (p < n && dg(t[p])) { nd++; p++; } }
+  if (!nd) return 1;
+  if (p < n && lower_(t[p]) == 'e') {
+    p++;
+    if (p < n && (t[p] == '+' || t[p] == '-')) p++;
+    if (p >= n || !dg(t[p])) return 1;
+    while (p < n && dg(t[p])) p++;
+  }
+  if (p != n) return 1;
+  return jsonnum_overflow(t, n) ? 1 : 0;  // ±Inf: ErrRange
 }
 
 // One sanitized field [a,b) of `fv` (npairs doubled quotes inside) → column c, row r.
@@ -382,6 +425,27 @@ __device__ int parse_cell(const CsvOpts &o, const CsvCol &c, int64_t r, const F 
     }
     case CK_STR: case CK_JSONNUM: {
       if (c.kind == CK_STR && cell_is_null(o, fv, a, b, npairs)) { c.lens[r] = 0; c.fstart[r] = 0x7FFFFFFFu; return 0; }
+      if (c.kind == CK_JSONNUM && o.dp_len && !npairs && b - a >= o.dp_len) {
+        // parseFloatValue (reader_csv.go:363-378): the first DecimalPoint becomes '.', kept only if ParseFloat takes the result
+        uint32_t k = PATCH_NONE;
+        for (uint32_t i = a; i + o.dp_len <= b && k == PATCH_NONE; i++) {
+          bool eq = true;
+          for (uint32_t j = 0; j < o.dp_len && eq; j++) eq = fv[i + j] == o.dp[j];
+          if (eq) k = i - a;
+        }
+        if (k != PATCH_NONE) {
+          const Patched<F> pt{fv, a, k, o.dp_len};
+          const uint32_t pn = (b - a) - o.dp_len + 1;
+          const int pe = parsefloat_err(pt, pn);
+          if (pe == 2) return TFGPU_ROW_HOST_FALLBACK;
+          if (pe == 0) {
+            struct View { const Patched<F> &t; __device__ uint32_t operator[](uint32_t i) const { return t[i]; } } v{pt};
+            if (!json_number_ok(v, 0, pn)) return TFGPU_ROW_CAST;
+            c.lens[r] = pn; c.fstart[r] = (uint32_t)(abs_start + a); c.patch[r] = k;
+            return 0;
+          }
+        }
+      }
       if (c.kind == CK_JSONNUM && (npairs || !json_number_ok(fv, a, b))) return TFGPU_ROW_CAST;
       c.lens[r] = (b - a) - npairs;
       c.fstart[r] = (uint32_t)(abs_start + a) | (npairs ? 0x80000000u : 0u);
@@ -392,7 +456,12 @@ __device__ int parse_cell(const CsvOpts &o, const CsvCol &c, int64_t r, const F 
       if (npairs) return TFGPU_ROW_CAST;
       int64_t sec = 0; int32_t ns = 0; int rc;
       if (c.kind == CK_TIMESTAMP && parse_int64(fv, a, b, false, &sec) == 0) rc = 0;  // parseTimestampValue :419-426
-      else rc = parse_datetime(fv, a, b, &sec, &ns);
+      else if (c.kind == CK_DATE && o.user_tp.n && gotime_parse_any(o.user_tp, fv, a, b, &sec, &ns)) rc = 0;  // parseDateValue :405-415
+      else {
+        // still a string: cast.ToTimeE → StringToDate, the first of its layouts that parses (strictify.go:118-143)
+        rc = parse_datetime(fv, a, b, &sec, &ns);
+        if (rc) { ns = 0; rc = gotime_parse_any(o.cast_tp, fv, a, b, &sec, &ns) ? 0 : TFGPU_ROW_CAST; }
+      }
       if (rc) return rc;
       ((int64_t *)c.values)[r] = sec;
       c.nanos[r] = ns;
@@ -428,6 +497,14 @@ __device__ void parse_line_hbm(const CsvParams &p, const bool have_row, const in
   int rerr = 0, rerr_col = -1, miss_col = 0x7FFFFFFF, cerr = 0, cerr_col = 0x7FFFFFFF;
   // a line that is just "\n" makes ReadLine return (nil, nil): zero fields (reader.go:146-150)
   const bool nil_line = have_row && (end - pos) <= 1;
+  if (have_row && o.quote == 0) {  // readAndDecodeLine: QuoteChar == 0 and a '"' anywhere in the line → errQuotingDisabled (reader.go:185-187)
+    for (uint64_t q = pos; q < end; q++) if (scan.at(q) == '"') { rerr = TFGPU_ROW_QUOTING_DISABLED; rerr_col = -1; break; }
+  }
+  if (have_row && o.multiline) {
+    // readMultiline drops empty physical lines even inside a quoted value (reader.go:119-124): such a value is not a byte
+    // range of the text any more — the host path rebuilds it
+    for (uint64_t q = pos; q + 2 < end; q++) if (scan.at(q) == '\n' && scan.at(q + 1) == '\n') { rerr = TFGPU_ROW_HOST_FALLBACK; rerr_col = -1; break; }
+  }
   bool active = have_row && !nil_line;
   bool in_quotes = false; uint32_t prev = 0xFFFFFFFFu;
   int32_t nfields = 0;          // fields produced so far by this lane
@@ -494,7 +571,7 @@ __device__ void parse_line_hbm(const CsvParams &p, const bool have_row, const in
 __global__ void __launch_bounds__(256) csv_parse_rows(CsvParams p) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool have_row = r < p.nrows;
-  parse_line_hbm(p, have_row, r, have_row ? p.row_start[r] : 0, have_row ? p.row_start[r + 1] : 0);
+  parse_line_hbm(p, have_row, r, have_row ? p.row_start[r] : 0, have_row ? (p.row_end ? p.row_end[r] : p.row_start[r + 1]) : 0);
 }
 
 // lines listed by the tile path: only the '\n' position is known; walk back to the line start
@@ -1498,7 +1575,7 @@ __global__ void csv_zero_err_lens(const uint8_t *err, int64_t nrows, const CsvCo
 }
 
 static constexpr int FS_HDR = 4;  // words in front of a column's fstart array; the last one is its flag word
-struct CopyCol { const uint32_t *offsets; const uint32_t *fstart; uint8_t *out; int32_t is_jsonnum; };
+struct CopyCol { const uint32_t *offsets; const uint32_t *fstart; uint8_t *out; int32_t is_jsonnum; const uint32_t *patch; uint32_t dp_len; };
 struct CopyParams { const uint8_t *data; int64_t nrows; const CopyCol *cols; int32_t ncols; uint8_t quote; };
 
 // lane = row, wave-uniform loop over string columns.  8-byte words where the
@@ -1515,6 +1592,11 @@ __global__ void __launch_bounds__(256) csv_copy_strings(CopyParams p) {
     uint8_t *dst = c.out + o0;
     if ((fsv & 0x7FFFFFFFu) == 0x7FFFFFFFu) { if (c.is_jsonnum) dst[0] = '0'; continue; }  // DefaultValue of a double is json.Number("0")
     uint64_t s = fsv & 0x7FFFFFFFu;
+    if (c.patch && c.patch[r] != PATCH_NONE) {  // DecimalPoint: the k bytes in front of it, a '.', the rest
+      const uint32_t k = c.patch[r];
+      for (uint32_t w = 0; w < n; w++) dst[w] = w < k ? (uint8_t)src.at(s + w) : w == k ? (uint8_t)'.' : (uint8_t)src.at(s + w + c.dp_len - 1);
+      continue;
+    }
     if (fsv & 0x80000000u) {  // collapse doubled quotes: "" → "
       uint32_t w = 0;
       while (w < n) {
@@ -1608,6 +1690,119 @@ __global__ void csv_shift_rows(const uint32_t *row_start, int64_t n, uint32_t *o
   if (i <= n) out[i] = row_start[i];
 }
 
+// ---- NewlinesInValue (readMultiline, reader.go:110-137): a row is the physical lines from one where no quote is open to the
+//      first after which checkCompleteQuotes holds; empty physical lines are skipped.  Per physical line the quote state
+//      machine is a function {outside, inside} → {outside, inside} (the escape rule only acts inside quotes, so both entry
+//      states are walked at once); composing those functions in line order gives every line's entry state. ----
+__global__ void __launch_bounds__(256) csv_ml_line_fn(const uint8_t *data, const uint32_t *row_start, int64_t nlines, uint8_t quote, uint8_t escape, uint8_t *fn) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlines) return;
+  const uint64_t a = row_start[i], b = row_start[i + 1];
+  if (b - a <= 1) { fn[i] = 2u | 4u; return; }  // identity, blank
+  MemBytes m(data);
+  uint32_t q0 = 0, q1 = 1, p0 = '\n', p1 = '\n';  // checkCompleteQuotes :190-218 under both entry states; prev = the previous line's '\n'
+  for (uint64_t k = a; k < b; k++) {
+    const uint32_t ch = m.at(k);
+    if (!(escape != 0 && p0 == escape && q0)) { if (quote != 0 && ch == quote) q0 ^= 1u; }
+    if (!(escape != 0 && p1 == escape && q1)) { if (quote != 0 && ch == quote) q1 ^= 1u; }
+    p0 = ch; p1 = ch;
+  }
+  fn[i] = (uint8_t)(q0 | (q1 << 1));
+}
+// one workgroup walks all lines, 1024 at a time: entry state of every line, then row begins / ends
+__global__ void __launch_bounds__(1024) csv_ml_rows(const uint8_t *fn, const uint32_t *row_start, int64_t nlines, uint32_t *row_begin, uint32_t *row_end, uint32_t *nrows_out) {
+  __shared__ uint32_t wf[16], wb[16], we[16];
+  __shared__ uint32_t carry[3];  // state, rows begun, rows ended
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { carry[0] = 0; carry[1] = 0; carry[2] = 0; }
+  __syncthreads();
+  for (int64_t base = 0; base < nlines; base += 1024) {
+    const int64_t i = base + tid;
+    const uint32_t f = i < nlines ? fn[i] : 2u;  // identity past the end
+    // inclusive scan of function composition within the wave (log steps), then across the 16 waves
+    uint32_t inc = f & 3u;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc = qf_compose(t, inc); }
+    if (lane == 63) wf[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 2u;
+    for (int k = 0; k < wv; k++) pre = qf_compose(pre, wf[k]);
+    uint32_t ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 2u;
+    const uint32_t before = qf_compose(pre, ex);            // everything of this chunk in front of line i
+    const uint32_t s_in = (before >> carry[0]) & 1u;         // applied to the state the chunk was entered with
+    const uint32_t s_out = ((f & 3u) >> s_in) & 1u;
+    const bool blank = (f & 4u) != 0 || i >= nlines;
+    const uint32_t isb = (!blank && s_in == 0) ? 1u : 0u, ise = (!blank && s_out == 0) ? 1u : 0u;
+    const uint32_t packed = wave_scan_add(isb | (ise << 16));
+    if (lane == 63) { wb[wv] = packed & 0xFFFFu; we[wv] = packed >> 16; }
+    __syncthreads();
+    uint32_t pb = carry[1], pe = carry[2];
+    for (int k = 0; k < wv; k++) { pb += wb[k]; pe += we[k]; }
+    if (isb) row_begin[pb + (packed & 0xFFFFu) - 1] = row_start[i];
+    if (ise) row_end[pe + (packed >> 16) - 1] = row_start[i + 1];
+    __syncthreads();
+    if (tid == 1023) {
+      uint32_t tb = 0, te = 0;
+      for (int k = 0; k < 16; k++) { tb += wb[k]; te += we[k]; }
+      carry[0] = s_out; carry[1] += tb; carry[2] += te;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *nrows_out = carry[2];  // complete rows (a row still open at the end of the chunk is not one)
+}
+
+// constructCI's system columns (reader_csv.go:275-290)
+__global__ void csv_fill_row_index(uint64_t *out, int64_t n, uint64_t base) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = base + (uint64_t)r;  // rowsCounter advances for every line read, failed or not (:217-220)
+}
+__global__ void csv_fill_const_text(uint32_t *off, uint8_t *data, int64_t n, const uint8_t *text, uint32_t len) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  off[r] = (uint32_t)r * len;
+  if (r < n) for (uint32_t i = 0; i < len; i++) data[(uint64_t)r * len + i] = text[i];
+}
+// csv.Reader.Encoding (reader.go:171-179): every byte through the charmap decoder's table, as UTF-8.  Two passes over
+// 4 KiB tiles: bytes out per tile, then the text.
+static constexpr int ENC_TILE = 4096;
+__device__ __forceinline__ uint32_t utf8_len(uint32_t r) { return r < 0x80 ? 1u : r < 0x800 ? 2u : 3u; }
+__global__ void __launch_bounds__(256) csv_decode_count(const uint8_t *in, uint64_t len, const uint32_t *table, uint32_t *tile_bytes) {
+  __shared__ uint32_t tab[256];
+  __shared__ uint32_t tot;
+  tab[threadIdx.x] = table[threadIdx.x];
+  if (threadIdx.x == 0) tot = 0;
+  __syncthreads();
+  uint32_t n = 0;
+  for (int i = 0; i < ENC_TILE / 256; i++) {
+    const uint64_t p = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)i * 256 + threadIdx.x;
+    if (p < len) n += utf8_len(tab[in[p]]);
+  }
+  atomicAdd(&tot, n);
+  __syncthreads();
+  if (threadIdx.x == 0) tile_bytes[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(64) csv_decode_write(const uint8_t *in, uint64_t len, const uint32_t *table, const uint32_t *tile_off, uint8_t *out) {
+  // one wave per tile, 64 bytes per step; positions by a ballot-free wave scan of the lengths
+  uint64_t o = tile_off[blockIdx.x];
+  for (int i = 0; i < ENC_TILE / 64; i++) {
+    const uint64_t p = (uint64_t)blockIdx.x * ENC_TILE + (uint64_t)i * 64 + threadIdx.x;
+    const uint32_t r = p < len ? table[in[p]] : 0u;
+    const uint32_t l = p < len ? utf8_len(r) : 0u;
+    const uint32_t inc = wave_scan_add(l);
+    if (l) {
+      uint8_t *d = out + o + inc - l;
+      if (l == 1) d[0] = (uint8_t)r;
+      else if (l == 2) { d[0] = (uint8_t)(0xC0 | (r >> 6)); d[1] = (uint8_t)(0x80 | (r & 0x3F)); }
+      else { const uint32_t q = r > 0xFFFF ? 0xFFFDu : r; d[0] = (uint8_t)(0xE0 | (q >> 12)); d[1] = (uint8_t)(0x80 | ((q >> 6) & 0x3F)); d[2] = (uint8_t)(0x80 | (q & 0x3F)); }
+    }
+    o += __shfl(inc, 63, 64);
+  }
+}
+__global__ void __launch_bounds__(256) csv_last_newline(const uint8_t *in, uint64_t len, uint32_t *last_plus1) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < len && in[p] == '\n') atomicMax(last_plus1, (uint32_t)p + 1u);
+}
+
 // Shared with the JSON ingest (tf_json.hip): out[0] = 0 and out[k] = offset one past the k-th '\n' of
 // data[0, len) (k = 1..n); returns n.  `data` must be 16-byte aligned and zero-padded past len.
 uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out) {
@@ -1641,7 +1836,7 @@ static void materialize_cols(const tfgpu_dbatch &b, const std::vector<const DCol
     const uint8_t *src = text ? text : ptr<uint8_t>(v.src);
     if (!src) throw Error(TFGPU_ERR_INVALID, "internal: text column " + d.name + " lost its source text");
     v.packed = dalloc(d.data_len + 8);
-    CopyCol c{ptr<uint32_t>(d.offsets), ptr<uint32_t>(v.fstart), ptr<uint8_t>(v.packed), v.jsonnum ? 1 : 0};
+    CopyCol c{ptr<uint32_t>(d.offsets), ptr<uint32_t>(v.fstart), ptr<uint8_t>(v.packed), v.jsonnum ? 1 : 0, nullptr, 0};
     Grp *g = nullptr;
     for (auto &x : groups) if (x.src == src && x.quote == v.quote) g = &x;
     if (!g) { groups.push_back(Grp{src, v.quote, {}, {}, {}}); g = &groups.back(); }
@@ -1679,12 +1874,76 @@ using namespace tf;
   catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
   catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
 
+static inline unsigned blocks_for(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
+
+// ---- csv.Splitter (pkg/csv/splitter.go:37-85): entries end at the '\n's that are outside double quotes ----
+namespace tf {
+__global__ void __launch_bounds__(256) csv_split_count(const uint8_t *data, const uint32_t *row_start, int64_t nlines, uint32_t *quotes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlines) return;
+  MemBytes m(data);
+  uint32_t c = 0;
+  for (uint64_t k = row_start[i]; k < row_start[i + 1]; k++) c += m.at(k) == '"';
+  quotes[i] = c;
+}
+// updateState: outsideQuote / closingQuote ⇔ an even number of '"' so far, quoteOpen ⇔ odd; ConsumeRow returns at a '\n'
+// read in a state that the '\n' itself leaves outside, i.e. after an even count
+__global__ void __launch_bounds__(256) csv_split_keep(const uint32_t *quotes_excl, const uint32_t *quotes, int64_t nlines, uint32_t *keep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nlines) keep[i] = ((quotes_excl[i] + quotes[i]) & 1u) ? 0u : 1u;
+}
+__global__ void __launch_bounds__(256) csv_split_scatter(const uint32_t *keep_scan, const uint32_t *row_start, int64_t nlines, uint32_t *out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nlines && keep_scan[i] != keep_scan[i + 1]) out[keep_scan[i]] = row_start[i + 1];
+}
+}  // namespace tf
+
+extern "C" int tfgpu_csv_split_rows(const void *bytes, uint64_t len, int mem, tfgpu_dbuf **row_ends, int64_t *nrows) {
+  TF_API_BEGIN
+  if (!row_ends || !nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_csv_split_rows: null argument");
+  if (len >= 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_csv_split_rows: chunk must be < 2 GiB");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  hipStream_t st = cx.stream;
+  Buf staged;
+  const uint8_t *data;
+  if (mem == TFGPU_MEM_HOST) {
+    staged = dalloc(len + 64);
+    h2d(staged->p, bytes, len);
+    TF_HIP(hipMemsetAsync((char *)staged->p + len, 0, 64, st));
+    data = ptr<uint8_t>(staged);
+  } else {
+    data = (const uint8_t *)bytes;
+    if (reinterpret_cast<uintptr_t>(data) & 15) return tf::fail(TFGPU_ERR_INVALID, "csv: device buffer must be 16-byte aligned");
+  }
+  Buf rs;
+  const uint32_t nl = newline_starts(data, len, &rs);
+  auto res = std::make_unique<tfgpu_dbuf>();
+  uint32_t m = 0;
+  res->mem = dalloc((size_t)(nl + 1) * 4 + 64);
+  if (nl) {
+    Buf q = dalloc((size_t)(nl + 1) * 4), qs = dalloc((size_t)(nl + 1) * 4), keep = dalloc((size_t)(nl + 1) * 4);
+    csv_split_count<<<blocks_for(nl, 256), 256, 0, st>>>(data, ptr<uint32_t>(rs), nl, ptr<uint32_t>(q));
+    exclusive_scan_u32(ptr<uint32_t>(q), ptr<uint32_t>(qs), nl, false);
+    csv_split_keep<<<blocks_for(nl, 256), 256, 0, st>>>(ptr<uint32_t>(qs), ptr<uint32_t>(q), nl, ptr<uint32_t>(keep));
+    exclusive_scan_u32(ptr<uint32_t>(keep), ptr<uint32_t>(keep), nl, true);
+    const uint32_t *h = d2h_u32(ptr<uint32_t>(keep) + nl);
+    csv_split_scatter<<<blocks_for(nl, 256), 256, 0, st>>>(ptr<uint32_t>(keep), ptr<uint32_t>(rs), nl, ptr<uint32_t>(res->mem));
+    tf::sync();
+    m = *h;
+  }
+  res->size = (uint64_t)m * 4;
+  *nrows = m;
+  *row_ends = res.release();
+  return TFGPU_OK;
+  TF_API_END
+}
+
 extern "C" void tfgpu_csv_options_default(tfgpu_csv_options *o) {  // csv.NewReader reader.go:337-350
   std::memset(o, 0, sizeof *o);
   o->delimiter = ','; o->quote_char = '"'; o->escape_char = '\\'; o->double_quote = 1;
 }
 
-static inline unsigned blocks_for(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
 
 extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes, uint64_t len, int mem,
                                tfgpu_dbatch **out, uint64_t *consumed, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
@@ -1694,10 +1953,9 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   // validDelimiter reader.go:326-328
   if (opts->delimiter == 0 || opts->delimiter == '\r' || opts->delimiter == '\n' || opts->delimiter >= 0x80)
     return tf::fail(TFGPU_ERR_CONFIG, "csv: invalid delimiter");
-  if (opts->newlines_in_value && opts->quote_char)
-    return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: NewlinesInValue (multi-line quoted fields) is not device-resident yet");
-  if (opts->n_timestamp_parsers > 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: user TimestampParsers layouts are not device-resident yet");
-  if (opts->decimal_point && opts->decimal_point[0]) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: DecimalPoint is not device-resident yet");
+  const bool multiline = opts->newlines_in_value && opts->quote_char;  // ReadLine :93-99
+  if (multiline && opts->escape_char == '\n') return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: NewlinesInValue with '\\n' as the escape character");
+  const std::string dp = (opts->decimal_point && opts->decimal_point[0]) ? opts->decimal_point : "";
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
   PinScope pin_scope;
@@ -1716,6 +1974,32 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     if (reinterpret_cast<uintptr_t>(data) & 15) return tf::fail(TFGPU_ERR_INVALID, "csv: device buffer must be 16-byte aligned");
   }
 
+  // ---- csv.Reader.Encoding: the whole chunk through the charmap table (lines are cut at the raw '\n' first, which is the
+  //      same thing as long as '\n' decodes to itself and nothing else decodes to it) ----
+  const uint8_t *raw_data = data; const uint64_t raw_len = len;
+  Buf decoded, raw_keep = staged;  // (the raw bytes are read once more for the consumed offset)
+  if (opts->encoding_table) {
+    const uint32_t *tab = opts->encoding_table;
+    for (int b = 0; b < 256; b++) if ((tab[b] == 0x0A) != (b == 0x0A)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: an Encoding that moves the line feed (EBCDIC code pages) is not device-resident");
+    Buf btab = upload_small(tab, 256 * 4);
+    const int64_t et = (int64_t)((len + ENC_TILE - 1) / ENC_TILE);
+    Buf tb = dalloc((size_t)(et + 1) * 4);
+    uint32_t dlen = 0;
+    if (et) {
+      csv_decode_count<<<(unsigned)et, 256, 0, st>>>(data, len, ptr<uint32_t>(btab), ptr<uint32_t>(tb));
+      exclusive_scan_u32(ptr<uint32_t>(tb), ptr<uint32_t>(tb), et, true);
+      const uint32_t *h = d2h_u32(ptr<uint32_t>(tb) + et);
+      tf::sync();
+      dlen = *h;
+    }
+    if ((uint64_t)len * 3 >= 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: chunk too large to decode in one piece");
+    decoded = dalloc((size_t)dlen + 64);
+    if (et) csv_decode_write<<<(unsigned)et, 64, 0, st>>>(data, len, ptr<uint32_t>(btab), ptr<uint32_t>(tb), ptr<uint8_t>(decoded));
+    TF_HIP(hipMemsetAsync((char *)decoded->p + dlen, 0, 64, st));
+    data = ptr<uint8_t>(decoded); len = dlen;
+    staged = decoded;  // the text the columns keep alive
+  }
+
   // ---- 1/2: line index ----
   int64_t ntiles = (int64_t)((len + NL_TILE - 1) / NL_TILE);
   Buf tile_counts = dalloc((size_t)(ntiles + 1) * 4);
@@ -1729,15 +2013,31 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   }
   // TFGPU_CSV_ROWPATH=1 forces the per-row path for whole chunks (the tile path's parity cross-check)
   static const bool force_rowpath = [] { const char *e = std::getenv("TFGPU_CSV_ROWPATH"); return e && e[0] == '1'; }();
-  const bool rowpath = force_rowpath || opts->escape_char == '\n' || opts->escape_char >= 0x80 || opts->quote_char >= 0x80;
+  // the tile kernels are specialised for the plain shape of the options; the rest takes the per-row path, which carries every rule
+  const bool rowpath = force_rowpath || opts->escape_char == '\n' || opts->escape_char >= 0x80 || opts->quote_char >= 0x80 || opts->quote_char == 0 ||
+                       opts->n_timestamp_parsers > 0 || !dp.empty() || multiline;
   Buf row_start;
   if (rowpath) {
     row_start = dalloc_zero((size_t)(nlines + 2) * 4);
     if (nlines) { KernelTimer t("csv_line_index"); csv_line_index<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ptr<uint32_t>(row_start)); }
   }
-  int64_t skip = std::min<int64_t>(std::max<int64_t>(opts->skip_rows, 0), nlines);
-  int64_t nrows = (int64_t)nlines - skip;
-  const uint32_t *rs = rowpath ? ptr<uint32_t>(row_start) + skip : nullptr;
+  int64_t nlogical = nlines;  // rows ReadLine yields
+  Buf ml_begin, ml_end;
+  if (multiline) {
+    Buf fn = dalloc((size_t)nlines + 16), cnt = dalloc_zero(4);
+    ml_begin = dalloc((size_t)(nlines + 1) * 4); ml_end = dalloc((size_t)(nlines + 1) * 4);
+    if (nlines) {
+      KernelTimer t("csv_line_index");
+      csv_ml_line_fn<<<blocks_for(nlines, 256), 256, 0, st>>>(data, ptr<uint32_t>(row_start), nlines, opts->quote_char, opts->escape_char, ptr<uint8_t>(fn));
+      csv_ml_rows<<<1, 1024, 0, st>>>(ptr<uint8_t>(fn), ptr<uint32_t>(row_start), nlines, ptr<uint32_t>(ml_begin), ptr<uint32_t>(ml_end), ptr<uint32_t>(cnt));
+    }
+    const uint32_t *h = d2h_u32(cnt->p);
+    tf::sync();
+    nlogical = *h;
+  }
+  int64_t skip = std::min<int64_t>(std::max<int64_t>(opts->skip_rows, 0), nlogical);
+  int64_t nrows = nlogical - skip;
+  const uint32_t *rs = multiline ? ptr<uint32_t>(ml_begin) + skip : rowpath ? ptr<uint32_t>(row_start) + skip : nullptr;
 
   // ---- column plan ----
   int ncols = schema->ncols;
@@ -1747,6 +2047,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   int nstr = 0;
   for (int i = 0; i < ncols; i++) {
     int k = schema->cols[i].dtype;
+    const std::string nm = schema->cols[i].name ? schema->cols[i].name : "";
+    if (nm == "__file_name" || nm == "__row_index") continue;
     if (k == TFGPU_T_UTF8 || k == TFGPU_T_BYTES || k == TFGPU_T_ANY || k == TFGPU_T_FLOAT64) nstr++;
   }
   int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
@@ -1757,10 +2059,21 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   int max_field = -1;
   int si = 0;
   std::vector<int> str_col_index;
+  std::vector<std::pair<int, int>> sys_cols;  // (schema index, 1 = __file_name | 2 = __row_index)
   for (int i = 0; i < ncols; i++) {
     const tfgpu_colschema &sc = schema->cols[i];
     CsvCol &c = cols[(size_t)i];
     std::memset(&c, 0, sizeof c);
+    const std::string cname = sc.name ? sc.name : "";
+    const int sys = cname == "__file_name" ? 1 : cname == "__row_index" ? 2 : 0;  // s3_reader.SystemColumnNames: no CSV field, no Path
+    if (sys) {
+      c.field = -1; c.next = -1; c.kind = CK_SYS;
+      DColumn d;
+      d.name = cname; d.dtype = sc.dtype; d.repr = sys == 1 ? TFGPU_R_STRING : TFGPU_R_UINT64;
+      sys_cols.push_back({i, sys});
+      db->cols.push_back(std::move(d));
+      continue;
+    }
     const char *path = sc.path ? sc.path : "";
     char *endp = nullptr;
     long idx = std::strtol(path, &endp, 10);
@@ -1814,6 +2127,29 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   auto up = [&](const void *src, size_t bytes) { return upload_small(src, bytes); };
   Buf bcols = up(cols.data(), cols.size() * sizeof(CsvCol)), bff = up(field_first.data(), field_first.size() * 4);
   Buf bloff = up(loff.data(), loff.size() * 4), bldata = up(ldata.data(), ldata.size());
+  // time layouts: the user's TimestampParsers, and spf13/cast v1.7.1 StringToDate's list (caste.go timeFormats) in its order
+  static const char *const CAST_LAYOUTS[] = {
+      "2006-01-02", "2006-01-02T15:04:05Z07:00", "2006-01-02T15:04:05", "Mon, 02 Jan 2006 15:04:05 -0700", "Mon, 02 Jan 2006 15:04:05 MST",
+      "02 Jan 06 15:04 -0700", "02 Jan 06 15:04 MST", "Monday, 02-Jan-06 15:04:05 MST", "2006-01-02 15:04:05.999999999 -0700 MST",
+      "2006-01-02T15:04:05-0700", "2006-01-02 15:04:05Z0700", "2006-01-02 15:04:05", "Mon Jan _2 15:04:05 2006", "Mon Jan _2 15:04:05 MST 2006",
+      "Mon Jan 02 15:04:05 -0700 2006", "2006-01-02 15:04:05Z07:00", "02 Jan 2006", "2006-01-02 15:04:05 -07:00", "2006-01-02 15:04:05 -0700",
+      "3:04PM", "Jan _2 15:04:05", "Jan _2 15:04:05.000", "Jan _2 15:04:05.000000", "Jan _2 15:04:05.000000000"};
+  std::vector<GtOp> gops; std::string glits; std::vector<uint16_t> gstart_user{0}, gstart_cast;
+  for (int i = 0; i < opts->n_timestamp_parsers; i++) { gotime_compile(opts->timestamp_parsers[i] ? opts->timestamp_parsers[i] : "", gops, glits); gstart_user.push_back((uint16_t)gops.size()); }
+  gstart_cast.push_back((uint16_t)gops.size());
+  for (const char *l : CAST_LAYOUTS) { gotime_compile(l, gops, glits); gstart_cast.push_back((uint16_t)gops.size()); }
+  Buf bgops = up(gops.data(), gops.size() * sizeof(GtOp)), bglits = up(glits.data(), glits.size());
+  Buf bgsu = up(gstart_user.data(), gstart_user.size() * 2), bgsc = up(gstart_cast.data(), gstart_cast.size() * 2), bdp = up(dp.data(), dp.size());
+  Buf patch_all;
+  if (!dp.empty()) {  // where a float64 cell's decimal point string sits (reader_csv.go:363-378)
+    int nf = 0;
+    for (auto &c : cols) if (c.kind == CK_JSONNUM) nf++;
+    patch_all = dalloc((size_t)std::max(nf, 1) * (size_t)std::max<int64_t>(nrows, 1) * 4);
+    TF_HIP(hipMemsetAsync(patch_all->p, 0xFF, patch_all->bytes, st));
+    int k = 0;
+    for (auto &c : cols) if (c.kind == CK_JSONNUM) c.patch = ptr<uint32_t>(patch_all) + (size_t)(k++) * (size_t)std::max<int64_t>(nrows, 1);
+    bcols = up(cols.data(), cols.size() * sizeof(CsvCol));
+  }
   Buf err = dalloc((size_t)nrows + 16), err_col = dalloc((size_t)nrows * 4 + 16), nerr = dalloc_zero(4);
 
   // lines the tile path hands to the per-row path (at most one per tile per pass) + consumed offset
@@ -1824,6 +2160,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   CsvParams pp;
   std::memset(&pp, 0, sizeof pp);
   pp.data = data; pp.len = len; pp.row_start = rs; pp.nrows = nrows;
+  pp.row_end = multiline ? ptr<uint32_t>(ml_end) + skip : nullptr;
   pp.tile_base = ptr<uint32_t>(tile_counts); pp.ntiles = ntiles; pp.skip_rows = skip;
   pp.slow_n = ptr<uint32_t>(slow); pp.last_end = ptr<uint32_t>(slow) + 1;
   pp.slow_row = ptr<uint32_t>(slow) + 2; pp.slow_end = ptr<uint32_t>(slow) + 2 + slow_cap;
@@ -1832,6 +2169,9 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.o.quoted_strings_can_be_null = opts->quoted_strings_can_be_null; pp.o.pad = 0;
   pp.o.n_null = opts->n_null_values; pp.o.n_true = opts->n_true_values; pp.o.n_false = opts->n_false_values;
   pp.o.list_off = ptr<uint32_t>(bloff); pp.o.list_data = ptr<uint8_t>(bldata);
+  pp.o.user_tp = GtSet{ptr<GtOp>(bgops), ptr<uint8_t>(bglits), ptr<uint16_t>(bgsu), opts->n_timestamp_parsers};
+  pp.o.cast_tp = GtSet{ptr<GtOp>(bgops), ptr<uint8_t>(bglits), ptr<uint16_t>(bgsc), (int32_t)(sizeof CAST_LAYOUTS / sizeof *CAST_LAYOUTS)};
+  pp.o.dp = ptr<uint8_t>(bdp); pp.o.dp_len = (uint32_t)dp.size(); pp.o.multiline = multiline ? 1u : 0u;
   pp.cols = ptr<CsvCol>(bcols); pp.ncols = ncols; pp.field_first = ptr<int32_t>(bff); pp.nfields_used = max_field + 1;
   pp.err = ptr<uint8_t>(err); pp.err_col = ptr<int32_t>(err_col); pp.nerr = ptr<uint32_t>(nerr);
   static const int ablate = [] { const char *e = std::getenv("TFGPU_CSV_ABLATE"); return e ? std::atoi(e) : 0; }();
@@ -1868,10 +2208,6 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.runs = ptr<CsvRun>(bruns); pp.nruns = (int32_t)runs.size();
   pp.null_checks = (opts->strings_can_be_null || opts->quoted_strings_can_be_null) ? 1 : 0;
 
-  // QuoteChar == 0 and the data holds '"' → errQuotingDisabled for that line (reader.go:182-184):
-  // the state machine cannot see it (quote disabled), so treat '"' as an error marker via the quote path
-  if (opts->quote_char == 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: QuoteChar=0 (quoting disabled) is not device-resident yet");
-
   if (ablate) {  // profiling only: what the skipped phases would have written must not be garbage
     TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)std::max(nstr, 1) * (size_t)seg_stride * 4, st));
     TF_HIP(hipMemsetAsync(fstart_all->p, 0, (size_t)std::max(nstr, 1) * (size_t)fstride * 4, st));
@@ -1886,7 +2222,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     const int64_t per_xcd = (ntiles + 7) / 8;
     { KernelTimer t("csv_parse_tiles"); csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_tiles_general"); csv_parse_tiles_general<<<(unsigned)std::min<int64_t>(ntiles, 2048), CT_THREADS, 0, st>>>(pp); }
-    { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 8192), 64, 0, st>>>(pp); }
+    { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 1024), 64, 0, st>>>(pp); }
   }
   if (nrows && nstr) {
     csv_zero_err_lens<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint8_t>(err), nrows, ptr<CsvCol>(bcols), ncols);
@@ -1931,7 +2267,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     for (int s = 0; s < nstr; s++) {
       DColumn &d = db->cols[(size_t)str_col_index[(size_t)s]];
       d.data = dalloc(d.data_len + 8);
-      cc.push_back(CopyCol{ptr<uint32_t>(d.offsets), cols[(size_t)str_col_index[(size_t)s]].fstart, ptr<uint8_t>(d.data), d.repr == TFGPU_R_JSONNUM ? 1 : 0});
+      const CsvCol &hc = cols[(size_t)str_col_index[(size_t)s]];
+      cc.push_back(CopyCol{ptr<uint32_t>(d.offsets), hc.fstart, ptr<uint8_t>(d.data), d.repr == TFGPU_R_JSONNUM ? 1 : 0, hc.patch, dp.empty() ? 0u : (uint32_t)dp.size()});
     }
     Buf bcc = up(cc.data(), cc.size() * sizeof(CopyCol));
     if (nrows) {
@@ -1941,6 +2278,27 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     }
   } else if (nstr && (!src_block || force_eager)) {
     materialize_from(*db, data);
+  }
+
+  for (auto &sy : sys_cols) {  // constructCI :275-290
+    DColumn &d = db->cols[(size_t)sy.first];
+    const int64_t n1 = std::max<int64_t>(nrows, 1);
+    if (sy.second == 2) {
+      d.values = dalloc((size_t)n1 * 8);
+      if (nrows) csv_fill_row_index<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint64_t>(d.values), nrows, opts->row_number_base);
+    } else {
+      const std::string fn = opts->file_name ? opts->file_name : "";
+      Buf btext = upload_small(fn.data(), fn.size());
+      d.offsets = dalloc((size_t)(nrows + 1) * 4 + 16);
+      d.data_len = (uint64_t)fn.size() * (uint64_t)nrows;
+      if (d.data_len >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "csv: __file_name column exceeds 4 GiB");
+      d.data = dalloc(d.data_len + 8);
+      csv_fill_const_text<<<blocks_for(nrows + 1, 256), 256, 0, st>>>(ptr<uint32_t>(d.offsets), ptr<uint8_t>(d.data), nrows, ptr<uint8_t>(btext), (uint32_t)fn.size());
+    }
+    if (opts->hide_system_cols) {  // config.hideSystemCols: both are nil
+      d.validity = dalloc_zero((size_t)(nrows + 7) / 8 + 8);
+      if (sy.second == 1) { d.data_len = 0; TF_HIP(hipMemsetAsync(d.offsets->p, 0, (size_t)(nrows + 1) * 4, st)); }
+    }
   }
 
   std::unique_ptr<tfgpu_dbatch> result;
@@ -1957,7 +2315,15 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   } else {
     result = std::move(db);
   }
-  if (consumed) *consumed = last;
+  uint64_t consumed_raw = last;
+  if (decoded) {  // offsets count the bytes read from the stream (reader.go:169): one past the last raw '\n'
+    Buf lp = dalloc_zero(4);
+    if (raw_len) csv_last_newline<<<blocks_for((int64_t)raw_len, 256), 256, 0, st>>>(raw_data, raw_len, ptr<uint32_t>(lp));
+    const uint32_t *h = d2h_u32(lp->p);
+    tf::sync();
+    consumed_raw = *h;
+  }
+  if (consumed) *consumed = consumed_raw;
   if (nerrs) *nerrs = ne;
   *out = result.release();
   return TFGPU_OK;

@@ -28,7 +28,7 @@ EXPORTS = [
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
-    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -78,6 +78,7 @@ def load():
     L.tfgpu_dbatch_free.argtypes = [P]
     L.tfgpu_dbatch_free.restype = None
     L.tfgpu_apply.argtypes = [C.POINTER(P), C.c_int, P, C.POINTER(P), C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
+    L.tfgpu_csv_split_rows.argtypes = [P, C.c_uint64, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
     L.tfgpu_transformation_create.argtypes = [C.POINTER(P), C.c_int, C.POINTER(P)]
     L.tfgpu_transformation_destroy.argtypes = [P]
     L.tfgpu_transformation_table_plan.argtypes = [P, C.c_char_p, C.c_char_p, C.POINTER(abi.CSchema), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
@@ -559,6 +560,18 @@ def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int =
     el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
           for i in range(min(int(nerr.value), max_errors))]
     return DeviceBatch(out), int(consumed.value), el
+
+
+def csv_split_rows(data) -> np.ndarray:
+    """csv.Splitter (pkg/csv/splitter.go): offsets one past the '\\n' of every complete entry of the chunk."""
+    init()
+    out, n = C.c_void_p(), C.c_int64(0)
+    p, ln, mem, keep = _bytes_arg(data)
+    _check(load().tfgpu_csv_split_rows(p, ln, mem, C.byref(out), C.byref(n)))
+    buf = DeviceBuffer(out)
+    raw = buf.download()
+    buf.free()
+    return np.frombuffer(raw, dtype=np.uint32)[: n.value].copy()
 
 
 def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data, msgs: Optional[abi.CMessages] = None, max_errors: int = 1 << 16):
