@@ -91,12 +91,13 @@ typedef enum tfgpu_repr {
  * filter_rows treats "Insert"/"insert" etc. as equal (filter_rows.go:92-96). */
 typedef enum tfgpu_kind {
   TFGPU_K_INSERT = 0, TFGPU_K_UPDATE = 1, TFGPU_K_DELETE = 2,
-  TFGPU_K_OTHER = 3 /* any non-row kind: passes through every row kernel */
+  TFGPU_K_OTHER = 3, /* any non-row kind: passes through every row kernel */
+  TFGPU_K_SYNCHRONIZE = 4 /* SynchronizeKind: a non-row kind too, but InsertsOnly counts it as an insert (change_item_collapse.go:37-44) */
 } tfgpu_kind;
 
 enum { TFGPU_MEM_HOST = 0, TFGPU_MEM_DEVICE = 1 };
 
-enum { TFGPU_COL_KEY = 1u /* ColSchema.PrimaryKey */, TFGPU_COL_REQUIRED = 2u };
+enum { TFGPU_COL_KEY = 1u /* ColSchema.PrimaryKey */, TFGPU_COL_REQUIRED = 2u, TFGPU_COL_FAKE_KEY = 4u /* ColSchema.FakeKey */ };
 
 /* One ColSchema (pkg/abstract/changeitem/col_schema.go:14-29). */
 typedef struct tfgpu_colschema {
@@ -105,6 +106,11 @@ typedef struct tfgpu_colschema {
   uint32_t flags;            /* TFGPU_COL_*                                   */
   const char *path;          /* ColSchema.Path (CSV: decimal column index)    */
   const char *original_type; /* ColSchema.OriginalType or NULL                */
+  /* the fields only the wire form reads (ChangeItem.MarshalJSON → NativeSerializer); NULL = ""    */
+  const char *table_schema;  /* ColSchema.TableSchema                         */
+  const char *table_name;    /* ColSchema.TableName                           */
+  const char *expression;    /* ColSchema.Expression                          */
+  const char *properties_json; /* json.Marshal(ColSchema.Properties) when the map is non-empty (the key is omitempty), else NULL */
 } tfgpu_colschema;
 
 typedef struct tfgpu_schema {
@@ -311,9 +317,10 @@ int tfgpu_wait(tfgpu_token *token, tfgpu_dbatch **transformed, tfgpu_dbatch **er
  * is the row whose Kind / OldKeys / LSN it keeps (the first of its chain); its values are the last writer's.
  * Batches with fewer than two rows, inserts only, or no key column come back unchanged.
  * Caller contract (the columnar batch cannot say more): every item shares the batch's ColumnNames — batches mixing
- * TOAST-style updates with fewer columns take the Go path (compareColumns, :7-35); TFGPU_K_OTHER must not stand for
- * SynchronizeKind here (InsertsOnly, :37-44, treats that one as an insert).  Keys are compared through 128-bit hashes of
- * their json.Marshal text.  TFGPU_ERR_UNSUPPORTED: NaN / Inf in a float key column, more than 2^29 rows.             */
+ * TOAST-style updates with fewer columns take the Go path (compareColumns, :7-35); SynchronizeKind items are uploaded as
+ * TFGPU_K_SYNCHRONIZE (InsertsOnly, :37-44, treats that one as an insert).  Keys are filed by 128-bit hashes of their
+ * json.Marshal text and, hash for hash, compared as strings: two rows share a key exactly when the reference's map would
+ * file them under one string.  TFGPU_ERR_UNSUPPORTED: NaN / Inf in a float key column, more than 2^29 rows.             */
 int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out);
 
 /* ChangeItem.KeysChanged (pkg/abstract/changeitem/change_item.go:237-286) for every row: changed[r] = 1 iff row r is an
@@ -476,7 +483,9 @@ int tfgpu_sr_json_parse(const tfgpu_sr_json_options *opts, const void *bytes, ui
 enum {
   TFGPU_FMT_CH_JSON_EACH_ROW = 1, /* httpuploader.MarshalCItoJSON             */
   TFGPU_FMT_JSON = 2,             /* pkg/serializer/json.go (sorted keys)     */
-  TFGPU_FMT_CSV = 3               /* pkg/serializer/csv.go                    */
+  TFGPU_FMT_CSV = 3,              /* pkg/serializer/csv.go                    */
+  TFGPU_FMT_RAW = 4               /* pkg/serializer/raw.go:24-63: a mirror item's `data` bytes (+ '\n' with AddClosingNewLine; the batch
+                                     serializer joins with '\n' otherwise, batch_factory.go:36-47); any other item: an error */
 };
 /* Target column of the ClickHouse sink — the fields of columntypes.TypeDescription
  * (pkg/providers/clickhouse/columntypes) that marshalValue / marshalTime read

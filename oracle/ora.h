@@ -53,7 +53,12 @@ typedef struct ora_colschema {
   int key;
   char *path;
   char *original_type;
+  /* the ColSchema fields only the wire form reads (col_schema.go:14-29): interned strings (ora_intern), never freed,
+   * so that the struct copies all over the oracle may share them */
+  const char *table_schema, *table_name, *expression, *properties_json;
+  int fake_key, required;
 } ora_colschema;
+const char *ora_intern(const char *s); /* NULL → "" */
 
 typedef struct ora_schema {
   int ncols;

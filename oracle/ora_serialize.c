@@ -332,7 +332,7 @@ char *ora_serialize_ex(int format, const ora_batch *bt, const tfgpu_serialize_op
   b.p = (char *)malloc(64); b.cap = 64;
   for (int64_t r = 0; r < bt->n; r++) {
     const ora_item *it = &bt->items[r];
-    if (it->kind == TFGPU_K_OTHER) continue; /* !IsRowEvent */
+    if (it->kind > TFGPU_K_DELETE) continue; /* !IsRowEvent */
     switch (format) {
       case TFGPU_FMT_CH_JSON_EACH_ROW: ch_row(&b, it, o); break;
       case TFGPU_FMT_JSON:
@@ -341,6 +341,15 @@ char *ora_serialize_ex(int format, const ora_batch *bt, const tfgpu_serialize_op
         else if (r + 1 < bt->n) sb_c(&b, '\n');            /* separator between items, none after the last */
         break;
       case TFGPU_FMT_CSV: csv_row(&b, it); break;
+      case TFGPU_FMT_RAW: { /* rawSerializer.Serialize raw.go:24-39 under batchSerializer (separator "\n" unless AddClosingNewLine) */
+        static const char *const MIRROR[] = {"topic", "partition", "seq_no", "write_time", "data", "meta", "sequence_key"};
+        int mirror = it->names && it->names->n == 7;
+        for (int c = 0; mirror && c < 7; c++) mirror = !strcmp(it->names->names[c], MIRROR[c]);
+        if (!mirror || !(it->values[4].kind == OV_BYTES || it->values[4].kind == OV_STRING)) { b.unsupported = 1; break; }
+        sb_put(&b, it->values[4].s, it->values[4].slen);
+        if ((o && o->add_closing_newline) || r + 1 < bt->n) sb_c(&b, '\n');
+        break;
+      }
       default: b.unsupported = 1;
     }
   }
@@ -436,7 +445,7 @@ static void item_set_values_from(ora_item *cur, const ora_item *c) {  /* compare
 ora_batch *ora_collapse(const ora_batch *in) {
   ora_batch *out = ora_batch_new();
   int passthrough = in->n < 2;
-  if (!passthrough) { passthrough = 1; for (int64_t i = 0; i < in->n; i++) if (in->items[i].kind != TFGPU_K_INSERT) { passthrough = 0; break; } }  /* InsertsOnly */
+  if (!passthrough) { passthrough = 1; for (int64_t i = 0; i < in->n; i++) if (in->items[i].kind != TFGPU_K_INSERT && in->items[i].kind != TFGPU_K_SYNCHRONIZE) { passthrough = 0; break; } }  /* InsertsOnly :37-44 */
   /* keyCols := input[0].MakeMapKeys(): the PrimaryKey columns of its TableSchema */
   char **kn = NULL; int nk = 0;
   if (!passthrough && in->items[0].schema) {
@@ -705,16 +714,24 @@ static void native_table_schema(sbuf *b, const tfgpu_schema *ts, const ora_schem
     const char *name = ts ? ts->cols[i].name : os->cols[i].name;
     int dtype = ts ? ts->cols[i].dtype : os->cols[i].dtype;
     int key = ts ? !!(ts->cols[i].flags & TFGPU_COL_KEY) : os->cols[i].key;
-    int req = ts ? !!(ts->cols[i].flags & TFGPU_COL_REQUIRED) : 0;
+    int req = ts ? !!(ts->cols[i].flags & TFGPU_COL_REQUIRED) : os->cols[i].required;
+    int fake = ts ? !!(ts->cols[i].flags & TFGPU_COL_FAKE_KEY) : os->cols[i].fake_key;
     const char *path = ts ? ts->cols[i].path : os->cols[i].path;
     const char *ot = ts ? ts->cols[i].original_type : os->cols[i].original_type;
+    const char *tsn = ts ? ts->cols[i].table_schema : os->cols[i].table_schema, *tbn = ts ? ts->cols[i].table_name : os->cols[i].table_name;
+    const char *ex = ts ? ts->cols[i].expression : os->cols[i].expression, *pj = ts ? ts->cols[i].properties_json : os->cols[i].properties_json;
     if (i) sb_c(b, ',');
-    sb_s(b, "{\"table_schema\":\"\",\"table_name\":\"\",\"path\":"); json_string(b, path ? path : "", path ? strlen(path) : 0, 1);
+    sb_s(b, "{\"table_schema\":"); json_string(b, tsn ? tsn : "", tsn ? strlen(tsn) : 0, 1);
+    sb_s(b, ",\"table_name\":"); json_string(b, tbn ? tbn : "", tbn ? strlen(tbn) : 0, 1);
+    sb_s(b, ",\"path\":"); json_string(b, path ? path : "", path ? strlen(path) : 0, 1);
     sb_s(b, ",\"name\":"); json_string(b, name ? name : "", name ? strlen(name) : 0, 1);
     sb_s(b, ",\"type\":"); { const char *tn = dtype > 0 && dtype < TFGPU_T__COUNT ? DTYPE_NAMES[dtype] : ""; json_string(b, tn, strlen(tn), 1); }
     sb_s(b, ",\"key\":"); sb_s(b, key ? "true" : "false");
-    sb_s(b, ",\"fake_key\":false,\"required\":"); sb_s(b, req ? "true" : "false");
-    sb_s(b, ",\"expression\":\"\",\"original_type\":"); json_string(b, ot ? ot : "", ot ? strlen(ot) : 0, 1);
+    sb_s(b, ",\"fake_key\":"); sb_s(b, fake ? "true" : "false");
+    sb_s(b, ",\"required\":"); sb_s(b, req ? "true" : "false");
+    sb_s(b, ",\"expression\":"); json_string(b, ex ? ex : "", ex ? strlen(ex) : 0, 1);
+    sb_s(b, ",\"original_type\":"); json_string(b, ot ? ot : "", ot ? strlen(ot) : 0, 1);
+    if (pj && pj[0]) { sb_s(b, ",\"properties\":"); sb_s(b, pj); } /* omitempty */
     sb_c(b, '}');
   }
   sb_c(b, ']');
@@ -771,7 +788,7 @@ static void native_item(sbuf *b, const ora_item *it, const tfgpu_queue_options *
 /* one element as the format's batcher sees it: returns 0, or 1 = the reference's Serialize returns an error */
 static int queue_element(sbuf *e, int format, const ora_item *it, const tfgpu_queue_options *o, const tfgpu_row_meta *m, const char *part) {
   if (format == TFGPU_QFMT_NATIVE) { native_item(e, it, o, m, part); return 0; }
-  if (it->kind == TFGPU_K_OTHER) return 0;                                   /* !IsRowEvent: empty bytes (json.go:51-53) */
+  if (it->kind > TFGPU_K_DELETE) return 0;                                    /* !IsRowEvent: empty bytes (json.go:51-53) */
   if (it->kind == TFGPU_K_UPDATE || it->kind == TFGPU_K_DELETE) return 1;    /* UnsupportedItemKinds (json.go:54-56)     */
   json_row(e, it, NULL);
   return 0;

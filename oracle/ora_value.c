@@ -31,6 +31,16 @@ ora_value ora_value_clone(const ora_value *v) {
 
 ora_batch *ora_batch_new(void) { return (ora_batch *)calloc(1, sizeof(ora_batch)); }
 
+/* a tiny string pool for the schema strings that are copied around by value */
+const char *ora_intern(const char *s) {
+  static char **pool = NULL; static int n = 0, cap = 0;
+  if (!s) s = "";
+  for (int i = 0; i < n; i++) if (strcmp(pool[i], s) == 0) return pool[i];
+  if (n == cap) { cap = cap ? cap * 2 : 32; pool = (char **)realloc(pool, sizeof(char *) * (size_t)cap); }
+  pool[n] = dups(s);
+  return pool[n++];
+}
+
 void ora_schema_unref(ora_schema *s) {
   if (!s) return;
   if (--s->refs > 0) return;
@@ -95,6 +105,10 @@ ora_schema *ora_schema_from(const tfgpu_schema *s) {
     r->cols[i].key = (s->cols[i].flags & TFGPU_COL_KEY) != 0;
     r->cols[i].path = dups(s->cols[i].path ? s->cols[i].path : "");
     r->cols[i].original_type = dups(s->cols[i].original_type ? s->cols[i].original_type : "");
+    r->cols[i].table_schema = ora_intern(s->cols[i].table_schema); r->cols[i].table_name = ora_intern(s->cols[i].table_name);
+    r->cols[i].expression = ora_intern(s->cols[i].expression);
+    r->cols[i].properties_json = s->cols[i].properties_json ? ora_intern(s->cols[i].properties_json) : NULL;
+    r->cols[i].fake_key = (s->cols[i].flags & TFGPU_COL_FAKE_KEY) != 0; r->cols[i].required = (s->cols[i].flags & TFGPU_COL_REQUIRED) != 0;
   }
   return r;
 }
@@ -300,9 +314,11 @@ tfgpu_schema *ora_batch_schema(const ora_batch *b) {
   for (int i = 0; i < o->ncols; i++) {
     s->cols[i].name = dups(o->cols[i].name);
     s->cols[i].dtype = o->cols[i].dtype;
-    s->cols[i].flags = o->cols[i].key ? TFGPU_COL_KEY : 0;
+    s->cols[i].flags = (o->cols[i].key ? TFGPU_COL_KEY : 0) | (o->cols[i].required ? TFGPU_COL_REQUIRED : 0) | (o->cols[i].fake_key ? TFGPU_COL_FAKE_KEY : 0);
     s->cols[i].path = dups(o->cols[i].path);
     s->cols[i].original_type = dups(o->cols[i].original_type);
+    s->cols[i].table_schema = o->cols[i].table_schema; s->cols[i].table_name = o->cols[i].table_name;  /* interned: not freed */
+    s->cols[i].expression = o->cols[i].expression; s->cols[i].properties_json = o->cols[i].properties_json;
   }
   return s;
 }

@@ -42,7 +42,7 @@ def test_struct_sizes():
     # plain C structs, natural alignment on x86-64
     assert C.sizeof(abi.CColumn) == 8 + 4 + 4 + 8 * 3 + 8 + 8 + 8
     assert C.sizeof(abi.CRowError) == 24
-    assert C.sizeof(abi.CColSchema) == 32
+    assert C.sizeof(abi.CColSchema) == 64
 
 
 def test_registry_lists_reference_type_names():

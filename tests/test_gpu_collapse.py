@@ -213,3 +213,50 @@ def test_configs4_pipeline_single_rank(tf, oracle):
     """ % (root, root))
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PIPELINE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_synchronize_items_count_as_inserts(tf, oracle):
+    """InsertsOnly (change_item_collapse.go:37-44) takes SynchronizeKind for an insert: a batch of inserts with duplicate keys
+    plus a synchronize item comes back unchanged — not deduplicated."""
+    from transferia_amd import workload
+    b, schema = workload.cdc_batch(500, keys=40, p_old=0.0)
+    b.kind[:] = abi.K_INSERT
+    b.kind[17] = abi.K_SYNCHRONIZE
+    b.old_keys, b.old_present = None, None
+    out = tf.collapse(tf.DeviceBatch.upload(b)).download()
+    ref = oracle.collapse(b, schema).batch
+    assert out.nrows == ref.nrows == 500
+    b.kind[17] = abi.K_OTHER  # any other non-row kind: the duplicates collapse
+    assert tf.collapse(tf.DeviceBatch.upload(b)).download().nrows == oracle.collapse(b, schema).batch.nrows < 500
+
+
+@pytest.mark.gpu
+def test_equal_hashes_are_settled_by_the_key_strings():
+    """With TFGPU_COLLAPSE_WEAK_HASH=1 the 128-bit hash keeps two bits: nearly every pair of keys collides and the string
+    compare in collapse_intern alone keeps distinct keys apart — the results must still be the oracle's (own process: the
+    switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFGPU_COLLAPSE_WEAK_HASH="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_collapse.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "reference_cases or random_batches or keys_that_print_alike"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.gpu
+def test_keys_that_print_alike(tf, oracle):
+    """Two byte strings that differ only in invalid UTF-8 print as the same JSON key (each bad byte becomes the escape \\ufffd,
+    encoding/json encode.go): the reference's map files them together, and so does the device — by comparing the key TEXT
+    when the raw values differ."""
+    schema = abi.Schema.of([["k", "utf8", True], ["v", "int64", False]])
+    rows = [[["string", b"a\xffb"], ["int64", 1]], [["string", b"a\xfeb"], ["int64", 2]], [["string", b"a\xef\xbf\xbdb"], ["int64", 3]], [["string", b"ab"], ["int64", 4]]]
+    b = abi.batch_from_rows(schema, ["k", "v"], rows, "db", "t", kinds=["update", "update", "update", "update"])
+    b.schema = schema
+    out = tf.collapse(tf.DeviceBatch.upload(b)).download()
+    ref = oracle.collapse(b, schema).batch
+    # 0xFF and 0xFE both print as the escape \\ufffd: one key; a real U+FFFD prints as its three bytes: another
+    assert out.nrows == ref.nrows == 3
+    assert sorted(int(x) for x in out.col("v").values) == sorted(int(x) for x in ref.col("v").values) == [2, 3, 4]

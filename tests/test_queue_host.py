@@ -55,8 +55,7 @@ def test_kafka_hash_partition_known_answers():
 
 
 # ---------------------------------------------------------------- MirrorSerializer (mirror_serializer_test.go:16-70) ----
-RAW = abi.Schema.of([["topic", "utf8"], ["partition", "uint32"], ["seq_no", "uint64"], ["write_time", "datetime"], ["data", "utf8"], ["meta", "any"],
-                     ["sequence_key", "string"]])
+RAW = queue.RAW_DATA_SCHEMA
 
 
 def _raw_message(key, data, offset=0):
@@ -82,3 +81,13 @@ def test_mirror_serializer_known_answers():
     bad = _raw_message("k", "v"); bad[4] = ["nil", None]
     with pytest.raises(ValueError):
         queue.mirror_messages(abi.batch_from_rows(RAW, names, [_raw_message("k", "v"), bad]))
+    # GetSequenceKey (mirror.go:70-75): a text sequence_key fails the []byte assertion; a schema other than RawDataSchema is refused
+    txt = _raw_message("k", "v"); txt[6] = ["string", "k"]
+    with pytest.raises(ValueError):
+        queue.mirror_messages(abi.batch_from_rows(RAW, names, [txt]))
+    other = abi.batch_from_rows(RAW, names, [_raw_message("k", "v")])
+    other.schema = abi.Schema.of([[c.name, c.dtype] for c in RAW.cols])  # same names, no key flags: not the raw-data schema
+    with pytest.raises(ValueError):
+        queue.mirror_messages(other)
+    other.schema = RAW
+    assert queue.mirror_messages(other) == [(b"k", b"v")]

@@ -275,3 +275,32 @@ def test_oracle_native_messages_parse_back(oracle):
             assert it["oldkeys"]["keyvalues"][0] == int(b.old_keys[0].values[r])
         else:
             assert it["oldkeys"] == {}
+
+
+@pytest.mark.gpu
+def test_sr_to_native_carries_the_colschema_wire_fields(tf, oracle):
+    """Confluent-SR → NativeSerializer (the configs[4] sink fed by an SR source): every ColSchema of an SR item carries the
+    message's TableSchema / TableName (jsonPropertyToJSONSchemaRow, utils_json.go:71-95) and ChangeItem.MarshalJSON marshals
+    them (col_schema.go:14-29) — so must the device, with fake_key / expression / properties besides.  Expected text: the
+    struct tags of col_schema.go written out by hand for one column, then device == oracle on the whole messages."""
+    import json as pyjson
+    from transferia_amd import confluent_sr
+    text = pyjson.dumps({"type": "object", "title": "shop.orders", "properties": {"id": {"type": "integer"}, "note": {"type": "string"}}, "required": ["id"]})
+    title, rows = confluent_sr.json_schema_rows(text)
+    ns, table = confluent_sr.build_json_table_id(title, confluent_sr.POLICY_DEBEZIUM_STYLE, "")
+    schema = confluent_sr.table_schema(rows, ns, table)
+    schema.cols[1].expression, schema.cols[1].fake_key, schema.cols[1].properties_json = "lower(note)", True, '{"default":"x"}'
+    frames = [b"\0" + (7).to_bytes(4, "big") + pyjson.dumps({"id": i, "note": "n%d" % i}).encode() for i in range(50)]
+    data, msgs = abi.messages(frames, list(range(50)), [0] * 50)
+    opts = confluent_sr.sr_json_options(7, text)
+    qo = abi.queue_options(abi.QFMT_NATIVE, table_schema=schema)
+    ref = oracle.sr_json_parse(opts, data, msgs)
+    exp = oracle.queue_serialize(qo, ref.batch, ref.schema)
+    got = tf.queue_serialize(qo, tf.sr_json_parse(opts, data, msgs).device_batch).messages()
+    assert got == exp and len(got) == 50
+    item = pyjson.loads(got[0])[0]
+    assert item["table_schema"][0] == {"table_schema": ns, "table_name": table, "path": "", "name": "id", "type": "int64", "key": False, "fake_key": False,
+                                       "required": True, "expression": "", "original_type": ""}
+    assert item["table_schema"][1] == {"table_schema": ns, "table_name": table, "path": "", "name": "note", "type": "utf8", "key": False, "fake_key": True,
+                                       "required": False, "expression": "lower(note)", "original_type": "", "properties": {"default": "x"}}
+    assert b'"fake_key":true,"required":false,"expression":"lower(note)","original_type":"","properties":{"default":"x"}}' in got[0]

@@ -11,7 +11,18 @@ import os as _os
 
 SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
 
-FMT = {"ch": abi.FMT_CH_JSON_EACH_ROW, "json": abi.FMT_JSON, "csv": abi.FMT_CSV}
+FMT = {"ch": abi.FMT_CH_JSON_EACH_ROW, "json": abi.FMT_JSON, "csv": abi.FMT_CSV, "raw": abi.FMT_RAW}
+
+
+def _case_batch(case):
+    """A case holds one item, or (Batch/Stream serializer canon) several items of one schema: those become
+    the rows of one batch -- what serializeBatch's loop (batch.go:40-57) sees, table names apart."""
+    if "items" in case:
+        first = case["items"][0]
+        item = {k: v for k, v in first.items() if k != "values"}
+        item["rows"] = [it["values"] for it in case["items"]]
+        return item_to_batch(item)
+    return item_to_batch(case["item"])
 
 
 def _opts(o):
@@ -31,7 +42,7 @@ def _check_case(case, text: bytes):
 
 def test_oracle_reference_vectors(oracle):
     for case in golden("serializers.json")["cases"]:
-        b, schema = item_to_batch(case["item"])
+        b, schema = _case_batch(case)
         out = oracle.serialize(FMT[case["format"]], b, schema, _opts(case["opts"]))
         assert out is not None, case["name"]
         _check_case(case, out)
@@ -101,7 +112,7 @@ def tf():
 @pytest.mark.gpu
 def test_gpu_reference_vectors(tf):
     for case in golden("serializers.json")["cases"]:
-        b, _ = item_to_batch(case["item"])
+        b, _ = _case_batch(case)
         out = tf.serialize(FMT[case["format"]], tf.DeviceBatch.upload(b), _opts(case["opts"])).download()
         _check_case(case, out)
 
@@ -168,3 +179,54 @@ def test_gpu_hits_chain_to_jsoneachrow(tf, oracle):
     ref2 = oracle.apply_chain([oracle.Transformer("filter_rows", {"filter": "eventdate >= 2013-07-15"})], ref.batch, ref.schema)
     exp = oracle.serialize(abi.FMT_CH_JSON_EACH_ROW, ref2.batch, ref2.schema)
     assert got == exp and got.count(b"\n") == res.transformed.nrows
+
+
+def _mirror_batch(datas, keys=None, repr_bytes=False):
+    from transferia_amd import queue
+    rows = []
+    for i, d in enumerate(datas):
+        rows.append([["string", "t"], ["int", 0], ["uint64", i], ["time", "2024-01-01T00:00:00Z"],
+                     ["nil", None] if d is None else (["bytes", d.encode("utf-8").decode("latin-1")] if repr_bytes else ["string", d]), ["nil", None], ["bytes", "k%d" % i]])
+    b = abi.batch_from_rows(queue.RAW_DATA_SCHEMA, list(queue.RAW_DATA_COLUMNS), rows, "", "t")
+    b.schema = queue.RAW_DATA_SCHEMA
+    return b
+
+
+def test_oracle_raw_rules(oracle):
+    """rawSerializer (raw.go:24-63): the `data` value, '\\n' between items, a closing '\\n' on request; anything that is
+    not a mirror item, or a nil `data`, is an error."""
+    from transferia_amd import queue
+    b = _mirror_batch(["a", "", "b\nc"])
+    assert oracle.serialize(abi.FMT_RAW, b, queue.RAW_DATA_SCHEMA) == b"a\n\nb\nc"
+    assert oracle.serialize(abi.FMT_RAW, b, queue.RAW_DATA_SCHEMA, _opts({"add_closing_newline": True})) == b"a\n\nb\nc\n"
+    assert oracle.serialize(abi.FMT_RAW, _mirror_batch(["a", None]), queue.RAW_DATA_SCHEMA) is None
+    s = abi.Schema.of([["a", "int32", True]])
+    assert oracle.serialize(abi.FMT_RAW, abi.batch_from_rows(s, ["a"], [[["int32", 1]]], "", "t"), s) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 64, 1000, 50021])
+def test_gpu_raw_matches_oracle(tf, oracle, n):
+    import random
+    from transferia_amd import queue
+    rng = random.Random(SEED0 + 77 + n)
+    alphabet = "ab\n\"\\é中 {}:,"
+    datas = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 3, 17, 64, 200]))) for _ in range(n)]
+    for rb in (False, True):
+        b = _mirror_batch(datas, repr_bytes=rb)
+        for o in ({}, {"add_closing_newline": True}):
+            ref = oracle.serialize(abi.FMT_RAW, b, queue.RAW_DATA_SCHEMA, _opts(o))
+            assert ref is not None
+            assert tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(b), _opts(o)).download() == ref
+
+
+@pytest.mark.gpu
+def test_gpu_raw_refusals(tf):
+    with pytest.raises(tf.TfgpuError):  # GetRawMessageData: unexpected data type <nil>
+        tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(_mirror_batch(["a", None, "b"])))
+    s = abi.Schema.of([["a", "int32", True]])
+    with pytest.raises(tf.TfgpuError):  # raw.go:29-31: not a mirror item
+        tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(abi.batch_from_rows(s, ["a"], [[["int32", 1]]], "", "t")))
+    e = _mirror_batch([])
+    assert tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(e)).download() == b""
+    assert tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(e), _opts({"add_closing_newline": True})).download() == b""

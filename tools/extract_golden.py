@@ -503,6 +503,22 @@ def serializers():
         {"name": "TestSerialize/json:newline", "format": "json", "opts": {"add_closing_newline": True}, "item": raw_item,
          "expect": canon_bytes("json_newline")},
     ]
+    # raw serializer: TestSerialize raw:* (one item), TestBatchSerializer / TestStreamSerializer raw:* over MakeChangeItems(10)
+    # (reference_test.go:261-278: data = "data<i>", table<i>, topic<i>, shard i, offset i; the stream serializer always closes lines)
+    cases.append({"name": "TestSerialize/raw:default", "format": "raw", "opts": {}, "item": raw_item, "expect": canon_bytes("raw_default")})
+    cases.append({"name": "TestSerialize/raw:newline", "format": "raw", "opts": {"add_closing_newline": True}, "item": raw_item, "expect": canon_bytes("raw_newline")})
+
+    def raw_items(n):
+        return [{"ns": "", "table": "table%d" % i, "schema": raw_schema, "names": [c[0] for c in raw_schema],
+                 "values": [["string", "topic%d" % i], ["int", i], ["uint64", i], ["time", "0001-01-01T00:00:00Z"], ["string", "data%d" % i],
+                            ["json", "null"], ["bytes", "stub"]]} for i in range(n)]
+    cbase = REF + "/pkg/serializer/reference/canondata/reference.reference.Test%s/result"
+    for test, name, opts in [("BatchSerializer_raw_default", "TestBatchSerializer/raw:default", {}),
+                             ("BatchSerializer_raw_newline", "TestBatchSerializer/raw:newline", {"add_closing_newline": True}),
+                             ("StreamSerializer_raw_default", "TestStreamSerializer/raw:default", {"add_closing_newline": True}),
+                             ("StreamSerializer_raw_newline", "TestStreamSerializer/raw:newline", {"add_closing_newline": True})]:
+        with open(cbase % test, "rb") as f:
+            cases.append({"name": name, "format": "raw", "opts": opts, "items": raw_items(10), "expect": f.read().decode("utf-8")})
     # json_test.go:52-110 TestJSONSerializerComplexAsStr (require.Contains fragments)
     complex_item = {"ns": "", "table": "", "schema": [["id", "int16", False], ["jsonObject", "any", False], ["jsonArray", "any", False], ["nil", "any", False]],
                     "names": ["id", "jsonObject", "jsonArray", "nil"],

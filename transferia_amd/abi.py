@@ -28,24 +28,25 @@ REPR_NP = {R_INT8: np.int8, R_INT16: np.int16, R_INT32: np.int32, R_INT64: np.in
            R_FLOAT64: np.float64, R_BOOL: np.uint8, R_TIME: np.int64, R_DURATION: np.int64}
 VAR_REPRS = (R_STRING, R_BYTES, R_JSONNUM, R_JSON)
 
-K_INSERT, K_UPDATE, K_DELETE, K_OTHER = 0, 1, 2, 3
-KIND_ID = {"insert": 0, "Insert": 0, "update": 1, "Update": 1, "delete": 2, "Delete": 2}
+K_INSERT, K_UPDATE, K_DELETE, K_OTHER, K_SYNCHRONIZE = 0, 1, 2, 3, 4
+KIND_ID = {"insert": 0, "Insert": 0, "update": 1, "Update": 1, "delete": 2, "Delete": 2, "synchronize": 4}
 
 MEM_HOST, MEM_DEVICE = 0, 1
-COL_KEY, COL_REQUIRED = 1, 2
+COL_KEY, COL_REQUIRED, COL_FAKE_KEY = 1, 2, 4
 
 ROWERR = {0: "OK", 1: "UNSUPPORTED_KIND", 2: "COLUMN_NOT_FOUND", 3: "INT_OVERFLOW", 4: "TYPE_PAIR", 5: "MISSING_CELL",
           6: "CAST", 7: "RANGE", 8: "QUOTE", 9: "DOUBLE_QUOTE", 10: "QUOTING_DISABLED", 11: "HOST_FALLBACK",
           12: "JSON_SYNTAX", 13: "PARSE_VAL", 14: "NIL_KEY", 15: "SR_SHORT", 16: "SR_MAGIC", 17: "SR_TYPE", 18: "SR_REQUIRED"}
 ROWERR_ID = {v: k for k, v in ROWERR.items()}
 
-FMT_CH_JSON_EACH_ROW, FMT_JSON, FMT_CSV = 1, 2, 3
+FMT_CH_JSON_EACH_ROW, FMT_JSON, FMT_CSV, FMT_RAW = 1, 2, 3, 4
 
 
 # ---- C structs -----------------------------------------------------------
 class CColSchema(C.Structure):
     _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("flags", C.c_uint32), ("path", C.c_char_p),
-                ("original_type", C.c_char_p)]
+                ("original_type", C.c_char_p), ("table_schema", C.c_char_p), ("table_name", C.c_char_p), ("expression", C.c_char_p),
+                ("properties_json", C.c_char_p)]
 
 
 class CSchema(C.Structure):
@@ -311,6 +312,11 @@ class ColSchema:
     path: str = ""
     original_type: str = ""
     required: bool = False
+    table_schema: str = ""     # ColSchema.TableSchema / TableName / Expression / FakeKey / Properties: read by the wire form only
+    table_name: str = ""
+    expression: str = ""
+    fake_key: bool = False
+    properties_json: str = ""
 
 
 @dataclass
@@ -340,9 +346,12 @@ class Schema:
         keep = []
         for i, c in enumerate(self.cols):
             n, p, o = _b(c.name), _b(c.path), _b(c.original_type)
-            keep += [n, p, o]
+            ts, tn, ex = _b(c.table_schema), _b(c.table_name), _b(c.expression)
+            pj = _b(c.properties_json) if c.properties_json else None
+            keep += [n, p, o, ts, tn, ex, pj]
             arr[i].name, arr[i].dtype, arr[i].path, arr[i].original_type = n, DTYPE_ID[c.dtype], p, o
-            arr[i].flags = (COL_KEY if c.key else 0) | (COL_REQUIRED if c.required else 0)
+            arr[i].table_schema, arr[i].table_name, arr[i].expression, arr[i].properties_json = ts, tn, ex, pj
+            arr[i].flags = (COL_KEY if c.key else 0) | (COL_REQUIRED if c.required else 0) | (COL_FAKE_KEY if c.fake_key else 0)
         s = CSchema(len(self.cols), arr)
         s._keep = (arr, keep)
         return s
@@ -353,7 +362,9 @@ class Schema:
         for i in range(cs.ncols):
             c = cs.cols[i]
             out.append(ColSchema(c.name.decode("utf-8"), DTYPES[c.dtype], bool(c.flags & COL_KEY),
-                                 (c.path or b"").decode(), (c.original_type or b"").decode(), bool(c.flags & COL_REQUIRED)))
+                                 (c.path or b"").decode(), (c.original_type or b"").decode(), bool(c.flags & COL_REQUIRED),
+                                 (c.table_schema or b"").decode(), (c.table_name or b"").decode(), (c.expression or b"").decode(),
+                                 bool(c.flags & COL_FAKE_KEY), (c.properties_json or b"").decode()))
         return Schema(out)
 
     def triples(self):

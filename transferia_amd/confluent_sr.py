@@ -23,13 +23,13 @@ POLICY_DEBEZIUM_STYLE, POLICY_TITLE = "debezium_style", "title"
 
 
 def _field(obj: dict, name: str):
-    """encoding/json matches struct fields by exact name first, then case-insensitively."""
-    if name in obj:
-        return obj[name]
-    for k, v in obj.items():
-        if k.lower() == name:
-            return v
-    return None
+    """encoding/json binds every key of the document to the struct field it names — exactly or, failing that, ignoring case —
+    in document order, so the LAST key that names the field is the one whose value stays (decode.go object())."""
+    out, want = None, name.lower()
+    for k, v in obj.items():  # json.loads keeps document order (a repeated identical key: the last one, as in Go)
+        if k == name or k.lower() == want:
+            out = v
+    return out
 
 
 def json_schema_rows(schema_text: str) -> Tuple[str, List[Tuple[str, int, bool]]]:
@@ -79,9 +79,10 @@ def sr_json_options(schema_id: int, schema_text: str, policy: str = POLICY_DEBEZ
     return abi.sr_json_options(schema_id, rows, ns, table, report_frame_errors=report_frame_errors)
 
 
-def table_schema(rows) -> abi.Schema:
-    """abstract.NewTableSchema(rows) of processPayload: one ColSchema per property."""
-    return abi.Schema([abi.ColSchema(n, SRT_DTYPE[t], False, "", "", bool(r)) for n, t, r in rows])
+def table_schema(rows, ns: str = "", table: str = "") -> abi.Schema:
+    """abstract.NewTableSchema(rows) of processPayload: one ColSchema per property, TableSchema / TableName set to the
+    message's table (jsonPropertyToJSONSchemaRow, utils_json.go:71-95) — the native wire form carries them."""
+    return abi.Schema([abi.ColSchema(n, SRT_DTYPE[t], False, "", "", bool(r), ns, table) for n, t, r in rows])
 
 
 class ConfluentSrParser:

@@ -120,6 +120,8 @@ int tfgpu_plan_result_schema(const tfgpu_plan *p, const tfgpu_schema *in, tfgpu_
     tfgpu_colschema &o = s->cols[s->ncols++];
     o.name = dup_cstr(name); o.dtype = dtype; o.flags = c.flags;
     o.path = dup_cstr(c.path ? c.path : ""); o.original_type = dup_cstr(orig);
+    o.table_schema = dup_cstr(c.table_schema ? c.table_schema : ""); o.table_name = dup_cstr(c.table_name ? c.table_name : "");
+    o.expression = dup_cstr(c.expression ? c.expression : ""); o.properties_json = c.properties_json ? dup_cstr(c.properties_json) : nullptr;
   }
   *out = s;
   return TFGPU_OK;
@@ -128,7 +130,11 @@ int tfgpu_plan_result_schema(const tfgpu_plan *p, const tfgpu_schema *in, tfgpu_
 
 void tfgpu_schema_free(tfgpu_schema *s) {
   if (!s) return;
-  for (int i = 0; i < s->ncols; i++) { std::free((void *)s->cols[i].name); std::free((void *)s->cols[i].path); std::free((void *)s->cols[i].original_type); }
+  for (int i = 0; i < s->ncols; i++) {
+    const tfgpu_colschema &c = s->cols[i];
+    std::free((void *)c.name); std::free((void *)c.path); std::free((void *)c.original_type);
+    std::free((void *)c.table_schema); std::free((void *)c.table_name); std::free((void *)c.expression); std::free((void *)c.properties_json);
+  }
   std::free(s->cols); std::free(s);
 }
 

@@ -71,12 +71,31 @@ struct HashParams {
   const uint8_t *old_present; int32_t has_old_keys;  // bitmap (null = every row) / the batch carries OldKeys at all
   uint64_t *h;        // [2n][2]: (h1 | 1, h2); h1 == 0: the row has no OldKeys
   uint32_t *badflag;  // a float key that json.Marshal refuses (NaN / Inf)
+  int32_t weak;
 };
 __device__ __forceinline__ bool float_bad(const DCol &c, int64_t r) {
   if (c.repr != TFGPU_R_FLOAT32 && c.repr != TFGPU_R_FLOAT64) return false;
   if (!is_valid(c, r)) return false;
   const double v = c.repr == TFGPU_R_FLOAT32 ? (double)((const float *)c.values)[r] : ((const double *)c.values)[r];
   return v != v || v == INFINITY || v == -INFINITY;
+}
+// the key string of entry j = (row j >> 1, current keys | OldKeys): CurrentKeysString / OldOrCurrentKeysString (change_item.go:314-358)
+template <class S> __device__ __forceinline__ bool emit_key(const HashParams &p, int64_t j, S &s) {
+  const int64_t r = j >> 1;
+  const bool old = j & 1;
+  bool bad = false;
+  s.put('[');
+  for (int k = 0; k < p.nkeys; k++) {
+    if (k) s.put(',');
+    const KCol &kc = p.keys[k];
+    const bool has = old ? kc.has_old : kc.has_cur;
+    if (!has) { put_lit(s, "null"); continue; }  // keys[k] = nil: the key column is not among the row's names
+    const DCol &c = old ? kc.old : kc.cur;
+    if (float_bad(c, r)) { bad = true; continue; }
+    emit_json_cell(s, c, r, 0, true);
+  }
+  s.put(']');
+  return bad;
 }
 __global__ void __launch_bounds__(256) collapse_hash(HashParams p) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,24 +104,61 @@ __global__ void __launch_bounds__(256) collapse_hash(HashParams p) {
   const bool old = j & 1;
   if (old && (!p.has_old_keys || (p.old_present && !((p.old_present[r >> 3] >> (r & 7)) & 1)))) { p.h[2 * j] = 0; p.h[2 * j + 1] = 0; return; }
   HashSink s;
-  s.put('[');
-  for (int k = 0; k < p.nkeys; k++) {
-    if (k) s.put(',');
-    const KCol &kc = p.keys[k];
-    const bool has = old ? kc.has_old : kc.has_cur;
-    if (!has) { put_lit(s, "null"); continue; }  // keys[k] = nil: the key column is not among the row's names
-    const DCol &c = old ? kc.old : kc.cur;
-    if (float_bad(c, r)) { *p.badflag = 1; continue; }
-    emit_json_cell(s, c, r, 0, true);
-  }
-  s.put(']');
+  if (emit_key(p, j, s)) *p.badflag = 1;
   s.finish();
+  if (p.weak) { s.h1 &= 3ull; s.h2 = 0; }  // TFGPU_COLLAPSE_WEAK_HASH=1 (tests): almost every key collides, the string compare decides
   p.h[2 * j] = s.h1 | 1ull;
   p.h[2 * j + 1] = s.h2;
 }
 
-// ---- 2. key ids: the slot a hash claims -------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) collapse_intern(const uint64_t *__restrict__ h, int64_t n2, uint32_t *owner, uint32_t mask, uint32_t *__restrict__ keyid) {
+// ---- 2. key ids: the slot a hash claims — and, hash for hash, the key strings compared, so that two entries share an id
+//      exactly when the reference's map would file them under one string ----------------------------------------
+struct WindowSink {  // the bytes [lo, lo + 64) of an emitted text
+  uint8_t *buf; uint32_t lo, pos = 0;
+  __device__ __forceinline__ void put(uint32_t c) { if (pos - lo < 64u) buf[pos - lo] = (uint8_t)c; pos++; }
+};
+__device__ bool key_text_equal(const HashParams &p, int64_t a, int64_t b) {
+  CountSink ca, cb;
+  emit_key(p, a, ca); emit_key(p, b, cb);
+  if (ca.n != cb.n) return false;
+  uint8_t wa[64], wb[64];
+  for (uint32_t lo = 0; lo < ca.n; lo += 64) {
+    WindowSink sa{wa, lo}, sb{wb, lo};
+    emit_key(p, a, sa); emit_key(p, b, sb);
+    const uint32_t m = ca.n - lo < 64u ? ca.n - lo : 64u;
+    for (uint32_t i = 0; i < m; i++) if (wa[i] != wb[i]) return false;
+  }
+  return true;
+}
+// Same key string?  Equal raw values of every key ⇒ equal strings; a fixed-width value that differs ⇒ different strings
+// (integers, bools, times and finite floats print injectively); var-width values that differ may still print alike
+// (invalid UTF-8 → U+FFFD): only then are the texts themselves compared.
+__device__ bool keys_equal(const HashParams &p, int64_t a, int64_t b) {
+  const int64_t ra = a >> 1, rb = b >> 1;
+  bool need_text = false;
+  for (int k = 0; k < p.nkeys; k++) {
+    const KCol &kc = p.keys[k];
+    const bool ha = (a & 1) ? kc.has_old : kc.has_cur, hb = (b & 1) ? kc.has_old : kc.has_cur;
+    const DCol &x = (a & 1) ? kc.old : kc.cur, &y = (b & 1) ? kc.old : kc.cur;
+    const bool na = !ha || !is_valid(x, ra), nb = !hb || !is_valid(y, rb);
+    if (na || nb) { if (na != nb) need_text = true; continue; }  // (a nil prints "null"; a JSON value may too: compare the text)
+    if (x.repr != y.repr) { need_text = true; continue; }
+    if (x.offsets) {
+      const uint32_t oa = x.offsets[ra], la = x.offsets[ra + 1] - oa, ob = y.offsets[rb], lb = y.offsets[rb + 1] - ob;
+      bool same = la == lb;
+      for (uint32_t i = 0; same && i < la; i++) same = x.data[oa + i] == y.data[ob + i];
+      if (!same) need_text = true;
+    } else {
+      const int w = repr_width_dev(x.repr);
+      const uint8_t *va = (const uint8_t *)x.values + ra * w, *vb = (const uint8_t *)y.values + rb * w;
+      for (int i = 0; i < w; i++) if (va[i] != vb[i]) return false;
+      if (x.repr == TFGPU_R_TIME && (x.nanos ? x.nanos[ra] : 0) != (y.nanos ? y.nanos[rb] : 0)) return false;
+    }
+  }
+  return need_text ? key_text_equal(p, a, b) : true;
+}
+__global__ void __launch_bounds__(256) collapse_intern(HashParams p, int64_t n2, uint32_t *owner, uint32_t mask, uint32_t *__restrict__ keyid) {
+  const uint64_t *__restrict__ h = p.h;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n2) return;
   const uint64_t a = h[2 * j], b = h[2 * j + 1];
@@ -111,8 +167,9 @@ __global__ void __launch_bounds__(256) collapse_intern(const uint64_t *__restric
   for (;;) {
     uint32_t o = __hip_atomic_load(&owner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (o == NOKEY) o = atomicCAS(&owner[slot], NOKEY, (uint32_t)j);
-    if (o == NOKEY || (h[2 * (int64_t)o] == a && h[2 * (int64_t)o + 1] == b)) { keyid[j] = slot; return; }
-    slot = (slot + 1) & mask;
+    if (o == NOKEY || o == (uint32_t)j) { keyid[j] = slot; return; }
+    if (h[2 * (int64_t)o] == a && h[2 * (int64_t)o + 1] == b && keys_equal(p, j, (int64_t)o)) { keyid[j] = slot; return; }
+    slot = (slot + 1) & mask;  // another key (or, once in 2^128, another string with this hash): probe on
   }
 }
 
@@ -220,7 +277,7 @@ __global__ void __launch_bounds__(256) collapse_select(int64_t n, const uint8_t 
 }
 __global__ void __launch_bounds__(256) collapse_any_non_insert(const uint8_t *kind, int64_t n, uint32_t *flag) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && kind[i] != TFGPU_K_INSERT) *flag = 1;
+  if (i < n && kind[i] != TFGPU_K_INSERT && kind[i] != TFGPU_K_SYNCHRONIZE) *flag = 1;  // InsertsOnly :37-44
 }
 
 // ---- ChangeItem.KeysChanged (change_item.go:237-286): reflect.DeepEqual of the old and the new value of every PK column ----
@@ -314,8 +371,10 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   hp.keys = ptr<KCol>(bkc); hp.nkeys = (int32_t)kc.size(); hp.n = n;
   hp.old_present = ptr<uint8_t>(in.old_present); hp.has_old_keys = in.old_keys.empty() ? 0 : 1;
   hp.h = ptr<uint64_t>(hashes); hp.badflag = ptr<uint32_t>(bad);
+  static const bool weak = [] { const char *e = std::getenv("TFGPU_COLLAPSE_WEAK_HASH"); return e && e[0] == '1'; }();
+  hp.weak = weak ? 1 : 0;
   collapse_hash<<<cgrid(n2), 256, 0, st>>>(hp);
-  collapse_intern<<<cgrid(n2), 256, 0, st>>>(ptr<uint64_t>(hashes), n2, ptr<uint32_t>(owner), (uint32_t)(cap - 1), ptr<uint32_t>(keyid));
+  collapse_intern<<<cgrid(n2), 256, 0, st>>>(hp, n2, ptr<uint32_t>(owner), (uint32_t)(cap - 1), ptr<uint32_t>(keyid));
   collapse_link<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent));
   Buf root = dalloc((size_t)n * 4), idx = dalloc((size_t)n * 4), sroot = dalloc((size_t)n * 4), sidx = dalloc((size_t)n * 4);
   collapse_roots<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent), ptr<uint32_t>(root), ptr<uint32_t>(idx));

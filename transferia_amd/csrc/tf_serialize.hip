@@ -185,7 +185,7 @@ __device__ __forceinline__ bool q_applies(const SerParams &p, uint32_t apply, in
   switch (apply) {
     case QA_NAMES: return !p.q.m_form || p.q.m_form[p.q.src_row ? p.q.src_row[r] : r] == 0;
     case QA_OLD: return p.q.has_old && (!p.q.old_present || ((p.q.old_present[r >> 3] >> (r & 7)) & 1));
-    case QA_ROW_EVENT: return !p.q.kind || p.q.kind[r] != TFGPU_K_OTHER;
+    case QA_ROW_EVENT: return !p.q.kind || p.q.kind[r] <= TFGPU_K_DELETE;
     default: return true;
   }
 }
@@ -447,9 +447,70 @@ __global__ void float_nonfinite_kernel(const void *values, int64_t n, int is32, 
 
 using namespace tf;
 
+// rawSerializer (pkg/serializer/raw.go:24-63) under the batch serializer: every row's `data` bytes, '\n' behind each (AddClosingNewLine)
+// or between them
+namespace tf {
+struct SegRawParams { const uint32_t *in_off; const uint8_t *in; const uint32_t *out_off; uint8_t *out; int64_t n; };
+// lane = row: its bytes as (unaligned) 8-byte words
+__global__ void __launch_bounds__(256) ser_raw_copy(SegRawParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n) return;
+  const uint32_t a = p.in_off[r], len = p.in_off[r + 1] - a;
+  const uint8_t *src = p.in + a; uint8_t *dst = p.out + p.out_off[r];
+  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+  uint32_t i = 0;
+  for (; i + 8 <= len; i += 8) reinterpret_cast<U64 *>(dst + i)->v = reinterpret_cast<const U64 *>(src + i)->v;
+  for (; i < len; i++) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) ser_raw_offsets(const uint32_t *in_off, int64_t n, uint32_t *out_off) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r <= n) out_off[r] = in_off[r] + (uint32_t)r;  // one '\n' per row in front of row r
+}
+__global__ void __launch_bounds__(256) ser_raw_newlines(const uint32_t *out_off, int64_t n, uint64_t total, uint8_t *out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && (uint64_t)out_off[r + 1] - 1 < total) out[out_off[r + 1] - 1] = '\n';
+}
+}  // namespace tf
+static int serialize_raw(const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out) {
+  static const char *const MIRROR[] = {"topic", "partition", "seq_no", "write_time", "data", "meta", "sequence_key"};  // changeitem.RawDataColumns (mirror.go:10-33)
+  bool mirror = b->cols.size() == 7;
+  for (size_t i = 0; mirror && i < 7; i++) mirror = b->cols[i].name == MIRROR[i];
+  if (!mirror) return tf::fail(TFGPU_ERR_INVALID, "raw serializer: unexpected input, expect no converted raw data");  // IsMirror (change_item.go:385-395)
+  const DColumn &d = b->cols[4];
+  if (d.repr != TFGPU_R_BYTES && d.repr != TFGPU_R_STRING) return tf::fail(TFGPU_ERR_INVALID, "raw serializer: unable to construct raw message data: unexpected data type, expected string or []byte");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  hipStream_t st = cx.stream;
+  materialize(*b);
+  const int64_t n = b->nrows;
+  if (d.validity && n) {  // a nil value is no []byte either (GetRawMessageData, mirror.go:78-87)
+    std::vector<uint8_t> bm((size_t)(n + 7) / 8);
+    d2h(bm.data(), d.validity->p, bm.size());
+    tf::sync();
+    for (int64_t r = 0; r < n; r++) if (!((bm[(size_t)r >> 3] >> (r & 7)) & 1)) return tf::fail(TFGPU_ERR_INVALID, "raw serializer: unable to construct raw message data: unexpected data type: <nil>");
+  }
+  const bool closing = opts && opts->add_closing_newline;
+  auto res = std::make_unique<tfgpu_dbuf>();
+  const uint64_t total = n ? d.data_len + (uint64_t)n - (closing ? 0 : 1) : 0;
+  if (total >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_serialize: output exceeds 4 GiB; split the batch by rows");
+  res->size = total;
+  res->mem = dalloc(total + 64);
+  if (n) {
+    Buf ooff = dalloc((size_t)(n + 2) * 4);
+    ser_raw_offsets<<<(unsigned)((n + 256) / 256), 256, 0, st>>>(ptr<uint32_t>(d.offsets), n, ptr<uint32_t>(ooff));
+    SegRawParams rp{ptr<uint32_t>(d.offsets), ptr<uint8_t>(d.payload()), ptr<uint32_t>(ooff), ptr<uint8_t>(res->mem), n};
+    { KernelTimer t("ser_raw"); ser_raw_copy<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(rp); }
+    ser_raw_newlines<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ptr<uint32_t>(ooff), n, total, ptr<uint8_t>(res->mem));
+  }
+  tf::sync();
+  *out = res.release();
+  return TFGPU_OK;
+}
+
 extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out) {
   try {
     if (!b || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize: null argument");
+    if (format == TFGPU_FMT_RAW) return serialize_raw(b, opts, out);
     if (format != TFGPU_FMT_CH_JSON_EACH_ROW && format != TFGPU_FMT_JSON && format != TFGPU_FMT_CSV)
       return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize: unknown format");
     Context &cx = ctx();
@@ -560,29 +621,37 @@ static void json_string_array(std::string &out, const std::vector<std::string> &
 }
 // json.Marshal([]ColSchema): col_schema.go:14-29 (Properties omitempty; the fields the ABI schema does not carry are zero)
 static void table_schema_json(std::string &out, const tfgpu_queue_options *o, const tfgpu_dbatch *b) {
-  struct Col { std::string name, path, ot; int dtype; bool key, req; };
+  struct Col { std::string name, path, ot; int dtype; bool key, req; std::string ts, tn, ex, props; bool fake; };
   std::vector<Col> cols;
   if (o->table_schema) {
     for (int i = 0; i < o->table_schema->ncols; i++) {
       const tfgpu_colschema &c = o->table_schema->cols[i];
-      cols.push_back({c.name ? c.name : "", c.path ? c.path : "", c.original_type ? c.original_type : "", c.dtype, (c.flags & TFGPU_COL_KEY) != 0, (c.flags & TFGPU_COL_REQUIRED) != 0});
+      cols.push_back({c.name ? c.name : "", c.path ? c.path : "", c.original_type ? c.original_type : "", c.dtype, (c.flags & TFGPU_COL_KEY) != 0, (c.flags & TFGPU_COL_REQUIRED) != 0,
+                      c.table_schema ? c.table_schema : "", c.table_name ? c.table_name : "", c.expression ? c.expression : "", c.properties_json ? c.properties_json : "",
+                      (c.flags & TFGPU_COL_FAKE_KEY) != 0});
     }
   } else {
     auto is_key = [&](const std::string &n) { for (auto &k : b->key_names) if (k == n) return true; return false; };
-    if (!b->schema.empty()) for (auto &pr : b->schema) cols.push_back({pr.first, "", "", pr.second, is_key(pr.first), false});
-    else for (auto &c : b->cols) cols.push_back({c.name, "", "", c.dtype, is_key(c.name), false});
+    if (!b->schema.empty()) for (auto &pr : b->schema) cols.push_back({pr.first, "", "", pr.second, is_key(pr.first), false, "", "", "", "", false});
+    else for (auto &c : b->cols) cols.push_back({c.name, "", "", c.dtype, is_key(c.name), false, "", "", "", "", false});
   }
   if (cols.empty()) return;  // len(c.TableSchema.columns) == 0: the key is omitted
   out += ",\"table_schema\":[";
   for (size_t i = 0; i < cols.size(); i++) {
     const Col &c = cols[i];
     if (i) out += ',';
-    out += "{\"table_schema\":\"\",\"table_name\":\"\",\"path\":"; json_key(out, c.path, true);
+    // json.Marshal(ColSchema): every field by its tag (col_schema.go:14-29), `properties` omitempty
+    out += "{\"table_schema\":"; json_key(out, c.ts, true);
+    out += ",\"table_name\":"; json_key(out, c.tn, true);
+    out += ",\"path\":"; json_key(out, c.path, true);
     out += ",\"name\":"; json_key(out, c.name, true);
     out += ",\"type\":"; json_key(out, c.dtype > 0 && c.dtype < TFGPU_T__COUNT ? QDTYPE_NAMES[c.dtype] : "", true);
     out += ",\"key\":"; out += c.key ? "true" : "false";
-    out += ",\"fake_key\":false,\"required\":"; out += c.req ? "true" : "false";
-    out += ",\"expression\":\"\",\"original_type\":"; json_key(out, c.ot, true);
+    out += ",\"fake_key\":"; out += c.fake ? "true" : "false";
+    out += ",\"required\":"; out += c.req ? "true" : "false";
+    out += ",\"expression\":"; json_key(out, c.ex, true);
+    out += ",\"original_type\":"; json_key(out, c.ot, true);
+    if (!c.props.empty()) { out += ",\"properties\":"; out += c.props; }
     out += '}';
   }
   out += ']';

@@ -66,6 +66,10 @@ def raw_column_messages(batch: abi.Batch, column_name: str, schema: Optional[abi
 
 
 RAW_DATA_COLUMNS = ("topic", "partition", "seq_no", "write_time", "data", "meta", "sequence_key")  # changeitem/mirror.go:23-32
+# RawDataSchema (changeitem/mirror.go:23-31): (name, DataType, PrimaryKey, path, OriginalType, Required)
+RAW_DATA_SCHEMA = abi.Schema.of([["topic", "utf8", True, "", "", True], ["partition", "uint32", True, "", "", True], ["seq_no", "uint64", True, "", "", True],
+                                 ["write_time", "datetime", True, "", "", True], ["data", "utf8", False, "", "mirror:binary"], ["meta", "any"],
+                                 ["sequence_key", "string"]])
 
 
 def is_mirror(batch: abi.Batch) -> bool:
@@ -73,15 +77,32 @@ def is_mirror(batch: abi.Batch) -> bool:
     return tuple(c.name for c in batch.cols) == RAW_DATA_COLUMNS
 
 
+def _is_raw_data_schema(schema: abi.Schema) -> bool:
+    """GetSequenceKey compares the TableSchema POINTER with RawDataSchema (mirror.go:71-73).  Value identity is the
+    closest a columnar batch has: same names, types, key / required flags and original types, position by position."""
+    want = RAW_DATA_SCHEMA.cols
+    return len(schema.cols) == len(want) and all(
+        (a.name, a.dtype, a.key, a.required, a.original_type) == (b.name, b.dtype, b.key, b.required, b.original_type) for a, b in zip(schema.cols, want))
+
+
 def mirror_messages(batch: abi.Batch) -> List[Tuple[Optional[bytes], bytes]]:
     """MirrorSerializer.Serialize for one table / PartID: (key, value) per row = (`sequence_key`, `data`) — two column
-    views, no kernel.  Raises ValueError where the reference returns its fatal errors: rows that are not mirror items
-    (mirror_serializer.go:16-18), a `data` value that is neither text nor bytes (mirror.go:78-87; nil included).
-    A nil `sequence_key` is a nil []byte there: the message has no key."""
+    views, no kernel.  Raises ValueError where the reference fails: rows that are not mirror items
+    (mirror_serializer.go:16-18); a TableSchema that is not RawDataSchema (GetSequenceKey, mirror.go:71-73 — checked when
+    the batch carries its schema); a `sequence_key` column that does not hold []byte (the unchecked `.([]byte)` at
+    mirror.go:74 panics on a string); a `data` value that is neither text nor bytes (mirror.go:78-87; nil included).
+    A null in the []byte `sequence_key` column is MakeRawMessage's typed nil []byte: the message has no key.  (An UNTYPED
+    nil interface would panic in Go; a column cannot tell the two apart and every producer in the reference passes a
+    []byte, so null is read as the typed nil.)"""
     if not is_mirror(batch):
         raise ValueError("MirrorSerializer should be used only with 'Mirror' changeItems")
+    schema = getattr(batch, "schema", None)
+    if schema is not None and not _is_raw_data_schema(schema):
+        raise ValueError("unable to get sequence key: changeItem should be 'mirror'")
     data, key = batch.cols[RAW_DATA_COLUMNS.index("data")], batch.cols[RAW_DATA_COLUMNS.index("sequence_key")]
-    if data.repr not in (abi.R_STRING, abi.R_BYTES) or key.repr not in (abi.R_STRING, abi.R_BYTES):
+    if key.repr != abi.R_BYTES and batch.nrows and any(key.is_valid(i) for i in range(batch.nrows)):
+        raise ValueError("interface conversion: sequence_key is not []byte")
+    if data.repr not in (abi.R_STRING, abi.R_BYTES):
         raise ValueError("unable to get message: unexpected data type, expected string or []byte")
     out = []
     for i in range(batch.nrows):
