@@ -638,15 +638,14 @@ class Configs4Workload(Base):
         self.shard = lib.Transformer("sharder_transformer", {"shardsCount": str(e.world), "columns": {"includeColumns": ["^id$"]}, "tables": {}})
         self.qopts = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 20, table_schema=self.schema)
         self.meta = abi.row_meta(self.n, ids=np.arange(self.n) % 97, lsns=np.arange(self.n, dtype=np.uint64) + 5, commit_times=np.full(self.n, 1700000000000000000, np.uint64))
-        if e.world > 1 or a.exchange:
+        if e.world > 1:
             import torch.distributed as dist
-            if e.world == 1 and not dist.is_initialized():
-                import socket
-                s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=e.device)
-            self.dist = dist
+            from transferia_amd import partition
+            self.comm = partition.device_comm(dist, lib)  # torch.distributed carries the 128-byte rendezvous id, nothing else
+        elif a.exchange:
+            self.comm = lib.Comm.create(lib.Comm.unique_id(), 0, 1)
         else:
-            self.dist = None
+            self.comm = None
 
     def rows(self):
         return self.n
@@ -656,9 +655,8 @@ class Configs4Workload(Base):
         lib = e.lib
         one = self.shard.apply(self.db).transformed
         grouped, counts = lib.partition(one, e.world)
-        if self.dist is not None:
-            from transferia_amd import partition
-            back, recv = partition.exchange_device_batch(self.dist, lib, grouped, counts, self.schema)
+        if self.comm is not None:
+            back, recv = self.comm.exchange(grouped, counts)
             grouped.free()
         else:
             back = grouped
@@ -676,7 +674,7 @@ class Configs4Workload(Base):
         e = self.env
         return {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys) -> sharder CRC32 % world -> tfgpu_partition -> all-to-all -> Collapse -> "
                             "native queue serializer (BASELINE.json configs[4] from the decoded batch on)", "rows_per_gpu_per_step": self.n,
-                "exchange": "torch.distributed all_to_all_single over RCCL" if self.dist is not None else "none (1 rank: every row stays)",
+                "exchange": "tfgpu_exchange: one grouped RCCL send/recv over all column buffers" if self.comm is not None else "none (1 rank: every row stays)",
                 "parallelism": f"hash-partition x{e.world}"}
 
     def extra(self):

@@ -338,6 +338,31 @@ int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed /* [nrows] */, i
  * the receive side rebuilds a batch from the received device buffers with tfgpu_batch_upload(mem = TFGPU_MEM_DEVICE). */
 int tfgpu_partition(const tfgpu_dbatch *in, int nparts, tfgpu_dbatch **out, int64_t *counts /* [nparts] */);
 
+/* Hash-partition, exchange half: the path's ONE data-path collective (one process per GPU, RCCL point-to-point over xGMI).
+ * The reference shards a transfer by giving each worker its own source partitions and lets sharder_transformer stamp
+ * PartID on every item (sharder.go:130-145) for the sink to route by; on N GPUs "one PartID -> one consumer" becomes an
+ * all-to-all of the rows tfgpu_partition grouped.
+ *   tfgpu_comm_unique_id: rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId); the shim hands it to the other
+ *     workers over its control plane (the coordinator's key-value state, cpclient) — here: torch.distributed broadcast.
+ *   tfgpu_comm_init: every rank joins (ncclCommInitRank) on the device tfgpu_init selected.  Collective.
+ *   tfgpu_exchange: collective.  `in` holds this rank's rows grouped by destination rank, counts[d] rows for rank d
+ *     (sum = nrows) — tfgpu_partition's output with nparts = world.  *out = the rows every rank sent to this one, source
+ *     ranks in order, row order inside a source kept; recv_counts[s] = rows from rank s (optional).  All column buffers,
+ *     validity, nanos, kinds, src_row, OldKeys (+ presence) travel; TableSchema / table id are taken from `in` (constant
+ *     per table); part_id of *out = this rank.  Ranks must hold the same columns in the same representation: a mismatch
+ *     is detected from the exchanged descriptors and fails with TFGPU_ERR_INVALID on EVERY rank, before any payload
+ *     moves.  A rank whose batch has no OldKeys while others have them sends nil OldKeys named by its TableSchema keys.
+ *     Runs on the calling lane's stream; RCCL itself is loaded on first use (librccl.so.1, or $TFGPU_RCCL_LIB).        */
+#define TFGPU_COMM_ID_BYTES 128
+typedef struct tfgpu_comm tfgpu_comm;
+int tfgpu_comm_unique_id(uint8_t id[TFGPU_COMM_ID_BYTES]);
+int tfgpu_comm_init(const uint8_t id[TFGPU_COMM_ID_BYTES], int rank, int world, tfgpu_comm **out);
+void tfgpu_comm_destroy(tfgpu_comm *c);
+int tfgpu_comm_rank(const tfgpu_comm *c);
+int tfgpu_comm_world(const tfgpu_comm *c);
+int tfgpu_exchange(tfgpu_comm *c, const tfgpu_dbatch *in, const int64_t *counts /* [world] */, tfgpu_dbatch **out,
+                   int64_t *recv_counts /* [world], optional */);
+
 /* ---- CSV ingest: pkg/csv.Reader + s3 CSVReader.doParse ------------------ */
 typedef struct tfgpu_csv_options {
   /* pkg/csv/reader.go:43-54, defaults from NewReader (reader.go:337-350)    */

@@ -272,10 +272,8 @@ def test_float_to_string_shortest(tf, oracle):
 
 def test_partition_rows_and_device_exchange(tf, oracle):
     """tfgpu_partition (rows grouped by the sharder's PartID, order kept inside a part) against a stable argsort of the
-    oracle's part ids; then the device half of the hash-partition exchange on a single-rank RCCL group: tensors view
-    the library's HBM buffers, all_to_all_single moves them, tfgpu_batch_upload(mem=DEVICE) rebuilds the batch."""
-    import socket
-    from transferia_amd import workload, partition
+    oracle's part ids; then tfgpu_exchange on a single-rank communicator (world_size 2 / 3: tests/test_hipemu.py)."""
+    from transferia_amd import workload
     schema = workload.hits_schema()
     data = workload.hits_csv(6000)
     opts = workload.hits_csv_options()
@@ -298,33 +296,20 @@ def test_partition_rows_and_device_exchange(tf, oracle):
             assert np.array_equal(a.values, b.values[order]), a.name
     with pytest.raises(tf.TfgpuError):
         tf.partition(sharded, 3)  # part ids 3, 4 fall outside
-    # single-rank RCCL group: the exchange is the identity, every buffer makes the round trip through torch + RCCL.
-    # Own process, torch first (as in bench.py): libtfgpu and torch must share ONE HIP runtime, the one torch loads.
-    import subprocess
-    import sys
-    import textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = textwrap.dedent("""
-        import socket, sys
-        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
-        import torch, torch.distributed as dist
-        torch.cuda.set_device(0); torch.cuda.init()
-        from transferia_amd import lib as tf, workload, partition, abi
-        from test_gpu_transformers import assert_batches_equal
-        tf.init(0)
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% port, world_size=1, rank=0, device_id=torch.device("cuda", 0))
-        schema = workload.hits_schema(); opts = workload.hits_csv_options()
-        db, _, errs = tf.csv_parse(opts, schema, workload.hits_csv(6000))
-        one = tf.Transformer("sharder_transformer", {"shardsCount": "1", "columns": {"includeColumns": ["^watchid$"]}}).apply(db).transformed
-        grouped, counts = tf.partition(one, 1)
-        assert counts == [6000]
-        back, recv = partition.exchange_device_batch(dist, tf, grouped, counts)
+    # single-rank communicator: tfgpu_exchange is the identity, every buffer makes the round trip through RCCL's
+    # grouped send/recv (self sends) and the offsets / bitmaps are rebuilt from what travelled.
+    from transferia_amd import workload
+    schema = workload.hits_schema(); opts = workload.hits_csv_options()
+    db, _, errs = tf.csv_parse(opts, schema, workload.hits_csv(6000))
+    one = tf.Transformer("sharder_transformer", {"shardsCount": "1", "columns": {"includeColumns": ["^watchid$"]}}).apply(db).transformed
+    grouped, counts = tf.partition(one, 1)
+    assert counts == [6000]
+    comm = tf.Comm.create(tf.Comm.unique_id(), 0, 1)
+    try:
+        back, recv = comm.exchange(grouped, counts)
         assert recv == [6000]
-        a, b = back.download(), db.download()
-        assert_batches_equal(a, b, "exchange identity")
-        dist.destroy_process_group()
-        print("EXCHANGE_OK")
-    """ % (root, root))
-    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "EXCHANGE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+        assert_batches_equal(back.download(), db.download(), "exchange identity")
+        with pytest.raises(tf.TfgpuError):
+            comm.exchange(grouped, [5999])  # counts must add up to the rows
+    finally:
+        comm.close()

@@ -16,3 +16,156 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_emulated_kernels_match_oracle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hipemu", "run_gpu_tests.py")], capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+
+
+EXCHANGE_WORKER = r"""
+import json, os, sys, time
+import numpy as np
+root, rank, world, case, idfile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from transferia_amd import abi, lib
+lib._LIBPATH = os.environ["TFGPU_TEST_EMU_LIB"]
+from oracle import oracle as ora
+ora.build()
+lib.init()
+
+SCHEMA = abi.Schema.of([["id", "int64", True], ["name", "utf8"], ["ts", "timestamp"], ["opt", "int32"]])
+NAMES = ["id", "name", "ts", "opt"]
+
+
+def make(r):
+    # rows of rank r as (host batch, python rows, kinds, old key values or None): deterministic, every rank can rebuild every other's
+    n = {"plain": 300 + 41 * r, "ragged": 300 + 41 * r, "empty_rank": 0 if r == 1 else 257, "mismatch": 50}[case]
+    lo = 1000 * r
+    lean = case == "ragged" and r == 1   # this rank has no nil anywhere, whole seconds only, no OldKeys, no kinds
+    rows = []
+    for i in range(n):
+        k = lo + i
+        rows.append([["int64", k * 7919 % 100003], ["nil", None] if (k % 11 == 0 and not lean) else ["string", ("n%d-" % k) * (k % 5)],
+                     ["time", (1_600_000_000 + k, 0 if lean else k % 1000)], ["nil", None] if (k % 5 == 0 and not lean) else ["int32", k]])
+    kinds = None if lean else [("insert", "update", "delete")[(lo + i) % 3] for i in range(n)]
+    schema = SCHEMA
+    if case == "mismatch" and r == 1:
+        schema = abi.Schema.of([["id", "int64", True], ["name", "utf8"], ["ts", "timestamp"], ["opt", "int64"]])
+        for row in rows:
+            if row[3][0] == "int32":
+                row[3][0] = "int64"
+    if n:
+        b = abi.batch_from_rows(schema, NAMES, rows, "db", "t", kinds)
+    else:  # a rank whose rows were all filtered away still holds the table's typed (empty) columns
+        z = np.zeros(0, np.int64)
+        b = abi.Batch([abi.Column("id", "int64", abi.R_INT64, values=z), abi.Column("name", "utf8", abi.R_STRING, offsets=np.zeros(1, np.uint32), data=np.zeros(0, np.uint8)),
+                       abi.Column("ts", "timestamp", abi.R_TIME, values=z, nanos=np.zeros(0, np.int32)), abi.Column("opt", "int32", abi.R_INT32, values=np.zeros(0, np.int32))],
+                      0, "db", "t", kind=np.zeros(0, np.uint8))
+    b.schema = schema
+    if lean:
+        for c in b.cols:
+            c.validity = None
+        b.col("ts").nanos = None
+        old = None
+    else:
+        present = np.array([(lo + i) % 3 != 0 and (lo + i) % 4 != 1 for i in range(n)], bool)
+        old = [(lo + i) * 3 if present[i] else None for i in range(n)]
+        b.old_keys = [abi.Column("id", "int64", abi.R_INT64, values=np.array([v or 0 for v in old], np.int64), validity=present.copy())]
+        b.old_present = present
+    return b, rows, kinds, old
+
+
+shard = {"shardsCount": str(world), "columns": {"includeColumns": ["^id$"]}}
+mine, _, _, _ = make(rank)
+db = lib.DeviceBatch.upload(mine)
+one = lib.Transformer("sharder_transformer", shard).apply(db).transformed
+grouped, counts = lib.partition(one, world)
+if rank == 0:
+    uid = lib.Comm.unique_id()
+    with open(idfile + ".tmp", "wb") as f:
+        f.write(uid)
+    os.rename(idfile + ".tmp", idfile)
+else:
+    t0 = time.time()
+    while not os.path.exists(idfile):
+        assert time.time() - t0 < 120
+        time.sleep(0.02)
+    uid = open(idfile, "rb").read()
+comm = lib.Comm.create(uid, rank, world)
+if case == "mismatch":
+    try:
+        comm.exchange(grouped, counts)
+        print(json.dumps({"rank": rank, "error": None}))
+    except lib.TfgpuError as e:
+        print(json.dumps({"rank": rank, "error": e.code == lib.ERR_INVALID and "representation" in str(e)}))
+    comm.close()
+    sys.exit(0)
+for _ in range(2):   # a communicator carries any number of exchanges
+    back, recv = comm.exchange(grouped, counts)
+got = back.download()
+
+# what the reference's sharder says every rank sends where (oracle), source ranks in order, row order kept
+exp_rows, exp_kinds, exp_old, exp_src, exp_recv = [], [], [], [], []
+for s in range(world):
+    hb, rows, kinds, old = make(s)
+    part = ora.Transformer("sharder_transformer", shard).apply(hb, SCHEMA).batch.part_id if hb.nrows else np.zeros(0, np.uint32)
+    sel = [i for i in range(hb.nrows) if int(part[i]) == rank]
+    exp_recv.append(len(sel))
+    exp_rows += [rows[i] for i in sel]
+    exp_kinds += [(kinds[i] if kinds else "insert") for i in sel]
+    exp_old += [(old[i] if old else None) for i in sel]
+    exp_src += sel
+assert recv == exp_recv, (recv, exp_recv)
+assert got.nrows == len(exp_rows)
+assert (got.table_ns, got.table_name) == ("db", "t")
+for j, name in enumerate(NAMES):
+    c = got.col(name)
+    for i in range(got.nrows):
+        g, e = c.pyvalue(i), exp_rows[i][j]
+        if e[0] == "string":
+            e = ["string", e[1].encode()]
+        if e[0] == "time":
+            e = ["time", tuple(e[1])]
+        assert g == e, (name, i, g, e)
+if got.nrows:
+    kid = {"insert": abi.K_INSERT, "update": abi.K_UPDATE, "delete": abi.K_DELETE}
+    assert [int(k) for k in got.kind] == [kid[k] for k in exp_kinds]
+    ok = got.old_keys[0]
+    assert ok.name == "id" and ok.repr == abi.R_INT64
+    pres = got.old_present if got.old_present is not None else np.ones(got.nrows, bool)
+    for i in range(got.nrows):
+        assert bool(pres[i]) == (exp_old[i] is not None), i
+        if exp_old[i] is not None:
+            assert ok.is_valid(i) and int(ok.values[i]) == exp_old[i]
+    assert [int(x) for x in got.part_id] == [rank] * got.nrows
+# and the consumer after the exchange takes it as is: Collapse on the received rows == the oracle's on the same rows
+col = lib.collapse(back).download()
+print(json.dumps({"rank": rank, "rows": got.nrows, "collapsed": col.nrows, "recv": recv, "sent": counts}))
+comm.close()
+"""
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("plain", 3), ("mismatch", 2)])
+def test_emulated_exchange_ranks(tmp_path, case, world):
+    """tfgpu_exchange on world_size 2 / 3 without a GPU: one process per rank, the emulated kernels, RCCL replaced by the
+    socket stand-in (tools/hipemu/fake_rccl.cpp) — the descriptor agreement, the grouped send/recv plan and the rebuild of
+    offsets / bitmaps / OldKeys are the product code.  Expected rows come from the oracle's sharder."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools", "hipemu"))
+    import build as emu_build
+    so = emu_build.build()
+    fake = os.path.join(os.path.dirname(so), "libfakerccl.so")
+    script = tmp_path / "worker.py"
+    script.write_text(EXCHANGE_WORKER)
+    env = dict(os.environ, TFGPU_TEST_EMU_LIB=so, TFGPU_RCCL_LIB=fake)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), case, str(tmp_path / "uid")], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    if case == "mismatch":
+        assert [o["error"] for o in outs] == [True] * world  # every rank refuses, nobody hangs
+        return
+    assert sum(o["rows"] for o in outs) == sum(sum(o["sent"]) for o in outs)
+    for r, o in enumerate(outs):
+        assert o["recv"] == [outs[s]["sent"][r] for s in range(world)]

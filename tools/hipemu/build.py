@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 UNITS = ["tf_runtime.hip", "tf_scan.hip", "tf_plan.cpp", "tf_transformation.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_serialize.hip", "tf_json.hip",
-         "tf_collapse.hip", "tf_srjson.hip"]  # = transferia_amd/build.py SOURCES
+         "tf_collapse.hip", "tf_srjson.hip", "tf_exchange.hip"]  # = transferia_amd/build.py SOURCES
 LAUNCH = re.compile(r"(\b[A-Za-z_][A-Za-z0-9_:]*(?:<[^<>;]*>)?)\s*<<<\s*([^;]*?)>>>\s*\(")
 
 
@@ -70,10 +70,17 @@ def build() -> str:
     import concurrent.futures
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, srcs))
-    r = subprocess.run(["g++", "-shared", "-fPIC", "-o", so, *objs], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-shared", "-fPIC", "-o", so, *objs, "-ldl", "-lpthread"], capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-6000:])
         raise RuntimeError("hipemu link failed")
+    # the stand-in for RCCL the emulated tfgpu_exchange binds through TFGPU_RCCL_LIB (world_size-2 tests)
+    fake_src, fake = os.path.join(HERE, "fake_rccl.cpp"), os.path.join(OUT, "libfakerccl.so")
+    if not os.path.exists(fake) or os.path.getmtime(fake) < os.path.getmtime(fake_src):
+        r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-o", fake, fake_src, "-lpthread"], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-6000:])
+            raise RuntimeError("fake rccl build failed")
     return so
 
 

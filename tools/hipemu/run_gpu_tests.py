@@ -19,12 +19,13 @@ from transferia_amd import lib  # noqa: E402
 
 lib._LIBPATH = so
 os.environ["TFGPU_TEST_EMU_LIB"] = so
+os.environ["TFGPU_RCCL_LIB"] = os.path.join(os.path.dirname(so), "libfakerccl.so")  # tfgpu_exchange's RCCL stand-in
 import pytest  # noqa: E402
 
-# everything marked gpu, except what needs the real device: full-size batches (minutes here), RCCL / torch.cuda, the static
+# everything marked gpu, except what needs the real device: full-size batches (minutes here), torch.cuda + real RCCL, the static
 # resource table of the gfx950 build.  Known emulator gap: the experimental JSON wave path (TFGPU_JSON_WAVES=1) parses the
 # subnormal-boundary literal 1e-308 as nil here and correctly on the MI355X.
-K = "not fullsize and not rccl and not resources and not pipeline_single_rank and not exchange and not wave_path_cross"
+K = "not fullsize and not rccl and not resources and not pipeline_single_rank and not wave_path_cross"
 args = sys.argv[1:]
 if "-k" in args:
     i = args.index("-k")

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libtfgpu.so")
-SOURCES = ["tf_runtime.hip", "tf_scan.hip", "tf_plan.cpp", "tf_transformation.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_serialize.hip", "tf_json.hip", "tf_collapse.hip", "tf_srjson.hip"]
+SOURCES = ["tf_runtime.hip", "tf_scan.hip", "tf_plan.cpp", "tf_transformation.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_serialize.hip", "tf_json.hip", "tf_collapse.hip", "tf_srjson.hip", "tf_exchange.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-function",
          "-x", "hip"]
 
@@ -62,7 +62,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in srcs]
     if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])

@@ -28,7 +28,7 @@ EXPORTS = [
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
-    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -90,6 +90,13 @@ def load():
     L.tfgpu_wait.argtypes = [P] + _push_tail
     L.tfgpu_collapse.argtypes = [P, C.POINTER(P)]
     L.tfgpu_partition.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
+    L.tfgpu_comm_unique_id.argtypes = [C.c_char_p]
+    L.tfgpu_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(P)]
+    L.tfgpu_comm_destroy.argtypes = [P]
+    L.tfgpu_comm_destroy.restype = None
+    L.tfgpu_comm_rank.argtypes = [P]
+    L.tfgpu_comm_world.argtypes = [P]
+    L.tfgpu_exchange.argtypes = [P, P, C.POINTER(C.c_int64), C.POINTER(P), C.POINTER(C.c_int64)]
     L.tfgpu_csv_options_default.argtypes = [C.POINTER(abi.CCsvOptions)]
     L.tfgpu_csv_options_default.restype = None
     L.tfgpu_csv_parse.argtypes = [C.POINTER(abi.CCsvOptions), C.POINTER(abi.CSchema), P, C.c_uint64, C.c_int, C.POINTER(P),
@@ -537,6 +544,49 @@ def partition(batch: DeviceBatch, nparts: int):
     counts = (C.c_int64 * nparts)()
     _check(load().tfgpu_partition(batch._h, nparts, C.byref(out), counts))
     return DeviceBatch(out), [int(c) for c in counts]
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """A communicator of the hash-partition exchange (tfgpu_comm_*): one per process, RCCL underneath."""
+
+    def __init__(self, h, rank: int, world: int):
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """Rank 0's rendezvous id (ncclGetUniqueId): hand it to every rank over the control plane."""
+        init()
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(load().tfgpu_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def create(uid: bytes, rank: int, world: int) -> "Comm":
+        init()
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError("a communicator id is %d bytes" % COMM_ID_BYTES)
+        h = C.c_void_p()
+        _check(load().tfgpu_comm_init(uid, rank, world, C.byref(h)))
+        return Comm(h, rank, world)
+
+    def exchange(self, batch: DeviceBatch, counts):
+        """tfgpu_exchange: `batch` grouped by destination rank (tfgpu_partition), counts[d] rows for rank d.
+        Returns (DeviceBatch of the rows sent to this rank, rows received from each source rank)."""
+        if len(counts) != self.world:
+            raise ValueError("one count per rank")
+        cin = (C.c_int64 * self.world)(*[int(c) for c in counts])
+        cout = (C.c_int64 * self.world)()
+        out = C.c_void_p()
+        _check(load().tfgpu_exchange(self._h, batch._h, cin, C.byref(out), cout))
+        return DeviceBatch(out), [int(c) for c in cout]
+
+    def close(self):
+        if self._h:
+            load().tfgpu_comm_destroy(self._h)
+            self._h = None
 
 
 def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int = 1 << 16):

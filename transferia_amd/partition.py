@@ -5,13 +5,12 @@ Local half (device): `sharder_transformer` with shardsCount = world size writes 
 SerializeToString(cols), ".")) % world (pkg/transformer/registry/sharder/sharder.go:130-145) and `tfgpu_partition`
 regroups the rows by it, so every column buffer is one contiguous run per destination rank.
 
-Exchange (this module): ONE `all_to_all_single` per column buffer — values, string lengths, string bytes, validity —
-over torch.distributed: backend "nccl" is RCCL on ROCm, whose all-to-all drives each GPU's 7 xGMI links at once (a ring
-would be per-link bound); "gloo" on CPU tensors in the tests.  Rows arrive grouped by source rank, each group in its
-original order, i.e. the order a single process would have produced for that key range.  No all-reduce anywhere.
-
-PyTorch is plumbing here (the collective and the tensor views over the library's buffers); the row data is produced
-and consumed by the HIP kernels behind the C ABI.
+Exchange: `tfgpu_exchange` behind the C ABI (csrc/tf_exchange.hip) — ONE grouped RCCL send/recv over every column buffer
+(values, text lengths, text bytes, validity, kinds, OldKeys), point-to-point so each GPU drives its 7 xGMI links at once
+(a ring would be per-link bound).  `exchange_device_batch` is its wrapper: torch.distributed only carries the 128-byte
+rendezvous id.  `exchange_host_batch` is the same exchange over host batches and a `gloo` group — the reference semantics
+the CPU tests pin the device path to.  Rows arrive grouped by source rank, each group in its original order, i.e. the
+order a single process would have produced for that key range.  No all-reduce anywhere.
 """
 from __future__ import annotations
 
@@ -90,89 +89,30 @@ def exchange_host_batch(dist, b: abi.Batch, counts: Sequence[int]) -> abi.Batch:
     return out
 
 
+_COMMS = {}
+
+
+def device_comm(dist, lib):
+    """The library communicator (tfgpu_comm_init) of a torch.distributed job: rank 0 makes the rendezvous id and the
+    existing process group carries its 128 bytes — the role the coordinator's shared state plays for the Go workers.
+    torch is only the control plane here; the payload moves inside tfgpu_exchange."""
+    key = (id(dist), dist.get_rank(), dist.get_world_size())
+    if key not in _COMMS:
+        box = [lib.Comm.unique_id() if dist.get_rank() == 0 else None]
+        if dist.get_world_size() > 1:
+            dist.broadcast_object_list(box, src=0)
+        _COMMS[key] = lib.Comm.create(box[0], dist.get_rank(), dist.get_world_size())
+    return _COMMS[key]
+
+
+def close_device_comms():
+    for c in _COMMS.values():
+        c.close()
+    _COMMS.clear()
+
+
 def exchange_device_batch(dist, lib, db, counts: Sequence[int], schema: "abi.Schema" = None):
-    """The same exchange with the column buffers left in HBM: torch tensors view the library's device buffers (CUDA
-    array interface), RCCL moves them, and the received buffers become a library batch again (device-to-device)."""
-    import ctypes as C
-
-    import torch
-    world = dist.get_world_size()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    recv = exchange_counts(dist, counts, dev)
-    n_in, n_out = int(sum(counts)), int(sum(recv))
-    v = db.view()
-
-    class _View:  # a device pointer as a CUDA-array-interface object
-        def __init__(self, ptr, nbytes):
-            self.__cuda_array_interface__ = {"shape": (max(int(nbytes), 1),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-
-    def tensor(ptr, nbytes):
-        return torch.as_tensor(_View(ptr, nbytes), device=dev)[: int(nbytes)]
-
-    lib.synchronize()  # the partition kernels ran on the library's stream, the collective runs on torch's
-    nold = int(v.n_old_keys)
-    keep, carr = [], (abi.CColumn * max(v.ncols + nold, 1))()
-    bounds = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-
-    def xchg_bits(ptr):
-        """a bitmap is not byte-aligned per destination: exchange one byte per row, repack"""
-        bits = tensor(ptr, (n_in + 7) // 8)
-        un = ((bits[:, None] >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).reshape(-1)[:n_in].contiguous()
-        rb = _a2a(dist, un, counts, recv)
-        pad = torch.zeros((n_out + 7) // 8 * 8, dtype=torch.uint8, device=dev)
-        pad[:n_out] = rb
-        packed = (pad.reshape(-1, 8) << torch.arange(8, device=dev, dtype=torch.uint8)).sum(1).to(torch.uint8)
-        keep.append(packed)
-        return packed.data_ptr()
-
-    def xchg(c, dst):
-        dst.name, dst.dtype, dst.repr = c.name, c.dtype, c.repr
-        if c.repr in abi.VAR_REPRS:
-            off = tensor(c.offsets, (n_in + 1) * 4).view(torch.int32)
-            lens = (off[1:] - off[:-1]).contiguous()
-            rl = _a2a(dist, lens, counts, recv)
-            ob = off[torch.as_tensor(bounds, device=dev)].to(torch.int64)
-            bsend = [int(x) for x in (ob[1:] - ob[:-1]).tolist()]
-            brecv = exchange_counts(dist, bsend, dev)
-            rd = _a2a(dist, tensor(c.data, int(c.data_len)), bsend, brecv)
-            ro = torch.zeros(n_out + 1, dtype=torch.int32, device=dev)
-            ro[1:] = torch.cumsum(rl, 0)
-            keep.extend([rl, rd, ro])
-            dst.offsets, dst.data, dst.data_len = ro.data_ptr(), rd.data_ptr() if rd.numel() else ro.data_ptr(), int(sum(brecv))
-        else:
-            w = np.dtype(abi.REPR_NP[c.repr]).itemsize
-            rv = _a2a(dist, tensor(c.values, n_in * w), counts, recv, w)
-            keep.append(rv)
-            dst.values = rv.data_ptr()
-            if c.nanos:
-                rn = _a2a(dist, tensor(c.nanos, n_in * 4), counts, recv, 4)
-                keep.append(rn)
-                dst.nanos = rn.data_ptr()
-        if c.validity:
-            dst.validity = xchg_bits(c.validity)
-    for i in range(v.ncols):
-        xchg(v.cols[i], carr[i])
-    for k in range(nold):
-        xchg(v.old_keys[k], carr[v.ncols + k])
-    hb = abi.CBatch()
-    hb.nrows, hb.ncols, hb.cols, hb.mem = n_out, v.ncols, carr, abi.MEM_DEVICE
-    hb.table_ns, hb.table_name = v.table_ns, v.table_name
-    if nold:  # ChangeItem.OldKeys travel with their rows: tfgpu_collapse on the receiving rank reads them
-        hb.n_old_keys = nold
-        hb.old_keys = C.cast(C.byref(carr, C.sizeof(abi.CColumn) * v.ncols), C.POINTER(abi.CColumn))
-        if v.old_keys_present:
-            hb.old_keys_present = xchg_bits(v.old_keys_present)
-    if v.kind:
-        rk = _a2a(dist, tensor(v.kind, n_in), counts, recv)
-        keep.append(rk); hb.kind = rk.data_ptr()
-    if v.src_row:
-        rs = _a2a(dist, tensor(v.src_row, n_in * 4), counts, recv, 4)
-        keep.append(rs); hb.src_row = rs.data_ptr()
-    if schema is not None:  # TableSchema (PrimaryKey flags) for tfgpu_collapse on the receiving rank: constant per table
-        cs = schema.to_c()
-        keep.append(cs)
-        hb.schema = C.pointer(cs)
-    torch.cuda.synchronize()
-    h = C.c_void_p()
-    lib._check(lib.load().tfgpu_batch_upload(C.byref(hb), C.byref(h)))
-    return lib.DeviceBatch(h), recv
+    """The same exchange with the column buffers left in HBM, behind the C ABI: tfgpu_exchange (one grouped RCCL
+    send/recv over all column buffers, csrc/tf_exchange.hip).  `schema` is accepted for symmetry with the host variant;
+    the device batch already carries its TableSchema.  Returns (DeviceBatch, rows received per source rank)."""
+    return device_comm(dist, lib).exchange(db, counts)
