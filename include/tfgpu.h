@@ -331,6 +331,16 @@ int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out);
  * its (Delete by OldKeys, Insert) pair before Collapse (clickhouse_local.go:108, ydb/sink.go:732, yt/sink/sink.go:379). */
 int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed /* [nrows] */, int64_t *nchanged /* optional */);
 
+/* util.DeepSizeof(item.ColumnValues) of every row (pkg/util/sizeof.go:7-93) — what measurer.AsyncPush stores in
+ * Size.Values for the Bufferer's byte trigger (pkg/middlewares/synchronizer/measurer.go:38-42) and what the s3 CSV reader
+ * stores in Size.Read (reader_csv.go:336): 24 + per column 16 + (nil: 0 | scalar: its size | string, json.Number:
+ * 16 + len | []byte: 24 + len | time.Time: 24 | `any`: the decoded value's size, numbers as json.Number, or as float64
+ * with TFGPU_SIZEOF_JSON_FLOAT64).  *total = the sum over rows; per_row (HOST, nrows entries) is optional.  Text payloads
+ * are not read.  One deviation: an `any` object that repeats a key is counted with every repeat (the decoded Go map keeps
+ * one entry); containers nested deeper than 64 → TFGPU_ERR_UNSUPPORTED.                                              */
+#define TFGPU_SIZEOF_JSON_FLOAT64 1u
+int tfgpu_dbatch_deepsizeof(const tfgpu_dbatch *in, uint32_t flags, uint64_t *per_row, uint64_t *total);
+
 /* Hash-partition, local half (BASELINE.json configs[4]: debezium stream → hash-partition → dedup → Kafka sink on 8 GPUs).
  * Rows are regrouped by part_id — what sharder_transformer wrote: PartID = itoa(CRC32_IEEE(join(SerializeToString(cols), "."))
  * % shards), sharder.go:130-145 — parts 0..nparts-1 in order, original row order kept inside a part; counts[d] = rows of
@@ -545,6 +555,23 @@ int tfgpu_dbuf_upload(const void *host, uint64_t len, tfgpu_dbuf **out);
  * buffer: the H2D half of the double-buffered pull loop (parsequeue.go:57-154). */
 int tfgpu_dbuf_alloc(uint64_t len, tfgpu_dbuf **out);
 int tfgpu_dbuf_write(tfgpu_dbuf *b, uint64_t offset, const void *host, uint64_t len);
+
+/* ---- ClickHouse Native column block -------------------------------------------------------------------- */
+/* The v2 ClickHouse sink turns every ChangeItem into a []any row (pkg/providers/clickhouse/async/marshaller.go:62-190) and
+ * appends it to a clickhouse-go batch, which encodes ClickHouse's Native column layout.  With the batch columnar in HBM
+ * the sink-side work is that layout itself:  varuint(ncols) varuint(nrows), then per column  string(name) string(type)
+ * [Nullable: nrows null-map bytes] data  — fixed-width values little-endian (nil / NULL → zero), String as varuint(len) +
+ * bytes.  `cols` lists the target table's columns in order, each naming a batch column and its ClickHouse type:
+ * Int8…Int64, UInt8…UInt64, Float32/64, Bool, String, Date, Date32, DateTime[('tz')], DateTime64(p[, 'tz']), each
+ * optionally inside Nullable(…).  The Go value must be the one the driver appends without conversion (int32 → Int32, …;
+ * time.Time → the four date types; text / []byte / any → String); YT date / datetime columns are clamped to
+ * [1970-01-01, 2106-01-01] first (columntypes.Restore, types.go:15-29, 92-104).  A time outside its column's range fails
+ * the call (TFGPU_ERR_INVALID, the driver's DateOverflowError fails the push); other types / conversions →
+ * TFGPU_ERR_UNSUPPORTED (Decimal, LowCardinality, Array, UUID, Enum, FixedString, json.Number → Float64: host).
+ * The encoder is a dependency of the reference (clickhouse-go v2.46.0 / ch-go v0.71.0), not part of it: PARITY UNPINNED —
+ * the oracle restates the same published format and the tests decode the block independently.                          */
+typedef struct tfgpu_ch_native_column { const char *name; const char *ch_type; } tfgpu_ch_native_column;
+int tfgpu_ch_native_block(const tfgpu_dbatch *in, const tfgpu_ch_native_column *cols, int32_t ncols, tfgpu_dbuf **out);
 
 /* ---- queue serializers: pkg/serializer/queue (the "→ Kafka sink" half of configs[4]) ---- */
 /* ChangeItem fields that are not columns (change_item.go:27-80).  Every array is indexed by the INPUT row of the

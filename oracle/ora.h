@@ -210,6 +210,13 @@ char *ora_serialize_ex(int format, const ora_batch *b, const tfgpu_serialize_opt
 char *ora_queue_serialize(const tfgpu_queue_options *o, const ora_batch *b, const tfgpu_row_meta *m, uint64_t *len,
                           uint64_t **msg_start, int64_t **msg_row, int64_t *nmsg);
 
+/* §8 f2: marshalChangeItemInto + the driver's Native block layout (ora_chnative.c); NULL = refused */
+char *ora_ch_native_block(const ora_batch *rows, const char *const *names, const char *const *types, int ncols, uint64_t *len);
+
+/* a23: util.DeepSizeof(ColumnValues) per item (ora_sizeof.c); flags & 1: JSON numbers decoded as float64 */
+uint64_t ora_deepsizeof(const ora_batch *b, int flags, uint64_t *per_row);
+uint64_t ora_deepsizeof_value(const ora_value *v, int flags);
+
 /* §8f.1 Confluent Schema Registry parser, JSON schemas (ora_srjson.c) */
 tfgpu_sr_frame *ora_sr_frames(const void *bytes, uint64_t len, const tfgpu_messages *msgs, int64_t *nframes); /* malloc'd */
 ora_batch *ora_sr_json_parse(const tfgpu_sr_json_options *o, const void *bytes, uint64_t len, const tfgpu_messages *msgs, int64_t **msg_of);

@@ -212,6 +212,38 @@ def serialize(fmt: int, batch: abi.Batch, schema: abi.Schema, opts=None):
     return out
 
 
+def ch_native_block(batch: abi.Batch, schema: abi.Schema, columns):
+    """One ClickHouse Native block of the batch (ora_chnative.c); `columns` = [(name, ClickHouse type), ...]; None = refused."""
+    L = lib()
+    cb, cs = batch.to_c(), schema.to_c()
+    rows = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    names = (C.c_char_p * len(columns))(*[c[0].encode() for c in columns])
+    types = (C.c_char_p * len(columns))(*[c[1].encode() for c in columns])
+    n = C.c_uint64(0)
+    L.ora_ch_native_block.restype = C.c_void_p
+    L.ora_ch_native_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    p = L.ora_ch_native_block(rows, names, types, len(columns), C.byref(n))
+    L.ora_batch_free(rows)
+    if not p:
+        return None
+    out = C.string_at(p, n.value)
+    L.free(C.c_void_p(p))
+    return out
+
+
+def deepsizeof(batch: abi.Batch, schema: abi.Schema, json_float64: bool = False):
+    """util.DeepSizeof(item.ColumnValues) per row (ora_sizeof.c): (total, per-row uint64 array)."""
+    L = lib()
+    cb, cs = batch.to_c(), schema.to_c()
+    rows = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    per = np.zeros(max(batch.nrows, 1), np.uint64)
+    L.ora_deepsizeof.restype = C.c_uint64
+    L.ora_deepsizeof.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    total = L.ora_deepsizeof(rows, 1 if json_float64 else 0, per.ctypes.data)
+    L.ora_batch_free(rows)
+    return int(total), per[:batch.nrows]
+
+
 def queue_serialize(opts: abi.CQueueOptions, batch: abi.Batch, schema: abi.Schema, meta: abi.CRowMeta = None):
     """queue.Serializer.Serialize for one table's rows → list of message values (bytes), or None where the reference's
     Serialize returns an error (or the value form is outside the restatement).  queue_serialize.rows = first row of

@@ -75,5 +75,11 @@ def test_compute_fails_loudly_without_gpu():
 
 def test_unknown_transformer_type():
     with pytest.raises(lib.TfgpuError) as ei:
-        lib.Transformer("lambda", {})
+        lib.Transformer("no_such_transformer", {})
     assert ei.value.code == lib.ERR_UNKNOWN_TYPE
+    # registered in the reference, host-only here: the shim learns it when it builds the chain (a14: `sql` runs clickhouse-local)
+    for name in ("sql", "lambda", "dbt", "number_to_float_transformer"):
+        with pytest.raises(lib.TfgpuError) as ei:
+            lib.Transformer(name, {"query": "select * from table"})
+        assert ei.value.code == lib.ERR_UNSUPPORTED, name
+

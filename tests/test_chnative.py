@@ -1,0 +1,155 @@
+"""ClickHouse Native column block: the oracle's row-by-row restatement decoded by an independent reader
+(CPU), the HIP encoder against the oracle byte for byte (GPU)."""
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+
+
+def _varuint(buf, at):
+    v, shift = 0, 0
+    while True:
+        b = buf[at]; at += 1
+        v |= (b & 0x7F) << shift
+        if b < 0x80:
+            return v, at
+        shift += 7
+
+
+def decode_block(buf: bytes):
+    """A reader of the Native format written from ClickHouse's format description (not from the encoders under test):
+    returns [(name, type, null map or None, values)]."""
+    ncols, at = _varuint(buf, 0)
+    nrows, at = _varuint(buf, at)
+    out = []
+    widths = {"Int8": "<i1", "Int16": "<i2", "Int32": "<i4", "Int64": "<i8", "UInt8": "<u1", "UInt16": "<u2", "UInt32": "<u4", "UInt64": "<u8", "Float32": "<f4",
+              "Float64": "<f8", "Bool": "<u1", "Date": "<u2", "Date32": "<i4", "DateTime": "<u4", "DateTime64": "<i8"}
+    for _ in range(ncols):
+        n, at = _varuint(buf, at); name = buf[at:at + n].decode(); at += n
+        n, at = _varuint(buf, at); typ = buf[at:at + n].decode(); at += n
+        inner, nulls = typ, None
+        if typ.startswith("Nullable("):
+            inner = typ[9:-1]
+            nulls = np.frombuffer(buf, np.uint8, nrows, at).copy(); at += nrows
+        base = inner.split("(")[0]
+        if base == "String":
+            vals = []
+            for _ in range(nrows):
+                n, at = _varuint(buf, at); vals.append(buf[at:at + n]); at += n
+        else:
+            dt = np.dtype(widths[base])
+            vals = np.frombuffer(buf, dt, nrows, at).copy(); at += nrows * dt.itemsize
+        out.append((name, typ, nulls, vals))
+    assert at == len(buf)
+    return out
+
+
+SCHEMA = abi.Schema.of([["id", "int64", True], ["i8", "int8"], ["u16", "uint16"], ["i32", "int32"], ["u64", "uint64"], ["f", "float"], ["d", "double"], ["b", "boolean"],
+                        ["s", "utf8"], ["x", "string"], ["j", "any"], ["day", "date"], ["dt", "datetime"], ["ts", "timestamp"]])
+COLUMNS = [("id", "Int64"), ("i8", "Nullable(Int8)"), ("u16", "UInt16"), ("i32", "Nullable(Int32)"), ("u64", "UInt64"), ("f", "Float32"), ("d", "Nullable(Float64)"),
+           ("b", "Bool"), ("s", "Nullable(String)"), ("x", "String"), ("j", "String"), ("day", "Date"), ("dt", "DateTime('UTC')"), ("ts", "DateTime64(6, 'UTC')"),
+           ("ts", "Nullable(DateTime64(3))"), ("day", "Date32"), ("b", "UInt8")]
+
+
+def _rows(n, seed=5):
+    import random
+    rng = random.Random(seed)
+    rows = []
+    for k in range(n):
+        def maybe(v, p=0.25):
+            return ["nil", None] if (k and rng.random() < p) else v   # row 0 types every column
+        rows.append([["int64", k - 3], maybe(["int8", rng.randrange(-128, 128)]), maybe(["uint16", rng.randrange(65536)]), maybe(["int32", -k]),
+                     maybe(["uint64", rng.getrandbits(64)]), maybe(["float32", float(np.float32(rng.uniform(-9, 9)))]), maybe(["float64", rng.uniform(-1e9, 1e9)]),
+                     maybe(["bool", k % 3 == 0]), maybe(["string", "é" * (k % 200)]), maybe(["bytes", "z" * (k % 7)]), maybe(["json", '{"k":[%d,null]}' % k]),
+                     maybe(["time", (86400 * (k % 40000), 0)]), maybe(["time", (rng.randrange(-10**9, 5 * 10**9), 0)]),
+                     maybe(["time", (rng.randrange(-2 * 10**9, 9 * 10**9), rng.randrange(10**9))])])
+    return rows
+
+
+def test_oracle_block_decodes(oracle):
+    rows = _rows(300)
+    b = abi.batch_from_rows(SCHEMA, [c.name for c in SCHEMA.cols], rows, "db", "t")
+    blk = oracle.ch_native_block(b, SCHEMA, COLUMNS)
+    dec = decode_block(blk)
+    assert [(d[0], d[1]) for d in dec] == COLUMNS
+    col = {c.name: i for i, c in enumerate(SCHEMA.cols)}
+    for (name, typ, nulls, vals) in dec:
+        j = col[name]
+        for r, row in enumerate(rows):
+            g, v = row[j]
+            if nulls is not None:
+                assert nulls[r] == (g == "nil")
+            if g == "nil":
+                assert (vals[r] == b"" if "String" in typ else vals[r] == 0), (name, typ, r)
+                continue
+            if "String" in typ:
+                assert vals[r] == (v.encode("utf-8") if g != "bytes" else v.encode("latin-1")), (name, r)
+            elif "Date32" in typ or typ == "Date":
+                assert int(vals[r]) == min(max(v[0], 0), 4291747200) // 86400
+            elif typ.startswith("DateTime("):
+                assert int(vals[r]) == min(max(v[0], 0), 4291747200)       # columntypes.Restore clamps YT datetime
+            elif "DateTime64" in typ:
+                p = 6 if "(6" in typ else 3
+                un = v[0] * 10**9 + v[1]
+                q = abs(un) // 10**(9 - p)
+                assert int(vals[r]) == (q if un >= 0 else -q)               # Go's truncating division
+            elif g == "bool":
+                assert int(vals[r]) == int(v)
+            elif g in ("float32", "float64"):
+                assert float(vals[r]) == v
+            else:
+                assert int(vals[r]) == v, (name, typ, r)
+    # refusals: a time past the column's range, an unknown type, a value that needs a conversion
+    s2 = abi.Schema.of([["ts", "timestamp"]])
+    far = abi.batch_from_rows(s2, ["ts"], [[["time", (10**10, 0)]]], "", "t")
+    assert oracle.ch_native_block(far, s2, [("ts", "DateTime64(6)")]) is None
+    assert oracle.ch_native_block(far, s2, [("ts", "Decimal(10, 2)")]) is None
+    assert oracle.ch_native_block(b, SCHEMA, [("i32", "Int64")]) is None
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 255, 3000, 40001])
+def test_gpu_block_matches_oracle(tf, oracle, n):
+    b = abi.batch_from_rows(SCHEMA, [c.name for c in SCHEMA.cols], _rows(n, seed=n), "db", "t")
+    b.schema = SCHEMA
+    exp = oracle.ch_native_block(b, SCHEMA, COLUMNS)
+    got = tf.ch_native_block(tf.DeviceBatch.upload(b), COLUMNS).download()
+    assert got == exp
+    assert len(decode_block(got)) == len(COLUMNS)
+
+
+@pytest.mark.gpu
+def test_gpu_block_headline_batch_and_refusals(tf, oracle):
+    from transferia_amd import workload
+    schema = workload.hits_schema()
+    data = workload.hits_csv(4000)
+    parsed, _, _ = tf.csv_parse(workload.hits_csv_options(), schema, data)
+    ref = oracle.csv_parse(workload.hits_csv_options(), schema, data, "", "")
+    chmap = {"int8": "Int8", "int16": "Int16", "int32": "Int32", "int64": "Int64", "uint8": "UInt8", "uint16": "UInt16", "uint32": "UInt32", "uint64": "UInt64",
+             "utf8": "String", "string": "String", "date": "Date", "datetime": "DateTime", "timestamp": "DateTime64(6)", "double": "Float64", "boolean": "Bool", "any": "String"}
+    cols = [(c.name, chmap[c.dtype]) for c in schema.cols if not (c.dtype == "double")]
+    exp = oracle.ch_native_block(ref.batch, ref.schema, cols)
+    assert exp is not None
+    assert tf.ch_native_block(parsed, cols).download() == exp
+    s2 = abi.Schema.of([["ts", "timestamp"], ["j", "any"], ["i", "int32"]])
+    b = abi.batch_from_rows(s2, ["ts", "j", "i"], [[["time", (5, 0)], ["json", "1"], ["int32", 1]], [["time", (10**10, 0)], ["json", '"str"'], ["int32", 2]]], "", "t")
+    b.schema = s2
+    db = tf.DeviceBatch.upload(b)
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.ch_native_block(db, [("ts", "DateTime64(6)")])
+    assert ei.value.code == tf.ERR_INVALID and "row 1" in str(ei.value)
+    for cols, code in (([("j", "String")], tf.ERR_UNSUPPORTED), ([("i", "Int64")], tf.ERR_UNSUPPORTED), ([("i", "Decimal(9, 2)")], tf.ERR_UNSUPPORTED),
+                       ([("nope", "Int32")], tf.ERR_INVALID)):
+        with pytest.raises(tf.TfgpuError) as ei:
+            tf.ch_native_block(db, cols)
+        assert ei.value.code == code, cols
+    assert oracle.ch_native_block(b, s2, [("j", "String")]) is None
+    e = abi.Batch([abi.Column("a", "int32", abi.R_INT32, values=np.zeros(0, np.int32))], 0, "", "t")
+    assert tf.ch_native_block(tf.DeviceBatch.upload(e), [("a", "Nullable(Int32)")]).download() == b"\x01\x00\x01a\x0fNullable(Int32)"

@@ -313,3 +313,43 @@ def test_partition_rows_and_device_exchange(tf, oracle):
             comm.exchange(grouped, [5999])  # counts must add up to the rows
     finally:
         comm.close()
+
+
+def test_deepsizeof_matches_oracle(tf, oracle):
+    """tfgpu_dbatch_deepsizeof (a23) against the restated util.DeepSizeof: every representation, nils, nested `any`
+    values with escapes, and the headline CSV batch with its text still unmaterialised."""
+    import random
+    rng = random.Random(11)
+    s = abi.Schema.of([["i8", "int8"], ["u16", "uint16"], ["i32", "int32"], ["i64", "int64"], ["f", "double"], ["g", "float"], ["b", "boolean"], ["s", "utf8"],
+                       ["x", "string"], ["t", "timestamp"], ["j", "any"], ["n", "double"]])
+    anys = ['1', '"a\\u00e9\\n\\ud83d\\ude00\\ud800"', '[]', '{}', '[1,[2,{"k":[true,null,"v"]}],-1.5e3]', '{"a":{"b":{"c":[1,2,3]}},"z":"\\"q\\""}', 'null', 'true',
+            ' { "sp" : [ 1 , 2 ] } ']
+    rows = []
+    for k in range(3000):
+        def maybe(v):
+            return ["nil", None] if rng.random() < 0.2 else v
+        rows.append([maybe(["int8", rng.randrange(-128, 128)]), maybe(["uint16", rng.randrange(65536)]), maybe(["int32", k]), maybe(["int64", -k]), maybe(["float64", k / 7]),
+                     maybe(["float32", 0.5]), maybe(["bool", k % 2 == 0]), maybe(["string", "é" * (k % 9)]), maybe(["bytes", "z" * (k % 5)]), maybe(["time", (k, k % 1000)]),
+                     maybe(["json", anys[k % len(anys)]]), maybe(["jsonnum", "1.25e%d" % (k % 30)])])
+    b = abi.batch_from_rows(s, [c.name for c in s.cols], rows, "", "t")
+    db = tf.DeviceBatch.upload(b)
+    for f64 in (False, True):
+        total, per = tf.deepsizeof(db, per_row=True, json_float64=f64)
+        etotal, eper = oracle.deepsizeof(b, s, json_float64=f64)
+        assert np.array_equal(per, eper) and total == etotal == int(per.sum())
+        assert tf.deepsizeof(db, json_float64=f64) == etotal
+    # the documented deviation: a repeated key is counted every time (the decoded map keeps one)
+    dup = abi.batch_from_rows(abi.Schema.of([["j", "any"]]), ["j"], [[["json", '{"a":1,"a":22}']]], "", "t")
+    assert oracle.deepsizeof(dup, abi.Schema.of([["j", "any"]]))[0] == 24 + 16 + 8 + (17 + 16 + 18)
+    assert tf.deepsizeof(tf.DeviceBatch.upload(dup)) == 24 + 16 + 8 + (17 + 16 + 17) + (17 + 16 + 18)
+    # the CSV reader's Size.Read: text columns stay views into the chunk
+    from transferia_amd import workload
+    schema = workload.hits_schema()
+    data = workload.hits_csv(5000)
+    parsed, _, _ = tf.csv_parse(workload.hits_csv_options(), schema, data)
+    ref = oracle.csv_parse(workload.hits_csv_options(), schema, data, "", "")
+    total, per = tf.deepsizeof(parsed, per_row=True)
+    etotal, eper = oracle.deepsizeof(ref.batch, ref.schema)
+    assert total == etotal and np.array_equal(per, eper)
+    e = abi.Batch([abi.Column("a", "int32", abi.R_INT32, values=np.zeros(0, np.int32))], 0, "", "t")
+    assert tf.deepsizeof(tf.DeviceBatch.upload(e)) == 0

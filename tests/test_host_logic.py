@@ -93,3 +93,23 @@ def test_workload_generator_is_row_addressable():
     assert whole == parts
     assert len(workload.hits_columns()) == 105
     assert whole.count(b"\n") == 300
+
+
+def test_deepsizeof_known_answers(oracle):
+    """util.DeepSizeof over ColumnValues, pinned to the formulas pkg/util/sizeof_test.go:12-140 states: a string is its
+    16-byte header + bytes, a []interface{} is 24 + per element 16 + the value, scalars are their type's size, a
+    map[string]interface{} is 8 + per entry key string + 16 + value."""
+    s = abi.Schema.of([["a", "utf8"], ["b", "utf8"]])
+    b = abi.batch_from_rows(s, ["a", "b"], [[["string", "a"], ["string", "b"]]], "", "t")
+    total, per = oracle.deepsizeof(b, s)
+    assert total == per[0] == 24 + 2 * 16 + 2 * 16 + 2            # "interface slice" case, first two elements
+    s = abi.Schema.of([["i", "int64"], ["u", "uint64"], ["s", "utf8"], ["f", "boolean"], ["n", "int32"], ["t", "timestamp"], ["x", "string"], ["j", "any"]])
+    row = [["int64", 64], ["uint64", 64], ["string", "0123456789"], ["bool", True], ["nil", None], ["time", (1, 2)], ["bytes", "abc"],
+           ["json", '{"i":64,"s":"0123456789"}']]
+    b = abi.batch_from_rows(s, [c.name for c in s.cols], [row], "", "t")
+    total, per = oracle.deepsizeof(b, s, json_float64=True)
+    # "map" case of the reference test: 8 + (16+1 + 16 + 8) + (16+1 + 16 + 16+10)
+    m = 8 + (17 + 16 + 8) + (17 + 16 + 26)
+    assert total == 24 + 8 * 16 + 8 + 8 + 26 + 1 + 0 + 24 + (24 + 3) + m
+    total2, _ = oracle.deepsizeof(b, s)  # UseNumber: 64 is json.Number("64") = 16 + 2
+    assert total2 == total + (18 - 8)

@@ -199,6 +199,7 @@ inline uint32_t atomicOr(uint32_t *p, uint32_t v) { uint32_t o = *p; *p |= v; re
 inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
 inline uint32_t atomicMax(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomicMin(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomicCAS(uint32_t *p, uint32_t c, uint32_t v) { uint32_t o = *p; if (o == c) *p = v; return o; }
 inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long c, unsigned long long v) { unsigned long long o = *p; if (o == c) *p = v; return o; }

@@ -70,6 +70,10 @@ class CRowError(C.Structure):
     _fields_ = [("row", C.c_int64), ("code", C.c_int32), ("step", C.c_int32), ("column", C.c_int32)]
 
 
+class CChNativeColumn(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ch_type", C.c_char_p)]
+
+
 class CTransformationStats(C.Structure):
     _fields_ = [("pushes", C.c_int64), ("items_in", C.c_int64), ("items_out", C.c_int64), ("dropped", C.c_int64), ("errors", C.c_int64),
                 ("elapsed_ns", C.c_int64), ("plans_built", C.c_int64)]

@@ -550,6 +550,19 @@ std::unique_ptr<tfgpu_plan> make_plan(const std::string &type_name, const std::s
     for (size_t i = 0; i < p->new_keys.size(); i++)
       for (size_t j = 0; j < i; j++)
         if (p->new_keys[i] == p->new_keys[j]) cfg_error("Can't use same keys column names twice: " + join_keys(p->new_keys));
+  } else if (type_name == "sql") {
+    // clickhouse/clickhouse_local.go:97-294: the rows go through an external `clickhouse-local --query Q` process, i.e.
+    // ClickHouse's SQL engine decides the result.  The stages around it exist on the device (tfgpu_keys_changed for
+    // SplitUpdatedPKeys, tfgpu_collapse, tfgpu_serialize(TFGPU_FMT_CH_JSON_EACH_ROW) for prepareInput); the query does
+    // not, and answering with anything but ClickHouse's own evaluation would break bit-parity.  Known type, host step.
+    throw Error(TFGPU_ERR_UNSUPPORTED, "sql transformer: the query is evaluated by clickhouse-local (an external SQL engine); keep this step on the host "
+                                       "(its input stages are tfgpu_keys_changed / tfgpu_collapse / tfgpu_serialize CH JSONEachRow)");
+  } else if (type_name == "lambda" || type_name == "dbt" || type_name == "logger" || type_name == "yt_dict_transformer" || type_name == "raw_doc_grouper" ||
+             type_name == "raw_cdc_doc_grouper" || type_name == "table_splitter_transformer" || type_name == "number_to_float_transformer" ||
+             type_name == "problem_item_detector" || type_name == "batch_splitter" || type_name == "filter_strm_access_log" || type_name == "jsonparser" ||
+             type_name == "regex_replace_transformer" || type_name == "filter_rows_by_ids" || type_name == "mongo_pk_extender") {
+    // registered in the reference (pkg/transformer/registry/*), outside the device subset (out of scope)
+    throw Error(TFGPU_ERR_UNSUPPORTED, "transformer type " + type_name + " has no device plan: keep it on the host");
   } else {
     throw Error(TFGPU_ERR_UNKNOWN_TYPE, "transformer type not registered: " + type_name);
   }

@@ -28,7 +28,7 @@ EXPORTS = [
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
-    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -90,6 +90,8 @@ def load():
     L.tfgpu_wait.argtypes = [P] + _push_tail
     L.tfgpu_collapse.argtypes = [P, C.POINTER(P)]
     L.tfgpu_partition.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
+    L.tfgpu_dbatch_deepsizeof.argtypes = [P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.tfgpu_ch_native_block.argtypes = [P, C.POINTER(abi.CChNativeColumn), C.c_int32, C.POINTER(P)]
     L.tfgpu_comm_unique_id.argtypes = [C.c_char_p]
     L.tfgpu_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(P)]
     L.tfgpu_comm_destroy.argtypes = [P]
@@ -544,6 +546,27 @@ def partition(batch: DeviceBatch, nparts: int):
     counts = (C.c_int64 * nparts)()
     _check(load().tfgpu_partition(batch._h, nparts, C.byref(out), counts))
     return DeviceBatch(out), [int(c) for c in counts]
+
+
+def ch_native_block(batch: DeviceBatch, columns) -> "DeviceBuffer":
+    """tfgpu_ch_native_block: the batch as one ClickHouse Native block; `columns` = [(batch column, ClickHouse type), ...]."""
+    init()
+    arr = (abi.CChNativeColumn * max(len(columns), 1))()
+    for i, (n, t) in enumerate(columns):
+        arr[i].name, arr[i].ch_type = n.encode(), t.encode()
+    out = C.c_void_p()
+    _check(load().tfgpu_ch_native_block(batch._h, arr, len(columns), C.byref(out)))
+    return DeviceBuffer(out)
+
+
+def deepsizeof(batch: DeviceBatch, per_row: bool = False, json_float64: bool = False):
+    """util.DeepSizeof(ColumnValues) of every row (tfgpu_dbatch_deepsizeof): the total, or (total, per-row uint64 array)."""
+    init()
+    total = C.c_uint64(0)
+    n = batch.nrows
+    rows = np.zeros(max(n, 1), np.uint64) if per_row else None
+    _check(load().tfgpu_dbatch_deepsizeof(batch._h, 1 if json_float64 else 0, rows.ctypes.data_as(C.POINTER(C.c_uint64)) if per_row else None, C.byref(total)))
+    return (int(total.value), rows[:n]) if per_row else int(total.value)
 
 
 COMM_ID_BYTES = 128
