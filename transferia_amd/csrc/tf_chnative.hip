@@ -19,7 +19,7 @@
 // `case nil`).  Values outside a column's range make the driver's Append fail (DateOverflowError) and the push with it:
 // here the call fails the same way, naming the first offending row.  PARITY UNPINNED for those range edges and for the
 // layout itself: the encoder is a dependency of the reference, not part of it; the oracle restates the same published
-// format (oracle/ora_chnative.c) and the tests decode the block independently.
+// format and the tests decode the block with an independent reader.
 //
 // Kernels are pure HBM streaming: one lane per value, 4/8-byte loads and stores; text columns are a length pass, one
 // segmented scan over all of them, and a copy pass.
