@@ -188,7 +188,16 @@ typedef enum tfgpu_rowerr {
   TFGPU_ROW_SR_MAGIC = 16,         /* confluent SR: first byte is not 0 (parser.go:113-116)       */
   TFGPU_ROW_SR_TYPE = 17,          /* confluent SR json: convertTypes "wrong type" / Number.Int64
                                       error (utils_json.go:97-128)                                */
-  TFGPU_ROW_SR_REQUIRED = 18       /* confluent SR json: required field absent (utils_json.go:54-56) */
+  TFGPU_ROW_SR_REQUIRED = 18,      /* confluent SR json: required field absent (utils_json.go:54-56) */
+  /* debezium parser (pkg/parsers/registry/debezium/engine/parser.go:33-57): why a message became an `_unparsed` item   */
+  TFGPU_ROW_DBZ_UNPACK = 19,       /* empty message, or IncludeSchema.Unpack's json.Unmarshal fails (include_schema.go:13-25) */
+  TFGPU_ROW_DBZ_PAYLOAD = 20,      /* UnmarshalPayload fails: no payload, or a Payload / Source field of the wrong JSON type
+                                      (receiver.go:151-154, debezium_schema.go:31-56)                                   */
+  TFGPU_ROW_DBZ_OP = 21,           /* opToKind: unknown op (kind.go:34-46)                                              */
+  TFGPU_ROW_DBZ_SCHEMA = 22,       /* receiveSchema fails: the schema does not unmarshal, or a field's Kafka type has no
+                                      receiver (receiver.go:60-96, receiver_engine.go:108-146)                          */
+  TFGPU_ROW_DBZ_FIELD = 23         /* a schema field is missing from before / after, or receiveField rejects its value
+                                      (receiver.go:216-230, receiver_engine.go:148-287)                                 */
 } tfgpu_rowerr;
 
 typedef struct tfgpu_row_error {
@@ -555,6 +564,72 @@ int tfgpu_dbuf_upload(const void *host, uint64_t len, tfgpu_dbuf **out);
  * buffer: the H2D half of the double-buffered pull loop (parsequeue.go:57-154). */
 int tfgpu_dbuf_alloc(uint64_t len, tfgpu_dbuf **out);
 int tfgpu_dbuf_write(tfgpu_dbuf *b, uint64_t offset, const void *host, uint64_t len);
+
+/* ---- Debezium ingest, inline schemas (the source of BASELINE.json configs[4]) ------------------------------- */
+/* DebeziumImpl.DoBatch with no schema registry (pkg/parsers/registry/debezium/engine/parser.go:33-130): every Kafka
+ * message is ONE event {"schema": …, "payload": …} and becomes one ChangeItem or one `_unparsed` item.  Two steps, because
+ * the Kafka Connect schema is data: the shim compiles it (host, once per distinct schema — the reference caches by the
+ * schema's hash too, receiver.go:60-96) and the device does everything per message.
+ *
+ * tfgpu_debezium_unpack — IncludeSchema.Unpack (pkg/debezium/unpacker/include_schema.go:13-25) for every message: the
+ * whole message is validated as one JSON value and the raw "schema" / "payload" members are located (exact key; the last
+ * duplicate wins).  frames[m] (HOST, nmsg entries): their spans, a 128-bit hash of the schema bytes (equal bytes ⇔ equal
+ * hash for grouping; FNV-style, not cryptographic) and code = TFGPU_ROW_OK / TFGPU_ROW_DBZ_UNPACK / TFGPU_ROW_HOST_FALLBACK
+ * (keys that match only by case folding or carry escapes, nesting deeper than 128).  A message without "payload" keeps
+ * payload_len = 0 (→ TFGPU_ROW_DBZ_PAYLOAD in the parse), without "schema" schema_len = 0.                              */
+typedef struct tfgpu_dbz_frame {
+  uint64_t schema_start;  uint64_t payload_start;
+  uint32_t schema_len;    uint32_t payload_len;
+  uint64_t schema_hash[2];
+  int32_t code;           int32_t reserved;
+} tfgpu_dbz_frame;
+int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_dbz_frame *frames);
+
+/* The receiver of one field of the before / after struct, as receiveFieldColSchema resolves it with an empty original type
+ * (pkg/debezium/receiver_engine.go:108-146, common/field_receiver_default.go:14-31): Kafka type → Go value → YT type.   */
+enum {
+  TFGPU_DBZ_BOOLEAN = 1, /* boolean → bool                                                "boolean" */
+  TFGPU_DBZ_INT8,        /* int8    → int8(json.Number.Int64())                            "int8"    */
+  TFGPU_DBZ_INT16,       /* int16   → int16(…)                                             "int16"   */
+  TFGPU_DBZ_INT32,       /* int32   → int32(…)                                             "int32"   */
+  TFGPU_DBZ_INT64,       /* int64   → int64                                                "int64"   */
+  TFGPU_DBZ_FLOAT64,     /* float / double → json.Number.Float64()                         "double"  */
+  TFGPU_DBZ_STRING,      /* string (any logical name) → the string; a number → its text    "utf8"    */
+  TFGPU_DBZ_BYTES,       /* bytes → base64.StdEncoding.DecodeString                        "string"  */
+  TFGPU_DBZ_DECIMAL,     /* bytes, org.apache.kafka.connect.data.Decimal → Base64ToNumeric(value, parameters.scale)  "utf8" */
+  TFGPU_DBZ_POINT,       /* struct io.debezium.data.geometry.Point → "(x,y)"               "utf8"    */
+  TFGPU_DBZ_VSD,         /* struct io.debezium.data.VariableScaleDecimal → json.Number     "double"  */
+  TFGPU_DBZ_HOST         /* arrays, __dt_original_type_info: every message of the schema → TFGPU_ROW_HOST_FALLBACK */
+};
+typedef struct tfgpu_dbz_field { const char *name; int32_t op; int32_t optional; int32_t scale; int32_t reserved; } tfgpu_dbz_field;
+typedef struct tfgpu_dbz_options {
+  uint64_t schema_hash[2];       /* frames with another hash are left to another call                                  */
+  int32_t nfields;               /* Schema.FindAfterSchema().Fields, in order; the before struct must list the same
+                                    fields (the shim checks; otherwise it keeps the schema on the host)                 */
+  const tfgpu_dbz_field *fields;
+} tfgpu_dbz_options;
+/* Per produced row, the ChangeItem members that are not columns (receiver.go:187-209).                                  */
+typedef struct tfgpu_dbz_row {
+  int64_t msg;            /* index of the Kafka message (= src_row of the row)                                          */
+  uint64_t lsn;           /* payload.source.lsn                                                                         */
+  uint64_t commit_time;   /* payload.source.ts_ms * 1 000 000                                                           */
+  uint32_t id;            /* payload.source.txId                                                                        */
+  uint8_t names_form;     /* 1 for Delete: ColumnNames / ColumnValues stay nil (tfgpu_row_meta.names_form)              */
+  uint8_t reserved[3];
+} tfgpu_dbz_row;
+/* Receiver.receive for every frame of opts->schema_hash (pkg/debezium/receiver.go:150-232): the payload is decoded like
+ * Decoder(UseNumber).Decode(&Payload); op → kind (c, r: Insert; u: Update; d: Delete); values from `before` for Delete,
+ * else `after`; every schema field must be present and is converted by its receiver (null → nil).  *out: one row per good
+ * message in message order — columns = the schema fields (TableSchema: key = !optional, table_schema / table_name =
+ * source.schema / source.table), kinds, src_row = message index; Update / Delete rows carry OldKeys = the key fields'
+ * values (of `after` for Update — what Receiver.add stores — of `before` for Delete); a Delete row's cells are nil and
+ * rows[r].names_form = 1.  rows (HOST, rows_cap entries) receives ID / LSN / CommitTime.  errs: one entry per message of
+ * this schema that the reference turns into an `_unparsed` item (row = step = message index, code = TFGPU_ROW_DBZ_*) or
+ * that the stock code must redo (TFGPU_ROW_HOST_FALLBACK: `__debezium_unavailable_value`, decimals wider than 64 bytes,
+ * values on which the reference panics, rows of another table than the first good row's).                              */
+int tfgpu_debezium_parse(const tfgpu_dbz_options *opts, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
+                         const tfgpu_dbz_frame *frames, tfgpu_dbatch **out, tfgpu_dbz_row *rows, int64_t rows_cap,
+                         tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
 /* ---- ClickHouse Native column block -------------------------------------------------------------------- */
 /* The v2 ClickHouse sink turns every ChangeItem into a []any row (pkg/providers/clickhouse/async/marshaller.go:62-190) and

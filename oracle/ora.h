@@ -111,6 +111,8 @@ ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema);
 tfgpu_batch *ora_to_columns(const ora_batch *b);
 void ora_columns_free(tfgpu_batch *cb);
 tfgpu_schema *ora_batch_schema(const ora_batch *b); /* schema of first row, malloc'd */
+tfgpu_schema *ora_batch_item_schema(const ora_batch *b, int64_t row); /* TableSchema of one item, malloc'd */
+const char *ora_batch_item_table(const ora_batch *b, int64_t row, int ns); /* Table, or Schema with ns != 0 */
 void ora_tschema_free(tfgpu_schema *s);
 
 /* ---- Go stdlib behaviours restated (strconv/fmt/time) ---- */
@@ -209,6 +211,10 @@ char *ora_serialize_ex(int format, const ora_batch *b, const tfgpu_serialize_opt
  * fails (or a value form is outside the restatement).  msg_start / msg_row are malloc'd with *nmsg + 1 entries. */
 char *ora_queue_serialize(const tfgpu_queue_options *o, const ora_batch *b, const tfgpu_row_meta *m, uint64_t *len,
                           uint64_t **msg_start, int64_t **msg_row, int64_t *nmsg);
+
+/* §8 f1: DebeziumImpl.DoBatch without a schema registry (ora_debezium.c) */
+ora_batch *ora_debezium_parse(const void *bytes, uint64_t len, const tfgpu_messages *msgs, int32_t **code, int64_t **row_of, uint32_t **id, uint64_t **lsn,
+                              uint64_t **commit_time, uint8_t **names_form);
 
 /* §8 f2: marshalChangeItemInto + the driver's Native block layout (ora_chnative.c); NULL = refused */
 char *ora_ch_native_block(const ora_batch *rows, const char *const *names, const char *const *types, int ncols, uint64_t *len);

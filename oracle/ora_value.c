@@ -305,10 +305,12 @@ void ora_columns_free(tfgpu_batch *cb) {
   free(cb);
 }
 
-tfgpu_schema *ora_batch_schema(const ora_batch *b) {
+tfgpu_schema *ora_batch_schema(const ora_batch *b) { return ora_batch_item_schema(b, 0); }
+const char *ora_batch_item_table(const ora_batch *b, int64_t row, int ns) { return row < b->n ? (ns ? b->items[row].ns : b->items[row].table) : ""; }
+tfgpu_schema *ora_batch_item_schema(const ora_batch *b, int64_t row) {
   tfgpu_schema *s = (tfgpu_schema *)calloc(1, sizeof *s);
-  if (b->n == 0 || !b->items[0].schema) return s;
-  const ora_schema *o = b->items[0].schema;
+  if (row >= b->n || !b->items[row].schema) return s;
+  const ora_schema *o = b->items[row].schema;
   s->ncols = o->ncols;
   s->cols = (tfgpu_colschema *)calloc((size_t)(o->ncols ? o->ncols : 1), sizeof(tfgpu_colschema));
   for (int i = 0; i < o->ncols; i++) {

@@ -212,6 +212,47 @@ def serialize(fmt: int, batch: abi.Batch, schema: abi.Schema, opts=None):
     return out
 
 
+def debezium_parse(data: bytes, msgs: abi.CMessages = None):
+    """DebeziumImpl.DoBatch without a schema registry (ora_debezium.c).  Returns (items, codes): codes[m] = TFGPU_ROW_* of
+    message m; items = one dict per parsed message, in message order: kind, names, values, old (OldKeys), src (message),
+    ns / table, schema (abi.Schema of the item's TableSchema), id / lsn / commit_time, names_form."""
+    L = lib()
+    P = C.c_void_p
+    L.ora_debezium_parse.restype = P
+    L.ora_debezium_parse.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(abi.CMessages)] + [C.POINTER(P)] * 6
+    L.ora_batch_item_schema.restype = C.POINTER(abi.CSchema)
+    L.ora_batch_item_schema.argtypes = [P, C.c_int64]
+    L.ora_batch_item_table.restype = C.c_char_p
+    L.ora_batch_item_table.argtypes = [P, C.c_int64, C.c_int]
+    nmsg = msgs.nmsg if msgs is not None else 1
+    ptrs = [P() for _ in range(6)]
+    t0 = time.perf_counter()
+    out = L.ora_debezium_parse(data, len(data), C.byref(msgs) if msgs is not None else None, *[C.byref(p) for p in ptrs])
+    debezium_parse.seconds = time.perf_counter() - t0
+    code = np.ctypeslib.as_array(C.cast(ptrs[0], C.POINTER(C.c_int32)), (max(nmsg, 1),))[:nmsg].copy()
+    n = L.ora_batch_len(out)
+    ids = np.ctypeslib.as_array(C.cast(ptrs[2], C.POINTER(C.c_uint32)), (max(nmsg, 1),))[:n].copy()
+    lsn = np.ctypeslib.as_array(C.cast(ptrs[3], C.POINTER(C.c_uint64)), (max(nmsg, 1),))[:n].copy()
+    ct = np.ctypeslib.as_array(C.cast(ptrs[4], C.POINTER(C.c_uint64)), (max(nmsg, 1),))[:n].copy()
+    nf = np.ctypeslib.as_array(C.cast(ptrs[5], C.POINTER(C.c_uint8)), (max(nmsg, 1),))[:n].copy()
+    items = _items_of(L, out) if debezium_parse.want_items else [None] * n
+    for r, it in enumerate(items):
+        if it is None:
+            continue
+        sp = L.ora_batch_item_schema(out, r)
+        it["schema"] = abi.Schema.from_c(sp.contents)
+        L.ora_tschema_free(sp)
+        it["ns"], it["table"] = L.ora_batch_item_table(out, r, 1).decode(), L.ora_batch_item_table(out, r, 0).decode()
+        it["id"], it["lsn"], it["commit_time"], it["names_form"] = int(ids[r]), int(lsn[r]), int(ct[r]), int(nf[r])
+    for p in ptrs:
+        L.free(p)
+    L.ora_batch_free(out)
+    return items, [int(c) for c in code]
+
+
+debezium_parse.want_items = True
+
+
 def ch_native_block(batch: abi.Batch, schema: abi.Schema, columns):
     """One ClickHouse Native block of the batch (ora_chnative.c); `columns` = [(name, ClickHouse type), ...]; None = refused."""
     L = lib()

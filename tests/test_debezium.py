@@ -1,0 +1,167 @@
+"""Debezium parser with inline schemas (the source of configs[4]): the oracle pinned to the reference's
+canon (CPU), the HIP path against the oracle and the same canon (GPU)."""
+import base64
+import json
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from util import golden
+
+
+def canon_value(v):
+    """One value of an oracle item ([gotype, v]) in the form the reference's canon JSON shows it."""
+    g, x = v
+    if g == "nil":
+        return None
+    if g == "bytes":
+        return base64.b64encode(x).decode()
+    if g in ("string", "json"):
+        return x.decode("utf-8")
+    if g == "jsonnum":
+        return Decimal(x.decode())
+    return x
+
+
+def same(a, b):
+    if isinstance(a, Decimal) or isinstance(b, Decimal):
+        return Decimal(str(a)) == Decimal(str(b)) if not isinstance(a, Decimal) or not isinstance(b, Decimal) else a == b
+    if isinstance(a, float) or isinstance(b, float):
+        return a is not None and b is not None and float(a) == float(b)
+    return a == b and type(a) is type(b)
+
+
+def check_item(it, exp, ctx):
+    assert it["kind"] == exp["kind"], ctx
+    assert (it["ns"], it["table"]) == (exp["schema"], exp["table"]), ctx
+    assert (it["id"], it["lsn"], it["commit_time"]) == (exp["id"], exp["lsn"], exp["commit_time"]), ctx
+    assert [[c.name, c.dtype, c.key, c.table_schema, c.table_name, c.original_type] for c in it["schema"].cols] == exp["table_schema"], ctx
+    if exp["names"] is None:
+        assert it["names"] == [] and it["names_form"] == 1, ctx
+    else:
+        assert it["names"] == exp["names"] and it["names_form"] == 0, ctx
+        for name, got, want in zip(it["names"], it["values"], exp["values"]):
+            assert same(canon_value(got), want), (ctx, name, got, want)
+    ok = exp["oldkeys"] or {}
+    assert [o[0] for o in it["old"]] == (ok.get("keynames") or []), ctx
+    assert [o[1][1] for o in it["old"]] == (ok.get("keyvalues") or []), ctx
+
+
+def test_oracle_reference_vectors(oracle):
+    for case in golden("debezium.json")["cases"]:
+        data, msgs = abi.messages([case["message"].encode("utf-8")])
+        items, codes = oracle.debezium_parse(data, msgs)
+        if case["expect"] is None:
+            assert items == [] and codes[0] != abi.ROW_OK, case["name"]
+            continue
+        assert codes == [abi.ROW_OK] and len(items) == 1, (case["name"], codes)
+        check_item(items[0], case["expect"], case["name"])
+
+
+# ---- a synthetic Postgres CDC stream in Debezium's envelope (the shape of configs[4]) ---------------------------------
+FIELDS = [("id", "int64", False, None), ("ver", "int32", True, None), ("flag", "boolean", True, None), ("score", "double", True, None),
+          ("name", "string", True, None), ("blob", "bytes", True, None),
+          ("amount", "bytes", True, {"name": "org.apache.kafka.connect.data.Decimal", "parameters": {"scale": "2", "connect.decimal.precision": "10"}}),
+          ("at", "int64", True, {"name": "io.debezium.time.MicroTimestamp"}), ("tz", "string", True, {"name": "io.debezium.time.ZonedTimestamp"}),
+          ("pt", "struct", True, {"name": "io.debezium.data.geometry.Point", "fields": [{"type": "double", "optional": False, "field": "x"},
+                                                                                       {"type": "double", "optional": False, "field": "y"}]}),
+          ("num", "struct", True, {"name": "io.debezium.data.VariableScaleDecimal", "fields": [{"type": "int32", "optional": False, "field": "scale"},
+                                                                                             {"type": "bytes", "optional": False, "field": "value"}]})]
+
+
+def envelope_schema(table="events", fields=FIELDS):
+    def struct(field):
+        fs = []
+        for n, t, opt, extra in fields:
+            f = {"type": t, "optional": opt, "field": n}
+            f.update(extra or {})
+            fs.append(f)
+        return {"type": "struct", "fields": fs, "optional": True, "name": "srv.public.%s.Value" % table, "field": field}
+    src = {"type": "struct", "fields": [{"type": "string", "optional": False, "field": "version"}, {"type": "int64", "optional": False, "field": "ts_ms"}],
+           "optional": False, "name": "io.debezium.connector.postgresql.Source", "field": "source"}
+    return {"type": "struct", "fields": [struct("before"), struct("after"), src, {"type": "string", "optional": False, "field": "op"},
+                                         {"type": "int64", "optional": True, "field": "ts_ms"}], "optional": False, "name": "srv.public.%s.Envelope" % table}
+
+
+def twos(v: int) -> str:
+    n = max(1, (v.bit_length() + 8) // 8)
+    return base64.b64encode(v.to_bytes(n, "big", signed=True)).decode()
+
+
+def cdc_messages(n, seed=3, table="events", weird=True):
+    """n Debezium events over n/4 keys: inserts / updates / deletes, nulls, escapes, every receiver of FIELDS; with `weird`
+    also the messages the reference turns into `_unparsed` items or panics on."""
+    import random
+    rng = random.Random(seed)
+    schema = json.dumps(envelope_schema(table), separators=(",", ":"))
+    out = []
+    for k in range(n):
+        key = rng.randrange(max(n // 4, 1))
+        def row():
+            return {"id": key, "ver": None if rng.random() < .1 else k, "flag": rng.choice([True, False, None]),
+                    "score": rng.choice([None, 0, -1.5e-7, 3.14e100, k / 7, 1e22]),
+                    "name": rng.choice([None, "", "plain", "é中\\\"q\\n", "\\u00e9\\ud83d\\ude00 x", "__debezium_unavailable", 17]),
+                    "blob": rng.choice([None, "", "yv66vg==", "AA==", base64.b64encode(bytes(rng.randrange(256) for _ in range(k % 23))).decode()]),
+                    "amount": rng.choice([None, twos(12345), twos(-1), twos(0), twos(-12345678901234567890), twos(5), twos(10**40 + k)]),
+                    "at": 1_600_000_000_000_000 + k, "tz": "2004-10-19T08:23:54Z",
+                    "pt": rng.choice([None, {"x": 23.4, "y": -44.5, "wkb": "AQE=", "srid": None}, {"y": 1, "x": "s"}]),
+                    "num": rng.choice([None, {"scale": 0, "value": twos(123456)}, {"scale": 3, "value": twos(-7)}, {"value": twos(99), "scale": 1}])}
+        op = rng.choice(["c", "c", "u", "u", "d", "r"])
+        payload = {"before": row() if op in ("u", "d") else None, "after": None if op == "d" else row(),
+                   "source": {"version": "1.9", "connector": "postgresql", "name": "srv", "ts_ms": 1_700_000_000_000 + k, "snapshot": "false", "db": "db", "schema": "public",
+                              "table": table, "txId": 500 + k, "lsn": 10_000 + 8 * k, "xmin": None}, "op": op, "ts_ms": 1_700_000_000_123 + k, "transaction": None}
+        ps = json.dumps(payload, separators=(",", ":")).replace("\\\\\\\\u", "\\\\u").replace("\\\\u", "\\u").replace('\\\\\\"', '\\"').replace("\\\\n", "\\n")
+        if weird and k % 11 == 5:
+            ps = rng.choice([ps.replace('"op":"%s"' % op, '"op":"x"'), ps.replace('"op":"%s"' % op, '"op":5'), ps.replace('"lsn":', '"lsn":-'),
+                             ps.replace('"txId":', '"txId":99999999999'), ps.replace('"ver":', '"Ver":'), ps.replace('"at":', '"at":1.5e3,"_":'),
+                             ps.replace('"flag":true', '"flag":"true"').replace('"flag":false', '"flag":0'), ps.replace('"blob":"yv66vg=="', '"blob":"yv66vg="'),
+                             ps.replace('"name":"plain"', '"name":"__debezium_unavailable_value"'), ps.replace('"score":0,', '"score":1e999,'),
+                             ps.replace('"id":%d' % key, '"id":1.0'), ps.replace('"tz":"2004-10-19T08:23:54Z"', '"tz":null')])
+        if k % 3 == 0:
+            msg = '{"schema":%s,"payload":%s}' % (schema, ps)
+        elif k % 3 == 1:
+            msg = '{"payload": %s ,\n "schema" : %s }' % (ps, schema)
+        else:
+            msg = '{"x":[1,{"schema":1}],"schema":0,"schema":%s,"payload":%s}' % (schema, ps)
+        if weird and k % 17 == 9:
+            msg = rng.choice(["", "{}", "null", "[]", msg[:-1], msg + "x", '{"payload":%s}' % ps, '{"schema":%s}' % schema, '{"schema":%s,"payload":null}' % schema,
+                              '{"schema":null,"payload":%s}' % ps, '{"schema":7,"payload":%s}' % ps, "\x00\x00\x00\x00\x01" + msg, '{"Schema":%s,"payload":%s}' % (schema, ps),
+                              '{"schema":%s,"payload":[1]}' % schema])
+        out.append(msg.encode("utf-8"))
+    return out
+
+
+def test_oracle_synthetic_stream_is_consistent(oracle):
+    msgs = cdc_messages(400)
+    data, m = abi.messages(msgs)
+    items, codes = oracle.debezium_parse(data, m)
+    assert len(items) == sum(c == abi.ROW_OK for c in codes)
+    seen = set(codes)
+    for c in (abi.ROW_OK, abi.ROW_DBZ_UNPACK, abi.ROW_DBZ_PAYLOAD, abi.ROW_DBZ_OP, abi.ROW_DBZ_SCHEMA, abi.ROW_DBZ_FIELD, abi.ROW_HOST_FALLBACK):
+        assert c in seen, c
+    kinds = {it["kind"] for it in items}
+    assert kinds == {"insert", "update", "delete"}
+    for it in items:
+        if it["kind"] == "delete":
+            assert it["names"] == [] and [o[0] for o in it["old"]] == ["id"] and it["names_form"] == 1
+        else:
+            assert it["names"] == [f[0] for f in FIELDS]
+            assert ([o[0] for o in it["old"]] == ["id"]) == (it["kind"] == "update")
+        assert [c.dtype for c in it["schema"].cols] == ["int64", "int32", "boolean", "double", "utf8", "string", "utf8", "int64", "utf8", "utf8", "double"]
+    # known answers of the receivers
+    one = json.dumps({"schema": envelope_schema(), "payload": {"before": None, "after": {
+        "id": 1, "ver": 4294967297, "flag": True, "score": 1e-7, "name": 12.50, "blob": "yv66vg==", "amount": twos(-5), "at": 5, "tz": "z",
+        "pt": {"x": 23.4, "y": None}, "num": {"scale": 2, "value": twos(10)}}, "source": {"schema": "s", "table": "t", "lsn": 7, "txId": 8, "ts_ms": 9}, "op": "c"}})
+    data, m = abi.messages([one.encode()])
+    items, codes = oracle.debezium_parse(data, m)
+    assert codes == [abi.ROW_OK]
+    vals = dict(zip(items[0]["names"], items[0]["values"]))
+    assert vals["ver"] == ["int32", 1]                       # int32(4294967297): Go's truncating conversion
+    assert vals["name"] == ["string", b"12.5"]               # a json.Number is taken by its text
+    assert vals["blob"] == ["bytes", bytes.fromhex("cafebabe")]
+    assert vals["amount"] == ["string", b"-0.05"]            # scale > len("5"): zero-padded to scale + 1 digits
+    assert vals["pt"] == ["string", b"(23.4,<nil>)"]
+    assert vals["num"] == ["jsonnum", b".10"]                # scale == len("10"): helpers.go:990 pads only when scale > len
+    assert (items[0]["id"], items[0]["lsn"], items[0]["commit_time"]) == (8, 7, 9_000_000)

@@ -899,6 +899,35 @@ def confluent_sr():
     write("confluent_sr.json", {"schemas": schemas, "messages": [base64.b64encode(x).decode() for x in lines], "items": exp})
 
 
+def debezium():
+    """Debezium parser, inline schemas: TestParser's canon (engine/gotest/canondata/result.json over engine/parser_test.jsonl,
+    one 13.6 KB Postgres event with every pg type), receiver_test.go's TestDelete message with the ChangeItem JSON it requires
+    (the test rewrites KeyTypes / CommitTime before comparing; the original values are kept here), TestUnparsed's `{}`."""
+    import re
+    eng = REF + "/pkg/parsers/registry/debezium/engine/"
+    with open(eng + "parser_test.jsonl") as f:
+        lines = [x for x in f.read().split("\n") if x]
+    items = canon(eng + "gotest/canondata/result.json", "gotest.gotest.TestParser")
+    assert len(lines) == len(items)
+    cases = []
+    for line, it in zip(lines, items):
+        cases.append({"name": "TestParser", "message": line, "expect": {
+            "kind": it["kind"], "schema": it["schema"], "table": it["table"], "id": it["id"], "lsn": it["nextlsn"], "commit_time": it["commitTime"],
+            "names": it["columnnames"], "values": it["columnvalues"], "oldkeys": it.get("oldkeys") or {},
+            "table_schema": [[c["name"], c["type"], c["key"], c["table_schema"], c["table_name"], c["original_type"]] for c in it["table_schema"]]}})
+    with open(REF + "/pkg/debezium/receiver_test.go") as f:
+        src = f.read()
+    msg = re.search(r"func TestDelete.*?debeziumMsg := `(.*?)`", src, re.S).group(1)
+    want = json.loads(re.search(r"func TestDelete.*?require\.Equal\(t, `(.*?)`, changeItem\.ToJSONString", src, re.S).group(1))
+    cases.append({"name": "TestDelete", "message": msg, "expect": {
+        "kind": want["kind"], "schema": want["schema"], "table": want["table"], "id": want["id"], "lsn": want["nextlsn"],
+        "commit_time": 1672943646565 * 1000000,   # source.ts_ms * 1e6; the test overwrites it with a wall-clock constant before comparing
+        "names": want["columnnames"], "values": None, "oldkeys": {"keynames": want["oldkeys"]["keynames"], "keyvalues": want["oldkeys"]["keyvalues"]},
+        "table_schema": [[c["name"], c["type"], c["key"], c["table_schema"], c["table_name"], c["original_type"]] for c in want["table_schema"]]}})
+    cases.append({"name": "TestUnparsed", "message": "{}", "expect": None})
+    write("debezium.json", {"cases": cases})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -912,4 +941,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium()
