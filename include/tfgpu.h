@@ -607,6 +607,10 @@ typedef struct tfgpu_dbz_options {
   int32_t nfields;               /* Schema.FindAfterSchema().Fields, in order; the before struct must list the same
                                     fields (the shim checks; otherwise it keeps the schema on the host)                 */
   const tfgpu_dbz_field *fields;
+  int32_t schema_code;           /* TFGPU_ROW_OK; or what receiveSchema decided for the whole schema (TFGPU_ROW_DBZ_SCHEMA:
+                                    it does not unmarshal / a Kafka type without receiver; TFGPU_ROW_HOST_FALLBACK) — the
+                                    payload and op checks still run first, as in Receiver.receive, and no row is produced */
+  int32_t reserved;
 } tfgpu_dbz_options;
 /* Per produced row, the ChangeItem members that are not columns (receiver.go:187-209).                                  */
 typedef struct tfgpu_dbz_row {

@@ -165,3 +165,111 @@ def test_oracle_synthetic_stream_is_consistent(oracle):
     assert vals["pt"] == ["string", b"(23.4,<nil>)"]
     assert vals["num"] == ["jsonnum", b".10"]                # scale == len("10"): helpers.go:990 pads only when scale > len
     assert (items[0]["id"], items[0]["lsn"], items[0]["commit_time"]) == (8, 7, 9_000_000)
+
+
+# ---- the HIP path -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+def device_items(tf, parsed):
+    """Rows of a debezium.Parsed as oracle-style items (message index → item)."""
+    b = parsed.batch.download()
+    out = {}
+    names = [c.name for c in b.cols]
+    for r in range(b.nrows):
+        kind = ["insert", "update", "delete"][int(b.kind[r])]
+        row = parsed.rows[r]
+        it = {"kind": kind, "ns": b.table_ns, "table": b.table_name, "schema": parsed.schema, "id": int(row["id"]), "lsn": int(row["lsn"]),
+              "commit_time": int(row["commit_time"]), "names_form": int(row["names_form"]), "src": int(b.src_row[r])}
+        assert int(row["msg"]) == int(b.src_row[r])
+        if kind == "delete":
+            assert not any(c.is_valid(r) for c in b.cols), "a Delete keeps ColumnValues nil"
+            it["names"], it["values"] = [], []
+        else:
+            it["names"], it["values"] = names, [c.pyvalue(r) for c in b.cols]
+        pres = b.old_present is None or bool(b.old_present[r])
+        it["old"] = [[k.name, k.pyvalue(r)] for k in (b.old_keys or [])] if pres and b.old_keys else []
+        assert pres == (kind != "insert")
+        out[int(b.src_row[r])] = it
+    return out
+
+
+def norm_old(old):
+    return [[n, (v[1] if not isinstance(v[1], (bytes, bytearray)) else bytes(v[1]))] for n, v in old]
+
+
+def assert_same_items(got, exp, ctx=""):
+    for k in ("kind", "ns", "table", "names", "id", "lsn", "commit_time", "names_form"):
+        assert got[k] == exp[k], (ctx, k, got[k], exp[k])
+    assert [[c.name, c.dtype, c.key, c.table_schema, c.table_name] for c in got["schema"].cols] == [[c.name, c.dtype, c.key, c.table_schema, c.table_name] for c in exp["schema"].cols], ctx
+    for n, a, b in zip(got["names"], got["values"], exp["values"]):
+        if a[0] in ("string", "bytes", "jsonnum"):
+            a = [a[0], bytes(a[1])]
+        assert a == b or (a[0] == b[0] == "float64" and a[1] != a[1] and b[1] != b[1]), (ctx, n, a, b)
+    assert [o[0] for o in got["old"]] == [o[0] for o in exp["old"]], ctx
+    assert [o[1][1] for o in got["old"]] == [o[1][1] for o in exp["old"]], ctx
+
+
+@pytest.mark.gpu
+def test_gpu_reference_vectors(tf):
+    from transferia_amd import debezium
+    for case in golden("debezium.json")["cases"]:
+        data, msgs = abi.messages([case["message"].encode("utf-8")])
+        parsed, errors = debezium.Parser(tf).parse(data, msgs)
+        if case["expect"] is None:
+            assert parsed == [] and list(errors) == [0] and errors[0] != abi.ROW_HOST_FALLBACK, case["name"]
+            continue
+        assert not errors and len(parsed) == 1, (case["name"], errors)
+        items = device_items(tf, parsed[0])
+        check_item(items[0], case["expect"], case["name"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,weird", [(1, False), (64, False), (700, True), (3000, True)])
+def test_gpu_stream_matches_oracle(tf, oracle, n, weird):
+    from transferia_amd import debezium
+    msgs = cdc_messages(n, seed=n, weird=weird)
+    if n == 3000:  # a second table in the same batch: two schemas, two device batches
+        other = cdc_messages(200, seed=7, table="orders", weird=False)
+        msgs = msgs[:1500] + other + msgs[1500:]
+    data, m = abi.messages(msgs)
+    exp_items, codes = oracle.debezium_parse(data, m)
+    parser = debezium.Parser(tf)
+    parsed, errors = parser.parse(data, m)
+    assert {k: v for k, v in enumerate(codes) if v != abi.ROW_OK} == errors
+    got = {}
+    for p in parsed:
+        got.update(device_items(tf, p))
+    exp = {it["src"]: it for it in exp_items}
+    assert sorted(got) == sorted(exp)
+    for k in exp:
+        assert_same_items(got[k], exp[k], k)
+    if n == 3000:
+        assert len(parsed) == 2 and {p.batch.table_id() for p in parsed} == {("public", "events"), ("public", "orders")}
+        assert len(parser.cache) >= 2
+    fb = sum(1 for c in errors.values() if c == abi.ROW_HOST_FALLBACK)
+    assert fb <= (0 if not weird else n // 8), fb   # the stock path is for the odd message, not the stream
+
+
+@pytest.mark.gpu
+def test_gpu_stream_feeds_collapse_and_native_serializer(tf, oracle):
+    """configs[4] from Debezium-envelope bytes: parse → Collapse → native queue serializer, equal to the oracle's chain."""
+    from transferia_amd import debezium
+    msgs = cdc_messages(2000, seed=21, weird=False)
+    data, m = abi.messages(msgs)
+    parsed, errors = debezium.Parser(tf).parse(data, m)
+    assert len(parsed) == 1 and all(c == abi.ROW_HOST_FALLBACK for c in errors.values())
+    p = parsed[0]
+    col = tf.collapse(p.batch)
+    assert 0 < col.nrows < p.batch.nrows
+    got = col.download()
+    # the oracle's Collapse over the device-parsed rows (same rows: parse parity is the test above)
+    host = p.batch.download()
+    host.schema = p.schema
+    ref = oracle.collapse(host, p.schema).batch
+    key = lambda b: sorted((int(b.kind[i]), int(b.src_row[i])) for i in range(b.nrows))
+    assert key(got) == key(ref)

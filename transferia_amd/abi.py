@@ -73,6 +73,29 @@ class CRowError(C.Structure):
     _fields_ = [("row", C.c_int64), ("code", C.c_int32), ("step", C.c_int32), ("column", C.c_int32)]
 
 
+class CDbzFrame(C.Structure):
+    _fields_ = [("schema_start", C.c_uint64), ("payload_start", C.c_uint64), ("schema_len", C.c_uint32), ("payload_len", C.c_uint32),
+                ("schema_hash", C.c_uint64 * 2), ("code", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CDbzField(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("op", C.c_int32), ("optional", C.c_int32), ("scale", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CDbzOptions(C.Structure):
+    _fields_ = [("schema_hash", C.c_uint64 * 2), ("nfields", C.c_int32), ("fields", C.POINTER(CDbzField)), ("schema_code", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CDbzRow(C.Structure):
+    _fields_ = [("msg", C.c_int64), ("lsn", C.c_uint64), ("commit_time", C.c_uint64), ("id", C.c_uint32), ("names_form", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+DBZ_BOOLEAN, DBZ_INT8, DBZ_INT16, DBZ_INT32, DBZ_INT64, DBZ_FLOAT64, DBZ_STRING, DBZ_BYTES, DBZ_DECIMAL, DBZ_POINT, DBZ_VSD, DBZ_HOST = range(1, 13)
+DBZ_ROW_DTYPE = np.dtype([("msg", "<i8"), ("lsn", "<u8"), ("commit_time", "<u8"), ("id", "<u4"), ("names_form", "u1"), ("reserved", "u1", 3)])
+DBZ_FRAME_DTYPE = np.dtype([("schema_start", "<u8"), ("payload_start", "<u8"), ("schema_len", "<u4"), ("payload_len", "<u4"), ("schema_hash", "<u8", 2),
+                            ("code", "<i4"), ("reserved", "<i4")])
+
+
 class CChNativeColumn(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ch_type", C.c_char_p)]
 

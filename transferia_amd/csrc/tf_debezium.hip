@@ -1,0 +1,825 @@
+// tf_debezium.hip — Debezium ingest with inline schemas (the source format of BASELINE.json configs[4]):
+//
+//   DebeziumImpl.DoBatch / Do / DoBuf / DoOne     pkg/parsers/registry/debezium/engine/parser.go:33-130
+//   IncludeSchema.Unpack                          pkg/debezium/unpacker/include_schema.go:13-25
+//   Receiver.receive / add                        pkg/debezium/receiver.go:150-232, 98-121
+//   receiveField / extractVal / convertVal        pkg/debezium/receiver_engine.go:148-371
+//   the default receivers                         pkg/debezium/common/field_receiver_default.go:40-355
+//   Payload / Source                              pkg/debezium/common/debezium_schema.go:31-56
+//   Base64ToNumeric                               pkg/debezium/typeutil/helpers.go:966-996
+//
+// A Debezium event is {"schema": <Kafka Connect schema, ~12 KB>, "payload": {"before", "after", "source", "op", …}}: one
+// message, one ChangeItem.  The schema is data, so the work splits: the shim compiles each distinct schema once (the
+// reference caches it by hash too) into a list of field receivers, and the device does everything that is per message —
+//   dbz_unpack          one lane per message: the whole message validated as one JSON value (encoding/json's grammar),
+//                       the raw "schema" / "payload" members located, the schema bytes hashed for grouping;
+//   dbz_parse           one lane per message of the schema at hand: the payload decoded like Decoder(UseNumber).Decode(
+//                       &Payload) — member types checked field by field, op → kind, source.{lsn, ts_ms, txId, schema,
+//                       table} read — then the before / after members matched against the (sorted) field names and every
+//                       value checked against its receiver in schema order: the first failure names the message's fate;
+//   dbz_table_rule      rows of another table than the first good row's go to the host (a batch has one TableID);
+//   dbz_cell_values     one lane per (field, row): bool / intN / float64 values, text lengths (strings unquoted, base64
+//                       decoded, decimals rendered, points formatted);
+//   dbz_cell_text       one lane per (text field, row): the bytes.
+// OldKeys cost nothing extra: Receiver.add stores the SAME converted value under ColumnValues and OldKeys, so the OldKeys
+// columns share the value buffers of the key columns and differ only in their validity (Update / Delete rows).
+// Latency-bound lane-per-message form (every lane walks ~13 KB of JSON); algorithmic bytes: message bytes in + column
+// bytes out.
+#include <algorithm>
+#include <cstring>
+
+#include "tf_jsonscan.hpp"
+
+namespace tf {
+namespace dbz {
+
+using namespace tf::sr;
+
+enum : uint8_t { ST_SKIP = 255 };  // a message of another schema; else TFGPU_ROW_OK or a tfgpu_rowerr
+constexpr int DEC_MAX = 64;        // decimals wider than this many bytes go to the host
+
+struct FRecv { uint32_t name_off, name_len; int32_t op, optional, scale; };
+struct Params {
+  const uint8_t *data;
+  const uint32_t *ms; int64_t nmsg;
+  tfgpu_dbz_frame *frames;                     // [nmsg]
+  uint64_t h0, h1;
+  int32_t schema_code;                         // TFGPU_ROW_OK, or the fate the host decided for every message of this schema
+  const FRecv *fields; int32_t nfields; const uint8_t *names;
+  const uint16_t *sorted;                      // field indices in name order (binary search)
+  uint32_t *vstart, *vlen; uint8_t *vtype;     // [nfields][nmsg]
+  uint8_t *status, *kind;                      // [nmsg]
+  uint64_t *lsn, *ts, *tabhash; uint32_t *txid;  // [nmsg]
+  uint32_t *tab_s, *tab_n;                     // [2][nmsg] spans of source.schema / source.table string literals
+  uint32_t *keep;                              // [nmsg + 1]
+  uint32_t *row_msg; int64_t nrows;
+  uint32_t *nerr;
+  unsigned long long *first_ok;                // lowest good message (atomicMin)
+  const double *p10; const uint64_t *p128;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h, uint64_t w) { h ^= w; h *= 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
+
+// A decoded key against an ASCII literal: 1 equal, 2 equal only under ASCII case folding (encoding/json's field match), 0 no
+__device__ int key_is(MemBytes &rd, uint32_t ks, uint32_t ke, const char *lit, uint32_t n) {
+  RuneIter it{&rd, nullptr, ks + 1, ke - 1};
+  bool exact = true;
+  for (uint32_t i = 0; i < n; i++) {
+    const int r = it.next();
+    if (r < 0) return 0;
+    if (r == (int)(uint8_t)lit[i]) continue;
+    if (r < 0x80 && ((uint32_t)r | 0x20u) == ((uint32_t)(uint8_t)lit[i] | 0x20u) && (((uint32_t)r | 0x20u) >= 'a' && ((uint32_t)r | 0x20u) <= 'z')) { exact = false; continue; }
+    return 0;
+  }
+  if (it.next() >= 0) return 0;
+  return exact ? 1 : 2;
+}
+
+// ---- IncludeSchema.Unpack ---------------------------------------------------------------------------------------------
+__device__ void unpack_message(const Params &p, int64_t m) {
+  tfgpu_dbz_frame fr{};
+  MemBytes rd(p.data);
+  uint32_t pos = p.ms[m]; const uint32_t end = p.ms[m + 1];
+  auto done = [&](int code) { fr.code = code; p.frames[m] = fr; };
+  if (pos >= end) return done(TFGPU_ROW_DBZ_UNPACK);                       // "debezium parser received empty message"
+  if (rd.at(pos) == 0) return done(end - pos < 5 ? TFGPU_ROW_HOST_FALLBACK /* buf[5:] panics */ : TFGPU_ROW_DBZ_UNPACK);
+  auto skip_ws = [&]() { while (pos < end && is_ws(rd.at(pos))) pos++; };
+  skip_ws();
+  if (pos >= end) return done(TFGPU_ROW_DBZ_UNPACK);
+  bool host = false;
+  if (rd.at(pos) != '{') {  // null leaves both RawMessages nil; any other valid value is an UnmarshalTypeError
+    uint32_t vt = 0;
+    const int rc = skip_value(rd, pos, end, vt);
+    skip_ws();
+    if (rc == 2) return done(TFGPU_ROW_HOST_FALLBACK);
+    if (rc || pos != end) return done(TFGPU_ROW_DBZ_UNPACK);
+    return done((vt & VT_MASK) == VT_NULL ? TFGPU_ROW_OK : TFGPU_ROW_DBZ_UNPACK);
+  }
+  pos++;
+  skip_ws();
+  if (pos >= end) return done(TFGPU_ROW_DBZ_UNPACK);
+  if (rd.at(pos) == '}') pos++;
+  else for (;;) {
+    skip_ws();
+    if (pos >= end || rd.at(pos) != '"') return done(TFGPU_ROW_DBZ_UNPACK);
+    const uint32_t ks = pos;
+    if (!scan_string(rd, pos, end)) return done(TFGPU_ROW_DBZ_UNPACK);
+    const uint32_t ke = pos;
+    skip_ws();
+    if (pos >= end || rd.at(pos) != ':') return done(TFGPU_ROW_DBZ_UNPACK);
+    pos++;
+    skip_ws();
+    const uint32_t vs = pos;
+    uint32_t vt = 0;
+    const int rc = skip_value(rd, pos, end, vt);
+    if (rc == 1) return done(TFGPU_ROW_DBZ_UNPACK);
+    if (rc == 2) return done(TFGPU_ROW_HOST_FALLBACK);
+    const int a = key_is(rd, ks, ke, "schema", 6), b = a ? 0 : key_is(rd, ks, ke, "payload", 7);
+    if (a == 2 || b == 2) host = true;
+    if (a) { fr.schema_start = vs; fr.schema_len = pos - vs; }
+    if (b) { fr.payload_start = vs; fr.payload_len = pos - vs; }
+    skip_ws();
+    if (pos >= end) return done(TFGPU_ROW_DBZ_UNPACK);
+    const uint32_t d = rd.at(pos);
+    if (d == ',') { pos++; continue; }
+    if (d == '}') { pos++; break; }
+    return done(TFGPU_ROW_DBZ_UNPACK);
+  }
+  skip_ws();
+  if (pos != end) return done(TFGPU_ROW_DBZ_UNPACK);  // "invalid character after top-level value"
+  if (host) return done(TFGPU_ROW_HOST_FALLBACK);
+  // equal schema bytes ⇔ equal hash: two 64-bit multiplicative lanes over 8-byte words, the length folded in
+  uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
+  const uint32_t s = (uint32_t)fr.schema_start, n = fr.schema_len;
+  uint32_t k = 0;
+  for (; k + 8 <= n; k += 8) { const uint64_t w = rd.word(s + k); h0 = mix64(h0, w); h1 = mix64(h1 + 0x9E3779B97F4A7C15ull, w ^ (w >> 31)); }
+  if (k < n) { const uint64_t w = rd.word(s + k) & ((1ull << (8 * (n - k))) - 1); h0 = mix64(h0, w); h1 = mix64(h1 + 1, w); }
+  fr.schema_hash[0] = mix64(h0, n); fr.schema_hash[1] = mix64(h1, ~(uint64_t)n);
+  done(TFGPU_ROW_OK);
+}
+__global__ void __launch_bounds__(128) dbz_unpack(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < p.nmsg) unpack_message(p, m);
+}
+
+// ---- values -------------------------------------------------------------------------------------------------------------
+// strconv.ParseUint(literal, 10, bits) as encoding/json applies it to an unsigned struct field
+__device__ bool lit_uint(MemBytes &rd, uint32_t s, uint32_t n, int bits, uint64_t *out) {
+  uint64_t v = 0;
+  if (!n) return false;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = rd.at(s + i);
+    if (c < '0' || c > '9') return false;
+    const uint64_t d = c - '0';
+    if (v > (~0ull - d) / 10) return false;
+    v = v * 10 + d;
+  }
+  if (bits < 64 && (v >> bits)) return false;
+  *out = v;
+  return true;
+}
+// The text a string / number value contributes (extractVal: a string, or a json.Number's text) as a rune stream
+struct TextIter {
+  RuneIter it; bool raw; MemBytes *rd; uint32_t p, e;
+  __device__ TextIter(MemBytes &r, uint32_t vt, uint32_t vs, uint32_t vl) : it{&r, nullptr, vs + 1, vs + vl - 1}, raw((vt & VT_MASK) == VT_NUM), rd(&r), p(vs), e(vs + vl) {}
+  __device__ int next() { if (raw) return p < e ? (int)rd->at(p++) : -1; return it.next(); }
+};
+__device__ __forceinline__ int b64v(int c) {
+  if (c >= 'A' && c <= 'Z') return c - 'A';
+  if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+  if (c >= '0' && c <= '9') return c - '0' + 52;
+  return c == '+' ? 62 : c == '/' ? 63 : -1;
+}
+// base64.StdEncoding.DecodeString over the decoded text: '\r' / '\n' skipped, padding required.  Bytes go to sink(b).
+// Returns the decoded length, or -1 on a CorruptInputError.
+template <class S> __device__ int b64_decode(TextIter t, S sink) {
+  int q0 = 0, q1 = 0, q2 = 0, nq = 0, pad = 0, n = 0;
+  for (int c; (c = t.next()) >= 0;) {
+    if (c == '\r' || c == '\n') continue;
+    if (c == '=') { if (++pad > 2) return -1; continue; }
+    if (pad) return -1;
+    const int v = c < 0x80 ? b64v(c) : -1;
+    if (v < 0) return -1;
+    if (nq == 0) q0 = v; else if (nq == 1) q1 = v; else if (nq == 2) q2 = v;
+    else { sink((uint32_t)(q0 << 2 | q1 >> 4) & 0xFF); sink((uint32_t)(q1 << 4 | q2 >> 2) & 0xFF); sink((uint32_t)(q2 << 6 | v) & 0xFF); n += 3; nq = -1; }
+    nq++;
+  }
+  if (nq == 1 || (nq == 0 && pad) || (nq == 2 && pad != 2) || (nq == 3 && pad != 1)) return -1;
+  if (nq >= 2) { sink((uint32_t)(q0 << 2 | q1 >> 4) & 0xFF); n++; }
+  if (nq == 3) { sink((uint32_t)(q1 << 4 | q2 >> 2) & 0xFF); n++; }
+  return n;
+}
+// typeutil.Base64ToNumeric into sink (text).  0 ok, 1 error (base64), 2 host (the reference panics, or wider than DEC_MAX)
+template <class S> __device__ int base64_to_numeric(TextIter t, int scale, S &o) {
+  uint8_t buf[DEC_MAX];
+  int bn = 0; bool over = false;
+  const int n = b64_decode(t, [&](uint32_t b) { if (bn < DEC_MAX) buf[bn++] = (uint8_t)b; else over = true; });
+  if (n < 0) return 1;
+  if (n == 0 || over) return 2;                                   // isHighestBitSet(in[0]) on an empty slice panics
+  const bool neg = buf[0] & 0x80;
+  if (neg) {                                                       // makeNegativeNum
+    for (int i = 0; i < bn; i++) buf[i] = (uint8_t)~buf[i];
+    for (int i = bn - 1; i >= 0; i--) if (++buf[i]) break;
+  }
+  char dig[DEC_MAX * 3 - 36];                                      // 64 bytes < 10^155
+  int nd = 0, first = 0;
+  while (first < bn && buf[first] == 0) first++;
+  while (first < bn) {
+    uint32_t rem = 0;
+    for (int i = first; i < bn; i++) { const uint32_t cur = rem * 256 + buf[i]; buf[i] = (uint8_t)(cur / 10); rem = cur % 10; }
+    dig[nd++] = (char)('0' + rem);
+    while (first < bn && buf[first] == 0) first++;
+  }
+  if (nd == 0) { o.put('0'); return 0; }                           // "0": no sign, no scale
+  if (scale < 0) return 2;                                         // the slicing panics
+  if (neg) o.put('-');
+  if (scale == 0) { for (int i = nd - 1; i >= 0; i--) o.put((uint32_t)dig[i]); return 0; }
+  int len = nd, zeros = 0;
+  if (scale > len) { zeros = scale - len + 1; len += zeros; }
+  // resultStr[0:len-scale] + "." + resultStr[len-scale:]
+  for (int i = 0; i < len; i++) {
+    if (i == len - scale) o.put('.');
+    o.put(i < zeros ? (uint32_t)'0' : (uint32_t)dig[nd - 1 - (i - zeros)]);
+  }
+  return 0;
+}
+// A member of a small struct value (Point, VariableScaleDecimal): the LAST member whose decoded key equals `lit`.
+__device__ bool struct_member(MemBytes &rd, uint32_t vs, uint32_t vl, const char *lit, uint32_t n, uint32_t *ms, uint32_t *ml, uint32_t *mt) {
+  uint32_t pos = vs + 1; const uint32_t end = vs + vl;
+  bool found = false;
+  auto skip_ws = [&]() { while (pos < end && is_ws(rd.at(pos))) pos++; };
+  skip_ws();
+  if (pos < end && rd.at(pos) == '}') return false;
+  for (;;) {
+    skip_ws();
+    const uint32_t ks = pos;
+    scan_string(rd, pos, end);
+    const uint32_t ke = pos;
+    skip_ws(); pos++; skip_ws();
+    const uint32_t s = pos; uint32_t vt = 0;
+    skip_value(rd, pos, end, vt);
+    if (key_is(rd, ks, ke, lit, n) == 1) { *ms = s; *ml = pos - s; *mt = vt; found = true; }
+    skip_ws();
+    if (pos >= end || rd.at(pos) != ',') break;
+    pos++;
+  }
+  return found;
+}
+// fmt %v of one Point coordinate: a json.Number's text, a string, <nil>, true / false.  false: a container (host)
+template <class S> __device__ bool point_part(S &o, MemBytes &rd, uint32_t s, uint32_t l, uint32_t vt) {
+  switch (vt & VT_MASK) {
+    case VT_NUM: for (uint32_t i = 0; i < l; i++) o.put(rd.at(s + i)); return true;
+    case VT_STR: emit_unquoted(o, rd, s, l); return true;
+    case VT_NULL: { const char *t = "<nil>"; for (int i = 0; i < 5; i++) o.put((uint32_t)t[i]); return true; }
+    case VT_TRUE: { const char *t = "true"; for (int i = 0; i < 4; i++) o.put((uint32_t)t[i]); return true; }
+    case VT_FALSE: { const char *t = "false"; for (int i = 0; i < 5; i++) o.put((uint32_t)t[i]); return true; }
+  }
+  return false;
+}
+// The text of a DECIMAL / POINT / VSD value into o.  0 ok, 1 error, 2 host.
+template <class S> __device__ int render_text(S &o, MemBytes &rd, const FRecv &f, uint32_t vtr, uint32_t vs, uint32_t vl) {
+  const uint32_t vt = vtr & VT_MASK;
+  if (f.op == TFGPU_DBZ_DECIMAL) {
+    if (vt != VT_STR && vt != VT_NUM) return 1;
+    if (f.scale == INT32_MIN) return 1;                            // strconv.Atoi(parameters.scale) fails
+    return base64_to_numeric(TextIter(rd, vt, vs, vl), f.scale, o);
+  }
+  if (vt != VT_OBJ) return 2;                                      // in.(map[string]interface{}) panics
+  if (f.op == TFGPU_DBZ_POINT) {
+    uint32_t xs, xl, xt, ys, yl, yt;
+    if (!struct_member(rd, vs, vl, "x", 1, &xs, &xl, &xt) || !struct_member(rd, vs, vl, "y", 1, &ys, &yl, &yt)) return 1;
+    o.put('(');
+    if (!point_part(o, rd, xs, xl, xt)) return 2;
+    o.put(',');
+    if (!point_part(o, rd, ys, yl, yt)) return 2;
+    o.put(')');
+    return 0;
+  }
+  uint32_t as, al, at, ss, sl, stt;
+  if (!struct_member(rd, vs, vl, "value", 5, &as, &al, &at)) return 1;
+  if ((at & VT_MASK) != VT_STR) return 2;                          // .(string) panics
+  int scale = 0;
+  if (struct_member(rd, vs, vl, "scale", 5, &ss, &sl, &stt)) {
+    if ((stt & VT_MASK) != VT_NUM) return 2;                       // .(json.Number) panics
+    int64_t x;
+    if (!number_int64(rd, ss, sl, &x)) return 1;
+    if (x > 2147483647ll || x < -2147483648ll) return 2;
+    scale = (int)x;
+  }
+  return base64_to_numeric(TextIter(rd, at, as, al), scale, o);
+}
+struct NullSink { __device__ __forceinline__ void put(uint32_t) {} };
+__device__ bool is_unavailable(MemBytes &rd, uint32_t vs, uint32_t vl) {
+  const char *w = "__debezium_unavailable_value";
+  RuneIter it{&rd, nullptr, vs + 1, vs + vl - 1};
+  for (int i = 0; i < 28; i++) if (it.next() != (int)w[i]) return false;
+  return it.next() < 0;
+}
+// receiveField for one present value: TFGPU_ROW_OK, TFGPU_ROW_DBZ_FIELD or TFGPU_ROW_HOST_FALLBACK
+__device__ int check_value(const Params &p, MemBytes &rd, const FRecv &f, uint32_t vtr, uint32_t vs, uint32_t vl) {
+  const uint32_t vt = vtr & VT_MASK;
+  if (vt == VT_NULL) return TFGPU_ROW_OK;
+  if (vt == VT_STR && vl >= 30 && is_unavailable(rd, vs, vl)) return TFGPU_ROW_HOST_FALLBACK;  // absent: ragged ColumnNames
+  switch (f.op) {
+    case TFGPU_DBZ_INT8: case TFGPU_DBZ_INT16: case TFGPU_DBZ_INT32: case TFGPU_DBZ_INT64: {
+      int64_t x;
+      return vt == VT_NUM && number_int64(rd, vs, vl, &x) ? TFGPU_ROW_OK : TFGPU_ROW_DBZ_FIELD;
+    }
+    case TFGPU_DBZ_BOOLEAN: return (vt == VT_TRUE || vt == VT_FALSE) ? TFGPU_ROW_OK : TFGPU_ROW_DBZ_FIELD;
+    case TFGPU_DBZ_FLOAT64: {
+      if (vt != VT_NUM) return TFGPU_ROW_DBZ_FIELD;
+      tf::Field fl{&rd, vs, vl};
+      double d;
+      const int rc = parse_float_go(fl, 0, vl, p.p10, p.p128, &d);
+      return rc == 0 ? TFGPU_ROW_OK : rc == 3 ? TFGPU_ROW_HOST_FALLBACK : TFGPU_ROW_DBZ_FIELD;
+    }
+    case TFGPU_DBZ_STRING: return (vt == VT_STR || vt == VT_NUM) ? TFGPU_ROW_OK : TFGPU_ROW_DBZ_FIELD;
+    case TFGPU_DBZ_BYTES:
+      if (vt != VT_STR && vt != VT_NUM) return TFGPU_ROW_DBZ_FIELD;
+      return b64_decode(TextIter(rd, vt, vs, vl), [](uint32_t) {}) >= 0 ? TFGPU_ROW_OK : TFGPU_ROW_DBZ_FIELD;
+    case TFGPU_DBZ_DECIMAL: case TFGPU_DBZ_POINT: case TFGPU_DBZ_VSD: {
+      NullSink s;
+      const int rc = render_text(s, rd, f, vtr, vs, vl);
+      return rc == 0 ? TFGPU_ROW_OK : rc == 1 ? TFGPU_ROW_DBZ_FIELD : TFGPU_ROW_HOST_FALLBACK;
+    }
+  }
+  return TFGPU_ROW_HOST_FALLBACK;
+}
+
+// ---- Receiver.receive for one message ---------------------------------------------------------------------------------
+__device__ int parse_message(const Params &p, int64_t m) {
+  const tfgpu_dbz_frame &fr = p.frames[m];
+  if (fr.payload_len == 0) return TFGPU_ROW_DBZ_PAYLOAD;             // Decode of no bytes: EOF
+  MemBytes rd(p.data);
+  uint32_t pos = (uint32_t)fr.payload_start; const uint32_t end = pos + fr.payload_len;
+  auto skip_ws = [&]() { while (pos < end && is_ws(rd.at(pos))) pos++; };
+  const uint32_t c0 = rd.at(pos);
+  if (c0 == 'n') return TFGPU_ROW_DBZ_OP;                            // null: the zero Payload, Op == ""
+  if (c0 != '{') return TFGPU_ROW_DBZ_PAYLOAD;                       // UnmarshalTypeError
+  // members of interest: the last occurrence wins
+  enum { M_AFTER, M_BEFORE, M_OP, M_SOURCE, M_TS, M_N };
+  uint32_t ms_[M_N], ml_[M_N], mt_[M_N];
+  for (int i = 0; i < M_N; i++) { ms_[i] = 0; ml_[i] = 0; mt_[i] = VT_ABSENT; }
+  bool fold = false;
+  // walks the members of the object at pos ('{'); calls on(ks, ke, vs, vl, vt) for each
+  auto members = [&](auto on) {
+    pos++;
+    skip_ws();
+    if (rd.at(pos) == '}') { pos++; return; }
+    for (;;) {
+      skip_ws();
+      const uint32_t ks = pos;
+      scan_string(rd, pos, end);
+      const uint32_t ke = pos;
+      skip_ws(); pos++; skip_ws();
+      const uint32_t vs = pos; uint32_t vt = 0;
+      skip_value(rd, pos, end, vt);
+      on(ks, ke, vs, pos - vs, vt);
+      skip_ws();
+      if (rd.at(pos) == ',') { pos++; continue; }
+      pos++;  // '}'
+      return;
+    }
+  };
+  static const char *const TOP[M_N] = {"after", "before", "op", "source", "ts_ms"};
+  const uint32_t TOPN[M_N] = {5, 6, 2, 6, 5};
+  members([&](uint32_t ks, uint32_t ke, uint32_t vs, uint32_t vl, uint32_t vt) {
+    for (int i = 0; i < M_N; i++) {
+      const int k = key_is(rd, ks, ke, TOP[i], TOPN[i]);
+      if (k) { ms_[i] = vs; ml_[i] = vl; mt_[i] = vt; if (k == 2) fold = true; return; }
+    }
+    if (key_is(rd, ks, ke, "transaction", 11) == 2) fold = true;
+  });
+  bool bad = false;
+  auto vt_of = [&](int i) { return mt_[i] & VT_MASK; };
+  if (vt_of(M_AFTER) != VT_ABSENT && vt_of(M_AFTER) != VT_OBJ && vt_of(M_AFTER) != VT_NULL) bad = true;
+  if (vt_of(M_BEFORE) != VT_ABSENT && vt_of(M_BEFORE) != VT_OBJ && vt_of(M_BEFORE) != VT_NULL) bad = true;
+  if (vt_of(M_OP) != VT_ABSENT && vt_of(M_OP) != VT_STR && vt_of(M_OP) != VT_NULL) bad = true;
+  if (vt_of(M_TS) == VT_NUM) { uint64_t x; if (!lit_uint(rd, ms_[M_TS], ml_[M_TS], 64, &x)) bad = true; }
+  else if (vt_of(M_TS) != VT_ABSENT && vt_of(M_TS) != VT_NULL) bad = true;
+  uint64_t lsn = 0, ts = 0, tx = 0, th = 0x6A09E667F3BCC908ull;
+  uint32_t sch_s = 0, sch_n = 0, tab_s = 0, tab_n = 0;
+  if (vt_of(M_SOURCE) == VT_OBJ) {
+    const uint32_t save = pos;
+    pos = ms_[M_SOURCE];
+    members([&](uint32_t ks, uint32_t ke, uint32_t vs, uint32_t vl, uint32_t vtr) {
+      const uint32_t vt = vtr & VT_MASK;
+      static const char *const STRS[8] = {"connector", "db", "name", "sequence", "snapshot", "version", "schema", "table"};
+      const uint32_t STRN[8] = {9, 2, 4, 8, 8, 7, 6, 5};
+      for (int i = 0; i < 8; i++) {
+        const int k = key_is(rd, ks, ke, STRS[i], STRN[i]);
+        if (!k) continue;
+        if (k == 2) fold = true;
+        if (vt == VT_STR) { if (i == 6) { sch_s = vs; sch_n = vl; } if (i == 7) { tab_s = vs; tab_n = vl; } }
+        else if (vt != VT_NULL) bad = true;
+        return;
+      }
+      int k;
+      if ((k = key_is(rd, ks, ke, "lsn", 3))) { if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 64, &lsn)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+      if ((k = key_is(rd, ks, ke, "ts_ms", 5))) { if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 64, &ts)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+      if ((k = key_is(rd, ks, ke, "txId", 4))) { if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 32, &tx)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+      if ((k = key_is(rd, ks, ke, "xmin", 4))) { if (k == 2) fold = true; int64_t x; if (vt == VT_NUM) { if (!number_int64(rd, vs, vl, &x)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+    });
+    pos = save;
+  } else if (vt_of(M_SOURCE) != VT_ABSENT && vt_of(M_SOURCE) != VT_NULL) bad = true;
+  if (bad) return TFGPU_ROW_DBZ_PAYLOAD;
+  if (fold) return TFGPU_ROW_HOST_FALLBACK;
+  // opToKind
+  int kind = -1;
+  if (vt_of(M_OP) == VT_STR) {
+    RuneIter it{&rd, nullptr, ms_[M_OP] + 1, ms_[M_OP] + ml_[M_OP] - 1};
+    const int r = it.next();
+    if (r >= 0 && it.next() < 0) kind = (r == 'c' || r == 'r') ? TFGPU_K_INSERT : r == 'u' ? TFGPU_K_UPDATE : r == 'd' ? TFGPU_K_DELETE : -1;
+  }
+  if (kind < 0) return TFGPU_ROW_DBZ_OP;
+  if (p.schema_code != TFGPU_ROW_OK) return p.schema_code;        // receiveSchema's fate, decided by the host for the whole schema
+  p.kind[m] = (uint8_t)kind;
+  p.lsn[m] = lsn; p.ts[m] = ts; p.txid[m] = (uint32_t)tx;
+  {  // TableID of the item: the decoded source.schema / source.table
+    RuneIter a{&rd, nullptr, sch_s + 1, sch_s + (sch_n ? sch_n - 1 : 1)};
+    if (sch_n) for (int r; (r = a.next()) >= 0;) th = mix64(th, (uint64_t)r);
+    th = mix64(th, 0xFFFFFFFFull);
+    RuneIter b{&rd, nullptr, tab_s + 1, tab_s + (tab_n ? tab_n - 1 : 1)};
+    if (tab_n) for (int r; (r = b.next()) >= 0;) th = mix64(th, (uint64_t)r);
+    p.tabhash[m] = th;
+    p.tab_s[m] = sch_s; p.tab_n[m] = sch_n; p.tab_s[p.nmsg + m] = tab_s; p.tab_n[p.nmsg + m] = tab_n;
+  }
+  // the values map: `before` for Delete, else `after`; every schema field must be in it
+  const int vi = kind == TFGPU_K_DELETE ? M_BEFORE : M_AFTER;
+  if (vt_of(vi) == VT_OBJ) {
+    const uint32_t save = pos;
+    pos = ms_[vi];
+    members([&](uint32_t ks, uint32_t ke, uint32_t vs, uint32_t vl, uint32_t vt) {
+      int lo = 0, hi = p.nfields - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const FRecv &f = p.fields[p.sorted[mid]];
+        RuneIter a{&rd, nullptr, ks + 1, ke - 1}, b{nullptr, p.names + f.name_off, 0, f.name_len};
+        const int c = rune_compare(a, b);
+        if (c == 0) { const int64_t i = (int64_t)p.sorted[mid] * p.nmsg + m; p.vstart[i] = vs; p.vlen[i] = vl; p.vtype[i] = (uint8_t)vt; return; }
+        if (c < 0) hi = mid - 1; else lo = mid + 1;
+      }
+    });
+    pos = save;
+  }
+  for (int j = 0; j < p.nfields; j++) {
+    const int64_t i = (int64_t)j * p.nmsg + m;
+    const uint32_t vtr = p.vtype[i];
+    if ((vtr & VT_MASK) == VT_ABSENT) return TFGPU_ROW_DBZ_FIELD;  // "unable to get field %s from 'after'"
+    const int rc = check_value(p, rd, p.fields[j], vtr, p.vstart[i], p.vlen[i]);
+    if (rc != TFGPU_ROW_OK) return rc;
+  }
+  return TFGPU_ROW_OK;
+}
+__global__ void __launch_bounds__(128) dbz_parse(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.nmsg) return;
+  const tfgpu_dbz_frame &fr = p.frames[m];
+  int st;
+  if (fr.code != TFGPU_ROW_OK || fr.schema_hash[0] != p.h0 || fr.schema_hash[1] != p.h1) st = ST_SKIP;
+  else st = parse_message(p, m);
+  p.status[m] = (uint8_t)st;
+  if (st == TFGPU_ROW_OK) atomicMin(p.first_ok, (unsigned long long)m);
+}
+// a batch carries ONE TableID: good rows of another table than the first good row's are the stock code's
+__global__ void __launch_bounds__(256) dbz_table_rule(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.nmsg) return;
+  uint32_t st = p.status[m];
+  const unsigned long long f = *p.first_ok;
+  if (st == TFGPU_ROW_OK && f < (unsigned long long)p.nmsg && p.tabhash[m] != p.tabhash[f]) { st = TFGPU_ROW_HOST_FALLBACK; p.status[m] = (uint8_t)st; }
+  p.keep[m] = st == TFGPU_ROW_OK ? 1u : 0u;
+  if (st != TFGPU_ROW_OK && st != ST_SKIP) atomicAdd(p.nerr, 1u);
+}
+__global__ void __launch_bounds__(256) dbz_row_msgs(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.nmsg || p.status[m] != TFGPU_ROW_OK) return;
+  p.row_msg[p.keep[m]] = (uint32_t)m;
+}
+// decoded source.schema / source.table of the first good message: [len u32][bytes ≤ 252] twice
+__global__ void dbz_table_name(Params p, uint8_t *out) {
+  const unsigned long long f = *p.first_ok;
+  if (threadIdx.x || f >= (unsigned long long)p.nmsg) return;
+  MemBytes rd(p.data);
+  for (int k = 0; k < 2; k++) {
+    const uint32_t s = p.tab_s[(int64_t)k * p.nmsg + f], n = p.tab_n[(int64_t)k * p.nmsg + f];
+    uint8_t *o = out + k * 256;
+    uint32_t len = 0;
+    if (n) {
+      RuneIter it{&rd, nullptr, s + 1, s + n - 1};
+      struct Cap { uint8_t *p; uint32_t n; __device__ void put(uint32_t c) { if (n < 252) p[4 + n] = (uint8_t)c; n++; } } cap{o, 0};
+      for (int r; (r = it.next()) >= 0;) put_utf8(cap, (uint32_t)r);
+      len = cap.n;
+    }
+    o[0] = (uint8_t)len; o[1] = (uint8_t)(len >> 8); o[2] = (uint8_t)(len >> 16); o[3] = (uint8_t)(len >> 24);
+  }
+}
+
+// ---- cells --------------------------------------------------------------------------------------------------------------
+struct OutCol {
+  int32_t op;
+  void *values;
+  uint32_t *lens;      // text columns: lengths, then offsets [nrows + 1]
+  uint8_t *data;
+  uint8_t *valid8, *old8;      // one byte per row: ColumnValues holds a non-nil value / OldKeys does
+  uint8_t *validity, *old_validity;
+};
+struct DbzRow { int64_t msg; uint64_t lsn, commit_time; uint32_t id; uint8_t names_form, pad[3]; };
+static_assert(sizeof(DbzRow) == sizeof(tfgpu_dbz_row), "row meta layout");
+
+__global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint8_t *kinds, uint8_t *old_present8, DbzRow *rows) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (int64_t)p.nfields * p.nrows) return;
+  const int j = (int)(it / p.nrows); const int64_t r = it - (int64_t)j * p.nrows;
+  const uint32_t m = p.row_msg[r];
+  const OutCol &c = cols[j];
+  const FRecv &f = p.fields[j];
+  const int64_t i = (int64_t)j * p.nmsg + m;
+  const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
+  const int kind = p.kind[m];
+  MemBytes rd(p.data);
+  if (j == 0) {
+    src_row[r] = (int32_t)m; kinds[r] = (uint8_t)kind; old_present8[r] = kind != TFGPU_K_INSERT;
+    rows[r] = DbzRow{(int64_t)m, p.lsn[m], p.ts[m] * 1000000ull, p.txid[m], (uint8_t)(kind == TFGPU_K_DELETE), {0, 0, 0}};
+  }
+  const bool nil = vt == VT_NULL;
+  c.valid8[r] = (!nil && kind != TFGPU_K_DELETE) ? 1 : 0;         // a Delete keeps ColumnNames / ColumnValues nil
+  if (c.old8) c.old8[r] = (!nil && kind != TFGPU_K_INSERT) ? 1 : 0;
+  switch (f.op) {
+    case TFGPU_DBZ_BOOLEAN: ((uint8_t *)c.values)[r] = vt == VT_TRUE; break;
+    case TFGPU_DBZ_INT8: case TFGPU_DBZ_INT16: case TFGPU_DBZ_INT32: case TFGPU_DBZ_INT64: {
+      int64_t x = 0;
+      if (!nil) number_int64(rd, vs, vl, &x);
+      if (f.op == TFGPU_DBZ_INT8) ((int8_t *)c.values)[r] = (int8_t)x;        // Go's truncating conversions
+      else if (f.op == TFGPU_DBZ_INT16) ((int16_t *)c.values)[r] = (int16_t)x;
+      else if (f.op == TFGPU_DBZ_INT32) ((int32_t *)c.values)[r] = (int32_t)x;
+      else ((int64_t *)c.values)[r] = x;
+      break;
+    }
+    case TFGPU_DBZ_FLOAT64: {
+      double d = 0;
+      if (!nil) { tf::Field fl{&rd, vs, vl}; parse_float_go(fl, 0, vl, p.p10, p.p128, &d); }
+      ((double *)c.values)[r] = d;
+      break;
+    }
+    case TFGPU_DBZ_STRING:
+      if (nil) c.lens[r] = 0;
+      else if (vt == VT_NUM) c.lens[r] = vl;
+      else if (vtr & VT_PLAIN) c.lens[r] = vl - 2;
+      else { CountSink s; emit_unquoted(s, rd, vs, vl); c.lens[r] = s.n; }
+      break;
+    case TFGPU_DBZ_BYTES: { int n = 0; if (!nil) n = b64_decode(TextIter(rd, vt, vs, vl), [](uint32_t) {}); c.lens[r] = n > 0 ? (uint32_t)n : 0u; break; }
+    default: { CountSink s; if (!nil) render_text(s, rd, f, vtr, vs, vl); c.lens[r] = s.n; }
+  }
+}
+__global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (int64_t)ntext * p.nrows) return;
+  const int t = (int)(it / p.nrows); const int64_t r = it - (int64_t)t * p.nrows;
+  const int j = text_cols[t];
+  const OutCol &c = cols[j];
+  const FRecv &f = p.fields[j];
+  const uint32_t m = p.row_msg[r];
+  const int64_t i = (int64_t)j * p.nmsg + m;
+  const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
+  if (vt == VT_NULL) return;
+  MemBytes rd(p.data);
+  ByteSink s{c.data + c.lens[r]};
+  auto copy_raw = [&](uint32_t a, uint32_t n) {
+    uint32_t k = 0;
+    for (; k + 8 <= n; k += 8) s.put_word(rd.word(a + k), 8);
+    if (k < n) s.put_word(rd.word(a + k) & ((1ull << (8 * (n - k))) - 1), n - k);
+  };
+  if (f.op == TFGPU_DBZ_STRING) {
+    if (vt == VT_NUM) copy_raw(vs, vl);
+    else if (vtr & VT_PLAIN) copy_raw(vs + 1, vl - 2);
+    else emit_unquoted(s, rd, vs, vl);
+  } else if (f.op == TFGPU_DBZ_BYTES) b64_decode(TextIter(rd, vt, vs, vl), [&](uint32_t b) { s.put(b); });
+  else render_text(s, rd, f, vtr, vs, vl);
+  s.flush();
+}
+__global__ void __launch_bounds__(256) dbz_pack_bits(const uint8_t *bytes, int64_t n, uint8_t *bits) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * 8 >= n) return;
+  uint32_t v = 0;
+  for (int k = 0; k < 8 && b * 8 + k < n; k++) v |= (uint32_t)(bytes[b * 8 + k] & 1u) << k;
+  bits[b] = (uint8_t)v;
+}
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
+
+struct Staged { Buf bytes, ms; Params p{}; };
+static void stage(Staged &s, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs) {
+  Context &cx = ctx();
+  if (len >= 0xFFFFFFF0ull) throw Error(TFGPU_ERR_UNSUPPORTED, "debezium: batch must be < 4 GiB (32-bit offsets)");
+  if (mem == TFGPU_MEM_HOST) {
+    s.bytes = dalloc(len + 64);
+    h2d(s.bytes->p, bytes, len);
+    TF_HIP(hipMemsetAsync((char *)s.bytes->p + len, 0, 64, cx.stream));
+    s.p.data = ptr<uint8_t>(s.bytes);
+  } else {
+    s.p.data = (const uint8_t *)bytes;
+    if (reinterpret_cast<uintptr_t>(s.p.data) & 15) throw Error(TFGPU_ERR_INVALID, "debezium: device buffer must be 16-byte aligned");
+  }
+  const int64_t nmsg = msgs ? msgs->nmsg : 1;
+  if (nmsg < 0 || (msgs && nmsg > 0 && !msgs->start)) throw Error(TFGPU_ERR_INVALID, "debezium: bad message batch");
+  std::vector<uint32_t> ms((size_t)nmsg + 1);
+  if (msgs) {
+    for (int64_t m = 0; m <= nmsg; m++) {
+      if (msgs->start[m] > len || (m && msgs->start[m] < msgs->start[m - 1])) throw Error(TFGPU_ERR_INVALID, "debezium: message offsets must be ascending and inside the buffer");
+      ms[(size_t)m] = (uint32_t)msgs->start[m];
+    }
+  } else { ms[0] = 0; ms[1] = (uint32_t)len; }
+  s.ms = dalloc(ms.size() * 4 + 16);
+  h2d(s.ms->p, ms.data(), ms.size() * 4);
+  s.p.ms = ptr<uint32_t>(s.ms); s.p.nmsg = nmsg;
+}
+
+}  // namespace dbz
+}  // namespace tf
+
+using namespace tf;
+
+#define TF_API_BEGIN try {
+#define TF_API_END                                                        \
+  }                                                                       \
+  catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }       \
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+
+extern "C" int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_dbz_frame *frames) {
+  TF_API_BEGIN
+  if ((len && !bytes) || !frames) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_unpack: null argument");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  dbz::Staged s;
+  dbz::stage(s, bytes, len, mem, msgs);
+  const int64_t nmsg = s.p.nmsg;
+  Buf fr = dalloc((size_t)std::max<int64_t>(nmsg, 1) * sizeof(tfgpu_dbz_frame));
+  s.p.frames = reinterpret_cast<tfgpu_dbz_frame *>(fr->p);
+  if (nmsg) { KernelTimer t("dbz_unpack"); dbz::dbz_unpack<<<dbz::nblk(nmsg, 128), 128, 0, cx.stream>>>(s.p); }
+  if (nmsg) d2h(frames, fr->p, (size_t)nmsg * sizeof(tfgpu_dbz_frame));
+  tf::sync();
+  return TFGPU_OK;
+  TF_API_END
+}
+
+extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
+                                    const tfgpu_dbz_frame *frames, tfgpu_dbatch **out, tfgpu_dbz_row *rows, int64_t rows_cap,
+                                    tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
+  TF_API_BEGIN
+  if (!o || !out || !frames || (len && !bytes) || (o->nfields && !o->fields)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_parse: null argument");
+  const int nf = o->nfields;
+  if (nf > 4096) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_parse: more than 4096 fields");
+  std::string names;
+  std::vector<dbz::FRecv> fields((size_t)std::max(nf, 1));
+  int schema_code = o->schema_code;
+  if (schema_code != TFGPU_ROW_OK && schema_code != TFGPU_ROW_DBZ_SCHEMA && schema_code != TFGPU_ROW_HOST_FALLBACK) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_parse: bad schema_code");
+  for (int j = 0; j < nf; j++) {
+    const tfgpu_dbz_field &f = o->fields[j];
+    if (!f.name || f.op < TFGPU_DBZ_BOOLEAN || f.op > TFGPU_DBZ_HOST) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_parse: bad field");
+    if (f.op == TFGPU_DBZ_HOST && schema_code == TFGPU_ROW_OK) schema_code = TFGPU_ROW_HOST_FALLBACK;
+    fields[(size_t)j] = dbz::FRecv{(uint32_t)names.size(), (uint32_t)std::strlen(f.name), f.op, f.optional ? 1 : 0, f.scale};
+    names += f.name;
+    names.append((8 - names.size() % 8) % 8, '\0');
+  }
+  std::vector<uint16_t> sorted((size_t)std::max(nf, 1));
+  for (int j = 0; j < nf; j++) sorted[(size_t)j] = (uint16_t)j;
+  std::sort(sorted.begin(), sorted.begin() + nf, [&](uint16_t a, uint16_t b) { return std::strcmp(o->fields[a].name, o->fields[b].name) < 0; });
+  for (int j = 1; j < nf; j++) if (!std::strcmp(o->fields[sorted[(size_t)j - 1]].name, o->fields[sorted[(size_t)j]].name))
+    return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_parse: the schema names a field twice (rows of the reference would repeat a column): host");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  hipStream_t st = cx.stream;
+  dbz::Staged s;
+  dbz::stage(s, bytes, len, mem, msgs);
+  dbz::Params &p = s.p;
+  const int64_t nmsg = p.nmsg, nma = std::max<int64_t>(nmsg, 1);
+  Buf bfr = dalloc((size_t)nma * sizeof(tfgpu_dbz_frame));
+  if (nmsg) h2d(bfr->p, frames, (size_t)nmsg * sizeof(tfgpu_dbz_frame));
+  p.frames = reinterpret_cast<tfgpu_dbz_frame *>(bfr->p);
+  p.h0 = o->schema_hash[0]; p.h1 = o->schema_hash[1]; p.schema_code = schema_code;
+  Buf bfields = upload_small(fields.data(), fields.size() * sizeof(dbz::FRecv)), bnames = upload_small(names.data(), std::max<size_t>(names.size(), 8)),
+      bsorted = upload_small(sorted.data(), sorted.size() * 2);
+  p.fields = ptr<dbz::FRecv>(bfields); p.nfields = nf; p.names = ptr<uint8_t>(bnames); p.sorted = ptr<uint16_t>(bsorted);
+  const size_t cells = (size_t)std::max(nf, 1) * (size_t)nma;
+  Buf vstart = dalloc(cells * 4), vlen = dalloc(cells * 4), vtype = dalloc_zero(cells + 16);
+  Buf status = dalloc_zero((size_t)nma + 16), kind = dalloc_zero((size_t)nma + 16), keep = dalloc_zero((size_t)(nma + 1) * 4 + 16), misc = dalloc_zero(32);
+  Buf lsn = dalloc_zero((size_t)nma * 8), ts = dalloc_zero((size_t)nma * 8), tabhash = dalloc_zero((size_t)nma * 8), txid = dalloc_zero((size_t)nma * 4),
+      tab_s = dalloc_zero((size_t)nma * 8), tab_n = dalloc_zero((size_t)nma * 8);
+  p.vstart = ptr<uint32_t>(vstart); p.vlen = ptr<uint32_t>(vlen); p.vtype = ptr<uint8_t>(vtype);
+  p.status = ptr<uint8_t>(status); p.kind = ptr<uint8_t>(kind); p.keep = ptr<uint32_t>(keep);
+  p.lsn = ptr<uint64_t>(lsn); p.ts = ptr<uint64_t>(ts); p.tabhash = ptr<uint64_t>(tabhash); p.txid = ptr<uint32_t>(txid);
+  p.tab_s = ptr<uint32_t>(tab_s); p.tab_n = ptr<uint32_t>(tab_n);
+  p.nerr = ptr<uint32_t>(misc); p.first_ok = ptr<unsigned long long>(misc) + 1;
+  TF_HIP(hipMemsetAsync(p.first_ok, 0xFF, 8, st));
+  p.p10 = pow10_table(); p.p128 = reinterpret_cast<const uint64_t *>(p.p10 + 632);
+  Buf tabname = dalloc_zero(512);
+  if (nmsg) {
+    { KernelTimer t("dbz_parse"); dbz::dbz_parse<<<dbz::nblk(nmsg, 128), 128, 0, st>>>(p); }
+    dbz::dbz_table_rule<<<dbz::nblk(nmsg, 256), 256, 0, st>>>(p);
+    dbz::dbz_table_name<<<1, 64, 0, st>>>(p, ptr<uint8_t>(tabname));
+  }
+  exclusive_scan_u32(p.keep, p.keep, nmsg, true);
+  const uint32_t *hrows = d2h_u32(p.keep + nmsg), *hnerr = d2h_u32(p.nerr);
+  uint8_t htab[512];
+  d2h(htab, tabname->p, 512);
+  tf::sync();
+  const int64_t nrows = *hrows, nra = std::max<int64_t>(nrows, 1);
+  const uint32_t nerr_total = *hnerr;
+  if (nrows > rows_cap && rows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_parse: more rows than `rows` holds");
+
+  auto db = std::make_unique<tfgpu_dbatch>();
+  db->nrows = nrows;
+  {
+    uint32_t l0, l1;
+    std::memcpy(&l0, htab, 4); std::memcpy(&l1, htab + 256, 4);
+    if (l0 > 252 || l1 > 252) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_parse: source.schema / source.table longer than 252 bytes");
+    db->ns.assign((const char *)htab + 4, l0); db->table.assign((const char *)htab + 260, l1);
+  }
+  db->src_row = dalloc((size_t)nra * 4); db->kind = dalloc_zero((size_t)nra + 16);
+  Buf row_msg = dalloc((size_t)nra * 4), drows = dalloc((size_t)nra * sizeof(tfgpu_dbz_row)), old8 = dalloc_zero((size_t)nra);
+  p.row_msg = ptr<uint32_t>(row_msg); p.nrows = nrows;
+  std::vector<dbz::OutCol> oc((size_t)std::max(nf, 1));
+  std::vector<int32_t> text_cols;
+  const int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
+  int ntext = 0, nkeys = 0;
+  for (int j = 0; j < nf; j++) { if (o->fields[j].op >= TFGPU_DBZ_STRING) ntext++; if (!o->fields[j].optional) nkeys++; }
+  Buf lens_all = dalloc_zero((size_t)std::max(ntext, 1) * (size_t)seg_stride * 4 + 16);
+  Buf valid8 = dalloc_zero((size_t)std::max(nf, 1) * (size_t)nra), oldv8 = dalloc_zero((size_t)std::max(nkeys, 1) * (size_t)nra);
+  int ti = 0, ki = 0;
+  for (int j = 0; j < nf; j++) {
+    const tfgpu_dbz_field &f = o->fields[j];
+    DColumn d;
+    d.name = f.name;
+    dbz::OutCol &c = oc[(size_t)j];
+    std::memset(&c, 0, sizeof c);
+    c.op = f.op;
+    auto fixed = [&](int dtype, int repr, size_t w) { d.dtype = dtype; d.repr = repr; d.values = dalloc_zero((size_t)nra * w); c.values = d.values->p; };
+    switch (f.op) {
+      case TFGPU_DBZ_BOOLEAN: fixed(TFGPU_T_BOOLEAN, TFGPU_R_BOOL, 1); break;
+      case TFGPU_DBZ_INT8: fixed(TFGPU_T_INT8, TFGPU_R_INT8, 1); break;
+      case TFGPU_DBZ_INT16: fixed(TFGPU_T_INT16, TFGPU_R_INT16, 2); break;
+      case TFGPU_DBZ_INT32: fixed(TFGPU_T_INT32, TFGPU_R_INT32, 4); break;
+      case TFGPU_DBZ_INT64: fixed(TFGPU_T_INT64, TFGPU_R_INT64, 8); break;
+      case TFGPU_DBZ_FLOAT64: fixed(TFGPU_T_FLOAT64, TFGPU_R_FLOAT64, 8); break;
+      case TFGPU_DBZ_BYTES: d.dtype = TFGPU_T_BYTES; d.repr = TFGPU_R_BYTES; break;
+      case TFGPU_DBZ_VSD: d.dtype = TFGPU_T_FLOAT64; d.repr = TFGPU_R_JSONNUM; break;
+      case TFGPU_DBZ_HOST: d.dtype = TFGPU_T_ANY; d.repr = TFGPU_R_JSON; break;
+      default: d.dtype = TFGPU_T_UTF8; d.repr = TFGPU_R_STRING;
+    }
+    if (f.op >= TFGPU_DBZ_STRING) {
+      d.offsets = subbuf(lens_all, (size_t)ti * (size_t)seg_stride * 4, (size_t)(nrows + 1) * 4);
+      c.lens = ptr<uint32_t>(d.offsets);
+      text_cols.push_back(j);
+      ti++;
+    }
+    c.valid8 = ptr<uint8_t>(valid8) + (size_t)j * (size_t)nra;
+    d.validity = dalloc_zero((size_t)((nra + 7) / 8) + 8);
+    c.validity = ptr<uint8_t>(d.validity);
+    if (!f.optional) {
+      c.old8 = ptr<uint8_t>(oldv8) + (size_t)ki * (size_t)nra;
+      ki++;
+      db->key_names.push_back(f.name);
+    }
+    db->schema.push_back({d.name, d.dtype});
+    db->cols.push_back(std::move(d));
+  }
+  Buf boc = upload_small(oc.data(), oc.size() * sizeof(dbz::OutCol));
+  if (nrows) {
+    dbz::dbz_row_msgs<<<dbz::nblk(nmsg, 256), 256, 0, st>>>(p);
+    if (nf) {
+      KernelTimer t("dbz_cell_values");
+      dbz::dbz_cell_values<<<dbz::nblk((int64_t)nf * nrows, 256), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint8_t>(db->kind), ptr<uint8_t>(old8),
+                                                                                reinterpret_cast<dbz::DbzRow *>(drows->p));
+    }
+  }
+  if (nf == 0 && nrows) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_parse: a table schema without fields");
+  if (ntext) {
+    exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);
+    std::vector<const uint32_t *> tot((size_t)ntext);
+    for (int t = 0; t < ntext; t++) tot[(size_t)t] = d2h_u32(ptr<uint32_t>(lens_all) + (int64_t)t * seg_stride + nrows);
+    tf::sync();
+    for (int t = 0; t < ntext; t++) {
+      DColumn &d = db->cols[(size_t)text_cols[(size_t)t]];
+      d.data_len = *tot[(size_t)t];
+      d.data = dalloc(d.data_len + 8);
+      oc[(size_t)text_cols[(size_t)t]].data = ptr<uint8_t>(d.data);
+    }
+    boc = upload_small(oc.data(), oc.size() * sizeof(dbz::OutCol));
+    Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
+    if (nrows) { KernelTimer t("dbz_cell_text"); dbz::dbz_cell_text<<<dbz::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc), ntext); }
+  }
+  // bitmaps: ColumnValues validity per column; OldKeys = the key columns' buffers under their own validity
+  const unsigned gb = dbz::nblk((nrows + 7) / 8, 256);
+  for (int j = 0; j < nf && nrows; j++) dbz::dbz_pack_bits<<<gb, 256, 0, st>>>(oc[(size_t)j].valid8, nrows, oc[(size_t)j].validity);
+  for (int j = 0; j < nf; j++) {
+    if (o->fields[j].optional) continue;
+    DColumn k = db->cols[(size_t)j];  // shares values / offsets / data
+    k.validity = dalloc_zero((size_t)((nra + 7) / 8) + 8);
+    if (nrows) dbz::dbz_pack_bits<<<gb, 256, 0, st>>>(oc[(size_t)j].old8, nrows, ptr<uint8_t>(k.validity));
+    db->old_keys.push_back(std::move(k));
+  }
+  if (!db->old_keys.empty()) {
+    db->old_present = dalloc_zero((size_t)((nra + 7) / 8) + 8);
+    if (nrows) dbz::dbz_pack_bits<<<gb, 256, 0, st>>>(ptr<uint8_t>(old8), nrows, ptr<uint8_t>(db->old_present));
+  }
+  if (rows && nrows) d2h(rows, drows->p, (size_t)nrows * sizeof(tfgpu_dbz_row));
+  int64_t ne = 0;
+  if (nerr_total) {
+    std::vector<uint8_t> hst((size_t)nmsg);
+    d2h(hst.data(), status->p, (size_t)nmsg);
+    tf::sync();
+    for (int64_t m = 0; m < nmsg; m++) {
+      const int c = hst[(size_t)m];
+      if (c == TFGPU_ROW_OK || c == dbz::ST_SKIP) continue;
+      if (errs && ne < errs_cap) errs[ne] = tfgpu_row_error{m, c, (int32_t)m, -1};
+      ne++;
+    }
+  }
+  tf::sync();
+  if (nerrs) *nerrs = ne;
+  *out = db.release();
+  return TFGPU_OK;
+  TF_API_END
+}

@@ -258,85 +258,6 @@ template <class S> __device__ void tskv_walk(MemBytes &rd, const uint64_t s, con
   }
 }
 
-// strconv.ParseFloat(s, 64) as atof64 decides it (strconv/atof.go): special(), readFloat, the exact
-// float path (atof64exact), then Eisel-Lemire — also on mantissa+1 when digits were truncated.  What is left
-// for Go's arbitrary-precision fallback (half-way cases, subnormals) is not decided here.
-// 0 ok, 1 syntax error, 2 range error (*out = ±Inf), 3 not decided (also hex floats and '_').
-template <class F> __device__ int parse_float_go(const F &f, uint32_t a, const uint32_t b, const double *p10, const uint64_t *p128, double *out) {
-  uint32_t i = a;
-  *out = 0;
-  if (i >= b) return 1;
-  bool neg = false, sign = false;
-  if (f[i] == '+') { i++; sign = true; } else if (f[i] == '-') { neg = true; sign = true; i++; }
-  {  // special(): [+-]?inf(inity)? | nan, case-insensitive
-    const uint32_t n = b - i;
-    auto eq = [&](const char *w, uint32_t wl) { if (n != wl) return false; for (uint32_t k = 0; k < wl; k++) if (lower_(f[i + k]) != (uint32_t)w[k]) return false; return true; };
-    if (eq("inf", 3) || eq("infinity", 8)) { *out = neg ? -INFINITY : INFINITY; return 0; }
-    if (!sign && eq("nan", 3)) { *out = NAN; return 0; }
-  }
-  if (b - i >= 2 && f[i] == '0' && lower_(f[i + 1]) == 'x') return 3;
-  uint64_t mant = 0;
-  int nd = 0, ndm = 0, dp = 0;
-  bool sawdot = false, sawdigits = false, trunc = false;
-  for (; i < b; i++) {
-    const uint32_t c = f[i];
-    if (c == '_') return 3;
-    if (c == '.') { if (sawdot) break; sawdot = true; dp = nd; continue; }
-    if (dg(c)) {
-      sawdigits = true;
-      if (c == '0' && nd == 0) { dp--; continue; }
-      nd++;
-      if (ndm < 19) { mant = mant * 10 + (c - '0'); ndm++; } else if (c != '0') trunc = true;
-      continue;
-    }
-    break;
-  }
-  if (!sawdigits) return 1;
-  if (!sawdot) dp = nd;
-  if (i < b && lower_(f[i]) == 'e') {
-    i++;
-    if (i >= b) return 1;
-    int esign = 1;
-    if (f[i] == '+') i++; else if (f[i] == '-') { i++; esign = -1; }
-    if (i >= b || !dg(f[i])) return 1;
-    int e = 0;
-    for (; i < b && (dg(f[i]) || f[i] == '_'); i++) {
-      if (f[i] == '_') return 3;
-      if (e < 10000) e = e * 10 + (int)(f[i] - '0');
-    }
-    dp += e * esign;
-  }
-  if (i != b) return 1;
-  if (mant == 0) { *out = neg ? -0.0 : 0.0; return 0; }
-  // decimal.floatBits: beyond these the slow path answers without looking at the digits
-  if (dp > 310) { *out = neg ? -INFINITY : INFINITY; return 2; }
-  if (dp < -330) { *out = neg ? -0.0 : 0.0; return 0; }
-  int exp10 = dp - ndm;
-  // 12300000000000000000e-3 and 123e13 are the same number: without trailing zeros the exact path decides
-  // integers Eisel-Lemire cannot (its 10^-k rows are rounded down), with the same correctly rounded result
-  if (!trunc && (mant >> 52)) while (mant % 10 == 0) { mant /= 10; exp10++; }
-  if (!trunc && !(mant >> 52)) {  // atof64exact
-    double v = (double)mant;
-    bool exact = true;
-    if (exp10 > 0 && exp10 <= 15 + 22) {
-      int e = exp10;
-      if (e > 22) { v *= p10[323 + e - 22]; e = 22; }
-      if (v > 1e15) exact = false; else v *= p10[323 + e];
-    } else if (exp10 < 0 && exp10 >= -22) v /= p10[323 - exp10];
-    else if (exp10 != 0) exact = false;
-    if (exact) { *out = neg ? -v : v; return 0; }
-  }
-  uint64_t bits;
-  if (!eisel_lemire64(mant, exp10, p128, &bits)) return 3;
-  if (trunc) {  // the truncated digits may still matter: confirm with the upper bound
-    uint64_t up;
-    if (!eisel_lemire64(mant + 1, exp10, p128, &up) || up != bits) return 3;
-  }
-  if (neg) bits |= 0x8000000000000000ull;
-  *out = __longlong_as_double((long long)bits);
-  return 0;
-}
-
 // f, err := strconv.ParseFloat(s, 64); if err != nil && !math.IsInf(f, 0) → 0 (fastfloat's fallback)
 template <class F> __device__ int strconv_or0(const F &f, uint32_t n, const double *p10, const uint64_t *p128, double *out) {
   const int rc = parse_float_go(f, 0, n, p10, p128, out);
@@ -1430,7 +1351,7 @@ __global__ void json_collect(const uint32_t *nerr, const uint32_t *lens_all, int
 
 // math.Pow10(n), n = -323..308, exactly as Go builds it: pow10postab32[n/32] * pow10tab[n%32] and
 // pow10negtab32[-n/32] / pow10tab[-n%32], every table entry being the correctly rounded literal.
-static const double *pow10_table() {
+const double *pow10_table() {
   Context &cx = ctx();
   if (!cx.pow10tab) {
     std::vector<double> t(632);

@@ -28,7 +28,7 @@ EXPORTS = [
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
-    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -91,6 +91,9 @@ def load():
     L.tfgpu_collapse.argtypes = [P, C.POINTER(P)]
     L.tfgpu_partition.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
     L.tfgpu_dbatch_deepsizeof.argtypes = [P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.tfgpu_debezium_unpack.argtypes = [P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), P]
+    L.tfgpu_debezium_parse.argtypes = [C.POINTER(abi.CDbzOptions), P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), P, C.POINTER(P), P, C.c_int64,
+                                       C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_ch_native_block.argtypes = [P, C.POINTER(abi.CChNativeColumn), C.c_int32, C.POINTER(P)]
     L.tfgpu_comm_unique_id.argtypes = [C.c_char_p]
     L.tfgpu_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(P)]
@@ -195,6 +198,11 @@ class DeviceBatch:
         """ChangeItem.TableSchema where the batch carries one of its own, else None (= the columns)."""
         v = self.view()
         return abi.Schema.from_c(v.schema.contents) if v.schema else None
+
+    def table_id(self):
+        """(Schema, Table) of the batch's rows."""
+        v = self.view()
+        return (v.table_ns or b"").decode("utf-8"), (v.table_name or b"").decode("utf-8")
 
     def column_names(self) -> List[str]:
         v = self.view()
@@ -714,6 +722,38 @@ def sr_json_parse(opts: abi.CSrJsonOptions, data, msgs: Optional[abi.CMessages] 
     ne, out = C.c_int64(0), C.c_void_p()
     _check(load().tfgpu_sr_json_parse(C.byref(opts), ptr_, n, mem, C.byref(msgs) if msgs is not None else None, C.byref(out), errs, max_errors, C.byref(ne)))
     return ParseResult(DeviceBatch(out), [(int(errs[i].row), int(errs[i].code), int(errs[i].step)) for i in range(min(int(ne.value), max_errors))])
+
+
+def debezium_unpack(data, msgs: Optional[abi.CMessages] = None) -> np.ndarray:
+    """IncludeSchema.Unpack for every message (tfgpu_debezium_unpack): a structured array (abi.DBZ_FRAME_DTYPE) of nmsg frames."""
+    init()
+    ptr_, n, mem, keep = _bytes_arg(data)
+    nmsg = msgs.nmsg if msgs is not None else 1
+    frames = np.zeros(max(nmsg, 1), abi.DBZ_FRAME_DTYPE)
+    _check(load().tfgpu_debezium_unpack(ptr_, n, mem, C.byref(msgs) if msgs is not None else None, frames.ctypes.data))
+    return frames[:nmsg]
+
+
+def debezium_parse(schema_hash, fields, data, frames: np.ndarray, msgs: Optional[abi.CMessages] = None, max_errors: int = 1 << 16, schema_code: int = 0):
+    """Receiver.receive for the frames of one schema (tfgpu_debezium_parse).  fields = [(name, DBZ_*, optional, scale)].
+    Returns (DeviceBatch, rows: structured array abi.DBZ_ROW_DTYPE, [(message, code)])."""
+    init()
+    ptr_, n, mem, keep = _bytes_arg(data)
+    nmsg = len(frames)
+    o = abi.CDbzOptions()
+    o.schema_hash[0], o.schema_hash[1] = int(schema_hash[0]), int(schema_hash[1])
+    arr = (abi.CDbzField * max(len(fields), 1))()
+    for i, (name, op, optional, scale) in enumerate(fields):
+        arr[i].name, arr[i].op, arr[i].optional, arr[i].scale = name.encode("utf-8"), op, 1 if optional else 0, scale
+    o.nfields, o.fields, o.schema_code = len(fields), arr, schema_code
+    rows = np.zeros(max(nmsg, 1), abi.DBZ_ROW_DTYPE)
+    fr = np.ascontiguousarray(frames)
+    errs = (abi.CRowError * max_errors)()
+    ne, out = C.c_int64(0), C.c_void_p()
+    _check(load().tfgpu_debezium_parse(C.byref(o), ptr_, n, mem, C.byref(msgs) if msgs is not None else None, fr.ctypes.data, C.byref(out), rows.ctypes.data, nmsg,
+                                       errs, max_errors, C.byref(ne)))
+    db = DeviceBatch(out)
+    return db, rows[:db.nrows], [(int(errs[i].row), int(errs[i].code)) for i in range(min(int(ne.value), max_errors))]
 
 
 def json_result_schema(opts: abi.CJsonOptions, fields: abi.Schema) -> abi.Schema:
