@@ -46,7 +46,13 @@ def test_tile_parser_resources():
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 def test_serializer_and_sr_resources():
     t = kernel_table("tf_serialize.hip")
-    assert find(t, "ser_cell_write")["scratch"] <= 256 and find(t, "ser_cell_len")["scratch"] <= 128  # the float formatter's digit buffer
+    # the sinks live in registers: every emitter is force-inlined (a sink passed by reference to a real call sits in scratch and
+    # every put() becomes a load-modify-store there: measured 10.5 ms -> 6.2 ms on configs[3]); what is left is the float
+    # formatter's digit buffer on the JSON / CSV paths
+    assert find(t, "ser_cell_write")["scratch"] <= 64 and find(t, "ser_cell_len")["scratch"] == 0
+    tiles = {k: v for k, v in t.items() if "ser_tile_write" in k}
+    assert len(tiles) == 3 and min(v["scratch"] for v in tiles.values()) == 0 and max(v["scratch"] for v in tiles.values()) <= 64
+    assert all(v["vgpr"] <= 168 for v in tiles.values())  # three workgroups of 48 KiB LDS per CU = 3 waves per SIMD
     assert find(t, "ser_fill_const")["vgpr"] <= 16
     t = kernel_table("tf_srjson.hip")
     # the parse kernel keeps per-depth key spans for the `any` order check in scratch (2 x 128 words) and nothing more

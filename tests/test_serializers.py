@@ -230,3 +230,22 @@ def test_gpu_raw_refusals(tf):
     e = _mirror_batch([])
     assert tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(e)).download() == b""
     assert tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(e), _opts({"add_closing_newline": True})).download() == b""
+
+
+@pytest.mark.gpu
+def test_gpu_rows_larger_than_the_lds_image(tf, oracle):
+    """ser_tile_write assembles runs of rows in a 48 KiB LDS image; runs that outgrow it (one 70 KB cell) are written by the
+    same workgroup straight to HBM.  Mixed batch: both paths, every format."""
+    import random
+    rng = random.Random(SEED0 + 31)
+    schema = abi.Schema.of([["k", "int64", True], ["s", "utf8", False], ["t", "utf8", False], ["d", "double", False]])
+    rows = []
+    for k in range(300):
+        big = "x\"é\n" * rng.choice([0, 1, 3, 17500, 12000]) if k % 37 == 5 else "ab" * (k % 50)
+        rows.append([["int64", k * 1_000_003], ["string", big], ["nil", None] if k % 7 == 0 else ["string", "t%d" % k], ["float64", k / 3]])
+    b = abi.batch_from_rows(schema, ["k", "s", "t", "d"], rows, "", "t")
+    for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
+        for o in ({}, {"add_closing_newline": True}):
+            ref = oracle.serialize(fmt, b, schema, _opts(o))
+            assert ref is not None
+            assert tf.serialize(fmt, tf.DeviceBatch.upload(b), _opts(o)).download() == ref, (fmt, o)

@@ -17,6 +17,8 @@
 #define __constant__ const
 #define __launch_bounds__(...)
 #define __shared__ static thread_local /* one instance per kernel and host thread: workgroups run one after another */
+/* dynamic LDS named at file scope (`extern __shared__ T name[];` in HIP): here a fixed 160 KiB per array */
+#define TF_DYNAMIC_LDS(type, name) static thread_local type name[(160 * 1024) / sizeof(type)]
 #define __builtin_amdgcn_fence(...) ((void)0)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };

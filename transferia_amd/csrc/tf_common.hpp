@@ -16,6 +16,11 @@
 
 #include "../../include/tfgpu.h"
 
+// dynamic LDS named at file scope (the CPU emulator's hip_runtime.h defines its own form)
+#ifndef TF_DYNAMIC_LDS
+#define TF_DYNAMIC_LDS(type, name) extern __shared__ type name[]
+#endif
+
 struct tfgpu_dbatch;
 
 namespace tf {

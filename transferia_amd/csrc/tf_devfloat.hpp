@@ -107,7 +107,7 @@ template <class S> __device__ __forceinline__ void put_exp(S &o, int exp) {  // 
 }
 // strconv.FormatFloat(f, fmt, -1, bits) for fmt 'f', 'e' and 'g' — 'g' with the shortest-mode threshold
 // (exponent < -4 || >= 21 is encoding/json's rule, not this one: here eprec = 6, or the digit count when larger).
-template <class S> __device__ void fmt_float(S &o, double f, char fmt, int bits) {
+template <class S> __device__ __forceinline__ void fmt_float(S &o, double f, char fmt, int bits) {
   if (f != f) { o.put('N'); o.put('a'); o.put('N'); return; }
   const bool neg = __double_as_longlong(f) < 0;
   if (f == INFINITY || f == -INFINITY) { o.put(neg ? '-' : '+'); o.put('I'); o.put('n'); o.put('f'); return; }
@@ -143,7 +143,7 @@ template <class S> __device__ void fmt_float(S &o, double f, char fmt, int bits)
 }
 // encoding/json floatEncoder: 'f' unless |f| < 1e-6 or >= 1e21, then 'e' with e-0X cleaned to e-X.  NaN / Inf are
 // an error in encoding/json: the caller must not come here with them.
-template <class S> __device__ void fmt_json_float(S &o, double f, int bits) {
+template <class S> __device__ __forceinline__ void fmt_json_float(S &o, double f, int bits) {
   const double a = f < 0 ? -f : f;
   bool e_form = false;
   if (a != 0) {

@@ -62,7 +62,7 @@ template <class S> __device__ __forceinline__ void put_lit(S &s, const char *p) 
 __device__ __forceinline__ uint32_t hexc(uint32_t n) { return n + (n < 10 ? '0' : 'a' - 10); }
 
 // writeQuoted (marshal.go:377-419)
-template <class S> __device__ void emit_ch_quoted(S &s, const uint8_t *p, uint32_t n) {
+template <class S> __device__ __forceinline__ void emit_ch_quoted(S &s, const uint8_t *p, uint32_t n) {
   s.put('"');
   for (uint32_t i = 0; i < n; i++) {
     if (i + 8 <= n) {  // eight bytes that need no escaping at once
@@ -82,7 +82,7 @@ template <class S> __device__ void emit_ch_quoted(S &s, const uint8_t *p, uint32
 }
 
 // encoding/json appendString: ", \, control bytes, invalid UTF-8 → �, U+2028/9; optional HTML escaping
-template <class S> __device__ void emit_json_string(S &s, const uint8_t *p, uint32_t n, bool html) {
+template <class S> __device__ __forceinline__ void emit_json_string(S &s, const uint8_t *p, uint32_t n, bool html) {
   s.put('"');
   uint32_t i = 0;
   while (i < n) {
@@ -121,7 +121,7 @@ template <class S> __device__ void emit_json_string(S &s, const uint8_t *p, uint
   s.put('"');
 }
 
-template <class S> __device__ void emit_base64(S &s, const uint8_t *p, uint32_t n) {  // base64.StdEncoding
+template <class S> __device__ __forceinline__ void emit_base64(S &s, const uint8_t *p, uint32_t n) {  // base64.StdEncoding
   const char *T = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
   uint32_t i = 0;
   for (; i + 3 <= n; i += 3) { uint32_t v = (p[i] << 16) | (p[i + 1] << 8) | p[i + 2]; s.put(T[v >> 18]); s.put(T[(v >> 12) & 63]); s.put(T[(v >> 6) & 63]); s.put(T[v & 63]); }
@@ -138,21 +138,75 @@ template <class S> __device__ __forceinline__ void emit_dec8(S &s, uint32_t v, b
   sink_word(s, w, nd, 0);
 }
 
+// exactly `width` (1..8) decimal digits of v, zero padded, as one word
+template <class S> __device__ __forceinline__ void emit_dec_pad(S &s, uint32_t v, uint32_t width) {
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < width; i++) { const uint32_t q = v / 10u; w = (w << 8) | ('0' + (v - q * 10u)); v = q; }
+  sink_word(s, w, width, 0);
+}
+// strconv.FormatUint / FormatInt(v, 10): eight-digit groups, each built in a register (no byte array: arrays indexed at run
+// time live in scratch memory, and a 19-digit hash column then costs ~80 scratch accesses per value)
+template <class S> __device__ __forceinline__ void emit_u64(S &s, uint64_t v) {
+  if (v < 100000000ull) { emit_dec8(s, (uint32_t)v, false); return; }
+  const uint64_t hi = v / 100000000ull;
+  const uint32_t lo = (uint32_t)(v - hi * 100000000ull);
+  if (hi < 100000000ull) emit_dec8(s, (uint32_t)hi, false);
+  else { const uint64_t top = hi / 100000000ull; emit_dec8(s, (uint32_t)top, false); emit_dec_pad(s, (uint32_t)(hi - top * 100000000ull), 8); }
+  emit_dec_pad(s, lo, 8);
+}
+template <class S> __device__ __forceinline__ void emit_i64(S &s, int64_t v) {
+  if (v < 0) { s.put('-'); emit_u64(s, (uint64_t)(-(v + 1)) + 1u); } else emit_u64(s, (uint64_t)v);
+}
+// time.Format pieces (UTC): "2006-01-02", "15:04:05", ".999999999" with trailing zeros trimmed — dev::fmt_date / fmt_clock /
+// fmt_frac9_trim without the byte window
+template <class S> __device__ __forceinline__ void emit_date(S &s, int64_t sec) {
+  int64_t y; int m, d;
+  dev::civil_from_days(dev::floordiv(sec, 86400), y, m, d);
+  uint64_t u = y < 0 ? (uint64_t)(-y) : (uint64_t)y;
+  if (y < 0) s.put('-');
+  if (u < 10000) emit_dec_pad(s, (uint32_t)u, 4); else emit_u64(s, u);
+  // "-MM-DD" as one word
+  const uint32_t mm = (uint32_t)m, dd = (uint32_t)d;
+  const uint64_t w = (uint64_t)'-' | (uint64_t)('0' + mm / 10) << 8 | (uint64_t)('0' + mm % 10) << 16 | (uint64_t)'-' << 24 | (uint64_t)('0' + dd / 10) << 32 | (uint64_t)('0' + dd % 10) << 40;
+  sink_word(s, w, 6, 0);
+}
+template <class S> __device__ __forceinline__ void emit_clock(S &s, int64_t sec) {
+  const uint32_t sod = (uint32_t)(sec - dev::floordiv(sec, 86400) * 86400);
+  const uint32_t h = sod / 3600u, mi = (sod / 60u) % 60u, ss = sod % 60u;
+  const uint64_t w = (uint64_t)('0' + h / 10) | (uint64_t)('0' + h % 10) << 8 | (uint64_t)':' << 16 | (uint64_t)('0' + mi / 10) << 24 | (uint64_t)('0' + mi % 10) << 32 |
+                     (uint64_t)':' << 40 | (uint64_t)('0' + ss / 10) << 48 | (uint64_t)('0' + ss % 10) << 56;
+  sink_word(s, w, 8, 0);
+}
+template <class S> __device__ __forceinline__ void emit_frac9_trim(S &s, int32_t nsec) {
+  if (nsec == 0) return;
+  uint32_t v = (uint32_t)nsec, n = 9;
+  while (v % 10u == 0) { v /= 10u; n--; }
+  s.put('.');
+  if (n == 9) { emit_dec_pad(s, v / 100000000u, 1); emit_dec_pad(s, v % 100000000u, 8); } else emit_dec_pad(s, v, n);
+}
+template <class S> __device__ __forceinline__ void emit_rfc3339nano(S &s, int64_t sec, int32_t nsec) {  // time.RFC3339Nano, UTC
+  emit_date(s, sec); s.put('T'); emit_clock(s, sec); emit_frac9_trim(s, nsec); s.put('Z');
+}
+template <class S> __device__ __forceinline__ void emit_time_string(S &s, int64_t sec, int32_t nsec) {  // Time.String(), UTC
+  emit_date(s, sec); s.put(' '); emit_clock(s, sec); emit_frac9_trim(s, nsec);
+  const char tail[] = " +0000 UTC";
+  for (int i = 0; i < 10; i++) s.put((uint32_t)tail[i]);
+}
+
 // strconv.FormatFloat(f, 'f', -1, bits) of a float column's value
-template <class S> __device__ void emit_float_f(S &s, const DCol &c, int64_t r) {
+template <class S> __device__ __forceinline__ void emit_float_f(S &s, const DCol &c, int64_t r) {
   if (c.repr == TFGPU_R_FLOAT32) dev::fmt_float(s, (double)((const float *)c.values)[r], 'f', 32);
   else dev::fmt_float(s, ((const double *)c.values)[r], 'f', 64);
 }
 
 // json.Marshal(float): encoding/json's floatEncoder
-template <class S> __device__ void emit_float_json(S &s, const DCol &c, int64_t r) {
+template <class S> __device__ __forceinline__ void emit_float_json(S &s, const DCol &c, int64_t r) {
   if (c.repr == TFGPU_R_FLOAT32) dev::fmt_json_float(s, (double)((const float *)c.values)[r], 32);
   else dev::fmt_json_float(s, ((const double *)c.values)[r], 64);
 }
 
 // The integer Go types as decimal text; returns false if the column is not an integer repr.
-template <class S> __device__ bool emit_int(S &s, const DCol &c, int64_t r) {
-  uint8_t t[24]; int n;
+template <class S> __device__ __forceinline__ bool emit_int(S &s, const DCol &c, int64_t r) {
   {  // the usual case: fewer than nine digits
     int64_t v; bool is_int = true;
     switch (c.repr) {
@@ -168,23 +222,22 @@ template <class S> __device__ bool emit_int(S &s, const DCol &c, int64_t r) {
     if (is_int && v > -100000000ll && v < 100000000ll) { emit_dec8(s, (uint32_t)(v < 0 ? -v : v), v < 0); return true; }
   }
   switch (c.repr) {
-    case TFGPU_R_INT8: n = dev::fmt_i64(t, ((const int8_t *)c.values)[r]); break;
-    case TFGPU_R_INT16: n = dev::fmt_i64(t, ((const int16_t *)c.values)[r]); break;
-    case TFGPU_R_INT32: n = dev::fmt_i64(t, ((const int32_t *)c.values)[r]); break;
-    case TFGPU_R_INT64: n = dev::fmt_i64(t, ((const int64_t *)c.values)[r]); break;
-    case TFGPU_R_UINT8: n = dev::fmt_u64(t, ((const uint8_t *)c.values)[r]); break;
-    case TFGPU_R_UINT16: n = dev::fmt_u64(t, ((const uint16_t *)c.values)[r]); break;
-    case TFGPU_R_UINT32: n = dev::fmt_u64(t, ((const uint32_t *)c.values)[r]); break;
-    case TFGPU_R_UINT64: n = dev::fmt_u64(t, ((const uint64_t *)c.values)[r]); break;
+    case TFGPU_R_INT8: emit_i64(s, ((const int8_t *)c.values)[r]); break;
+    case TFGPU_R_INT16: emit_i64(s, ((const int16_t *)c.values)[r]); break;
+    case TFGPU_R_INT32: emit_i64(s, ((const int32_t *)c.values)[r]); break;
+    case TFGPU_R_INT64: emit_i64(s, ((const int64_t *)c.values)[r]); break;
+    case TFGPU_R_UINT8: emit_u64(s, ((const uint8_t *)c.values)[r]); break;
+    case TFGPU_R_UINT16: emit_u64(s, ((const uint16_t *)c.values)[r]); break;
+    case TFGPU_R_UINT32: emit_u64(s, ((const uint32_t *)c.values)[r]); break;
+    case TFGPU_R_UINT64: emit_u64(s, ((const uint64_t *)c.values)[r]); break;
     default: return false;
   }
-  emit_small(s, t, n);
   return true;
 }
 
 // json.Marshal of one Go value held in a column cell (the encoding/json serializer's values, and the elements of
 // Collapse's key arrays): nil → null, []byte → base64, time.Time → RFC 3339, json.Number / pre-marshalled `any` verbatim.
-template <class S> __device__ void emit_json_cell(S &s, const DCol &c, int64_t r, int any_as_string, bool html) {
+template <class S> __device__ __forceinline__ void emit_json_cell(S &s, const DCol &c, int64_t r, int any_as_string, bool html) {
   if (!is_valid(c, r)) { put_lit(s, "null"); return; }
   const uint8_t *vp = nullptr; uint32_t vn = 0;
   if (c.offsets) { vp = c.data + c.offsets[r]; vn = c.offsets[r + 1] - c.offsets[r]; }
@@ -194,8 +247,8 @@ template <class S> __device__ void emit_json_cell(S &s, const DCol &c, int64_t r
     case TFGPU_R_STRING: emit_json_string(s, vp, vn, html); return;
     case TFGPU_R_BYTES: s.put('"'); emit_base64(s, vp, vn); s.put('"'); return;
     case TFGPU_R_JSONNUM: if (vn) put_bytes(s, vp, vn); else s.put('0'); return;
-    case TFGPU_R_TIME: { s.put('"'); int n = dev::fmt_rfc3339nano(t, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); emit_small(s, t, n); s.put('"'); return; }
-    case TFGPU_R_DURATION: { int n = dev::fmt_i64(t, ((const int64_t *)c.values)[r]); emit_small(s, t, n); return; }
+    case TFGPU_R_TIME: s.put('"'); emit_rfc3339nano(s, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); s.put('"'); return;
+    case TFGPU_R_DURATION: emit_i64(s, ((const int64_t *)c.values)[r]); return;
     case TFGPU_R_JSON:
       if (c.dtype == TFGPU_T_ANY && any_as_string) emit_json_string(s, vp, vn, html);
       else put_bytes(s, vp, vn);

@@ -16,6 +16,7 @@
 
 #include "tf_emit.hpp"
 #include "tf_f64range.hpp"
+#include "tf_wave.hpp"
 
 namespace tf {
 
@@ -58,13 +59,14 @@ struct SerParams {
   int32_t *last_present;   // CH: index of the last emitted column per row, -1 = none
   unsigned long long *total64;  // sum of the row lengths (the offsets are 32-bit)
   uint8_t *out;
+  int32_t ablate;          // TFGPU_SER_ABLATE (measurement only): 1 = the write pass skips text cells, 2 = it skips the others, 3 = the len pass skips text cells
   QueueParams q;
 };
 
 __device__ __forceinline__ int64_t pow10_i64(int k) { int64_t r = 1; while (k-- > 0) r *= 10; return r; }
 
 // ---- one value, ClickHouse JSONEachRow (marshalValue).  Returns false when the column is skipped. ----
-template <class S> __device__ bool emit_ch_value(S &s, const SCol &sc, int64_t r, int any_as_string) {
+template <class S> __device__ __forceinline__ bool emit_ch_value(S &s, const SCol &sc, int64_t r, int any_as_string) {
   const DCol &c = sc.c;
   const bool is_text = c.repr == TFGPU_R_STRING || c.repr == TFGPU_R_BYTES;
   const uint8_t *vp = nullptr; uint32_t vn = 0;
@@ -90,7 +92,7 @@ template <class S> __device__ bool emit_ch_value(S &s, const SCol &sc, int64_t r
     case TFGPU_T_BYTES: case TFGPU_T_UTF8:
       if (c.repr == TFGPU_R_STRING) { emit_ch_quoted(s, vp, vn); return true; }
       if (c.repr == TFGPU_R_BYTES) {
-        if (fl & TFGPU_CH_ARRAY) { s.put('['); for (uint32_t i = 0; i < vn; i++) { if (i) s.put(','); int n = dev::fmt_u64(t, vp[i]); emit_small(s, t, n); } s.put(']'); }
+        if (fl & TFGPU_CH_ARRAY) { s.put('['); for (uint32_t i = 0; i < vn; i++) { if (i) s.put(','); emit_u64(s, vp[i]); } s.put(']'); }
         else emit_ch_quoted(s, vp, vn);
         return true;
       }
@@ -101,13 +103,13 @@ template <class S> __device__ bool emit_ch_value(S &s, const SCol &sc, int64_t r
     case TFGPU_T_DATE: case TFGPU_T_DATETIME: case TFGPU_T_TIMESTAMP:
       if (c.repr == TFGPU_R_TIME) {  // marshalTime :65-80
         const int64_t sec = ((const int64_t *)c.values)[r]; const int32_t ns = c.nanos ? c.nanos[r] : 0;
-        if (fl & TFGPU_CH_STRING) { s.put('"'); int n = dev::fmt_time_string(t, sec, ns); emit_small(s, t, n); s.put('"'); }
+        if (fl & TFGPU_CH_STRING) { s.put('"'); emit_time_string(s, sec, ns); s.put('"'); }
         else if (fl & TFGPU_CH_DATETIME64) {
           int64_t full = sec * 1000000000LL + ns;
           if (sc.prec > 0 && sc.prec < 9) full = full / pow10_i64(9 - (int)sc.prec);
-          int n = dev::fmt_i64(t, full); emit_small(s, t, n);
-        } else if (fl & TFGPU_CH_DATE) { s.put('"'); int n = dev::fmt_date(t, sec); emit_small(s, t, n); s.put('"'); }
-        else { int n = dev::fmt_i64(t, sec); emit_small(s, t, n); }
+          emit_i64(s, full);
+        } else if (fl & TFGPU_CH_DATE) { s.put('"'); emit_date(s, sec); s.put('"'); }
+        else emit_i64(s, sec);
         return true;
       }
       break;
@@ -116,7 +118,7 @@ template <class S> __device__ bool emit_ch_value(S &s, const SCol &sc, int64_t r
   // marshalGeneric :318-359
   if (c.repr == TFGPU_R_STRING) { emit_ch_quoted(s, vp, vn); return true; }
   if (c.repr == TFGPU_R_BYTES) {
-    if (fl & TFGPU_CH_ARRAY) { s.put('['); for (uint32_t i = 0; i < vn; i++) { if (i) s.put(','); int n = dev::fmt_u64(t, vp[i]); emit_small(s, t, n); } s.put(']'); }
+    if (fl & TFGPU_CH_ARRAY) { s.put('['); for (uint32_t i = 0; i < vn; i++) { if (i) s.put(','); emit_u64(s, vp[i]); } s.put(']'); }
     else emit_ch_quoted(s, vp, vn);
     return true;
   }
@@ -124,7 +126,7 @@ template <class S> __device__ bool emit_ch_value(S &s, const SCol &sc, int64_t r
   const bool dbl = c.dtype != TFGPU_T_ANY || any_as_string || (fl & TFGPU_CH_STRING);
   if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) { if (dbl) s.put('"'); emit_int(s, c, r); if (dbl) s.put('"'); return true; }
   if (c.repr == TFGPU_R_BOOL) { if (dbl) s.put('"'); put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); if (dbl) s.put('"'); return true; }
-  if (c.repr == TFGPU_R_DURATION) { if (dbl) s.put('"'); int n = dev::fmt_i64(t, ((const int64_t *)c.values)[r]); emit_small(s, t, n); if (dbl) s.put('"'); return true; }
+  if (c.repr == TFGPU_R_DURATION) { if (dbl) s.put('"'); emit_i64(s, ((const int64_t *)c.values)[r]); if (dbl) s.put('"'); return true; }
   if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { if (dbl) s.put('"'); emit_float_json(s, c, r); if (dbl) s.put('"'); return true; }
   if (c.repr == TFGPU_R_JSONNUM || c.repr == TFGPU_R_JSON) {
     if (c.repr == TFGPU_R_JSONNUM && vn == 0) { if (dbl) s.put('"'); s.put('0'); if (dbl) s.put('"'); return true; }  // json.Number("") encodes as 0
@@ -156,7 +158,7 @@ __device__ bool csv_needs_quotes(const uint8_t *p, uint32_t n) {  // Writer.fiel
   }
   return false;
 }
-template <class S> __device__ void emit_csv_field(S &s, const SCol &sc, int64_t r) {
+template <class S> __device__ __forceinline__ void emit_csv_field(S &s, const SCol &sc, int64_t r) {
   const DCol &c = sc.c;
   if (!is_valid(c, r)) return;  // nil → ""
   const uint8_t *vp = nullptr; uint32_t vn = 0;
@@ -173,7 +175,7 @@ template <class S> __device__ void emit_csv_field(S &s, const SCol &sc, int64_t 
       else put_bytes(s, vp, vn);
       return;
     case TFGPU_R_BOOL: put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); return;
-    case TFGPU_R_TIME: { int n = dev::fmt_time_string(t, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); emit_small(s, t, n); return; }  // fmt.Stringer
+    case TFGPU_R_TIME: emit_time_string(s, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); return;  // fmt.Stringer
     case TFGPU_R_DURATION: { int n = dev::fmt_duration(t, ((const int64_t *)c.values)[r]); emit_small(s, t, n); return; }
     case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_f(s, c, r); return;
     default: emit_int(s, c, r);
@@ -190,7 +192,7 @@ __device__ __forceinline__ bool q_applies(const SerParams &p, uint32_t apply, in
   }
 }
 // bytes a Marshaler returned, as json.Marshal's compact(escapeHTML) leaves them: <, >, & and U+2028/9 become \uXXXX
-template <class S> __device__ void put_html_compact(S &s, const uint8_t *p, uint32_t n) {
+template <class S> __device__ __forceinline__ void put_html_compact(S &s, const uint8_t *p, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {
     const uint32_t c = p[i];
     if (c == '<' || c == '>' || c == '&') { put_lit(s, "\\u00"); s.put(hexc(c >> 4)); s.put(hexc(c & 15)); }
@@ -198,29 +200,29 @@ template <class S> __device__ void put_html_compact(S &s, const uint8_t *p, uint
     else s.put(c);
   }
 }
-template <class S> __device__ void emit_meta_string(S &s, const uint32_t *off, const uint8_t *data, int64_t k) {
+template <class S> __device__ __forceinline__ void emit_meta_string(S &s, const uint32_t *off, const uint8_t *data, int64_t k) {
   if (!off) { s.put('"'); s.put('"'); return; }
   emit_json_string(s, data + off[k], off[k + 1] - off[k], true);
 }
-template <class S> __device__ void emit_native_header(S &s, const SerParams &p, int64_t r) {
+template <class S> __device__ __forceinline__ void emit_native_header(S &s, const SerParams &p, int64_t r) {
   const QueueParams &q = p.q;
   const int64_t k = q.src_row ? q.src_row[r] : r;
   uint8_t t[24]; int n;
-  put_lit(s, "{\"id\":"); n = dev::fmt_u64(t, q.m_id ? q.m_id[k] : 0u); emit_small(s, t, n);
-  put_lit(s, ",\"nextlsn\":"); n = dev::fmt_u64(t, q.m_lsn ? q.m_lsn[k] : 0ull); emit_small(s, t, n);
-  put_lit(s, ",\"commitTime\":"); n = dev::fmt_u64(t, q.m_commit ? q.m_commit[k] : 0ull); emit_small(s, t, n);
-  put_lit(s, ",\"txPosition\":"); n = dev::fmt_i64(t, q.m_counter ? q.m_counter[k] : 0ll); emit_small(s, t, n);
+  put_lit(s, "{\"id\":"); emit_u64(s, q.m_id ? q.m_id[k] : 0u);
+  put_lit(s, ",\"nextlsn\":"); emit_u64(s, q.m_lsn ? q.m_lsn[k] : 0ull);
+  put_lit(s, ",\"commitTime\":"); emit_u64(s, q.m_commit ? q.m_commit[k] : 0ull);
+  put_lit(s, ",\"txPosition\":"); emit_i64(s, q.m_counter ? q.m_counter[k] : 0ll);
   const uint32_t kd = q.kind ? q.kind[r] : (uint32_t)TFGPU_K_INSERT;
   put_lit(s, ",\"kind\":\""); put_lit(s, kd == TFGPU_K_INSERT ? "insert" : kd == TFGPU_K_UPDATE ? "update" : "delete"); s.put('"');
   put_bytes(s, p.blob + q.hdr_off, q.hdr_len);
   if (q.gpart) {  // PartID of the row's group, already a JSON string
     int g = 0; while (g + 1 < q.ngroups && r >= q.gstart[g + 1]) g++;
     put_bytes(s, p.blob + q.gpart[g], q.gpart[g + 1] - q.gpart[g]);
-  } else { s.put('"'); if (q.part_id) { n = dev::fmt_u64(t, q.part_id[r]); emit_small(s, t, n); } s.put('"'); }
+  } else { s.put('"'); if (q.part_id) emit_u64(s, q.part_id[r]); s.put('"'); }
   const uint32_t form = q.m_form ? q.m_form[k] : 0u;
   if (form == 1) put_lit(s, ",\"columnnames\":null"); else if (form != 0) put_lit(s, ",\"columnnames\":[]");
 }
-template <class S> __device__ void emit_native_trailer(S &s, const SerParams &p, int64_t r) {
+template <class S> __device__ __forceinline__ void emit_native_trailer(S &s, const SerParams &p, int64_t r) {
   const QueueParams &q = p.q;
   const int64_t k = q.src_row ? q.src_row[r] : r;
   if (q_applies(p, QA_OLD, r)) s.put(']');
@@ -229,7 +231,7 @@ template <class S> __device__ void emit_native_trailer(S &s, const SerParams &p,
   put_lit(s, ",\"query\":"); emit_meta_string(s, q.m_q_off, q.m_q, k);
   s.put('}');
 }
-template <class S> __device__ bool emit_queue_cell(S &s, const SerParams &p, const SCol &sc, int64_t r) {
+template <class S> __device__ __forceinline__ bool emit_queue_cell(S &s, const SerParams &p, const SCol &sc, int64_t r) {
   if (!q_applies(p, sc.apply, r)) return false;
   switch (sc.kind) {
     case QC_HEADER: emit_native_header(s, p, r); return true;
@@ -268,6 +270,19 @@ template <class S> __device__ __forceinline__ bool emit_cell(S &s, const SerPara
   }
 }
 
+// the same with the format fixed at compile time and no queue formats: the tile kernels instantiate one format each, which
+// keeps the other formats' code (and the registers it would spill) out of their loops
+template <int FMT, class S> __device__ __forceinline__ bool emit_cell_fmt(S &s, const SerParams &p, const SCol &sc, int64_t r) {
+  if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) {
+    if (!is_valid(sc.c, r)) return false;
+    put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
+    return emit_ch_value(s, sc, r, p.any_as_string);
+  }
+  put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
+  if (FMT == TFGPU_FMT_JSON) emit_json_value(s, sc, r, p.any_as_string); else emit_csv_field(s, sc, r);
+  return true;
+}
+
 // (1) cell lengths; item = column * nrows + row
 __global__ void __launch_bounds__(256) ser_cell_len(SerParams p) {
   const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +290,7 @@ __global__ void __launch_bounds__(256) ser_cell_len(SerParams p) {
   const int32_t ci = (int32_t)(it / p.nrows); const int64_t r = it - (int64_t)ci * p.nrows;
   if (p.q.qformat && p.cols[ci].kind == QC_CONST) { p.cell[it] = q_applies(p, p.cols[ci].apply, r) ? p.cols[ci].pre_len : 0u; return; }
   CountSink s;
+  if (p.ablate == 3 && (p.cols[ci].c.repr == TFGPU_R_STRING || p.cols[ci].c.repr == TFGPU_R_BYTES)) { p.cell[it] = 8; return; }
   const bool present = emit_cell(s, p, p.cols[ci], r);
   uint32_t n = present ? s.n : 0;
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW && present) n += 1;  // its ',' (or the closing '}' for the last one)
@@ -310,7 +326,10 @@ __global__ void __launch_bounds__(256) ser_cell_write(SerParams p) {
   const SCol &sc = p.cols[ci];
   if (p.q.qformat && ((sc.kind == QC_CONST && sc.pre_len > QCONST_INLINE) || !q_applies(p, sc.apply, r))) return;
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW && !is_valid(sc.c, r)) return;
-  const uint64_t base = (uint64_t)p.row_len[r] + p.cell[it];
+  uint64_t base = (uint64_t)p.row_len[r] + p.cell[it];
+  if (p.ablate == 4) base = (uint64_t)(it % (int64_t)(p.row_len[p.nrows] / 24)) * 24;  // measurement: every cell at a lane-contiguous 24-byte slot
+  if (p.ablate && p.ablate != 4) { const bool text = sc.c.repr == TFGPU_R_STRING || sc.c.repr == TFGPU_R_BYTES; if ((p.ablate == 1 || p.ablate == 3) == text) return; }
+  if (p.ablate == 4 && (sc.c.repr == TFGPU_R_STRING || sc.c.repr == TFGPU_R_BYTES)) return;
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW) {
     // a null-marshalling value must leave no bytes: probe first (rare: only `any` columns can do it)
     if (sc.c.repr == TFGPU_R_JSON || sc.c.repr == TFGPU_R_JSONNUM) { CountSink probe; if (!emit_cell(probe, p, sc, r)) return; }
@@ -336,6 +355,156 @@ __global__ void __launch_bounds__(256) ser_row_frame(SerParams p) {
   const bool nl = p.closing_newline || r + 1 < p.nrows;
   row[len - 1 - (nl ? 1 : 0)] = '}';
   if (nl) row[len - 1] = '\n';
+}
+
+// (4') cells at their final position, one workgroup per run of consecutive rows, the run's text assembled in LDS first.
+// ser_cell_write scatters: a cell's ~20 bytes land in the middle of a row that 100 other lanes fill at other times, so HBM
+// sees every 8-byte store as its own masked partial write (measured on configs[3]: 19 GB of writes for 2.5 GB of text, the
+// kernel bound by that).  Here the lanes drop their bytes into an LDS image of the run (disjoint bytes OR-ed into zeroed
+// words: no alignment rules, no ordering) and the image leaves as whole aligned words, 512 consecutive bytes per wave store.
+// Runs whose text exceeds the image are written the old way by the same workgroup.
+constexpr uint32_t TILE_WORDS = 12288;  // 48 KiB image: three workgroups per CU
+TF_DYNAMIC_LDS(uint32_t, img);           // dynamic LDS, named at file scope so that the sink's atomics are ds_or_b32 (through a
+                                          // pointer member they compile to flat_atomic_or: the flat path, several times slower)
+struct LdsSink {
+  uint32_t pos; uint64_t acc = 0; uint32_t n = 0;
+  // the low k (1..8) bytes of v (upper bytes zero) at byte position pos
+  __device__ __forceinline__ void store(uint64_t v, uint32_t k) {
+    const uint32_t w = pos >> 2, a = pos & 3u, sh = a * 8;
+    atomicOr(&img[w], (uint32_t)(v << sh));
+    if (a + k > 4) atomicOr(&img[w + 1], sh ? (uint32_t)(v >> (32 - sh)) : (uint32_t)(v >> 32));
+    if (a + k > 8) atomicOr(&img[w + 2], (uint32_t)(v >> (64 - sh)));
+    pos += k;
+  }
+  __device__ __forceinline__ void put(uint32_t c) {
+    acc |= (uint64_t)(c & 0xFFu) << (8 * n);
+    if (++n == 8) { store(acc, 8); acc = 0; n = 0; }
+  }
+  __device__ __forceinline__ void put_word(uint64_t w, uint32_t k) {
+    acc |= w << (8 * n);
+    const uint32_t t = n + k;
+    if (t >= 8) { store(acc, 8); acc = n ? w >> (8 * (8 - n)) : 0; n = t - 8; } else n = t;
+  }
+  __device__ __forceinline__ void flush() { if (n) { store(acc, n); acc = 0; n = 0; } }
+};
+// One workgroup = 64 consecutive rows x one chunk of consecutive columns.  Every wave keeps the scatter kernel's shape — one
+// column per step, lane = row: uniform control flow, scalar column descriptors, coalesced value loads — but the bytes go to the
+// LDS image, where the chunk's cells of one row form one contiguous SEGMENT; the segments then leave as aligned 8-byte words.
+template <int FMT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) ser_tile_write(SerParams p, int32_t cols_per_chunk, int32_t nchunks, uint32_t *big, uint32_t *nbig) {
+  __shared__ uint32_t seg_at[65], seg_src[64];   // segment rr: image bytes [seg_at[rr], seg_at[rr+1]), row bytes from seg_src[rr]
+  const int64_t r0 = (int64_t)(blockIdx.x / nchunks) * 64;
+  const int32_t c0 = (int32_t)(blockIdx.x % nchunks) * cols_per_chunk, c1 = min(p.ncols, c0 + cols_per_chunk);
+  const int nr = (int)(p.nrows - r0 < 64 ? p.nrows - r0 : 64);
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: the column descriptor stays in SGPRs
+  if (wave == 0) {
+    uint32_t s = 0, len = 0;
+    if (lane < nr) {
+      const int64_t r = r0 + lane;
+      s = c0 == 0 ? 0u : p.cell[(int64_t)c0 * p.nrows + r];
+      const uint32_t e = c1 == p.ncols ? p.row_len[r + 1] - p.row_len[r] : p.cell[(int64_t)c1 * p.nrows + r];
+      len = e - s;
+    }
+    const uint32_t incl = wave_scan_add(len);   // segments start on 4-byte boundaries of the image? no: packed, byte granular
+    seg_src[lane] = s; seg_at[lane] = incl - len;
+    if (lane == 63) seg_at[64] = incl;
+  }
+  __syncthreads();
+  const uint32_t bytes = seg_at[64];
+  if (bytes > TILE_WORDS * 4 - 16) {  // the tile outgrows the image: ser_tile_scatter writes it straight to HBM
+    if (t == 0) big[atomicAdd(nbig, 1u)] = blockIdx.x;
+    return;
+  }
+  for (uint32_t i = t; i < (bytes + 19) / 4; i += 256) img[i] = 0;
+  __syncthreads();
+  const int64_t r = r0 + lane;
+  const bool live = lane < nr;
+  const uint32_t row_at = live ? p.row_len[r] : 0u;
+  constexpr bool closer = FMT == TFGPU_FMT_CH_JSON_EACH_ROW;
+  for (int32_t cv = c0 + wave; cv < c1; cv += 4) {
+    const int32_t ci = __builtin_amdgcn_readfirstlane(cv);  // wave-uniform by construction; said so, the descriptor loads are scalar
+    const SCol &sc = p.cols[ci];
+    if (!live) continue;
+    if (closer && !is_valid(sc.c, r)) continue;
+    if (closer && (sc.c.repr == TFGPU_R_JSON || sc.c.repr == TFGPU_R_JSONNUM)) { CountSink probe; if (!emit_cell_fmt<FMT>(probe, p, sc, r)) continue; }
+    const uint32_t off = p.cell[(int64_t)ci * p.nrows + r];
+    LdsSink w{seg_at[lane] + (off - seg_src[lane])};
+    emit_cell_fmt<FMT>(w, p, sc, r);
+    if (closer) w.put((p.last_present[r] == ci) ? '}' : ',');
+    w.flush();
+  }
+  // the row frames (ser_row_frame): '{' belongs to the first chunk's segment, the tail to the last one's
+  if (wave == 0 && live) {
+    const uint32_t len = p.row_len[r + 1] - row_at;
+    auto byte_at = [&](uint32_t o, uint32_t c) {
+      const uint32_t q = seg_at[lane] + (o - seg_src[lane]);
+      atomicOr(&img[q >> 2], c << ((q & 3u) * 8));
+    };
+    if (c0 == 0 && FMT != TFGPU_FMT_CSV) byte_at(0, '{');
+    if (c1 == p.ncols) {
+      if (FMT == TFGPU_FMT_CSV) byte_at(len - 1, '\n');
+      else if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) { if (p.last_present[r] < 0) byte_at(len - 2, '}'); byte_at(len - 1, '\n'); }
+      else {
+        const bool nl = p.closing_newline || r + 1 < p.nrows;
+        byte_at(len - 1 - (nl ? 1 : 0), '}');
+        if (nl) byte_at(len - 1, '\n');
+      }
+    }
+  }
+  __syncthreads();
+  // segments → HBM, 16 rows per wave: bytes up to the destination's first 8-byte boundary, whole aligned words, the tail
+  auto img_byte = [&](uint32_t o) { return (uint8_t)(img[o >> 2] >> ((o & 3u) * 8)); };
+  for (int rr = wave; rr < nr; rr += 4) {
+    const uint32_t a = seg_at[rr], n = seg_at[rr + 1] - a;
+    uint8_t *dst = p.out + (uint64_t)p.row_len[r0 + rr] + seg_src[rr];
+    const uint32_t head = min((uint32_t)((8 - (reinterpret_cast<uintptr_t>(dst) & 7)) & 7), n);
+    if ((uint32_t)lane < head) dst[lane] = img_byte(a + lane);
+    const uint32_t nw = (n - head) >> 3;
+    for (uint32_t i = lane; i < nw; i += 64) {
+      const uint32_t o = a + head + i * 8, w = o >> 2, sh = (o & 3u) * 8;
+      const uint64_t lo = img[w] | ((uint64_t)img[w + 1] << 32);
+      const uint64_t v = sh ? (lo >> sh) | ((uint64_t)img[w + 2] << (64 - sh)) : lo;
+      *reinterpret_cast<uint64_t *>(dst + head + i * 8) = v;
+    }
+    const uint32_t done = head + nw * 8;
+    if (lane < 8 && done + lane < n) dst[done + lane] = img_byte(a + done + lane);
+  }
+}
+
+// the tiles ser_tile_write listed (one huge cell makes 64 rows of a chunk outgrow the image): lane per cell, scattered stores
+__global__ void __launch_bounds__(256) ser_tile_scatter(SerParams p, int32_t cols_per_chunk, int32_t nchunks, const uint32_t *big, const uint32_t *nbig) {
+  for (uint32_t k = blockIdx.x; k < *nbig; k += gridDim.x) {
+    const uint32_t tile = big[k];
+    const int64_t r0 = (int64_t)(tile / nchunks) * 64;
+    const int32_t c0 = (int32_t)(tile % nchunks) * cols_per_chunk, c1 = min(p.ncols, c0 + cols_per_chunk);
+    const int nr = (int)(p.nrows - r0 < 64 ? p.nrows - r0 : 64);
+    const bool closer = p.format == TFGPU_FMT_CH_JSON_EACH_ROW;
+    for (int it = threadIdx.x; it < (c1 - c0) * nr; it += 256) {
+      const int32_t ci = c0 + it / nr; const int64_t r = r0 + it % nr;
+      const SCol &sc = p.cols[ci];
+      if (closer && !is_valid(sc.c, r)) continue;
+      if (closer && (sc.c.repr == TFGPU_R_JSON || sc.c.repr == TFGPU_R_JSONNUM)) { CountSink probe; if (!emit_cell(probe, p, sc, r)) continue; }
+      WriteSink w{p.out + (uint64_t)p.row_len[r] + p.cell[(int64_t)ci * p.nrows + r]};
+      emit_cell(w, p, sc, r);
+      if (closer) w.put((p.last_present[r] == ci) ? '}' : ',');
+      w.flush();
+    }
+    if ((int)threadIdx.x < nr) {
+      const int64_t r = r0 + threadIdx.x;
+      uint8_t *row = p.out + p.row_len[r];
+      const uint32_t len = p.row_len[r + 1] - p.row_len[r];
+      if (c0 == 0 && p.format != TFGPU_FMT_CSV) row[0] = '{';
+      if (c1 == p.ncols) {
+        if (p.format == TFGPU_FMT_CSV) row[len - 1] = '\n';
+        else if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW) { if (p.last_present[r] < 0) row[len - 2] = '}'; row[len - 1] = '\n'; }
+        else {
+          const bool nl = p.closing_newline || r + 1 < p.nrows;
+          row[len - 1 - (nl ? 1 : 0)] = '}';
+          if (nl) row[len - 1] = '\n';
+        }
+      }
+    }
+  }
 }
 
 // queue formats: the message frame once the cut plan is known.  Native: "[" before the first element of a message, ","
@@ -575,6 +744,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     Buf cell = dalloc((size_t)std::max(ncols, 1) * (size_t)n * 4), row_len = dalloc((size_t)(n + 1) * 4 + 16), last = dalloc((size_t)n * 4 + 16);
     SerParams p{};
     p.cols = ptr<SCol>(bsc); p.ncols = ncols; p.nrows = n; p.format = format; p.any_as_string = any_as_string;
+    { const char *ab = std::getenv("TFGPU_SER_ABLATE"); p.ablate = ab ? std::atoi(ab) : 0; }
     p.closing_newline = opts ? opts->add_closing_newline : 0;
     p.blob = ptr<uint8_t>(bblob); p.cell = ptr<uint32_t>(cell); p.row_len = ptr<uint32_t>(row_len); p.last_present = ptr<int32_t>(last);
     Buf tot64 = dalloc_zero(8);
@@ -591,8 +761,23 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     res->size = *htot;
     res->mem = dalloc(res->size + 64);
     p.out = ptr<uint8_t>(res->mem);
-    { KernelTimer t("ser_cell_write"); if (ncell) ser_cell_write<<<blocks(ncell), 256, 0, st>>>(p); }
-    { KernelTimer t("ser_row_frame"); ser_row_frame<<<blocks(n), 256, 0, st>>>(p); }
+    static const bool scatter = [] { const char *e = std::getenv("TFGPU_SER_SCATTER"); return e && *e == '1'; }();  // the previous write pass, for A/B runs
+    if (scatter) {
+      { KernelTimer t("ser_cell_write"); if (ncell) ser_cell_write<<<blocks(ncell), 256, 0, st>>>(p); }
+      { KernelTimer t("ser_row_frame"); ser_row_frame<<<blocks(n), 256, 0, st>>>(p); }
+    } else {
+      // columns per workgroup: 64 rows of the chunk are about 36 KB of text on average, so a tile rarely outgrows the 48 KiB image
+      const uint64_t avg_cell = std::max<uint64_t>(res->size / ((uint64_t)n * (uint64_t)std::max(ncols, 1)), 1);
+      const int32_t cpc = (int32_t)std::min<uint64_t>(std::max<uint64_t>(36000 / (64 * avg_cell), 1), (uint64_t)std::max(ncols, 1));
+      const int32_t nchunks = (std::max(ncols, 1) + cpc - 1) / cpc;
+      const int64_t ntiles = ((n + 63) / 64) * nchunks;
+      Buf big = dalloc_zero((size_t)(ntiles + 1) * 4);
+      KernelTimer t("ser_tile_write");
+      if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_tile_write<TFGPU_FMT_CH_JSON_EACH_ROW><<<(unsigned)ntiles, 256, TILE_WORDS * 4, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
+      else if (format == TFGPU_FMT_JSON) ser_tile_write<TFGPU_FMT_JSON><<<(unsigned)ntiles, 256, TILE_WORDS * 4, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
+      else ser_tile_write<TFGPU_FMT_CSV><<<(unsigned)ntiles, 256, TILE_WORDS * 4, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
+      ser_tile_scatter<<<(unsigned)std::min<int64_t>(ntiles, 1024), 256, 0, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
+    }
     *out = res.release();
     return TFGPU_OK;
   } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }

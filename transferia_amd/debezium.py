@@ -191,11 +191,15 @@ class Parser:
     def parse(self, data, msgs: Optional[abi.CMessages] = None, host_bytes: Optional[bytes] = None):
         lib = self.lib
         frames = lib.debezium_unpack(data, msgs)
-        errors = {int(m): int(frames["code"][m]) for m in np.nonzero(frames["code"])[0]}
+        bad = np.nonzero(frames["code"])[0]
+        errors = dict(zip(bad.tolist(), frames["code"][bad].tolist()))
         ok = np.nonzero(frames["code"] == 0)[0]
         groups: Dict[Tuple[int, int], int] = {}
-        for m in ok:  # first message of every distinct schema
-            groups.setdefault((int(frames["schema_hash"][m][0]), int(frames["schema_hash"][m][1])), int(m))
+        if len(ok):  # first message of every distinct schema
+            hashes = frames["schema_hash"][ok]
+            _u, first = np.unique(hashes, axis=0, return_index=True)
+            for i in sorted(first):
+                groups[(int(hashes[i][0]), int(hashes[i][1]))] = int(ok[i])
         out = []
         for key, m in groups.items():
             if key not in self.cache:
