@@ -289,7 +289,7 @@ class CsvWorkload(Base):
         rows, sel = s["parsed_rows"], s["out_rows"] / max(s["parsed_rows"], 1)
         # compaction: fixed-width values, and for the late-materialised text columns 8 bytes per cell (length + position)
         gather = int((1 + sel) * (s["fixed_bytes"] + 8 * s["nstr"] * rows))
-        return {"csv_count_newlines": self.csv_bytes, "csv_parse_tiles": self.csv_bytes + s["fixed_bytes"],  # read every input byte once, write every fixed-width value once
+        return {"csv_count_newlines": self.csv_bytes, "csv_parse_regular": self.csv_bytes + s["fixed_bytes"],  # read every input byte once, write every fixed-width value once
                 "csv_parse_rows": self.csv_bytes + s["fixed_bytes"], "csv_copy_words": 2 * s["str_bytes"], "scan_u32_segments": 12 * rows * s["nstr"],
                 "mask_hmac_sha256": 72 * rows,                  # 4 B in + 64 B hex + 4 B offset per value
                 "filter_rows_eval": int((8 + 4 + 0.125) * rows), "compact_gather": gather, "scan_u32": 12 * rows}

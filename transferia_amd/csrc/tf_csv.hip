@@ -2220,7 +2220,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   } else if (nlines) {
     // header lines are parsed by nobody: err[] of the data rows is written by exactly one of the two kernels
     const int64_t per_xcd = (ntiles + 7) / 8;
-    { KernelTimer t("csv_parse_tiles"); csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
+    { KernelTimer t("csv_parse_regular"); csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_tiles_general"); csv_parse_tiles_general<<<(unsigned)std::min<int64_t>(ntiles, 2048), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 1024), 64, 0, st>>>(pp); }
   }
