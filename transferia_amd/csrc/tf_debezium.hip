@@ -56,6 +56,8 @@ struct Params {
   uint32_t *nerr;
   unsigned long long *first_ok;                // lowest good message (atomicMin)
   const double *p10; const uint64_t *p128;
+  // the fast path of dbz_unpack: messages that start with the bytes message `ref` holds in front of its payload value
+  int64_t ref; uint32_t plen; uint8_t *same;   // same[m] = 1: the first plen bytes equal the reference's
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t h, uint64_t w) { h ^= w; h *= 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
@@ -76,6 +78,7 @@ __device__ int key_is(MemBytes &rd, uint32_t ks, uint32_t ke, const char *lit, u
 }
 
 // ---- IncludeSchema.Unpack ---------------------------------------------------------------------------------------------
+__device__ bool unpack_fast(const Params &p, int64_t m);
 __device__ void unpack_message(const Params &p, int64_t m) {
   tfgpu_dbz_frame fr{};
   MemBytes rd(p.data);
@@ -140,6 +143,62 @@ __device__ void unpack_message(const Params &p, int64_t m) {
 __global__ void __launch_bounds__(128) dbz_unpack(Params p) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m < p.nmsg) unpack_message(p, m);
+}
+__global__ void __launch_bounds__(128) dbz_unpack_rest(Params p) {   // every message but the reference, which is done
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.nmsg || m == p.ref) return;
+  if (p.same[m] && unpack_fast(p, m)) return;
+  unpack_message(p, m);
+}
+
+// The reference caches the compiled schema by a hash of its bytes (receiver.go:61-66) because a topic repeats ONE schema in
+// every message.  Made literal: the message that opens the batch is walked in full; every other message whose first `plen`
+// bytes — everything in front of the payload value: `{"schema":{…12 KB…},"payload":` — equal the reference's inherits its
+// schema span and hash, and only its payload value and the closing brace are validated.  A wave compares one message
+// (64 lanes x 8 bytes per step: a memcmp at HBM speed instead of a 12 KB serial walk per lane).
+__device__ __forceinline__ uint64_t read8u(const uint8_t *base, uint64_t a) {  // 8 bytes at any alignment (buffers carry >= 64 bytes of slack)
+  const uint32_t sh = (uint32_t)(a & 7) * 8;
+  const uint64_t *q = reinterpret_cast<const uint64_t *>(base + (a & ~7ull));
+  const uint64_t x = q[0];
+  return sh ? (x >> sh) | (q[1] << (64 - sh)) : x;
+}
+__global__ void __launch_bounds__(256) dbz_prefix_same(Params p) {
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.nmsg) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t a = p.ms[m], r = p.ms[p.ref];
+  bool diff = (uint64_t)p.ms[m + 1] - a < (uint64_t)p.plen + 2;   // room for a value and the closing brace
+  if (!diff) {
+    const uint32_t nw = p.plen >> 3;
+    for (uint32_t w = lane; w < nw; w += 64) diff |= read8u(p.data, a + 8ull * w) != read8u(p.data, r + 8ull * w);
+    const uint32_t tail = p.plen & 7u;
+    if (lane == 0 && tail) { const uint64_t mask = (1ull << (8 * tail)) - 1; diff |= ((read8u(p.data, a + 8ull * nw) ^ read8u(p.data, r + 8ull * nw)) & mask) != 0; }
+  }
+  const bool any = __any(diff);
+  if (lane == 0) p.same[m] = any ? 0 : 1;
+}
+// the remainder of a message that shares the reference's prefix: the payload value, white space, '}', white space, the end
+__device__ bool unpack_fast(const Params &p, int64_t m) {
+  const tfgpu_dbz_frame &rf = p.frames[p.ref];
+  MemBytes rd(p.data);
+  const uint32_t a = p.ms[m], end = p.ms[m + 1];
+  uint32_t pos = a + p.plen;
+  auto skip_ws = [&]() { while (pos < end && is_ws(rd.at(pos))) pos++; };
+  const uint32_t vs = pos;
+  uint32_t vt = 0;
+  if (pos >= end || skip_value(rd, pos, end, vt) != 0) return false;
+  const uint32_t ve = pos;
+  skip_ws();
+  if (pos >= end || rd.at(pos) != '}') return false;   // more members (or an error): the full walk decides
+  pos++;
+  skip_ws();
+  if (pos != end) return false;
+  tfgpu_dbz_frame fr = rf;
+  fr.schema_start = rf.schema_start - p.ms[p.ref] + a;
+  fr.payload_start = vs; fr.payload_len = ve - vs;
+  fr.code = TFGPU_ROW_OK;
+  p.frames[m] = fr;
+  return true;
 }
 
 // ---- values -------------------------------------------------------------------------------------------------------------
@@ -637,7 +696,30 @@ extern "C" int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, c
   const int64_t nmsg = s.p.nmsg;
   Buf fr = dalloc((size_t)std::max<int64_t>(nmsg, 1) * sizeof(tfgpu_dbz_frame));
   s.p.frames = reinterpret_cast<tfgpu_dbz_frame *>(fr->p);
-  if (nmsg) { KernelTimer t("dbz_unpack"); dbz::dbz_unpack<<<dbz::nblk(nmsg, 128), 128, 0, cx.stream>>>(s.p); }
+  static const bool no_fast = [] { const char *e = std::getenv("TFGPU_DBZ_FULL_WALK"); return e && *e == '1'; }();  // A/B runs
+  if (nmsg >= 64 && !no_fast) {
+    // the opening message in full, alone; then every message that shares its bytes up to the payload value walks only the rest
+    dbz::Params one = s.p;
+    one.nmsg = 1;
+    { KernelTimer t("dbz_unpack"); dbz::dbz_unpack<<<1, 128, 0, cx.stream>>>(one); }
+    tfgpu_dbz_frame f0;
+    d2h(&f0, fr->p, sizeof f0);
+    std::vector<uint32_t> ms01(2);
+    d2h(ms01.data(), s.ms->p, 8);
+    tf::sync();
+    const uint64_t msg_end = ms01[1];
+    // usable when the payload is the LAST member: the message is prefix + payload value + '}' (+ white space)
+    const bool usable = f0.code == TFGPU_ROW_OK && f0.schema_len && f0.payload_len && f0.payload_start > f0.schema_start &&
+                        f0.payload_start + f0.payload_len < msg_end;
+    if (usable) {
+      Buf same = dalloc_zero((size_t)nmsg + 16);
+      s.p.ref = 0; s.p.plen = (uint32_t)(f0.payload_start - ms01[0]); s.p.same = ptr<uint8_t>(same);
+      { KernelTimer t("dbz_prefix_same"); dbz::dbz_prefix_same<<<(unsigned)((nmsg + 3) / 4), 256, 0, cx.stream>>>(s.p); }
+      { KernelTimer t("dbz_unpack"); dbz::dbz_unpack_rest<<<dbz::nblk(nmsg, 128), 128, 0, cx.stream>>>(s.p); }
+    } else {
+      KernelTimer t("dbz_unpack"); dbz::dbz_unpack<<<dbz::nblk(nmsg, 128), 128, 0, cx.stream>>>(s.p);
+    }
+  } else if (nmsg) { KernelTimer t("dbz_unpack"); dbz::dbz_unpack<<<dbz::nblk(nmsg, 128), 128, 0, cx.stream>>>(s.p); }
   if (nmsg) d2h(frames, fr->p, (size_t)nmsg * sizeof(tfgpu_dbz_frame));
   tf::sync();
   return TFGPU_OK;
