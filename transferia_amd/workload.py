@@ -159,3 +159,49 @@ def cdc_batch(nrows: int, keys: int = 0, seed: int = SEED, p_old: float = 0.6, p
     b.old_keys = [abi.Column("id", "int64", abi.R_INT64, values=old, validity=present.copy())]
     b.old_present = present
     return b, schema
+
+
+def debezium_cdc_messages(nmsg: int, keys: int = 0, seed: int = SEED, table: str = "events"):
+    """BASELINE.json configs[4] from its real source format: a Postgres CDC stream in Debezium's JSON envelope with the Kafka
+    Connect schema inlined in every message (the JsonConverter default).  Table public.<table>: id int64 (PK), ver int32,
+    payload text (24 bytes), amount numeric(10,2) (Decimal), ts MicroTimestamp; 35 % inserts / 45 % updates / 20 % deletes over
+    `keys` primary keys (default nmsg / 4).  Returns the list of message values (bytes), ~2 KB each."""
+    import base64
+    import json
+    rng = np.random.default_rng(seed)
+    keys = keys or max(nmsg // 4, 1)
+
+    def struct(field):
+        return {"type": "struct", "optional": True, "name": "srv.public.%s.Value" % table, "field": field, "fields": [
+            {"type": "int64", "optional": False, "field": "id"}, {"type": "int32", "optional": True, "field": "ver"},
+            {"type": "string", "optional": True, "field": "payload"},
+            {"type": "bytes", "optional": True, "name": "org.apache.kafka.connect.data.Decimal", "version": 1,
+             "parameters": {"scale": "2", "connect.decimal.precision": "10"}, "field": "amount"},
+            {"type": "int64", "optional": True, "name": "io.debezium.time.MicroTimestamp", "version": 1, "field": "ts"}]}
+    source = {"type": "struct", "optional": False, "name": "io.debezium.connector.postgresql.Source", "field": "source", "fields": [
+        {"type": "string", "optional": False, "field": f} for f in ("version", "connector", "name")] + [
+        {"type": "int64", "optional": False, "field": "ts_ms"}, {"type": "string", "optional": True, "field": "snapshot"},
+        {"type": "string", "optional": False, "field": "db"}, {"type": "string", "optional": False, "field": "schema"},
+        {"type": "string", "optional": False, "field": "table"}, {"type": "int64", "optional": True, "field": "txId"},
+        {"type": "int64", "optional": True, "field": "lsn"}, {"type": "int64", "optional": True, "field": "xmin"}]}
+    schema = json.dumps({"type": "struct", "optional": False, "name": "srv.public.%s.Envelope" % table, "fields": [
+        struct("before"), struct("after"), source, {"type": "string", "optional": False, "field": "op"}, {"type": "int64", "optional": True, "field": "ts_ms"}]},
+        separators=(",", ":"))
+    ids = rng.integers(0, keys, size=nmsg)
+    ops = rng.choice(np.array(["c", "u", "d"]), size=nmsg, p=[0.35, 0.45, 0.20])
+    pay = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)[rng.integers(0, 16, size=(nmsg, 24))]
+    cents = rng.integers(-10**9, 10**9, size=nmsg)
+    out = []
+    for k in range(nmsg):
+        c = int(cents[k])
+        row = '{"id":%d,"ver":%d,"payload":"%s","amount":"%s","ts":%d}' % (
+            int(ids[k]), k, pay[k].tobytes().decode(), base64.b64encode(c.to_bytes(max(1, (c.bit_length() + 8) // 8), "big", signed=True)).decode(),
+            1_700_000_000_000_000 + k)
+        op = str(ops[k])
+        before = row if op in ("u", "d") else "null"
+        after = "null" if op == "d" else row
+        payload = ('{"before":%s,"after":%s,"source":{"version":"2.4.0.Final","connector":"postgresql","name":"srv","ts_ms":%d,"snapshot":"false","db":"db",'
+                   '"schema":"public","table":"%s","txId":%d,"lsn":%d,"xmin":null},"op":"%s","ts_ms":%d,"transaction":null}') % (
+            before, after, 1_700_000_000_000 + k, table, 500 + k, 10_000 + 8 * k, op, 1_700_000_000_123 + k)
+        out.append(('{"schema":%s,"payload":%s}' % (schema, payload)).encode())
+    return out
