@@ -186,11 +186,15 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
     x = p;
   }
 }
-__global__ void __launch_bounds__(256) collapse_link(const uint32_t *__restrict__ keyid, int64_t n, uint32_t *parent) {
+__global__ void __launch_bounds__(256) collapse_link(const uint32_t *__restrict__ keyid, const uint8_t *__restrict__ kind, int64_t n, uint32_t *parent) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   uint32_t a = keyid[2 * r], b = keyid[2 * r + 1];
   if (b == NOKEY || a == b) return;
+  // A Delete that has OldKeys is named by them and its ColumnValues are never read (change_item_collapse.go:108-118): tying its
+  // current key in would only merge components — sources whose deletes carry no columns (pg, Debezium) give every such row the
+  // SAME current key ("null"), and one lane would then replay the whole batch.
+  if (kind && kind[r] == TFGPU_K_DELETE) return;
   for (;;) {  // the larger root is hung under the smaller one: roots only ever decrease, no cycles
     a = uf_find(parent, a); b = uf_find(parent, b);
     if (a == b) return;
@@ -198,10 +202,11 @@ __global__ void __launch_bounds__(256) collapse_link(const uint32_t *__restrict_
     if (atomicCAS(&parent[a], a, b) == a) return;
   }
 }
-__global__ void __launch_bounds__(256) collapse_roots(const uint32_t *__restrict__ keyid, int64_t n, uint32_t *parent, uint32_t *__restrict__ root, uint32_t *__restrict__ idx) {
+__global__ void __launch_bounds__(256) collapse_roots(const uint32_t *__restrict__ keyid, const uint8_t *__restrict__ kind, int64_t n, uint32_t *parent, uint32_t *__restrict__ root, uint32_t *__restrict__ idx) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  root[r] = uf_find(parent, keyid[2 * r]);
+  const uint32_t ko = keyid[2 * r + 1];
+  root[r] = uf_find(parent, (kind && kind[r] == TFGPU_K_DELETE && ko != NOKEY) ? ko : keyid[2 * r]);  // the key that names the row
   idx[r] = (uint32_t)r;
 }
 
@@ -375,9 +380,9 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   hp.weak = weak ? 1 : 0;
   collapse_hash<<<cgrid(n2), 256, 0, st>>>(hp);
   collapse_intern<<<cgrid(n2), 256, 0, st>>>(hp, n2, ptr<uint32_t>(owner), (uint32_t)(cap - 1), ptr<uint32_t>(keyid));
-  collapse_link<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent));
+  collapse_link<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), ptr<uint8_t>(in.kind), n, ptr<uint32_t>(parent));
   Buf root = dalloc((size_t)n * 4), idx = dalloc((size_t)n * 4), sroot = dalloc((size_t)n * 4), sidx = dalloc((size_t)n * 4);
-  collapse_roots<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), n, ptr<uint32_t>(parent), ptr<uint32_t>(root), ptr<uint32_t>(idx));
+  collapse_roots<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), ptr<uint8_t>(in.kind), n, ptr<uint32_t>(parent), ptr<uint32_t>(root), ptr<uint32_t>(idx));
   timer.reset(); timer = std::make_unique<KernelTimer>("collapse_sort");
   {
     size_t tmp_bytes = 0;
