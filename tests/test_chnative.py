@@ -4,6 +4,9 @@ import numpy as np
 import pytest
 
 from transferia_amd import abi
+import os as _os
+
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))
 
 
 def _varuint(buf, at):
@@ -117,7 +120,7 @@ def tf():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 255, 3000, 40001])
 def test_gpu_block_matches_oracle(tf, oracle, n):
-    b = abi.batch_from_rows(SCHEMA, [c.name for c in SCHEMA.cols], _rows(n, seed=n), "db", "t")
+    b = abi.batch_from_rows(SCHEMA, [c.name for c in SCHEMA.cols], _rows(n, seed=n + SEED0), "db", "t")
     b.schema = SCHEMA
     exp = oracle.ch_native_block(b, SCHEMA, COLUMNS)
     got = tf.ch_native_block(tf.DeviceBatch.upload(b), COLUMNS).download()

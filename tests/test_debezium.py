@@ -9,6 +9,9 @@ import pytest
 
 from transferia_amd import abi
 from util import golden
+import os as _os
+
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
 
 
 def canon_value(v):
@@ -232,9 +235,9 @@ def test_gpu_reference_vectors(tf):
 @pytest.mark.parametrize("n,weird", [(1, False), (64, False), (700, True), (3000, True)])
 def test_gpu_stream_matches_oracle(tf, oracle, n, weird):
     from transferia_amd import debezium
-    msgs = cdc_messages(n, seed=n, weird=weird)
+    msgs = cdc_messages(n, seed=n + SEED0, weird=weird)
     if n == 3000:  # a second table in the same batch: two schemas, two device batches
-        other = cdc_messages(200, seed=7, table="orders", weird=False)
+        other = cdc_messages(200, seed=7 + SEED0, table="orders", weird=False)
         msgs = msgs[:1500] + other + msgs[1500:]
     data, m = abi.messages(msgs)
     exp_items, codes = oracle.debezium_parse(data, m)
@@ -262,7 +265,7 @@ def test_gpu_stream_feeds_collapse_and_native_serializer(tf, oracle):
     Collapse of the oracle's parse."""
     from transferia_amd import debezium, workload
     n = 3000
-    msgs = workload.debezium_cdc_messages(n, seed=21)
+    msgs = workload.debezium_cdc_messages(n, seed=21 + SEED0)
     data, m = abi.messages(msgs)
     parsed, errors = debezium.Parser(tf).parse(data, m)
     assert len(parsed) == 1 and not errors
