@@ -303,3 +303,21 @@ def test_gpu_stream_feeds_collapse_and_native_serializer(tf, oracle):
     kinds = [it for x in out[:50] for it in json.loads(x)]
     dels = [it for it in kinds if it["kind"] == "delete"]
     assert dels and all(it["columnnames"] is None and it["oldkeys"]["keynames"] == ["id"] for it in dels)   # a Delete keeps ColumnNames nil
+
+
+@pytest.mark.gpu
+def test_gpu_parse_refuses_foreign_frames(tf):
+    """tfgpu_debezium_parse takes the frames back from the host: spans outside their message are refused before any lane runs."""
+    from transferia_amd import debezium
+    msgs = cdc_messages(8, weird=False)
+    data, m = abi.messages(msgs)
+    frames = tf.debezium_unpack(data, m)
+    comp = debezium.compile_schema(data[int(frames["schema_start"][0]):int(frames["schema_start"][0]) + int(frames["schema_len"][0])])
+    key = (int(frames["schema_hash"][0][0]), int(frames["schema_hash"][0][1]))
+    bad = frames.copy()
+    bad["payload_start"][3] = len(data) + 1000
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.debezium_parse(key, comp, data, bad, m)
+    assert ei.value.code == tf.ERR_INVALID
+    db, rows, errs = tf.debezium_parse(key, comp, data, frames, m)
+    assert db.nrows + len(errs) == 8

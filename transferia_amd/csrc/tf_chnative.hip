@@ -226,7 +226,11 @@ extern "C" int tfgpu_ch_native_block(const tfgpu_dbatch *in, const tfgpu_ch_nati
       return tf::fail(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_ch_native_block: column ") + cols[i].name + ": its Go values do not append to " + cols[i].ch_type + " without a conversion");
     put_string(p.head, cols[i].name);
     put_string(p.head, cols[i].ch_type);
-    if (p.t.base == CB_STRING) { p.str_slot = (int)text.size(); text.push_back(p.c); }
+    if (p.t.base == CB_STRING) {
+      if (p.c->data_len + 5ull * (uint64_t)n >= 0xFFFFFFF0ull)  // the encoded lengths are scanned in 32 bits
+        return tf::fail(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_ch_native_block: column ") + cols[i].name + " exceeds 4 GiB of text; split the batch by rows");
+      p.str_slot = (int)text.size(); text.push_back(p.c);
+    }
   }
   if (!text.empty()) materialize(*in, &text);
   KernelTimer timer("ch_native_block");

@@ -757,6 +757,15 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
   dbz::stage(s, bytes, len, mem, msgs);
   dbz::Params &p = s.p;
   const int64_t nmsg = p.nmsg, nma = std::max<int64_t>(nmsg, 1);
+  // the frames come back from the host: spans that leave their message would send lanes outside the buffer
+  for (int64_t m = 0; m < nmsg; m++) {
+    const tfgpu_dbz_frame &f = frames[m];
+    if (f.code != TFGPU_ROW_OK) continue;
+    const uint64_t a = msgs ? msgs->start[m] : 0, z = msgs ? msgs->start[m + 1] : len;
+    const bool s_ok = f.schema_len == 0 || (f.schema_start >= a && f.schema_start + f.schema_len <= z);
+    const bool p_ok = f.payload_len == 0 || (f.payload_start >= a && f.payload_start + f.payload_len <= z);
+    if (!s_ok || !p_ok) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_parse: frame " + std::to_string(m) + " does not lie inside its message (frames must come from tfgpu_debezium_unpack over the same bytes)");
+  }
   Buf bfr = dalloc((size_t)nma * sizeof(tfgpu_dbz_frame));
   if (nmsg) h2d(bfr->p, frames, (size_t)nmsg * sizeof(tfgpu_dbz_frame));
   p.frames = reinterpret_cast<tfgpu_dbz_frame *>(bfr->p);
