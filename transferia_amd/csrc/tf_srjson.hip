@@ -39,6 +39,7 @@ struct Params {
   uint32_t *row_frame; int64_t nrows;          // [nrows]
   uint32_t *nerr;
   uint16_t *guess;                             // [GUESS_N]: property the m-th member of a payload matched last time (a hint, verified)
+  const uint8_t *nozero;                       // [nmsg] or null: 1 = no 0x00 byte after the 5-byte prefix (sr_find_zero): ONE frame to the end
 };
 constexpr uint32_t GUESS_N = 1024;
 
@@ -57,7 +58,8 @@ template <class F> __device__ uint32_t walk_frames(const Params &p, int64_t m, F
     a += 5;
     uint64_t e = a;  // bytes.Index(buf, []byte{0}): eight bytes per step (the lowest zero-byte flag of the SWAR test is exact)
     bool hit = false;
-    while (e + 8 <= z) {
+    if (k == 0 && p.nozero && p.nozero[m]) { e = z; hit = true; }  // the cooperative pre-pass saw no terminator: the payload runs to the end
+    while (!hit && e + 8 <= z) {
       const uint64_t w = rd.word(e), t = (w - 0x0101010101010101ull) & ~w & 0x8080808080808080ull;
       if (t) { e += (uint32_t)(__ffsll((long long)t) - 1) >> 3; hit = true; break; }
       e += 8;
@@ -68,6 +70,27 @@ template <class F> __device__ uint32_t walk_frames(const Params &p, int64_t m, F
     k++; a = e;
   }
   return k;
+}
+// bytes.Index(payload, 0x00) for the usual message — ONE frame that runs to the end — without a lane walking 2 KB serially:
+// a wave per message, 64 lanes x 8 bytes per step (a memchr at HBM speed); messages that do hold a 0x00 take the walk.
+__global__ void __launch_bounds__(256) sr_find_zero(Params p, uint8_t *nozero) {
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.nmsg) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t a = (uint64_t)p.ms[m] + 5, z = p.ms[m + 1];
+  bool zero = false;
+  if (z > a) {
+    const uint64_t n = z - a, nw = n >> 3;
+    for (uint64_t w = lane; w < nw; w += 64) {
+      const uint64_t pos = a + 8 * w; const uint32_t sh = (uint32_t)(pos & 7) * 8;
+      const uint64_t *q = reinterpret_cast<const uint64_t *>(p.data + (pos & ~7ull));
+      const uint64_t x = sh ? (q[0] >> sh) | (q[1] << (64 - sh)) : q[0];
+      zero |= ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull) != 0;
+    }
+    if (lane < (int)(n & 7)) zero |= p.data[a + 8 * nw + lane] == 0;
+  }
+  const bool any = __any(zero);
+  if (lane == 0) nozero[m] = (z >= a && !any) ? 1 : 0;
 }
 // The count pass keeps every message's FIRST frame: the usual message holds exactly one, and the fill pass then copies it
 // instead of walking the bytes a second time.
@@ -301,7 +324,7 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_
 
 // input bytes + message starts in HBM, frames counted and listed; returns the frame count
 struct Staged {
-  Buf bytes, ms, fcount, frames, first;
+  Buf bytes, ms, fcount, frames, first, nozero;
   Params p{};
   int64_t nframes = 0;
 };
@@ -333,7 +356,13 @@ static void stage_frames(Staged &s, const void *bytes, uint64_t len, int mem, co
   s.p.ms = ptr<uint32_t>(s.ms); s.p.nmsg = nmsg; s.p.fcount = ptr<uint32_t>(s.fcount);
   s.first = dalloc((size_t)std::max<int64_t>(nmsg, 1) * sizeof(tfgpu_sr_frame));
   const tfgpu_sr_frame *first = reinterpret_cast<const tfgpu_sr_frame *>(s.first->p);
-  if (nmsg) { KernelTimer t("sr_frames"); sr_count_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p, reinterpret_cast<tfgpu_sr_frame *>(s.first->p)); }
+  s.nozero = dalloc_zero((size_t)std::max<int64_t>(nmsg, 1) + 16);
+  if (nmsg) {
+    KernelTimer t("sr_frames");
+    sr_find_zero<<<(unsigned)((nmsg + 3) / 4), 256, 0, st>>>(s.p, ptr<uint8_t>(s.nozero));
+    s.p.nozero = ptr<uint8_t>(s.nozero);
+    sr_count_frames<<<nblk(nmsg, 256), 256, 0, st>>>(s.p, reinterpret_cast<tfgpu_sr_frame *>(s.first->p));
+  }
   exclusive_scan_u32(s.p.fcount, s.p.fcount, nmsg, true);
   const uint32_t *h = d2h_u32(s.p.fcount + nmsg);
   tf::sync();  // also fences the pageable sources (bytes, ms)
