@@ -33,7 +33,8 @@ struct Params {
   tfgpu_sr_frame *frames; int64_t nframes;
   uint32_t schema_id; int32_t report_frame_errors;
   const Prop *props; int32_t nprops; const uint8_t *names;
-  uint32_t *vstart, *vlen; uint8_t *vtype;     // [nprops][nframes]: where the property's value sits in the payload
+  uint64_t *vrec;                              // [nprops][nframes]: where the property's value sits in the payload, one word per
+                                               // cell — start (32) | length (24) | VT_* (8): one store / one load instead of three
   uint8_t *status;                             // [nframes]
   uint32_t *keep;                              // [nframes + 1] → row index
   uint32_t *row_frame; int64_t nrows;          // [nrows]
@@ -175,7 +176,8 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
         }
         if (found >= 0 && member < GUESS_N) p.guess[member] = (uint16_t)found;  // racing writers all store a valid hint
       }
-      if (found >= 0) { const int64_t i = (int64_t)found * p.nframes + f; p.vstart[i] = vs; p.vlen[i] = pos - vs; p.vtype[i] = (uint8_t)vt; }
+      if (pos - vs >= (1u << 24)) return TFGPU_ROW_HOST_FALLBACK;  // a 16 MiB value does not fit the span word
+      if (found >= 0) p.vrec[(int64_t)found * p.nframes + f] = (uint64_t)vs | (uint64_t)(pos - vs) << 32 | (uint64_t)(vt & 0xFFu) << 56;
       member++;
       skip_ws();
       if (pos >= end) return TFGPU_ROW_JSON_SYNTAX;
@@ -189,19 +191,20 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
   bool fallback = false;
   for (int j = 0; j < p.nprops; j++) {
     const int64_t i = (int64_t)j * p.nframes + f;
-    const uint32_t vt = p.vtype[i] & VT_MASK;
+    const uint64_t rec = p.vrec[i];
+    const uint32_t vt = (uint32_t)(rec >> 56) & VT_MASK;
     const Prop &pr = p.props[j];
     if (vt == VT_ABSENT) { if (pr.required) return TFGPU_ROW_SR_REQUIRED; continue; }
     if (vt == VT_NULL && !pr.required) continue;
     switch (pr.json_type) {
       case TFGPU_SRT_BOOLEAN: if (vt != VT_TRUE && vt != VT_FALSE) return TFGPU_ROW_SR_TYPE; break;
-      case TFGPU_SRT_INTEGER: { int64_t x; if (vt != VT_NUM || !number_int64(rd, p.vstart[i], p.vlen[i], &x)) return TFGPU_ROW_SR_TYPE; break; }
+      case TFGPU_SRT_INTEGER: { int64_t x; if (vt != VT_NUM || !number_int64(rd, (uint32_t)rec, (uint32_t)(rec >> 32) & 0xFFFFFFu, &x)) return TFGPU_ROW_SR_TYPE; break; }
       case TFGPU_SRT_NUMBER: if (vt != VT_NUM) return TFGPU_ROW_SR_TYPE; break;
       case TFGPU_SRT_STRING: if (vt != VT_STR) return TFGPU_ROW_SR_TYPE; break;
       default:
         if (vt == VT_OBJ || vt == VT_ARR) {
-          const int ord = any_keys_order(rd, p.vstart[i], p.vlen[i]);
-          if (ord == 1) p.vtype[i] = (uint8_t)(vt | VT_CANON);
+          const int ord = any_keys_order(rd, (uint32_t)rec, (uint32_t)(rec >> 32) & 0xFFFFFFu);
+          if (ord == 1) p.vrec[i] = rec | (uint64_t)VT_CANON << 56;
           else if (ord == 2) fallback = true;
         }
     }
@@ -260,7 +263,8 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
   const uint32_t f = p.row_frame[r];
   const OutCol &c = cols[j];
   const int64_t i = (int64_t)j * p.nframes + f;
-  const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
+  const uint64_t rec = p.vrec[i];
+  const uint32_t vtr = (uint32_t)(rec >> 56), vt = vtr & VT_MASK, vs = (uint32_t)rec, vl = (uint32_t)(rec >> 32) & 0xFFFFFFu;
   MemBytes rd(p.data);
   if constexpr (CANON) {
     if (!(vtr & VT_CANON)) return;
@@ -293,7 +297,8 @@ __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols
   const OutCol &c = cols[j];
   const uint32_t f = p.row_frame[r];
   const int64_t i = (int64_t)j * p.nframes + f;
-  const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
+  const uint64_t rec = p.vrec[i];
+  const uint32_t vtr = (uint32_t)(rec >> 56), vt = vtr & VT_MASK, vs = (uint32_t)rec, vl = (uint32_t)(rec >> 32) & 0xFFFFFFu;
   if (vt == VT_ABSENT || vt == VT_NULL) return;
   if (((vtr & VT_CANON) != 0) != CANON) return;
   MemBytes rd(p.data);
@@ -422,11 +427,11 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
   sr::Params &p = s.p;
   const int64_t nf = s.nframes, nfa = std::max<int64_t>(nf, 1);
   Buf bprops = upload_small(props.data(), std::max<size_t>(props.size(), 1) * sizeof(sr::Prop)), bnames = upload_small(names.data(), names.size());
-  Buf vstart = dalloc((size_t)std::max(np, 1) * (size_t)nfa * 4), vlen = dalloc((size_t)std::max(np, 1) * (size_t)nfa * 4), vtype = dalloc_zero((size_t)std::max(np, 1) * (size_t)nfa + 16);
+  Buf vrec = dalloc_zero((size_t)std::max(np, 1) * (size_t)nfa * 8 + 16);  // VT_ABSENT = 0
   Buf status = dalloc_zero((size_t)nfa + 16), keep = dalloc_zero((size_t)(nfa + 1) * 4 + 16), nerr = dalloc_zero(16);
   p.schema_id = o->schema_id; p.report_frame_errors = o->report_frame_errors;
   p.props = ptr<sr::Prop>(bprops); p.nprops = np; p.names = ptr<uint8_t>(bnames);
-  p.vstart = ptr<uint32_t>(vstart); p.vlen = ptr<uint32_t>(vlen); p.vtype = ptr<uint8_t>(vtype);
+  p.vrec = ptr<uint64_t>(vrec);
   p.status = ptr<uint8_t>(status); p.keep = ptr<uint32_t>(keep); p.nerr = ptr<uint32_t>(nerr);
   Buf guess = dalloc(sr::GUESS_N * 2 + 16);
   TF_HIP(hipMemsetAsync(guess->p, 0xFF, sr::GUESS_N * 2, st));
