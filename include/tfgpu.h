@@ -584,6 +584,20 @@ typedef struct tfgpu_dbz_frame {
   int32_t code;           int32_t reserved;
 } tfgpu_dbz_frame;
 int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_dbz_frame *frames);
+/* The same with the shim's schema cache (receiver.go:61-66 caches by the schema's hash) handed in: `known` is the head of a
+ * message of an EARLIER batch up to its payload value — `{"schema":{…},"payload":` — as tfgpu_debezium_unpack framed it
+ * (bytes [message start, payload_start); schema_off = schema_start - message start).  Messages that begin with exactly these
+ * bytes inherit its schema span and hash and only their payload value and closing brace are walked; every other message takes
+ * the full walk.  The result equals tfgpu_debezium_unpack's; what is saved is the one serial 12 KB walk per batch.          */
+typedef struct tfgpu_dbz_prefix {
+  const void *bytes;        /* HOST */
+  uint32_t len;
+  uint32_t schema_off, schema_len;
+  uint32_t reserved;
+  uint64_t schema_hash[2];
+} tfgpu_dbz_prefix;
+int tfgpu_debezium_unpack_cached(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, const tfgpu_dbz_prefix *known,
+                                 tfgpu_dbz_frame *frames);
 
 /* The receiver of one field of the before / after struct, as receiveFieldColSchema resolves it with an empty original type
  * (pkg/debezium/receiver_engine.go:108-146, common/field_receiver_default.go:14-31): Kafka type → Go value → YT type.   */

@@ -321,3 +321,30 @@ def test_gpu_parse_refuses_foreign_frames(tf):
     assert ei.value.code == tf.ERR_INVALID
     db, rows, errs = tf.debezium_parse(key, comp, data, frames, m)
     assert db.nrows + len(errs) == 8
+
+
+@pytest.mark.gpu
+def test_gpu_unpack_with_a_cached_prefix_equals_the_full_walk(tf, oracle):
+    """tfgpu_debezium_unpack_cached: the head of an earlier batch's message stands in for the per-batch reference walk; frames and
+    everything downstream are the same, for messages that share the head and for those that do not."""
+    from transferia_amd import debezium
+    first = cdc_messages(50, seed=SEED0 + 5, weird=False)
+    parser = debezium.Parser(tf)
+    d0, m0 = abi.messages(first)
+    parser.parse(d0, m0)
+    assert parser.known is not None and parser.known[0].endswith(b'"payload":')
+    msgs = cdc_messages(900, seed=SEED0 + 6, weird=True) + cdc_messages(60, seed=SEED0 + 8, table="orders", weird=False)
+    data, m = abi.messages(msgs)
+    plain = tf.debezium_unpack(data, m)
+    cached = tf.debezium_unpack(data, m, parser.known)
+    for f in ("schema_start", "payload_start", "schema_len", "payload_len", "code"):
+        assert np.array_equal(plain[f], cached[f]), f
+    assert np.array_equal(plain["schema_hash"], cached["schema_hash"])
+    parsed, errors = parser.parse(data, m)     # the cache-hit path end to end
+    exp_items, codes = oracle.debezium_parse(data, m)
+    assert {k: v for k, v in enumerate(codes) if v != abi.ROW_OK} == errors
+    got = {}
+    for p in parsed:
+        got.update(device_items(tf, p))
+    for it in exp_items:
+        assert_same_items(got[it["src"]], it, it["src"])

@@ -78,6 +78,10 @@ class CDbzFrame(C.Structure):
                 ("schema_hash", C.c_uint64 * 2), ("code", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CDbzPrefix(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("len", C.c_uint32), ("schema_off", C.c_uint32), ("schema_len", C.c_uint32), ("reserved", C.c_uint32), ("schema_hash", C.c_uint64 * 2)]
+
+
 class CDbzField(C.Structure):
     _fields_ = [("name", C.c_char_p), ("op", C.c_int32), ("optional", C.c_int32), ("scale", C.c_int32), ("reserved", C.c_int32)]
 

@@ -58,6 +58,8 @@ struct Params {
   const double *p10; const uint64_t *p128;
   // the fast path of dbz_unpack: messages that start with the bytes message `ref` holds in front of its payload value
   int64_t ref; uint32_t plen; uint8_t *same;   // same[m] = 1: the first plen bytes equal the reference's
+  const uint8_t *pref;                         // the reference prefix when it is not message `ref` of this batch (a cached one): ref = -1
+  tfgpu_dbz_frame pframe;                      // … and its frame, offsets relative to the message start
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t h, uint64_t w) { h ^= w; h *= 0x9E3779B97F4A7C15ull; return h ^ (h >> 29); }
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(128) dbz_unpack(Params p) {
 }
 __global__ void __launch_bounds__(128) dbz_unpack_rest(Params p) {   // every message but the reference, which is done
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= p.nmsg || m == p.ref) return;
+  if (m >= p.nmsg || m == p.ref) return;   // ref = -1 with a cached prefix: every message is walked here
   if (p.same[m] && unpack_fast(p, m)) return;
   unpack_message(p, m);
 }
@@ -166,20 +168,23 @@ __global__ void __launch_bounds__(256) dbz_prefix_same(Params p) {
   const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= p.nmsg) return;
   const int lane = threadIdx.x & 63;
-  const uint64_t a = p.ms[m], r = p.ms[p.ref];
+  const uint64_t a = p.ms[m];
+  const uint8_t *rb = p.pref ? p.pref : p.data;
+  const uint64_t r = p.pref ? 0 : p.ms[p.ref];
   bool diff = (uint64_t)p.ms[m + 1] - a < (uint64_t)p.plen + 2;   // room for a value and the closing brace
   if (!diff) {
     const uint32_t nw = p.plen >> 3;
-    for (uint32_t w = lane; w < nw; w += 64) diff |= read8u(p.data, a + 8ull * w) != read8u(p.data, r + 8ull * w);
+    for (uint32_t w = lane; w < nw; w += 64) diff |= read8u(p.data, a + 8ull * w) != read8u(rb, r + 8ull * w);
     const uint32_t tail = p.plen & 7u;
-    if (lane == 0 && tail) { const uint64_t mask = (1ull << (8 * tail)) - 1; diff |= ((read8u(p.data, a + 8ull * nw) ^ read8u(p.data, r + 8ull * nw)) & mask) != 0; }
+    if (lane == 0 && tail) { const uint64_t mask = (1ull << (8 * tail)) - 1; diff |= ((read8u(p.data, a + 8ull * nw) ^ read8u(rb, r + 8ull * nw)) & mask) != 0; }
   }
   const bool any = __any(diff);
   if (lane == 0) p.same[m] = any ? 0 : 1;
 }
 // the remainder of a message that shares the reference's prefix: the payload value, white space, '}', white space, the end
 __device__ bool unpack_fast(const Params &p, int64_t m) {
-  const tfgpu_dbz_frame &rf = p.frames[p.ref];
+  const tfgpu_dbz_frame rf = p.pref ? p.pframe : p.frames[p.ref];
+  const uint64_t rstart = p.pref ? 0 : p.ms[p.ref];
   MemBytes rd(p.data);
   const uint32_t a = p.ms[m], end = p.ms[m + 1];
   uint32_t pos = a + p.plen;
@@ -194,7 +199,7 @@ __device__ bool unpack_fast(const Params &p, int64_t m) {
   skip_ws();
   if (pos != end) return false;
   tfgpu_dbz_frame fr = rf;
-  fr.schema_start = rf.schema_start - p.ms[p.ref] + a;
+  fr.schema_start = rf.schema_start - rstart + a;
   fr.payload_start = vs; fr.payload_len = ve - vs;
   fr.code = TFGPU_ROW_OK;
   p.frames[m] = fr;
@@ -686,9 +691,11 @@ using namespace tf;
   catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
   catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
 
-extern "C" int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_dbz_frame *frames) {
+static int debezium_unpack_impl(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_dbz_frame *frames, const tfgpu_dbz_prefix *known) {
   TF_API_BEGIN
   if ((len && !bytes) || !frames) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_unpack: null argument");
+  if (known && (!known->bytes || known->len < 2 || known->schema_off + (uint64_t)known->schema_len > known->len))
+    return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_unpack_cached: bad prefix");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
   dbz::Staged s;
@@ -697,6 +704,21 @@ extern "C" int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, c
   Buf fr = dalloc((size_t)std::max<int64_t>(nmsg, 1) * sizeof(tfgpu_dbz_frame));
   s.p.frames = reinterpret_cast<tfgpu_dbz_frame *>(fr->p);
   static const bool no_fast = [] { const char *e = std::getenv("TFGPU_DBZ_FULL_WALK"); return e && *e == '1'; }();  // A/B runs
+  if (known && nmsg && !no_fast) {
+    // a prefix the shim validated in an earlier batch (its schema cache): no message of this batch is walked in full unless it differs
+    Buf pb = dalloc((size_t)known->len + 64), same = dalloc_zero((size_t)nmsg + 16);
+    h2d(pb->p, known->bytes, known->len);
+    TF_HIP(hipMemsetAsync((char *)pb->p + known->len, 0, 64, cx.stream));
+    s.p.ref = -1; s.p.plen = known->len; s.p.same = ptr<uint8_t>(same); s.p.pref = ptr<uint8_t>(pb);
+    std::memset(&s.p.pframe, 0, sizeof s.p.pframe);
+    s.p.pframe.schema_start = known->schema_off; s.p.pframe.schema_len = known->schema_len;
+    s.p.pframe.schema_hash[0] = known->schema_hash[0]; s.p.pframe.schema_hash[1] = known->schema_hash[1];
+    { KernelTimer t("dbz_prefix_same"); dbz::dbz_prefix_same<<<(unsigned)((nmsg + 3) / 4), 256, 0, cx.stream>>>(s.p); }
+    { KernelTimer t("dbz_unpack"); dbz::dbz_unpack_rest<<<dbz::nblk(nmsg, 128), 128, 0, cx.stream>>>(s.p); }
+    d2h(frames, fr->p, (size_t)nmsg * sizeof(tfgpu_dbz_frame));
+    tf::sync();
+    return TFGPU_OK;
+  }
   if (nmsg >= 64 && !no_fast) {
     // the opening message in full, alone; then every message that shares its bytes up to the payload value walks only the rest
     dbz::Params one = s.p;
@@ -724,6 +746,14 @@ extern "C" int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, c
   tf::sync();
   return TFGPU_OK;
   TF_API_END
+}
+
+extern "C" int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_dbz_frame *frames) {
+  return debezium_unpack_impl(bytes, len, mem, msgs, frames, nullptr);
+}
+extern "C" int tfgpu_debezium_unpack_cached(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, const tfgpu_dbz_prefix *known, tfgpu_dbz_frame *frames) {
+  if (!known) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_unpack_cached: null prefix");
+  return debezium_unpack_impl(bytes, len, mem, msgs, frames, known);
 }
 
 extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,

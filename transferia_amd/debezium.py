@@ -187,10 +187,11 @@ class Parser:
     def __init__(self, lib):
         self.lib = lib
         self.cache: Dict[Tuple[int, int], object] = {}
+        self.known = None   # (prefix bytes, schema_off, schema_len, hash) of the last batch's opening message: the cache hit path
 
     def parse(self, data, msgs: Optional[abi.CMessages] = None, host_bytes: Optional[bytes] = None):
         lib = self.lib
-        frames = lib.debezium_unpack(data, msgs)
+        frames = lib.debezium_unpack(data, msgs, self.known)
         bad = np.nonzero(frames["code"])[0]
         errors = dict(zip(bad.tolist(), frames["code"][bad].tolist()))
         ok = np.nonzero(frames["code"] == 0)[0]
@@ -205,6 +206,13 @@ class Parser:
             if key not in self.cache:
                 a, n = int(frames["schema_start"][m]), int(frames["schema_len"][m])
                 raw = self._bytes(data, host_bytes, a, n)
+                head = host_bytes if host_bytes is not None else (data if isinstance(data, (bytes, bytearray)) else None)
+                if self.known is None and m == 0 and head is not None and int(frames["payload_len"][m]):
+                    # the opening message's head up to its payload value, for the next batches (tfgpu_debezium_unpack_cached);
+                    # usable when the payload is the message's last member (message 0 starts at offset 0)
+                    ps = int(frames["payload_start"][m])
+                    if a < ps:
+                        self.known = (bytes(head[:ps]), a, n, key)
                 try:
                     self.cache[key] = compile_schema(raw)
                 except SchemaError:

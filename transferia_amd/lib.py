@@ -28,7 +28,7 @@ EXPORTS = [
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
-    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -92,6 +92,7 @@ def load():
     L.tfgpu_partition.argtypes = [P, C.c_int, C.POINTER(P), C.POINTER(C.c_int64)]
     L.tfgpu_dbatch_deepsizeof.argtypes = [P, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.tfgpu_debezium_unpack.argtypes = [P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), P]
+    L.tfgpu_debezium_unpack_cached.argtypes = [P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), C.POINTER(abi.CDbzPrefix), P]
     L.tfgpu_debezium_parse.argtypes = [C.POINTER(abi.CDbzOptions), P, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), P, C.POINTER(P), P, C.c_int64,
                                        C.POINTER(abi.CRowError), C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_ch_native_block.argtypes = [P, C.POINTER(abi.CChNativeColumn), C.c_int32, C.POINTER(P)]
@@ -724,13 +725,23 @@ def sr_json_parse(opts: abi.CSrJsonOptions, data, msgs: Optional[abi.CMessages] 
     return ParseResult(DeviceBatch(out), [(int(errs[i].row), int(errs[i].code), int(errs[i].step)) for i in range(min(int(ne.value), max_errors))])
 
 
-def debezium_unpack(data, msgs: Optional[abi.CMessages] = None) -> np.ndarray:
-    """IncludeSchema.Unpack for every message (tfgpu_debezium_unpack): a structured array (abi.DBZ_FRAME_DTYPE) of nmsg frames."""
+def debezium_unpack(data, msgs: Optional[abi.CMessages] = None, known=None) -> np.ndarray:
+    """IncludeSchema.Unpack for every message (tfgpu_debezium_unpack): a structured array (abi.DBZ_FRAME_DTYPE) of nmsg frames.
+    known = (prefix bytes, schema_off, schema_len, (hash0, hash1)) of an earlier batch: tfgpu_debezium_unpack_cached."""
     init()
     ptr_, n, mem, keep = _bytes_arg(data)
     nmsg = msgs.nmsg if msgs is not None else 1
     frames = np.zeros(max(nmsg, 1), abi.DBZ_FRAME_DTYPE)
-    _check(load().tfgpu_debezium_unpack(ptr_, n, mem, C.byref(msgs) if msgs is not None else None, frames.ctypes.data))
+    pm = C.byref(msgs) if msgs is not None else None
+    if known is None:
+        _check(load().tfgpu_debezium_unpack(ptr_, n, mem, pm, frames.ctypes.data))
+    else:
+        pre, so, sl, h = known
+        buf = np.frombuffer(pre, dtype=np.uint8)
+        k = abi.CDbzPrefix()
+        k.bytes, k.len, k.schema_off, k.schema_len = buf.ctypes.data, len(pre), so, sl
+        k.schema_hash[0], k.schema_hash[1] = int(h[0]), int(h[1])
+        _check(load().tfgpu_debezium_unpack_cached(ptr_, n, mem, pm, C.byref(k), frames.ctypes.data))
     return frames[:nmsg]
 
 
