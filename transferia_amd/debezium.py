@@ -198,9 +198,12 @@ class Parser:
         groups: Dict[Tuple[int, int], int] = {}
         if len(ok):  # first message of every distinct schema
             hashes = frames["schema_hash"][ok]
-            _u, first = np.unique(hashes, axis=0, return_index=True)
-            for i in sorted(first):
-                groups[(int(hashes[i][0]), int(hashes[i][1]))] = int(ok[i])
+            if (hashes[:, 0] == hashes[0, 0]).all() and (hashes[:, 1] == hashes[0, 1]).all():  # the usual topic: one schema
+                groups[(int(hashes[0][0]), int(hashes[0][1]))] = int(ok[0])
+            else:
+                _u, first = np.unique(hashes, axis=0, return_index=True)
+                for i in sorted(first):
+                    groups[(int(hashes[i][0]), int(hashes[i][1]))] = int(ok[i])
         out = []
         for key, m in groups.items():
             if key not in self.cache:
