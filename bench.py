@@ -830,7 +830,7 @@ class DebeziumWorkload(Base):
     Postgres event with its inline schema (engine/parser_test.jsonl, carried in tests/golden/debezium.json) replicated per
     batch, every message → one ChangeItem of 61 columns."""
     metric = "messages/sec through the Debezium parser (inline schema, 13.6 KB Postgres event replicated per batch) -> device ChangeItem columns"
-    default_rows = 1 << 16
+    default_rows = 1 << 17
 
     def setup(self):
         e, a = self.env, self.args

@@ -66,6 +66,19 @@ __device__ __forceinline__ uint64_t mix64(uint64_t h, uint64_t w) { h ^= w; h *=
 
 // A decoded key against an ASCII literal: 1 equal, 2 equal only under ASCII case folding (encoding/json's field match), 0 no
 __device__ int key_is(MemBytes &rd, uint32_t ks, uint32_t ke, const char *lit, uint32_t n) {
+  // a decoded key is never longer than its literal, and equal length means no escapes: most candidates fall out on the length
+  const uint32_t raw = ke - ks - 2;
+  if (raw < n) return 0;
+  if (raw == n) {
+    bool exact = true;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t c = rd.at(ks + 1 + i), l = (uint8_t)lit[i];
+      if (c == l) continue;
+      if ((c | 0x20u) == (l | 0x20u) && (c | 0x20u) >= 'a' && (c | 0x20u) <= 'z') { exact = false; continue; }
+      return 0;
+    }
+    return exact ? 1 : 2;
+  }
   RuneIter it{&rd, nullptr, ks + 1, ke - 1};
   bool exact = true;
   for (uint32_t i = 0; i < n; i++) {
@@ -77,6 +90,12 @@ __device__ int key_is(MemBytes &rd, uint32_t ks, uint32_t ke, const char *lit, u
   }
   if (it.next() >= 0) return 0;
   return exact ? 1 : 2;
+}
+// the raw key bytes against a field name of the same length (no escapes can be involved then)
+__device__ __forceinline__ bool key_eq_name(MemBytes &rd, uint32_t ks, uint32_t ke, const uint8_t *name, uint32_t n) {
+  if (ke - ks - 2 != n) return false;
+  for (uint32_t i = 0; i < n; i++) if (rd.at(ks + 1 + i) != name[i]) return false;
+  return true;
 }
 
 // ---- IncludeSchema.Unpack ---------------------------------------------------------------------------------------------
@@ -493,7 +512,13 @@ __device__ int parse_message(const Params &p, int64_t m) {
   if (vt_of(vi) == VT_OBJ) {
     const uint32_t save = pos;
     pos = ms_[vi];
+    int ordinal = 0;  // producers write the members in schema order: the field of the same ordinal is tried first (verified, a hint only)
     members([&](uint32_t ks, uint32_t ke, uint32_t vs, uint32_t vl, uint32_t vt) {
+      const int guess = ordinal++;
+      if (guess < p.nfields) {
+        const FRecv &g = p.fields[guess];
+        if (key_eq_name(rd, ks, ke, p.names + g.name_off, g.name_len)) { const int64_t i = (int64_t)guess * p.nmsg + m; p.vstart[i] = vs; p.vlen[i] = vl; p.vtype[i] = (uint8_t)vt; return; }
+      }
       int lo = 0, hi = p.nfields - 1;
       while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
