@@ -2,6 +2,7 @@
 // Collapse's key strings (tf_collapse.hip): encoding/json strings, base64, integers, shortest floats.  Every emitter is a
 // template over a sink with put(byte), so the same code counts, writes or hashes.
 #pragma once
+#include <type_traits>
 #include "tf_devcol.hpp"
 #include "tf_devfmt.hpp"
 #include "tf_devfloat.hpp"
@@ -131,7 +132,12 @@ template <class S> __device__ __forceinline__ void emit_base64(S &s, const uint8
 
 template <class S> __device__ __forceinline__ void emit_small(S &s, const uint8_t *t, int n) { for (int i = 0; i < n; i++) s.put(t[i]); }
 // decimal text of v < 10^8 built in a register (32-bit arithmetic, no scratch array) and handed over as one word
+// decimal digits of v < 10^8
+__device__ __forceinline__ uint32_t ndigits8(uint32_t v) {
+  return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u);
+}
 template <class S> __device__ __forceinline__ void emit_dec8(S &s, uint32_t v, bool neg) {
+  if constexpr (std::is_same_v<S, CountSink>) { s.n += ndigits8(v) + (neg ? 1u : 0u); return; }  // the length pass only counts
   uint64_t w = 0; uint32_t nd = 0;
   do { const uint32_t q = v / 10u; w = (w << 8) | ('0' + (v - q * 10u)); v = q; nd++; } while (v);
   if (neg) s.put('-');
@@ -140,6 +146,7 @@ template <class S> __device__ __forceinline__ void emit_dec8(S &s, uint32_t v, b
 
 // exactly `width` (1..8) decimal digits of v, zero padded, as one word
 template <class S> __device__ __forceinline__ void emit_dec_pad(S &s, uint32_t v, uint32_t width) {
+  if constexpr (std::is_same_v<S, CountSink>) { s.n += width; return; }
   uint64_t w = 0;
   for (uint32_t i = 0; i < width; i++) { const uint32_t q = v / 10u; w = (w << 8) | ('0' + (v - q * 10u)); v = q; }
   sink_word(s, w, width, 0);
