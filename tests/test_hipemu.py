@@ -24,7 +24,8 @@ import numpy as np
 root, rank, world, case, idfile = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 from transferia_amd import abi, lib
-lib._LIBPATH = os.environ["TFGPU_TEST_EMU_LIB"]
+if os.environ.get("TFGPU_TEST_EMU_LIB"):   # the CPU pre-flight; without it: the real library, one GPU per rank (LOCAL_RANK)
+    lib._LIBPATH = os.environ["TFGPU_TEST_EMU_LIB"]
 from oracle import oracle as ora
 ora.build()
 lib.init()
@@ -169,3 +170,39 @@ def test_emulated_exchange_ranks(tmp_path, case, world):
     assert sum(o["rows"] for o in outs) == sum(sum(o["sent"]) for o in outs)
     for r, o in enumerate(outs):
         assert o["recv"] == [outs[s]["sent"][r] for s in range(world)]
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: tfgpu_exchange between two processes over real RCCL / xGMI")
+@pytest.mark.parametrize("case", ["plain", "ragged", "empty_rank", "mismatch"])
+def test_exchange_two_gpus(tmp_path, case):
+    """The same worker as the emulated world_size-2 test, on two MI355X: one process per GPU, librccl, the rendezvous id through a
+    file.  Runs only where two GPUs are visible (the build box has one)."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(EXCHANGE_WORKER)
+    procs = []
+    for r in range(2):
+        env = {k: v for k, v in os.environ.items() if k not in ("TFGPU_TEST_EMU_LIB", "TFGPU_RCCL_LIB")}
+        env.update(LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", case, str(tmp_path / "uid")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([ln for ln in o.strip().splitlines() if ln.startswith("{")][-1]))
+    outs.sort(key=lambda d: d["rank"])
+    if case == "mismatch":
+        assert [o["error"] for o in outs] == [True, True]
+        return
+    for r, o in enumerate(outs):
+        assert o["recv"] == [outs[s]["sent"][r] for s in range(2)]
