@@ -644,7 +644,9 @@ typedef struct tfgpu_dbz_row {
  * rows[r].names_form = 1.  rows (HOST, rows_cap entries) receives ID / LSN / CommitTime.  errs: one entry per message of
  * this schema that the reference turns into an `_unparsed` item (row = step = message index, code = TFGPU_ROW_DBZ_*) or
  * that the stock code must redo (TFGPU_ROW_HOST_FALLBACK: `__debezium_unavailable_value`, decimals wider than 64 bytes,
- * values on which the reference panics, rows of another table than the first good row's).                              */
+ * values on which the reference panics, rows of another table than the first good row's, a payload / source key that
+ * repeats — encoding/json decodes every occurrence into the same struct field and merges maps — or binds only by case
+ * folding).                              */
 int tfgpu_debezium_parse(const tfgpu_dbz_options *opts, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
                          const tfgpu_dbz_frame *frames, tfgpu_dbatch **out, tfgpu_dbz_row *rows, int64_t rows_cap,
                          tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);

@@ -44,6 +44,13 @@ static const jv *field_of(const jv *obj, const char *name, int *folded) {
   return hit;
 }
 
+/* how many members of obj bind struct field `name` (exactly or by case folding) */
+static int occurrences(const jv *obj, const char *name) {
+  size_t n = strlen(name); int c = 0;
+  for (int i = 0; i < obj->nk; i++) if (obj->klen[i] == n && !strncasecmp(obj->keys[i], name, n)) c++;
+  return c;
+}
+
 /* strconv.ParseUint(text, 10, bits) of a JSON number literal as encoding/json applies it to unsigned fields */
 static int lit_uint(const jv *v, int bits, uint64_t *out) {
   if (v->n == 0) return 0;
@@ -317,7 +324,9 @@ static int receive_message(const unsigned char *p, size_t n, ora_batch *out, uin
   if (p[0] == 0) return n < 5 ? TFGPU_ROW_HOST_FALLBACK /* buf[5:] panics */ : TFGPU_ROW_DBZ_UNPACK;
   /* IncludeSchema.Unpack: json.Unmarshal(message, &struct{Schema, Payload json.RawMessage}) — the whole message must be one valid value */
   jp s = {p, p + n, 0, 0};
+  jv_keep_dups = 1;   /* struct fields see every occurrence of their key; the map lookups below take the last one */
   jv *msg = parse_value(&s);
+  jv_keep_dups = 0;
   if (!s.err) { ws(&s); if (s.p != s.e) s.err = 1; }
   if (s.err || !msg) { jv_free(msg); return TFGPU_ROW_DBZ_UNPACK; }
   int rc = TFGPU_ROW_OK, fold = 0;
@@ -332,9 +341,12 @@ static int receive_message(const unsigned char *p, size_t n, ora_batch *out, uin
   const jv *after = NULL, *before = NULL, *source = NULL;
   char *op = strdup(""), *sschema = strdup(""), *stable = strdup("");
   uint64_t v_lsn = 0, v_ts = 0, v_tx = 0;
+  int dup = 0;   /* a struct key that repeats: encoding/json decodes every occurrence INTO the same field (maps and structs merge) — not restated */
   if (payload->t == JV_OBJ) {
     const jv *v; int f;
     int bad = 0;
+    static const char *ptop[] = {"after", "before", "op", "source", "ts_ms", "transaction"};
+    for (int i = 0; i < 6; i++) if (occurrences(payload, ptop[i]) > 1) dup = 1;
     if ((v = field_of(payload, "after", &f))) { fold |= f; if (v->t == JV_OBJ) after = v; else if (v->t != JV_NULL) bad = 1; }
     if ((v = field_of(payload, "before", &f))) { fold |= f; if (v->t == JV_OBJ) before = v; else if (v->t != JV_NULL) bad = 1; }
     if (!str_field(payload, "op", &op, &fold)) bad = 1;
@@ -344,6 +356,8 @@ static int receive_message(const unsigned char *p, size_t n, ora_batch *out, uin
       fold |= f;
       if (v->t == JV_OBJ) {
         source = v;
+        static const char *sf[] = {"connector", "db", "lsn", "name", "schema", "sequence", "snapshot", "table", "ts_ms", "txId", "version", "xmin"};
+        for (int i = 0; i < 12; i++) if (occurrences(v, sf[i]) > 1) dup = 1;
         char *d = strdup("");
         static const char *strs[] = {"connector", "db", "name", "sequence", "snapshot", "version"};
         for (int i = 0; i < 6; i++) if (!str_field(v, strs[i], &d, &fold)) bad = 1;
@@ -357,6 +371,7 @@ static int receive_message(const unsigned char *p, size_t n, ora_batch *out, uin
       } else if (v->t != JV_NULL) bad = 1;
     }
     if (bad) rc = TFGPU_ROW_DBZ_PAYLOAD;
+    if (dup) rc = TFGPU_ROW_HOST_FALLBACK;   /* decided before the type errors, like the device */
   } else if (payload->t != JV_NULL) rc = TFGPU_ROW_DBZ_PAYLOAD;    /* UnmarshalTypeError */
   if (rc == TFGPU_ROW_OK && fold) rc = TFGPU_ROW_HOST_FALLBACK;
   int kind = -1;

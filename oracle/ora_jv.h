@@ -30,8 +30,9 @@ static void jv_free(jv *v) {
   for (int i = 0; i < v->nk; i++) { jv_free(v->kids[i]); if (v->keys) free(v->keys[i]); }
   free(v->kids); free(v->keys); free(v->klen); free(v->s); free(v);
 }
+static int jv_keep_dups = 0;  /* 1: objects keep every member in document order (struct decoding looks at each occurrence); 0: a map */
 static void jv_add(jv *c, char *key, size_t klen, jv *kid) {
-  if (c->t == JV_OBJ) for (int i = 0; i < c->nk; i++) if (c->klen[i] == klen && !memcmp(c->keys[i], key, klen)) {  /* m[key] = v: the last one wins */
+  if (c->t == JV_OBJ && !jv_keep_dups) for (int i = 0; i < c->nk; i++) if (c->klen[i] == klen && !memcmp(c->keys[i], key, klen)) {  /* m[key] = v: the last one wins */
     jv_free(c->kids[i]); c->kids[i] = kid; free(key); return;
   }
   if (c->nk == c->cap) {

@@ -423,7 +423,7 @@ __device__ int parse_message(const Params &p, int64_t m) {
   enum { M_AFTER, M_BEFORE, M_OP, M_SOURCE, M_TS, M_N };
   uint32_t ms_[M_N], ml_[M_N], mt_[M_N];
   for (int i = 0; i < M_N; i++) { ms_[i] = 0; ml_[i] = 0; mt_[i] = VT_ABSENT; }
-  bool fold = false;
+  bool fold = false, dup = false;  // dup: a struct key repeats — encoding/json decodes every occurrence into the same field (maps and structs merge): host
   // walks the members of the object at pos ('{'); calls on(ks, ke, vs, vl, vt) for each
   auto members = [&](auto on) {
     pos++;
@@ -444,14 +444,15 @@ __device__ int parse_message(const Params &p, int64_t m) {
       return;
     }
   };
+  bool seen_tx = false;
   static const char *const TOP[M_N] = {"after", "before", "op", "source", "ts_ms"};
   const uint32_t TOPN[M_N] = {5, 6, 2, 6, 5};
   members([&](uint32_t ks, uint32_t ke, uint32_t vs, uint32_t vl, uint32_t vt) {
     for (int i = 0; i < M_N; i++) {
       const int k = key_is(rd, ks, ke, TOP[i], TOPN[i]);
-      if (k) { ms_[i] = vs; ml_[i] = vl; mt_[i] = vt; if (k == 2) fold = true; return; }
+      if (k) { if ((mt_[i] & VT_MASK) != VT_ABSENT) dup = true; ms_[i] = vs; ml_[i] = vl; mt_[i] = vt; if (k == 2) fold = true; return; }
     }
-    if (key_is(rd, ks, ke, "transaction", 11) == 2) fold = true;
+    if (const int k = key_is(rd, ks, ke, "transaction", 11)) { if (k == 2) fold = true; if (seen_tx) dup = true; seen_tx = true; }
   });
   bool bad = false;
   auto vt_of = [&](int i) { return mt_[i] & VT_MASK; };
@@ -465,6 +466,7 @@ __device__ int parse_message(const Params &p, int64_t m) {
   if (vt_of(M_SOURCE) == VT_OBJ) {
     const uint32_t save = pos;
     pos = ms_[M_SOURCE];
+    uint32_t seen = 0;
     members([&](uint32_t ks, uint32_t ke, uint32_t vs, uint32_t vl, uint32_t vtr) {
       const uint32_t vt = vtr & VT_MASK;
       static const char *const STRS[8] = {"connector", "db", "name", "sequence", "snapshot", "version", "schema", "table"};
@@ -473,18 +475,21 @@ __device__ int parse_message(const Params &p, int64_t m) {
         const int k = key_is(rd, ks, ke, STRS[i], STRN[i]);
         if (!k) continue;
         if (k == 2) fold = true;
+        if (seen & (1u << i)) dup = true;
+        seen |= 1u << i;
         if (vt == VT_STR) { if (i == 6) { sch_s = vs; sch_n = vl; } if (i == 7) { tab_s = vs; tab_n = vl; } }
         else if (vt != VT_NULL) bad = true;
         return;
       }
       int k;
-      if ((k = key_is(rd, ks, ke, "lsn", 3))) { if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 64, &lsn)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
-      if ((k = key_is(rd, ks, ke, "ts_ms", 5))) { if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 64, &ts)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
-      if ((k = key_is(rd, ks, ke, "txId", 4))) { if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 32, &tx)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
-      if ((k = key_is(rd, ks, ke, "xmin", 4))) { if (k == 2) fold = true; int64_t x; if (vt == VT_NUM) { if (!number_int64(rd, vs, vl, &x)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+      if ((k = key_is(rd, ks, ke, "lsn", 3))) { if (seen & 0x100u) dup = true; seen |= 0x100u; if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 64, &lsn)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+      if ((k = key_is(rd, ks, ke, "ts_ms", 5))) { if (seen & 0x200u) dup = true; seen |= 0x200u; if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 64, &ts)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+      if ((k = key_is(rd, ks, ke, "txId", 4))) { if (seen & 0x400u) dup = true; seen |= 0x400u; if (k == 2) fold = true; if (vt == VT_NUM) { if (!lit_uint(rd, vs, vl, 32, &tx)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
+      if ((k = key_is(rd, ks, ke, "xmin", 4))) { if (seen & 0x800u) dup = true; seen |= 0x800u; if (k == 2) fold = true; int64_t x; if (vt == VT_NUM) { if (!number_int64(rd, vs, vl, &x)) bad = true; } else if (vt != VT_NULL) bad = true; return; }
     });
     pos = save;
   } else if (vt_of(M_SOURCE) != VT_ABSENT && vt_of(M_SOURCE) != VT_NULL) bad = true;
+  if (dup) return TFGPU_ROW_HOST_FALLBACK;
   if (bad) return TFGPU_ROW_DBZ_PAYLOAD;
   if (fold) return TFGPU_ROW_HOST_FALLBACK;
   // opToKind
