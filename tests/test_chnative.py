@@ -54,7 +54,7 @@ COLUMNS = [("id", "Int64"), ("i8", "Nullable(Int8)"), ("u16", "UInt16"), ("i32",
            ("ts", "Nullable(DateTime64(3))"), ("day", "Date32"), ("b", "UInt8")]
 
 
-def _rows(n, seed=5):
+def _rows(n, seed=5):   # every 97th text cell is 20 000 bytes: a three-byte varuint length
     import random
     rng = random.Random(seed)
     rows = []
@@ -63,7 +63,7 @@ def _rows(n, seed=5):
             return ["nil", None] if (k and rng.random() < p) else v   # row 0 types every column
         rows.append([["int64", k - 3], maybe(["int8", rng.randrange(-128, 128)]), maybe(["uint16", rng.randrange(65536)]), maybe(["int32", -k]),
                      maybe(["uint64", rng.getrandbits(64)]), maybe(["float32", float(np.float32(rng.uniform(-9, 9)))]), maybe(["float64", rng.uniform(-1e9, 1e9)]),
-                     maybe(["bool", k % 3 == 0]), maybe(["string", "é" * (k % 200) if k % 97 else "long" * 5000]),   # 20 000 bytes: a three-byte varuint maybe(["bytes", "z" * (k % 7)]), maybe(["json", '{"k":[%d,null]}' % k]),
+                     maybe(["bool", k % 3 == 0]), maybe(["string", "é" * (k % 200) if k % 97 else "long" * 5000]), maybe(["bytes", "z" * (k % 7)]), maybe(["json", '{"k":[%d,null]}' % k]),
                      maybe(["time", (86400 * (k % 40000), 0)]), maybe(["time", (rng.randrange(-10**9, 5 * 10**9), 0)]),
                      maybe(["time", (rng.randrange(-2 * 10**9, 9 * 10**9), rng.randrange(10**9))])])
     return rows
