@@ -623,6 +623,56 @@ class Configs3Workload(Base):
         return out
 
 
+class Configs0Workload(Configs3Workload):
+    """BASELINE.json configs[0]: the plumbing case — rename_tables + mask_field on 1M synthetic ChangeItems, nothing parsed and
+    nothing serialized (devnull → devnull).  The reference runs it on the CPU only; here the same two transformers run on
+    resident columns and the oracle's single-thread time for the same chain is printed beside it."""
+    metric = "ChangeItems/sec through rename_tables + mask_field(ClientIP), devnull -> devnull, on resident hits columns"
+    CH = [("rename_tables", {"renameTables": [{"originalName": {"nameSpace": "", "name": "hits"}, "newName": {"nameSpace": "bench", "name": "hits_masked"}}]}), MASK]
+
+    def setup(self):
+        e, a = self.env, self.args
+        lib = e.lib
+        dbuf, self.csv_bytes, _ = stage_shard(lib, e.workload, a.rows * e.rank, a.rows)
+        db, _, errs = lib.csv_parse(e.workload.hits_csv_options(), e.workload.hits_schema(), dbuf)
+        assert not errs
+        host = db.download()
+        db.free(); dbuf.free()
+        host.table_ns, host.table_name = "", "hits"
+        self.db = lib.DeviceBatch.upload(host)
+        self.n = self.db.nrows
+        self.plans = [lib.Transformer(t, c) for t, c in self.CH]
+
+    def step(self, keep=False):
+        tr = self.env.lib.apply_chain(self.plans, self.db)
+        if keep:
+            assert tr.transformed.table_id() == ("bench", "hits_masked"), tr.transformed.table_id()
+            self.state.update(in_bytes=self.db.payload_bytes(), out_bytes=0, kept_bytes=tr.transformed.payload_bytes(), errors=len(tr.errors))
+        tr.transformed.free()
+
+    def alg(self):
+        return {"mask_hmac_sha256": 72 * self.n}
+
+    def config(self):
+        return {"workload": "1M synthetic hits ChangeItems resident in HBM -> rename_tables + mask_field -> devnull (BASELINE.json configs[0]: the plumbing case, CPU-only in the reference)",
+                "rows_per_gpu_per_step": self.n, "columns": 105, "chain": [t for t, _ in self.CH], "parallelism": f"row-range shard x{self.env.world}, no collective"}
+
+    def extra(self):
+        return {}
+
+    def cpu(self):
+        from oracle import oracle as ora
+        e = self.env
+        k = min(self.args.cpu_rows, self.n)
+        r1 = ora.csv_parse(e.workload.hits_csv_options(), e.workload.hits_schema(), e.workload.hits_csv(k), "", "hits")
+        r2 = ora.apply_chain([ora.Transformer(t, c) for t, c in self.CH], r1.batch, r1.schema)
+        out = {"value": round(k / r2.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{k} rows: oracle rename_tables + mask_field ({r2.seconds:.2f}s) on already-typed rows, single thread (one table = one goroutine, transformation.go:131-135)",
+               "note": "C restatement of the Go reference, not the Go binary"}
+        out.update(host_info())
+        return out
+
+
 class Configs4Workload(Base):
     """BASELINE.json configs[4], from the decoded CDC batch on: hash-partition by key (sharder CRC32 % world → tfgpu_partition →
     all-to-all over RCCL/xGMI) → Collapse (PK-keyed dedup) → native queue serializer (Kafka-ready messages)."""
@@ -886,7 +936,7 @@ class DebeziumWorkload(Base):
         return out
 
 
-WORKLOADS = {"debezium": DebeziumWorkload, "configs4d": Configs4DebeziumWorkload, "csv": CsvWorkload, "json": JsonWorkload, "sr": SrWorkload, "configs2": Configs2Workload, "configs3": Configs3Workload,
+WORKLOADS = {"configs0": Configs0Workload, "debezium": DebeziumWorkload, "configs4d": Configs4DebeziumWorkload, "csv": CsvWorkload, "json": JsonWorkload, "sr": SrWorkload, "configs2": Configs2Workload, "configs3": Configs3Workload,
              "configs4": Configs4Workload, "collapse": CollapseWorkload}
 
 
@@ -897,7 +947,7 @@ class Env:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="csv",
-                    help="csv = BASELINE.json configs[1] (the bench line); configs2/3/4 = the other GPU configs; json / sr / collapse = component benchmarks")
+                    help="csv = BASELINE.json configs[1] (the bench line); configs0 = the plumbing case; configs2/3/4 = the other GPU configs; json / sr / collapse = component benchmarks")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: enough for a timed region of >= 1 s)")
     ap.add_argument("--warmup", type=int, default=5)

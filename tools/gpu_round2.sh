@@ -9,7 +9,7 @@ timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -40 > "$OUT
 echo "== gpu tests"; tail -3 "$OUT/pytest_gpu.log"
 timeout 200 python __graft_entry__.py --smoke > "$OUT/smoke.log" 2>&1; echo "== smoke"; tail -1 "$OUT/smoke.log"
 timeout 600 python bench.py > "$OUT/bench_csv.json" 2> "$OUT/bench_csv.err"; echo "== csv rc=$?"
-for w in configs2 configs3 configs4 configs4d json sr collapse debezium; do
+for w in configs0 configs2 configs3 configs4 configs4d json sr collapse debezium; do
   timeout 400 python bench.py --workload $w > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; echo "== $w rc=$?"
 done
 python - "$OUT" <<'PY'
