@@ -623,51 +623,62 @@ class Configs3Workload(Base):
         return out
 
 
-class Configs0Workload(Configs3Workload):
-    """BASELINE.json configs[0]: the plumbing case — rename_tables + mask_field on 1M synthetic ChangeItems, nothing parsed and
-    nothing serialized (devnull → devnull).  The reference runs it on the CPU only; here the same two transformers run on
-    resident columns and the oracle's single-thread time for the same chain is printed beside it."""
-    metric = "ChangeItems/sec through rename_tables + mask_field(ClientIP), devnull -> devnull, on resident hits columns"
-    CH = [("rename_tables", {"renameTables": [{"originalName": {"nameSpace": "", "name": "hits"}, "newName": {"nameSpace": "bench", "name": "hits_masked"}}]}), MASK]
+class Configs0Workload(Base):
+    """BASELINE.json configs[0] (SURVEY §8d "Config 1"): the plumbing case — 1 M rows of the 4-column table
+    (id int64, name utf8, ip int32, ts timestamp) through rename_tables + mask_field(ip), nothing parsed and nothing serialized
+    (devnull -> devnull).  The reference runs it on the CPU only; here the same two transformers run on resident columns and
+    the oracle's single-thread time for the same chain on the same rows is printed beside it."""
+    metric = "ChangeItems/sec through rename_tables + mask_field(ip), devnull -> devnull, on a resident 4-column table"
+    default_rows = 1 << 20
+    CH = [("rename_tables", {"renameTables": [{"originalName": {"nameSpace": "public", "name": "users"}, "newName": {"nameSpace": "bench", "name": "users_masked"}}]}),
+          ("mask_field", {"maskFunctionHash": {"userDefinedSalt": "clickbench-salt"}, "columns": ["ip"]})]
+
+    def table(self, row0, n):
+        abi = self.env.abi
+        rng = np.random.default_rng(0x5EEDC11C + row0)
+        lens = rng.integers(3, 24, n)
+        off = np.zeros(n + 1, np.uint32); off[1:] = np.cumsum(lens)
+        data = rng.integers(97, 123, int(off[-1])).astype(np.uint8)
+        cols = [abi.Column("id", "int64", abi.R_INT64, values=np.arange(row0, row0 + n, dtype=np.int64)),
+                abi.Column("name", "utf8", abi.R_STRING, offsets=off, data=data),
+                abi.Column("ip", "int32", abi.R_INT32, values=rng.integers(-2**31, 2**31, n).astype(np.int32)),
+                abi.Column("ts", "timestamp", abi.R_TIME, values=rng.integers(1372636800, 1375315200, n), nanos=np.zeros(n, np.int32))]
+        return abi.Batch(cols, n, "public", "users"), abi.Schema.of([["id", "int64", True], ["name", "utf8", False], ["ip", "int32", False], ["ts", "timestamp", False]])
 
     def setup(self):
         e, a = self.env, self.args
-        lib = e.lib
-        dbuf, self.csv_bytes, _ = stage_shard(lib, e.workload, a.rows * e.rank, a.rows)
-        db, _, errs = lib.csv_parse(e.workload.hits_csv_options(), e.workload.hits_schema(), dbuf)
-        assert not errs
-        host = db.download()
-        db.free(); dbuf.free()
-        host.table_ns, host.table_name = "", "hits"
-        self.db = lib.DeviceBatch.upload(host)
+        host, _ = self.table(a.rows * e.rank, a.rows)
+        self.db = e.lib.DeviceBatch.upload(host)
         self.n = self.db.nrows
-        self.plans = [lib.Transformer(t, c) for t, c in self.CH]
+        self.plans = [e.lib.Transformer(t, c) for t, c in self.CH]
+
+    def rows(self):
+        return self.n
 
     def step(self, keep=False):
         tr = self.env.lib.apply_chain(self.plans, self.db)
         if keep:
-            assert tr.transformed.table_id() == ("bench", "hits_masked"), tr.transformed.table_id()
+            assert tr.transformed.table_id() == ("bench", "users_masked"), tr.transformed.table_id()
             self.state.update(in_bytes=self.db.payload_bytes(), out_bytes=0, kept_bytes=tr.transformed.payload_bytes(), errors=len(tr.errors))
         tr.transformed.free()
 
     def alg(self):
-        return {"mask_hmac_sha256": 72 * self.n}
+        return {"mask_hmac_sha256": 68 * self.n}  # 4 B of int32 in, 64 B of hex out
+
+    def int_roofline(self, kernels):
+        return Configs3Workload.int_roofline(self, kernels)
 
     def config(self):
-        return {"workload": "1M synthetic hits ChangeItems resident in HBM -> rename_tables + mask_field -> devnull (BASELINE.json configs[0]: the plumbing case, CPU-only in the reference)",
-                "rows_per_gpu_per_step": self.n, "columns": 105, "chain": [t for t, _ in self.CH], "parallelism": f"row-range shard x{self.env.world}, no collective"}
-
-    def extra(self):
-        return {}
+        return {"workload": "4-column table (id int64, name utf8, ip int32, ts timestamp) resident in HBM -> rename_tables + mask_field(ip) -> devnull (BASELINE.json configs[0]: the plumbing case, CPU-only in the reference)",
+                "rows_per_gpu_per_step": self.n, "columns": 4, "chain": [t for t, _ in self.CH], "parallelism": f"row-range shard x{self.env.world}, no collective"}
 
     def cpu(self):
         from oracle import oracle as ora
-        e = self.env
         k = min(self.args.cpu_rows, self.n)
-        r1 = ora.csv_parse(e.workload.hits_csv_options(), e.workload.hits_schema(), e.workload.hits_csv(k), "", "hits")
-        r2 = ora.apply_chain([ora.Transformer(t, c) for t, c in self.CH], r1.batch, r1.schema)
-        out = {"value": round(k / r2.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
-               "sample": f"{k} rows: oracle rename_tables + mask_field ({r2.seconds:.2f}s) on already-typed rows, single thread (one table = one goroutine, transformation.go:131-135)",
+        b, schema = self.table(0, k)
+        r = ora.apply_chain([ora.Transformer(t, c) for t, c in self.CH], b, schema)
+        out = {"value": round(k / r.seconds, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{k} rows: oracle rename_tables + mask_field ({r.seconds:.2f}s) on the same typed rows, single thread (one table = one goroutine, transformation.go:131-135)",
                "note": "C restatement of the Go reference, not the Go binary"}
         out.update(host_info())
         return out
