@@ -234,7 +234,10 @@ static void json_value(sbuf *b, const ora_value *v, int dtype, int any_as_string
   switch (v->kind) {
     case OV_NIL: sb_s(b, "null"); return;
     case OV_BOOL: sb_s(b, v->v.b ? "true" : "false"); return;
-    case OV_STRING: json_string(b, v->s, v->slen, 0); return;
+    case OV_STRING:
+      if (dtype != TFGPU_T_BYTES) { json_string(b, v->s, v->slen, 0); return; }
+      /* strictify first (serializer/strictify.go:24-36): castx.ToByteSliceE turns a Go string under "string" into []byte */
+      /* fallthrough */
     case OV_BYTES: sb_c(b, '"'); base64_std(b, (const unsigned char *)v->s, v->slen); sb_c(b, '"'); return;
     case OV_JSONNUM: if (v->slen) sb_put(b, v->s, v->slen); else sb_c(b, '0'); return;
     case OV_TIME: sb_c(b, '"'); n = ora_fmt_rfc3339nano(t, v->v.t.sec, v->v.t.nsec); sb_put(b, t, n); sb_c(b, '"'); return; /* Time.MarshalJSON */
@@ -246,6 +249,13 @@ static void json_value(sbuf *b, const ora_value *v, int dtype, int any_as_string
     default: break;
   }
   if (is_int_kind(v->kind)) { put_int(b, v); return; }
+  if ((v->kind == OV_F32 || v->kind == OV_F64) && dtype == TFGPU_T_FLOAT64) {
+    /* strictify first: "double" becomes json.Number(castx.ToStringE(v)) = FormatFloat(v, 'f', -1, bits) (strictify.go:119-124,
+     * caste.go:36-49, 59-62), written as it stands; "NaN" / "+Inf" are no JSON number literals: Marshal fails */
+    const double d = v->kind == OV_F32 ? (double)v->v.f32 : v->v.f64;
+    if (d != d || d - d != 0) b->unsupported = 1; else put_float_f(b, v);
+    return;
+  }
   if (v->kind == OV_F32 || v->kind == OV_F64) { /* floatEncoder; NaN / Inf fail the whole Marshal (UnsupportedValueError) */
     n = v->kind == OV_F32 ? ora_json_float(t, (double)v->v.f32, 32) : ora_json_float(t, v->v.f64, 64);
     if (!n) b->unsupported = 1; else sb_put(b, t, n);
@@ -271,6 +281,16 @@ static void json_row(sbuf *b, const ora_item *it, const tfgpu_serialize_options 
   }
   sb_c(b, '}');
   free(k);
+}
+
+/* what json.Marshal's compact(escape=true) does to bytes a Marshaler returned: <, >, & and U+2028/9 become \uXXXX */
+static void put_html_compact(sbuf *b, const char *s, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    unsigned char c = (unsigned char)s[i];
+    if (c == '<' || c == '>' || c == '&') { sb_s(b, "\\u00"); sb_c(b, HEXC[c >> 4]); sb_c(b, HEXC[c & 15]); }
+    else if (c == 0xE2 && i + 2 < n && (unsigned char)s[i + 1] == 0x80 && ((unsigned char)s[i + 2] & 0xFE) == 0xA8) { sb_s(b, "\\u202"); sb_c(b, HEXC[(unsigned char)s[i + 2] & 0xF]); i += 2; }
+    else sb_c(b, (char)c);
+  }
 }
 
 /* encoding/csv Writer.fieldNeedsQuotes + quoted write (Comma ',', UseCRLF false) */
@@ -305,9 +325,10 @@ static void csv_row(sbuf *b, const ora_item *it) {
     int dt = dtype_by_index(it, i);
     sbuf c = {0}; char t[128]; size_t n;
     if (v->kind == OV_NIL) { /* "" */ }
-    else if (dt == TFGPU_T_BYTES) { if (v->kind == OV_BYTES) base64_std(&c, (const unsigned char *)v->s, v->slen); else b->unsupported = 1; }
+    else if (dt == TFGPU_T_BYTES) { if (v->kind == OV_BYTES || v->kind == OV_STRING) base64_std(&c, (const unsigned char *)v->s, v->slen); else b->unsupported = 1; }
     else if (dt == TFGPU_T_ANY) { /* json.Marshal(value) */
-      if (v->kind == OV_JSON || v->kind == OV_JSONNUM) sb_put(&c, v->s, v->slen);
+      if (v->kind == OV_JSON) put_html_compact(&c, v->s, v->slen);  /* Marshal escapes HTML; the JSON serializer's Encoder does not */
+      else if (v->kind == OV_JSONNUM) sb_put(&c, v->s, v->slen);
       else if (is_int_kind(v->kind)) put_int(&c, v);
       else if (v->kind == OV_BOOL) sb_s(&c, v->v.b ? "true" : "false");
       else if (v->kind == OV_STRING) json_string(&c, v->s, v->slen, 1);
@@ -669,16 +690,6 @@ int64_t ora_batch_len(const ora_batch *b) { return b->n; }
 static const char *DTYPE_NAMES[] = {"", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float", "double",
                                     "boolean", "string", "utf8", "date", "datetime", "timestamp", "interval", "any"};
 static const char *KIND_NAMES[] = {"insert", "update", "delete"};
-
-/* what json.Marshal's compact(escape=true) does to bytes a Marshaler returned: <, >, & and U+2028/9 become \uXXXX */
-static void put_html_compact(sbuf *b, const char *s, size_t n) {
-  for (size_t i = 0; i < n; i++) {
-    unsigned char c = (unsigned char)s[i];
-    if (c == '<' || c == '>' || c == '&') { sb_s(b, "\\u00"); sb_c(b, HEXC[c >> 4]); sb_c(b, HEXC[c & 15]); }
-    else if (c == 0xE2 && i + 2 < n && (unsigned char)s[i + 1] == 0x80 && ((unsigned char)s[i + 2] & 0xFE) == 0xA8) { sb_s(b, "\\u202"); sb_c(b, HEXC[(unsigned char)s[i + 2] & 0xF]); i += 2; }
-    else sb_c(b, (char)c);
-  }
-}
 
 /* encoding/json of one boxed ColumnValues / KeyValues element, escapeHTML on */
 static void native_value(sbuf *b, const ora_value *v) {

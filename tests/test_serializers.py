@@ -48,6 +48,53 @@ def test_oracle_reference_vectors(oracle):
         _check_case(case, out)
 
 
+def _canon_tables():
+    """TestBatchSerializer / TestStreamSerializer csv + json over the first 10 items of every all-databases canon case
+    (reference_test.go:80-259): per table the rows and the lines of the three canon `result` files that belong to them."""
+    out = []
+    for t in golden("serializers_canon.json")["tables"]:
+        item = dict(t["common"], rows=t["rows"])
+        out.append((t, item))
+    return out
+
+
+CANON_VARIANTS = [("json", "json", {}), ("json_newline", "json", {"add_closing_newline": True}), ("csv", "csv", {})]
+
+
+def _check_canon(serialize):
+    done = skipped = 0
+    for t, item in _canon_tables():
+        if "skip" in t:  # time.Time with a zone offset: the column form holds UTC instants only (INTEGRATION.md)
+            skipped += len(t["rows"])
+            continue
+        b, schema = item_to_batch(item)
+        for key, fmt, o in CANON_VARIANTS:
+            out = serialize(FMT[fmt], b, schema, _opts(o))
+            assert out is not None, (t["name"], key)
+            assert out.decode("utf-8") == t["expect"][key], (t["name"], key)
+        done += len(t["rows"])
+    assert (done, skipped) == (116, 2)  # of the 118 items of ReadChangeItems(10)
+
+
+def test_oracle_batch_serializer_canon(oracle):
+    _check_canon(lambda f, b, schema, o: oracle.serialize(f, b, schema, o))
+
+
+def test_oracle_strictify_first_rules(oracle):
+    """What the canon above pins, as small cases: the serializers strictify first, so a Go string under "string" leaves as
+    base64, a Go float under "double" as FormatFloat(v, 'f', -1, bits); the CSV serializer's `any` is json.Marshal (HTML escaped)."""
+    schema = abi.Schema.of([["b", "string", False], ["d", "double", False], ["f", "float", False], ["a", "any", False]])
+    rows = [[["string", "hi\x00"], ["float64", 1e21], ["float32", 1e21], ["json", '{"k":"<&>"}']],
+            [["string", ""], ["float64", 5e-324], ["float32", 1.5], ["json", '"<"']]]
+    b = abi.batch_from_rows(schema, ["b", "d", "f", "a"], rows, "", "t")
+    js = oracle.serialize(abi.FMT_JSON, b, schema).decode()
+    assert js.split("\n")[0] == '{"a":{"k":"<&>"},"b":"aGkA","d":1000000000000000000000,"f":1e+21}'
+    assert js.split("\n")[1] == '{"a":"<","b":"","d":0.' + "0" * 323 + '5,"f":1.5}'
+    cs = oracle.serialize(abi.FMT_CSV, b, schema).decode()
+    assert cs.split("\n")[0] == 'aGkA,1000000000000000000000,1000000000000000000000,"{""k"":""\\u003c\\u0026\\u003e""}"'
+    assert cs.split("\n")[1] == ',0.' + "0" * 323 + '5,1.5,"""\\u003c"""'
+
+
 def test_oracle_escaping_rules(oracle):
     """encoding/json vs writeQuoted differ exactly where SURVEY §7 says: <>& stay (escapeHTML off),
     U+2028/9 and invalid UTF-8 are rewritten by encoding/json only, writeQuoted keeps raw bytes."""
@@ -115,6 +162,11 @@ def test_gpu_reference_vectors(tf):
         b, _ = _case_batch(case)
         out = tf.serialize(FMT[case["format"]], tf.DeviceBatch.upload(b), _opts(case["opts"])).download()
         _check_case(case, out)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_serializer_canon(tf):
+    _check_canon(lambda f, b, schema, o: tf.serialize(f, tf.DeviceBatch.upload(b), o).download())
 
 
 @pytest.mark.gpu

@@ -35,10 +35,13 @@ def canon(path, key):
         return json.load(f)[key]
 
 
-def write(name, obj):
+def write(name, obj, compact=False):
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, name), "w") as f:
-        json.dump(obj, f, indent=1, ensure_ascii=False, sort_keys=True)
+        if compact:
+            json.dump(obj, f, ensure_ascii=False, sort_keys=True, separators=(",", ":"))
+        else:
+            json.dump(obj, f, indent=1, ensure_ascii=False, sort_keys=True)
         f.write("\n")
     print("wrote", name)
 
@@ -557,6 +560,152 @@ def serializers():
     write("serializers.json", {"cases": cases})
 
 
+# ---------------------------------------------------------------------------
+# Batch / Stream serializer canon over the all-databases fixture corpus:
+#   pkg/serializer/reference/reference_test.go:80-148 (TestBatchSerializer csv / json), :150-232 (TestStreamSerializer),
+#   ReadChangeItems :234-259 = the first 10 items of every tests/canon/<provider>/canondata/*/extracted, cases ordered by
+#   name descending (tests/canon/all_databases.go:68-124).  One output line per item, so the canon `result` files split
+#   into per-case expectations.  `any` values are written the way the cgo side hands them over: the JSON text
+#   encoding/json produces for the Go value with HTML escaping off (sorted map keys, floatEncoder digits, base64 []byte).
+# ---------------------------------------------------------------------------
+class _Raw(str):
+    """a JSON number literal as written (json.Number values must not pass through a Python float)"""
+
+
+def _go_float(x, bits):
+    """encoding/json floatEncoder (encode.go): shortest digits, %e below 1e-6 and from 1e21 on, exponent without padding"""
+    import math
+    import numpy as np
+    if x == 0:
+        return "-0" if math.copysign(1, x) < 0 else "0"
+    t = np.format_float_scientific(np.float32(x) if bits == 32 else np.float64(x), unique=True, trim="-")
+    mant, exp = t.split("e")
+    e = int(exp)
+    neg = mant.startswith("-")
+    digits = mant.lstrip("-").replace(".", "")
+    if e < -6 or e >= 21:
+        out = digits[0] + ("." + digits[1:] if len(digits) > 1 else "") + "e" + ("-" if e < 0 else "+") + ("%02d" % abs(e))
+        if out[-4:-1] in ("e-0", "e+0"):
+            out = out[:-2] + out[-1]
+    elif e >= 0:
+        out = digits + "0" * (e + 1 - len(digits)) if len(digits) <= e + 1 else digits[:e + 1] + "." + digits[e + 1:]
+    else:
+        out = "0." + "0" * (-e - 1) + digits
+    return ("-" if neg else "") + out
+
+
+def _go_string(s):
+    out = ['"']
+    for ch in s:
+        o = ord(ch)
+        if ch in '"\\':
+            out.append("\\" + ch)
+        elif ch in "\n\r\t\b\f":
+            out.append({"\n": "\\n", "\r": "\\r", "\t": "\\t", "\b": "\\b", "\f": "\\f"}[ch])
+        elif o < 0x20 or o in (0x2028, 0x2029):
+            out.append("\\u%04x" % o)
+        else:
+            out.append(ch)
+    out.append('"')
+    return "".join(out)
+
+
+_GO_INTS = ("int", "int8", "int16", "int32", "int64", "uint", "uint8", "uint16", "uint32", "uint64")
+
+
+def _go_marshal(v):
+    """json.Marshal (escapeHTML off) of a canonized typed value"""
+    t, x = v["type"], v["value"]
+    if t == "nil" or x is None:
+        return "null"
+    if t in _GO_INTS or t == "time.Duration":
+        return str(int(x))
+    if t in ("float64", "float32"):
+        return _go_float(float(x), 64 if t == "float64" else 32)
+    if t == "json.Number":
+        return str(x)
+    if t == "bool":
+        return "true" if x else "false"
+    if t in ("string", "time.Time", "[]uint8"):  # canon already holds []byte as base64
+        return _go_string(x)
+    if t == "[]interface {}":
+        return "[" + ",".join(_go_marshal(e) for e in x) + "]"
+    if t == "map[string]interface {}":
+        return "{" + ",".join(_go_string(k) + ":" + _go_marshal(x[k]) for k in sorted(x, key=lambda k: k.encode())) + "}"
+    if t.startswith("[]"):
+        et = t[3:] if t.startswith("[]*") else t[2:]
+        return "[" + ",".join(_go_marshal({"type": et, "value": e}) for e in x) + "]"
+    raise ValueError(t)
+
+
+def _typed_cell(v, dtype):
+    import base64
+    t, x = v["type"], v["value"]
+    if t == "nil":
+        return ["nil", None]
+    if dtype == "any":
+        return ["json", _go_marshal(v)]
+    if t == "time.Time":
+        return ["time", x]
+    if t == "time.Duration":
+        return ["duration", int(x)]
+    if t == "[]uint8":
+        return ["bytes", base64.b64decode(x).decode("latin-1")]
+    if t == "json.Number":
+        return ["jsonnum", str(x)]
+    if t == "string":
+        return ["string", x]
+    if t in _GO_INTS:
+        return [t, int(x)]
+    if t in ("float32", "float64"):
+        return [t, float(x)]
+    if t == "bool":
+        return [t, bool(x)]
+    raise ValueError((t, dtype))
+
+
+def serializer_canon():
+    import glob
+    roots = [("clickhouse", "tests/canon/clickhouse/canondata/*/extracted"), ("mysql", "tests/canon/mysql/canondata/*/extracted"),
+             ("postgres", "tests/canon/postgres/gotest/canondata/*/extracted"), ("ydb", "tests/canon/ydb/canondata/*/extracted"),
+             ("yt", "tests/canon/yt/canondata/*/extracted")]
+    tables = []
+    for prov, g in roots:
+        for f in sorted(glob.glob(REF + "/" + g)):
+            with open(f) as fh:
+                items = json.load(fh, parse_float=_Raw, parse_int=_Raw)[:10]
+            tables.append((f.split("/")[-2].split(".")[-1], prov, items, f[len(REF) + 1:]))
+    tables.sort(key=lambda c: c[0], reverse=True)
+
+    def result(name):
+        with open(REF + "/pkg/serializer/reference/canondata/reference.reference.Test%s/result" % name, "rb") as f:
+            return f.read().decode("utf-8")
+    js, jn, cs = result("BatchSerializer_json_default"), result("BatchSerializer_json_newline"), result("BatchSerializer_csv_default")
+    assert jn == js + "\n" and result("StreamSerializer_json_default") == jn and result("StreamSerializer_json_newline") == jn
+    assert result("StreamSerializer_csv_default") == cs and cs.endswith("\n")
+    jl, cl = js.split("\n"), cs[:-1].split("\n")
+    assert len(jl) == len(cl) == sum(len(t[2]) for t in tables)
+    cases, pos = [], 0
+    for name, prov, items, path in tables:
+        sch = items[0]["TableSchema"]["value"]
+        k = len(items)
+        common = {"ns": items[0]["Schema"]["value"], "table": items[0]["Table"]["value"], "schema": [[c["name"], c["type"], bool(c["key"])] for c in sch],
+                  "original_types": {c["name"]: c["original_type"] for c in sch}, "names": items[0]["ColumnNames"]["value"]}
+        its = []
+        for it in items:
+            assert it["ColumnNames"]["value"] == common["names"] and it["Kind"]["value"] == "insert"
+            its.append({"values": [_typed_cell(v, c["type"]) for v, c in zip(it["ColumnValues"]["value"], sch)]})
+        zoned = any(g == "time" and not x.endswith("Z") for it in its for g, x in it["values"])
+        # json: TestBatchSerializer/json:default; json_newline: TestBatchSerializer/json:newline = TestStreamSerializer/json:default
+        # = TestStreamSerializer/json:newline; csv: TestBatchSerializer/csv:default = TestStreamSerializer/csv:default
+        case = {"name": "%s:%s" % (prov, name), "ref": path, "common": common, "rows": [it["values"] for it in its],
+                "expect": {"json": "\n".join(jl[pos:pos + k]), "json_newline": "".join(x + "\n" for x in jl[pos:pos + k]), "csv": "".join(x + "\n" for x in cl[pos:pos + k])}}
+        if zoned:  # the column form holds UTC instants only: such items stay with the stock code (INTEGRATION.md)
+            case["skip"] = "time.Time values with a non-UTC Location"
+        cases.append(case)
+        pos += k
+    write("serializers_canon.json", {"tables": cases}, compact=True)
+
 
 # ---------------------------------------------------------------------------
 # generic JSON parser (a17)
@@ -941,4 +1090,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium()

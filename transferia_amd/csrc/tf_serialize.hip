@@ -139,9 +139,26 @@ template <class S> __device__ __forceinline__ bool emit_ch_value(S &s, const SCo
 
 // ---- one value, encoding/json (jsonSerializer) ----
 template <class S> __device__ __forceinline__ void emit_json_value(S &s, const SCol &sc, int64_t r, int any_as_string) {
-  emit_json_cell(s, sc.c, r, any_as_string, false);  // SetEscapeHTML(false), json_format.go
+  const DCol &c = sc.c;
+  // the batch / stream serializers strictify first (serializer/strictify.go:24-36): a Go string under "string" becomes []byte
+  // (castx.ToByteSliceE), a Go float under "double" becomes json.Number(FormatFloat(v, 'f', -1, bits)) (caste.go:36-49, 59-62)
+  if (c.dtype == TFGPU_T_BYTES && c.repr == TFGPU_R_STRING && is_valid(c, r)) {
+    s.put('"'); emit_base64(s, c.data + c.offsets[r], c.offsets[r + 1] - c.offsets[r]); s.put('"');
+    return;
+  }
+  if (c.dtype == TFGPU_T_FLOAT64 && (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) && is_valid(c, r)) { emit_float_f(s, c, r); return; }
+  emit_json_cell(s, c, r, any_as_string, false);  // SetEscapeHTML(false), json_format.go
 }
 
+// bytes a Marshaler returned, as json.Marshal's compact(escapeHTML) leaves them: <, >, & and U+2028/9 become \uXXXX
+template <class S> __device__ __forceinline__ void put_html_compact(S &s, const uint8_t *p, uint32_t n) {
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = p[i];
+    if (c == '<' || c == '>' || c == '&') { put_lit(s, "\\u00"); s.put(hexc(c >> 4)); s.put(hexc(c & 15)); }
+    else if (c == 0xE2 && i + 2 < n && p[i + 1] == 0x80 && (p[i + 2] & 0xFE) == 0xA8) { put_lit(s, "\\u202"); s.put(hexc(p[i + 2] & 0xF)); i += 2; }
+    else s.put(c);
+  }
+}
 // ---- one field, encoding/csv over toCsvValue ----
 __device__ bool csv_needs_quotes(const uint8_t *p, uint32_t n) {  // Writer.fieldNeedsQuotes, Comma ','
   if (n == 0) return false;
@@ -164,7 +181,12 @@ template <class S> __device__ __forceinline__ void emit_csv_field(S &s, const SC
   const uint8_t *vp = nullptr; uint32_t vn = 0;
   if (c.offsets) { vp = c.data + c.offsets[r]; vn = c.offsets[r + 1] - c.offsets[r]; }
   uint8_t t[64];
-  if (c.dtype == TFGPU_T_BYTES) { emit_base64(s, vp, vn); return; }  // repr is []byte (host-checked)
+  if (c.dtype == TFGPU_T_BYTES) { emit_base64(s, vp, vn); return; }  // []byte, or a Go string strictified to it (host-checked)
+  if (c.dtype == TFGPU_T_ANY && c.repr == TFGPU_R_JSON) {  // json.Marshal(value): unlike the JSON serializer's Encoder it escapes HTML
+    if (csv_needs_quotes(vp, vn)) { s.put('"'); CsvQuoteSink<S> q{s}; put_html_compact(q, vp, vn); s.put('"'); }
+    else put_html_compact(s, vp, vn);
+    return;
+  }
   if (c.dtype == TFGPU_T_ANY && c.repr == TFGPU_R_STRING) {           // json.Marshal(string): always holds '"'
     s.put('"'); CsvQuoteSink<S> q{s}; emit_json_string(q, vp, vn, true); s.put('"');
     return;
@@ -189,15 +211,6 @@ __device__ __forceinline__ bool q_applies(const SerParams &p, uint32_t apply, in
     case QA_OLD: return p.q.has_old && (!p.q.old_present || ((p.q.old_present[r >> 3] >> (r & 7)) & 1));
     case QA_ROW_EVENT: return !p.q.kind || p.q.kind[r] <= TFGPU_K_DELETE;
     default: return true;
-  }
-}
-// bytes a Marshaler returned, as json.Marshal's compact(escapeHTML) leaves them: <, >, & and U+2028/9 become \uXXXX
-template <class S> __device__ __forceinline__ void put_html_compact(S &s, const uint8_t *p, uint32_t n) {
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t c = p[i];
-    if (c == '<' || c == '>' || c == '&') { put_lit(s, "\\u00"); s.put(hexc(c >> 4)); s.put(hexc(c & 15)); }
-    else if (c == 0xE2 && i + 2 < n && p[i + 1] == 0x80 && (p[i + 2] & 0xFE) == 0xA8) { put_lit(s, "\\u202"); s.put(hexc(p[i + 2] & 0xF)); i += 2; }
-    else s.put(c);
   }
 }
 template <class S> __device__ __forceinline__ void emit_meta_string(S &s, const uint32_t *off, const uint8_t *data, int64_t k) {
@@ -597,7 +610,7 @@ static void require_supported(int format, const DColumn &c, int any_as_string) {
     const bool temporal = c.dtype == TFGPU_T_DATE || c.dtype == TFGPU_T_DATETIME || c.dtype == TFGPU_T_TIMESTAMP;
     if (c.repr == TFGPU_R_TIME && !temporal) bad("time.Time under a non-temporal DataType (generic JSON fallback)");
   } else if (format == TFGPU_FMT_CSV) {
-    if (c.dtype == TFGPU_T_BYTES && c.repr != TFGPU_R_BYTES) bad("\"string\" (bytes) column not holding []byte");
+    if (c.dtype == TFGPU_T_BYTES && c.repr != TFGPU_R_BYTES && c.repr != TFGPU_R_STRING) bad("\"string\" (bytes) column holding neither []byte nor a Go string");
     if (c.dtype == TFGPU_T_ANY && (c.repr == TFGPU_R_TIME || c.repr == TFGPU_R_DURATION || c.repr == TFGPU_R_BYTES)) bad("`any` column holding a non-JSON-native Go value");
     if (c.dtype != TFGPU_T_ANY && c.repr == TFGPU_R_JSON) bad("map/slice value under a scalar DataType");
   }
