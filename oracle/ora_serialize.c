@@ -229,8 +229,11 @@ static void ch_row(sbuf *b, const ora_item *it, const tfgpu_serialize_options *o
 }
 
 /* ---- encoding/json of one value of a strictified row ---- */
-static void json_value(sbuf *b, const ora_value *v, int dtype, int any_as_string) {
+static void json_value(sbuf *b, const ora_value *v, int dtype, int any_as_string, int strictified) {
   char t[128]; size_t n;
+  /* strictified: the batch / stream serializers wrap jsonSerializer in strictifyingSerializer (batch_factory / strictify.go);
+   * the queue JSON serializer calls NewJSONSerializer bare (queue/json_serializer.go:22-29) and writes values as they are */
+  if (!strictified && (dtype == TFGPU_T_BYTES || dtype == TFGPU_T_FLOAT64)) dtype = TFGPU_T_INVALID;
   switch (v->kind) {
     case OV_NIL: sb_s(b, "null"); return;
     case OV_BOOL: sb_s(b, v->v.b ? "true" : "false"); return;
@@ -267,7 +270,7 @@ static void json_value(sbuf *b, const ora_value *v, int dtype, int any_as_string
 typedef struct { const char *name; int idx; } keyref;
 static int key_cmp(const void *a, const void *b) { return strcmp(((const keyref *)a)->name, ((const keyref *)b)->name); }
 
-static void json_row(sbuf *b, const ora_item *it, const tfgpu_serialize_options *o) {
+static void json_row(sbuf *b, const ora_item *it, const tfgpu_serialize_options *o, int strictified) {
   int n = it->nvalues;
   keyref *k = (keyref *)malloc(sizeof(keyref) * (size_t)(n ? n : 1));
   for (int i = 0; i < n; i++) { k[i].name = it->names->names[i]; k[i].idx = i; }
@@ -277,7 +280,7 @@ static void json_row(sbuf *b, const ora_item *it, const tfgpu_serialize_options 
     if (j) sb_c(b, ',');
     json_string(b, k[j].name, strlen(k[j].name), 0);
     sb_c(b, ':');
-    json_value(b, &it->values[k[j].idx], dtype_by_index(it, k[j].idx), o ? o->any_as_string : 0);
+    json_value(b, &it->values[k[j].idx], dtype_by_index(it, k[j].idx), o ? o->any_as_string : 0, strictified);
   }
   sb_c(b, '}');
   free(k);
@@ -357,7 +360,7 @@ char *ora_serialize_ex(int format, const ora_batch *bt, const tfgpu_serialize_op
     switch (format) {
       case TFGPU_FMT_CH_JSON_EACH_ROW: ch_row(&b, it, o); break;
       case TFGPU_FMT_JSON:
-        json_row(&b, it, o);
+        json_row(&b, it, o, 1);
         if (o && o->add_closing_newline) sb_c(&b, '\n');   /* per item, json.go:66-72; batch separator is nil then */
         else if (r + 1 < bt->n) sb_c(&b, '\n');            /* separator between items, none after the last */
         break;
@@ -413,7 +416,7 @@ static char *keys_string(char **keynames, int nkeys, char **names, int nnames, c
     if (k) sb_c(&b, ',');
     const ora_value *v = NULL;
     for (int i = 0; i < nnames; i++) if (!strcmp(names[i], keynames[k])) v = &values[i];  /* a later duplicate name wins, like the map write */
-    if (!v || v->kind == OV_NIL) sb_s(&b, "null"); else json_value(&b, v, TFGPU_T_INVALID, 0);
+    if (!v || v->kind == OV_NIL) sb_s(&b, "null"); else json_value(&b, v, TFGPU_T_INVALID, 0, 0);
   }
   sb_c(&b, ']');
   sb_c(&b, 0);
@@ -801,7 +804,7 @@ static int queue_element(sbuf *e, int format, const ora_item *it, const tfgpu_qu
   if (format == TFGPU_QFMT_NATIVE) { native_item(e, it, o, m, part); return 0; }
   if (it->kind > TFGPU_K_DELETE) return 0;                                    /* !IsRowEvent: empty bytes (json.go:51-53) */
   if (it->kind == TFGPU_K_UPDATE || it->kind == TFGPU_K_DELETE) return 1;    /* UnsupportedItemKinds (json.go:54-56)     */
-  json_row(e, it, NULL);
+  json_row(e, it, NULL, 0);
   return 0;
 }
 

@@ -212,6 +212,27 @@ def test_gpu_queue_matches_oracle(tf, oracle, n):
 
 
 @pytest.mark.gpu
+def test_gpu_queue_canon_corpus(tf, oracle):
+    """The all-databases corpus (tests/golden/serializers_canon.json: arrays, hstore, decimals as json.Number, FixedString, YT
+    composite values) as input to the native and JSON queue serializers: device against the oracle."""
+    from util import golden
+    checked = 0
+    for t in golden("serializers_canon.json")["tables"]:
+        b, schema = item_to_batch(dict(t["common"], rows=t["rows"]))
+        db = tf.DeviceBatch.upload(b)
+        for o in (abi.queue_options(abi.QFMT_NATIVE, table_schema=schema), abi.queue_options(abi.QFMT_NATIVE, omit_table_schema=True, enabled=True, max_change_items=2),
+                  abi.queue_options(abi.QFMT_JSON), abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=600)):
+            ref = oracle.queue_serialize(o, b, schema)
+            if ref is None:
+                with pytest.raises(tf.TfgpuError):
+                    tf.queue_serialize(o, db, None)
+                continue
+            assert tf.queue_serialize(o, db, None).messages() == ref, t["name"]
+            checked += 1
+    assert checked >= 120, checked
+
+
+@pytest.mark.gpu
 def test_gpu_queue_errors_and_empty(tf, oracle):
     schema = abi.Schema.of([["k", "int32", True]])
     b = abi.batch_from_rows(schema, ["k"], [[["int32", 1]], [["int32", 2]]], "", "t", ["insert", "update"])

@@ -170,6 +170,26 @@ def test_gpu_batch_serializer_canon(tf):
 
 
 @pytest.mark.gpu
+def test_gpu_canon_corpus_jsoneachrow(tf, oracle):
+    """The same corpus as input to MarshalCItoJSON (the reference only benchmarks it there, httpuploader/bench/bench_test.go):
+    device against the oracle on every provider's value forms; what the oracle does not restate the device must refuse."""
+    same = refused = 0
+    for t, item in _canon_tables():
+        b, schema = item_to_batch(item)
+        for o in ({}, {"any_as_string": True}):
+            ref = oracle.serialize(abi.FMT_CH_JSON_EACH_ROW, b, schema, _opts(o))
+            if ref is None:
+                with pytest.raises(tf.TfgpuError):
+                    tf.serialize(abi.FMT_CH_JSON_EACH_ROW, tf.DeviceBatch.upload(b), _opts(o))
+                refused += 1
+                continue
+            got = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, tf.DeviceBatch.upload(b), _opts(o)).download()
+            assert got == ref, (t["name"], o)
+            same += 1
+    assert same >= 60, (same, refused)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 2, 63, 1000, 20011])
 def test_gpu_serializers_match_oracle(tf, oracle, n):
     rng = np.random.default_rng(SEED0 + (100 + n))
