@@ -19,6 +19,7 @@
 #define __shared__ static thread_local /* one instance per kernel and host thread: workgroups run one after another */
 /* dynamic LDS named at file scope (`extern __shared__ T name[];` in HIP): here a fixed 160 KiB per array */
 #define TF_DYNAMIC_LDS(type, name) static thread_local type name[(160 * 1024) / sizeof(type)]
+#define TF_GLOBAL_PTR(T, p) ((T *)(p))
 #define __builtin_amdgcn_fence(...) ((void)0)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };

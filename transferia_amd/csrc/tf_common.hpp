@@ -21,6 +21,12 @@
 #define TF_DYNAMIC_LDS(type, name) extern __shared__ type name[]
 #endif
 
+// a pointer known to address device (global) memory, e.g. one read back from LDS as an integer: stores through it are
+// global_store instead of flat_store (the CPU emulator's hip_runtime.h defines the plain cast)
+#ifndef TF_GLOBAL_PTR
+#define TF_GLOBAL_PTR(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
+#endif
+
 struct tfgpu_dbatch;
 
 namespace tf {

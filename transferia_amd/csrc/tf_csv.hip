@@ -1149,26 +1149,38 @@ struct CsvRun { int32_t kind, width, first, ncols; };  // consecutive tcols of o
 // what the cell loops of csv_parse_regular share
 struct RegTile {
   const uint8_t *sb; const uint16_t *fposx; const uint32_t *qmask; const uint16_t *qpre; uint8_t *slowf; const uint64_t *colp0, *colp1; const uint16_t *colfield;
-  uint32_t nr, NF; float inv_nr; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote;
+  uint32_t nr, NF, step_q, step_r; float inv_nr; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote;
 };
 // one cell of a run: item → (column, line), its output row and its byte range [fs, fend) in the tile
 struct RegCell { bool on; uint32_t col, jj, fs, fend; int32_t r; };
-__device__ __forceinline__ RegCell reg_cell(const RegTile &t, uint32_t first_col, uint32_t it, uint32_t items) {
-  RegCell c;
+// A wave's items of one run are it0, it0 + 512, it0 + 1024, … (slots of 64 items dealt round-robin to 8 waves): the first
+// (column offset, line) pair comes from one division, the following ones from adding 512 / nr and 512 % nr with one carry.
+struct ItemIter { uint32_t it, oi, jj; };
+__device__ __forceinline__ ItemIter item_first(const RegTile &t, uint32_t it) {
   // it / nr through the float reciprocal (rounded down, so the quotient is never too large; it < 2^24): all full-rate ops
   uint32_t oi = (uint32_t)(__uint2float_rz(it) * t.inv_nr);
   uint32_t jj = it - __umul24(oi, t.nr);
   if (jj >= t.nr) { oi++; jj -= t.nr; }
-  c.col = first_col + oi; c.jj = jj;
-  c.r = t.row0 + (int32_t)jj;
-  c.on = it < items && c.r >= 0;  // header lines produce nothing
+  return ItemIter{it, oi, jj};
+}
+__device__ __forceinline__ void item_next(const RegTile &t, ItemIter &x) {
+  x.it += 512u; x.oi += t.step_q; x.jj += t.step_r;
+  if (x.jj >= t.nr) { x.jj -= t.nr; x.oi++; }
+}
+__device__ __forceinline__ RegCell reg_cell(const RegTile &t, uint32_t first_col, const ItemIter &x, uint32_t items) {
+  RegCell c;
+  c.col = first_col + x.oi; c.jj = x.jj;
+  c.r = t.row0 + (int32_t)x.jj;
+  c.on = x.it < items && c.r >= 0;  // header lines produce nothing
   c.fs = 0; c.fend = 0;
   if (c.on) {
-    const uint32_t kr = __umul24(jj, t.NF) + (uint32_t)t.colfield[c.col];  // < nr * NF <= the index's size (checked before the cells)
+    const uint32_t kr = __umul24(x.jj, t.NF) + (uint32_t)t.colfield[c.col];  // < nr * NF <= the index's size (checked before the cells)
     c.fs = (uint32_t)t.fposx[kr] + 1; c.fend = t.fposx[kr + 1];
   }
   return c;
 }
+// the column buffers are device allocations: say so, or the pointer read back from LDS makes every store a flat_store
+template <class T> __device__ __forceinline__ T *global_ptr(uint64_t p) { return TF_GLOBAL_PTR(T, p); }
 // number of quote characters in tile positions [a, b), a <= b: prefix counts per 32-byte word + the bitmap
 __device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint32_t b) {
   const uint32_t ca = (uint32_t)t.qpre[a >> 5] + (uint32_t)__popc(t.qmask[a >> 5] & ((1u << (a & 31)) - 1u));
@@ -1176,27 +1188,40 @@ __device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint
   return cb - ca;
 }
 
-// Up to eight decimal digits that END at tile position `end` (nd of them, 1..8): the 8-byte window [end - 8, end) holds
-// them right-aligned, so no shifting by the field length is needed — mask what precedes them, check, two v_dot4 per four.
-// Returns false on a non-digit.
-__device__ __forceinline__ bool digits8_end(const uint8_t *sb, uint32_t end, uint32_t nd, uint32_t *out) {
+// The 8-byte window [end - 8, end) of the tile as two words (byte 0 of lo = sb[end - 8]): three aligned LDS words, two v_alignbyte.
+__device__ __forceinline__ void window8(const uint8_t *sb, uint32_t end, uint32_t *lo, uint32_t *hi) {
   const int e8 = (int)end - 8;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(sb + (e8 & ~3));
   const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
-  const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)e8) ^ 0x30303030u, hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)e8) ^ 0x30303030u;
+  *lo = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)e8); *hi = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)e8);
+}
+// Up to eight decimal digits that END the window (nd of them, 1..8): they sit right-aligned, so no shifting by the field
+// length is needed — mask what precedes them, check, two v_dot4 per four.  Returns false on a non-digit.
+template <bool NARROW = false>
+__device__ __forceinline__ bool digits8_window(uint32_t wlo, uint32_t whi, uint32_t nd, uint32_t *out) {
+  const uint32_t lo = wlo ^ 0x30303030u, hi = whi ^ 0x30303030u;
   const uint64_t keep = ~0ull << (8 * (8 - nd));  // nd >= 1
   const uint32_t tlo = lo & (uint32_t)keep, thi = hi & (uint32_t)(keep >> 32);
-  *out = __umul24(four_dot(tlo), 10000u) + four_dot(thi);  // < 10^8
+  if (NARROW) *out = __umul24(tlo >> 24, 10000u) + four_dot(thi);  // callers that reject nd > 5 anyway: the fifth digit is tlo's top byte
+  else *out = __umul24(four_dot(tlo), 10000u) + four_dot(thi);     // < 10^8
   return (((tlo + 0x76767676u) | tlo | (thi + 0x76767676u) | thi) & 0x80808080u) == 0;
+}
+__device__ __forceinline__ bool digits8_end(const uint8_t *sb, uint32_t end, uint32_t nd, uint32_t *out) {
+  uint32_t lo, hi;
+  window8(sb, end, &lo, &hi);
+  return digits8_window(lo, hi, nd, out);
 }
 
 template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
-    const RegCell c = reg_cell(t, (uint32_t)run.first, (s - sbase) * 64 + (uint32_t)lane, items);
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  if (s0 >= sbase + nslots) return;
+  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
+  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     if (!c.on) continue;
-    T *const out = (T *)t.colp0[c.col];
+    T *const out = global_ptr<T>(t.colp0[c.col]);
     const uint32_t n = c.fend - c.fs;
     const uint32_t c0 = t.sb[c.fs];
     const bool neg = c0 == '-', sgn = neg || c0 == '+';
@@ -1205,11 +1230,14 @@ template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const R
     bool ok = nd - 1u < 19u && n <= 0x7FFFu && !(nd > 1 && t.sb[c.fend - nd] == '0');
     if constexpr (KIND == CK_UINT && W == 8) ok = ok && !sgn;  // ParseUint takes no sign
     uint32_t g0v = 0;
-    ok = digits8_end(t.sb, c.fend, min(nd, 8u), &g0v) && ok;
+    uint32_t wlo, whi;
+    window8(t.sb, c.fend, &wlo, &whi);
+    ok = digits8_window<(W < 4)>(wlo, whi, min(nd, 8u), &g0v) && ok;
     if (W < 4 || nd <= 8) {
       if constexpr (W < 4) {
-        if constexpr (KIND == CK_INT) ok = ok && nd <= 8 && g0v <= (1u << (W * 8 - 1)) - (neg ? 0u : 1u);
-        else ok = ok && nd <= 8 && g0v <= (1u << (W * 8)) - 1u;
+        // six digits and more are out of range whatever they are (no leading zeros): the narrow digit sum reads five
+        if constexpr (KIND == CK_INT) ok = ok && nd <= 5 && g0v <= (1u << (W * 8 - 1)) - (neg ? 0u : 1u);
+        else ok = ok && nd <= 5 && g0v <= (1u << (W * 8)) - 1u;
       }
       if constexpr (KIND == CK_UINT) ok = ok && !(neg && g0v != 0);
       if (ok) out[c.r] = (T)(neg ? -(int32_t)g0v : (int32_t)g0v);
@@ -1229,10 +1257,13 @@ template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const R
 
 __device__ __forceinline__ void reg_cells_str(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
-    const RegCell c = reg_cell(t, (uint32_t)run.first, (s - sbase) * 64 + (uint32_t)lane, items);
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  if (s0 >= sbase + nslots) return;
+  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
+  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     if (!c.on) continue;
-    uint32_t *const lens = (uint32_t *)t.colp0[c.col], *const fstart = (uint32_t *)t.colp1[c.col];
+    uint32_t *const lens = global_ptr<uint32_t>(t.colp0[c.col]), *const fstart = global_ptr<uint32_t>(t.colp1[c.col]);
     const uint32_t n = c.fend - c.fs;
     if (n == 0) { lens[c.r] = 0; fstart[c.r] = t.g0 + c.fs; continue; }
     bool done = false;
@@ -1266,10 +1297,13 @@ __device__ __forceinline__ uint32_t dig2(uint32_t w, int byte, uint32_t *bad) { 
 }
 template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
-    const RegCell c = reg_cell(t, (uint32_t)run.first, (s - sbase) * 64 + (uint32_t)lane, items);
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  if (s0 >= sbase + nslots) return;
+  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
+  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     if (!c.on) continue;
-    int64_t *const sec = (int64_t *)t.colp0[c.col]; int32_t *const nanos = (int32_t *)t.colp1[c.col];
+    int64_t *const sec = global_ptr<int64_t>(t.colp0[c.col]); int32_t *const nanos = global_ptr<int32_t>(t.colp1[c.col]);
     const uint32_t n = c.fend - c.fs;
     bool done = false;
     if ((n == 10 || n == 19) && t.sb[c.fs + 4] == '-') {
@@ -1498,7 +1532,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   {
     RegTile t;
     t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.slowf = slowf; t.colp0 = colp0; t.colp1 = colp1; t.colfield = colfield;
-    t.nr = nr; t.NF = NF; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
+    t.nr = nr; t.NF = NF; t.step_q = 512u / nr; t.step_r = 512u - t.step_q * nr; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
     t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0;
     uint32_t sbase = 0;
     for (int ri = 0; ri < p.nruns; ri++) {
