@@ -29,4 +29,7 @@ for w in csv configs3 debezium; do
   f=$(find "$OUT/prof_$w" -name "*kernel_stats.csv" | head -1); echo "== rocprof $w"; [ -n "$f" ] && head -8 "$f" | cut -c1-150
 done
 bash tools/gpu_pmc2.sh "csv_parse_regular" $TAG/pmc_csv csv 5 > "$OUT/pmc_csv.log" 2>&1; tail -12 "$OUT/pmc_csv.log"
+if [ -n "$ICACHE" ]; then  # instruction-cache behaviour of the largest kernel (one pass)
+  bash tools/gpu_pmc2.sh "ser_tile_write" $TAG/pmc_icache configs3 1 "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" > "$OUT/pmc_icache.log" 2>&1; tail -8 "$OUT/pmc_icache.log"
+fi
 echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s"
