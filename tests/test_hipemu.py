@@ -173,9 +173,14 @@ def test_emulated_exchange_ranks(tmp_path, case, world):
 
 
 def _gpu_count():
+    """Devices as the library itself sees them.  Deliberately NOT through torch: this runs at collection time, and importing
+    torch there loads torch's own bundled HIP / HSA / RCCL copies into the test process before libtfgpu.so — the RCCL the
+    library then binds (dlopen by soname finds the bundled one) fails its init with 'no ROCm-capable device is detected'."""
     try:
-        import torch
-        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+        import ctypes
+        from transferia_amd import lib
+        n = ctypes.c_int(0)
+        return int(n.value) if lib.load().tfgpu_device_count(ctypes.byref(n)) == 0 else 0
     except Exception:  # noqa: BLE001
         return 0
 

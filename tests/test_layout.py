@@ -87,3 +87,16 @@ def test_product_never_touches_the_emulator():
     lib_src = open(os.path.join(PKG, "lib.py"), encoding="utf-8").read()
     assert re.search(r'_LIBPATH\s*=\s*os\.path\.join\(_HERE,\s*"libtfgpu\.so"\)', lib_src)
     assert not re.search(r"environ[^\n]*LIB", lib_src)
+
+
+def test_collecting_the_suite_does_not_import_torch():
+    """torch brings its own HIP / HSA / RCCL copies; loaded into the test process before libtfgpu.so (at collection time, say,
+    through a skipif that counts GPUs) they are what the library's RCCL binding then finds, and its init fails on the GPU box.
+    Tests that need torch import it inside a worker process."""
+    import subprocess
+    import sys
+    code = ("import sys, pytest\n"
+            "pytest.main(['--collect-only', '-q', '-p', 'no:cacheprovider', %r])\n"
+            "print('TORCH-LOADED' if 'torch' in sys.modules else 'TORCH-FREE')\n") % os.path.join(ROOT, "tests")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT).stdout
+    assert "TORCH-FREE" in out, out[-2000:]
