@@ -79,6 +79,11 @@ struct Context {
   std::mutex mu;  // serialises API calls that enqueue on the stream
   int num_cus = 256;
   std::shared_ptr<struct DevMem> pow10tab;  // math.Pow10(n), n = -323..308 (tf_json.hip)
+  // read-only descriptor tables already in HBM, by content (upload_const): a steady stream of same-shaped batches re-sends
+  // the same column / plan tables call after call
+  struct ConstEntry { uint64_t hash; std::vector<uint8_t> bytes; std::shared_ptr<struct DevMem> mem; uint64_t stamp; };
+  std::vector<ConstEntry> consts;
+  uint64_t const_clock = 0;
 
   hipEvent_t get_event();
   void prof_begin(const char *name, Pending &p);
@@ -116,6 +121,8 @@ template <class T> inline T *ptr(const Buf &b) { return b ? reinterpret_cast<T *
 void h2d(void *dst, const void *src, size_t n);
 void h2d_small(void *dst, const void *src, size_t n);  // via the pinned arena: truly async
 Buf upload_small(const void *src, size_t n);
+// the same for tables no kernel ever writes: an identical table uploaded earlier on this lane is handed out again (no copy)
+Buf upload_const(const void *src, size_t n);
 // n uint32 words read back into the pinned arena; valid after the next sync()
 const uint32_t *d2h_u32(const void *dev, size_t n = 1);
 struct PinScope { PinScope() {} };  // (the pinned arena is a ring; nothing to do per call)

@@ -2158,7 +2158,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   std::vector<uint32_t> loff{0}; std::string ldata;
   auto add_list = [&](int n, const char *const *v) { for (int i = 0; i < n; i++) { ldata += v[i] ? v[i] : ""; loff.push_back((uint32_t)ldata.size()); } };
   add_list(opts->n_null_values, opts->null_values); add_list(opts->n_true_values, opts->true_values); add_list(opts->n_false_values, opts->false_values);
-  auto up = [&](const void *src, size_t bytes) { return upload_small(src, bytes); };
+  auto up = [&](const void *src, size_t bytes) { return upload_const(src, bytes); };  // tables the kernels only read
   Buf bcols = up(cols.data(), cols.size() * sizeof(CsvCol)), bff = up(field_first.data(), field_first.size() * 4);
   Buf bloff = up(loff.data(), loff.size() * 4), bldata = up(ldata.data(), ldata.size());
   // time layouts: the user's TimestampParsers, and spf13/cast v1.7.1 StringToDate's list (caste.go timeFormats) in its order

@@ -46,6 +46,7 @@ static void destroy_lane(std::unique_ptr<Context> &c) {
   for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : c->free_events) hipEventDestroy(e);
   c->pow10tab.reset();
+  c->consts.clear();
   c->blocks.trim();
   if (c->pin_base) hipHostFree(c->pin_base);
   hipStreamDestroy(c->stream);
@@ -172,6 +173,26 @@ Buf upload_small(const void *src, size_t n) {
   Buf b = dalloc(n + 16);
   h2d_small(b->p, src, n);
   return b;
+}
+Buf upload_const(const void *src, size_t n) {
+  static const bool off = [] { const char *e = std::getenv("TFGPU_NO_CONST_CACHE"); return e && e[0] == '1'; }();  // A/B measurements
+  if (n == 0 || n > (32u << 10) || off) return upload_small(src, n);
+  Context &cx = ctx();
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over 8-byte steps, tail bytewise
+  const uint8_t *b = static_cast<const uint8_t *>(src);
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); h = (h ^ w) * 1099511628211ull; }
+  for (; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  for (auto &e : cx.consts)
+    if (e.hash == h && e.bytes.size() == n && !std::memcmp(e.bytes.data(), src, n)) { e.stamp = ++cx.const_clock; return e.mem; }
+  Buf m = upload_small(src, n);
+  if (cx.consts.size() >= 128) {  // drop the entry used longest ago
+    size_t old = 0;
+    for (size_t k = 1; k < cx.consts.size(); k++) if (cx.consts[k].stamp < cx.consts[old].stamp) old = k;
+    cx.consts.erase(cx.consts.begin() + (long)old);
+  }
+  cx.consts.push_back(Context::ConstEntry{h, std::vector<uint8_t>(b, b + n), m, ++cx.const_clock});
+  return m;
 }
 void d2h(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, ctx().stream)); }
 void d2d(void *dst, const void *src, size_t n) { if (n) TF_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, ctx().stream)); }

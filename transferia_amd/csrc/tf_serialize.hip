@@ -753,7 +753,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     auto res = std::make_unique<tfgpu_dbuf>();
     if (n == 0 || (ncols == 0 && format == TFGPU_FMT_CSV && n == 0)) { res->mem = dalloc(64); res->size = 0; *out = res.release(); return TFGPU_OK; }
 
-    Buf bsc = upload_small(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_small(blob.data(), blob.size());
+    Buf bsc = upload_const(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_const(blob.data(), blob.size());
     Buf cell = dalloc((size_t)std::max(ncols, 1) * (size_t)n * 4), row_len = dalloc((size_t)(n + 1) * 4 + 16), last = dalloc((size_t)n * 4 + 16);
     SerParams p{};
     p.cols = ptr<SCol>(bsc); p.ncols = ncols; p.nrows = n; p.format = format; p.any_as_string = any_as_string;
@@ -995,7 +995,7 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
       q.gstart = ptr<int64_t>(a); q.gpart = ptr<uint32_t>(c);
     }
 
-    Buf bsc = upload_small(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_small(blob.data(), blob.size());
+    Buf bsc = upload_const(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_const(blob.data(), blob.size());
     Buf cell = dalloc((size_t)ncell * (size_t)n * 4), row_len = dalloc((size_t)(n + 1) * 4 + 16), mflags = dalloc((size_t)n + 16);
     SerParams p{};
     p.cols = ptr<SCol>(bsc); p.ncols = ncell; p.nrows = n; p.format = TFGPU_FMT_JSON; p.any_as_string = 0; p.closing_newline = 0;

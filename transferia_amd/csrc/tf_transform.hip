@@ -565,25 +565,25 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   if (in.src_row) fx.push_back(GFix{in.src_row->p, out->src_row->p, 4, 0});
   else fx.push_back(GFix{nullptr, out->src_row->p, 4, 0});
   if (m && !bits.empty()) {
-    Buf bb = upload_small(bits.data(), bits.size() * sizeof(GBit));
+    Buf bb = upload_const(bits.data(), bits.size() * sizeof(GBit));
     gather_bitmap_all<<<dim3(grid_for((m + 7) / 8, 256), (unsigned)bits.size()), 256, 0, st>>>(ptr<GBit>(bb), sp, m);
   }
-  Buf bfx = upload_small(fx.data(), fx.size() * sizeof(GFix));
+  Buf bfx = upload_const(fx.data(), fx.size() * sizeof(GFix));
   if (m) gather_fixed_all<<<g, 256, 0, st>>>(ptr<GFix>(bfx), (int)fx.size(), sp, m);
   if (nvar) {
-    Buf bvr = upload_small(vr.data(), vr.size() * sizeof(GVar));
+    Buf bvr = upload_const(vr.data(), vr.size() * sizeof(GVar));
     if (m) gather_len_all<<<g, 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), m, nvar, seg_stride);
     if (m) {  // long cells: short runs of rows; short cells: long runs (the fixed latency of a run needs bytes to amortise over)
       std::vector<GVar> lng, sht;
       for (size_t i = 0; i < vr.size(); i++) if (vr[i].out_data) ((col_at(var_cols[i]).data_len >= (uint64_t)in.nrows * 8) ? lng : sht).push_back(vr[i]);
-      Buf blng = upload_small(lng.data(), lng.size() * sizeof(GVar)), bsht = upload_small(sht.data(), sht.size() * sizeof(GVar));
+      Buf blng = upload_const(lng.data(), lng.size() * sizeof(GVar)), bsht = upload_const(sht.data(), sht.size() * sizeof(GVar));
       if (!lng.empty()) gather_bytes_all<1><<<dim3(grid_for(m, 256), (unsigned)lng.size()), 256, 0, st>>>(ptr<GVar>(blng), sp, m);
       if (!sht.empty()) gather_bytes_cells<<<dim3(grid_for(m, 256), (unsigned)sht.size()), 256, 0, st>>>(ptr<GVar>(bsht), sp, m);
       std::vector<GVar> lz;
       for (auto &x : vr) if (x.fstart && x.has_special) lz.push_back(x);
       if (!lz.empty()) {
-        Buf blz = upload_small(lz.data(), lz.size() * sizeof(GVar));
+        Buf blz = upload_const(lz.data(), lz.size() * sizeof(GVar));
         gather_text_special<<<dim3(grid_for(m, 256), (unsigned)lz.size()), 256, 0, st>>>(ptr<GVar>(blz), sp, m);
       }
     }
@@ -665,7 +665,7 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_rows(const tfgpu_plan &p, cons
     if (c.lazy()) { DColumn shell = c; shell.view = nullptr; cols.push_back(dcol_of(shell)); }  // no term reads it: its payload stays unpacked
     else cols.push_back(dcol_of(c));
   }
-  auto up = [&](const void *src, size_t bytes) { return upload_small(src, bytes); };
+  auto up = [&](const void *src, size_t bytes) { return upload_const(src, bytes); };  // tables the kernels only read
   Buf bcols = up(cols.data(), cols.size() * sizeof(DCol)), bterms = up(terms.data(), terms.size() * sizeof(DTerm));
   Buf bexpr = up(expr_start.data(), expr_start.size() * 4), bints = up(ints.data(), ints.size() * 8), bfl = up(floats.data(), floats.size() * 8);
   Buf bsoff = up(soff.data(), soff.size() * 4), bsd = up(sdata.data(), sdata.size());
