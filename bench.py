@@ -405,7 +405,7 @@ class JsonWorkload(_Prepared):
 
     def alg(self):
         s = self.state
-        return {"json_parse_lines": len(self.data) + s["parsed_bytes"], "csv_count_newlines": len(self.data), "ser_tile_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"],
+        return {"json_parse_tiles": len(self.data) + s["parsed_bytes"], "json_parse_lines": len(self.data) + s["parsed_bytes"], "csv_count_newlines": len(self.data), "ser_tile_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"],
                 "ser_cell_len": s["kept_bytes"], "json_copy_cells": 2 * s["parsed_bytes"]}
 
     def config(self):

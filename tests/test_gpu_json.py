@@ -476,6 +476,85 @@ def test_rest_column_on_device(tf, oracle):
         assert 9 in got and 10 not in got and 4 not in got and 5 not in got
 
 
+def _tile_lines(rng, n):
+    """Lines a producer's serializer would emit — one key order, typed values — with the perturbations the tile parser must
+    hand to the per-line parser (or decide exactly as it would): another key order, a missing / extra / repeated key, blanks,
+    nested values, escapes, numbers at the edges of their types, malformed text."""
+    def val(key):
+        r = rng.random()
+        if rng.random() < 0.85:  # the usual value of the column
+            usual = {"i8": lambda: rng.randrange(-128, 128), "u16": lambda: rng.randrange(0, 65536), "k": lambda: rng.randrange(-10**6, 10**6),
+                     "i64": lambda: rng.randrange(-2**63, 2**63), "u64": lambda: rng.randrange(0, 2**63), "d": lambda: rng.choice([rng.randrange(-10**6, 10**6), rng.random() * 1000]),
+                     "b": lambda: rng.random() < 0.5, "t": lambda: rng.randrange(1_300_000_000, 1_400_000_000), "a": lambda: rng.choice(["D", "5", "ok"]),
+                     "s": lambda: rng.choice(["", "plain", "Заголовок", "x" * rng.randrange(0, 60) + '"q"']), "y": lambda: "http://example.com/?q=%d" % rng.randrange(10**6)}
+            return usual[key]()
+        if key in ("i8", "u16", "k"):
+            return rng.choice([0, 1, -1, 127, 128, 255, 65535, 65536, -32769, 2**31 - 1, 2**31, -2**31 - 1, rng.randrange(-10**6, 10**6)])
+        if key in ("i64", "u64"):
+            return rng.choice([0, -1, 10**17, 10**18 - 1, 10**18, 2**63 - 1, 2**63, 2**64 - 1, -2**63, -2**63 - 1, 10**19 - 1, 10**19, 10**20, rng.randrange(-2**63, 2**63)])
+        if key == "d":
+            return rng.choice([0, 7, -7, 10**15 - 1, 10**15, 10**16, 0.5, -1.25, 1e5, 1.5e-7, 3.0e300, 12345.678])
+        if key == "b":
+            return rng.choice([True, False, 0, 1, "true", None]) if r < 0.3 else rng.random() < 0.5
+        if key == "t":
+            return rng.choice([0, 1_370_000_000, 10**15, 10**16, -5, 1.5, "2020-01-01", None]) if r < 0.3 else rng.randrange(1_300_000_000, 1_400_000_000)
+        if key == "a":
+            return rng.choice(["D", "5", "", " {x", "nul", "a<b", "q\"q", "é", 5, 1.5, True, None, [1, 2], {"z": 1}, "  n"])
+        pad = "x" * rng.randrange(0, 60)  # moves the following bytes across the 16 / 48 / 64-byte chunk borders
+        return rng.choice(["", "plain", pad, pad + '"', pad + "\\", pad + "\\\\" + '"', pad + "\\" * rng.randrange(1, 70), "tab\there", "Заголовок", "[{,:}]", "a,b:c", pad + "é"])
+    keys = ["k", "i8", "u16", "i64", "u64", "d", "b", "s", "y", "t", "a"]
+    out = []
+    for i in range(n):
+        doc = [(key, val(key)) for key in keys]
+        r = rng.random()
+        if r < 0.01: doc[2], doc[5] = doc[5], doc[2]
+        elif r < 0.02: del doc[rng.randrange(1, len(doc))]
+        elif r < 0.03: doc.insert(rng.randrange(len(doc) + 1), ("extra%d" % rng.randrange(3), rng.choice([1, "x", None, [1], 2.5])))
+        elif r < 0.04: doc.append(doc[rng.randrange(len(doc))])
+        elif r < 0.045: doc = []
+        sep = (",", ":") if rng.random() < 0.9 else rng.choice([(", ", ": "), (" ,\t", " : "), (",", ": ")])
+        body = sep[0].join(json.dumps(key) + sep[1] + json.dumps(v, ensure_ascii=rng.random() < 0.5, separators=sep) for key, v in doc)
+        line = ("{" + rng.choice(["", "", " "]) + body + rng.choice(["", "", " "]) + "}").encode("utf-8")
+        r = rng.random()
+        if r < 0.005: line = line[:rng.randrange(1, len(line))]                     # cut short
+        elif r < 0.01: line = line.replace(b":", b"::", 1)
+        elif r < 0.015: line = line.replace(b'"', b"'", 1)
+        elif r < 0.017: line = line[:-1] + b',"pad":"' + b"z" * 26000 + b'"}'         # longer than a tile
+        elif r < 0.027: line = line.replace(b"7", b"007", 1)
+        elif r < 0.037: line = line.replace(b"1", b"-0", 1)
+        if b"\n" not in line:
+            out.append(line)
+    return out
+
+
+def test_tile_path_against_the_per_line_grammar(tf, oracle):
+    """json_parse_tiles decides only what it is sure of and lists the rest: whatever mix of lines it gets, the batch must
+    be the oracle's, line for line."""
+    rng = random.Random(SEED0 + 4242)
+    fields = abi.Schema.of(EDGE_FIELDS)
+    lines = _tile_lines(rng, 8000)
+    for kw in ({}, {"use_numbers_in_any": True, "null_keys_allowed": True}, {"add_rest": True, "add_dedupe_keys": True}):
+        opts = abi.json_options(topic="t", **kw)
+        out, errs, nfb = compare(tf, oracle, opts, fields, b"\n".join(lines), None, "tiles %s" % kw, max_fallback=len(lines))
+        assert out.nrows > 1000
+    # one object per message (no newline between them), the bench's shape
+    vals = lines[:1500]
+    data, msgs = abi.messages(vals, list(range(len(vals))), [1_700_000_000_000_000_000 + i for i in range(len(vals))])
+    compare(tf, oracle, abi.json_options(topic="t", add_dedupe_keys=True), fields, data, msgs, "tiles as messages", max_fallback=len(vals))
+
+
+def test_per_line_path_cross_check():
+    """The tile parser is the default; with TFGPU_JSON_TILES=0 every line takes the per-line parser.  Both must pass the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFGPU_JSON_TILES="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_json.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "edge or random or flat or canon or rules or aux or messages or tile_path or float or rest"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_wave_path_cross_check():
     """The wave-cooperative parser (TFGPU_JSON_WAVEPATH=1: simdjson-style stage 1 on the scalar unit, members on lanes)
     and the per-line parser are two independent implementations of the same grammar: the edge-case, fuzz and flat

@@ -27,12 +27,15 @@
 // HBM-bound byte kernel: algorithmic traffic B_json + B_bin per row.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "tf_common.hpp"
 #include "tf_devfmt.hpp"
 #include "tf_devfloat.hpp"
 #include "tf_devparse.hpp"
+#include "tf_wave.hpp"
+#include "tf_swar.hpp"
 
 namespace tf {
 
@@ -971,6 +974,15 @@ __global__ void __launch_bounds__(256) json_parse_listed(JParams p, const uint32
   parse_json_line<true>(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i]);
 }
 
+// the lines the tile path hands over, through the lean per-line parser first; what needs the map emitter is listed again
+__global__ void __launch_bounds__(256) json_parse_listed_lean(JParams p, const uint32_t *slow_n, const uint32_t *slow_seg, uint32_t *heavy_n, uint32_t *heavy_seg) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= *slow_n) return;
+  const uint32_t i = slow_seg[k];
+  const uint64_t s = p.seg_start[i];
+  if (parse_json_line<false>(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i])) { const uint32_t q = atomicAdd(heavy_n, 1u); heavy_seg[q] = i; }
+}
+
 // ---------------------------------------------------------------------------
 // wave path.  One 64-lane wave owns a line.  Stage 1 is simdjson's, on the scalar unit: 64 bytes per step, one
 // byte per lane, every character class a ballot (a 64-bit mask in SGPRs), escaped quotes by the add-carry trick,
@@ -1192,6 +1204,496 @@ __global__ void __launch_bounds__(256) json_parse_waves(JParams p, uint32_t *slo
       if (!fb && nm && p.rest_lens) { p.rest_fstart[r] = (uint32_t)base; p.rest_meta[r] = (JM_REST_EMPTY << 28); p.rest_lens[r] = 2; }  // every key was known: {}
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// tile path.  The CSV tile parser's shape applied to NDJSON: a workgroup stages a run of consecutive lines in LDS,
+// classifies its bytes once with SWAR masks (unescaped quotes by the backslash-run carry trick, the in-string state by a
+// prefix xor carried across lanes and waves), indexes the separators { } [ ] , : that lie outside strings, and then
+// treats (member, line) pairs as cells dealt to the waves by VALUE KIND — members sorted by the kind of the column that
+// reads them, lines fastest — so that a wave runs one typed parse per step and neighbouring lanes store neighbouring
+// rows of one column.  The member → column map is looked up once per tile, for its first line; every other line must
+// spell the same keys in the same order (bytes compared in LDS), which is what a producer's serializer emits.
+// Only what is certain is decided here: compact flat objects (no blank outside strings), values that are strings,
+// null / true / false or plain decimal integers.  Every other line — another key sequence, a nested value, a float, a
+// blank, anything that does not validate — is listed for json_parse_listed, which re-parses it whole.
+// ---------------------------------------------------------------------------
+static constexpr int JT_THREADS = 512;
+static constexpr int JT_CPT = 3;                           // 16-byte chunks per thread
+static constexpr int JT_BYTES = JT_THREADS * JT_CPT * 16;  // 24 KiB of text per tile
+static constexpr int JT_LINES = 32;                        // lines per tile at most
+static constexpr int JT_SCAP = 4608;                       // separators indexed per tile
+static constexpr int JT_MEM = 192;                         // members per line
+static constexpr int JT_OWN = 512;                         // columns (duplicate-key check)
+static constexpr int JT_KREF = 4096;                       // bytes of key text the member map keeps
+enum JtClass : uint32_t { JTC_SKIP = 0, JTC_I8, JTC_I16, JTC_I32, JTC_I64, JTC_U8, JTC_U16, JTC_U32, JTC_U64, JTC_TEXT, JTC_ANY, JTC_BOOL, JTC_TIME, JTC_F64, JTC_COUNT };
+
+struct JtTile {
+  const uint8_t *sb; const uint16_t *spos; const uint32_t *qmask; const uint16_t *qpre, *bpre;
+  uint32_t g0;
+};
+// unescaped quotes / backslashes in tile positions [a, b), a <= b
+__device__ __forceinline__ uint32_t jt_quotes_in(const JtTile &t, uint32_t a, uint32_t b) {
+  const uint32_t ca = (uint32_t)t.qpre[a >> 5] + (uint32_t)__popc(t.qmask[a >> 5] & ((1u << (a & 31)) - 1u));
+  const uint32_t cb = (uint32_t)t.qpre[b >> 5] + (uint32_t)__popc(t.qmask[b >> 5] & ((1u << (b & 31)) - 1u));
+  return cb - ca;
+}
+// the 8 bytes at tile position a (any alignment), little-endian
+__device__ __forceinline__ uint64_t jt_word(const uint8_t *sb, uint32_t a) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(sb + (a & ~3u));
+  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+  return (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, a) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, a) << 32);
+}
+__device__ __forceinline__ bool jt_same2(const uint8_t *sb, uint32_t a, const uint8_t *kr, uint32_t b, uint32_t n) {  // n bytes at sb + a and at kr + b (b a multiple of 8)
+  for (uint32_t k = 0; k < n; k += 8) {
+    const uint32_t nb = n - k < 8 ? n - k : 8u;
+    const uint64_t m = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
+    if ((jt_word(sb, a + k) ^ *reinterpret_cast<const uint64_t *>(kr + b + k)) & m) return false;
+  }
+  return true;
+}
+// -?digits with at most 19 digits (their value fits 64 bits unsigned).  false: not that form.
+__device__ __forceinline__ bool jt_int_token(const uint8_t *sb, uint32_t vs, uint32_t ve, bool *neg, uint64_t *mag, uint32_t *ndig) {
+  const uint32_t n = ve - vs;
+  const bool ng = sb[vs] == '-';
+  const uint32_t nd = n - (ng ? 1u : 0u);
+  if (nd - 1u >= 19u) return false;
+  uint32_t g0v = 0, g1v = 0, g2v = 0, lo, hi;
+  window8(sb, ve, &lo, &hi);
+  bool ok = digits8_window(lo, hi, min(nd, 8u), &g0v);
+  if (nd > 8) { window8(sb, ve - 8, &lo, &hi); ok = digits8_window(lo, hi, min(nd - 8, 8u), &g1v) && ok; }
+  if (nd > 16) { window8(sb, ve - 16, &lo, &hi); ok = digits8_window(lo, hi, nd - 16, &g2v) && ok; }
+  *neg = ng; *ndig = nd;
+  *mag = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;
+  return ok;
+}
+// parseRawNumber's token: a run of [0-9.+-eE] that is not a lone sign (inf / nan spellings: per-line path)
+__device__ __forceinline__ bool jt_number_chars(const uint8_t *sb, uint32_t vs, uint32_t ve) {
+  if (ve - vs > 64u) return false;
+  for (uint32_t i = vs; i < ve; i++) { const uint32_t d = (uint32_t)sb[i] - 0x2Bu; if (!(d < 64u && ((0x0400000004007FEDull >> d) & 1ull))) return false; }
+  return !(ve - vs == 1 && (sb[vs] == '-' || sb[vs] == '+'));
+}
+// the rare cells (a float that is not a plain integer, a string with escapes) read their bytes from HBM, where the tile just was
+__device__ __forceinline__ bool jt_float_token(const uint8_t *data, uint64_t at, uint32_t n, const double *p10, const uint64_t *p128, double *out) {
+  MemBytes aux(data);
+  const Field tok{&aux, at, n};
+  return ff_best_effort(tok, n, p10, p128, out) == 0;
+}
+__device__ __forceinline__ uint32_t jt_unescaped_len(const uint8_t *data, uint64_t at, uint32_t n) {
+  MemBytes aux(data);
+  CountSink cs;
+  unescape_walk(aux, at, n, cs);
+  return cs.n;
+}
+__device__ __forceinline__ bool jt_ws(uint32_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+__device__ __forceinline__ bool jt_lit(const uint8_t *sb, uint32_t vs, uint32_t n, uint32_t word, uint32_t len) {  // the 4 first bytes + length
+  return n == len && (uint32_t)jt_word(sb, vs) == word && (len == 4 || sb[vs + 4] == 'e');
+}
+
+__global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int32_t lines_per_tile, uint32_t *slow_n, uint32_t *slow_seg) {
+  __shared__ __attribute__((aligned(16))) uint8_t sbuf[16 + JT_BYTES + 48];
+  __shared__ uint16_t spos[JT_SCAP + 2];
+  __shared__ uint32_t qmask[JT_BYTES / 32 + 1], smask[JT_BYTES / 32 + 1];  // unescaped quotes; inside a string after the byte
+  __shared__ uint16_t qpre[JT_BYTES / 32 + 2], bpre[JT_BYTES / 32 + 2];    // quotes / backslashes in front of each 32-byte word
+  __shared__ uint32_t bmask[JT_BYTES / 32 + 1];
+  __shared__ uint32_t wpar[JT_THREADS / 64], wcnt[JT_THREADS / 64], wqc[JT_THREADS / 64], wbc[JT_THREADS / 64];
+  __shared__ uint16_t lstart[JT_LINES], lend[JT_LINES], lbase[JT_LINES], lK[JT_LINES];
+  __shared__ int32_t lrow[JT_LINES];
+  __shared__ uint8_t lslow[JT_LINES];
+  __shared__ int16_t mcol[JT_MEM];
+  __shared__ uint16_t mks[JT_MEM], mkn[JT_MEM];
+  __shared__ uint8_t mcls[JT_MEM], perm[JT_MEM];
+  __shared__ uint64_t mp0[JT_MEM], mp1[JT_MEM], mp2[JT_MEM], mp3[JT_MEM];
+  __shared__ uint16_t owner[JT_OWN];
+  __shared__ uint32_t cfirst[JTC_COUNT + 1];
+  __shared__ uint32_t misc[4];  // 0: tile cannot be taken, 1: separators
+  // the member map outlives a tile: a workgroup walks many tiles, and a stream keeps its key order
+  __shared__ __attribute__((aligned(16))) uint8_t kref[JT_KREF + 32];  // the keys the map was built from, back to back
+  __shared__ uint16_t mko[JT_MEM];
+  __shared__ uint32_t mapst[4];  // 0: members of the mapped key sequence, 1: the map is valid, 2: lines of this tile that spell other keys
+  uint8_t *const sb = sbuf + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 4) mapst[tid] = 0;
+  const int64_t ntiles = (p.nseg + lines_per_tile - 1) / lines_per_tile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  __syncthreads();  // the previous tile's LDS is free
+  const int64_t i0 = tile * lines_per_tile;
+  const int nl = (int)min<int64_t>(lines_per_tile, p.nseg - i0);
+  auto all_slow = [&]() {  // every line of the tile goes to the per-line kernel
+    for (int j = tid; j < nl; j += JT_THREADS) if (p.seg_len[i0 + j]) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)(i0 + j); }
+  };
+  // the tile's byte range: from its first non-empty line to the end of its last one
+  uint32_t first = 0xFFFFFFFFu, last = 0;
+  for (int j = 0; j < nl; j++) {  // (uniform: a handful of scalar loads)
+    const uint32_t n = p.seg_len[i0 + j];
+    if (!n) continue;
+    const uint32_t s = p.seg_start[i0 + j];
+    if (first == 0xFFFFFFFFu) first = s;
+    last = s + n;
+  }
+  if (first == 0xFFFFFFFFu) continue;  // nothing but empty lines
+  const uint32_t g0 = first & ~15u;
+  if (last - g0 > (uint32_t)JT_BYTES || nl > JT_LINES || p.ncols > JT_OWN) { all_slow(); continue; }
+
+  // ---- stage: coalesced 16 B per lane ----
+#pragma unroll
+  for (int it = 0; it < JT_CPT; it++) {
+    const int chunk = it * JT_THREADS + tid;
+    const uint32_t gp = g0 + (uint32_t)chunk * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gp < last) v = *reinterpret_cast<const uint4 *>(p.data + gp);  // the buffer is padded past its payload
+    *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
+  }
+  if (tid < 4) { reinterpret_cast<uint32_t *>(sbuf)[tid] = 0; misc[tid] = 0; }
+  if (tid < 12) reinterpret_cast<uint32_t *>(sbuf + 16 + JT_BYTES)[tid] = 0;
+  if (tid < nl) {
+    const uint32_t n = p.seg_len[i0 + tid], s = p.seg_start[i0 + tid];
+    lstart[tid] = (uint16_t)(n ? s - g0 : 0); lend[tid] = (uint16_t)(n ? s - g0 + n : 0);
+    lrow[tid] = n ? (int32_t)p.seg_ord[i0 + tid] : -1;
+    lslow[tid] = n ? 0 : 2;  // 2: no line here
+  }
+  for (int i = tid; i < JT_OWN; i += JT_THREADS) owner[i] = 0xFFFFu;
+  __syncthreads();
+
+  // ---- pass 1: byte classes of this thread's 48 bytes ----
+  const uint32_t base_chunk = (uint32_t)tid * JT_CPT, tpos = base_chunk * 16;
+  uint64_t Q = 0, B = 0, S = 0;
+  {
+#pragma unroll
+    for (int q = 0; q < JT_CPT; q++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sb + (base_chunk + q) * 16);
+      const Chunk16 ck = chunk16(v);
+      Q |= (uint64_t)class16(ck, 0x22222222u) << (16 * q);
+      B |= (uint64_t)class16(ck, 0x5C5C5C5Cu) << (16 * q);
+      const uint32_t st = class16(ck, 0x3A3A3A3Au) | class16(ck, 0x2C2C2C2Cu) | class16(ck, 0x7B7B7B7Bu) | class16(ck, 0x7D7D7D7Du) | class16(ck, 0x5B5B5B5Bu) | class16(ck, 0x5D5D5D5Du);
+      S |= (uint64_t)st << (16 * q);
+    }
+  }
+  {  // what precedes the tile's first line (up to 15 bytes, the tail of the line before) belongs to another tile
+    const uint32_t frs = first - g0;
+    if (tpos < frs) { const uint64_t keep = frs - tpos >= 64 ? 0ull : ~0ull << (frs - tpos); Q &= keep; B &= keep; S &= keep; }
+  }
+  // quotes escaped by an odd run of backslashes; a run that reaches back over this thread's first byte is counted in LDS
+  uint32_t bad = 0;
+  {
+    uint32_t k = 0;  // backslashes directly in front of this thread's bytes (sb[-1] is a zero pad byte)
+    while (k < 64 && sb[(int)tpos - 1 - (int)k] == '\\') k++;
+    if (k >= 64) bad = 1;
+    const uint64_t carry = k & 1u;
+    uint64_t bs = B & ~carry;
+    const uint64_t follows = (bs << 1) | carry;
+    const uint64_t even = 0x5555555555555555ull;
+    const uint64_t odd_starts = bs & ~even & ~follows;
+    const uint64_t sum = odd_starts + bs;
+    const uint64_t escaped = (even ^ (sum << 1)) & follows;
+    Q &= ~escaped;
+  }
+  uint32_t par = (uint32_t)__popcll(Q) & 1u;
+  const uint64_t pb = __ballot(par != 0);
+  const uint32_t par_in = lanes_below(pb) & 1u;
+  if (lane == 0) wpar[wv] = (uint32_t)__popcll(pb) & 1u;
+  // quote / backslash words of 32 bytes: this thread's 48 bytes are one and a half of them → write 16-bit halves
+  {
+    uint16_t *q16 = reinterpret_cast<uint16_t *>(qmask), *b16 = reinterpret_cast<uint16_t *>(bmask);
+#pragma unroll
+    for (int q = 0; q < JT_CPT; q++) { q16[base_chunk + q] = (uint16_t)(Q >> (16 * q)); b16[base_chunk + q] = (uint16_t)(B >> (16 * q)); }
+  }
+  if (__any(bad != 0) && lane == 0) misc[0] = 1u;
+  __syncthreads();
+
+  // ---- pass 2: inside-string state, separators outside strings ----
+  uint32_t s_in = par_in;
+  for (int i = 0; i < wv; i++) s_in ^= wpar[i];
+  uint64_t px = Q;  // bit i = parity of the unescaped quotes in bytes [0, i]
+  px ^= px << 1; px ^= px << 2; px ^= px << 4; px ^= px << 8; px ^= px << 16; px ^= px << 32;
+  const uint64_t inside = (px ^ (s_in ? ~0ull : 0ull)) & 0xFFFFFFFFFFFFull;
+  S &= ~inside & 0xFFFFFFFFFFFFull;
+  {
+    uint16_t *s16 = reinterpret_cast<uint16_t *>(smask);
+#pragma unroll
+    for (int q = 0; q < JT_CPT; q++) s16[base_chunk + q] = (uint16_t)(inside >> (16 * q));
+  }
+  const uint32_t cnt = (uint32_t)__popcll(S);
+  const uint32_t cinc = wave_scan_add(cnt);
+  // prefix counts per 32-byte word: words 3*tid/2 … — computed by the threads that own a word's first half
+  const uint32_t qc = (uint32_t)__popcll(Q), bc = (uint32_t)__popcll(B);
+  const uint32_t qinc = wave_scan_add(qc), binc = wave_scan_add(bc);
+  if (lane == 63) { wcnt[wv] = cinc; wqc[wv] = qinc; wbc[wv] = binc; }
+  __syncthreads();
+  uint32_t cpre = 0, ctot = 0, qb = qinc - qc, bb = binc - bc;
+  for (int i = 0; i < JT_THREADS / 64; i++) { const uint32_t x = wcnt[i]; if (i < wv) { cpre += x; qb += wqc[i]; bb += wbc[i]; } ctot += x; }
+  if (misc[0] || ctot > (uint32_t)JT_SCAP) { all_slow(); continue; }  // uniform
+  {
+    // separator index
+    uint32_t k = cpre + cinc - cnt;
+    uint64_t m = S;
+    while (m) { const uint32_t b = (uint32_t)__ffsll((long long)m) - 1; m &= m - 1; spos[k++] = (uint16_t)(tpos + b); }
+    if (tid == 0) { misc[1] = ctot; spos[ctot] = 0xFFFFu; }
+    // quotes / backslashes in front of every 32-byte word that STARTS in this thread's bytes (tpos = 48 * tid: words start at
+    // multiples of 32 → at tpos when tid is even, at tpos + 16 when tid is odd, and at tpos + 32 when tid is even)
+#pragma unroll
+    for (int q = 0; q < JT_CPT; q++) {
+      const uint32_t cp = tpos + 16u * q;
+      if ((cp & 31u) == 0) {
+        const uint64_t below = q ? (1ull << (16 * q)) - 1 : 0ull;
+        qpre[cp >> 5] = (uint16_t)(qb + (uint32_t)__popcll(Q & below));
+        bpre[cp >> 5] = (uint16_t)(bb + (uint32_t)__popcll(B & below));
+      }
+    }
+    if (tid == JT_THREADS - 1) { qpre[JT_BYTES / 32] = (uint16_t)(qb + qc); bpre[JT_BYTES / 32] = (uint16_t)(bb + bc); }
+  }
+  __syncthreads();
+
+  JtTile t;
+  t.sb = sb; t.spos = spos; t.qmask = qmask; t.qpre = qpre; t.bpre = bpre; t.g0 = g0;
+  const uint32_t nsep = misc[1];
+  auto backslashes_in = [&](uint32_t a, uint32_t b) {
+    const uint32_t ca = (uint32_t)bpre[a >> 5] + (uint32_t)__popc(bmask[a >> 5] & ((1u << (a & 31)) - 1u));
+    const uint32_t cb = (uint32_t)bpre[b >> 5] + (uint32_t)__popc(bmask[b >> 5] & ((1u << (b & 31)) - 1u));
+    return cb - ca;
+  };
+  // ---- lines: where their separators start, how many, the frame { … } ----
+  if (tid < nl && lslow[tid] == 0) {
+    const uint32_t ls = lstart[tid], le = lend[tid];
+    uint32_t lo = 0, hi = nsep;  // first separator at or after ls
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (spos[mid] < ls) lo = mid + 1; else hi = mid; }
+    const uint32_t b0 = lo;
+    hi = nsep;                   // first separator at or after le
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (spos[mid] < le) lo = mid + 1; else hi = mid; }
+    const uint32_t c = lo - b0;
+    const bool in_before = ls ? ((smask[(ls - 1) >> 5] >> ((ls - 1) & 31)) & 1u) : false;  // a string open across the line start
+    const bool in_after = (smask[(le - 1) >> 5] >> ((le - 1) & 31)) & 1u;
+    bool ok = !in_before && !in_after && c >= 3 && (c & 1u) && spos[b0] == ls && spos[b0 + c - 1] == le - 1 && sb[ls] == '{' && sb[le - 1] == '}' && (c - 1) / 2 <= (uint32_t)JT_MEM;
+    lbase[tid] = (uint16_t)b0; lK[tid] = (uint16_t)((c - 1) / 2);
+    if (!ok) lslow[tid] = 1;
+  }
+  __syncthreads();
+  // the reference line: the tile's first line (uniform reads)
+  int jref = 0;
+  while (jref < nl && lslow[jref] == 2) jref++;
+  const bool build_map = mapst[1] == 0;  // uniform
+  if (build_map && (jref >= nl || lslow[jref])) { all_slow(); continue; }
+  const uint32_t bref = build_map ? lbase[jref] : 0u;
+  const uint32_t K = build_map ? lK[jref] : mapst[0];
+
+  // ---- member map: looked up for the first line of the first tile this workgroup sees, kept while the lines keep spelling it ----
+  if (build_map) {
+    uint32_t mbad = 0;
+    for (uint32_t m = (uint32_t)tid; m < K; m += JT_THREADS) {
+      const uint32_t pp = spos[bref + 2 * m], pc = spos[bref + 1 + 2 * m];
+      int32_t kc = JS_UNKNOWN;
+      uint32_t cls = JTC_SKIP;
+      uint64_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+      // sep ws* "key" ws* : — blanks outside strings are skipped the way fastjson's skipWS does
+      uint32_t kq = pp + 1, ke = pc;
+      while (kq < pc && jt_ws(sb[kq])) kq++;
+      while (ke > kq && jt_ws(sb[ke - 1])) ke--;
+      const bool framed = ke >= kq + 2 && sb[kq] == '"' && sb[ke - 1] == '"' && sb[pc] == ':' && jt_quotes_in(t, pp + 1, pc) == 2 && backslashes_in(kq, ke) == 0;
+      const uint32_t ks = kq + 1, kn = framed ? ke - 1 - ks : 0;
+      if (!framed) mbad = 1;
+      else {
+        uint32_t h = 0x9E3779B9u;
+        for (uint32_t k = 0; k < kn; k += 8) {
+          const uint32_t nb = kn - k < 8 ? kn - k : 8u;
+          h = key_mix(h, jt_word(sb, ks + k) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1));
+        }
+        h = key_finish(h, kn);
+        for (uint32_t sl_ = h & p.slot_mask;; sl_ = (sl_ + 1) & p.slot_mask) {
+          const JSlot sl = p.slots[sl_];
+          if (sl.slen == ~0u) break;
+          if (sl.hash == h && sl.slen == kn) {
+            bool same = true;
+            for (uint32_t k = 0; k < kn && same; k += 8) {
+              const uint32_t nb = kn - k < 8 ? kn - k : 8u;
+              same = (jt_word(sb, ks + k) & (nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1)) == *reinterpret_cast<const uint64_t *>(p.names + sl.soff + k);
+            }
+            if (same) { kc = sl.col; if (sl.aux) mbad = 1; break; }
+          }
+        }
+        if (p.add_rest && kc == JS_UNKNOWN) mbad = 1;  // `_rest` will not be {}: the per-line path writes it
+        if (kc >= 0) {
+          const JCol c = p.cols[kc];
+          if (c.next >= 0) mbad = 1;  // several columns read this key: per-line path
+          switch (c.kind) {
+            case JK_INT: cls = c.width == 1 ? JTC_I8 : c.width == 2 ? JTC_I16 : c.width == 4 ? JTC_I32 : JTC_I64; q0 = (uint64_t)c.values; break;
+            case JK_UINT: cls = c.width == 1 ? JTC_U8 : c.width == 2 ? JTC_U16 : c.width == 4 ? JTC_U32 : JTC_U64; q0 = (uint64_t)c.values; break;
+            case JK_F64: cls = JTC_F64; q0 = (uint64_t)c.values; break;
+            case JK_BOOL: cls = JTC_BOOL; q0 = (uint64_t)c.values; break;
+            case JK_TEXT: cls = JTC_TEXT; q0 = (uint64_t)c.lens; q1 = (uint64_t)c.fstart; q3 = (uint64_t)c.meta; break;
+            case JK_ANY: cls = JTC_ANY; q0 = (uint64_t)c.lens; q1 = (uint64_t)c.fstart; q3 = (uint64_t)c.meta; break;
+            default: cls = JTC_TIME; q0 = (uint64_t)c.values; q1 = (uint64_t)c.nanos;
+          }
+          q2 = (uint64_t)c.cellst;
+        }
+      }
+      mcol[m] = (int16_t)kc; mks[m] = (uint16_t)ks; mkn[m] = (uint16_t)kn; mcls[m] = (uint8_t)cls;
+      mp0[m] = q0; mp1[m] = q1; mp2[m] = q2; mp3[m] = q3;
+    }
+    if (mbad) misc[0] = 1u;
+  }
+  __syncthreads();
+  if (build_map) {
+  // a key read twice: "the last one wins" needs the members in order → per-line path
+  for (uint32_t m = (uint32_t)tid; m < K; m += JT_THREADS) if (mcol[m] >= 0) owner[mcol[m]] = (uint16_t)m;
+  if (tid == 0) {  // where each key's text is kept
+    uint32_t o = 0;
+    for (uint32_t m = 0; m < K; m++) { mko[m] = (uint16_t)o; o += ((uint32_t)mkn[m] + 7u) & ~7u; if (o > (uint32_t)JT_KREF) { misc[0] = 1u; break; } }
+  }
+  }
+  __syncthreads();
+  if (build_map && !misc[0]) {
+  for (uint32_t m = (uint32_t)tid; m < K; m += JT_THREADS) {
+    if (mcol[m] >= 0 && owner[mcol[m]] != (uint16_t)m) misc[0] = 1u;
+    for (uint32_t k = 0; k < mkn[m]; k += 8) *reinterpret_cast<uint64_t *>(kref + mko[m] + k) = jt_word(sb, (uint32_t)mks[m] + k);  // (the bytes past the key are never compared)
+  }
+  for (uint32_t m = (uint32_t)tid; m < K; m += JT_THREADS) if (mcol[m] >= 0) owner[mcol[m]] = 0xFFFFu;  // for the next map
+  }
+  // members by class (counting sort by wave 0: K <= 192 is three rounds of 64 lanes)
+  if (build_map && wv == 0) {
+    uint32_t nxt = 0;
+    for (uint32_t c = 0; c < JTC_COUNT; c++) {
+      if (lane == 0) cfirst[c] = nxt;
+      for (uint32_t r0 = 0; r0 < K; r0 += 64) {
+        const uint32_t m = r0 + (uint32_t)lane;
+        const bool mine = m < K && mcls[m] == c;
+        const uint64_t bal = __ballot(mine);
+        if (mine) perm[nxt + lanes_below(bal)] = (uint8_t)m;
+        nxt += (uint32_t)__popcll(bal);
+      }
+    }
+    if (lane == 0) cfirst[JTC_COUNT] = nxt;
+  }
+  __syncthreads();
+  if (misc[0]) { all_slow(); continue; }  // uniform (a map that could not be built stays invalid)
+  if (build_map && tid == 0) { mapst[0] = K; mapst[1] = 1u; }
+  if (tid == 0) mapst[2] = 0;
+  __syncthreads();
+
+  // ---- cells: class by class, items (member, line) with lines fastest, slots of 64 dealt round-robin to the waves ----
+  {
+    const uint32_t unl = (uint32_t)nl;
+    uint32_t sbase = 0;
+    for (uint32_t c = 0; c < JTC_COUNT; c++) {
+      const uint32_t f0 = cfirst[c], nm = cfirst[c + 1] - f0;
+      if (!nm) continue;
+      const uint32_t items = nm * unl, nslots = (items + 63) >> 6;
+      for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
+        const uint32_t it = (s - sbase) * 64 + (uint32_t)lane;
+        if (it >= items) continue;
+        const uint32_t oi = it / unl, j = it - oi * unl;
+        if (lslow[j]) continue;
+        if (lK[j] != K) { if (lslow[j] == 0) { lslow[j] = 1; atomicAdd(&mapst[2], 1u); } continue; }
+        const uint32_t m = perm[f0 + oi];
+        const uint32_t b = lbase[j];
+        const uint32_t pp = spos[b + 2 * m], pc = spos[b + 1 + 2 * m], pn = spos[b + 2 + 2 * m];
+        const uint32_t kn = mkn[m];
+        // sep ws* "key" ws* : ws* value ws* sep — the key spelled as in the reference line
+        uint32_t kq = pp + 1, ke = pc;
+        while (kq < pc && jt_ws(sb[kq])) kq++;
+        while (ke > kq && jt_ws(sb[ke - 1])) ke--;
+        bool ok = ke == kq + 2 + kn && sb[pc] == ':' && sb[kq] == '"' && sb[ke - 1] == '"' && sb[pn] == (m + 1 == K ? '}' : ',');
+        if (ok && !jt_same2(sb, kq + 1, kref, mko[m], kn)) { ok = false; if (lslow[j] == 0) atomicAdd(&mapst[2], 1u); }
+        uint32_t vs = pc + 1, ve = pn;
+        while (vs < pn && jt_ws(sb[vs])) vs++;
+        while (ve > vs && jt_ws(sb[ve - 1])) ve--;
+        const uint32_t n = ve - vs;
+        ok = ok && n > 0;
+        const int32_t r = lrow[j];
+        if (ok) {
+          const uint32_t c0 = sb[vs];
+          const bool is_null = jt_lit(sb, vs, n, 0x6C6C756Eu, 4);
+          uint8_t *const cellst = TF_GLOBAL_PTR(uint8_t, mp2[m]);
+          if (c == JTC_SKIP) {
+            // nobody reads the value, but the line must still be one the per-line parser accepts
+            if (c0 == '"') ok = n >= 2 && sb[ve - 1] == '"' && jt_quotes_in(t, vs, ve) == 2;
+            else { bool ng; uint64_t mag; uint32_t nd; ok = is_null || jt_lit(sb, vs, n, 0x65757274u, 4) || jt_lit(sb, vs, n, 0x736C6166u, 5) || (jt_quotes_in(t, vs, ve) == 0 && (jt_int_token(sb, vs, ve, &ng, &mag, &nd) || jt_number_chars(sb, vs, ve))); }
+          } else if (is_null) {
+            cellst[r] = JC_NIL;  // (text lengths are zero already)
+          } else if (c >= JTC_I8 && c <= JTC_U64) {
+            bool ng; uint64_t mag; uint32_t nd;
+            ok = c0 != '"' && jt_int_token(sb, vs, ve, &ng, &mag, &nd);
+            if (c >= JTC_U8) ok = ok && !ng;  // ParseUint64BestEffort of "-5" is 0: per-line path
+            if (ok) {
+              // fastfloat.ParseInt64BestEffort / ParseUint64BestEffort: a token of more than 18 characters goes through
+              // strconv.ParseInt, whose range error makes the value 0; then intN(v.GetInt()), Go's truncating conversion
+              int64_t v = ng ? (int64_t)(0 - mag) : (int64_t)mag;
+              if (c <= JTC_I64 && n > 18 && mag > (ng ? (1ull << 63) : (1ull << 63) - 1)) v = 0;
+              const uint32_t w = (c - 1u) & 3u;
+              if (w == 0) TF_GLOBAL_PTR(int8_t, mp0[m])[r] = (int8_t)v;
+              else if (w == 1) TF_GLOBAL_PTR(int16_t, mp0[m])[r] = (int16_t)v;
+              else if (w == 2) TF_GLOBAL_PTR(int32_t, mp0[m])[r] = (int32_t)v;
+              else TF_GLOBAL_PTR(int64_t, mp0[m])[r] = v;
+              cellst[r] = JC_OK;
+            }
+          } else if (c == JTC_TIME) {
+            // extractTimeValue: json.Number → ParseInt; float64 → int64(math.Abs(f)).  Plain digits that a float64 holds exactly
+            bool ng; uint64_t mag; uint32_t nd;
+            ok = c0 != '"' && jt_int_token(sb, vs, ve, &ng, &mag, &nd) && !ng && nd <= 15;
+            if (ok) { TF_GLOBAL_PTR(int64_t, mp0[m])[r] = (int64_t)mag; TF_GLOBAL_PTR(int32_t, mp1[m])[r] = 0; cellst[r] = JC_OK; }
+          } else if (c == JTC_F64) {
+            bool ng; uint64_t mag; uint32_t nd;
+            if (c0 != '"' && jt_int_token(sb, vs, ve, &ng, &mag, &nd) && nd <= 15 && !(ng && mag == 0)) {
+              TF_GLOBAL_PTR(double, mp0[m])[r] = ng ? -(double)mag : (double)mag; cellst[r] = JC_OK;  // exact: what ParseBestEffort gives
+            } else {
+              ok = c0 != '"' && jt_number_chars(sb, vs, ve);
+              double v = 0;
+              if (ok) ok = jt_float_token(p.data, (uint64_t)g0 + vs, n, p.pow10, p.pow128, &v);  // (bytes from HBM: the tile just read them)
+              if (ok) { TF_GLOBAL_PTR(double, mp0[m])[r] = v; cellst[r] = JC_OK; }
+            }
+          } else if (c == JTC_BOOL) {
+            const bool tr = jt_lit(sb, vs, n, 0x65757274u, 4), fl = jt_lit(sb, vs, n, 0x736C6166u, 5);
+            ok = tr || fl;
+            if (ok) { TF_GLOBAL_PTR(uint8_t, mp0[m])[r] = tr ? 1 : 0; cellst[r] = JC_OK; }
+          } else {  // JTC_TEXT, JTC_ANY
+            uint32_t *const lens = TF_GLOBAL_PTR(uint32_t, mp0[m]), *const fstart = TF_GLOBAL_PTR(uint32_t, mp1[m]), *const meta = TF_GLOBAL_PTR(uint32_t, mp3[m]);
+            if (c0 == '"') {
+              ok = n >= 2 && sb[ve - 1] == '"' && jt_quotes_in(t, vs, ve) == 2;
+              const uint32_t sn = n - 2, ss = vs + 1;
+              const bool bs = ok && backslashes_in(ss, ss + sn) != 0;
+              if (ok && c == JTC_TEXT) {
+                if (!bs) { fstart[r] = g0 + ss; meta[r] = sn | (JM_COPY << 28); lens[r] = sn; }
+                else { fstart[r] = g0 + ss; meta[r] = sn | (JM_UNESCAPE << 28); lens[r] = jt_unescaped_len(p.data, (uint64_t)g0 + ss, sn); }
+                cellst[r] = JC_OK;
+              } else if (ok) {
+                // `any` holding a string: printable ASCII without " \ < > &, not an object or `null` in disguise (ParseVal)
+                ok = !bs && sn <= 256;
+                for (uint32_t q = 0; q < sn && ok; q++) { const uint32_t ch = sb[ss + q]; ok = ch >= 0x20u && ch <= 0x7Eu && ch != '<' && ch != '>' && ch != '&'; }
+                if (ok) {
+                  uint32_t i = 0;
+                  while (i < sn && (sb[ss + i] == ' ' || sb[ss + i] == '\t')) i++;
+                  if (i < sn && (sb[ss + i] == '{' || sb[ss + i] == 'n')) ok = false;
+                }
+                if (ok) { fstart[r] = g0 + ss; meta[r] = sn | (JM_QUOTED << 28); lens[r] = sn + 2; cellst[r] = JC_OK; }
+              }
+            } else {
+              const bool lit = jt_lit(sb, vs, n, 0x65757274u, 4) || jt_lit(sb, vs, n, 0x736C6166u, 5);
+              bool ng = false; uint64_t mag = 0; uint32_t nd = 0;
+              const bool num = !lit && jt_quotes_in(t, vs, ve) == 0 && jt_int_token(sb, vs, ve, &ng, &mag, &nd);
+              if (c == JTC_TEXT) ok = lit || num || (jt_quotes_in(t, vs, ve) == 0 && jt_number_chars(sb, vs, ve));  // the raw token
+              else ok = lit || (num && p.use_numbers && !(nd > 1 && sb[ve - nd] == '0'));  // json.Number text as it stands; float64 text: per-line path
+              if (ok) { fstart[r] = g0 + vs; meta[r] = n | (JM_COPY << 28); lens[r] = n; cellst[r] = JC_OK; }
+            }
+          }
+        }
+        if (!ok) lslow[j] = 1;
+      }
+      sbase += nslots;
+    }
+  }
+  __syncthreads();
+  // ---- per line: a row, or handed to the per-line kernel ----
+  if (tid < nl && lslow[tid] != 2) {
+    if (lslow[tid]) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)(i0 + tid); }
+    else {
+      const int32_t r = lrow[tid];
+      p.linest[r] = JL_ROW;
+      p.line_pos[r] = g0 + lstart[tid];
+      if (p.rest_lens) { p.rest_fstart[r] = g0 + lstart[tid]; p.rest_meta[r] = (JM_REST_EMPTY << 28); p.rest_lens[r] = 2; }  // every key was known: {}
+    }
+  }
+  // most of the tile spelled other keys: the stream changed its key order — the next tile maps its own first line
+  if (tid == 0 && mapst[2] * 2 > (uint32_t)nl) mapst[1] = 0;
+  }  // tiles
 }
 
 // ---------------------------------------------------------------------------
@@ -1661,7 +2163,27 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   // (13.6 vs 6.7 ms, profiles/r01y_json_paths.txt).  Kept as the parity cross-check of the grammar and as the
   // starting point for a kind-sorted member phase.
   static const bool wavepath = [] { const char *e = std::getenv("TFGPU_JSON_WAVEPATH"); return e && e[0] == '1'; }();
-  if (nlines && (!wavepath || tskv)) {
+  // The tile path (default for Format json; TFGPU_JSON_TILES=0 for A/B runs): lines staged in LDS, cells by value kind.
+  static const bool tilepath = [] { const char *e = std::getenv("TFGPU_JSON_TILES"); return !(e && e[0] == '0'); }();
+  if (nlines && tilepath && !tskv && !wavepath) {
+    const uint64_t avg = std::max<uint64_t>(len / (uint64_t)std::max<int64_t>(nseg, 1), 1);
+    const int32_t per_tile = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)JT_BYTES * 3 / 4 / avg, 1), (uint64_t)JT_LINES);
+    Buf slow = dalloc((size_t)(nseg + 1) * 4), heavy = dalloc((size_t)(nseg + 1) * 4);
+    TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
+    TF_HIP(hipMemsetAsync(heavy->p, 0, 4, st));
+    // persistent workgroups (two per CU fit its LDS): each walks every (2 * CUs)-th tile and keeps its member map
+    const unsigned ntile = jblocks(nseg, per_tile), nblk = (unsigned)std::min<int64_t>((int64_t)ntile, (int64_t)cx.num_cus * 2);
+    { KernelTimer t("json_parse_tiles"); json_parse_tiles<<<nblk, JT_THREADS, 0, st>>>(pp, per_tile, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+    { KernelTimer t("json_parse_listed"); json_parse_listed_lean<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1, ptr<uint32_t>(heavy), ptr<uint32_t>(heavy) + 1);
+      json_parse_listed<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(heavy), ptr<uint32_t>(heavy) + 1); }
+    static const bool dbg = [] { const char *e = std::getenv("TFGPU_JSON_TILE_DEBUG"); return e && e[0] == '1'; }();
+    if (dbg) {  // how many lines the tile path handed over (diagnostics only: costs a synchronisation)
+      const uint32_t *a = d2h_u32(slow->p), *b = d2h_u32(heavy->p);
+      tf::sync();
+      std::fprintf(stderr, "[tfgpu] json tiles: %lld lines, %d per tile, %u to the per-line parser, %u of them to the map emitter\n", (long long)nseg, (int)per_tile, *a, *b);
+    }
+  }
+  else if (nlines && (!wavepath || tskv)) {
     Buf slow = dalloc((size_t)(nseg + 1) * 4);  // lines that need the map emitter: re-parsed by the kernel that carries it
     TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
     { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
