@@ -1318,22 +1318,27 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   __syncthreads();  // the previous tile's LDS is free
   const int64_t i0 = tile * lines_per_tile;
-  const int nl = (int)min<int64_t>(lines_per_tile, p.nseg - i0);
+  int nl = (int)min<int64_t>(lines_per_tile, p.nseg - i0);  // lines_per_tile <= JT_LINES <= 64: one lane per line
   auto all_slow = [&]() {  // every line of the tile goes to the per-line kernel
     for (int j = tid; j < nl; j += JT_THREADS) if (p.seg_len[i0 + j]) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)(i0 + j); }
   };
-  // the tile's byte range: from its first non-empty line to the end of its last one
-  uint32_t first = 0xFFFFFFFFu, last = 0;
-  for (int j = 0; j < nl; j++) {  // (uniform: a handful of scalar loads)
-    const uint32_t n = p.seg_len[i0 + j];
-    if (!n) continue;
-    const uint32_t s = p.seg_start[i0 + j];
-    if (first == 0xFFFFFFFFu) first = s;
-    last = s + n;
+  // the tile's byte range: from its first non-empty line to the end of the last one that still fits (every wave works it
+  // out for itself: one vector load per wave instead of a scalar loop over the lines)
+  uint32_t first, last, g0;
+  {
+    const uint32_t ln = lane < nl ? p.seg_len[i0 + lane] : 0u, ls_ = lane < nl ? p.seg_start[i0 + lane] : 0u;
+    const uint64_t nonempty = __ballot(ln != 0);
+    if (!nonempty) continue;  // nothing but empty lines
+    first = (uint32_t)__shfl((int)ls_, __ffsll((long long)nonempty) - 1, 64);
+    g0 = first & ~15u;
+    const uint64_t fits = __ballot(ln != 0 && ls_ + ln - g0 <= (uint32_t)JT_BYTES);  // lines are in ascending order: a prefix of the non-empty ones
+    if (!fits || p.ncols > JT_OWN) { all_slow(); continue; }
+    const int hi = 63 - __clzll((long long)fits);
+    last = (uint32_t)__shfl((int)(ls_ + ln), hi, 64);
+    // the lines behind the last one that fits: per-line kernel
+    if (wv == 0 && lane > hi && ln != 0) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)(i0 + lane); }
+    nl = hi + 1;
   }
-  if (first == 0xFFFFFFFFu) continue;  // nothing but empty lines
-  const uint32_t g0 = first & ~15u;
-  if (last - g0 > (uint32_t)JT_BYTES || nl > JT_LINES || p.ncols > JT_OWN) { all_slow(); continue; }
 
   // ---- stage: coalesced 16 B per lane ----
 #pragma unroll
@@ -1351,6 +1356,7 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
     lstart[tid] = (uint16_t)(n ? s - g0 : 0); lend[tid] = (uint16_t)(n ? s - g0 + n : 0);
     lrow[tid] = n ? (int32_t)p.seg_ord[i0 + tid] : -1;
     lslow[tid] = n ? 0 : 2;  // 2: no line here
+    lbase[tid] = 0xFFFFu;
   }
   for (int i = tid; i < JT_OWN; i += JT_THREADS) owner[i] = 0xFFFFu;
   __syncthreads();
@@ -1372,6 +1378,8 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   {  // what precedes the tile's first line (up to 15 bytes, the tail of the line before) belongs to another tile
     const uint32_t frs = first - g0;
     if (tpos < frs) { const uint64_t keep = frs - tpos >= 64 ? 0ull : ~0ull << (frs - tpos); Q &= keep; B &= keep; S &= keep; }
+    const uint32_t lim = last - g0;  // … and so does the head of the next line that the last 16-byte chunk brought along
+    if (tpos + 48u > lim) { const uint64_t keep = lim <= tpos ? 0ull : (1ull << (lim - tpos)) - 1; Q &= keep; B &= keep; S &= keep; }
   }
   // quotes escaped by an odd run of backslashes; a run that reaches back over this thread's first byte is counted in LDS
   uint32_t bad = 0;
@@ -1427,7 +1435,12 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
     // separator index
     uint32_t k = cpre + cinc - cnt;
     uint64_t m = S;
-    while (m) { const uint32_t b = (uint32_t)__ffsll((long long)m) - 1; m &= m - 1; spos[k++] = (uint16_t)(tpos + b); }
+    while (m) {
+      const uint32_t b = (uint32_t)__ffsll((long long)m) - 1; m &= m - 1;
+      const uint32_t pos = tpos + b;
+      if (sb[pos] == '{') for (int j = 0; j < nl; j++) if (lstart[j] == pos && lslow[j] == 0) lbase[j] = (uint16_t)k;  // a line's own brace: where its separators start
+      spos[k++] = (uint16_t)pos;
+    }
     if (tid == 0) { misc[1] = ctot; spos[ctot] = 0xFFFFu; }
     // quotes / backslashes in front of every 32-byte word that STARTS in this thread's bytes (tpos = 48 * tid: words start at
     // multiples of 32 → at tpos when tid is even, at tpos + 16 when tid is odd, and at tpos + 32 when tid is even)
@@ -1455,15 +1468,13 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   // ---- lines: where their separators start, how many, the frame { … } ----
   if (tid < nl && lslow[tid] == 0) {
     const uint32_t ls = lstart[tid], le = lend[tid];
-    uint32_t lo = 0, hi = nsep;  // first separator at or after ls
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (spos[mid] < ls) lo = mid + 1; else hi = mid; }
-    const uint32_t b0 = lo;
-    hi = nsep;                   // first separator at or after le
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (spos[mid] < le) lo = mid + 1; else hi = mid; }
-    const uint32_t c = lo - b0;
+    const uint32_t b0 = lbase[tid];  // written by the index sweep when the line's first byte is a brace outside strings
+    uint32_t b1 = nsep;              // the next line's, or the end of the index
+    for (int j = tid + 1; j < nl; j++) if (lslow[j] != 2) { b1 = lbase[j]; break; }
+    const uint32_t c = (b0 != 0xFFFFu && b1 != 0xFFFFu && b1 > b0) ? b1 - b0 : 0u;
     const bool in_before = ls ? ((smask[(ls - 1) >> 5] >> ((ls - 1) & 31)) & 1u) : false;  // a string open across the line start
     const bool in_after = (smask[(le - 1) >> 5] >> ((le - 1) & 31)) & 1u;
-    bool ok = !in_before && !in_after && c >= 3 && (c & 1u) && spos[b0] == ls && spos[b0 + c - 1] == le - 1 && sb[ls] == '{' && sb[le - 1] == '}' && (c - 1) / 2 <= (uint32_t)JT_MEM;
+    bool ok = !in_before && !in_after && c >= 3 && (c & 1u) && spos[b0 < nsep ? b0 : 0] == ls && spos[b0 + c - 1] == le - 1 && sb[ls] == '{' && sb[le - 1] == '}' && (c - 1) / 2 <= (uint32_t)JT_MEM;
     lbase[tid] = (uint16_t)b0; lK[tid] = (uint16_t)((c - 1) / 2);
     if (!ok) lslow[tid] = 1;
   }
@@ -2167,7 +2178,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   static const bool tilepath = [] { const char *e = std::getenv("TFGPU_JSON_TILES"); return !(e && e[0] == '0'); }();
   if (nlines && tilepath && !tskv && !wavepath) {
     const uint64_t avg = std::max<uint64_t>(len / (uint64_t)std::max<int64_t>(nseg, 1), 1);
-    const int32_t per_tile = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)JT_BYTES * 3 / 4 / avg, 1), (uint64_t)JT_LINES);
+    const int32_t per_tile = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(JT_BYTES - 16) * 8 / (avg * 9), 1), (uint64_t)JT_LINES);
     Buf slow = dalloc((size_t)(nseg + 1) * 4), heavy = dalloc((size_t)(nseg + 1) * 4);
     TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
     TF_HIP(hipMemsetAsync(heavy->p, 0, 4, st));
