@@ -1219,8 +1219,9 @@ __global__ void __launch_bounds__(256) json_parse_waves(JParams p, uint32_t *slo
 // blank, anything that does not validate — is listed for json_parse_listed, which re-parses it whole.
 // ---------------------------------------------------------------------------
 static constexpr int JT_THREADS = 512;
-static constexpr int JT_CPT = 3;                           // 16-byte chunks per thread
-static constexpr int JT_BYTES = JT_THREADS * JT_CPT * 16;  // 24 KiB of text per tile
+static constexpr int JT_CPT = 4;                           // 16-byte chunks per thread
+static constexpr int JT_BYTES = JT_THREADS * JT_CPT * 16;  // 32 KiB of text per tile
+static constexpr uint64_t JT_MASK = JT_CPT == 4 ? ~0ull : (1ull << (16 * (JT_CPT & 3))) - 1;  // this thread's bytes as mask bits
 static constexpr int JT_LINES = 32;                        // lines per tile at most
 static constexpr int JT_SCAP = 4608;                       // separators indexed per tile
 static constexpr int JT_MEM = 192;                         // members per line
@@ -1379,7 +1380,7 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
     const uint32_t frs = first - g0;
     if (tpos < frs) { const uint64_t keep = frs - tpos >= 64 ? 0ull : ~0ull << (frs - tpos); Q &= keep; B &= keep; S &= keep; }
     const uint32_t lim = last - g0;  // … and so does the head of the next line that the last 16-byte chunk brought along
-    if (tpos + 48u > lim) { const uint64_t keep = lim <= tpos ? 0ull : (1ull << (lim - tpos)) - 1; Q &= keep; B &= keep; S &= keep; }
+    if (tpos + (uint32_t)JT_CPT * 16u > lim) { const uint64_t keep = lim <= tpos ? 0ull : (1ull << (lim - tpos)) - 1; Q &= keep; B &= keep; S &= keep; }
   }
   // quotes escaped by an odd run of backslashes; a run that reaches back over this thread's first byte is counted in LDS
   uint32_t bad = 0;
@@ -1414,8 +1415,8 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   for (int i = 0; i < wv; i++) s_in ^= wpar[i];
   uint64_t px = Q;  // bit i = parity of the unescaped quotes in bytes [0, i]
   px ^= px << 1; px ^= px << 2; px ^= px << 4; px ^= px << 8; px ^= px << 16; px ^= px << 32;
-  const uint64_t inside = (px ^ (s_in ? ~0ull : 0ull)) & 0xFFFFFFFFFFFFull;
-  S &= ~inside & 0xFFFFFFFFFFFFull;
+  const uint64_t inside = (px ^ (s_in ? ~0ull : 0ull)) & JT_MASK;
+  S &= ~inside & JT_MASK;
   {
     uint16_t *s16 = reinterpret_cast<uint16_t *>(smask);
 #pragma unroll
