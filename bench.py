@@ -462,7 +462,7 @@ class SrWorkload(_Prepared):
 
     def alg(self):
         s = self.state
-        return {"sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
+        return {"sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
                 "ser_cell_write": s["parsed_bytes"] + s["out_bytes"], "ser_cell_len": s["parsed_bytes"]}
 
     def config(self):
@@ -526,7 +526,7 @@ class Configs2Workload(_Prepared):
 
     def alg(self):
         s = self.state
-        return {"sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
+        return {"sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
                 "ser_tile_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "compact_gather": int(s["parsed_bytes"] + s["kept_bytes"])}
 
     def config(self):

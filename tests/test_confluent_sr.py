@@ -314,11 +314,7 @@ def _random_payloads(rng, n):
     return schema, out
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 64, 1000, 20000])
-def test_gpu_matches_oracle(tf, oracle, n):
-    rng = np.random.default_rng(SEED0 + (4000 + n))
-    schema, payloads = _random_payloads(rng, n)
+def _compare_with_oracle(tf, oracle, rng, schema, payloads, upload, min_rows):
     frames = [b"\0" + (5 if rng.random() < 0.9 else 6).to_bytes(4, "big") + p for p in payloads]
     msgs, i = [], 0
     while i < len(frames):  # 1-3 frames per Kafka message
@@ -329,7 +325,7 @@ def test_gpu_matches_oracle(tf, oracle, n):
     assert tf.sr_frames(data, cm) == oracle.sr_frames(data, cm)
     o = confluent_sr.sr_json_options(5, schema)
     ref = oracle.sr_json_parse(o, data, cm)
-    got = tf.sr_json_parse(o, tf.DeviceBuffer.upload(data) if n == 1000 else data, cm)
+    got = tf.sr_json_parse(o, tf.DeviceBuffer.upload(data) if upload else data, cm)
     FB = abi.ROWERR_ID["HOST_FALLBACK"]
     gerr = {e[0]: e[1] for e in got.errors}
     rerr = {e[0]: e[1] for e in ref.errors}
@@ -346,8 +342,68 @@ def test_gpu_matches_oracle(tf, oracle, n):
     for k in fallback:  # the oracle parsed it: a row whose `any` value needed Go's key ordering
         assert k in rrows
     assert set(grows) <= set(rrows)
-    assert not fallback and (n < 1000 or len(grows) > n // 4)  # unsorted `any` objects are sorted on the device
+    assert not fallback and len(grows) >= min_rows  # unsorted `any` objects are sorted on the device
     assert [c.dtype for c in got.batch.cols] == ["any", "boolean", "int64", "double", "any", "utf8", "utf8"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 64, 1000, 20000])
+def test_gpu_matches_oracle(tf, oracle, n):
+    rng = np.random.default_rng(SEED0 + (4000 + n))
+    schema, payloads = _random_payloads(rng, n)
+    _compare_with_oracle(tf, oracle, rng, schema, payloads, n == 1000, 0 if n < 1000 else n // 4 + 1)
+
+
+def _regular_payloads(rng, n):
+    """What one producer emits — the same keys in the same order, compact or with blanks — with the values and the
+    defects the tile parser has to decide or hand over exactly as parse_frame would: escapes, control bytes, numbers at
+    the edge of int64, leading zeros, wrong types, nulls under required properties, missing / extra / repeated / reordered keys."""
+    schema = _random_payloads(rng, 0)[0]
+    strs = ['""', '"a"', '"plain text"', '"x' + "y" * 70 + '"', '"\\u00e9\\n\\t\\\\\\/\\""', '"\\ud83d\\ude00"', '"<&>\u2028"', '"\u00e9\u4e2d"', '"bad \\q"', '"\\u12"', '"tab\there"', '"\\\\"', '"q\\"q"']
+    ints = ["0", "-0", "12", "-9223372036854775808", "9223372036854775807", "9223372036854775808", "-9223372036854775809", "99999999999999999999", "007", "1.5", "1e3", "-", '"5"', "null", "true"]
+    nums = ["0", "-0", "12", "1.5", "1e3", "-1.25E-7", "123.2970700287221458280", "1E+400", "1.", ".5", "01.5", "null", '"x"']
+    out = []
+    for _ in range(n):
+        usual = rng.random() < 0.85
+        members = [('"in"', str(int(rng.integers(-10**9, 10**9))) if usual or rng.random() < 0.5 else ints[rng.integers(0, len(ints))]),
+                   ('"st"', strs[rng.integers(0, 4)] if usual or rng.random() < 0.5 else strs[rng.integers(0, len(strs))]),
+                   ('"nu"', str(int(rng.integers(0, 1000))) if usual or rng.random() < 0.5 else nums[rng.integers(0, len(nums))]),
+                   ('"bo"', ["true", "false", "null"][rng.integers(0, 3)] if usual or rng.random() < 0.5 else ['"true"', "1", "tru"][rng.integers(0, 3)]),
+                   ('"\u00e9\u4e2d"', strs[rng.integers(0, 3)]), ('"unknown"', ["1", '"x"', "null", "[1]"][rng.integers(0, 4 if not usual else 3)])]
+        r = rng.random()
+        if r < 0.01: members[0], members[2] = members[2], members[0]
+        elif r < 0.02: del members[int(rng.integers(0, len(members)))]
+        elif r < 0.03: members.append(members[int(rng.integers(0, len(members)))])
+        elif r < 0.04: members.insert(2, ('"ob"', ['{"b":1,"a":2}', "[]", '"s"'][rng.integers(0, 3)]))
+        sep = (",", ":") if rng.random() < 0.9 else [(", ", ": "), (" ,\t", " : ")][rng.integers(0, 2)]
+        body = "{" + sep[0].join(k + sep[1] + v for k, v in members) + "}"
+        r = rng.random()
+        if r < 0.005: body = body[:-1]
+        elif r < 0.01: body = body + " trailing"
+        elif r < 0.015: body = " " + body
+        out.append(body.encode("utf-8"))
+    return schema, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [40, 3000, 20000])
+def test_gpu_tile_path_matches_oracle(tf, oracle, n):
+    rng = np.random.default_rng(SEED0 + (4100 + n))
+    schema, payloads = _regular_payloads(rng, n)
+    _compare_with_oracle(tf, oracle, rng, schema, payloads, n == 3000, n // 4)
+
+
+@pytest.mark.gpu
+def test_gpu_per_frame_path_cross_check():
+    """sr_parse_tiles is the default; TFGPU_SR_TILES=0 sends every payload through parse_frame.  Both must pass the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFGPU_SR_TILES="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_confluent_sr.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "canon or vectors or framing or matches_oracle or parser_object"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
 
 
 # ---------------------------------------------------------------- oracle vs an independent JSON implementation ----

@@ -18,8 +18,11 @@
 // First form of the path: correct and HBM-resident, latency-bound (every lane walks its own payload), like the per-line
 // generic JSON parser before its tile form.  Algorithmic bytes: B_json in + B_bin out per frame.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "tf_jsonscan.hpp"
+#include "tf_jsontile.hpp"
 
 namespace tf {
 namespace sr {
@@ -211,6 +214,259 @@ __device__ uint32_t parse_frame(const Params &p, const int64_t f) {
   }
   return fallback ? (uint32_t)TFGPU_ROW_HOST_FALLBACK : (uint32_t)ST_OK;
 }
+// ---------------------------------------------------------------------------
+// tile path (tf_jsontile.hpp): consecutive payloads staged in LDS, classified and indexed once; a cell is a (member, payload)
+// pair and only has to say where the member's value lies and what it is — the span word the value kernels read — and
+// whether the property takes it.  The member → property map is found once (binary search over the sorted names) and kept
+// while the payloads keep spelling the same keys.  Compact or blank-separated flat objects whose values are strings without
+// escapes, literals or numbers are decided here; every other payload goes to parse_frame through sr_parse_listed.
+// ---------------------------------------------------------------------------
+// encoding/json's number: -? (0 | [1-9][0-9]*) (. [0-9]+)? ([eE] [+-]? [0-9]+)?
+__device__ __forceinline__ bool st_json_number(const uint8_t *sb, uint32_t a, uint32_t b) {
+  uint32_t i = a;
+  auto dg = [&](uint32_t k) { return k < b && sb[k] >= '0' && sb[k] <= '9'; };
+  if (i < b && sb[i] == '-') i++;
+  if (!dg(i)) return false;
+  if (sb[i] == '0') i++; else while (dg(i)) i++;
+  if (i < b && sb[i] == '.') { i++; if (!dg(i)) return false; while (dg(i)) i++; }
+  if (i < b && (sb[i] == 'e' || sb[i] == 'E')) { i++; if (i < b && (sb[i] == '+' || sb[i] == '-')) i++; if (!dg(i)) return false; while (dg(i)) i++; }
+  return i == b;
+}
+// bytes [a, b): bit 0 = some byte >= 0x80, bit 1 = some byte < 0x20
+__device__ __forceinline__ uint32_t st_byte_classes(const uint8_t *sb, uint32_t a, uint32_t b) {
+  const uint64_t ONES = 0x0101010101010101ull, HI = 0x8080808080808080ull;
+  uint32_t f = 0;
+  for (uint32_t k = a; k < b; k += 8) {
+    const uint32_t nb = b - k < 8 ? b - k : 8u;
+    uint64_t w = jt_word(sb, k);
+    if (nb < 8) { const uint64_t m = (1ull << (8 * nb)) - 1; w = (w & m) | (ONES * 0x20 & ~m); }  // the bytes past b read as blanks
+    if (w & HI) f |= 1u;
+    if ((w - ONES * 0x20) & ~w & HI) f |= 2u;
+  }
+  return f;
+}
+// the escapes of a string body [a, b) as encoding/json's scanner takes them: \" \\ \/ \b \f \n \r \t \uXXXX
+__device__ __forceinline__ bool st_escapes_ok(const uint8_t *sb, uint32_t a, uint32_t b) {
+  for (uint32_t i = a; i < b; i++) {
+    if (sb[i] != '\\') continue;
+    if (i + 1 >= b) return false;
+    const uint32_t d = sb[i + 1];
+    i++;
+    if (d == 'u') {
+      if (b - (i + 1) < 4) return false;
+      for (uint32_t k = 1; k <= 4; k++) { const uint32_t h = sb[i + k]; if (!((h >= '0' && h <= '9') || ((h | 0x20u) >= 'a' && (h | 0x20u) <= 'f'))) return false; }
+      i += 4;
+    } else if (!(d == '"' || d == '\\' || d == '/' || d == 'b' || d == 'f' || d == 'n' || d == 'r' || d == 't')) return false;
+  }
+  return true;
+}
+// raw key bytes against a property name (8-byte aligned, zero-padded): <0, 0, >0 as bytes.Compare
+__device__ __forceinline__ int st_key_compare(const uint8_t *sb, uint32_t ks, uint32_t kn, const uint8_t *nm, uint32_t nlen) {
+  const uint32_t m = kn < nlen ? kn : nlen;
+  for (uint32_t q = 0; q < m; q += 8) {
+    const uint32_t nb = m - q < 8 ? m - q : 8u;
+    const uint64_t mask = nb >= 8 ? ~0ull : (1ull << (8 * nb)) - 1;
+    const uint64_t x = jt_word(sb, ks + q) & mask, y = *reinterpret_cast<const uint64_t *>(nm + q) & mask;
+    if (x != y) { const uint32_t sh = ((uint32_t)(__ffsll((long long)(x ^ y)) - 1) >> 3) * 8; return ((x >> sh) & 0xFF) < ((y >> sh) & 0xFF) ? -1 : 1; }
+  }
+  return kn == nlen ? 0 : kn < nlen ? -1 : 1;
+}
+
+__global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_t frames_per_tile, uint32_t *slow_n, uint32_t *slow_f) {
+  __shared__ JtLds L;
+  uint8_t *const sb = L.sbuf + 16;
+  uint16_t *const spos = L.spos, *const lstart = L.lstart, *const lend = L.lend, *const lbase = L.lbase, *const lK = L.lK;
+  uint32_t *const misc = L.misc;
+  uint8_t *const lslow = L.lslow;
+  __shared__ uint32_t lerr[JT_LINES];  // the first failing property of the payload in name order: prop << 8 | code
+  __shared__ int16_t mprop[JT_MEM];
+  __shared__ uint16_t mks[JT_MEM], mkn[JT_MEM], mko[JT_MEM];
+  __shared__ uint8_t mtype[JT_MEM], mreq[JT_MEM];
+  __shared__ uint16_t owner[JT_OWN];
+  __shared__ __attribute__((aligned(16))) uint8_t kref[JT_KREF + 32];
+  __shared__ uint32_t mapst[4];  // 0: members, 1: valid, 2: payloads of this tile that spell other keys, 3: first required property no member gives
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 4) mapst[tid] = 0;
+  const int64_t ntiles = (p.nframes + frames_per_tile - 1) / frames_per_tile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  __syncthreads();
+  const int64_t f0 = tile * frames_per_tile;
+  int nl = (int)min<int64_t>(frames_per_tile, p.nframes - f0);
+  auto hand_over = [&](int64_t f) { const uint32_t k = atomicAdd(slow_n, 1u); slow_f[k] = (uint32_t)f; };
+  uint32_t first, last, g0;
+  bool ours_here = false;
+  {
+    uint32_t ln = 0, ls_ = 0;
+    if (lane < nl) {
+      const tfgpu_sr_frame fr = p.frames[f0 + lane];
+      ours_here = fr.code == 0 && fr.schema_id == p.schema_id;
+      if (!ours_here) { if (wv == 0) p.status[f0 + lane] = fr.code ? (uint8_t)fr.code : (uint8_t)ST_OTHER; }
+      else if (fr.len == 0 || fr.start + fr.len > 0xFFFFFFFFull) { if (wv == 0) hand_over(f0 + lane); ours_here = false; }
+      else { ln = fr.len; ls_ = (uint32_t)fr.start; }
+    }
+    const uint64_t nonempty = __ballot(ln != 0);
+    if (!nonempty) continue;
+    first = (uint32_t)__shfl((int)ls_, __ffsll((long long)nonempty) - 1, 64);
+    g0 = first & ~15u;
+    const uint64_t fits = __ballot(ln != 0 && ls_ + ln - g0 <= (uint32_t)JT_BYTES);
+    if (!fits || p.nprops > JT_OWN) { if (wv == 0 && ln != 0) hand_over(f0 + lane); continue; }
+    const int hi = 63 - __clzll((long long)fits);
+    last = (uint32_t)__shfl((int)(ls_ + ln), hi, 64);
+    if (wv == 0 && lane > hi && ln != 0) hand_over(f0 + lane);
+    nl = hi + 1;
+    if (wv == 0 && lane < nl) {
+      lstart[lane] = (uint16_t)(ln ? ls_ - g0 : 0); lend[lane] = (uint16_t)(ln ? ls_ - g0 + ln : 0);
+      lslow[lane] = ln ? 0 : 2; lbase[lane] = 0xFFFFu; lerr[lane] = 0xFFFFFFFFu;
+    }
+  }
+  auto all_slow = [&]() { if (tid < nl && lslow[tid] != 2) hand_over(f0 + tid); };
+  for (int i = tid; i < JT_OWN; i += JT_THREADS) owner[i] = 0xFFFFu;
+  if (!jt_front(L, p.data, first, last, g0, nl)) { all_slow(); continue; }
+  JtTile t;
+  t.sb = sb; t.spos = spos; t.qmask = L.qmask; t.qpre = L.qpre; t.bpre = L.bpre; t.g0 = g0;
+  int jref = 0;
+  while (jref < nl && lslow[jref] == 2) jref++;
+  const bool build_map = mapst[1] == 0;  // uniform
+  if (build_map && (jref >= nl || lslow[jref])) { all_slow(); continue; }
+  const uint32_t bref = build_map ? lbase[jref] : 0u;
+  const uint32_t K = build_map ? lK[jref] : mapst[0];
+  // ---- member map: which property reads the m-th member (binary search over the sorted names), the key text kept ----
+  if (build_map) {
+    uint32_t mbad = 0;
+    for (uint32_t m = (uint32_t)tid; m < K; m += JT_THREADS) {
+      const uint32_t pp = spos[bref + 2 * m], pc = spos[bref + 1 + 2 * m];
+      uint32_t kq = pp + 1, ke = pc;
+      while (kq < pc && jt_ws(sb[kq])) kq++;
+      while (ke > kq && jt_ws(sb[ke - 1])) ke--;
+      // a key without escapes: plain ASCII is its own decoding; with other bytes it is decoded rune by rune (invalid UTF-8
+      // becomes U+FFFD), so only byte equality with a property name decides anything — no match: parse_frame
+      const bool framed = ke >= kq + 2 && sb[kq] == '"' && sb[ke - 1] == '"' && sb[pc] == ':' && jt_quotes_in(t, pp + 1, pc) == 2 && jt_backslashes_in(L, kq, ke) == 0;
+      const uint32_t ks = kq + 1, kn = framed ? ke - 1 - ks : 0;
+      const uint32_t kcl = framed ? st_byte_classes(sb, ks, ks + kn) : 2u;
+      int found = -1;
+      if (!framed || (kcl & 2u)) mbad = 1;
+      else {
+        int lo = 0, hi = p.nprops - 1;
+        while (lo <= hi) {
+          const int mid = (lo + hi) >> 1;
+          const Prop pr = p.props[mid];
+          const int c = st_key_compare(sb, ks, kn, p.names + pr.name_off, pr.name_len);
+          if (c == 0) { found = mid; break; }
+          if (c < 0) hi = mid - 1; else lo = mid + 1;
+        }
+        if (found < 0 && (kcl & 1u)) mbad = 1;
+      }
+      mprop[m] = (int16_t)found; mks[m] = (uint16_t)ks; mkn[m] = (uint16_t)kn;
+      mtype[m] = found >= 0 ? (uint8_t)p.props[found].json_type : 0; mreq[m] = found >= 0 ? (uint8_t)(p.props[found].required != 0) : 0;
+    }
+    if (mbad) misc[0] = 1u;
+  }
+  __syncthreads();
+  if (build_map) {
+    for (uint32_t m = (uint32_t)tid; m < K; m += JT_THREADS) if (mprop[m] >= 0) owner[mprop[m]] = (uint16_t)m;
+    if (tid == 0) {
+      uint32_t o = 0;
+      for (uint32_t m = 0; m < K; m++) { mko[m] = (uint16_t)o; o += ((uint32_t)mkn[m] + 7u) & ~7u; if (o > (uint32_t)JT_KREF) { misc[0] = 1u; break; } }
+    }
+  }
+  __syncthreads();
+  if (build_map && !misc[0]) {
+    for (uint32_t m = (uint32_t)tid; m < K; m += JT_THREADS) {
+      if (mprop[m] >= 0 && owner[mprop[m]] != (uint16_t)m) misc[0] = 1u;  // a key read twice: the last one wins → parse_frame
+      for (uint32_t k = 0; k < mkn[m]; k += 8) *reinterpret_cast<uint64_t *>(kref + mko[m] + k) = jt_word(sb, (uint32_t)mks[m] + k);
+    }
+    if (tid == 0) {  // processPayload walks the properties in name order: the first required one no member gives
+      uint32_t miss = 0xFFFFFFFFu;
+      for (int j = 0; j < p.nprops; j++) if (p.props[j].required && owner[j] == 0xFFFFu) { miss = ((uint32_t)j << 8) | (uint32_t)TFGPU_ROW_SR_REQUIRED; break; }
+      mapst[3] = miss;
+    }
+  }
+  __syncthreads();
+  if (misc[0]) { all_slow(); continue; }  // uniform
+  if (build_map && tid == 0) { mapst[0] = K; mapst[1] = 1u; }
+  if (tid == 0) mapst[2] = 0;
+  __syncthreads();
+
+  // ---- cells ----
+  {
+    const uint32_t unl = (uint32_t)nl, items = K * unl;
+    for (uint32_t it = (uint32_t)tid; it < items; it += JT_THREADS) {
+      const uint32_t m = it / unl, j = it - m * unl;
+      if (lslow[j]) continue;
+      if (lK[j] != K) { if (lslow[j] == 0) { lslow[j] = 1; atomicAdd(&mapst[2], 1u); } continue; }
+      const uint32_t b = lbase[j];
+      const uint32_t pp = spos[b + 2 * m], pc = spos[b + 1 + 2 * m], pn = spos[b + 2 + 2 * m];
+      const uint32_t kn = mkn[m];
+      uint32_t kq = pp + 1, ke = pc;
+      while (kq < pc && jt_ws(sb[kq])) kq++;
+      while (ke > kq && jt_ws(sb[ke - 1])) ke--;
+      bool ok = ke == kq + 2 + kn && sb[pc] == ':' && sb[kq] == '"' && sb[ke - 1] == '"' && sb[pn] == (m + 1 == K ? '}' : ',');
+      if (ok && !jt_same2(sb, kq + 1, kref, mko[m], kn)) { ok = false; if (lslow[j] == 0) atomicAdd(&mapst[2], 1u); }
+      uint32_t vs = pc + 1, ve = pn;
+      while (vs < pn && jt_ws(sb[vs])) vs++;
+      while (ve > vs && jt_ws(sb[ve - 1])) ve--;
+      const uint32_t n = ve - vs;
+      ok = ok && n > 0;
+      uint32_t vt = VT_ABSENT;
+      bool isint = false, inrange = false;
+      if (ok) {
+        const uint32_t c0 = sb[vs];
+        if (c0 == '"') {
+          ok = n >= 2 && sb[ve - 1] == '"' && jt_quotes_in(t, vs, ve) == 2;
+          const uint32_t cl = ok ? st_byte_classes(sb, vs + 1, ve - 1) : 0u;
+          if (cl & 2u) ok = false;  // a control byte inside a string literal is a syntax error
+          const bool esc = ok && jt_backslashes_in(L, vs, ve) != 0;
+          if (esc) ok = st_escapes_ok(sb, vs + 1, ve - 1);  // (decoded by the value kernels, as for every string that is not plain)
+          vt = VT_STR | (((cl & 1u) || esc) ? 0u : (uint32_t)VT_PLAIN);
+        } else if (jt_lit(sb, vs, n, 0x6C6C756Eu, 4)) vt = VT_NULL;
+        else if (jt_lit(sb, vs, n, 0x65757274u, 4)) vt = VT_TRUE;
+        else if (jt_lit(sb, vs, n, 0x736C6166u, 5)) vt = VT_FALSE;
+        else {
+          bool ng; uint64_t mag; uint32_t nd;
+          if (jt_quotes_in(t, vs, ve) != 0) ok = false;
+          else if (jt_int_token(sb, vs, ve, &ng, &mag, &nd)) {
+            if (nd > 1 && sb[ve - nd] == '0') ok = false;  // a leading zero: "invalid character after top-level value"
+            isint = true; inrange = mag <= (ng ? (1ull << 63) : (1ull << 63) - 1);
+            vt = VT_NUM;
+          } else { ok = st_json_number(sb, vs, ve); vt = VT_NUM; }
+        }
+      }
+      if (!ok) { lslow[j] = 1; continue; }
+      const int32_t pj = mprop[m];
+      if (pj < 0) continue;  // no property of the schema: json.Unmarshal keeps it, processPayload never asks
+      p.vrec[(int64_t)pj * p.nframes + (f0 + j)] = (uint64_t)(g0 + vs) | (uint64_t)n << 32 | (uint64_t)(vt & 0xFFu) << 56;
+      const uint32_t base = vt & VT_MASK;
+      if (base == VT_NULL && !mreq[m]) continue;
+      bool good = true;
+      switch (mtype[m]) {
+        case TFGPU_SRT_BOOLEAN: good = base == VT_TRUE || base == VT_FALSE; break;
+        case TFGPU_SRT_INTEGER: good = base == VT_NUM && isint && inrange; break;
+        case TFGPU_SRT_NUMBER: good = base == VT_NUM; break;
+        case TFGPU_SRT_STRING: good = base == VT_STR; break;
+        default: break;
+      }
+      if (!good) atomicMin(&lerr[j], ((uint32_t)pj << 8) | (uint32_t)TFGPU_ROW_SR_TYPE);
+    }
+  }
+  __syncthreads();
+  if (tid < nl && lslow[tid] != 2) {
+    if (lslow[tid]) hand_over(f0 + tid);
+    else {
+      const uint32_t e = min(lerr[tid], mapst[3]);
+      p.status[f0 + tid] = e == 0xFFFFFFFFu ? (uint8_t)ST_OK : (uint8_t)(e & 0xFFu);
+    }
+  }
+  if (tid == 0 && mapst[2] * 2 > (uint32_t)nl) mapst[1] = 0;
+  }  // tiles
+}
+// the payloads the tile path hands over
+__global__ void __launch_bounds__(128) sr_parse_listed(Params p, const uint32_t *slow_n, const uint32_t *slow_f) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= *slow_n) return;
+  const int64_t f = slow_f[k];
+  p.status[f] = (uint8_t)parse_frame(p, f);
+}
+
 __global__ void __launch_bounds__(128) sr_parse_frames(Params p) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= p.nframes) return;
@@ -437,6 +693,22 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
   TF_HIP(hipMemsetAsync(guess->p, 0xFF, sr::GUESS_N * 2, st));
   p.guess = ptr<uint16_t>(guess);
   if (nf) {
+    static const bool tilepath = [] { const char *e = std::getenv("TFGPU_SR_TILES"); return !(e && e[0] == '0'); }();  // 0: A/B runs
+    if (tilepath) {
+      const uint64_t avg = std::max<uint64_t>(len / (uint64_t)nfa, 1);
+      const int32_t per_tile = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(JT_BYTES - 16) * 8 / (avg * 9), 1), (uint64_t)JT_LINES);
+      Buf slow = dalloc((size_t)(nf + 1) * 4 + 16);
+      TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
+      const unsigned ntile = sr::nblk(nf, per_tile), nb = (unsigned)std::min<int64_t>((int64_t)ntile, (int64_t)cx.num_cus * 2);
+      { KernelTimer t("sr_parse_tiles"); sr::sr_parse_tiles<<<nb, JT_THREADS, 0, st>>>(p, per_tile, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+      { KernelTimer t("sr_parse_frames"); sr::sr_parse_listed<<<sr::nblk(nf, 128), 128, 0, st>>>(p, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+      static const bool dbg = [] { const char *e = std::getenv("TFGPU_JSON_TILE_DEBUG"); return e && e[0] == '1'; }();
+      if (dbg) {
+        const uint32_t *a = d2h_u32(slow->p);
+        tf::sync();
+        std::fprintf(stderr, "[tfgpu] sr tiles: %lld frames, %d per tile, %u to parse_frame\n", (long long)nf, (int)per_tile, *a);
+      }
+    } else
     { KernelTimer t("sr_parse_frames"); sr::sr_parse_frames<<<sr::nblk(nf, 128), 128, 0, st>>>(p); }
     { KernelTimer t("sr_message_rule"); sr::sr_message_rule<<<sr::nblk(p.nmsg, 256), 256, 0, st>>>(p); }
   }
