@@ -1253,7 +1253,10 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid < 4) mapst[tid] = 0;
   const int64_t ntiles = (p.nseg + lines_per_tile - 1) / lines_per_tile;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // a workgroup takes a contiguous run of tiles: the short column segments two neighbouring tiles write share cache lines,
+  // and written one after the other by the same CU they leave its L2 as whole lines
+  const int64_t tiles_each = (ntiles + gridDim.x - 1) / gridDim.x;
+  for (int64_t tile = (int64_t)blockIdx.x * tiles_each; tile < min(ntiles, ((int64_t)blockIdx.x + 1) * tiles_each); tile++) {
   __syncthreads();  // the previous tile's LDS is free
   const int64_t i0 = tile * lines_per_tile;
   int nl = (int)min<int64_t>(lines_per_tile, p.nseg - i0);  // lines_per_tile <= JT_LINES <= 64: one lane per line
@@ -1395,6 +1398,7 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   // ---- cells: class by class, items (member, line) with lines fastest, slots of 64 dealt round-robin to the waves ----
   {
     const uint32_t unl = (uint32_t)nl;
+    const float inv_nl = __uint_as_float(__float_as_uint(1.0f / (float)unl) - 2u);
     uint32_t sbase = 0;
     for (uint32_t c = 0; c < JTC_COUNT; c++) {
       const uint32_t f0 = cfirst[c], nm = cfirst[c + 1] - f0;
@@ -1403,7 +1407,8 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
       for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
         const uint32_t it = (s - sbase) * 64 + (uint32_t)lane;
         if (it >= items) continue;
-        const uint32_t oi = it / unl, j = it - oi * unl;
+        uint32_t oi = (uint32_t)(__uint2float_rz(it) * inv_nl), j = it - oi * unl;  // it / unl by a reciprocal a hair too small + one correction
+        if (j >= unl) { oi++; j -= unl; }
         if (lslow[j]) continue;
         if (lK[j] != K) { if (lslow[j] == 0) { lslow[j] = 1; atomicAdd(&mapst[2], 1u); } continue; }
         const uint32_t m = perm[f0 + oi];

@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t jt_backslashes_in(const JtLds &L, uint32_t a
 // Stage the bytes [g0, last) of `data` (g0 a multiple of 16, first = the first line's offset), classify, index, frame the
 // lines.  The caller has written lstart / lend / lslow / lbase (= 0xFFFF) of its nl lines.  All threads of the workgroup
 // call it (it holds the barriers); false (uniform): the tile cannot be taken.
-__device__ __forceinline__ bool jt_front(JtLds &L, const uint8_t *data, const uint32_t first, const uint32_t last, const uint32_t g0, const int nl) {
+__device__ __forceinline__ bool jt_front(JtLds &L, const uint8_t *data, const uint32_t first, const uint32_t last, const uint32_t g0, const int nl, const int ablate = 0) {
   uint8_t *const sbuf = L.sbuf, *const sb = L.sbuf + 16;
   uint16_t *const spos = L.spos, *const qpre = L.qpre, *const bpre = L.bpre, *const lstart = L.lstart, *const lend = L.lend, *const lbase = L.lbase, *const lK = L.lK;
   uint32_t *const qmask = L.qmask, *const smask = L.smask, *const bmask = L.bmask, *const wpar = L.wpar, *const wcnt = L.wcnt, *const wqc = L.wqc, *const wbc = L.wbc, *const misc = L.misc;
@@ -107,6 +107,7 @@ __device__ __forceinline__ bool jt_front(JtLds &L, const uint8_t *data, const ui
   if (tid < 4) { reinterpret_cast<uint32_t *>(sbuf)[tid] = 0; misc[tid] = 0; }
   if (tid < 12) reinterpret_cast<uint32_t *>(sbuf + 16 + JT_BYTES)[tid] = 0;
   __syncthreads();
+  if (ablate == 1) return false;  // (TFGPU_JT_ABLATE, profiling only: leave after phase n; the tile then goes to the per-line parser)
 
 
   // ---- pass 1: byte classes of this thread's 48 bytes ----
@@ -167,6 +168,7 @@ __device__ __forceinline__ bool jt_front(JtLds &L, const uint8_t *data, const ui
   }
   if (__any(bad != 0) && lane == 0) misc[0] = 1u;
   __syncthreads();
+  if (ablate == 2) { if ((Q ^ B ^ S) == 0x1234567ull) misc[3] = 1u; return false; }
 
   // ---- pass 2: inside-string state, separators outside strings ----
   uint32_t s_in = par_in;
@@ -216,6 +218,7 @@ __device__ __forceinline__ bool jt_front(JtLds &L, const uint8_t *data, const ui
   }
   __syncthreads();
 
+  if (ablate == 3) return false;
   const uint32_t nsep = misc[1];
   // ---- lines: where their separators start, how many, the frame { … } ----
   if (tid < nl && lslow[tid] == 0) {

@@ -272,7 +272,7 @@ __device__ __forceinline__ int st_key_compare(const uint8_t *sb, uint32_t ks, ui
   return kn == nlen ? 0 : kn < nlen ? -1 : 1;
 }
 
-__global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_t frames_per_tile, uint32_t *slow_n, uint32_t *slow_f) {
+__global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_t frames_per_tile, uint32_t *slow_n, uint32_t *slow_f, int ablate) {
   __shared__ JtLds L;
   uint8_t *const sb = L.sbuf + 16;
   uint16_t *const spos = L.spos, *const lstart = L.lstart, *const lend = L.lend, *const lbase = L.lbase, *const lK = L.lK;
@@ -281,14 +281,18 @@ __global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_
   __shared__ uint32_t lerr[JT_LINES];  // the first failing property of the payload in name order: prop << 8 | code
   __shared__ int16_t mprop[JT_MEM];
   __shared__ uint16_t mks[JT_MEM], mkn[JT_MEM], mko[JT_MEM];
-  __shared__ uint8_t mtype[JT_MEM], mreq[JT_MEM];
+  __shared__ uint8_t mtype[JT_MEM], mreq[JT_MEM], perm[JT_MEM];
+  __shared__ uint32_t cfirst[3];  // members whose property is a string come last: a wave's cells are all strings or all scalars
   __shared__ uint16_t owner[JT_OWN];
   __shared__ __attribute__((aligned(16))) uint8_t kref[JT_KREF + 32];
   __shared__ uint32_t mapst[4];  // 0: members, 1: valid, 2: payloads of this tile that spell other keys, 3: first required property no member gives
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid < 4) mapst[tid] = 0;
   const int64_t ntiles = (p.nframes + frames_per_tile - 1) / frames_per_tile;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // a workgroup takes a contiguous run of tiles: the short column segments two neighbouring tiles write share cache lines,
+  // and written one after the other by the same CU they leave its L2 as whole lines
+  const int64_t tiles_each = (ntiles + gridDim.x - 1) / gridDim.x;
+  for (int64_t tile = (int64_t)blockIdx.x * tiles_each; tile < min(ntiles, ((int64_t)blockIdx.x + 1) * tiles_each); tile++) {
   __syncthreads();
   const int64_t f0 = tile * frames_per_tile;
   int nl = (int)min<int64_t>(frames_per_tile, p.nframes - f0);
@@ -321,7 +325,8 @@ __global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_
   }
   auto all_slow = [&]() { if (tid < nl && lslow[tid] != 2) hand_over(f0 + tid); };
   for (int i = tid; i < JT_OWN; i += JT_THREADS) owner[i] = 0xFFFFu;
-  if (!jt_front(L, p.data, first, last, g0, nl)) { all_slow(); continue; }
+  if (!jt_front(L, p.data, first, last, g0, nl, ablate)) { all_slow(); continue; }
+  if (ablate == 4) { all_slow(); continue; }
   JtTile t;
   t.sb = sb; t.spos = spos; t.qmask = L.qmask; t.qpre = L.qpre; t.bpre = L.bpre; t.g0 = g0;
   int jref = 0;
@@ -375,6 +380,20 @@ __global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_
       if (mprop[m] >= 0 && owner[mprop[m]] != (uint16_t)m) misc[0] = 1u;  // a key read twice: the last one wins → parse_frame
       for (uint32_t k = 0; k < mkn[m]; k += 8) *reinterpret_cast<uint64_t *>(kref + mko[m] + k) = jt_word(sb, (uint32_t)mks[m] + k);
     }
+    if (wv == 0) {  // string properties behind the others (their cells walk the string's bytes: long loops that scalars should not wait for)
+      uint32_t nxt = 0;
+      for (uint32_t c = 0; c < 2; c++) {
+        if (lane == 0) cfirst[c] = nxt;
+        for (uint32_t r0 = 0; r0 < K; r0 += 64) {
+          const uint32_t m = r0 + (uint32_t)lane;
+          const bool mine = m < K && (uint32_t)(mtype[m] == TFGPU_SRT_STRING && mprop[m] >= 0) == c;
+          const uint64_t bal = __ballot(mine);
+          if (mine) perm[nxt + lanes_below(bal)] = (uint8_t)m;
+          nxt += (uint32_t)__popcll(bal);
+        }
+      }
+      if (lane == 0) cfirst[2] = nxt;
+    }
     if (tid == 0) {  // processPayload walks the properties in name order: the first required one no member gives
       uint32_t miss = 0xFFFFFFFFu;
       for (int j = 0; j < p.nprops; j++) if (p.props[j].required && owner[j] == 0xFFFFu) { miss = ((uint32_t)j << 8) | (uint32_t)TFGPU_ROW_SR_REQUIRED; break; }
@@ -387,11 +406,16 @@ __global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_
   if (tid == 0) mapst[2] = 0;
   __syncthreads();
 
+  if (ablate == 5) { all_slow(); continue; }
   // ---- cells ----
-  {
-    const uint32_t unl = (uint32_t)nl, items = K * unl;
+  for (uint32_t cls = 0; cls < 2; cls++) {
+    const uint32_t unl = (uint32_t)nl, f0c = cfirst[cls], items = (cfirst[cls + 1] - f0c) * unl;
+    const float inv = __uint_as_float(__float_as_uint(1.0f / (float)unl) - 2u);  // it / unl by a reciprocal a hair too small + one correction
     for (uint32_t it = (uint32_t)tid; it < items; it += JT_THREADS) {
-      const uint32_t m = it / unl, j = it - m * unl;
+      uint32_t oi = (uint32_t)(__uint2float_rz(it) * inv);
+      uint32_t j = it - oi * unl;
+      if (j >= unl) { oi++; j -= unl; }
+      const uint32_t m = perm[f0c + oi];
       if (lslow[j]) continue;
       if (lK[j] != K) { if (lslow[j] == 0) { lslow[j] = 1; atomicAdd(&mapst[2], 1u); } continue; }
       const uint32_t b = lbase[j];
@@ -700,7 +724,8 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
       Buf slow = dalloc((size_t)(nf + 1) * 4 + 16);
       TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
       const unsigned ntile = sr::nblk(nf, per_tile), nb = (unsigned)std::min<int64_t>((int64_t)ntile, (int64_t)cx.num_cus * 2);
-      { KernelTimer t("sr_parse_tiles"); sr::sr_parse_tiles<<<nb, JT_THREADS, 0, st>>>(p, per_tile, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+      { KernelTimer t("sr_parse_tiles"); static const int ablate = [] { const char *e = std::getenv("TFGPU_JT_ABLATE"); return e ? std::atoi(e) : 0; }();
+        sr::sr_parse_tiles<<<nb, JT_THREADS, 0, st>>>(p, per_tile, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1, ablate); }
       { KernelTimer t("sr_parse_frames"); sr::sr_parse_listed<<<sr::nblk(nf, 128), 128, 0, st>>>(p, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
       static const bool dbg = [] { const char *e = std::getenv("TFGPU_JSON_TILE_DEBUG"); return e && e[0] == '1'; }();
       if (dbg) {
