@@ -70,9 +70,16 @@ def test_json_kernels_stay_lean():
     """The kernels every line / cell runs through do not carry the map emitter (any containers, `_rest`): lines and cells that
     need it go through json_parse_listed and the second copy launch, which do."""
     t = kernel_table("tf_json.hip")
-    lines, listed = find(t, "json_parse_lines"), find(t, "json_parse_listed")
+    lines, listed = find(t, "json_parse_linesE"), find(t, "json_parse_listedE")
     assert lines["vgpr"] <= 168 and lines["scratch"] <= 320, lines
     assert listed["vgpr"] > lines["vgpr"]
+    lean_listed = find(t, "json_parse_listed_lean")  # what the tile parser hands over goes through the lean grammar first
+    assert lean_listed["vgpr"] <= 168 and lean_listed["scratch"] <= 320, lean_listed
+    # the tile parser: 512 threads at four waves per SIMD (128 VGPRs, a small spill), two workgroups of LDS per CU
+    tiles = find(t, "json_parse_tiles")
+    assert tiles["vgpr"] <= 128 and tiles["scratch"] <= 128 and tiles["lds"] * 2 <= 160 * 1024, tiles
+    sr_tiles = find(kernel_table("tf_srjson.hip"), "sr_parse_tiles")
+    assert sr_tiles["vgpr"] <= 128 and sr_tiles["scratch"] <= 128 and sr_tiles["lds"] * 2 <= 160 * 1024, sr_tiles
     copies = {k: v for k, v in t.items() if "json_copy_cells" in k}
     assert len(copies) == 2
     lean = min(copies.values(), key=lambda v: v["vgpr"])
