@@ -1294,9 +1294,9 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   JtTile t;
   t.sb = sb; t.spos = spos; t.qmask = qmask; t.qpre = qpre; t.bpre = bpre; t.g0 = g0;
   auto backslashes_in = [&](uint32_t a, uint32_t b) { return jt_backslashes_in(L, a, b); };
-  // the reference line: the tile's first line (uniform reads)
+  // the reference line (uniform reads)
   int jref = 0;
-  while (jref < nl && lslow[jref] == 2) jref++;
+  while (jref < nl && lslow[jref] != 0) jref++;  // the first line that is framed: the one whose keys are looked up when there is no map
   const bool build_map = mapst[1] == 0;  // uniform
   if (build_map && (jref >= nl || lslow[jref])) { all_slow(); continue; }
   const uint32_t bref = build_map ? lbase[jref] : 0u;

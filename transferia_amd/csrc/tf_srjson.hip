@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_
   JtTile t;
   t.sb = sb; t.spos = spos; t.qmask = L.qmask; t.qpre = L.qpre; t.bpre = L.bpre; t.g0 = g0;
   int jref = 0;
-  while (jref < nl && lslow[jref] == 2) jref++;
+  while (jref < nl && lslow[jref] != 0) jref++;  // the first line that is framed: the one whose keys are looked up when there is no map
   const bool build_map = mapst[1] == 0;  // uniform
   if (build_map && (jref >= nl || lslow[jref])) { all_slow(); continue; }
   const uint32_t bref = build_map ? lbase[jref] : 0u;
