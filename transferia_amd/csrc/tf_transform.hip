@@ -422,19 +422,30 @@ __global__ void __launch_bounds__(256) build_selection_kernel(const uint32_t *__
 // All fixed-width arrays of a batch (values, nanos, kind, part_id, src_row) in ONE launch: lane = output
 // row, wave-uniform loop over the arrays, so every store is coalesced and the selection vector is read once.
 struct GFix { const void *in; void *out; int32_t width; int32_t pad; };
-__global__ void __launch_bounds__(256) gather_fixed_all(const GFix *__restrict__ a, int na, const int32_t *__restrict__ sel, int64_t m) {
+// the arrays arrive sorted by element width (n1 of one byte, then n2, n4, n8), so every loop below has one element type and
+// no branch between its loads: a lane requests eight arrays' values before it stores the first — one wait for memory per
+// eight arrays instead of one per array (the kernel used to be a chain of 78 round trips per lane)
+template <class T> __device__ __forceinline__ void gather_run(const GFix *__restrict__ a, int lo, int hi, int32_t s, int64_t k) {
+  constexpr int U = 8;
+  int i = lo;
+  for (; i + U <= hi; i += U) {
+    T v[U];
+#pragma unroll
+    for (int q = 0; q < U; q++) v[q] = TF_GLOBAL_PTR(const T, a[i + q].in)[s];
+#pragma unroll
+    for (int q = 0; q < U; q++) TF_GLOBAL_PTR(T, a[i + q].out)[k] = v[q];
+  }
+  for (; i < hi; i++) TF_GLOBAL_PTR(T, a[i].out)[k] = TF_GLOBAL_PTR(const T, a[i].in)[s];
+}
+__global__ void __launch_bounds__(256) gather_fixed_all(const GFix *__restrict__ a, int n1, int n2, int n4, int n8, uint32_t *__restrict__ ident, const int32_t *__restrict__ sel, int64_t m) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= m) return;
   const int32_t s = sel[k];
-  for (int i = 0; i < na; i++) {
-    const GFix g = a[i];
-    switch (g.width) {
-      case 1: ((uint8_t *)g.out)[k] = ((const uint8_t *)g.in)[s]; break;
-      case 2: ((uint16_t *)g.out)[k] = ((const uint16_t *)g.in)[s]; break;
-      case 4: ((uint32_t *)g.out)[k] = g.in ? ((const uint32_t *)g.in)[s] : (uint32_t)s; break;  // in == NULL: identity src_row
-      default: ((uint64_t *)g.out)[k] = ((const uint64_t *)g.in)[s];
-    }
-  }
+  if (ident) ident[k] = (uint32_t)s;  // src_row of a batch that had none: the identity
+  gather_run<uint8_t>(a, 0, n1, s, k);
+  gather_run<uint16_t>(a, n1, n1 + n2, s, k);
+  gather_run<uint32_t>(a, n1 + n2, n1 + n2 + n4, s, k);
+  gather_run<uint64_t>(a, n1 + n2 + n4, n1 + n2 + n4 + n8, s, k);
 }
 // validity bitmaps of all columns in one launch: one thread per output byte (8 rows), blockIdx.y = bitmap
 struct GBit { const uint8_t *in; uint8_t *out; };
@@ -563,13 +574,19 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   if (in.part_id) { out->part_id = dalloc((size_t)m * 4); fx.push_back(GFix{in.part_id->p, out->part_id->p, 4, 0}); }
   out->src_row = dalloc((size_t)m * 4);
   if (in.src_row) fx.push_back(GFix{in.src_row->p, out->src_row->p, 4, 0});
-  else fx.push_back(GFix{nullptr, out->src_row->p, 4, 0});
+  uint32_t *const ident = in.src_row ? nullptr : ptr<uint32_t>(out->src_row);
+
   if (m && !bits.empty()) {
     Buf bb = upload_const(bits.data(), bits.size() * sizeof(GBit));
     gather_bitmap_all<<<dim3(grid_for((m + 7) / 8, 256), (unsigned)bits.size()), 256, 0, st>>>(ptr<GBit>(bb), sp, m);
   }
+  std::stable_sort(fx.begin(), fx.end(), [](const GFix &x, const GFix &y) { return x.width < y.width; });
+  int nw[4] = {0, 0, 0, 0};
+  for (auto &x : fx) nw[x.width == 1 ? 0 : x.width == 2 ? 1 : x.width == 4 ? 2 : 3]++;
+  const int nfx[4] = {nw[0], nw[1], nw[2], nw[3]};
+  if (fx.empty()) fx.push_back(GFix{nullptr, nullptr, 0, 0});  // (never read: every count is zero)
   Buf bfx = upload_const(fx.data(), fx.size() * sizeof(GFix));
-  if (m) gather_fixed_all<<<g, 256, 0, st>>>(ptr<GFix>(bfx), (int)fx.size(), sp, m);
+  if (m) gather_fixed_all<<<g, 256, 0, st>>>(ptr<GFix>(bfx), nfx[0], nfx[1], nfx[2], nfx[3], ident, sp, m);
   if (nvar) {
     Buf bvr = upload_const(vr.data(), vr.size() * sizeof(GVar));
     if (m) gather_len_all<<<g, 256, 0, st>>>(ptr<GVar>(bvr), nvar, sp, m);
