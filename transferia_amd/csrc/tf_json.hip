@@ -34,6 +34,7 @@
 #include "tf_devfmt.hpp"
 #include "tf_devfloat.hpp"
 #include "tf_devparse.hpp"
+#include "tf_segcopy.hpp"
 #include "tf_wave.hpp"
 #include "tf_swar.hpp"
 #include "tf_jsontile.hpp"
@@ -1634,8 +1635,18 @@ __global__ void json_const_text(const uint8_t *text, uint32_t n, int64_t nrows, 
 // ---------------------------------------------------------------------------
 struct JCopyCol { const uint32_t *offsets, *fstart, *meta; uint8_t *out; };
 // HEAVY == false: every cell but those the map emitter writes; HEAVY == true: only those (a second launch over the same grid)
+// The cells that are a plain byte range of the input (JM_COPY: strings without escapes, raw number / literal tokens — nearly all of
+// them) are packed destination-centrically (tf_segcopy.hpp: a lane owns aligned 8-byte words of the column's payload and pulls
+// their bytes from the text); every other cell is zero-filled here and written by json_copy_cells afterwards.
+__global__ void __launch_bounds__(256) json_copy_words(const uint8_t *data, const JCopyCol *cols, int64_t nlines) {
+  __shared__ uint32_t doff[256 + 1];
+  __shared__ uint32_t soff[256];
+  const JCopyCol c = cols[blockIdx.y];
+  auto so = [&](int64_t g) { return (c.meta[g] >> 28) == JM_COPY ? c.fstart[g] : SEG_NONE; };
+  segcopy_run<1>(c.offsets, nlines, (int64_t)blockIdx.x * 256, data, c.out, so, doff, soff);
+}
 template <bool HEAVY>
-__global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCol *cols, int64_t nlines) {
+__global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCol *cols, int64_t nlines, int plain_done) {
   const uint8_t *data = jp.data; const double *pow10 = jp.pow10; const uint64_t *pow128 = jp.pow128;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nlines) return;
@@ -1647,6 +1658,7 @@ __global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCo
   uint8_t *dst = c.out + o0;
   MemBytes rd(data);
   if ((mode == JM_ANYCANON || mode == JM_REST) != HEAVY) return;
+  if (mode == JM_COPY && plain_done) return;  // json_copy_words moved it
   if constexpr (HEAVY) {
     StoreSink sk{dst};
     if (mode == JM_ANYCANON) fj_emit_any(sk, jp, rd, s, s + srclen); else rest_emit(sk, jp, rd, s, s + srclen);
@@ -2084,8 +2096,10 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   if (nlines && nstr) {
     Buf bcc = upload_small(cc.data(), cc.size() * sizeof(JCopyCol));
     KernelTimer t("json_copy_cells");
-    json_copy_cells<false><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines);
-    json_copy_cells<true><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines);
+    static const bool words = [] { const char *e = std::getenv("TFGPU_JSON_COPY_WORDS"); return !(e && e[0] == '0'); }();  // 0: A/B runs
+    if (words) json_copy_words<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(data, ptr<JCopyCol>(bcc), nlines);
+    json_copy_cells<false><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines, words ? 1 : 0);
+    json_copy_cells<true><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines, words ? 1 : 0);
   }
 
   // ---- dropped lines: `_unparsed` rows / host fallback are reported, skipped lines vanish ----

@@ -316,7 +316,18 @@ __global__ void __launch_bounds__(256) ser_row_layout(SerParams p) {
   uint32_t off = (p.format == TFGPU_FMT_CSV) ? 0u : 1u;  // '{'
   if (p.q.qformat) off = p.q.qformat == TFGPU_QFMT_NATIVE ? 1u : 0u;  // '[' or ',' in front of every native element
   int32_t last = -1;
-  for (int32_t c = 0; c < p.ncols; c++) {
+  // eight lengths are requested before the first offset is stored: the loop is a lane's walk over its row's cells, and with a
+  // load and a store to the same array in every step the compiler has to wait for each load in turn
+  constexpr int U = 8;
+  int32_t c = 0;
+  for (; c + U <= p.ncols; c += U) {
+    uint32_t n[U];
+#pragma unroll
+    for (int q = 0; q < U; q++) n[q] = p.cell[(int64_t)(c + q) * p.nrows + r];
+#pragma unroll
+    for (int q = 0; q < U; q++) { p.cell[(int64_t)(c + q) * p.nrows + r] = off; if (n[q]) last = c + q; off += n[q]; }
+  }
+  for (; c < p.ncols; c++) {
     const uint32_t n = p.cell[(int64_t)c * p.nrows + r];
     p.cell[(int64_t)c * p.nrows + r] = off;
     if (n) last = c;
