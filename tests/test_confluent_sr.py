@@ -394,6 +394,31 @@ def test_gpu_tile_path_matches_oracle(tf, oracle, n):
 
 
 @pytest.mark.gpu
+def test_gpu_tile_path_chunk_border_sweep(tf, oracle):
+    """Quotes, escaped quotes and backslash runs moved byte by byte across the chunk / thread borders of the tile parser's
+    classification; the five prefix bytes between payloads carry quote and backslash bytes of their own (schema ids 0x22, 0x5C)."""
+    rng = np.random.default_rng(SEED0 + 4200)
+    schema = _random_payloads(rng, 0)[0]
+    tails = ['', '\\"', '\\\\', '\\\\\\"', '\\' * 6, '\\' * 63 + '\\"', '\\' * 64, '\\' * 65 + 'n', '"', 'é', '\\u00e9', '\\q', ',"in":', '}{']
+    payloads = []
+    for pad in range(0, 140):
+        for i, tail in enumerate(tails):
+            payloads.append(('{"in":%d,"st":"%s","nu":%d}' % (pad * 16 + i, "x" * pad + tail, i)).encode("utf-8"))
+    _compare_with_oracle(tf, oracle, rng, schema, payloads, False, len(payloads) // 3)
+    # the same payloads behind schema ids whose bytes are '"' and '\\': not ours, and their prefix bytes must not leak into the next payload's parity
+    o = confluent_sr.sr_json_options(5, schema)
+    frames = []
+    for k, pl in enumerate(payloads[:900]):
+        sid = 5 if k % 3 else 0x2222225C
+        frames.append(b"\0" + sid.to_bytes(4, "big") + pl)
+    data, cm = abi.messages(frames, offsets=np.arange(len(frames)))
+    ref = oracle.sr_json_parse(o, data, cm)
+    got = tf.sr_json_parse(o, data, cm)
+    assert sorted((e[0], e[1]) for e in got.errors) == sorted((e[0], e[1]) for e in ref.errors)
+    assert abi.batch_rows(got.batch) == abi.batch_rows(ref.batch) and list(got.batch.src_row) == list(ref.batch.src_row)
+
+
+@pytest.mark.gpu
 def test_gpu_per_frame_path_cross_check():
     """sr_parse_tiles is the default; TFGPU_SR_TILES=0 sends every payload through parse_frame.  Both must pass the suite."""
     import os

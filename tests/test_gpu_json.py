@@ -543,6 +543,25 @@ def test_tile_path_against_the_per_line_grammar(tf, oracle):
     compare(tf, oracle, abi.json_options(topic="t", add_dedupe_keys=True), fields, data, msgs, "tiles as messages", max_fallback=len(vals))
 
 
+def test_tile_path_chunk_border_sweep(tf, oracle):
+    """Quotes, escaped quotes and backslash runs moved byte by byte across the 16-byte chunk, the 64-byte thread and the tile
+    borders of the tile parser's classification (the escaped-quote carry and the in-string parity cross lanes and waves there)."""
+    fields = abi.Schema.of(EDGE_FIELDS)
+    tails = ['', '\\"', '\\\\', '\\\\\\"', '\\' * 6, '\\' * 63 + '\\"', '\\' * 64, '\\' * 65 + 'n', '"', 'é', '\\u00e9', ',"k":', '}{']
+    lines = []
+    for pad in range(0, 140):
+        for i, tail in enumerate(tails):
+            body = "x" * pad + tail
+            # the string is written by hand (json.dumps would re-escape): only well-formed escape sequences stay valid JSON
+            lines.append(('{"k":%d,"s":"%s","y":"%s","i8":%d}' % (pad * 16 + i, body, "z" * (pad % 7), i)).encode("utf-8"))
+    opts = abi.json_options(topic="t")
+    out, errs, nfb = compare(tf, oracle, opts, fields, b"\n".join(lines), None, "border sweep", max_fallback=len(lines))
+    assert out.nrows > len(lines) // 2
+    vals = lines[:600]
+    data, msgs = abi.messages(vals, list(range(len(vals))), [0] * len(vals))
+    compare(tf, oracle, opts, fields, data, msgs, "border sweep as messages", max_fallback=len(vals))
+
+
 def test_per_line_path_cross_check():
     """The tile parser is the default; with TFGPU_JSON_TILES=0 every line takes the per-line parser.  Both must pass the suite."""
     import os
