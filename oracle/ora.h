@@ -230,4 +230,9 @@ ora_batch *ora_sr_json_parse(const tfgpu_sr_json_options *o, const void *bytes, 
 #ifdef __cplusplus
 }
 #endif
+/* lookupComplex over a top-level string value (ora_lookup.c; parsers/generic/lookup.go:10-59).  segs[0] is the top-level key
+ * (already resolved to `top`), segs[1..] the nested field names. */
+enum { ORA_LOOKUP_STRING = 0, ORA_LOOKUP_ERROR = 1, ORA_LOOKUP_NIL = 2, ORA_LOOKUP_OTHER = 3 };
+int ora_lookup_complex(const char *top, size_t topn, const char *const *segs, int nsegs, char **out, size_t *outn);
+
 #endif

@@ -904,7 +904,38 @@ ora_batch *ora_json_parse(const tfgpu_json_options *o, const tfgpu_schema *field
           }
           if (kt != col->dtype) { unrestated = 1; continue; }
         }
-        if (strchr(cp, '.') || strchr(cp, '/')) { unrestated = 1; continue; }  /* IsNestedKey → lookupComplex: not restated */
+        if (strchr(cp, '.') || strchr(cp, '/')) {
+          /* IsNestedKey (col_schema.go:95-97) → lookupComplex (generic_parser.go:323-347, lookup.go:10-38): strings.Split(path, "."),
+           * or by "/" when that gives one part; the first name picks the top-level value, which must be a Go string holding JSON */
+          char *pc = dup_cstr(cp);
+          const char *segs[32]; int ns = 0;
+          const char sepc = strchr(cp, '.') ? '.' : '/';
+          for (char *q = pc, *start = pc;; q++) if (*q == sepc || !*q) { const int last = !*q; *q = 0; if (ns < 32) segs[ns++] = start; start = q + 1; if (last) break; }
+          const fj_value *top = NULL;
+          const size_t l0 = strlen(segs[0]);
+          for (int i = 0; i < root->nkids; i++) {
+            size_t kl; char *k = fj_unescape(root->keys[i], root->klen[i], &kl);
+            if (kl == l0 && !memcmp(k, segs[0], kl)) top = root->kids[i];
+            free(k);
+          }
+          const int is_key = (col->flags & TFGPU_COL_KEY) != 0, is_req = (col->flags & TFGPU_COL_REQUIRED) != 0;
+          int rcl = ORA_LOOKUP_ERROR; char *sv = NULL; size_t svn = 0;
+          if (ns >= 32 || (top && top->t != FJ_STR && top->t != FJ_NULL) || (top && top->t == FJ_STR && o->unescape_string_values && !tskv)) { unrestated = 1; free(pc); continue; }  /* a map at the top (Format json): not restated */
+          if (top && top->t == FJ_STR) { size_t tn; char *ts = fj_unescape(top->s, top->n, &tn); rcl = ora_lookup_complex(ts, tn, segs, ns, &sv, &svn); free(ts); }
+          /* (top absent: "unable to get field"; top nil: "unexpected value type: <nil>" — errors both) */
+          free(pc);
+          if (rcl == ORA_LOOKUP_OTHER) { unrestated = 1; continue; }
+          if (rcl == ORA_LOOKUP_ERROR || rcl == ORA_LOOKUP_NIL) {
+            if (!o->null_keys_allowed && (is_key || is_req)) { status = ORA_JL_UNPARSED; code = TFGPU_ROW_NIL_KEY; ecol = c; }  /* "lookupComplex error" / "lookupComplex nil … required" */
+            continue;
+          }
+          ora_value v = val_str(OV_STRING, sv, svn); free(sv);
+          const int rcp = parse_val(&v, col->dtype, o);
+          if (rcp == 2) { unrestated = 1; ora_value_free(&v); continue; }
+          if (rcp == 1) { ora_value_free(&v); if (!o->null_keys_allowed) { status = ORA_JL_UNPARSED; code = TFGPU_ROW_PARSE_VAL; ecol = c; } continue; }  /* ParseVal error: _unparsed whatever the column's flags */
+          vals[c] = v;
+          continue;
+        }
         size_t cpl = strlen(cp);
         const fj_value *found = NULL;
         for (int i = 0; i < root->nkids; i++) {

@@ -138,3 +138,36 @@ def test_any_and_rest_marshal_match_python_json(oracle):
     for (v, extra), row in zip(docs, r.rows):
         assert row[1][1].decode("utf-8") == _go_marshal(v)
         assert row[2][1].decode("utf-8") == _go_marshal(extra)
+
+
+def test_lookup_complex_rules(oracle):
+    """lookupComplex + parseJSON (parsers/generic/lookup.go:10-59) through makeChangeItem (generic_parser.go:323-347): the
+    nested-path columns of the metrika canon, as small cases.  Oracle only — the device refuses a nested ColSchema.Path."""
+    # [name, type, key, path, original_type, required]
+    fields = abi.Schema.of([["k", "int32", True], ["s", "utf8", False, "ev.a.b"], ["t", "utf8", False, "ev/c"], ["n", "int32", False, "ev.num"], ["q", "utf8", False, "ev.a.zz"]])
+    opts = abi.json_options(topic="t", format="tskv")
+    lines = [
+        b'k=1\tev={"a":{"b":"x"},"c":"y","num":"12"}',            # a map inside the decoded map, '/' as the separator, ParseVal of a string
+        b'k=2\tev={"a":"{\\"b\\":\\"inner\\"}","c":null}',           # a string that holds JSON again is parsed again; null → nil
+        b'k=3\tev={\\\\"a\\\\": {\\\\"b\\\\": \\\\"dbl\\\\"}, \\\\"c\\\\": \\\\"e\\\\"}',   # \\\\" → \\" does not help, dropping every backslash does
+        b'k=4\tev=not json',                                         # parseJSON fails three times: the cells stay nil
+        b'k=5\tev=null',                                             # a nil map: "unable to get field"
+        b'k=6\tother=1',                                             # no top-level value at all
+        b'k=7\tev={"a":{"b":5},"num":"zz"}',                        # a number at the end: not restated; ParseVal error on a plain column: _unparsed
+        b'k=8\tev={"a":{"b":"x"}} trailing',                        # invalid character after top-level value → retries → error
+    ]
+    data, msgs = abi.messages([b"\n".join(lines)], [0], [0])
+    r = oracle.json_parse(opts, fields, data, msgs)
+    rows = {int(r.rows[i][0][1]): r.rows[i] for i in range(r.nrows)}
+    assert rows[1][1:5] == [["string", b"x"], ["string", b"y"], ["int32", 12], ["nil", None]]
+    assert rows[2][1:3] == [["string", b"inner"], ["nil", None]]
+    assert rows[3][1:3] == [["string", b"dbl"], ["string", b"e"]]
+    for k in (4, 5, 6, 8):
+        assert rows[k][1:5] == [["nil", None]] * 4, k
+    assert 7 not in rows  # "ParseVal error n raw(zz)": an _unparsed item whatever the column's flags
+    # a required nested column that cannot be found makes the line an _unparsed item
+    req = abi.Schema.of([["k", "int32", True], ["s", "utf8", False, "ev.a.b", "", True]])
+    r2 = oracle.json_parse(opts, req, data, msgs)
+    got = sorted(int(r2.rows[i][0][1]) for i in range(r2.nrows))
+    assert got == [1, 2, 3, 7], got   # 4, 5, 6, 8: lookup errors → _unparsed
+    assert oracle.JL_UNRESTATED in {ln[0] for ln in r2.lines}  # line 7: a number at the end of the path (ParseVal of a float64) is not restated
