@@ -20,6 +20,7 @@
 /* dynamic LDS named at file scope (`extern __shared__ T name[];` in HIP): here a fixed 160 KiB per array */
 #define TF_DYNAMIC_LDS(type, name) static thread_local type name[(160 * 1024) / sizeof(type)]
 #define TF_GLOBAL_PTR(T, p) ((T *)(p))
+#define TF_CONST_PTR(T, p) ((const T *)(p))
 #define __builtin_amdgcn_fence(...) ((void)0)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
@@ -118,6 +119,7 @@ inline unsigned long long __ballot(int p) {
   for (int i = 0; i < 64; i++) if (((w.mask >> i) & 1ull) && w.snap[i]) r |= 1ull << i;
   return r;
 }
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return __ballot(p ? 1 : 0); }
 inline int __any(int p) { return __ballot(p) != 0; }
 inline int __all(int p) { hipemu::Wave &w = hipemu::wave_sync(p ? 1ull : 0ull); for (int i = 0; i < 64; i++) if (((w.mask >> i) & 1ull) && !w.snap[i]) return 0; return 1; }
 inline unsigned long long __activemask() { hipemu::Wave &w = hipemu::wave_sync(0); return w.mask; }
@@ -171,6 +173,7 @@ inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {
 inline unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned off, unsigned w) { return w >= 32 ? v >> off : (v >> off) & ((1u << w) - 1u); }
 inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_sync(0); }  // lanes run one after another here: a real exchange point
 inline void __builtin_amdgcn_s_sleep(int) {}
+inline unsigned long long __builtin_amdgcn_s_memtime() { return 0; }
 inline void __builtin_amdgcn_s_barrier() { __syncthreads(); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }

@@ -49,7 +49,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("TFGPU_EXTRA_HIPCC_FLAGS", "").split(), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-8000:]))

@@ -27,6 +27,12 @@
 #define TF_GLOBAL_PTR(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
 #endif
 
+// a pointer to device memory that no kernel writes while this one runs (uploaded descriptor tables), read through the
+// constant address space: a load whose address is wave-uniform becomes an s_load and its result lives in SGPRs
+#ifndef TF_CONST_PTR
+#define TF_CONST_PTR(T, p) ((const __attribute__((address_space(4))) T *)(p))
+#endif
+
 struct tfgpu_dbatch;
 
 namespace tf {

@@ -31,6 +31,15 @@ __device__ __forceinline__ uint32_t class16(const Chunk16 &c, uint32_t pat4) {
   const uint32_t d2 = __builtin_amdgcn_udot4(ne_bytes(c, 2, pat4), W, B, false), d3 = __builtin_amdgcn_udot4(ne_bytes(c, 3, pat4), W, B, false);
   return ~((d0 >> 7) | (d1 >> 3) | (d2 << 1) | (d3 << 5)) & 0xFFFFu;
 }
+// The same mask with the four v_dot4 chained in pairs through the accumulator: weights 1..8 for the first word of a
+// pair and 16..128 for the second give 0x7F * 255 + 128 * (the 8-bit mask of the bytes that differ), so what is left to
+// combine is one shift each way.
+__device__ __forceinline__ uint32_t class16c(const Chunk16 &c, uint32_t pat4) {
+  const uint32_t WL = 0x08040201u, WH = 0x80402010u, B = 0u - 0x7Fu * 255u;
+  const uint32_t a = __builtin_amdgcn_udot4(ne_bytes(c, 1, pat4), WH, __builtin_amdgcn_udot4(ne_bytes(c, 0, pat4), WL, B, false), false);
+  const uint32_t b = __builtin_amdgcn_udot4(ne_bytes(c, 3, pat4), WH, __builtin_amdgcn_udot4(ne_bytes(c, 2, pat4), WL, B, false), false);
+  return ~((a >> 7) | (b << 1)) & 0xFFFFu;
+}
 // does any of the 16 bytes equal the ASCII byte replicated in pat4?
 __device__ __forceinline__ bool any16(const Chunk16 &c, uint32_t pat4) {
   return ((ne_bytes(c, 0, pat4) & ne_bytes(c, 1, pat4) & ne_bytes(c, 2, pat4) & ne_bytes(c, 3, pat4)) & 0x80808080u) != 0x80808080u;
