@@ -33,6 +33,12 @@
 #define TF_CONST_PTR(T, p) ((const __attribute__((address_space(4))) T *)(p))
 #endif
 
+// a value the optimizer must treat as unknown (keeps two neighbouring narrow LDS reads from being merged into one
+// misaligned wide read)
+#ifndef TF_OPAQUE
+#define TF_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 struct tfgpu_dbatch;
 
 namespace tf {

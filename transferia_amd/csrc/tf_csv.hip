@@ -324,8 +324,6 @@ struct CsvParams {
   int32_t has_unmapped;        // some field index < nfields_used feeds no column
   const TCol *tcols;           // columns sorted by (kind, width): neighbouring lanes run one code path
   unsigned long long *dbg_phase;  // TFGPU_CSV_PHASES=1 (profiling only): shader cycles per phase of csv_parse_regular, summed over its workgroups
-  uint8_t *arena;              // the batch's output arena: every column buffer is a view into it
-  const uint32_t *rcols;       // the same columns for csv_parse_regular: {p0 - arena, p1 - arena (4-byte units), field:16 | kind:8 | width:8}
   int32_t null_checks;         // strings_can_be_null || quoted_strings_can_be_null
   uint8_t *err;                // per row tfgpu_rowerr
   int32_t *err_col;
@@ -344,6 +342,8 @@ struct CsvParams {
   uint32_t *gen_n;             // pieces csv_parse_regular hands to the general tile kernel
   uint32_t *gen_tile;          //   (first granule, granules <= CT_T / CSV_GRAN) pairs
   int32_t force_general;       // TFGPU_CSV_GENERAL=1: every tile takes the general kernel (parity cross-check of the two)
+  const struct CsvRun *runs;   // tcols grouped into runs of one (kind, width)
+  int32_t nruns;
 };
 
 __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v) {
@@ -1112,19 +1112,20 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles_general(CsvPara
 // quote, every line's quotes balanced (the quote state a '\n' resets is already "outside"), every line the same
 // number NF >= 2 of fields, everything fits the LDS index.  Then splitString's state machine is a plain prefix
 // parity of the quote characters, field k of line j is ordinal j * NF + k of the index, and nothing per line has to
-// be looked up.  A tile that is anything else is handed, as 28 KiB pieces, to csv_parse_tiles_general (above), which
-// carries the complete state machine; a CELL that is anything but plain still flags its line for csv_parse_listed.
-//
-// Round 3 shape of the cell phase: a LANE IS A LINE, A WAVE TAKES A COLUMN.  The tile is p.tile_bytes long — the host
-// picks it (whole 4 KiB granules) so that a tile holds a little under 64 lines — and every wave walks the columns
-// wv, wv + 8, … of the (kind, width)-sorted list with its 64 lanes on the tile's lines 0..63 (then 64..127, …).  What
-// used to be per cell is now per column and lives in SGPRs (the descriptor is read through the constant address
-// space): the output pointer, the field number, the kind.  What is per lane is loop-invariant: the line's slot in the
-// field index (jj * NF) and its output row.  A cell is: two u16 index reads, three aligned words of text, and for the
-// common shapes — an unsigned canonical decimal of at most eight digits, a plain or empty text cell — one
-// straight-line path chosen per wave by a ballot; signs, long integers, quoted text and dates take the careful path
-// of that column.  VALU cost per 64 cells: ≈ 25 instructions (narrow integers) instead of ≈ 200.
+// be looked up.  A tile that is anything else is handed, whole, to csv_parse_tiles_general (above), which carries
+// the complete state machine; a CELL that is anything but plain still flags its line for csv_parse_listed.
 //   barriers: stage | quote parity per wave | field-end counts per wave | index | cells | epilogue
+//
+// Round 3.  The kernel issues VALU instructions 96 % of its time, so the work of the round went into what it issues
+// (profiles/r05*): (1) the cell loops pick, per slot of 64 cells and with one ballot, a straight-line tier for the shapes
+// almost every cell has — an unsigned canonical decimal of at most five (narrow types) or eight digits, a signed one of
+// up to nineteen through three windows of eight without a branch, an empty / plain / "quoted" text cell — and keep the
+// general code for the rest; (2) the byte classes chain their v_dot4 in pairs through the accumulator; (3) the escape
+// character is looked for where the tile's few quote characters are walked, not in every chunk; (4) the tile's line
+// counts arrive by scalar loads when the kernel starts — the two vector loads the epilogue used to issue waited for
+// every store of the cell phase (≈ 10 000 cycles of a workgroup's 46 000).  A lane-per-line / wave-per-column variant
+// with 44 KiB tiles was built and measured first (commit c60a587): a third fewer VALU instructions in the cells, but two
+// workgroups per CU instead of three, and 0.96 ms against this kernel's 0.75 before the changes above.
 // ---------------------------------------------------------------------------
 // days since 1970-01-01 of a civil date with 0 <= y <= 9999, in 32-bit arithmetic (constant divisors only)
 __device__ __forceinline__ int32_t days_from_civil32(uint32_t y, uint32_t m, uint32_t d) {
@@ -1139,86 +1140,76 @@ __device__ __forceinline__ uint32_t days_in_month32(uint32_t m, uint32_t y) {
   return m == 2 ? 28u + leap : 30u + ((0x15AAu >> m) & 1u);  // bit m set for the 31-day months 1,3,5,7,8,10,12
 }
 
-static constexpr int CR_THREADS = 512;
-static constexpr int CR_SPILL = 4096;                      // look-behind: the first line of a tile starts at most this far in front of it
-#ifndef CR_TMAX_KB
-#define CR_TMAX_KB 44
-#endif
-#ifndef CR_FCAP_N
-#define CR_FCAP_N 6912
-#endif
-static constexpr int CR_TMAX = CR_TMAX_KB * 1024;           // largest tile the host may pick (whole granules)
-static constexpr int CR_BYTES = CR_TMAX + CR_SPILL;        // 48 KiB of text in LDS
-static constexpr int CR_CPT = CR_BYTES / 16 / CR_THREADS;  // 16-byte chunks per thread at the largest tile (blocked)
-static constexpr int CR_FCAP = CR_FCAP_N;                       // field ends indexed per tile (44 KiB of hits text: ≈ 5 800)
-static constexpr int CR_RCAP = 1024;                       // lines per tile
-static constexpr uint32_t CR_KDUMMY = CR_FCAP + 2;         // index slot of the empty field idle lanes read
-static constexpr int CR_LCOLS = 8 * 21;                    // columns whose descriptors fit the waves' lanes, three words each (more: general path)
-static_assert(CR_CPT * 16 * CR_THREADS == CR_BYTES, "tile must divide evenly");
-static_assert(CR_BYTES <= 65536, "positions are 16-bit");
-static_assert(CR_TMAX % CSV_GRAN == 0 && CR_SPILL % 16 == 0, "tiles are whole granules");
-static constexpr int CR_TSTEP = 16 * CR_THREADS;            // tile + look-behind is a whole number of 16-byte chunks per thread: tiles of 28, 36, 44 KiB
-static constexpr int CR_TMIN = 4 * CR_TSTEP - CR_SPILL;      // four chunks per thread put the look-behind window into wave 0's bytes
-static_assert(CR_SPILL <= 64 * 4 * 16 && (CR_TMIN % CSV_GRAN) == 0, "look-behind within wave 0");
+static constexpr int CR_FCAP = 4608;   // field ends the regular kernel indexes per tile (28 KiB of single-digit fields would be 14 000; hits averages 3 800)
+static constexpr int CR_LCOLS = 128;   // columns whose descriptors it stages in LDS
+static constexpr uint32_t CR_KDUMMY = CR_FCAP + 2;  // index slot of the empty field idle lanes read
+struct CsvRun { int32_t kind, width, first, ncols; };  // consecutive tcols of one (kind, width); kind -1: DefaultValue columns (no field)
 
 // what the cell loops of csv_parse_regular share
 struct RegTile {
-  const uint8_t *sb; const uint16_t *fposx; const uint32_t *qmask; const uint16_t *qpre; const uint2 *keeptab; uint8_t *slowf;
-  uint32_t nr, NF; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote;
+  const uint8_t *sb; const uint16_t *fposx; const uint32_t *qmask; const uint16_t *qpre; const uint2 *keeptab; uint8_t *slowf; const uint64_t *colp0, *colp1; const uint16_t *colfield;
+  uint32_t nr, NF, step_q, step_r; float inv_nr; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote; int32_t ablate;
 };
-// what a lane keeps for its line while the wave walks its columns
-struct RegLane { bool act; uint32_t jj, k0, r; };  // has a line that produces a row; line in the tile; index slot of its field 0; output row
-// A column descriptor as the cell loop carries it, in SGPRs.  Three words per column (two offsets into the batch's output
-// arena, field | kind | width): every wave keeps the words of ITS columns one per lane in a VGPR for the whole tile and
-// picks them with v_readlane — no memory latency between two columns (a scalar load per column is waited for at the
-// first LDS use of the column; LDS reads of one address by 64 lanes cost 16+ LDS cycles each: both were measured) — so
-// the NEXT column's index entries can be requested while this column's cells are computed.
-struct RegCol { uint8_t *p0, *p1; uint32_t meta; };  // the two output arrays; meta = field:16 (signed) | kind:8 | width:8
-__device__ __forceinline__ int regcol_field(uint32_t meta) { return (int)(int16_t)(uint16_t)meta; }
-struct RegXY { uint32_t x, y; };  // the field is [x + 1, y)
-__device__ __forceinline__ RegXY regxy_read(const RegTile &t, const RegLane &ln, uint32_t meta) {
-  const int f = regcol_field(meta);
-  const uint32_t kr = (ln.act && f >= 0) ? ln.k0 + (uint32_t)f : CR_KDUMMY;  // < nr * NF <= the index's size (checked before the cells)
-  // two ds_read_u16 on purpose (volatile): merged into one ds_read_b32 at a 2-byte aligned address the pair costs 64 LDS
-  // cycles per wave — byte-addressed LDS reads run at 1/13 of the aligned rate on gfx950 (tools/microbench/valu_rate.hip)
-  const volatile uint16_t *q = t.fposx + kr;
-  return RegXY{q[0], q[1]};
+// one cell of a run: item → (column, line), its output row and its byte range [fs, fend) in the tile
+struct RegCell { bool on; uint32_t col, jj, fs, fend; int32_t r; };
+// A wave's items of one run are it0, it0 + 512, it0 + 1024, … (slots of 64 items dealt round-robin to 8 waves): the first
+// (column offset, line) pair comes from one division, the following ones from adding 512 / nr and 512 % nr with one carry.
+struct ItemIter { uint32_t it, oi, jj; };
+__device__ __forceinline__ ItemIter item_first(const RegTile &t, uint32_t it) {
+  // it / nr through the float reciprocal (rounded down, so the quotient is never too large; it < 2^24): all full-rate ops
+  uint32_t oi = (uint32_t)(__uint2float_rz(it) * t.inv_nr);
+  uint32_t jj = it - __umul24(oi, t.nr);
+  if (jj >= t.nr) { oi++; jj -= t.nr; }
+  return ItemIter{it, oi, jj};
 }
-// store to a column whose base is wave-uniform: scalar base + the lane's 32-bit byte offset
-template <class T> __device__ __forceinline__ void col_store(T *base, uint32_t r, T v) {
-  *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (uint64_t)(r * (uint32_t)sizeof(T))) = v;
+__device__ __forceinline__ void item_next(const RegTile &t, ItemIter &x) {
+  x.it += 512u; x.oi += t.step_q; x.jj += t.step_r;
+  if (x.jj >= t.nr) { x.jj -= t.nr; x.oi++; }
 }
-// a column descriptor through the constant address space: its address is wave-uniform, so the six words arrive by s_load
-template <class T> __device__ __forceinline__ T *global_ptr(const void *p) { return TF_GLOBAL_PTR(T, p); }
-
-// number of quote characters in tile positions [a, b), a <= b: prefix counts per 16-byte chunk + the bitmap
+__device__ __forceinline__ RegCell reg_cell(const RegTile &t, uint32_t first_col, const ItemIter &x, uint32_t items) {
+  RegCell c;
+  c.col = first_col + x.oi; c.jj = x.jj;
+  c.r = t.row0 + (int32_t)x.jj;
+  c.on = x.it < items && c.r >= 0;  // header lines produce nothing
+  // (idle lanes read the index's empty dummy field: the straight-line tiers run without a per-lane branch)
+  const uint32_t kr = c.on ? __umul24(x.jj, t.NF) + (uint32_t)t.colfield[c.col] : CR_KDUMMY;  // < nr * NF <= the index's size (checked before the cells)
+  // two ds_read_u16 on purpose (the second index is hidden from the optimizer): merged into one ds_read_b32 at a 2-byte
+  // aligned address the pair would cost 64 LDS cycles per wave — byte-addressed LDS reads run at 1/13 of the aligned rate
+  // on gfx950 (tools/microbench/valu_rate.hip)
+  uint32_t kr1 = kr + 1;
+  TF_OPAQUE(kr1);
+  c.fs = (uint32_t)t.fposx[kr] + 1; c.fend = t.fposx[kr1];
+  return c;
+}
+// the column buffers are device allocations: say so, or the pointer read back from LDS makes every store a flat_store
+template <class T> __device__ __forceinline__ T *global_ptr(uint64_t p) { return TF_GLOBAL_PTR(T, p); }
+// number of quote characters in tile positions [a, b), a <= b: prefix counts per 32-byte word + the bitmap
 __device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint32_t b) {
-  const uint16_t *qm16 = reinterpret_cast<const uint16_t *>(t.qmask);
-  const uint32_t ca = (uint32_t)t.qpre[a >> 4] + (uint32_t)__popc((uint32_t)qm16[a >> 4] & ((1u << (a & 15)) - 1u));
-  const uint32_t cb = (uint32_t)t.qpre[b >> 4] + (uint32_t)__popc((uint32_t)qm16[b >> 4] & ((1u << (b & 15)) - 1u));
+  const uint32_t ca = (uint32_t)t.qpre[a >> 5] + (uint32_t)__popc(t.qmask[a >> 5] & ((1u << (a & 31)) - 1u));
+  const uint32_t cb = (uint32_t)t.qpre[b >> 5] + (uint32_t)__popc(t.qmask[b >> 5] & ((1u << (b & 31)) - 1u));
   return cb - ca;
 }
-// (The 8-byte window [end - 8, end) of the tile is three aligned LDS words and two v_alignbyte: byte-addressed
-// ds_read_b64 works on gfx950 but runs at 1/13 of the aligned rate — tools/microbench/valu_rate.hip.)
 
-// ---- integers: strconv.ParseInt / ParseUint(cell, 0, bits) for [+-]?(0|[1-9][0-9]*); anything else → per-row path ----
-template <int KIND, int W> __device__ __forceinline__ void col_cells_int(const RegTile &t, const RegCol &tc, const RegLane &ln, const RegXY xy) {
+template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
-  constexpr uint32_t FASTD = W < 4 ? 5u : 8u;  // digits the straight path takes (more cannot fit / need a second window)
-  T *const out = global_ptr<T>(tc.p0);
-  {
-    const bool act = ln.act;
-    const uint32_t jj = ln.jj, r = ln.r;
-    const uint32_t x = xy.x, y = xy.y;
-    const uint32_t n1 = y - x;                                  // the field's length + 1
-    const uint32_t c0 = t.sb[x + 1];
+  constexpr uint32_t FASTD = W < 4 ? 5u : 8u;  // digits the first tier takes (more cannot fit / need a second window)
+  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  if (s0 >= sbase + nslots) return;
+  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
+  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
+    T *const out = global_ptr<T>(t.colp0[c.on ? c.col : (uint32_t)run.first]);
+    const uint32_t n = c.fend - c.fs;
+    const uint32_t c0 = t.sb[c.fs];
     uint32_t wlo, whi;
-    window8(t.sb, y, &wlo, &whi);
-    // straight path: no sign, no leading zero (a lone "0" is fine; a first byte above '9' fails the digit check), 1..FASTD digits
-    const bool fast = (c0 >= '1' || n1 == 2u) && n1 - 2u < FASTD;
-    bool bad = false;
-    if (wave_all(fast || !act)) {
-      const uint2 keep = t.keeptab[n1 - 1u];  // the top n bytes of the window
+    window8(t.sb, c.fend, &wlo, &whi);
+    bool bad;
+    // first tier: no sign, no leading zero (a lone "0" is fine; a first byte above '9' fails the digit check), 1..FASTD digits
+    const bool fast = (c0 >= '1' || n == 1u) && n - 1u < FASTD;
+    if (t.ablate == 31) { if (c.on && fast && wlo == 0x12345678u && whi == 77u) out[c.r] = 0; continue; }  // (profiling: the slot's skeleton and reads only)
+    if (wave_all(fast || !c.on)) {
+      const uint2 keep = t.keeptab[c.on ? n : 0u];  // the top n bytes of the window
       const uint32_t tlo = (wlo ^ 0x30303030u) & keep.x, thi = (whi ^ 0x30303030u) & keep.y;
       bad = (((tlo + 0x76767676u) | tlo | (thi + 0x76767676u) | thi) & 0x80808080u) != 0;
       uint32_t v;
@@ -1226,95 +1217,94 @@ template <int KIND, int W> __device__ __forceinline__ void col_cells_int(const R
         v = __umul24(tlo >> 24, 10000u) + four_dot(thi);
         if constexpr (KIND == CK_INT) bad = bad || v > (1u << (W * 8 - 1)) - 1u; else bad = bad || v > (1u << (W * 8)) - 1u;
       } else v = __umul24(four_dot(tlo), 10000u) + four_dot(thi);  // < 10^8: in range for 32 and 64 bits
-      if (act && !bad) col_store(out, r, (T)v);
+      if (c.on && !bad) out[c.r] = (T)v;
     } else if constexpr (W >= 4) {
       // second tier, straight-line as well: [+-]?(0|[1-9][0-9]*) of up to 19 digits.  The 24 bytes in front of the field's end
       // are three windows of eight; a window's digits are kept by the same table (none of them: the window counts as zero).
-      const uint32_t n = n1 - 1u;
       const bool neg = c0 == '-', sgn = neg || c0 == '+';
       const uint32_t nd = n - (sgn ? 1u : 0u);  // digits
-      const uint32_t fd = sgn ? (uint32_t)t.sb[x + 2] : c0;  // the first of them
+      const uint32_t fd = sgn ? (uint32_t)t.sb[c.fs + 1] : c0;  // the first of them
       bool ok = nd - 1u < 19u && !(nd > 1 && fd == '0');
       if constexpr (KIND == CK_UINT && W == 8) ok = ok && !sgn;  // ParseUint takes no sign
+      const uint32_t y = c.fend;
       const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (int)((y - 24u) & ~3u));
       const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
       const uint32_t w2lo = __builtin_amdgcn_alignbyte(d1, d0, y), w2hi = __builtin_amdgcn_alignbyte(d2, d1, y);  // [y - 24, y - 16)
       const uint32_t w1lo = __builtin_amdgcn_alignbyte(d3, d2, y), w1hi = __builtin_amdgcn_alignbyte(d4, d3, y);  // [y - 16, y - 8); [y - 8, y) is wlo, whi
-      const uint32_t n0 = min(nd, 8u), n1d = min(nd - n0, 8u), n2d = min(nd - n0 - n1d, 8u);
+      const uint32_t ndc = min(nd, 24u), n0 = min(ndc, 8u), n1d = min(ndc - n0, 8u), n2d = min(ndc - n0 - n1d, 8u);
       const uint2 k0 = t.keeptab[n0], k1 = t.keeptab[n1d], k2 = t.keeptab[n2d];
       const uint32_t a0 = (wlo ^ 0x30303030u) & k0.x, b0 = (whi ^ 0x30303030u) & k0.y;
       const uint32_t a1 = (w1lo ^ 0x30303030u) & k1.x, b1 = (w1hi ^ 0x30303030u) & k1.y;
       const uint32_t a2 = (w2lo ^ 0x30303030u) & k2.x, b2 = (w2hi ^ 0x30303030u) & k2.y;
       const uint32_t nondigit = ((a0 + 0x76767676u) | a0 | (b0 + 0x76767676u) | b0 | (a1 + 0x76767676u) | a1 | (b1 + 0x76767676u) | b1 |
                                  (a2 + 0x76767676u) | a2 | (b2 + 0x76767676u) | b2) & 0x80808080u;
-      ok = ok && nondigit == 0 && nd <= 19u;
+      ok = ok && nondigit == 0;
       const uint32_t g0v = __umul24(four_dot(a0), 10000u) + four_dot(b0), g1v = __umul24(four_dot(a1), 10000u) + four_dot(b1);
-      const uint32_t g2v = __umul24(four_dot(a2), 10000u) + four_dot(b2);  // < 10^8 each; g2v < 1000
+      const uint32_t g2v = __umul24(four_dot(a2), 10000u) + four_dot(b2);  // < 10^8 each; nd <= 19: g2v < 1000
       const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;  // < 10^19 < 2^64
       if constexpr (KIND == CK_INT) ok = ok && v <= (neg ? (1ull << (W * 8 - 1)) : (1ull << (W * 8 - 1)) - 1);
       else ok = ok && !(neg && v != 0) && (W == 8 || v <= (1ull << (W * 8 % 64)) - 1);
-      if (act && ok) col_store(out, r, (T)(neg ? (int64_t)(0 - v) : (int64_t)v));
+      if (c.on && ok) out[c.r] = (T)(neg ? (int64_t)(0 - v) : (int64_t)v);
       bad = !ok;
-    } else if (act) {
+    } else {
       // the narrow types' rare shapes (a sign, a leading zero, too many digits)
-      const uint32_t n = n1 - 1u;
       const bool neg = c0 == '-', sgn = neg || c0 == '+';
       const uint32_t nd = n - (sgn ? 1u : 0u);  // digits
-      bool ok = nd - 1u < 19u && !(nd > 1 && t.sb[y - nd] == '0');
+      bool ok = nd - 1u < 19u && !(nd > 1 && t.sb[c.fend - min(nd, 24u)] == '0');
       uint32_t g0v = 0;
       ok = digits8_window<true>(wlo, whi, min(nd, 8u), &g0v) && ok;
       // six digits and more are out of range whatever they are (no leading zeros): the narrow digit sum reads five
       if constexpr (KIND == CK_INT) ok = ok && nd <= 5 && g0v <= (1u << (W * 8 - 1)) - (neg ? 0u : 1u);
       else ok = ok && nd <= 5 && g0v <= (1u << (W * 8)) - 1u && !(neg && g0v != 0);
-      if (ok) col_store(out, r, (T)(neg ? -(int32_t)g0v : (int32_t)g0v));
+      if (c.on && ok) out[c.r] = (T)(neg ? -(int32_t)g0v : (int32_t)g0v);
       bad = !ok;
     }
-    if (act && bad) t.slowf[jj] = 1;
+    if (c.on && bad) t.slowf[c.jj] = 1;
   }
 }
 
-// ---- text: sanitizeElement (reader.go:273-305) for a cell with nothing to trim — plain at both ends, or enclosed in
-//      quotes — recorded as (length, position in the source | doubled quotes inside); the bytes stay where they are ----
-__device__ __forceinline__ void col_cells_str(const RegTile &t, const RegCol &tc, const RegLane &ln, const RegXY xy) {
-  uint32_t *const lens = global_ptr<uint32_t>(tc.p0), *const fstart = global_ptr<uint32_t>(tc.p1);
-  do {
-    const bool act = ln.act;
-    const uint32_t jj = ln.jj, r = ln.r;
-    const uint32_t x = xy.x, y = xy.y;
-    const uint32_t n1 = y - x;
-    const uint32_t c_first = t.sb[x + 1], c_last = t.sb[y - 1];
-    const uint32_t qn = quotes_in(t, x + 1, y);  // quote characters in the field
+__device__ __forceinline__ void reg_cells_str(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
+  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  if (s0 >= sbase + nslots) return;
+  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
+  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
+    const uint32_t col = c.on ? c.col : (uint32_t)run.first;
+    uint32_t *const lens = global_ptr<uint32_t>(t.colp0[col]), *const fstart = global_ptr<uint32_t>(t.colp1[col]);
+    const uint32_t n = c.fend - c.fs;
+    const uint32_t c_first = t.sb[c.fs], c_last = t.sb[c.fend - 1];
+    const uint32_t qn = quotes_in(t, c.fs, c.fend);  // quote characters in the field
     // straight path: empty; no quote inside and printable ASCII (not a space, not DEL) at both ends; or enclosed in the
     // only two quotes it holds ("…": unquote, nothing to collapse)
     const bool plain = qn == 0 && c_first - 0x21u < 0x5Eu && c_last - 0x21u < 0x5Eu;
     const bool quoted = qn == 2 && c_first == t.quote && c_last == t.quote;  // (n >= 2 then: two quote characters are in it)
-    if (wave_all(n1 == 1u || plain || quoted || !act)) {
+    if (wave_all(n == 0 || plain || quoted || !c.on)) {
       const uint32_t q1 = quoted ? 1u : 0u;
-      if (act) { col_store(lens, r, n1 - 1u - 2u * q1); col_store(fstart, r, t.g0 + x + 1u + q1); }
+      if (c.on) { lens[c.r] = n - 2u * q1; fstart[c.r] = t.g0 + c.fs + q1; }
       continue;
     }
-    if (!act) continue;
-    const uint32_t fs = x + 1u, fend = y, n = n1 - 1u;
-    if (n == 0) { col_store(lens, r, 0u); col_store(fstart, r, t.g0 + fs); continue; }
+    if (!c.on) continue;
+    if (n == 0) { lens[c.r] = 0; fstart[c.r] = t.g0 + c.fs; continue; }
     bool done = false;
-    {
+    if (n <= 0x7FFFu) {
       // nothing to trim: either enclosed in quotes ("…": unquote) or plain at both ends
-      uint32_t a = fs, b = fend;
+      uint32_t a = c.fs, b = c.fend;
       bool ok = false;
       if (c_first == t.quote && c_last == t.quote && n >= 2) { a++; b--; ok = true; }
-      else ok = c_first != t.quote && c_last != t.quote && starts_plain(t.sb, fs, fend, c_first, t.quote) && ends_plain(t.sb, fs, fend, c_last, t.quote);
+      else ok = c_first != t.quote && c_last != t.quote && starts_plain(t.sb, c.fs, c.fend, c_first, t.quote) && ends_plain(t.sb, c.fs, c.fend, c_last, t.quote);
       if (ok) {
-        const uint32_t npairs = (qn && any_quote(t.qmask, a, b)) ? count_quote_pairs(t.qmask, a, b) : 0u;
+        const uint32_t npairs = quotes_in(t, a, b) ? count_quote_pairs(t.qmask, a, b) : 0u;
         if (!(npairs && !t.double_quote)) {  // errDoubleQuotesDisabled: per-row path
-          col_store(lens, r, (b - a) - npairs);
-          col_store(fstart, r, (t.g0 + a) | (npairs ? 0x80000000u : 0u));
+          lens[c.r] = (b - a) - npairs;
+          fstart[c.r] = (t.g0 + a) | (npairs ? 0x80000000u : 0u);
           if (npairs) fstart[-1] = 1u;  // the column holds cells that are not a plain byte range
           done = true;
         }
       }
     }
-    if (!done) t.slowf[jj] = 1;
-  } while (false);
+    if (!done) t.slowf[c.jj] = 1;
+  }
 }
 
 // 2006-01-02 | 2006-01-02[ T]15:04:05 (cast.StringToDate layouts); a timestamp column also takes plain decimal
@@ -1324,26 +1314,29 @@ __device__ __forceinline__ uint32_t dig2(uint32_t w, int byte, uint32_t *bad) { 
   *bad |= (a > 9u) | (b > 9u);
   return a * 10 + b;
 }
-template <int KIND> __device__ __forceinline__ void col_cells_time(const RegTile &t, const RegCol &tc, const RegLane &ln, const RegXY xy) {
-  int64_t *const sec = global_ptr<int64_t>(tc.p0); int32_t *const nanos = global_ptr<int32_t>(tc.p1);
-  do {
-    if (!ln.act) continue;
-    const uint32_t jj = ln.jj, r = ln.r;
-    const uint32_t fs = xy.x + 1u, fend = xy.y;
-    const uint32_t n = fend - fs;
+template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
+  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  if (s0 >= sbase + nslots) return;
+  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
+  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
+    if (!c.on) continue;
+    int64_t *const sec = global_ptr<int64_t>(t.colp0[c.col]); int32_t *const nanos = global_ptr<int32_t>(t.colp1[c.col]);
+    const uint32_t n = c.fend - c.fs;
     bool done = false;
-    if ((n == 10 || n == 19) && t.sb[fs + 4] == '-') {
+    if ((n == 10 || n == 19) && t.sb[c.fs + 4] == '-') {
       // the 20 bytes from the field's start as five words: "2006" "-01-" "02 1" "5:04" ":05."
-      const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (fs & ~3u));
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (c.fs & ~3u));
       const uint32_t x0 = w[0], x1 = w[1], x2 = w[2], x3 = w[3], x4 = w[4], x5 = w[5];
-      const uint32_t w0 = __builtin_amdgcn_alignbyte(x1, x0, fs), w1 = __builtin_amdgcn_alignbyte(x2, x1, fs), w2 = __builtin_amdgcn_alignbyte(x3, x2, fs);
+      const uint32_t w0 = __builtin_amdgcn_alignbyte(x1, x0, c.fs), w1 = __builtin_amdgcn_alignbyte(x2, x1, c.fs), w2 = __builtin_amdgcn_alignbyte(x3, x2, c.fs);
       uint32_t bad = 0;
       const uint32_t y = dig2(w0, 0, &bad) * 100 + dig2(w0, 2, &bad);
       const uint32_t mo = dig2(w1, 1, &bad), d = dig2(w2, 0, &bad);
       bad |= (w1 & 0xFF0000FFu) != 0x2D00002Du;  // '-' .. '-'
       uint32_t h = 0, mi = 0, se = 0;
       if (n == 19) {
-        const uint32_t w3 = __builtin_amdgcn_alignbyte(x4, x3, fs), w4 = __builtin_amdgcn_alignbyte(x5, x4, fs);
+        const uint32_t w3 = __builtin_amdgcn_alignbyte(x4, x3, c.fs), w4 = __builtin_amdgcn_alignbyte(x5, x4, c.fs);
         const uint32_t sep = (w2 >> 16) & 0xFFu;
         bad |= !(sep == ' ' || sep == 'T') | (((w3 >> 8) & 0xFFu) != ':') | ((w4 & 0xFFu) != ':');
         h = (((w2 >> 24) & 0xFFu) - '0') * 10 + ((w3 & 0xFFu) - '0');
@@ -1352,161 +1345,136 @@ template <int KIND> __device__ __forceinline__ void col_cells_time(const RegTile
       }
       const bool ok = !bad && mo >= 1 && mo <= 12 && d >= 1 && d <= days_in_month32(mo, y) && h <= 23 && mi <= 59 && se <= 59;
       if (ok) {
-        sec[r] = (int64_t)days_from_civil32(y, mo, d) * 86400 + (int64_t)(h * 3600 + mi * 60 + se);
-        nanos[r] = 0;
+        sec[c.r] = (int64_t)days_from_civil32(y, mo, d) * 86400 + (int64_t)(h * 3600 + mi * 60 + se);
+        nanos[c.r] = 0;
         done = true;
       }
     } else if (KIND == CK_TIMESTAMP && n - 1u < 19u) {
       // ParseInt(s, 10, 64): [+-]?digits, leading zeros are fine in base 10
-      const uint32_t c0 = t.sb[fs];
+      const uint32_t c0 = t.sb[c.fs];
       const bool neg = c0 == '-', sgn = neg || c0 == '+';
       const uint32_t nd = n - (sgn ? 1u : 0u);
       uint32_t g0v = 0, g1v = 0, g2v = 0;
       bool ok = nd - 1u < 18u;
-      ok = digits8_end(t.sb, fend, min(nd, 8u), &g0v) && ok;
-      if (nd > 8) ok = digits8_end(t.sb, fend - 8, min(nd - 8, 8u), &g1v) && ok;
-      if (nd > 16) ok = digits8_end(t.sb, fend - 16, nd - 16, &g2v) && ok;
+      ok = digits8_end(t.sb, c.fend, min(nd, 8u), &g0v) && ok;
+      if (nd > 8) ok = digits8_end(t.sb, c.fend - 8, min(nd - 8, 8u), &g1v) && ok;
+      if (nd > 16) ok = digits8_end(t.sb, c.fend - 16, nd - 16, &g2v) && ok;
       if (ok) {
         const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;
-        sec[r] = neg ? -(int64_t)v : (int64_t)v; nanos[r] = 0; done = true;
+        sec[c.r] = neg ? -(int64_t)v : (int64_t)v; nanos[c.r] = 0; done = true;
       }
     }
-    if (!done) t.slowf[jj] = 1;
-  } while (false);
-}
-
-// a tile's bytes, coalesced 16 B/lane
-__device__ __forceinline__ void reg_tile_fetch(const CsvParams &p, const int64_t tile, uint4 (&R)[CR_CPT]) {
-  const uint32_t nbytes = p.tile_bytes + CR_SPILL, cpt = nbytes / (16 * CR_THREADS);
-  const int64_t g0 = tile * (int64_t)p.tile_bytes - CR_SPILL;
-  const bool valid = tile >= 0 && tile < p.ntiles;
-  if (valid && g0 >= 0 && (uint64_t)(g0 + nbytes) <= p.len) {
-    const uint8_t *src = p.data + g0;
-#pragma unroll
-    for (int it = 0; it < CR_CPT; it++)
-      if ((uint32_t)it < cpt) R[it] = *reinterpret_cast<const uint4 *>(src + (size_t)(it * CR_THREADS + threadIdx.x) * 16);
-  } else {
-#pragma unroll
-    for (int it = 0; it < CR_CPT; it++) {
-      const int64_t gp = g0 + (int64_t)(it * CR_THREADS + threadIdx.x) * 16;
-      R[it] = make_uint4(0, 0, 0, 0);
-      if (valid && (uint32_t)it < cpt && gp >= 0 && (uint64_t)gp < p.len) R[it] = *reinterpret_cast<const uint4 *>(p.data + gp);  // buffer is zero-padded past len
-    }
+    if (!done) t.slowf[c.jj] = 1;
   }
 }
 
-// One tile per workgroup.  (Persistent workgroups that walk several tiles, with the next tile's bytes requested a tile
-// ahead — into registers, or just touched into L2 — were measured and lost: 24 more VGPRs spill, and workgroups that all
-// start together stay in step, so the two on a CU are in the same phase instead of one loading while the other computes.)
-__device__ __forceinline__ void parse_tile_regular(const CsvParams &p, const int64_t tile, const uint32_t vtab) {
-  __shared__ __attribute__((aligned(16))) uint8_t sbuf[32 + CR_BYTES + 48];  // 32 bytes in front: the 24-byte window of a cell that ends within the tile's first bytes
-  __shared__ uint16_t fposx[CR_FCAP + 4];    // [k + 1] = end of field k; [0] = first line's start - 1; [CR_KDUMMY], [CR_KDUMMY + 1]: an empty field for the lanes without a line
-  __shared__ uint32_t qmask[CR_BYTES / 32];  // bitmap of quote characters
-  __shared__ uint32_t nlbits[(CR_FCAP + 32) / 32];  // bit k + 1: field k ends its line
-  __shared__ uint16_t qpre[CR_BYTES / 16 + 2];      // quote characters in front of each 16-byte chunk
+__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) {
+  static_assert(CT_SPILL == 64 * CT_CPT * 16, "the look-behind window is exactly wave 0's bytes");
+  __shared__ __attribute__((aligned(16))) uint8_t sbuf[32 + CT_BYTES + 48];  // 32 bytes in front: the 24-byte window of a cell that ends within the tile's first bytes
+  __shared__ uint16_t fposx[CR_FCAP + 4];    // [k + 1] = end of field k; [0] = first line's start - 1; [CR_KDUMMY], [CR_KDUMMY + 1]: an empty field for idle lanes
   __shared__ uint2 keeptab[9];               // [n]: mask of the top n bytes of an 8-byte window
-  __shared__ uint8_t slowf[CR_RCAP];         // line needs the per-row path
-  __shared__ uint32_t wpar[CR_THREADS / 64];
-  __shared__ uint32_t wqc[CR_THREADS / 64];
-  __shared__ uint32_t wcnt[CR_THREADS / 64];
+  __shared__ uint32_t qmask[CT_BYTES / 32];  // bitmap of quote characters
+  __shared__ uint32_t nlbits[(CR_FCAP + 32) / 32];  // bit k + 1: field k ends its line
+  __shared__ uint16_t qpre[CT_BYTES / 32 + 2];      // quote characters in front of each 32-byte word
+  __shared__ uint32_t wqc[CT_THREADS / 64];
+  __shared__ uint8_t slowf[CT_RCAP];         // line needs the per-row path
+  __shared__ uint64_t colp0[CR_LCOLS], colp1[CR_LCOLS];
+  __shared__ uint16_t colfield[CR_LCOLS];
+  __shared__ uint32_t wpar[CT_THREADS / 64];
+  __shared__ uint32_t wcnt[CT_THREADS / 64];
   __shared__ uint32_t misc[4];               // 0: first line's start, 1: tile is not regular, 2: NF
   uint8_t *const sb = sbuf + 32;
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const CsvOpts &o = p.o;
-  const uint32_t T = p.tile_bytes, gpt = T / CSV_GRAN;
-  const uint32_t nbytes = T + CR_SPILL, cpt = nbytes / (16 * CR_THREADS);  // staged bytes; 16-byte chunks per thread (blocked): 4, 5 or 6
-  unsigned long long tstamp = p.dbg_phase ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull;
-  auto phase = [&](int k) {  // profiling only: thread 0 adds the cycles since the previous stamp to slot k
-    if (p.dbg_phase && tid == 0) { const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memtime(); atomicAdd(p.dbg_phase + k, now - tstamp); tstamp = now; }
-  };
-
-  // ---- stage: coalesced 16 B/lane (L2 hits: the tile was touched while the one before it was parsed) ----
-  {
-    uint4 R[CR_CPT];
-    reg_tile_fetch(p, tile, R);
-#pragma unroll
-    for (int it = 0; it < CR_CPT; it++)
-      if ((uint32_t)it < cpt) *reinterpret_cast<uint4 *>(sb + (size_t)(it * CR_THREADS + tid) * 16) = R[it];
-  }
-  if (tid < 4) misc[tid] = 0;
-  if (tid < 12) reinterpret_cast<uint32_t *>(sb + nbytes)[tid] = 0;  // the bytes past the tile that cell windows may touch
-  if (tid < 8) reinterpret_cast<uint32_t *>(sbuf)[tid] = 0;          // … and those in front of it
-  if (tid == 16) { fposx[CR_KDUMMY] = 8; fposx[CR_KDUMMY + 1] = 9; }
-  if (tid < 9) { const uint64_t k = tid ? ~0ull << (8 * (8 - tid)) : 0ull; keeptab[tid] = make_uint2((uint32_t)k, (uint32_t)(k >> 32)); }
-  for (int i = tid; i < (CR_FCAP + 32) / 32; i += CR_THREADS) nlbits[i] = 0;
-  __syncthreads();
-  phase(0);
-
+  // XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
+  const int64_t per_xcd = (p.ntiles + 7) / 8;
+  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (tile >= p.ntiles) return;
-  const int64_t gr0 = tile * gpt, gr1 = min(gr0 + (int64_t)gpt, p.ngran);
-  const auto *gpre = TF_CONST_PTR(uint32_t, p.gran_pre);  // wave-uniform indices: scalar loads, which the bytes in flight for the next tile do not have to be waited for
+  // the tile's lines from the exclusive scan of the newline counts per 4 KiB granule: wave-uniform addresses, read by the
+  // scalar unit now — a vector load at the end of the kernel would wait for every store of the cell phase
+  constexpr int64_t GPT = CT_T / CSV_GRAN;
+  const int64_t gr0 = tile * GPT, gr1 = min(gr0 + GPT, p.ngran);
+  const auto *gpre = TF_CONST_PTR(uint32_t, p.gran_pre);
   const uint32_t line0 = gpre[gr0], line1 = gpre[gr1], lines_all = gpre[p.ngran];
   const uint32_t nlines = line1 - line0;
   if (nlines == 0) return;  // no line ends here (inside a very long line)
-  const int64_t g0 = tile * (int64_t)T - CR_SPILL;  // absolute offset of sb[0]
-  // hand the tile to the general kernel, in pieces of at most CT_T bytes (whole granules)
-  auto give_up = [&]() {
-    if (tid == 0) {
-      for (int64_t g = gr0; g < gr1; g += CT_T / CSV_GRAN) {
-        const uint32_t slot = atomicAdd(p.gen_n, 1u);
-        p.gen_tile[2 * slot] = (uint32_t)g; p.gen_tile[2 * slot + 1] = (uint32_t)min((int64_t)(CT_T / CSV_GRAN), gr1 - g);
-      }
-    }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const CsvOpts &o = p.o;
+  const int64_t g0 = tile * CT_T - CT_SPILL;  // absolute offset of sb[0]
+  auto give_up = [&]() { if (tid == 0) { const uint32_t slot = atomicAdd(p.gen_n, 1u); p.gen_tile[2 * slot] = (uint32_t)gr0; p.gen_tile[2 * slot + 1] = (uint32_t)(gr1 - gr0); } };
+  unsigned long long tstamp = p.dbg_phase ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull;
+  auto phase = [&](int k) {  // TFGPU_CSV_PHASES=1, profiling only: thread 0 adds the cycles since the previous stamp to slot k
+    if (p.dbg_phase && tid == 0) { const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memtime(); atomicAdd(p.dbg_phase + k, now - tstamp); tstamp = now; }
   };
-  if (p.force_general || nlines > (uint32_t)CR_RCAP || p.ncols > CR_LCOLS) { give_up(); return; }
-  if (p.ablate == 1) return;  // (TFGPU_CSV_ABLATE, profiling only: leave after phase n; results are not valid)
+  if (p.force_general || nlines > (uint32_t)CT_RCAP || p.ncols > CR_LCOLS) { give_up(); return; }
 
-  // ---- pass 1: per-byte classes of this thread's bytes, as 16-bit masks per 16-byte chunk.  (An escape character in
-  //      front of a quote — the one thing the plain parity cannot express — is looked for where the quotes are walked.) ----
-  const uint32_t base_chunk = tid * cpt;
-  uint32_t qm[CR_CPT], dm[CR_CPT], nl[CR_CPT];
-  uint32_t bad = 0;
-  {
-    const uint32_t q4 = o.quote * 0x01010101u, d4 = o.delim * 0x01010101u;
+  // ---- stage: coalesced 16 B/lane ----
+  if (g0 >= 0 && (uint64_t)(g0 + CT_BYTES) <= p.len) {
+    const uint8_t *src = p.data + g0;
 #pragma unroll
-    for (int q = 0; q < CR_CPT; q++) {
-      qm[q] = 0; dm[q] = 0; nl[q] = 0;
-      if ((uint32_t)q < cpt) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(sb + (base_chunk + q) * 16);
-        const Chunk16 ck = chunk16(v);
-        qm[q] = class16c(ck, q4); dm[q] = class16c(ck, d4); nl[q] = class16c(ck, 0x0A0A0A0Au);
-        reinterpret_cast<uint16_t *>(qmask)[base_chunk + q] = (uint16_t)qm[q];
-      }
+    for (int it = 0; it < CT_CPT; it++) {
+      const int chunk = it * CT_THREADS + tid;
+      *reinterpret_cast<uint4 *>(sb + chunk * 16) = *reinterpret_cast<const uint4 *>(src + chunk * 16);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < CT_CPT; it++) {
+      const int chunk = it * CT_THREADS + tid;
+      const int64_t gp = g0 + (int64_t)chunk * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gp >= 0 && (uint64_t)gp < p.len) v = *reinterpret_cast<const uint4 *>(p.data + gp);  // buffer is zero-padded past len
+      *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
     }
   }
-  uint32_t qc = 0;  // all of this thread's quote characters (also those in front of the first line: the counts are only ever subtracted)
+  for (int i = tid; i < p.ncols; i += CT_THREADS) { const TCol tc = p.tcols[i]; colp0[i] = (uint64_t)tc.p0; colp1[i] = (uint64_t)tc.p1; colfield[i] = (uint16_t)tc.field; }
+  if (tid < 4) misc[tid] = 0;
+  if (tid < 12) reinterpret_cast<uint32_t *>(sb + CT_BYTES)[tid] = 0;  // the bytes past the tile that cell windows may touch
+  if (tid >= 64 && tid < 72) reinterpret_cast<uint32_t *>(sbuf)[tid - 64] = 0;  // … and those in front of it
+  if (tid == 80) { fposx[CR_KDUMMY] = 8; fposx[CR_KDUMMY + 1] = 9; }
+  if (tid >= 96 && tid < 105) { const int n8 = tid - 96; const uint64_t k = n8 ? ~0ull << (8 * (8 - n8)) : 0ull; keeptab[n8] = make_uint2((uint32_t)k, (uint32_t)(k >> 32)); }
+  for (int i = tid; i < (CR_FCAP + 32) / 32; i += CT_THREADS) nlbits[i] = 0;
+  __syncthreads();
+  phase(0);
+  if (p.ablate == 1) return;  // (TFGPU_CSV_ABLATE, profiling only: leave after phase n; results are not valid)
+
+  // ---- pass 1: per-byte classes of this thread's 64 bytes, as 16-bit masks per 16-byte chunk ----
+  const int base_chunk = tid * CT_CPT;
+  uint32_t qm[CT_CPT], dm[CT_CPT], nl[CT_CPT];
+  uint32_t bad = 0;
+  {
+    // (An escape character in front of a quote — the one thing the plain parity cannot express — is looked for where the
+    //  tile's quote characters are walked, in the index sweep.)
+    const uint32_t q4 = o.quote * 0x01010101u, d4 = o.delim * 0x01010101u;
 #pragma unroll
-  for (int q = 0; q < CR_CPT; q++) qc += (uint32_t)__popc(qm[q]);
-  const uint32_t qinc = wave_scan_add(qc);
-  if (lane == 63) wqc[wv] = qinc;
+    for (int q = 0; q < CT_CPT; q++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sb + (base_chunk + q) * 16);
+      const Chunk16 ck = chunk16(v);
+      qm[q] = class16c(ck, q4); dm[q] = class16c(ck, d4); nl[q] = class16c(ck, 0x0A0A0A0Au);
+      reinterpret_cast<uint16_t *>(qmask)[base_chunk + q] = (uint16_t)qm[q];
+    }
+  }
   if (wv == 0) {
-    // the first line this tile owns starts behind the last '\n' of the look-behind window [0, CR_SPILL), which lies in
-    // wave 0's bytes (cpt >= 4); what precedes it belongs to the tile before (the highest lane holding such a '\n'
-    // holds the last one)
+    // the first line this tile owns starts behind the last '\n' of the look-behind window; what precedes it belongs to
+    // the tile before (the highest lane holding a '\n' holds the last one)
     int mx = -1;
 #pragma unroll
-    for (int q = 0; q < CR_CPT; q++) {
-      const uint32_t cpos = (base_chunk + q) * 16;
-      if (nl[q] && cpos < (uint32_t)CR_SPILL) mx = (int)cpos + 31 - __clz((int)nl[q]);
-    }
+    for (int q = 0; q < CT_CPT; q++) if (nl[q]) mx = (base_chunk + q) * 16 + 31 - __clz((int)nl[q]);
     const uint64_t holders = __ballot(mx >= 0);
-    int frs0 = 0;
-    if (holders) frs0 = __shfl(mx, 63 - __clzll((long long)holders), 64) + 1;
-    else if (g0 <= 0) frs0 = (int)(-g0);  // the buffer starts inside the window: line 0 starts at absolute 0
-    else bad |= 1u;                       // the first line started before the window: general path
+    int frs = 0;
+    if (holders) frs = __shfl(mx, 63 - __clzll((long long)holders), 64) + 1;
+    else if (g0 <= 0) frs = (int)(-g0);  // the buffer starts inside the window: line 0 starts at absolute 0
+    else bad |= 1u;                      // the first line started before the window: general path
 #pragma unroll
-    for (int q = 0; q < CR_CPT; q++) {
-      const int cpos = (int)(base_chunk + q) * 16;
+    for (int q = 0; q < CT_CPT; q++) {
+      const int cpos = (base_chunk + q) * 16;
       uint32_t keep = 0xFFFFu;
-      if (cpos + 16 <= frs0) keep = 0; else if (cpos < frs0) keep = 0xFFFFu & ~((1u << (frs0 - cpos)) - 1u);
+      if (cpos + 16 <= frs) keep = 0; else if (cpos < frs) keep = 0xFFFFu & ~((1u << (frs - cpos)) - 1u);
       qm[q] &= keep; dm[q] &= keep; nl[q] &= keep;
     }
-    if (lane == 0) misc[0] = (uint32_t)frs0;
+    if (lane == 0) misc[0] = (uint32_t)frs;
   }
   uint32_t par = 0;
 #pragma unroll
-  for (int q = 0; q < CR_CPT; q++) par ^= (uint32_t)__popc(qm[q]);
+  for (int q = 0; q < CT_CPT; q++) par ^= (uint32_t)__popc(qm[q]);
   par &= 1u;
   const uint64_t pb = __ballot(par != 0);
   const uint32_t par_in = lanes_below(pb) & 1u;  // parity of the quotes of this wave's bytes before this thread's
@@ -1515,24 +1483,15 @@ __device__ __forceinline__ void parse_tile_regular(const CsvParams &p, const int
   __syncthreads();
   phase(1);
   if (p.ablate == 2) { if (par_in == 77u + qm[0] + dm[1] + nl[2] + qm[3] + dm[0] + nl[0]) p.err[0] = 1; return; }
-  const uint32_t frs = misc[0];
 
   // ---- pass 2: field ends = delimiters outside quotes, and every '\n' ----
   uint32_t s_in = par_in;
   for (int i = 0; i < wv; i++) s_in ^= wpar[i];
-  {
-    uint32_t qb = qinc - qc;
-    for (int i = 0; i < wv; i++) qb += wqc[i];
-#pragma unroll
-    for (int q = 0; q < CR_CPT; q++)
-      if ((uint32_t)q < cpt) { qpre[base_chunk + q] = (uint16_t)qb; qb += (uint32_t)__popc((uint32_t)reinterpret_cast<const uint16_t *>(qmask)[base_chunk + q]); }
-    if (tid == CR_THREADS - 1) qpre[base_chunk + cpt] = (uint16_t)qb;
-  }
-  uint32_t fe[CR_CPT];
+  uint32_t fe[CT_CPT];
   uint32_t cnt = 0;
   bad = 0;
 #pragma unroll
-  for (int q = 0; q < CR_CPT; q++) {
+  for (int q = 0; q < CT_CPT; q++) {
     uint32_t px = qm[q];  // bit i = parity of the quotes in bytes [0, i]
     px ^= px << 1; px ^= px << 2; px ^= px << 4; px ^= px << 8;
     const uint32_t inq = (px ^ (s_in ? 0xFFFFu : 0u)) & 0xFFFFu;
@@ -1542,116 +1501,117 @@ __device__ __forceinline__ void parse_tile_regular(const CsvParams &p, const int
     cnt += (uint32_t)__popc(fe[q]) | ((uint32_t)__popc(nl[q]) << 16);
   }
   const uint32_t cinc = wave_scan_add(cnt);
-  if (lane == 63) wcnt[wv] = cinc;
+  const uint32_t qlo = (uint32_t)__popc(qmask[tid * 2]), qc = qlo + (uint32_t)__popc(qmask[tid * 2 + 1]);  // (all of the tile's quotes, also those in front of the first line)
+  const uint32_t qinc = wave_scan_add(qc);
+  if (lane == 63) { wcnt[wv] = cinc; wqc[wv] = qinc; }
   if (__any(bad != 0) && lane == 0) misc[1] = 1u;
   __syncthreads();
   phase(2);
 
   uint32_t cpre = 0, ctot = 0;
-  for (int i = 0; i < CR_THREADS / 64; i++) { const uint32_t x = wcnt[i]; if (i < wv) cpre += x; ctot += x; }
+  for (int i = 0; i < CT_THREADS / 64; i++) { const uint32_t x = wcnt[i]; if (i < wv) cpre += x; ctot += x; }
   const uint32_t nfe = ctot & 0xFFFFu, nr = ctot >> 16;
   if (misc[1] || nfe > (uint32_t)CR_FCAP || nr != nlines) { give_up(); return; }  // uniform: LDS flags were written before the barrier
+  const uint32_t frs = misc[0];
   if (p.ablate == 3) { if (fe[0] + fe[1] + fe[2] + fe[3] == 0xFFFFFFFFu) p.err[0] = 1; return; }
 
   // ---- index: one sweep over this thread's field ends, two chunks (32 bytes) per loop ----
   {
     const uint32_t cex = cpre + cinc - cnt;
-    uint32_t k = cex & 0xFFFFu, jl = cex >> 16;
+    uint32_t k = cex & 0xFFFFu;
 #pragma unroll
-    for (int h = 0; h < CR_CPT; h += 2) {
+    for (int h = 0; h < CT_CPT; h += 2) {
       uint32_t m = fe[h] | (fe[h + 1] << 16);
-      const uint32_t nlh = nl[h] | (nl[h + 1] << 16), qmh = qm[h] | (qm[h + 1] << 16);
-      const uint32_t cpos = (base_chunk + h) * 16;
+      const uint32_t nlh = nl[h] | (nl[h + 1] << 16);
+      const uint32_t cpos = (uint32_t)(base_chunk + h) * 16;
       if (nlh) {  // the rare '\n's: which ordinals end a line; the first of the tile gives NF
-        uint32_t mm = nlh;
+        uint32_t mm = nlh, j = (cex >> 16) + (h ? (uint32_t)__popc(nl[0] | (nl[1] << 16)) : 0u);
         while (mm) {
           const uint32_t b = (uint32_t)__ffs((int)mm) - 1; mm &= mm - 1;
           const uint32_t kk = k + (uint32_t)__popc(m & ((2u << b) - 1u));  // = ordinal + 1
           atomicOr(&nlbits[kk >> 5], 1u << (kk & 31));
-          if (jl == 0) misc[2] = kk;
-          jl++;
-        }
-      }
-      if (qmh && o.escape != 0) {  // the rare quotes: an escape character directly in front of one (reader.go:233-240) needs the byte-wise state machine: general path
-        uint32_t mm = qmh;
-        while (mm) {
-          const uint32_t b = (uint32_t)__ffs((int)mm) - 1; mm &= mm - 1;
-          if (sb[(int)(cpos + b) - 1] == o.escape) misc[1] = 1u;
+          if (j == 0) misc[2] = kk;
+          j++;
         }
       }
       while (m) {
         const uint32_t b = (uint32_t)__ffs((int)m) - 1; m &= m - 1;
         fposx[++k] = (uint16_t)(cpos + b);
       }
+      if (o.escape != 0) {  // an escape character directly in front of a quote (reader.go:233-240) needs the byte-wise state machine: general path
+        uint32_t mm = qm[h] | (qm[h + 1] << 16);
+        while (mm) {
+          const uint32_t b = (uint32_t)__ffs((int)mm) - 1; mm &= mm - 1;
+          if (sb[(int)(cpos + b) - 1] == o.escape) misc[1] = 1u;  // (read after the cells; until then they are computed optimistically)
+        }
+      }
     }
     if (tid == 0) fposx[0] = (uint16_t)(frs - 1);
-    for (uint32_t i = tid; i < nr; i += CR_THREADS) slowf[i] = 0;
+    for (uint32_t i = tid; i < nr; i += CT_THREADS) slowf[i] = 0;
+    uint32_t qb = qinc - qc;
+    for (int i = 0; i < wv; i++) qb += wqc[i];
+    qpre[tid * 2] = (uint16_t)qb; qpre[tid * 2 + 1] = (uint16_t)(qb + qlo);
+    if (tid == CT_THREADS - 1) qpre[CT_BYTES / 32] = (uint16_t)(qb + qc);
   }
   __syncthreads();
   phase(3);
   if (p.ablate == 4) return;
   const uint32_t NF = misc[2];  // fields of the first line; every line must have as many
   if (NF < 2 || NF < (uint32_t)p.nfields_used || nr * NF > nfe) { give_up(); return; }  // uniform.  (A lone "\n" is a line of no fields, reader.go:146-150.)
-  for (uint32_t jj = tid; jj < nr; jj += CR_THREADS) {
+  for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
     const uint32_t idx = (jj + 1) * NF;
     if (idx > nfe || !((nlbits[idx >> 5] >> (idx & 31)) & 1u)) misc[1] = 1u;  // read after the next barrier; until then the cells are computed optimistically
   }
 
-  // ---- cells: wave wv takes columns wv, wv + 8, … of the (kind, width)-sorted list; lane = line ----
+  // ---- cells, run by run: a run is a set of columns of one kind and width, its items (column, line) with lines
+  //      fastest, so that column stores are coalesced; 64 items are one slot, and the slots of all runs are dealt
+  //      round-robin to the waves ----
   {
     RegTile t;
-    t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.keeptab = keeptab; t.slowf = slowf;
-    t.nr = nr; t.NF = NF;
-    t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0;
-    for (uint32_t jb = 0; jb < nr; jb += 64) {
-      RegLane ln;
-      ln.jj = jb + (uint32_t)lane;
-      const int32_t row = t.row0 + (int32_t)ln.jj;
-      ln.act = ln.jj < nr && row >= 0;  // header lines produce nothing
-      ln.k0 = __umul24(ln.jj, NF); ln.r = (uint32_t)row;
-      // this wave's columns, the index entries of the next one requested before this one's cells are computed
-      const int last = p.ncols - 1;
-      if (wv > last) continue;
-      RegXY xy0 = regxy_read(t, ln, (uint32_t)__builtin_amdgcn_readlane((int)vtab, 2));
-      int slot = 0;
-      for (int ci = wv; ci <= last; ci += CR_THREADS / 64, slot++) {
-        RegCol tc;
-        tc.p0 = p.arena + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)vtab, 3 * slot) * 4u;
-        tc.p1 = p.arena + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)vtab, 3 * slot + 1) * 4u;
-        const uint32_t meta = tc.meta = (uint32_t)__builtin_amdgcn_readlane((int)vtab, 3 * slot + 2);
-        const RegXY xy1 = regxy_read(t, ln, (uint32_t)__builtin_amdgcn_readlane((int)vtab, min(3 * slot + 5, 62)));  // (past the last column: some field of the line, not used)
-        const int width = (int)(meta >> 24);
-        const int kind = (int16_t)(uint16_t)meta < 0 ? -1 : (int)((meta >> 16) & 0xFFu);
-        bool skip = p.ablate >= 10 && p.ablate != ((kind == CK_INT || kind == CK_UINT) ? 11 : kind == CK_STR ? 12 : 13);  // 10: no cells; 11: integer columns only; 12: text only; 13: date / timestamp only
-        if (p.ablate >= 20) skip = !((kind == CK_INT || kind == CK_UINT) && width == (p.ablate == 21 ? 2 : p.ablate == 22 ? 4 : 8));  // 21 / 22 / 23: the 2- / 4- / 8-byte integer columns only
-        if (!skip) switch (kind) {
-          case CK_INT:
-            if (width == 1) col_cells_int<CK_INT, 1>(t, tc, ln, xy0); else if (width == 2) col_cells_int<CK_INT, 2>(t, tc, ln, xy0);
-            else if (width == 4) col_cells_int<CK_INT, 4>(t, tc, ln, xy0); else col_cells_int<CK_INT, 8>(t, tc, ln, xy0);
-            break;
-          case CK_UINT:
-            if (width == 1) col_cells_int<CK_UINT, 1>(t, tc, ln, xy0); else if (width == 2) col_cells_int<CK_UINT, 2>(t, tc, ln, xy0);
-            else if (width == 4) col_cells_int<CK_UINT, 4>(t, tc, ln, xy0); else col_cells_int<CK_UINT, 8>(t, tc, ln, xy0);
-            break;
-          case CK_STR: col_cells_str(t, tc, ln, xy0); break;
-          case CK_DATE: col_cells_time<CK_DATE>(t, tc, ln, xy0); break;
-          case CK_TIMESTAMP: col_cells_time<CK_TIMESTAMP>(t, tc, ln, xy0); break;
-          default:
-            if (ln.act) {
-              if (kind < 0) {  // DefaultValue columns (ColSchema.Path < 0)
-                CsvCol c{}; c.kind = (int32_t)((meta >> 16) & 0xFFu); c.width = width; c.values = (void *)tc.p0; c.nanos = (int32_t *)tc.p1; c.lens = (uint32_t *)tc.p0; c.fstart = (uint32_t *)tc.p1;
-                store_default(c, row);
-              } else slowf[ln.jj] = 1;  // bool, float32, json.Number, interval cells: the per-row path carries their rules
-            }
-        }
-        xy0 = xy1;
+    t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.keeptab = keeptab; t.slowf = slowf; t.colp0 = colp0; t.colp1 = colp1; t.colfield = colfield;
+    t.nr = nr; t.NF = NF; t.step_q = 512u / nr; t.step_r = 512u - t.step_q * nr; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
+    t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0; t.ablate = p.ablate;
+    uint32_t sbase = 0;
+    for (int ri = 0; ri < p.nruns; ri++) {
+      const CsvRun run = p.runs[ri];
+      const uint32_t items = (uint32_t)run.ncols * nr, nslots = (items + 63) >> 6;
+      if (p.ablate >= 10) {  // 10: no cells; 11: integer runs only; 12: text runs only; 13: date / timestamp runs only
+        const int grp = (run.kind == CK_INT || run.kind == CK_UINT) ? 11 : run.kind == CK_STR ? 12 : 13;
+        if (p.ablate != grp && !(p.ablate == 31 && grp == 11)) { sbase += nslots; continue; }
       }
+      switch (run.kind) {
+        case CK_INT:
+          if (run.width == 1) reg_cells_int<CK_INT, 1>(t, run, sbase, wv, lane); else if (run.width == 2) reg_cells_int<CK_INT, 2>(t, run, sbase, wv, lane);
+          else if (run.width == 4) reg_cells_int<CK_INT, 4>(t, run, sbase, wv, lane); else reg_cells_int<CK_INT, 8>(t, run, sbase, wv, lane);
+          break;
+        case CK_UINT:
+          if (run.width == 1) reg_cells_int<CK_UINT, 1>(t, run, sbase, wv, lane); else if (run.width == 2) reg_cells_int<CK_UINT, 2>(t, run, sbase, wv, lane);
+          else if (run.width == 4) reg_cells_int<CK_UINT, 4>(t, run, sbase, wv, lane); else reg_cells_int<CK_UINT, 8>(t, run, sbase, wv, lane);
+          break;
+        case CK_STR: reg_cells_str(t, run, sbase, wv, lane); break;
+        case CK_DATE: reg_cells_time<CK_DATE>(t, run, sbase, wv, lane); break;
+        case CK_TIMESTAMP: reg_cells_time<CK_TIMESTAMP>(t, run, sbase, wv, lane); break;
+        default:
+          for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
+            const uint32_t it = (s - sbase) * 64 + (uint32_t)lane;
+            if (it >= items) continue;
+            const uint32_t oi = it / nr, jj = it - oi * nr;
+            const int32_t r = t.row0 + (int32_t)jj;
+            if (r < 0) continue;
+            if (run.kind < 0) {  // DefaultValue columns (ColSchema.Path < 0)
+              const TCol tc = p.tcols[run.first + oi];
+              CsvCol c{}; c.kind = tc.kind; c.width = tc.width; c.values = tc.p0; c.nanos = (int32_t *)tc.p1; c.lens = (uint32_t *)tc.p0; c.fstart = (uint32_t *)tc.p1;
+              store_default(c, r);
+            } else slowf[jj] = 1;  // bool, float32, json.Number, interval cells: the per-row path carries their rules
+          }
+      }
+      sbase += nslots;
     }
     // ---- sanitizeElement also runs on fields no column reads: anything but a plain field flags the line ----
     if (p.has_unmapped || NF != (uint32_t)p.nfields_used) {
       const uint32_t tot2 = nr * NF;
       const uint32_t inv_nf = 0xFFFFFFFFu / NF + 1;
-      for (uint32_t it = tid; it < tot2; it += CR_THREADS) {
+      for (uint32_t it = tid; it < tot2; it += CT_THREADS) {
         uint32_t jj = __umulhi(it, inv_nf);
         uint32_t f = it - jj * NF;
         if (f >= NF) { jj++; f -= NF; }
@@ -1665,9 +1625,9 @@ __device__ __forceinline__ void parse_tile_regular(const CsvParams &p, const int
   phase(4);  // (thread 0's own cells)
   __syncthreads();
   phase(5);
-  if (misc[1]) { give_up(); return; }  // some line has another number of fields: nothing of the above counts
+  if (misc[1]) { give_up(); return; }  // some line has another number of fields, or a quote is escaped: nothing of the above counts
   // ---- per line: clean, or handed to the per-row path ----
-  for (uint32_t jj = tid; jj < nr; jj += CR_THREADS) {
+  for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
     const int64_t r = (int64_t)line0 + jj - p.skip_rows;
     if (r < 0) continue;
     if (slowf[jj] || p.null_checks) {
@@ -1679,17 +1639,6 @@ __device__ __forceinline__ void parse_tile_regular(const CsvParams &p, const int
   // one past the last '\n' of the chunk: only the tile that owns the last line has it (30 000 atomics on one word are not free)
   if (tid == 0 && line1 == lines_all) atomicMax(p.last_end, (uint32_t)(g0 + fposx[nr * NF] + 1));
   phase(6);
-}
-
-// XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
-__global__ void __launch_bounds__(CR_THREADS, 4) csv_parse_regular(CsvParams p) {
-  const int64_t per_xcd = (p.ntiles + 7) / 8;
-  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (tile >= p.ntiles) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint32_t vtab = 0;  // lane 3 s + w: word w of the descriptor of this wave's s-th column (wv + 8 s)
-  { const int sl = lane / 3, ci = wv + (CR_THREADS / 64) * sl; if (lane < 63 && ci < p.ncols && p.ncols <= CR_LCOLS) vtab = p.rcols[ci * 3 + (lane - 3 * sl)]; }
-  parse_tile_regular(p, tile, vtab);
 }
 
 // rows that failed contribute no string bytes
@@ -2179,7 +2128,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   }
   int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
   // One arena for everything the parse kernels write per column (values, nanos, text lengths and positions): the column
-  // buffers are views into it, and csv_parse_regular addresses them as 32-bit offsets from one base.
+  // buffers are views into it — one block from the lane's cache per chunk instead of two hundred.
   auto a256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
   const size_t lens_bytes = a256((size_t)std::max(nstr, 1) * (size_t)seg_stride * 4 + 16 + 64);
   size_t arena_bytes = lens_bytes;
@@ -2303,24 +2252,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   TF_HIP(hipMemsetAsync(slow->p, 0, 8, st));
   Buf gen = dalloc((size_t)(2 * (ngran + 2) + 2) * 4);  // [0] = count, then (first granule, granules) pairs
   TF_HIP(hipMemsetAsync(gen->p, 0, 8, st));
-  // The regular kernel's tile: a lane is a line there, so the tile should hold a little under a multiple of 64 lines
-  // (the margin keeps the usual spread of line lengths from spilling into one more pass of 64) and its field ends must fit
-  // the LDS index.  28, 36 or 44 KiB (tile + look-behind = 4, 5 or 6 chunks of 16 bytes per thread).
-  uint32_t tile_bytes = CR_TMIN;
-  if (nlines) {
-    const double row = (double)len / (double)nlines;  // bytes per line
-    const double fields_per_byte = (double)std::max(max_field + 1, 2) / row;
-    double best = -1;
-    for (uint32_t tb = CR_TMIN; tb <= (uint32_t)CR_TMAX; tb += CR_TSTEP) {
-      const double lines = tb / row, spread = 2.0 + 0.6 * std::sqrt(lines);
-      if (tb > (uint32_t)CR_TMIN && (lines + spread > (double)CR_RCAP || tb * fields_per_byte > 0.93 * CR_FCAP)) break;
-      const double passes = std::ceil((lines + spread) / 64.0);
-      const double util = lines / (passes * 64.0);  // lanes at work in the cell phase
-      if (util >= best) { best = util; tile_bytes = tb; }
-    }
-  }
-  static const int tile_override = [] { const char *e = std::getenv("TFGPU_CSV_TILE_KB"); return e ? std::atoi(e) : 0; }();  // A/B measurements only
-  if (tile_override == 28 || tile_override == 36 || tile_override == 44) tile_bytes = (uint32_t)tile_override * 1024u;
+  const uint32_t tile_bytes = CT_T;  // csv_parse_regular's tile: seven granules
   const int64_t rtiles = (int64_t)((len + tile_bytes - 1) / tile_bytes);
   CsvParams pp;
   std::memset(&pp, 0, sizeof pp);
@@ -2362,18 +2294,18 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   }
   Buf btcols = up(tcols.data(), tcols.size() * sizeof(TCol));
   pp.tcols = ptr<TCol>(btcols);
-  std::vector<uint32_t> rcols((size_t)ncols * 3 + 3, 0u);
-  for (int i = 0; i < ncols; i++) {
-    const TCol &t = tcols[(size_t)i];
-    auto off4 = [&](const void *q) { return q ? (uint32_t)(((const uint8_t *)q - ptr<uint8_t>(arena)) >> 2) : 0u; };
-    rcols[(size_t)i * 3] = off4(t.p0); rcols[(size_t)i * 3 + 1] = off4(t.p1);
-    rcols[(size_t)i * 3 + 2] = (uint32_t)(uint16_t)t.field | ((uint32_t)t.kind << 16) | ((uint32_t)t.width << 24);
-  }
-  Buf brcols = up(rcols.data(), rcols.size() * 4);
-  pp.rcols = ptr<uint32_t>(brcols); pp.arena = ptr<uint8_t>(arena);
   static const bool phases = [] { const char *e = std::getenv("TFGPU_CSV_PHASES"); return e && e[0] == '1'; }();
   Buf bphase;
   if (phases) { bphase = dalloc_zero(8 * 8); pp.dbg_phase = ptr<unsigned long long>(bphase); }
+  std::vector<CsvRun> runs;
+  for (int i = 0; i < ncols; i++) {
+    const TCol &t = tcols[(size_t)i];
+    const int kind = t.field < 0 ? -1 : (int)t.kind, width = t.field < 0 ? 0 : (int)t.width;
+    if (!runs.empty() && runs.back().kind == kind && runs.back().width == width && runs.back().first + runs.back().ncols == i) runs.back().ncols++;
+    else runs.push_back(CsvRun{kind, width, i, 1});
+  }
+  Buf bruns = up(runs.data(), runs.size() * sizeof(CsvRun));
+  pp.runs = ptr<CsvRun>(bruns); pp.nruns = (int32_t)runs.size();
   pp.null_checks = (opts->strings_can_be_null || opts->quoted_strings_can_be_null) ? 1 : 0;
 
   if (ablate) {  // profiling only: what the skipped phases would have written must not be garbage
@@ -2388,7 +2320,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   } else if (nlines) {
     // header lines are parsed by nobody: err[] of the data rows is written by exactly one of the two kernels
     const int64_t per_xcd = (rtiles + 7) / 8;
-    { KernelTimer t("csv_parse_regular"); csv_parse_regular<<<(unsigned)(per_xcd * 8), CR_THREADS, 0, st>>>(pp); }
+    { KernelTimer t("csv_parse_regular"); csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_tiles_general"); csv_parse_tiles_general<<<(unsigned)std::min<int64_t>(ntiles + rtiles, 2048), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 1024), 64, 0, st>>>(pp); }
   }
@@ -2407,7 +2339,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   const uint32_t hnerr = hsum[0], last = hsum[1];
   if (phases && !rowpath) {
     unsigned long long ph[8]; d2h(ph, bphase->p, sizeof ph); tf::sync();
-    std::fprintf(stderr, "tfgpu csv phases (shader cycles per workgroup, %lld tiles): stage %.0f classify %.0f fields %.0f index %.0f cells(wave 0) %.0f cells-barrier %.0f epilogue %.0f\n", (long long)rtiles,
+    std::fprintf(stderr, "tfgpu csv phases (s_memtime ticks per workgroup, %lld tiles): stage %.0f classify %.0f fields %.0f index %.0f cells(wave 0) %.0f cells-barrier %.0f epilogue %.0f\n", (long long)rtiles,
                  (double)ph[0] / rtiles, (double)ph[1] / rtiles, (double)ph[2] / rtiles, (double)ph[3] / rtiles, (double)ph[4] / rtiles, (double)ph[5] / rtiles, (double)ph[6] / rtiles);
   }
   static const bool debug = [] { const char *e = std::getenv("TFGPU_CSV_DEBUG"); return e && e[0] == '1'; }();
