@@ -404,7 +404,9 @@ static const char *DAYS[] = {"Sunday", "Monday", "Tuesday", "Wednesday", "Thursd
 
 enum { C_NONE, C_LONGMONTH, C_MONTH, C_NUMMONTH, C_ZEROMONTH, C_LONGWEEKDAY, C_WEEKDAY, C_DAY, C_UNDERDAY, C_ZERODAY,
        C_HOUR, C_HOUR12, C_ZEROHOUR12, C_MINUTE, C_ZEROMINUTE, C_SECOND, C_ZEROSECOND, C_LONGYEAR, C_YEAR, C_PM, C_pm,
-       C_TZ, C_ISOTZ, C_ISOTZCOLON, C_ISOTZSHORT, C_NUMTZ, C_NUMTZCOLON, C_NUMTZSHORT, C_FRAC0, C_FRAC9, C_ZEROYEARDAY };
+       C_TZ, C_ISOTZ, C_ISOTZCOLON, C_ISOTZSHORT, C_NUMTZ, C_NUMTZCOLON, C_NUMTZSHORT, C_FRAC0, C_FRAC9, C_ZEROYEARDAY, C_UNDERYEARDAY };
+
+static int lower_start(const char *s, size_t n) { return n > 0 && s[0] >= 'a' && s[0] <= 'z'; } /* startsWithLowerCase */
 
 static int starts(const char *s, size_t n, const char *p) { size_t l = strlen(p); return n >= l && memcmp(s, p, l) == 0; }
 
@@ -416,11 +418,11 @@ static int next_chunk(const char *l, size_t n, size_t *plen, size_t *clen, int *
     switch (s[0]) {
       case 'J':
         if (starts(s, r, "January")) { *clen = 7; return C_LONGMONTH; }
-        if (starts(s, r, "Jan")) { *clen = 3; return C_MONTH; }
+        if (starts(s, r, "Jan") && !lower_start(s + 3, r - 3)) { *clen = 3; return C_MONTH; }
         break;
       case 'M':
         if (starts(s, r, "Monday")) { *clen = 6; return C_LONGWEEKDAY; }
-        if (starts(s, r, "Mon")) { *clen = 3; return C_WEEKDAY; }
+        if (starts(s, r, "Mon") && !lower_start(s + 3, r - 3)) { *clen = 3; return C_WEEKDAY; }
         if (starts(s, r, "MST")) { *clen = 3; return C_TZ; }
         break;
       case '0':
@@ -441,6 +443,7 @@ static int next_chunk(const char *l, size_t n, size_t *plen, size_t *clen, int *
           if (starts(s + 1, r - 1, "2006")) { *plen = i + 1; *clen = 4; return C_LONGYEAR; }
           *clen = 2; return C_UNDERDAY;
         }
+        if (r >= 3 && s[1] == '_' && s[2] == '2') { *clen = 3; return C_UNDERYEARDAY; }
         break;
       case '3': *clen = 1; return C_HOUR12;
       case '4': *clen = 1; return C_MINUTE;
@@ -498,6 +501,28 @@ static int days_in(int m, int64_t y) {
   return dm[m - 1];
 }
 
+/* time.skip: runs of spaces are equivalent; a space of the layout also takes no space at the value's end */
+static int skip_prefix(const char **s, size_t *n, const char *pre, size_t plen) {
+  while (plen > 0) {
+    if (pre[0] == ' ') {
+      if (*n > 0 && (*s)[0] != ' ') return 1;
+      while (plen > 0 && pre[0] == ' ') { pre++; plen--; }
+      while (*n > 0 && (*s)[0] == ' ') { (*s)++; (*n)--; }
+      continue;
+    }
+    if (*n == 0 || (*s)[0] != pre[0]) return 1;
+    pre++; plen--; (*s)++; (*n)--;
+  }
+  return 0;
+}
+/* time.parseSignedOffset: length of [+-]digits with a value <= 23, else 0 */
+static size_t signed_offset(const char *s, size_t n) {
+  if (n == 0 || (s[0] != '+' && s[0] != '-')) return 0;
+  size_t k = 1; unsigned long long x = 0;
+  while (k < n && isdigit((unsigned char)s[k])) { if (x < (1ull << 62)) x = x * 10 + (unsigned)(s[k] - '0'); k++; }
+  return (k > 1 && x <= 23) ? k : 0;
+}
+
 int ora_time_parse(const char *layout, const char *val, size_t n, int64_t *osec, int32_t *onsec) {
   const char *l = layout; size_t ln = strlen(layout);
   const char *s = val;
@@ -508,8 +533,7 @@ int ora_time_parse(const char *layout, const char *val, size_t n, int64_t *osec,
     size_t plen, clen; int fd;
     int c = next_chunk(l, ln, &plen, &clen, &fd);
     /* literal prefix must match */
-    if (n < plen || memcmp(s, l, plen) != 0) return 1;
-    s += plen; n -= plen;
+    if (skip_prefix(&s, &n, l, plen)) return 1;
     if (c == C_NONE) { if (n != 0) return 1; break; }
     l += plen + clen; ln -= plen + clen;
     int v;
@@ -534,10 +558,12 @@ int ora_time_parse(const char *layout, const char *val, size_t n, int64_t *osec,
       case C_DAY: case C_UNDERDAY: case C_ZERODAY:
         if (c == C_UNDERDAY && n > 0 && s[0] == ' ') { s++; n--; }
         if (getnum(&s, &n, c == C_ZERODAY, &v)) return 1; day = v; break;
-      case C_ZEROYEARDAY: {
-        if (n < 3) return 1;
-        for (int i = 0; i < 3; i++) if (!isdigit((unsigned char)s[i])) return 1;
-        yday = (s[0] - '0') * 100 + (s[1] - '0') * 10 + (s[2] - '0'); s += 3; n -= 3; break;
+      case C_ZEROYEARDAY: case C_UNDERYEARDAY: { /* getnum3 */
+        if (c == C_UNDERYEARDAY) for (int i = 0; i < 2; i++) if (n > 0 && s[0] == ' ') { s++; n--; }
+        int nd = 0; yday = 0;
+        while (nd < 3 && (size_t)nd < n && isdigit((unsigned char)s[nd])) { yday = yday * 10 + (s[nd] - '0'); nd++; }
+        if (nd == 0 || (c == C_ZEROYEARDAY && nd != 3)) return 1;
+        s += nd; n -= (size_t)nd; break;
       }
       case C_HOUR: if (getnum(&s, &n, 0, &v) || v < 0 || v >= 24) return 1; hour = v; break;
       case C_HOUR12: case C_ZEROHOUR12:
@@ -585,21 +611,18 @@ int ora_time_parse(const char *layout, const char *val, size_t n, int64_t *osec,
         have_zoff = 1; break;
       }
       case C_TZ: {
-        /* time.parseTimeZone: "UTC", 3-4 upper-case letters (+ optional T), GMT±N */
+        /* time.parseTimeZone: "UTC"; ChST / MeST; GMT with an optional signed hour; a bare signed hour; 3-5 capitals.
+         * A name never moves the instant (Go keeps the wall time under a fabricated location). */
         if (n >= 3 && !memcmp(s, "UTC", 3)) { s += 3; n -= 3; break; }
+        if (n < 3) return 1;
+        if (n >= 4 && (!memcmp(s, "ChST", 4) || !memcmp(s, "MeST", 4))) { s += 4; n -= 4; break; }
+        if (!memcmp(s, "GMT", 3)) { size_t k = 3 + signed_offset(s + 3, n - 3); s += k; n -= k; break; }
+        if (s[0] == '+' || s[0] == '-') { size_t k = signed_offset(s, n); if (!k) return 1; s += k; n -= k; break; }
         size_t j = 0; while (j < n && j < 6 && s[j] >= 'A' && s[j] <= 'Z') j++;
         if (j < 3 || j > 5) return 1;
         if (j == 5 && s[4] != 'T') return 1;
         if (j == 4 && !(s[3] == 'T' || !memcmp(s, "WITA", 4))) return 1;
-        if (j == 3 && !memcmp(s, "GMT", 3)) {
-          s += 3; n -= 3;
-          if (n > 0 && (s[0] == '+' || s[0] == '-')) { /* GMT±hh */
-            size_t k = 1; int hv = 0; while (k < n && isdigit((unsigned char)s[k])) { hv = hv * 10 + (s[k] - '0'); k++; }
-            if (k > 1 && hv <= 23) { s += k; n -= k; }
-          }
-          break;
-        }
-        s += j; n -= j; /* unknown abbreviation: Go fabricates a zero-offset location */
+        s += j; n -= j;
         break;
       }
       case C_FRAC0: {
@@ -623,9 +646,15 @@ int ora_time_parse(const char *layout, const char *val, size_t n, int64_t *osec,
   }
   if (pm_set) { if (pm && hour < 12) hour += 12; else if (!pm && hour == 12) hour = 0; }
   if (!have_year) year = 0;
-  if (yday >= 0) {
-    if (yday < 1 || yday > 365 + (days_in(2, year) == 29)) return 1;
-    if (month < 0) { int m = 1, d = yday; while (d > days_in(m, year)) { d -= days_in(m, year); m++; } month = m; day = d; }
+  if (yday >= 0) { /* the day of the year decides; a month / day the value also gave must agree (format.go "day-of-year does not match") */
+    int m = 0, d = 0;
+    if (days_in(2, year) == 29) { if (yday == 31 + 29) { m = 2; d = 29; } else if (yday > 31 + 29) yday--; }
+    if (yday < 1 || yday > 365) return 1;
+    if (m == 0) { m = 1; d = yday; while (d > days_in(m, 1)) { d -= days_in(m, 1); m++; } }
+    if (month >= 0 && month != m) return 1;
+    month = m;
+    if (day >= 0 && day != d) return 1;
+    day = d;
   } else {
     if (month < 0) month = 1;
     if (day < 0) day = 1;

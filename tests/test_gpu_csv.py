@@ -382,6 +382,34 @@ def test_user_timestamp_layouts_and_cast_layouts(tf, oracle):
         assert out.nrows > 1500 and len(errs) > 300
 
 
+def test_go_time_parse_golden(tf, oracle):
+    """time.Parse corner cases the ADVICE review listed (space runs, signed-hour zone names, ChST / MeST, GMT before the
+    capitals are counted, the lower-case guard of nextStdChunk, __2 / 002 day-of-year rules): the inputs of
+    tests/golden/gotime.json (hand-derived from time/format.go; the oracle is pinned to it in test_oracle_golden.py) through
+    the device's compiled layouts — a datetime cell under one user layout.  A layout without a year gets one in front
+    (year 0 is outside what the CSV path stores), so the expectation is the oracle's time.Parse of the same pair."""
+    g = golden("gotime.json")
+    schema = abi.Schema.of([["id", "int32", True, "0"], ["ts", "datetime", False, "1"]])  # (TimestampParsers are tried on date / datetime cells: reader_csv.go:405-415)
+    checked = 0
+    for k, (layout, value, _expect, why) in enumerate(g["cases"]):
+        if "2006" not in layout:
+            layout, value = "2006 " + layout, "2021 " + value
+        expect = oracle.time_parse(layout, value)
+        cell = '"' + value + '"' if ("," in value or value != value.strip()) else value
+        opts = abi.csv_options(timestamp_parsers=[layout])
+        data = ("%d,%s\n" % (k, cell)).encode()
+        db, _, errs = tf.csv_parse(opts, schema, data, max_errors=16)
+        out = db.download()
+        assert not [e for e in errs if e[1] == "HOST_FALLBACK"], (layout, value, "handed to the host")
+        ref = oracle.csv_parse(opts, schema, data, "ns", "t")
+        assert out.nrows == ref.batch.nrows and len(errs) == len(ref.errors), (layout, value, why, errs, ref.errors)
+        if expect is not None and ref.batch.nrows == 1:
+            c = out.col("ts")
+            assert [int(c.values[0]), int(c.nanos[0]) if c.nanos is not None else 0] == [int(expect[0]), int(expect[1])], (layout, value, why)
+            checked += 1
+    assert checked >= 18
+
+
 def test_decimal_point(tf, oracle):
     """DecimalPoint (reader_csv.go:363-378): the first occurrence becomes '.', kept only when strconv.ParseFloat takes the
     result.  The reference's TestParseFloatValue values, then a sweep against the oracle."""

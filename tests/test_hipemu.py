@@ -36,9 +36,9 @@ NAMES = ["id", "name", "ts", "opt"]
 
 def make(r):
     # rows of rank r as (host batch, python rows, kinds, old key values or None): deterministic, every rank can rebuild every other's
-    n = {"plain": 300 + 41 * r, "ragged": 300 + 41 * r, "empty_rank": 0 if r == 1 else 257, "mismatch": 50}[case]
+    n = {"plain": 300 + 41 * r, "ragged": 300 + 41 * r, "empty_rank": 0 if r == 1 else 257, "mismatch": 50, "unnamed_old": 60}[case]
     lo = 1000 * r
-    lean = case == "ragged" and r == 1   # this rank has no nil anywhere, whole seconds only, no OldKeys, no kinds
+    lean = case in ("ragged", "unnamed_old") and r == 1   # this rank has no nil anywhere, whole seconds only, no OldKeys, no kinds
     rows = []
     for i in range(n):
         k = lo + i
@@ -46,6 +46,8 @@ def make(r):
                      ["time", (1_600_000_000 + k, 0 if lean else k % 1000)], ["nil", None] if (k % 5 == 0 and not lean) else ["int32", k]])
     kinds = None if lean else [("insert", "update", "delete")[(lo + i) % 3] for i in range(n)]
     schema = SCHEMA
+    if case == "unnamed_old" and r == 1:  # … and no key in its TableSchema either: it cannot name the OldKeys the others carry
+        schema = abi.Schema.of([["id", "int64"], ["name", "utf8"], ["ts", "timestamp"], ["opt", "int32"]])
     if case == "mismatch" and r == 1:
         schema = abi.Schema.of([["id", "int64", True], ["name", "utf8"], ["ts", "timestamp"], ["opt", "int64"]])
         for row in rows:
@@ -89,12 +91,12 @@ else:
         time.sleep(0.02)
     uid = open(idfile, "rb").read()
 comm = lib.Comm.create(uid, rank, world)
-if case == "mismatch":
+if case in ("mismatch", "unnamed_old"):
     try:
         comm.exchange(grouped, counts)
         print(json.dumps({"rank": rank, "error": None}))
     except lib.TfgpuError as e:
-        print(json.dumps({"rank": rank, "error": e.code == lib.ERR_INVALID and "representation" in str(e)}))
+        print(json.dumps({"rank": rank, "error": e.code == lib.ERR_INVALID and ("representation" if case == "mismatch" else "cannot name") in str(e)}))
     comm.close()
     sys.exit(0)
 for _ in range(2):   # a communicator carries any number of exchanges
@@ -143,7 +145,7 @@ comm.close()
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("plain", 3), ("mismatch", 2)])
+@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("plain", 3), ("mismatch", 2), ("unnamed_old", 2)])
 def test_emulated_exchange_ranks(tmp_path, case, world):
     """tfgpu_exchange on world_size 2 / 3 without a GPU: one process per rank, the emulated kernels, RCCL replaced by the
     socket stand-in (tools/hipemu/fake_rccl.cpp) — the descriptor agreement, the grouped send/recv plan and the rebuild of
@@ -164,8 +166,8 @@ def test_emulated_exchange_ranks(tmp_path, case, world):
         assert p.returncode == 0, e[-3000:]
         outs.append(json.loads(o.strip().splitlines()[-1]))
     outs.sort(key=lambda d: d["rank"])
-    if case == "mismatch":
-        assert [o["error"] for o in outs] == [True] * world  # every rank refuses, nobody hangs
+    if case in ("mismatch", "unnamed_old"):
+        assert [o["error"] for o in outs] == [True] * world  # every rank refuses (the one that cannot name the OldKeys AND its peers), nobody hangs
         return
     assert sum(o["rows"] for o in outs) == sum(sum(o["sent"]) for o in outs)
     for r, o in enumerate(outs):

@@ -203,3 +203,16 @@ def test_csv_splitter_cases(oracle):
         ends = oracle.csv_split_rows(data)
         rows = [data[a:b].decode() for a, b in zip([0] + ends[:-1], ends)]
         assert rows == case["rows"] and data[ends[-1] if ends else 0:].decode() == case["eof_rest"], case["name"]
+
+
+def test_time_parse_golden():
+    """oracle/ora_gofmt.c's time.Parse against tests/golden/gotime.json — corner cases hand-derived from Go's time/format.go
+    (no Go toolchain here: the file says so): space runs in skip(), signed-hour zone names, ChST / MeST, GMT tested before the
+    capitals are counted, nextStdChunk's lower-case guard, the __2 / 002 day-of-year chunks and their consistency checks."""
+    import json
+    import os
+    from oracle import oracle as ora
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gotime.json")))
+    for layout, value, expect, why in g["cases"]:
+        got = ora.time_parse(layout, value)
+        assert (None if got is None else [int(got[0]), int(got[1])]) == expect, (layout, value, why)

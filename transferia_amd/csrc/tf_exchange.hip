@@ -217,13 +217,28 @@ std::unique_ptr<tfgpu_dbatch> exchange(tfgpu_comm &cm, const tfgpu_dbatch &in, c
       int64_t rp = M(r, o_col + (size_t)j * 3);
       if (rp < 0) continue;
       if (d.repr == TFGPU_R_INVALID) { d.repr = (int)rp; d.dtype = (int)M(r, o_col + (size_t)j * 3 + 1); }
-      else if (d.repr != (int)rp) throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: ranks disagree on the representation of column " + std::to_string(j));
+      else if (d.repr != (int)rp || d.dtype != (int)M(r, o_col + (size_t)j * 3 + 1))
+        throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: ranks disagree on the representation / type of column " + std::to_string(j));
       d.validity |= (M(r, o_col + (size_t)j * 3 + 2) & CF_VALIDITY) != 0;
       d.nanos |= (M(r, o_col + (size_t)j * 3 + 2) & CF_NANOS) != 0;
     }
   }
-  if (nold && !local_old && (int64_t)in.key_names.size() != nold)
-    throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: other ranks carry OldKeys and this one cannot name them (no TableSchema keys on the batch)");
+  // Every failure is evaluated for EVERY rank from what the two all-gathers brought (the same matrix on all ranks), so all
+  // ranks throw together before any payload moves: a rank that failed alone would leave its peers inside ncclGroupEnd.
+  for (int r = 0; r < W; r++)
+    if (nold && hdr_all[(size_t)r * 3 + 1] == 0 && hdr_all[(size_t)r * 3 + 2] != nold)
+      throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: some ranks carry OldKeys and rank " + std::to_string(r) + " cannot name them (no TableSchema keys on its batch)");
+  for (int d = 0; d < W; d++) {
+    int64_t rows_d = 0;
+    for (int r = 0; r < W; r++) rows_d += M(r, o_rows + (size_t)d);
+    if (rows_d > 0x7fffffff) throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: more than 2^31-1 rows land on rank " + std::to_string(d));
+    for (int64_t j = 0; j < C; j++) {
+      if (!repr_is_var(desc[(size_t)j].repr)) continue;
+      uint64_t bytes_d = 0;
+      for (int r = 0; r < W; r++) bytes_d += (uint64_t)M(r, o_bytes + (size_t)j * W + (size_t)d);
+      if (bytes_d > 0xffffffffull) throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: text column " + std::to_string(j) + " of more than 4 GiB lands on rank " + std::to_string(d));
+    }
+  }
   int64_t bflags = 0;
   bool some_lacks_old = false;
   for (int r = 0; r < W; r++) { bflags |= M(r, 0); some_lacks_old |= nold && hdr_all[(size_t)r * 3 + 1] == 0; }
@@ -234,7 +249,6 @@ std::unique_ptr<tfgpu_dbatch> exchange(tfgpu_comm &cm, const tfgpu_dbatch &in, c
   std::vector<int64_t> got_rows((size_t)W);
   int64_t n_out = 0;
   for (int r = 0; r < W; r++) { got_rows[(size_t)r] = M(r, o_rows + (size_t)me); n_out += got_rows[(size_t)r]; }
-  if (n_out > 0x7fffffff) throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: more than 2^31-1 rows land on one rank");
   std::vector<int64_t> send_rows(counts, counts + W);
 
   // ---- 2. plan every buffer's move, then one grouped RCCL call
@@ -279,7 +293,6 @@ std::unique_ptr<tfgpu_dbatch> exchange(tfgpu_comm &cm, const tfgpu_dbatch &in, c
         mv.got[(size_t)r] = M(r, o_bytes + (size_t)j * W + (size_t)me);
         total += (uint64_t)mv.got[(size_t)r];
       }
-      if (total > 0xffffffffull) throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: a text column of more than 4 GiB lands on one rank");
       o.data = dalloc(std::max<uint64_t>(total, 1));
       o.data_len = total;
       mv.recv = ptr<uint8_t>(o.data);

@@ -16,7 +16,7 @@ namespace tf {
 enum GtCode : uint8_t {
   GT_END = 0, GT_LONGMONTH, GT_MONTH, GT_NUMMONTH, GT_ZEROMONTH, GT_LONGWEEKDAY, GT_WEEKDAY, GT_DAY, GT_UNDERDAY, GT_ZERODAY,
   GT_HOUR, GT_HOUR12, GT_ZEROHOUR12, GT_MINUTE, GT_ZEROMINUTE, GT_SECOND, GT_ZEROSECOND, GT_LONGYEAR, GT_YEAR, GT_PM, GT_pm,
-  GT_TZ, GT_ISOTZ, GT_ISOTZCOLON, GT_ISOTZSHORT, GT_NUMTZ, GT_NUMTZCOLON, GT_NUMTZSHORT, GT_FRAC0, GT_FRAC9, GT_ZEROYEARDAY
+  GT_TZ, GT_ISOTZ, GT_ISOTZCOLON, GT_ISOTZSHORT, GT_NUMTZ, GT_NUMTZCOLON, GT_NUMTZSHORT, GT_FRAC0, GT_FRAC9, GT_ZEROYEARDAY, GT_UNDERYEARDAY
 };
 // one op = the literal text in front of a chunk + the chunk; the last op of a layout is GT_END with the trailing literal
 struct GtOp { uint8_t code, fd /* fraction digits of GT_FRAC0/9 */, next_frac /* the op behind is a fraction glued to this one */, pad; uint16_t lit_off, lit_len; };
@@ -24,6 +24,7 @@ struct GtOp { uint8_t code, fd /* fraction digits of GT_FRAC0/9 */, next_frac /*
 // ---- host: time.nextStdChunk over the whole layout -----------------------------------------------------------------
 inline void gotime_compile(const std::string &layout, std::vector<GtOp> &ops, std::string &lits) {
   auto starts = [&](size_t i, const char *p) { return layout.compare(i, std::char_traits<char>::length(p), p) == 0; };
+  auto lower_at = [&](size_t i) { return i < layout.size() && layout[i] >= 'a' && layout[i] <= 'z'; };  // startsWithLowerCase: "Month" is not "Mon" + "th"
   size_t lit0 = 0, i = 0;
   const size_t n = layout.size();
   const size_t first = ops.size();
@@ -39,8 +40,8 @@ inline void gotime_compile(const std::string &layout, std::vector<GtOp> &ops, st
     const size_t r = n - i;
     bool hit = true;
     switch (c) {
-      case 'J': if (starts(i, "January")) emit(GT_LONGMONTH, i, 7, 0); else if (starts(i, "Jan")) emit(GT_MONTH, i, 3, 0); else hit = false; break;
-      case 'M': if (starts(i, "Monday")) emit(GT_LONGWEEKDAY, i, 6, 0); else if (starts(i, "Mon")) emit(GT_WEEKDAY, i, 3, 0); else if (starts(i, "MST")) emit(GT_TZ, i, 3, 0); else hit = false; break;
+      case 'J': if (starts(i, "January")) emit(GT_LONGMONTH, i, 7, 0); else if (starts(i, "Jan") && !lower_at(i + 3)) emit(GT_MONTH, i, 3, 0); else hit = false; break;
+      case 'M': if (starts(i, "Monday")) emit(GT_LONGWEEKDAY, i, 6, 0); else if (starts(i, "Mon") && !lower_at(i + 3)) emit(GT_WEEKDAY, i, 3, 0); else if (starts(i, "MST")) emit(GT_TZ, i, 3, 0); else hit = false; break;
       case '0':
         if (r >= 2 && layout[i + 1] >= '1' && layout[i + 1] <= '6') {
           static const uint8_t m[] = {0, GT_ZEROMONTH, GT_ZERODAY, GT_ZEROHOUR12, GT_ZEROMINUTE, GT_ZEROSECOND, GT_YEAR};
@@ -54,7 +55,8 @@ inline void gotime_compile(const std::string &layout, std::vector<GtOp> &ops, st
         if (r >= 2 && layout[i + 1] == '2') {
           if (starts(i + 1, "2006")) { emit(GT_LONGYEAR, i + 1, 4, 0); }  // "_2006" is a literal '_' followed by the year
           else emit(GT_UNDERDAY, i, 2, 0);
-        } else hit = false;
+        } else if (r >= 3 && layout[i + 1] == '_' && layout[i + 2] == '2') emit(GT_UNDERYEARDAY, i, 3, 0);
+        else hit = false;
         break;
       case '3': emit(GT_HOUR12, i, 1, 0); break;
       case '4': emit(GT_MINUTE, i, 1, 0); break;
@@ -142,6 +144,30 @@ template <class F> __device__ __forceinline__ int32_t gt_nanos(const F &f, uint3
 static __constant__ char GT_MONTHS[12][10] = {"January", "February", "March", "April", "May", "June", "July", "August", "September", "October", "November", "December"};
 static __constant__ char GT_DAYS[7][10] = {"Sunday", "Monday", "Tuesday", "Wednesday", "Thursday", "Friday", "Saturday"};
 
+// time.skip: the literal text in front of a chunk, runs of spaces treated as equivalent (a space of the layout takes any
+// run of spaces of the value — also none at the value's end)
+template <class F> __device__ __forceinline__ bool gt_skip(const F &f, uint32_t &p, uint32_t b, const uint8_t *lit, uint32_t n) {
+  uint32_t i = 0;
+  while (i < n) {
+    if (lit[i] == ' ') {
+      if (p < b && f[p] != ' ') return false;
+      while (i < n && lit[i] == ' ') i++;
+      while (p < b && f[p] == ' ') p++;
+      continue;
+    }
+    if (p >= b || f[p] != lit[i]) return false;
+    i++; p++;
+  }
+  return true;
+}
+// time.parseSignedOffset: [+-]digits with a value of at most 23; the length taken, 0 if it is not one
+template <class F> __device__ __forceinline__ uint32_t gt_signed_offset(const F &f, uint32_t p, uint32_t b) {
+  if (p >= b || (f[p] != '+' && f[p] != '-')) return 0;
+  uint32_t k = 1; uint64_t x = 0;
+  while (p + k < b && gt_digit(f[p + k])) { if (x < (1ull << 62)) x = x * 10 + (f[p + k] - '0'); k++; }  // (leadingInt fails on overflow: still > 23 here)
+  return (k > 1 && x <= 23) ? k : 0;
+}
+
 // time.Parse(layout, f[a, b)): true on success
 template <class F> __device__ bool gotime_parse(const GtOp *ops, int nops, const uint8_t *lits, const F &f, uint32_t a, uint32_t b, int64_t *osec, int32_t *onsec) {
   uint32_t p = a;
@@ -151,9 +177,7 @@ template <class F> __device__ bool gotime_parse(const GtOp *ops, int nops, const
   int zoff = 0;
   for (int oi = 0; oi < nops; oi++) {
     const GtOp op = ops[oi];
-    if (b - p < op.lit_len) return false;  // the literal text in front of the chunk
-    for (uint32_t k = 0; k < op.lit_len; k++) if (f[p + k] != lits[op.lit_off + k]) return false;
-    p += op.lit_len;
+    if (!gt_skip(f, p, b, lits + op.lit_off, op.lit_len)) return false;  // the literal text in front of the chunk
     switch (op.code) {
       case GT_END: if (p != b) return false; break;  // extra text
       case GT_YEAR:
@@ -176,11 +200,14 @@ template <class F> __device__ bool gotime_parse(const GtOp *ops, int nops, const
         if (!gt_getnum(f, p, b, op.code == GT_ZERODAY, &v)) return false;
         day = v;  // checked against the month once everything is known
         break;
-      case GT_ZEROYEARDAY:
-        if (b - p < 3) return false;
-        for (int k = 0; k < 3; k++) if (!gt_digit(f[p + k])) return false;
-        yday = (f[p] - '0') * 100 + (f[p + 1] - '0') * 10 + (f[p + 2] - '0'); p += 3;
+      case GT_ZEROYEARDAY: case GT_UNDERYEARDAY: {  // getnum3: three digits, or up to three behind up to two spaces
+        if (op.code == GT_UNDERYEARDAY) for (int k = 0; k < 2; k++) if (p < b && f[p] == ' ') p++;
+        int nd = 0; yday = 0;
+        while (nd < 3 && p + nd < b && gt_digit(f[p + nd])) { yday = yday * 10 + (int)(f[p + nd] - '0'); nd++; }
+        if (nd == 0 || (op.code == GT_ZEROYEARDAY && nd != 3)) return false;
+        p += nd;
         break;
+      }
       case GT_HOUR: if (!gt_getnum(f, p, b, false, &v) || v < 0 || v >= 24) return false; hour = v; break;
       case GT_HOUR12: case GT_ZEROHOUR12: if (!gt_getnum(f, p, b, op.code == GT_ZEROHOUR12, &v) || v < 0 || v > 12) return false; hour = v; break;
       case GT_MINUTE: case GT_ZEROMINUTE: if (!gt_getnum(f, p, b, op.code == GT_ZEROMINUTE, &v) || v < 0 || v >= 60) return false; mi = v; break;
@@ -222,22 +249,17 @@ template <class F> __device__ bool gotime_parse(const GtOp *ops, int nops, const
         have_zoff = true;
         break;
       }
-      case GT_TZ: {  // time.parseTimeZone: "UTC", three or four capitals (+ 'T'), "GMT" with an optional hour offset
+      case GT_TZ: {  // time.parseTimeZone.  A name never moves the instant (Go fabricates a location for it and keeps the wall time)
         if (b - p >= 3 && f[p] == 'U' && f[p + 1] == 'T' && f[p + 2] == 'C') { p += 3; break; }
+        if (b - p < 3) return false;
+        if (b - p >= 4 && (f[p] == 'C' || f[p] == 'M') && f[p + 2] == 'S' && f[p + 3] == 'T' && ((f[p] == 'C' && f[p + 1] == 'h') || (f[p] == 'M' && f[p + 1] == 'e'))) { p += 4; break; }  // ChST, MeST
+        if (f[p] == 'G' && f[p + 1] == 'M' && f[p + 2] == 'T') { p += 3; p += gt_signed_offset(f, p, b); break; }  // GMT, GMT+3 (anything else behind it is the next chunk's business)
+        if (f[p] == '+' || f[p] == '-') { const uint32_t k = gt_signed_offset(f, p, b); if (!k) return false; p += k; break; }  // zones that only have "+03"
         uint32_t j = 0;
         while (p + j < b && j < 6 && f[p + j] >= 'A' && f[p + j] <= 'Z') j++;
         if (j < 3 || j > 5) return false;
         if (j == 5 && f[p + 4] != 'T') return false;
         if (j == 4 && !(f[p + 3] == 'T' || (f[p] == 'W' && f[p + 1] == 'I' && f[p + 2] == 'T' && f[p + 3] == 'A'))) return false;
-        if (j == 3 && f[p] == 'G' && f[p + 1] == 'M' && f[p + 2] == 'T') {
-          p += 3;
-          if (p < b && (f[p] == '+' || f[p] == '-')) {
-            uint32_t k = 1; int hv = 0;
-            while (p + k < b && gt_digit(f[p + k])) { hv = hv * 10 + (int)(f[p + k] - '0'); k++; }
-            if (k > 1 && hv <= 23) p += k;
-          }
-          break;
-        }
         p += j;
         break;
       }
@@ -261,9 +283,15 @@ template <class F> __device__ bool gotime_parse(const GtOp *ops, int nops, const
   }
   if (pm_set) { if (pm && hour < 12) hour += 12; else if (!pm && hour == 12) hour = 0; }
   if (!have_year) year = 0;
-  if (yday >= 0) {
-    if (yday < 1 || yday > 365 + (gt_days_in(2, year) == 29 ? 1 : 0)) return false;
-    if (month < 0) { int m = 1, d = yday; while (d > gt_days_in(m, year)) { d -= gt_days_in(m, year); m++; } month = m; day = d; }
+  if (yday >= 0) {  // the day of the year decides month and day; what the value also gave must agree
+    int m = 0, d = 0;
+    if (gt_days_in(2, year) == 29) { if (yday == 31 + 29) { m = 2; d = 29; } else if (yday > 31 + 29) yday--; }
+    if (yday < 1 || yday > 365) return false;
+    if (m == 0) { m = 1; d = yday; while (d > gt_days_in(m, 1)) { d -= gt_days_in(m, 1); m++; } }  // (a common year's months: the leap day is out already)
+    if (month >= 0 && month != m) return false;
+    month = m;
+    if (day >= 0 && day != d) return false;
+    day = d;
   } else {
     if (month < 0) month = 1;
     if (day < 0) day = 1;
