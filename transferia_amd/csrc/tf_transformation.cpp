@@ -128,13 +128,17 @@ struct Executor {
   std::condition_variable cv;
   std::deque<std::function<void()>> q;
   std::vector<std::thread> workers;
+  int alive = 0, failed = 0;  // workers bound to a lane / workers whose lane could not be bound (under mu)
   bool stop = false;
   void start(int n) {
     std::lock_guard<std::mutex> lk(mu);
     while ((int)workers.size() < n) {
       const int lane = 1 + (int)workers.size();  // lane 0 stays with the caller's synchronous calls
       workers.emplace_back([this, lane] {
-        if (tfgpu_lane_use(lane % tfgpu_lane_count()) != TFGPU_OK) return;
+        const bool bound = tfgpu_lane_use(lane % tfgpu_lane_count()) == TFGPU_OK;
+        { std::lock_guard<std::mutex> lk2(mu); if (bound) alive++; else failed++; }
+        cv.notify_all();
+        if (!bound) return;  // (a job is never left waiting for this worker: submit() refuses when nobody is alive)
         for (;;) {
           std::function<void()> job;
           {
@@ -148,12 +152,24 @@ struct Executor {
       });
     }
   }
-  void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+  // false: no worker could bind its lane — the job would never run
+  bool submit(std::function<void()> f) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [this] { return alive > 0 || failed >= (int)workers.size(); });  // until the first worker reports in
+      if (alive == 0) return false;
+      q.push_back(std::move(f));
+    }
+    cv.notify_one();
+    return true;
+  }
+  bool empty() { std::lock_guard<std::mutex> lk(mu); return workers.empty(); }
   void shutdown() {
     { std::lock_guard<std::mutex> lk(mu); stop = true; }
     cv.notify_all();
     for (auto &w : workers) if (w.joinable()) w.join();
-    workers.clear(); stop = false;
+    std::lock_guard<std::mutex> lk(mu);
+    workers.clear(); stop = false; alive = 0; failed = 0;
   }
   ~Executor() { shutdown(); }
 };
@@ -229,7 +245,7 @@ int tfgpu_executor_start(int workers) {
 int tfgpu_transformation_push_async(tfgpu_transformation *t, const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_token **token) {
   TF_API_BEGIN
   if (!t || !in || !token) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_transformation_push_async: null argument");
-  if (g_exec.workers.empty()) g_exec.start(2);
+  if (g_exec.empty()) g_exec.start(2);
   auto tok = std::make_unique<tfgpu_token>();
   TF_HIP(hipEventCreateWithFlags(&tok->ready, hipEventDisableTiming));
   TF_HIP(hipEventRecord(tok->ready, ctx().stream));
@@ -240,7 +256,11 @@ int tfgpu_transformation_push_async(tfgpu_transformation *t, const tfgpu_dbatch 
   auto prom = std::make_shared<std::promise<int>>();
   tok->done = prom->get_future();
   tfgpu_token *raw = tok.get();
-  g_exec.submit([t, in, cols, has_schema, raw, prom] {
+  // the job holds its own copy of the batch (the column buffers are shared_ptr: a cheap copy): the caller may free its
+  // handle before tfgpu_wait
+  auto batch = std::make_shared<tfgpu_dbatch>(*in);
+  const bool queued = g_exec.submit([t, batch, cols, has_schema, raw, prom] {
+    const tfgpu_dbatch *in = batch.get();
     int rc = TFGPU_OK;
     try {
       TF_HIP(hipStreamWaitEvent(ctx().stream, raw->ready, 0));
@@ -252,6 +272,7 @@ int tfgpu_transformation_push_async(tfgpu_transformation *t, const tfgpu_dbatch 
     catch (const std::exception &e) { rc = TFGPU_ERR_INVALID; raw->error = e.what(); }
     prom->set_value(rc);
   });
+  if (!queued) { (void)hipEventDestroy(tok->ready); return tf::fail(TFGPU_ERR_DEVICE, "tfgpu_transformation_push_async: no executor worker could bind a device lane"); }
   *token = tok.release();
   return TFGPU_OK;
   TF_API_END

@@ -449,6 +449,15 @@ class PushToken:
         h, self._h = self._h, None
         return self._owner._collect(lambda *a: load().tfgpu_wait(h, *a), self._max)
 
+    def __del__(self):
+        # a token dropped without wait(): the job may still be running (the library keeps its own copy of the batch), and
+        # the token + its event belong to the library until tfgpu_wait takes them
+        try:
+            if self._h is not None:
+                self.wait().transformed.free()
+        except Exception:
+            pass
+
 
 class Transformation:
     """transformation (pkg/transformer/transformation.go:20-45) behind the C ABI: the transformers in config order
