@@ -240,8 +240,19 @@ int tfgpu_host_free(void *p);
 /* transformer.New(type, cfg…) — pkg/transformer/registry.go:36-47.
  * `type_name` is the YAML key ("mask_field", "filter_rows", "rename_tables",
  * "filter_columns", "skip_events", "convert_to_string", "convert_to_datetime",
- * "sharder_transformer"); `config_json` is the same JSON object the Go
- * factory receives.                                                         */
+ * "sharder_transformer", "replace_primary_key", "sql"); `config_json` is the
+ * same JSON object the Go factory receives.
+ * "sql" (pkg/transformer/registry/clickhouse/clickhouse_local.go:97-294; the
+ * reference evaluates the query in an external clickhouse-local process) has
+ * a device plan for the predicate + cast subset:
+ *   SELECT * | col | expr [AS] alias, … FROM table [WHERE col op literal
+ *   [AND …] [OR …]] with expr = integer / string literals, col ± integer,
+ *   toInt8…toUInt64(expr), toString(col), toDateTime(col)
+ * (transferia_amd/csrc/tf_sql.cpp).  A query outside it answers
+ * TFGPU_ERR_UNSUPPORTED naming the construct — the shim keeps the stock
+ * transformer for it; a malformed query answers TFGPU_ERR_CONFIG.  Apply
+ * runs Collapse first like the reference; a batch holding Updates that move
+ * their primary key (SplitUpdatedPKeys) answers TFGPU_ERR_UNSUPPORTED.      */
 int tfgpu_plan_create(const char *type_name, const char *config_json, tfgpu_plan **out);
 void tfgpu_plan_destroy(tfgpu_plan *plan);
 const char *tfgpu_plan_type(const tfgpu_plan *plan);                /* Type()        */

@@ -48,7 +48,7 @@ def test_struct_sizes():
 def test_registry_lists_reference_type_names():
     # YAML keys of the reference (pkg/transformer/registry/*/): same names, drop-in
     assert set(lib.registry()) == {"mask_field", "rename_tables", "filter_columns", "skip_events", "filter_rows",
-                                   "convert_to_string", "convert_to_datetime", "sharder_transformer", "replace_primary_key"}
+                                   "convert_to_string", "convert_to_datetime", "sharder_transformer", "replace_primary_key", "sql"}
 
 
 def _no_gpu():
@@ -77,9 +77,14 @@ def test_unknown_transformer_type():
     with pytest.raises(lib.TfgpuError) as ei:
         lib.Transformer("no_such_transformer", {})
     assert ei.value.code == lib.ERR_UNKNOWN_TYPE
-    # registered in the reference, host-only here: the shim learns it when it builds the chain (a14: `sql` runs clickhouse-local)
-    for name in ("sql", "lambda", "dbt", "number_to_float_transformer"):
+    # registered in the reference, host-only here: the shim learns it when it builds the chain
+    for name in ("lambda", "dbt", "number_to_float_transformer"):
         with pytest.raises(lib.TfgpuError) as ei:
             lib.Transformer(name, {"query": "select * from table"})
         assert ei.value.code == lib.ERR_UNSUPPORTED, name
+    # a14 `sql`: the predicate + cast subset has a device plan, anything else is refused by name (tests/test_sql.py)
+    assert lib.Transformer("sql", {"query": "select * from table"}).type() == "sql"
+    with pytest.raises(lib.TfgpuError) as ei:
+        lib.Transformer("sql", {"query": "select count() from table"})
+    assert ei.value.code == lib.ERR_UNSUPPORTED
 

@@ -15,7 +15,7 @@ namespace tf { std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &
 // blank-import list of the reference: pkg/transformer/registry/registry.go:3-20
 // (device-resident subset; see DESIGN.md for what stays on the host)
 static const char *REGISTRY[] = {"mask_field", "rename_tables", "filter_columns", "skip_events", "filter_rows",
-                                 "convert_to_string", "convert_to_datetime", "sharder_transformer", "replace_primary_key"};
+                                 "convert_to_string", "convert_to_datetime", "sharder_transformer", "replace_primary_key", "sql"};
 
 static char *dup_cstr(const std::string &s) {
   char *r = (char *)std::malloc(s.size() + 1);
@@ -24,8 +24,20 @@ static char *dup_cstr(const std::string &s) {
 }
 
 namespace tf {
+std::string type_name(int dtype) {
+  static const char *const N[] = {"", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float", "double", "boolean", "string", "utf8", "date", "datetime",
+                                  "timestamp", "interval", "any"};
+  return dtype > 0 && dtype < TFGPU_T__COUNT ? N[dtype] : "?";
+}
 void plan_result_columns(const tfgpu_plan &p, std::vector<SchemaCol> &cols) {
   std::vector<SchemaCol> out;
+  if (p.kind == PK_SQL) {  // clickhouse_local.go:351-421: the query's result columns, keys by name; a result without a key is refused
+    bool has_key = false;
+    for (const SqlOut &o : sql_resolve(p, cols)) { out.push_back(SchemaCol{o.name, o.yt, o.key ? (uint32_t)TFGPU_COL_KEY : 0u}); has_key |= o.key; }
+    if (!has_key) throw Error(TFGPU_ERR_CONFIG, "sql: result table has no primary key");
+    cols.swap(out);
+    return;
+  }
   if (p.kind == PK_REPLACE_PK) {  // replace_primary_key.go:108-131
     if (p.new_keys.size() == 1) { for (auto &c : cols) { if (p.is_new_key(c.name)) c.flags |= TFGPU_COL_KEY; else c.flags &= ~(uint32_t)TFGPU_COL_KEY; } return; }
     for (auto &k : p.new_keys) for (auto &c : cols) if (c.name == k) { SchemaCol o = c; o.flags |= TFGPU_COL_KEY; out.push_back(o); break; }
@@ -84,6 +96,25 @@ int tfgpu_plan_suitable(const tfgpu_plan *p, const char *ns, const char *name, c
 int tfgpu_plan_result_schema(const tfgpu_plan *p, const tfgpu_schema *in, tfgpu_schema **out) {
   TF_API_BEGIN
   if (!p || !in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_plan_result_schema: null argument");
+  if (p->kind == PK_SQL) {  // a new table schema: names, YT types of the ClickHouse result types, OriginalType "ch:<type>", keys by name
+    std::vector<SchemaCol> cols;
+    for (int i = 0; i < in->ncols; i++) cols.push_back(SchemaCol{in->cols[i].name ? in->cols[i].name : "", in->cols[i].dtype, in->cols[i].flags});
+    const std::vector<SqlOut> outs = sql_resolve(*p, cols);
+    bool has_key = false;
+    for (auto &o : outs) has_key |= o.key;
+    if (!has_key) return tf::fail(TFGPU_ERR_CONFIG, "sql: result table has no primary key");
+    static const char *const CH[] = {"", "Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16", "UInt32", "UInt64", "Float64", "String", "Date", "DateTime", "DateTime64(9)"};
+    auto *rs = (tfgpu_schema *)std::calloc(1, sizeof(tfgpu_schema));
+    rs->cols = (tfgpu_colschema *)std::calloc(std::max<size_t>(outs.size(), 1), sizeof(tfgpu_colschema));
+    for (auto &o : outs) {
+      tfgpu_colschema &c = rs->cols[rs->ncols++];
+      c.name = dup_cstr(o.name); c.dtype = o.yt; c.flags = o.key ? TFGPU_COL_KEY : 0u;
+      c.path = dup_cstr(""); c.original_type = dup_cstr(std::string("ch:") + CH[o.ch]);
+      c.table_schema = dup_cstr(""); c.table_name = dup_cstr(""); c.expression = dup_cstr(""); c.properties_json = nullptr;
+    }
+    *out = rs;
+    return TFGPU_OK;
+  }
   auto *s = (tfgpu_schema *)std::calloc(1, sizeof(tfgpu_schema));
   s->cols = (tfgpu_colschema *)std::calloc((size_t)std::max(in->ncols, 1), sizeof(tfgpu_colschema));
   std::vector<int> order((size_t)in->ncols);

@@ -551,12 +551,13 @@ std::unique_ptr<tfgpu_plan> make_plan(const std::string &type_name, const std::s
       for (size_t j = 0; j < i; j++)
         if (p->new_keys[i] == p->new_keys[j]) cfg_error("Can't use same keys column names twice: " + join_keys(p->new_keys));
   } else if (type_name == "sql") {
-    // clickhouse/clickhouse_local.go:97-294: the rows go through an external `clickhouse-local --query Q` process, i.e.
-    // ClickHouse's SQL engine decides the result.  The stages around it exist on the device (tfgpu_keys_changed for
-    // SplitUpdatedPKeys, tfgpu_collapse, tfgpu_serialize(TFGPU_FMT_CH_JSON_EACH_ROW) for prepareInput); the query does
-    // not, and answering with anything but ClickHouse's own evaluation would break bit-parity.  Known type, host step.
-    throw Error(TFGPU_ERR_UNSUPPORTED, "sql transformer: the query is evaluated by clickhouse-local (an external SQL engine); keep this step on the host "
-                                       "(its input stages are tfgpu_keys_changed / tfgpu_collapse / tfgpu_serialize CH JSONEachRow)");
+    // clickhouse/clickhouse_local.go:60-63, 436-452: {tables, query}.  The reference runs the query in an external
+    // clickhouse-local process; the device takes the predicate + cast subset tf_sql.cpp documents and refuses the rest by
+    // name, so such a transformer stays on the host.
+    p->kind = PK_SQL;
+    p->tables = tables_of(cfg); p->columns.init({}, {});
+    p->sql_query = cfg.s("query");
+    sql_parse(p->sql_query, *p);
   } else if (type_name == "lambda" || type_name == "dbt" || type_name == "logger" || type_name == "yt_dict_transformer" || type_name == "raw_doc_grouper" ||
              type_name == "raw_cdc_doc_grouper" || type_name == "table_splitter_transformer" || type_name == "number_to_float_transformer" ||
              type_name == "problem_item_detector" || type_name == "batch_splitter" || type_name == "filter_strm_access_log" || type_name == "jsonparser" ||
@@ -620,6 +621,8 @@ bool plan_suitable(const tfgpu_plan &p, const std::string &ns, const std::string
       for (int i = 0; i < s.ncols; i++) if (p.is_new_key(s.cols[i].name ? s.cols[i].name : "")) hits++;
       return hits == p.new_keys.size();
     }
+    case PK_SQL:  // clickhouse_local.go:335-349: the table filter decides; a result without columns / key is only warned about
+      return p.tables.match_table(ns, name);
     case PK_TO_DATETIME:  // to_datetime.go:63-76
       if (!p.tables.match_table(ns, name)) return false;
       if (p.columns.empty()) return false;
@@ -648,6 +651,7 @@ std::string plan_description(const tfgpu_plan &p) {
     case PK_FILTER_COLUMNS: return "Column filter";
     case PK_SKIP_EVENTS: return "skips the following event types";
     case PK_FILTER_ROWS: return "Transformer for filtering rows by provided filter.";
+    case PK_SQL: return "SQL transfer";  // clickhouse_local.go:430-432
     case PK_TO_STRING:
       if (p.columns.empty()) return "Transform to string all column values";
       return "Transform to string column values (include: " + trim100(join(p.columns.include_src, "|")) + ", exclude: " + trim100(join(p.columns.exclude_src, "|")) + ")";

@@ -58,7 +58,27 @@ std::vector<FTerm> parse_filter(const std::string &src);  // throws Error(TFGPU_
 
 }  // namespace tf
 
-enum PlanKind { PK_MASK, PK_RENAME, PK_FILTER_COLUMNS, PK_SKIP_EVENTS, PK_FILTER_ROWS, PK_TO_STRING, PK_TO_DATETIME, PK_SHARDER, PK_REPLACE_PK };
+enum PlanKind { PK_MASK, PK_RENAME, PK_FILTER_COLUMNS, PK_SKIP_EVENTS, PK_FILTER_ROWS, PK_TO_STRING, PK_TO_DATETIME, PK_SHARDER, PK_REPLACE_PK, PK_SQL };
+
+namespace tf {
+// ---- `sql` transformer, device subset (tf_sql.cpp) ----------------------------------------------------------------------
+enum SqlType : int32_t { SQL_PENDING = 0, SQL_I8, SQL_I16, SQL_I32, SQL_I64, SQL_U8, SQL_U16, SQL_U32, SQL_U64, SQL_F64, SQL_STRING, SQL_DATE, SQL_DATETIME, SQL_DATETIME64 };  // ClickHouse types
+enum SqlItemKind : int32_t { SQL_STAR, SQL_COLUMN, SQL_CONST_INT, SQL_CONST_STR, SQL_INT_EXPR, SQL_TO_STRING, SQL_TO_DATETIME };
+struct SqlStep { bool is_cast; int ty; int64_t addend; bool minus; };  // toIntN(...) / ± integer literal (ty: the literal's type)
+struct SqlItem {  // one entry of the select list as parsed
+  int kind = SQL_COLUMN;
+  std::string name;  // result column name (alias, or the column's own)
+  std::string src;   // source column
+  int cast = 0;      // ClickHouse type of a constant / toString / toDateTime result
+  int64_t ival = 0; std::string sval;
+  std::vector<SqlStep> steps;  // SQL_INT_EXPR: applied to the source column in order
+};
+struct SqlOp { int64_t addend; int ty; };  // v = wrap(v + addend, ty)
+struct SqlOut {  // one result column over a concrete input schema
+  int kind = SQL_COLUMN; std::string name; int src = -1; int ch = SQL_PENDING, yt = 0; bool key = false;
+  int64_t ival = 0; std::string sval; std::vector<SqlOp> ops;
+};
+}  // namespace tf
 
 struct tfgpu_plan {
   int kind = PK_MASK;
@@ -79,6 +99,10 @@ struct tfgpu_plan {
   // sharder_transformer
   int64_t shards = 1;
   bool is_random = false;
+  // sql (device subset: tf_sql.cpp); the WHERE clause is `exprs`, an OR of ANDs like filter_rows'
+  std::string sql_query;
+  std::vector<tf::SqlItem> sql_items;
+  bool sql_has_where = false;
   // replace_primary_key
   std::vector<std::string> new_keys;
   bool is_new_key(const std::string &n) const {
@@ -103,6 +127,9 @@ std::string plan_description(const tfgpu_plan &p);
 bool is_system_table(const std::string &name);
 void sha256_midstate(const uint8_t block[64], uint32_t out[8]);
 
+void sql_parse(const std::string &query, tfgpu_plan &p);                                              // tf_sql.cpp
+std::vector<SqlOut> sql_resolve(const tfgpu_plan &p, const std::vector<SchemaCol> &in);            // tf_sql.cpp
+std::string type_name(int dtype);                                                                    // YT type name of a TFGPU_T_* code
 // Apply one plan to a device batch (tf_transform.hip). `errs` collects row errors.
 struct ApplyCtx {
   std::vector<tfgpu_row_error> errs;

@@ -648,20 +648,27 @@ static void collect_row_errors(const Buf &err, const Buf &err_term, int64_t n, A
   for (int64_t r = 0; r < n; r++) if (he[(size_t)r]) ax.errs.push_back(tfgpu_row_error{r, he[(size_t)r], ax.step, err_term ? ht[(size_t)r] : -1});
 }
 
+// The predicate program (an OR of ANDs of terms) over a batch, then the compaction of the kept rows.  `check_kinds`:
+// filter_rows' rule that only Inserts may be filtered (Update / Delete rows are fatal row errors); the sql transformer
+// evaluates its WHERE on every row event.
+static std::unique_ptr<tfgpu_dbatch> run_filter(const std::vector<FExpr> &exprs, bool table_applies, bool check_kinds, const tfgpu_dbatch &in, ApplyCtx &ax);
 static std::unique_ptr<tfgpu_dbatch> apply_filter_rows(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {
   // pass-through conditions that hold for the whole batch (one table per batch)
   if (!p.tables.match_table(in.ns, in.table) || is_system_table(in.table)) {
     // impossible kinds still raise errors before the table check (filter_rows.go:103-113)
     if (!in.kind) return shallow_copy(in);
   }
-  bool table_applies = p.tables.match_table(in.ns, in.table) && !is_system_table(in.table);
+  const bool table_applies = p.tables.match_table(in.ns, in.table) && !is_system_table(in.table);
+  return run_filter(p.exprs, table_applies, true, in, ax);
+}
+static std::unique_ptr<tfgpu_dbatch> run_filter(const std::vector<FExpr> &p_exprs, bool table_applies, bool check_kinds, const tfgpu_dbatch &in, ApplyCtx &ax) {
   int64_t n = in.nrows;
   hipStream_t st = ctx().stream;
   // device program
   std::vector<DTerm> terms; std::vector<int32_t> expr_start{0};
   std::vector<int64_t> ints; std::vector<double> floats; std::vector<uint32_t> soff; std::string sdata;
   if (table_applies) {
-    for (auto &e : p.exprs) {
+    for (auto &e : p_exprs) {
       for (auto &t : e.terms) {
         DTerm d{};
         d.col = -1;
@@ -698,9 +705,9 @@ static std::unique_ptr<tfgpu_dbatch> apply_filter_rows(const tfgpu_plan &p, cons
   Buf keep = dalloc((size_t)(n + 1) * 4), err = dalloc((size_t)n + 1), eterm = dalloc((size_t)n * 4 + 4), nerr = dalloc_zero(4);
   FilterParams fp;
   fp.cols = ptr<DCol>(bcols); fp.ncols = (int32_t)cols.size(); fp.terms = ptr<DTerm>(bterms); fp.expr_start = ptr<int32_t>(bexpr);
-  fp.nexpr = table_applies ? (int32_t)p.exprs.size() : 0;
+  fp.nexpr = table_applies ? (int32_t)p_exprs.size() : 0;
   fp.ints = ptr<int64_t>(bints); fp.floats = ptr<double>(bfl); fp.str_off = ptr<uint32_t>(bsoff); fp.str_data = ptr<uint8_t>(bsd);
-  fp.kind = ptr<uint8_t>(in.kind); fp.nrows = n; fp.keep = ptr<uint32_t>(keep); fp.err = ptr<uint8_t>(err); fp.err_term = ptr<int32_t>(eterm); fp.nerr = ptr<uint32_t>(nerr);
+  fp.kind = check_kinds ? ptr<uint8_t>(in.kind) : nullptr; fp.nrows = n; fp.keep = ptr<uint32_t>(keep); fp.err = ptr<uint8_t>(err); fp.err_term = ptr<int32_t>(eterm); fp.nerr = ptr<uint32_t>(nerr);
   if (!table_applies) {
     // only the kind check applies: emulate with zero expressions and keep-all for inserts
     fp.nexpr = -1;
@@ -950,6 +957,206 @@ static std::unique_ptr<tfgpu_dbatch> apply_replace_pk(const tfgpu_plan &p, const
 }
 
 // ============================================================================
+// a14 sql — clickhouse/clickhouse_local.go:97-294, the predicate + cast subset of tf_sql.cpp
+//   Apply: SplitUpdatedPKeys → Collapse → rows as JSONEachRow (nil → the ClickHouse type's default) → query → rows back,
+//   each re-attached to the input row with the same primary key: meta, kind, and for Update / Delete the result's values as
+//   OldKeys (Delete: no column values).  Here the query is evaluated row by row on the device, so "the input row with the
+//   same key" is the row the result row came from; that is the same thing as long as the key columns pass through the
+//   select list under their own names (required below) and no key repeats in the sub-batch (Collapse sees to that).
+// ============================================================================
+std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in);        // tf_collapse.hip
+int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags);   // tf_collapse.hip
+
+struct SqlIntParams { const void *src; int32_t src_repr; const uint8_t *validity; int64_t n; int64_t addend[8]; int32_t ty[8]; int32_t nops; void *out; int32_t out_ty; };
+__device__ __forceinline__ int64_t sql_wrap(int64_t v, int ty) {
+  switch (ty) {
+    case SQL_I8: return (int8_t)v; case SQL_I16: return (int16_t)v; case SQL_I32: return (int32_t)v;
+    case SQL_U8: return (uint8_t)v; case SQL_U16: return (uint16_t)v; case SQL_U32: return (uint32_t)v;
+    default: return v;  // 64 bits either way
+  }
+}
+__global__ void __launch_bounds__(256) sql_int_kernel(SqlIntParams p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n) return;
+  int64_t v = 0;
+  const bool nil = p.validity && !((p.validity[r >> 3] >> (r & 7)) & 1);  // a nil value reaches ClickHouse as the type's default
+  if (!nil) switch (p.src_repr) {
+    case TFGPU_R_INT8: v = ((const int8_t *)p.src)[r]; break; case TFGPU_R_INT16: v = ((const int16_t *)p.src)[r]; break;
+    case TFGPU_R_INT32: v = ((const int32_t *)p.src)[r]; break; case TFGPU_R_INT64: v = ((const int64_t *)p.src)[r]; break;
+    case TFGPU_R_UINT8: case TFGPU_R_BOOL: v = ((const uint8_t *)p.src)[r]; break; case TFGPU_R_UINT16: v = ((const uint16_t *)p.src)[r]; break;
+    case TFGPU_R_UINT32: v = ((const uint32_t *)p.src)[r]; break; default: v = (int64_t)((const uint64_t *)p.src)[r];
+  }
+  for (int i = 0; i < p.nops; i++) v = sql_wrap((int64_t)((uint64_t)v + (uint64_t)p.addend[i]), p.ty[i]);
+  switch (p.out_ty) {
+    case SQL_I8: case SQL_U8: ((uint8_t *)p.out)[r] = (uint8_t)v; break;
+    case SQL_I16: case SQL_U16: ((uint16_t *)p.out)[r] = (uint16_t)v; break;
+    case SQL_I32: case SQL_U32: ((uint32_t *)p.out)[r] = (uint32_t)v; break;
+    default: ((uint64_t *)p.out)[r] = (uint64_t)v;
+  }
+}
+__global__ void __launch_bounds__(256) sql_const_text_kernel(uint32_t *off, uint8_t *data, int64_t n, const uint8_t *text, uint32_t len) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  off[r] = (uint32_t)r * len;
+  if (r < n) for (uint32_t k = 0; k < len; k++) data[(uint64_t)r * len + k] = text[k];
+}
+__global__ void __launch_bounds__(256) sql_zero_nil_kernel(uint8_t *values, int32_t width, const uint8_t *validity, int64_t n) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || ((validity[r >> 3] >> (r & 7)) & 1)) return;
+  for (int k = 0; k < width; k++) values[r * width + k] = 0;
+}
+__global__ void __launch_bounds__(256) sql_kind_bitmaps_kernel(const uint8_t *kind, int64_t n, uint8_t *has_old, uint8_t *has_cols) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * 8 >= n) return;
+  uint8_t o = 0, c = 0;
+  for (int k = 0; k < 8 && b * 8 + k < n; k++) {
+    const uint8_t kd = kind[b * 8 + k];
+    if (kd == TFGPU_K_UPDATE || kd == TFGPU_K_DELETE) o |= (uint8_t)(1u << k);
+    if (kd != TFGPU_K_DELETE) c |= (uint8_t)(1u << k);
+  }
+  has_old[b] = o; has_cols[b] = c;
+}
+static int sql_repr_of(int ch) {
+  switch (ch) {
+    case SQL_I8: return TFGPU_R_INT8; case SQL_I16: return TFGPU_R_INT16; case SQL_I32: return TFGPU_R_INT32; case SQL_I64: return TFGPU_R_INT64;
+    case SQL_U8: return TFGPU_R_UINT8; case SQL_U16: return TFGPU_R_UINT16; case SQL_U32: return TFGPU_R_UINT32; case SQL_U64: return TFGPU_R_UINT64;
+    case SQL_F64: return TFGPU_R_FLOAT64; case SQL_STRING: return TFGPU_R_STRING; default: return TFGPU_R_TIME;
+  }
+}
+
+static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_dbatch &in0, ApplyCtx &ax) {
+  hipStream_t st = ctx().stream;
+  // the input schema as ResultSchema sees it (clickhouse_local.go:351-421)
+  std::vector<SchemaCol> sc;
+  auto is_key = [&](const std::string &n) { for (auto &k : in0.key_names) if (k == n) return true; return false; };
+  if (!in0.schema.empty()) for (auto &c : in0.schema) sc.push_back(SchemaCol{c.first, c.second, is_key(c.first) ? (uint32_t)TFGPU_COL_KEY : 0u});
+  else for (auto &c : in0.cols) sc.push_back(SchemaCol{c.name, c.dtype, is_key(c.name) ? (uint32_t)TFGPU_COL_KEY : 0u});
+  const std::vector<SqlOut> outs = sql_resolve(p, sc);
+  bool has_key = false;
+  for (auto &o : outs) has_key |= o.key;
+  if (!has_key) throw Error(TFGPU_ERR_CONFIG, "sql: result table has no primary key");  // ResultSchema :417-419
+  for (auto &k : in0.key_names) {  // see the header of this section
+    bool through = false;
+    for (auto &o : outs) through |= o.kind == SQL_COLUMN && o.name == k && o.src >= 0 && sc[(size_t)o.src].name == k;
+    if (!through) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: the primary key column " + k + " must pass through the select list unchanged (the reference re-attaches row meta by key)");
+  }
+  for (auto &c : sc) if (c.dtype == TFGPU_T_FLOAT32 || c.dtype == TFGPU_T_INTERVAL) {
+    for (auto &o : outs) if (o.src >= 0 && sc[(size_t)o.src].name == c.name) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: column " + c.name + " (" + type_name(c.dtype) + ") reaches ClickHouse as text of another type: host step");
+  }
+  if (in0.nrows == 0) { auto e = shallow_copy(in0); e->cols.clear(); return e; }
+  // SplitUpdatedPKeys (utils.go:75-128): an Update that moves its primary key cuts the batch into sub-batches with a
+  // Delete + Insert pair of their own; such batches stay on the host
+  std::vector<uint8_t> kflags((size_t)in0.nrows);
+  if (in0.kind && !in0.old_keys.empty() && keys_changed_rows(in0, kflags.data()) > 0)
+    throw Error(TFGPU_ERR_UNSUPPORTED, "sql: the batch holds Updates that change their primary key (SplitUpdatedPKeys sub-batches): host step");
+  std::unique_ptr<tfgpu_dbatch> col = collapse_rows(in0);  // abstract.Collapse (last write per key wins)
+  const tfgpu_dbatch &in = *col;
+  const int64_t n0 = in.nrows;
+  {
+    std::vector<const DColumn *> need;
+    for (auto &c : in.cols) need.push_back(&c);
+    materialize(in);
+  }
+  // nil → the ClickHouse default (MarshalCItoJSON omits nil columns, JSONEachRow fills the type's default): 0 / ''
+  auto w = shallow_copy(in);
+  for (auto &c : w->cols) {
+    if (!c.validity) continue;
+    if (!repr_is_var(c.repr)) {
+      const size_t width = repr_width(c.repr);
+      Buf v = dalloc((size_t)std::max<int64_t>(n0, 1) * width);
+      TF_HIP(hipMemcpyAsync(v->p, c.values->p, (size_t)n0 * width, hipMemcpyDeviceToDevice, st));
+      if (n0) sql_zero_nil_kernel<<<grid_for(n0, 256), 256, 0, st>>>(ptr<uint8_t>(v), (int32_t)width, ptr<uint8_t>(c.validity), n0);
+      c.values = v;
+      if (c.nanos) { Buf nn = dalloc((size_t)std::max<int64_t>(n0, 1) * 4); TF_HIP(hipMemcpyAsync(nn->p, c.nanos->p, (size_t)n0 * 4, hipMemcpyDeviceToDevice, st)); if (n0) sql_zero_nil_kernel<<<grid_for(n0, 256), 256, 0, st>>>(ptr<uint8_t>(nn), 4, ptr<uint8_t>(c.validity), n0); c.nanos = nn; }
+    }
+    c.validity = nullptr;  // (a nil text cell has no bytes: it is '' already)
+  }
+  // WHERE on every row event
+  std::unique_ptr<tfgpu_dbatch> kept = p.sql_has_where ? run_filter(p.exprs, true, false, *w, ax) : std::move(w);
+  const int64_t n = kept->nrows;
+  // the select list
+  auto out = std::make_unique<tfgpu_dbatch>();
+  out->nrows = n; out->ns = kept->ns; out->table = kept->table; out->kind = kept->kind; out->src_row = kept->src_row; out->part_id = kept->part_id;
+  if (!out->src_row && p.sql_has_where) out->src_row = kept->src_row;
+  for (const SqlOut &o : outs) {
+    DColumn c;
+    const DColumn *src = nullptr;
+    if (o.src >= 0) {
+      for (auto &kc : kept->cols) if (kc.name == sc[(size_t)o.src].name) { src = &kc; break; }
+      if (!src) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: column " + sc[(size_t)o.src].name + " is in the TableSchema and not among the batch's ColumnNames");
+    }
+    switch (o.kind) {
+      case SQL_COLUMN:
+        c = *src;
+        if (o.ch == SQL_STRING) { c.repr = TFGPU_R_STRING; }                           // Restore keeps a Go string under DataType "string"
+        else if (src->repr == TFGPU_R_BOOL) { c.repr = TFGPU_R_UINT8; }                // boolean → UInt8
+        break;
+      case SQL_CONST_INT: case SQL_INT_EXPR: {
+        c.repr = sql_repr_of(o.ch);
+        const size_t width = repr_width(c.repr);
+        c.values = dalloc((size_t)std::max<int64_t>(n, 1) * width);
+        SqlIntParams ip{};
+        ip.src = src ? src->values->p : nullptr; ip.src_repr = src ? src->repr : TFGPU_R_INT64; ip.validity = nullptr; ip.n = n; ip.out = c.values->p; ip.out_ty = o.ch;
+        if (o.kind == SQL_CONST_INT) { ip.nops = 1; ip.addend[0] = o.ival; ip.ty[0] = o.ch; static const int64_t zero = 0; (void)zero; }
+        else {
+          if (o.ops.size() > 8) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: more than eight cast / arithmetic steps in one expression");
+          ip.nops = (int32_t)o.ops.size();
+          for (size_t k = 0; k < o.ops.size(); k++) { ip.addend[k] = o.ops[k].addend; ip.ty[k] = o.ops[k].ty; }
+        }
+        Buf zeros;
+        if (!src) { zeros = dalloc_zero((size_t)std::max<int64_t>(n, 1) * 8); ip.src = zeros->p; }
+        KernelTimer t("sql_int_expr");
+        if (n) sql_int_kernel<<<grid_for(n, 256), 256, 0, st>>>(ip);
+        break;
+      }
+      case SQL_CONST_STR: {
+        c.repr = TFGPU_R_STRING;
+        const uint64_t total = (uint64_t)o.sval.size() * (uint64_t)n;
+        if (total >> 32) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: a constant text column of more than 4 GiB");
+        Buf text = upload_small(o.sval.data(), o.sval.size());
+        c.offsets = dalloc((size_t)(n + 1) * 4 + 16); c.data = dalloc(total + 8); c.data_len = total;
+        sql_const_text_kernel<<<grid_for(n + 1, 256), 256, 0, st>>>(ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.data), n, ptr<uint8_t>(text), (uint32_t)o.sval.size());
+        break;
+      }
+      case SQL_TO_STRING:
+        if (repr_is_var(src->repr)) { c = *src; c.repr = TFGPU_R_STRING; }
+        else c = column_to_string(*src, n, false, 24);
+        break;
+      case SQL_TO_DATETIME:
+        if (src->repr == TFGPU_R_TIME) { c = *src; break; }
+        c.repr = TFGPU_R_TIME;
+        c.values = dalloc_zero((size_t)std::max<int64_t>(n, 1) * 8);
+        if (n && src->repr == TFGPU_R_INT32) todatetime_kernel<int32_t><<<grid_for(n, 256), 256, 0, st>>>(ptr<int32_t>(src->values), n, ptr<int64_t>(c.values));
+        else if (n && src->repr == TFGPU_R_UINT32) todatetime_kernel<uint32_t><<<grid_for(n, 256), 256, 0, st>>>(ptr<uint32_t>(src->values), n, ptr<int64_t>(c.values));
+        else if (n && (src->repr == TFGPU_R_INT64 || src->repr == TFGPU_R_UINT64)) todatetime_kernel<int64_t><<<grid_for(n, 256), 256, 0, st>>>(ptr<int64_t>(src->values), n, ptr<int64_t>(c.values));
+        else if (n) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: toDateTime() of a value that is not held as a 32 / 64-bit integer");
+        break;
+      default: throw Error(TFGPU_ERR_INVALID, "sql: internal output kind");
+    }
+    c.name = o.name; c.dtype = o.yt; c.validity = nullptr;
+    out->cols.push_back(std::move(c));
+    out->schema.emplace_back(o.name, o.yt);
+    if (o.key) out->key_names.push_back(o.name);
+  }
+  // Update / Delete: OldKeys = the result row (names and values); Delete: no column values (clickhouse_local.go:277-285)
+  if (out->kind && n) {
+    std::vector<uint8_t> hk((size_t)n);
+    d2h(hk.data(), out->kind->p, hk.size());
+    sync();
+    bool any_old = false, any_del = false;
+    for (uint8_t k : hk) { any_old |= k == TFGPU_K_UPDATE || k == TFGPU_K_DELETE; any_del |= k == TFGPU_K_DELETE; }
+    if (any_old) {
+      Buf has_old = dalloc((size_t)(n + 7) / 8 + 8), has_cols = dalloc((size_t)(n + 7) / 8 + 8);
+      sql_kind_bitmaps_kernel<<<grid_for((n + 7) / 8, 256), 256, 0, st>>>(ptr<uint8_t>(out->kind), n, ptr<uint8_t>(has_old), ptr<uint8_t>(has_cols));
+      out->old_keys = out->cols;  // buffers shared
+      out->old_present = has_old;
+      if (any_del) for (auto &c : out->cols) c.validity = has_cols;
+    }
+  }
+  return out;
+}
+
+// ============================================================================
 // hash-partition, local half (config 5): rows grouped by PartID, original order kept inside a part
 // ============================================================================
 __global__ void part_keep_kernel(const uint32_t *part_id, int64_t n, uint32_t d, uint32_t *keep) {
@@ -994,6 +1201,7 @@ std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch
     case PK_TO_DATETIME: return apply_to_datetime(p, in);
     case PK_SHARDER: return apply_sharder(p, in, nullptr);
     case PK_REPLACE_PK: return apply_replace_pk(p, in);
+    case PK_SQL: return apply_sql(p, in, ax);
   }
   throw Error(TFGPU_ERR_INVALID, "unknown plan kind");
 }
