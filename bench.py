@@ -176,6 +176,19 @@ def run_threads(fn, parts):
 # workloads: setup() stages inputs in HBM (untimed), step() is one pass, alg() the algorithmic bytes per step of each
 # kernel (SURVEY §8d per-row figures x rows), cpu() the oracle on a bounded sample
 # ----------------------------------------------------------------------------------------------------------------
+class ctypes_void:
+    """a void* out-parameter for the few raw C-ABI calls bench.py makes itself"""
+
+    def __init__(self):
+        import ctypes
+        self._p = ctypes.c_void_p()
+        self.ref = ctypes.byref(self._p)
+
+    @property
+    def value(self):
+        return self._p.value
+
+
 class Base:
     metric = ""
     scaling = "weak"
@@ -343,6 +356,33 @@ class CsvWorkload(Base):
             out["pcie_inclusive"] = res
         return out
 
+    def parity_against(self, ref, n1):
+        """One device step over the bench's shard; its output rows whose source row is below n1 against `ref`, the oracle's
+        parse + mask + filter of the first n1 rows of the same CSV."""
+        lib, abi = self.env.lib, self.env.abi
+        db, _, errs = lib.csv_parse(self.opts, self.schema, self.dbuf)
+        res = lib.apply_chain(self.plans, db)
+        out = res.transformed.download()
+        res.transformed.free(); db.free()
+        src = out.src_row if out.src_row is not None else np.arange(out.nrows, dtype=np.int32)
+        m = int(np.searchsorted(src, n1))  # kept rows are in input order
+        if m != ref.nrows or not np.array_equal(src[:m], ref.src_row):
+            return {"identical": False, "checked_input_rows": n1, "error": "kept rows differ: %d vs %d" % (m, ref.nrows)}
+        for a, b in zip(out.cols, ref.cols):
+            ok = a.name == b.name and a.repr == b.repr
+            if ok and a.repr in abi.VAR_REPRS:
+                end = int(a.offsets[m])
+                ok = np.array_equal(a.offsets[:m + 1], b.offsets[:m + 1]) and bytes(a.data[:end]) == bytes(b.data[:end])
+            elif ok:
+                ok = np.array_equal(a.values[:m], b.values[:m]) and (a.nanos is None or b.nanos is None or np.array_equal(a.nanos[:m], b.nanos[:m]))
+            if ok and (a.validity is not None or b.validity is not None):
+                va = a.validity[:m] if a.validity is not None else np.ones(m, bool)
+                vb = b.validity[:m] if b.validity is not None else np.ones(m, bool)
+                ok = np.array_equal(va, vb)
+            if not ok:
+                return {"identical": False, "checked_input_rows": n1, "error": "column %s differs" % a.name}
+        return {"identical": True, "checked_input_rows": n1, "compared_output_rows": m, "columns": len(out.cols), "row_errors": len(errs) + len(res.errors)}
+
     def cpu(self):
         e, a = self.env, self.args
         from oracle import oracle as ora
@@ -358,6 +398,13 @@ class CsvWorkload(Base):
                "note": "C restatement of the Go reference (row-oriented boxed values), not the Go binary; expect the Go binary to be ~2-3x faster per core "
                        "(BenchmarkTextFetcher: a 105-column row in ~6 us including parse)"}
         out.update(host_info())
+        # The oracle's result over these n1 rows is also the checker of the bench's own output: one more (untimed) device step,
+        # its kept rows that come from the first n1 input rows compared value for value (the product never calls the oracle;
+        # this is bench.py's cpu_baseline leg using its by-product).
+        try:
+            out["parity"] = self.parity_against(r2.batch, n1)
+        except Exception as ex:  # noqa: BLE001
+            out["parity"] = {"identical": False, "error": str(ex)[:300]}
         # leg (ii): every host core, the reference's parallelism shape for SEVERAL tables / snapshot parts (one sink pipeline each,
         # load_snapshot.go:962): independent slices, one oracle pipeline per core, each in its own process (a clean interpreter
         # forks the workers: no GIL between them, no HIP state inherited)
@@ -576,6 +623,7 @@ class Configs3Workload(Base):
         assert not errs
         host = db.download()  # packs every column; re-upload = plain resident columns, no reference to the CSV text
         db.free(); dbuf.free()
+        self.host_copy = host  # (the lanes of the d2h side measurement upload their own resident copy)
         self.db = lib.DeviceBatch.upload(host)
         self.n = self.db.nrows
         self.plans = [lib.Transformer(t, c) for t, c in self.CH]
@@ -609,6 +657,69 @@ class Configs3Workload(Base):
 
     def extra(self):
         return {"text_out_bytes_per_step": self.state["out_bytes"]}
+
+    def side_measurements(self):
+        """Never `value`: the sink leg.  Every step ends with the JSONEachRow bytes copied to PINNED host memory
+        (hipMemcpyAsync D2H on the lane's stream, the bytes httpuploader would POST: marshal.go:82-125) — on one lane, and on
+        several, where the D2H of one batch runs beside the kernels of the next (parsequeue.go:118-154: push beside parse)."""
+        e, a = self.env, self.args
+        lib, abi = e.lib, e.abi
+        if a.pcie_steps <= 0 or e.rank != 0:
+            return {}
+        cap = int(self.state["out_bytes"] * 1.05) + (1 << 20)
+        res = {}
+        for nl in sorted({1, max(1, min(a.pcie_lanes, lib.lane_count()))}):
+            pinned = []
+            for _ in range(nl):
+                hb = lib.HostBuffer.__new__(lib.HostBuffer)
+                pp = ctypes_void()
+                lib._check(lib.load().tfgpu_host_alloc(cap, pp.ref))
+                hb.ptr, hb.size = pp.value, cap
+                pinned.append(hb)
+            kk = max(a.pcie_steps, 2) * nl
+            go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
+            errs = []
+
+            def lane_main(k, pinned=pinned, nl=nl, kk=kk, go=go, done=done):
+                try:
+                    lib.lane_use(k)
+                    db = self.db if k == 0 else lib.DeviceBatch.upload(self.host_copy)
+                    def one():
+                        tr = lib.apply_chain(self.plans, db)
+                        out = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
+                        lib._check(lib.load().tfgpu_dbuf_download(out._h, pinned[k].ptr, out.size))  # D2H into pinned memory, then the lane's sync
+                        out.free(); tr.transformed.free()
+                    one()
+                    lib.synchronize()
+                    go.wait()
+                    for i in range(kk):
+                        if i % nl == k:
+                            one()
+                    lib.synchronize()
+                    done.wait()
+                    if k:
+                        db.free()
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex); go.abort(); done.abort()
+            ths = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
+            for t in ths:
+                t.start()
+            go.wait()
+            t0 = time.perf_counter()
+            done.wait()
+            dt = time.perf_counter() - t0
+            for t in ths:
+                t.join()
+            lib.lane_use(0)
+            for hb in pinned:
+                hb.free()
+            if errs:
+                res[f"lanes_{nl}"] = {"error": str(errs[0])[:200]}
+            else:
+                res[f"lanes_{nl}"] = {"rows_per_s": round(self.n * kk / dt, 1), "gb_per_s_d2h": round(self.state["out_bytes"] * kk / dt / 1e9, 2), "ms_per_step": round(dt / kk * 1e3, 3)}
+        res["note"] = ("every step's JSONEachRow text (%.2f GB) is copied to pinned host memory inside the step; with several lanes the D2H of one batch runs beside "
+                       "the kernels of another; PCIe Gen5 x16 bounds the copy at ~55-60 GB/s" % (self.state["out_bytes"] / 1e9))
+        return {"d2h_inclusive": res}
 
     def cpu(self):
         from oracle import oracle as ora
@@ -1070,8 +1181,14 @@ def main():
         out["cpu_baseline"] = cpu
         out["kernels"] = kernels
         out.update(side)
-        if cpu:
-            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        if cpu and isinstance(cpu.get("parity"), dict):
+            out["parity_checked_rows"] = cpu["parity"].get("checked_input_rows", 0) if cpu["parity"].get("identical") else 0
+        # the comparison that means something end to end: input from pinned host memory (PCIe inside) against the CPU path on
+        # every host core; the HBM-resident `value` over one CPU core is a ratio of two different jobs and is not printed
+        pc = (side.get("pcie_inclusive") or {}) if isinstance(side, dict) else {}
+        best = max((v.get("rows_per_s", 0) for k, v in pc.items() if isinstance(v, dict)), default=0)
+        if cpu and best and isinstance(cpu.get("all_cores"), dict) and cpu["all_cores"].get("value"):
+            out["pcie_inclusive_vs_cpu_all_cores"] = round(best / cpu["all_cores"]["value"], 1)
         try:  # RCCL prints its version banner through C stdio: flush that first, the JSON line is the last one
             import ctypes
             ctypes.CDLL(None).fflush(None)
