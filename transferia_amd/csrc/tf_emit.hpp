@@ -54,23 +54,46 @@ __device__ __forceinline__ uint64_t swar_has_zero(uint64_t v) { return (v - 0x01
 __device__ __forceinline__ uint64_t swar_has(uint64_t w, uint32_t c) { return swar_has_zero(w ^ (0x0101010101010101ull * c)); }
 __device__ __forceinline__ uint64_t swar_has_less(uint64_t w, uint32_t c) { return (w - 0x0101010101010101ull * c) & ~w & 0x8080808080808080ull; }
 
+// A lane's walk over one text cell, eight bytes per step.  The loads run TWO steps ahead of the bytes being looked at: the step's
+// branches depend on the bytes, so the compiler cannot start the next load before they are taken, and a cell of n bytes would
+// otherwise cost n / 8 memory round trips in a row.
+struct TextWords {
+  const uint8_t *p; uint32_t n, i = 0; uint64_t w0 = 0, w1 = 0;
+  __device__ __forceinline__ TextWords(const uint8_t *p_, uint32_t n_) : p(p_), n(n_) {
+    if (n >= 8) w0 = load8(p);
+    if (n >= 16) w1 = load8(p + 8);
+  }
+  __device__ __forceinline__ bool more() const { return i + 8 <= n; }
+  __device__ __forceinline__ uint64_t next() {  // the eight bytes at i; i moves on
+    const uint64_t w = w0;
+    w0 = w1;
+    w1 = i + 24 <= n ? load8(p + i + 16) : 0;
+    i += 8;
+    return w;
+  }
+  // the last n - i (< 8) bytes as one word; `len` receives their count
+  __device__ __forceinline__ uint64_t tail(uint32_t &len) {
+    len = n - i;
+    uint64_t w = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 7; k++) if (k < len) w |= (uint64_t)p[i + k] << (8 * k);
+    i = n;
+    return w;
+  }
+};
 template <class S> __device__ __forceinline__ void put_bytes(S &s, const uint8_t *p, uint32_t n) {
-  uint32_t i = 0;
-  for (; i + 8 <= n; i += 8) sink_word(s, load8(p + i), 8, 0);
-  if (i < n) { uint64_t w = 0; for (uint32_t k = 0; i + k < n; k++) w |= (uint64_t)p[i + k] << (8 * k); sink_word(s, w, n - i, 0); }
+  TextWords t(p, n);
+  while (t.more()) sink_word(s, t.next(), 8, 0);
+  uint32_t k; const uint64_t w = t.tail(k);
+  if (k) sink_word(s, w, k, 0);
 }
 template <class S> __device__ __forceinline__ void put_lit(S &s, const char *p) { while (*p) s.put((uint8_t)*p++); }
 __device__ __forceinline__ uint32_t hexc(uint32_t n) { return n + (n < 10 ? '0' : 'a' - 10); }
 
 // writeQuoted (marshal.go:377-419)
-template <class S> __device__ __forceinline__ void emit_ch_quoted(S &s, const uint8_t *p, uint32_t n) {
-  s.put('"');
-  for (uint32_t i = 0; i < n; i++) {
-    if (i + 8 <= n) {  // eight bytes that need no escaping at once
-      const uint64_t w = load8(p + i);
-      if (!(swar_has_less(w, 0x20) | swar_has(w, '"') | swar_has(w, '\\'))) { sink_word(s, w, 8, 0); i += 7; continue; }
-    }
-    const uint32_t c = p[i];
+template <class S> __device__ __forceinline__ void ch_quoted_bytes(S &s, uint64_t w, uint32_t k) {  // the low k bytes of w, one by one
+  for (uint32_t b = 0; b < k; b++) {
+    const uint32_t c = (uint32_t)(w >> (8 * b)) & 0xFFu;
     if (c >= 0x20 && c != '"' && c != '\\') { s.put(c); continue; }
     s.put('\\');
     switch (c) {
@@ -79,6 +102,17 @@ template <class S> __device__ __forceinline__ void emit_ch_quoted(S &s, const ui
       default: s.put('u'); s.put('0'); s.put('0'); s.put(hexc(c >> 4)); s.put(hexc(c & 15));
     }
   }
+}
+template <class S> __device__ __forceinline__ void emit_ch_quoted(S &s, const uint8_t *p, uint32_t n) {
+  s.put('"');
+  TextWords t(p, n);
+  while (t.more()) {
+    const uint64_t w = t.next();
+    if (!(swar_has_less(w, 0x20) | swar_has(w, '"') | swar_has(w, '\\'))) sink_word(s, w, 8, 0);  // eight bytes that need no escaping at once
+    else ch_quoted_bytes(s, w, 8);
+  }
+  uint32_t k; const uint64_t w = t.tail(k);
+  if (k) { if (!(swar_has_less(w | (~0ull << (8 * k)), 0x20) | swar_has(w, '"') | swar_has(w, '\\'))) sink_word(s, w, k, 0); else ch_quoted_bytes(s, w, k); }
   s.put('"');
 }
 
@@ -200,69 +234,88 @@ template <class S> __device__ __forceinline__ void emit_time_string(S &s, int64_
   for (int i = 0; i < 10; i++) s.put((uint32_t)tail[i]);
 }
 
+// The fixed-size part of one cell — value bits (or the text cell's two offsets), nanoseconds, validity — as one load group.
+// The serializers' chunk walks issue the groups of a whole chunk before the first cell is formatted: formatting is a chain of
+// data-dependent branches the compiler cannot move a load across, and a lane that loads, formats, loads, formats pays a full
+// HBM round trip per cell.
+struct CellBits {
+  uint64_t v;     // fixed-width reprs: the value as stored, zero-extended; text reprs: begin | end << 32
+  int32_t ns;     // TIME: nanoseconds
+  bool valid;
+};
+__device__ __forceinline__ CellBits load_cell(const DCol &c, int64_t r) {
+  CellBits b; b.v = 0; b.ns = 0;
+  b.valid = is_valid(c, r);
+  if (c.offsets) b.v = (uint64_t)c.offsets[r] | ((uint64_t)c.offsets[r + 1] << 32);
+  else switch (c.repr) {
+    case TFGPU_R_INT8: case TFGPU_R_UINT8: case TFGPU_R_BOOL: b.v = ((const uint8_t *)c.values)[r]; break;
+    case TFGPU_R_INT16: case TFGPU_R_UINT16: b.v = ((const uint16_t *)c.values)[r]; break;
+    case TFGPU_R_INT32: case TFGPU_R_UINT32: case TFGPU_R_FLOAT32: b.v = ((const uint32_t *)c.values)[r]; break;
+    case TFGPU_R_INT64: case TFGPU_R_UINT64: case TFGPU_R_FLOAT64: case TFGPU_R_DURATION: b.v = ((const uint64_t *)c.values)[r]; break;
+    case TFGPU_R_TIME: b.v = ((const uint64_t *)c.values)[r]; if (c.nanos) b.ns = c.nanos[r]; break;
+    default: break;
+  }
+  return b;
+}
+__device__ __forceinline__ const uint8_t *cell_text(const DCol &c, const CellBits &b, uint32_t &n) {
+  if (!c.offsets) { n = 0; return nullptr; }
+  const uint32_t o = (uint32_t)b.v;
+  n = (uint32_t)(b.v >> 32) - o;
+  return c.data + o;
+}
+__device__ __forceinline__ double cell_f64(const DCol &c, const CellBits &b) {
+  return c.repr == TFGPU_R_FLOAT32 ? (double)__uint_as_float((uint32_t)b.v) : __longlong_as_double((long long)b.v);
+}
+
 // strconv.FormatFloat(f, 'f', -1, bits) of a float column's value
-template <class S> __device__ __forceinline__ void emit_float_f(S &s, const DCol &c, int64_t r) {
-  if (c.repr == TFGPU_R_FLOAT32) dev::fmt_float(s, (double)((const float *)c.values)[r], 'f', 32);
-  else dev::fmt_float(s, ((const double *)c.values)[r], 'f', 64);
+template <class S> __device__ __forceinline__ void emit_float_f(S &s, const DCol &c, const CellBits &b) {
+  dev::fmt_float(s, cell_f64(c, b), 'f', c.repr == TFGPU_R_FLOAT32 ? 32 : 64);
 }
 
 // json.Marshal(float): encoding/json's floatEncoder
-template <class S> __device__ __forceinline__ void emit_float_json(S &s, const DCol &c, int64_t r) {
-  if (c.repr == TFGPU_R_FLOAT32) dev::fmt_json_float(s, (double)((const float *)c.values)[r], 32);
-  else dev::fmt_json_float(s, ((const double *)c.values)[r], 64);
+template <class S> __device__ __forceinline__ void emit_float_json(S &s, const DCol &c, const CellBits &b) {
+  dev::fmt_json_float(s, cell_f64(c, b), c.repr == TFGPU_R_FLOAT32 ? 32 : 64);
 }
 
 // The integer Go types as decimal text; returns false if the column is not an integer repr.
-template <class S> __device__ __forceinline__ bool emit_int(S &s, const DCol &c, int64_t r) {
-  {  // the usual case: fewer than nine digits
-    int64_t v; bool is_int = true;
-    switch (c.repr) {
-      case TFGPU_R_INT8: v = ((const int8_t *)c.values)[r]; break;
-      case TFGPU_R_INT16: v = ((const int16_t *)c.values)[r]; break;
-      case TFGPU_R_INT32: v = ((const int32_t *)c.values)[r]; break;
-      case TFGPU_R_INT64: v = ((const int64_t *)c.values)[r]; break;
-      case TFGPU_R_UINT8: v = ((const uint8_t *)c.values)[r]; break;
-      case TFGPU_R_UINT16: v = ((const uint16_t *)c.values)[r]; break;
-      case TFGPU_R_UINT32: v = ((const uint32_t *)c.values)[r]; break;
-      default: is_int = false; v = 0;
-    }
-    if (is_int && v > -100000000ll && v < 100000000ll) { emit_dec8(s, (uint32_t)(v < 0 ? -v : v), v < 0); return true; }
-  }
+template <class S> __device__ __forceinline__ bool emit_int(S &s, const DCol &c, const CellBits &b) {
+  int64_t v;
   switch (c.repr) {
-    case TFGPU_R_INT8: emit_i64(s, ((const int8_t *)c.values)[r]); break;
-    case TFGPU_R_INT16: emit_i64(s, ((const int16_t *)c.values)[r]); break;
-    case TFGPU_R_INT32: emit_i64(s, ((const int32_t *)c.values)[r]); break;
-    case TFGPU_R_INT64: emit_i64(s, ((const int64_t *)c.values)[r]); break;
-    case TFGPU_R_UINT8: emit_u64(s, ((const uint8_t *)c.values)[r]); break;
-    case TFGPU_R_UINT16: emit_u64(s, ((const uint16_t *)c.values)[r]); break;
-    case TFGPU_R_UINT32: emit_u64(s, ((const uint32_t *)c.values)[r]); break;
-    case TFGPU_R_UINT64: emit_u64(s, ((const uint64_t *)c.values)[r]); break;
+    case TFGPU_R_INT8: v = (int8_t)b.v; break;
+    case TFGPU_R_INT16: v = (int16_t)b.v; break;
+    case TFGPU_R_INT32: v = (int32_t)b.v; break;
+    case TFGPU_R_INT64: v = (int64_t)b.v; break;
+    case TFGPU_R_UINT8: case TFGPU_R_UINT16: case TFGPU_R_UINT32: v = (int64_t)b.v; break;  // zero-extended by the load
+    case TFGPU_R_UINT64: emit_u64(s, b.v); return true;
     default: return false;
   }
+  if (v > -100000000ll && v < 100000000ll) emit_dec8(s, (uint32_t)(v < 0 ? -v : v), v < 0);  // the usual case: fewer than nine digits
+  else emit_i64(s, v);
   return true;
 }
 
 // json.Marshal of one Go value held in a column cell (the encoding/json serializer's values, and the elements of
 // Collapse's key arrays): nil → null, []byte → base64, time.Time → RFC 3339, json.Number / pre-marshalled `any` verbatim.
-template <class S> __device__ __forceinline__ void emit_json_cell(S &s, const DCol &c, int64_t r, int any_as_string, bool html) {
-  if (!is_valid(c, r)) { put_lit(s, "null"); return; }
-  const uint8_t *vp = nullptr; uint32_t vn = 0;
-  if (c.offsets) { vp = c.data + c.offsets[r]; vn = c.offsets[r + 1] - c.offsets[r]; }
-  uint8_t t[64];
+template <class S> __device__ __forceinline__ void emit_json_cell(S &s, const DCol &c, const CellBits &b, int any_as_string, bool html) {
+  if (!b.valid) { put_lit(s, "null"); return; }
+  uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
   switch (c.repr) {
-    case TFGPU_R_BOOL: put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); return;
+    case TFGPU_R_BOOL: put_lit(s, (uint8_t)b.v ? "true" : "false"); return;
     case TFGPU_R_STRING: emit_json_string(s, vp, vn, html); return;
     case TFGPU_R_BYTES: s.put('"'); emit_base64(s, vp, vn); s.put('"'); return;
     case TFGPU_R_JSONNUM: if (vn) put_bytes(s, vp, vn); else s.put('0'); return;
-    case TFGPU_R_TIME: s.put('"'); emit_rfc3339nano(s, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); s.put('"'); return;
-    case TFGPU_R_DURATION: emit_i64(s, ((const int64_t *)c.values)[r]); return;
+    case TFGPU_R_TIME: s.put('"'); emit_rfc3339nano(s, (int64_t)b.v, b.ns); s.put('"'); return;
+    case TFGPU_R_DURATION: emit_i64(s, (int64_t)b.v); return;
     case TFGPU_R_JSON:
       if (c.dtype == TFGPU_T_ANY && any_as_string) emit_json_string(s, vp, vn, html);
       else put_bytes(s, vp, vn);
       return;
-    case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_json(s, c, r); return;
-    default: emit_int(s, c, r);
+    case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_json(s, c, b); return;
+    default: emit_int(s, c, b);
   }
+}
+template <class S> __device__ __forceinline__ void emit_json_cell(S &s, const DCol &c, int64_t r, int any_as_string, bool html) {
+  emit_json_cell(s, c, load_cell(c, r), any_as_string, html);
 }
 
 }  // namespace tf

@@ -66,20 +66,18 @@ struct SerParams {
 __device__ __forceinline__ int64_t pow10_i64(int k) { int64_t r = 1; while (k-- > 0) r *= 10; return r; }
 
 // ---- one value, ClickHouse JSONEachRow (marshalValue).  Returns false when the column is skipped. ----
-template <class S> __device__ __forceinline__ bool emit_ch_value(S &s, const SCol &sc, int64_t r, int any_as_string) {
+template <class S> __device__ __forceinline__ bool emit_ch_value(S &s, const SCol &sc, const CellBits &b, int any_as_string) {
   const DCol &c = sc.c;
   const bool is_text = c.repr == TFGPU_R_STRING || c.repr == TFGPU_R_BYTES;
-  const uint8_t *vp = nullptr; uint32_t vn = 0;
-  if (c.offsets) { vp = c.data + c.offsets[r]; vn = c.offsets[r + 1] - c.offsets[r]; }
+  uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
   const uint32_t fl = sc.ch_flags;
   if ((fl & TFGPU_CH_DECIMAL) && is_text) { put_bytes(s, vp, vn); return true; }
-  uint8_t t[64];
   switch (c.dtype) {
     case TFGPU_T_INT8: case TFGPU_T_INT16: case TFGPU_T_INT32: case TFGPU_T_INT64: case TFGPU_T_UINT8: case TFGPU_T_UINT16:
     case TFGPU_T_UINT32: case TFGPU_T_UINT64: case TFGPU_T_FLOAT32: case TFGPU_T_FLOAT64: case TFGPU_T_INTERVAL: {
       const bool q = fl & TFGPU_CH_STRING;
-      if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) { if (q) s.put('"'); emit_int(s, c, r); if (q) s.put('"'); return true; }
-      if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { if (q) s.put('"'); emit_float_f(s, c, r); if (q) s.put('"'); return true; }
+      if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) { if (q) s.put('"'); emit_int(s, c, b); if (q) s.put('"'); return true; }
+      if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { if (q) s.put('"'); emit_float_f(s, c, b); if (q) s.put('"'); return true; }
       if (c.repr == TFGPU_R_JSONNUM) {
         if (q) s.put('"');
         const int o = jsonnum_overflow(vp, vn);
@@ -98,11 +96,11 @@ template <class S> __device__ __forceinline__ bool emit_ch_value(S &s, const SCo
       }
       break;
     case TFGPU_T_BOOLEAN:
-      if (c.repr == TFGPU_R_BOOL) { put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); return true; }
+      if (c.repr == TFGPU_R_BOOL) { put_lit(s, (uint8_t)b.v ? "true" : "false"); return true; }
       break;
     case TFGPU_T_DATE: case TFGPU_T_DATETIME: case TFGPU_T_TIMESTAMP:
       if (c.repr == TFGPU_R_TIME) {  // marshalTime :65-80
-        const int64_t sec = ((const int64_t *)c.values)[r]; const int32_t ns = c.nanos ? c.nanos[r] : 0;
+        const int64_t sec = (int64_t)b.v; const int32_t ns = b.ns;
         if (fl & TFGPU_CH_STRING) { s.put('"'); emit_time_string(s, sec, ns); s.put('"'); }
         else if (fl & TFGPU_CH_DATETIME64) {
           int64_t full = sec * 1000000000LL + ns;
@@ -124,10 +122,10 @@ template <class S> __device__ __forceinline__ bool emit_ch_value(S &s, const SCo
   }
   // json.Marshal(v) of the remaining Go types, double-marshalled when the target is a string
   const bool dbl = c.dtype != TFGPU_T_ANY || any_as_string || (fl & TFGPU_CH_STRING);
-  if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) { if (dbl) s.put('"'); emit_int(s, c, r); if (dbl) s.put('"'); return true; }
-  if (c.repr == TFGPU_R_BOOL) { if (dbl) s.put('"'); put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); if (dbl) s.put('"'); return true; }
-  if (c.repr == TFGPU_R_DURATION) { if (dbl) s.put('"'); emit_i64(s, ((const int64_t *)c.values)[r]); if (dbl) s.put('"'); return true; }
-  if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { if (dbl) s.put('"'); emit_float_json(s, c, r); if (dbl) s.put('"'); return true; }
+  if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) { if (dbl) s.put('"'); emit_int(s, c, b); if (dbl) s.put('"'); return true; }
+  if (c.repr == TFGPU_R_BOOL) { if (dbl) s.put('"'); put_lit(s, (uint8_t)b.v ? "true" : "false"); if (dbl) s.put('"'); return true; }
+  if (c.repr == TFGPU_R_DURATION) { if (dbl) s.put('"'); emit_i64(s, (int64_t)b.v); if (dbl) s.put('"'); return true; }
+  if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { if (dbl) s.put('"'); emit_float_json(s, c, b); if (dbl) s.put('"'); return true; }
   if (c.repr == TFGPU_R_JSONNUM || c.repr == TFGPU_R_JSON) {
     if (c.repr == TFGPU_R_JSONNUM && vn == 0) { if (dbl) s.put('"'); s.put('0'); if (dbl) s.put('"'); return true; }  // json.Number("") encodes as 0
     if (vn == 4 && vp[0] == 'n' && vp[1] == 'u' && vp[2] == 'l' && vp[3] == 'l') return false;  // value is null: skip the column
@@ -138,16 +136,17 @@ template <class S> __device__ __forceinline__ bool emit_ch_value(S &s, const SCo
 }
 
 // ---- one value, encoding/json (jsonSerializer) ----
-template <class S> __device__ __forceinline__ void emit_json_value(S &s, const SCol &sc, int64_t r, int any_as_string) {
+template <class S> __device__ __forceinline__ void emit_json_value(S &s, const SCol &sc, const CellBits &b, int any_as_string) {
   const DCol &c = sc.c;
   // the batch / stream serializers strictify first (serializer/strictify.go:24-36): a Go string under "string" becomes []byte
   // (castx.ToByteSliceE), a Go float under "double" becomes json.Number(FormatFloat(v, 'f', -1, bits)) (caste.go:36-49, 59-62)
-  if (c.dtype == TFGPU_T_BYTES && c.repr == TFGPU_R_STRING && is_valid(c, r)) {
-    s.put('"'); emit_base64(s, c.data + c.offsets[r], c.offsets[r + 1] - c.offsets[r]); s.put('"');
+  if (c.dtype == TFGPU_T_BYTES && c.repr == TFGPU_R_STRING && b.valid) {
+    uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
+    s.put('"'); emit_base64(s, vp, vn); s.put('"');
     return;
   }
-  if (c.dtype == TFGPU_T_FLOAT64 && (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) && is_valid(c, r)) { emit_float_f(s, c, r); return; }
-  emit_json_cell(s, c, r, any_as_string, false);  // SetEscapeHTML(false), json_format.go
+  if (c.dtype == TFGPU_T_FLOAT64 && (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) && b.valid) { emit_float_f(s, c, b); return; }
+  emit_json_cell(s, c, b, any_as_string, false);  // SetEscapeHTML(false), json_format.go
 }
 
 // bytes a Marshaler returned, as json.Marshal's compact(escapeHTML) leaves them: <, >, & and U+2028/9 become \uXXXX
@@ -175,11 +174,10 @@ __device__ bool csv_needs_quotes(const uint8_t *p, uint32_t n) {  // Writer.fiel
   }
   return false;
 }
-template <class S> __device__ __forceinline__ void emit_csv_field(S &s, const SCol &sc, int64_t r) {
+template <class S> __device__ __forceinline__ void emit_csv_field(S &s, const SCol &sc, const CellBits &b) {
   const DCol &c = sc.c;
-  if (!is_valid(c, r)) return;  // nil → ""
-  const uint8_t *vp = nullptr; uint32_t vn = 0;
-  if (c.offsets) { vp = c.data + c.offsets[r]; vn = c.offsets[r + 1] - c.offsets[r]; }
+  if (!b.valid) return;  // nil → ""
+  uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
   uint8_t t[64];
   if (c.dtype == TFGPU_T_BYTES) { emit_base64(s, vp, vn); return; }  // []byte, or a Go string strictified to it (host-checked)
   if (c.dtype == TFGPU_T_ANY && c.repr == TFGPU_R_JSON) {  // json.Marshal(value): unlike the JSON serializer's Encoder it escapes HTML
@@ -196,11 +194,11 @@ template <class S> __device__ __forceinline__ void emit_csv_field(S &s, const SC
       if (csv_needs_quotes(vp, vn)) { s.put('"'); CsvQuoteSink<S> q{s}; put_bytes(q, vp, vn); s.put('"'); }
       else put_bytes(s, vp, vn);
       return;
-    case TFGPU_R_BOOL: put_lit(s, ((const uint8_t *)c.values)[r] ? "true" : "false"); return;
-    case TFGPU_R_TIME: emit_time_string(s, ((const int64_t *)c.values)[r], c.nanos ? c.nanos[r] : 0); return;  // fmt.Stringer
-    case TFGPU_R_DURATION: { int n = dev::fmt_duration(t, ((const int64_t *)c.values)[r]); emit_small(s, t, n); return; }
-    case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_f(s, c, r); return;
-    default: emit_int(s, c, r);
+    case TFGPU_R_BOOL: put_lit(s, (uint8_t)b.v ? "true" : "false"); return;
+    case TFGPU_R_TIME: emit_time_string(s, (int64_t)b.v, b.ns); return;  // fmt.Stringer
+    case TFGPU_R_DURATION: { int n = dev::fmt_duration(t, (int64_t)b.v); emit_small(s, t, n); return; }
+    case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: emit_float_f(s, c, b); return;
+    default: emit_int(s, c, b);
   }
 }
 
@@ -270,30 +268,17 @@ template <class S> __device__ __forceinline__ bool emit_cell(S &s, const SerPara
       CountSink probe;  // a column whose value marshals to null is dropped together with its key
       (void)probe;
       put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
-      return emit_ch_value(s, sc, r, p.any_as_string);
+      return emit_ch_value(s, sc, load_cell(sc.c, r), p.any_as_string);
     }
     case TFGPU_FMT_JSON:
       put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
-      emit_json_value(s, sc, r, p.any_as_string);
+      emit_json_value(s, sc, load_cell(sc.c, r), p.any_as_string);
       return true;
     default:
       put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
-      emit_csv_field(s, sc, r);
+      emit_csv_field(s, sc, load_cell(sc.c, r));
       return true;
   }
-}
-
-// the same with the format fixed at compile time and no queue formats: the tile kernels instantiate one format each, which
-// keeps the other formats' code (and the registers it would spill) out of their loops
-template <int FMT, class S> __device__ __forceinline__ bool emit_cell_fmt(S &s, const SerParams &p, const SCol &sc, int64_t r) {
-  if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) {
-    if (!is_valid(sc.c, r)) return false;
-    put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
-    return emit_ch_value(s, sc, r, p.any_as_string);
-  }
-  put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
-  if (FMT == TFGPU_FMT_JSON) emit_json_value(s, sc, r, p.any_as_string); else emit_csv_field(s, sc, r);
-  return true;
 }
 
 // (1) cell lengths; item = column * nrows + row
@@ -381,153 +366,219 @@ __global__ void __launch_bounds__(256) ser_row_frame(SerParams p) {
   if (nl) row[len - 1] = '\n';
 }
 
-// (4') cells at their final position, one workgroup per run of consecutive rows, the run's text assembled in LDS first.
-// ser_cell_write scatters: a cell's ~20 bytes land in the middle of a row that 100 other lanes fill at other times, so HBM
-// sees every 8-byte store as its own masked partial write (measured on configs[3]: 19 GB of writes for 2.5 GB of text, the
-// kernel bound by that).  Here the lanes drop their bytes into an LDS image of the run (disjoint bytes OR-ed into zeroed
-// words: no alignment rules, no ordering) and the image leaves as whole aligned words, 512 consecutive bytes per wave store.
-// Runs whose text exceeds the image are written the old way by the same workgroup.
-constexpr uint32_t TILE_WORDS = 12288;  // 48 KiB image: three workgroups per CU
-TF_DYNAMIC_LDS(uint32_t, img);           // dynamic LDS, named at file scope so that the sink's atomics are ds_or_b32 (through a
-                                          // pointer member they compile to flat_atomic_or: the flat path, several times slower)
+// ---- the text formats' passes: chunk walks ---------------------------------------------------------------------------
+// A row is cut into CHUNKS of consecutive columns (the host picks the cuts so that a chunk is ~130 bytes of text per row).
+// One wave = 64 consecutive rows x one chunk, lane = row: the lane WALKS its chunk's cells in column order with one sink —
+// the column descriptor is scalar, every lane of the wave runs the same column's code, value loads are coalesced — so
+//   * the length pass stores one number per (row, chunk) instead of one per cell (hits: 19 instead of 105 per row),
+//   * the write pass needs no per-cell offsets: a cell starts where the lane's previous cell ended, the sink is flushed once
+//     per chunk, and the lane's bytes go to ITS segment of the wave's LDS image with plain 8-byte stores (segments start on
+//     8-byte boundaries of the image: no sharing, no atomics, no zeroing), which then leaves as aligned 8-byte words.
+// The JSONEachRow separator moves in FRONT of the cell ('{' before the row's first present cell, ',' before the others), so
+// the prefix is a per-column constant but for its first byte and nobody has to know which column is a row's last.
+constexpr uint32_t WAVE_IMG_BYTES = 12288;   // per wave: 4 waves x 12 KiB = 48 KiB per workgroup, three workgroups per CU
+TF_DYNAMIC_LDS(uint32_t, img);               // named at file scope: the sink's stores are ds_write (through a pointer member: flat)
+
 struct LdsSink {
-  uint32_t pos; uint64_t acc = 0; uint32_t n = 0;
-  // the low k (1..8) bytes of v (upper bytes zero) at byte position pos
-  __device__ __forceinline__ void store(uint64_t v, uint32_t k) {
-    const uint32_t w = pos >> 2, a = pos & 3u, sh = a * 8;
-    atomicOr(&img[w], (uint32_t)(v << sh));
-    if (a + k > 4) atomicOr(&img[w + 1], sh ? (uint32_t)(v >> (32 - sh)) : (uint32_t)(v >> 32));
-    if (a + k > 8) atomicOr(&img[w + 2], (uint32_t)(v >> (64 - sh)));
-    pos += k;
-  }
+  uint32_t pos;                 // byte offset in img, a multiple of 8
+  uint64_t acc = 0; uint32_t n = 0;
+  __device__ __forceinline__ void store() { img[pos >> 2] = (uint32_t)acc; img[(pos >> 2) + 1] = (uint32_t)(acc >> 32); pos += 8; }
   __device__ __forceinline__ void put(uint32_t c) {
     acc |= (uint64_t)(c & 0xFFu) << (8 * n);
-    if (++n == 8) { store(acc, 8); acc = 0; n = 0; }
+    if (++n == 8) { store(); acc = 0; n = 0; }
   }
   __device__ __forceinline__ void put_word(uint64_t w, uint32_t k) {
     acc |= w << (8 * n);
     const uint32_t t = n + k;
-    if (t >= 8) { store(acc, 8); acc = n ? w >> (8 * (8 - n)) : 0; n = t - 8; } else n = t;
+    if (t >= 8) { store(); acc = (w >> 1) >> (63 - 8 * n); n = t - 8; } else n = t;  // (w >> 1) >> 63 == 0 when nothing was held
   }
-  __device__ __forceinline__ void flush() { if (n) { store(acc, n); acc = 0; n = 0; } }
+  __device__ __forceinline__ void flush() { if (n) store(); }
 };
-// One workgroup = 64 consecutive rows x one chunk of consecutive columns.  Every wave keeps the scatter kernel's shape — one
-// column per step, lane = row: uniform control flow, scalar column descriptors, coalesced value loads — but the bytes go to the
-// LDS image, where the chunk's cells of one row form one contiguous SEGMENT; the segments then leave as aligned 8-byte words.
-template <int FMT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) ser_tile_write(SerParams p, int32_t cols_per_chunk, int32_t nchunks, uint32_t *big, uint32_t *nbig) {
-  __shared__ uint32_t seg_at[65], seg_src[64];   // segment rr: image bytes [seg_at[rr], seg_at[rr+1]), row bytes from seg_src[rr]
-  const int64_t r0 = (int64_t)(blockIdx.x / nchunks) * 64;
-  const int32_t c0 = (int32_t)(blockIdx.x % nchunks) * cols_per_chunk, c1 = min(p.ncols, c0 + cols_per_chunk);
-  const int nr = (int)(p.nrows - r0 < 64 ? p.nrows - r0 : 64);
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: the column descriptor stays in SGPRs
-  if (wave == 0) {
-    uint32_t s = 0, len = 0;
-    if (lane < nr) {
-      const int64_t r = r0 + lane;
-      s = c0 == 0 ? 0u : p.cell[(int64_t)c0 * p.nrows + r];
-      const uint32_t e = c1 == p.ncols ? p.row_len[r + 1] - p.row_len[r] : p.cell[(int64_t)c1 * p.nrows + r];
-      len = e - s;
-    }
-    const uint32_t incl = wave_scan_add(len);   // segments start on 4-byte boundaries of the image? no: packed, byte granular
-    seg_src[lane] = s; seg_at[lane] = incl - len;
-    if (lane == 63) seg_at[64] = incl;
-  }
-  __syncthreads();
-  const uint32_t bytes = seg_at[64];
-  if (bytes > TILE_WORDS * 4 - 16) {  // the tile outgrows the image: ser_tile_scatter writes it straight to HBM
-    if (t == 0) big[atomicAdd(nbig, 1u)] = blockIdx.x;
-    return;
-  }
-  for (uint32_t i = t; i < (bytes + 19) / 4; i += 256) img[i] = 0;
-  __syncthreads();
-  const int64_t r = r0 + lane;
-  const bool live = lane < nr;
-  const uint32_t row_at = live ? p.row_len[r] : 0u;
-  constexpr bool closer = FMT == TFGPU_FMT_CH_JSON_EACH_ROW;
-  for (int32_t cv = c0 + wave; cv < c1; cv += 4) {
-    const int32_t ci = __builtin_amdgcn_readfirstlane(cv);  // wave-uniform by construction; said so, the descriptor loads are scalar
-    const SCol &sc = p.cols[ci];
-    if (!live) continue;
-    if (closer && !is_valid(sc.c, r)) continue;
-    if (closer && (sc.c.repr == TFGPU_R_JSON || sc.c.repr == TFGPU_R_JSONNUM)) { CountSink probe; if (!emit_cell_fmt<FMT>(probe, p, sc, r)) continue; }
-    const uint32_t off = p.cell[(int64_t)ci * p.nrows + r];
-    LdsSink w{seg_at[lane] + (off - seg_src[lane])};
-    emit_cell_fmt<FMT>(w, p, sc, r);
-    if (closer) w.put((p.last_present[r] == ci) ? '}' : ',');
-    w.flush();
-  }
-  // the row frames (ser_row_frame): '{' belongs to the first chunk's segment, the tail to the last one's
-  if (wave == 0 && live) {
-    const uint32_t len = p.row_len[r + 1] - row_at;
-    auto byte_at = [&](uint32_t o, uint32_t c) {
-      const uint32_t q = seg_at[lane] + (o - seg_src[lane]);
-      atomicOr(&img[q >> 2], c << ((q & 3u) * 8));
-    };
-    if (c0 == 0 && FMT != TFGPU_FMT_CSV) byte_at(0, '{');
-    if (c1 == p.ncols) {
-      if (FMT == TFGPU_FMT_CSV) byte_at(len - 1, '\n');
-      else if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) { if (p.last_present[r] < 0) byte_at(len - 2, '}'); byte_at(len - 1, '\n'); }
-      else {
-        const bool nl = p.closing_newline || r + 1 < p.nrows;
-        byte_at(len - 1 - (nl ? 1 : 0), '}');
-        if (nl) byte_at(len - 1, '\n');
-      }
-    }
-  }
-  __syncthreads();
-  // segments → HBM, 16 rows per wave: bytes up to the destination's first 8-byte boundary, whole aligned words, the tail
-  auto img_byte = [&](uint32_t o) { return (uint8_t)(img[o >> 2] >> ((o & 3u) * 8)); };
-  for (int rr = wave; rr < nr; rr += 4) {
-    const uint32_t a = seg_at[rr], n = seg_at[rr + 1] - a;
-    uint8_t *dst = p.out + (uint64_t)p.row_len[r0 + rr] + seg_src[rr];
-    const uint32_t head = min((uint32_t)((8 - (reinterpret_cast<uintptr_t>(dst) & 7)) & 7), n);
-    if ((uint32_t)lane < head) dst[lane] = img_byte(a + lane);
-    const uint32_t nw = (n - head) >> 3;
-    for (uint32_t i = lane; i < nw; i += 64) {
-      const uint32_t o = a + head + i * 8, w = o >> 2, sh = (o & 3u) * 8;
-      const uint64_t lo = img[w] | ((uint64_t)img[w + 1] << 32);
-      const uint64_t v = sh ? (lo >> sh) | ((uint64_t)img[w + 2] << (64 - sh)) : lo;
-      *reinterpret_cast<uint64_t *>(dst + head + i * 8) = v;
-    }
-    const uint32_t done = head + nw * 8;
-    if (lane < 8 && done + lane < n) dst[done + lane] = img_byte(a + done + lane);
-  }
+
+struct ChunkPlan {
+  const int32_t *cut;      // [nchunks + 1] first column of every chunk
+  int32_t nchunks;
+  uint32_t *chunk;         // [nchunks][nrows]: bytes of the chunk's cells, then (ser_chunk_layout) their offset inside the row
+  const uint32_t *recs;    // [ncols][REC_WORDS]: the column records (below)
+  int32_t direct;          // measurement: 1 = every tile goes straight to HBM
+  int32_t order;           // tile order: 0 = a row group's chunks are neighbours, 1 = a chunk's row groups are
+  int64_t ngroups;         // row groups of 64
+};
+__device__ __forceinline__ void tile_of(const ChunkPlan &cp, int64_t tile, int32_t &k, int64_t &r0) {
+  if (cp.order) { k = (int32_t)(tile / cp.ngroups); r0 = (tile - (int64_t)k * cp.ngroups) * 64; }
+  else { k = (int32_t)(tile % cp.nchunks); r0 = (tile / cp.nchunks) * 64; }
+  k = __builtin_amdgcn_readfirstlane(k);
+}
+// A column's record: its descriptor and the first bytes of its prefix as 32 dwords.  The wave loads a record with ONE coalesced
+// load (lane = dword) and the fields come out of that register by v_readlane — scalars, like s_load results, but without a
+// scalar-memory round trip per field group in front of every cell (measured: ~50 s_load + s_waitcnt per 5-cell tile, two thirds
+// of the wave time waiting).
+constexpr int REC_WORDS = 32, REC_PREFIX_WORD = 16, REC_PREFIX_BYTES = 32;
+enum { RW_VALUES = 0, RW_OFFSETS = 2, RW_DATA = 4, RW_NANOS = 6, RW_VALIDITY = 8, RW_REPR = 10, RW_DTYPE = 11, RW_PRE_OFF = 12, RW_PRE_LEN = 13, RW_CH_FLAGS = 14, RW_PREC = 15 };
+__device__ __forceinline__ uint32_t rec_word(uint32_t rec, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)rec, k); }
+__device__ __forceinline__ uint64_t rec_word64(uint32_t rec, int k) { return (uint64_t)rec_word(rec, k) | ((uint64_t)rec_word(rec, k + 1) << 32); }
+__device__ __forceinline__ DCol rec_dcol(uint32_t rec) {
+  DCol c;
+  c.values = reinterpret_cast<const void *>(rec_word64(rec, RW_VALUES));
+  c.offsets = reinterpret_cast<const uint32_t *>(rec_word64(rec, RW_OFFSETS));
+  c.data = reinterpret_cast<const uint8_t *>(rec_word64(rec, RW_DATA));
+  c.nanos = reinterpret_cast<const int32_t *>(rec_word64(rec, RW_NANOS));
+  c.validity = reinterpret_cast<const uint8_t *>(rec_word64(rec, RW_VALIDITY));
+  c.repr = (int32_t)rec_word(rec, RW_REPR); c.dtype = (int32_t)rec_word(rec, RW_DTYPE);
+  return c;
 }
 
-// the tiles ser_tile_write listed (one huge cell makes 64 rows of a chunk outgrow the image): lane per cell, scattered stores
-__global__ void __launch_bounds__(256) ser_tile_scatter(SerParams p, int32_t cols_per_chunk, int32_t nchunks, const uint32_t *big, const uint32_t *nbig) {
-  for (uint32_t k = blockIdx.x; k < *nbig; k += gridDim.x) {
-    const uint32_t tile = big[k];
-    const int64_t r0 = (int64_t)(tile / nchunks) * 64;
-    const int32_t c0 = (int32_t)(tile % nchunks) * cols_per_chunk, c1 = min(p.ncols, c0 + cols_per_chunk);
-    const int nr = (int)(p.nrows - r0 < 64 ? p.nrows - r0 : 64);
-    const bool closer = p.format == TFGPU_FMT_CH_JSON_EACH_ROW;
-    for (int it = threadIdx.x; it < (c1 - c0) * nr; it += 256) {
-      const int32_t ci = c0 + it / nr; const int64_t r = r0 + it % nr;
-      const SCol &sc = p.cols[ci];
-      if (closer && !is_valid(sc.c, r)) continue;
-      if (closer && (sc.c.repr == TFGPU_R_JSON || sc.c.repr == TFGPU_R_JSONNUM)) { CountSink probe; if (!emit_cell(probe, p, sc, r)) continue; }
-      WriteSink w{p.out + (uint64_t)p.row_len[r] + p.cell[(int64_t)ci * p.nrows + r]};
-      emit_cell(w, p, sc, r);
-      if (closer) w.put((p.last_present[r] == ci) ? '}' : ',');
-      w.flush();
+// the cells [c0, c1) of row r, in order.  `first`: JSONEachRow only — the row has emitted nothing yet.
+// Groups of WALK_AHEAD cells: the group's records, then every load of the group (validity byte, value or offsets, nanoseconds)
+// are issued before its first cell is formatted, so a lane waits for memory twice per group instead of three or four times per
+// cell.  ALL 64 lanes of the wave must run the walk (the records live across its lanes).
+constexpr int WALK_AHEAD = 8;
+template <int FMT, class S> __device__ __forceinline__ void walk_cell(S &s, const SerParams &p, uint32_t rec, const CellBits &b, bool &first) {
+  // every v_readlane up here, in uniform control flow
+  SCol sc;
+  sc.c = rec_dcol(rec);
+  sc.pre_off = rec_word(rec, RW_PRE_OFF); sc.pre_len = rec_word(rec, RW_PRE_LEN); sc.ch_flags = rec_word(rec, RW_CH_FLAGS); sc.prec = rec_word(rec, RW_PREC);
+  sc.kind = 0; sc.apply = 0;
+  uint64_t pw[REC_PREFIX_BYTES / 8];
+#pragma unroll
+  for (int w = 0; w < REC_PREFIX_BYTES / 8; w++) pw[w] = rec_word64(rec, REC_PREFIX_WORD + 2 * w);
+  if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) {
+    if (!b.valid) return;  // nil values are omitted (marshal.go:100-102)
+    if (p.ablate && (p.ablate == 1) == (sc.c.offsets != nullptr)) return;  // measurement only: 1 = no text cells, 2 = only text cells
+    // a column whose value marshals to null is dropped together with its key (only `any` columns can do it)
+    if (sc.c.repr == TFGPU_R_JSON || sc.c.repr == TFGPU_R_JSONNUM) { CountSink probe; if (!emit_ch_value(probe, sc, b, p.any_as_string)) return; }
+    pw[0] |= first ? '{' : ',';  // the record's prefix starts with a zero byte for it
+    first = false;
+  }
+  const uint32_t n = sc.pre_len;
+#pragma unroll
+  for (int w = 0; w < REC_PREFIX_BYTES / 8; w++) if (n > 8u * w) sink_word(s, pw[w], min(n - 8u * w, 8u), 0);
+  if (n > (uint32_t)REC_PREFIX_BYTES) put_bytes(s, p.blob + sc.pre_off + REC_PREFIX_BYTES, n - REC_PREFIX_BYTES);
+  if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) emit_ch_value(s, sc, b, p.any_as_string);
+  else if (FMT == TFGPU_FMT_JSON) emit_json_value(s, sc, b, p.any_as_string);
+  else emit_csv_field(s, sc, b);
+}
+template <int FMT, class S> __device__ __forceinline__ void walk_chunk(S &s, const SerParams &p, const ChunkPlan &cp, int32_t c0, int32_t c1, int64_t r, bool &first) {
+  if (FMT == TFGPU_FMT_JSON && c0 == 0) s.put('{');
+  const int lane = threadIdx.x & 63;
+  for (int32_t cg = c0; cg < c1; cg += WALK_AHEAD) {  // c0, c1 are wave-uniform (the callers say so)
+    uint32_t rec[WALK_AHEAD];
+    CellBits b[WALK_AHEAD];
+#pragma unroll
+    for (int j = 0; j < WALK_AHEAD; j++) rec[j] = cp.recs[(int64_t)min(cg + j, c1 - 1) * REC_WORDS + (lane & (REC_WORDS - 1))];
+#pragma unroll
+    for (int j = 0; j < WALK_AHEAD; j++) { b[j].v = 0; b[j].ns = 0; b[j].valid = false; if (cg + j < c1) b[j] = load_cell(rec_dcol(rec[j]), r); }
+    // ONE copy of the formatting code: the group is a register queue, shifted down by one after every cell
+    const int32_t cn = min(c1 - cg, WALK_AHEAD);
+    for (int32_t j = 0; j < cn; j++) {
+      walk_cell<FMT>(s, p, rec[0], b[0], first);
+#pragma unroll
+      for (int q = 0; q + 1 < WALK_AHEAD; q++) { b[q] = b[q + 1]; rec[q] = rec[q + 1]; }
     }
-    if ((int)threadIdx.x < nr) {
-      const int64_t r = r0 + threadIdx.x;
-      uint8_t *row = p.out + p.row_len[r];
-      const uint32_t len = p.row_len[r + 1] - p.row_len[r];
-      if (c0 == 0 && p.format != TFGPU_FMT_CSV) row[0] = '{';
-      if (c1 == p.ncols) {
-        if (p.format == TFGPU_FMT_CSV) row[len - 1] = '\n';
-        else if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW) { if (p.last_present[r] < 0) row[len - 2] = '}'; row[len - 1] = '\n'; }
-        else {
-          const bool nl = p.closing_newline || r + 1 < p.nrows;
-          row[len - 1 - (nl ? 1 : 0)] = '}';
-          if (nl) row[len - 1] = '\n';
-        }
-      }
+  }
+}
+// what closes a row, written by the lane of the row's last chunk
+template <int FMT, class S> __device__ __forceinline__ void row_tail(S &s, const SerParams &p, int64_t r, bool first) {
+  if (FMT == TFGPU_FMT_CSV) { s.put('\n'); return; }
+  if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) { if (first) s.put('{'); s.put('}'); s.put('\n'); return; }
+  s.put('}');
+  if (p.closing_newline || r + 1 < p.nrows) s.put('\n');
+}
+
+// (1) bytes per (row, chunk)
+template <int FMT>
+__global__ void __launch_bounds__(256) ser_chunk_len(SerParams p, ChunkPlan cp) {
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int32_t k; int64_t r0;
+  tile_of(cp, tile, k, r0);
+  if (k >= cp.nchunks || r0 >= p.nrows) return;
+  const int32_t c0 = __builtin_amdgcn_readfirstlane(cp.cut[k]), c1 = __builtin_amdgcn_readfirstlane(cp.cut[k + 1]);
+  const int64_t rl = r0 + (threadIdx.x & 63), r = min(rl, p.nrows - 1);  // lanes past the end repeat the last row: the walk needs the whole wave
+  CountSink s;
+  bool first = false;
+  walk_chunk<FMT>(s, p, cp, c0, c1, r, first);
+  if (rl < p.nrows) cp.chunk[(int64_t)k * p.nrows + r] = s.n;
+}
+// (2) per row: chunk lengths → offsets inside the row, row length
+template <int FMT>
+__global__ void __launch_bounds__(256) ser_chunk_layout(SerParams p, ChunkPlan cp) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  uint32_t off = 0;
+  constexpr int U = 8;  // the lengths are requested before the first offset is stored (a load and a store to one array per step)
+  int32_t k = 0;
+  for (; k + U <= cp.nchunks; k += U) {
+    uint32_t n[U];
+#pragma unroll
+    for (int q = 0; q < U; q++) n[q] = cp.chunk[(int64_t)(k + q) * p.nrows + r];
+#pragma unroll
+    for (int q = 0; q < U; q++) { cp.chunk[(int64_t)(k + q) * p.nrows + r] = off; off += n[q]; }
+  }
+  for (; k < cp.nchunks; k++) { const uint32_t n = cp.chunk[(int64_t)k * p.nrows + r]; cp.chunk[(int64_t)k * p.nrows + r] = off; off += n; }
+  CountSink t;
+  row_tail<FMT>(t, p, r, off == 0);
+  p.row_len[r] = off + t.n;
+  atomicAdd(p.total64, (unsigned long long)(off + t.n));
+}
+// (4) the text
+template <int FMT>
+__global__ void __launch_bounds__(256) ser_chunk_write(SerParams p, ChunkPlan cp) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  int32_t k; int64_t r0;
+  tile_of(cp, tile, k, r0);
+  if (k >= cp.nchunks || r0 >= p.nrows) return;
+  const bool live = r0 + lane < p.nrows;
+  const int64_t r = min(r0 + lane, p.nrows - 1);  // lanes past the end repeat the last row, byte for byte and at the same place: the walk needs the whole wave
+  const bool last_chunk = k + 1 == cp.nchunks;
+  const uint64_t row_at = p.row_len[r];
+  const uint32_t s0 = cp.chunk[(int64_t)k * p.nrows + r];
+  const uint32_t len = (last_chunk ? p.row_len[r + 1] - (uint32_t)row_at : cp.chunk[(int64_t)(k + 1) * p.nrows + r]) - s0;
+  uint8_t *dst = p.out + row_at + s0;
+  const int32_t c0 = __builtin_amdgcn_readfirstlane(cp.cut[k]), c1 = __builtin_amdgcn_readfirstlane(cp.cut[k + 1]);
+  bool first = s0 == 0;
+  const uint32_t cap = live ? (len + 7u) & ~7u : 0u;
+  const uint32_t incl = wave_scan_add(cap);
+  const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+  if (cp.direct || total > WAVE_IMG_BYTES) {  // the tile outgrows the image (a long text cell): the same walk, straight to HBM
+    WriteSink w{dst};
+    walk_chunk<FMT>(w, p, cp, c0, c1, r, first);
+    if (last_chunk) row_tail<FMT>(w, p, r, first);
+    w.flush();
+    return;
+  }
+  const uint32_t base = wave * WAVE_IMG_BYTES;
+  const uint32_t last_at = (uint32_t)__builtin_amdgcn_readlane(incl - cap, (int)min(p.nrows - 1 - r0, (int64_t)63));  // (the whole wave reads it)
+  const uint32_t at = base + (live ? incl - cap : last_at);
+  {
+    LdsSink w{at};
+    walk_chunk<FMT>(w, p, cp, c0, c1, r, first);
+    if (last_chunk) row_tail<FMT>(w, p, r, first);
+    w.flush();
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the other lanes' image bytes
+  __builtin_amdgcn_wave_barrier();
+  // segments → HBM, four at a time (16 lanes each): bytes up to the destination's first 8-byte boundary, aligned words, the tail
+  const int sub = lane & 15, grp = lane >> 4;
+  const uint32_t dlo = (uint32_t)reinterpret_cast<uintptr_t>(dst), dhi = (uint32_t)(reinterpret_cast<uintptr_t>(dst) >> 32);
+  auto img_byte = [&](uint32_t o) { return (uint8_t)(img[o >> 2] >> ((o & 3u) * 8)); };
+  for (int it = 0; it < 16; it++) {
+    const int src = it * 4 + grp;
+    const uint32_t a = __shfl(at, src), n = __shfl(live ? len : 0u, src);
+    uint8_t *d = reinterpret_cast<uint8_t *>(((uint64_t)__shfl(dhi, src) << 32) | __shfl(dlo, src));
+    if (n == 0) continue;
+    const uint32_t head = min((uint32_t)((8 - (reinterpret_cast<uintptr_t>(d) & 7)) & 7), n);
+    if ((uint32_t)sub < head) d[sub] = img_byte(a + sub);
+    const uint32_t nw = (n - head) >> 3, sh = head * 8;   // a is a multiple of 8: every word of the segment sits at the same shift
+    for (uint32_t i = sub; i < nw; i += 16) {
+      const uint32_t w = (a >> 2) + i * 2;
+      const uint64_t lo = img[w] | ((uint64_t)img[w + 1] << 32);
+      uint64_t v = lo;
+      if (sh) { const uint64_t hi = img[w + 2] | ((uint64_t)img[w + 3] << 32); v = (lo >> sh) | (hi << (64 - sh)); }
+      *reinterpret_cast<uint64_t *>(d + head + i * 8) = v;
     }
+    const uint32_t done = head + nw * 8;
+    if (sub < 8 && done + sub < n) d[done + sub] = img_byte(a + done + sub);
   }
 }
 
@@ -739,6 +790,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
       for (int i = 0; i + 1 < ncols; i++) if (b->cols[(size_t)order[(size_t)i]].name == b->cols[(size_t)order[(size_t)i + 1]].name)
         return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_serialize: duplicate column names");
 
+    static const bool scatter = [] { const char *e = std::getenv("TFGPU_SER_SCATTER"); return e && *e == '1'; }();  // the per-cell passes (the queue formats' own), for A/B runs
     std::string blob;
     std::vector<SCol> sc((size_t)ncols);
     for (int j = 0; j < ncols; j++) {
@@ -746,7 +798,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
       SCol &s = sc[(size_t)j];
       s.c = dcol_of(c);
       s.pre_off = (uint32_t)blob.size();
-      if (format == TFGPU_FMT_CH_JSON_EACH_ROW) { blob += '"'; blob += c.name; blob += "\":"; }  // writeColName: raw name
+      if (format == TFGPU_FMT_CH_JSON_EACH_ROW) { if (!scatter) blob += '\0'; blob += '"'; blob += c.name; blob += "\":"; }  // writeColName: raw name (the chunk walks put '{' or ',' into the leading byte)
       else if (format == TFGPU_FMT_JSON) { if (j) blob += ','; json_key(blob, c.name); blob += ':'; }
       else if (j) blob += ',';
       s.pre_len = (uint32_t)blob.size() - s.pre_off;
@@ -765,42 +817,97 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     if (n == 0 || (ncols == 0 && format == TFGPU_FMT_CSV && n == 0)) { res->mem = dalloc(64); res->size = 0; *out = res.release(); return TFGPU_OK; }
 
     Buf bsc = upload_const(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_const(blob.data(), blob.size());
-    Buf cell = dalloc((size_t)std::max(ncols, 1) * (size_t)n * 4), row_len = dalloc((size_t)(n + 1) * 4 + 16), last = dalloc((size_t)n * 4 + 16);
+    Buf row_len = dalloc((size_t)(n + 1) * 4 + 16), last = dalloc((size_t)n * 4 + 16);
     SerParams p{};
     p.cols = ptr<SCol>(bsc); p.ncols = ncols; p.nrows = n; p.format = format; p.any_as_string = any_as_string;
     { const char *ab = std::getenv("TFGPU_SER_ABLATE"); p.ablate = ab ? std::atoi(ab) : 0; }
     p.closing_newline = opts ? opts->add_closing_newline : 0;
-    p.blob = ptr<uint8_t>(bblob); p.cell = ptr<uint32_t>(cell); p.row_len = ptr<uint32_t>(row_len); p.last_present = ptr<int32_t>(last);
+    p.blob = ptr<uint8_t>(bblob); p.row_len = ptr<uint32_t>(row_len); p.last_present = ptr<int32_t>(last);
     Buf tot64 = dalloc_zero(8);
     p.total64 = reinterpret_cast<unsigned long long *>(tot64->p);
     const int64_t ncell = (int64_t)ncols * n;
-    { KernelTimer t("ser_cell_len"); if (ncell) ser_cell_len<<<blocks(ncell), 256, 0, st>>>(p); }
-    { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
+    Buf cell, bcut, brecs;
+    ChunkPlan cp{};
+    if (scatter) {
+      cell = dalloc((size_t)std::max(ncols, 1) * (size_t)n * 4);
+      p.cell = ptr<uint32_t>(cell);
+      { KernelTimer t("ser_cell_len"); if (ncell) ser_cell_len<<<blocks(ncell), 256, 0, st>>>(p); }
+      { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
+    } else {
+      // the cuts: consecutive columns until the ESTIMATED text of a row's chunk passes the target (64 rows of a chunk share a 12 KiB
+      // image, i.e. 192 bytes per row; an estimate that is off only sends more tiles down the direct path)
+      static const uint32_t target = [] { const char *e = std::getenv("TFGPU_SER_CHUNK_BYTES"); return e ? (uint32_t)std::atoi(e) : 136u; }();
+      std::vector<int32_t> cut{0};
+      double acc = 0;
+      for (int j = 0; j < ncols; j++) {
+        const DColumn &c = b->cols[(size_t)order[(size_t)j]];
+        double est = sc[(size_t)j].pre_len + 1.0;
+        switch (c.repr) {
+          case TFGPU_R_INT8: case TFGPU_R_UINT8: est += 2; break;
+          case TFGPU_R_INT16: case TFGPU_R_UINT16: est += 4; break;
+          case TFGPU_R_INT32: case TFGPU_R_UINT32: est += 8; break;
+          case TFGPU_R_INT64: case TFGPU_R_UINT64: case TFGPU_R_DURATION: est += 16; break;
+          case TFGPU_R_BOOL: est += 5; break;
+          case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: est += 14; break;
+          case TFGPU_R_TIME: est += 24; break;
+          default: est += 2.0 + (double)c.data_len / (double)n * (format == TFGPU_FMT_JSON && c.repr == TFGPU_R_BYTES ? 1.34 : 1.0);
+        }
+        if (j > cut.back() && acc + est > target) { cut.push_back(j); acc = 0; }
+        acc += est;
+      }
+      cut.push_back(ncols);
+      if (ncols == 0) cut = {0, 0};
+      cp.nchunks = (int32_t)cut.size() - 1;
+      bcut = upload_const(cut.data(), cut.size() * sizeof(int32_t));
+      cp.cut = ptr<int32_t>(bcut);
+      std::vector<uint32_t> recs((size_t)std::max(ncols, 1) * REC_WORDS, 0u);
+      for (int j = 0; j < ncols; j++) {
+        const SCol &d = sc[(size_t)j];
+        uint32_t *w = recs.data() + (size_t)j * REC_WORDS;
+        auto put64 = [&](int k, const void *q) { const uint64_t v = reinterpret_cast<uintptr_t>(q); w[k] = (uint32_t)v; w[k + 1] = (uint32_t)(v >> 32); };
+        put64(RW_VALUES, d.c.values); put64(RW_OFFSETS, d.c.offsets); put64(RW_DATA, d.c.data); put64(RW_NANOS, d.c.nanos); put64(RW_VALIDITY, d.c.validity);
+        w[RW_REPR] = (uint32_t)d.c.repr; w[RW_DTYPE] = (uint32_t)d.c.dtype; w[RW_PRE_OFF] = d.pre_off; w[RW_PRE_LEN] = d.pre_len; w[RW_CH_FLAGS] = d.ch_flags; w[RW_PREC] = d.prec;
+        std::memcpy(w + REC_PREFIX_WORD, blob.data() + d.pre_off, std::min<size_t>(d.pre_len, REC_PREFIX_BYTES));
+      }
+      brecs = upload_const(recs.data(), recs.size() * 4);
+      cp.recs = ptr<uint32_t>(brecs);
+      cell = dalloc((size_t)cp.nchunks * (size_t)n * 4);
+      cp.chunk = ptr<uint32_t>(cell);
+      { const char *e = std::getenv("TFGPU_SER_DIRECT"); cp.direct = e && *e == '1'; }
+      { const char *e = std::getenv("TFGPU_SER_ORDER"); cp.order = e ? std::atoi(e) : 1; }
+      cp.ngroups = (n + 63) / 64;
+      const unsigned grid = (unsigned)((((n + 63) / 64) * cp.nchunks + 3) / 4);
+      {
+        KernelTimer t("ser_chunk_len");
+        if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_chunk_len<TFGPU_FMT_CH_JSON_EACH_ROW><<<grid, 256, 0, st>>>(p, cp);
+        else if (format == TFGPU_FMT_JSON) ser_chunk_len<TFGPU_FMT_JSON><<<grid, 256, 0, st>>>(p, cp);
+        else ser_chunk_len<TFGPU_FMT_CSV><<<grid, 256, 0, st>>>(p, cp);
+      }
+      {
+        KernelTimer t("ser_chunk_layout");
+        if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_chunk_layout<TFGPU_FMT_CH_JSON_EACH_ROW><<<blocks(n), 256, 0, st>>>(p, cp);
+        else if (format == TFGPU_FMT_JSON) ser_chunk_layout<TFGPU_FMT_JSON><<<blocks(n), 256, 0, st>>>(p, cp);
+        else ser_chunk_layout<TFGPU_FMT_CSV><<<blocks(n), 256, 0, st>>>(p, cp);
+      }
+    }
     exclusive_scan_u32(p.row_len, p.row_len, n, true);
     const uint32_t *htot = d2h_u32(p.row_len + n);
     const uint32_t *h64 = d2h_u32(tot64->p, 2);
     tf::sync();
-    if (h64[1] != 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_serialize: output exceeds 4 GiB; split the batch by rows (the reference serialises 25 000-row chunks, batch.go:18)");
     // a uint32 offset space: batches whose text exceeds 4 GiB must be split by rows (batch.go chunks at 25 000 rows)
+    if (h64[1] != 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_serialize: output exceeds 4 GiB; split the batch by rows (the reference serialises 25 000-row chunks, batch.go:18)");
     res->size = *htot;
     res->mem = dalloc(res->size + 64);
     p.out = ptr<uint8_t>(res->mem);
-    static const bool scatter = [] { const char *e = std::getenv("TFGPU_SER_SCATTER"); return e && *e == '1'; }();  // the previous write pass, for A/B runs
     if (scatter) {
       { KernelTimer t("ser_cell_write"); if (ncell) ser_cell_write<<<blocks(ncell), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_frame"); ser_row_frame<<<blocks(n), 256, 0, st>>>(p); }
     } else {
-      // columns per workgroup: 64 rows of the chunk are about 36 KB of text on average, so a tile rarely outgrows the 48 KiB image
-      const uint64_t avg_cell = std::max<uint64_t>(res->size / ((uint64_t)n * (uint64_t)std::max(ncols, 1)), 1);
-      const int32_t cpc = (int32_t)std::min<uint64_t>(std::max<uint64_t>(36000 / (64 * avg_cell), 1), (uint64_t)std::max(ncols, 1));
-      const int32_t nchunks = (std::max(ncols, 1) + cpc - 1) / cpc;
-      const int64_t ntiles = ((n + 63) / 64) * nchunks;
-      Buf big = dalloc_zero((size_t)(ntiles + 1) * 4);
-      KernelTimer t("ser_tile_write");
-      if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_tile_write<TFGPU_FMT_CH_JSON_EACH_ROW><<<(unsigned)ntiles, 256, TILE_WORDS * 4, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
-      else if (format == TFGPU_FMT_JSON) ser_tile_write<TFGPU_FMT_JSON><<<(unsigned)ntiles, 256, TILE_WORDS * 4, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
-      else ser_tile_write<TFGPU_FMT_CSV><<<(unsigned)ntiles, 256, TILE_WORDS * 4, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
-      ser_tile_scatter<<<(unsigned)std::min<int64_t>(ntiles, 1024), 256, 0, st>>>(p, cpc, nchunks, ptr<uint32_t>(big) + 1, ptr<uint32_t>(big));
+      const unsigned grid = (unsigned)((((n + 63) / 64) * cp.nchunks + 3) / 4);
+      KernelTimer t("ser_chunk_write");
+      if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_chunk_write<TFGPU_FMT_CH_JSON_EACH_ROW><<<grid, 256, 4 * WAVE_IMG_BYTES + 64, st>>>(p, cp);
+      else if (format == TFGPU_FMT_JSON) ser_chunk_write<TFGPU_FMT_JSON><<<grid, 256, 4 * WAVE_IMG_BYTES + 64, st>>>(p, cp);
+      else ser_chunk_write<TFGPU_FMT_CSV><<<grid, 256, 4 * WAVE_IMG_BYTES + 64, st>>>(p, cp);
     }
     *out = res.release();
     return TFGPU_OK;
