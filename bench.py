@@ -452,7 +452,7 @@ class JsonWorkload(_Prepared):
 
     def alg(self):
         s = self.state
-        return {"json_parse_tiles": len(self.data) + s["parsed_bytes"], "json_parse_lines": len(self.data) + s["parsed_bytes"], "csv_count_newlines": len(self.data), "ser_tile_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"],
+        return {"json_parse_tiles": len(self.data) + s["parsed_bytes"], "json_parse_lines": len(self.data) + s["parsed_bytes"], "csv_count_newlines": len(self.data), "ser_chunk_write": s["kept_bytes"] + s["out_bytes"], "ser_chunk_len": s["kept_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"],
                 "ser_cell_len": s["kept_bytes"], "json_copy_cells": 2 * s["parsed_bytes"]}
 
     def config(self):
@@ -576,7 +576,7 @@ class Configs2Workload(_Prepared):
     def alg(self):
         s = self.state
         return {"sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
-                "ser_tile_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "compact_gather": int(s["parsed_bytes"] + s["kept_bytes"])}
+                "ser_chunk_write": s["kept_bytes"] + s["out_bytes"], "ser_chunk_len": s["kept_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "compact_gather": int(s["parsed_bytes"] + s["kept_bytes"])}
 
     def config(self):
         return {"workload": "Kafka JSON (confluent_sr JSON schema, one flat hits object per message) -> replace_primary_key + sql transformer (predicate + casts) "
@@ -641,7 +641,7 @@ class Configs3Workload(Base):
 
     def alg(self):
         s = self.state
-        return {"mask_hmac_sha256": 72 * self.n, "ser_tile_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "sharder_crc32": (8 + 4) * self.n,
+        return {"mask_hmac_sha256": 72 * self.n, "ser_chunk_write": s["kept_bytes"] + s["out_bytes"], "ser_chunk_len": s["kept_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "sharder_crc32": (8 + 4) * self.n,
                 "tostring_write": 2 * 18 * self.n, "todatetime": 12 * self.n}
 
     def int_roofline(self, kernels):

@@ -306,8 +306,8 @@ def test_gpu_raw_refusals(tf):
 
 @pytest.mark.gpu
 def test_gpu_rows_larger_than_the_lds_image(tf, oracle):
-    """ser_tile_write assembles runs of rows in a 48 KiB LDS image; runs that outgrow it (one 70 KB cell) are written by the
-    same workgroup straight to HBM.  Mixed batch: both paths, every format."""
+    """ser_chunk_write assembles 64 rows of a column chunk in the wave's 12 KiB LDS image; tiles that outgrow it (one 70 KB cell)
+    are written by the same wave straight to HBM.  Mixed batch: both paths, every format."""
     import random
     rng = random.Random(SEED0 + 31)
     schema = abi.Schema.of([["k", "int64", True], ["s", "utf8", False], ["t", "utf8", False], ["d", "double", False]])

@@ -22,6 +22,7 @@
 #define TF_GLOBAL_PTR(T, p) ((T *)(p))
 #define TF_CONST_PTR(T, p) ((const T *)(p))
 #define TF_OPAQUE(x) ((void)(x))
+#define TF_KEEP(x) ((void)(x))
 #define __builtin_amdgcn_fence(...) ((void)0)
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };

@@ -35,6 +35,11 @@
 
 // a value the optimizer must treat as unknown (keeps two neighbouring narrow LDS reads from being merged into one
 // misaligned wide read)
+// a value the compiler must have in a vector register HERE although nothing reads it: the tail end of a load issued early only
+// to bring its cache line in (the CPU emulator's hip_runtime.h defines the no-op)
+#ifndef TF_KEEP
+#define TF_KEEP(x) asm volatile("" ::"v"(x))
+#endif
 #ifndef TF_OPAQUE
 #define TF_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif

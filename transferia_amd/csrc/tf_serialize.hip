@@ -432,7 +432,13 @@ __device__ __forceinline__ DCol rec_dcol(uint32_t rec) {
 // Groups of WALK_AHEAD cells: the group's records, then every load of the group (validity byte, value or offsets, nanoseconds)
 // are issued before its first cell is formatted, so a lane waits for memory twice per group instead of three or four times per
 // cell.  ALL 64 lanes of the wave must run the walk (the records live across its lanes).
-constexpr int WALK_AHEAD = 8;
+#ifndef TF_SER_LEN_AHEAD
+#define TF_SER_LEN_AHEAD 8
+#endif
+#ifndef TF_SER_WRITE_AHEAD
+#define TF_SER_WRITE_AHEAD 8
+#endif
+constexpr int LEN_AHEAD = TF_SER_LEN_AHEAD, WRITE_AHEAD = TF_SER_WRITE_AHEAD;
 template <int FMT, class S> __device__ __forceinline__ void walk_cell(S &s, const SerParams &p, uint32_t rec, const CellBits &b, bool &first) {
   // every v_readlane up here, in uniform control flow
   SCol sc;
@@ -458,7 +464,7 @@ template <int FMT, class S> __device__ __forceinline__ void walk_cell(S &s, cons
   else if (FMT == TFGPU_FMT_JSON) emit_json_value(s, sc, b, p.any_as_string);
   else emit_csv_field(s, sc, b);
 }
-template <int FMT, class S> __device__ __forceinline__ void walk_chunk(S &s, const SerParams &p, const ChunkPlan &cp, int32_t c0, int32_t c1, int64_t r, bool &first) {
+template <int FMT, int WALK_AHEAD, class S> __device__ __forceinline__ void walk_chunk(S &s, const SerParams &p, const ChunkPlan &cp, int32_t c0, int32_t c1, int64_t r, bool &first) {
   if (FMT == TFGPU_FMT_JSON && c0 == 0) s.put('{');
   const int lane = threadIdx.x & 63;
   for (int32_t cg = c0; cg < c1; cg += WALK_AHEAD) {  // c0, c1 are wave-uniform (the callers say so)
@@ -475,6 +481,7 @@ template <int FMT, class S> __device__ __forceinline__ void walk_chunk(S &s, con
 #pragma unroll
       for (int q = 0; q + 1 < WALK_AHEAD; q++) { b[q] = b[q + 1]; rec[q] = rec[q + 1]; }
     }
+
   }
 }
 // what closes a row, written by the lane of the row's last chunk
@@ -496,7 +503,7 @@ __global__ void __launch_bounds__(256) ser_chunk_len(SerParams p, ChunkPlan cp) 
   const int64_t rl = r0 + (threadIdx.x & 63), r = min(rl, p.nrows - 1);  // lanes past the end repeat the last row: the walk needs the whole wave
   CountSink s;
   bool first = false;
-  walk_chunk<FMT>(s, p, cp, c0, c1, r, first);
+  walk_chunk<FMT, LEN_AHEAD>(s, p, cp, c0, c1, r, first);
   if (rl < p.nrows) cp.chunk[(int64_t)k * p.nrows + r] = s.n;
 }
 // (2) per row: chunk lengths → offsets inside the row, row length
@@ -542,7 +549,7 @@ __global__ void __launch_bounds__(256) ser_chunk_write(SerParams p, ChunkPlan cp
   const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
   if (cp.direct || total > WAVE_IMG_BYTES) {  // the tile outgrows the image (a long text cell): the same walk, straight to HBM
     WriteSink w{dst};
-    walk_chunk<FMT>(w, p, cp, c0, c1, r, first);
+    walk_chunk<FMT, WRITE_AHEAD>(w, p, cp, c0, c1, r, first);
     if (last_chunk) row_tail<FMT>(w, p, r, first);
     w.flush();
     return;
@@ -552,7 +559,7 @@ __global__ void __launch_bounds__(256) ser_chunk_write(SerParams p, ChunkPlan cp
   const uint32_t at = base + (live ? incl - cap : last_at);
   {
     LdsSink w{at};
-    walk_chunk<FMT>(w, p, cp, c0, c1, r, first);
+    walk_chunk<FMT, WRITE_AHEAD>(w, p, cp, c0, c1, r, first);
     if (last_chunk) row_tail<FMT>(w, p, r, first);
     w.flush();
   }
