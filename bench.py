@@ -227,10 +227,10 @@ class CsvWorkload(Base):
         self.dbuf, self.csv_bytes, _ = stage_shard(e.lib, e.workload, self.row0, a.rows)
         self.nl = 1
 
-    def step(self, keep=False, buf=None):
+    def step(self, keep=False, buf=None, plans=None):
         lib = self.env.lib
         db, consumed, errs = lib.csv_parse(self.opts, self.schema, buf if buf is not None else self.dbuf)
-        res = lib.apply_chain(self.plans, db)
+        res = lib.apply_chain(plans if plans is not None else self.plans, db)
         if keep:
             s = self.state
             s["parsed_rows"], s["parsed_bytes"] = db.nrows, db.payload_bytes()
@@ -253,8 +253,49 @@ class CsvWorkload(Base):
 
     # the K timed steps, spread round-robin over `lanes` host threads, each bound to its own device lane (stream + HBM
     # cache) and reading its own HBM-resident copy of the shard; lanes = 1 is the strictly serial bench line
+    def timed_devices(self, steps):
+        """One process, several devices (tfgpu_init_devices): lane k lives on the k-th device of --devices, stages ITS row-range
+        shard there and runs every one of the K steps over it — the same weak-scaling job as one process per GPU, driven by one
+        worker with a thread per device.  No data-path collective; the lanes meet at two host barriers."""
+        e, a = self.env, self.args
+        nl = len(e.devices)
+        go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
+        errs = []
+
+        def lane_main(k):
+            try:
+                e.lib.lane_use(k)
+                buf = self.dbuf if k == 0 else stage_shard(e.lib, e.workload, self.row0 + a.rows * k, a.rows)[0]
+                plans = self.plans if k == 0 else [e.lib.Transformer(t, c) for t, c in CHAIN]
+                for _ in range(max(min(a.warmup, 2), 1)):
+                    self.step(buf=buf, plans=plans)
+                e.lib.synchronize()
+                go.wait()
+                for _ in range(steps):
+                    self.step(buf=buf, plans=plans)
+                e.lib.synchronize()
+                done.wait()
+            except Exception as ex:  # noqa: BLE001
+                errs.append(ex)
+                go.abort(); done.abort()
+        threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
+        for t in threads:
+            t.start()
+        go.wait()
+        t0 = time.perf_counter()
+        done.wait()
+        dt = time.perf_counter() - t0
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0]
+        e.lib.lane_use(0)
+        return dt
+
     def timed(self, steps, nlanes=None, host_bufs=None):
         e, a = self.env, self.args
+        if getattr(e, "devices", None) and nlanes is None and host_bufs is None:
+            return self.timed_devices(steps)
         nl = max(1, min(nlanes or a.lanes, steps, e.lib.lane_count()))
         go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
         lane_err = []
@@ -321,7 +362,7 @@ class CsvWorkload(Base):
         return {"workload": "ClickBench hits-1M CSV parse -> mask(ip)+filter(EventDate) -> devnull (BASELINE.json configs[1])",
                 "rows_per_gpu_per_step": s["parsed_rows"], "csv_bytes_per_gpu_per_step": self.csv_bytes, "columns": len(self.schema.cols),
                 "chain": [t for t, _ in CHAIN], "filter_selectivity": round(s["out_rows"] / max(s["parsed_rows"], 1), 4),
-                "parallelism": f"row-range shard x{e.world}, no collective"}
+                "parallelism": f"row-range shard x{len(e.devices) if getattr(e, 'devices', None) else e.world}, no collective"}
 
     def extra(self):
         s, e, a = self.state, self.env, self.args
@@ -1084,6 +1125,8 @@ def main():
     ap.add_argument("--overlap-lanes", type=int, default=3, help="side measurement (never `value`): the same steps spread over this many lanes (0 = skip)")
     ap.add_argument("--pcie-steps", type=int, default=2, help="side measurement (never `value`): passes per lane that start from PINNED HOST memory (0 = skip)")
     ap.add_argument("--pcie-lanes", type=int, default=3)
+    ap.add_argument("--devices", default="", help="ONE process driving several devices (csv workload): comma-separated HIP device ids, lane k on the k-th "
+                    "(tfgpu_init_devices); without it --gpus N > 1 expects one process per GPU under torch.distributed.run")
     ap.add_argument("--exchange", type=int, default=1, help="configs4 at 1 rank: 1 = every buffer still makes the RCCL round trip, 0 = skip the collective")
     args = ap.parse_args()
 
@@ -1098,7 +1141,14 @@ def main():
     e.device = torch.device("cuda", local_rank)
     e.group = tdist.Group("nccl", e.device)  # RCCL: barrier + MAX of the wall time (+ the configs4 exchange)
     e.lib, e.abi, e.workload = lib, abi, workload
-    lib.init(local_rank)
+    e.devices = [int(x) for x in args.devices.split(",") if x.strip() != ""] if args.devices else None
+    if e.devices:
+        if world != 1 or args.workload != "csv":
+            raise SystemExit("--devices is the one-process mode of the csv workload: run it without torch.distributed.run")
+        lib.init_devices(e.devices)
+        args.overlap_lanes = 0; args.pcie_steps = 0
+    else:
+        lib.init(local_rank)
 
     def sync_all():
         lib.synchronize()
@@ -1169,11 +1219,14 @@ def main():
 
     if rank == 0:
         rows = W.rows()
-        value = rows * world * args.steps / dt
-        out = {"metric": W.metric, "value": round(value, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        shards = len(e.devices) if e.devices else world
+        value = rows * shards * args.steps / dt
+        out = {"metric": W.metric, "value": round(value, 1), "unit": "rows/s", "n_gpus": len(set(e.devices)) if e.devices else world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": W.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "config": W.config()}
         out.update(W.extra())
+        if e.devices:
+            out["process_model"] = {"mode": "one process, one host thread and one lane per device (tfgpu_init_devices)", "devices": e.devices, "row_range_shards": shards}
         out["row_errors"] = W.state.get("errors", 0)
         out["roofline"] = roofline
         if int_roof:

@@ -216,6 +216,11 @@ int tfgpu_abi_version(void);
 const char *tfgpu_last_error(void);
 /* Bind the calling process to HIP device `device` (one process per GPU).    */
 int tfgpu_init(int device);
+/* Bind the process to SEVERAL devices: lane k (below) lives on devices[k mod ndevices], so one worker process — one Go
+ * worker with a goroutine per lane — drives every GPU of the node with a row-range shard each (tfgpu_shard_rows), the
+ * shape SURVEY §8(e) gives the path: transformation.go:131-135 is one goroutine per table over independent rows.
+ * tfgpu_init(d) is the list {d}.  A second call with another list fails until tfgpu_shutdown.                       */
+int tfgpu_init_devices(const int *devices, int ndevices);
 int tfgpu_shutdown(void);
 int tfgpu_device_count(int *out);
 int tfgpu_synchronize(void);
@@ -227,10 +232,29 @@ void *tfgpu_stream(void);
  * process's GPU; a host thread (goroutine locked to its OS thread) binds itself to lane k and every call it
  * makes is enqueued there, so work on different lanes overlaps on the device: H2D of chunk N+1 beside the
  * kernels of chunk N beside the D2H of chunk N-1.  Lane 0 exists after tfgpu_init and is every thread's
- * default.  Handles (dbatch, dbuf) must be used and freed on the lane that made them.               */
+ * default.  Handles (dbatch, dbuf) must be used and freed on the lane that made them.  With a device
+ * list (tfgpu_init_devices) lane k is a lane of device k mod ndevices.                                */
 int tfgpu_lane_count(void);        /* how many lanes may be used (0 .. count-1)                          */
 int tfgpu_lane_use(int lane);      /* bind the calling thread; creates the lane on first use             */
 int tfgpu_lane_current(void);
+int tfgpu_lane_device(int lane, int *device);  /* the HIP device lane `lane` lives (or will live) on            */
+
+/* Row-range shards of a device batch and their ordered merge (tf_shard.hip) — how one process spreads a batch over the
+ * lanes of several devices.  Nothing on the path looks across rows (transformation.go:131-135, filter / mask / cast are
+ * per row), so the shards need no exchange; abstract.Collapse is the exception and has tfgpu_exchange.
+ *   tfgpu_dbatch_slice:   rows [row0, row0 + nrows) as a batch of the calling lane; row0 must be a multiple of 8.
+ *   tfgpu_dbatch_to_lane: `b` as a batch of lane `lane`: a deep copy (hipMemcpyAsync over xGMI / PCIe) when that lane is
+ *                         on another device, shared immutable buffers otherwise.  `b` must be complete on its own lane.
+ *   tfgpu_shard_rows:     nshards balanced row ranges cut at multiples of 64 rows; out[g] lives on lane lanes[g] (lanes
+ *                         == NULL: lane g); row0[g] (optional) = first row of shard g in `b`.  Called on b's lane.
+ *   tfgpu_dbatch_concat:  the parts' rows, parts in order, on the calling lane.  The parts may live on any lane / device
+ *                         (their lanes synchronised by the caller); columns, representations, TableSchema and table id
+ *                         must agree.  row_base[g] (optional) is added to part g's src_row (a part without src_row
+ *                         counts 0, 1, …), which turns shard-local source rows back into rows of the sharded batch.    */
+int tfgpu_dbatch_slice(const tfgpu_dbatch *b, int64_t row0, int64_t nrows, tfgpu_dbatch **out);
+int tfgpu_dbatch_to_lane(const tfgpu_dbatch *b, int lane, tfgpu_dbatch **out);
+int tfgpu_shard_rows(const tfgpu_dbatch *b, int nshards, const int *lanes, tfgpu_dbatch **out, int64_t *row0);
+int tfgpu_dbatch_concat(const tfgpu_dbatch *const *parts, int nparts, const int64_t *row_base, tfgpu_dbatch **out);
 
 /* Pinned staging memory (hipHostMalloc) for double-buffered H2D/D2H.        */
 int tfgpu_host_alloc(size_t bytes, void **out);

@@ -29,13 +29,13 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 typedef int hipError_t;
-enum { hipSuccess = 0 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 typedef struct emuStream *hipStream_t;
 typedef struct emuEvent *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
 struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; char name[64]; };
 
 inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
@@ -59,8 +59,11 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
+/* HIPEMU_DEVICES=G fakes G devices (one address space, as under unified addressing): the several-devices-in-one-process logic
+ * of tf_runtime.hip / tf_shard.hip runs here, nothing about peer copies is proven */
+inline int &hipemu_current_device() { static thread_local int d = 0; return d; }
+inline hipError_t hipGetDeviceCount(int *n) { const char *e = std::getenv("HIPEMU_DEVICES"); *n = e ? std::max(1, std::atoi(e)) : 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { int n; hipGetDeviceCount(&n); if (d < 0 || d >= n) return hipErrorInvalidValue; hipemu_current_device() = d; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(p, 0, sizeof *p); std::strcpy(p->gcnArchName, "gfx950:hipemu"); p->multiProcessorCount = 256; return hipSuccess; }
 
 inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }

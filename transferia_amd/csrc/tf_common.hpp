@@ -108,6 +108,14 @@ struct Context {
   void prof_flush();
 };
 Context &ctx();  // throws TFGPU_ERR_DEVICE if tfgpu_init has not succeeded
+int bind_lane(int lane);   // binds the calling thread (and its HIP device) to `lane`; returns the lane it was bound to before
+int current_lane();
+int lane_device(int lane);
+struct LaneScope {         // the calling thread works on another lane for a while (allocations for it, copies to it)
+  int prev;
+  explicit LaneScope(int lane) : prev(bind_lane(lane)) {}
+  ~LaneScope() { try { bind_lane(prev); } catch (...) {} }
+};
 
 // RAII marker: times everything enqueued between ctor and dtor under `name`.
 struct KernelTimer {
@@ -123,6 +131,7 @@ struct DevMem {
   size_t bytes = 0, cls = 0;
   std::shared_ptr<DevMem> parent;  // set for views into a larger block (see subbuf)
   struct BlockCache *owner = nullptr;  // the lane's cache the block returns to
+  int device = -1;                     // the HIP device the block lives on
   explicit DevMem(size_t n);
   DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n);
   ~DevMem();

@@ -11,37 +11,64 @@ namespace tf {
 
 void executor_shutdown();  // tf_transformation.cpp
 static thread_local std::string g_last_error;
-// Lanes: independent (stream, HBM block cache, pinned ring, profiler) sets of ONE device.  A host thread binds
-// itself to a lane with tfgpu_lane_use(); calls on different lanes overlap on the GPU — parse of batch N+1 on one
-// lane beside transform / serialize / D2H of batch N on another (the parsequeue's parallel workers,
-// parsequeue.go:57-154, map onto lanes).  Buffers belong to the lane that made them.
-static constexpr int MAX_LANES = 8;
+// Lanes: independent (device, stream, HBM block cache, pinned ring, profiler) sets.  A host thread binds itself to a lane
+// with tfgpu_lane_use(); calls on different lanes overlap — on one GPU the parse of batch N+1 beside transform / serialize /
+// D2H of batch N (the parsequeue's parallel workers, parsequeue.go:57-154, map onto lanes), and with a device list
+// (tfgpu_init_devices) lane k lives on device k mod G, so ONE process drives several GPUs, a row-range shard each
+// (tfgpu_shard_rows / tfgpu_dbatch_concat, tf_shard.hip).  Buffers belong to the lane that made them.
+static constexpr int MAX_LANES = 32;
 static std::unique_ptr<Context> g_lanes[MAX_LANES];
 static thread_local int g_lane = 0;
-static int g_device = -1, g_num_cus = 256;
+static std::vector<int> g_devices;      // the process's device list; lane k -> g_devices[k % size]
+static std::vector<int> g_device_cus;   // multiProcessorCount of each
 static std::mutex g_init_mu;
+static int lane_device_index(int lane) { return g_devices.empty() ? 0 : lane % (int)g_devices.size(); }
 #define g_ctx g_lanes[0]
 
 void set_last_error(const std::string &m) { g_last_error = m; }
 int fail(int code, const std::string &m) { g_last_error = m; return code; }
 
+// the HIP device is a per-thread setting: a thread that reaches a lane (bound, or lane 0 by default) works on that lane's device
+static thread_local int t_device = -1;
+static void ensure_device(int device) {
+  if (t_device == device) return;
+  TF_HIP(hipSetDevice(device));
+  t_device = device;
+}
 Context &ctx() {
   if (!g_ctx) throw Error(TFGPU_ERR_DEVICE, "tfgpu_init() has not been called (or no gfx950 device): no CPU fallback exists");
   Context *c = g_lanes[g_lane].get();
   if (!c) throw Error(TFGPU_ERR_INVALID, "this thread is bound to a lane that no longer exists");
+  ensure_device(c->device);
   return *c;
 }
-static std::unique_ptr<Context> make_lane() {
+static std::unique_ptr<Context> make_lane(int lane) {  // the caller's HIP device is the lane's when this returns
   auto c = std::make_unique<Context>();
-  c->device = g_device;
-  c->num_cus = g_num_cus;
+  c->device = g_devices[(size_t)lane_device_index(lane)];
+  c->num_cus = g_device_cus[(size_t)lane_device_index(lane)];
+  ensure_device(c->device);
   TF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->pin_cap = 8u << 20;
-  TF_HIP(hipHostMalloc(&c->pin_base, c->pin_cap, hipHostMallocDefault));
+  TF_HIP(hipHostMalloc(&c->pin_base, c->pin_cap, hipHostMallocPortable));
   return c;
 }
+// binds the calling thread to `lane` (created on first use) and makes the lane's device the thread's HIP device
+int bind_lane(int lane) {
+  if (lane < 0 || lane >= MAX_LANES) throw Error(TFGPU_ERR_INVALID, "lane out of range");
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  if (!g_ctx) throw Error(TFGPU_ERR_DEVICE, "tfgpu_init() has not been called");
+  if (!g_lanes[lane]) g_lanes[lane] = make_lane(lane);
+  ensure_device(g_lanes[lane]->device);
+  const int prev = g_lane;
+  g_lane = lane;
+  return prev;
+}
+int current_lane() { return g_lane; }
+int lane_device(int lane) { return (lane < 0 || g_devices.empty()) ? -1 : g_devices[(size_t)lane_device_index(lane)]; }
 static void destroy_lane(std::unique_ptr<Context> &c) {
   if (!c) return;
+  t_device = -1;
+  hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : c->free_events) hipEventDestroy(e);
@@ -126,11 +153,12 @@ void BlockCache::trim() {
 
 DevMem::DevMem(size_t n) : bytes(n) {
   Context &c = ctx();
+  device = c.device;
   cls = size_class(n + 16);  // 16 bytes of slack: kernels read whole aligned words around payloads
   p = c.blocks.get(cls);
   owner = &c.blocks;
 }
-DevMem::DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n) : p((char *)owner->p + off), bytes(n), cls(0), parent(std::move(owner)) {}
+DevMem::DevMem(std::shared_ptr<DevMem> owner, size_t off, size_t n) : p((char *)owner->p + off), bytes(n), cls(0), parent(std::move(owner)) { device = parent->device; }
 DevMem::~DevMem() {
   if (parent) return;  // a view: the owner returns the block
   if (p && owner && g_ctx) owner->put(p, cls);  // back to the cache of the lane whose stream ordered its use
@@ -240,29 +268,33 @@ int tfgpu_device_count(int *out) {
   return TFGPU_OK;
 }
 
-int tfgpu_init(int device) {
+int tfgpu_init_devices(const int *devices, int ndevices) {
   TF_API_BEGIN
+  if (!devices || ndevices <= 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_init_devices: empty device list");
   std::lock_guard<std::mutex> lk(g_init_mu);
+  const std::vector<int> want(devices, devices + ndevices);
   if (g_ctx) {
-    if (g_ctx->device == device) return TFGPU_OK;
-    return tf::fail(TFGPU_ERR_INVALID, "tfgpu_init: process already bound to another device (one process per GPU)");
+    if (g_devices == want) return TFGPU_OK;
+    return tf::fail(TFGPU_ERR_INVALID, "tfgpu_init: process already bound to another device list (tfgpu_shutdown first)");
   }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) return tf::fail(TFGPU_ERR_DEVICE, "no HIP device visible; this library has no CPU fallback");
-  if (device < 0 || device >= n) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_init: device index out of range");
-  TF_HIP(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  TF_HIP(hipGetDeviceProperties(&prop, device));
-  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
-    return tf::fail(TFGPU_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-  g_device = device;
-  g_num_cus = prop.multiProcessorCount;
-  auto c = make_lane();
-  g_ctx = std::move(c);
+  std::vector<int> cus;
+  for (int d : want) {
+    if (d < 0 || d >= n) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_init: device index out of range");
+    hipDeviceProp_t prop;
+    TF_HIP(hipGetDeviceProperties(&prop, d));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+      return tf::fail(TFGPU_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    cus.push_back(prop.multiProcessorCount);
+  }
+  g_devices = want; g_device_cus = cus;
+  g_ctx = make_lane(0);
   return TFGPU_OK;
   TF_API_END
 }
+int tfgpu_init(int device) { return tfgpu_init_devices(&device, 1); }
 
 int tfgpu_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_init_mu);
@@ -270,6 +302,8 @@ int tfgpu_shutdown(void) {
   executor_shutdown();  // the push workers hold lanes
   for (int i = MAX_LANES - 1; i >= 0; i--) destroy_lane(g_lanes[i]);
   g_lane = 0;
+  t_device = -1;
+  g_devices.clear(); g_device_cus.clear();
   return TFGPU_OK;
 }
 
@@ -277,11 +311,16 @@ int tfgpu_lane_count(void) { return MAX_LANES; }
 int tfgpu_lane_use(int lane) {
   TF_API_BEGIN
   if (lane < 0 || lane >= MAX_LANES) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_lane_use: lane out of range");
+  bind_lane(lane);
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_lane_device(int lane, int *device) {
+  TF_API_BEGIN
+  if (!device || lane < 0 || lane >= MAX_LANES) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_lane_device: bad argument");
   std::lock_guard<std::mutex> lk(g_init_mu);
   if (!g_ctx) return tf::fail(TFGPU_ERR_DEVICE, "tfgpu_init() has not been called");
-  TF_HIP(hipSetDevice(g_device));  // the HIP device is a per-thread setting
-  if (!g_lanes[lane]) g_lanes[lane] = make_lane();
-  g_lane = lane;
+  *device = lane_device(lane);
   return TFGPU_OK;
   TF_API_END
 }
@@ -299,7 +338,7 @@ void *tfgpu_stream(void) { return (g_ctx && g_lanes[g_lane]) ? (void *)g_lanes[g
 int tfgpu_host_alloc(size_t bytes, void **out) {
   TF_API_BEGIN
   ctx();
-  TF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  TF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable));
   return TFGPU_OK;
   TF_API_END
 }

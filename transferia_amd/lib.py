@@ -24,7 +24,7 @@ _lib = None
 
 EXPORTS = [
     "tfgpu_abi_version", "tfgpu_last_error", "tfgpu_init", "tfgpu_shutdown", "tfgpu_device_count", "tfgpu_synchronize",
-    "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
+    "tfgpu_init_devices", "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_lane_device", "tfgpu_dbatch_slice", "tfgpu_dbatch_to_lane", "tfgpu_shard_rows", "tfgpu_dbatch_concat", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
@@ -151,6 +151,22 @@ def init(device: Optional[int] = None) -> int:
     return device
 
 
+def init_devices(devices) -> List[int]:
+    """Bind this process to several GPUs: lane k lives on devices[k % len(devices)] (one worker process driving the node)."""
+    global _initialised
+    devices = [int(d) for d in devices]
+    arr = (C.c_int * len(devices))(*devices)
+    _check(load().tfgpu_init_devices(arr, len(devices)))
+    _initialised = devices[0]
+    return devices
+
+
+def lane_device(lane: int) -> int:
+    d = C.c_int(-1)
+    _check(load().tfgpu_lane_device(int(lane), C.byref(d)))
+    return int(d.value)
+
+
 def lane_use(lane: int):
     """Bind the calling thread to lane `lane` (its own stream / HBM cache / pinned ring): calls made by
     threads on different lanes overlap on the device, the way the parsequeue's workers overlap."""
@@ -194,6 +210,34 @@ class DeviceBatch:
     @property
     def nrows(self) -> int:
         return int(self.view().nrows)
+
+    # ---- one process, several GPUs: row-range shards and their ordered merge (tf_shard.hip) ----
+    def slice(self, row0: int, nrows: int) -> "DeviceBatch":
+        h = C.c_void_p()
+        _check(load().tfgpu_dbatch_slice(self._h, C.c_int64(row0), C.c_int64(nrows), C.byref(h)))
+        return DeviceBatch(h)
+
+    def to_lane(self, lane: int) -> "DeviceBatch":
+        h = C.c_void_p()
+        _check(load().tfgpu_dbatch_to_lane(self._h, int(lane), C.byref(h)))
+        return DeviceBatch(h)
+
+    def shard_rows(self, nshards: int, lanes=None):
+        """-> ([DeviceBatch per shard, shard g on lane lanes[g] (default g)], [first row of each shard])"""
+        hs = (C.c_void_p * nshards)()
+        row0 = (C.c_int64 * nshards)()
+        la = (C.c_int * nshards)(*[int(x) for x in lanes]) if lanes is not None else None
+        _check(load().tfgpu_shard_rows(self._h, int(nshards), la, hs, row0))
+        return [DeviceBatch(C.c_void_p(hs[g])) for g in range(nshards)], [int(row0[g]) for g in range(nshards)]
+
+    @staticmethod
+    def concat(parts, row_base=None) -> "DeviceBatch":
+        n = len(parts)
+        hs = (C.c_void_p * n)(*[p._h for p in parts])
+        rb = (C.c_int64 * n)(*[int(x) for x in row_base]) if row_base is not None else None
+        h = C.c_void_p()
+        _check(load().tfgpu_dbatch_concat(hs, n, rb, C.byref(h)))
+        return DeviceBatch(h)
 
     def table_schema(self) -> Optional[abi.Schema]:
         """ChangeItem.TableSchema where the batch carries one of its own, else None (= the columns)."""
