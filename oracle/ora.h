@@ -129,6 +129,8 @@ size_t ora_fmt_duration(char *dst, int64_t ns);            /* Duration.String() 
 int ora_parse_int(const char *s, size_t n, int base, int bits, int64_t *out);
 int ora_parse_uint(const char *s, size_t n, int base, int bits, uint64_t *out);
 int ora_parse_float(const char *s, size_t n, int bits, double *out); /* strconv.ParseFloat */
+int ora_parse_duration(const char *s, size_t n, int64_t *out);              /* time.ParseDuration: 0 ok, 1 error */
+int ora_cast_string_to_duration(const char *s, size_t n, int64_t *out);     /* cast.ToDurationE(string) */
 int ora_parse_bool(const char *s, size_t n, int *out);     /* strconv.ParseBool */
 /* time.Parse(layout, s) for the layouts used on the path; returns 0 on success */
 int ora_time_parse(const char *layout, const char *s, size_t n, int64_t *sec, int32_t *nsec);

@@ -419,7 +419,12 @@ static int strictify_value(ora_value *v, int dtype) {
     case TFGPU_T_INTERVAL:
       if (v->kind == OV_DURATION) return 0;
       if (v->kind >= OV_I8 && v->kind <= OV_I64) { v->kind = OV_DURATION; return 0; }
-      return TFGPU_ROW_HOST_FALLBACK; /* time.ParseDuration of strings: not restated */
+      if (v->kind == OV_STRING) { /* cast.ToDurationE(string): time.ParseDuration, "ns" appended to a text without unit letters */
+        int64_t d;
+        if (ora_cast_string_to_duration(v->s, v->slen, &d)) return TFGPU_ROW_CAST;
+        ora_value_free(v); v->kind = OV_DURATION; v->v.i = d; return 0;
+      }
+      return TFGPU_ROW_HOST_FALLBACK; /* the other Go kinds under an interval column (floats, json.Number): not restated */
     case TFGPU_T_ANY: return 0;
   }
   return TFGPU_ROW_CAST;

@@ -665,3 +665,83 @@ int ora_time_parse(const char *layout, const char *val, size_t n, int64_t *osec,
   *osec = t; *onsec = nsec;
   return 0;
 }
+
+/* time.ParseDuration (Go time/format.go), as the reference reaches it through spf13/cast v1.7.1 (go.mod:64; not vendored under
+ * /root/reference — restated from the published source): [-+]?([0-9]*(\.[0-9]*)?[a-z]+)+, units ns us µs μs ms s m h, leadingInt /
+ * leadingFraction with their overflow rules, the fraction added through float64.  0 = ok, 1 = error. */
+static int leading_int(const char **ps, const char *e, uint64_t *x) {
+  const char *s = *ps; *x = 0;
+  for (; s < e && *s >= '0' && *s <= '9'; s++) {
+    if (*x > (1ull << 63) / 10) return 1;
+    *x = *x * 10 + (uint64_t)(*s - '0');
+    if (*x > 1ull << 63) return 1;
+  }
+  *ps = s;
+  return 0;
+}
+int ora_parse_duration(const char *s, size_t n, int64_t *out) {
+  const char *e = s + n;
+  uint64_t d = 0; int neg = 0;
+  *out = 0;
+  if (s < e && (*s == '-' || *s == '+')) { neg = *s == '-'; s++; }
+  if (e - s == 1 && *s == '0') return 0;
+  if (s == e) return 1;
+  while (s < e) {
+    uint64_t v = 0, f = 0; double scale = 1;
+    if (!(*s == '.' || (*s >= '0' && *s <= '9'))) return 1;
+    const char *pl = s;
+    if (leading_int(&s, e, &v)) return 1;
+    int pre = s != pl, post = 0;
+    if (s < e && *s == '.') {
+      s++;
+      const char *pf = s; int over = 0;
+      for (; s < e && *s >= '0' && *s <= '9'; s++) {
+        if (over) continue;
+        if (f > ((1ull << 63) - 1) / 10) { over = 1; continue; }
+        uint64_t y = f * 10 + (uint64_t)(*s - '0');
+        if (y > 1ull << 63) { over = 1; continue; }
+        f = y; scale *= 10;
+      }
+      post = s != pf;
+    }
+    if (!pre && !post) return 1;
+    const char *u = s;
+    while (s < e && !(*s == '.' || (*s >= '0' && *s <= '9'))) s++;
+    size_t ul = (size_t)(s - u);
+    if (ul == 0) return 1; /* missing unit */
+    uint64_t unit;
+    if (ul == 2 && !memcmp(u, "ns", 2)) unit = 1;
+    else if ((ul == 2 && !memcmp(u, "us", 2)) || (ul == 3 && !memcmp(u, "\xC2\xB5s", 3)) || (ul == 3 && !memcmp(u, "\xCE\xBCs", 3))) unit = 1000;
+    else if (ul == 2 && !memcmp(u, "ms", 2)) unit = 1000000;
+    else if (ul == 1 && *u == 's') unit = 1000000000ull;
+    else if (ul == 1 && *u == 'm') unit = 60000000000ull;
+    else if (ul == 1 && *u == 'h') unit = 3600000000000ull;
+    else return 1; /* unknown unit */
+    if (v > (1ull << 63) / unit) return 1;
+    v *= unit;
+    if (f > 0) {
+      v += (uint64_t)((double)f * ((double)unit / scale));
+      if (v > 1ull << 63) return 1;
+    }
+    d += v;
+    if (d > 1ull << 63) return 1;
+  }
+  if (neg) { *out = (int64_t)(0 - d); return 0; }
+  if (d > (1ull << 63) - 1) return 1;
+  *out = (int64_t)d;
+  return 0;
+}
+/* cast.ToDurationE(string) (spf13/cast v1.7.1 caste.go): strings.ContainsAny(s, "nsuµmh") ? ParseDuration(s) : ParseDuration(s + "ns") */
+int ora_cast_string_to_duration(const char *s, size_t n, int64_t *out) {
+  int has = 0;
+  for (size_t i = 0; i < n && !has; i++) {
+    unsigned char c = (unsigned char)s[i];
+    has = c == 'n' || c == 's' || c == 'u' || c == 'm' || c == 'h' || (c == 0xC2 && i + 1 < n && (unsigned char)s[i + 1] == 0xB5);
+  }
+  if (has) return ora_parse_duration(s, n, out);
+  char *t = (char *)malloc(n + 3);
+  memcpy(t, s, n); memcpy(t + n, "ns", 2);
+  int rc = ora_parse_duration(t, n + 2, out);
+  free(t);
+  return rc;
+}

@@ -84,6 +84,10 @@ def lib():
     L.ora_fmt_duration.argtypes = [C.c_char_p, C.c_int64]
     L.ora_parse_int.restype = C.c_int
     L.ora_parse_int.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    L.ora_parse_duration.restype = C.c_int
+    L.ora_parse_duration.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]
+    L.ora_cast_string_to_duration.restype = C.c_int
+    L.ora_cast_string_to_duration.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]
     L.ora_time_parse.restype = C.c_int
     L.ora_time_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     L.ora_json_parse.restype = P
@@ -449,6 +453,13 @@ def parse_int(s: str, base: int = 0, bits: int = 64):
     b = s.encode()
     rc = lib().ora_parse_int(b, len(b), base, bits, C.byref(out))
     return rc, int(out.value)
+
+
+def parse_duration(s: bytes, cast: bool = False):
+    """time.ParseDuration(s) — or, with cast, spf13/cast's ToDurationE(string) in front of it; None = error"""
+    d = C.c_int64(0)
+    f = lib().ora_cast_string_to_duration if cast else lib().ora_parse_duration
+    return None if f(s, len(s), C.byref(d)) else int(d.value)
 
 
 def time_parse(layout: str, s: str):

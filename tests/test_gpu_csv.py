@@ -444,3 +444,36 @@ def test_csv_splitter(tf, oracle):
     for n in [0, 1, 17, 5000, 300_000]:
         data = rng.choice(alphabet, n).tobytes()
         assert [int(x) for x in tf.csv_split_rows(data)] == oracle.csv_split_rows(data), n
+
+
+def test_float32_and_interval_cells_on_device(tf, oracle):
+    """strictify's last two string targets (strictify.go:44-157): float32 = strconv.ParseFloat(s, 32) (atof32exact + Eisel-Lemire;
+    what Go leaves to its decimal slow path goes back to the host, bounded below) and interval = cast.ToDurationE(string) =
+    time.ParseDuration, "ns" appended to a text without unit letters.  Go's own ParseDuration table first, then random cells."""
+    g = golden("goduration.json")
+    S = abi.Schema.of([["k", "int32", True, "0"], ["d", "interval", False, "1"], ["f", "float", False, "2"]])
+    texts = [bytes.fromhex(h) for h, _, _ in g["parse_duration"] + g["cast"]]
+    texts = [t for t in texts if not any(c in t for c in b',"\r\n') and t == t.strip() and t.isascii() or t in ("12µs".encode(), "12μs".encode())]
+    floats = [b"1", b"0.1", b"3.4028235e38", b"3.4028236e38", b"1e39", b"-1e-46", b"16777217", b"16777216.5", b"1.17549435e-38", b"0.000001", b"123456789012345678901234567890",
+              b"1e10", b"1e11", b"9999999e10", b"7.038531e-26", b"inf", b"-Infinity", b"nan", b"+nan", b"1_0", b"0x1p3", b"1e", b".", b"5.", b".5", b"1,5", b""]
+    lines = []
+    for i, t in enumerate(texts):
+        f = floats[i % len(floats)]
+        f = b'"%s"' % f if b"," in f else f
+        lines.append(b"%d,%s,%s" % (i, t, f))
+    out, errs = compare(tf, oracle, dict(), S, b"\n".join(lines) + b"\n", "go tables", max_fallback=len(lines) // 4)
+    assert out.nrows >= len(lines) // 3
+    rng = np.random.default_rng(SEED0 + 41)
+    units = [b"ns", b"us", b"ms", b"s", b"m", b"h", "µs".encode(), b"", b"d"]
+    rows = []
+    for i in range(6000):
+        parts = b"".join(b"%d%s%s" % (rng.integers(0, 10 ** int(rng.integers(1, 6))), (b".%d" % rng.integers(0, 1000)) if rng.integers(0, 3) == 0 else b"", units[int(rng.integers(0, len(units)))])
+                         for _ in range(int(rng.integers(1, 4))))
+        mant = b"%d.%d" % (rng.integers(0, 10 ** int(rng.integers(1, 12))), rng.integers(0, 10 ** int(rng.integers(1, 10))))
+        ftxt = mant + ((b"e%d" % rng.integers(-40, 40)) if rng.integers(0, 2) else b"")
+        rows.append(b"%d,%s%s,%s%s" % (i, b"-" if rng.integers(0, 5) == 0 else b"", parts, b"-" if rng.integers(0, 4) == 0 else b"", ftxt))
+    out, errs = compare(tf, oracle, dict(), S, b"\n".join(rows) + b"\n", "random", max_fallback=60)
+    assert out.nrows > 1500
+    # DecimalPoint applies to float32 cells as to doubles; null values to intervals
+    S2 = abi.Schema.of([["d", "interval", False, "0"], ["f", "float", False, "1"]])
+    compare(tf, oracle, dict(decimal_point="#", null_values=["NULL", ""], strings_can_be_null=1), S2, b"NULL,1#5\n1h,2#25e1\n,#5\n3,1#2#3\n", "decimal point")

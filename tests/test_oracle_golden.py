@@ -216,3 +216,16 @@ def test_time_parse_golden():
     for layout, value, expect, why in g["cases"]:
         got = ora.time_parse(layout, value)
         assert (None if got is None else [int(got[0]), int(got[1])]) == expect, (layout, value, why)
+
+
+def test_parse_duration_golden():
+    """oracle/ora_gofmt.c's time.ParseDuration against Go's own published test tables, and cast.ToDurationE(string) in front of it
+    (tests/golden/goduration.json, written by tools/gen_goduration_golden.py; restated by hand, the file says so)."""
+    import json
+    import os
+    from oracle import oracle as ora
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "goduration.json")))
+    for hx, expect, text in g["parse_duration"]:
+        assert ora.parse_duration(bytes.fromhex(hx)) == expect, text
+    for hx, expect, text in g["cast"]:
+        assert ora.parse_duration(bytes.fromhex(hx), cast=True) == expect, text

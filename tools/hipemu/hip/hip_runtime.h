@@ -69,6 +69,8 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(
 inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
 inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 inline unsigned __float_as_uint(float f) { unsigned v; std::memcpy(&v, &f, 4); return v; }
 inline float __uint_as_float(unsigned v) { float f; std::memcpy(&f, &v, 4); return f; }
 inline float __uint2float_rz(unsigned x) { float f = (float)x; if ((double)f > (double)x) f = std::nextafterf(f, 0.0f); return f; }

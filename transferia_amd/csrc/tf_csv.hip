@@ -150,6 +150,7 @@ struct CsvOpts {
   const uint8_t *dp;         // AdditionalReaderOptions.DecimalPoint
   uint32_t dp_len;
   uint32_t multiline;        // NewlinesInValue: a row may span physical lines
+  const uint64_t *p128;      // Eisel-Lemire's 128-bit powers of ten when the schema holds a float32 column, else null
 };
 
 // sanitizeElement reader.go:273-324: TrimSpace, unquote, count ""-pairs.
@@ -490,7 +491,39 @@ __device__ int parse_cell(const CsvOpts &o, const CsvCol &c, int64_t r, const F 
       ((uint8_t *)c.values)[r] = (uint8_t)v;
       return 0;
     }
-    default:  // CK_F32 (strconv.ParseFloat 32-bit rounding), CK_INTERVAL: host path
+    case CK_F32: {  // parseFloatValue :363-378 (DecimalPoint), then strictify: cast.ToFloat32E(string) = strconv.ParseFloat(s, 32), any error fails the row
+      if (npairs) return TFGPU_ROW_CAST;  // a '"' survives in the text: not a number
+      float v = 0; int rc = -1;
+      if (o.dp_len && b - a >= o.dp_len) {
+        uint32_t k = PATCH_NONE;
+        for (uint32_t i = a; i + o.dp_len <= b && k == PATCH_NONE; i++) {
+          bool eq = true;
+          for (uint32_t j = 0; j < o.dp_len && eq; j++) eq = fv[i + j] == o.dp[j];
+          if (eq) k = i - a;
+        }
+        if (k != PATCH_NONE) {  // the replaced text is the value only if ParseFloat(…, 64) takes it
+          const Patched<F> pt{fv, a, k, o.dp_len};
+          const uint32_t pn = (b - a) - o.dp_len + 1;
+          const int pe = parsefloat_err(pt, pn);
+          if (pe == 2) return TFGPU_ROW_HOST_FALLBACK;
+          if (pe == 0) rc = parse_float32_go(pt, 0, pn, o.p128, &v);
+        }
+      }
+      if (rc < 0) rc = parse_float32_go(fv, a, b, o.p128, &v);
+      if (rc == 3) return TFGPU_ROW_HOST_FALLBACK;  // Go's decimal slow path (half-way cases, subnormals, the overflow edge), hex floats, '_'
+      if (rc) return TFGPU_ROW_CAST;                // syntax or range: ToFloat32E returns the error
+      ((float *)c.values)[r] = v;
+      return 0;
+    }
+    case CK_INTERVAL: {  // parseNullValues, then strictify: cast.ToDurationE(string) (strictify.go:142-147)
+      if (cell_is_null(o, fv, a, b, npairs)) { store_default(c, r); return 0; }
+      if (npairs) return TFGPU_ROW_CAST;  // a '"' in the text reads as part of a unit: unknown unit
+      int64_t d;
+      if (parse_duration_go(fv, a, b, &d)) return TFGPU_ROW_CAST;
+      ((int64_t *)c.values)[r] = d;
+      return 0;
+    }
+    default:
       return TFGPU_ROW_HOST_FALLBACK;
   }
 }
@@ -2269,6 +2302,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.o.user_tp = GtSet{ptr<GtOp>(bgops), ptr<uint8_t>(bglits), ptr<uint16_t>(bgsu), opts->n_timestamp_parsers};
   pp.o.cast_tp = GtSet{ptr<GtOp>(bgops), ptr<uint8_t>(bglits), ptr<uint16_t>(bgsc), (int32_t)(sizeof CAST_LAYOUTS / sizeof *CAST_LAYOUTS)};
   pp.o.dp = ptr<uint8_t>(bdp); pp.o.dp_len = (uint32_t)dp.size(); pp.o.multiline = multiline ? 1u : 0u;
+  pp.o.p128 = nullptr;
+  for (auto &c : cols) if (c.kind == CK_F32) pp.o.p128 = reinterpret_cast<const uint64_t *>(pow10_table() + 632);
   pp.cols = ptr<CsvCol>(bcols); pp.ncols = ncols; pp.field_first = ptr<int32_t>(bff); pp.nfields_used = max_field + 1;
   pp.err = ptr<uint8_t>(err); pp.err_col = ptr<int32_t>(err_col); pp.nerr = ptr<uint32_t>(nerr);
   static const int ablate = [] { const char *e = std::getenv("TFGPU_CSV_ABLATE"); return e ? std::atoi(e) : 0; }();

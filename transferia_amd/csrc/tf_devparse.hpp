@@ -296,6 +296,185 @@ template <class F> __device__ int parse_float_go(const F &f, uint32_t a, const u
   return 0;
 }
 
+// strconv.eiselLemire32: the same with float32's widths (23 mantissa bits, bias 127, 38 discarded bits)
+__device__ __forceinline__ bool eisel_lemire32(uint64_t man, int exp10, const uint64_t *tab, uint32_t *bits_out) {
+  if (exp10 < -348 || exp10 > 347) return false;
+  const int clz = __clzll((long long)man);
+  man <<= clz;
+  uint64_t ret_exp2 = (uint64_t)((217706 * exp10 >> 16) + 64 + 127) - (uint64_t)clz;
+  const uint64_t plo = tab[2 * (exp10 + 348)], phi = tab[2 * (exp10 + 348) + 1];
+  uint64_t x_hi = __umul64hi(man, phi), x_lo = man * phi;
+  constexpr uint64_t M = 0x3FFFFFFFFFull;
+  if ((x_hi & M) == M && x_lo + man < man) {  // wider approximation
+    const uint64_t y_hi = __umul64hi(man, plo), y_lo = man * plo;
+    uint64_t m_hi = x_hi;
+    const uint64_t m_lo = x_lo + y_hi;
+    if (m_lo < x_lo) m_hi++;
+    if ((m_hi & M) == M && m_lo + 1 == 0 && y_lo + man < man) return false;
+    x_hi = m_hi; x_lo = m_lo;
+  }
+  const uint64_t msb = x_hi >> 63;
+  uint64_t ret_man = x_hi >> (msb + 38);
+  ret_exp2 -= 1 ^ msb;
+  if (x_lo == 0 && (x_hi & M) == 0 && (ret_man & 3) == 1) return false;  // half-way ambiguity
+  ret_man += ret_man & 1;
+  ret_man >>= 1;
+  if (ret_man >> 24) { ret_man >>= 1; ret_exp2 += 1; }
+  if (ret_exp2 - 1 >= 0xFF - 1) return false;  // subnormal or Inf/NaN space
+  *bits_out = (uint32_t)(ret_exp2 << 23 | (ret_man & 0x007FFFFFull));
+  return true;
+}
+
+// strconv.ParseFloat(s, 32) as atof32 decides it: special(), readFloat, atof32exact (float32 arithmetic, mantissa < 2^24,
+// powers up to 10^10), then eiselLemire32 — on mantissa + 1 as well when digits were truncated.  Same return codes as
+// parse_float_go; what Go leaves to its decimal slow path (half-way cases, subnormals, the overflow boundary) is 3.
+template <class F> __device__ int parse_float32_go(const F &f, uint32_t a, const uint32_t b, const uint64_t *p128, float *out) {
+  uint32_t i = a;
+  *out = 0;
+  if (i >= b) return 1;
+  bool neg = false, sign = false;
+  if (f[i] == '+') { i++; sign = true; } else if (f[i] == '-') { neg = true; sign = true; i++; }
+  {
+    const uint32_t n = b - i;
+    auto eq = [&](const char *w, uint32_t wl) { if (n != wl) return false; for (uint32_t k = 0; k < wl; k++) if (lower_(f[i + k]) != (uint32_t)w[k]) return false; return true; };
+    if (eq("inf", 3) || eq("infinity", 8)) { *out = neg ? -INFINITY : INFINITY; return 0; }
+    if (!sign && eq("nan", 3)) { *out = NAN; return 0; }
+  }
+  if (b - i >= 2 && f[i] == '0' && lower_(f[i + 1]) == 'x') return 3;
+  uint64_t mant = 0;
+  int nd = 0, ndm = 0, dp = 0;
+  bool sawdot = false, sawdigits = false, trunc = false;
+  for (; i < b; i++) {
+    const uint32_t c = f[i];
+    if (c == '_') return 3;
+    if (c == '.') { if (sawdot) break; sawdot = true; dp = nd; continue; }
+    if (dg(c)) {
+      sawdigits = true;
+      if (c == '0' && nd == 0) { dp--; continue; }
+      nd++;
+      if (ndm < 19) { mant = mant * 10 + (c - '0'); ndm++; } else if (c != '0') trunc = true;
+      continue;
+    }
+    break;
+  }
+  if (!sawdigits) return 1;
+  if (!sawdot) dp = nd;
+  if (i < b && lower_(f[i]) == 'e') {
+    i++;
+    if (i >= b) return 1;
+    int esign = 1;
+    if (f[i] == '+') i++; else if (f[i] == '-') { i++; esign = -1; }
+    if (i >= b || !dg(f[i])) return 1;
+    int e = 0;
+    for (; i < b && (dg(f[i]) || f[i] == '_'); i++) {
+      if (f[i] == '_') return 3;
+      if (e < 10000) e = e * 10 + (int)(f[i] - '0');
+    }
+    dp += e * esign;
+  }
+  if (i != b) return 1;
+  if (mant == 0) { *out = neg ? -0.0f : 0.0f; return 0; }
+  // the value is in [10^(dp-1), 10^dp): above float32's largest (3.4e38) from dp = 40 on — ±Inf and ErrRange out of Go's slow
+  // path — and below half its smallest subnormal (7e-46) up to dp = -46, which rounds to ±0 without an error
+  if (dp > 39) { *out = neg ? -INFINITY : INFINITY; return 2; }
+  if (dp < -45) { *out = neg ? -0.0f : 0.0f; return 0; }
+  const int exp10 = dp - ndm;
+  if (!trunc && !(mant >> 23)) {  // atof32exact
+    const float P[11] = {1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+    float v = (float)mant;
+    bool exact = true;
+    if (exp10 > 0 && exp10 <= 7 + 10) {
+      int e = exp10;
+      if (e > 10) { v = __fmul_rn(v, P[e - 10]); e = 10; }
+      if (v > 1e7f) exact = false; else v = __fmul_rn(v, P[e]);
+    } else if (exp10 < 0 && exp10 >= -10) v = __fdiv_rn(v, P[-exp10]);
+    else if (exp10 != 0) exact = false;
+    if (exact) { *out = neg ? -v : v; return 0; }
+  }
+  uint32_t bits;
+  if (!eisel_lemire32(mant, exp10, p128, &bits)) return 3;
+  if (trunc) {
+    uint32_t up;
+    if (!eisel_lemire32(mant + 1, exp10, p128, &up) || up != bits) return 3;
+  }
+  if (neg) bits |= 0x80000000u;
+  *out = __uint_as_float(bits);
+  return 0;
+}
+
+// time.ParseDuration (time/format.go) behind spf13/cast v1.7.1's ToDurationE(string) (caste.go: a string holding none of
+// "nsuµmh" gets "ns" appended): [-+]?([0-9]*(\.[0-9]*)?unit)+ with leadingInt / leadingFraction's overflow rules and the
+// fraction added through float64 exactly as Go does.  0 = ok, 1 = error.
+template <class F> __device__ int parse_duration_go(const F &f, uint32_t a, uint32_t b, int64_t *out) {
+  *out = 0;
+  bool has_unit_char = false;
+  for (uint32_t i = a; i < b; i++) {
+    const uint32_t c = f[i];
+    if (c == 'n' || c == 's' || c == 'u' || c == 'm' || c == 'h' || (c == 0xC2 && i + 1 < b && f[i + 1] == 0xB5)) { has_unit_char = true; break; }
+  }
+  uint32_t i = a;
+  bool neg = false;
+  if (i < b && (f[i] == '-' || f[i] == '+')) { neg = f[i] == '-'; i++; }
+  // (ParseDuration's `s == "0"` shortcut cannot be reached: "0" holds no unit character, so it arrives as "0ns")
+  if (i >= b) return 1;  // "" or a bare sign: the text is "ns", which starts with no digit
+  constexpr uint64_t TOP = 1ull << 63;
+  uint64_t d = 0;
+  bool appended_done = false;  // the appended "ns" is the unit of the last (and only unit-less) group
+  while (i < b) {
+    if (!(f[i] == '.' || dg(f[i]))) return 1;
+    uint64_t v = 0, fr = 0; double scale = 1;
+    const uint32_t pl = i;
+    for (; i < b && dg(f[i]); i++) {  // leadingInt
+      if (v > TOP / 10) return 1;
+      v = v * 10 + (f[i] - '0');
+      if (v > TOP) return 1;
+    }
+    const bool pre = i != pl;
+    bool post = false;
+    if (i < b && f[i] == '.') {
+      i++;
+      const uint32_t pf = i;
+      bool over = false;
+      for (; i < b && dg(f[i]); i++) {  // leadingFraction
+        if (over) continue;
+        if (fr > (TOP - 1) / 10) { over = true; continue; }
+        const uint64_t y = fr * 10 + (f[i] - '0');
+        if (y > TOP) { over = true; continue; }
+        fr = y; scale *= 10;
+      }
+      post = i != pf;
+    }
+    if (!pre && !post) return 1;
+    uint32_t u0 = i;
+    for (; i < b; i++) { const uint32_t c = f[i]; if (c == '.' || dg(c)) break; }
+    uint64_t unit = 0;
+    const uint32_t ul = i - u0;
+    if (ul == 0) {
+      if (has_unit_char || appended_done || i != b) return 1;  // missing unit
+      unit = 1; appended_done = true;                            // the appended "ns"
+    } else {
+      auto is = [&](const char *w, uint32_t wl) { if (ul != wl) return false; for (uint32_t k = 0; k < wl; k++) if (f[u0 + k] != (uint32_t)(uint8_t)w[k]) return false; return true; };
+      // without a unit character in the text "ns" is appended to the LAST unit: "5x" reads the unit "xns"
+      if (!has_unit_char) return 1;
+      if (is("ns", 2)) unit = 1; else if (is("us", 2) || is("\xC2\xB5s", 3) || is("\xCE\xBCs", 3)) unit = 1000;
+      else if (is("ms", 2)) unit = 1000000; else if (is("s", 1)) unit = 1000000000ull; else if (is("m", 1)) unit = 60000000000ull;
+      else if (is("h", 1)) unit = 3600000000000ull; else return 1;
+    }
+    if (v > TOP / unit) return 1;
+    v *= unit;
+    if (fr > 0) {
+      v += (uint64_t)((double)fr * ((double)unit / scale));
+      if (v > TOP) return 1;
+    }
+    d += v;
+    if (d > TOP) return 1;
+  }
+  if (neg) { *out = (int64_t)(0 - d); return 0; }
+  if (d > TOP - 1) return 1;
+  *out = (int64_t)d;
+  return 0;
+}
+
 // math.Pow10(n), n = -323..308 (632 doubles) followed by the 128-bit powers of Eisel-Lemire (696 x 2 words): HBM-resident,
 // built once per lane (tf_json.hip)
 const double *pow10_table();
