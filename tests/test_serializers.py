@@ -306,7 +306,7 @@ def test_gpu_raw_refusals(tf):
 
 @pytest.mark.gpu
 def test_gpu_rows_larger_than_the_lds_image(tf, oracle):
-    """ser_chunk_write assembles 64 rows of a column chunk in the wave's 12 KiB LDS image; tiles that outgrow it (one 70 KB cell)
+    """ser_chunk_write assembles 64 rows of a column chunk in the wave's 9 KiB LDS image; tiles that outgrow it (one 70 KB cell)
     are written by the same wave straight to HBM.  Mixed batch: both paths, every format."""
     import random
     rng = random.Random(SEED0 + 31)

@@ -252,7 +252,10 @@ __device__ __forceinline__ CellBits load_cell(const DCol &c, int64_t r) {
     case TFGPU_R_INT16: case TFGPU_R_UINT16: b.v = ((const uint16_t *)c.values)[r]; break;
     case TFGPU_R_INT32: case TFGPU_R_UINT32: case TFGPU_R_FLOAT32: b.v = ((const uint32_t *)c.values)[r]; break;
     case TFGPU_R_INT64: case TFGPU_R_UINT64: case TFGPU_R_FLOAT64: case TFGPU_R_DURATION: b.v = ((const uint64_t *)c.values)[r]; break;
-    case TFGPU_R_TIME: b.v = ((const uint64_t *)c.values)[r]; if (c.nanos) b.ns = c.nanos[r]; break;
+    case TFGPU_R_TIME:
+      b.v = ((const uint64_t *)c.values)[r];
+      if (c.nanos) b.ns = c.nanos[r];
+      break;
     default: break;
   }
   return b;

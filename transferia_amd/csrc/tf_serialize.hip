@@ -376,7 +376,10 @@ __global__ void __launch_bounds__(256) ser_row_frame(SerParams p) {
 //     8-byte boundaries of the image: no sharing, no atomics, no zeroing), which then leaves as aligned 8-byte words.
 // The JSONEachRow separator moves in FRONT of the cell ('{' before the row's first present cell, ',' before the others), so
 // the prefix is a per-column constant but for its first byte and nobody has to know which column is a row's last.
-constexpr uint32_t WAVE_IMG_BYTES = 12288;   // per wave: 4 waves x 12 KiB = 48 KiB per workgroup, three workgroups per CU
+#ifndef TF_SER_WAVE_IMG
+#define TF_SER_WAVE_IMG 9216
+#endif
+constexpr uint32_t WAVE_IMG_BYTES = TF_SER_WAVE_IMG;   // per wave: 4 waves x 9 KiB = 36 KiB per workgroup, four workgroups per CU
 TF_DYNAMIC_LDS(uint32_t, img);               // named at file scope: the sink's stores are ds_write (through a pointer member: flat)
 
 struct LdsSink {
@@ -432,11 +435,19 @@ __device__ __forceinline__ DCol rec_dcol(uint32_t rec) {
 // Groups of WALK_AHEAD cells: the group's records, then every load of the group (validity byte, value or offsets, nanoseconds)
 // are issued before its first cell is formatted, so a lane waits for memory twice per group instead of three or four times per
 // cell.  ALL 64 lanes of the wave must run the walk (the records live across its lanes).
+// four waves per SIMD for the length pass: it is latency-bound (three waves: 1.51 ms, four: 1.26 ms on configs[3]; five spill too much)
+#ifndef TF_SER_LEN_ATTR
+#define TF_SER_LEN_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+// … and for the write pass (9 KiB of image per wave: 16 waves x 9 KiB per CU; measured 3.04 -> 2.8 ms with a lookahead of four)
+#ifndef TF_SER_WRITE_ATTR
+#define TF_SER_WRITE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 #ifndef TF_SER_LEN_AHEAD
 #define TF_SER_LEN_AHEAD 8
 #endif
 #ifndef TF_SER_WRITE_AHEAD
-#define TF_SER_WRITE_AHEAD 8
+#define TF_SER_WRITE_AHEAD 4
 #endif
 constexpr int LEN_AHEAD = TF_SER_LEN_AHEAD, WRITE_AHEAD = TF_SER_WRITE_AHEAD;
 template <int FMT, class S> __device__ __forceinline__ void walk_cell(S &s, const SerParams &p, uint32_t rec, const CellBits &b, bool &first) {
@@ -494,7 +505,7 @@ template <int FMT, class S> __device__ __forceinline__ void row_tail(S &s, const
 
 // (1) bytes per (row, chunk)
 template <int FMT>
-__global__ void __launch_bounds__(256) ser_chunk_len(SerParams p, ChunkPlan cp) {
+__global__ void __launch_bounds__(256) TF_SER_LEN_ATTR ser_chunk_len(SerParams p, ChunkPlan cp) {
   const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   int32_t k; int64_t r0;
   tile_of(cp, tile, k, r0);
@@ -529,7 +540,7 @@ __global__ void __launch_bounds__(256) ser_chunk_layout(SerParams p, ChunkPlan c
 }
 // (4) the text
 template <int FMT>
-__global__ void __launch_bounds__(256) ser_chunk_write(SerParams p, ChunkPlan cp) {
+__global__ void __launch_bounds__(256) TF_SER_WRITE_ATTR ser_chunk_write(SerParams p, ChunkPlan cp) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   int32_t k; int64_t r0;
@@ -841,9 +852,9 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
       { KernelTimer t("ser_cell_len"); if (ncell) ser_cell_len<<<blocks(ncell), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
     } else {
-      // the cuts: consecutive columns until the ESTIMATED text of a row's chunk passes the target (64 rows of a chunk share a 12 KiB
-      // image, i.e. 192 bytes per row; an estimate that is off only sends more tiles down the direct path)
-      static const uint32_t target = [] { const char *e = std::getenv("TFGPU_SER_CHUNK_BYTES"); return e ? (uint32_t)std::atoi(e) : 136u; }();
+      // the cuts: consecutive columns until the ESTIMATED text of a row's chunk passes the target (64 rows of a chunk share a 9 KiB
+      // image, i.e. 144 bytes per row; an estimate that is off only sends more tiles down the direct path)
+      static const uint32_t target = [] { const char *e = std::getenv("TFGPU_SER_CHUNK_BYTES"); return e ? (uint32_t)std::atoi(e) : 112u; }();
       std::vector<int32_t> cut{0};
       double acc = 0;
       for (int j = 0; j < ncols; j++) {
