@@ -353,9 +353,25 @@ class CsvWorkload(Base):
         if not k:
             return None
         ach = MASK_INT_OPS_PER_VALUE * self.state["parsed_rows"] / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
-        return {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s",
-                "frac": round(ach / INT32_PEAK_TOPS, 4), "int_ops_per_value": MASK_INT_OPS_PER_VALUE,
-                "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low"}
+        out = {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s",
+               "frac": round(ach / INT32_PEAK_TOPS, 4), "int_ops_per_value": MASK_INT_OPS_PER_VALUE,
+               "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low"}
+        # the same fraction from the kernel's MEASURED VALU instruction count per value (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of this
+        # very source, tools/gpu_round3.sh) instead of the algorithmic tally: instructions issued, against one per lane per cycle
+        try:
+            import hashlib
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f).get("mask_hmac_sha256")
+            with open(os.path.join(ROOT, "transferia_amd", "csrc", t["source_file"]), "rb") as f:
+                if hashlib.sha256(f.read()).hexdigest() == t["source_sha256"]:
+                    per = t["valu_instructions_per_value"]
+                    issued = per * self.state["parsed_rows"] / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
+                    out["measured_valu_instructions_per_value"] = per
+                    out["issued"] = round(issued, 2)
+                    out["issue_frac"] = round(issued / INT32_PEAK_TOPS, 4)
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+        return out
 
     def config(self):
         s, e = self.state, self.env
@@ -1195,15 +1211,18 @@ def main():
     if dom and alg.get(dom):
         per_launch = alg[dom] / max(kernels[dom]["launches_per_step"], 1)
         achieved = per_launch / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        # HBM traffic per launch cannot be read inside this process: it comes from the rocprofv3 --pmc passes whose summary is
-        # committed under profiles/ (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections); null when the recorded launch
-        # shape is not this run's.
+        # HBM traffic per launch cannot be read inside this process: it comes from the rocprofv3 --pmc passes of tools/gpu_round3.sh
+        # (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections), which stamp profiles/pmc_traffic.json with the sha256 of
+        # the kernel's source file — a number measured on another build of the kernel (or another launch shape) is not printed.
         traffic = None
         try:
+            import hashlib
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 t = json.load(f).get(dom)
             if t and t["rows_per_launch"] == W.rows() and t.get("workload", "csv") == args.workload:
-                traffic = t["bytes_per_launch"]
+                with open(os.path.join(ROOT, "transferia_amd", "csrc", t["source_file"]), "rb") as f:
+                    fresh = hashlib.sha256(f.read()).hexdigest() == t["source_sha256"]
+                traffic = t["bytes_per_launch"] if fresh else None
         except (OSError, ValueError, KeyError):
             pass
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
