@@ -376,6 +376,17 @@ class Schema:
         return "invalid"
 
     def to_c(self):
+        # memoised on the content: building 105 tfgpu_colschema structs through ctypes is ~0.5 ms of Python, paid by every call
+        # that takes a schema; a Go caller converts its TableSchema once
+        fp = tuple((c.name, c.dtype, c.key, c.path, c.original_type, c.required, c.table_schema, c.table_name, c.expression, c.fake_key, c.properties_json) for c in self.cols)
+        hit = self.__dict__.get("_c_memo")
+        if hit is not None and hit[0] == fp:
+            return hit[1]
+        s = self._to_c()
+        self.__dict__["_c_memo"] = (fp, s)
+        return s
+
+    def _to_c(self):
         arr = (CColSchema * max(len(self.cols), 1))()
         keep = []
         for i, c in enumerate(self.cols):

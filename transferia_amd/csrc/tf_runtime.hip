@@ -49,7 +49,8 @@ static std::unique_ptr<Context> make_lane(int lane) {  // the caller's HIP devic
   ensure_device(c->device);
   TF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->pin_cap = 8u << 20;
-  TF_HIP(hipHostMalloc(&c->pin_base, c->pin_cap, hipHostMallocPortable));
+  // (portable pinned memory only when there is more than one device to be portable to: on a single device the plain form)
+  TF_HIP(hipHostMalloc(&c->pin_base, c->pin_cap, g_devices.size() > 1 ? hipHostMallocPortable : hipHostMallocDefault));
   return c;
 }
 // binds the calling thread to `lane` (created on first use) and makes the lane's device the thread's HIP device
@@ -338,7 +339,7 @@ void *tfgpu_stream(void) { return (g_ctx && g_lanes[g_lane]) ? (void *)g_lanes[g
 int tfgpu_host_alloc(size_t bytes, void **out) {
   TF_API_BEGIN
   ctx();
-  TF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable));
+  TF_HIP(hipHostMalloc(out, bytes ? bytes : 1, g_devices.size() > 1 ? hipHostMallocPortable : hipHostMallocDefault));
   return TFGPU_OK;
   TF_API_END
 }

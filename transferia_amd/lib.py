@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import threading
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -467,7 +468,7 @@ def apply_chain(transformers: Sequence[Transformer], batch: DeviceBatch, max_err
     n = len(transformers)
     arr = (C.c_void_p * max(n, 1))(*[t._h for t in transformers])
     out = C.c_void_p()
-    errs = (abi.CRowError * max_errors)()
+    errs = _errbuf(max_errors)
     nerr = C.c_int64(0)
     _check(load().tfgpu_apply(arr, n, batch._h, C.byref(out), errs, max_errors, C.byref(nerr)))
     el = [(int(errs[i].row), abi.ROWERR.get(int(errs[i].code), str(errs[i].code)), int(errs[i].step), int(errs[i].column))
@@ -676,14 +677,30 @@ class Comm:
             self._h = None
 
 
-def csv_parse(opts: abi.CCsvOptions, schema: abi.Schema, data, max_errors: int = 1 << 16):
-    """s3 CSVReader.parseCSVRows + Strictify on device.  `data` is bytes or a DeviceBuffer.
+_tls = threading.local()
+
+
+def _errbuf(max_errors: int):
+    """the per-row error array of a call, kept per thread and size: allocating (and zeroing) 2^16 entries costs ~70 us of host time
+    per call, which a Go caller with its own slice never pays"""
+    cache = getattr(_tls, "errs", None)
+    if cache is None:
+        cache = _tls.errs = {}
+    buf = cache.get(max_errors)
+    if buf is None:
+        buf = cache[max_errors] = (abi.CRowError * max_errors)()
+    return buf
+
+
+def csv_parse(opts: abi.CCsvOptions, schema, data, max_errors: int = 1 << 16):
+    """s3 CSVReader.parseCSVRows + Strictify on device.  `data` is bytes or a DeviceBuffer; `schema` an abi.Schema or the
+    tfgpu_schema it converts to (abi.Schema.to_c() of 105 columns is ~0.5 ms of Python: callers with a fixed schema convert once).
     Returns (DeviceBatch, consumed_bytes, errors)."""
     init()
     L = load()
-    cs = schema.to_c()
+    cs = schema if isinstance(schema, abi.CSchema) else schema.to_c()
     out, consumed, nerr = C.c_void_p(), C.c_uint64(0), C.c_int64(0)
-    errs = (abi.CRowError * max_errors)()
+    errs = _errbuf(max_errors)
     if isinstance(data, DeviceBuffer):
         _check(L.tfgpu_csv_parse(C.byref(opts), C.byref(cs), data.ptr, data.size, abi.MEM_DEVICE, C.byref(out), C.byref(consumed), errs,
                                  max_errors, C.byref(nerr)))
@@ -719,7 +736,7 @@ def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data, msgs: Optional[
     L = load()
     cs = fields.to_c()
     out, nerr = C.c_void_p(), C.c_int64(0)
-    errs = (abi.CRowError * max_errors)()
+    errs = _errbuf(max_errors)
     mp = C.byref(msgs) if msgs is not None else None
     if isinstance(data, DeviceBuffer):
         _check(L.tfgpu_json_parse(C.byref(opts), C.byref(cs), data.ptr, data.size, abi.MEM_DEVICE, mp, C.byref(out), errs, max_errors, C.byref(nerr)))
@@ -774,7 +791,7 @@ def sr_json_parse(opts: abi.CSrJsonOptions, data, msgs: Optional[abi.CMessages] 
     part_id = message index) + [(frame ordinal, code, message index)] for the frames that become `_unparsed` items."""
     init()
     ptr_, n, mem, keep = _bytes_arg(data)
-    errs = (abi.CRowError * max_errors)()
+    errs = _errbuf(max_errors)
     ne, out = C.c_int64(0), C.c_void_p()
     _check(load().tfgpu_sr_json_parse(C.byref(opts), ptr_, n, mem, C.byref(msgs) if msgs is not None else None, C.byref(out), errs, max_errors, C.byref(ne)))
     return ParseResult(DeviceBatch(out), [(int(errs[i].row), int(errs[i].code), int(errs[i].step)) for i in range(min(int(ne.value), max_errors))])
@@ -814,7 +831,7 @@ def debezium_parse(schema_hash, fields, data, frames: np.ndarray, msgs: Optional
     o.nfields, o.fields, o.schema_code = len(fields), arr, schema_code
     rows = np.zeros(max(nmsg, 1), abi.DBZ_ROW_DTYPE)
     fr = np.ascontiguousarray(frames)
-    errs = (abi.CRowError * max_errors)()
+    errs = _errbuf(max_errors)
     ne, out = C.c_int64(0), C.c_void_p()
     _check(load().tfgpu_debezium_parse(C.byref(o), ptr_, n, mem, C.byref(msgs) if msgs is not None else None, fr.ctypes.data, C.byref(out), rows.ctypes.data, nmsg,
                                        errs, max_errors, C.byref(ne)))
