@@ -256,6 +256,48 @@ int tfgpu_dbatch_to_lane(const tfgpu_dbatch *b, int lane, tfgpu_dbatch **out);
 int tfgpu_shard_rows(const tfgpu_dbatch *b, int nshards, const int *lanes, tfgpu_dbatch **out, int64_t *row0);
 int tfgpu_dbatch_concat(const tfgpu_dbatch *const *parts, int nparts, const int64_t *row_base, tfgpu_dbatch **out);
 
+/* ---- ParseQueue and Bufferer: the scheduling either side of the device path (tf_pipeline.cpp) ----------------------------
+ * tfgpu_parsequeue = parsequeue.ParseQueue[TData] (pkg/parsequeue/parsequeue.go:16-217): bounded-parallel parse, in-order
+ * push, in-order ack.  `msg` is the caller's handle of a message batch (TData).  Add() starts parse(user, msg, slot, &parsed) at
+ * once on a thread of its own and blocks while `parallelism` parses are in flight; slot is in [0, parallelism) and unique among
+ * the parses running at the same time — the shim binds it to a device lane (tfgpu_lane_use(1 + slot % lanes)), so parses
+ * overlap on the GPU.  In Add order: push(user, parsed, &ticket) = sink.AsyncPush (must not block on the sink), then
+ * wait(user, ticket, timeout_ms) = the read of its error channel (0 = pushed, TFGPU_PQ_PENDING = not yet, else the error), then
+ * ack(user, msg, push_start_ns).  The first error of a parse, a push or an ack cancels the queue; Add then fails and
+ * tfgpu_parsequeue_error returns that error's code and "parse queue: <stage> error: …".  parallelism 0 = 10, below 2 = 2, as
+ * parsequeue.New.  Close cancels and joins; it does not wait for pending pushes (the reference's Close does not either).    */
+#define TFGPU_PQ_PENDING (-1)
+typedef struct tfgpu_parsequeue tfgpu_parsequeue;
+typedef int (*tfgpu_pq_parse_fn)(void *user, uint64_t msg, int slot, void **parsed);
+typedef int (*tfgpu_pq_push_fn)(void *user, void *parsed, uint64_t *ticket);
+typedef int (*tfgpu_pq_wait_fn)(void *user, uint64_t ticket, int64_t timeout_ms);
+typedef int (*tfgpu_pq_ack_fn)(void *user, uint64_t msg, int64_t push_start_ns);
+int tfgpu_parsequeue_create(int parallelism, tfgpu_pq_parse_fn parse, tfgpu_pq_push_fn push, tfgpu_pq_wait_fn wait, tfgpu_pq_ack_fn ack, void *user, tfgpu_parsequeue **out);
+int tfgpu_parsequeue_add(tfgpu_parsequeue *q, uint64_t msg);
+int tfgpu_parsequeue_error(tfgpu_parsequeue *q, char *msg, size_t cap);   /* 0 = no error so far */
+int tfgpu_parsequeue_close(tfgpu_parsequeue *q);
+void tfgpu_parsequeue_destroy(tfgpu_parsequeue *q);
+
+/* tfgpu_bufferer = middlewares/synchronizer/bufferer (bufferer.go:16-249, buffer.go:26-56): pushes of device batches are
+ * collected until TriggingCount rows, TriggingSize bytes of Values (tfgpu_dbatch_deepsizeof's total: the caller passes it),
+ * TriggingInterval since the start of the last flush, or a non-row item (zero = the trigger does not apply; Close flushes
+ * what is left).  One flush is in flight at a time; the next one waits for it.  A flush hands the sink ONE batch: the only
+ * buffered batch itself, or — the single concat copy of buffer.Flush — tfgpu_dbatch_concat of the buffered batches on the
+ * calling process's device (concat_on_device = 1; with 0 `merged` is NULL for several parts and the sink sees `parts`).
+ * flush(user, merged, parts, nparts, nrows, values_size) returns the sink's error, which every buffered push's ticket then
+ * carries (tfgpu_bufferer_wait; TFGPU_PQ_PENDING on a timeout, timeout_ms < 0 = wait).  The batches stay the caller's: they
+ * may be freed once their ticket is answered.  async_push blocks until the collector has taken the item (the reference's
+ * unbuffered input channel: backpressure).                                                                               */
+typedef struct tfgpu_bufferer tfgpu_bufferer;
+typedef struct tfgpu_bufferer_stats { int64_t flush_all, flush_on_count, flush_on_size, flush_on_interval, flush_on_non_row; } tfgpu_bufferer_stats;
+typedef int (*tfgpu_buf_flush_fn)(void *user, const tfgpu_dbatch *merged, const tfgpu_dbatch *const *parts, int nparts, int64_t nrows, uint64_t values_size);
+int tfgpu_bufferer_create(int64_t trigging_count, uint64_t trigging_size, int64_t trigging_interval_ms, int concat_on_device, tfgpu_buf_flush_fn flush, void *user, tfgpu_bufferer **out);
+int tfgpu_bufferer_async_push(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int64_t nrows, uint64_t values_size, int has_non_row_item, uint64_t *ticket);
+int tfgpu_bufferer_wait(tfgpu_bufferer *b, uint64_t ticket, int64_t timeout_ms);
+int tfgpu_bufferer_get_stats(tfgpu_bufferer *b, tfgpu_bufferer_stats *out);
+int tfgpu_bufferer_close(tfgpu_bufferer *b);
+void tfgpu_bufferer_destroy(tfgpu_bufferer *b);
+
 /* Pinned staging memory (hipHostMalloc) for double-buffered H2D/D2H.        */
 int tfgpu_host_alloc(size_t bytes, void **out);
 int tfgpu_host_free(void *p);
