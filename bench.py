@@ -1149,6 +1149,8 @@ def main():
 
     import torch  # first: libtfgpu and torch must share the HIP runtime torch loads
     from transferia_amd import abi, dist as tdist, lib, workload
+    if os.environ.get("TFGPU_LIB_VARIANT"):  # measurement only: an A/B build of the same sources (tools/build_variant.sh); the binding itself knows one library
+        lib._LIBPATH = os.path.join(os.path.dirname(lib._LIBPATH), "variants", "libtfgpu_%s.so" % os.environ["TFGPU_LIB_VARIANT"])
     rank, local_rank, world = tdist.env_rank()
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)

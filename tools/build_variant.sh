@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B builds: one translation unit recompiled with extra -D flags and linked with the product's other objects into
-# transferia_amd/variants/libtfgpu_<name>.so; TFGPU_LIB_VARIANT=<name> makes transferia_amd.lib load it (measurement only).
+# transferia_amd/variants/libtfgpu_<name>.so; TFGPU_LIB_VARIANT=<name> makes bench.py load it (measurement only).
 # usage: tools/build_variant.sh NAME UNIT.hip "-DX=… -DY=…"
 set -e
 cd "$(dirname "$0")/.."

@@ -21,8 +21,6 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.path.join(_HERE, "libtfgpu.so")
-if os.environ.get("TFGPU_LIB_VARIANT"):  # measurement only: an A/B build of the same sources (tools/build_variant.sh)
-    _LIBPATH = os.path.join(_HERE, "variants", "libtfgpu_%s.so" % os.environ["TFGPU_LIB_VARIANT"])
 _lib = None
 
 EXPORTS = [
