@@ -298,6 +298,18 @@ int tfgpu_bufferer_get_stats(tfgpu_bufferer *b, tfgpu_bufferer_stats *out);
 int tfgpu_bufferer_close(tfgpu_bufferer *b);
 void tfgpu_bufferer_destroy(tfgpu_bufferer *b);
 
+/* strictify.Strictify (pkg/abstract/changeitem/strictify/strictify.go:17-157) over a device batch — the first step of the
+ * strictifying serializers (pkg/serializer/strictify.go:24-36): every column named by `schema` (NULL: the batch's own
+ * TableSchema, else the columns' DataTypes) is brought to the strict Go type of its DataType; other columns are shared as they
+ * are.  Device-resident conversions: a Go string / json.Number under any DataType (the CSV ingest's own cell conversions:
+ * ParseInt of trimZeroDecimal, ParseBool, ParseFloat 32, castx.ToJSONNumberE, cast.StringToDate's layouts, time.ParseDuration)
+ * and the integer kinds + bool under integer / bool / float / time / interval DataTypes (Go conversions, then toSignedInt /
+ * toUnsignedInt's limits).  The reference fails the WHOLE call on the first value that cannot be converted and changes
+ * nothing: TFGPU_ERR_INVALID with that value's row and column in *bad_row / *bad_col (rows in order, a row's columns in
+ * order) and "failed to strictify the value of column [i] "name"" as the message.  A (DataType, Go kind) pair or a value form
+ * that only the host decides answers TFGPU_ERR_UNSUPPORTED naming it.                                                   */
+int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_dbatch **out, int64_t *bad_row, int32_t *bad_col);
+
 /* Pinned staging memory (hipHostMalloc) for double-buffered H2D/D2H.        */
 int tfgpu_host_alloc(size_t bytes, void **out);
 int tfgpu_host_free(void *p);

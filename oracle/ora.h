@@ -182,6 +182,7 @@ ora_batch *ora_csv_parse(const tfgpu_csv_options *o, const tfgpu_schema *schema,
 
 int64_t ora_csv_split_rows(const void *bytes, uint64_t len, uint64_t **ends); /* csv.Splitter (pkg/csv/splitter.go) */
 /* getCorrespondingValue alone (reader_csv.go:345-452), for the reference's TestParse*Value tables */
+ora_batch *ora_strictify(ora_batch *b); /* strictify.Strictify over every item, in place; failing items are reported and left as they were */
 ora_batch *ora_csv_corresponding_value(const tfgpu_csv_options *o, const char *s, uint64_t n, int dtype);
 
 /* ---- a17: generic JSON parser (pkg/parsers/generic/generic_parser.go) — ora_jsonparse.c ---- */

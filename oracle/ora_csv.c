@@ -521,3 +521,32 @@ int64_t ora_csv_split_rows(const void *bytes, uint64_t len, uint64_t **ends) {
   *ends = e;
   return n;
 }
+
+/* strictify.Strictify (pkg/abstract/changeitem/strictify/strictify.go:17-42) over every item of a batch, the way the
+ * strictifying serializers call it (pkg/serializer/strictify.go:24-36): ColumnValues become the strict Go type of the column's
+ * DataType in the item's TableSchema; a column the schema does not name keeps its value; an item one of whose values cannot be
+ * converted is left unchanged ("all values remain unchanged") and reported as (row index, tfgpu_rowerr).  In place. */
+ora_batch *ora_strictify(ora_batch *b) {
+  for (int64_t r = 0; r < b->n; r++) {
+    ora_item *it = &b->items[r];
+    if (!it->schema || !it->names) continue;
+    ora_value *tmp = (ora_value *)calloc((size_t)(it->nvalues ? it->nvalues : 1), sizeof(ora_value));
+    int err = 0;
+    for (int i = 0; i < it->nvalues; i++) tmp[i] = ora_value_clone(&it->values[i]);
+    for (int i = 0; i < it->nvalues && !err; i++) {
+      const char *nm = i < it->names->n ? it->names->names[i] : NULL;
+      for (int k = 0; nm && k < it->schema->ncols; k++)
+        if (strcmp(it->schema->cols[k].name, nm) == 0) { err = strictify_value(&tmp[i], it->schema->cols[k].dtype); break; }
+    }
+    if (err) {
+      for (int i = 0; i < it->nvalues; i++) ora_value_free(&tmp[i]);
+      free(tmp);
+      ora_batch_add_error(b, r, err, "strictify");
+      continue;
+    }
+    for (int i = 0; i < it->nvalues; i++) ora_value_free(&it->values[i]);
+    free(it->values);
+    it->values = tmp;
+  }
+  return b;
+}

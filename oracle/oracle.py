@@ -185,6 +185,24 @@ class Transformer:
         return apply_chain([self], batch, schema)
 
 
+def strictify(batch: abi.Batch, schema: abi.Schema) -> Result:
+    """strictify.Strictify over every row (the strictifying serializers' first step); Result.errors = rows that could not be
+    converted (left unchanged), in row order"""
+    L = lib()
+    L.ora_strictify.restype = C.c_void_p
+    L.ora_strictify.argtypes = [C.c_void_p]
+    cb, cs = batch.to_c(), schema.to_c()
+    cur = L.ora_from_columns(C.byref(cb), C.byref(cs))
+    t0 = time.perf_counter()
+    cur = L.ora_strictify(cur)
+    dt = time.perf_counter() - t0
+    errs = _errors_of(L, cur)
+    if errs:  # the reference fails the call and leaves every value as it was: there is no (column-uniform) result to show
+        L.ora_batch_free(cur)
+        return Result(None, schema, errs, dt)
+    return _finish(L, cur, dt)
+
+
 def apply_chain(transformers, batch: abi.Batch, schema: abi.Schema) -> Result:
     """Row-model Apply chain; only the Apply calls are timed (boxing the test
     input into rows and unboxing the result are test I/O)."""

@@ -2469,3 +2469,192 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   return TFGPU_OK;
   TF_API_END
 }
+
+// ======================================================================================================
+// tfgpu_strictify — strictify.Strictify (pkg/abstract/changeitem/strictify/strictify.go:17-157) over a device batch: what the
+// strictifying serializers run before they serialize (pkg/serializer/strictify.go:24-36).  Every column named by the
+// TableSchema is brought to the strict Go type of its DataType.  The text → typed conversions ARE the CSV ingest's cell
+// conversions (parse_cell with reader options that do nothing); the integer family converts with Go's range rules.
+// ======================================================================================================
+namespace tf {
+
+enum StrictMode : int32_t { SM_TEXT = 1, SM_TEXT_JSONNUM_OUT = 2, SM_INTS = 3, SM_JSONNUM_TO_TIME = 4 };
+struct StrictCol {
+  int32_t mode, src_repr;
+  const void *values; const uint32_t *offsets; const uint8_t *data; const uint8_t *validity;
+  CsvCol out;
+};
+__device__ __forceinline__ bool strict_load_int(const StrictCol &c, int64_t r, int64_t *v, uint64_t *u, bool *is_unsigned) {
+  *is_unsigned = false;
+  switch (c.src_repr) {
+    case TFGPU_R_INT8: *v = ((const int8_t *)c.values)[r]; return true;
+    case TFGPU_R_INT16: *v = ((const int16_t *)c.values)[r]; return true;
+    case TFGPU_R_INT32: *v = ((const int32_t *)c.values)[r]; return true;
+    case TFGPU_R_INT64: *v = ((const int64_t *)c.values)[r]; return true;
+    case TFGPU_R_UINT8: case TFGPU_R_BOOL: *u = ((const uint8_t *)c.values)[r]; break;
+    case TFGPU_R_UINT16: *u = ((const uint16_t *)c.values)[r]; break;
+    case TFGPU_R_UINT32: *u = ((const uint32_t *)c.values)[r]; break;
+    case TFGPU_R_UINT64: *u = ((const uint64_t *)c.values)[r]; break;
+    default: return false;
+  }
+  *is_unsigned = true; *v = (int64_t)*u;
+  return true;
+}
+// item = column * nrows + row; first_bad[column] = min over failing rows of (row << 8 | tfgpu_rowerr)
+__global__ void __launch_bounds__(256) strictify_cells(CsvOpts o, const StrictCol *cols, int32_t ncols, int64_t nrows, unsigned long long *first_bad) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (int64_t)ncols * nrows) return;
+  const int32_t j = (int32_t)(it / nrows); const int64_t r = it - (int64_t)j * nrows;
+  const StrictCol &c = cols[j];
+  if (c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) { if (c.mode != SM_TEXT_JSONNUM_OUT) store_default(c.out, r); return; }  // nil stays nil
+  int rc = 0;
+  if (c.mode == SM_INTS) {
+    int64_t v = 0; uint64_t u = 0; bool uns = false;
+    strict_load_int(c, r, &v, &u, &uns);
+    switch (c.out.kind) {
+      case CK_INT:  // cast.ToInt64E of an integer kind is a Go conversion (a uint64 wraps), then toSignedInt's limits (strictify.go:159-169)
+        if (v < c.out.lo || v > (int64_t)c.out.hi) rc = TFGPU_ROW_RANGE; else store_int(c.out, r, v);
+        break;
+      case CK_UINT:  // errNegativeNotAllowed, then toUnsignedInt's limit (:171-181)
+        if (!uns && v < 0) rc = TFGPU_ROW_CAST;
+        else { const uint64_t x = uns ? u : (uint64_t)v; if (x > c.out.hi) rc = TFGPU_ROW_RANGE; else if (c.out.width == 8) ((uint64_t *)c.out.values)[r] = x; else store_int(c.out, r, (int64_t)x); }
+        break;
+      case CK_BOOL: ((uint8_t *)c.out.values)[r] = (uns ? u != 0 : v != 0) ? 1 : 0; break;
+      case CK_F32: ((float *)c.out.values)[r] = uns ? (float)(double)u : (float)(double)v; break;
+      case CK_DATE: case CK_TIMESTAMP: ((int64_t *)c.out.values)[r] = v; c.out.nanos[r] = 0; break;
+      default: ((int64_t *)c.out.values)[r] = v;  // CK_INTERVAL: time.Duration(v)
+    }
+  } else {
+    const uint32_t a = c.offsets[r], n = c.offsets[r + 1] - a;
+    MemBytes rd(c.data);
+    const Field fv{&rd, a, n};
+    if (c.mode == SM_TEXT_JSONNUM_OUT) rc = json_number_ok(fv, 0, n) ? 0 : TFGPU_ROW_CAST;  // castx.ToJSONNumberE: the text itself is the json.Number
+    else if (c.mode == SM_JSONNUM_TO_TIME) {  // cast.ToTimeE(json.Number): its Int64 as Unix seconds
+      int64_t sec;
+      if (parse_int64(fv, 0, n, false, &sec)) rc = TFGPU_ROW_CAST; else { ((int64_t *)c.out.values)[r] = sec; c.out.nanos[r] = 0; }
+    } else rc = parse_cell(o, c.out, r, fv, 0, n, 0, 0);
+  }
+  if (rc) atomicMin(&first_bad[j], ((unsigned long long)r << 8) | (unsigned long long)rc);
+}
+
+}  // namespace tf
+
+extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_dbatch **out, int64_t *bad_row, int32_t *bad_col) {
+  TF_API_BEGIN
+  if (!in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_strictify: null argument");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  hipStream_t st = cx.stream;
+  materialize(*in);
+  const int64_t n = in->nrows;
+  if (bad_row) *bad_row = -1;
+  if (bad_col) *bad_col = -1;
+  auto dtype_of = [&](const DColumn &c) -> int {  // tableSchema[columnName]; a column the schema does not name is left alone
+    if (schema) { for (int i = 0; i < schema->ncols; i++) if (schema->cols[i].name && c.name == schema->cols[i].name) return schema->cols[i].dtype; return -1; }
+    if (!in->schema.empty()) { for (auto &p : in->schema) if (p.first == c.name) return p.second; return -1; }
+    return c.dtype;
+  };
+  auto r = std::make_unique<tfgpu_dbatch>(*in);  // shares every buffer; converted columns are replaced below
+  std::vector<StrictCol> sc; std::vector<int> which;
+  bool need_p128 = false;
+  for (size_t i = 0; i < in->cols.size(); i++) {
+    const DColumn &c = in->cols[i];
+    const int dt = dtype_of(c);
+    if (dt < 0 || dt == TFGPU_T_ANY) continue;
+    DColumn &d = r->cols[i];
+    d.dtype = dt;
+    CsvCol oc{}; int strict = TFGPU_R_INVALID;
+    switch (dt) {
+      case TFGPU_T_INT8: oc.kind = CK_INT; oc.width = 1; oc.lo = INT8_MIN; oc.hi = INT8_MAX; strict = TFGPU_R_INT8; break;
+      case TFGPU_T_INT16: oc.kind = CK_INT; oc.width = 2; oc.lo = INT16_MIN; oc.hi = INT16_MAX; strict = TFGPU_R_INT16; break;
+      case TFGPU_T_INT32: oc.kind = CK_INT; oc.width = 4; oc.lo = INT32_MIN; oc.hi = INT32_MAX; strict = TFGPU_R_INT32; break;
+      case TFGPU_T_INT64: oc.kind = CK_INT; oc.width = 8; oc.lo = INT64_MIN; oc.hi = INT64_MAX; strict = TFGPU_R_INT64; break;
+      case TFGPU_T_UINT8: oc.kind = CK_UINT; oc.width = 1; oc.hi = UINT8_MAX; strict = TFGPU_R_UINT8; break;
+      case TFGPU_T_UINT16: oc.kind = CK_UINT; oc.width = 2; oc.hi = UINT16_MAX; strict = TFGPU_R_UINT16; break;
+      case TFGPU_T_UINT32: oc.kind = CK_UINT; oc.width = 4; oc.hi = UINT32_MAX; strict = TFGPU_R_UINT32; break;
+      case TFGPU_T_UINT64: oc.kind = CK_UINT; oc.width = 8; oc.hi = ~0ull; strict = TFGPU_R_UINT64; break;
+      case TFGPU_T_BOOLEAN: oc.kind = CK_BOOL; oc.width = 1; strict = TFGPU_R_BOOL; break;
+      case TFGPU_T_DATE: case TFGPU_T_DATETIME: case TFGPU_T_TIMESTAMP: oc.kind = CK_DATE; oc.width = 8; strict = TFGPU_R_TIME; break;  // cast.ToTimeE: StringToDate only (no reader step)
+      case TFGPU_T_FLOAT32: oc.kind = CK_F32; oc.width = 4; strict = TFGPU_R_FLOAT32; break;
+      case TFGPU_T_FLOAT64: oc.kind = CK_JSONNUM; strict = TFGPU_R_JSONNUM; break;
+      case TFGPU_T_UTF8: oc.kind = CK_STR; strict = TFGPU_R_STRING; break;
+      case TFGPU_T_BYTES: oc.kind = CK_STR; strict = TFGPU_R_BYTES; break;
+      case TFGPU_T_INTERVAL: oc.kind = CK_INTERVAL; oc.width = 8; strict = TFGPU_R_DURATION; break;
+      default: return tf::fail(TFGPU_ERR_CONFIG, "tfgpu_strictify: cannot strictify value of unknown type (column " + c.name + ")");
+    }
+    if (c.repr == strict) continue;  // already the strict Go type
+    const bool text = c.repr == TFGPU_R_STRING || c.repr == TFGPU_R_JSONNUM;
+    const bool ints = (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) || c.repr == TFGPU_R_BOOL;
+    auto unsupported = [&]() { return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_strictify: column " + c.name + ": a " + std::string(type_name(dt)) + " column holding Go values of representation " + std::to_string(c.repr) + " is converted on the host (cast." "To…E of that kind is not device-resident)"); };
+    StrictCol s{};
+    s.src_repr = c.repr; s.values = c.values ? c.values->p : nullptr; s.offsets = ptr<uint32_t>(c.offsets); s.data = ptr<uint8_t>(c.payload()); s.validity = ptr<uint8_t>(c.validity);
+    if (text && (oc.kind == CK_STR)) {  // castx.ToStringE / ToByteSliceE of a string (or of a json.Number's text): the same bytes
+      if (c.repr == TFGPU_R_JSONNUM && dt == TFGPU_T_BYTES) return unsupported();
+      d.repr = strict;
+      continue;
+    }
+    if (c.repr == TFGPU_R_BYTES && dt == TFGPU_T_UTF8) { d.repr = TFGPU_R_STRING; continue; }  // ToStringE([]byte) = string(b)
+    if (text && oc.kind == CK_JSONNUM) { if (c.repr != TFGPU_R_STRING) continue; s.mode = SM_TEXT_JSONNUM_OUT; d.repr = TFGPU_R_JSONNUM; }
+    else if (text) {
+      if (c.repr == TFGPU_R_JSONNUM && oc.kind == CK_INTERVAL) return unsupported();
+      s.mode = (c.repr == TFGPU_R_JSONNUM && oc.kind == CK_DATE) ? SM_JSONNUM_TO_TIME : SM_TEXT;
+      if (oc.kind == CK_F32) need_p128 = true;
+    } else if (ints) {
+      if (oc.kind == CK_STR || oc.kind == CK_JSONNUM) return unsupported();                 // castx.ToStringE of an integer: the convert_to_string kernels' job
+      if (oc.kind == CK_INTERVAL && (c.repr >= TFGPU_R_UINT8 && c.repr <= TFGPU_R_UINT64)) return unsupported();
+      if (c.repr == TFGPU_R_BOOL && (oc.kind == CK_DATE || oc.kind == CK_INTERVAL || oc.kind == CK_F32)) return unsupported();
+      s.mode = SM_INTS;
+    } else return unsupported();
+    if (s.mode != SM_TEXT_JSONNUM_OUT) {
+      d.values = dalloc((size_t)std::max<int64_t>(n, 1) * (size_t)oc.width);
+      d.offsets = nullptr; d.data = nullptr; d.view = nullptr; d.data_len = 0; d.nanos = nullptr;
+      if (oc.kind == CK_DATE) d.nanos = dalloc((size_t)std::max<int64_t>(n, 1) * 4);
+      d.repr = strict;
+      oc.values = d.values->p; oc.nanos = ptr<int32_t>(d.nanos);
+    }
+    s.out = oc;
+    sc.push_back(s); which.push_back((int)i);
+  }
+  if (!sc.empty() && n > 0) {
+    // neutral reader options: no null / true / false lists, no DecimalPoint, no user layouts — what is left of parse_cell is strictifyValue
+    static const char *const CAST_LAYOUTS[] = {
+        "2006-01-02", "2006-01-02T15:04:05Z07:00", "2006-01-02T15:04:05", "Mon, 02 Jan 2006 15:04:05 -0700", "Mon, 02 Jan 2006 15:04:05 MST",
+        "02 Jan 06 15:04 -0700", "02 Jan 06 15:04 MST", "Monday, 02-Jan-06 15:04:05 MST", "2006-01-02 15:04:05.999999999 -0700 MST",
+        "2006-01-02T15:04:05-0700", "2006-01-02 15:04:05Z0700", "2006-01-02 15:04:05", "Mon Jan _2 15:04:05 2006", "Mon Jan _2 15:04:05 MST 2006",
+        "Mon Jan 02 15:04:05 -0700 2006", "2006-01-02 15:04:05Z07:00", "02 Jan 2006", "2006-01-02 15:04:05 -07:00", "2006-01-02 15:04:05 -0700",
+        "3:04PM", "Jan _2 15:04:05", "Jan _2 15:04:05.000", "Jan _2 15:04:05.000000", "Jan _2 15:04:05.000000000"};
+    std::vector<GtOp> gops; std::string glits; std::vector<uint16_t> gstart{0};
+    for (const char *l : CAST_LAYOUTS) { gotime_compile(l, gops, glits); gstart.push_back((uint16_t)gops.size()); }
+    Buf bgops = upload_const(gops.data(), gops.size() * sizeof(GtOp)), bglits = upload_const(glits.data(), glits.size()), bgs = upload_const(gstart.data(), gstart.size() * 2);
+    CsvOpts o{};
+    o.delim = ','; o.quote = '"';
+    o.user_tp = GtSet{ptr<GtOp>(bgops), ptr<uint8_t>(bglits), ptr<uint16_t>(bgs), 0};
+    o.cast_tp = GtSet{ptr<GtOp>(bgops), ptr<uint8_t>(bglits), ptr<uint16_t>(bgs), (int32_t)(sizeof CAST_LAYOUTS / sizeof *CAST_LAYOUTS)};
+    o.p128 = need_p128 ? reinterpret_cast<const uint64_t *>(pow10_table() + 632) : nullptr;
+    Buf bsc = upload_small(sc.data(), sc.size() * sizeof(StrictCol));
+    Buf bad = dalloc(sc.size() * 8);
+    TF_HIP(hipMemsetAsync(bad->p, 0xFF, sc.size() * 8, st));
+    {
+      KernelTimer t("strictify_cells");
+      const int64_t items = (int64_t)sc.size() * n;
+      strictify_cells<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(o, reinterpret_cast<const StrictCol *>(bsc->p), (int32_t)sc.size(), n, reinterpret_cast<unsigned long long *>(bad->p));
+    }
+    std::vector<uint64_t> hb(sc.size());
+    d2h(hb.data(), bad->p, hb.size() * 8);
+    tf::sync();
+    // the first failing value in the reference's order: rows in order, a row's columns in order
+    uint64_t best = ~0ull; int bcol = -1;
+    for (size_t k = 0; k < hb.size(); k++) if (hb[k] != ~0ull && ((hb[k] >> 8) < (best >> 8) || best == ~0ull)) { best = hb[k]; bcol = which[k]; }
+    if (bcol >= 0) {
+      const int64_t row = (int64_t)(best >> 8); const int code = (int)(best & 0xFF);
+      if (bad_row) *bad_row = row;
+      if (bad_col) *bad_col = bcol;
+      if (code == TFGPU_ROW_HOST_FALLBACK)
+        return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_strictify: row " + std::to_string(row) + ", column " + in->cols[(size_t)bcol].name + ": a value form the device does not decide (Go's decimal slow path, a free-form date): strictify this batch on the host");
+      return tf::fail(TFGPU_ERR_INVALID, "failed to strictify the value of column [" + std::to_string(bcol) + "] \"" + in->cols[(size_t)bcol].name + "\": row " + std::to_string(row) + ": " + (code == TFGPU_ROW_RANGE ? "value is out of the type's range" : "unable to cast the value"));
+    }
+  }
+  *out = r.release();
+  return TFGPU_OK;
+  TF_API_END
+}
