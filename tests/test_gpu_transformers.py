@@ -355,3 +355,34 @@ def test_deepsizeof_matches_oracle(tf, oracle):
     assert total == etotal and np.array_equal(per, eper)
     e = abi.Batch([abi.Column("a", "int32", abi.R_INT32, values=np.zeros(0, np.int32))], 0, "", "t")
     assert tf.deepsizeof(tf.DeviceBatch.upload(e)) == 0
+
+
+def test_replace_primary_key_on_a_run_that_already_carries_old_keys(tf):
+    """Every pg / Debezium CDC batch carries OldKeys; replace_primary_key (Apply + createOldKeys, replace_primary_key.go:51-101) overwrites
+    them on Update rows with the new keys' CURRENT values and leaves the other rows' as they are (expectation written out from those
+    lines: the oracle does not model this transformer)."""
+    schema = abi.Schema.of([["id", "int64", True], ["v", "utf8"], ["n", "int32"]])
+    rng = np.random.default_rng(SEED0 + 77)
+    n = 700
+    rows = [[["int64", int(rng.integers(0, 1 << 40))], ["string", "v%d" % i], ["nil", None] if i % 9 == 0 else ["int32", i]] for i in range(n)]
+    kinds = [("insert", "update", "delete")[int(rng.integers(0, 3))] for _ in range(n)]
+    b = abi.batch_from_rows(schema, ["id", "v", "n"], rows, "db", "t", kinds)
+    b.schema = schema
+    present = np.array([k != "insert" for k in kinds], bool)
+    old_vals = rng.integers(0, 1 << 40, n).astype(np.int64)
+    b.old_keys = [abi.Column("id", "int64", abi.R_INT64, values=old_vals.copy(), validity=present.copy())]
+    b.old_present = present
+    out = tf.Transformer("replace_primary_key", {"keys": ["id"], "tables": {}}).apply(tf.DeviceBatch.upload(b)).transformed.download()
+    assert_batches_equal(out, b, "ColumnValues are untouched")
+    upd = np.array([k == "update" for k in kinds])
+    pg = out.old_present if out.old_present is not None else np.ones(n, bool)
+    assert np.array_equal(pg, present | upd)
+    og = out.old_keys[0]
+    vg = og.validity if og.validity is not None else np.ones(n, bool)
+    assert og.name == "id" and np.array_equal(vg & pg, present | upd)
+    want = np.where(upd, b.col("id").values, old_vals)
+    assert np.array_equal(og.values[pg], want[pg])
+    # other key names than the ones carried: per-item KeyNames, left to the stock transformer
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.Transformer("replace_primary_key", {"keys": ["n"], "tables": {}}).apply(tf.DeviceBatch.upload(b))
+    assert ei.value.code == tf.ERR_UNSUPPORTED

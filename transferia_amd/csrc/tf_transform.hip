@@ -928,6 +928,31 @@ __global__ void kind_is_kernel(const uint8_t *kind, int64_t n, uint8_t k, uint8_
   for (int j = 0; j < 8; j++) { const int64_t r = b * 8 + j; if (r < n && kind[r] == k) v |= 1u << j; }
   bits[b] = (uint8_t)v;
 }
+__global__ void kind_any_kernel(const uint8_t *kind, int64_t n, uint8_t k, uint32_t *flag) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && kind[r] == k) *flag = 1u;
+}
+__global__ void bitmap_or_kernel(uint8_t *a, const uint8_t *b, int64_t nbytes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nbytes) a[i] |= b[i];
+}
+// OldKeys of a run whose rows already carry some: an Update takes the key column's current value, any other row keeps its old one
+// (one thread per validity byte = 8 rows)
+__global__ void replace_pk_select_kernel(const uint8_t *kind, int64_t n, int w, const uint8_t *cur, const uint8_t *cur_valid, const uint8_t *old, const uint8_t *old_valid,
+                                         uint8_t *out, uint8_t *out_valid) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * 8 >= n) return;
+  uint32_t v = 0;
+  for (int j = 0; j < 8; j++) {
+    const int64_t r = b * 8 + j;
+    if (r >= n) break;
+    const bool upd = kind[r] == TFGPU_K_UPDATE;
+    const uint8_t *src = upd ? cur : old, *sv = upd ? cur_valid : old_valid;
+    for (int k = 0; k < w; k++) out[r * w + k] = src[r * w + k];
+    if (!sv || ((sv[r >> 3] >> (r & 7)) & 1)) v |= 1u << j;
+  }
+  out_valid[b] = (uint8_t)v;
+}
 // replace_primary_key.go:82-101: the TableSchema is replaced (keys first / flags rewritten); ColumnNames and ColumnValues
 // stay as they are; an Update gets OldKeys = the NEW keys' current values (createOldKeys :51-80).
 static std::unique_ptr<tfgpu_dbatch> apply_replace_pk(const tfgpu_plan &p, const tfgpu_dbatch &in) {
@@ -939,19 +964,47 @@ static std::unique_ptr<tfgpu_dbatch> apply_replace_pk(const tfgpu_plan &p, const
   out->schema.clear(); out->key_names.clear();
   for (auto &c : cols) { out->schema.emplace_back(c.name, c.dtype); if (c.flags & TFGPU_COL_KEY) out->key_names.push_back(c.name); }
   bool has_update = false;
-  if (in.kind && in.nrows) {
-    std::vector<uint8_t> hk((size_t)in.nrows);
-    d2h(hk.data(), in.kind->p, hk.size());
+  if (in.kind && in.nrows) {  // one flag word read back, not the kinds
+    Buf flag = dalloc_zero(4);
+    kind_any_kernel<<<grid_for(in.nrows, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), in.nrows, (uint8_t)TFGPU_K_UPDATE, ptr<uint32_t>(flag));
+    const uint32_t *h = d2h_u32(flag->p);
     sync();
-    for (uint8_t k : hk) if (k == TFGPU_K_UPDATE) { has_update = true; break; }
+    has_update = *h != 0;
   }
   if (has_update) {
-    if (!in.old_keys.empty()) throw Error(TFGPU_ERR_UNSUPPORTED, "replace_primary_key: a run that mixes Updates with rows that already carry OldKeys of other key names needs per-item KeyNames; not columnar");
+    std::vector<DColumn> cur;
     for (auto &k : p.new_keys)  // key order; a key missing from ColumnNames leaves a nil value in the reference — not modelled
-      for (auto &c : in.cols) if (c.name == k) { out->old_keys.push_back(c); break; }
-    if (out->old_keys.size() != p.new_keys.size()) throw Error(TFGPU_ERR_UNSUPPORTED, "replace_primary_key: a new key is not among the batch's columns");
-    out->old_present = dalloc((size_t)(in.nrows + 7) / 8 + 8);
-    kind_is_kernel<<<grid_for((in.nrows + 7) / 8, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), in.nrows, (uint8_t)TFGPU_K_UPDATE, ptr<uint8_t>(out->old_present));
+      for (auto &c : in.cols) if (c.name == k) { cur.push_back(c); break; }
+    if (cur.size() != p.new_keys.size()) throw Error(TFGPU_ERR_UNSUPPORTED, "replace_primary_key: a new key is not among the batch's columns");
+    if (in.old_keys.empty()) {
+      out->old_keys = cur;
+      out->old_present = dalloc((size_t)(in.nrows + 7) / 8 + 8);
+      kind_is_kernel<<<grid_for((in.nrows + 7) / 8, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), in.nrows, (uint8_t)TFGPU_K_UPDATE, ptr<uint8_t>(out->old_present));
+    } else {
+      // the batch already carries OldKeys (every pg / Debezium CDC batch does): Updates get the NEW keys' current values, the other
+      // rows keep theirs.  Columnar only when both sets have the same names, types and fixed-width representations (per-item
+      // KeyNames otherwise: that run stays with the stock transformer)
+      bool same = in.old_keys.size() == cur.size();
+      for (size_t i = 0; same && i < cur.size(); i++)
+        same = in.old_keys[i].name == cur[i].name && in.old_keys[i].repr == cur[i].repr && in.old_keys[i].dtype == cur[i].dtype && !repr_is_var(cur[i].repr) && cur[i].repr != TFGPU_R_TIME;
+      if (!same) throw Error(TFGPU_ERR_UNSUPPORTED, "replace_primary_key: a run that mixes Updates with rows carrying OldKeys of other key names (or text / time keys) needs per-item KeyNames; not columnar");
+      const int64_t n = in.nrows;
+      out->old_keys.clear();
+      for (size_t i = 0; i < cur.size(); i++) {
+        DColumn d = in.old_keys[i];
+        const int w = repr_width(cur[i].repr);
+        d.values = dalloc((size_t)n * (size_t)w);
+        d.validity = dalloc((size_t)(n + 7) / 8 + 8);
+        replace_pk_select_kernel<<<grid_for((n + 7) / 8, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), n, w, (const uint8_t *)cur[i].values->p, ptr<uint8_t>(cur[i].validity),
+                                                                                      (const uint8_t *)in.old_keys[i].values->p, ptr<uint8_t>(in.old_keys[i].validity), (uint8_t *)d.values->p, ptr<uint8_t>(d.validity));
+        out->old_keys.push_back(std::move(d));
+      }
+      if (in.old_present) {  // present = Update, or it was
+        out->old_present = dalloc((size_t)(n + 7) / 8 + 8);
+        kind_is_kernel<<<grid_for((n + 7) / 8, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), n, (uint8_t)TFGPU_K_UPDATE, ptr<uint8_t>(out->old_present));
+        bitmap_or_kernel<<<grid_for((n + 7) / 8, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(out->old_present), ptr<uint8_t>(in.old_present), (n + 7) / 8);
+      }
+    }
   }
   return out;
 }
