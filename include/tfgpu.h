@@ -298,6 +298,16 @@ int tfgpu_bufferer_get_stats(tfgpu_bufferer *b, tfgpu_bufferer_stats *out);
 int tfgpu_bufferer_close(tfgpu_bufferer *b);
 void tfgpu_bufferer_destroy(tfgpu_bufferer *b);
 
+/* Parquet object → device columns (tf_parquet.hip; pkg/providers/s3/reader/registry/parquet/reader_parquet.go:137-283, which reads
+ * rows through parquet-go and boxes every value).  `bytes` is the whole object in HOST memory (the footer and the page headers
+ * are walked on the host; the object is uploaded once and every value is decoded on the device).  `schema` = the TableSchema
+ * given to Read: its columns are looked up in the file by name (a column the file lacks is nil in every row, :256-259); NULL =
+ * every leaf of the file.  Values keep Parquet's physical Go types (bool, int32, int64, float32, float64, string / []byte); DATE
+ * becomes time.Time as parseLogicalDate makes it.  Flat schemas, UNCOMPRESSED chunks, data pages v1 / v2, PLAIN and dictionary
+ * encodings; anything else answers TFGPU_ERR_UNSUPPORTED naming it.  PARITY UNPINNED against the reference (no .parquet input
+ * under /root/reference, parquet-go not vendored): the tests pin it to pyarrow's reading of the same files.               */
+int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out);
+
 /* strictify.Strictify (pkg/abstract/changeitem/strictify/strictify.go:17-157) over a device batch — the first step of the
  * strictifying serializers (pkg/serializer/strictify.go:24-36): every column named by `schema` (NULL: the batch's own
  * TableSchema, else the columns' DataTypes) is brought to the strict Go type of its DataType; other columns are shared as they

@@ -1,0 +1,123 @@
+"""tfgpu_parquet_read (tf_parquet.hip) against an independent reader: files written by pyarrow in the shapes real writers produce —
+dictionary pages with RLE / bit-packed indices, PLAIN fall-back pages, optional columns (definition levels), data pages v1 and v2,
+several row groups, tiny and large pages — and read back by pyarrow.  PARITY UNPINNED against the reference (no .parquet input in
+its tree, parquet-go not vendored): what is checked is that every value and every null equals what pyarrow reads."""
+import io
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+
+pa = pytest.importorskip("pyarrow")
+pq = pytest.importorskip("pyarrow.parquet")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+def table(n, seed, nulls=True):
+    rng = np.random.default_rng(seed)
+
+    def opt(vals, every):
+        return [None if (nulls and i % every == 0) else v for i, v in enumerate(vals)]
+    return pa.table({
+        "i32": pa.array(opt([int(x) for x in rng.integers(-1000, 1000, n)], 7), pa.int32()),
+        "i64": pa.array(opt([int(x) for x in rng.integers(-(1 << 60), 1 << 60, n)], 11), pa.int64()),
+        "few": pa.array([int(x) for x in rng.integers(0, 3, n)], pa.int64()),
+        "f32": pa.array(opt([float(np.float32(x)) for x in rng.standard_normal(n)], 13), pa.float32()),
+        "f64": pa.array(opt([float(x) for x in rng.standard_normal(n)], 5), pa.float64()),
+        "b": pa.array(opt([bool(x) for x in rng.integers(0, 2, n)], 9), pa.bool_()),
+        "cat": pa.array(opt(["category-%d" % (i % 37) for i in range(n)], 6), pa.string()),
+        "url": pa.array(opt(["http://host/%d/%s" % (i, "x" * int(rng.integers(0, 90))) for i in range(n)], 4), pa.string()),
+        "bin": pa.array(opt([bytes(rng.integers(0, 256, int(rng.integers(0, 12))).astype(np.uint8)) for _ in range(n)], 8), pa.binary()),
+        "day": pa.array(opt([int(x) for x in rng.integers(-5000, 20000, n)], 10), pa.date32()),
+    })
+
+
+def check(tf, t, **write_kw):
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="NONE", **write_kw)
+    data = buf.getvalue()
+    ref = pq.read_table(io.BytesIO(data))
+    out = tf.parquet_read(data, None, "ns", "tbl").download()
+    assert out.nrows == ref.num_rows and (out.table_ns, out.table_name) == ("ns", "tbl")
+    assert [c.name for c in out.cols] == ref.column_names
+    for c in out.cols:
+        want = ref.column(c.name).to_pylist()
+        valid = c.validity if c.validity is not None else np.ones(out.nrows, bool)
+        assert [bool(v) for v in valid] == [w is not None for w in want], c.name
+        for i, w in enumerate(want):
+            if w is None:
+                continue
+            if c.repr in abi.VAR_REPRS:
+                got = c.get_bytes(i)
+                assert got == (w.encode() if isinstance(w, str) else w), (c.name, i)
+            elif c.repr == abi.R_TIME:
+                assert int(c.values[i]) == (w - __import__("datetime").date(1970, 1, 1)).days * 86400 and (c.nanos is None or int(c.nanos[i]) == 0), (c.name, i)
+            elif c.repr in (abi.R_FLOAT32, abi.R_FLOAT64):
+                assert float(c.values[i]) == w or (w != w and c.values[i] != c.values[i]), (c.name, i)
+            else:
+                assert c.values[i] == w, (c.name, i, c.values[i], w)
+    reprs = {c.name: c.repr for c in out.cols}
+    assert reprs == {"i32": abi.R_INT32, "i64": abi.R_INT64, "few": abi.R_INT64, "f32": abi.R_FLOAT32, "f64": abi.R_FLOAT64, "b": abi.R_BOOL, "cat": abi.R_STRING,
+                     "url": abi.R_STRING, "bin": abi.R_BYTES, "day": abi.R_TIME}
+    return out
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 64, 1000, 20011])
+def test_dictionary_pages_as_pyarrow_writes_them(tf, n):
+    check(tf, table(n, 100 + n))
+
+
+def test_plain_pages_small_pages_v2_pages_and_row_groups(tf):
+    t = table(6000, 5)
+    check(tf, t, use_dictionary=False)                                       # PLAIN values, length-prefixed byte arrays
+    check(tf, t, use_dictionary=False, data_page_size=512)                    # hundreds of pages per chunk
+    check(tf, t, data_page_size=256, dictionary_pagesize_limit=2048)          # dictionary first, PLAIN after the dictionary outgrows its page
+    check(tf, t, data_page_version="2.0")                                     # v2 headers: level lengths in the header, RLE booleans
+    check(tf, t, data_page_version="2.0", use_dictionary=False, data_page_size=1024)
+    check(tf, t, row_group_size=1000)                                         # six row groups: a dictionary per chunk
+    check(tf, table(3000, 6, nulls=False))                                    # required-like data (still optional in the schema)
+    req = pa.schema([pa.field("k", pa.int64(), nullable=False), pa.field("s", pa.string(), nullable=False)])
+    tt = pa.table({"k": pa.array(range(500), pa.int64()), "s": pa.array(["s%d" % i for i in range(500)])}, schema=req)
+    buf = io.BytesIO()
+    pq.write_table(tt, buf, compression="NONE")
+    out = tf.parquet_read(buf.getvalue()).download()                          # REQUIRED leaves: no definition levels at all
+    assert [int(x) for x in out.col("k").values] == list(range(500)) and out.col("k").validity is None
+    assert [out.col("s").get_bytes(i) for i in (0, 499)] == [b"s0", b"s499"]
+
+
+def test_schema_selects_columns_and_missing_ones_are_nil(tf):
+    t = table(300, 8)
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="NONE")
+    schema = abi.Schema.of([["url", "utf8"], ["nope", "int64"], ["i32", "int32", True]])
+    out = tf.parquet_read(buf.getvalue(), schema).download()
+    assert [c.name for c in out.cols] == ["url", "nope", "i32"]
+    assert not out.col("nope").validity.any()
+    assert out.col("i32").dtype == "int32" and out.col("url").dtype == "utf8"
+
+
+def test_what_stays_with_the_stock_reader_is_refused_by_name(tf):
+    t = table(100, 9)
+    for kw, word in [(dict(compression="SNAPPY"), "compressed"), (dict(compression="NONE", use_dictionary=False, column_encoding={"i64": "DELTA_BINARY_PACKED"}), "encoding")]:
+        buf = io.BytesIO()
+        pq.write_table(t, buf, **kw)
+        with pytest.raises(tf.TfgpuError) as ei:
+            tf.parquet_read(buf.getvalue())
+        assert ei.value.code == tf.ERR_UNSUPPORTED and word in str(ei.value), str(ei.value)
+    nested = pa.table({"l": pa.array([[1, 2], [3]], pa.list_(pa.int32()))})
+    buf = io.BytesIO()
+    pq.write_table(nested, buf, compression="NONE")
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.parquet_read(buf.getvalue())
+    assert ei.value.code == tf.ERR_UNSUPPORTED
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.parquet_read(b"PAR1 this is not a parquet file PAR1")
+    assert ei.value.code == tf.ERR_INVALID

@@ -1,0 +1,501 @@
+// tf_parquet.hip — Parquet column chunks → device columns (the source format of BASELINE.json configs[3]).
+//
+// The reference reads Parquet through github.com/parquet-go/parquet-go (not under /root/reference) one ROW at a time into a
+// map[string]any and boxes every value (pkg/providers/s3/reader/registry/parquet/reader_parquet.go:137-283: pr.Read(&row),
+// constructCI, parseParquetField: DATE → time.Unix(0, 0).Add(24h * days), everything else through abstract.Restore).  The file
+// format itself is columnar, so here a column chunk goes to its device column without ever becoming rows:
+//
+//   host   the footer and the page headers (Thrift compact protocol, a few hundred small structs), and the RUN HEADERS of the
+//          RLE / bit-packed hybrid streams (definition levels, dictionary indices): one table of segments per column, each
+//          (first ordinal, count, kind, where the packed bits are | the run's value), plus the (offset, length) of every entry
+//          of a byte-array dictionary.  The host never touches a value.
+//   device the whole file is uploaded once; per column: definition levels → validity (a row finds its run by binary search),
+//          a scan gives every present row the ordinal of its value, and the value comes from its segment — PLAIN (the bytes
+//          themselves), a dictionary index (RLE run or bit-packed, any width) into the chunk's dictionary, PLAIN booleans;
+//          PLAIN byte arrays are length-prefixed, so one lane per page walks the prefixes once; text is then packed with the
+//          destination-centric copy the CSV ingest uses (tf_segcopy.hpp), straight out of the file image.
+//
+// Scope: flat schemas (required / optional leaves), data pages v1 and v2, PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY / RLE,
+// BOOLEAN, INT32, INT64, FLOAT, DOUBLE, BYTE_ARRAY, the DATE annotation; UNCOMPRESSED pages.  Compressed pages, nested
+// columns, INT96, FIXED_LEN_BYTE_ARRAY, DELTA_* and BYTE_STREAM_SPLIT are refused by name (TFGPU_ERR_UNSUPPORTED).
+// PARITY UNPINNED against the reference: /root/reference holds no .parquet input, and the Go values parquet-go hands to
+// abstract.Restore are that library's choice; the tests pin the decoder to an independent reader (pyarrow) instead.
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+#include "tf_common.hpp"
+#include "tf_segcopy.hpp"
+#define PQD(...) do { if (std::getenv("TFGPU_PQ_DEBUG")) { std::fprintf(stderr, __VA_ARGS__); std::fflush(stderr); } } while (0)  /* the page walk, line by line */
+
+namespace tf {
+namespace pq {
+
+// ---- Thrift compact protocol (the subset Parquet's metadata uses) -------------------------------------------------------
+struct TReader {
+  const uint8_t *p, *e;
+  bool ok = true;
+  uint64_t varint() {
+    uint64_t v = 0; int sh = 0;
+    while (p < e) { const uint8_t b = *p++; v |= (uint64_t)(b & 0x7F) << sh; if (!(b & 0x80)) return v; sh += 7; if (sh > 63) break; }
+    ok = false; return 0;
+  }
+  int64_t zz() { const uint64_t v = varint(); return (int64_t)(v >> 1) ^ -(int64_t)(v & 1); }
+  // field header: returns the compact type (0 = stop), sets id
+  int field(int &id) {
+    if (p >= e) { ok = false; return 0; }
+    const uint8_t b = *p++;
+    if (b == 0) return 0;
+    const int delta = b >> 4, ty = b & 15;
+    if (delta) id += delta; else id = (int)zz();
+    return ty;
+  }
+  std::string binary() { const uint64_t n = varint(); if (!ok || n > (uint64_t)(e - p)) { ok = false; return ""; } std::string s((const char *)p, (size_t)n); p += n; return s; }
+  void list(int &ety, uint32_t &n) {
+    if (p >= e) { ok = false; n = 0; ety = 0; return; }
+    const uint8_t b = *p++;
+    n = b >> 4; ety = b & 15;
+    if (n == 15) n = (uint32_t)varint();
+  }
+  void skip(int ty) {
+    if (!ok) return;
+    switch (ty) {
+      case 1: case 2: break;                       // bool in the header
+      case 3: p++; break;
+      case 4: case 5: case 6: varint(); break;
+      case 7: p += 8; break;
+      case 8: { const uint64_t n = varint(); if (n > (uint64_t)(e - p)) ok = false; else p += n; break; }
+      case 9: case 10: { int et; uint32_t n; list(et, n); for (uint32_t i = 0; i < n && ok; i++) { if (et == 1 || et == 2) p++; else skip(et); } break; }
+      case 11: { const uint64_t n = varint(); if (n) { const uint8_t kv = *p++; for (uint64_t i = 0; i < n && ok; i++) { skip(kv >> 4); skip(kv & 15); } } break; }
+      case 12: { int id = 0; for (;;) { const int t = field(id); if (!t || !ok) break; skip(t); } break; }
+      default: ok = false;
+    }
+    if (p > e) ok = false;
+  }
+};
+
+enum { T_BOOLEAN = 0, T_INT32 = 1, T_INT64 = 2, T_INT96 = 3, T_FLOAT = 4, T_DOUBLE = 5, T_BYTE_ARRAY = 6, T_FLBA = 7 };
+enum { E_PLAIN = 0, E_PLAIN_DICT = 2, E_RLE = 3, E_RLE_DICT = 8 };
+enum { L_NONE = 0, L_STRING = 1, L_DATE = 6 };
+
+struct SchemaEl { int type = -1, rep = 0, conv = -1, nchildren = 0, logical = L_NONE; std::string name; };
+struct ColChunk { int type = -1, codec = 0; int64_t num_values = 0, data_off = -1, dict_off = -1, total_comp = 0; std::vector<std::string> path; };
+struct RowGroup { int64_t num_rows = 0; std::vector<ColChunk> cols; };
+struct FileMeta { std::vector<SchemaEl> schema; std::vector<RowGroup> groups; int64_t num_rows = 0; };
+
+static void parse_schema_el(TReader &r, SchemaEl &s) {
+  int id = 0;
+  for (;;) {
+    const int t = r.field(id);
+    if (!t || !r.ok) break;
+    switch (id) {
+      case 1: s.type = (int)r.zz(); break;
+      case 3: s.rep = (int)r.zz(); break;
+      case 4: s.name = r.binary(); break;
+      case 5: s.nchildren = (int)r.zz(); break;
+      case 6: s.conv = (int)r.zz(); break;
+      case 10: { int lid = 0; for (;;) { const int lt = r.field(lid); if (!lt || !r.ok) break; s.logical = lid; r.skip(lt); } break; }  // the union's set member
+      default: r.skip(t);
+    }
+  }
+}
+static void parse_col_meta(TReader &r, ColChunk &c) {
+  int id = 0;
+  for (;;) {
+    const int t = r.field(id);
+    if (!t || !r.ok) break;
+    switch (id) {
+      case 1: c.type = (int)r.zz(); break;
+      case 3: { int et; uint32_t n; r.list(et, n); for (uint32_t i = 0; i < n && r.ok; i++) c.path.push_back(r.binary()); break; }
+      case 4: c.codec = (int)r.zz(); break;
+      case 5: c.num_values = r.zz(); break;
+      case 7: c.total_comp = r.zz(); break;
+      case 9: c.data_off = r.zz(); break;
+      case 11: c.dict_off = r.zz(); break;
+      default: r.skip(t);
+    }
+  }
+}
+static bool parse_footer(const uint8_t *f, uint64_t len, FileMeta &m, std::string &why) {
+  if (len < 12 || std::memcmp(f, "PAR1", 4) || std::memcmp(f + len - 4, "PAR1", 4)) { why = "not a Parquet file (PAR1 magic)"; return false; }
+  uint32_t flen; std::memcpy(&flen, f + len - 8, 4);
+  if ((uint64_t)flen + 12 > len) { why = "footer length out of range"; return false; }
+  TReader r{f + len - 8 - flen, f + len - 8};
+  int id = 0;
+  for (;;) {
+    const int t = r.field(id);
+    if (!t || !r.ok) break;
+    if (id == 2) { int et; uint32_t n; r.list(et, n); for (uint32_t i = 0; i < n && r.ok; i++) { SchemaEl s; parse_schema_el(r, s); m.schema.push_back(s); } }
+    else if (id == 3) m.num_rows = r.zz();
+    else if (id == 4) {
+      int et; uint32_t n; r.list(et, n);
+      for (uint32_t i = 0; i < n && r.ok; i++) {
+        RowGroup g; int gid = 0;
+        for (;;) {
+          const int gt = r.field(gid);
+          if (!gt || !r.ok) break;
+          if (gid == 1) {
+            int cet; uint32_t cn; r.list(cet, cn);
+            for (uint32_t k = 0; k < cn && r.ok; k++) {
+              ColChunk c; int cid = 0;
+              for (;;) { const int ct = r.field(cid); if (!ct || !r.ok) break; if (cid == 3) parse_col_meta(r, c); else r.skip(ct); }
+              g.cols.push_back(c);
+            }
+          } else if (gid == 3) g.num_rows = r.zz();
+          else r.skip(gt);
+        }
+        m.groups.push_back(g);
+      }
+    } else r.skip(t);
+  }
+  if (!r.ok) { why = "malformed footer (Thrift)"; return false; }
+  return true;
+}
+struct PageHeader { int type = -1, usize = 0, csize = 0, nvalues = 0, enc = 0, def_enc = E_RLE, def_len = 0, rep_len = 0, v2 = 0; bool compressed_v2 = true; };
+static bool parse_page_header(TReader &r, PageHeader &h) {
+  int id = 0;
+  for (;;) {
+    const int t = r.field(id);
+    if (!t || !r.ok) break;
+    if (id == 1) h.type = (int)r.zz();
+    else if (id == 2) h.usize = (int)r.zz();
+    else if (id == 3) h.csize = (int)r.zz();
+    else if (id == 5 || id == 7 || id == 8) {
+      int sid = 0;
+      if (id == 8) h.v2 = 1;
+      for (;;) {
+        const int st = r.field(sid);
+        if (!st || !r.ok) break;
+        if (sid == 1) h.nvalues = (int)r.zz();
+        else if (id == 5 && sid == 2) h.enc = (int)r.zz();
+        else if (id == 5 && sid == 3) h.def_enc = (int)r.zz();
+        else if (id == 7 && sid == 2) h.enc = (int)r.zz();
+        else if (id == 8 && sid == 4) h.enc = (int)r.zz();
+        else if (id == 8 && sid == 5) h.def_len = (int)r.zz();
+        else if (id == 8 && sid == 6) h.rep_len = (int)r.zz();
+        else if (id == 8 && sid == 7) h.compressed_v2 = st == 1;
+        else r.skip(st);
+      }
+    } else r.skip(t);
+  }
+  return r.ok;
+}
+
+// ---- the segment table a column's rows / values look themselves up in ----------------------------------------------------
+enum : uint32_t { SG_RLE = 0, SG_PACKED = 1, SG_PLAIN = 2, SG_PLAIN_BOOL = 3, SG_PLAIN_TEXT = 4 };
+struct Seg {
+  uint32_t start, count;   // first ordinal (levels: row of the column; values: ordinal among the present values) and length
+  uint32_t kind, bw;       // SG_*; bit width of packed values
+  uint64_t at;             // file offset of the packed bits / plain bytes; SG_RLE: the run's value
+  uint32_t dict_base, pad; // dictionary indices: first entry of this chunk's dictionary in the column's concatenated dictionary
+};
+// host: RLE / bit-packed hybrid run headers of [p, e) holding `total` values of width bw; appends segments with ordinals from `ord`
+static bool hybrid_runs(const uint8_t *file, const uint8_t *p, const uint8_t *e, uint32_t bw, uint64_t total, uint64_t ord, uint32_t dict_base, std::vector<Seg> &out, uint64_t *ones) {
+  uint64_t got = 0;
+  const uint32_t vbytes = (bw + 7) / 8;
+  while (got < total) {
+    TReader r{p, e};
+    const uint64_t h = r.varint();
+    if (!r.ok) return false;
+    p = r.p;
+    if (h & 1) {
+      const uint64_t groups = h >> 1, nbytes = groups * bw;
+      if (nbytes > (uint64_t)(e - p)) return false;
+      const uint64_t n = std::min<uint64_t>(groups * 8, total - got);
+      out.push_back(Seg{(uint32_t)(ord + got), (uint32_t)n, SG_PACKED, bw, (uint64_t)(p - file), dict_base, 0});
+      if (ones) for (uint64_t i = 0; i < n; i++) *ones += (p[i >> 3] >> (i & 7)) & 1;  // (levels of width 1: the present rows)
+      p += nbytes; got += n;
+    } else {
+      const uint64_t n = std::min<uint64_t>(h >> 1, total - got);
+      if (vbytes > (uint64_t)(e - p)) return false;
+      uint64_t v = 0;
+      std::memcpy(&v, p, vbytes);
+      p += vbytes;
+      if ((h >> 1) == 0) return false;
+      out.push_back(Seg{(uint32_t)(ord + got), (uint32_t)n, SG_RLE, bw, v, dict_base, 0});
+      if (ones && v) *ones += n;
+      got += n;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ const Seg &find_seg(const Seg *segs, int32_t n, uint32_t ord) {
+  int lo = 0, hi = n - 1;  // the last segment whose start <= ord
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].start <= ord) lo = mid; else hi = mid - 1; }
+  return segs[lo];
+}
+__device__ __forceinline__ uint64_t load_unaligned(const uint8_t *file, uint64_t at, uint32_t nbytes) {  // nbytes <= 8
+  uint64_t v = seg_read8(file, at);
+  return nbytes >= 8 ? v : v & ((1ull << (8 * nbytes)) - 1);
+}
+__device__ __forceinline__ uint32_t seg_value(const uint8_t *file, const Seg &s, uint32_t ord) {  // an RLE / packed integer (level, dictionary index, boolean)
+  if (s.kind == SG_RLE) return (uint32_t)s.at;
+  const uint64_t bit = (uint64_t)(ord - s.start) * s.bw;
+  const uint64_t w = seg_read8(file, s.at + (bit >> 3)) >> (bit & 7);
+  return (uint32_t)(w & ((s.bw >= 32) ? 0xFFFFFFFFull : ((1ull << s.bw) - 1)));
+}
+// definition levels → present[r] (u32, scanned into ordinals afterwards)
+__global__ void __launch_bounds__(256) pq_levels(const uint8_t *file, const Seg *segs, int32_t nsegs, int64_t nrows, uint32_t *present) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  present[r] = nsegs ? seg_value(file, find_seg(segs, nsegs, (uint32_t)r), (uint32_t)r) : 1u;
+}
+__global__ void __launch_bounds__(256) pq_pack_validity(const uint32_t *rank, int64_t nrows, uint8_t *bits) {  // rank = exclusive scan of present, rank[nrows] = total
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b * 8 >= nrows) return;
+  uint32_t v = 0;
+  for (int j = 0; j < 8; j++) { const int64_t r = b * 8 + j; if (r < nrows && rank[r + 1] != rank[r]) v |= 1u << j; }
+  bits[b] = (uint8_t)v;
+}
+struct FixedOut { void *values; int32_t width; int32_t as_date; };
+// one row: its value by ordinal — PLAIN bytes, or a dictionary index into dict (fixed-width entries, file offsets of the chunks' PLAIN dictionary pages)
+__global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint64_t *dict_at, FixedOut o) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const uint32_t k = rank[r];
+  uint64_t v = 0;
+  if (rank[r + 1] != k) {
+    const Seg &s = find_seg(segs, nsegs, k);
+    const uint32_t w = (uint32_t)(o.as_date ? 4 : o.width);
+    if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (uint64_t)(k - s.start) * w, w);
+    else if (s.kind == SG_PLAIN_BOOL) v = (file[s.at + ((k - s.start) >> 3)] >> ((k - s.start) & 7)) & 1;
+    else {
+      const uint32_t idx = seg_value(file, s, k);
+      v = o.width == 1 && !dict_at ? idx : load_unaligned(file, dict_at[s.dict_base] + (uint64_t)idx * w, w);  // (booleans under RLE are their own values)
+    }
+    if (o.as_date) v = (uint64_t)((int64_t)(int32_t)v * 86400);  // parseLogicalDate: time.Unix(0, 0).Add(24h * days)
+  }
+  switch (o.width) {
+    case 1: ((uint8_t *)o.values)[r] = (uint8_t)v; break;
+    case 4: ((uint32_t *)o.values)[r] = (uint32_t)v; break;
+    default: ((uint64_t *)o.values)[r] = v;
+  }
+}
+// PLAIN byte arrays: one lane per page walks the 4-byte length prefixes once
+struct TextPage { uint64_t at; uint32_t ord, count; };
+__global__ void __launch_bounds__(64) pq_walk_text(const uint8_t *file, const TextPage *pages, int32_t npages, uint32_t *val_off, uint32_t *val_len) {
+  const int32_t pg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pg >= npages) return;
+  uint64_t at = pages[pg].at;
+  for (uint32_t i = 0; i < pages[pg].count; i++) {
+    const uint32_t n = (uint32_t)load_unaligned(file, at, 4);
+    val_off[pages[pg].ord + i] = (uint32_t)(at + 4);
+    val_len[pages[pg].ord + i] = n;
+    at += 4 + (uint64_t)n;
+  }
+}
+// one row of a byte-array column: where its bytes are in the file image, and how many
+__global__ void __launch_bounds__(256) pq_text_cells(const uint8_t *file, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint32_t *val_off, const uint32_t *val_len,
+                                                     const uint32_t *dict_off, const uint32_t *dict_len, uint32_t *src_off, uint32_t *lens) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const uint32_t k = rank[r];
+  uint32_t so = SEG_NONE, n = 0;
+  if (rank[r + 1] != k) {
+    const Seg &s = find_seg(segs, nsegs, k);
+    if (s.kind == SG_PLAIN_TEXT) { so = val_off[k]; n = val_len[k]; }
+    else { const uint32_t idx = s.dict_base + seg_value(file, s, k); so = dict_off[idx]; n = dict_len[idx]; }
+  }
+  src_off[r] = n ? so : SEG_NONE;
+  lens[r] = n;
+}
+template <int RPT>
+__global__ void __launch_bounds__(256) pq_pack_text(const uint32_t *dst_off, int64_t nrows, const uint8_t *file, uint8_t *dst, const uint32_t *src_off) {
+  __shared__ uint32_t doff[256 * RPT + 1], soff[256 * RPT];
+  const int64_t k0 = (int64_t)blockIdx.x * (256 * RPT);
+  if (k0 >= nrows) return;
+  segcopy_run<RPT>(dst_off, nrows, k0, file, dst, [&](int64_t r) { return src_off[r]; }, doff, soff);
+}
+
+}  // namespace pq
+}  // namespace tf
+
+using namespace tf;
+using namespace tf::pq;
+
+#define TF_API_BEGIN try {
+#define TF_API_END                                                        \
+  }                                                                       \
+  catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }       \
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+
+extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out) {
+  TF_API_BEGIN
+  if (!bytes || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: null argument");
+  if (mem != TFGPU_MEM_HOST) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the footer and the page headers are walked on the host: pass the object in host memory (pinned for an asynchronous upload)");
+  if (len >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: objects of 4 GiB and more: read them row group by row group");
+  const uint8_t *f = static_cast<const uint8_t *>(bytes);
+  FileMeta m; std::string why;
+  if (!parse_footer(f, len, m, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: " + why);
+  PQD("footer: %zu schema els, %zu groups, %lld rows\n", m.schema.size(), m.groups.size(), (long long)m.num_rows);
+  if (m.schema.empty()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: empty schema");
+  // flat schemas: the root and its leaves
+  std::vector<SchemaEl> leaves(m.schema.begin() + 1, m.schema.end());
+  for (auto &s : leaves) if (s.nchildren || s.rep == 2) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + s.name + ": nested / repeated columns are read by the stock reader");
+  int64_t nrows = 0;
+  for (auto &g : m.groups) { nrows += g.num_rows; if (g.cols.size() != leaves.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a row group does not hold every leaf column"); }
+  if (nrows > 0x7FFFFFF0ll) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: more than 2^31 rows in one object");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  hipStream_t st = cx.stream;
+  Buf file = dalloc((size_t)len + 64);
+  h2d(file->p, f, (size_t)len);   // the upload runs while the host walks the pages
+  TF_HIP(hipMemsetAsync((char *)file->p + len, 0, 64, st));
+  const uint8_t *dfile = ptr<uint8_t>(file);
+
+  auto db = std::make_unique<tfgpu_dbatch>();
+  db->nrows = nrows; db->ns = table_ns ? table_ns : ""; db->table = table_name ? table_name : "";
+  std::vector<int> want;  // leaf index per output column (or -1: the file does not have it → nil, reader_parquet.go:256-259)
+  std::vector<std::pair<std::string, int>> outcols;
+  if (schema) {
+    for (int i = 0; i < schema->ncols; i++) {
+      const char *nm = schema->cols[i].name ? schema->cols[i].name : "";
+      int at = -1;
+      for (size_t k = 0; k < leaves.size(); k++) if (leaves[k].name == nm) at = (int)k;
+      want.push_back(at); outcols.push_back({nm, schema->cols[i].dtype});
+      db->schema.push_back({nm, schema->cols[i].dtype});
+      if (schema->cols[i].flags & TFGPU_COL_KEY) db->key_names.push_back(nm);
+    }
+  } else for (size_t k = 0; k < leaves.size(); k++) { want.push_back((int)k); outcols.push_back({leaves[k].name, -1}); }
+
+  std::vector<Buf> keep;  // tables the kernels read until the final sync
+  for (size_t oc = 0; oc < want.size(); oc++) {
+    DColumn d;
+    d.name = outcols[oc].first;
+    if (want[oc] < 0) {  // nil for every row
+      d.repr = TFGPU_R_STRING; d.dtype = outcols[oc].second >= 0 ? outcols[oc].second : TFGPU_T_UTF8;
+      d.offsets = dalloc_zero((size_t)(nrows + 1) * 4); d.data = dalloc(8); d.data_len = 0; d.validity = dalloc_zero((size_t)(nrows + 7) / 8 + 8);
+      db->cols.push_back(std::move(d));
+      continue;
+    }
+    const SchemaEl &leaf = leaves[(size_t)want[oc]];
+    PQD("column %s type %d rep %d logical %d conv %d\n", leaf.name.c_str(), leaf.type, leaf.rep, leaf.logical, leaf.conv);
+    const bool optional = leaf.rep == 1;
+    const bool is_date = leaf.logical == L_DATE || leaf.conv == 6;
+    const bool is_text = leaf.type == T_BYTE_ARRAY;
+    switch (leaf.type) {
+      case T_BOOLEAN: d.repr = TFGPU_R_BOOL; break;
+      case T_INT32: d.repr = is_date ? TFGPU_R_TIME : TFGPU_R_INT32; break;
+      case T_INT64: d.repr = TFGPU_R_INT64; break;
+      case T_FLOAT: d.repr = TFGPU_R_FLOAT32; break;
+      case T_DOUBLE: d.repr = TFGPU_R_FLOAT64; break;
+      case T_BYTE_ARRAY: d.repr = (leaf.logical == L_STRING || leaf.conv == 0) ? TFGPU_R_STRING : TFGPU_R_BYTES; break;
+      default: return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": " + (leaf.type == T_INT96 ? "INT96" : "FIXED_LEN_BYTE_ARRAY") + " values are read by the stock reader");
+    }
+    d.dtype = outcols[oc].second >= 0 ? outcols[oc].second
+              : d.repr == TFGPU_R_BOOL ? TFGPU_T_BOOLEAN : d.repr == TFGPU_R_INT32 ? TFGPU_T_INT32 : d.repr == TFGPU_R_INT64 ? TFGPU_T_INT64 : d.repr == TFGPU_R_FLOAT32 ? TFGPU_T_FLOAT32
+              : d.repr == TFGPU_R_FLOAT64 ? TFGPU_T_FLOAT64 : d.repr == TFGPU_R_TIME ? TFGPU_T_DATE : d.repr == TFGPU_R_STRING ? TFGPU_T_UTF8 : TFGPU_T_BYTES;
+    const uint32_t width = leaf.type == T_BOOLEAN ? 1 : (leaf.type == T_INT32 || leaf.type == T_FLOAT) ? 4 : 8;
+
+    std::vector<Seg> lev, val;
+    std::vector<TextPage> tpages;
+    std::vector<uint64_t> dict_at;                 // fixed-width dictionaries: file offset of each chunk's entries
+    std::vector<uint32_t> dict_off, dict_len;      // byte-array dictionaries: every entry of every chunk
+    uint64_t row0 = 0, ord = 0;
+    for (auto &g : m.groups) {
+      const ColChunk &c = g.cols[(size_t)want[oc]];
+      if (c.codec != 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": compressed pages (codec " + std::to_string(c.codec) + ") are read by the stock reader; this path takes UNCOMPRESSED chunks");
+      uint64_t pos = (uint64_t)((c.dict_off > 0 && c.dict_off < c.data_off) ? c.dict_off : c.data_off);
+      const uint64_t end = pos + (uint64_t)c.total_comp;
+      if (end > len) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column chunk out of range");
+      uint32_t dict_base = 0;
+      int64_t seen = 0;
+      while (pos < end && seen < c.num_values) {
+        TReader r{f + pos, f + end};
+        PageHeader h;
+        if (!parse_page_header(r, h) || h.csize < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed page header in column " + leaf.name);
+        const uint8_t *pl = r.p, *pe = r.p + h.csize;
+        PQD("  page at %llu type %d csize %d nvalues %d enc %d v2 %d\n", (unsigned long long)pos, h.type, h.csize, h.nvalues, h.enc, h.v2);
+        if (pe > f + end) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: page out of range in column " + leaf.name);
+        if (h.type == 2) {  // dictionary page: PLAIN entries
+          if (h.enc != E_PLAIN && h.enc != E_PLAIN_DICT) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: dictionary page encoding " + std::to_string(h.enc));
+          if (is_text) {
+            dict_base = (uint32_t)dict_off.size();
+            const uint8_t *q = pl;
+            for (int i = 0; i < h.nvalues; i++) {
+              if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated dictionary in column " + leaf.name);
+              uint32_t n; std::memcpy(&n, q, 4);
+              dict_off.push_back((uint32_t)(q + 4 - f)); dict_len.push_back(n);
+              q += 4 + (uint64_t)n;
+            }
+          } else { dict_base = (uint32_t)dict_at.size(); dict_at.push_back((uint64_t)(pl - f)); }
+        } else if (h.type == 0 || h.type == 3) {
+          if (h.v2 && h.rep_len) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: repetition levels");
+          const uint8_t *q = pl;
+          uint64_t present = (uint64_t)h.nvalues;
+          if (optional) {
+            const uint8_t *ls, *le;
+            if (h.v2) { ls = q; le = q + h.def_len; q = le; }
+            else { if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page"); uint32_t L; std::memcpy(&L, q, 4); ls = q + 4; le = ls + L; q = le; }
+            if (le > pe || (!h.v2 && h.def_enc != E_RLE)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: definition levels of column " + leaf.name + " are not RLE");
+            present = 0;
+            if (!hybrid_runs(f, ls, le, 1, (uint64_t)h.nvalues, row0 + (uint64_t)seen, 0, lev, &present)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed definition levels in column " + leaf.name);
+          }
+          if (h.enc == E_PLAIN) {
+            if (is_text) { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)(q - f), (uint32_t)ord, (uint32_t)present}); }
+            else val.push_back(Seg{(uint32_t)ord, (uint32_t)present, leaf.type == T_BOOLEAN ? SG_PLAIN_BOOL : SG_PLAIN, 0, (uint64_t)(q - f), 0, 0});
+          } else if (h.enc == E_RLE_DICT || h.enc == E_PLAIN_DICT) {
+            if (q >= pe && present) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page");
+            const uint32_t bw = present ? *q : 0;
+            if (bw > 32) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: dictionary index width");
+            if (present && !hybrid_runs(f, q + 1, pe, bw, present, ord, dict_base, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed dictionary indices in column " + leaf.name);
+          } else if (h.enc == E_RLE && leaf.type == T_BOOLEAN) {  // booleans of v2 pages: a length-prefixed hybrid of width 1
+            if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page");
+            uint32_t L; std::memcpy(&L, q, 4);
+            if (!hybrid_runs(f, q + 4, std::min(q + 4 + L, pe), 1, present, ord, 0, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed boolean run in column " + leaf.name);
+          } else return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": value encoding " + std::to_string(h.enc) + " (DELTA_* / BYTE_STREAM_SPLIT) is read by the stock reader");
+          ord += present; seen += h.nvalues;
+        }
+        pos = (uint64_t)(pe - f);
+      }
+      if (seen != c.num_values || c.num_values != g.num_rows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": pages do not add up to the row group's rows");
+      row0 += (uint64_t)g.num_rows;
+    }
+    if (nrows == 0) {
+      if (is_text) { d.offsets = dalloc_zero(8); d.data = dalloc(8); } else { d.values = dalloc(8); if (d.repr == TFGPU_R_TIME) d.nanos = dalloc(8); }
+      db->cols.push_back(std::move(d));
+      continue;
+    }
+    PQD("  %zu level segs, %zu value segs, %zu text pages, ord %llu\n", lev.size(), val.size(), tpages.size(), (unsigned long long)ord);
+    Buf blev = lev.empty() ? nullptr : upload_small(lev.data(), lev.size() * sizeof(Seg));
+    Buf bval = val.empty() ? nullptr : upload_small(val.data(), val.size() * sizeof(Seg));
+    Buf rank = dalloc((size_t)(nrows + 2) * 4);
+    pq_levels<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(blev), (int32_t)lev.size(), nrows, ptr<uint32_t>(rank));
+    exclusive_scan_u32(ptr<uint32_t>(rank), ptr<uint32_t>(rank), nrows, true);
+    if (optional) { d.validity = dalloc((size_t)(nrows + 7) / 8 + 8); pq_pack_validity<<<(unsigned)(((nrows + 7) / 8 + 255) / 256), 256, 0, st>>>(ptr<uint32_t>(rank), nrows, ptr<uint8_t>(d.validity)); }
+    keep.push_back(blev); keep.push_back(bval); keep.push_back(rank);
+    KernelTimer t(is_text ? "pq_text" : "pq_values");
+    if (!is_text) {
+      Buf bdict = dict_at.empty() ? nullptr : upload_small(dict_at.data(), dict_at.size() * 8);
+      keep.push_back(bdict);
+      const uint32_t ow = d.repr == TFGPU_R_TIME ? 8 : width;
+      d.values = dalloc((size_t)nrows * ow);
+      if (d.repr == TFGPU_R_TIME) d.nanos = dalloc_zero((size_t)nrows * 4);
+      pq_values_fixed<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), FixedOut{d.values->p, (int32_t)ow, is_date ? 1 : 0});
+    } else {
+      Buf voff = dalloc((size_t)std::max<uint64_t>(ord, 1) * 4), vlen = dalloc((size_t)std::max<uint64_t>(ord, 1) * 4);
+      Buf btp = tpages.empty() ? nullptr : upload_small(tpages.data(), tpages.size() * sizeof(TextPage));
+      if (!tpages.empty()) pq_walk_text<<<(unsigned)((tpages.size() + 63) / 64), 64, 0, st>>>(dfile, reinterpret_cast<const TextPage *>(btp->p), (int32_t)tpages.size(), ptr<uint32_t>(voff), ptr<uint32_t>(vlen));
+      Buf bdo = dict_off.empty() ? nullptr : upload_small(dict_off.data(), dict_off.size() * 4), bdl = dict_len.empty() ? nullptr : upload_small(dict_len.data(), dict_len.size() * 4);
+      Buf soff = dalloc((size_t)nrows * 4);
+      d.offsets = dalloc((size_t)(nrows + 1) * 4 + 16);
+      pq_text_cells<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)val.size(), ptr<uint32_t>(rank), nrows, ptr<uint32_t>(voff), ptr<uint32_t>(vlen), ptr<uint32_t>(bdo), ptr<uint32_t>(bdl),
+                                                                     ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets));
+      exclusive_scan_u32(ptr<uint32_t>(d.offsets), ptr<uint32_t>(d.offsets), nrows, true);
+      const uint32_t *htot = d2h_u32(ptr<uint32_t>(d.offsets) + nrows);
+      tf::sync();
+      d.data_len = *htot;
+      d.data = dalloc((size_t)d.data_len + 16);
+      constexpr int RPT = 4;
+      pq_pack_text<RPT><<<(unsigned)((nrows + 256 * RPT - 1) / (256 * RPT)), 256, 0, st>>>(ptr<uint32_t>(d.offsets), nrows, dfile, ptr<uint8_t>(d.data), ptr<uint32_t>(soff));
+      keep.push_back(voff); keep.push_back(vlen); keep.push_back(btp); keep.push_back(bdo); keep.push_back(bdl); keep.push_back(soff);
+    }
+    db->cols.push_back(std::move(d));
+  }
+  tf::sync();
+  *out = db.release();
+  return TFGPU_OK;
+  TF_API_END
+}

@@ -25,7 +25,7 @@ _lib = None
 
 EXPORTS = [
     "tfgpu_abi_version", "tfgpu_last_error", "tfgpu_init", "tfgpu_shutdown", "tfgpu_device_count", "tfgpu_synchronize",
-    "tfgpu_init_devices", "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_lane_device", "tfgpu_dbatch_slice", "tfgpu_dbatch_to_lane", "tfgpu_shard_rows", "tfgpu_dbatch_concat", "tfgpu_strictify", "tfgpu_parsequeue_create", "tfgpu_parsequeue_add", "tfgpu_parsequeue_error", "tfgpu_parsequeue_close", "tfgpu_parsequeue_destroy", "tfgpu_bufferer_create", "tfgpu_bufferer_async_push", "tfgpu_bufferer_wait", "tfgpu_bufferer_get_stats", "tfgpu_bufferer_close", "tfgpu_bufferer_destroy", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
+    "tfgpu_init_devices", "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_lane_device", "tfgpu_dbatch_slice", "tfgpu_dbatch_to_lane", "tfgpu_shard_rows", "tfgpu_dbatch_concat", "tfgpu_strictify", "tfgpu_parquet_read", "tfgpu_parsequeue_create", "tfgpu_parsequeue_add", "tfgpu_parsequeue_error", "tfgpu_parsequeue_close", "tfgpu_parsequeue_destroy", "tfgpu_bufferer_create", "tfgpu_bufferer_async_push", "tfgpu_bufferer_wait", "tfgpu_bufferer_get_stats", "tfgpu_bufferer_close", "tfgpu_bufferer_destroy", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
@@ -166,6 +166,16 @@ def lane_device(lane: int) -> int:
     d = C.c_int(-1)
     _check(load().tfgpu_lane_device(int(lane), C.byref(d)))
     return int(d.value)
+
+
+def parquet_read(data: bytes, schema: Optional[abi.Schema] = None, ns: str = "", table: str = "") -> "DeviceBatch":
+    """ReaderParquet.Read's decode on the device: a whole Parquet object (host bytes) → one device batch"""
+    init()
+    out = C.c_void_p()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    cs = schema.to_c() if schema is not None else None
+    _check(load().tfgpu_parquet_read(C.c_void_p(buf.ctypes.data), C.c_uint64(len(buf)), abi.MEM_HOST, C.byref(cs) if cs is not None else None, ns.encode(), table.encode(), C.byref(out)))
+    return DeviceBatch(out)
 
 
 def strictify(batch: "DeviceBatch", schema: Optional[abi.Schema] = None) -> "DeviceBatch":
