@@ -716,6 +716,64 @@ class Configs3Workload(Base):
     def extra(self):
         return {"text_out_bytes_per_step": self.state["out_bytes"]}
 
+    def parquet_source(self):
+        """Never `value`: the same step from configs[3]'s REAL source format.  The resident columns are written as one Parquet
+        object (pyarrow, uncompressed — the codec the device path takes — dictionary encoding as pyarrow chooses it, one row group)
+        into pinned host memory; a step is tfgpu_parquet_read (upload of the object + decode on the device) + the chain + JSONEachRow."""
+        e, a = self.env, self.args
+        lib, abi = e.lib, e.abi
+        try:
+            import io
+            import pyarrow as pa
+            import pyarrow.parquet as pq
+        except Exception as ex:  # noqa: BLE001
+            return {"parquet_source": {"skipped": "pyarrow: %s" % ex}}
+        h = self.host_copy
+        arrays, names = [], []
+        for c in h.cols:
+            valid = c.validity
+            vbuf = pa.py_buffer(np.packbits(valid, bitorder="little").tobytes()) if valid is not None else None
+            if c.repr in abi.VAR_REPRS:
+                off = c.offsets.astype(np.int32)
+                arr = pa.Array.from_buffers(pa.string() if c.repr == abi.R_STRING else pa.binary(), h.nrows, [vbuf, pa.py_buffer(off.tobytes()), pa.py_buffer(bytes(c.data[: int(off[-1])]))])
+            elif c.repr == abi.R_TIME:
+                arr = pa.array(c.values.astype(np.int64), pa.int64(), mask=None if valid is None else ~valid)   # (epoch seconds as INT64: the decode cost of a time column)
+            else:
+                arr = pa.array(c.values, mask=None if valid is None else ~valid)
+            arrays.append(arr); names.append(c.name)
+        buf = io.BytesIO()
+        pq.write_table(pa.table(arrays, names=names), buf, compression="NONE", row_group_size=h.nrows)
+        data = buf.getvalue()
+        pinned = lib.HostBuffer(data)
+        schema = abi.Schema.of([[c.name, c.dtype] for c in h.cols])
+        cs = schema.to_c()
+        import ctypes as C
+
+        def one():
+            out = C.c_void_p()
+            lib._check(lib.load().tfgpu_parquet_read(C.c_void_p(pinned.ptr), C.c_uint64(len(data)), abi.MEM_HOST, C.byref(cs), b"", b"hits", C.byref(out)))
+            db = lib.DeviceBatch(out)
+            tr = lib.apply_chain(self.plans, db)
+            o = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
+            o.free(); tr.transformed.free(); db.free()
+        one(); lib.synchronize()
+        k = 5
+        t0 = time.perf_counter()
+        for _ in range(k):
+            one()
+        lib.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        lib.prof_reset(); lib.prof_enable(True)
+        one()
+        lib.prof_enable(False)
+        prof = {n: round(ms / max(l, 1), 4) for n, l, ms in lib.prof_get() if n.startswith("pq_")}
+        lib.prof_reset()
+        pinned.free()
+        return {"parquet_source": {"object_bytes": len(data), "rows_per_s": round(h.nrows / dt, 1), "ms_per_step": round(dt * 1e3, 3), "gb_per_s_parquet_in": round(len(data) / dt / 1e9, 2),
+                                   "decode_kernels_avg_ms": prof,
+                                   "note": "uncompressed Parquet written by pyarrow from the same columns (time columns as INT64), in pinned host memory; a step uploads the object (PCIe inside), "
+                                           "decodes it on the device, then runs the chain and the serializer; parity of the decode is pinned to pyarrow, not to the reference (DESIGN §7 f3)"}}
+
     def side_measurements(self):
         """Never `value`: the sink leg.  Every step ends with the JSONEachRow bytes copied to PINNED host memory
         (hipMemcpyAsync D2H on the lane's stream, the bytes httpuploader would POST: marshal.go:82-125) — on one lane, and on
@@ -777,7 +835,12 @@ class Configs3Workload(Base):
                 res[f"lanes_{nl}"] = {"rows_per_s": round(self.n * kk / dt, 1), "gb_per_s_d2h": round(self.state["out_bytes"] * kk / dt / 1e9, 2), "ms_per_step": round(dt / kk * 1e3, 3)}
         res["note"] = ("every step's JSONEachRow text (%.2f GB) is copied to pinned host memory inside the step; with several lanes the D2H of one batch runs beside "
                        "the kernels of another; PCIe Gen5 x16 bounds the copy at ~55-60 GB/s" % (self.state["out_bytes"] / 1e9))
-        return {"d2h_inclusive": res}
+        out = {"d2h_inclusive": res}
+        try:
+            out.update(self.parquet_source())
+        except Exception as ex:  # noqa: BLE001
+            out["parquet_source"] = {"error": str(ex)[:300]}
+        return out
 
     def cpu(self):
         from oracle import oracle as ora

@@ -121,3 +121,36 @@ def test_what_stays_with_the_stock_reader_is_refused_by_name(tf):
     with pytest.raises(tf.TfgpuError) as ei:
         tf.parquet_read(b"PAR1 this is not a parquet file PAR1")
     assert ei.value.code == tf.ERR_INVALID
+
+
+def test_wide_object_whose_segment_tables_outgrow_the_pinned_ring(tf):
+    """Hundreds of small pages per chunk and dozens of columns: the host's segment tables (megabytes in all) travel through the lane's 8 MB
+    pinned ring more than once around — the text columns' sizes must not be read back through it (a bug the bench shape found)."""
+    rng = np.random.default_rng(77)
+    n, ncols = 60000, 48
+    cols = {}
+    for j in range(ncols):
+        if j % 4 == 3:
+            cols["s%d" % j] = pa.array(["v%d-%d" % (j, int(x)) for x in rng.integers(0, 1000, n)])
+        else:
+            vals = rng.integers(0, 1 << 40, n)
+            cols["c%d" % j] = pa.array(vals, pa.int64(), mask=(rng.integers(0, 9, n) == 0))
+    t = pa.table(cols)
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="NONE", data_page_size=512, use_dictionary=[k for k in cols if k.startswith("s")])
+    data = buf.getvalue()
+    out = tf.parquet_read(data).download()
+    ref = pq.read_table(io.BytesIO(data))
+    for c in out.cols:
+        col = ref.column(c.name).combine_chunks()
+        if c.repr == abi.R_INT64:
+            want = col.to_numpy(zero_copy_only=False)
+            valid = ~np.isnan(want) if want.dtype.kind == "f" else np.ones(n, bool)
+            got_valid = c.validity if c.validity is not None else np.ones(n, bool)
+            assert np.array_equal(got_valid, valid), c.name
+            assert np.array_equal(c.values[valid], np.asarray(col.drop_null().to_numpy())), c.name
+        else:
+            want = col.to_pylist()
+            assert int(c.offsets[-1]) == sum(len(w) for w in want), c.name
+            for i in (0, 1, n // 2, n - 1):
+                assert c.get_bytes(i) == want[i].encode(), (c.name, i)
