@@ -520,8 +520,10 @@ __global__ void __launch_bounds__(256) TF_SER_LEN_ATTR ser_chunk_len(SerParams p
 // (2) per row: chunk lengths → offsets inside the row, row length
 template <int FMT>
 __global__ void __launch_bounds__(256) ser_chunk_layout(SerParams p, ChunkPlan cp) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= p.nrows) return;
+  const int64_t rl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = rl < p.nrows;                    // (lanes past the end stay for the wave's sum: they redo the last row and add nothing)
+  const int64_t r = live ? rl : p.nrows - 1;
+  if (p.nrows <= 0) return;
   uint32_t off = 0;
   constexpr int U = 8;  // the lengths are requested before the first offset is stored (a load and a store to one array per step)
   int32_t k = 0;
@@ -530,13 +532,20 @@ __global__ void __launch_bounds__(256) ser_chunk_layout(SerParams p, ChunkPlan c
 #pragma unroll
     for (int q = 0; q < U; q++) n[q] = cp.chunk[(int64_t)(k + q) * p.nrows + r];
 #pragma unroll
-    for (int q = 0; q < U; q++) { cp.chunk[(int64_t)(k + q) * p.nrows + r] = off; off += n[q]; }
+    for (int q = 0; q < U; q++) { if (live) cp.chunk[(int64_t)(k + q) * p.nrows + r] = off; off += n[q]; }
   }
-  for (; k < cp.nchunks; k++) { const uint32_t n = cp.chunk[(int64_t)k * p.nrows + r]; cp.chunk[(int64_t)k * p.nrows + r] = off; off += n; }
+  for (; k < cp.nchunks; k++) { const uint32_t n = cp.chunk[(int64_t)k * p.nrows + r]; if (live) cp.chunk[(int64_t)k * p.nrows + r] = off; off += n; }
   CountSink t;
   row_tail<FMT>(t, p, r, off == 0);
-  p.row_len[r] = off + t.n;
-  atomicAdd(p.total64, (unsigned long long)(off + t.n));
+  if (live) p.row_len[r] = off + t.n;
+  // the 64-bit total (the offsets are 32-bit: the host refuses an output of 4 GiB and more): one atomic per wave, not per row —
+  // a million atomics on one address were most of this kernel's 0.21 ms
+  unsigned long long sum = live ? (unsigned long long)(off + t.n) : 0ull;
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t lo = __shfl_down((uint32_t)sum, d, 64), hi = __shfl_down((uint32_t)(sum >> 32), d, 64);
+    if ((int)(threadIdx.x & 63) + d < 64) sum += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.total64, sum);
 }
 // (4) the text
 template <int FMT>
