@@ -766,8 +766,10 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     std::memset(&c, 0, sizeof c);
     c.json_type = pr.json_type;
     switch (pr.json_type) {
-      case TFGPU_SRT_BOOLEAN: d.dtype = TFGPU_T_BOOLEAN; d.repr = TFGPU_R_BOOL; d.values = dalloc_zero((size_t)nra); c.values = d.values->p; break;
-      case TFGPU_SRT_INTEGER: d.dtype = TFGPU_T_INT64; d.repr = TFGPU_R_INT64; d.values = dalloc_zero((size_t)nra * 8); c.values = d.values->p; break;
+      // (sr_cell_values writes every row of every property and sr_pack_validity every byte of every bitmap: no zero fills — they were ~200
+      //  hipMemsetAsync launches per batch, a millisecond of host time)
+      case TFGPU_SRT_BOOLEAN: d.dtype = TFGPU_T_BOOLEAN; d.repr = TFGPU_R_BOOL; d.values = dalloc((size_t)nra); c.values = d.values->p; break;
+      case TFGPU_SRT_INTEGER: d.dtype = TFGPU_T_INT64; d.repr = TFGPU_R_INT64; d.values = dalloc((size_t)nra * 8); c.values = d.values->p; break;
       case TFGPU_SRT_NUMBER: d.dtype = TFGPU_T_FLOAT64; d.repr = TFGPU_R_JSONNUM; break;
       case TFGPU_SRT_STRING: d.dtype = TFGPU_T_UTF8; d.repr = TFGPU_R_STRING; break;
       default: d.dtype = TFGPU_T_ANY; d.repr = TFGPU_R_JSON;
@@ -779,7 +781,7 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
       ti++;
     }
     c.valid8 = ptr<uint8_t>(valid8) + (size_t)j * (size_t)nra;
-    d.validity = dalloc_zero((size_t)((nra + 7) / 8) + 8);
+    d.validity = dalloc((size_t)((nra + 7) / 8) + 8);
     c.validity = ptr<uint8_t>(d.validity);
     db->schema.push_back({d.name, d.dtype});
     db->cols.push_back(std::move(d));
