@@ -1053,10 +1053,20 @@ __global__ void __launch_bounds__(256) sql_const_text_kernel(uint32_t *off, uint
   off[r] = (uint32_t)r * len;
   if (r < n) for (uint32_t k = 0; k < len; k++) data[(uint64_t)r * len + k] = text[k];
 }
-__global__ void __launch_bounds__(256) sql_zero_nil_kernel(uint8_t *values, int32_t width, const uint8_t *validity, int64_t n) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n || ((validity[r >> 3] >> (r & 7)) & 1)) return;
-  for (int k = 0; k < width; k++) values[r * width + k] = 0;
+struct SqlNilCol { const uint8_t *src; uint8_t *dst; const uint8_t *validity; int32_t width; };
+// dst[r] = the value, or the type's zero where the row is nil; item = column * n + row
+__global__ void __launch_bounds__(256) sql_default_nils_kernel(const SqlNilCol *cols, int32_t ncols, int64_t n) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (int64_t)ncols * n) return;
+  const int32_t j = (int32_t)(it / n); const int64_t r = it - (int64_t)j * n;
+  const SqlNilCol c = cols[j];
+  const bool ok = (c.validity[r >> 3] >> (r & 7)) & 1;
+  switch (c.width) {
+    case 1: c.dst[r] = ok ? c.src[r] : 0; break;
+    case 2: ((uint16_t *)c.dst)[r] = ok ? ((const uint16_t *)c.src)[r] : 0; break;
+    case 4: ((uint32_t *)c.dst)[r] = ok ? ((const uint32_t *)c.src)[r] : 0u; break;
+    default: ((uint64_t *)c.dst)[r] = ok ? ((const uint64_t *)c.src)[r] : 0ull;
+  }
 }
 __global__ void __launch_bounds__(256) sql_kind_bitmaps_kernel(const uint8_t *kind, int64_t n, uint8_t *has_old, uint8_t *has_cols) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1112,17 +1122,24 @@ static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_
   }
   // nil → the ClickHouse default (MarshalCItoJSON omits nil columns, JSONEachRow fills the type's default): 0 / ''
   auto w = shallow_copy(in);
-  for (auto &c : w->cols) {
-    if (!c.validity) continue;
-    if (!repr_is_var(c.repr)) {
-      const size_t width = repr_width(c.repr);
-      Buf v = dalloc((size_t)std::max<int64_t>(n0, 1) * width);
-      TF_HIP(hipMemcpyAsync(v->p, c.values->p, (size_t)n0 * width, hipMemcpyDeviceToDevice, st));
-      if (n0) sql_zero_nil_kernel<<<grid_for(n0, 256), 256, 0, st>>>(ptr<uint8_t>(v), (int32_t)width, ptr<uint8_t>(c.validity), n0);
-      c.values = v;
-      if (c.nanos) { Buf nn = dalloc((size_t)std::max<int64_t>(n0, 1) * 4); TF_HIP(hipMemcpyAsync(nn->p, c.nanos->p, (size_t)n0 * 4, hipMemcpyDeviceToDevice, st)); if (n0) sql_zero_nil_kernel<<<grid_for(n0, 256), 256, 0, st>>>(ptr<uint8_t>(nn), 4, ptr<uint8_t>(c.validity), n0); c.nanos = nn; }
+  {
+    std::vector<SqlNilCol> nil;  // every nullable fixed-width array in ONE launch (an SR / JSON batch has ~100 of them: a copy + a kernel each before)
+    for (auto &c : w->cols) {
+      if (!c.validity) continue;
+      if (!repr_is_var(c.repr)) {
+        const size_t width = repr_width(c.repr);
+        Buf v = dalloc((size_t)std::max<int64_t>(n0, 1) * width);
+        nil.push_back(SqlNilCol{(const uint8_t *)c.values->p, ptr<uint8_t>(v), ptr<uint8_t>(c.validity), (int32_t)width});
+        c.values = v;
+        if (c.nanos) { Buf nn = dalloc((size_t)std::max<int64_t>(n0, 1) * 4); nil.push_back(SqlNilCol{(const uint8_t *)c.nanos->p, ptr<uint8_t>(nn), ptr<uint8_t>(c.validity), 4}); c.nanos = nn; }
+      }
+      c.validity = nullptr;  // (a nil text cell has no bytes: it is '' already)
     }
-    c.validity = nullptr;  // (a nil text cell has no bytes: it is '' already)
+    if (!nil.empty() && n0) {
+      Buf bn = upload_small(nil.data(), nil.size() * sizeof(SqlNilCol));
+      KernelTimer t("sql_default_nils");
+      sql_default_nils_kernel<<<grid_for((int64_t)nil.size() * n0, 256), 256, 0, st>>>(reinterpret_cast<const SqlNilCol *>(bn->p), (int32_t)nil.size(), n0);
+    }
   }
   // WHERE on every row event
   std::unique_ptr<tfgpu_dbatch> kept = p.sql_has_where ? run_filter(p.exprs, true, false, *w, ax) : std::move(w);
