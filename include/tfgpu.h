@@ -396,6 +396,16 @@ typedef struct tfgpu_transformation_stats {
   int64_t plans_built;  /* AddTablePlan calls (cache misses)                  */
 } tfgpu_transformation_stats;
 int tfgpu_transformation_create(tfgpu_plan *const *transformers, int n, tfgpu_transformation **out); /* plans stay the caller's */
+/* The chain as middlewares.Transformation builds it (pkg/middlewares/transformation.go:12-36) from the transfer's own
+ * transformer.Transformers JSON (pkg/transformer/abstract.go:21-66): {"transformers":[{"<type>":{config},"transformerId":…},…],
+ * "errorsOutput":{"Type":"sink"|"devnull"}}.  Every entry's type is util.Snakify of its key ("maskField" -> "mask_field"), its
+ * config goes to tfgpu_plan_create as it is, the plans are owned by the transformation; `extra` = Transformation.ExtraTransformers,
+ * appended after them (the caller's).  A type that has no device plan fails the call with that type's code and "unable to init:
+ * <type>: …" — the shim then builds the stock chain.                                                                        */
+int tfgpu_transformation_from_config(const char *transformers_json, tfgpu_plan *const *extra, int n_extra, tfgpu_transformation **out);
+int tfgpu_transformation_size(const tfgpu_transformation *t);
+const char *tfgpu_transformation_plan_type(const tfgpu_transformation *t, int i);
+const char *tfgpu_transformation_errors_output(const tfgpu_transformation *t);   /* "sink", "devnull" or "" */
 void tfgpu_transformation_destroy(tfgpu_transformation *t);
 int tfgpu_transformation_table_plan(tfgpu_transformation *t, const char *table_ns, const char *table_name, const tfgpu_schema *schema,
                                     int32_t *idx, int32_t cap, int32_t *n);

@@ -113,3 +113,43 @@ def test_deepsizeof_known_answers(oracle):
     assert total == 24 + 8 * 16 + 8 + 8 + 26 + 1 + 0 + 24 + (24 + 3) + m
     total2, _ = oracle.deepsizeof(b, s)  # UseNumber: 64 is json.Number("64") = 16 + 2
     assert total2 == total + (18 - 8)
+
+
+def test_transformation_chain_from_the_transfers_config():
+    """middlewares.Transformation (pkg/middlewares/transformation.go:12-36): the chain is built from the transfer's
+    transformer.Transformers value — one-of entries keyed by the (camelCase or snake_case) type name, an optional transformerId
+    beside it, errorsOutput — in config order, ExtraTransformers after; a type without a device plan fails the whole construction
+    by name.  Host-only: no device needed."""
+    import ctypes as C
+    import json
+    from transferia_amd import lib
+    L = lib.load()
+    L.tfgpu_transformation_plan_type.restype = C.c_char_p
+    L.tfgpu_transformation_errors_output.restype = C.c_char_p
+    L.tfgpu_transformation_from_config.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.tfgpu_transformation_size.argtypes = [C.c_void_p]
+    L.tfgpu_transformation_plan_type.argtypes = [C.c_void_p, C.c_int]
+    L.tfgpu_transformation_errors_output.argtypes = [C.c_void_p]
+    L.tfgpu_transformation_destroy.argtypes = [C.c_void_p]
+    cfg = {"debugMode": False, "errorsOutput": {"Type": "devnull", "Config": None}, "transformers": [
+        {"maskField": {"tables": {"includeTables": ["^hits$"]}, "columns": ["clientip"], "maskFunctionHash": {"userDefinedSalt": "s"}}, "transformerId": "t-1"},
+        {"transformerId": "t-2", "filterRows": {"tables": {}, "filter": "eventdate >= '2013-07-15'"}},
+        {"convert_to_string": {"columns": {"includeColumns": ["^regionid$"]}, "tables": {}}},
+        {"replacePrimaryKey": {"keys": ["watchid"], "tables": {}}},
+        {"sql": {"tables": {}, "query": "select *, toString(userid) as u from table where regionid >= 40"}}]}
+    h = C.c_void_p()
+    extra = lib.Transformer("rename_tables", {"renameTables": [{"originalName": {"namespace": "a", "name": "b"}, "newName": {"namespace": "c", "name": "d"}}]})
+    arr = (C.c_void_p * 1)(extra._h)
+    assert L.tfgpu_transformation_from_config(json.dumps(cfg).encode(), arr, 1, C.byref(h)) == 0, L.tfgpu_last_error()
+    n = L.tfgpu_transformation_size(h)
+    assert [L.tfgpu_transformation_plan_type(h, i).decode() for i in range(n)] == ["mask_field", "filter_rows", "convert_to_string", "replace_primary_key", "sql", "rename_tables"]
+    assert L.tfgpu_transformation_errors_output(h) == b"devnull"
+    L.tfgpu_transformation_destroy(h)
+    # no transformers at all
+    assert L.tfgpu_transformation_from_config(b'{"transformers": null}', None, 0, C.byref(h)) == 0 and L.tfgpu_transformation_size(h) == 0
+    L.tfgpu_transformation_destroy(h)
+    # a registered host-only type, an unknown type, a bad config: the construction fails as a whole, naming the transformer
+    for entry, code, word in [({"lambda": {}}, lib.ERR_UNSUPPORTED, "unable to init: lambda"), ({"noSuchThing": {}}, lib.ERR_UNKNOWN_TYPE, "unable to init: no_such_thing"),
+                              ({"filterRows": {"tables": {}, "filter": "a >"}}, lib.ERR_CONFIG, "unable to init: filter_rows")]:
+        rc = L.tfgpu_transformation_from_config(json.dumps({"transformers": [cfg["transformers"][0], entry]}).encode(), None, 0, C.byref(h))
+        assert rc == code and word in L.tfgpu_last_error().decode(), (entry, rc, L.tfgpu_last_error())

@@ -28,6 +28,9 @@ void plan_result_columns(const tfgpu_plan &p, std::vector<SchemaCol> &cols);    
 
 struct tfgpu_transformation {
   std::vector<const tfgpu_plan *> transformers;  // config order, then ExtraTransformers (middlewares/transformation.go:15-22)
+  std::vector<tfgpu_plan *> owned;                // plans built here from the transfer's config (tfgpu_transformation_from_config)
+  std::string errors_output;                      // Transformers.ErrorsOutput.Type: "sink" | "devnull" | ""
+  ~tfgpu_transformation() { for (auto *p : owned) tfgpu_plan_destroy(p); }
   std::mutex mu;                                  // u.mutex: plans are prepared under it (transformation.go:93-95)
   std::map<std::string, std::vector<int>> plan;   // (TableID, schema) -> indices of the Suitable transformers, in order
   tfgpu_transformation_stats st{};
@@ -177,6 +180,79 @@ Executor g_exec;
 }  // namespace
 namespace tf { void executor_shutdown() { g_exec.shutdown(); } }
 
+namespace {
+struct RawJson {  // just enough of a scanner to cut member names and raw value spans out of a JSON text
+  const char *p, *e;
+  void ws() { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+  [[noreturn]] void bad(const char *m) { throw tf::Error(TFGPU_ERR_CONFIG, std::string("transformation config: ") + m); }
+  std::string str() {
+    if (p >= e || *p != '"') bad("expected a string");
+    std::string o; p++;
+    while (p < e && *p != '"') { if (*p == '\\' && p + 1 < e) { o += p[1]; p += 2; } else o += *p++; }
+    if (p >= e) bad("unterminated string");
+    p++;
+    return o;
+  }
+  std::pair<const char *, const char *> value() {  // the span of one value
+    ws();
+    const char *a = p;
+    if (p >= e) bad("unexpected end");
+    if (*p == '"') { str(); return {a, p}; }
+    if (*p == '{' || *p == '[') {
+      int depth = 0;
+      while (p < e) {
+        if (*p == '"') { str(); continue; }
+        if (*p == '{' || *p == '[') depth++;
+        else if (*p == '}' || *p == ']') { depth--; if (!depth) { p++; return {a, p}; } }
+        p++;
+      }
+      bad("unbalanced brackets");
+    }
+    while (p < e && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\r' && *p != '\t') p++;
+    return {a, p};
+  }
+  // members of the object at p: f(name, value span)
+  template <class F> void object(F f) {
+    ws();
+    if (p >= e || *p != '{') bad("expected an object");
+    p++; ws();
+    if (p < e && *p == '}') { p++; return; }
+    for (;;) {
+      ws(); std::string k = str(); ws();
+      if (p >= e || *p != ':') bad("expected ':'");
+      p++;
+      auto v = value();
+      f(k, v.first, v.second);
+      ws();
+      if (p < e && *p == ',') { p++; continue; }
+      if (p < e && *p == '}') { p++; return; }
+      bad("expected ',' or '}'");
+    }
+  }
+};
+// util.Snakify (pkg/util/snaker.go:8-17): "(.)([A-Z][a-z]+)" -> "$1_$2", then "([a-z0-9])([A-Z])" -> "$1_$2", then ToLower
+std::string snakify(const std::string &in) {
+  auto up = [](char c) { return c >= 'A' && c <= 'Z'; };
+  auto lo = [](char c) { return c >= 'a' && c <= 'z'; };
+  std::string a;
+  for (size_t i = 0; i < in.size();) {
+    if (i + 2 < in.size() + 0 && i + 1 < in.size() && up(in[i + 1]) && i + 2 < in.size() && lo(in[i + 2])) {
+      size_t k = i + 2;
+      while (k < in.size() && lo(in[k])) k++;
+      a += in[i]; a += '_'; a.append(in, i + 1, k - (i + 1));
+      i = k;
+    } else a += in[i++];
+  }
+  std::string b;
+  for (size_t i = 0; i < a.size();) {
+    if (i + 1 < a.size() && (lo(a[i]) || (a[i] >= '0' && a[i] <= '9')) && up(a[i + 1])) { b += a[i]; b += '_'; b += a[i + 1]; i += 2; }
+    else b += a[i++];
+  }
+  for (auto &c : b) if (up(c)) c = (char)(c - 'A' + 'a');
+  return b;
+}
+}  // namespace
+
 extern "C" {
 
 int tfgpu_transformation_create(tfgpu_plan *const *transformers, int n, tfgpu_transformation **out) {
@@ -189,6 +265,53 @@ int tfgpu_transformation_create(tfgpu_plan *const *transformers, int n, tfgpu_tr
   TF_API_END
 }
 void tfgpu_transformation_destroy(tfgpu_transformation *t) { delete t; }
+
+// ---- the chain as middlewares.Transformation builds it (pkg/middlewares/transformation.go:12-36) from the transfer's
+//      transformer.Transformers value (pkg/transformer/abstract.go:21-66): {"debugMode":…, "transformers":[{"<type>":{config},
+//      "transformerId":"…"}, …], "errorsOutput":{"Type":"sink"|"devnull", …}} -------------------------------------------------
+
+int tfgpu_transformation_from_config(const char *transformers_json, tfgpu_plan *const *extra, int n_extra, tfgpu_transformation **out) {
+  TF_API_BEGIN
+  if (!transformers_json || !out || (n_extra > 0 && !extra)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_transformation_from_config: null argument");
+  auto t = std::make_unique<tfgpu_transformation>();
+  RawJson top{transformers_json, transformers_json + std::strlen(transformers_json)};
+  top.object([&](const std::string &k, const char *a, const char *b) {
+    if (k == "transformers") {
+      RawJson arr{a, b};
+      arr.ws();
+      if (arr.p < arr.e && *arr.p == 'n') return;  // null: no transformers
+      if (arr.p >= arr.e || *arr.p != '[') arr.bad("\"transformers\" is not a list");
+      arr.p++; arr.ws();
+      if (arr.p < arr.e && *arr.p == ']') return;
+      for (;;) {
+        // Transformer.Type() / Config(): the one member that is not "transformerId" (abstract.go:23-49)
+        std::string type, cfg;
+        arr.object([&](const std::string &name, const char *va, const char *vb) { if (name != "transformerId" && type.empty()) { type = snakify(name); cfg.assign(va, vb); } });
+        if (type.empty()) arr.bad("a transformer entry without a type");
+        tfgpu_plan *plan = nullptr;
+        const int rc = tfgpu_plan_create(type.c_str(), cfg.c_str(), &plan);
+        if (rc) throw tf::Error(rc, "unable to init: " + type + ": " + tfgpu_last_error());  // middlewares/transformation.go:18-20
+        t->owned.push_back(plan);
+        t->transformers.push_back(plan);
+        arr.ws();
+        if (arr.p < arr.e && *arr.p == ',') { arr.p++; continue; }
+        if (arr.p < arr.e && *arr.p == ']') break;
+        arr.bad("expected ',' or ']' in \"transformers\"");
+      }
+    } else if (k == "errorsOutput") {
+      RawJson eo{a, b};
+      eo.ws();
+      if (eo.p < eo.e && *eo.p == '{') eo.object([&](const std::string &name, const char *va, const char *vb) { if (name == "Type" || name == "type") { RawJson s{va, vb}; s.ws(); if (s.p < s.e && *s.p == '"') t->errors_output = s.str(); } });
+    }
+  });
+  for (int i = 0; i < n_extra; i++) { if (!extra[i]) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_transformation_from_config: null extra transformer"); t->transformers.push_back(extra[i]); }  // Transformation.ExtraTransformers
+  *out = t.release();
+  return TFGPU_OK;
+  TF_API_END
+}
+int tfgpu_transformation_size(const tfgpu_transformation *t) { return t ? (int)t->transformers.size() : 0; }
+const char *tfgpu_transformation_plan_type(const tfgpu_transformation *t, int i) { return (t && i >= 0 && i < (int)t->transformers.size()) ? tfgpu_plan_type(t->transformers[(size_t)i]) : ""; }
+const char *tfgpu_transformation_errors_output(const tfgpu_transformation *t) { return t ? t->errors_output.c_str() : ""; }
 
 int tfgpu_transformation_table_plan(tfgpu_transformation *t, const char *ns, const char *table, const tfgpu_schema *schema, int32_t *idx, int32_t cap, int32_t *n) {
   TF_API_BEGIN
