@@ -282,10 +282,12 @@ template <class S> __device__ __forceinline__ bool emit_cell(S &s, const SerPara
 }
 
 // (1) cell lengths; item = column * nrows + row
+// (grid: x = 256-row blocks, y = column — the column is a scalar, so the descriptor loads are scalar loads and the switches on
+//  representation / DataType are scalar branches: with item = column * nrows + row every lane loaded its own copy of the descriptor)
 __global__ void __launch_bounds__(256) ser_cell_len(SerParams p) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)p.ncols * p.nrows) return;
-  const int32_t ci = (int32_t)(it / p.nrows); const int64_t r = it - (int64_t)ci * p.nrows;
+  const int32_t ci = (int32_t)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  const int64_t it = (int64_t)ci * p.nrows + r;
   if (p.q.qformat && p.cols[ci].kind == QC_CONST) { p.cell[it] = q_applies(p, p.cols[ci].apply, r) ? p.cols[ci].pre_len : 0u; return; }
   CountSink s;
   if (p.ablate == 3 && (p.cols[ci].c.repr == TFGPU_R_STRING || p.cols[ci].c.repr == TFGPU_R_BYTES)) { p.cell[it] = 8; return; }
@@ -329,9 +331,9 @@ __global__ void __launch_bounds__(256) ser_row_layout(SerParams p) {
 }
 // (4) cells at their final position
 __global__ void __launch_bounds__(256) ser_cell_write(SerParams p) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)p.ncols * p.nrows) return;
-  const int32_t ci = (int32_t)(it / p.nrows); const int64_t r = it - (int64_t)ci * p.nrows;
+  const int32_t ci = (int32_t)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  const int64_t it = (int64_t)ci * p.nrows + r;
   const SCol &sc = p.cols[ci];
   if (p.q.qformat && ((sc.kind == QC_CONST && sc.pre_len > QCONST_INLINE) || !q_applies(p, sc.apply, r))) return;
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW && !is_valid(sc.c, r)) return;
@@ -858,7 +860,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     if (scatter) {
       cell = dalloc((size_t)std::max(ncols, 1) * (size_t)n * 4);
       p.cell = ptr<uint32_t>(cell);
-      { KernelTimer t("ser_cell_len"); if (ncell) ser_cell_len<<<blocks(ncell), 256, 0, st>>>(p); }
+      { KernelTimer t("ser_cell_len"); if (ncell) ser_cell_len<<<dim3(blocks(n), (unsigned)ncols), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
     } else {
       // the cuts: consecutive columns until the ESTIMATED text of a row's chunk passes the target (64 rows of a chunk share a 9 KiB
@@ -927,7 +929,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     res->mem = dalloc(res->size + 64);
     p.out = ptr<uint8_t>(res->mem);
     if (scatter) {
-      { KernelTimer t("ser_cell_write"); if (ncell) ser_cell_write<<<blocks(ncell), 256, 0, st>>>(p); }
+      { KernelTimer t("ser_cell_write"); if (ncell) ser_cell_write<<<dim3(blocks(n), (unsigned)ncols), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_frame"); ser_row_frame<<<blocks(n), 256, 0, st>>>(p); }
     } else {
       const unsigned grid = (unsigned)((((n + 63) / 64) * cp.nchunks + 3) / 4);
@@ -1149,8 +1151,7 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
     p.total64 = reinterpret_cast<unsigned long long *>(tot64->p);
     q.msg_flags = ptr<uint8_t>(mflags);
     p.q = q;
-    const int64_t ncells = (int64_t)ncell * n;
-    { KernelTimer t("ser_cell_len"); ser_cell_len<<<blocks(ncells), 256, 0, st>>>(p); }
+    { KernelTimer t("ser_cell_len"); if (ncell && n) ser_cell_len<<<dim3(blocks(n), (unsigned)ncell), 256, 0, st>>>(p); }
     { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
 
     // ---- the cut plan (host: the batchers' sequential greedy loop over the element lengths) ----
@@ -1177,7 +1178,7 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
     res->size = total;
     res->mem = dalloc(res->size + 64);
     p.out = ptr<uint8_t>(res->mem);
-    { KernelTimer t("ser_cell_write"); ser_cell_write<<<blocks(ncells), 256, 0, st>>>(p); }
+    { KernelTimer t("ser_cell_write"); if (ncell && n) ser_cell_write<<<dim3(blocks(n), (unsigned)ncell), 256, 0, st>>>(p); }
     for (int ci = 0; ci < ncell; ci++) if (sc[(size_t)ci].kind == QC_CONST && sc[(size_t)ci].pre_len > QCONST_INLINE) {
       const uint32_t chunks = (sc[(size_t)ci].pre_len + 4095u) / 4096u;
       KernelTimer t("ser_fill_const");
