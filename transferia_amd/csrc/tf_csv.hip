@@ -2502,9 +2502,8 @@ __device__ __forceinline__ bool strict_load_int(const StrictCol &c, int64_t r, i
 }
 // item = column * nrows + row; first_bad[column] = min over failing rows of (row << 8 | tfgpu_rowerr)
 __global__ void __launch_bounds__(256) strictify_cells(CsvOpts o, const StrictCol *cols, int32_t ncols, int64_t nrows, unsigned long long *first_bad) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)ncols * nrows) return;
-  const int32_t j = (int32_t)(it / nrows); const int64_t r = it - (int64_t)j * nrows;
+  const int32_t j = (int32_t)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the column is the grid's y: a scalar)
+  if (r >= nrows || j >= ncols) return;
   const StrictCol &c = cols[j];
   if (c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) { if (c.mode != SM_TEXT_JSONNUM_OUT) store_default(c.out, r); return; }  // nil stays nil
   int rc = 0;
@@ -2636,8 +2635,7 @@ extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schem
     TF_HIP(hipMemsetAsync(bad->p, 0xFF, sc.size() * 8, st));
     {
       KernelTimer t("strictify_cells");
-      const int64_t items = (int64_t)sc.size() * n;
-      strictify_cells<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(o, reinterpret_cast<const StrictCol *>(bsc->p), (int32_t)sc.size(), n, reinterpret_cast<unsigned long long *>(bad->p));
+      strictify_cells<<<dim3((unsigned)((n + 255) / 256), (unsigned)sc.size()), 256, 0, st>>>(o, reinterpret_cast<const StrictCol *>(bsc->p), (int32_t)sc.size(), n, reinterpret_cast<unsigned long long *>(bad->p));
     }
     std::vector<uint64_t> hb(sc.size());
     d2h(hb.data(), bad->p, hb.size() * 8);

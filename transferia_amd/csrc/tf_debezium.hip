@@ -602,9 +602,8 @@ struct DbzRow { int64_t msg; uint64_t lsn, commit_time; uint32_t id; uint8_t nam
 static_assert(sizeof(DbzRow) == sizeof(tfgpu_dbz_row), "row meta layout");
 
 __global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint8_t *kinds, uint8_t *old_present8, DbzRow *rows) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)p.nfields * p.nrows) return;
-  const int j = (int)(it / p.nrows); const int64_t r = it - (int64_t)j * p.nrows;
+  const int j = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the field is the grid's y: a scalar)
+  if (r >= p.nrows) return;
   const uint32_t m = p.row_msg[r];
   const OutCol &c = cols[j];
   const FRecv &f = p.fields[j];
@@ -647,9 +646,8 @@ __global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *c
   }
 }
 __global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)ntext * p.nrows) return;
-  const int t = (int)(it / p.nrows); const int64_t r = it - (int64_t)t * p.nrows;
+  const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
   const int j = text_cols[t];
   const OutCol &c = cols[j];
   const FRecv &f = p.fields[j];
@@ -921,7 +919,7 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     dbz::dbz_row_msgs<<<dbz::nblk(nmsg, 256), 256, 0, st>>>(p);
     if (nf) {
       KernelTimer t("dbz_cell_values");
-      dbz::dbz_cell_values<<<dbz::nblk((int64_t)nf * nrows, 256), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint8_t>(db->kind), ptr<uint8_t>(old8),
+      dbz::dbz_cell_values<<<dim3(dbz::nblk(nrows, 256), (unsigned)nf), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint8_t>(db->kind), ptr<uint8_t>(old8),
                                                                                 reinterpret_cast<dbz::DbzRow *>(drows->p));
     }
   }
@@ -939,7 +937,7 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     }
     boc = upload_small(oc.data(), oc.size() * sizeof(dbz::OutCol));
     Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
-    if (nrows) { KernelTimer t("dbz_cell_text"); dbz::dbz_cell_text<<<dbz::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc), ntext); }
+    if (nrows) { KernelTimer t("dbz_cell_text"); dbz::dbz_cell_text<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc), ntext); }
   }
   // bitmaps: ColumnValues validity per column; OldKeys = the key columns' buffers under their own validity
   const unsigned gb = dbz::nblk((nrows + 7) / 8, 256);

@@ -536,10 +536,10 @@ struct OutCol {
 // CANON == false: every cell but the `any` values that need the sorting emitter; CANON == true: only those (a second launch
 // when the schema has `any` properties) — the kernel every cell runs through does not carry the emitter's frame stack.
 template <bool CANON>
+// (grid: x = 256-row blocks, y = property: the property is a scalar — its descriptor comes by scalar loads, the switch on its JSON type is a scalar branch)
 __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)p.nprops * p.nrows) return;
-  const int j = (int)(it / p.nrows); const int64_t r = it - (int64_t)j * p.nrows;
+  const int j = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
   const uint32_t f = p.row_frame[r];
   const OutCol &c = cols[j];
   const int64_t i = (int64_t)j * p.nframes + f;
@@ -570,9 +570,8 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
 }
 template <bool CANON>
 __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)ntext * p.nrows) return;
-  const int t = (int)(it / p.nrows); const int64_t r = it - (int64_t)t * p.nrows;
+  const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
   const int j = text_cols[t];
   const OutCol &c = cols[j];
   const uint32_t f = p.row_frame[r];
@@ -791,8 +790,8 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     sr::sr_row_frames<<<sr::nblk(nf, 256), 256, 0, st>>>(p);
     if (np) {
       KernelTimer t("sr_cell_values");
-      sr::sr_cell_values<false><<<sr::nblk((int64_t)np * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
-      if (has_any) sr::sr_cell_values<true><<<sr::nblk((int64_t)np * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
+      sr::sr_cell_values<false><<<dim3(sr::nblk(nrows, 256), (unsigned)np), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
+      if (has_any) sr::sr_cell_values<true><<<dim3(sr::nblk(nrows, 256), (unsigned)np), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
     }
     if (np) sr::sr_pack_validity<<<sr::nblk((int64_t)np * ((nrows + 7) / 8), 256), 256, 0, st>>>(ptr<sr::OutCol>(boc), np, nrows);
   }
@@ -812,8 +811,8 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
     if (nrows) {
       KernelTimer t("sr_cell_text");
-      sr::sr_cell_text<false><<<sr::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
-      if (has_any) sr::sr_cell_text<true><<<sr::nblk((int64_t)ntext * nrows, 256), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
+      sr::sr_cell_text<false><<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
+      if (has_any) sr::sr_cell_text<true><<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
     }
   }
   // ---- frames the reference turns into `_unparsed` items / rows for the stock path ----

@@ -1056,9 +1056,8 @@ __global__ void __launch_bounds__(256) sql_const_text_kernel(uint32_t *off, uint
 struct SqlNilCol { const uint8_t *src; uint8_t *dst; const uint8_t *validity; int32_t width; };
 // dst[r] = the value, or the type's zero where the row is nil; item = column * n + row
 __global__ void __launch_bounds__(256) sql_default_nils_kernel(const SqlNilCol *cols, int32_t ncols, int64_t n) {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= (int64_t)ncols * n) return;
-  const int32_t j = (int32_t)(it / n); const int64_t r = it - (int64_t)j * n;
+  const int32_t j = (int32_t)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the column is the grid's y: a scalar)
+  if (r >= n || j >= ncols) return;
   const SqlNilCol c = cols[j];
   const bool ok = (c.validity[r >> 3] >> (r & 7)) & 1;
   switch (c.width) {
@@ -1138,7 +1137,7 @@ static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_
     if (!nil.empty() && n0) {
       Buf bn = upload_small(nil.data(), nil.size() * sizeof(SqlNilCol));
       KernelTimer t("sql_default_nils");
-      sql_default_nils_kernel<<<grid_for((int64_t)nil.size() * n0, 256), 256, 0, st>>>(reinterpret_cast<const SqlNilCol *>(bn->p), (int32_t)nil.size(), n0);
+      sql_default_nils_kernel<<<dim3(grid_for(n0, 256), (unsigned)nil.size()), 256, 0, st>>>(reinterpret_cast<const SqlNilCol *>(bn->p), (int32_t)nil.size(), n0);
     }
   }
   // WHERE on every row event
