@@ -670,12 +670,15 @@ __global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *col
   else render_text(s, rd, f, vtr, vs, vl);
   s.flush();
 }
-__global__ void __launch_bounds__(256) dbz_pack_bits(const uint8_t *bytes, int64_t n, uint8_t *bits) {
+struct PackJob { const uint8_t *bytes; uint8_t *bits; };
+// every byte-per-row flag array of a batch → its bitmap, in one launch (grid y = the array)
+__global__ void __launch_bounds__(256) dbz_pack_bits_all(const PackJob *jobs, int64_t n) {
+  const PackJob j = jobs[blockIdx.y];
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b * 8 >= n) return;
   uint32_t v = 0;
-  for (int k = 0; k < 8 && b * 8 + k < n; k++) v |= (uint32_t)(bytes[b * 8 + k] & 1u) << k;
-  bits[b] = (uint8_t)v;
+  for (int k = 0; k < 8 && b * 8 + k < n; k++) v |= (uint32_t)(j.bytes[b * 8 + k] & 1u) << k;
+  j.bits[b] = (uint8_t)v;
 }
 
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
@@ -941,17 +944,22 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
   }
   // bitmaps: ColumnValues validity per column; OldKeys = the key columns' buffers under their own validity
   const unsigned gb = dbz::nblk((nrows + 7) / 8, 256);
-  for (int j = 0; j < nf && nrows; j++) dbz::dbz_pack_bits<<<gb, 256, 0, st>>>(oc[(size_t)j].valid8, nrows, oc[(size_t)j].validity);
+  std::vector<dbz::PackJob> jobs;  // one launch for all of them (a 61-column table made ~70 launches here)
+  for (int j = 0; j < nf; j++) jobs.push_back(dbz::PackJob{oc[(size_t)j].valid8, oc[(size_t)j].validity});
   for (int j = 0; j < nf; j++) {
     if (o->fields[j].optional) continue;
     DColumn k = db->cols[(size_t)j];  // shares values / offsets / data
     k.validity = dalloc_zero((size_t)((nra + 7) / 8) + 8);
-    if (nrows) dbz::dbz_pack_bits<<<gb, 256, 0, st>>>(oc[(size_t)j].old8, nrows, ptr<uint8_t>(k.validity));
+    jobs.push_back(dbz::PackJob{oc[(size_t)j].old8, ptr<uint8_t>(k.validity)});
     db->old_keys.push_back(std::move(k));
   }
   if (!db->old_keys.empty()) {
     db->old_present = dalloc_zero((size_t)((nra + 7) / 8) + 8);
-    if (nrows) dbz::dbz_pack_bits<<<gb, 256, 0, st>>>(ptr<uint8_t>(old8), nrows, ptr<uint8_t>(db->old_present));
+    jobs.push_back(dbz::PackJob{ptr<uint8_t>(old8), ptr<uint8_t>(db->old_present)});
+  }
+  if (nrows && !jobs.empty()) {
+    Buf bj = upload_small(jobs.data(), jobs.size() * sizeof(dbz::PackJob));
+    dbz::dbz_pack_bits_all<<<dim3(gb, (unsigned)jobs.size()), 256, 0, st>>>(reinterpret_cast<const dbz::PackJob *>(bj->p), nrows);
   }
   if (rows && nrows) d2h(rows, drows->p, (size_t)nrows * sizeof(tfgpu_dbz_row));
   int64_t ne = 0;
