@@ -13,6 +13,7 @@
 #include "tf_devcol.hpp"
 #include "tf_segcopy.hpp"
 #include "tf_textview.hpp"
+#include "tf_emit.hpp"
 
 namespace tf {
 
@@ -105,15 +106,57 @@ struct MaskParams {
   uint8_t *out;  // nrows * 64 hex bytes
 };
 
+// The text of an integer (or "<nil>") is at most 21 bytes: built in three registers as a little-endian byte string — the emitters of
+// tf_emit.hpp hand over eight digits per word — it becomes the one message block of the inner hash with six byte swaps, instead of a
+// scratch byte buffer read back byte by byte into a dynamically indexed w[] (that detour was a fifth of the kernel's instructions).
+struct Text24 {
+  uint64_t t0 = 0, t1 = 0, t2 = 0; uint32_t n = 0;
+  __device__ __forceinline__ void put_word(uint64_t w, uint32_t k) {  // the low k (1..8) bytes of w, the rest zero
+    const uint32_t at = n & 7u, sh = at * 8, seg = n >> 3;
+    const uint64_t lo = w << sh, hi = (w >> 1) >> (63 - sh);            // (w >> 1) >> 63 == 0 when at == 0
+    if (seg == 0) { t0 |= lo; t1 |= hi; } else if (seg == 1) { t1 |= lo; t2 |= hi; } else t2 |= lo;
+    n += k;
+  }
+  __device__ __forceinline__ void put(uint32_t c) { put_word(c & 0xFFu, 1); }
+};
+__device__ __forceinline__ bool mask_small_int(const DCol &c, int64_t r, Text24 &s) {  // false: not an integer column
+  if (!is_valid(c, r)) { s.put_word(0x3E6C696E3Cull /* "<nil>" */, 5); return true; }
+  switch (c.repr) {
+    case TFGPU_R_INT8: emit_i64(s, ((const int8_t *)c.values)[r]); return true;
+    case TFGPU_R_INT16: emit_i64(s, ((const int16_t *)c.values)[r]); return true;
+    case TFGPU_R_INT32: emit_i64(s, ((const int32_t *)c.values)[r]); return true;
+    case TFGPU_R_INT64: emit_i64(s, ((const int64_t *)c.values)[r]); return true;
+    case TFGPU_R_UINT8: emit_u64(s, ((const uint8_t *)c.values)[r]); return true;
+    case TFGPU_R_UINT16: emit_u64(s, ((const uint16_t *)c.values)[r]); return true;
+    case TFGPU_R_UINT32: emit_u64(s, ((const uint32_t *)c.values)[r]); return true;
+    case TFGPU_R_UINT64: emit_u64(s, ((const uint64_t *)c.values)[r]); return true;
+    default: return false;
+  }
+}
+
 __global__ void __launch_bounds__(256) mask_hmac_kernel(MaskParams p) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.nrows) return;
-  uint8_t buf[64];
-  const uint8_t *ext;
-  int len = serialize_small(p.col, r, buf, &ext);
   uint32_t st[8], w[16];
 #pragma unroll
   for (int i = 0; i < 8; i++) st[i] = p.ipad[i];
+  const bool small_int = p.col.repr >= TFGPU_R_INT8 && p.col.repr <= TFGPU_R_UINT64;  // (a property of the column: a scalar branch)
+  if (small_int) {
+    Text24 s;
+    mask_small_int(p.col, r, s);
+    const uint32_t len = s.n;
+    s.put_word(0x80, 1);  // the padding byte right behind the text; the block's tail is zeros and the bit length (len <= 21 < 56)
+    w[0] = __builtin_bswap32((uint32_t)s.t0); w[1] = __builtin_bswap32((uint32_t)(s.t0 >> 32));
+    w[2] = __builtin_bswap32((uint32_t)s.t1); w[3] = __builtin_bswap32((uint32_t)(s.t1 >> 32));
+    w[4] = __builtin_bswap32((uint32_t)s.t2); w[5] = __builtin_bswap32((uint32_t)(s.t2 >> 32));
+#pragma unroll
+    for (int i = 6; i < 15; i++) w[i] = 0;
+    w[15] = (64 + len) * 8;
+    sha256_compress(st, w);
+  } else {
+  uint8_t buf[64];
+  const uint8_t *ext;
+  int len = serialize_small(p.col, r, buf, &ext);
   // inner hash: the ipad block is already absorbed; stream the message
   int off = 0;
   uint64_t bits = (uint64_t)(64 + len) * 8;
@@ -130,6 +173,7 @@ __global__ void __launch_bounds__(256) mask_hmac_kernel(MaskParams p) {
     if (take < 64 && !pad_done) { w[take >> 2] |= 0x80u << (24 - 8 * (take & 3)); pad_done = true; if (take < 56) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; len_done = true; } }
     else if (pad_done) { w[14] = (uint32_t)(bits >> 32); w[15] = (uint32_t)bits; len_done = true; }
     sha256_compress(st, w);
+  }
   }
   // outer hash: opad block absorbed; message = 32-byte inner digest
 #pragma unroll
