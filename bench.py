@@ -356,7 +356,9 @@ class CsvWorkload(Base):
         ach = MASK_INT_OPS_PER_VALUE * self.state["parsed_rows"] / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
         out = {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s",
                "frac": round(ach / INT32_PEAK_TOPS, 4), "int_ops_per_value": MASK_INT_OPS_PER_VALUE,
-               "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low"}
+               "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low.  int_ops_per_value tallies two-input 32-bit "
+                       "operations; gfx950's v_add3 / v_xor3 / v_bfi / v_alignbit carry two or three of them per instruction, so `frac` can approach 1 while the VALU "
+                       "issues fewer instructions than that — `issue_frac` (measured instructions, when profiles/pmc_traffic.json is of this build) is the issue-slot view"}
         # the same fraction from the kernel's MEASURED VALU instruction count per value (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of this
         # very source, tools/gpu_round3.sh) instead of the algorithmic tally: instructions issued, against one per lane per cycle
         try:
