@@ -1,0 +1,1162 @@
+"""oracle/dbz_emitter.py — TEST INFRASTRUCTURE ONLY (see oracle/ora.h): a CPU restatement of the reference's Debezium EMITTER for
+Postgres-typed rows, the `DebeziumSerializer` of the queue sinks (pkg/serializer/queue/debezium_serializer.go:26-79):
+
+  Emitter.emitKV / emitOneDebeziumMessage            pkg/debezium/emitter_value_converter.go:574-690
+  valPayload / buildSource / makeKey / buildKV       emitter_value_converter.go:232-300, 328-382, 456-527
+  ToKafkaSchemaKey / ToKafkaSchemaVal                emitter_value_converter.go:384-448
+  getFieldDescr / AddFieldDescr                      pkg/debezium/fields_descr.go:19-96
+  buildSourceSchemaDescr                             pkg/debezium/fields_descr_source.go:7-107
+  kindToOp                                           pkg/debezium/kind.go:8-32
+  AddPg / GetKafkaTypeDescrByPgType                  pkg/debezium/pg/emitter.go:20-260, 262-629
+  addCommon / mapYtTypeToKafkaType                   pkg/debezium/emitter_common.go:68-226
+  typeutil helpers (bits, decimals, times, ranges)   pkg/debezium/typeutil/helpers.go, field_descr.go
+  PackerIncludeSchema.Pack                           pkg/debezium/packer/packer_include_schema.go:14-40
+  EnrichedWithDefaults                               pkg/debezium/parameters/parameters.go:140-215
+  abstract.Restore (what UnmarshalChangeItem applies) pkg/abstract/restore.go:20-290
+
+Everything the reference builds is a Go map marshalled by util.JSONMarshalUnescape (pkg/util/encode_json.go:10-19): keys in byte
+order, no HTML escaping.  Only the product's test-suite, smoke() and bench.py's cpu_baseline leg use this file; the product never does.
+
+Not restated (third-party parsers the reference calls; NotRestated is raised by name): pg:interval (pgtype.Interval.DecodeText),
+hstore given as text (HstoreToJSON), string inputs of `timestamp without time zone` (pgtype.Timestamp.Set(string)), pg arrays,
+mysql: / ydb: original types, the schema-registry packers (Confluent JSON / skip-schema).  PINNED against the reference's fixtures
+pkg/debezium/pg/tests/testdata/emitter_crud_test__*.txt (copied to tests/golden/debezium_emitter/) the way the reference's own test
+compares them (pkg/debezium/testutil/test.go:24-152: the fixtures come from a vanilla Debezium, so both sides are normalised).
+"""
+import base64
+import json
+import math
+import re
+from decimal import Decimal, ROUND_HALF_UP
+
+from oracle import oracle as _ora
+
+
+class EmitError(Exception):
+    pass
+
+
+class UnknownTypeError(EmitError):
+    pass
+
+
+class NotRestated(Exception):
+    pass
+
+
+# ---- Go values ----------------------------------------------------------------------------------------------------------------------
+class JN(str):
+    """json.Number"""
+
+
+class F32(float):
+    pass
+
+
+class F64(float):
+    pass
+
+
+class Raw(bytes):
+    """json.RawMessage"""
+
+
+class GoBytes(bytes):
+    """[]byte (marshals as base64); plain `bytes` is a Go string"""
+
+
+def _b(s):
+    return s.encode("utf-8") if isinstance(s, str) else bytes(s)
+
+
+def go_json_string(s: bytes) -> bytes:
+    """encoding/json appendString, escapeHTML = false"""
+    out = bytearray(b'"')
+    i, n = 0, len(s)
+    while i < n:
+        c = s[i]
+        if c < 0x80:
+            if c >= 0x20 and c not in (0x22, 0x5C):
+                out.append(c)
+            elif c == 0x22:
+                out += b'\\"'
+            elif c == 0x5C:
+                out += b"\\\\"
+            elif c == 8:
+                out += b"\\b"
+            elif c == 12:
+                out += b"\\f"
+            elif c == 10:
+                out += b"\\n"
+            elif c == 13:
+                out += b"\\r"
+            elif c == 9:
+                out += b"\\t"
+            else:
+                out += b"\\u00%02x" % c
+            i += 1
+            continue
+        need, lo, hi = 0, 0x80, 0xBF
+        if 0xC2 <= c <= 0xDF:
+            need = 1
+        elif 0xE0 <= c <= 0xEF:
+            need = 2
+            lo = 0xA0 if c == 0xE0 else lo
+            hi = 0x9F if c == 0xED else hi
+        elif 0xF0 <= c <= 0xF4:
+            need = 3
+            lo = 0x90 if c == 0xF0 else lo
+            hi = 0x8F if c == 0xF4 else hi
+        ok = need > 0 and i + need < n
+        if ok:
+            for k in range(1, need + 1):
+                d = s[i + k]
+                if not ((lo if k == 1 else 0x80) <= d <= (hi if k == 1 else 0xBF)):
+                    ok = False
+                    break
+        if not ok:
+            out += b"\\ufffd"
+            i += 1
+            continue
+        if s[i:i + 3] in (b"\xe2\x80\xa8", b"\xe2\x80\xa9"):
+            out += b"\\u2028" if s[i + 2] == 0xA8 else b"\\u2029"
+        else:
+            out += s[i:i + need + 1]
+        i += need + 1
+    out.append(0x22)
+    return bytes(out)
+
+
+_NUM = re.compile(rb"^-?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][+-]?[0-9]+)?$")
+
+
+def gomarshal(v) -> bytes:
+    """util.JSONMarshalUnescape"""
+    if v is None:
+        return b"null"
+    if v is True:
+        return b"true"
+    if v is False:
+        return b"false"
+    if isinstance(v, Raw):
+        return bytes(v)
+    if isinstance(v, JN):
+        t = _b(v)
+        if not _NUM.match(t):
+            raise EmitError("json: invalid number literal %r" % v)
+        return t
+    if isinstance(v, (F32, F64)):
+        if math.isnan(v) or math.isinf(v):
+            raise EmitError("json: unsupported value: %r" % float(v))
+        return _ora.json_float(float(v), 32 if isinstance(v, F32) else 64).encode()
+    if isinstance(v, GoBytes):
+        return b'"' + base64.b64encode(bytes(v)) + b'"'
+    if isinstance(v, (bytes, str)):
+        return go_json_string(_b(v))
+    if isinstance(v, int):
+        return b"%d" % v
+    if isinstance(v, float):
+        raise TypeError("bare float: wrap it in F32 / F64")
+    if isinstance(v, dict):
+        items = sorted(((_b(k), x) for k, x in v.items()), key=lambda kv: kv[0])
+        return b"{" + b",".join(go_json_string(k) + b":" + gomarshal(x) for k, x in items) + b"}"
+    if isinstance(v, (list, tuple)):
+        return b"[" + b",".join(gomarshal(x) for x in v) + b"]"
+    raise TypeError(type(v))
+
+
+def decode_any(text: bytes):
+    """jsonx.NewDefaultDecoder (UseNumber): numbers stay json.Number, strings become Go strings (bytes)"""
+    def conv(x):
+        if isinstance(x, dict):
+            return {_b(k): conv(y) for k, y in x.items()}
+        if isinstance(x, list):
+            return [conv(y) for y in x]
+        if isinstance(x, str) and not isinstance(x, JN):
+            return _b(x)
+        return x
+    return conv(json.loads(text.decode("utf-8", "surrogateescape"), parse_float=JN, parse_int=JN, parse_constant=JN))
+
+
+def trunc_div(a: int, b: int) -> int:
+    """Go's integer division"""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b > 0) else -q
+
+
+# ---- parameters (parameters.go:140-215) -----------------------------------------------------------------------------------------------
+DEFAULTS = {
+    "database.dbname": "", "topic.prefix": "", "dt.unknown.types.policy": "fail", "dt.add.original.type.info": "false", "dt.source.type": "",
+    "dt.mysql.timezone": "UTC", "dt.batching.max.size": "0", "dt.write.into.one.topic": "false", "time.precision.mode": "adaptive",
+    "decimal.handling.mode": "precise", "hstore.handling.mode": "map", "interval.handling.mode": "numeric", "tombstones.on.delete": "true",
+    "binary.handling.mode": "bytes", "money.fraction.digits": "2", "unavailable.value.placeholder": "__debezium_unavailable_value",
+    "key.converter": "org.apache.kafka.connect.json.JsonConverter", "value.converter": "org.apache.kafka.connect.json.JsonConverter",
+    "key.converter.schemas.enable": "true", "value.converter.schemas.enable": "true",
+}
+
+
+def enriched(params):
+    out = dict(DEFAULTS)
+    out.update(params or {})
+    return out
+
+
+# ---- ColSchema / items ----------------------------------------------------------------------------------------------------------------
+class Col:
+    def __init__(self, name, dtype, key=False, original_type="", properties=None):
+        self.name, self.dtype, self.key, self.original_type, self.properties = name, dtype, bool(key), original_type or "", properties or {}
+
+
+class Item:
+    """one ChangeItem: values are (gotype, value) pairs as transferia_amd.abi spells them — "nil", "bool", "int8".."uint64", "float32",
+    "float64", "string" / "bytes" (bytes), "jsonnum" (text), "json" (the marshalled `any`), "time" ((unix seconds, nanoseconds[, zone
+    offset in seconds]))"""
+
+    def __init__(self, kind, schema, table, cols, names, values, old_names=(), old_values=(), id=0, lsn=0, commit_time=0, tx_id=""):
+        self.kind, self.schema, self.table, self.cols = kind, schema, table, list(cols)
+        self.names, self.values, self.old_names, self.old_values = list(names), list(values), list(old_names), list(old_values)
+        self.id, self.lsn, self.commit_time, self.tx_id = id, lsn, commit_time, tx_id
+
+
+INTS = ("int8", "int16", "int32", "int64")
+UINTS = ("uint8", "uint16", "uint32", "uint64")
+
+
+def _text(v):
+    g, x = v
+    return _b(x)
+
+
+def _jn_int64(x) -> int:
+    t = _b(x)
+    if not re.match(rb"^[+-]?[0-9]+$", t) or not (-(1 << 63) <= int(t) < (1 << 63)):
+        raise EmitError("strconv.ParseInt: parsing %r" % t)
+    return int(t)
+
+
+def _jn_float64(x) -> float:
+    rc = _go_parse_float(_b(x))
+    if rc is None:
+        raise EmitError("strconv.ParseFloat: parsing %r" % x)
+    return rc
+
+
+def _go_parse_float(t: bytes):
+    if not re.match(rb"^[+-]?((\d[\d_]*\.?[\d_]*|\.\d[\d_]*)([eE][+-]?\d+)?|inf|infinity|nan)$", t, re.I) or b"_" in t:
+        if not re.match(rb"^[+-]?0[xX]", t):
+            return None
+        try:
+            return float.fromhex(t.decode())
+        except ValueError:
+            return None
+    try:
+        f = float(t)
+    except ValueError:
+        return None
+    if math.isinf(f) and not re.match(rb"^[+-]?inf", t, re.I):
+        return None   # ErrRange
+    return f
+
+
+# ---- typeutil -------------------------------------------------------------------------------------------------------------------------
+def bits_to_debezium(bits: bytes) -> bytes:
+    """ChangeItemsBitsToDebeziumHonest (helpers.go:48-78)"""
+    size = (len(bits) + 7) // 8
+    buf = bytearray(size)
+    found = False
+    for i in range(len(bits) - 1, -1, -1):
+        if bits[i] == 0x31:
+            found = True
+            buf[i // 8] |= 1 << (7 - (i % 8))
+    if not found:
+        return b""
+    return base64.b64encode(bytes(reversed(buf)))
+
+
+def get_time_precision(t: str) -> int:
+    if t == "timestamp without time zone":
+        return 6
+    prec = -1
+    for rx in (r"^time\((\d)\) without time zone", r"^timestamp\((\d)\) without time zone", r"^mysql:timestamp\((\d)\)", r"^mysql:datetime\((\d)\)"):
+        m = re.match(rx, t)
+        if m:
+            prec = int(m.group(1))
+    return prec
+
+
+def get_time_divider(t: str) -> int:
+    """GetTimeDivider (helpers.go:106-123)"""
+    if t.startswith("time without time zone") or t.startswith("timestamp without time zone"):
+        return 1
+    p = get_time_precision(t)
+    if p == -1:
+        raise EmitError("unable to match any pattern to string: %s" % t)
+    return 1000 if 1 <= p <= 3 else 1
+
+
+def without_provider(t: str) -> str:
+    i = t.find(":")
+    return "" if i < 0 else t[i + 1:]
+
+
+def decimal_precision_scale(t: str):
+    """DecimalGetPrecisionAndScale (helpers.go:174-195): (putScaleToValue, precision, scale)"""
+    if t == "":
+        return False, 0, 0
+    if t == "numeric" or t.startswith("numeric[]"):
+        return True, 0, 0
+    m = re.match(r"^numeric\((\d+),(\d+)\)", t)
+    if m:
+        return False, int(m.group(1)), int(m.group(2))
+    raise EmitError("unable to parse dataTypeVerbose: %s" % t)
+
+
+def is_pg_numeric(t: str) -> bool:
+    return t == "pg:numeric" or re.search(r"pg:numeric\(\d+,\d+\)", t) is not None
+
+
+def _shopspring(s: bytes) -> Decimal:
+    if not re.match(rb"^[+-]?(\d+\.?\d*|\.\d+)([eE][+-]?\d+)?$", s):
+        raise EmitError("can't convert %r to decimal" % s)
+    return Decimal(s.decode())
+
+
+def _dec_string(d: Decimal) -> bytes:
+    """shopspring Decimal.String(): plain digits, trailing fractional zeros trimmed"""
+    t = format(d, "f")
+    if "." in t:
+        t = t.rstrip("0").rstrip(".")
+    return t.encode()
+
+
+def exponential_to_numeric(s: bytes) -> bytes:
+    """ExponentialFloatFormToNumeric (helpers.go:340-365)"""
+    if s == b"":
+        raise EmitError("empty string as an input is not supported")
+    neg = s[:1] == b"-"
+    body = s[1:] if neg else s
+    if b"e" in body or b"E" in body:
+        body = _dec_string(_shopspring(body))
+    return (b"-" if neg else b"") + body
+
+
+def decimal_primitives(dec: bytes):
+    """DecimalToDebeziumPrimitivesImpl (helpers.go:388-419), its two's complement as written (bytes of ^|x| lose their leading zeros)"""
+    scale = 0
+    digits = dec
+    dot = dec.find(b".")
+    if dot != -1:
+        scale = len(dec) - 1 - dot
+        digits = dec[:dot] + dec[dot + 1:]
+    if all(c in b"0-" for c in digits):
+        buf = b"\x00"
+    else:
+        if not re.match(rb"^[+-]?[0-9]+(_?[0-9]+)*$", digits):
+            raise EmitError("unable to parse string as int: %r" % digits)
+        x = int(digits.replace(b"_", b""))
+        if x < 0:
+            mag = (-x).to_bytes(((-x).bit_length() + 7) // 8, "big")
+            v = int.from_bytes(bytes(b ^ 0xFF for b in mag), "big") + 1
+            buf = v.to_bytes((v.bit_length() + 7) // 8, "big")
+            if not (buf[0] & 0x80):
+                buf = b"\xff" + buf
+        else:
+            buf = x.to_bytes((x.bit_length() + 7) // 8, "big")
+            if buf[0] & 0x80:
+                buf = b"\x00" + buf
+    return base64.b64encode(buf), scale
+
+
+def decimal_to_debezium(dec: bytes, type_wo_provider: str, params):
+    """DecimalToDebezium (helpers.go:269-322)"""
+    mode = params["decimal.handling.mode"]
+    if mode == "precise":
+        norm = exponential_to_numeric(dec)
+        put_scale, _, schema_scale = decimal_precision_scale(type_wo_provider)
+        if schema_scale > 0:
+            d = _shopspring(norm)
+            q = d.quantize(Decimal(1).scaleb(-schema_scale), rounding=ROUND_HALF_UP)
+            norm = format(q, "f").encode()
+        value, scale = decimal_primitives(norm)
+        return {"scale": scale, "value": value} if put_scale else value
+    if mode == "double":
+        f = _go_parse_float(dec)
+        if f is None:
+            raise EmitError("unable to parse float %r" % dec)
+        return F64(f)
+    if mode == "string":
+        return dec
+    raise EmitError("unknown DecimalHandlingMode: %s" % mode)
+
+
+_PG_TS = [(re.compile(rb"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)Z$"), None), (re.compile(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)Z$"), None),
+          (re.compile(rb"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)([+-])(\d\d):(\d\d)$"), "hm"), (re.compile(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)([+-])(\d\d)$"), "h")]
+
+
+def days_from_civil(y, m, d):
+    y -= m <= 2
+    era = (y if y >= 0 else y - 399) // 400
+    yoe = y - era * 400
+    doy = (153 * (m + (-3 if m > 2 else 9)) + 2) // 5 + d - 1
+    doe = yoe * 365 + yoe // 4 - yoe // 100 + doy
+    return era * 146097 + doe - 719468
+
+
+def civil_from_days(z):
+    z += 719468
+    era = (z if z >= 0 else z - 146096) // 146097
+    doe = z - era * 146097
+    yoe = (doe - doe // 1460 + doe // 36524 - doe // 146096) // 365
+    y = yoe + era * 400
+    doy = doe - (365 * yoe + yoe // 4 - yoe // 100)
+    mp = (5 * doy + 2) // 153
+    d = doy - (153 * mp + 2) // 5 + 1
+    m = mp + (3 if mp < 10 else -9)
+    return y + (m <= 2), m, d
+
+
+def parse_pg_datetime_tz(s: bytes):
+    """ParsePgDateTimeWithTimezone (helpers.go:446-467): the layout is picked from s[10] and the last byte; → (sec, nsec, offset)"""
+    if len(s) < 11:
+        raise EmitError("index out of range")   # the reference panics
+    idx = (0 if s[-1:] == b"Z" else 2) if s[10:11] == b"T" else (1 if s[-1:] == b"Z" else 3)
+    rx, zone = _PG_TS[idx]
+    m = rx.match(s)
+    if not m:
+        raise EmitError("time.Parse: %r" % s)
+    y, mo, d, h, mi, sec = (int(m.group(i)) for i in range(1, 7))
+    if not (1 <= mo <= 12 and 1 <= d <= 31 and h < 24 and mi < 60 and sec < 60):
+        raise EmitError("time.Parse: %r out of range" % s)
+    off = 0
+    if zone:
+        off = int(m.group(8)) * 3600 + (int(m.group(9)) * 60 if zone == "hm" else 0)
+        if m.group(7) == b"-":
+            off = -off
+    return days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + sec - off, 0, off
+
+
+def _clock(sec):
+    sod = sec % 86400
+    return b"%02d:%02d:%02d" % (sod // 3600, sod // 60 % 60, sod % 60)
+
+
+def sprintf_debezium_time(t):
+    """SprintfDebeziumTime (helpers.go:1105-1114)"""
+    sec, nsec = t[0], t[1]
+    y, m, d = civil_from_days(sec // 86400)
+    head = b"%04d-%02d-%02dT" % (y, m, d) + _clock(sec)
+    frac = (b"%09d" % nsec).rstrip(b"0")
+    return head + (b"." + frac if frac else b"") + b"Z"
+
+
+def unescape_unicode(s: bytes) -> bytes:
+    """typeutil.UnescapeUnicode (helpers.go:530-550)"""
+    out = bytearray()
+    while s:
+        if s[0] == 0x5C and len(s) > 5 and s[1:2] == b"u":
+            h = s[2:6]
+            if re.match(rb"^[0-9a-fA-F]{4}$", h):
+                out += chr(int(h, 16) & 0xFF).encode("utf-8")
+                s = s[6:]
+                continue
+        out += s[:1]
+        s = s[1:]
+    return bytes(out)
+
+
+def _pg_clock_micros(s: bytes):
+    """pgtype.Time.DecodeText (jackc/pgtype v1.14: time.go): HH:MM:SS[.ffffff]"""
+    m = re.match(rb"^(\d\d):(\d\d):(\d\d)(?:\.(\d{1,6}))?$", s)
+    if not m:
+        raise EmitError("cannot decode %r into Time" % s)
+    us = (int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))) * 1000000
+    if m.group(4):
+        us += int(m.group(4).ljust(6, b"0"))
+    return us
+
+
+# ---- AddPg (pg/emitter.go:262-629) ----------------------------------------------------------------------------------------------------
+def _ts_kind(t, what):
+    return re.match(r"^pg:%s(\(\d\))? %s time zone$" % (what[0], what[1]), t) is not None
+
+
+def is_time_tz(t):
+    return _ts_kind(t, ("time", "with"))
+
+
+def is_time_notz(t):
+    return _ts_kind(t, ("time", "without"))
+
+
+def is_ts_tz(t):
+    return _ts_kind(t, ("timestamp", "with"))
+
+
+def is_ts_notz(t):
+    return _ts_kind(t, ("timestamp", "without"))
+
+
+def add_pg(col: Col, v, original_type: str, into_arr: bool, params):
+    g, x = v
+    if g == "nil":
+        return None
+    t = original_type
+    if t == "pg:boolean":
+        if g != "bool":
+            raise NotRestated("pg:boolean given %s" % g)
+        return bool(x)
+    if t == "pg:bit(1)":
+        return g == "string" and _b(x) == b"1"
+    if t in ("pg:smallint", "pg:integer"):
+        ok = ("int16", "int64", "jsonnum") if t == "pg:smallint" else ("int32", "int64", "jsonnum")
+        if g not in ok:
+            raise EmitError("unknown type of value for %s: %s" % (t, g))
+        return _jn_int64(x) if g == "jsonnum" else int(x)
+    if t == "pg:oid":
+        if g in ("int32", "int64", "uint32"):
+            return int(x)
+        if g == "float64":
+            return int(x)
+        if g == "jsonnum":
+            return _jn_int64(x)
+        raise EmitError("unknown type of value: %s" % g)
+    if t == "pg:bigint":
+        if g == "int64":
+            return int(x)
+        if g == "jsonnum":
+            return _jn_int64(x)
+        raise EmitError("unknown type of value: %s" % g)
+    if t == "pg:real":
+        if g == "float64":
+            return F32(_f32(float(x)))
+        if g == "jsonnum":
+            return F32(_f32(_jn_float64(x)))
+        if g == "float32":
+            return F32(float(x))
+        raise EmitError("unknown type of value for 'pg:real': %s" % g)
+    if t == "pg:double precision":
+        if g == "float64":
+            f = float(x)
+        elif g == "jsonnum":
+            f = _jn_float64(x)
+        else:
+            raise EmitError("unknown type of value for 'pg:double precision': %s" % g)
+        return b"NaN" if math.isnan(f) else b"-Infinity" if f == -math.inf else b"Infinity" if f == math.inf else F64(f)
+    if t == "pg:bytea":
+        if g == "string":
+            s = _b(x)
+        elif g == "bytes":
+            s = base64.b64encode(_b(x))
+        else:
+            raise EmitError("unknown type of value for pg:bytea: %s" % g)
+        if params["binary.handling.mode"] != "bytes":
+            raise EmitError("unsupported binary.handling.mode: %s" % params["binary.handling.mode"])
+        return s
+    if t in ("pg:json", "pg:jsonb"):
+        return gomarshal(_any_value(v))
+    if t == "pg:xml":
+        return unescape_unicode(_need_string(v, t))
+    if t == "pg:uuid":
+        if g != "string":
+            raise EmitError("unknown type of value for uuid: %s" % g)
+        return _b(x)
+    if t == "pg:point":
+        s = _need_string(v, t)
+        arr = s[1:-1].split(b",")
+        if len(arr) != 2:
+            raise EmitError("unknown format of point: %r" % s)
+        fx, fy = _go_parse_float(arr[0]), _go_parse_float(arr[1])
+        if fx is None or fy is None:
+            raise EmitError("unable to format float: %r" % s)
+        return {"x": F64(fx), "y": F64(fy), "wkb": b"", "srid": None}
+    if t == "pg:inet":
+        if g != "string":
+            raise NotRestated("pg:inet given %s" % g)
+        s = _b(x)
+        return s[:-3] if s.endswith(b"/32") else s
+    if t in ("pg:int4range", "pg:int8range", "pg:text", "pg:cidr", "pg:macaddr", "pg:USER-DEFINED:citext"):
+        return _need_string(v, t)
+    if t == "pg:numrange":
+        s = _need_string(v, t)
+        m = re.match(rb"^[\[(]([^,\"]*),([^,\"]*)[\])]$", s)   # pgtype.ParseUntypedTextRange, unquoted bounds only
+        if not m:
+            raise NotRestated("numrange %r" % s)
+        return b"[" + exponential_to_numeric(m.group(1)) + b"," + exponential_to_numeric(m.group(2)) + b")"
+    if t == "pg:tsrange":
+        s = _need_string(v, t)
+        parts = [b'"' + (p[1:-1] if len(p) > 0 and p[:1] == b'"' and p[-1:] == b'"' else p) + b'"' for p in s[1:-1].split(b",")]
+        return s[:1] + b",".join(parts) + s[-1:]
+    if t == "pg:tstzrange":
+        s = _need_string(v, t)
+        m = re.match(rb"^[\[(]\"?([^,\"]+)\"?,\"?([^,\"]+)\"?[\])]$", s)
+        if not m:
+            raise NotRestated("tstzrange %r" % s)
+        out = []
+        for bound in (m.group(1), m.group(2)):   # pgtype.Timestamptz.DecodeText: 2006-01-02 15:04:05[.f]{Z|±hh[:mm[:ss]]}
+            mm = re.match(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)(?:\.\d+)?(Z|[+-]\d\d(?::\d\d(?::\d\d)?)?)$", bound)
+            if not mm:
+                raise NotRestated("tstzrange bound %r" % bound)
+            y, mo, d, h, mi, sec = (int(mm.group(i)) for i in range(1, 7))
+            z = mm.group(7)
+            off = 0
+            if z != b"Z":
+                pp = [int(q) for q in z[1:].split(b":")] + [0, 0]
+                off = (pp[0] * 3600 + pp[1] * 60 + pp[2]) * (-1 if z[:1] == b"-" else 1)
+            u = days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + sec - off
+            yy, m2, dd = civil_from_days(u // 86400)
+            out.append(b'"%04d-%02d-%02d ' % (yy, m2, dd) + _clock(u) + b'+00"')
+        return s[:1] + out[0] + b"," + out[1] + s[-1:]
+    if t == "pg:daterange":
+        if g != "string":
+            raise NotRestated("pg:daterange given %s" % g)
+        return _b(x)
+    if t == "pg:date":
+        if g == "string":
+            sec = parse_pg_datetime_tz(_b(x))[0]
+        elif g == "time":
+            sec = x[0]
+        else:
+            raise EmitError("unknown type of value for pg:date: %s" % g)
+        return trunc_div(sec, 86400)
+    if t == "pg:money":
+        return decimal_to_debezium_primitives(_need_string(v, t)[1:], params)
+    if t == "pg:USER-DEFINED:hstore":
+        if g == "json":
+            a = decode_any(_b(x))
+            if isinstance(a, dict):
+                return gomarshal(a)
+        raise NotRestated("hstore given %s" % g)
+    if is_time_tz(t):
+        if g != "string":
+            raise EmitError("pg - unable to process %s: expected string, got %s" % (t, g))
+        s = _b(x)
+        m = re.match(rb"^(\d\d):(\d\d):(\d\d)(?:\.(\d{1,6}))?([+-])(\d\d)(?::(\d\d))?(?::(\d\d))?$", s)
+        if not m:
+            raise EmitError("failed to decode TIME WITH TIME ZONE %r" % s)
+        off = (int(m.group(6)) * 3600 + int(m.group(7) or 0) * 60 + int(m.group(8) or 0)) * (-1 if m.group(5) == b"-" else 1)
+        sod = (int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3)) - off) % 86400
+        frac = b"" if into_arr or not m.group(4) else m.group(4).ljust(6, b"0").rstrip(b"0")
+        return _clock(sod) + (b"." + frac if frac else b"") + b"Z"
+    if is_time_notz(t):
+        if g != "string":
+            raise NotRestated("time without time zone given %s" % g)
+        us = _pg_clock_micros(_b(x))
+        div = 1 if into_arr else get_time_divider(without_provider(t))
+        r = trunc_div(us, div)
+        return r - (r % 1000) if into_arr else r
+    if is_ts_notz(t):
+        if g != "time":
+            raise NotRestated("timestamp without time zone given %s" % g)
+        off = x[2] if len(x) > 2 else 0   # pgtype.Timestamp.Set(time.Time) keeps the wall clock of the value's location
+        micro = (x[0] + off) * 1000000 + x[1] // 1000
+        return trunc_div(micro, 1 if into_arr else get_time_divider(without_provider(t)))
+    if is_ts_tz(t):
+        if g == "time":
+            return sprintf_debezium_time(x)
+        if g == "string":
+            return sprintf_debezium_time(parse_pg_datetime_tz(_b(x)))
+        raise EmitError("unknown type of value for 'pg:timestamp with time zone': %s" % g)
+    if is_pg_numeric(t):
+        if g not in ("string", "jsonnum"):
+            raise EmitError("unknown type of value for 'pg:numeric': %s" % g)
+        return decimal_to_debezium(_b(x), without_provider(t), params)
+    if t.startswith("pg:bit(") or t.startswith("pg:bit varying("):
+        return bits_to_debezium(_need_string(v, t))
+    if t.startswith("pg:character(") or t.startswith("pg:character varying(") or t in ("pg:character", "pg:character varying"):
+        return _need_string(v, t)
+    if t.startswith("pg:interval"):
+        raise NotRestated("pg:interval (pgtype.Interval.DecodeText)")
+    if col.properties.get("pg:enum_all_values") is not None:
+        return _need_string(v, t)
+    raise UnknownTypeError("unknown column type: %s, column name: %s" % (t, col.name))
+
+
+def decimal_to_debezium_primitives(dec: bytes, params):
+    """DecimalToDebeziumPrimitives (helpers.go:421-436)"""
+    mode = params["decimal.handling.mode"]
+    if mode == "precise":
+        return decimal_primitives(dec)[0]
+    if mode == "double":
+        f = _go_parse_float(dec)
+        if f is None:
+            raise EmitError("strconv.ParseFloat %r" % dec)
+        return F64(f)
+    return dec
+
+
+def _f32(f: float) -> float:
+    import numpy as np
+    with np.errstate(over="ignore"):
+        return float(np.float32(f))
+
+
+def _need_string(v, t):
+    if v[0] != "string":
+        raise EmitError("interface conversion: %s is %s, not string" % (t, v[0]))   # the reference panics
+    return _b(v[1])
+
+
+def _any_value(v):
+    g, x = v
+    if g == "json":
+        return decode_any(_b(x))
+    if g == "string":
+        return _b(x)
+    if g == "jsonnum":
+        return JN(_b(x).decode())
+    if g == "bool":
+        return bool(x)
+    raise NotRestated("any value given %s" % g)
+
+
+def add_common(col: Col, v):
+    """addCommon (emitter_common.go:68-170)"""
+    g, x = v
+    if g == "nil":
+        return None
+    d = col.dtype
+    if d in INTS:
+        if g in INTS:
+            return int(x)
+        if g == "jsonnum":
+            _jn_int64(x)
+            return JN(_b(x).decode())
+        raise EmitError("unable for extract signed int")
+    if d in UINTS:
+        if g in INTS or g in UINTS:
+            return int(x) & 0xFFFFFFFFFFFFFFFF
+        if g == "jsonnum":
+            t = _b(x)
+            if not re.match(rb"^\+?[0-9]+$", t) or int(t) >= 1 << 64:
+                raise EmitError("unable to parse uint64")
+            return int(t)
+        raise EmitError("unable for extract unsigned int")
+    if d in ("float", "double"):
+        if g == "float32":
+            return F32(float(x))
+        if g == "float64":
+            return F64(float(x))
+        if g == "jsonnum":
+            return JN(_b(x).decode())
+        raise EmitError("unknown input data type for type float: %s" % g)
+    if d == "string":
+        if g in ("string", "bytes"):
+            return base64.b64encode(_b(x))
+        raise EmitError("unknown input data type for type bytes(yt:string): %s" % g)
+    if d == "utf8":
+        if g == "string":
+            return _b(x)
+        if g == "bytes":
+            return GoBytes(_b(x))
+        if g == "time":
+            return trunc_div(x[0], 86400)
+        raise EmitError("unknown input data type for type string(yt:utf8): %s" % g)
+    if d == "boolean":
+        if g == "bool":
+            return bool(x)
+        if g == "int8":
+            return int(x) == 1
+        raise EmitError("unknown input data type for type bool: %s" % g)
+    if d in ("datetime", "timestamp"):
+        if g == "time":
+            return sprintf_debezium_time(x)   # time.Time.MarshalJSON = RFC3339Nano, the same text for UTC values
+        raise EmitError("unknown input data type for type %s: %s" % (d, g))
+    if d == "any":
+        if g == "string":
+            return _b(x)
+        if g == "json":
+            a = decode_any(_b(x))
+            if isinstance(a, dict):
+                return gomarshal(a)
+        raise EmitError("unknown input data type for type any: %s" % g)
+    raise EmitError("unknown input data type: %s" % d)
+
+
+YT_KAFKA = {"int64": "int64", "int32": "int32", "int16": "int16", "int8": "int8", "uint64": "int64", "uint32": "int32", "uint16": "int16", "uint8": "int8",
+            "float": "float", "double": "double", "string": "bytes", "utf8": "string", "boolean": "boolean", "any": "string"}
+
+
+# ---- field descriptions (fields_descr.go, pg/emitter.go:20-260) -----------------------------------------------------------------------
+PG_PLAIN = {"pg:boolean": ("boolean", ""), "pg:bit(1)": ("boolean", ""), "pg:smallint": ("int16", ""), "pg:integer": ("int32", ""), "pg:bigint": ("int64", ""),
+            "pg:oid": ("int64", ""), "pg:real": ("float", ""), "pg:double precision": ("double", ""), "pg:bytea": ("bytes", ""),
+            "pg:json": ("string", "io.debezium.data.Json"), "pg:jsonb": ("string", "io.debezium.data.Json"), "pg:xml": ("string", "io.debezium.data.Xml"),
+            "pg:uuid": ("string", "io.debezium.data.Uuid"), "pg:inet": ("string", ""), "pg:int4range": ("string", ""), "pg:int8range": ("string", ""),
+            "pg:numrange": ("string", ""), "pg:tsrange": ("string", ""), "pg:tstzrange": ("string", ""), "pg:daterange": ("string", ""), "pg:text": ("string", ""),
+            "pg:date": ("int32", "io.debezium.time.Date"), "pg:cidr": ("string", ""), "pg:macaddr": ("string", ""), "pg:character": ("string", ""),
+            "pg:character varying": ("string", ""), "pg:USER-DEFINED:hstore": ("string", "io.debezium.data.Json"), "pg:USER-DEFINED:citext": ("string", "")}
+
+
+def _decimal_mode_descr(params, precise):
+    mode = params["decimal.handling.mode"]
+    if mode == "precise":
+        return precise
+    if mode == "double":
+        return "double", "", None
+    if mode == "string":
+        return "string", "", None
+    return "", "", None
+
+
+def pg_type_descr(col: Col, into_arr, params):
+    """GetKafkaTypeDescrByPgType + the extractor it returns: (kafka type, debezium name, extra)"""
+    t = col.original_type
+    if t in PG_PLAIN:
+        return PG_PLAIN[t] + (None,)
+    if t == "pg:point":
+        return "struct", "io.debezium.data.geometry.Point", {"doc": "Geometry (POINT)", "fields": [
+            {"type": "double", "optional": False, "field": "x"}, {"type": "double", "optional": False, "field": "y"},
+            {"type": "bytes", "optional": True, "field": "wkb"}, {"type": "int32", "optional": True, "field": "srid"}]}
+    if t == "pg:money":
+        return _decimal_mode_descr(params, ("bytes", "org.apache.kafka.connect.data.Decimal", {"parameters": {"scale": "2"}}))
+    if t.startswith("pg:bit(") or t.startswith("pg:bit varying("):
+        body = t[7:] if t.startswith("pg:bit(") else t[15:]
+        return "bytes", "io.debezium.data.Bits", {"parameters": {"length": body[:body.index(")")]}}
+    if t.startswith("pg:character(") or t.startswith("pg:character varying("):
+        return "string", "", None
+    if t.startswith("pg:interval"):
+        return "int64", "io.debezium.time.MicroDuration", None
+    if is_time_tz(t):
+        return "string", "io.debezium.time.ZonedTime", None
+    if is_time_notz(t):
+        div = 1 if into_arr else _divider_or_zero(t)
+        return ("int64", "io.debezium.time.MicroTime", None) if div == 1 else ("int32", "io.debezium.time.Time", None)
+    if is_ts_tz(t):
+        return "string", "io.debezium.time.ZonedTimestamp", None
+    if is_ts_notz(t):
+        div = 1 if into_arr else _divider_or_zero(t)
+        return ("int64", "io.debezium.time.MicroTimestamp", None) if div == 1 else ("int64", "io.debezium.time.Timestamp", None)
+    if is_pg_numeric(t):
+        put_scale, precision, scale = decimal_precision_scale(without_provider(t))
+        if put_scale:
+            precise = ("struct", "io.debezium.data.VariableScaleDecimal", {"doc": "Variable scaled decimal", "fields": [
+                {"type": "int32", "optional": False, "field": "scale"}, {"type": "bytes", "optional": False, "field": "value"}]})
+        else:
+            precise = ("bytes", "org.apache.kafka.connect.data.Decimal", {"parameters": {"scale": "%d" % scale, "connect.decimal.precision": "%d" % precision}})
+        return _decimal_mode_descr(params, precise)
+    enum = col.properties.get("pg:enum_all_values")
+    if enum is not None:
+        return "string", "io.debezium.data.Enum", {"version": 1, "parameters": {"allowed": ",".join(enum)}}
+    raise UnknownTypeError("unknown pgType: %s" % t)
+
+
+def _divider_or_zero(t):
+    try:
+        return get_time_divider(without_provider(t))
+    except EmitError:
+        return 0
+
+
+def field_descr(col: Col, params, into_arr=False):
+    """getFieldDescr (fields_descr.go:19-69)"""
+    t = col.original_type
+    if t == "":
+        if col.dtype == "timestamp":
+            kafka, name, extra = "string", "io.debezium.time.ZonedTimestamp", None
+        elif col.dtype in YT_KAFKA:
+            kafka, name, extra = YT_KAFKA[col.dtype], "", None
+        else:
+            raise EmitError("unable to find yt type: %s" % col.dtype)
+    elif t.startswith("pg:"):
+        if t.endswith("[]"):
+            raise NotRestated("pg arrays")
+        kafka, name, extra = pg_type_descr(col, into_arr, params)
+    elif t.startswith("mysql:") or t.startswith("ydb:"):
+        raise NotRestated(t)
+    else:
+        raise EmitError("unknown original type: %s" % t)
+    d = {"type": kafka, "optional": not col.key}
+    if not into_arr:
+        d["field"] = col.name
+    if name:
+        d["name"], d["version"] = name, 1
+    d.update(extra or {})
+    if params["dt.add.original.type.info"] == "true":
+        d["__dt_original_type_info"] = {"original_type": t}
+    return d
+
+
+def fields_descr(cols, params, keys_only=False):
+    """arrColSchemaToFieldsDescr / …Keys (emitter_value_converter.go:99-137)"""
+    out = []
+    for c in cols:
+        if keys_only and not c.key:
+            continue
+        try:
+            out.append(field_descr(c, params))
+        except UnknownTypeError:
+            policy = params["dt.unknown.types.policy"]
+            if keys_only or policy == "fail":
+                raise
+            if policy == "skip":
+                continue
+            out.append(field_descr(Col(c.name, "utf8", c.key, ""), params))
+    return out
+
+
+def source_schema(source_type):
+    """buildSourceSchemaDescr (fields_descr_source.go:7-107)"""
+    fields = [{"type": "string", "optional": False, "field": "version"}, {"type": "string", "optional": False, "field": "connector"},
+              {"type": "string", "optional": False, "field": "name"}, {"type": "int64", "optional": False, "field": "ts_ms"},
+              {"type": "string", "optional": True, "name": "io.debezium.data.Enum", "version": 1, "parameters": {"allowed": "true,last,false"}, "default": "false", "field": "snapshot"},
+              {"type": "string", "optional": False, "field": "db"}, {"type": "string", "optional": False, "field": "table"}]
+    d = {"type": "struct", "optional": False, "field": "source"}
+    if source_type == "pg":
+        d["name"] = "io.debezium.connector.postgresql.Source"
+        fields += [{"type": "int64", "optional": True, "field": "lsn"}, {"type": "string", "optional": False, "field": "schema"},
+                   {"type": "int64", "optional": True, "field": "txId"}, {"type": "int64", "optional": True, "field": "xmin"}]
+    elif source_type in ("mysql", "ydb"):
+        raise NotRestated("source type %s" % source_type)
+    d["fields"] = fields
+    return d
+
+
+# ---- the emitter ----------------------------------------------------------------------------------------------------------------------
+REGULAR, DELETE_EVENT, TOMBSTONE, INSERT_EVENT = 0, 1, 2, 3
+
+
+class Emitter:
+    def __init__(self, params=None, version="1.1.2.Final", drop_keys=False, ignore_unknown_sources=False):
+        self.given = dict(params or {})
+        self.params = enriched(params)
+        self.database, self.server = self.given.get("database.dbname", ""), self.given.get("topic.prefix", "")
+        self.version, self.drop_keys, self.ignore_unknown_sources = version, drop_keys, ignore_unknown_sources
+        for k in ("key.converter", "value.converter"):
+            if self.params[k] != "org.apache.kafka.connect.json.JsonConverter":
+                raise NotRestated(self.params[k])
+        for k in ("key.converter.schemas.enable", "value.converter.schemas.enable"):
+            if self.params[k] != "true":
+                raise NotRestated("%s=false (PackerSkipSchema)" % k)
+
+    # makeValues (emitter_value_converter.go:202-242)
+    def make_values(self, cols, names, values, keys_only):
+        index = {c.name: c for c in cols}
+        out = {}
+        for nm, v in zip(names, values):
+            if nm not in index:
+                raise EmitError("invalid changeItem - column absent in schema: %s" % nm)
+            c = index[nm]
+            if keys_only and not c.key:
+                continue
+            try:
+                out[nm] = self.add(c, v)
+            except UnknownTypeError:
+                policy = self.params["dt.unknown.types.policy"]
+                if policy == "skip":
+                    continue
+                if policy == "to_string":
+                    out[nm] = _b(v[1]) if v[0] == "string" else gomarshal(_any_value(v))
+                    continue
+                raise
+        return out
+
+    def add(self, c: Col, v):
+        t = c.original_type
+        if t.startswith("pg:"):
+            if t.endswith("[]"):
+                raise NotRestated("pg arrays")
+            return add_pg(c, v, t, False, self.params)
+        if t.startswith("mysql:") or t.startswith("ydb:"):
+            raise NotRestated(t)
+        if self.ignore_unknown_sources:
+            return add_common(c, v)
+        raise EmitError("unknown source type")
+
+    def build_kv(self, it: Item, keys_only):
+        out = self.make_values(it.cols, it.names, it.values, keys_only)
+        if keys_only:
+            return out
+        if len(it.cols) > len(it.names):   # TOAST
+            have = set(it.names)
+            for c in it.cols:
+                if c.name not in have:
+                    out[c.name] = _b(self.params["unavailable.value.placeholder"])
+        return out
+
+    def make_key(self, it: Item, use_after):
+        if use_after or len(it.old_names) == 0:
+            return self.build_kv(it, True)
+        return self.make_values(it.cols, it.old_names, it.old_values, True)
+
+    def build_source(self, it: Item, snapshot):
+        d = {"version": self.version, "name": self.server, "ts_ms": it.commit_time // 1000000, "snapshot": "true" if snapshot else "false",
+             "db": self.database, "table": it.table}
+        st = self.params["dt.source.type"]
+        if st == "pg":
+            d.update({"connector": "postgresql", "lsn": it.lsn, "schema": it.schema, "txId": it.id, "xmin": None})
+        elif st in ("mysql", "ydb"):
+            raise NotRestated("source type %s" % st)
+        return d
+
+    def schema_key(self, it: Item):
+        return gomarshal({"fields": fields_descr(it.cols, self.params, True), "name": "%s.%s.%s.Key" % (self.server, it.schema, it.table),
+                          "optional": False, "type": "struct"})
+
+    def schema_val(self, it: Item):
+        f = fields_descr(it.cols, self.params)
+        nm = "%s.%s.%s.Value" % (self.server, it.schema, it.table)
+        fields = [{"type": "struct", "fields": f, "optional": True, "name": nm, "field": "before"},
+                  {"type": "struct", "fields": f, "optional": True, "name": nm, "field": "after"},
+                  source_schema(self.params["dt.source.type"]),
+                  {"type": "string", "optional": False, "field": "op"}, {"type": "int64", "optional": True, "field": "ts_ms"},
+                  {"type": "struct", "fields": [{"type": "string", "optional": False, "field": "id"}, {"type": "int64", "optional": False, "field": "total_order"},
+                                                {"type": "int64", "optional": False, "field": "data_collection_order"}], "optional": True, "field": "transaction"}]
+        return gomarshal({"type": "struct", "fields": fields, "optional": False, "name": "%s.%s.%s.Envelope" % (self.server, it.schema, it.table)})
+
+    def val_payload(self, it: Item, snapshot, emit_type):
+        if it.kind == "insert":
+            op = "r" if snapshot else "c"
+        elif it.kind == "update":
+            op = {REGULAR: "u", DELETE_EVENT: "d", INSERT_EVENT: "c"}[emit_type]
+        elif it.kind == "delete":
+            op = "d"
+        else:
+            raise EmitError("unsupported kind: %s" % it.kind)
+        if op == "d":
+            after = None
+            before = {c.name: None for c in it.cols}
+            before.update(self.make_values(it.cols, it.old_names, it.old_values, False))
+        else:
+            after = self.build_kv(it, False)
+            npk = sum(1 for c in it.cols if c.key)
+            before = self.make_values(it.cols, it.old_names, it.old_values, False) if op == "u" and len(it.old_names) > npk else None
+        ts_ms = trunc_div(it.commit_time, 1000000)   # GetPayloadTSMS: time.Unix(ct / 1e9, ct % 1e9).UnixNano() / 1e6
+        return gomarshal({"before": before, "after": after, "source": self.build_source(it, snapshot), "op": op, "ts_ms": ts_ms, "transaction": None})
+
+    @staticmethod
+    def pack(payload: bytes, schema: bytes) -> bytes:
+        return gomarshal({"schema": Raw(schema), "payload": Raw(payload)})
+
+    def emit_one(self, it: Item, snapshot, emit_type):
+        key = None
+        if not self.drop_keys:
+            key = self.pack(gomarshal(self.make_key(it, emit_type == INSERT_EVENT)), self.schema_key(it))
+        if emit_type == TOMBSTONE:
+            return key, None
+        return key, self.pack(self.val_payload(it, snapshot, emit_type), self.schema_val(it))
+
+    def keys_changed(self, it: Item) -> bool:
+        """ChangeItem.KeysChanged (change_item.go:237-286), over Go values: same dynamic type and same value"""
+        if it.kind != "update":
+            return False
+        for c in it.cols:
+            if not c.key:
+                continue
+            old = next((v for n, v in zip(it.old_names, it.old_values) if n == c.name), ("nil", None))
+            new = next((v for n, v in zip(it.names, it.values) if n == c.name), ("nil", None))
+            if old[0] != new[0] or (old[0] != "nil" and _norm(old) != _norm(new)):
+                return True
+        return False
+
+    def emit_kv(self, it: Item, snapshot=False):
+        """emitKV (emitter_value_converter.go:629-672): [(key bytes or None, value bytes or None)]"""
+        if it.kind not in ("insert", "update", "delete"):
+            return []
+        skip_tomb = self.params["tombstones.on.delete"] == "false"
+        if self.keys_changed(it):
+            types = [DELETE_EVENT, TOMBSTONE, INSERT_EVENT]
+        elif it.kind == "delete":
+            types = [DELETE_EVENT, TOMBSTONE]
+        else:
+            types = [REGULAR]
+        return [self.emit_one(it, snapshot, t) for t in types if not (t == TOMBSTONE and skip_tomb)]
+
+
+def _norm(v):
+    g, x = v
+    if g in ("string", "bytes", "jsonnum", "json"):
+        return _b(x)
+    if g == "time":
+        return tuple(x)
+    return x
+
+
+# ---- what UnmarshalChangeItem does to a fixture (restore.go:20-290), for the value kinds the pg fixtures hold --------------------------
+def restore(col: Col, raw):
+    if raw is None:
+        return ("nil", None)
+    d = col.dtype
+    if d in ("date", "datetime", "timestamp"):
+        if isinstance(raw, str) and not isinstance(raw, JN):
+            m = re.match(r"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)(?:\.(\d{1,9}))?(Z|[+-]\d\d:\d\d)$", raw)   # time.RFC3339Nano
+            if not m:
+                raise NotRestated("dateparse.ParseAny(%r)" % raw)
+            y, mo, dd, h, mi, s = (int(m.group(i)) for i in range(1, 7))
+            ns = int((m.group(7) or "").ljust(9, "0") or 0)
+            z = m.group(8)
+            off = 0 if z == "Z" else (int(z[1:3]) * 3600 + int(z[4:6]) * 60) * (-1 if z[0] == "-" else 1)
+            return ("time", (days_from_civil(y, mo, dd) * 86400 + h * 3600 + mi * 60 + s - off, ns, off))
+        raise NotRestated("%s from %r" % (d, raw))
+    if d in INTS or d in UINTS:
+        if isinstance(raw, JN):
+            if "." in raw or "e" in raw or "E" in raw:
+                raise NotRestated("cast of %r" % raw)
+            return (d, int(raw))
+        raise NotRestated("%s from %r" % (d, raw))
+    if d == "double":
+        if isinstance(raw, JN):
+            return ("jsonnum", _b(raw))
+        if isinstance(raw, str):
+            f = _go_parse_float(_b(raw))
+            return ("nil", None) if raw == "" or f is None else ("float64", f)
+        return ("nil", None)
+    if d == "boolean":
+        return _plain(raw)
+    if d in ("string", "utf8"):
+        if col.original_type == "pg:bytea":
+            if isinstance(raw, str):
+                try:
+                    return ("bytes", base64.b64decode(raw, validate=True))
+                except Exception:
+                    return ("bytes", b"")
+        if isinstance(raw, str) and not isinstance(raw, JN):
+            return ("string", _b(raw))
+        return ("string", gomarshal(_go(raw)))   # json.Marshal(value): HTML escaping not restated (no such value in the fixtures)
+    if d == "any":
+        if isinstance(raw, str) and not isinstance(raw, JN):
+            if col.original_type.startswith("pg:timestamp"):
+                raise NotRestated("pg:timestamp in an any column")
+            if col.original_type.startswith("pg:"):
+                return ("string", _b(raw))
+            raise NotRestated("tryUnmarshalJSON")
+        return _plain(raw)
+    return _plain(raw)
+
+
+def _go(raw):
+    if isinstance(raw, dict):
+        return {_b(k): _go(v) for k, v in raw.items()}
+    if isinstance(raw, list):
+        return [_go(v) for v in raw]
+    if isinstance(raw, str) and not isinstance(raw, JN):
+        return _b(raw)
+    return raw
+
+
+def _plain(raw):
+    if raw is None:
+        return ("nil", None)
+    if isinstance(raw, bool):
+        return ("bool", raw)
+    if isinstance(raw, JN):
+        return ("jsonnum", _b(raw))
+    if isinstance(raw, str):
+        return ("string", _b(raw))
+    return ("json", gomarshal(_go(raw)))
+
+
+def unmarshal_change_item(text: bytes) -> Item:
+    """abstract.UnmarshalChangeItem (restore.go:375-385) for one of the reference's ChangeItem fixtures"""
+    d = json.loads(text.decode("utf-8"), parse_float=JN, parse_int=JN)
+    cols = [Col(c["name"], c["type"], c.get("key", False), c.get("original_type", ""), c.get("properties") or {}) for c in d["table_schema"]]
+    index = {c.name: c for c in cols}
+    names = d.get("columnnames") or []
+    values = [restore(index[n], v) for n, v in zip(names, d.get("columnvalues") or [])]
+    ok = d.get("oldkeys") or {}
+    onames = ok.get("keynames") or []
+    ovals = list(ok.get("keyvalues") or [])
+    if d["kind"] != "insert":
+        ovals = [restore(index[n], v) for n, v in zip(onames, ovals)]
+    else:
+        ovals = [_plain(v) for v in ovals]
+    return Item(d["kind"], d["schema"], d["table"], cols, names, values, onames, ovals, int(d.get("id", 0)), int(d.get("nextlsn", 0)),
+                int(d.get("commitTime", 0)), d.get("tx_id", ""))

@@ -80,6 +80,8 @@ def lib():
     L.ora_fnv1a32.argtypes = [C.c_char_p, C.c_size_t]
     L.ora_fmt_float.restype = C.c_size_t
     L.ora_fmt_float.argtypes = [C.c_char_p, C.c_double, C.c_char, C.c_int]
+    L.ora_json_float.restype = C.c_size_t
+    L.ora_json_float.argtypes = [C.c_char_p, C.c_double, C.c_int]
     L.ora_fmt_duration.restype = C.c_size_t
     L.ora_fmt_duration.argtypes = [C.c_char_p, C.c_int64]
     L.ora_parse_int.restype = C.c_int
@@ -457,6 +459,13 @@ def crc32(data: bytes) -> int:
 def fmt_float(f: float, fmt: str = "g", bits: int = 64) -> str:
     buf = C.create_string_buffer(400)
     n = lib().ora_fmt_float(buf, f, fmt.encode(), bits)
+    return buf.raw[:n].decode()
+
+
+def json_float(f: float, bits: int = 64) -> str:
+    """encoding/json's floatEncoder (encode.go): shortest digits, 'f' form inside [1e-6, 1e21), else 'e' with a trimmed exponent"""
+    buf = C.create_string_buffer(64)
+    n = lib().ora_json_float(buf, f, bits)
     return buf.raw[:n].decode()
 
 

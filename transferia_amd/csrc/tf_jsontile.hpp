@@ -8,12 +8,15 @@
 
 namespace tf {
 
-static constexpr int JT_THREADS = 512;
+#ifndef TF_JT_THREADS
+#define TF_JT_THREADS 512
+#endif
+static constexpr int JT_THREADS = TF_JT_THREADS;
 static constexpr int JT_CPT = 4;                           // 16-byte chunks per thread
 static constexpr int JT_BYTES = JT_THREADS * JT_CPT * 16;  // 32 KiB of text per tile
 static constexpr uint64_t JT_MASK = JT_CPT == 4 ? ~0ull : (1ull << (16 * (JT_CPT & 3))) - 1;  // this thread's bytes as mask bits
 static constexpr int JT_LINES = 32;                        // lines per tile at most
-static constexpr int JT_SCAP = 4608;                       // separators indexed per tile
+static constexpr int JT_SCAP = 9 * JT_THREADS;             // separators indexed per tile
 static constexpr int JT_MEM = 192;                         // members per line
 static constexpr int JT_OWN = 512;                         // columns (duplicate-key check)
 static constexpr int JT_KREF = 4096;                       // bytes of key text the member map keeps
