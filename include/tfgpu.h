@@ -834,6 +834,39 @@ typedef struct tfgpu_queue_options {
 int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b, const tfgpu_row_meta *meta,
                           tfgpu_dbuf **values, uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg);
 
+/* ---- Debezium emitter: queue.DebeziumSerializer (the "debezium" sink format of configs[4]) ----
+ * Emitter.EmitKV for every row of one table's batch (pkg/serializer/queue/debezium_serializer.go:26-43,
+ * pkg/debezium/emitter_value_converter.go:574-690): 0..3 messages per ChangeItem — one for an insert or a plain update, (delete,
+ * tombstone) for a delete, (delete, tombstone, insert) for an update whose primary key changed (ChangeItem.KeysChanged), the
+ * tombstones dropped under tombstones.on.delete=false.  Message m: key = keys[key_start[m], key_start[m+1]) (empty with
+ * drop_keys), value = values[val_start[m], val_start[m+1]) or nil when val_null[m] (a tombstone); msg_row[m] = the batch row it
+ * came from.  Every array has room for cap+1 (starts) / cap entries; cap = 3 * nrows is always enough.
+ * Both halves are PackerIncludeSchema's {"payload":…,"schema":…} (packer/packer_include_schema.go:14-40) — Go maps marshalled by
+ * util.JSONMarshalUnescape, members in byte order, no HTML escaping.  `table_schema` is TableSchema.Columns() with OriginalType
+ * and the PrimaryKey flags (the batch itself carries neither); columns of the schema missing from the batch are TOASTed
+ * (unavailable.value.placeholder).  Row meta: id → source.txId, lsn → source.lsn, commit_time → both ts_ms (NULL = zeros).
+ * Parameters: the format settings map (parameters.go:140-215 fills the defaults): database.dbname, topic.prefix, dt.source.type
+ * ("" | "pg"), decimal.handling.mode (precise | string), tombstones.on.delete, dt.add.original.type.info,
+ * unavailable.value.placeholder, dt.unknown.types.policy.
+ * Device-resident Postgres types (pkg/debezium/pg/emitter.go:262-629): boolean, bit(1), smallint, integer, bigint, oid, real, double
+ * precision, text / character* / uuid / cidr / macaddr / citext / int4range / int8range / daterange, inet, bytea, date and
+ * timestamp[(p)] with / without time zone as time.Time, json / jsonb, numeric[(p,s)] up to 38 digits, bit(n) / bit varying(n).
+ * Anything else — other original types (interval, time, money, point, hstore, xml, the quoted ranges, arrays, enums, mysql: / ydb:),
+ * schema-registry converters, key / value schemas disabled, a value of a Go type the device does not convert — is refused BY NAME
+ * with TFGPU_ERR_UNSUPPORTED and travels through the stock emitter; where the reference itself returns an error (an unknown
+ * type under policy "fail", a json.Number that is no integer, "unknown type of value") the call fails with TFGPU_ERR_INVALID.  */
+typedef struct tfgpu_dbz_emit_options {
+  const char *const *param_keys;    /* connector parameters: nparams (key, value) pairs                  */
+  const char *const *param_values;
+  int32_t nparams;
+  const char *version;              /* source.version; NULL = "1.1.2.Final" (debezium_serializer.go:118) */
+  int32_t drop_keys;                /* dropKeys: no message keys                                         */
+  int32_t snapshot;                 /* isSnapshot: inserts are op "r", source.snapshot = "true"          */
+  const tfgpu_schema *table_schema; /* required                                                          */
+} tfgpu_dbz_emit_options;
+int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *opts, const tfgpu_dbatch *b, const tfgpu_row_meta *meta, tfgpu_dbuf **keys, uint64_t *key_start,
+                        tfgpu_dbuf **values, uint64_t *val_start, uint8_t *val_null, int64_t *msg_row, int64_t cap, int64_t *nmsg);
+
 /* ---- profiling hooks (bench.py / rocprof cross-check) ------------------- */
 /* Per-kernel accumulated device time measured with HIP events on the library
  * stream.  Enable, run, then read back name/launches/total_ms.              */

@@ -351,9 +351,9 @@ def decimal_primitives(dec: bytes):
     if all(c in b"0-" for c in digits):
         buf = b"\x00"
     else:
-        if not re.match(rb"^[+-]?[0-9]+(_?[0-9]+)*$", digits):
+        if not re.match(rb"^[+-]?[0-9]+$", digits):   # big.Int.SetString(s, 10): underscores only with base 0
             raise EmitError("unable to parse string as int: %r" % digits)
-        x = int(digits.replace(b"_", b""))
+        x = int(digits)
         if x < 0:
             mag = (-x).to_bytes(((-x).bit_length() + 7) // 8, "big")
             v = int.from_bytes(bytes(b ^ 0xFF for b in mag), "big") + 1

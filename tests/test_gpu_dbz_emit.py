@@ -1,0 +1,272 @@
+"""tfgpu_debezium_emit (tf_dbzemit.hip) = queue.DebeziumSerializer / Emitter.EmitKV (pkg/serializer/queue/debezium_serializer.go:26-43,
+pkg/debezium/emitter_value_converter.go:574-690) against the oracle's emitter (oracle/dbz_emitter.py, pinned to the reference's
+fixtures in test_dbz_emitter_oracle.py): every key and every value byte for byte — random Postgres-typed rows through every
+device-resident converter, inserts / updates / deletes with OldKeys (tombstones, key changes, replica identity full), the parameter
+variants, the reference's own CRUD fixtures cut to the device-resident columns, and what is refused by name."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from oracle import dbz_emitter as E
+
+pytestmark = pytest.mark.gpu
+PARAMS = {"database.dbname": "pguser", "topic.prefix": "fullfillment", "dt.add.original.type.info": "false", "dt.source.type": "pg"}
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+# name, DataType, key, OriginalType
+TABLE = [("id", "int32", True, "pg:integer"), ("bl", "boolean", False, "pg:boolean"), ("b1", "utf8", False, "pg:bit(1)"), ("si", "int16", False, "pg:smallint"),
+         ("big", "int64", False, "pg:bigint"), ("oid_", "any", False, "pg:oid"), ("re", "double", False, "pg:real"), ("re32", "float", False, "pg:real"),
+         ("d", "double", False, "pg:double precision"), ("dn", "double", False, "pg:double precision"), ("t", "utf8", False, "pg:text"),
+         ("vc", "utf8", False, "pg:character varying(256)"), ("uid", "utf8", False, "pg:uuid"), ("ip", "any", False, "pg:inet"), ("ba", "string", False, "pg:bytea"),
+         ("bas", "string", False, "pg:bytea"), ("dt", "date", False, "pg:date"), ("ts", "timestamp", False, "pg:timestamp without time zone"),
+         ("ts3", "timestamp", False, "pg:timestamp(3) without time zone"), ("tz", "timestamp", False, "pg:timestamp with time zone"), ("j", "any", False, "pg:jsonb"),
+         ("js", "any", False, "pg:json"), ("nu", "double", False, "pg:numeric"), ("n52", "double", False, "pg:numeric(5,2)"), ("n180", "utf8", False, "pg:numeric(18,0)"),
+         ("bits", "utf8", False, "pg:bit varying(24)"), ("b8", "utf8", False, "pg:bit(8)"), ("ir", "any", False, "pg:int4range"), ("z_last", "utf8", False, "pg:USER-DEFINED:citext"),
+         ("A_first", "int64", False, "pg:bigint")]
+
+
+def schema_of(table):
+    return abi.Schema.of([[n, d, k, "", o] for n, d, k, o in table])
+
+
+def cols_of(table):
+    return [E.Col(n, d, k, o) for n, d, k, o in table]
+
+
+TEXTS = ["", "plain", "quote\" back\\slash", "<tag attr='x'>&amp;</tag>", "tab\tnl\nctl\x01\x1f", "юникод ✓ \u2028 \u2029", "x" * 300, "bad \xff utf8 \xc3"]
+NUMS = ["0", "-0", "0.00", "1", "-1", "127", "128", "-128", "-129", "255", "-255", "-256", "65535", "-16777215", "123.67", "-123.675", "123.674999", "0.005", "-0.005", "9.995",
+        "1e2", "1.50e1", "19e-1", "-19e-1", ".123e3", "1e-2", "12345678901234567890123456789012345678", "-99999999999999999999999999999999999999", "00012.300", "+5", "5.", "1.277559e+7"]
+
+
+def random_rows(n, seed):
+    # (n52 skips the two 38-digit numbers: two more fractional digits carry them past the device's 128 bits — refused, see the last test)
+    rng = np.random.default_rng(seed)
+    rows = []
+    for r in range(n):
+        def pick(lst):
+            return lst[int(rng.integers(0, len(lst)))]
+        f = float(rng.standard_normal()) * 10.0 ** int(rng.integers(-12, 25))
+        sec = int(rng.integers(-3000000000, 4000000000))
+        row = [["int32", int(rng.integers(-2 ** 31, 2 ** 31))], ["bool", bool(rng.integers(0, 2))], ["string", pick(["1", "0", "", "11"])], ["int16", int(rng.integers(-32768, 32768))],
+               pick([["int64", int(rng.integers(-2 ** 62, 2 ** 62))], ["int64", -5]]), ["jsonnum", str(int(rng.integers(0, 2 ** 32)))], ["float64", f], ["float32", float(np.float32(f % 1e30))],
+               ["float64", pick([f, 0.0, -0.0, 1e21, 1e-7, 123456789.125, 5e-324, 1.7976931348623157e308])], ["float64", pick([float("nan"), float("inf"), float("-inf"), 1.5])],
+               ["string", pick(TEXTS)], ["string", pick(TEXTS)], ["string", "a0eebc99-9c0b-4ef8-bb6d-6bb9bd380a11"], ["string", pick(["192.168.1.5/32", "10.0.0.0/8", "::1/128", "/32", "32"])],
+               ["bytes", bytes(rng.integers(0, 256, int(rng.integers(0, 20))).astype(np.uint8))], ["string", "yv66vg=="], ["time", (sec - sec % 86400, 0)],
+               ["time", (sec, int(rng.integers(0, 10 ** 9)))], ["time", (sec, int(rng.integers(0, 1000)) * 1000000)], ["time", (sec, pick([0, 120000000, 123456789, 999999999]))],
+               ["json", pick(['{"k1":"v1"}', '[1,2.5,"x",null,true]', '"just a string"', '12.5', 'null', '{"a":{"b":["<&>","\\"q\\""]},"z":1e5}'])], ["string", pick(['{"raw": "text"}', "plain"])],
+               ["jsonnum", pick(NUMS[:29])], ["jsonnum", pick(NUMS[:26] + NUMS[28:])], ["string", pick(["12345", "-7", "0", "999999999999999999"])],
+               ["string", pick(["101011110000", "0", "1", "000000000", "1000000010101110", ""])], ["string", "10101111"], ["string", "[3,7)"], ["string", pick(TEXTS)],
+               ["int64", int(rng.integers(-10, 10))]]
+        for k in range(1, len(row)):
+            if rng.integers(0, 9) == 0:
+                row[k] = ["nil", None]
+        rows.append(row)
+    return rows
+
+
+def items_of(batch, cols, meta_lists=None):
+    ids, lsns, cts = meta_lists or ([0] * batch.nrows, [0] * batch.nrows, [0] * batch.nrows)
+    kind_name = {abi.K_INSERT: "insert", abi.K_UPDATE: "update", abi.K_DELETE: "delete"}
+    out = []
+    old = getattr(batch, "old_keys", None) or []
+    pres = getattr(batch, "old_present", None)
+    for r in range(batch.nrows):
+        k = "insert" if batch.kind is None else kind_name.get(int(batch.kind[r]), "other")
+        has = bool(old) and (pres is None or bool(pres[r]))
+        out.append(E.Item(k, batch.table_ns, batch.table_name, cols, [c.name for c in batch.cols], [tuple(c.pyvalue(r)) for c in batch.cols],
+                          [c.name for c in old] if has else [], [tuple(c.pyvalue(r)) for c in old] if has else [], ids[r], lsns[r], cts[r]))
+    return out
+
+
+def emit_both(tf, batch, table, params, meta_lists=None, **kw):
+    schema = schema_of(table)
+    n = batch.nrows
+    meta = abi.row_meta(n, ids=meta_lists[0], lsns=meta_lists[1], commit_times=meta_lists[2]) if meta_lists else None
+    got = tf.debezium_emit(abi.dbz_emit_options(params, schema, **kw), tf.DeviceBatch.upload(batch), meta)
+    em = E.Emitter(params, kw.get("version") or "1.1.2.Final", drop_keys=kw.get("drop_keys", False))
+    want, rows = [], []
+    for r, it in enumerate(items_of(batch, cols_of(table), meta_lists)):
+        for kv in em.emit_kv(it, snapshot=kw.get("snapshot", False)):
+            want.append((kv[0] if kv[0] is not None else b"", kv[1]))
+            rows.append(r)
+    return got, want, rows
+
+
+def assert_same(got, want, rows):
+    msgs = got.messages()
+    assert len(msgs) == len(want)
+    assert [int(x) for x in got.msg_row] == rows
+    for i, (a, b) in enumerate(zip(msgs, want)):
+        if a != b:
+            for part in (0, 1):
+                x, y = a[part], b[part]
+                if x != y and x is not None and y is not None:
+                    k = next((j for j in range(min(len(x), len(y))) if x[j] != y[j]), min(len(x), len(y)))
+                    raise AssertionError("message %d (row %d) %s differs at byte %d:\n  device %r\n  oracle %r" % (i, rows[i], "key" if part == 0 else "value", k, x[max(0, k - 60):k + 60], y[max(0, k - 60):k + 60]))
+            assert a == b, (i, rows[i])
+
+
+@pytest.mark.parametrize("n", [1, 63, 700])
+def test_every_device_resident_type_against_the_oracle(tf, n):
+    rows = random_rows(n, 40 + n)
+    names = [t[0] for t in TABLE]
+    batch = abi.batch_from_rows(schema_of(TABLE), names, rows, "public", "basic_types")
+    rng = np.random.default_rng(n)
+    meta = ([int(x) for x in rng.integers(0, 2 ** 32, n)], [int(x) for x in rng.integers(0, 2 ** 62, n)], [int(x) for x in rng.integers(0, 2 ** 62, n)])
+    got, want, rws = emit_both(tf, batch, TABLE, PARAMS, meta)
+    assert_same(got, want, rws)
+    assert all(v is not None and json.loads(v)["payload"]["op"] == "c" for _, v in got.messages())
+    # the messages are JSON documents whose schema half names every column once
+    doc = json.loads(got.messages()[0][1])
+    assert [f["field"] for f in doc["schema"]["fields"][1]["fields"]] == names
+
+
+def crud_batch(n, seed, full_identity=False):
+    """inserts, updates (some of them moving the primary key), deletes; OldKeys = the key, or every column (REPLICA IDENTITY FULL)"""
+    table = [("id", "int32", True, "pg:integer"), ("k2", "utf8", True, "pg:text"), ("v", "int64", False, "pg:bigint"), ("s", "utf8", False, "pg:text"), ("n", "double", False, "pg:numeric(10,3)")]
+    rng = np.random.default_rng(seed)
+    rows, kinds, old_rows, present = [], [], [], []
+    for r in range(n):
+        kind = ["insert", "update", "delete"][int(rng.integers(0, 3))]
+        row = [["int32", int(rng.integers(0, 50))], ["string", "k%d" % rng.integers(0, 5)], ["int64", int(rng.integers(-99, 99))], ["string", "s%d" % r], ["jsonnum", "%d.%d" % (rng.integers(0, 999), rng.integers(0, 9999))]]
+        if rng.integers(0, 7) == 0:
+            row[2] = ["nil", None]
+        old = [list(x) for x in row]
+        if kind == "update" and rng.integers(0, 2):   # the row's key moved: its old key differs in one or both key columns
+            which = int(rng.integers(0, 3))
+            if which != 1:
+                old[0] = ["int32", int(rng.integers(50, 99))]
+            if which != 0:
+                old[1] = ["string", "was-%d" % r]
+        if kind != "insert":
+            old[3] = ["string", "before %d" % r]
+        rows.append(row)
+        kinds.append(kind)
+        old_rows.append(old)
+        present.append(kind != "insert" and (kind != "delete" or rng.integers(0, 6) != 0))
+    names = [t[0] for t in table]
+    sch = schema_of(table)
+    b = abi.batch_from_rows(sch, names, rows, "public", "crud", kinds=kinds)
+    old_names = names if full_identity else names[:2]
+    ob = abi.batch_from_rows(sch, old_names, [[o[names.index(nm)] for nm in old_names] for o in old_rows], "public", "crud")
+    b.old_keys, b.old_present = ob.cols, np.array(present, bool)
+    return table, b
+
+
+@pytest.mark.parametrize("full_identity", [False, True])
+@pytest.mark.parametrize("params", [{}, {"tombstones.on.delete": "false"}, {"dt.source.type": ""}], ids=["default", "no-tombstones", "no-source-type"])
+def test_updates_deletes_and_key_changes(tf, full_identity, params):
+    table, b = crud_batch(400, 7 + full_identity, full_identity)
+    n = b.nrows
+    meta = (list(range(100, 100 + n)), [5000 + 3 * r for r in range(n)], [1649273150231781000 + 977 * r for r in range(n)])
+    got, want, rows = emit_both(tf, b, table, dict(PARAMS, **params), meta)
+    assert_same(got, want, rows)
+    ops = [None if v is None else json.loads(v)["payload"]["op"] for _, v in got.messages()]
+    assert {"c", "u", "d"} <= set(ops) and ((None in ops) == (params.get("tombstones.on.delete") != "false"))
+    assert len(ops) > n   # deletes and key-changing updates fan out
+    if full_identity:
+        assert any(v is not None and json.loads(v)["payload"]["op"] == "u" and json.loads(v)["payload"]["before"] is not None for _, v in got.messages())
+
+
+def test_parameter_variants(tf):
+    table, b = crud_batch(60, 3)
+    n = b.nrows
+    meta = (list(range(n)), list(range(n)), [10 ** 18 + r for r in range(n)])
+    for params, kw in [({"decimal.handling.mode": "string"}, {}), ({"dt.add.original.type.info": "true"}, {}), ({}, {"drop_keys": True}), ({}, {"snapshot": True}),
+                       ({"unavailable.value.placeholder": "<toast>"}, {}), ({}, {"version": "2.0.0"}), ({"topic.prefix": "pre\"fix", "database.dbname": "dβ"}, {})]:
+        got, want, rows = emit_both(tf, b, table, dict(PARAMS, **params), meta, **kw)
+        assert_same(got, want, rows)
+    # TOAST: a schema column the rows do not carry becomes the placeholder (buildKV, emitter_value_converter.go:311-323)
+    wide = table + [("toasted", "utf8", False, "pg:text")]
+    got, want, rows = emit_both(tf, b, wide, PARAMS, meta)
+    assert_same(got, want, rows)
+    assert b'"toasted":"__debezium_unavailable_value"' in got.messages()[0][1] or b'"toasted":null' in got.messages()[0][1]
+    # no rows, and rows of a non-row kind: no messages
+    empty = abi.batch_from_rows(schema_of(table), [t[0] for t in table], [], "public", "crud")
+    assert len(tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(table)), tf.DeviceBatch.upload(empty))) == 0
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter")
+DEVICE_TYPES = ("pg:boolean", "pg:bit(1)", "pg:smallint", "pg:integer", "pg:bigint", "pg:oid", "pg:real", "pg:double precision", "pg:bytea", "pg:json", "pg:jsonb", "pg:uuid",
+                "pg:inet", "pg:int4range", "pg:int8range", "pg:daterange", "pg:text", "pg:date", "pg:cidr", "pg:macaddr", "pg:USER-DEFINED:citext")
+
+
+def device_resident(t):
+    return (t in DEVICE_TYPES or t.startswith("pg:character") or t.startswith("pg:bit(") or t.startswith("pg:bit varying(") or t.startswith("pg:timestamp") or E.is_pg_numeric(t))
+
+
+@pytest.mark.parametrize("name", ["insert", "update0", "update1", "update2", "delete"])
+def test_the_references_crud_fixtures_cut_to_the_device_columns(tf, name):
+    """the fixtures the oracle is pinned on (test_dbz_emitter_oracle.py), cut to the device-resident columns, timestamps as UTC instants
+    (what a Postgres source produces; the fixtures' +04:00 wall clocks are an artefact of their JSON round trip)"""
+    from test_dbz_emitter_oracle import read
+    it = E.unmarshal_change_item(read(name))
+    keep = [c for c in it.cols if device_resident(c.original_type)]
+    assert len(keep) >= 40
+    kn = {c.name for c in keep}
+    table = [(c.name, c.dtype, c.key, c.original_type) for c in keep]
+
+    def typed(v):
+        g, x = v
+        if g == "time":
+            return ["time", (x[0] + (x[2] if len(x) > 2 else 0), x[1])]
+        if g in ("string", "bytes", "jsonnum", "json"):
+            return [g, bytes(x)]
+        return [g, x]
+    names = [nm for nm in it.names if nm in kn]
+    if not names:   # the delete fixture carries no column values: every device column as nil keeps the batch's shape
+        names = [c.name for c in keep]
+        vals = [["nil", None] for _ in names]
+    else:
+        vals = [typed(v) for nm, v in zip(it.names, it.values) if nm in kn]
+    b = abi.batch_from_rows(schema_of(table), names, [vals], it.schema, it.table, kinds=[it.kind])
+    if it.old_names:
+        ob = abi.batch_from_rows(schema_of(table), it.old_names, [[typed(v) for v in it.old_values]], it.schema, it.table)
+        b.old_keys, b.old_present = ob.cols, np.array([True])
+    got, want, rows = emit_both(tf, b, table, PARAMS, ([it.id], [it.lsn], [it.commit_time]))
+    assert_same(got, want, rows)
+    assert len(want) == {"insert": 1, "update0": 1, "update1": 1, "update2": 3, "delete": 2}[name]
+
+
+def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
+    def call(table, rows, params=PARAMS, **kw):
+        b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "t")
+        return tf.debezium_emit(abi.dbz_emit_options(params, schema_of(table), **kw), tf.DeviceBatch.upload(b))
+    base = [("id", "int32", True, "pg:integer")]
+    for t in ("pg:interval", "pg:time without time zone", "pg:time(3) with time zone", "pg:money", "pg:point", "pg:USER-DEFINED:hstore", "pg:xml", "pg:numrange", "pg:integer[]",
+              "mysql:int(11)"):
+        with pytest.raises(tf.TfgpuError) as ei:
+            call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", "1"]]])
+        assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value) and "stock emitter" in str(ei.value), str(ei.value)
+    for params in ({"key.converter": "io.confluent.connect.json.JsonSchemaConverter"}, {"value.converter.schemas.enable": "false"}, {"dt.source.type": "mysql"},
+                   {"decimal.handling.mode": "double"}):
+        with pytest.raises(tf.TfgpuError) as ei:
+            call(base + [("x", "double", False, "pg:numeric")], [[["int32", 1], ["jsonnum", "1"]]], dict(PARAMS, **params))
+        assert ei.value.code == tf.ERR_UNSUPPORTED, str(ei.value)
+    # where the reference itself returns an error
+    for table, row, word in [(base + [("x", "utf8", False, "pg:some_unknown_type")], [["int32", 1], ["string", "1"]], "unknown pgType"),
+                             (base + [("x", "utf8", False, "")], [["int32", 1], ["string", "1"]], "unknown source type"),
+                             (base + [("x", "int32", False, "pg:integer")], [["int32", 1], ["jsonnum", "1.5"]], "unable to emit value, colName: x"),
+                             (base + [("x", "int32", False, "pg:integer")], [["int32", 1], ["string", "1"]], "unable to emit value, colName: x"),
+                             (base + [("x", "double", False, "pg:numeric")], [["int32", 1], ["string", "NaN"]], "unable to emit value, colName: x"),
+                             (base + [("x", "double", False, "pg:real")], [["int32", 1], ["float64", float("nan")]], "unable to emit value, colName: x")]:
+        with pytest.raises(tf.TfgpuError) as ei:
+            call(table, [row])
+        assert ei.value.code == tf.ERR_INVALID and word in str(ei.value), str(ei.value)
+    with pytest.raises(tf.TfgpuError) as ei:   # past 128 bits: not decided on the device
+        call(base + [("x", "double", False, "pg:numeric")], [[["int32", 1], ["jsonnum", "4" + "0" * 38]]])
+    assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value)
+    with pytest.raises(tf.TfgpuError) as ei:   # a column the schema does not know
+        b = abi.batch_from_rows(schema_of(base + [("y", "utf8", False, "pg:text")]), ["id", "y"], [[["int32", 1], ["string", "1"]]], "public", "t")
+        tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(base)), tf.DeviceBatch.upload(b))
+    assert ei.value.code == tf.ERR_INVALID and "column absent in schema: y" in str(ei.value)

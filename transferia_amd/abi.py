@@ -232,6 +232,26 @@ class CQueueOptions(C.Structure):
                 ("old_key_types", C.POINTER(C.c_char_p)), ("ngroups", C.c_int32), ("group_rows", C.c_void_p), ("group_part_ids", C.POINTER(C.c_char_p))]
 
 
+class CDbzEmitOptions(C.Structure):
+    _fields_ = [("param_keys", C.POINTER(C.c_char_p)), ("param_values", C.POINTER(C.c_char_p)), ("nparams", C.c_int32), ("version", C.c_char_p),
+                ("drop_keys", C.c_int32), ("snapshot", C.c_int32), ("table_schema", C.POINTER(CSchema))]
+
+
+def dbz_emit_options(params: dict, table_schema: "Schema", version=None, drop_keys=False, snapshot=False) -> CDbzEmitOptions:
+    """NewDebeziumSerializer's arguments (pkg/serializer/queue/debezium_serializer.go:117-127): the format settings, dropKeys, isSnapshot."""
+    o = CDbzEmitOptions()
+    items = list((params or {}).items())
+    ks = (C.c_char_p * max(len(items), 1))(*[_b(k) for k, _ in items])
+    vs = (C.c_char_p * max(len(items), 1))(*[_b(v) for _, v in items])
+    cs = table_schema.to_c()
+    o.param_keys, o.param_values, o.nparams = ks, vs, len(items)
+    o.version = _b(version) if version is not None else None
+    o.drop_keys, o.snapshot = int(bool(drop_keys)), int(bool(snapshot))
+    o.table_schema = C.pointer(cs)
+    o._keep = [ks, vs, cs]
+    return o
+
+
 def _var(strings, n):
     parts = [_b(x) for x in strings]
     off = np.zeros(n + 1, np.uint32)

@@ -1,0 +1,804 @@
+// tf_dbzemit.hip — tfgpu_debezium_emit: the Debezium EMITTER of the queue sinks, from device columns.
+//
+// Reference: queue.DebeziumSerializer.serialize (pkg/serializer/queue/debezium_serializer.go:26-43) → Emitter.EmitKV
+// (pkg/debezium/emitter_value_converter.go:574-690): 0..3 (key, value) messages per ChangeItem — one for an insert or a plain
+// update, (delete, tombstone) for a delete, (delete, tombstone, insert) for an update that changed its primary key.  Every
+// message is PackerIncludeSchema.Pack (packer/packer_include_schema.go:14-40): {"payload":P,"schema":S} with S rendered once per
+// table (ToKafkaSchemaKey / ToKafkaSchemaVal, :384-448; getFieldDescr, fields_descr.go:19-69; buildSourceSchemaDescr,
+// fields_descr_source.go:7-107) and P = valPayload (:456-527) / makeKey (:255-271), all Go maps marshalled by
+// util.JSONMarshalUnescape: members in byte order of their names, no HTML escaping.
+//
+// Here: the host renders S and a CELL LIST per stream (keys, values) — constants, converted column values (AddPg,
+// pkg/debezium/pg/emitter.go:262-629) and the op / source / ts_ms tail, each with the predicate of the events it belongs to —
+// and three kernels run it over the event list: cell lengths (grid y = cell, so descriptors are scalar), per-event layout,
+// cells written at their final place; constants longer than 64 bytes (S is kilobytes) are filled by a fourth, coalesced pass.
+// HBM-bound byte work: the schema constant dominates the bytes of a message, as it does in the reference's output.
+//
+// Device-resident original types (everything else is refused BY NAME with TFGPU_ERR_UNSUPPORTED and stays with the stock
+// emitter): pg:boolean, bit(1), smallint, integer, bigint, oid, real, double precision, text / character* / uuid / cidr /
+// macaddr / citext / int4range / int8range / daterange, inet, bytea, date, timestamp[(p)] with / without time zone (time.Time
+// values), json / jsonb, numeric[(p,s)] (precise: up to 38 digits; string), bit(n) / bit varying(n).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "tf_common.hpp"
+#include "tf_emit.hpp"
+#include "tf_devparse.hpp"
+
+namespace tf {
+namespace dbz {
+
+enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
+// which events a cell belongs to
+enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
+       EA_KEY = 8 /* every event */, EA_KEY_NEW, EA_KEY_OLD };
+enum { EV_REGULAR = 0, EV_DELETE = 1, EV_TOMBSTONE = 2, EV_INSERT = 3 };  // emitType (emitter_value_converter.go:76-97)
+enum { TN_NONE = 0, TN_LSN, TN_TS, TN_ID };
+constexpr uint32_t CONST_INLINE = 64;
+
+struct ECell {
+  DCol c;
+  uint32_t pre_off, pre_len;  // constant bytes in front of the value (EC_CONST: the constant itself)
+  uint32_t kind, apply, dk;
+  uint32_t arg;               // DK_TS: divider; DK_NUMERIC: schema scale | put-scale << 16
+  uint32_t from_old;          // the column is an OldKeys column: nil in rows without OldKeys
+};
+struct EParams {
+  const ECell *cells; int32_t ncells;
+  int64_t nev;
+  const int32_t *ev_row; const uint8_t *ev_type;  // null: event e is row e, regular
+  const uint8_t *kind; const uint8_t *old_present; const int32_t *src_row;
+  int32_t has_old, has_prev, snapshot;
+  const uint32_t *m_id; const uint64_t *m_lsn, *m_commit;
+  const uint8_t *blob;
+  uint32_t tseg_off[6], tseg_len[6]; int32_t tnum[6]; int32_t ntseg;  // EC_TAIL: ,"op":" <op> then segment k followed by number k
+  const double *p10; const uint64_t *p128;
+  uint32_t *cell;      // [ncells][nev]
+  uint32_t *ev_len;    // [nev+1]
+  unsigned long long *total64, *err;  // err[0]: first (event << 16 | cell) the reference fails on, err[1]: first one left to the host
+  uint8_t *out;
+};
+
+struct PtrView { const uint8_t *p; __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; } };
+
+__device__ __forceinline__ int64_t trunc_div(int64_t a, int64_t b) { return a / b; }  // Go and C++ both truncate toward zero
+
+__device__ __forceinline__ uint32_t event_op(const EParams &p, int64_t e, int64_t r) {
+  const uint32_t k = p.kind ? p.kind[r] : (uint32_t)TFGPU_K_INSERT;
+  const uint32_t t = p.ev_type ? p.ev_type[e] : (uint32_t)EV_REGULAR;
+  if (k == TFGPU_K_INSERT) return p.snapshot ? 'r' : 'c';
+  if (k == TFGPU_K_UPDATE) return t == EV_REGULAR ? 'u' : t == EV_DELETE ? 'd' : 'c';
+  return 'd';
+}
+__device__ __forceinline__ bool row_has_old(const EParams &p, int64_t r) { return p.has_old && (!p.old_present || ((p.old_present[r >> 3] >> (r & 7)) & 1)); }
+__device__ __forceinline__ bool applies(const EParams &p, uint32_t apply, int64_t e, int64_t r) {
+  const uint32_t t = p.ev_type ? p.ev_type[e] : (uint32_t)EV_REGULAR;
+  if (apply >= EA_KEY) {
+    if (apply == EA_KEY) return true;
+    const bool from_new = t == EV_INSERT || !row_has_old(p, r);  // makeKey: useAfter || len(OldKeys.KeyNames) == 0
+    return (apply == EA_KEY_NEW) == from_new;
+  }
+  if (t == EV_TOMBSTONE) return false;
+  const uint32_t op = event_op(p, e, r);
+  switch (apply) {
+    case EA_AFTER: return op != 'd';
+    case EA_AFTER_NULL: return op == 'd';
+    case EA_BEFORE_D: return op == 'd';
+    case EA_BEFORE_U: return op == 'u' && p.has_prev && row_has_old(p, r);
+    case EA_BEFORE_NULL: return op != 'd' && !(op == 'u' && p.has_prev && row_has_old(p, r));
+    default: return true;
+  }
+}
+
+// a JSON string whose content is itself written through emit_json_string: only '"' and '\' are left to escape
+template <class S> struct JsonEscSink {
+  S &s;
+  __device__ __forceinline__ void put(uint32_t c) { if (c == '"' || c == '\\') s.put('\\'); s.put(c); }
+};
+
+template <class S, class G> __device__ __forceinline__ void emit_base64_gen(S &s, uint32_t n, const G &get) {
+  const char *T = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+  uint32_t i = 0;
+  for (; i + 3 <= n; i += 3) {
+    const uint32_t v = get(i) << 16 | get(i + 1) << 8 | get(i + 2);
+    s.put(T[v >> 18]); s.put(T[(v >> 12) & 63]); s.put(T[(v >> 6) & 63]); s.put(T[v & 63]);
+  }
+  if (n - i == 1) { const uint32_t v = get(i) << 16; s.put(T[v >> 18]); s.put(T[(v >> 12) & 63]); s.put('='); s.put('='); }
+  else if (n - i == 2) { const uint32_t v = get(i) << 16 | get(i + 1) << 8; s.put(T[v >> 18]); s.put(T[(v >> 12) & 63]); s.put(T[(v >> 6) & 63]); s.put('='); }
+}
+
+typedef unsigned __int128 u128;
+__device__ __forceinline__ bool mul10(u128 &c, uint32_t add) {
+  const u128 lim = (~(u128)0 - 9) / 10;
+  if (c > lim) return false;
+  c = c * 10 + add;
+  return true;
+}
+// DecimalToDebeziumHandlingModePrecise (typeutil/helpers.go:269-300) over the value's text: ExponentialFloatFormToNumeric (:340-365,
+// shopspring's String()), StringFixed(schema scale) when the type has one, DecimalToDebeziumPrimitivesImpl (:388-419) — whose two's
+// complement is computed from big.Int.Bytes() of the inverted magnitude (leading zero bytes lost): restated as written.
+// 0 ok, 1 the reference fails, 2 not decided here (more than 38 digits, an exponent past ±64)
+template <class S> __device__ int emit_numeric(S &s, const uint8_t *t, uint32_t n, uint32_t schema_scale, bool put_scale) {
+  if (n == 0) return 1;  // "empty string as an input is not supported"
+  bool has_e = false, only0 = true;
+  int32_t first_dot = -1;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t c = t[i];
+    if (c == 'e' || c == 'E') has_e = true;
+    if (c == '.' && first_dot < 0) { first_dot = (int32_t)i; continue; }
+    if (c != '0' && c != '-') only0 = false;
+  }
+  bool neg = false; u128 C = 0; int32_t sc = 0;
+  bool zero_text = false;
+  if (!has_e && schema_scale == 0 && only0) { zero_text = true; sc = first_dot < 0 ? 0 : (int32_t)n - 1 - first_dot; }  // containsOnly(decimalInt, '0', '-')
+  else {
+    uint32_t i = 0;
+    bool lead_neg = false;
+    if (has_e && t[0] == '-') { lead_neg = true; i = 1; }  // the sign is split off before shopspring sees the rest
+    if (i < n && (t[i] == '+' || t[i] == '-')) { if (lead_neg) return 2; neg = t[i] == '-'; i++; }
+    if (lead_neg) neg = true;
+    uint32_t nd = 0; int32_t F = 0; bool dot = false;
+    for (; i < n; i++) {
+      const uint32_t c = t[i];
+      if (c >= '0' && c <= '9') { if (!mul10(C, c - '0')) return 2; nd++; if (dot) F++; }
+      else if (c == '.' && !dot) dot = true;
+      else break;
+    }
+    if (nd == 0) return 1;
+    int32_t E = 0;
+    if (i < n) {
+      if (t[i] != 'e' && t[i] != 'E') return 1;
+      i++;
+      bool eneg = false;
+      if (i < n && (t[i] == '+' || t[i] == '-')) { eneg = t[i] == '-'; i++; }
+      if (i >= n) return 1;
+      for (; i < n; i++) { const uint32_t c = t[i]; if (c < '0' || c > '9') return 1; E = E * 10 + (int32_t)(c - '0'); if (E > 64) return 2; }
+      if (eneg) E = -E;
+    }
+    sc = F - E;
+    if (has_e) {  // Decimal.String(): no exponent, trailing fractional zeros trimmed
+      if (C == 0) sc = 0;
+      while (sc > 0 && C % 10 == 0) { C /= 10; sc--; }
+      while (sc < 0) { if (!mul10(C, 0)) return 2; sc++; }
+    }
+    if (schema_scale > 0) {  // StringFixed: half away from zero
+      while (sc > (int32_t)schema_scale + 1) { C /= 10; sc--; }
+      if (sc == (int32_t)schema_scale + 1) { const uint32_t d = (uint32_t)(C % 10); C /= 10; if (d >= 5) C += 1; sc--; }
+      while (sc < (int32_t)schema_scale) { if (!mul10(C, 0)) return 2; sc++; }
+    }
+    if (sc < 0) return 1;
+  }
+  uint8_t buf[17]; uint32_t bn = 0;
+  if (zero_text || C == 0) { buf[0] = 0; bn = 1; }
+  else {
+    uint32_t L = 0; { u128 x = C; while (x) { L++; x >>= 8; } }
+    if (neg) {
+      const u128 mask = L == 16 ? ~(u128)0 : (((u128)1 << (8 * L)) - 1);
+      const u128 v = ((~C) & mask) + 1;   // big.Int.SetBytes(^bytes) + 1: C >= 1, so no carry out of L bytes
+      uint32_t L2 = 0; { u128 x = v; while (x) { L2++; x >>= 8; } }
+      const bool top = (uint32_t)(v >> (8 * (L2 - 1))) & 0x80u;
+      if (!top) buf[bn++] = 0xFF;
+      for (uint32_t k = 0; k < L2; k++) buf[bn++] = (uint8_t)(v >> (8 * (L2 - 1 - k)));
+    } else {
+      const bool top = (uint32_t)(C >> (8 * (L - 1))) & 0x80u;
+      if (top) buf[bn++] = 0;
+      for (uint32_t k = 0; k < L; k++) buf[bn++] = (uint8_t)(C >> (8 * (L - 1 - k)));
+    }
+  }
+  if (put_scale) { put_lit(s, "{\"scale\":"); emit_u64(s, (uint64_t)sc); put_lit(s, ",\"value\":"); }
+  s.put('"'); emit_base64_gen(s, bn, [&](uint32_t i) { return (uint32_t)buf[i]; }); s.put('"');
+  if (put_scale) s.put('}');
+  return 0;
+}
+
+template <class S> __device__ __forceinline__ int emit_int_text(S &s, const uint8_t *t, uint32_t n) {  // json.Number.Int64()
+  int64_t v; PtrView f{t};
+  if (parse_int64(f, 0, n, false, &v) != 0) return 1;
+  emit_i64(s, v);
+  return 0;
+}
+
+// AddPg for one non-nil value: 0 ok, 1 the reference returns an error, 2 left to the host
+template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell &ec, const CellBits &b) {
+  const DCol &c = ec.c;
+  uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
+  switch (ec.dk) {
+    case DK_BOOL: put_lit(s, (uint8_t)b.v ? "true" : "false"); return 0;
+    case DK_BIT1: put_lit(s, (vn == 1 && vp[0] == '1') ? "true" : "false"); return 0;
+    case DK_SMALLINT: case DK_INTEGER: case DK_BIGINT: case DK_OID:
+      if (c.repr == TFGPU_R_JSONNUM) return emit_int_text(s, vp, vn);
+      if (c.repr == TFGPU_R_FLOAT64) {  // pg:oid, restored snapshot: int64(t)
+        const double d = __longlong_as_double((long long)b.v);
+        if (!(d > -9.2e18 && d < 9.2e18)) return 2;
+        emit_i64(s, (int64_t)d); return 0;
+      }
+      emit_int(s, c, b); return 0;
+    case DK_REAL: {
+      double d;
+      if (c.repr == TFGPU_R_JSONNUM) { PtrView f{vp}; const int rc = parse_float_go(f, 0, vn, p.p10, p.p128, &d); if (rc == 3) return 2; if (rc) return 1; }
+      else d = cell_f64(c, b);
+      const float f32 = (float)d;
+      if (f32 != f32 || f32 - f32 != 0.f) return 1;  // json: unsupported value
+      dev::fmt_json_float(s, (double)f32, 32); return 0;
+    }
+    case DK_DOUBLE: {
+      double d;
+      if (c.repr == TFGPU_R_JSONNUM) { PtrView f{vp}; const int rc = parse_float_go(f, 0, vn, p.p10, p.p128, &d); if (rc == 3) return 2; if (rc) return 1; }
+      else d = cell_f64(c, b);
+      if (d != d) { put_lit(s, "\"NaN\""); return 0; }
+      if (d - d != 0) { put_lit(s, d < 0 ? "\"-Infinity\"" : "\"Infinity\""); return 0; }
+      dev::fmt_json_float(s, d, 64); return 0;
+    }
+    case DK_STRING: emit_json_string(s, vp, vn, false); return 0;
+    case DK_INET: if (vn >= 3 && vp[vn - 3] == '/' && vp[vn - 2] == '3' && vp[vn - 1] == '2') vn -= 3; emit_json_string(s, vp, vn, false); return 0;
+    case DK_BYTEA:
+      if (c.repr == TFGPU_R_BYTES) { s.put('"'); emit_base64(s, vp, vn); s.put('"'); }
+      else emit_json_string(s, vp, vn, false);
+      return 0;
+    case DK_DATE: emit_i64(s, trunc_div((int64_t)b.v, 86400)); return 0;
+    case DK_TS: emit_i64(s, trunc_div((int64_t)b.v * 1000000 + b.ns / 1000, (int64_t)ec.arg)); return 0;
+    case DK_TSTZ: s.put('"'); emit_rfc3339nano(s, (int64_t)b.v, b.ns); s.put('"'); return 0;  // SprintfDebeziumTime (helpers.go:1105-1114)
+    case DK_JSON:
+      if (c.repr == TFGPU_R_JSON) { emit_json_string(s, vp, vn, false); return 0; }  // the column holds json.Marshal's text: marshalling it again is the identity
+      { s.put('"'); JsonEscSink<S> q{s}; emit_json_string(q, vp, vn, false); s.put('"'); }  // a Go string: its marshal, as a string
+      return 0;
+    case DK_NUMERIC: return emit_numeric(s, vp, vn, ec.arg & 0xFFFFu, (ec.arg >> 16) != 0);
+    case DK_NUMERIC_TEXT: emit_json_string(s, vp, vn, false); return 0;
+    case DK_BITS: {  // ChangeItemsBitsToDebeziumHonest (helpers.go:48-78)
+      bool any = false;
+      for (uint32_t i = 0; i < vn; i++) if (vp[i] == '1') { any = true; break; }
+      s.put('"');
+      if (any) {
+        const uint32_t size = (vn + 7) / 8;
+        emit_base64_gen(s, size, [&](uint32_t j) {
+          const uint32_t k = size - 1 - j; uint32_t v = 0;
+          for (uint32_t q = 0; q < 8; q++) { const uint32_t i = 8 * k + q; if (i < vn && vp[i] == '1') v |= 1u << (7 - q); }
+          return v; });
+      }
+      s.put('"');
+      return 0;
+    }
+    case DK_WRONG_TYPE: return 1;
+    default: return 2;
+  }
+}
+
+template <class S> __device__ __forceinline__ void emit_tail(S &s, const EParams &p, int64_t e, int64_t r) {
+  const int64_t k = p.src_row ? p.src_row[r] : r;
+  const uint64_t commit = p.m_commit ? p.m_commit[k] : 0ull;
+  put_lit(s, ",\"op\":\""); s.put(event_op(p, e, r));
+  for (int q = 0; q < p.ntseg; q++) {
+    put_bytes(s, p.blob + p.tseg_off[q], p.tseg_len[q]);
+    switch (p.tnum[q]) {
+      case TN_LSN: emit_u64(s, p.m_lsn ? p.m_lsn[k] : 0ull); break;
+      case TN_TS: emit_u64(s, commit / 1000000ull); break;  // CommitTime / 1000000; GetPayloadTSMS().UnixNano() / 1000000 is the same number
+      case TN_ID: emit_u64(s, p.m_id ? p.m_id[k] : 0u); break;
+      default: break;
+    }
+  }
+}
+
+// one cell of one event; returns the error class (0 = none)
+template <class S> __device__ __forceinline__ int emit_cell(S &s, const EParams &p, const ECell &ec, int64_t e, int64_t r) {
+  if (ec.kind == EC_CONST) { put_bytes(s, p.blob + ec.pre_off, ec.pre_len); return 0; }
+  if (ec.kind == EC_TAIL) { emit_tail(s, p, e, r); return 0; }
+  put_bytes(s, p.blob + ec.pre_off, ec.pre_len);
+  if (ec.from_old && !row_has_old(p, r)) { put_lit(s, "null"); return 0; }
+  const CellBits b = load_cell(ec.c, r);
+  if (!b.valid) { put_lit(s, "null"); return 0; }
+  return emit_value(s, p, ec, b);
+}
+
+__global__ void __launch_bounds__(256) dbz_cell_len(EParams p) {
+  const int32_t ci = (int32_t)blockIdx.y; const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.nev) return;
+  const ECell &ec = p.cells[ci];
+  const int64_t r = p.ev_row ? p.ev_row[e] : e;
+  uint32_t n = 0;
+  if (applies(p, ec.apply, e, r)) {
+    if (ec.kind == EC_CONST) n = ec.pre_len;
+    else {
+      CountSink s;
+      const int rc = emit_cell(s, p, ec, e, r);
+      if (rc) atomicMin(&p.err[rc - 1], ((unsigned long long)e << 16) | (unsigned long long)ci);
+      n = s.n;
+    }
+  }
+  p.cell[(int64_t)ci * p.nev + e] = n;
+}
+__global__ void __launch_bounds__(256) dbz_event_layout(EParams p) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.nev) return;
+  uint32_t off = 0;
+  constexpr int U = 8;
+  int32_t c = 0;
+  for (; c + U <= p.ncells; c += U) {
+    uint32_t n[U];
+#pragma unroll
+    for (int q = 0; q < U; q++) n[q] = p.cell[(int64_t)(c + q) * p.nev + e];
+#pragma unroll
+    for (int q = 0; q < U; q++) { p.cell[(int64_t)(c + q) * p.nev + e] = off; off += n[q]; }
+  }
+  for (; c < p.ncells; c++) { const uint32_t n = p.cell[(int64_t)c * p.nev + e]; p.cell[(int64_t)c * p.nev + e] = off; off += n; }
+  p.ev_len[e] = off;
+  atomicAdd(p.total64, (unsigned long long)off);
+}
+__global__ void __launch_bounds__(256) dbz_cell_write(EParams p) {
+  const int32_t ci = (int32_t)blockIdx.y; const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.nev) return;
+  const ECell &ec = p.cells[ci];
+  if (ec.kind == EC_CONST && ec.pre_len > CONST_INLINE) return;  // dbz_fill_const
+  const int64_t r = p.ev_row ? p.ev_row[e] : e;
+  if (!applies(p, ec.apply, e, r)) return;
+  WriteSink w{p.out + (uint64_t)p.ev_len[e] + p.cell[(int64_t)ci * p.nev + e]};
+  emit_cell(w, p, ec, e, r);
+  w.flush();
+}
+// a long constant (the schema half of a message) into every event that holds it: one workgroup per (event, 4 KiB piece)
+__global__ void __launch_bounds__(256) dbz_fill_const(EParams p, int32_t ci, uint32_t pieces) {
+  const int64_t e = (int64_t)(blockIdx.x / pieces); const uint32_t piece = blockIdx.x % pieces;
+  const ECell &ec = p.cells[ci];
+  const int64_t r = p.ev_row ? p.ev_row[e] : e;
+  if (!applies(p, ec.apply, e, r)) return;
+  uint8_t *dst = p.out + (uint64_t)p.ev_len[e] + p.cell[(int64_t)ci * p.nev + e];
+  const uint8_t *src = p.blob + ec.pre_off;
+  const uint32_t a = piece * 4096u, b = min(a + 4096u, ec.pre_len);
+  // the destination's alignment decides the split: bytes up to its next 4-byte boundary, dwords, a byte tail
+  const uint32_t head = min((uint32_t)((4 - ((uintptr_t)(dst + a) & 3)) & 3), b - a);
+  if (threadIdx.x < head) dst[a + threadIdx.x] = src[a + threadIdx.x];
+  const uint32_t a4 = a + head, words = (b - a4) / 4;
+  struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
+  for (uint32_t w = threadIdx.x; w < words; w += 256) reinterpret_cast<uint32_t *>(dst + a4)[w] = reinterpret_cast<const U32 *>(src + a4)[w].v;
+  const uint32_t t0 = a4 + words * 4;
+  if (threadIdx.x < b - t0) dst[t0 + threadIdx.x] = src[t0 + threadIdx.x];
+}
+
+static inline unsigned blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + 255) / 256); }
+
+// ---- host: Go's JSON text -------------------------------------------------------------------------------------------------
+static void jstr(std::string &out, const std::string &s) {  // encoding/json appendString, escapeHTML = false
+  static const char *HEX = "0123456789abcdef";
+  out.push_back('"');
+  const size_t n = s.size();
+  for (size_t i = 0; i < n;) {
+    const unsigned char c = (unsigned char)s[i];
+    if (c < 0x80) {
+      if (c >= 0x20 && c != '"' && c != '\\') out.push_back((char)c);
+      else switch (c) {
+        case '"': out += "\\\""; break; case '\\': out += "\\\\"; break; case '\b': out += "\\b"; break; case '\f': out += "\\f"; break;
+        case '\n': out += "\\n"; break; case '\r': out += "\\r"; break; case '\t': out += "\\t"; break;
+        default: out += "\\u00"; out.push_back(HEX[c >> 4]); out.push_back(HEX[c & 15]);
+      }
+      i++; continue;
+    }
+    size_t need = 0; unsigned char lo = 0x80, hi = 0xBF;
+    if (c >= 0xC2 && c <= 0xDF) need = 1;
+    else if (c >= 0xE0 && c <= 0xEF) { need = 2; if (c == 0xE0) lo = 0xA0; if (c == 0xED) hi = 0x9F; }
+    else if (c >= 0xF0 && c <= 0xF4) { need = 3; if (c == 0xF0) lo = 0x90; if (c == 0xF4) hi = 0x8F; }
+    bool ok = need > 0 && i + need < n;
+    for (size_t k = 1; ok && k <= need; k++) { const unsigned char d = (unsigned char)s[i + k]; if (d < (k == 1 ? lo : 0x80) || d > (k == 1 ? hi : 0xBF)) ok = false; }
+    if (!ok) { out += "\\ufffd"; i++; continue; }
+    if (need == 2 && c == 0xE2 && (unsigned char)s[i + 1] == 0x80 && ((unsigned char)s[i + 2] == 0xA8 || (unsigned char)s[i + 2] == 0xA9)) out += (unsigned char)s[i + 2] == 0xA8 ? "\\u2028" : "\\u2029";
+    else out.append(s, i, need + 1);
+    i += need + 1;
+  }
+  out.push_back('"');
+}
+static std::string jstr(const std::string &s) { std::string o; jstr(o, s); return o; }
+
+static bool starts(const std::string &s, const char *p) { return s.compare(0, std::strlen(p), p) == 0; }
+// "pg:<what>[(d)] <with|without> time zone" (providers/postgres/type.go:140-237): d = -1 without a parameter, -2 = no match
+static int time_family(const std::string &t, const char *what, const char *tz) {
+  const std::string head = std::string("pg:") + what, tail = std::string(" ") + tz + " time zone";
+  if (!starts(t, head.c_str())) return -2;
+  size_t i = head.size();
+  int d = -1;
+  if (i + 2 < t.size() && t[i] == '(' && t[i + 1] >= '0' && t[i + 1] <= '6' && t[i + 2] == ')') { d = t[i + 1] - '0'; i += 3; }
+  return t.compare(i, std::string::npos, tail) == 0 ? d : -2;
+}
+// typeutil.IsPgNumeric / DecimalGetPrecisionAndScale (helpers.go:1142-1148, 174-195): 0 no, 1 "pg:numeric", 2 "pg:numeric(p,s)"
+static int numeric_family(const std::string &t, int *precision, int *scale) {
+  if (t == "pg:numeric") return 1;
+  if (!starts(t, "pg:numeric(")) return 0;
+  size_t i = 11; int p = 0, s = 0; size_t a = i;
+  while (i < t.size() && t[i] >= '0' && t[i] <= '9' && p < 100000) p = p * 10 + (t[i++] - '0');
+  if (i == a || i >= t.size() || t[i] != ',') return 0;
+  a = ++i;
+  while (i < t.size() && t[i] >= '0' && t[i] <= '9' && s < 100000) s = s * 10 + (t[i++] - '0');
+  if (i == a || i >= t.size() || t[i] != ')') return 0;
+  *precision = p; *scale = s;
+  return 2;
+}
+
+struct Params {
+  std::map<std::string, std::string> m;
+  const std::string &get(const char *k) const { static const std::string empty; auto it = m.find(k); return it == m.end() ? empty : it->second; }
+};
+struct ColPlan { uint32_t dk = 0, arg = 0; std::string descr; };  // the converter and the column's field description
+
+[[noreturn]] static void unsupported(const std::string &col, const std::string &what) {
+  throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: column " + col + ": " + what + " stays with the stock emitter");
+}
+// getFieldDescr (fields_descr.go:19-69) + GetKafkaTypeDescrByPgType (pg/emitter.go:222-260), and the device converter of the type
+static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
+  const std::string name = cs.name ? cs.name : "", t = cs.original_type ? cs.original_type : "";
+  ColPlan cp;
+  if (t.empty()) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unknown source type (no OriginalType; emitter_value_converter.go:188-196)");
+  if (!starts(t, "pg:")) unsupported(name, "original type " + t);
+  if (t.size() > 2 && t.compare(t.size() - 2, 2, "[]") == 0) unsupported(name, "array type " + t);
+  std::string kafka, dname, extra;  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
+  static const struct { const char *t; const char *kafka; const char *name; uint32_t dk; } PLAIN[] = {
+    {"pg:boolean", "boolean", "", DK_BOOL}, {"pg:bit(1)", "boolean", "", DK_BIT1}, {"pg:smallint", "int16", "", DK_SMALLINT}, {"pg:integer", "int32", "", DK_INTEGER},
+    {"pg:bigint", "int64", "", DK_BIGINT}, {"pg:oid", "int64", "", DK_OID}, {"pg:real", "float", "", DK_REAL}, {"pg:double precision", "double", "", DK_DOUBLE},
+    {"pg:bytea", "bytes", "", DK_BYTEA}, {"pg:json", "string", "io.debezium.data.Json", DK_JSON}, {"pg:jsonb", "string", "io.debezium.data.Json", DK_JSON},
+    {"pg:uuid", "string", "io.debezium.data.Uuid", DK_STRING}, {"pg:inet", "string", "", DK_INET}, {"pg:int4range", "string", "", DK_STRING},
+    {"pg:int8range", "string", "", DK_STRING}, {"pg:daterange", "string", "", DK_STRING}, {"pg:text", "string", "", DK_STRING},
+    {"pg:date", "int32", "io.debezium.time.Date", DK_DATE}, {"pg:cidr", "string", "", DK_STRING}, {"pg:macaddr", "string", "", DK_STRING},
+    {"pg:character", "string", "", DK_STRING}, {"pg:character varying", "string", "", DK_STRING}, {"pg:USER-DEFINED:citext", "string", "", DK_STRING}};
+  bool found = false;
+  for (auto &e : PLAIN) if (t == e.t) { kafka = e.kafka; dname = e.name; cp.dk = e.dk; found = true; break; }
+  int prec = 0, scale = 0, d;
+  if (found) {}
+  else if (t == "pg:xml" || t == "pg:point" || t == "pg:numrange" || t == "pg:tsrange" || t == "pg:tstzrange" || t == "pg:money" || t == "pg:USER-DEFINED:hstore" ||
+           starts(t, "pg:interval") || time_family(t, "time", "with") != -2 || time_family(t, "time", "without") != -2) unsupported(name, "original type " + t);
+  else if (starts(t, "pg:bit(") || starts(t, "pg:bit varying(")) {
+    const size_t a = starts(t, "pg:bit(") ? 7 : 15, z = t.find(')', a);
+    if (z == std::string::npos) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unsupported pg type, can't find closing bracket: " + t);
+    kafka = "bytes"; dname = "io.debezium.data.Bits"; extra = ",\"parameters\":{\"length\":" + jstr(t.substr(a, z - a)) + "}"; cp.dk = DK_BITS;
+  } else if (starts(t, "pg:character(") || starts(t, "pg:character varying(")) { kafka = "string"; cp.dk = DK_STRING; }
+  else if ((d = time_family(t, "timestamp", "with")) != -2) { kafka = "string"; dname = "io.debezium.time.ZonedTimestamp"; cp.dk = DK_TSTZ; }
+  else if ((d = time_family(t, "timestamp", "without")) != -2) {
+    const uint32_t divider = (d >= 1 && d <= 3) ? 1000u : 1u;  // GetTimeDivider (helpers.go:106-123)
+    kafka = "int64"; dname = divider == 1 ? "io.debezium.time.MicroTimestamp" : "io.debezium.time.Timestamp"; cp.dk = DK_TS; cp.arg = divider;
+  } else if ((d = numeric_family(t, &prec, &scale)) != 0) {
+    const std::string &mode = P.get("decimal.handling.mode");
+    if (mode == "precise") {
+      cp.dk = DK_NUMERIC;
+      if (d == 1) {
+        kafka = "struct"; dname = "io.debezium.data.VariableScaleDecimal"; cp.arg = 1u << 16;
+        extra = ",\"doc\":\"Variable scaled decimal\"";  // "doc" < "field": placed by the assembler below
+      } else {
+        if (scale > 0xFFFF) unsupported(name, "numeric scale beyond 65535");
+        kafka = "bytes"; dname = "org.apache.kafka.connect.data.Decimal"; cp.arg = (uint32_t)scale;
+        extra = ",\"parameters\":{\"connect.decimal.precision\":\"" + std::to_string(prec) + "\",\"scale\":\"" + std::to_string(scale) + "\"}";
+      }
+    } else if (mode == "string") { kafka = "string"; cp.dk = DK_NUMERIC_TEXT; }
+    else unsupported(name, "decimal.handling.mode=" + mode);
+  } else if (cs.properties_json && std::strstr(cs.properties_json, "pg:enum_all_values")) unsupported(name, "enum type " + t);
+  else {
+    const std::string &policy = P.get("dt.unknown.types.policy");
+    if (policy == "fail") throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown pgType: " + t + " (column " + name + ")");
+    unsupported(name, "dt.unknown.types.policy=" + policy + " for " + t);
+  }
+  // the description, members in key order: __dt_original_type_info, doc, field, fields, name, optional, parameters, type, version
+  std::string o = "{";
+  if (P.get("dt.add.original.type.info") == "true") o += "\"__dt_original_type_info\":{\"original_type\":" + jstr(t) + "},";
+  const bool var_scale = cp.dk == DK_NUMERIC && (cp.arg >> 16);
+  if (var_scale) o += "\"doc\":\"Variable scaled decimal\",";
+  o += "\"field\":" + jstr(name);
+  if (var_scale) o += ",\"fields\":[{\"field\":\"scale\",\"optional\":false,\"type\":\"int32\"},{\"field\":\"value\",\"optional\":false,\"type\":\"bytes\"}]";
+  if (!dname.empty()) o += ",\"name\":" + jstr(dname);
+  o += std::string(",\"optional\":") + ((cs.flags & TFGPU_COL_KEY) ? "false" : "true");
+  if (!var_scale && !extra.empty()) o += extra;
+  o += ",\"type\":" + jstr(kafka);
+  if (!dname.empty()) o += ",\"version\":1";
+  o += "}";
+  cp.descr = o;
+  return cp;
+}
+
+// which Go dynamic types AddPg takes for the type: 0 ok, 1 the reference's "unknown type of value", 2 host
+static int repr_ok(uint32_t dk, int repr) {
+  auto in = [&](std::initializer_list<int> l) { for (int x : l) if (x == repr) return true; return false; };
+  switch (dk) {
+    case DK_BOOL: return in({TFGPU_R_BOOL}) ? 0 : 2;
+    case DK_BIT1: case DK_STRING: case DK_INET: case DK_BITS: return in({TFGPU_R_STRING}) ? 0 : 2;
+    case DK_SMALLINT: return in({TFGPU_R_INT16, TFGPU_R_INT64, TFGPU_R_JSONNUM}) ? 0 : 1;
+    case DK_INTEGER: return in({TFGPU_R_INT32, TFGPU_R_INT64, TFGPU_R_JSONNUM}) ? 0 : 1;
+    case DK_BIGINT: return in({TFGPU_R_INT64, TFGPU_R_JSONNUM}) ? 0 : 1;
+    case DK_OID: return in({TFGPU_R_INT32, TFGPU_R_INT64, TFGPU_R_UINT32, TFGPU_R_FLOAT64, TFGPU_R_JSONNUM}) ? 0 : 1;
+    case DK_REAL: return in({TFGPU_R_FLOAT32, TFGPU_R_FLOAT64, TFGPU_R_JSONNUM}) ? 0 : 1;
+    case DK_DOUBLE: return in({TFGPU_R_FLOAT64, TFGPU_R_JSONNUM}) ? 0 : 1;
+    case DK_BYTEA: return in({TFGPU_R_STRING, TFGPU_R_BYTES}) ? 0 : 1;
+    case DK_DATE: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
+    case DK_TS: return in({TFGPU_R_TIME}) ? 0 : 2;
+    case DK_TSTZ: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
+    case DK_JSON: return in({TFGPU_R_JSON, TFGPU_R_STRING}) ? 0 : 2;
+    case DK_NUMERIC: case DK_NUMERIC_TEXT: return in({TFGPU_R_STRING, TFGPU_R_JSONNUM}) ? 0 : 1;
+    default: return 2;
+  }
+}
+
+// one stream's cells
+struct CellList {
+  std::vector<ECell> cells;
+  std::string *blob;
+  void push_const(uint32_t apply, const std::string &text) {
+    if (text.empty()) return;
+    if (!cells.empty() && cells.back().kind == EC_CONST && cells.back().apply == apply && cells.back().pre_off + cells.back().pre_len == blob->size()) {
+      *blob += text; cells.back().pre_len += (uint32_t)text.size(); return;
+    }
+    ECell c{}; c.kind = EC_CONST; c.apply = apply; c.pre_off = (uint32_t)blob->size(); c.pre_len = (uint32_t)text.size();
+    *blob += text; cells.push_back(c);
+  }
+  void push_value(uint32_t apply, const std::string &prefix, const DColumn &col, const ColPlan &cp, bool from_old) {
+    // a Go type AddPg does not take for this column fails (or leaves to the host) the first NON-NIL value of it, as the reference's type
+    // switches do: a column of nils has no type to object to
+    const int rk = repr_ok(cp.dk, col.repr);
+    ECell c{}; c.kind = EC_VALUE; c.apply = apply; c.pre_off = (uint32_t)blob->size(); c.pre_len = (uint32_t)prefix.size();
+    *blob += prefix; c.c = dcol_of(col); c.dk = rk ? (uint32_t)(DK_WRONG_TYPE + rk - 1) : cp.dk; c.arg = cp.arg; c.from_old = from_old ? 1u : 0u;
+    cells.push_back(c);
+  }
+};
+struct Member { std::string name; const DColumn *col; const ColPlan *plan; bool from_old; std::string constant; };
+// one Go map as an object: members in key order, `{` … `}` (or `{}`)
+static void push_object(CellList &L, uint32_t apply, std::vector<Member> ms) {
+  std::stable_sort(ms.begin(), ms.end(), [](const Member &a, const Member &b) { return a.name < b.name; });
+  for (size_t i = 1; i < ms.size(); i++) if (ms[i].name == ms[i - 1].name) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: column name " + ms[i].name + " repeats: stays with the stock emitter");
+  if (ms.empty()) { L.push_const(apply, "{}"); return; }
+  for (size_t i = 0; i < ms.size(); i++) {
+    const std::string pre = std::string(i ? "," : "{") + jstr(ms[i].name) + ":";
+    if (ms[i].col) L.push_value(apply, pre, *ms[i].col, *ms[i].plan, ms[i].from_old);
+    else L.push_const(apply, pre + ms[i].constant);
+  }
+  L.push_const(apply, "}");
+}
+
+struct Stream { Buf out; std::vector<uint32_t> start; uint64_t total = 0; };
+
+static Stream run_stream(EParams p, const CellList &L, const std::string &blob, hipStream_t st, const char *what) {
+  Stream S;
+  const int64_t nev = p.nev;
+  Buf dcells = upload_small(L.cells.data(), L.cells.size() * sizeof(ECell));
+  std::string padded = blob; padded.append(16, '\0');  // the text readers load whole words
+  Buf dblob = upload_small(padded.data(), padded.size());
+  Buf cell = dalloc((size_t)L.cells.size() * nev * 4 + 16), ev_len = dalloc((size_t)(nev + 1) * 4 + 16), acc = dalloc_zero(8);
+  Buf err = dalloc(16);
+  TF_HIP(hipMemsetAsync(err->p, 0xFF, 16, st));
+  p.cells = ptr<ECell>(dcells); p.ncells = (int32_t)L.cells.size(); p.blob = ptr<uint8_t>(dblob);
+  p.cell = ptr<uint32_t>(cell); p.ev_len = ptr<uint32_t>(ev_len); p.total64 = ptr<unsigned long long>(acc); p.err = ptr<unsigned long long>(err);
+  { KernelTimer t("dbz_cell_len"); dbz_cell_len<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
+  { KernelTimer t("dbz_event_layout"); dbz_event_layout<<<blocks(nev), 256, 0, st>>>(p); }
+  uint64_t host[3];
+  d2h(host, acc->p, 8); d2h(host + 1, err->p, 16);
+  sync();
+  if (host[1] != ~0ull || host[2] != ~0ull) {
+    const bool invalid = host[1] != ~0ull && (host[2] == ~0ull || host[1] <= host[2]);
+    const uint64_t key = invalid ? host[1] : host[2];
+    const int64_t e = (int64_t)(key >> 16); const uint32_t ci = (uint32_t)(key & 0xFFFF);
+    std::string nm = "?";
+    {  // the member name is the tail of the cell's prefix: …"name":
+      const ECell &ec = L.cells[ci]; std::string pre = blob.substr(ec.pre_off, ec.pre_len);
+      const size_t q2 = pre.rfind("\":"), q1 = q2 == std::string::npos ? q2 : pre.rfind('"', q2 - 1);
+      if (q1 != std::string::npos) nm = pre.substr(q1 + 1, q2 - q1 - 1);
+    }
+    if (invalid) throw Error(TFGPU_ERR_INVALID, std::string("tfgpu_debezium_emit: ") + what + " of event " + std::to_string(e) + ": unable to emit value, colName: " + nm);
+    throw Error(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + what + " of event " + std::to_string(e) + ", column " + nm +
+                ": a value the device leaves to the stock emitter (a Go type it does not convert for this column, a numeric beyond 38 digits, a float text Go decides with big arithmetic)");
+  }
+  S.total = host[0];
+  if (S.total > 0xFFFFFFF0ull) throw Error(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + what + "s of one call exceed 4 GiB (" + std::to_string(S.total) + " bytes): emit the batch in slices");
+  exclusive_scan_u32(p.ev_len, p.ev_len, nev, true);
+  S.out = dalloc(S.total + 64);
+  p.out = ptr<uint8_t>(S.out);
+  { KernelTimer t("dbz_cell_write"); dbz_cell_write<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
+  for (size_t ci = 0; ci < L.cells.size(); ci++) if (L.cells[ci].kind == EC_CONST && L.cells[ci].pre_len > CONST_INLINE) {
+    const uint32_t pieces = (L.cells[ci].pre_len + 4095) / 4096;
+    if ((uint64_t)nev * pieces > 0x7FFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: too many events for one call");
+    KernelTimer t("dbz_fill_const");
+    dbz_fill_const<<<(unsigned)(nev * pieces), 256, 0, st>>>(p, (int32_t)ci, pieces);
+  }
+  S.start.resize((size_t)nev + 1);
+  d2h(S.start.data(), p.ev_len, (size_t)(nev + 1) * 4);
+  sync();
+  return S;
+}
+
+}  // namespace dbz
+
+int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags);  // tf_collapse.hip
+template <class T> static const T *dbz_meta(const tfgpu_row_meta *m, const T *p, size_t count, std::vector<Buf> &keep) {
+  if (!m || !p) return nullptr;
+  if (m->mem == TFGPU_MEM_DEVICE) return p;
+  Buf d = dalloc(count * sizeof(T) + 16);
+  h2d(d->p, p, count * sizeof(T));
+  keep.push_back(d);
+  return reinterpret_cast<const T *>(d->p);
+}
+}  // namespace tf
+
+extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_dbatch *b, const tfgpu_row_meta *meta, tfgpu_dbuf **keys, uint64_t *key_start,
+                                   tfgpu_dbuf **values, uint64_t *val_start, uint8_t *val_null, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
+  using namespace tf; using namespace tf::dbz;
+  try {
+    if (!o || !b || !keys || !values || !nmsg || !o->table_schema || (cap > 0 && (!key_start || !val_start || !val_null || !msg_row)))
+      return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: null argument");
+    Context &cx = ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    hipStream_t st = cx.stream;
+    const int64_t n = b->nrows;
+    // ---- connector parameters (parameters.go:140-215) ----
+    Params P;
+    static const char *const DEFAULTS[][2] = {{"database.dbname", ""}, {"topic.prefix", ""}, {"dt.unknown.types.policy", "fail"}, {"dt.add.original.type.info", "false"},
+      {"dt.source.type", ""}, {"decimal.handling.mode", "precise"}, {"tombstones.on.delete", "true"}, {"binary.handling.mode", "bytes"},
+      {"unavailable.value.placeholder", "__debezium_unavailable_value"}, {"key.converter", "org.apache.kafka.connect.json.JsonConverter"},
+      {"value.converter", "org.apache.kafka.connect.json.JsonConverter"}, {"key.converter.schemas.enable", "true"}, {"value.converter.schemas.enable", "true"}};
+    for (auto &d : DEFAULTS) P.m[d[0]] = d[1];
+    for (int i = 0; i < o->nparams; i++) if (o->param_keys[i]) P.m[o->param_keys[i]] = o->param_values[i] ? o->param_values[i] : "";
+    for (const char *k : {"key.converter", "value.converter"}) if (P.get(k) != "org.apache.kafka.connect.json.JsonConverter") return fail(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + k + "=" + P.get(k) + " (schema registry packers) stays with the stock emitter");
+    for (const char *k : {"key.converter.schemas.enable", "value.converter.schemas.enable"}) if (P.get(k) != "true") return fail(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + k + "=false (PackerSkipSchema) stays with the stock emitter");
+    if (P.get("binary.handling.mode") != "bytes") return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unsupported binary.handling.mode: " + P.get("binary.handling.mode"));
+    const std::string &source_type = P.get("dt.source.type");
+    if (!source_type.empty() && source_type != "pg") return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: dt.source.type=" + source_type + " stays with the stock emitter");
+    const std::string server = P.get("topic.prefix"), database = P.get("database.dbname"), version = o->version ? o->version : "1.1.2.Final";
+    const bool skip_tombstones = P.get("tombstones.on.delete") == "false";
+
+    auto kres = std::make_unique<tfgpu_dbuf>(), vres = std::make_unique<tfgpu_dbuf>();
+    if (n == 0) { kres->mem = dalloc(64); vres->mem = dalloc(64); *keys = kres.release(); *values = vres.release(); *nmsg = 0; if (cap >= 0 && key_start) { key_start[0] = 0; val_start[0] = 0; } return TFGPU_OK; }
+    if (meta && meta->n < 0) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: row meta with a negative length");
+    materialize(*b);
+
+    // ---- the table's columns ----
+    const tfgpu_schema &ts = *o->table_schema;
+    std::map<std::string, int> index;
+    std::vector<ColPlan> plans((size_t)ts.ncols);
+    int npk = 0;
+    for (int i = 0; i < ts.ncols; i++) {
+      const std::string nm = ts.cols[i].name ? ts.cols[i].name : "";
+      index[nm] = i;   // mapColToIndex: the last one of a repeated name
+      plans[(size_t)i] = plan_column(ts.cols[i], P);
+      if (ts.cols[i].flags & TFGPU_COL_KEY) npk++;
+    }
+    auto col_index = [&](const std::string &nm) -> int {
+      auto it = index.find(nm);
+      if (it == index.end()) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: invalid changeItem - column absent in schema: " + nm);
+      return it->second;
+    };
+    const bool has_old = !b->old_keys.empty();
+    const bool has_prev = (int)b->old_keys.size() > npk;  // hasPreviousValues (emitter_value_converter.go:274-283)
+
+    // ---- the schema halves (ToKafkaSchemaKey / ToKafkaSchemaVal) ----
+    std::string fields_all, fields_key;
+    for (int i = 0; i < ts.ncols; i++) {
+      if (!fields_all.empty()) fields_all += ",";
+      fields_all += plans[(size_t)i].descr;
+      if (ts.cols[i].flags & TFGPU_COL_KEY) { if (!fields_key.empty()) fields_key += ","; fields_key += plans[(size_t)i].descr; }
+    }
+    const std::string record = server + "." + b->ns + "." + b->table;
+    const std::string key_schema = "{\"fields\":[" + fields_key + "],\"name\":" + jstr(record + ".Key") + ",\"optional\":false,\"type\":\"struct\"}";
+    auto side = [&](const char *field) { return "{\"field\":\"" + std::string(field) + "\",\"fields\":[" + fields_all + "],\"name\":" + jstr(record + ".Value") + ",\"optional\":true,\"type\":\"struct\"}"; };
+    auto f = [](const char *field, const char *type, bool optional) { return std::string("{\"field\":\"") + field + "\",\"optional\":" + (optional ? "true" : "false") + ",\"type\":\"" + type + "\"}"; };
+    std::string src_fields = f("version", "string", false) + "," + f("connector", "string", false) + "," + f("name", "string", false) + "," + f("ts_ms", "int64", false) +
+      ",{\"default\":\"false\",\"field\":\"snapshot\",\"name\":\"io.debezium.data.Enum\",\"optional\":true,\"parameters\":{\"allowed\":\"true,last,false\"},\"type\":\"string\",\"version\":1}," +
+      f("db", "string", false) + "," + f("table", "string", false);
+    std::string src_schema = "{\"field\":\"source\",\"fields\":[";
+    if (source_type == "pg") src_fields += "," + f("lsn", "int64", true) + "," + f("schema", "string", false) + "," + f("txId", "int64", true) + "," + f("xmin", "int64", true);
+    src_schema += src_fields + "],";
+    if (source_type == "pg") src_schema += "\"name\":\"io.debezium.connector.postgresql.Source\",";
+    src_schema += "\"optional\":false,\"type\":\"struct\"}";
+    const std::string tx_schema = "{\"field\":\"transaction\",\"fields\":[" + f("id", "string", false) + "," + f("total_order", "int64", false) + "," + f("data_collection_order", "int64", false) + "],\"optional\":true,\"type\":\"struct\"}";
+    const std::string val_schema = "{\"fields\":[" + side("before") + "," + side("after") + "," + src_schema + "," + f("op", "string", false) + "," + f("ts_ms", "int64", true) + "," + tx_schema +
+      "],\"name\":" + jstr(record + ".Envelope") + ",\"optional\":false,\"type\":\"struct\"}";
+
+    // ---- events ----
+    std::vector<int32_t> ev_row; std::vector<uint8_t> ev_type;
+    bool identity = true;
+    if (b->kind) {
+      std::vector<uint8_t> kinds((size_t)n), changed((size_t)n, 0);
+      d2h(kinds.data(), b->kind->p, (size_t)n); sync();
+      bool any_update = false, only_inserts = true;
+      for (int64_t r = 0; r < n; r++) { if (kinds[(size_t)r] == TFGPU_K_UPDATE) any_update = true; if (kinds[(size_t)r] != TFGPU_K_INSERT) only_inserts = false; }
+      if (!only_inserts) {
+        identity = false;
+        if (any_update) {  // ChangeItem.KeysChanged (change_item.go:237-286) over the TableSchema's PrimaryKey columns — the ones `table_schema` flags
+          tfgpu_dbatch view;
+          view.nrows = n; view.cols = b->cols; view.old_keys = b->old_keys; view.old_present = b->old_present; view.kind = b->kind;
+          for (int i = 0; i < ts.ncols; i++) if (ts.cols[i].flags & TFGPU_COL_KEY) view.key_names.push_back(ts.cols[i].name ? ts.cols[i].name : "");
+          keys_changed_rows(view, changed.data());
+        }
+        for (int64_t r = 0; r < n; r++) {
+          const uint8_t k = kinds[(size_t)r];
+          auto ev = [&](uint8_t t) { ev_row.push_back((int32_t)r); ev_type.push_back(t); };
+          if (k == TFGPU_K_INSERT) ev(EV_REGULAR);
+          else if (k == TFGPU_K_UPDATE) { if (changed[(size_t)r]) { ev(EV_DELETE); if (!skip_tombstones) ev(EV_TOMBSTONE); ev(EV_INSERT); } else ev(EV_REGULAR); }
+          else if (k == TFGPU_K_DELETE) { ev(EV_DELETE); if (!skip_tombstones) ev(EV_TOMBSTONE); }
+          // other kinds emit nothing (emitKV :630-632)
+        }
+      }
+    }
+    const int64_t nev = identity ? n : (int64_t)ev_row.size();
+    if (cap >= 0 && nev > cap) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: " + std::to_string(nev) + " messages, room for " + std::to_string(cap));
+    *nmsg = nev;
+    if (nev == 0) { kres->mem = dalloc(64); vres->mem = dalloc(64); *keys = kres.release(); *values = vres.release(); if (key_start) { key_start[0] = 0; val_start[0] = 0; } return TFGPU_OK; }
+
+    std::vector<Buf> keep;
+    EParams p{};
+    p.nev = nev;
+    if (!identity) {
+      Buf a = dalloc((size_t)nev * 4 + 16), t = dalloc((size_t)nev + 16);
+      h2d(a->p, ev_row.data(), (size_t)nev * 4); h2d(t->p, ev_type.data(), (size_t)nev);
+      keep.push_back(a); keep.push_back(t);
+      p.ev_row = ptr<int32_t>(a); p.ev_type = ptr<uint8_t>(t);
+    }
+    p.kind = ptr<uint8_t>(b->kind); p.old_present = ptr<uint8_t>(b->old_present); p.src_row = ptr<int32_t>(b->src_row);
+    p.has_old = has_old; p.has_prev = has_prev; p.snapshot = o->snapshot ? 1 : 0;
+    if (meta) {
+      // every row's entry must exist: src_row (or the row index) is below meta->n
+      if (!b->src_row && meta->n < n) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: row meta shorter than the batch");
+      p.m_id = dbz_meta(meta, meta->id, (size_t)meta->n, keep); p.m_lsn = dbz_meta(meta, meta->lsn, (size_t)meta->n, keep); p.m_commit = dbz_meta(meta, meta->commit_time, (size_t)meta->n, keep);
+    }
+    p.p10 = pow10_table(); p.p128 = reinterpret_cast<const uint64_t *>(p.p10 + 632);
+
+    // ---- values: {"payload":{"after":A,"before":B,"op":…,"source":{…},"transaction":null,"ts_ms":N},"schema":S} ----
+    std::string blob;
+    CellList V; V.blob = &blob;
+    {
+      V.push_const(EA_VALUE, "{\"payload\":{\"after\":");
+      V.push_const(EA_AFTER_NULL, "null");
+      std::vector<Member> after;
+      std::vector<char> in_batch((size_t)ts.ncols, 0);
+      for (auto &c : b->cols) { const int i = col_index(c.name); in_batch[(size_t)i] = 1; after.push_back({c.name, &c, &plans[(size_t)i], false, ""}); }
+      if (ts.ncols > (int)b->cols.size())  // TOAST (buildKV :311-323)
+        for (int i = 0; i < ts.ncols; i++) if (!in_batch[(size_t)i]) after.push_back({ts.cols[i].name ? ts.cols[i].name : "", nullptr, nullptr, false, jstr(P.get("unavailable.value.placeholder"))});
+      push_object(V, EA_AFTER, after);
+      V.push_const(EA_VALUE, ",\"before\":");
+      V.push_const(EA_BEFORE_NULL, "null");
+      std::vector<Member> before_d, before_u;
+      std::vector<char> in_old((size_t)ts.ncols, 0);
+      for (auto &c : b->old_keys) { const int i = col_index(c.name); in_old[(size_t)i] = 1; before_d.push_back({c.name, &c, &plans[(size_t)i], true, ""}); before_u.push_back({c.name, &c, &plans[(size_t)i], true, ""}); }
+      for (int i = 0; i < ts.ncols; i++) if (!in_old[(size_t)i] && index[ts.cols[i].name ? ts.cols[i].name : ""] == i) before_d.push_back({ts.cols[i].name ? ts.cols[i].name : "", nullptr, nullptr, false, "null"});
+      push_object(V, EA_BEFORE_D, before_d);
+      if (has_prev) push_object(V, EA_BEFORE_U, before_u);
+      ECell tail{}; tail.kind = EC_TAIL; tail.apply = EA_VALUE; V.cells.push_back(tail);
+      V.push_const(EA_VALUE, ",\"schema\":" + val_schema + "}");
+      // the tail's segments: source is a map too — connector, db, lsn, name, schema, snapshot, table, ts_ms, txId, version, xmin
+      std::vector<std::pair<std::string, int>> segs;
+      const std::string snap = o->snapshot ? "true" : "false";
+      if (source_type == "pg") {
+        segs.push_back({"\",\"source\":{\"connector\":\"postgresql\",\"db\":" + jstr(database) + ",\"lsn\":", TN_LSN});
+        segs.push_back({",\"name\":" + jstr(server) + ",\"schema\":" + jstr(b->ns) + ",\"snapshot\":\"" + snap + "\",\"table\":" + jstr(b->table) + ",\"ts_ms\":", TN_TS});
+        segs.push_back({",\"txId\":", TN_ID});
+        segs.push_back({",\"version\":" + jstr(version) + ",\"xmin\":null},\"transaction\":null,\"ts_ms\":", TN_TS});
+      } else {
+        segs.push_back({"\",\"source\":{\"db\":" + jstr(database) + ",\"name\":" + jstr(server) + ",\"snapshot\":\"" + snap + "\",\"table\":" + jstr(b->table) + ",\"ts_ms\":", TN_TS});
+        segs.push_back({",\"version\":" + jstr(version) + "},\"transaction\":null,\"ts_ms\":", TN_TS});
+      }
+      segs.push_back({"}", TN_NONE});
+      p.ntseg = (int32_t)segs.size();
+      for (size_t q = 0; q < segs.size(); q++) { p.tseg_off[q] = (uint32_t)blob.size(); p.tseg_len[q] = (uint32_t)segs[q].first.size(); p.tnum[q] = segs[q].second; blob += segs[q].first; }
+    }
+    // ---- keys: {"payload":{pk members},"schema":KS} ----
+    CellList K; K.blob = &blob;
+    if (!o->drop_keys) {
+      K.push_const(EA_KEY, "{\"payload\":");
+      std::vector<Member> from_new, from_old;
+      for (auto &c : b->cols) { const int i = col_index(c.name); if (ts.cols[i].flags & TFGPU_COL_KEY) from_new.push_back({c.name, &c, &plans[(size_t)i], false, ""}); }
+      for (auto &c : b->old_keys) { const int i = col_index(c.name); if (ts.cols[i].flags & TFGPU_COL_KEY) from_old.push_back({c.name, &c, &plans[(size_t)i], true, ""}); }
+      push_object(K, EA_KEY_NEW, from_new);
+      if (has_old) push_object(K, EA_KEY_OLD, from_old);
+      K.push_const(EA_KEY, ",\"schema\":" + key_schema + "}");
+    }
+    if (V.cells.size() > 0xFFFF || K.cells.size() > 0xFFFF) return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: more than 65535 cells per message");
+
+    Stream SV = run_stream(p, V, blob, st, "value");
+    Stream SK;
+    if (!o->drop_keys) SK = run_stream(p, K, blob, st, "key");
+    else { SK.out = dalloc(64); SK.start.assign((size_t)nev + 1, 0u); }
+    kres->mem = SK.out; kres->size = SK.total; vres->mem = SV.out; vres->size = SV.total;
+    for (int64_t e = 0; e <= nev; e++) { key_start[e] = SK.start[(size_t)e]; val_start[e] = SV.start[(size_t)e]; }
+    for (int64_t e = 0; e < nev; e++) {
+      val_null[e] = (!identity && ev_type[(size_t)e] == EV_TOMBSTONE) ? 1 : 0;
+      msg_row[e] = identity ? e : ev_row[(size_t)e];
+    }
+    *keys = kres.release(); *values = vres.release();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}

@@ -29,7 +29,7 @@ EXPORTS = [
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_from_config", "tfgpu_transformation_size", "tfgpu_transformation_plan_type", "tfgpu_transformation_errors_output", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
-    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_debezium_emit", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -116,6 +116,7 @@ def load():
                                       C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_serialize.argtypes = [C.c_int, P, C.POINTER(P)]
     L.tfgpu_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(P)]
+    L.tfgpu_debezium_emit.argtypes = [C.POINTER(abi.CDbzEmitOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(P), P, C.POINTER(P), P, P, P, C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_queue_serialize.argtypes = [C.POINTER(abi.CQueueOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(P), P, P, C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_dbuf_size.argtypes = [P, C.POINTER(C.c_uint64)]
     L.tfgpu_dbuf_ptr.argtypes = [P]
@@ -907,6 +908,36 @@ def queue_serialize(opts: abi.CQueueOptions, batch: DeviceBatch, meta: Optional[
                                         start.ctypes.data, row.ctypes.data, cap, C.byref(n)))
     k = int(n.value)
     return QueueMessages(DeviceBuffer(out), start[:k + 1].copy(), row[:k + 1].copy())
+
+
+class DebeziumMessages:
+    """Emitter.EmitKV's (key, value) pairs for one table's rows: keys and values back to back in HBM, where each one starts, which
+    values are nil (tombstones) and the batch row every message came from."""
+
+    def __init__(self, keys: DeviceBuffer, key_start, values: DeviceBuffer, val_start, val_null, msg_row):
+        self.keys, self.key_start, self.values, self.val_start, self.val_null, self.msg_row = keys, key_start, values, val_start, val_null, msg_row
+
+    def __len__(self):
+        return len(self.msg_row)
+
+    def messages(self):
+        """[(key bytes, value bytes or None)]"""
+        k, v = self.keys.download(), self.values.download()
+        return [(k[int(self.key_start[i]):int(self.key_start[i + 1])], None if self.val_null[i] else v[int(self.val_start[i]):int(self.val_start[i + 1])])
+                for i in range(len(self))]
+
+
+def debezium_emit(opts: abi.CDbzEmitOptions, batch: DeviceBatch, meta: Optional[abi.CRowMeta] = None) -> DebeziumMessages:
+    """queue.DebeziumSerializer (pkg/serializer/queue/debezium_serializer.go) for one table's rows, from device columns."""
+    init()
+    cap = 3 * batch.nrows
+    ks, vs = np.zeros(cap + 1, np.uint64), np.zeros(cap + 1, np.uint64)
+    nul, row = np.zeros(cap + 1, np.uint8), np.zeros(cap + 1, np.int64)
+    ko, vo, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+    _check(load().tfgpu_debezium_emit(C.byref(opts), batch._h, C.byref(meta) if meta is not None else None, C.byref(ko), ks.ctypes.data, C.byref(vo),
+                                      vs.ctypes.data, nul.ctypes.data, row.ctypes.data, cap, C.byref(n)))
+    k = int(n.value)
+    return DebeziumMessages(DeviceBuffer(ko), ks[:k + 1].copy(), DeviceBuffer(vo), vs[:k + 1].copy(), nul[:k].copy(), row[:k].copy())
 
 
 def fqtn(ns: str, table: str) -> str:
