@@ -935,6 +935,17 @@ class Configs4Workload(Base):
         self.db = lib.DeviceBatch.upload(b)
         self.shard = lib.Transformer("sharder_transformer", {"shardsCount": str(e.world), "columns": {"includeColumns": ["^id$"]}, "tables": {}})
         self.qopts = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 20, table_schema=self.schema)
+        self.debezium = getattr(a, "sink", "native") == "debezium"
+        if self.debezium:
+            # the same table as a Postgres source describes it (OriginalType per column), the serializer's settings as the Kafka sink passes them
+            self.pg_schema = abi.Schema([abi.ColSchema(c.name, c.dtype, c.key, "", "pg:text" if c.dtype == "utf8" else "pg:bigint") for c in self.schema.cols])
+            self.dbz_params = {"database.dbname": "db", "topic.prefix": "srv", "dt.source.type": "pg"}
+            self.dopts = abi.dbz_emit_options(self.dbz_params, self.pg_schema)
+            self.metric = "ChangeItems/sec through hash-partition (RCCL all-to-all) -> Collapse -> Debezium emitter (key + value, inline schemas), CDC stream"
+            tb, _ = e.workload.cdc_batch(64, seed=1)
+            tiny = lib.debezium_emit(self.dopts, lib.DeviceBatch.upload(tb), abi.row_meta(64, ids=np.arange(64), lsns=np.arange(64, dtype=np.uint64), commit_times=np.full(64, 1, np.uint64)))
+            k0, v0 = next((k, v) for k, v in tiny.messages() if v is not None)
+            self.const_key, self.const_val = len(k0) - k0.index(b',"schema":'), len(v0) - v0.index(b',"schema":')   # the constant tails dbz_fill_const writes
         self.meta = abi.row_meta(self.n, ids=np.arange(self.n) % 97, lsns=np.arange(self.n, dtype=np.uint64) + 5, commit_times=np.full(self.n, 1700000000000000000, np.uint64))
         if e.world > 1:
             import torch.distributed as dist
@@ -959,19 +970,30 @@ class Configs4Workload(Base):
         else:
             back = grouped
         col = lib.collapse(back)
-        out = lib.queue_serialize(self.qopts, col, self.meta if e.world == 1 else None)
-        if keep:
-            self.state.update(in_bytes=self.db.payload_bytes(), out_rows=col.nrows, out_bytes=out.values.size, messages=len(out))
+        if self.debezium:
+            out = lib.debezium_emit(self.dopts, col, self.meta if e.world == 1 else None)
+            if keep:
+                nv = int(len(out) - out.val_null.sum())
+                self.state.update(in_bytes=self.db.payload_bytes(), out_rows=col.nrows, out_bytes=out.values.size + out.keys.size, messages=len(out),
+                                  const_bytes=len(out) * self.const_key + nv * self.const_val, tombstones=int(out.val_null.sum()))
+            out.keys.free()
+        else:
+            out = lib.queue_serialize(self.qopts, col, self.meta if e.world == 1 else None)
+            if keep:
+                self.state.update(in_bytes=self.db.payload_bytes(), out_rows=col.nrows, out_bytes=out.values.size, messages=len(out))
         out.values.free(); col.free(); back.free(); one.free()
 
     def alg(self):
         s = self.state
+        if self.debezium:   # dbz_fill_const writes the schema halves (their source is a few KB, cache-resident); the cell pass reads the columns and writes the payload halves
+            return {"dbz_fill_const": s["const_bytes"], "dbz_cell_write": s["in_bytes"] + s["out_bytes"] - s["const_bytes"], "compact_gather": 2 * s["in_bytes"], "sharder_crc32": 12 * self.n}
         return {"ser_cell_write": s["in_bytes"] + s["out_bytes"], "compact_gather": 2 * s["in_bytes"], "sharder_crc32": 12 * self.n}
 
     def config(self):
         e = self.env
         return {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys) -> sharder CRC32 % world -> tfgpu_partition -> all-to-all -> Collapse -> "
-                            "native queue serializer (BASELINE.json configs[4] from the decoded batch on)", "rows_per_gpu_per_step": self.n,
+                            + ("Debezium emitter: Emitter.EmitKV per row, key + value, PackerIncludeSchema" if self.debezium else "native queue serializer") +
+                            " (BASELINE.json configs[4] from the decoded batch on)", "rows_per_gpu_per_step": self.n, "sink": "debezium" if self.debezium else "native",
                 "exchange": "tfgpu_exchange: one grouped RCCL send/recv over all column buffers" if self.comm is not None else "none (1 rank: every row stays)",
                 "parallelism": f"hash-partition x{e.world}"}
 
@@ -988,6 +1010,29 @@ class Configs4Workload(Base):
         a = r1.batch
         a.schema = s2
         meta = e.abi.row_meta(k, ids=np.arange(k) % 97, lsns=np.arange(k, dtype=np.uint64) + 5, commit_times=np.full(k, 1700000000000000000, np.uint64))
+        if self.debezium:
+            import time
+            from oracle import dbz_emitter as E
+            em = E.Emitter(self.dbz_params, "1.1.2.Final")
+            cols = [E.Col(c.name, c.dtype, c.key, c.original_type) for c in self.pg_schema.cols]
+            m = min(a.nrows, 1 << 13)   # the emitter's restatement is Python: a bounded slice of the collapsed rows
+            names = [c.name for c in a.cols]
+            t0 = time.perf_counter()
+            nmsg = 0
+            for r in range(m):
+                has = bool(a.old_present[r]) if getattr(a, "old_present", None) is not None else bool(getattr(a, "old_keys", None))
+                it = E.Item({0: "insert", 1: "update", 2: "delete"}.get(int(a.kind[r]), "other") if a.kind is not None else "insert", "public", "events", cols, names,
+                            [tuple(c.pyvalue(r)) for c in a.cols], [c.name for c in a.old_keys] if has else [], [tuple(c.pyvalue(r)) for c in a.old_keys] if has else [],
+                            int(r % 97), r + 5, 1700000000000000000)
+                nmsg += len(em.emit_kv(it))
+            t_emit = time.perf_counter() - t0
+            sec = r1.seconds + t_emit * (a.nrows / max(m, 1))
+            out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+                   "sample": f"a {k}-row slice of the same stream: oracle Collapse ({r1.seconds:.2f}s) + the emitter's Python restatement on {m} of its {a.nrows} surviving rows "
+                             f"({t_emit:.2f}s, {nmsg} messages; scaled to the slice), single thread",
+                   "note": "the emitter leg is a PYTHON restatement (oracle/dbz_emitter.py): a parity checker, far slower than the Go emitter — not a performance baseline"}
+            out.update(host_info())
+            return out
         ora.queue_serialize(self.qopts, a, s2, meta)
         sec = r1.seconds + ora.queue_serialize.seconds
         out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
@@ -1209,6 +1254,8 @@ def main():
     ap.add_argument("--pcie-lanes", type=int, default=3)
     ap.add_argument("--devices", default="", help="ONE process driving several devices (csv workload): comma-separated HIP device ids, lane k on the k-th "
                     "(tfgpu_init_devices); without it --gpus N > 1 expects one process per GPU under torch.distributed.run")
+    ap.add_argument("--sink", default="native", choices=["native", "debezium"], help="configs4: the queue sink's format — the native serializer, or the Debezium emitter "
+                    "(queue.DebeziumSerializer, key + value with inline schemas: tfgpu_debezium_emit)")
     ap.add_argument("--exchange", type=int, default=1, help="configs4 at 1 rank: 1 = every buffer still makes the RCCL round trip, 0 = skip the collective")
     args = ap.parse_args()
 

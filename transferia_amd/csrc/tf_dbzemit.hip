@@ -340,23 +340,31 @@ __global__ void __launch_bounds__(256) dbz_cell_write(EParams p) {
   emit_cell(w, p, ec, e, r);
   w.flush();
 }
-// a long constant (the schema half of a message) into every event that holds it: one workgroup per (event, 4 KiB piece)
+// a long constant (the schema half of a message) into every event that holds it: one WAVE per (event, 2 KiB piece) — a key's schema is a
+// few hundred bytes, a value's a few KiB, so a workgroup per event would leave most of its lanes without a byte to move
+constexpr uint32_t FILL_PIECE = 2048;
 __global__ void __launch_bounds__(256) dbz_fill_const(EParams p, int32_t ci, uint32_t pieces) {
-  const int64_t e = (int64_t)(blockIdx.x / pieces); const uint32_t piece = blockIdx.x % pieces;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const int64_t e = item / pieces; const uint32_t piece = (uint32_t)(item % pieces);
+  if (e >= p.nev) return;
   const ECell &ec = p.cells[ci];
-  const int64_t r = p.ev_row ? p.ev_row[e] : e;
-  if (!applies(p, ec.apply, e, r)) return;
+  // a wave's stores wait for what says where they go: with 10^5..10^6 waves of one or two stores each, the chain event → row → kind → … is the
+  // kernel's duration.  The schema halves belong to every event (keys) or to every event but the tombstones (values): one load, beside the offsets'
+  if (ec.apply == EA_VALUE) { if (p.ev_type && p.ev_type[e] == EV_TOMBSTONE) return; }
+  else if (ec.apply != EA_KEY) { const int64_t r = p.ev_row ? p.ev_row[e] : e; if (!applies(p, ec.apply, e, r)) return; }
   uint8_t *dst = p.out + (uint64_t)p.ev_len[e] + p.cell[(int64_t)ci * p.nev + e];
   const uint8_t *src = p.blob + ec.pre_off;
-  const uint32_t a = piece * 4096u, b = min(a + 4096u, ec.pre_len);
-  // the destination's alignment decides the split: bytes up to its next 4-byte boundary, dwords, a byte tail
-  const uint32_t head = min((uint32_t)((4 - ((uintptr_t)(dst + a) & 3)) & 3), b - a);
-  if (threadIdx.x < head) dst[a + threadIdx.x] = src[a + threadIdx.x];
-  const uint32_t a4 = a + head, words = (b - a4) / 4;
-  struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
-  for (uint32_t w = threadIdx.x; w < words; w += 256) reinterpret_cast<uint32_t *>(dst + a4)[w] = reinterpret_cast<const U32 *>(src + a4)[w].v;
-  const uint32_t t0 = a4 + words * 4;
-  if (threadIdx.x < b - t0) dst[t0 + threadIdx.x] = src[t0 + threadIdx.x];
+  const uint32_t a = piece * FILL_PIECE, b = min(a + FILL_PIECE, ec.pre_len);
+  // the destination's alignment decides the split: bytes up to its next 16-byte boundary, 16-byte stores (one per lane and KiB), a byte tail;
+  // the source sits wherever the blob put it: unaligned 16-byte loads of a few cache-resident KiB
+  const uint32_t head = min((uint32_t)((16 - ((uintptr_t)(dst + a) & 15)) & 15), b - a);
+  if (lane < head) dst[a + lane] = src[a + lane];
+  const uint32_t a16 = a + head, quads = (b - a16) / 16;
+  struct __attribute__((packed, aligned(1))) U128 { uint32_t x, y, z, w; };
+  for (uint32_t q = lane; q < quads; q += 64) { const U128 v = reinterpret_cast<const U128 *>(src + a16)[q]; reinterpret_cast<uint4 *>(dst + a16)[q] = make_uint4(v.x, v.y, v.z, v.w); }
+  const uint32_t t0 = a16 + quads * 16;
+  if (lane < b - t0) dst[t0 + lane] = src[t0 + lane];
 }
 
 static inline unsigned blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + 255) / 256); }
@@ -589,10 +597,11 @@ static Stream run_stream(EParams p, const CellList &L, const std::string &blob, 
   p.out = ptr<uint8_t>(S.out);
   { KernelTimer t("dbz_cell_write"); dbz_cell_write<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
   for (size_t ci = 0; ci < L.cells.size(); ci++) if (L.cells[ci].kind == EC_CONST && L.cells[ci].pre_len > CONST_INLINE) {
-    const uint32_t pieces = (L.cells[ci].pre_len + 4095) / 4096;
-    if ((uint64_t)nev * pieces > 0x7FFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: too many events for one call");
+    const uint32_t pieces = (L.cells[ci].pre_len + FILL_PIECE - 1) / FILL_PIECE;
+    const uint64_t items = (uint64_t)nev * pieces;
+    if (items > 0x1FFFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: too many events for one call");
     KernelTimer t("dbz_fill_const");
-    dbz_fill_const<<<(unsigned)(nev * pieces), 256, 0, st>>>(p, (int32_t)ci, pieces);
+    dbz_fill_const<<<(unsigned)((items + 3) / 4), 256, 0, st>>>(p, (int32_t)ci, pieces);
   }
   S.start.resize((size_t)nev + 1);
   d2h(S.start.data(), p.ev_len, (size_t)(nev + 1) * 4);
