@@ -17,7 +17,9 @@
 // Device-resident original types (everything else is refused BY NAME with TFGPU_ERR_UNSUPPORTED and stays with the stock
 // emitter): pg:boolean, bit(1), smallint, integer, bigint, oid, real, double precision, text / character* / uuid / cidr /
 // macaddr / citext / int4range / int8range / daterange, inet, bytea, date, timestamp[(p)] with / without time zone (time.Time
-// values), json / jsonb, numeric[(p,s)] (precise: up to 38 digits; string), bit(n) / bit varying(n).
+// values), time[(p)] with / without time zone, json / jsonb, hstore (a map), xml, numeric[(p,s)] (precise: up to 38 digits;
+// string), money, bit(n) / bit varying(n), point, tsrange, numrange and tstzrange (two plain bounds).  Texts whose reading belongs
+// to jackc/pgtype's parsers (interval; infinity / empty / unbounded ranges; odd clock shapes) are left to the host, value by value.
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -33,7 +35,7 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
@@ -124,8 +126,8 @@ __device__ __forceinline__ bool mul10(u128 &c, uint32_t add) {
 // shopspring's String()), StringFixed(schema scale) when the type has one, DecimalToDebeziumPrimitivesImpl (:388-419) — whose two's
 // complement is computed from big.Int.Bytes() of the inverted magnitude (leading zero bytes lost): restated as written.
 // 0 ok, 1 the reference fails, 2 not decided here (more than 38 digits, an exponent past ±64)
-template <class S> __device__ int emit_numeric(S &s, const uint8_t *t, uint32_t n, uint32_t schema_scale, bool put_scale) {
-  if (n == 0) return 1;  // "empty string as an input is not supported"
+template <class S> __device__ int emit_numeric(S &s, const uint8_t *t, uint32_t n, uint32_t schema_scale, bool put_scale, bool verbatim = false) {
+  if (n == 0 && !verbatim) return 1;  // "empty string as an input is not supported" (DecimalToDebeziumPrimitives alone takes "" as zero)
   bool has_e = false, only0 = true;
   int32_t first_dot = -1;
   for (uint32_t i = 0; i < n; i++) {
@@ -134,6 +136,7 @@ template <class S> __device__ int emit_numeric(S &s, const uint8_t *t, uint32_t 
     if (c == '.' && first_dot < 0) { first_dot = (int32_t)i; continue; }
     if (c != '0' && c != '-') only0 = false;
   }
+  if (verbatim && has_e) return 1;  // no ExponentialFloatFormToNumeric in front: big.Int.SetString refuses the letter
   bool neg = false; u128 C = 0; int32_t sc = 0;
   bool zero_text = false;
   if (!has_e && schema_scale == 0 && only0) { zero_text = true; sc = first_dot < 0 ? 0 : (int32_t)n - 1 - first_dot; }  // containsOnly(decimalInt, '0', '-')
@@ -204,6 +207,103 @@ template <class S> __device__ __forceinline__ int emit_int_text(S &s, const uint
   return 0;
 }
 
+
+// the text between a JSON string's quotes: emit_json_string through a sink that drops its first and its last byte
+template <class S> struct BodySink {
+  S &s; uint32_t state = 0, held = 0;
+  __device__ __forceinline__ void put(uint32_t c) { if (state == 0) { state = 1; return; } if (state == 2) s.put(held); held = c; state = 2; }
+};
+template <class S> __device__ __forceinline__ void json_body(S &s, const uint8_t *p, uint32_t n) { BodySink<S> b{s}; emit_json_string(b, p, n, false); }
+__device__ __forceinline__ bool dg2(const uint8_t *p, uint32_t &v) { if (p[0] < '0' || p[0] > '9' || p[1] < '0' || p[1] > '9') return false; v = (p[0] - '0') * 10u + (p[1] - '0'); return true; }
+// "HH:MM:SS[.f{1,6}]" → microseconds of the day, *end = where the clock text stops; false = not this shape
+__device__ __forceinline__ bool clock_micros(const uint8_t *t, uint32_t n, int64_t *us, uint32_t *end) {
+  uint32_t h, m, sec;
+  if (n < 8 || !dg2(t, h) || t[2] != ':' || !dg2(t + 3, m) || t[5] != ':' || !dg2(t + 6, sec)) return false;
+  int64_t v = ((int64_t)h * 3600 + m * 60 + sec) * 1000000;
+  uint32_t i = 8;
+  if (i < n && t[i] == '.') {
+    uint32_t k = 0, f = 0; i++;
+    while (i < n && t[i] >= '0' && t[i] <= '9' && k < 6) { f = f * 10 + (t[i] - '0'); i++; k++; }
+    if (k == 0) return false;
+    for (; k < 6; k++) f *= 10;
+    v += f;
+  }
+  *us = v; *end = i;
+  return true;
+}
+// a zone "Z" | "±hh[:mm[:ss]]" at [i, n): seconds east, false = not this shape
+__device__ __forceinline__ bool zone_seconds(const uint8_t *t, uint32_t i, uint32_t n, int32_t *off) {
+  if (i + 1 == n && t[i] == 'Z') { *off = 0; return true; }
+  if (i >= n || (t[i] != '+' && t[i] != '-')) return false;
+  const bool neg = t[i] == '-'; i++;
+  uint32_t h = 0, m = 0, sec = 0;
+  if (i + 2 > n || !dg2(t + i, h)) return false; i += 2;
+  if (i < n) { if (t[i] != ':' || i + 3 > n || !dg2(t + i + 1, m)) return false; i += 3; }
+  if (i < n) { if (t[i] != ':' || i + 3 > n || !dg2(t + i + 1, sec)) return false; i += 3; }
+  if (i != n) return false;
+  const int32_t v = (int32_t)(h * 3600 + m * 60 + sec);
+  *off = neg ? -v : v;
+  return true;
+}
+template <class S> __device__ __forceinline__ void emit_u128(S &s, u128 v) {
+  uint8_t d[40]; int k = 0;
+  do { d[k++] = (uint8_t)('0' + (uint32_t)(v % 10)); v /= 10; } while (v);
+  while (k) s.put(d[--k]);
+}
+// ExponentialFloatFormToNumeric (typeutil/helpers.go:340-365) of one bound: the text as it is without an exponent, shopspring's String() with one.
+// 0 ok, 1 the reference fails, 2 host
+template <class S> __device__ int emit_exp_numeric(S &s, const uint8_t *t, uint32_t n) {
+  if (n == 0) return 2;  // an unbounded side: pgtype's business
+  bool has_e = false;
+  for (uint32_t i = 0; i < n; i++) if (t[i] == 'e' || t[i] == 'E') has_e = true;
+  if (!has_e) { json_body(s, t, n); return 0; }
+  uint32_t i = 0; bool neg = false;
+  if (t[0] == '-') { neg = true; i = 1; }
+  if (i < n && (t[i] == '+' || t[i] == '-')) return 2;
+  u128 C = 0; uint32_t nd = 0; int32_t F = 0, E = 0; bool dot = false;
+  for (; i < n; i++) { const uint32_t c = t[i]; if (c >= '0' && c <= '9') { if (!mul10(C, c - '0')) return 2; nd++; if (dot) F++; } else if (c == '.' && !dot) dot = true; else break; }
+  if (nd == 0 || i >= n || (t[i] != 'e' && t[i] != 'E')) return 1;
+  i++;
+  bool eneg = false;
+  if (i < n && (t[i] == '+' || t[i] == '-')) { eneg = t[i] == '-'; i++; }
+  if (i >= n) return 1;
+  for (; i < n; i++) { const uint32_t c = t[i]; if (c < '0' || c > '9') return 1; E = E * 10 + (int32_t)(c - '0'); if (E > 64) return 2; }
+  int32_t sc = F - (eneg ? -E : E);
+  if (C == 0) sc = 0;
+  while (sc > 0 && C % 10 == 0) { C /= 10; sc--; }
+  while (sc < 0) { if (!mul10(C, 0)) return 2; sc++; }
+  if (neg) s.put('-');
+  if (sc == 0) { emit_u128(s, C); return 0; }
+  u128 pw = 1; for (int32_t k = 0; k < sc; k++) pw *= 10;   // sc <= 38 + 64: C < 10^38 keeps C / pw meaningful only while pw fits
+  if (sc > 38) {  // 0.000…digits
+    put_lit(s, "0."); uint32_t dl = 0; { u128 x = C; while (x) { dl++; x /= 10; } }
+    for (int32_t k = 0; k < sc - (int32_t)dl; k++) s.put('0');
+    emit_u128(s, C); return 0;
+  }
+  emit_u128(s, C / pw); s.put('.');
+  const u128 fr = C % pw; uint32_t dl = 0; { u128 x = fr; while (x) { dl++; x /= 10; } }
+  for (int32_t k = 0; k < sc - (int32_t)dl; k++) s.put('0');
+  if (fr) emit_u128(s, fr);
+  return 0;
+}
+// "YYYY-MM-DD HH:MM:SS[.f]zone" (pgtype.Timestamptz.DecodeText's shapes) → unix seconds; false = not this shape
+__device__ __forceinline__ bool pg_tstz_seconds(const uint8_t *t, uint32_t n, int64_t *out) {
+  if (n < 20) return false;
+  for (int k = 0; k < 4; k++) if (t[k] < '0' || t[k] > '9') return false;
+  uint32_t mo, d; int64_t us; uint32_t end; int32_t off;
+  if (t[4] != '-' || !dg2(t + 5, mo) || t[7] != '-' || !dg2(t + 8, d) || t[10] != ' ') return false;
+  if (!clock_micros(t + 11, n - 11, &us, &end)) return false;
+  {  // any count of fractional digits: the zone starts after them
+    uint32_t i = 11 + 8;
+    if (i < n && t[i] == '.') { i++; while (i < n && t[i] >= '0' && t[i] <= '9') i++; }
+    if (!zone_seconds(t, i, n, &off)) return false;
+  }
+  const int64_t y = (t[0] - '0') * 1000 + (t[1] - '0') * 100 + (t[2] - '0') * 10 + (t[3] - '0');
+  if (mo < 1 || mo > 12 || d < 1 || d > (uint32_t)dev::days_in_month((int)mo, y)) return false;
+  *out = dev::days_from_civil(y, (int)mo, (int)d) * 86400 + us / 1000000 - off;
+  return true;
+}
+
 // AddPg for one non-nil value: 0 ok, 1 the reference returns an error, 2 left to the host
 template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell &ec, const CellBits &b) {
   const DCol &c = ec.c;
@@ -263,6 +363,95 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
       }
       s.put('"');
       return 0;
+    }
+    case DK_TIME: {  // pgtype.Time.Scan(string) → Microseconds / divider (pg/emitter.go:541-561)
+      int64_t us; uint32_t end;
+      if (!clock_micros(vp, vn, &us, &end) || end != vn) return 2;
+      emit_i64(s, trunc_div(us, (int64_t)ec.arg)); return 0;
+    }
+    case DK_TIMETZ: {  // TimeWithTimeZoneToTime(val).UTC().Format("15:04:05.999999Z") (pg/emitter.go:524-540)
+      int64_t us; uint32_t end; int32_t off;
+      if (!clock_micros(vp, vn, &us, &end) || end >= vn || vp[end] == 'Z' || !zone_seconds(vp, end, vn, &off)) return 2;
+      int64_t sod = (us / 1000000 - off) % 86400; if (sod < 0) sod += 86400;
+      s.put('"'); emit_clock(s, sod);
+      uint32_t f = (uint32_t)(us % 1000000);
+      if (f) { uint8_t d[6]; for (int k = 5; k >= 0; k--) { d[k] = (uint8_t)('0' + f % 10); f /= 10; } int last = 5; while (d[last] == '0') last--; s.put('.'); for (int k = 0; k <= last; k++) s.put(d[k]); }
+      s.put('Z'); s.put('"'); return 0;
+    }
+    case DK_MONEY:  // DecimalToDebeziumPrimitives(colVal.(string)[1:]) (pg/emitter.go:477-482)
+      if (vn == 0) return 2;  // the reference's slice expression panics
+      if (ec.arg) { emit_json_string(s, vp + 1, vn - 1, false); return 0; }  // decimal.handling.mode = string
+      return emit_numeric(s, vp + 1, vn - 1, 0, false, true);
+    case DK_XML: {  // typeutil.UnescapeUnicode (helpers.go:530-550): \uXXXX becomes the rune byte(XXXX); piecewise escaping is exact (the insertions are whole runes)
+      s.put('"');
+      uint32_t a = 0, i = 0;
+      while (i < vn) {
+        if (vp[i] == '\\' && vn - i > 5 && vp[i + 1] == 'u') {
+          uint32_t u = 0; bool hex = true;
+          for (uint32_t k = 2; k < 6; k++) { const uint32_t c = vp[i + k]; const uint32_t d = c >= '0' && c <= '9' ? c - '0' : (c | 32) >= 'a' && (c | 32) <= 'f' ? (c | 32) - 'a' + 10 : 99; if (d == 99) hex = false; u = u * 16 + d; }
+          if (hex) {
+            if (i > a) json_body(s, vp + a, i - a);
+            uint8_t r[2]; const uint32_t b = u & 0xFF; uint32_t rn = 1;
+            if (b < 0x80) r[0] = (uint8_t)b; else { r[0] = (uint8_t)(0xC0 | (b >> 6)); r[1] = (uint8_t)(0x80 | (b & 0x3F)); rn = 2; }
+            json_body(s, r, rn);
+            i += 6; a = i; continue;
+          }
+        }
+        i++;
+      }
+      if (vn > a) json_body(s, vp + a, vn - a);
+      s.put('"'); return 0;
+    }
+    case DK_POINT: {  // PointToDebezium (helpers.go:552-572)
+      if (vn < 2) return 2;
+      uint32_t comma = 0, commas = 0;
+      for (uint32_t i = 1; i + 1 < vn; i++) if (vp[i] == ',') { if (!commas) comma = i; commas++; }
+      if (commas != 1) return 1;
+      double x, y; PtrView f{vp};
+      int rc = parse_float_go(f, 1, comma, p.p10, p.p128, &x); if (rc == 3) return 2; if (rc) return 1;
+      rc = parse_float_go(f, comma + 1, vn - 1, p.p10, p.p128, &y); if (rc == 3) return 2; if (rc) return 1;
+      if (x != x || y != y || x - x != 0 || y - y != 0) return 1;  // json: unsupported value
+      put_lit(s, "{\"srid\":null,\"wkb\":\"\",\"x\":"); dev::fmt_json_float(s, x, 64); put_lit(s, ",\"y\":"); dev::fmt_json_float(s, y, 64); s.put('}');
+      return 0;
+    }
+    case DK_TSRANGE: {  // pg/emitter.go:432-442: every comma-separated part unquoted, then quoted
+      if (vn < 2 || vp[0] >= 0x80 || vp[vn - 1] >= 0x80) return 2;
+      s.put('"'); json_body(s, vp, 1);
+      uint32_t a = 1;
+      for (uint32_t i = 1; i <= vn - 1; i++) if (i == vn - 1 || vp[i] == ',') {
+        uint32_t pa = a, pb = i;
+        if (pb - pa == 1 && vp[pa] == '"') return 2;  // UnquoteIfQuoted of a lone quote panics
+        if (pb > pa && vp[pa] == '"' && vp[pb - 1] == '"') { pa++; pb--; }
+        if (a != 1) s.put(',');
+        put_lit(s, "\\\""); json_body(s, vp + pa, pb - pa); put_lit(s, "\\\"");
+        a = i + 1;
+      }
+      json_body(s, vp + vn - 1, 1); s.put('"'); return 0;
+    }
+    case DK_NUMRANGE: {  // NumRangeToDebezium (helpers.go:574-591), the unquoted two-bound form
+      if (vn < 3 || (vp[0] != '[' && vp[0] != '(') || (vp[vn - 1] != ']' && vp[vn - 1] != ')')) return 2;
+      uint32_t comma = 0, commas = 0;
+      for (uint32_t i = 1; i + 1 < vn; i++) { if (vp[i] == ',') { if (!commas) comma = i; commas++; } if (vp[i] == '"' || vp[i] == '\\') return 2; }
+      if (commas != 1) return 2;
+      put_lit(s, "\"[");
+      int rc = emit_exp_numeric(s, vp + 1, comma - 1); if (rc) return rc;
+      s.put(',');
+      rc = emit_exp_numeric(s, vp + comma + 1, vn - 1 - (comma + 1)); if (rc) return rc;
+      put_lit(s, ")\""); return 0;
+    }
+    case DK_TSTZRANGE: {  // TstZRangeQuote (helpers.go:604-614): both bounds in UTC as "2006-01-02 15:04:05+00", the input's brackets
+      if (vn < 3 || (vp[0] != '[' && vp[0] != '(') || (vp[vn - 1] != ']' && vp[vn - 1] != ')')) return 2;
+      uint32_t comma = 0, commas = 0;
+      for (uint32_t i = 1; i + 1 < vn; i++) if (vp[i] == ',') { if (!commas) comma = i; commas++; }
+      if (commas != 1) return 2;
+      uint32_t la = 1, lb = comma, ra = comma + 1, rb = vn - 1;
+      if (lb - la >= 2 && vp[la] == '"' && vp[lb - 1] == '"') { la++; lb--; }
+      if (rb - ra >= 2 && vp[ra] == '"' && vp[rb - 1] == '"') { ra++; rb--; }
+      int64_t l, r;
+      if (!pg_tstz_seconds(vp + la, lb - la, &l) || !pg_tstz_seconds(vp + ra, rb - ra, &r)) return 2;
+      s.put('"'); s.put(vp[0]);
+      put_lit(s, "\\\""); emit_date(s, l); s.put(' '); emit_clock(s, l); put_lit(s, "+00\\\",\\\""); emit_date(s, r); s.put(' '); emit_clock(s, r); put_lit(s, "+00\\\"");
+      s.put(vp[vn - 1]); s.put('"'); return 0;
     }
     case DK_WRONG_TYPE: return 1;
     default: return 2;
@@ -453,8 +642,25 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
   for (auto &e : PLAIN) if (t == e.t) { kafka = e.kafka; dname = e.name; cp.dk = e.dk; found = true; break; }
   int prec = 0, scale = 0, d;
   if (found) {}
-  else if (t == "pg:xml" || t == "pg:point" || t == "pg:numrange" || t == "pg:tsrange" || t == "pg:tstzrange" || t == "pg:money" || t == "pg:USER-DEFINED:hstore" ||
-           starts(t, "pg:interval") || time_family(t, "time", "with") != -2 || time_family(t, "time", "without") != -2) unsupported(name, "original type " + t);
+  else if (t == "pg:xml") { kafka = "string"; dname = "io.debezium.data.Xml"; cp.dk = DK_XML; }
+  else if (t == "pg:USER-DEFINED:hstore") { kafka = "string"; dname = "io.debezium.data.Json"; cp.dk = DK_JSON; cp.arg = 1; }  // a map marshals as pg:json does; hstore TEXT is HstoreToJSON's (host)
+  else if (t == "pg:numrange") { kafka = "string"; cp.dk = DK_NUMRANGE; }
+  else if (t == "pg:tsrange") { kafka = "string"; cp.dk = DK_TSRANGE; }
+  else if (t == "pg:tstzrange") { kafka = "string"; cp.dk = DK_TSTZRANGE; }
+  else if (t == "pg:point") { kafka = "struct"; dname = "io.debezium.data.geometry.Point"; cp.dk = DK_POINT; }
+  else if (t == "pg:money") {
+    const std::string &mode = P.get("decimal.handling.mode");
+    cp.dk = DK_MONEY;
+    if (mode == "precise") { kafka = "bytes"; dname = "org.apache.kafka.connect.data.Decimal"; extra = ",\"parameters\":{\"scale\":\"2\"}"; }
+    else if (mode == "string") { kafka = "string"; cp.arg = 1; }
+    else unsupported(name, "decimal.handling.mode=" + mode);
+  }
+  else if (starts(t, "pg:interval")) unsupported(name, "original type " + t);   // pgtype.Interval.DecodeText
+  else if ((d = time_family(t, "time", "with")) != -2) { kafka = "string"; dname = "io.debezium.time.ZonedTime"; cp.dk = DK_TIMETZ; }
+  else if ((d = time_family(t, "time", "without")) != -2) {
+    const uint32_t divider = (d >= 1 && d <= 3) ? 1000u : 1u;  // GetTimeDivider (helpers.go:106-123)
+    kafka = divider == 1 ? "int64" : "int32"; dname = divider == 1 ? "io.debezium.time.MicroTime" : "io.debezium.time.Time"; cp.dk = DK_TIME; cp.arg = divider;
+  }
   else if (starts(t, "pg:bit(") || starts(t, "pg:bit varying(")) {
     const size_t a = starts(t, "pg:bit(") ? 7 : 15, z = t.find(')', a);
     if (z == std::string::npos) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unsupported pg type, can't find closing bracket: " + t);
@@ -489,8 +695,11 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
   if (P.get("dt.add.original.type.info") == "true") o += "\"__dt_original_type_info\":{\"original_type\":" + jstr(t) + "},";
   const bool var_scale = cp.dk == DK_NUMERIC && (cp.arg >> 16);
   if (var_scale) o += "\"doc\":\"Variable scaled decimal\",";
+  if (cp.dk == DK_POINT) o += "\"doc\":\"Geometry (POINT)\",";
   o += "\"field\":" + jstr(name);
   if (var_scale) o += ",\"fields\":[{\"field\":\"scale\",\"optional\":false,\"type\":\"int32\"},{\"field\":\"value\",\"optional\":false,\"type\":\"bytes\"}]";
+  if (cp.dk == DK_POINT) o += ",\"fields\":[{\"field\":\"x\",\"optional\":false,\"type\":\"double\"},{\"field\":\"y\",\"optional\":false,\"type\":\"double\"},{\"field\":\"wkb\",\"optional\":true,\"type\":\"bytes\"},"
+                            "{\"field\":\"srid\",\"optional\":true,\"type\":\"int32\"}]";
   if (!dname.empty()) o += ",\"name\":" + jstr(dname);
   o += std::string(",\"optional\":") + ((cs.flags & TFGPU_COL_KEY) ? "false" : "true");
   if (!var_scale && !extra.empty()) o += extra;
@@ -502,7 +711,7 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
 }
 
 // which Go dynamic types AddPg takes for the type: 0 ok, 1 the reference's "unknown type of value", 2 host
-static int repr_ok(uint32_t dk, int repr) {
+static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
   auto in = [&](std::initializer_list<int> l) { for (int x : l) if (x == repr) return true; return false; };
   switch (dk) {
     case DK_BOOL: return in({TFGPU_R_BOOL}) ? 0 : 2;
@@ -517,7 +726,8 @@ static int repr_ok(uint32_t dk, int repr) {
     case DK_DATE: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
     case DK_TS: return in({TFGPU_R_TIME}) ? 0 : 2;
     case DK_TSTZ: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
-    case DK_JSON: return in({TFGPU_R_JSON, TFGPU_R_STRING}) ? 0 : 2;
+    case DK_JSON: return in({TFGPU_R_JSON}) || (in({TFGPU_R_STRING}) && !arg) ? 0 : 2;
+    case DK_TIME: case DK_TIMETZ: case DK_MONEY: case DK_XML: case DK_POINT: case DK_TSRANGE: case DK_NUMRANGE: case DK_TSTZRANGE: return in({TFGPU_R_STRING}) ? 0 : 2;
     case DK_NUMERIC: case DK_NUMERIC_TEXT: return in({TFGPU_R_STRING, TFGPU_R_JSONNUM}) ? 0 : 1;
     default: return 2;
   }
@@ -538,7 +748,7 @@ struct CellList {
   void push_value(uint32_t apply, const std::string &prefix, const DColumn &col, const ColPlan &cp, bool from_old) {
     // a Go type AddPg does not take for this column fails (or leaves to the host) the first NON-NIL value of it, as the reference's type
     // switches do: a column of nils has no type to object to
-    const int rk = repr_ok(cp.dk, col.repr);
+    const int rk = repr_ok(cp.dk, col.repr, cp.arg);
     ECell c{}; c.kind = EC_VALUE; c.apply = apply; c.pre_off = (uint32_t)blob->size(); c.pre_len = (uint32_t)prefix.size();
     *blob += prefix; c.c = dcol_of(col); c.dk = rk ? (uint32_t)(DK_WRONG_TYPE + rk - 1) : cp.dk; c.arg = cp.arg; c.from_old = from_old ? 1u : 0u;
     cells.push_back(c);
