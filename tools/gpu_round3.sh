@@ -54,6 +54,7 @@ timeout 600 python bench.py > "$OUT/bench_csv.json" 2> "$OUT/bench_csv.err"; ech
 for w in configs0 configs2 configs3 configs4 configs4d json sr collapse debezium; do
   timeout 400 python bench.py --workload $w > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; echo "== $w rc=$?"
 done
+timeout 400 python bench.py --workload configs4 --sink debezium > "$OUT/bench_configs4_debezium.json" 2> "$OUT/bench_configs4_debezium.err"; echo "== configs4 --sink debezium rc=$?"
 python - "$OUT" <<'PY'
 import json,sys,glob,os
 for f in sorted(glob.glob(sys.argv[1]+"/bench_*.json")):
@@ -70,4 +71,7 @@ for w in csv configs2 configs3 json sr debezium; do
   find "$OUT/prof_$w" -name '*kernel_trace*' -delete
   f=$(find "$OUT/prof_$w" -name "*kernel_stats.csv" | head -1); echo "== rocprof $w"; [ -n "$f" ] && head -6 "$f" | cut -c1-150
 done
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -f csv -d "$GRAFT_REPO_ROOT/$OUT/prof_configs4_debezium" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --workload configs4 --sink debezium --steps 5 --warmup 2 --cpu-rows 0 > "$GRAFT_REPO_ROOT/$OUT/prof_configs4_debezium.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof_configs4_debezium.err" )
+find "$OUT/prof_configs4_debezium" -name '*kernel_trace*' -delete
+f=$(find "$OUT/prof_configs4_debezium" -name "*kernel_stats.csv" | head -1); echo "== rocprof configs4 --sink debezium"; [ -n "$f" ] && head -6 "$f" | cut -c1-150
 echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s"

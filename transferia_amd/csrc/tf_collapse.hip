@@ -431,10 +431,10 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   return out;
 }
 
-// flags to a host array; returns how many rows changed their primary key
-int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags) {
+// the flags on the device (n bytes, 1 = the row's primary key changed) and, optionally, their count behind them (a uint32 at flags + align4(n));
+// a null Buf when the schema has no PrimaryKey column (nothing can change)
+Buf keys_changed_device(const tfgpu_dbatch &in, Buf *count_out) {
   const int64_t n = in.nrows;
-  if (n == 0) return 0;
   hipStream_t st = ctx().stream;
   materialize(in);
   std::vector<KCol> kc;
@@ -444,13 +444,23 @@ int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags) {
     if (const DColumn *c = find_first(in.old_keys, name)) { k.old = dcol_of(*c); k.has_old = 1; }
     kc.push_back(k);
   }
-  if (kc.empty()) { std::memset(host_flags, 0, (size_t)n); return 0; }  // no PrimaryKey column: nothing can change
+  if (kc.empty() || n == 0) return nullptr;
   Buf bkc = upload_small(kc.data(), kc.size() * sizeof(KCol));
   Buf flags = dalloc((size_t)n + 16), count = dalloc_zero(4);
   KeysChangedParams p{};
   p.keys = ptr<KCol>(bkc); p.nkeys = (int32_t)kc.size(); p.n = n; p.kind = ptr<uint8_t>(in.kind); p.old_present = ptr<uint8_t>(in.old_present);
   p.has_old_keys = in.old_keys.empty() ? 0 : 1; p.out = ptr<uint8_t>(flags); p.count = ptr<uint32_t>(count);
   { KernelTimer t("keys_changed"); keys_changed_kernel<<<cgrid(n), 256, 0, st>>>(p); }
+  if (count_out) *count_out = count;
+  return flags;
+}
+// flags to a host array; returns how many rows changed their primary key
+int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags) {
+  const int64_t n = in.nrows;
+  if (n == 0) return 0;
+  Buf count;
+  Buf flags = keys_changed_device(in, &count);
+  if (!flags) { std::memset(host_flags, 0, (size_t)n); return 0; }  // no PrimaryKey column: nothing can change
   const uint32_t *h = d2h_u32(count->p);
   d2h(host_flags, flags->p, (size_t)n);
   sync();

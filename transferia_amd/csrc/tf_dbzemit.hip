@@ -21,6 +21,9 @@
 // string), money, bit(n) / bit varying(n), point, tsrange, numrange and tstzrange (two plain bounds).  Texts whose reading belongs
 // to jackc/pgtype's parsers (interval; infinity / empty / unbounded ranges; odd clock shapes) are left to the host, value by value.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -556,6 +559,28 @@ __global__ void __launch_bounds__(256) dbz_fill_const(EParams p, int32_t ci, uin
   if (lane < b - t0) dst[t0 + lane] = src[t0 + lane];
 }
 
+// the event list (emitKV, emitter_value_converter.go:629-672): per row its number of messages, then — after a scan — (row, emitType) of each
+__device__ __forceinline__ uint32_t row_events(uint32_t kind, bool changed, int skip_tomb) {
+  if (kind == TFGPU_K_INSERT) return 1;
+  if (kind == TFGPU_K_UPDATE) return changed ? (skip_tomb ? 2u : 3u) : 1u;
+  if (kind == TFGPU_K_DELETE) return skip_tomb ? 1u : 2u;
+  return 0;  // other kinds emit nothing
+}
+__global__ void __launch_bounds__(256) dbz_event_count(const uint8_t *kind, const uint8_t *changed, int64_t n, int skip_tomb, uint32_t *cnt) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) cnt[r] = row_events(kind[r], changed && changed[r], skip_tomb);
+}
+__global__ void __launch_bounds__(256) dbz_event_fill(const uint8_t *kind, const uint8_t *changed, int64_t n, int skip_tomb, const uint32_t *at, int32_t *ev_row, uint8_t *ev_type) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t k = kind[r]; const bool ch = changed && changed[r];
+  uint32_t e = at[r];
+  auto ev = [&](uint32_t t) { ev_row[e] = (int32_t)r; ev_type[e] = (uint8_t)t; e++; };
+  if (k == TFGPU_K_INSERT) ev(EV_REGULAR);
+  else if (k == TFGPU_K_UPDATE) { if (ch) { ev(EV_DELETE); if (!skip_tomb) ev(EV_TOMBSTONE); ev(EV_INSERT); } else ev(EV_REGULAR); }
+  else if (k == TFGPU_K_DELETE) { ev(EV_DELETE); if (!skip_tomb) ev(EV_TOMBSTONE); }
+}
+
 static inline unsigned blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + 255) / 256); }
 
 // ---- host: Go's JSON text -------------------------------------------------------------------------------------------------
@@ -821,7 +846,7 @@ static Stream run_stream(EParams p, const CellList &L, const std::string &blob, 
 
 }  // namespace dbz
 
-int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags);  // tf_collapse.hip
+Buf keys_changed_device(const tfgpu_dbatch &in, Buf *count_out);  // tf_collapse.hip
 template <class T> static const T *dbz_meta(const tfgpu_row_meta *m, const T *p, size_t count, std::vector<Buf> &keep) {
   if (!m || !p) return nullptr;
   if (m->mem == TFGPU_MEM_DEVICE) return p;
@@ -842,6 +867,9 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     std::lock_guard<std::mutex> lk(cx.mu);
     hipStream_t st = cx.stream;
     const int64_t n = b->nrows;
+    static const bool timing = std::getenv("TFGPU_DBZ_TIMING") != nullptr;   // measurement only: host phases to stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!timing) return; auto t = std::chrono::steady_clock::now(); std::fprintf(stderr, "dbz_emit %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count()); t_prev = t; };
     // ---- connector parameters (parameters.go:140-215) ----
     Params P;
     static const char *const DEFAULTS[][2] = {{"database.dbname", ""}, {"topic.prefix", ""}, {"dt.unknown.types.policy", "fail"}, {"dt.add.original.type.info", "false"},
@@ -905,46 +933,40 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     const std::string val_schema = "{\"fields\":[" + side("before") + "," + side("after") + "," + src_schema + "," + f("op", "string", false) + "," + f("ts_ms", "int64", true) + "," + tx_schema +
       "],\"name\":" + jstr(record + ".Envelope") + ",\"optional\":false,\"type\":\"struct\"}";
 
-    // ---- events ----
-    std::vector<int32_t> ev_row; std::vector<uint8_t> ev_type;
+    lap("plan");
+    // ---- events: on the device (a count per row, a scan, a fill); the host learns only how many there are ----
+    Buf d_ev_row, d_ev_type;
     bool identity = true;
+    int64_t nev = n;
     if (b->kind) {
-      std::vector<uint8_t> kinds((size_t)n), changed((size_t)n, 0);
-      d2h(kinds.data(), b->kind->p, (size_t)n); sync();
-      bool any_update = false, only_inserts = true;
-      for (int64_t r = 0; r < n; r++) { if (kinds[(size_t)r] == TFGPU_K_UPDATE) any_update = true; if (kinds[(size_t)r] != TFGPU_K_INSERT) only_inserts = false; }
-      if (!only_inserts) {
-        identity = false;
-        if (any_update) {  // ChangeItem.KeysChanged (change_item.go:237-286) over the TableSchema's PrimaryKey columns — the ones `table_schema` flags
-          tfgpu_dbatch view;
-          view.nrows = n; view.cols = b->cols; view.old_keys = b->old_keys; view.old_present = b->old_present; view.kind = b->kind;
-          for (int i = 0; i < ts.ncols; i++) if (ts.cols[i].flags & TFGPU_COL_KEY) view.key_names.push_back(ts.cols[i].name ? ts.cols[i].name : "");
-          keys_changed_rows(view, changed.data());
-        }
-        for (int64_t r = 0; r < n; r++) {
-          const uint8_t k = kinds[(size_t)r];
-          auto ev = [&](uint8_t t) { ev_row.push_back((int32_t)r); ev_type.push_back(t); };
-          if (k == TFGPU_K_INSERT) ev(EV_REGULAR);
-          else if (k == TFGPU_K_UPDATE) { if (changed[(size_t)r]) { ev(EV_DELETE); if (!skip_tombstones) ev(EV_TOMBSTONE); ev(EV_INSERT); } else ev(EV_REGULAR); }
-          else if (k == TFGPU_K_DELETE) { ev(EV_DELETE); if (!skip_tombstones) ev(EV_TOMBSTONE); }
-          // other kinds emit nothing (emitKV :630-632)
-        }
+      identity = false;
+      Buf changed;
+      {  // ChangeItem.KeysChanged (change_item.go:237-286) over the TableSchema's PrimaryKey columns — the ones `table_schema` flags
+        tfgpu_dbatch view;
+        view.nrows = n; view.cols = b->cols; view.old_keys = b->old_keys; view.old_present = b->old_present; view.kind = b->kind;
+        for (int i = 0; i < ts.ncols; i++) if (ts.cols[i].flags & TFGPU_COL_KEY) view.key_names.push_back(ts.cols[i].name ? ts.cols[i].name : "");
+        changed = keys_changed_device(view, nullptr);
+      }
+      Buf cnt = dalloc((size_t)(n + 1) * 4 + 16);
+      dbz_event_count<<<blocks(n), 256, 0, st>>>(ptr<uint8_t>(b->kind), ptr<uint8_t>(changed), n, skip_tombstones ? 1 : 0, ptr<uint32_t>(cnt));
+      exclusive_scan_u32(ptr<uint32_t>(cnt), ptr<uint32_t>(cnt), n, true);
+      const uint32_t *h = d2h_u32(ptr<uint32_t>(cnt) + n);
+      sync();
+      nev = *h;
+      if (nev > 0) {
+        d_ev_row = dalloc((size_t)nev * 4 + 16); d_ev_type = dalloc((size_t)nev + 16);
+        dbz_event_fill<<<blocks(n), 256, 0, st>>>(ptr<uint8_t>(b->kind), ptr<uint8_t>(changed), n, skip_tombstones ? 1 : 0, ptr<uint32_t>(cnt), ptr<int32_t>(d_ev_row), ptr<uint8_t>(d_ev_type));
       }
     }
-    const int64_t nev = identity ? n : (int64_t)ev_row.size();
     if (cap >= 0 && nev > cap) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: " + std::to_string(nev) + " messages, room for " + std::to_string(cap));
     *nmsg = nev;
     if (nev == 0) { kres->mem = dalloc(64); vres->mem = dalloc(64); *keys = kres.release(); *values = vres.release(); if (key_start) { key_start[0] = 0; val_start[0] = 0; } return TFGPU_OK; }
 
+    lap("events");
     std::vector<Buf> keep;
     EParams p{};
     p.nev = nev;
-    if (!identity) {
-      Buf a = dalloc((size_t)nev * 4 + 16), t = dalloc((size_t)nev + 16);
-      h2d(a->p, ev_row.data(), (size_t)nev * 4); h2d(t->p, ev_type.data(), (size_t)nev);
-      keep.push_back(a); keep.push_back(t);
-      p.ev_row = ptr<int32_t>(a); p.ev_type = ptr<uint8_t>(t);
-    }
+    p.ev_row = ptr<int32_t>(d_ev_row); p.ev_type = ptr<uint8_t>(d_ev_type);
     p.kind = ptr<uint8_t>(b->kind); p.old_present = ptr<uint8_t>(b->old_present); p.src_row = ptr<int32_t>(b->src_row);
     p.has_old = has_old; p.has_prev = has_prev; p.snapshot = o->snapshot ? 1 : 0;
     if (meta) {
@@ -1005,17 +1027,23 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     }
     if (V.cells.size() > 0xFFFF || K.cells.size() > 0xFFFF) return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: more than 65535 cells per message");
 
+    lap("cells");
     Stream SV = run_stream(p, V, blob, st, "value");
+    lap("values");
     Stream SK;
     if (!o->drop_keys) SK = run_stream(p, K, blob, st, "key");
     else { SK.out = dalloc(64); SK.start.assign((size_t)nev + 1, 0u); }
+    lap("keys");
     kres->mem = SK.out; kres->size = SK.total; vres->mem = SV.out; vres->size = SV.total;
+    std::vector<int32_t> ev_row; std::vector<uint8_t> ev_type;
+    if (!identity) { ev_row.resize((size_t)nev); ev_type.resize((size_t)nev); d2h(ev_row.data(), d_ev_row->p, (size_t)nev * 4); d2h(ev_type.data(), d_ev_type->p, (size_t)nev); sync(); }
     for (int64_t e = 0; e <= nev; e++) { key_start[e] = SK.start[(size_t)e]; val_start[e] = SV.start[(size_t)e]; }
     for (int64_t e = 0; e < nev; e++) {
       val_null[e] = (!identity && ev_type[(size_t)e] == EV_TOMBSTONE) ? 1 : 0;
       msg_row[e] = identity ? e : ev_row[(size_t)e];
     }
     *keys = kres.release(); *values = vres.release();
+    lap("outputs");
     return TFGPU_OK;
   } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
   catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
