@@ -209,6 +209,37 @@ def test_parameter_variants(tf):
     assert len(tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(table)), tf.DeviceBatch.upload(empty))) == 0
 
 
+def test_rows_moved_by_a_transformer_no_meta_and_keyless_tables(tf):
+    """row meta rides on src_row (the fan-in key every row-moving step keeps): after filter_rows the surviving rows still name their own ID / LSN /
+    CommitTime; without meta they are the Go zero values; a table without a PrimaryKey has `{}` keys; OldKeys that name no key column give `{}` too"""
+    table, b = crud_batch(300, 11)
+    n = b.nrows
+    meta = (list(range(7, 7 + n)), [10 ** 9 + r for r in range(n)], [1600000000000000000 + 1000003 * r for r in range(n)])
+    db = tf.DeviceBatch.upload(b)
+    kept = tf.Transformer("filter_rows", {"filter": "v >= 0"}).apply(db).transformed
+    host = kept.download()
+    assert 0 < host.nrows < n and host.src_row is not None
+    got = tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(table)), kept, abi.row_meta(n, ids=meta[0], lsns=meta[1], commit_times=meta[2]))
+    em = E.Emitter(PARAMS)
+    want, rows = [], []
+    src = [int(x) for x in host.src_row]
+    for r, it in enumerate(items_of(host, cols_of(table), ([meta[0][k] for k in src], [meta[1][k] for k in src], [meta[2][k] for k in src]))):
+        for kv in em.emit_kv(it):
+            want.append((kv[0], kv[1]))
+            rows.append(r)
+    assert_same(got, want, rows)
+    got, want, rows = emit_both(tf, b, table, PARAMS, None)   # no meta: lsn / txId / ts_ms are 0
+    assert_same(got, want, rows)
+    assert b'"lsn":0,' in got.messages()[0][1] and b'"ts_ms":0}' in got.messages()[0][1]
+    keyless = [(nm, d, False, o) for nm, d, _k, o in table]
+    got, want, rows = emit_both(tf, b, keyless, PARAMS, meta)
+    assert_same(got, want, rows)
+    assert got.messages()[0][0].startswith(b'{"payload":{},"schema":{"fields":[],')
+    other = [("id", "int32", False, "pg:integer"), ("k2", "utf8", False, "pg:text"), ("v", "int64", True, "pg:bigint"), ("s", "utf8", False, "pg:text"), ("n", "double", False, "pg:numeric(10,3)")]
+    got, want, rows = emit_both(tf, b, other, PARAMS, meta)   # the key is `v`; OldKeys (id, k2) name no key column
+    assert_same(got, want, rows)
+
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter")
 DEVICE_TYPES = ("pg:xml", "pg:point", "pg:numrange", "pg:tsrange", "pg:tstzrange", "pg:money", "pg:USER-DEFINED:hstore", "pg:boolean", "pg:bit(1)", "pg:smallint", "pg:integer", "pg:bigint", "pg:oid", "pg:real", "pg:double precision", "pg:bytea", "pg:json", "pg:jsonb", "pg:uuid",
                 "pg:inet", "pg:int4range", "pg:int8range", "pg:daterange", "pg:text", "pg:date", "pg:cidr", "pg:macaddr", "pg:USER-DEFINED:citext")
