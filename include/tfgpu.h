@@ -841,8 +841,9 @@ int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b
  * tombstones dropped under tombstones.on.delete=false.  Message m: key = keys[key_start[m], key_start[m+1]) (empty with
  * drop_keys), value = values[val_start[m], val_start[m+1]) or nil when val_null[m] (a tombstone); msg_row[m] = the batch row it
  * came from.  Every array has room for cap+1 (starts) / cap entries; cap = 3 * nrows is always enough.
- * Both halves are PackerIncludeSchema's {"payload":…,"schema":…} (packer/packer_include_schema.go:14-40) — Go maps marshalled by
- * util.JSONMarshalUnescape, members in byte order, no HTML escaping.  `table_schema` is TableSchema.Columns() with OriginalType
+ * Both halves are PackerIncludeSchema's {"payload":…,"schema":…} (packer/packer_include_schema.go:14-40) — or the payload alone under
+ * key / value.converter.schemas.enable=false (PackerSkipSchema) — Go maps marshalled by util.JSONMarshalUnescape, members in byte
+ * order, no HTML escaping; a schema-registry URL / YSR namespace selects packers that stay with the host (packer/factory.go:13-98).  `table_schema` is TableSchema.Columns() with OriginalType
  * and the PrimaryKey flags (the batch itself carries neither); columns of the schema missing from the batch are TOASTed
  * (unavailable.value.placeholder).  Row meta: id → source.txId, lsn → source.lsn, commit_time → both ts_ms (NULL = zeros).
  * Parameters: the format settings map (parameters.go:140-215 fills the defaults): database.dbname, topic.prefix, dt.source.type
@@ -853,7 +854,7 @@ int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b
  * timestamp[(p)] with / without time zone as time.Time, time[(p)] with / without time zone, json / jsonb, hstore as a map, xml,
  * numeric[(p,s)] up to 38 digits, money, bit(n) / bit varying(n), point, tsrange, numrange and tstzrange in their plain two-bound
  * forms.  Anything else — interval, arrays, enums, mysql: / ydb: types, hstore / range / time texts only pgtype's parsers decide,
- * schema-registry converters, key / value schemas disabled, a value of a Go type the device does not convert — is refused BY NAME
+ * the schema-registry packers, a value of a Go type the device does not convert — is refused BY NAME
  * with TFGPU_ERR_UNSUPPORTED and travels through the stock emitter; where the reference itself returns an error (an unknown
  * type under policy "fail", a json.Number that is no integer, "unknown type of value") the call fails with TFGPU_ERR_INVALID.  */
 typedef struct tfgpu_dbz_emit_options {

@@ -920,12 +920,15 @@ class Emitter:
         self.params = enriched(params)
         self.database, self.server = self.given.get("database.dbname", ""), self.given.get("topic.prefix", "")
         self.version, self.drop_keys, self.ignore_unknown_sources = version, drop_keys, ignore_unknown_sources
-        for k in ("key.converter", "value.converter"):
-            if self.params[k] != "org.apache.kafka.connect.json.JsonConverter":
-                raise NotRestated(self.params[k])
-        for k in ("key.converter.schemas.enable", "value.converter.schemas.enable"):
-            if self.params[k] != "true":
-                raise NotRestated("%s=false (PackerSkipSchema)" % k)
+        # the packers (packer/factory.go:13-98) and parameters.Validate (validate.go:5-17)
+        for k in ("key.converter.schema.registry.url", "value.converter.schema.registry.url", "value.converter.ysr.namespace.id"):
+            if self.given.get(k, ""):
+                raise NotRestated("%s: the schema-registry packers" % k)
+        self.key_schema = self.given.get("key.converter.schemas.enable", "") != "false"
+        self.val_schema = self.given.get("value.converter.schemas.enable", "") != "false"
+        bs = self.given.get("dt.batching.max.size", "")
+        if re.match(r"^[+-]?[0-9]{1,18}$", bs) and int(bs) != 0:
+            raise EmitError("dt.batching.max.size can be used ONLY with schema-registry for values encoding" if drop_keys else "dt.batching.max.size can be used only with lb/yds")
 
     # makeValues (emitter_value_converter.go:202-242)
     def make_values(self, cols, names, values, keys_only):
@@ -1029,10 +1032,13 @@ class Emitter:
     def emit_one(self, it: Item, snapshot, emit_type):
         key = None
         if not self.drop_keys:
-            key = self.pack(gomarshal(self.make_key(it, emit_type == INSERT_EVENT)), self.schema_key(it))
+            key = gomarshal(self.make_key(it, emit_type == INSERT_EVENT))
+            if self.key_schema:   # PackerIncludeSchema, else PackerSkipSchema (packer_skip_schema.go:12-19): the payload alone
+                key = self.pack(key, self.schema_key(it))
         if emit_type == TOMBSTONE:
             return key, None
-        return key, self.pack(self.val_payload(it, snapshot, emit_type), self.schema_val(it))
+        val = self.val_payload(it, snapshot, emit_type)
+        return key, (self.pack(val, self.schema_val(it)) if self.val_schema else val)
 
     def keys_changed(self, it: Item) -> bool:
         """ChangeItem.KeysChanged (change_item.go:237-286), over Go values: same dynamic type and same value"""

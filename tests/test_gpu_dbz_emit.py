@@ -196,7 +196,9 @@ def test_parameter_variants(tf):
     n = b.nrows
     meta = (list(range(n)), list(range(n)), [10 ** 18 + r for r in range(n)])
     for params, kw in [({"decimal.handling.mode": "string"}, {}), ({"dt.add.original.type.info": "true"}, {}), ({}, {"drop_keys": True}), ({}, {"snapshot": True}),
-                       ({"unavailable.value.placeholder": "<toast>"}, {}), ({}, {"version": "2.0.0"}), ({"topic.prefix": "pre\"fix", "database.dbname": "dβ"}, {})]:
+                       ({"unavailable.value.placeholder": "<toast>"}, {}), ({}, {"version": "2.0.0"}), ({"topic.prefix": "pre\"fix", "database.dbname": "dβ"}, {}),
+                       ({"key.converter.schemas.enable": "false"}, {}), ({"value.converter.schemas.enable": "false", "key.converter": "io.confluent.connect.json.JsonSchemaConverter"}, {}),
+                       ({"key.converter.schemas.enable": "false", "value.converter.schemas.enable": "false", "dt.batching.max.size": "abc"}, {})]:
         got, want, rows = emit_both(tf, b, table, dict(PARAMS, **params), meta, **kw)
         assert_same(got, want, rows)
     # TOAST: a schema column the rows do not carry becomes the placeholder (buildKV, emitter_value_converter.go:311-323)
@@ -291,7 +293,7 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", "1"]]])
         assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value) and "stock emitter" in str(ei.value), str(ei.value)
-    for params in ({"key.converter": "io.confluent.connect.json.JsonSchemaConverter"}, {"value.converter.schemas.enable": "false"}, {"dt.source.type": "mysql"},
+    for params in ({"key.converter.schema.registry.url": "http://sr:8081"}, {"value.converter.ysr.namespace.id": "ns"}, {"dt.source.type": "mysql"},
                    {"decimal.handling.mode": "double"}):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "double", False, "pg:numeric")], [[["int32", 1], ["jsonnum", "1"]]], dict(PARAMS, **params))
@@ -319,6 +321,9 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
     with pytest.raises(tf.TfgpuError) as ei:   # past 128 bits: not decided on the device
         call(base + [("x", "double", False, "pg:numeric")], [[["int32", 1], ["jsonnum", "4" + "0" * 38]]])
     assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value)
+    with pytest.raises(tf.TfgpuError) as ei:   # parameters.Validate
+        call(base, [[["int32", 1]]], dict(PARAMS, **{"dt.batching.max.size": "1048576"}))
+    assert ei.value.code == tf.ERR_INVALID and "dt.batching.max.size" in str(ei.value)
     with pytest.raises(tf.TfgpuError) as ei:   # a column the schema does not know
         b = abi.batch_from_rows(schema_of(base + [("y", "utf8", False, "pg:text")]), ["id", "y"], [[["int32", 1], ["string", "1"]]], "public", "t")
         tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(base)), tf.DeviceBatch.upload(b))

@@ -3,7 +3,8 @@
 // Reference: queue.DebeziumSerializer.serialize (pkg/serializer/queue/debezium_serializer.go:26-43) → Emitter.EmitKV
 // (pkg/debezium/emitter_value_converter.go:574-690): 0..3 (key, value) messages per ChangeItem — one for an insert or a plain
 // update, (delete, tombstone) for a delete, (delete, tombstone, insert) for an update that changed its primary key.  Every
-// message is PackerIncludeSchema.Pack (packer/packer_include_schema.go:14-40): {"payload":P,"schema":S} with S rendered once per
+// message is PackerIncludeSchema.Pack (packer/packer_include_schema.go:14-40; PackerSkipSchema's bare payload when the settings
+// disable schemas): {"payload":P,"schema":S} with S rendered once per
 // table (ToKafkaSchemaKey / ToKafkaSchemaVal, :384-448; getFieldDescr, fields_descr.go:19-69; buildSourceSchemaDescr,
 // fields_descr_source.go:7-107) and P = valPayload (:456-527) / makeKey (:255-271), all Go maps marshalled by
 // util.JSONMarshalUnescape: members in byte order of their names, no HTML escaping.
@@ -875,11 +876,21 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     static const char *const DEFAULTS[][2] = {{"database.dbname", ""}, {"topic.prefix", ""}, {"dt.unknown.types.policy", "fail"}, {"dt.add.original.type.info", "false"},
       {"dt.source.type", ""}, {"decimal.handling.mode", "precise"}, {"tombstones.on.delete", "true"}, {"binary.handling.mode", "bytes"},
       {"unavailable.value.placeholder", "__debezium_unavailable_value"}, {"key.converter", "org.apache.kafka.connect.json.JsonConverter"},
-      {"value.converter", "org.apache.kafka.connect.json.JsonConverter"}, {"key.converter.schemas.enable", "true"}, {"value.converter.schemas.enable", "true"}};
+      {"value.converter", "org.apache.kafka.connect.json.JsonConverter"}, {"key.converter.schemas.enable", "true"}, {"value.converter.schemas.enable", "true"},
+      {"dt.batching.max.size", "0"}};
     for (auto &d : DEFAULTS) P.m[d[0]] = d[1];
     for (int i = 0; i < o->nparams; i++) if (o->param_keys[i]) P.m[o->param_keys[i]] = o->param_values[i] ? o->param_values[i] : "";
-    for (const char *k : {"key.converter", "value.converter"}) if (P.get(k) != "org.apache.kafka.connect.json.JsonConverter") return fail(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + k + "=" + P.get(k) + " (schema registry packers) stays with the stock emitter");
-    for (const char *k : {"key.converter.schemas.enable", "value.converter.schemas.enable"}) if (P.get(k) != "true") return fail(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + k + "=false (PackerSkipSchema) stays with the stock emitter");
+    // the packers (packer/factory.go:13-98): a schema registry URL / YSR namespace selects the registry packers (host), schemas.enable=false the
+    // payload-only packer, anything else PackerIncludeSchema; the converter class names are not consulted there
+    for (const char *k : {"key.converter.schema.registry.url", "value.converter.schema.registry.url", "value.converter.ysr.namespace.id"})
+      if (!P.get(k).empty()) return fail(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + k + " is set: the schema-registry packers stay with the stock emitter");
+    const bool key_schema = P.get("key.converter.schemas.enable") != "false", val_schema = P.get("value.converter.schemas.enable") != "false";
+    {  // parameters.Validate (validate.go:5-17): dt.batching.max.size needs a schema registry (or logbroker)
+      const std::string &bs = P.get("dt.batching.max.size");
+      long long v = 0; bool ok = !bs.empty();   // strconv.Atoi: anything it refuses counts as 0
+      { size_t i = (bs[0] == '+' || bs[0] == '-') ? 1 : 0; if (i >= bs.size() || bs.size() - i > 18) ok = false; for (; ok && i < bs.size(); i++) { if (bs[i] < '0' || bs[i] > '9') ok = false; else v = v * 10 + (bs[i] - '0'); } }
+      if (ok && v != 0) return fail(TFGPU_ERR_INVALID, o->drop_keys ? "tfgpu_debezium_emit: dt.batching.max.size can be used ONLY with schema-registry for values encoding" : "tfgpu_debezium_emit: dt.batching.max.size can be used only with lb/yds");
+    }
     if (P.get("binary.handling.mode") != "bytes") return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unsupported binary.handling.mode: " + P.get("binary.handling.mode"));
     const std::string &source_type = P.get("dt.source.type");
     if (!source_type.empty() && source_type != "pg") return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: dt.source.type=" + source_type + " stays with the stock emitter");
@@ -918,7 +929,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       if (ts.cols[i].flags & TFGPU_COL_KEY) { if (!fields_key.empty()) fields_key += ","; fields_key += plans[(size_t)i].descr; }
     }
     const std::string record = server + "." + b->ns + "." + b->table;
-    const std::string key_schema = "{\"fields\":[" + fields_key + "],\"name\":" + jstr(record + ".Key") + ",\"optional\":false,\"type\":\"struct\"}";
+    const std::string key_schema_json = "{\"fields\":[" + fields_key + "],\"name\":" + jstr(record + ".Key") + ",\"optional\":false,\"type\":\"struct\"}";
     auto side = [&](const char *field) { return "{\"field\":\"" + std::string(field) + "\",\"fields\":[" + fields_all + "],\"name\":" + jstr(record + ".Value") + ",\"optional\":true,\"type\":\"struct\"}"; };
     auto f = [](const char *field, const char *type, bool optional) { return std::string("{\"field\":\"") + field + "\",\"optional\":" + (optional ? "true" : "false") + ",\"type\":\"" + type + "\"}"; };
     std::string src_fields = f("version", "string", false) + "," + f("connector", "string", false) + "," + f("name", "string", false) + "," + f("ts_ms", "int64", false) +
@@ -930,7 +941,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     if (source_type == "pg") src_schema += "\"name\":\"io.debezium.connector.postgresql.Source\",";
     src_schema += "\"optional\":false,\"type\":\"struct\"}";
     const std::string tx_schema = "{\"field\":\"transaction\",\"fields\":[" + f("id", "string", false) + "," + f("total_order", "int64", false) + "," + f("data_collection_order", "int64", false) + "],\"optional\":true,\"type\":\"struct\"}";
-    const std::string val_schema = "{\"fields\":[" + side("before") + "," + side("after") + "," + src_schema + "," + f("op", "string", false) + "," + f("ts_ms", "int64", true) + "," + tx_schema +
+    const std::string val_schema_json = "{\"fields\":[" + side("before") + "," + side("after") + "," + src_schema + "," + f("op", "string", false) + "," + f("ts_ms", "int64", true) + "," + tx_schema +
       "],\"name\":" + jstr(record + ".Envelope") + ",\"optional\":false,\"type\":\"struct\"}";
 
     lap("plan");
@@ -980,7 +991,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     std::string blob;
     CellList V; V.blob = &blob;
     {
-      V.push_const(EA_VALUE, "{\"payload\":{\"after\":");
+      V.push_const(EA_VALUE, val_schema ? "{\"payload\":{\"after\":" : "{\"after\":");
       V.push_const(EA_AFTER_NULL, "null");
       std::vector<Member> after;
       std::vector<char> in_batch((size_t)ts.ncols, 0);
@@ -997,7 +1008,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       push_object(V, EA_BEFORE_D, before_d);
       if (has_prev) push_object(V, EA_BEFORE_U, before_u);
       ECell tail{}; tail.kind = EC_TAIL; tail.apply = EA_VALUE; V.cells.push_back(tail);
-      V.push_const(EA_VALUE, ",\"schema\":" + val_schema + "}");
+      if (val_schema) V.push_const(EA_VALUE, ",\"schema\":" + val_schema_json + "}");
       // the tail's segments: source is a map too — connector, db, lsn, name, schema, snapshot, table, ts_ms, txId, version, xmin
       std::vector<std::pair<std::string, int>> segs;
       const std::string snap = o->snapshot ? "true" : "false";
@@ -1017,13 +1028,13 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     // ---- keys: {"payload":{pk members},"schema":KS} ----
     CellList K; K.blob = &blob;
     if (!o->drop_keys) {
-      K.push_const(EA_KEY, "{\"payload\":");
+      if (key_schema) K.push_const(EA_KEY, "{\"payload\":");
       std::vector<Member> from_new, from_old;
       for (auto &c : b->cols) { const int i = col_index(c.name); if (ts.cols[i].flags & TFGPU_COL_KEY) from_new.push_back({c.name, &c, &plans[(size_t)i], false, ""}); }
       for (auto &c : b->old_keys) { const int i = col_index(c.name); if (ts.cols[i].flags & TFGPU_COL_KEY) from_old.push_back({c.name, &c, &plans[(size_t)i], true, ""}); }
       push_object(K, EA_KEY_NEW, from_new);
       if (has_old) push_object(K, EA_KEY_OLD, from_old);
-      K.push_const(EA_KEY, ",\"schema\":" + key_schema + "}");
+      if (key_schema) K.push_const(EA_KEY, ",\"schema\":" + key_schema_json + "}");
     }
     if (V.cells.size() > 0xFFFF || K.cells.size() > 0xFFFF) return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: more than 65535 cells per message");
 
