@@ -17,8 +17,7 @@ Postgres-typed rows, the `DebeziumSerializer` of the queue sinks (pkg/serializer
 Everything the reference builds is a Go map marshalled by util.JSONMarshalUnescape (pkg/util/encode_json.go:10-19): keys in byte
 order, no HTML escaping.  Only the product's test-suite, smoke() and bench.py's cpu_baseline leg use this file; the product never does.
 
-Not restated (third-party parsers the reference calls; NotRestated is raised by name): pg:interval (pgtype.Interval.DecodeText),
-hstore given as text (HstoreToJSON), string inputs of `timestamp without time zone` (pgtype.Timestamp.Set(string)), pg arrays,
+Not restated (third-party parsers the reference calls; NotRestated is raised by name): hstore given as text (HstoreToJSON), string inputs of `timestamp without time zone` (pgtype.Timestamp.Set(string)), pg arrays,
 mysql: / ydb: original types, the schema-registry packers (Confluent JSON / skip-schema).  PINNED against the reference's fixtures
 pkg/debezium/pg/tests/testdata/emitter_crud_test__*.txt (copied to tests/golden/debezium_emitter/) the way the reference's own test
 compares them (pkg/debezium/testutil/test.go:24-152: the fixtures come from a vanilla Debezium, so both sides are normalised).
@@ -475,6 +474,73 @@ def _pg_clock_micros(s: bytes):
     return us
 
 
+def _go_atoi64(t: bytes) -> int:
+    if not re.match(rb"^[+-]?[0-9]+$", t) or not (-(1 << 63) <= int(t) < (1 << 63)):
+        raise EmitError("bad interval format")
+    return int(t)
+
+
+def _wrap(x: int, bits: int) -> int:
+    x &= (1 << bits) - 1
+    return x - (1 << bits) if x >> (bits - 1) else x
+
+
+def pg_interval_decode(src: bytes):
+    """jackc/pgtype v1.12.0 (go.mod:340 pins it) Interval.DecodeText, restated from the module's published source — the module itself is not in
+    the reference's tree: space-separated (count, unit) pairs, an optional trailing [-]H:MM:SS[.ffffff]; → (months, days, microseconds)"""
+    parts = src.split(b" ")
+    months = days = micro = 0
+    for i in range(0, len(parts) - 1, 2):
+        sc = _go_atoi64(parts[i])
+        unit = parts[i + 1]
+        if unit in (b"year", b"years"):
+            months = _wrap(months + _wrap(_wrap(sc * 12, 64), 32), 32)
+        elif unit in (b"mon", b"mons"):
+            months = _wrap(months + _wrap(sc, 32), 32)
+        elif unit in (b"day", b"days"):
+            days = _wrap(sc, 32)
+    if len(parts) % 2 == 1:
+        tp = parts[-1].split(b":", 2)
+        if len(tp) != 3:
+            raise EmitError("bad interval format")
+        if tp[0] == b"":
+            raise NotRestated("interval: index out of range in pgtype")
+        neg = tp[0][:1] == b"-"
+        if neg:
+            tp[0] = tp[0][1:]
+        h, m = _go_atoi64(tp[0]), _go_atoi64(tp[1])
+        sp = tp[2].split(b".")
+        sec = _go_atoi64(sp[0])
+        us = 0
+        if len(sp) == 2:
+            us = _go_atoi64(sp[1])
+            for _ in range(6 - len(sp[1])):
+                us *= 10
+        micro = _wrap(_wrap(h * 3600000000, 64) + _wrap(m * 60000000, 64) + _wrap(sec * 1000000, 64) + us, 64)
+        if neg:
+            micro = _wrap(-micro, 64)
+    return months, days, micro
+
+
+def parse_postgres_interval(s: bytes, mode: str) -> int:
+    """ParsePostgresInterval over ExtractPostgresIntervalArray (typeutil/helpers.go:469-507, 658-727): the uint64 the reference marshals"""
+    if mode != "numeric":
+        raise EmitError("unsupported interval.handling.mode: %s" % mode)
+    months, days, micro = pg_interval_decode(s.replace(b"months", b"mons").replace(b"month", b"mon"))
+    years, mrem = trunc_div(months, 12), months - trunc_div(months, 12) * 12
+    hours = minutes = seconds = us = 0
+    if micro != 0:
+        rem = micro
+        hours = trunc_div(rem, 3600000000)
+        rem -= hours * 3600000000
+        minutes = trunc_div(rem, 60000000)
+        rem -= minutes * 60000000
+        seconds = trunc_div(rem, 1000000)
+        us = abs(rem - seconds * 1000000)   # the array holds |microseconds| as six digits: the sign is gone when it is parsed back
+    total = _wrap(years * 31557600 + mrem * 2629800 + days * 86400 + hours * 3600 + minutes * 60 + seconds, 64)
+    return ((total & ((1 << 64) - 1)) * 1000000 + us) & ((1 << 64) - 1)
+
+
 # ---- AddPg (pg/emitter.go:262-629) ----------------------------------------------------------------------------------------------------
 def _ts_kind(t, what):
     return re.match(r"^pg:%s(\(\d\))? %s time zone$" % (what[0], what[1]), t) is not None
@@ -665,7 +731,7 @@ def add_pg(col: Col, v, original_type: str, into_arr: bool, params):
     if t.startswith("pg:character(") or t.startswith("pg:character varying(") or t in ("pg:character", "pg:character varying"):
         return _need_string(v, t)
     if t.startswith("pg:interval"):
-        raise NotRestated("pg:interval (pgtype.Interval.DecodeText)")
+        return parse_postgres_interval(_need_string(v, t), params["interval.handling.mode"])
     if col.properties.get("pg:enum_all_values") is not None:
         return _need_string(v, t)
     raise UnknownTypeError("unknown column type: %s, column name: %s" % (t, col.name))

@@ -35,7 +35,7 @@ TABLE = [("id", "int32", True, "pg:integer"), ("bl", "boolean", False, "pg:boole
          ("A_first", "int64", False, "pg:bigint"), ("tm3", "utf8", False, "pg:time(3) without time zone"), ("tm", "utf8", False, "pg:time without time zone"),
          ("ttz", "utf8", False, "pg:time with time zone"), ("ttz1", "utf8", False, "pg:time(1) with time zone"), ("mo", "utf8", False, "pg:money"), ("xm", "any", False, "pg:xml"),
          ("pt", "any", False, "pg:point"), ("tsr", "any", False, "pg:tsrange"), ("nr", "any", False, "pg:numrange"), ("tzr", "any", False, "pg:tstzrange"),
-         ("hs", "any", False, "pg:USER-DEFINED:hstore")]
+         ("hs", "any", False, "pg:USER-DEFINED:hstore"), ("iv", "utf8", False, "pg:interval"), ("iv2", "utf8", False, "pg:interval day to second")]
 
 
 def schema_of(table):
@@ -79,7 +79,10 @@ def random_rows(n, seed):
                ["string", pick(["[19e-1,191e-2)", "[1.9,1.91)", "(1,2]", "[-1.5e3,1e-2)", "[.123e3,1.277559e+7]", "(0e5,-0.0)"])],
                ["string", pick(['[2010-01-01 01:00:00-05,2010-01-01 02:00:00-08)', '["2010-01-01 09:00:00+03","2010-01-01 13:00:00+03")', "[2010-01-01 06:00:00Z,2010-01-01 10:00:00Z)",
                                 "(2020-02-29 23:59:59.123+05:30,2021-01-01 00:00:00+00]"])],
-               ["json", pick(['{"a":"1","b":"2"}', '{}', '{"k":null}'])]]
+               ["json", pick(['{"a":"1","b":"2"}', '{}', '{"k":null}'])],
+               ["string", pick(["1 day 01:00:00.000000", "1 month", "1 year", "40 years", "14 mon 3 day 04:05:06.000007", "1 year 2 mons 3 days 04:05:06.00007", "-1 days +02:03:00",
+                                "1 mon -2 days", "-00:00:01", "-00:00:00.5", "00:00:00", "3 fortnights 01:02:03", "2 months 5 days", "25:61:61.1234567", "1 day"])],
+               ["string", pick(["3 days 04:05:06", "04:05:06.5", "-3 days -04:05:06.123456"])]]
         for k in range(1, len(row)):
             if rng.integers(0, 9) == 0:
                 row[k] = ["nil", None]
@@ -248,7 +251,7 @@ DEVICE_TYPES = ("pg:xml", "pg:point", "pg:numrange", "pg:tsrange", "pg:tstzrange
 
 
 def device_resident(t):
-    return (t in DEVICE_TYPES or t.startswith("pg:character") or t.startswith("pg:bit(") or t.startswith("pg:bit varying(") or t.startswith("pg:timestamp") or t.startswith("pg:time") or E.is_pg_numeric(t))
+    return (t in DEVICE_TYPES or t.startswith("pg:character") or t.startswith("pg:bit(") or t.startswith("pg:bit varying(") or t.startswith("pg:timestamp") or t.startswith("pg:time") or t.startswith("pg:interval") or E.is_pg_numeric(t))
 
 
 @pytest.mark.parametrize("name", ["insert", "update0", "update1", "update2", "delete"])
@@ -258,7 +261,7 @@ def test_the_references_crud_fixtures_cut_to_the_device_columns(tf, name):
     from test_dbz_emitter_oracle import read
     it = E.unmarshal_change_item(read(name))
     keep = [c for c in it.cols if device_resident(c.original_type)]
-    assert len(keep) == 58   # every column of the fixtures' table but `iv` (pg:interval)
+    assert len(keep) == 59   # every column of the fixtures' table
     kn = {c.name for c in keep}
     table = [(c.name, c.dtype, c.key, c.original_type) for c in keep]
 
@@ -289,7 +292,7 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
         b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "t")
         return tf.debezium_emit(abi.dbz_emit_options(params, schema_of(table), **kw), tf.DeviceBatch.upload(b))
     base = [("id", "int32", True, "pg:integer")]
-    for t in ("pg:interval", "pg:interval day to second", "pg:integer[]", "mysql:int(11)", "ydb:Int64"):
+    for t in ("pg:integer[]", "pg:interval[]", "mysql:int(11)", "ydb:Int64"):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", "1"]]])
         assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value) and "stock emitter" in str(ei.value), str(ei.value)
@@ -314,13 +317,17 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", v]]])
         assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value), (t, v, str(ei.value))
-    for t, v in (("pg:point", "(1,2,3)"), ("pg:point", "(a,b)"), ("pg:money", "$1,000.00"), ("pg:money", "$1e3"), ("pg:numrange", "[1ee2,3)")):
+    for t, v in (("pg:point", "(1,2,3)"), ("pg:point", "(a,b)"), ("pg:money", "$1,000.00"), ("pg:money", "$1e3"), ("pg:numrange", "[1ee2,3)"), ("pg:interval", "one day"), ("pg:interval", "1 day 01:02"),
+                 ("pg:interval", "1 day 01:02:03.")):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", v]]])
         assert ei.value.code == tf.ERR_INVALID and "colName: x" in str(ei.value), (t, v, str(ei.value))
     with pytest.raises(tf.TfgpuError) as ei:   # past 128 bits: not decided on the device
         call(base + [("x", "double", False, "pg:numeric")], [[["int32", 1], ["jsonnum", "4" + "0" * 38]]])
     assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value)
+    with pytest.raises(tf.TfgpuError) as ei:   # "unsupported interval.handling.mode" (ParsePostgresInterval)
+        call(base + [("x", "utf8", False, "pg:interval")], [[["int32", 1], ["string", "1 day"]]], dict(PARAMS, **{"interval.handling.mode": "string"}))
+    assert ei.value.code == tf.ERR_INVALID and "colName: x" in str(ei.value)
     with pytest.raises(tf.TfgpuError) as ei:   # parameters.Validate
         call(base, [[["int32", 1]]], dict(PARAMS, **{"dt.batching.max.size": "1048576"}))
     assert ei.value.code == tf.ERR_INVALID and "dt.batching.max.size" in str(ei.value)

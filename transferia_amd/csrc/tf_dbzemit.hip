@@ -19,8 +19,8 @@
 // emitter): pg:boolean, bit(1), smallint, integer, bigint, oid, real, double precision, text / character* / uuid / cidr /
 // macaddr / citext / int4range / int8range / daterange, inet, bytea, date, timestamp[(p)] with / without time zone (time.Time
 // values), time[(p)] with / without time zone, json / jsonb, hstore (a map), xml, numeric[(p,s)] (precise: up to 38 digits;
-// string), money, bit(n) / bit varying(n), point, tsrange, numrange and tstzrange (two plain bounds).  Texts whose reading belongs
-// to jackc/pgtype's parsers (interval; infinity / empty / unbounded ranges; odd clock shapes) are left to the host, value by value.
+// string), money, bit(n) / bit varying(n), point, interval, tsrange, numrange and tstzrange (two plain bounds).  Texts whose reading
+// belongs to jackc/pgtype's parsers (infinity / empty / unbounded ranges; odd clock shapes) are left to the host, value by value.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -39,7 +39,7 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
@@ -457,6 +457,56 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
       put_lit(s, "\\\""); emit_date(s, l); s.put(' '); emit_clock(s, l); put_lit(s, "+00\\\",\\\""); emit_date(s, r); s.put(' '); emit_clock(s, r); put_lit(s, "+00\\\"");
       s.put(vp[vn - 1]); s.put('"'); return 0;
     }
+    case DK_INTERVAL: {  // ParsePostgresInterval (typeutil/helpers.go:469-507) over pgtype v1.12.0's Interval.DecodeText: (count, unit) pairs, then [-]H:MM:SS[.f]
+      uint32_t parts = 1;
+      for (uint32_t i = 0; i < vn; i++) if (vp[i] == ' ') parts++;
+      int32_t months = 0, days = 0; int64_t micro = 0;
+      PtrView f{vp};
+      uint32_t a = 0;  // start of the current part
+      auto part_end = [&](uint32_t from) { uint32_t e = from; while (e < vn && vp[e] != ' ') e++; return e; };
+      for (uint32_t k = 0; k + 1 < parts; k += 2) {
+        const uint32_t e0 = part_end(a), a1 = e0 + 1, e1 = part_end(a1);
+        int64_t sc;
+        if (parse_int64(f, a, e0, false, &sc) != 0) return 1;  // "bad interval format"
+        const uint8_t *u = vp + a1; const uint32_t ul = e1 - a1;
+        auto is = [&](const char *w, uint32_t wl) { if (ul != wl) return false; for (uint32_t q = 0; q < wl; q++) if (u[q] != (uint8_t)w[q]) return false; return true; };
+        if (is("year", 4) || is("years", 5)) months = (int32_t)((uint32_t)months + (uint32_t)((uint64_t)sc * 12ull));
+        else if (is("mon", 3) || is("mons", 4) || is("month", 5) || is("months", 6)) months = (int32_t)((uint32_t)months + (uint32_t)(uint64_t)sc);  // ("months" → "mons", "month" → "mon" first)
+        else if (is("day", 3) || is("days", 4)) days = (int32_t)(uint32_t)(uint64_t)sc;
+        a = e1 + 1;
+      }
+      if (parts & 1) {
+        uint32_t c1 = vn, c2 = vn;
+        for (uint32_t i = a; i < vn; i++) if (vp[i] == ':') { if (c1 == vn) c1 = i; else { c2 = i; break; } }
+        if (c2 == vn) return 1;          // fewer than three ':'-separated pieces
+        if (c1 == a) return 2;           // an empty hour text: pgtype indexes its first byte
+        bool neg = false; uint32_t ha = a;
+        if (vp[a] == '-') { neg = true; ha++; }
+        int64_t h, m, sec, us = 0;
+        if (parse_int64(f, ha, c1, false, &h) != 0 || parse_int64(f, c1 + 1, c2, false, &m) != 0) return 1;
+        uint32_t d1 = vn, dots = 0;
+        for (uint32_t i = c2 + 1; i < vn; i++) if (vp[i] == '.') { if (!dots) d1 = i; dots++; }
+        if (parse_int64(f, c2 + 1, d1, false, &sec) != 0) return 1;
+        if (dots == 1) {
+          if (parse_int64(f, d1 + 1, vn, false, &us) != 0) return 1;
+          for (uint32_t q = vn - d1 - 1; q < 6; q++) us = (int64_t)((uint64_t)us * 10ull);
+        }
+        uint64_t mu = (uint64_t)h * 3600000000ull + (uint64_t)m * 60000000ull + (uint64_t)sec * 1000000ull + (uint64_t)us;
+        if (neg) mu = 0ull - mu;
+        micro = (int64_t)mu;
+      }
+      const int64_t years = months / 12, mrem = months % 12;
+      int64_t hours = 0, minutes = 0, seconds = 0; uint64_t usabs = 0;
+      if (micro != 0) {
+        int64_t rem = micro;
+        hours = rem / 3600000000ll; rem %= 3600000000ll;
+        minutes = rem / 60000000ll; rem %= 60000000ll;
+        seconds = rem / 1000000ll; rem %= 1000000ll;
+        usabs = (uint64_t)(rem < 0 ? -rem : rem);  // the array holds |microseconds|: the sign is gone when it is parsed back
+      }
+      const uint64_t total = (uint64_t)years * 31557600ull + (uint64_t)mrem * 2629800ull + (uint64_t)(int64_t)days * 86400ull + (uint64_t)hours * 3600ull + (uint64_t)minutes * 60ull + (uint64_t)seconds;
+      emit_u64(s, total * 1000000ull + usabs); return 0;
+    }
     case DK_WRONG_TYPE: return 1;
     default: return 2;
   }
@@ -681,7 +731,10 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
     else if (mode == "string") { kafka = "string"; cp.arg = 1; }
     else unsupported(name, "decimal.handling.mode=" + mode);
   }
-  else if (starts(t, "pg:interval")) unsupported(name, "original type " + t);   // pgtype.Interval.DecodeText
+  else if (starts(t, "pg:interval")) {
+    kafka = "int64"; dname = "io.debezium.time.MicroDuration";
+    cp.dk = P.get("interval.handling.mode") == "numeric" ? DK_INTERVAL : DK_WRONG_TYPE;  // "unsupported interval.handling.mode" fails the first non-nil value
+  }
   else if ((d = time_family(t, "time", "with")) != -2) { kafka = "string"; dname = "io.debezium.time.ZonedTime"; cp.dk = DK_TIMETZ; }
   else if ((d = time_family(t, "time", "without")) != -2) {
     const uint32_t divider = (d >= 1 && d <= 3) ? 1000u : 1u;  // GetTimeDivider (helpers.go:106-123)
@@ -753,7 +806,8 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_TS: return in({TFGPU_R_TIME}) ? 0 : 2;
     case DK_TSTZ: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
     case DK_JSON: return in({TFGPU_R_JSON}) || (in({TFGPU_R_STRING}) && !arg) ? 0 : 2;
-    case DK_TIME: case DK_TIMETZ: case DK_MONEY: case DK_XML: case DK_POINT: case DK_TSRANGE: case DK_NUMRANGE: case DK_TSTZRANGE: return in({TFGPU_R_STRING}) ? 0 : 2;
+    case DK_TIME: case DK_TIMETZ: case DK_MONEY: case DK_XML: case DK_POINT: case DK_TSRANGE: case DK_NUMRANGE: case DK_TSTZRANGE: case DK_INTERVAL: return in({TFGPU_R_STRING}) ? 0 : 2;
+    case DK_WRONG_TYPE: return 0;
     case DK_NUMERIC: case DK_NUMERIC_TEXT: return in({TFGPU_R_STRING, TFGPU_R_JSONNUM}) ? 0 : 1;
     default: return 2;
   }
@@ -877,7 +931,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       {"dt.source.type", ""}, {"decimal.handling.mode", "precise"}, {"tombstones.on.delete", "true"}, {"binary.handling.mode", "bytes"},
       {"unavailable.value.placeholder", "__debezium_unavailable_value"}, {"key.converter", "org.apache.kafka.connect.json.JsonConverter"},
       {"value.converter", "org.apache.kafka.connect.json.JsonConverter"}, {"key.converter.schemas.enable", "true"}, {"value.converter.schemas.enable", "true"},
-      {"dt.batching.max.size", "0"}};
+      {"dt.batching.max.size", "0"}, {"interval.handling.mode", "numeric"}};
     for (auto &d : DEFAULTS) P.m[d[0]] = d[1];
     for (int i = 0; i < o->nparams; i++) if (o->param_keys[i]) P.m[o->param_keys[i]] = o->param_values[i] ? o->param_values[i] : "";
     // the packers (packer/factory.go:13-98): a schema registry URL / YSR namespace selects the registry packers (host), schemas.enable=false the
