@@ -8,6 +8,7 @@ Postgres-typed rows, the `DebeziumSerializer` of the queue sinks (pkg/serializer
   buildSourceSchemaDescr                             pkg/debezium/fields_descr_source.go:7-107
   kindToOp                                           pkg/debezium/kind.go:8-32
   AddPg / GetKafkaTypeDescrByPgType                  pkg/debezium/pg/emitter.go:20-260, 262-629
+  AddYDB / GetKafkaTypeDescrByYDBType                pkg/debezium/ydb/emitter.go:15-232
   addCommon / mapYtTypeToKafkaType                   pkg/debezium/emitter_common.go:68-226
   typeutil helpers (bits, decimals, times, ranges)   pkg/debezium/typeutil/helpers.go, field_descr.go
   PackerIncludeSchema.Pack                           pkg/debezium/packer/packer_include_schema.go:14-40
@@ -18,7 +19,7 @@ Everything the reference builds is a Go map marshalled by util.JSONMarshalUnesca
 order, no HTML escaping.  Only the product's test-suite, smoke() and bench.py's cpu_baseline leg use this file; the product never does.
 
 Not restated (third-party parsers the reference calls; NotRestated is raised by name): hstore given as text (HstoreToJSON), string inputs of `timestamp without time zone` (pgtype.Timestamp.Set(string)), pg arrays,
-mysql: / ydb: original types, the schema-registry packers (Confluent JSON / skip-schema).  PINNED against the reference's fixtures
+mysql: original types, the schema-registry packers (Confluent JSON / skip-schema).  PINNED against the reference's fixtures
 pkg/debezium/pg/tests/testdata/emitter_crud_test__*.txt (copied to tests/golden/debezium_emitter/) the way the reference's own test
 compares them (pkg/debezium/testutil/test.go:24-152: the fixtures come from a vanilla Debezium, so both sides are normalised).
 """
@@ -775,6 +776,80 @@ def _any_value(v):
     raise NotRestated("any value given %s" % g)
 
 
+YDB_PLAIN = {"ydb:Bool": ("boolean", ""), "ydb:Int8": ("int8", ""), "ydb:Int16": ("int16", ""), "ydb:Int32": ("int32", ""), "ydb:Int64": ("int64", ""), "ydb:Uint8": ("int8", ""),
+             "ydb:Uint16": ("int16", ""), "ydb:Uint32": ("int32", ""), "ydb:Uint64": ("int64", ""), "ydb:Float": ("float", ""), "ydb:Double": ("double", ""), "ydb:String": ("bytes", ""),
+             "ydb:Utf8": ("string", ""), "ydb:Json": ("string", "io.debezium.data.Json"), "ydb:JsonDocument": ("string", "io.debezium.data.Json"), "ydb:Uuid": ("string", ""),
+             "ydb:Date": ("int32", "io.debezium.time.Date"), "ydb:Datetime": ("int64", "io.debezium.time.Timestamp"), "ydb:Timestamp": ("int64", "io.debezium.time.MicroTimestamp"),
+             "ydb:Interval": ("int64", "io.debezium.time.MicroDuration")}
+
+
+def ydb_type_descr(t: str, params):
+    """GetKafkaTypeDescrByYDBType (ydb/emitter.go:112-121)"""
+    if t == "ydb:Decimal":
+        return _decimal_mode_descr(params, ("bytes", "org.apache.kafka.connect.data.Decimal", {"parameters": {"scale": "9", "connect.decimal.precision": "22"}}))
+    if t == "ydb:DyNumber":
+        return "struct", "io.debezium.data.VariableScaleDecimal", {"doc": "Variable scaled decimal", "fields": [
+            {"type": "int32", "optional": False, "field": "scale"}, {"type": "bytes", "optional": False, "field": "value"}]}
+    if t in YDB_PLAIN:
+        return YDB_PLAIN[t] + (None,)
+    raise UnknownTypeError("unknown ydbType: %s" % t)
+
+
+def go_value(v):
+    """the Go value as json.Marshal sees it (v.AddVal(colName, colVal))"""
+    g, x = v
+    if g == "nil":
+        return None
+    if g == "bool":
+        return bool(x)
+    if g in INTS or g in UINTS or g == "duration":
+        return int(x)
+    if g == "float32":
+        return F32(float(x))
+    if g == "float64":
+        return F64(float(x))
+    if g == "string":
+        return _b(x)
+    if g == "bytes":
+        return GoBytes(_b(x))
+    if g == "jsonnum":
+        return JN(_b(x).decode())
+    if g == "json":
+        return decode_any(_b(x))
+    if g == "time":
+        return sprintf_debezium_time(x)   # time.Time.MarshalJSON: RFC3339Nano — the same text for UTC values
+    raise NotRestated(g)
+
+
+def add_ydb(col: Col, v, t: str, params):
+    """AddYDB (ydb/emitter.go:123-232)"""
+    g, x = v
+    if g == "nil":
+        return None
+    if t in ("ydb:Bool", "ydb:Int8", "ydb:Int16", "ydb:Int32", "ydb:Int64", "ydb:Uint8", "ydb:Uint16", "ydb:Uint32", "ydb:Float", "ydb:Double", "ydb:String", "ydb:Utf8", "ydb:Interval"):
+        return go_value(v)
+    if t == "ydb:Uint64":
+        if g != "uint64":
+            raise EmitError("unknown type of value for ydb:Uint64: %s" % g)
+        return _wrap(int(x), 64)
+    if t == "ydb:Decimal":
+        return decimal_to_debezium(_need_string(v, t), "numeric(22,9)", params)
+    if t == "ydb:DyNumber":
+        if g not in ("string", "jsonnum"):
+            raise EmitError("unknown type of value for ydb:DyNumber: %s" % g)
+        return decimal_to_debezium(_b(x), "numeric", dict(params, **{"decimal.handling.mode": "precise"}))
+    if t in ("ydb:Json", "ydb:JsonDocument"):
+        return gomarshal(go_value(v))
+    if t == "ydb:Uuid":
+        return _need_string(v, t)
+    if t in ("ydb:Date", "ydb:Datetime", "ydb:Timestamp"):
+        if g != "time":
+            raise EmitError("impossible type %s(%s): %s expect time.Time" % (col.name, t, g))
+        micro = x[0] * 1000000 + x[1] // 1000
+        return _wrap(trunc_div(x[0], 86400), 32) if t == "ydb:Date" else trunc_div(micro, 1000) if t == "ydb:Datetime" else micro
+    raise UnknownTypeError("unknown column type: %s, column name: %s" % (t, col.name))
+
+
 def add_common(col: Col, v):
     """addCommon (emitter_common.go:68-170)"""
     g, x = v
@@ -926,7 +1001,9 @@ def field_descr(col: Col, params, into_arr=False):
         if t.endswith("[]"):
             raise NotRestated("pg arrays")
         kafka, name, extra = pg_type_descr(col, into_arr, params)
-    elif t.startswith("mysql:") or t.startswith("ydb:"):
+    elif t.startswith("ydb:"):
+        kafka, name, extra = ydb_type_descr(t, params)
+    elif t.startswith("mysql:"):
         raise NotRestated(t)
     else:
         raise EmitError("unknown original type: %s" % t)
@@ -970,7 +1047,7 @@ def source_schema(source_type):
         d["name"] = "io.debezium.connector.postgresql.Source"
         fields += [{"type": "int64", "optional": True, "field": "lsn"}, {"type": "string", "optional": False, "field": "schema"},
                    {"type": "int64", "optional": True, "field": "txId"}, {"type": "int64", "optional": True, "field": "xmin"}]
-    elif source_type in ("mysql", "ydb"):
+    elif source_type == "mysql":
         raise NotRestated("source type %s" % source_type)
     d["fields"] = fields
     return d
@@ -1024,7 +1101,9 @@ class Emitter:
             if t.endswith("[]"):
                 raise NotRestated("pg arrays")
             return add_pg(c, v, t, False, self.params)
-        if t.startswith("mysql:") or t.startswith("ydb:"):
+        if t.startswith("ydb:"):
+            return add_ydb(c, v, t, self.params)
+        if t.startswith("mysql:"):
             raise NotRestated(t)
         if self.ignore_unknown_sources:
             return add_common(c, v)
@@ -1052,7 +1131,9 @@ class Emitter:
         st = self.params["dt.source.type"]
         if st == "pg":
             d.update({"connector": "postgresql", "lsn": it.lsn, "schema": it.schema, "txId": it.id, "xmin": None})
-        elif st in ("mysql", "ydb"):
+        elif st == "ydb":
+            d.update({"txId": _b(it.tx_id) if it.tx_id else None, "step": it.commit_time})
+        elif st == "mysql":
             raise NotRestated("source type %s" % st)
         return d
 
@@ -1158,6 +1239,10 @@ def restore(col: Col, raw):
             off = 0 if z == "Z" else (int(z[1:3]) * 3600 + int(z[4:6]) * 60) * (-1 if z[0] == "-" else 1)
             return ("time", (days_from_civil(y, mo, dd) * 86400 + h * 3600 + mi * 60 + s - off, ns, off))
         raise NotRestated("%s from %r" % (d, raw))
+    if d == "interval":
+        if isinstance(raw, JN) and re.match(r"^[+-]?[0-9]+$", raw):
+            return ("duration", int(raw))
+        raise NotRestated("interval from %r" % raw)
     if d in INTS or d in UINTS:
         if isinstance(raw, JN):
             if "." in raw or "e" in raw or "E" in raw:
@@ -1174,7 +1259,7 @@ def restore(col: Col, raw):
     if d == "boolean":
         return _plain(raw)
     if d in ("string", "utf8"):
-        if col.original_type == "pg:bytea":
+        if col.original_type in ("pg:bytea", "ydb:String"):
             if isinstance(raw, str):
                 try:
                     return ("bytes", base64.b64decode(raw, validate=True))

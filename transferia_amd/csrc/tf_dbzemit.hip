@@ -39,13 +39,13 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
        EA_KEY = 8 /* every event */, EA_KEY_NEW, EA_KEY_OLD };
 enum { EV_REGULAR = 0, EV_DELETE = 1, EV_TOMBSTONE = 2, EV_INSERT = 3 };  // emitType (emitter_value_converter.go:76-97)
-enum { TN_NONE = 0, TN_LSN, TN_TS, TN_ID };
+enum { TN_NONE = 0, TN_LSN, TN_TS, TN_ID, TN_STEP, TN_TXID };
 constexpr uint32_t CONST_INLINE = 64;
 
 struct ECell {
@@ -62,6 +62,7 @@ struct EParams {
   const uint8_t *kind; const uint8_t *old_present; const int32_t *src_row;
   int32_t has_old, has_prev, snapshot;
   const uint32_t *m_id; const uint64_t *m_lsn, *m_commit;
+  const uint32_t *m_tx_off; const uint8_t *m_tx;  // ChangeItem.TxID (dt.source.type = ydb)
   const uint8_t *blob;
   uint32_t tseg_off[6], tseg_len[6]; int32_t tnum[6]; int32_t ntseg;  // EC_TAIL: ,"op":" <op> then segment k followed by number k
   const double *p10; const uint64_t *p128;
@@ -352,7 +353,7 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
       if (c.repr == TFGPU_R_JSON) { emit_json_string(s, vp, vn, false); return 0; }  // the column holds json.Marshal's text: marshalling it again is the identity
       { s.put('"'); JsonEscSink<S> q{s}; emit_json_string(q, vp, vn, false); s.put('"'); }  // a Go string: its marshal, as a string
       return 0;
-    case DK_NUMERIC: return emit_numeric(s, vp, vn, ec.arg & 0xFFFFu, (ec.arg >> 16) != 0);
+    case DK_NUMERIC: return emit_numeric(s, vp, vn, ec.arg & 0xFFFFu, ((ec.arg >> 16) & 1u) != 0);
     case DK_NUMERIC_TEXT: emit_json_string(s, vp, vn, false); return 0;
     case DK_BITS: {  // ChangeItemsBitsToDebeziumHonest (helpers.go:48-78)
       bool any = false;
@@ -507,6 +508,12 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
       const uint64_t total = (uint64_t)years * 31557600ull + (uint64_t)mrem * 2629800ull + (uint64_t)(int64_t)days * 86400ull + (uint64_t)hours * 3600ull + (uint64_t)minutes * 60ull + (uint64_t)seconds;
       emit_u64(s, total * 1000000ull + usabs); return 0;
     }
+    case DK_MARSHAL: {  // v.AddVal(colName, colVal): json.Marshal of the Go value as it is (ydb/emitter.go:130-160)
+      if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { const double d = cell_f64(c, b); if (d != d || d - d != 0) return 1; }  // json: unsupported value
+      emit_json_cell(s, c, b, 0, false); return 0;
+    }
+    case DK_YDB_UINT64: emit_i64(s, (int64_t)b.v); return 0;  // int64(t)
+    case DK_YDB_DATE: emit_i64(s, (int64_t)(int32_t)(uint32_t)(uint64_t)trunc_div((int64_t)b.v, 86400)); return 0;  // DateToInt32
     case DK_WRONG_TYPE: return 1;
     default: return 2;
   }
@@ -522,6 +529,11 @@ template <class S> __device__ __forceinline__ void emit_tail(S &s, const EParams
       case TN_LSN: emit_u64(s, p.m_lsn ? p.m_lsn[k] : 0ull); break;
       case TN_TS: emit_u64(s, commit / 1000000ull); break;  // CommitTime / 1000000; GetPayloadTSMS().UnixNano() / 1000000 is the same number
       case TN_ID: emit_u64(s, p.m_id ? p.m_id[k] : 0u); break;
+      case TN_STEP: emit_u64(s, commit); break;
+      case TN_TXID:  // *string: nil for an empty TxID (emitter_value_converter.go:370-376)
+        if (!p.m_tx_off || p.m_tx_off[k + 1] == p.m_tx_off[k]) put_lit(s, "null");
+        else emit_json_string(s, p.m_tx + p.m_tx_off[k], p.m_tx_off[k + 1] - p.m_tx_off[k], false);
+        break;
       default: break;
     }
   }
@@ -703,9 +715,34 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
   const std::string name = cs.name ? cs.name : "", t = cs.original_type ? cs.original_type : "";
   ColPlan cp;
   if (t.empty()) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unknown source type (no OriginalType; emitter_value_converter.go:188-196)");
-  if (!starts(t, "pg:")) unsupported(name, "original type " + t);
-  if (t.size() > 2 && t.compare(t.size() - 2, 2, "[]") == 0) unsupported(name, "array type " + t);
   std::string kafka, dname, extra;  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
+  bool found = false;
+  if (starts(t, "ydb:")) {  // GetKafkaTypeDescrByYDBType / AddYDB (ydb/emitter.go:15-232)
+    static const struct { const char *t; const char *kafka; const char *name; uint32_t dk, arg; } YDB[] = {
+      {"ydb:Bool", "boolean", "", DK_MARSHAL, 0}, {"ydb:Int8", "int8", "", DK_MARSHAL, 0}, {"ydb:Int16", "int16", "", DK_MARSHAL, 0}, {"ydb:Int32", "int32", "", DK_MARSHAL, 0},
+      {"ydb:Int64", "int64", "", DK_MARSHAL, 0}, {"ydb:Uint8", "int8", "", DK_MARSHAL, 0}, {"ydb:Uint16", "int16", "", DK_MARSHAL, 0}, {"ydb:Uint32", "int32", "", DK_MARSHAL, 0},
+      {"ydb:Uint64", "int64", "", DK_YDB_UINT64, 0}, {"ydb:Float", "float", "", DK_MARSHAL, 0}, {"ydb:Double", "double", "", DK_MARSHAL, 0}, {"ydb:String", "bytes", "", DK_MARSHAL, 0},
+      {"ydb:Utf8", "string", "", DK_MARSHAL, 0}, {"ydb:Json", "string", "io.debezium.data.Json", DK_JSON, 0}, {"ydb:JsonDocument", "string", "io.debezium.data.Json", DK_JSON, 0},
+      {"ydb:Uuid", "string", "", DK_STRING, 0}, {"ydb:Date", "int32", "io.debezium.time.Date", DK_YDB_DATE, 0}, {"ydb:Datetime", "int64", "io.debezium.time.Timestamp", DK_TS, 1000},
+      {"ydb:Timestamp", "int64", "io.debezium.time.MicroTimestamp", DK_TS, 1}, {"ydb:Interval", "int64", "io.debezium.time.MicroDuration", DK_MARSHAL, 0}};
+    for (auto &e : YDB) if (t == e.t) { kafka = e.kafka; dname = e.name; cp.dk = e.dk; cp.arg = e.arg; found = true; break; }
+    if (!found && t == "ydb:Decimal") {
+      const std::string &mode = P.get("decimal.handling.mode");
+      found = true;
+      if (mode == "precise") { kafka = "bytes"; dname = "org.apache.kafka.connect.data.Decimal"; cp.dk = DK_NUMERIC; cp.arg = 9u | (1u << 17);  // numeric(22,9); colVal.(string)
+        extra = ",\"parameters\":{\"connect.decimal.precision\":\"22\",\"scale\":\"9\"}"; }
+      else if (mode == "string") { kafka = "string"; cp.dk = DK_NUMERIC_TEXT; cp.arg = 1u << 17; }
+      else unsupported(name, "decimal.handling.mode=" + mode);
+    }
+    if (!found && t == "ydb:DyNumber") { found = true; kafka = "struct"; dname = "io.debezium.data.VariableScaleDecimal"; cp.dk = DK_NUMERIC; cp.arg = 1u << 16; }
+    if (!found) {
+      const std::string &policy = P.get("dt.unknown.types.policy");
+      if (policy == "fail") throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown ydbType: " + t + " (column " + name + ")");
+      unsupported(name, "dt.unknown.types.policy=" + policy + " for " + t);
+    }
+  }
+  else if (!starts(t, "pg:")) unsupported(name, "original type " + t);
+  else if (t.size() > 2 && t.compare(t.size() - 2, 2, "[]") == 0) unsupported(name, "array type " + t);  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
   static const struct { const char *t; const char *kafka; const char *name; uint32_t dk; } PLAIN[] = {
     {"pg:boolean", "boolean", "", DK_BOOL}, {"pg:bit(1)", "boolean", "", DK_BIT1}, {"pg:smallint", "int16", "", DK_SMALLINT}, {"pg:integer", "int32", "", DK_INTEGER},
     {"pg:bigint", "int64", "", DK_BIGINT}, {"pg:oid", "int64", "", DK_OID}, {"pg:real", "float", "", DK_REAL}, {"pg:double precision", "double", "", DK_DOUBLE},
@@ -714,8 +751,7 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
     {"pg:int8range", "string", "", DK_STRING}, {"pg:daterange", "string", "", DK_STRING}, {"pg:text", "string", "", DK_STRING},
     {"pg:date", "int32", "io.debezium.time.Date", DK_DATE}, {"pg:cidr", "string", "", DK_STRING}, {"pg:macaddr", "string", "", DK_STRING},
     {"pg:character", "string", "", DK_STRING}, {"pg:character varying", "string", "", DK_STRING}, {"pg:USER-DEFINED:citext", "string", "", DK_STRING}};
-  bool found = false;
-  for (auto &e : PLAIN) if (t == e.t) { kafka = e.kafka; dname = e.name; cp.dk = e.dk; found = true; break; }
+  if (!found) for (auto &e : PLAIN) if (t == e.t) { kafka = e.kafka; dname = e.name; cp.dk = e.dk; found = true; break; }
   int prec = 0, scale = 0, d;
   if (found) {}
   else if (t == "pg:xml") { kafka = "string"; dname = "io.debezium.data.Xml"; cp.dk = DK_XML; }
@@ -772,7 +808,7 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
   // the description, members in key order: __dt_original_type_info, doc, field, fields, name, optional, parameters, type, version
   std::string o = "{";
   if (P.get("dt.add.original.type.info") == "true") o += "\"__dt_original_type_info\":{\"original_type\":" + jstr(t) + "},";
-  const bool var_scale = cp.dk == DK_NUMERIC && (cp.arg >> 16);
+  const bool var_scale = cp.dk == DK_NUMERIC && ((cp.arg >> 16) & 1u);
   if (var_scale) o += "\"doc\":\"Variable scaled decimal\",";
   if (cp.dk == DK_POINT) o += "\"doc\":\"Geometry (POINT)\",";
   o += "\"field\":" + jstr(name);
@@ -808,7 +844,10 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_JSON: return in({TFGPU_R_JSON}) || (in({TFGPU_R_STRING}) && !arg) ? 0 : 2;
     case DK_TIME: case DK_TIMETZ: case DK_MONEY: case DK_XML: case DK_POINT: case DK_TSRANGE: case DK_NUMRANGE: case DK_TSTZRANGE: case DK_INTERVAL: return in({TFGPU_R_STRING}) ? 0 : 2;
     case DK_WRONG_TYPE: return 0;
-    case DK_NUMERIC: case DK_NUMERIC_TEXT: return in({TFGPU_R_STRING, TFGPU_R_JSONNUM}) ? 0 : 1;
+    case DK_NUMERIC: case DK_NUMERIC_TEXT: return in({TFGPU_R_STRING}) ? 0 : ((arg >> 17) & 1u) ? 2 : in({TFGPU_R_JSONNUM}) ? 0 : 1;  // ydb:Decimal asserts a string
+    case DK_MARSHAL: return 0;
+    case DK_YDB_UINT64: return in({TFGPU_R_UINT64}) ? 0 : 1;
+    case DK_YDB_DATE: return in({TFGPU_R_TIME}) ? 0 : 1;
     default: return 2;
   }
 }
@@ -947,7 +986,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     }
     if (P.get("binary.handling.mode") != "bytes") return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unsupported binary.handling.mode: " + P.get("binary.handling.mode"));
     const std::string &source_type = P.get("dt.source.type");
-    if (!source_type.empty() && source_type != "pg") return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: dt.source.type=" + source_type + " stays with the stock emitter");
+    if (!source_type.empty() && source_type != "pg" && source_type != "ydb") return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: dt.source.type=" + source_type + " stays with the stock emitter");
     const std::string server = P.get("topic.prefix"), database = P.get("database.dbname"), version = o->version ? o->version : "1.1.2.Final";
     const bool skip_tombstones = P.get("tombstones.on.delete") == "false";
 
@@ -1038,6 +1077,11 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       // every row's entry must exist: src_row (or the row index) is below meta->n
       if (!b->src_row && meta->n < n) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: row meta shorter than the batch");
       p.m_id = dbz_meta(meta, meta->id, (size_t)meta->n, keep); p.m_lsn = dbz_meta(meta, meta->lsn, (size_t)meta->n, keep); p.m_commit = dbz_meta(meta, meta->commit_time, (size_t)meta->n, keep);
+      if (source_type == "ydb" && meta->tx_id_offsets && meta->n > 0) {
+        uint32_t tx_bytes = 0;
+        if (meta->mem == TFGPU_MEM_DEVICE) { const uint32_t *h = d2h_u32(meta->tx_id_offsets + meta->n); sync(); tx_bytes = *h; } else tx_bytes = meta->tx_id_offsets[meta->n];
+        p.m_tx_off = dbz_meta(meta, meta->tx_id_offsets, (size_t)meta->n + 1, keep); p.m_tx = dbz_meta(meta, meta->tx_id_data, (size_t)tx_bytes, keep);
+      }
     }
     p.p10 = pow10_table(); p.p128 = reinterpret_cast<const uint64_t *>(p.p10 + 632);
 
@@ -1071,6 +1115,11 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
         segs.push_back({",\"name\":" + jstr(server) + ",\"schema\":" + jstr(b->ns) + ",\"snapshot\":\"" + snap + "\",\"table\":" + jstr(b->table) + ",\"ts_ms\":", TN_TS});
         segs.push_back({",\"txId\":", TN_ID});
         segs.push_back({",\"version\":" + jstr(version) + ",\"xmin\":null},\"transaction\":null,\"ts_ms\":", TN_TS});
+      } else if (source_type == "ydb") {   // + txId (*string) and step = CommitTime (emitter_value_converter.go:368-377)
+        segs.push_back({"\",\"source\":{\"db\":" + jstr(database) + ",\"name\":" + jstr(server) + ",\"snapshot\":\"" + snap + "\",\"step\":", TN_STEP});
+        segs.push_back({",\"table\":" + jstr(b->table) + ",\"ts_ms\":", TN_TS});
+        segs.push_back({",\"txId\":", TN_TXID});
+        segs.push_back({",\"version\":" + jstr(version) + "},\"transaction\":null,\"ts_ms\":", TN_TS});
       } else {
         segs.push_back({"\",\"source\":{\"db\":" + jstr(database) + ",\"name\":" + jstr(server) + ",\"snapshot\":\"" + snap + "\",\"table\":" + jstr(b->table) + ",\"ts_ms\":", TN_TS});
         segs.push_back({",\"version\":" + jstr(version) + "},\"transaction\":null,\"ts_ms\":", TN_TS});
