@@ -847,14 +847,15 @@ int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b
  * and the PrimaryKey flags (the batch itself carries neither); columns of the schema missing from the batch are TOASTed
  * (unavailable.value.placeholder).  Row meta: id → source.txId, lsn → source.lsn, commit_time → both ts_ms (NULL = zeros).
  * Parameters: the format settings map (parameters.go:140-215 fills the defaults): database.dbname, topic.prefix, dt.source.type
- * ("" | "pg" | "ydb"), decimal.handling.mode (precise | string), tombstones.on.delete, dt.add.original.type.info,
+ * ("" | "pg" | "ydb" | "mysql"), decimal.handling.mode (precise | string), tombstones.on.delete, dt.add.original.type.info,
  * unavailable.value.placeholder, dt.unknown.types.policy.
  * Device-resident Postgres types (pkg/debezium/pg/emitter.go:262-629): boolean, bit(1), smallint, integer, bigint, oid, real, double
  * precision, text / character* / uuid / cidr / macaddr / citext / int4range / int8range / daterange, inet, bytea, date and
  * timestamp[(p)] with / without time zone as time.Time, time[(p)] with / without time zone, json / jsonb, hstore as a map, xml,
  * numeric[(p,s)] up to 38 digits, money, bit(n) / bit varying(n), point, interval, tsrange, numrange and tstzrange in their plain
  * two-bound forms; and the ydb: types (pkg/debezium/ydb/emitter.go:123-232) with dt.source.type = "ydb" (source.txId = the row meta's
- * TxID, source.step = CommitTime).  Anything else — arrays, enums, mysql: types, hstore / range / time texts only pgtype's parsers decide,
+ * TxID, source.step = CommitTime) and the mysql: types (pkg/debezium/mysql/emitter.go:168-388) with dt.source.type = "mysql" (source.db =
+ * the schema, file / pos from the LSN, gtid = TxID).  Anything else — Postgres arrays and enums, binaries / bits given as base64 text, hstore / range / time texts only pgtype's parsers decide,
  * the schema-registry packers, a value of a Go type the device does not convert — is refused BY NAME
  * with TFGPU_ERR_UNSUPPORTED and travels through the stock emitter; where the reference itself returns an error (an unknown
  * type under policy "fail", a json.Number that is no integer, "unknown type of value") the call fails with TFGPU_ERR_INVALID.  */

@@ -9,6 +9,7 @@ Postgres-typed rows, the `DebeziumSerializer` of the queue sinks (pkg/serializer
   kindToOp                                           pkg/debezium/kind.go:8-32
   AddPg / GetKafkaTypeDescrByPgType                  pkg/debezium/pg/emitter.go:20-260, 262-629
   AddYDB / GetKafkaTypeDescrByYDBType                pkg/debezium/ydb/emitter.go:15-232
+  AddMysql / GetKafkaTypeDescrByMysqlType            pkg/debezium/mysql/emitter.go:20-388
   addCommon / mapYtTypeToKafkaType                   pkg/debezium/emitter_common.go:68-226
   typeutil helpers (bits, decimals, times, ranges)   pkg/debezium/typeutil/helpers.go, field_descr.go
   PackerIncludeSchema.Pack                           pkg/debezium/packer/packer_include_schema.go:14-40
@@ -19,7 +20,7 @@ Everything the reference builds is a Go map marshalled by util.JSONMarshalUnesca
 order, no HTML escaping.  Only the product's test-suite, smoke() and bench.py's cpu_baseline leg use this file; the product never does.
 
 Not restated (third-party parsers the reference calls; NotRestated is raised by name): hstore given as text (HstoreToJSON), string inputs of `timestamp without time zone` (pgtype.Timestamp.Set(string)), pg arrays,
-mysql: original types, the schema-registry packers (Confluent JSON / skip-schema).  PINNED against the reference's fixtures
+mysql binaries / bits given as base64 text, the schema-registry packers (Confluent JSON / skip-schema).  PINNED against the reference's fixtures
 pkg/debezium/pg/tests/testdata/emitter_crud_test__*.txt (copied to tests/golden/debezium_emitter/) the way the reference's own test
 compares them (pkg/debezium/testutil/test.go:24-152: the fixtures come from a vanilla Debezium, so both sides are normalised).
 """
@@ -850,6 +851,195 @@ def add_ydb(col: Col, v, t: str, params):
     raise UnknownTypeError("unknown column type: %s, column name: %s" % (t, col.name))
 
 
+# ---- MySQL (pkg/debezium/mysql/emitter.go) ---------------------------------------------------------------------------------------------
+def trim_mysql_type(t: str) -> str:
+    """abstract.TrimMySQLType (restore.go:303-310)"""
+    for i, ch in enumerate(t):
+        if not ("a" <= ch <= "z") and ch != ":":
+            return t[:i]
+    return t
+
+
+MYSQL_BINARY = {"mysql:tinyblob", "mysql:blob", "mysql:mediumblob", "mysql:longblob", "mysql:binary", "mysql:varbinary", "mysql:bit", "mysql:geometry", "mysql:geomcollection",
+                "mysql:geometrycollection", "mysql:point", "mysql:multipoint", "mysql:linestring", "mysql:multilinestring", "mysql:polygon", "mysql:multipolygon"}
+
+
+def unwrap_enums_and_sets(s: str) -> str:
+    """typeutil.UnwrapMysqlEnumsAndSets (helpers.go:1022-1038)"""
+    out = ""
+    while True:
+        s = s[1:]
+        i = s.find("'")
+        if i == -1:
+            raise EmitError("unable to find right quote")
+        out += s[:i] + ","
+        if i + 2 >= len(s):
+            break
+        s = s[i + 2:]
+    return out[:-1]
+
+
+def mysql_time_precision(t: str, what: str) -> int:
+    m = re.match(r"^mysql:%s\((\d)\)" % what, t)
+    return int(m.group(1)) if m else -1
+
+
+def mysql_type_descr(col: Col, snapshot: bool, params):
+    """GetKafkaTypeDescrByMysqlType (mysql/emitter.go:20-166) and the extractor it returns"""
+    t = col.original_type
+    plain = {"mysql:blob": ("bytes", ""), "mysql:date": ("int32", "io.debezium.time.Date"), "mysql:json": ("string", "io.debezium.data.Json"), "mysql:longblob": ("bytes", ""),
+             "mysql:longtext": ("string", ""), "mysql:mediumblob": ("bytes", ""), "mysql:mediumtext": ("string", ""), "mysql:text": ("string", ""), "mysql:tinyblob": ("bytes", ""),
+             "mysql:tinytext": ("string", ""), "mysql:time": ("int64", "io.debezium.time.MicroTime")}
+    if t in plain:
+        return plain[t] + (None,)
+    unsigned = t.endswith(" unsigned")
+    if t.startswith("mysql:bigint"):
+        return "int64", "", None
+    if t.startswith("mysql:binary(") or t.startswith("mysql:varbinary("):
+        return "bytes", "", None
+    if t.startswith("mysql:bit("):
+        if t == "mysql:bit(1)":
+            return "boolean", "", None
+        return "bytes", "io.debezium.data.Bits", {"parameters": {"length": t[10:t.index(")", 10)]}}
+    if t.startswith("mysql:char(") or t.startswith("mysql:varchar("):
+        return "string", "", None
+    if t.startswith("mysql:datetime"):
+        p = mysql_time_precision(t, "datetime")
+        return ("int64", "io.debezium.time.Timestamp", None) if 1 <= p <= 3 else ("int64", "io.debezium.time.MicroTimestamp", None) if p != -1 else ("int64", "io.debezium.time.Timestamp", None)
+    if t.startswith("mysql:decimal("):
+        m = re.match(r"^mysql:decimal\((\d+),(\d+)\)", t)
+        pr, sc = (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+        return _decimal_mode_descr(params, ("bytes", "org.apache.kafka.connect.data.Decimal", {"parameters": {"scale": "%d" % sc, "connect.decimal.precision": "%d" % pr}}))
+    if t.startswith("mysql:float") or t.startswith("mysql:double"):
+        return "double", "", None
+    if t.startswith("mysql:enum("):
+        return "string", "io.debezium.data.Enum", {"parameters": {"allowed": unwrap_enums_and_sets(t[11:-1])}}
+    if t.startswith("mysql:int"):
+        return ("int64" if unsigned and (snapshot or not col.key) else "int32"), "", None
+    if t.startswith("mysql:mediumint"):
+        return "int32", "", None
+    if t.startswith("mysql:set("):
+        return "string", "io.debezium.data.EnumSet", {"parameters": {"allowed": unwrap_enums_and_sets(t[10:-1])}}
+    if t.startswith("mysql:smallint"):
+        return ("int32" if unsigned else "int16"), "", None
+    if t.startswith("mysql:time("):
+        return "int64", "io.debezium.time.MicroTime", None
+    if t.startswith("mysql:timestamp"):
+        return "string", "io.debezium.time.ZonedTimestamp", None
+    if t.startswith("mysql:tinyint"):
+        return ("boolean" if t == "mysql:tinyint(1)" else "int16"), "", None
+    if t.startswith("mysql:year"):
+        return "int32", "io.debezium.time.Year", None
+    raise EmitError("unknown mysqlType: %s" % t)   # (not an UnknownTypeError: GetKafkaTypeDescrByMysqlType returns a plain error)
+
+
+def add_mysql(col: Col, v, t: str, params):
+    """AddMysql (mysql/emitter.go:168-388)"""
+    g, x = v
+    if g == "nil":
+        return None
+    u = trim_mysql_type(t)
+    if u in ("mysql:int", "mysql:mediumint"):
+        if g not in ("int32", "uint32"):
+            raise EmitError("unknown type of value for %s: %s" % (u, g))
+        return int(x)
+    if u == "mysql:bigint":
+        if g == "int64":
+            return int(x)
+        if g == "uint64":
+            return _wrap(int(x), 64)
+        raise EmitError("unknown type of value for mysql:bigint: %s" % g)
+    if u in ("mysql:binary", "mysql:varbinary", "mysql:longblob", "mysql:mediumblob", "mysql:blob", "mysql:tinyblob"):
+        if g == "bytes":
+            buf = _b(x)
+        elif g == "string":
+            raise NotRestated("mysql binary given as base64 text")
+        else:
+            raise EmitError("unknown type of mysql binary type: %s" % g)
+        if not t.startswith("mysql:varbinary"):
+            m = re.match(r"^.*\((\d)\).*", t)   # MysqlFitBinaryLength: ONE digit between the parentheses
+            if m:
+                if int(m.group(1)) < len(buf):
+                    raise NotRestated("MysqlFitBinaryLength: make() with a negative length panics")
+                buf = buf + b"\x00" * (int(m.group(1)) - len(buf))
+        if params["binary.handling.mode"] != "bytes":
+            raise EmitError("unsupported binary.handling.mode")
+        return base64.b64encode(buf)
+    if u == "mysql:bit":
+        if t == "mysql:bit(1)":
+            if g == "string":
+                return _b(x) in (b"AQ==", b"AAAAAAAAAAE=")
+            if g == "bytes":
+                buf = _b(x)
+                if len(buf) == 8:
+                    return buf[7] == 1
+                if len(buf) != 1:
+                    raise EmitError("type mysql:bit has len(t) != 1, len: %d" % len(buf))
+                return buf[0] == 1
+            raise NotRestated("mysql:bit(1) given %s: no value is added" % g)
+        if g != "bytes":
+            raise NotRestated("mysql:bit given %s" % g)
+        buf = _b(x)
+        size = int(t[10:t.index(")", 10)])
+        div = (size + 7) // 8
+        if div > len(buf):
+            raise NotRestated("ShrinkMysqlBit: slice bounds out of range")
+        return base64.b64encode(bytes(reversed(buf[len(buf) - div:])))
+    if u in ("mysql:float", "mysql:double"):
+        if g == "jsonnum":
+            return F64(_jn_float64(x))
+        if g == "float64":
+            return F64(float(x))
+        if g == "float32" and u == "mysql:float":
+            return F64(float(x))
+        raise EmitError("unknown type of value for %s: %s" % (u, g))
+    if u == "mysql:tinyint":
+        if t == "mysql:tinyint(1)":
+            if g != "int8":
+                raise NotRestated("tinyint(1) given %s: the type assertion panics" % g)
+            return int(x) == 1
+        if g not in ("int8", "uint8"):
+            raise EmitError("unknown type of value for mysql:tinyint: %s" % g)
+        return int(x)
+    if u in ("mysql:char", "mysql:varchar", "mysql:longtext", "mysql:mediumtext", "mysql:text", "mysql:tinytext", "mysql:set", "mysql:enum"):
+        return _need_string(v, t)
+    if u == "mysql:smallint":
+        if g not in ("int16", "uint16"):
+            raise EmitError("unknown type of value for mysql:smallint: %s" % g)
+        return int(x)
+    if u == "mysql:json":
+        return gomarshal(go_value(v))
+    if u in ("mysql:timestamp", "mysql:datetime", "mysql:date"):
+        if g != "time":
+            raise NotRestated("%s given %s: the type assertion panics" % (u, g))
+        sec, ns = x[0], x[1]
+        if u == "mysql:date":
+            return trunc_div(sec, 86400)
+        if u == "mysql:timestamp":
+            prec = 0 if t == "mysql:timestamp" else mysql_time_precision(t, "timestamp")
+            if prec < 0:
+                raise NotRestated("FormatTime with precision -1: the slice panics")
+            y, mo, d = civil_from_days(sec // 86400)
+            frac = (b"%06d" % (ns // 1000))[:prec].rstrip(b"0")
+            return b"%04d-%02d-%02dT" % (y, mo, d) + _clock(sec) + (b"." + frac if frac else b"") + b"Z"
+        div = 1000 if t == "mysql:datetime" or mysql_time_precision(t, "datetime") <= 3 else 1000000
+        return ((sec & ((1 << 64) - 1)) * div + ns // (1000000000 // div)) & ((1 << 64) - 1)
+    if u == "mysql:time":
+        s_ = _need_string(v, t)
+        m = re.match(rb"^(\d\d):(\d\d):(\d\d)(?:\.(\d{1,6}))?$", s_)
+        if not m or len(s_) == 9 or not (int(m.group(1)) < 24 and int(m.group(2)) < 60 and int(m.group(3)) < 60):
+            raise EmitError("unable to parse time %r" % s_)
+        return (int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))) * 1000000 + int((m.group(4) or b"").ljust(6, b"0") or 0)
+    if u == "mysql:decimal":
+        return decimal_to_debezium_primitives(_b(x) if g == "jsonnum" else b"", params)
+    if u == "mysql:year":
+        s_ = _need_string(v, t)
+        if not re.match(rb"^[+-]?[0-9]{1,18}$", s_):
+            raise EmitError("strconv.Atoi %r" % s_)
+        return int(s_)
+    raise UnknownTypeError("unknown column type: %s, column name: %s" % (t, col.name))
+
+
 def add_common(col: Col, v):
     """addCommon (emitter_common.go:68-170)"""
     g, x = v
@@ -987,7 +1177,7 @@ def _divider_or_zero(t):
         return 0
 
 
-def field_descr(col: Col, params, into_arr=False):
+def field_descr(col: Col, params, into_arr=False, snapshot=False):
     """getFieldDescr (fields_descr.go:19-69)"""
     t = col.original_type
     if t == "":
@@ -1004,7 +1194,7 @@ def field_descr(col: Col, params, into_arr=False):
     elif t.startswith("ydb:"):
         kafka, name, extra = ydb_type_descr(t, params)
     elif t.startswith("mysql:"):
-        raise NotRestated(t)
+        kafka, name, extra = mysql_type_descr(col, snapshot, params)
     else:
         raise EmitError("unknown original type: %s" % t)
     d = {"type": kafka, "optional": not col.key}
@@ -1018,14 +1208,14 @@ def field_descr(col: Col, params, into_arr=False):
     return d
 
 
-def fields_descr(cols, params, keys_only=False):
+def fields_descr(cols, params, keys_only=False, snapshot=False):
     """arrColSchemaToFieldsDescr / …Keys (emitter_value_converter.go:99-137)"""
     out = []
     for c in cols:
         if keys_only and not c.key:
             continue
         try:
-            out.append(field_descr(c, params))
+            out.append(field_descr(c, params, snapshot=snapshot))
         except UnknownTypeError:
             policy = params["dt.unknown.types.policy"]
             if keys_only or policy == "fail":
@@ -1048,7 +1238,11 @@ def source_schema(source_type):
         fields += [{"type": "int64", "optional": True, "field": "lsn"}, {"type": "string", "optional": False, "field": "schema"},
                    {"type": "int64", "optional": True, "field": "txId"}, {"type": "int64", "optional": True, "field": "xmin"}]
     elif source_type == "mysql":
-        raise NotRestated("source type %s" % source_type)
+        d["name"] = "io.debezium.connector.mysql.Source"
+        fields[-1]["optional"] = True
+        fields += [{"type": "string", "optional": False, "field": "file"}, {"type": "string", "optional": True, "field": "gtid"}, {"type": "int64", "optional": False, "field": "pos"},
+                   {"type": "string", "optional": True, "field": "query"}, {"type": "int32", "optional": False, "field": "row"}, {"type": "int64", "optional": False, "field": "server_id"},
+                   {"type": "int64", "optional": True, "field": "thread"}]
     d["fields"] = fields
     return d
 
@@ -1104,7 +1298,7 @@ class Emitter:
         if t.startswith("ydb:"):
             return add_ydb(c, v, t, self.params)
         if t.startswith("mysql:"):
-            raise NotRestated(t)
+            return add_mysql(c, v, t, self.params)
         if self.ignore_unknown_sources:
             return add_common(c, v)
         raise EmitError("unknown source type")
@@ -1133,16 +1327,17 @@ class Emitter:
             d.update({"connector": "postgresql", "lsn": it.lsn, "schema": it.schema, "txId": it.id, "xmin": None})
         elif st == "ydb":
             d.update({"txId": _b(it.tx_id) if it.tx_id else None, "step": it.commit_time})
-        elif st == "mysql":
-            raise NotRestated("source type %s" % st)
+        elif st == "mysql":   # LSNToFileAndPos (helpers.go:1101-1103)
+            d.update({"db": it.schema, "connector": "mysql", "file": "mysql-log.%06d" % (it.lsn // 1000000000000), "pos": it.lsn % 1000000000000,
+                      "gtid": _b(it.tx_id) if it.tx_id else None, "query": None, "row": 0, "server_id": 0, "thread": None})
         return d
 
-    def schema_key(self, it: Item):
-        return gomarshal({"fields": fields_descr(it.cols, self.params, True), "name": "%s.%s.%s.Key" % (self.server, it.schema, it.table),
+    def schema_key(self, it: Item, snapshot=False):
+        return gomarshal({"fields": fields_descr(it.cols, self.params, True, snapshot), "name": "%s.%s.%s.Key" % (self.server, it.schema, it.table),
                           "optional": False, "type": "struct"})
 
-    def schema_val(self, it: Item):
-        f = fields_descr(it.cols, self.params)
+    def schema_val(self, it: Item, snapshot=False):
+        f = fields_descr(it.cols, self.params, False, snapshot)
         nm = "%s.%s.%s.Value" % (self.server, it.schema, it.table)
         fields = [{"type": "struct", "fields": f, "optional": True, "name": nm, "field": "before"},
                   {"type": "struct", "fields": f, "optional": True, "name": nm, "field": "after"},
@@ -1164,6 +1359,8 @@ class Emitter:
         if op == "d":
             after = None
             before = {c.name: None for c in it.cols}
+            if self.params["dt.source.type"] == "mysql":
+                before.update(self.make_values(it.cols, it.names, it.values, False))
             before.update(self.make_values(it.cols, it.old_names, it.old_values, False))
         else:
             after = self.build_kv(it, False)
@@ -1181,11 +1378,11 @@ class Emitter:
         if not self.drop_keys:
             key = gomarshal(self.make_key(it, emit_type == INSERT_EVENT))
             if self.key_schema:   # PackerIncludeSchema, else PackerSkipSchema (packer_skip_schema.go:12-19): the payload alone
-                key = self.pack(key, self.schema_key(it))
+                key = self.pack(key, self.schema_key(it, snapshot))
         if emit_type == TOMBSTONE:
             return key, None
         val = self.val_payload(it, snapshot, emit_type)
-        return key, (self.pack(val, self.schema_val(it)) if self.val_schema else val)
+        return key, (self.pack(val, self.schema_val(it, snapshot)) if self.val_schema else val)
 
     def keys_changed(self, it: Item) -> bool:
         """ChangeItem.KeysChanged (change_item.go:237-286), over Go values: same dynamic type and same value"""
@@ -1259,6 +1456,12 @@ def restore(col: Col, raw):
     if d == "boolean":
         return _plain(raw)
     if d in ("string", "utf8"):
+        if trim_mysql_type(col.original_type) in MYSQL_BINARY or col.original_type.startswith("mysql:binary") or col.original_type.startswith("mysql:blob"):
+            if isinstance(raw, str) and not isinstance(raw, JN):
+                try:
+                    return ("bytes", base64.b64decode(raw, validate=True))
+                except Exception:
+                    return ("bytes", b"")
         if col.original_type in ("pg:bytea", "ydb:String"):
             if isinstance(raw, str):
                 try:

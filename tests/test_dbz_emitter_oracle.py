@@ -208,3 +208,26 @@ def test_ydb_values_and_source_against_the_references_tests():
         (_k, val), = E.Emitter(params).emit_kv(E.Item("insert", "", "test", tbl, ["id"], [("uint64", 1)], tx_id=tx, commit_time=77))
         assert val == b'{"after":{"id":1},"before":null,"op":"c","source":{"db":"public","name":"my_topic","snapshot":"false","step":77,"table":"test","ts_ms":0,' + member + \
             b',"version":"1.1.2.Final"},"transaction":null,"ts_ms":0}'
+
+
+@pytest.mark.parametrize("fixture", ["mysql_emitter_vals_test__canon_change_item.txt", "mysql_emitter_vals_test__canon_change_item_v8.txt"])
+def test_mysql_values_against_the_references_test(fixture):
+    """pkg/debezium/mysql/tests/emitter_vals_test.go:14-135 (TestMysqlValByValInsert / …V8: BuildKVMap of the canon ChangeItems against mysqlDebeziumCanonizedValuesSnapshot)"""
+    with open(os.path.join(GOLD, fixture), "rb") as f:
+        it = E.unmarshal_change_item(f.read())
+    after = E.Emitter({"topic.prefix": "fullfillment"}).build_kv(it, False)
+    F = E.F64
+    want = {"pk": 1, "bool1": False, "bool2": True, "bit": True, "bit16": b"nwA=", "tinyint_": 1, "tinyint_def": 22, "tinyint_u": 255, "tinyint1": True, "tinyint1u": 1, "smallint_": 1000, "smallint5": 100,
+            "smallint_u": 10, "mediumint_": 1, "mediumint5": 11, "mediumint_u": 111, "int_": 9, "integer_": 99, "integer5": 999, "int_u": 9999, "bigint_": 8, "bigint5": 88, "bigint_u": 888,
+            "real_": F(123.45), "real_10_2": F(99999.99), "float_": F(1.23), "float_53": F(1.23), "double_": F(2.34), "double_precision": F(2.34), "char_": b"a", "char5": b"abc", "varchar5": b"blab",
+            "binary_": b"nw==", "binary5": b"nwAAAAA=", "varbinary5": b"n58=", "tinyblob_": b"n5+f", "tinytext_": b"qwerty12345", "blob_": b"/w==", "text_": b"my-text", "mediumblob_": b"q80=",
+            "mediumtext_": b"my-mediumtext", "longblob_": b"q80=", "longtext_": b"my-longtext", "json_": b'{"k1":"v1"}', "enum_": b"x-small", "set_": b"a", "year_": 1901, "year4": 2155,
+            "timestamp_": b"1999-01-01T00:00:01Z", "timestamp0": b"1999-10-19T10:23:54Z", "timestamp1": b"2004-10-19T10:23:54.1Z", "timestamp2": b"2004-10-19T10:23:54.12Z",
+            "timestamp3": b"2004-10-19T10:23:54.123Z", "timestamp4": b"2004-10-19T10:23:54.1234Z", "timestamp5": b"2004-10-19T10:23:54.12345Z", "timestamp6": b"2004-10-19T10:23:54.123456Z",
+            "date_": -354285, "time_": 14706000000, "time0": 14706000000, "time1": 14706100000, "time2": 14706120000, "time3": 14706123000, "time4": 14706123400, "time5": 14706123450,
+            "time6": 14706123456, "datetime_": 1577891410000, "datetime0": 1577891410000, "datetime1": 1577891410100, "datetime2": 1577891410120, "datetime3": 1577891410123,
+            "datetime4": 1577891410123400, "datetime5": 1577891410123450, "datetime6": 1577891410123456, "NUMERIC_": b"SZYC0g==", "NUMERIC_5": b"MDk=", "NUMERIC_5_2": b"MDk=",
+            "DECIMAL_": b"AIvQODU=", "DECIMAL_5": b"W5s=", "DECIMAL_5_2": b"Wmk="}
+    assert set(after) == set(want), sorted(set(after) ^ set(want))
+    for k, v in want.items():
+        assert after[k] == v and type(after[k]) is type(v), (k, after[k], v)

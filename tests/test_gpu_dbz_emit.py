@@ -292,6 +292,51 @@ def test_ydb_typed_rows_and_the_ydb_source_block(tf):
     assert b'"Decimal_":"Nnt8pAA="' in got.messages()[0][1] and b'"DyNumber_":{"scale":0,"value":"ew=="}' in got.messages()[0][1] and b'"txId":"tx-1"' in got.messages()[0][1]
 
 
+def typed_row(it):
+    return [["time", (x[0], x[1])] if g == "time" else [g, (bytes(x) if isinstance(x, (bytes, bytearray)) else x)] for g, x in it.values]
+
+
+@pytest.mark.parametrize("fixture", ["mysql_emitter_vals_test__canon_change_item.txt", "mysql_emitter_vals_test__canon_change_item_v8.txt"])
+def test_mysql_typed_rows_and_the_mysql_source_block(tf, fixture):
+    """AddMysql (pkg/debezium/mysql/emitter.go:168-388) and dt.source.type = mysql (db = the ChangeItem's schema, file / pos from the LSN, gtid = TxID; a delete's `before`
+    takes the row's own values): the reference's canon ChangeItems for this emitter — 79 columns whose expected values the oracle reproduces — as an insert, a snapshot insert,
+    an update and a delete"""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter", fixture), "rb") as f:
+        it = E.unmarshal_change_item(f.read())
+    table = [(c.name, c.dtype, c.key, c.original_type) for c in it.cols]
+    params = {"topic.prefix": "fullfillment", "dt.source.type": "mysql"}
+    row = typed_row(it)
+    for kinds, kw in ((["insert"], {}), (["insert"], {"snapshot": True}), (["update", "delete", "delete"], {})):
+        b = abi.batch_from_rows(schema_of(table), it.names, [row] * len(kinds), it.schema, it.table, kinds=kinds)
+        n = len(kinds)
+        if n > 1:
+            ob = abi.batch_from_rows(schema_of(table), ["pk"], [[["uint32", 1]], [["uint32", 1]], [["uint32", 7]]], it.schema, it.table)
+            b.old_keys, b.old_present = ob.cols, np.array([True, True, False])   # the last delete has no OldKeys: `before` is the row's own values
+        meta = ([5] * n, [3000000000123 + r for r in range(n)], [1700000000123456789] * n, ["gtid-%d" % r if r else "" for r in range(n)])
+        got, want, rws = emit_both(tf, b, table, params, meta, **kw)
+        assert_same(got, want, rws)
+    v = got.messages()[-2][1]
+    assert b'"file":"mysql-log.000003"' in v and b'"pos":125' in v and b'"gtid":"gtid-2"' in v and b'"db":"%s"' % it.schema.encode() in v and b'"before":{"DECIMAL_":"AIvQODU="' in v
+    # other Go shapes of the same types, and what the reference fails on
+    small = [("pk", "uint32", True, "mysql:int(10) unsigned"), ("f", "double", False, "mysql:float"), ("b", "string", False, "mysql:binary(5)"), ("bits", "string", False, "mysql:bit(16)"),
+             ("b1", "string", False, "mysql:bit(1)"), ("t", "utf8", False, "mysql:time(3)"), ("d", "double", False, "mysql:decimal(5,2)"), ("y", "utf8", False, "mysql:year(4)"),
+             ("dt", "timestamp", False, "mysql:datetime(6)"), ("ts", "timestamp", False, "mysql:timestamp(3)"), ("e", "utf8", False, "mysql:enum('a','b''c')")]
+    rows = [[["uint32", 4000000000], ["float32", 1.1], ["bytes", b"\x9f"], ["bytes", b"\x00\x00\x00\x00\x00\x00\x01\x9f"], ["bytes", b"\x00\x00\x00\x00\x00\x00\x00\x01"], ["string", "23:59:59.999"],
+             ["jsonnum", "-231.45"], ["string", "-5"], ["time", (-1, 999999000)], ["time", (1098181434, 123999000)], ["string", "a"]],
+            [["uint32", 1], ["jsonnum", "1e-3"], ["bytes", b"12345"], ["bytes", b"\x01\x02"], ["string", "AAAAAAAAAAE="], ["string", "00:00:00"], ["nil", None], ["string", "+2024"],
+             ["time", (0, 0)], ["time", (0, 0)], ["nil", None]]]
+    for one in rows:   # (a column holds one Go type: the two rows are two batches)
+        b = abi.batch_from_rows(schema_of(small), [t[0] for t in small], [one], "db", "t")
+        got, want, rws = emit_both(tf, b, small, params, None)
+        assert_same(got, want, rws)
+    for col, val in (("t", ["string", "24:00:00.000"]), ("t", ["string", "04:05:06."]), ("y", ["string", "19x1"]), ("f", ["string", "1.5"]), ("pk", ["int64", 5])):
+        bad = [list(r) for r in rows[:1]]
+        bad[0][[t[0] for t in small].index(col)] = val
+        with pytest.raises(tf.TfgpuError) as ei:
+            tf.debezium_emit(abi.dbz_emit_options(params, schema_of(small)), tf.DeviceBatch.upload(abi.batch_from_rows(schema_of(small), [t[0] for t in small], bad, "db", "t")))
+        assert ei.value.code == tf.ERR_INVALID and "colName: " + col in str(ei.value), (col, str(ei.value))
+
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter")
 DEVICE_TYPES = ("pg:xml", "pg:point", "pg:numrange", "pg:tsrange", "pg:tstzrange", "pg:money", "pg:USER-DEFINED:hstore", "pg:boolean", "pg:bit(1)", "pg:smallint", "pg:integer", "pg:bigint", "pg:oid", "pg:real", "pg:double precision", "pg:bytea", "pg:json", "pg:jsonb", "pg:uuid",
                 "pg:inet", "pg:int4range", "pg:int8range", "pg:daterange", "pg:text", "pg:date", "pg:cidr", "pg:macaddr", "pg:USER-DEFINED:citext")
@@ -339,11 +384,11 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
         b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "t")
         return tf.debezium_emit(abi.dbz_emit_options(params, schema_of(table), **kw), tf.DeviceBatch.upload(b))
     base = [("id", "int32", True, "pg:integer")]
-    for t in ("pg:integer[]", "pg:interval[]", "mysql:int(11)"):
+    for t in ("pg:integer[]", "pg:interval[]", "oracle:NUMBER"):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", "1"]]])
         assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value) and "stock emitter" in str(ei.value), str(ei.value)
-    for params in ({"key.converter.schema.registry.url": "http://sr:8081"}, {"value.converter.ysr.namespace.id": "ns"}, {"dt.source.type": "mysql"},
+    for params in ({"key.converter.schema.registry.url": "http://sr:8081"}, {"value.converter.ysr.namespace.id": "ns"}, {"dt.source.type": "oracle"},
                    {"decimal.handling.mode": "double"}):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "double", False, "pg:numeric")], [[["int32", 1], ["jsonnum", "1"]]], dict(PARAMS, **params))

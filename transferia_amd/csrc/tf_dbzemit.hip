@@ -21,6 +21,7 @@
 // values), time[(p)] with / without time zone, json / jsonb, hstore (a map), xml, numeric[(p,s)] (precise: up to 38 digits;
 // string), money, bit(n) / bit varying(n), point, interval, tsrange, numrange and tstzrange (two plain bounds).  Texts whose reading
 // belongs to jackc/pgtype's parsers (infinity / empty / unbounded ranges; odd clock shapes) are left to the host, value by value.
+// The ydb: (ydb/emitter.go) and mysql: (mysql/emitter.go) families are resident as well, with their `source` blocks.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -39,13 +40,13 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
        EA_KEY = 8 /* every event */, EA_KEY_NEW, EA_KEY_OLD };
 enum { EV_REGULAR = 0, EV_DELETE = 1, EV_TOMBSTONE = 2, EV_INSERT = 3 };  // emitType (emitter_value_converter.go:76-97)
-enum { TN_NONE = 0, TN_LSN, TN_TS, TN_ID, TN_STEP, TN_TXID };
+enum { TN_NONE = 0, TN_LSN, TN_TS, TN_ID, TN_STEP, TN_TXID, TN_FILE6, TN_POS };
 constexpr uint32_t CONST_INLINE = 64;
 
 struct ECell {
@@ -54,6 +55,7 @@ struct ECell {
   uint32_t kind, apply, dk;
   uint32_t arg;               // DK_TS: divider; DK_NUMERIC: schema scale | put-scale << 16
   uint32_t from_old;          // the column is an OldKeys column: nil in rows without OldKeys
+  DCol alt; uint32_t dk_alt, has_alt;  // … unless the row's own value stands in (a MySQL delete's `before`: ColumnValues under the OldKeys)
 };
 struct EParams {
   const ECell *cells; int32_t ncells;
@@ -310,10 +312,9 @@ __device__ __forceinline__ bool pg_tstz_seconds(const uint8_t *t, uint32_t n, in
 }
 
 // AddPg for one non-nil value: 0 ok, 1 the reference returns an error, 2 left to the host
-template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell &ec, const CellBits &b) {
-  const DCol &c = ec.c;
+template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell &ec, const DCol &c, uint32_t dk, const CellBits &b) {
   uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
-  switch (ec.dk) {
+  switch (dk) {
     case DK_BOOL: put_lit(s, (uint8_t)b.v ? "true" : "false"); return 0;
     case DK_BIT1: put_lit(s, (vn == 1 && vp[0] == '1') ? "true" : "false"); return 0;
     case DK_SMALLINT: case DK_INTEGER: case DK_BIGINT: case DK_OID:
@@ -514,6 +515,58 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
     }
     case DK_YDB_UINT64: emit_i64(s, (int64_t)b.v); return 0;  // int64(t)
     case DK_YDB_DATE: emit_i64(s, (int64_t)(int32_t)(uint32_t)(uint64_t)trunc_div((int64_t)b.v, 86400)); return 0;  // DateToInt32
+    case DK_INT_REPRS:  // the MySQL integer families: the Go types the reference's switch names, as they are (a uint64 through int64(t))
+      if (c.repr == TFGPU_R_UINT64) { emit_i64(s, (int64_t)b.v); return 0; }
+      emit_int(s, c, b); return 0;
+    case DK_MY_TINYINT1: put_lit(s, (int8_t)b.v == 1 ? "true" : "false"); return 0;
+    case DK_MY_FLOAT: {
+      double d;
+      if (c.repr == TFGPU_R_JSONNUM) { PtrView f{vp}; const int rc = parse_float_go(f, 0, vn, p.p10, p.p128, &d); if (rc == 3) return 2; if (rc) return 1; }
+      else d = cell_f64(c, b);  // a float32 widens: float64(t)
+      if (d != d || d - d != 0) return 1;
+      dev::fmt_json_float(s, d, 64); return 0;
+    }
+    case DK_MY_BINARY: {  // MysqlFitBinaryLength (zero padding up to a ONE-digit length) + ParseBytea (helpers.go:1062-1080, 509-528)
+      uint32_t total = vn;
+      if (ec.arg) { const uint32_t want = ec.arg - 1; if (want < vn) return 2; total = want; }  // make() with a negative length panics
+      s.put('"'); emit_base64_gen(s, total, [&](uint32_t i) { return i < vn ? (uint32_t)vp[i] : 0u; }); s.put('"'); return 0;
+    }
+    case DK_MY_BIT1:
+      if (c.repr == TFGPU_R_STRING) { const bool t = (vn == 4 && vp[0] == 'A' && vp[1] == 'Q' && vp[2] == '=' && vp[3] == '=') || (vn == 12 && vp[10] == 'E' && vp[11] == '=' && vp[0] == 'A' && vp[1] == 'A' && vp[2] == 'A' && vp[3] == 'A' && vp[4] == 'A' && vp[5] == 'A' && vp[6] == 'A' && vp[7] == 'A' && vp[8] == 'A' && vp[9] == 'A'); put_lit(s, t ? "true" : "false"); return 0; }
+      if (vn == 8) { put_lit(s, vp[7] == 1 ? "true" : "false"); return 0; }
+      if (vn != 1) return 1;  // "type mysql:bit has len(t) != 1"
+      put_lit(s, vp[0] == 1 ? "true" : "false"); return 0;
+    case DK_MY_BITS: {  // ShrinkMysqlBit + ParseMysqlBit: the last ceil(size / 8) bytes, reversed (helpers.go:1040-1060, 900-918)
+      const uint32_t div = (ec.arg + 7) / 8;
+      if (div > vn) return 2;
+      s.put('"'); emit_base64_gen(s, div, [&](uint32_t i) { return (uint32_t)vp[vn - 1 - i]; }); s.put('"'); return 0;
+    }
+    case DK_MY_TIMESTAMP: {  // FormatTime(t.UTC(), precision) (helpers.go:795-805)
+      s.put('"'); emit_date(s, (int64_t)b.v); s.put('T'); emit_clock(s, (int64_t)b.v);
+      uint32_t f = (uint32_t)(b.ns / 1000); uint8_t d[6]; for (int k = 5; k >= 0; k--) { d[k] = (uint8_t)('0' + f % 10); f /= 10; }
+      int last = (int)ec.arg - 1; while (last >= 0 && d[last] == '0') last--;
+      if (last >= 0) { s.put('.'); for (int k = 0; k <= last; k++) s.put(d[k]); }
+      s.put('Z'); s.put('"'); return 0;
+    }
+    case DK_MY_DATETIME: emit_u64(s, (uint64_t)(int64_t)b.v * (uint64_t)ec.arg + (uint64_t)((uint32_t)b.ns / (1000000000u / ec.arg))); return 0;
+    case DK_MY_TIME: {  // ParseTimeWithoutTZ: the layout is chosen by the text's length (helpers.go:729-757)
+      int64_t us; uint32_t end; uint32_t h, m, sec;
+      if (vn != 8 && (vn < 10 || vn > 15)) return 1;
+      if (!clock_micros(vp, vn, &us, &end) || end != vn) return 1;
+      dg2(vp, h); dg2(vp + 3, m); dg2(vp + 6, sec);
+      if (h > 23 || m > 59 || sec > 59) return 1;  // time.Parse: out of range
+      emit_u64(s, (uint64_t)us); return 0;
+    }
+    case DK_MY_DECIMAL: {  // DecimalToDebeziumPrimitives of the json.Number's text — of "" for any other Go type (mysql/emitter.go:362-371)
+      const bool num = c.repr == TFGPU_R_JSONNUM;
+      if (ec.arg) { emit_json_string(s, vp, num ? vn : 0u, false); return 0; }  // decimal.handling.mode = string
+      return emit_numeric(s, vp, num ? vn : 0u, 0, false, true);
+    }
+    case DK_MY_YEAR: {  // strconv.Atoi
+      int64_t y; PtrView f{vp};
+      if (parse_int64(f, 0, vn, false, &y) != 0) return 1;
+      emit_i64(s, y); return 0;
+    }
     case DK_WRONG_TYPE: return 1;
     default: return 2;
   }
@@ -530,6 +583,8 @@ template <class S> __device__ __forceinline__ void emit_tail(S &s, const EParams
       case TN_TS: emit_u64(s, commit / 1000000ull); break;  // CommitTime / 1000000; GetPayloadTSMS().UnixNano() / 1000000 is the same number
       case TN_ID: emit_u64(s, p.m_id ? p.m_id[k] : 0u); break;
       case TN_STEP: emit_u64(s, commit); break;
+      case TN_FILE6: { const uint64_t f = (p.m_lsn ? p.m_lsn[k] : 0ull) / 1000000000000ull; if (f < 1000000ull) emit_dec_pad(s, (uint32_t)f, 6); else emit_u64(s, f); break; }  // LSNToFileAndPos: "%06d"
+      case TN_POS: emit_u64(s, (p.m_lsn ? p.m_lsn[k] : 0ull) % 1000000000000ull); break;
       case TN_TXID:  // *string: nil for an empty TxID (emitter_value_converter.go:370-376)
         if (!p.m_tx_off || p.m_tx_off[k + 1] == p.m_tx_off[k]) put_lit(s, "null");
         else emit_json_string(s, p.m_tx + p.m_tx_off[k], p.m_tx_off[k + 1] - p.m_tx_off[k], false);
@@ -544,10 +599,15 @@ template <class S> __device__ __forceinline__ int emit_cell(S &s, const EParams 
   if (ec.kind == EC_CONST) { put_bytes(s, p.blob + ec.pre_off, ec.pre_len); return 0; }
   if (ec.kind == EC_TAIL) { emit_tail(s, p, e, r); return 0; }
   put_bytes(s, p.blob + ec.pre_off, ec.pre_len);
-  if (ec.from_old && !row_has_old(p, r)) { put_lit(s, "null"); return 0; }
+  if (ec.from_old && !row_has_old(p, r)) {
+    if (!ec.has_alt) { put_lit(s, "null"); return 0; }
+    const CellBits b = load_cell(ec.alt, r);
+    if (!b.valid) { put_lit(s, "null"); return 0; }
+    return emit_value(s, p, ec, ec.alt, ec.dk_alt, b);
+  }
   const CellBits b = load_cell(ec.c, r);
   if (!b.valid) { put_lit(s, "null"); return 0; }
-  return emit_value(s, p, ec, b);
+  return emit_value(s, p, ec, ec.c, ec.dk, b);
 }
 
 __global__ void __launch_bounds__(256) dbz_cell_len(EParams p) {
@@ -711,7 +771,7 @@ struct ColPlan { uint32_t dk = 0, arg = 0; std::string descr; };  // the convert
   throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: column " + col + ": " + what + " stays with the stock emitter");
 }
 // getFieldDescr (fields_descr.go:19-69) + GetKafkaTypeDescrByPgType (pg/emitter.go:222-260), and the device converter of the type
-static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
+static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snapshot) {
   const std::string name = cs.name ? cs.name : "", t = cs.original_type ? cs.original_type : "";
   ColPlan cp;
   if (t.empty()) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unknown source type (no OriginalType; emitter_value_converter.go:188-196)");
@@ -740,6 +800,59 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P) {
       if (policy == "fail") throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown ydbType: " + t + " (column " + name + ")");
       unsupported(name, "dt.unknown.types.policy=" + policy + " for " + t);
     }
+  }
+  else if (starts(t, "mysql:")) {  // GetKafkaTypeDescrByMysqlType / AddMysql (mysql/emitter.go:20-388)
+    std::string u = t; for (size_t i = 0; i < t.size(); i++) if (!((t[i] >= 'a' && t[i] <= 'z') || t[i] == ':')) { u = t.substr(0, i); break; }  // abstract.TrimMySQLType
+    const bool uns = t.size() > 9 && t.compare(t.size() - 9, 9, " unsigned") == 0;
+    auto paren_digit = [&](const char *what) -> int { const std::string h = std::string("mysql:") + what + "("; if (!starts(t, h.c_str()) || t.size() < h.size() + 2 || t[h.size()] < '0' || t[h.size()] > '9' || t[h.size() + 1] != ')') return -1; return t[h.size()] - '0'; };
+    auto bit = [](int r) { return 1u << r; };
+    found = true;
+    if (u == "mysql:int" || u == "mysql:mediumint") { kafka = (u == "mysql:int" && uns && (snapshot || !(cs.flags & TFGPU_COL_KEY))) ? "int64" : "int32"; cp.dk = DK_INT_REPRS; cp.arg = bit(TFGPU_R_INT32) | bit(TFGPU_R_UINT32); }
+    else if (u == "mysql:bigint") { kafka = "int64"; cp.dk = DK_INT_REPRS; cp.arg = bit(TFGPU_R_INT64) | bit(TFGPU_R_UINT64); }
+    else if (u == "mysql:smallint") { kafka = uns ? "int32" : "int16"; cp.dk = DK_INT_REPRS; cp.arg = bit(TFGPU_R_INT16) | bit(TFGPU_R_UINT16); }
+    else if (u == "mysql:tinyint") { if (t == "mysql:tinyint(1)") { kafka = "boolean"; cp.dk = DK_MY_TINYINT1; } else { kafka = "int16"; cp.dk = DK_INT_REPRS; cp.arg = bit(TFGPU_R_INT8) | bit(TFGPU_R_UINT8); } }
+    else if (u == "mysql:float" || u == "mysql:double") { kafka = "double"; cp.dk = DK_MY_FLOAT; cp.arg = u == "mysql:float" ? 1u : 0u; }
+    else if (t == "mysql:blob" || t == "mysql:longblob" || t == "mysql:mediumblob" || t == "mysql:tinyblob" || starts(t, "mysql:binary(") || starts(t, "mysql:varbinary(")) {
+      kafka = "bytes"; cp.dk = DK_MY_BINARY;
+      if (!starts(t, "mysql:varbinary")) { const size_t q = t.find('('); if (q != std::string::npos && q + 2 < t.size() && t[q + 1] >= '0' && t[q + 1] <= '9' && t[q + 2] == ')') cp.arg = (uint32_t)(t[q + 1] - '0') + 1u; }  // `^.*\((\d)\).*`
+    }
+    else if (starts(t, "mysql:bit(")) {
+      const size_t z = t.find(')', 10);
+      if (z == std::string::npos) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unsupported pg type, can't find closing bracket: " + t);
+      if (t == "mysql:bit(1)") { kafka = "boolean"; cp.dk = DK_MY_BIT1; }
+      else { kafka = "bytes"; dname = "io.debezium.data.Bits"; extra = ",\"parameters\":{\"length\":" + jstr(t.substr(10, z - 10)) + "}"; cp.dk = DK_MY_BITS; cp.arg = (uint32_t)std::min<long>(std::atol(t.substr(10, z - 10).c_str()), 1 << 20); }
+    }
+    else if (t == "mysql:longtext" || t == "mysql:mediumtext" || t == "mysql:text" || t == "mysql:tinytext" || starts(t, "mysql:char(") || starts(t, "mysql:varchar(")) { kafka = "string"; cp.dk = DK_STRING; }
+    else if (starts(t, "mysql:enum(") || starts(t, "mysql:set(")) {
+      const bool en = starts(t, "mysql:enum(");
+      std::string raw = t.substr(en ? 11 : 10, t.size() - (en ? 11 : 10) - 1), allowed;  // UnwrapMysqlEnumsAndSets (helpers.go:1022-1038)
+      for (std::string str = raw;;) { if (str.empty()) break; str = str.substr(1); const size_t q = str.find('\''); if (q == std::string::npos) { allowed.clear(); break; } allowed += str.substr(0, q) + ","; if (q + 2 >= str.size()) break; str = str.substr(q + 2); }
+      if (!allowed.empty()) allowed.pop_back();
+      kafka = "string"; dname = en ? "io.debezium.data.Enum" : "io.debezium.data.EnumSet"; extra = ",\"parameters\":{\"allowed\":" + jstr(allowed) + "}"; cp.dk = DK_STRING;
+    }
+    else if (t == "mysql:json") { kafka = "string"; dname = "io.debezium.data.Json"; cp.dk = DK_JSON; }
+    else if (t == "mysql:date") { kafka = "int32"; dname = "io.debezium.time.Date"; cp.dk = DK_DATE; }
+    else if (starts(t, "mysql:datetime")) {
+      const int pd = paren_digit("datetime");
+      kafka = "int64"; dname = (pd >= 1 && pd <= 3) || pd == -1 ? "io.debezium.time.Timestamp" : "io.debezium.time.MicroTimestamp";  // GetTimeDivider fails without a "(d)": divider 0
+      cp.dk = DK_MY_DATETIME; cp.arg = (t == "mysql:datetime" || pd <= 3) ? 1000u : 1000000u;
+    }
+    else if (starts(t, "mysql:timestamp")) {
+      const int pd = t == "mysql:timestamp" ? 0 : paren_digit("timestamp");
+      if (pd < 0) unsupported(name, "original type " + t);  // FormatTime with precision -1 panics
+      kafka = "string"; dname = "io.debezium.time.ZonedTimestamp"; cp.dk = DK_MY_TIMESTAMP; cp.arg = (uint32_t)pd;
+    }
+    else if (t == "mysql:time" || starts(t, "mysql:time(")) { kafka = "int64"; dname = "io.debezium.time.MicroTime"; cp.dk = DK_MY_TIME; }
+    else if (starts(t, "mysql:decimal(")) {
+      const std::string &mode = P.get("decimal.handling.mode");
+      int pr = 0, sc = 0; { size_t i = 14; size_t a = i; while (i < t.size() && t[i] >= '0' && t[i] <= '9' && pr < 100000) pr = pr * 10 + (t[i++] - '0'); bool ok = i > a && i < t.size() && t[i] == ','; a = ++i; while (ok && i < t.size() && t[i] >= '0' && t[i] <= '9' && sc < 100000) sc = sc * 10 + (t[i++] - '0'); if (!(ok && i > a && i < t.size() && t[i] == ')')) { pr = 0; sc = 0; } }
+      cp.dk = DK_MY_DECIMAL;
+      if (mode == "precise") { kafka = "bytes"; dname = "org.apache.kafka.connect.data.Decimal"; extra = ",\"parameters\":{\"connect.decimal.precision\":\"" + std::to_string(pr) + "\",\"scale\":\"" + std::to_string(sc) + "\"}"; }
+      else if (mode == "string") { kafka = "string"; cp.arg = 1; }
+      else unsupported(name, "decimal.handling.mode=" + mode);
+    }
+    else if (starts(t, "mysql:year")) { kafka = "int32"; dname = "io.debezium.time.Year"; cp.dk = DK_MY_YEAR; }
+    else throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown mysqlType: " + t + " (column " + name + ")");
   }
   else if (!starts(t, "pg:")) unsupported(name, "original type " + t);
   else if (t.size() > 2 && t.compare(t.size() - 2, 2, "[]") == 0) unsupported(name, "array type " + t);  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
@@ -846,6 +959,15 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_WRONG_TYPE: return 0;
     case DK_NUMERIC: case DK_NUMERIC_TEXT: return in({TFGPU_R_STRING}) ? 0 : ((arg >> 17) & 1u) ? 2 : in({TFGPU_R_JSONNUM}) ? 0 : 1;  // ydb:Decimal asserts a string
     case DK_MARSHAL: return 0;
+    case DK_INT_REPRS: return repr > 0 && repr < 32 && ((arg >> repr) & 1u) ? 0 : 1;
+    case DK_MY_TINYINT1: return in({TFGPU_R_INT8}) ? 0 : 2;
+    case DK_MY_FLOAT: return in({TFGPU_R_FLOAT64, TFGPU_R_JSONNUM}) || (arg && in({TFGPU_R_FLOAT32})) ? 0 : 1;
+    case DK_MY_BINARY: return in({TFGPU_R_BYTES}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
+    case DK_MY_BIT1: return in({TFGPU_R_BYTES, TFGPU_R_STRING}) ? 0 : 2;
+    case DK_MY_BITS: return in({TFGPU_R_BYTES}) ? 0 : 2;
+    case DK_MY_TIMESTAMP: case DK_MY_DATETIME: return in({TFGPU_R_TIME}) ? 0 : 2;
+    case DK_MY_TIME: case DK_MY_YEAR: return in({TFGPU_R_STRING}) ? 0 : 2;
+    case DK_MY_DECIMAL: return 0;
     case DK_YDB_UINT64: return in({TFGPU_R_UINT64}) ? 0 : 1;
     case DK_YDB_DATE: return in({TFGPU_R_TIME}) ? 0 : 1;
     default: return 2;
@@ -864,16 +986,17 @@ struct CellList {
     ECell c{}; c.kind = EC_CONST; c.apply = apply; c.pre_off = (uint32_t)blob->size(); c.pre_len = (uint32_t)text.size();
     *blob += text; cells.push_back(c);
   }
-  void push_value(uint32_t apply, const std::string &prefix, const DColumn &col, const ColPlan &cp, bool from_old) {
+  void push_value(uint32_t apply, const std::string &prefix, const DColumn &col, const ColPlan &cp, bool from_old, const DColumn *alt = nullptr) {
     // a Go type AddPg does not take for this column fails (or leaves to the host) the first NON-NIL value of it, as the reference's type
     // switches do: a column of nils has no type to object to
     const int rk = repr_ok(cp.dk, col.repr, cp.arg);
     ECell c{}; c.kind = EC_VALUE; c.apply = apply; c.pre_off = (uint32_t)blob->size(); c.pre_len = (uint32_t)prefix.size();
     *blob += prefix; c.c = dcol_of(col); c.dk = rk ? (uint32_t)(DK_WRONG_TYPE + rk - 1) : cp.dk; c.arg = cp.arg; c.from_old = from_old ? 1u : 0u;
+    if (alt) { const int ra = repr_ok(cp.dk, alt->repr, cp.arg); c.alt = dcol_of(*alt); c.dk_alt = ra ? (uint32_t)(DK_WRONG_TYPE + ra - 1) : cp.dk; c.has_alt = 1; }
     cells.push_back(c);
   }
 };
-struct Member { std::string name; const DColumn *col; const ColPlan *plan; bool from_old; std::string constant; };
+struct Member { std::string name; const DColumn *col; const ColPlan *plan; bool from_old; std::string constant; const DColumn *alt = nullptr; };
 // one Go map as an object: members in key order, `{` … `}` (or `{}`)
 static void push_object(CellList &L, uint32_t apply, std::vector<Member> ms) {
   std::stable_sort(ms.begin(), ms.end(), [](const Member &a, const Member &b) { return a.name < b.name; });
@@ -881,7 +1004,7 @@ static void push_object(CellList &L, uint32_t apply, std::vector<Member> ms) {
   if (ms.empty()) { L.push_const(apply, "{}"); return; }
   for (size_t i = 0; i < ms.size(); i++) {
     const std::string pre = std::string(i ? "," : "{") + jstr(ms[i].name) + ":";
-    if (ms[i].col) L.push_value(apply, pre, *ms[i].col, *ms[i].plan, ms[i].from_old);
+    if (ms[i].col) L.push_value(apply, pre, *ms[i].col, *ms[i].plan, ms[i].from_old, ms[i].alt);
     else L.push_const(apply, pre + ms[i].constant);
   }
   L.push_const(apply, "}");
@@ -986,7 +1109,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     }
     if (P.get("binary.handling.mode") != "bytes") return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unsupported binary.handling.mode: " + P.get("binary.handling.mode"));
     const std::string &source_type = P.get("dt.source.type");
-    if (!source_type.empty() && source_type != "pg" && source_type != "ydb") return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: dt.source.type=" + source_type + " stays with the stock emitter");
+    if (!source_type.empty() && source_type != "pg" && source_type != "ydb" && source_type != "mysql") return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: dt.source.type=" + source_type + " stays with the stock emitter");
     const std::string server = P.get("topic.prefix"), database = P.get("database.dbname"), version = o->version ? o->version : "1.1.2.Final";
     const bool skip_tombstones = P.get("tombstones.on.delete") == "false";
 
@@ -1003,7 +1126,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     for (int i = 0; i < ts.ncols; i++) {
       const std::string nm = ts.cols[i].name ? ts.cols[i].name : "";
       index[nm] = i;   // mapColToIndex: the last one of a repeated name
-      plans[(size_t)i] = plan_column(ts.cols[i], P);
+      plans[(size_t)i] = plan_column(ts.cols[i], P, o->snapshot != 0);
       if (ts.cols[i].flags & TFGPU_COL_KEY) npk++;
     }
     auto col_index = [&](const std::string &nm) -> int {
@@ -1029,9 +1152,15 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       ",{\"default\":\"false\",\"field\":\"snapshot\",\"name\":\"io.debezium.data.Enum\",\"optional\":true,\"parameters\":{\"allowed\":\"true,last,false\"},\"type\":\"string\",\"version\":1}," +
       f("db", "string", false) + "," + f("table", "string", false);
     std::string src_schema = "{\"field\":\"source\",\"fields\":[";
+    if (source_type == "mysql") {   // the `table` field turns optional, seven more fields (fields_descr_source.go:70-103)
+      const std::string tbl = f("table", "string", false); src_fields.replace(src_fields.rfind(tbl), tbl.size(), f("table", "string", true));
+      src_fields += "," + f("file", "string", false) + "," + f("gtid", "string", true) + "," + f("pos", "int64", false) + "," + f("query", "string", true) + "," + f("row", "int32", false) + "," +
+                    f("server_id", "int64", false) + "," + f("thread", "int64", true);
+    }
     if (source_type == "pg") src_fields += "," + f("lsn", "int64", true) + "," + f("schema", "string", false) + "," + f("txId", "int64", true) + "," + f("xmin", "int64", true);
     src_schema += src_fields + "],";
     if (source_type == "pg") src_schema += "\"name\":\"io.debezium.connector.postgresql.Source\",";
+    if (source_type == "mysql") src_schema += "\"name\":\"io.debezium.connector.mysql.Source\",";
     src_schema += "\"optional\":false,\"type\":\"struct\"}";
     const std::string tx_schema = "{\"field\":\"transaction\",\"fields\":[" + f("id", "string", false) + "," + f("total_order", "int64", false) + "," + f("data_collection_order", "int64", false) + "],\"optional\":true,\"type\":\"struct\"}";
     const std::string val_schema_json = "{\"fields\":[" + side("before") + "," + side("after") + "," + src_schema + "," + f("op", "string", false) + "," + f("ts_ms", "int64", true) + "," + tx_schema +
@@ -1077,7 +1206,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       // every row's entry must exist: src_row (or the row index) is below meta->n
       if (!b->src_row && meta->n < n) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: row meta shorter than the batch");
       p.m_id = dbz_meta(meta, meta->id, (size_t)meta->n, keep); p.m_lsn = dbz_meta(meta, meta->lsn, (size_t)meta->n, keep); p.m_commit = dbz_meta(meta, meta->commit_time, (size_t)meta->n, keep);
-      if (source_type == "ydb" && meta->tx_id_offsets && meta->n > 0) {
+      if ((source_type == "ydb" || source_type == "mysql") && meta->tx_id_offsets && meta->n > 0) {
         uint32_t tx_bytes = 0;
         if (meta->mem == TFGPU_MEM_DEVICE) { const uint32_t *h = d2h_u32(meta->tx_id_offsets + meta->n); sync(); tx_bytes = *h; } else tx_bytes = meta->tx_id_offsets[meta->n];
         p.m_tx_off = dbz_meta(meta, meta->tx_id_offsets, (size_t)meta->n + 1, keep); p.m_tx = dbz_meta(meta, meta->tx_id_data, (size_t)tx_bytes, keep);
@@ -1101,8 +1230,15 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       V.push_const(EA_BEFORE_NULL, "null");
       std::vector<Member> before_d, before_u;
       std::vector<char> in_old((size_t)ts.ncols, 0);
-      for (auto &c : b->old_keys) { const int i = col_index(c.name); in_old[(size_t)i] = 1; before_d.push_back({c.name, &c, &plans[(size_t)i], true, ""}); before_u.push_back({c.name, &c, &plans[(size_t)i], true, ""}); }
-      for (int i = 0; i < ts.ncols; i++) if (!in_old[(size_t)i] && index[ts.cols[i].name ? ts.cols[i].name : ""] == i) before_d.push_back({ts.cols[i].name ? ts.cols[i].name : "", nullptr, nullptr, false, "null"});
+      // a delete's `before`: every column nil, under the row's own values when the source is MySQL, under the OldKeys (valPayload :463-486)
+      const bool my_before = source_type == "mysql";
+      auto own = [&](const std::string &nm) -> const DColumn * { if (!my_before) return nullptr; for (auto &c : b->cols) if (c.name == nm) return &c; return nullptr; };
+      for (auto &c : b->old_keys) { const int i = col_index(c.name); in_old[(size_t)i] = 1; Member m{c.name, &c, &plans[(size_t)i], true, ""}; before_u.push_back(m); m.alt = own(c.name); before_d.push_back(m); }
+      for (int i = 0; i < ts.ncols; i++) if (!in_old[(size_t)i] && index[ts.cols[i].name ? ts.cols[i].name : ""] == i) {
+        const std::string nm = ts.cols[i].name ? ts.cols[i].name : "";
+        if (const DColumn *c = own(nm)) before_d.push_back({nm, c, &plans[(size_t)i], false, ""});
+        else before_d.push_back({nm, nullptr, nullptr, false, "null"});
+      }
       push_object(V, EA_BEFORE_D, before_d);
       if (has_prev) push_object(V, EA_BEFORE_U, before_u);
       ECell tail{}; tail.kind = EC_TAIL; tail.apply = EA_VALUE; V.cells.push_back(tail);
@@ -1115,6 +1251,12 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
         segs.push_back({",\"name\":" + jstr(server) + ",\"schema\":" + jstr(b->ns) + ",\"snapshot\":\"" + snap + "\",\"table\":" + jstr(b->table) + ",\"ts_ms\":", TN_TS});
         segs.push_back({",\"txId\":", TN_ID});
         segs.push_back({",\"version\":" + jstr(version) + ",\"xmin\":null},\"transaction\":null,\"ts_ms\":", TN_TS});
+      } else if (source_type == "mysql") {   // db = ChangeItem.Schema, file / pos from the LSN, gtid = TxID (emitter_value_converter.go:352-367)
+        segs.push_back({"\",\"source\":{\"connector\":\"mysql\",\"db\":" + jstr(b->ns) + ",\"file\":\"mysql-log.", TN_FILE6});
+        segs.push_back({"\",\"gtid\":", TN_TXID});
+        segs.push_back({",\"name\":" + jstr(server) + ",\"pos\":", TN_POS});
+        segs.push_back({",\"query\":null,\"row\":0,\"server_id\":0,\"snapshot\":\"" + snap + "\",\"table\":" + jstr(b->table) + ",\"thread\":null,\"ts_ms\":", TN_TS});
+        segs.push_back({",\"version\":" + jstr(version) + "},\"transaction\":null,\"ts_ms\":", TN_TS});
       } else if (source_type == "ydb") {   // + txId (*string) and step = CommitTime (emitter_value_converter.go:368-377)
         segs.push_back({"\",\"source\":{\"db\":" + jstr(database) + ",\"name\":" + jstr(server) + ",\"snapshot\":\"" + snap + "\",\"step\":", TN_STEP});
         segs.push_back({",\"table\":" + jstr(b->table) + ",\"ts_ms\":", TN_TS});
