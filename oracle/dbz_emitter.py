@@ -19,7 +19,7 @@ Postgres-typed rows, the `DebeziumSerializer` of the queue sinks (pkg/serializer
 Everything the reference builds is a Go map marshalled by util.JSONMarshalUnescape (pkg/util/encode_json.go:10-19): keys in byte
 order, no HTML escaping.  Only the product's test-suite, smoke() and bench.py's cpu_baseline leg use this file; the product never does.
 
-Not restated (third-party parsers the reference calls; NotRestated is raised by name): hstore given as text (HstoreToJSON), string inputs of `timestamp without time zone` (pgtype.Timestamp.Set(string)), pg arrays,
+Not restated (third-party parsers the reference calls; NotRestated is raised by name): hstore given as text (HstoreToJSON), string inputs of `timestamp without time zone` (pgtype.Timestamp.Set(string)), pg arrays given as text,
 mysql binaries / bits given as base64 text, the schema-registry packers (Confluent JSON / skip-schema).  PINNED against the reference's fixtures
 pkg/debezium/pg/tests/testdata/emitter_crud_test__*.txt (copied to tests/golden/debezium_emitter/) the way the reference's own test
 compares them (pkg/debezium/testutil/test.go:24-152: the fixtures come from a vanilla Debezium, so both sides are normalised).
@@ -1188,8 +1188,11 @@ def field_descr(col: Col, params, into_arr=False, snapshot=False):
         else:
             raise EmitError("unable to find yt type: %s" % col.dtype)
     elif t.startswith("pg:"):
-        if t.endswith("[]"):
-            raise NotRestated("pg arrays")
+        if t.endswith("[]"):   # AddFieldDescr (fields_descr.go:71-96): the element's description (no `field`) under "items"
+            d = {"items": field_descr(Col(col.name, col.dtype, col.key, t[:-2], col.properties), params, True, snapshot), "field": col.name, "type": "array", "optional": not col.key}
+            if params["dt.add.original.type.info"] == "true":
+                d["__dt_original_type_info"] = {"original_type": t}
+            return d
         kafka, name, extra = pg_type_descr(col, into_arr, params)
     elif t.startswith("ydb:"):
         kafka, name, extra = ydb_type_descr(t, params)
@@ -1292,8 +1295,20 @@ class Emitter:
     def add(self, c: Col, v):
         t = c.original_type
         if t.startswith("pg:"):
-            if t.endswith("[]"):
-                raise NotRestated("pg arrays")
+            if t.endswith("[]"):   # add (emitter_value_converter.go:139-168): every element through AddPg(intoArr = true)
+                if v[0] == "nil":
+                    return None
+                if v[0] == "list":   # []interface{} whose elements Restore already typed (restore.go:47-52)
+                    pairs = v[1]
+                else:
+                    arr = decode_any(_b(v[1])) if v[0] == "json" else None
+                    if arr is None and v[0] == "json":
+                        return None
+                    if not isinstance(arr, list):
+                        raise NotRestated("a pg array given as %s" % v[0])
+                    pairs = [("nil", None) if el is None else ("bool", el) if isinstance(el, bool) else ("jsonnum", _b(el)) if isinstance(el, JN) else ("string", el) if isinstance(el, bytes)
+                             else ("json", gomarshal(el)) for el in arr]
+                return [add_pg(c, pair, t[:-2], True, self.params) for pair in pairs]
             return add_pg(c, v, t, False, self.params)
         if t.startswith("ydb:"):
             return add_ydb(c, v, t, self.params)
@@ -1424,6 +1439,8 @@ def _norm(v):
 def restore(col: Col, raw):
     if raw is None:
         return ("nil", None)
+    if isinstance(raw, list):   # Restore recurses into []any with the same column (restore.go:47-52)
+        return ("list", [restore(col, x) for x in raw])
     d = col.dtype
     if d in ("date", "datetime", "timestamp"):
         if isinstance(raw, str) and not isinstance(raw, JN):
@@ -1473,8 +1490,14 @@ def restore(col: Col, raw):
         return ("string", gomarshal(_go(raw)))   # json.Marshal(value): HTML escaping not restated (no such value in the fixtures)
     if d == "any":
         if isinstance(raw, str) and not isinstance(raw, JN):
-            if col.original_type.startswith("pg:timestamp"):
-                raise NotRestated("pg:timestamp in an any column")
+            if col.original_type.startswith("pg:timestamp"):   # arrays of timestamps: their elements come back as time.Time (restore.go:248-257)
+                m = re.match(r"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)(?:\.(\d{1,9}))?(Z|[+-]\d\d:\d\d)$", raw)
+                if not m:
+                    return ("string", _b(raw))
+                y, mo, dd, h, mi, sc = (int(m.group(i)) for i in range(1, 7))
+                z = m.group(8)
+                off = 0 if z == "Z" else (int(z[1:3]) * 3600 + int(z[4:6]) * 60) * (-1 if z[0] == "-" else 1)
+                return ("time", (days_from_civil(y, mo, dd) * 86400 + h * 3600 + mi * 60 + sc - off, int((m.group(7) or "").ljust(9, "0") or 0), off))
             if col.original_type.startswith("pg:"):
                 return ("string", _b(raw))
             raise NotRestated("tryUnmarshalJSON")

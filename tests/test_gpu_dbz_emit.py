@@ -39,11 +39,12 @@ TABLE = [("id", "int32", True, "pg:integer"), ("bl", "boolean", False, "pg:boole
 
 
 def schema_of(table):
-    return abi.Schema.of([[n, d, k, "", o] for n, d, k, o in table])
+    """(name, DataType, key, OriginalType[, Properties])"""
+    return abi.Schema([abi.ColSchema(t[0], t[1], t[2], "", t[3], properties_json=(json.dumps(t[4], separators=(",", ":")) if len(t) > 4 else "")) for t in table])
 
 
 def cols_of(table):
-    return [E.Col(n, d, k, o) for n, d, k, o in table]
+    return [E.Col(t[0], t[1], t[2], t[3], (t[4] if len(t) > 4 else None)) for t in table]
 
 
 TEXTS = ["", "plain", "quote\" back\\slash", "<tag attr='x'>&amp;</tag>", "tab\tnl\nctl\x01\x1f", "юникод ✓ \u2028 \u2029", "x" * 300, "bad \xff utf8 \xc3"]
@@ -337,6 +338,53 @@ def test_mysql_typed_rows_and_the_mysql_source_block(tf, fixture):
         assert ei.value.code == tf.ERR_INVALID and "colName: " + col in str(ei.value), (col, str(ei.value))
 
 
+def test_pg_arrays_and_enums(tf):
+    """pg arrays whose elements AddPg(intoArr) leaves as they are — the integer family (through json.Number.Int64()), the text family, booleans — with their "items" field
+    descriptions (AddFieldDescr, fields_descr.go:71-96), and enum columns (Properties[pg:enum_all_values] → io.debezium.data.Enum); then the reference's array canon ChangeItem
+    (pg/tests/testdata/emitter_vals_test__canon_change_item_arr.txt: the oracle reproduces TestPgArrByArrInsert's table) cut to those families"""
+    table = [("id", "int32", True, "pg:integer"), ("ai", "any", False, "pg:integer[]"), ("ab", "any", False, "pg:bigint[]"), ("asi", "any", False, "pg:smallint[]"), ("at", "any", False, "pg:text[]"),
+             ("av", "utf8", False, "pg:character varying(5)[]"), ("au", "any", False, "pg:uuid[]"), ("abl", "any", False, "pg:boolean[]"),
+             ("mood", "utf8", False, "pg:mood", {"pg:enum_all_values": ["sad", "ok", "ha\"ppy", "süß"]})]
+    rng = np.random.default_rng(31)
+    rows = []
+    for r in range(200):
+        def pick(lst):
+            return lst[int(rng.integers(0, len(lst)))]
+        rows.append([["int32", r], ["json", pick(["[1,2]", "[]", "[-0,null,9223372036854775807]", "[-9223372036854775808]", "null", "[0]"])], ["json", pick(["[1,2]", "[null]"])], ["json", "[1,-2]"],
+                     ["json", pick(['["a","<b>&",null]', '["q\\"uote","back\\\\slash","\\u2028"]', "[]", '[""]', '["юникод"]'])], ["json", '["varc","varc"]'],
+                     ["json", '["a0eebc99-9c0b-4ef8-bb6d-6bb9bd380a11"]'], ["json", pick(["[true,false,null]", "[]"])], ["string", pick(["sad", "ok"])]])
+        for k in range(1, 9):
+            if rng.integers(0, 9) == 0:
+                rows[-1][k] = ["nil", None]
+    b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "arrs")
+    for params in (PARAMS, dict(PARAMS, **{"dt.add.original.type.info": "true"})):
+        got, want, rws = emit_both(tf, b, table, params, None)
+        assert_same(got, want, rws)
+    v = got.messages()[0][1]
+    assert b'{"__dt_original_type_info":{"original_type":"pg:integer[]"},"field":"ai","items":{"__dt_original_type_info":{"original_type":"pg:integer"},"optional":true,"type":"int32"},"optional":true,"type":"array"}' in v
+    assert b'"parameters":{"allowed":"sad,ok,ha\\"ppy,s\xc3\xbc\xc3\x9f"}' in v
+    with open(os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter", "pg_emitter_vals_test__canon_change_item_arr.txt"), "rb") as f:
+        it = E.unmarshal_change_item(f.read())
+    fam = ("pg:integer", "pg:boolean[]", "pg:smallint[]", "pg:integer[]", "pg:bigint[]", "pg:character[]", "pg:character varying(256)[]", "pg:character varying(5)[]", "pg:uuid[]", "pg:text[]")
+    keep = [c for c in it.cols if c.original_type in fam]
+    assert len(keep) == 12
+    table = [(c.name, c.dtype, c.key, c.original_type) for c in keep]
+    vals = []
+    for c in keep:
+        g, x = it.values[it.names.index(c.name)]
+        vals.append(["json", E.gomarshal([E.go_value(p) for p in x])] if g == "list" else [g, x])
+    one = abi.batch_from_rows(schema_of(table), [c.name for c in keep], [vals], it.schema, it.table)
+    got, want, rws = emit_both(tf, one, table, {"database.dbname": "pguser", "topic.prefix": "fullfillment", "dt.source.type": "pg"}, None)
+    assert_same(got, want, rws)
+    base = [("id", "int32", True, "pg:integer")]
+    for t, v, code in (("pg:integer[]", "[1.5]", tf.ERR_INVALID), ("pg:integer[]", '["1"]', tf.ERR_INVALID), ("pg:integer[]", "[[1]]", tf.ERR_INVALID), ("pg:text[]", "[1]", tf.ERR_UNSUPPORTED),
+                       ("pg:integer[]", '{"a":1}', tf.ERR_UNSUPPORTED), ("pg:numeric[]", "[1]", tf.ERR_UNSUPPORTED), ("pg:integer[][]", "[[1]]", tf.ERR_UNSUPPORTED)):
+        bb = abi.batch_from_rows(schema_of(base + [("x", "any", False, t)]), ["id", "x"], [[["int32", 1], ["json", v]]], "public", "t")
+        with pytest.raises(tf.TfgpuError) as ei:
+            tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(base + [("x", "any", False, t)])), tf.DeviceBatch.upload(bb))
+        assert ei.value.code == code, (t, v, str(ei.value))
+
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter")
 DEVICE_TYPES = ("pg:xml", "pg:point", "pg:numrange", "pg:tsrange", "pg:tstzrange", "pg:money", "pg:USER-DEFINED:hstore", "pg:boolean", "pg:bit(1)", "pg:smallint", "pg:integer", "pg:bigint", "pg:oid", "pg:real", "pg:double precision", "pg:bytea", "pg:json", "pg:jsonb", "pg:uuid",
                 "pg:inet", "pg:int4range", "pg:int8range", "pg:daterange", "pg:text", "pg:date", "pg:cidr", "pg:macaddr", "pg:USER-DEFINED:citext")
@@ -384,7 +432,7 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
         b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "t")
         return tf.debezium_emit(abi.dbz_emit_options(params, schema_of(table), **kw), tf.DeviceBatch.upload(b))
     base = [("id", "int32", True, "pg:integer")]
-    for t in ("pg:integer[]", "pg:interval[]", "oracle:NUMBER"):
+    for t in ("pg:interval[]", "pg:inet[]", "oracle:NUMBER"):
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", "1"]]])
         assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value) and "stock emitter" in str(ei.value), str(ei.value)

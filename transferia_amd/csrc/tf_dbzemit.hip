@@ -40,7 +40,7 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_ARR_INT, DK_ARR_STRING, DK_ARR_COPY, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
@@ -567,6 +567,34 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
       if (parse_int64(f, 0, vn, false, &y) != 0) return 1;
       emit_i64(s, y); return 0;
     }
+    case DK_ARR_INT: case DK_ARR_STRING: case DK_ARR_COPY: {  // add (emitter_value_converter.go:139-168): every element of a []interface{} through AddPg(intoArr)
+      if (vn == 4 && vp[0] == 'n' && vp[1] == 'u' && vp[2] == 'l' && vp[3] == 'l') { put_lit(s, "null"); return 0; }
+      if (vn < 2 || vp[0] != '[' || vp[vn - 1] != ']') return 2;  // not a slice: the reference emits an empty array
+      if (dk == DK_ARR_COPY) { put_bytes(s, vp, vn); return 0; }   // pg:boolean passes every element through as it is
+      s.put('[');
+      uint32_t i = 1; bool first = true;
+      PtrView f{vp};
+      while (i < vn - 1) {
+        if (!first) { if (vp[i] != ',') return 2; i++; s.put(','); }
+        first = false;
+        const uint32_t c0 = vp[i];
+        if (c0 == 'n') { if (i + 4 > vn - 1 || vp[i + 1] != 'u' || vp[i + 2] != 'l' || vp[i + 3] != 'l') return 2; put_lit(s, "null"); i += 4; continue; }
+        if (dk == DK_ARR_INT) {
+          if (c0 == '"' || c0 == '[' || c0 == '{' || c0 == 't' || c0 == 'f') return 1;  // "unknown type of value for pg:integer"
+          uint32_t e = i; while (e < vn - 1 && vp[e] != ',') e++;
+          int64_t v;
+          if (parse_int64(f, i, e, false, &v) != 0) return 1;  // "unable to get int64 from json.Number"
+          emit_i64(s, v); i = e;
+        } else {
+          if (c0 != '"') return 2;  // colVal.(string) panics on anything else
+          uint32_t e = i + 1;
+          while (e < vn - 1 && vp[e] != '"') e += vp[e] == '\\' ? 2 : 1;
+          if (e >= vn - 1) return 2;
+          put_bytes(s, vp + i, e + 1 - i); i = e + 1;  // the text is json.Marshal's own: marshalling the string again writes the same bytes
+        }
+      }
+      s.put(']'); return 0;
+    }
     case DK_WRONG_TYPE: return 1;
     default: return 2;
   }
@@ -771,9 +799,23 @@ struct ColPlan { uint32_t dk = 0, arg = 0; std::string descr; };  // the convert
   throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: column " + col + ": " + what + " stays with the stock emitter");
 }
 // getFieldDescr (fields_descr.go:19-69) + GetKafkaTypeDescrByPgType (pg/emitter.go:222-260), and the device converter of the type
-static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snapshot) {
-  const std::string name = cs.name ? cs.name : "", t = cs.original_type ? cs.original_type : "";
+static std::vector<std::string> enum_values(const char *props, bool *ok);
+static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snapshot, bool into_arr = false, const char *type_override = nullptr) {
+  const std::string name = cs.name ? cs.name : "", t = type_override ? type_override : (cs.original_type ? cs.original_type : "");
   ColPlan cp;
+  if (!into_arr && starts(t, "pg:") && t.size() > 5 && t.compare(t.size() - 2, 2, "[]") == 0) {  // AddFieldDescr (fields_descr.go:71-96): the element's description under "items"
+    const std::string et = t.substr(0, t.size() - 2);
+    ColPlan el = plan_column(cs, P, snapshot, true, et.c_str());
+    if (el.dk == DK_SMALLINT || el.dk == DK_INTEGER || el.dk == DK_BIGINT) cp.dk = DK_ARR_INT;
+    else if (el.dk == DK_STRING) cp.dk = DK_ARR_STRING;
+    else if (el.dk == DK_BOOL) cp.dk = DK_ARR_COPY;
+    else unsupported(name, "an array of " + et);
+    std::string o = "{";
+    if (P.get("dt.add.original.type.info") == "true") o += "\"__dt_original_type_info\":{\"original_type\":" + jstr(t) + "},";
+    o += "\"field\":" + jstr(name) + ",\"items\":" + el.descr + ",\"optional\":" + ((cs.flags & TFGPU_COL_KEY) ? "false" : "true") + ",\"type\":\"array\"}";
+    cp.descr = o;
+    return cp;
+  }
   if (t.empty()) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unknown source type (no OriginalType; emitter_value_converter.go:188-196)");
   std::string kafka, dname, extra;  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
   bool found = false;
@@ -855,7 +897,7 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
     else throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown mysqlType: " + t + " (column " + name + ")");
   }
   else if (!starts(t, "pg:")) unsupported(name, "original type " + t);
-  else if (t.size() > 2 && t.compare(t.size() - 2, 2, "[]") == 0) unsupported(name, "array type " + t);  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
+  else if (t.size() > 2 && t.compare(t.size() - 2, 2, "[]") == 0) unsupported(name, "array type " + t);  // an array of arrays  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
   static const struct { const char *t; const char *kafka; const char *name; uint32_t dk; } PLAIN[] = {
     {"pg:boolean", "boolean", "", DK_BOOL}, {"pg:bit(1)", "boolean", "", DK_BIT1}, {"pg:smallint", "int16", "", DK_SMALLINT}, {"pg:integer", "int32", "", DK_INTEGER},
     {"pg:bigint", "int64", "", DK_BIGINT}, {"pg:oid", "int64", "", DK_OID}, {"pg:real", "float", "", DK_REAL}, {"pg:double precision", "double", "", DK_DOUBLE},
@@ -912,7 +954,13 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
       }
     } else if (mode == "string") { kafka = "string"; cp.dk = DK_NUMERIC_TEXT; }
     else unsupported(name, "decimal.handling.mode=" + mode);
-  } else if (cs.properties_json && std::strstr(cs.properties_json, "pg:enum_all_values")) unsupported(name, "enum type " + t);
+  } else if (cs.properties_json && std::strstr(cs.properties_json, "\"pg:enum_all_values\"")) {  // pgEnum (pg/emitter.go:165-173): Properties[pg:enum_all_values]
+    bool ok = false;
+    const std::vector<std::string> vals = enum_values(cs.properties_json, &ok);
+    if (!ok) unsupported(name, "enum type " + t + " (its pg:enum_all_values property is not a list of strings)");
+    std::string joined; for (size_t i = 0; i < vals.size(); i++) { if (i) joined += ","; joined += vals[i]; }
+    kafka = "string"; dname = "io.debezium.data.Enum"; extra = ",\"parameters\":{\"allowed\":" + jstr(joined) + "}"; cp.dk = DK_STRING;
+  }
   else {
     const std::string &policy = P.get("dt.unknown.types.policy");
     if (policy == "fail") throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown pgType: " + t + " (column " + name + ")");
@@ -924,18 +972,59 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
   const bool var_scale = cp.dk == DK_NUMERIC && ((cp.arg >> 16) & 1u);
   if (var_scale) o += "\"doc\":\"Variable scaled decimal\",";
   if (cp.dk == DK_POINT) o += "\"doc\":\"Geometry (POINT)\",";
-  o += "\"field\":" + jstr(name);
-  if (var_scale) o += ",\"fields\":[{\"field\":\"scale\",\"optional\":false,\"type\":\"int32\"},{\"field\":\"value\",\"optional\":false,\"type\":\"bytes\"}]";
-  if (cp.dk == DK_POINT) o += ",\"fields\":[{\"field\":\"x\",\"optional\":false,\"type\":\"double\"},{\"field\":\"y\",\"optional\":false,\"type\":\"double\"},{\"field\":\"wkb\",\"optional\":true,\"type\":\"bytes\"},"
-                            "{\"field\":\"srid\",\"optional\":true,\"type\":\"int32\"}]";
-  if (!dname.empty()) o += ",\"name\":" + jstr(dname);
-  o += std::string(",\"optional\":") + ((cs.flags & TFGPU_COL_KEY) ? "false" : "true");
+  std::string sep = "";
+  if (!into_arr) { o += "\"field\":" + jstr(name); sep = ","; }
+  if (var_scale) o += sep + "\"fields\":[{\"field\":\"scale\",\"optional\":false,\"type\":\"int32\"},{\"field\":\"value\",\"optional\":false,\"type\":\"bytes\"}]";
+  if (var_scale) sep = ",";
+  if (cp.dk == DK_POINT) { o += sep + "\"fields\":[{\"field\":\"x\",\"optional\":false,\"type\":\"double\"},{\"field\":\"y\",\"optional\":false,\"type\":\"double\"},{\"field\":\"wkb\",\"optional\":true,\"type\":\"bytes\"},"
+                            "{\"field\":\"srid\",\"optional\":true,\"type\":\"int32\"}]"; sep = ","; }
+  if (!dname.empty()) { o += sep + "\"name\":" + jstr(dname); sep = ","; }
+  o += sep + "\"optional\":" + ((cs.flags & TFGPU_COL_KEY) ? "false" : "true");
   if (!var_scale && !extra.empty()) o += extra;
   o += ",\"type\":" + jstr(kafka);
   if (!dname.empty()) o += ",\"version\":1";
   o += "}";
   cp.descr = o;
   return cp;
+}
+
+// the list of strings under "pg:enum_all_values" in json.Marshal(ColSchema.Properties)
+static std::vector<std::string> enum_values(const char *props, bool *ok) {
+  std::vector<std::string> out; *ok = false;
+  const char *p = std::strstr(props, "\"pg:enum_all_values\"");
+  if (!p) return out;
+  p += std::strlen("\"pg:enum_all_values\"");
+  while (*p == ' ') p++;
+  if (*p != ':') return out;
+  p++; while (*p == ' ') p++;
+  if (*p != '[') return out;
+  p++;
+  for (;;) {
+    while (*p == ' ' || *p == ',') p++;
+    if (*p == ']') { *ok = true; return out; }
+    if (*p != '"') return out;
+    p++;
+    std::string v;
+    while (*p && *p != '"') {
+      if (*p != '\\') { v.push_back(*p++); continue; }
+      p++;
+      switch (*p) {
+        case 'n': v.push_back('\n'); break; case 't': v.push_back('\t'); break; case 'r': v.push_back('\r'); break; case 'b': v.push_back('\b'); break; case 'f': v.push_back('\f'); break;
+        case 'u': {
+          unsigned cp = 0; for (int k = 1; k <= 4; k++) { const char c = p[k]; if (!c) return out; cp = cp * 16 + (unsigned)(c >= '0' && c <= '9' ? c - '0' : (c | 32) - 'a' + 10); }
+          p += 4;
+          if (cp < 0x80) v.push_back((char)cp); else if (cp < 0x800) { v.push_back((char)(0xC0 | (cp >> 6))); v.push_back((char)(0x80 | (cp & 0x3F))); }
+          else { v.push_back((char)(0xE0 | (cp >> 12))); v.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); v.push_back((char)(0x80 | (cp & 0x3F))); }  // (surrogate pairs: not in enum labels we decode)
+          break;
+        }
+        default: if (!*p) return out; v.push_back(*p);
+      }
+      p++;
+    }
+    if (*p != '"') return out;
+    p++;
+    out.push_back(v);
+  }
 }
 
 // which Go dynamic types AddPg takes for the type: 0 ok, 1 the reference's "unknown type of value", 2 host
@@ -968,6 +1057,7 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_MY_TIMESTAMP: case DK_MY_DATETIME: return in({TFGPU_R_TIME}) ? 0 : 2;
     case DK_MY_TIME: case DK_MY_YEAR: return in({TFGPU_R_STRING}) ? 0 : 2;
     case DK_MY_DECIMAL: return 0;
+    case DK_ARR_INT: case DK_ARR_STRING: case DK_ARR_COPY: return in({TFGPU_R_JSON}) ? 0 : 2;
     case DK_YDB_UINT64: return in({TFGPU_R_UINT64}) ? 0 : 1;
     case DK_YDB_DATE: return in({TFGPU_R_TIME}) ? 0 : 1;
     default: return 2;
