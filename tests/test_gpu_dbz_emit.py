@@ -394,14 +394,18 @@ def device_resident(t):
     return (t in DEVICE_TYPES or t.startswith("pg:character") or t.startswith("pg:bit(") or t.startswith("pg:bit varying(") or t.startswith("pg:timestamp") or t.startswith("pg:time") or t.startswith("pg:interval") or E.is_pg_numeric(t))
 
 
-@pytest.mark.parametrize("name", ["insert", "update0", "update1", "update2", "delete"])
+@pytest.mark.parametrize("name", ["insert", "update0", "update1", "update2", "delete", "ri_update", "ri_delete"])
 def test_the_references_crud_fixtures_cut_to_the_device_columns(tf, name):
     """the fixtures the oracle is pinned on (test_dbz_emitter_oracle.py), cut to the device-resident columns, timestamps as UTC instants
     (what a Postgres source produces; the fixtures' +04:00 wall clocks are an artefact of their JSON round trip)"""
     from test_dbz_emitter_oracle import read
-    it = E.unmarshal_change_item(read(name))
+    if name.startswith("ri_"):   # REPLICA IDENTITY FULL: OldKeys hold every column (emitter_replica_identity__canon_change_item_*.txt)
+        with open(os.path.join(GOLD, "emitter_replica_identity__canon_change_item_%s.txt" % name[3:]), "rb") as f:
+            it = E.unmarshal_change_item(f.read())
+    else:
+        it = E.unmarshal_change_item(read(name))
     keep = [c for c in it.cols if device_resident(c.original_type)]
-    assert len(keep) == 59   # every column of the fixtures' table
+    assert len(keep) == len(it.cols) == (2 if name.startswith("ri_") else 59)   # every column of the fixtures' tables
     kn = {c.name for c in keep}
     table = [(c.name, c.dtype, c.key, c.original_type) for c in keep]
 
@@ -424,7 +428,9 @@ def test_the_references_crud_fixtures_cut_to_the_device_columns(tf, name):
         b.old_keys, b.old_present = ob.cols, np.array([True])
     got, want, rows = emit_both(tf, b, table, PARAMS, ([it.id], [it.lsn], [it.commit_time]))
     assert_same(got, want, rows)
-    assert len(want) == {"insert": 1, "update0": 1, "update1": 1, "update2": 3, "delete": 2}[name]
+    assert len(want) == {"insert": 1, "update0": 1, "update1": 1, "update2": 3, "delete": 2, "ri_update": 1, "ri_delete": 2}[name]
+    if name == "ri_update":
+        assert isinstance(json.loads(got.messages()[0][1])["payload"]["before"], dict)   # the old row, not null
 
 
 def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
