@@ -84,3 +84,14 @@ def test_json_kernels_stay_lean():
     assert len(copies) == 2
     lean = min(copies.values(), key=lambda v: v["vgpr"])
     assert lean["vgpr"] <= 80 and lean["scratch"] == 0, lean
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_debezium_emitter_resources():
+    t = kernel_table("tf_dbzemit.hip")
+    # the cell kernels carry every converter (40 cases): their sinks stay in registers — the only scratch is the converters' small digit / byte buffers
+    # (a 128-bit decimal's 17 bytes, a 40-digit text) — and the fill kernel, which writes most of the bytes, is a handful of registers per lane
+    assert find(t, "dbz_cell_len")["scratch"] <= 256 and find(t, "dbz_cell_write")["scratch"] <= 256
+    assert find(t, "dbz_cell_len")["vgpr"] <= 160 and find(t, "dbz_cell_write")["vgpr"] <= 160
+    assert find(t, "dbz_fill_const")["vgpr"] <= 32 and find(t, "dbz_fill_const")["scratch"] == 0
+    assert find(t, "dbz_event_layout")["scratch"] == 0 and find(t, "dbz_event_count")["scratch"] == 0 and find(t, "dbz_event_fill")["scratch"] == 0
