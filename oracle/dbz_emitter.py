@@ -390,8 +390,11 @@ def decimal_to_debezium(dec: bytes, type_wo_provider: str, params):
     raise EmitError("unknown DecimalHandlingMode: %s" % mode)
 
 
-_PG_TS = [(re.compile(rb"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)Z$"), None), (re.compile(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)Z$"), None),
-          (re.compile(rb"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)([+-])(\d\d):(\d\d)$"), "hm"), (re.compile(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)([+-])(\d\d)$"), "h")]
+# time.Parse takes a fractional second after the seconds field even when the layout has none (time/format.go: "stdSecond … followed by a fraction")
+_FR = rb"(?:[.,](\d+))?"
+_PG_TS = [(re.compile(rb"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)" + _FR + rb"Z$"), None), (re.compile(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)" + _FR + rb"Z$"), None),
+          (re.compile(rb"^(\d{4})-(\d\d)-(\d\d)T(\d\d):(\d\d):(\d\d)" + _FR + rb"([+-])(\d\d):(\d\d)$"), "hm"),
+          (re.compile(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)" + _FR + rb"([+-])(\d\d)$"), "h")]
 
 
 def days_from_civil(y, m, d):
@@ -428,12 +431,13 @@ def parse_pg_datetime_tz(s: bytes):
     y, mo, d, h, mi, sec = (int(m.group(i)) for i in range(1, 7))
     if not (1 <= mo <= 12 and 1 <= d <= 31 and h < 24 and mi < 60 and sec < 60):
         raise EmitError("time.Parse: %r out of range" % s)
+    ns = int((m.group(7) or b"")[:9].ljust(9, b"0") or 0)
     off = 0
     if zone:
-        off = int(m.group(8)) * 3600 + (int(m.group(9)) * 60 if zone == "hm" else 0)
-        if m.group(7) == b"-":
+        off = int(m.group(9)) * 3600 + (int(m.group(10)) * 60 if zone == "hm" else 0)
+        if m.group(8) == b"-":
             off = -off
-    return days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + sec - off, 0, off
+    return days_from_civil(y, mo, d) * 86400 + h * 3600 + mi * 60 + sec - off, ns, off
 
 
 def _clock(sec):
