@@ -1030,7 +1030,7 @@ def add_mysql(col: Col, v, t: str, params):
         return ((sec & ((1 << 64) - 1)) * div + ns // (1000000000 // div)) & ((1 << 64) - 1)
     if u == "mysql:time":
         s_ = _need_string(v, t)
-        m = re.match(rb"^(\d\d):(\d\d):(\d\d)(?:\.(\d{1,6}))?$", s_)
+        m = re.match(rb"^(\d\d):(\d\d):(\d\d)(?:[.,](\d{1,6}))?$", s_)
         if not m or len(s_) == 9 or not (int(m.group(1)) < 24 and int(m.group(2)) < 60 and int(m.group(3)) < 60):
             raise EmitError("unable to parse time %r" % s_)
         return (int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))) * 1000000 + int((m.group(4) or b"").ljust(6, b"0") or 0)

@@ -223,12 +223,12 @@ template <class S> struct BodySink {
 template <class S> __device__ __forceinline__ void json_body(S &s, const uint8_t *p, uint32_t n) { BodySink<S> b{s}; emit_json_string(b, p, n, false); }
 __device__ __forceinline__ bool dg2(const uint8_t *p, uint32_t &v) { if (p[0] < '0' || p[0] > '9' || p[1] < '0' || p[1] > '9') return false; v = (p[0] - '0') * 10u + (p[1] - '0'); return true; }
 // "HH:MM:SS[.f{1,6}]" → microseconds of the day, *end = where the clock text stops; false = not this shape
-__device__ __forceinline__ bool clock_micros(const uint8_t *t, uint32_t n, int64_t *us, uint32_t *end) {
+__device__ __forceinline__ bool clock_micros(const uint8_t *t, uint32_t n, int64_t *us, uint32_t *end, bool comma_ok = false) {
   uint32_t h, m, sec;
   if (n < 8 || !dg2(t, h) || t[2] != ':' || !dg2(t + 3, m) || t[5] != ':' || !dg2(t + 6, sec)) return false;
   int64_t v = ((int64_t)h * 3600 + m * 60 + sec) * 1000000;
   uint32_t i = 8;
-  if (i < n && t[i] == '.') {
+  if (i < n && (t[i] == '.' || (comma_ok && t[i] == ','))) {  // (time.Parse takes a comma for the period of a fractional second; pgtype's strconv-based readers do not)
     uint32_t k = 0, f = 0; i++;
     while (i < n && t[i] >= '0' && t[i] <= '9' && k < 6) { f = f * 10 + (t[i] - '0'); i++; k++; }
     if (k == 0) return false;
@@ -552,7 +552,7 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
     case DK_MY_TIME: {  // ParseTimeWithoutTZ: the layout is chosen by the text's length (helpers.go:729-757)
       int64_t us; uint32_t end; uint32_t h, m, sec;
       if (vn != 8 && (vn < 10 || vn > 15)) return 1;
-      if (!clock_micros(vp, vn, &us, &end) || end != vn) return 1;
+      if (!clock_micros(vp, vn, &us, &end, true) || end != vn) return 1;
       dg2(vp, h); dg2(vp + 3, m); dg2(vp + 6, sec);
       if (h > 23 || m > 59 || sec > 59) return 1;  // time.Parse: out of range
       emit_u64(s, (uint64_t)us); return 0;
