@@ -697,7 +697,15 @@ def add_pg(col: Col, v, original_type: str, into_arr: bool, params):
             a = decode_any(_b(x))
             if isinstance(a, dict):
                 return gomarshal(a)
-        raise NotRestated("hstore given %s" % g)
+            raise EmitError("unknown type of value for pg:USER-DEFINED:hstore")
+        if g == "string":   # HstoreToJSON (providers/postgres/hstore.go:27-43)
+            s_ = _b(x)
+            if s_ == b"":
+                return b"{}"
+            if s_[:1] == b"{":
+                return s_
+            raise NotRestated("HstoreToMap (pgtype's hstore reader)")
+        raise EmitError("unknown type of value for pg:USER-DEFINED:hstore: %s" % g)
     if is_time_tz(t):
         if g != "string":
             raise EmitError("pg - unable to process %s: expected string, got %s" % (t, g))

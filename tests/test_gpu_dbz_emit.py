@@ -35,7 +35,7 @@ TABLE = [("id", "int32", True, "pg:integer"), ("bl", "boolean", False, "pg:boole
          ("A_first", "int64", False, "pg:bigint"), ("tm3", "utf8", False, "pg:time(3) without time zone"), ("tm", "utf8", False, "pg:time without time zone"),
          ("ttz", "utf8", False, "pg:time with time zone"), ("ttz1", "utf8", False, "pg:time(1) with time zone"), ("mo", "utf8", False, "pg:money"), ("xm", "any", False, "pg:xml"),
          ("pt", "any", False, "pg:point"), ("tsr", "any", False, "pg:tsrange"), ("nr", "any", False, "pg:numrange"), ("tzr", "any", False, "pg:tstzrange"),
-         ("hs", "any", False, "pg:USER-DEFINED:hstore"), ("iv", "utf8", False, "pg:interval"), ("iv2", "utf8", False, "pg:interval day to second")]
+         ("hs", "any", False, "pg:USER-DEFINED:hstore"), ("hst", "any", False, "pg:USER-DEFINED:hstore"), ("iv", "utf8", False, "pg:interval"), ("iv2", "utf8", False, "pg:interval day to second")]
 
 
 def schema_of(table):
@@ -80,7 +80,7 @@ def random_rows(n, seed):
                ["string", pick(["[19e-1,191e-2)", "[1.9,1.91)", "(1,2]", "[-1.5e3,1e-2)", "[.123e3,1.277559e+7]", "(0e5,-0.0)"])],
                ["string", pick(['[2010-01-01 01:00:00-05,2010-01-01 02:00:00-08)', '["2010-01-01 09:00:00+03","2010-01-01 13:00:00+03")', "[2010-01-01 06:00:00Z,2010-01-01 10:00:00Z)",
                                 "(2020-02-29 23:59:59.123+05:30,2021-01-01 00:00:00+00]"])],
-               ["json", pick(['{"a":"1","b":"2"}', '{}', '{"k":null}'])],
+               ["json", pick(['{"a":"1","b":"2"}', '{}', '{"k":null}'])], ["string", pick(["", '{"already": "json"}', "{"])],
                ["string", pick(["1 day 01:00:00.000000", "1 month", "1 year", "40 years", "14 mon 3 day 04:05:06.000007", "1 year 2 mons 3 days 04:05:06.00007", "-1 days +02:03:00",
                                 "1 mon -2 days", "-00:00:01", "-00:00:00.5", "00:00:00", "3 fortnights 01:02:03", "2 months 5 days", "25:61:61.1234567", "1 day"])],
                ["string", pick(["3 days 04:05:06", "04:05:06.5", "-3 days -04:05:06.123456"])]]

@@ -40,7 +40,7 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_ARR_INT, DK_ARR_STRING, DK_ARR_COPY, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_ARR_INT, DK_ARR_STRING, DK_ARR_COPY, DK_HSTORE, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
@@ -595,6 +595,11 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
       }
       s.put(']'); return 0;
     }
+    case DK_HSTORE:  // a map marshals as pg:json does; text goes through HstoreToJSON (providers/postgres/hstore.go:27-43): "" is {}, a text that opens with '{' is taken as JSON already
+      if (c.repr == TFGPU_R_JSON) { emit_json_string(s, vp, vn, false); return 0; }
+      if (vn == 0) { put_lit(s, "\"{}\""); return 0; }
+      if (vp[0] != '{') return 2;  // HstoreToMap: pgtype's hstore reader
+      emit_json_string(s, vp, vn, false); return 0;
     case DK_WRONG_TYPE: return 1;
     default: return 2;
   }
@@ -910,7 +915,7 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
   int prec = 0, scale = 0, d;
   if (found) {}
   else if (t == "pg:xml") { kafka = "string"; dname = "io.debezium.data.Xml"; cp.dk = DK_XML; }
-  else if (t == "pg:USER-DEFINED:hstore") { kafka = "string"; dname = "io.debezium.data.Json"; cp.dk = DK_JSON; cp.arg = 1; }  // a map marshals as pg:json does; hstore TEXT is HstoreToJSON's (host)
+  else if (t == "pg:USER-DEFINED:hstore") { kafka = "string"; dname = "io.debezium.data.Json"; cp.dk = DK_HSTORE; }
   else if (t == "pg:numrange") { kafka = "string"; cp.dk = DK_NUMRANGE; }
   else if (t == "pg:tsrange") { kafka = "string"; cp.dk = DK_TSRANGE; }
   else if (t == "pg:tstzrange") { kafka = "string"; cp.dk = DK_TSTZRANGE; }
@@ -1043,7 +1048,8 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_DATE: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
     case DK_TS: return in({TFGPU_R_TIME}) ? 0 : 2;
     case DK_TSTZ: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
-    case DK_JSON: return in({TFGPU_R_JSON}) || (in({TFGPU_R_STRING}) && !arg) ? 0 : 2;
+    case DK_JSON: return in({TFGPU_R_JSON, TFGPU_R_STRING}) ? 0 : 2;
+    case DK_HSTORE: return in({TFGPU_R_JSON, TFGPU_R_STRING}) ? 0 : 1;
     case DK_TIME: case DK_TIMETZ: case DK_MONEY: case DK_XML: case DK_POINT: case DK_TSRANGE: case DK_NUMRANGE: case DK_TSTZRANGE: case DK_INTERVAL: return in({TFGPU_R_STRING}) ? 0 : 2;
     case DK_WRONG_TYPE: return 0;
     case DK_NUMERIC: case DK_NUMERIC_TEXT: return in({TFGPU_R_STRING}) ? 0 : ((arg >> 17) & 1u) ? 2 : in({TFGPU_R_JSONNUM}) ? 0 : 1;  // ydb:Decimal asserts a string
