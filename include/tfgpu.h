@@ -855,8 +855,8 @@ int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b
  * numeric[(p,s)] up to 38 digits, money, bit(n) / bit varying(n), point, interval, tsrange, numrange and tstzrange in their plain
  * two-bound forms; and the ydb: types (pkg/debezium/ydb/emitter.go:123-232) with dt.source.type = "ydb" (source.txId = the row meta's
  * TxID, source.step = CommitTime) and the mysql: types (pkg/debezium/mysql/emitter.go:168-388) with dt.source.type = "mysql" (source.db =
- * the schema, file / pos from the LSN, gtid = TxID).  Postgres enums (Properties[pg:enum_all_values]) and arrays of
- * the integer / text / boolean families.  Anything else — arrays of other element types, binaries / bits given as base64 text, hstore / range / time texts only pgtype's parsers decide,
+ * the schema, file / pos from the LSN, gtid = TxID).  Postgres enums (Properties[pg:enum_all_values]) and arrays
+ * (every element type but `timestamp without time zone`).  Anything else — arrays of arrays, binaries / bits given as base64 text, hstore / range / time texts only pgtype's parsers decide,
  * the schema-registry packers, a value of a Go type the device does not convert — is refused BY NAME
  * with TFGPU_ERR_UNSUPPORTED and travels through the stock emitter; where the reference itself returns an error (an unknown
  * type under policy "fail", a json.Number that is no integer, "unknown type of value") the call fails with TFGPU_ERR_INVALID.  */

@@ -40,7 +40,7 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_ARR_INT, DK_ARR_STRING, DK_ARR_COPY, DK_HSTORE, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_ARR_INT, DK_ARR_STRING, DK_ARR_COPY, DK_HSTORE, DK_ARR_ELEM, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
@@ -55,6 +55,7 @@ struct ECell {
   uint32_t kind, apply, dk;
   uint32_t arg;               // DK_TS: divider; DK_NUMERIC: schema scale | put-scale << 16
   uint32_t from_old;          // the column is an OldKeys column: nil in rows without OldKeys
+  uint32_t edk;               // DK_ARR_ELEM: the converter of one element
   DCol alt; uint32_t dk_alt, has_alt;  // … unless the row's own value stands in (a MySQL delete's `before`: ColumnValues under the OldKeys)
 };
 struct EParams {
@@ -311,8 +312,39 @@ __device__ __forceinline__ bool pg_tstz_seconds(const uint8_t *t, uint32_t n, in
   return true;
 }
 
+// ParsePgDateTimeWithTimezone (typeutil/helpers.go:446-467): the layout is picked by in[10] and the last byte — "2006-01-02T15:04:05Z", "2006-01-02 15:04:05Z",
+// "2006-01-02T15:04:05-07:00", "2006-01-02 15:04:05-07" — and time.Parse takes a fractional second after the seconds.  0 ok, 1 the reference fails, 2 host
+__device__ __forceinline__ int pg_datetime_tz(const uint8_t *t, uint32_t n, int64_t *sec, int32_t *nsec) {
+  if (n < 11) return 2;  // in[10] panics
+  const bool tee = t[10] == 'T', zed = t[n - 1] == 'Z';
+  for (int k = 0; k < 4; k++) if (t[k] < '0' || t[k] > '9') return 1;
+  uint32_t mo, d, h, m, sc;
+  if (n < 19 || t[4] != '-' || !dg2(t + 5, mo) || t[7] != '-' || !dg2(t + 8, d) || t[10] != (tee ? 'T' : ' ') || !dg2(t + 11, h) || t[13] != ':' || !dg2(t + 14, m) || t[16] != ':' || !dg2(t + 17, sc)) return 1;
+  uint32_t i = 19; int32_t ns = 0;
+  if (i < n && (t[i] == '.' || t[i] == ',') && i + 1 < n && t[i + 1] >= '0' && t[i + 1] <= '9') {
+    uint32_t k = 0; i++;
+    while (i < n && t[i] >= '0' && t[i] <= '9') { if (k < 9) { ns = ns * 10 + (int32_t)(t[i] - '0'); k++; } i++; }
+    for (; k < 9; k++) ns *= 10;
+  }
+  int32_t off = 0;
+  if (zed) { if (i + 1 != n) return 1; }
+  else {
+    if (i >= n || (t[i] != '+' && t[i] != '-')) return 1;
+    const bool neg = t[i] == '-'; uint32_t zh, zm = 0; i++;
+    if (i + 2 > n || !dg2(t + i, zh)) return 1; i += 2;
+    if (tee) { if (i + 3 != n || t[i] != ':' || !dg2(t + i + 1, zm)) return 1; }
+    else if (i != n) return 1;
+    if (zh > 23 || zm > 59) return 1;
+    off = (int32_t)(zh * 3600 + zm * 60); if (neg) off = -off;
+  }
+  const int64_t y = (t[0] - '0') * 1000 + (t[1] - '0') * 100 + (t[2] - '0') * 10 + (t[3] - '0');
+  if (mo < 1 || mo > 12 || d < 1 || d > (uint32_t)dev::days_in_month((int)mo, y) || h > 23 || m > 59 || sc > 59) return 1;
+  *sec = dev::days_from_civil(y, (int)mo, (int)d) * 86400 + (int64_t)h * 3600 + m * 60 + sc - off; *nsec = ns;
+  return 0;
+}
+
 // AddPg for one non-nil value: 0 ok, 1 the reference returns an error, 2 left to the host
-template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell &ec, const DCol &c, uint32_t dk, const CellBits &b) {
+template <class S> __device__ int emit_scalar(S &s, const EParams &p, const ECell &ec, const DCol &c, uint32_t dk, const CellBits &b) {
   uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
   switch (dk) {
     case DK_BOOL: put_lit(s, (uint8_t)b.v ? "true" : "false"); return 0;
@@ -347,9 +379,17 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
       if (c.repr == TFGPU_R_BYTES) { s.put('"'); emit_base64(s, vp, vn); s.put('"'); }
       else emit_json_string(s, vp, vn, false);
       return 0;
-    case DK_DATE: emit_i64(s, trunc_div((int64_t)b.v, 86400)); return 0;
+    case DK_DATE: {
+      int64_t sec = (int64_t)b.v; int32_t ns;
+      if (c.repr == TFGPU_R_STRING) { const int rc = pg_datetime_tz(vp, vn, &sec, &ns); if (rc) return rc; }  // "restored snapshot": ParsePgDateTimeWithTimezone
+      emit_i64(s, trunc_div(sec, 86400)); return 0;
+    }
     case DK_TS: emit_i64(s, trunc_div((int64_t)b.v * 1000000 + b.ns / 1000, (int64_t)ec.arg)); return 0;
-    case DK_TSTZ: s.put('"'); emit_rfc3339nano(s, (int64_t)b.v, b.ns); s.put('"'); return 0;  // SprintfDebeziumTime (helpers.go:1105-1114)
+    case DK_TSTZ: {  // SprintfDebeziumTime (helpers.go:1105-1114)
+      int64_t sec = (int64_t)b.v; int32_t ns = b.ns;
+      if (c.repr == TFGPU_R_STRING) { const int rc = pg_datetime_tz(vp, vn, &sec, &ns); if (rc) return rc; }
+      s.put('"'); emit_rfc3339nano(s, sec, ns); s.put('"'); return 0;
+    }
     case DK_JSON:
       if (c.repr == TFGPU_R_JSON) { emit_json_string(s, vp, vn, false); return 0; }  // the column holds json.Marshal's text: marshalling it again is the identity
       { s.put('"'); JsonEscSink<S> q{s}; emit_json_string(q, vp, vn, false); s.put('"'); }  // a Go string: its marshal, as a string
@@ -373,14 +413,15 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
     case DK_TIME: {  // pgtype.Time.Scan(string) → Microseconds / divider (pg/emitter.go:541-561)
       int64_t us; uint32_t end;
       if (!clock_micros(vp, vn, &us, &end) || end != vn) return 2;
-      emit_i64(s, trunc_div(us, (int64_t)ec.arg)); return 0;
+      { int64_t r = trunc_div(us, (int64_t)(ec.arg & 0xFFFFu)); if (ec.arg >> 16) r -= r % 1000; emit_i64(s, r); }  // into an array: divider 1, milliseconds' accuracy
+      return 0;
     }
     case DK_TIMETZ: {  // TimeWithTimeZoneToTime(val).UTC().Format("15:04:05.999999Z") (pg/emitter.go:524-540)
       int64_t us; uint32_t end; int32_t off;
       if (!clock_micros(vp, vn, &us, &end) || end >= vn || vp[end] == 'Z' || !zone_seconds(vp, end, vn, &off)) return 2;
       int64_t sod = (us / 1000000 - off) % 86400; if (sod < 0) sod += 86400;
       s.put('"'); emit_clock(s, sod);
-      uint32_t f = (uint32_t)(us % 1000000);
+      uint32_t f = ec.arg ? 0u : (uint32_t)(us % 1000000);  // into an array: "15:04:05Z"
       if (f) { uint8_t d[6]; for (int k = 5; k >= 0; k--) { d[k] = (uint8_t)('0' + f % 10); f /= 10; } int last = 5; while (d[last] == '0') last--; s.put('.'); for (int k = 0; k <= last; k++) s.put(d[k]); }
       s.put('Z'); s.put('"'); return 0;
     }
@@ -605,6 +646,61 @@ template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell
   }
 }
 
+// which Go types AddPg takes for an ARRAY ELEMENT (a json.Number, a string, a bool, a nested value): 0 ok, 1 the reference's error, 2 host
+__device__ __forceinline__ int elem_ok(uint32_t dk, int repr) {
+  const bool str = repr == TFGPU_R_STRING, num = repr == TFGPU_R_JSONNUM;
+  switch (dk) {
+    case DK_SMALLINT: case DK_INTEGER: case DK_BIGINT: case DK_OID: case DK_REAL: case DK_DOUBLE: return num ? 0 : 1;
+    case DK_NUMERIC: case DK_NUMERIC_TEXT: return (str || num) ? 0 : (repr == TFGPU_R_JSON ? 2 : 1);  // (a map {Int, Exp}: host)
+    case DK_BYTEA: return str ? 0 : 1;
+    case DK_DATE: case DK_TSTZ: return str ? 0 : 1;
+    case DK_JSON: return 0;
+    case DK_BIT1: return 0;
+    case DK_INET: case DK_TIME: case DK_TIMETZ: case DK_MONEY: case DK_XML: case DK_POINT: case DK_TSRANGE: case DK_NUMRANGE: case DK_TSTZRANGE: case DK_INTERVAL: case DK_BITS: case DK_HSTORE: return str ? 0 : 2;
+    default: return 2;
+  }
+}
+template <class S> __device__ int emit_value(S &s, const EParams &p, const ECell &ec, const DCol &c, uint32_t dk, const CellBits &b) {
+  if (dk != DK_ARR_ELEM) return emit_scalar(s, p, ec, c, dk, b);
+  // add (emitter_value_converter.go:139-168): every element of the []interface{} through AddPg(intoArr = true); the column holds json.Marshal's text of the slice
+  uint32_t vn; const uint8_t *vp = cell_text(c, b, vn);
+  if (vn == 4 && vp[0] == 'n' && vp[1] == 'u' && vp[2] == 'l' && vp[3] == 'l') { put_lit(s, "null"); return 0; }
+  if (vn < 2 || vp[0] != '[' || vp[vn - 1] != ']') return 2;
+  const uint32_t base = (uint32_t)b.v;  // the cell's first byte inside the column's data
+  s.put('[');
+  uint32_t i = 1; bool first = true;
+  while (i < vn - 1) {
+    if (!first) { if (vp[i] != ',') return 2; i++; s.put(','); }
+    first = false;
+    const uint32_t c0 = vp[i];
+    uint32_t e = i; int repr;
+    if (c0 == '"') { e = i + 1; bool esc = false; while (e < vn - 1 && vp[e] != '"') { if (vp[e] == '\\') { esc = true; e++; } e++; } if (e >= vn - 1) return 2; e++; repr = TFGPU_R_STRING; if (esc && ec.edk != DK_JSON) return 2; }
+    else if (c0 == '[' || c0 == '{') {  // a nested value: skipped as a whole (strings inside may hold brackets)
+      int depth = 0; bool in = false;
+      for (; e < vn - 1; e++) { const uint32_t ch = vp[e]; if (in) { if (ch == '\\') e++; else if (ch == '"') in = false; continue; } if (ch == '"') in = true; else if (ch == '[' || ch == '{') depth++; else if (ch == ']' || ch == '}') { if (--depth == 0) { e++; break; } } }
+      repr = TFGPU_R_JSON;
+    } else { while (e < vn - 1 && vp[e] != ',') e++; repr = (c0 == 't' || c0 == 'f') ? TFGPU_R_BOOL : c0 == 'n' ? 0 : TFGPU_R_JSONNUM; }
+    if (repr == 0) { if (e - i != 4) return 2; put_lit(s, "null"); i = e; continue; }
+    DCol ce = c; ce.repr = repr; ce.validity = nullptr;
+    CellBits be; be.ns = 0; be.valid = true;
+    int rc;
+    if (ec.edk == DK_JSON) { be.v = (uint64_t)(base + i) | ((uint64_t)(base + e) << 32); ce.repr = TFGPU_R_JSON; rc = emit_scalar(s, p, ec, ce, DK_JSON, be); }  // JSONMarshalUnescape of the element, as a string
+    else {
+      rc = elem_ok(ec.edk, repr);
+      if (rc) return rc;
+      if (repr == TFGPU_R_STRING) be.v = (uint64_t)(base + i + 1) | ((uint64_t)(base + e - 1) << 32);  // between the quotes: no escapes in there (checked)
+      else if (repr == TFGPU_R_BOOL) { be.v = c0 == 't'; ce.offsets = nullptr; }
+      else be.v = (uint64_t)(base + i) | ((uint64_t)(base + e) << 32);
+      if (ec.edk == DK_BIT1 && repr != TFGPU_R_STRING) { put_lit(s, "false"); rc = 0; }  // colVal == "1" is false for any other Go type
+      else rc = emit_scalar(s, p, ec, ce, ec.edk, be);
+    }
+    if (rc) return rc;
+    i = e;
+  }
+  s.put(']');
+  return 0;
+}
+
 template <class S> __device__ __forceinline__ void emit_tail(S &s, const EParams &p, int64_t e, int64_t r) {
   const int64_t k = p.src_row ? p.src_row[r] : r;
   const uint64_t commit = p.m_commit ? p.m_commit[k] : 0ull;
@@ -798,7 +894,7 @@ struct Params {
   std::map<std::string, std::string> m;
   const std::string &get(const char *k) const { static const std::string empty; auto it = m.find(k); return it == m.end() ? empty : it->second; }
 };
-struct ColPlan { uint32_t dk = 0, arg = 0; std::string descr; };  // the converter and the column's field description
+struct ColPlan { uint32_t dk = 0, arg = 0, edk = 0; std::string descr; };  // the converter and the column's field description
 
 [[noreturn]] static void unsupported(const std::string &col, const std::string &what) {
   throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: column " + col + ": " + what + " stays with the stock emitter");
@@ -814,7 +910,8 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
     if (el.dk == DK_SMALLINT || el.dk == DK_INTEGER || el.dk == DK_BIGINT) cp.dk = DK_ARR_INT;
     else if (el.dk == DK_STRING) cp.dk = DK_ARR_STRING;
     else if (el.dk == DK_BOOL) cp.dk = DK_ARR_COPY;
-    else unsupported(name, "an array of " + et);
+    else if (el.dk == DK_TS || el.dk == DK_WRONG_TYPE || el.dk >= DK_MARSHAL) unsupported(name, "an array of " + et);  // timestamp texts are pgtype.Timestamp.Set's
+    else { cp.dk = DK_ARR_ELEM; cp.edk = el.dk; cp.arg = el.arg; }
     std::string o = "{";
     if (P.get("dt.add.original.type.info") == "true") o += "\"__dt_original_type_info\":{\"original_type\":" + jstr(t) + "},";
     o += "\"field\":" + jstr(name) + ",\"items\":" + el.descr + ",\"optional\":" + ((cs.flags & TFGPU_COL_KEY) ? "false" : "true") + ",\"type\":\"array\"}";
@@ -931,10 +1028,10 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
     kafka = "int64"; dname = "io.debezium.time.MicroDuration";
     cp.dk = P.get("interval.handling.mode") == "numeric" ? DK_INTERVAL : DK_WRONG_TYPE;  // "unsupported interval.handling.mode" fails the first non-nil value
   }
-  else if ((d = time_family(t, "time", "with")) != -2) { kafka = "string"; dname = "io.debezium.time.ZonedTime"; cp.dk = DK_TIMETZ; }
+  else if ((d = time_family(t, "time", "with")) != -2) { kafka = "string"; dname = "io.debezium.time.ZonedTime"; cp.dk = DK_TIMETZ; cp.arg = into_arr ? 1u : 0u; }
   else if ((d = time_family(t, "time", "without")) != -2) {
-    const uint32_t divider = (d >= 1 && d <= 3) ? 1000u : 1u;  // GetTimeDivider (helpers.go:106-123)
-    kafka = divider == 1 ? "int64" : "int32"; dname = divider == 1 ? "io.debezium.time.MicroTime" : "io.debezium.time.Time"; cp.dk = DK_TIME; cp.arg = divider;
+    const uint32_t divider = (!into_arr && d >= 1 && d <= 3) ? 1000u : 1u;  // GetTimeDivider (helpers.go:106-123); 1 into an array
+    kafka = divider == 1 ? "int64" : "int32"; dname = divider == 1 ? "io.debezium.time.MicroTime" : "io.debezium.time.Time"; cp.dk = DK_TIME; cp.arg = divider | (into_arr ? 1u << 16 : 0u);
   }
   else if (starts(t, "pg:bit(") || starts(t, "pg:bit varying(")) {
     const size_t a = starts(t, "pg:bit(") ? 7 : 15, z = t.find(')', a);
@@ -1045,9 +1142,9 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_REAL: return in({TFGPU_R_FLOAT32, TFGPU_R_FLOAT64, TFGPU_R_JSONNUM}) ? 0 : 1;
     case DK_DOUBLE: return in({TFGPU_R_FLOAT64, TFGPU_R_JSONNUM}) ? 0 : 1;
     case DK_BYTEA: return in({TFGPU_R_STRING, TFGPU_R_BYTES}) ? 0 : 1;
-    case DK_DATE: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
+    case DK_DATE: return in({TFGPU_R_TIME, TFGPU_R_STRING}) ? 0 : 1;
     case DK_TS: return in({TFGPU_R_TIME}) ? 0 : 2;
-    case DK_TSTZ: return in({TFGPU_R_TIME}) ? 0 : in({TFGPU_R_STRING}) ? 2 : 1;
+    case DK_TSTZ: return in({TFGPU_R_TIME, TFGPU_R_STRING}) ? 0 : 1;
     case DK_JSON: return in({TFGPU_R_JSON, TFGPU_R_STRING}) ? 0 : 2;
     case DK_HSTORE: return in({TFGPU_R_JSON, TFGPU_R_STRING}) ? 0 : 1;
     case DK_TIME: case DK_TIMETZ: case DK_MONEY: case DK_XML: case DK_POINT: case DK_TSRANGE: case DK_NUMRANGE: case DK_TSTZRANGE: case DK_INTERVAL: return in({TFGPU_R_STRING}) ? 0 : 2;
@@ -1063,7 +1160,7 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_MY_TIMESTAMP: case DK_MY_DATETIME: return in({TFGPU_R_TIME}) ? 0 : 2;
     case DK_MY_TIME: case DK_MY_YEAR: return in({TFGPU_R_STRING}) ? 0 : 2;
     case DK_MY_DECIMAL: return 0;
-    case DK_ARR_INT: case DK_ARR_STRING: case DK_ARR_COPY: return in({TFGPU_R_JSON}) ? 0 : 2;
+    case DK_ARR_INT: case DK_ARR_STRING: case DK_ARR_COPY: case DK_ARR_ELEM: return in({TFGPU_R_JSON}) ? 0 : 2;
     case DK_YDB_UINT64: return in({TFGPU_R_UINT64}) ? 0 : 1;
     case DK_YDB_DATE: return in({TFGPU_R_TIME}) ? 0 : 1;
     default: return 2;
@@ -1087,7 +1184,7 @@ struct CellList {
     // switches do: a column of nils has no type to object to
     const int rk = repr_ok(cp.dk, col.repr, cp.arg);
     ECell c{}; c.kind = EC_VALUE; c.apply = apply; c.pre_off = (uint32_t)blob->size(); c.pre_len = (uint32_t)prefix.size();
-    *blob += prefix; c.c = dcol_of(col); c.dk = rk ? (uint32_t)(DK_WRONG_TYPE + rk - 1) : cp.dk; c.arg = cp.arg; c.from_old = from_old ? 1u : 0u;
+    *blob += prefix; c.c = dcol_of(col); c.dk = rk ? (uint32_t)(DK_WRONG_TYPE + rk - 1) : cp.dk; c.arg = cp.arg; c.edk = cp.edk; c.from_old = from_old ? 1u : 0u;
     if (alt) { const int ra = repr_ok(cp.dk, alt->repr, cp.arg); c.alt = dcol_of(*alt); c.dk_alt = ra ? (uint32_t)(DK_WRONG_TYPE + ra - 1) : cp.dk; c.has_alt = 1; }
     cells.push_back(c);
   }
