@@ -946,7 +946,13 @@ class Configs4Workload(Base):
             tiny = lib.debezium_emit(self.dopts, lib.DeviceBatch.upload(tb), abi.row_meta(64, ids=np.arange(64), lsns=np.arange(64, dtype=np.uint64), commit_times=np.full(64, 1, np.uint64)))
             k0, v0 = next((k, v) for k, v in tiny.messages() if v is not None)
             self.const_key, self.const_val = len(k0) - k0.index(b',"schema":'), len(v0) - v0.index(b',"schema":')   # the constant tails dbz_fill_const writes
-        self.meta = abi.row_meta(self.n, ids=np.arange(self.n) % 97, lsns=np.arange(self.n, dtype=np.uint64) + 5, commit_times=np.full(self.n, 1700000000000000000, np.uint64))
+        # ChangeItem.ID / LSN / CommitTime by input row: inputs like the columns, so resident in HBM when the timed region starts (tfgpu_row_meta.mem = DEVICE); until r05k the
+        # bench handed them over as pageable host arrays and their 20 MB upload sat inside every step (0.4 ms of it)
+        self.meta = abi.CRowMeta()
+        self._meta_keep = [lib.DeviceBuffer.upload(np.ascontiguousarray(a, dt).tobytes()) for a, dt in ((np.arange(self.n) % 97, np.uint32), (np.arange(self.n, dtype=np.uint64) + 5, np.uint64),
+                                                                                                      (np.full(self.n, 1700000000000000000, np.uint64), np.uint64))]
+        self.meta.id, self.meta.lsn, self.meta.commit_time = (b.ptr for b in self._meta_keep)
+        self.meta.n, self.meta.mem = self.n, abi.MEM_DEVICE
         if e.world > 1:
             import torch.distributed as dist
             from transferia_amd import partition

@@ -1205,22 +1205,32 @@ static void push_object(CellList &L, uint32_t apply, std::vector<Member> ms) {
 
 struct Stream { Buf out; std::vector<uint32_t> start; uint64_t total = 0; };
 
-static Stream run_stream(EParams p, const CellList &L, const std::string &blob, hipStream_t st, const char *what) {
+// One stream in two halves, so that the keys' and the values' kernels queue behind one another and the host waits twice per call, not four times:
+// measure = cell lengths + per-event layout (+ the read-back of the total and of the first failing cell), write = scan, cells, constants (+ the starts' read-back).
+struct StreamRun {
+  EParams p; const CellList *L; const std::string *blob; const char *what;
+  Buf dcells, dblob, cell, ev_len, acc, err;
+  uint64_t host[3];
   Stream S;
+};
+static void stream_measure(StreamRun &R, EParams p, const CellList &L, const std::string &blob, hipStream_t st, const char *what) {
   const int64_t nev = p.nev;
-  Buf dcells = upload_small(L.cells.data(), L.cells.size() * sizeof(ECell));
+  R.L = &L; R.blob = &blob; R.what = what;
+  R.dcells = upload_small(L.cells.data(), L.cells.size() * sizeof(ECell));
   std::string padded = blob; padded.append(16, '\0');  // the text readers load whole words
-  Buf dblob = upload_small(padded.data(), padded.size());
-  Buf cell = dalloc((size_t)L.cells.size() * nev * 4 + 16), ev_len = dalloc((size_t)(nev + 1) * 4 + 16), acc = dalloc_zero(8);
-  Buf err = dalloc(16);
-  TF_HIP(hipMemsetAsync(err->p, 0xFF, 16, st));
-  p.cells = ptr<ECell>(dcells); p.ncells = (int32_t)L.cells.size(); p.blob = ptr<uint8_t>(dblob);
-  p.cell = ptr<uint32_t>(cell); p.ev_len = ptr<uint32_t>(ev_len); p.total64 = ptr<unsigned long long>(acc); p.err = ptr<unsigned long long>(err);
+  R.dblob = upload_small(padded.data(), padded.size());
+  R.cell = dalloc((size_t)L.cells.size() * nev * 4 + 16); R.ev_len = dalloc((size_t)(nev + 1) * 4 + 16); R.acc = dalloc_zero(8);
+  R.err = dalloc(16);
+  TF_HIP(hipMemsetAsync(R.err->p, 0xFF, 16, st));
+  p.cells = ptr<ECell>(R.dcells); p.ncells = (int32_t)L.cells.size(); p.blob = ptr<uint8_t>(R.dblob);
+  p.cell = ptr<uint32_t>(R.cell); p.ev_len = ptr<uint32_t>(R.ev_len); p.total64 = ptr<unsigned long long>(R.acc); p.err = ptr<unsigned long long>(R.err);
+  R.p = p;
   { KernelTimer t("dbz_cell_len"); dbz_cell_len<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
   { KernelTimer t("dbz_event_layout"); dbz_event_layout<<<blocks(nev), 256, 0, st>>>(p); }
-  uint64_t host[3];
-  d2h(host, acc->p, 8); d2h(host + 1, err->p, 16);
-  sync();
+  d2h(R.host, R.acc->p, 8); d2h(R.host + 1, R.err->p, 16);
+}
+static void stream_check(StreamRun &R) {  // after the sync that follows stream_measure
+  const CellList &L = *R.L; const std::string &blob = *R.blob; const char *what = R.what; const uint64_t *host = R.host;
   if (host[1] != ~0ull || host[2] != ~0ull) {
     const bool invalid = host[1] != ~0ull && (host[2] == ~0ull || host[1] <= host[2]);
     const uint64_t key = invalid ? host[1] : host[2];
@@ -1235,11 +1245,14 @@ static Stream run_stream(EParams p, const CellList &L, const std::string &blob, 
     throw Error(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + what + " of event " + std::to_string(e) + ", column " + nm +
                 ": a value the device leaves to the stock emitter (a Go type it does not convert for this column, a numeric beyond 38 digits, a float text Go decides with big arithmetic)");
   }
-  S.total = host[0];
-  if (S.total > 0xFFFFFFF0ull) throw Error(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + what + "s of one call exceed 4 GiB (" + std::to_string(S.total) + " bytes): emit the batch in slices");
+  R.S.total = host[0];
+  if (R.S.total > 0xFFFFFFF0ull) throw Error(TFGPU_ERR_UNSUPPORTED, std::string("tfgpu_debezium_emit: ") + what + "s of one call exceed 4 GiB (" + std::to_string(R.S.total) + " bytes): emit the batch in slices");
+}
+static void stream_write(StreamRun &R, hipStream_t st) {
+  EParams &p = R.p; const CellList &L = *R.L; const int64_t nev = p.nev;
   exclusive_scan_u32(p.ev_len, p.ev_len, nev, true);
-  S.out = dalloc(S.total + 64);
-  p.out = ptr<uint8_t>(S.out);
+  R.S.out = dalloc(R.S.total + 64);
+  p.out = ptr<uint8_t>(R.S.out);
   { KernelTimer t("dbz_cell_write"); dbz_cell_write<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
   for (size_t ci = 0; ci < L.cells.size(); ci++) if (L.cells[ci].kind == EC_CONST && L.cells[ci].pre_len > CONST_INLINE) {
     const uint32_t pieces = (L.cells[ci].pre_len + FILL_PIECE - 1) / FILL_PIECE;
@@ -1248,10 +1261,8 @@ static Stream run_stream(EParams p, const CellList &L, const std::string &blob, 
     KernelTimer t("dbz_fill_const");
     dbz_fill_const<<<(unsigned)((items + 3) / 4), 256, 0, st>>>(p, (int32_t)ci, pieces);
   }
-  S.start.resize((size_t)nev + 1);
-  d2h(S.start.data(), p.ev_len, (size_t)(nev + 1) * 4);
-  sync();
-  return S;
+  R.S.start.resize((size_t)nev + 1);
+  d2h(R.S.start.data(), p.ev_len, (size_t)(nev + 1) * 4);
 }
 
 }  // namespace dbz
@@ -1477,15 +1488,22 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     if (V.cells.size() > 0xFFFF || K.cells.size() > 0xFFFF) return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: more than 65535 cells per message");
 
     lap("cells");
-    Stream SV = run_stream(p, V, blob, st, "value");
-    lap("values");
-    Stream SK;
-    if (!o->drop_keys) SK = run_stream(p, K, blob, st, "key");
-    else { SK.out = dalloc(64); SK.start.assign((size_t)nev + 1, 0u); }
-    lap("keys");
-    kres->mem = SK.out; kres->size = SK.total; vres->mem = SV.out; vres->size = SV.total;
+    StreamRun RV, RK;
+    stream_measure(RV, p, V, blob, st, "value");
+    if (!o->drop_keys) stream_measure(RK, p, K, blob, st, "key");
+    sync();
+    stream_check(RV);
+    if (!o->drop_keys) stream_check(RK);
+    lap("measure");
+    stream_write(RV, st);
+    if (!o->drop_keys) stream_write(RK, st);
     std::vector<int32_t> ev_row; std::vector<uint8_t> ev_type;
-    if (!identity) { ev_row.resize((size_t)nev); ev_type.resize((size_t)nev); d2h(ev_row.data(), d_ev_row->p, (size_t)nev * 4); d2h(ev_type.data(), d_ev_type->p, (size_t)nev); sync(); }
+    if (!identity) { ev_row.resize((size_t)nev); ev_type.resize((size_t)nev); d2h(ev_row.data(), d_ev_row->p, (size_t)nev * 4); d2h(ev_type.data(), d_ev_type->p, (size_t)nev); }
+    sync();
+    if (o->drop_keys) { RK.S.out = dalloc(64); RK.S.start.assign((size_t)nev + 1, 0u); }
+    Stream &SV = RV.S, &SK = RK.S;
+    lap("write");
+    kres->mem = SK.out; kres->size = SK.total; vres->mem = SV.out; vres->size = SV.total;
     for (int64_t e = 0; e <= nev; e++) { key_start[e] = SK.start[(size_t)e]; val_start[e] = SV.start[(size_t)e]; }
     for (int64_t e = 0; e < nev; e++) {
       val_null[e] = (!identity && ev_type[(size_t)e] == EV_TOMBSTONE) ? 1 : 0;
