@@ -992,7 +992,8 @@ class Configs4Workload(Base):
     def alg(self):
         s = self.state
         if self.debezium:   # dbz_fill_const writes the schema halves (their source is a few KB, cache-resident); the cell pass reads the columns and writes the payload halves
-            return {"dbz_fill_const": s["const_bytes"], "dbz_cell_write": s["in_bytes"] + s["out_bytes"] - s["const_bytes"], "compact_gather": 2 * s["in_bytes"], "sharder_crc32": 12 * self.n}
+            cells = s["in_bytes"] + s["out_bytes"] - s["const_bytes"]
+            return {"dbz_fill_const": s["const_bytes"], "dbz_walk_write": cells, "dbz_cell_write": cells, "compact_gather": 2 * s["in_bytes"], "sharder_crc32": 12 * self.n}
         return {"ser_cell_write": s["in_bytes"] + s["out_bytes"], "compact_gather": 2 * s["in_bytes"], "sharder_crc32": 12 * self.n}
 
     def config(self):

@@ -94,4 +94,5 @@ def test_debezium_emitter_resources():
     assert find(t, "dbz_cell_len")["scratch"] <= 256 and find(t, "dbz_cell_write")["scratch"] <= 256
     assert find(t, "dbz_cell_len")["vgpr"] <= 160 and find(t, "dbz_cell_write")["vgpr"] <= 160
     assert find(t, "dbz_fill_const")["vgpr"] <= 32 and find(t, "dbz_fill_const")["scratch"] == 0
+    assert find(t, "dbz_walk_len")["scratch"] <= 256 and find(t, "dbz_walk_write")["scratch"] <= 256 and find(t, "dbz_walk_write")["vgpr"] <= 160
     assert find(t, "dbz_event_layout")["scratch"] == 0 and find(t, "dbz_event_count")["scratch"] == 0 and find(t, "dbz_event_fill")["scratch"] == 0

@@ -11,8 +11,9 @@
 //
 // Here: the host renders S and a CELL LIST per stream (keys, values) — constants, converted column values (AddPg,
 // pkg/debezium/pg/emitter.go:262-629) and the op / source / ts_ms tail, each with the predicate of the events it belongs to —
-// and three kernels run it over the event list: cell lengths (grid y = cell, so descriptors are scalar), per-event layout,
-// cells written at their final place; constants longer than 64 bytes (S is kilobytes) are filled by a fourth, coalesced pass.
+// and the kernels run it over the event list: a length pass and a write pass in which one lane walks one event's cells (descriptors are
+// scalar: every lane is at the same cell), a scan between them; constants longer than 64 bytes (S is kilobytes) are filled by a
+// coalesced pass of their own.
 // HBM-bound byte work: the schema constant dominates the bytes of a message, as it does in the reference's output.
 //
 // Device-resident original types (everything else is refused BY NAME with TFGPU_ERR_UNSUPPORTED and stays with the stock
@@ -784,10 +785,49 @@ __global__ void __launch_bounds__(256) dbz_cell_write(EParams p) {
   emit_cell(w, p, ec, e, r);
   w.flush();
 }
+// The same two passes as ONE LANE PER EVENT walking its cells with one sink (the default; TFGPU_DBZ_WALK=0 keeps the cell-major kernels above for comparison): a message's
+// payload half is a few hundred bytes spread over ~20 cells, and a lane per (cell, event) writes each cell's few bytes at a time no other byte of the same cache lines is
+// written — the line is fetched, merged and written back once per cell.  A lane that walks its event writes the payload front to back; the cells are the same for every lane
+// (descriptors are scalar loads, the converter switch a scalar branch), only `applies` diverges.  The per-cell length array and the layout kernel are not needed: the length
+// pass keeps one running count, the write pass one running pointer, and the place of a long constant is noted for dbz_fill_const as the walk passes it.
+__global__ void __launch_bounds__(256) dbz_walk_len(EParams p) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.nev) return;
+  const int64_t r = p.ev_row ? p.ev_row[e] : e;
+  CountSink s;
+  for (int32_t ci = 0; ci < p.ncells; ci++) {
+    const ECell &ec = p.cells[ci];
+    if (!applies(p, ec.apply, e, r)) continue;
+    if (ec.kind == EC_CONST) { s.n += ec.pre_len; continue; }
+    const int rc = emit_cell(s, p, ec, e, r);
+    if (rc) atomicMin(&p.err[rc - 1], ((unsigned long long)e << 16) | (unsigned long long)ci);
+  }
+  p.ev_len[e] = s.n;
+  atomicAdd(p.total64, (unsigned long long)s.n);
+}
+__global__ void __launch_bounds__(256) dbz_walk_write(EParams p, uint32_t *const_at /* [long constants][nev] */) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.nev) return;
+  const int64_t r = p.ev_row ? p.ev_row[e] : e;
+  uint8_t *const base = p.out + (uint64_t)p.ev_len[e];
+  WriteSink w{base};
+  int32_t slot = 0;
+  for (int32_t ci = 0; ci < p.ncells; ci++) {
+    const ECell &ec = p.cells[ci];
+    const bool is_long = ec.kind == EC_CONST && ec.pre_len > CONST_INLINE;
+    if (applies(p, ec.apply, e, r)) {
+      if (is_long) { w.flush(); const_at[(int64_t)slot * p.nev + e] = (uint32_t)(w.p - base); w.p += ec.pre_len; }  // dbz_fill_const writes it
+      else emit_cell(w, p, ec, e, r);
+    }
+    if (is_long) slot++;
+  }
+  w.flush();
+}
+
 // a long constant (the schema half of a message) into every event that holds it: one WAVE per (event, 2 KiB piece) — a key's schema is a
 // few hundred bytes, a value's a few KiB, so a workgroup per event would leave most of its lanes without a byte to move
 constexpr uint32_t FILL_PIECE = 2048;
-__global__ void __launch_bounds__(256) dbz_fill_const(EParams p, int32_t ci, uint32_t pieces) {
+__global__ void __launch_bounds__(256) dbz_fill_const(EParams p, int32_t ci, uint32_t pieces, const uint32_t *at /* [nev]: where the constant sits inside its event */) {
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   const int64_t e = item / pieces; const uint32_t piece = (uint32_t)(item % pieces);
@@ -797,7 +837,7 @@ __global__ void __launch_bounds__(256) dbz_fill_const(EParams p, int32_t ci, uin
   // kernel's duration.  The schema halves belong to every event (keys) or to every event but the tombstones (values): one load, beside the offsets'
   if (ec.apply == EA_VALUE) { if (p.ev_type && p.ev_type[e] == EV_TOMBSTONE) return; }
   else if (ec.apply != EA_KEY) { const int64_t r = p.ev_row ? p.ev_row[e] : e; if (!applies(p, ec.apply, e, r)) return; }
-  uint8_t *dst = p.out + (uint64_t)p.ev_len[e] + p.cell[(int64_t)ci * p.nev + e];
+  uint8_t *dst = p.out + (uint64_t)p.ev_len[e] + at[e];
   const uint8_t *src = p.blob + ec.pre_off;
   const uint32_t a = piece * FILL_PIECE, b = min(a + FILL_PIECE, ec.pre_len);
   // the destination's alignment decides the split: bytes up to its next 16-byte boundary, 16-byte stores (one per lane and KiB), a byte tail;
@@ -1209,7 +1249,8 @@ struct Stream { Buf out; std::vector<uint32_t> start; uint64_t total = 0; };
 // measure = cell lengths + per-event layout (+ the read-back of the total and of the first failing cell), write = scan, cells, constants (+ the starts' read-back).
 struct StreamRun {
   EParams p; const CellList *L; const std::string *blob; const char *what;
-  Buf dcells, dblob, cell, ev_len, acc, err;
+  Buf dcells, dblob, cell, ev_len, acc, err, const_at;
+  bool walk = true;
   uint64_t host[3];
   Stream S;
 };
@@ -1219,14 +1260,20 @@ static void stream_measure(StreamRun &R, EParams p, const CellList &L, const std
   R.dcells = upload_small(L.cells.data(), L.cells.size() * sizeof(ECell));
   std::string padded = blob; padded.append(16, '\0');  // the text readers load whole words
   R.dblob = upload_small(padded.data(), padded.size());
-  R.cell = dalloc((size_t)L.cells.size() * nev * 4 + 16); R.ev_len = dalloc((size_t)(nev + 1) * 4 + 16); R.acc = dalloc_zero(8);
+  static const bool walk_default = [] { const char *e = std::getenv("TFGPU_DBZ_WALK"); return !(e && e[0] == '0'); }();  // A/B measurements
+  R.walk = walk_default;
+  if (!R.walk) R.cell = dalloc((size_t)L.cells.size() * nev * 4 + 16);
+  R.ev_len = dalloc((size_t)(nev + 1) * 4 + 16); R.acc = dalloc_zero(8);
   R.err = dalloc(16);
   TF_HIP(hipMemsetAsync(R.err->p, 0xFF, 16, st));
   p.cells = ptr<ECell>(R.dcells); p.ncells = (int32_t)L.cells.size(); p.blob = ptr<uint8_t>(R.dblob);
   p.cell = ptr<uint32_t>(R.cell); p.ev_len = ptr<uint32_t>(R.ev_len); p.total64 = ptr<unsigned long long>(R.acc); p.err = ptr<unsigned long long>(R.err);
   R.p = p;
-  { KernelTimer t("dbz_cell_len"); dbz_cell_len<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
-  { KernelTimer t("dbz_event_layout"); dbz_event_layout<<<blocks(nev), 256, 0, st>>>(p); }
+  if (R.walk) { KernelTimer t("dbz_walk_len"); dbz_walk_len<<<blocks(nev), 256, 0, st>>>(p); }
+  else {
+    { KernelTimer t("dbz_cell_len"); dbz_cell_len<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
+    { KernelTimer t("dbz_event_layout"); dbz_event_layout<<<blocks(nev), 256, 0, st>>>(p); }
+  }
   d2h(R.host, R.acc->p, 8); d2h(R.host + 1, R.err->p, 16);
 }
 static void stream_check(StreamRun &R) {  // after the sync that follows stream_measure
@@ -1253,13 +1300,21 @@ static void stream_write(StreamRun &R, hipStream_t st) {
   exclusive_scan_u32(p.ev_len, p.ev_len, nev, true);
   R.S.out = dalloc(R.S.total + 64);
   p.out = ptr<uint8_t>(R.S.out);
-  { KernelTimer t("dbz_cell_write"); dbz_cell_write<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
+  size_t nlong = 0;
+  for (auto &c : L.cells) if (c.kind == EC_CONST && c.pre_len > CONST_INLINE) nlong++;
+  if (R.walk) {
+    R.const_at = dalloc(std::max<size_t>(nlong, 1) * (size_t)nev * 4 + 16);
+    KernelTimer t("dbz_walk_write"); dbz_walk_write<<<blocks(nev), 256, 0, st>>>(p, ptr<uint32_t>(R.const_at));
+  } else { KernelTimer t("dbz_cell_write"); dbz_cell_write<<<dim3(blocks(nev), (unsigned)L.cells.size()), 256, 0, st>>>(p); }
+  size_t slot = 0;
   for (size_t ci = 0; ci < L.cells.size(); ci++) if (L.cells[ci].kind == EC_CONST && L.cells[ci].pre_len > CONST_INLINE) {
     const uint32_t pieces = (L.cells[ci].pre_len + FILL_PIECE - 1) / FILL_PIECE;
     const uint64_t items = (uint64_t)nev * pieces;
     if (items > 0x1FFFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: too many events for one call");
+    const uint32_t *at = R.walk ? ptr<uint32_t>(R.const_at) + slot * (size_t)nev : p.cell + ci * (size_t)nev;
     KernelTimer t("dbz_fill_const");
-    dbz_fill_const<<<(unsigned)((items + 3) / 4), 256, 0, st>>>(p, (int32_t)ci, pieces);
+    dbz_fill_const<<<(unsigned)((items + 3) / 4), 256, 0, st>>>(p, (int32_t)ci, pieces, at);
+    slot++;
   }
   R.S.start.resize((size_t)nev + 1);
   d2h(R.S.start.data(), p.ev_len, (size_t)(nev + 1) * 4);
