@@ -846,6 +846,8 @@ int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b
  * order, no HTML escaping; a schema-registry URL / YSR namespace selects packers that stay with the host (packer/factory.go:13-98).  `table_schema` is TableSchema.Columns() with OriginalType
  * and the PrimaryKey flags (the batch itself carries neither); columns of the schema missing from the batch are TOASTed
  * (unavailable.value.placeholder).  Row meta: id → source.txId, lsn → source.lsn, commit_time → both ts_ms (NULL = zeros).
+ * An `any` value (TFGPU_R_JSON) is taken as what the ABI says it is — json.Marshal's text of the Go value: compact, object members in key order, HTML bytes not
+ * escaped — so marshalling it again (pg:json, hstore maps, arrays) is the identity and the emitter copies it; a producer that keeps source text there must canonicalise it.
  * Parameters: the format settings map (parameters.go:140-215 fills the defaults): database.dbname, topic.prefix, dt.source.type
  * ("" | "pg" | "ydb" | "mysql"), decimal.handling.mode (precise | string), tombstones.on.delete, dt.add.original.type.info,
  * unavailable.value.placeholder, dt.unknown.types.policy.
