@@ -399,6 +399,63 @@ def test_pg_arrays_and_enums(tf):
         assert ei.value.code == code, (t, v, str(ei.value))
 
 
+def test_emit_then_receive_round_trip(tf):
+    """a size-independent property: what the emitter writes, the Debezium RECEIVER of this library (tf_debezium.hip, pinned to the reference's receiver canon on its own) reads back
+    as the same rows — kinds, values, OldKeys of updates and deletes, ID / LSN / CommitTime at Debezium's millisecond accuracy, table id, key flags — although the two halves
+    were built and pinned apart (the reference's emitter_chain tests make the same trip, pkg/debezium/pg/tests/emitter_chain_test.go)"""
+    from decimal import Decimal
+    from transferia_amd import debezium
+    table = [("id", "int32", True, "pg:integer"), ("big", "int64", False, "pg:bigint"), ("t", "utf8", False, "pg:text"), ("b", "boolean", False, "pg:boolean"), ("d", "double", False, "pg:double precision"),
+             ("si", "int16", False, "pg:smallint"), ("n", "double", False, "pg:numeric(10,2)")]
+    rng = np.random.default_rng(77)
+    n = 3000
+    rows, kinds = [], []
+    for r in range(n):
+        rows.append([["int32", r], ["int64", int(rng.integers(-2 ** 62, 2 ** 62))], ["string", TEXTS[int(rng.integers(0, len(TEXTS) - 1))] + str(r)], ["bool", bool(rng.integers(0, 2))],
+                     ["float64", float(rng.standard_normal()) * 10.0 ** int(rng.integers(-8, 12))], ["int16", int(rng.integers(-2 ** 15, 2 ** 15))],
+                     ["jsonnum", "%d.%02d" % (rng.integers(-10 ** 6, 10 ** 6), rng.integers(0, 100))]])
+        for k in range(1, 7):
+            if rng.integers(0, 11) == 0:
+                rows[-1][k] = ["nil", None]
+        kinds.append(["insert", "update", "delete"][int(rng.integers(0, 3))])
+    names = [t[0] for t in table]
+    b = abi.batch_from_rows(schema_of(table), names, rows, "public", "rt", kinds=kinds)
+    ob = abi.batch_from_rows(schema_of(table), ["id"], [[r[0]] for r in rows], "public", "rt")
+    b.old_keys, b.old_present = ob.cols, np.array([k != "insert" for k in kinds])
+    ids, lsns, cts = [int(x) for x in rng.integers(0, 2 ** 31, n)], [int(x) for x in rng.integers(0, 2 ** 53, n)], [1700000000000000000 + 1000000 * int(x) for x in rng.integers(0, 10 ** 9, n)]
+    out = tf.debezium_emit(abi.dbz_emit_options({"database.dbname": "db", "topic.prefix": "srv", "dt.source.type": "pg"}, schema_of(table)), tf.DeviceBatch.upload(b),
+                           abi.row_meta(n, ids=ids, lsns=lsns, commit_times=cts))
+    msgs = out.messages()
+    vals = [v for _k, v in msgs if v is not None]
+    src = [int(out.msg_row[i]) for i, (_k, v) in enumerate(msgs) if v is not None]
+    assert len(vals) == n and src == list(range(n)) and len(msgs) == n + kinds.count("delete")   # a tombstone behind every delete
+    data, cm = abi.messages(vals)
+    parsed, errors = debezium.Parser(tf).parse(data, cm, host_bytes=data)
+    assert not errors and len(parsed) == 1
+    pr = parsed[0]
+    hb = pr.batch.download()
+    assert hb.nrows == n and (hb.table_ns, hb.table_name) == ("public", "rt") and [c.name for c in hb.cols] == names
+    assert [c.key for c in pr.schema.cols] == [t[2] for t in table]
+    assert [int(k) for k in hb.kind] == [{"insert": abi.K_INSERT, "update": abi.K_UPDATE, "delete": abi.K_DELETE}[k] for k in kinds]
+    assert [int(x) for x in pr.rows["id"]] == ids and [int(x) for x in pr.rows["lsn"]] == lsns and [int(x) for x in pr.rows["commit_time"]] == cts
+    assert [bool(x) for x in hb.old_present] == [k != "insert" for k in kinds] and [c.name for c in hb.old_keys] == ["id"]
+    for r in range(n):
+        if kinds[r] != "insert":
+            assert hb.old_keys[0].pyvalue(r) == ["int32", r]
+        for ci, c in enumerate(hb.cols):
+            got, want = c.pyvalue(r), rows[r][ci]
+            if kinds[r] == "delete":
+                assert got[0] == "nil", (r, c.name, got)   # a delete's values travel in `before`: OldKeys
+            elif want[0] == "nil":
+                assert got[0] == "nil", (r, c.name, got)
+            elif c.name == "n":
+                assert Decimal(got[1].decode()) == Decimal(want[1]), (r, got, want)   # Decimal bytes back to a numeric text
+            elif c.name == "t":
+                assert got == ["string", want[1].encode("utf-8", "surrogateescape") if isinstance(want[1], str) else want[1]], (r, got, want)
+            else:
+                assert got == want, (r, c.name, got, want)
+
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "debezium_emitter")
 DEVICE_TYPES = ("pg:xml", "pg:point", "pg:numrange", "pg:tsrange", "pg:tstzrange", "pg:money", "pg:USER-DEFINED:hstore", "pg:boolean", "pg:bit(1)", "pg:smallint", "pg:integer", "pg:bigint", "pg:oid", "pg:real", "pg:double precision", "pg:bytea", "pg:json", "pg:jsonb", "pg:uuid",
                 "pg:inet", "pg:int4range", "pg:int8range", "pg:daterange", "pg:text", "pg:date", "pg:cidr", "pg:macaddr", "pg:USER-DEFINED:citext")
