@@ -1339,6 +1339,8 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
   try {
     if (!o || !b || !keys || !values || !nmsg || !o->table_schema || (cap > 0 && (!key_start || !val_start || !val_null || !msg_row)))
       return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: null argument");
+    if (o->nparams < 0 || (o->nparams > 0 && (!o->param_keys || !o->param_values))) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: nparams without the key / value arrays");
+    if (o->table_schema->ncols < 0 || (o->table_schema->ncols > 0 && !o->table_schema->cols)) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: table_schema without columns");
     Context &cx = ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
     hipStream_t st = cx.stream;
