@@ -214,6 +214,18 @@ def test_parameter_variants(tf):
     got, want, rows = emit_both(tf, b, wide, PARAMS, meta)
     assert_same(got, want, rows)
     assert b'"toasted":"__debezium_unavailable_value"' in got.messages()[0][1] or b'"toasted":null' in got.messages()[0][1]
+    # dt.unknown.types.policy = to_string: a type the emitter does not know is described as a plain string and its values go through UnknownTypeToString
+    odd = [("id", "int32", True, "pg:integer"), ("u", "utf8", False, "pg:USER-DEFINED:mytype"), ("g", "any", False, "pg:box"), ("f", "double", False, "pg:tsvector_like")]
+    orows = [[["int32", r], ["string", "raw <%d>" % r] if r % 3 else ["nil", None], ["json", '{"a":[%d,"q\\"x"]}' % r], ["jsonnum", "%d.50" % r]] for r in range(40)]
+    ob_ = abi.batch_from_rows(schema_of(odd), [t[0] for t in odd], orows, "public", "odd")
+    for extra_params in ({}, {"dt.add.original.type.info": "true"}):
+        got, want, rows = emit_both(tf, ob_, odd, dict(PARAMS, **{"dt.unknown.types.policy": "to_string"}, **extra_params), None)
+        assert_same(got, want, rows)
+    assert b'"g":"{\\"a\\":[1,\\"q\\\\\\"x\\"]}"' in got.messages()[1][1] and b'{"__dt_original_type_info":{"original_type":""},"field":"u","optional":true,"type":"string"}' in got.messages()[1][1]
+    for policy in ("skip", "fail"):
+        with pytest.raises(tf.TfgpuError) as ei:
+            tf.debezium_emit(abi.dbz_emit_options(dict(PARAMS, **{"dt.unknown.types.policy": policy}), schema_of(odd)), tf.DeviceBatch.upload(ob_))
+        assert ei.value.code == (tf.ERR_UNSUPPORTED if policy == "skip" else tf.ERR_INVALID), str(ei.value)
     # no rows, and rows of a non-row kind: no messages
     empty = abi.batch_from_rows(schema_of(table), [t[0] for t in table], [], "public", "crud")
     assert len(tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(table)), tf.DeviceBatch.upload(empty))) == 0

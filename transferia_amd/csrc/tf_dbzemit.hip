@@ -41,7 +41,7 @@ namespace tf {
 namespace dbz {
 
 enum { DK_BOOL = 1, DK_BIT1, DK_SMALLINT, DK_INTEGER, DK_BIGINT, DK_OID, DK_REAL, DK_DOUBLE, DK_STRING, DK_INET, DK_BYTEA, DK_DATE, DK_TS, DK_TSTZ,
-       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_ARR_INT, DK_ARR_STRING, DK_ARR_COPY, DK_HSTORE, DK_ARR_ELEM, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
+       DK_JSON, DK_NUMERIC, DK_NUMERIC_TEXT, DK_BITS, DK_TIME, DK_TIMETZ, DK_MONEY, DK_XML, DK_POINT, DK_TSRANGE, DK_NUMRANGE, DK_TSTZRANGE, DK_INTERVAL, DK_MARSHAL, DK_YDB_UINT64, DK_YDB_DATE, DK_INT_REPRS, DK_MY_TINYINT1, DK_MY_FLOAT, DK_MY_BINARY, DK_MY_BIT1, DK_MY_BITS, DK_MY_TIMESTAMP, DK_MY_DATETIME, DK_MY_TIME, DK_MY_DECIMAL, DK_MY_YEAR, DK_ARR_INT, DK_ARR_STRING, DK_ARR_COPY, DK_HSTORE, DK_ARR_ELEM, DK_TO_STRING, DK_WRONG_TYPE = 100 /* "unknown type of value" */, DK_HOST_TYPE = 101 };
 enum { EC_CONST = 0, EC_VALUE = 1, EC_TAIL = 2 };
 // which events a cell belongs to
 enum { EA_VALUE = 0 /* every event that has a value */, EA_AFTER, EA_AFTER_NULL, EA_BEFORE_NULL, EA_BEFORE_D, EA_BEFORE_U,
@@ -637,6 +637,11 @@ template <class S> __device__ int emit_scalar(S &s, const EParams &p, const ECel
       }
       s.put(']'); return 0;
     }
+    case DK_TO_STRING:  // typeutil.UnknownTypeToString (helpers.go:1150-1161): a string as it is, anything else as its JSONMarshalUnescape text
+      if (c.repr == TFGPU_R_STRING) { emit_json_string(s, vp, vn, false); return 0; }
+      if (c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) { const double d = cell_f64(c, b); if (d != d || d - d != 0) return 1; }
+      { s.put('"'); JsonEscSink<S> q{s}; emit_json_cell(q, c, b, 0, false); s.put('"'); }
+      return 0;
     case DK_HSTORE:  // a map marshals as pg:json does; text goes through HstoreToJSON (providers/postgres/hstore.go:27-43): "" is {}, a text that opens with '{' is taken as JSON already
       if (c.repr == TFGPU_R_JSON) { emit_json_string(s, vp, vn, false); return 0; }
       if (vn == 0) { put_lit(s, "\"{}\""); return 0; }
@@ -960,7 +965,7 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
   }
   if (t.empty()) throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: column " + name + ": unknown source type (no OriginalType; emitter_value_converter.go:188-196)");
   std::string kafka, dname, extra;  // extra: further members, already in key order relative to each other ("doc" / "fields" / "parameters")
-  bool found = false;
+  bool found = false, unknown_to_string = false;
   if (starts(t, "ydb:")) {  // GetKafkaTypeDescrByYDBType / AddYDB (ydb/emitter.go:15-232)
     static const struct { const char *t; const char *kafka; const char *name; uint32_t dk, arg; } YDB[] = {
       {"ydb:Bool", "boolean", "", DK_MARSHAL, 0}, {"ydb:Int8", "int8", "", DK_MARSHAL, 0}, {"ydb:Int16", "int16", "", DK_MARSHAL, 0}, {"ydb:Int32", "int32", "", DK_MARSHAL, 0},
@@ -982,7 +987,8 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
     if (!found) {
       const std::string &policy = P.get("dt.unknown.types.policy");
       if (policy == "fail") throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown ydbType: " + t + " (column " + name + ")");
-      unsupported(name, "dt.unknown.types.policy=" + policy + " for " + t);
+      if (policy != "to_string" || (cs.flags & TFGPU_COL_KEY) || into_arr) unsupported(name, "dt.unknown.types.policy=" + policy + " for " + t);  // (skip: a member that exists only when its value is nil)
+      found = true; unknown_to_string = true; kafka = "string"; cp.dk = DK_TO_STRING;
     }
   }
   else if (starts(t, "mysql:")) {  // GetKafkaTypeDescrByMysqlType / AddMysql (mysql/emitter.go:20-388)
@@ -1106,11 +1112,12 @@ static ColPlan plan_column(const tfgpu_colschema &cs, const Params &P, bool snap
   else {
     const std::string &policy = P.get("dt.unknown.types.policy");
     if (policy == "fail") throw Error(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: unable to add field description: unknown pgType: " + t + " (column " + name + ")");
-    unsupported(name, "dt.unknown.types.policy=" + policy + " for " + t);
+    if (policy != "to_string" || (cs.flags & TFGPU_COL_KEY) || into_arr) unsupported(name, "dt.unknown.types.policy=" + policy + " for " + t);  // (skip: a member that exists only when its value is nil)
+    unknown_to_string = true; kafka = "string"; cp.dk = DK_TO_STRING;   // the column is described as a utf8 column without an original type (emitter_value_converter.go:108-117)
   }
   // the description, members in key order: __dt_original_type_info, doc, field, fields, name, optional, parameters, type, version
   std::string o = "{";
-  if (P.get("dt.add.original.type.info") == "true") o += "\"__dt_original_type_info\":{\"original_type\":" + jstr(t) + "},";
+  if (P.get("dt.add.original.type.info") == "true") o += "\"__dt_original_type_info\":{\"original_type\":" + jstr(unknown_to_string ? std::string() : t) + "},";
   const bool var_scale = cp.dk == DK_NUMERIC && ((cp.arg >> 16) & 1u);
   if (var_scale) o += "\"doc\":\"Variable scaled decimal\",";
   if (cp.dk == DK_POINT) o += "\"doc\":\"Geometry (POINT)\",";
@@ -1199,7 +1206,7 @@ static int repr_ok(uint32_t dk, int repr, uint32_t arg = 0) {
     case DK_MY_BITS: return in({TFGPU_R_BYTES}) ? 0 : 2;
     case DK_MY_TIMESTAMP: case DK_MY_DATETIME: return in({TFGPU_R_TIME}) ? 0 : 2;
     case DK_MY_TIME: case DK_MY_YEAR: return in({TFGPU_R_STRING}) ? 0 : 2;
-    case DK_MY_DECIMAL: return 0;
+    case DK_MY_DECIMAL: case DK_TO_STRING: return 0;
     case DK_ARR_INT: case DK_ARR_STRING: case DK_ARR_COPY: case DK_ARR_ELEM: return in({TFGPU_R_JSON}) ? 0 : 2;
     case DK_YDB_UINT64: return in({TFGPU_R_UINT64}) ? 0 : 1;
     case DK_YDB_DATE: return in({TFGPU_R_TIME}) ? 0 : 1;
