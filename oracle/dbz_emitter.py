@@ -28,7 +28,7 @@ import base64
 import json
 import math
 import re
-from decimal import Decimal, ROUND_HALF_UP
+from decimal import Decimal, ROUND_HALF_UP, localcontext
 
 from oracle import oracle as _ora
 
@@ -355,6 +355,8 @@ def decimal_primitives(dec: bytes):
         if not re.match(rb"^[+-]?[0-9]+$", digits):   # big.Int.SetString(s, 10): underscores only with base 0
             raise EmitError("unable to parse string as int: %r" % digits)
         x = int(digits)
+        if x == 0:   # a zero spelt with a '+': big.Int.Bytes() is empty and isHighestBitSet indexes it (helpers.go:966-968)
+            raise NotRestated("DecimalToDebeziumPrimitivesImpl panics on %r" % dec)
         if x < 0:
             mag = (-x).to_bytes(((-x).bit_length() + 7) // 8, "big")
             v = int.from_bytes(bytes(b ^ 0xFF for b in mag), "big") + 1
@@ -376,7 +378,9 @@ def decimal_to_debezium(dec: bytes, type_wo_provider: str, params):
         put_scale, _, schema_scale = decimal_precision_scale(type_wo_provider)
         if schema_scale > 0:
             d = _shopspring(norm)
-            q = d.quantize(Decimal(1).scaleb(-schema_scale), rounding=ROUND_HALF_UP)
+            with localcontext() as ctx:   # shopspring is arbitrary-precision: no 28-digit context
+                ctx.prec = 400
+                q = d.quantize(Decimal(1).scaleb(-schema_scale), rounding=ROUND_HALF_UP)
             norm = format(q, "f").encode()
         value, scale = decimal_primitives(norm)
         return {"scale": scale, "value": value} if put_scale else value

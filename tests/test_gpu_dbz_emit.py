@@ -411,6 +411,47 @@ def test_pg_arrays_and_enums(tf):
         assert ei.value.code == code, (t, v, str(ei.value))
 
 
+def test_decimal_texts_through_every_numeric_converter(tf):
+    """DecimalToDebezium / DecimalToDebeziumPrimitives (typeutil/helpers.go:269-436) over random decimal texts — leading zeros, signs, exponents, long fractions — for pg:numeric (variable
+    scale), numeric(p,s) with and without a scale, money, ydb:Decimal / DyNumber and mysql:decimal.  Texts the reference fails on (or panics on: a zero spelt with '+') are found by the
+    oracle first and replaced: the device's answer to those is checked in the refusal tests"""
+    import random
+    rnd = random.Random(5)
+
+    def num():
+        digs = "".join(rnd.choice("0123456789") for _ in range(rnd.randint(1, 12)))
+        frac = "".join(rnd.choice("0123456789") for _ in range(rnd.randint(0, 8)))
+        s = digs + ("." + frac if frac and rnd.random() < 0.7 else "")
+        if rnd.random() < 0.15:
+            s = "0" * rnd.randint(1, 3) + s
+        if rnd.random() < 0.3:
+            s = "-" + s
+        elif rnd.random() < 0.05:
+            s = "+" + s
+        if rnd.random() < 0.3:
+            s += rnd.choice("eE") + rnd.choice(["", "+", "-"]) + str(rnd.randint(0, 6))
+        if rnd.random() < 0.03:
+            s = rnd.choice(["0", "-0", "0.000", "-0.0", ".5", "5.", "-.5e1", "1e0", "00", "-"])
+        return s
+    table = [("id", "int32", True, "pg:integer"), ("a", "double", False, "pg:numeric"), ("b", "double", False, "pg:numeric(20,4)"), ("c", "double", False, "pg:numeric(9,0)"), ("m", "utf8", False, "pg:money"),
+             ("y", "utf8", False, "ydb:Decimal"), ("z", "double", False, "ydb:DyNumber"), ("q", "double", False, "mysql:decimal(10,2)")]
+    n = 1500
+    rows = [[["int32", r], ["jsonnum", num()], ["jsonnum", num()], ["jsonnum", num()], ["string", "$" + num()], ["string", num()], ["jsonnum", num()], ["jsonnum", num()]] for r in range(n)]
+    em, cols, replaced = E.Emitter(PARAMS), cols_of(table), 0
+    for row in rows:
+        for ci in range(1, len(table)):
+            try:
+                em.add(cols[ci], tuple(row[ci]))
+            except (E.EmitError, E.NotRestated):
+                row[ci] = [row[ci][0], "$1.5" if table[ci][0] == "m" else "12.5"]
+                replaced += 1
+    assert replaced < n   # most texts are good ones
+    b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "nums")
+    for params in (PARAMS, dict(PARAMS, **{"decimal.handling.mode": "string"})):
+        got, want, rws = emit_both(tf, b, table, params, None)
+        assert_same(got, want, rws)
+
+
 def test_emit_then_receive_round_trip(tf):
     """a size-independent property: what the emitter writes, the Debezium RECEIVER of this library (tf_debezium.hip, pinned to the reference's receiver canon on its own) reads back
     as the same rows — kinds, values, OldKeys of updates and deletes, ID / LSN / CommitTime at Debezium's millisecond accuracy, table id, key flags — although the two halves
@@ -543,6 +584,10 @@ def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
     # values whose text is a third-party parser's business (pgtype), and hstore given as text (HstoreToJSON): the host's
     for t, v in (("pg:time without time zone", "4:05:06"), ("pg:time with time zone", "04:05:06Z"), ("pg:numrange", "empty"), ("pg:numrange", "[,5)"), ("pg:tstzrange", "[-infinity,2010-01-01 00:00:00Z)"),
                  ("pg:USER-DEFINED:hstore", '"a"=>"1"'), ("pg:tsrange", "x")):
+        with pytest.raises(tf.TfgpuError) as ei:
+            call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", v]]])
+        assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value), (t, v, str(ei.value))
+    for t, v in (("pg:numeric", "+0.0"), ("pg:money", "$+0")):   # DecimalToDebeziumPrimitivesImpl indexes an empty byte slice: the reference panics
         with pytest.raises(tf.TfgpuError) as ei:
             call(base + [("x", "utf8", False, t)], [[["int32", 1], ["string", v]]])
         assert ei.value.code == tf.ERR_UNSUPPORTED and "column x" in str(ei.value), (t, v, str(ei.value))

@@ -185,6 +185,7 @@ template <class S> __device__ int emit_numeric(S &s, const uint8_t *t, uint32_t 
       while (sc < (int32_t)schema_scale) { if (!mul10(C, 0)) return 2; sc++; }
     }
     if (sc < 0) return 1;
+    if (C == 0 && !has_e && schema_scale == 0) return 2;  // a zero spelt with a '+' ("+0.0"): the reference indexes an empty byte slice (isHighestBitSet, helpers.go:966-968)
   }
   uint8_t buf[17]; uint32_t bn = 0;
   if (zero_text || C == 0) { buf[0] = 0; bn = 1; }
