@@ -244,7 +244,7 @@ def _jn_float64(x) -> float:
 
 def _go_parse_float(t: bytes):
     if not re.match(rb"^[+-]?((\d[\d_]*\.?[\d_]*|\.\d[\d_]*)([eE][+-]?\d+)?|inf|infinity|nan)$", t, re.I) or b"_" in t:
-        if not re.match(rb"^[+-]?0[xX]", t):
+        if not re.match(rb"^[+-]?0[xX][0-9a-fA-F]*\.?[0-9a-fA-F]*[pP][+-]?[0-9]+$", t):   # a hexadecimal mantissa requires a 'p' exponent
             return None
         try:
             return float.fromhex(t.decode())
@@ -410,6 +410,10 @@ def days_from_civil(y, m, d):
     return era * 146097 + doe - 719468
 
 
+def _days_in_month(y, m):
+    return 29 if m == 2 and (y % 4 == 0 and (y % 100 != 0 or y % 400 == 0)) else (31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31)[m - 1]
+
+
 def civil_from_days(z):
     z += 719468
     era = (z if z >= 0 else z - 146096) // 146097
@@ -433,11 +437,13 @@ def parse_pg_datetime_tz(s: bytes):
     if not m:
         raise EmitError("time.Parse: %r" % s)
     y, mo, d, h, mi, sec = (int(m.group(i)) for i in range(1, 7))
-    if not (1 <= mo <= 12 and 1 <= d <= 31 and h < 24 and mi < 60 and sec < 60):
+    if not (1 <= mo <= 12 and 1 <= d <= _days_in_month(y, mo) and h < 24 and mi < 60 and sec < 60):
         raise EmitError("time.Parse: %r out of range" % s)
     ns = int((m.group(7) or b"")[:9].ljust(9, b"0") or 0)
     off = 0
     if zone:
+        if int(m.group(9)) > 24 or (zone == "hm" and int(m.group(10)) > 60):   # time.Parse: "time zone offset hour / minute out of range"
+            raise EmitError("time.Parse: %r zone out of range" % s)
         off = int(m.group(9)) * 3600 + (int(m.group(10)) * 60 if zone == "hm" else 0)
         if m.group(8) == b"-":
             off = -off
@@ -476,8 +482,8 @@ def unescape_unicode(s: bytes) -> bytes:
 def _pg_clock_micros(s: bytes):
     """pgtype.Time.DecodeText (jackc/pgtype v1.14: time.go): HH:MM:SS[.ffffff]"""
     m = re.match(rb"^(\d\d):(\d\d):(\d\d)(?:\.(\d{1,6}))?$", s)
-    if not m:
-        raise EmitError("cannot decode %r into Time" % s)
+    if not m or int(m.group(1)) > 23 or int(m.group(2)) > 59 or int(m.group(3)) > 59:
+        raise NotRestated("pgtype.Time.DecodeText(%r)" % s)
     us = (int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3))) * 1000000
     if m.group(4):
         us += int(m.group(4).ljust(6, b"0"))
@@ -654,25 +660,29 @@ def add_pg(col: Col, v, original_type: str, into_arr: bool, params):
         return _need_string(v, t)
     if t == "pg:numrange":
         s = _need_string(v, t)
-        m = re.match(rb"^[\[(]([^,\"]*),([^,\"]*)[\])]$", s)   # pgtype.ParseUntypedTextRange, unquoted bounds only
+        m = re.match(rb"^[\[(]([^,\"\\]*),([^,\"\\]*)[\])]$", s)   # pgtype.ParseUntypedTextRange, unquoted bounds without escapes only
         if not m:
             raise NotRestated("numrange %r" % s)
         return b"[" + exponential_to_numeric(m.group(1)) + b"," + exponential_to_numeric(m.group(2)) + b")"
     if t == "pg:tsrange":
         s = _need_string(v, t)
+        if len(s) < 2 or any(p == b'"' for p in s[1:-1].split(b",")):
+            raise NotRestated("tsrange %r: the reference's slice expressions panic" % s)
         parts = [b'"' + (p[1:-1] if len(p) > 0 and p[:1] == b'"' and p[-1:] == b'"' else p) + b'"' for p in s[1:-1].split(b",")]
         return s[:1] + b",".join(parts) + s[-1:]
     if t == "pg:tstzrange":
         s = _need_string(v, t)
-        m = re.match(rb"^[\[(]\"?([^,\"]+)\"?,\"?([^,\"]+)\"?[\])]$", s)
+        m = re.match(rb'^[\[(](?:"([^,"]+)"|([^,"]+)),(?:"([^,"]+)"|([^,"]+))[\])]$', s)   # pgtype.ParseUntypedTextRange: two bounds, each quoted as a whole or not at all
         if not m:
             raise NotRestated("tstzrange %r" % s)
         out = []
-        for bound in (m.group(1), m.group(2)):   # pgtype.Timestamptz.DecodeText: 2006-01-02 15:04:05[.f]{Z|±hh[:mm[:ss]]}
+        for bound in (m.group(1) or m.group(2), m.group(3) or m.group(4)):   # pgtype.Timestamptz.DecodeText: 2006-01-02 15:04:05[.f]{Z|±hh[:mm[:ss]]}
             mm = re.match(rb"^(\d{4})-(\d\d)-(\d\d) (\d\d):(\d\d):(\d\d)(?:\.\d+)?(Z|[+-]\d\d(?::\d\d(?::\d\d)?)?)$", bound)
             if not mm:
                 raise NotRestated("tstzrange bound %r" % bound)
             y, mo, d, h, mi, sec = (int(mm.group(i)) for i in range(1, 7))
+            if not (1 <= mo <= 12 and 1 <= d <= _days_in_month(y, mo) and h < 24 and mi < 60 and sec < 60):
+                raise NotRestated("tstzrange bound %r: what time.Parse says about the field is pgtype's business" % bound)
             z = mm.group(7)
             off = 0
             if z != b"Z":
@@ -715,8 +725,8 @@ def add_pg(col: Col, v, original_type: str, into_arr: bool, params):
             raise EmitError("pg - unable to process %s: expected string, got %s" % (t, g))
         s = _b(x)
         m = re.match(rb"^(\d\d):(\d\d):(\d\d)(?:\.(\d{1,6}))?([+-])(\d\d)(?::(\d\d))?(?::(\d\d))?$", s)
-        if not m:
-            raise EmitError("failed to decode TIME WITH TIME ZONE %r" % s)
+        if not m or int(m.group(1)) > 23 or int(m.group(2)) > 59 or int(m.group(3)) > 59:
+            raise NotRestated("pgtype.Timestamptz.DecodeText(%r)" % s)
         off = (int(m.group(6)) * 3600 + int(m.group(7) or 0) * 60 + int(m.group(8) or 0)) * (-1 if m.group(5) == b"-" else 1)
         sod = (int(m.group(1)) * 3600 + int(m.group(2)) * 60 + int(m.group(3)) - off) % 86400
         frac = b"" if into_arr or not m.group(4) else m.group(4).ljust(6, b"0").rstrip(b"0")

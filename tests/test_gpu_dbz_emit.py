@@ -452,6 +452,86 @@ def test_decimal_texts_through_every_numeric_converter(tf):
         assert_same(got, want, rws)
 
 
+def test_text_converters_on_random_and_damaged_texts(tf):
+    """the converters that READ text (clock and zone texts, intervals, ranges, points, xml escapes, bit strings, dates) on random well-formed texts — byte for byte against the
+    oracle — and on damaged ones, one call each: where the oracle says the reference fails, the device fails the call or leaves it to the host, never emits; where the oracle
+    says "pgtype's business" (NotRestated), the device leaves the value to the host"""
+    import random
+    rnd = random.Random(11)
+
+    def clock():
+        return "%02d:%02d:%02d" % (rnd.randint(0, 23), rnd.randint(0, 59), rnd.randint(0, 59)) + ("." + "".join(rnd.choice("0123456789") for _ in range(rnd.randint(1, 6))) if rnd.random() < 0.6 else "")
+
+    def zone():
+        return rnd.choice(["+", "-"]) + "%02d" % rnd.randint(0, 14) + (":%02d" % rnd.choice([0, 30, 45]) if rnd.random() < 0.4 else "")
+
+    def date():
+        return "%04d-%02d-%02d" % (rnd.randint(1, 9999), rnd.randint(1, 12), rnd.randint(1, 28))
+
+    def stamp():
+        return date() + " " + clock().split(".")[0] + ("." + str(rnd.randint(0, 999999)) if rnd.random() < 0.3 else "") + rnd.choice(["Z", zone()])
+    gens = {
+        "pg:time(3) without time zone": clock, "pg:time without time zone": clock, "pg:time with time zone": lambda: clock() + zone(),
+        "pg:interval": lambda: (rnd.choice(["", "%d year%s " % (rnd.randint(-3, 30), rnd.choice(["", "s"]))]) + rnd.choice(["", "%d mon%s " % (rnd.randint(-11, 20), rnd.choice(["", "s", "th", "ths"]))]) +
+                                rnd.choice(["", "%d day%s " % (rnd.randint(-40, 400), rnd.choice(["", "s"]))]) + rnd.choice(["", rnd.choice(["", "-", "+"]) + clock()])),
+        "pg:tstzrange": lambda: rnd.choice("[(") + rnd.choice(['"%s"', "%s"]) % stamp() + "," + rnd.choice(['"%s"', "%s"]) % stamp() + rnd.choice("])"),
+        "pg:tsrange": lambda: rnd.choice("[(") + rnd.choice(['"%s"', "%s"]) % stamp()[:19] + "," + stamp()[:19] + rnd.choice("])"),
+        "pg:numrange": lambda: rnd.choice("[(") + NUMS[rnd.randrange(26)] + "," + NUMS[rnd.randrange(26)] + rnd.choice("])"),
+        "pg:point": lambda: "(%s,%s)" % (rnd.choice(["1.5", "-0", "1e10", "23.4", "+7", "1E3"]), rnd.choice(["2", "-44.5", "1e-7", ".5"])),
+        "pg:xml": lambda: "".join(rnd.choice(["<a>", "\\u003c", "\\u00e9", "\\u12", "\\uZZZZ", "x", "é", "\\", "\\u0041", '"']) for _ in range(rnd.randint(0, 8))),
+        "pg:bit varying(64)": lambda: "".join(rnd.choice("01") for _ in range(rnd.randint(0, 40))),
+        "pg:date": lambda: date() + rnd.choice(["T00:00:00Z", " 00:00:00Z", "T00:00:00" + zone()[:3] + ":00", " 00:00:00" + zone()[:3]]),
+        "pg:timestamp with time zone": lambda: rnd.choice([lambda: date() + "T" + clock() + "Z", lambda: date() + " " + clock() + zone()[:3], lambda: date() + "T" + clock() + zone()[:3] + ":30"])(),
+        "mysql:time(6)": clock, "mysql:year(4)": lambda: str(rnd.randint(1901, 2155)),
+    }
+    types = list(gens)
+    table = [("id", "int32", True, "pg:integer")] + [("c%d" % i, "utf8", False, t) for i, t in enumerate(types)]
+    cols, em = cols_of(table), E.Emitter(PARAMS)
+
+    def oracle_says(ci, text):
+        try:
+            E.gomarshal(em.add(cols[ci], ("string", text.encode("utf-8", "surrogateescape"))))
+            return "ok"
+        except E.NotRestated:
+            return "host"
+        except E.EmitError:
+            return "invalid"
+    rows = []
+    for r in range(600):
+        row = [["int32", r]]
+        for ci, t in enumerate(types, 1):
+            v = gens[t]()
+            row.append(["string", v] if oracle_says(ci, v) == "ok" else ["nil", None])
+        rows.append(row)
+    assert sum(1 for row in rows for c in row[1:] if c[0] == "string") > 0.8 * 600 * len(types)
+    b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "txt")
+    got, want, rws = emit_both(tf, b, table, PARAMS, None)
+    assert_same(got, want, rws)
+
+    def damaged(s_):
+        if not s_:
+            return s_ + rnd.choice("0:.-+ ,Z\"[")
+        i = rnd.randrange(len(s_))
+        k = rnd.random()
+        return s_[:i] + s_[i + 1:] if k < 0.35 else s_[:i] + rnd.choice("0123456789:.-+ ,Zz\"[](){}eT/\\u") + (s_[i:] if k < 0.7 else s_[i + 1:])
+    seen = {"invalid": 0, "host": 0, "ok": 0}
+    for k in range(260):
+        ci = 1 + k % len(types)
+        t, v = types[ci - 1], damaged(gens[types[ci - 1]]())
+        verdict = oracle_says(ci, v)
+        one = [("id", "int32", True, "pg:integer"), ("x", "utf8", False, t)]
+        bb = abi.batch_from_rows(schema_of(one), ["id", "x"], [[["int32", 1], ["string", v]]], "public", "t")
+        try:
+            out = tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(one)), tf.DeviceBatch.upload(bb))
+            assert verdict == "ok", (t, v, verdict)   # the device emits only what the oracle can check …
+            item = E.Item("insert", "public", "t", cols_of(one), ["id", "x"], [("int32", 1), ("string", v.encode("utf-8", "surrogateescape"))])
+            assert out.messages() == em.emit_kv(item), (t, v)   # … and then the same bytes
+        except tf.TfgpuError as e:
+            assert (verdict, e.code) in (("invalid", tf.ERR_INVALID), ("invalid", tf.ERR_UNSUPPORTED), ("host", tf.ERR_UNSUPPORTED), ("ok", tf.ERR_UNSUPPORTED)), (t, v, verdict, e.code)
+        seen[verdict] += 1
+    assert seen["invalid"] > 20 and seen["host"] > 5
+
+
 def test_emit_then_receive_round_trip(tf):
     """a size-independent property: what the emitter writes, the Debezium RECEIVER of this library (tf_debezium.hip, pinned to the reference's receiver canon on its own) reads back
     as the same rows — kinds, values, OldKeys of updates and deletes, ID / LSN / CommitTime at Debezium's millisecond accuracy, table id, key flags — although the two halves

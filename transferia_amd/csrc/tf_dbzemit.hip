@@ -229,6 +229,7 @@ __device__ __forceinline__ bool dg2(const uint8_t *p, uint32_t &v) { if (p[0] < 
 __device__ __forceinline__ bool clock_micros(const uint8_t *t, uint32_t n, int64_t *us, uint32_t *end, bool comma_ok = false) {
   uint32_t h, m, sec;
   if (n < 8 || !dg2(t, h) || t[2] != ':' || !dg2(t + 3, m) || t[5] != ':' || !dg2(t + 6, sec)) return false;
+  if (!comma_ok && (h > 23 || m > 59 || sec > 59)) return false;  // what pgtype's readers make of such a field is theirs to say (the callers leave the value to the host)
   int64_t v = ((int64_t)h * 3600 + m * 60 + sec) * 1000000;
   uint32_t i = 8;
   if (i < n && (t[i] == '.' || (comma_ok && t[i] == ','))) {  // (time.Parse takes a comma for the period of a fractional second; pgtype's strconv-based readers do not)
@@ -269,7 +270,8 @@ template <class S> __device__ int emit_exp_numeric(S &s, const uint8_t *t, uint3
   if (!has_e) { json_body(s, t, n); return 0; }
   uint32_t i = 0; bool neg = false;
   if (t[0] == '-') { neg = true; i = 1; }
-  if (i < n && (t[i] == '+' || t[i] == '-')) return 2;
+  if (i < n && t[i] == '+' && !neg) i++;  // shopspring takes a '+'
+  else if (i < n && (t[i] == '+' || t[i] == '-')) return 2;
   u128 C = 0; uint32_t nd = 0; int32_t F = 0, E = 0; bool dot = false;
   for (; i < n; i++) { const uint32_t c = t[i]; if (c >= '0' && c <= '9') { if (!mul10(C, c - '0')) return 2; nd++; if (dot) F++; } else if (c == '.' && !dot) dot = true; else break; }
   if (nd == 0 || i >= n || (t[i] != 'e' && t[i] != 'E')) return 1;
@@ -336,7 +338,7 @@ __device__ __forceinline__ int pg_datetime_tz(const uint8_t *t, uint32_t n, int6
     if (i + 2 > n || !dg2(t + i, zh)) return 1; i += 2;
     if (tee) { if (i + 3 != n || t[i] != ':' || !dg2(t + i + 1, zm)) return 1; }
     else if (i != n) return 1;
-    if (zh > 23 || zm > 59) return 1;
+    if (zh > 24 || zm > 60) return 1;  // time.Parse's own ranges for a zone offset
     off = (int32_t)(zh * 3600 + zm * 60); if (neg) off = -off;
   }
   const int64_t y = (t[0] - '0') * 1000 + (t[1] - '0') * 100 + (t[2] - '0') * 10 + (t[3] - '0');
