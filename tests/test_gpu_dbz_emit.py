@@ -411,6 +411,50 @@ def test_pg_arrays_and_enums(tf):
         assert ei.value.code == code, (t, v, str(ei.value))
 
 
+def test_mysql_random_rows_with_updates_and_deletes(tf):
+    """31 MySQL-typed columns of random values in the Go shapes a MySQL source produces, as inserts, updates and deletes with and without OldKeys: `before` of a delete takes the
+    row's own values under the OldKeys (valPayload, emitter_value_converter.go:463-486), `source` carries file / pos / gtid"""
+    import random
+    rnd = random.Random(3)
+    table = [("pk", "uint32", True, "mysql:int(10) unsigned"), ("bi", "int64", False, "mysql:bigint(20)"), ("bu", "uint64", False, "mysql:bigint(20) unsigned"), ("ti", "int8", False, "mysql:tinyint(4)"),
+             ("t1", "int8", False, "mysql:tinyint(1)"), ("si", "uint16", False, "mysql:smallint(5) unsigned"), ("mi", "int32", False, "mysql:mediumint(9)"), ("f", "double", False, "mysql:float"),
+             ("d", "double", False, "mysql:double(10,2)"), ("c", "utf8", False, "mysql:varchar(5)"), ("b3", "string", False, "mysql:binary(3)"), ("b16", "string", False, "mysql:binary(16)"),
+             ("vb", "string", False, "mysql:varbinary(5)"), ("bl", "string", False, "mysql:blob"), ("bit1", "string", False, "mysql:bit(1)"), ("bit9", "string", False, "mysql:bit(9)"),
+             ("bit64", "string", False, "mysql:bit(64)"), ("j", "any", False, "mysql:json"), ("ts", "timestamp", False, "mysql:timestamp"), ("ts4", "timestamp", False, "mysql:timestamp(4)"),
+             ("dt", "timestamp", False, "mysql:datetime"), ("dt2", "timestamp", False, "mysql:datetime(2)"), ("dt6", "timestamp", False, "mysql:datetime(6)"), ("da", "date", False, "mysql:date"),
+             ("tm", "utf8", False, "mysql:time"), ("tm3", "utf8", False, "mysql:time(3)"), ("dec", "double", False, "mysql:decimal(12,4)"), ("y", "utf8", False, "mysql:year(4)"),
+             ("e", "utf8", False, "mysql:enum('a','b')"), ("s", "utf8", False, "mysql:set('x','y','z')"), ("tx", "utf8", False, "mysql:longtext")]
+    n = 400
+    rows = []
+
+    def rb(k):
+        return bytes(rnd.randrange(256) for _ in range(k))
+    for r in range(n):
+        sec, us = rnd.randint(-2 * 10 ** 9, 4 * 10 ** 9), rnd.randint(0, 999999)
+        f = rnd.gauss(0, 1) * 10.0 ** rnd.randint(-10, 15)
+        row = [["uint32", rnd.randint(0, 2 ** 32 - 1)], ["int64", rnd.randint(-2 ** 63, 2 ** 63 - 1)], ["uint64", rnd.randint(0, 2 ** 64 - 1)], ["int8", rnd.randint(-128, 127)], ["int8", rnd.choice([0, 1, 1, 2, -1])],
+               ["uint16", rnd.randint(0, 65535)], ["int32", rnd.randint(-2 ** 23, 2 ** 23)], ["jsonnum", "%.7g" % f], ["float64", f], ["string", TEXTS[rnd.randrange(7)][:20]],
+               ["bytes", rb(rnd.randint(0, 3))], ["bytes", rb(rnd.randint(0, 20))], ["bytes", rb(rnd.randint(0, 5))], ["bytes", rb(rnd.randint(0, 40))],
+               ["bytes", rnd.choice([b"\x01", b"\x00", b"\x00" * 7 + b"\x01", b"\x02", b"\x00" * 8])], ["bytes", rb(rnd.choice([2, 8]))], ["bytes", rb(8)],
+               ["json", rnd.choice(['{"k1":"v1"}', "[1,2]", '"s"', "null", "7"])], ["time", (sec, 0)], ["time", (sec, us * 1000)], ["time", (sec, us * 1000)], ["time", (sec, us * 1000)],
+               ["time", (sec, us * 1000)], ["time", (sec - sec % 86400, 0)], ["string", "%02d:%02d:%02d" % (rnd.randint(0, 23), rnd.randint(0, 59), rnd.randint(0, 59))],
+               ["string", "%02d:%02d:%02d.%03d" % (rnd.randint(0, 23), rnd.randint(0, 59), rnd.randint(0, 59), rnd.randint(0, 999))],
+               ["jsonnum", "%d.%04d" % (rnd.randint(-10 ** 7, 10 ** 7), rnd.randint(0, 9999))], ["string", str(rnd.randint(1901, 2155))], ["string", rnd.choice("ab")], ["string", rnd.choice(["x", "x,y", ""])],
+               ["string", TEXTS[rnd.randrange(8)]]]
+        for k in range(1, len(row)):
+            if rnd.random() < 0.08:
+                row[k] = ["nil", None]
+        rows.append(row)
+    kinds = [rnd.choice(["insert", "update", "delete"]) for _ in range(n)]
+    b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "db1", "tbl", kinds=kinds)
+    ob = abi.batch_from_rows(schema_of(table), ["pk"], [[r[0]] for r in rows], "db1", "tbl")
+    b.old_keys, b.old_present = ob.cols, np.array([k != "insert" and rnd.random() < 0.8 for k in kinds])
+    meta = (list(range(n)), [rnd.randint(0, 10 ** 15) for _ in range(n)], [rnd.randint(0, 2 ** 62) for _ in range(n)], [rnd.choice(["", "gtid:%d" % r]) for r in range(n)])
+    got, want, rws = emit_both(tf, b, table, {"topic.prefix": "p", "dt.source.type": "mysql"}, meta)
+    assert_same(got, want, rws)
+    assert any(v is not None and b'"op":"d"' in v and b'"before":{"b16":"' in v for _k, v in got.messages())
+
+
 def test_decimal_texts_through_every_numeric_converter(tf):
     """DecimalToDebezium / DecimalToDebeziumPrimitives (typeutil/helpers.go:269-436) over random decimal texts — leading zeros, signs, exponents, long fractions — for pg:numeric (variable
     scale), numeric(p,s) with and without a scale, money, ydb:Decimal / DyNumber and mysql:decimal.  Texts the reference fails on (or panics on: a zero spelt with '+') are found by the
