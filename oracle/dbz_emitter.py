@@ -379,7 +379,7 @@ def decimal_to_debezium(dec: bytes, type_wo_provider: str, params):
         if schema_scale > 0:
             d = _shopspring(norm)
             with localcontext() as ctx:   # shopspring is arbitrary-precision: no 28-digit context
-                ctx.prec = 400
+                ctx.prec = 20000
                 q = d.quantize(Decimal(1).scaleb(-schema_scale), rounding=ROUND_HALF_UP)
             norm = format(q, "f").encode()
         value, scale = decimal_primitives(norm)
