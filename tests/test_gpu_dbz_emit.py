@@ -576,6 +576,28 @@ def test_text_converters_on_random_and_damaged_texts(tf):
     assert seen["invalid"] > 20 and seen["host"] > 5
 
 
+def test_row_range_shards_emit_the_same_messages(tf):
+    """SURVEY §8(e) for this path: rows are independent, so a batch cut into row ranges (tfgpu_shard_rows, one shard per rank / device / lane) emits, shard by shard, exactly the messages
+    of the whole batch in order — no data-path collective; a shard's row meta is the slice of its rows (tfgpu_shard_rows reports each shard's first row)"""
+    table, b = crud_batch(700, 19)
+    n = b.nrows
+    meta = (list(range(n)), [7 * r for r in range(n)], [1600000000000000000 + 999983 * r for r in range(n)])
+    opts = abi.dbz_emit_options(PARAMS, schema_of(table))
+    rm = abi.row_meta(n, ids=meta[0], lsns=meta[1], commit_times=meta[2])
+    db = tf.DeviceBatch.upload(b)
+    whole = tf.debezium_emit(opts, db, rm)
+    want = whole.messages()
+    for g in (2, 3, 8):
+        shards, row0 = db.shard_rows(g, lanes=[0] * g)
+        got, rows = [], []
+        for sh, r0 in zip(shards, row0):
+            k = sh.nrows
+            out = tf.debezium_emit(opts, sh, abi.row_meta(k, ids=meta[0][r0:r0 + k], lsns=meta[1][r0:r0 + k], commit_times=meta[2][r0:r0 + k]))
+            got += out.messages()
+            rows += [int(x) + r0 for x in out.msg_row]
+        assert got == want and rows == [int(x) for x in whole.msg_row], g
+
+
 def test_emit_then_receive_round_trip(tf):
     """a size-independent property: what the emitter writes, the Debezium RECEIVER of this library (tf_debezium.hip, pinned to the reference's receiver canon on its own) reads back
     as the same rows — kinds, values, OldKeys of updates and deletes, ID / LSN / CommitTime at Debezium's millisecond accuracy, table id, key flags — although the two halves
