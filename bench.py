@@ -113,7 +113,32 @@ def host_info():
                     break
     except OSError:
         pass
-    return {"nproc": os.cpu_count() or 1, "cpu_model": model}
+    return {"nproc": os.cpu_count() or 1, "usable_cores": usable_cores(), "cpu_model": model}
+
+
+def usable_cores():
+    """Hardware threads this process may actually run on: the scheduler affinity mask capped by the cgroup CPU quota (a container on
+    a 256-thread host is typically given a handful; 256 workers on an 8-CPU quota measure the quota, not the reference)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts and parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read().split()[0]))))
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            pass
+    return max(n, 1)
 
 
 ALL_CORES_HELPER = r"""
@@ -495,7 +520,7 @@ class CsvWorkload(Base):
         # leg (ii): every host core, the reference's parallelism shape for SEVERAL tables / snapshot parts (one sink pipeline each,
         # load_snapshot.go:962): independent slices, one oracle pipeline per core, each in its own process (a clean interpreter
         # forks the workers: no GIL between them, no HIP state inherited)
-        nc = out["nproc"]
+        nc = out["usable_cores"]
         if nc > 1 and a.cpu_all_rows > 0:
             reps = 4
             per = 16384  # 65 536 rows per worker over the timed passes
