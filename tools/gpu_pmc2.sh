@@ -15,7 +15,7 @@ SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INS
 [ -n "$CUSTOM" ] && SETS=("$CUSTOM") && NSETS=1
 for set in "${SETS[@]}"; do
   i=$((i+1)); [ $i -gt $NSETS ] && break
-  timeout 600 rocprofv3 --pmc $set --kernel-include-regex "$K" -f csv -d "$OUT/p$i" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --workload $WL --steps 1 --warmup 1 --cpu-rows 0 --prof-steps 1 --overlap-lanes 0 --pcie-steps 0 > "$OUT/p$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-include-regex "$K" -f csv -d "$OUT/p$i" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --workload $WL --steps 1 --passes 1 --warmup 1 --cpu-rows 0 --prof-steps 1 --overlap-lanes 0 --pcie-steps 0 > "$OUT/p$i.log" 2>&1
   f=$(find "$OUT/p$i" -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python - "$f" <<'PY' | tee -a "$OUT/summary.txt"
 import csv, sys, collections

@@ -41,8 +41,9 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 static constexpr int NL_THREADS = 256;
 static constexpr int NL_ITERS = 7;
 static constexpr int NL_TILE = NL_THREADS * 16 * NL_ITERS;  // 28 KiB per workgroup
-static constexpr int CSV_GRAN = NL_THREADS * 16;          // 4 KiB: the unit newline counts are kept in
-static_assert(NL_TILE == NL_ITERS * CSV_GRAN, "a workgroup iteration is a granule");
+static constexpr int CSV_GRAN = 64 * 16;                  // 1 KiB (what one wave reads per iteration): the unit newline counts are kept in
+static constexpr int NL_GPT = NL_TILE / CSV_GRAN;           // granules per workgroup of the line-index kernels
+static_assert(NL_TILE == NL_GPT * CSV_GRAN && NL_THREADS * 16 == 4 * CSV_GRAN, "a wave iteration is a granule");
 
 __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
   // bit i set iff byte i of the 16-byte chunk is '\n'
@@ -51,13 +52,22 @@ __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     uint32_t x = w[k] ^ 0x0A0A0A0Au;
-    uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;  // 0x80 where the byte is zero (exact for the lowest hit, see below)
-    // the borrow trick can flag a byte that follows a true zero byte; verify each byte
     uint32_t b0 = ((x & 0xFFu) == 0), b1 = ((x & 0xFF00u) == 0), b2 = ((x & 0xFF0000u) == 0), b3 = ((x & 0xFF000000u) == 0);
-    (void)z;
     m |= (b0 | b1 << 1 | b2 << 2 | b3 << 3) << (4 * k);
   }
   return m;
+}
+// number of '\n' among the 16 bytes: exact zero-byte flags by SWAR (no borrow between bytes), summed with one v_dot4 per word
+__device__ __forceinline__ uint32_t nl_count16(uint4 v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t x = w[k] ^ 0x0A0A0A0Au;
+    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;  // 0x80 where the byte is '\n'
+    acc = __builtin_amdgcn_udot4(z >> 7, 0x01010101u, acc, false);
+  }
+  return acc;
 }
 
 __device__ __forceinline__ uint4 load16_guard(const uint8_t *base, uint64_t pos, uint64_t len) {
@@ -71,24 +81,19 @@ __device__ __forceinline__ uint4 load16_guard(const uint8_t *base, uint64_t pos,
   return v;
 }
 
-// '\n' per 4 KiB granule (CSV_GRAN = one iteration of the workgroup: 256 lanes x 16 B); tiles of any whole number of
+// '\n' per 1 KiB granule (CSV_GRAN = what one wave reads per iteration: 64 lanes x 16 B); tiles of any whole number of
 // granules take their first line and their line count from the exclusive scan of these
 __global__ void __launch_bounds__(NL_THREADS) csv_count_newlines(const uint8_t *__restrict__ data, uint64_t len, uint32_t *__restrict__ gran_counts, int64_t ngran) {
-  __shared__ uint32_t red[NL_ITERS][NL_THREADS / 64];
   const uint64_t tile = (uint64_t)blockIdx.x * NL_TILE;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int it = 0; it < NL_ITERS; it++) {
     const uint64_t pos = tile + ((uint64_t)it * NL_THREADS + threadIdx.x) * 16;
     uint32_t cnt = 0;
-    if (pos < len) cnt = (uint32_t)__popc(nl_mask16(load16_guard(data, pos, len)));
+    if (pos < len) cnt = nl_count16(load16_guard(data, pos, len));
     const uint32_t inc = wave_scan_add(cnt);
-    if (lane == 63) red[it][wv] = inc;
-  }
-  __syncthreads();
-  if (threadIdx.x < NL_ITERS) {
-    const int64_t g = (int64_t)blockIdx.x * NL_ITERS + threadIdx.x;
-    if (g < ngran) gran_counts[g] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    const int64_t g = (int64_t)blockIdx.x * NL_GPT + it * 4 + wv;
+    if (lane == 63 && g < ngran) gran_counts[g] = inc;
   }
 }
 
@@ -96,7 +101,7 @@ __global__ void __launch_bounds__(NL_THREADS) csv_line_index(const uint8_t *__re
                                                             uint32_t *__restrict__ row_start /* [nlines+1], row_start[0] preset */) {
   __shared__ uint32_t wsum[NL_THREADS / 64];
   uint64_t tile = (uint64_t)blockIdx.x * NL_TILE;
-  uint32_t base = tile_base[(int64_t)blockIdx.x * NL_ITERS];  // exclusive scan of the granule counts
+  uint32_t base = tile_base[(int64_t)blockIdx.x * NL_GPT];  // exclusive scan of the granule counts
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int it = 0; it < NL_ITERS; it++) {
     uint64_t pos = tile + ((uint64_t)it * NL_THREADS + threadIdx.x) * 16;
@@ -345,6 +350,11 @@ struct CsvParams {
   int32_t force_general;       // TFGPU_CSV_GENERAL=1: every tile takes the general kernel (parity cross-check of the two)
   const struct CsvRun *runs;   // tcols grouped into runs of one (kind, width)
   int32_t nruns;
+  // csv_parse_lanes (lane = line): the column buffers as 4-byte offsets into one arena, dealt to the 16 waves in blocks
+  uint8_t *arena;
+  const uint32_t *lcols;       // [16 waves][64]: word 4 s + w of wave v = word w of its s-th column {p0 offset, p1 offset, field:16 | kind:8 | width:8, -}
+  const uint32_t *lwave_ncols; // [16]: columns per wave
+  uint32_t tile_cpt;           // 16-byte chunks per thread: the tile is 15, 30 or 45 KiB
 };
 
 __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v) {
@@ -1234,6 +1244,22 @@ template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const R
     const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     T *const out = global_ptr<T>(t.colp0[c.on ? c.col : (uint32_t)run.first]);
     const uint32_t n = c.fend - c.fs;
+    if (t.ablate != 31 && wave_all(n - 1u < 4u || !c.on)) {
+      // tier A: one to four characters, an unsigned canonical decimal — the common cell of a flag / small-integer column.  One
+      // aligned LDS word pair holds the field's bytes [fend - 4, fend); masks come from shifts (an LDS table read costs the CU
+      // as much as six VALU instructions), the leading-zero rule from the first character in byte 0.
+      const uint32_t *w4 = reinterpret_cast<const uint32_t *>(t.sb + (int)((c.fend & ~3u) - 4u));
+      const uint32_t xr = __builtin_amdgcn_alignbyte(w4[1], w4[0], c.fend) ^ 0x30303030u;
+      const uint32_t sh = 32u - 8u * n;             // (an idle lane's n = 0 shifts by nothing: its result is not stored)
+      const uint32_t f0 = xr >> sh;                 // first character in byte 0
+      const uint32_t d = f0 << sh;                  // units in byte 3, …, thousands in byte 0; what precedes the field is zero
+      bool badA = ((((d + 0x76767676u) | d) & 0x80808080u) != 0) | (((f0 & 0xFFu) == 0) & (n > 1u));  // a byte above 9; a leading zero in front of more digits
+      const uint32_t v = __umul24(d & 0xFFu, 1000u) + __builtin_amdgcn_udot4(d, 0x010A6400u, 0u, false);
+      if constexpr (W == 1) badA = badA | (v > ((KIND == CK_INT) ? 127u : 255u));
+      if (c.on && !badA) out[c.r] = (T)v;
+      if (c.on && badA) t.slowf[c.jj] = 1;
+      continue;
+    }
     const uint32_t c0 = t.sb[c.fs];
     uint32_t wlo, whi;
     window8(t.sb, c.fend, &wlo, &whi);
@@ -1673,6 +1699,8 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   if (tid == 0 && line1 == lines_all) atomicMax(p.last_end, (uint32_t)(g0 + fposx[nr * NF] + 1));
   phase(6);
 }
+
+#include "tf_csv_lanes.inc"
 
 // rows that failed contribute no string bytes
 __global__ void csv_zero_err_lens(const uint8_t *err, int64_t nrows, const CsvCol *cols, int32_t ncols) {
@@ -2316,7 +2344,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   for (int i = 0; i < ncols; i++) order[(size_t)i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
     const CsvCol &a = cols[(size_t)x], &b = cols[(size_t)y];
-    return a.kind != b.kind ? a.kind < b.kind : a.width < b.width;
+    return a.kind != b.kind ? a.kind < b.kind : a.width != b.width ? a.width < b.width : a.field < b.field;
   });
   std::vector<TCol> tcols((size_t)ncols);
   for (int i = 0; i < ncols; i++) {
@@ -2343,6 +2371,55 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.runs = ptr<CsvRun>(bruns); pp.nruns = (int32_t)runs.size();
   pp.null_checks = (opts->strings_can_be_null || opts->quoted_strings_can_be_null) ? 1 : 0;
 
+  // ---- csv_parse_lanes: the sorted columns cut into 16 contiguous blocks of about equal cost, one per wave; the tile sized so
+  //      that it holds just under 64 lines (or a multiple), within the index's capacity ----
+  // (Measured on the MI355X, profiles/r06c-e: 0.765 ms per 2^20 hits rows against csv_parse_regular's 0.728 — the cells issue a third
+  //  fewer VALU instructions, the byte phases of a 1024-thread workgroup more; both kernels end at 4.2e8 VALU wave-instructions and
+  //  issue VALU 91 % of the time.  It stays selectable, TFGPU_CSV_LANES=1, as the base for the next step)
+  static const bool lanes_on = [] { const char *e = std::getenv("TFGPU_CSV_LANES"); return e && e[0] == '1'; }();
+  bool use_lanes = lanes_on && !rowpath && ncols <= CL_MAXCOLS && nlines > 0;
+  int64_t ltiles = 0;
+  Buf blcols, blwn;
+  if (use_lanes) {
+    auto cost = [](const TCol &t) { return t.field < 0 ? 1 : (t.kind == CK_INT || t.kind == CK_UINT) ? (t.width == 8 ? 3 : 2) : t.kind == CK_STR ? 4 : 8; };
+    int total = 0;
+    for (auto &t : tcols) total += cost(t);
+    std::vector<uint32_t> lcols((size_t)CL_WAVES * 64, 0u), lwn((size_t)CL_WAVES, 0u);
+    int ci = 0, spent = 0;
+    for (int w = 0; w < CL_WAVES && ci < ncols; w++) {
+      // columns for this wave: until its share of the remaining cost is used up (at least one, at most CL_WCOLS, and never
+      // fewer than what the remaining waves can still take)
+      const int share = (total - spent + (CL_WAVES - w) - 1) / (CL_WAVES - w);
+      int got = 0, s = 0;
+      while (ci < ncols && s < CL_WCOLS && (s == 0 || got + cost(tcols[(size_t)ci]) <= share || ncols - ci > (CL_WAVES - w - 1) * CL_WCOLS)) {
+        const TCol &t = tcols[(size_t)ci];
+        const uint64_t o0 = t.p0 ? (uint64_t)((uint8_t *)t.p0 - (uint8_t *)arena->p) : 0, o1 = t.p1 ? (uint64_t)((uint8_t *)t.p1 - (uint8_t *)arena->p) : 0;
+        if ((o0 | o1) & 3) { use_lanes = false; break; }
+        lcols[(size_t)w * 64 + 4 * s] = (uint32_t)(o0 >> 2); lcols[(size_t)w * 64 + 4 * s + 1] = (uint32_t)(o1 >> 2);
+        lcols[(size_t)w * 64 + 4 * s + 2] = (uint32_t)(uint16_t)t.field | ((uint32_t)t.kind << 16) | ((uint32_t)t.width << 24);
+        got += cost(t); s++; ci++;
+      }
+      lwn[(size_t)w] = (uint32_t)s; spent += got;
+    }
+    if (ci < ncols) use_lanes = false;
+    if (use_lanes) {
+      // lines per tile: the largest tile whose expected line count stays under 64 m - margin for some m, and whose expected
+      // field count fits the index; rows longer than ~700 bytes get the largest tile whatever its count
+      const double avg_row = (double)len / (double)nlines, nf_est = std::max<double>(max_field + 1, 1);
+      uint32_t cpt = 1;
+      for (uint32_t c = CL_CPT_MAX; c >= 1; c--) {
+        const double lines = cl_tile(c) / avg_row;
+        if (lines * nf_est <= 0.88 * CL_FCAP && lines <= 0.88 * CL_RCAP) { cpt = c; break; }
+      }
+      pp.tile_cpt = cpt;
+      ltiles = (int64_t)((len + cl_tile(cpt) - 1) / cl_tile(cpt));
+      pp.ntiles = ltiles;
+      pp.arena = (uint8_t *)arena->p;
+      blcols = up(lcols.data(), lcols.size() * 4); blwn = up(lwn.data(), lwn.size() * 4);
+      pp.lcols = ptr<uint32_t>(blcols); pp.lwave_ncols = ptr<uint32_t>(blwn);
+    }
+  }
+
   if (ablate) {  // profiling only: what the skipped phases would have written must not be garbage
     TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)std::max(nstr, 1) * (size_t)seg_stride * 4, st));
     TF_HIP(hipMemsetAsync(fstart_all->p, 0, (size_t)std::max(nstr, 1) * (size_t)fstride * 4, st));
@@ -2354,8 +2431,15 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     csv_parse_rows<<<blocks_for(nrows, 256), 256, 0, st>>>(pp);
   } else if (nlines) {
     // header lines are parsed by nobody: err[] of the data rows is written by exactly one of the two kernels
-    const int64_t per_xcd = (rtiles + 7) / 8;
-    { KernelTimer t("csv_parse_regular"); csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp); }
+    if (use_lanes) {
+      const int64_t per_xcd = (ltiles + 7) / 8;
+      KernelTimer t("csv_parse_lanes");
+      csv_parse_lanes<<<(unsigned)(per_xcd * 8), CL_THREADS, 0, st>>>(pp);
+    } else {
+      const int64_t per_xcd = (rtiles + 7) / 8;
+      KernelTimer t("csv_parse_regular");
+      csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp);
+    }
     { KernelTimer t("csv_parse_tiles_general"); csv_parse_tiles_general<<<(unsigned)std::min<int64_t>(ntiles + rtiles, 2048), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 1024), 64, 0, st>>>(pp); }
   }
@@ -2382,7 +2466,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     uint32_t g = 0, sl = 0;
     d2h(&g, gen->p, 4); d2h(&sl, slow->p, 4);
     tf::sync();
-    std::fprintf(stderr, "tfgpu csv: %lld tiles of %u KiB, %u general pieces; %u lines, %u per-row\n", (long long)rtiles, tile_bytes / 1024u, g, nlines, sl);
+    std::fprintf(stderr, "tfgpu csv: %s, %lld tiles of %u KiB, %u general pieces; %u lines, %u per-row\n", use_lanes ? "lanes" : "regular", (long long)(use_lanes ? ltiles : rtiles), (use_lanes ? cl_tile(pp.tile_cpt) : tile_bytes) / 1024u, g, nlines, sl);
   }
 
   // ---- string payloads: offsets are views into the scanned lens array.  The tile path leaves the cells where they
