@@ -1525,6 +1525,8 @@ __global__ void __launch_bounds__(JT_THREADS, 4) json_parse_tiles(JParams p, int
   }  // tiles
 }
 
+#include "tf_jsonquick.inc"
+
 // ---------------------------------------------------------------------------
 // line boundaries
 // ---------------------------------------------------------------------------
@@ -2022,16 +2024,31 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     Buf slow = dalloc((size_t)(nseg + 1) * 4), heavy = dalloc((size_t)(nseg + 1) * 4);
     TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
     TF_HIP(hipMemsetAsync(heavy->p, 0, 4, st));
+    // json_parse_quick (tf_jsonquick.inc) when no column needs what it leaves out (float tokens) and a line's members fit its map;
+    // json_parse_tiles otherwise (and with TFGPU_JSON_QUICK=0, for A/B runs and as the cross-check of the two)
+    static const bool quick_off = [] { const char *e = std::getenv("TFGPU_JSON_QUICK"); return e && e[0] == '0'; }();
+    bool quick = !quick_off && nraw <= JQ_MEM;
+    for (auto &c : cols) if (c.kind == JK_F64) quick = false;
+    static const int jt_ablate = [] { const char *e = std::getenv("TFGPU_JT_ABLATE"); return e ? std::atoi(e) : 0; }();
+    int32_t used_per_tile = per_tile;
+    if (quick) {
+      const int32_t qper = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(JQ_BYTES - 16) * 8 / (avg * 9), 1), (uint64_t)JQ_LINES);
+      used_per_tile = qper;
+      Buf bmap = dalloc(sizeof(JqMap));
+      { KernelTimer t("json_quick_map"); json_quick_map<<<1, JQ_THREADS, 0, st>>>(pp, ptr<JqMap>(bmap)); }
+      { KernelTimer t("json_parse_quick"); json_parse_quick<<<jblocks(nseg, qper), JQ_THREADS, 0, st>>>(pp, ptr<JqMap>(bmap), qper, nalloc, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1, jt_ablate); }
+    } else {
     // persistent workgroups (two per CU fit its LDS): each walks every (2 * CUs)-th tile and keeps its member map
     const unsigned ntile = jblocks(nseg, per_tile), nblk = (unsigned)std::min<int64_t>((int64_t)ntile, (int64_t)cx.num_cus * 2);
     { KernelTimer t("json_parse_tiles"); json_parse_tiles<<<nblk, JT_THREADS, 0, st>>>(pp, per_tile, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+    }
     { KernelTimer t("json_parse_listed"); json_parse_listed_lean<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1, ptr<uint32_t>(heavy), ptr<uint32_t>(heavy) + 1);
       json_parse_listed<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(heavy), ptr<uint32_t>(heavy) + 1); }
     static const bool dbg = [] { const char *e = std::getenv("TFGPU_JSON_TILE_DEBUG"); return e && e[0] == '1'; }();
     if (dbg) {  // how many lines the tile path handed over (diagnostics only: costs a synchronisation)
       const uint32_t *a = d2h_u32(slow->p), *b = d2h_u32(heavy->p);
       tf::sync();
-      std::fprintf(stderr, "[tfgpu] json tiles: %lld lines, %d per tile, %u to the per-line parser, %u of them to the map emitter\n", (long long)nseg, (int)per_tile, *a, *b);
+      std::fprintf(stderr, "[tfgpu] json tiles: %lld lines, %d per tile, %u to the per-line parser, %u of them to the map emitter\n", (long long)nseg, (int)used_per_tile, *a, *b);
     }
   }
   else if (nlines && (!wavepath || tskv)) {
