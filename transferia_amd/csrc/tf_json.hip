@@ -38,6 +38,7 @@
 #include "tf_wave.hpp"
 #include "tf_swar.hpp"
 #include "tf_jsontile.hpp"
+#include "tf_jsonquick.hpp"
 
 namespace tf {
 

@@ -23,6 +23,7 @@
 
 #include "tf_jsonscan.hpp"
 #include "tf_jsontile.hpp"
+#include "tf_jsonquick.hpp"
 
 namespace tf {
 namespace sr {
@@ -44,6 +45,7 @@ struct Params {
   uint32_t *nerr;
   uint16_t *guess;                             // [GUESS_N]: property the m-th member of a payload matched last time (a hint, verified)
   const uint8_t *nozero;                       // [nmsg] or null: 1 = no 0x00 byte after the 5-byte prefix (sr_find_zero): ONE frame to the end
+  const int64_t *ival;                         // [nprops][nframes] or null: values of `integer` cells whose span word carries VT_IVAL (sr_parse_quick)
 };
 constexpr uint32_t GUESS_N = 1024;
 
@@ -483,6 +485,8 @@ __global__ void __launch_bounds__(JT_THREADS, 4) sr_parse_tiles(Params p, int32_
   if (tid == 0 && mapst[2] * 2 > (uint32_t)nl) mapst[1] = 0;
   }  // tiles
 }
+#include "tf_srquick.inc"
+
 // the payloads the tile path hands over
 __global__ void __launch_bounds__(128) sr_parse_listed(Params p, const uint32_t *slow_n, const uint32_t *slow_f) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,7 +562,12 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
   c.valid8[r] = nil ? 0 : 1;
   switch (c.json_type) {
     case TFGPU_SRT_BOOLEAN: ((uint8_t *)c.values)[r] = vt == VT_TRUE ? 1 : 0; break;
-    case TFGPU_SRT_INTEGER: { int64_t x = 0; if (!nil) number_int64(rd, vs, vl, &x); ((int64_t *)c.values)[r] = x; break; }
+    case TFGPU_SRT_INTEGER: {
+      int64_t x = 0;
+      if (!nil) { if ((vtr & 0x80u) && p.ival) x = p.ival[i]; else number_int64(rd, vs, vl, &x); }  // VT_IVAL: converted while the payload was in LDS
+      ((int64_t *)c.values)[r] = x;
+      break;
+    }
     case TFGPU_SRT_NUMBER: c.lens[r] = nil ? 0u : vl; break;
     case TFGPU_SRT_STRING:
       if (nil) c.lens[r] = 0;
@@ -712,6 +721,7 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
   p.props = ptr<sr::Prop>(bprops); p.nprops = np; p.names = ptr<uint8_t>(bnames);
   p.vrec = ptr<uint64_t>(vrec);
   p.status = ptr<uint8_t>(status); p.keep = ptr<uint32_t>(keep); p.nerr = ptr<uint32_t>(nerr);
+  Buf bmap, bival;  // sr_parse_quick's member map and the integer cells it converts in LDS
   Buf guess = dalloc(sr::GUESS_N * 2 + 16);
   TF_HIP(hipMemsetAsync(guess->p, 0xFF, sr::GUESS_N * 2, st));
   p.guess = ptr<uint16_t>(guess);
@@ -722,15 +732,28 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
       const int32_t per_tile = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(JT_BYTES - 16) * 8 / (avg * 9), 1), (uint64_t)JT_LINES);
       Buf slow = dalloc((size_t)(nf + 1) * 4 + 16);
       TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
+      static const int ablate = [] { const char *e = std::getenv("TFGPU_JT_ABLATE"); return e ? std::atoi(e) : 0; }();
+      static const bool quick_off = [] { const char *e = std::getenv("TFGPU_SR_QUICK"); return e && e[0] == '0'; }();  // 0: the round-2 tile kernel (A/B runs, cross-check)
+      int32_t used_per_tile = per_tile;
+      if (!quick_off && np <= JQ_MEM) {
+        const int32_t qper = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(JQ_BYTES - 16) * 8 / (avg * 9), 1), (uint64_t)JQ_LINES);
+        used_per_tile = qper;
+        bmap = dalloc(sizeof(sr::SrqMap));
+        bival = dalloc((size_t)std::max(np, 1) * (size_t)nfa * 8 + 16);
+        p.ival = ptr<int64_t>(bival);
+        { KernelTimer t("sr_quick_map"); sr::sr_quick_map<<<1, JQ_THREADS, 0, st>>>(p, ptr<sr::SrqMap>(bmap)); }
+        { KernelTimer t("sr_parse_quick"); sr::sr_parse_quick<<<sr::nblk(nf, qper), JQ_THREADS, 0, st>>>(p, ptr<sr::SrqMap>(bmap), qper, ptr<int64_t>(bival), ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1, ablate); }
+      } else {
       const unsigned ntile = sr::nblk(nf, per_tile), nb = (unsigned)std::min<int64_t>((int64_t)ntile, (int64_t)cx.num_cus * 2);
-      { KernelTimer t("sr_parse_tiles"); static const int ablate = [] { const char *e = std::getenv("TFGPU_JT_ABLATE"); return e ? std::atoi(e) : 0; }();
+      { KernelTimer t("sr_parse_tiles");
         sr::sr_parse_tiles<<<nb, JT_THREADS, 0, st>>>(p, per_tile, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1, ablate); }
+      }
       { KernelTimer t("sr_parse_frames"); sr::sr_parse_listed<<<sr::nblk(nf, 128), 128, 0, st>>>(p, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
       static const bool dbg = [] { const char *e = std::getenv("TFGPU_JSON_TILE_DEBUG"); return e && e[0] == '1'; }();
       if (dbg) {
         const uint32_t *a = d2h_u32(slow->p);
         tf::sync();
-        std::fprintf(stderr, "[tfgpu] sr tiles: %lld frames, %d per tile, %u to parse_frame\n", (long long)nf, (int)per_tile, *a);
+        std::fprintf(stderr, "[tfgpu] sr tiles: %lld frames, %d per tile, %u to parse_frame\n", (long long)nf, (int)used_per_tile, *a);
       }
     } else
     { KernelTimer t("sr_parse_frames"); sr::sr_parse_frames<<<sr::nblk(nf, 128), 128, 0, st>>>(p); }
