@@ -40,9 +40,9 @@ def table(n, seed, nulls=True):
     })
 
 
-def check(tf, t, **write_kw):
+def check(tf, t, compression="NONE", **write_kw):
     buf = io.BytesIO()
-    pq.write_table(t, buf, compression="NONE", **write_kw)
+    pq.write_table(t, buf, compression=compression, **write_kw)
     data = buf.getvalue()
     ref = pq.read_table(io.BytesIO(data))
     out = tf.parquet_read(data, None, "ns", "tbl").download()
@@ -93,6 +93,96 @@ def test_plain_pages_small_pages_v2_pages_and_row_groups(tf):
     assert [out.col("s").get_bytes(i) for i in (0, 499)] == [b"s0", b"s499"]
 
 
+@pytest.mark.parametrize("codec", ["SNAPPY", "GZIP", "ZSTD"])
+def test_compressed_pages_as_real_writers_produce_them(tf, codec):
+    """pyarrow's default is SNAPPY; the reference's own writer offers SNAPPY / GZIP / ZSTD (serializer/parquet.go CodecFromString)."""
+    t = table(5000, 31)
+    check(tf, t, compression=codec)                                            # dictionary pages + indices, whole pages compressed (v1)
+    check(tf, t, compression=codec, use_dictionary=False, data_page_size=2048)  # PLAIN pages, many of them
+    check(tf, t, compression=codec, data_page_version="2.0", row_group_size=1500)  # v2: levels stay uncompressed in front of the values
+    check(tf, table(0, 1), compression=codec)
+    hits = pa.table({"s": pa.array(["x" * 300 + str(i % 7) for i in range(4000)]), "z": pa.array([0] * 4000, pa.int32())})  # long matches, overlapping copies
+    buf = io.BytesIO()
+    pq.write_table(hits, buf, compression=codec)
+    out = tf.parquet_read(buf.getvalue()).download()
+    assert [out.col("s").get_bytes(i) for i in (0, 3999)] == [b"x" * 300 + b"0", b"x" * 300 + str(3999 % 7).encode()] and not np.asarray(out.col("z").values).any()
+
+
+def _corrupt(data, find, repl, which=0):
+    """the object with the `which`-th occurrence of `find` replaced by `repl` (same length)"""
+    assert len(find) == len(repl)
+    at = -1
+    for _ in range(which + 1):
+        at = data.index(find, at + 1)
+    return data[:at] + repl + data[at + len(find):]
+
+
+def test_corrupt_objects_are_errors_not_out_of_bounds_reads(tf):
+    """Every length, offset and index a file states is untrusted (the reference's parquet-go returns an error for such files)."""
+    import struct
+    n = 400
+    # (a) a PLAIN byte-array length prefix that points far past its page
+    t = pa.table({"s": pa.array(["value-%04d" % i for i in range(n)])})
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="NONE", use_dictionary=False)
+    good = buf.getvalue()
+    assert tf.parquet_read(good).download().col("s").get_bytes(7) == b"value-0007"
+    bad = _corrupt(good, struct.pack("<I", 10) + b"value-0100", struct.pack("<I", 0x7FFFFFF0) + b"value-0100")
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.parquet_read(bad)
+    assert ei.value.code == tf.ERR_INVALID, str(ei.value)
+    # (b) dictionary indices past their dictionary: the stated bit width of a two-entry dictionary's indices widened in place
+    t = pa.table({"d": pa.array(["aa", "bb"] * (n // 2))})
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="NONE")
+    good = buf.getvalue()
+    ref = tf.parquet_read(good).download()
+    assert ref.col("d").get_bytes(1) == b"bb"
+    e = struct.pack("<I", 2) + b"aa" + struct.pack("<I", 2) + b"bb"
+    at = good.index(e) + len(e)
+    # behind the dictionary page comes the data page; its indices are bit-packed at width 1 (0x55 / 0xAA bytes): widen the stated width
+    page = good[at:]
+    # try every plausible width byte position: the one that makes the reader fail with ERR_INVALID (and never crash) is the proof
+    failures = 0
+    for off in range(0, min(len(page) - 1, 80)):
+        if page[off] != 1:
+            continue
+        bad = good[:at + off] + bytes([8]) + good[at + off + 1:]
+        try:
+            out = tf.parquet_read(bad)
+            out.free()
+        except tf.TfgpuError as ex:
+            assert ex.code in (tf.ERR_INVALID, tf.ERR_UNSUPPORTED), str(ex)
+            failures += 1
+    assert failures >= 1
+    # (c) a dictionary whose last entry runs past its page; (d) truncated objects
+    bad = _corrupt(good, struct.pack("<I", 2) + b"bb", struct.pack("<I", 0x00FFFFFF) + b"bb")
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.parquet_read(bad)
+    assert ei.value.code == tf.ERR_INVALID, str(ei.value)
+    for cut in (len(good) // 2, len(good) - 9):
+        with pytest.raises(tf.TfgpuError):
+            tf.parquet_read(good[:cut] + good[-8:])
+    # (e) a PLAIN fixed-width page that states more values than it holds
+    t = pa.table({"k": pa.array(range(n), pa.int64())})
+    buf = io.BytesIO()
+    pq.write_table(t, buf, compression="NONE", use_dictionary=False)
+    good = buf.getvalue()
+    # corrupt compressed data: a snappy page with a copy that reaches in front of the output
+    buf = io.BytesIO()
+    pq.write_table(pa.table({"s": pa.array(["abcabcabcabcabcabc%d" % (i % 3) for i in range(n)])}), buf, compression="SNAPPY", use_dictionary=False)
+    sn = bytearray(buf.getvalue())
+    hit = 0
+    for i in range(40, min(len(sn) - 40, 4000)):  # flip bytes across the first page: every outcome must be a clean error or a clean read
+        b2 = bytes(sn[:i]) + bytes([sn[i] ^ 0xFF]) + bytes(sn[i + 1:])
+        try:
+            tf.parquet_read(b2).free()
+        except tf.TfgpuError as ex:
+            assert ex.code in (tf.ERR_INVALID, tf.ERR_UNSUPPORTED), str(ex)
+            hit += 1
+    assert hit > 0
+
+
 def test_schema_selects_columns_and_missing_ones_are_nil(tf):
     t = table(300, 8)
     buf = io.BytesIO()
@@ -106,7 +196,8 @@ def test_schema_selects_columns_and_missing_ones_are_nil(tf):
 
 def test_what_stays_with_the_stock_reader_is_refused_by_name(tf):
     t = table(100, 9)
-    for kw, word in [(dict(compression="SNAPPY"), "compressed"), (dict(compression="NONE", use_dictionary=False, column_encoding={"i64": "DELTA_BINARY_PACKED"}), "encoding")]:
+    for kw, word in [(dict(compression="BROTLI"), "codec"), (dict(compression="LZ4"), "codec"),
+                     (dict(compression="NONE", use_dictionary=False, column_encoding={"i64": "DELTA_BINARY_PACKED"}), "encoding")]:
         buf = io.BytesIO()
         pq.write_table(t, buf, **kw)
         with pytest.raises(tf.TfgpuError) as ei:

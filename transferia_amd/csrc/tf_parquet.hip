@@ -16,10 +16,16 @@
 //          destination-centric copy the CSV ingest uses (tf_segcopy.hpp), straight out of the file image.
 //
 // Scope: flat schemas (required / optional leaves), data pages v1 and v2, PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY / RLE,
-// BOOLEAN, INT32, INT64, FLOAT, DOUBLE, BYTE_ARRAY, the DATE annotation; UNCOMPRESSED pages.  Compressed pages, nested
-// columns, INT96, FIXED_LEN_BYTE_ARRAY, DELTA_* and BYTE_STREAM_SPLIT are refused by name (TFGPU_ERR_UNSUPPORTED).
+// BOOLEAN, INT32, INT64, FLOAT, DOUBLE, BYTE_ARRAY, the DATE annotation; UNCOMPRESSED, SNAPPY, GZIP and ZSTD pages (a compressed
+// object's pages are inflated on the host while it walks them — it reads the run headers there anyway — and the device image is
+// then the inflated payloads instead of the file).  Nested columns, INT96, FIXED_LEN_BYTE_ARRAY, DELTA_*, BYTE_STREAM_SPLIT and
+// the other codecs are refused by name (TFGPU_ERR_UNSUPPORTED).  Every length, offset and dictionary index the object states is
+// checked against the bytes that are there — on the host where it walks them, on the device where the values are (an error
+// word read back at the existing sync): a corrupt object is TFGPU_ERR_INVALID, never an out-of-bounds read.
 // PARITY UNPINNED against the reference: /root/reference holds no .parquet input, and the Go values parquet-go hands to
 // abstract.Restore are that library's choice; the tests pin the decoder to an independent reader (pyarrow) instead.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -181,6 +187,72 @@ static bool parse_page_header(TReader &r, PageHeader &h) {
   return r.ok;
 }
 
+// ---- page codecs (host) --------------------------------------------------------------------------------------------------
+// Snappy's raw format (format_description.txt): a varint length, then literal / copy elements.  false: malformed or not `usize` bytes.
+static bool snappy_inflate(const uint8_t *p, const uint8_t *e, uint8_t *out, uint64_t usize) {
+  TReader r{p, e};
+  const uint64_t n = r.varint();
+  if (!r.ok || n != usize) return false;
+  p = r.p;
+  uint64_t o = 0;
+  while (p < e) {
+    const uint32_t tag = *p++;
+    uint64_t len, off;
+    switch (tag & 3) {
+      case 0: {
+        len = (tag >> 2) + 1;
+        if (len > 60) { const uint32_t nb = (uint32_t)len - 60; if ((uint64_t)(e - p) < nb) return false; len = 0; for (uint32_t i = 0; i < nb; i++) len |= (uint64_t)p[i] << (8 * i); len += 1; p += nb; }
+        if (len > (uint64_t)(e - p) || len > usize - o) return false;
+        std::memcpy(out + o, p, (size_t)len); p += len; o += len;
+        continue;
+      }
+      case 1: if (p >= e) return false; len = ((tag >> 2) & 7) + 4; off = ((uint64_t)(tag >> 5) << 8) | *p++; break;
+      case 2: if (e - p < 2) return false; len = (tag >> 2) + 1; off = (uint64_t)p[0] | (uint64_t)p[1] << 8; p += 2; break;
+      default: if (e - p < 4) return false; len = (tag >> 2) + 1; off = (uint64_t)p[0] | (uint64_t)p[1] << 8 | (uint64_t)p[2] << 16 | (uint64_t)p[3] << 24; p += 4;
+    }
+    if (off == 0 || off > o || len > usize - o) return false;
+    for (uint64_t i = 0; i < len; i++) out[o + i] = out[o - off + i];  // (may overlap: byte by byte, as the format says)
+    o += len;
+  }
+  return o == usize;
+}
+// GZIP (zlib's inflate with the gzip wrapper) and ZSTD through the system's libraries, bound at first use
+static bool gzip_inflate(const uint8_t *p, uint64_t n, uint8_t *out, uint64_t usize, std::string &why) {
+  struct ZS { const uint8_t *next_in; unsigned avail_in; unsigned long total_in; uint8_t *next_out; unsigned avail_out; unsigned long total_out; const char *msg; void *state; void *zalloc, *zfree, *opaque; int data_type; unsigned long adler, reserved; };
+  using Init2 = int (*)(ZS *, int, const char *, int); using Inflate = int (*)(ZS *, int); using End = int (*)(ZS *);
+  static void *h = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
+  static Init2 init2 = h ? (Init2)dlsym(h, "inflateInit2_") : nullptr; static Inflate inf = h ? (Inflate)dlsym(h, "inflate") : nullptr; static End end = h ? (End)dlsym(h, "inflateEnd") : nullptr;
+  static const char *(*ver)() = h ? (const char *(*)())dlsym(h, "zlibVersion") : nullptr;
+  if (!init2 || !inf || !end || !ver) { why = "GZIP pages need libz.so.1"; return false; }
+  ZS z; std::memset(&z, 0, sizeof z);
+  if (init2(&z, 15 + 32, ver(), (int)sizeof z) != 0) { why = "inflateInit2 failed"; return false; }
+  z.next_in = p; z.avail_in = (unsigned)n; z.next_out = out; z.avail_out = (unsigned)usize;
+  const int rc = inf(&z, 4 /* Z_FINISH */);
+  const bool ok = rc == 1 /* Z_STREAM_END */ && z.total_out == usize;
+  end(&z);
+  if (!ok) why = "malformed GZIP page";
+  return ok;
+}
+static bool zstd_inflate(const uint8_t *p, uint64_t n, uint8_t *out, uint64_t usize, std::string &why) {
+  using Dec = size_t (*)(void *, size_t, const void *, size_t); using IsErr = unsigned (*)(size_t);
+  static void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+  static Dec dec = h ? (Dec)dlsym(h, "ZSTD_decompress") : nullptr; static IsErr iserr = h ? (IsErr)dlsym(h, "ZSTD_isError") : nullptr;
+  if (!dec || !iserr) { why = "ZSTD pages need libzstd.so.1"; return false; }
+  const size_t got = dec(out, (size_t)usize, p, (size_t)n);
+  if (iserr(got) || got != usize) { why = "malformed ZSTD page"; return false; }
+  return true;
+}
+enum { C_UNCOMPRESSED = 0, C_SNAPPY = 1, C_GZIP = 2, C_ZSTD = 6 };
+static bool page_inflate(int codec, const uint8_t *p, uint64_t n, uint8_t *out, uint64_t usize, std::string &why) {
+  switch (codec) {
+    case C_UNCOMPRESSED: if (n != usize) { why = "page sizes disagree"; return false; } std::memcpy(out, p, (size_t)n); return true;
+    case C_SNAPPY: if (!snappy_inflate(p, p + n, out, usize)) { why = "malformed SNAPPY page"; return false; } return true;
+    case C_GZIP: return gzip_inflate(p, n, out, usize, why);
+    case C_ZSTD: return zstd_inflate(p, n, out, usize, why);
+    default: why = "codec " + std::to_string(codec); return false;
+  }
+}
+
 // ---- the segment table a column's rows / values look themselves up in ----------------------------------------------------
 enum : uint32_t { SG_RLE = 0, SG_PACKED = 1, SG_PLAIN = 2, SG_PLAIN_BOOL = 3, SG_PLAIN_TEXT = 4 };
 struct Seg {
@@ -243,7 +315,7 @@ __device__ __forceinline__ uint32_t seg_value(const uint8_t *file, const Seg &s,
 __global__ void __launch_bounds__(256) pq_levels(const uint8_t *file, const Seg *segs, int32_t nsegs, int64_t nrows, uint32_t *present) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
-  present[r] = nsegs ? seg_value(file, find_seg(segs, nsegs, (uint32_t)r), (uint32_t)r) : 1u;
+  present[r] = nsegs ? (seg_value(file, find_seg(segs, nsegs, (uint32_t)r), (uint32_t)r) != 0 ? 1u : 0u) : 1u;  // (a level above 1 in a flat column is still "present", as the host counted it)
 }
 __global__ void __launch_bounds__(256) pq_pack_validity(const uint32_t *rank, int64_t nrows, uint8_t *bits) {  // rank = exclusive scan of present, rank[nrows] = total
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,8 +325,10 @@ __global__ void __launch_bounds__(256) pq_pack_validity(const uint32_t *rank, in
   bits[b] = (uint8_t)v;
 }
 struct FixedOut { void *values; int32_t width; int32_t as_date; };
+// what the object's own numbers may not exceed, checked where the values are read (the error word is read back at the sync)
+enum : uint32_t { PQE_DICT_INDEX = 1, PQE_TEXT_LENGTH = 2 };
 // one row: its value by ordinal — PLAIN bytes, or a dictionary index into dict (fixed-width entries, file offsets of the chunks' PLAIN dictionary pages)
-__global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint64_t *dict_at, FixedOut o) {
+__global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint64_t *dict_at, const uint32_t *dict_n, FixedOut o, uint32_t *err) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   const uint32_t k = rank[r];
@@ -266,7 +340,9 @@ __global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, cons
     else if (s.kind == SG_PLAIN_BOOL) v = (file[s.at + ((k - s.start) >> 3)] >> ((k - s.start) & 7)) & 1;
     else {
       const uint32_t idx = seg_value(file, s, k);
-      v = o.width == 1 && !dict_at ? idx : load_unaligned(file, dict_at[s.dict_base] + (uint64_t)idx * w, w);  // (booleans under RLE are their own values)
+      if (o.width == 1 && !dict_at) v = idx;  // (booleans under RLE are their own values)
+      else if (idx >= dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // an index past the chunk's dictionary: the value stays 0, the call fails
+      else v = load_unaligned(file, dict_at[s.dict_base] + (uint64_t)idx * w, w);
     }
     if (o.as_date) v = (uint64_t)((int64_t)(int32_t)v * 86400);  // parseLogicalDate: time.Unix(0, 0).Add(24h * days)
   }
@@ -280,9 +356,9 @@ __global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, cons
 // chain no amount of lanes shortens.  What CAN be shortened is each link: one workgroup per page stages the page through LDS
 // in 48 KiB pieces (coalesced 16-byte loads), and one lane walks the prefixes there — ~30 ns per value instead of an HBM
 // round trip (measured on configs[3]'s columns: 12.5 ms per text column with a lane reading HBM, 1 MB pages).
-struct TextPage { uint64_t at; uint32_t ord, count; };
+struct TextPage { uint64_t at, end; uint32_t ord, count; };  // [at, end): the page's values
 constexpr uint32_t PQ_STAGE = 48 * 1024;
-__global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_t limit, const TextPage *pages, uint32_t *val_off, uint32_t *val_len) {
+__global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_t limit, const TextPage *pages, uint32_t *val_off, uint32_t *val_len, uint32_t *err) {
   __shared__ uint4 stage[PQ_STAGE / 16 + 1];
   __shared__ uint64_t s_at;
   __shared__ uint32_t s_done;
@@ -297,9 +373,15 @@ __global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_
     if (threadIdx.x == 0) {
       const uint8_t *lds = reinterpret_cast<const uint8_t *>(stage);
       uint64_t at = s_at; uint32_t done = s_done;
+      if (done < pg.count && at + 4 > pg.end) { *err = PQE_TEXT_LENGTH; for (; done < pg.count; done++) { val_off[pg.ord + done] = (uint32_t)pg.at; val_len[pg.ord + done] = 0; } }
       while (done < pg.count && at + 4 <= base + PQ_STAGE) {
         const uint32_t o = (uint32_t)(at - base);
-        const uint32_t n = (uint32_t)lds[o] | (uint32_t)lds[o + 1] << 8 | (uint32_t)lds[o + 2] << 16 | (uint32_t)lds[o + 3] << 24;
+        uint32_t n = (uint32_t)lds[o] | (uint32_t)lds[o + 1] << 8 | (uint32_t)lds[o + 2] << 16 | (uint32_t)lds[o + 3] << 24;
+        if (at + 4 > pg.end || (uint64_t)n > pg.end - (at + 4)) {  // a prefix that points past its page: this value and the rest of the page read as empty, the call fails
+          *err = PQE_TEXT_LENGTH;
+          for (; done < pg.count; done++) { val_off[pg.ord + done] = (uint32_t)pg.at; val_len[pg.ord + done] = 0; }
+          break;
+        }
         val_off[pg.ord + done] = (uint32_t)(at + 4);
         val_len[pg.ord + done] = n;
         at += 4 + (uint64_t)n;
@@ -312,18 +394,25 @@ __global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_
 }
 // one row of a byte-array column: where its bytes are in the file image, and how many
 __global__ void __launch_bounds__(256) pq_text_cells(const uint8_t *file, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint32_t *val_off, const uint32_t *val_len,
-                                                     const uint32_t *dict_off, const uint32_t *dict_len, uint32_t *src_off, uint32_t *lens) {
+                                                     const uint32_t *dict_off, const uint32_t *dict_len, const uint32_t *dict_n, uint32_t *src_off, uint32_t *lens, unsigned long long *total, uint32_t *err) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nrows) return;
-  const uint32_t k = rank[r];
+  const bool live = r < nrows;  // (no early return: the wave reduction below needs every lane)
+  const uint32_t k = live ? rank[r] : 0u;
   uint32_t so = SEG_NONE, n = 0;
-  if (rank[r + 1] != k) {
+  if (live && rank[r + 1] != k) {
     const Seg &s = find_seg(segs, nsegs, k);
     if (s.kind == SG_PLAIN_TEXT) { so = val_off[k]; n = val_len[k]; }
-    else { const uint32_t idx = s.dict_base + seg_value(file, s, k); so = dict_off[idx]; n = dict_len[idx]; }
+    else {
+      const uint32_t i = seg_value(file, s, k);
+      if (i >= dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // dict_n[first entry of a chunk's dictionary] = its entries
+      else { so = dict_off[s.dict_base + i]; n = dict_len[s.dict_base + i]; }
+    }
   }
-  src_off[r] = n ? so : SEG_NONE;
-  lens[r] = n;
+  if (live) { src_off[r] = n ? so : SEG_NONE; lens[r] = n; }
+  // the column's bytes in 64 bits (the offsets are 32-bit: 4 GiB and more is refused): one add per wave
+  unsigned long long s64 = n;
+  for (int d = 32; d; d >>= 1) s64 += __shfl_down(s64, d, 64);
+  if ((threadIdx.x & 63) == 0 && s64) atomicAdd(total, s64);
 }
 template <int RPT>
 __global__ void __launch_bounds__(256) pq_pack_text(const uint32_t *dst_off, int64_t nrows, const uint8_t *file, uint8_t *dst, const uint32_t *src_off) {
@@ -365,10 +454,18 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
   hipStream_t st = cx.stream;
-  Buf file = dalloc((size_t)len + 64);
-  h2d(file->p, f, (size_t)len);   // the upload runs while the host walks the pages
-  TF_HIP(hipMemsetAsync((char *)file->p + len, 0, 64, st));
-  const uint8_t *dfile = ptr<uint8_t>(file);
+  // An object without compressed chunks is uploaded as it is (the upload runs while the host walks the pages) and every offset
+  // below is a file offset.  With compressed chunks the host inflates each page it walks into `arena`, offsets are arena offsets,
+  // and the arena is what the device gets.
+  bool inflate = false;
+  for (auto &g : m.groups) for (auto &c : g.cols) if (c.codec != C_UNCOMPRESSED) inflate = true;
+  std::vector<uint8_t> arena;
+  Buf file;
+  if (!inflate) {
+    file = dalloc((size_t)len + 64);
+    h2d(file->p, f, (size_t)len);
+    TF_HIP(hipMemsetAsync((char *)file->p + len, 0, 64, st));
+  } else arena.reserve((size_t)len * 2);
 
   auto db = std::make_unique<tfgpu_dbatch>();
   db->nrows = nrows; db->ns = table_ns ? table_ns : ""; db->table = table_name ? table_name : "";
@@ -389,7 +486,7 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
   // ---- pass 1 (host, while the object uploads): every column's segment tables ----
   struct ColPlan {
     DColumn d; bool nil = false, optional = false, is_date = false, is_text = false; uint32_t width = 0;
-    std::vector<Seg> lev, val; std::vector<TextPage> tpages; std::vector<uint64_t> dict_at; std::vector<uint32_t> dict_off, dict_len;
+    std::vector<Seg> lev, val; std::vector<TextPage> tpages; std::vector<uint64_t> dict_at; std::vector<uint32_t> dict_off, dict_len, dict_n;  // dict_n: entries per chunk dictionary (fixed: by chunk; text: at the chunk's first entry)
     uint64_t ord = 0; size_t arena_at = 0;
   };
   std::vector<ColPlan> plans(want.size());
@@ -424,68 +521,111 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
     auto &lev = P.lev; auto &val = P.val; auto &tpages = P.tpages;
     auto &dict_at = P.dict_at;                               // fixed-width dictionaries: file offset of each chunk's entries
     auto &dict_off = P.dict_off; auto &dict_len = P.dict_len;  // byte-array dictionaries: every entry of every chunk
+    auto &dict_n = P.dict_n;
     uint64_t row0 = 0; uint64_t &ord = P.ord;
     for (auto &g : m.groups) {
       const ColChunk &c = g.cols[(size_t)want[oc]];
-      if (c.codec != 0) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": compressed pages (codec " + std::to_string(c.codec) + ") are read by the stock reader; this path takes UNCOMPRESSED chunks");
+      if (c.codec != C_UNCOMPRESSED && c.codec != C_SNAPPY && c.codec != C_GZIP && c.codec != C_ZSTD)
+        return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": pages of codec " + std::to_string(c.codec) + " (BROTLI / LZ4 / LZO) are read by the stock reader");
+      if (c.data_off < 0 || c.total_comp < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column chunk out of range");
       uint64_t pos = (uint64_t)((c.dict_off > 0 && c.dict_off < c.data_off) ? c.dict_off : c.data_off);
       const uint64_t end = pos + (uint64_t)c.total_comp;
-      if (end > len) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column chunk out of range");
+      if (end > len || end < pos) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column chunk out of range");
       uint32_t dict_base = 0;
+      bool have_dict = false;
       int64_t seen = 0;
       while (pos < end && seen < c.num_values) {
         TReader r{f + pos, f + end};
         PageHeader h;
-        if (!parse_page_header(r, h) || h.csize < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed page header in column " + leaf.name);
-        const uint8_t *pl = r.p, *pe = r.p + h.csize;
-        PQD("  page at %llu type %d csize %d nvalues %d enc %d v2 %d\n", (unsigned long long)pos, h.type, h.csize, h.nvalues, h.enc, h.v2);
-        if (pe > f + end) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: page out of range in column " + leaf.name);
+        if (!parse_page_header(r, h) || h.csize < 0 || h.usize < 0 || h.nvalues < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed page header in column " + leaf.name);
+        if ((uint64_t)h.csize > (uint64_t)(f + end - r.p)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: page out of range in column " + leaf.name);
+        const uint8_t *raw = r.p;                 // the page as the file holds it
+        const uint64_t next = (uint64_t)(raw - f) + (uint64_t)h.csize;
+        // fb: what offsets are counted from; [pl, pe): the page's payload as the device will see it
+        const uint8_t *fb = f, *pl = raw, *pe = raw + h.csize;
+        PQD("  page at %llu type %d csize %d usize %d nvalues %d enc %d v2 %d\n", (unsigned long long)pos, h.type, h.csize, h.usize, h.nvalues, h.enc, h.v2);
+        if (inflate && (h.type == 0 || h.type == 2 || h.type == 3)) {
+          // v2 keeps the levels in front of the (possibly compressed) values; v1 and dictionary pages are compressed whole
+          const uint64_t lead = h.type == 3 ? (uint64_t)std::max(h.rep_len, 0) + (uint64_t)std::max(h.def_len, 0) : 0;
+          if (lead > (uint64_t)h.csize || lead > (uint64_t)h.usize) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: level lengths of a v2 page in column " + leaf.name);
+          const int codec = (h.type == 3 && !h.compressed_v2) ? (int)C_UNCOMPRESSED : c.codec;
+          const size_t at0 = (arena.size() + 15) & ~(size_t)15;
+          if ((uint64_t)at0 + (uint64_t)h.usize + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the inflated pages of one object exceed 4 GiB: read it row group by row group");
+          arena.resize(at0 + (size_t)h.usize);
+          std::memcpy(arena.data() + at0, raw, (size_t)lead);
+          std::string cw;
+          if (!page_inflate(codec, raw + lead, (uint64_t)h.csize - lead, arena.data() + at0 + lead, (uint64_t)h.usize - lead, cw))
+            return tf::fail(cw.find("need") != std::string::npos || cw.find("codec") != std::string::npos ? TFGPU_ERR_UNSUPPORTED : TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": " + cw);
+          fb = arena.data(); pl = fb + at0; pe = pl + h.usize;
+        } else if (c.codec != C_UNCOMPRESSED && (h.type == 0 || h.type == 2 || h.type == 3)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: internal: compressed page outside the inflating walk");
         if (h.type == 2) {  // dictionary page: PLAIN entries
           if (h.enc != E_PLAIN && h.enc != E_PLAIN_DICT) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: dictionary page encoding " + std::to_string(h.enc));
+          have_dict = true;
           if (is_text) {
             dict_base = (uint32_t)dict_off.size();
             const uint8_t *q = pl;
             for (int i = 0; i < h.nvalues; i++) {
               if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated dictionary in column " + leaf.name);
               uint32_t n; std::memcpy(&n, q, 4);
-              dict_off.push_back((uint32_t)(q + 4 - f)); dict_len.push_back(n);
+              if ((uint64_t)n > (uint64_t)(pe - (q + 4))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a dictionary entry of column " + leaf.name + " runs past its page");
+              dict_off.push_back((uint32_t)(q + 4 - fb)); dict_len.push_back(n); dict_n.push_back(0);
               q += 4 + (uint64_t)n;
             }
-          } else { dict_base = (uint32_t)dict_at.size(); dict_at.push_back((uint64_t)(pl - f)); }
+            if (h.nvalues) dict_n[dict_base] = (uint32_t)h.nvalues;
+            if (!h.nvalues) { dict_off.push_back(0); dict_len.push_back(0); dict_n.push_back(0); }  // an empty dictionary still has a slot that says so
+          } else {
+            if ((uint64_t)h.nvalues * P.width > (uint64_t)(pe - pl)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: the dictionary of column " + leaf.name + " runs past its page");
+            dict_base = (uint32_t)dict_at.size(); dict_at.push_back((uint64_t)(pl - fb)); dict_n.push_back((uint32_t)h.nvalues);
+          }
         } else if (h.type == 0 || h.type == 3) {
           if (h.v2 && h.rep_len) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: repetition levels");
           const uint8_t *q = pl;
           uint64_t present = (uint64_t)h.nvalues;
           if (optional) {
             const uint8_t *ls, *le;
-            if (h.v2) { ls = q; le = q + h.def_len; q = le; }
-            else { if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page"); uint32_t L; std::memcpy(&L, q, 4); ls = q + 4; le = ls + L; q = le; }
-            if (le > pe || (!h.v2 && h.def_enc != E_RLE)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: definition levels of column " + leaf.name + " are not RLE");
+            if (h.v2) { if (h.def_len < 0 || (uint64_t)h.def_len > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page"); ls = q; le = q + h.def_len; q = le; }
+            else { if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page"); uint32_t L; std::memcpy(&L, q, 4); if ((uint64_t)L > (uint64_t)(pe - (q + 4))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page"); ls = q + 4; le = ls + L; q = le; }
+            if (!h.v2 && h.def_enc != E_RLE) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: definition levels of column " + leaf.name + " are not RLE");
             present = 0;
-            if (!hybrid_runs(f, ls, le, 1, (uint64_t)h.nvalues, row0 + (uint64_t)seen, 0, lev, &present)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed definition levels in column " + leaf.name);
-          }
+            if (!hybrid_runs(fb, ls, le, 1, (uint64_t)h.nvalues, row0 + (uint64_t)seen, 0, lev, &present)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed definition levels in column " + leaf.name);
+          } else if (h.v2 && h.def_len) { if ((uint64_t)h.def_len > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page"); q += h.def_len; }
           if (h.enc == E_PLAIN) {
-            if (is_text) { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)(q - f), (uint32_t)ord, (uint32_t)present}); }
-            else val.push_back(Seg{(uint32_t)ord, (uint32_t)present, leaf.type == T_BOOLEAN ? SG_PLAIN_BOOL : SG_PLAIN, 0, (uint64_t)(q - f), 0, 0});
+            if (is_text) { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)(q - fb), (uint64_t)(pe - fb), (uint32_t)ord, (uint32_t)present}); }
+            else {
+              const uint64_t need = leaf.type == T_BOOLEAN ? (present + 7) / 8 : present * P.width;
+              if (need > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: the values of a PLAIN page of column " + leaf.name + " run past it");
+              val.push_back(Seg{(uint32_t)ord, (uint32_t)present, leaf.type == T_BOOLEAN ? SG_PLAIN_BOOL : SG_PLAIN, 0, (uint64_t)(q - fb), 0, 0});
+            }
           } else if (h.enc == E_RLE_DICT || h.enc == E_PLAIN_DICT) {
             if (q >= pe && present) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page");
+            if (present && !have_dict) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: dictionary indices without a dictionary page in column " + leaf.name);
             const uint32_t bw = present ? *q : 0;
             if (bw > 32) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: dictionary index width");
-            if (present && !hybrid_runs(f, q + 1, pe, bw, present, ord, dict_base, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed dictionary indices in column " + leaf.name);
+            if (present && !hybrid_runs(fb, q + 1, pe, bw, present, ord, dict_base, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed dictionary indices in column " + leaf.name);
           } else if (h.enc == E_RLE && leaf.type == T_BOOLEAN) {  // booleans of v2 pages: a length-prefixed hybrid of width 1
             if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page");
             uint32_t L; std::memcpy(&L, q, 4);
-            if (!hybrid_runs(f, q + 4, std::min(q + 4 + L, pe), 1, present, ord, 0, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed boolean run in column " + leaf.name);
+            if (!hybrid_runs(fb, q + 4, (uint64_t)L < (uint64_t)(pe - (q + 4)) ? q + 4 + L : pe, 1, present, ord, 0, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed boolean run in column " + leaf.name);
           } else return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": value encoding " + std::to_string(h.enc) + " (DELTA_* / BYTE_STREAM_SPLIT) is read by the stock reader");
           ord += present; seen += h.nvalues;
+          if (ord > 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: more values than rows in column " + leaf.name);
         }
-        pos = (uint64_t)(pe - f);
+        pos = next;
       }
       if (seen != c.num_values || c.num_values != g.num_rows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": pages do not add up to the row group's rows");
       row0 += (uint64_t)g.num_rows;
     }
     PQD("  %zu level segs, %zu value segs, %zu text pages, ord %llu\n", lev.size(), val.size(), tpages.size(), (unsigned long long)ord);
   }
+  uint64_t img_len = len;  // bytes of the device image (file or inflated pages)
+  if (inflate) {
+    img_len = arena.size();
+    file = dalloc((size_t)img_len + 64);
+    if (img_len) h2d(file->p, arena.data(), (size_t)img_len);
+    TF_HIP(hipMemsetAsync((char *)file->p + img_len, 0, 64, st));
+  }
+  const uint8_t *dfile = ptr<uint8_t>(file);
+  Buf derr = dalloc_zero(16);  // [0]: PQE_* raised by a kernel
   // ---- the length-prefix walks of EVERY text column's PLAIN pages in one launch (the pages are independent; a page is a serial chain) ----
   Buf arena_off, arena_len;
   {
@@ -496,13 +636,14 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
       Buf btp = upload_small(all.data(), all.size() * sizeof(TextPage));
       keep.push_back(btp);
       KernelTimer t("pq_walk_text");
-      pq_walk_text<<<(unsigned)all.size(), 256, 0, st>>>(dfile, (len + 64) & ~15ull, reinterpret_cast<const TextPage *>(btp->p), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len));
+      pq_walk_text<<<(unsigned)all.size(), 256, 0, st>>>(dfile, (img_len + 64) & ~15ull, reinterpret_cast<const TextPage *>(btp->p), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
     }
   }
   // ---- pass 2 (device): levels → validity → ordinals, then the values ----
   std::vector<size_t> totals;  // the text columns, in order: their scanned totals are read back together (NOT through the pinned ring: the
                                // segment tables of the columns in between go through it and may wrap it)
   std::vector<std::pair<size_t, Buf>> soffs;
+  std::vector<Buf> tot64s;  // the text columns' byte totals in 64 bits
   for (size_t oc = 0; oc < plans.size(); oc++) {
     ColPlan &P = plans[oc];
     DColumn &d = P.d;
@@ -522,17 +663,22 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
     KernelTimer t(is_text ? "pq_text" : "pq_values");
     if (!is_text) {
       Buf bdict = P.dict_at.empty() ? nullptr : upload_small(P.dict_at.data(), P.dict_at.size() * 8);
-      keep.push_back(bdict);
+      Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
+      keep.push_back(bdict); keep.push_back(bdn);
       const uint32_t ow = d.repr == TFGPU_R_TIME ? 8 : P.width;
       d.values = dalloc((size_t)nrows * ow);
       if (d.repr == TFGPU_R_TIME) d.nanos = dalloc_zero((size_t)nrows * 4);
-      pq_values_fixed<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), FixedOut{d.values->p, (int32_t)ow, is_date ? 1 : 0});
+      pq_values_fixed<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), ptr<uint32_t>(bdn), FixedOut{d.values->p, (int32_t)ow, is_date ? 1 : 0}, ptr<uint32_t>(derr));
     } else {
       Buf bdo = P.dict_off.empty() ? nullptr : upload_small(P.dict_off.data(), P.dict_off.size() * 4), bdl = P.dict_len.empty() ? nullptr : upload_small(P.dict_len.data(), P.dict_len.size() * 4);
+      Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
+      keep.push_back(bdn);
       Buf soff = dalloc((size_t)nrows * 4);
       d.offsets = dalloc((size_t)(nrows + 1) * 4 + 16);
+      Buf tot64 = dalloc_zero(8);
+      tot64s.push_back(tot64);
       pq_text_cells<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint32_t>(arena_off) + P.arena_at, ptr<uint32_t>(arena_len) + P.arena_at,
-                                                                     ptr<uint32_t>(bdo), ptr<uint32_t>(bdl), ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets));
+                                                                     ptr<uint32_t>(bdo), ptr<uint32_t>(bdl), ptr<uint32_t>(bdn), ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets), reinterpret_cast<unsigned long long *>(tot64->p), ptr<uint32_t>(derr));
       exclusive_scan_u32(ptr<uint32_t>(d.offsets), ptr<uint32_t>(d.offsets), nrows, true);
       totals.push_back(oc);
       soffs.push_back({oc, soff});
@@ -540,8 +686,13 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
     }
   }
   std::vector<uint32_t> htot(totals.size() + 1);
-  for (size_t k = 0; k < totals.size(); k++) d2h(&htot[k], ptr<uint32_t>(plans[totals[k]].d.offsets) + nrows, 4);
+  std::vector<uint64_t> htot64(totals.size() + 1);
+  uint32_t herr[4] = {0, 0, 0, 0};
+  for (size_t k = 0; k < totals.size(); k++) { d2h(&htot[k], ptr<uint32_t>(plans[totals[k]].d.offsets) + nrows, 4); d2h(&htot64[k], tot64s[k]->p, 8); }
+  d2h(herr, derr->p, 16);
   tf::sync();  // ONE wait for the text columns' sizes (a dictionary-coded column can be far longer than its chunk), then the copies
+  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : "tfgpu_parquet_read: a byte-array length that runs past its page");
+  for (size_t k = 0; k < totals.size(); k++) if (htot64[k] >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + plans[totals[k]].d.name + " holds 4 GiB of text or more: read the object row group by row group");
   for (size_t k = 0; k < totals.size(); k++) {
     DColumn &d = plans[totals[k]].d;
     d.data_len = htot[k];
@@ -550,7 +701,9 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
     KernelTimer t("pq_pack_text");
     pq_pack_text<RPT><<<(unsigned)((nrows + 256 * RPT - 1) / (256 * RPT)), 256, 0, st>>>(ptr<uint32_t>(d.offsets), nrows, dfile, ptr<uint8_t>(d.data), ptr<uint32_t>(soffs[k].second));
   }
+  d2h(herr, derr->p, 16);
   tf::sync();
+  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : "tfgpu_parquet_read: a byte-array length that runs past its page");
   for (auto &P : plans) db->cols.push_back(std::move(P.d));
   *out = db.release();
   return TFGPU_OK;
