@@ -265,17 +265,21 @@ int tfgpu_dbatch_concat(const tfgpu_dbatch *const *parts, int nparts, const int6
  * wait(user, ticket, timeout_ms) = the read of its error channel (0 = pushed, TFGPU_PQ_PENDING = not yet, else the error), then
  * ack(user, msg, push_start_ns).  The first error of a parse, a push or an ack cancels the queue; Add then fails and
  * tfgpu_parsequeue_error returns that error's code and "parse queue: <stage> error: …".  parallelism 0 = 10, below 2 = 2, as
- * parsequeue.New.  Close cancels and joins; it does not wait for pending pushes (the reference's Close does not either).    */
+ * parsequeue.New.  Close cancels and joins; it does not wait for pending pushes (the reference's Close does not either).
+ * A parse result the queue never hands to push() — the queue was cancelled by an error, or closed with parses in flight — goes
+ * to release(user, parsed) during Close, when one is set (tfgpu_parsequeue_set_release); without it the shim owns those handles. */
 #define TFGPU_PQ_PENDING (-1)
 typedef struct tfgpu_parsequeue tfgpu_parsequeue;
 typedef int (*tfgpu_pq_parse_fn)(void *user, uint64_t msg, int slot, void **parsed);
 typedef int (*tfgpu_pq_push_fn)(void *user, void *parsed, uint64_t *ticket);
 typedef int (*tfgpu_pq_wait_fn)(void *user, uint64_t ticket, int64_t timeout_ms);
 typedef int (*tfgpu_pq_ack_fn)(void *user, uint64_t msg, int64_t push_start_ns);
+typedef void (*tfgpu_pq_release_fn)(void *user, void *parsed);
 int tfgpu_parsequeue_create(int parallelism, tfgpu_pq_parse_fn parse, tfgpu_pq_push_fn push, tfgpu_pq_wait_fn wait, tfgpu_pq_ack_fn ack, void *user, tfgpu_parsequeue **out);
 int tfgpu_parsequeue_add(tfgpu_parsequeue *q, uint64_t msg);
 int tfgpu_parsequeue_error(tfgpu_parsequeue *q, char *msg, size_t cap);   /* 0 = no error so far */
 int tfgpu_parsequeue_close(tfgpu_parsequeue *q);
+int tfgpu_parsequeue_set_release(tfgpu_parsequeue *q, tfgpu_pq_release_fn release);
 void tfgpu_parsequeue_destroy(tfgpu_parsequeue *q);
 
 /* tfgpu_bufferer = middlewares/synchronizer/bufferer (bufferer.go:16-249, buffer.go:26-56): pushes of device batches are
@@ -287,12 +291,17 @@ void tfgpu_parsequeue_destroy(tfgpu_parsequeue *q);
  * flush(user, merged, parts, nparts, nrows, values_size) returns the sink's error, which every buffered push's ticket then
  * carries (tfgpu_bufferer_wait; TFGPU_PQ_PENDING on a timeout, timeout_ms < 0 = wait).  The batches stay the caller's: they
  * may be freed once their ticket is answered.  async_push blocks until the collector has taken the item (the reference's
- * unbuffered input channel: backpressure).                                                                               */
+ * unbuffered input channel: backpressure).  A ticket's final answer (anything but TFGPU_PQ_PENDING) is given ONCE: the ticket is
+ * forgotten with it.  src_row of a merged batch: async_push_meta states how many rows the batch's SOURCE had (meta_rows: what its
+ * src_row counts in, e.g. the rows before a filter); when every buffered batch states it, part g's src_row is shifted by the
+ * source rows of the parts in front of it — the sink lines its row metas up the same way; when one does not (async_push), the
+ * merged batch carries no src_row at all rather than one that collides across parts (the parts keep theirs).                */
 typedef struct tfgpu_bufferer tfgpu_bufferer;
 typedef struct tfgpu_bufferer_stats { int64_t flush_all, flush_on_count, flush_on_size, flush_on_interval, flush_on_non_row; } tfgpu_bufferer_stats;
 typedef int (*tfgpu_buf_flush_fn)(void *user, const tfgpu_dbatch *merged, const tfgpu_dbatch *const *parts, int nparts, int64_t nrows, uint64_t values_size);
 int tfgpu_bufferer_create(int64_t trigging_count, uint64_t trigging_size, int64_t trigging_interval_ms, int concat_on_device, tfgpu_buf_flush_fn flush, void *user, tfgpu_bufferer **out);
 int tfgpu_bufferer_async_push(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int64_t nrows, uint64_t values_size, int has_non_row_item, uint64_t *ticket);
+int tfgpu_bufferer_async_push_meta(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int64_t nrows, uint64_t values_size, int has_non_row_item, int64_t meta_rows, uint64_t *ticket);
 int tfgpu_bufferer_wait(tfgpu_bufferer *b, uint64_t ticket, int64_t timeout_ms);
 int tfgpu_bufferer_get_stats(tfgpu_bufferer *b, tfgpu_bufferer_stats *out);
 int tfgpu_bufferer_close(tfgpu_bufferer *b);

@@ -204,11 +204,14 @@ INIT, DONE, ROW = "init_load", "done_load", "row"
 class MockSinker:
     """NewMockSinker(errors): Push returns the next error of the list (then nil) and keeps the items of successful pushes"""
 
-    def __init__(self, errors=()):
+    def __init__(self, errors=(), delay=None):
         self.items, self.errors, self.i = [], list(errors), 0
         self.mu = threading.Lock()
+        self.delay = delay   # an Event the push waits for first (a sink that takes its time)
 
     def push(self, items):
+        if self.delay is not None:
+            self.delay.wait(5)
         with self.mu:
             err = self.errors[self.i] if self.i < len(self.errors) else 0
             self.i += 1
@@ -412,6 +415,110 @@ def test_bufferer_flush_is_one_device_concat():
     L.tfgpu_bufferer_destroy.argtypes = [C.c_void_p]
     L.tfgpu_bufferer_close(h)
     L.tfgpu_bufferer_destroy(h)
+
+
+def test_bufferer_ticket_is_answered_once_and_then_forgotten():
+    """a replication pushes for days: a ticket whose final answer was fetched is gone (the collector keeps no history);
+    TFGPU_PQ_PENDING is not a final answer and keeps the ticket"""
+    release = threading.Event()
+    m = MockSinker(delay=release)
+    b = Bufferer(1, 0, 0, m)
+    t = b.async_push([ROW])
+    assert b.wait(t, 20) == PENDING and b.wait(t, 20) == PENDING   # still there
+    release.set()
+    assert b.wait(t) == 0
+    assert b.wait(t) != 0 and b.wait(t, 10) != PENDING               # unknown by now
+    tickets = [b.async_push([ROW]) for _ in range(50)]
+    assert len(set(tickets)) == 50 and [b.wait(x) for x in tickets] == [0] * 50
+    b.close()
+
+
+def test_parsequeue_releases_results_nobody_pushes():
+    """a cancelled queue drops the results of parses that were already running: they go to the release callback at Close
+    (tfgpu_parsequeue_set_release), each exactly once, and never a result that push() took"""
+    RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+    mu = threading.Lock()
+    parsed, pushed, released = set(), set(), []
+
+    def parse(u, m, s, out):
+        time.sleep(0.002)
+        with mu:
+            parsed.add(int(m) + 1)
+        out[0] = int(m) + 1
+        return 0
+
+    def push(u, p, t):
+        with mu:
+            pushed.add(int(p))
+        t[0] = int(p)
+        return 55 if int(p) == 6 else 0   # the sixth push fails: the queue is cancelled with parses in flight
+
+    def rel(u, p):
+        with mu:
+            released.append(int(p))
+    q = Queue(6, parse, push, lambda u, t, ms: 0, lambda u, m, st: 0)
+    cb = RELEASE(rel)
+    q.L.tfgpu_parsequeue_set_release.argtypes = [C.c_void_p, RELEASE]
+    assert q.L.tfgpu_parsequeue_set_release(q.h, cb) == 0
+    for i in range(200):
+        if q.add(i) != 0:
+            break
+    wait_for(lambda: q.error()[0] != 0)
+    q.close()
+    assert q.error()[0] == 55
+    assert len(released) == len(set(released)) and not (set(released) & pushed)
+    assert set(released) | pushed == parsed   # every parse result went to the sink or to the release callback
+
+
+@pytest.mark.gpu
+def test_bufferer_merged_src_row_lines_up_with_the_parts_sources():
+    """batches that come out of a row filter carry src_row into THEIR source; merged, part g's src_row is shifted by the source rows
+    of the parts in front of it when every push states them (async_push_meta), and dropped — never colliding — when one does not"""
+    lib.init()
+    L = lib.load()
+    got = []
+
+    def flush(user, merged, parts, nparts, nrows, size):
+        view = lib.DeviceBatch(C.c_void_p(merged))
+        b = view.download()
+        view._h = None
+        has_src = bool(view.view().src_row)   # (download() reads a NULL src_row as the identity: ask the view)
+        got.append((nparts, [int(x) for x in b.src_row] if has_src else None, [int(x) for x in b.cols[0].values]))
+        return 0
+    cb = FLUSH(flush)
+    L.tfgpu_bufferer_create.argtypes = [C.c_int64, C.c_uint64, C.c_int64, C.c_int, FLUSH, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.tfgpu_bufferer_async_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    L.tfgpu_bufferer_async_push_meta.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_int, C.c_int64, C.POINTER(C.c_uint64)]
+    L.tfgpu_bufferer_wait.argtypes = [C.c_void_p, C.c_uint64, C.c_int64]
+    L.tfgpu_bufferer_close.argtypes = [C.c_void_p]
+    L.tfgpu_bufferer_destroy.argtypes = [C.c_void_p]
+    schema = abi.Schema.of([["id", "int64", True], ["s", "utf8"]])
+    keep = lib.Transformer("filter_rows", {"filter": "id > 1"})
+    for with_meta in (True, False):
+        h = C.c_void_p()
+        assert L.tfgpu_bufferer_create(4, 0, 0, 1, cb, None, C.byref(h)) == 0
+        held, tickets = [], []
+        for k in range(2):
+            rows = [[["int64", 10 * k + i], ["string", "r%d" % i]] for i in range(4)]   # ids 0..3 and 10..13: the filter drops 0 and 1 of the first
+            src = lib.DeviceBatch.upload(abi.batch_from_rows(schema, ["id", "s"], rows, "db", "t"))
+            res = lib.apply_chain([keep], src)
+            held += [src, res.transformed]
+            t = C.c_uint64(0)
+            n = res.transformed.nrows
+            if with_meta:
+                assert L.tfgpu_bufferer_async_push_meta(h, res.transformed._h, n, 64, 0, 4, C.byref(t)) == 0
+            else:
+                assert L.tfgpu_bufferer_async_push(h, res.transformed._h, n, 64, 0, C.byref(t)) == 0
+            tickets.append(t.value)
+        L.tfgpu_bufferer_close(h)
+        assert [L.tfgpu_bufferer_wait(h, t, -1) for t in tickets] == [0, 0]
+        L.tfgpu_bufferer_destroy(h)
+        for x in held:
+            x.free()
+    (n1, src1, ids1), (n2, src2, ids2) = got
+    assert n1 == n2 == 2 and ids1 == ids2 == [2, 3, 10, 11, 12, 13]
+    assert src1 == [2, 3, 4, 5, 6, 7]   # the second part's rows 0..3 behind the first part's four source rows
+    assert src2 is None
 
 
 @pytest.mark.gpu

@@ -148,6 +148,7 @@ void h2d(void *dst, const void *src, size_t n);
 void h2d_small(void *dst, const void *src, size_t n);  // via the pinned arena: truly async
 Buf upload_small(const void *src, size_t n);
 // the same for tables no kernel ever writes: an identical table uploaded earlier on this lane is handed out again (no copy)
+void dbatch_drop_src_row(struct ::tfgpu_dbatch *b);  // tf_shard.hip
 Buf upload_const(const void *src, size_t n);
 // n uint32 words read back into the pinned arena; valid after the next sync()
 const uint32_t *d2h_u32(const void *dev, size_t n = 1);

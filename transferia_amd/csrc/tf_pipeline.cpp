@@ -25,6 +25,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "tf_common.hpp"
@@ -37,6 +38,7 @@ struct ParseTask {
   int slot = 0;
   std::mutex mu; std::condition_variable cv;
   bool done = false; int err = 0; void *parsed = nullptr;
+  bool handed = false;                // push() took `parsed` (under mu): it is the sink's from then on
   std::atomic<bool> finished{false};  // the parse thread has nothing left to do: it may be joined without waiting
   std::thread th;
 };
@@ -47,6 +49,7 @@ struct AckTask { uint64_t msg; uint64_t ticket; int64_t push_start_ns; };
 struct tfgpu_parsequeue {
   int parallelism = 0;
   tfgpu_pq_parse_fn parse = nullptr; tfgpu_pq_push_fn push = nullptr; tfgpu_pq_wait_fn wait = nullptr; tfgpu_pq_ack_fn ack = nullptr;
+  tfgpu_pq_release_fn release = nullptr;  // what becomes of a parse result nobody pushes (a cancelled queue): tfgpu_parsequeue_set_release
   void *user = nullptr;
   std::mutex mu; std::condition_variable cv;
   bool cancelled = false;
@@ -89,6 +92,7 @@ static void pq_push_loop(tfgpu_parsequeue *q) {
     if (t->err) { q->fail(t->err, "parsing error: message " + std::to_string(t->msg)); return; }
     uint64_t ticket = 0;
     const int64_t st = now_ns();
+    { std::lock_guard<std::mutex> lk(t->mu); t->handed = true; }
     const int rc = q->push(q->user, t->parsed, &ticket);
     if (rc) { q->fail(rc, "push error: message " + std::to_string(t->msg)); return; }
     std::lock_guard<std::mutex> lk(q->mu);
@@ -126,6 +130,7 @@ struct BufTicket {
 };
 struct Buffer {
   std::vector<const tfgpu_dbatch *> batches;
+  std::vector<int64_t> meta_rows;  // per batch: rows of the source batch its src_row counts in, or -1 (unknown)
   int64_t rows = 0; uint64_t values_size = 0;
   std::vector<std::shared_ptr<BufTicket>> tickets;
 };
@@ -139,7 +144,7 @@ struct tfgpu_bufferer {
   std::mutex mu; std::condition_variable cv;
   bool closed = false, closing = false;
   // the input "channel" (unbuffered: a push returns once run() has taken the item)
-  struct Input { const tfgpu_dbatch *b; int64_t rows; uint64_t size; int non_row; std::shared_ptr<tf::BufTicket> t; };
+  struct Input { const tfgpu_dbatch *b; int64_t rows; uint64_t size; int non_row; int64_t meta_rows; std::shared_ptr<tf::BufTicket> t; };
   std::deque<Input> in;
   uint64_t taken = 0, offered = 0;
   std::thread run_th;
@@ -148,7 +153,9 @@ struct tfgpu_bufferer {
   std::thread flush_th; bool flush_active = false;
   std::chrono::steady_clock::time_point timer_at; bool timer_fired = true, timer_ticking = false;
   tfgpu_bufferer_stats stats{};
-  std::vector<std::shared_ptr<tf::BufTicket>> all_tickets;
+  // tickets whose answer has not been fetched yet (an answered and fetched ticket is gone: a replication pushes for days)
+  std::unordered_map<uint64_t, std::shared_ptr<tf::BufTicket>> tickets;
+  uint64_t next_ticket = 0;
 };
 
 namespace tf {
@@ -164,7 +171,13 @@ static void buf_flush(tfgpu_bufferer *b) {  // bufferer.flush: wait for the flus
       const tfgpu_dbatch *one = nullptr; tfgpu_dbatch *merged = nullptr;
       if (t->batches.size() == 1 || !b->concat_on_device) one = t->batches.size() == 1 ? t->batches[0] : nullptr;  // "to not copy changeitems"
       else if (t->batches.size() > 1) {
-        err = tfgpu_dbatch_concat(t->batches.data(), (int)t->batches.size(), nullptr, &merged);  // the single concat copy (buffer.go:38-45)
+        // src_row of the merged batch: with every part's source extent known the parts' source rows line up behind one another
+        // (the sink concatenates its row metas in the same order); otherwise a merged src_row would collide across parts and is dropped
+        bool known = true;
+        std::vector<int64_t> base(t->batches.size(), 0);
+        for (size_t g = 0; g < t->batches.size(); g++) { if (t->meta_rows[g] < 0) known = false; if (g + 1 < t->batches.size()) base[g + 1] = base[g] + std::max<int64_t>(t->meta_rows[g], 0); }
+        err = tfgpu_dbatch_concat(t->batches.data(), (int)t->batches.size(), known ? base.data() : nullptr, &merged);  // the single concat copy (buffer.go:38-45)
+        if (!err && !known) tf::dbatch_drop_src_row(merged);
         one = merged;
       }
       if (!err) err = b->flush_fn(b->user, one, t->batches.data(), (int)t->batches.size(), t->rows, t->values_size);
@@ -205,7 +218,7 @@ static void buf_run(tfgpu_bufferer *b) {
       if (b->flush_th.joinable()) b->flush_th.join();
       return;
     }
-    b->buf->batches.push_back(it.b); b->buf->rows += it.rows; b->buf->values_size += it.size; b->buf->tickets.push_back(it.t);
+    b->buf->batches.push_back(it.b); b->buf->meta_rows.push_back(it.meta_rows); b->buf->rows += it.rows; b->buf->values_size += it.size; b->buf->tickets.push_back(it.t);
     if (b->trig_count > 0 && b->buf->rows >= b->trig_count) { b->stats.flush_on_count++; buf_flush(b); continue; }
     if (b->trig_size > 0 && b->buf->values_size >= b->trig_size) { b->stats.flush_on_size++; buf_flush(b); continue; }
     if (b->trig_interval_ms > 0 && b->timer_fired) { b->stats.flush_on_interval++; buf_flush(b); continue; }
@@ -244,15 +257,17 @@ int tfgpu_parsequeue_add(tfgpu_parsequeue *q, uint64_t msg) {
     if (q->cancelled) return tf::fail(TFGPU_ERR_INVALID, "parse queue failed on sending parse task");
     t->slot = q->free_slots.back(); q->free_slots.pop_back();
     while (!q->all.empty() && q->all.front()->finished.load()) { q->all.front()->th.join(); q->all.pop_front(); }
+    // the thread exists before the task is published (a Close on another thread must find it joinable), and it is created
+    // while mu is held: its body takes mu only after the parse
+    t->th = std::thread([q, t] {
+      void *parsed = nullptr;
+      const int rc = q->parse(q->user, t->msg, t->slot, &parsed);
+      { std::lock_guard<std::mutex> lk(t->mu); t->done = true; t->err = rc; t->parsed = parsed; t->cv.notify_all(); }
+      { std::lock_guard<std::mutex> lk(q->mu); q->free_slots.push_back(t->slot); q->cv.notify_all(); }
+      t->finished.store(true);
+    });
     q->all.push_back(t);
   }
-  t->th = std::thread([q, t] {
-    void *parsed = nullptr;
-    const int rc = q->parse(q->user, t->msg, t->slot, &parsed);
-    { std::lock_guard<std::mutex> lk(t->mu); t->done = true; t->err = rc; t->parsed = parsed; t->cv.notify_all(); }
-    { std::lock_guard<std::mutex> lk(q->mu); q->free_slots.push_back(t->slot); q->cv.notify_all(); }
-    t->finished.store(true);
-  });
   std::unique_lock<std::mutex> lk(q->mu);
   // the buffered channel of parallelism - 2 tasks: Add blocks here while it is full
   q->cv.wait(lk, [&] { return q->cancelled || (int)q->push_q.size() < std::max(q->parallelism - 2, 1); });
@@ -277,6 +292,21 @@ int tfgpu_parsequeue_close(tfgpu_parsequeue *q) {
   std::deque<std::shared_ptr<ParseTask>> all;
   { std::lock_guard<std::mutex> lk(q->mu); all.swap(q->all); }
   for (auto &t : all) if (t->th.joinable()) t->th.join();
+  // results of parses that nobody pushed (the queue was cancelled, or closed with work in flight): theirs to release
+  std::deque<std::shared_ptr<ParseTask>> pending;
+  { std::lock_guard<std::mutex> lk(q->mu); pending.swap(q->push_q); }
+  for (auto &t : all) { bool found = false; for (auto &x : pending) if (x == t) found = true; if (!found) pending.push_back(t); }
+  for (auto &t : pending) {
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (t->done && !t->handed && t->parsed && !t->err && q->release) q->release(q->user, t->parsed);
+    t->handed = true;
+  }
+  return TFGPU_OK;
+}
+int tfgpu_parsequeue_set_release(tfgpu_parsequeue *q, tfgpu_pq_release_fn release) {
+  if (!q) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parsequeue_set_release: null queue");
+  std::lock_guard<std::mutex> lk(q->mu);
+  q->release = release;
   return TFGPU_OK;
 }
 void tfgpu_parsequeue_destroy(tfgpu_parsequeue *q) { if (q) { tfgpu_parsequeue_close(q); delete q; } }
@@ -291,29 +321,43 @@ int tfgpu_bufferer_create(int64_t trigging_count, uint64_t trigging_size, int64_
   return TFGPU_OK;
 }
 
-int tfgpu_bufferer_async_push(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int64_t nrows, uint64_t values_size, int has_non_row_item, uint64_t *ticket) {
+int tfgpu_bufferer_async_push_meta(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int64_t nrows, uint64_t values_size, int has_non_row_item, int64_t meta_rows, uint64_t *ticket) {
   if (!b || !ticket) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_bufferer_async_push: null argument");
   auto t = std::make_shared<BufTicket>();
   std::unique_lock<std::mutex> lk(b->mu);
-  b->all_tickets.push_back(t);
-  *ticket = b->all_tickets.size();
+  const uint64_t id = ++b->next_ticket;
+  b->tickets.emplace(id, t);
+  *ticket = id;
   if (b->closed || b->closing) { t->finish(TFGPU_ERR_INVALID); return TFGPU_OK; }  // AsyncPushConcurrencyErr rides on the ticket
   if (nrows == 0) { t->finish(0); return TFGPU_OK; }
-  b->in.push_back({batch, nrows, values_size, has_non_row_item, t});
+  b->in.push_back({batch, nrows, values_size, has_non_row_item, meta_rows, t});
   const uint64_t mine = ++b->offered;
   b->cv.notify_all();
   b->cv.wait(lk, [&] { return b->taken >= mine; });  // an unbuffered channel: the push returns when run() has the item
   return TFGPU_OK;
 }
+int tfgpu_bufferer_async_push(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int64_t nrows, uint64_t values_size, int has_non_row_item, uint64_t *ticket) {
+  return tfgpu_bufferer_async_push_meta(b, batch, nrows, values_size, has_non_row_item, -1, ticket);
+}
 
 int tfgpu_bufferer_wait(tfgpu_bufferer *b, uint64_t ticket, int64_t timeout_ms) {
   if (!b) return TFGPU_ERR_INVALID;
   std::shared_ptr<BufTicket> t;
-  { std::lock_guard<std::mutex> lk(b->mu); if (ticket == 0 || ticket > b->all_tickets.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_bufferer_wait: unknown ticket"); t = b->all_tickets[ticket - 1]; }
-  std::unique_lock<std::mutex> lk(t->mu);
-  if (timeout_ms < 0) t->cv.wait(lk, [&] { return t->done; });
-  else if (!t->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return t->done; })) return TFGPU_PQ_PENDING;
-  return t->err;
+  {
+    std::lock_guard<std::mutex> lk(b->mu);
+    auto it = b->tickets.find(ticket);
+    if (it == b->tickets.end()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_bufferer_wait: unknown ticket (or its answer was fetched already)");
+    t = it->second;
+  }
+  int err;
+  {
+    std::unique_lock<std::mutex> lk(t->mu);
+    if (timeout_ms < 0) t->cv.wait(lk, [&] { return t->done; });
+    else if (!t->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return t->done; })) return TFGPU_PQ_PENDING;
+    err = t->err;
+  }
+  { std::lock_guard<std::mutex> lk(b->mu); b->tickets.erase(ticket); }  // a final answer is given once
+  return err;
 }
 
 int tfgpu_bufferer_get_stats(tfgpu_bufferer *b, tfgpu_bufferer_stats *out) {

@@ -174,6 +174,12 @@ static std::unique_ptr<tfgpu_dbatch> concat(const std::vector<const tfgpu_dbatch
     for (size_t i = 0; i < p0.cols.size(); i++) if (!same_shape(p->cols[i], p0.cols[i])) throw Error(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: column " + p0.cols[i].name + " differs between parts");
     for (size_t i = 0; i < p0.old_keys.size(); i++) if (!same_shape(p->old_keys[i], p0.old_keys[i])) throw Error(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: OldKeys column " + p0.old_keys[i].name + " differs between parts");
     if (p->schema != p0.schema || p->key_names != p0.key_names || p->ns != p0.ns || p->table != p0.table) throw Error(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: the parts belong to different tables / schemas");
+    // late-materialised text (CSV cells still in their source text) is packed by kernels on the CALLING lane's stream: fine for a part
+    // of this device, not for one whose text lives on another (no peer mapping is assumed) — such a part must be complete on its
+    // own lane first (tfgpu_dbatch_to_lane packs before it copies)
+    bool lazy_remote = false;
+    for (auto &c : p->cols) if (c.view && !c.view->packed && !c.data && c.view->fstart && c.view->fstart->device != ctx().device) lazy_remote = true;
+    if (lazy_remote) throw Error(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: a part on another device still holds unpacked text columns: move it with tfgpu_dbatch_to_lane (which packs) first");
     materialize(*p);
   }
   hipStream_t st = ctx().stream;
@@ -275,6 +281,9 @@ static std::unique_ptr<tfgpu_dbatch> concat(const std::vector<const tfgpu_dbatch
   tf::sync();  // staged copies of remote bitmaps die with this scope
   return r;
 }
+
+// (the bufferer's flush: a merged batch whose parts' source rows cannot be lined up carries none)
+void dbatch_drop_src_row(tfgpu_dbatch *b) { if (b) b->src_row = nullptr; }
 
 }  // namespace tf
 
