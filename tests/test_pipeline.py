@@ -481,8 +481,8 @@ def test_bufferer_merged_src_row_lines_up_with_the_parts_sources():
     def flush(user, merged, parts, nparts, nrows, size):
         view = lib.DeviceBatch(C.c_void_p(merged))
         b = view.download()
-        view._h = None
         has_src = bool(view.view().src_row)   # (download() reads a NULL src_row as the identity: ask the view)
+        view._h = None
         got.append((nparts, [int(x) for x in b.src_row] if has_src else None, [int(x) for x in b.cols[0].values]))
         return 0
     cb = FLUSH(flush)
