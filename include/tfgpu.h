@@ -312,10 +312,24 @@ void tfgpu_bufferer_destroy(tfgpu_bufferer *b);
  * are walked on the host; the object is uploaded once and every value is decoded on the device).  `schema` = the TableSchema
  * given to Read: its columns are looked up in the file by name (a column the file lacks is nil in every row, :256-259); NULL =
  * every leaf of the file.  Values keep Parquet's physical Go types (bool, int32, int64, float32, float64, string / []byte); DATE
- * becomes time.Time as parseLogicalDate makes it.  Flat schemas, UNCOMPRESSED chunks, data pages v1 / v2, PLAIN and dictionary
- * encodings; anything else answers TFGPU_ERR_UNSUPPORTED naming it.  PARITY UNPINNED against the reference (no .parquet input
+ * becomes time.Time as parseLogicalDate makes it.  Flat schemas, UNCOMPRESSED / SNAPPY / GZIP / ZSTD chunks (a compressed object's
+ * pages are inflated on the host while it walks them), data pages v1 / v2, PLAIN and dictionary encodings; anything else answers
+ * TFGPU_ERR_UNSUPPORTED naming it, and a corrupt object (a length, offset or dictionary index past what is there) TFGPU_ERR_INVALID.  PARITY UNPINNED against the reference (no .parquet input
  * under /root/reference, parquet-go not vendored): the tests pin it to pyarrow's reading of the same files.               */
 int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out);
+
+/* Device columns → a Parquet object (tf_parquetw.hip; pkg/serializer/parquet.go:53-200 parquetBatchSerializer.Serialize + Close,
+ * parquet_format.go:13-135 BuildParquetSchema / toParquetValue).  `schema` = the TableSchema: its columns become the fields of the
+ * group "table" in NAME order (parquet.Group is a map), typed by primitiveTypesMap (intN → INT(N), float64 → STRING: its decimal
+ * text, date → DATE, datetime / timestamp / interval → TIMESTAMP(NANOS), any → JSON), OPTIONAL unless TFGPU_COL_REQUIRED; a
+ * column the batch lacks is null in every row.  `codec` = CodecFromString's names ("SNAPPY", "GZIP", "ZSTD"; anything else:
+ * uncompressed).  Row groups are cut by row_group_max_rows, else by row_group_max_bytes over the PLAIN sizes (both 0: 128 MiB,
+ * NewParquetBatchSerializer's default), at multiples of eight rows; one PLAIN v1 data page per column chunk.  *bytes is pinned
+ * host memory of *len bytes: free it with tfgpu_host_free.  The batch's values must have the Go types Strictify gives them
+ * (tfgpu_strictify first: that is NewStrictifyingBatchSerializer); a float64 VALUE (fmt's %v) is refused by name.  PARITY
+ * UNPINNED: the byte layout is the writing library's (parquet-go) choice; the tests pin values, nulls, logical types and field
+ * order to what pyarrow reads back.                                                                                          */
+int tfgpu_parquet_write(const tfgpu_dbatch *b, const tfgpu_schema *schema, const char *codec, int64_t row_group_max_rows, uint64_t row_group_max_bytes, void **bytes, uint64_t *len);
 
 /* strictify.Strictify (pkg/abstract/changeitem/strictify/strictify.go:17-157) over a device batch — the first step of the
  * strictifying serializers (pkg/serializer/strictify.go:24-36): every column named by `schema` (NULL: the batch's own

@@ -25,7 +25,7 @@ _lib = None
 
 EXPORTS = [
     "tfgpu_abi_version", "tfgpu_last_error", "tfgpu_init", "tfgpu_shutdown", "tfgpu_device_count", "tfgpu_synchronize",
-    "tfgpu_init_devices", "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_lane_device", "tfgpu_dbatch_slice", "tfgpu_dbatch_to_lane", "tfgpu_shard_rows", "tfgpu_dbatch_concat", "tfgpu_strictify", "tfgpu_parquet_read", "tfgpu_parsequeue_create", "tfgpu_parsequeue_add", "tfgpu_parsequeue_error", "tfgpu_parsequeue_close", "tfgpu_parsequeue_set_release", "tfgpu_parsequeue_destroy", "tfgpu_bufferer_create", "tfgpu_bufferer_async_push", "tfgpu_bufferer_async_push_meta", "tfgpu_bufferer_wait", "tfgpu_bufferer_get_stats", "tfgpu_bufferer_close", "tfgpu_bufferer_destroy", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
+    "tfgpu_init_devices", "tfgpu_stream", "tfgpu_lane_count", "tfgpu_lane_use", "tfgpu_lane_current", "tfgpu_lane_device", "tfgpu_dbatch_slice", "tfgpu_dbatch_to_lane", "tfgpu_shard_rows", "tfgpu_dbatch_concat", "tfgpu_strictify", "tfgpu_parquet_read", "tfgpu_parquet_write", "tfgpu_parsequeue_create", "tfgpu_parsequeue_add", "tfgpu_parsequeue_error", "tfgpu_parsequeue_close", "tfgpu_parsequeue_set_release", "tfgpu_parsequeue_destroy", "tfgpu_bufferer_create", "tfgpu_bufferer_async_push", "tfgpu_bufferer_async_push_meta", "tfgpu_bufferer_wait", "tfgpu_bufferer_get_stats", "tfgpu_bufferer_close", "tfgpu_bufferer_destroy", "tfgpu_host_alloc", "tfgpu_host_free", "tfgpu_plan_create", "tfgpu_plan_destroy", "tfgpu_plan_type",
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_from_config", "tfgpu_transformation_size", "tfgpu_transformation_plan_type", "tfgpu_transformation_errors_output", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
@@ -177,6 +177,21 @@ def parquet_read(data: bytes, schema: Optional[abi.Schema] = None, ns: str = "",
     cs = schema.to_c() if schema is not None else None
     _check(load().tfgpu_parquet_read(C.c_void_p(buf.ctypes.data), C.c_uint64(len(buf)), abi.MEM_HOST, C.byref(cs) if cs is not None else None, ns.encode(), table.encode(), C.byref(out)))
     return DeviceBatch(out)
+
+
+def parquet_write(batch: "DeviceBatch", schema: abi.Schema, codec: str = "", row_group_max_rows: int = 0, row_group_max_bytes: int = 0) -> bytes:
+    """parquetBatchSerializer.Serialize + Close of one batch: the Parquet object as bytes (codec: "", "SNAPPY", "GZIP", "ZSTD")"""
+    init()
+    p, n = C.c_void_p(), C.c_uint64(0)
+    cs = schema.to_c()
+    L = load()
+    L.tfgpu_parquet_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    _check(L.tfgpu_parquet_write(batch._h, C.byref(cs), codec.encode(), row_group_max_rows, row_group_max_bytes, C.byref(p), C.byref(n)))
+    try:
+        return C.string_at(p.value, n.value)
+    finally:
+        L.tfgpu_host_free.argtypes = [C.c_void_p]
+        L.tfgpu_host_free(p)
 
 
 def strictify(batch: "DeviceBatch", schema: Optional[abi.Schema] = None) -> "DeviceBatch":
