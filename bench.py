@@ -700,6 +700,98 @@ class Configs2Workload(_Prepared):
         s = self.state
         return {"rows_out_per_step": s["out_rows"], "text_out_bytes_per_step": s["out_bytes"]}
 
+    def side_measurements(self):
+        """Never `value`: configs[2] says "async double-buffer" and north_star "overlapping Kafka pull and ClickHouse push" — the
+        pull AND the push inside the step, together.  Every step takes its Kafka bytes from PINNED host memory (hipMemcpyAsync H2D on
+        the lane's stream: the pull), parses and transforms them, serializes JSONEachRow and copies the text back into pinned host
+        memory (D2H: what httpuploader would POST).  On one lane the three legs follow each other; on several lanes (the parsequeue's
+        shape: parse of batch N+1 beside the push of batch N, parsequeue.go:118-154) the H2D of one batch, the kernels of another and
+        the D2H of a third share the GPU and both directions of the PCIe link.  overlap_efficiency = the longest of the three legs
+        alone (H2D at the measured one-lane copy rate, kernels = the HBM-resident step, D2H likewise) over the measured step."""
+        e, a = self.env, self.args
+        lib, abi = e.lib, e.abi
+        if a.pcie_steps <= 0 or e.rank != 0:
+            return {}
+        cap = int(self.state["out_bytes"] * 1.05) + (1 << 20)
+        res = {}
+        kernels_ms = getattr(self, "dt", 0) / max(getattr(self, "total_passes", 1), 1) * 1e3  # the HBM-resident step of the timed region
+        # each direction alone, one lane: what the link gives this message size
+        hin = lib.HostBuffer(self.data)
+        lib.lane_use(0)
+        t0 = time.perf_counter()
+        import ctypes
+        for _ in range(3):
+            hd = ctypes.c_void_p()
+            lib._check(lib.load().tfgpu_dbuf_upload(ctypes.c_void_p(hin.ptr), hin.size, ctypes.byref(hd)))
+            lib.synchronize()
+            lib.DeviceBuffer(hd).free()
+        h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
+        for nl in sorted({1, max(1, min(a.pcie_lanes, lib.lane_count()))}):
+            ins, outs = [lib.HostBuffer(self.data) for _ in range(nl)], []
+            for _ in range(nl):
+                hb = lib.HostBuffer.__new__(lib.HostBuffer)
+                pp = ctypes_void()
+                lib._check(lib.load().tfgpu_host_alloc(cap, pp.ref))
+                hb.ptr, hb.size = pp.value, cap
+                outs.append(hb)
+            kk = max(a.pcie_steps, 2) * nl
+            go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
+            errs = []
+
+            def lane_main(k, ins=ins, outs=outs, nl=nl, kk=kk, go=go, done=done):
+                try:
+                    lib.lane_use(k)
+                    plans = self.plans if k == 0 else [lib.Transformer(t, c) for t, c in self.CH]
+                    stage = self.stage if k == 0 else lib.Transformation(plans)
+
+                    def one():
+                        res_ = lib.sr_json_parse(self.opts, ins[k], self.msgs)          # pull: H2D from pinned memory inside the call
+                        tr = stage.push_run(res_.device_batch)
+                        out = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
+                        lib._check(lib.load().tfgpu_dbuf_download(out._h, outs[k].ptr, out.size))  # push: D2H into pinned memory
+                        for _, eb in tr.error_batches:
+                            eb.free()
+                        out.free(); tr.transformed.free(); res_.device_batch.free()
+                    one()
+                    lib.synchronize()
+                    go.wait()
+                    for i in range(kk):
+                        if i % nl == k:
+                            one()
+                    lib.synchronize()
+                    done.wait()
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex); go.abort(); done.abort()
+            ths = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
+            for t in ths:
+                t.start()
+            try:
+                go.wait()
+                t0 = time.perf_counter()
+                done.wait()
+                dt = time.perf_counter() - t0
+            except threading.BrokenBarrierError:
+                dt = float("nan")
+            for t in ths:
+                t.join()
+            lib.lane_use(0)
+            for hb in ins + outs:
+                hb.free()
+            if errs:
+                res[f"lanes_{nl}"] = {"error": str(errs[0])[:200]}
+                continue
+            step_ms = dt / kk * 1e3
+            d2h_ms = self.state["out_bytes"] / 52e9 * 1e3  # the D2H leg alone at the link's measured one-direction rate (configs3 d2h_inclusive: 52 GB/s)
+            res[f"lanes_{nl}"] = {"rows_per_s": round(self.n * kk / dt, 1), "ms_per_step": round(step_ms, 3),
+                                  "gb_per_s_h2d": round(len(self.data) * kk / dt / 1e9, 2), "gb_per_s_d2h": round(self.state["out_bytes"] * kk / dt / 1e9, 2),
+                                  "legs_alone_ms": {"h2d": round(h2d_ms, 3), "kernels": round(kernels_ms, 3), "d2h": round(d2h_ms, 3)},
+                                  "overlap_efficiency": round(max(h2d_ms, kernels_ms, d2h_ms) / step_ms, 3)}
+        hin.free()
+        res["note"] = ("every step pulls its %.2f GB of Kafka bytes from pinned host memory (H2D), runs parse + replace_primary_key + sql + JSONEachRow, and pushes the "
+                       "%.2f GB of text back into pinned host memory (D2H); with several lanes the three legs of different batches overlap: H2D of batch N+1, "
+                       "kernels of N, D2H of N-1 (PCIe Gen5 x16 is full duplex, ~52-54 GB/s per direction measured)" % (len(self.data) / 1e9, self.state["out_bytes"] / 1e9))
+        return {"pull_push_concurrent": res}
+
     def cpu(self):
         from oracle import oracle as ora
         abi = self.env.abi

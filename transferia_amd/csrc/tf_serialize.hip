@@ -409,8 +409,21 @@ struct ChunkPlan {
   int32_t order;           // tile order: 0 = a row group's chunks are neighbours, 1 = a chunk's row groups are
   int64_t ngroups;         // row groups of 64
 };
+// workgroups of four tiles; the XCD-aware order needs a whole number of workgroups per XCD (the tiles past the end do nothing)
+static inline unsigned ser_grid(const ChunkPlan &cp) {
+  const int64_t nb = (cp.ngroups * cp.nchunks + 3) >> 2;
+  return (unsigned)(cp.order == 2 ? ((nb + 7) >> 3) << 3 : nb);
+}
 __device__ __forceinline__ void tile_of(const ChunkPlan &cp, int64_t tile, int32_t &k, int64_t &r0) {
-  if (cp.order) { k = (int32_t)(tile / cp.ngroups); r0 = (tile - (int64_t)k * cp.ngroups) * 64; }
+  if (cp.order == 2) {
+    // a row group's chunks are neighbours AND on one XCD: workgroups are dealt to the eight XCDs round-robin (blockIdx & 7), each
+    // XCD has its own L2 — so XCD x takes the x-th eighth of the row groups, and the partial cache lines at the seams between a
+    // row's chunks (written by different waves within microseconds) meet in ONE L2 and leave it as whole lines
+    const int64_t b = tile >> 2, nb = ((cp.ngroups * cp.nchunks + 3) >> 2), per = (nb + 7) >> 3;
+    const int64_t vt = (((b & 7) * per + (b >> 3)) << 2) | (tile & 3);
+    k = (int32_t)(vt % cp.nchunks); r0 = (vt / cp.nchunks) * 64;
+  }
+  else if (cp.order) { k = (int32_t)(tile / cp.ngroups); r0 = (tile - (int64_t)k * cp.ngroups) * 64; }
   else { k = (int32_t)(tile % cp.nchunks); r0 = (tile / cp.nchunks) * 64; }
   k = __builtin_amdgcn_readfirstlane(k);
 }
@@ -903,9 +916,9 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
       cell = dalloc((size_t)cp.nchunks * (size_t)n * 4);
       cp.chunk = ptr<uint32_t>(cell);
       { const char *e = std::getenv("TFGPU_SER_DIRECT"); cp.direct = e && *e == '1'; }
-      { const char *e = std::getenv("TFGPU_SER_ORDER"); cp.order = e ? std::atoi(e) : 1; }
+      { const char *e = std::getenv("TFGPU_SER_ORDER"); cp.order = e ? std::atoi(e) : 1; }  // (2, the XCD-aware form of 0, measured like 0: 3.18 ms against 2.62 for order 1 on configs[3] — the reads of 64 consecutive rows per column decide, not the seams of the writes; profiles/r06o_*)
       cp.ngroups = (n + 63) / 64;
-      const unsigned grid = (unsigned)((((n + 63) / 64) * cp.nchunks + 3) / 4);
+      const unsigned grid = ser_grid(cp);
       {
         KernelTimer t("ser_chunk_len");
         if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_chunk_len<TFGPU_FMT_CH_JSON_EACH_ROW><<<grid, 256, 0, st>>>(p, cp);
@@ -932,7 +945,7 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
       { KernelTimer t("ser_cell_write"); if (ncell) ser_cell_write<<<dim3(blocks(n), (unsigned)ncols), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_frame"); ser_row_frame<<<blocks(n), 256, 0, st>>>(p); }
     } else {
-      const unsigned grid = (unsigned)((((n + 63) / 64) * cp.nchunks + 3) / 4);
+      const unsigned grid = ser_grid(cp);
       KernelTimer t("ser_chunk_write");
       if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_chunk_write<TFGPU_FMT_CH_JSON_EACH_ROW><<<grid, 256, 4 * WAVE_IMG_BYTES + 64, st>>>(p, cp);
       else if (format == TFGPU_FMT_JSON) ser_chunk_write<TFGPU_FMT_JSON><<<grid, 256, 4 * WAVE_IMG_BYTES + 64, st>>>(p, cp);

@@ -788,9 +788,11 @@ def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data, msgs: Optional[
 
 
 def _bytes_arg(data):
-    """(pointer, length, mem, keep-alive) of host bytes or a DeviceBuffer."""
+    """(pointer, length, mem, keep-alive) of host bytes, a pinned HostBuffer or a DeviceBuffer."""
     if isinstance(data, DeviceBuffer):
         return data.ptr, data.size, abi.MEM_DEVICE, data
+    if isinstance(data, HostBuffer):
+        return data.ptr, data.size, abi.MEM_HOST, data
     buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
     return buf.ctypes.data, len(data), abi.MEM_HOST, buf
 
