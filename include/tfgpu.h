@@ -783,6 +783,37 @@ int tfgpu_debezium_parse(const tfgpu_dbz_options *opts, const void *bytes, uint6
                          const tfgpu_dbz_frame *frames, tfgpu_dbatch **out, tfgpu_dbz_row *rows, int64_t rows_cap,
                          tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
+/* The host half of the receiver (tf_dbzrecv.cpp) — what the reference does once per distinct schema, and DoBatch's loop.
+ *
+ * tfgpu_debezium_compile_schema — Receiver.receiveSchema (pkg/debezium/receiver.go:60-96) for one schema's bytes: UnmarshalSchema
+ * with encoding/json's struct binding (debezium_schema.go:12-29; the last duplicate of a key wins, a key that binds only by case
+ * folding -> host), the `before` / `after` structs, every field's receiver with an empty original type (receiveFieldColSchema,
+ * receiver_engine.go:108-146; TypeToDefault and the Point / VariableScaleDecimal / Decimal matchers,
+ * common/field_receiver_default.go:14-31, 258-355).  tfgpu_dbz_schema_info: code = TFGPU_ROW_OK and the `after` struct's fields
+ * in order (the tfgpu_dbz_options.fields of tfgpu_debezium_parse), or what the whole schema is: TFGPU_ROW_DBZ_SCHEMA (it does
+ * not unmarshal, a Kafka type without receiver) / TFGPU_ROW_HOST_FALLBACK (before != after, a repeated field name, a nil
+ * before / after struct, folded keys); `why` says which.
+ *
+ * tfgpu_dbz_receiver — DebeziumImpl over message batches (parser.go:120-130) with the reference's schema cache (receiver.go:61-66,
+ * keyed by the device's hash of the schema bytes) and the head of the opening message kept for tfgpu_debezium_unpack_cached.
+ * tfgpu_dbz_receive: unpack, group the messages by schema, compile the schemas seen for the first time, parse every group;
+ * *ngroups tables came out (in order of first appearance), msg_codes[m] (HOST, nmsg entries, optional) = TFGPU_ROW_OK or why
+ * message m becomes an `_unparsed` item / goes to the stock code.  host_copy: the same bytes in host memory when `bytes` is a
+ * device buffer (a new schema's text is read there instead of being copied back), or NULL.  tfgpu_dbz_receive_group: table g's
+ * rows — the device batch (src_row = message index; the caller's from then on), per-row ID / LSN / CommitTime / names_form,
+ * and the schema's fields (TableSchema: PrimaryKey = !optional, TableSchema / TableName = the batch's table id); rows and fields
+ * stay valid until the next tfgpu_dbz_receive on this receiver.                                                             */
+typedef struct tfgpu_dbz_schema tfgpu_dbz_schema;
+int tfgpu_debezium_compile_schema(const void *schema_bytes, uint64_t len, tfgpu_dbz_schema **out);
+int tfgpu_dbz_schema_info(const tfgpu_dbz_schema *s, int32_t *code, const tfgpu_dbz_field **fields, int32_t *nfields, const char **why);
+void tfgpu_dbz_schema_free(tfgpu_dbz_schema *s);
+typedef struct tfgpu_dbz_receiver tfgpu_dbz_receiver;
+int tfgpu_dbz_receiver_create(tfgpu_dbz_receiver **out);
+void tfgpu_dbz_receiver_destroy(tfgpu_dbz_receiver *r);
+int tfgpu_dbz_receiver_known(const tfgpu_dbz_receiver *r, tfgpu_dbz_prefix *known);  /* the head it keeps (len 0: none yet); bytes stay the receiver's */
+int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, int mem, const void *host_copy, const tfgpu_messages *msgs, int32_t *ngroups, int32_t *msg_codes);
+int tfgpu_dbz_receive_group(tfgpu_dbz_receiver *r, int32_t g, tfgpu_dbatch **batch, const tfgpu_dbz_row **rows, int64_t *nrows, const tfgpu_dbz_field **fields, int32_t *nfields);
+
 /* ---- ClickHouse Native column block -------------------------------------------------------------------- */
 /* The v2 ClickHouse sink turns every ChangeItem into a []any row (pkg/providers/clickhouse/async/marshaller.go:62-190) and
  * appends it to a clickhouse-go batch, which encodes ClickHouse's Native column layout.  With the batch columnar in HBM

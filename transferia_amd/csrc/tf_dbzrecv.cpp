@@ -1,0 +1,315 @@
+// tf_dbzrecv.cpp — the host half of the Debezium receiver behind the C ABI: what the reference does ONCE PER SCHEMA before any
+// value is touched, and the loop that hands each group of messages to the device.
+//
+//   Receiver.receiveSchema / receiveTableSchema    pkg/debezium/receiver.go:60-96, 45-59
+//   receiveFieldColSchema                          pkg/debezium/receiver_engine.go:108-146
+//   TypeToDefault, Point / VariableScaleDecimal /
+//   Decimal matchers                               pkg/debezium/common/field_receiver_default.go:14-31, 258-355
+//   Schema (encoding/json struct binding)          pkg/debezium/common/debezium_schema.go:12-29, 84-101
+//   DebeziumImpl.DoBatch                           pkg/parsers/registry/debezium/engine/parser.go:120-130
+//
+// Scope: NewDebeziumImpl(logger, nil, threads) — no schema registry, no original-type table.  The reference caches the compiled
+// schema by a hash of its bytes (receiver.go:61-66); so does tfgpu_dbz_receiver, keyed by the device's hash of the same bytes,
+// and it keeps the head of the batch's opening message for tfgpu_debezium_unpack_cached.  Per message everything is
+// tfgpu_debezium_unpack / tfgpu_debezium_parse (tf_debezium.hip); nothing here touches a value.
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "tf_common.hpp"
+#include "tf_plan.hpp"
+
+namespace tf {
+namespace dbzrecv {
+
+struct SchemaError { std::string why; };  // receiveSchema fails: every message of the schema becomes an `_unparsed` item
+struct HostOnly { std::string why; };     // the stock code must handle this schema
+
+// strings.EqualFold against an ASCII field name: ASCII case folding plus the two runes Unicode folds onto ASCII letters
+// (U+017F LATIN SMALL LETTER LONG S → s, U+212A KELVIN SIGN → k)
+static bool equal_fold_ascii(const std::string &key, const char *name) {
+  size_t i = 0, j = 0;
+  const size_t n = key.size(), m = std::strlen(name);
+  while (i < n && j < m) {
+    unsigned char c = (unsigned char)key[i];
+    char folded;
+    if (c < 0x80) { folded = (char)std::tolower(c); i++; }
+    else if (c == 0xC5 && i + 1 < n && (unsigned char)key[i + 1] == 0xBF) { folded = 's'; i += 2; }
+    else if (c == 0xE2 && i + 2 < n && (unsigned char)key[i + 1] == 0x84 && (unsigned char)key[i + 2] == 0xAA) { folded = 'k'; i += 3; }
+    else return false;
+    if (folded != (char)std::tolower((unsigned char)name[j])) return false;
+    j++;
+  }
+  return i == n && j == m;
+}
+// encoding/json's struct-field binding: a key names the field exactly or under case folding; the LAST such key wins.  A key
+// that matches only by folding is left to the host (the device binds exact keys only).
+static const Json *member(const Json &obj, const char *name) {
+  const Json *out = nullptr;
+  for (auto &kv : obj.obj) {
+    if (kv.first == name) out = &kv.second;
+    else if (equal_fold_ascii(kv.first, name)) throw HostOnly{"key " + kv.first + " binds " + name + " by case folding"};
+  }
+  return out;
+}
+static std::string string_field(const Json &obj, const char *name) {
+  const Json *v = member(obj, name);
+  if (!v || v->type == Json::Null) return "";
+  if (v->type != Json::Str) throw SchemaError{std::string("json: cannot unmarshal into Go struct field Schema.") + name + " of type string"};
+  return v->str;
+}
+static bool go_int64_literal(const std::string &t) {  // what json.Unmarshal takes for an int field: an integer literal in range
+  size_t i = 0;
+  if (i < t.size() && t[i] == '-') i++;
+  if (i >= t.size()) return false;
+  for (size_t k = i; k < t.size(); k++) if (t[k] < '0' || t[k] > '9') return false;
+  const std::string digits = t.substr(i);
+  if (digits.size() > 19) return false;
+  if (digits.size() == 19) { const std::string lim = t[0] == '-' ? "9223372036854775808" : "9223372036854775807"; if (digits > lim) return false; }
+  return true;
+}
+
+// debezium_schema.go:12-22, as json.Unmarshal fills it
+struct Schema {
+  std::string field, name, type, scale;
+  bool optional = false, has_parameters = false, has_dt_info = false;
+  std::vector<Schema> fields;
+  const Schema *find(const std::string &f) const { for (auto &s : fields) if (s.field == f) return &s; return nullptr; }  // FindSchemaDescr: the first one
+};
+static Schema unmarshal(const Json *node, int depth) {
+  Schema s;
+  if (!node || node->type == Json::Null) return s;
+  if (node->type != Json::Obj || depth > 64) throw SchemaError{"json: cannot unmarshal into Go value of type common.Schema"};
+  s.field = string_field(*node, "field"); s.name = string_field(*node, "name"); s.type = string_field(*node, "type");
+  if (const Json *v = member(*node, "optional"); v && v->type != Json::Null) { if (v->type != Json::Bool) throw SchemaError{"Schema.optional"}; s.optional = v->b; }
+  if (const Json *v = member(*node, "version"); v && v->type != Json::Null) { if (v->type != Json::Num || !go_int64_literal(v->str)) throw SchemaError{"Schema.version"}; }
+  if (const Json *v = member(*node, "parameters"); v && v->type != Json::Null) {
+    if (v->type != Json::Obj) throw SchemaError{"Schema.parameters"};
+    s.has_parameters = true;
+    for (const char *k : {"length", "connect.decimal.precision", "allowed"}) string_field(*v, k);
+    s.scale = string_field(*v, "scale");
+  }
+  if (const Json *v = member(*node, "items"); v && v->type != Json::Null) { if (v->type != Json::Obj) throw SchemaError{"Schema.items"}; unmarshal(v, depth + 1); }
+  if (const Json *v = member(*node, "__dt_original_type_info"); v && v->type != Json::Null) s.has_dt_info = true;
+  if (const Json *v = member(*node, "fields"); v && v->type != Json::Null) {
+    if (v->type != Json::Arr) throw SchemaError{"Schema.fields"};
+    for (auto &x : v->arr) s.fields.push_back(unmarshal(&x, depth + 1));
+  }
+  return s;
+}
+struct Field { std::string name; int32_t op, optional, scale; };
+// (DBZ_* op, scale) of one field with an empty original type: receiveFieldColSchema + the default matchers
+static void receiver_of(const Schema &f, int32_t &op, int32_t &scale) {
+  scale = 0;
+  if (f.has_dt_info || f.type == "array") { op = TFGPU_DBZ_HOST; return; }
+  static const std::map<std::string, int> simple = {{"int8", TFGPU_DBZ_INT8}, {"int16", TFGPU_DBZ_INT16}, {"int32", TFGPU_DBZ_INT32}, {"int64", TFGPU_DBZ_INT64}, {"boolean", TFGPU_DBZ_BOOLEAN},
+                                                    {"string", TFGPU_DBZ_STRING}, {"float", TFGPU_DBZ_FLOAT64}, {"double", TFGPU_DBZ_FLOAT64}};
+  auto it = simple.find(f.type);
+  if (it != simple.end()) { op = it->second; return; }
+  if (f.type == "struct") {
+    if (f.name == "io.debezium.data.geometry.Point") { op = TFGPU_DBZ_POINT; return; }
+    if (f.name == "io.debezium.data.VariableScaleDecimal") { op = TFGPU_DBZ_VSD; return; }
+  }
+  if (f.type == "bytes") {
+    if (f.name == "org.apache.kafka.connect.data.Decimal") {
+      op = TFGPU_DBZ_DECIMAL;
+      if (f.has_parameters && !f.scale.empty()) {  // strconv.Atoi; a scale that does not parse fails every non-nil value ("unable to parse scale")
+        const std::string &t = f.scale;
+        size_t i = (t[0] == '+' || t[0] == '-') ? 1 : 0;
+        bool ok = i < t.size() && t.size() - i <= 11;
+        for (size_t k = i; k < t.size() && ok; k++) ok = t[k] >= '0' && t[k] <= '9';
+        long long v = 0;
+        if (ok) { v = std::strtoll(t.c_str(), nullptr, 10); ok = v >= INT32_MIN && v <= INT32_MAX; }
+        scale = ok ? (int32_t)v : INT32_MIN;
+      }
+      return;
+    }
+    op = TFGPU_DBZ_BYTES; return;
+  }
+  throw SchemaError{"unable to find field receiver - even default, for kafka type: " + f.type};
+}
+// receiveSchema for one distinct schema: the fields of the `after` struct; code = TFGPU_ROW_OK, or what the whole schema is
+static int compile(const uint8_t *bytes, size_t len, std::vector<Field> &out, std::string &why) {
+  out.clear();
+  try {
+    if (!len) throw SchemaError{"unexpected end of JSON input"};
+    Json node;
+    try { node = Json::parse(std::string((const char *)bytes, len)); }
+    catch (const Error &e) { throw SchemaError{e.what()}; }
+    if (node.type != Json::Null && node.type != Json::Obj) throw SchemaError{"json: cannot unmarshal into Go value of type common.Schema"};
+    const Schema top = unmarshal(&node, 0);
+    const Schema *before = top.find("before"), *after = top.find("after");
+    if (!before || !after) throw HostOnly{"receiveTableSchema(nil): the reference dereferences a nil schema"};
+    std::vector<Field> b, a;
+    for (auto *which : {before, after}) {
+      auto &dst = which == before ? b : a;
+      for (auto &f : which->fields) { Field x; x.name = f.field; x.optional = f.optional ? 1 : 0; receiver_of(f, x.op, x.scale); dst.push_back(x); }
+    }
+    bool same = a.size() == b.size();
+    for (size_t i = 0; i < a.size() && same; i++) same = a[i].name == b[i].name && a[i].op == b[i].op && a[i].optional == b[i].optional && a[i].scale == b[i].scale;
+    if (!same) throw HostOnly{"before and after structs differ: Delete rows would have another TableSchema than the rest"};
+    for (size_t i = 0; i < a.size(); i++) for (size_t j = i + 1; j < a.size(); j++) if (a[i].name == a[j].name) throw HostOnly{"a field name repeats"};
+    out = a;
+    return TFGPU_ROW_OK;
+  } catch (const SchemaError &e) { why = e.why; return TFGPU_ROW_DBZ_SCHEMA; }
+  catch (const HostOnly &e) { why = e.why; return TFGPU_ROW_HOST_FALLBACK; }
+}
+
+}  // namespace dbzrecv
+}  // namespace tf
+
+using namespace tf;
+using namespace tf::dbzrecv;
+
+struct tfgpu_dbz_schema {
+  int code = 0; std::string why;
+  std::vector<Field> fields;
+  std::vector<tfgpu_dbz_field> cfields;  // views of `fields` for the C side
+  void seal() { cfields.clear(); for (auto &f : fields) cfields.push_back(tfgpu_dbz_field{f.name.c_str(), f.op, f.optional, f.scale, 0}); }
+};
+struct tfgpu_dbz_receiver {
+  std::map<std::pair<uint64_t, uint64_t>, std::shared_ptr<tfgpu_dbz_schema>> cache;
+  // the head of an earlier batch's opening message up to its payload value (tfgpu_debezium_unpack_cached)
+  bool have_known = false; std::string known_bytes; uint32_t known_off = 0, known_len = 0; uint64_t known_hash[2] = {0, 0};
+  // the last batch's results
+  struct Group { std::shared_ptr<tfgpu_dbz_schema> schema; tfgpu_dbatch *batch = nullptr; std::vector<tfgpu_dbz_row> rows; int64_t nrows = 0; };
+  std::vector<Group> groups;
+  std::vector<tfgpu_dbz_frame> frames;
+  void drop() { for (auto &g : groups) if (g.batch) tfgpu_dbatch_free(g.batch); groups.clear(); }
+};
+
+extern "C" {
+
+int tfgpu_debezium_compile_schema(const void *schema_bytes, uint64_t len, tfgpu_dbz_schema **out) {
+  if (!out || (len && !schema_bytes)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_compile_schema: null argument");
+  auto s = std::make_unique<tfgpu_dbz_schema>();
+  try { s->code = compile((const uint8_t *)schema_bytes, (size_t)len, s->fields, s->why); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  s->seal();
+  *out = s.release();
+  return TFGPU_OK;
+}
+int tfgpu_dbz_schema_info(const tfgpu_dbz_schema *s, int32_t *code, const tfgpu_dbz_field **fields, int32_t *nfields, const char **why) {
+  if (!s) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_schema_info: null schema");
+  if (code) *code = s->code;
+  if (fields) *fields = s->cfields.data();
+  if (nfields) *nfields = (int32_t)s->cfields.size();
+  if (why) *why = s->why.c_str();
+  return TFGPU_OK;
+}
+void tfgpu_dbz_schema_free(tfgpu_dbz_schema *s) { delete s; }
+
+int tfgpu_dbz_receiver_create(tfgpu_dbz_receiver **out) {
+  if (!out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receiver_create: null argument");
+  *out = new tfgpu_dbz_receiver();
+  return TFGPU_OK;
+}
+void tfgpu_dbz_receiver_destroy(tfgpu_dbz_receiver *r) { if (r) { r->drop(); delete r; } }
+// the head the receiver keeps for tfgpu_debezium_unpack_cached (0 = none yet); `known->bytes` stays the receiver's
+int tfgpu_dbz_receiver_known(const tfgpu_dbz_receiver *r, tfgpu_dbz_prefix *known) {
+  if (!r || !known) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receiver_known: null argument");
+  std::memset(known, 0, sizeof *known);
+  if (!r->have_known) return TFGPU_OK;
+  known->bytes = r->known_bytes.data(); known->len = (uint32_t)r->known_bytes.size(); known->schema_off = r->known_off; known->schema_len = r->known_len;
+  known->schema_hash[0] = r->known_hash[0]; known->schema_hash[1] = r->known_hash[1];
+  return TFGPU_OK;
+}
+
+// One message batch.  host_copy (optional): the same bytes in host memory when `bytes` is a device buffer — a new schema's text
+// and the opening message's head are taken from it instead of being copied back from the device.
+int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, int mem, const void *host_copy, const tfgpu_messages *msgs, int32_t *ngroups, int32_t *msg_codes) {
+  if (!r || (len && !bytes) || !ngroups) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receive: null argument");
+  try {
+    r->drop();
+    const int64_t nmsg = msgs ? msgs->nmsg : 1;
+    r->frames.assign((size_t)std::max<int64_t>(nmsg, 1), tfgpu_dbz_frame{});
+    int rc;
+    if (r->have_known) {
+      tfgpu_dbz_prefix k{};
+      k.bytes = r->known_bytes.data(); k.len = (uint32_t)r->known_bytes.size(); k.schema_off = r->known_off; k.schema_len = r->known_len;
+      k.schema_hash[0] = r->known_hash[0]; k.schema_hash[1] = r->known_hash[1];
+      rc = tfgpu_debezium_unpack_cached(bytes, len, mem, msgs, &k, r->frames.data());
+    } else rc = tfgpu_debezium_unpack(bytes, len, mem, msgs, r->frames.data());
+    if (rc) return rc;
+    if (msg_codes) for (int64_t m = 0; m < nmsg; m++) msg_codes[m] = r->frames[(size_t)m].code;
+    // the first message of every distinct schema, in order of first appearance
+    std::vector<std::pair<std::pair<uint64_t, uint64_t>, int64_t>> firsts;
+    {
+      std::pair<uint64_t, uint64_t> last{0, 0}; bool have_last = false;
+      std::map<std::pair<uint64_t, uint64_t>, bool> seen;
+      for (int64_t m = 0; m < nmsg; m++) {
+        const tfgpu_dbz_frame &f = r->frames[(size_t)m];
+        if (f.code) continue;
+        const std::pair<uint64_t, uint64_t> key{f.schema_hash[0], f.schema_hash[1]};
+        if (have_last && key == last) continue;  // the usual topic: one schema
+        last = key; have_last = true;
+        if (seen.emplace(key, true).second) firsts.push_back({key, m});
+      }
+    }
+    const uint8_t *host = mem == TFGPU_MEM_HOST ? (const uint8_t *)bytes : (const uint8_t *)host_copy;
+    std::vector<tfgpu_row_error> errs((size_t)std::max<int64_t>(nmsg, 1));
+    for (auto &fm : firsts) {
+      const int64_t m = fm.second;
+      const tfgpu_dbz_frame &f0 = r->frames[(size_t)m];
+      auto it = r->cache.find(fm.first);
+      if (it == r->cache.end()) {
+        std::string raw((size_t)f0.schema_len, '\0');
+        if (f0.schema_len) {
+          if (host) std::memcpy(&raw[0], host + f0.schema_start, f0.schema_len);
+          else { d2h(&raw[0], (const uint8_t *)bytes + f0.schema_start, f0.schema_len); tf::sync(); }  // a device buffer without a host copy: once per schema per process
+        }
+        if (!r->have_known && m == 0 && f0.payload_len && f0.schema_start < f0.payload_start) {
+          // the opening message's head up to its payload value, for the next batches; usable when the payload is the message's
+          // last member (message 0 starts at offset 0)
+          const uint64_t ps = f0.payload_start;
+          r->known_bytes.resize((size_t)ps);
+          if (host) std::memcpy(&r->known_bytes[0], host, (size_t)ps);
+          else { d2h(&r->known_bytes[0], bytes, (size_t)ps); tf::sync(); }
+          r->known_off = (uint32_t)f0.schema_start; r->known_len = f0.schema_len; r->known_hash[0] = fm.first.first; r->known_hash[1] = fm.first.second;
+          r->have_known = true;
+        }
+        auto s = std::make_shared<tfgpu_dbz_schema>();
+        s->code = compile((const uint8_t *)raw.data(), raw.size(), s->fields, s->why);
+        s->seal();
+        it = r->cache.emplace(fm.first, s).first;
+      }
+      const std::shared_ptr<tfgpu_dbz_schema> &s = it->second;
+      tfgpu_dbz_options o{};
+      o.schema_hash[0] = fm.first.first; o.schema_hash[1] = fm.first.second;
+      o.nfields = s->code ? 0 : (int32_t)s->cfields.size(); o.fields = s->code ? nullptr : s->cfields.data(); o.schema_code = s->code;
+      tfgpu_dbz_receiver::Group g;
+      g.schema = s;
+      g.rows.resize((size_t)std::max<int64_t>(nmsg, 1));
+      int64_t ne = 0;
+      rc = tfgpu_debezium_parse(&o, bytes, len, mem, msgs, r->frames.data(), &g.batch, g.rows.data(), nmsg, errs.data(), (int64_t)errs.size(), &ne);
+      if (rc) return rc;
+      if (msg_codes) for (int64_t i = 0; i < std::min<int64_t>(ne, (int64_t)errs.size()); i++) if (errs[(size_t)i].row >= 0 && errs[(size_t)i].row < nmsg) msg_codes[errs[(size_t)i].row] = errs[(size_t)i].code;
+      tfgpu_batch v{};
+      if (g.batch && tfgpu_dbatch_view(g.batch, &v) == TFGPU_OK) g.nrows = v.nrows;
+      if (s->code || g.nrows == 0) { if (g.batch) tfgpu_dbatch_free(g.batch); continue; }  // a schema that fails as a whole produces no rows
+      g.rows.resize((size_t)g.nrows);
+      r->groups.push_back(std::move(g));
+    }
+    *ngroups = (int32_t)r->groups.size();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
+// One table's rows of the last batch.  *batch passes to the caller (tfgpu_dbatch_free); rows / fields stay the receiver's until
+// the next tfgpu_dbz_receive.
+int tfgpu_dbz_receive_group(tfgpu_dbz_receiver *r, int32_t g, tfgpu_dbatch **batch, const tfgpu_dbz_row **rows, int64_t *nrows, const tfgpu_dbz_field **fields, int32_t *nfields) {
+  if (!r || g < 0 || g >= (int32_t)r->groups.size() || !batch) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receive_group: bad argument");
+  auto &G = r->groups[(size_t)g];
+  if (!G.batch) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receive_group: the group's batch was taken already");
+  *batch = G.batch; G.batch = nullptr;
+  if (rows) *rows = G.rows.data();
+  if (nrows) *nrows = G.nrows;
+  if (fields) *fields = G.schema->cfields.data();
+  if (nfields) *nfields = (int32_t)G.schema->cfields.size();
+  return TFGPU_OK;
+}
+
+}  // extern "C"

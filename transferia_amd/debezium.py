@@ -1,6 +1,6 @@
-"""Host side of the Debezium parser with inline schemas: what the reference does ONCE PER SCHEMA before any
-value is touched — unmarshal the Kafka Connect schema, find the `before` / `after` structs, resolve every field to its
-receiver and column type — and the loop that hands each group of messages to the device.
+"""ctypes pass-through to the Debezium receiver's host half, which lives behind the C ABI (csrc/tf_dbzrecv.cpp: schema compilation,
+the schema cache, DoBatch's loop) — what the reference does ONCE PER SCHEMA before any value is touched, and the loop that hands
+each group of messages to the device.  A cgo shim binds the same entry points.
 
     Receiver.receiveSchema / receiveTableSchema    pkg/debezium/receiver.go:60-96, 45-59
     receiveFieldColSchema                          pkg/debezium/receiver_engine.go:108-146
@@ -15,7 +15,7 @@ The per-message work is tfgpu_debezium_unpack / tfgpu_debezium_parse (csrc/tf_de
 """
 from __future__ import annotations
 
-import json
+import ctypes as C
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -35,136 +35,37 @@ class HostOnly(ValueError):
     """The stock code must handle this schema (arrays, __dt_original_type_info, keys bound by case folding, a Go panic)."""
 
 
-class _Obj(list):
-    """A JSON object as its (key, value) pairs in document order (json.loads object_pairs_hook); arrays stay plain lists."""
-
-
-def _member(pairs, name: str):
-    """encoding/json's struct-field binding: a key names the field exactly or under case folding; the LAST such key wins.
-    Returns (value, found); a key that matches only by folding is left to the host (the device binds exact keys only)."""
-    out, found = None, False
-    for k, v in pairs:
-        if k == name:
-            out, found = v, True
-        elif k.lower() == name.lower():
-            raise HostOnly("key %r binds %r by case folding" % (k, name))
-    return out, found
-
-
-def _string(pairs, name: str) -> str:
-    v, found = _member(pairs, name)
-    if not found or v is None:
-        return ""
-    if not isinstance(v, str):
-        raise SchemaError("json: cannot unmarshal %s into Go struct field Schema.%s of type string" % (type(v).__name__, name))
-    return v
-
-
-class _Schema:
-    """debezium_schema.go:12-22, as json.Unmarshal fills it."""
-
-    def __init__(self, node, depth=0):
-        self.field = self.name = self.type = self.scale = ""
-        self.optional, self.fields, self.has_parameters, self.has_dt_info = False, [], False, False
-        if node is None:
-            return
-        if not isinstance(node, _Obj) or depth > 64:
-            raise SchemaError("json: cannot unmarshal into Go value of type common.Schema")
-        self.field, self.name, self.type = _string(node, "field"), _string(node, "name"), _string(node, "type")
-        v, found = _member(node, "optional")
-        if found and v is not None:
-            if not isinstance(v, bool):
-                raise SchemaError("Schema.optional")
-            self.optional = v
-        v, found = _member(node, "version")
-        if found and v is not None and (isinstance(v, bool) or not isinstance(v, int) or not -(1 << 63) <= v < (1 << 63)):
-            raise SchemaError("Schema.version")
-        v, found = _member(node, "parameters")
-        if found and v is not None:
-            if not _is_object(v):
-                raise SchemaError("Schema.parameters")
-            self.has_parameters = True
-            for k in ("length", "connect.decimal.precision", "allowed"):
-                _string(v, k)
-            self.scale = _string(v, "scale")
-        v, found = _member(node, "items")
-        if found and v is not None:
-            if not _is_object(v):
-                raise SchemaError("Schema.items")
-            _Schema(v, depth + 1)
-        v, found = _member(node, "__dt_original_type_info")
-        self.has_dt_info = found and v is not None
-        v, found = _member(node, "fields")
-        if found and v is not None:
-            if not isinstance(v, list) or isinstance(v, _Obj):
-                raise SchemaError("Schema.fields")
-            self.fields = [_Schema(x, depth + 1) for x in v]
-
-    def find(self, field_name: str) -> Optional["_Schema"]:
-        for f in self.fields:  # FindSchemaDescr: the first one
-            if f.field == field_name:
-                return f
-        return None
-
-
-def _is_object(v) -> bool:
-    return isinstance(v, _Obj)
-
-
-def _receiver(f: _Schema) -> Tuple[int, int]:
-    """(DBZ_* op, scale) of one field with an empty original type: receiveFieldColSchema + the default matchers."""
-    if f.has_dt_info or f.type == "array":
-        return abi.DBZ_HOST, 0
-    simple = {"int8": abi.DBZ_INT8, "int16": abi.DBZ_INT16, "int32": abi.DBZ_INT32, "int64": abi.DBZ_INT64, "boolean": abi.DBZ_BOOLEAN, "string": abi.DBZ_STRING,
-              "float": abi.DBZ_FLOAT64, "double": abi.DBZ_FLOAT64}
-    if f.type in simple:
-        return simple[f.type], 0
-    if f.type == "struct":
-        if f.name == "io.debezium.data.geometry.Point":
-            return abi.DBZ_POINT, 0
-        if f.name == "io.debezium.data.VariableScaleDecimal":
-            return abi.DBZ_VSD, 0
-    if f.type == "bytes":
-        if f.name == "org.apache.kafka.connect.data.Decimal":
-            scale = 0
-            if f.has_parameters and f.scale != "":
-                try:  # strconv.Atoi
-                    if not f.scale.lstrip("+-").isdigit() or not f.scale.lstrip("+-").isascii():
-                        raise ValueError
-                    scale = int(f.scale)
-                    if not INT32_MIN <= scale < (1 << 31):
-                        raise ValueError
-                except ValueError:
-                    scale = INT32_MIN  # every non-nil value fails ("unable to parse scale")
-            return abi.DBZ_DECIMAL, scale
-        return abi.DBZ_BYTES, 0
-    raise SchemaError("unable to find field receiver - even default, for kafka type: %s" % f.type)
-
-
 def compile_schema(schema_bytes: bytes):
-    """receiveSchema for one distinct schema: [(name, DBZ_*, optional, scale)] of the `after` struct.
-    Raises SchemaError (→ TFGPU_ROW_DBZ_SCHEMA for every message of the schema) or HostOnly (→ TFGPU_ROW_HOST_FALLBACK)."""
-    if not schema_bytes:
-        raise SchemaError("unexpected end of JSON input")
+    """receiveSchema for one distinct schema (tfgpu_debezium_compile_schema, csrc/tf_dbzrecv.cpp): [(name, DBZ_*, optional, scale)] of
+    the `after` struct.  Raises SchemaError (→ TFGPU_ROW_DBZ_SCHEMA for every message of the schema) or HostOnly (→ TFGPU_ROW_HOST_FALLBACK)."""
+    from . import lib
+    L = lib.load()
+    buf = np.frombuffer(schema_bytes, dtype=np.uint8) if len(schema_bytes) else np.zeros(1, np.uint8)
+    h = C.c_void_p()
+    L.tfgpu_debezium_compile_schema.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib._check(L.tfgpu_debezium_compile_schema(C.c_void_p(buf.ctypes.data), len(schema_bytes), C.byref(h)))
     try:
-        node = json.loads(schema_bytes.decode("utf-8", "replace"), object_pairs_hook=_Obj)
-    except RecursionError:
-        raise HostOnly("schema nested too deep")
-    if node is not None and not _is_object(node):
-        raise SchemaError("json: cannot unmarshal into Go value of type common.Schema")
-    top = _Schema(node)
-    before, after = top.find("before"), top.find("after")
-    if before is None or after is None:
-        raise HostOnly("receiveTableSchema(nil): the reference dereferences a nil schema")
-    out = []
-    for which in (before, after):
-        fields = [(f.field,) + _receiver(f) + (f.optional,) for f in which.fields]
-        out.append([(n, op, opt, scale) for (n, op, scale, opt) in fields])
-    if out[0] != out[1]:
-        raise HostOnly("before and after structs differ: Delete rows would have another TableSchema than the rest")
-    if len({f[0] for f in out[1]}) != len(out[1]):
-        raise HostOnly("a field name repeats")
-    return out[1]
+        code, why, fields = _schema_info(L, h)
+    finally:
+        L.tfgpu_dbz_schema_free.argtypes = [C.c_void_p]
+        L.tfgpu_dbz_schema_free(h)
+    if code == abi.ROW_DBZ_SCHEMA:
+        raise SchemaError(why)
+    if code == abi.ROW_HOST_FALLBACK:
+        raise HostOnly(why)
+    return fields
+
+
+def _fields_of(ptr, n):
+    return [((ptr[i].name or b"").decode("utf-8", "replace"), int(ptr[i].op), bool(ptr[i].optional), int(ptr[i].scale)) for i in range(n)]
+
+
+def _schema_info(L, h):
+    code, n, why = C.c_int32(0), C.c_int32(0), C.c_char_p()
+    fp = C.POINTER(abi.CDbzField)()
+    L.tfgpu_dbz_schema_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(abi.CDbzField)), C.POINTER(C.c_int32), C.POINTER(C.c_char_p)]
+    L.tfgpu_dbz_schema_info(h, C.byref(code), C.byref(fp), C.byref(n), C.byref(why))
+    return int(code.value), (why.value or b"").decode("utf-8", "replace"), _fields_of(fp, int(n.value))
 
 
 def table_schema(fields, ns: str, table: str) -> abi.Schema:
@@ -181,65 +82,61 @@ class Parsed:
 
 
 class Parser:
-    """DebeziumImpl over message batches.  parse() returns ([Parsed per distinct schema, in order of first appearance],
+    """DebeziumImpl over message batches: a pass-through to tfgpu_dbz_receiver (csrc/tf_dbzrecv.cpp), which keeps the schema cache and
+    the opening message's head.  parse() returns ([Parsed per distinct schema, in order of first appearance],
     {message index: TFGPU_ROW_* code} for the messages that become `_unparsed` items or go to the stock code)."""
 
     def __init__(self, lib):
         self.lib = lib
-        self.cache: Dict[Tuple[int, int], object] = {}
-        self.known = None   # (prefix bytes, schema_off, schema_len, hash) of the last batch's opening message: the cache hit path
+        L = lib.load()
+        lib.init()
+        self.cache: Dict[tuple, abi.Schema] = {}  # the distinct (table, fields) seen so far — a view for diagnostics; the cache itself is the receiver's
+        self._h = C.c_void_p()
+        L.tfgpu_dbz_receiver_create.argtypes = [C.POINTER(C.c_void_p)]
+        lib._check(L.tfgpu_dbz_receiver_create(C.byref(self._h)))
+        L.tfgpu_dbz_receive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
+        L.tfgpu_dbz_receive_group.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.POINTER(abi.CDbzField)), C.POINTER(C.c_int32)]
+        L.tfgpu_dbz_receiver_destroy.argtypes = [C.c_void_p]
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.load().tfgpu_dbz_receiver_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def known(self):
+        """(prefix bytes, schema_off, schema_len, hash) of the head the receiver keeps for tfgpu_debezium_unpack_cached, or None"""
+        k = abi.CDbzPrefix()
+        L = self.lib.load()
+        L.tfgpu_dbz_receiver_known.argtypes = [C.c_void_p, C.POINTER(abi.CDbzPrefix)]
+        self.lib._check(L.tfgpu_dbz_receiver_known(self._h, C.byref(k)))
+        if not k.len:
+            return None
+        return (C.string_at(k.bytes, k.len), int(k.schema_off), int(k.schema_len), (int(k.schema_hash[0]), int(k.schema_hash[1])))
 
     def parse(self, data, msgs: Optional[abi.CMessages] = None, host_bytes: Optional[bytes] = None):
         lib = self.lib
-        frames = lib.debezium_unpack(data, msgs, self.known)
-        bad = np.nonzero(frames["code"])[0]
-        errors = dict(zip(bad.tolist(), frames["code"][bad].tolist()))
-        ok = np.nonzero(frames["code"] == 0)[0]
-        groups: Dict[Tuple[int, int], int] = {}
-        if len(ok):  # first message of every distinct schema
-            hashes = frames["schema_hash"][ok]
-            if (hashes[:, 0] == hashes[0, 0]).all() and (hashes[:, 1] == hashes[0, 1]).all():  # the usual topic: one schema
-                groups[(int(hashes[0][0]), int(hashes[0][1]))] = int(ok[0])
-            else:
-                _u, first = np.unique(hashes, axis=0, return_index=True)
-                for i in sorted(first):
-                    groups[(int(hashes[i][0]), int(hashes[i][1]))] = int(ok[i])
+        L = lib.load()
+        ptr_, n, mem, keep = lib._bytes_arg(data)
+        nmsg = int(msgs.nmsg) if msgs is not None else 1
+        codes = np.zeros(max(nmsg, 1), np.int32)
+        ng = C.c_int32(0)
+        hb = np.frombuffer(host_bytes, dtype=np.uint8) if host_bytes else None
+        lib._check(L.tfgpu_dbz_receive(self._h, ptr_, n, mem, C.c_void_p(hb.ctypes.data) if hb is not None else None, C.byref(msgs) if msgs is not None else None,
+                                       C.byref(ng), C.c_void_p(codes.ctypes.data)))
         out = []
-        for key, m in groups.items():
-            if key not in self.cache:
-                a, n = int(frames["schema_start"][m]), int(frames["schema_len"][m])
-                raw = self._bytes(data, host_bytes, a, n)
-                head = host_bytes if host_bytes is not None else (data if isinstance(data, (bytes, bytearray)) else None)
-                if self.known is None and m == 0 and head is not None and int(frames["payload_len"][m]):
-                    # the opening message's head up to its payload value, for the next batches (tfgpu_debezium_unpack_cached);
-                    # usable when the payload is the message's last member (message 0 starts at offset 0)
-                    ps = int(frames["payload_start"][m])
-                    if a < ps:
-                        self.known = (bytes(head[:ps]), a, n, key)
-                try:
-                    self.cache[key] = compile_schema(raw)
-                except SchemaError:
-                    self.cache[key] = abi.ROW_DBZ_SCHEMA
-                except HostOnly:
-                    self.cache[key] = abi.ROW_HOST_FALLBACK
-            comp = self.cache[key]
-            if isinstance(comp, int):  # receiveSchema's fate comes after the payload / op checks: the device still runs those
-                _db, _rows, errs = lib.debezium_parse(key, [], data, frames, msgs, schema_code=comp)
-                for mm, code in errs:
-                    errors[mm] = code
-                continue
-            db, rows, errs = lib.debezium_parse(key, comp, data, frames, msgs)
-            for mm, code in errs:
-                errors[mm] = code
-            if db.nrows:
-                ns, table = db.table_id()
-                out.append(Parsed(db, rows, table_schema(comp, ns, table)))
-        return out, errors
-
-    @staticmethod
-    def _bytes(data, host_bytes, a, n) -> bytes:
-        if host_bytes is not None:
-            return host_bytes[a:a + n]
-        if isinstance(data, (bytes, bytearray, memoryview)):
-            return bytes(data[a:a + n])
-        return data.download()[a:a + n]  # a DeviceBuffer without a host copy: rare (one schema per table per process)
+        for g in range(int(ng.value)):
+            bh, rp, nr, fp, nf = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.POINTER(abi.CDbzField)(), C.c_int32(0)
+            lib._check(L.tfgpu_dbz_receive_group(self._h, g, C.byref(bh), C.byref(rp), C.byref(nr), C.byref(fp), C.byref(nf)))
+            db = lib.DeviceBatch(bh)
+            rows = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(int(nr.value) * abi.DBZ_ROW_DTYPE.itemsize,)).view(abi.DBZ_ROW_DTYPE).copy() if nr.value else np.zeros(0, abi.DBZ_ROW_DTYPE)
+            ns, table = db.table_id()
+            fields = _fields_of(fp, int(nf.value))
+            sch = table_schema(fields, ns, table)
+            self.cache.setdefault((ns, table, tuple(fields)), sch)
+            out.append(Parsed(db, rows, sch))
+        bad = np.nonzero(codes[:nmsg])[0]
+        return out, dict(zip(bad.tolist(), codes[bad].tolist()))
