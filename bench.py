@@ -1234,9 +1234,7 @@ class Configs4DebeziumWorkload(Base):
             self.qopts = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 20, table_schema=p.schema, old_key_types=["int64"])
         meta = None
         if e.world == 1:  # ID / LSN / CommitTime / names_form ride on src_row = message index
-            ids, lsns, cts, nf = np.zeros(self.n, np.uint32), np.zeros(self.n, np.uint64), np.zeros(self.n, np.uint64), np.zeros(self.n, np.uint8)
-            m = p.rows["msg"]
-            ids[m], lsns[m], cts[m], nf[m] = p.rows["id"], p.rows["lsn"], p.rows["commit_time"], p.rows["names_form"]
+            ids, lsns, cts, nf = p.meta()   # the receiver lays them out by message index (tfgpu_dbz_receive_group_meta)
             meta = abi.row_meta(self.n, ids=ids, lsns=lsns, commit_times=cts, names_form=nf)
         one = self.shard.apply(p.batch).transformed
         grouped, counts = lib.partition(one, e.world)
@@ -1466,6 +1464,15 @@ def main():
     if args.steps <= 0:  # no K given: a timed region of >= 1 s
         args.steps = 24
     W.total_passes = args.steps * passes
+    if os.environ.get("TFGPU_BENCH_HOSTPROF") == "1":  # where the HOST spends a pass (stderr; the JSON line is unaffected): cProfile over a few untimed passes
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(5):
+            W.step()
+        lib.synchronize()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
     dt = e.group.max_seconds(W.timed(args.steps * passes))
     W.dt = dt
     ms_per_pass = dt / (args.steps * passes) * 1e3

@@ -813,6 +813,9 @@ void tfgpu_dbz_receiver_destroy(tfgpu_dbz_receiver *r);
 int tfgpu_dbz_receiver_known(const tfgpu_dbz_receiver *r, tfgpu_dbz_prefix *known);  /* the head it keeps (len 0: none yet); bytes stay the receiver's */
 int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, int mem, const void *host_copy, const tfgpu_messages *msgs, int32_t *ngroups, int32_t *msg_codes);
 int tfgpu_dbz_receive_group(tfgpu_dbz_receiver *r, int32_t g, tfgpu_dbatch **batch, const tfgpu_dbz_row **rows, int64_t *nrows, const tfgpu_dbz_field **fields, int32_t *nfields);
+/* table g's ID / LSN / CommitTime / names_form by MESSAGE index — the arrays a tfgpu_row_meta of the whole message batch takes
+ * (nmsg entries each, zeroed first; NULL: not wanted): the rows' src_row is the message index, so this is their row meta.      */
+int tfgpu_dbz_receive_group_meta(tfgpu_dbz_receiver *r, int32_t g, int64_t nmsg, uint32_t *ids, uint64_t *lsns, uint64_t *commit_times, uint8_t *names_form);
 
 /* ---- ClickHouse Native column block -------------------------------------------------------------------- */
 /* The v2 ClickHouse sink turns every ChangeItem into a []any row (pkg/providers/clickhouse/async/marshaller.go:62-190) and

@@ -312,4 +312,25 @@ int tfgpu_dbz_receive_group(tfgpu_dbz_receiver *r, int32_t g, tfgpu_dbatch **bat
   return TFGPU_OK;
 }
 
+// The ChangeItem members that are not columns, laid out by MESSAGE index (= src_row of the group's rows) — the arrays a
+// tfgpu_row_meta of the whole message batch takes (ids u32, lsns u64, commit_times u64, names_form u8; nmsg entries each, zeroed
+// first): what the shim would otherwise scatter row by row.  Call it before the next tfgpu_dbz_receive.
+int tfgpu_dbz_receive_group_meta(tfgpu_dbz_receiver *r, int32_t g, int64_t nmsg, uint32_t *ids, uint64_t *lsns, uint64_t *commit_times, uint8_t *names_form) {
+  if (!r || g < 0 || g >= (int32_t)r->groups.size() || nmsg < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receive_group_meta: bad argument");
+  const auto &G = r->groups[(size_t)g];
+  if (ids) std::memset(ids, 0, (size_t)nmsg * 4);
+  if (lsns) std::memset(lsns, 0, (size_t)nmsg * 8);
+  if (commit_times) std::memset(commit_times, 0, (size_t)nmsg * 8);
+  if (names_form) std::memset(names_form, 0, (size_t)nmsg);
+  for (int64_t i = 0; i < G.nrows; i++) {
+    const tfgpu_dbz_row &w = G.rows[(size_t)i];
+    if (w.msg < 0 || w.msg >= nmsg) continue;
+    if (ids) ids[w.msg] = w.id;
+    if (lsns) lsns[w.msg] = w.lsn;
+    if (commit_times) commit_times[w.msg] = w.commit_time;
+    if (names_form) names_form[w.msg] = w.names_form;
+  }
+  return TFGPU_OK;
+}
+
 }  // extern "C"

@@ -77,8 +77,9 @@ class Parsed:
     """One table's rows of a message batch: the device batch (src_row = message index), per-row ID / LSN / CommitTime /
     names_form (abi.DBZ_ROW_DTYPE) and the TableSchema the items carry."""
 
-    def __init__(self, batch, rows: np.ndarray, schema: abi.Schema):
+    def __init__(self, batch, rows: np.ndarray, schema: abi.Schema, meta=None):
         self.batch, self.rows, self.schema = batch, rows, schema
+        self.meta = meta   # () -> (ids, lsns, commit_times, names_form) by message index (tfgpu_dbz_receive_group_meta); valid until the next parse()
 
 
 class Parser:
@@ -105,6 +106,13 @@ class Parser:
                 self._h = None
         except Exception:  # noqa: BLE001
             pass
+
+    def _meta(self, g, nmsg):
+        ids, lsns, cts, nf = np.empty(nmsg, np.uint32), np.empty(nmsg, np.uint64), np.empty(nmsg, np.uint64), np.empty(nmsg, np.uint8)
+        L = self.lib.load()
+        L.tfgpu_dbz_receive_group_meta.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib._check(L.tfgpu_dbz_receive_group_meta(self._h, g, nmsg, ids.ctypes.data, lsns.ctypes.data, cts.ctypes.data, nf.ctypes.data))
+        return ids, lsns, cts, nf
 
     @property
     def known(self):
@@ -137,6 +145,6 @@ class Parser:
             fields = _fields_of(fp, int(nf.value))
             sch = table_schema(fields, ns, table)
             self.cache.setdefault((ns, table, tuple(fields)), sch)
-            out.append(Parsed(db, rows, sch))
+            out.append(Parsed(db, rows, sch, meta=(lambda g=g, nmsg=nmsg: self._meta(g, nmsg))))
         bad = np.nonzero(codes[:nmsg])[0]
         return out, dict(zip(bad.tolist(), codes[bad].tolist()))
