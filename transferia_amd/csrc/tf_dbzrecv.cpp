@@ -177,7 +177,9 @@ struct tfgpu_dbz_receiver {
   struct Group { std::shared_ptr<tfgpu_dbz_schema> schema; tfgpu_dbatch *batch = nullptr; std::vector<tfgpu_dbz_row> rows; int64_t nrows = 0; };
   std::vector<Group> groups;
   std::vector<tfgpu_dbz_frame> frames;
-  void drop() { for (auto &g : groups) if (g.batch) tfgpu_dbatch_free(g.batch); groups.clear(); }
+  std::vector<tfgpu_row_error> errs;
+  std::vector<std::vector<tfgpu_dbz_row>> spare_rows;
+  void drop() { for (auto &g : groups) { if (g.batch) tfgpu_dbatch_free(g.batch); spare_rows.push_back(std::move(g.rows)); } groups.clear(); }
 };
 
 extern "C" {
@@ -224,7 +226,7 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
   try {
     r->drop();
     const int64_t nmsg = msgs ? msgs->nmsg : 1;
-    r->frames.assign((size_t)std::max<int64_t>(nmsg, 1), tfgpu_dbz_frame{});
+    if ((int64_t)r->frames.size() < std::max<int64_t>(nmsg, 1)) r->frames.resize((size_t)std::max<int64_t>(nmsg, 1));  // (filled by the unpack call: no need to clear 48 bytes per message per batch)
     int rc;
     if (r->have_known) {
       tfgpu_dbz_prefix k{};
@@ -249,7 +251,8 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
       }
     }
     const uint8_t *host = mem == TFGPU_MEM_HOST ? (const uint8_t *)bytes : (const uint8_t *)host_copy;
-    std::vector<tfgpu_row_error> errs((size_t)std::max<int64_t>(nmsg, 1));
+    std::vector<tfgpu_row_error> &errs = r->errs;
+    if ((int64_t)errs.size() < std::max<int64_t>(nmsg, 1)) errs.resize((size_t)std::max<int64_t>(nmsg, 1));
     for (auto &fm : firsts) {
       const int64_t m = fm.second;
       const tfgpu_dbz_frame &f0 = r->frames[(size_t)m];
@@ -281,15 +284,15 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
       o.nfields = s->code ? 0 : (int32_t)s->cfields.size(); o.fields = s->code ? nullptr : s->cfields.data(); o.schema_code = s->code;
       tfgpu_dbz_receiver::Group g;
       g.schema = s;
-      g.rows.resize((size_t)std::max<int64_t>(nmsg, 1));
+      if (!r->spare_rows.empty()) { g.rows.swap(r->spare_rows.back()); r->spare_rows.pop_back(); }  // (buffers of earlier batches: no 32 bytes per message to clear)
+      if ((int64_t)g.rows.size() < std::max<int64_t>(nmsg, 1)) g.rows.resize((size_t)std::max<int64_t>(nmsg, 1));
       int64_t ne = 0;
       rc = tfgpu_debezium_parse(&o, bytes, len, mem, msgs, r->frames.data(), &g.batch, g.rows.data(), nmsg, errs.data(), (int64_t)errs.size(), &ne);
       if (rc) return rc;
       if (msg_codes) for (int64_t i = 0; i < std::min<int64_t>(ne, (int64_t)errs.size()); i++) if (errs[(size_t)i].row >= 0 && errs[(size_t)i].row < nmsg) msg_codes[errs[(size_t)i].row] = errs[(size_t)i].code;
       tfgpu_batch v{};
       if (g.batch && tfgpu_dbatch_view(g.batch, &v) == TFGPU_OK) g.nrows = v.nrows;
-      if (s->code || g.nrows == 0) { if (g.batch) tfgpu_dbatch_free(g.batch); continue; }  // a schema that fails as a whole produces no rows
-      g.rows.resize((size_t)g.nrows);
+      if (s->code || g.nrows == 0) { if (g.batch) tfgpu_dbatch_free(g.batch); r->spare_rows.push_back(std::move(g.rows)); continue; }  // a schema that fails as a whole produces no rows
       r->groups.push_back(std::move(g));
     }
     *ngroups = (int32_t)r->groups.size();

@@ -140,7 +140,7 @@ class Parser:
             bh, rp, nr, fp, nf = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.POINTER(abi.CDbzField)(), C.c_int32(0)
             lib._check(L.tfgpu_dbz_receive_group(self._h, g, C.byref(bh), C.byref(rp), C.byref(nr), C.byref(fp), C.byref(nf)))
             db = lib.DeviceBatch(bh)
-            rows = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(int(nr.value) * abi.DBZ_ROW_DTYPE.itemsize,)).view(abi.DBZ_ROW_DTYPE).copy() if nr.value else np.zeros(0, abi.DBZ_ROW_DTYPE)
+            rows = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(int(nr.value) * abi.DBZ_ROW_DTYPE.itemsize,)).view(abi.DBZ_ROW_DTYPE) if nr.value else np.zeros(0, abi.DBZ_ROW_DTYPE)  # (a view of the receiver's buffer: valid until the next parse())
             ns, table = db.table_id()
             fields = _fields_of(fp, int(nf.value))
             sch = table_schema(fields, ns, table)
