@@ -412,7 +412,7 @@ class CsvWorkload(Base):
                        "operations; gfx950's v_add3 / v_xor3 / v_bfi / v_alignbit carry two or three of them per instruction, so `frac` can approach 1 while the VALU "
                        "issues fewer instructions than that — `issue_frac` (measured instructions, when profiles/pmc_traffic.json is of this build) is the issue-slot view"}
         # the same fraction from the kernel's MEASURED VALU instruction count per value (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of this
-        # very source, tools/gpu_round3.sh) instead of the algorithmic tally: instructions issued, against one per lane per cycle
+        # very source, tools/gpu_visit.sh evidence) instead of the algorithmic tally: instructions issued, against one per lane per cycle
         try:
             import hashlib
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -565,7 +565,7 @@ class JsonWorkload(_Prepared):
 
     def alg(self):
         s = self.state
-        return {"json_parse_tiles": len(self.data) + s["parsed_bytes"], "json_parse_lines": len(self.data) + s["parsed_bytes"], "csv_count_newlines": len(self.data), "ser_chunk_write": s["kept_bytes"] + s["out_bytes"], "ser_chunk_len": s["kept_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"],
+        return {"json_parse_quick": len(self.data) + s["parsed_bytes"], "json_parse_tiles": len(self.data) + s["parsed_bytes"], "json_parse_lines": len(self.data) + s["parsed_bytes"], "csv_count_newlines": len(self.data), "ser_chunk_write": s["kept_bytes"] + s["out_bytes"], "ser_chunk_len": s["kept_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"],
                 "ser_cell_len": s["kept_bytes"], "json_copy_cells": 2 * s["parsed_bytes"]}
 
     def config(self):
@@ -622,7 +622,7 @@ class SrWorkload(_Prepared):
 
     def alg(self):
         s = self.state
-        return {"sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
+        return {"sr_parse_quick": len(self.data), "sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
                 "ser_cell_write": s["parsed_bytes"] + s["out_bytes"], "ser_cell_len": s["parsed_bytes"]}
 
     def config(self):
@@ -688,7 +688,7 @@ class Configs2Workload(_Prepared):
 
     def alg(self):
         s = self.state
-        return {"sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
+        return {"sr_parse_quick": len(self.data), "sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
                 "ser_chunk_write": s["kept_bytes"] + s["out_bytes"], "ser_chunk_len": s["kept_bytes"], "ser_cell_write": s["kept_bytes"] + s["out_bytes"], "ser_cell_len": s["kept_bytes"], "compact_gather": int(s["parsed_bytes"] + s["kept_bytes"])}
 
     def config(self):

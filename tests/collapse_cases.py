@@ -5,7 +5,7 @@ import numpy as np
 from transferia_amd import abi
 import os as _os
 
-SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (TFGPU_TEST_SEED=n bash tools/gpu_visit.sh tests TAG)
 
 KINDS = ["insert", "update", "delete", "other"]
 STRS = [b"", b"a", b"b", b"<x>&", "é".encode(), b"\\u003c", b'"', b"a\x00", "\ufffd".encode(), b"\xff", b"\xfe", b"a\xc3"]  # the last three: invalid UTF-8

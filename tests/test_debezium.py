@@ -11,7 +11,7 @@ from transferia_amd import abi
 from util import golden
 import os as _os
 
-SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (TFGPU_TEST_SEED=n bash tools/gpu_visit.sh tests TAG)
 
 
 def canon_value(v):

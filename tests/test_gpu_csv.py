@@ -8,7 +8,7 @@ from util import golden
 from test_gpu_transformers import assert_batches_equal
 import os as _os
 
-SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (tools/gpu_soak.sh)
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))  # 0 = the committed seeds; other values: soak runs (TFGPU_TEST_SEED=n bash tools/gpu_visit.sh tests TAG)
 
 pytestmark = pytest.mark.gpu
 

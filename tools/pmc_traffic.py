@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Builds OUT/pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE (and the mask kernel's SQ_INSTS_VALU / SQ_WAVES) passes that
+tools/gpu_visit.sh `traffic` ran: HBM bytes per launch = FETCH_SIZE x 2 (the gfx950 correction for wide coalesced reads,
+MI355X_MICROARCH.md "HBM") + WRITE_SIZE, both in KiB.  Every entry is stamped with the sha256 of the kernel's source file: bench.py
+prints roofline.traffic only when that stamp matches the source it runs."""
+import hashlib
+import json
+import re
+import sys
+
+out = sys.argv[1]
+res = {}
+
+
+def sha(name):
+    return hashlib.sha256(open("transferia_amd/csrc/" + name, "rb").read()).hexdigest()
+
+
+try:
+    mv = {m.group(1): float(m.group(2)) for m in (re.search(r"(SQ_INSTS_VALU|SQ_WAVES)\s+per_dispatch=([0-9.e+]+)", l) for l in open(out + "/pmc_mask.log") if "mask_hmac" in l) if m}
+    if "SQ_INSTS_VALU" in mv and mv.get("SQ_WAVES"):
+        res["mask_hmac_sha256"] = {"workload": "csv", "rows_per_launch": 1 << 20, "valu_wave_instructions_per_launch": mv["SQ_INSTS_VALU"], "waves": mv["SQ_WAVES"],
+                                   "valu_instructions_per_value": round(mv["SQ_INSTS_VALU"] / mv["SQ_WAVES"], 1), "source_file": "tf_transform.hip", "source_sha256": sha("tf_transform.hip"),
+                                   "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES of this build (a wave-instruction is one instruction for each of the wave's 64 values)"}
+except OSError:
+    pass
+for kern, wl, src, rows in (("csv_parse_regular", "csv", "tf_csv.hip", 1 << 20), ("json_parse_quick", "json", "tf_jsonquick.inc", 1 << 18), ("ser_chunk_write", "configs3", "tf_serialize.hip", 1 << 20)):
+    vals = {}
+    for leg in ("fetch", "write"):
+        try:
+            for line in open(f"{out}/pmc_{wl}_{leg}.log"):
+                m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+per_dispatch=([0-9.e+]+)", line)
+                if m and kern[:12] in line:
+                    vals[m.group(1)] = float(m.group(2))
+        except OSError:
+            pass
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        b = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
+        res[kern] = {"rows_per_launch": rows, "workload": wl, "bytes_per_launch": b, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "source_file": src, "source_sha256": sha(src),
+                     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB, separate passes) of this build, tools/gpu_visit.sh evidence; FETCH_SIZE x2 per MI355X_MICROARCH.md"}
+json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
+print("== traffic", {k: v.get("bytes_per_launch", v.get("valu_instructions_per_value")) for k, v in res.items()})
