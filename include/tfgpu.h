@@ -628,11 +628,21 @@ typedef struct tfgpu_sr_frame {
 } tfgpu_sr_frame;
 int tfgpu_sr_frames(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_sr_frame *frames,
                     int64_t cap, int64_t *nframes);
+struct tfgpu_sr_schema; struct tfgpu_sr_property;
+int tfgpu_sr_compile_schema(const char *schema_text, uint64_t len, const char *policy, const char *manual_table_name, struct tfgpu_sr_schema **out);
+int tfgpu_sr_schema_info(const struct tfgpu_sr_schema *s, const struct tfgpu_sr_property **props, int32_t *nprops, const char **table_ns, const char **table_name, const char **title);
+void tfgpu_sr_schema_free(struct tfgpu_sr_schema *s);
 
 /* One property of the JSON schema as jsonPropertyToJSONSchemaRow resolves it (utils_json.go:71-95, types_json.go:25-32):
  * the `type` (through oneOf), and whether it is required (listed in "required" and no oneOf null).                  */
 enum { TFGPU_SRT_BOOLEAN = 1, TFGPU_SRT_INTEGER = 2, TFGPU_SRT_NUMBER = 3, TFGPU_SRT_STRING = 4, TFGPU_SRT_ANY = 5 };
 typedef struct tfgpu_sr_property { const char *name; int32_t json_type; int32_t required; } tfgpu_sr_property;
+/* The per-schema set-up behind the ABI (tf_dbzrecv.cpp): unmarshal the JSON schema text the registry returned, resolve every
+ * property (utils_json.go:15-21, 71-95; types_json.go:25-32), derive the table id (BuildJSONTableID, table_name_policy.go:73-92;
+ * policy "debezium_style" — the default — or "title"; a non-empty manual_table_name wins).  tfgpu_sr_schema_info: the properties
+ * in util.MapKeysInOrder order and the table id — what tfgpu_sr_json_options takes.  TFGPU_ERR_CONFIG carries the reference's
+ * own error texts (a schema whose type is not "object", a title that does not split, a property type without a column type).   */
+typedef struct tfgpu_sr_schema tfgpu_sr_schema;
 typedef struct tfgpu_sr_json_options {
   uint32_t schema_id;           /* frames carrying another id are left to another call                      */
   int32_t nprops;

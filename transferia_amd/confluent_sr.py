@@ -1,7 +1,8 @@
-"""Host side of the Confluent Schema Registry parser's JSON-schema path: the per-schema set-up the
-reference does in Go before any message is touched — unmarshal the JSON schema, resolve every property to a column
-(type through `oneOf`, required set) and derive the table id from the title.  It runs once per schema id (the shim
-caches it next to the registry client); the per-message work is tfgpu_sr_frames / tfgpu_sr_json_parse.
+"""ctypes pass-through to the Confluent Schema Registry parser's per-schema set-up, which lives behind the C ABI
+(tfgpu_sr_compile_schema, csrc/tf_dbzrecv.cpp): unmarshal the JSON schema, resolve every property to a column (type through
+`oneOf`, required set), derive the table id from the title.  It runs once per schema id (the shim caches it next to the
+registry client); the per-message work is tfgpu_sr_frames / tfgpu_sr_json_parse.  What stays here is the test harness's
+`ConfluentSrParser`, which turns device batches back into reference-ordered items for comparison with the oracle.
 
     JSONProperties, jsonPropertyToJSONSchemaRow   engine/utils_json.go:15-21, 71-95
     jsonSchemaTypes                               engine/types_json.go:25-32
@@ -9,7 +10,7 @@ caches it next to the registry client); the per-message work is tfgpu_sr_frames 
 """
 from __future__ import annotations
 
-import json
+import ctypes as C
 from typing import List, Optional, Tuple
 
 from . import abi
@@ -22,60 +23,43 @@ SRT_DTYPE = {abi.SRT_BOOLEAN: "boolean", abi.SRT_INTEGER: "int64", abi.SRT_NUMBE
 POLICY_DEBEZIUM_STYLE, POLICY_TITLE = "debezium_style", "title"
 
 
-def _field(obj: dict, name: str):
-    """encoding/json binds every key of the document to the struct field it names — exactly or, failing that, ignoring case —
-    in document order, so the LAST key that names the field is the one whose value stays (decode.go object())."""
-    out, want = None, name.lower()
-    for k, v in obj.items():  # json.loads keeps document order (a repeated identical key: the last one, as in Go)
-        if k == name or k.lower() == want:
-            out = v
-    return out
+def _compile(schema_text: str, policy: str, manual_table_name: str):
+    """tfgpu_sr_compile_schema (csrc/tf_dbzrecv.cpp): (title, [(name, SRT_*, required)], ns, table).  The reference's errors are ValueError."""
+    from . import lib
+    L = lib.load()
+    raw = schema_text.encode("utf-8") if isinstance(schema_text, str) else bytes(schema_text)
+    h = C.c_void_p()
+    L.tfgpu_sr_compile_schema.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    rc = L.tfgpu_sr_compile_schema(raw, len(raw), policy.encode(), (manual_table_name or "").encode(), C.byref(h))
+    if rc:
+        raise ValueError((L.tfgpu_last_error() or b"").decode("utf-8", "replace"))
+    try:
+        pp, n, ns, tn, title = C.POINTER(abi.CSrProperty)(), C.c_int32(0), C.c_char_p(), C.c_char_p(), C.c_char_p()
+        L.tfgpu_sr_schema_info.argtypes = [C.c_void_p, C.POINTER(C.POINTER(abi.CSrProperty)), C.POINTER(C.c_int32), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]
+        L.tfgpu_sr_schema_info(h, C.byref(pp), C.byref(n), C.byref(ns), C.byref(tn), C.byref(title))
+        rows = [((pp[i].name or b"").decode("utf-8", "replace"), int(pp[i].json_type), bool(pp[i].required)) for i in range(int(n.value))]
+        return (title.value or b"").decode("utf-8", "replace"), rows, (ns.value or b"").decode("utf-8", "replace"), (tn.value or b"").decode("utf-8", "replace")
+    finally:
+        L.tfgpu_sr_schema_free.argtypes = [C.c_void_p]
+        L.tfgpu_sr_schema_free(h)
 
 
 def json_schema_rows(schema_text: str) -> Tuple[str, List[Tuple[str, int, bool]]]:
     """(title, [(name, SRT_*, required)]) in util.MapKeysInOrder order — what processPayload iterates."""
-    js = json.loads(schema_text)
-    if not isinstance(js, dict) or _field(js, "type") != "object":
-        raise ValueError("json schema type must be 'object'")  # utils_json.go:35-37
-    required = set(_field(js, "required") or [])
-    props = _field(js, "properties") or {}
-    rows = []
-    for name in sorted(props, key=lambda s: s.encode("utf-8")):  # Go compares strings bytewise
-        p = props[name]
-        t = _JSON_TYPES.get(_field(p, "type") or "")
-        req = name in required
-        one_of = _field(p, "oneOf")
-        if one_of is not None:
-            for q in one_of:
-                qt = _field(q, "type") or ""
-                if qt == "null":
-                    req = False
-                else:
-                    t = _JSON_TYPES.get(qt)
-        if t is None:
-            raise ValueError("property %r: JSON-schema type without a column type (DataType \"\" in the reference)" % name)
-        rows.append((name, t, req))
-    return _field(js, "title") or "", rows
+    title, rows, _ns, _tn = _compile(schema_text, POLICY_TITLE, "")
+    return title, rows
 
 
 def build_json_table_id(title: str, policy: str = POLICY_DEBEZIUM_STYLE, manual_table_name: str = "") -> Tuple[str, str]:
-    """(ChangeItem.Schema, ChangeItem.Table)."""
-    if manual_table_name:
-        return "", manual_table_name
-    if policy == POLICY_DEBEZIUM_STYLE:
-        parts = title.split(".", 1)
-        if len(parts) != 2:
-            raise ValueError("Can't split title '%s' from json into schema and table names" % title)
-        return parts[0], parts[1]
-    if policy == POLICY_TITLE:
-        return "", title
-    raise ValueError("invalid JSONTableNamePolicy")
+    """(ChangeItem.Schema, ChangeItem.Table) — BuildJSONTableID through the same entry point (a schema that holds only the title)."""
+    import json
+    _t, _rows, ns, table = _compile(json.dumps({"type": "object", "title": title}), policy, manual_table_name)
+    return ns, table
 
 
 def sr_json_options(schema_id: int, schema_text: str, policy: str = POLICY_DEBEZIUM_STYLE, manual_table_name: str = "",
                     report_frame_errors: bool = True) -> abi.CSrJsonOptions:
-    title, rows = json_schema_rows(schema_text)
-    ns, table = build_json_table_id(title, policy, manual_table_name)
+    _title, rows, ns, table = _compile(schema_text, policy, manual_table_name)
     return abi.sr_json_options(schema_id, rows, ns, table, report_frame_errors=report_frame_errors)
 
 

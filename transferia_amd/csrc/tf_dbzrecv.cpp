@@ -1,4 +1,5 @@
-// tf_dbzrecv.cpp — the host half of the Debezium receiver behind the C ABI: what the reference does ONCE PER SCHEMA before any
+// tf_dbzrecv.cpp — the host halves of the two schema-carrying Kafka parsers behind the C ABI.  Confluent-SR JSON schemas: at the
+// end of the file (tfgpu_sr_compile_schema).  The Debezium receiver: what the reference does ONCE PER SCHEMA before any
 // value is touched, and the loop that hands each group of messages to the device.
 //
 //   Receiver.receiveSchema / receiveTableSchema    pkg/debezium/receiver.go:60-96, 45-59
@@ -12,6 +13,7 @@
 // schema by a hash of its bytes (receiver.go:61-66); so does tfgpu_dbz_receiver, keyed by the device's hash of the same bytes,
 // and it keeps the head of the batch's opening message for tfgpu_debezium_unpack_cached.  Per message everything is
 // tfgpu_debezium_unpack / tfgpu_debezium_parse (tf_debezium.hip); nothing here touches a value.
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -335,5 +337,99 @@ int tfgpu_dbz_receive_group_meta(tfgpu_dbz_receiver *r, int32_t g, int64_t nmsg,
   }
   return TFGPU_OK;
 }
+
+}  // extern "C"
+
+// ======================================================================================================================
+// Confluent Schema Registry, JSON schemas: the per-schema set-up of the reference — unmarshal the JSON schema, resolve every
+// property to a column (type through `oneOf`, the required set), derive the table id from the title.
+//   JSONProperties, jsonPropertyToJSONSchemaRow   pkg/parsers/registry/confluentschemaregistry/engine/utils_json.go:15-21, 71-95
+//   jsonSchemaTypes                               engine/types_json.go:25-32
+//   BuildJSONTableID                              table_name_policy/table_name_policy.go:73-92
+// Runs once per schema id (the shim caches it next to its registry client); per message: tfgpu_sr_frames / tfgpu_sr_json_parse.
+// ======================================================================================================================
+namespace tf {
+namespace srschema {
+// encoding/json binds every key of the document to the struct field it names — exactly or, failing that, ignoring case — in
+// document order, so the LAST key that names the field is the one whose value stays (decode.go object())
+static const Json *last_field(const Json &obj, const char *name) {
+  const Json *out = nullptr;
+  if (obj.type != Json::Obj) return nullptr;
+  for (auto &kv : obj.obj) if (kv.first == name || dbzrecv::equal_fold_ascii(kv.first, name)) out = &kv.second;
+  return out;
+}
+static int json_type_of(const Json *t) {  // types_json.go:25-32 — 0: no column type
+  if (!t || t->type != Json::Str) return 0;
+  const std::string &s = t->str;
+  if (s == "array" || s == "object") return TFGPU_SRT_ANY;
+  if (s == "boolean") return TFGPU_SRT_BOOLEAN;
+  if (s == "integer") return TFGPU_SRT_INTEGER;
+  if (s == "number") return TFGPU_SRT_NUMBER;
+  if (s == "string") return TFGPU_SRT_STRING;
+  return 0;
+}
+}  // namespace srschema
+}  // namespace tf
+
+struct tfgpu_sr_schema {
+  std::string title, ns, table;
+  std::vector<std::string> names;
+  std::vector<tfgpu_sr_property> props;
+};
+
+extern "C" {
+
+int tfgpu_sr_compile_schema(const char *schema_text, uint64_t len, const char *policy, const char *manual_table_name, tfgpu_sr_schema **out) {
+  using namespace tf::srschema;
+  if (!out || (len && !schema_text)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_compile_schema: null argument");
+  try {
+    Json js = Json::parse(std::string(schema_text ? schema_text : "", (size_t)len));
+    const Json *ty = last_field(js, "type");
+    if (js.type != Json::Obj || !ty || ty->type != Json::Str || ty->str != "object") return tf::fail(TFGPU_ERR_CONFIG, "json schema type must be 'object'");  // utils_json.go:35-37
+    auto s = std::make_unique<tfgpu_sr_schema>();
+    std::vector<std::string> required;
+    if (const Json *r = last_field(js, "required"); r && r->type == Json::Arr) for (auto &x : r->arr) if (x.type == Json::Str) required.push_back(x.str);
+    std::map<std::string, const Json *> props;  // std::string compares bytewise, as Go's sort.Strings does; a repeated key: the last one
+    if (const Json *p = last_field(js, "properties"); p && p->type == Json::Obj) for (auto &kv : p->obj) props[kv.first] = &kv.second;
+    for (auto &kv : props) {
+      const Json &p = *kv.second;
+      int t = json_type_of(last_field(p, "type"));
+      bool req = std::find(required.begin(), required.end(), kv.first) != required.end();
+      if (const Json *one = last_field(p, "oneOf"); one && one->type == Json::Arr)
+        for (auto &q : one->arr) {
+          const Json *qt = last_field(q, "type");
+          if (qt && qt->type == Json::Str && qt->str == "null") req = false;
+          else t = json_type_of(qt);
+        }
+      if (!t) return tf::fail(TFGPU_ERR_CONFIG, "property " + kv.first + ": JSON-schema type without a column type (DataType \"\" in the reference)");
+      s->names.push_back(kv.first);
+      s->props.push_back(tfgpu_sr_property{nullptr, t, req ? 1 : 0});
+    }
+    for (size_t i = 0; i < s->props.size(); i++) s->props[i].name = s->names[i].c_str();
+    if (const Json *t = last_field(js, "title"); t && t->type == Json::Str) s->title = t->str;
+    // BuildJSONTableID
+    const std::string pol = policy && policy[0] ? policy : "debezium_style", manual = manual_table_name ? manual_table_name : "";
+    if (!manual.empty()) s->table = manual;
+    else if (pol == "debezium_style") {
+      const size_t dot = s->title.find('.');
+      if (dot == std::string::npos) return tf::fail(TFGPU_ERR_CONFIG, "Can't split title '" + s->title + "' from json into schema and table names");
+      s->ns = s->title.substr(0, dot); s->table = s->title.substr(dot + 1);
+    } else if (pol == "title") s->table = s->title;
+    else return tf::fail(TFGPU_ERR_CONFIG, "invalid JSONTableNamePolicy");
+    *out = s.release();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+}
+int tfgpu_sr_schema_info(const tfgpu_sr_schema *s, const tfgpu_sr_property **props, int32_t *nprops, const char **table_ns, const char **table_name, const char **title) {
+  if (!s) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_schema_info: null schema");
+  if (props) *props = s->props.data();
+  if (nprops) *nprops = (int32_t)s->props.size();
+  if (table_ns) *table_ns = s->ns.c_str();
+  if (table_name) *table_name = s->table.c_str();
+  if (title) *title = s->title.c_str();
+  return TFGPU_OK;
+}
+void tfgpu_sr_schema_free(tfgpu_sr_schema *s) { delete s; }
 
 }  // extern "C"
