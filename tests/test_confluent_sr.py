@@ -431,6 +431,19 @@ def test_gpu_per_frame_path_cross_check():
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+@pytest.mark.gpu
+def test_gpu_tile_front_cross_check():
+    """sr_parse_quick is the default front; TFGPU_SR_QUICK=0 sends every batch through sr_parse_tiles.  Both must pass the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFGPU_SR_QUICK="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_confluent_sr.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "canon or vectors or framing or matches_oracle or parser_object or border"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 # ---------------------------------------------------------------- oracle vs an independent JSON implementation ----
 def _py_rand(rng, depth=0):
     t = rng.random()

@@ -574,6 +574,19 @@ def test_per_line_path_cross_check():
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_tile_path_cross_check():
+    """json_parse_quick is the default front; with TFGPU_JSON_QUICK=0 every batch goes through json_parse_tiles (the form batches
+    with float64 columns or > 128 members still take).  Both must pass the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFGPU_JSON_QUICK="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_json.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "edge or random or flat or canon or rules or aux or messages or tile_path or float or rest"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 def test_wave_path_cross_check():
     """The wave-cooperative parser (TFGPU_JSON_WAVEPATH=1: simdjson-style stage 1 on the scalar unit, members on lanes)
     and the per-line parser are two independent implementations of the same grammar: the edge-case, fuzz and flat

@@ -25,7 +25,7 @@ import pytest  # noqa: E402
 # everything marked gpu, except what needs the real device: full-size batches (minutes here), torch.cuda + real RCCL, the static
 # resource table of the gfx950 build.  Known emulator gap: the experimental JSON wave path (TFGPU_JSON_WAVES=1) parses the
 # subnormal-boundary literal 1e-308 as nil here and correctly on the MI355X.
-K = "not fullsize and not rccl and not resources and not pipeline_single_rank and not wave_path_cross and not path_cross_check"
+K = "not fullsize and not rccl and not resources and not pipeline_single_rank and not cross_check"
 args = sys.argv[1:]
 if "-k" in args:
     i = args.index("-k")
