@@ -184,6 +184,58 @@ def test_tile_path_shapes(tf, oracle):
     compare(tf, oracle, dict(skip_rows=3, include_missing_columns=1), S4, normal, "skip3")
 
 
+def test_single_pass_form_and_its_fallbacks():
+    """The single-pass CSV form is opt-in (TFGPU_CSV_SPEC=1, read once per process): its own cases and the tile-shape stress run
+    in a process that has it on."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TFGPU_CSV_SPEC="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "single_pass_cases or tile_path_shapes or hits_small or random_bytes"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_single_pass_cases(tf, oracle):
+    """A lane that has parsed a chunk of this shape sizes the next chunk's buffers from it and lets csv_parse_regular count the
+    lines itself (no csv_count_newlines pass); a chunk with more lines than expected, a header longer than the chunk's lines, or
+    a last line that spans the last tiles is parsed again the two-pass way.  Every answer must be the oracle's."""
+    rng = np.random.default_rng(SEED0 + 23)
+    kw = dict(include_missing_columns=1)
+
+    def rows(n, width):
+        return b"".join(b"%d,s%d,%d,\"q,%d\"\n" % (i, rng.integers(0, 10 ** width), i * 7, i) for i in range(n))
+
+    def kernels():
+        return {name for name, _n, _ms in tf.prof_get()}
+
+    a = rows(6000, 6)
+    compare(tf, oracle, kw, S4, a, "first chunk (count pass)")
+    tf.prof_enable(True)
+    try:
+        tf.prof_reset()
+        compare(tf, oracle, kw, S4, a, "same chunk again")
+        k = kernels()
+        if _os.environ.get("TFGPU_CSV_SPEC") != "1":
+            return  # the two-pass default: nothing more to see here
+        assert "csv_parse_regular" in k and "csv_count_newlines" not in k, k
+        tf.prof_reset()
+        compare(tf, oracle, kw, S4, rows(5000, 9), "longer lines: fewer than expected")
+        assert "csv_count_newlines" not in kernels()
+        tf.prof_reset()
+        compare(tf, oracle, kw, S4, rows(20000, 1), "shorter lines: more than the buffers hold")
+        assert "csv_count_newlines" in kernels()  # parsed again
+    finally:
+        tf.prof_enable(False)
+    compare(tf, oracle, kw, S4, rows(20000, 1), "the same density again")
+    compare(tf, oracle, kw, S4, rows(9000, 1) + b"7,\"" + b"ab" * 40000 + b"\",8,z\n", "a last line across the last three tiles")
+    compare(tf, oracle, kw, S4, rows(9000, 1) + b"7,\"" + b"ab" * 40000, "an unfinished last line across the last three tiles")
+    compare(tf, oracle, dict(skip_rows=3, include_missing_columns=1), S4, b"h\n" + b"x" * 70000 + b"\n", "fewer lines than the header skips")
+    compare(tf, oracle, dict(skip_rows=2, include_missing_columns=1), S4, rows(9000, 2), "skip 2")
+    compare(tf, oracle, kw, S4, b"\n" * 70000, "nil lines only")
+    compare(tf, oracle, kw, S4, rows(3000, 3) + b"1\n" * 40000 + rows(3000, 3), "a dense stretch in the middle")
+
+
 def test_unmapped_fields_are_still_sanitized(tf, oracle):
     """sanitizeElement runs on every field of a line, also those no column reads (reader.go:240-266)."""
     schema = abi.Schema.of([["a", "int32", True, "0"], ["d", "utf8", False, "3"]])

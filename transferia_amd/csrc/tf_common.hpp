@@ -101,6 +101,9 @@ struct Context {
   struct ConstEntry { uint64_t hash; std::vector<uint8_t> bytes; std::shared_ptr<struct DevMem> mem; uint64_t stamp; };
   std::vector<ConstEntry> consts;
   uint64_t const_clock = 0;
+  // tfgpu_csv_parse's single-pass form: bytes per line of the last chunk this lane parsed, and that chunk's column count
+  double csv_hint_bpl = 0.0;
+  int csv_hint_ncols = -1;
 
   hipEvent_t get_event();
   void prof_begin(const char *name, Pending &p);

@@ -355,7 +355,43 @@ struct CsvParams {
   const uint32_t *lcols;       // [16 waves][64]: word 4 s + w of wave v = word w of its s-th column {p0 offset, p1 offset, field:16 | kind:8 | width:8, -}
   const uint32_t *lwave_ncols; // [16]: columns per wave
   uint32_t tile_cpt;           // 16-byte chunks per thread: the tile is 15, 30 or 45 KiB
+  // single-pass form (csv_parse_regular counts its own lines): [0] ticket counter, [1] overflow flag, [2 + t] state of tile t,
+  // [2 + ntiles + t] one past the last '\n' tile t owns (0: none)
+  uint32_t *spec;              // null: the line counts come from csv_count_newlines (gran_pre)
+  uint32_t cap_lines;          // lines the column buffers were sized for
 };
+
+// ---- one pass instead of two: the tile kernel finds its first line's index itself ----------------------------------------
+// csv_count_newlines reads the whole chunk only to tell every tile how many lines precede it.  With `spec` set, tiles take
+// tickets in arrival order, each publishes the number of '\n' it owns as soon as it has classified its bytes, and one wave
+// looks back over its predecessors' words (Merrill & Garland's decoupled look-back: a word is empty, a tile's own count, or
+// the inclusive count up to and including the tile).  Tickets, not blockIdx: the tile with the lowest unfinished ticket is
+// always resident, so the wait cannot deadlock whatever order the dispatcher picks.  The host sizes the column buffers from
+// the previous chunk's bytes per line; a chunk with more lines than that sets the overflow word and is parsed again the
+// two-pass way.
+static constexpr uint32_t SP_AGG = 1u << 30, SP_INC = 2u << 30, SP_VAL = (1u << 30) - 1u;
+// all 64 lanes of ONE wave; returns the number of lines in front of tile `t` and leaves the tile's inclusive count published
+__device__ __forceinline__ uint32_t spec_lookback(uint32_t *state, int64_t t, uint32_t own, int lane) {
+  if (t == 0) { if (lane == 0) __atomic_store_n(&state[0], SP_INC | own, __ATOMIC_RELAXED); return 0u; }
+  if (lane == 0) __atomic_store_n(&state[t], SP_AGG | own, __ATOMIC_RELAXED);
+  uint32_t excl = 0;
+  int64_t base = t - 1;
+  for (;;) {
+    const int64_t idx = base - lane;
+    const uint32_t w = idx >= 0 ? __atomic_load_n(&state[idx], __ATOMIC_RELAXED) : SP_INC;
+    const uint64_t inc = __ballot((w >> 30) == 2u), empty = __ballot((w >> 30) == 0u);
+    const int fi = inc ? __ffsll((long long)inc) - 1 : 63;     // the nearest predecessor that already knows its inclusive count
+    const uint64_t need = fi == 63 ? ~0ull : ((2ull << fi) - 1ull);
+    if (empty & need) { __builtin_amdgcn_s_sleep(1); continue; }  // someone in between has not classified its bytes yet
+    uint32_t v = lane <= fi ? (w & SP_VAL) : 0u;
+    v = wave_scan_add(v);
+    excl += (uint32_t)__shfl((int)v, 63, 64);
+    if (inc) break;
+    base -= 64;
+  }
+  if (lane == 0) __atomic_store_n(&state[t], SP_INC | ((excl + own) & SP_VAL), __ATOMIC_RELAXED);
+  return excl;
+}
 
 __device__ __forceinline__ void store_int(const CsvCol &c, int64_t r, int64_t v) {
   switch (c.width) {
@@ -737,7 +773,7 @@ __device__ __forceinline__ uint32_t qf_compose(uint32_t first, uint32_t then) {
 }
 
 // One piece: the lines whose '\n' lies in granules [gstart, gstart + gcount), gcount * CSV_GRAN <= CT_T.
-__device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int64_t gstart, const int64_t gcount) {
+__device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int64_t gstart, const int64_t gcount, const uint32_t spec_line0, const uint32_t spec_nlines) {
   __shared__ __attribute__((aligned(16))) uint8_t sb[CT_BYTES + 48];
   __shared__ uint16_t fpos[CT_FCAP];   // field-end position | bit15 = it is the line's '\n'
   __shared__ uint16_t rowend[CT_RCAP]; // ordinal of each line's last field
@@ -750,8 +786,8 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
   __shared__ uint32_t wcnt[CT_THREADS / 64];
 
   const int64_t gend = min(gstart + gcount, p.ngran);
-  const uint32_t line0 = p.gran_pre[gstart];
-  const uint32_t nlines = p.gran_pre[gend] - line0;
+  const uint32_t line0 = p.spec ? spec_line0 : p.gran_pre[gstart];
+  const uint32_t nlines = p.spec ? spec_nlines : p.gran_pre[gend] - line0;
   if (nlines == 0) return;  // no line ends here (inside a very long line)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1137,7 +1173,10 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
     bstart = next_bstart;
     jb += nr; kb = kend + 1;
   }
-  if (tid == 0) atomicMax(p.last_end, (uint32_t)(g0 + bstart));  // one past the last '\n' this tile owns
+  if (tid == 0) {  // one past the last '\n' this tile owns
+    atomicMax(p.last_end, (uint32_t)(g0 + bstart));
+    if (p.spec) p.spec[2 + p.ntiles + gstart / (CT_T / CSV_GRAN)] = (uint32_t)(g0 + bstart);
+  }
 }
 
 // The tiles csv_parse_regular could not take (anything but the plain shape it is specialised for), one after another
@@ -1145,7 +1184,9 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
 __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_tiles_general(CsvParams p) {
   const uint32_t n = *p.gen_n;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    parse_tile_general(p, (int64_t)p.gen_tile[2 * i], (int64_t)p.gen_tile[2 * i + 1]);
+    const bool sp = p.spec != nullptr;
+    const uint32_t *e = p.gen_tile + (size_t)(sp ? 4 : 2) * i;
+    parse_tile_general(p, (int64_t)e[0], (int64_t)e[1], sp ? e[2] : 0u, sp ? e[3] : 0u);
     __syncthreads();
   }
 }
@@ -1442,29 +1483,47 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   __shared__ uint32_t wpar[CT_THREADS / 64];
   __shared__ uint32_t wcnt[CT_THREADS / 64];
   __shared__ uint32_t misc[4];               // 0: first line's start, 1: tile is not regular, 2: NF
+  __shared__ uint32_t spec_sh[2];            // single-pass form: 0 = this workgroup's ticket, 1 = lines in front of its tile
   uint8_t *const sb = sbuf + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool spec = p.spec != nullptr;
 
-  // XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
-  const int64_t per_xcd = (p.ntiles + 7) / 8;
-  const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  int64_t tile;
+  if (spec) {  // tiles in arrival order (see spec_lookback)
+    if (tid == 0) spec_sh[0] = atomicAdd(p.spec, 1u);
+    __syncthreads();
+    tile = (int64_t)spec_sh[0];
+  } else {  // XCD-aware tile order: consecutive tiles (which share their look-behind bytes) run on one XCD's L2
+    const int64_t per_xcd = (p.ntiles + 7) / 8;
+    tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  }
   if (tile >= p.ntiles) return;
   // the tile's lines from the exclusive scan of the newline counts per 4 KiB granule: wave-uniform addresses, read by the
   // scalar unit now — a vector load at the end of the kernel would wait for every store of the cell phase
   constexpr int64_t GPT = CT_T / CSV_GRAN;
   const int64_t gr0 = tile * GPT, gr1 = min(gr0 + GPT, p.ngran);
   const auto *gpre = TF_CONST_PTR(uint32_t, p.gran_pre);
-  const uint32_t line0 = gpre[gr0], line1 = gpre[gr1], lines_all = gpre[p.ngran];
-  const uint32_t nlines = line1 - line0;
-  if (nlines == 0) return;  // no line ends here (inside a very long line)
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t line0 = 0, line1 = 0, lines_all = 0, nlines = 0;
+  if (!spec) {
+    line0 = gpre[gr0]; line1 = gpre[gr1]; lines_all = gpre[p.ngran];
+    nlines = line1 - line0;
+    if (nlines == 0) return;  // no line ends here (inside a very long line)
+  }
   const CsvOpts &o = p.o;
   const int64_t g0 = tile * CT_T - CT_SPILL;  // absolute offset of sb[0]
-  auto give_up = [&]() { if (tid == 0) { const uint32_t slot = atomicAdd(p.gen_n, 1u); p.gen_tile[2 * slot] = (uint32_t)gr0; p.gen_tile[2 * slot + 1] = (uint32_t)(gr1 - gr0); } };
+  // a piece for the general kernel: (first granule, granules) and, in the single-pass form, (first line, lines)
+  auto give_up = [&]() {
+    if (tid == 0) {
+      const uint32_t slot = atomicAdd(p.gen_n, 1u);
+      if (spec) { p.gen_tile[4 * slot] = (uint32_t)gr0; p.gen_tile[4 * slot + 1] = (uint32_t)(gr1 - gr0); p.gen_tile[4 * slot + 2] = line0; p.gen_tile[4 * slot + 3] = nlines; }
+      else { p.gen_tile[2 * slot] = (uint32_t)gr0; p.gen_tile[2 * slot + 1] = (uint32_t)(gr1 - gr0); }
+    }
+  };
   unsigned long long tstamp = p.dbg_phase ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull;
   auto phase = [&](int k) {  // TFGPU_CSV_PHASES=1, profiling only: thread 0 adds the cycles since the previous stamp to slot k
     if (p.dbg_phase && tid == 0) { const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memtime(); atomicAdd(p.dbg_phase + k, now - tstamp); tstamp = now; }
   };
-  if (p.force_general || nlines > (uint32_t)CT_RCAP || p.ncols > CR_LCOLS) { give_up(); return; }
+  if (!spec && (p.force_general || nlines > (uint32_t)CT_RCAP || p.ncols > CR_LCOLS)) { give_up(); return; }  // (the host does not pick the single-pass form with force_general or that many columns)
 
   // ---- stage: coalesced 16 B/lane ----
   if (g0 >= 0 && (uint64_t)(g0 + CT_BYTES) <= p.len) {
@@ -1570,7 +1629,21 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   uint32_t cpre = 0, ctot = 0;
   for (int i = 0; i < CT_THREADS / 64; i++) { const uint32_t x = wcnt[i]; if (i < wv) cpre += x; ctot += x; }
   const uint32_t nfe = ctot & 0xFFFFu, nr = ctot >> 16;
-  if (misc[1] || nfe > (uint32_t)CR_FCAP || nr != nlines) { give_up(); return; }  // uniform: LDS flags were written before the barrier
+  if (spec) {
+    // the tile's own count is final here, whatever becomes of the tile: publish it and find the lines in front.  The last wave
+    // does it (its value reaches the others at the next barrier); on the early exits below it is the one that stays.
+    nlines = nr;
+    const bool quit = misc[1] || nfe > (uint32_t)CR_FCAP || nr > (uint32_t)CT_RCAP || nr == 0;
+    if (wv == CT_THREADS / 64 - 1) {
+      line0 = spec_lookback(p.spec + 2, tile, nr, lane);
+      if (lane == 0) spec_sh[1] = line0;
+      if (quit && nr != 0 && lane == 0) {
+        if (line0 + nr > p.cap_lines) p.spec[1] = 1u;
+        else { const uint32_t slot = atomicAdd(p.gen_n, 1u); p.gen_tile[4 * slot] = (uint32_t)gr0; p.gen_tile[4 * slot + 1] = (uint32_t)(gr1 - gr0); p.gen_tile[4 * slot + 2] = line0; p.gen_tile[4 * slot + 3] = nr; }
+      }
+    }
+    if (quit) return;
+  } else if (misc[1] || nfe > (uint32_t)CR_FCAP || nr != nlines) { give_up(); return; }  // uniform: LDS flags were written before the barrier
   const uint32_t frs = misc[0];
   if (p.ablate == 3) { if (fe[0] + fe[1] + fe[2] + fe[3] == 0xFFFFFFFFu) p.err[0] = 1; return; }
 
@@ -1615,6 +1688,10 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   __syncthreads();
   phase(3);
   if (p.ablate == 4) return;
+  if (spec) {
+    line0 = spec_sh[1]; line1 = line0 + nr;
+    if (line1 > p.cap_lines) { if (tid == 0) p.spec[1] = 1u; return; }  // more lines than the buffers were sized for: the host parses the chunk again
+  }
   const uint32_t NF = misc[2];  // fields of the first line; every line must have as many
   if (NF < 2 || NF < (uint32_t)p.nfields_used || nr * NF > nfe) { give_up(); return; }  // uniform.  (A lone "\n" is a line of no fields, reader.go:146-150.)
   for (uint32_t jj = tid; jj < nr; jj += CT_THREADS) {
@@ -1696,7 +1773,8 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
     } else p.err[r] = 0;
   }
   // one past the last '\n' of the chunk: only the tile that owns the last line has it (30 000 atomics on one word are not free)
-  if (tid == 0 && line1 == lines_all) atomicMax(p.last_end, (uint32_t)(g0 + fposx[nr * NF] + 1));
+  // (single-pass form: nobody knows the total yet; every tile leaves its own last '\n', csv_collect takes the last tile's that has one)
+  if (tid == 0) { if (spec) p.spec[2 + p.ntiles + tile] = (uint32_t)(g0 + fposx[nr * NF] + 1); else if (line1 == lines_all) atomicMax(p.last_end, (uint32_t)(g0 + fposx[nr * NF] + 1)); }
   phase(6);
 }
 
@@ -1805,11 +1883,25 @@ __global__ void __launch_bounds__(256) csv_copy_special(CopyParams p) {
 }
 
 // one contiguous summary for a single read-back: [nerr, consumed, total bytes of each string column]
+// (single-pass form: `nrows` is what the buffers were sized for; the true count is the last tile's inclusive line count)
 __global__ void csv_collect(const uint32_t *nerr, const uint32_t *last, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, const uint32_t *fstart_all,
-                            int64_t fstride, uint32_t *out) {
+                            int64_t fstride, uint32_t *out, const uint32_t *spec, int64_t ntiles, int64_t skip) {
   int i = threadIdx.x;
+  if (spec) {
+    const uint32_t nl = ntiles ? (spec[2 + ntiles - 1] & SP_VAL) : 0u;
+    if (i == 2) { out[2 + 2 * nstr] = nl; out[3 + 2 * nstr] = spec[1]; }
+    nrows = min(nrows, max((int64_t)nl - skip, (int64_t)0));
+    // the chunk's last '\n': the highest tile that owns one (all 64 lanes)
+    uint32_t le = 0;
+    for (int64_t hi = ntiles - 1; hi >= 0 && le == 0; hi -= 64) {
+      const int64_t t = hi - i;
+      const uint32_t v = t >= 0 ? spec[2 + ntiles + t] : 0u;
+      const uint64_t has = __ballot(v != 0);
+      if (has) le = (uint32_t)__shfl((int)v, __ffsll((long long)has) - 1, 64);
+    }
+    if (i == 1) out[1] = le;
+  } else if (i == 1) out[1] = *last;
   if (i == 0) out[0] = *nerr;
-  if (i == 1) out[1] = *last;
   for (int s = i; s < nstr; s += blockDim.x) { out[2 + s] = lens_all[(int64_t)s * seg_stride + nrows]; out[2 + nstr + s] = fstart_all[(int64_t)s * fstride + FS_HDR - 1]; }
 }
 __global__ void csv_zero_flags(uint32_t *fstart_all, int64_t fstride, int nstr) {
@@ -2080,8 +2172,10 @@ extern "C" void tfgpu_csv_options_default(tfgpu_csv_options *o) {  // csv.NewRea
 }
 
 
-extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes, uint64_t len, int mem,
-                               tfgpu_dbatch **out, uint64_t *consumed, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
+// `allow_spec`: the single-pass form may be used (csv_parse_regular counts its own lines, the buffers sized from the lane's
+// previous chunk).  *retry = the chunk held more lines than that (or ended oddly): nothing was returned, call again without it.
+static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes, uint64_t len, int mem,
+                          tfgpu_dbatch **out, uint64_t *consumed, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs, bool allow_spec, bool *retry) {
   TF_API_BEGIN
   if (!opts || !schema || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_csv_parse: null argument");
   if (len >= 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_csv_parse: chunk must be < 2 GiB (the reference reads 20 MiB chunks, chunk_reader.go:12)");
@@ -2138,20 +2232,35 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   // ---- 1/2: line index ----
   const int64_t ntiles = (int64_t)((len + NL_TILE - 1) / NL_TILE);   // workgroups of the line-index kernels (28 KiB each)
   const int64_t ngran = (int64_t)((len + CSV_GRAN - 1) / CSV_GRAN);  // newline counts are kept per 4 KiB granule
-  Buf tile_counts = dalloc((size_t)(ngran + 1) * 4);
+  // TFGPU_CSV_ROWPATH=1 forces the per-row path for whole chunks (the tile path's parity cross-check)
+  static const bool force_rowpath = [] { const char *e = std::getenv("TFGPU_CSV_ROWPATH"); return e && e[0] == '1'; }();
+  // the tile kernels are specialised for the plain shape of the options; the rest takes the per-row path, which carries every rule
+  const bool rowpath = force_rowpath || opts->escape_char == '\n' || opts->escape_char >= 0x80 || opts->quote_char >= 0x80 || opts->quote_char == 0 ||
+                       opts->n_timestamp_parsers > 0 || !dp.empty() || multiline;
+  // ---- the single-pass form (TFGPU_CSV_SPEC=1): a lane that has parsed a chunk of this shape before sizes the buffers from that
+  //      chunk's bytes per line (+ 1/16) and lets the tile kernel count; more lines than that → *retry.
+  //      OFF by default.  Measured on the MI355X (profiles/r06s_ab_csv_*.json): the count pass and its read-back go (0.163 + 0.014 ms)
+  //      but csv_parse_regular grows from 0.728 to 1.014 ms — a ticket and a look-back are three to five dependent round trips
+  //      to memory-side coherent words (the eight XCDs share no L2), ~8 us per workgroup of a 20 us lifetime, and with three
+  //      workgroups per CU there is nobody to hide them behind.  The step: 1.77 ms two-pass, 1.89 ms single-pass. ----
+  static const bool spec_off = [] { const char *e = std::getenv("TFGPU_CSV_SPEC"); return !(e && e[0] == '1'); }();
+  static const bool spec_blockers = [] { for (const char *n : {"TFGPU_CSV_ABLATE", "TFGPU_CSV_GENERAL", "TFGPU_CSV_PHASES", "TFGPU_CSV_LANES"}) { const char *e = std::getenv(n); if (e && e[0] && e[0] != '0') return true; } return false; }();
+  const bool spec = allow_spec && !spec_off && !spec_blockers && !rowpath && schema->ncols <= CR_LCOLS && cx.csv_hint_ncols == schema->ncols && cx.csv_hint_bpl >= 1.0 &&
+                    len >= 2 * (uint64_t)CT_T && len < (1ull << 30);
+  uint32_t cap_lines = 0;
+  Buf tile_counts = dalloc((size_t)((spec ? 0 : ngran) + 1) * 4);
   uint32_t nlines = 0;
-  if (ntiles) {
+  if (spec) {
+    const double est = (double)len / cx.csv_hint_bpl;
+    cap_lines = (uint32_t)std::min<double>((double)len, est + est / 16.0 + 64.0);
+    nlines = cap_lines;  // everything below is sized for this many; the true count arrives with the summary
+  } else if (ntiles) {
     { KernelTimer t("csv_count_newlines"); csv_count_newlines<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ngran); }
     exclusive_scan_u32(ptr<uint32_t>(tile_counts), ptr<uint32_t>(tile_counts), ngran, true);
     const uint32_t *h = d2h_u32(ptr<uint32_t>(tile_counts) + ngran);
     tf::sync();
     nlines = *h;
   }
-  // TFGPU_CSV_ROWPATH=1 forces the per-row path for whole chunks (the tile path's parity cross-check)
-  static const bool force_rowpath = [] { const char *e = std::getenv("TFGPU_CSV_ROWPATH"); return e && e[0] == '1'; }();
-  // the tile kernels are specialised for the plain shape of the options; the rest takes the per-row path, which carries every rule
-  const bool rowpath = force_rowpath || opts->escape_char == '\n' || opts->escape_char >= 0x80 || opts->quote_char >= 0x80 || opts->quote_char == 0 ||
-                       opts->n_timestamp_parsers > 0 || !dp.empty() || multiline;
   Buf row_start;
   if (rowpath) {
     row_start = dalloc_zero((size_t)(nlines + 2) * 4);
@@ -2311,10 +2420,12 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   const int64_t slow_cap = (int64_t)nlines + 5 * (ngran + 1) + 8;  // every line at most once, plus long / over-wide ones per piece
   Buf slow = dalloc((size_t)(2 * slow_cap + 2) * 4);
   TF_HIP(hipMemsetAsync(slow->p, 0, 8, st));
-  Buf gen = dalloc((size_t)(2 * (ngran + 2) + 2) * 4);  // [0] = count, then (first granule, granules) pairs
+  Buf gen = dalloc((size_t)(4 * (ngran + 2) + 2) * 4);  // [0] = count, then (first granule, granules) pairs — with (first line, lines) in the single-pass form
   TF_HIP(hipMemsetAsync(gen->p, 0, 8, st));
   const uint32_t tile_bytes = CT_T;  // csv_parse_regular's tile: seven granules
   const int64_t rtiles = (int64_t)((len + tile_bytes - 1) / tile_bytes);
+  Buf spec_state;
+  if (spec) { spec_state = dalloc((size_t)(2 * rtiles + 2) * 4); TF_HIP(hipMemsetAsync(spec_state->p, 0, (size_t)(2 * rtiles + 2) * 4, st)); }
   CsvParams pp;
   std::memset(&pp, 0, sizeof pp);
   pp.data = data; pp.len = len; pp.row_start = rs; pp.nrows = nrows;
@@ -2338,6 +2449,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   pp.ablate = ablate;
   static const bool force_general = [] { const char *e = std::getenv("TFGPU_CSV_GENERAL"); return e && e[0] == '1'; }();
   pp.gen_n = ptr<uint32_t>(gen); pp.gen_tile = ptr<uint32_t>(gen) + 1; pp.force_general = force_general ? 1 : 0;
+  pp.spec = spec ? ptr<uint32_t>(spec_state) : nullptr; pp.cap_lines = cap_lines;
   pp.has_unmapped = 0;
   for (int f = 0; f <= max_field; f++) if (field_first[(size_t)f] < 0) pp.has_unmapped = 1;
   std::vector<int32_t> order((size_t)ncols);
@@ -2438,7 +2550,7 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     } else {
       const int64_t per_xcd = (rtiles + 7) / 8;
       KernelTimer t("csv_parse_regular");
-      csv_parse_regular<<<(unsigned)(per_xcd * 8), CT_THREADS, 0, st>>>(pp);
+      csv_parse_regular<<<(unsigned)(spec ? rtiles : per_xcd * 8), CT_THREADS, 0, st>>>(pp);
     }
     { KernelTimer t("csv_parse_tiles_general"); csv_parse_tiles_general<<<(unsigned)std::min<int64_t>(ntiles + rtiles, 2048), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 1024), 64, 0, st>>>(pp); }
@@ -2450,12 +2562,20 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
     TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)nstr * (size_t)seg_stride * 4, st));
   }
   // ---- one read-back: error count, consumed offset, string totals ----
-  Buf summary = dalloc((size_t)(2 * nstr + 2) * 4);
+  Buf summary = dalloc((size_t)(2 * nstr + 4) * 4);
   csv_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), rowpath ? ptr<uint32_t>(row_start) + nlines : pp.last_end, ptr<uint32_t>(lens_all),
-                                seg_stride, nrows, nstr, ptr<uint32_t>(fstart_all), fstride, ptr<uint32_t>(summary));
-  const uint32_t *hsum = d2h_u32(summary->p, (size_t)(2 * nstr) + 2);
+                                seg_stride, nrows, nstr, ptr<uint32_t>(fstart_all), fstride, ptr<uint32_t>(summary), pp.spec, rtiles, skip);
+  const uint32_t *hsum = d2h_u32(summary->p, (size_t)(2 * nstr) + 4);
   tf::sync();
   const uint32_t hnerr = hsum[0], last = hsum[1];
+  if (spec) {
+    const uint32_t nl_true = hsum[2 + 2 * nstr], overflow = hsum[3 + 2 * nstr];
+    // more lines than the buffers hold, fewer than the header skips, or the last '\n' outside the last two tiles: the two-pass way
+    if (overflow || nl_true > cap_lines || (int64_t)nl_true < skip || (nl_true && !last)) { *retry = true; return TFGPU_OK; }
+    nlines = nl_true; nlogical = nl_true; nrows = (int64_t)nl_true - skip;
+    db->nrows = nrows;
+  }
+  if (!rowpath && nlines >= 16 && last) { cx.csv_hint_bpl = (double)last / (double)nlines; cx.csv_hint_ncols = schema->ncols; }
   if (phases && !rowpath) {
     unsigned long long ph[8]; d2h(ph, bphase->p, sizeof ph); tf::sync();
     std::fprintf(stderr, "tfgpu csv phases (s_memtime ticks per workgroup, %lld tiles): stage %.0f classify %.0f fields %.0f index %.0f cells(wave 0) %.0f cells-barrier %.0f epilogue %.0f\n", (long long)rtiles,
@@ -2552,6 +2672,14 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
   *out = result.release();
   return TFGPU_OK;
   TF_API_END
+}
+
+extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema *schema, const void *bytes, uint64_t len, int mem,
+                               tfgpu_dbatch **out, uint64_t *consumed, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
+  bool retry = false;
+  int rc = csv_parse_body(opts, schema, bytes, len, mem, out, consumed, errs, errs_cap, nerrs, true, &retry);
+  if (rc == TFGPU_OK && retry) { retry = false; rc = csv_parse_body(opts, schema, bytes, len, mem, out, consumed, errs, errs_cap, nerrs, false, &retry); }
+  return rc;
 }
 
 // ======================================================================================================
