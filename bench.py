@@ -1250,7 +1250,7 @@ class Configs4DebeziumWorkload(Base):
         out.values.free(); col.free(); back.free(); one.free(); p.batch.free()
 
     def alg(self):
-        return {"dbz_unpack": self.nbytes, "dbz_parse": self.nbytes // 6}
+        return {"dbz_unpack": self.nbytes, "dbz_parse": self.nbytes // 6, "dbz_parse_quick": self.nbytes // 6}
 
     def config(self):
         e = self.env
@@ -1348,7 +1348,8 @@ class DebeziumWorkload(Base):
             p.batch.free()
 
     def alg(self):
-        return {"dbz_parse": self.payload_bytes() + self.state.get("out_bytes", 0), "dbz_unpack": self.nbytes}
+        pb = self.payload_bytes() + self.state.get("out_bytes", 0)
+        return {"dbz_parse": pb, "dbz_parse_quick": pb, "dbz_unpack": self.nbytes, "dbz_prefix_same": self.nbytes}
 
     def payload_bytes(self):
         i = self.msg.index(b'"payload":')

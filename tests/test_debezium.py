@@ -279,6 +279,85 @@ def test_gpu_stream_matches_oracle(tf, oracle, n, weird):
     assert fb <= (0 if not weird else n // 8), fb   # the stock path is for the odd message, not the stream
 
 
+def quick_stream(n, seed):
+    """workload.debezium_cdc_messages (every field a type dbz_parse_quick reads) with every 7th message bent: shapes the quick kernel must
+    hand to the walker (blanks, other member orders, escapes, repeated keys, wrong types, numbers out of range, bad base64) and
+    shapes it must take (nulls, empty strings, negative numbers)."""
+    import random
+    from transferia_amd import workload
+    rng = random.Random(seed)
+    msgs = workload.debezium_cdc_messages(n, seed=seed)
+    out = []
+    for k, raw in enumerate(msgs):
+        t = raw.decode()
+        if k % 7 == 3:
+            i = t.index('"payload":') + 10
+            head, ps = t[:i], t[i:-1]
+            ps = rng.choice([
+                ps.replace('"op":', '"op" :'), ps.replace(',"after":', ', "after":'), ps.replace('"ver":', '"v\\u0065r":'), ps.replace('"ver":', '"Ver":'),
+                ps.replace('"id":', '"id":0'), ps.replace('"id":', '"id":-'), ps.replace('"id":', '"id":1.5e1,"x":'), ps.replace('"lsn":', '"lsn":-'),
+                ps.replace('"txId":', '"txId":99999999999'), ps.replace('"txId":', '"txId":null,"_":'), ps.replace('"xmin":null', '"xmin":17'), ps.replace('"xmin":null', '"xmin":"17"'),
+                ps.replace('"snapshot":"false"', '"snapshot":false'), ps.replace('"snapshot":"false"', '"snapshot":null'), ps.replace('"snapshot":"false"', '"snapshot":"fa\\nlse"'),
+                ps.replace('"snapshot":"false"', '"snapshot":"fa\\xlse"'), ps.replace('"table":"events"', '"table":"ev\\u0065nts"'), ps.replace('"table":"events"', '"table":null'),
+                ps.replace('"schema":"public"', '"schema":"p\u00fcblic"'), ps.replace('"transaction":null', '"transaction":{"id":"5:7","total_order":1,"data_collection_order":2}'),
+                ps.replace('"transaction":null', '"transaction":[1,2]'), ps.replace('"payload":"', '"payload":"__debezium_unavailable_value'), ps.replace('"payload":"', '"payload":"\\"q\\" '),
+                ps.replace('"payload":"', '"payload":"\u00e9\u4e2d'), ps.replace('"payload":"', '"payload":"a,b}{"'), ps.replace('"payload":"', '"payload":null,"p2":"'),
+                ps.replace('"amount":"', '"amount":"=='), ps.replace('"amount":"', '"amount":"AAAA'), ps.replace('"amount":"', '"amount":null,"a2":"'), ps.replace('"amount":', '"amount":""' + ',"a2":'),
+                ps.replace('"ts":', '"ts":null,"t2":'), ps.replace('"ts":', '"ts":9223372036854775808,"t2":'), ps.replace('"ts":', '"ts":-9223372036854775808,"t2":'),
+                ps.replace('"op":"c"', '"op":"r"').replace('"op":"u"', '"op":"x"').replace('"op":"d"', '"op":"\\u0064"'), ps.replace('"op":', '"op":5,"op2":'),
+                ps.replace('"before":null', '"before":{}'), ps.replace('"after":null', '"after":7'), ps.replace(',"source":{', ',"source":null,"s2":{'),
+                ps.replace('"ts_ms":', '"ts_ms":null,"x":', 1), ps.replace('"source":{', '"source":{"lsn":1,'), ps.replace('"db":"db"', '"db":"d\tb"'),
+                ps[:-1] + ',"extra":1}', ps.replace('{"before":', '{"after":null,"before":'), ps.replace('"ver":', '"ver":1,"ver":'), '{"op":"c"}', 'null', '{}',
+            ])
+            t = head + ps + "}"
+        out.append(t.encode("utf-8"))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 5000])
+def test_gpu_quick_path_matches_oracle(tf, oracle, n, capfd):
+    """dbz_parse_quick (the tile kernel for payloads that spell the first payload's members) against the oracle, and that it does
+    take the stream: only the bent messages may reach the walker."""
+    import os
+    from transferia_amd import debezium
+    msgs = quick_stream(n, 41 + SEED0)
+    data, m = abi.messages(msgs)
+    exp_items, codes = oracle.debezium_parse(data, m)
+    os.environ["TFGPU_DBZ_DEBUG"] = "1"
+    try:
+        parser = debezium.Parser(tf)
+        parsed, errors = parser.parse(data, m)
+    finally:
+        del os.environ["TFGPU_DBZ_DEBUG"]
+    want = expected_errors(codes, exp_items, msgs)
+    assert want == errors
+    got = {}
+    for p in parsed:
+        got.update(device_items(tf, p))
+    exp = {it["src"]: it for it in exp_items if it["src"] not in want}
+    assert sorted(got) == sorted(exp)
+    for k in exp:
+        assert_same_items(got[k], exp[k], k)
+    err = capfd.readouterr().err
+    if os.environ.get("TFGPU_DBZ_QUICK") != "0":
+        import re
+        mm = re.search(r"tfgpu dbz quick: (\d+) messages, (\d+) tiles, (\d+) to the walker", err)
+        assert mm, err[-500:]
+        assert int(mm.group(3)) <= n // 7 + 2, mm.group(0)
+
+
+@pytest.mark.gpu
+def test_gpu_walker_cross_check():
+    """TFGPU_DBZ_QUICK=0: every message through dbz_parse.  Both forms must pass the file."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TFGPU_DBZ_QUICK="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "not cross_check"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
 @pytest.mark.gpu
 def test_gpu_stream_feeds_collapse_and_native_serializer(tf, oracle):
     """configs[4] from Debezium-envelope bytes: parse -> sharder -> partition -> exchange (one rank) -> Collapse -> native

@@ -96,3 +96,11 @@ def test_debezium_emitter_resources():
     assert find(t, "dbz_fill_const")["vgpr"] <= 32 and find(t, "dbz_fill_const")["scratch"] == 0
     assert find(t, "dbz_walk_len")["scratch"] <= 256 and find(t, "dbz_walk_write")["scratch"] <= 256 and find(t, "dbz_walk_write")["vgpr"] <= 160
     assert find(t, "dbz_event_layout")["scratch"] == 0 and find(t, "dbz_event_count")["scratch"] == 0 and find(t, "dbz_event_fill")["scratch"] == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_quick_tile_parsers_fit_three_workgroups_per_cu():
+    # 448 threads x 3 workgroups = 21 waves per CU: at most 96 VGPRs, no scratch, a third of the CU's 160 KB of LDS each
+    for src, name in (("tf_json.hip", "json_parse_quick"), ("tf_srjson.hip", "sr_parse_quick"), ("tf_debezium.hip", "dbz_parse_quick")):
+        k = find(kernel_table(src), name)
+        assert k["scratch"] == 0 and k["vgpr"] <= 96 and k["lds"] * 3 <= 160 * 1024, (name, k)

@@ -26,9 +26,14 @@
 // Latency-bound lane-per-message form (every lane walks ~13 KB of JSON); algorithmic bytes: message bytes in + column
 // bytes out.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "tf_jsonscan.hpp"
+#include "tf_wave.hpp"
+#include "tf_swar.hpp"
+#include "tf_jsonquick.hpp"
 
 namespace tf {
 namespace dbz {
@@ -555,6 +560,200 @@ __global__ void __launch_bounds__(128) dbz_parse(Params p) {
   p.status[m] = (uint8_t)st;
   if (st == TFGPU_ROW_OK) atomicMin(p.first_ok, (unsigned long long)m);
 }
+#include "tf_dbzquick.inc"
+
+// The segment map of dbz_parse_quick from the group's first payload (host code: 1-2 KB of text, once per call).  false: the
+// payload is not of the shape the quick kernel reads (blanks, arrays, nested values, escaped or repeated keys, `after` in front of
+// `before`, a values map that is not the schema's fields in schema order): the walker takes every message, as before.
+static bool build_quick_map(const std::string &s, const std::vector<std::string> &names, const std::vector<int> &ops, DqMap &M) {
+  std::memset(&M, 0, sizeof M);
+  M.slot_ent[0] = M.slot_ent[1] = -1; M.opent = ~0u;
+  const int F = (int)names.size();
+  if (F < 1 || F > DQ_F) return false;
+  size_t kr = 0;
+  auto add_text = [&](const std::string &t, uint16_t &ko, uint16_t &kn) {
+    const size_t room = (t.size() + 7) / 8 * 8;
+    if (kr + room + 8 > (size_t)DQ_KREF || t.size() > 0x7FFF) return false;
+    ko = (uint16_t)kr; kn = (uint16_t)t.size();
+    std::memcpy(M.kref + kr, t.data(), t.size());
+    kr += room;
+    return true;
+  };
+  std::vector<std::string> fkey((size_t)F);
+  for (int f = 0; f < F; f++) {
+    for (unsigned char c : names[(size_t)f]) if (c < 0x20 || c >= 0x7F || c == '"' || c == '\\') return false;  // (a producer may spell such a key with or without escapes)
+    fkey[(size_t)f] = "\"" + names[(size_t)f] + "\":";
+    M.fkn[f] = (uint16_t)fkey[(size_t)f].size();
+  }
+  const size_t n = s.size();
+  size_t i = 0;
+  auto lower = [](std::string k) { for (auto &c : k) if (c >= 'A' && c <= 'Z') c = (char)(c + 32); return k; };
+  // a key literal at i: plain ASCII, no escapes; leaves i behind the ':'
+  auto key = [&](std::string &k) {
+    if (i >= n || s[i] != '"') return false;
+    size_t e = i + 1;
+    while (e < n && s[e] != '"') { const unsigned char c = (unsigned char)s[e]; if (c < 0x20 || c >= 0x7F || c == '\\') return false; e++; }
+    if (e + 1 >= n || s[e + 1] != ':') return false;
+    k = s.substr(i + 1, e - i - 1);
+    i = e + 2;
+    return true;
+  };
+  // a scalar at i (the payload is valid JSON: its extent is all that is asked); leaves i behind it
+  auto scalar = [&]() {
+    if (i >= n) return false;
+    const char c = s[i];
+    if (c == '"') { size_t e = i + 1; while (e < n && s[e] != '"') e += s[e] == '\\' ? 2 : 1; if (e >= n) return false; i = e + 1; return true; }
+    if (c == '{' || c == '[') return false;
+    size_t e = i;
+    while (e < n && (std::isalnum((unsigned char)s[e]) || s[e] == '-' || s[e] == '+' || s[e] == '.')) e++;
+    if (e == i) return false;
+    i = e;
+    return true;
+  };
+  auto add_ent = [&](const std::string &prefix, uint8_t role, char sep, uint8_t slot) {
+    if (M.nent >= (uint32_t)DQ_ENT || (sep != ',' && sep != '}')) return false;
+    DqEnt &e = M.ent[M.nent];
+    if (!add_text(prefix, e.ko, e.kn)) return false;
+    e.role = role; e.sep = (uint8_t)sep; e.slot = slot;
+    M.nent++;
+    return true;
+  };
+  // a values map at i ('{'): the schema's fields in schema order, scalars or — Point, VariableScaleDecimal — objects of scalars
+  struct RowDesc { std::vector<DqRow> row; std::vector<std::string> text; std::vector<uint8_t> gk, gfirst; };
+  auto row_object = [&](RowDesc &d) {
+    i++;
+    for (int f = 0; f < F; f++) {
+      if (s.compare(i, fkey[(size_t)f].size(), fkey[(size_t)f])) return false;
+      i += fkey[(size_t)f].size();
+      if (i >= n) return false;
+      const bool lastf = f + 1 == F;
+      if (s[i] == '{') {
+        if (ops[(size_t)f] != TFGPU_DBZ_POINT && ops[(size_t)f] != TFGPU_DBZ_VSD) return false;
+        if (d.gk.size() >= (size_t)DQ_G) return false;
+        const uint8_t g = (uint8_t)d.gk.size();
+        d.gfirst.push_back((uint8_t)d.row.size());
+        i++;
+        if (i < n && s[i] == '}') return false;
+        std::string pre = fkey[(size_t)f] + "{";
+        int k = 0; bool has_x = false, has_y = false, has_value = false;
+        for (;;) {
+          const size_t k0 = i;
+          std::string k2;
+          if (!key(k2)) return false;
+          uint8_t role = IR_ANY;
+          if (ops[(size_t)f] == TFGPU_DBZ_VSD) { if (k2 == "value") { if (has_value) return false; has_value = true; role = IR_B64; } else if (k2 == "scale") role = IR_SCALE; }
+          else { if (k2 == "x") has_x = true; if (k2 == "y") has_y = true; }
+          for (const char *nm : {"value", "scale", "x", "y"}) if (lower(k2) == nm && k2 != nm) return false;
+          pre += s.substr(k0, i - k0);
+          if (!scalar() || i >= n) return false;
+          const char c = s[i];
+          if (c != ',' && c != '}') return false;
+          DqRow r{}; r.kind = k == 0 ? RK_HEAD : RK_INNER; r.field = (uint8_t)f; r.grp = g; r.role = role; r.gb = g; r.last = c == '}' ? 1 : 0;
+          d.row.push_back(r); d.text.push_back(pre); pre.clear();
+          k++; i++;
+          if (c == '}') break;
+        }
+        if (k > 255 || (ops[(size_t)f] == TFGPU_DBZ_VSD ? !has_value : !(has_x && has_y))) return false;
+        // (the walker takes the LAST member of a name; a repeated one sends the map away)
+        for (size_t a = d.row.size() - (size_t)k; a < d.row.size(); a++) for (size_t b = a + 1; b < d.row.size(); b++) {
+          auto keyof = [&](size_t q) { const std::string &t = d.text[q]; const size_t e = t.rfind("\":"); const size_t b0 = t.rfind('"', e - 1); return t.substr(b0 + 1, e - b0 - 1); };
+          if (keyof(a) == keyof(b)) return false;
+        }
+        d.gk.push_back((uint8_t)k);
+        d.row[d.gfirst[g]].last = lastf ? 1 : 0;   // RK_HEAD: what follows it when it is null; whether its object is one member long is gk's to say
+        DqRow t{}; t.kind = RK_TAIL; t.field = (uint8_t)f; t.grp = g; t.gb = g; t.last = lastf ? 1 : 0;
+        d.row.push_back(t); d.text.push_back("");
+        if (i >= n || s[i] != (lastf ? '}' : ',')) return false;
+        i++;
+      } else {
+        if (!scalar() || i >= n || s[i] != (lastf ? '}' : ',')) return false;
+        DqRow r{}; r.kind = RK_FIELD; r.field = (uint8_t)f; r.gb = (uint8_t)d.gk.size(); r.last = lastf ? 1 : 0;
+        d.row.push_back(r); d.text.push_back(fkey[(size_t)f]);
+        i++;
+      }
+    }
+    return true;
+  };
+  static const char *const TOP[] = {"before", "after", "source", "op", "ts_ms", "transaction"};
+  static const char *const SRC[] = {"connector", "db", "name", "sequence", "snapshot", "version", "schema", "table", "lsn", "ts_ms", "txid", "xmin"};
+  static const char *const SRC_EXACT[] = {"connector", "db", "name", "sequence", "snapshot", "version", "schema", "table", "lsn", "ts_ms", "txId", "xmin"};
+  static const uint8_t SRC_ROLE[] = {DR_SSTR, DR_SSTR, DR_SSTR, DR_SSTR, DR_SSTR, DR_SSTR, DR_SCHEMA, DR_TABLE, DR_LSN, DR_STS, DR_TXID, DR_XMIN};
+  if (n < 2 || s[0] != '{') return false;
+  i = 1;
+  size_t seg = 0;  // where the current segment starts
+  uint32_t seen_top = 0;
+  RowDesc best;
+  for (;;) {
+    std::string k;
+    if (!key(k)) return false;
+    int top = -1;
+    for (int t = 0; t < 6; t++) if (lower(k) == TOP[t]) { if (k != TOP[t]) return false; top = t; }   // (a key Go would bind by case folding: the walker sends those to the host)
+    if (top >= 0) { if (seen_top & (1u << top)) return false; seen_top |= 1u << top; }
+    if (i >= n) return false;
+    char sep;
+    if (top == 0 || top == 1) {  // a slot: null, or a values map
+      if (top == 0 && (seen_top & 2u)) return false;  // `after` in front of `before`
+      const std::string prefix = s.substr(seg, i - seg);
+      if (s[i] == 'n') { if (s.compare(i, 4, "null")) return false; i += 4; }
+      else if (s[i] == '{') {
+        RowDesc d;
+        if (!row_object(d)) return false;
+        if (d.row.size() > best.row.size()) best = std::move(d);   // (with both maps present: the one with more struct fields spelled out)
+      } else return false;
+      if (i >= n) return false;
+      sep = s[i];
+      M.slot_ent[top] = (int32_t)M.nent;
+      if (!add_ent(prefix, DR_SLOT, sep, (uint8_t)top)) return false;
+    } else if (s[i] == '{') {   // source, transaction, anything else: its members flattened, scalars only
+      i++;
+      if (i < n && s[i] == '}') return false;
+      uint32_t seen_src = 0;
+      for (;;) {
+        std::string k2;
+        if (!key(k2)) return false;
+        uint8_t role = DR_ANY;
+        if (top == 2) for (int t = 0; t < 12; t++) if (lower(k2) == SRC[t]) {
+          if (k2 != SRC_EXACT[t] || (seen_src & (1u << t))) return false;
+          seen_src |= 1u << t; role = SRC_ROLE[t];
+        }
+        const std::string prefix = s.substr(seg, i - seg);
+        if (!scalar() || i >= n) return false;
+        const char c = s[i];
+        if (!add_ent(prefix, role, c, 0)) return false;
+        i++;
+        seg = i;
+        if (c == '}') break;
+      }
+      if (i >= n) return false;
+      sep = s[i];
+      if (!add_ent("", DR_EMPTY, sep, 0)) return false;  // what lies between that '}' and the separator behind it: nothing
+    } else {
+      const std::string prefix = s.substr(seg, i - seg);
+      const bool is_null = !s.compare(i, 4, "null");
+      if (!scalar() || i >= n) return false;
+      sep = s[i];
+      const uint8_t role = top == 2 ? DR_NULL : top == 3 ? DR_OP : top == 4 ? DR_TS : DR_ANY;
+      if (top == 2 && !is_null) return false;
+      if (top == 3) M.opent = M.nent;
+      if (!add_ent(prefix, role, sep, 0)) return false;
+    }
+    i++;
+    seg = i;
+    if (sep == '}') break;
+  }
+  if (i != n || M.opent == ~0u || best.row.empty() || best.row.size() > (size_t)DQ_ROW) return false;
+  for (size_t r = 0; r < best.row.size(); r++) {
+    DqRow &R = best.row[r];
+    if (!add_text(best.text[r], R.ko, R.kn)) return false;
+    M.row[r] = R;
+  }
+  M.nrow = (uint32_t)best.row.size(); M.ngrp = (uint32_t)best.gk.size();
+  for (size_t g = 0; g < best.gk.size(); g++) { M.gk[g] = best.gk[g]; M.gfirst[g] = best.gfirst[g]; }
+  M.nf = (uint32_t)F;
+  M.valid = 1;
+  return true;
+}
+
 // a batch carries ONE TableID: good rows of another table than the first good row's are the stock code's
 __global__ void __launch_bounds__(256) dbz_table_rule(Params p) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -847,8 +1046,79 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
   TF_HIP(hipMemsetAsync(p.first_ok, 0xFF, 8, st));
   p.p10 = pow10_table(); p.p128 = reinterpret_cast<const uint64_t *>(p.p10 + 632);
   Buf tabname = dalloc_zero(512);
+  // ---- dbz_parse_quick for the messages that spell the group's first payload's members (tf_dbzquick.inc); TFGPU_DBZ_QUICK=0: the walker for all ----
+  static const bool quick_off = [] { const char *e = std::getenv("TFGPU_DBZ_QUICK"); return e && e[0] == '0'; }();
+  bool quick = !quick_off && schema_code == TFGPU_ROW_OK && nf >= 1 && nf <= dbz::DQ_F && nmsg >= 64;
+  for (int j = 0; quick && j < nf; j++) {
+    const int op = o->fields[j].op;
+    if (op == TFGPU_DBZ_HOST) quick = false;
+  }
+  auto eligible = [&](int64_t m) {
+    const tfgpu_dbz_frame &f = frames[m];
+    return f.code == TFGPU_ROW_OK && f.schema_hash[0] == p.h0 && f.schema_hash[1] == p.h1 && f.payload_len >= 2 && f.payload_len <= (uint32_t)JQ_BYTES - 32u;
+  };
+  Buf bmap, bqlist, btile, bslow;
+  int64_t qtiles = 0;
+  if (quick) {
+    int64_t m0 = -1;
+    for (int64_t m = 0; m < nmsg && m0 < 0; m++) if (eligible(m)) m0 = m;
+    dbz::DqMap map;
+    quick = false;
+    if (m0 >= 0) {
+      std::string pay((size_t)frames[m0].payload_len, '\0');
+      if (mem == TFGPU_MEM_HOST) std::memcpy(&pay[0], (const uint8_t *)bytes + frames[m0].payload_start, pay.size());
+      else { d2h(&pay[0], p.data + frames[m0].payload_start, pay.size()); tf::sync(); }
+      std::vector<std::string> fnames;
+      std::vector<int> fops;
+      for (int j = 0; j < nf; j++) { fnames.push_back(o->fields[j].name); fops.push_back(o->fields[j].op); }
+      quick = dbz::build_quick_map(pay, fnames, fops, map);
+    }
+    if (quick) {
+      // tiles: consecutive eligible messages while their 16-byte chunks fit the tile's text and there are at most JQ_LINES of them
+      std::vector<uint32_t> qlist, tile_first{0}, slow;
+      qlist.reserve((size_t)nmsg);
+      uint32_t used = 0, lines = 0;
+      for (int64_t m = 0; m < nmsg; m++) {
+        if (!eligible(m)) { slow.push_back((uint32_t)m); continue; }
+        const uint32_t ps = (uint32_t)frames[m].payload_start, pl = frames[m].payload_len;
+        const uint32_t chunks = (((ps + pl + 15u) & ~15u) - (ps & ~15u)) >> 4;
+        if (lines == (uint32_t)JQ_LINES || (used + chunks) * 16u > (uint32_t)JQ_BYTES) { tile_first.push_back((uint32_t)qlist.size()); used = 0; lines = 0; }
+        qlist.push_back((uint32_t)m); used += chunks; lines++;
+      }
+      tile_first.push_back((uint32_t)qlist.size());
+      qtiles = (int64_t)tile_first.size() - 1;
+      if (qlist.empty()) quick = false;
+      else {
+        bmap = upload_const(&map, sizeof map);
+        bqlist = dalloc(qlist.size() * 4 + 16); h2d(bqlist->p, qlist.data(), qlist.size() * 4);
+        btile = dalloc(tile_first.size() * 4 + 16); h2d(btile->p, tile_first.data(), tile_first.size() * 4);
+        bslow = dalloc((size_t)(nmsg + 1) * 4 + 16);
+        const uint32_t ns = (uint32_t)slow.size();
+        h2d(bslow->p, &ns, 4);
+        if (ns) h2d((char *)bslow->p + 4, slow.data(), slow.size() * 4);
+      }
+    }
+  }
   if (nmsg) {
-    { KernelTimer t("dbz_parse"); dbz::dbz_parse<<<dbz::nblk(nmsg, 128), 128, 0, st>>>(p); }
+    if (quick) {
+      Buf taken = dalloc_zero((size_t)nmsg + 16);
+      dbz::QParams qp{p, reinterpret_cast<const dbz::DqMap *>(bmap->p), ptr<uint32_t>(bqlist), ptr<uint32_t>(btile), ptr<uint32_t>(bslow), ptr<uint32_t>(bslow) + 1, ptr<uint8_t>(taken)};
+      { KernelTimer t("dbz_parse_quick"); dbz::dbz_parse_quick<<<(unsigned)qtiles, JQ_THREADS, 0, st>>>(qp); }
+      std::vector<uint16_t> ff;
+      for (int j = 0; j < nf; j++) if (o->fields[j].op == TFGPU_DBZ_FLOAT64) ff.push_back((uint16_t)j);
+      if (!ff.empty()) {
+        Buf bff = upload_small(ff.data(), ff.size() * 2);
+        KernelTimer t("dbz_quick_floats");
+        dbz::dbz_quick_floats<<<dbz::nblk(nmsg, 128), 128, 0, st>>>(qp, ptr<uint16_t>(bff), (int)ff.size());
+      }
+      { KernelTimer t("dbz_parse"); dbz::dbz_parse_listed<<<dbz::nblk(nmsg, 128), 128, 0, st>>>(p, ptr<uint32_t>(bslow) + 1, ptr<uint32_t>(bslow)); }
+      if (const char *e = std::getenv("TFGPU_DBZ_DEBUG"); e && e[0] == '1') {  // how the messages were routed (costs a sync)
+        uint32_t ns = 0;
+        d2h(&ns, bslow->p, 4); tf::sync();
+        std::fprintf(stderr, "tfgpu dbz quick: %lld messages, %lld tiles, %u to the walker\n", (long long)nmsg, (long long)qtiles, ns);
+      }
+      dbz::dbz_first_ok<<<dbz::nblk(nmsg, 256), 256, 0, st>>>(p);
+    } else { KernelTimer t("dbz_parse"); dbz::dbz_parse<<<dbz::nblk(nmsg, 128), 128, 0, st>>>(p); }
     dbz::dbz_table_rule<<<dbz::nblk(nmsg, 256), 256, 0, st>>>(p);
     dbz::dbz_table_name<<<1, 64, 0, st>>>(p, ptr<uint8_t>(tabname));
   }

@@ -64,16 +64,20 @@ __device__ __forceinline__ uint32_t jq_lower(const uint16_t *spos, uint32_t nsep
 
 // Stage the bytes [g0, last), classify, index the separators ',' '}' outside strings, frame the lines.  All threads call it
 // (it holds the barriers); false (uniform): the tile cannot be taken.
-template <class LDS> __device__ __forceinline__ bool jq_front(LDS &L, const uint8_t *data, const uint32_t first, const uint32_t last, const uint32_t g0, const int nl, const int ablate) {
+// (STAGE = false: the caller has put the lines' bytes into L.sbuf + 16 itself — payloads gathered from apart — and left
+// everything that belongs to no line zero.)
+template <class LDS, bool STAGE = true> __device__ __forceinline__ bool jq_front(LDS &L, const uint8_t *data, const uint32_t first, const uint32_t last, const uint32_t g0, const int nl, const int ablate) {
   uint8_t *const sb = L.sbuf + 16;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if constexpr (STAGE) {
 #pragma unroll
-  for (int it = 0; it < JQ_CPT; it++) {
-    const int chunk = it * JQ_THREADS + tid;
-    const uint32_t gp = g0 + (uint32_t)chunk * 16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (gp < last) v = *reinterpret_cast<const uint4 *>(data + gp);  // the buffer is padded past its payload
-    *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
+    for (int it = 0; it < JQ_CPT; it++) {
+      const int chunk = it * JQ_THREADS + tid;
+      const uint32_t gp = g0 + (uint32_t)chunk * 16;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (gp < last) v = *reinterpret_cast<const uint4 *>(data + gp);  // the buffer is padded past its payload
+      *reinterpret_cast<uint4 *>(sb + chunk * 16) = v;
+    }
   }
   if (tid < 4) { reinterpret_cast<uint32_t *>(L.sbuf)[tid] = 0; L.misc[tid] = 0; }
   if (tid >= 64 && tid < 76) reinterpret_cast<uint32_t *>(L.sbuf + 16 + JQ_BYTES)[tid - 64] = 0;
