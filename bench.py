@@ -1349,7 +1349,7 @@ class DebeziumWorkload(Base):
 
     def alg(self):
         pb = self.payload_bytes() + self.state.get("out_bytes", 0)
-        return {"dbz_parse": pb, "dbz_parse_quick": pb, "dbz_unpack": self.nbytes, "dbz_prefix_same": self.nbytes}
+        return {"dbz_parse": pb, "dbz_parse_quick": pb, "dbz_cell_values": pb, "dbz_cell_text": pb, "dbz_unpack": self.nbytes, "dbz_prefix_same": self.nbytes}
 
     def payload_bytes(self):
         i = self.msg.index(b'"payload":')

@@ -165,22 +165,49 @@ static int compile(const uint8_t *bytes, size_t len, std::vector<Field> &out, st
 using namespace tf;
 using namespace tf::dbzrecv;
 
+namespace tf { namespace dbz { void dbz_trust_frames(bool on); void dbz_tentative_frames(bool on); bool dbz_last_parse_was_quick(); } }
+
 struct tfgpu_dbz_schema {
   int code = 0; std::string why;
   std::vector<Field> fields;
   std::vector<tfgpu_dbz_field> cfields;  // views of `fields` for the C side
   void seal() { cfields.clear(); for (auto &f : fields) cfields.push_back(tfgpu_dbz_field{f.name.c_str(), f.op, f.optional, f.scale, 0}); }
 };
+// a host array the device copies into and out of: page-locked (hipHostMalloc), so the copy is one DMA at link speed instead of the
+// runtime's staged pageable copy (5 MB of frames and 4 MB of row meta per 2^17 messages, both ways, every batch)
+template <class T> struct PinVec {
+  T *p = nullptr; size_t n = 0;
+  PinVec() = default;
+  PinVec(const PinVec &) = delete; PinVec &operator=(const PinVec &) = delete;
+  PinVec(PinVec &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  PinVec &operator=(PinVec &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~PinVec() { release(); }
+  void release() { if (p) tfgpu_host_free(p); p = nullptr; n = 0; }
+  void resize(size_t k) {  // grows only; contents are not kept (every user fills it before reading)
+    if (k <= n) return;
+    release();
+    void *q = nullptr;
+    if (tfgpu_host_alloc(k * sizeof(T), &q) != TFGPU_OK) throw std::bad_alloc();
+    p = (T *)q; n = k;
+  }
+  void swap(PinVec &o) { std::swap(p, o.p); std::swap(n, o.n); }
+  T *data() { return p; } const T *data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct tfgpu_dbz_receiver {
   std::map<std::pair<uint64_t, uint64_t>, std::shared_ptr<tfgpu_dbz_schema>> cache;
   // the head of an earlier batch's opening message up to its payload value (tfgpu_debezium_unpack_cached)
+  bool last_quick = false;  // the last batch's messages went through dbz_parse_quick
   bool have_known = false; std::string known_bytes; uint32_t known_off = 0, known_len = 0; uint64_t known_hash[2] = {0, 0};
   // the last batch's results
-  struct Group { std::shared_ptr<tfgpu_dbz_schema> schema; tfgpu_dbatch *batch = nullptr; std::vector<tfgpu_dbz_row> rows; int64_t nrows = 0; };
+  struct Group { std::shared_ptr<tfgpu_dbz_schema> schema; tfgpu_dbatch *batch = nullptr; PinVec<tfgpu_dbz_row> rows; int64_t nrows = 0; };
   std::vector<Group> groups;
-  std::vector<tfgpu_dbz_frame> frames;
+  PinVec<tfgpu_dbz_frame> frames;
   std::vector<tfgpu_row_error> errs;
-  std::vector<std::vector<tfgpu_dbz_row>> spare_rows;
+  std::vector<PinVec<tfgpu_dbz_row>> spare_rows;
   void drop() { for (auto &g : groups) { if (g.batch) tfgpu_dbatch_free(g.batch); spare_rows.push_back(std::move(g.rows)); } groups.clear(); }
 };
 
@@ -234,6 +261,9 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
       tfgpu_dbz_prefix k{};
       k.bytes = r->known_bytes.data(); k.len = (uint32_t)r->known_bytes.size(); k.schema_off = r->known_off; k.schema_len = r->known_len;
       k.schema_hash[0] = r->known_hash[0]; k.schema_hash[1] = r->known_hash[1];
+      // payload spans claimed from the messages' ends instead of walked (tf_debezium.hip, Params::tent) once the tile parser has
+      // taken a batch of this receiver: it proves them, or the walker walks them
+      struct Tent { bool on; explicit Tent(bool o) : on(o) { if (on) tf::dbz::dbz_tentative_frames(true); } ~Tent() { if (on) tf::dbz::dbz_tentative_frames(false); } } tent(r->last_quick);
       rc = tfgpu_debezium_unpack_cached(bytes, len, mem, msgs, &k, r->frames.data());
     } else rc = tfgpu_debezium_unpack(bytes, len, mem, msgs, r->frames.data());
     if (rc) return rc;
@@ -289,8 +319,12 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
       if (!r->spare_rows.empty()) { g.rows.swap(r->spare_rows.back()); r->spare_rows.pop_back(); }  // (buffers of earlier batches: no 32 bytes per message to clear)
       if ((int64_t)g.rows.size() < std::max<int64_t>(nmsg, 1)) g.rows.resize((size_t)std::max<int64_t>(nmsg, 1));
       int64_t ne = 0;
-      rc = tfgpu_debezium_parse(&o, bytes, len, mem, msgs, r->frames.data(), &g.batch, g.rows.data(), nmsg, errs.data(), (int64_t)errs.size(), &ne);
+      {
+        struct Trust { Trust() { tf::dbz::dbz_trust_frames(true); } ~Trust() { tf::dbz::dbz_trust_frames(false); } } trust;  // r->frames is what the unpack call above wrote, untouched: its device copy serves (tf_debezium.hip)
+        rc = tfgpu_debezium_parse(&o, bytes, len, mem, msgs, r->frames.data(), &g.batch, g.rows.data(), nmsg, errs.data(), (int64_t)errs.size(), &ne);
+      }
       if (rc) return rc;
+      r->last_quick = tf::dbz::dbz_last_parse_was_quick();
       if (msg_codes) for (int64_t i = 0; i < std::min<int64_t>(ne, (int64_t)errs.size()); i++) if (errs[(size_t)i].row >= 0 && errs[(size_t)i].row < nmsg) msg_codes[errs[(size_t)i].row] = errs[(size_t)i].code;
       tfgpu_batch v{};
       if (g.batch && tfgpu_dbatch_view(g.batch, &v) == TFGPU_OK) g.nrows = v.nrows;
