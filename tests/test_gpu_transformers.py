@@ -246,6 +246,30 @@ def test_chain_and_skip_events(tf, oracle):
     assert not res.errors and not ref.errors
 
 
+def test_filter_hops_over_masks_it_does_not_read(tf, oracle):
+    """A filter_rows behind mask_field transformers runs in front of those whose columns it does not read (chain_sequence,
+    tf_transform.hip): Transformed rows, their order and the row errors are those of the configured order (the oracle's)."""
+    rng = np.random.default_rng(SEED0 + 77)
+    b, schema = _random_batch(rng, 5000)
+    b.kind = rng.choice(np.array([0, 0, 0, 0, 1, 2], np.uint8), 5000)  # updates / deletes: filter_rows' fatal rows
+    m = lambda *cols: ("mask_field", {"maskFunctionHash": {"userDefinedSalt": "pepper"}, "columns": list(cols)})
+    chains = [
+        [m("i32"), ("filter_rows", {"filter": "i64 > 0"})],                                  # hops
+        [m("i32"), m("s", "u8"), ("filter_rows", {"filter": "i16 >= -5 AND d < 2030-01-01"})],  # hops over both
+        [m("i32"), m("s"), ("filter_rows", {"filter": "s ~ 'a'"})],                            # reads the second mask's column: stays
+        [m("s"), m("i32"), ("filter_rows", {"filter": "s ~ 'a'"})],                            # hops over one, stops at the other
+        [m("i32"), ("filter_rows", {"filter": "i32 > '8'"})],                                # compares the hex digest: stays
+        [m("i64"), ("filter_rows", {"filter": "i8 > 0"}), m("i16"), ("filter_rows", {"filter": "u16 < 30000"}), ("convert_to_string", {"columns": {"includeColumns": ["^u8$"]}})],
+    ]
+    for chain in chains:
+        res = tf.apply_chain([tf.Transformer(a, c) for a, c in chain], tf.DeviceBatch.upload(b))
+        ref = oracle.apply_chain([oracle.Transformer(a, c) for a, c in chain], b, schema)
+        out = res.transformed.download()
+        assert_batches_equal(out, ref.batch, str(chain))
+        assert np.array_equal(out.src_row, ref.batch.src_row), chain
+        assert sorted((e[0], e[1]) for e in res.errors) == sorted((e[0], abi.ROWERR[e[1]]) for e in ref.errors), chain
+
+
 def test_float_to_string_shortest(tf, oracle):
     """fmt %v of Go floats (SerializeToString, to_string.go:170): shortest round-trip digits, %e below 1e-4 and
     from 1e21 on per strconv's %g — float64 and float32, against the oracle's digit search."""

@@ -116,6 +116,12 @@ def test_errors_keep_the_failing_transformers_input(tf):
     assert list(errs.col("id").values) == list(bad)
     assert errs.col("ip").repr == abi.R_STRING and all(len(errs.col("ip").get_bytes(i)) == 64 for i in range(errs.nrows))  # masked, as filter_rows saw it
     assert all(errs.col(TRANSFORM_ERROR_COLUMN).get_bytes(i).startswith(b"fatal") for i in range(errs.nrows))
+    # (the library runs this filter in front of the mask it does not read — chain_sequence, tf_transform.hip — and masks the rows
+    #  it refused afterwards: they must carry the same HMACs the mask alone gives those rows)
+    alone = chain[0].apply(tf.DeviceBatch.upload(b)).transformed.download()
+    assert [errs.col("ip").get_bytes(i) for i in range(errs.nrows)] == [alone.col("ip").get_bytes(int(r)) for r in bad]
+    ok = ok.download() if hasattr(ok, "download") else ok
+    assert [ok.col("ip").get_bytes(i) for i in range(ok.nrows)] == [alone.col("ip").get_bytes(int(r)) for r in np.flatnonzero(kinds == abi.K_INSERT)]
     st = stage.stats()
     assert st["errors"] == len(bad) and st["dropped"] == len(bad)
     quiet = []

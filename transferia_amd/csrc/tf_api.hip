@@ -177,9 +177,13 @@ int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tf
   ApplyCtx ax;
   std::unique_ptr<tfgpu_dbatch> cur = std::make_unique<tfgpu_dbatch>(*in);
   // transformation.do (transformation.go:252-274): toApply = t.Apply(toApply).Transformed
-  for (int i = 0; i < nplans; i++) {
+  std::vector<std::vector<int>> hopped;
+  const std::vector<int> seq = chain_sequence(plans, nplans, &hopped);  // a filter_rows in front of the mask_fields it does not read
+  for (int q = 0; q < nplans; q++) {
+    const int i = seq[(size_t)q];
     ax.step = i;
     size_t before = ax.errs.size();
+    for (int m : hopped[(size_t)q]) mask_precheck(*plans[m], *cur);  // what those masks would have refused comes first, as in the configured order
     std::unique_ptr<tfgpu_dbatch> next = apply_plan(*plans[i], *cur, ax);
     // errors are reported against rows of the ORIGINAL input batch
     if (ax.errs.size() > before && cur->src_row) {

@@ -136,4 +136,6 @@ struct ApplyCtx {
   int step = 0;
 };
 std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax);
+void mask_precheck(const tfgpu_plan &p, const tfgpu_dbatch &in);  // throws what apply_mask would refuse for the whole batch
+std::vector<int> chain_sequence(const tfgpu_plan *const *plans, int n, std::vector<std::vector<int>> *hopped);  // see tf_transform.hip
 }  // namespace tf

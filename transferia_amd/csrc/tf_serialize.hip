@@ -411,11 +411,19 @@ struct ChunkPlan {
 };
 // workgroups of four tiles; the XCD-aware order needs a whole number of workgroups per XCD (the tiles past the end do nothing)
 static inline unsigned ser_grid(const ChunkPlan &cp) {
+  if (cp.order == 3) return (unsigned)(cp.ngroups * ((cp.nchunks + 3) >> 2));
   const int64_t nb = (cp.ngroups * cp.nchunks + 3) >> 2;
   return (unsigned)(cp.order == 2 ? ((nb + 7) >> 3) << 3 : nb);
 }
 __device__ __forceinline__ void tile_of(const ChunkPlan &cp, int64_t tile, int32_t &k, int64_t &r0) {
-  if (cp.order == 2) {
+  if (cp.order == 3) {
+    // a workgroup's four waves take four NEIGHBOURING chunks of one row group — the seams between their segments are written
+    // within microseconds by one CU and leave its L2 as whole lines — while consecutive workgroups take consecutive row groups of
+    // the same four chunks: the reads stay within those chunks' columns, as in order 1
+    const int64_t b = tile >> 2, quad = b / cp.ngroups;
+    k = (int32_t)(quad * 4 + (tile & 3)); r0 = (b - quad * cp.ngroups) * 64;
+  }
+  else if (cp.order == 2) {
     // a row group's chunks are neighbours AND on one XCD: workgroups are dealt to the eight XCDs round-robin (blockIdx & 7), each
     // XCD has its own L2 — so XCD x takes the x-th eighth of the row groups, and the partial cache lines at the seams between a
     // row's chunks (written by different waves within microseconds) meet in ONE L2 and leave it as whole lines

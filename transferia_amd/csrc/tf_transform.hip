@@ -211,6 +211,44 @@ __global__ void fill_offsets_stride_kernel(uint32_t *off, int64_t n, uint32_t st
 
 static std::unique_ptr<tfgpu_dbatch> shallow_copy(const tfgpu_dbatch &in) { return std::make_unique<tfgpu_dbatch>(in); }
 
+// what apply_mask refuses for a whole batch, before anything is computed
+void mask_precheck(const tfgpu_plan &p, const tfgpu_dbatch &in) {
+  for (auto &c : in.cols) {
+    if (!p.mask_has(c.name)) continue;
+    require_serializable(c, "mask_field");
+    if ((uint64_t)in.nrows * 64 > 0xFFFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "mask_field: batch too large for 32-bit offsets; split the batch by rows");
+  }
+}
+// transformation.do runs the transformers in their configured order.  A filter_rows directly behind mask_field transformers whose
+// columns it does not read gives the same Transformed rows, the same row errors and the same failed inputs (once those are masked:
+// push_run does) when it runs FIRST — mask_field raises no row errors, changes no other column and drops no row — and the HMACs of
+// the rows it drops are never computed (45 % of them on configs[1]).  Returns the execution sequence; hopped[k] = the masks the
+// k-th executed plan (a filter) went in front of.
+std::vector<int> chain_sequence(const tfgpu_plan *const *plans, int n, std::vector<std::vector<int>> *hopped) {
+  static const bool off = [] { const char *e = std::getenv("TFGPU_CHAIN_REORDER"); return e && e[0] == '0'; }();
+  std::vector<int> seq((size_t)n);
+  for (int i = 0; i < n; i++) seq[(size_t)i] = i;
+  if (hopped) hopped->assign((size_t)n, {});
+  if (off) return seq;
+  for (int j = 1; j < n; j++) {
+    if (plans[seq[(size_t)j]]->kind != PK_FILTER_ROWS) continue;
+    const tfgpu_plan &f = *plans[seq[(size_t)j]];
+    int k = j;
+    std::vector<int> over;
+    while (k > 0 && plans[seq[(size_t)k - 1]]->kind == PK_MASK) {
+      const tfgpu_plan &m = *plans[seq[(size_t)k - 1]];
+      bool reads = false;
+      for (auto &e : f.exprs) for (auto &t : e.terms) if (m.mask_has(t.attr)) reads = true;
+      if (reads) break;
+      over.insert(over.begin(), seq[(size_t)k - 1]);
+      std::swap(seq[(size_t)k - 1], seq[(size_t)k]);
+      k--;
+    }
+    if (hopped) (*hopped)[(size_t)k] = over;
+  }
+  return seq;
+}
+
 static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu_dbatch &in) {
   auto out = shallow_copy(in);
   for (auto &sc : out->schema) if (p.mask_has(sc.first)) sc.second = TFGPU_T_UTF8;  // hmac_hasher.go:35-46

@@ -88,15 +88,23 @@ static void push_run(tfgpu_transformation &t, const tfgpu_dbatch &in, const tfgp
   const std::vector<int> plan = table_plan(t, in.ns, in.table, schema_of(in, schema));
   std::lock_guard<std::mutex> lk(ctx().mu);
   std::unique_ptr<tfgpu_dbatch> cur = std::make_unique<tfgpu_dbatch>(in);
-  for (int pi : plan) {  // transformation.do :252-274
+  std::vector<const tfgpu_plan *> chain;
+  for (int pi : plan) chain.push_back(t.transformers[(size_t)pi]);
+  std::vector<std::vector<int>> hopped;
+  const std::vector<int> seq = chain_sequence(chain.data(), (int)chain.size(), &hopped);  // a filter_rows in front of the mask_fields it does not read
+  for (size_t q = 0; q < seq.size(); q++) {  // transformation.do :252-274
+    const int pi = plan[(size_t)seq[q]];
     ApplyCtx ax;
     ax.step = pi;
+    for (int m : hopped[q]) mask_precheck(*chain[(size_t)m], *cur);
     std::unique_ptr<tfgpu_dbatch> next = apply_plan(*t.transformers[(size_t)pi], *cur, ax);
     if (!ax.errs.empty()) {
       std::vector<int32_t> rows(ax.errs.size());
       for (size_t k = 0; k < ax.errs.size(); k++) rows[k] = (int32_t)ax.errs[k].row;
       Buf sel = upload_small(rows.data(), rows.size() * 4);
-      o.failed.push_back(gather_rows(*cur, sel, (int64_t)rows.size()));  // TransformerError.Input = the item handed to THIS transformer
+      std::unique_ptr<tfgpu_dbatch> refused = gather_rows(*cur, sel, (int64_t)rows.size());
+      for (int m : hopped[q]) { ApplyCtx mx; refused = apply_plan(*chain[(size_t)m], *refused, mx); }  // as the configured order would have handed them over: masked
+      o.failed.push_back(std::move(refused));  // TransformerError.Input = the item handed to THIS transformer
       o.failed_step.push_back(pi);
       if (cur->src_row) {  // errs[].row is reported against the ORIGINAL input
         std::vector<int32_t> sr((size_t)cur->nrows);
