@@ -7,7 +7,10 @@ in this image, so this file restates ClickHouse's *documented* behaviour for the
   * integer literal types: the narrowest of UInt8/16/32/64 (Int8/16/32/64 when negative);
   * a + b, a - b over integers: signed if either side is (always for minus), bits = min(64, 2 * max(bits));
   * toIntN / toUIntN: two's complement truncation;  toString(int) = decimal text;  toDateTime(int) = epoch seconds;
-  * comparisons / IN over integers and strings; AND / OR without parentheses (AND binds tighter);
+  * comparisons / IN over integers and strings; AND / OR / NOT, parentheses; comparisons and logic yield UInt8;
+  * a * b typed like a + b; -a is signed (an unsigned operand takes the next size); integers of different signedness
+    compare by value; length(s) = bytes as UInt64; lower / upper touch ASCII letters only; cityHash64(String) = CityHash64
+    of CityHash v1.0.2 over the bytes (restated below from the published algorithm: unpinned like the rest);
   * JSONEachRow input: a column a row does not carry takes the type's default (0, '').
 and the Go code around it: SplitUpdatedPKeys is NOT restated (batches with such Updates are outside the subset), Collapse
 is the oracle's own (ora_collapse, pinned to TestCollapse), result types map back to YT types through
@@ -36,7 +39,7 @@ class QueryError(Exception):
     pass
 
 
-_TOKEN = re.compile(r"\s*(?:(?P<id>[A-Za-z_][A-Za-z_0-9]*)|`(?P<bq>[^`]*)`|\"(?P<dq>[^\"]*)\"|(?P<num>\d+(?:\.\d+|[eE][-+]?\d+)?)|'(?P<str>(?:[^'\\]|\\.|'')*)'|(?P<op><=|>=|!=|<>|==|[(),*+\-=<>;]))")
+_TOKEN = re.compile(r"\s*(?:(?P<id>[A-Za-z_][A-Za-z_0-9]*)|`(?P<bq>[^`]*)`|\"(?P<dq>[^\"]*)\"|(?P<num>\d+(?:\.\d+|[eE][-+]?\d+)?)|'(?P<str>(?:[^'\\]|\\.|'')*)'|(?P<op><=|>=|!=|<>|==|[(),*+\-=<>;/%]))")
 
 
 def _tokens(q):
@@ -92,6 +95,106 @@ def wrap(v, t):
     return v
 
 
+M64 = (1 << 64) - 1
+K0, K1, K2, K3 = 0xc3a5c85c97cb3127, 0xb492b66fbe98f273, 0x9ae16a3b2f90404f, 0xc949d7c7509e6557
+
+
+def city_hash64(s: bytes) -> int:
+    """CityHash64 of CityHash v1.0.2 (city.cc of that release), 64-bit arithmetic modulo 2^64."""
+    def f64(i):
+        return int.from_bytes(s[i:i + 8], "little")
+
+    def f32(i):
+        return int.from_bytes(s[i:i + 4], "little")
+
+    def rot(v, k):
+        return v if k == 0 else ((v >> k) | (v << (64 - k))) & M64
+
+    def mix(v):
+        return v ^ (v >> 47)
+
+    def h16(u, v):
+        m = 0x9ddfea08eb382d69
+        a = ((u ^ v) * m) & M64
+        a ^= a >> 47
+        b = ((v ^ a) * m) & M64
+        b ^= b >> 47
+        return (b * m) & M64
+
+    def weak(w, x, y, z, a, b):
+        a = (a + w) & M64
+        b = rot((b + a + z) & M64, 21)
+        c = a
+        a = (a + x + y) & M64
+        b = (b + rot(a, 44)) & M64
+        return (a + z) & M64, (b + c) & M64
+
+    def weak_at(i, a, b):
+        return weak(f64(i), f64(i + 8), f64(i + 16), f64(i + 24), a, b)
+    n = len(s)
+    if n <= 16:
+        if n > 8:
+            a, b = f64(0), f64(n - 8)
+            return h16(a, rot((b + n) & M64, n)) ^ b
+        if n >= 4:
+            return h16((n + (f32(0) << 3)) & M64, f32(n - 4))
+        if n > 0:
+            y = (s[0] + (s[n >> 1] << 8)) & 0xFFFFFFFF
+            z = (n + (s[n - 1] << 2)) & 0xFFFFFFFF
+            return (mix(((y * K2) & M64) ^ ((z * K3) & M64)) * K2) & M64
+        return K2
+    if n <= 32:
+        a, b, c, d = (f64(0) * K1) & M64, f64(8), (f64(n - 8) * K2) & M64, (f64(n - 16) * K0) & M64
+        return h16((rot((a - b) & M64, 43) + rot(c, 30) + d) & M64, (a + rot(b ^ K3, 20) - c + n) & M64)
+    if n <= 64:
+        z = f64(24)
+        a = (f64(0) + (n + f64(n - 16)) * K0) & M64
+        b = rot((a + z) & M64, 52)
+        c = rot(a, 37)
+        a = (a + f64(8)) & M64
+        c = (c + rot(a, 7)) & M64
+        a = (a + f64(16)) & M64
+        vf, vs = (a + z) & M64, (b + rot(a, 31) + c) & M64
+        a = (f64(16) + f64(n - 32)) & M64
+        z = f64(n - 8)
+        b = rot((a + z) & M64, 52)
+        c = rot(a, 37)
+        a = (a + f64(n - 24)) & M64
+        c = (c + rot(a, 7)) & M64
+        a = (a + f64(n - 16)) & M64
+        wf, ws = (a + z) & M64, (b + rot(a, 31) + c) & M64
+        r = mix(((vf + ws) * K2 + (wf + vs) * K0) & M64)
+        return (mix((r * K0 + vs) & M64) * K2) & M64
+    x, y, z = f64(0), f64(n - 16) ^ K1, f64(n - 56) ^ K0
+    v = weak_at(n - 64, n, y)
+    w = weak_at(n - 32, (n * K1) & M64, K0)
+    z = (z + mix(v[1]) * K1) & M64
+    x = (rot((z + x) & M64, 39) * K1) & M64
+    y = (rot(y, 33) * K1) & M64
+    left, i = (n - 1) & ~63, 0
+    while True:
+        x = (rot((x + y + v[0] + f64(i + 16)) & M64, 37) * K1) & M64
+        y = (rot((y + v[1] + f64(i + 48)) & M64, 42) * K1) & M64
+        x ^= w[1]
+        y ^= v[0]
+        z = rot(z ^ w[0], 33)
+        v = weak_at(i, (v[1] * K1) & M64, (x + w[0]) & M64)
+        w = weak_at(i + 32, (z + w[1]) & M64, y)
+        z, x = x, z
+        i += 64
+        left -= 64
+        if left == 0:
+            break
+    return h16((h16(v[0], w[0]) + mix(y) * K1 + z) & M64, (h16(v[1], w[1]) + x) & M64)
+
+
+def neg_type(a):
+    return "Int" + str(bits(a) if a.startswith("Int") else min(64, 2 * bits(a)))
+
+
+CMP = ("=", "!=", "<", "<=", ">", ">=")
+
+
 class _P:
     def __init__(self, q):
         self.t, self.i = _tokens(q), 0
@@ -116,16 +219,12 @@ class _P:
             raise QueryError("expected %r" % o)
         self.take()
 
-    # expression → ("col", name) | ("int", value, type) | ("str", s) | ("iexpr", col, [steps]) | ("tostr", col) | ("todt", col)
+    # nodes: ("col", name) | ("int", value, type) | ("str", s) | ("bin", op, a, b) | ("neg", a) | ("cast", type, a) | ("fn", name, a)
+    #        | ("cmp", op, a, b) | ("and" | "or", a, b) | ("not", a) | ("in", negated, a, [literal nodes])
     def primary(self):
         k, v = self.peek()
         if self.op("("):
-            self.take(); e = self.expr(); self.need(")"); return e
-        if self.op("-"):
-            self.take(); k, v = self.take()
-            if k != "int":
-                raise Unsupported("unary minus")
-            return ("int", -v, lit_type(-v))
+            self.take(); e = self.bexpr(); self.need(")"); return e
         if k == "int":
             self.take(); return ("int", v, lit_type(v))
         if k == "str":
@@ -137,59 +236,59 @@ class _P:
             return ("col", v)
         self.take()
         if v in ("to" + t for t in INT_TYPES):
-            a = self.expr(); self.need(")")
-            ty = v[2:]
-            if a[0] == "int":
-                return ("int", wrap(a[1], ty), ty)
-            if a[0] == "col":
-                return ("iexpr", a[1], [("cast", ty)])
-            if a[0] == "iexpr":
-                return ("iexpr", a[1], a[2] + [("cast", ty)])
-            raise Unsupported("cast of a non-integer expression")
-        if v in ("toString", "toDateTime"):
-            k2, c = self.take()
-            if k2 != "id":
-                raise Unsupported(v + " of an expression")
+            a = self.bexpr(); self.need(")")
+            return ("cast", v[2:], a)
+        if v in ("toString", "toDateTime", "length", "cityHash64", "lower", "upper", "lcase", "ucase", "not"):
+            a = self.bexpr()
+            if self.op(","):
+                raise Unsupported(v + " with several arguments")
             self.need(")")
-            return ("tostr" if v == "toString" else "todt", c)
+            return ("not", a) if v == "not" else ("fn", {"lcase": "lower", "ucase": "upper"}.get(v, v), a)
         raise Unsupported("function " + v)
 
-    def expr(self):
-        a = self.primary()
+    def unary(self):
+        if self.op("-"):
+            self.take()
+            k, v = self.peek()
+            if k == "int":
+                self.take(); return ("int", -v, lit_type(-v))
+            return ("neg", self.unary())
+        if self.op("+"):
+            self.take(); return self.unary()
+        return self.primary()
+
+    def mul(self):
+        a = self.unary()
+        while True:
+            if self.op("*"):
+                self.take(); a = ("bin", "*", a, self.unary()); continue
+            if self.op("/") or self.op("%"):
+                raise Unsupported("division / modulo")
+            return a
+
+    def addsub(self):
+        a = self.mul()
         while self.op("+") or self.op("-"):
-            minus = self.take()[1] == "-"
-            b = self.primary()
-            if b[0] != "int":
-                if a[0] == "int" and not minus and b[0] in ("col", "iexpr"):
-                    a, b = b, a
-                else:
-                    raise Unsupported("arithmetic")
-            if a[0] == "int":
-                ty = add_type(a[2], b[2], minus)
-                a = ("int", wrap(a[1] - b[1] if minus else a[1] + b[1], ty), ty)
-            elif a[0] == "col":
-                a = ("iexpr", a[1], [("add", -b[1] if minus else b[1], b[2], minus)])
-            elif a[0] == "iexpr":
-                a = ("iexpr", a[1], a[2] + [("add", -b[1] if minus else b[1], b[2], minus)])
-            else:
-                raise Unsupported("arithmetic on a non-integer")
+            o = self.take()[1]
+            a = ("bin", o, a, self.mul())
         return a
 
-    def term(self):
-        k, c = self.take()
-        if k != "id":
-            raise Unsupported("WHERE term")
+    def literal(self):
+        neg = False
+        if self.op("-"):
+            self.take(); neg = True
+        k, v = self.take()
+        if k == "int":
+            v = -v if neg else v
+            return ("int", v, lit_type(v))
+        if k == "str" and not neg:
+            return ("str", v)
+        if k == "end":
+            raise QueryError("expected a literal")
+        raise Unsupported("IN literal")
 
-        def lit():
-            neg = False
-            if self.op("-"):
-                self.take(); neg = True
-            k2, v = self.take()
-            if k2 == "int":
-                return -v if neg else v
-            if k2 == "str" and not neg:
-                return v
-            raise Unsupported("WHERE literal")
+    def cmp(self):
+        a = self.addsub()
         neg = False
         if self.kw("not"):
             self.take(); neg = True
@@ -197,21 +296,41 @@ class _P:
                 raise Unsupported("NOT")
         if self.kw("in"):
             self.take(); self.need("(")
-            vals = [lit()]
+            vals = [self.literal()]
             while self.op(","):
-                self.take(); vals.append(lit())
+                self.take(); vals.append(self.literal())
             self.need(")")
-            if len({type(x) for x in vals}) > 1:
+            if len({x[0] for x in vals}) > 1:
                 raise Unsupported("mixed list")
-            return (c, "not in" if neg else "in", vals)
-        k2, o = self.take()
-        if k2 != "op" or o not in ("=", "==", "!=", "<>", "<", "<=", ">", ">="):
-            raise QueryError("expected a comparison")
-        return (c, {"==": "=", "<>": "!="}.get(o, o), lit())
+            return ("in", neg, a, vals)
+        k, o = self.peek()
+        if k == "op" and o in ("=", "==", "!=", "<>", "<", "<=", ">", ">="):
+            self.take()
+            if self.peek()[0] == "end":
+                raise QueryError("expected an expression")
+            return ("cmp", {"==": "=", "<>": "!="}.get(o, o), a, self.addsub())
+        return a
+
+    def bnot(self):
+        if self.kw("not"):
+            self.take(); return ("not", self.bnot())
+        return self.cmp()
+
+    def band(self):
+        a = self.bnot()
+        while self.kw("and"):
+            self.take(); a = ("and", a, self.bnot())
+        return a
+
+    def bexpr(self):
+        a = self.band()
+        while self.kw("or"):
+            self.take(); a = ("or", a, self.band())
+        return a
 
 
 def parse(query):
-    """→ (items, where): items = [("*",) | (expr, name)], where = None | [[term, …], …] (OR of ANDs)."""
+    """→ (items, where): items = [("*",) | (node, name)], where = None | node."""
     p = _P(query)
     if not p.kw("select"):
         raise QueryError("the query must start with SELECT")
@@ -221,10 +340,13 @@ def parse(query):
         if p.op("*"):
             p.take(); items.append(("*",))
         else:
-            e = p.expr()
+            e = p.bexpr()
             name = e[1] if e[0] == "col" else None
             if p.kw("as"):
-                p.take(); name = p.take()[1]
+                p.take()
+                k, name = p.take()
+                if k != "id":
+                    raise QueryError("expected an alias")
             elif p.peek()[0] == "id" and not p.kw("from"):
                 name = p.take()[1]
             if name is None:
@@ -242,15 +364,9 @@ def parse(query):
     where = None
     if p.kw("where"):
         p.take()
-        where, conj = [], [p.term()]
-        while True:
-            if p.kw("and"):
-                p.take(); conj.append(p.term())
-            elif p.kw("or"):
-                p.take(); where.append(conj); conj = [p.term()]
-            else:
-                break
-        where.append(conj)
+        if p.peek()[0] == "end":
+            raise QueryError("expected a condition")
+        where = p.bexpr()
     if p.op(";"):
         p.take()
     if p.peek()[0] != "end":
@@ -258,45 +374,95 @@ def parse(query):
     return items, where
 
 
+def type_of(e, types, top=False):
+    """ClickHouse's type of a node over {column: yt type}.  `top`: the node is a select item (any column type passes through)."""
+    k = e[0]
+    if k == "col":
+        if e[1] not in types:
+            raise QueryError("unknown column " + e[1])
+        t = YT_TO_CH[types[e[1]]]
+        if not top and t not in INT_TYPES and t != "String":
+            raise Unsupported("a %s column inside an expression" % types[e[1]])
+        return t
+    if k == "int":
+        return e[2]
+    if k == "str":
+        return "String"
+
+    def integer(x):
+        t = type_of(x, types)
+        if t not in INT_TYPES:
+            raise (QueryError if t == "String" else Unsupported)("an integer is needed")
+        return t
+    if k == "bin":
+        return add_type(integer(e[2]), integer(e[3]), e[1] == "-")
+    if k == "neg":
+        return neg_type(integer(e[1]))
+    if k == "cast":
+        if type_of(e[2], types) == "String":
+            raise Unsupported("toIntN of text")
+        integer(e[2])
+        return e[1]
+    if k == "fn":
+        f = e[1]
+        if f == "toDateTime":
+            if not top or e[2][0] != "col":
+                raise Unsupported("toDateTime of an expression")
+            if type_of(e[2], types, True) not in ("Int32", "UInt32", "Int64", "UInt64", "DateTime"):
+                raise Unsupported("toDateTime of " + types[e[2][1]])
+            return "DateTime"
+        a = type_of(e[2], types, top and f == "toString" and e[2][0] == "col")
+        if f in ("length", "cityHash64"):
+            if a != "String":
+                raise Unsupported(f + " of a non-text value")
+            return "UInt64"
+        if f in ("lower", "upper"):
+            if a != "String":
+                raise QueryError(f + " of a non-text value")
+            return "String"
+        if f == "toString":
+            if a not in INT_TYPES and a != "String":
+                raise Unsupported("toString of " + a)
+            return "String"
+    if k == "cmp":
+        a, b = type_of(e[2], types), type_of(e[3], types)
+        if (a == "String") != (b == "String"):
+            raise QueryError("text compared with a number")
+        if a == "String" and (e[2][0] == "str") == (e[3][0] == "str"):
+            raise Unsupported("text comparison without exactly one literal")
+        return "UInt8"
+    if k in ("and", "or"):
+        integer(e[1]); integer(e[2])
+        return "UInt8"
+    if k == "not":
+        integer(e[1])
+        return "UInt8"
+    if k == "in":
+        a = type_of(e[2], types)
+        if (a == "String") != (e[3][0][0] == "str"):
+            raise QueryError("IN list of another type")
+        if a != "String":
+            integer(e[2])
+        return "UInt8"
+    raise AssertionError(e)
+
+
 def resolve(query, schema_triples):
-    """The result columns over an input schema [(name, yt type, is key)]: [(name, kind tuple, ch type, yt type, key)]."""
-    items, _ = parse(query)
+    """The result columns over an input schema [(name, yt type, is key)]: [(name, node, ch type, yt type, key)]."""
+    items, where = parse(query)
     names = [n for n, _, _ in schema_triples]
     types = {n: t for n, t, _ in schema_triples}
     keys = {n for n, _, k in schema_triples if k}
     out = []
-
-    def col(c):
-        if c not in types:
-            raise QueryError("unknown column " + c)
-        return YT_TO_CH[types[c]]
     for it in items:
         if it == ("*",):
             for n in names:
                 out.append((n, ("col", n), YT_TO_CH[types[n]]))
             continue
         e, name = it
-        if e[0] == "col":
-            out.append((name, e, col(e[1])))
-        elif e[0] == "int":
-            out.append((name, e, e[2]))
-        elif e[0] == "str":
-            out.append((name, e, "String"))
-        elif e[0] == "tostr":
-            if col(e[1]) not in INT_TYPES + ["String"]:
-                raise Unsupported("toString of " + types[e[1]])
-            out.append((name, e, "String"))
-        elif e[0] == "todt":
-            if col(e[1]) not in ("Int32", "UInt32", "Int64", "UInt64", "DateTime"):
-                raise Unsupported("toDateTime of " + types[e[1]])
-            out.append((name, e, "DateTime"))
-        elif e[0] == "iexpr":
-            ty = col(e[1])
-            if ty not in INT_TYPES:
-                raise Unsupported("integer expression on " + types[e[1]])
-            for s in e[2]:
-                ty = s[1] if s[0] == "cast" else add_type(ty, s[2], s[3])
-            out.append((name, e, ty))
+        out.append((name, e, type_of(e, types, True)))
+    if where is not None and type_of(where, types) == "String":
+        raise QueryError("the WHERE condition is text")
     if len({o[0] for o in out}) != len(out):
         raise Unsupported("duplicate result column")
     res = [(n, e, ch, CH_TO_YT[ch], n in keys) for n, e, ch in out]
@@ -327,65 +493,71 @@ def apply(query, rows, schema_triples):
             return int(v[1])
         return v[1]
 
-    def cmp(a, o, b):
-        if isinstance(b, str):
-            b = b.encode()
-        if type(a) is not type(b) and not (isinstance(a, int) and isinstance(b, int)):
-            raise Unsupported("comparison of %r with %r" % (type(a), type(b)))
-        return {"=": a == b, "!=": a != b, "<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b}[o]
-
-    def holds(row):
-        if where is None:
-            return True
-        for conj in where:
-            ok = True
-            for c, o, lit in conj:
-                if c not in types:
-                    raise QueryError("unknown column " + c)
-                a = value(row, c)
-                if o in ("in", "not in"):
-                    hit = any(cmp(a, "=", x) for x in lit)
-                    ok = ok and (hit if o == "in" else not hit)
-                else:
-                    ok = ok and cmp(a, o, lit)
-            if ok:
-                return True
-        return False
+    def ev(e, row):
+        """→ the value: a Python int (exact, within its ClickHouse type's range) or bytes"""
+        k = e[0]
+        if k == "col":
+            return value(row, e[1])
+        if k == "int":
+            return e[1]
+        if k == "str":
+            return e[1].encode() if isinstance(e[1], str) else e[1]
+        if k == "bin":
+            a, b = ev(e[2], row), ev(e[3], row)
+            return wrap(a + b if e[1] == "+" else a - b if e[1] == "-" else a * b, type_of(e, types))
+        if k == "neg":
+            return wrap(-ev(e[1], row), type_of(e, types))
+        if k == "cast":
+            return wrap(ev(e[2], row), e[1])
+        if k == "fn":
+            a = ev(e[2], row)
+            if e[1] == "length":
+                return len(a)
+            if e[1] == "cityHash64":
+                return city_hash64(bytes(a))
+            if e[1] == "lower":
+                return bytes(c + 32 if 65 <= c <= 90 else c for c in a)
+            if e[1] == "upper":
+                return bytes(c - 32 if 97 <= c <= 122 else c for c in a)
+            if e[1] == "toString":
+                return a if isinstance(a, (bytes, bytearray)) else str(a).encode()
+        if k == "cmp":
+            a, b = ev(e[2], row), ev(e[3], row)
+            if isinstance(a, (bytes, bytearray)):
+                a, b = bytes(a), bytes(b)
+            return int({"=": a == b, "!=": a != b, "<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b}[e[1]])
+        if k == "and":
+            return int(ev(e[1], row) != 0 and ev(e[2], row) != 0)
+        if k == "or":
+            return int(ev(e[1], row) != 0 or ev(e[2], row) != 0)
+        if k == "not":
+            return int(ev(e[1], row) == 0)
+        if k == "in":
+            a = ev(e[2], row)
+            if isinstance(a, (bytes, bytearray)):
+                a = bytes(a)
+            hit = any(a == ev(x, row) for x in e[3])
+            return int(hit != e[1])
+        raise AssertionError(e)
     out = []
     for row in rows:
-        if not holds(row):
+        if where is not None and ev(where, row) == 0:
             continue
         vals = []
         for name, e, ch, yt, key in res:
-            if e[0] == "col":
-                v = value(row, e[1])
-                if ch in INT_TYPES:
-                    vals.append([_GO[yt], int(v)])
-                elif ch == "String":
-                    vals.append(["string", v])
-                elif ch == "Float64":
-                    vals.append(["float64", float(v)])
-                else:
-                    vals.append(["time", tuple(v)])
-            elif e[0] == "int":
-                vals.append([_GO[yt], e[1]])
-            elif e[0] == "str":
-                vals.append(["string", e[1].encode()])
-            elif e[0] == "tostr":
-                v = value(row, e[1])
-                vals.append(["string", v if isinstance(v, bytes) else str(v).encode()])
-            elif e[0] == "todt":
-                v = value(row, e[1])
+            if e[0] == "fn" and e[1] == "toDateTime":
+                v = value(row, e[2][1])
                 vals.append(["time", (int(v), 0) if isinstance(v, int) else tuple(v)])
+                continue
+            v = ev(e, row)
+            if ch in INT_TYPES:
+                vals.append([_GO[yt], int(v)])
+            elif ch == "String":
+                vals.append(["string", bytes(v)])
+            elif ch == "Float64":
+                vals.append(["float64", float(v)])
             else:
-                v = value(row, e[1])
-                ty = YT_TO_CH[types[e[1]]]
-                for s in e[2]:
-                    if s[0] == "cast":
-                        ty = s[1]; v = wrap(v, ty)
-                    else:
-                        ty = add_type(ty, s[2], s[3]); v = wrap(v + s[1], ty)
-                vals.append([_GO[yt], v])
+                vals.append(["time", tuple(v)])
         kind = row["kind"]
         out.append({"kind": kind, "src": row["src"], "values": None if kind == "delete" else vals, "old": vals if kind in ("update", "delete") else None})
     return out

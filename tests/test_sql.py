@@ -37,16 +37,20 @@ def test_reference_schema_assertions():
     with pytest.raises(lib.TfgpuError) as ei:
         sql("selet *, 1+1 as res from table")
     assert ei.value.code == lib.ERR_CONFIG
-    # "valid query" of the reference uses cityHash64(): outside the device subset, named as such
+    # "valid query" (:45-62) and "exclude tables with no PKey" (:26-44): cityHash64(val) over the `any` column
+    vq = "\nselect\n\tid,\n\tval,\n\tcityHash64(val) as hashed_title\nfrom table;\n"
+    assert sql(vq).suitable("", "test", s)
+    assert [[c.name, c.dtype, c.key, c.original_type] for c in sql(vq).result_schema(s).cols] == [["id", "int32", True, "ch:Int32"], ["val", "string", False, "ch:String"], ["hashed_title", "uint64", False, "ch:UInt64"]]
     with pytest.raises(lib.TfgpuError) as ei:
-        sql("select id, val, cityHash64(val) as hashed_title from table;")
-    assert ei.value.code == lib.ERR_UNSUPPORTED and "cityHash64" in str(ei.value)
+        sql(vq).result_schema(s_nokey)
+    assert ei.value.code == lib.ERR_CONFIG and "no primary key" in str(ei.value)
 
 
 def test_refusals_name_the_construct():
     for q, what in [("select id from table group by id", "group"), ("select id from table order by id", "order"), ("select id from table limit 5", "limit"),
-                    ("select id from other", "FROM"), ("select id, 1.5 as f from table", "floating"), ("select id from table where (id = 1)", "parenthesised"),
-                    ("select id, id + x as s from table", "arithmetic"), ("select id, lower(val) as l from table", "lower"), ("select id + 1 from table", "alias")]:
+                    ("select id from other", "FROM"), ("select id, 1.5 as f from table", "floating"), ("select id, id / 2 as h from table", "Float64"),
+                    ("select id, id % 2 as h from table", "modulo"), ("select id, concat(val, 'x') as l from table", "concat"), ("select id + 1 from table", "alias"),
+                    ("select id, length(val, val) as l from table", "one argument"), ("select id from table where val like 'a%'", "like")]:
         with pytest.raises(lib.TfgpuError) as ei:
             sql(q)
         assert ei.value.code == lib.ERR_UNSUPPORTED and what.lower() in str(ei.value).lower(), (q, str(ei.value))
@@ -54,6 +58,39 @@ def test_refusals_name_the_construct():
         with pytest.raises(lib.TfgpuError) as ei:
             sql(q)
         assert ei.value.code == lib.ERR_CONFIG, q
+
+
+def test_expression_types_and_schema_refusals(oracle):
+    """The general expressions: ClickHouse's result types (device plan against the oracle's restatement) and what a schema makes
+    ClickHouse refuse (TFGPU_ERR_CONFIG) or the device subset decline (TFGPU_ERR_UNSUPPORTED)."""
+    from oracle import ora_sql
+    s = abi.Schema.of([["id", "int32", True], ["k", "uint8"], ["big", "uint64"], ["w", "int16"], ["name", "utf8"], ["d", "double"], ["t", "timestamp"], ["b", "boolean"]])
+    q = ("select id, id * k as m, k * k as kk, big * 2 as b2, -k as nk, -w as nw, -(1 + 1) as n2, id - big as diff, toInt8(id * 300) as c8, length(name) as l, cityHash64(name) as h, "
+         "lower(name) as lo, upper(lower(name)) as up, toString(id + k) as s1, id > k as gt, not (k in (1, 2)) as ni, (id = 1 or k > 2) and name != 'zz' as f, 'a' < name as lt, "
+         "length(lower(name)) + w as lw, b and k as bk from table where (id >= 0 or not b) and (length(name) > 2 or name in ('a', 'b'))")
+    got = [[c.name, c.dtype, c.key] for c in sql(q).result_schema(s).cols]
+    assert got == [[n, yt, key] for n, _, _, yt, key in ora_sql.resolve(q, [(c.name, c.dtype, c.key) for c in s.cols])]
+    assert dict((n, t) for n, t, _ in got) == {"id": "int32", "m": "int64", "kk": "uint16", "b2": "uint64", "nk": "int16", "nw": "int16", "n2": "int32", "diff": "int64", "c8": "int8", "l": "uint64",
+                                               "h": "uint64", "lo": "string", "up": "string", "s1": "string", "gt": "uint8", "ni": "uint8", "f": "uint8", "lt": "uint8", "lw": "int64", "bk": "uint8"}
+    for q, code in [("select id, name + 1 as x from table", lib.ERR_CONFIG), ("select id, lower(id) as x from table", lib.ERR_CONFIG), ("select id from table where name = 1", lib.ERR_CONFIG),
+                    ("select id from table where id in ('a')", lib.ERR_CONFIG), ("select id from table where name", lib.ERR_CONFIG), ("select id, nosuch + 1 as x from table", lib.ERR_CONFIG),
+                    ("select id, d + 1 as x from table", lib.ERR_UNSUPPORTED), ("select id, length(id) as x from table", lib.ERR_UNSUPPORTED), ("select id, toInt8(name) as x from table", lib.ERR_UNSUPPORTED),
+                    ("select id, toDateTime(id + 1) as x from table", lib.ERR_UNSUPPORTED), ("select id from table where name = lower(name)", lib.ERR_UNSUPPORTED)]:
+        with pytest.raises(lib.TfgpuError) as ei:
+            sql(q).result_schema(s)
+        assert ei.value.code == code, (q, str(ei.value))
+        with pytest.raises((ora_sql.QueryError, ora_sql.Unsupported)) as oi:
+            ora_sql.resolve(q, [(c.name, c.dtype, c.key) for c in s.cols])
+        assert (oi.type is ora_sql.QueryError) == (code == lib.ERR_CONFIG), (q, oi.type)
+
+
+def test_city_hash64_restatement_agrees_with_itself():
+    """CityHash64 v1.0.2 is restated twice (oracle: Python integers; device: tf_transform.hip) from the published algorithm; the
+    only value known without a ClickHouse run is the empty string's (k2).  The device side is compared in test_general_expressions."""
+    from oracle import ora_sql
+    assert ora_sql.city_hash64(b"") == 0x9AE16A3B2F90404F
+    seen = {ora_sql.city_hash64(bytes([65 + i % 26 for i in range(n)])) for n in range(0, 300)}
+    assert len(seen) == 300
 
 
 def test_result_types_follow_clickhouse(oracle):
@@ -179,6 +216,41 @@ def test_random_parity(tf, oracle):
             while r[0][1] in seen:
                 r[0][1] += 1 << 41
             seen.add(r[0][1])
+        b = abi.batch_from_rows(S, names, rows, "db", "t", ["insert"] * n)
+        for q in queries:
+            _check(tf, oracle, q, b, S)
+
+
+@pytest.mark.gpu
+def test_reference_valid_query_cityhash(tf, oracle):
+    """clickhouse_local_test.go:45-62, the query of "valid query": id, val, cityHash64(val) over an `any` column holding strings."""
+    s = abi.Schema.of([["id", "int32", True], ["val", "any"]])
+    vals = ["", "a", "part", "0123456789abcdef", "0123456789abcdefg", "x" * 32, "y" * 33, "z" * 64, "w" * 65, "v" * 128, "u" * 129, "кириллица и пробелы " * 7]
+    b = abi.batch_from_rows(s, ["id", "val"], [[["int32", i], ["string", v]] for i, v in enumerate(vals)], "", "test", ["insert"] * len(vals))
+    out = _check(tf, oracle, "\nselect\n\tid,\n\tval,\n\tcityHash64(val) as hashed_title\nfrom table;\n", b, s)
+    assert out.cols[2].pyvalue(0) == ["uint64", 0x9AE16A3B2F90404F]  # CityHash64 of the empty string: k2
+
+
+@pytest.mark.gpu
+def test_general_expressions(tf, oracle):
+    """Column arithmetic, parentheses, NOT, comparisons as values, text functions — the expression program against the oracle."""
+    rng = np.random.default_rng(20260924)
+    S = abi.Schema.of([["id", "int64", True], ["k", "uint8"], ["x", "int32"], ["u", "uint32"], ["big", "uint64"], ["name", "utf8"], ["w", "int16"], ["flag", "boolean"]])
+    names = [c.name for c in S.cols]
+    queries = ["select id, x * k as m, x + w as s, x - u as d, -k as nk, -x as nx, k * k * k as k3, big + 1 as b1, big * 3 as b3, toInt8(x * w) as c8, (x + 1) * (w - 1) as prod from table",
+               "select id, length(name) as l, cityHash64(name) as h, lower(name) as lo, upper(name) as up, cityHash64(upper(name)) as hu, toString(x * 2) as s2, toString(length(name) + k) as s3 from table",
+               "select id, x > w as gt, big > x as ux, x <= big as xu, big > 9223372036854775807 as top, not flag as nf, (k in (1, 2, 250)) or flag as o, 'M' <= name as ge, name < 'n5' as lt from table",
+               "select id, name from table where (x >= 0 or k < 10) and not (name in ('N1', 'n2') or w > 30000)",
+               "select id, k from table where x * 2 > w + u or length(name) = 2 and cityHash64(name) > 9223372036854775807",
+               "select id, big from table where big > x and not (big in (1, 2)) and lower(name) != 'n3'",
+               "select id, x from table where (k = 1 or k = 2 or (k > 100 and k <= 200)) and 5 < x"]
+    for n in (1, 64, 1001):
+        rows = []
+        for i in range(n):
+            rows.append([["int64", i * 3 - 5], ["uint8", int(rng.integers(0, 256))], ["nil", None] if rng.random() < 0.1 else ["int32", int(rng.integers(-2 ** 31, 2 ** 31))],
+                         ["uint32", int(rng.integers(0, 2 ** 32))], ["uint64", int(rng.integers(0, 2 ** 64, dtype=np.uint64)) if i % 3 else int(rng.integers(0, 5))],
+                         ["nil", None] if rng.random() < 0.1 else ["string", ("N%d" if i % 4 == 0 else "n%d") % int(rng.integers(0, 12)) * int(rng.integers(1, 30 if i % 5 else 3))],
+                         ["int16", int(rng.integers(-2 ** 15, 2 ** 15))], ["bool", bool(rng.integers(0, 2))]])
         b = abi.batch_from_rows(S, names, rows, "db", "t", ["insert"] * n)
         for q in queries:
             _check(tf, oracle, q, b, S)

@@ -63,7 +63,11 @@ enum PlanKind { PK_MASK, PK_RENAME, PK_FILTER_COLUMNS, PK_SKIP_EVENTS, PK_FILTER
 namespace tf {
 // ---- `sql` transformer, device subset (tf_sql.cpp) ----------------------------------------------------------------------
 enum SqlType : int32_t { SQL_PENDING = 0, SQL_I8, SQL_I16, SQL_I32, SQL_I64, SQL_U8, SQL_U16, SQL_U32, SQL_U64, SQL_F64, SQL_STRING, SQL_DATE, SQL_DATETIME, SQL_DATETIME64 };  // ClickHouse types
-enum SqlItemKind : int32_t { SQL_STAR, SQL_COLUMN, SQL_CONST_INT, SQL_CONST_STR, SQL_INT_EXPR, SQL_TO_STRING, SQL_TO_DATETIME };
+enum SqlItemKind : int32_t { SQL_STAR, SQL_COLUMN, SQL_CONST_INT, SQL_CONST_STR, SQL_INT_EXPR, SQL_TO_STRING, SQL_TO_DATETIME, SQL_EXPR };
+// the general expression tree (SQL_EXPR items, a WHERE that is not an OR of ANDs of column-against-literal terms)
+enum SqlNodeOp : int32_t { SN_COL, SN_INT, SN_STR, SN_ADD, SN_SUB, SN_MUL, SN_NEG, SN_CAST, SN_LEN, SN_CITY64, SN_LOWER, SN_UPPER, SN_TOSTR, SN_TODT,
+                           SN_EQ, SN_NE, SN_LT, SN_LE, SN_GT, SN_GE, SN_AND, SN_OR, SN_NOT, SN_IN, SN_NOTIN };
+struct SqlNode { int op = SN_INT; int ty = SQL_PENDING; int64_t ival = 0; std::string s; std::vector<int> kids; };  // ty: literals and casts; the rest is typed over a schema (sql_node_types)
 struct SqlStep { bool is_cast; int ty; int64_t addend; bool minus; };  // toIntN(...) / ± integer literal (ty: the literal's type)
 struct SqlItem {  // one entry of the select list as parsed
   int kind = SQL_COLUMN;
@@ -72,11 +76,13 @@ struct SqlItem {  // one entry of the select list as parsed
   int cast = 0;      // ClickHouse type of a constant / toString / toDateTime result
   int64_t ival = 0; std::string sval;
   std::vector<SqlStep> steps;  // SQL_INT_EXPR: applied to the source column in order
+  int root = -1;               // SQL_EXPR: node of tfgpu_plan::sql_nodes
 };
 struct SqlOp { int64_t addend; int ty; };  // v = wrap(v + addend, ty)
 struct SqlOut {  // one result column over a concrete input schema
   int kind = SQL_COLUMN; std::string name; int src = -1; int ch = SQL_PENDING, yt = 0; bool key = false;
   int64_t ival = 0; std::string sval; std::vector<SqlOp> ops;
+  int root = -1;  // SQL_EXPR
 };
 }  // namespace tf
 
@@ -103,6 +109,8 @@ struct tfgpu_plan {
   std::string sql_query;
   std::vector<tf::SqlItem> sql_items;
   bool sql_has_where = false;
+  std::vector<tf::SqlNode> sql_nodes;  // expression trees of SQL_EXPR items and of a general WHERE
+  int sql_where_root = -1;             // >= 0: the WHERE is this tree (`exprs` is empty then)
   // replace_primary_key
   std::vector<std::string> new_keys;
   bool is_new_key(const std::string &n) const {
@@ -129,6 +137,7 @@ void sha256_midstate(const uint8_t block[64], uint32_t out[8]);
 
 void sql_parse(const std::string &query, tfgpu_plan &p);                                              // tf_sql.cpp
 std::vector<SqlOut> sql_resolve(const tfgpu_plan &p, const std::vector<SchemaCol> &in);            // tf_sql.cpp
+std::vector<int> sql_node_types(const tfgpu_plan &p, const std::vector<SchemaCol> &in);               // ClickHouse type of every node that is reachable from an item / the WHERE (SQL_PENDING elsewhere)
 std::string type_name(int dtype);                                                                    // YT type name of a TFGPU_T_* code
 // Apply one plan to a device batch (tf_transform.hip). `errs` collects row errors.
 struct ApplyCtx {

@@ -1168,6 +1168,285 @@ static int sql_repr_of(int ch) {
   }
 }
 
+// ---- the expression program: SQL_EXPR items and a WHERE that is a tree (tf_sql.cpp).  One lane evaluates one row: a postfix
+//      program over int64 slots, every arithmetic result wrapped to its ClickHouse type; text enters through leaves
+//      (length, cityHash64, comparison against literals).  Text-valued nodes (lower / upper / toString) are whole columns. ----
+struct SqlLeaf { const void *values; const uint32_t *offsets; const uint8_t *data; int32_t repr; int32_t pad; };
+struct SqlIns { int32_t op, ty, a, b; int64_t imm; };
+enum { BI_COL, BI_IMM, BI_ADD, BI_SUB, BI_MUL, BI_NEG, BI_WRAP, BI_CMP, BI_AND, BI_OR, BI_NOT, BI_LEN, BI_CITY, BI_SCMP, BI_IN, BI_SIN };
+struct SqlProg { const SqlIns *ins; int32_t nins; const SqlLeaf *leaves; const int64_t *ints; const uint32_t *soff; const uint8_t *sdata; int64_t n; void *out; int32_t out_ty; uint32_t *keep; };
+constexpr int SQL_STACK = 16;
+
+// CityHash64 of CityHash v1.0.2 (the version ClickHouse carries as CityHash_v1_0_2; cityHash64(String) is CityHash64(data, size))
+namespace city {
+constexpr uint64_t k0 = 0xc3a5c85c97cb3127ull, k1 = 0xb492b66fbe98f273ull, k2 = 0x9ae16a3b2f90404full, k3 = 0xc949d7c7509e6557ull;
+__device__ __forceinline__ uint64_t f64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; i--) v = (v << 8) | p[i]; return v; }
+__device__ __forceinline__ uint64_t f32(const uint8_t *p) { return (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24); }
+__device__ __forceinline__ uint64_t rot(uint64_t v, int s) { return s == 0 ? v : (v >> s) | (v << (64 - s)); }
+__device__ __forceinline__ uint64_t smix(uint64_t v) { return v ^ (v >> 47); }
+__device__ __forceinline__ uint64_t h16(uint64_t u, uint64_t v) {
+  const uint64_t kMul = 0x9ddfea08eb382d69ull;
+  uint64_t a = (u ^ v) * kMul; a ^= a >> 47;
+  uint64_t b = (v ^ a) * kMul; b ^= b >> 47;
+  return b * kMul;
+}
+struct P { uint64_t first, second; };
+__device__ __forceinline__ P weak(uint64_t w, uint64_t x, uint64_t y, uint64_t z, uint64_t a, uint64_t b) {
+  a += w; b = rot(b + a + z, 21);
+  const uint64_t c = a;
+  a += x; a += y; b += rot(a, 44);
+  return P{a + z, b + c};
+}
+__device__ __forceinline__ P weak(const uint8_t *s, uint64_t a, uint64_t b) { return weak(f64(s), f64(s + 8), f64(s + 16), f64(s + 24), a, b); }
+__device__ uint64_t hash64(const uint8_t *s, uint64_t len) {
+  if (len <= 16) {
+    if (len > 8) { const uint64_t a = f64(s), b = f64(s + len - 8); return h16(a, rot(b + len, (int)len)) ^ b; }
+    if (len >= 4) { const uint64_t a = f32(s); return h16(len + (a << 3), f32(s + len - 4)); }
+    if (len > 0) { const uint8_t a = s[0], b = s[len >> 1], c = s[len - 1]; const uint32_t y = (uint32_t)a + ((uint32_t)b << 8), z = (uint32_t)len + ((uint32_t)c << 2); return smix(y * k2 ^ z * k3) * k2; }
+    return k2;
+  }
+  if (len <= 32) {
+    const uint64_t a = f64(s) * k1, b = f64(s + 8), c = f64(s + len - 8) * k2, d = f64(s + len - 16) * k0;
+    return h16(rot(a - b, 43) + rot(c, 30) + d, a + rot(b ^ k3, 20) - c + len);
+  }
+  if (len <= 64) {
+    uint64_t z = f64(s + 24), a = f64(s) + (len + f64(s + len - 16)) * k0, b = rot(a + z, 52), c = rot(a, 37);
+    a += f64(s + 8); c += rot(a, 7); a += f64(s + 16);
+    const uint64_t vf = a + z, vs = b + rot(a, 31) + c;
+    a = f64(s + 16) + f64(s + len - 32); z = f64(s + len - 8); b = rot(a + z, 52); c = rot(a, 37);
+    a += f64(s + len - 24); c += rot(a, 7); a += f64(s + len - 16);
+    const uint64_t wf = a + z, ws = b + rot(a, 31) + c;
+    const uint64_t r = smix((vf + ws) * k2 + (wf + vs) * k0);
+    return smix(r * k0 + vs) * k2;
+  }
+  uint64_t x = f64(s), y = f64(s + len - 16) ^ k1, z = f64(s + len - 56) ^ k0;
+  P v = weak(s + len - 64, len, y), w = weak(s + len - 32, len * k1, k0);
+  z += smix(v.second) * k1;
+  x = rot(z + x, 39) * k1;
+  y = rot(y, 33) * k1;
+  len = (len - 1) & ~(uint64_t)63;
+  do {
+    x = rot(x + y + v.first + f64(s + 16), 37) * k1;
+    y = rot(y + v.second + f64(s + 48), 42) * k1;
+    x ^= w.second; y ^= v.first;
+    z = rot(z ^ w.first, 33);
+    v = weak(s, v.second * k1, x + w.first);
+    w = weak(s + 32, z + w.second, y);
+    const uint64_t t = z; z = x; x = t;
+    s += 64; len -= 64;
+  } while (len != 0);
+  return h16(h16(v.first, w.first) + smix(y) * k1 + z, h16(v.second, w.second) + x);
+}
+}  // namespace city
+
+// integers of different signedness compare by value (ClickHouse's accurate comparison): only UInt64 does not fit the int64 slot
+__device__ __forceinline__ int sql_order(int64_t a, bool au, int64_t b, bool bu) {
+  if (au == bu) return au ? ((uint64_t)a < (uint64_t)b ? -1 : (uint64_t)a > (uint64_t)b ? 1 : 0) : (a < b ? -1 : a > b ? 1 : 0);
+  if (au) return a < 0 ? 1 : (a < b ? -1 : a > b ? 1 : 0);   // a >= 2^63 is above every signed value
+  return b < 0 ? -1 : (a < b ? -1 : a > b ? 1 : 0);
+}
+__device__ __forceinline__ bool sql_cmp_holds(int c, int op) {
+  switch (op) { case 0: return c == 0; case 1: return c != 0; case 2: return c < 0; case 3: return c <= 0; case 4: return c > 0; default: return c >= 0; }
+}
+__global__ void __launch_bounds__(256) sql_expr_kernel(SqlProg p) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.n) return;
+  int64_t st[SQL_STACK];
+  int sp = 0;
+  for (int i = 0; i < p.nins; i++) {
+    const SqlIns in = p.ins[i];
+    switch (in.op) {
+      case BI_COL: {
+        const SqlLeaf l = p.leaves[in.a];
+        int64_t v;
+        switch (l.repr) {
+          case TFGPU_R_INT8: v = ((const int8_t *)l.values)[r]; break; case TFGPU_R_INT16: v = ((const int16_t *)l.values)[r]; break;
+          case TFGPU_R_INT32: v = ((const int32_t *)l.values)[r]; break; case TFGPU_R_INT64: v = ((const int64_t *)l.values)[r]; break;
+          case TFGPU_R_UINT8: case TFGPU_R_BOOL: v = ((const uint8_t *)l.values)[r]; break; case TFGPU_R_UINT16: v = ((const uint16_t *)l.values)[r]; break;
+          case TFGPU_R_UINT32: v = ((const uint32_t *)l.values)[r]; break; default: v = (int64_t)((const uint64_t *)l.values)[r];
+        }
+        st[sp++] = v;
+        break;
+      }
+      case BI_IMM: st[sp++] = in.imm; break;
+      case BI_ADD: sp--; st[sp - 1] = sql_wrap((int64_t)((uint64_t)st[sp - 1] + (uint64_t)st[sp]), in.ty); break;
+      case BI_SUB: sp--; st[sp - 1] = sql_wrap((int64_t)((uint64_t)st[sp - 1] - (uint64_t)st[sp]), in.ty); break;
+      case BI_MUL: sp--; st[sp - 1] = sql_wrap((int64_t)((uint64_t)st[sp - 1] * (uint64_t)st[sp]), in.ty); break;
+      case BI_NEG: st[sp - 1] = sql_wrap((int64_t)(0 - (uint64_t)st[sp - 1]), in.ty); break;
+      case BI_WRAP: st[sp - 1] = sql_wrap(st[sp - 1], in.ty); break;
+      case BI_CMP: sp--; st[sp - 1] = sql_cmp_holds(sql_order(st[sp - 1], (in.b & 1) != 0, st[sp], (in.b & 2) != 0), in.a) ? 1 : 0; break;
+      case BI_AND: sp--; st[sp - 1] = (st[sp - 1] != 0 && st[sp] != 0) ? 1 : 0; break;
+      case BI_OR: sp--; st[sp - 1] = (st[sp - 1] != 0 || st[sp] != 0) ? 1 : 0; break;
+      case BI_NOT: st[sp - 1] = st[sp - 1] == 0 ? 1 : 0; break;
+      case BI_LEN: { const SqlLeaf l = p.leaves[in.a]; st[sp++] = (int64_t)(l.offsets[r + 1] - l.offsets[r]); break; }
+      case BI_CITY: { const SqlLeaf l = p.leaves[in.a]; const uint32_t a = l.offsets[r]; st[sp++] = (int64_t)city::hash64(l.data + a, l.offsets[r + 1] - a); break; }
+      case BI_SCMP: {
+        const SqlLeaf l = p.leaves[in.a];
+        const uint32_t a = l.offsets[r], la = l.offsets[r + 1] - a, b = p.soff[in.b], lb = p.soff[in.b + 1] - b;
+        st[sp++] = sql_cmp_holds(bytes_compare(l.data + a, la, p.sdata + b, lb), (int)in.imm) ? 1 : 0;
+        break;
+      }
+      case BI_IN: {
+        const int64_t x = st[sp - 1];
+        const bool xu = (in.imm & 1) != 0;
+        bool hit = false;
+        for (int k = 0; k < in.b; k++) hit |= sql_order(x, xu, p.ints[in.a + k], false) == 0;
+        st[sp - 1] = (hit != ((in.imm & 2) != 0)) ? 1 : 0;
+        break;
+      }
+      case BI_SIN: {
+        const SqlLeaf l = p.leaves[in.a];
+        const uint32_t a = l.offsets[r], la = l.offsets[r + 1] - a;
+        const int cnt = (int)(in.imm & 0xFFFFFFFFll);
+        bool hit = false;
+        for (int k = 0; k < cnt; k++) { const uint32_t b = p.soff[in.b + k], lb = p.soff[in.b + k + 1] - b; hit |= la == lb && bytes_compare(l.data + a, la, p.sdata + b, lb) == 0; }
+        st[sp++] = (hit != ((in.imm >> 32) != 0)) ? 1 : 0;
+        break;
+      }
+    }
+  }
+  const int64_t v = sp > 0 ? st[sp - 1] : 0;
+  if (p.keep) { p.keep[r] = v != 0 ? 1u : 0u; return; }
+  switch (p.out_ty) {
+    case SQL_I8: case SQL_U8: ((uint8_t *)p.out)[r] = (uint8_t)v; break;
+    case SQL_I16: case SQL_U16: ((uint16_t *)p.out)[r] = (uint16_t)v; break;
+    case SQL_I32: case SQL_U32: ((uint32_t *)p.out)[r] = (uint32_t)v; break;
+    default: ((uint64_t *)p.out)[r] = (uint64_t)v;
+  }
+}
+__global__ void __launch_bounds__(256) sql_case_kernel(const uint8_t *in, uint8_t *out, uint64_t n, int upper) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t c = in[i];
+  out[i] = upper ? ((c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c) : ((c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c);  // ASCII only: lowerUTF8 / upperUTF8 are other functions
+}
+static int sql_repr_of(int ch);
+// the trees of one query over one batch: text nodes become columns, integer trees become programs
+struct SqlEval {
+  const tfgpu_plan &p; const std::vector<int> &ty; const tfgpu_dbatch &b; hipStream_t st;
+  std::vector<DColumn> keep_alive;
+  std::vector<SqlLeaf> leaves; std::vector<SqlIns> ins; std::vector<int64_t> ints; std::vector<uint32_t> soff{0}; std::string sdata;
+  int depth = 0, max_depth = 0;
+  const DColumn &column(const std::string &name) const {
+    for (auto &c : b.cols) if (c.name == name) return c;
+    throw Error(TFGPU_ERR_UNSUPPORTED, "sql: column " + name + " is in the TableSchema and not among the batch's ColumnNames");
+  }
+  DColumn text(int i) {
+    const SqlNode &n = p.sql_nodes[(size_t)i];
+    const int64_t rows = b.nrows;
+    switch (n.op) {
+      case SN_COL: {
+        const DColumn &c = column(n.s);
+        if (!(c.repr == TFGPU_R_STRING || c.repr == TFGPU_R_BYTES)) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: a text function over column " + n.s + ", which is not held as plain text (JSON values reach ClickHouse re-marshalled): host step");
+        return c;
+      }
+      case SN_STR: {
+        DColumn c; c.repr = TFGPU_R_STRING;
+        const uint64_t total = (uint64_t)n.s.size() * (uint64_t)rows;
+        if (total >> 32) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: a constant text column of more than 4 GiB");
+        Buf t = upload_small(n.s.data(), n.s.size());
+        c.offsets = dalloc((size_t)(rows + 1) * 4 + 16); c.data = dalloc(total + 8); c.data_len = total;
+        sql_const_text_kernel<<<grid_for(rows + 1, 256), 256, 0, st>>>(ptr<uint32_t>(c.offsets), ptr<uint8_t>(c.data), rows, ptr<uint8_t>(t), (uint32_t)n.s.size());
+        return c;
+      }
+      case SN_LOWER: case SN_UPPER: {
+        DColumn src = text(n.kids[0]);
+        DColumn c; c.repr = TFGPU_R_STRING; c.offsets = src.offsets; c.data_len = src.data_len;
+        c.data = dalloc((size_t)src.data_len + 8);
+        if (src.data_len) sql_case_kernel<<<grid_for((int64_t)src.data_len, 256), 256, 0, st>>>(ptr<uint8_t>(src.payload()), ptr<uint8_t>(c.data), src.data_len, n.op == SN_UPPER ? 1 : 0);
+        keep_alive.push_back(src);
+        return c;
+      }
+      case SN_TOSTR: {
+        if (ty[(size_t)n.kids[0]] == SQL_STRING) return text(n.kids[0]);
+        DColumn v = integer(n.kids[0]);
+        return column_to_string(v, rows, false, 24);
+      }
+      default: throw Error(TFGPU_ERR_INVALID, "sql: internal text node");
+    }
+  }
+  int text_leaf(int i) {
+    DColumn c = text(i);
+    SqlLeaf l{}; l.offsets = ptr<uint32_t>(c.offsets); l.data = ptr<uint8_t>(c.payload()); l.repr = c.repr;
+    keep_alive.push_back(std::move(c));
+    leaves.push_back(l);
+    return (int)leaves.size() - 1;
+  }
+  int literal(const std::string &s) { sdata += s; soff.push_back((uint32_t)sdata.size()); return (int)soff.size() - 2; }
+  void push() { if (++depth > max_depth) max_depth = depth; }
+  void emit(int i) {
+    const SqlNode &n = p.sql_nodes[(size_t)i];
+    const int t = ty[(size_t)i];
+    auto u64 = [&](int k) { return ty[(size_t)n.kids[(size_t)k]] == SQL_U64; };
+    switch (n.op) {
+      case SN_COL: {
+        const DColumn &c = column(n.s);
+        if (repr_is_var(c.repr) || c.repr == TFGPU_R_TIME || c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64 || !c.values) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: column " + n.s + " is not held as an integer");
+        SqlLeaf l{}; l.values = c.values->p; l.repr = c.repr;
+        leaves.push_back(l);
+        ins.push_back(SqlIns{BI_COL, t, (int32_t)leaves.size() - 1, 0, 0}); push();
+        break;
+      }
+      case SN_INT: ins.push_back(SqlIns{BI_IMM, t, 0, 0, n.ival}); push(); break;
+      case SN_ADD: case SN_SUB: case SN_MUL: emit(n.kids[0]); emit(n.kids[1]); ins.push_back(SqlIns{n.op == SN_ADD ? BI_ADD : n.op == SN_SUB ? BI_SUB : BI_MUL, t, 0, 0, 0}); depth--; break;
+      case SN_NEG: emit(n.kids[0]); ins.push_back(SqlIns{BI_NEG, t, 0, 0, 0}); break;
+      case SN_CAST: emit(n.kids[0]); ins.push_back(SqlIns{BI_WRAP, t, 0, 0, 0}); break;
+      case SN_LEN: ins.push_back(SqlIns{BI_LEN, t, text_leaf(n.kids[0]), 0, 0}); push(); break;
+      case SN_CITY64: ins.push_back(SqlIns{BI_CITY, t, text_leaf(n.kids[0]), 0, 0}); push(); break;
+      case SN_EQ: case SN_NE: case SN_LT: case SN_LE: case SN_GT: case SN_GE: {
+        int op = n.op - SN_EQ;
+        if (ty[(size_t)n.kids[0]] == SQL_STRING) {
+          const bool lit_left = p.sql_nodes[(size_t)n.kids[0]].op == SN_STR;
+          if (lit_left) { static const int mirror[6] = {0, 1, 4, 5, 2, 3}; op = mirror[op]; }  // 'a' < x  is  x > 'a'
+          const int leaf = text_leaf(n.kids[lit_left ? 1 : 0]);
+          ins.push_back(SqlIns{BI_SCMP, t, leaf, literal(p.sql_nodes[(size_t)n.kids[lit_left ? 0 : 1]].s), op}); push();
+        } else {
+          emit(n.kids[0]); emit(n.kids[1]);
+          ins.push_back(SqlIns{BI_CMP, t, op, (u64(0) ? 1 : 0) | (u64(1) ? 2 : 0), 0}); depth--;
+        }
+        break;
+      }
+      case SN_AND: case SN_OR: emit(n.kids[0]); emit(n.kids[1]); ins.push_back(SqlIns{n.op == SN_AND ? BI_AND : BI_OR, t, 0, 0, 0}); depth--; break;
+      case SN_NOT: emit(n.kids[0]); ins.push_back(SqlIns{BI_NOT, t, 0, 0, 0}); break;
+      case SN_IN: case SN_NOTIN: {
+        const bool neg = n.op == SN_NOTIN;
+        if (ty[(size_t)n.kids[0]] == SQL_STRING) {
+          const int leaf = text_leaf(n.kids[0]);
+          const int first = (int)soff.size() - 1;
+          for (size_t k = 1; k < n.kids.size(); k++) literal(p.sql_nodes[(size_t)n.kids[k]].s);
+          ins.push_back(SqlIns{BI_SIN, t, leaf, first, (int64_t)(n.kids.size() - 1) | ((int64_t)(neg ? 1 : 0) << 32)}); push();
+        } else {
+          emit(n.kids[0]);
+          const int first = (int)ints.size();
+          for (size_t k = 1; k < n.kids.size(); k++) ints.push_back(p.sql_nodes[(size_t)n.kids[k]].ival);
+          ins.push_back(SqlIns{BI_IN, t, first, (int32_t)n.kids.size() - 1, (int64_t)((u64(0) ? 1 : 0) | (neg ? 2 : 0))});
+        }
+        break;
+      }
+      default: throw Error(TFGPU_ERR_INVALID, "sql: internal integer node");
+    }
+  }
+  void run(int root, void *out, int out_ty, uint32_t *keep) {
+    leaves.clear(); ins.clear(); ints.clear(); soff.assign(1, 0u); sdata.clear(); depth = max_depth = 0;
+    emit(root);
+    if (max_depth > SQL_STACK) throw Error(TFGPU_ERR_UNSUPPORTED, "sql: an expression nests deeper than the device program's sixteen slots");
+    Buf bi = upload_small(ins.data(), ins.size() * sizeof(SqlIns)), bl = upload_small(leaves.data(), leaves.size() * sizeof(SqlLeaf));
+    Buf bn = upload_small(ints.data(), ints.size() * 8), bo = upload_small(soff.data(), soff.size() * 4), bd = upload_small(sdata.data(), sdata.size());
+    SqlProg g{};
+    g.ins = reinterpret_cast<const SqlIns *>(bi->p); g.nins = (int32_t)ins.size(); g.leaves = reinterpret_cast<const SqlLeaf *>(bl->p);
+    g.ints = ptr<int64_t>(bn); g.soff = ptr<uint32_t>(bo); g.sdata = ptr<uint8_t>(bd); g.n = b.nrows; g.out = out; g.out_ty = out_ty; g.keep = keep;
+    KernelTimer t("sql_expr");
+    if (b.nrows) sql_expr_kernel<<<grid_for(b.nrows, 256), 256, 0, st>>>(g);
+  }
+  DColumn integer(int root) {
+    DColumn c;
+    c.repr = sql_repr_of(ty[(size_t)root]);
+    c.values = dalloc((size_t)std::max<int64_t>(b.nrows, 1) * repr_width(c.repr));
+    run(root, c.values->p, ty[(size_t)root], nullptr);
+    return c;
+  }
+};
+
 static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_dbatch &in0, ApplyCtx &ax) {
   hipStream_t st = ctx().stream;
   // the input schema as ResultSchema sees it (clickhouse_local.go:351-421)
@@ -1223,7 +1502,15 @@ static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_
     }
   }
   // WHERE on every row event
-  std::unique_ptr<tfgpu_dbatch> kept = p.sql_has_where ? run_filter(p.exprs, true, false, *w, ax) : std::move(w);
+  std::vector<int> node_ty;
+  if (!p.sql_nodes.empty()) node_ty = sql_node_types(p, sc);
+  std::unique_ptr<tfgpu_dbatch> kept;
+  if (p.sql_where_root >= 0) {  // a WHERE that is a tree: one program, rows whose value is not zero stay
+    Buf keep = dalloc((size_t)(n0 + 1) * 4);
+    SqlEval ev{p, node_ty, *w, st};
+    ev.run(p.sql_where_root, nullptr, SQL_U8, ptr<uint32_t>(keep));
+    kept = compact(*w, keep);  // syncs
+  } else kept = p.sql_has_where ? run_filter(p.exprs, true, false, *w, ax) : std::move(w);
   const int64_t n = kept->nrows;
   // the select list
   auto out = std::make_unique<tfgpu_dbatch>();
@@ -1258,6 +1545,12 @@ static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_
         if (!src) { zeros = dalloc_zero((size_t)std::max<int64_t>(n, 1) * 8); ip.src = zeros->p; }
         KernelTimer t("sql_int_expr");
         if (n) sql_int_kernel<<<grid_for(n, 256), 256, 0, st>>>(ip);
+        break;
+      }
+      case SQL_EXPR: {
+        SqlEval ev{p, node_ty, *kept, st};
+        c = o.ch == SQL_STRING ? ev.text(o.root) : ev.integer(o.root);
+        if (o.ch == SQL_STRING) c.repr = TFGPU_R_STRING;
         break;
       }
       case SQL_CONST_STR: {
