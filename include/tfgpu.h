@@ -569,7 +569,11 @@ int tfgpu_csv_split_rows(const void *bytes, uint64_t len, int mem, tfgpu_dbuf **
 /* generic.AuxParserOpts (pkg/parsers/generic/generic_parser.go:40-77) as the "json" parser
  * registry fills them (pkg/parsers/registry/json/parser_json.go:62-86).  Options whose value
  * forms are not device-resident are rejected with TFGPU_ERR_UNSUPPORTED at call time
- * (unescape_string_values, unpack_bytes_base64, TimeField, TableSplitter, nested ColSchema.Path). */
+ * (unescape_string_values, unpack_bytes_base64, TimeField, TableSplitter).  A nested ColSchema.Path
+ * ("EventValue.LogInfo", "a/b/c": lookupComplex + parseJSON, pkg/parsers/generic/lookup.go:10-59) is
+ * walked on the device for string / null targets, the retries of parseJSON included; lines whose
+ * target is a number, bool or container, or whose member names are not plain ASCII, come back as
+ * TFGPU_ROW_HOST_FALLBACK; together with AddRest it is TFGPU_ERR_UNSUPPORTED.                        */
 typedef struct tfgpu_json_options {
   uint8_t add_rest;               /* AddRest: `_rest` column (any)                           */
   uint8_t add_dedupe_keys;        /* AddDedupeKeys: _timestamp,_partition,_offset,_idx       */
@@ -696,6 +700,19 @@ typedef struct tfgpu_serialize_options {
  * (marshal.go:82-125).  tfgpu_serialize == tfgpu_serialize_ex with NULL options.          */
 int tfgpu_serialize(int format, const tfgpu_dbatch *b, tfgpu_dbuf **out);
 int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out);
+/* batchSerializer as a component (pkg/serializer/batch.go:20-209; NewBatchSerializer, batch_factory.go:31-63): the
+ * BatchSerializerConfig, Serialize's parts of `threshold` items joined by the separator with ONE trailing separator trimmed
+ * (:84-116; the undivided path :75-82 trims nothing), SerializeAndWrite's ordered Write calls (:119-209).  The device
+ * serializes the batch at once — the joined parts are the batch's text — so the call adds the trim (for_writer == 0) or
+ * reports where each Write of the reference ends (for_writer != 0: part_ends[0 .. *nparts), byte offsets into *out; the shim
+ * replays writer.Write per part).  concurrency 0 = runtime.GOMAXPROCS(0), which the caller states in `gomaxprocs`;
+ * threshold 0 = DefaultBatchSerializerThreshold (25 000); disable_concurrency = one part, no strictifying wrapper (the
+ * StrictifyingSerializer of the concurrent form is tfgpu_strictify, called first by the shim).  Formats: RAW, JSON, CSV.   */
+typedef struct tfgpu_batch_serializer_config {
+  int32_t concurrency, threshold, disable_concurrency, gomaxprocs;
+} tfgpu_batch_serializer_config;
+int tfgpu_serialize_batch(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, const tfgpu_batch_serializer_config *cfg,
+                          int for_writer, tfgpu_dbuf **out, uint64_t *part_ends, int64_t part_cap, int64_t *nparts);
 int tfgpu_dbuf_size(const tfgpu_dbuf *b, uint64_t *out);
 void *tfgpu_dbuf_ptr(const tfgpu_dbuf *b); /* device pointer */
 int tfgpu_dbuf_download(const tfgpu_dbuf *b, void *host, uint64_t cap);

@@ -1,9 +1,8 @@
 /*
  * oracle/ora_lookup.c — lookupComplex (pkg/parsers/generic/lookup.go:10-59): a nested ColSchema.Path ("EventValue.LogInfo",
  * "EventValue/PlaceCoordinates/lat") walked through a top-level STRING value that holds JSON — parseJSON's json.Unmarshal
- * into map[string]interface{}, retried after its two textual un-escapings.  TEST INFRASTRUCTURE ONLY (see ora.h): the device
- * refuses nested paths (tfgpu_json_parse answers TFGPU_ERR_UNSUPPORTED); this restatement exists so that the generic-parser
- * canon cases `metrika` and `metrika_complex` pin the oracle.
+ * into map[string]interface{}, retried after its two textual un-escapings.  TEST INFRASTRUCTURE ONLY (see ora.h): the checker
+ * of the device's store_nested (tf_json.hip), pinned by the generic-parser canon cases `metrika` and `metrika_complex`.
  * Restated: targets that end at a JSON string or null, and every failure.  A number / bool / map / slice at the end is
  * reported as ORA_LOOKUP_OTHER (ParseVal of encoding/json's float64 and friends: not restated).
  */

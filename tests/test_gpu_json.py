@@ -122,13 +122,84 @@ def test_reference_parser_canon(tf, oracle, case):
     """tests/canon/parser {json, mdb} and pkg/parsers/generic canon inputs."""
     from transferia_amd import lib
     opts, fields, data, msgs = case_inputs(case)
-    if case["options"].get("unpack_bytes_base64") or case.get("nested_paths"):  # (nested ColSchema.Path: lookupComplex stays on the host)
+    if case["options"].get("unpack_bytes_base64"):
         with pytest.raises(lib.TfgpuError) as e:
             tf.json_parse(opts, fields, data, msgs)
         assert e.value.code == lib.ERR_UNSUPPORTED
         return
     # free-form datetime strings, float64 inside `any`, unknown keys under AddRest: host lines
     compare(tf, oracle, opts, fields, data, msgs, case["name"], max_fallback=len(case["rows"]))
+
+
+def test_lookup_complex_on_the_device(tf, oracle):
+    """Nested ColSchema.Path (lookupComplex + parseJSON, parsers/generic/lookup.go:10-59) in the per-line parser: what the device
+    decides it decides like the oracle (tests/test_json_oracle.py::test_lookup_complex_rules holds the same lines against the
+    reference's rules), the rest — a decoded string that differs from its bytes on the way, a retry that could change the text, a
+    number / bool / container at the end — is handed to the host and named so."""
+    fields = abi.Schema.of([["k", "int32", True], ["s", "utf8", False, "ev.a.b"], ["t", "utf8", False, "ev/c"], ["n", "int32", False, "ev.num"], ["q", "utf8", False, "ev.a.zz"]])
+    lines = [
+        b'k=1\tev={"a":{"b":"x"},"c":"y","num":"12"}',
+        b'k=2\tev={"a":"{\\"b\\":\\"inner\\"}","c":null}',           # a string that holds escaped JSON: the decoded string is not its bytes — host
+        b'k=3\tev={\\\\"a\\\\": {\\\\"b\\\\": \\\\"dbl\\\\"}, \\\\"c\\\\": \\\\"e\\\\"}',   # the retries rewrite backslashes — host
+        b'k=4\tev=not json', b'k=5\tev=null', b'k=6\tother=1',
+        b'k=7\tev={"a":{"b":5},"num":"zz"}',                        # a number at the end: host
+        b'k=8\tev={"a":{"b":"x"}} trailing',
+        b'k=9\tev={"a":{"b":"q\\"uote \\\\ \\/ \\n\\t end"},"c":"caf\xc3\xa9 \xe2\x82\xac","num":"-7"}',   # simple escapes, UTF-8
+        b'k=10\tev={"a":{"b":"one","b":"two"},"c":"","num":"0x1F"}',           # the last duplicate wins; strconv.ParseInt base prefixes
+        b'k=11\tev= {"a" : { "zz" : "far" , "b" : null } , "c" : "sp ace" }  ',
+        b'k=12\tev={"a":{"b":"\\u0041"},"c":"x"}',                            # a \\u escape at the end: host
+        b'k=13\tev={"a":{"b":"bad \xff utf8"},"c":"x"}',                     # U+FFFD replacement: host
+        b'k=14\tev={"a":[1,2],"c":"x"}',                                       # unexpected value type on the way: nil
+        b'k=15\tev={"a":{"b":"x"},"c":"y","num":"99999999999"}',                # ParseVal error behind lookupComplex: _unparsed
+        b'k=16\tev={"a":"{}","c":"y"}',                                         # a plain string on the way is parsed again: no such field
+        b'k=17\tev={"a":"[1]","c":"y"}', b'k=18\tev={"a":{"b":"x"},"c":"y",}', b'k=19\tev=[{"a":1}]', b'k=20\tev="str"', b'k=21\tev=',
+        b'k=22\tev={"a":{"b":"x"},"c":"y"}\tev={"a":{"b":"second"},"c":"wins"}',  # the last duplicate of the top-level key wins too
+        b'k=23\tev={"\\u0061":{"b":"x"},"c":"y"}',                             # a member name with an escape: host
+    ]
+    data, msgs = abi.messages([b"\n".join(lines)], [0], [0])
+    for nka in (False, True):
+        for fl in (fields, abi.Schema.of([["k", "int32", True], ["s", "utf8", False, "ev.a.b", "", True], ["t", "utf8", False, "ev/c"]])):
+            opts = abi.json_options(topic="t", format="tskv", null_keys_allowed=nka)
+            out, errs, nfb = compare(tf, oracle, opts, fl, data, msgs, "lookup nka=%s" % nka, max_fallback=3)
+            assert nfb == 3  # lines 7 (a number at the end), 13 (ill-formed UTF-8 to decode), 23 (an escaped member name)
+    # Format json: the top-level value must be a JSON string without escapes (the Go string is then its bytes)
+    jl = [b'{"k": 1, "ev": "{}"}', b'{"k": 2, "ev": "not json"}', b'{"k": 3, "ev": null}', b'{"k": 4}', b'{"k": 5, "ev": {"a": {"b": "x"}}}', b'{"k": 6, "ev": "{\\"a\\":{\\"b\\":\\"x\\"}}"}', b'{"k": 7, "ev": 12}',
+          b'{"k": 8, "ev": "[1, 2]"}', b'{"k": 9, "ev": "null"}']
+    data, msgs = abi.messages([b"\n".join(jl)], [0], [0])
+    out, errs, nfb = compare(tf, oracle, abi.json_options(topic="t"), fields, data, msgs, "lookup json", max_fallback=3)
+    assert nfb == 3  # lines 5, 6, 7
+
+
+def test_lookup_complex_random(tf, oracle):
+    """Random nested documents under a TSKV key: every line the device keeps agrees with the oracle, cell for cell."""
+    import json as pyjson
+    import random
+    rng = random.Random(SEED0 + 4242) if "SEED0" in globals() else random.Random(4242)
+    fields = abi.Schema.of([["k", "int32", True], ["s", "utf8", False, "ev.a.b"], ["t", "utf8", False, "ev/c"], ["n", "int64", False, "ev.a.num"], ["u", "any", False, "ev.d.e.f"]])
+    words = ["x", "", "long value with spaces", "caf\u00e9", "q\"uote", "back\\slash", "tab\there", "12", "-5", "0x10", "{}", "null", "a/b", "\u20ac"]
+
+    def leaf():
+        r = rng.random()
+        return rng.choice(words) if r < 0.6 else None if r < 0.7 else rng.randrange(-5, 5) if r < 0.8 else rng.choice([True, [1], {"z": 1}])
+
+    lines = []
+    for i in range(400):
+        doc = {}
+        if rng.random() < 0.9:
+            a = {}
+            if rng.random() < 0.8: a["b"] = leaf()
+            if rng.random() < 0.7: a["num"] = rng.choice(["1", "-2", "999999999999", "zz", 7, None])
+            if rng.random() < 0.2: a["b "] = "near miss"
+            doc["a"] = a if rng.random() < 0.9 else rng.choice(["str", 5, None, [a]])
+        if rng.random() < 0.8: doc["c"] = leaf()
+        if rng.random() < 0.5: doc["d"] = {"e": {"f": leaf()}} if rng.random() < 0.8 else {"e": leaf()}
+        text = pyjson.dumps(doc, ensure_ascii=rng.random() < 0.5, separators=rng.choice([(",", ":"), (", ", ": ")]))
+        if rng.random() < 0.05: text = text[:-1]
+        if rng.random() < 0.05: text += " x"
+        lines.append(("k=%d\tev=%s" % (i, text)).encode("utf-8"))
+    data, msgs = abi.messages([b"\n".join(lines)], [0], [0])
+    out, errs, nfb = compare(tf, oracle, abi.json_options(topic="t", format="tskv"), fields, data, msgs, "lookup random", max_fallback=400)
+    assert out.nrows > 100, (out.nrows, nfb)
 
 
 EDGE_FIELDS = [["i8", "int8"], ["u16", "uint16"], ["i64", "int64"], ["u64", "uint64"], ["d", "double"], ["b", "boolean"],

@@ -142,7 +142,7 @@ def test_any_and_rest_marshal_match_python_json(oracle):
 
 def test_lookup_complex_rules(oracle):
     """lookupComplex + parseJSON (parsers/generic/lookup.go:10-59) through makeChangeItem (generic_parser.go:323-347): the
-    nested-path columns of the metrika canon, as small cases.  Oracle only — the device refuses a nested ColSchema.Path."""
+    nested-path columns of the metrika canon, as small cases, against the reference's rules (the device runs the same lines against this oracle in tests/test_gpu_json.py::test_lookup_complex_on_the_device)."""
     # [name, type, key, path, original_type, required]
     fields = abi.Schema.of([["k", "int32", True], ["s", "utf8", False, "ev.a.b"], ["t", "utf8", False, "ev/c"], ["n", "int32", False, "ev.num"], ["q", "utf8", False, "ev.a.zz"]])
     opts = abi.json_options(topic="t", format="tskv")

@@ -292,6 +292,80 @@ def test_gpu_raw_matches_oracle(tf, oracle, n):
             assert tf.serialize(abi.FMT_RAW, tf.DeviceBatch.upload(b), _opts(o)).download() == ref
 
 
+def _batch_serializer_go(serialize_rows, n, sep, concurrency, threshold, disable, for_writer):
+    """pkg/serializer/batch.go restated over a per-slice serializer (rows [a, b) → the items joined by `sep`, none behind the last):
+    Serialize (:73-117) or the Write calls of SerializeAndWrite (:119-209)."""
+    if disable:
+        concurrency, threshold = 1, 0
+    else:
+        threshold = threshold or 25000
+    if concurrency < 2 or n <= threshold:
+        whole = serialize_rows(0, n)
+        return [whole] if for_writer else whole
+    parts = [serialize_rows(a, min(a + threshold, n)) for a in range(0, n, threshold)]
+    if for_writer:
+        return [p_ + (sep if i != len(parts) - 1 else b"") for i, p_ in enumerate(parts)]
+    joined = sep.join(parts)
+    return joined[: len(joined) - len(sep)] if sep and joined.endswith(sep) else joined
+
+
+@pytest.mark.gpu
+def test_gpu_batch_serializer_parts(tf, oracle):
+    """batchSerializer as a component (tfgpu_serialize_batch): parts of `threshold` items, the one trimmed separator of Serialize,
+    the Write calls of SerializeAndWrite — against batch.go restated over the oracle's serializers."""
+    from transferia_amd import queue
+    rng = np.random.default_rng(SEED0 + 4321)
+    b, schema = _random_batch(rng, 211)
+    datas = ["m%d" % i + ("\n" if i % 7 == 0 else "") for i in range(210)] + ["ends with the separator\n"]
+    mirror = _mirror_batch(datas, repr_bytes=True)
+    cases = [(abi.FMT_JSON, b, schema, {}), (abi.FMT_JSON, b, schema, {"add_closing_newline": True}), (abi.FMT_CSV, b, schema, {}),
+             (abi.FMT_RAW, mirror, queue.RAW_DATA_SCHEMA, {}), (abi.FMT_RAW, mirror, queue.RAW_DATA_SCHEMA, {"add_closing_newline": True})]
+    for fmt, bt, sch, o in cases:
+        db = tf.DeviceBatch.upload(bt)
+        sep = b"" if fmt == abi.FMT_CSV or o.get("add_closing_newline") else b"\n"
+
+        def rows(a, e, bt=bt, sch=sch, fmt=fmt, o=o):
+            if a >= e:
+                return b""
+            r = oracle.serialize(fmt, abi.slice_batch(bt, a, e) if hasattr(abi, "slice_batch") else _slice(bt, a, e), sch, _opts(o))
+            assert r is not None
+            return r
+        for conc, thr, dis in [(4, 16, False), (4, 211, False), (4, 210, False), (1, 16, False), (0, 50, False), (4, 16, True), (2, 1, False), (3, 100, False)]:
+            want = _batch_serializer_go(rows, bt.nrows, sep, conc or 8, thr, dis, False)
+            got = tf.serialize_batch(fmt, db, _opts(o), concurrency=conc, threshold=thr, disable_concurrency=dis, gomaxprocs=8).download()
+            assert got == want, (fmt, o, conc, thr, dis, len(got), len(want))
+            writes = _batch_serializer_go(rows, bt.nrows, sep, conc or 8, thr, dis, True)
+            buf, ends = tf.serialize_batch(fmt, db, _opts(o), concurrency=conc, threshold=thr, disable_concurrency=dis, gomaxprocs=8, for_writer=True)
+            text = buf.download()
+            assert text == b"".join(writes), (fmt, o, conc, thr, dis)
+            assert ends == list(np.cumsum([len(w) for w in writes])), (fmt, o, conc, thr, dis, ends[:4])
+
+
+def _slice(b, a, e):
+    import copy
+    out = copy.copy(b)
+    out.nrows = e - a
+    out.cols = []
+    for c in b.cols:
+        d = copy.copy(c)
+        if c.repr in abi.VAR_REPRS:
+            o0, o1 = int(c.offsets[a]), int(c.offsets[e])
+            d.offsets = (c.offsets[a:e + 1] - c.offsets[a]).astype(np.uint32)
+            d.data = c.data[o0:o1].copy() if o1 > o0 else np.zeros(1, np.uint8)
+        else:
+            d.values = c.values[a:e].copy()
+            if getattr(c, "nanos", None) is not None:
+                d.nanos = c.nanos[a:e].copy()
+        if getattr(c, "validity", None) is not None:
+            d.validity = c.validity[a:e].copy()
+        out.cols.append(d)
+    for k in ("kind", "src_row", "part_id"):
+        v = getattr(b, k, None)
+        if v is not None:
+            setattr(out, k, v[a:e].copy())
+    return out
+
+
 @pytest.mark.gpu
 def test_gpu_raw_refusals(tf):
     with pytest.raises(tf.TfgpuError):  # GetRawMessageData: unexpected data type <nil>

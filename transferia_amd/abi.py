@@ -167,6 +167,10 @@ class CSerializeOptions(C.Structure):
                 ("ch_flags", C.POINTER(C.c_uint32)), ("ch_precision", C.POINTER(C.c_uint8))]
 
 
+class CBatchSerializerConfig(C.Structure):
+    _fields_ = [("concurrency", C.c_int32), ("threshold", C.c_int32), ("disable_concurrency", C.c_int32), ("gomaxprocs", C.c_int32)]
+
+
 CH_STRING, CH_DATE, CH_DATETIME64, CH_DECIMAL, CH_ARRAY = 1, 2, 4, 8, 16
 
 

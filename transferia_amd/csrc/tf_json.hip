@@ -39,6 +39,7 @@
 #include "tf_swar.hpp"
 #include "tf_jsontile.hpp"
 #include "tf_jsonquick.hpp"
+#include "tf_jsonscan.hpp"  // encoding/json's grammar: what lookupComplex's json.Unmarshal accepts
 
 namespace tf {
 
@@ -46,7 +47,7 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 uint32_t newline_starts(const uint8_t *data, uint64_t len, Buf *out);           // tf_csv.hip
 
 enum JKind : int32_t { JK_INT, JK_UINT, JK_F64, JK_BOOL, JK_TEXT, JK_ANY, JK_DATETIME };
-enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4, JM_TSKV = 5, JM_ANYCANON = 6, JM_REST = 7, JM_REST_EMPTY = 8 };
+enum JMode : uint32_t { JM_COPY = 0, JM_UNESCAPE = 1, JM_QUOTED = 2, JM_COMPACT = 3, JM_FLOAT = 4, JM_TSKV = 5, JM_ANYCANON = 6, JM_REST = 7, JM_REST_EMPTY = 8, JM_SCRATCH = 9 /* a byte range of JParams::scratch (lookupComplex) */ };
 enum JLineSt : uint8_t { JL_ROW = 0, JL_SKIPPED = 1, JL_SYNTAX = 2, JL_FALLBACK = 3 };
 enum JCellSt : uint8_t { JC_NIL = 0, JC_OK = 1, JC_ERR = 2 };
 enum JVal : int32_t { V_NULL, V_STR, V_NUM, V_TRUE, V_FALSE, V_OBJ, V_ARR };
@@ -62,7 +63,9 @@ struct JCol {
   uint32_t *fstart; // text: absolute offset of the source bytes
   uint32_t *meta;   // text: source length | JMode << 28
   uint8_t *cellst;  // JCellSt per line
+  uint32_t npath_off, npath_n;  // a nested ColSchema.Path (lookupComplex): npath_n field names behind the top-level key, at names + npath_off as (u16 length, bytes) …
 };
+static constexpr uint32_t JCOL_NESTED = 0x10000u;  // JCol.flags: the column reads through lookupComplex (its ParseVal errors follow generic_parser.go:338-346)
 
 // open-addressing table over the top-level keys the parser knows: ColPath (or ColumnName) → column
 struct JSlot { uint32_t hash; int32_t col; uint32_t soff, slen; uint32_t aux; };  // slen == ~0u: empty; aux: the key is an aux column's name
@@ -83,6 +86,7 @@ struct JParams {
   uint32_t *rest_lens, *rest_fstart, *rest_meta;  // `_rest` column (AddRest): text cell per line, null without it
   uint8_t format;        // TFGPU_JFMT_*
   uint8_t tskv_unescape; // Format tskv + UnescapeStringValues: tryToUnescapeTSKV on the values
+  uint8_t *scratch;      // as large as the input, only with nested ColSchema.Paths: where lookupComplex's rewritten / decoded texts are built
 };
 
 __device__ __forceinline__ uint32_t fnv1a(uint32_t h, uint32_t c) { return (h ^ c) * 16777619u; }
@@ -557,7 +561,7 @@ __device__ __forceinline__ void jtext(const JCol &c, int64_t r, uint64_t src, ui
 // 1 stored, 0 the value form is the host's, 2 (HEAVY == false only) the cell needs the map emitter: the line is re-parsed
 // by json_parse_listed, whose kernel carries it — the kernel every line runs through stays lean.
 template <bool HEAVY>
-__device__ int store_cell(const JParams &p, const JCol &c, const int64_t r, MemBytes &aux, const int vtype, const uint64_t vstart,
+__device__ int store_cell_plain(const JParams &p, const JCol &c, const int64_t r, MemBytes &aux, const int vtype, const uint64_t vstart,
                            const uint64_t vend, const JStr &sv, const uint32_t clen, const bool kbad) {
   uint8_t st = JC_OK;
   const Field tok{&aux, vstart, (uint32_t)(vend - vstart)};  // raw token of numbers / literals / containers
@@ -671,6 +675,174 @@ __device__ int store_cell(const JParams &p, const JCol &c, const int64_t r, MemB
   }
   c.cellst[r] = st;
   return true;
+}
+
+// ---------------------------------------------------------------------------
+// lookupComplex (pkg/parsers/generic/lookup.go:10-59; generic_parser.go:323-347): a column whose ColSchema.Path has '.' or '/'
+// reads item[first name] — which must be a Go STRING holding JSON — json.Unmarshal's it into a map, takes the next name, and so
+// on; a string on the way is parsed again, a map is walked.  parseJSON tries the text as it is, then with every `\\"` turned
+// into `\"` ("possible double escape": what the metrika logs need), then without any backslash.  The rewritten texts and the
+// decoded strings are built in a scratch copy of the input (JParams::scratch, same offsets: none of them is longer than what it
+// is made from), so every step reads plain memory through the encoding/json scanner (tf_jsonscan.hpp).
+// Decided here: every outcome whose target is a string or null, or an error.  Handed to the host: a member name that is not plain
+// ASCII (compared after decoding), ill-formed UTF-8 inside a string that must be decoded (U+FFFD grows it), a number / bool /
+// container at the end of the path (ParseVal of encoding/json's float64: not restated by the oracle either), nesting beyond 128.
+// 1 stored (a value, nil or a ParseVal error), 0 host.
+// ---------------------------------------------------------------------------
+struct NText { bool scr; uint32_t s, e; };
+// every byte >= 0x80 of [s, e) sits in a well-formed UTF-8 sequence (utf8.DecodeRune's ranges): decoding never grows the text
+__device__ bool nested_utf8_ok(MemBytes &rd, uint32_t s, uint32_t e) {
+  for (uint32_t i = s; i < e;) {
+    const uint32_t c = rd.at(i);
+    if (c < 0x80) { i++; continue; }
+    uint32_t need = 0, lo = 0x80, hi = 0xBF;
+    if (c >= 0xC2 && c <= 0xDF) need = 1;
+    else if (c >= 0xE0 && c <= 0xEF) { need = 2; if (c == 0xE0) lo = 0xA0; if (c == 0xED) hi = 0x9F; }
+    else if (c >= 0xF0 && c <= 0xF4) { need = 3; if (c == 0xF0) lo = 0x90; if (c == 0xF4) hi = 0x8F; }
+    if (!need || e - i <= need) return false;
+    for (uint32_t k = 1; k <= need; k++) { const uint32_t d = rd.at(i + k); if (d < (k == 1 ? lo : 0x80u) || d > (k == 1 ? hi : 0xBFu)) return false; }
+    i += need + 1;
+  }
+  return true;
+}
+// json.Unmarshal(text, &map[string]interface{}): 1 = the text is one valid value and an object (at *at), 0 = it is not (invalid, or
+// another kind of value: no map), -1 = nesting beyond what the scanner walks
+__device__ int nested_try(MemBytes &rd, uint32_t s, uint32_t e, uint32_t *at) {
+  uint32_t pos = s;
+  while (pos < e && sr::is_ws(rd.at(pos))) pos++;
+  if (pos >= e) return 0;
+  const bool object = rd.at(pos) == '{';
+  uint32_t q = pos, vt = 0;
+  const int rc = sr::skip_value(rd, q, e, vt);
+  if (rc == 2) return -1;
+  if (rc != 0) return 0;
+  while (q < e && sr::is_ws(rd.at(q))) q++;
+  if (q != e || !object) return 0;
+  *at = pos;
+  return 1;
+}
+// parseJSON (lookup.go:41-59).  1 = t holds a text whose value is an object at *at, 2 = error (no map), 0 = host
+__device__ int nested_parse(const JParams &p, NText &t, uint32_t *at) {
+  {
+    MemBytes rd(t.scr ? p.scratch : p.data);
+    const int r = nested_try(rd, t.s, t.e, at);
+    if (r) return r < 0 ? 0 : 1;
+    bool bs = false;
+    for (uint32_t i = t.s; i < t.e && !bs; i++) bs = rd.at(i) == '\\';
+    if (!bs) return 2;  // the retries would try the same text
+  }
+  {  // strings.ReplaceAll(s, `\\"`, `\"`): left to right, non-overlapping
+    MemBytes rd(t.scr ? p.scratch : p.data);
+    sr::ByteSink o{p.scratch + t.s};
+    uint32_t n = 0;
+    for (uint32_t i = t.s; i < t.e;) {
+      if (t.e - i >= 3 && rd.at(i) == '\\' && rd.at(i + 1) == '\\' && rd.at(i + 2) == '"') { o.put('\\'); o.put('"'); n += 2; i += 3; }
+      else { o.put(rd.at(i)); n++; i++; }
+    }
+    o.flush();
+    t.scr = true; t.e = t.s + n;
+  }
+  {
+    MemBytes rd(p.scratch);
+    const int r = nested_try(rd, t.s, t.e, at);
+    if (r) return r < 0 ? 0 : 1;
+  }
+  {  // strings.ReplaceAll(s, `\`, ``)
+    MemBytes rd(p.scratch);
+    sr::ByteSink o{p.scratch + t.s};
+    uint32_t n = 0;
+    for (uint32_t i = t.s; i < t.e; i++) { const uint32_t c = rd.at(i); if (c != '\\') { o.put(c); n++; } }
+    o.flush();
+    t.e = t.s + n;
+  }
+  MemBytes rd(p.scratch);
+  const int r = nested_try(rd, t.s, t.e, at);
+  return r < 0 ? 0 : r ? 1 : 2;
+}
+// the Go string of the JSON string token [fs, fe) of text t (decode.go unquote) → t2; false: host
+__device__ bool nested_decode(const JParams &p, const NText &t, uint32_t fs, uint32_t fe, bool plain, NText &t2) {
+  if (plain && !t.scr) { t2 = NText{false, fs + 1, fe - 1}; return true; }  // its bytes, where they lie
+  MemBytes rd(t.scr ? p.scratch : p.data);
+  if (!plain && !nested_utf8_ok(rd, fs + 1, fe - 1)) return false;
+  sr::ByteSink o{p.scratch + fs + 1};
+  sr::CountSink cnt;
+  sr::emit_unquoted(cnt, rd, fs, fe - fs);
+  MemBytes rd2(t.scr ? p.scratch : p.data);
+  sr::emit_unquoted(o, rd2, fs, fe - fs);  // (in place when t is the scratch: every rune leaves at most the bytes it took)
+  o.flush();
+  t2 = NText{true, fs + 1, fs + 1 + cnt.n};
+  return true;
+}
+__device__ int store_nested(const JParams &p, const JCol &c, const int64_t r, const int vtype, const JStr &sv) {
+  auto nil = [&]() { if (c.kind == JK_TEXT || c.kind == JK_ANY) c.lens[r] = 0; c.cellst[r] = JC_NIL; return 1; };  // "lookupComplex error" / nil: json_finish applies the key / required rule
+  if (vtype == V_NULL) return nil();  // unexpected value type: <nil>
+  if (vtype != V_STR || sv.bs || !p.scratch) return 0;
+  if ((sv.s + sv.n) >> 32) return 0;
+  NText t{false, (uint32_t)sv.s, (uint32_t)(sv.s + sv.n)};  // the Go string lookupComplex holds: parsed when a name is taken from it
+  bool is_obj = false;                                       // … or an object of an already validated text: walked
+  uint32_t at = 0;
+  const uint8_t *seg = p.names + c.npath_off;
+  for (uint32_t k = 0; k < c.npath_n; k++) {
+    const uint32_t sl = (uint32_t)seg[0] | ((uint32_t)seg[1] << 8);
+    const uint8_t *name = seg + 2;
+    seg += 2 + sl;
+    if (!is_obj) { const int pr = nested_parse(p, t, &at); if (pr == 0) return 0; if (pr == 2) return nil(); }  // unable to parse json / a nil map: unable to get field
+    else at = t.s;
+    // members of the object at `at`: the LAST member with this name wins (a Go map)
+    MemBytes rd(t.scr ? p.scratch : p.data);
+    uint32_t fs = 0, fe = 0, ft = sr::VT_ABSENT;
+    uint32_t pos = at + 1;
+    for (;;) {
+      while (pos < t.e && sr::is_ws(rd.at(pos))) pos++;
+      if (pos >= t.e) return 0;  // (cannot happen in validated text)
+      if (rd.at(pos) == '}') break;
+      if (rd.at(pos) == ',') { pos++; continue; }
+      const uint32_t ks = pos + 1;
+      bool kplain = false;
+      if (rd.at(pos) != '"' || !sr::scan_string(rd, pos, t.e, &kplain)) return 0;
+      if (!kplain) return 0;  // compared after decoding: host
+      const uint32_t kn = pos - 1 - ks;
+      bool same = kn == sl;
+      for (uint32_t i = 0; i < kn && same; i++) same = rd.at(ks + i) == name[i];
+      while (pos < t.e && sr::is_ws(rd.at(pos))) pos++;
+      if (pos >= t.e || rd.at(pos) != ':') return 0;
+      pos++;
+      while (pos < t.e && sr::is_ws(rd.at(pos))) pos++;
+      const uint32_t vs0 = pos;
+      uint32_t vt = 0;
+      if (sr::skip_value(rd, pos, t.e, vt) != 0) return 0;
+      if (same) { fs = vs0; fe = pos; ft = vt; }
+    }
+    if (ft == sr::VT_ABSENT) return nil();  // unable to get field
+    const uint32_t vk = ft & sr::VT_MASK;
+    const bool last = k + 1 == c.npath_n;
+    if (vk == sr::VT_STR) {
+      NText t2;
+      if (!nested_decode(p, t, fs, fe, (ft & sr::VT_PLAIN) != 0, t2)) return 0;
+      if (!last) { t = t2; is_obj = false; continue; }
+      // ParseVal(the string, DataType)
+      if (c.kind == JK_TEXT) {
+        jtext(c, r, t2.s, t2.e - t2.s, t2.scr ? JM_SCRATCH : JM_COPY, t2.e - t2.s);
+        c.cellst[r] = JC_OK;
+        return 1;
+      }
+      if (c.kind == JK_ANY && t2.scr) return 0;  // (its text cell would be cut from the input)
+      MemBytes rv(t2.scr ? p.scratch : p.data);
+      JStr v{};
+      v.s = t2.s; v.n = t2.e - t2.s; v.hash = 0; v.ctrl = false; v.bs = false; v.plain = !t2.scr;
+      return store_cell_plain<false>(p, c, r, rv, V_STR, (uint64_t)t2.s, (uint64_t)t2.e, v, 0, false) == 1 ? 1 : 0;
+    }
+    if (last) return vk == sr::VT_NULL ? nil() : 0;  // nil; or ParseVal of float64 / bool / map / slice: host
+    if (vk == sr::VT_OBJ) { t = NText{t.scr, fs, fe}; is_obj = true; continue; }
+    return nil();  // unexpected value type
+  }
+  return 0;
+}
+template <bool HEAVY>
+__device__ __forceinline__ int store_cell(const JParams &p, const JCol &c, const int64_t r, MemBytes &aux, const int vtype, const uint64_t vstart,
+                                          const uint64_t vend, const JStr &sv, const uint32_t clen, const bool kbad) {
+  if (c.npath_n) return store_nested(p, c, r, vtype, sv);
+  return store_cell_plain<HEAVY>(p, c, r, aux, vtype, vstart, vend, sv, clen, kbad);
 }
 
 // ---------------------------------------------------------------------------
@@ -1589,7 +1761,8 @@ __global__ void __launch_bounds__(256) json_finish(JFinish p) {
     for (int32_t c = 0; c < p.ncols; c++) {
       const uint8_t cs = p.cols[c].cellst[r];
       const bool key = p.cols[c].flags & TFGPU_COL_KEY, req = p.cols[c].flags & TFGPU_COL_REQUIRED;
-      if (cs == JC_ERR) { if ((!p.null_keys_allowed && key) || req) { code = TFGPU_ROW_PARSE_VAL; ecol = c; break; } }
+      const bool nested = p.cols[c].flags & JCOL_NESTED;  // a ParseVal error behind lookupComplex: _unparsed whatever the column's flags (generic_parser.go:338-343)
+      if (cs == JC_ERR) { if (nested ? !p.null_keys_allowed : ((!p.null_keys_allowed && key) || req)) { code = TFGPU_ROW_PARSE_VAL; ecol = c; break; } }
       else if (cs == JC_NIL && (key || req) && !p.null_keys_allowed) { code = TFGPU_ROW_NIL_KEY; ecol = c; break; }
     }
   }
@@ -1672,6 +1845,7 @@ __global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCo
   if (mode == JM_COMPACT) { StoreSink sk{dst}; compact_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_TSKV) { StoreSink sk{dst}; tskv_walk(rd, s, srclen, sk); sk.finish(); return; }
   if (mode == JM_REST_EMPTY) { dst[0] = '{'; dst[1] = '}'; return; }
+  if (mode == JM_SCRATCH) { MemBytes rs(jp.scratch); StoreSink sk{dst}; for (uint32_t i = 0; i < srclen; i++) sk.put(rs.at(s + i)); sk.finish(); return; }
   if (mode == JM_FLOAT) {  // the number token again, as encoding/json prints the float64 it parses to
     const Field tok{&rd, s, srclen};
     double v = 0;
@@ -1805,16 +1979,29 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   // ---- column plan ----
   std::vector<JCol> cols((size_t)nraw);
   std::vector<std::string> lookup((size_t)nraw);
+  std::vector<std::pair<int, std::string>> nested_blobs;  // (column, its path names behind the first)
   for (int i = 0; i < nraw; i++) {
     const tfgpu_colschema &sc = fields->cols[i];
     const std::string name = sc.name ? sc.name : "", path = (sc.path && sc.path[0]) ? sc.path : name;
     const std::string &key = path;  // makeChangeItem reads item[key.ColPath()] (:351); IgnoreColumnPaths only re-keys colTypeMap / known
-    if (key.find('.') != std::string::npos || key.find('/') != std::string::npos)
-      return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: column " + name + ": nested ColSchema.Path (lookupComplex) is not device-resident");
     lookup[(size_t)i] = key;
     JCol &c = cols[(size_t)i];
     std::memset(&c, 0, sizeof c);
     c.flags = sc.flags; c.next = -1;
+    if (key.find('.') != std::string::npos || key.find('/') != std::string::npos) {
+      // IsNestedKey (col_schema.go:95-97) → lookupComplex: strings.Split(path, "."), or by "/" when that gives one part (lookup.go:11-14)
+      const char sep = key.find('.') != std::string::npos ? '.' : '/';
+      std::vector<std::string> segs;
+      for (size_t a = 0;;) { const size_t b = key.find(sep, a); segs.push_back(key.substr(a, b == std::string::npos ? std::string::npos : b - a)); if (b == std::string::npos) break; a = b + 1; }
+      if (segs.size() > 16) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: column " + name + ": a nested ColSchema.Path of more than 16 names");
+      if (opts->add_rest) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: column " + name + ": a nested ColSchema.Path together with AddRest (the top-level member is not a known name: it belongs to _rest)");
+      lookup[(size_t)i] = segs[0];
+      std::string blob;
+      for (size_t k = 1; k < segs.size(); k++) { if (segs[k].size() > 0xFFFF) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: nested path name too long"); blob += (char)(segs[k].size() & 0xFF); blob += (char)(segs[k].size() >> 8); blob += segs[k]; }
+      nested_blobs.push_back({i, blob});
+      c.npath_n = (uint32_t)segs.size() - 1;
+      c.flags |= JCOL_NESTED;
+    }
     switch (sc.dtype) {
       case TFGPU_T_INT8: c.kind = JK_INT; c.width = 1; break;
       case TFGPU_T_INT16: c.kind = JK_INT; c.width = 2; break;
@@ -1847,6 +2034,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     }
     for (auto &a : aux) put(a.name, a.dtype);
     for (int i = 0; i < nraw; i++) {
+      if (cols[(size_t)i].npath_n) continue;  // reads a Go string whatever colTypeMap says of its first name (anything else: host)
       int t = TFGPU_T_INVALID;
       for (auto &e : col_type) if (e.first == lookup[(size_t)i]) t = e.second;
       if (t != fields->cols[i].dtype)
@@ -1887,6 +2075,10 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     names += e.first;
     names.append((8 - names.size() % 8) % 8, '\0');  // whole 8-byte words: the device compares a word at a time
   }
+
+  for (auto &nb : nested_blobs) { cols[(size_t)nb.first].npath_off = (uint32_t)names.size(); names += nb.second; }
+  names.append((8 - names.size() % 8) % 8 + 8, '\0');
+  const bool any_nested = !nested_blobs.empty();
 
   // ---- input in HBM ----
   Buf staged;
@@ -2005,6 +2197,8 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   pp.pow10 = pow10_table(); pp.pow128 = reinterpret_cast<const uint64_t *>(pp.pow10 + 632); pp.linest = ptr<uint8_t>(linest); pp.line_pos = ptr<uint32_t>(line_pos);
   pp.add_rest = opts->add_rest; pp.use_numbers = opts->use_numbers_in_any;
   pp.format = opts->format; pp.tskv_unescape = tskv && opts->unescape_string_values;
+  Buf scratch;
+  if (any_nested) { scratch = dalloc_zero(len + 64); pp.scratch = ptr<uint8_t>(scratch); }
   if (rest_seg >= 0) {
     pp.rest_lens = ptr<uint32_t>(lens_all) + (int64_t)rest_seg * seg_stride;
     pp.rest_fstart = ptr<uint32_t>(fstart_all) + (int64_t)rest_seg * 2 * nalloc;
@@ -2019,7 +2213,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   static const bool wavepath = [] { const char *e = std::getenv("TFGPU_JSON_WAVEPATH"); return e && e[0] == '1'; }();
   // The tile path (default for Format json; TFGPU_JSON_TILES=0 for A/B runs): lines staged in LDS, cells by value kind.
   static const bool tilepath = [] { const char *e = std::getenv("TFGPU_JSON_TILES"); return !(e && e[0] == '0'); }();
-  if (nlines && tilepath && !tskv && !wavepath) {
+  if (nlines && tilepath && !tskv && !wavepath && !any_nested) {  // (lookupComplex lives in the per-line parser)
     const uint64_t avg = std::max<uint64_t>(len / (uint64_t)std::max<int64_t>(nseg, 1), 1);
     const int32_t per_tile = (int32_t)std::min<uint64_t>(std::max<uint64_t>((uint64_t)(JT_BYTES - 16) * 8 / (avg * 9), 1), (uint64_t)JT_LINES);
     Buf slow = dalloc((size_t)(nseg + 1) * 4), heavy = dalloc((size_t)(nseg + 1) * 4);
@@ -2052,7 +2246,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
       std::fprintf(stderr, "[tfgpu] json tiles: %lld lines, %d per tile, %u to the per-line parser, %u of them to the map emitter\n", (long long)nseg, (int)used_per_tile, *a, *b);
     }
   }
-  else if (nlines && (!wavepath || tskv)) {
+  else if (nlines && (!wavepath || tskv || any_nested)) {
     Buf slow = dalloc((size_t)(nseg + 1) * 4);  // lines that need the map emitter: re-parsed by the kernel that carries it
     TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
     { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }

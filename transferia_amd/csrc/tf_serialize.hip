@@ -765,6 +765,8 @@ __global__ void __launch_bounds__(256) ser_raw_newlines(const uint32_t *out_off,
   if (r < n && (uint64_t)out_off[r + 1] - 1 < total) out[out_off[r + 1] - 1] = '\n';
 }
 }  // namespace tf
+// tfgpu_serialize_batch asks the serializers for where each row's text starts (a device array of nrows + 1 offsets)
+static thread_local tf::Buf *g_row_offsets_out = nullptr;
 static int serialize_raw(const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out) {
   static const char *const MIRROR[] = {"topic", "partition", "seq_no", "write_time", "data", "meta", "sequence_key"};  // changeitem.RawDataColumns (mirror.go:10-33)
   bool mirror = b->cols.size() == 7;
@@ -795,6 +797,7 @@ static int serialize_raw(const tfgpu_dbatch *b, const tfgpu_serialize_options *o
     SegRawParams rp{ptr<uint32_t>(d.offsets), ptr<uint8_t>(d.payload()), ptr<uint32_t>(ooff), ptr<uint8_t>(res->mem), n};
     { KernelTimer t("ser_raw"); ser_raw_copy<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(rp); }
     ser_raw_newlines<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(ptr<uint32_t>(ooff), n, total, ptr<uint8_t>(res->mem));
+    if (g_row_offsets_out) *g_row_offsets_out = ooff;
   }
   tf::sync();
   *out = res.release();
@@ -940,8 +943,8 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
         else ser_chunk_layout<TFGPU_FMT_CSV><<<blocks(n), 256, 0, st>>>(p, cp);
       }
     }
-    exclusive_scan_u32(p.row_len, p.row_len, n, true);
-    const uint32_t *htot = d2h_u32(p.row_len + n);
+        exclusive_scan_u32(p.row_len, p.row_len, n, true);
+    if (g_row_offsets_out) *g_row_offsets_out = row_len; const uint32_t *htot = d2h_u32(p.row_len + n);
     const uint32_t *h64 = d2h_u32(tot64->p, 2);
     tf::sync();
     // a uint32 offset space: batches whose text exceeds 4 GiB must be split by rows (batch.go chunks at 25 000 rows)
@@ -967,6 +970,67 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
 }
 
 extern "C" int tfgpu_serialize(int format, const tfgpu_dbatch *b, tfgpu_dbuf **out) { return tfgpu_serialize_ex(format, b, nullptr, out); }
+
+// batchSerializer (pkg/serializer/batch.go): Serialize (:73-117) cuts batches above the threshold into parts of `threshold`
+// items, serializes them side by side and joins them with the separator — the text of the whole batch — then trims ONE
+// trailing separator (bytes.TrimSuffix, :112-114), which the undivided path (:75-82) does not; SerializeAndWrite (:119-209)
+// writes the parts in order, each but the last followed by the separator, and trims nothing.  The device serializes the
+// batch at once; what this call adds is exactly those two differences: the trim, and where the reference's Write calls end.
+extern "C" int tfgpu_serialize_batch(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, const tfgpu_batch_serializer_config *cfg,
+                                     int for_writer, tfgpu_dbuf **out, uint64_t *part_ends, int64_t part_cap, int64_t *nparts) {
+  try {
+    if (!b || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize_batch: null argument");
+    if (format != TFGPU_FMT_JSON && format != TFGPU_FMT_CSV && format != TFGPU_FMT_RAW)
+      return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize_batch: the batch serializers are raw, json and csv (batch_factory.go:31-63)");
+    // newBatchSerializer (:37-71)
+    int64_t concurrency = 1, threshold = 0;
+    if (!(cfg && cfg->disable_concurrency)) {
+      concurrency = cfg && cfg->concurrency ? cfg->concurrency : (cfg && cfg->gomaxprocs > 0 ? cfg->gomaxprocs : 1);  // runtime.GOMAXPROCS(0) is the caller's
+      threshold = cfg && cfg->threshold ? cfg->threshold : 25000;                                                        // DefaultBatchSerializerThreshold
+    }
+    const int64_t n = b->nrows;
+    const bool parts = concurrency >= 2 && n > threshold;
+    const bool sep = format != TFGPU_FMT_CSV && !(opts && opts->add_closing_newline);  // "\n" (batch_factory.go:36-39); the csv serializer has none (:54-58)
+    tf::Buf row_off;
+    g_row_offsets_out = (parts && for_writer) ? &row_off : nullptr;
+    tfgpu_dbuf *text = nullptr;
+    const int rc = tfgpu_serialize_ex(format, b, opts, &text);
+    g_row_offsets_out = nullptr;
+    if (rc != TFGPU_OK) return rc;
+    std::unique_ptr<tfgpu_dbuf> res(text);
+    int64_t np = 1;
+    if (parts && !for_writer && sep && res->size) {  // bytes.TrimSuffix(joined, separator)
+      tf::Context &cx = tf::ctx();
+      std::lock_guard<std::mutex> lk(cx.mu);
+      uint8_t last = 0;
+      tf::d2h(&last, (const uint8_t *)res->mem->p + res->size - 1, 1);
+      tf::sync();
+      if (last == '\n') res->size--;
+    }
+    if (for_writer) {
+      np = parts ? (n + threshold - 1) / threshold : 1;  // the Write calls: one per part, or one for the undivided batch
+      if (part_ends) {
+        if (np > part_cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize_batch: part_ends is too small");
+        if (!parts) part_ends[0] = res->size;
+        else {
+          tf::Context &cx = tf::ctx();
+          std::lock_guard<std::mutex> lk(cx.mu);
+          std::vector<uint32_t> at((size_t)np);
+          // part i ends where row (i + 1) * threshold starts: its text, then the separator in front of the next part
+          for (int64_t i = 0; i + 1 < np; i++) tf::d2h(&at[(size_t)i], (const uint32_t *)row_off->p + (i + 1) * threshold, 4);
+          tf::sync();
+          for (int64_t i = 0; i + 1 < np; i++) part_ends[i] = at[(size_t)i];
+          part_ends[np - 1] = res->size;
+        }
+      }
+    }
+    if (nparts) *nparts = np;
+    *out = res.release();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { g_row_offsets_out = nullptr; return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { g_row_offsets_out = nullptr; return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::exception &e) { g_row_offsets_out = nullptr; return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
 
 // ======================================================================================================
 // tfgpu_queue_serialize — pkg/serializer/queue: NativeSerializer / JSONSerializer for one table's rows.

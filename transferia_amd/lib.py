@@ -29,7 +29,7 @@ EXPORTS = [
     "tfgpu_plan_description", "tfgpu_plan_suitable", "tfgpu_plan_result_schema", "tfgpu_schema_free", "tfgpu_registry_count",
     "tfgpu_registry_name", "tfgpu_batch_upload", "tfgpu_dbatch_view", "tfgpu_dbatch_download", "tfgpu_dbatch_free",
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_from_config", "tfgpu_transformation_size", "tfgpu_transformation_plan_type", "tfgpu_transformation_errors_output", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
-    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_sr_compile_schema", "tfgpu_sr_schema_info", "tfgpu_sr_schema_free", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_debezium_compile_schema", "tfgpu_dbz_schema_info", "tfgpu_dbz_schema_free", "tfgpu_dbz_receiver_create", "tfgpu_dbz_receiver_destroy", "tfgpu_dbz_receiver_known", "tfgpu_dbz_receive", "tfgpu_dbz_receive_group", "tfgpu_dbz_receive_group_meta", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_debezium_emit", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
+    "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_sr_compile_schema", "tfgpu_sr_schema_info", "tfgpu_sr_schema_free", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_debezium_compile_schema", "tfgpu_dbz_schema_info", "tfgpu_dbz_schema_free", "tfgpu_dbz_receiver_create", "tfgpu_dbz_receiver_destroy", "tfgpu_dbz_receiver_known", "tfgpu_dbz_receive", "tfgpu_dbz_receive_group", "tfgpu_dbz_receive_group_meta", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_serialize_batch", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_debezium_emit", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
     "tfgpu_prof_get",
 ]
@@ -116,6 +116,7 @@ def load():
                                       C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_serialize.argtypes = [C.c_int, P, C.POINTER(P)]
     L.tfgpu_serialize_ex.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(P)]
+    L.tfgpu_serialize_batch.argtypes = [C.c_int, P, C.POINTER(abi.CSerializeOptions), C.POINTER(abi.CBatchSerializerConfig), C.c_int, C.POINTER(P), C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_debezium_emit.argtypes = [C.POINTER(abi.CDbzEmitOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(P), P, C.POINTER(P), P, P, P, C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_queue_serialize.argtypes = [C.POINTER(abi.CQueueOptions), P, C.POINTER(abi.CRowMeta), C.POINTER(P), P, P, C.c_int64, C.POINTER(C.c_int64)]
     L.tfgpu_dbuf_size.argtypes = [P, C.POINTER(C.c_uint64)]
@@ -898,6 +899,20 @@ def serialize(fmt: int, batch: DeviceBatch, opts: Optional[abi.CSerializeOptions
     else:
         _check(load().tfgpu_serialize_ex(fmt, batch._h, C.byref(opts), C.byref(out)))
     return DeviceBuffer(out)
+
+
+def serialize_batch(fmt: int, batch: DeviceBatch, opts: Optional[abi.CSerializeOptions] = None, concurrency: int = 0, threshold: int = 0, disable_concurrency: bool = False,
+                    gomaxprocs: int = 8, for_writer: bool = False):
+    """batchSerializer.Serialize (→ DeviceBuffer) / SerializeAndWrite (→ (DeviceBuffer, [where each Write call ends]))."""
+    init()
+    cfg = abi.CBatchSerializerConfig(int(concurrency), int(threshold), int(bool(disable_concurrency)), int(gomaxprocs))
+    out = C.c_void_p()
+    cap = max(1, (batch.nrows + max(threshold or 25000, 1) - 1) // max(threshold or 25000, 1))
+    ends = (C.c_uint64 * cap)()
+    nparts = C.c_int64(0)
+    _check(load().tfgpu_serialize_batch(fmt, batch._h, C.byref(opts) if opts is not None else None, C.byref(cfg), int(bool(for_writer)), C.byref(out), ends, cap, C.byref(nparts)))
+    buf = DeviceBuffer(out)
+    return (buf, [int(ends[i]) for i in range(nparts.value)]) if for_writer else buf
 
 
 class QueueMessages:
