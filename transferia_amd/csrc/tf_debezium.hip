@@ -32,6 +32,7 @@
 #include <cstring>
 
 #include "tf_jsonscan.hpp"
+#include "tf_segcopy.hpp"
 #include "tf_wave.hpp"
 #include "tf_swar.hpp"
 #include "tf_jsonquick.hpp"
@@ -871,7 +872,35 @@ __global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *c
     default: { CountSink s; if (!nil) render_text(s, rd, f, vtr, vs, vl); c.lens[r] = s.n; }
   }
 }
-__global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
+// The text cells that are a plain byte range of the message (a string field's string without escapes, or its number token) go
+// through tf_segcopy.hpp's destination-centric packing, like the CSV / JSON / SR text columns; the others (escapes, base64,
+// rendered logical types) are zero-filled there and written by dbz_cell_text, launched for the columns that hold such cells.
+__device__ __forceinline__ uint32_t dbz_plain_src(const Params &p, int j, int64_t r, bool *special) {
+  const int64_t i = (int64_t)j * p.nmsg + p.row_msg[r];
+  const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK;
+  if (vt == VT_NULL) return SEG_NONE;
+  if (p.fields[j].op == TFGPU_DBZ_STRING) {
+    if (vt == VT_NUM) return p.vstart[i];
+    if (vtr & VT_PLAIN) return p.vstart[i] + 1;
+  }
+  if (special) *special = true;
+  return SEG_NONE;
+}
+__global__ void __launch_bounds__(256) dbz_mark_special(Params p, const int32_t *text_cols, uint32_t *spec) {
+  const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool special = false;
+  if (r < p.nrows) dbz_plain_src(p, text_cols[t], r, &special);
+  if (__any(special) && (threadIdx.x & 63) == 0) atomicOr(&spec[t], 1u);
+}
+__global__ void __launch_bounds__(256) dbz_copy_words(Params p, const OutCol *cols, const int32_t *text_cols) {
+  __shared__ uint32_t doff[256 + 1];
+  __shared__ uint32_t soff[256];
+  const int j = text_cols[blockIdx.y];
+  const OutCol c = cols[j];
+  auto so = [&](int64_t r) { return dbz_plain_src(p, j, r, nullptr); };
+  segcopy_run<1>(c.lens, p.nrows, (int64_t)blockIdx.x * 256, p.data, c.data, so, doff, soff);
+}
+__global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext, int plain_done) {
   const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.nrows) return;
   const int j = text_cols[t];
@@ -881,6 +910,7 @@ __global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *col
   const int64_t i = (int64_t)j * p.nmsg + m;
   const uint32_t vtr = p.vtype[i], vt = vtr & VT_MASK, vs = p.vstart[i], vl = p.vlen[i];
   if (vt == VT_NULL) return;
+  if (plain_done && f.op == TFGPU_DBZ_STRING && (vt == VT_NUM || (vtr & VT_PLAIN))) return;  // dbz_copy_words moved it
   MemBytes rd(p.data);
   ByteSink s{c.data + c.lens[r]};
   auto copy_raw = [&](uint32_t a, uint32_t n) {
@@ -1282,6 +1312,10 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     Buf totals = dalloc((size_t)ntext * 4 + 16);
     dbz::dbz_gather_totals<<<1, 64, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, nrows, ntext, ptr<uint32_t>(totals));
     const uint32_t *tot = d2h_u32(totals->p, (size_t)ntext);   // one read-back for all the text columns' sizes, one block for their bytes
+    static const bool words = [] { const char *e = std::getenv("TFGPU_DBZ_COPY_WORDS"); return !(e && e[0] == '0'); }();  // 0: A/B runs
+    Buf spec = dalloc_zero((size_t)ntext * 4), btc0 = upload_small(text_cols.data(), text_cols.size() * 4);
+    if (nrows && words) dbz::dbz_mark_special<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<int32_t>(btc0), ptr<uint32_t>(spec));
+    const uint32_t *hspec = d2h_u32(spec->p, (size_t)ntext);
     tf::sync();
     size_t text_bytes = 0;
     for (int t = 0; t < ntext; t++) text_bytes += a256((size_t)tot[t] + 8);
@@ -1296,7 +1330,15 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     }
     boc = upload_small(oc.data(), oc.size() * sizeof(dbz::OutCol));
     Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
-    if (nrows) { KernelTimer t("dbz_cell_text"); dbz::dbz_cell_text<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc), ntext); }
+    if (nrows) {
+      KernelTimer t("dbz_cell_text");
+      if (words) {
+        dbz::dbz_copy_words<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc));
+        std::vector<int32_t> sp;
+        for (int t2 = 0; t2 < ntext; t2++) if (hspec[t2]) sp.push_back(text_cols[(size_t)t2]);
+        if (!sp.empty()) { Buf bsp = upload_small(sp.data(), sp.size() * 4); dbz::dbz_cell_text<<<dim3(dbz::nblk(nrows, 256), (unsigned)sp.size()), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(bsp), (int32_t)sp.size(), 1); }
+      } else dbz::dbz_cell_text<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc), ntext, 0);
+    }
   }
   // bitmaps: ColumnValues validity per column; OldKeys = the key columns' buffers under their own validity
   const unsigned gb = dbz::nblk((nrows + 7) / 8, 256);

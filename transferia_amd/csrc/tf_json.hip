@@ -1861,10 +1861,25 @@ __global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCo
   sk.finish();
 }
 
-__global__ void json_collect(const uint32_t *nerr, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, const uint32_t *has_nil, int ncols, uint32_t *out) {
+// Which text columns hold cells that are not a plain byte range (bit 0: escapes to undo, compaction, quoting, a float to print,
+// scratch text; bit 1: cells the map emitter writes)?  A lean kernel at full occupancy: the kernels that carry those walkers are
+// launched for the columns that need them, not for every (line, column) pair to find out that nearly all of them have nothing to do
+// (two such launches were 0.46 ms of the json step's 3.4).
+__global__ void __launch_bounds__(256) json_mark_special(const uint32_t *lens_all, int64_t seg_stride, const uint32_t *const *metas, int64_t nlines, uint32_t *spec) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = (int)blockIdx.y;
+  uint32_t f = 0;
+  if (r < nlines) {
+    const uint32_t *off = lens_all + (int64_t)s * seg_stride;
+    if (off[r + 1] != off[r]) { const uint32_t mode = metas[s][r] >> 28; f = (mode == JM_ANYCANON || mode == JM_REST) ? 2u : mode != JM_COPY ? 1u : 0u; }
+  }
+  const uint32_t any = (__any(f & 1u) ? 1u : 0u) | (__any(f & 2u) ? 2u : 0u);
+  if (any && (threadIdx.x & 63) == 0) atomicOr(&spec[s], any);
+}
+__global__ void json_collect(const uint32_t *nerr, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, const uint32_t *has_nil, int ncols, const uint32_t *spec, uint32_t *out) {
   const int i = threadIdx.x;
   if (i == 0) out[0] = *nerr;
-  for (int s = i; s < nstr; s += blockDim.x) out[1 + s] = lens_all[(int64_t)s * seg_stride + nrows];
+  for (int s = i; s < nstr; s += blockDim.x) { out[1 + s] = lens_all[(int64_t)s * seg_stride + nrows]; out[1 + nstr + ncols + s] = spec[s]; }
   for (int c = i; c < ncols; c += blockDim.x) out[1 + nstr + c] = has_nil[c];
 }
 
@@ -2298,9 +2313,16 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     if (nraw) json_validity<<<dim3(jblocks((nlines + 7) / 8, 256), (unsigned)nraw), 256, 0, st>>>(ptr<JCol>(bcols), nlines, (uint8_t *const *)bvp->p, ptr<uint32_t>(keep), ptr<uint32_t>(has_nil));
   }
   if (nstr) exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nlines, nstr, seg_stride);
-  Buf summary = dalloc((size_t)(nstr + nraw + 1) * 4);
-  json_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), ptr<uint32_t>(lens_all), seg_stride, nlines, nstr, ptr<uint32_t>(has_nil), nraw, ptr<uint32_t>(summary));
-  const uint32_t *hsum = d2h_u32(summary->p, (size_t)nstr + nraw + 1);
+  Buf spec = dalloc_zero((size_t)std::max(nstr, 1) * 4);
+  if (nlines && nstr) {
+    std::vector<const uint32_t *> metas((size_t)nstr);
+    for (int sg = 0; sg < nstr; sg++) metas[(size_t)sg] = sg == rest_seg ? pp.rest_meta : cols[(size_t)str_col_index[(size_t)sg]].meta;
+    Buf bm = upload_small(metas.data(), metas.size() * sizeof(uint32_t *));
+    json_mark_special<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, (const uint32_t *const *)bm->p, nlines, ptr<uint32_t>(spec));
+  }
+  Buf summary = dalloc((size_t)(2 * nstr + nraw + 1) * 4);
+  json_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), ptr<uint32_t>(lens_all), seg_stride, nlines, nstr, ptr<uint32_t>(has_nil), nraw, ptr<uint32_t>(spec), ptr<uint32_t>(summary));
+  const uint32_t *hsum = d2h_u32(summary->p, (size_t)2 * nstr + nraw + 1);
   tf::sync();
   const uint32_t hnerr = hsum[0];
   for (int i = 0; i < nraw; i++) if (!hsum[1 + nstr + i]) db->cols[(size_t)i].validity = nullptr;  // no nil among the kept lines
@@ -2321,8 +2343,15 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     KernelTimer t("json_copy_cells");
     static const bool words = [] { const char *e = std::getenv("TFGPU_JSON_COPY_WORDS"); return !(e && e[0] == '0'); }();  // 0: A/B runs
     if (words) json_copy_words<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(data, ptr<JCopyCol>(bcc), nlines);
-    json_copy_cells<false><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines, words ? 1 : 0);
-    json_copy_cells<true><<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(pp, ptr<JCopyCol>(bcc), nlines, words ? 1 : 0);
+    // the walkers only where json_mark_special saw their cells (every column without TFGPU_JSON_COPY_WORDS: the plain cells are theirs then)
+    std::vector<JCopyCol> light, heavy;
+    for (int sg = 0; sg < nstr; sg++) {
+      const uint32_t f = hsum[1 + nstr + nraw + sg];
+      if ((f & 1u) || !words) light.push_back(cc[(size_t)sg]);
+      if (f & 2u) heavy.push_back(cc[(size_t)sg]);
+    }
+    if (!light.empty()) { Buf bl = upload_small(light.data(), light.size() * sizeof(JCopyCol)); json_copy_cells<false><<<dim3(jblocks(nlines, 256), (unsigned)light.size()), 256, 0, st>>>(pp, ptr<JCopyCol>(bl), nlines, words ? 1 : 0); }
+    if (!heavy.empty()) { Buf bh = upload_small(heavy.data(), heavy.size() * sizeof(JCopyCol)); json_copy_cells<true><<<dim3(jblocks(nlines, 256), (unsigned)heavy.size()), 256, 0, st>>>(pp, ptr<JCopyCol>(bh), nlines, words ? 1 : 0); }
   }
 
   // ---- dropped lines: `_unparsed` rows / host fallback are reported, skipped lines vanish ----

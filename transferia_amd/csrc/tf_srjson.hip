@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "tf_jsonscan.hpp"
+#include "tf_segcopy.hpp"
 #include "tf_jsontile.hpp"
 #include "tf_jsonquick.hpp"
 
@@ -577,8 +578,38 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
     default: if (!(vtr & VT_CANON)) { CountSink s; if (!nil) emit_any(s, rd, vs, vl); c.lens[r] = s.n; }  // flagged cells: the CANON launch
   }
 }
+// The text cells that are a plain byte range of the message — number tokens, strings without escapes: nearly all of them — are
+// packed destination-centrically (tf_segcopy.hpp: a lane owns aligned 8-byte words of the column's payload and pulls their bytes
+// from the messages; a wave stores 512 contiguous bytes); the other cells are zero-filled here and written by sr_cell_text, which
+// is launched for the columns sr_mark_special found such cells in.  (One lane copying one cell's bytes was 0.59 ms for the 2^18
+// hits messages' text; the same bytes through json_copy_words take 0.21.)
+__device__ __forceinline__ uint32_t sr_plain_src(const Params &p, const OutCol &c, int j, int64_t r, bool *special) {
+  const uint64_t rec = p.vrec[(int64_t)j * p.nframes + p.row_frame[r]];
+  const uint32_t vtr = (uint32_t)(rec >> 56), vt = vtr & VT_MASK, vs = (uint32_t)rec;
+  if (vt == VT_ABSENT || vt == VT_NULL) return SEG_NONE;
+  if (!(vtr & VT_CANON)) {
+    if (c.json_type == TFGPU_SRT_NUMBER) return vs;
+    if (c.json_type == TFGPU_SRT_STRING && (vtr & VT_PLAIN)) return vs + 1;
+    if (special) *special = true;
+  }
+  return SEG_NONE;
+}
+__global__ void __launch_bounds__(256) sr_mark_special(Params p, const OutCol *cols, const int32_t *text_cols, uint32_t *spec) {
+  const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool special = false;
+  if (r < p.nrows) sr_plain_src(p, cols[text_cols[t]], text_cols[t], r, &special);
+  if (__any(special) && (threadIdx.x & 63) == 0) atomicOr(&spec[t], 1u);
+}
+__global__ void __launch_bounds__(256) sr_copy_words(Params p, const OutCol *cols, const int32_t *text_cols) {
+  __shared__ uint32_t doff[256 + 1];
+  __shared__ uint32_t soff[256];
+  const int j = text_cols[blockIdx.y];
+  const OutCol c = cols[j];
+  auto so = [&](int64_t r) { return sr_plain_src(p, c, j, r, nullptr); };
+  segcopy_run<1>(c.lens, p.nrows, (int64_t)blockIdx.x * 256, p.data, c.data, so, doff, soff);
+}
 template <bool CANON>
-__global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext) {
+__global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext, int plain_done) {
   const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.nrows) return;
   const int j = text_cols[t];
@@ -589,6 +620,7 @@ __global__ void __launch_bounds__(256) sr_cell_text(Params p, const OutCol *cols
   const uint32_t vtr = (uint32_t)(rec >> 56), vt = vtr & VT_MASK, vs = (uint32_t)rec, vl = (uint32_t)(rec >> 32) & 0xFFFFFFu;
   if (vt == VT_ABSENT || vt == VT_NULL) return;
   if (((vtr & VT_CANON) != 0) != CANON) return;
+  if (!CANON && plain_done && (c.json_type == TFGPU_SRT_NUMBER || (c.json_type == TFGPU_SRT_STRING && (vtr & VT_PLAIN)))) return;  // sr_copy_words moved it
   MemBytes rd(p.data);
   ByteSink s{c.data + c.lens[r]};
   if constexpr (CANON) { emit_any_canon(s, rd, vs, vl); s.flush(); return; }
@@ -823,6 +855,10 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);  // offsets in place, the total at [nrows]
     std::vector<const uint32_t *> tot((size_t)ntext);
     for (int t = 0; t < ntext; t++) tot[(size_t)t] = d2h_u32(ptr<uint32_t>(lens_all) + (int64_t)t * seg_stride + nrows);
+    static const bool words = [] { const char *e = std::getenv("TFGPU_SR_COPY_WORDS"); return !(e && e[0] == '0'); }();  // 0: A/B runs
+    Buf spec = dalloc_zero((size_t)ntext * 4), btc0 = upload_small(text_cols.data(), text_cols.size() * 4);
+    if (nrows && words) sr::sr_mark_special<<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc0), ptr<uint32_t>(spec));
+    const uint32_t *hspec = d2h_u32(spec->p, (size_t)ntext);
     tf::sync();
     for (int t = 0; t < ntext; t++) {
       DColumn &d = db->cols[(size_t)text_cols[(size_t)t]];
@@ -834,8 +870,13 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
     if (nrows) {
       KernelTimer t("sr_cell_text");
-      sr::sr_cell_text<false><<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
-      if (has_any) sr::sr_cell_text<true><<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext);
+      if (words) {
+        sr::sr_copy_words<<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc));
+        std::vector<int32_t> sp;  // the columns that hold cells the walkers write
+        for (int t2 = 0; t2 < ntext; t2++) if (hspec[t2]) sp.push_back(text_cols[(size_t)t2]);
+        if (!sp.empty()) { Buf bsp = upload_small(sp.data(), sp.size() * 4); sr::sr_cell_text<false><<<dim3(sr::nblk(nrows, 256), (unsigned)sp.size()), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(bsp), (int32_t)sp.size(), 1); }
+      } else sr::sr_cell_text<false><<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext, 0);
+      if (has_any) sr::sr_cell_text<true><<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc), ntext, 0);
     }
   }
   // ---- frames the reference turns into `_unparsed` items / rows for the stock path ----
