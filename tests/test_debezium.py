@@ -396,7 +396,7 @@ def test_gpu_walker_cross_check():
     import subprocess
     import sys
     env = dict(os.environ, TFGPU_DBZ_QUICK="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "not cross_check"], env=env, capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "not cross_check"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
 
 

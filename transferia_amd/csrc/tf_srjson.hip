@@ -855,7 +855,9 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);  // offsets in place, the total at [nrows]
     std::vector<const uint32_t *> tot((size_t)ntext);
     for (int t = 0; t < ntext; t++) tot[(size_t)t] = d2h_u32(ptr<uint32_t>(lens_all) + (int64_t)t * seg_stride + nrows);
-    static const bool words = [] { const char *e = std::getenv("TFGPU_SR_COPY_WORDS"); return !(e && e[0] == '0'); }();  // 0: A/B runs
+    // OFF by default: measured on the MI355X (gpurun r07b, 2^18 hits messages) sr_cell_text is 0.60 ms one lane per cell and 0.65 ms this way —
+    // a third of the text (Cyrillic titles, strings with escapes) is not VT_PLAIN and still takes the walkers, and the marking pass re-reads the value records
+    static const bool words = [] { const char *e = std::getenv("TFGPU_SR_COPY_WORDS"); return e && e[0] == '1'; }();
     Buf spec = dalloc_zero((size_t)ntext * 4), btc0 = upload_small(text_cols.data(), text_cols.size() * 4);
     if (nrows && words) sr::sr_mark_special<<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc0), ptr<uint32_t>(spec));
     const uint32_t *hspec = d2h_u32(spec->p, (size_t)ntext);
