@@ -915,6 +915,28 @@ typedef struct tfgpu_queue_options {
  * fails with TFGPU_ERR_INVALID if there are more messages (cap = nrows is always enough).
  * Rows of a non-row kind are TFGPU_ERR_UNSUPPORTED (they travel through the stock serializer); JSON format fails with
  * TFGPU_ERR_UNSUPPORTED on update / delete rows exactly where the reference returns its "unsupported kind" error.   */
+/* The queue serializers whose messages ARE column bytes, and the Kafka writer's partitioner — the host halves of SURVEY §8 f4 behind
+ * the ABI (round 4; they were Python):
+ *   tfgpu_queue_raw_column   RawColumnSerializer.Serialize for one table / PartID (pkg/serializer/queue/raw_column_serializer.go:21-73):
+ *                            a message per row = the value of `column`; the rows the reference skips with a warning (the column absent
+ *                            from ColumnNames or from the TableSchema, a DataType that is neither "utf8" nor "string", a value that is
+ *                            no Go string / []byte — nil included) give no message.  `schema` NULL = the batch's own.
+ *   tfgpu_queue_mirror       MirrorSerializer.Serialize (mirror_serializer.go:15-52; changeitem/mirror.go:23-87): (key, value) per row =
+ *                            (`sequence_key`, `data`); TFGPU_ERR_INVALID with the reference's message where it fails (not mirror items, a
+ *                            TableSchema that is not RawDataSchema, a `sequence_key` that is not []byte, a nil `data`).  key_nil[r] = 1: no key.
+ *   tfgpu_queue_part_groups  splitByTablePartID for one table (split.go:5-12): rows grouped by PartID, groups by first appearance.
+ *   tfgpu_kafka_hash_partition / tfgpu_kafka_partitions
+ *                            kafka-go's Hash balancer (vendor_patched/github.com/segmentio/kafka-go/balancer.go:153-181): FNV-1a(32) of the
+ *                            key as an int32, Go's remainder, a negative result negated; -1 for a nil key (round robin there).  The second
+ *                            form hashes a whole key column on the device.
+ * *values / *keys: the bytes back to back in HBM (the column's own buffer when every row has a value); msg_start / key_start: HOST arrays of
+ * cap + 1 offsets, message m = [msg_start[m], msg_start[m + 1]).                                                                          */
+int tfgpu_queue_raw_column(const tfgpu_dbatch *b, const char *column, const tfgpu_schema *schema, tfgpu_dbuf **values, uint32_t *msg_start, int64_t cap, int64_t *nmsg);
+int tfgpu_queue_mirror(const tfgpu_dbatch *b, const tfgpu_schema *schema, tfgpu_dbuf **values, uint32_t *msg_start, tfgpu_dbuf **keys, uint32_t *key_start,
+                       uint8_t *key_nil, int64_t cap, int64_t *nmsg);
+int tfgpu_queue_part_groups(const tfgpu_dbatch *b, int32_t *order, int64_t *group_rows, uint32_t *group_part_id, int64_t cap, int64_t *ngroups);
+int32_t tfgpu_kafka_hash_partition(const void *key, int64_t len, int32_t npartitions);
+int tfgpu_kafka_partitions(const tfgpu_dbatch *b, const char *key_column, int32_t npartitions, int32_t *partitions);
 int tfgpu_queue_serialize(const tfgpu_queue_options *opts, const tfgpu_dbatch *b, const tfgpu_row_meta *meta,
                           tfgpu_dbuf **values, uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg);
 

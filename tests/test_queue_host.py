@@ -1,8 +1,12 @@
-"""Host side of the queue serializers (transferia_amd/queue.py): RawColumnSerializer, message keys, PartID groups —
-pinned to pkg/serializer/queue/raw_column_serializer_test.go:21-245 and split.go."""
+"""The queue serializers whose messages are column bytes, message keys, PartID groups, the Kafka hash balancer.  The CPU tests pin
+the checker (oracle/ora_queue.py) to pkg/serializer/queue/raw_column_serializer_test.go:21-245, mirror_serializer_test.go, split.go
+and kafka-go's balancer_test.go; the gpu tests run the same vectors and random batches through the C ABI
+(tfgpu_queue_raw_column / _mirror / _part_groups, tfgpu_kafka_*; transferia_amd/queue.py) against it."""
 import numpy as np
+import pytest
 
-from transferia_amd import abi, queue
+from oracle import ora_queue as queue
+from transferia_amd import abi
 
 SCHEMA = abi.Schema.of([["extra_column", "int64"], ["test_column", "utf8"], ["other_extra_column", "any"]])
 
@@ -65,7 +69,6 @@ def _raw_message(key, data, offset=0):
 
 
 def test_mirror_serializer_known_answers():
-    import pytest
     names = list(queue.RAW_DATA_COLUMNS)
     one = abi.batch_from_rows(RAW, names, [_raw_message("stub", "aboba123")])
     assert queue.is_mirror(one) and queue.mirror_messages(one) == [(b"stub", b"aboba123")]  # TestMirrorSerializerTopicName
@@ -91,3 +94,77 @@ def test_mirror_serializer_known_answers():
         queue.mirror_messages(other)
     other.schema = RAW
     assert queue.mirror_messages(other) == [(b"k", b"v")]
+
+
+# ---------------------------------------------------------------- the same through the C ABI ----
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init(0)
+    return lib
+
+
+@pytest.mark.gpu
+def test_gpu_raw_column_and_mirror_vectors(tf):
+    from transferia_amd import queue as dq
+    up = tf.DeviceBatch.upload
+    b = _batch([[["int64", 1], ["string", "kek"], ["nil", None]], [["int64", 2], ["string", "lel"], ["nil", None]], [["int64", 3], ["string", "wtf"], ["nil", None]]])
+    assert dq.raw_column_messages(up(b), "test_column", SCHEMA) == [b"kek", b"lel", b"wtf"]
+    b2 = _batch([[["int64", 2], ["bytes", "lel"], ["nil", None]], [["int64", 3], ["bytes", "wtf"], ["nil", None]]])
+    assert dq.raw_column_messages(up(b2), "test_column", SCHEMA) == [b"lel", b"wtf"]
+    assert dq.raw_column_messages(up(_batch([[["int64", 1], ["nil", None]]], names=("extra_column", "other_extra_column"))), "test_column", SCHEMA) == []
+    ints = abi.Schema.of([["extra_column", "int64"], ["test_column", "int64"], ["other_extra_column", "any"]])
+    assert dq.raw_column_messages(up(_batch([[["int64", 1], ["int64", 100500], ["nil", None]]], schema=SCHEMA)), "test_column", SCHEMA) == []
+    assert dq.raw_column_messages(up(_batch([[["int64", 2], ["int64", 100500], ["nil", None]]], schema=ints)), "test_column", ints) == []
+    b3 = _batch([[["int64", 1], ["nil", None], ["nil", None]], [["int64", 3], ["string", "wtf"], ["nil", None]]])
+    assert dq.raw_column_messages(up(b3), "test_column", SCHEMA) == [b"wtf"]
+    no_col = abi.Schema.of([["extra_column", "int64"], ["other_extra_column", "any"]])
+    assert dq.raw_column_messages(up(_batch([[["int64", 1], ["string", "kek"], ["nil", None]]])), "test_column", no_col) == []
+    names = list(queue.RAW_DATA_COLUMNS)
+    two = abi.batch_from_rows(RAW, names, [_raw_message("sequence_key_1", "aboba1"), _raw_message("sequence_key_2", "aboba2", 1), _raw_message(None, "", 2)])
+    assert dq.mirror_messages(up(two), RAW) == [(b"sequence_key_1", b"aboba1"), (b"sequence_key_2", b"aboba2"), (None, b"")]
+    assert dq.mirror_messages(up(abi.batch_from_rows(RAW, names, [])), RAW) == []
+    with pytest.raises(tf.TfgpuError, match="Mirror"):
+        dq.mirror_messages(up(_batch([[["int64", 1], ["string", "kek"], ["nil", None]]])))
+    bad = _raw_message("k", "v"); bad[4] = ["nil", None]
+    with pytest.raises(tf.TfgpuError, match="<nil>"):
+        dq.mirror_messages(up(abi.batch_from_rows(RAW, names, [_raw_message("k", "v"), bad])), RAW)
+    txt = _raw_message("k", "v"); txt[6] = ["string", "k"]
+    with pytest.raises(tf.TfgpuError, match="sequence_key"):
+        dq.mirror_messages(up(abi.batch_from_rows(RAW, names, [txt])), RAW)
+    with pytest.raises(tf.TfgpuError, match="should be 'mirror'"):
+        dq.mirror_messages(up(abi.batch_from_rows(RAW, names, [_raw_message("k", "v")])), abi.Schema.of([[c.name, c.dtype] for c in RAW.cols]))
+    for k, n, p in [(b"blah", 2, 0), (b"blah", 3, 1), (b"boop", 3, 2), (b"20", 16, 1)]:
+        assert dq.kafka_hash_partition(k, n) == p
+    assert dq.kafka_hash_partition(None, 3) is None
+
+
+@pytest.mark.gpu
+def test_gpu_queue_random_against_the_checker(tf):
+    import random
+    from transferia_amd import queue as dq
+    rng = random.Random(20260924)
+    names = list(queue.RAW_DATA_COLUMNS)
+    for n in (1, 7, 300, 5000):
+        rows = [_raw_message(None if rng.random() < 0.2 else "".join(rng.choice("abc\x00\xff\u00e9") for _ in range(rng.randrange(0, 40))), "d" * rng.randrange(0, 90) + str(i), i) for i in range(n)]
+        hb = abi.batch_from_rows(RAW, names, rows)
+        hb.schema = RAW
+        db = tf.DeviceBatch.upload(hb)
+        assert dq.mirror_messages(db, RAW) == queue.mirror_messages(hb)
+        assert dq.raw_column_messages(db, "data", RAW) == queue.raw_column_messages(hb, "data", RAW)
+        for np_ in (1, 3, 16, 1000):
+            want = [queue.kafka_hash_partition(k, np_) for k, _ in queue.mirror_messages(hb)]
+            assert dq.kafka_partitions(db, "sequence_key", np_) == want
+        # raw column with nil rows in between
+        rows2 = [[["int64", i], ["nil", None] if rng.random() < 0.3 else ["string", "v%d" % i * rng.randrange(1, 5)], ["nil", None]] for i in range(n)]
+        hb2 = _batch(rows2)
+        assert dq.raw_column_messages(tf.DeviceBatch.upload(hb2), "test_column", SCHEMA) == queue.raw_column_messages(hb2, "test_column", SCHEMA)
+    # part groups behind a sharder
+    sch = abi.Schema.of([["id", "int64", True], ["v", "utf8"]])
+    hb = abi.batch_from_rows(sch, ["id", "v"], [[["int64", i * 7919 % 1000], ["string", "x"]] for i in range(2000)], "db", "t")
+    res = tf.Transformer("sharder_transformer", {"columns": {"includeColumns": ["id"]}, "shardsCount": "5"}).apply(tf.DeviceBatch.upload(hb))
+    sharded = res.transformed
+    order, counts, ids = dq.part_groups(sharded)
+    pid = sharded.download().part_id
+    o2, c2, i2 = queue.part_groups(np.asarray(pid), 2000)
+    assert order.tolist() == o2.tolist() and counts == c2 and ids == i2

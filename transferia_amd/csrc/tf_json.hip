@@ -841,7 +841,9 @@ __device__ int store_nested(const JParams &p, const JCol &c, const int64_t r, co
 template <bool HEAVY>
 __device__ __forceinline__ int store_cell(const JParams &p, const JCol &c, const int64_t r, MemBytes &aux, const int vtype, const uint64_t vstart,
                                           const uint64_t vend, const JStr &sv, const uint32_t clen, const bool kbad) {
-  if (c.npath_n) return store_nested(p, c, r, vtype, sv);
+  if (c.npath_n) {  // lookupComplex lives in the kernels that carry the map emitter: the ones every line runs through stay lean
+    if constexpr (!HEAVY) return 2; else return store_nested(p, c, r, vtype, sv);
+  }
   return store_cell_plain<HEAVY>(p, c, r, aux, vtype, vstart, vend, sv, clen, kbad);
 }
 
@@ -1079,11 +1081,12 @@ __device__ bool parse_json_line(const JParams &p, const int64_t r, const uint64_
 // GenericParser.Unmarshal, Format "tskv" (generic_parser.go:732-746): strings.Split(line, "\t"), SplitN(field, "=", 2); a field
 // without '=' is skipped, every value is a Go string (ParseVal's string branch types it), the last duplicate of a key wins.
 // Unmarshal cannot fail here: a line is a row, skipped (no key=value field at all), or handed to the host.
-__device__ void parse_tskv_line(const JParams &p, const int64_t r, const uint64_t ls, const uint64_t le) {
+template <bool HEAVY>
+__device__ bool parse_tskv_line(const JParams &p, const int64_t r, const uint64_t ls, const uint64_t le) {
   MemBytes rd(p.data), aux(p.data);
   uint64_t pos = ls;
   uint32_t kids = 0;
-  bool fallback = false;
+  bool fallback = false, heavy = false;
   for (;;) {
     uint64_t fe = pos, eq = ~0ull;
     bool bs = false, ctrl = false, hi = false, quote = false;
@@ -1119,8 +1122,12 @@ __device__ void parse_tskv_line(const JParams &p, const int64_t r, const uint64_
         sv.s = eq + 1; sv.n = (uint32_t)(fe - eq - 1); sv.hash = 0;
         sv.bs = p.tskv_unescape && bs;  // raw bytes ARE the value unless tryToUnescapeTSKV runs
         sv.ctrl = ctrl; sv.plain = !bs && !ctrl && !hi && !quote;
-        for (int32_t ci = kcol; ci >= 0; ci = p.cols[ci].next)
-          if (store_cell<false>(p, p.cols[ci], r, aux, V_STR, eq + 1, fe, sv, 0, false) != 1) { fallback = true; break; }  // strings never need the map emitter
+        for (int32_t ci = kcol; ci >= 0; ci = p.cols[ci].next) {
+          const int rc = store_cell<HEAVY>(p, p.cols[ci], r, aux, V_STR, eq + 1, fe, sv, 0, false);  // strings never need the map emitter; a nested path needs the kernel that carries it
+          if (rc == 2) { heavy = true; break; }
+          if (rc != 1) { fallback = true; break; }
+        }
+        if (heavy) return true;
       }
     }
     if (fe >= le) break;
@@ -1129,6 +1136,7 @@ __device__ void parse_tskv_line(const JParams &p, const int64_t r, const uint64_
   p.linest[r] = fallback ? JL_FALLBACK : kids == 0 ? JL_SKIPPED : JL_ROW;
   if (!fallback && kids && p.rest_lens) { p.rest_fstart[r] = (uint32_t)ls; p.rest_meta[r] = (JM_REST_EMPTY << 28); p.rest_lens[r] = 2; }
   p.line_pos[r] = (uint32_t)ls;
+  return false;
 }
 
 __global__ void __launch_bounds__(256) json_parse_lines(JParams p, uint32_t *slow_n, uint32_t *slow_seg) {
@@ -1137,8 +1145,8 @@ __global__ void __launch_bounds__(256) json_parse_lines(JParams p, uint32_t *slo
   const uint32_t n = p.seg_len[i];
   if (!n) return;
   const uint64_t s = p.seg_start[i];
-  if (p.format == TFGPU_JFMT_TSKV) parse_tskv_line(p, (int64_t)p.seg_ord[i], s, s + n);
-  else if (parse_json_line<false>(p, (int64_t)p.seg_ord[i], s, s + n)) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)i; }  // → json_parse_listed
+  const bool again = p.format == TFGPU_JFMT_TSKV ? parse_tskv_line<false>(p, (int64_t)p.seg_ord[i], s, s + n) : parse_json_line<false>(p, (int64_t)p.seg_ord[i], s, s + n);
+  if (again) { const uint32_t k = atomicAdd(slow_n, 1u); slow_seg[k] = (uint32_t)i; }  // → json_parse_listed
 }
 // the lines the wave path hands over (nested values, anything it does not fully understand): one lane per line
 __global__ void __launch_bounds__(256) json_parse_listed(JParams p, const uint32_t *slow_n, const uint32_t *slow_seg) {
@@ -1146,7 +1154,8 @@ __global__ void __launch_bounds__(256) json_parse_listed(JParams p, const uint32
   if (k >= *slow_n) return;
   const uint32_t i = slow_seg[k];
   const uint64_t s = p.seg_start[i];
-  parse_json_line<true>(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i]);
+  if (p.format == TFGPU_JFMT_TSKV) parse_tskv_line<true>(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i]);
+  else parse_json_line<true>(p, (int64_t)p.seg_ord[i], s, s + p.seg_len[i]);
 }
 
 // the lines the tile path hands over, through the lean per-line parser first; what needs the map emitter is listed again
@@ -2265,7 +2274,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     Buf slow = dalloc((size_t)(nseg + 1) * 4);  // lines that need the map emitter: re-parsed by the kernel that carries it
     TF_HIP(hipMemsetAsync(slow->p, 0, 4, st));
     { KernelTimer t("json_parse_lines"); json_parse_lines<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
-    if (!tskv) { KernelTimer t("json_parse_listed"); json_parse_listed<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
+    if (!tskv || any_nested) { KernelTimer t("json_parse_listed"); json_parse_listed<<<jblocks(nseg, 256), 256, 0, st>>>(pp, ptr<uint32_t>(slow), ptr<uint32_t>(slow) + 1); }
   }
   else if (nlines) {
     Buf slow = dalloc((size_t)(nseg + 1) * 4);

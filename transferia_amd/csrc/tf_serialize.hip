@@ -1033,6 +1033,202 @@ extern "C" int tfgpu_serialize_batch(int format, const tfgpu_dbatch *b, const tf
 }
 
 // ======================================================================================================
+// The queue serializers whose messages ARE column bytes, and the Kafka writer's partitioner: RawColumnSerializer
+// (raw_column_serializer.go:21-73), MirrorSerializer (mirror_serializer.go:15-52; changeitem/mirror.go:23-87), splitByTablePartID
+// (split.go:5-12), kafka-go's Hash balancer (vendor_patched/github.com/segmentio/kafka-go/balancer.go:153-181).  No kernels of their
+// own: a message value is the named column's cell, so the result is that column's (offsets, bytes) — shared when every row has a
+// value, gathered over the rows that do otherwise — and the rules around it are the reference's, row for row.
+// ======================================================================================================
+namespace tf {
+std::unique_ptr<tfgpu_dbatch> gather_rows(const tfgpu_dbatch &in, const Buf &sel, int64_t m);  // tf_transform.hip
+static const char *const RAW_DATA_COLUMNS[7] = {"topic", "partition", "seq_no", "write_time", "data", "meta", "sequence_key"};
+static bool is_mirror_batch(const tfgpu_dbatch &b) {  // ChangeItem.IsMirror (change_item.go:385-395): ColumnNames are exactly RawDataColumns, in order
+  if (b.cols.size() != 7) return false;
+  for (size_t i = 0; i < 7; i++) if (b.cols[i].name != RAW_DATA_COLUMNS[i]) return false;
+  return true;
+}
+// GetSequenceKey compares the TableSchema POINTER with RawDataSchema (mirror.go:71-73); value identity is the closest a columnar
+// batch has: names, types, key / required flags and original types, position by position
+static bool is_raw_data_schema(const tfgpu_schema &s) {
+  static const struct { const char *name; int dtype; uint32_t flags; const char *ot; } W[7] = {
+      {"topic", TFGPU_T_UTF8, TFGPU_COL_KEY | TFGPU_COL_REQUIRED, ""}, {"partition", TFGPU_T_UINT32, TFGPU_COL_KEY | TFGPU_COL_REQUIRED, ""},
+      {"seq_no", TFGPU_T_UINT64, TFGPU_COL_KEY | TFGPU_COL_REQUIRED, ""}, {"write_time", TFGPU_T_DATETIME, TFGPU_COL_KEY | TFGPU_COL_REQUIRED, ""},
+      {"data", TFGPU_T_UTF8, 0, "mirror:binary"}, {"meta", TFGPU_T_ANY, 0, ""}, {"sequence_key", TFGPU_T_BYTES, 0, ""}};
+  if (s.ncols != 7) return false;
+  for (int i = 0; i < 7; i++) {
+    const tfgpu_colschema &c = s.cols[i];
+    if (std::string(c.name ? c.name : "") != W[i].name || c.dtype != W[i].dtype || (c.flags & (TFGPU_COL_KEY | TFGPU_COL_REQUIRED)) != W[i].flags || std::string(c.original_type ? c.original_type : "") != W[i].ot) return false;
+  }
+  return true;
+}
+// the cells of one text column as messages: every row (all_rows) or the rows that hold a value; offsets to the host
+static void column_messages(const tfgpu_dbatch &b, const DColumn &c, bool all_rows, tfgpu_dbuf **values, uint32_t *msg_start, uint8_t *nil, int64_t cap, int64_t *nmsg) {
+  const int64_t n = b.nrows;
+  std::vector<uint8_t> bm;
+  int64_t valid = n;
+  if (c.validity && n) {
+    bm.resize((size_t)(n + 7) / 8);
+    d2h(bm.data(), c.validity->p, bm.size());
+    sync();
+    valid = 0;
+    for (int64_t r = 0; r < n; r++) valid += (bm[(size_t)r >> 3] >> (r & 7)) & 1;
+  }
+  const int64_t m = all_rows ? n : valid;
+  if (m > cap) throw Error(TFGPU_ERR_INVALID, "queue: more messages than msg_start has room for");
+  auto res = std::make_unique<tfgpu_dbuf>();
+  if (all_rows || valid == n) {  // the column's own buffers (a nil cell has no bytes)
+    res->mem = c.payload(); res->size = c.data_len;
+    if (m) d2h(msg_start, c.offsets->p, (size_t)(m + 1) * 4); else msg_start[0] = 0;
+    if (nil) for (int64_t r = 0; r < n; r++) nil[r] = bm.empty() ? 0 : (uint8_t)(1 ^ ((bm[(size_t)r >> 3] >> (r & 7)) & 1));
+    sync();
+  } else {
+    std::vector<int32_t> sel;
+    for (int64_t r = 0; r < n; r++) if ((bm[(size_t)r >> 3] >> (r & 7)) & 1) sel.push_back((int32_t)r);
+    tfgpu_dbatch one;
+    one.nrows = n; one.cols.push_back(c); one.cols[0].validity = nullptr;
+    Buf bsel = upload_small(sel.data(), std::max<size_t>(sel.size(), 1) * 4);
+    std::unique_ptr<tfgpu_dbatch> g = gather_rows(one, bsel, m);
+    const DColumn &gc = g->cols[0];
+    res->mem = gc.payload(); res->size = gc.data_len;
+    if (m) d2h(msg_start, gc.offsets->p, (size_t)(m + 1) * 4); else msg_start[0] = 0;
+    sync();
+  }
+  *nmsg = m;
+  *values = res.release();
+}
+}  // namespace tf
+
+extern "C" int tfgpu_queue_raw_column(const tfgpu_dbatch *b, const char *column, const tfgpu_schema *schema, tfgpu_dbuf **values, uint32_t *msg_start, int64_t cap, int64_t *nmsg) {
+  try {
+    if (!b || !column || !values || !msg_start || !nmsg || cap < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_raw_column: null argument");
+    tf::Context &cx = tf::ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    *nmsg = 0; *values = nullptr; msg_start[0] = 0;
+    auto none = [&]() { auto r = std::make_unique<tfgpu_dbuf>(); r->mem = tf::dalloc(64); r->size = 0; *values = r.release(); return TFGPU_OK; };  // every row skipped with a warning
+    const tf::DColumn *c = nullptr;
+    for (auto &x : b->cols) if (x.name == column) { c = &x; break; }
+    if (!c) return none();  // "column is not found in the change item" (:37-41)
+    int dtype = c->dtype;
+    if (schema) {
+      const tfgpu_colschema *sc = nullptr;
+      for (int i = 0; i < schema->ncols; i++) if (schema->cols[i].name && std::string(schema->cols[i].name) == column) { sc = &schema->cols[i]; break; }
+      if (!sc) return none();  // "table schema does not contain column" (:43-49)
+      dtype = sc->dtype;
+    } else if (!b->schema.empty()) {
+      bool found = false;
+      for (auto &pr : b->schema) if (pr.first == column) { dtype = pr.second; found = true; break; }
+      if (!found) return none();
+    }
+    if (dtype != TFGPU_T_UTF8 && dtype != TFGPU_T_BYTES) return none();                      // "unexpected column type" (:51-55)
+    if (c->repr != TFGPU_R_STRING && c->repr != TFGPU_R_BYTES) return none();                // "unexpected column value type" (:57-70): nil included, per row below
+    tf::materialize(*b);
+    tf::column_messages(*b, *c, false, values, msg_start, nullptr, cap, nmsg);
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
+
+extern "C" int tfgpu_queue_mirror(const tfgpu_dbatch *b, const tfgpu_schema *schema, tfgpu_dbuf **values, uint32_t *msg_start, tfgpu_dbuf **keys, uint32_t *key_start,
+                                  uint8_t *key_nil, int64_t cap, int64_t *nmsg) {
+  try {
+    if (!b || !values || !msg_start || !keys || !key_start || !key_nil || !nmsg || cap < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_mirror: null argument");
+    tf::Context &cx = tf::ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    if (!tf::is_mirror_batch(*b)) return tf::fail(TFGPU_ERR_INVALID, "MirrorSerializer should be used only with 'Mirror' changeItems");  // mirror_serializer.go:16-18
+    if (schema && !tf::is_raw_data_schema(*schema)) return tf::fail(TFGPU_ERR_INVALID, "unable to get sequence key: changeItem should be 'mirror'");  // mirror.go:71-73
+    const tf::DColumn &data = b->cols[4], &key = b->cols[6];
+    if (data.repr != TFGPU_R_STRING && data.repr != TFGPU_R_BYTES) return tf::fail(TFGPU_ERR_INVALID, "unable to get message: unexpected data type, expected string or []byte");  // mirror.go:78-87
+    tf::materialize(*b);
+    int64_t nk = 0, nv = 0;
+    std::vector<uint8_t> dnil((size_t)std::max<int64_t>(b->nrows, 1));
+    tfgpu_dbuf *v = nullptr, *k = nullptr;
+    tf::column_messages(*b, data, true, &v, msg_start, dnil.data(), cap, &nv);
+    std::unique_ptr<tfgpu_dbuf> hv(v);
+    for (int64_t r = 0; r < b->nrows; r++) if (dnil[(size_t)r]) return tf::fail(TFGPU_ERR_INVALID, "unable to get message: unexpected data type: <nil>, expected string or []byte");
+    if (key.repr == TFGPU_R_BYTES) tf::column_messages(*b, key, true, &k, key_start, key_nil, cap, &nk);
+    else {  // every producer passes a []byte; a null is MakeRawMessage's typed nil — anything else fails the `.([]byte)` assertion (mirror.go:74)
+      std::vector<uint8_t> bm((size_t)(b->nrows + 7) / 8, 0);
+      if (key.validity && b->nrows) { tf::d2h(bm.data(), key.validity->p, bm.size()); tf::sync(); }
+      for (int64_t r = 0; r < b->nrows; r++) if (!key.validity || ((bm[(size_t)r >> 3] >> (r & 7)) & 1)) return tf::fail(TFGPU_ERR_INVALID, "interface conversion: sequence_key is not []byte");
+      auto e = std::make_unique<tfgpu_dbuf>(); e->mem = tf::dalloc(64); e->size = 0; k = e.release();
+      for (int64_t r = 0; r <= b->nrows; r++) key_start[r] = 0;
+      for (int64_t r = 0; r < b->nrows; r++) key_nil[r] = 1;
+    }
+    *values = hv.release(); *keys = k; *nmsg = nv;
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
+
+// splitByTablePartID for one table (split.go:5-12): rows grouped by ChangeItem.PartID; Go maps iterate in no defined order — the groups
+// come out by first appearance.  order[nrows]: the rows, group after group, input order inside a group; group_rows / group_part_id per group.
+extern "C" int tfgpu_queue_part_groups(const tfgpu_dbatch *b, int32_t *order, int64_t *group_rows, uint32_t *group_part_id, int64_t cap, int64_t *ngroups) {
+  try {
+    if (!b || !order || !group_rows || !group_part_id || !ngroups || cap < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_part_groups: bad argument");
+    tf::Context &cx = tf::ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    const int64_t n = b->nrows;
+    if (!b->part_id) { for (int64_t r = 0; r < n; r++) order[r] = (int32_t)r; group_rows[0] = n; group_part_id[0] = 0; *ngroups = 1; return TFGPU_OK; }
+    std::vector<uint32_t> pid((size_t)n);
+    if (n) { tf::d2h(pid.data(), b->part_id->p, (size_t)n * 4); tf::sync(); }
+    std::vector<uint32_t> ids; std::vector<std::vector<int32_t>> rows;
+    for (int64_t r = 0; r < n; r++) {
+      size_t g = 0;
+      while (g < ids.size() && ids[g] != pid[(size_t)r]) g++;
+      if (g == ids.size()) { if ((int64_t)g >= cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_part_groups: more groups than the arrays hold"); ids.push_back(pid[(size_t)r]); rows.emplace_back(); }
+      rows[g].push_back((int32_t)r);
+    }
+    int64_t at = 0;
+    for (size_t g = 0; g < ids.size(); g++) { group_rows[g] = (int64_t)rows[g].size(); group_part_id[g] = ids[g]; for (int32_t r : rows[g]) order[at++] = r; }
+    *ngroups = (int64_t)ids.size();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
+
+// kafka-go's Hash balancer with its default hasher (balancer.go:153-181; Sarama's hashPartitioner): FNV-1a(32) of the key, taken as an
+// int32, Go's truncated remainder, a negative result negated.  -1: a nil key (round robin there).
+extern "C" int32_t tfgpu_kafka_hash_partition(const void *key, int64_t len, int32_t npartitions) {
+  if (!key || len < 0 || npartitions <= 0) return -1;
+  uint32_t h = 0x811C9DC5u;
+  for (int64_t i = 0; i < len; i++) h = (h ^ ((const uint8_t *)key)[i]) * 0x01000193u;
+  int32_t p = (int32_t)h % npartitions;
+  return p < 0 ? -p : p;
+}
+namespace tf {
+__global__ void __launch_bounds__(256) kafka_partition_kernel(const uint32_t *off, const uint8_t *data, const uint8_t *validity, int64_t n, int32_t np, int32_t *out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  if (validity && !((validity[r >> 3] >> (r & 7)) & 1)) { out[r] = -1; return; }
+  uint32_t h = 0x811C9DC5u;
+  for (uint32_t i = off[r]; i < off[r + 1]; i++) h = (h ^ data[i]) * 0x01000193u;
+  const int32_t p = (int32_t)h % np;
+  out[r] = p < 0 ? -p : p;
+}
+}  // namespace tf
+// … for a column of keys at once (the Mirror serializer's `sequence_key`, a RawColumn key column): partitions[r], -1 for a nil key
+extern "C" int tfgpu_kafka_partitions(const tfgpu_dbatch *b, const char *key_column, int32_t npartitions, int32_t *partitions) {
+  try {
+    if (!b || !key_column || !partitions || npartitions <= 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_kafka_partitions: bad argument");
+    tf::Context &cx = tf::ctx();
+    std::lock_guard<std::mutex> lk(cx.mu);
+    const tf::DColumn *c = nullptr;
+    for (auto &x : b->cols) if (x.name == key_column) { c = &x; break; }
+    if (!c) return tf::fail(TFGPU_ERR_INVALID, std::string("tfgpu_kafka_partitions: no column ") + key_column);
+    if (c->repr != TFGPU_R_STRING && c->repr != TFGPU_R_BYTES) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_kafka_partitions: the key column holds no bytes");
+    tf::materialize(*b);
+    const int64_t n = b->nrows;
+    if (!n) return TFGPU_OK;
+    tf::Buf out = tf::dalloc((size_t)n * 4);
+    tf::kafka_partition_kernel<<<(unsigned)((n + 255) / 256), 256, 0, cx.stream>>>(tf::ptr<uint32_t>(c->offsets), tf::ptr<uint8_t>(c->payload()), tf::ptr<uint8_t>(c->validity), n, npartitions, tf::ptr<int32_t>(out));
+    tf::d2h(partitions, out->p, (size_t)n * 4);
+    tf::sync();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
+
+// ======================================================================================================
 // tfgpu_queue_serialize — pkg/serializer/queue: NativeSerializer / JSONSerializer for one table's rows.
 // Same four passes as tfgpu_serialize_ex over a longer cell list (header, constants, values, old-key values, trailer);
 // between the length pass and the scan the element lengths go to the host once, where BatchNative / BatchJSON's greedy
