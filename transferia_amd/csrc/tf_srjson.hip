@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(256) sr_mark_special(Params p, const OutCol *c
   const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool special = false;
   if (r < p.nrows) sr_plain_src(p, cols[text_cols[t]], text_cols[t], r, &special);
-  if (__any(special) && (threadIdx.x & 63) == 0) atomicOr(&spec[t], 1u);
+  if (__any(special) && (threadIdx.x & 63) == 0 && !__atomic_load_n(&spec[t], __ATOMIC_RELAXED)) atomicOr(&spec[t], 1u);  // (a flag that is up is seen by a plain L2 read: no atomic per wave)
 }
 __global__ void __launch_bounds__(256) sr_copy_words(Params p, const OutCol *cols, const int32_t *text_cols) {
   __shared__ uint32_t doff[256 + 1];
