@@ -887,9 +887,13 @@ __device__ __forceinline__ uint32_t dbz_plain_src(const Params &p, int j, int64_
   return SEG_NONE;
 }
 __global__ void __launch_bounds__(256) dbz_mark_special(Params p, const int32_t *text_cols, uint32_t *spec) {
-  const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int RPT = 16;  // rows per lane (a lane that looks at one cell and leaves makes the launch dispatch-bound)
+  const int t = (int)blockIdx.y;
   bool special = false;
-  if (r < p.nrows) dbz_plain_src(p, text_cols[t], r, &special);
+  for (int k = 0; k < RPT; k++) {
+    const int64_t r = ((int64_t)blockIdx.x * RPT + k) * 256 + threadIdx.x;
+    if (r < p.nrows) dbz_plain_src(p, text_cols[t], r, &special);
+  }
   if (__any(special) && (threadIdx.x & 63) == 0 && !__atomic_load_n(&spec[t], __ATOMIC_RELAXED)) atomicOr(&spec[t], 1u);  // (a flag that is up is seen by a plain L2 read: no atomic per wave)
 }
 __global__ void __launch_bounds__(256) dbz_copy_words(Params p, const OutCol *cols, const int32_t *text_cols) {
@@ -1314,7 +1318,7 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     const uint32_t *tot = d2h_u32(totals->p, (size_t)ntext);   // one read-back for all the text columns' sizes, one block for their bytes
     static const bool words = [] { const char *e = std::getenv("TFGPU_DBZ_COPY_WORDS"); return !(e && e[0] == '0'); }();  // 0: A/B runs
     Buf spec = dalloc_zero((size_t)ntext * 4), btc0 = upload_small(text_cols.data(), text_cols.size() * 4);
-    if (nrows && words) dbz::dbz_mark_special<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<int32_t>(btc0), ptr<uint32_t>(spec));
+    if (nrows && words) dbz::dbz_mark_special<<<dim3(dbz::nblk(nrows, 256 * 16), (unsigned)ntext), 256, 0, st>>>(p, ptr<int32_t>(btc0), ptr<uint32_t>(spec));
     const uint32_t *hspec = d2h_u32(spec->p, (size_t)ntext);
     tf::sync();
     size_t text_bytes = 0;

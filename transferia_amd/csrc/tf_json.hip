@@ -1875,12 +1875,14 @@ __global__ void __launch_bounds__(256) json_copy_cells(JParams jp, const JCopyCo
 // launched for the columns that need them, not for every (line, column) pair to find out that nearly all of them have nothing to do
 // (two such launches were 0.46 ms of the json step's 3.4).
 __global__ void __launch_bounds__(256) json_mark_special(const uint32_t *lens_all, int64_t seg_stride, const uint32_t *const *metas, int64_t nlines, uint32_t *spec) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int RPT = 16;  // rows per lane: a lane that looks at one cell and leaves makes the launch dispatch-bound (34 k workgroups: 0.2 ms)
   const int s = (int)blockIdx.y;
+  const uint32_t *off = lens_all + (int64_t)s * seg_stride, *meta = metas[s];
   uint32_t f = 0;
-  if (r < nlines) {
-    const uint32_t *off = lens_all + (int64_t)s * seg_stride;
-    if (off[r + 1] != off[r]) { const uint32_t mode = metas[s][r] >> 28; f = (mode == JM_ANYCANON || mode == JM_REST) ? 2u : mode != JM_COPY ? 1u : 0u; }
+#pragma unroll 4
+  for (int k = 0; k < RPT; k++) {
+    const int64_t r = ((int64_t)blockIdx.x * RPT + k) * 256 + threadIdx.x;
+    if (r < nlines && off[r + 1] != off[r]) { const uint32_t mode = meta[r] >> 28; f |= (mode == JM_ANYCANON || mode == JM_REST) ? 2u : mode != JM_COPY ? 1u : 0u; }
   }
   const uint32_t any = (__any(f & 1u) ? 1u : 0u) | (__any(f & 2u) ? 2u : 0u);
   // (one atomic per column, not per wave: a flag that is already up is seen by a plain L2 read — 134 k atomics on 33 words were 0.5 ms)
@@ -2328,7 +2330,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     std::vector<const uint32_t *> metas((size_t)nstr);
     for (int sg = 0; sg < nstr; sg++) metas[(size_t)sg] = sg == rest_seg ? pp.rest_meta : cols[(size_t)str_col_index[(size_t)sg]].meta;
     Buf bm = upload_small(metas.data(), metas.size() * sizeof(uint32_t *));
-    json_mark_special<<<dim3(jblocks(nlines, 256), (unsigned)nstr), 256, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, (const uint32_t *const *)bm->p, nlines, ptr<uint32_t>(spec));
+    json_mark_special<<<dim3(jblocks(nlines, 256 * 16), (unsigned)nstr), 256, 0, st>>>(ptr<uint32_t>(lens_all), seg_stride, (const uint32_t *const *)bm->p, nlines, ptr<uint32_t>(spec));
   }
   Buf summary = dalloc((size_t)(2 * nstr + nraw + 1) * 4);
   json_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), ptr<uint32_t>(lens_all), seg_stride, nlines, nstr, ptr<uint32_t>(has_nil), nraw, ptr<uint32_t>(spec), ptr<uint32_t>(summary));

@@ -542,8 +542,7 @@ struct OutCol {
 // when the schema has `any` properties) — the kernel every cell runs through does not carry the emitter's frame stack.
 template <bool CANON>
 // (grid: x = 256-row blocks, y = property: the property is a scalar — its descriptor comes by scalar loads, the switch on its JSON type is a scalar branch)
-__global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id) {
-  const int j = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void sr_cell_value_one(const Params &p, const OutCol *cols, int32_t *src_row, uint32_t *part_id, const int j, const int64_t r) {
   if (r >= p.nrows) return;
   const uint32_t f = p.row_frame[r];
   const OutCol &c = cols[j];
@@ -578,6 +577,17 @@ __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *co
     default: if (!(vtr & VT_CANON)) { CountSink s; if (!nil) emit_any(s, rd, vs, vl); c.lens[r] = s.n; }  // flagged cells: the CANON launch
   }
 }
+// SR_VALUES_RPT rows per lane: 2^18 rows x 105 properties at one cell per lane are 107 k workgroups that each do a handful of loads and
+// stores — the launch runs at the dispatcher's pace, not the memory's
+#ifndef TF_SR_VALUES_RPT
+#define TF_SR_VALUES_RPT 4
+#endif
+template <bool CANON>
+__global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id) {
+  const int j = (int)blockIdx.y;
+#pragma unroll
+  for (int k = 0; k < TF_SR_VALUES_RPT; k++) sr_cell_value_one<CANON>(p, cols, src_row, part_id, j, ((int64_t)blockIdx.x * TF_SR_VALUES_RPT + k) * 256 + threadIdx.x);
+}
 // The text cells that are a plain byte range of the message — number tokens, strings without escapes: nearly all of them — are
 // packed destination-centrically (tf_segcopy.hpp: a lane owns aligned 8-byte words of the column's payload and pulls their bytes
 // from the messages; a wave stores 512 contiguous bytes); the other cells are zero-filled here and written by sr_cell_text, which
@@ -595,9 +605,13 @@ __device__ __forceinline__ uint32_t sr_plain_src(const Params &p, const OutCol &
   return SEG_NONE;
 }
 __global__ void __launch_bounds__(256) sr_mark_special(Params p, const OutCol *cols, const int32_t *text_cols, uint32_t *spec) {
-  const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int RPT = 16;  // rows per lane (a lane that looks at one cell and leaves makes the launch dispatch-bound)
+  const int t = (int)blockIdx.y;
   bool special = false;
-  if (r < p.nrows) sr_plain_src(p, cols[text_cols[t]], text_cols[t], r, &special);
+  for (int k = 0; k < RPT; k++) {
+    const int64_t r = ((int64_t)blockIdx.x * RPT + k) * 256 + threadIdx.x;
+    if (r < p.nrows) sr_plain_src(p, cols[text_cols[t]], text_cols[t], r, &special);
+  }
   if (__any(special) && (threadIdx.x & 63) == 0 && !__atomic_load_n(&spec[t], __ATOMIC_RELAXED)) atomicOr(&spec[t], 1u);  // (a flag that is up is seen by a plain L2 read: no atomic per wave)
 }
 __global__ void __launch_bounds__(256) sr_copy_words(Params p, const OutCol *cols, const int32_t *text_cols) {
@@ -845,8 +859,8 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     sr::sr_row_frames<<<sr::nblk(nf, 256), 256, 0, st>>>(p);
     if (np) {
       KernelTimer t("sr_cell_values");
-      sr::sr_cell_values<false><<<dim3(sr::nblk(nrows, 256), (unsigned)np), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
-      if (has_any) sr::sr_cell_values<true><<<dim3(sr::nblk(nrows, 256), (unsigned)np), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
+      sr::sr_cell_values<false><<<dim3(sr::nblk(nrows, 256 * TF_SR_VALUES_RPT), (unsigned)np), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
+      if (has_any) sr::sr_cell_values<true><<<dim3(sr::nblk(nrows, 256 * TF_SR_VALUES_RPT), (unsigned)np), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
     }
     if (np) sr::sr_pack_validity<<<sr::nblk((int64_t)np * ((nrows + 7) / 8), 256), 256, 0, st>>>(ptr<sr::OutCol>(boc), np, nrows);
   }
@@ -859,7 +873,7 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     // a third of the text (Cyrillic titles, strings with escapes) is not VT_PLAIN and still takes the walkers, and the marking pass re-reads the value records
     static const bool words = [] { const char *e = std::getenv("TFGPU_SR_COPY_WORDS"); return e && e[0] == '1'; }();
     Buf spec = dalloc_zero((size_t)ntext * 4), btc0 = upload_small(text_cols.data(), text_cols.size() * 4);
-    if (nrows && words) sr::sr_mark_special<<<dim3(sr::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc0), ptr<uint32_t>(spec));
+    if (nrows && words) sr::sr_mark_special<<<dim3(sr::nblk(nrows, 256 * 16), (unsigned)ntext), 256, 0, st>>>(p, ptr<sr::OutCol>(boc), ptr<int32_t>(btc0), ptr<uint32_t>(spec));
     const uint32_t *hspec = d2h_u32(spec->p, (size_t)ntext);
     tf::sync();
     for (int t = 0; t < ntext; t++) {
