@@ -577,10 +577,11 @@ __device__ __forceinline__ void sr_cell_value_one(const Params &p, const OutCol 
     default: if (!(vtr & VT_CANON)) { CountSink s; if (!nil) emit_any(s, rd, vs, vl); c.lens[r] = s.n; }  // flagged cells: the CANON launch
   }
 }
-// SR_VALUES_RPT rows per lane: 2^18 rows x 105 properties at one cell per lane are 107 k workgroups that each do a handful of loads and
-// stores — the launch runs at the dispatcher's pace, not the memory's
+// TF_SR_VALUES_RPT rows per lane.  1: measured on the MI355X (gpurun r07r, 2^18 rows x 105 properties) four rows per lane take 0.65 ms
+// against 0.36 for one — the cell's dependent loads (row → frame → value record → converted value) do not overlap across the unrolled
+// rows the way they do across lanes; the launch is not dispatch-bound, unlike the marking kernels
 #ifndef TF_SR_VALUES_RPT
-#define TF_SR_VALUES_RPT 4
+#define TF_SR_VALUES_RPT 1
 #endif
 template <bool CANON>
 __global__ void __launch_bounds__(256) sr_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id) {
