@@ -112,10 +112,41 @@ def test_integer_kinds_convert_with_gos_rules(tf, oracle):
         assert ei.value.code == tf.ERR_INVALID and ei.value.bad == (9, bad_col)
 
 
+def test_numbers_bools_and_times_under_text_types(tf, oracle):
+    """castx.ToStringE of an integer kind / bool / time.Time / time.Duration (caste.go:58-106): strconv's decimal text, FormatBool,
+    Time.String(), Duration.String(); castx.ToByteSliceE (:16-28) takes []byte and string only — anything else fails the call at its
+    first value."""
+    schema = abi.Schema.of([["a", "utf8"], ["b", "utf8"], ["c", "utf8"], ["d", "utf8"], ["e", "utf8"], ["f", "utf8"], ["k", "int32"]])
+    names = [c.name for c in schema.cols]
+    rng = np.random.default_rng(11)
+    rows = [[["int64", int(rng.integers(-(1 << 62), 1 << 62))], ["uint64", int(rng.integers(0, 1 << 63)) * 2 + 1], ["int8", int(rng.integers(-128, 128))], ["bool", bool(r & 1)],
+             ["time", "20%02d-%02d-%02dT%02d:%02d:%02d.%09dZ" % (rng.integers(0, 99), rng.integers(1, 13), rng.integers(1, 29), rng.integers(0, 24), rng.integers(0, 60), rng.integers(0, 60), rng.integers(0, 10 ** 9) if r % 3 else 0)],
+             ["string", "already text %d" % r], ["int32", r]] for r in range(700)]
+    rows[5][0] = ["nil", None]; rows[9][3] = ["nil", None]; rows[11][4] = ["nil", None]
+    host = abi.batch_from_rows(schema, names, rows, "db", "t")
+    ref = oracle.strictify(host, schema)
+    assert not ref.errors
+    out = tf.strictify(tf.DeviceBatch.upload(host), schema).download()
+    assert_batches_equal(out, ref.batch, "to text")
+    assert out.col("a").repr == abi.R_STRING and out.col("a").get_bytes(0) == str(rows[0][0][1]).encode() and out.col("d").get_bytes(1) == b"true"
+    # under "string" ([]byte): the first value of the integer column fails the call; a column of nils does not
+    bschema = abi.Schema.of([["a", "string"], ["k", "int32"]])
+    hb = abi.batch_from_rows(bschema, ["a", "k"], [[["nil", None], ["int32", 0]], [["int64", 7], ["int32", 1]], [["int64", 8], ["int32", 2]]], "db", "t")
+    rb = oracle.strictify(hb, bschema)
+    assert rb.errors and rb.errors[0][0] == 1
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.strictify(tf.DeviceBatch.upload(hb), bschema)
+    assert ei.value.code == tf.ERR_INVALID and ei.value.bad == (1, 0)
+    nils = abi.batch_from_rows(bschema, ["a", "k"], [[["nil", None], ["int32", 0]], [["nil", None], ["int32", 1]]], "db", "t")
+    nils.cols[0] = abi.Column("a", "string", abi.R_INT64, values=np.zeros(2, np.int64), validity=np.zeros(2, bool))
+    o2 = tf.strictify(tf.DeviceBatch.upload(nils), bschema).download()
+    assert o2.col("a").repr == abi.R_BYTES and [o2.col("a").pyvalue(i) for i in range(2)] == [["nil", None]] * 2
+
+
 def test_pairs_left_to_the_host_are_refused_by_name(tf):
     schema = abi.Schema.of([["a", "utf8"]])
-    host = abi.batch_from_rows(schema, ["a"], [[["int64", 5]], [["int64", 6]]], "db", "t")
-    with pytest.raises(tf.TfgpuError) as ei:   # castx.ToStringE(int64): the convert_to_string transformer's kernels, not strictify's
+    host = abi.batch_from_rows(schema, ["a"], [[["float64", 5.5]], [["float64", 6.25]]], "db", "t")
+    with pytest.raises(tf.TfgpuError) as ei:   # castx.ToStringE(float64) is FormatFloat(f, 'f', -1, 64): the serializers print it, strictify hands it back
         tf.strictify(tf.DeviceBatch.upload(host), schema)
     assert ei.value.code == tf.ERR_UNSUPPORTED and "column a" in str(ei.value)
     # a column the schema does not name is left alone

@@ -2690,7 +2690,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
 // ======================================================================================================
 namespace tf {
 
-enum StrictMode : int32_t { SM_TEXT = 1, SM_TEXT_JSONNUM_OUT = 2, SM_INTS = 3, SM_JSONNUM_TO_TIME = 4 };
+enum StrictMode : int32_t { SM_TEXT = 1, SM_TEXT_JSONNUM_OUT = 2, SM_INTS = 3, SM_JSONNUM_TO_TIME = 4, SM_FAIL = 5 /* no conversion exists: every value fails */ };
+DColumn column_to_text(const DColumn &c, int64_t n, bool to_bytes);  // tf_transform.hip: fmt's %v of integers, bools, time.Time, time.Duration = their strconv / String() forms
 struct StrictCol {
   int32_t mode, src_repr;
   const void *values; const uint32_t *offsets; const uint8_t *data; const uint8_t *validity;
@@ -2717,9 +2718,10 @@ __global__ void __launch_bounds__(256) strictify_cells(CsvOpts o, const StrictCo
   const int32_t j = (int32_t)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the column is the grid's y: a scalar)
   if (r >= nrows || j >= ncols) return;
   const StrictCol &c = cols[j];
-  if (c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) { if (c.mode != SM_TEXT_JSONNUM_OUT) store_default(c.out, r); return; }  // nil stays nil
+  if (c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) { if (c.mode != SM_TEXT_JSONNUM_OUT && c.mode != SM_FAIL) store_default(c.out, r); return; }  // nil stays nil
   int rc = 0;
-  if (c.mode == SM_INTS) {
+  if (c.mode == SM_FAIL) rc = TFGPU_ROW_CAST;  // castx.ToByteSliceE of anything but []byte / string: "no known conversion"
+  else if (c.mode == SM_INTS) {
     int64_t v = 0; uint64_t u = 0; bool uns = false;
     strict_load_int(c, r, &v, &u, &uns);
     switch (c.out.kind) {
@@ -2767,6 +2769,7 @@ extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schem
   };
   auto r = std::make_unique<tfgpu_dbatch>(*in);  // shares every buffer; converted columns are replaced below
   std::vector<StrictCol> sc; std::vector<int> which;
+  std::vector<size_t> to_text;  // columns whose strict form is their text (castx.ToStringE of a number / bool / time): made after the checks, they cannot fail
   bool need_p128 = false;
   for (size_t i = 0; i < in->cols.size(); i++) {
     const DColumn &c = in->cols[i];
@@ -2810,13 +2813,22 @@ extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schem
       if (c.repr == TFGPU_R_JSONNUM && oc.kind == CK_INTERVAL) return unsupported();
       s.mode = (c.repr == TFGPU_R_JSONNUM && oc.kind == CK_DATE) ? SM_JSONNUM_TO_TIME : SM_TEXT;
       if (oc.kind == CK_F32) need_p128 = true;
+    } else if ((ints || c.repr == TFGPU_R_TIME || c.repr == TFGPU_R_DURATION) && dt == TFGPU_T_UTF8) {
+      to_text.push_back(i);  // castx.ToStringE (caste.go:58-106): FormatInt / FormatUint / FormatBool, Time.String(), Duration.String()
+      continue;
+    } else if ((ints || c.repr == TFGPU_R_TIME || c.repr == TFGPU_R_DURATION || c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) && dt == TFGPU_T_BYTES) {
+      s.mode = SM_FAIL;        // castx.ToByteSliceE (caste.go:16-28) takes []byte and string only: the first value fails the call
     } else if (ints) {
-      if (oc.kind == CK_STR || oc.kind == CK_JSONNUM) return unsupported();                 // castx.ToStringE of an integer: the convert_to_string kernels' job
+      if (oc.kind == CK_STR || oc.kind == CK_JSONNUM) return unsupported();                 // an integer under "double": castx.ToJSONNumberE of its text — host
       if (oc.kind == CK_INTERVAL && (c.repr >= TFGPU_R_UINT8 && c.repr <= TFGPU_R_UINT64)) return unsupported();
       if (c.repr == TFGPU_R_BOOL && (oc.kind == CK_DATE || oc.kind == CK_INTERVAL || oc.kind == CK_F32)) return unsupported();
       s.mode = SM_INTS;
     } else return unsupported();
-    if (s.mode != SM_TEXT_JSONNUM_OUT) {
+    if (s.mode == SM_FAIL) {  // reached only when every row is nil: an all-nil []byte column
+      d.values = nullptr; d.nanos = nullptr; d.view = nullptr; d.data_len = 0;
+      d.offsets = dalloc_zero((size_t)(n + 1) * 4 + 16); d.data = dalloc(16);
+      d.repr = strict;
+    } else if (s.mode != SM_TEXT_JSONNUM_OUT) {
       d.values = dalloc((size_t)std::max<int64_t>(n, 1) * (size_t)oc.width);
       d.offsets = nullptr; d.data = nullptr; d.view = nullptr; d.data_len = 0; d.nanos = nullptr;
       if (oc.kind == CK_DATE) d.nanos = dalloc((size_t)std::max<int64_t>(n, 1) * 4);
@@ -2863,6 +2875,12 @@ extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schem
         return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_strictify: row " + std::to_string(row) + ", column " + in->cols[(size_t)bcol].name + ": a value form the device does not decide (Go's decimal slow path, a free-form date): strictify this batch on the host");
       return tf::fail(TFGPU_ERR_INVALID, "failed to strictify the value of column [" + std::to_string(bcol) + "] \"" + in->cols[(size_t)bcol].name + "\": row " + std::to_string(row) + ": " + (code == TFGPU_ROW_RANGE ? "value is out of the type's range" : "unable to cast the value"));
     }
+  }
+  for (size_t i : to_text) {
+    const int dt = r->cols[i].dtype;
+    DColumn t = column_to_text(in->cols[i], n, false);
+    t.name = in->cols[i].name; t.dtype = dt;
+    r->cols[i] = std::move(t);
   }
   *out = r.release();
   return TFGPU_OK;

@@ -827,16 +827,19 @@ static std::unique_ptr<tfgpu_dbatch> apply_skip_events(const tfgpu_plan &p, cons
 // ============================================================================
 // a6 convert_to_string — to_string.go:58-97
 // ============================================================================
-__global__ void __launch_bounds__(256) tostring_len_kernel(DCol c, int64_t n, uint32_t *len) {
+// nil_empty: a nil value has no text (strictify leaves nil alone; convert_to_string prints "<nil>")
+__global__ void __launch_bounds__(256) tostring_len_kernel(DCol c, int64_t n, uint32_t *len, int nil_empty) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   uint8_t buf[64]; const uint8_t *ext;
+  if (nil_empty && c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) { len[r] = 0; return; }
   len[r] = (uint32_t)serialize_small(c, r, buf, &ext);
 }
-__global__ void __launch_bounds__(256) tostring_write_kernel(DCol c, int64_t n, const uint32_t *off, uint8_t *data) {
+__global__ void __launch_bounds__(256) tostring_write_kernel(DCol c, int64_t n, const uint32_t *off, uint8_t *data, int nil_empty) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   uint8_t buf[64]; const uint8_t *ext;
+  if (nil_empty && c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) return;
   int len = serialize_small(c, r, buf, &ext);
   uint8_t *dst = data + off[r];
   const uint8_t *src = ext ? ext : buf;
@@ -846,23 +849,25 @@ __global__ void __launch_bounds__(256) tostring_write_kernel(DCol c, int64_t n, 
   for (; i < len; i++) dst[i] = src[i];
 }
 
-static DColumn column_to_string(const DColumn &c, int64_t n, bool to_bytes, int max_len_hint) {
+static DColumn column_to_string(const DColumn &c, int64_t n, bool to_bytes, int max_len_hint, int nil_empty = 0) {
   hipStream_t st = ctx().stream;
   DColumn o;
   o.name = c.name; o.dtype = to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8; o.repr = to_bytes ? TFGPU_R_BYTES : TFGPU_R_STRING;
   o.offsets = dalloc((size_t)(n + 1) * 4);
   DCol dc = dcol_of(c);  // callers materialise text columns first
   KernelTimer t("to_string");
-  if (n) tostring_len_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets));
+  if (n) tostring_len_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets), nil_empty);
   exclusive_scan_u32(ptr<uint32_t>(o.offsets), ptr<uint32_t>(o.offsets), n, true);
   uint64_t cap = repr_is_var(c.repr) ? c.data_len + (uint64_t)n * 5 : (uint64_t)n * (uint64_t)max_len_hint;
   o.data = dalloc(cap);
-  if (n) tostring_write_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data));
+  if (n) tostring_write_kernel<<<grid_for(n, 256), 256, 0, st>>>(dc, n, ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data), nil_empty);
   const uint32_t *tot = d2h_u32(ptr<uint32_t>(o.offsets) + n);
   sync();
   o.data_len = *tot;
   return o;
 }
+
+DColumn column_to_text(const DColumn &c, int64_t n, bool to_bytes) { DColumn o = column_to_string(c, n, to_bytes, 64, 1); o.validity = c.validity; return o; }  // for tfgpu_strictify (tf_csv.hip)
 
 static std::unique_ptr<tfgpu_dbatch> apply_to_string(const tfgpu_plan &p, const tfgpu_dbatch &in) {
   if (p.skip_utc) {
