@@ -306,7 +306,7 @@ static int cast_string_to_date(const char *s, size_t n, int64_t *sec, int32_t *n
 
 /* castx.ToStringE caste.go:58-106 for the dynamic types we carry */
 static char *castx_to_string(const ora_value *v, size_t *len) {
-  char b[64]; size_t n;
+  char b[512]; size_t n;  /* FormatFloat(f, 'f', -1, 64) of 5e-324 is 326 bytes, of MaxFloat64 309 */
   switch (v->kind) {
     case OV_STRING: case OV_JSONNUM: case OV_BYTES: *len = v->slen; return dupn(v->s, v->slen);
     case OV_BOOL: return v->v.b ? (*len = 4, dups("true")) : (*len = 5, dups("false"));

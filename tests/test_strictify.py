@@ -143,10 +143,42 @@ def test_numbers_bools_and_times_under_text_types(tf, oracle):
     assert o2.col("a").repr == abi.R_BYTES and [o2.col("a").pyvalue(i) for i in range(2)] == [["nil", None]] * 2
 
 
+def test_go_floats_under_every_numeric_and_text_type(tf, oracle):
+    """A Go float64 / float32 value: FormatFloat(f, 'f', -1, bits) under "utf8" and (castx.ToJSONNumberE) as the json.Number of "double";
+    int64(f) / uint64(f) with toSignedInt / toUnsignedInt's limits, f != 0, float32(f) under the numeric types."""
+    import struct
+    schema = abi.Schema.of([["s", "utf8"], ["d", "double"], ["i", "int32"], ["u", "uint16"], ["b", "boolean"], ["f", "float"], ["t", "utf8"], ["k", "int32"]])
+    names = [c.name for c in schema.cols]
+    rng = np.random.default_rng(17)
+    specials = [0.0, -0.0, 1.0, 0.1, 1e21, 1e-7, 123456789.125, 5e-324, 1.7976931348623157e308, float("inf"), float("-inf"), float("nan"), 4.35, 1e15, 0.000001]
+    rows = []
+    for r in range(600):
+        x = specials[r] if r < len(specials) else struct.unpack("<d", struct.pack("<Q", int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))))[0] if r % 3 == 0 else float(rng.uniform(-1e6, 1e6))
+        y = float(np.float32(rng.uniform(-3e4, 3e4)))
+        rows.append([["float64", x], ["float64", x], ["float64", float(rng.uniform(-2e9, 2e9))], ["float32", float(np.float32(rng.uniform(0, 65000)))], ["float64", float(r % 3)],
+                     ["float64", x if x == x and abs(x) < 3e38 else 1.5], ["float32", y], ["int32", r]])
+    rows[20][2] = ["nil", None]; rows[21][0] = ["nil", None]; rows[22][1] = ["nil", None]
+    host = abi.batch_from_rows(schema, names, rows, "db", "t")
+    ref = oracle.strictify(host, schema)
+    assert not ref.errors
+    out = tf.strictify(tf.DeviceBatch.upload(host), schema).download()
+    assert_batches_equal(out, ref.batch, "floats")
+    assert out.col("s").get_bytes(4) == b"1000000000000000000000" and out.col("s").get_bytes(9) == b"+Inf" and out.col("d").repr == abi.R_JSONNUM
+    for bad_col, v, code in [(2, ["float64", 3e9], tf.ERR_INVALID), (3, ["float32", -1.0], tf.ERR_INVALID), (3, ["float32", 70000.0], tf.ERR_INVALID), (2, ["float64", float("nan")], tf.ERR_UNSUPPORTED)]:
+        rows2 = [list(x) for x in rows]
+        rows2[33][bad_col] = v
+        h2 = abi.batch_from_rows(schema, names, rows2, "db", "t")
+        with pytest.raises(tf.TfgpuError) as ei:
+            tf.strictify(tf.DeviceBatch.upload(h2), schema)
+        assert ei.value.code == code and ei.value.bad == (33, bad_col), (v, str(ei.value))
+        if code == tf.ERR_INVALID:
+            assert oracle.strictify(h2, schema).errors[0][0] == 33
+
+
 def test_pairs_left_to_the_host_are_refused_by_name(tf):
-    schema = abi.Schema.of([["a", "utf8"]])
+    schema = abi.Schema.of([["a", "interval"]])
     host = abi.batch_from_rows(schema, ["a"], [[["float64", 5.5]], [["float64", 6.25]]], "db", "t")
-    with pytest.raises(tf.TfgpuError) as ei:   # castx.ToStringE(float64) is FormatFloat(f, 'f', -1, 64): the serializers print it, strictify hands it back
+    with pytest.raises(tf.TfgpuError) as ei:   # cast.ToDurationE(float64): not restated
         tf.strictify(tf.DeviceBatch.upload(host), schema)
     assert ei.value.code == tf.ERR_UNSUPPORTED and "column a" in str(ei.value)
     # a column the schema does not name is left alone

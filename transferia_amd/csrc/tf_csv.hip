@@ -23,6 +23,7 @@
 
 #include "tf_devfmt.hpp"
 #include "tf_devparse.hpp"
+#include "tf_devfloat.hpp"
 #include "tf_segcopy.hpp"
 #include "tf_textview.hpp"
 #include "tf_wave.hpp"
@@ -2690,7 +2691,8 @@ extern "C" int tfgpu_csv_parse(const tfgpu_csv_options *opts, const tfgpu_schema
 // ======================================================================================================
 namespace tf {
 
-enum StrictMode : int32_t { SM_TEXT = 1, SM_TEXT_JSONNUM_OUT = 2, SM_INTS = 3, SM_JSONNUM_TO_TIME = 4, SM_FAIL = 5 /* no conversion exists: every value fails */ };
+enum StrictMode : int32_t { SM_TEXT = 1, SM_TEXT_JSONNUM_OUT = 2, SM_INTS = 3, SM_JSONNUM_TO_TIME = 4, SM_FAIL = 5 /* no conversion exists: every value fails */,
+                            SM_FLOATS = 6 /* Go float64 / float32 values under integer / bool / float DataTypes */ };
 DColumn column_to_text(const DColumn &c, int64_t n, bool to_bytes);  // tf_transform.hip: fmt's %v of integers, bools, time.Time, time.Duration = their strconv / String() forms
 struct StrictCol {
   int32_t mode, src_repr;
@@ -2721,6 +2723,24 @@ __global__ void __launch_bounds__(256) strictify_cells(CsvOpts o, const StrictCo
   if (c.validity && !((c.validity[r >> 3] >> (r & 7)) & 1)) { if (c.mode != SM_TEXT_JSONNUM_OUT && c.mode != SM_FAIL) store_default(c.out, r); return; }  // nil stays nil
   int rc = 0;
   if (c.mode == SM_FAIL) rc = TFGPU_ROW_CAST;  // castx.ToByteSliceE of anything but []byte / string: "no known conversion"
+  else if (c.mode == SM_FLOATS) {
+    // cast.ToInt64E / ToUint64E / ToBoolE / ToFloat32E of a float: Go conversions (caste.go of spf13/cast); what a conversion of a NaN or of a
+    // magnitude beyond the integer range yields is the machine's business, so those go back to the host
+    const double f = c.src_repr == TFGPU_R_FLOAT32 ? (double)((const float *)c.values)[r] : ((const double *)c.values)[r];
+    switch (c.out.kind) {
+      case CK_INT:
+        if (!(f > -9223372036854775808.0 && f < 9223372036854775808.0)) rc = TFGPU_ROW_HOST_FALLBACK;
+        else { const int64_t x = (int64_t)f; if (x < c.out.lo || x > (int64_t)c.out.hi) rc = TFGPU_ROW_RANGE; else store_int(c.out, r, x); }
+        break;
+      case CK_UINT:
+        if (f != f || f >= 18446744073709551616.0) rc = TFGPU_ROW_HOST_FALLBACK;
+        else if (f < 0) rc = TFGPU_ROW_CAST;  // errNegativeNotAllowed
+        else { const uint64_t x = (uint64_t)f; if (x > c.out.hi) rc = TFGPU_ROW_RANGE; else if (c.out.width == 8) ((uint64_t *)c.out.values)[r] = x; else store_int(c.out, r, (int64_t)x); }
+        break;
+      case CK_BOOL: ((uint8_t *)c.out.values)[r] = f != 0 ? 1 : 0; break;
+      default: ((float *)c.out.values)[r] = (float)f;  // CK_F32
+    }
+  }
   else if (c.mode == SM_INTS) {
     int64_t v = 0; uint64_t u = 0; bool uns = false;
     strict_load_int(c, r, &v, &u, &uns);
@@ -2750,6 +2770,34 @@ __global__ void __launch_bounds__(256) strictify_cells(CsvOpts o, const StrictCo
   if (rc) atomicMin(&first_bad[j], ((unsigned long long)r << 8) | (unsigned long long)rc);
 }
 
+// castx.ToStringE of a Go float (caste.go:64-67): strconv.FormatFloat(f, 'f', -1, bits) — the text of a "utf8" column, and (through
+// castx.ToJSONNumberE) the json.Number of a "double" one
+__global__ void __launch_bounds__(256) strict_float_text(const void *values, int is32, const uint8_t *validity, int64_t n, uint32_t *off, uint8_t *data) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const bool nil = validity && !((validity[r >> 3] >> (r & 7)) & 1);
+  const double f = is32 ? (double)((const float *)values)[r] : ((const double *)values)[r];
+  if (!data) { dev::CountOut c; if (!nil) dev::fmt_float(c, f, 'f', is32 ? 32 : 64); off[r] = c.n; return; }
+  if (nil) return;
+  dev::StoreOut o{data + off[r]};
+  dev::fmt_float(o, f, 'f', is32 ? 32 : 64);
+}
+static DColumn float_column_text(const DColumn &c, int64_t n) {
+  hipStream_t st = ctx().stream;
+  DColumn o;
+  o.offsets = dalloc((size_t)(n + 1) * 4 + 16);
+  const int is32 = c.repr == TFGPU_R_FLOAT32;
+  if (n) strict_float_text<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(c.values->p, is32, ptr<uint8_t>(c.validity), n, ptr<uint32_t>(o.offsets), nullptr);
+  exclusive_scan_u32(ptr<uint32_t>(o.offsets), ptr<uint32_t>(o.offsets), n, true);
+  const uint32_t *tot = d2h_u32(ptr<uint32_t>(o.offsets) + n);
+  tf::sync();
+  o.data_len = *tot;
+  o.data = dalloc((size_t)o.data_len + 16);
+  if (n) strict_float_text<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(c.values->p, is32, ptr<uint8_t>(c.validity), n, ptr<uint32_t>(o.offsets), ptr<uint8_t>(o.data));
+  o.validity = c.validity;
+  return o;
+}
+
 }  // namespace tf
 
 extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_dbatch **out, int64_t *bad_row, int32_t *bad_col) {
@@ -2769,6 +2817,7 @@ extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schem
   };
   auto r = std::make_unique<tfgpu_dbatch>(*in);  // shares every buffer; converted columns are replaced below
   std::vector<StrictCol> sc; std::vector<int> which;
+  std::vector<size_t> float_text;  // Go floats under "utf8" / "double": FormatFloat 'f'
   std::vector<size_t> to_text;  // columns whose strict form is their text (castx.ToStringE of a number / bool / time): made after the checks, they cannot fail
   bool need_p128 = false;
   for (size_t i = 0; i < in->cols.size(); i++) {
@@ -2818,6 +2867,11 @@ extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schem
       continue;
     } else if ((ints || c.repr == TFGPU_R_TIME || c.repr == TFGPU_R_DURATION || c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) && dt == TFGPU_T_BYTES) {
       s.mode = SM_FAIL;        // castx.ToByteSliceE (caste.go:16-28) takes []byte and string only: the first value fails the call
+    } else if ((c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) && (dt == TFGPU_T_UTF8 || dt == TFGPU_T_FLOAT64)) {
+      float_text.push_back(i);  // FormatFloat(f, 'f', -1, bits): the string, or — every such text parses (fastfloat takes "NaN" and "+Inf" too) — the json.Number
+      continue;
+    } else if ((c.repr == TFGPU_R_FLOAT32 || c.repr == TFGPU_R_FLOAT64) && (oc.kind == CK_INT || oc.kind == CK_UINT || oc.kind == CK_BOOL || oc.kind == CK_F32)) {
+      s.mode = SM_FLOATS;
     } else if (ints) {
       if (oc.kind == CK_STR || oc.kind == CK_JSONNUM) return unsupported();                 // an integer under "double": castx.ToJSONNumberE of its text — host
       if (oc.kind == CK_INTERVAL && (c.repr >= TFGPU_R_UINT8 && c.repr <= TFGPU_R_UINT64)) return unsupported();
@@ -2875,6 +2929,12 @@ extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schem
         return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_strictify: row " + std::to_string(row) + ", column " + in->cols[(size_t)bcol].name + ": a value form the device does not decide (Go's decimal slow path, a free-form date): strictify this batch on the host");
       return tf::fail(TFGPU_ERR_INVALID, "failed to strictify the value of column [" + std::to_string(bcol) + "] \"" + in->cols[(size_t)bcol].name + "\": row " + std::to_string(row) + ": " + (code == TFGPU_ROW_RANGE ? "value is out of the type's range" : "unable to cast the value"));
     }
+  }
+  for (size_t i : float_text) {
+    const int dt = r->cols[i].dtype;
+    DColumn t = float_column_text(in->cols[i], n);
+    t.name = in->cols[i].name; t.dtype = dt; t.repr = dt == TFGPU_T_FLOAT64 ? TFGPU_R_JSONNUM : TFGPU_R_STRING;
+    r->cols[i] = std::move(t);
   }
   for (size_t i : to_text) {
     const int dt = r->cols[i].dtype;
