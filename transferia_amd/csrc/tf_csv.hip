@@ -351,6 +351,10 @@ struct CsvParams {
   int32_t force_general;       // TFGPU_CSV_GENERAL=1: every tile takes the general kernel (parity cross-check of the two)
   const struct CsvRun *runs;   // tcols grouped into runs of one (kind, width)
   int32_t nruns;
+  // column-lane cell phase (csv_parse_regular): runs cut into tasks of at most 64 columns, each given to one wave
+  const struct CsvTask *tasks; // sorted by wave
+  const int32_t *wave_task;    // [9]: tasks of wave w are [wave_task[w], wave_task[w + 1])
+  int32_t col_lanes;           // 1: the cells run column-lane; 0: the item form (slots of 64 (column, line) items)
   // csv_parse_lanes (lane = line): the column buffers as 4-byte offsets into one arena, dealt to the 16 waves in blocks
   uint8_t *arena;
   const uint32_t *lcols;       // [16 waves][64]: word 4 s + w of wave v = word w of its s-th column {p0 offset, p1 offset, field:16 | kind:8 | width:8, -}
@@ -1229,6 +1233,7 @@ static constexpr int CR_FCAP = 4608;   // field ends the regular kernel indexes 
 static constexpr int CR_LCOLS = 128;   // columns whose descriptors it stages in LDS
 static constexpr uint32_t CR_KDUMMY = CR_FCAP + 2;  // index slot of the empty field idle lanes read
 struct CsvRun { int32_t kind, width, first, ncols; };  // consecutive tcols of one (kind, width); kind -1: DefaultValue columns (no field)
+struct CsvTask { int32_t kind, width, first, ncols; };  // a piece of a run of the fast kinds (integers, text, date / timestamp): ncols <= 64
 
 // what the cell loops of csv_parse_regular share
 struct RegTile {
@@ -1275,95 +1280,132 @@ __device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint
   return cb - ca;
 }
 
+// one integer cell (c: its line, byte range, output row) of a column whose values live at `out`; every lane of the wave calls it
+template <int KIND, int W, class T> __device__ __forceinline__ void reg_int_body(const RegTile &t, const RegCell &c, T *const out) {
+  constexpr uint32_t FASTD = W < 4 ? 5u : 8u;  // digits the first tier takes (more cannot fit / need a second window)
+  const uint32_t n = c.fend - c.fs;
+  if (t.ablate != 31 && wave_all(n - 1u < 4u || !c.on)) {
+    // tier A: one to four characters, an unsigned canonical decimal — the common cell of a flag / small-integer column.  One
+    // aligned LDS word pair holds the field's bytes [fend - 4, fend); masks come from shifts (an LDS table read costs the CU
+    // as much as six VALU instructions), the leading-zero rule from the first character in byte 0.
+    const uint32_t *w4 = reinterpret_cast<const uint32_t *>(t.sb + (int)((c.fend & ~3u) - 4u));
+    const uint32_t xr = __builtin_amdgcn_alignbyte(w4[1], w4[0], c.fend) ^ 0x30303030u;
+    const uint32_t sh = 32u - 8u * n;             // (an idle lane's n = 0 shifts by nothing: its result is not stored)
+    const uint32_t f0 = xr >> sh;                 // first character in byte 0
+    const uint32_t d = f0 << sh;                  // units in byte 3, …, thousands in byte 0; what precedes the field is zero
+    bool badA = ((((d + 0x76767676u) | d) & 0x80808080u) != 0) | (((f0 & 0xFFu) == 0) & (n > 1u));  // a byte above 9; a leading zero in front of more digits
+    const uint32_t v = __umul24(d & 0xFFu, 1000u) + __builtin_amdgcn_udot4(d, 0x010A6400u, 0u, false);
+    if constexpr (W == 1) badA = badA | (v > ((KIND == CK_INT) ? 127u : 255u));
+    if (c.on && !badA) out[c.r] = (T)v;
+    if (c.on && badA) t.slowf[c.jj] = 1;
+    return;
+  }
+  const uint32_t c0 = t.sb[c.fs];
+  uint32_t wlo, whi;
+  window8(t.sb, c.fend, &wlo, &whi);
+  bool bad;
+  // first tier: no sign, no leading zero (a lone "0" is fine; a first byte above '9' fails the digit check), 1..FASTD digits
+  const bool fast = (c0 >= '1' || n == 1u) && n - 1u < FASTD;
+  if (t.ablate == 31) { if (c.on && fast && wlo == 0x12345678u && whi == 77u) out[c.r] = 0; return; }  // (profiling: the slot's skeleton and reads only)
+  if (wave_all(fast || !c.on)) {
+    const uint2 keep = t.keeptab[c.on ? n : 0u];  // the top n bytes of the window
+    const uint32_t tlo = (wlo ^ 0x30303030u) & keep.x, thi = (whi ^ 0x30303030u) & keep.y;
+    bad = (((tlo + 0x76767676u) | tlo | (thi + 0x76767676u) | thi) & 0x80808080u) != 0;
+    uint32_t v;
+    if constexpr (W < 4) {
+      v = __umul24(tlo >> 24, 10000u) + four_dot(thi);
+      if constexpr (KIND == CK_INT) bad = bad || v > (1u << (W * 8 - 1)) - 1u; else bad = bad || v > (1u << (W * 8)) - 1u;
+    } else v = __umul24(four_dot(tlo), 10000u) + four_dot(thi);  // < 10^8: in range for 32 and 64 bits
+    if (c.on && !bad) out[c.r] = (T)v;
+  } else if constexpr (W >= 4) {
+    // second tier, straight-line as well: [+-]?(0|[1-9][0-9]*) of up to 19 digits.  The 24 bytes in front of the field's end
+    // are three windows of eight; a window's digits are kept by the same table (none of them: the window counts as zero).
+    const bool neg = c0 == '-', sgn = neg || c0 == '+';
+    const uint32_t nd = n - (sgn ? 1u : 0u);  // digits
+    const uint32_t fd = sgn ? (uint32_t)t.sb[c.fs + 1] : c0;  // the first of them
+    bool ok = nd - 1u < 19u && !(nd > 1 && fd == '0');
+    if constexpr (KIND == CK_UINT && W == 8) ok = ok && !sgn;  // ParseUint takes no sign
+    const uint32_t y = c.fend;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (int)((y - 24u) & ~3u));
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+    const uint32_t w2lo = __builtin_amdgcn_alignbyte(d1, d0, y), w2hi = __builtin_amdgcn_alignbyte(d2, d1, y);  // [y - 24, y - 16)
+    const uint32_t w1lo = __builtin_amdgcn_alignbyte(d3, d2, y), w1hi = __builtin_amdgcn_alignbyte(d4, d3, y);  // [y - 16, y - 8); [y - 8, y) is wlo, whi
+    const uint32_t ndc = min(nd, 24u), n0 = min(ndc, 8u), n1d = min(ndc - n0, 8u), n2d = min(ndc - n0 - n1d, 8u);
+    const uint2 k0 = t.keeptab[n0], k1 = t.keeptab[n1d], k2 = t.keeptab[n2d];
+    const uint32_t a0 = (wlo ^ 0x30303030u) & k0.x, b0 = (whi ^ 0x30303030u) & k0.y;
+    const uint32_t a1 = (w1lo ^ 0x30303030u) & k1.x, b1 = (w1hi ^ 0x30303030u) & k1.y;
+    const uint32_t a2 = (w2lo ^ 0x30303030u) & k2.x, b2 = (w2hi ^ 0x30303030u) & k2.y;
+    const uint32_t nondigit = ((a0 + 0x76767676u) | a0 | (b0 + 0x76767676u) | b0 | (a1 + 0x76767676u) | a1 | (b1 + 0x76767676u) | b1 |
+                               (a2 + 0x76767676u) | a2 | (b2 + 0x76767676u) | b2) & 0x80808080u;
+    ok = ok && nondigit == 0;
+    const uint32_t g0v = __umul24(four_dot(a0), 10000u) + four_dot(b0), g1v = __umul24(four_dot(a1), 10000u) + four_dot(b1);
+    const uint32_t g2v = __umul24(four_dot(a2), 10000u) + four_dot(b2);  // < 10^8 each; nd <= 19: g2v < 1000
+    const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;  // < 10^19 < 2^64
+    if constexpr (KIND == CK_INT) ok = ok && v <= (neg ? (1ull << (W * 8 - 1)) : (1ull << (W * 8 - 1)) - 1);
+    else ok = ok && !(neg && v != 0) && (W == 8 || v <= (1ull << (W * 8 % 64)) - 1);
+    if (c.on && ok) out[c.r] = (T)(neg ? (int64_t)(0 - v) : (int64_t)v);
+    bad = !ok;
+  } else {
+    // the narrow types' rare shapes (a sign, a leading zero, too many digits)
+    const bool neg = c0 == '-', sgn = neg || c0 == '+';
+    const uint32_t nd = n - (sgn ? 1u : 0u);  // digits
+    bool ok = nd - 1u < 19u && !(nd > 1 && t.sb[c.fend - min(nd, 24u)] == '0');
+    uint32_t g0v = 0;
+    ok = digits8_window<true>(wlo, whi, min(nd, 8u), &g0v) && ok;
+    // six digits and more are out of range whatever they are (no leading zeros): the narrow digit sum reads five
+    if constexpr (KIND == CK_INT) ok = ok && nd <= 5 && g0v <= (1u << (W * 8 - 1)) - (neg ? 0u : 1u);
+    else ok = ok && nd <= 5 && g0v <= (1u << (W * 8)) - 1u && !(neg && g0v != 0);
+    if (c.on && ok) out[c.r] = (T)(neg ? -(int32_t)g0v : (int32_t)g0v);
+    bad = !ok;
+  }
+  if (c.on && bad) t.slowf[c.jj] = 1;
+}
 template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
-  constexpr uint32_t FASTD = W < 4 ? 5u : 8u;  // digits the first tier takes (more cannot fit / need a second window)
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
   const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
   if (s0 >= sbase + nslots) return;
   ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
   for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
     const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
-    T *const out = global_ptr<T>(t.colp0[c.on ? c.col : (uint32_t)run.first]);
-    const uint32_t n = c.fend - c.fs;
-    if (t.ablate != 31 && wave_all(n - 1u < 4u || !c.on)) {
-      // tier A: one to four characters, an unsigned canonical decimal — the common cell of a flag / small-integer column.  One
-      // aligned LDS word pair holds the field's bytes [fend - 4, fend); masks come from shifts (an LDS table read costs the CU
-      // as much as six VALU instructions), the leading-zero rule from the first character in byte 0.
-      const uint32_t *w4 = reinterpret_cast<const uint32_t *>(t.sb + (int)((c.fend & ~3u) - 4u));
-      const uint32_t xr = __builtin_amdgcn_alignbyte(w4[1], w4[0], c.fend) ^ 0x30303030u;
-      const uint32_t sh = 32u - 8u * n;             // (an idle lane's n = 0 shifts by nothing: its result is not stored)
-      const uint32_t f0 = xr >> sh;                 // first character in byte 0
-      const uint32_t d = f0 << sh;                  // units in byte 3, …, thousands in byte 0; what precedes the field is zero
-      bool badA = ((((d + 0x76767676u) | d) & 0x80808080u) != 0) | (((f0 & 0xFFu) == 0) & (n > 1u));  // a byte above 9; a leading zero in front of more digits
-      const uint32_t v = __umul24(d & 0xFFu, 1000u) + __builtin_amdgcn_udot4(d, 0x010A6400u, 0u, false);
-      if constexpr (W == 1) badA = badA | (v > ((KIND == CK_INT) ? 127u : 255u));
-      if (c.on && !badA) out[c.r] = (T)v;
-      if (c.on && badA) t.slowf[c.jj] = 1;
-      continue;
-    }
-    const uint32_t c0 = t.sb[c.fs];
-    uint32_t wlo, whi;
-    window8(t.sb, c.fend, &wlo, &whi);
-    bool bad;
-    // first tier: no sign, no leading zero (a lone "0" is fine; a first byte above '9' fails the digit check), 1..FASTD digits
-    const bool fast = (c0 >= '1' || n == 1u) && n - 1u < FASTD;
-    if (t.ablate == 31) { if (c.on && fast && wlo == 0x12345678u && whi == 77u) out[c.r] = 0; continue; }  // (profiling: the slot's skeleton and reads only)
-    if (wave_all(fast || !c.on)) {
-      const uint2 keep = t.keeptab[c.on ? n : 0u];  // the top n bytes of the window
-      const uint32_t tlo = (wlo ^ 0x30303030u) & keep.x, thi = (whi ^ 0x30303030u) & keep.y;
-      bad = (((tlo + 0x76767676u) | tlo | (thi + 0x76767676u) | thi) & 0x80808080u) != 0;
-      uint32_t v;
-      if constexpr (W < 4) {
-        v = __umul24(tlo >> 24, 10000u) + four_dot(thi);
-        if constexpr (KIND == CK_INT) bad = bad || v > (1u << (W * 8 - 1)) - 1u; else bad = bad || v > (1u << (W * 8)) - 1u;
-      } else v = __umul24(four_dot(tlo), 10000u) + four_dot(thi);  // < 10^8: in range for 32 and 64 bits
-      if (c.on && !bad) out[c.r] = (T)v;
-    } else if constexpr (W >= 4) {
-      // second tier, straight-line as well: [+-]?(0|[1-9][0-9]*) of up to 19 digits.  The 24 bytes in front of the field's end
-      // are three windows of eight; a window's digits are kept by the same table (none of them: the window counts as zero).
-      const bool neg = c0 == '-', sgn = neg || c0 == '+';
-      const uint32_t nd = n - (sgn ? 1u : 0u);  // digits
-      const uint32_t fd = sgn ? (uint32_t)t.sb[c.fs + 1] : c0;  // the first of them
-      bool ok = nd - 1u < 19u && !(nd > 1 && fd == '0');
-      if constexpr (KIND == CK_UINT && W == 8) ok = ok && !sgn;  // ParseUint takes no sign
-      const uint32_t y = c.fend;
-      const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (int)((y - 24u) & ~3u));
-      const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
-      const uint32_t w2lo = __builtin_amdgcn_alignbyte(d1, d0, y), w2hi = __builtin_amdgcn_alignbyte(d2, d1, y);  // [y - 24, y - 16)
-      const uint32_t w1lo = __builtin_amdgcn_alignbyte(d3, d2, y), w1hi = __builtin_amdgcn_alignbyte(d4, d3, y);  // [y - 16, y - 8); [y - 8, y) is wlo, whi
-      const uint32_t ndc = min(nd, 24u), n0 = min(ndc, 8u), n1d = min(ndc - n0, 8u), n2d = min(ndc - n0 - n1d, 8u);
-      const uint2 k0 = t.keeptab[n0], k1 = t.keeptab[n1d], k2 = t.keeptab[n2d];
-      const uint32_t a0 = (wlo ^ 0x30303030u) & k0.x, b0 = (whi ^ 0x30303030u) & k0.y;
-      const uint32_t a1 = (w1lo ^ 0x30303030u) & k1.x, b1 = (w1hi ^ 0x30303030u) & k1.y;
-      const uint32_t a2 = (w2lo ^ 0x30303030u) & k2.x, b2 = (w2hi ^ 0x30303030u) & k2.y;
-      const uint32_t nondigit = ((a0 + 0x76767676u) | a0 | (b0 + 0x76767676u) | b0 | (a1 + 0x76767676u) | a1 | (b1 + 0x76767676u) | b1 |
-                                 (a2 + 0x76767676u) | a2 | (b2 + 0x76767676u) | b2) & 0x80808080u;
-      ok = ok && nondigit == 0;
-      const uint32_t g0v = __umul24(four_dot(a0), 10000u) + four_dot(b0), g1v = __umul24(four_dot(a1), 10000u) + four_dot(b1);
-      const uint32_t g2v = __umul24(four_dot(a2), 10000u) + four_dot(b2);  // < 10^8 each; nd <= 19: g2v < 1000
-      const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;  // < 10^19 < 2^64
-      if constexpr (KIND == CK_INT) ok = ok && v <= (neg ? (1ull << (W * 8 - 1)) : (1ull << (W * 8 - 1)) - 1);
-      else ok = ok && !(neg && v != 0) && (W == 8 || v <= (1ull << (W * 8 % 64)) - 1);
-      if (c.on && ok) out[c.r] = (T)(neg ? (int64_t)(0 - v) : (int64_t)v);
-      bad = !ok;
-    } else {
-      // the narrow types' rare shapes (a sign, a leading zero, too many digits)
-      const bool neg = c0 == '-', sgn = neg || c0 == '+';
-      const uint32_t nd = n - (sgn ? 1u : 0u);  // digits
-      bool ok = nd - 1u < 19u && !(nd > 1 && t.sb[c.fend - min(nd, 24u)] == '0');
-      uint32_t g0v = 0;
-      ok = digits8_window<true>(wlo, whi, min(nd, 8u), &g0v) && ok;
-      // six digits and more are out of range whatever they are (no leading zeros): the narrow digit sum reads five
-      if constexpr (KIND == CK_INT) ok = ok && nd <= 5 && g0v <= (1u << (W * 8 - 1)) - (neg ? 0u : 1u);
-      else ok = ok && nd <= 5 && g0v <= (1u << (W * 8)) - 1u && !(neg && g0v != 0);
-      if (c.on && ok) out[c.r] = (T)(neg ? -(int32_t)g0v : (int32_t)g0v);
-      bad = !ok;
-    }
-    if (c.on && bad) t.slowf[c.jj] = 1;
+    reg_int_body<KIND, W, T>(t, c, global_ptr<T>(t.colp0[c.on ? c.col : (uint32_t)run.first]));
   }
 }
 
+__device__ __forceinline__ void reg_str_body(const RegTile &t, const RegCell &c, uint32_t *const lens, uint32_t *const fstart) {
+  const uint32_t n = c.fend - c.fs;
+  const uint32_t c_first = t.sb[c.fs], c_last = t.sb[c.fend - 1];
+  const uint32_t qn = quotes_in(t, c.fs, c.fend);  // quote characters in the field
+  // straight path: empty; no quote inside and printable ASCII (not a space, not DEL) at both ends; or enclosed in the
+  // only two quotes it holds ("…": unquote, nothing to collapse)
+  const bool plain = qn == 0 && c_first - 0x21u < 0x5Eu && c_last - 0x21u < 0x5Eu;
+  const bool quoted = qn == 2 && c_first == t.quote && c_last == t.quote;  // (n >= 2 then: two quote characters are in it)
+  if (wave_all(n == 0 || plain || quoted || !c.on)) {
+    const uint32_t q1 = quoted ? 1u : 0u;
+    if (c.on) { lens[c.r] = n - 2u * q1; fstart[c.r] = t.g0 + c.fs + q1; }
+    return;
+  }
+  if (!c.on) return;
+  if (n == 0) { lens[c.r] = 0; fstart[c.r] = t.g0 + c.fs; return; }
+  bool done = false;
+  if (n <= 0x7FFFu) {
+    // nothing to trim: either enclosed in quotes ("…": unquote) or plain at both ends
+    uint32_t a = c.fs, b = c.fend;
+    bool ok = false;
+    if (c_first == t.quote && c_last == t.quote && n >= 2) { a++; b--; ok = true; }
+    else ok = c_first != t.quote && c_last != t.quote && starts_plain(t.sb, c.fs, c.fend, c_first, t.quote) && ends_plain(t.sb, c.fs, c.fend, c_last, t.quote);
+    if (ok) {
+      const uint32_t npairs = quotes_in(t, a, b) ? count_quote_pairs(t.qmask, a, b) : 0u;
+      if (!(npairs && !t.double_quote)) {  // errDoubleQuotesDisabled: per-row path
+        lens[c.r] = (b - a) - npairs;
+        fstart[c.r] = (t.g0 + a) | (npairs ? 0x80000000u : 0u);
+        if (npairs) fstart[-1] = 1u;  // the column holds cells that are not a plain byte range
+        done = true;
+      }
+    }
+  }
+  if (!done) t.slowf[c.jj] = 1;
+}
 __device__ __forceinline__ void reg_cells_str(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
   const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
@@ -1372,39 +1414,7 @@ __device__ __forceinline__ void reg_cells_str(const RegTile &t, const CsvRun &ru
   for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
     const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     const uint32_t col = c.on ? c.col : (uint32_t)run.first;
-    uint32_t *const lens = global_ptr<uint32_t>(t.colp0[col]), *const fstart = global_ptr<uint32_t>(t.colp1[col]);
-    const uint32_t n = c.fend - c.fs;
-    const uint32_t c_first = t.sb[c.fs], c_last = t.sb[c.fend - 1];
-    const uint32_t qn = quotes_in(t, c.fs, c.fend);  // quote characters in the field
-    // straight path: empty; no quote inside and printable ASCII (not a space, not DEL) at both ends; or enclosed in the
-    // only two quotes it holds ("…": unquote, nothing to collapse)
-    const bool plain = qn == 0 && c_first - 0x21u < 0x5Eu && c_last - 0x21u < 0x5Eu;
-    const bool quoted = qn == 2 && c_first == t.quote && c_last == t.quote;  // (n >= 2 then: two quote characters are in it)
-    if (wave_all(n == 0 || plain || quoted || !c.on)) {
-      const uint32_t q1 = quoted ? 1u : 0u;
-      if (c.on) { lens[c.r] = n - 2u * q1; fstart[c.r] = t.g0 + c.fs + q1; }
-      continue;
-    }
-    if (!c.on) continue;
-    if (n == 0) { lens[c.r] = 0; fstart[c.r] = t.g0 + c.fs; continue; }
-    bool done = false;
-    if (n <= 0x7FFFu) {
-      // nothing to trim: either enclosed in quotes ("…": unquote) or plain at both ends
-      uint32_t a = c.fs, b = c.fend;
-      bool ok = false;
-      if (c_first == t.quote && c_last == t.quote && n >= 2) { a++; b--; ok = true; }
-      else ok = c_first != t.quote && c_last != t.quote && starts_plain(t.sb, c.fs, c.fend, c_first, t.quote) && ends_plain(t.sb, c.fs, c.fend, c_last, t.quote);
-      if (ok) {
-        const uint32_t npairs = quotes_in(t, a, b) ? count_quote_pairs(t.qmask, a, b) : 0u;
-        if (!(npairs && !t.double_quote)) {  // errDoubleQuotesDisabled: per-row path
-          lens[c.r] = (b - a) - npairs;
-          fstart[c.r] = (t.g0 + a) | (npairs ? 0x80000000u : 0u);
-          if (npairs) fstart[-1] = 1u;  // the column holds cells that are not a plain byte range
-          done = true;
-        }
-      }
-    }
-    if (!done) t.slowf[c.jj] = 1;
+    reg_str_body(t, c, global_ptr<uint32_t>(t.colp0[col]), global_ptr<uint32_t>(t.colp1[col]));
   }
 }
 
@@ -1415,6 +1425,51 @@ __device__ __forceinline__ uint32_t dig2(uint32_t w, int byte, uint32_t *bad) { 
   *bad |= (a > 9u) | (b > 9u);
   return a * 10 + b;
 }
+template <int KIND> __device__ __forceinline__ void reg_time_body(const RegTile &t, const RegCell &c, int64_t *const sec, int32_t *const nanos) {
+  if (!c.on) return;
+  const uint32_t n = c.fend - c.fs;
+  bool done = false;
+  if ((n == 10 || n == 19) && t.sb[c.fs + 4] == '-') {
+    // the 20 bytes from the field's start as five words: "2006" "-01-" "02 1" "5:04" ":05."
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (c.fs & ~3u));
+    const uint32_t x0 = w[0], x1 = w[1], x2 = w[2], x3 = w[3], x4 = w[4], x5 = w[5];
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(x1, x0, c.fs), w1 = __builtin_amdgcn_alignbyte(x2, x1, c.fs), w2 = __builtin_amdgcn_alignbyte(x3, x2, c.fs);
+    uint32_t bad = 0;
+    const uint32_t y = dig2(w0, 0, &bad) * 100 + dig2(w0, 2, &bad);
+    const uint32_t mo = dig2(w1, 1, &bad), d = dig2(w2, 0, &bad);
+    bad |= (w1 & 0xFF0000FFu) != 0x2D00002Du;  // '-' .. '-'
+    uint32_t h = 0, mi = 0, se = 0;
+    if (n == 19) {
+      const uint32_t w3 = __builtin_amdgcn_alignbyte(x4, x3, c.fs), w4 = __builtin_amdgcn_alignbyte(x5, x4, c.fs);
+      const uint32_t sep = (w2 >> 16) & 0xFFu;
+      bad |= !(sep == ' ' || sep == 'T') | (((w3 >> 8) & 0xFFu) != ':') | ((w4 & 0xFFu) != ':');
+      h = (((w2 >> 24) & 0xFFu) - '0') * 10 + ((w3 & 0xFFu) - '0');
+      bad |= (((w2 >> 24) & 0xFFu) - '0' > 9u) | ((w3 & 0xFFu) - '0' > 9u);
+      mi = dig2(w3, 2, &bad); se = dig2(w4, 1, &bad);
+    }
+    const bool ok = !bad && mo >= 1 && mo <= 12 && d >= 1 && d <= days_in_month32(mo, y) && h <= 23 && mi <= 59 && se <= 59;
+    if (ok) {
+      sec[c.r] = (int64_t)days_from_civil32(y, mo, d) * 86400 + (int64_t)(h * 3600 + mi * 60 + se);
+      nanos[c.r] = 0;
+      done = true;
+    }
+  } else if (KIND == CK_TIMESTAMP && n - 1u < 19u) {
+    // ParseInt(s, 10, 64): [+-]?digits, leading zeros are fine in base 10
+    const uint32_t c0 = t.sb[c.fs];
+    const bool neg = c0 == '-', sgn = neg || c0 == '+';
+    const uint32_t nd = n - (sgn ? 1u : 0u);
+    uint32_t g0v = 0, g1v = 0, g2v = 0;
+    bool ok = nd - 1u < 18u;
+    ok = digits8_end(t.sb, c.fend, min(nd, 8u), &g0v) && ok;
+    if (nd > 8) ok = digits8_end(t.sb, c.fend - 8, min(nd - 8, 8u), &g1v) && ok;
+    if (nd > 16) ok = digits8_end(t.sb, c.fend - 16, nd - 16, &g2v) && ok;
+    if (ok) {
+      const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;
+      sec[c.r] = neg ? -(int64_t)v : (int64_t)v; nanos[c.r] = 0; done = true;
+    }
+  }
+  if (!done) t.slowf[c.jj] = 1;
+}
 template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
   const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
@@ -1423,51 +1478,57 @@ template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile
   for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
     const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     if (!c.on) continue;
-    int64_t *const sec = global_ptr<int64_t>(t.colp0[c.col]); int32_t *const nanos = global_ptr<int32_t>(t.colp1[c.col]);
-    const uint32_t n = c.fend - c.fs;
-    bool done = false;
-    if ((n == 10 || n == 19) && t.sb[c.fs + 4] == '-') {
-      // the 20 bytes from the field's start as five words: "2006" "-01-" "02 1" "5:04" ":05."
-      const uint32_t *w = reinterpret_cast<const uint32_t *>(t.sb + (c.fs & ~3u));
-      const uint32_t x0 = w[0], x1 = w[1], x2 = w[2], x3 = w[3], x4 = w[4], x5 = w[5];
-      const uint32_t w0 = __builtin_amdgcn_alignbyte(x1, x0, c.fs), w1 = __builtin_amdgcn_alignbyte(x2, x1, c.fs), w2 = __builtin_amdgcn_alignbyte(x3, x2, c.fs);
-      uint32_t bad = 0;
-      const uint32_t y = dig2(w0, 0, &bad) * 100 + dig2(w0, 2, &bad);
-      const uint32_t mo = dig2(w1, 1, &bad), d = dig2(w2, 0, &bad);
-      bad |= (w1 & 0xFF0000FFu) != 0x2D00002Du;  // '-' .. '-'
-      uint32_t h = 0, mi = 0, se = 0;
-      if (n == 19) {
-        const uint32_t w3 = __builtin_amdgcn_alignbyte(x4, x3, c.fs), w4 = __builtin_amdgcn_alignbyte(x5, x4, c.fs);
-        const uint32_t sep = (w2 >> 16) & 0xFFu;
-        bad |= !(sep == ' ' || sep == 'T') | (((w3 >> 8) & 0xFFu) != ':') | ((w4 & 0xFFu) != ':');
-        h = (((w2 >> 24) & 0xFFu) - '0') * 10 + ((w3 & 0xFFu) - '0');
-        bad |= (((w2 >> 24) & 0xFFu) - '0' > 9u) | ((w3 & 0xFFu) - '0' > 9u);
-        mi = dig2(w3, 2, &bad); se = dig2(w4, 1, &bad);
-      }
-      const bool ok = !bad && mo >= 1 && mo <= 12 && d >= 1 && d <= days_in_month32(mo, y) && h <= 23 && mi <= 59 && se <= 59;
-      if (ok) {
-        sec[c.r] = (int64_t)days_from_civil32(y, mo, d) * 86400 + (int64_t)(h * 3600 + mi * 60 + se);
-        nanos[c.r] = 0;
-        done = true;
-      }
-    } else if (KIND == CK_TIMESTAMP && n - 1u < 19u) {
-      // ParseInt(s, 10, 64): [+-]?digits, leading zeros are fine in base 10
-      const uint32_t c0 = t.sb[c.fs];
-      const bool neg = c0 == '-', sgn = neg || c0 == '+';
-      const uint32_t nd = n - (sgn ? 1u : 0u);
-      uint32_t g0v = 0, g1v = 0, g2v = 0;
-      bool ok = nd - 1u < 18u;
-      ok = digits8_end(t.sb, c.fend, min(nd, 8u), &g0v) && ok;
-      if (nd > 8) ok = digits8_end(t.sb, c.fend - 8, min(nd - 8, 8u), &g1v) && ok;
-      if (nd > 16) ok = digits8_end(t.sb, c.fend - 16, nd - 16, &g2v) && ok;
-      if (ok) {
-        const uint64_t v = ((uint64_t)g2v * 100000000ull + g1v) * 100000000ull + g0v;
-        sec[c.r] = neg ? -(int64_t)v : (int64_t)v; nanos[c.r] = 0; done = true;
-      }
-    }
-    if (!done) t.slowf[c.jj] = 1;
+    reg_time_body<KIND>(t, c, global_ptr<int64_t>(t.colp0[c.col]), global_ptr<int32_t>(t.colp1[c.col]));
   }
 }
+
+// ---- the column-lane form of the cell phase -----------------------------------------------------------------------------------
+// A wave takes a TASK: G <= 64 columns of one (kind, width).  Lane l owns column first + l % G for the whole task and the lines
+// jj = it * P + l / G (P = 64 / G lines per step), so everything a cell's column fixes — its field ordinal, its output pointers —
+// is read ONCE per task into the lane's registers, and a step's skeleton is: the line (one add), the index entry (one mad), two
+// index reads, the row.  The item form pays per cell for the (column, line) of a slot item (a carry chain), three descriptor reads
+// from LDS and the slot bookkeeping of every run in every wave.  A lane's stores go to its own column: a wave store touches G
+// cache lines with P consecutive values each (the tile's 35 lines of a column are 70-280 contiguous bytes: they meet in L2).
+struct LaneCol { uint32_t g, ph, P; bool live; };  // P is wave-uniform (a scalar): the step loops below are scalar loops
+__device__ __forceinline__ LaneCol lane_col(const CsvTask &k, int lane) {
+  const uint32_t G = (uint32_t)__builtin_amdgcn_readfirstlane(k.ncols), P = 64u / G;
+  const uint32_t ph = (uint32_t)((uint32_t)lane * (65536u / G + 1u)) >> 16;  // lane / G for lane < 64 (G <= 64)
+  return LaneCol{(uint32_t)lane - ph * G, ph, P, ph < P};
+}
+__device__ __forceinline__ RegCell lane_cell(const RegTile &t, const LaneCol &lc, uint32_t jj0, uint32_t colfield) {
+  RegCell c;
+  c.jj = jj0 + lc.ph; c.col = 0;
+  c.r = t.row0 + (int32_t)c.jj;
+  c.on = lc.live && c.jj < t.nr && c.r >= 0;  // header lines produce nothing
+  const uint32_t kr = c.on ? __umul24(c.jj, t.NF) + colfield : CR_KDUMMY;
+  uint32_t kr1 = kr + 1;
+  TF_OPAQUE(kr1);  // (two ds_read_u16: see reg_cell)
+  c.fs = (uint32_t)t.fposx[kr] + 1; c.fend = t.fposx[kr1];
+  return c;
+}
+template <int KIND, int W> __device__ __forceinline__ void task_cells_int(const RegTile &t, const CsvTask &k, int lane) {
+  using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
+  const LaneCol lc = lane_col(k, lane);
+  const uint32_t col = (uint32_t)k.first + (lc.live ? lc.g : 0u);
+  const uint32_t colfield = t.colfield[col];
+  T *const out = global_ptr<T>(t.colp0[col]);
+  for (uint32_t jj0 = 0; jj0 < t.nr; jj0 += lc.P) reg_int_body<KIND, W, T>(t, lane_cell(t, lc, jj0, colfield), out);
+}
+__device__ __forceinline__ void task_cells_str(const RegTile &t, const CsvTask &k, int lane) {
+  const LaneCol lc = lane_col(k, lane);
+  const uint32_t col = (uint32_t)k.first + (lc.live ? lc.g : 0u);
+  const uint32_t colfield = t.colfield[col];
+  uint32_t *const lens = global_ptr<uint32_t>(t.colp0[col]), *const fstart = global_ptr<uint32_t>(t.colp1[col]);
+  for (uint32_t jj0 = 0; jj0 < t.nr; jj0 += lc.P) reg_str_body(t, lane_cell(t, lc, jj0, colfield), lens, fstart);
+}
+template <int KIND> __device__ __forceinline__ void task_cells_time(const RegTile &t, const CsvTask &k, int lane) {
+  const LaneCol lc = lane_col(k, lane);
+  const uint32_t col = (uint32_t)k.first + (lc.live ? lc.g : 0u);
+  const uint32_t colfield = t.colfield[col];
+  int64_t *const sec = global_ptr<int64_t>(t.colp0[col]); int32_t *const nanos = global_ptr<int32_t>(t.colp1[col]);
+  for (uint32_t jj0 = 0; jj0 < t.nr; jj0 += lc.P) reg_time_body<KIND>(t, lane_cell(t, lc, jj0, colfield), sec, nanos);
+}
+__device__ __forceinline__ bool task_kind(int kind) { return kind == CK_INT || kind == CK_UINT || kind == CK_STR || kind == CK_DATE || kind == CK_TIMESTAMP; }
 
 __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) {
   static_assert(CT_SPILL == 64 * CT_CPT * 16, "the look-behind window is exactly wave 0's bytes");
@@ -1708,9 +1769,32 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
     t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.keeptab = keeptab; t.slowf = slowf; t.colp0 = colp0; t.colp1 = colp1; t.colfield = colfield;
     t.nr = nr; t.NF = NF; t.step_q = 512u / nr; t.step_r = 512u - t.step_q * nr; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
     t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0; t.ablate = p.ablate;
+    if (p.col_lanes) {
+      for (int ti = p.wave_task[wv]; ti < p.wave_task[wv + 1]; ti++) {
+        const CsvTask k = p.tasks[ti];
+        if (p.ablate >= 10) {  // 10: no cells; 11: integer tasks only; 12: text; 13: date / timestamp
+          const int grp = (k.kind == CK_INT || k.kind == CK_UINT) ? 11 : k.kind == CK_STR ? 12 : 13;
+          if (p.ablate != grp && !(p.ablate == 31 && grp == 11)) continue;
+        }
+        switch (k.kind) {
+          case CK_INT:
+            if (k.width == 1) task_cells_int<CK_INT, 1>(t, k, lane); else if (k.width == 2) task_cells_int<CK_INT, 2>(t, k, lane);
+            else if (k.width == 4) task_cells_int<CK_INT, 4>(t, k, lane); else task_cells_int<CK_INT, 8>(t, k, lane);
+            break;
+          case CK_UINT:
+            if (k.width == 1) task_cells_int<CK_UINT, 1>(t, k, lane); else if (k.width == 2) task_cells_int<CK_UINT, 2>(t, k, lane);
+            else if (k.width == 4) task_cells_int<CK_UINT, 4>(t, k, lane); else task_cells_int<CK_UINT, 8>(t, k, lane);
+            break;
+          case CK_STR: task_cells_str(t, k, lane); break;
+          case CK_DATE: task_cells_time<CK_DATE>(t, k, lane); break;
+          default: task_cells_time<CK_TIMESTAMP>(t, k, lane);
+        }
+      }
+    }
     uint32_t sbase = 0;
     for (int ri = 0; ri < p.nruns; ri++) {
       const CsvRun run = p.runs[ri];
+      if (p.col_lanes && task_kind(run.kind)) continue;  // its cells ran as tasks
       const uint32_t items = (uint32_t)run.ncols * nr, nslots = (items + 63) >> 6;
       if (p.ablate >= 10) {  // 10: no cells; 11: integer runs only; 12: text runs only; 13: date / timestamp runs only
         const int grp = (run.kind == CK_INT || run.kind == CK_UINT) ? 11 : run.kind == CK_STR ? 12 : 13;
@@ -2482,6 +2566,33 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   }
   Buf bruns = up(runs.data(), runs.size() * sizeof(CsvRun));
   pp.runs = ptr<CsvRun>(bruns); pp.nruns = (int32_t)runs.size();
+  // ---- the column-lane cell phase: runs of the fast kinds cut into tasks of <= 64 columns (pieces of about 16: four lines per step),
+  //      dealt to the eight waves longest first (TFGPU_CSV_COL_LANES=0: the item form, for A/B runs and as the cross-check) ----
+  static const bool col_lanes = [] { const char *e = std::getenv("TFGPU_CSV_COL_LANES"); return !(e && e[0] == '0'); }();
+  std::vector<CsvTask> tasks; std::vector<int32_t> wave_task(CT_THREADS / 64 + 1, 0);
+  if (col_lanes) {
+    struct Pending { CsvTask k; int cost; };
+    std::vector<Pending> pend;
+    for (auto &r : runs) {
+      if (!(r.kind == CK_INT || r.kind == CK_UINT || r.kind == CK_STR || r.kind == CK_DATE || r.kind == CK_TIMESTAMP)) continue;
+      const int unit = (r.kind == CK_INT || r.kind == CK_UINT) ? (r.width == 8 ? 5 : r.width == 4 ? 3 : 2) : r.kind == CK_STR ? 4 : 6;  // relative cost of a cell
+      const int pieces = r.ncols <= 21 ? 1 : (r.ncols + 15) / 16;
+      for (int q = 0, at = 0; q < pieces; q++) {
+        const int n = (r.ncols - at + (pieces - q) - 1) / (pieces - q);
+        pend.push_back({CsvTask{r.kind, r.width, r.first + at, n}, n * unit});
+        at += n;
+      }
+    }
+    std::stable_sort(pend.begin(), pend.end(), [](const Pending &a, const Pending &b) { return a.cost > b.cost; });
+    const int nw = CT_THREADS / 64;
+    std::vector<int> load((size_t)nw, 0); std::vector<std::vector<CsvTask>> per((size_t)nw);
+    for (auto &q : pend) { int w = 0; for (int i = 1; i < nw; i++) if (load[(size_t)i] < load[(size_t)w]) w = i; load[(size_t)w] += q.cost; per[(size_t)w].push_back(q.k); }
+    for (int w = 0; w < nw; w++) { wave_task[(size_t)w] = (int32_t)tasks.size(); for (auto &k : per[(size_t)w]) tasks.push_back(k); }
+    wave_task[(size_t)nw] = (int32_t)tasks.size();
+  }
+  if (tasks.empty()) tasks.push_back(CsvTask{0, 0, 0, 1});
+  Buf btasks = up(tasks.data(), std::max<size_t>(tasks.size(), 1) * sizeof(CsvTask)), bwt = up(wave_task.data(), wave_task.size() * 4);
+  pp.tasks = ptr<CsvTask>(btasks); pp.wave_task = ptr<int32_t>(bwt); pp.col_lanes = col_lanes ? 1 : 0;
   pp.null_checks = (opts->strings_can_be_null || opts->quoted_strings_can_be_null) ? 1 : 0;
 
   // ---- csv_parse_lanes: the sorted columns cut into 16 contiguous blocks of about equal cost, one per wave; the tile sized so
