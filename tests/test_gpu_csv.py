@@ -257,6 +257,20 @@ def test_row_path_equals_tile_path():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_column_lane_form_equals_item_form():
+    """TFGPU_CSV_COL_LANES=2 (pieces of 8 columns): csv_parse_cols, the column-lane cell phase of the regular-tile kernel —
+    slower than the item form on the MI355X and off by default, kept with its measurements; it must pass the same cases."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, TFGPU_CSV_COL_LANES="2", TFGPU_CSV_COL_PIECE="8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_csv.py", "-m", "gpu", "-q", "-x", "-k",
+                        "edge_lines or typed_columns or random_bytes or tile_path_shapes or unmapped or hits_small"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_lanes_overlap_and_agree(tf, oracle):
     """Two host threads on two device lanes (tfgpu_lane_use) parse + transform concurrently; each result is
     identical to the single-lane result (the parsequeue's parallel workers, parsequeue.go:57-154)."""

@@ -1238,7 +1238,7 @@ struct CsvTask { int32_t kind, width, first, ncols; };  // a piece of a run of t
 // what the cell loops of csv_parse_regular share
 struct RegTile {
   const uint8_t *sb; const uint16_t *fposx; const uint32_t *qmask; const uint16_t *qpre; const uint2 *keeptab; uint8_t *slowf; const uint64_t *colp0, *colp1; const uint16_t *colfield;
-  uint32_t nr, NF, step_q, step_r; float inv_nr; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote; int32_t ablate;
+  uint32_t nr, NF, step_q, step_r; float inv_nr; int32_t row0; uint32_t g0; uint32_t quote; bool double_quote; int32_t ablate; int32_t col_mode;
 };
 // one cell of a run: item → (column, line), its output row and its byte range [fs, fend) in the tile
 struct RegCell { bool on; uint32_t col, jj, fs, fend; int32_t r; };
@@ -1490,8 +1490,12 @@ template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile
 // from LDS and the slot bookkeeping of every run in every wave.  A lane's stores go to its own column: a wave store touches G
 // cache lines with P consecutive values each (the tile's 35 lines of a column are 70-280 contiguous bytes: they meet in L2).
 struct LaneCol { uint32_t g, ph, P; bool live; };  // P is wave-uniform (a scalar): the step loops below are scalar loops
-__device__ __forceinline__ LaneCol lane_col(const CsvTask &k, int lane) {
+__device__ __forceinline__ LaneCol lane_col(const CsvTask &k, int lane, int mode) {
   const uint32_t G = (uint32_t)__builtin_amdgcn_readfirstlane(k.ncols), P = 64u / G;
+  if (mode == 2) {  // a column's P lines on NEIGHBOURING lanes: a wave store is G runs of P consecutive values
+    const uint32_t g = (uint32_t)((uint32_t)lane * (65536u / P + 1u)) >> 16;  // lane / P
+    return LaneCol{g, (uint32_t)lane - g * P, P, g < G};
+  }
   const uint32_t ph = (uint32_t)((uint32_t)lane * (65536u / G + 1u)) >> 16;  // lane / G for lane < 64 (G <= 64)
   return LaneCol{(uint32_t)lane - ph * G, ph, P, ph < P};
 }
@@ -1508,21 +1512,21 @@ __device__ __forceinline__ RegCell lane_cell(const RegTile &t, const LaneCol &lc
 }
 template <int KIND, int W> __device__ __forceinline__ void task_cells_int(const RegTile &t, const CsvTask &k, int lane) {
   using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
-  const LaneCol lc = lane_col(k, lane);
+  const LaneCol lc = lane_col(k, lane, t.col_mode);
   const uint32_t col = (uint32_t)k.first + (lc.live ? lc.g : 0u);
   const uint32_t colfield = t.colfield[col];
   T *const out = global_ptr<T>(t.colp0[col]);
   for (uint32_t jj0 = 0; jj0 < t.nr; jj0 += lc.P) reg_int_body<KIND, W, T>(t, lane_cell(t, lc, jj0, colfield), out);
 }
 __device__ __forceinline__ void task_cells_str(const RegTile &t, const CsvTask &k, int lane) {
-  const LaneCol lc = lane_col(k, lane);
+  const LaneCol lc = lane_col(k, lane, t.col_mode);
   const uint32_t col = (uint32_t)k.first + (lc.live ? lc.g : 0u);
   const uint32_t colfield = t.colfield[col];
   uint32_t *const lens = global_ptr<uint32_t>(t.colp0[col]), *const fstart = global_ptr<uint32_t>(t.colp1[col]);
   for (uint32_t jj0 = 0; jj0 < t.nr; jj0 += lc.P) reg_str_body(t, lane_cell(t, lc, jj0, colfield), lens, fstart);
 }
 template <int KIND> __device__ __forceinline__ void task_cells_time(const RegTile &t, const CsvTask &k, int lane) {
-  const LaneCol lc = lane_col(k, lane);
+  const LaneCol lc = lane_col(k, lane, t.col_mode);
   const uint32_t col = (uint32_t)k.first + (lc.live ? lc.g : 0u);
   const uint32_t colfield = t.colfield[col];
   int64_t *const sec = global_ptr<int64_t>(t.colp0[col]); int32_t *const nanos = global_ptr<int32_t>(t.colp1[col]);
@@ -1530,7 +1534,7 @@ template <int KIND> __device__ __forceinline__ void task_cells_time(const RegTil
 }
 __device__ __forceinline__ bool task_kind(int kind) { return kind == CK_INT || kind == CK_UINT || kind == CK_STR || kind == CK_DATE || kind == CK_TIMESTAMP; }
 
-__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) {
+template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(const CsvParams &p) {
   static_assert(CT_SPILL == 64 * CT_CPT * 16, "the look-behind window is exactly wave 0's bytes");
   __shared__ __attribute__((aligned(16))) uint8_t sbuf[32 + CT_BYTES + 48];  // 32 bytes in front: the 24-byte window of a cell that ends within the tile's first bytes
   __shared__ uint16_t fposx[CR_FCAP + 4];    // [k + 1] = end of field k; [0] = first line's start - 1; [CR_KDUMMY], [CR_KDUMMY + 1]: an empty field for idle lanes
@@ -1768,8 +1772,8 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
     RegTile t;
     t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.keeptab = keeptab; t.slowf = slowf; t.colp0 = colp0; t.colp1 = colp1; t.colfield = colfield;
     t.nr = nr; t.NF = NF; t.step_q = 512u / nr; t.step_r = 512u - t.step_q * nr; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
-    t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0; t.ablate = p.ablate;
-    if (p.col_lanes) {
+    t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0; t.ablate = p.ablate; t.col_mode = p.col_lanes;
+    if constexpr (COLS) {
       for (int ti = p.wave_task[wv]; ti < p.wave_task[wv + 1]; ti++) {
         const CsvTask k = p.tasks[ti];
         if (p.ablate >= 10) {  // 10: no cells; 11: integer tasks only; 12: text; 13: date / timestamp
@@ -1794,7 +1798,7 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
     uint32_t sbase = 0;
     for (int ri = 0; ri < p.nruns; ri++) {
       const CsvRun run = p.runs[ri];
-      if (p.col_lanes && task_kind(run.kind)) continue;  // its cells ran as tasks
+      if (COLS && task_kind(run.kind)) continue;  // its cells ran as tasks
       const uint32_t items = (uint32_t)run.ncols * nr, nslots = (items + 63) >> 6;
       if (p.ablate >= 10) {  // 10: no cells; 11: integer runs only; 12: text runs only; 13: date / timestamp runs only
         const int grp = (run.kind == CK_INT || run.kind == CK_UINT) ? 11 : run.kind == CK_STR ? 12 : 13;
@@ -1862,6 +1866,11 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) 
   if (tid == 0) { if (spec) p.spec[2 + p.ntiles + tile] = (uint32_t)(g0 + fposx[nr * NF] + 1); else if (line1 == lines_all) atomicMax(p.last_end, (uint32_t)(g0 + fposx[nr * NF] + 1)); }
   phase(6);
 }
+
+// the kernel of the bench line: the item form of the cell phase
+__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_regular(CsvParams p) { csv_parse_regular_body<false>(p); }
+// … and with the column-lane form (TFGPU_CSV_COL_LANES=1 | 2): built, measured, slower — see the host code
+__global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_cols(CsvParams p) { csv_parse_regular_body<true>(p); }
 
 #include "tf_csv_lanes.inc"
 
@@ -2568,7 +2577,13 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   pp.runs = ptr<CsvRun>(bruns); pp.nruns = (int32_t)runs.size();
   // ---- the column-lane cell phase: runs of the fast kinds cut into tasks of <= 64 columns (pieces of about 16: four lines per step),
   //      dealt to the eight waves longest first (TFGPU_CSV_COL_LANES=0: the item form, for A/B runs and as the cross-check) ----
-  static const bool col_lanes = [] { const char *e = std::getenv("TFGPU_CSV_COL_LANES"); return !(e && e[0] == '0'); }();
+  // OFF by default.  Measured on the MI355X (gpurun r07s / r07t, 2^20 hits rows, one box): 0.946 ms (pieces of 16 columns), 0.816 (8), 0.825 (4),
+  // 1.23 (32) against the item form's 0.741 — although a step issues a third fewer VALU instructions (≈ 30 against ≈ 48 in the one-to-four-digit
+  // tier).  Group by group (TFGPU_CSV_ABLATE): integers +0.30 ms against +0.17, text +0.48 against +0.15, times +0.10 against +0.065.  A tile holds
+  // 35 lines: a task is a handful of DEPENDENT steps (index reads → window → store) in ONE wave, seven other waves of the workgroup wait at the
+  // barrier behind the longest task, and lines-per-step rounding wastes a quarter of the lanes; the item form deals 58 independent slots round-robin
+  // to all eight waves.  Which lanes hold a column's lines (1 | 2) makes no difference: the stores are not what it waits for.
+  static const int col_lanes = [] { const char *e = std::getenv("TFGPU_CSV_COL_LANES"); return e ? std::atoi(e) : 0; }();  // 0: item form; 1: columns on neighbouring lanes; 2: a column's lines on neighbouring lanes
   std::vector<CsvTask> tasks; std::vector<int32_t> wave_task(CT_THREADS / 64 + 1, 0);
   if (col_lanes) {
     struct Pending { CsvTask k; int cost; };
@@ -2576,7 +2591,8 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
     for (auto &r : runs) {
       if (!(r.kind == CK_INT || r.kind == CK_UINT || r.kind == CK_STR || r.kind == CK_DATE || r.kind == CK_TIMESTAMP)) continue;
       const int unit = (r.kind == CK_INT || r.kind == CK_UINT) ? (r.width == 8 ? 5 : r.width == 4 ? 3 : 2) : r.kind == CK_STR ? 4 : 6;  // relative cost of a cell
-      const int pieces = r.ncols <= 21 ? 1 : (r.ncols + 15) / 16;
+      static const int piece = [] { const char *e = std::getenv("TFGPU_CSV_COL_PIECE"); return e ? std::max(1, std::min(64, std::atoi(e))) : 16; }();
+      const int pieces = r.ncols <= piece + piece / 3 ? 1 : (r.ncols + piece - 1) / piece;
       for (int q = 0, at = 0; q < pieces; q++) {
         const int n = (r.ncols - at + (pieces - q) - 1) / (pieces - q);
         pend.push_back({CsvTask{r.kind, r.width, r.first + at, n}, n * unit});
@@ -2592,7 +2608,7 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   }
   if (tasks.empty()) tasks.push_back(CsvTask{0, 0, 0, 1});
   Buf btasks = up(tasks.data(), std::max<size_t>(tasks.size(), 1) * sizeof(CsvTask)), bwt = up(wave_task.data(), wave_task.size() * 4);
-  pp.tasks = ptr<CsvTask>(btasks); pp.wave_task = ptr<int32_t>(bwt); pp.col_lanes = col_lanes ? 1 : 0;
+  pp.tasks = ptr<CsvTask>(btasks); pp.wave_task = ptr<int32_t>(bwt); pp.col_lanes = col_lanes;
   pp.null_checks = (opts->strings_can_be_null || opts->quoted_strings_can_be_null) ? 1 : 0;
 
   // ---- csv_parse_lanes: the sorted columns cut into 16 contiguous blocks of about equal cost, one per wave; the tile sized so
@@ -2662,7 +2678,8 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
     } else {
       const int64_t per_xcd = (rtiles + 7) / 8;
       KernelTimer t("csv_parse_regular");
-      csv_parse_regular<<<(unsigned)(spec ? rtiles : per_xcd * 8), CT_THREADS, 0, st>>>(pp);
+      if (pp.col_lanes) csv_parse_cols<<<(unsigned)(spec ? rtiles : per_xcd * 8), CT_THREADS, 0, st>>>(pp);
+      else csv_parse_regular<<<(unsigned)(spec ? rtiles : per_xcd * 8), CT_THREADS, 0, st>>>(pp);
     }
     { KernelTimer t("csv_parse_tiles_general"); csv_parse_tiles_general<<<(unsigned)std::min<int64_t>(ntiles + rtiles, 2048), CT_THREADS, 0, st>>>(pp); }
     { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 1024), 64, 0, st>>>(pp); }
