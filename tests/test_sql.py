@@ -257,6 +257,67 @@ def test_general_expressions(tf, oracle):
 
 
 @pytest.mark.gpu
+def test_random_expression_trees(tf, oracle):
+    """Random integer / boolean expression trees over columns of every integer width (and literals at the type edges): ClickHouse's
+    result types and wrapped values, device program against the oracle's typed evaluation — select items and WHERE alike."""
+    import random
+    import os
+    rng = random.Random(20260925 + int(os.environ.get("TFGPU_TEST_SEED", "0")))
+    S = abi.Schema.of([["id", "int64", True], ["a", "int8"], ["b", "uint8"], ["c", "int16"], ["d", "uint16"], ["e", "int32"], ["f", "uint32"], ["g", "int64"], ["h", "uint64"], ["s", "utf8"]])
+    names = [c.name for c in S.cols]
+    ints = ["a", "b", "c", "d", "e", "f", "g", "h"]
+    lits = ["0", "1", "2", "7", "127", "128", "255", "256", "32767", "65535", "65536", "2147483647", "4294967295", "4294967296", "9223372036854775807", "-1", "-128", "-129", "-32768", "-2147483648", "-9223372036854775807"]
+
+    def iexpr(depth):
+        r = rng.random()
+        if depth <= 0 or r < 0.25:
+            return rng.choice(ints) if rng.random() < 0.7 else rng.choice(lits)
+        if r < 0.6:
+            return "(%s %s %s)" % (iexpr(depth - 1), rng.choice(["+", "-", "*"]), iexpr(depth - 1))
+        if r < 0.7:
+            return "-(%s)" % iexpr(depth - 1)
+        if r < 0.85:
+            return "to%s(%s)" % (rng.choice(["Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16", "UInt32", "UInt64"]), iexpr(depth - 1))
+        if r < 0.92:
+            return "length(%s)" % rng.choice(["s", "lower(s)", "toString(%s)" % iexpr(depth - 1)])
+        return bexpr(depth - 1)
+
+    def bexpr(depth):
+        r = rng.random()
+        if depth <= 0 or r < 0.45:
+            return "(%s %s %s)" % (iexpr(depth), rng.choice(["=", "!=", "<", "<=", ">", ">="]), iexpr(depth))
+        if r < 0.6:
+            return "(%s %sin (%s))" % (iexpr(depth), rng.choice(["", "not "]), ", ".join(rng.sample(lits, rng.randrange(1, 5))))
+        if r < 0.7:
+            return "(s %s '%s')" % (rng.choice(["=", "!=", "<", ">="]), rng.choice(["", "n1", "N3", "zz"]))
+        if r < 0.8:
+            return "(not %s)" % bexpr(depth - 1)
+        return "(%s %s %s)" % (bexpr(depth - 1), rng.choice(["and", "or"]), bexpr(depth - 1))
+
+    edges = {"a": [-128, 127, 0, -1], "b": [0, 255, 1], "c": [-32768, 32767], "d": [0, 65535], "e": [-2 ** 31, 2 ** 31 - 1], "f": [0, 2 ** 32 - 1], "g": [-2 ** 63, 2 ** 63 - 1, 0], "h": [0, 2 ** 64 - 1, 2 ** 63]}
+    go = {"a": "int8", "b": "uint8", "c": "int16", "d": "uint16", "e": "int32", "f": "uint32", "g": "int64", "h": "uint64"}
+    rows = []
+    for i in range(300):
+        row = [["int64", i]]
+        for n in ints:
+            lo, hi = min(edges[n]), max(edges[n])
+            row.append([go[n], rng.choice(edges[n]) if rng.random() < 0.3 else rng.randint(lo, hi) if rng.random() < 0.5 else rng.randint(max(lo, -50), min(hi, 50))])
+        row.append(["string", rng.choice(["", "n1", "N3", "zz", "longer text", "n1"])])
+        rows.append(row)
+    b = abi.batch_from_rows(S, names, rows, "db", "t", ["insert"] * len(rows))
+    done = 0
+    for _ in range(60):
+        items = ", ".join("%s as x%d" % (iexpr(3) if rng.random() < 0.7 else bexpr(2), k) for k in range(rng.randrange(1, 5)))
+        q = "select id, %s from table" % items + (" where %s" % bexpr(2) if rng.random() < 0.6 else "")
+        try:
+            _check(tf, oracle, q, b, S)
+            done += 1
+        except lib.TfgpuError as e:  # a tree deeper than the program's sixteen slots is the only refusal a generated query may meet
+            assert e.code == lib.ERR_UNSUPPORTED and "sixteen" in str(e), (q, str(e))
+    assert done >= 50
+
+
+@pytest.mark.gpu
 def test_key_must_pass_through_and_pkey_moves_stay_on_the_host(tf):
     S = abi.Schema.of([["id", "int32", True], ["v", "int32"]])
     b = abi.batch_from_rows(S, ["id", "v"], [[["int32", 1], ["int32", 2]]], "db", "t", ["insert"])

@@ -111,6 +111,7 @@ struct tfgpu_plan {
   bool sql_has_where = false;
   std::vector<tf::SqlNode> sql_nodes;  // expression trees of SQL_EXPR items and of a general WHERE
   int sql_where_root = -1;             // >= 0: the WHERE is this tree (`exprs` is empty then)
+  int sql_where_tree = -1;             // the WHERE's tree whatever its shape (a UInt64 column sends the filter_rows form to it too: sql_where_as_tree)
   // replace_primary_key
   std::vector<std::string> new_keys;
   bool is_new_key(const std::string &n) const {
@@ -137,6 +138,7 @@ void sha256_midstate(const uint8_t block[64], uint32_t out[8]);
 
 void sql_parse(const std::string &query, tfgpu_plan &p);                                              // tf_sql.cpp
 std::vector<SqlOut> sql_resolve(const tfgpu_plan &p, const std::vector<SchemaCol> &in);            // tf_sql.cpp
+bool sql_where_as_tree(const tfgpu_plan &p, const std::vector<SchemaCol> &in);                        // the WHERE runs as the expression program over this schema
 std::vector<int> sql_node_types(const tfgpu_plan &p, const std::vector<SchemaCol> &in);               // ClickHouse type of every node that is reachable from an item / the WHERE (SQL_PENDING elsewhere)
 std::string type_name(int dtype);                                                                    // YT type name of a TFGPU_T_* code
 // Apply one plan to a device batch (tf_transform.hip). `errs` collects row errors.

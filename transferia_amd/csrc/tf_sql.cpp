@@ -357,6 +357,7 @@ void sql_parse(const std::string &query, tfgpu_plan &p) {
     ps.adv();
     if (ps.cur.k == Tok::End) Lexer::bad("expected a condition at the end of the query");
     const int root = ps.bexpr();
+    p.sql_where_tree = root;
     if (!lower_where(p.sql_nodes, root, p.exprs)) p.sql_where_root = root;
     p.sql_has_where = true;
   }
@@ -383,6 +384,15 @@ int sql_ch_of(int yt) {
     case TFGPU_T_DATE: return SQL_DATE; case TFGPU_T_DATETIME: return SQL_DATETIME; case TFGPU_T_TIMESTAMP: return SQL_DATETIME64;
     default: return SQL_PENDING;
   }
+}
+
+// filter_rows' predicate program compares integers the way Go's matchValue does — a uint64 above MaxInt64 is an error row there, a
+// value like any other in ClickHouse — so a WHERE in filter_rows' shape that names a UInt64 column runs as the expression program too
+bool sql_where_as_tree(const tfgpu_plan &p, const std::vector<SchemaCol> &in) {
+  if (p.sql_where_root >= 0) return true;
+  for (const FExpr &e : p.exprs) for (const FTerm &t : e.terms)
+    for (auto &c : in) if (c.name == t.attr && c.dtype == TFGPU_T_UINT64) return p.sql_where_tree >= 0;
+  return false;
 }
 
 // ClickHouse's type of every node of the expression trees over a concrete schema.  TFGPU_ERR_CONFIG: what ClickHouse refuses
@@ -441,7 +451,7 @@ std::vector<int> sql_node_types(const tfgpu_plan &p, const std::vector<SchemaCol
     return t;
   };
   for (const SqlItem &it : p.sql_items) if (it.kind == SQL_EXPR) go(it.root);
-  if (p.sql_where_root >= 0) { const int t = go(p.sql_where_root); if (!is_int(t)) throw Error(TFGPU_ERR_CONFIG, "sql: the WHERE condition is text (ClickHouse: illegal type for filter)"); }
+  if (sql_where_as_tree(p, in)) { const int t = go(p.sql_where_tree); if (!is_int(t)) throw Error(TFGPU_ERR_CONFIG, "sql: the WHERE condition is text (ClickHouse: illegal type for filter)"); }
   return ty;
 }
 
@@ -495,7 +505,7 @@ std::vector<SqlOut> sql_resolve(const tfgpu_plan &p, const std::vector<SchemaCol
       default: throw Error(TFGPU_ERR_INVALID, "sql: internal item kind");
     }
   }
-  if (p.sql_where_root >= 0 && types.empty()) types = sql_node_types(p, in);  // a WHERE ClickHouse would refuse is refused with the schema
+  if (sql_where_as_tree(p, in) && types.empty()) types = sql_node_types(p, in);  // a WHERE ClickHouse would refuse is refused with the schema
   for (const FExpr &e : p.exprs) for (const FTerm &t : e.terms) {  // the WHERE in filter_rows' form: the same refusals
     const int ct = sql_ch_of(in[(size_t)need(t.attr)].dtype);
     if ((ct == SQL_STRING && t.vtype == FV_INT) || (is_int(ct) && t.vtype == FV_STRING))

@@ -1364,7 +1364,9 @@ struct SqlEval {
       }
       case SN_TOSTR: {
         if (ty[(size_t)n.kids[0]] == SQL_STRING) return text(n.kids[0]);
-        DColumn v = integer(n.kids[0]);
+        SqlEval sub{p, ty, b, st};  // (its own program: this one may be half emitted — toString inside length() inside an expression)
+        DColumn v = sub.integer(n.kids[0]);
+        for (auto &k : sub.keep_alive) keep_alive.push_back(k);
         return column_to_string(v, rows, false, 24);
       }
       default: throw Error(TFGPU_ERR_INVALID, "sql: internal text node");
@@ -1510,10 +1512,10 @@ static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_
   std::vector<int> node_ty;
   if (!p.sql_nodes.empty()) node_ty = sql_node_types(p, sc);
   std::unique_ptr<tfgpu_dbatch> kept;
-  if (p.sql_where_root >= 0) {  // a WHERE that is a tree: one program, rows whose value is not zero stay
+  if (sql_where_as_tree(p, sc)) {  // a WHERE that is a tree (or names a UInt64 column): one program, rows whose value is not zero stay
     Buf keep = dalloc((size_t)(n0 + 1) * 4);
     SqlEval ev{p, node_ty, *w, st};
-    ev.run(p.sql_where_root, nullptr, SQL_U8, ptr<uint32_t>(keep));
+    ev.run(p.sql_where_tree, nullptr, SQL_U8, ptr<uint32_t>(keep));
     kept = compact(*w, keep);  // syncs
   } else kept = p.sql_has_where ? run_filter(p.exprs, true, false, *w, ax) : std::move(w);
   const int64_t n = kept->nrows;
