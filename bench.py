@@ -401,6 +401,10 @@ class CsvWorkload(Base):
                 "mask_hmac_sha256": 72 * rows,                  # 4 B in + 64 B hex + 4 B offset per value
                 "filter_rows_eval": int((8 + 4 + 0.125) * rows), "compact_gather": gather, "scan_u32": 12 * rows}
 
+    def alg_views(self):
+        s = self.state
+        return {"csv_parse_regular": 8 * s["nstr"] * s["parsed_rows"], "csv_parse_rows": 8 * s["nstr"] * s["parsed_rows"]}
+
     def int_roofline(self, kernels):
         k = kernels.get("mask_hmac_sha256")
         if not k:
@@ -1538,6 +1542,14 @@ def main():
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_ms": round(launch_ms, 4), "launch_ms_source": source,
                     "consistent": bool(consistent), "kernels_ms_per_pass": round(kernel_sum_ms, 4), "timed_ms_per_pass": round(ms_per_pass, 4), "event_passes": nprof}
+        # `achieved` counts the conservative figure (input bytes + fixed-width values).  The CSV parse kernel also writes a (length, position)
+        # pair per text cell — the late-materialised form of SURVEY 8(d)'s "every output column byte", 8 bytes per cell instead of offset + text:
+        # stated next to it, never instead of it
+        extra = W.alg_views().get(dom) if hasattr(W, "alg_views") else None
+        if extra:
+            extra = extra / max(kernels[dom]["launches_per_step"], 1)
+            roofline["text_view_bytes_per_launch"] = int(extra)
+            roofline["frac_with_text_views"] = round((per_launch + extra) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     int_roof = W.int_roofline(kernels)
     for k, v in kernels.items():
         b = alg.get(k)
