@@ -180,7 +180,7 @@ def test_lookup_complex_random(tf, oracle):
 
     def leaf():
         r = rng.random()
-        return rng.choice(words) if r < 0.6 else None if r < 0.7 else rng.randrange(-5, 5) if r < 0.8 else rng.choice([True, [1], {"z": 1}])
+        return rng.choice(words) if r < 0.8 else None if r < 0.9 else rng.randrange(-5, 5) if r < 0.94 else rng.choice([True, [1], {"z": 1}])  # (non-strings at a path's end are the host's)
 
     lines = []
     for i in range(400):
@@ -188,18 +188,23 @@ def test_lookup_complex_random(tf, oracle):
         if rng.random() < 0.9:
             a = {}
             if rng.random() < 0.8: a["b"] = leaf()
-            if rng.random() < 0.7: a["num"] = rng.choice(["1", "-2", "999999999999", "zz", 7, None])
+            if rng.random() < 0.7: a["num"] = rng.choice(["1", "-2", "999999999999", "zz", "12", "0", 7, None])
             if rng.random() < 0.2: a["b "] = "near miss"
             doc["a"] = a if rng.random() < 0.9 else rng.choice(["str", 5, None, [a]])
         if rng.random() < 0.8: doc["c"] = leaf()
         if rng.random() < 0.5: doc["d"] = {"e": {"f": leaf()}} if rng.random() < 0.8 else {"e": leaf()}
+        if isinstance(doc.get("a"), dict) and rng.random() < 0.25:  # a string that holds the inner object's JSON: parsed again on the way
+            doc["a"] = pyjson.dumps(doc["a"], ensure_ascii=rng.random() < 0.5)
         text = pyjson.dumps(doc, ensure_ascii=rng.random() < 0.5, separators=rng.choice([(",", ":"), (", ", ": ")]))
+        if rng.random() < 0.2:   # the metrika logs' double escaping: not JSON as written, JSON after parseJSON's first retry
+            text = text.replace('\\"', '\\\\"')
+        if rng.random() < 0.05: text = text.replace('"', '\\"')   # … or only after every backslash is dropped
         if rng.random() < 0.05: text = text[:-1]
         if rng.random() < 0.05: text += " x"
         lines.append(("k=%d\tev=%s" % (i, text)).encode("utf-8"))
     data, msgs = abi.messages([b"\n".join(lines)], [0], [0])
     out, errs, nfb = compare(tf, oracle, abi.json_options(topic="t", format="tskv"), fields, data, msgs, "lookup random", max_fallback=400)
-    assert out.nrows > 100, (out.nrows, nfb)
+    assert out.nrows > 100 and nfb < 200, (out.nrows, nfb)
 
 
 EDGE_FIELDS = [["i8", "int8"], ["u16", "uint16"], ["i64", "int64"], ["u64", "uint64"], ["d", "double"], ["b", "boolean"],

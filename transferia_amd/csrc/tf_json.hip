@@ -63,6 +63,7 @@ struct JCol {
   uint32_t *fstart; // text: absolute offset of the source bytes
   uint32_t *meta;   // text: source length | JMode << 28
   uint8_t *cellst;  // JCellSt per line
+  uint32_t scr_base;            // a nested ColSchema.Path: where this column's scratch copy of the input starts in JParams::scratch
   uint32_t npath_off, npath_n;  // a nested ColSchema.Path (lookupComplex): npath_n field names behind the top-level key, at names + npath_off as (u16 length, bytes) …
 };
 static constexpr uint32_t JCOL_NESTED = 0x10000u;  // JCol.flags: the column reads through lookupComplex (its ParseVal errors follow generic_parser.go:338-346)
@@ -722,9 +723,9 @@ __device__ int nested_try(MemBytes &rd, uint32_t s, uint32_t e, uint32_t *at) {
   return 1;
 }
 // parseJSON (lookup.go:41-59).  1 = t holds a text whose value is an object at *at, 2 = error (no map), 0 = host
-__device__ int nested_parse(const JParams &p, NText &t, uint32_t *at) {
+__device__ int nested_parse(const JParams &p, uint8_t *const scr, NText &t, uint32_t *at) {
   {
-    MemBytes rd(t.scr ? p.scratch : p.data);
+    MemBytes rd(t.scr ? scr : p.data);
     const int r = nested_try(rd, t.s, t.e, at);
     if (r) return r < 0 ? 0 : 1;
     bool bs = false;
@@ -732,8 +733,8 @@ __device__ int nested_parse(const JParams &p, NText &t, uint32_t *at) {
     if (!bs) return 2;  // the retries would try the same text
   }
   {  // strings.ReplaceAll(s, `\\"`, `\"`): left to right, non-overlapping
-    MemBytes rd(t.scr ? p.scratch : p.data);
-    sr::ByteSink o{p.scratch + t.s};
+    MemBytes rd(t.scr ? scr : p.data);
+    sr::ByteSink o{scr + t.s};
     uint32_t n = 0;
     for (uint32_t i = t.s; i < t.e;) {
       if (t.e - i >= 3 && rd.at(i) == '\\' && rd.at(i + 1) == '\\' && rd.at(i + 2) == '"') { o.put('\\'); o.put('"'); n += 2; i += 3; }
@@ -743,31 +744,31 @@ __device__ int nested_parse(const JParams &p, NText &t, uint32_t *at) {
     t.scr = true; t.e = t.s + n;
   }
   {
-    MemBytes rd(p.scratch);
+    MemBytes rd(scr);
     const int r = nested_try(rd, t.s, t.e, at);
     if (r) return r < 0 ? 0 : 1;
   }
   {  // strings.ReplaceAll(s, `\`, ``)
-    MemBytes rd(p.scratch);
-    sr::ByteSink o{p.scratch + t.s};
+    MemBytes rd(scr);
+    sr::ByteSink o{scr + t.s};
     uint32_t n = 0;
     for (uint32_t i = t.s; i < t.e; i++) { const uint32_t c = rd.at(i); if (c != '\\') { o.put(c); n++; } }
     o.flush();
     t.e = t.s + n;
   }
-  MemBytes rd(p.scratch);
+  MemBytes rd(scr);
   const int r = nested_try(rd, t.s, t.e, at);
   return r < 0 ? 0 : r ? 1 : 2;
 }
 // the Go string of the JSON string token [fs, fe) of text t (decode.go unquote) → t2; false: host
-__device__ bool nested_decode(const JParams &p, const NText &t, uint32_t fs, uint32_t fe, bool plain, NText &t2) {
+__device__ bool nested_decode(const JParams &p, uint8_t *const scr, const NText &t, uint32_t fs, uint32_t fe, bool plain, NText &t2) {
   if (plain && !t.scr) { t2 = NText{false, fs + 1, fe - 1}; return true; }  // its bytes, where they lie
-  MemBytes rd(t.scr ? p.scratch : p.data);
+  MemBytes rd(t.scr ? scr : p.data);
   if (!plain && !nested_utf8_ok(rd, fs + 1, fe - 1)) return false;
-  sr::ByteSink o{p.scratch + fs + 1};
+  sr::ByteSink o{scr + fs + 1};
   sr::CountSink cnt;
   sr::emit_unquoted(cnt, rd, fs, fe - fs);
-  MemBytes rd2(t.scr ? p.scratch : p.data);
+  MemBytes rd2(t.scr ? scr : p.data);
   sr::emit_unquoted(o, rd2, fs, fe - fs);  // (in place when t is the scratch: every rune leaves at most the bytes it took)
   o.flush();
   t2 = NText{true, fs + 1, fs + 1 + cnt.n};
@@ -777,6 +778,7 @@ __device__ int store_nested(const JParams &p, const JCol &c, const int64_t r, co
   auto nil = [&]() { if (c.kind == JK_TEXT || c.kind == JK_ANY) c.lens[r] = 0; c.cellst[r] = JC_NIL; return 1; };  // "lookupComplex error" / nil: json_finish applies the key / required rule
   if (vtype == V_NULL) return nil();  // unexpected value type: <nil>
   if (vtype != V_STR || sv.bs || !p.scratch) return 0;
+  uint8_t *const scr = p.scratch + c.scr_base;  // this column's own copy: columns that read one top-level value must not rewrite each other's texts
   if ((sv.s + sv.n) >> 32) return 0;
   NText t{false, (uint32_t)sv.s, (uint32_t)(sv.s + sv.n)};  // the Go string lookupComplex holds: parsed when a name is taken from it
   bool is_obj = false;                                       // … or an object of an already validated text: walked
@@ -786,10 +788,10 @@ __device__ int store_nested(const JParams &p, const JCol &c, const int64_t r, co
     const uint32_t sl = (uint32_t)seg[0] | ((uint32_t)seg[1] << 8);
     const uint8_t *name = seg + 2;
     seg += 2 + sl;
-    if (!is_obj) { const int pr = nested_parse(p, t, &at); if (pr == 0) return 0; if (pr == 2) return nil(); }  // unable to parse json / a nil map: unable to get field
+    if (!is_obj) { const int pr = nested_parse(p, scr, t, &at); if (pr == 0) return 0; if (pr == 2) return nil(); }  // unable to parse json / a nil map: unable to get field
     else at = t.s;
     // members of the object at `at`: the LAST member with this name wins (a Go map)
-    MemBytes rd(t.scr ? p.scratch : p.data);
+    MemBytes rd(t.scr ? scr : p.data);
     uint32_t fs = 0, fe = 0, ft = sr::VT_ABSENT;
     uint32_t pos = at + 1;
     for (;;) {
@@ -818,16 +820,16 @@ __device__ int store_nested(const JParams &p, const JCol &c, const int64_t r, co
     const bool last = k + 1 == c.npath_n;
     if (vk == sr::VT_STR) {
       NText t2;
-      if (!nested_decode(p, t, fs, fe, (ft & sr::VT_PLAIN) != 0, t2)) return 0;
+      if (!nested_decode(p, scr, t, fs, fe, (ft & sr::VT_PLAIN) != 0, t2)) return 0;
       if (!last) { t = t2; is_obj = false; continue; }
       // ParseVal(the string, DataType)
       if (c.kind == JK_TEXT) {
-        jtext(c, r, t2.s, t2.e - t2.s, t2.scr ? JM_SCRATCH : JM_COPY, t2.e - t2.s);
+        jtext(c, r, t2.scr ? c.scr_base + t2.s : t2.s, t2.e - t2.s, t2.scr ? JM_SCRATCH : JM_COPY, t2.e - t2.s);
         c.cellst[r] = JC_OK;
         return 1;
       }
       if (c.kind == JK_ANY && t2.scr) return 0;  // (its text cell would be cut from the input)
-      MemBytes rv(t2.scr ? p.scratch : p.data);
+      MemBytes rv(t2.scr ? scr : p.data);
       JStr v{};
       v.s = t2.s; v.n = t2.e - t2.s; v.hash = 0; v.ctrl = false; v.bs = false; v.plain = !t2.scr;
       return store_cell_plain<false>(p, c, r, rv, V_STR, (uint64_t)t2.s, (uint64_t)t2.e, v, 0, false) == 1 ? 1 : 0;
@@ -2103,7 +2105,7 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
     names.append((8 - names.size() % 8) % 8, '\0');  // whole 8-byte words: the device compares a word at a time
   }
 
-  for (auto &nb : nested_blobs) { cols[(size_t)nb.first].npath_off = (uint32_t)names.size(); names += nb.second; }
+  { size_t k = 0; for (auto &nb : nested_blobs) { cols[(size_t)nb.first].npath_off = (uint32_t)names.size(); names += nb.second; cols[(size_t)nb.first].scr_base = (uint32_t)(k++ * ((len + 64 + 63) & ~63ull)); } }
   names.append((8 - names.size() % 8) % 8 + 8, '\0');
   const bool any_nested = !nested_blobs.empty();
 
@@ -2225,7 +2227,12 @@ extern "C" int tfgpu_json_parse(const tfgpu_json_options *opts, const tfgpu_sche
   pp.add_rest = opts->add_rest; pp.use_numbers = opts->use_numbers_in_any;
   pp.format = opts->format; pp.tskv_unescape = tskv && opts->unescape_string_values;
   Buf scratch;
-  if (any_nested) { scratch = dalloc_zero(len + 64); pp.scratch = ptr<uint8_t>(scratch); }
+  if (any_nested) {  // one copy-sized region per nested column (cells are 32-bit offsets into it)
+    const uint64_t per = (len + 64 + 63) & ~63ull;
+    if (per * nested_blobs.size() >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "json: nested ColSchema.Path columns x batch bytes exceed 4 GiB of scratch; split the batch");
+    scratch = dalloc_zero(per * nested_blobs.size());
+    pp.scratch = ptr<uint8_t>(scratch);
+  }
   if (rest_seg >= 0) {
     pp.rest_lens = ptr<uint32_t>(lens_all) + (int64_t)rest_seg * seg_stride;
     pp.rest_fstart = ptr<uint32_t>(fstart_all) + (int64_t)rest_seg * 2 * nalloc;
