@@ -196,6 +196,7 @@ typedef enum tfgpu_rowerr {
   TFGPU_ROW_DBZ_OP = 21,           /* opToKind: unknown op (kind.go:34-46)                                              */
   TFGPU_ROW_DBZ_SCHEMA = 22,       /* receiveSchema fails: the schema does not unmarshal, or a field's Kafka type has no
                                       receiver (receiver.go:60-96, receiver_engine.go:108-146)                          */
+  TFGPU_ROW_DROPPED = 24,          /* registry-framed Debezium: an earlier event of the same Kafka message failed; DoBuf stops there */
   TFGPU_ROW_DBZ_FIELD = 23         /* a schema field is missing from before / after, or receiveField rejects its value
                                       (receiver.go:216-230, receiver_engine.go:148-287)                                 */
 } tfgpu_rowerr;
@@ -843,6 +844,39 @@ int tfgpu_dbz_receive_group(tfgpu_dbz_receiver *r, int32_t g, tfgpu_dbatch **bat
 /* table g's ID / LSN / CommitTime / names_form by MESSAGE index — the arrays a tfgpu_row_meta of the whole message batch takes
  * (nmsg entries each, zeroed first; NULL: not wanted): the rows' src_row is the message index, so this is their row meta.      */
 int tfgpu_dbz_receive_group_meta(tfgpu_dbz_receiver *r, int32_t g, int64_t nmsg, uint32_t *ids, uint64_t *lsns, uint64_t *commit_times, uint8_t *names_form);
+
+/* ---- Debezium events framed by a schema registry (NewDebeziumImpl with a registry client; the f1 remainder of SURVEY §8) ---------
+ * DebeziumImpl.DoOne (pkg/parsers/registry/debezium/engine/parser.go:33-57) cuts a Kafka message into EVENTS  0x00 | schema id
+ * (BE uint32) | payload up to the next 0x00 byte — the cut tfgpu_sr_frames makes; SchemaRegistry.Unpack
+ * (pkg/debezium/unpacker/schema_registry.go:18-34) fetches the schema by id (network: stays with the shim) and
+ * Receiver.convertSchemaFormat (receiver.go:118-139) turns the registry's ConfluentJSONSchema into the Kafka Connect form the
+ * receiver reads (ToKafkaJSONSchema, pkg/schemaregistry/format/json_schema_format.go:120-164).
+ *
+ * tfgpu_debezium_compile_registry_schema: convertSchemaFormat + receiveSchema for one registry schema text — encoding/json's
+ * binding of ConfluentJSONSchema (every field's JSON type checked), oneOf → optional, properties ordered by connect.index,
+ * confluentTypeToKafka; then what tfgpu_debezium_compile_schema does.  Same result object (tfgpu_dbz_schema_info).
+ * tfgpu_dbz_receiver_add_registry_schema: the same, kept by the receiver under `schema_id`.
+ * tfgpu_debezium_registry_frames: the first half of UnmarshalPayload for every event of tfgpu_sr_frames — the span of the ONE value
+ * json.Decoder reads behind the prefix (frames[e].payload_*; code = TFGPU_ROW_DBZ_PAYLOAD when it is not JSON,
+ * TFGPU_ROW_SR_MAGIC for a first byte that is not 0 — DoOne looks at it before the length — TFGPU_ROW_HOST_FALLBACK for a zero-led tail
+ * shorter than the prefix: the reference's buf[5:] panics);
+ * frames[e].schema_hash = {schema id, TFGPU_DBZ_REGISTRY_HASH}.  event_msgs: one slot per event (start[e] = where the event
+ * starts, nmsg = the number of events) — what tfgpu_debezium_parse takes as `msgs` with these frames.
+ * tfgpu_dbz_receive_registry: DoBatch with a registry.  events (HOST, events_cap entries) receives tfgpu_sr_frames' list,
+ * *nevents its length (larger than events_cap: TFGPU_ERR_INVALID, nothing done).  Schema ids nobody registered are listed in
+ * missing_ids (first missing_cap of *nmissing): register them and call again — nothing was parsed (*ngroups = 0).  Otherwise
+ * every group of events with one schema id is parsed; event_codes[e] (HOST, events_cap entries) = TFGPU_ROW_OK, why event e
+ * becomes an `_unparsed` item, TFGPU_ROW_HOST_FALLBACK (the stock code takes the whole Kafka message: every event of it carries
+ * this code), or TFGPU_ROW_DROPPED: an earlier event of the same Kafka message failed and DoBuf stopped there (DoOne returns a
+ * nil rest).  The groups' rows (tfgpu_dbz_receive_group; src_row and rows[i].msg = the EVENT's ordinal; events[e].msg / .index =
+ * its Kafka message and QueueMessageMeta.Index) hold the events with TFGPU_ROW_OK only.                                       */
+#define TFGPU_DBZ_REGISTRY_HASH 0x5343484D52454749ull
+int tfgpu_debezium_compile_registry_schema(const void *schema_text, uint64_t len, tfgpu_dbz_schema **out);
+int tfgpu_dbz_receiver_add_registry_schema(tfgpu_dbz_receiver *r, uint32_t schema_id, const void *schema_text, uint64_t len);
+int tfgpu_debezium_registry_frames(const void *bytes, uint64_t len, int mem, const tfgpu_messages *event_msgs, const tfgpu_sr_frame *events, tfgpu_dbz_frame *frames);
+int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
+                               tfgpu_sr_frame *events, int64_t events_cap, int64_t *nevents, int32_t *event_codes,
+                               uint32_t *missing_ids, int32_t missing_cap, int32_t *nmissing, int32_t *ngroups);
 
 /* ---- ClickHouse Native column block -------------------------------------------------------------------- */
 /* The v2 ClickHouse sink turns every ChangeItem into a []any row (pkg/providers/clickhouse/async/marshaller.go:62-190) and

@@ -277,6 +277,120 @@ def debezium_parse(data: bytes, msgs: abi.CMessages = None):
 debezium_parse.want_items = True
 
 
+def debezium_parse_sr(data: bytes, msgs: abi.CMessages, registry):
+    """DebeziumImpl.DoBatch with a schema registry (NewDebeziumImpl(logger, client, threads)); registry: schema id → the registry's
+    schema text (bytes).  Restated on top of debezium_parse: DoBuf / DoOne's cut of a Kafka message into events
+    (pkg/parsers/registry/debezium/engine/parser.go:33-71), SchemaRegistry.Unpack (pkg/debezium/unpacker/schema_registry.go:18-34),
+    convertSchemaFormat (receiver.go:118-139, ora_srformat.py), the json.Decoder half of UnmarshalPayload (one value; a scalar must be
+    followed by white space or the end), then Receiver.receive(schema, payload) — which is what the inline-schema path runs on the
+    two raw members of `{"schema": …, "payload": …}`, so each event is handed to it in that envelope.
+    Returns (events, items, codes): events[e] = (message, index inside it, schema id or None); codes[e] = TFGPU_ROW_* with the
+    DoBuf rule applied (TFGPU_ROW_DROPPED behind a failed event, TFGPU_ROW_HOST_FALLBACK for every event of a message the stock code
+    must redo); items = {e: item} for the events that are ChangeItems."""
+    import json as pyjson
+    from . import ora_srformat as F
+    nmsg = msgs.nmsg
+    starts = np.ctypeslib.as_array(C.cast(msgs.start, C.POINTER(C.c_uint64)), (nmsg + 1,))
+    ROW_SR_MAGIC, ROW_DROPPED = 16, 24
+    events, pre, payloads = [], [], []
+    for m in range(nmsg):
+        buf = data[int(starts[m]):int(starts[m + 1])]
+        idx = 0
+        while buf:
+            if buf[0] != 0:   # "debezium parser configured with SR, but magic byte is not NULL": unparsed, nil rest
+                events.append((m, idx, None)); pre.append(ROW_SR_MAGIC); payloads.append(None)
+                break
+            if len(buf) < 5:  # buf[5:] panics
+                events.append((m, idx, None)); pre.append(abi.ROW_HOST_FALLBACK); payloads.append(None)
+                break
+            z = buf.find(b"\x00", 5)
+            n = len(buf) if z < 0 else z
+            events.append((m, idx, int.from_bytes(buf[1:5], "big"))); pre.append(abi.ROW_OK); payloads.append(buf[5:n])
+            buf = buf[n:]
+            idx += 1
+    converted = {}
+
+    def kafka_text(sid):
+        if sid not in converted:
+            try:
+                converted[sid] = F.convert_schema_format(registry[sid])
+            except F.Unbindable:
+                converted[sid] = abi.ROW_DBZ_SCHEMA
+            except F.GoPanic:
+                converted[sid] = abi.ROW_HOST_FALLBACK
+        return converted[sid]
+
+    def bad_constant(_name):
+        raise ValueError("not JSON")
+    dec = pyjson.JSONDecoder(parse_constant=bad_constant)
+    codes = list(pre)
+    synth, synth_ev = [], []
+    for e, (m, idx, sid) in enumerate(events):
+        if codes[e]:
+            continue
+        kt = kafka_text(sid)
+        text = payloads[e].decode("latin-1")
+        i = 0
+        while i < len(text) and text[i] in " \t\r\n":
+            i += 1
+        if i == len(text):
+            value = b""   # Decode: io.EOF
+        else:
+            try:
+                _v, end = dec.raw_decode(text, i)
+            except (ValueError, RecursionError):
+                codes[e] = abi.ROW_DBZ_PAYLOAD
+                continue
+            if text[i] not in "{[" and end < len(text) and text[end] not in " \t\r\n":
+                codes[e] = abi.ROW_DBZ_PAYLOAD   # invalid character after top-level value
+                continue
+            value = text[i:end].encode("latin-1")
+        if not value:
+            codes[e] = abi.ROW_DBZ_PAYLOAD
+            continue
+        if isinstance(kt, int):  # receive: UnmarshalPayload and opToKind come first, then receiveSchema fails (a schema that is no object fails there too)
+            synth.append(b'{"schema":7,"payload":' + value + b"}")
+            synth_ev.append((e, kt))
+            continue
+        synth.append(b'{"schema":' + kt + b',"payload":' + value + b"}")
+        synth_ev.append((e, None))
+    items = {}
+    if synth:
+        sdata, smsgs = abi.messages(synth)
+        its, cs = debezium_parse(sdata, smsgs)
+        for it in its:
+            e = synth_ev[it["src"]][0]
+            it["src"] = e
+            items[e] = it
+        for k, c in enumerate(cs):
+            e, fate = synth_ev[k]
+            codes[e] = fate if (fate is not None and c == abi.ROW_DBZ_SCHEMA) else c
+    # DoBuf: the first failed event ends its message; an event for the stock code takes the message with it
+    a = 0
+    while a < len(events):
+        z = a
+        while z < len(events) and events[z][0] == events[a][0]:
+            z += 1
+        host = False
+        for e in range(a, z):
+            if codes[e] == abi.ROW_HOST_FALLBACK:
+                host = True
+            if codes[e]:
+                break
+        dead = False
+        for e in range(a, z):
+            if host:
+                codes[e] = abi.ROW_HOST_FALLBACK
+            elif dead:
+                codes[e] = ROW_DROPPED
+            elif codes[e]:
+                dead = True
+            if codes[e]:
+                items.pop(e, None)
+        a = z
+    return events, items, codes
+
+
 def ch_native_block(batch: abi.Batch, schema: abi.Schema, columns):
     """One ClickHouse Native block of the batch (ora_chnative.c); `columns` = [(name, ClickHouse type), ...]; None = refused."""
     L = lib()

@@ -93,13 +93,9 @@ def twos(v: int) -> str:
     return base64.b64encode(v.to_bytes(n, "big", signed=True)).decode()
 
 
-def cdc_messages(n, seed=3, table="events", weird=True):
-    """n Debezium events over n/4 keys: inserts / updates / deletes, nulls, escapes, every receiver of FIELDS; with `weird`
-    also the messages the reference turns into `_unparsed` items or panics on."""
-    import random
-    rng = random.Random(seed)
-    schema = json.dumps(envelope_schema(table), separators=(",", ":"))
-    out = []
+def cdc_payloads(rng, n, table="events", weird=True):
+    """The payloads of n Debezium events over n/4 keys, one at a time (the caller shares `rng`): inserts / updates / deletes, nulls,
+    escapes, every receiver of FIELDS; with `weird` also payloads the reference turns into `_unparsed` items or panics on."""
     for k in range(n):
         key = rng.randrange(max(n // 4, 1))
         def row():
@@ -126,6 +122,16 @@ def cdc_messages(n, seed=3, table="events", weird=True):
                              ps.replace('"score":0,', '"score":0.1e-400,'), ps.replace('"id":%d' % key, '"id":0%d' % key), ps.replace('"at":', '"at":-9223372036854775808,"at2":'),
                              ps.replace('"at":', '"at":9223372036854775808,"_":'), ps.replace('"source":{', '"source":{"lsn":"x",'), ps.replace('"source":{', '"source":null,"s2":{'),
                              ps.replace('"op":"%s"' % op, '"op":"\\u0063"'), ps.replace('"flag":null', '"flag":null,"flag":true')])
+        yield k, ps
+
+
+def cdc_messages(n, seed=3, table="events", weird=True):
+    """The same events in the inline-schema envelope; with `weird` also the messages IncludeSchema.Unpack rejects."""
+    import random
+    rng = random.Random(seed)
+    schema = json.dumps(envelope_schema(table), separators=(",", ":"))
+    out = []
+    for k, ps in cdc_payloads(rng, n, table, weird):
         if k % 3 == 0:
             msg = '{"schema":%s,"payload":%s}' % (schema, ps)
         elif k % 3 == 1:

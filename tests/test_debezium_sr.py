@@ -1,0 +1,229 @@
+"""Debezium events framed by a schema registry (NewDebeziumImpl with a registry client; the f1 remainder of SURVEY §8):
+0x00 | schema id | payload, several events per Kafka message, the registry's ConfluentJSONSchema converted to the Kafka Connect form.
+CPU: the oracle's format conversion pinned to the reference's fixtures, the C side's schema compilation against it.
+GPU: tfgpu_dbz_receive_registry against the oracle."""
+import json
+import random
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from util import golden
+from test_debezium import SEED0, assert_same_items, cdc_payloads, device_items, envelope_schema
+
+
+# ---- pkg/schemaregistry/format, pinned to its own tests' fixtures -------------------------------------------------------------
+def test_format_fixture_properties():
+    """json_schema_format_test.go: TestMarshalUnmarshal{Kafka,Confluent}[Arrays] (the structs keep every field of the fixtures),
+    TestKafkaToConfluentToKafka[Arrays] (identity), TestCanonizeMakeClosedContentModelTrue (canon file).  The fixtures are one
+    envelope in both forms, so Confluent → Kafka of one must be the other."""
+    from oracle import ora_srformat as F
+    g = golden("sr_format.json")
+    for sfx in ("", "_arr"):
+        k, c = g["kafka" + sfx], g["confluent" + sfx]
+        kb, cb = F.bind_kafka(k), F.bind_confluent(c)
+        assert kb == k and cb == c
+        assert F.to_kafka(F.to_confluent(kb)) == kb
+        assert F.to_kafka(cb) == kb
+    assert F.to_confluent(F.to_kafka(F.bind_confluent(g["confluent"])), closed=True) == g["closed_canon"]
+
+
+def test_format_edges():
+    from oracle import ora_srformat as F
+    assert F.to_kafka(F.bind_confluent({"oneOf": [{"type": "null"}, {"type": "integer", "connect.type": "int16"}]})) == {"type": "int16", "optional": True}
+    assert F.to_kafka(F.bind_confluent({"type": "number"})) == {"type": "bytes", "optional": False}
+    assert F.to_kafka(F.bind_confluent({"type": "number", "connect.type": "float32"}))["type"] == "float"
+    assert F.to_kafka(F.bind_confluent({"type": "string", "connect.type": "bytes", "connect.parameters": {"scale": "2"}, "title": "org.apache.kafka.connect.data.Decimal"})) == \
+        {"type": "bytes", "optional": False, "name": "org.apache.kafka.connect.data.Decimal", "parameters": {"scale": "2"}}
+    with pytest.raises(F.GoPanic):
+        F.to_kafka(F.bind_confluent({"properties": {"a": {}, "b": {"connect.index": 1}}}))
+    assert F.to_kafka(F.bind_confluent({"properties": {"a": {}}}))["fields"] == [{"type": "", "optional": False, "field": "a"}]   # one property: sort.Slice compares nothing
+    with pytest.raises(F.Unbindable):
+        F.bind_confluent({"connect.index": 1.5})
+    with pytest.raises(F.Unbindable):
+        F.bind_confluent({"oneOf": {}})
+
+
+# ---- the C side's convertSchemaFormat + receiveSchema (host code: no GPU needed) --------------------------------------------
+def registry_text(table="events"):
+    from oracle import ora_srformat as F
+    return json.dumps(F.to_confluent(F.bind_kafka(envelope_schema(table))), separators=(",", ":")).encode()
+
+
+def test_compile_registry_schema_equals_the_inline_compile():
+    from transferia_amd import debezium
+    g = golden("sr_format.json")
+    for sfx in ("", "_arr"):
+        try:
+            want = debezium.compile_schema(json.dumps(g["kafka" + sfx]).encode())
+        except debezium.HostOnly:
+            with pytest.raises(debezium.HostOnly):
+                debezium.compile_registry_schema(json.dumps(g["confluent" + sfx]).encode())
+            continue
+        assert debezium.compile_registry_schema(json.dumps(g["confluent" + sfx]).encode()) == want and len(want) == (60 if not sfx else 37)
+    assert debezium.compile_registry_schema(registry_text()) == debezium.compile_schema(json.dumps(envelope_schema()).encode())
+
+
+BROKEN = [b'{"title": 5}', b"[1]", b"", b'{"connect.version": 1.5}', b'{"properties": {"before": 7}}', b'{"oneOf": [3]}', b'{"connect.parameters": {"scale": 2}}', b"{"]
+HOST = [b'{"properties":{"a":{},"b":{}}}', b'{"properties":{"a":{"connect.index":1},"b":{"connect.index":1}}}', b"null", b'{"oneOf":[{"type":"null"}]}', b'{"Type": "object"}']
+
+
+def test_compile_registry_schema_failures_follow_the_oracle():
+    from oracle import ora_srformat as F
+    from transferia_amd import debezium
+    for text in BROKEN:
+        with pytest.raises(F.Unbindable):
+            F.convert_schema_format(text)
+        with pytest.raises(debezium.SchemaError):
+            debezium.compile_registry_schema(text)
+    for text in HOST:
+        with pytest.raises(debezium.HostOnly):
+            debezium.compile_registry_schema(text)
+
+
+# ---- streams ------------------------------------------------------------------------------------------------------------------
+def frame(sid, payload: bytes) -> bytes:
+    return b"\x00" + int(sid).to_bytes(4, "big") + payload
+
+
+def sr_stream(n, seed, weird=True):
+    """n events of two tables (registry ids 7 and 300) packed into Kafka messages of one to three events; with `weird` also the
+    payloads and framings the reference turns into `_unparsed` items, stops a message at, or panics on."""
+    rng = random.Random(seed)
+    ev = [(7, ps) for _k, ps in cdc_payloads(rng, n, "events", weird)] + [(300, ps) for _k, ps in cdc_payloads(rng, max(n // 8, 1), "orders", False)]
+    rng.shuffle(ev)
+    msgs, cur = [], b""
+    for i, (sid, ps) in enumerate(ev):
+        body = ps.encode("utf-8")
+        r = rng.random()
+        if r < 0.15:
+            body = rng.choice([b" ", b"\n\t ", b""]) + body + rng.choice([b"\n", b" \r\n", b"  "])
+        if weird and i % 13 == 6:
+            body = rng.choice([b"", b"   ", b"null", b"nullx", b"null x", b"[1]", b"7", b'"s"', body[:-1], body + b" trailing garbage", body + b"}", b"{" + body, b"tru", b"{}"])
+        if weird and i % 29 == 11:
+            sid = rng.choice([41, 42, 43])   # a schema that does not bind / panics in the reference / converts to a struct without `after`
+        cur += frame(sid, body)
+        tail = weird and i % 37 == 20
+        if tail:   # what the next DoOne call meets at the end of a Kafka message: a stump shorter than the prefix (buf[5:] panics), or bytes that stay in the payload
+            cur += rng.choice([b"\x00", b"\x00\x00\x00", b"\x01abc", b"garbage"])
+        if tail or rng.random() < 0.6:
+            msgs.append(cur)
+            cur = b""
+    msgs.append(cur)
+    if weird:
+        msgs += [b"", b"\x00\x00", b"x", frame(7, b'{"op":"c"}')]
+    return msgs
+
+
+REGISTRY = {41: b'{"title": 5}', 42: b'{"properties":{"a":{},"b":{}}}', 43: b'{"type":"object","properties":{"x":{"type":"string","connect.index":0}}}'}
+
+
+def registry():
+    reg = dict(REGISTRY)
+    reg[7], reg[300] = registry_text("events"), registry_text("orders")
+    return reg
+
+
+def expected_fates(codes, items, events):
+    """the oracle's fates plus the device's one-table-per-group rule (an item whose TableID differs from the first good item of its schema id)"""
+    out = {e: c for e, c in enumerate(codes) if c}
+    first = {}
+    for e in sorted(items):
+        sid = events[e][2]
+        ref = first.setdefault(sid, (items[e]["ns"], items[e]["table"]))
+        if (items[e]["ns"], items[e]["table"]) != ref:
+            out[e] = abi.ROW_HOST_FALLBACK
+    return out
+
+
+def apply_message_rule(fates, events):
+    """DoBuf's rule once more, after fates were added: a message with a host event goes to the host whole, events behind a failed one drop"""
+    out = dict(fates)
+    by_msg = {}
+    for e, (m, _i, _s) in enumerate(events):
+        by_msg.setdefault(m, []).append(e)
+    for es in by_msg.values():
+        host, dead = False, False
+        for e in es:
+            if out.get(e) == abi.ROW_HOST_FALLBACK:
+                host = True
+            if out.get(e):
+                break
+        for e in es:
+            if host:
+                out[e] = abi.ROW_HOST_FALLBACK
+            elif dead:
+                out[e] = abi.ROW_DROPPED
+            elif out.get(e):
+                dead = True
+    return out
+
+
+def test_oracle_sr_stream_is_consistent(oracle):
+    """the restated DoBatch over a stream: every event has a fate, good ones are the payloads' own items"""
+    msgs = sr_stream(300, 5)
+    data, m = abi.messages(msgs)
+    events, items, codes = oracle.debezium_parse_sr(data, m, registry())
+    assert len(events) == len(codes) and len(items) > 150
+    assert all(codes[e] == abi.ROW_OK for e in items)
+    seen = {c for c in codes}
+    assert {abi.ROW_OK, abi.ROW_DBZ_PAYLOAD, abi.ROW_DBZ_SCHEMA, abi.ROW_HOST_FALLBACK, abi.ROW_DROPPED, abi.ROW_SR_MAGIC} <= seen, seen
+    assert {it["table"] for it in items.values()} == {"events", "orders", ""}   # (a payload whose `source` is null: empty Schema / Table)
+    for (mm, idx, _sid), nxt in zip(events, events[1:]):
+        assert nxt[0] > mm or nxt[1] == idx + 1
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,weird", [(1, False), (200, False), (900, True)])
+def test_gpu_registry_stream_matches_oracle(tf, oracle, n, weird):
+    from transferia_amd import debezium
+    msgs = sr_stream(n, 100 + n + SEED0, weird)
+    data, m = abi.messages(msgs)
+    reg = registry()
+    exp_events, exp_items, codes = oracle.debezium_parse_sr(data, m, reg)
+    parser = debezium.Parser(tf)
+    parsed, missing, _ = parser.parse_registry(data, m)
+    used = sorted({e[2] for e in exp_events if e[2] is not None})
+    assert parsed is None and sorted(missing) == used      # nothing registered yet: the shim learns the ids it has to fetch
+    for sid in used:
+        parser.add_registry_schema(sid, reg[sid])
+    parsed, errors, events = parser.parse_registry(data, m)
+    assert events == exp_events
+    want = apply_message_rule(expected_fates(codes, exp_items, exp_events), exp_events)
+    assert errors == want, ({k: (errors.get(k), want.get(k)) for k in set(errors) | set(want) if errors.get(k) != want.get(k)})
+    got = {}
+    for p in parsed:
+        got.update(device_items(tf, p))
+    exp = {e: it for e, it in exp_items.items() if e not in want}
+    assert sorted(got) == sorted(exp)
+    for e in exp:
+        assert_same_items(got[e], exp[e], e)
+    if n >= 200:
+        assert {p.batch.table_id() for p in parsed} == {("public", "events"), ("public", "orders")}
+    fb = sum(1 for c in errors.values() if c == abi.ROW_HOST_FALLBACK)
+    assert fb <= (0 if not weird else len(exp_events) // 6), fb
+
+
+@pytest.mark.gpu
+def test_gpu_registry_frames_refuse_foreign_events(tf):
+    """events that do not come from tfgpu_sr_frames over the same bytes are refused, not followed"""
+    import ctypes as C
+    L = tf.load()
+    data = frame(7, b'{"op":"c"}')
+    ev = (abi.CSrFrame * 1)()
+    ev[0].msg, ev[0].start, ev[0].len, ev[0].schema_id = 0, 5, 4000, 7
+    starts = np.array([0, len(data)], np.uint64)
+    em = abi.CMessages()
+    em.nmsg, em.start = 1, starts.ctypes.data
+    fr = (abi.CDbzFrame * 1)()
+    L.tfgpu_debezium_registry_frames.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(abi.CMessages), C.POINTER(abi.CSrFrame), C.POINTER(abi.CDbzFrame)]
+    rc = L.tfgpu_debezium_registry_frames(data, len(data), abi.MEM_HOST, C.byref(em), ev, fr)
+    assert rc == tf.ERR_INVALID

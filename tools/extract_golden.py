@@ -1081,6 +1081,19 @@ def debezium():
     write("debezium.json", {"cases": cases})
 
 
+def sr_format():
+    """pkg/schemaregistry/format: the two fixture pairs json_schema_format_test.go embeds (the Postgres all-types Debezium envelope in Kafka
+    Connect and in Confluent JSON-schema form, without and with array columns) and the canon of TestCanonizeMakeClosedContentModelTrue."""
+    d = REF + "/pkg/schemaregistry/format/"
+    out = {"source": "pkg/schemaregistry/format/{full_*_test.json, gotest/canondata/result.json}"}
+    for name in ("kafka", "confluent", "kafka_arr", "confluent_arr"):
+        a, b = name.split("_")[0], "_arr" if name.endswith("_arr") else ""
+        with open(d + "full_%s_json_schema%s_test.json" % (a, b)) as f:
+            out[name] = json.load(f)
+    out["closed_canon"] = canon(d + "gotest/canondata/result.json", "gotest.gotest.TestCanonizeMakeClosedContentModelTrue")
+    write("sr_format.json", out, compact=True)
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -1094,4 +1107,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium(); sr_format()

@@ -133,15 +133,103 @@ static void receiver_of(const Schema &f, int32_t &op, int32_t &scale) {
   throw SchemaError{"unable to find field receiver - even default, for kafka type: " + f.type};
 }
 // receiveSchema for one distinct schema: the fields of the `after` struct; code = TFGPU_ROW_OK, or what the whole schema is
-static int compile(const uint8_t *bytes, size_t len, std::vector<Field> &out, std::string &why) {
+// ---- Schema-registry framed events (NewReceiver with a registry client: receiver.go:221-235) ------------------------------------
+// The registry's schema text is a ConfluentJSONSchema; convertSchemaFormat (receiver.go:118-139) unmarshals it, turns it into a
+// KafkaJSONSchema (ToKafkaJSONSchema, pkg/schemaregistry/format/json_schema_format.go:120-164) and marshals that for
+// UnmarshalSchema.  from_confluent does the three steps in one: the ConfluentJSONSchema as json.Unmarshal binds it (:52-68; every
+// field's JSON type checked like the struct's), straight into the Schema UnmarshalSchema would read from the marshalled text.
+//   oneOf: the first entry whose type is not "null", made optional (:121-129)
+//   properties: sorted by *connect.index (:139-141; sort.Slice — a nil index among two or more properties is the reference's nil
+//     dereference, equal indexes leave the order to pdqsort: both host)
+//   type: confluentTypeToKafka(type, connect.type) (:70-96)
+static std::string confluent_type_to_kafka(const std::string &json_type, const std::string &connect_type) {
+  if (json_type == "object") return "struct";
+  if (json_type == "string") return connect_type == "bytes" ? "bytes" : "string";
+  if (json_type == "boolean") return "boolean";
+  if (json_type == "integer") return connect_type;
+  if (json_type == "number") return connect_type == "float64" ? "double" : connect_type == "float32" ? "float" : "bytes";
+  if (json_type == "array") return "array";
+  return "";
+}
+static std::string cstring_field(const Json &obj, const char *name) {
+  const Json *v = member(obj, name);
+  if (!v || v->type == Json::Null) return "";
+  if (v->type != Json::Str) throw SchemaError{std::string("json: cannot unmarshal into Go struct field ConfluentJSONSchema.") + name + " of type string"};
+  return v->str;
+}
+static Schema from_confluent(const Json *node, int depth) {
+  Schema s;  // (a null binds nothing: the zero ConfluentJSONSchema, whose Kafka form is {"type":"","optional":false})
+  if (!node || node->type == Json::Null) return s;
+  if (node->type != Json::Obj || depth > 64) throw SchemaError{"json: cannot unmarshal into Go value of type format.ConfluentJSONSchema"};
+  // json.Unmarshal binds every field before ToKafkaJSONSchema looks at any: type errors anywhere fail the schema
+  const std::string type = cstring_field(*node, "type"), connect_type = cstring_field(*node, "connect.type"), title = cstring_field(*node, "title");
+  cstring_field(*node, "description");
+  if (const Json *v = member(*node, "connect.version"); v && v->type != Json::Null) { if (v->type != Json::Num || !go_int64_literal(v->str)) throw SchemaError{"ConfluentJSONSchema.connect.version"}; }
+  if (const Json *v = member(*node, "additionalProperties"); v && v->type != Json::Null) { if (v->type != Json::Bool) throw SchemaError{"ConfluentJSONSchema.additionalProperties"}; }
+  bool has_parameters = false; std::string scale;
+  if (const Json *v = member(*node, "connect.parameters"); v && v->type != Json::Null) {
+    if (v->type != Json::Obj) throw SchemaError{"ConfluentJSONSchema.connect.parameters"};
+    has_parameters = true;
+    for (const char *k : {"length", "connect.decimal.precision", "allowed"}) cstring_field(*v, k);
+    scale = cstring_field(*v, "scale");
+  }
+  const Json *dt = member(*node, "__dt_original_type_info");
+  const bool has_dt = dt && dt->type != Json::Null;
+  Schema items; bool has_items = false;
+  if (const Json *v = member(*node, "items"); v && v->type != Json::Null) { if (v->type != Json::Obj) throw SchemaError{"ConfluentJSONSchema.items"}; items = from_confluent(v, depth + 1); has_items = true; }
+  std::vector<Schema> one_of; std::vector<std::string> one_of_type;
+  if (const Json *v = member(*node, "oneOf"); v && v->type != Json::Null) {
+    if (v->type != Json::Arr) throw SchemaError{"ConfluentJSONSchema.oneOf"};
+    for (auto &x : v->arr) {
+      if (x.type != Json::Null && x.type != Json::Obj) throw SchemaError{"ConfluentJSONSchema.oneOf"};
+      one_of_type.push_back(x.type == Json::Obj ? cstring_field(x, "type") : std::string());
+      one_of.push_back(from_confluent(&x, depth + 1));
+    }
+  }
+  struct Prop { std::string name; const Json *node; bool has_index; long long index; Schema conv; };
+  std::vector<Prop> props;
+  if (const Json *v = member(*node, "connect.index"); v && v->type != Json::Null) { if (v->type != Json::Num || !go_int64_literal(v->str)) throw SchemaError{"ConfluentJSONSchema.connect.index"}; }
+  if (const Json *v = member(*node, "properties"); v && v->type != Json::Null) {
+    if (v->type != Json::Obj) throw SchemaError{"ConfluentJSONSchema.properties"};
+    for (auto &kv : v->obj) {  // a Go map: the last occurrence of a name is the entry
+      if (kv.second.type != Json::Null && kv.second.type != Json::Obj) throw SchemaError{"ConfluentJSONSchema.properties"};
+      Prop pr{kv.first, &kv.second, false, 0, from_confluent(&kv.second, depth + 1)};
+      if (kv.second.type == Json::Obj) if (const Json *ix = member(kv.second, "connect.index"); ix && ix->type != Json::Null) { pr.has_index = true; pr.index = std::strtoll(ix->str.c_str(), nullptr, 10); }
+      bool replaced = false;
+      for (auto &q : props) if (q.name == pr.name) { q = pr; replaced = true; break; }
+      if (!replaced) props.push_back(std::move(pr));
+    }
+  }
+  (void)has_items;
+  // ---- ToKafkaJSONSchema ----
+  for (size_t i = 0; i < one_of.size(); i++) {
+    if (one_of_type[i] == "null") continue;
+    Schema f = one_of[i];
+    f.optional = true;
+    return f;
+  }
+  if (props.size() >= 2) {
+    for (auto &q : props) if (!q.has_index) throw HostOnly{"a property without connect.index: the reference dereferences a nil *int while sorting"};
+    std::stable_sort(props.begin(), props.end(), [](const Prop &a, const Prop &b) { return a.index < b.index; });
+    for (size_t i = 1; i < props.size(); i++) if (props[i].index == props[i - 1].index) throw HostOnly{"two properties share a connect.index: sort.Slice leaves their order open"};
+  }
+  for (auto &q : props) { Schema f = q.conv; f.field = q.name; s.fields.push_back(std::move(f)); }
+  s.type = confluent_type_to_kafka(type, connect_type);
+  s.name = title;
+  s.has_parameters = has_parameters; s.scale = scale;
+  s.has_dt_info = has_dt;
+  return s;
+}
+
+static int compile(const uint8_t *bytes, size_t len, std::vector<Field> &out, std::string &why, bool confluent = false) {
   out.clear();
   try {
     if (!len) throw SchemaError{"unexpected end of JSON input"};
     Json node;
     try { node = Json::parse(std::string((const char *)bytes, len)); }
     catch (const Error &e) { throw SchemaError{e.what()}; }
-    if (node.type != Json::Null && node.type != Json::Obj) throw SchemaError{"json: cannot unmarshal into Go value of type common.Schema"};
-    const Schema top = unmarshal(&node, 0);
+    if (node.type != Json::Null && node.type != Json::Obj) throw SchemaError{confluent ? "json: cannot unmarshal into Go value of type format.ConfluentJSONSchema" : "json: cannot unmarshal into Go value of type common.Schema"};
+    const Schema top = confluent ? from_confluent(&node, 0) : unmarshal(&node, 0);
     const Schema *before = top.find("before"), *after = top.find("after");
     if (!before || !after) throw HostOnly{"receiveTableSchema(nil): the reference dereferences a nil schema"};
     std::vector<Field> b, a;
@@ -165,6 +253,7 @@ static int compile(const uint8_t *bytes, size_t len, std::vector<Field> &out, st
 using namespace tf;
 using namespace tf::dbzrecv;
 
+namespace tf { std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep); }  // tf_transform.hip
 namespace tf { namespace dbz { void dbz_trust_frames(bool on); void dbz_tentative_frames(bool on); bool dbz_last_parse_was_quick(); } }
 
 struct tfgpu_dbz_schema {
@@ -199,6 +288,7 @@ template <class T> struct PinVec {
 
 struct tfgpu_dbz_receiver {
   std::map<std::pair<uint64_t, uint64_t>, std::shared_ptr<tfgpu_dbz_schema>> cache;
+  std::map<uint32_t, std::shared_ptr<tfgpu_dbz_schema>> registry;  // schema id → the compiled registry schema (tfgpu_dbz_receiver_add_registry_schema)
   // the head of an earlier batch's opening message up to its payload value (tfgpu_debezium_unpack_cached)
   bool last_quick = false;  // the last batch's messages went through dbz_parse_quick
   bool have_known = false; std::string known_bytes; uint32_t known_off = 0, known_len = 0; uint64_t known_hash[2] = {0, 0};
@@ -337,6 +427,137 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
   catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
   catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
 }
+// ---- events framed by a schema registry ------------------------------------------------------------------------------------------
+int tfgpu_debezium_compile_registry_schema(const void *schema_text, uint64_t len, tfgpu_dbz_schema **out) {
+  if (!out || (len && !schema_text)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_compile_registry_schema: null argument");
+  auto s = std::make_unique<tfgpu_dbz_schema>();
+  try { s->code = compile((const uint8_t *)schema_text, (size_t)len, s->fields, s->why, true); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  s->seal();
+  *out = s.release();
+  return TFGPU_OK;
+}
+int tfgpu_dbz_receiver_add_registry_schema(tfgpu_dbz_receiver *r, uint32_t schema_id, const void *schema_text, uint64_t len) {
+  if (!r || (len && !schema_text)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receiver_add_registry_schema: null argument");
+  try {
+    auto s = std::make_shared<tfgpu_dbz_schema>();
+    s->code = compile((const uint8_t *)schema_text, (size_t)len, s->fields, s->why, true);
+    s->seal();
+    r->registry[schema_id] = s;
+    return TFGPU_OK;
+  } catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+}
+// DoBatch with a registry: frame (tfgpu_sr_frames), payload spans (tfgpu_debezium_registry_frames), one parse per schema id, then
+// DoBuf's rule over the events of each Kafka message.
+int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
+                               tfgpu_sr_frame *events, int64_t events_cap, int64_t *nevents, int32_t *event_codes,
+                               uint32_t *missing_ids, int32_t missing_cap, int32_t *nmissing, int32_t *ngroups) {
+  if (!r || (len && !bytes) || !ngroups || !nevents || !nmissing || (events_cap && (!events || !event_codes)) || events_cap < 0 || missing_cap < 0 || (missing_cap && !missing_ids))
+    return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receive_registry: bad argument");
+  try {
+    r->drop();
+    *ngroups = 0; *nmissing = 0;
+    int rc = tfgpu_sr_frames(bytes, len, mem, msgs, events, events_cap, nevents);
+    if (rc) return rc;
+    const int64_t n = *nevents;
+    // schema ids in order of first appearance; the ones nobody registered
+    std::vector<uint32_t> ids;
+    {
+      std::map<uint32_t, bool> seen;
+      for (int64_t e = 0; e < n; e++) if (!events[e].code && seen.emplace(events[e].schema_id, true).second) ids.push_back(events[e].schema_id);
+    }
+    for (uint32_t id : ids) if (!r->registry.count(id)) { if (*nmissing < missing_cap) missing_ids[*nmissing] = id; ++*nmissing; }
+    if (*nmissing) return TFGPU_OK;
+    if (!n) return TFGPU_OK;
+    // one slot per event: [where it starts, where the next one starts)
+    std::vector<uint64_t> starts((size_t)n + 1), offs((size_t)n);
+    std::vector<int64_t> wts((size_t)n);
+    for (int64_t e = 0; e < n; e++) {
+      const tfgpu_sr_frame &f = events[e];
+      starts[(size_t)e] = f.code ? f.start : f.start - 5;
+      if (msgs && msgs->offset) offs[(size_t)e] = msgs->offset[f.msg];
+      if (msgs && msgs->write_time_ns) wts[(size_t)e] = msgs->write_time_ns[f.msg];
+    }
+    starts[(size_t)n] = len;
+    for (int64_t e = n - 1; e >= 0; e--) if (starts[(size_t)e] > starts[(size_t)e + 1]) starts[(size_t)e] = starts[(size_t)e + 1];  // (cannot happen with tfgpu_sr_frames' list; the device call checks the spans)
+    tfgpu_messages em{};
+    em.nmsg = n; em.start = starts.data(); em.offset = msgs && msgs->offset ? offs.data() : nullptr; em.write_time_ns = msgs && msgs->write_time_ns ? wts.data() : nullptr;
+    if ((int64_t)r->frames.size() < n) r->frames.resize((size_t)n);
+    rc = tfgpu_debezium_registry_frames(bytes, len, mem, &em, events, r->frames.data());
+    if (rc) return rc;
+    for (int64_t e = 0; e < n; e++) event_codes[e] = r->frames[(size_t)e].code;
+    std::vector<tfgpu_row_error> &errs = r->errs;
+    if ((int64_t)errs.size() < n) errs.resize((size_t)n);
+    for (uint32_t id : ids) {
+      const std::shared_ptr<tfgpu_dbz_schema> &s = r->registry[id];
+      tfgpu_dbz_options o{};
+      o.schema_hash[0] = id; o.schema_hash[1] = TFGPU_DBZ_REGISTRY_HASH;
+      o.nfields = s->code ? 0 : (int32_t)s->cfields.size(); o.fields = s->code ? nullptr : s->cfields.data(); o.schema_code = s->code;
+      tfgpu_dbz_receiver::Group g;
+      g.schema = s;
+      if (!r->spare_rows.empty()) { g.rows.swap(r->spare_rows.back()); r->spare_rows.pop_back(); }
+      if ((int64_t)g.rows.size() < n) g.rows.resize((size_t)n);
+      int64_t ne = 0;
+      {
+        struct Trust { Trust() { tf::dbz::dbz_trust_frames(true); } ~Trust() { tf::dbz::dbz_trust_frames(false); } } trust;  // r->frames is what the call above wrote, untouched
+        rc = tfgpu_debezium_parse(&o, bytes, len, mem, &em, r->frames.data(), &g.batch, g.rows.data(), n, errs.data(), (int64_t)errs.size(), &ne);
+      }
+      if (rc) return rc;
+      for (int64_t i = 0; i < std::min<int64_t>(ne, (int64_t)errs.size()); i++) if (errs[(size_t)i].row >= 0 && errs[(size_t)i].row < n) event_codes[errs[(size_t)i].row] = errs[(size_t)i].code;
+      tfgpu_batch v{};
+      if (g.batch && tfgpu_dbatch_view(g.batch, &v) == TFGPU_OK) g.nrows = v.nrows;
+      if (s->code || g.nrows == 0) { if (g.batch) tfgpu_dbatch_free(g.batch); r->spare_rows.push_back(std::move(g.rows)); continue; }
+      r->groups.push_back(std::move(g));
+    }
+    // DoBuf (parser.go:59-71): the first event that fails ends its Kafka message — DoOne hands back a nil rest; an event the stock
+    // code must redo takes its whole message there
+    bool any_lost = false;
+    for (int64_t a = 0; a < n;) {
+      int64_t z = a;
+      while (z < n && events[z].msg == events[a].msg) z++;
+      bool host = false;
+      for (int64_t e = a; e < z && !host; e++) { if (event_codes[e] == TFGPU_ROW_HOST_FALLBACK) host = true; else if (event_codes[e]) break; }
+      bool dead = false;
+      for (int64_t e = a; e < z; e++) {
+        if (host) { any_lost |= event_codes[e] == TFGPU_ROW_OK; event_codes[e] = TFGPU_ROW_HOST_FALLBACK; }
+        else if (dead) { any_lost |= event_codes[e] == TFGPU_ROW_OK; event_codes[e] = TFGPU_ROW_DROPPED; }
+        else if (event_codes[e]) dead = true;
+      }
+      a = z;
+    }
+    if (any_lost) {  // rows of events that are no items after all: cut them out (runs of kept rows, sliced and joined)
+      std::vector<tfgpu_dbz_receiver::Group> kept;
+      for (auto &G : r->groups) {
+        std::vector<uint32_t> keep((size_t)G.nrows + 1, 0u);
+        int64_t nk = 0;
+        for (int64_t i = 0; i < G.nrows; i++) {
+          if (event_codes[G.rows[(size_t)i].msg]) continue;
+          keep[(size_t)i] = 1u;
+          G.rows[(size_t)nk++] = G.rows[(size_t)i];
+        }
+        if (nk == G.nrows) { kept.push_back(std::move(G)); continue; }
+        if (nk == 0) { tfgpu_dbatch_free(G.batch); G.batch = nullptr; r->spare_rows.push_back(std::move(G.rows)); continue; }
+        std::unique_ptr<tfgpu_dbatch> cut;
+        {
+          Context &cx = ctx();
+          std::lock_guard<std::mutex> lk(cx.mu);
+          Buf dk = dalloc(keep.size() * 4 + 16);
+          h2d(dk->p, keep.data(), keep.size() * 4);
+          cut = tf::compact_rows(*G.batch, dk);  // syncs
+        }
+        tfgpu_dbatch_free(G.batch);
+        G.batch = cut.release(); G.nrows = nk;
+        kept.push_back(std::move(G));
+      }
+      r->groups = std::move(kept);
+    }
+    *ngroups = (int32_t)r->groups.size();
+    return TFGPU_OK;
+  } catch (const tf::Error &e) { return tf::fail(e.code, e.what()); }
+  catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
+}
+
 // One table's rows of the last batch.  *batch passes to the caller (tfgpu_dbatch_free); rows / fields stay the receiver's until
 // the next tfgpu_dbz_receive.
 int tfgpu_dbz_receive_group(tfgpu_dbz_receiver *r, int32_t g, tfgpu_dbatch **batch, const tfgpu_dbz_row **rows, int64_t *nrows, const tfgpu_dbz_field **fields, int32_t *nfields) {

@@ -945,6 +945,43 @@ __global__ void dbz_gather_totals(const uint32_t *lens_all, int64_t seg_stride, 
   for (int t = threadIdx.x; t < ntext; t += blockDim.x) out[t] = lens_all[(int64_t)t * seg_stride + nrows];
 }
 
+// ---- schema-registry framed events (NewReceiver with a registry client) ---------------------------------------------------------
+// DebeziumImpl.DoOne (pkg/parsers/registry/debezium/engine/parser.go:33-57) cuts a Kafka message into events 0x00 | schema id | payload
+// exactly as the Confluent-SR parser cuts its frames (tfgpu_sr_frames); SchemaRegistry.Unpack (pkg/debezium/unpacker/schema_registry.go:
+// 18-34) hands Receiver.receive the bytes behind the five-byte prefix, and UnmarshalPayload (common/debezium_schema.go:62-68) runs a
+// json.Decoder over them: white space, ONE value — an object or array ends at its bracket whatever follows, any other value must be
+// followed by white space or the end — then the struct binding parse_message restates.  This kernel is that first half: the span of
+// the value for tfgpu_debezium_parse, or the event's fate.  A message too short for buf[5:] is the reference's panic (host).
+__global__ void __launch_bounds__(128) dbz_registry_frames(Params p, const tfgpu_sr_frame *ev) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= p.nmsg) return;
+  const tfgpu_sr_frame f = ev[e];
+  tfgpu_dbz_frame fr;
+  fr.schema_start = 0; fr.schema_len = 0; fr.payload_start = f.start; fr.payload_len = 0; fr.reserved = 0;
+  fr.schema_hash[0] = f.schema_id; fr.schema_hash[1] = TFGPU_DBZ_REGISTRY_HASH;
+  fr.code = TFGPU_ROW_OK;
+  MemBytes rd(p.data);
+  if (f.code) {  // DoOne looks at the magic byte first (parser.go:37-39), then slices buf[5:]
+    fr.code = f.code;
+    if (f.code == TFGPU_ROW_SR_SHORT) fr.code = f.len && rd.at((uint32_t)f.start) != 0 ? TFGPU_ROW_SR_MAGIC : TFGPU_ROW_HOST_FALLBACK;
+    p.frames[e] = fr;
+    return;
+  }
+  uint32_t pos = (uint32_t)f.start; const uint32_t end = pos + f.len;
+  while (pos < end && is_ws(rd.at(pos))) pos++;
+  if (pos < end) {  // (nothing but white space: Decode's io.EOF — payload_len stays 0, TFGPU_ROW_DBZ_PAYLOAD in the parse)
+    const uint32_t vs = pos;
+    uint32_t vt = 0;
+    const int rc = skip_value(rd, pos, end, vt);
+    const uint32_t kind = vt & VT_MASK;
+    if (rc == 2) fr.code = TFGPU_ROW_HOST_FALLBACK;
+    else if (rc != 0) fr.code = TFGPU_ROW_DBZ_PAYLOAD;
+    else if (kind != VT_OBJ && kind != VT_ARR && pos < end && !is_ws(rd.at(pos))) fr.code = TFGPU_ROW_DBZ_PAYLOAD;  // "invalid character after top-level value"
+    else { fr.payload_start = vs; fr.payload_len = pos - vs; }
+  }
+  p.frames[e] = fr;
+}
+
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
 
 struct Staged { Buf bytes, ms; Params p{}; };
@@ -1085,6 +1122,32 @@ extern "C" int tfgpu_debezium_unpack(const void *bytes, uint64_t len, int mem, c
 extern "C" int tfgpu_debezium_unpack_cached(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, const tfgpu_dbz_prefix *known, tfgpu_dbz_frame *frames) {
   if (!known) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_unpack_cached: null prefix");
   return debezium_unpack_impl(bytes, len, mem, msgs, frames, known);
+}
+
+extern "C" int tfgpu_debezium_registry_frames(const void *bytes, uint64_t len, int mem, const tfgpu_messages *event_msgs, const tfgpu_sr_frame *events, tfgpu_dbz_frame *frames) {
+  TF_API_BEGIN
+  if ((len && !bytes) || !frames || !event_msgs || (event_msgs->nmsg && !events)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_registry_frames: null argument");
+  Context &cx = ctx();
+  std::lock_guard<std::mutex> lk(cx.mu);
+  dbz::Staged s;
+  dbz::stage(s, bytes, len, mem, event_msgs);
+  const int64_t n = s.p.nmsg;
+  for (int64_t e = 0; e < n; e++) {  // the events come back from the host: a span that leaves its slot would send a lane outside the buffer
+    const tfgpu_sr_frame &f = events[e];
+    if (f.start < event_msgs->start[e] || f.start + (uint64_t)f.len > event_msgs->start[e + 1])
+      return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_registry_frames: event " + std::to_string(e) + " does not lie inside its slot (events must come from tfgpu_sr_frames over the same bytes)");
+  }
+  Buf fr = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_dbz_frame)), ev = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_sr_frame));
+  s.p.frames = reinterpret_cast<tfgpu_dbz_frame *>(fr->p);
+  if (n) {
+    h2d(ev->p, events, (size_t)n * sizeof(tfgpu_sr_frame));
+    { KernelTimer t("dbz_registry_frames"); dbz::dbz_registry_frames<<<dbz::nblk(n, 128), 128, 0, cx.stream>>>(s.p, reinterpret_cast<const tfgpu_sr_frame *>(ev->p)); }
+    d2h(frames, fr->p, (size_t)n * sizeof(tfgpu_dbz_frame));
+    tf::sync();
+  }
+  dbz::g_frames = dbz::FrameCache{frames, n, bytes, fr, nullptr};
+  return TFGPU_OK;
+  TF_API_END
 }
 
 extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,

@@ -9,7 +9,8 @@ each group of messages to the device.  A cgo shim binds the same entry points (I
     Schema                                         pkg/debezium/common/debezium_schema.go:12-29, 84-101
     DebeziumImpl.DoBatch                           pkg/parsers/registry/debezium/engine/parser.go:120-130
 
-Scope: NewDebeziumImpl(logger, nil, threads) — no schema registry, no original-type table.  The reference caches the
+Scope: NewDebeziumImpl(logger, nil, threads) — no original-type table; with a schema registry (events framed 0x00 | schema id |
+payload, pkg/debezium/unpacker/schema_registry.go) through Parser.add_registry_schema / parse_registry.  The reference caches the
 compiled schema by a hash of its bytes (receiver.go:61-66); so does `Parser`, keyed by the device's hash of the same bytes.
 The per-message work is tfgpu_debezium_unpack / tfgpu_debezium_parse (csrc/tf_debezium.hip).
 """
@@ -44,6 +45,25 @@ def compile_schema(schema_bytes: bytes):
     h = C.c_void_p()
     L.tfgpu_debezium_compile_schema.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     lib._check(L.tfgpu_debezium_compile_schema(C.c_void_p(buf.ctypes.data), len(schema_bytes), C.byref(h)))
+    try:
+        code, why, fields = _schema_info(L, h)
+    finally:
+        L.tfgpu_dbz_schema_free.argtypes = [C.c_void_p]
+        L.tfgpu_dbz_schema_free(h)
+    if code == abi.ROW_DBZ_SCHEMA:
+        raise SchemaError(why)
+    if code == abi.ROW_HOST_FALLBACK:
+        raise HostOnly(why)
+    return fields
+
+
+def compile_registry_schema(schema_text: bytes):
+    """convertSchemaFormat + receiveSchema for a registry (ConfluentJSONSchema) text: like compile_schema."""
+    from . import lib
+    L = lib.load()
+    h = C.c_void_p()
+    L.tfgpu_debezium_compile_registry_schema.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    lib._check(L.tfgpu_debezium_compile_registry_schema(schema_text, len(schema_text), C.byref(h)))
     try:
         code, why, fields = _schema_info(L, h)
     finally:
@@ -148,3 +168,48 @@ class Parser:
             out.append(Parsed(db, rows, sch, meta=(lambda g=g, nmsg=nmsg: self._meta(g, nmsg))))
         bad = np.nonzero(codes[:nmsg])[0]
         return out, dict(zip(bad.tolist(), codes[bad].tolist()))
+
+    # ---- events framed by a schema registry (NewDebeziumImpl(logger, client, threads)) ----
+    def add_registry_schema(self, schema_id: int, schema_text: bytes):
+        """The registry's answer for one schema id (ConfluentJSONSchema text): converted and compiled once, kept by the receiver."""
+        L = self.lib.load()
+        L.tfgpu_dbz_receiver_add_registry_schema.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64]
+        self.lib._check(L.tfgpu_dbz_receiver_add_registry_schema(self._h, schema_id, schema_text, len(schema_text)))
+
+    def parse_registry(self, data, msgs: Optional[abi.CMessages] = None):
+        """DoBatch with a registry (tfgpu_dbz_receive_registry).  Returns None, missing ids when some schema id was never registered
+        (nothing parsed: fetch them, add_registry_schema, call again); otherwise ([Parsed per schema id; src_row = event ordinal],
+        {event ordinal: TFGPU_ROW_* code}, events = [(Kafka message, index inside it, schema id)])."""
+        lib = self.lib
+        L = lib.load()
+        ptr_, n, mem, keep = lib._bytes_arg(data)
+        L.tfgpu_dbz_receive_registry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(abi.CSrFrame), C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
+                                                 C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        cap = 1024
+        while True:
+            ev = (abi.CSrFrame * cap)()
+            codes = np.zeros(cap, np.int32)
+            missing = np.zeros(64, np.uint32)
+            nev, nmiss, ng = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+            rc = L.tfgpu_dbz_receive_registry(self._h, ptr_, n, mem, C.byref(msgs) if msgs is not None else None, ev, cap, C.byref(nev), C.c_void_p(codes.ctypes.data),
+                                              C.c_void_p(missing.ctypes.data), 64, C.byref(nmiss), C.byref(ng))
+            if rc and nev.value > cap:
+                cap = int(nev.value)
+                continue
+            lib._check(rc)
+            break
+        if nmiss.value:
+            return None, [int(x) for x in missing[:min(int(nmiss.value), 64)]], None
+        nevents = int(nev.value)
+        out = []
+        for g in range(int(ng.value)):
+            bh, rp, nr, fp, nf = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.POINTER(abi.CDbzField)(), C.c_int32(0)
+            lib._check(L.tfgpu_dbz_receive_group(self._h, g, C.byref(bh), C.byref(rp), C.byref(nr), C.byref(fp), C.byref(nf)))
+            db = lib.DeviceBatch(bh)
+            rows = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(int(nr.value) * abi.DBZ_ROW_DTYPE.itemsize,)).view(abi.DBZ_ROW_DTYPE).copy() if nr.value else np.zeros(0, abi.DBZ_ROW_DTYPE)
+            ns, table = db.table_id()
+            fields = _fields_of(fp, int(nf.value))
+            out.append(Parsed(db, rows, table_schema(fields, ns, table), meta=(lambda g=g, nevents=nevents: self._meta(g, nevents))))
+        events = [(int(ev[e].msg), int(ev[e].index), int(ev[e].schema_id) if not ev[e].code else None) for e in range(nevents)]
+        bad = np.nonzero(codes[:nevents])[0]
+        return out, dict(zip(bad.tolist(), codes[bad].tolist())), events
