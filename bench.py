@@ -1384,7 +1384,59 @@ class DebeziumWorkload(Base):
         return out
 
 
-WORKLOADS = {"configs0": Configs0Workload, "debezium": DebeziumWorkload, "configs4d": Configs4DebeziumWorkload, "csv": CsvWorkload, "json": JsonWorkload, "sr": SrWorkload, "configs2": Configs2Workload, "configs3": Configs3Workload,
+class DebeziumSrWorkload(DebeziumWorkload):
+    """The same Postgres event as `debezium`, in the wire form a schema registry gives it (NewDebeziumImpl with a registry client): the
+    Kafka message is 0x00 | schema id | payload — 1.4 KB instead of 13.6 KB — and the schema is the registry's ConfluentJSONSchema text,
+    converted and compiled once per id (tfgpu_dbz_receiver_add_registry_schema); per batch tfgpu_dbz_receive_registry."""
+    metric = "messages/sec through the Debezium parser (schema-registry framed: 0x00 | id | payload of the same Postgres event) -> device ChangeItem columns"
+
+    def setup(self):
+        e, a = self.env, self.args
+        lib, abi = e.lib, e.abi
+        from transferia_amd import debezium
+        with open(os.path.join(ROOT, "tests", "golden", "debezium.json")) as f:
+            inline = [c for c in json.load(f)["cases"] if c["name"] == "TestParser"][0]["message"].encode("utf-8")
+        self.schema_text, self.msg = e.workload.registry_framed(inline, 101)
+        self.n = a.rows
+        data, self.msgs = abi.messages([self.msg] * self.n)
+        self.nbytes = len(data)
+        self.dbuf = lib.DeviceBuffer.upload(data)
+        self.parser = debezium.Parser(lib)
+        self.parser.add_registry_schema(101, self.schema_text)
+
+    def step(self, keep=False):
+        parsed, errors, events = self.parser.parse_registry(self.dbuf, self.msgs)
+        if keep:
+            self.state.update(out_rows=sum(p.batch.nrows for p in parsed), out_bytes=sum(p.batch.payload_bytes() for p in parsed), errors=len(errors))
+        for p in parsed:
+            p.batch.free()
+
+    def alg(self):
+        pb = self.nbytes + self.state.get("out_bytes", 0)
+        return {"dbz_parse": pb, "dbz_parse_quick": pb, "dbz_cell_values": pb, "dbz_cell_text": pb, "dbz_registry_frames": self.nbytes, "sr_frames": self.nbytes}
+
+    def config(self):
+        return {"workload": "Debezium events framed by a schema registry: 0x00 | schema id | payload of one Postgres event (61 columns, every pg type) replicated per batch; "
+                            "the registry's ConfluentJSONSchema converted + compiled once on the host, framing + payload spans + receive on device",
+                "messages_per_gpu_per_step": self.n, "bytes_per_message": len(self.msg), "parallelism": f"message-range shard x{self.env.world}, no collective"}
+
+    def cpu(self):
+        from oracle import oracle as ora
+        abi = self.env.abi
+        k = max(64, min(self.n, self.args.cpu_rows // 64))
+        data, msgs = abi.messages([self.msg] * k)
+        ora.debezium_parse.want_items = False
+        t0 = time.perf_counter()
+        ora.debezium_parse_sr(data, msgs, {101: self.schema_text})
+        sec = time.perf_counter() - t0
+        out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{k} events x {len(self.msg)} B: the oracle's DoBatch with a registry (Python cut + the C Receive per event, schema compiled per event) ({sec:.2f}s)",
+               "note": "C / Python restatement of the Go reference, not the Go binary"}
+        out.update(host_info())
+        return out
+
+
+WORKLOADS = {"configs0": Configs0Workload, "debezium": DebeziumWorkload, "debezium_sr": DebeziumSrWorkload, "configs4d": Configs4DebeziumWorkload, "csv": CsvWorkload, "json": JsonWorkload, "sr": SrWorkload, "configs2": Configs2Workload, "configs3": Configs3Workload,
              "configs4": Configs4Workload, "collapse": CollapseWorkload}
 
 

@@ -205,3 +205,54 @@ def debezium_cdc_messages(nmsg: int, keys: int = 0, seed: int = SEED, table: str
             before, after, 1_700_000_000_000 + k, table, 500 + k, 10_000 + 8 * k, op, 1_700_000_000_123 + k)
         out.append(('{"schema":%s,"payload":%s}' % (schema, payload)).encode())
     return out
+
+
+def kafka_to_confluent_schema(k: dict) -> dict:
+    """A Kafka Connect JSON schema in the form a Confluent schema registry stores it (what the Debezium serializer registers:
+    KafkaJSONSchema.ToConfluentSchema, pkg/schemaregistry/format/json_schema_format.go:166-258) — input generation for the
+    registry-framed Debezium workload."""
+    if k.get("optional"):
+        inner = dict(k)
+        inner["optional"] = False
+        return {"oneOf": [{"type": "null"}, kafka_to_confluent_schema(inner)]}
+    ints = ("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64")
+    t = k.get("type", "")
+    jt, ct = ("integer", t) if t in ints else {"float": ("number", "float32"), "double": ("number", "float64"), "string": ("string", ""), "struct": ("object", ""),
+                                                "bytes": ("string", "bytes"), "boolean": ("boolean", ""), "array": ("array", "")}.get(t, ("", ""))
+    c = {}
+    if k.get("parameters") is not None:
+        c["connect.parameters"] = k["parameters"]
+    if ct:
+        c["connect.type"] = ct
+    if k.get("version"):
+        c["connect.version"] = k["version"]
+    if k.get("default") is not None:
+        c["default"] = k["default"]
+    if k.get("doc"):
+        c["description"] = k["doc"]
+    if k.get("items") is not None:
+        c["items"] = kafka_to_confluent_schema(k["items"])
+    if k.get("fields"):
+        c["properties"] = {}
+        for i, f in enumerate(k["fields"]):
+            p = kafka_to_confluent_schema(f)
+            p["connect.index"] = i
+            c["properties"][f.get("field", "")] = p
+    if k.get("name"):
+        c["title"] = k["name"]
+    if jt:
+        c["type"] = jt
+    if k.get("__dt_original_type_info") is not None:
+        c["__dt_original_type_info"] = k["__dt_original_type_info"]
+    return c
+
+
+def registry_framed(message: bytes, schema_id: int):
+    """An inline-schema Debezium message as (registry schema text, event bytes 0x00 | schema id | payload)."""
+    import json
+    doc = json.loads(message)
+    i = message.index(b'"payload":') + len(b'"payload":')
+    payload = message[i:message.rindex(b"}")].strip()
+    assert json.loads(payload) == doc["payload"]
+    text = json.dumps(kafka_to_confluent_schema(doc["schema"]), separators=(",", ":")).encode()
+    return text, b"\x00" + int(schema_id).to_bytes(4, "big") + payload
