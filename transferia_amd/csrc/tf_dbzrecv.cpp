@@ -483,7 +483,12 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
     tfgpu_messages em{};
     em.nmsg = n; em.start = starts.data(); em.offset = msgs && msgs->offset ? offs.data() : nullptr; em.write_time_ns = msgs && msgs->write_time_ns ? wts.data() : nullptr;
     if ((int64_t)r->frames.size() < n) r->frames.resize((size_t)n);
-    rc = tfgpu_debezium_registry_frames(bytes, len, mem, &em, events, r->frames.data());
+    {
+      // payload spans claimed from the events' ends instead of walked once the tile parser has taken a batch of this receiver: it
+      // proves them, or the walker walks them (tf_debezium.hip, Params::tent)
+      struct Tent { bool on; explicit Tent(bool o) : on(o) { if (on) tf::dbz::dbz_tentative_frames(true); } ~Tent() { if (on) tf::dbz::dbz_tentative_frames(false); } } tent(r->last_quick);
+      rc = tfgpu_debezium_registry_frames(bytes, len, mem, &em, events, r->frames.data());
+    }
     if (rc) return rc;
     for (int64_t e = 0; e < n; e++) event_codes[e] = r->frames[(size_t)e].code;
     std::vector<tfgpu_row_error> &errs = r->errs;
@@ -503,6 +508,7 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
         rc = tfgpu_debezium_parse(&o, bytes, len, mem, &em, r->frames.data(), &g.batch, g.rows.data(), n, errs.data(), (int64_t)errs.size(), &ne);
       }
       if (rc) return rc;
+      r->last_quick = tf::dbz::dbz_last_parse_was_quick();
       for (int64_t i = 0; i < std::min<int64_t>(ne, (int64_t)errs.size()); i++) if (errs[(size_t)i].row >= 0 && errs[(size_t)i].row < n) event_codes[errs[(size_t)i].row] = errs[(size_t)i].code;
       tfgpu_batch v{};
       if (g.batch && tfgpu_dbatch_view(g.batch, &v) == TFGPU_OK) g.nrows = v.nrows;

@@ -575,11 +575,12 @@ __device__ int parse_message(const Params &p, int64_t m) {
   }
   return TFGPU_ROW_OK;
 }
+__device__ void registry_walk(const Params &p, int64_t e);  // (schema-registry framed events, below)
 __global__ void __launch_bounds__(128) dbz_parse(Params p) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= p.nmsg) return;
   const bool claimed = p.tent && p.tent[m];
-  if (claimed) { unpack_message(p, m); p.tent[m] = 0; }  // a claimed span: IncludeSchema.Unpack's walk first
+  if (claimed) { if (p.tent[m] == 2) registry_walk(p, m); else unpack_message(p, m); p.tent[m] = 0; }  // a claimed span: IncludeSchema.Unpack's walk (or the registry form's) first
   const tfgpu_dbz_frame &fr = p.frames[m];
   int st;
   if (claimed && fr.code != TFGPU_ROW_OK) st = fr.code;   // (the host saw code OK for the claim: the walk's verdict is reported here)
@@ -952,6 +953,29 @@ __global__ void dbz_gather_totals(const uint32_t *lens_all, int64_t seg_stride, 
 // json.Decoder over them: white space, ONE value — an object or array ends at its bracket whatever follows, any other value must be
 // followed by white space or the end — then the struct binding parse_message restates.  This kernel is that first half: the span of
 // the value for tfgpu_debezium_parse, or the event's fate.  A message too short for buf[5:] is the reference's panic (host).
+// the walk over one event's bytes behind the prefix: [start, start + len)
+__device__ void registry_payload(const Params &p, tfgpu_dbz_frame &fr, uint32_t start, uint32_t len) {
+  MemBytes rd(p.data);
+  fr.payload_start = start; fr.payload_len = 0; fr.code = TFGPU_ROW_OK;
+  uint32_t pos = start; const uint32_t end = start + len;
+  while (pos < end && is_ws(rd.at(pos))) pos++;
+  if (pos >= end) return;  // (nothing but white space: Decode's io.EOF — payload_len stays 0, TFGPU_ROW_DBZ_PAYLOAD in the parse)
+  const uint32_t vs = pos;
+  uint32_t vt = 0;
+  const int rc = skip_value(rd, pos, end, vt);
+  const uint32_t kind = vt & VT_MASK;
+  if (rc == 2) fr.code = TFGPU_ROW_HOST_FALLBACK;
+  else if (rc != 0) fr.code = TFGPU_ROW_DBZ_PAYLOAD;
+  else if (kind != VT_OBJ && kind != VT_ARR && pos < end && !is_ws(rd.at(pos))) fr.code = TFGPU_ROW_DBZ_PAYLOAD;  // "invalid character after top-level value"
+  else { fr.payload_start = vs; fr.payload_len = pos - vs; }
+}
+// a claimed span nobody proved (Params::tent[e] == 2): the walk after all.  The event's bytes are its slot behind the prefix.
+__device__ void registry_walk(const Params &p, int64_t e) {
+  tfgpu_dbz_frame fr = p.frames[e];
+  const uint32_t a = p.ms[e] + 5u, z = p.ms[e + 1];
+  registry_payload(p, fr, a, z - a);
+  p.frames[e] = fr;
+}
 __global__ void __launch_bounds__(128) dbz_registry_frames(Params p, const tfgpu_sr_frame *ev) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= p.nmsg) return;
@@ -967,18 +991,19 @@ __global__ void __launch_bounds__(128) dbz_registry_frames(Params p, const tfgpu
     p.frames[e] = fr;
     return;
   }
-  uint32_t pos = (uint32_t)f.start; const uint32_t end = pos + f.len;
-  while (pos < end && is_ws(rd.at(pos))) pos++;
-  if (pos < end) {  // (nothing but white space: Decode's io.EOF — payload_len stays 0, TFGPU_ROW_DBZ_PAYLOAD in the parse)
-    const uint32_t vs = pos;
-    uint32_t vt = 0;
-    const int rc = skip_value(rd, pos, end, vt);
-    const uint32_t kind = vt & VT_MASK;
-    if (rc == 2) fr.code = TFGPU_ROW_HOST_FALLBACK;
-    else if (rc != 0) fr.code = TFGPU_ROW_DBZ_PAYLOAD;
-    else if (kind != VT_OBJ && kind != VT_ARR && pos < end && !is_ws(rd.at(pos))) fr.code = TFGPU_ROW_DBZ_PAYLOAD;  // "invalid character after top-level value"
-    else { fr.payload_start = vs; fr.payload_len = pos - vs; }
+  if (p.tent) {  // blank* '{' … '}' blank*: the span between the braces is a CLAIM — dbz_parse_quick proves it an object when it takes the
+                 // event (every byte compared or validated); for an event it does not take the walker runs registry_walk first
+    uint32_t a = (uint32_t)f.start, z = a + f.len;
+    while (a < z && is_ws(rd.at(a))) a++;
+    while (z > a && is_ws(rd.at(z - 1))) z--;
+    if (z >= a + 2 && rd.at(a) == '{' && rd.at(z - 1) == '}') {
+      fr.payload_start = a; fr.payload_len = z - a;
+      p.frames[e] = fr;
+      p.tent[e] = 2;
+      return;
+    }
   }
+  registry_payload(p, fr, (uint32_t)f.start, f.len);
   p.frames[e] = fr;
 }
 
@@ -1139,13 +1164,16 @@ extern "C" int tfgpu_debezium_registry_frames(const void *bytes, uint64_t len, i
   }
   Buf fr = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_dbz_frame)), ev = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_sr_frame));
   s.p.frames = reinterpret_cast<tfgpu_dbz_frame *>(fr->p);
+  Buf tent;
+  static const bool tent_off = [] { const char *e = std::getenv("TFGPU_DBZ_TENTATIVE"); return e && e[0] == '0'; }();
+  if (dbz::g_tentative && !tent_off && n) { tent = dalloc_zero((size_t)n + 16); s.p.tent = ptr<uint8_t>(tent); }
   if (n) {
     h2d(ev->p, events, (size_t)n * sizeof(tfgpu_sr_frame));
     { KernelTimer t("dbz_registry_frames"); dbz::dbz_registry_frames<<<dbz::nblk(n, 128), 128, 0, cx.stream>>>(s.p, reinterpret_cast<const tfgpu_sr_frame *>(ev->p)); }
     d2h(frames, fr->p, (size_t)n * sizeof(tfgpu_dbz_frame));
     tf::sync();
   }
-  dbz::g_frames = dbz::FrameCache{frames, n, bytes, fr, nullptr};
+  dbz::g_frames = dbz::FrameCache{frames, n, bytes, fr, tent};
   return TFGPU_OK;
   TF_API_END
 }

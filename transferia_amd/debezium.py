@@ -24,6 +24,7 @@ import numpy as np
 from . import abi
 
 INT32_MIN = -(1 << 31)
+SR_FRAME_DTYPE = np.dtype([("msg", "<i8"), ("start", "<u8"), ("len", "<u4"), ("schema_id", "<u4"), ("code", "<i4"), ("index", "<i4")])   # tfgpu_sr_frame
 OP_DTYPE = {abi.DBZ_BOOLEAN: "boolean", abi.DBZ_INT8: "int8", abi.DBZ_INT16: "int16", abi.DBZ_INT32: "int32", abi.DBZ_INT64: "int64", abi.DBZ_FLOAT64: "double",
             abi.DBZ_STRING: "utf8", abi.DBZ_BYTES: "string", abi.DBZ_DECIMAL: "utf8", abi.DBZ_POINT: "utf8", abi.DBZ_VSD: "double", abi.DBZ_HOST: "any"}
 
@@ -179,22 +180,23 @@ class Parser:
     def parse_registry(self, data, msgs: Optional[abi.CMessages] = None):
         """DoBatch with a registry (tfgpu_dbz_receive_registry).  Returns None, missing ids when some schema id was never registered
         (nothing parsed: fetch them, add_registry_schema, call again); otherwise ([Parsed per schema id; src_row = event ordinal],
-        {event ordinal: TFGPU_ROW_* code}, events = [(Kafka message, index inside it, schema id)])."""
+        {event ordinal: TFGPU_ROW_* code}, events = tfgpu_sr_frames' list as a structured array: msg, start, len, schema_id, code, index)."""
         lib = self.lib
         L = lib.load()
         ptr_, n, mem, keep = lib._bytes_arg(data)
         L.tfgpu_dbz_receive_registry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(abi.CSrFrame), C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
                                                  C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-        cap = 1024
+        cap = getattr(self, "_ev_cap", 1024)
         while True:
-            ev = (abi.CSrFrame * cap)()
-            codes = np.zeros(cap, np.int32)
+            if getattr(self, "_ev", None) is None or len(self._ev) < cap:   # kept across batches: 36 bytes per event are not allocated per call
+                self._ev, self._codes, self._ev_cap = np.zeros(cap, SR_FRAME_DTYPE), np.zeros(cap, np.int32), cap
+            ev, codes = self._ev, self._codes
             missing = np.zeros(64, np.uint32)
             nev, nmiss, ng = C.c_int64(0), C.c_int32(0), C.c_int32(0)
-            rc = L.tfgpu_dbz_receive_registry(self._h, ptr_, n, mem, C.byref(msgs) if msgs is not None else None, ev, cap, C.byref(nev), C.c_void_p(codes.ctypes.data),
-                                              C.c_void_p(missing.ctypes.data), 64, C.byref(nmiss), C.byref(ng))
+            rc = L.tfgpu_dbz_receive_registry(self._h, ptr_, n, mem, C.byref(msgs) if msgs is not None else None, C.cast(C.c_void_p(ev.ctypes.data), C.POINTER(abi.CSrFrame)), cap, C.byref(nev),
+                                              C.c_void_p(codes.ctypes.data), C.c_void_p(missing.ctypes.data), 64, C.byref(nmiss), C.byref(ng))
             if rc and nev.value > cap:
-                cap = int(nev.value)
+                cap = int(nev.value) + int(nev.value) // 8
                 continue
             lib._check(rc)
             break
@@ -210,6 +212,5 @@ class Parser:
             ns, table = db.table_id()
             fields = _fields_of(fp, int(nf.value))
             out.append(Parsed(db, rows, table_schema(fields, ns, table), meta=(lambda g=g, nevents=nevents: self._meta(g, nevents))))
-        events = [(int(ev[e].msg), int(ev[e].index), int(ev[e].schema_id) if not ev[e].code else None) for e in range(nevents)]
         bad = np.nonzero(codes[:nevents])[0]
-        return out, dict(zip(bad.tolist(), codes[bad].tolist())), events
+        return out, dict(zip(bad.tolist(), codes[bad].tolist())), ev[:nevents]   # events: a view (msg, start, len, schema_id, code, index), valid until the next call
