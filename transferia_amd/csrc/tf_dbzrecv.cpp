@@ -296,6 +296,7 @@ struct tfgpu_dbz_receiver {
   struct Group { std::shared_ptr<tfgpu_dbz_schema> schema; tfgpu_dbatch *batch = nullptr; PinVec<tfgpu_dbz_row> rows; int64_t nrows = 0; };
   std::vector<Group> groups;
   PinVec<tfgpu_dbz_frame> frames;
+  PinVec<tfgpu_sr_frame> events;   // registry form: tfgpu_sr_frames' list (page-locked: one DMA down, and its device copy serves the next call)
   std::vector<tfgpu_row_error> errs;
   std::vector<PinVec<tfgpu_dbz_row>> spare_rows;
   void drop() { for (auto &g : groups) { if (g.batch) tfgpu_dbatch_free(g.batch); spare_rows.push_back(std::move(g.rows)); } groups.clear(); }
@@ -457,14 +458,27 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
   try {
     r->drop();
     *ngroups = 0; *nmissing = 0;
+    // into the receiver's own page-locked list first (the caller's array is pageable: a staged copy of 32 bytes per event), grown to
+    // what the batch needs; the caller's copy is made at the end
+    if ((int64_t)r->events.size() < std::max<int64_t>(events_cap, 1)) r->events.resize((size_t)std::max<int64_t>(events_cap, 1));
+    tfgpu_sr_frame *const caller_events = events;
+    events = r->events.data();
     int rc = tfgpu_sr_frames(bytes, len, mem, msgs, events, events_cap, nevents);
     if (rc) return rc;
     const int64_t n = *nevents;
+    struct CopyOut { tfgpu_sr_frame *dst; const tfgpu_sr_frame *src; const int64_t &n; ~CopyOut() { if (n > 0) std::memcpy(dst, src, (size_t)n * sizeof(tfgpu_sr_frame)); } } copy_out{caller_events, events, *nevents};
     // schema ids in order of first appearance; the ones nobody registered
     std::vector<uint32_t> ids;
     {
       std::map<uint32_t, bool> seen;
-      for (int64_t e = 0; e < n; e++) if (!events[e].code && seen.emplace(events[e].schema_id, true).second) ids.push_back(events[e].schema_id);
+      uint32_t last = 0; bool have_last = false;
+      for (int64_t e = 0; e < n; e++) {
+        if (events[e].code) continue;
+        const uint32_t id = events[e].schema_id;
+        if (have_last && id == last) continue;  // the usual topic: one schema
+        last = id; have_last = true;
+        if (seen.emplace(id, true).second) ids.push_back(id);
+      }
     }
     for (uint32_t id : ids) if (!r->registry.count(id)) { if (*nmissing < missing_cap) missing_ids[*nmissing] = id; ++*nmissing; }
     if (*nmissing) return TFGPU_OK;
@@ -487,6 +501,7 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
       // payload spans claimed from the events' ends instead of walked once the tile parser has taken a batch of this receiver: it
       // proves them, or the walker walks them (tf_debezium.hip, Params::tent)
       struct Tent { bool on; explicit Tent(bool o) : on(o) { if (on) tf::dbz::dbz_tentative_frames(true); } ~Tent() { if (on) tf::dbz::dbz_tentative_frames(false); } } tent(r->last_quick);
+      struct Trust { Trust() { tf::dbz::dbz_trust_frames(true); } ~Trust() { tf::dbz::dbz_trust_frames(false); } } trust;  // `events` is what tfgpu_sr_frames wrote, untouched
       rc = tfgpu_debezium_registry_frames(bytes, len, mem, &em, events, r->frames.data());
     }
     if (rc) return rc;

@@ -1039,6 +1039,7 @@ static void stage(Staged &s, const void *bytes, uint64_t len, int mem, const tfg
 }  // namespace dbz
 }  // namespace tf
 
+namespace tf { namespace sr { Buf last_frames_device(const tfgpu_sr_frame *host, int64_t n, const void *bytes); } }  // tf_srjson.hip
 using namespace tf;
 
 #define TF_API_BEGIN try {
@@ -1157,18 +1158,22 @@ extern "C" int tfgpu_debezium_registry_frames(const void *bytes, uint64_t len, i
   dbz::Staged s;
   dbz::stage(s, bytes, len, mem, event_msgs);
   const int64_t n = s.p.nmsg;
-  for (int64_t e = 0; e < n; e++) {  // the events come back from the host: a span that leaves its slot would send a lane outside the buffer
+  // the list tfgpu_sr_frames wrote, handed back untouched by the receiver (it says so: dbz_trust_frames): its device copy serves
+  Buf ev = dbz::g_trust ? sr::last_frames_device(events, n, bytes) : Buf();
+  const bool ev_trusted = (bool)ev;
+  for (int64_t e = 0; e < n && !ev_trusted; e++) {  // the events come back from the host: a span that leaves its slot would send a lane outside the buffer
     const tfgpu_sr_frame &f = events[e];
     if (f.start < event_msgs->start[e] || f.start + (uint64_t)f.len > event_msgs->start[e + 1])
       return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_registry_frames: event " + std::to_string(e) + " does not lie inside its slot (events must come from tfgpu_sr_frames over the same bytes)");
   }
-  Buf fr = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_dbz_frame)), ev = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_sr_frame));
+  Buf fr = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_dbz_frame));
+  if (!ev_trusted) ev = dalloc((size_t)std::max<int64_t>(n, 1) * sizeof(tfgpu_sr_frame));
   s.p.frames = reinterpret_cast<tfgpu_dbz_frame *>(fr->p);
   Buf tent;
   static const bool tent_off = [] { const char *e = std::getenv("TFGPU_DBZ_TENTATIVE"); return e && e[0] == '0'; }();
   if (dbz::g_tentative && !tent_off && n) { tent = dalloc_zero((size_t)n + 16); s.p.tent = ptr<uint8_t>(tent); }
   if (n) {
-    h2d(ev->p, events, (size_t)n * sizeof(tfgpu_sr_frame));
+    if (!ev_trusted) h2d(ev->p, events, (size_t)n * sizeof(tfgpu_sr_frame));
     { KernelTimer t("dbz_registry_frames"); dbz::dbz_registry_frames<<<dbz::nblk(n, 128), 128, 0, cx.stream>>>(s.p, reinterpret_cast<const tfgpu_sr_frame *>(ev->p)); }
     d2h(frames, fr->p, (size_t)n * sizeof(tfgpu_dbz_frame));
     tf::sync();
