@@ -40,7 +40,10 @@ std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  /
 // line index
 // ---------------------------------------------------------------------------
 static constexpr int NL_THREADS = 256;
-static constexpr int NL_ITERS = 7;
+#ifndef TF_NL_ITERS
+#define TF_NL_ITERS 7
+#endif
+static constexpr int NL_ITERS = TF_NL_ITERS;  // (TF_NL_ITERS / TF_CT_THREADS / TF_CR_FCAP: tile-size A/B builds, tools/build_variant.sh)
 static constexpr int NL_TILE = NL_THREADS * 16 * NL_ITERS;  // 28 KiB per workgroup
 static constexpr int CSV_GRAN = 64 * 16;                  // 1 KiB (what one wave reads per iteration): the unit newline counts are kept in
 static constexpr int NL_GPT = NL_TILE / CSV_GRAN;           // granules per workgroup of the line-index kernels
@@ -699,7 +702,12 @@ __global__ void __launch_bounds__(64) csv_parse_listed(CsvParams p) {
 // lane per cell, lines fastest, so every column store is coalesced and every
 // wave runs one column type.
 // ---------------------------------------------------------------------------
-static constexpr int CT_THREADS = 512;
+#ifndef TF_CT_THREADS
+#define TF_CT_THREADS 512
+#endif
+static constexpr int CT_THREADS = TF_CT_THREADS;
+static constexpr uint32_t CT_WAVES = CT_THREADS / 64;  // slots of 64 items are dealt round-robin to them
+static_assert((CT_WAVES & (CT_WAVES - 1)) == 0, "wave count must be a power of two");
 static constexpr int CT_T = NL_TILE;            // bytes whose '\n' this workgroup owns
 static constexpr int CT_SPILL = 4096;           // look-behind: longest line staged in LDS
 static constexpr int CT_BYTES = CT_T + CT_SPILL;
@@ -1229,7 +1237,10 @@ __device__ __forceinline__ uint32_t days_in_month32(uint32_t m, uint32_t y) {
   return m == 2 ? 28u + leap : 30u + ((0x15AAu >> m) & 1u);  // bit m set for the 31-day months 1,3,5,7,8,10,12
 }
 
-static constexpr int CR_FCAP = 4608;   // field ends the regular kernel indexes per tile (28 KiB of single-digit fields would be 14 000; hits averages 3 800)
+#ifndef TF_CR_FCAP
+#define TF_CR_FCAP 4608
+#endif
+static constexpr int CR_FCAP = TF_CR_FCAP;   // field ends the regular kernel indexes per tile (28 KiB of single-digit fields would be 14 000; hits averages 3 800)
 static constexpr int CR_LCOLS = 128;   // columns whose descriptors it stages in LDS
 static constexpr uint32_t CR_KDUMMY = CR_FCAP + 2;  // index slot of the empty field idle lanes read
 struct CsvRun { int32_t kind, width, first, ncols; };  // consecutive tcols of one (kind, width); kind -1: DefaultValue columns (no field)
@@ -1253,7 +1264,7 @@ __device__ __forceinline__ ItemIter item_first(const RegTile &t, uint32_t it) {
   return ItemIter{it, oi, jj};
 }
 __device__ __forceinline__ void item_next(const RegTile &t, ItemIter &x) {
-  x.it += 512u; x.oi += t.step_q; x.jj += t.step_r;
+  x.it += 64u * CT_WAVES; x.oi += t.step_q; x.jj += t.step_r;
   if (x.jj >= t.nr) { x.jj -= t.nr; x.oi++; }
 }
 __device__ __forceinline__ RegCell reg_cell(const RegTile &t, uint32_t first_col, const ItemIter &x, uint32_t items) {
@@ -1363,10 +1374,10 @@ template <int KIND, int W, class T> __device__ __forceinline__ void reg_int_body
 template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u));
   if (s0 >= sbase + nslots) return;
   ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
-  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+  for (uint32_t s = s0; s < sbase + nslots; s += CT_WAVES, item_next(t, x)) {
     const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     reg_int_body<KIND, W, T>(t, c, global_ptr<T>(t.colp0[c.on ? c.col : (uint32_t)run.first]));
   }
@@ -1408,10 +1419,10 @@ __device__ __forceinline__ void reg_str_body(const RegTile &t, const RegCell &c,
 }
 __device__ __forceinline__ void reg_cells_str(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u));
   if (s0 >= sbase + nslots) return;
   ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
-  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+  for (uint32_t s = s0; s < sbase + nslots; s += CT_WAVES, item_next(t, x)) {
     const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     const uint32_t col = c.on ? c.col : (uint32_t)run.first;
     reg_str_body(t, c, global_ptr<uint32_t>(t.colp0[col]), global_ptr<uint32_t>(t.colp1[col]));
@@ -1472,10 +1483,10 @@ template <int KIND> __device__ __forceinline__ void reg_time_body(const RegTile 
 }
 template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & 7u);
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u));
   if (s0 >= sbase + nslots) return;
   ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
-  for (uint32_t s = s0; s < sbase + nslots; s += 8, item_next(t, x)) {
+  for (uint32_t s = s0; s < sbase + nslots; s += CT_WAVES, item_next(t, x)) {
     const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
     if (!c.on) continue;
     reg_time_body<KIND>(t, c, global_ptr<int64_t>(t.colp0[c.col]), global_ptr<int32_t>(t.colp1[c.col]));
@@ -1771,7 +1782,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
   {
     RegTile t;
     t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.keeptab = keeptab; t.slowf = slowf; t.colp0 = colp0; t.colp1 = colp1; t.colfield = colfield;
-    t.nr = nr; t.NF = NF; t.step_q = 512u / nr; t.step_r = 512u - t.step_q * nr; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
+    t.nr = nr; t.NF = NF; t.step_q = 64u * CT_WAVES / nr; t.step_r = 64u * CT_WAVES - t.step_q * nr; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
     t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0; t.ablate = p.ablate; t.col_mode = p.col_lanes;
     if constexpr (COLS) {
       for (int ti = p.wave_task[wv]; ti < p.wave_task[wv + 1]; ti++) {
@@ -1817,7 +1828,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
         case CK_DATE: reg_cells_time<CK_DATE>(t, run, sbase, wv, lane); break;
         case CK_TIMESTAMP: reg_cells_time<CK_TIMESTAMP>(t, run, sbase, wv, lane); break;
         default:
-          for (uint32_t s = sbase + (((uint32_t)wv - sbase) & 7u); s < sbase + nslots; s += 8) {
+          for (uint32_t s = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u)); s < sbase + nslots; s += CT_WAVES) {
             const uint32_t it = (s - sbase) * 64 + (uint32_t)lane;
             if (it >= items) continue;
             const uint32_t oi = it / nr, jj = it - oi * nr;
