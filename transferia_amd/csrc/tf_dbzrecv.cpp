@@ -546,7 +546,7 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
       }
       a = z;
     }
-    if (any_lost) {  // rows of events that are no items after all: cut them out (runs of kept rows, sliced and joined)
+    if (any_lost) {  // rows of events that are no items after all: cut out of their group's batch (a keep mask, compact_rows) and of its row meta
       std::vector<tfgpu_dbz_receiver::Group> kept;
       for (auto &G : r->groups) {
         std::vector<uint32_t> keep((size_t)G.nrows + 1, 0u);
