@@ -1282,6 +1282,30 @@ __device__ __forceinline__ RegCell reg_cell(const RegTile &t, uint32_t first_col
   c.fs = (uint32_t)t.fposx[kr] + 1; c.fend = t.fposx[kr1];
   return c;
 }
+// A wave's slots of one run.  TF_CSV_PREFETCH=1 (A/B builds) reads the NEXT slot's index entries before the current slot's body runs,
+// so that the two ds_read_u16 of slot s + 8 ride under slot s's arithmetic instead of heading its dependent chain (index → window →
+// store).  Measured (gpurun r08g): 1.04-1.09 ms against 0.74 — the kernel sits at the 80 VGPRs six waves per SIMD allow, the second
+// cell in flight spills 76 bytes per lane to scratch.  Off.
+#ifndef TF_CSV_PREFETCH
+#define TF_CSV_PREFETCH 0
+#endif
+template <class Body> __device__ __forceinline__ void for_slots(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane, Body body) {
+  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6, end = sbase + nslots;
+  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u));
+  if (s0 >= end) return;
+  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
+#if TF_CSV_PREFETCH
+  RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
+  for (uint32_t s = s0; s < end; s += CT_WAVES) {
+    RegCell cn = c;
+    if (s + CT_WAVES < end) { item_next(t, x); cn = reg_cell(t, (uint32_t)run.first, x, items); }  // (wave-uniform)
+    body(c);
+    c = cn;
+  }
+#else
+  for (uint32_t s = s0; s < end; s += CT_WAVES, item_next(t, x)) body(reg_cell(t, (uint32_t)run.first, x, items));
+#endif
+}
 // the column buffers are device allocations: say so, or the pointer read back from LDS makes every store a flat_store
 template <class T> __device__ __forceinline__ T *global_ptr(uint64_t p) { return TF_GLOBAL_PTR(T, p); }
 // number of quote characters in tile positions [a, b), a <= b: prefix counts per 32-byte word + the bitmap
@@ -1373,14 +1397,7 @@ template <int KIND, int W, class T> __device__ __forceinline__ void reg_int_body
 }
 template <int KIND, int W> __device__ __forceinline__ void reg_cells_int(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
   using T = std::conditional_t<W == 1, int8_t, std::conditional_t<W == 2, int16_t, std::conditional_t<W == 4, int32_t, int64_t>>>;
-  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u));
-  if (s0 >= sbase + nslots) return;
-  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
-  for (uint32_t s = s0; s < sbase + nslots; s += CT_WAVES, item_next(t, x)) {
-    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
-    reg_int_body<KIND, W, T>(t, c, global_ptr<T>(t.colp0[c.on ? c.col : (uint32_t)run.first]));
-  }
+  for_slots(t, run, sbase, wv, lane, [&](const RegCell &c) { reg_int_body<KIND, W, T>(t, c, global_ptr<T>(t.colp0[c.on ? c.col : (uint32_t)run.first])); });
 }
 
 __device__ __forceinline__ void reg_str_body(const RegTile &t, const RegCell &c, uint32_t *const lens, uint32_t *const fstart) {
@@ -1418,15 +1435,10 @@ __device__ __forceinline__ void reg_str_body(const RegTile &t, const RegCell &c,
   if (!done) t.slowf[c.jj] = 1;
 }
 __device__ __forceinline__ void reg_cells_str(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
-  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u));
-  if (s0 >= sbase + nslots) return;
-  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
-  for (uint32_t s = s0; s < sbase + nslots; s += CT_WAVES, item_next(t, x)) {
-    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
+  for_slots(t, run, sbase, wv, lane, [&](const RegCell &c) {
     const uint32_t col = c.on ? c.col : (uint32_t)run.first;
     reg_str_body(t, c, global_ptr<uint32_t>(t.colp0[col]), global_ptr<uint32_t>(t.colp1[col]));
-  }
+  });
 }
 
 // 2006-01-02 | 2006-01-02[ T]15:04:05 (cast.StringToDate layouts); a timestamp column also takes plain decimal
@@ -1482,15 +1494,10 @@ template <int KIND> __device__ __forceinline__ void reg_time_body(const RegTile 
   if (!done) t.slowf[c.jj] = 1;
 }
 template <int KIND> __device__ __forceinline__ void reg_cells_time(const RegTile &t, const CsvRun &run, uint32_t sbase, int wv, int lane) {
-  const uint32_t items = (uint32_t)run.ncols * t.nr, nslots = (items + 63) >> 6;
-  const uint32_t s0 = sbase + (((uint32_t)wv - sbase) & (CT_WAVES - 1u));
-  if (s0 >= sbase + nslots) return;
-  ItemIter x = item_first(t, (s0 - sbase) * 64 + (uint32_t)lane);
-  for (uint32_t s = s0; s < sbase + nslots; s += CT_WAVES, item_next(t, x)) {
-    const RegCell c = reg_cell(t, (uint32_t)run.first, x, items);
-    if (!c.on) continue;
+  for_slots(t, run, sbase, wv, lane, [&](const RegCell &c) {
+    if (!c.on) return;
     reg_time_body<KIND>(t, c, global_ptr<int64_t>(t.colp0[c.col]), global_ptr<int32_t>(t.colp1[c.col]));
-  }
+  });
 }
 
 // ---- the column-lane form of the cell phase -----------------------------------------------------------------------------------
