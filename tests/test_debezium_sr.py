@@ -82,6 +82,105 @@ def test_compile_registry_schema_failures_follow_the_oracle():
             debezium.compile_registry_schema(text)
 
 
+def _random_struct(rng, depth=0):
+    types = ["int8", "int16", "int32", "int64", "boolean", "string", "float", "double", "bytes", "struct", "array", "weird"]
+    fields = []
+    for i in range(rng.randrange(1, 7)):
+        t = rng.choice(types if depth < 2 else types[:9])
+        f = {"type": t, "optional": rng.random() < 0.5, "field": "f%d_%d" % (depth, i)}
+        if t == "bytes" and rng.random() < 0.5:
+            f["name"] = "org.apache.kafka.connect.data.Decimal"
+            f["parameters"] = {"scale": rng.choice(["2", "0", "x", "-3", ""]), "connect.decimal.precision": "10"}
+        if t == "struct":
+            f["name"] = rng.choice(["io.debezium.data.geometry.Point", "io.debezium.data.VariableScaleDecimal", "other.Struct"])
+            f["fields"] = _random_struct(rng, depth + 1)["fields"]
+        if t == "array":
+            f["items"] = {"type": "int32", "optional": True}
+        if rng.random() < 0.1:
+            f["version"] = rng.randrange(1, 4)
+        if rng.random() < 0.1:
+            f["default"] = rng.choice([0, "d", False, 1.5])
+        if rng.random() < 0.05:
+            f["__dt_original_type_info"] = {"original_type": "pg:integer"}
+        fields.append(f)
+    return {"type": "struct", "fields": fields, "optional": False}
+
+
+def _mutate(rng, node):
+    """one random damage to a ConfluentJSONSchema document (in place); returns a label"""
+    objs = []
+
+    def walk(o):
+        if isinstance(o, dict):
+            objs.append(o)
+            for v in list(o.values()):
+                walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+    walk(node)
+    o = rng.choice(objs)
+    kind = rng.randrange(6)
+    if kind == 0 and "connect.index" in o:
+        del o["connect.index"]; return "no index"
+    if kind == 1 and "connect.index" in o:
+        o["connect.index"] = 0; return "index 0"
+    if kind == 2:
+        k = rng.choice(["title", "type", "connect.type", "description"]); o[k] = rng.choice([5, [], {}, True]); return "bad " + k
+    if kind == 3:
+        k = rng.choice(["connect.version", "connect.index"]); o[k] = rng.choice([1.5, "1", [], 1e30]); return "bad " + k
+    if kind == 4:
+        k = rng.choice(["oneOf", "properties", "items", "connect.parameters", "additionalProperties"]); o[k] = rng.choice([7, "s", [3], {"a": 4}]); return "bad " + k
+    o["type"] = rng.choice(["null", "object", "string", "integer", "bogus"]); return "type swap"
+
+
+def test_compile_registry_schema_random():
+    """random envelopes in both forms compile alike; random damage to the registry form ends where the oracle's conversion + the inline
+    compile of its result end (a schema that does not bind / the reference's nil dereference / a receiver-less type / the fields)"""
+    from oracle import ora_srformat as F
+    from transferia_amd import debezium
+    rng = random.Random(77 + SEED0)
+    outcomes = {}
+    for it in range(300):
+        row = _random_struct(rng)
+        row["optional"] = True
+        env = {"type": "struct", "optional": False, "name": "srv.public.t.Envelope",
+               "fields": [dict(row, field="before"), dict(row, field="after"), {"type": "string", "optional": False, "field": "op"}]}
+        conf = F.to_confluent(F.bind_kafka(env))
+        label = "intact"
+        if it % 2:
+            label = _mutate(rng, conf)
+        text = json.dumps(conf).encode()
+
+        def inline(kafka_text):
+            try:
+                return ("fields", debezium.compile_schema(kafka_text))
+            except debezium.SchemaError:
+                return ("schema error", None)
+            except debezium.HostOnly:
+                return ("host", None)
+        try:
+            want = inline(F.convert_schema_format(text))
+        except F.Unbindable:
+            want = ("schema error", None)
+        except F.GoPanic:
+            want = ("host", None)
+        try:
+            got = ("fields", debezium.compile_registry_schema(text))
+        except debezium.SchemaError:
+            got = ("schema error", None)
+        except debezium.HostOnly:
+            got = ("host", None)
+        if it % 2 == 0:
+            assert got == inline(json.dumps(env).encode()), (it, "the two forms of one envelope")
+        # the C side may always hand a schema to the host; it must never decide differently
+        assert got == want or got[0] == "host", (it, label, got[0], want[0], text[:300])
+        outcomes[(label.split()[0], got[0], want[0])] = outcomes.get((label.split()[0], got[0], want[0]), 0) + 1
+    kinds = {k[1] for k in outcomes}
+    assert {"fields", "schema error", "host"} <= kinds, outcomes
+    assert sum(v for k, v in outcomes.items() if k[1] == "host" and k[2] != "host") <= 20, outcomes   # conservative answers stay rare
+
+
 # ---- streams ------------------------------------------------------------------------------------------------------------------
 def frame(sid, payload: bytes) -> bytes:
     return b"\x00" + int(sid).to_bytes(4, "big") + payload
