@@ -63,6 +63,8 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms =
  * of tf_runtime.hip / tf_shard.hip runs here, nothing about peer copies is proven */
 inline int &hipemu_current_device() { static thread_local int d = 0; return d; }
 inline hipError_t hipGetDeviceCount(int *n) { const char *e = std::getenv("HIPEMU_DEVICES"); *n = e ? std::max(1, std::atoi(e)) : 1; return hipSuccess; }
+inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipSetDevice(int d) { int n; hipGetDeviceCount(&n); if (d < 0 || d >= n) return hipErrorInvalidValue; hipemu_current_device() = d; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { std::memset(p, 0, sizeof *p); std::strcpy(p->gcnArchName, "gfx950:hipemu"); p->multiProcessorCount = 256; return hipSuccess; }
 

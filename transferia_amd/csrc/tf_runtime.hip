@@ -291,6 +291,17 @@ int tfgpu_init_devices(const int *devices, int ndevices) {
     cus.push_back(prop.multiProcessorCount);
   }
   g_devices = want; g_device_cus = cus;
+  // Buffers move between the lanes' devices (tfgpu_dbatch_to_lane, tfgpu_dbatch_concat: hipMemcpyAsync, hipMemcpyDefault).  With the
+  // peer mapping enabled that copy is one DMA over xGMI; without it the runtime stages through host memory.  Best effort: a pair
+  // that cannot be mapped (or already is) keeps the staged copy, which is correct either way.
+  for (size_t i = 0; i < want.size(); i++)
+    for (size_t j = 0; j < want.size(); j++) {
+      if (want[i] == want[j]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, want[i], want[j]) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+      if (hipSetDevice(want[i]) != hipSuccess || hipDeviceEnablePeerAccess(want[j], 0) != hipSuccess) (void)hipGetLastError();
+    }
+  t_device = -1;  // (the loop may have left another device current)
   g_ctx = make_lane(0);
   return TFGPU_OK;
   TF_API_END
