@@ -196,6 +196,7 @@ typedef enum tfgpu_rowerr {
   TFGPU_ROW_DBZ_OP = 21,           /* opToKind: unknown op (kind.go:34-46)                                              */
   TFGPU_ROW_DBZ_SCHEMA = 22,       /* receiveSchema fails: the schema does not unmarshal, or a field's Kafka type has no
                                       receiver (receiver.go:60-96, receiver_engine.go:108-146)                          */
+  TFGPU_ROW_SR_PROTO = 25,         /* confluent SR protobuf: the schema text does not compile, or the message bytes do not unmarshal (format_protobuf.go:44-53) */
   TFGPU_ROW_DROPPED = 24,          /* registry-framed Debezium: an earlier event of the same Kafka message failed; DoBuf stops there */
   TFGPU_ROW_DBZ_FIELD = 23         /* a schema field is missing from before / after, or receiveField rejects its value
                                       (receiver.go:216-230, receiver_engine.go:148-287)                                 */
@@ -669,6 +670,39 @@ typedef struct tfgpu_sr_json_options {
  * message the shim applies the "first error ends the message" rule across its calls.                                */
 int tfgpu_sr_json_parse(const tfgpu_sr_json_options *opts, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
                         tfgpu_dbatch **out, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
+
+/* ---- Confluent Schema Registry ingest, PROTOBUF schemas ("then JSON/Protobuf") -------------------------------------
+ * makeChangeItemsFromMessageWithProtobuf (pkg/parsers/registry/confluentschemaregistry/engine/format_protobuf.go:16-90): a Kafka
+ * message is  0x00 | schema id (BE uint32) | message indexes | protobuf bytes — ONE item per Kafka message (doWithSchema consumes
+ * the whole rest, parser.go:46-48).  The message is unmarshalled by the descriptor compiled from the registry's .proto text
+ * (mdBuilder.toMD, md_builder.go:26-70) and unpacked field by field (unpackProtobufDynamicMessage, utils_protobuf.go:87-112):
+ * one column per field of the message in declaration order, typed by protoSchemaTypes (types_protobuf.go:16-35: int32 / sint32 /
+ * sfixed32 -> int32, …, string -> utf8, bytes -> string, enum -> utf8 holding the int32 number, message -> any); an absent field is
+ * its proto3 zero value, an absent message field nil; kind Insert; table id from BuildProtobufTableID (table_name_policy.go:51-71).
+ *
+ * tfgpu_sr_compile_proto (tf_protoschema.cpp): the descriptor for what the device decodes — proto3 messages whose fields are singular
+ * scalars / enums, or singular messages of such fields (`any` columns: json.Marshal of the map of ALL their fields, keys sorted;
+ * confluent.type.Decimal is built in).  tfgpu_pb_schema_info: code = TFGPU_ROW_OK and the fields, TFGPU_ROW_SR_PROTO (the text does
+ * not compile / the record name does not split: every message of the schema is `_unparsed`) or TFGPU_ROW_HOST_FALLBACK with `why`
+ * (repeated / map / oneof fields, proto2, deeper nesting, other imports: the stock code).  policy: "debezium_style" (default) |
+ * "message_name"; message_name: "" = the first message of the file (getRecordName).
+ * tfgpu_sr_proto_parse: every Kafka message whose prefix carries schema_id.  *out: one row per good message (src_row = part_id =
+ * message index); errs: row = step = message index, code = TFGPU_ROW_SR_PROTO (the bytes do not unmarshal), TFGPU_ROW_SR_SHORT /
+ * TFGPU_ROW_SR_MAGIC (only with report_frame_errors), TFGPU_ROW_HOST_FALLBACK (message indexes other than the single 0 byte, a known
+ * field met with another wire type, a message field met twice, groups, NaN / Inf inside a message field).  With a schema whose code
+ * is not TFGPU_ROW_OK every message of the id gets that code.  Parity: the .proto compiler and the dynamic message are dependencies
+ * of the reference; the oracle restates the published language subset and wire format and is pinned to the reference's two PROTOBUF
+ * test vectors (parser_test.go TestClient: schemas 5 and 6, test_protobuf_{0,1}.bin, canon).                                     */
+enum { TFGPU_PB_DOUBLE = 1, TFGPU_PB_FLOAT, TFGPU_PB_INT64, TFGPU_PB_UINT64, TFGPU_PB_INT32, TFGPU_PB_FIXED64, TFGPU_PB_FIXED32, TFGPU_PB_BOOL, TFGPU_PB_STRING,
+       TFGPU_PB_BYTES, TFGPU_PB_UINT32, TFGPU_PB_SFIXED32, TFGPU_PB_SFIXED64, TFGPU_PB_SINT32, TFGPU_PB_SINT64, TFGPU_PB_ENUM, TFGPU_PB_MESSAGE };
+typedef struct tfgpu_pb_member { const char *name; int32_t number; int32_t ptype; } tfgpu_pb_member;
+typedef struct tfgpu_pb_field { const char *name; int32_t number; int32_t ptype; int32_t nmembers; const tfgpu_pb_member *members; /* of a MESSAGE field, sorted by name */ } tfgpu_pb_field;
+typedef struct tfgpu_pb_schema tfgpu_pb_schema;
+int tfgpu_sr_compile_proto(const char *schema_text, uint64_t len, const char *policy, const char *manual_table_name, const char *message_name, tfgpu_pb_schema **out);
+int tfgpu_pb_schema_info(const tfgpu_pb_schema *s, int32_t *code, const tfgpu_pb_field **fields, int32_t *nfields, const char **table_ns, const char **table_name, const char **record, const char **why);
+void tfgpu_pb_schema_free(tfgpu_pb_schema *s);
+int tfgpu_sr_proto_parse(const tfgpu_pb_schema *s, uint32_t schema_id, int32_t report_frame_errors, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
+                         tfgpu_dbatch **out, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs);
 
 /* ---- serialize ---------------------------------------------------------- */
 enum {

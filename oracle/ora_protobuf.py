@@ -1,0 +1,494 @@
+"""TEST INFRASTRUCTURE — the checker's restatement of the Confluent-SR parser's PROTOBUF branch, never part of the product path.
+
+    makeChangeItemsFromMessageWithProtobuf        pkg/parsers/registry/confluentschemaregistry/engine/format_protobuf.go:16-90
+    unpackProtobufDynamicMessage / handleField    engine/utils_protobuf.go:58-112
+    unpackVal / unpackNotRepeatedVal              engine/types_protobuf.go:36-149 (protoSchemaTypes :16-35)
+    mdBuilder.toMD / getRecordName                engine/md_builder.go:26-70, utils_protobuf.go:27-32
+    BuildProtobufTableID                          table_name_policy/table_name_policy.go:51-71
+    ConfluentSrImpl.DoOne / doWithSchema          engine/parser.go:108-120, 30-59 (a protobuf payload is the whole rest of the message)
+
+The schema compiler (jhump/protoreflect v1.15 protoparse) and the dynamic message (jhump dynamic.Message over golang/protobuf's wire
+format) are dependencies of the reference, not part of it: this file restates the published proto3 language subset and wire format for
+what the device takes — a message whose fields are singular scalars, enums, or singular messages made of such fields — and says
+HostOnly for the rest (repeated / map fields, proto2 defaults and groups, well-known types whose Go structs the reference marshals
+instead of walking, imports it does not know).  Pinned to the reference's own vectors: tests/golden/sr_protobuf.json holds the two
+PROTOBUF schemas, messages and canon items of engine/parser_test.go's TestClient."""
+import base64
+import re
+import struct
+
+SCALARS = {"double": "double", "float": "float", "int64": "int64", "uint64": "uint64", "int32": "int32", "fixed64": "uint64", "fixed32": "uint32", "bool": "boolean",
+           "string": "utf8", "bytes": "string", "uint32": "uint32", "sfixed32": "int32", "sfixed64": "int64", "sint32": "int32", "sint64": "int64"}   # protoSchemaTypes
+VARINT = {"int64", "uint64", "int32", "bool", "uint32", "sint32", "sint64", "enum"}
+FIX64 = {"double", "fixed64", "sfixed64"}
+FIX32 = {"float", "fixed32", "sfixed32"}
+# imports whose messages are restated here (confluent-kafka-go v2 schemaregistry/confluent/type/decimal.proto)
+BUILTIN = {"confluent.type.Decimal": [("value", 1, "bytes"), ("precision", 2, "uint32"), ("scale", 3, "int32")]}
+BUILTIN_FILES = {"confluent/meta.proto", "confluent/type/decimal.proto"}
+
+
+class ProtoError(ValueError):
+    """protoparse fails: "unable to build MessageDescriptor" — every message of the schema is `_unparsed`"""
+
+
+class HostOnly(ValueError):
+    """outside what is restated: the stock code decides"""
+
+
+_TOK = re.compile(r'\s+|//[^\n]*|/\*.*?\*/|(?P<str>"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\')|(?P<id>[A-Za-z_][A-Za-z0-9_]*(?:\.[A-Za-z_][A-Za-z0-9_]*)*|\.[A-Za-z_][A-Za-z0-9_.]*)|(?P<num>[-+]?[0-9][0-9A-Za-z_.+-]*)|(?P<sym>[{}\[\]()<>=;,:])', re.S)
+
+
+def _tokens(text):
+    out, i = [], 0
+    while i < len(text):
+        m = _TOK.match(text, i)
+        if not m or m.end() == i:
+            raise ProtoError("bad character at %d" % i)
+        i = m.end()
+        if m.lastgroup:
+            out.append((m.lastgroup, m.group(m.lastgroup)))
+    return out
+
+
+class _Msg:
+    def __init__(self, name, full):
+        self.name, self.full, self.fields, self.messages, self.enums = name, full, [], [], []
+
+
+class _P:
+    def __init__(self, text):
+        self.t, self.i = _tokens(text), 0
+        self.package, self.syntax, self.imports, self.messages, self.enums = "", "proto2", [], [], []
+
+    def peek(self):
+        return self.t[self.i] if self.i < len(self.t) else ("eof", "")
+
+    def next(self):
+        tok = self.peek()
+        self.i += 1
+        return tok
+
+    def expect(self, val):
+        k, v = self.next()
+        if v != val:
+            raise ProtoError("expected %r, got %r" % (val, v))
+
+    def ident(self):
+        k, v = self.next()
+        if k != "id":
+            raise ProtoError("expected a name, got %r" % v)
+        return v
+
+    def skip_statement(self):   # … ; with balanced brackets inside
+        depth = 0
+        while True:
+            k, v = self.next()
+            if k == "eof":
+                raise ProtoError("unexpected end")
+            if v in "{[(<" and k == "sym":
+                depth += 1
+            elif v in "}])>" and k == "sym":
+                depth -= 1
+            elif v == ";" and depth == 0:
+                return
+
+    def skip_block(self):   # { … }
+        self.expect("{")
+        depth = 1
+        while depth:
+            k, v = self.next()
+            if k == "eof":
+                raise ProtoError("unexpected end")
+            if k == "sym" and v == "{":
+                depth += 1
+            elif k == "sym" and v == "}":
+                depth -= 1
+
+    def file(self):
+        while self.peek()[0] != "eof":
+            k, v = self.peek()
+            if v == "syntax":
+                self.next(); self.expect("=")
+                self.syntax = self.next()[1].strip("\"'")
+                self.expect(";")
+            elif v == "package":
+                self.next(); self.package = self.ident(); self.expect(";")
+            elif v == "import":
+                self.next()
+                if self.peek()[1] in ("public", "weak"):
+                    self.next()
+                self.imports.append(self.next()[1].strip("\"'")); self.expect(";")
+            elif v == "option":
+                self.skip_statement()
+            elif v == "message":
+                self.messages.append(self.message(self.package))
+            elif v == "enum":
+                self.next(); name = self.ident(); self.skip_block(); self.enums.append((self.package + "." if self.package else "") + name)
+            elif v in ("service", "extend"):
+                raise HostOnly(v)
+            elif v == ";":
+                self.next()
+            else:
+                raise ProtoError("unexpected %r" % v)
+
+    def message(self, scope):
+        self.expect("message")
+        name = self.ident()
+        m = _Msg(name, (scope + "." if scope else "") + name)
+        self.expect("{")
+        while True:
+            k, v = self.peek()
+            if v == "}" and k == "sym":
+                self.next()
+                return m
+            if k == "eof":
+                raise ProtoError("unexpected end")
+            if v == "message":
+                m.messages.append(self.message(m.full))
+            elif v == "enum":
+                self.next(); en = self.ident(); self.skip_block(); m.enums.append(m.full + "." + en)
+            elif v in ("option", "reserved"):
+                self.skip_statement()
+            elif v in ("extensions", "extend", "group"):
+                raise HostOnly(v)
+            elif v == "oneof":
+                raise HostOnly("oneof")   # (GetKnownFields order and the unset member's value are the dynamic message's business)
+            elif v == ";":
+                self.next()
+            else:
+                m.fields.append(self.field())
+
+    def field(self):
+        label = ""
+        if self.peek()[1] in ("optional", "required", "repeated"):
+            label = self.next()[1]
+        if self.peek()[1] == "map":
+            raise HostOnly("map field")
+        if self.peek()[1] == "group":
+            raise HostOnly("group")
+        typ = self.ident()
+        name = self.ident()
+        self.expect("=")
+        k, num = self.next()
+        if k != "num":
+            raise ProtoError("field number")
+        has_default = False
+        if self.peek()[1] == "[":
+            depth = 0
+            while True:
+                k, v = self.next()
+                if k == "eof":
+                    raise ProtoError("unexpected end")
+                if k == "id" and v == "default" and depth == 1:
+                    has_default = True
+                if k == "sym" and v in "[{(<":
+                    depth += 1
+                elif k == "sym" and v in "]})>":
+                    depth -= 1
+                    if depth == 0:
+                        break
+        self.expect(";")
+        return {"name": name, "number": int(num, 0), "label": label, "type": typ, "default": has_default}
+
+
+def _all_messages(msgs):
+    for m in msgs:
+        yield m
+        yield from _all_messages(m.messages)
+
+
+def _all_enums(p):
+    out = set(p.enums)
+    for m in _all_messages(p.messages):
+        out.update(m.enums)
+    return out
+
+
+def _resolve(p, scope_full, typ):
+    """protobuf name resolution: innermost scope outwards; a leading dot is fully qualified"""
+    msgs = {m.full: m for m in _all_messages(p.messages)}
+    enums = _all_enums(p)
+    if typ.startswith("."):
+        cands = [typ[1:]]
+    else:
+        parts = scope_full.split(".") if scope_full else []
+        cands = [".".join(parts[:i] + [typ]) for i in range(len(parts), -1, -1)]
+    for c in cands:
+        if c in msgs:
+            return "message", msgs[c]
+        if c in enums:
+            return "enum", None
+        if c in BUILTIN:
+            return "builtin", c
+    raise HostOnly("type %s is not in this file (an import the device does not restate)" % typ)
+
+
+def compile_schema(text: str, policy: str = "debezium_style", manual_table_name: str = "", message_name: str = ""):
+    """toMD + BuildProtobufTableID + the column list: {"record", "ns", "table", "fields": [(name, proto type, yt type, members or None)]}
+    — members = [(name, number, proto type)] of a singular message field.  dirtyPatch (utils_protobuf.go:34-56) only adds an import."""
+    p = _P(text)
+    p.file()
+    for imp in p.imports:
+        if imp not in BUILTIN_FILES:
+            raise HostOnly("import %s" % imp)
+    if not p.messages:
+        raise HostOnly("no message in the file: the reference dereferences a nil descriptor")
+    record = message_name
+    md = None
+    if record:
+        md = next((m for m in _all_messages(p.messages) if m.full == record), None)
+    if md is None:
+        md = p.messages[0]   # getRecordName: the first message of the file
+        record = md.full
+    if manual_table_name:
+        ns, table = "", manual_table_name
+    elif policy == "debezium_style":
+        parts = record.split(".")
+        if len(parts) != 4:
+            raise ProtoError("Can't split recordName '%s' into schema and table names" % record)
+        ns, table = parts[1], parts[2]
+    elif policy == "message_name":
+        ns, table = "", record.split(".")[-1]
+    else:
+        raise ProtoError("invalid ProtobufTableNamePolicy")
+
+    def members_of(kind, ref, depth):
+        if kind == "builtin":
+            return list(BUILTIN[ref])
+        out, seen2 = [], set()
+        for f in ref.fields:
+            if f["label"] == "repeated" or f["default"] or f["label"] == "required" or (p.syntax != "proto3"):
+                raise HostOnly("a nested message the device does not walk")
+            if f["number"] in seen2 or f["number"] <= 0 or f["number"] > 536870911:
+                raise ProtoError("field number")
+            seen2.add(f["number"])
+            if f["type"] in SCALARS:
+                out.append((f["name"], f["number"], f["type"]))
+            else:
+                k2, _r2 = _resolve(p, ref.full, f["type"])
+                if k2 != "enum":
+                    raise HostOnly("messages nested deeper than one level")
+                out.append((f["name"], f["number"], "enum"))
+        if len({m[0] for m in out}) != len(out):
+            raise ProtoError("a field name repeats")
+        return out
+    if p.syntax != "proto3":
+        raise HostOnly("proto2: required / default / groups")
+    fields, seen = [], set()
+    for f in md.fields:
+        if f["label"] == "repeated":
+            raise HostOnly("repeated field")
+        if f["default"]:
+            raise HostOnly("default option")
+        if f["number"] in seen or f["number"] <= 0 or f["number"] > 536870911:
+            raise ProtoError("field number")
+        seen.add(f["number"])
+        if f["type"] in SCALARS:
+            fields.append((f["name"], f["number"], f["type"], SCALARS[f["type"]], None))
+            continue
+        kind, ref = _resolve(p, md.full, f["type"])
+        if kind == "enum":
+            fields.append((f["name"], f["number"], "enum", "utf8", None))
+        else:
+            fields.append((f["name"], f["number"], "message", "any", members_of(kind, ref, 1)))
+    if len({f[0] for f in fields}) != len(fields):
+        raise ProtoError("a field name repeats")
+    return {"record": record, "ns": ns, "table": table, "fields": fields}
+
+
+# ---- wire format (developers.google.com/protocol-buffers/docs/encoding) -----------------------------------------------------------
+class WireError(ValueError):
+    pass
+
+
+def _varint(b, i):
+    v, s = 0, 0
+    while True:
+        if i >= len(b) or s >= 70:
+            raise WireError("varint")
+        c = b[i]
+        i += 1
+        v |= (c & 0x7F) << s
+        s += 7
+        if not c & 0x80:
+            return v & 0xFFFFFFFFFFFFFFFF, i
+
+
+def _scalar(ptype, wt, raw):
+    """the Go value of one occurrence: (gotype, value)"""
+    if ptype in ("int32", "enum"):
+        v = raw & 0xFFFFFFFF
+        return ("int32", v - (1 << 32) if v >> 31 else v)
+    if ptype == "int64":
+        return ("int64", raw - (1 << 64) if raw >> 63 else raw)
+    if ptype == "uint32":
+        return ("uint32", raw & 0xFFFFFFFF)
+    if ptype == "uint64":
+        return ("uint64", raw)
+    if ptype == "sint32":
+        v = raw & 0xFFFFFFFF
+        return ("int32", (v >> 1) ^ -(v & 1))
+    if ptype == "sint64":
+        return ("int64", (raw >> 1) ^ -(raw & 1))
+    if ptype == "bool":
+        return ("bool", raw != 0)
+    if ptype == "fixed32":
+        return ("uint32", raw)
+    if ptype == "sfixed32":
+        return ("int32", raw - (1 << 32) if raw >> 31 else raw)
+    if ptype == "float":
+        return ("float32", struct.unpack("<f", struct.pack("<I", raw))[0])
+    if ptype == "fixed64":
+        return ("uint64", raw)
+    if ptype == "sfixed64":
+        return ("int64", raw - (1 << 64) if raw >> 63 else raw)
+    if ptype == "double":
+        return ("float64", struct.unpack("<d", struct.pack("<Q", raw))[0])
+    raise AssertionError(ptype)
+
+
+_ZERO = {"int32": ("int32", 0), "enum": ("int32", 0), "int64": ("int64", 0), "uint32": ("uint32", 0), "uint64": ("uint64", 0), "sint32": ("int32", 0), "sint64": ("int64", 0),
+         "bool": ("bool", False), "fixed32": ("uint32", 0), "sfixed32": ("int32", 0), "float": ("float32", 0.0), "fixed64": ("uint64", 0), "sfixed64": ("int64", 0),
+         "double": ("float64", 0.0), "string": ("string", b""), "bytes": ("bytes", b"")}
+
+
+def _want_wt(ptype):
+    return 0 if ptype in VARINT else 1 if ptype in FIX64 else 5 if ptype in FIX32 else 2
+
+
+def decode_fields(b: bytes, fields):
+    """fields = [(name, number, ptype, …)] → {number: last occurrence} — (wt, raw int | bytes).  A known field met with another wire
+    type, a message field met twice (merged by protobuf), a group: HostOnly.  Truncation: WireError."""
+    by_num = {f[1]: f for f in fields}
+    out, i, twice = {}, 0, False
+    while i < len(b):
+        tag, i = _varint(b, i)
+        num, wt = tag >> 3, tag & 7
+        if num == 0:
+            raise WireError("field number 0")
+        if wt == 0:
+            raw, i = _varint(b, i)
+        elif wt == 1:
+            if i + 8 > len(b):
+                raise WireError("fixed64")
+            raw = int.from_bytes(b[i:i + 8], "little"); i += 8
+        elif wt == 5:
+            if i + 4 > len(b):
+                raise WireError("fixed32")
+            raw = int.from_bytes(b[i:i + 4], "little"); i += 4
+        elif wt == 2:
+            n, i = _varint(b, i)
+            if i + n > len(b):
+                raise WireError("length")
+            raw = b[i:i + n]; i += n
+        else:
+            raise HostOnly("group / unknown wire type")
+        f = by_num.get(num)
+        if f is None:
+            continue
+        if wt != _want_wt(f[2]):
+            raise HostOnly("wire type of a known field")
+        if f[2] == "message":
+            if num in out:
+                twice = True
+            decode_fields(raw, [(n, k, t) for n, k, t in f[4]]) if len(f) > 4 and f[4] else None   # a nested message unmarshals eagerly
+        out[num] = raw
+    if twice:
+        raise HostOnly("a message field met twice (protobuf merges them)")
+    return out
+
+
+def _go_json(v):
+    """json.Marshal of a nested message's map value"""
+    from . import oracle as ora
+    g, x = v
+    if g == "bool":
+        return b"true" if x else b"false"
+    if g in ("int32", "int64", "uint32", "uint64"):
+        return str(x).encode()
+    if g in ("float32", "float64"):
+        if x != x or x in (float("inf"), float("-inf")):
+            raise HostOnly("json.Marshal fails on NaN / Inf")
+        return ora.json_float(x, 32 if g == "float32" else 64).encode()
+    if g == "bytes":
+        return b'"' + base64.b64encode(x) + b'"'
+    if g == "string":
+        from .dbz_emitter import go_json_string
+        return go_json_string(x)   # (the column's internal text: HTML escaping is the serializers' business, as for every `any`)
+    raise AssertionError(g)
+
+
+def unpack(schema, payload: bytes):
+    """unpackProtobufDynamicMessage: [(gotype, value)] in field order; nested messages as ("json", marshalled map, keys sorted)"""
+    top = decode_fields(payload, schema["fields"])
+    vals = []
+    for name, num, ptype, _yt, members in schema["fields"]:
+        raw = top.get(num)
+        if ptype == "message":
+            if raw is None:
+                vals.append(("nil", None))   # a typed nil *dynamic.Message: `return nil, nil`
+                continue
+            inner = decode_fields(raw, [(n, k, t) for n, k, t in members])
+            parts = []
+            for mn, mk, mt in sorted(members):
+                r2 = inner.get(mk)
+                v = _ZERO[mt] if r2 is None else ((("string", bytes(r2)) if mt == "string" else ("bytes", bytes(r2))) if mt in ("string", "bytes") else _scalar(mt, 0, r2))
+                parts.append(_json_key(mn) + b":" + _go_json(v))
+            vals.append(("json", b"{" + b",".join(parts) + b"}"))
+        elif raw is None:
+            vals.append(_ZERO[ptype])
+        elif ptype == "string":
+            vals.append(("string", bytes(raw)))
+        elif ptype == "bytes":
+            vals.append(("bytes", bytes(raw)))
+        else:
+            vals.append(_scalar(ptype, 0, raw))
+    return vals
+
+
+def _json_key(name):
+    from .dbz_emitter import go_json_string
+    return go_json_string(name.encode())
+
+
+ROW_SR_SHORT, ROW_SR_MAGIC, ROW_HOST_FALLBACK, ROW_SR_PROTO = 15, 16, 11, 25
+
+
+def parse_messages(messages, registry, policy="debezium_style", manual_table_name=""):
+    """ConfluentSrImpl.Do per Kafka message for PROTOBUF schemas; registry: id → schema text.  Returns one entry per message:
+    ("item", {ns, table, names, yt types, values}) | ("unparsed", code) | ("host", None) | ("none", None) for an empty message."""
+    compiled = {}
+    out = []
+    for buf in messages:
+        if len(buf) == 0:
+            out.append(("none", None)); continue
+        if len(buf) < 5:
+            out.append(("unparsed", ROW_SR_SHORT)); continue
+        if buf[0] != 0:
+            out.append(("unparsed", ROW_SR_MAGIC)); continue
+        sid = int.from_bytes(buf[1:5], "big")
+        rest = buf[5:]
+        if len(rest) == 0:
+            out.append(("host", None)); continue    # buf[0] of an empty slice: the reference panics
+        if rest[0] != 0:
+            out.append(("host", None)); continue    # message indexes: another message of the file (handleMessageIndexes) — not restated
+        if sid not in compiled:
+            try:
+                compiled[sid] = compile_schema(registry[sid].decode("utf-8"), policy, manual_table_name)
+            except ProtoError:
+                compiled[sid] = ROW_SR_PROTO
+            except HostOnly:
+                compiled[sid] = None
+        sch = compiled[sid]
+        if sch is None:
+            out.append(("host", None)); continue
+        if sch == ROW_SR_PROTO:
+            out.append(("unparsed", ROW_SR_PROTO)); continue
+        try:
+            vals = unpack(sch, rest[1:])
+        except WireError:
+            out.append(("unparsed", ROW_SR_PROTO)); continue
+        except HostOnly:
+            out.append(("host", None)); continue
+        out.append(("item", {"ns": sch["ns"], "table": sch["table"], "names": [f[0] for f in sch["fields"]], "types": [f[3] for f in sch["fields"]], "values": vals}))
+    return out

@@ -1,0 +1,314 @@
+"""Confluent-SR parser, PROTOBUF schemas: the oracle pinned to the reference's two protobuf test vectors (CPU), the C
+side's .proto compilation against the oracle's (CPU: host code), tfgpu_sr_proto_parse against the oracle and the same vectors (GPU)."""
+import base64
+import json
+import random
+import struct
+
+import numpy as np
+import pytest
+
+from transferia_amd import abi
+from util import golden
+import os as _os
+
+SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))
+PB = {"double": 1, "float": 2, "int64": 3, "uint64": 4, "int32": 5, "fixed64": 6, "fixed32": 7, "bool": 8, "string": 9, "bytes": 10, "uint32": 11, "sfixed32": 12, "sfixed64": 13,
+      "sint32": 14, "sint64": 15, "enum": 16, "message": 17}
+
+
+def canon_of(v):
+    g, x = v
+    if g == "nil":
+        return None
+    if g == "bytes":
+        return base64.b64encode(bytes(x)).decode()
+    if g == "string":
+        return bytes(x).decode("utf-8")
+    if g == "json":
+        return json.loads(bytes(x))
+    return x
+
+
+def close(a, b):
+    if isinstance(b, float) or isinstance(a, float):
+        return a == b or abs(a - b) <= abs(b) * 1e-6   # (the canon prints float32 values through float64)
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(close(a[k], b[k]) for k in a)
+    return a == b
+
+
+def test_oracle_reference_vectors():
+    """parser_test.go TestClient: schemas 5 and 6 of testdata/test_schemas.json, test_protobuf_{0,1}.bin, the canon items"""
+    from oracle import ora_protobuf as P
+    for c in golden("sr_protobuf.json")["cases"]:
+        msg = base64.b64decode(c["message_b64"])
+        (kind, it), = P.parse_messages([msg], {c["schema_id"]: c["schema"].encode()})
+        exp = c["expect"]
+        assert kind == "item" and (it["ns"], it["table"]) == (exp["schema"], exp["table"])
+        assert it["names"] == exp["names"] and it["types"] == [t[1] for t in exp["table_schema"]]
+        for n, v, w in zip(it["names"], it["values"], exp["values"]):
+            assert close(canon_of(v), w), (n, v, w)
+        assert {t[3] for t in exp["table_schema"]} == {it["ns"]} and {t[4] for t in exp["table_schema"]} == {it["table"]}
+
+
+# ---- schema texts ---------------------------------------------------------------------------------------------------------------
+SCALAR_TYPES = ["double", "float", "int64", "uint64", "int32", "fixed64", "fixed32", "bool", "string", "bytes", "uint32", "sfixed32", "sfixed64", "sint32", "sint64"]
+
+
+def random_proto(rng, damage=False):
+    """a proto3 file of the shape the device takes (plus, with `damage`, one of the shapes it must name and hand over or refuse)"""
+    used = set()
+
+    def num():
+        while True:
+            k = rng.choice([rng.randrange(1, 16), rng.randrange(16, 2048), rng.randrange(2048, 300000)])
+            if k not in used and not 19000 <= k <= 19999:
+                used.add(k)
+                return k
+    pkg = "srv.%s.%s" % (rng.choice(["public", "ns1"]), rng.choice(["t1", "orders"]))
+    lines = ['syntax = "proto3";', "package %s;" % pkg]
+    if rng.random() < 0.3:
+        lines.append('import "confluent/type/decimal.proto";')
+    body, nested = [], []
+    nf = rng.randrange(1, 12)
+    for i in range(nf):
+        r = rng.random()
+        opt = ' [(confluent.field_meta) = { params: [ { value: "int16", key: "connect.type" } ] }]' if rng.random() < 0.15 else ""
+        if r < 0.7:
+            body.append("  %s%s f%d = %d%s;" % ("optional " if rng.random() < 0.1 else "", rng.choice(SCALAR_TYPES), i, num(), opt))
+        elif r < 0.8:
+            body.append("  Color f%d = %d; // an enum" % (i, num()))
+        elif r < 0.9 and 'import "confluent/type/decimal.proto";' in lines:
+            body.append("  confluent.type.Decimal f%d = %d%s;" % (i, num(), opt))
+        else:
+            saved = used
+            used = set()
+            members = ["    %s m%d = %d;" % (rng.choice(SCALAR_TYPES + ["Color"]), k, num()) for k in range(rng.randrange(1, 5))]
+            used = saved
+            nested.append("  message N%d {\n%s\n  }" % (i, "\n".join(members)))
+            body.append("  %sN%d f%d = %d;" % (rng.choice(["", "Value.", pkg + ".Value.", "." + pkg + ".Value."]), i, i, num()))   # protobuf's scoping: relative, partly and fully qualified
+    label = "intact"
+    if damage:
+        label = rng.choice(["repeated", "map", "oneof", "proto2", "default", "import", "unknown type", "deep", "syntax", "dup number", "reserved ok", "comment ok", "short name"])
+        if label == "repeated":
+            body.append("  repeated int32 rr = %d;" % num())
+        elif label == "map":
+            body.append("  map<string, int32> mm = %d;" % num())
+        elif label == "oneof":
+            body.append("  oneof oo { int32 oa = %d; string ob = %d; }" % (num(), num()))
+        elif label == "proto2":
+            lines[0] = 'syntax = "proto2";'
+        elif label == "default":
+            body.append("  int32 dd = %d [default = 5];" % num())
+        elif label == "import":
+            lines.append('import "google/protobuf/timestamp.proto";')
+        elif label == "unknown type":
+            body.append("  google.protobuf.Timestamp ts = %d;" % num())
+        elif label == "deep":
+            nested.append("  message Deep { Inner i = 1; message Inner { int32 x = 1; } }")
+            body.append("  Deep dp = %d;" % num())
+        elif label == "syntax":
+            body.append("  int32 = ;")
+        elif label == "dup number":
+            body.append("  int32 dupa = 7777;\n  int32 dupb = 7777;")
+        elif label == "reserved ok":
+            body.append("  reserved 9000 to 9010, 9999;\n  reserved \"zz\";\n  option deprecated = true;")
+        elif label == "comment ok":
+            body.append("  /* a block\n comment */ // and a line one")
+        elif label == "short name":
+            lines[1] = "package short;"
+    text = "\n".join(lines) + "\n\nenum Color { RED = 0; GREEN = 1; }\n\nmessage Value {\n" + "\n".join(body + nested) + "\n}\nmessage Other { int32 z = 1; }\n"
+    return text, label
+
+
+def compile_both(text, policy="debezium_style", manual="", message_name=""):
+    from oracle import ora_protobuf as P
+    from transferia_amd import confluent_sr, lib
+    try:
+        o = P.compile_schema(text, policy, manual, message_name)
+        want = ("ok", o["record"], o["ns"], o["table"], [(f[0], f[1], PB[f[2]], sorted((m[0], m[1], PB[m[2]]) for m in (f[4] or []))) for f in o["fields"]])
+    except P.ProtoError:
+        want = ("proto",)
+    except P.HostOnly:
+        want = ("host",)
+    s = confluent_sr.ProtoSchema(lib, text.encode(), policy, manual, message_name)
+    if s.code == abi.ROW_OK:
+        got = ("ok", s.record, s.ns, s.table, [(n, k, t, sorted(m)) for n, k, t, m in s.fields])
+    else:
+        got = ("proto",) if s.code == abi.ROW_SR_PROTO else ("host",)
+    return got, want, s
+
+
+def test_compile_reference_schemas():
+    for c in golden("sr_protobuf.json")["cases"]:
+        got, want, s = compile_both(c["schema"])
+        assert got == want and got[0] == "ok"
+        assert (s.ns, s.table, s.record) == ("public", "timmyb32r_favourite_table", "dbserver1.public.timmyb32r_favourite_table.Value")
+        assert [[f.name, f.dtype] for f in s.table_schema().cols] == [[t[0], t[1]] for t in c["expect"]["table_schema"]]
+        for pol, man, exp in (("message_name", "", ("", "Value")), ("debezium_style", "blablabla", ("", "blablabla"))):   # format_protobuf_test.go TestProtobufTableNamePolicy
+            g2, w2, s2 = compile_both(c["schema"], pol, man)
+            assert g2 == w2 and (s2.ns, s2.table) == exp
+
+
+def test_compile_random_protos():
+    rng = random.Random(11 + SEED0)
+    seen = {}
+    for it in range(400):
+        text, label = random_proto(rng, damage=it % 2 == 1)
+        got, want, _s = compile_both(text, message_name=rng.choice(["", "", "srv.public.t1.Other", "nope"]))
+        assert got == want, (label, got[0], want[0], text)
+        seen[(label, got[0])] = seen.get((label, got[0]), 0) + 1
+    assert {k[1] for k in seen} == {"ok", "host", "proto"}, seen
+
+
+# ---- wire messages --------------------------------------------------------------------------------------------------------------
+def varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def enc_field(num, ptype, rng):
+    """one occurrence of a field, its value random"""
+    if ptype in ("int32", "int64", "uint32", "uint64", "sint32", "sint64", "bool", "enum"):
+        v = rng.choice([0, 1, 2, 127, 128, 300, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, (1 << 63) - 1, 1 << 63, (1 << 64) - 1, rng.getrandbits(64), rng.getrandbits(20)])
+        return varint(num << 3) + varint(v)
+    if ptype in ("double", "fixed64", "sfixed64"):
+        raw = struct.pack("<d", rng.choice([0.0, -0.0, 1.5, 3.14e-100, 1e21, 1e-7, 123456789.125, float(rng.getrandbits(50))])) if ptype == "double" else struct.pack("<Q", rng.getrandbits(64))
+        return varint(num << 3 | 1) + raw
+    if ptype in ("float", "fixed32", "sfixed32"):
+        raw = struct.pack("<f", rng.choice([0.0, 2.2, 1.45e-10, -7.5, 16777216.0, 3.4e38])) if ptype == "float" else struct.pack("<I", rng.getrandbits(32))
+        return varint(num << 3 | 5) + raw
+    body = rng.choice([b"", b"plain", "café €".encode(), b"q\"uote\\ <tag> & \n", bytes(rng.randrange(256) for _ in range(rng.randrange(40))), b"\xff\xfe broken utf8"])
+    return varint(num << 3 | 2) + varint(len(body)) + body
+
+
+def random_message(rng, sch, weird):
+    """a wire message for a compiled oracle schema; with `weird` also the shapes that do not unmarshal or go to the host"""
+    parts = []
+    for name, num, ptype, _yt, members in sch["fields"]:
+        if rng.random() < 0.2:
+            continue
+        reps = 2 if rng.random() < 0.1 and ptype != "message" else 1
+        for _ in range(reps):
+            if ptype == "message":
+                inner = b"".join(enc_field(mk, mt, rng) for _mn, mk, mt in members if rng.random() < 0.7)
+                if rng.random() < 0.1:
+                    inner += varint(5555 << 3) + varint(7)   # an unknown member
+                parts.append(varint(num << 3 | 2) + varint(len(inner)) + inner)
+            else:
+                parts.append(enc_field(num, ptype, rng))
+    if rng.random() < 0.3:
+        parts.append(varint(4444 << 3 | 2) + varint(3) + b"unk")   # an unknown field
+    rng.shuffle(parts)
+    body = b"".join(parts)
+    if weird:
+        k = rng.randrange(12)
+        if k == 0 and body:
+            body = body[:-1]                                       # truncated
+        elif k == 1:
+            body += b"\x80"                                        # a tag that never ends
+        elif k == 2:
+            body += varint(3 << 3 | 3)                             # a group
+        elif k == 3 and sch["fields"]:
+            f = rng.choice(sch["fields"])
+            body += varint(f[1] << 3 | (5 if f[2] not in ("float", "fixed32", "sfixed32") else 0)) + (b"\x00\x00\x00\x00" if f[2] not in ("float", "fixed32", "sfixed32") else b"\x01")   # a known field, another wire type
+        elif k == 4:
+            msgs = [f for f in sch["fields"] if f[2] == "message"]
+            if msgs:
+                body += varint(msgs[0][1] << 3 | 2) + varint(0) + varint(msgs[0][1] << 3 | 2) + varint(0)   # a message field twice
+        elif k == 5:
+            body += varint(0) + varint(1)                          # field number 0
+        elif k == 6:
+            body += varint(9 << 3 | 2) + varint(1000)              # a length past the end
+    return body
+
+
+def frame(sid, body, index=b"\x00"):
+    return b"\x00" + int(sid).to_bytes(4, "big") + index + body
+
+
+@pytest.fixture(scope="module")
+def tf():
+    from transferia_amd import lib
+    lib.init()
+    return lib
+
+
+def device_rows(batch):
+    b = batch.download()
+    return {int(b.src_row[r]): [c.pyvalue(r) for c in b.cols] for r in range(b.nrows)}, b
+
+
+@pytest.mark.gpu
+def test_gpu_reference_vectors(tf):
+    from transferia_amd import confluent_sr
+    for c in golden("sr_protobuf.json")["cases"]:
+        msg = base64.b64decode(c["message_b64"])
+        s = confluent_sr.ProtoSchema(tf, c["schema"].encode())
+        data, m = abi.messages([msg])
+        batch, errors = s.parse(c["schema_id"], data, m)
+        assert not errors
+        rows, b = device_rows(batch)
+        exp = c["expect"]
+        assert (b.table_ns, b.table_name) == (exp["schema"], exp["table"]) and [col.name for col in b.cols] == exp["names"]
+        assert [col.dtype for col in b.cols] == [t[1] for t in exp["table_schema"]]
+        for n, v, w in zip(exp["names"], rows[0], exp["values"]):
+            assert close(canon_of(v), w), (n, v, w)
+        assert b.kind is None or [int(k) for k in b.kind] == [abi.K_INSERT]   # (no kind array: every row an Insert)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weird", [False, True])
+def test_gpu_random_messages_match_oracle(tf, oracle, weird):
+    from oracle import ora_protobuf as P
+    from transferia_amd import confluent_sr
+    rng = random.Random(500 + SEED0 + (1 if weird else 0))
+    checked = hosts = 0
+    for trial in range(12):
+        while True:
+            text, _ = random_proto(rng)
+            try:
+                sch = P.compile_schema(text)
+                break
+            except (P.HostOnly, P.ProtoError):
+                continue
+        sid = 40 + trial
+        msgs = [frame(sid, random_message(rng, sch, weird and k % 3 == 0)) for k in range(150)]
+        if weird:
+            msgs += [b"", b"\x00\x00", b"x" + msgs[0], frame(sid, b"", index=b""), frame(sid, b"\x08\x01", index=b"\x02\x00"), frame(sid + 1000, b"\x08\x01")]
+        want = P.parse_messages(msgs, {sid: text.encode(), sid + 1000: text.encode()})
+        s = confluent_sr.ProtoSchema(tf, text.encode())
+        assert s.code == abi.ROW_OK
+        data, m = abi.messages(msgs)
+        batch, errors = s.parse(sid, data, m)
+        rows, b = device_rows(batch)
+        assert [c.dtype for c in b.cols] == [f[3] for f in sch["fields"]]
+        for k, (kind, it) in enumerate(want):
+            other = len(msgs[k]) >= 5 and msgs[k][0] == 0 and int.from_bytes(msgs[k][1:5], "big") != sid
+            if kind == "none" or other:
+                assert k not in rows and k not in errors, (k, kind)
+            elif kind == "unparsed":
+                assert errors.get(k) == it and k not in rows, (k, errors.get(k), it)
+            elif kind == "host":
+                assert errors.get(k) == abi.ROW_HOST_FALLBACK and k not in rows, (k, errors.get(k))
+                hosts += 1
+            else:
+                assert k in rows and k not in errors, (k, errors.get(k), msgs[k])
+                for f, got, w in zip(sch["fields"], rows[k], it["values"]):
+                    if w[0] == "nil":
+                        assert got[0] == "nil", (f, got)
+                    elif w[0] in ("float32", "float64"):
+                        assert got[0] == w[0] and (struct.pack("<d", got[1]) == struct.pack("<d", w[1]) or (got[1] != got[1] and w[1] != w[1])), (f, got, w)
+                    elif w[0] == "json":
+                        assert bytes(got[1]) == w[1], (f, got, w)
+                    else:
+                        assert abi.norm_value(got) == abi.norm_value(w), (f, got, w)
+                checked += 1
+    assert checked > 600 and (not weird or hosts > 10), (checked, hosts)

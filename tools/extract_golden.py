@@ -1094,6 +1094,26 @@ def sr_format():
     write("sr_format.json", out, compact=True)
 
 
+def sr_protobuf():
+    """Confluent-SR parser, PROTOBUF schemas: the two protobuf schemas of engine/testdata/test_schemas.json (ids 5, 6), the two wire
+    messages (testdata/test_protobuf_{0,1}.bin) and their items in TestClient's canon (engine/gotest/canondata/result.json: the last two
+    of its 55 — parser_test.go:49-52 appends the .bin messages after the JSON lines)."""
+    import base64
+    eng = REF + "/pkg/parsers/registry/confluentschemaregistry/engine/"
+    with open(eng + "testdata/test_schemas.json") as f:
+        schemas = json.load(f)
+    items = canon(eng + "gotest/canondata/result.json", "gotest.gotest.TestClient")
+    cases = []
+    for k, (sid, it) in enumerate(zip(("5", "6"), items[-2:])):
+        assert schemas[sid]["schemaType"] == "PROTOBUF"
+        with open(eng + "testdata/test_protobuf_%d.bin" % k, "rb") as f:
+            msg = f.read()
+        cases.append({"schema_id": int(sid), "schema": schemas[sid]["schema"], "message_b64": base64.b64encode(msg).decode(),
+                      "expect": {"kind": it["kind"], "schema": it["schema"], "table": it["table"], "names": it["columnnames"], "values": it["columnvalues"],
+                                 "table_schema": [[c["name"], c["type"], c["key"], c["table_schema"], c["table_name"]] for c in it["table_schema"]]}})
+    write("sr_protobuf.json", {"cases": cases})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -1107,4 +1127,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium(); sr_format()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium(); sr_format(); sr_protobuf()

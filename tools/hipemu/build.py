@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-UNITS = ["tf_runtime.hip", "tf_shard.hip", "tf_scan.hip", "tf_plan.cpp", "tf_sql.cpp", "tf_transformation.cpp", "tf_pipeline.cpp", "tf_dbzrecv.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_parquet.hip", "tf_parquetw.hip", "tf_dbzemit.hip", "tf_serialize.hip", "tf_json.hip",
-         "tf_collapse.hip", "tf_srjson.hip", "tf_exchange.hip", "tf_sizeof.hip", "tf_chnative.hip", "tf_debezium.hip"]  # = transferia_amd/build.py SOURCES
+UNITS = ["tf_runtime.hip", "tf_shard.hip", "tf_scan.hip", "tf_plan.cpp", "tf_sql.cpp", "tf_transformation.cpp", "tf_pipeline.cpp", "tf_dbzrecv.cpp", "tf_protoschema.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_parquet.hip", "tf_parquetw.hip", "tf_dbzemit.hip", "tf_serialize.hip", "tf_json.hip",
+         "tf_collapse.hip", "tf_srjson.hip", "tf_exchange.hip", "tf_sizeof.hip", "tf_chnative.hip", "tf_debezium.hip", "tf_protobuf.hip"]  # = transferia_amd/build.py SOURCES
 LAUNCH = re.compile(r"(\b[A-Za-z_][A-Za-z0-9_:]*(?:<[^<>;]*>)?)\s*<<<\s*([^;]*?)>>>\s*\(")
 
 

@@ -37,7 +37,7 @@ COL_KEY, COL_REQUIRED, COL_FAKE_KEY = 1, 2, 4
 ROWERR = {0: "OK", 1: "UNSUPPORTED_KIND", 2: "COLUMN_NOT_FOUND", 3: "INT_OVERFLOW", 4: "TYPE_PAIR", 5: "MISSING_CELL",
           6: "CAST", 7: "RANGE", 8: "QUOTE", 9: "DOUBLE_QUOTE", 10: "QUOTING_DISABLED", 11: "HOST_FALLBACK",
           12: "JSON_SYNTAX", 13: "PARSE_VAL", 14: "NIL_KEY", 15: "SR_SHORT", 16: "SR_MAGIC", 17: "SR_TYPE", 18: "SR_REQUIRED",
-          19: "DBZ_UNPACK", 20: "DBZ_PAYLOAD", 21: "DBZ_OP", 22: "DBZ_SCHEMA", 23: "DBZ_FIELD", 24: "DROPPED"}
+          19: "DBZ_UNPACK", 20: "DBZ_PAYLOAD", 21: "DBZ_OP", 22: "DBZ_SCHEMA", 23: "DBZ_FIELD", 24: "DROPPED", 25: "SR_PROTO"}
 ROWERR_ID = {v: k for k, v in ROWERR.items()}
 for _k, _v in ROWERR.items():
     globals()["ROW_" + _v] = _k

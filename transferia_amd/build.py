@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libtfgpu.so")
-SOURCES = ["tf_runtime.hip", "tf_shard.hip", "tf_scan.hip", "tf_plan.cpp", "tf_sql.cpp", "tf_transformation.cpp", "tf_pipeline.cpp", "tf_dbzrecv.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_parquet.hip", "tf_parquetw.hip", "tf_dbzemit.hip", "tf_serialize.hip", "tf_json.hip", "tf_collapse.hip", "tf_srjson.hip", "tf_exchange.hip", "tf_sizeof.hip", "tf_chnative.hip", "tf_debezium.hip"]
+SOURCES = ["tf_runtime.hip", "tf_shard.hip", "tf_scan.hip", "tf_plan.cpp", "tf_sql.cpp", "tf_transformation.cpp", "tf_pipeline.cpp", "tf_dbzrecv.cpp", "tf_protoschema.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_parquet.hip", "tf_parquetw.hip", "tf_dbzemit.hip", "tf_serialize.hip", "tf_json.hip", "tf_collapse.hip", "tf_srjson.hip", "tf_exchange.hip", "tf_sizeof.hip", "tf_chnative.hip", "tf_debezium.hip", "tf_protobuf.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-function",
          "-x", "hip"]
 

@@ -134,3 +134,62 @@ class ConfluentSrParser:
             if "unparsed" in it:
                 dead_msg.add(f[0])
         return out
+
+
+# ---- PROTOBUF schemas (engine/format_protobuf.go, utils_protobuf.go, types_protobuf.go) — pass-throughs to csrc/tf_protoschema.cpp / tf_protobuf.hip ----
+PB_DTYPE = {abi_pb: dt for abi_pb, dt in enumerate([None, "double", "float", "int64", "uint64", "int32", "uint64", "uint32", "boolean", "utf8", "string", "uint32", "int32", "int64",
+                                                     "int32", "int64", "utf8", "any"])}   # protoSchemaTypes by TFGPU_PB_*
+
+
+class _CPbMember(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("number", C.c_int32), ("ptype", C.c_int32)]
+
+
+class _CPbField(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("number", C.c_int32), ("ptype", C.c_int32), ("nmembers", C.c_int32), ("members", C.POINTER(_CPbMember))]
+
+
+class ProtoSchema:
+    """One registry .proto text compiled for the device (tfgpu_sr_compile_proto): code = abi.ROW_OK with `fields` = [(name, number,
+    TFGPU_PB_*, [(member, number, TFGPU_PB_*)])], or ROW_SR_PROTO / ROW_HOST_FALLBACK with `why`; ns / table / record as the reference
+    derives them (BuildProtobufTableID, getRecordName)."""
+
+    def __init__(self, lib, text: bytes, policy: str = "debezium_style", manual_table_name: str = "", message_name: str = ""):
+        self.lib = lib
+        L = lib.load()
+        self._h = C.c_void_p()
+        L.tfgpu_sr_compile_proto.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        lib._check(L.tfgpu_sr_compile_proto(text, len(text), policy.encode(), manual_table_name.encode(), message_name.encode(), C.byref(self._h)))
+        code, nf = C.c_int32(0), C.c_int32(0)
+        fp = C.POINTER(_CPbField)()
+        ns, table, record, why = C.c_char_p(), C.c_char_p(), C.c_char_p(), C.c_char_p()
+        L.tfgpu_pb_schema_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(_CPbField)), C.POINTER(C.c_int32)] + [C.POINTER(C.c_char_p)] * 4
+        lib._check(L.tfgpu_pb_schema_info(self._h, C.byref(code), C.byref(fp), C.byref(nf), C.byref(ns), C.byref(table), C.byref(record), C.byref(why)))
+        self.code, self.why = int(code.value), (why.value or b"").decode()
+        self.ns, self.table, self.record = (ns.value or b"").decode(), (table.value or b"").decode(), (record.value or b"").decode()
+        self.fields = [(fp[i].name.decode(), int(fp[i].number), int(fp[i].ptype), [(fp[i].members[k].name.decode(), int(fp[i].members[k].number), int(fp[i].members[k].ptype)) for k in range(fp[i].nmembers)])
+                       for i in range(nf.value)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.load().tfgpu_pb_schema_free.argtypes = [C.c_void_p]
+                self.lib.load().tfgpu_pb_schema_free(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    def table_schema(self) -> abi.Schema:
+        return abi.Schema([abi.ColSchema(n, PB_DTYPE[t], False, "", "", False, self.ns, self.table) for (n, _k, t, _m) in self.fields])
+
+    def parse(self, schema_id: int, data, msgs=None, report_frame_errors: bool = True):
+        """tfgpu_sr_proto_parse → (DeviceBatch, {message index: TFGPU_ROW_* code})"""
+        lib = self.lib
+        L = lib.load()
+        ptr_, n, mem, keep = lib._bytes_arg(data)
+        nmsg = int(msgs.nmsg) if msgs is not None else 1
+        errs = (abi.CRowError * max(nmsg, 1))()
+        ne, out = C.c_int64(0), C.c_void_p()
+        L.tfgpu_sr_proto_parse.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        lib._check(L.tfgpu_sr_proto_parse(self._h, schema_id, 1 if report_frame_errors else 0, ptr_, n, mem, C.byref(msgs) if msgs is not None else None, C.byref(out), errs, max(nmsg, 1), C.byref(ne)))
+        return lib.DeviceBatch(out), {int(errs[i].row): int(errs[i].code) for i in range(min(int(ne.value), max(nmsg, 1)))}
