@@ -681,22 +681,23 @@ int tfgpu_sr_json_parse(const tfgpu_sr_json_options *opts, const void *bytes, ui
  * its proto3 zero value, an absent message field nil; kind Insert; table id from BuildProtobufTableID (table_name_policy.go:51-71).
  *
  * tfgpu_sr_compile_proto (tf_protoschema.cpp): the descriptor for what the device decodes — proto3 messages whose fields are singular
- * scalars / enums, or singular messages of such fields (`any` columns: json.Marshal of the map of ALL their fields, keys sorted;
- * confluent.type.Decimal is built in).  tfgpu_pb_schema_info: code = TFGPU_ROW_OK and the fields, TFGPU_ROW_SR_PROTO (the text does
+ * scalars / enums, repeated scalars / enums (`any` columns: the array of their elements, packed or not, `[]` when absent), or singular
+ * messages of singular scalar / enum fields (`any` columns: the map of ALL their fields, keys sorted; confluent.type.Decimal is built in).  tfgpu_pb_schema_info: code = TFGPU_ROW_OK and the fields, TFGPU_ROW_SR_PROTO (the text does
  * not compile / the record name does not split: every message of the schema is `_unparsed`) or TFGPU_ROW_HOST_FALLBACK with `why`
- * (repeated / map / oneof fields, proto2, deeper nesting, other imports: the stock code).  policy: "debezium_style" (default) |
+ * (repeated message / map / oneof fields, proto2, deeper nesting, other imports: the stock code).  policy: "debezium_style" (default) |
  * "message_name"; message_name: "" = the first message of the file (getRecordName).
  * tfgpu_sr_proto_parse: every Kafka message whose prefix carries schema_id.  *out: one row per good message (src_row = part_id =
  * message index); errs: row = step = message index, code = TFGPU_ROW_SR_PROTO (the bytes do not unmarshal), TFGPU_ROW_SR_SHORT /
  * TFGPU_ROW_SR_MAGIC (only with report_frame_errors), TFGPU_ROW_HOST_FALLBACK (message indexes other than the single 0 byte, a known
- * field met with another wire type, a message field met twice, groups, NaN / Inf inside a message field).  With a schema whose code
+ * field met with another wire type, a message field met twice, groups, a NaN / Inf inside an `any` value — it has no JSON text).  With a schema whose code
  * is not TFGPU_ROW_OK every message of the id gets that code.  Parity: the .proto compiler and the dynamic message are dependencies
  * of the reference; the oracle restates the published language subset and wire format and is pinned to the reference's two PROTOBUF
  * test vectors (parser_test.go TestClient: schemas 5 and 6, test_protobuf_{0,1}.bin, canon).                                     */
 enum { TFGPU_PB_DOUBLE = 1, TFGPU_PB_FLOAT, TFGPU_PB_INT64, TFGPU_PB_UINT64, TFGPU_PB_INT32, TFGPU_PB_FIXED64, TFGPU_PB_FIXED32, TFGPU_PB_BOOL, TFGPU_PB_STRING,
        TFGPU_PB_BYTES, TFGPU_PB_UINT32, TFGPU_PB_SFIXED32, TFGPU_PB_SFIXED64, TFGPU_PB_SINT32, TFGPU_PB_SINT64, TFGPU_PB_ENUM, TFGPU_PB_MESSAGE };
 typedef struct tfgpu_pb_member { const char *name; int32_t number; int32_t ptype; } tfgpu_pb_member;
-typedef struct tfgpu_pb_field { const char *name; int32_t number; int32_t ptype; int32_t nmembers; const tfgpu_pb_member *members; /* of a MESSAGE field, sorted by name */ } tfgpu_pb_field;
+typedef struct tfgpu_pb_field { const char *name; int32_t number; int32_t ptype; int32_t nmembers; const tfgpu_pb_member *members; /* of a MESSAGE field, sorted by name */
+                                int32_t repeated; /* a repeated scalar / enum field: an `any` column, the JSON array of its elements */ int32_t reserved; } tfgpu_pb_field;
 typedef struct tfgpu_pb_schema tfgpu_pb_schema;
 int tfgpu_sr_compile_proto(const char *schema_text, uint64_t len, const char *policy, const char *manual_table_name, const char *message_name, tfgpu_pb_schema **out);
 int tfgpu_pb_schema_info(const tfgpu_pb_schema *s, int32_t *code, const tfgpu_pb_field **fields, int32_t *nfields, const char **table_ns, const char **table_name, const char **record, const char **why);

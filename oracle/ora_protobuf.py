@@ -276,21 +276,22 @@ def compile_schema(text: str, policy: str = "debezium_style", manual_table_name:
         raise HostOnly("proto2: required / default / groups")
     fields, seen = [], set()
     for f in md.fields:
-        if f["label"] == "repeated":
-            raise HostOnly("repeated field")
         if f["default"]:
             raise HostOnly("default option")
         if f["number"] in seen or f["number"] <= 0 or f["number"] > 536870911:
             raise ProtoError("field number")
         seen.add(f["number"])
+        rep = f["label"] == "repeated"   # handleField: a repeated field is an `any` column
         if f["type"] in SCALARS:
-            fields.append((f["name"], f["number"], f["type"], SCALARS[f["type"]], None))
+            fields.append((f["name"], f["number"], f["type"], "any" if rep else SCALARS[f["type"]], None, rep))
             continue
         kind, ref = _resolve(p, md.full, f["type"])
         if kind == "enum":
-            fields.append((f["name"], f["number"], "enum", "utf8", None))
+            fields.append((f["name"], f["number"], "enum", "any" if rep else "utf8", None, rep))
+        elif rep:
+            raise HostOnly("repeated message field")
         else:
-            fields.append((f["name"], f["number"], "message", "any", members_of(kind, ref, 1)))
+            fields.append((f["name"], f["number"], "message", "any", members_of(kind, ref, 1), False))
     if len({f[0] for f in fields}) != len(fields):
         raise ProtoError("a field name repeats")
     return {"record": record, "ns": ns, "table": table, "fields": fields}
@@ -360,7 +361,7 @@ def decode_fields(b: bytes, fields):
     """fields = [(name, number, ptype, …)] → {number: last occurrence} — (wt, raw int | bytes).  A known field met with another wire
     type, a message field met twice (merged by protobuf), a group: HostOnly.  Truncation: WireError."""
     by_num = {f[1]: f for f in fields}
-    out, i, twice = {}, 0, False
+    out, i, twice, reps = {}, 0, False, {}
     while i < len(b):
         tag, i = _varint(b, i)
         num, wt = tag >> 3, tag & 7
@@ -386,6 +387,24 @@ def decode_fields(b: bytes, fields):
         f = by_num.get(num)
         if f is None:
             continue
+        if len(f) > 5 and f[5]:   # repeated: every occurrence in wire order; numeric kinds also packed (length-delimited runs)
+            elems = reps.setdefault(num, [])
+            if wt == _want_wt(f[2]):
+                elems.append(raw)
+            elif wt == 2 and _want_wt(f[2]) != 2:
+                j = 0
+                while j < len(raw):
+                    if _want_wt(f[2]) == 0:
+                        v, j = _varint(raw, j)
+                    else:
+                        w = 8 if _want_wt(f[2]) == 1 else 4
+                        if j + w > len(raw):
+                            raise WireError("packed run")
+                        v = int.from_bytes(raw[j:j + w], "little"); j += w
+                    elems.append(v)
+            else:
+                raise HostOnly("wire type of a known field")
+            continue
         if wt != _want_wt(f[2]):
             raise HostOnly("wire type of a known field")
         if f[2] == "message":
@@ -395,6 +414,7 @@ def decode_fields(b: bytes, fields):
         out[num] = raw
     if twice:
         raise HostOnly("a message field met twice (protobuf merges them)")
+    out.update({("rep", k): v for k, v in reps.items()})
     return out
 
 
@@ -408,7 +428,7 @@ def _go_json(v):
         return str(x).encode()
     if g in ("float32", "float64"):
         if x != x or x in (float("inf"), float("-inf")):
-            raise HostOnly("json.Marshal fails on NaN / Inf")
+            raise HostOnly("a NaN / Inf inside an `any` value has no JSON text")
         return ora.json_float(x, 32 if g == "float32" else 64).encode()
     if g == "bytes":
         return b'"' + base64.b64encode(x) + b'"'
@@ -422,8 +442,15 @@ def unpack(schema, payload: bytes):
     """unpackProtobufDynamicMessage: [(gotype, value)] in field order; nested messages as ("json", marshalled map, keys sorted)"""
     top = decode_fields(payload, schema["fields"])
     vals = []
-    for name, num, ptype, _yt, members in schema["fields"]:
+    for name, num, ptype, _yt, members, rep in schema["fields"]:
         raw = top.get(num)
+        if rep:   # unpackRepeatedVal: []interface{} of the elements' Go values; an absent field is the empty slice
+            parts = []
+            for r2 in top.get(("rep", num), []):
+                v = (("string", bytes(r2)) if ptype == "string" else ("bytes", bytes(r2))) if ptype in ("string", "bytes") else _scalar(ptype, 0, r2)
+                parts.append(_go_json(v))
+            vals.append(("json", b"[" + b",".join(parts) + b"]"))
+            continue
         if ptype == "message":
             if raw is None:
                 vals.append(("nil", None))   # a typed nil *dynamic.Message: `return nil, nil`

@@ -52,6 +52,53 @@ def test_oracle_reference_vectors():
         assert {t[3] for t in exp["table_schema"]} == {it["ns"]} and {t[4] for t in exp["table_schema"]} == {it["table"]}
 
 
+def unpack_val_case():
+    """TestUnpackVal reduced to what the device takes: std_data_types.proto without its map field (16) and its repeated message field (19),
+    the test's literal values re-encoded, the canon's Names / Vals for the fields that stay"""
+    u = golden("sr_protobuf.json")["unpack_val"]
+    lines, skip = [], 0
+    for ln in u["proto"].split("\n"):
+        if "google/protobuf/timestamp.proto" in ln or "mapField" in ln or "RepeatedMessage=" in ln:
+            continue
+        if "message repeatedMessage" in ln or "message StdDataTypesMsgList" in ln:
+            skip = 1
+        if skip:
+            if "}" in ln:
+                skip = 0
+            continue
+        lines.append(ln)
+    text = "\n".join(lines)
+    text = text[text.index("message StdDataTypesMsg"):]   # the record is the FIRST message of the file (getRecordName)
+    text = 'syntax = "proto3";\n' + text
+    L = u["literals"]
+    num = {n: i + 1 for i, n in enumerate(["doubleField", "floatField", "int32Field", "int64Field", "uint32Field", "uint64Field", "sint32Field", "sint64Field", "fixed32Field",
+                                           "fixed64Field", "sfixed32Field", "sfixed64Field", "boolField", "stringField", "bytesField"])}
+    zz = lambda v: (v << 1) ^ (v >> 63)
+    b = varint(1 << 3 | 1) + struct.pack("<d", L["doubleField"]) + varint(2 << 3 | 5) + struct.pack("<f", L["floatField"])
+    for n in ("int32Field", "int64Field", "uint32Field", "uint64Field"):
+        b += varint(num[n] << 3) + varint(L[n])
+    b += varint(7 << 3) + varint(zz(L["sint32Field"])) + varint(8 << 3) + varint(zz(L["sint64Field"]))
+    b += varint(9 << 3 | 5) + struct.pack("<I", L["fixed32Field"]) + varint(10 << 3 | 1) + struct.pack("<Q", L["fixed64Field"])
+    b += varint(11 << 3 | 5) + struct.pack("<i", L["sfixed32Field"]) + varint(12 << 3 | 1) + struct.pack("<q", L["sfixed64Field"])
+    b += varint(13 << 3) + varint(1) + varint(14 << 3 | 2) + varint(len(L["stringField"])) + L["stringField"].encode() + varint(15 << 3 | 2) + varint(len(L["bytesField"])) + L["bytesField"].encode()
+    for e in L["repeatedField"]:
+        b += varint(17 << 3 | 2) + varint(len(e)) + e.encode()
+    mf = L["msgField"]
+    inner = varint(1 << 3 | 2) + varint(len(mf["stringField"])) + mf["stringField"].encode() + varint(2 << 3) + varint(mf["int32Field"]) + varint(3 << 3) + varint(mf["enumField"])
+    b += varint(18 << 3 | 2) + varint(len(inner)) + inner
+    want = {n: v for n, v in zip(u["names"], u["vals"]) if n not in ("mapField", "RepeatedMessage")}
+    return text, b, want
+
+
+def test_oracle_unpack_val_canon():
+    from oracle import ora_protobuf as P
+    text, body, want = unpack_val_case()
+    (kind, it), = P.parse_messages([frame(1, body)], {1: text.encode()}, manual_table_name="t")
+    assert kind == "item" and it["names"] == list(want)
+    for n, v in zip(it["names"], it["values"]):
+        assert close(canon_of(v), want[n]), (n, v, want[n])
+
+
 # ---- schema texts ---------------------------------------------------------------------------------------------------------------
 SCALAR_TYPES = ["double", "float", "int64", "uint64", "int32", "fixed64", "fixed32", "bool", "string", "bytes", "uint32", "sfixed32", "sfixed64", "sint32", "sint64"]
 
@@ -76,7 +123,7 @@ def random_proto(rng, damage=False):
         r = rng.random()
         opt = ' [(confluent.field_meta) = { params: [ { value: "int16", key: "connect.type" } ] }]' if rng.random() < 0.15 else ""
         if r < 0.7:
-            body.append("  %s%s f%d = %d%s;" % ("optional " if rng.random() < 0.1 else "", rng.choice(SCALAR_TYPES), i, num(), opt))
+            body.append("  %s%s f%d = %d%s;" % (rng.choice(["optional ", "repeated ", "repeated ", "", "", "", "", "", "", ""]), rng.choice(SCALAR_TYPES), i, num(), opt))
         elif r < 0.8:
             body.append("  Color f%d = %d; // an enum" % (i, num()))
         elif r < 0.9 and 'import "confluent/type/decimal.proto";' in lines:
@@ -92,7 +139,8 @@ def random_proto(rng, damage=False):
     if damage:
         label = rng.choice(["repeated", "map", "oneof", "proto2", "default", "import", "unknown type", "deep", "syntax", "dup number", "reserved ok", "comment ok", "short name"])
         if label == "repeated":
-            body.append("  repeated int32 rr = %d;" % num())
+            nested.append("  message Rep { int32 x = 1; }")
+            body.append("  repeated Rep rr = %d;" % num())
         elif label == "map":
             body.append("  map<string, int32> mm = %d;" % num())
         elif label == "oneof":
@@ -127,14 +175,14 @@ def compile_both(text, policy="debezium_style", manual="", message_name=""):
     from transferia_amd import confluent_sr, lib
     try:
         o = P.compile_schema(text, policy, manual, message_name)
-        want = ("ok", o["record"], o["ns"], o["table"], [(f[0], f[1], PB[f[2]], sorted((m[0], m[1], PB[m[2]]) for m in (f[4] or []))) for f in o["fields"]])
+        want = ("ok", o["record"], o["ns"], o["table"], [(f[0], f[1], PB[f[2]], sorted((m[0], m[1], PB[m[2]]) for m in (f[4] or [])), f[5]) for f in o["fields"]])
     except P.ProtoError:
         want = ("proto",)
     except P.HostOnly:
         want = ("host",)
     s = confluent_sr.ProtoSchema(lib, text.encode(), policy, manual, message_name)
     if s.code == abi.ROW_OK:
-        got = ("ok", s.record, s.ns, s.table, [(n, k, t, sorted(m)) for n, k, t, m in s.fields])
+        got = ("ok", s.record, s.ns, s.table, [(n, k, t, sorted(m), rep) for n, k, t, m, rep in s.fields])
     else:
         got = ("proto",) if s.code == abi.ROW_SR_PROTO else ("host",)
     return got, want, s
@@ -192,8 +240,16 @@ def enc_field(num, ptype, rng):
 def random_message(rng, sch, weird):
     """a wire message for a compiled oracle schema; with `weird` also the shapes that do not unmarshal or go to the host"""
     parts = []
-    for name, num, ptype, _yt, members in sch["fields"]:
+    for name, num, ptype, _yt, members, rep in sch["fields"]:
         if rng.random() < 0.2:
+            continue
+        if rep:
+            for _ in range(rng.randrange(1, 4)):
+                if ptype not in ("string", "bytes") and rng.random() < 0.6:   # a packed run of the elements' bodies
+                    run = b"".join(enc_field(1, ptype, rng)[1:] for _k in range(rng.randrange(0, 5)))
+                    parts.append(varint(num << 3 | 2) + varint(len(run)) + run)
+                else:
+                    parts.append(enc_field(num, ptype, rng))
             continue
         reps = 2 if rng.random() < 0.1 and ptype != "message" else 1
         for _ in range(reps):
@@ -262,6 +318,21 @@ def test_gpu_reference_vectors(tf):
         for n, v, w in zip(exp["names"], rows[0], exp["values"]):
             assert close(canon_of(v), w), (n, v, w)
         assert b.kind is None or [int(k) for k in b.kind] == [abi.K_INSERT]   # (no kind array: every row an Insert)
+
+
+@pytest.mark.gpu
+def test_gpu_unpack_val_canon(tf):
+    from transferia_amd import confluent_sr
+    text, body, want = unpack_val_case()
+    s = confluent_sr.ProtoSchema(tf, text.encode(), manual_table_name="t")
+    assert s.code == abi.ROW_OK, s.why
+    data, m = abi.messages([frame(1, body)])
+    batch, errors = s.parse(1, data, m)
+    assert not errors
+    rows, b = device_rows(batch)
+    assert [c.name for c in b.cols] == list(want) and b.table_name == "t"
+    for n, v in zip(want, rows[0]):
+        assert close(canon_of(v), want[n]), (n, v, want[n])
 
 
 @pytest.mark.gpu

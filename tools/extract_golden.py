@@ -1111,7 +1111,16 @@ def sr_protobuf():
         cases.append({"schema_id": int(sid), "schema": schemas[sid]["schema"], "message_b64": base64.b64encode(msg).decode(),
                       "expect": {"kind": it["kind"], "schema": it["schema"], "table": it["table"], "names": it["columnnames"], "values": it["columnvalues"],
                                  "table_schema": [[c["name"], c["type"], c["key"], c["table_schema"], c["table_name"]] for c in it["table_schema"]]}})
-    write("sr_protobuf.json", {"cases": cases})
+    # TestUnpackVal (types_protobuf_test.go:20-97): the message is proto.Marshal'ed by the test from literal values, so only its canon
+    # OUTPUT is a file; the literals are transcribed here and the tests re-encode them.  Names / Vals as the canon holds them.
+    u = canon(eng + "gotest/canondata/result.json", "gotest.gotest.TestUnpackVal")
+    with open(eng + "testdata/types_protobuf_test_data/std_data_types.proto") as f:
+        proto = f.read()
+    unpack = {"proto": proto, "names": u["Names"], "vals": u["Vals"],
+              "literals": {"doubleField": 1.11, "floatField": 2.2, "int32Field": 2, "int64Field": 3, "uint32Field": 4, "uint64Field": 5, "sint32Field": 6, "sint64Field": 7,
+                           "fixed32Field": 8, "fixed64Field": 9, "sfixed32Field": 10, "sfixed64Field": 11, "boolField": True, "stringField": "string", "bytesField": "bytes",
+                           "repeatedField": ["1", "2", "3"], "msgField": {"stringField": "stringField", "int32Field": 2, "enumField": 1}}}
+    write("sr_protobuf.json", {"cases": cases, "unpack_val": unpack})
 
 
 def hits_schema():

@@ -146,12 +146,12 @@ class _CPbMember(C.Structure):
 
 
 class _CPbField(C.Structure):
-    _fields_ = [("name", C.c_char_p), ("number", C.c_int32), ("ptype", C.c_int32), ("nmembers", C.c_int32), ("members", C.POINTER(_CPbMember))]
+    _fields_ = [("name", C.c_char_p), ("number", C.c_int32), ("ptype", C.c_int32), ("nmembers", C.c_int32), ("members", C.POINTER(_CPbMember)), ("repeated", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ProtoSchema:
     """One registry .proto text compiled for the device (tfgpu_sr_compile_proto): code = abi.ROW_OK with `fields` = [(name, number,
-    TFGPU_PB_*, [(member, number, TFGPU_PB_*)])], or ROW_SR_PROTO / ROW_HOST_FALLBACK with `why`; ns / table / record as the reference
+    TFGPU_PB_*, [(member, number, TFGPU_PB_*)], repeated)], or ROW_SR_PROTO / ROW_HOST_FALLBACK with `why`; ns / table / record as the reference
     derives them (BuildProtobufTableID, getRecordName)."""
 
     def __init__(self, lib, text: bytes, policy: str = "debezium_style", manual_table_name: str = "", message_name: str = ""):
@@ -167,7 +167,7 @@ class ProtoSchema:
         lib._check(L.tfgpu_pb_schema_info(self._h, C.byref(code), C.byref(fp), C.byref(nf), C.byref(ns), C.byref(table), C.byref(record), C.byref(why)))
         self.code, self.why = int(code.value), (why.value or b"").decode()
         self.ns, self.table, self.record = (ns.value or b"").decode(), (table.value or b"").decode(), (record.value or b"").decode()
-        self.fields = [(fp[i].name.decode(), int(fp[i].number), int(fp[i].ptype), [(fp[i].members[k].name.decode(), int(fp[i].members[k].number), int(fp[i].members[k].ptype)) for k in range(fp[i].nmembers)])
+        self.fields = [(fp[i].name.decode(), int(fp[i].number), int(fp[i].ptype), [(fp[i].members[k].name.decode(), int(fp[i].members[k].number), int(fp[i].members[k].ptype)) for k in range(fp[i].nmembers)], bool(fp[i].repeated))
                        for i in range(nf.value)]
 
     def __del__(self):
@@ -180,7 +180,7 @@ class ProtoSchema:
             pass
 
     def table_schema(self) -> abi.Schema:
-        return abi.Schema([abi.ColSchema(n, PB_DTYPE[t], False, "", "", False, self.ns, self.table) for (n, _k, t, _m) in self.fields])
+        return abi.Schema([abi.ColSchema(n, "any" if rep else PB_DTYPE[t], False, "", "", False, self.ns, self.table) for (n, _k, t, _m, rep) in self.fields])
 
     def parse(self, schema_id: int, data, msgs=None, report_frame_errors: bool = True):
         """tfgpu_sr_proto_parse → (DeviceBatch, {message index: TFGPU_ROW_* code})"""

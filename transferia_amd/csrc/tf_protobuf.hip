@@ -12,7 +12,8 @@
 //                   the JSON paths' tile staging would apply if this format becomes a bench line.
 //   pb_cells        lane = (row, field): the Go value — truncation / zigzag / bit casts — into the column; text lengths
 //   pb_text         lane = (row, text field): string / bytes copied, message fields marshalled (all members, keys sorted, absent
-//                   members as their zero values: unpackNotRepeatedVal walks GetKnownFields)
+//                   members as their zero values: unpackNotRepeatedVal walks GetKnownFields), repeated fields as the array of their
+//                   elements (unpackRepeatedVal; packed runs unrolled)
 // HBM layout: rec[field][message] (8 bytes: raw value, or start | len << 32) + present[field][message] — a message's fields are
 // scattered over 8 * nfields bytes per message, coalesced across messages in the cell kernels.
 #include <hip/hip_runtime.h>
@@ -32,7 +33,7 @@ namespace tf {
 namespace pbd {
 
 enum : uint8_t { ST_OK = 0, ST_SKIP = 250 };  // other values: TFGPU_ROW_* codes
-struct DField { int32_t number, ptype, mem_off, nmem; uint32_t name_off, name_len; };  // members / names: offsets into the tables below
+struct DField { int32_t number, ptype, mem_off, nmem; uint32_t name_off, name_len; int32_t repeated, pad; };  // members / names: offsets into the tables below
 struct DMember { int32_t number, ptype; uint32_t name_off, name_len; };
 
 struct Params {
@@ -111,8 +112,21 @@ __global__ void __launch_bounds__(128) pb_decode(Params p) {
     for (int f = 0; f < p.nfields; f++) {
       const DField &fd = p.fields[f];
       if ((uint32_t)fd.number != num) continue;
-      if ((int)wt != want_wt(fd.ptype)) return 2;                                  // a known field with another wire type
       const int64_t i = (int64_t)f * p.nmsg + m;
+      if (fd.repeated) {  // every occurrence is an element; numeric kinds also arrive packed: a length-delimited run of them
+        const int ew = want_wt(fd.ptype);
+        if ((int)wt != ew) {
+          if (wt != 2) return 2;
+          uint32_t q = (uint32_t)raw; const uint32_t qe = q + len;
+          while (q < qe) {
+            if (ew == 0) { uint64_t v; if (!varint(d, q, qe, &v)) return 1; }
+            else { const uint32_t w = ew == 1 ? 8u : 4u; if (qe - q < w) return 1; q += w; }
+          }
+        }
+        p.present[i] = 1;
+        return 0;
+      }
+      if ((int)wt != want_wt(fd.ptype)) return 2;                                  // a known field with another wire type
       if (fd.ptype == TFGPU_PB_MESSAGE) {
         if (p.present[i]) twice = true;                                            // protobuf merges the occurrences
         const int r2 = walk(d, (uint32_t)raw, (uint32_t)raw + len, [&](uint32_t n2, uint32_t w2, uint64_t, uint32_t) {
@@ -190,6 +204,31 @@ template <class S> __device__ bool emit_message(S &s, const Params &p, const DFi
   return true;
 }
 
+// a repeated field's []interface{}: the elements of every occurrence in wire order, packed runs unrolled.  false: a NaN / Inf element
+template <class S> __device__ bool emit_array(S &s, const Params &p, const DField &fd, uint32_t a, uint32_t z) {
+  const uint8_t *d = p.data;
+  const int ew = want_wt(fd.ptype);
+  bool first = true, ok = true;
+  s.put('[');
+  walk(d, a, z, [&](uint32_t num, uint32_t wt, uint64_t raw, uint32_t len) {
+    if (num != (uint32_t)fd.number) return 0;
+    auto one = [&](uint64_t r) { if (!first) s.put(','); first = false; if (!emit_member(s, d, fd.ptype, true, r)) ok = false; };
+    if ((int)wt == ew) one(wt == 2 ? (raw | ((uint64_t)len << 32)) : raw);
+    else {  // packed (pb_decode let nothing else through)
+      uint32_t q = (uint32_t)raw; const uint32_t qe = q + len;
+      while (q < qe) {
+        uint64_t v = 0;
+        if (ew == 0) { if (!varint(d, q, qe, &v)) break; }
+        else { const int w = ew == 1 ? 8 : 4; v = le(d, q, w); q += (uint32_t)w; }
+        one(v);
+      }
+    }
+    return 0;
+  });
+  s.put(']');
+  return ok;
+}
+
 __global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id, uint32_t *host_rows) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
@@ -202,6 +241,13 @@ __global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, in
   const bool present = p.present[i] != 0;
   const uint64_t raw = present ? p.rec[i] : 0ull;
   bool valid = true;
+  if (fd.repeated) {  // an absent repeated field is the empty slice: []
+    CountSink s;
+    if (!emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1])) { host_rows[r] = 1; s.n = 0; }
+    c.lens[r] = s.n;
+    atomicOr(reinterpret_cast<uint32_t *>(c.validity) + (r >> 5), 1u << (r & 31));
+    return;
+  }
   switch (fd.ptype) {
     case TFGPU_PB_STRING: case TFGPU_PB_BYTES: c.lens[r] = present ? (uint32_t)(raw >> 32) : 0u; break;
     case TFGPU_PB_MESSAGE:
@@ -227,9 +273,16 @@ __global__ void __launch_bounds__(256) pb_text(Params p, const OutCol *cols, con
   const DField &fd = p.fields[j];
   const uint32_t m = p.row_msg[r];
   const int64_t i = (int64_t)j * p.nmsg + m;
+  uint8_t *out = c.data + c.lens[r];  // (offsets by now)
+  if (fd.repeated) {
+    if (c.lens[r + 1] == c.lens[r]) return;  // (a row for the host: nothing was counted)
+    WriteSink s{out};
+    emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
+    s.flush();
+    return;
+  }
   if (!p.present[i]) return;
   const uint64_t raw = p.rec[i];
-  uint8_t *out = c.data + c.lens[r];  // (offsets by now)
   if (fd.ptype == TFGPU_PB_MESSAGE) {
     if (c.lens[r + 1] == c.lens[r]) return;  // (a row for the host: nothing was counted)
     WriteSink s{out};
@@ -297,7 +350,7 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
   members.clear();
   for (int j = 0; j < nf; j++) {
     pbd::DField &d = fields[(size_t)j];
-    d.number = fl[j].number; d.ptype = fl[j].ptype; d.mem_off = (int32_t)members.size(); d.nmem = fl[j].nmembers;
+    d.number = fl[j].number; d.ptype = fl[j].ptype; d.mem_off = (int32_t)members.size(); d.nmem = fl[j].nmembers; d.repeated = fl[j].repeated; d.pad = 0;
     d.name_off = (uint32_t)names.size(); d.name_len = (uint32_t)std::strlen(fl[j].name); names += fl[j].name;
     for (int k = 0; k < fl[j].nmembers; k++) {
       const tfgpu_pb_member &mb = fl[j].members[k];
@@ -332,7 +385,7 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
   const int64_t seg_stride = ((nrows + 1 + 3) / 4) * 4;
   int ntext = 0;
   bool has_msg = false;
-  for (int j = 0; j < nf; j++) { const int t = fl[j].ptype; if (t == TFGPU_PB_STRING || t == TFGPU_PB_BYTES || t == TFGPU_PB_MESSAGE) ntext++; if (t == TFGPU_PB_MESSAGE) has_msg = true; }
+  for (int j = 0; j < nf; j++) { const int t = fl[j].ptype; if (fl[j].repeated || t == TFGPU_PB_STRING || t == TFGPU_PB_BYTES || t == TFGPU_PB_MESSAGE) ntext++; if (fl[j].repeated || t == TFGPU_PB_MESSAGE) has_msg = true; }
   Buf lens_all = dalloc_zero((size_t)std::max(ntext, 1) * (size_t)seg_stride * 4 + 16);
   int ti = 0;
   for (int j = 0; j < nf; j++) {
@@ -342,7 +395,8 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
     std::memset(&c, 0, sizeof c);
     c.ptype = fl[j].ptype;
     auto fixed = [&](int dtype, int repr, size_t w) { d.dtype = dtype; d.repr = repr; d.values = dalloc((size_t)nra * w + 8); c.values = d.values->p; };
-    switch (fl[j].ptype) {  // protoSchemaTypes (types_protobuf.go:16-35) and the Go value unpackNotRepeatedVal asserts
+    if (fl[j].repeated) { d.dtype = TFGPU_T_ANY; d.repr = TFGPU_R_JSON; }   // handleField: a repeated field is `any`
+    else switch (fl[j].ptype) {  // protoSchemaTypes (types_protobuf.go:16-35) and the Go value unpackNotRepeatedVal asserts
       case TFGPU_PB_DOUBLE: fixed(TFGPU_T_FLOAT64, TFGPU_R_FLOAT64, 8); break;
       case TFGPU_PB_FLOAT: fixed(TFGPU_T_FLOAT32, TFGPU_R_FLOAT32, 4); break;
       case TFGPU_PB_INT64: case TFGPU_PB_SFIXED64: case TFGPU_PB_SINT64: fixed(TFGPU_T_INT64, TFGPU_R_INT64, 8); break;
@@ -388,7 +442,7 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
     Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
     if (nrows) { KernelTimer t("pb_text"); pbd::pb_text<<<dim3(pbd::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(btc)); }
   }
-  // rows whose message field holds a NaN / Inf (json.Marshal fails in the reference's generic branch — here: the stock code decides)
+  // rows whose `any` value holds a NaN / Inf: the reference keeps the Go float inside the map / slice, the column's JSON text cannot
   std::vector<uint32_t> hostm;
   std::unique_ptr<tfgpu_dbatch> result = std::move(db);
   if (has_msg && nrows) {

@@ -6,8 +6,8 @@
 //   BuildProtobufTableID                          table_name_policy/table_name_policy.go:51-71
 //
 // The compiler itself (jhump/protoreflect protoparse) is a dependency of the reference, not part of it.  Restated here: the proto3
-// language subset whose messages the device takes — singular scalar and enum fields, and singular message fields whose own fields are
-// singular scalars / enums (the shape of both PROTOBUF schemas in the reference's parser test) — with protobuf's scoping rule for type
+// language subset whose messages the device takes — singular and repeated scalar / enum fields, and singular message fields whose own
+// fields are singular scalars / enums (the shape of both PROTOBUF schemas in the reference's parser test) — with protobuf's scoping rule for type
 // names.  Everything else is named and handed to the stock code (TFGPU_ROW_HOST_FALLBACK for every message of the schema): repeated
 // and map fields, oneof, proto2 (required / default / groups / extensions), services, imports other than confluent/meta.proto and
 // confluent/type/decimal.proto (whose Decimal message is built in).  A text that does not parse is TFGPU_ROW_SR_PROTO ("unable to
@@ -176,7 +176,7 @@ static const std::map<std::string, int> SCALAR = {
     {"sfixed64", TFGPU_PB_SFIXED64}, {"sint32", TFGPU_PB_SINT32}, {"sint64", TFGPU_PB_SINT64}};
 
 struct Member { std::string name; int32_t number, ptype; };
-struct Field { std::string name; int32_t number, ptype; std::vector<Member> members; };
+struct Field { std::string name; int32_t number, ptype; std::vector<Member> members; bool repeated = false; };
 
 static void collect(const std::vector<std::unique_ptr<Msg>> &ms, std::map<std::string, const Msg *> &msgs, std::vector<std::string> &enums) {
   for (auto &m : ms) { msgs[m->full] = m.get(); for (auto &e : m->enums) enums.push_back(e); collect(m->messages, msgs, enums); }
@@ -231,16 +231,16 @@ static Compiled compile(const std::string &text, const std::string &policy, cons
   };
   std::map<long long, bool> seen;
   for (auto &f : md->fields) {
-    if (f.label == "repeated") throw HostOnly{"repeated field"};
     if (f.has_default) throw HostOnly{"default option"};
     if (f.number <= 0 || f.number > 536870911 || !seen.emplace(f.number, true).second) throw SyntaxError{"field number"};
     Field o;
-    o.name = f.name; o.number = (int32_t)f.number;
+    o.name = f.name; o.number = (int32_t)f.number; o.repeated = f.label == "repeated";
     auto sc = SCALAR.find(f.type);
     if (sc != SCALAR.end()) { o.ptype = sc->second; out.fields.push_back(std::move(o)); continue; }
     const Msg *ref = nullptr;
     const int kind = resolve(md->full, f.type, &ref);
     if (kind == 2) { o.ptype = TFGPU_PB_ENUM; out.fields.push_back(std::move(o)); continue; }
+    if (o.repeated) throw HostOnly{"repeated message field"};
     o.ptype = TFGPU_PB_MESSAGE;
     if (kind == 3) o.members = {{"value", 1, TFGPU_PB_BYTES}, {"precision", 2, TFGPU_PB_UINT32}, {"scale", 3, TFGPU_PB_INT32}};  // confluent/type/decimal.proto
     else {
@@ -280,7 +280,7 @@ struct tfgpu_pb_schema {
       for (auto &m : f.members) ms.push_back(tfgpu_pb_member{m.name.c_str(), m.number, m.ptype});
       cmembers.push_back(std::move(ms));
     }
-    for (size_t i = 0; i < c.fields.size(); i++) cfields.push_back(tfgpu_pb_field{c.fields[i].name.c_str(), c.fields[i].number, c.fields[i].ptype, (int32_t)cmembers[i].size(), cmembers[i].empty() ? nullptr : cmembers[i].data()});
+    for (size_t i = 0; i < c.fields.size(); i++) cfields.push_back(tfgpu_pb_field{c.fields[i].name.c_str(), c.fields[i].number, c.fields[i].ptype, (int32_t)cmembers[i].size(), cmembers[i].empty() ? nullptr : cmembers[i].data(), c.fields[i].repeated ? 1 : 0, 0});
   }
 };
 
