@@ -1436,7 +1436,57 @@ class DebeziumSrWorkload(DebeziumWorkload):
         return out
 
 
-WORKLOADS = {"configs0": Configs0Workload, "debezium": DebeziumWorkload, "debezium_sr": DebeziumSrWorkload, "configs4d": Configs4DebeziumWorkload, "csv": CsvWorkload, "json": JsonWorkload, "sr": SrWorkload, "configs2": Configs2Workload, "configs3": Configs3Workload,
+class SrProtoWorkload(DebeziumWorkload):
+    """Confluent-SR wire bytes with a PROTOBUF schema: the reference's own 60-column test message (engine/testdata/test_protobuf_1.bin with schema 6
+    of test_schemas.json — every pg type through the Confluent protobuf converter, nested Point / VariableScaleDecimal / Decimal messages) replicated
+    per batch, every message → one ChangeItem (tfgpu_sr_proto_parse; the schema compiled once: tfgpu_sr_compile_proto)."""
+    metric = "messages/sec through the Confluent-SR parser, PROTOBUF schema (the reference's 784-byte 60-column test message replicated per batch) -> device ChangeItem columns"
+    default_rows = 1 << 18
+
+    def setup(self):
+        e, a = self.env, self.args
+        lib, abi = e.lib, e.abi
+        import base64
+        from transferia_amd import confluent_sr
+        with open(os.path.join(ROOT, "tests", "golden", "sr_protobuf.json")) as f:
+            case = json.load(f)["cases"][1]
+        self.msg, self.sid, self.text = base64.b64decode(case["message_b64"]), int(case["schema_id"]), case["schema"].encode()
+        self.n = a.rows
+        data, self.msgs = abi.messages([self.msg] * self.n)
+        self.nbytes = len(data)
+        self.dbuf = lib.DeviceBuffer.upload(data)
+        self.schema = confluent_sr.ProtoSchema(lib, self.text)
+        assert self.schema.code == abi.ROW_OK, self.schema.why
+
+    def step(self, keep=False):
+        batch, errors = self.schema.parse(self.sid, self.dbuf, self.msgs)
+        if keep:
+            self.state.update(out_rows=batch.nrows, out_bytes=batch.payload_bytes(), errors=len(errors))
+        batch.free()
+
+    def alg(self):
+        pb = self.nbytes + self.state.get("out_bytes", 0)
+        return {"pb_decode": self.nbytes, "pb_cells": pb, "pb_text": pb}
+
+    def config(self):
+        return {"workload": "Confluent-SR wire bytes, PROTOBUF schema: 0x00 | schema id | 0x00 | protobuf of the reference's 60-column test message, replicated per batch; "
+                            "wire format decoded on device, the .proto text compiled once on the host",
+                "messages_per_gpu_per_step": self.n, "bytes_per_message": len(self.msg), "parallelism": f"message-range shard x{self.env.world}, no collective"}
+
+    def cpu(self):
+        from oracle import ora_protobuf as P
+        k = max(64, min(self.n, self.args.cpu_rows // 256))
+        t0 = time.perf_counter()
+        P.parse_messages([self.msg] * k, {self.sid: self.text})
+        sec = time.perf_counter() - t0
+        out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{k} messages x {len(self.msg)} B: the oracle's PYTHON restatement of the protobuf branch ({sec:.2f}s)",
+               "note": "a Python parity checker, far slower than the Go parser: not a performance baseline"}
+        out.update(host_info())
+        return out
+
+
+WORKLOADS = {"configs0": Configs0Workload, "debezium": DebeziumWorkload, "debezium_sr": DebeziumSrWorkload, "sr_proto": SrProtoWorkload, "configs4d": Configs4DebeziumWorkload, "csv": CsvWorkload, "json": JsonWorkload, "sr": SrWorkload, "configs2": Configs2Workload, "configs3": Configs3Workload,
              "configs4": Configs4Workload, "collapse": CollapseWorkload}
 
 

@@ -72,7 +72,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; print('
     tests
     traffic
     timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_csv.json" 2> "$OUT/bench_csv.err"; echo "== csv (the driver's command line) rc=$?"; line "$OUT/bench_csv.json"
-    bench "configs0 configs2 configs3 configs4 configs4d json sr collapse debezium debezium_sr"
+    bench "configs0 configs2 configs3 configs4 configs4d json sr sr_proto collapse debezium debezium_sr"
     timeout 400 python bench.py --workload configs4 --sink debezium > "$OUT/bench_configs4_debezium.json" 2> "$OUT/bench_configs4_debezium.err"; echo "== configs4 --sink debezium rc=$?"; line "$OUT/bench_configs4_debezium.json"
     stats "csv configs2 configs3 json sr debezium debezium_sr configs4d"
     echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s" ;;
