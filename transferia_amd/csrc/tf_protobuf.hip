@@ -155,7 +155,7 @@ struct OutCol {
   void *values;        // fixed-width kinds
   uint32_t *lens;      // text kinds: lengths, then offsets [nrows + 1]
   uint8_t *data;
-  uint8_t *validity;   // bitmap (zeroed; set bits by atomicOr on whole bytes' words)
+  uint8_t *validity;   // bitmap, written 64 rows (one wave) at a time
 };
 
 // the Go value of a scalar occurrence (unpackNotRepeatedVal's type assertions: int32 / int64 / uint32 / uint64 / float32 / float64 / bool)
@@ -232,38 +232,39 @@ template <class S> __device__ bool emit_array(S &s, const Params &p, const DFiel
 __global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id, uint32_t *host_rows) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
-  if (r >= p.nrows) return;
-  const uint32_t m = p.row_msg[r];
-  if (j == 0) { src_row[r] = (int32_t)m; part_id[r] = m; }
+  const bool in = r < p.nrows;
   const OutCol &c = cols[j];
   const DField &fd = p.fields[j];
-  const int64_t i = (int64_t)j * p.nmsg + m;
-  const bool present = p.present[i] != 0;
-  const uint64_t raw = present ? p.rec[i] : 0ull;
-  bool valid = true;
-  if (fd.repeated) {  // an absent repeated field is the empty slice: []
-    CountSink s;
-    if (!emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1])) { host_rows[r] = 1; s.n = 0; }
-    c.lens[r] = s.n;
-    atomicOr(reinterpret_cast<uint32_t *>(c.validity) + (r >> 5), 1u << (r & 31));
-    return;
+  bool valid = in;
+  if (in) {
+    const uint32_t m = p.row_msg[r];
+    if (j == 0) { src_row[r] = (int32_t)m; part_id[r] = m; }
+    const int64_t i = (int64_t)j * p.nmsg + m;
+    const bool present = p.present[i] != 0;
+    const uint64_t raw = present ? p.rec[i] : 0ull;
+    if (fd.repeated) {  // an absent repeated field is the empty slice: []
+      CountSink s;
+      if (!emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1])) { host_rows[r] = 1; s.n = 0; }
+      c.lens[r] = s.n;
+    } else switch (fd.ptype) {
+      case TFGPU_PB_STRING: case TFGPU_PB_BYTES: c.lens[r] = present ? (uint32_t)(raw >> 32) : 0u; break;
+      case TFGPU_PB_MESSAGE:
+        if (!present) { c.lens[r] = 0; valid = false; }   // a nil *dynamic.Message: nil
+        else {
+          CountSink s;
+          if (!emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32))) { host_rows[r] = 1; s.n = 0; }
+          c.lens[r] = s.n;
+        }
+        break;
+      case TFGPU_PB_DOUBLE: case TFGPU_PB_INT64: case TFGPU_PB_UINT64: case TFGPU_PB_FIXED64: case TFGPU_PB_SFIXED64: case TFGPU_PB_SINT64:
+        ((uint64_t *)c.values)[r] = (uint64_t)as_i64(fd.ptype, raw); break;
+      case TFGPU_PB_BOOL: ((uint8_t *)c.values)[r] = raw != 0; break;
+      default: ((uint32_t *)c.values)[r] = fd.ptype == TFGPU_PB_FLOAT ? (uint32_t)raw : (uint32_t)as_i64(fd.ptype, raw);
+    }
   }
-  switch (fd.ptype) {
-    case TFGPU_PB_STRING: case TFGPU_PB_BYTES: c.lens[r] = present ? (uint32_t)(raw >> 32) : 0u; break;
-    case TFGPU_PB_MESSAGE:
-      if (!present) { c.lens[r] = 0; valid = false; }   // a nil *dynamic.Message: nil
-      else {
-        CountSink s;
-        if (!emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32))) { host_rows[r] = 1; s.n = 0; }
-        c.lens[r] = s.n;
-      }
-      break;
-    case TFGPU_PB_DOUBLE: case TFGPU_PB_INT64: case TFGPU_PB_UINT64: case TFGPU_PB_FIXED64: case TFGPU_PB_SFIXED64: case TFGPU_PB_SINT64:
-      ((uint64_t *)c.values)[r] = (uint64_t)as_i64(fd.ptype, raw); break;
-    case TFGPU_PB_BOOL: ((uint8_t *)c.values)[r] = raw != 0; break;
-    default: ((uint32_t *)c.values)[r] = fd.ptype == TFGPU_PB_FLOAT ? (uint32_t)raw : (uint32_t)as_i64(fd.ptype, raw);
-  }
-  if (valid) atomicOr(reinterpret_cast<uint32_t *>(c.validity) + (r >> 5), 1u << (r & 31));
+  // the validity bitmap a wave at a time: 64 consecutive rows are one aligned 8-byte word (one store instead of 64 atomics on two words)
+  const uint64_t bal = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && in) reinterpret_cast<uint64_t *>(c.validity)[r >> 6] = bal;
 }
 __global__ void __launch_bounds__(256) pb_text(Params p, const OutCol *cols, const int32_t *text_cols) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,9 +290,9 @@ __global__ void __launch_bounds__(256) pb_text(Params p, const OutCol *cols, con
     emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32));
     s.flush();
   } else {
-    const uint8_t *src = p.data + (uint32_t)raw;
-    const uint32_t n = (uint32_t)(raw >> 32);
-    for (uint32_t k = 0; k < n; k++) out[k] = src[k];
+    WriteSink s{out};
+    put_bytes(s, p.data + (uint32_t)raw, (uint32_t)(raw >> 32));   // eight bytes at a time
+    s.flush();
   }
 }
 
@@ -416,7 +417,7 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
       text_cols.push_back(j);
       ti++;
     }
-    d.validity = dalloc_zero((size_t)((nra + 31) / 32) * 4 + 8);
+    d.validity = dalloc_zero((size_t)((nra + 63) / 64) * 8 + 8);
     c.validity = ptr<uint8_t>(d.validity);
     db->schema.push_back({d.name, d.dtype});
     db->cols.push_back(std::move(d));
