@@ -41,6 +41,7 @@ struct Params {
   const uint8_t *data; const uint32_t *ms; int64_t nmsg;
   uint32_t schema_id; int32_t schema_code, report_frame_errors;
   const DField *fields; int32_t nfields; const DMember *members; const uint8_t *names;
+  const int16_t *lut; int32_t lutn;    // field number → field index (-1: unknown) for numbers below lutn; larger numbers are searched
   uint64_t *rec; uint8_t *present;     // [nfields][nmsg]
   uint8_t *status; uint32_t *keep;     // [nmsg], [nmsg + 1]
   uint32_t *nerr;
@@ -111,9 +112,11 @@ __global__ void __launch_bounds__(128) pb_decode(Params p) {
   for (int f = 0; f < p.nfields; f++) p.present[(int64_t)f * p.nmsg + m] = 0;
   bool twice = false;
   const int rc = walk(d, a + 6, z, [&](uint32_t num, uint32_t wt, uint64_t raw, uint32_t len) {
-    for (int f = 0; f < p.nfields; f++) {
+    int f = -1;
+    if (num < (uint32_t)p.lutn) f = p.lut[num];
+    else for (int k = 0; k < p.nfields; k++) if ((uint32_t)p.fields[k].number == num) { f = k; break; }
+    if (f >= 0) {
       const DField &fd = p.fields[f];
-      if ((uint32_t)fd.number != num) continue;
       const int64_t i = (int64_t)f * p.nmsg + m;
       if (fd.repeated) {  // every occurrence is an element; numeric kinds also arrive packed: a length-delimited run of them
         const int ew = want_wt(fd.ptype);
@@ -326,6 +329,7 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
   const char *ns = "", *table = "";
   tfgpu_pb_schema_info(sch, &code, &fl, &nf, &ns, &table, nullptr, nullptr);
   if (len >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR protobuf: batch must be < 4 GiB (32-bit offsets)");
+  if (nf > 4096) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR protobuf: more than 4096 fields");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
   hipStream_t st = cx.stream;
@@ -368,11 +372,15 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
   }
   names.append(16, '\0');
   if (members.empty()) members.push_back(pbd::DMember{0, 0, 0, 0});
+  std::vector<int16_t> lut(1024, (int16_t)-1);
+  for (int j = 0; j < nf; j++) if (fl[j].number < (int32_t)lut.size()) lut[(size_t)fl[j].number] = (int16_t)j;
+  Buf blut = upload_small(lut.data(), lut.size() * 2);
   Buf bfields = upload_small(fields.data(), fields.size() * sizeof(pbd::DField)), bmembers = upload_small(members.data(), members.size() * sizeof(pbd::DMember)), bnames = upload_small(names.data(), names.size());
   Buf rec = dalloc((size_t)std::max(nf, 1) * (size_t)nma * 8 + 16), present = dalloc((size_t)std::max(nf, 1) * (size_t)nma + 16);
   Buf status = dalloc_zero((size_t)nma + 16), keep = dalloc_zero((size_t)(nma + 1) * 4 + 16), nerr = dalloc_zero(16);
   p.ms = ptr<uint32_t>(bms); p.nmsg = nmsg; p.schema_id = schema_id; p.schema_code = code; p.report_frame_errors = report_frame_errors;
   p.fields = ptr<pbd::DField>(bfields); p.nfields = code == TFGPU_ROW_OK ? nf : 0; p.members = ptr<pbd::DMember>(bmembers); p.names = ptr<uint8_t>(bnames);
+  p.lut = ptr<int16_t>(blut); p.lutn = (int32_t)lut.size();
   p.rec = ptr<uint64_t>(rec); p.present = ptr<uint8_t>(present); p.status = ptr<uint8_t>(status); p.keep = ptr<uint32_t>(keep); p.nerr = ptr<uint32_t>(nerr);
   if (nmsg) { KernelTimer t("pb_decode"); pbd::pb_decode<<<pbd::nblk(nmsg, 128), 128, 0, st>>>(p); }
   exclusive_scan_u32(p.keep, p.keep, nmsg, true);
