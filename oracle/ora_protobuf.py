@@ -365,8 +365,8 @@ def decode_fields(b: bytes, fields):
     while i < len(b):
         tag, i = _varint(b, i)
         num, wt = tag >> 3, tag & 7
-        if num == 0:
-            raise WireError("field number 0")
+        if num == 0 or num > 536870911:
+            raise HostOnly("field number 0 / beyond 2^29 - 1: what the reference's decoder makes of it is not pinned")
         if wt == 0:
             raw, i = _varint(b, i)
         elif wt == 1:

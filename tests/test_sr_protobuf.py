@@ -280,7 +280,7 @@ def random_message(rng, sch, weird):
             if msgs:
                 body += varint(msgs[0][1] << 3 | 2) + varint(0) + varint(msgs[0][1] << 3 | 2) + varint(0)   # a message field twice
         elif k == 5:
-            body += varint(0) + varint(1)                          # field number 0
+            body += varint(0) + varint(1)                          # field number 0 (the stock code's)
         elif k == 6:
             body += varint(9 << 3 | 2) + varint(1000)              # a length past the end
     return body
@@ -383,3 +383,67 @@ def test_gpu_random_messages_match_oracle(tf, oracle, weird):
                         assert abi.norm_value(got) == abi.norm_value(w), (f, got, w)
                 checked += 1
     assert checked > 600 and (not weird or hosts > 10), (checked, hosts)
+
+
+@pytest.mark.gpu
+def test_gpu_damaged_bytes_match_oracle(tf, oracle):
+    """random byte strings and bit-flipped / spliced valid messages: every message ends where the oracle ends it (item with the same
+    values, `_unparsed`, or the stock code) — and nothing reads outside its message"""
+    from oracle import ora_protobuf as P
+    from transferia_amd import confluent_sr
+    rng = random.Random(900 + SEED0)
+    fates = {}
+    for trial in range(6):
+        while True:
+            text, _ = random_proto(rng)
+            try:
+                sch = P.compile_schema(text)
+                break
+            except (P.HostOnly, P.ProtoError):
+                continue
+        sid = 7 + trial
+        msgs = []
+        for k in range(400):
+            r = rng.random()
+            if r < 0.3:
+                body = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 40)))
+            else:
+                body = bytearray(random_message(rng, sch, False))
+                for _ in range(rng.randrange(1, 4)):
+                    if not body:
+                        break
+                    op = rng.randrange(4)
+                    i = rng.randrange(len(body))
+                    if op == 0:
+                        body[i] ^= 1 << rng.randrange(8)
+                    elif op == 1:
+                        del body[i:i + rng.randrange(1, 4)]
+                    elif op == 2:
+                        body[i:i] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 4)))
+                    else:
+                        body[i] = rng.choice([0x00, 0x7F, 0x80, 0xFF, 0x08, 0x12])
+                body = bytes(body)
+            msgs.append(frame(sid, body))
+        want = P.parse_messages(msgs, {sid: text.encode()})
+        s = confluent_sr.ProtoSchema(tf, text.encode())
+        data, m = abi.messages(msgs)
+        batch, errors = s.parse(sid, data, m)
+        rows, b = device_rows(batch)
+        for k, (kind, it) in enumerate(want):
+            fates[kind] = fates.get(kind, 0) + 1
+            if kind == "unparsed":
+                assert errors.get(k) == it and k not in rows, (k, errors.get(k), it, msgs[k])
+            elif kind == "host":
+                assert errors.get(k) == abi.ROW_HOST_FALLBACK and k not in rows, (k, errors.get(k), msgs[k])
+            else:
+                assert k in rows and k not in errors, (k, errors.get(k), msgs[k])
+                for f, got, w in zip(sch["fields"], rows[k], it["values"]):
+                    if w[0] == "nil":
+                        assert got[0] == "nil", (f, got)
+                    elif w[0] in ("float32", "float64"):
+                        assert got[0] == w[0] and (struct.pack("<d", got[1]) == struct.pack("<d", w[1]) or (got[1] != got[1] and w[1] != w[1])), (f, got, w)
+                    elif w[0] == "json":
+                        assert bytes(got[1]) == w[1], (f, got, w, msgs[k])
+                    else:
+                        assert abi.norm_value(got) == abi.norm_value(w), (f, got, w)
+    assert fates.get("item", 0) > 300 and fates.get("unparsed", 0) > 300 and fates.get("host", 0) > 50, fates

@@ -78,7 +78,7 @@ template <class F> __device__ int walk(MemBytes &d, uint32_t a, uint32_t z, F on
     if (!varint(d, i, z, &tag)) return 1;
     const uint32_t wt = (uint32_t)tag & 7u;
     const uint64_t num = tag >> 3;
-    if (num == 0 || num > 536870911ull) return 1;   // "illegal tag 0" / out of range
+    if (num == 0 || num > 536870911ull) return 2;   // field number 0 / beyond 2^29 - 1: what the reference's decoder makes of it is not pinned
     uint64_t raw = 0; uint32_t len = 0;
     if (wt == 0) { if (!varint(d, i, z, &raw)) return 1; }
     else if (wt == 1) { if (z - i < 8) return 1; raw = le(d, i, 8); i += 8; }
