@@ -131,7 +131,7 @@ def random_proto(rng, damage=False):
         else:
             saved = used
             used = set()
-            members = ["    %s m%d = %d;" % (rng.choice(SCALAR_TYPES + ["Color"]), k, num()) for k in range(rng.randrange(1, 5))]
+            members = ["    %s m%d = %d;" % (rng.choice(SCALAR_TYPES + ["Color"]), k, num()) for k in range(rng.choice([1, 2, 3, 4, 4, 11]))]   # (more than eight members: the device finds them a walk each)
             used = saved
             nested.append("  message N%d {\n%s\n  }" % (i, "\n".join(members)))
             body.append("  %sN%d f%d = %d;" % (rng.choice(["", "Value.", pkg + ".Value.", "." + pkg + ".Value."]), i, i, num()))   # protobuf's scoping: relative, partly and fully qualified
