@@ -477,6 +477,31 @@ def sr_json_parse(opts: abi.CSrJsonOptions, data: bytes, msgs: abi.CMessages = N
     return res
 
 
+def sr_proto_parse(schema_id: int, schema_text: bytes, data: bytes, msgs: abi.CMessages = None, policy: str = "debezium_style", manual_table_name: str = ""):
+    """The PROTOBUF branch of the Confluent-SR parser for the messages carrying schema_id (ora_protobuf.py): the shape of
+    transferia_amd.lib.sr_proto_parse — (ns, table, names, {message index: values}, {message index: code})."""
+    from . import ora_protobuf as P
+    nmsg = msgs.nmsg if msgs is not None else 1
+    starts = np.ctypeslib.as_array(C.cast(msgs.start, C.POINTER(C.c_uint64)), (nmsg + 1,)) if msgs is not None else [0, len(data)]
+    mine, idx = [], []
+    for m in range(nmsg):
+        buf = data[int(starts[m]):int(starts[m + 1])]
+        if len(buf) >= 5 and buf[0] == 0 and int.from_bytes(buf[1:5], "big") == schema_id:
+            mine.append(buf); idx.append(m)
+    res = P.parse_messages(mine, {schema_id: schema_text}, policy, manual_table_name)
+    ns = table = ""
+    names, rows, errors = [], {}, {}
+    for m, (kind, it) in zip(idx, res):
+        if kind == "item":
+            ns, table, names = it["ns"], it["table"], it["names"]
+            rows[m] = it["values"]
+        elif kind == "unparsed":
+            errors[m] = it
+        elif kind == "host":
+            errors[m] = abi.ROW_HOST_FALLBACK
+    return ns, table, names, rows, errors
+
+
 def filter_parse_check(expr: str):
     err = C.create_string_buffer(256)
     n = lib().ora_filter_parse_check(expr.encode("utf-8"), err, 256)

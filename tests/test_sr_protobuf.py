@@ -99,6 +99,30 @@ def test_oracle_unpack_val_canon():
         assert close(canon_of(v), want[n]), (n, v, want[n])
 
 
+def _check_whole_test_client(engine):
+    """parser_test.go TestClient in full: the 53 JSON lines and the two protobuf messages through ONE ConfluentSrParser.do_batch over the
+    test's registry (5 JSON schemas, 2 PROTOBUF) — 55 items in the canon's order"""
+    from transferia_amd import confluent_sr
+    G = golden("confluent_sr.json")
+    PBG = golden("sr_protobuf.json")["cases"]
+    msgs = [base64.b64decode(x) for x in G["messages"]] + [base64.b64decode(c["message_b64"]) for c in PBG]
+    keep = [i for i, x in enumerate(msgs) if x]   # (the test skips empty lines)
+    data, m = abi.messages([msgs[i] for i in keep])
+    got = confluent_sr.ConfluentSrParser(G["schemas"]).do_batch(engine, data, m)
+    assert all("kind" in x for x in got), [x for x in got if "kind" not in x]
+    exp = list(G["items"]) + [c["expect"] for c in PBG]
+    assert len(got) == len(exp) == 55
+    for it, e in zip(got, exp):
+        assert (it["schema"], it["table"], it["names"]) == (e["schema"], e["table"], e["names"])
+        for n, v, w in zip(it["names"], it["values"], e["values"]):
+            assert close(canon_of(v) if v[0] != "jsonnum" else float(bytes(v[1])), w) or canon_of(v) == w, (e["table"], n, v, w)
+    assert [it["msg"] for it in got[-2:]] == [len(keep) - 2, len(keep) - 1]
+
+
+def test_oracle_whole_test_client(oracle):
+    _check_whole_test_client(oracle)
+
+
 # ---- schema texts ---------------------------------------------------------------------------------------------------------------
 SCALAR_TYPES = ["double", "float", "int64", "uint64", "int32", "fixed64", "fixed32", "bool", "string", "bytes", "uint32", "sfixed32", "sfixed64", "sint32", "sint64"]
 
@@ -318,6 +342,11 @@ def test_gpu_reference_vectors(tf):
         for n, v, w in zip(exp["names"], rows[0], exp["values"]):
             assert close(canon_of(v), w), (n, v, w)
         assert b.kind is None or [int(k) for k in b.kind] == [abi.K_INSERT]   # (no kind array: every row an Insert)
+
+
+@pytest.mark.gpu
+def test_gpu_whole_test_client(tf):
+    _check_whole_test_client(tf)
 
 
 @pytest.mark.gpu

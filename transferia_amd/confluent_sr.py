@@ -69,6 +69,9 @@ def table_schema(rows, ns: str = "", table: str = "") -> abi.Schema:
     return abi.Schema([abi.ColSchema(n, SRT_DTYPE[t], False, "", "", bool(r), ns, table) for n, t, r in rows])
 
 
+PROTO_POLICY = {"debezium_style": "debezium_style", "title": "message_name"}  # JSON table-name policy of the parser → the protobuf one it goes with (DefaultDerivedTableNamePolicy: both debezium_style)
+
+
 class ConfluentSrParser:
     """ConfluentSrImpl.DoBatch for JSON schemas (engine/parser.go:108-152) over an engine that provides
     `sr_frames(data, msgs)` and `sr_json_parse(opts, data, msgs)` — transferia_amd.lib on the device (the tests also run it
@@ -93,11 +96,38 @@ class ConfluentSrParser:
             self._plans[sid] = None if not ent or ent.get("schemaType") != "JSON" else ent["schema"]
         return self._plans[sid]
 
+    def _proto(self, sid: int):
+        ent = self.registry.get(sid) or self.registry.get(str(sid))
+        return ent["schema"] if ent and ent.get("schemaType") == "PROTOBUF" else None
+
     def do_batch(self, engine, data, msgs=None):
         frames = engine.sr_frames(data, msgs)
         fate = {}  # frame ordinal → item
         first = True
-        for sid in sorted({f[3] for f in frames if f[4] == 0}):
+        # PROTOBUF schemas: the payload is the whole rest of its Kafka message (doWithSchema, parser.go:46-48), so only a message's
+        # FIRST frame is one — what the JSON cut found behind it are bytes of the same protobuf message
+        proto_msgs = {}
+        for k, f in enumerate(frames):
+            if f[5] == 0 and f[4] == 0 and self._proto(f[3]) is not None:
+                proto_msgs[f[0]] = (k, f[3])
+        ignored = set()
+        if proto_msgs:
+            ignored = {k for k, f in enumerate(frames) if f[0] in proto_msgs and proto_msgs[f[0]][0] != k}
+            for sid in sorted({v[1] for v in proto_msgs.values()}):
+                text = self._proto(sid)
+                ns, table, names, rows, errors = engine.sr_proto_parse(sid, text.encode() if isinstance(text, str) else text, data, msgs,
+                                                                       PROTO_POLICY.get(self.policy, "debezium_style"), self.manual)
+                for m, (k, s2) in proto_msgs.items():
+                    if s2 != sid:
+                        continue
+                    if m in rows:
+                        fate[k] = {"kind": "insert", "schema": ns, "table": table, "names": names, "values": rows[m], "msg": m, "index": 0}
+                    elif errors.get(m) == abi.ROWERR_ID["HOST_FALLBACK"]:
+                        fate[k] = {"fallback": True, "msg": m}
+                    elif m in errors:
+                        fate[k] = {"unparsed": errors[m], "msg": m, "index": 0}
+        proto_frames = {v[0] for v in proto_msgs.values()}
+        for sid in sorted({f[3] for k, f in enumerate(frames) if f[4] == 0 and k not in ignored and k not in proto_frames}):
             text = self._plan(sid)
             if text is None:
                 for k, f in enumerate(frames):
@@ -123,7 +153,7 @@ class ConfluentSrParser:
         out, dead_msg, host_msgs = [], set(), set()
         for k, f in enumerate(frames):  # the reference's order; the first `_unparsed` frame of a message ends it
             it = fate.get(k)
-            if f[0] in dead_msg or f[0] in host_msgs or it is None:
+            if k in ignored or f[0] in dead_msg or f[0] in host_msgs or it is None:
                 continue
             if it.get("fallback"):
                 host_msgs.add(f[0])

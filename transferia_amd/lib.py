@@ -838,6 +838,19 @@ def sr_json_parse(opts: abi.CSrJsonOptions, data, msgs: Optional[abi.CMessages] 
     return ParseResult(DeviceBatch(out), [(int(errs[i].row), int(errs[i].code), int(errs[i].step)) for i in range(min(int(ne.value), max_errors))])
 
 
+def sr_proto_parse(schema_id: int, schema_text: bytes, data, msgs: Optional[abi.CMessages] = None, policy: str = "debezium_style", manual_table_name: str = ""):
+    """Confluent SR parser, PROTOBUF schema `schema_id` (tfgpu_sr_compile_proto + tfgpu_sr_proto_parse).  Returns
+    (ns, table, names, {message index: [(gotype, value)]}, {message index: TFGPU_ROW_* code}); with a schema the device does not take
+    every message of the id carries the schema's code."""
+    import sys
+    from . import confluent_sr
+    s = confluent_sr.ProtoSchema(sys.modules[__name__], schema_text, policy, manual_table_name)
+    db, errors = s.parse(schema_id, data, msgs, report_frame_errors=False)
+    b = db.download()
+    rows = {int(b.src_row[r]): [c.pyvalue(r) for c in b.cols] for r in range(b.nrows)}
+    return s.ns, s.table, [c.name for c in b.cols], rows, errors
+
+
 def debezium_unpack(data, msgs: Optional[abi.CMessages] = None, known=None) -> np.ndarray:
     """IncludeSchema.Unpack for every message (tfgpu_debezium_unpack): a structured array (abi.DBZ_FRAME_DTYPE) of nmsg frames.
     known = (prefix bytes, schema_off, schema_len, (hash0, hash1)) of an earlier batch: tfgpu_debezium_unpack_cached."""
