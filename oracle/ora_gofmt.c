@@ -46,6 +46,28 @@ static int shortest_digits(double f, int bits, char *digits, int *dp) {
     int ok;
     if (bits == 32) ok = (strtof(buf, NULL) == (float)f);
     else ok = (strtod(buf, NULL) == f);
+    if (!ok && p < maxp) {
+      /* An exact power of two has a rounding interval half as wide below as above: the correctly rounded p-digit decimal can fall
+       * outside it while its neighbour in the last digit lies inside.  strconv's shortest mode (ryuFtoaShortest) takes the
+       * shortest decimal INSIDE the interval, so the neighbours are candidates too (at most one of them parses back). */
+      char *e0 = strchr(buf, 'e');
+      int ex0 = atoi(e0 + 1);
+      unsigned long long D = 0;
+      for (char *c = buf; c < e0; c++) if (*c >= '0' && *c <= '9') D = D * 10 + (unsigned long long)(*c - '0');
+      unsigned long long lim = 1;
+      for (int k = 0; k < p; k++) lim *= 10;
+      for (int delta = -1; delta <= 1 && !ok; delta += 2) {
+        unsigned long long C = D + (unsigned long long)(long long)delta;
+        int ex = ex0;
+        if (C >= lim) { C /= 10; ex++; }
+        if (C < lim / 10) continue;   /* (fewer digits: an earlier p would have taken it) */
+        char cand[64], dg[32];
+        snprintf(dg, sizeof dg, "%llu", C);
+        if (p > 1) snprintf(cand, sizeof cand, "%c.%se%d", dg[0], dg + 1, ex); else snprintf(cand, sizeof cand, "%ce%d", dg[0], ex);
+        const int good = bits == 32 ? (strtof(cand, NULL) == (float)f) : (strtod(cand, NULL) == f);
+        if (good) { snprintf(buf, sizeof buf, "%s", cand); ok = 1; }
+      }
+    }
     if (ok || p == maxp) {
       /* buf = d.ddddde[+-]XX */
       int nd = 0;

@@ -476,3 +476,53 @@ def test_gpu_damaged_bytes_match_oracle(tf, oracle):
                     else:
                         assert abi.norm_value(got) == abi.norm_value(w), (f, got, w)
     assert fates.get("item", 0) > 300 and fates.get("unparsed", 0) > 300 and fates.get("host", 0) > 50, fates
+
+
+def test_oracle_shortest_floats_at_powers_of_two(oracle):
+    """An exact power of two has a rounding interval half as wide below as above; the shortest decimal inside it need not be the
+    correctly rounded one (2^-1007: 7.291122019556398e-304, sixteen digits, although ...397 is closer).  Found by the damaged-bytes
+    test; every power of two and its neighbours against Python's repr."""
+    import math
+    from decimal import Decimal
+    vals = []
+    for k in range(-1074, 1024):
+        x = math.ldexp(1.0, k)
+        vals += [x, math.nextafter(x, 0.0), math.nextafter(x, math.inf)]
+    rng = random.Random(5)
+    vals += [struct.unpack("<d", struct.pack("<Q", rng.getrandbits(63)))[0] for _ in range(20000)]
+    bad = []
+    for x in vals:
+        if x == 0.0 or math.isinf(x) or x != x:
+            continue
+        got = oracle.fmt_float(x, "e", 64)
+        if Decimal(got) != Decimal(repr(x)):   # Python's repr: David Gay's shortest round-trip digits, independent of both sides
+            bad.append((x.hex(), got, repr(x)))
+    assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+def test_gpu_shortest_floats_at_powers_of_two(tf, oracle):
+    """the same values through the device's formatter (a repeated double field: the array of their encoding/json texts)"""
+    import math
+    from transferia_amd import confluent_sr
+    s = confluent_sr.ProtoSchema(tf, b'syntax = "proto3"; package a.b.c; message V { repeated double f = 1; repeated float g = 2; }')
+    vals = []
+    for k in range(-1074, 1024):
+        x = math.ldexp(1.0, k)
+        vals += [x, math.nextafter(x, 0.0), math.nextafter(x, math.inf), -x]
+    f32 = []
+    for k in range(-149, 128):
+        x = math.ldexp(1.0, k)
+        f32 += [x, struct.unpack("<f", struct.pack("<I", struct.unpack("<I", struct.pack("<f", x))[0] + 1))[0]]
+    body = varint(1 << 3 | 2) + varint(8 * len(vals)) + b"".join(struct.pack("<d", v) for v in vals)
+    body += varint(2 << 3 | 2) + varint(4 * len(f32)) + b"".join(struct.pack("<f", v) for v in f32)
+    data, m = abi.messages([frame(1, body)])
+    batch, errors = s.parse(1, data, m)
+    assert not errors
+    rows, _b = device_rows(batch)
+    got64 = bytes(rows[0][0][1])[1:-1].split(b",")
+    got32 = bytes(rows[0][1][1])[1:-1].split(b",")
+    assert len(got64) == len(vals) and len(got32) == len(f32)
+    bad = [(v.hex(), g, oracle.json_float(v, 64)) for v, g in zip(vals, got64) if g.decode() != oracle.json_float(v, 64)]
+    bad += [(v.hex(), g, oracle.json_float(v, 32)) for v, g in zip(f32, got32) if g.decode() != oracle.json_float(v, 32)]
+    assert not bad, bad[:5]

@@ -10,8 +10,10 @@
 //                   length-delimited one); a message-typed field's bytes are walked too, so that a row is only made of bytes that
 //                   unmarshal.  HBM-bound in principle (each byte read once); one lane per message is latency-bound for long ones —
 //                   the JSON paths' tile staging would apply if this format becomes a bench line.
-//   pb_cells        lane = (row, field): the Go value — truncation / zigzag / bit casts — into the column; text lengths
-//   pb_text         lane = (row, text field): string / bytes copied, message fields marshalled (all members, keys sorted, absent
+//   pb_cells<ANY>   lane = (row, field): the Go value — truncation / zigzag / bit casts — into the column; text lengths (the `any`
+//                   columns, whose lengths need the JSON emitter, in their own launch: the emitter's registers would otherwise set
+//                   the occupancy of every cheap cell)
+//   pb_text_copy / pb_text_any   lane = (row, text field): string / bytes copied; message fields marshalled (all members, keys sorted, absent
 //                   members as their zero values: unpackNotRepeatedVal walks GetKnownFields), repeated fields as the array of their
 //                   elements (unpackRepeatedVal; packed runs unrolled)
 // HBM layout: rec[field][message] (8 bytes: raw value, or start | len << 32) + present[field][message] — a message's fields are
@@ -155,6 +157,11 @@ __global__ void __launch_bounds__(256) pb_row_msgs(Params p) {
   if (m < p.nmsg && p.status[m] == ST_OK) p.row_msg[p.keep[m]] = (uint32_t)m;
 }
 
+__global__ void __launch_bounds__(256) pb_src_rows(Params p, int32_t *src_row, uint32_t *part_id) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < p.nrows) { src_row[r] = (int32_t)p.row_msg[r]; part_id[r] = p.row_msg[r]; }
+}
+
 struct OutCol {
   int32_t ptype;
   void *values;        // fixed-width kinds
@@ -238,33 +245,35 @@ template <class S> __device__ bool emit_array(S &s, const Params &p, const DFiel
   return ok;
 }
 
-__global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, int32_t *src_row, uint32_t *part_id, uint32_t *host_rows) {
+// ANY = false: the columns whose cells are a few instructions each (fixed-width values, string / bytes lengths) — a kernel of a dozen
+// registers at full occupancy; ANY = true: the `any` columns, whose lengths come from the JSON emitter (float formatting, base64, the
+// string escaper: 120 VGPRs).  One kernel for both ran every cheap cell at the emitter's occupancy.
+template <bool ANY> __global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, const int32_t *list, int32_t *src_row, uint32_t *part_id, uint32_t *host_rows) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
+  const int j = list[blockIdx.y];
   const bool in = r < p.nrows;
   const OutCol &c = cols[j];
   const DField &fd = p.fields[j];
   bool valid = in;
   if (in) {
     const uint32_t m = p.row_msg[r];
-    if (j == 0) { src_row[r] = (int32_t)m; part_id[r] = m; }
+    if (blockIdx.y == 0 && !ANY) { src_row[r] = (int32_t)m; part_id[r] = m; }
     const int64_t i = (int64_t)j * p.nmsg + m;
     const bool present = p.present[i] != 0;
     const uint64_t raw = present ? p.rec[i] : 0ull;
-    if (fd.repeated) {  // an absent repeated field is the empty slice: []
-      CountSink s;
-      if (!emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1])) { host_rows[r] = 1; s.n = 0; }
-      c.lens[r] = s.n;
+    if constexpr (ANY) {
+      if (fd.repeated) {  // an absent repeated field is the empty slice: []
+        CountSink s;
+        if (!emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1])) { host_rows[r] = 1; s.n = 0; }
+        c.lens[r] = s.n;
+      } else if (!present) { c.lens[r] = 0; valid = false; }   // a nil *dynamic.Message: nil
+      else {
+        CountSink s;
+        if (!emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32))) { host_rows[r] = 1; s.n = 0; }
+        c.lens[r] = s.n;
+      }
     } else switch (fd.ptype) {
       case TFGPU_PB_STRING: case TFGPU_PB_BYTES: c.lens[r] = present ? (uint32_t)(raw >> 32) : 0u; break;
-      case TFGPU_PB_MESSAGE:
-        if (!present) { c.lens[r] = 0; valid = false; }   // a nil *dynamic.Message: nil
-        else {
-          CountSink s;
-          if (!emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32))) { host_rows[r] = 1; s.n = 0; }
-          c.lens[r] = s.n;
-        }
-        break;
       case TFGPU_PB_DOUBLE: case TFGPU_PB_INT64: case TFGPU_PB_UINT64: case TFGPU_PB_FIXED64: case TFGPU_PB_SFIXED64: case TFGPU_PB_SINT64:
         ((uint64_t *)c.values)[r] = (uint64_t)as_i64(fd.ptype, raw); break;
       case TFGPU_PB_BOOL: ((uint8_t *)c.values)[r] = raw != 0; break;
@@ -275,34 +284,33 @@ __global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, in
   const uint64_t bal = __ballot(valid);
   if ((threadIdx.x & 63) == 0 && in) reinterpret_cast<uint64_t *>(c.validity)[r >> 6] = bal;
 }
-__global__ void __launch_bounds__(256) pb_text(Params p, const OutCol *cols, const int32_t *text_cols) {
+// string / bytes cells: their bytes, eight at a time (the light half of the text pass)
+__global__ void __launch_bounds__(256) pb_text_copy(Params p, const OutCol *cols, const int32_t *list) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.nrows) return;
-  const int j = text_cols[blockIdx.y];
+  const int j = list[blockIdx.y];
+  const OutCol &c = cols[j];
+  const int64_t i = (int64_t)j * p.nmsg + p.row_msg[r];
+  if (!p.present[i]) return;
+  const uint64_t raw = p.rec[i];
+  WriteSink s{c.data + c.lens[r]};  // (offsets by now)
+  put_bytes(s, p.data + (uint32_t)raw, (uint32_t)(raw >> 32));
+  s.flush();
+}
+// `any` cells: message fields and repeated fields marshalled
+__global__ void __launch_bounds__(256) pb_text_any(Params p, const OutCol *cols, const int32_t *list) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= p.nrows) return;
+  const int j = list[blockIdx.y];
   const OutCol &c = cols[j];
   const DField &fd = p.fields[j];
   const uint32_t m = p.row_msg[r];
   const int64_t i = (int64_t)j * p.nmsg + m;
-  uint8_t *out = c.data + c.lens[r];  // (offsets by now)
-  if (fd.repeated) {
-    if (c.lens[r + 1] == c.lens[r]) return;  // (a row for the host: nothing was counted)
-    WriteSink s{out};
-    emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
-    s.flush();
-    return;
-  }
-  if (!p.present[i]) return;
-  const uint64_t raw = p.rec[i];
-  if (fd.ptype == TFGPU_PB_MESSAGE) {
-    if (c.lens[r + 1] == c.lens[r]) return;  // (a row for the host: nothing was counted)
-    WriteSink s{out};
-    emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32));
-    s.flush();
-  } else {
-    WriteSink s{out};
-    put_bytes(s, p.data + (uint32_t)raw, (uint32_t)(raw >> 32));   // eight bytes at a time
-    s.flush();
-  }
+  if (c.lens[r + 1] == c.lens[r]) return;  // nil, or a row for the host: nothing was counted
+  WriteSink s{c.data + c.lens[r]};
+  if (fd.repeated) emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
+  else { const uint64_t raw = p.rec[i]; emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32)); }
+  s.flush();
 }
 
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
@@ -439,11 +447,17 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
     db->schema.push_back({d.name, d.dtype});
     db->cols.push_back(std::move(d));
   }
+  std::vector<int32_t> light_cols, any_cols;
+  for (int j = 0; j < nf; j++) ((fl[j].repeated || fl[j].ptype == TFGPU_PB_MESSAGE) ? any_cols : light_cols).push_back(j);
   Buf boc = upload_small(oc.data(), oc.size() * sizeof(pbd::OutCol));
   if (nrows) {
     pbd::pb_row_msgs<<<pbd::nblk(nmsg, 256), 256, 0, st>>>(p);
     KernelTimer t("pb_cells");
-    pbd::pb_cells<<<dim3(pbd::nblk(nrows, 256), (unsigned)nf), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id), ptr<uint32_t>(host_rows));
+    const int32_t none = 0;
+    Buf bl = light_cols.empty() ? upload_small(&none, 4) : upload_small(light_cols.data(), light_cols.size() * 4), ba = any_cols.empty() ? upload_small(&none, 4) : upload_small(any_cols.data(), any_cols.size() * 4);
+    if (!light_cols.empty()) pbd::pb_cells<false><<<dim3(pbd::nblk(nrows, 256), (unsigned)light_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bl), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id), ptr<uint32_t>(host_rows));
+    else pbd::pb_src_rows<<<pbd::nblk(nrows, 256), 256, 0, st>>>(p, ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
+    if (!any_cols.empty()) pbd::pb_cells<true><<<dim3(pbd::nblk(nrows, 256), (unsigned)any_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(ba), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id), ptr<uint32_t>(host_rows));
   }
   if (ntext) {
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);
@@ -457,8 +471,13 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
       oc[(size_t)text_cols[(size_t)t]].data = ptr<uint8_t>(d.data);
     }
     boc = upload_small(oc.data(), oc.size() * sizeof(pbd::OutCol));
-    Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
-    if (nrows) { KernelTimer t("pb_text"); pbd::pb_text<<<dim3(pbd::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(btc)); }
+    if (nrows) {
+      KernelTimer t("pb_text");
+      std::vector<int32_t> copy_cols, any_text;
+      for (int32_t j : text_cols) ((fl[j].repeated || fl[j].ptype == TFGPU_PB_MESSAGE) ? any_text : copy_cols).push_back(j);
+      if (!copy_cols.empty()) { Buf bc = upload_small(copy_cols.data(), copy_cols.size() * 4); pbd::pb_text_copy<<<dim3(pbd::nblk(nrows, 256), (unsigned)copy_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bc)); }
+      if (!any_text.empty()) { Buf bc = upload_small(any_text.data(), any_text.size() * 4); pbd::pb_text_any<<<dim3(pbd::nblk(nrows, 256), (unsigned)any_text.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bc)); }
+    }
   }
   // rows whose `any` value holds a NaN / Inf: the reference keeps the Go float inside the map / slice, the column's JSON text cannot
   std::vector<uint32_t> hostm;
