@@ -498,6 +498,22 @@ def test_oracle_shortest_floats_at_powers_of_two(oracle):
         if Decimal(got) != Decimal(repr(x)):   # Python's repr: David Gay's shortest round-trip digits, independent of both sides
             bad.append((x.hex(), got, repr(x)))
     assert not bad, bad[:5]
+    # float32: numpy's Dragon4 in unique mode is the independent implementation
+    bad32 = []
+    f32 = []
+    for k in range(-149, 128):
+        b = struct.unpack("<I", struct.pack("<f", math.ldexp(1.0, k)))[0]
+        f32 += [b, b + 1, max(b - 1, 1)]
+    f32 += [rng.getrandbits(31) for _ in range(20000)]
+    for b in f32:
+        x = np.frombuffer(struct.pack("<I", b), np.float32)[0]
+        if not np.isfinite(x) or x == 0:
+            continue
+        got = oracle.fmt_float(float(x), "e", 32)
+        want = np.format_float_scientific(x, unique=True, trim="-")
+        if Decimal(got) != Decimal(want):
+            bad32.append((hex(b), got, want))
+    assert not bad32, bad32[:5]
 
 
 @pytest.mark.gpu
