@@ -498,6 +498,29 @@ def test_oracle_shortest_floats_at_powers_of_two(oracle):
         if Decimal(got) != Decimal(repr(x)):   # Python's repr: David Gay's shortest round-trip digits, independent of both sides
             bad.append((x.hex(), got, repr(x)))
     assert not bad, bad[:5]
+
+    # the three forms the path prints floats in, rebuilt from repr's digits: strconv 'f' with the shortest digits (castx.ToStringE, the
+    # CSV / to_string texts) and encoding/json's floatEncoder ('f' inside [1e-6, 1e21), else 'e' with e-0X trimmed to e-X)
+    def go_json_float(x):
+        d = Decimal(repr(x)).normalize()
+        a = abs(x)
+        if a != 0 and (a < 1e-6 or a >= 1e21):
+            sign, digits, exp = d.as_tuple()
+            ds = "".join(map(str, digits))
+            e10 = exp + len(ds) - 1
+            t = ("-" if sign else "") + ds[0] + ("." + ds[1:] if len(ds) > 1 else "") + "e" + ("-" if e10 < 0 else "+") + str(abs(e10)).rjust(2, "0")
+            return t[:-2] + t[-1] if t[-4:-1] == "e-0" else t
+        return format(d, "f")
+    vals += [1e-6, 9.999999999999999e-7, 1e21, 9.999999999999999e20, 1e-7, 1e22, 123456789.125, 0.1, 5e-324, 1.7976931348623157e308, -1e-6, -1e21]
+    bad2 = []
+    for x in vals:
+        if x == 0.0 or math.isinf(x) or x != x:
+            continue
+        if oracle.json_float(x, 64) != go_json_float(x):
+            bad2.append(("json", x.hex(), oracle.json_float(x, 64), go_json_float(x)))
+        if oracle.fmt_float(x, "f", 64) != format(Decimal(repr(x)).normalize(), "f"):
+            bad2.append(("f", x.hex(), oracle.fmt_float(x, "f", 64)[:40]))
+    assert not bad2, bad2[:5]
     # float32: numpy's Dragon4 in unique mode is the independent implementation
     bad32 = []
     f32 = []
