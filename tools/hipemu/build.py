@@ -12,7 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+SANITIZE = os.environ.get("HIPEMU_SANITIZE") == "1"   # AddressSanitizer + UBSan build (tools/hipemu/run_gpu_tests.py under LD_PRELOAD=libasan): hostile-input runs
+OUT = os.path.join(HERE, "_build_asan" if SANITIZE else "_build")
 UNITS = ["tf_runtime.hip", "tf_shard.hip", "tf_scan.hip", "tf_plan.cpp", "tf_sql.cpp", "tf_transformation.cpp", "tf_pipeline.cpp", "tf_dbzrecv.cpp", "tf_protoschema.cpp", "tf_transform.hip", "tf_api.hip", "tf_csv.hip", "tf_parquet.hip", "tf_parquetw.hip", "tf_dbzemit.hip", "tf_serialize.hip", "tf_json.hip",
          "tf_collapse.hip", "tf_srjson.hip", "tf_exchange.hip", "tf_sizeof.hip", "tf_chnative.hip", "tf_debezium.hip", "tf_protobuf.hip"]  # = transferia_amd/build.py SOURCES
 LAUNCH = re.compile(r"(\b[A-Za-z_][A-Za-z0-9_:]*(?:<[^<>;]*>)?)\s*<<<\s*([^;]*?)>>>\s*\(")
@@ -62,6 +63,8 @@ def build() -> str:
         if os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
             return obj
         cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-c", "-Wno-unused-result", "-I", HERE, "-I", CSRC, "-o", obj, src]
+        if SANITIZE:
+            cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize=alignment,shift"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-6000:])
@@ -70,7 +73,7 @@ def build() -> str:
     import concurrent.futures
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, srcs))
-    r = subprocess.run(["g++", "-shared", "-fPIC", "-o", so, *objs, "-ldl", "-lpthread"], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-shared", "-fPIC", *(["-fsanitize=address,undefined"] if SANITIZE else []), "-o", so, *objs, "-ldl", "-lpthread"], capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-6000:])
         raise RuntimeError("hipemu link failed")
