@@ -131,7 +131,9 @@ class _P:
             else:
                 raise ProtoError("unexpected %r" % v)
 
-    def message(self, scope):
+    def message(self, scope, depth=1):
+        if depth > 64:
+            raise HostOnly("messages nested deeper than 64 levels")
         self.expect("message")
         name = self.ident()
         m = _Msg(name, (scope + "." if scope else "") + name)
@@ -144,7 +146,7 @@ class _P:
             if k == "eof":
                 raise ProtoError("unexpected end")
             if v == "message":
-                m.messages.append(self.message(m.full))
+                m.messages.append(self.message(m.full, depth + 1))
             elif v == "enum":
                 self.next(); en = self.ident(); self.skip_block(); m.enums.append(m.full + "." + en)
             elif v in ("option", "reserved"):

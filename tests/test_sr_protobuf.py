@@ -223,6 +223,15 @@ def test_compile_reference_schemas():
             assert g2 == w2 and (s2.ns, s2.table) == exp
 
 
+def test_compile_deep_nesting_is_named_not_crashed():
+    deep = 'syntax = "proto3"; package a.b.c; ' + "".join("message M%d { " % k for k in range(3000)) + "int32 x = 1;" + " }" * 3000
+    got, want, s = compile_both(deep)
+    assert got == want == ("host",) and "64" in s.why
+    ok = 'syntax = "proto3"; package a.b.c; ' + "".join("message M%d { " % k for k in range(60)) + "int32 x = 1;" + " }" * 60
+    got, want, _s = compile_both(ok)
+    assert got == want and got[0] == "ok"
+
+
 def test_compile_random_protos():
     rng = random.Random(11 + SEED0)
     seen = {}

@@ -124,7 +124,9 @@ struct Parser {
       else throw SyntaxError{"unexpected " + k.s};
     }
   }
+  int depth = 0;
   std::unique_ptr<Msg> message(const std::string &scope) {
+    struct Depth { int &d; explicit Depth(int &x) : d(x) { if (++d > 64) throw HostOnly{"messages nested deeper than 64 levels"}; } ~Depth() { d--; } } guard(depth);
     expect("message");
     auto m = std::make_unique<Msg>();
     m->name = ident();
