@@ -181,6 +181,18 @@ def test_compile_registry_schema_random():
     assert sum(v for k, v in outcomes.items() if k[1] == "host" and k[2] != "host") <= 20, outcomes   # conservative answers stay rare
 
 
+def test_compile_deeply_nested_schema_is_handed_over_not_followed():
+    """a schema text nested thousands of levels deep (a registry's answer, or the `schema` member of a hostile message) must not take the
+    host's stack with it"""
+    from transferia_amd import debezium
+    deep = b'{"properties":' * 5000 + b"{}" + b"}" * 5000
+    with pytest.raises(debezium.HostOnly):
+        debezium.compile_registry_schema(deep)
+    deep2 = b'{"fields":[' * 5000 + b"{}" + b"]}" * 5000
+    with pytest.raises(debezium.HostOnly):
+        debezium.compile_schema(deep2)
+
+
 # ---- streams ------------------------------------------------------------------------------------------------------------------
 def frame(sid, payload: bytes) -> bytes:
     return b"\x00" + int(sid).to_bytes(4, "big") + payload

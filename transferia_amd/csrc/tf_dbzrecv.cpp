@@ -227,7 +227,10 @@ static int compile(const uint8_t *bytes, size_t len, std::vector<Field> &out, st
     if (!len) throw SchemaError{"unexpected end of JSON input"};
     Json node;
     try { node = Json::parse(std::string((const char *)bytes, len)); }
-    catch (const Error &e) { throw SchemaError{e.what()}; }
+    catch (const Error &e) {
+      if (std::strstr(e.what(), "nesting deeper")) throw HostOnly{e.what()};  // (encoding/json would still read it: the stock code decides)
+      throw SchemaError{e.what()};
+    }
     if (node.type != Json::Null && node.type != Json::Obj) throw SchemaError{confluent ? "json: cannot unmarshal into Go value of type format.ConfluentJSONSchema" : "json: cannot unmarshal into Go value of type common.Schema"};
     const Schema top = confluent ? from_confluent(&node, 0) : unmarshal(&node, 0);
     const Schema *before = top.find("before"), *after = top.find("after");

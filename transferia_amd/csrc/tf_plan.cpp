@@ -54,7 +54,10 @@ struct JP {
     p++;
     return o;
   }
+  int depth = 0;  // (encoding/json stops at 10 000 levels; nothing on this path nests past a few dozen — a text that does is refused by name
+                  //  rather than followed down the stack)
   Json val() {
+    struct Depth { int &d; JP &jp; Depth(int &x, JP &j) : d(x), jp(j) { if (++d > 512) jp.bad("nesting deeper than 512 levels"); } ~Depth() { d--; } } guard(depth, *this);
     ws();
     if (p >= e) bad("unexpected end");
     Json j;
