@@ -155,6 +155,12 @@ def test_corrupt_objects_are_errors_not_out_of_bounds_reads(tf):
             assert ex.code in (tf.ERR_INVALID, tf.ERR_UNSUPPORTED), str(ex)
             failures += 1
     assert failures >= 1
+    # (e) a footer of structs nested a hundred thousand deep (every byte a field header "struct, id + 1"): refused, not followed down the stack
+    deep = b"PAR1" + b"\x1c" * 100000
+    deep = deep + struct.pack("<I", 100000) + b"PAR1"
+    with pytest.raises(tf.TfgpuError) as ei:
+        tf.parquet_read(deep)
+    assert ei.value.code in (tf.ERR_INVALID, tf.ERR_UNSUPPORTED), str(ei.value)
     # (c) a dictionary whose last entry runs past its page; (d) truncated objects
     bad = _corrupt(good, struct.pack("<I", 2) + b"bb", struct.pack("<I", 0x00FFFFFF) + b"bb")
     with pytest.raises(tf.TfgpuError) as ei:

@@ -63,8 +63,11 @@ struct TReader {
     n = b >> 4; ety = b & 15;
     if (n == 15) n = (uint32_t)varint();
   }
+  int depth = 0;  // (a footer is a few structs deep; a hostile one must not take the host's stack: nested skips stop at 64)
   void skip(int ty) {
     if (!ok) return;
+    struct Depth { int &d; explicit Depth(int &x) : d(x) { d++; } ~Depth() { d--; } } guard(depth);
+    if (depth > 64) { ok = false; return; }
     switch (ty) {
       case 1: case 2: break;                       // bool in the header
       case 3: p++; break;
@@ -72,7 +75,7 @@ struct TReader {
       case 7: p += 8; break;
       case 8: { const uint64_t n = varint(); if (n > (uint64_t)(e - p)) ok = false; else p += n; break; }
       case 9: case 10: { int et; uint32_t n; list(et, n); for (uint32_t i = 0; i < n && ok; i++) { if (et == 1 || et == 2) p++; else skip(et); } break; }
-      case 11: { const uint64_t n = varint(); if (n) { const uint8_t kv = *p++; for (uint64_t i = 0; i < n && ok; i++) { skip(kv >> 4); skip(kv & 15); } } break; }
+      case 11: { const uint64_t n = varint(); if (n) { if (p >= e) { ok = false; break; } const uint8_t kv = *p++; for (uint64_t i = 0; i < n && ok; i++) { skip(kv >> 4); skip(kv & 15); } } break; }
       case 12: { int id = 0; for (;;) { const int t = field(id); if (!t || !ok) break; skip(t); } break; }
       default: ok = false;
     }
