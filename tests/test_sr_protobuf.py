@@ -574,3 +574,25 @@ def test_gpu_shortest_floats_at_powers_of_two(tf, oracle):
     bad = [(v.hex(), g, oracle.json_float(v, 64)) for v, g in zip(vals, got64) if g.decode() != oracle.json_float(v, 64)]
     bad += [(v.hex(), g, oracle.json_float(v, 32)) for v, g in zip(f32, got32) if g.decode() != oracle.json_float(v, 32)]
     assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _os.environ.get("TFGPU_TEST_EMU_LIB"), reason="written after round 4's last GPU minute: it runs in the CPU pre-flight (tools/hipemu) until a visit has run it on hardware")
+def test_gpu_protobuf_rows_feed_the_serializers(tf, oracle):
+    """the parsed batch as the sinks get it: an enum's number under its `utf8` column, a message field's map, a repeated field's array — the
+    three text serializers print the device batch as the oracle prints the downloaded one"""
+    from transferia_amd import confluent_sr
+    text = (b'syntax = "proto3"; package a.b.c; enum Color { RED = 0; GREEN = 1; } '
+            b'message V { int32 id = 1; Color col = 2; string s = 3; P p = 4; repeated sint64 r = 5; bytes raw = 6; double d = 7; message P { double x = 1; string n = 2; } }')
+    s = confluent_sr.ProtoSchema(tf, text)
+    assert s.code == abi.ROW_OK, s.why
+    rng = random.Random(3)
+    sch = {"fields": [(n, k, {v: kk for kk, v in PB.items()}[t], None, [(mn, mk, {v: kk for kk, v in PB.items()}[mt]) for mn, mk, mt in mem] or None, rep) for n, k, t, mem, rep in s.fields]}
+    msgs = [frame(1, random_message(rng, sch, False)) for _ in range(200)]
+    data, m = abi.messages(msgs)
+    db, errors = s.parse(1, data, m)
+    assert not errors and db.nrows == 200
+    host = db.download()
+    schema = s.table_schema()
+    for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
+        assert tf.serialize(fmt, db).download() == oracle.serialize(fmt, host, schema), fmt
