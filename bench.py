@@ -267,7 +267,7 @@ class Base:
 
 class CsvWorkload(Base):
     """BASELINE.json configs[1]."""
-    metric = "ChangeItems/sec through CSV parse -> mask(ClientIP)+filter(EventDate) -> devnull, ClickBench hits"
+    metric = "ChangeItems/sec through CSV parse -> mask(ClientIP)+filter(EventDate) -> devnull, ClickBench hits, HBM-resident input (the PCIe-inclusive rate is `pcie_inclusive`)"
     default_rows = 1 << 20
 
     def setup(self):
@@ -391,6 +391,14 @@ class CsvWorkload(Base):
         self.nl = nl if host_bufs is None and nlanes is None else self.nl
         return dt
 
+    def mask_rows(self, kernels=None):
+        """Rows the mask kernel is LAUNCHED on: the library's own count (tfgpu_prof_get_units) — behind a hoisted filter_rows
+        (tf_transform.hip chain_sequence) that is the kept rows, not the parsed rows."""
+        k = (kernels or getattr(self, "kernels", None) or {}).get("mask_hmac_sha256") or {}
+        if not k.get("units_per_step"):
+            raise RuntimeError("the library reported no row count for mask_hmac_sha256: its roofline cannot be priced")
+        return k["units_per_step"]
+
     def alg(self):
         s = self.state
         rows, sel = s["parsed_rows"], s["out_rows"] / max(s["parsed_rows"], 1)
@@ -398,7 +406,7 @@ class CsvWorkload(Base):
         gather = int((1 + sel) * (s["fixed_bytes"] + 8 * s["nstr"] * rows))
         return {"csv_count_newlines": self.csv_bytes, "csv_parse_regular": self.csv_bytes + s["fixed_bytes"],  # read every input byte once, write every fixed-width value once
                 "csv_parse_rows": self.csv_bytes + s["fixed_bytes"], "csv_copy_words": 2 * s["str_bytes"], "scan_u32_segments": 12 * rows * s["nstr"],
-                "mask_hmac_sha256": 72 * rows,                  # 4 B in + 64 B hex + 4 B offset per value
+                "mask_hmac_sha256": 72 * self.mask_rows(),      # 4 B in + 64 B hex + 4 B offset per value it is launched on
                 "filter_rows_eval": int((8 + 4 + 0.125) * rows), "compact_gather": gather, "scan_u32": 12 * rows}
 
     def alg_views(self):
@@ -409,9 +417,10 @@ class CsvWorkload(Base):
         k = kernels.get("mask_hmac_sha256")
         if not k:
             return None
-        ach = MASK_INT_OPS_PER_VALUE * self.state["parsed_rows"] / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
+        mrows = self.mask_rows(kernels)
+        ach = MASK_INT_OPS_PER_VALUE * mrows / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
         out = {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s",
-               "frac": round(ach / INT32_PEAK_TOPS, 4), "int_ops_per_value": MASK_INT_OPS_PER_VALUE,
+               "frac": round(ach / INT32_PEAK_TOPS, 4), "int_ops_per_value": MASK_INT_OPS_PER_VALUE, "values_per_step": mrows,
                "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low.  int_ops_per_value tallies two-input 32-bit "
                        "operations; gfx950's v_add3 / v_xor3 / v_bfi / v_alignbit carry two or three of them per instruction, so `frac` can approach 1 while the VALU "
                        "issues fewer instructions than that — `issue_frac` (measured instructions, when profiles/pmc_traffic.json is of this build) is the issue-slot view"}
@@ -424,7 +433,7 @@ class CsvWorkload(Base):
             with open(os.path.join(ROOT, "transferia_amd", "csrc", t["source_file"]), "rb") as f:
                 if hashlib.sha256(f.read()).hexdigest() == t["source_sha256"]:
                     per = t["valu_instructions_per_value"]
-                    issued = per * self.state["parsed_rows"] / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
+                    issued = per * mrows / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
                     out["measured_valu_instructions_per_value"] = per
                     out["issued"] = round(issued, 2)
                     out["issue_frac"] = round(issued / INT32_PEAK_TOPS, 4)
@@ -857,8 +866,10 @@ class Configs3Workload(Base):
         k = kernels.get("mask_hmac_sha256")
         if not k:
             return None
-        ach = MASK_INT_OPS_PER_VALUE * self.n / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
-        return {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s", "frac": round(ach / INT32_PEAK_TOPS, 4)}
+        mrows = k.get("units_per_step") or self.n  # the library's own count of the rows the kernel was launched on
+        ach = MASK_INT_OPS_PER_VALUE * mrows / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
+        return {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s", "frac": round(ach / INT32_PEAK_TOPS, 4),
+                "values_per_step": mrows}
 
     def config(self):
         return {"workload": "hits columns resident in HBM as if decoded from Parquet -> mask + sharder + casts -> ClickHouse JSONEachRow (BASELINE.json configs[3], per-GPU shard)",
@@ -1591,13 +1602,16 @@ def main():
     for _ in range(2):
         W.step()
     lib.prof_reset()
-    per_pass = {}
+    per_pass, units = {}, {}
     nprof = max(args.prof_steps, 1)
     for i in range(nprof):
         W.step()
         for n, l, ms in lib.prof_get():
             if l:
                 per_pass.setdefault(n, []).append((l, ms))
+        for n, u in lib.prof_units().items():
+            if u:
+                units.setdefault(n, []).append(u)
         lib.prof_reset()
     lib.prof_enable(False)
     kernels = {}
@@ -1609,10 +1623,13 @@ def main():
             ms_step = float(np.median([ms for _, ms in samples]))
             lps = float(np.median([l for l, _ in samples]))
         kernels[n] = {"launches_per_step": lps, "avg_ms": ms_step / max(lps, 1e-9), "ms_per_step": ms_step}
+        if units.get(n):  # the rows the kernel's launches were issued over, as the library counted them (tfgpu_prof_get_units)
+            kernels[n]["units_per_step"] = int(np.median(units[n]))
     kernel_sum_ms = sum(v["ms_per_step"] for v in kernels.values())
 
     side = W.side_measurements() if hasattr(W, "side_measurements") else {}
 
+    W.kernels = kernels
     alg = W.alg()
     dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if kernels else None
     roofline = None
@@ -1671,6 +1688,9 @@ def main():
         out["passes_per_step"] = passes
         out["config"]["rows_per_pass"] = rows
         out["config"]["rows_per_gpu_per_step"] = rows * passes
+        for key in [k for k in out["config"] if k.endswith("_bytes_per_gpu_per_step")]:  # setup() knows one pass; a step is `passes` of them
+            out["config"][key.replace("_per_gpu_per_step", "_per_pass")] = out["config"][key]
+            out["config"][key] = out["config"][key] * passes
         out.update(W.extra())
         if e.devices:
             out["process_model"] = {"mode": "one process, one host thread and one lane per device (tfgpu_init_devices)", "devices": e.devices, "row_range_shards": shards}
@@ -1681,6 +1701,13 @@ def main():
         out["cpu_baseline"] = cpu
         out["kernels"] = kernels
         out.update(side)
+        # A fraction above 1 means the arithmetic around a kernel is wrong (or the kernel is not doing the work it is priced for):
+        # such a line is not printed.
+        bad = [(n, r.get("kernel"), f) for n, r in (("roofline", roofline), ("int_roofline", int_roof)) if r
+               for f in (r.get("frac"), r.get("issue_frac"), r.get("frac_with_text_views")) if f is not None and f > 1.0]
+        bad += [("kernels", n, v["alg_gb_s"] / HBM_PEAK_GBS) for n, v in kernels.items() if v.get("alg_gb_s", 0) > HBM_PEAK_GBS]
+        if bad:
+            raise SystemExit("bench.py refuses to print a roofline fraction above 1: %r" % bad)
         if cpu and isinstance(cpu.get("parity"), dict):
             out["parity_checked_rows"] = cpu["parity"].get("checked_input_rows", 0) if cpu["parity"].get("identical") else 0
         # the comparison that means something end to end: input from pinned host memory (PCIe inside) against the CPU path on

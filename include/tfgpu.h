@@ -294,7 +294,8 @@ void tfgpu_parsequeue_destroy(tfgpu_parsequeue *q);
  * carries (tfgpu_bufferer_wait; TFGPU_PQ_PENDING on a timeout, timeout_ms < 0 = wait).  The batches stay the caller's: they
  * may be freed once their ticket is answered.  async_push blocks until the collector has taken the item (the reference's
  * unbuffered input channel: backpressure).  A ticket's final answer (anything but TFGPU_PQ_PENDING) is given ONCE: the ticket is
- * forgotten with it.  src_row of a merged batch: async_push_meta states how many rows the batch's SOURCE had (meta_rows: what its
+ * forgotten with it.  A push that is answered at creation (an empty batch, a closed bufferer) returns a reserved id (bit 63
+ * set) that carries its answer: it holds no state, may be waited on any number of times, or never.  src_row of a merged batch: async_push_meta states how many rows the batch's SOURCE had (meta_rows: what its
  * src_row counts in, e.g. the rows before a filter); when every buffered batch states it, part g's src_row is shifted by the
  * source rows of the parts in front of it — the sink lines its row metas up the same way; when one does not (async_push), the
  * merged batch carries no src_row at all rather than one that collides across parts (the parts keep theirs).                */
@@ -1056,6 +1057,10 @@ int tfgpu_prof_enable(int on);
 int tfgpu_prof_reset(void);
 int tfgpu_prof_count(void);
 int tfgpu_prof_get(int i, const char **name, int64_t *launches, double *total_ms);
+/* The units (rows for the row kernels) entry i's timed launches were issued over, summed; 0 when the call site states
+ * none.  bench.py prices a kernel against the rows it was LAUNCHED on (a mask behind a hoisted filter sees the kept rows,
+ * tf_transform.hip chain_sequence), not the rows of the batch that entered the chain.                                  */
+int tfgpu_prof_get_units(int i, int64_t *units);
 
 #ifdef __cplusplus
 }

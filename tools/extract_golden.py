@@ -1123,6 +1123,32 @@ def sr_protobuf():
     write("sr_protobuf.json", {"cases": cases, "unpack_val": unpack})
 
 
+def parquet_reader():
+    """The reference's 30 Parquet reader canon outputs (tests/canon/s3/parquet/canondata/*/extracted, produced by canon_test.go
+    TestCanonSource through reader_parquet.go:137-340 and parquet_schema_resolver.go:81-158 over the apache/parquet-testing corpus;
+    rowsCutter keeps the first three row items of the first push): per file the ColumnNames, the TableSchema
+    (name, type, original_type, key, required) and every kept row as [Go type, value] cells — nested values as the canon's own tree."""
+    import glob
+    base = REF + "/tests/canon/s3/parquet/canondata/"
+    files = {}
+    for d in sorted(glob.glob(base + "parquet.parquet.TestCanonSource_*_canon_0")):
+        name = os.path.basename(d)[len("parquet.parquet.TestCanonSource_"):-len("_canon_0")]
+        with open(d + "/extracted") as f:
+            items = json.load(f)
+        it0 = items[0]
+        rows = []
+        for it in items:
+            assert it["ColumnNames"]["value"] == it0["ColumnNames"]["value"] and it["Kind"]["value"] == "insert"
+            assert it["Schema"]["value"] == "s3_source_parquet" and it["Table"]["value"] == name
+            rows.append([[v["type"], v["value"]] for v in it["ColumnValues"]["value"]])
+        files[name] = {"names": it0["ColumnNames"]["value"], "counters": [it["Counter"]["value"] for it in items],
+                       "table_schema": [[c["name"], c["type"], c["original_type"], c["key"], c["required"]] for c in it0["TableSchema"]["value"]],
+                       "rows": rows}
+    assert len(files) == 30
+    write("parquet_reader.json", {"source": "tests/canon/s3/parquet/canondata/parquet.parquet.TestCanonSource_<file>_canon_0/extracted (canon_test.go:92-141)",
+                                  "files": files}, compact=True)
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -1136,4 +1162,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium(); sr_format(); sr_protobuf()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium(); sr_format(); sr_protobuf(); parquet_reader()

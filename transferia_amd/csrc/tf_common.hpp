@@ -68,6 +68,7 @@ struct ProfEntry {
   std::string name;
   int64_t launches = 0;
   double total_ms = 0;
+  int64_t units = 0;  // rows / values / bytes the timed launches were issued over (KernelTimer's second argument), summed
 };
 
 struct BlockCache {
@@ -90,7 +91,7 @@ struct Context {
   template <class T> T *pin_n(size_t n) { return reinterpret_cast<T *>(pin(n * sizeof(T))); }
   bool prof_on = false;
   std::vector<ProfEntry> prof;
-  struct Pending { int idx; hipEvent_t a, b; };
+  struct Pending { int idx; hipEvent_t a, b; int64_t units = 0; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   std::mutex mu;  // serialises API calls that enqueue on the stream
@@ -124,7 +125,7 @@ struct LaneScope {         // the calling thread works on another lane for a whi
 struct KernelTimer {
   Context::Pending p{-1, nullptr, nullptr};
   bool on;
-  explicit KernelTimer(const char *name) : on(ctx().prof_on) { if (on) ctx().prof_begin(name, p); }
+  explicit KernelTimer(const char *name, int64_t units = 0) : on(ctx().prof_on) { if (on) { ctx().prof_begin(name, p); p.units = units; } }
   ~KernelTimer() { if (on) ctx().prof_end(p); }
 };
 
@@ -227,5 +228,8 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, bool with_
 // Segmented variant for `nseg` equally-long arrays laid out back to back
 // (used for the string columns of a batch): each segment scanned on its own.
 void exclusive_scan_u32_segments(uint32_t *inout, int64_t seg_len, int nseg, int64_t seg_stride);
+// totals[s] += sum of segment s's seg_len entries, in 64 bits (the scans above wrap at 4 GiB: callers that size a 32-bit-offset
+// column from a scan's total check this sum first).  totals must be zeroed; enqueued on the lane's stream.
+void sum_u32_segments_u64(const uint32_t *in, int64_t seg_len, int nseg, int64_t seg_stride, unsigned long long *totals);
 
 }  // namespace tf

@@ -83,7 +83,8 @@ struct Schema {
 static Schema unmarshal(const Json *node, int depth) {
   Schema s;
   if (!node || node->type == Json::Null) return s;
-  if (node->type != Json::Obj || depth > 64) throw SchemaError{"json: cannot unmarshal into Go value of type common.Schema"};
+  if (depth > 64) throw HostOnly{"schema nested deeper than 64 levels (encoding/json reads up to 10000: the stock code decides)"};
+  if (node->type != Json::Obj) throw SchemaError{"json: cannot unmarshal into Go value of type common.Schema"};
   s.field = string_field(*node, "field"); s.name = string_field(*node, "name"); s.type = string_field(*node, "type");
   if (const Json *v = member(*node, "optional"); v && v->type != Json::Null) { if (v->type != Json::Bool) throw SchemaError{"Schema.optional"}; s.optional = v->b; }
   if (const Json *v = member(*node, "version"); v && v->type != Json::Null) { if (v->type != Json::Num || !go_int64_literal(v->str)) throw SchemaError{"Schema.version"}; }
@@ -160,7 +161,8 @@ static std::string cstring_field(const Json &obj, const char *name) {
 static Schema from_confluent(const Json *node, int depth) {
   Schema s;  // (a null binds nothing: the zero ConfluentJSONSchema, whose Kafka form is {"type":"","optional":false})
   if (!node || node->type == Json::Null) return s;
-  if (node->type != Json::Obj || depth > 64) throw SchemaError{"json: cannot unmarshal into Go value of type format.ConfluentJSONSchema"};
+  if (depth > 64) throw HostOnly{"schema nested deeper than 64 levels (encoding/json reads up to 10000: the stock code decides)"};
+  if (node->type != Json::Obj) throw SchemaError{"json: cannot unmarshal into Go value of type format.ConfluentJSONSchema"};
   // json.Unmarshal binds every field before ToKafkaJSONSchema looks at any: type errors anywhere fail the schema
   const std::string type = cstring_field(*node, "type"), connect_type = cstring_field(*node, "connect.type"), title = cstring_field(*node, "title");
   cstring_field(*node, "description");

@@ -33,6 +33,15 @@ struct MemBytes {
     if (w2idx != i + 1) { win2 = reinterpret_cast<const uint64_t *>(base)[i + 1]; w2idx = i + 1; }
     return (win >> sh) | (win2 << (64 - sh));
   }
+  // the n (<= 8) bytes at [pos, pos + n), zero-extended: the following word is loaded only when the value reaches into it, so no
+  // load starts beyond the aligned 8-byte word that holds the value's last byte (a caller's device buffer carries no padding)
+  __device__ __forceinline__ uint64_t bytes(uint64_t pos, int n) {
+    const uint32_t sh = (uint32_t)(pos & 7) * 8;
+    if (sh + (uint32_t)n * 8 > 64) { const uint64_t w = word(pos); return n == 8 ? w : (w & ((1ull << (n * 8)) - 1)); }
+    (void)at(pos);
+    const uint64_t w = win >> sh;
+    return n == 8 ? w : (w & ((1ull << (n * 8)) - 1));
+  }
 };
 // A field view: absolute [start, start+n) through a MemBytes reader (HBM, slow path).
 struct Field {

@@ -311,6 +311,8 @@ int tfgpu_parsequeue_set_release(tfgpu_parsequeue *q, tfgpu_pq_release_fn releas
 }
 void tfgpu_parsequeue_destroy(tfgpu_parsequeue *q) { if (q) { tfgpu_parsequeue_close(q); delete q; } }
 
+static constexpr uint64_t BUF_TICKET_DONE = 1ull << 63;  // ids of pushes answered at creation: the low 32 bits are the answer
+
 int tfgpu_bufferer_create(int64_t trigging_count, uint64_t trigging_size, int64_t trigging_interval_ms, int concat_on_device, tfgpu_buf_flush_fn flush, void *user, tfgpu_bufferer **out) {
   if (!flush || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_bufferer_create: null argument");
   auto b = std::make_unique<tfgpu_bufferer>();
@@ -323,13 +325,15 @@ int tfgpu_bufferer_create(int64_t trigging_count, uint64_t trigging_size, int64_
 
 int tfgpu_bufferer_async_push_meta(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int64_t nrows, uint64_t values_size, int has_non_row_item, int64_t meta_rows, uint64_t *ticket) {
   if (!b || !ticket) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_bufferer_async_push: null argument");
-  auto t = std::make_shared<BufTicket>();
   std::unique_lock<std::mutex> lk(b->mu);
+  // A push that is answered at once (into a closed bufferer: AsyncPushConcurrencyErr rides on the ticket; or an empty batch) gets a
+  // reserved id that carries its answer — nothing is registered, so a caller that never waits on such a ticket leaks nothing.
+  if (b->closed || b->closing) { *ticket = BUF_TICKET_DONE | (uint32_t)TFGPU_ERR_INVALID; return TFGPU_OK; }
+  if (nrows == 0) { *ticket = BUF_TICKET_DONE | (uint32_t)TFGPU_OK; return TFGPU_OK; }
+  auto t = std::make_shared<BufTicket>();
   const uint64_t id = ++b->next_ticket;
   b->tickets.emplace(id, t);
   *ticket = id;
-  if (b->closed || b->closing) { t->finish(TFGPU_ERR_INVALID); return TFGPU_OK; }  // AsyncPushConcurrencyErr rides on the ticket
-  if (nrows == 0) { t->finish(0); return TFGPU_OK; }
   b->in.push_back({batch, nrows, values_size, has_non_row_item, meta_rows, t});
   const uint64_t mine = ++b->offered;
   b->cv.notify_all();
@@ -342,6 +346,7 @@ int tfgpu_bufferer_async_push(tfgpu_bufferer *b, const tfgpu_dbatch *batch, int6
 
 int tfgpu_bufferer_wait(tfgpu_bufferer *b, uint64_t ticket, int64_t timeout_ms) {
   if (!b) return TFGPU_ERR_INVALID;
+  if (ticket & BUF_TICKET_DONE) return (int)(int32_t)(uint32_t)ticket;  // answered when it was pushed
   std::shared_ptr<BufTicket> t;
   {
     std::lock_guard<std::mutex> lk(b->mu);

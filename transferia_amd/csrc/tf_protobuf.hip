@@ -70,7 +70,7 @@ __device__ __forceinline__ bool varint(MemBytes &rd, uint32_t &i, uint32_t end, 
   }
   return false;
 }
-__device__ __forceinline__ uint64_t le(MemBytes &rd, uint32_t i, int n) { const uint64_t w = rd.word(i); return n == 8 ? w : (w & 0xFFFFFFFFull); }
+__device__ __forceinline__ uint64_t le(MemBytes &rd, uint32_t i, int n) { return rd.bytes(i, n); }  // never past the word holding the value's last byte
 
 // One message's fields over [a, z): calls on(number, wire type, raw value or start, len) for every field; 0 ok, 1 does not unmarshal, 2 host
 template <class F> __device__ int walk(MemBytes &d, uint32_t a, uint32_t z, F on) {
@@ -319,6 +319,13 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_
 std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  // tf_transform.hip
 }  // namespace tf
 
+// 32-bit offsets hold less than 4 GiB per column.  TFGPU_TEST_TEXT_LIMIT (tests only) lowers the bound so that the refusal can be
+// exercised without a 4 GiB batch.
+static bool text_total_exceeds(uint64_t bytes) {
+  static const uint64_t limit = [] { const char *e = std::getenv("TFGPU_TEST_TEXT_LIMIT"); return e && *e ? (uint64_t)std::strtoull(e, nullptr, 10) : 0xFFFFFFF0ull; }();
+  return bytes >= limit;
+}
+
 using namespace tf;
 
 #define TF_API_BEGIN try {
@@ -460,10 +467,19 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
     if (!any_cols.empty()) pbd::pb_cells<true><<<dim3(pbd::nblk(nrows, 256), (unsigned)any_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(ba), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id), ptr<uint32_t>(host_rows));
   }
   if (ntext) {
+    // The `any` marshalling expands its input (absent members as "name":0, \u00XX, base64): a column's bytes are summed in 64 bits
+    // BEFORE the 32-bit scan, and a column of 4 GiB or more is refused — the scan would wrap and the text kernels write at wrapped offsets.
+    Buf tot64 = dalloc_zero((size_t)ntext * 8 + 16);
+    sum_u32_segments_u64(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride, ptr<unsigned long long>(tot64));
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);
     std::vector<const uint32_t *> tot((size_t)ntext);
     for (int t = 0; t < ntext; t++) tot[(size_t)t] = d2h_u32(ptr<uint32_t>(lens_all) + (int64_t)t * seg_stride + nrows);
+    const uint32_t *h64 = d2h_u32(tot64->p, (size_t)ntext * 2);
     tf::sync();
+    for (int t = 0; t < ntext; t++) {
+      const uint64_t bytes = (uint64_t)h64[2 * t] | (uint64_t)h64[2 * t + 1] << 32;
+      if (text_total_exceeds(bytes)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_sr_proto_parse: column " + db->cols[(size_t)text_cols[(size_t)t]].name + " holds 4 GiB of text or more: split the batch");
+    }
     for (int t = 0; t < ntext; t++) {
       DColumn &d = db->cols[(size_t)text_cols[(size_t)t]];
       d.data_len = *tot[(size_t)t];

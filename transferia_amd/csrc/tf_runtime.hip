@@ -90,7 +90,7 @@ hipEvent_t Context::get_event() {
 void Context::prof_begin(const char *name, Pending &p) {
   int idx = -1;
   for (size_t i = 0; i < prof.size(); i++) if (prof[i].name == name) { idx = (int)i; break; }
-  if (idx < 0) { prof.push_back(ProfEntry{name, 0, 0}); idx = (int)prof.size() - 1; }
+  if (idx < 0) { prof.push_back(ProfEntry{name, 0, 0, 0}); idx = (int)prof.size() - 1; }
   p.idx = idx; p.a = get_event(); p.b = get_event();
   TF_HIP(hipEventRecord(p.a, stream));
 }
@@ -104,7 +104,7 @@ void Context::prof_flush() {
   hipStreamSynchronize(stream);
   for (auto &p : pending) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof[p.idx].launches++; prof[p.idx].total_ms += ms; }
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { prof[p.idx].launches++; prof[p.idx].total_ms += ms; prof[p.idx].units += p.units; }
     free_events.push_back(p.a); free_events.push_back(p.b);
   }
   pending.clear();
@@ -567,6 +567,12 @@ int tfgpu_prof_get(int i, const char **name, int64_t *launches, double *total_ms
   Context *c = g_ctx ? g_lanes[g_lane].get() : nullptr;
   if (!c || i < 0 || i >= (int)c->prof.size()) return TFGPU_ERR_INVALID;
   *name = c->prof[i].name.c_str(); *launches = c->prof[i].launches; *total_ms = c->prof[i].total_ms;
+  return TFGPU_OK;
+}
+int tfgpu_prof_get_units(int i, int64_t *units) {
+  Context *c = g_ctx ? g_lanes[g_lane].get() : nullptr;
+  if (!c || !units || i < 0 || i >= (int)c->prof.size()) return TFGPU_ERR_INVALID;
+  *units = c->prof[i].units;
   return TFGPU_OK;
 }
 

@@ -107,6 +107,20 @@ static void scan_impl(const uint32_t *in, uint32_t *out, int64_t n, int64_t seg_
   scan_apply_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, out, ptr<uint32_t>(sums), n, seg_stride, nblocks, with_total ? 1 : 0);
 }
 
+__global__ void __launch_bounds__(SCAN_THREADS) sum_u64_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t seg_stride, unsigned long long *totals) {
+  const uint32_t *src = in + (int64_t)blockIdx.y * seg_stride;
+  unsigned long long s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * SCAN_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SCAN_THREADS) s += src[i];
+  for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(totals + blockIdx.y, s);
+}
+
+void sum_u32_segments_u64(const uint32_t *in, int64_t seg_len, int nseg, int64_t seg_stride, unsigned long long *totals) {
+  if (nseg <= 0 || seg_len <= 0) return;
+  const int64_t nb = std::min<int64_t>((seg_len + SCAN_THREADS * 8 - 1) / (SCAN_THREADS * 8), 1024);
+  sum_u64_kernel<<<dim3((unsigned)nb, (unsigned)nseg), SCAN_THREADS, 0, ctx().stream>>>(in, seg_len, seg_stride, totals);
+}
+
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, bool with_total) {
   KernelTimer t("scan_u32");
   scan_impl(in, out, n, 0, 1, with_total);

@@ -274,7 +274,7 @@ static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu
     std::memcpy(mp.opad, p.opad_state, sizeof mp.opad);
     mp.nrows = n; mp.out = ptr<uint8_t>(o.data);
     {
-      KernelTimer t("mask_hmac_sha256");
+      KernelTimer t("mask_hmac_sha256", n);
       if (n) mask_hmac_kernel<<<grid_for(n, 256), 256, 0, st>>>(mp);
     }
     fill_offsets_stride_kernel<<<grid_for(n + 1, 256), 256, 0, st>>>(ptr<uint32_t>(o.offsets), n, 64);
