@@ -310,15 +310,37 @@ int tfgpu_bufferer_get_stats(tfgpu_bufferer *b, tfgpu_bufferer_stats *out);
 int tfgpu_bufferer_close(tfgpu_bufferer *b);
 void tfgpu_bufferer_destroy(tfgpu_bufferer *b);
 
-/* Parquet object → device columns (tf_parquet.hip; pkg/providers/s3/reader/registry/parquet/reader_parquet.go:137-283, which reads
- * rows through parquet-go and boxes every value).  `bytes` is the whole object in HOST memory (the footer and the page headers
- * are walked on the host; the object is uploaded once and every value is decoded on the device).  `schema` = the TableSchema
- * given to Read: its columns are looked up in the file by name (a column the file lacks is nil in every row, :256-259); NULL =
- * every leaf of the file.  Values keep Parquet's physical Go types (bool, int32, int64, float32, float64, string / []byte); DATE
- * becomes time.Time as parseLogicalDate makes it.  Flat schemas, UNCOMPRESSED / SNAPPY / GZIP / ZSTD chunks (a compressed object's
- * pages are inflated on the host while it walks them), data pages v1 / v2, PLAIN and dictionary encodings; anything else answers
- * TFGPU_ERR_UNSUPPORTED naming it, and a corrupt object (a length, offset or dictionary index past what is there) TFGPU_ERR_INVALID.  PARITY UNPINNED against the reference (no .parquet input
- * under /root/reference, parquet-go not vendored): the tests pin it to pyarrow's reading of the same files.               */
+/* Parquet object → device columns (tf_parquet.hip; pkg/providers/s3/reader/registry/parquet/reader_parquet.go:137-340, which reads
+ * rows through parquet-go and boxes every value, and parquet_schema_resolver.go:81-158).  `bytes` is the whole object in HOST memory
+ * (the footer and the page headers are walked on the host; the object is uploaded once and every value is decoded on the device).
+ *
+ * tfgpu_parquet_resolve_schema = resolveSchema + the system columns (hide_system_cols = 0: `__file_name` utf8 and `__row_index`
+ * uint64 in front, both keys — s3_reader.AppendSystemColsTableSchema for a schema without a key): a leaf is typed by its physical
+ * type, then its logical type, then its converted type (BOOLEAN boolean, INT32 int32, INT64 int64, FLOAT float, DOUBLE double, INT96
+ * utf8, BYTE_ARRAY / FIXED_LEN_BYTE_ARRAY string; DATE date, STRING / UUID / ENUM utf8, INT(…) int64 / uint64, DECIMAL double,
+ * TIMESTAMP timestamp), a group is `any`; original_type = "parquet:" + the node's type string.  Free with tfgpu_schema_free.
+ *
+ * tfgpu_parquet_read_object = Read + constructCI + parseParquetField.  `schema` = the TableSchema given to Read: its columns are looked
+ * up in the file by name (a column the file lacks is nil in every row, :256-259); NULL = every top-level field of the file.  With a
+ * file_name the system columns of `schema` are the reader's own: `__file_name` = file_name, `__row_index` = the 1-based row (uint64).
+ * Values are what abstract.Restore (pkg/abstract/restore.go:20-260) makes of parquet-go's physical Go values under the column's
+ * DataType: bool, int32, int64, float32, float64; BYTE_ARRAY and FIXED_LEN_BYTE_ARRAY []byte → string under `string` / `utf8`;
+ * int32 → int64 / uint64 and float32 → float64 when the DataType says so; INT96 → the decimal text of its 96 bits
+ * (deprecated.Int96.String()); DATE → time.Time (parseLogicalDate); an INT64 under `timestamp` → ytschema.Timestamp(v).Time(), i.e.
+ * MICROseconds whatever unit the file states; DECIMAL (typed double) → nil in every row (its int32 / int64 / []byte value falls to
+ * Restore's default).  Data pages v1 / v2; PLAIN, dictionary, RLE (booleans), DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY and
+ * DELTA_BYTE_ARRAY (this one expanded on the host while it walks the page) encodings; UNCOMPRESSED / SNAPPY / GZIP / ZSTD / LZ4_RAW
+ * chunks (a compressed object's pages are inflated on the host while it walks them).  A requested column that is a group (nested /
+ * repeated: the `any` tree parquet-go builds) answers TFGPU_ERR_UNSUPPORTED naming it — the flat columns next to it are read when the
+ * schema leaves the group out; BYTE_STREAM_SPLIT, BROTLI / LZO / hadoop-LZ4 likewise.  A corrupt object (a length, offset or
+ * dictionary index past what is there, a page claiming more than its bytes can inflate to) is TFGPU_ERR_INVALID.
+ * PARITY: the type mapping, the OriginalType strings, the Go value types and the first rows of the reference's 20 flat reader canon
+ * files (tests/canon/s3/parquet/canondata → tests/golden/parquet_reader.json) are reproduced on inputs re-created from the canon's
+ * values (tests/test_parquet_canon.py); its 10 files with nested columns are refused by name.  The file-format decoder itself
+ * (parquet-go, not under /root/reference) is pinned to pyarrow's reading of the same files (tests/test_parquet.py).
+ * tfgpu_parquet_read = tfgpu_parquet_read_object without a file name (system column names are then looked up in the file).    */
+int tfgpu_parquet_resolve_schema(const void *bytes, uint64_t len, int hide_system_cols, tfgpu_schema **out);
+int tfgpu_parquet_read_object(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, tfgpu_dbatch **out);
 int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out);
 
 /* Device columns → a Parquet object (tf_parquetw.hip; pkg/serializer/parquet.go:53-200 parquetBatchSerializer.Serialize + Close,

@@ -66,7 +66,7 @@ def check(tf, t, compression="NONE", **write_kw):
                 assert c.values[i] == w, (c.name, i, c.values[i], w)
     reprs = {c.name: c.repr for c in out.cols}
     assert reprs == {"i32": abi.R_INT32, "i64": abi.R_INT64, "few": abi.R_INT64, "f32": abi.R_FLOAT32, "f64": abi.R_FLOAT64, "b": abi.R_BOOL, "cat": abi.R_STRING,
-                     "url": abi.R_STRING, "bin": abi.R_BYTES, "day": abi.R_TIME}
+                     "url": abi.R_STRING, "bin": abi.R_STRING, "day": abi.R_TIME}  # ([]byte under a `string` column is string(v): restore.go:222-229)
     return out
 
 
@@ -202,8 +202,8 @@ def test_schema_selects_columns_and_missing_ones_are_nil(tf):
 
 def test_what_stays_with_the_stock_reader_is_refused_by_name(tf):
     t = table(100, 9)
-    for kw, word in [(dict(compression="BROTLI"), "codec"), (dict(compression="LZ4"), "codec"),
-                     (dict(compression="NONE", use_dictionary=False, column_encoding={"i64": "DELTA_BINARY_PACKED"}), "encoding")]:
+    for kw, word in [(dict(compression="BROTLI"), "codec"),
+                     (dict(compression="NONE", use_dictionary=False, column_encoding={"f64": "BYTE_STREAM_SPLIT"}), "encoding")]:
         buf = io.BytesIO()
         pq.write_table(t, buf, **kw)
         with pytest.raises(tf.TfgpuError) as ei:
@@ -218,6 +218,74 @@ def test_what_stays_with_the_stock_reader_is_refused_by_name(tf):
     with pytest.raises(tf.TfgpuError) as ei:
         tf.parquet_read(b"PAR1 this is not a parquet file PAR1")
     assert ei.value.code == tf.ERR_INVALID
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 129, 5000, 20011])
+def test_delta_encodings_and_lz4_raw(tf, n):
+    """DELTA_BINARY_PACKED (int32 / int64 / dates, any miniblock width incl. 0 and 64-bit wrap-around deltas), DELTA_LENGTH_BYTE_ARRAY and
+    DELTA_BYTE_ARRAY text, optional and required, several pages and row groups, under LZ4_RAW and uncompressed."""
+    t = table(n, 300 + n)
+    rng = np.random.default_rng(n)
+    wild = pa.array([int(x) for x in rng.integers(-(1 << 63), (1 << 63) - 1, n, dtype=np.int64)], pa.int64())   # deltas that wrap
+    t = t.append_column("wild", wild).append_column("const", pa.array([7] * n, pa.int32()))
+    enc = {"i32": "DELTA_BINARY_PACKED", "i64": "DELTA_BINARY_PACKED", "few": "DELTA_BINARY_PACKED", "day": "DELTA_BINARY_PACKED", "wild": "DELTA_BINARY_PACKED", "const": "DELTA_BINARY_PACKED",
+           "cat": "DELTA_BYTE_ARRAY", "url": "DELTA_LENGTH_BYTE_ARRAY", "bin": "DELTA_LENGTH_BYTE_ARRAY"}
+    for comp in ("NONE", "LZ4"):
+        for kw in (dict(), dict(data_page_size=300, row_group_size=max(n // 3, 1)), dict(data_page_version="2.0")):
+            buf = io.BytesIO()
+            pq.write_table(t, buf, compression=comp, use_dictionary=False, column_encoding=enc, **kw)
+            data = buf.getvalue()
+            ref = pq.read_table(io.BytesIO(data))
+            out = tf.parquet_read(data).download()
+            assert out.nrows == n
+            for c in out.cols:
+                want = ref.column(c.name).to_pylist()
+                valid = c.validity if c.validity is not None else np.ones(n, bool)
+                assert [bool(v) for v in valid] == [w is not None for w in want], (c.name, comp, kw)
+                for i, w in enumerate(want):
+                    if w is None:
+                        continue
+                    if c.repr in abi.VAR_REPRS:
+                        assert c.get_bytes(i) == (w.encode() if isinstance(w, str) else w), (c.name, i, comp, kw)
+                    elif c.repr == abi.R_TIME:
+                        assert int(c.values[i]) == (w - __import__("datetime").date(1970, 1, 1)).days * 86400, (c.name, i)
+                    elif c.repr in (abi.R_FLOAT32, abi.R_FLOAT64):
+                        assert float(c.values[i]) == w, (c.name, i)
+                    else:
+                        assert c.values[i] == w, (c.name, i, comp, kw)
+
+
+def test_int96_fixed_len_and_restore_conversions(tf):
+    """INT96 → the decimal text of its 96 bits (also before 1970 and dictionary-coded); FIXED_LEN_BYTE_ARRAY → string; what Restore makes of a
+    value under the resolver's DataType: INT(8/16/32, signed) → int64, unsigned → uint64, float under `double`, TIMESTAMP → microseconds."""
+    import datetime
+    from oracle import ora_parquet as op
+    n = 700
+    rng = np.random.default_rng(5)
+    ts = [None if i % 9 == 0 else datetime.datetime(1960 + i % 90, 1 + i % 12, 1 + i % 28, i % 24, i % 60, i % 60, i * 1000 % 1000000) for i in range(n)]
+    t = pa.table({"ts96": pa.array(ts, pa.timestamp("ns")),
+                  "flba": pa.array([None if i % 7 == 0 else bytes(rng.integers(0, 256, 5).astype(np.uint8)) for i in range(n)], pa.binary(5)),
+                  "i8": pa.array([int(x) for x in rng.integers(-128, 127, n)], pa.int8()), "u16": pa.array([int(x) for x in rng.integers(0, 65535, n)], pa.uint16()),
+                  "u64": pa.array([int(x) for x in rng.integers(0, 1 << 62, n)], pa.uint64()),
+                  "tsus": pa.array([None if i % 5 == 0 else int(x) for i, x in enumerate(rng.integers(-(1 << 50), 1 << 50, n))], pa.timestamp("us")),
+                  "tsms": pa.array([int(x) for x in rng.integers(0, 1 << 40, n)], pa.timestamp("ms"))})
+    for kw in (dict(use_dictionary=False), dict(use_dictionary=True), dict(use_dictionary=False, compression="ZSTD", data_page_size=256)):
+        # (pyarrow's INT96 switch is per file: the INT96 column is written in a file of its own shape, the rest beside it)
+        buf = io.BytesIO()
+        pq.write_table(t.select(["ts96", "flba"]), buf, use_deprecated_int96_timestamps=True, store_schema=False, **kw)
+        buf2 = io.BytesIO()
+        pq.write_table(t.drop(["ts96"]), buf2, store_schema=False, **kw)
+        for data in (buf.getvalue(), buf2.getvalue()):
+            sch = tf.parquet_resolve_schema(data)
+            osch = op.resolve_schema(data)
+            assert [[c.name, c.dtype, c.original_type or "", bool(c.key), bool(c.required)] for c in sch.cols] == [list(c) for c in osch]
+            out = tf.parquet_read(data, sch, "ns", "t", file_name="f.parquet").download()
+            ref = op.read(data, osch, "f.parquet")
+            import test_parquet_canon as tc
+            got = tc.device_cells(out)
+            assert len(got) == len(ref) == n
+            for r in range(n):
+                assert [tc.exact_cell(c) for c in got[r]] == [tc.exact_cell(c) for c in ref[r]], r
 
 
 def test_wide_object_whose_segment_tables_outgrow_the_pinned_ring(tf):

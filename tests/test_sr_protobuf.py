@@ -12,6 +12,8 @@ from transferia_amd import abi
 from util import golden
 import os as _os
 
+ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+
 SEED0 = int(_os.environ.get("TFGPU_TEST_SEED", "0"))
 PB = {"double": 1, "float": 2, "int64": 3, "uint64": 4, "int32": 5, "fixed64": 6, "fixed32": 7, "bool": 8, "string": 9, "bytes": 10, "uint32": 11, "sfixed32": 12, "sfixed64": 13,
       "sint32": 14, "sint64": 15, "enum": 16, "message": 17}
@@ -577,7 +579,6 @@ def test_gpu_shortest_floats_at_powers_of_two(tf, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not _os.environ.get("TFGPU_TEST_EMU_LIB"), reason="written after round 4's last GPU minute: it runs in the CPU pre-flight (tools/hipemu) until a visit has run it on hardware")
 def test_gpu_protobuf_rows_feed_the_serializers(tf, oracle):
     """the parsed batch as the sinks get it: an enum's number under its `utf8` column, a message field's map, a repeated field's array — the
     three text serializers print the device batch as the oracle prints the downloaded one"""
@@ -596,3 +597,43 @@ def test_gpu_protobuf_rows_feed_the_serializers(tf, oracle):
     schema = s.table_schema()
     for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
         assert tf.serialize(fmt, db).download() == oracle.serialize(fmt, host, schema), fmt
+
+
+@pytest.mark.gpu
+def test_gpu_text_column_past_32_bit_offsets_is_refused(tf):
+    """An `any` column's JSON text is many times its wire bytes: a column's bytes are summed in 64 bits before the 32-bit scan and a
+    column of 4 GiB or more is refused (TFGPU_ERR_UNSUPPORTED, "split the batch") instead of wrapping.  The bound is lowered through
+    TFGPU_TEST_TEXT_LIMIT (read once per process: a subprocess) so that the refusal is exercised without a 4 GiB batch."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from transferia_amd import abi, confluent_sr, lib
+if os.environ.get("TFGPU_TEST_EMU_LIB"):
+    lib._LIBPATH = os.environ["TFGPU_TEST_EMU_LIB"]
+lib.init()
+text = b'syntax = "proto3"; package a.b.c; message V { int32 id = 1; P p = 2; string s = 3; message P { double x = 1; string n = 2; int64 a = 3; int64 b = 4; } }'
+s = confluent_sr.ProtoSchema(lib, text)
+assert s.code == abi.ROW_OK, s.why
+def varint(v):
+    out = b""
+    while True:
+        b = v & 0x7F; v >>= 7
+        if v: out += bytes([b | 0x80])
+        else: return out + bytes([b])
+msgs = [b"\0\0\0\0\x01\0" + varint(1 << 3) + varint(i) + varint(2 << 3 | 2) + varint(0) for i in range(3000)]   # an EMPTY nested message: ~40 bytes of JSON from 2
+data, m = abi.messages(msgs)
+try:
+    s.parse(1, data, m)
+    print("PARSED")
+except lib.TfgpuError as ex:
+    print("REFUSED", ex.code == lib.ERR_UNSUPPORTED, "split the batch" in str(ex), "column p" in str(ex))
+""" % (ROOT, ROOT)
+    env = dict(_os.environ, TFGPU_TEST_TEXT_LIMIT="50000")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == "REFUSED True True True", r.stdout[-2000:] + r.stderr[-2000:]
+    env = dict(_os.environ, TFGPU_TEST_TEXT_LIMIT="")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "PARSED", r.stdout[-2000:] + r.stderr[-2000:]

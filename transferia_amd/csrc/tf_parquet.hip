@@ -15,15 +15,22 @@
 //          PLAIN byte arrays are length-prefixed, so one lane per page walks the prefixes once; text is then packed with the
 //          destination-centric copy the CSV ingest uses (tf_segcopy.hpp), straight out of the file image.
 //
-// Scope: flat schemas (required / optional leaves), data pages v1 and v2, PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY / RLE,
-// BOOLEAN, INT32, INT64, FLOAT, DOUBLE, BYTE_ARRAY, the DATE annotation; UNCOMPRESSED, SNAPPY, GZIP and ZSTD pages (a compressed
-// object's pages are inflated on the host while it walks them — it reads the run headers there anyway — and the device image is
-// then the inflated payloads instead of the file).  Nested columns, INT96, FIXED_LEN_BYTE_ARRAY, DELTA_*, BYTE_STREAM_SPLIT and
-// the other codecs are refused by name (TFGPU_ERR_UNSUPPORTED).  Every length, offset and dictionary index the object states is
-// checked against the bytes that are there — on the host where it walks them, on the device where the values are (an error
-// word read back at the existing sync): a corrupt object is TFGPU_ERR_INVALID, never an out-of-bounds read.
-// PARITY UNPINNED against the reference: /root/reference holds no .parquet input, and the Go values parquet-go hands to
-// abstract.Restore are that library's choice; the tests pin the decoder to an independent reader (pyarrow) instead.
+// Scope: top-level leaves (required / optional) of any schema — a requested GROUP (nested / repeated: the `any` tree parquet-go builds)
+// is refused by name, the flat columns beside it are read; data pages v1 and v2; PLAIN, PLAIN_DICTIONARY / RLE_DICTIONARY, RLE
+// (booleans), DELTA_BINARY_PACKED and DELTA_LENGTH_BYTE_ARRAY (block headers on the host, the deltas unpacked and prefix-summed by one
+// wave per page: pq_delta), DELTA_BYTE_ARRAY (a prefix chain: expanded by the host while it walks the page); BOOLEAN, INT32, INT64,
+// INT96 (→ the decimal text of its 96 bits), FLOAT, DOUBLE, BYTE_ARRAY, FIXED_LEN_BYTE_ARRAY; the DATE / TIMESTAMP / INT / DECIMAL
+// annotations as abstract.Restore treats their values; UNCOMPRESSED, SNAPPY, GZIP, ZSTD and LZ4_RAW pages (a compressed object's pages
+// are inflated on the host while it walks them — it reads the run headers there anyway — and the device image is then the inflated
+// payloads instead of the file).  BYTE_STREAM_SPLIT and the other codecs are refused by name (TFGPU_ERR_UNSUPPORTED).  Every length,
+// offset and dictionary index the object states is checked against the bytes that are there — on the host where it walks them, on
+// the device where the values are (an error word read back at the existing sync): a corrupt object is TFGPU_ERR_INVALID, never an
+// out-of-bounds read.
+// PARITY: the schema resolver (parquet_schema_resolver.go:81-158) and the value mapping (parseParquetField, abstract.Restore) are pinned
+// to the reference's own reader canon — 30 files under tests/canon/s3/parquet/canondata, extracted into tests/golden/parquet_reader.json
+// and reproduced on inputs re-created from the canon's values (tests/test_parquet_canon.py): the 20 flat files value for value, the
+// 10 with nested columns refused by name.  The page decoder stands against pyarrow's reading of the same bytes (tests/test_parquet.py):
+// parquet-go itself is not under /root/reference.
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -84,27 +91,75 @@ struct TReader {
 };
 
 enum { T_BOOLEAN = 0, T_INT32 = 1, T_INT64 = 2, T_INT96 = 3, T_FLOAT = 4, T_DOUBLE = 5, T_BYTE_ARRAY = 6, T_FLBA = 7 };
-enum { E_PLAIN = 0, E_PLAIN_DICT = 2, E_RLE = 3, E_RLE_DICT = 8 };
-enum { L_NONE = 0, L_STRING = 1, L_DATE = 6 };
+enum { E_PLAIN = 0, E_PLAIN_DICT = 2, E_RLE = 3, E_DELTA_BINARY_PACKED = 5, E_DELTA_LENGTH_BYTE_ARRAY = 6, E_DELTA_BYTE_ARRAY = 7, E_RLE_DICT = 8 };
+// LogicalType's union members (parquet.thrift)
+enum { L_NONE = 0, L_STRING = 1, L_MAP = 2, L_LIST = 3, L_ENUM = 4, L_DECIMAL = 5, L_DATE = 6, L_TIME = 7, L_TIMESTAMP = 8, L_INTEGER = 10, L_UNKNOWN = 11, L_JSON = 12, L_BSON = 13, L_UUID = 14, L_FLOAT16 = 15 };
 
-struct SchemaEl { int type = -1, rep = 0, conv = -1, nchildren = 0, logical = L_NONE; std::string name; };
-struct ColChunk { int type = -1, codec = 0; int64_t num_values = 0, data_off = -1, dict_off = -1, total_comp = 0; std::vector<std::string> path; };
+struct SchemaEl {
+  int type = -1, type_len = 0, rep = 0, conv = -1, nchildren = 0, logical = L_NONE;
+  int scale = 0, precision = 0;          // DECIMAL (the logical type's, else the element's own fields 7 / 8)
+  int int_bits = 0; bool int_signed = true;  // INTEGER
+  bool utc = true; int unit = 0;         // TIME / TIMESTAMP: 1 MILLIS, 2 MICROS, 3 NANOS
+  std::string name;
+};
+struct ColChunk { int type = -1, codec = 0; int64_t num_values = 0, data_off = -1, dict_off = -1, total_comp = 0, total_uncomp = 0; std::vector<std::string> path; };
 struct RowGroup { int64_t num_rows = 0; std::vector<ColChunk> cols; };
 struct FileMeta { std::vector<SchemaEl> schema; std::vector<RowGroup> groups; int64_t num_rows = 0; };
 
+static void parse_logical(TReader &r, SchemaEl &s) {  // the union's set member, with the fields the type strings and the resolver read
+  int lid = 0;
+  for (;;) {
+    const int lt = r.field(lid);
+    if (!lt || !r.ok) break;
+    s.logical = lid;
+    if (lt != 12) { r.skip(lt); continue; }
+    int fid = 0;
+    for (;;) {
+      const int ft = r.field(fid);
+      if (!ft || !r.ok) break;
+      if (lid == L_DECIMAL && fid == 1) s.scale = (int)r.zz();
+      else if (lid == L_DECIMAL && fid == 2) s.precision = (int)r.zz();
+      else if (lid == L_INTEGER && fid == 1) { if (r.p < r.e) s.int_bits = (int8_t)*r.p++; else r.ok = false; }
+      else if (lid == L_INTEGER && fid == 2) s.int_signed = ft == 1;
+      else if ((lid == L_TIME || lid == L_TIMESTAMP) && fid == 1) s.utc = ft == 1;
+      else if ((lid == L_TIME || lid == L_TIMESTAMP) && fid == 2 && ft == 12) { int uid = 0; for (;;) { const int ut = r.field(uid); if (!ut || !r.ok) break; s.unit = uid; r.skip(ut); } }
+      else r.skip(ft);
+    }
+  }
+}
 static void parse_schema_el(TReader &r, SchemaEl &s) {
-  int id = 0;
+  int id = 0, el_scale = 0, el_precision = 0;
   for (;;) {
     const int t = r.field(id);
     if (!t || !r.ok) break;
     switch (id) {
       case 1: s.type = (int)r.zz(); break;
+      case 2: s.type_len = (int)r.zz(); break;
       case 3: s.rep = (int)r.zz(); break;
       case 4: s.name = r.binary(); break;
       case 5: s.nchildren = (int)r.zz(); break;
       case 6: s.conv = (int)r.zz(); break;
-      case 10: { int lid = 0; for (;;) { const int lt = r.field(lid); if (!lt || !r.ok) break; s.logical = lid; r.skip(lt); } break; }  // the union's set member
+      case 7: el_scale = (int)r.zz(); break;
+      case 8: el_precision = (int)r.zz(); break;
+      case 10: parse_logical(r, s); break;
       default: r.skip(t);
+    }
+  }
+  // A leaf that carries only the legacy converted type is typed by it (parquet-go builds the node's Type from whichever annotation
+  // is there — the canon's fixed_length_decimal_legacy prints DECIMAL(13,2)); a GROUP is not (the canon's datapage_v2 `e` stays "group").
+  if (s.nchildren == 0 && (s.logical == L_NONE || s.logical == L_UNKNOWN) && s.conv >= 0) {
+    switch (s.conv) {
+      case 0: s.logical = L_STRING; break;
+      case 4: s.logical = L_ENUM; break;
+      case 5: s.logical = L_DECIMAL; s.scale = el_scale; s.precision = el_precision; break;
+      case 6: s.logical = L_DATE; break;
+      case 7: case 8: s.logical = L_TIME; s.utc = true; s.unit = s.conv == 7 ? 1 : 2; break;
+      case 9: case 10: s.logical = L_TIMESTAMP; s.utc = true; s.unit = s.conv == 9 ? 1 : 2; break;
+      case 11: case 12: case 13: case 14: s.logical = L_INTEGER; s.int_signed = false; s.int_bits = 8 << (s.conv - 11); break;
+      case 15: case 16: case 17: case 18: s.logical = L_INTEGER; s.int_signed = true; s.int_bits = 8 << (s.conv - 15); break;
+      case 19: s.logical = L_JSON; break;
+      case 20: s.logical = L_BSON; break;
+      default: break;
     }
   }
 }
@@ -118,12 +173,82 @@ static void parse_col_meta(TReader &r, ColChunk &c) {
       case 3: { int et; uint32_t n; r.list(et, n); for (uint32_t i = 0; i < n && r.ok; i++) c.path.push_back(r.binary()); break; }
       case 4: c.codec = (int)r.zz(); break;
       case 5: c.num_values = r.zz(); break;
+      case 6: c.total_uncomp = r.zz(); break;
       case 7: c.total_comp = r.zz(); break;
       case 9: c.data_off = r.zz(); break;
       case 11: c.dict_off = r.zz(); break;
       default: r.skip(t);
     }
   }
+}
+
+// ---- the file's top-level fields, as the reference's resolver and row reader see them ---------------------------------------
+// parquet_schema_resolver.go:92-153 walks meta.Schema().Fields(): a leaf is typed by its physical type, then its logical type,
+// then its converted type; a group is TypeAny.  OriginalType = "parquet:" + el.Type().String().  The strings of DECIMAL(p,s),
+// STRING, INT32 … FIXED_LEN_BYTE_ARRAY(n), group and LIST are pinned by the reference's reader canon (tests/golden/parquet_reader.json);
+// INT(bits,signed), TIME(…) and TIMESTAMP(…) restate parquet-go's format package and are not.
+struct TopField {
+  SchemaEl el;
+  bool group = false;
+  int leaf = -1;        // index of the leaf's column chunk in a row group (leaves in depth-first order)
+  int dtype = TFGPU_T_ANY;
+  std::string type_string;
+};
+static bool top_fields(const FileMeta &m, std::vector<TopField> &out, int &nleaves, std::string &why) {
+  if (m.schema.empty()) { why = "empty schema"; return false; }
+  size_t at = 1;
+  nleaves = 0;
+  // leaves under schema[at] (inclusive), advancing `at`; depth-guarded (a hostile footer must not take the host's stack)
+  struct Walk { const FileMeta &m; size_t &at; int &nleaves; bool ok = true;
+    void sub(int depth) {
+      if (at >= m.schema.size() || depth > 64) { ok = false; return; }
+      const SchemaEl &e = m.schema[at++];
+      if (e.nchildren <= 0) { nleaves++; return; }
+      for (int i = 0; i < e.nchildren && ok; i++) sub(depth + 1);
+    } } w{m, at, nleaves};
+  for (int i = 0; i < m.schema[0].nchildren; i++) {
+    if (at >= m.schema.size()) { why = "schema tree runs past its elements"; return false; }
+    TopField f;
+    f.el = m.schema[at];
+    if (f.el.nchildren > 0 || f.el.rep == 2) {  // a group — or a repeated leaf, which is a list of its values
+      f.group = true;
+      f.type_string = f.el.nchildren > 0 ? (f.el.logical == L_LIST ? "LIST" : f.el.logical == L_MAP ? "MAP" : "group") : "";
+      const int before = nleaves;
+      w.sub(0);
+      if (!w.ok) { why = "schema tree runs past its elements"; return false; }
+      f.leaf = before;
+    } else {
+      f.leaf = nleaves++;
+      at++;
+    }
+    out.push_back(f);
+  }
+  if (at != m.schema.size()) { why = "schema elements outside the tree"; return false; }
+  static const char *phys[] = {"BOOLEAN", "INT32", "INT64", "INT96", "FLOAT", "DOUBLE", "BYTE_ARRAY", "FIXED_LEN_BYTE_ARRAY"};
+  static const int phys_t[] = {TFGPU_T_BOOLEAN, TFGPU_T_INT32, TFGPU_T_INT64, TFGPU_T_UTF8, TFGPU_T_FLOAT32, TFGPU_T_FLOAT64, TFGPU_T_BYTES, TFGPU_T_BYTES};
+  static const char *units[] = {"", "MILLIS", "MICROS", "NANOS"};
+  for (auto &f : out) {
+    const SchemaEl &e = f.el;
+    if (f.group) { f.dtype = TFGPU_T_ANY; if (f.type_string.empty()) f.type_string = (e.type >= 0 && e.type <= 7) ? phys[e.type] : "group"; continue; }
+    if (e.type < 0 || e.type > 7) { why = "column " + e.name + ": unknown physical type"; return false; }
+    f.dtype = phys_t[e.type];
+    f.type_string = e.type == T_FLBA ? "FIXED_LEN_BYTE_ARRAY(" + std::to_string(e.type_len) + ")" : phys[e.type];
+    switch (e.logical) {
+      case L_DATE: f.dtype = TFGPU_T_DATE; f.type_string = "DATE"; break;
+      case L_STRING: f.dtype = TFGPU_T_UTF8; f.type_string = "STRING"; break;
+      case L_INTEGER: f.dtype = e.int_signed ? TFGPU_T_INT64 : TFGPU_T_UINT64; f.type_string = "INT(" + std::to_string(e.int_bits) + "," + (e.int_signed ? "true" : "false") + ")"; break;
+      case L_DECIMAL: f.dtype = TFGPU_T_FLOAT64; f.type_string = "DECIMAL(" + std::to_string(e.precision) + "," + std::to_string(e.scale) + ")"; break;  // (> 8 digits: TypeString, then the converted type DECIMAL every decimal node also has makes it Float64)
+      case L_TIMESTAMP: f.dtype = TFGPU_T_TIMESTAMP; f.type_string = std::string("TIMESTAMP(isAdjustedToUTC=") + (e.utc ? "true" : "false") + ",unit=" + units[e.unit & 3] + ")"; break;
+      case L_TIME: f.type_string = std::string("TIME(isAdjustedToUTC=") + (e.utc ? "true" : "false") + ",unit=" + units[e.unit & 3] + ")"; break;
+      case L_UUID: f.dtype = TFGPU_T_UTF8; f.type_string = "UUID"; break;
+      case L_ENUM: f.dtype = TFGPU_T_UTF8; f.type_string = "ENUM"; break;
+      case L_JSON: f.type_string = "JSON"; break;
+      case L_BSON: f.type_string = "BSON"; break;
+      case L_FLOAT16: f.type_string = "FLOAT16"; break;
+      default: break;
+    }
+  }
+  return true;
 }
 static bool parse_footer(const uint8_t *f, uint64_t len, FileMeta &m, std::string &why) {
   if (len < 12 || std::memcmp(f, "PAR1", 4) || std::memcmp(f + len - 4, "PAR1", 4)) { why = "not a Parquet file (PAR1 magic)"; return false; }
@@ -245,24 +370,112 @@ static bool zstd_inflate(const uint8_t *p, uint64_t n, uint8_t *out, uint64_t us
   if (iserr(got) || got != usize) { why = "malformed ZSTD page"; return false; }
   return true;
 }
-enum { C_UNCOMPRESSED = 0, C_SNAPPY = 1, C_GZIP = 2, C_ZSTD = 6 };
+// LZ4's block format (lz4_Block_format.md) — the LZ4_RAW codec: sequences of (token, literals, 2-byte offset, match).  false: malformed
+// or not `usize` bytes.
+static bool lz4_raw_inflate(const uint8_t *p, const uint8_t *e, uint8_t *out, uint64_t usize) {
+  uint64_t o = 0;
+  while (p < e) {
+    const uint32_t tok = *p++;
+    uint64_t lit = tok >> 4;
+    if (lit == 15) { uint8_t b; do { if (p >= e) return false; b = *p++; lit += b; } while (b == 255); }
+    if (lit > (uint64_t)(e - p) || lit > usize - o) return false;
+    std::memcpy(out + o, p, (size_t)lit); p += lit; o += lit;
+    if (p == e) break;  // the last sequence is literals only
+    if (e - p < 2) return false;
+    const uint64_t off = (uint64_t)p[0] | (uint64_t)p[1] << 8; p += 2;
+    uint64_t ml = tok & 15;
+    if (ml == 15) { uint8_t b; do { if (p >= e) return false; b = *p++; ml += b; } while (b == 255); }
+    ml += 4;
+    if (off == 0 || off > o || ml > usize - o) return false;
+    for (uint64_t i = 0; i < ml; i++) out[o + i] = out[o - off + i];  // (may overlap)
+    o += ml;
+  }
+  return o == usize;
+}
+enum { C_UNCOMPRESSED = 0, C_SNAPPY = 1, C_GZIP = 2, C_ZSTD = 6, C_LZ4_RAW = 7 };
 static bool page_inflate(int codec, const uint8_t *p, uint64_t n, uint8_t *out, uint64_t usize, std::string &why) {
   switch (codec) {
     case C_UNCOMPRESSED: if (n != usize) { why = "page sizes disagree"; return false; } std::memcpy(out, p, (size_t)n); return true;
     case C_SNAPPY: if (!snappy_inflate(p, p + n, out, usize)) { why = "malformed SNAPPY page"; return false; } return true;
     case C_GZIP: return gzip_inflate(p, n, out, usize, why);
     case C_ZSTD: return zstd_inflate(p, n, out, usize, why);
+    case C_LZ4_RAW: if (!lz4_raw_inflate(p, p + n, out, usize)) { why = "malformed LZ4_RAW page"; return false; } return true;
     default: why = "codec " + std::to_string(codec); return false;
   }
 }
+// What `csize` compressed bytes can at most inflate to: the page header's uncompressed_page_size is the object's own claim, and the
+// arena is sized from it BEFORE a byte has been inflated — a few KB of headers each claiming 2 GiB must not make the host zero-fill
+// gigabytes.  Ratios of the formats: snappy copies 64 bytes per 3-byte element, LZ4 255 bytes per extra length byte, deflate 1032 : 1,
+// zstd an RLE block of 128 KiB from 4 bytes.
+static uint64_t max_inflated(int codec, uint64_t csize) {
+  switch (codec) {
+    case C_UNCOMPRESSED: return csize;
+    case C_SNAPPY: return 64 + csize * 22;
+    case C_LZ4_RAW: return 64 + csize * 255;
+    case C_GZIP: return 4096 + csize * 1032;
+    default: return 131072 + csize * 32768;
+  }
+}
+
+// DELTA_BINARY_PACKED (Encodings.md): <block size> <miniblocks per block> <total count> <first value: zigzag> then blocks of
+// <min delta: zigzag> <bit width per miniblock> <miniblocks>.  The host walks the HEADERS only: where every miniblock's bits are, its
+// width and its block's min delta — the deltas themselves are unpacked and prefix-summed on the device (pq_delta), one wave per page.
+struct DMini { uint64_t at; int64_t min_delta; uint32_t count, bw; };        // `count` live values of this miniblock (the last one is padded)
+struct DStream { int64_t first; uint64_t total; size_t mini0, mini1; const uint8_t *end; };  // minis [mini0, mini1) of `minis`; end: one past the stream
+static bool delta_headers(const uint8_t *fb, const uint8_t *p, const uint8_t *e, std::vector<DMini> &minis, DStream &ds) {
+  TReader r{p, e};
+  const uint64_t block = r.varint(), mpb = r.varint(), total = r.varint();
+  const int64_t first = r.zz();
+  if (!r.ok || mpb == 0 || mpb > 4096 || block == 0 || block % 128 || block % mpb || (block / mpb) % 32 || total > 0x7FFFFFF0ull) return false;
+  const uint64_t vpm = block / mpb;
+  ds.first = first; ds.total = total; ds.mini0 = minis.size();
+  uint64_t left = total ? total - 1 : 0;
+  while (left) {
+    const int64_t md = r.zz();
+    if (!r.ok || (uint64_t)(r.e - r.p) < mpb) return false;
+    const uint8_t *bws = r.p;
+    r.p += mpb;
+    for (uint64_t j = 0; j < mpb && left; j++) {
+      const uint32_t bw = bws[j];
+      if (bw > 64) return false;
+      const uint64_t nbytes = vpm * bw / 8;
+      if (nbytes > (uint64_t)(r.e - r.p)) return false;
+      const uint64_t n = std::min<uint64_t>(vpm, left);
+      minis.push_back(DMini{(uint64_t)(r.p - fb), md, (uint32_t)n, bw});
+      r.p += nbytes; left -= n;
+    }
+  }
+  ds.mini1 = minis.size(); ds.end = r.p;
+  return true;
+}
+// the same stream decoded on the HOST: only for DELTA_BYTE_ARRAY pages, whose values are prefixes of their predecessors — a chain the
+// host expands into plain length-prefixed values while it walks the page (the rare encoding of sorted string columns)
+static bool delta_decode_host(const uint8_t *fb, const std::vector<DMini> &minis, const DStream &ds, std::vector<int64_t> &out) {
+  out.clear();
+  if (!ds.total) return true;
+  uint64_t v = (uint64_t)ds.first;
+  out.push_back((int64_t)v);
+  for (size_t m = ds.mini0; m < ds.mini1; m++) {
+    const DMini &mi = minis[m];
+    for (uint32_t i = 0; i < mi.count; i++) {
+      uint64_t d = 0;
+      const uint64_t bit = (uint64_t)i * mi.bw;
+      for (uint32_t b = 0; b < mi.bw; b++) { const uint64_t q = bit + b; d |= (uint64_t)((fb[mi.at + (q >> 3)] >> (q & 7)) & 1) << b; }
+      v += d + (uint64_t)mi.min_delta;
+      out.push_back((int64_t)v);
+    }
+  }
+  return out.size() == ds.total;
+}
 
 // ---- the segment table a column's rows / values look themselves up in ----------------------------------------------------
-enum : uint32_t { SG_RLE = 0, SG_PACKED = 1, SG_PLAIN = 2, SG_PLAIN_BOOL = 3, SG_PLAIN_TEXT = 4 };
+enum : uint32_t { SG_RLE = 0, SG_PACKED = 1, SG_PLAIN = 2, SG_PLAIN_BOOL = 3, SG_PLAIN_TEXT = 4, SG_FIXED_TEXT = 5 /* FIXED_LEN_BYTE_ARRAY: value k at `at` + k * bw */ };
 struct Seg {
   uint32_t start, count;   // first ordinal (levels: row of the column; values: ordinal among the present values) and length
   uint32_t kind, bw;       // SG_*; bit width of packed values
   uint64_t at;             // file offset of the packed bits / plain bytes; SG_RLE: the run's value
-  uint32_t dict_base, pad; // dictionary indices: first entry of this chunk's dictionary in the column's concatenated dictionary
+  uint32_t dict_base;      // dictionary indices: first entry of this chunk's dictionary in the column's concatenated dictionary
+  uint32_t in_tail;        // 1: `at` counts from the image's TAIL (values a kernel decoded there: DELTA_BINARY_PACKED pages)
 };
 // host: RLE / bit-packed hybrid run headers of [p, e) holding `total` values of width bw; appends segments with ordinals from `ord`
 static bool hybrid_runs(const uint8_t *file, const uint8_t *p, const uint8_t *e, uint32_t bw, uint64_t total, uint64_t ord, uint32_t dict_base, std::vector<Seg> &out, uint64_t *ones) {
@@ -327,33 +540,154 @@ __global__ void __launch_bounds__(256) pq_pack_validity(const uint32_t *rank, in
   for (int j = 0; j < 8; j++) { const int64_t r = b * 8 + j; if (r < nrows && rank[r + 1] != rank[r]) v |= 1u << j; }
   bits[b] = (uint8_t)v;
 }
-struct FixedOut { void *values; int32_t width; int32_t as_date; };
+// What abstract.Restore (pkg/abstract/restore.go:20-260) makes of the physical value under the column's DataType — the cases a Parquet
+// value can meet: float32 under "double" → float64; an int32 under "int64" → cast.ToInt64; an int32 / int64 under "uint64" →
+// cast.ToUint64 (a negative value does not cast: 0); an int64 under "timestamp" → ytschema.Timestamp(v).Time(): MICROseconds
+// whatever unit the file states; DATE (parseLogicalDate, reader_parquet.go:285-297) → time.Unix(0, 0).Add(24h * days).
+enum : int32_t { CV_SAME = 0, CV_DATE = 1, CV_TS_MICROS = 2, CV_I32_I64 = 3, CV_I32_U64 = 4, CV_I64_U64 = 5, CV_F32_F64 = 6 };
+struct FixedOut { void *values; int32_t *nanos; int32_t in_width, out_width, conv; };
 // what the object's own numbers may not exceed, checked where the values are read (the error word is read back at the sync)
 enum : uint32_t { PQE_DICT_INDEX = 1, PQE_TEXT_LENGTH = 2 };
-// one row: its value by ordinal — PLAIN bytes, or a dictionary index into dict (fixed-width entries, file offsets of the chunks' PLAIN dictionary pages)
-__global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint64_t *dict_at, const uint32_t *dict_n, FixedOut o, uint32_t *err) {
+// one row: its value by ordinal — PLAIN bytes (of the file, or of the tail a DELTA page was decoded into), or a dictionary index into
+// dict (fixed-width entries, file offsets of the chunks' PLAIN dictionary pages)
+__global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, uint64_t tail_base, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint64_t *dict_at, const uint32_t *dict_n, FixedOut o, uint32_t *err) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   const uint32_t k = rank[r];
   uint64_t v = 0;
+  int32_t ns = 0;
   if (rank[r + 1] != k) {
     const Seg &s = find_seg(segs, nsegs, k);
-    const uint32_t w = (uint32_t)(o.as_date ? 4 : o.width);
-    if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (uint64_t)(k - s.start) * w, w);
+    const uint32_t w = (uint32_t)o.in_width;
+    if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (s.in_tail ? tail_base : 0) + (uint64_t)(k - s.start) * w, w);
     else if (s.kind == SG_PLAIN_BOOL) v = (file[s.at + ((k - s.start) >> 3)] >> ((k - s.start) & 7)) & 1;
     else {
       const uint32_t idx = seg_value(file, s, k);
-      if (o.width == 1 && !dict_at) v = idx;  // (booleans under RLE are their own values)
+      if (o.in_width == 1 && !dict_at) v = idx;  // (booleans under RLE are their own values)
       else if (idx >= dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // an index past the chunk's dictionary: the value stays 0, the call fails
       else v = load_unaligned(file, dict_at[s.dict_base] + (uint64_t)idx * w, w);
     }
-    if (o.as_date) v = (uint64_t)((int64_t)(int32_t)v * 86400);  // parseLogicalDate: time.Unix(0, 0).Add(24h * days)
+    switch (o.conv) {
+      case CV_DATE: v = (uint64_t)((int64_t)(int32_t)v * 86400); break;
+      case CV_TS_MICROS: { const int64_t us = (int64_t)v; int64_t sec = us / 1000000, rem = us % 1000000; if (rem < 0) { rem += 1000000; sec--; } v = (uint64_t)sec; ns = (int32_t)(rem * 1000); break; }
+      case CV_I32_I64: v = (uint64_t)(int64_t)(int32_t)v; break;
+      case CV_I32_U64: v = (int32_t)v < 0 ? 0 : (uint64_t)(int32_t)v; break;
+      case CV_I64_U64: v = (int64_t)v < 0 ? 0 : v; break;
+      case CV_F32_F64: v = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)v)); break;
+      default: break;
+    }
   }
-  switch (o.width) {
+  switch (o.out_width) {
     case 1: ((uint8_t *)o.values)[r] = (uint8_t)v; break;
     case 4: ((uint32_t *)o.values)[r] = (uint32_t)v; break;
     default: ((uint64_t *)o.values)[r] = v;
   }
+  if (o.nanos) o.nanos[r] = ns;
+}
+// DELTA_BINARY_PACKED / DELTA_LENGTH_BYTE_ARRAY pages: ONE WAVE per page walks its miniblocks in order; a miniblock's deltas are
+// unpacked one per lane (any width up to 64 bits), prefix-summed across the wave (wrapping 64-bit adds, as the format says) and carried
+// into the next one.  mode 0: value i → `width` bytes at tail[out_at + i * width] (the column's PLAIN values of this page);
+// mode 1: the values are LENGTHS of a DELTA_LENGTH_BYTE_ARRAY page → val_len[ord + i], val_off[ord + i] = data_at + their running sum
+// (a length that is negative or runs past `data_end` empties the rest of the page and fails the call).
+struct DPage { int64_t first; uint64_t out_at, data_at, data_end; uint32_t total, mini0, mini1, mode, width, ord, pad0, pad1; };
+__global__ void __launch_bounds__(256) pq_delta(const uint8_t *file, uint8_t *tail, const DMini *minis, const DPage *pages, int32_t npages, uint32_t *val_off, uint32_t *val_len, uint32_t *err) {
+  const int lane = threadIdx.x & 63;
+  const int32_t pi = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (pi >= npages) return;
+  const DPage pg = pages[pi];
+  if (!pg.total) return;
+  uint64_t run = (uint64_t)pg.first;   // the last decoded value
+  uint64_t pos = pg.data_at;           // mode 1: where the next value's bytes start
+  bool bad = false;                    // mode 1: a length ran past the page — this value and the rest read as empty
+  auto put = [&](uint32_t i, uint64_t v, uint64_t at, bool empty) {  // value i of the page
+    if (pg.mode == 0) {
+      if (pg.width == 4) *reinterpret_cast<uint32_t *>(tail + pg.out_at + (uint64_t)i * 4) = (uint32_t)v;
+      else *reinterpret_cast<uint64_t *>(tail + pg.out_at + (uint64_t)i * 8) = v;
+    } else { val_len[pg.ord + i] = empty ? 0u : (uint32_t)v; val_off[pg.ord + i] = empty ? (uint32_t)pg.data_at : (uint32_t)at; }
+  };
+  if (pg.mode == 1 && ((int64_t)run < 0 || run > pg.data_end - pos)) bad = true;
+  if (lane == 0) put(0, run, pos, bad);
+  if (pg.mode == 1 && !bad) pos += run;
+  uint32_t done = 1;
+  for (uint32_t m = pg.mini0; m < pg.mini1; m++) {
+    const DMini mi = minis[m];
+    for (uint32_t b = 0; b < mi.count; b += 64) {
+      const uint32_t i = b + lane;
+      const bool live = i < mi.count;
+      uint64_t d = 0;
+      if (live) {
+        if (mi.bw) {
+          const uint64_t bit = (uint64_t)i * mi.bw;
+          d = seg_read8(file, mi.at + (bit >> 3)) >> (bit & 7);
+          if ((bit & 7) + mi.bw > 64) d |= (uint64_t)file[mi.at + (bit >> 3) + 8] << (64 - (bit & 7));
+          if (mi.bw < 64) d &= (1ull << mi.bw) - 1;
+        }
+        d += (uint64_t)mi.min_delta;
+      }
+      uint64_t inc = d;  // inclusive scan of the deltas across the wave (dead lanes add 0)
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) { const uint64_t t = __shfl_up(inc, sh, 64); if (lane >= sh) inc += t; }
+      const uint64_t v = run + inc;
+      const uint32_t n = mi.count - b < 64 ? mi.count - b : 64;
+      if (pg.mode == 0) { if (live) put(done + lane, v, 0, false); }
+      else {
+        // the values are lengths: their own running sum places the bytes
+        const bool mine_bad = live && ((int64_t)v < 0 || v > 0xFFFFFFFFull);
+        const uint64_t len = live && !mine_bad ? v : 0;
+        uint64_t lsum = len;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) { const uint64_t t = __shfl_up(lsum, sh, 64); if (lane >= sh) lsum += t; }
+        const uint64_t at = pos + lsum - len;
+        const bool over = live && (mine_bad || at > pg.data_end || len > pg.data_end - at);
+        const unsigned long long anybad = __ballot(over);
+        const int first_bad = bad ? 0 : (anybad ? __ffsll(anybad) - 1 : 64);
+        if (live) put(done + lane, v, at, lane >= first_bad);
+        if (anybad) bad = true;
+        pos += __shfl(lsum, (int)n - 1, 64);
+      }
+      run = __shfl(v, (int)n - 1, 64);
+      done += n;
+    }
+  }
+  if (bad && lane == 0) *err = PQE_TEXT_LENGTH;
+}
+// INT96 → the text of deprecated.Int96.String() (parseParquetField, reader_parquet.go:303-305): the 96-bit two's-complement integer
+// (nanoseconds of the day in the low 64 bits, the Julian day above them) in decimal.  One row per lane: the 12 bytes by ordinal (PLAIN
+// or through the chunk's dictionary), at most 29 digits and a sign into the row's 32-byte slot of the tail; the packing copy reads it there.
+__global__ void __launch_bounds__(256) pq_int96_text(const uint8_t *file, uint8_t *tail, uint64_t tail_base, uint64_t slot0, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows,
+                                                     const uint64_t *dict_at, const uint32_t *dict_n, uint32_t *src_off, uint32_t *lens, uint32_t *err) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const uint32_t k = rank[r];
+  if (rank[r + 1] == k) { src_off[r] = SEG_NONE; lens[r] = 0; return; }
+  const Seg &s = find_seg(segs, nsegs, k);
+  uint64_t at = 0; bool ok = true;
+  if (s.kind == SG_PLAIN) at = s.at + (uint64_t)(k - s.start) * 12;
+  else { const uint32_t idx = seg_value(file, s, k); if (idx >= dict_n[s.dict_base]) { *err = PQE_DICT_INDEX; ok = false; } else at = dict_at[s.dict_base] + (uint64_t)idx * 12; }
+  uint32_t w0 = 0, w1 = 0, w2 = 0;
+  if (ok) { const uint64_t lo = seg_read8(file, at); w0 = (uint32_t)lo; w1 = (uint32_t)(lo >> 32); w2 = (uint32_t)load_unaligned(file, at + 8, 4); }
+  const bool neg = (w2 >> 31) != 0;
+  if (neg) {  // magnitude of the two's-complement value
+    w0 = ~w0; w1 = ~w1; w2 = ~w2;
+    if (++w0 == 0) if (++w1 == 0) ++w2;
+  }
+  char dig[40]; int nd = 0;
+  while (w0 | w1 | w2) {  // long division by 10^9, nine digits a round
+    uint64_t rem = 0, cur;
+    cur = (rem << 32) | w2; w2 = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u;
+    cur = (rem << 32) | w1; w1 = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u;
+    cur = (rem << 32) | w0; w0 = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u;
+    uint32_t part = (uint32_t)rem;
+    const bool more = (w0 | w1 | w2) != 0;
+    for (int j = 0; j < 9 && (more || part || j == 0); j++) { dig[nd++] = (char)('0' + part % 10); part /= 10; }
+  }
+  if (!nd) dig[nd++] = '0';
+  uint8_t *dst = tail + slot0 + (uint64_t)r * 32;
+  int n = 0;
+  if (neg) dst[n++] = '-';
+  for (int j = nd - 1; j >= 0; j--) dst[n++] = (uint8_t)dig[j];
+  src_off[r] = (uint32_t)(tail_base + slot0 + (uint64_t)r * 32);
+  lens[r] = (uint32_t)n;
 }
 // PLAIN byte arrays are length-prefixed: the position of value i + 1 is known only after the length of value i has been read, a
 // chain no amount of lanes shortens.  What CAN be shortened is each link: one workgroup per page stages the page through LDS
@@ -405,6 +739,7 @@ __global__ void __launch_bounds__(256) pq_text_cells(const uint8_t *file, const 
   if (live && rank[r + 1] != k) {
     const Seg &s = find_seg(segs, nsegs, k);
     if (s.kind == SG_PLAIN_TEXT) { so = val_off[k]; n = val_len[k]; }
+    else if (s.kind == SG_FIXED_TEXT) { so = (uint32_t)(s.at + (uint64_t)(k - s.start) * s.bw); n = s.bw; }
     else {
       const uint32_t i = seg_value(file, s, k);
       if (i >= dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // dict_n[first entry of a chunk's dictionary] = its entries
@@ -425,6 +760,17 @@ __global__ void __launch_bounds__(256) pq_pack_text(const uint32_t *dst_off, int
   segcopy_run<RPT>(dst_off, nrows, k0, file, dst, [&](int64_t r) { return src_off[r]; }, doff, soff);
 }
 
+__global__ void __launch_bounds__(256) pq_row_index(uint64_t *v, int64_t nrows) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrows) v[r] = (uint64_t)r + 1;
+}
+__global__ void __launch_bounds__(256) pq_file_name(const uint8_t *name, uint32_t n, int64_t nrows, uint32_t *off, uint8_t *data) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nrows) return;
+  off[r] = (uint32_t)((uint64_t)r * n);
+  if (r < nrows) for (uint32_t i = 0; i < n; i++) data[(uint64_t)r * n + i] = name[i];
+}
+
 }  // namespace pq
 }  // namespace tf
 
@@ -438,97 +784,120 @@ using namespace tf::pq;
   catch (const std::bad_alloc &) { return tf::fail(TFGPU_ERR_NOMEM, "out of host memory"); } \
   catch (const std::exception &e) { return tf::fail(TFGPU_ERR_INVALID, e.what()); }
 
-extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out) {
-  TF_API_BEGIN
-  if (!bytes || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: null argument");
-  if (mem != TFGPU_MEM_HOST) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the footer and the page headers are walked on the host: pass the object in host memory (pinned for an asynchronous upload)");
-  if (len >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: objects of 4 GiB and more: read them row group by row group");
-  const uint8_t *f = static_cast<const uint8_t *>(bytes);
+struct NeedArena {};  // thrown by the walk when a page must be rewritten on the host (DELTA_BYTE_ARRAY) and the object was to be uploaded as it is
+
+static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, bool force_arena, tfgpu_dbatch **out) {
   FileMeta m; std::string why;
   if (!parse_footer(f, len, m, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: " + why);
   PQD("footer: %zu schema els, %zu groups, %lld rows\n", m.schema.size(), m.groups.size(), (long long)m.num_rows);
-  if (m.schema.empty()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: empty schema");
-  // flat schemas: the root and its leaves
-  std::vector<SchemaEl> leaves(m.schema.begin() + 1, m.schema.end());
-  for (auto &s : leaves) if (s.nchildren || s.rep == 2) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + s.name + ": nested / repeated columns are read by the stock reader");
+  std::vector<TopField> fields; int nleaves = 0;
+  if (!top_fields(m, fields, nleaves, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: " + why);
   int64_t nrows = 0;
-  for (auto &g : m.groups) { nrows += g.num_rows; if (g.cols.size() != leaves.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a row group does not hold every leaf column"); }
+  for (auto &g : m.groups) { nrows += g.num_rows; if ((int)g.cols.size() != nleaves) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a row group does not hold every leaf column"); }
   if (nrows > 0x7FFFFFF0ll) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: more than 2^31 rows in one object");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
   hipStream_t st = cx.stream;
-  // An object without compressed chunks is uploaded as it is (the upload runs while the host walks the pages) and every offset
-  // below is a file offset.  With compressed chunks the host inflates each page it walks into `arena`, offsets are arena offsets,
-  // and the arena is what the device gets.
-  bool inflate = false;
+  // An object without compressed chunks is uploaded as it is and every offset below is a file offset.  With compressed chunks (or a
+  // page the host has to rewrite) the host inflates each page it walks into `arena`, offsets are arena offsets, and the arena is
+  // what the device gets.  Either way the device image gets a TAIL behind it: room for what kernels decode for other kernels
+  // (DELTA_BINARY_PACKED values, INT96 texts), sized by the walk.
+  bool inflate = force_arena;
   for (auto &g : m.groups) for (auto &c : g.cols) if (c.codec != C_UNCOMPRESSED) inflate = true;
   std::vector<uint8_t> arena;
-  Buf file;
-  if (!inflate) {
-    file = dalloc((size_t)len + 64);
-    h2d(file->p, f, (size_t)len);
-    TF_HIP(hipMemsetAsync((char *)file->p + len, 0, 64, st));
-  } else arena.reserve((size_t)len * 2);
+  if (inflate) arena.reserve((size_t)len * 2);
 
   auto db = std::make_unique<tfgpu_dbatch>();
   db->nrows = nrows; db->ns = table_ns ? table_ns : ""; db->table = table_name ? table_name : "";
-  std::vector<int> want;  // leaf index per output column (or -1: the file does not have it → nil, reader_parquet.go:256-259)
+  enum { W_NIL = -1, W_FILE_NAME = -2, W_ROW_INDEX = -3 };
+  std::vector<int> want;  // field index per output column, or W_*: the file does not have it → nil (reader_parquet.go:256-259); a system column
   std::vector<std::pair<std::string, int>> outcols;
   if (schema) {
     for (int i = 0; i < schema->ncols; i++) {
       const char *nm = schema->cols[i].name ? schema->cols[i].name : "";
-      int at = -1;
-      for (size_t k = 0; k < leaves.size(); k++) if (leaves[k].name == nm) at = (int)k;
+      int at = W_NIL;
+      for (size_t k = 0; k < fields.size(); k++) if (fields[k].el.name == nm) at = (int)k;
+      // constructCI (reader_parquet.go:243-255): the system columns are the reader's own, whatever the file holds under those names
+      if (file_name && !std::strcmp(nm, "__file_name")) at = W_FILE_NAME;
+      if (file_name && !std::strcmp(nm, "__row_index")) at = W_ROW_INDEX;
       want.push_back(at); outcols.push_back({nm, schema->cols[i].dtype});
       db->schema.push_back({nm, schema->cols[i].dtype});
       if (schema->cols[i].flags & TFGPU_COL_KEY) db->key_names.push_back(nm);
     }
-  } else for (size_t k = 0; k < leaves.size(); k++) { want.push_back((int)k); outcols.push_back({leaves[k].name, -1}); }
+  } else for (size_t k = 0; k < fields.size(); k++) { want.push_back((int)k); outcols.push_back({fields[k].el.name, -1}); }
 
   std::vector<Buf> keep;  // tables the kernels read until the final sync
-  // ---- pass 1 (host, while the object uploads): every column's segment tables ----
+  // ---- pass 1 (host): every column's segment tables ----
   struct ColPlan {
-    DColumn d; bool nil = false, optional = false, is_date = false, is_text = false; uint32_t width = 0;
+    DColumn d; bool nil = false, optional = false, is_text = false, is_int96 = false; uint32_t width = 0; int32_t conv = CV_SAME, out_width = 0;
     std::vector<Seg> lev, val; std::vector<TextPage> tpages; std::vector<uint64_t> dict_at; std::vector<uint32_t> dict_off, dict_len, dict_n;  // dict_n: entries per chunk dictionary (fixed: by chunk; text: at the chunk's first entry)
-    uint64_t ord = 0; size_t arena_at = 0;
+    uint64_t ord = 0; size_t arena_at = 0; uint64_t slot0 = 0;
   };
   std::vector<ColPlan> plans(want.size());
+  std::vector<DMini> minis; std::vector<DPage> dpages;
+  uint64_t tail_need = 0;
+  auto tail_take = [&](uint64_t bytes) { const uint64_t at = tail_need; tail_need += (bytes + 15) & ~15ull; return at; };
   for (size_t oc = 0; oc < want.size(); oc++) {
     ColPlan &P = plans[oc];
     DColumn &d = P.d;
     d.name = outcols[oc].first;
-    if (want[oc] < 0) {  // nil for every row
+    auto all_nil = [&](int dtype) {
       P.nil = true;
-      d.repr = TFGPU_R_STRING; d.dtype = outcols[oc].second >= 0 ? outcols[oc].second : TFGPU_T_UTF8;
+      d.repr = TFGPU_R_STRING; d.dtype = dtype;
       d.offsets = dalloc_zero((size_t)(nrows + 1) * 4); d.data = dalloc(8); d.data_len = 0; d.validity = dalloc_zero((size_t)(nrows + 7) / 8 + 8);
+    };
+    if (want[oc] == W_FILE_NAME || want[oc] == W_ROW_INDEX) { P.nil = true; continue; }  // filled in pass 2
+    if (want[oc] < 0) { all_nil(outcols[oc].second >= 0 ? outcols[oc].second : TFGPU_T_UTF8); continue; }
+    const TopField &fld = fields[(size_t)want[oc]];
+    const SchemaEl &leaf = fld.el;
+    if (fld.group) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": nested / repeated columns (the `any` tree parquet-go builds) are read by the stock reader");
+    PQD("column %s type %d rep %d logical %d conv %d\n", leaf.name.c_str(), leaf.type, leaf.rep, leaf.logical, leaf.conv);
+    const int dtype = outcols[oc].second >= 0 ? outcols[oc].second : fld.dtype;
+    // A DECIMAL is typed `double` by the resolver and its int32 / int64 / []byte value falls to Restore's default: nil in every row
+    // (pinned by the canon's five decimal files).  The pages are not read.
+    if (leaf.logical == L_DECIMAL) {
+      if (dtype != TFGPU_T_FLOAT64) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": a DECIMAL under another DataType than the resolver's double is read by the stock reader");
+      all_nil(dtype);
       continue;
     }
-    const SchemaEl &leaf = leaves[(size_t)want[oc]];
-    PQD("column %s type %d rep %d logical %d conv %d\n", leaf.name.c_str(), leaf.type, leaf.rep, leaf.logical, leaf.conv);
     const bool optional = P.optional = leaf.rep == 1;
-    const bool is_date = P.is_date = leaf.logical == L_DATE || leaf.conv == 6;
-    const bool is_text = P.is_text = leaf.type == T_BYTE_ARRAY;
+    const bool is_date = leaf.logical == L_DATE;
+    const bool is_int96 = P.is_int96 = leaf.type == T_INT96;
+    const bool is_flba = leaf.type == T_FLBA;
+    const bool is_text = P.is_text = leaf.type == T_BYTE_ARRAY || is_flba;
+    if (is_flba && (leaf.type_len <= 0 || leaf.type_len > (1 << 20))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": FIXED_LEN_BYTE_ARRAY length");
+    P.width = leaf.type == T_BOOLEAN ? 1 : (leaf.type == T_INT32 || leaf.type == T_FLOAT) ? 4 : is_int96 ? 12 : is_flba ? (uint32_t)leaf.type_len : 8;
+    P.out_width = (int32_t)P.width;
     switch (leaf.type) {
       case T_BOOLEAN: d.repr = TFGPU_R_BOOL; break;
-      case T_INT32: d.repr = is_date ? TFGPU_R_TIME : TFGPU_R_INT32; break;
-      case T_INT64: d.repr = TFGPU_R_INT64; break;
-      case T_FLOAT: d.repr = TFGPU_R_FLOAT32; break;
+      case T_INT32:
+        if (is_date) { d.repr = TFGPU_R_TIME; P.conv = CV_DATE; P.out_width = 8; }
+        else if (dtype == TFGPU_T_INT64) { d.repr = TFGPU_R_INT64; P.conv = CV_I32_I64; P.out_width = 8; }
+        else if (dtype == TFGPU_T_UINT64) { d.repr = TFGPU_R_UINT64; P.conv = CV_I32_U64; P.out_width = 8; }
+        else d.repr = TFGPU_R_INT32;
+        break;
+      case T_INT64:
+        if (dtype == TFGPU_T_TIMESTAMP) { d.repr = TFGPU_R_TIME; P.conv = CV_TS_MICROS; }
+        else if (dtype == TFGPU_T_UINT64) { d.repr = TFGPU_R_UINT64; P.conv = CV_I64_U64; }
+        else d.repr = TFGPU_R_INT64;
+        break;
+      case T_FLOAT: if (dtype == TFGPU_T_FLOAT64) { d.repr = TFGPU_R_FLOAT64; P.conv = CV_F32_F64; P.out_width = 8; } else d.repr = TFGPU_R_FLOAT32; break;
       case T_DOUBLE: d.repr = TFGPU_R_FLOAT64; break;
-      case T_BYTE_ARRAY: d.repr = (leaf.logical == L_STRING || leaf.conv == 0) ? TFGPU_R_STRING : TFGPU_R_BYTES; break;
-      default: return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": " + (leaf.type == T_INT96 ? "INT96" : "FIXED_LEN_BYTE_ARRAY") + " values are read by the stock reader");
+      // []byte under a "string" / "utf8" column is string(v) (restore.go:222-229) — both BYTE_ARRAY flavours and FIXED_LEN_BYTE_ARRAY;
+      // INT96 is its decimal text
+      default: d.repr = (dtype == TFGPU_T_BYTES || dtype == TFGPU_T_UTF8) ? TFGPU_R_STRING : TFGPU_R_BYTES; break;
     }
-    d.dtype = outcols[oc].second >= 0 ? outcols[oc].second
-              : d.repr == TFGPU_R_BOOL ? TFGPU_T_BOOLEAN : d.repr == TFGPU_R_INT32 ? TFGPU_T_INT32 : d.repr == TFGPU_R_INT64 ? TFGPU_T_INT64 : d.repr == TFGPU_R_FLOAT32 ? TFGPU_T_FLOAT32
-              : d.repr == TFGPU_R_FLOAT64 ? TFGPU_T_FLOAT64 : d.repr == TFGPU_R_TIME ? TFGPU_T_DATE : d.repr == TFGPU_R_STRING ? TFGPU_T_UTF8 : TFGPU_T_BYTES;
-    P.width = leaf.type == T_BOOLEAN ? 1 : (leaf.type == T_INT32 || leaf.type == T_FLOAT) ? 4 : 8;
+    if (is_int96) d.repr = TFGPU_R_STRING;
+    d.dtype = dtype;
+    if (is_int96) P.slot0 = tail_take((uint64_t)std::max<int64_t>(nrows, 1) * 32);
     auto &lev = P.lev; auto &val = P.val; auto &tpages = P.tpages;
     auto &dict_at = P.dict_at;                               // fixed-width dictionaries: file offset of each chunk's entries
     auto &dict_off = P.dict_off; auto &dict_len = P.dict_len;  // byte-array dictionaries: every entry of every chunk
     auto &dict_n = P.dict_n;
     uint64_t row0 = 0; uint64_t &ord = P.ord;
     for (auto &g : m.groups) {
-      const ColChunk &c = g.cols[(size_t)want[oc]];
-      if (c.codec != C_UNCOMPRESSED && c.codec != C_SNAPPY && c.codec != C_GZIP && c.codec != C_ZSTD)
+      const ColChunk &c = g.cols[(size_t)fld.leaf];
+      if (c.codec != C_UNCOMPRESSED && c.codec != C_SNAPPY && c.codec != C_GZIP && c.codec != C_ZSTD && c.codec != C_LZ4_RAW)
         return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": pages of codec " + std::to_string(c.codec) + " (BROTLI / LZ4 / LZO) are read by the stock reader");
       if (c.data_off < 0 || c.total_comp < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column chunk out of range");
       uint64_t pos = (uint64_t)((c.dict_off > 0 && c.dict_off < c.data_off) ? c.dict_off : c.data_off);
@@ -547,12 +916,15 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
         // fb: what offsets are counted from; [pl, pe): the page's payload as the device will see it
         const uint8_t *fb = f, *pl = raw, *pe = raw + h.csize;
         PQD("  page at %llu type %d csize %d usize %d nvalues %d enc %d v2 %d\n", (unsigned long long)pos, h.type, h.csize, h.usize, h.nvalues, h.enc, h.v2);
+        size_t page_at0 = 0;
         if (inflate && (h.type == 0 || h.type == 2 || h.type == 3)) {
           // v2 keeps the levels in front of the (possibly compressed) values; v1 and dictionary pages are compressed whole
           const uint64_t lead = h.type == 3 ? (uint64_t)std::max(h.rep_len, 0) + (uint64_t)std::max(h.def_len, 0) : 0;
           if (lead > (uint64_t)h.csize || lead > (uint64_t)h.usize) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: level lengths of a v2 page in column " + leaf.name);
           const int codec = (h.type == 3 && !h.compressed_v2) ? (int)C_UNCOMPRESSED : c.codec;
-          const size_t at0 = (arena.size() + 15) & ~(size_t)15;
+          if ((uint64_t)h.usize - lead > max_inflated(codec, (uint64_t)h.csize - lead))
+            return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": a page states an uncompressed size its " + std::to_string(h.csize) + " bytes cannot inflate to");
+          const size_t at0 = page_at0 = (arena.size() + 15) & ~(size_t)15;
           if ((uint64_t)at0 + (uint64_t)h.usize + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the inflated pages of one object exceed 4 GiB: read it row group by row group");
           arena.resize(at0 + (size_t)h.usize);
           std::memcpy(arena.data() + at0, raw, (size_t)lead);
@@ -568,11 +940,16 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
             dict_base = (uint32_t)dict_off.size();
             const uint8_t *q = pl;
             for (int i = 0; i < h.nvalues; i++) {
-              if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated dictionary in column " + leaf.name);
-              uint32_t n; std::memcpy(&n, q, 4);
-              if ((uint64_t)n > (uint64_t)(pe - (q + 4))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a dictionary entry of column " + leaf.name + " runs past its page");
-              dict_off.push_back((uint32_t)(q + 4 - fb)); dict_len.push_back(n); dict_n.push_back(0);
-              q += 4 + (uint64_t)n;
+              uint32_t n;
+              if (is_flba) { n = P.width; if ((uint64_t)n > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated dictionary in column " + leaf.name); dict_off.push_back((uint32_t)(q - fb)); q += n; }
+              else {
+                if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated dictionary in column " + leaf.name);
+                std::memcpy(&n, q, 4);
+                if ((uint64_t)n > (uint64_t)(pe - (q + 4))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a dictionary entry of column " + leaf.name + " runs past its page");
+                dict_off.push_back((uint32_t)(q + 4 - fb));
+                q += 4 + (uint64_t)n;
+              }
+              dict_len.push_back(n); dict_n.push_back(0);
             }
             if (h.nvalues) dict_n[dict_base] = (uint32_t)h.nvalues;
             if (!h.nvalues) { dict_off.push_back(0); dict_len.push_back(0); dict_n.push_back(0); }  // an empty dictionary still has a slot that says so
@@ -593,7 +970,10 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
             if (!hybrid_runs(fb, ls, le, 1, (uint64_t)h.nvalues, row0 + (uint64_t)seen, 0, lev, &present)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed definition levels in column " + leaf.name);
           } else if (h.v2 && h.def_len) { if ((uint64_t)h.def_len > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page"); q += h.def_len; }
           if (h.enc == E_PLAIN) {
-            if (is_text) { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)(q - fb), (uint64_t)(pe - fb), (uint32_t)ord, (uint32_t)present}); }
+            if (is_flba) {
+              if (present * P.width > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: the values of a PLAIN page of column " + leaf.name + " run past it");
+              val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_FIXED_TEXT, P.width, (uint64_t)(q - fb), 0, 0});
+            } else if (is_text) { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)(q - fb), (uint64_t)(pe - fb), (uint32_t)ord, (uint32_t)present}); }
             else {
               const uint64_t need = leaf.type == T_BOOLEAN ? (present + 7) / 8 : present * P.width;
               if (need > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: the values of a PLAIN page of column " + leaf.name + " run past it");
@@ -605,14 +985,58 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
             const uint32_t bw = present ? *q : 0;
             if (bw > 32) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: dictionary index width");
             if (present && !hybrid_runs(fb, q + 1, pe, bw, present, ord, dict_base, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed dictionary indices in column " + leaf.name);
-          } else if (h.enc == E_RLE && leaf.type == T_BOOLEAN) {  // booleans of v2 pages: a length-prefixed hybrid of width 1
+          } else if (h.enc == E_RLE && leaf.type == T_BOOLEAN) {  // RLE booleans: a length-prefixed hybrid of width 1
             if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page");
             uint32_t L; std::memcpy(&L, q, 4);
             if (!hybrid_runs(fb, q + 4, (uint64_t)L < (uint64_t)(pe - (q + 4)) ? q + 4 + L : pe, 1, present, ord, 0, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed boolean run in column " + leaf.name);
-          } else return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": value encoding " + std::to_string(h.enc) + " (DELTA_* / BYTE_STREAM_SPLIT) is read by the stock reader");
+          } else if (h.enc == E_DELTA_BINARY_PACKED && (leaf.type == T_INT32 || leaf.type == T_INT64)) {
+            // the block headers say where every miniblock is; pq_delta decodes the page into the image's tail as PLAIN values
+            DStream ds;
+            if (!delta_headers(fb, q, pe, minis, ds) || ds.total != present) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed DELTA_BINARY_PACKED page in column " + leaf.name);
+            const uint64_t out_at = tail_take(present * P.width);
+            dpages.push_back(DPage{ds.first, out_at, 0, 0, (uint32_t)present, (uint32_t)ds.mini0, (uint32_t)ds.mini1, 0, P.width, 0, 0, 0});
+            val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN, 0, out_at, 0, 1});
+          } else if (h.enc == E_DELTA_LENGTH_BYTE_ARRAY && leaf.type == T_BYTE_ARRAY) {
+            // the lengths are a DELTA_BINARY_PACKED stream, the bytes follow it back to back: pq_delta turns the lengths into (offset, length)
+            DStream ds;
+            if (!delta_headers(fb, q, pe, minis, ds) || ds.total != present) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed DELTA_LENGTH_BYTE_ARRAY page in column " + leaf.name);
+            dpages.push_back(DPage{ds.first, 0, (uint64_t)(ds.end - fb), (uint64_t)(pe - fb), (uint32_t)present, (uint32_t)ds.mini0, (uint32_t)ds.mini1, 1, 4, (uint32_t)ord, (uint32_t)oc, 0});
+            val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0});
+          } else if (h.enc == E_DELTA_BYTE_ARRAY && (leaf.type == T_BYTE_ARRAY || is_flba)) {
+            // every value is a prefix of its predecessor plus a suffix: a chain.  The host expands the page into plain values in the
+            // arena (FIXED_LEN_BYTE_ARRAY: back to back; BYTE_ARRAY: length-prefixed) and the page is then a PLAIN one.
+            if (!inflate) throw NeedArena{};
+            std::vector<DMini> hm; DStream pre, suf;
+            std::vector<int64_t> pl_, sl_;
+            if (!delta_headers(fb, q, pe, hm, pre) || pre.total != present || !delta_decode_host(fb, hm, pre, pl_)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed DELTA_BYTE_ARRAY prefixes in column " + leaf.name);
+            hm.clear();
+            if (!delta_headers(fb, pre.end, pe, hm, suf) || suf.total != present || !delta_decode_host(fb, hm, suf, sl_)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed DELTA_BYTE_ARRAY suffixes in column " + leaf.name);
+            const size_t src_off = (size_t)(suf.end - fb), src_end = (size_t)(pe - fb);
+            std::vector<uint8_t> exp;
+            std::string prev, cur;
+            size_t sp = src_off;
+            for (uint64_t i = 0; i < present; i++) {
+              const int64_t a = pl_[(size_t)i], b = sl_[(size_t)i];
+              if (a < 0 || b < 0 || (uint64_t)a > prev.size() || (uint64_t)b > src_end - sp) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a DELTA_BYTE_ARRAY value of column " + leaf.name + " runs past its page");
+              cur.assign(prev, 0, (size_t)a);
+              cur.append((const char *)fb + sp, (size_t)b); sp += (size_t)b;
+              if (is_flba) { if (cur.size() != P.width) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: a DELTA_BYTE_ARRAY value of column " + leaf.name + " has another length than the type"); }
+              else { const uint32_t n = (uint32_t)cur.size(); exp.insert(exp.end(), (const uint8_t *)&n, (const uint8_t *)&n + 4); }
+              exp.insert(exp.end(), cur.begin(), cur.end());
+              if (exp.size() > 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the expanded pages of one object exceed 4 GiB: read it row group by row group");
+              prev.swap(cur);
+            }
+            const size_t at0 = (arena.size() + 15) & ~(size_t)15;
+            if ((uint64_t)at0 + exp.size() + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the inflated pages of one object exceed 4 GiB: read it row group by row group");
+            arena.resize(at0);  // (fb may move: nothing below reads through it)
+            arena.insert(arena.end(), exp.begin(), exp.end());
+            if (is_flba) val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_FIXED_TEXT, P.width, (uint64_t)at0, 0, 0});
+            else { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)at0, (uint64_t)(at0 + exp.size()), (uint32_t)ord, (uint32_t)present}); }
+          } else return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": value encoding " + std::to_string(h.enc) + " (BYTE_STREAM_SPLIT, or a DELTA_* encoding over this type) is read by the stock reader");
           ord += present; seen += h.nvalues;
           if (ord > 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: more values than rows in column " + leaf.name);
         }
+        (void)page_at0;
         pos = next;
       }
       if (seen != c.num_values || c.num_values != g.num_rows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": pages do not add up to the row group's rows");
@@ -620,26 +1044,42 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
     }
     PQD("  %zu level segs, %zu value segs, %zu text pages, ord %llu\n", lev.size(), val.size(), tpages.size(), (unsigned long long)ord);
   }
-  uint64_t img_len = len;  // bytes of the device image (file or inflated pages)
-  if (inflate) {
-    img_len = arena.size();
-    file = dalloc((size_t)img_len + 64);
-    if (img_len) h2d(file->p, arena.data(), (size_t)img_len);
-    TF_HIP(hipMemsetAsync((char *)file->p + img_len, 0, 64, st));
-  }
+  // ---- the device image: the object (or the inflated pages), 64 bytes of slack, then the tail ----
+  const uint64_t img_len = inflate ? arena.size() : len;
+  const uint64_t tail_base = (img_len + 64 + 15) & ~15ull;
+  if (tail_base + tail_need + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the object and what is decoded beside it exceed 4 GiB: read it row group by row group");
+  Buf file = dalloc((size_t)(tail_base + tail_need) + 64);
+  if (img_len) h2d(file->p, inflate ? arena.data() : f, (size_t)img_len);
+  TF_HIP(hipMemsetAsync((char *)file->p + img_len, 0, (size_t)(tail_base - img_len), st));
   const uint8_t *dfile = ptr<uint8_t>(file);
+  uint8_t *dtail = ptr<uint8_t>(file) + tail_base;
   Buf derr = dalloc_zero(16);  // [0]: PQE_* raised by a kernel
-  // ---- the length-prefix walks of EVERY text column's PLAIN pages in one launch (the pages are independent; a page is a serial chain) ----
+  // ---- (offset, length) of every PLAIN / DELTA_LENGTH byte-array value: the length-prefix walks of the PLAIN pages in one launch (the
+  //      pages are independent; a page is a serial chain), the DELTA pages by prefix sums ----
   Buf arena_off, arena_len;
   {
     size_t total = 0; std::vector<TextPage> all;
-    for (auto &P : plans) if (P.is_text && !P.nil) { P.arena_at = total; for (auto tp : P.tpages) { tp.ord += (uint32_t)total; all.push_back(tp); } total += (size_t)P.ord; }
+    for (size_t oc = 0; oc < plans.size(); oc++) {
+      ColPlan &P = plans[oc];
+      if (!P.is_text || P.nil) continue;
+      P.arena_at = total;
+      for (auto tp : P.tpages) { tp.ord += (uint32_t)total; all.push_back(tp); }
+      for (auto &dp : dpages) if (dp.mode == 1 && dp.pad0 == (uint32_t)oc) dp.ord += (uint32_t)total;
+      total += (size_t)P.ord;
+    }
     arena_off = dalloc(std::max<size_t>(total, 1) * 4); arena_len = dalloc(std::max<size_t>(total, 1) * 4);
     if (!all.empty() && nrows) {
       Buf btp = upload_small(all.data(), all.size() * sizeof(TextPage));
       keep.push_back(btp);
       KernelTimer t("pq_walk_text");
       pq_walk_text<<<(unsigned)all.size(), 256, 0, st>>>(dfile, (img_len + 64) & ~15ull, reinterpret_cast<const TextPage *>(btp->p), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
+    }
+    if (!dpages.empty() && nrows) {
+      DMini none{};
+      Buf bm = upload_small(minis.empty() ? &none : minis.data(), std::max<size_t>(minis.size(), 1) * sizeof(DMini)), bp = upload_small(dpages.data(), dpages.size() * sizeof(DPage));
+      keep.push_back(bm); keep.push_back(bp);
+      KernelTimer t("pq_delta");
+      pq_delta<<<(unsigned)((dpages.size() * 64 + 255) / 256), 256, 0, st>>>(dfile, dtail, reinterpret_cast<const DMini *>(bm->p), reinterpret_cast<const DPage *>(bp->p), (int32_t)dpages.size(), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
     }
   }
   // ---- pass 2 (device): levels → validity → ordinals, then the values ----
@@ -650,10 +1090,26 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
   for (size_t oc = 0; oc < plans.size(); oc++) {
     ColPlan &P = plans[oc];
     DColumn &d = P.d;
+    if (want[oc] == W_ROW_INDEX) {  // constructCI: vals[i] = idx, the 1-based row of the object (uint64)
+      d.repr = TFGPU_R_UINT64; d.dtype = outcols[oc].second >= 0 ? outcols[oc].second : TFGPU_T_UINT64;
+      d.values = dalloc((size_t)std::max<int64_t>(nrows, 1) * 8);
+      if (nrows) pq_row_index<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(ptr<uint64_t>(d.values), nrows);
+      continue;
+    }
+    if (want[oc] == W_FILE_NAME) {  // vals[i] = fileName in every row
+      const size_t fl = std::strlen(file_name);
+      if ((uint64_t)fl * (uint64_t)nrows >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: __file_name holds 4 GiB of text or more: read the object row group by row group");
+      d.repr = TFGPU_R_STRING; d.dtype = outcols[oc].second >= 0 ? outcols[oc].second : TFGPU_T_UTF8;
+      d.offsets = dalloc((size_t)(nrows + 1) * 4 + 16); d.data_len = (uint64_t)fl * (uint64_t)nrows; d.data = dalloc((size_t)d.data_len + 16);
+      Buf nm = upload_small(file_name, fl + 1);
+      keep.push_back(nm);
+      pq_file_name<<<(unsigned)((nrows + 1 + 255) / 256), 256, 0, st>>>(ptr<uint8_t>(nm), (uint32_t)fl, nrows, ptr<uint32_t>(d.offsets), ptr<uint8_t>(d.data));
+      continue;
+    }
     if (P.nil) continue;
-    const bool optional = P.optional, is_date = P.is_date, is_text = P.is_text;
+    const bool optional = P.optional, is_text = P.is_text;
     if (nrows == 0) {
-      if (is_text) { d.offsets = dalloc_zero(8); d.data = dalloc(8); } else { d.values = dalloc(8); if (d.repr == TFGPU_R_TIME) d.nanos = dalloc(8); }
+      if (is_text || P.is_int96) { d.offsets = dalloc_zero(8); d.data = dalloc(8); } else { d.values = dalloc(8); if (d.repr == TFGPU_R_TIME) d.nanos = dalloc(8); }
       continue;
     }
     Buf blev = P.lev.empty() ? nullptr : upload_small(P.lev.data(), P.lev.size() * sizeof(Seg));
@@ -663,29 +1119,38 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
     exclusive_scan_u32(ptr<uint32_t>(rank), ptr<uint32_t>(rank), nrows, true);
     if (optional) { d.validity = dalloc((size_t)(nrows + 7) / 8 + 8); pq_pack_validity<<<(unsigned)(((nrows + 7) / 8 + 255) / 256), 256, 0, st>>>(ptr<uint32_t>(rank), nrows, ptr<uint8_t>(d.validity)); }
     keep.push_back(blev); keep.push_back(bval); keep.push_back(rank);
-    KernelTimer t(is_text ? "pq_text" : "pq_values");
-    if (!is_text) {
+    KernelTimer t(is_text || P.is_int96 ? "pq_text" : "pq_values");
+    if (!is_text && !P.is_int96) {
       Buf bdict = P.dict_at.empty() ? nullptr : upload_small(P.dict_at.data(), P.dict_at.size() * 8);
       Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
       keep.push_back(bdict); keep.push_back(bdn);
-      const uint32_t ow = d.repr == TFGPU_R_TIME ? 8 : P.width;
-      d.values = dalloc((size_t)nrows * ow);
-      if (d.repr == TFGPU_R_TIME) d.nanos = dalloc_zero((size_t)nrows * 4);
-      pq_values_fixed<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), ptr<uint32_t>(bdn), FixedOut{d.values->p, (int32_t)ow, is_date ? 1 : 0}, ptr<uint32_t>(derr));
+      d.values = dalloc((size_t)nrows * (size_t)P.out_width);
+      if (d.repr == TFGPU_R_TIME) d.nanos = P.conv == CV_TS_MICROS ? dalloc((size_t)nrows * 4) : dalloc_zero((size_t)nrows * 4);
+      pq_values_fixed<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, tail_base, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), ptr<uint32_t>(bdn),
+                                                                       FixedOut{d.values->p, P.conv == CV_TS_MICROS ? ptr<int32_t>(d.nanos) : nullptr, (int32_t)P.width, P.out_width, P.conv}, ptr<uint32_t>(derr));
     } else {
-      Buf bdo = P.dict_off.empty() ? nullptr : upload_small(P.dict_off.data(), P.dict_off.size() * 4), bdl = P.dict_len.empty() ? nullptr : upload_small(P.dict_len.data(), P.dict_len.size() * 4);
-      Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
-      keep.push_back(bdn);
       Buf soff = dalloc((size_t)nrows * 4);
       d.offsets = dalloc((size_t)(nrows + 1) * 4 + 16);
       Buf tot64 = dalloc_zero(8);
       tot64s.push_back(tot64);
-      pq_text_cells<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint32_t>(arena_off) + P.arena_at, ptr<uint32_t>(arena_len) + P.arena_at,
-                                                                     ptr<uint32_t>(bdo), ptr<uint32_t>(bdl), ptr<uint32_t>(bdn), ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets), reinterpret_cast<unsigned long long *>(tot64->p), ptr<uint32_t>(derr));
+      if (P.is_int96) {
+        Buf bdict = P.dict_at.empty() ? nullptr : upload_small(P.dict_at.data(), P.dict_at.size() * 8);
+        Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
+        keep.push_back(bdict); keep.push_back(bdn);
+        pq_int96_text<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, dtail, tail_base, P.slot0, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), ptr<uint32_t>(bdn),
+                                                                       ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets), ptr<uint32_t>(derr));
+        // (29 digits and a sign per row at most: the column cannot reach 4 GiB under the 2^31-row bound, tot64 stays 0)
+      } else {
+        Buf bdo = P.dict_off.empty() ? nullptr : upload_small(P.dict_off.data(), P.dict_off.size() * 4), bdl = P.dict_len.empty() ? nullptr : upload_small(P.dict_len.data(), P.dict_len.size() * 4);
+        Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
+        keep.push_back(bdn); keep.push_back(bdo); keep.push_back(bdl);
+        pq_text_cells<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint32_t>(arena_off) + P.arena_at, ptr<uint32_t>(arena_len) + P.arena_at,
+                                                                       ptr<uint32_t>(bdo), ptr<uint32_t>(bdl), ptr<uint32_t>(bdn), ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets), reinterpret_cast<unsigned long long *>(tot64->p), ptr<uint32_t>(derr));
+      }
       exclusive_scan_u32(ptr<uint32_t>(d.offsets), ptr<uint32_t>(d.offsets), nrows, true);
       totals.push_back(oc);
       soffs.push_back({oc, soff});
-      keep.push_back(bdo); keep.push_back(bdl); keep.push_back(soff);
+      keep.push_back(soff);
     }
   }
   std::vector<uint32_t> htot(totals.size() + 1);
@@ -709,6 +1174,49 @@ extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, cons
   if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : "tfgpu_parquet_read: a byte-array length that runs past its page");
   for (auto &P : plans) db->cols.push_back(std::move(P.d));
   *out = db.release();
+  return TFGPU_OK;
+}
+
+extern "C" int tfgpu_parquet_read_object(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, tfgpu_dbatch **out) {
+  TF_API_BEGIN
+  if (!bytes || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: null argument");
+  if (mem != TFGPU_MEM_HOST) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the footer and the page headers are walked on the host: pass the object in host memory (pinned for an asynchronous upload)");
+  if (len >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: objects of 4 GiB and more: read them row group by row group");
+  const uint8_t *f = static_cast<const uint8_t *>(bytes);
+  try { return parquet_read_impl(f, len, schema, table_ns, table_name, file_name, false, out); }
+  catch (const NeedArena &) { return parquet_read_impl(f, len, schema, table_ns, table_name, file_name, true, out); }
+  TF_API_END
+}
+extern "C" int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out) {
+  return tfgpu_parquet_read_object(bytes, len, mem, schema, table_ns, table_name, nullptr, out);
+}
+
+// parquet_schema_resolver.go:81-158 resolveSchema + s3_reader.AppendSystemColsTableSchema (the inferred schema has no key: the two
+// system columns become it) — host only, the footer is all it reads.
+extern "C" int tfgpu_parquet_resolve_schema(const void *bytes, uint64_t len, int hide_system_cols, tfgpu_schema **out) {
+  TF_API_BEGIN
+  if (!bytes || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_resolve_schema: null argument");
+  FileMeta m; std::string why;
+  if (!parse_footer(static_cast<const uint8_t *>(bytes), len, m, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_resolve_schema: " + why);
+  std::vector<TopField> fields; int nleaves = 0;
+  if (!top_fields(m, fields, nleaves, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_resolve_schema: " + why);
+  const int nsys = hide_system_cols ? 0 : 2;
+  auto *s = (tfgpu_schema *)std::calloc(1, sizeof(tfgpu_schema));
+  if (!s) throw std::bad_alloc();
+  s->ncols = (int32_t)fields.size() + nsys;
+  s->cols = (tfgpu_colschema *)std::calloc((size_t)std::max(s->ncols, 1), sizeof(tfgpu_colschema));
+  if (!s->cols) { std::free(s); throw std::bad_alloc(); }
+  if (nsys) {
+    s->cols[0].name = strdup("__file_name"); s->cols[0].dtype = TFGPU_T_UTF8; s->cols[0].flags = TFGPU_COL_KEY;
+    s->cols[1].name = strdup("__row_index"); s->cols[1].dtype = TFGPU_T_UINT64; s->cols[1].flags = TFGPU_COL_KEY;
+  }
+  for (size_t k = 0; k < fields.size(); k++) {
+    tfgpu_colschema &c = s->cols[(size_t)nsys + k];
+    c.name = strdup(fields[k].el.name.c_str());
+    c.dtype = fields[k].dtype;
+    c.original_type = strdup(("parquet:" + fields[k].type_string).c_str());
+  }
+  *out = s;
   return TFGPU_OK;
   TF_API_END
 }

@@ -31,7 +31,7 @@ EXPORTS = [
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_from_config", "tfgpu_transformation_size", "tfgpu_transformation_plan_type", "tfgpu_transformation_errors_output", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
     "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_sr_compile_schema", "tfgpu_sr_schema_info", "tfgpu_sr_schema_free", "tfgpu_sr_compile_proto", "tfgpu_pb_schema_info", "tfgpu_pb_schema_free", "tfgpu_sr_proto_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_debezium_compile_schema", "tfgpu_dbz_schema_info", "tfgpu_dbz_schema_free", "tfgpu_dbz_receiver_create", "tfgpu_dbz_receiver_destroy", "tfgpu_dbz_receiver_known", "tfgpu_dbz_receive", "tfgpu_dbz_receive_group", "tfgpu_dbz_receive_group_meta", "tfgpu_debezium_compile_registry_schema", "tfgpu_dbz_receiver_add_registry_schema", "tfgpu_debezium_registry_frames", "tfgpu_dbz_receive_registry", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_serialize_batch", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_queue_raw_column", "tfgpu_queue_mirror", "tfgpu_queue_part_groups", "tfgpu_kafka_hash_partition", "tfgpu_kafka_partitions", "tfgpu_debezium_emit", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
-    "tfgpu_prof_get", "tfgpu_prof_get_units",
+    "tfgpu_prof_get", "tfgpu_prof_get_units", "tfgpu_parquet_read_object", "tfgpu_parquet_resolve_schema",
 ]
 
 
@@ -171,14 +171,31 @@ def lane_device(lane: int) -> int:
     return int(d.value)
 
 
-def parquet_read(data: bytes, schema: Optional[abi.Schema] = None, ns: str = "", table: str = "") -> "DeviceBatch":
-    """ReaderParquet.Read's decode on the device: a whole Parquet object (host bytes) → one device batch"""
+def parquet_read(data: bytes, schema: Optional[abi.Schema] = None, ns: str = "", table: str = "", file_name: Optional[str] = None) -> "DeviceBatch":
+    """ReaderParquet.Read's decode on the device: a whole Parquet object (host bytes) → one device batch.  With file_name the
+    schema's `__file_name` / `__row_index` are the reader's system columns (constructCI)."""
     init()
     out = C.c_void_p()
     buf = np.frombuffer(data, dtype=np.uint8)
     cs = schema.to_c() if schema is not None else None
-    _check(load().tfgpu_parquet_read(C.c_void_p(buf.ctypes.data), C.c_uint64(len(buf)), abi.MEM_HOST, C.byref(cs) if cs is not None else None, ns.encode(), table.encode(), C.byref(out)))
+    L = load()
+    L.tfgpu_parquet_read_object.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    _check(L.tfgpu_parquet_read_object(C.c_void_p(buf.ctypes.data), C.c_uint64(len(buf)), abi.MEM_HOST, C.byref(cs) if cs is not None else None, ns.encode(), table.encode(),
+                                       file_name.encode() if file_name is not None else None, C.byref(out)))
     return DeviceBatch(out)
+
+
+def parquet_resolve_schema(data: bytes, hide_system_cols: bool = False) -> abi.Schema:
+    """ParquetSchemaResolver.resolveSchema (+ the system columns): the TableSchema the reference infers from the object's footer"""
+    L = load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = C.POINTER(abi.CSchema)()
+    L.tfgpu_parquet_resolve_schema.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.POINTER(abi.CSchema))]
+    _check(L.tfgpu_parquet_resolve_schema(C.c_void_p(buf.ctypes.data), C.c_uint64(len(buf)), 1 if hide_system_cols else 0, C.byref(out)))
+    try:
+        return abi.Schema.from_c(out.contents)
+    finally:
+        L.tfgpu_schema_free(out)
 
 
 def parquet_write(batch: "DeviceBatch", schema: abi.Schema, codec: str = "", row_group_max_rows: int = 0, row_group_max_bytes: int = 0) -> bytes:
