@@ -28,11 +28,15 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-INT32_PEAK_TOPS = 39.3    # 256 CUs x 64 lanes x 2.4 GHz, one 32-bit integer VALU op per lane per clock (same guide)
-# mask_field per value: HMAC-SHA256 with cached ipad / opad midstates = 2 compressions of 64 rounds; a round is
-# Sigma1 (5) + Ch (3) + Sigma0 (5) + Maj (3) + 7 adds, the message schedule sigma0 + sigma1 + 3 adds (13) for 48 of the
-# 64 rounds: ~33 int32 ops per round -> 2 x 64 x 33 = 4224, plus ~180 for the decimal text and the 64 hex characters
-MASK_INT_OPS_PER_VALUE = 4400
+INT32_PEAK_TOPS = 39.3    # 256 CUs x 64 lanes x 2.4 GHz, one VALU INSTRUCTION per lane per clock (same guide): an issue peak, so the work is priced in instructions
+# mask_field per value: HMAC-SHA256 with cached ipad / opad midstates = 2 compressions.  The fewest gfx950 VALU instructions that
+# compute one (v_alignbit_b32 = a rotate, v_xor3_b32, v_bfi_b32, v_add3_u32 each fold two or three two-input operations): a round is
+# Sigma1 (3 rotates + xor3 = 4) + Ch (bfi = 1) + Sigma0 (4) + Maj (xor + bfi = 2) + t1 (two add3 = 2) + new e, new a (2) = 15; the
+# message schedule of 48 rounds sigma0 (2 rotates + shift + xor3 = 4) + sigma1 (4) + add3 + add (2) = 10; 8 feed-forward adds:
+# 64 x 15 + 48 x 10 + 8 = 1 448 per compression, 2 896 per value, plus ~250 for the decimal text, the padding, the byte swaps and
+# the 64 hex characters.  (Until round 4 the tally counted two-input OPERATIONS, 4 400 — against an instruction peak that can exceed 1.)
+# The kernel's MEASURED count is in profiles/pmc_traffic.json (issue_frac below): 3 900.
+MASK_INT_OPS_PER_VALUE = 3150
 
 MASK = ("mask_field", {"maskFunctionHash": {"userDefinedSalt": "clickbench-salt"}, "columns": ["clientip"]})
 CHAIN = [MASK, ("filter_rows", {"filter": "eventdate >= 2013-07-15"})]
@@ -228,6 +232,54 @@ def run_threads(fn, parts):
 # workloads: setup() stages inputs in HBM (untimed), step() is one pass, alg() the algorithmic bytes per step of each
 # kernel (SURVEY §8d per-row figures x rows), cpu() the oracle on a bounded sample
 # ----------------------------------------------------------------------------------------------------------------
+
+# ----------------------------------------------------------------------------------------------------------------
+# post-run parity: every workload line re-checks its own configuration against the oracle on a bounded sample (untimed; the
+# product never calls the oracle — this is the cpu_baseline leg using its by-product)
+# ----------------------------------------------------------------------------------------------------------------
+def _cells_same(a, b):
+    if a == b:
+        return True
+    if a[0] == "json" and b[0] in ("string", "bool", "jsonnum"):  # an `any` column holds json.Marshal's text of the oracle's Go value
+        want = (b'"' + b[1] + b'"') if b[0] == "string" else (b"true" if b[1] else b"false") if b[0] == "bool" else b[1]
+        return a[1] == want
+    return a[0] == b[0] and a[0] in ("float32", "float64") and a[1] != a[1] and b[1] != b[1]  # NaN
+
+
+def _rows_diff(abi, got_rows, want_rows):
+    """index of the first row that differs (cells as abi.norm_value), or -1"""
+    if len(got_rows) != len(want_rows):
+        return min(len(got_rows), len(want_rows))
+    for i, (g, w) in enumerate(zip(got_rows, want_rows)):
+        if len(g) != len(w) or not all(_cells_same(x, y) for x, y in zip(g, w)):
+            return i
+    return -1
+
+
+def _batch_diff(abi, dev, ref):
+    """None when two host batches hold the same columns and cells, else what differs first"""
+    if [c.name for c in dev.cols] != [c.name for c in ref.cols]:
+        return "column names"
+    if [c.repr for c in dev.cols] != [c.repr for c in ref.cols]:
+        return "column representations"
+    d = _rows_diff(abi, abi.batch_rows(dev), abi.batch_rows(ref))
+    return None if d < 0 else "row %d" % d
+
+
+def _parity(k, what, err=None, **kw):
+    out = {"identical": err is None, "checked_input_rows": k, "checked": what}
+    if err is not None:
+        out["error"] = str(err)[:300]
+    out.update(kw)
+    return out
+
+
+def _guard_parity(fn):
+    try:
+        return fn()
+    except Exception as ex:  # noqa: BLE001
+        return {"identical": False, "error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+
 class ctypes_void:
     """a void* out-parameter for the few raw C-ABI calls bench.py makes itself"""
 
@@ -280,10 +332,16 @@ class CsvWorkload(Base):
         self.dbuf, self.csv_bytes, _ = stage_shard(e.lib, e.workload, self.row0, a.rows)
         self.nl = 1
 
-    def step(self, keep=False, buf=None, plans=None):
+    def step(self, keep=False, buf=None, plans=None, dense=False):
         lib = self.env.lib
         db, consumed, errs = lib.csv_parse(self.opts, self.cschema, buf if buf is not None else self.dbuf)
         res = lib.apply_chain(plans if plans is not None else self.plans, db)
+        # the devnull sink: counts the items it is pushed and drops them.  filter_rows hands its kept rows on as a SELECTION over the
+        # parsed batch (tfgpu_dbatch::pending) and nothing here reads a column of them, so no dense copy of the kept rows is made;
+        # `dense` (the dense_sink side measurement) is a sink that asks for one
+        self.sunk = res.transformed.nrows
+        if dense:
+            res.transformed.dense()
         if keep:
             s = self.state
             s["parsed_rows"], s["parsed_bytes"] = db.nrows, db.payload_bytes()
@@ -421,9 +479,9 @@ class CsvWorkload(Base):
         ach = MASK_INT_OPS_PER_VALUE * mrows / max(k["launches_per_step"], 1) / (k["avg_ms"] * 1e-3) / 1e12
         out = {"kernel": "mask_hmac_sha256", "bound": "int32_valu", "achieved": round(ach, 2), "peak": INT32_PEAK_TOPS, "unit": "Top/s",
                "frac": round(ach / INT32_PEAK_TOPS, 4), "int_ops_per_value": MASK_INT_OPS_PER_VALUE, "values_per_step": mrows,
-               "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low.  int_ops_per_value tallies two-input 32-bit "
-                       "operations; gfx950's v_add3 / v_xor3 / v_bfi / v_alignbit carry two or three of them per instruction, so `frac` can approach 1 while the VALU "
-                       "issues fewer instructions than that — `issue_frac` (measured instructions, when profiles/pmc_traffic.json is of this build) is the issue-slot view"}
+               "note": "mask is ALU-bound (2 SHA-256 compressions per 72 algorithmic bytes): its HBM fraction is legitimately low.  int_ops_per_value is the FEWEST gfx950 VALU "
+                       "instructions that compute one value (v_add3 / v_xor3 / v_bfi / v_alignbit counted as one each), `peak` one VALU instruction per lane per clock: `frac` is the share "
+                       "of the issue slots that minimum would fill.  `issue_frac` prices the kernel's MEASURED instruction count instead (when profiles/pmc_traffic.json is of this build)"}
         # the same fraction from the kernel's MEASURED VALU instruction count per value (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES of this
         # very source, tools/gpu_visit.sh evidence) instead of the algorithmic tally: instructions issued, against one per lane per cycle
         try:
@@ -446,6 +504,7 @@ class CsvWorkload(Base):
         return {"workload": "ClickBench hits-1M CSV parse -> mask(ip)+filter(EventDate) -> devnull (BASELINE.json configs[1])",
                 "rows_per_gpu_per_step": s["parsed_rows"], "csv_bytes_per_gpu_per_step": self.csv_bytes, "columns": len(self.schema.cols),
                 "chain": [t for t, _ in CHAIN], "filter_selectivity": round(s["out_rows"] / max(s["parsed_rows"], 1), 4),
+                "sink": "devnull: counts the pushed rows (tfgpu_dbatch_nrows) and drops them; the kept rows stay a selection over the parsed batch, no dense copy is made (side measurement dense_sink: a sink that asks for one)",
                 "parallelism": f"row-range shard x{len(e.devices) if getattr(e, 'devices', None) else e.world}, no collective"}
 
     def extra(self):
@@ -466,6 +525,20 @@ class CsvWorkload(Base):
             out["overlapped_lanes"] = {"lanes": min(a.overlap_lanes, e.lib.lane_count()), "steps": k, "rows_per_s": round(a.rows * e.world * k / dt2, 1), "ms_per_step": round(dt2 / k * 1e3, 3),
                                        "note": "the same steps spread over several device lanes (parse of batch N+1 beside the transform of batch N); "
                                                "kernels of different lanes share the GPU, so per-kernel spans are not comparable"}
+        if e.rank == 0:  # a sink that reads every column: the kept rows are gathered (what every step did until round 5)
+            e.lib.synchronize()
+            kk = max(min(k, 50), 3)
+            for _ in range(2):
+                self.step(dense=True)
+            e.lib.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(kk):
+                self.step(dense=True)
+            e.lib.synchronize()
+            dtd = time.perf_counter() - t0
+            out["dense_sink"] = {"steps": kk, "ms_per_step": round(dtd / kk * 1e3, 3), "rows_per_s": round(a.rows * kk / dtd, 1),
+                                 "note": "the same pass with a sink that asks for the kept rows as dense columns (tfgpu_dbatch_dense: compact_gather over all 105 columns, text cells still "
+                                         "positions in the CSV) — the devnull sink of configs[1] does not"}
         if a.pcie_steps > 0 and e.rank == 0:
             raw = self.dbuf.download()
             res = {}
@@ -599,7 +672,30 @@ class JsonWorkload(_Prepared):
                "sample": f"{k} of the same messages through the oracle's generic JSON parser only ({r1.seconds:.2f}s), single thread",
                "note": "C restatement of the Go reference (fastjson value tree, boxed values per row), not the Go binary"}
         out.update(host_info())
+        out["parity"] = _guard_parity(lambda: self.parity(min(k, 4096)))
         return out
+
+    def parity(self, k):
+        """parse of the first k messages against the oracle's rows; then mask + filter + JSONEachRow of that batch, device against oracle"""
+        from oracle import oracle as ora
+        lib, abi = self.env.lib, self.env.abi
+        d2, m2 = abi.messages(self.vals[:k], list(range(k)), [1_700_000_000_000_000_000 + i for i in range(k)])
+        ref = ora.json_parse(self.opts, self.fields, d2, m2)
+        db, errs = lib.json_parse(self.opts, self.fields, d2, m2)
+        host = db.download()
+        if errs or host.nrows != ref.nrows:
+            return _parity(k, "parse", "rows %d vs %d, %d device errors" % (host.nrows, ref.nrows, len(errs)))
+        d = _rows_diff(abi, abi.batch_rows(host), [[abi.norm_value(v) for v in r] for r in ref.rows])
+        if d >= 0:
+            return _parity(k, "parse", "row %d differs" % d)
+        res = lib.apply_chain(self.plans, db)
+        text = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, res.transformed).download()
+        host.schema = ref.schema
+        r2 = ora.apply_chain([ora.Transformer(t, c) for t, c in JSON_CHAIN], host, ref.schema)
+        want = ora.serialize(abi.FMT_CH_JSON_EACH_ROW, r2.batch, r2.schema)
+        if bytes(text) != bytes(want):
+            return _parity(k, "chain + JSONEachRow", "text differs (%d vs %d bytes)" % (len(text), len(want)))
+        return _parity(k, "json parse (cell for cell) + mask + filter + JSONEachRow (byte for byte)", compared_output_rows=r2.batch.nrows, compared_output_bytes=len(want))
 
 
 def sr_inputs(e, a):
@@ -659,7 +755,27 @@ class SrWorkload(_Prepared):
                "sample": f"{k} of the same messages through the oracle's SR JSON parser ({r1.seconds:.2f}s) + queue JSON serializer ({ora.queue_serialize.seconds:.2f}s), single thread",
                "note": "C restatement of the Go reference (decoded value tree, boxed values per row), not the Go binary"}
         out.update(host_info())
+        out["parity"] = _guard_parity(lambda: self.parity(min(k, 4096)))
         return out
+
+    def parity(self, k):
+        from oracle import oracle as ora
+        lib, abi = self.env.lib, self.env.abi
+        d2, m2 = abi.messages(self.frames[:k], list(range(k)), [1_700_000_000_000_000_000 + i for i in range(k)])
+        ref = ora.sr_json_parse(self.opts, d2, m2)
+        res = lib.sr_json_parse(self.opts, d2, m2)
+        host = res.device_batch.download()
+        if res.errors or ref.errors:
+            return _parity(k, "parse", "row errors: %d device, %d oracle" % (len(res.errors), len(ref.errors)))
+        why = _batch_diff(abi, host, ref.batch)
+        if why:
+            return _parity(k, "parse", why)
+        got = lib.queue_serialize(self.qopts, res.device_batch)
+        want = ora.queue_serialize(self.qopts, ref.batch, ref.schema)
+        text = bytes(got.values.download())
+        if want is None or text != b"".join(want) or len(got) != len(want):
+            return _parity(k, "queue JSON serializer", "messages differ")
+        return _parity(k, "SR JSON parse (cell for cell) + queue JSON serializer (byte for byte)", compared_messages=len(want), compared_output_bytes=len(text))
 
 
 class Configs2Workload(_Prepared):
@@ -821,7 +937,42 @@ class Configs2Workload(_Prepared):
                "note": "C restatement of the Go reference, not the Go binary, and without the reference's clickhouse-local fork/exec and double JSON round trip "
                        "(clickhouse_local.go:145-210), i.e. faster than the reference's sql transformer; the reference parses with GOMAXPROCS goroutines (generic_parser.go:406-438)"}
         out.update(host_info())
+        out["parity"] = _guard_parity(lambda: self.parity(min(k, 2048)))
         return out
+
+    def parity(self, k):
+        """SR parse of the first k messages against the oracle; replace_primary_key + sql on that batch against oracle/ora_sql.py (the
+        restatement of ClickHouse's documented typing — `sql` parity is unpinned by construction: no clickhouse-local here); JSONEachRow
+        of the result against the oracle's serializer"""
+        from oracle import oracle as ora, ora_sql
+        lib, abi = self.env.lib, self.env.abi
+        d2, m2 = abi.messages(self.frames[:k], list(range(k)), [1_700_000_000_000_000_000 + i for i in range(k)])
+        ref = ora.sr_json_parse(self.opts, d2, m2)
+        res = lib.sr_json_parse(self.opts, d2, m2)
+        host = res.device_batch.download()
+        why = _batch_diff(abi, host, ref.batch)
+        if why or res.errors:
+            return _parity(k, "parse", why or "device row errors")
+        tr = self.stage.push_run(res.device_batch)
+        out = tr.transformed.download()
+        keyed = [(c.name, c.dtype, c.name == "watchid") for c in ref.schema.cols]
+        rows = [{"kind": "insert", "src": i, "values": {c.name: c.pyvalue(i) for c in host.cols}} for i in range(host.nrows)]
+        exp = ora_sql.apply(self.QUERY, rows, keyed)
+        if out.nrows != len(exp):
+            return _parity(k, "replace_primary_key + sql", "rows %d vs %d" % (out.nrows, len(exp)))
+        for i, e in enumerate(exp):
+            got = [c.pyvalue(i) for c in out.cols]
+            if [[g[0], g[1] if not isinstance(g[1], tuple) else tuple(g[1])] for g in got] != [[v[0], v[1]] for v in e["values"]]:
+                return _parity(k, "replace_primary_key + sql", "row %d differs" % i)
+        text = bytes(lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed).download())
+        rs = ora_sql.resolve(self.QUERY, keyed)
+        osch = abi.Schema.of([[r[0], r[3], bool(r[4])] for r in rs])
+        out.schema = osch
+        want = bytes(ora.serialize(abi.FMT_CH_JSON_EACH_ROW, out, osch))
+        if text != want:
+            return _parity(k, "JSONEachRow", "text differs (%d vs %d bytes)" % (len(text), len(want)))
+        return _parity(k, "SR JSON parse (cell for cell) + replace_primary_key + sql against oracle/ora_sql.py (cell for cell; sql parity is unpinned: no clickhouse-local here) + JSONEachRow (byte for byte)",
+                       compared_output_rows=out.nrows, compared_output_bytes=len(want))
 
 
 class Configs3Workload(Base):
@@ -1017,7 +1168,31 @@ class Configs3Workload(Base):
                "sample": f"{k} rows: oracle chain ({r2.seconds:.2f}s) + JSONEachRow ({ts:.2f}s) on already-typed rows, single thread (one table = one goroutine, transformation.go:131-135)",
                "note": "C restatement of the Go reference, not the Go binary"}
         out.update(host_info())
+        out["parity"] = _guard_parity(lambda: self.parity(min(k, 8192), r1))
         return out
+
+    def parity(self, k, r1):
+        """the first k rows of the resident table (= the oracle's parse of the same CSV rows, checked) through the chain + JSONEachRow,
+        device against oracle, byte for byte"""
+        from oracle import oracle as ora
+        lib, abi = self.env.lib, self.env.abi
+        k = (k // 8) * 8
+        head = self.db.slice(0, k)
+        host = head.download()
+        rb = r1.batch
+        ref_head = abi.Batch([abi.Column(c.name, c.dtype, c.repr, values=None if c.values is None else c.values[:k], nanos=None if c.nanos is None else c.nanos[:k],
+                                         offsets=None if c.offsets is None else c.offsets[:k + 1].copy(), data=None if c.data is None else c.data[:int(c.offsets[k])],
+                                         validity=None if c.validity is None else c.validity[:k]) for c in rb.cols], k, rb.table_ns, rb.table_name)
+        why = _batch_diff(abi, host, ref_head)
+        if why:
+            return _parity(k, "resident columns", why)
+        tr = lib.apply_chain(self.plans, head)
+        text = bytes(lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed).download())
+        r2 = ora.apply_chain([ora.Transformer(t, c) for t, c in self.CH], ref_head, r1.schema)
+        want = bytes(ora.serialize(abi.FMT_CH_JSON_EACH_ROW, r2.batch, r2.schema))
+        if text != want:
+            return _parity(k, "chain + JSONEachRow", "text differs (%d vs %d bytes)" % (len(text), len(want)))
+        return _parity(k, "resident columns (cell for cell) + mask + sharder + casts + JSONEachRow (byte for byte)", compared_output_rows=r2.batch.nrows, compared_output_bytes=len(want))
 
 
 class Configs0Workload(Base):
@@ -1065,6 +1240,46 @@ class Configs0Workload(Base):
     def int_roofline(self, kernels):
         return Configs3Workload.int_roofline(self, kernels)
 
+    def side_measurements(self):
+        """Never `value`: Apply([]ChangeItem) as transformation.do would call it (transformation.go:252-257) — the rows start as boxed
+        []interface{} items on the host, are fanned out into column buffers, cross the C ABI once and are fanned back in.  A C++
+        model of the Go data and of INTEGRATION.md §2's binding (tools/fanout/fanout_harness.cpp: there is no Go toolchain here)."""
+        e, a = self.env, self.args
+        if not getattr(a, "from_rows", False) or e.rank != 0:
+            return {}
+        import ctypes as C
+        so = os.path.join(ROOT, "tools", "fanout", "libfanout.so")
+        if not os.path.exists(so):
+            return {"from_rows": {"error": "tools/fanout/libfanout.so is not built (__graft_entry__.build())"}}
+        H = C.CDLL(so)
+        H.fanout_run.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]
+
+        def run(n, cols, touch, plans, ns, table, reps=3):
+            names = (C.c_char_p * len(cols))(*[c[0].encode() for c in cols]); tags = (C.c_int32 * len(cols))(*[c[1] for c in cols])
+            t = (C.c_int32 * len(touch))(*touch)
+            pt = (C.c_char_p * len(plans))(*[p[0].encode() for p in plans]); pc = (C.c_char_p * len(plans))(*[json.dumps(p[1]).encode() for p in plans])
+            out = C.create_string_buffer(4096)
+            H.fanout_run(e.lib._LIBPATH.encode(), n, len(cols), names, tags, t, len(touch), pt, pc, len(plans), ns.encode(), table.encode(), reps, out, 4096)
+            d = json.loads(out.value.decode())
+            if "ms" in d:
+                tot = sum(d["ms"].values())
+                d["ms_total"] = round(tot, 3)
+                d["rows_per_s"] = round(n / (tot * 1e-3), 1)
+            return d
+        four = [("id", 1), ("name", 4), ("ip", 2), ("ts", 5)]
+        tagof = {"int16": 3, "int32": 2, "int64": 1, "utf8": 4, "timestamp": 5, "date": 6, "any": 4}
+        hits = [(n, tagof[t]) for n, t, _ in e.workload.hits_columns()]
+        hidx = {n: i for i, (n, _) in enumerate(hits)}
+        n0, nh = min(self.n, 1 << 20), 1 << 18
+        res = {"configs0_all_columns": run(n0, four, [0, 1, 2, 3], self.CH, "public", "users"),
+               "configs0_touched_columns_only": run(n0, four, [2], self.CH, "public", "users"),
+               "hits_mask_filter_2_of_105_columns": run(nh, hits, [hidx["clientip"], hidx["eventdate"]], CHAIN, "default", "hits"),
+               "note": "per call of Apply(items): fan_out = one type switch per cell of the fanned-out columns into pinned staging; upload / apply / download = the one C-ABI crossing "
+                       "(tfgpu_batch_upload, tfgpu_apply, tfgpu_dbatch_download); fan_in = a new item per kept row, untouched cells re-use the input's boxed values by src_row, the "
+                       "rewritten column is boxed.  `touched_columns_only` fans out just what the chain reads (SURVEY 7: only materialise columns the chain touches).  A C++ model "
+                       "of the Go data (16-byte interface words → heap boxes), not Go: no garbage collector, no write barriers — read it as a LOWER bound on the Go binding's host cost"}
+        return {"from_rows": res}
+
     def config(self):
         return {"workload": "4-column table (id int64, name utf8, ip int32, ts timestamp) resident in HBM -> rename_tables + mask_field(ip) -> devnull (BASELINE.json configs[0]: the plumbing case, CPU-only in the reference)",
                 "rows_per_gpu_per_step": self.n, "columns": 4, "chain": [t for t, _ in self.CH], "parallelism": f"row-range shard x{self.env.world}, no collective"}
@@ -1078,6 +1293,20 @@ class Configs0Workload(Base):
                "sample": f"{k} rows: oracle rename_tables + mask_field ({r.seconds:.2f}s) on the same typed rows, single thread (one table = one goroutine, transformation.go:131-135)",
                "note": "C restatement of the Go reference, not the Go binary"}
         out.update(host_info())
+
+        def check():
+            kk = (min(k, 1 << 16) // 8) * 8
+            tr = self.env.lib.apply_chain(self.plans, self.db.slice(0, kk))
+            got = tr.transformed.download()
+            rb = r.batch
+            want = self.env.abi.Batch([self.env.abi.Column(c.name, c.dtype, c.repr, values=None if c.values is None else c.values[:kk], nanos=None if c.nanos is None else c.nanos[:kk],
+                                                           offsets=None if c.offsets is None else c.offsets[:kk + 1].copy(), data=None if c.data is None else c.data[:int(c.offsets[kk])],
+                                                           validity=None if c.validity is None else c.validity[:kk]) for c in rb.cols], kk, rb.table_ns, rb.table_name)
+            why = _batch_diff(self.env.abi, got, want)
+            if why is None and (got.table_ns, got.table_name) != ("bench", "users_masked"):
+                why = "table id"
+            return _parity(kk, "rename_tables + mask_field, cell for cell", why, compared_output_rows=kk)
+        out["parity"] = _guard_parity(check)
         return out
 
 
@@ -1200,13 +1429,34 @@ class Configs4Workload(Base):
                    "note": "the emitter leg is a PYTHON restatement (oracle/dbz_emitter.py): a parity checker, far slower than the Go emitter — not a performance baseline"}
             out.update(host_info())
             return out
-        ora.queue_serialize(self.qopts, a, s2, meta)
+        want = ora.queue_serialize(self.qopts, a, s2, meta)
         sec = r1.seconds + ora.queue_serialize.seconds
         out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
                "sample": f"a {k}-row slice of the same stream: oracle Collapse ({r1.seconds:.2f}s) + native serializer ({ora.queue_serialize.seconds:.2f}s), single thread",
                "note": "C restatement of the Go reference (json.Marshal key strings, string-keyed maps), not the Go binary; context: the reference's own debezium parser "
                        "benchmark tops out at ~26 k msg/s on 10 cores (multithreadig_test.md)"}
         out.update(host_info())
+
+        def check():
+            lib, abi = e.lib, e.abi
+            one = self.shard.apply(lib.DeviceBatch.upload(b2)).transformed
+            grouped, counts = lib.partition(one, e.world)
+            back = self.comm.exchange(grouped, counts)[0] if self.comm is not None else grouped
+            col = lib.collapse(back)
+            host = col.download()
+            why = _batch_diff(abi, host, a)
+            if why is None and not np.array_equal(host.src_row, a.src_row):
+                why = "kept rows (src_row)"
+            if why is None and host.kind is not None and a.kind is not None and not np.array_equal(host.kind, a.kind):
+                why = "kinds"
+            if why:
+                return _parity(k, "sharder + partition + exchange + Collapse", why)
+            got = lib.queue_serialize(self.qopts, col, meta)
+            if want is None or bytes(got.values.download()) != b"".join(want) or len(got) != len(want):
+                return _parity(k, "native queue serializer", "messages differ")
+            return _parity(k, "sharder + partition + exchange (1 rank) + Collapse (cell for cell, kept rows, kinds) + native queue serializer (byte for byte)",
+                           compared_output_rows=host.nrows, compared_messages=len(want))
+        out["parity"] = _guard_parity(check)
         return out
 
 
@@ -1526,6 +1776,8 @@ def main():
                     "(tfgpu_init_devices); without it --gpus N > 1 expects one process per GPU under torch.distributed.run")
     ap.add_argument("--sink", default="native", choices=["native", "debezium"], help="configs4: the queue sink's format — the native serializer, or the Debezium emitter "
                     "(queue.DebeziumSerializer, key + value with inline schemas: tfgpu_debezium_emit)")
+    ap.add_argument("--from-rows", action="store_true", help="configs0: also cross the boundary the way the reference would — boxed []interface{} rows fanned out into column buffers, "
+                    "one crossing, fanned back in (tools/fanout/fanout_harness.cpp, INTEGRATION.md §2), timed per leg")
     ap.add_argument("--exchange", type=int, default=1, help="configs4 at 1 rank: 1 = every buffer still makes the RCCL round trip, 0 = skip the collective")
     args = ap.parse_args()
 
@@ -1591,8 +1843,13 @@ def main():
         lib.synchronize()
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
-    dt = e.group.max_seconds(W.timed(args.steps * passes))
+    my_dt = W.timed(args.steps * passes)
+    dt = e.group.max_seconds(my_dt)
     W.dt = dt
+    # the N-GPU run validates itself: every rank's own time and rows arrive on rank 0 through the collective library
+    rank_ms = e.group.all_gather_float(my_dt / args.steps * 1e3)
+    rank_rows = e.group.all_gather_float(float(W.rows() * passes))
+    ranks_seen = e.group.sum_int(1)
     ms_per_pass = dt / (args.steps * passes) * 1e3
 
     # ---- per-kernel device time: HIP events on the library stream, IMMEDIATELY after the timed region (before any side
@@ -1694,6 +1951,10 @@ def main():
         out.update(W.extra())
         if e.devices:
             out["process_model"] = {"mode": "one process, one host thread and one lane per device (tfgpu_init_devices)", "devices": e.devices, "row_range_shards": shards}
+        out["multi_gpu"] = {"rccl_ranks_seen": ranks_seen, "world_size": world, "per_rank_ms_per_step": [round(x, 3) for x in rank_ms],
+                            "per_rank_rows_per_step": [int(x) for x in rank_rows],
+                            "n1_equivalent": "every rank runs exactly the N=1 step over its own row-range shard (rows %d.. of the same synthetic table): value = sum of per_rank_rows_per_step x steps / max time" % (rows * (world - 1)),
+                            "measured_beyond_one_gpu": "nothing beyond N=1 had been measured on hardware when this was written (README.md): at N>1 this line is the first evidence" if world > 1 else None}
         out["row_errors"] = W.state.get("errors", 0)
         out["roofline"] = roofline
         if int_roof:
@@ -1705,11 +1966,15 @@ def main():
         # such a line is not printed.
         bad = [(n, r.get("kernel"), f) for n, r in (("roofline", roofline), ("int_roofline", int_roof)) if r
                for f in (r.get("frac"), r.get("issue_frac"), r.get("frac_with_text_views")) if f is not None and f > 1.0]
-        bad += [("kernels", n, v["alg_gb_s"] / HBM_PEAK_GBS) for n, v in kernels.items() if v.get("alg_gb_s", 0) > HBM_PEAK_GBS]
+        for n, v in kernels.items():  # a secondary kernel priced against bytes it does not see (a hand-over path that ran on a few rows): its figure is withheld, not printed
+            if v.get("alg_gb_s", 0) > HBM_PEAK_GBS and n != dom:
+                v["alg_gb_s"] = None
+                v["alg_note"] = "launched on a fraction of the batch: not priced"
         if bad:
             raise SystemExit("bench.py refuses to print a roofline fraction above 1: %r" % bad)
         if cpu and isinstance(cpu.get("parity"), dict):
             out["parity_checked_rows"] = cpu["parity"].get("checked_input_rows", 0) if cpu["parity"].get("identical") else 0
+            out["parity"] = {k: v for k, v in cpu["parity"].items() if k in ("identical", "checked", "checked_input_rows", "error")}
         # the comparison that means something end to end: input from pinned host memory (PCIe inside) against the CPU path on
         # every host core; the HBM-resident `value` over one CPU core is a ratio of two different jobs and is not printed
         pc = (side.get("pcie_inclusive") or {}) if isinstance(side, dict) else {}

@@ -410,6 +410,12 @@ const char *tfgpu_registry_name(int i);
 int tfgpu_batch_upload(const tfgpu_batch *host, tfgpu_dbatch **out);
 /* Borrowed view with DEVICE pointers (valid until tfgpu_dbatch_free).       */
 int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *view);
+/* The batch's rows (len(items)) without touching its columns: the rows of a batch that left filter_rows / skip_events may still be a
+ * SELECTION over the batch the filter read (gathered by the first call that reads columns: view, download, a serializer, any
+ * transformer but mask_field) — a sink that only counts and drops (devnull) never pays for the gather.  -1 for NULL.           */
+int64_t tfgpu_dbatch_nrows(const tfgpu_dbatch *b);
+/* Gathers the rows of a batch that are still a selection, now (a sink that is about to read every column anyway); no-op otherwise. */
+int tfgpu_dbatch_dense(const tfgpu_dbatch *b);
 /* Copy into caller-allocated host buffers sized from the view.              */
 int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *host_out);
 void tfgpu_dbatch_free(tfgpu_dbatch *b);

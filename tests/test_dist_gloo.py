@@ -38,7 +38,9 @@ WORKER = textwrap.dedent("""
     mx = g.max_seconds(dt)
     rows = g.sum_int(shard.count(b"\\n"))
     g.barrier()
-    print(json.dumps({{"rank": g.rank, "lo": lo, "hi": hi, "sha": hashlib.sha256(shard).hexdigest(), "len": len(shard), "dt": dt, "max": mx, "rows": rows}}))
+    per_rank = g.all_gather_float(dt)   # what bench.py prints per rank (multi_gpu.per_rank_ms_per_step)
+    seen = g.sum_int(1)
+    print(json.dumps({{"rank": g.rank, "lo": lo, "hi": hi, "sha": hashlib.sha256(shard).hexdigest(), "len": len(shard), "dt": dt, "max": mx, "rows": rows, "per_rank": per_rank, "seen": seen}}))
     g.close()
 """)
 
@@ -65,6 +67,8 @@ def test_two_ranks_over_gloo(tmp_path):
     # every rank sees the slowest rank's time; the job's rows are the sum of the shards
     assert abs(outs[0]["max"] - outs[1]["max"]) < 1e-9 and outs[0]["max"] >= outs[1]["dt"] - 1e-9 and outs[0]["max"] > outs[0]["dt"]
     assert outs[0]["rows"] == outs[1]["rows"] == 3001
+    # every rank's own time reaches every rank, in rank order; the ranks count themselves
+    assert outs[0]["per_rank"] == outs[1]["per_rank"] == [outs[0]["dt"], outs[1]["dt"]] and outs[0]["seen"] == outs[1]["seen"] == 2
     # shards in rank order == the single-process input
     whole = workload.hits_csv(3001, header=False)
     a = workload.hits_csv(outs[0]["hi"], row0=0, header=False)

@@ -410,3 +410,52 @@ def test_replace_primary_key_on_a_run_that_already_carries_old_keys(tf):
     with pytest.raises(tf.TfgpuError) as ei:
         tf.Transformer("replace_primary_key", {"keys": ["n"], "tables": {}}).apply(tf.DeviceBatch.upload(b))
     assert ei.value.code == tf.ERR_UNSUPPORTED
+
+
+def test_kept_rows_stay_a_selection_until_read(tf, oracle):
+    """filter_rows / skip_events hand their kept rows on as a selection over the batch they read (tfgpu_dbatch::pending, tf_common.hpp);
+    the row count is known without a gather, mask_field reads THROUGH the selection, and every consumer that reads columns gets exactly
+    what it gets from the same rows gathered up front."""
+    rng = np.random.default_rng(SEED0 + 991)
+    b, schema = _random_batch(rng, 4000)
+    b.kind = rng.choice(np.array([0, 0, 0, 1], np.uint8), 4000)
+    filt = tf.Transformer("filter_rows", {"filter": "i64 > 0"})
+    skip = tf.Transformer("skip_events", {"events": ["update"]})
+    mask = tf.Transformer("mask_field", {"maskFunctionHash": {"userDefinedSalt": "s"}, "columns": ["i32", "s"]})
+    mask2 = tf.Transformer("mask_field", {"maskFunctionHash": {"userDefinedSalt": "t"}, "columns": ["s", "u8"]})
+    ref = oracle.apply_chain([oracle.Transformer("skip_events", {"events": ["update"]}), oracle.Transformer("filter_rows", {"filter": "i64 > 0"})], b, schema)
+
+    def kept():  # a fresh batch whose rows are a selection: skip_events (forces nothing: the input is dense), then filter_rows
+        return tf.apply_chain([skip, filt], tf.DeviceBatch.upload(b)).transformed
+    p = kept()
+    assert p.nrows == ref.batch.nrows and 0 < p.nrows < 4000          # no column was touched
+    dense = tf.DeviceBatch.upload(kept().download())                    # the same rows, gathered (download reads columns)
+    assert_batches_equal(dense.download(), ref.batch, "gathered")
+    # mask → mask over the selection, then read
+    got = tf.apply_chain([mask, mask2], kept()).transformed.download()
+    want = oracle.apply_chain([oracle.Transformer("mask_field", {"maskFunctionHash": {"userDefinedSalt": "s"}, "columns": ["i32", "s"]}),
+                               oracle.Transformer("mask_field", {"maskFunctionHash": {"userDefinedSalt": "t"}, "columns": ["s", "u8"]})], ref.batch, ref.schema)
+    assert_batches_equal(got, want.batch, "mask over a selection")
+    assert np.array_equal(got.src_row, want.batch.src_row)
+    # consumers: the selection against the gathered rows
+    for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
+        assert tf.serialize(fmt, kept()).download() == tf.serialize(fmt, dense).download(), fmt
+    assert tf.deepsizeof(kept()) == tf.deepsizeof(dense)
+    shard = tf.Transformer("sharder_transformer", {"shardsCount": "3", "columns": {"includeColumns": ["^i64$"]}})
+    sharded = tf.apply_chain([shard, skip, filt], tf.DeviceBatch.upload(b)).transformed               # part_id rides through the selection
+    a, ca = tf.partition(sharded, 3)
+    d, cd = tf.partition(tf.apply_chain([shard], dense).transformed, 3)
+    assert list(ca) == list(cd)
+    assert_batches_equal(a.download(), d.download(), "partition")
+    assert_batches_equal(kept().slice(8, 100).download(), dense.slice(8, 100).download(), "slice")
+    assert_batches_equal(tf.DeviceBatch.concat([kept(), kept()]).download(), tf.DeviceBatch.concat([dense, dense]).download(), "concat")
+    q = abi.queue_options(abi.QFMT_JSON, enabled=False)
+    assert tf.queue_serialize(q, kept()).values.download() == tf.queue_serialize(q, dense).values.download()
+    # a second filter reads columns: the first one's rows are gathered for it
+    two = tf.apply_chain([filt, tf.Transformer("filter_rows", {"filter": "i32 > 0"})], tf.DeviceBatch.upload(b)).transformed.download()
+    want2 = oracle.apply_chain([oracle.Transformer("filter_rows", {"filter": "i64 > 0"}), oracle.Transformer("filter_rows", {"filter": "i32 > 0"})], b, schema)
+    assert_batches_equal(two, want2.batch, "filter after filter")
+    # a view gathers in place: the handle then shows the same rows densely, again and again
+    p2 = kept()
+    assert p2.view().ncols == len(b.cols) and p2.nrows == ref.batch.nrows
+    assert_batches_equal(p2.download(), ref.batch, "view, then download")

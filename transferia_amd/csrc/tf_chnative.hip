@@ -207,6 +207,7 @@ bool repr_fits(int repr, ChBase b) {
 
 extern "C" int tfgpu_ch_native_block(const tfgpu_dbatch *in, const tfgpu_ch_native_column *cols, int32_t ncols, tfgpu_dbuf **out) {
   TF_API_BEGIN
+  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!in || !out || ncols < 0 || (ncols && !cols)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_ch_native_block: bad argument");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);

@@ -471,6 +471,7 @@ int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags) {
 
 extern "C" int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed, int64_t *nchanged) {
   try {
+  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!in || !changed) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_keys_changed: null argument");
     std::lock_guard<std::mutex> lk(tf::ctx().mu);
     const int64_t c = tf::keys_changed_rows(*in, changed);
@@ -483,6 +484,7 @@ extern "C" int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed, int6
 
 extern "C" int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out) {
   try {
+  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_collapse: null argument");
     std::lock_guard<std::mutex> lk(tf::ctx().mu);
     *out = tf::collapse_rows(*in).release();

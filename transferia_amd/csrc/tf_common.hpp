@@ -197,15 +197,33 @@ struct DColumn {
 };
 // Packs the lazy text columns of `b` (all of them, or only those listed) from their source text; no-op otherwise.
 void materialize(const struct ::tfgpu_dbatch &b, const std::vector<const DColumn *> *only = nullptr);
+// Gathers the rows of a batch whose rows are still a selection (tfgpu_dbatch::pending); no-op otherwise.  dense() takes the lane's
+// mutex itself (call it BEFORE locking); dense_locked() is for callers that hold it.
+void dense(const struct ::tfgpu_dbatch *b);
+void dense_locked(const struct ::tfgpu_dbatch &b);
 // The library-owned HBM block that starts at `p` (a tfgpu_dbuf), or null for foreign pointers.
 Buf find_device_block(const void *p);
 void register_device_block(const Buf &b);
 
 }  // namespace tf
 
+// Rows a row filter kept but nobody has read yet (late materialisation of ROWS, the counterpart of TextView): filter_rows and
+// skip_events hand on "rows sel[0 .. nrows) of the batch I read" instead of gathering 100 columns for a sink that may drop them
+// (devnull), a serializer that walks a selection anyway, or a next transformer that reads two of them.  The kept ChangeItems of the
+// reference alias the input items the same way (filter_rows.go:99-125 appends the item, it copies no value).  tf::dense() gathers —
+// every C-ABI entry that reads a batch's columns calls it first; transformers that can work through a selection (mask_field) do.
+namespace tf {
+struct PendingRows {
+  std::shared_ptr<const struct ::tfgpu_dbatch> src;  // the dense batch the filter read
+  Buf sel;                                           // int32[nrows]: the kept rows of src, ascending
+};
+}  // namespace tf
+
 struct tfgpu_dbatch {
   int64_t nrows = 0;
-  std::vector<tf::DColumn> cols;
+  std::vector<tf::DColumn> cols;                    // EMPTY while `pending` is set
+  std::shared_ptr<tf::PendingRows> pending;         // set: this batch is nrows selected rows of pending->src, not gathered yet
+  std::vector<tf::DColumn> replaced;                // with `pending`: columns already computed over the kept rows (dense, by name)
   std::vector<std::pair<std::string, int>> schema;  // TableSchema (name, DataType) in order; empty = same as cols
   std::vector<std::string> key_names;               // names of the PrimaryKey columns of that schema (MakeMapKeys)
   std::vector<tf::DColumn> old_keys;                // OldKeys.KeyValues by KeyNames; empty = no row has OldKeys

@@ -2948,6 +2948,7 @@ static DColumn float_column_text(const DColumn &c, int64_t n) {
 
 extern "C" int tfgpu_strictify(const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_dbatch **out, int64_t *bad_row, int32_t *bad_col) {
   TF_API_BEGIN
+  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_strictify: null argument");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);

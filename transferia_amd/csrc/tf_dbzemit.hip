@@ -1347,6 +1347,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
                                    tfgpu_dbuf **values, uint64_t *val_start, uint8_t *val_null, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
   using namespace tf; using namespace tf::dbz;
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!o || !b || !keys || !values || !nmsg || !o->table_schema || (cap > 0 && (!key_start || !val_start || !val_null || !msg_row)))
       return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: null argument");
     if (o->nparams < 0 || (o->nparams > 0 && (!o->param_keys || !o->param_values))) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: nparams without the key / value arrays");

@@ -417,6 +417,7 @@ int tfgpu_comm_world(const tfgpu_comm *c) { return c ? c->world : 0; }
 
 int tfgpu_exchange(tfgpu_comm *c, const tfgpu_dbatch *in, const int64_t *counts, tfgpu_dbatch **out, int64_t *recv_counts) {
   TF_API_BEGIN
+  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!c || !in || !counts || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_exchange: null argument");
   std::lock_guard<std::mutex> lk(c->mu);       // a communicator carries one collective at a time
   std::lock_guard<std::mutex> lk2(ctx().mu);

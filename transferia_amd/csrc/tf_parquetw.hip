@@ -192,6 +192,7 @@ using namespace tf::pqw;
 
 extern "C" int tfgpu_parquet_write(const tfgpu_dbatch *b, const tfgpu_schema *schema, const char *codec_name, int64_t row_group_max_rows, uint64_t row_group_max_bytes, void **bytes, uint64_t *len) {
   TF_API_BEGIN
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !schema || !bytes || !len || (schema->ncols && !schema->cols)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_write: null argument");
   const std::string cn = codec_name ? codec_name : "";
   const int codec = cn == "SNAPPY" ? C_SNAPPY : cn == "GZIP" ? C_GZIP : cn == "ZSTD" ? C_ZSTD : C_UNCOMPRESSED;  // CodecFromString: anything else is uncompressed

@@ -422,8 +422,18 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
 struct ViewStore { std::vector<tfgpu_column> cols; std::vector<tfgpu_colschema> scols; tfgpu_schema schema; };
 static thread_local ViewStore g_view;
 
+int64_t tfgpu_dbatch_nrows(const tfgpu_dbatch *b) { return b ? b->nrows : -1; }
+int tfgpu_dbatch_dense(const tfgpu_dbatch *b) {
+  TF_API_BEGIN
+  if (!b) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_dense: null argument");
+  tf::dense(b);
+  return TFGPU_OK;
+  TF_API_END
+}
+
 int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   TF_API_BEGIN
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !v) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_view: null argument");
   { std::lock_guard<std::mutex> lk(ctx().mu); materialize(*b); }  // the view exposes packed payload pointers
   g_view.cols.assign(b->cols.size() + b->old_keys.size(), tfgpu_column{});
@@ -459,6 +469,7 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
 
 int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
   TF_API_BEGIN
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !h) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: null argument");
   if (h->ncols != (int32_t)b->cols.size() || h->nrows != b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: shape mismatch");
   if (h->n_old_keys && h->n_old_keys != (int32_t)b->old_keys.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: old-key shape mismatch");

@@ -806,6 +806,7 @@ static int serialize_raw(const tfgpu_dbatch *b, const tfgpu_serialize_options *o
 
 extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out) {
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!b || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize: null argument");
     if (format == TFGPU_FMT_RAW) return serialize_raw(b, opts, out);
     if (format != TFGPU_FMT_CH_JSON_EACH_ROW && format != TFGPU_FMT_JSON && format != TFGPU_FMT_CSV)
@@ -979,6 +980,7 @@ extern "C" int tfgpu_serialize(int format, const tfgpu_dbatch *b, tfgpu_dbuf **o
 extern "C" int tfgpu_serialize_batch(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, const tfgpu_batch_serializer_config *cfg,
                                      int for_writer, tfgpu_dbuf **out, uint64_t *part_ends, int64_t part_cap, int64_t *nparts) {
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!b || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize_batch: null argument");
     if (format != TFGPU_FMT_JSON && format != TFGPU_FMT_CSV && format != TFGPU_FMT_RAW)
       return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize_batch: the batch serializers are raw, json and csv (batch_factory.go:31-63)");
@@ -1100,6 +1102,7 @@ static void column_messages(const tfgpu_dbatch &b, const DColumn &c, bool all_ro
 
 extern "C" int tfgpu_queue_raw_column(const tfgpu_dbatch *b, const char *column, const tfgpu_schema *schema, tfgpu_dbuf **values, uint32_t *msg_start, int64_t cap, int64_t *nmsg) {
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!b || !column || !values || !msg_start || !nmsg || cap < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_raw_column: null argument");
     tf::Context &cx = tf::ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
@@ -1131,6 +1134,7 @@ extern "C" int tfgpu_queue_raw_column(const tfgpu_dbatch *b, const char *column,
 extern "C" int tfgpu_queue_mirror(const tfgpu_dbatch *b, const tfgpu_schema *schema, tfgpu_dbuf **values, uint32_t *msg_start, tfgpu_dbuf **keys, uint32_t *key_start,
                                   uint8_t *key_nil, int64_t cap, int64_t *nmsg) {
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!b || !values || !msg_start || !keys || !key_start || !key_nil || !nmsg || cap < 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_mirror: null argument");
     tf::Context &cx = tf::ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
@@ -1164,6 +1168,7 @@ extern "C" int tfgpu_queue_mirror(const tfgpu_dbatch *b, const tfgpu_schema *sch
 // come out by first appearance.  order[nrows]: the rows, group after group, input order inside a group; group_rows / group_part_id per group.
 extern "C" int tfgpu_queue_part_groups(const tfgpu_dbatch *b, int32_t *order, int64_t *group_rows, uint32_t *group_part_id, int64_t cap, int64_t *ngroups) {
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!b || !order || !group_rows || !group_part_id || !ngroups || cap < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_part_groups: bad argument");
     tf::Context &cx = tf::ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
@@ -1209,6 +1214,7 @@ __global__ void __launch_bounds__(256) kafka_partition_kernel(const uint32_t *of
 // … for a column of keys at once (the Mirror serializer's `sequence_key`, a RawColumn key column): partitions[r], -1 for a nil key
 extern "C" int tfgpu_kafka_partitions(const tfgpu_dbatch *b, const char *key_column, int32_t npartitions, int32_t *partitions) {
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!b || !key_column || !partitions || npartitions <= 0) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_kafka_partitions: bad argument");
     tf::Context &cx = tf::ctx();
     std::lock_guard<std::mutex> lk(cx.mu);
@@ -1318,6 +1324,7 @@ template <class T> static const T *meta_array(const tfgpu_row_meta *m, const T *
 extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_dbatch *b, const tfgpu_row_meta *meta, tfgpu_dbuf **values,
                                      uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
   try {
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!o || !b || !values || !nmsg || (cap > 0 && (!msg_start || !msg_row))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: null argument");
     if (o->format != TFGPU_QFMT_NATIVE && o->format != TFGPU_QFMT_JSON) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: unknown format");
     const bool native = o->format == TFGPU_QFMT_NATIVE;

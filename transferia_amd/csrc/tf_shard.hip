@@ -300,6 +300,7 @@ extern "C" {
 
 int tfgpu_dbatch_slice(const tfgpu_dbatch *b, int64_t row0, int64_t nrows, tfgpu_dbatch **out) {
   TF_API_BEGIN
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !out || row0 < 0 || nrows < 0 || row0 + nrows > b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_slice: bad argument");
   if (row0 & 7) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_slice: row0 must be a multiple of 8 (bitmaps are cut at byte boundaries)");
   std::lock_guard<std::mutex> lk(ctx().mu);
@@ -312,6 +313,7 @@ int tfgpu_dbatch_slice(const tfgpu_dbatch *b, int64_t row0, int64_t nrows, tfgpu
 
 int tfgpu_dbatch_to_lane(const tfgpu_dbatch *b, int lane, tfgpu_dbatch **out) {
   TF_API_BEGIN
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !out || lane < 0 || lane >= tfgpu_lane_count()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_to_lane: bad argument");
   { std::lock_guard<std::mutex> lk(ctx().mu); materialize(*b); tf::sync(); }  // everything enqueued for `b` on this lane has run
   *out = to_lane(*b, lane).release();
@@ -321,6 +323,7 @@ int tfgpu_dbatch_to_lane(const tfgpu_dbatch *b, int lane, tfgpu_dbatch **out) {
 
 int tfgpu_shard_rows(const tfgpu_dbatch *b, int nshards, const int *lanes, tfgpu_dbatch **out, int64_t *row0) {
   TF_API_BEGIN
+  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !out || nshards < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_shard_rows: bad argument");
   for (int g = 0; lanes && g < nshards; g++) if (lanes[g] < 0 || lanes[g] >= tfgpu_lane_count()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_shard_rows: lane out of range");
   std::vector<int64_t> cuts((size_t)nshards + 1, 0);
@@ -349,6 +352,7 @@ int tfgpu_dbatch_concat(const tfgpu_dbatch *const *parts, int nparts, const int6
   if (!parts || !out || nparts < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: bad argument");
   std::vector<const tfgpu_dbatch *> v;
   for (int g = 0; g < nparts; g++) { if (!parts[g]) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: null part"); v.push_back(parts[g]); }
+  for (auto *b : v) tf::dense(b);  // rows that are still a selection (tfgpu_dbatch::pending)
   std::lock_guard<std::mutex> lk(ctx().mu);
   *out = concat(v, row_base).release();
   return TFGPU_OK;

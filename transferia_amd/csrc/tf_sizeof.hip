@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) deepsizeof_rows(const SzCol *cols, int nc
 
 extern "C" int tfgpu_dbatch_deepsizeof(const tfgpu_dbatch *in, uint32_t flags, uint64_t *per_row, uint64_t *total) {
   TF_API_BEGIN
+  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!in || !total) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_deepsizeof: null argument");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);

@@ -104,6 +104,7 @@ struct MaskParams {
   uint32_t ipad[8], opad[8];
   int64_t nrows;
   uint8_t *out;  // nrows * 64 hex bytes
+  const int32_t *sel;  // non-null: output row r hashes the column's row sel[r] (the batch's rows are still a selection)
 };
 
 // The text of an integer (or "<nil>") is at most 21 bytes: built in three registers as a little-endian byte string — the emitters of
@@ -135,8 +136,9 @@ __device__ __forceinline__ bool mask_small_int(const DCol &c, int64_t r, Text24 
 }
 
 __global__ void __launch_bounds__(256) mask_hmac_kernel(MaskParams p) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= p.nrows) return;
+  const int64_t ro = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // the row written
+  if (ro >= p.nrows) return;
+  const int64_t r = p.sel ? (int64_t)p.sel[ro] : ro;                   // the row read
   uint32_t st[8], w[16];
 #pragma unroll
   for (int i = 0; i < 8; i++) st[i] = p.ipad[i];
@@ -187,7 +189,7 @@ __global__ void __launch_bounds__(256) mask_hmac_kernel(MaskParams p) {
   for (int i = 0; i < 8; i++) so[i] = p.opad[i];
   sha256_compress(so, w);
   // hex.EncodeToString: 64 lower-case hex chars, stored as 4 x 16 bytes
-  uint4 *dst = reinterpret_cast<uint4 *>(p.out + r * 64);
+  uint4 *dst = reinterpret_cast<uint4 *>(p.out + ro * 64);
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     uint32_t o[4];
@@ -213,8 +215,11 @@ static std::unique_ptr<tfgpu_dbatch> shallow_copy(const tfgpu_dbatch &in) { retu
 
 // what apply_mask refuses for a whole batch, before anything is computed
 void mask_precheck(const tfgpu_plan &p, const tfgpu_dbatch &in) {
-  for (auto &c : in.cols) {
+  for (auto &c : (in.pending ? in.pending->src->cols : in.cols)) {
     if (!p.mask_has(c.name)) continue;
+    bool done = false;
+    for (auto &r : in.replaced) if (r.name == c.name) done = true;  // (masked already: a string, always serializable)
+    if (done) continue;
     require_serializable(c, "mask_field");
     if ((uint64_t)in.nrows * 64 > 0xFFFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "mask_field: batch too large for 32-bit offsets; split the batch by rows");
   }
@@ -253,15 +258,20 @@ static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu
   auto out = shallow_copy(in);
   for (auto &sc : out->schema) if (p.mask_has(sc.first)) sc.second = TFGPU_T_UTF8;  // hmac_hasher.go:35-46
   hipStream_t st = ctx().stream;
+  // The batch's rows may still be a selection over the batch a filter_rows read (tfgpu_dbatch::pending): the hash reads the masked
+  // column's kept rows THROUGH the selection and its 64-byte digests are the first column of the result that exists densely —
+  // the other hundred columns stay ungathered until somebody reads them.
+  const tfgpu_dbatch &from = in.pending ? *in.pending->src : in;
+  const int32_t *sel = in.pending ? ptr<int32_t>(in.pending->sel) : nullptr;
+  auto replaced_at = [&](const std::string &name) -> int { for (size_t i = 0; i < in.replaced.size(); i++) if (in.replaced[i].name == name) return (int)i; return -1; };
   {
     std::vector<const DColumn *> need;
-    for (auto &c : in.cols) if (p.mask_has(c.name)) need.push_back(&c);
-    materialize(in, &need);
+    for (auto &c : from.cols) if (p.mask_has(c.name) && replaced_at(c.name) < 0) need.push_back(&c);
+    materialize(from, &need);
   }
-  for (auto &c : out->cols) {
-    if (!p.mask_has(c.name)) continue;
+  const int64_t n = in.nrows;
+  auto mask_one = [&](const DColumn &c, const int32_t *through) {
     require_serializable(c, "mask_field");
-    int64_t n = in.nrows;
     if ((uint64_t)n * 64 > 0xFFFFFFFFull) throw Error(TFGPU_ERR_UNSUPPORTED, "mask_field: batch too large for 32-bit offsets; split the batch by rows");
     DColumn o;
     o.name = c.name; o.dtype = TFGPU_T_UTF8; o.repr = TFGPU_R_STRING;
@@ -272,13 +282,23 @@ static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu
     mp.col = dcol_of(c);
     std::memcpy(mp.ipad, p.ipad_state, sizeof mp.ipad);
     std::memcpy(mp.opad, p.opad_state, sizeof mp.opad);
-    mp.nrows = n; mp.out = ptr<uint8_t>(o.data);
+    mp.nrows = n; mp.out = ptr<uint8_t>(o.data); mp.sel = through;
     {
       KernelTimer t("mask_hmac_sha256", n);
       if (n) mask_hmac_kernel<<<grid_for(n, 256), 256, 0, st>>>(mp);
     }
     fill_offsets_stride_kernel<<<grid_for(n + 1, 256), 256, 0, st>>>(ptr<uint32_t>(o.offsets), n, 64);
-    c = std::move(o);
+    return o;
+  };
+  if (!in.pending) {
+    for (auto &c : out->cols) if (p.mask_has(c.name)) c = mask_one(c, nullptr);
+    return out;
+  }
+  for (auto &c : from.cols) {
+    if (!p.mask_has(c.name)) continue;
+    const int ri = replaced_at(c.name);
+    if (ri >= 0) out->replaced[(size_t)ri] = mask_one(in.replaced[(size_t)ri], nullptr);  // (already dense over the kept rows)
+    else out->replaced.push_back(mask_one(c, sel));
   }
   return out;
 }
@@ -606,7 +626,8 @@ __global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int
 }
 
 // Gather all columns of `in` through `sel` (m output rows).
-static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const Buf &sel, int64_t m) {
+static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const Buf &sel, int64_t m, const std::vector<DColumn> *skip = nullptr) {
+  // (skip: columns — by name — whose kept rows exist already: they are not gathered, their slot takes the given column)
   auto out = std::make_unique<tfgpu_dbatch>();
   out->nrows = m; out->ns = in.ns; out->table = in.table; out->schema = in.schema;
   hipStream_t st = ctx().stream;
@@ -621,11 +642,17 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
   out->cols.reserve(ncur); out->old_keys.reserve(in.old_keys.size());
   out->key_names = in.key_names;
   int nvar = 0;
-  for (size_t i = 0; i < nall; i++) if (repr_is_var(col_at(i).repr)) nvar++;
+  for (size_t i = 0; i < nall; i++) if (repr_is_var(col_at(i).repr) && !(skip && i < ncur && [&] { for (auto &r : *skip) if (r.name == in.cols[i].name) return true; return false; }())) nvar++;
   const int64_t seg_stride = ((m + 1 + 3) / 4) * 4;
   Buf lens_all = nvar ? dalloc((size_t)nvar * (size_t)seg_stride * 4 + 16) : nullptr;
+  auto skipped = [&](size_t ai) -> const DColumn * {
+    if (!skip || ai >= ncur) return nullptr;
+    for (auto &r : *skip) if (r.name == in.cols[ai].name) return &r;
+    return nullptr;
+  };
   for (size_t ai = 0; ai < nall; ai++) {
     const DColumn &c = col_at(ai);
+    if (const DColumn *have = skipped(ai)) { out->cols.push_back(*have); continue; }
     DColumn o;
     o.name = c.name; o.dtype = c.dtype; o.repr = c.repr;
     if (repr_is_var(c.repr)) {
@@ -706,8 +733,14 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
 
 std::unique_ptr<tfgpu_dbatch> gather_rows(const tfgpu_dbatch &in, const Buf &sel, int64_t m) { return gather_batch(in, sel, m); }  // for tf_collapse.hip
 
-// keep flags (uint32 0/1, n+1 slots) → compacted batch; identity if all kept
-static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /* n+1 u32 */) {
+// TFGPU_LAZY_ROWS=0: the row filters gather their kept rows at once (the form of rounds 1-4; A/B measurements)
+static bool lazy_rows_on() {
+  static const bool off = [] { const char *e = std::getenv("TFGPU_LAZY_ROWS"); return e && e[0] == '0'; }();
+  return !off;
+}
+// keep flags (uint32 0/1, n+1 slots) → compacted batch; identity if all kept.  lazy: the kept rows are handed on as a selection
+// over `in` (tfgpu_dbatch::pending) and gathered when — and if — somebody reads them.
+static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /* n+1 u32 */, bool lazy = false) {
   int64_t n = in.nrows;
   exclusive_scan_u32(ptr<uint32_t>(keep), ptr<uint32_t>(keep), n, true);
   const uint32_t *hm = d2h_u32(ptr<uint32_t>(keep) + n);
@@ -716,7 +749,32 @@ static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /*
   if ((int64_t)m == n) return shallow_copy(in);
   Buf sel = dalloc((size_t)m * 4 + 4);
   if (n) build_selection_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint32_t>(keep), n, ptr<int32_t>(sel));
+  if (lazy && lazy_rows_on() && !in.pending && m) {
+    auto out = std::make_unique<tfgpu_dbatch>();
+    out->nrows = m; out->ns = in.ns; out->table = in.table; out->schema = in.schema; out->key_names = in.key_names;
+    auto pr = std::make_shared<PendingRows>();
+    pr->src = std::make_shared<const tfgpu_dbatch>(in);  // (a shallow copy: the buffers are shared)
+    pr->sel = sel;
+    out->pending = std::move(pr);
+    return out;
+  }
   return gather_batch(in, sel, m);
+}
+
+void dense_locked(const tfgpu_dbatch &b) {
+  if (!b.pending) return;
+  tfgpu_dbatch &mb = const_cast<tfgpu_dbatch &>(b);  // (the handle's observable value does not change: the same rows, now gathered)
+  std::shared_ptr<PendingRows> pr = b.pending;
+  std::unique_ptr<tfgpu_dbatch> g = gather_batch(*pr->src, pr->sel, b.nrows, b.replaced.empty() ? nullptr : &b.replaced);
+  mb.cols = std::move(g->cols); mb.old_keys = std::move(g->old_keys); mb.old_present = g->old_present;
+  mb.kind = g->kind; mb.src_row = g->src_row; mb.part_id = g->part_id;
+  mb.replaced.clear();
+  mb.pending.reset();
+}
+void dense(const tfgpu_dbatch *b) {
+  if (!b || !b->pending) return;
+  std::lock_guard<std::mutex> lk(ctx().mu);
+  dense_locked(*b);
 }
 
 std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep) { return compact(in, keep); }
@@ -799,7 +857,7 @@ static std::unique_ptr<tfgpu_dbatch> run_filter(const std::vector<FExpr> &p_expr
     if (n) filter_eval_kernel<<<grid_for(n, 256), 256, 0, st>>>(fp);
   }
   const uint32_t *hn = d2h_u32(nerr->p);
-  auto out = compact(in, keep);  // syncs
+  auto out = compact(in, keep, true);  // syncs; the kept rows stay a selection until somebody reads them
   if (*hn) collect_row_errors(err, eterm, n, ax);
   return out;
 }
@@ -821,7 +879,7 @@ static std::unique_ptr<tfgpu_dbatch> apply_skip_events(const tfgpu_plan &p, cons
   }
   Buf keep = dalloc((size_t)(n + 1) * 4);
   if (n) kind_keep_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(in.kind), n, mask, ptr<uint32_t>(keep));
-  return compact(in, keep);
+  return compact(in, keep, true);
 }
 
 // ============================================================================
@@ -1518,6 +1576,7 @@ static std::unique_ptr<tfgpu_dbatch> apply_sql(const tfgpu_plan &p, const tfgpu_
     ev.run(p.sql_where_tree, nullptr, SQL_U8, ptr<uint32_t>(keep));
     kept = compact(*w, keep);  // syncs
   } else kept = p.sql_has_where ? run_filter(p.exprs, true, false, *w, ax) : std::move(w);
+  dense_locked(*kept);  // (the select list reads the kept rows' columns right away)
   const int64_t n = kept->nrows;
   // the select list
   auto out = std::make_unique<tfgpu_dbatch>();
@@ -1642,6 +1701,7 @@ std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &in, int nparts,
 }
 
 std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {
+  if (in.pending && p.kind != PK_MASK) dense_locked(in);  // (the callers hold the lane's mutex) only mask_field reads through a selection
   switch (p.kind) {
     case PK_MASK: return apply_mask(p, in);
     case PK_RENAME: return apply_rename(p, in);

@@ -68,6 +68,18 @@ class Group:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
+    def all_gather_float(self, v: float):
+        """[v of rank 0, v of rank 1, …] on every rank (one all_gather): what bench.py prints per rank so that the first N-GPU
+        run validates itself (every rank present, no straggler hidden behind the MAX)."""
+        if self.dist is None:
+            return [float(v)]
+        import torch
+        dev = self.device if self.device is not None else "cpu"
+        mine = torch.tensor([v], dtype=torch.float64, device=dev)
+        outs = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(outs, mine)
+        return [float(t.item()) for t in outs]
+
     def close(self):
         if self.dist is not None:
             self.dist.destroy_process_group()

@@ -31,7 +31,7 @@ EXPORTS = [
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_from_config", "tfgpu_transformation_size", "tfgpu_transformation_plan_type", "tfgpu_transformation_errors_output", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
     "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_sr_compile_schema", "tfgpu_sr_schema_info", "tfgpu_sr_schema_free", "tfgpu_sr_compile_proto", "tfgpu_pb_schema_info", "tfgpu_pb_schema_free", "tfgpu_sr_proto_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_debezium_compile_schema", "tfgpu_dbz_schema_info", "tfgpu_dbz_schema_free", "tfgpu_dbz_receiver_create", "tfgpu_dbz_receiver_destroy", "tfgpu_dbz_receiver_known", "tfgpu_dbz_receive", "tfgpu_dbz_receive_group", "tfgpu_dbz_receive_group_meta", "tfgpu_debezium_compile_registry_schema", "tfgpu_dbz_receiver_add_registry_schema", "tfgpu_debezium_registry_frames", "tfgpu_dbz_receive_registry", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_serialize_batch", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_queue_raw_column", "tfgpu_queue_mirror", "tfgpu_queue_part_groups", "tfgpu_kafka_hash_partition", "tfgpu_kafka_partitions", "tfgpu_debezium_emit", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
-    "tfgpu_prof_get", "tfgpu_prof_get_units", "tfgpu_parquet_read_object", "tfgpu_parquet_resolve_schema",
+    "tfgpu_prof_get", "tfgpu_prof_get_units", "tfgpu_parquet_read_object", "tfgpu_parquet_resolve_schema", "tfgpu_dbatch_nrows", "tfgpu_dbatch_dense",
 ]
 
 
@@ -131,6 +131,9 @@ def load():
     L.tfgpu_prof_enable.argtypes = [C.c_int]
     L.tfgpu_prof_get.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.tfgpu_prof_get_units.argtypes = [C.c_int, C.POINTER(C.c_int64)]
+    L.tfgpu_dbatch_nrows.restype = C.c_int64
+    L.tfgpu_dbatch_nrows.argtypes = [C.c_void_p]
+    L.tfgpu_dbatch_dense.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -269,7 +272,12 @@ class DeviceBatch:
 
     @property
     def nrows(self) -> int:
-        return int(self.view().nrows)
+        return int(load().tfgpu_dbatch_nrows(self._h))  # (no column is touched: a filter's kept rows may still be a selection)
+
+    def dense(self) -> "DeviceBatch":
+        """gathers the kept rows now if they are still a selection (tfgpu_dbatch_dense); returns self"""
+        _check(load().tfgpu_dbatch_dense(self._h))
+        return self
 
     # ---- one process, several GPUs: row-range shards and their ordered merge (tf_shard.hip) ----
     def slice(self, row0: int, nrows: int) -> "DeviceBatch":
