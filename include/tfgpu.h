@@ -388,7 +388,16 @@ int tfgpu_host_free(void *p);
  * TFGPU_ERR_UNSUPPORTED naming the construct — the shim keeps the stock
  * transformer for it; a malformed query answers TFGPU_ERR_CONFIG.  Apply
  * runs Collapse first like the reference; a batch holding Updates that move
- * their primary key (SplitUpdatedPKeys) answers TFGPU_ERR_UNSUPPORTED.      */
+ * their primary key (SplitUpdatedPKeys) answers TFGPU_ERR_UNSUPPORTED.
+ * PARITY of "sql" is UNPINNED by construction: the authority is a ClickHouse
+ * binary that is not here; device and oracle (oracle/ora_sql.py) restate
+ * ClickHouse's documented typing and arithmetic.  That includes cityHash64:
+ * both sides restate CityHash v1.0.2 from its published description and
+ * agree with each other; the only value either is checked against is the
+ * empty string's (= the constant k2) — a shared misreading of the 17-32 /
+ * 33-64 / > 64-byte branches would not be caught here.  Row-wise expressions
+ * are where the device subset ends: aggregates, joins and several
+ * statements stay with the stock transformer.                                */
 int tfgpu_plan_create(const char *type_name, const char *config_json, tfgpu_plan **out);
 void tfgpu_plan_destroy(tfgpu_plan *plan);
 const char *tfgpu_plan_type(const tfgpu_plan *plan);                /* Type()        */

@@ -102,7 +102,7 @@ struct SchemaEl {
   bool utc = true; int unit = 0;         // TIME / TIMESTAMP: 1 MILLIS, 2 MICROS, 3 NANOS
   std::string name;
 };
-struct ColChunk { int type = -1, codec = 0; int64_t num_values = 0, data_off = -1, dict_off = -1, total_comp = 0, total_uncomp = 0; std::vector<std::string> path; };
+struct ColChunk { int type = -1, codec = 0; int64_t num_values = 0, data_off = -1, dict_off = -1, total_comp = 0, total_uncomp = 0; uint32_t enc_mask = 0 /* bit e: the chunk lists encoding e */; std::vector<std::string> path; };
 struct RowGroup { int64_t num_rows = 0; std::vector<ColChunk> cols; };
 struct FileMeta { std::vector<SchemaEl> schema; std::vector<RowGroup> groups; int64_t num_rows = 0; };
 
@@ -170,6 +170,7 @@ static void parse_col_meta(TReader &r, ColChunk &c) {
     if (!t || !r.ok) break;
     switch (id) {
       case 1: c.type = (int)r.zz(); break;
+      case 2: { int et; uint32_t n; r.list(et, n); for (uint32_t i = 0; i < n && r.ok; i++) { const int64_t e = r.zz(); if (e >= 0 && e < 32) c.enc_mask |= 1u << e; } break; }
       case 3: { int et; uint32_t n; r.list(et, n); for (uint32_t i = 0; i < n && r.ok; i++) c.path.push_back(r.binary()); break; }
       case 4: c.codec = (int)r.zz(); break;
       case 5: c.num_values = r.zz(); break;
@@ -806,6 +807,29 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   for (auto &g : m.groups) for (auto &c : g.cols) if (c.codec != C_UNCOMPRESSED) inflate = true;
   std::vector<uint8_t> arena;
   if (inflate) arena.reserve((size_t)len * 2);
+  // An uncompressed object starts uploading NOW, beside the host's page walk: what the tail can need at most is in the footer (a
+  // chunk lists its encodings: DELTA_BINARY_PACKED values decode into the tail, an INT96 column's texts live there, a
+  // DELTA_BYTE_ARRAY chunk sends the whole object through the arena instead).
+  Buf file;
+  uint64_t tail_base = 0, tail_cap = 0;
+  if (!inflate) {
+    uint64_t bound = 64;
+    for (size_t k = 0; k < fields.size(); k++) {
+      if (fields[k].group) continue;
+      const SchemaEl &e = fields[k].el;
+      if (e.type == T_INT96) bound += (uint64_t)std::max<int64_t>(nrows, 1) * 32 + 16;
+      for (auto &g : m.groups) {
+        const ColChunk &c = g.cols[(size_t)fields[k].leaf];
+        if ((c.enc_mask >> E_DELTA_BINARY_PACKED) & 1u) bound += (uint64_t)std::max<int64_t>(c.num_values, 0) * 8 + 16 * (uint64_t)(std::max<int64_t>(c.num_values, 0) / 64 + 2);  // (every page's share is rounded up to 16 bytes)
+      }
+    }
+    tail_base = (len + 64 + 15) & ~15ull;
+    tail_cap = bound;
+    if (tail_base + tail_cap + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the object and what is decoded beside it exceed 4 GiB: read it row group by row group");
+    file = dalloc((size_t)(tail_base + tail_cap) + 64);
+    h2d(file->p, f, (size_t)len);
+    TF_HIP(hipMemsetAsync((char *)file->p + len, 0, (size_t)(tail_base - len), st));
+  }
 
   auto db = std::make_unique<tfgpu_dbatch>();
   db->nrows = nrows; db->ns = table_ns ? table_ns : ""; db->table = table_name ? table_name : "";
@@ -1046,11 +1070,16 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   }
   // ---- the device image: the object (or the inflated pages), 64 bytes of slack, then the tail ----
   const uint64_t img_len = inflate ? arena.size() : len;
-  const uint64_t tail_base = (img_len + 64 + 15) & ~15ull;
-  if (tail_base + tail_need + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the object and what is decoded beside it exceed 4 GiB: read it row group by row group");
-  Buf file = dalloc((size_t)(tail_base + tail_need) + 64);
-  if (img_len) h2d(file->p, inflate ? arena.data() : f, (size_t)img_len);
-  TF_HIP(hipMemsetAsync((char *)file->p + img_len, 0, (size_t)(tail_base - img_len), st));
+  if (inflate) {
+    tail_base = (img_len + 64 + 15) & ~15ull;
+    if (tail_base + tail_need + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the object and what is decoded beside it exceed 4 GiB: read it row group by row group");
+    file = dalloc((size_t)(tail_base + tail_need) + 64);
+    if (img_len) h2d(file->p, arena.data(), (size_t)img_len);
+    TF_HIP(hipMemsetAsync((char *)file->p + img_len, 0, (size_t)(tail_base - img_len), st));
+  } else if (tail_need > tail_cap) {
+    // a chunk whose pages use an encoding its metadata does not list: the footer's bound does not hold — through the arena, sized by the walk
+    throw NeedArena{};
+  }
   const uint8_t *dfile = ptr<uint8_t>(file);
   uint8_t *dtail = ptr<uint8_t>(file) + tail_base;
   Buf derr = dalloc_zero(16);  // [0]: PQE_* raised by a kernel
