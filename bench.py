@@ -1105,13 +1105,15 @@ class Configs3Workload(Base):
         cs = schema.to_c()
         import ctypes as C
 
-        def one():
+        def one(plans=None, read_only=False):
             out = C.c_void_p()
             lib._check(lib.load().tfgpu_parquet_read(C.c_void_p(pinned.ptr), C.c_uint64(len(data)), abi.MEM_HOST, C.byref(cs), b"", b"hits", C.byref(out)))
             db = lib.DeviceBatch(out)
-            tr = lib.apply_chain(self.plans, db)
-            o = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
-            o.free(); tr.transformed.free(); db.free()
+            if not read_only:
+                tr = lib.apply_chain(plans if plans is not None else self.plans, db)
+                o = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
+                o.free(); tr.transformed.free()
+            db.free()
         one(); lib.synchronize()
         k = 5
         t0 = time.perf_counter()
@@ -1119,16 +1121,54 @@ class Configs3Workload(Base):
             one()
         lib.synchronize()
         dt = (time.perf_counter() - t0) / k
+        t0 = time.perf_counter()
+        for _ in range(k):
+            one(read_only=True)
+        lib.synchronize()
+        dt_read = (time.perf_counter() - t0) / k
         lib.prof_reset(); lib.prof_enable(True)
         one()
         lib.prof_enable(False)
         prof = {n: round(ms / max(l, 1), 4) for n, l, ms in lib.prof_get() if n.startswith("pq_")}
         lib.prof_reset()
+        # the same step on three lanes: the upload of one object beside the decode / chain / serializer of another
+        nl, kk = 3, 9
+        go, done, errs = threading.Barrier(nl + 1), threading.Barrier(nl + 1), []
+
+        def lane_main(j):
+            try:
+                lib.lane_use(j)
+                plans = self.plans if j == 0 else [lib.Transformer(t, c) for t, c in self.CH]
+                one(plans); lib.synchronize()
+                go.wait()
+                for i in range(kk):
+                    if i % nl == j:
+                        one(plans)
+                lib.synchronize()
+                done.wait()
+            except Exception as ex:  # noqa: BLE001
+                errs.append(ex); go.abort(); done.abort()
+        ths = [threading.Thread(target=lane_main, args=(j,)) for j in range(nl)]
+        for t in ths:
+            t.start()
+        try:
+            go.wait()
+            t0 = time.perf_counter()
+            done.wait()
+            dt3 = (time.perf_counter() - t0) / kk
+        except threading.BrokenBarrierError:
+            dt3 = float("nan")
+        for t in ths:
+            t.join()
+        lib.lane_use(0)
         pinned.free()
         return {"parquet_source": {"object_bytes": len(data), "rows_per_s": round(h.nrows / dt, 1), "ms_per_step": round(dt * 1e3, 3), "gb_per_s_parquet_in": round(len(data) / dt / 1e9, 2),
+                                   "read_only_ms": round(dt_read * 1e3, 3), "read_only_gb_per_s": round(len(data) / dt_read / 1e9, 2),
+                                   "lanes_3": {"ms_per_step": round(dt3 * 1e3, 3), "gb_per_s_parquet_in": round(len(data) / dt3 / 1e9, 2), "rows_per_s": round(h.nrows / dt3, 1)} if not errs else {"error": str(errs[0])[:200]},
                                    "decode_kernels_avg_ms": prof,
                                    "note": "uncompressed Parquet written by pyarrow from the same columns (time columns as INT64), in pinned host memory; a step uploads the object (PCIe inside), "
-                                           "decodes it on the device, then runs the chain and the serializer; parity of the decode is pinned to pyarrow, not to the reference (DESIGN §7 f3)"}}
+                                           "decodes it on the device, then runs the chain and the serializer (read_only: upload + decode alone; lanes_3: whole steps of three lanes side by side); "
+                                           "the decoder's parity: tests/test_parquet.py (pyarrow's reading of the same bytes) and tests/test_parquet_canon.py (the reference's reader canon)"}}
 
     def side_measurements(self):
         """Never `value`: the sink leg.  Every step ends with the JSONEachRow bytes copied to PINNED host memory

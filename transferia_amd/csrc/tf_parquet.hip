@@ -554,10 +554,10 @@ enum : uint32_t { PQE_DICT_INDEX = 1, PQE_TEXT_LENGTH = 2 };
 __global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, uint64_t tail_base, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint64_t *dict_at, const uint32_t *dict_n, FixedOut o, uint32_t *err) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
-  const uint32_t k = rank[r];
+  const uint32_t k = rank ? rank[r] : (uint32_t)r;   // (no rank: every row holds a value, its ordinal is the row)
   uint64_t v = 0;
   int32_t ns = 0;
-  if (rank[r + 1] != k) {
+  if (!rank || rank[r + 1] != k) {
     const Seg &s = find_seg(segs, nsegs, k);
     const uint32_t w = (uint32_t)o.in_width;
     if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (s.in_tail ? tail_base : 0) + (uint64_t)(k - s.start) * w, w);
@@ -659,8 +659,8 @@ __global__ void __launch_bounds__(256) pq_int96_text(const uint8_t *file, uint8_
                                                      const uint64_t *dict_at, const uint32_t *dict_n, uint32_t *src_off, uint32_t *lens, uint32_t *err) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
-  const uint32_t k = rank[r];
-  if (rank[r + 1] == k) { src_off[r] = SEG_NONE; lens[r] = 0; return; }
+  const uint32_t k = rank ? rank[r] : (uint32_t)r;
+  if (rank && rank[r + 1] == k) { src_off[r] = SEG_NONE; lens[r] = 0; return; }
   const Seg &s = find_seg(segs, nsegs, k);
   uint64_t at = 0; bool ok = true;
   if (s.kind == SG_PLAIN) at = s.at + (uint64_t)(k - s.start) * 12;
@@ -735,9 +735,9 @@ __global__ void __launch_bounds__(256) pq_text_cells(const uint8_t *file, const 
                                                      const uint32_t *dict_off, const uint32_t *dict_len, const uint32_t *dict_n, uint32_t *src_off, uint32_t *lens, unsigned long long *total, uint32_t *err) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = r < nrows;  // (no early return: the wave reduction below needs every lane)
-  const uint32_t k = live ? rank[r] : 0u;
+  const uint32_t k = live ? (rank ? rank[r] : (uint32_t)r) : 0u;
   uint32_t so = SEG_NONE, n = 0;
-  if (live && rank[r + 1] != k) {
+  if (live && (!rank || rank[r + 1] != k)) {
     const Seg &s = find_seg(segs, nsegs, k);
     if (s.kind == SG_PLAIN_TEXT) { so = val_off[k]; n = val_len[k]; }
     else if (s.kind == SG_FIXED_TEXT) { so = (uint32_t)(s.at + (uint64_t)(k - s.start) * s.bw); n = s.bw; }
@@ -1141,13 +1141,19 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
       if (is_text || P.is_int96) { d.offsets = dalloc_zero(8); d.data = dalloc(8); } else { d.values = dalloc(8); if (d.repr == TFGPU_R_TIME) d.nanos = dalloc(8); }
       continue;
     }
-    Buf blev = P.lev.empty() ? nullptr : upload_small(P.lev.data(), P.lev.size() * sizeof(Seg));
     Buf bval = P.val.empty() ? nullptr : upload_small(P.val.data(), P.val.size() * sizeof(Seg));
-    Buf rank = dalloc((size_t)(nrows + 2) * 4);
-    pq_levels<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(blev), (int32_t)P.lev.size(), nrows, ptr<uint32_t>(rank));
-    exclusive_scan_u32(ptr<uint32_t>(rank), ptr<uint32_t>(rank), nrows, true);
-    if (optional) { d.validity = dalloc((size_t)(nrows + 7) / 8 + 8); pq_pack_validity<<<(unsigned)(((nrows + 7) / 8 + 255) / 256), 256, 0, st>>>(ptr<uint32_t>(rank), nrows, ptr<uint8_t>(d.validity)); }
-    keep.push_back(blev); keep.push_back(bval); keep.push_back(rank);
+    keep.push_back(bval);
+    // The host counted the present values while it read the level runs' headers: a column whose every row holds a value (required, or
+    // optional without a nil — the usual case) needs no levels, no ordinals and no validity: the ordinal of a row's value is the row.
+    Buf rank;
+    if ((int64_t)P.ord != nrows) {
+      Buf blev = P.lev.empty() ? nullptr : upload_small(P.lev.data(), P.lev.size() * sizeof(Seg));
+      rank = dalloc((size_t)(nrows + 2) * 4);
+      pq_levels<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(blev), (int32_t)P.lev.size(), nrows, ptr<uint32_t>(rank));
+      exclusive_scan_u32(ptr<uint32_t>(rank), ptr<uint32_t>(rank), nrows, true);
+      if (optional) { d.validity = dalloc((size_t)(nrows + 7) / 8 + 8); pq_pack_validity<<<(unsigned)(((nrows + 7) / 8 + 255) / 256), 256, 0, st>>>(ptr<uint32_t>(rank), nrows, ptr<uint8_t>(d.validity)); }
+      keep.push_back(blev); keep.push_back(rank);
+    }
     KernelTimer t(is_text || P.is_int96 ? "pq_text" : "pq_values");
     if (!is_text && !P.is_int96) {
       Buf bdict = P.dict_at.empty() ? nullptr : upload_small(P.dict_at.data(), P.dict_at.size() * 8);

@@ -495,7 +495,7 @@ template <int FMT, class S> __device__ __forceinline__ void walk_cell(S &s, cons
   for (int w = 0; w < REC_PREFIX_BYTES / 8; w++) if (n > 8u * w) sink_word(s, pw[w], min(n - 8u * w, 8u), 0);
   if (n > (uint32_t)REC_PREFIX_BYTES) put_bytes(s, p.blob + sc.pre_off + REC_PREFIX_BYTES, n - REC_PREFIX_BYTES);
   if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) emit_ch_value(s, sc, b, p.any_as_string);
-  else if (FMT == TFGPU_FMT_JSON) emit_json_value(s, sc, b, p.any_as_string);
+  else if (FMT == TFGPU_FMT_JSON) { if (p.q.qformat) emit_json_cell(s, sc.c, b, 0, false); else emit_json_value(s, sc, b, p.any_as_string); }  // (queue JSON: serializeQueueItemToJSON does not strictify)
   else emit_csv_field(s, sc, b);
 }
 template <int FMT, int WALK_AHEAD, class S> __device__ __forceinline__ void walk_chunk(S &s, const SerParams &p, const ChunkPlan &cp, int32_t c0, int32_t c1, int64_t r, bool &first) {
@@ -523,7 +523,8 @@ template <int FMT, class S> __device__ __forceinline__ void row_tail(S &s, const
   if (FMT == TFGPU_FMT_CSV) { s.put('\n'); return; }
   if (FMT == TFGPU_FMT_CH_JSON_EACH_ROW) { if (first) s.put('{'); s.put('}'); s.put('\n'); return; }
   s.put('}');
-  if (p.closing_newline || r + 1 < p.nrows) s.put('\n');
+  if (p.q.qformat) { if (p.q.msg_flags && !(p.q.msg_flags[r] & 2)) s.put('\n'); }  // queue JSON (BatchJSON): "\n" after every element but the last of its message; none while the cut plan is unknown (the length passes)
+  else if (p.closing_newline || r + 1 < p.nrows) s.put('\n');
 }
 
 // (1) bytes per (row, chunk)
@@ -804,6 +805,59 @@ static int serialize_raw(const tfgpu_dbatch *b, const tfgpu_serialize_options *o
   return TFGPU_OK;
 }
 
+// The chunk plan of the text formats' walks (ser_chunk_len / layout / write): where a row's columns are cut, the per-column records
+// the waves read, the (row, chunk) length table.  `order`: the columns in output order; sc / blob: their descriptors and key prefixes.
+struct ChunkSetup { ChunkPlan cp{}; Buf bcut, brecs, cell; };
+static ChunkSetup make_chunk_setup(const tfgpu_dbatch *b, int format, const std::vector<int> &order, const std::vector<SCol> &sc, const std::string &blob, int64_t n) {
+  ChunkSetup cs;
+  ChunkPlan &cp = cs.cp;
+  Buf &bcut = cs.bcut, &brecs = cs.brecs, &cell = cs.cell;
+  const int ncols = (int)order.size();
+  // the cuts: consecutive columns until the ESTIMATED text of a row's chunk passes the target (64 rows of a chunk share a 9 KiB
+  // image, i.e. 144 bytes per row; an estimate that is off only sends more tiles down the direct path)
+  static const uint32_t target = [] { const char *e = std::getenv("TFGPU_SER_CHUNK_BYTES"); return e ? (uint32_t)std::atoi(e) : 112u; }();
+  std::vector<int32_t> cut{0};
+  double acc = 0;
+  for (int j = 0; j < ncols; j++) {
+    const DColumn &c = b->cols[(size_t)order[(size_t)j]];
+    double est = sc[(size_t)j].pre_len + 1.0;
+    switch (c.repr) {
+      case TFGPU_R_INT8: case TFGPU_R_UINT8: est += 2; break;
+      case TFGPU_R_INT16: case TFGPU_R_UINT16: est += 4; break;
+      case TFGPU_R_INT32: case TFGPU_R_UINT32: est += 8; break;
+      case TFGPU_R_INT64: case TFGPU_R_UINT64: case TFGPU_R_DURATION: est += 16; break;
+      case TFGPU_R_BOOL: est += 5; break;
+      case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: est += 14; break;
+      case TFGPU_R_TIME: est += 24; break;
+      default: est += 2.0 + (double)c.data_len / (double)n * (format == TFGPU_FMT_JSON && c.repr == TFGPU_R_BYTES ? 1.34 : 1.0);
+    }
+    if (j > cut.back() && acc + est > target) { cut.push_back(j); acc = 0; }
+    acc += est;
+  }
+  cut.push_back(ncols);
+  if (ncols == 0) cut = {0, 0};
+  cp.nchunks = (int32_t)cut.size() - 1;
+  bcut = upload_const(cut.data(), cut.size() * sizeof(int32_t));
+  cp.cut = ptr<int32_t>(bcut);
+  std::vector<uint32_t> recs((size_t)std::max(ncols, 1) * REC_WORDS, 0u);
+  for (int j = 0; j < ncols; j++) {
+    const SCol &d = sc[(size_t)j];
+    uint32_t *w = recs.data() + (size_t)j * REC_WORDS;
+    auto put64 = [&](int k, const void *q) { const uint64_t v = reinterpret_cast<uintptr_t>(q); w[k] = (uint32_t)v; w[k + 1] = (uint32_t)(v >> 32); };
+    put64(RW_VALUES, d.c.values); put64(RW_OFFSETS, d.c.offsets); put64(RW_DATA, d.c.data); put64(RW_NANOS, d.c.nanos); put64(RW_VALIDITY, d.c.validity);
+    w[RW_REPR] = (uint32_t)d.c.repr; w[RW_DTYPE] = (uint32_t)d.c.dtype; w[RW_PRE_OFF] = d.pre_off; w[RW_PRE_LEN] = d.pre_len; w[RW_CH_FLAGS] = d.ch_flags; w[RW_PREC] = d.prec;
+    std::memcpy(w + REC_PREFIX_WORD, blob.data() + d.pre_off, std::min<size_t>(d.pre_len, REC_PREFIX_BYTES));
+  }
+  brecs = upload_const(recs.data(), recs.size() * 4);
+  cp.recs = ptr<uint32_t>(brecs);
+  cell = dalloc((size_t)cp.nchunks * (size_t)n * 4);
+  cp.chunk = ptr<uint32_t>(cell);
+  { const char *e = std::getenv("TFGPU_SER_DIRECT"); cp.direct = e && *e == '1'; }
+  { const char *e = std::getenv("TFGPU_SER_ORDER"); cp.order = e ? std::atoi(e) : 1; }  // (2, the XCD-aware form of 0, measured like 0: 3.18 ms against 2.62 for order 1 on configs[3] — the reads of 64 consecutive rows per column decide, not the seams of the writes; profiles/r06o_*)
+  cp.ngroups = (n + 63) / 64;
+  return cs;
+}
+
 extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out) {
   try {
   tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
@@ -888,48 +942,8 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
       { KernelTimer t("ser_cell_len"); if (ncell) ser_cell_len<<<dim3(blocks(n), (unsigned)ncols), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
     } else {
-      // the cuts: consecutive columns until the ESTIMATED text of a row's chunk passes the target (64 rows of a chunk share a 9 KiB
-      // image, i.e. 144 bytes per row; an estimate that is off only sends more tiles down the direct path)
-      static const uint32_t target = [] { const char *e = std::getenv("TFGPU_SER_CHUNK_BYTES"); return e ? (uint32_t)std::atoi(e) : 112u; }();
-      std::vector<int32_t> cut{0};
-      double acc = 0;
-      for (int j = 0; j < ncols; j++) {
-        const DColumn &c = b->cols[(size_t)order[(size_t)j]];
-        double est = sc[(size_t)j].pre_len + 1.0;
-        switch (c.repr) {
-          case TFGPU_R_INT8: case TFGPU_R_UINT8: est += 2; break;
-          case TFGPU_R_INT16: case TFGPU_R_UINT16: est += 4; break;
-          case TFGPU_R_INT32: case TFGPU_R_UINT32: est += 8; break;
-          case TFGPU_R_INT64: case TFGPU_R_UINT64: case TFGPU_R_DURATION: est += 16; break;
-          case TFGPU_R_BOOL: est += 5; break;
-          case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: est += 14; break;
-          case TFGPU_R_TIME: est += 24; break;
-          default: est += 2.0 + (double)c.data_len / (double)n * (format == TFGPU_FMT_JSON && c.repr == TFGPU_R_BYTES ? 1.34 : 1.0);
-        }
-        if (j > cut.back() && acc + est > target) { cut.push_back(j); acc = 0; }
-        acc += est;
-      }
-      cut.push_back(ncols);
-      if (ncols == 0) cut = {0, 0};
-      cp.nchunks = (int32_t)cut.size() - 1;
-      bcut = upload_const(cut.data(), cut.size() * sizeof(int32_t));
-      cp.cut = ptr<int32_t>(bcut);
-      std::vector<uint32_t> recs((size_t)std::max(ncols, 1) * REC_WORDS, 0u);
-      for (int j = 0; j < ncols; j++) {
-        const SCol &d = sc[(size_t)j];
-        uint32_t *w = recs.data() + (size_t)j * REC_WORDS;
-        auto put64 = [&](int k, const void *q) { const uint64_t v = reinterpret_cast<uintptr_t>(q); w[k] = (uint32_t)v; w[k + 1] = (uint32_t)(v >> 32); };
-        put64(RW_VALUES, d.c.values); put64(RW_OFFSETS, d.c.offsets); put64(RW_DATA, d.c.data); put64(RW_NANOS, d.c.nanos); put64(RW_VALIDITY, d.c.validity);
-        w[RW_REPR] = (uint32_t)d.c.repr; w[RW_DTYPE] = (uint32_t)d.c.dtype; w[RW_PRE_OFF] = d.pre_off; w[RW_PRE_LEN] = d.pre_len; w[RW_CH_FLAGS] = d.ch_flags; w[RW_PREC] = d.prec;
-        std::memcpy(w + REC_PREFIX_WORD, blob.data() + d.pre_off, std::min<size_t>(d.pre_len, REC_PREFIX_BYTES));
-      }
-      brecs = upload_const(recs.data(), recs.size() * 4);
-      cp.recs = ptr<uint32_t>(brecs);
-      cell = dalloc((size_t)cp.nchunks * (size_t)n * 4);
-      cp.chunk = ptr<uint32_t>(cell);
-      { const char *e = std::getenv("TFGPU_SER_DIRECT"); cp.direct = e && *e == '1'; }
-      { const char *e = std::getenv("TFGPU_SER_ORDER"); cp.order = e ? std::atoi(e) : 1; }  // (2, the XCD-aware form of 0, measured like 0: 3.18 ms against 2.62 for order 1 on configs[3] — the reads of 64 consecutive rows per column decide, not the seams of the writes; profiles/r06o_*)
-      cp.ngroups = (n + 63) / 64;
+      ChunkSetup csu = make_chunk_setup(b, format, order, sc, blob, n);
+      cp = csu.cp; bcut = csu.bcut; brecs = csu.brecs; cell = csu.cell;
       const unsigned grid = ser_grid(cp);
       {
         KernelTimer t("ser_chunk_len");
@@ -1321,6 +1335,72 @@ template <class T> static const T *meta_array(const tfgpu_row_meta *m, const T *
 
 }  // namespace tf
 
+// queue JSON (BatchJSON over pkg/serializer/json.go rows) by chunk walks; the caller holds the lane's mutex and has run the checks
+static int queue_json_chunks(const tfgpu_queue_options *o, const tfgpu_dbatch *b, const std::vector<int64_t> &gstart, tfgpu_dbuf **values, uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
+  using namespace tf;
+  hipStream_t st = ctx().stream;
+  const int64_t n = b->nrows;
+  const int ncols = (int)b->cols.size();
+  std::vector<int> order((size_t)ncols);
+  for (int i = 0; i < ncols; i++) order[(size_t)i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->cols[(size_t)x].name < b->cols[(size_t)y].name; });
+  for (int i = 0; i + 1 < ncols; i++) if (b->cols[(size_t)order[(size_t)i]].name == b->cols[(size_t)order[(size_t)i + 1]].name)
+    return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: duplicate column names");
+  std::string blob;
+  std::vector<SCol> sc((size_t)ncols);
+  for (int j = 0; j < ncols; j++) {
+    const DColumn &c = b->cols[(size_t)order[(size_t)j]];
+    SCol &x = sc[(size_t)j];
+    x.c = dcol_of(c);
+    x.pre_off = (uint32_t)blob.size();
+    if (j) blob += ',';
+    json_key(blob, c.name); blob += ':';
+    x.pre_len = (uint32_t)blob.size() - x.pre_off;
+    x.ch_flags = 0; x.prec = 0;
+  }
+  Buf bsc = upload_const(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_const(blob.data(), blob.size());
+  Buf row_len = dalloc((size_t)(n + 1) * 4 + 16), mflags = dalloc((size_t)n + 16), tot64 = dalloc_zero(8);
+  ChunkSetup cs = make_chunk_setup(b, TFGPU_FMT_JSON, order, sc, blob, n);
+  SerParams p{};
+  p.cols = ptr<SCol>(bsc); p.ncols = ncols; p.nrows = n; p.format = TFGPU_FMT_JSON; p.any_as_string = 0; p.closing_newline = 0;
+  p.blob = ptr<uint8_t>(bblob); p.row_len = ptr<uint32_t>(row_len); p.last_present = nullptr;
+  p.total64 = reinterpret_cast<unsigned long long *>(tot64->p);
+  p.q.qformat = TFGPU_QFMT_JSON; p.q.msg_flags = nullptr;  // (no frame yet: the length passes give the ELEMENT lengths the cut plan is made of)
+  const unsigned grid = ser_grid(cs.cp);
+  { KernelTimer t("ser_chunk_len"); ser_chunk_len<TFGPU_FMT_JSON><<<grid, 256, 0, st>>>(p, cs.cp); }
+  { KernelTimer t("ser_chunk_layout"); ser_chunk_layout<TFGPU_FMT_JSON><<<blocks(n), 256, 0, st>>>(p, cs.cp); }
+  // ---- the cut plan (host: the batchers' sequential greedy loop over the element lengths) ----
+  std::vector<uint32_t> elen((size_t)n);
+  std::vector<uint8_t> hflags((size_t)n, 0);
+  d2h(elen.data(), p.row_len, (size_t)n * 4);
+  tf::sync();
+  for (size_t g = 0; g + 1 < gstart.size(); g++) queue_cut_plan(o, elen.data() + gstart[g], gstart[g + 1] - gstart[g], 0u, hflags.data() + gstart[g]);
+  int64_t nm = 0; uint64_t total = 0;
+  for (int64_t r = 0; r < n; r++) {
+    if (hflags[(size_t)r] & 1) { if (nm < cap) { msg_start[nm] = total; msg_row[nm] = r; } nm++; }
+    total += elen[(size_t)r] + ((hflags[(size_t)r] & 2) ? 0u : 1u);
+  }
+  if (nm > cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: more messages than msg_start / msg_row hold");
+  if (total >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: output exceeds 4 GiB; split the batch by rows");
+  msg_start[nm] = total; msg_row[nm] = n;
+  h2d(mflags->p, hflags.data(), (size_t)n);
+  p.q.msg_flags = ptr<uint8_t>(mflags);
+  ser_queue_tail_len<<<blocks(n), 256, 0, st>>>(p);
+  exclusive_scan_u32(p.row_len, p.row_len, n, true);
+  const uint32_t *htot = d2h_u32(p.row_len + n);
+  tf::sync();  // (hflags may die after this)
+  if (*htot != (uint32_t)total) return tf::fail(TFGPU_ERR_DEVICE, "tfgpu_queue_serialize: internal: device and host disagree on the output size");
+  auto res = std::make_unique<tfgpu_dbuf>();
+  res->size = total;
+  res->mem = dalloc(res->size + 64);
+  p.out = ptr<uint8_t>(res->mem);
+  { KernelTimer t("ser_chunk_write"); ser_chunk_write<TFGPU_FMT_JSON><<<grid, 256, 4 * WAVE_IMG_BYTES + 64, st>>>(p, cs.cp); }
+  tf::sync();
+  *nmsg = nm;
+  *values = res.release();
+  return TFGPU_OK;
+}
+
 extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_dbatch *b, const tfgpu_row_meta *meta, tfgpu_dbuf **values,
                                      uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
   try {
@@ -1352,14 +1432,23 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
     };
     for (auto &c : b->cols) nonfinite(c);
     for (int k = 0; k < nold; k++) nonfinite(b->old_keys[(size_t)k]);
+    bool has_nonrow = false;
     {
       const uint32_t *h = d2h_u32(flags->p, 2);
       tf::sync();
+      has_nonrow = (h[0] & 8u) != 0;
       if (h[0] & 16u) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: src_row outside the row meta");
       if (native && (h[0] & 8u)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: non-row kinds are serialised by the stock NativeSerializer");
       if (!native && (h[0] & 6u)) return tf::fail(TFGPU_ERR_UNSUPPORTED, "JsonSerializer: unsupported kind: update / delete (json.go:54-56)");
       if (h[1]) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: json: unsupported value: NaN or Inf");
     }
+
+    // The JSON format's element is the text serializer's row (pkg/serializer/json.go: one map per item, keys sorted) — it goes through
+    // the same chunk walks (ser_chunk_len / layout / write<JSON>, twice as fast per byte as the per-cell passes below), with the
+    // BatchJSON frame as the row tail: "\n" after every element but the last of its message, known once the cut plan is.  Non-row
+    // items (an empty element each) keep the per-cell passes.
+    static const bool cell_passes = [] { const char *e = std::getenv("TFGPU_SER_SCATTER"); return e && *e == '1'; }();
+    if (!native && !has_nonrow && !cell_passes) return queue_json_chunks(o, b, gstart, values, msg_start, msg_row, cap, nmsg);
 
     // ---- the cell list ----
     std::string blob;
