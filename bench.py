@@ -732,7 +732,8 @@ class SrWorkload(_Prepared):
     def alg(self):
         s = self.state
         return {"sr_parse_quick": len(self.data), "sr_parse_tiles": len(self.data), "sr_parse_frames": len(self.data), "sr_cell_values": len(self.data) + s["parsed_bytes"], "sr_cell_text": 2 * s["parsed_bytes"],
-                "ser_cell_write": s["parsed_bytes"] + s["out_bytes"], "ser_cell_len": s["parsed_bytes"]}
+                "ser_cell_write": s["parsed_bytes"] + s["out_bytes"], "ser_cell_len": s["parsed_bytes"],
+                "ser_chunk_write": s["parsed_bytes"] + s["out_bytes"], "ser_chunk_len": s["parsed_bytes"]}
 
     def config(self):
         return {"workload": "Kafka messages in the Schema Registry wire format (one flat hits object each) -> SR JSON parser -> queue JSON serializer, 1 MiB batches "
@@ -855,6 +856,47 @@ class Configs2Workload(_Prepared):
             lib.synchronize()
             lib.DeviceBuffer(hd).free()
         h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
+        # what the link gives when BOTH directions run and nothing else does: two lanes, one re-uploading the input, one re-downloading a
+        # buffer of the output's size — the ceiling of any pull / push overlap on this box
+        try:
+            dev_out = lib.DeviceBuffer.alloc(cap)
+            hout = lib.HostBuffer.__new__(lib.HostBuffer)
+            pp = ctypes_void()
+            lib._check(lib.load().tfgpu_host_alloc(dev_out.size, pp.ref))
+            hout.ptr, hout.size = pp.value, dev_out.size
+            go2, nrep = threading.Barrier(3), 6
+            tms = {}
+
+            def up():
+                lib.lane_use(1)
+                go2.wait()
+                t0_ = time.perf_counter()
+                for _ in range(nrep):
+                    hd_ = ctypes.c_void_p()
+                    lib._check(lib.load().tfgpu_dbuf_upload(ctypes.c_void_p(hin.ptr), hin.size, ctypes.byref(hd_)))
+                    lib.synchronize()
+                    lib.DeviceBuffer(hd_).free()
+                tms["h2d"] = time.perf_counter() - t0_
+
+            def down():
+                lib.lane_use(2)
+                go2.wait()
+                t0_ = time.perf_counter()
+                for _ in range(nrep):
+                    lib._check(lib.load().tfgpu_dbuf_download(dev_out._h, hout.ptr, dev_out.size))
+                tms["d2h"] = time.perf_counter() - t0_
+            ths2 = [threading.Thread(target=up), threading.Thread(target=down)]
+            for t in ths2:
+                t.start()
+            go2.wait()
+            for t in ths2:
+                t.join()
+            lib.lane_use(0)
+            res["copies_alone_concurrent"] = {"gb_per_s_h2d": round(hin.size * nrep / tms["h2d"] / 1e9, 2), "gb_per_s_d2h": round(dev_out.size * nrep / tms["d2h"] / 1e9, 2),
+                                              "note": "both directions of the link at once, no kernels: the ceiling of the pull / push overlap here"}
+            hout.free(); dev_out.free()
+        except Exception as ex:  # noqa: BLE001
+            res["copies_alone_concurrent"] = {"error": str(ex)[:200]}
         # lanes: 1 (the three legs follow each other), --pcie-lanes, and twice that — two batches in flight per pull / transform / push
         # stage, so that a lane waiting for its copy never leaves a direction of the link idle (the double buffer of configs[2])
         for nl in sorted({1, max(1, min(a.pcie_lanes, lib.lane_count())), max(1, min(2 * a.pcie_lanes, lib.lane_count()))}):
@@ -917,47 +959,13 @@ class Configs2Workload(_Prepared):
                                   "gb_per_s_h2d": round(len(self.data) * kk / dt / 1e9, 2), "gb_per_s_d2h": round(self.state["out_bytes"] * kk / dt / 1e9, 2),
                                   "legs_alone_ms": {"h2d": round(h2d_ms, 3), "kernels": round(kernels_ms, 3), "d2h": round(d2h_ms, 3)},
                                   "overlap_efficiency": round(max(h2d_ms, kernels_ms, d2h_ms) / step_ms, 3)}
-        # what the link gives when BOTH directions run and nothing else does: two lanes, one re-uploading the input, one re-downloading a
-        # buffer of the output's size — the ceiling of any pull / push overlap on this box
-        try:
-            dev_out = lib.DeviceBuffer.alloc(cap)
-            hout = lib.HostBuffer.__new__(lib.HostBuffer)
-            pp = ctypes_void()
-            lib._check(lib.load().tfgpu_host_alloc(dev_out.size, pp.ref))
-            hout.ptr, hout.size = pp.value, dev_out.size
-            go2, nrep = threading.Barrier(3), 6
-            tms = {}
-
-            def up():
-                lib.lane_use(1)
-                go2.wait()
-                t0_ = time.perf_counter()
-                for _ in range(nrep):
-                    hd_ = ctypes.c_void_p()
-                    lib._check(lib.load().tfgpu_dbuf_upload(ctypes.c_void_p(hin.ptr), hin.size, ctypes.byref(hd_)))
-                    lib.synchronize()
-                    lib.DeviceBuffer(hd_).free()
-                tms["h2d"] = time.perf_counter() - t0_
-
-            def down():
-                lib.lane_use(2)
-                go2.wait()
-                t0_ = time.perf_counter()
-                for _ in range(nrep):
-                    lib._check(lib.load().tfgpu_dbuf_download(dev_out._h, hout.ptr, dev_out.size))
-                tms["d2h"] = time.perf_counter() - t0_
-            ths2 = [threading.Thread(target=up), threading.Thread(target=down)]
-            for t in ths2:
-                t.start()
-            go2.wait()
-            for t in ths2:
-                t.join()
-            lib.lane_use(0)
-            res["copies_alone_concurrent"] = {"gb_per_s_h2d": round(hin.size * nrep / tms["h2d"] / 1e9, 2), "gb_per_s_d2h": round(dev_out.size * nrep / tms["d2h"] / 1e9, 2),
-                                              "note": "both directions of the link at once, no kernels: the ceiling of the pull / push overlap here"}
-            hout.free(); dev_out.free()
-        except Exception as ex:  # noqa: BLE001
-            res["copies_alone_concurrent"] = {"error": str(ex)[:200]}
+            dup = res.get("copies_alone_concurrent") or {}
+            if dup.get("gb_per_s_h2d") and dup.get("gb_per_s_d2h"):
+                # with both directions busy the link itself gives each less than it gives alone: the step no overlap can beat is the
+                # longest leg at the rates measured for the two copies running side by side
+                h2d_dup, d2h_dup = len(self.data) / dup["gb_per_s_h2d"] / 1e6, self.state["out_bytes"] / dup["gb_per_s_d2h"] / 1e6
+                res[f"lanes_{nl}"]["legs_duplex_ms"] = {"h2d": round(h2d_dup, 3), "d2h": round(d2h_dup, 3)}
+                res[f"lanes_{nl}"]["overlap_efficiency_vs_duplex_ceiling"] = round(max(h2d_dup, d2h_dup, kernels_ms) / step_ms, 3)
         hin.free()
         res["note"] = ("every step pulls its %.2f GB of Kafka bytes from pinned host memory (H2D), runs parse + replace_primary_key + sql + JSONEachRow, and pushes the "
                        "%.2f GB of text back into pinned host memory (D2H); with several lanes the three legs of different batches overlap: H2D of batch N+1, "

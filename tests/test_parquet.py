@@ -319,3 +319,37 @@ def test_wide_object_whose_segment_tables_outgrow_the_pinned_ring(tf):
             assert int(c.offsets[-1]) == sum(len(w) for w in want), c.name
             for i in (0, 1, n // 2, n - 1):
                 assert c.get_bytes(i) == want[i].encode(), (c.name, i)
+
+
+def test_plain_text_walk_by_pointer_jumping(tf):
+    """PLAIN byte arrays are a chain of length prefixes, followed 8 KiB at a time by pointer jumping (pq_walk_text): runs of empty values
+    (2048 chain elements a window), values longer than a window (one jump), lengths that look like text and text that looks like lengths,
+    pages that end inside a window — all against pyarrow's reading."""
+    rng = np.random.default_rng(12)
+    n = 30000
+    def val(i):
+        k = i % 11
+        if k < 5:
+            return b""
+        if k == 5:
+            return bytes(rng.integers(0, 256, int(rng.integers(1, 9))).astype(np.uint8))            # any bytes, zeros included
+        if k == 6:
+            return b"\x00\x00\x00\x00" * int(rng.integers(1, 40))                                     # looks like a run of empty values
+        if k == 7:
+            return (b"\x03\x00\x00\x00abc") * int(rng.integers(1, 30))                                # looks like values
+        if k == 8:
+            return bytes(rng.integers(32, 127, int(rng.integers(9000, 30000))).astype(np.uint8)) if i % 331 == 8 else b"x" * int(rng.integers(0, 300))
+        return ("v%d" % i).encode()
+    vals = [None if i % 97 == 0 else val(i) for i in range(n)]
+    t = pa.table({"b": pa.array(vals, pa.binary()), "k": pa.array(range(n), pa.int64())})
+    for kw in (dict(), dict(data_page_size=3000), dict(data_page_size=100000, data_page_version="2.0"), dict(row_group_size=7001)):
+        buf = io.BytesIO()
+        pq.write_table(t, buf, compression="NONE", use_dictionary=False, **kw)
+        out = tf.parquet_read(buf.getvalue()).download()
+        c = out.col("b")
+        valid = c.validity if c.validity is not None else np.ones(n, bool)
+        assert [bool(v) for v in valid] == [v is not None for v in vals], kw
+        lens = np.diff(c.offsets.astype(np.int64))
+        assert [int(x) for x in lens] == [len(v) if v is not None else 0 for v in vals], kw
+        assert bytes(c.data[: int(c.offsets[-1])]) == b"".join(v for v in vals if v is not None), kw
+        assert np.array_equal(out.col("k").values, np.arange(n)), kw

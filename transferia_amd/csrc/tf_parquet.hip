@@ -40,6 +40,13 @@
 #include "tf_common.hpp"
 #include "tf_segcopy.hpp"
 #define PQD(...) do { if (std::getenv("TFGPU_PQ_DEBUG")) { std::fprintf(stderr, __VA_ARGS__); std::fflush(stderr); } } while (0)  /* the page walk, line by line */
+#include <chrono>
+// TFGPU_PQ_TIMES=1 (measurement only): host milliseconds since the call began, at the ends of its phases, on stderr
+struct PqClock {
+  const bool on = std::getenv("TFGPU_PQ_TIMES") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void at(const char *what) const { if (on) { std::fprintf(stderr, "pq %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); std::fflush(stderr); } }
+};
 
 namespace tf {
 namespace pq {
@@ -470,7 +477,8 @@ static bool delta_decode_host(const uint8_t *fb, const std::vector<DMini> &minis
 }
 
 // ---- the segment table a column's rows / values look themselves up in ----------------------------------------------------
-enum : uint32_t { SG_RLE = 0, SG_PACKED = 1, SG_PLAIN = 2, SG_PLAIN_BOOL = 3, SG_PLAIN_TEXT = 4, SG_FIXED_TEXT = 5 /* FIXED_LEN_BYTE_ARRAY: value k at `at` + k * bw */ };
+enum : uint32_t { SG_RLE = 0, SG_PACKED = 1, SG_PLAIN = 2, SG_PLAIN_BOOL = 3, SG_PLAIN_TEXT = 4, SG_FIXED_TEXT = 5 /* FIXED_LEN_BYTE_ARRAY: value k at `at` + k * bw */,
+                      SG_INDEX = 6 /* a page's dictionary indices (or RLE booleans) expanded by pq_hybrid: value k = the bw-BYTE word at tail + at + k * bw */ };
 struct Seg {
   uint32_t start, count;   // first ordinal (levels: row of the column; values: ordinal among the present values) and length
   uint32_t kind, bw;       // SG_*; bit width of packed values
@@ -494,8 +502,10 @@ static bool hybrid_runs(const uint8_t *file, const uint8_t *p, const uint8_t *e,
       out.push_back(Seg{(uint32_t)(ord + got), (uint32_t)n, SG_PACKED, bw, (uint64_t)(p - file), dict_base, 0});
       if (ones) {  // (levels of width 1: the present rows)
         const uint64_t full = n >> 3;
-        for (uint64_t i = 0; i < full; i++) *ones += (uint64_t)__builtin_popcount(p[i]);
-        for (uint64_t i = full * 8; i < n; i++) *ones += (p[i >> 3] >> (i & 7)) & 1;
+        uint64_t i = 0;
+        for (; i + 8 <= full; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); *ones += (uint64_t)__builtin_popcountll(w); }  // (eight level bytes a step: megabytes of them per object)
+        for (; i < full; i++) *ones += (uint64_t)__builtin_popcount(p[i]);
+        for (uint64_t j = full * 8; j < n; j++) *ones += (p[j >> 3] >> (j & 7)) & 1;
       }
       p += nbytes; got += n;
     } else {
@@ -522,24 +532,15 @@ __device__ __forceinline__ uint64_t load_unaligned(const uint8_t *file, uint64_t
   uint64_t v = seg_read8(file, at);
   return nbytes >= 8 ? v : v & ((1ull << (8 * nbytes)) - 1);
 }
-__device__ __forceinline__ uint32_t seg_value(const uint8_t *file, const Seg &s, uint32_t ord) {  // an RLE / packed integer (level, dictionary index, boolean)
+__device__ __forceinline__ uint32_t seg_value(const uint8_t *file, const Seg &s, uint32_t ord, uint64_t tail_base = 0) {  // an RLE / packed integer (level, dictionary index, boolean)
   if (s.kind == SG_RLE) return (uint32_t)s.at;
+  if (s.kind == SG_INDEX) {
+    const uint8_t *q = file + tail_base + s.at + (uint64_t)(ord - s.start) * s.bw;
+    return s.bw == 1 ? (uint32_t)*q : s.bw == 2 ? (uint32_t)*reinterpret_cast<const uint16_t *>(q) : *reinterpret_cast<const uint32_t *>(q);
+  }
   const uint64_t bit = (uint64_t)(ord - s.start) * s.bw;
   const uint64_t w = seg_read8(file, s.at + (bit >> 3)) >> (bit & 7);
   return (uint32_t)(w & ((s.bw >= 32) ? 0xFFFFFFFFull : ((1ull << s.bw) - 1)));
-}
-// definition levels → present[r] (u32, scanned into ordinals afterwards)
-__global__ void __launch_bounds__(256) pq_levels(const uint8_t *file, const Seg *segs, int32_t nsegs, int64_t nrows, uint32_t *present) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nrows) return;
-  present[r] = nsegs ? (seg_value(file, find_seg(segs, nsegs, (uint32_t)r), (uint32_t)r) != 0 ? 1u : 0u) : 1u;  // (a level above 1 in a flat column is still "present", as the host counted it)
-}
-__global__ void __launch_bounds__(256) pq_pack_validity(const uint32_t *rank, int64_t nrows, uint8_t *bits) {  // rank = exclusive scan of present, rank[nrows] = total
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b * 8 >= nrows) return;
-  uint32_t v = 0;
-  for (int j = 0; j < 8; j++) { const int64_t r = b * 8 + j; if (r < nrows && rank[r + 1] != rank[r]) v |= 1u << j; }
-  bits[b] = (uint8_t)v;
 }
 // What abstract.Restore (pkg/abstract/restore.go:20-260) makes of the physical value under the column's DataType — the cases a Parquet
 // value can meet: float32 under "double" → float64; an int32 under "int64" → cast.ToInt64; an int32 / int64 under "uint64" →
@@ -548,43 +549,7 @@ __global__ void __launch_bounds__(256) pq_pack_validity(const uint32_t *rank, in
 enum : int32_t { CV_SAME = 0, CV_DATE = 1, CV_TS_MICROS = 2, CV_I32_I64 = 3, CV_I32_U64 = 4, CV_I64_U64 = 5, CV_F32_F64 = 6 };
 struct FixedOut { void *values; int32_t *nanos; int32_t in_width, out_width, conv; };
 // what the object's own numbers may not exceed, checked where the values are read (the error word is read back at the sync)
-enum : uint32_t { PQE_DICT_INDEX = 1, PQE_TEXT_LENGTH = 2 };
-// one row: its value by ordinal — PLAIN bytes (of the file, or of the tail a DELTA page was decoded into), or a dictionary index into
-// dict (fixed-width entries, file offsets of the chunks' PLAIN dictionary pages)
-__global__ void __launch_bounds__(256) pq_values_fixed(const uint8_t *file, uint64_t tail_base, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint64_t *dict_at, const uint32_t *dict_n, FixedOut o, uint32_t *err) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nrows) return;
-  const uint32_t k = rank ? rank[r] : (uint32_t)r;   // (no rank: every row holds a value, its ordinal is the row)
-  uint64_t v = 0;
-  int32_t ns = 0;
-  if (!rank || rank[r + 1] != k) {
-    const Seg &s = find_seg(segs, nsegs, k);
-    const uint32_t w = (uint32_t)o.in_width;
-    if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (s.in_tail ? tail_base : 0) + (uint64_t)(k - s.start) * w, w);
-    else if (s.kind == SG_PLAIN_BOOL) v = (file[s.at + ((k - s.start) >> 3)] >> ((k - s.start) & 7)) & 1;
-    else {
-      const uint32_t idx = seg_value(file, s, k);
-      if (o.in_width == 1 && !dict_at) v = idx;  // (booleans under RLE are their own values)
-      else if (idx >= dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // an index past the chunk's dictionary: the value stays 0, the call fails
-      else v = load_unaligned(file, dict_at[s.dict_base] + (uint64_t)idx * w, w);
-    }
-    switch (o.conv) {
-      case CV_DATE: v = (uint64_t)((int64_t)(int32_t)v * 86400); break;
-      case CV_TS_MICROS: { const int64_t us = (int64_t)v; int64_t sec = us / 1000000, rem = us % 1000000; if (rem < 0) { rem += 1000000; sec--; } v = (uint64_t)sec; ns = (int32_t)(rem * 1000); break; }
-      case CV_I32_I64: v = (uint64_t)(int64_t)(int32_t)v; break;
-      case CV_I32_U64: v = (int32_t)v < 0 ? 0 : (uint64_t)(int32_t)v; break;
-      case CV_I64_U64: v = (int64_t)v < 0 ? 0 : v; break;
-      case CV_F32_F64: v = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)v)); break;
-      default: break;
-    }
-  }
-  switch (o.out_width) {
-    case 1: ((uint8_t *)o.values)[r] = (uint8_t)v; break;
-    case 4: ((uint32_t *)o.values)[r] = (uint32_t)v; break;
-    default: ((uint64_t *)o.values)[r] = v;
-  }
-  if (o.nanos) o.nanos[r] = ns;
-}
+enum : uint32_t { PQE_DICT_INDEX = 1, PQE_TEXT_LENGTH = 2, PQE_HYBRID = 3 };
 // DELTA_BINARY_PACKED / DELTA_LENGTH_BYTE_ARRAY pages: ONE WAVE per page walks its miniblocks in order; a miniblock's deltas are
 // unpacked one per lane (any width up to 64 bits), prefix-summed across the wave (wrapping 64-bit adds, as the format says) and carried
 // into the next one.  mode 0: value i → `width` bytes at tail[out_at + i * width] (the column's PLAIN values of this page);
@@ -652,6 +617,58 @@ __global__ void __launch_bounds__(256) pq_delta(const uint8_t *file, uint8_t *ta
   }
   if (bad && lane == 0) *err = PQE_TEXT_LENGTH;
 }
+// The RLE / bit-packed hybrid stream of a page's dictionary indices (or RLE booleans) → one bw-byte word per value in the tail.  A
+// writer that alternates short literal groups and short repeats leaves a run header every few dozen values — a million and a half
+// of them in a 2^20-row object of a hundred dictionary-coded columns: walked on the host (a 32-byte segment each) they cost more than
+// the upload of the object.  Here ONE WAVE per page walks the headers (every lane reads the same bytes) and its 64 lanes expand each
+// run together.  A stream that ends early, a run of no values or a width above 32 fails the call (PQE_HYBRID).
+struct HPage { uint64_t at, end, out_at; uint32_t bw, total, out_w, pad; };
+__global__ void __launch_bounds__(256) pq_hybrid(const uint8_t *file, uint8_t *tail, const HPage *pages, int32_t npages, uint32_t *err) {
+  const int lane = threadIdx.x & 63;
+  const int32_t pi = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (pi >= npages) return;
+  const HPage pg = pages[pi];
+  uint8_t *out = tail + pg.out_at;
+  auto put = [&](uint32_t i, uint32_t v) {
+    if (pg.out_w == 1) out[i] = (uint8_t)v; else if (pg.out_w == 2) reinterpret_cast<uint16_t *>(out)[i] = (uint16_t)v; else reinterpret_cast<uint32_t *>(out)[i] = v;
+  };
+  const uint32_t vbytes = (pg.bw + 7) / 8;
+  const uint32_t mask = pg.bw >= 32 ? 0xFFFFFFFFu : ((1u << pg.bw) - 1u);
+  uint64_t pos = pg.at;
+  uint32_t done = 0;
+  bool bad = false;
+  while (done < pg.total && !bad) {
+    // the run header: a varint of at most five bytes for counts below 2^32 (uniform across the wave)
+    if (pos >= pg.end) { bad = true; break; }
+    const uint64_t w = seg_read8(file, pos);
+    uint64_t h = 0; uint32_t nb = 0;
+    for (; nb < 8; nb++) { const uint32_t b = (uint32_t)(w >> (8 * nb)) & 0xFFu; h |= (uint64_t)(b & 0x7Fu) << (7 * nb); if (!(b & 0x80u)) { nb++; break; } }
+    if (nb == 8 && ((w >> 56) & 0x80u)) { bad = true; break; }
+    if (pos + nb > pg.end) { bad = true; break; }
+    pos += nb;
+    if (h & 1) {
+      const uint64_t groups = h >> 1, nbytes = groups * pg.bw;
+      if (groups == 0 || nbytes > pg.end - pos) { bad = true; break; }  // (a run of no groups makes no progress)
+      const uint32_t n = (uint32_t)(groups * 8 < (uint64_t)(pg.total - done) ? groups * 8 : (uint64_t)(pg.total - done));
+      for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
+        const uint64_t bit = (uint64_t)i * pg.bw;
+        put(done + i, (uint32_t)(seg_read8(file, pos + (bit >> 3)) >> (bit & 7)) & mask);
+      }
+      pos += nbytes; done += n;
+    } else {
+      const uint64_t cnt = h >> 1;
+      if (cnt == 0 || vbytes > pg.end - pos) { bad = true; break; }
+      const uint32_t v = (uint32_t)load_unaligned(file, pos, vbytes ? vbytes : 1) & (vbytes ? 0xFFFFFFFFu : 0u);
+      const uint32_t n = (uint32_t)(cnt < (uint64_t)(pg.total - done) ? cnt : (uint64_t)(pg.total - done));
+      for (uint32_t i = (uint32_t)lane; i < n; i += 64) put(done + i, v);
+      pos += vbytes; done += n;
+    }
+  }
+  if (bad) {  // the rest of the page reads as index 0 (its dictionary's first entry, or past an empty one: caught there); the call fails
+    for (uint32_t i = done + (uint32_t)lane; i < pg.total; i += 64) put(i, 0u);
+    if (lane == 0) *err = PQE_HYBRID;
+  }
+}
 // INT96 → the text of deprecated.Int96.String() (parseParquetField, reader_parquet.go:303-305): the 96-bit two's-complement integer
 // (nanoseconds of the day in the low 64 bits, the Julian day above them) in decimal.  One row per lane: the 12 bytes by ordinal (PLAIN
 // or through the chunk's dictionary), at most 29 digits and a sign into the row's 32-byte slot of the tail; the packing copy reads it there.
@@ -664,7 +681,7 @@ __global__ void __launch_bounds__(256) pq_int96_text(const uint8_t *file, uint8_
   const Seg &s = find_seg(segs, nsegs, k);
   uint64_t at = 0; bool ok = true;
   if (s.kind == SG_PLAIN) at = s.at + (uint64_t)(k - s.start) * 12;
-  else { const uint32_t idx = seg_value(file, s, k); if (idx >= dict_n[s.dict_base]) { *err = PQE_DICT_INDEX; ok = false; } else at = dict_at[s.dict_base] + (uint64_t)idx * 12; }
+  else { const uint32_t idx = seg_value(file, s, k, tail_base); if (idx >= dict_n[s.dict_base]) { *err = PQE_DICT_INDEX; ok = false; } else at = dict_at[s.dict_base] + (uint64_t)idx * 12; }
   uint32_t w0 = 0, w1 = 0, w2 = 0;
   if (ok) { const uint64_t lo = seg_read8(file, at); w0 = (uint32_t)lo; w1 = (uint32_t)(lo >> 32); w2 = (uint32_t)load_unaligned(file, at + 8, 4); }
   const bool neg = (w2 >> 31) != 0;
@@ -690,68 +707,110 @@ __global__ void __launch_bounds__(256) pq_int96_text(const uint8_t *file, uint8_
   src_off[r] = (uint32_t)(tail_base + slot0 + (uint64_t)r * 32);
   lens[r] = (uint32_t)n;
 }
-// PLAIN byte arrays are length-prefixed: the position of value i + 1 is known only after the length of value i has been read, a
-// chain no amount of lanes shortens.  What CAN be shortened is each link: one workgroup per page stages the page through LDS
-// in 48 KiB pieces (coalesced 16-byte loads), and one lane walks the prefixes there — ~30 ns per value instead of an HBM
-// round trip (measured on configs[3]'s columns: 12.5 ms per text column with a lane reading HBM, 1 MB pages).
+// PLAIN byte arrays are length-prefixed: the position of value i + 1 is known only after the length of value i has been read — a
+// chain.  Until round 5 one lane per page walked it (~270 ns a value: 3.5 ms for the text columns of a 2^20-row hits object).  The
+// chain is followed by POINTER JUMPING instead: a workgroup takes the page 8 KiB at a time; every byte position p of the window
+// computes where a value starting THERE would end (next[p] = p + 4 + the four bytes at p, or "dead" when that runs past the page) —
+// all 8192 positions at once, no position knowing whether it is a boundary; then log2(values in the window) rounds of
+// mark[next^k[p]] |= mark[p], next^2k = next^k ∘ next^k find exactly the positions the true chain visits from the window's first
+// byte (a boundary by construction).  Ranks by a popcount scan, one (offset, length) store per value, and the chain's exit from
+// the window is the next window's start.  A value longer than the window is one jump.
 struct TextPage { uint64_t at, end; uint32_t ord, count; };  // [at, end): the page's values
-constexpr uint32_t PQ_STAGE = 48 * 1024;
+constexpr uint32_t PW = 8192, PW_EXIT = 0xFFFEu, PW_DEAD = 0xFFFFu;
 __global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_t limit, const TextPage *pages, uint32_t *val_off, uint32_t *val_len, uint32_t *err) {
-  __shared__ uint4 stage[PQ_STAGE / 16 + 1];
+  __shared__ uint32_t stage[PW / 4 + 4];
+  __shared__ uint16_t nx[2][PW];
+  __shared__ uint32_t mark[PW / 32];
+  __shared__ uint32_t wsum[4];
   __shared__ uint64_t s_at;
-  __shared__ uint32_t s_done;
+  __shared__ uint32_t s_done, s_more, s_bad_ord, s_exit;
   const TextPage pg = pages[blockIdx.x];
-  if (threadIdx.x == 0) { s_at = pg.at; s_done = 0; }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { s_at = pg.at; s_done = 0; s_bad_ord = 0xFFFFFFFFu; }
   __syncthreads();
-  while (s_done < pg.count) {
-    const uint64_t base = s_at & ~15ull;
-    for (uint32_t i = threadIdx.x; i < PQ_STAGE / 16 + 1; i += 256)  // a read past the page is harmless, one past the image (`limit`: its 64 bytes of slack included) is not
-      stage[i] = base + (uint64_t)i * 16 + 16 <= limit ? reinterpret_cast<const uint4 *>(file + base)[i] : make_uint4(0, 0, 0, 0);
+  // the length field at window position p (any alignment): two staged words funnelled
+  auto len_at = [&](uint32_t p) { return __builtin_amdgcn_alignbyte(stage[(p >> 2) + 1], stage[p >> 2], p & 3u); };
+  for (;;) {
+    const uint64_t at = s_at;
+    const uint32_t done = s_done;
+    if (done >= pg.count || s_bad_ord != 0xFFFFFFFFu) break;  // (uniform: written before the last barrier of the round)
+    for (uint32_t i = (uint32_t)tid; i < PW / 4 + 4; i += 256) {
+      const uint64_t a = at + 4ull * i;
+      stage[i] = a + 8 <= limit ? (uint32_t)load_unaligned(file, a, 4) : 0u;  // (a read past the page is harmless, one past the image is not)
+    }
+    mark[tid] = tid == 0 ? 1u : 0u;  // the window starts on a boundary
+    if (tid == 0) { s_more = 1; s_exit = 0xFFFFFFFFu; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint8_t *lds = reinterpret_cast<const uint8_t *>(stage);
-      uint64_t at = s_at; uint32_t done = s_done;
-      if (done < pg.count && at + 4 > pg.end) { *err = PQE_TEXT_LENGTH; for (; done < pg.count; done++) { val_off[pg.ord + done] = (uint32_t)pg.at; val_len[pg.ord + done] = 0; } }
-      while (done < pg.count && at + 4 <= base + PQ_STAGE) {
-        const uint32_t o = (uint32_t)(at - base);
-        uint32_t n = (uint32_t)lds[o] | (uint32_t)lds[o + 1] << 8 | (uint32_t)lds[o + 2] << 16 | (uint32_t)lds[o + 3] << 24;
-        if (at + 4 > pg.end || (uint64_t)n > pg.end - (at + 4)) {  // a prefix that points past its page: this value and the rest of the page read as empty, the call fails
-          *err = PQE_TEXT_LENGTH;
-          for (; done < pg.count; done++) { val_off[pg.ord + done] = (uint32_t)pg.at; val_len[pg.ord + done] = 0; }
-          break;
-        }
-        val_off[pg.ord + done] = (uint32_t)(at + 4);
-        val_len[pg.ord + done] = n;
-        at += 4 + (uint64_t)n;
-        done++;
+#pragma unroll 4
+    for (uint32_t j = 0; j < PW / 256; j++) {
+      const uint32_t p = j * 256 + (uint32_t)tid;
+      uint32_t v = PW_DEAD;
+      if (at + p + 4 <= pg.end) {
+        const uint32_t n = len_at(p);
+        if ((uint64_t)n <= pg.end - (at + p + 4)) { const uint64_t t = (uint64_t)p + 4 + n; v = t < PW ? (uint32_t)t : PW_EXIT; }
       }
-      s_at = at; s_done = done;
+      nx[0][p] = (uint16_t)v;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int round = 0; round < 14; round++) {
+      const bool more = s_more != 0;
+      __syncthreads();
+      if (!more) break;
+      if (tid == 0) s_more = 0;
+      __syncthreads();
+      bool fresh = false;
+#pragma unroll 4
+      for (uint32_t j = 0; j < PW / 256; j++) {
+        const uint32_t p = j * 256 + (uint32_t)tid;
+        const uint32_t c = nx[cur][p];
+        uint32_t c2 = c;
+        if (c < PW) {
+          if ((mark[p >> 5] >> (p & 31)) & 1u) { const uint32_t bit = 1u << (c & 31); if (!(atomicOr(&mark[c >> 5], bit) & bit)) fresh = true; }
+          c2 = nx[cur][c];
+        }
+        nx[cur ^ 1][p] = (uint16_t)c2;
+      }
+      if (fresh) s_more = 1;
+      __syncthreads();
+      cur ^= 1;
+    }
+    // the marked positions are the chain's values in this window, in order: ranks, then one store pair each
+    const uint32_t m = mark[tid];
+    const uint32_t cnt = (uint32_t)__popc(m);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t base = inc - cnt, total = 0;
+    for (int w = 0; w < 4; w++) { const uint32_t x = wsum[w]; if (w < wv) base += x; total += x; }
+    uint32_t mm = m, k = 0;
+    while (mm) {
+      const uint32_t b = (uint32_t)__ffs((int)mm) - 1; mm &= mm - 1;
+      const uint32_t p = (uint32_t)tid * 32 + b, ord = done + base + k;
+      k++;
+      const bool fits = at + p + 4 <= pg.end;
+      const uint32_t n = fits ? len_at(p) : 0u;
+      const bool ok = fits && (uint64_t)n <= pg.end - (at + p + 4);
+      if (!ok) { if (ord < pg.count) atomicMin(&s_bad_ord, ord); continue; }  // a prefix that points past its page: this value and the rest of the page read as empty, the call fails
+      if (ord < pg.count) { val_off[pg.ord + ord] = (uint32_t)(at + p + 4); val_len[pg.ord + ord] = n; }
+      if ((uint64_t)p + 4 + n >= PW) s_exit = p + 4 + n;  // (the chain's last value in the window: at most one)
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t nd = done + total;
+      if (s_bad_ord == 0xFFFFFFFFu && nd < pg.count && s_exit == 0xFFFFFFFFu) s_bad_ord = nd;  // the page ended before its values did
+      s_done = nd < pg.count ? nd : pg.count;
+      if (s_exit != 0xFFFFFFFFu) s_at = at + s_exit;
     }
     __syncthreads();
   }
-}
-// one row of a byte-array column: where its bytes are in the file image, and how many
-__global__ void __launch_bounds__(256) pq_text_cells(const uint8_t *file, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t nrows, const uint32_t *val_off, const uint32_t *val_len,
-                                                     const uint32_t *dict_off, const uint32_t *dict_len, const uint32_t *dict_n, uint32_t *src_off, uint32_t *lens, unsigned long long *total, uint32_t *err) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = r < nrows;  // (no early return: the wave reduction below needs every lane)
-  const uint32_t k = live ? (rank ? rank[r] : (uint32_t)r) : 0u;
-  uint32_t so = SEG_NONE, n = 0;
-  if (live && (!rank || rank[r + 1] != k)) {
-    const Seg &s = find_seg(segs, nsegs, k);
-    if (s.kind == SG_PLAIN_TEXT) { so = val_off[k]; n = val_len[k]; }
-    else if (s.kind == SG_FIXED_TEXT) { so = (uint32_t)(s.at + (uint64_t)(k - s.start) * s.bw); n = s.bw; }
-    else {
-      const uint32_t i = seg_value(file, s, k);
-      if (i >= dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // dict_n[first entry of a chunk's dictionary] = its entries
-      else { so = dict_off[s.dict_base + i]; n = dict_len[s.dict_base + i]; }
-    }
+  const uint32_t bad = s_bad_ord;
+  if (bad != 0xFFFFFFFFu) {
+    for (uint32_t o = bad + (uint32_t)tid; o < pg.count; o += 256) { val_off[pg.ord + o] = (uint32_t)pg.at; val_len[pg.ord + o] = 0; }
+    if (tid == 0) *err = PQE_TEXT_LENGTH;
   }
-  if (live) { src_off[r] = n ? so : SEG_NONE; lens[r] = n; }
-  // the column's bytes in 64 bits (the offsets are 32-bit: 4 GiB and more is refused): one add per wave
-  unsigned long long s64 = n;
-  for (int d = 32; d; d >>= 1) s64 += __shfl_down(s64, d, 64);
-  if ((threadIdx.x & 63) == 0 && s64) atomicAdd(total, s64);
 }
 template <int RPT>
 __global__ void __launch_bounds__(256) pq_pack_text(const uint32_t *dst_off, int64_t nrows, const uint8_t *file, uint8_t *dst, const uint32_t *src_off) {
@@ -761,6 +820,85 @@ __global__ void __launch_bounds__(256) pq_pack_text(const uint32_t *dst_off, int
   segcopy_run<RPT>(dst_off, nrows, k0, file, dst, [&](int64_t r) { return src_off[r]; }, doff, soff);
 }
 
+// ---- pass 2, one launch per step over ALL columns of a kind (grid.y = column): a hundred columns launched one by one cost a
+//      hundred times a HIP call's ~15 us for every step, more than the kernels run ----
+struct LevDesc { const Seg *segs; int32_t nsegs, pad; uint32_t *present; uint8_t *bits; };   // present: u32[stride] (row flags → ranks after the scan); bits: the validity bitmap or null
+struct FixedDesc { const Seg *segs; int32_t nsegs, pad; const uint32_t *rank; const uint64_t *dict_at; const uint32_t *dict_n; FixedOut o; };
+struct TextDesc { const Seg *segs; int32_t nsegs, pad; const uint32_t *rank, *val_off, *val_len, *dict_off, *dict_len, *dict_n; uint32_t *src_off, *lens; unsigned long long *total; };
+__global__ void __launch_bounds__(256) pq_levels_all(const uint8_t *file, const LevDesc *descs, int64_t nrows) {
+  const LevDesc &d = descs[blockIdx.y];
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  d.present[r] = d.nsegs ? (seg_value(file, find_seg(d.segs, d.nsegs, (uint32_t)r), (uint32_t)r) != 0 ? 1u : 0u) : 1u;
+}
+__global__ void __launch_bounds__(256) pq_pack_validity_all(const LevDesc *descs, int64_t nrows) {
+  const LevDesc &d = descs[blockIdx.y];
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (!d.bits || b * 8 >= nrows) return;
+  const uint32_t *rank = d.present;
+  uint32_t v = 0;
+  for (int j = 0; j < 8; j++) { const int64_t r = b * 8 + j; if (r < nrows && rank[r + 1] != rank[r]) v |= 1u << j; }
+  d.bits[b] = (uint8_t)v;
+}
+__device__ __forceinline__ void pq_fixed_row(const uint8_t *file, uint64_t tail_base, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t r, const uint64_t *dict_at, const uint32_t *dict_n, const FixedOut &o, uint32_t *err) {
+  const uint32_t k = rank ? rank[r] : (uint32_t)r;   // (no rank: every row holds a value, its ordinal is the row)
+  uint64_t v = 0;
+  int32_t ns = 0;
+  if (!rank || rank[r + 1] != k) {
+    const Seg &s = find_seg(segs, nsegs, k);
+    const uint32_t w = (uint32_t)o.in_width;
+    if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (s.in_tail ? tail_base : 0) + (uint64_t)(k - s.start) * w, w);
+    else if (s.kind == SG_PLAIN_BOOL) v = (file[s.at + ((k - s.start) >> 3)] >> ((k - s.start) & 7)) & 1;
+    else {
+      const uint32_t idx = seg_value(file, s, k, tail_base);
+      if (o.in_width == 1 && !dict_at) v = idx;  // (booleans under RLE are their own values)
+      else if (idx >= dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // an index past the chunk's dictionary: the value stays 0, the call fails
+      else v = load_unaligned(file, dict_at[s.dict_base] + (uint64_t)idx * w, w);
+    }
+    switch (o.conv) {
+      case CV_DATE: v = (uint64_t)((int64_t)(int32_t)v * 86400); break;
+      case CV_TS_MICROS: { const int64_t us = (int64_t)v; int64_t sec = us / 1000000, rem = us % 1000000; if (rem < 0) { rem += 1000000; sec--; } v = (uint64_t)sec; ns = (int32_t)(rem * 1000); break; }
+      case CV_I32_I64: v = (uint64_t)(int64_t)(int32_t)v; break;
+      case CV_I32_U64: v = (int32_t)v < 0 ? 0 : (uint64_t)(int32_t)v; break;
+      case CV_I64_U64: v = (int64_t)v < 0 ? 0 : v; break;
+      case CV_F32_F64: v = (uint64_t)__double_as_longlong((double)__uint_as_float((uint32_t)v)); break;
+      default: break;
+    }
+  }
+  switch (o.out_width) {
+    case 1: ((uint8_t *)o.values)[r] = (uint8_t)v; break;
+    case 4: ((uint32_t *)o.values)[r] = (uint32_t)v; break;
+    default: ((uint64_t *)o.values)[r] = v;
+  }
+  if (o.nanos) o.nanos[r] = ns;
+}
+__global__ void __launch_bounds__(256) pq_values_all(const uint8_t *file, uint64_t tail_base, const FixedDesc *descs, int64_t nrows, uint32_t *err) {
+  const FixedDesc &d = descs[blockIdx.y];
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  pq_fixed_row(file, tail_base, d.segs, d.nsegs, d.rank, r, d.dict_at, d.dict_n, d.o, err);
+}
+__global__ void __launch_bounds__(256) pq_text_cells_all(const uint8_t *file, uint64_t tail_base, const TextDesc *descs, int64_t nrows, uint32_t *err) {
+  const TextDesc &d = descs[blockIdx.y];
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = r < nrows;  // (no early return: the wave reduction below needs every lane)
+  const uint32_t k = live ? (d.rank ? d.rank[r] : (uint32_t)r) : 0u;
+  uint32_t so = SEG_NONE, n = 0;
+  if (live && (!d.rank || d.rank[r + 1] != k)) {
+    const Seg &s = find_seg(d.segs, d.nsegs, k);
+    if (s.kind == SG_PLAIN_TEXT) { so = d.val_off[k]; n = d.val_len[k]; }
+    else if (s.kind == SG_FIXED_TEXT) { so = (uint32_t)(s.at + (uint64_t)(k - s.start) * s.bw); n = s.bw; }
+    else {
+      const uint32_t i = seg_value(file, s, k, tail_base);
+      if (i >= d.dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // dict_n[first entry of a chunk's dictionary] = its entries
+      else { so = d.dict_off[s.dict_base + i]; n = d.dict_len[s.dict_base + i]; }
+    }
+  }
+  if (live) { d.src_off[r] = n ? so : SEG_NONE; d.lens[r] = n; }
+  unsigned long long s64 = n;  // the column's bytes in 64 bits (the offsets are 32-bit: 4 GiB and more is refused): one add per wave
+  for (int sh = 32; sh; sh >>= 1) s64 += __shfl_down(s64, sh, 64);
+  if ((threadIdx.x & 63) == 0 && s64) atomicAdd(d.total, s64);
+}
 __global__ void __launch_bounds__(256) pq_row_index(uint64_t *v, int64_t nrows) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r < nrows) v[r] = (uint64_t)r + 1;
@@ -788,8 +926,10 @@ using namespace tf::pq;
 struct NeedArena {};  // thrown by the walk when a page must be rewritten on the host (DELTA_BYTE_ARRAY) and the object was to be uploaded as it is
 
 static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, bool force_arena, tfgpu_dbatch **out) {
+  PqClock clk;
   FileMeta m; std::string why;
   if (!parse_footer(f, len, m, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: " + why);
+  clk.at("footer parsed");
   PQD("footer: %zu schema els, %zu groups, %lld rows\n", m.schema.size(), m.groups.size(), (long long)m.num_rows);
   std::vector<TopField> fields; int nleaves = 0;
   if (!top_fields(m, fields, nleaves, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: " + why);
@@ -820,6 +960,8 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
       if (e.type == T_INT96) bound += (uint64_t)std::max<int64_t>(nrows, 1) * 32 + 16;
       for (auto &g : m.groups) {
         const ColChunk &c = g.cols[(size_t)fields[k].leaf];
+        if (c.enc_mask & ((1u << E_PLAIN_DICT) | (1u << E_RLE_DICT) | (e.type == T_BOOLEAN ? (1u << E_RLE) : 0u)))   // expanded indices: at most 4 bytes a value
+          bound += (uint64_t)std::max<int64_t>(c.num_values, 0) * 4 + 16 * (uint64_t)(std::max<int64_t>(c.num_values, 0) / 64 + 2);
         if ((c.enc_mask >> E_DELTA_BINARY_PACKED) & 1u) bound += (uint64_t)std::max<int64_t>(c.num_values, 0) * 8 + 16 * (uint64_t)(std::max<int64_t>(c.num_values, 0) / 64 + 2);  // (every page's share is rounded up to 16 bytes)
       }
     }
@@ -829,6 +971,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
     file = dalloc((size_t)(tail_base + tail_cap) + 64);
     h2d(file->p, f, (size_t)len);
     TF_HIP(hipMemsetAsync((char *)file->p + len, 0, (size_t)(tail_base - len), st));
+    clk.at("upload issued");
   }
 
   auto db = std::make_unique<tfgpu_dbatch>();
@@ -858,7 +1001,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
     uint64_t ord = 0; size_t arena_at = 0; uint64_t slot0 = 0;
   };
   std::vector<ColPlan> plans(want.size());
-  std::vector<DMini> minis; std::vector<DPage> dpages;
+  std::vector<DMini> minis; std::vector<DPage> dpages; std::vector<HPage> hpages;
   uint64_t tail_need = 0;
   auto tail_take = [&](uint64_t bytes) { const uint64_t at = tail_need; tail_need += (bytes + 15) & ~15ull; return at; };
   for (size_t oc = 0; oc < want.size(); oc++) {
@@ -1008,11 +1151,21 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
             if (present && !have_dict) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: dictionary indices without a dictionary page in column " + leaf.name);
             const uint32_t bw = present ? *q : 0;
             if (bw > 32) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: dictionary index width");
-            if (present && !hybrid_runs(fb, q + 1, pe, bw, present, ord, dict_base, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed dictionary indices in column " + leaf.name);
+            if (present) {  // the run headers stay unread here: pq_hybrid expands the stream into the tail, one wave per page
+              const uint32_t ow = bw <= 8 ? 1u : bw <= 16 ? 2u : 4u;
+              const uint64_t out_at = tail_take(present * ow);
+              hpages.push_back(HPage{(uint64_t)(q + 1 - fb), (uint64_t)(pe - fb), out_at, bw, (uint32_t)present, ow, 0});
+              val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_INDEX, ow, out_at, dict_base, 1});
+            }
           } else if (h.enc == E_RLE && leaf.type == T_BOOLEAN) {  // RLE booleans: a length-prefixed hybrid of width 1
             if (q + 4 > pe) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page");
             uint32_t L; std::memcpy(&L, q, 4);
-            if (!hybrid_runs(fb, q + 4, (uint64_t)L < (uint64_t)(pe - (q + 4)) ? q + 4 + L : pe, 1, present, ord, 0, val, nullptr)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: malformed boolean run in column " + leaf.name);
+            if (present) {
+              const uint8_t *he = (uint64_t)L < (uint64_t)(pe - (q + 4)) ? q + 4 + L : pe;
+              const uint64_t out_at = tail_take(present);
+              hpages.push_back(HPage{(uint64_t)(q + 4 - fb), (uint64_t)(he - fb), out_at, 1u, (uint32_t)present, 1u, 0});
+              val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_INDEX, 1u, out_at, 0, 1});
+            }
           } else if (h.enc == E_DELTA_BINARY_PACKED && (leaf.type == T_INT32 || leaf.type == T_INT64)) {
             // the block headers say where every miniblock is; pq_delta decodes the page into the image's tail as PLAIN values
             DStream ds;
@@ -1068,6 +1221,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
     }
     PQD("  %zu level segs, %zu value segs, %zu text pages, ord %llu\n", lev.size(), val.size(), tpages.size(), (unsigned long long)ord);
   }
+  clk.at("page walk done (host)");
   // ---- the device image: the object (or the inflated pages), 64 bytes of slack, then the tail ----
   const uint64_t img_len = inflate ? arena.size() : len;
   if (inflate) {
@@ -1103,6 +1257,12 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
       KernelTimer t("pq_walk_text");
       pq_walk_text<<<(unsigned)all.size(), 256, 0, st>>>(dfile, (img_len + 64) & ~15ull, reinterpret_cast<const TextPage *>(btp->p), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
     }
+    if (!hpages.empty() && nrows) {
+      Buf bh = upload_small(hpages.data(), hpages.size() * sizeof(HPage));
+      keep.push_back(bh);
+      KernelTimer t("pq_hybrid");
+      pq_hybrid<<<(unsigned)((hpages.size() * 64 + 255) / 256), 256, 0, st>>>(dfile, dtail, reinterpret_cast<const HPage *>(bh->p), (int32_t)hpages.size(), ptr<uint32_t>(derr));
+    }
     if (!dpages.empty() && nrows) {
       DMini none{};
       Buf bm = upload_small(minis.empty() ? &none : minis.data(), std::max<size_t>(minis.size(), 1) * sizeof(DMini)), bp = upload_small(dpages.data(), dpages.size() * sizeof(DPage));
@@ -1111,11 +1271,16 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
       pq_delta<<<(unsigned)((dpages.size() * 64 + 255) / 256), 256, 0, st>>>(dfile, dtail, reinterpret_cast<const DMini *>(bm->p), reinterpret_cast<const DPage *>(bp->p), (int32_t)dpages.size(), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
     }
   }
-  // ---- pass 2 (device): levels → validity → ordinals, then the values ----
-  std::vector<size_t> totals;  // the text columns, in order: their scanned totals are read back together (NOT through the pinned ring: the
-                               // segment tables of the columns in between go through it and may wrap it)
+  clk.at("text walks enqueued");
+  // ---- pass 2 (device): levels → validity → ordinals, then the values — one launch per step over all the columns of a kind ----
+  std::vector<size_t> totals;  // the text columns, in order: their scanned totals are read back together
   std::vector<std::pair<size_t, Buf>> soffs;
-  std::vector<Buf> tot64s;  // the text columns' byte totals in 64 bits
+  Buf tot64_all;               // the text columns' byte totals in 64 bits
+  // every small table the kernels read (segment tables, dictionary tables, the descriptors themselves) travels in ONE copy
+  std::vector<uint8_t> blob;
+  auto blob_put = [&](const void *src, size_t n) -> size_t { const size_t at = (blob.size() + 15) & ~(size_t)15; blob.resize(at + n); if (n) std::memcpy(blob.data() + at, src, n); return at; };
+  struct Pending2 { size_t oc; size_t val_at, lev_at, dict_at_at, dict_n_at, dict_off_at, dict_len_at; };
+  std::vector<Pending2> fixed_cols, text_cols, lev_cols, int96_cols;
   for (size_t oc = 0; oc < plans.size(); oc++) {
     ColPlan &P = plans[oc];
     DColumn &d = P.d;
@@ -1136,65 +1301,100 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
       continue;
     }
     if (P.nil) continue;
-    const bool optional = P.optional, is_text = P.is_text;
     if (nrows == 0) {
-      if (is_text || P.is_int96) { d.offsets = dalloc_zero(8); d.data = dalloc(8); } else { d.values = dalloc(8); if (d.repr == TFGPU_R_TIME) d.nanos = dalloc(8); }
+      if (P.is_text || P.is_int96) { d.offsets = dalloc_zero(8); d.data = dalloc(8); } else { d.values = dalloc(8); if (d.repr == TFGPU_R_TIME) d.nanos = dalloc(8); }
       continue;
     }
-    Buf bval = P.val.empty() ? nullptr : upload_small(P.val.data(), P.val.size() * sizeof(Seg));
-    keep.push_back(bval);
+    Pending2 q{oc, 0, 0, 0, 0, 0, 0};
+    q.val_at = blob_put(P.val.data(), P.val.size() * sizeof(Seg));
     // The host counted the present values while it read the level runs' headers: a column whose every row holds a value (required, or
     // optional without a nil — the usual case) needs no levels, no ordinals and no validity: the ordinal of a row's value is the row.
-    Buf rank;
-    if ((int64_t)P.ord != nrows) {
-      Buf blev = P.lev.empty() ? nullptr : upload_small(P.lev.data(), P.lev.size() * sizeof(Seg));
-      rank = dalloc((size_t)(nrows + 2) * 4);
-      pq_levels<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(blev), (int32_t)P.lev.size(), nrows, ptr<uint32_t>(rank));
-      exclusive_scan_u32(ptr<uint32_t>(rank), ptr<uint32_t>(rank), nrows, true);
-      if (optional) { d.validity = dalloc((size_t)(nrows + 7) / 8 + 8); pq_pack_validity<<<(unsigned)(((nrows + 7) / 8 + 255) / 256), 256, 0, st>>>(ptr<uint32_t>(rank), nrows, ptr<uint8_t>(d.validity)); }
-      keep.push_back(blev); keep.push_back(rank);
+    if ((int64_t)P.ord != nrows) { q.lev_at = blob_put(P.lev.data(), P.lev.size() * sizeof(Seg)); lev_cols.push_back(q); }
+    if (P.is_text) { q.dict_off_at = blob_put(P.dict_off.data(), P.dict_off.size() * 4); q.dict_len_at = blob_put(P.dict_len.data(), P.dict_len.size() * 4); }
+    else q.dict_at_at = blob_put(P.dict_at.data(), P.dict_at.size() * 8);
+    q.dict_n_at = blob_put(P.dict_n.data(), P.dict_n.size() * 4);
+    (P.is_text ? text_cols : P.is_int96 ? int96_cols : fixed_cols).push_back(q);
+  }
+  if (nrows && !(fixed_cols.empty() && text_cols.empty() && int96_cols.empty())) {
+    // ranks of the columns that hold nils: flags → one segmented scan; a column's rank array is a slice of rank_all
+    const int64_t rstride = ((nrows + 2 + 3) / 4) * 4;
+    Buf rank_all = lev_cols.empty() ? nullptr : dalloc((size_t)lev_cols.size() * (size_t)rstride * 4 + 16);
+    std::map<size_t, uint32_t *> rank_of;
+    for (size_t k = 0; k < lev_cols.size(); k++) rank_of[lev_cols[k].oc] = ptr<uint32_t>(rank_all) + (int64_t)k * rstride;
+    const size_t nt = text_cols.size() + int96_cols.size();
+    const int64_t lstride = ((nrows + 1 + 3) / 4) * 4;
+    Buf lens_all = nt ? dalloc(nt * (size_t)lstride * 4 + 16) : nullptr;
+    tot64_all = dalloc_zero((nt + 1) * 8);
+    // descriptors (device pointers into the blob, whose address is known before it is filled)
+    std::vector<LevDesc> ld; std::vector<FixedDesc> fd; std::vector<TextDesc> td;
+    const size_t blob_cap = blob.size() + 64 + (lev_cols.size() * sizeof(LevDesc) + fixed_cols.size() * sizeof(FixedDesc) + text_cols.size() * sizeof(TextDesc)) + 64;
+    Buf bblob = dalloc(blob_cap);
+    const uint8_t *B = ptr<uint8_t>(bblob);
+    keep.push_back(bblob); keep.push_back(rank_all);
+    for (auto &q : lev_cols) {
+      ColPlan &P = plans[q.oc];
+      if (P.optional) P.d.validity = dalloc((size_t)(nrows + 7) / 8 + 8);
+      ld.push_back(LevDesc{reinterpret_cast<const Seg *>(B + q.lev_at), (int32_t)P.lev.size(), 0, rank_of[q.oc], ptr<uint8_t>(P.d.validity)});
     }
-    KernelTimer t(is_text || P.is_int96 ? "pq_text" : "pq_values");
-    if (!is_text && !P.is_int96) {
-      Buf bdict = P.dict_at.empty() ? nullptr : upload_small(P.dict_at.data(), P.dict_at.size() * 8);
-      Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
-      keep.push_back(bdict); keep.push_back(bdn);
+    for (auto &q : fixed_cols) {
+      ColPlan &P = plans[q.oc];
+      DColumn &d = P.d;
       d.values = dalloc((size_t)nrows * (size_t)P.out_width);
       if (d.repr == TFGPU_R_TIME) d.nanos = P.conv == CV_TS_MICROS ? dalloc((size_t)nrows * 4) : dalloc_zero((size_t)nrows * 4);
-      pq_values_fixed<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, tail_base, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), ptr<uint32_t>(bdn),
-                                                                       FixedOut{d.values->p, P.conv == CV_TS_MICROS ? ptr<int32_t>(d.nanos) : nullptr, (int32_t)P.width, P.out_width, P.conv}, ptr<uint32_t>(derr));
-    } else {
-      Buf soff = dalloc((size_t)nrows * 4);
-      d.offsets = dalloc((size_t)(nrows + 1) * 4 + 16);
-      Buf tot64 = dalloc_zero(8);
-      tot64s.push_back(tot64);
-      if (P.is_int96) {
-        Buf bdict = P.dict_at.empty() ? nullptr : upload_small(P.dict_at.data(), P.dict_at.size() * 8);
-        Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
-        keep.push_back(bdict); keep.push_back(bdn);
-        pq_int96_text<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, dtail, tail_base, P.slot0, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint64_t>(bdict), ptr<uint32_t>(bdn),
-                                                                       ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets), ptr<uint32_t>(derr));
-        // (29 digits and a sign per row at most: the column cannot reach 4 GiB under the 2^31-row bound, tot64 stays 0)
-      } else {
-        Buf bdo = P.dict_off.empty() ? nullptr : upload_small(P.dict_off.data(), P.dict_off.size() * 4), bdl = P.dict_len.empty() ? nullptr : upload_small(P.dict_len.data(), P.dict_len.size() * 4);
-        Buf bdn = P.dict_n.empty() ? nullptr : upload_small(P.dict_n.data(), P.dict_n.size() * 4);
-        keep.push_back(bdn); keep.push_back(bdo); keep.push_back(bdl);
-        pq_text_cells<<<(unsigned)((nrows + 255) / 256), 256, 0, st>>>(dfile, ptr<Seg>(bval), (int32_t)P.val.size(), ptr<uint32_t>(rank), nrows, ptr<uint32_t>(arena_off) + P.arena_at, ptr<uint32_t>(arena_len) + P.arena_at,
-                                                                       ptr<uint32_t>(bdo), ptr<uint32_t>(bdl), ptr<uint32_t>(bdn), ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets), reinterpret_cast<unsigned long long *>(tot64->p), ptr<uint32_t>(derr));
-      }
-      exclusive_scan_u32(ptr<uint32_t>(d.offsets), ptr<uint32_t>(d.offsets), nrows, true);
-      totals.push_back(oc);
-      soffs.push_back({oc, soff});
-      keep.push_back(soff);
+      fd.push_back(FixedDesc{reinterpret_cast<const Seg *>(B + q.val_at), (int32_t)P.val.size(), 0, rank_of.count(q.oc) ? rank_of[q.oc] : nullptr,
+                             P.dict_at.empty() ? nullptr : reinterpret_cast<const uint64_t *>(B + q.dict_at_at), P.dict_n.empty() ? nullptr : reinterpret_cast<const uint32_t *>(B + q.dict_n_at),
+                             FixedOut{d.values->p, P.conv == CV_TS_MICROS ? ptr<int32_t>(d.nanos) : nullptr, (int32_t)P.width, P.out_width, P.conv}});
     }
+    size_t ti = 0;
+    for (auto &q : text_cols) {
+      ColPlan &P = plans[q.oc];
+      DColumn &d = P.d;
+      Buf soff = dalloc((size_t)nrows * 4);
+      d.offsets = subbuf(lens_all, ti * (size_t)lstride * 4, (size_t)(nrows + 1) * 4);
+      td.push_back(TextDesc{reinterpret_cast<const Seg *>(B + q.val_at), (int32_t)P.val.size(), 0, rank_of.count(q.oc) ? rank_of[q.oc] : nullptr,
+                            ptr<uint32_t>(arena_off) + P.arena_at, ptr<uint32_t>(arena_len) + P.arena_at,
+                            P.dict_off.empty() ? nullptr : reinterpret_cast<const uint32_t *>(B + q.dict_off_at), P.dict_len.empty() ? nullptr : reinterpret_cast<const uint32_t *>(B + q.dict_len_at),
+                            P.dict_n.empty() ? nullptr : reinterpret_cast<const uint32_t *>(B + q.dict_n_at), ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets),
+                            reinterpret_cast<unsigned long long *>(tot64_all->p) + ti});
+      totals.push_back(q.oc); soffs.push_back({q.oc, soff}); keep.push_back(soff);
+      ti++;
+    }
+    const size_t ld_at = blob_put(ld.data(), ld.size() * sizeof(LevDesc)), fd_at = blob_put(fd.data(), fd.size() * sizeof(FixedDesc)), td_at = blob_put(td.data(), td.size() * sizeof(TextDesc));
+    if (blob.size() > blob_cap) return tf::fail(TFGPU_ERR_DEVICE, "tfgpu_parquet_read: internal: table blob outgrew its buffer");
+    h2d_small(bblob->p, blob.data(), blob.size());
+    const unsigned gx = (unsigned)((nrows + 255) / 256);
+    if (!ld.empty()) {
+      pq_levels_all<<<dim3(gx, (unsigned)ld.size()), 256, 0, st>>>(dfile, reinterpret_cast<const LevDesc *>(B + ld_at), nrows);
+      exclusive_scan_u32_segments(ptr<uint32_t>(rank_all), nrows, (int)ld.size(), rstride);
+      pq_pack_validity_all<<<dim3((unsigned)(((nrows + 7) / 8 + 255) / 256), (unsigned)ld.size()), 256, 0, st>>>(reinterpret_cast<const LevDesc *>(B + ld_at), nrows);
+    }
+    if (!fd.empty()) { KernelTimer t("pq_values"); pq_values_all<<<dim3(gx, (unsigned)fd.size()), 256, 0, st>>>(dfile, tail_base, reinterpret_cast<const FixedDesc *>(B + fd_at), nrows, ptr<uint32_t>(derr)); }
+    if (!td.empty()) { KernelTimer t("pq_text"); pq_text_cells_all<<<dim3(gx, (unsigned)td.size()), 256, 0, st>>>(dfile, tail_base, reinterpret_cast<const TextDesc *>(B + td_at), nrows, ptr<uint32_t>(derr)); }
+    for (auto &q : int96_cols) {  // (rare: one launch per column)
+      ColPlan &P = plans[q.oc];
+      DColumn &d = P.d;
+      Buf soff = dalloc((size_t)nrows * 4);
+      d.offsets = subbuf(lens_all, ti * (size_t)lstride * 4, (size_t)(nrows + 1) * 4);
+      KernelTimer t("pq_text");
+      pq_int96_text<<<gx, 256, 0, st>>>(dfile, dtail, tail_base, P.slot0, reinterpret_cast<const Seg *>(B + q.val_at), (int32_t)P.val.size(), rank_of.count(q.oc) ? rank_of[q.oc] : nullptr, nrows,
+                                        P.dict_at.empty() ? nullptr : reinterpret_cast<const uint64_t *>(B + q.dict_at_at), P.dict_n.empty() ? nullptr : reinterpret_cast<const uint32_t *>(B + q.dict_n_at),
+                                        ptr<uint32_t>(soff), ptr<uint32_t>(d.offsets), ptr<uint32_t>(derr));
+      // (29 digits and a sign per row at most: the column cannot reach 4 GiB under the 2^31-row bound, its 64-bit total stays 0)
+      totals.push_back(q.oc); soffs.push_back({q.oc, soff}); keep.push_back(soff);
+      ti++;
+    }
+    if (nt) exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, (int)nt, lstride);
   }
   std::vector<uint32_t> htot(totals.size() + 1);
   std::vector<uint64_t> htot64(totals.size() + 1);
   uint32_t herr[4] = {0, 0, 0, 0};
-  for (size_t k = 0; k < totals.size(); k++) { d2h(&htot[k], ptr<uint32_t>(plans[totals[k]].d.offsets) + nrows, 4); d2h(&htot64[k], tot64s[k]->p, 8); }
+  for (size_t k = 0; k < totals.size(); k++) d2h(&htot[k], ptr<uint32_t>(plans[totals[k]].d.offsets) + nrows, 4);
+  if (!totals.empty()) d2h(htot64.data(), tot64_all->p, totals.size() * 8);
   d2h(herr, derr->p, 16);
+  clk.at("columns enqueued");
   tf::sync();  // ONE wait for the text columns' sizes (a dictionary-coded column can be far longer than its chunk), then the copies
-  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : "tfgpu_parquet_read: a byte-array length that runs past its page");
+  clk.at("first sync");
+  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
   for (size_t k = 0; k < totals.size(); k++) if (htot64[k] >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + plans[totals[k]].d.name + " holds 4 GiB of text or more: read the object row group by row group");
   for (size_t k = 0; k < totals.size(); k++) {
     DColumn &d = plans[totals[k]].d;
@@ -1206,7 +1406,8 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   }
   d2h(herr, derr->p, 16);
   tf::sync();
-  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : "tfgpu_parquet_read: a byte-array length that runs past its page");
+  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
+  clk.at("second sync");
   for (auto &P : plans) db->cols.push_back(std::move(P.d));
   *out = db.release();
   return TFGPU_OK;
