@@ -321,10 +321,10 @@ def test_wide_object_whose_segment_tables_outgrow_the_pinned_ring(tf):
                 assert c.get_bytes(i) == want[i].encode(), (c.name, i)
 
 
-def test_plain_text_walk_by_pointer_jumping(tf):
-    """PLAIN byte arrays are a chain of length prefixes, followed 8 KiB at a time by pointer jumping (pq_walk_text): runs of empty values
-    (2048 chain elements a window), values longer than a window (one jump), lengths that look like text and text that looks like lengths,
-    pages that end inside a window — all against pyarrow's reading."""
+def test_plain_text_walk_windows(tf):
+    """PLAIN byte arrays are a chain of length prefixes, walked 16 KiB at a time (pq_walk_text): runs of empty values (4096 links a window),
+    values longer than a window (the next window starts behind them), lengths that look like text and text that looks like lengths, pages
+    that end inside a window — all against pyarrow's reading."""
     rng = np.random.default_rng(12)
     n = 30000
     def val(i):

@@ -707,108 +707,59 @@ __global__ void __launch_bounds__(256) pq_int96_text(const uint8_t *file, uint8_
   src_off[r] = (uint32_t)(tail_base + slot0 + (uint64_t)r * 32);
   lens[r] = (uint32_t)n;
 }
-// PLAIN byte arrays are length-prefixed: the position of value i + 1 is known only after the length of value i has been read — a
-// chain.  Until round 5 one lane per page walked it (~270 ns a value: 3.5 ms for the text columns of a 2^20-row hits object).  The
-// chain is followed by POINTER JUMPING instead: a workgroup takes the page 8 KiB at a time; every byte position p of the window
-// computes where a value starting THERE would end (next[p] = p + 4 + the four bytes at p, or "dead" when that runs past the page) —
-// all 8192 positions at once, no position knowing whether it is a boundary; then log2(values in the window) rounds of
-// mark[next^k[p]] |= mark[p], next^2k = next^k ∘ next^k find exactly the positions the true chain visits from the window's first
-// byte (a boundary by construction).  Ranks by a popcount scan, one (offset, length) store per value, and the chain's exit from
-// the window is the next window's start.  A value longer than the window is one jump.
+// PLAIN byte arrays are length-prefixed: the position of value i + 1 is known only after the length of value i has been read, a
+// chain no amount of lanes shortens.  What CAN be shortened is each link.  One workgroup per page stages the page 16 KiB at a time
+// (256 threads, the window starting ON a boundary, so a length field sits at a known byte of two staged words), ONE lane walks the
+// prefixes there — a link is one two-word LDS read, a funnel shift, a bound check and a two-word LDS write: the (offset, length)
+// pairs collect in LDS — and all threads then write the window's pairs out coalesced.  (Round 4's walk read the prefix byte by byte and
+// stored each pair to HBM from the walking lane: ~270 ns a value.  Pointer jumping over all 8192 byte positions of a window — every
+// position computes where a value starting there would end, log2 rounds of mark / jump-doubling find the chain — was built and measured in
+// round 5: 4.6 ms against the old walk's 3.5 on the hits object; with one workgroup per page the rounds are LDS-latency-bound too.)
 struct TextPage { uint64_t at, end; uint32_t ord, count; };  // [at, end): the page's values
-constexpr uint32_t PW = 8192, PW_EXIT = 0xFFFEu, PW_DEAD = 0xFFFFu;
+constexpr uint32_t PQ_STAGE = 16384, PQ_OUT = PQ_STAGE / 4;
 __global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_t limit, const TextPage *pages, uint32_t *val_off, uint32_t *val_len, uint32_t *err) {
-  __shared__ uint32_t stage[PW / 4 + 4];
-  __shared__ uint16_t nx[2][PW];
-  __shared__ uint32_t mark[PW / 32];
-  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t stage[PQ_STAGE / 4 + 4];
+  __shared__ uint32_t o_off[PQ_OUT], o_len[PQ_OUT];
   __shared__ uint64_t s_at;
-  __shared__ uint32_t s_done, s_more, s_bad_ord, s_exit;
+  __shared__ uint32_t s_done, s_cnt, s_bad;
   const TextPage pg = pages[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { s_at = pg.at; s_done = 0; s_bad_ord = 0xFFFFFFFFu; }
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_at = pg.at; s_done = 0; s_bad = 0; }
   __syncthreads();
-  // the length field at window position p (any alignment): two staged words funnelled
-  auto len_at = [&](uint32_t p) { return __builtin_amdgcn_alignbyte(stage[(p >> 2) + 1], stage[p >> 2], p & 3u); };
   for (;;) {
     const uint64_t at = s_at;
     const uint32_t done = s_done;
-    if (done >= pg.count || s_bad_ord != 0xFFFFFFFFu) break;  // (uniform: written before the last barrier of the round)
-    for (uint32_t i = (uint32_t)tid; i < PW / 4 + 4; i += 256) {
+    if (done >= pg.count || s_bad) break;  // (uniform: written before the round's last barrier)
+    for (uint32_t i = (uint32_t)tid; i < PQ_STAGE / 4 + 4; i += 256) {
       const uint64_t a = at + 4ull * i;
       stage[i] = a + 8 <= limit ? (uint32_t)load_unaligned(file, a, 4) : 0u;  // (a read past the page is harmless, one past the image is not)
     }
-    mark[tid] = tid == 0 ? 1u : 0u;  // the window starts on a boundary
-    if (tid == 0) { s_more = 1; s_exit = 0xFFFFFFFFu; }
-    __syncthreads();
-#pragma unroll 4
-    for (uint32_t j = 0; j < PW / 256; j++) {
-      const uint32_t p = j * 256 + (uint32_t)tid;
-      uint32_t v = PW_DEAD;
-      if (at + p + 4 <= pg.end) {
-        const uint32_t n = len_at(p);
-        if ((uint64_t)n <= pg.end - (at + p + 4)) { const uint64_t t = (uint64_t)p + 4 + n; v = t < PW ? (uint32_t)t : PW_EXIT; }
-      }
-      nx[0][p] = (uint16_t)v;
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int round = 0; round < 14; round++) {
-      const bool more = s_more != 0;
-      __syncthreads();
-      if (!more) break;
-      if (tid == 0) s_more = 0;
-      __syncthreads();
-      bool fresh = false;
-#pragma unroll 4
-      for (uint32_t j = 0; j < PW / 256; j++) {
-        const uint32_t p = j * 256 + (uint32_t)tid;
-        const uint32_t c = nx[cur][p];
-        uint32_t c2 = c;
-        if (c < PW) {
-          if ((mark[p >> 5] >> (p & 31)) & 1u) { const uint32_t bit = 1u << (c & 31); if (!(atomicOr(&mark[c >> 5], bit) & bit)) fresh = true; }
-          c2 = nx[cur][c];
-        }
-        nx[cur ^ 1][p] = (uint16_t)c2;
-      }
-      if (fresh) s_more = 1;
-      __syncthreads();
-      cur ^= 1;
-    }
-    // the marked positions are the chain's values in this window, in order: ranks, then one store pair each
-    const uint32_t m = mark[tid];
-    const uint32_t cnt = (uint32_t)__popc(m);
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t base = inc - cnt, total = 0;
-    for (int w = 0; w < 4; w++) { const uint32_t x = wsum[w]; if (w < wv) base += x; total += x; }
-    uint32_t mm = m, k = 0;
-    while (mm) {
-      const uint32_t b = (uint32_t)__ffs((int)mm) - 1; mm &= mm - 1;
-      const uint32_t p = (uint32_t)tid * 32 + b, ord = done + base + k;
-      k++;
-      const bool fits = at + p + 4 <= pg.end;
-      const uint32_t n = fits ? len_at(p) : 0u;
-      const bool ok = fits && (uint64_t)n <= pg.end - (at + p + 4);
-      if (!ok) { if (ord < pg.count) atomicMin(&s_bad_ord, ord); continue; }  // a prefix that points past its page: this value and the rest of the page read as empty, the call fails
-      if (ord < pg.count) { val_off[pg.ord + ord] = (uint32_t)(at + p + 4); val_len[pg.ord + ord] = n; }
-      if ((uint64_t)p + 4 + n >= PW) s_exit = p + 4 + n;  // (the chain's last value in the window: at most one)
-    }
     __syncthreads();
     if (tid == 0) {
-      const uint32_t nd = done + total;
-      if (s_bad_ord == 0xFFFFFFFFu && nd < pg.count && s_exit == 0xFFFFFFFFu) s_bad_ord = nd;  // the page ended before its values did
-      s_done = nd < pg.count ? nd : pg.count;
-      if (s_exit != 0xFFFFFFFFu) s_at = at + s_exit;
+      uint64_t o = 0;  // byte offset of the next prefix in the window
+      uint32_t cnt = 0;
+      const uint32_t want = pg.count - done;
+      while (cnt < want && o + 4 <= PQ_STAGE) {
+        const uint32_t oo = (uint32_t)o;
+        const uint64_t abs = at + o;
+        const uint32_t n = __builtin_amdgcn_alignbyte(stage[(oo >> 2) + 1], stage[oo >> 2], oo & 3u);
+        if (abs + 4 > pg.end || (uint64_t)n > pg.end - (abs + 4)) { s_bad = 1; break; }  // a prefix that points past its page: this value and the rest of the page read as empty, the call fails
+        o_off[cnt] = (uint32_t)(abs + 4); o_len[cnt] = n;
+        cnt++;
+        o += 4ull + n;
+      }
+      s_cnt = cnt;
+      s_at = at + o;
     }
     __syncthreads();
+    const uint32_t cnt = s_cnt;
+    for (uint32_t i = (uint32_t)tid; i < cnt; i += 256) { val_off[pg.ord + done + i] = o_off[i]; val_len[pg.ord + done + i] = o_len[i]; }
+    __syncthreads();
+    if (tid == 0) s_done = done + cnt;
+    __syncthreads();
   }
-  const uint32_t bad = s_bad_ord;
-  if (bad != 0xFFFFFFFFu) {
-    for (uint32_t o = bad + (uint32_t)tid; o < pg.count; o += 256) { val_off[pg.ord + o] = (uint32_t)pg.at; val_len[pg.ord + o] = 0; }
+  if (s_bad) {
+    for (uint32_t o = s_done + (uint32_t)tid; o < pg.count; o += 256) { val_off[pg.ord + o] = (uint32_t)pg.at; val_len[pg.ord + o] = 0; }
     if (tid == 0) *err = PQE_TEXT_LENGTH;
   }
 }
