@@ -56,6 +56,7 @@ traffic() {  # HBM bytes per launch of the dominant kernels: FETCH_SIZE / WRITE_
     bash tools/gpu_pmc2.sh "$1" $TAG/pmc_$2 $2 1 "WRITE_SIZE" > "$OUT/pmc_$2_write.log" 2>&1
   done
   bash tools/gpu_pmc2.sh "mask_hmac" $TAG/pmc_mask csv 1 "SQ_INSTS_VALU SQ_WAVES" > "$OUT/pmc_mask.log" 2>&1
+  bash tools/gpu_pmc2.sh "csv_parse_regular" $TAG/pmc_csv_valu csv 1 "SQ_INSTS_VALU SQ_WAVES SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" > "$OUT/pmc_csv_valu.log" 2>&1
   python tools/pmc_traffic.py "$OUT" && cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
 }
 case $MODE in
@@ -72,7 +73,8 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; print('
     tests
     traffic
     timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_csv.json" 2> "$OUT/bench_csv.err"; echo "== csv (the driver's command line) rc=$?"; line "$OUT/bench_csv.json"
-    bench "configs0 configs2 configs3 configs4 configs4d json sr sr_proto collapse debezium debezium_sr"
+    bench "configs0" "--from-rows"
+    bench "configs2 configs3 configs4 configs4d json sr sr_proto collapse debezium debezium_sr"
     timeout 400 python bench.py --workload configs4 --sink debezium > "$OUT/bench_configs4_debezium.json" 2> "$OUT/bench_configs4_debezium.err"; echo "== configs4 --sink debezium rc=$?"; line "$OUT/bench_configs4_debezium.json"
     stats "csv configs2 configs3 json sr debezium debezium_sr configs4d"
     echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s" ;;

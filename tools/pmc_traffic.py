@@ -38,5 +38,14 @@ for kern, wl, src, rows in (("csv_parse_regular", "csv", "tf_csv.hip", 1 << 20),
         b = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
         res[kern] = {"rows_per_launch": rows, "workload": wl, "bytes_per_launch": b, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "source_file": src, "source_sha256": sha(src),
                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB, separate passes) of this build, tools/gpu_visit.sh evidence; FETCH_SIZE x2 per MI355X_MICROARCH.md"}
+try:  # the dominant kernel's instruction counters (one pass of their own): what its time is made of
+    cv = {m.group(1): float(m.group(2)) for m in (re.search(r"(SQ_INSTS_VALU|SQ_WAVES|SQ_WAIT_INST_LDS|SQ_INSTS_LDS|SQ_WAVE_CYCLES|SQ_BUSY_CYCLES)\s+per_dispatch=([0-9.e+]+)", l)
+                                                  for l in open(out + "/pmc_csv_valu.log") if "csv_parse_regul" in l) if m}
+    if "csv_parse_regular" in res and cv.get("SQ_WAVES"):
+        res["csv_parse_regular"].update({"valu_wave_instructions_per_launch": cv.get("SQ_INSTS_VALU"), "lds_wave_instructions_per_launch": cv.get("SQ_INSTS_LDS"), "waves": cv["SQ_WAVES"],
+                                         "wait_inst_lds_cycles": cv.get("SQ_WAIT_INST_LDS"), "wave_cycles": cv.get("SQ_WAVE_CYCLES"),
+                                         "valu_issue_ms_at_4_cycles": round((cv.get("SQ_INSTS_VALU") or 0) * 4 / 1024 / 2.4e9 * 1e3, 4)})
+except OSError:
+    pass
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 print("== traffic", {k: v.get("bytes_per_launch", v.get("valu_instructions_per_value")) for k, v in res.items()})

@@ -528,6 +528,19 @@ __device__ __forceinline__ const Seg &find_seg(const Seg *segs, int32_t n, uint3
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].start <= ord) lo = mid; else hi = mid - 1; }
   return segs[lo];
 }
+// the same, for a workgroup of consecutive rows: ordinals grow with the rows, so ONE lane searches for the block's first ordinal and
+// every row walks forward from there — usually not at all (a page holds thousands of rows), instead of log2(pages) dependent loads a row
+__device__ __forceinline__ const Seg &find_seg_block(const Seg *segs, int32_t n, uint32_t ord, uint32_t first_ord, int *hint /* shared */) {
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].start <= first_ord) lo = mid; else hi = mid - 1; }
+    *hint = lo;
+  }
+  __syncthreads();
+  int i = *hint;
+  while (i + 1 < n && segs[i + 1].start <= ord) i++;
+  return segs[i];
+}
 __device__ __forceinline__ uint64_t load_unaligned(const uint8_t *file, uint64_t at, uint32_t nbytes) {  // nbytes <= 8
   uint64_t v = seg_read8(file, at);
   return nbytes >= 8 ? v : v & ((1ull << (8 * nbytes)) - 1);
@@ -791,12 +804,11 @@ __global__ void __launch_bounds__(256) pq_pack_validity_all(const LevDesc *descs
   for (int j = 0; j < 8; j++) { const int64_t r = b * 8 + j; if (r < nrows && rank[r + 1] != rank[r]) v |= 1u << j; }
   d.bits[b] = (uint8_t)v;
 }
-__device__ __forceinline__ void pq_fixed_row(const uint8_t *file, uint64_t tail_base, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t r, const uint64_t *dict_at, const uint32_t *dict_n, const FixedOut &o, uint32_t *err) {
+__device__ __forceinline__ void pq_fixed_row(const uint8_t *file, uint64_t tail_base, const Seg *segs, int32_t nsegs, const uint32_t *rank, int64_t r, const uint64_t *dict_at, const uint32_t *dict_n, const FixedOut &o, uint32_t *err, const Seg &s) {
   const uint32_t k = rank ? rank[r] : (uint32_t)r;   // (no rank: every row holds a value, its ordinal is the row)
   uint64_t v = 0;
   int32_t ns = 0;
   if (!rank || rank[r + 1] != k) {
-    const Seg &s = find_seg(segs, nsegs, k);
     const uint32_t w = (uint32_t)o.in_width;
     if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (s.in_tail ? tail_base : 0) + (uint64_t)(k - s.start) * w, w);
     else if (s.kind == SG_PLAIN_BOOL) v = (file[s.at + ((k - s.start) >> 3)] >> ((k - s.start) & 7)) & 1;
@@ -824,19 +836,22 @@ __device__ __forceinline__ void pq_fixed_row(const uint8_t *file, uint64_t tail_
   if (o.nanos) o.nanos[r] = ns;
 }
 __global__ void __launch_bounds__(256) pq_values_all(const uint8_t *file, uint64_t tail_base, const FixedDesc *descs, int64_t nrows, uint32_t *err) {
+  __shared__ int hint;
   const FixedDesc &d = descs[blockIdx.y];
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= nrows) return;
-  pq_fixed_row(file, tail_base, d.segs, d.nsegs, d.rank, r, d.dict_at, d.dict_n, d.o, err);
+  const int64_t r0 = (int64_t)blockIdx.x * blockDim.x, rl = r0 + threadIdx.x, r = rl < nrows ? rl : nrows - 1;  // (every thread reaches the barrier of the block search)
+  const Seg &s = find_seg_block(d.segs, d.nsegs, d.rank ? d.rank[r] : (uint32_t)r, d.rank ? d.rank[r0] : (uint32_t)r0, &hint);
+  if (rl >= nrows) return;
+  pq_fixed_row(file, tail_base, d.segs, d.nsegs, d.rank, r, d.dict_at, d.dict_n, d.o, err, s);
 }
 __global__ void __launch_bounds__(256) pq_text_cells_all(const uint8_t *file, uint64_t tail_base, const TextDesc *descs, int64_t nrows, uint32_t *err) {
+  __shared__ int hint;
   const TextDesc &d = descs[blockIdx.y];
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = r < nrows;  // (no early return: the wave reduction below needs every lane)
-  const uint32_t k = live ? (d.rank ? d.rank[r] : (uint32_t)r) : 0u;
+  const int64_t r0 = (int64_t)blockIdx.x * blockDim.x, r = r0 + threadIdx.x;
+  const bool live = r < nrows;  // (no early return: the block search's barrier and the wave reduction below need every lane)
+  const uint32_t k = live ? (d.rank ? d.rank[r] : (uint32_t)r) : 0xFFFFFFFFu;
+  const Seg &s = find_seg_block(d.segs, d.nsegs, live ? k : 0u, d.rank ? d.rank[r0] : (uint32_t)r0, &hint);
   uint32_t so = SEG_NONE, n = 0;
   if (live && (!d.rank || d.rank[r + 1] != k)) {
-    const Seg &s = find_seg(d.segs, d.nsegs, k);
     if (s.kind == SG_PLAIN_TEXT) { so = d.val_off[k]; n = d.val_len[k]; }
     else if (s.kind == SG_FIXED_TEXT) { so = (uint32_t)(s.at + (uint64_t)(k - s.start) * s.bw); n = s.bw; }
     else {
