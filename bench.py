@@ -274,6 +274,15 @@ def _parity(k, what, err=None, **kw):
     return out
 
 
+def _test_helpers(name):
+    """the GPU tests' own comparison helpers (tests/ travels with the tree): the bench lines check themselves with the code the suite uses"""
+    t = os.path.join(ROOT, "tests")
+    if t not in sys.path:
+        sys.path.insert(0, t)
+    import importlib
+    return importlib.import_module(name)
+
+
 def _guard_parity(fn):
     try:
         return fn()
@@ -1506,12 +1515,16 @@ class Configs4Workload(Base):
             names = [c.name for c in a.cols]
             t0 = time.perf_counter()
             nmsg = 0
+            emitted = []
             for r in range(m):
                 has = bool(a.old_present[r]) if getattr(a, "old_present", None) is not None else bool(getattr(a, "old_keys", None))
+                sr_ = int(a.src_row[r]) if a.src_row is not None else r
                 it = E.Item({0: "insert", 1: "update", 2: "delete"}.get(int(a.kind[r]), "other") if a.kind is not None else "insert", "public", "events", cols, names,
                             [tuple(c.pyvalue(r)) for c in a.cols], [c.name for c in a.old_keys] if has else [], [tuple(c.pyvalue(r)) for c in a.old_keys] if has else [],
-                            int(r % 97), r + 5, 1700000000000000000)
-                nmsg += len(em.emit_kv(it))
+                            int(sr_ % 97), sr_ + 5, 1700000000000000000)
+                kv = em.emit_kv(it)
+                emitted += kv
+                nmsg += len(kv)
             t_emit = time.perf_counter() - t0
             sec = r1.seconds + t_emit * (a.nrows / max(m, 1))
             out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
@@ -1519,6 +1532,24 @@ class Configs4Workload(Base):
                              f"({t_emit:.2f}s, {nmsg} messages; scaled to the slice), single thread",
                    "note": "the emitter leg is a PYTHON restatement (oracle/dbz_emitter.py): a parity checker, far slower than the Go emitter — not a performance baseline"}
             out.update(host_info())
+
+            def check_dbz():
+                lib, abi = e.lib, e.abi
+                head = abi.Batch([abi.Column(c.name, c.dtype, c.repr, values=None if c.values is None else c.values[:m], nanos=None if c.nanos is None else c.nanos[:m],
+                                             offsets=None if c.offsets is None else c.offsets[:m + 1].copy(), data=None if c.data is None else c.data[:int(c.offsets[m])],
+                                             validity=None if c.validity is None else c.validity[:m]) for c in a.cols], m, a.table_ns, a.table_name,
+                                 kind=None if a.kind is None else a.kind[:m], src_row=None if a.src_row is None else a.src_row[:m])
+                head.schema = s2
+                if a.old_keys:
+                    head.old_keys = [abi.Column(c.name, c.dtype, c.repr, values=None if c.values is None else c.values[:m], offsets=None if c.offsets is None else c.offsets[:m + 1].copy(),
+                                                data=None if c.data is None else c.data[:int(c.offsets[m])], validity=None if c.validity is None else c.validity[:m]) for c in a.old_keys]
+                    head.old_present = None if a.old_present is None else a.old_present[:m]
+                got = lib.debezium_emit(self.dopts, lib.DeviceBatch.upload(head), meta).messages()
+                want = [(kk_, v_) for kk_, v_ in emitted]
+                if [(bytes(x) if x is not None else None, bytes(y) if y is not None else None) for x, y in got] != [(bytes(x) if x is not None else None, bytes(y) if y is not None else None) for x, y in want]:
+                    return _parity(m, "Debezium emitter", "messages differ (%d vs %d)" % (len(got), len(want)))
+                return _parity(m, "Debezium emitter: every key and value message (inline schemas, tombstones) of the first %d collapsed rows against oracle/dbz_emitter.py, byte for byte" % m, compared_messages=len(want))
+            out["parity"] = _guard_parity(check_dbz)
             return out
         want = ora.queue_serialize(self.qopts, a, s2, meta)
         sec = r1.seconds + ora.queue_serialize.seconds
@@ -1632,6 +1663,43 @@ class Configs4DebeziumWorkload(Base):
                          f"~1.2 us per row (bench.py --workload configs4)",
                "note": "C restatement of the Go reference, not the Go binary; published Go figures for the parse half: 3.1 k (1 thread) … 14.8 k (64 threads) msg/s on an M1 Pro"}
         out.update(host_info())
+
+        def check():
+            td = _test_helpers("test_debezium")
+            lib, abi = e.lib, e.abi
+            kk = min(k, 2048)
+            mlist = e.workload.debezium_cdc_messages(kk, seed=0x5EED)
+            d2, m2 = abi.messages(mlist)
+            ora.debezium_parse.want_items = True
+            exp_items, codes = ora.debezium_parse(d2, m2)
+            ora.debezium_parse.want_items = False
+            parsed, errors = self.parser.parse(d2, m2)
+            if len(parsed) != 1 or errors:
+                return _parity(kk, "parse", "%d batches, %d errors" % (len(parsed), len(errors)))
+            p = parsed[0]
+            got = td.device_items(lib, p)
+            for it in exp_items:
+                td.assert_same_items(got[it["src"]], it, it["src"])
+            one = self.shard.apply(p.batch).transformed
+            grouped, counts = lib.partition(one, e.world)
+            back = self.comm.exchange(grouped, counts)[0] if self.comm is not None else grouped
+            col = lib.collapse(back)
+            a = col.download()
+            host = p.batch.download(); host.schema = p.schema
+            ref = ora.collapse(host, p.schema).batch
+            key = lambda b: sorted((int(b.kind[i]), int(b.src_row[i])) for i in range(b.nrows))
+            if key(a) != key(ref):
+                return _parity(kk, "Collapse", "surviving rows differ")
+            ids, lsns, cts, nf = p.meta()
+            meta = abi.row_meta(kk, ids=ids, lsns=lsns, commit_times=cts, names_form=nf)
+            o = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 20, table_schema=p.schema, old_key_types=["int64"])
+            outm = lib.queue_serialize(o, col, meta).messages()
+            a.schema = p.schema
+            if outm != ora.queue_serialize(o, a, p.schema, meta):
+                return _parity(kk, "native queue serializer", "messages differ")
+            return _parity(kk, "Debezium receiver (item for item) + sharder + partition + exchange (1 rank) + Collapse (surviving rows) + native queue serializer (byte for byte)",
+                           compared_output_rows=a.nrows, compared_messages=len(outm))
+        out["parity"] = _guard_parity(check)
         return out
 
 
@@ -1670,6 +1738,20 @@ class CollapseWorkload(Base):
                "sample": f"a {k}-row slice of the same stream through the oracle's Collapse ({r1.seconds:.2f}s), single thread",
                "note": "C restatement of the Go reference (json.Marshal key strings, string-keyed maps, boxed values), not the Go binary"}
         out.update(host_info())
+
+        def check():
+            e = self.env
+            got = e.lib.collapse(e.lib.DeviceBatch.upload(b2)).download()
+            why = _batch_diff(e.abi, got, r1.batch)
+            if why is None and not (np.array_equal(got.src_row, r1.batch.src_row) and np.array_equal(got.kind, r1.batch.kind)):
+                why = "kept rows / kinds"
+            if why is None and (got.old_keys or r1.batch.old_keys):
+                ga, gb = got.old_keys or [], r1.batch.old_keys or []
+                pa_, pb_ = got.old_present, r1.batch.old_present
+                if [c.name for c in ga] != [c.name for c in gb] or not np.array_equal(pa_ if pa_ is not None else np.ones(got.nrows, bool), pb_ if pb_ is not None else np.ones(got.nrows, bool)):
+                    why = "OldKeys"
+            return _parity(k, "Collapse: surviving rows, their order, kinds, cells and OldKeys presence against the oracle", why, compared_output_rows=got.nrows)
+        out["parity"] = _guard_parity(check)
         return out
 
 
@@ -1733,6 +1815,24 @@ class DebeziumWorkload(Base):
                "sample": f"{k} messages x {len(self.msg)} B: oracle Receive per message, schema re-compiled every message (the reference's benchmark disables its cache too) ({sec:.2f}s)",
                "note": "C restatement of the Go reference, not the Go binary"}
         out.update(host_info())
+
+        def check():
+            td = _test_helpers("test_debezium")
+            kk = min(k, 256)
+            d2, m2 = abi.messages([self.msg] * kk)
+            ora.debezium_parse.want_items = True
+            exp_items, codes = ora.debezium_parse(d2, m2)
+            ora.debezium_parse.want_items = False
+            parsed, errors = self.parser.parse(d2, m2)
+            if errors or sum(p.batch.nrows for p in parsed) != len(exp_items):
+                return _parity(kk, "parse", "%d device errors, %d rows vs %d items" % (len(errors), sum(p.batch.nrows for p in parsed), len(exp_items)))
+            got = {}
+            for p in parsed:
+                got.update(td.device_items(self.env.lib, p))
+            for it in exp_items:
+                td.assert_same_items(got[it["src"]], it, it["src"])
+            return _parity(kk, "Debezium receiver: every message's item (kind, table, schema, 61 column values, OldKeys, row meta) against the oracle", compared_output_rows=len(exp_items))
+        out["parity"] = _guard_parity(check)
         return out
 
 
@@ -1785,6 +1885,24 @@ class DebeziumSrWorkload(DebeziumWorkload):
                "sample": f"{k} events x {len(self.msg)} B: the oracle's DoBatch with a registry (Python cut + the C Receive per event, schema compiled per event) ({sec:.2f}s)",
                "note": "C / Python restatement of the Go reference, not the Go binary"}
         out.update(host_info())
+
+        def check():
+            td = _test_helpers("test_debezium")
+            kk = min(k, 256)
+            d2, m2 = abi.messages([self.msg] * kk)
+            ora.debezium_parse.want_items = True
+            exp_events, exp_items, codes = ora.debezium_parse_sr(d2, m2, {101: self.schema_text})
+            ora.debezium_parse.want_items = False
+            parsed, errors, events = self.parser.parse_registry(d2, m2)
+            if errors or sum(p.batch.nrows for p in parsed) != len(exp_items):
+                return _parity(kk, "parse", "%d device errors, %d rows vs %d items" % (len(errors), sum(p.batch.nrows for p in parsed), len(exp_items)))
+            got = {}
+            for p in parsed:
+                got.update(td.device_items(self.env.lib, p))
+            for ev, it in exp_items.items():
+                td.assert_same_items(got[ev], it, ev)
+            return _parity(kk, "registry-framed Debezium receiver: framing + every event's item against the oracle", compared_output_rows=len(exp_items))
+        out["parity"] = _guard_parity(check)
         return out
 
 
@@ -1835,6 +1953,28 @@ class SrProtoWorkload(DebeziumWorkload):
                "sample": f"{k} messages x {len(self.msg)} B: the oracle's PYTHON restatement of the protobuf branch ({sec:.2f}s)",
                "note": "a Python parity checker, far slower than the Go parser: not a performance baseline"}
         out.update(host_info())
+
+        def check():
+            import struct
+            abi = self.env.abi
+            kk = min(k, 256)
+            want = P.parse_messages([self.msg] * kk, {self.sid: self.text})
+            d2, m2 = abi.messages([self.msg] * kk)
+            batch, errors = self.schema.parse(self.sid, d2, m2)
+            b = batch.download()
+            if errors or b.nrows != kk:
+                return _parity(kk, "parse", "%d device errors, %d rows" % (len(errors), b.nrows))
+            for r, (kind, it) in enumerate(want):
+                if kind not in ("item", "row", "ok") and not isinstance(it, dict):
+                    return _parity(kk, "parse", "the oracle did not parse message %d (%s)" % (r, kind))
+                for c, w in zip(b.cols, it["values"]):
+                    g = c.pyvalue(r)
+                    same = (g[0] == "nil") if w[0] == "nil" else (g[0] == w[0] and (struct.pack("<d", g[1]) == struct.pack("<d", w[1]) or (g[1] != g[1] and w[1] != w[1]))) if w[0] in ("float32", "float64") \
+                        else (bytes(g[1]) == w[1]) if w[0] == "json" else abi.norm_value(g) == abi.norm_value(w)
+                    if not same:
+                        return _parity(kk, "parse", "message %d column %s differs" % (r, c.name))
+            return _parity(kk, "Confluent-SR protobuf parser: every message's 60 column values against the oracle", compared_output_rows=kk)
+        out["parity"] = _guard_parity(check)
         return out
 
 
