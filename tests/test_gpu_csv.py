@@ -197,8 +197,9 @@ def test_single_pass_form_and_its_fallbacks():
 
 
 def test_single_pass_cases(tf, oracle):
-    """A lane that has parsed a chunk of this shape sizes the next chunk's buffers from it and lets csv_parse_regular count the
-    lines itself (no csv_count_newlines pass); a chunk with more lines than expected, a header longer than the chunk's lines, or
+    """A lane that has parsed a chunk of this shape sizes the next chunk's buffers from it — by default without waiting for
+    csv_count_newlines' total (the sized-ahead form), with TFGPU_CSV_SPEC=1 letting csv_parse_regular count the lines itself (no
+    csv_count_newlines pass); a chunk with more lines than expected, a header longer than the chunk's lines, or
     a last line that spans the last tiles is parsed again the two-pass way.  Every answer must be the oracle's."""
     rng = np.random.default_rng(SEED0 + 23)
     kw = dict(include_missing_columns=1)
@@ -216,15 +217,25 @@ def test_single_pass_cases(tf, oracle):
         tf.prof_reset()
         compare(tf, oracle, kw, S4, a, "same chunk again")
         k = kernels()
-        if _os.environ.get("TFGPU_CSV_SPEC") != "1":
-            return  # the two-pass default: nothing more to see here
-        assert "csv_parse_regular" in k and "csv_count_newlines" not in k, k
+        spec = _os.environ.get("TFGPU_CSV_SPEC") == "1"
+        ahead = not spec and _os.environ.get("TFGPU_CSV_AHEAD") != "0"   # the default: two passes, buffers sized ahead of the count
+
+        def launches(name):
+            return sum(n for nm, n, _ms in tf.prof_get() if nm == name)
+        if spec:
+            assert "csv_parse_regular" in k and "csv_count_newlines" not in k, k
         tf.prof_reset()
         compare(tf, oracle, kw, S4, rows(5000, 9), "longer lines: fewer than expected")
-        assert "csv_count_newlines" not in kernels()
+        if spec:
+            assert "csv_count_newlines" not in kernels()
+        if ahead:
+            assert launches("csv_count_newlines") == 1 and launches("csv_parse_regular") == 1
         tf.prof_reset()
         compare(tf, oracle, kw, S4, rows(20000, 1), "shorter lines: more than the buffers hold")
-        assert "csv_count_newlines" in kernels()  # parsed again
+        if spec:
+            assert "csv_count_newlines" in kernels()  # parsed again
+        if ahead:
+            assert launches("csv_count_newlines") == 2 and launches("csv_parse_regular") == 2   # parsed again, the count read back first
     finally:
         tf.prof_enable(False)
     compare(tf, oracle, kw, S4, rows(20000, 1), "the same density again")

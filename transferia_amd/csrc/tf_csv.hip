@@ -367,6 +367,9 @@ struct CsvParams {
   // [2 + ntiles + t] one past the last '\n' tile t owns (0: none)
   uint32_t *spec;              // null: the line counts come from csv_count_newlines (gran_pre)
   uint32_t cap_lines;          // lines the column buffers were sized for
+  // sized-ahead form (two passes, no read-back between them): the host sized the buffers for cap_lines before csv_count_newlines
+  // had finished; a tile whose lines end beyond that sets this word and writes nothing, and the host parses the chunk again
+  uint32_t *ovf;               // null: the buffers were sized from the true count
 };
 
 // ---- one pass instead of two: the tile kernel finds its first line's index itself ----------------------------------------
@@ -1592,6 +1595,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
     line0 = gpre[gr0]; line1 = gpre[gr1]; lines_all = gpre[p.ngran];
     nlines = line1 - line0;
     if (nlines == 0) return;  // no line ends here (inside a very long line)
+    if (p.ovf && line1 > p.cap_lines) { if (tid == 0) *p.ovf = 1u; return; }  // sized-ahead form: more lines than the buffers hold (uniform)
   }
   const CsvOpts &o = p.o;
   const int64_t g0 = tile * CT_T - CT_SPILL;  // absolute offset of sb[0]
@@ -1893,8 +1897,10 @@ __global__ void __launch_bounds__(CT_THREADS, 6) csv_parse_cols(CsvParams p) { c
 #include "tf_csv_lanes.inc"
 
 // rows that failed contribute no string bytes
-__global__ void csv_zero_err_lens(const uint8_t *err, int64_t nrows, const CsvCol *cols, int32_t ncols) {
+// (sized-ahead form: `nrows` is what the buffers were sized for, err[] beyond the true count — lines_total - skip — was written by nobody)
+__global__ void csv_zero_err_lens(const uint8_t *err, int64_t nrows, const CsvCol *cols, int32_t ncols, const uint32_t *lines_total, int64_t skip) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lines_total) nrows = min(nrows, max((int64_t)*lines_total - skip, (int64_t)0));
   if (r >= nrows || !err[r]) return;
   for (int32_t ci = 0; ci < ncols; ci++) if (cols[ci].lens) cols[ci].lens[r] = 0;
 }
@@ -1997,9 +2003,14 @@ __global__ void __launch_bounds__(256) csv_copy_special(CopyParams p) {
 // one contiguous summary for a single read-back: [nerr, consumed, total bytes of each string column]
 // (single-pass form: `nrows` is what the buffers were sized for; the true count is the last tile's inclusive line count)
 __global__ void csv_collect(const uint32_t *nerr, const uint32_t *last, const uint32_t *lens_all, int64_t seg_stride, int64_t nrows, int nstr, const uint32_t *fstart_all,
-                            int64_t fstride, uint32_t *out, const uint32_t *spec, int64_t ntiles, int64_t skip) {
+                            int64_t fstride, uint32_t *out, const uint32_t *spec, int64_t ntiles, int64_t skip, const uint32_t *lines_total, const uint32_t *ovf) {
   int i = threadIdx.x;
-  if (spec) {
+  if (ovf) {  // sized-ahead form: `nrows` is what the buffers were sized for; the true count is csv_count_newlines' total
+    const uint32_t nl = *lines_total;
+    if (i == 2) { out[2 + 2 * nstr] = nl; out[3 + 2 * nstr] = *ovf; }
+    nrows = min(nrows, max((int64_t)nl - skip, (int64_t)0));
+    if (i == 1) out[1] = *last;
+  } else if (spec) {
     const uint32_t nl = ntiles ? (spec[2 + ntiles - 1] & SP_VAL) : 0u;
     if (i == 2) { out[2 + 2 * nstr] = nl; out[3 + 2 * nstr] = spec[1]; }
     nrows = min(nrows, max((int64_t)nl - skip, (int64_t)0));
@@ -2016,8 +2027,13 @@ __global__ void csv_collect(const uint32_t *nerr, const uint32_t *last, const ui
   if (i == 0) out[0] = *nerr;
   for (int s = i; s < nstr; s += blockDim.x) { out[2 + s] = lens_all[(int64_t)s * seg_stride + nrows]; out[2 + nstr + s] = fstart_all[(int64_t)s * fstride + FS_HDR - 1]; }
 }
-__global__ void csv_zero_flags(uint32_t *fstart_all, int64_t fstride, int nstr) {
+// everything the parse kernels count into, in one launch: the text columns' flag words, the two hand-over lists' counters (and the
+// consumed offset behind the first), the error count, the sized-ahead form's overflow word
+__global__ void csv_zero_flags(uint32_t *fstart_all, int64_t fstride, int nstr, uint32_t *slow, uint32_t *gen, uint32_t *nerr, uint32_t *ovf) {
   for (int s = threadIdx.x; s < nstr; s += blockDim.x) fstart_all[(int64_t)s * fstride + FS_HDR - 1] = 0;
+  if (threadIdx.x < 2) { slow[threadIdx.x] = 0; gen[threadIdx.x] = 0; }
+  if (threadIdx.x == 2) *nerr = 0;
+  if (threadIdx.x == 3 && ovf) *ovf = 0;
 }
 __global__ void csv_keep_from_err(const uint8_t *err, int64_t n, uint32_t *keep) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2359,19 +2375,29 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   static const bool spec_blockers = [] { for (const char *n : {"TFGPU_CSV_ABLATE", "TFGPU_CSV_GENERAL", "TFGPU_CSV_PHASES", "TFGPU_CSV_LANES"}) { const char *e = std::getenv(n); if (e && e[0] && e[0] != '0') return true; } return false; }();
   const bool spec = allow_spec && !spec_off && !spec_blockers && !rowpath && schema->ncols <= CR_LCOLS && cx.csv_hint_ncols == schema->ncols && cx.csv_hint_bpl >= 1.0 &&
                     len >= 2 * (uint64_t)CT_T && len < (1ull << 30);
+  // ---- the sized-ahead form (default; TFGPU_CSV_AHEAD=0 turns it off): the two passes as they are, but a lane that has parsed a chunk
+  //      of this shape before sizes the buffers from that chunk's bytes per line (+ 1/16) and does NOT wait for the count — the column plan
+  //      below is made while csv_count_newlines runs, the tile kernel is queued behind it, and the true count arrives with the one
+  //      read-back at the end.  A tile whose lines end beyond the buffers sets a flag and writes nothing → *retry. ----
+  static const bool ahead_off = [] { const char *e = std::getenv("TFGPU_CSV_AHEAD"); return e && e[0] == '0'; }();
+  const bool ahead = allow_spec && !ahead_off && !spec && !spec_blockers && !rowpath && cx.csv_hint_ncols == schema->ncols && cx.csv_hint_bpl >= 1.0 &&
+                     len >= 2 * (uint64_t)CT_T && len < (1ull << 30);
   uint32_t cap_lines = 0;
   Buf tile_counts = dalloc((size_t)((spec ? 0 : ngran) + 1) * 4);
   uint32_t nlines = 0;
-  if (spec) {
+  if (spec || ahead) {
     const double est = (double)len / cx.csv_hint_bpl;
     cap_lines = (uint32_t)std::min<double>((double)len, est + est / 16.0 + 64.0);
     nlines = cap_lines;  // everything below is sized for this many; the true count arrives with the summary
-  } else if (ntiles) {
+  }
+  if (!spec && ntiles) {
     { KernelTimer t("csv_count_newlines"); csv_count_newlines<<<(unsigned)ntiles, NL_THREADS, 0, st>>>(data, len, ptr<uint32_t>(tile_counts), ngran); }
     exclusive_scan_u32(ptr<uint32_t>(tile_counts), ptr<uint32_t>(tile_counts), ngran, true);
-    const uint32_t *h = d2h_u32(ptr<uint32_t>(tile_counts) + ngran);
-    tf::sync();
-    nlines = *h;
+    if (!ahead) {
+      const uint32_t *h = d2h_u32(ptr<uint32_t>(tile_counts) + ngran);
+      tf::sync();
+      nlines = *h;
+    }
   }
   Buf row_start;
   if (rowpath) {
@@ -2431,7 +2457,6 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   Buf lens_all = carve((size_t)std::max(nstr, 1) * (size_t)seg_stride * 4 + 16);
   const int64_t fstride = ((std::max<int64_t>(nrows, 1) + 3) / 4) * 4 + FS_HDR;
   Buf fstart_all = carve((size_t)std::max(nstr, 1) * (size_t)fstride * 4);
-  if (nstr) csv_zero_flags<<<1, 64, 0, st>>>(ptr<uint32_t>(fstart_all), fstride, nstr);
   int max_field = -1;
   int si = 0;
   std::vector<int> str_col_index;
@@ -2526,14 +2551,12 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
     for (auto &c : cols) if (c.kind == CK_JSONNUM) c.patch = ptr<uint32_t>(patch_all) + (size_t)(k++) * (size_t)std::max<int64_t>(nrows, 1);
     bcols = up(cols.data(), cols.size() * sizeof(CsvCol));
   }
-  Buf err = dalloc((size_t)nrows + 16), err_col = dalloc((size_t)nrows * 4 + 16), nerr = dalloc_zero(4);
+  Buf err = dalloc((size_t)nrows + 16), err_col = dalloc((size_t)nrows * 4 + 16), nerr = dalloc(4);
 
   // lines the tile path hands to the per-row path (at most one per tile per pass) + consumed offset
   const int64_t slow_cap = (int64_t)nlines + 5 * (ngran + 1) + 8;  // every line at most once, plus long / over-wide ones per piece
   Buf slow = dalloc((size_t)(2 * slow_cap + 2) * 4);
-  TF_HIP(hipMemsetAsync(slow->p, 0, 8, st));
   Buf gen = dalloc((size_t)(4 * (ngran + 2) + 2) * 4);  // [0] = count, then (first granule, granules) pairs — with (first line, lines) in the single-pass form
-  TF_HIP(hipMemsetAsync(gen->p, 0, 8, st));
   const uint32_t tile_bytes = CT_T;  // csv_parse_regular's tile: seven granules
   const int64_t rtiles = (int64_t)((len + tile_bytes - 1) / tile_bytes);
   Buf spec_state;
@@ -2562,6 +2585,9 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   static const bool force_general = [] { const char *e = std::getenv("TFGPU_CSV_GENERAL"); return e && e[0] == '1'; }();
   pp.gen_n = ptr<uint32_t>(gen); pp.gen_tile = ptr<uint32_t>(gen) + 1; pp.force_general = force_general ? 1 : 0;
   pp.spec = spec ? ptr<uint32_t>(spec_state) : nullptr; pp.cap_lines = cap_lines;
+  Buf ahead_ovf;
+  if (ahead) { ahead_ovf = dalloc(4); pp.ovf = ptr<uint32_t>(ahead_ovf); }
+  csv_zero_flags<<<1, 64, 0, st>>>(ptr<uint32_t>(fstart_all), fstride, nstr, ptr<uint32_t>(slow), ptr<uint32_t>(gen), ptr<uint32_t>(nerr), pp.ovf);
   pp.has_unmapped = 0;
   for (int f = 0; f <= max_field; f++) if (field_first[(size_t)f] < 0) pp.has_unmapped = 1;
   std::vector<int32_t> order((size_t)ncols);
@@ -2703,7 +2729,7 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
     { KernelTimer t("csv_parse_listed"); csv_parse_listed<<<(unsigned)std::min<int64_t>(blocks_for(slow_cap, 64), 1024), 64, 0, st>>>(pp); }
   }
   if (nrows && nstr) {
-    csv_zero_err_lens<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint8_t>(err), nrows, ptr<CsvCol>(bcols), ncols);
+    csv_zero_err_lens<<<blocks_for(nrows, 256), 256, 0, st>>>(ptr<uint8_t>(err), nrows, ptr<CsvCol>(bcols), ncols, ahead ? ptr<uint32_t>(tile_counts) + ngran : nullptr, skip);
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, nstr, seg_stride);
   } else if (nstr) {
     TF_HIP(hipMemsetAsync(lens_all->p, 0, (size_t)nstr * (size_t)seg_stride * 4, st));
@@ -2711,11 +2737,12 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   // ---- one read-back: error count, consumed offset, string totals ----
   Buf summary = dalloc((size_t)(2 * nstr + 4) * 4);
   csv_collect<<<1, 64, 0, st>>>(ptr<uint32_t>(nerr), rowpath ? ptr<uint32_t>(row_start) + nlines : pp.last_end, ptr<uint32_t>(lens_all),
-                                seg_stride, nrows, nstr, ptr<uint32_t>(fstart_all), fstride, ptr<uint32_t>(summary), pp.spec, rtiles, skip);
+                                seg_stride, nrows, nstr, ptr<uint32_t>(fstart_all), fstride, ptr<uint32_t>(summary), pp.spec, rtiles, skip,
+                                ptr<uint32_t>(tile_counts) + (spec ? 0 : ngran), pp.ovf);
   const uint32_t *hsum = d2h_u32(summary->p, (size_t)(2 * nstr) + 4);
   tf::sync();
   const uint32_t hnerr = hsum[0], last = hsum[1];
-  if (spec) {
+  if (spec || ahead) {
     const uint32_t nl_true = hsum[2 + 2 * nstr], overflow = hsum[3 + 2 * nstr];
     // more lines than the buffers hold, fewer than the header skips, or the last '\n' outside the last two tiles: the two-pass way
     if (overflow || nl_true > cap_lines || (int64_t)nl_true < skip || (nl_true && !last)) { *retry = true; return TFGPU_OK; }

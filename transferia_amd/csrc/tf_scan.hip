@@ -9,6 +9,7 @@ namespace tf {
 static constexpr int SCAN_THREADS = 256;
 static constexpr int SCAN_ITEMS = 16;
 static constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096
+static constexpr int64_t RAW_SUMS_MAX = 1024;
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   const int lane = threadIdx.x & 63;
@@ -55,8 +56,19 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                                  const uint32_t *__restrict__ block_base, int64_t n,
-                                                                 int64_t seg_stride, int64_t nblocks, int write_total) {
+                                                                 int64_t seg_stride, int64_t nblocks, int write_total, int raw_sums) {
   __shared__ uint32_t lds[4];
+  // raw_sums: block_base holds the workgroups' own totals, not their scan — each workgroup adds up the ones in front of it (at most
+  // RAW_SUMS_MAX words from L2) instead of a third launch scanning them
+  uint32_t bb = 0;
+  if (block_base) {
+    const uint32_t *bs = block_base + (int64_t)blockIdx.y * nblocks;
+    if (raw_sums) {
+      uint32_t part = 0;
+      for (int64_t i = threadIdx.x; i < (int64_t)blockIdx.x; i += SCAN_THREADS) part += bs[i];
+      block_excl_scan(part, &bb, lds);
+    } else bb = bs[blockIdx.x];
+  }
   const uint32_t *src = in + (int64_t)blockIdx.y * seg_stride;
   uint32_t *dst = out + (int64_t)blockIdx.y * seg_stride;
   int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
@@ -74,7 +86,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
   uint32_t tot;
-  uint32_t ex = block_excl_scan(s, &tot, lds) + (block_base ? block_base[(int64_t)blockIdx.y * nblocks + blockIdx.x] : 0);
+  uint32_t ex = block_excl_scan(s, &tot, lds) + bb;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) { uint32_t t = v[i]; v[i] = ex; ex += t; }
   if (fast) {
@@ -98,13 +110,14 @@ static void scan_impl(const uint32_t *in, uint32_t *out, int64_t n, int64_t seg_
   int64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
   dim3 grid((unsigned)nblocks, (unsigned)nseg);
   if (nblocks == 1) {
-    scan_apply_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, out, nullptr, n, seg_stride, 1, with_total ? 1 : 0);
+    scan_apply_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, out, nullptr, n, seg_stride, 1, with_total ? 1 : 0, 0);
     return;
   }
   Buf sums = dalloc((size_t)nblocks * nseg * 4 + 4);
   scan_reduce_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, ptr<uint32_t>(sums), n, seg_stride, nblocks);
-  scan_impl(ptr<uint32_t>(sums), ptr<uint32_t>(sums), nblocks, nblocks, nseg, false);
-  scan_apply_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, out, ptr<uint32_t>(sums), n, seg_stride, nblocks, with_total ? 1 : 0);
+  const bool raw = nblocks <= RAW_SUMS_MAX;  // two launches instead of three up to 4 Mi elements a segment
+  if (!raw) scan_impl(ptr<uint32_t>(sums), ptr<uint32_t>(sums), nblocks, nblocks, nseg, false);
+  scan_apply_kernel<<<grid, SCAN_THREADS, 0, st>>>(in, out, ptr<uint32_t>(sums), n, seg_stride, nblocks, with_total ? 1 : 0, raw ? 1 : 0);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) sum_u64_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t seg_stride, unsigned long long *totals) {

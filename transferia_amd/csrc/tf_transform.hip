@@ -744,11 +744,11 @@ static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /*
   int64_t n = in.nrows;
   exclusive_scan_u32(ptr<uint32_t>(keep), ptr<uint32_t>(keep), n, true);
   const uint32_t *hm = d2h_u32(ptr<uint32_t>(keep) + n);
+  Buf sel = dalloc((size_t)n * 4 + 4);  // sized for every row: the selection is built while the count travels to the host
+  if (n) build_selection_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint32_t>(keep), n, ptr<int32_t>(sel));
   sync();
   const uint32_t m = *hm;
   if ((int64_t)m == n) return shallow_copy(in);
-  Buf sel = dalloc((size_t)m * 4 + 4);
-  if (n) build_selection_kernel<<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint32_t>(keep), n, ptr<int32_t>(sel));
   if (lazy && lazy_rows_on() && !in.pending && m) {
     auto out = std::make_unique<tfgpu_dbatch>();
     out->nrows = m; out->ns = in.ns; out->table = in.table; out->schema = in.schema; out->key_names = in.key_names;
