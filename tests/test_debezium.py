@@ -498,3 +498,22 @@ def test_gpu_unpack_with_a_cached_prefix_equals_the_full_walk(tf, oracle):
     for it in exp_items:
         if it["src"] not in want:
             assert_same_items(got[it["src"]], it, it["src"])
+    # the usual batch of the usual topic — every message OK, the known schema, a payload the tile parser takes: the frames stay on the
+    # device (FrameCache::uniform in tf_debezium.hip), frame 0 and three counters come down instead, no host loop over the messages runs
+    usual = cdc_messages(700, seed=SEED0 + 9, weird=False)
+    du, mu = abi.messages(usual)
+    tf.prof_enable(True)
+    try:
+        tf.prof_reset()
+        parsed, errors = parser.parse(du, mu)
+        assert "dbz_frame_stats" in {name for name, _n, _ms in tf.prof_get()}
+    finally:
+        tf.prof_enable(False)
+    exp_items, codes = oracle.debezium_parse(du, mu)
+    assert errors == expected_errors(codes, exp_items, usual) == {}
+    got = {}
+    for p in parsed:
+        got.update(device_items(tf, p))
+    assert len(got) == len(exp_items) == 700
+    for it in exp_items:
+        assert_same_items(got[it["src"]], it, it["src"])

@@ -333,6 +333,44 @@ def test_gpu_registry_stream_matches_oracle(tf, oracle, n, weird):
 
 
 @pytest.mark.gpu
+def test_gpu_registry_usual_batch_keeps_its_frames_on_the_device(tf, oracle):
+    """Every event OK, one schema id, payloads the tile parser takes: tfgpu_debezium_registry_frames answers that with frame 0 and three
+    counters (FrameCache::uniform in tf_debezium.hip), the receiver runs none of its per-event loops — and the items are the oracle's."""
+    import random
+    from transferia_amd import debezium
+    rng = random.Random(SEED0 + 77)
+    ev = [ps.encode("utf-8") for _k, ps in cdc_payloads(rng, 600, "events", False)]
+    msgs, cur = [], b""
+    for i, body in enumerate(ev):
+        cur += frame(7, body)
+        if i % 3 == 2:
+            msgs.append(cur)
+            cur = b""
+    if cur:
+        msgs.append(cur)
+    data, m = abi.messages(msgs)
+    reg = registry()
+    exp_events, exp_items, codes = oracle.debezium_parse_sr(data, m, reg)
+    parser = debezium.Parser(tf)
+    parser.add_registry_schema(7, reg[7])
+    for round_ in range(2):   # (the second batch also claims the payload spans from the events' ends)
+        tf.prof_enable(True)
+        try:
+            tf.prof_reset()
+            parsed, errors, events = parser.parse_registry(data, m)
+            assert "dbz_frame_stats" in {name for name, _n, _ms in tf.prof_get()}
+        finally:
+            tf.prof_enable(False)
+        assert errors == {} and len(events) == 600
+        got = {}
+        for p in parsed:
+            got.update(device_items(tf, p))
+        assert sorted(got) == sorted(exp_items) and len(got) == 600
+        for e in exp_items:
+            assert_same_items(got[e], exp_items[e], (round_, e))
+
+
+@pytest.mark.gpu
 def test_gpu_registry_frames_refuse_foreign_events(tf):
     """events that do not come from tfgpu_sr_frames over the same bytes are refused, not followed"""
     import ctypes as C

@@ -14,7 +14,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("<")[0].replace("tf::", "").replace("(anonymous namespace)::", "")))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[2].endswith(anchor)]
+    starts = [i for i, r in enumerate(rows) if anchor in r[2]]
     if len(starts) < 3:
         print("anchor", anchor, "seen", len(starts), "times"); return
     a, b = starts[which], starts[which + 1]

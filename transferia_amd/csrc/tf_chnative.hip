@@ -251,10 +251,9 @@ extern "C" int tfgpu_ch_native_block(const tfgpu_dbatch *in, const tfgpu_ch_nati
     if (n) {
       chn_str_len<<<dim3((unsigned)((n + 255) / 256), (unsigned)nstr), 256, 0, st>>>(ptr<StrCol>(dstr), n, stride, ptr<uint32_t>(lens), ptr<unsigned long long>(bad) + 1);
       exclusive_scan_u32_segments(ptr<uint32_t>(lens), n, nstr, stride);
-      std::vector<uint32_t> tot((size_t)nstr);
-      for (int k = 0; k < nstr; k++) d2h(&tot[(size_t)k], ptr<uint32_t>(lens) + (size_t)k * stride + n, 4);
+      const uint32_t *tot = segment_totals_to_host(ptr<uint32_t>(lens), n, nstr, stride);
       sync();
-      for (int k = 0; k < nstr; k++) str_bytes[(size_t)k] = tot[(size_t)k];
+      for (int k = 0; k < nstr; k++) str_bytes[(size_t)k] = tot[k];
     }
   }
   // layout

@@ -246,6 +246,8 @@ void exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, bool with_
 // Segmented variant for `nseg` equally-long arrays laid out back to back
 // (used for the string columns of a batch): each segment scanned on its own.
 void exclusive_scan_u32_segments(uint32_t *inout, int64_t seg_len, int nseg, int64_t seg_stride);
+const uint32_t *any_nonzero_to_host(const uint32_t *v, int64_t n);  // one flag word read back; valid after the next sync
+const uint32_t *segment_totals_to_host(const uint32_t *scanned, int64_t seg_len, int nseg, int64_t seg_stride);  // one launch + one read-back; valid after the next sync
 // totals[s] += sum of segment s's seg_len entries, in 64 bits (the scans above wrap at 4 GiB: callers that size a 32-bit-offset
 // column from a scan's total check this sum first).  totals must be zeroed; enqueued on the lane's stream.
 void sum_u32_segments_u64(const uint32_t *in, int64_t seg_len, int nseg, int64_t seg_stride, unsigned long long *totals);

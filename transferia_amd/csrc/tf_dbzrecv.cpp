@@ -13,6 +13,8 @@
 // schema by a hash of its bytes (receiver.go:61-66); so does tfgpu_dbz_receiver, keyed by the device's hash of the same bytes,
 // and it keeps the head of the batch's opening message for tfgpu_debezium_unpack_cached.  Per message everything is
 // tfgpu_debezium_unpack / tfgpu_debezium_parse (tf_debezium.hip); nothing here touches a value.
+#include <chrono>
+#include <cstdio>
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -259,7 +261,7 @@ using namespace tf;
 using namespace tf::dbzrecv;
 
 namespace tf { std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep); }  // tf_transform.hip
-namespace tf { namespace dbz { void dbz_trust_frames(bool on); void dbz_tentative_frames(bool on); bool dbz_last_parse_was_quick(); } }
+namespace tf { namespace dbz { void dbz_trust_frames(bool on); void dbz_tentative_frames(bool on); bool dbz_last_parse_was_quick(); void dbz_lazy_frames(bool on, uint64_t h0, uint64_t h1); bool dbz_last_unpack_uniform(); } }
 
 struct tfgpu_dbz_schema {
   int code = 0; std::string why;
@@ -301,6 +303,7 @@ struct tfgpu_dbz_receiver {
   struct Group { std::shared_ptr<tfgpu_dbz_schema> schema; tfgpu_dbatch *batch = nullptr; PinVec<tfgpu_dbz_row> rows; int64_t nrows = 0; };
   std::vector<Group> groups;
   PinVec<tfgpu_dbz_frame> frames;
+  std::vector<uint64_t> ev_starts, ev_offs; std::vector<int64_t> ev_wts;   // registry form: one slot per event, kept across batches
   PinVec<tfgpu_sr_frame> events;   // registry form: tfgpu_sr_frames' list (page-locked: one DMA down, and its device copy serves the next call)
   std::vector<tfgpu_row_error> errs;
   std::vector<PinVec<tfgpu_dbz_row>> spare_rows;
@@ -353,6 +356,7 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
     const int64_t nmsg = msgs ? msgs->nmsg : 1;
     if ((int64_t)r->frames.size() < std::max<int64_t>(nmsg, 1)) r->frames.resize((size_t)std::max<int64_t>(nmsg, 1));  // (filled by the unpack call: no need to clear 48 bytes per message per batch)
     int rc;
+    bool uniform = false;
     if (r->have_known) {
       tfgpu_dbz_prefix k{};
       k.bytes = r->known_bytes.data(); k.len = (uint32_t)r->known_bytes.size(); k.schema_off = r->known_off; k.schema_len = r->known_len;
@@ -360,13 +364,21 @@ int tfgpu_dbz_receive(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, in
       // payload spans claimed from the messages' ends instead of walked (tf_debezium.hip, Params::tent) once the tile parser has
       // taken a batch of this receiver: it proves them, or the walker walks them
       struct Tent { bool on; explicit Tent(bool o) : on(o) { if (on) tf::dbz::dbz_tentative_frames(true); } ~Tent() { if (on) tf::dbz::dbz_tentative_frames(false); } } tent(r->last_quick);
+      // … and the frames themselves only when they are not all alike (tf_debezium.hip, FrameCache::uniform): the usual batch of the
+      // usual topic answers "every message OK, this schema, a payload the tile parser takes" with frame 0 and nothing else
+      struct Lazy { Lazy() { tf::dbz::dbz_lazy_frames(true, 0, 0); } ~Lazy() { tf::dbz::dbz_lazy_frames(false, 0, 0); } } lazy;
       rc = tfgpu_debezium_unpack_cached(bytes, len, mem, msgs, &k, r->frames.data());
+      uniform = rc == TFGPU_OK && nmsg > 0 && tf::dbz::dbz_last_unpack_uniform();
     } else rc = tfgpu_debezium_unpack(bytes, len, mem, msgs, r->frames.data());
     if (rc) return rc;
-    if (msg_codes) for (int64_t m = 0; m < nmsg; m++) msg_codes[m] = r->frames[(size_t)m].code;
+    if (msg_codes) {
+      if (uniform) std::fill(msg_codes, msg_codes + nmsg, 0);
+      else for (int64_t m = 0; m < nmsg; m++) msg_codes[m] = r->frames[(size_t)m].code;
+    }
     // the first message of every distinct schema, in order of first appearance
     std::vector<std::pair<std::pair<uint64_t, uint64_t>, int64_t>> firsts;
-    {
+    if (uniform) firsts.push_back({{r->frames[0].schema_hash[0], r->frames[0].schema_hash[1]}, 0});
+    else {
       std::pair<uint64_t, uint64_t> last{0, 0}; bool have_last = false;
       std::map<std::pair<uint64_t, uint64_t>, bool> seen;
       for (int64_t m = 0; m < nmsg; m++) {
@@ -455,13 +467,26 @@ int tfgpu_dbz_receiver_add_registry_schema(tfgpu_dbz_receiver *r, uint32_t schem
 }
 // DoBatch with a registry: frame (tfgpu_sr_frames), payload spans (tfgpu_debezium_registry_frames), one parse per schema id, then
 // DoBuf's rule over the events of each Kafka message.
+// TFGPU_DBZ_HOSTTIME=1 (profiling only): wall time between marks of the receiver's host code, to stderr
+struct RecvClock {
+  bool on; std::chrono::steady_clock::time_point t0;
+  RecvClock() : on([] { const char *e = std::getenv("TFGPU_DBZ_HOSTTIME"); return e && e[0] == '1'; }()), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char *name) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "tfgpu hosttime receiver: %-28s %.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs,
                                tfgpu_sr_frame *events, int64_t events_cap, int64_t *nevents, int32_t *event_codes,
                                uint32_t *missing_ids, int32_t missing_cap, int32_t *nmissing, int32_t *ngroups) {
   if (!r || (len && !bytes) || !ngroups || !nevents || !nmissing || (events_cap && (!events || !event_codes)) || events_cap < 0 || missing_cap < 0 || (missing_cap && !missing_ids))
     return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbz_receive_registry: bad argument");
   try {
+    RecvClock rc_clock;
     r->drop();
+    rc_clock.mark("drop");
     *ngroups = 0; *nmissing = 0;
     // into the receiver's own page-locked list first (the caller's array is pageable: a staged copy of 32 bytes per event), grown to
     // what the batch needs; the caller's copy is made at the end
@@ -470,6 +495,7 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
     events = r->events.data();
     int rc = tfgpu_sr_frames(bytes, len, mem, msgs, events, events_cap, nevents);
     if (rc) return rc;
+    rc_clock.mark("tfgpu_sr_frames");
     const int64_t n = *nevents;
     struct CopyOut { tfgpu_sr_frame *dst; const tfgpu_sr_frame *src; const int64_t &n; ~CopyOut() { if (n > 0) std::memcpy(dst, src, (size_t)n * sizeof(tfgpu_sr_frame)); } } copy_out{caller_events, events, *nevents};
     // schema ids in order of first appearance; the ones nobody registered
@@ -488,9 +514,13 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
     for (uint32_t id : ids) if (!r->registry.count(id)) { if (*nmissing < missing_cap) missing_ids[*nmissing] = id; ++*nmissing; }
     if (*nmissing) return TFGPU_OK;
     if (!n) return TFGPU_OK;
+    rc_clock.mark("schema ids");
     // one slot per event: [where it starts, where the next one starts)
-    std::vector<uint64_t> starts((size_t)n + 1), offs((size_t)n);
-    std::vector<int64_t> wts((size_t)n);
+    std::vector<uint64_t> &starts = r->ev_starts, &offs = r->ev_offs;   // (kept across batches: 24 bytes per event are not allocated and paged in per call)
+    std::vector<int64_t> &wts = r->ev_wts;
+    if ((int64_t)starts.size() < n + 1) starts.resize((size_t)n + 1);
+    if ((int64_t)offs.size() < n) offs.resize((size_t)n);
+    if ((int64_t)wts.size() < n) wts.resize((size_t)n);
     for (int64_t e = 0; e < n; e++) {
       const tfgpu_sr_frame &f = events[e];
       starts[(size_t)e] = f.code ? f.start : f.start - 5;
@@ -502,15 +532,24 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
     tfgpu_messages em{};
     em.nmsg = n; em.start = starts.data(); em.offset = msgs && msgs->offset ? offs.data() : nullptr; em.write_time_ns = msgs && msgs->write_time_ns ? wts.data() : nullptr;
     if ((int64_t)r->frames.size() < n) r->frames.resize((size_t)n);
+    rc_clock.mark("event slots");
+    bool uniform = false;
     {
       // payload spans claimed from the events' ends instead of walked once the tile parser has taken a batch of this receiver: it
       // proves them, or the walker walks them (tf_debezium.hip, Params::tent)
       struct Tent { bool on; explicit Tent(bool o) : on(o) { if (on) tf::dbz::dbz_tentative_frames(true); } ~Tent() { if (on) tf::dbz::dbz_tentative_frames(false); } } tent(r->last_quick);
       struct Trust { Trust() { tf::dbz::dbz_trust_frames(true); } ~Trust() { tf::dbz::dbz_trust_frames(false); } } trust;  // `events` is what tfgpu_sr_frames wrote, untouched
+      // … and the frames themselves only when they are not all alike (every event OK, the batch's one schema id, a payload the tile parser takes)
+      struct Lazy { bool on; Lazy(bool o, uint32_t id) : on(o) { if (on) tf::dbz::dbz_lazy_frames(true, id, TFGPU_DBZ_REGISTRY_HASH); } ~Lazy() { if (on) tf::dbz::dbz_lazy_frames(false, 0, 0); } } lazy(ids.size() == 1, ids.empty() ? 0u : ids[0]);
       rc = tfgpu_debezium_registry_frames(bytes, len, mem, &em, events, r->frames.data());
+      uniform = rc == TFGPU_OK && ids.size() == 1 && tf::dbz::dbz_last_unpack_uniform();
     }
     if (rc) return rc;
-    for (int64_t e = 0; e < n; e++) event_codes[e] = r->frames[(size_t)e].code;
+    rc_clock.mark("registry_frames");
+    if (uniform) std::fill(event_codes, event_codes + n, 0);
+    else for (int64_t e = 0; e < n; e++) event_codes[e] = r->frames[(size_t)e].code;
+    rc_clock.mark("event codes");
+    bool codes_clean = uniform;
     std::vector<tfgpu_row_error> &errs = r->errs;
     if ((int64_t)errs.size() < n) errs.resize((size_t)n);
     for (uint32_t id : ids) {
@@ -530,15 +569,17 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
       if (rc) return rc;
       r->last_quick = tf::dbz::dbz_last_parse_was_quick();
       for (int64_t i = 0; i < std::min<int64_t>(ne, (int64_t)errs.size()); i++) if (errs[(size_t)i].row >= 0 && errs[(size_t)i].row < n) event_codes[errs[(size_t)i].row] = errs[(size_t)i].code;
+      if (ne) codes_clean = false;
       tfgpu_batch v{};
       if (g.batch && tfgpu_dbatch_view(g.batch, &v) == TFGPU_OK) g.nrows = v.nrows;
       if (s->code || g.nrows == 0) { if (g.batch) tfgpu_dbatch_free(g.batch); r->spare_rows.push_back(std::move(g.rows)); continue; }
       r->groups.push_back(std::move(g));
     }
+    rc_clock.mark("parse per schema");
     // DoBuf (parser.go:59-71): the first event that fails ends its Kafka message — DoOne hands back a nil rest; an event the stock
     // code must redo takes its whole message there
     bool any_lost = false;
-    for (int64_t a = 0; a < n;) {
+    for (int64_t a = 0; a < n && !codes_clean;) {   // (every code zero: nothing ends, nothing is redone)
       int64_t z = a;
       while (z < n && events[z].msg == events[a].msg) z++;
       bool host = false;
@@ -551,6 +592,7 @@ int tfgpu_dbz_receive_registry(tfgpu_dbz_receiver *r, const void *bytes, uint64_
       }
       a = z;
     }
+    rc_clock.mark("DoBuf rule");
     if (any_lost) {  // rows of events that are no items after all: cut out of their group's batch (a keep mask, compact_rows) and of its row meta
       std::vector<tfgpu_dbz_receiver::Group> kept;
       for (auto &G : r->groups) {

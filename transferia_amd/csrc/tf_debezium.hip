@@ -1053,10 +1053,41 @@ using namespace tf;
 // tfgpu_debezium_parse, unmodified — it says so (dbz_trust_frames) and the 5 MB of frames per 2^17 messages are neither checked
 // nor uploaded again.  Any other caller's frames are checked and uploaded as before.
 namespace tf { namespace dbz {
-struct FrameCache { const tfgpu_dbz_frame *host = nullptr; int64_t nmsg = -1; const void *bytes = nullptr; Buf dev, tent; };
+// `uniform`: every frame is OK, carries the known schema hash and a payload the tile parser can stage — the receiver asked for
+// that answer instead of the frames (dbz_lazy_frames): only frame 0 and its payload's bytes came down, with the widest payload in chunks
+struct FrameCache { const tfgpu_dbz_frame *host = nullptr; int64_t nmsg = -1; const void *bytes = nullptr; Buf dev, tent; bool uniform = false; uint32_t max_chunks = 0; std::string pay0; };
 static thread_local FrameCache g_frames;
-static thread_local bool g_trust = false, g_tentative = false, g_last_quick = false;
+static thread_local bool g_trust = false, g_tentative = false, g_last_quick = false, g_lazy = false;
 void dbz_trust_frames(bool on) { g_trust = on; }
+// the receiver, around its unpack call: when the batch is uniform (see FrameCache) `frames` receives frame 0 only — 48 bytes instead
+// of 5 MB per 2^17 messages, and none of the three host loops over them runs
+static thread_local uint64_t g_lazy_h0 = 0, g_lazy_h1 = 0;
+// (h0, h1): the schema hash every frame must carry — tfgpu_debezium_registry_frames has no other way to know it; the cached-prefix call uses its prefix's
+void dbz_lazy_frames(bool on, uint64_t h0, uint64_t h1) { g_lazy = on; g_lazy_h0 = h0; g_lazy_h1 = h1; }
+bool dbz_last_unpack_uniform() { return g_frames.uniform; }
+struct FrameStats { uint32_t n_odd, max_chunks, pay_len, pad; tfgpu_dbz_frame f0; uint8_t pay[JQ_BYTES]; };
+// one thread per frame: how many are not (OK, hash (h0, h1), payload of 2 .. JQ_BYTES - 32 bytes), the widest payload in the 16-byte
+// chunks the tile parser stages; workgroup 0 also leaves frame 0 and its payload's bytes
+__global__ void __launch_bounds__(256) dbz_frame_stats(const tfgpu_dbz_frame *fr, int64_t nmsg, uint64_t h0, uint64_t h1, const uint8_t *data, FrameStats *out) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t odd = 0, chunks = 0;
+  if (m < nmsg) {
+    const tfgpu_dbz_frame f = fr[m];
+    const bool ok = f.code == TFGPU_ROW_OK && f.schema_hash[0] == h0 && f.schema_hash[1] == h1 && f.payload_len >= 2 && f.payload_len <= (uint32_t)JQ_BYTES - 32u;
+    odd = ok ? 0u : 1u;
+    const uint32_t ps = (uint32_t)f.payload_start, pl = f.payload_len;
+    if (ok) chunks = (((ps + pl + 15u) & ~15u) - (ps & ~15u)) >> 4;
+  }
+  const uint64_t any_odd = __ballot(odd != 0);
+  for (int d = 32; d; d >>= 1) chunks = max(chunks, (uint32_t)__shfl_xor((int)chunks, d, 64));
+  if ((threadIdx.x & 63) == 0) { if (any_odd) atomicAdd(&out->n_odd, (uint32_t)__popcll(any_odd)); atomicMax(&out->max_chunks, chunks); }
+  if (blockIdx.x == 0 && nmsg > 0) {
+    const tfgpu_dbz_frame f = fr[0];
+    if (threadIdx.x == 0) { out->f0 = f; out->pay_len = f.code == TFGPU_ROW_OK && f.payload_len <= (uint32_t)JQ_BYTES ? f.payload_len : 0u; }
+    if (f.code == TFGPU_ROW_OK && f.payload_len <= (uint32_t)JQ_BYTES)
+      for (uint32_t i = threadIdx.x; i < f.payload_len; i += 256) out->pay[i] = data[f.payload_start + i];
+  }
+}
 // the receiver, around its unpack call: spans may be claimed from the messages' ends (Params::tent) — it will hand the frames to
 // tfgpu_debezium_parse under dbz_trust_frames, where the claims are proven or the full walk is run
 void dbz_tentative_frames(bool on) { g_tentative = on; }
@@ -1075,6 +1106,24 @@ struct HostClock {
     t0 = t1;
   }
 };
+
+
+// The lazy form of the two frame calls (dbz_lazy_frames): count the frames that are not (OK, hash (h0, h1), a payload the tile parser stages);
+// none → frame 0, its payload's bytes and the widest payload come down instead of the frames, the cache says `uniform`, true is returned.
+static bool frames_stay_down(const dbz::Params &p, int64_t n, uint64_t h0, uint64_t h1, tfgpu_dbz_frame *frames, const void *bytes, const Buf &fr, const Buf &tent) {
+  static const bool lazy_off = [] { const char *e = std::getenv("TFGPU_DBZ_LAZY_FRAMES"); return e && e[0] == '0'; }();  // A/B runs
+  if (!dbz::g_lazy || lazy_off || n <= 0) return false;
+  Context &cx = ctx();
+  Buf bst = dalloc(sizeof(dbz::FrameStats));
+  TF_HIP(hipMemsetAsync(bst->p, 0, 16, cx.stream));
+  { KernelTimer t("dbz_frame_stats"); dbz::dbz_frame_stats<<<dbz::nblk(n, 256), 256, 0, cx.stream>>>(p.frames, n, h0, h1, p.data, reinterpret_cast<dbz::FrameStats *>(bst->p)); }
+  const dbz::FrameStats *hs = reinterpret_cast<const dbz::FrameStats *>(d2h_u32(bst->p, sizeof(dbz::FrameStats) / 4));
+  tf::sync();
+  if (hs->n_odd) return false;
+  frames[0] = hs->f0;
+  dbz::g_frames = dbz::FrameCache{frames, n, bytes, fr, tent, true, std::max<uint32_t>(hs->max_chunks, 1u), std::string(reinterpret_cast<const char *>(hs->pay), hs->pay_len)};
+  return true;
+}
 
 static int debezium_unpack_impl(const void *bytes, uint64_t len, int mem, const tfgpu_messages *msgs, tfgpu_dbz_frame *frames, const tfgpu_dbz_prefix *known) {
   TF_API_BEGIN
@@ -1106,6 +1155,7 @@ static int debezium_unpack_impl(const void *bytes, uint64_t len, int mem, const 
     { KernelTimer t("dbz_prefix_same"); dbz::dbz_prefix_same<<<(unsigned)((nmsg + 3) / 4), 256, 0, cx.stream>>>(s.p); }
     { KernelTimer t("dbz_unpack"); dbz::dbz_unpack_rest<<<dbz::nblk(nmsg, 128), 128, 0, cx.stream>>>(s.p); }
     hc.mark(tent ? "kernels (claimed spans)" : "kernels");
+    if (frames_stay_down(s.p, nmsg, known->schema_hash[0], known->schema_hash[1], frames, bytes, fr, tent)) { hc.mark("frame stats down"); return TFGPU_OK; }
     d2h(frames, fr->p, (size_t)nmsg * sizeof(tfgpu_dbz_frame));
     tf::sync();
     hc.mark("frames down");
@@ -1175,6 +1225,7 @@ extern "C" int tfgpu_debezium_registry_frames(const void *bytes, uint64_t len, i
   if (n) {
     if (!ev_trusted) h2d(ev->p, events, (size_t)n * sizeof(tfgpu_sr_frame));
     { KernelTimer t("dbz_registry_frames"); dbz::dbz_registry_frames<<<dbz::nblk(n, 128), 128, 0, cx.stream>>>(s.p, reinterpret_cast<const tfgpu_sr_frame *>(ev->p)); }
+    if (frames_stay_down(s.p, n, dbz::g_lazy_h0, dbz::g_lazy_h1, frames, bytes, fr, tent)) return TFGPU_OK;
     d2h(frames, fr->p, (size_t)n * sizeof(tfgpu_dbz_frame));
     tf::sync();
   }
@@ -1236,10 +1287,17 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
       bsorted = upload_small(sorted.data(), sorted.size() * 2);
   p.fields = ptr<dbz::FRecv>(bfields); p.nfields = nf; p.names = ptr<uint8_t>(bnames); p.sorted = ptr<uint16_t>(bsorted);
   const size_t cells = (size_t)std::max(nf, 1) * (size_t)nma;
-  Buf vstart = dalloc(cells * 4), vlen = dalloc(cells * 4), vtype = dalloc_zero(cells + 16);
-  Buf status = dalloc_zero((size_t)nma + 16), kind = dalloc_zero((size_t)nma + 16), keep = dalloc_zero((size_t)(nma + 1) * 4 + 16), misc = dalloc_zero(32);
-  Buf lsn = dalloc_zero((size_t)nma * 8), ts = dalloc_zero((size_t)nma * 8), tabhash = dalloc_zero((size_t)nma * 8), txid = dalloc_zero((size_t)nma * 4),
-      tab_s = dalloc_zero((size_t)nma * 8), tab_n = dalloc_zero((size_t)nma * 8);
+  Buf vstart = dalloc(cells * 4), vlen = dalloc(cells * 4);
+  // everything that starts as z0block, as views of one block cleared by one fill (twelve fills of their own were 60 us of every batch)
+  auto z0a64 = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  const size_t z0sizes[] = {cells + 16, (size_t)nma + 16, (size_t)nma + 16, (size_t)(nma + 1) * 4 + 16, 32, (size_t)nma * 8, (size_t)nma * 8, (size_t)nma * 8, (size_t)nma * 4, (size_t)nma * 8, (size_t)nma * 8, 512};
+  size_t z0total = 0;
+  for (size_t z : z0sizes) z0total += z0a64(z);
+  Buf z0block = dalloc_zero(z0total);
+  size_t z0off = 0; int z0i = 0;
+  auto zview = [&]() { Buf b = subbuf(z0block, z0off, z0sizes[z0i]); z0off += z0a64(z0sizes[z0i]); z0i++; return b; };
+  Buf vtype = zview(), status = zview(), kind = zview(), keep = zview(), misc = zview();
+  Buf lsn = zview(), ts = zview(), tabhash = zview(), txid = zview(), tab_s = zview(), tab_n = zview();
   p.vstart = ptr<uint32_t>(vstart); p.vlen = ptr<uint32_t>(vlen); p.vtype = ptr<uint8_t>(vtype);
   p.status = ptr<uint8_t>(status); p.kind = ptr<uint8_t>(kind); p.keep = ptr<uint32_t>(keep);
   p.lsn = ptr<uint64_t>(lsn); p.ts = ptr<uint64_t>(ts); p.tabhash = ptr<uint64_t>(tabhash); p.txid = ptr<uint32_t>(txid);
@@ -1247,7 +1305,7 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
   p.nerr = ptr<uint32_t>(misc); p.first_ok = ptr<unsigned long long>(misc) + 1;
   TF_HIP(hipMemsetAsync(p.first_ok, 0xFF, 8, st));
   p.p10 = pow10_table(); p.p128 = reinterpret_cast<const uint64_t *>(p.p10 + 632);
-  Buf tabname = dalloc_zero(512);
+  Buf tabname = zview();
   hc.mark("frames check + up, buffers");
   // ---- dbz_parse_quick for the messages that spell the group's first payload's members (tf_dbzquick.inc); TFGPU_DBZ_QUICK=0: the walker for all ----
   static const bool quick_off = [] { const char *e = std::getenv("TFGPU_DBZ_QUICK"); return e && e[0] == '0'; }();
@@ -1263,10 +1321,16 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
   Buf bmap, bslow;
   int64_t qtiles = 0;
   uint32_t lpt = 0;
+  // (a uniform batch, FrameCache: the unpack call answered all of this on the device; `frames` holds frame 0 only)
+  const bool uni = trusted && dbz::g_frames.uniform && frames[0].schema_hash[0] == p.h0 && frames[0].schema_hash[1] == p.h1 && dbz::g_frames.pay0.size() == frames[0].payload_len;
+  if (trusted && dbz::g_frames.uniform && !uni) {  // the caller's schema is not the one every frame carries: no frame is eligible, nothing else to look at
+    quick = false;
+  }
   if (quick) {
     int64_t m0 = -1;
     uint32_t maxchunks = 1;   // the longest payload the tile kernel could take, in 16-byte chunks as it stages them
-    for (int64_t m = 0; m < nmsg; m++) {
+    if (uni) { m0 = 0; maxchunks = dbz::g_frames.max_chunks; }
+    else for (int64_t m = 0; m < nmsg; m++) {
       if (!eligible(m)) continue;
       if (m0 < 0) m0 = m;
       const uint32_t ps = (uint32_t)frames[m].payload_start, pl = frames[m].payload_len;
@@ -1276,7 +1340,8 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     quick = false;
     if (m0 >= 0) {
       std::string pay((size_t)frames[m0].payload_len, '\0');
-      if (mem == TFGPU_MEM_HOST) std::memcpy(&pay[0], (const uint8_t *)bytes + frames[m0].payload_start, pay.size());
+      if (uni) pay = dbz::g_frames.pay0;
+      else if (mem == TFGPU_MEM_HOST) std::memcpy(&pay[0], (const uint8_t *)bytes + frames[m0].payload_start, pay.size());
       else { d2h(&pay[0], p.data + frames[m0].payload_start, pay.size()); tf::sync(); }
       std::vector<std::string> fnames;
       std::vector<int> fops;

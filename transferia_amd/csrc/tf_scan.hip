@@ -134,6 +134,30 @@ void sum_u32_segments_u64(const uint32_t *in, int64_t seg_len, int nseg, int64_t
   sum_u64_kernel<<<dim3((unsigned)nb, (unsigned)nseg), SCAN_THREADS, 0, ctx().stream>>>(in, seg_len, seg_stride, totals);
 }
 
+__global__ void segment_totals_kernel(const uint32_t *lens_all, int64_t seg_stride, int64_t n, int nseg, uint32_t *out) {
+  for (int t = threadIdx.x; t < nseg; t += blockDim.x) out[t] = lens_all[(int64_t)t * seg_stride + n];
+}
+// the totals exclusive_scan_u32_segments left at [seg_len] of every segment, gathered by one launch into one read-back (the pointer is
+// valid after the next sync) — nseg four-byte copies of their own were 5 us each
+const uint32_t *segment_totals_to_host(const uint32_t *scanned, int64_t seg_len, int nseg, int64_t seg_stride) {
+  if (nseg <= 0) return nullptr;
+  Buf out = dalloc((size_t)nseg * 4);
+  segment_totals_kernel<<<1, 256, 0, ctx().stream>>>(scanned, seg_stride, seg_len, nseg, ptr<uint32_t>(out));
+  return d2h_u32(out->p, (size_t)nseg);
+}
+
+__global__ void __launch_bounds__(256) any_nonzero_kernel(const uint32_t *v, int64_t n, uint32_t *flag) {
+  bool hit = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) hit |= v[i] != 0;
+  if (__ballot(hit) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+// is any of v[0 .. n) non-zero?  One word read back (valid after the next sync) instead of the array.
+const uint32_t *any_nonzero_to_host(const uint32_t *v, int64_t n) {
+  Buf flag = dalloc_zero(4);
+  if (n > 0) any_nonzero_kernel<<<(unsigned)std::min<int64_t>((n + 255) / 256, 1024), 256, 0, ctx().stream>>>(v, n, ptr<uint32_t>(flag));
+  return d2h_u32(flag->p, 1);
+}
+
 void exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, bool with_total) {
   KernelTimer t("scan_u32");
   scan_impl(in, out, n, 0, 1, with_total);

@@ -877,8 +877,7 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
   if (np == 0 && nrows) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR json: a schema without properties");
   if (ntext) {
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);  // offsets in place, the total at [nrows]
-    std::vector<const uint32_t *> tot((size_t)ntext);
-    for (int t = 0; t < ntext; t++) tot[(size_t)t] = d2h_u32(ptr<uint32_t>(lens_all) + (int64_t)t * seg_stride + nrows);
+    const uint32_t *tot = segment_totals_to_host(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);
     // OFF by default: measured on the MI355X (gpurun r07b, 2^18 hits messages) sr_cell_text is 0.60 ms one lane per cell and 0.65 ms this way —
     // a third of the text (Cyrillic titles, strings with escapes) is not VT_PLAIN and still takes the walkers, and the marking pass re-reads the value records
     static const bool words = [] { const char *e = std::getenv("TFGPU_SR_COPY_WORDS"); return e && e[0] == '1'; }();
@@ -888,7 +887,7 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     tf::sync();
     for (int t = 0; t < ntext; t++) {
       DColumn &d = db->cols[(size_t)text_cols[(size_t)t]];
-      d.data_len = *tot[(size_t)t];
+      d.data_len = tot[t];
       d.data = dalloc(d.data_len + 8);
       oc[(size_t)text_cols[(size_t)t]].data = ptr<uint8_t>(d.data);
     }

@@ -112,6 +112,7 @@ class Parser:
         self.lib = lib
         L = lib.load()
         lib.init()
+        self._schemas: Dict[tuple, abi.Schema] = {}
         self.cache: Dict[tuple, abi.Schema] = {}  # the distinct (table, fields) seen so far — a view for diagnostics; the cache itself is the receiver's
         self._h = C.c_void_p()
         L.tfgpu_dbz_receiver_create.argtypes = [C.POINTER(C.c_void_p)]
@@ -127,6 +128,19 @@ class Parser:
                 self._h = None
         except Exception:  # noqa: BLE001
             pass
+
+    def _group_schema(self, db, fp, nf):
+        """The TableSchema of one group.  The receiver keeps a compiled schema for its whole life and hands out the same field array for it in
+        every batch: the Python objects built from it (one per field) are kept by (that array's address, table) instead of rebuilt per batch."""
+        ns, table = db.table_id()
+        key = (C.addressof(fp.contents) if nf else 0, nf, ns, table)
+        hit = self._schemas.get(key)
+        if hit is None:
+            fields = _fields_of(fp, nf)
+            hit = table_schema(fields, ns, table)
+            self._schemas[key] = hit
+            self.cache.setdefault((ns, table, tuple(fields)), hit)
+        return hit
 
     def _meta(self, g, nmsg):
         ids, lsns, cts, nf = np.empty(nmsg, np.uint32), np.empty(nmsg, np.uint64), np.empty(nmsg, np.uint64), np.empty(nmsg, np.uint8)
@@ -151,7 +165,9 @@ class Parser:
         L = lib.load()
         ptr_, n, mem, keep = lib._bytes_arg(data)
         nmsg = int(msgs.nmsg) if msgs is not None else 1
-        codes = np.zeros(max(nmsg, 1), np.int32)
+        if getattr(self, "_msg_codes", None) is None or len(self._msg_codes) < max(nmsg, 1):   # kept across batches; the call writes every entry
+            self._msg_codes = np.zeros(max(nmsg, 1), np.int32)
+        codes = self._msg_codes
         ng = C.c_int32(0)
         hb = np.frombuffer(host_bytes, dtype=np.uint8) if host_bytes else None
         lib._check(L.tfgpu_dbz_receive(self._h, ptr_, n, mem, C.c_void_p(hb.ctypes.data) if hb is not None else None, C.byref(msgs) if msgs is not None else None,
@@ -162,10 +178,7 @@ class Parser:
             lib._check(L.tfgpu_dbz_receive_group(self._h, g, C.byref(bh), C.byref(rp), C.byref(nr), C.byref(fp), C.byref(nf)))
             db = lib.DeviceBatch(bh)
             rows = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(int(nr.value) * abi.DBZ_ROW_DTYPE.itemsize,)).view(abi.DBZ_ROW_DTYPE) if nr.value else np.zeros(0, abi.DBZ_ROW_DTYPE)  # (a view of the receiver's buffer: valid until the next parse())
-            ns, table = db.table_id()
-            fields = _fields_of(fp, int(nf.value))
-            sch = table_schema(fields, ns, table)
-            self.cache.setdefault((ns, table, tuple(fields)), sch)
+            sch = self._group_schema(db, fp, int(nf.value))
             out.append(Parsed(db, rows, sch, meta=(lambda g=g, nmsg=nmsg: self._meta(g, nmsg))))
         bad = np.nonzero(codes[:nmsg])[0]
         return out, dict(zip(bad.tolist(), codes[bad].tolist()))
@@ -208,9 +221,7 @@ class Parser:
             bh, rp, nr, fp, nf = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.POINTER(abi.CDbzField)(), C.c_int32(0)
             lib._check(L.tfgpu_dbz_receive_group(self._h, g, C.byref(bh), C.byref(rp), C.byref(nr), C.byref(fp), C.byref(nf)))
             db = lib.DeviceBatch(bh)
-            rows = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(int(nr.value) * abi.DBZ_ROW_DTYPE.itemsize,)).view(abi.DBZ_ROW_DTYPE).copy() if nr.value else np.zeros(0, abi.DBZ_ROW_DTYPE)
-            ns, table = db.table_id()
-            fields = _fields_of(fp, int(nf.value))
-            out.append(Parsed(db, rows, table_schema(fields, ns, table), meta=(lambda g=g, nevents=nevents: self._meta(g, nevents))))
+            rows = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint8)), shape=(int(nr.value) * abi.DBZ_ROW_DTYPE.itemsize,)).view(abi.DBZ_ROW_DTYPE) if nr.value else np.zeros(0, abi.DBZ_ROW_DTYPE)  # (a view of the receiver's buffer: valid until the next call)
+            out.append(Parsed(db, rows, self._group_schema(db, fp, int(nf.value)), meta=(lambda g=g, nevents=nevents: self._meta(g, nevents))))
         bad = np.nonzero(codes[:nevents])[0]
         return out, dict(zip(bad.tolist(), codes[bad].tolist())), ev[:nevents]   # events: a view (msg, start, len, schema_id, code, index), valid until the next call
