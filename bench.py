@@ -561,6 +561,29 @@ class CsvWorkload(Base):
             res["note"] = ("input in pinned host memory (hipHostMalloc), hipMemcpyAsync on each lane's stream inside the step: with several lanes the H2D of "
                            "one batch runs beside the kernels of another; PCIe Gen5 x16 bounds this at ~55-60 GB/s")
             out["pcie_inclusive"] = res
+        if a.pcie_steps > 0 and e.rank == 0 and e.world == 1 and not a.no_pull_push:
+            # configs[1]'s sink is devnull: nothing to push.  The pull AND the push overlapped is configs[2]'s job ("async double-buffer"), measured
+            # here too so that the default line carries it: that workload's three-stage pipeline (one puller, two transform lanes, one pusher)
+            try:
+                import copy
+                a2 = copy.copy(a)
+                a2.rows = 0
+                W2 = Configs2Workload(a2, e)
+                a2.rows = W2.default_rows
+                W2.setup()
+                W2.step(); W2.step(keep=True)
+                e.lib.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    W2.step()
+                e.lib.synchronize()
+                W2.dt, W2.total_passes = time.perf_counter() - t0, 5
+                pp = W2.side_measurements(only_pipeline=True).get("pull_push_concurrent", {})
+                out["configs2_pull_push"] = {"workload": "configs[2]: SR wire bytes -> replace_primary_key + sql -> JSONEachRow, %d rows a batch" % W2.n,
+                                             "hbm_resident_ms_per_step": round(W2.dt / 5 * 1e3, 3), "copies_alone_concurrent": pp.get("copies_alone_concurrent"),
+                                             "pipeline_3_stage": pp.get("pipeline_3_stage")}
+            except Exception as ex:  # noqa: BLE001
+                out["configs2_pull_push"] = {"error": str(ex)[:200]}
         return out
 
     def parity_against(self, ref, n1):
@@ -839,7 +862,7 @@ class Configs2Workload(_Prepared):
         s = self.state
         return {"rows_out_per_step": s["out_rows"], "text_out_bytes_per_step": s["out_bytes"]}
 
-    def side_measurements(self):
+    def side_measurements(self, only_pipeline=False):
         """Never `value`: configs[2] says "async double-buffer" and north_star "overlapping Kafka pull and ClickHouse push" — the
         pull AND the push inside the step, together.  Every step takes its Kafka bytes from PINNED host memory (hipMemcpyAsync H2D on
         the lane's stream: the pull), parses and transforms them, serializes JSONEachRow and copies the text back into pinned host
@@ -908,7 +931,7 @@ class Configs2Workload(_Prepared):
             res["copies_alone_concurrent"] = {"error": str(ex)[:200]}
         # lanes: 1 (the three legs follow each other), --pcie-lanes, and twice that — two batches in flight per pull / transform / push
         # stage, so that a lane waiting for its copy never leaves a direction of the link idle (the double buffer of configs[2])
-        for nl in sorted({1, max(1, min(a.pcie_lanes, lib.lane_count())), max(1, min(2 * a.pcie_lanes, lib.lane_count()))}):
+        for nl in ([] if only_pipeline else sorted({1, max(1, min(a.pcie_lanes, lib.lane_count())), max(1, min(2 * a.pcie_lanes, lib.lane_count()))})):
             ins, outs = [lib.HostBuffer(self.data) for _ in range(nl)], []
             for _ in range(nl):
                 hb = lib.HostBuffer.__new__(lib.HostBuffer)
@@ -975,6 +998,115 @@ class Configs2Workload(_Prepared):
                 h2d_dup, d2h_dup = len(self.data) / dup["gb_per_s_h2d"] / 1e6, self.state["out_bytes"] / dup["gb_per_s_d2h"] / 1e6
                 res[f"lanes_{nl}"]["legs_duplex_ms"] = {"h2d": round(h2d_dup, 3), "d2h": round(d2h_dup, 3)}
                 res[f"lanes_{nl}"]["overlap_efficiency_vs_duplex_ceiling"] = round(max(h2d_dup, d2h_dup, kernels_ms) / step_ms, 3)
+        # ---- the same work as a three-stage pipeline: ONE puller (H2D back to back on its own lane), transform lanes that take device-resident
+        #      batches, ONE pusher (D2H back to back on its own lane), bounded queues of two batches between the stages — the double buffer of
+        #      configs[2] spelled out: neither direction of the link ever waits for a lane to finish its other two legs ----
+        try:
+            import queue as _queue
+            ncomp = 2
+            kk = max(a.pcie_steps, 2) * 6
+            hins = [lib.HostBuffer(self.data) for _ in range(2)]
+            houts = []
+            for _ in range(2):
+                hb = lib.HostBuffer.__new__(lib.HostBuffer)
+                pp = ctypes_void()
+                lib._check(lib.load().tfgpu_host_alloc(cap, pp.ref))
+                hb.ptr, hb.size = pp.value, cap
+                houts.append(hb)
+            q_in, q_out = _queue.Queue(maxsize=2), _queue.Queue(maxsize=2)
+            errs = []
+            go = threading.Barrier(ncomp + 3)
+            tdone = {}
+
+            def puller():
+                try:
+                    lib.lane_use(ncomp + 1)
+                    go.wait()
+                    for i in range(kk):
+                        hd_ = ctypes.c_void_p()
+                        lib._check(lib.load().tfgpu_dbuf_upload(ctypes.c_void_p(hins[i % 2].ptr), hins[i % 2].size, ctypes.byref(hd_)))
+                        lib.synchronize()   # the batch is in HBM: another lane may read it
+                        q_in.put(lib.DeviceBuffer(hd_))
+                    for _ in range(ncomp):
+                        q_in.put(None)
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex); go.abort()
+                    for _ in range(ncomp):
+                        q_in.put(None)
+
+            def transformer(k):
+                try:
+                    lib.lane_use(k)
+                    plans = self.plans if k == 0 else [lib.Transformer(t, c) for t, c in self.CH]
+                    stage = self.stage if k == 0 else lib.Transformation(plans)
+                    warm = lib.DeviceBuffer.upload(self.data)
+                    r0 = lib.sr_json_parse(self.opts, warm, self.msgs); t0_ = stage.push_run(r0.device_batch); o0 = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, t0_.transformed)
+                    for _, eb in t0_.error_batches:
+                        eb.free()
+                    o0.free(); t0_.transformed.free(); r0.device_batch.free(); warm.free()
+                    lib.synchronize()
+                    go.wait()
+                    while True:
+                        din = q_in.get()
+                        if din is None:
+                            break
+                        res_ = lib.sr_json_parse(self.opts, din, self.msgs)     # device-resident bytes: no copy inside the call
+                        tr = stage.push_run(res_.device_batch)
+                        out = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
+                        for _, eb in tr.error_batches:
+                            eb.free()
+                        tr.transformed.free(); res_.device_batch.free(); din.free()
+                        lib.synchronize()
+                        q_out.put(out)
+                    q_out.put(None)
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex); go.abort(); q_out.put(None)
+
+            def pusher():
+                try:
+                    lib.lane_use(ncomp + 2)
+                    go.wait()
+                    ends, i = 0, 0
+                    while ends < ncomp:
+                        out = q_out.get()
+                        if out is None:
+                            ends += 1
+                            continue
+                        lib._check(lib.load().tfgpu_dbuf_download(out._h, houts[i % 2].ptr, out.size))   # returns when the text is in pinned memory
+                        out.free(); i += 1
+                    tdone["n"] = i
+                    tdone["t"] = time.perf_counter()
+                except Exception as ex:  # noqa: BLE001
+                    errs.append(ex); go.abort()
+            ths = [threading.Thread(target=puller), threading.Thread(target=pusher)] + [threading.Thread(target=transformer, args=(k,)) for k in range(ncomp)]
+            for t in ths:
+                t.start()
+            try:
+                go.wait()
+                t0 = time.perf_counter()
+            except threading.BrokenBarrierError:
+                t0 = float("nan")
+            for t in ths:
+                t.join()
+            lib.lane_use(0)
+            for hb in hins + houts:
+                hb.free()
+            if errs or tdone.get("n") != kk:
+                res["pipeline_3_stage"] = {"error": str(errs[0])[:200] if errs else "batches lost"}
+            else:
+                dt = tdone["t"] - t0
+                step_ms = dt / kk * 1e3
+                ent = {"rows_per_s": round(self.n * kk / dt, 1), "ms_per_step": round(step_ms, 3), "transform_lanes": ncomp, "batches": kk,
+                       "gb_per_s_h2d": round(len(self.data) * kk / dt / 1e9, 2), "gb_per_s_d2h": round(self.state["out_bytes"] * kk / dt / 1e9, 2),
+                       "overlap_efficiency": round(max(h2d_ms, kernels_ms, self.state["out_bytes"] / 52e9 * 1e3) / step_ms, 3),
+                       "note": "one puller, %d transform lanes, one pusher, queues of two batches between them; the first batch's pull and the last batch's push are inside the time" % ncomp}
+                dup = res.get("copies_alone_concurrent") or {}
+                if dup.get("gb_per_s_h2d") and dup.get("gb_per_s_d2h"):
+                    h2d_dup, d2h_dup = len(self.data) / dup["gb_per_s_h2d"] / 1e6, self.state["out_bytes"] / dup["gb_per_s_d2h"] / 1e6
+                    ent["overlap_efficiency_vs_duplex_ceiling"] = round(max(h2d_dup, d2h_dup, kernels_ms) / step_ms, 3)
+                res["pipeline_3_stage"] = ent
+        except Exception as ex:  # noqa: BLE001
+            res["pipeline_3_stage"] = {"error": str(ex)[:200]}
         hin.free()
         res["note"] = ("every step pulls its %.2f GB of Kafka bytes from pinned host memory (H2D), runs parse + replace_primary_key + sql + JSONEachRow, and pushes the "
                        "%.2f GB of text back into pinned host memory (D2H); with several lanes the three legs of different batches overlap: H2D of batch N+1, "
@@ -2001,6 +2133,7 @@ def main():
     ap.add_argument("--step-ms", type=float, default=50.0)
     ap.add_argument("--lanes", type=int, default=1, help="device lanes (host threads) the steps are spread over (1 = strictly serial, the bench line)")
     ap.add_argument("--overlap-lanes", type=int, default=3, help="side measurement (never `value`): the same steps spread over this many lanes (0 = skip)")
+    ap.add_argument("--no-pull-push", action="store_true", help="csv workload: skip the configs[2] pull || push side measurement")
     ap.add_argument("--pcie-steps", type=int, default=2, help="side measurement (never `value`): passes per lane that start from PINNED HOST memory (0 = skip)")
     ap.add_argument("--pcie-lanes", type=int, default=3)
     ap.add_argument("--devices", default="", help="ONE process driving several devices (csv workload): comma-separated HIP device ids, lane k on the k-th "
