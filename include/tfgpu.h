@@ -338,10 +338,18 @@ void tfgpu_bufferer_destroy(tfgpu_bufferer *b);
  * files (tests/canon/s3/parquet/canondata → tests/golden/parquet_reader.json) are reproduced on inputs re-created from the canon's
  * values (tests/test_parquet_canon.py); its 10 files with nested columns are refused by name.  The file-format decoder itself
  * (parquet-go, not under /root/reference) is pinned to pyarrow's reading of the same files (tests/test_parquet.py).
- * tfgpu_parquet_read = tfgpu_parquet_read_object without a file name (system column names are then looked up in the file).    */
+ * tfgpu_parquet_read = tfgpu_parquet_read_object without a file name (system column names are then looked up in the file).
+ * tfgpu_parquet_read_staged = tfgpu_parquet_read_object for an object somebody else's copy engine has already brought into HBM (the
+ * puller of a pull / decode pipeline: the reader's upload is then not in front of its kernels): `bytes` stays the host copy the
+ * footer and the page headers are walked in, `staged` (tfgpu_dbuf_alloc + tfgpu_dbuf_write, or tfgpu_dbuf_upload of a padded copy)
+ * holds the same `len` bytes at offset 0 and is at least tfgpu_parquet_staging_size(bytes, len) long — the reader writes what it
+ * decodes beside the object (expanded dictionary indices, DELTA_BINARY_PACKED values, INT96 texts) behind it.  The buffer stays the
+ * caller's and may be freed when the call returns.  A compressed object's pages are inflated on the host: `staged` is not used. */
 int tfgpu_parquet_resolve_schema(const void *bytes, uint64_t len, int hide_system_cols, tfgpu_schema **out);
 int tfgpu_parquet_read_object(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, tfgpu_dbatch **out);
 int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out);
+int tfgpu_parquet_staging_size(const void *bytes, uint64_t len, uint64_t *need);
+int tfgpu_parquet_read_staged(const void *bytes, uint64_t len, const tfgpu_dbuf *staged, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, tfgpu_dbatch **out);
 
 /* Device columns → a Parquet object (tf_parquetw.hip; pkg/serializer/parquet.go:53-200 parquetBatchSerializer.Serialize + Close,
  * parquet_format.go:13-135 BuildParquetSchema / toParquetValue).  `schema` = the TableSchema: its columns become the fields of the

@@ -257,6 +257,76 @@ def test_delta_encodings_and_lz4_raw(tf, n):
                         assert c.values[i] == w, (c.name, i, comp, kw)
 
 
+def test_staged_object_reads_like_an_uploaded_one(tf):
+    """tfgpu_parquet_read_staged: the object already in HBM (a pull / decode pipeline's puller brought it), room for the decoded tail behind it —
+    the same batch as tfgpu_parquet_read_object uploads and decodes, for plain, dictionary, DELTA and INT96 columns; a buffer that is too
+    short is refused; a compressed object ignores the staging buffer."""
+    import datetime
+    n = 3000
+    t = table(n, 41)
+    t = t.append_column("ts96", pa.array([None if i % 11 == 0 else datetime.datetime(2001 + i % 20, 1 + i % 12, 1 + i % 28, i % 24) for i in range(n)], pa.timestamp("ns")))
+    for comp, kw in (("NONE", dict(use_dictionary=True, use_deprecated_int96_timestamps=True)),
+                     ("NONE", dict(use_dictionary=False, column_encoding={"i32": "DELTA_BINARY_PACKED", "i64": "DELTA_BINARY_PACKED", "url": "DELTA_LENGTH_BYTE_ARRAY"}, data_page_size=2000, row_group_size=1100, use_deprecated_int96_timestamps=True)),
+                     ("SNAPPY", dict(use_deprecated_int96_timestamps=True))):
+        buf = io.BytesIO()
+        pq.write_table(t, buf, compression=comp, **kw)
+        data = buf.getvalue()
+        want = tf.parquet_read(data).download()
+        need = tf.parquet_staging_size(data)
+        assert need >= len(data) + 64
+        staged = tf.DeviceBuffer.alloc(need)
+        staged.write(0, np.frombuffer(data, np.uint8), len(data))
+        got = tf.parquet_read_staged(data, staged).download()
+        staged.free()
+        assert got.nrows == want.nrows == n and [c.name for c in got.cols] == [c.name for c in want.cols]
+        for a, b in zip(got.cols, want.cols):
+            assert a.repr == b.repr and a.dtype == b.dtype, a.name
+            va = a.validity if a.validity is not None else np.ones(n, bool)
+            vb = b.validity if b.validity is not None else np.ones(n, bool)
+            assert np.array_equal(va, vb), a.name
+            if a.repr in abi.VAR_REPRS:
+                assert np.array_equal(a.offsets, b.offsets) and bytes(a.data[: int(a.offsets[-1])]) == bytes(b.data[: int(b.offsets[-1])]), (a.name, comp)
+            else:
+                assert np.array_equal(a.values[va], b.values[vb]), (a.name, comp)
+        if comp == "NONE":
+            short = tf.DeviceBuffer.alloc(len(data) + 16)
+            short.write(0, np.frombuffer(data, np.uint8), len(data))
+            with pytest.raises(tf.TfgpuError) as ei:
+                tf.parquet_read_staged(data, short)
+            assert ei.value.code == tf.ERR_INVALID
+            short.free()
+
+
+def test_wave_walk_equals_one_lane_walk():
+    """TFGPU_PQ_WALK_SPEC=1 (read once per process): pq_walk_text's windows by all 64 lanes of a wave — guessed slice entries settled against
+    the neighbours' exits; built, measured no faster than the one-lane walk on the MI355X and off by default — must read the same values."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("TFGPU_PQ_WALK_SPEC"):
+        pytest.skip("already inside the wave-walk run")
+    env = dict(os.environ, TFGPU_PQ_WALK_SPEC="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "plain_text_walk or plain_pages_small or delta_encodings or damaged_objects or corrupt_objects"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+
+
+def test_upload_in_pieces_equals_one_copy():
+    """An object of 32 MiB and more goes up in pieces on the lane's copy stream, the page kernels of a piece queued behind its event
+    (UploadPieces in tf_parquet.hip).  TFGPU_PQ_PIECES=3 (read once per process) cuts the small objects of these tests the same way."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("TFGPU_PQ_PIECES"):
+        pytest.skip("already inside the pieces run")
+    env = dict(os.environ, TFGPU_PQ_PIECES="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "delta_encodings or staged_object or int96_fixed or plain_text_walk or dictionary_pages or plain_pages_small or damaged_objects"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+
+
 def test_int96_fixed_len_and_restore_conversions(tf):
     """INT96 → the decimal text of its 96 bits (also before 1970 and dictionary-coded); FIXED_LEN_BYTE_ARRAY → string; what Restore makes of a
     value under the resolver's DataType: INT(8/16/32, signed) → int64, unsigned → uint64, float under `double`, TIMESTAMP → microseconds."""

@@ -10,7 +10,7 @@
 #   ablate   TAG ENVVAR KERNEL WORKLOAD "n1 n2 …"  KERNEL's time with ENVVAR=n (TFGPU_CSV_ABLATE / TFGPU_JT_ABLATE / TFGPU_SER_ABLATE)
 #   pmc      TAG KERNEL WORKLOAD NSETS ["C1 C2 …"]  rocprofv3 --pmc passes for one kernel (sets of tools/gpu_pmc2.sh, or one custom set)
 #   stats    TAG "w1 w2 …"                        rocprofv3 --kernel-trace --stats per workload (the timed region only, no side legs)
-#   timeline TAG WORKLOAD ANCHOR                 one pass of WORKLOAD as a timeline of dispatches (tools/timeline.py): offsets, durations, idle gaps
+#   timeline TAG WORKLOAD ANCHOR ["bench args" [pass]]  one pass of WORKLOAD as a timeline of dispatches (tools/timeline.py): offsets, durations, idle gaps
 #   evidence TAG                                  tests + smoke + HBM-traffic PMC (pmc_traffic.json) + every bench line + stats
 cd "$GRAFT_REPO_ROOT" || exit 1
 MODE=${1:-tests}; TAG=${2:-visit}; OUT=gpurun_out/$TAG; mkdir -p "$OUT"; shift 2
@@ -70,9 +70,9 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; print('
   pmc) bash tools/gpu_pmc2.sh "$1" "$TAG/pmc_$1" "${2:-csv}" "${3:-2}" "$4"; cp "$OUT/pmc_$1/summary.txt" "$OUT/pmc_$1.txt" ;;
   stats) stats "${1:-csv}" ;;
   timeline)
-    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -f csv -d "$GRAFT_REPO_ROOT/$OUT/tl_$1" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --workload $1 --steps 4 --passes 1 --warmup 2 --prof-steps 1 $QUIET > "$GRAFT_REPO_ROOT/$OUT/tl_$1.json" 2> "$GRAFT_REPO_ROOT/$OUT/tl_$1.err" )
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -f csv -d "$GRAFT_REPO_ROOT/$OUT/tl_$1" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --workload $1 --steps 4 --passes 1 --warmup 2 --prof-steps 1 ${3:-$QUIET} > "$GRAFT_REPO_ROOT/$OUT/tl_$1.json" 2> "$GRAFT_REPO_ROOT/$OUT/tl_$1.err" )
     f=$(find "$OUT/tl_$1" -name '*kernel_trace.csv' | head -1)
-    [ -n "$f" ] && python tools/timeline.py "$f" "$2" 3 | tee "$OUT/timeline_$1.txt"
+    [ -n "$f" ] && python tools/timeline.py "$f" "$2" ${4:-3} | tee "$OUT/timeline_$1.txt"
     rm -rf "$OUT/tl_$1" ;;
   evidence)
     date +%s > "$OUT/t0"

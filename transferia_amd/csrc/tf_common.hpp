@@ -83,6 +83,7 @@ struct BlockCache {
 struct Context {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // created on first use: a large upload in pieces beside the kernels that read the pieces already there (tf_parquet.hip)
   BlockCache blocks;
   // pinned ring for small host<->device tables and read-backs
   void *pin_base = nullptr;

@@ -46,6 +46,7 @@ struct PqClock {
   const bool on = std::getenv("TFGPU_PQ_TIMES") != nullptr;
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void at(const char *what) const { if (on) { std::fprintf(stderr, "pq %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); std::fflush(stderr); } }
+  ~PqClock() { at("left (locals destroyed)"); }
 };
 
 namespace tf {
@@ -730,32 +731,176 @@ __global__ void __launch_bounds__(256) pq_int96_text(const uint8_t *file, uint8_
 // round 5: 4.6 ms against the old walk's 3.5 on the hits object; with one workgroup per page the rounds are LDS-latency-bound too.)
 struct TextPage { uint64_t at, end; uint32_t ord, count; };  // [at, end): the page's values
 constexpr uint32_t PQ_STAGE = 16384, PQ_OUT = PQ_STAGE / 4;
-__global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_t limit, const TextPage *pages, uint32_t *val_off, uint32_t *val_len, uint32_t *err) {
-  __shared__ uint32_t stage[PQ_STAGE / 4 + 4];
+constexpr uint32_t PQ_SLICE = PQ_STAGE / 64;
+__global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_t limit, const TextPage *pages, uint32_t *val_off, uint32_t *val_len, uint32_t *err, int spec_on, uint32_t *dbg) {
+  // (one word of padding per 64: lane i of the wave walk reads words 64 i + j — without it all 64 lanes would meet in one LDS bank)
+  __shared__ uint32_t stage_[PQ_STAGE / 4 + 4 + PQ_STAGE / 256 + 1];
+  auto S = [&](uint32_t w) -> uint32_t & { return stage_[w + (w >> 6)]; };
   __shared__ uint32_t o_off[PQ_OUT], o_len[PQ_OUT];
   __shared__ uint64_t s_at;
-  __shared__ uint32_t s_done, s_cnt, s_bad;
+  __shared__ uint32_t s_done, s_cnt, s_bad, s_spec;
   const TextPage pg = pages[blockIdx.x];
   const int tid = threadIdx.x;
   if (tid == 0) { s_at = pg.at; s_done = 0; s_bad = 0; }
   __syncthreads();
   for (;;) {
-    const uint64_t at = s_at;
+    // the window is staged from the 16-byte line its first value starts in: `at` is that line, `sh` where the value starts in it — every offset
+    // below counts from `at`.  Four (one thread: five) aligned 16-byte loads a thread, all in flight together; a word at a time through
+    // unaligned 8-byte pairs they were most of this kernel's time
+    const uint64_t at0 = s_at, at = at0 & ~15ull;
+    const uint32_t sh = (uint32_t)(at0 - at);
     const uint32_t done = s_done;
     if (done >= pg.count || s_bad) break;  // (uniform: written before the round's last barrier)
-    for (uint32_t i = (uint32_t)tid; i < PQ_STAGE / 4 + 4; i += 256) {
-      const uint64_t a = at + 4ull * i;
-      stage[i] = a + 8 <= limit ? (uint32_t)load_unaligned(file, a, 4) : 0u;  // (a read past the page is harmless, one past the image is not)
+    {
+      uint4 v[5];
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const uint32_t c = (uint32_t)tid + 256u * (uint32_t)j;
+        const uint64_t a = at + 16ull * c;
+        v[j] = (c <= PQ_STAGE / 16 && a + 16 <= limit) ? *reinterpret_cast<const uint4 *>(file + a) : make_uint4(0, 0, 0, 0);  // (a read past the page is harmless, one past the image is not)
+      }
+#pragma unroll
+      for (int j = 0; j < 5; j++) {
+        const uint32_t c = (uint32_t)tid + 256u * (uint32_t)j;
+        if (c <= PQ_STAGE / 16) { S(4 * c) = v[j].x; S(4 * c + 1) = v[j].y; S(4 * c + 2) = v[j].z; S(4 * c + 3) = v[j].w; }
+      }
     }
     __syncthreads();
-    if (tid == 0) {
-      uint64_t o = 0;  // byte offset of the next prefix in the window
+    // ---- the window by all 64 lanes of wave 0 (round 5): lane i owns the values that START in bytes [256 i, 256 i + 256) of the window.  Where its
+    //      first value starts is what the lane in front hands over — a chain — so every lane first GUESSES (the first offset of its slice from
+    //      which three prefixes in a row stay inside the page), walks its slice, and the guesses are then checked against the neighbours' exits
+    //      and re-walked where they differ, a few rounds; the counts are scanned and the pairs written.  A window that does not settle, holds a
+    //      prefix that points past its page, or more values than the page has left takes the one-lane walk below, which carries those rules. ----
+    bool spec_ok = false;
+    if (spec_on == 2) {  // TFGPU_PQ_WALK_SPEC=2, profiling only (the values are NOT valid): no walk at all — what staging, barriers and the flush cost
+      if (tid == 0) { const uint32_t want = pg.count - done; s_cnt = want < 800u ? want : 800u; s_at = at0 + PQ_STAGE - 16; s_spec = 1; }
+    } else
+    if (tid < 64 && spec_on) {
+      const uint32_t want = pg.count - done;
+      const uint32_t s0 = (uint32_t)tid * PQ_SLICE, s1 = s0 + PQ_SLICE;
+      auto rd = [&](uint32_t o) { return __builtin_amdgcn_alignbyte(S((o >> 2) + 1), S(o >> 2), o & 3u); };
+      auto fits = [&](uint32_t o, uint32_t n) { const uint64_t abs = at + o; return abs + 4 <= pg.end && (uint64_t)n <= pg.end - (abs + 4); };
+      // walk the values that start in [e, s1): where the chain leaves the slice, how many, whether a prefix pointed past the page
+      auto walk = [&](uint32_t e, uint32_t &cnt, bool &bad, bool write, uint32_t base) {
+        uint32_t o = e; cnt = 0; bad = false;
+        while (o < s1 && o + 4 <= PQ_STAGE && at + o < pg.end) {   // (the page's last value ends at pg.end: a clean stop, not a prefix)
+          // four empty values at once where sixteen zero bytes lie ahead inside the slice and the page (their reads do not depend on each other)
+          if (o + 16 <= s1 && at + o + 16 <= pg.end) {
+            if ((rd(o) | rd(o + 4) | rd(o + 8) | rd(o + 12)) == 0u) {
+              if (write) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) { o_off[base + cnt + k] = (uint32_t)(at + o + 4 * k + 4); o_len[base + cnt + k] = 0; }
+              }
+              cnt += 4; o += 16;
+              continue;
+            }
+          }
+          const uint32_t n = rd(o);
+          if (!fits(o, n)) { bad = true; break; }
+          if (write) { o_off[base + cnt] = (uint32_t)(at + o + 4); o_len[base + cnt] = n; }
+          cnt++;
+          o += 4u + n;   // (n <= the page's bytes < 2^32 - 2^24: no wrap worth guarding beyond `fits`)
+        }
+        return o;
+      };
+      // the last non-zero byte in front of the slice (all slices before it): where a run of empty values (zero bytes) that reaches into the slice began
+      int lnz = -1;
+      for (uint32_t w = s0 / 4; w < s1 / 4; w++) { const uint32_t v = S(w); if (v) lnz = (int)(4 * w + (3u - (uint32_t)__builtin_clz(v) / 8u)); }
+      if (tid == 0 && lnz < (int)sh) lnz = (int)sh - 1;   // (the window's first value starts at sh: what lies in front of it is not this window's)
+      int left = lnz;
+      for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(left, d, 64); if (tid >= d) left = max(left, t); }
+      left = __shfl_up(left, 1, 64);
+      if (tid == 0) left = -1;
+      uint32_t entry = tid == 0 ? sh : s1;   // s1: nothing starts in the slice as far as the lane can tell — the lanes in front will say
+      bool pass = false;                     // … and the lane hands its neighbour's exit on
+      const bool dead = tid != 0 && at + s0 >= pg.end;   // the slice lies behind the page's last value: whatever arrives passes through
+      if (dead) pass = true;
+      if (tid != 0 && !dead) {
+        if ((S(s0 / 4) | S(s0 / 4 + 1)) == 0u) {   // inside a run of zeros: empty values, aligned with the byte behind the last non-zero one
+          const uint32_t first = (uint32_t)(left + 1);
+          entry = s0 + ((first + 4u - (s0 & 3u)) & 3u);
+        } else {
+          // a prefix of a value shorter than 16 MiB ends in a zero byte, text holds none, and what follows a prefix is text: the candidates are the
+          // offsets three bytes in front of the LAST zero of a run of zeros.  The first four are collected first (64 lanes, 65 words, no
+          // branches that depend on the data), then proven in lockstep — a proof is a chain of dependent reads, and 64 lanes proving candidates
+          // at 64 different moments would run them one after another
+          uint32_t cq[4] = {s1, s1, s1, s1};
+          uint32_t nc = 0;
+          for (uint32_t k = s0 / 4; k <= (s1 + 2) / 4; k++) {
+            const uint32_t v = S(k), nx = (v >> 8) | (S(k + 1) << 24);   // nx: the byte behind each byte of v
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) {
+              const bool hit = ((v >> (8 * b)) & 0xFFu) == 0u && ((nx >> (8 * b)) & 0xFFu) != 0u;
+              const uint32_t z = 4 * k + b;
+              if (hit && z >= s0 + 3 && z - 3 < s1 && nc < 4) { cq[nc < 3 ? nc : 3] = z - 3; nc++; }
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const uint32_t q = cq[t];
+            // three non-empty values in a row (at most twelve links) that stay inside the page, all of them READ: a link that leaves the window
+            // proves nothing (two bytes in front of a true prefix read as a length of 65536 and more), the page's end reached is proof enough
+            uint32_t x = q, hops = 0, real = 0; bool ok = entry == s1 && q < s1;
+            while (ok && real < 3 && hops < 12) {
+              if (at + x == pg.end) break;
+              if (x + 4 > PQ_STAGE) { ok = false; break; }
+              const uint32_t n = rd(x);
+              if (!fits(x, n)) { ok = false; break; }
+              hops++; real += n ? 1u : 0u;
+              x += 4u + n;
+            }
+            if (ok) entry = q;
+          }
+          pass = entry == s1;
+        }
+      }
+      uint32_t cnt = 0; bool bad = false;
+      uint32_t ex = walk(entry, cnt, bad, false, 0u);
+      // settle: the exit of the nearest lane in front that holds values must be this lane's entry.  Only the FIRST lane that disagrees takes its
+      // neighbour's word and walks again (the lanes in front of it all agree: their word is final) — a wrong guess costs one round, and cannot
+      // push a wrong exit through lanes that had guessed right
+      int rounds = 0;
+      for (;; rounds++) {
+        int src = pass ? -1 : tid;   // the nearest lane in front that holds values (lane 0 always does)
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(src, d, 64); if (tid >= d) src = max(src, t); }
+        src = __shfl_up(src, 1, 64);
+        const uint32_t front = (uint32_t)__shfl((int)ex, tid ? src : 0, 64);   // (lane 0 never looks at it)
+        bool need = false;
+        if (tid != 0) {
+          if (pass) { if (front >= s1 || dead) { entry = front; ex = front; cnt = 0; } else need = true; }
+          else need = front != entry;
+        }
+        const uint64_t m = __ballot(need);
+        if (!m) { spec_ok = true; break; }
+        if (rounds >= 10 || (rounds == 0 && __popcll(m) > 12)) break;
+        if (tid == __ffsll((long long)m) - 1) { pass = false; entry = front; ex = walk(entry, cnt, bad, false, 0u); }
+      }
+      uint32_t incl = cnt;
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64); if (tid >= d) incl += t; }
+      const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+      const uint32_t last_exit = (uint32_t)__shfl((int)ex, 63, 64);
+      spec_ok = spec_ok && !__ballot(bad) && total <= want && total <= PQ_OUT && total > 0;
+      if (spec_ok) {
+        walk(entry, cnt, bad, true, incl - cnt);
+        if (tid == 0) { s_cnt = total; s_at = at + last_exit; }
+      }
+      if (tid == 0) s_spec = spec_ok ? 1u : 0u;
+      if (dbg && tid == 0) {  // TFGPU_PQ_DEBUG=1: how the windows went
+        atomicAdd(dbg, 1u); atomicAdd(dbg + 5, (uint32_t)rounds);
+        if (spec_ok) atomicAdd(dbg + 1, 1u); else if (rounds >= 10 || rounds == 0) atomicAdd(dbg + 2, 1u); else if (__ballot(bad)) atomicAdd(dbg + 3, 1u); else atomicAdd(dbg + 4, 1u);
+      }
+    }
+    if (tid == 0 && !spec_on) s_spec = 0;
+    if (spec_on == 2) for (uint32_t i = (uint32_t)tid; i < 800u; i += 256) { o_off[i] = (uint32_t)at; o_len[i] = 0; }
+    __syncthreads();
+    if (tid == 0 && !s_spec) {
+      uint64_t o = sh;  // byte offset of the next prefix in the window
       uint32_t cnt = 0;
       const uint32_t want = pg.count - done;
       while (cnt < want && o + 4 <= PQ_STAGE) {
         const uint32_t oo = (uint32_t)o;
         const uint64_t abs = at + o;
-        const uint32_t n = __builtin_amdgcn_alignbyte(stage[(oo >> 2) + 1], stage[oo >> 2], oo & 3u);
+        const uint32_t n = __builtin_amdgcn_alignbyte(S((oo >> 2) + 1), S(oo >> 2), oo & 3u);
         if (abs + 4 > pg.end || (uint64_t)n > pg.end - (abs + 4)) { s_bad = 1; break; }  // a prefix that points past its page: this value and the rest of the page read as empty, the call fails
         o_off[cnt] = (uint32_t)(abs + 4); o_len[cnt] = n;
         cnt++;
@@ -771,17 +916,24 @@ __global__ void __launch_bounds__(256) pq_walk_text(const uint8_t *file, uint64_
     if (tid == 0) s_done = done + cnt;
     __syncthreads();
   }
+  if (dbg && tid == 0) { atomicMax(dbg + 6, (uint32_t)((pg.end - pg.at + PQ_STAGE - 1) / PQ_STAGE)); atomicAdd(dbg + 7, 1u); }
   if (s_bad) {
     for (uint32_t o = s_done + (uint32_t)tid; o < pg.count; o += 256) { val_off[pg.ord + o] = (uint32_t)pg.at; val_len[pg.ord + o] = 0; }
     if (tid == 0) *err = PQE_TEXT_LENGTH;
   }
 }
+// … every text column in one launch (grid.y = column), and the words the host wants from many buffers in one read-back
+struct PackDesc { const uint32_t *dst_off; uint8_t *dst; const uint32_t *src_off; };
 template <int RPT>
-__global__ void __launch_bounds__(256) pq_pack_text(const uint32_t *dst_off, int64_t nrows, const uint8_t *file, uint8_t *dst, const uint32_t *src_off) {
+__global__ void __launch_bounds__(256) pq_pack_text_all(const PackDesc *descs, int64_t nrows, const uint8_t *file) {
   __shared__ uint32_t doff[256 * RPT + 1], soff[256 * RPT];
+  const PackDesc d = descs[blockIdx.y];
   const int64_t k0 = (int64_t)blockIdx.x * (256 * RPT);
   if (k0 >= nrows) return;
-  segcopy_run<RPT>(dst_off, nrows, k0, file, dst, [&](int64_t r) { return src_off[r]; }, doff, soff);
+  segcopy_run<RPT>(d.dst_off, nrows, k0, file, d.dst, [&](int64_t r) { return d.src_off[r]; }, doff, soff);
+}
+__global__ void pq_gather_words(const uint32_t *const *at, int n, uint32_t *out) {
+  for (int k = threadIdx.x; k < n; k += blockDim.x) out[k] = *at[k];
 }
 
 // ---- pass 2, one launch per step over ALL columns of a kind (grid.y = column): a hundred columns launched one by one cost a
@@ -843,27 +995,42 @@ __global__ void __launch_bounds__(256) pq_values_all(const uint8_t *file, uint64
   if (rl >= nrows) return;
   pq_fixed_row(file, tail_base, d.segs, d.nsegs, d.rank, r, d.dict_at, d.dict_n, d.o, err, s);
 }
+// four rows a thread (a workgroup = 1024 consecutive rows of one column: one block search of the segment table per 1024 rows); the
+// column's bytes in 64 bits are summed from the lengths by sum_u32_segments_u64 afterwards (an atomic per wave on one word per column was
+// most of this kernel's time)
+constexpr int PQ_TEXT_RPT = 4;
 __global__ void __launch_bounds__(256) pq_text_cells_all(const uint8_t *file, uint64_t tail_base, const TextDesc *descs, int64_t nrows, uint32_t *err) {
   __shared__ int hint;
   const TextDesc &d = descs[blockIdx.y];
-  const int64_t r0 = (int64_t)blockIdx.x * blockDim.x, r = r0 + threadIdx.x;
-  const bool live = r < nrows;  // (no early return: the block search's barrier and the wave reduction below need every lane)
-  const uint32_t k = live ? (d.rank ? d.rank[r] : (uint32_t)r) : 0xFFFFFFFFu;
-  const Seg &s = find_seg_block(d.segs, d.nsegs, live ? k : 0u, d.rank ? d.rank[r0] : (uint32_t)r0, &hint);
-  uint32_t so = SEG_NONE, n = 0;
-  if (live && (!d.rank || d.rank[r + 1] != k)) {
-    if (s.kind == SG_PLAIN_TEXT) { so = d.val_off[k]; n = d.val_len[k]; }
-    else if (s.kind == SG_FIXED_TEXT) { so = (uint32_t)(s.at + (uint64_t)(k - s.start) * s.bw); n = s.bw; }
-    else {
-      const uint32_t i = seg_value(file, s, k, tail_base);
-      if (i >= d.dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // dict_n[first entry of a chunk's dictionary] = its entries
-      else { so = d.dict_off[s.dict_base + i]; n = d.dict_len[s.dict_base + i]; }
-    }
+  const int64_t r0 = (int64_t)blockIdx.x * (256 * PQ_TEXT_RPT);
+  if (r0 >= nrows) return;  // (uniform)
+  if (threadIdx.x == 0) {
+    const uint32_t first_ord = d.rank ? d.rank[r0] : (uint32_t)r0;
+    int lo = 0, hi = d.nsegs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.segs[mid].start <= first_ord) lo = mid; else hi = mid - 1; }
+    hint = lo;
   }
-  if (live) { d.src_off[r] = n ? so : SEG_NONE; d.lens[r] = n; }
-  unsigned long long s64 = n;  // the column's bytes in 64 bits (the offsets are 32-bit: 4 GiB and more is refused): one add per wave
-  for (int sh = 32; sh; sh >>= 1) s64 += __shfl_down(s64, sh, 64);
-  if ((threadIdx.x & 63) == 0 && s64) atomicAdd(d.total, s64);
+  __syncthreads();
+  int si = hint;
+#pragma unroll
+  for (int j = 0; j < PQ_TEXT_RPT; j++) {
+    const int64_t r = r0 + (int64_t)j * 256 + threadIdx.x;
+    if (r >= nrows) break;
+    const uint32_t k = d.rank ? d.rank[r] : (uint32_t)r;
+    while (si + 1 < d.nsegs && d.segs[si + 1].start <= k) si++;   // ordinals grow with the rows: forward only
+    const Seg &s = d.segs[si];
+    uint32_t so = SEG_NONE, n = 0;
+    if (!d.rank || d.rank[r + 1] != k) {
+      if (s.kind == SG_PLAIN_TEXT) { so = d.val_off[k]; n = d.val_len[k]; }
+      else if (s.kind == SG_FIXED_TEXT) { so = (uint32_t)(s.at + (uint64_t)(k - s.start) * s.bw); n = s.bw; }
+      else {
+        const uint32_t i = seg_value(file, s, k, tail_base);
+        if (i >= d.dict_n[s.dict_base]) *err = PQE_DICT_INDEX;  // dict_n[first entry of a chunk's dictionary] = its entries
+        else { so = d.dict_off[s.dict_base + i]; n = d.dict_len[s.dict_base + i]; }
+      }
+    }
+    d.src_off[r] = n ? so : SEG_NONE; d.lens[r] = n;
+  }
 }
 __global__ void __launch_bounds__(256) pq_row_index(uint64_t *v, int64_t nrows) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -891,7 +1058,74 @@ using namespace tf::pq;
 
 struct NeedArena {};  // thrown by the walk when a page must be rewritten on the host (DELTA_BYTE_ARRAY) and the object was to be uploaded as it is
 
-static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, bool force_arena, tfgpu_dbatch **out) {
+// An uncompressed object goes up in pieces on the lane's copy stream, an event behind each: the page kernels of a piece are queued behind
+// ITS event, so the walks of the pages already in HBM run beside the upload of the rest instead of after all of it.
+struct UploadPieces {
+  std::vector<uint64_t> end;      // piece i = [end[i - 1], end[i]) of the object
+  std::vector<hipEvent_t> ev;
+  hipStream_t main = nullptr;
+  ~UploadPieces() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); if (first_) (void)hipEventDestroy(first_); }
+  int piece_of(uint64_t last_byte_end) const { int i = 0; while (i + 1 < (int)end.size() && end[(size_t)i] < last_byte_end) i++; return i; }
+  void wait(int i) const { if (i >= 0 && i < (int)ev.size()) TF_HIP(hipStreamWaitEvent(main, ev[(size_t)i], 0)); }
+  void start(void *dst, const uint8_t *src, uint64_t len) {
+    Context &cx = ctx();
+    main = cx.stream;
+    if (!cx.copy_stream) TF_HIP(hipStreamCreateWithFlags(&cx.copy_stream, hipStreamNonBlocking));
+    static const int forced = [] { const char *e = std::getenv("TFGPU_PQ_PIECES"); return e ? std::atoi(e) : 0; }();  // A/B runs (1 = one copy, as before)
+    // ONE piece unless asked: measured on the MI355X (gpurun r11n, the 556 MB hits object) eight pieces on the copy stream make the read 41.8 ms
+    // against 22.8 with one copy on the lane's stream — the copy stream's transfers and the kernels waiting on their events do not run side by side here
+    const int k = forced > 0 ? forced : 1;
+    TF_HIP(hipEventCreateWithFlags(&first_, hipEventDisableTiming));
+    TF_HIP(hipEventRecord(first_, main));
+    TF_HIP(hipStreamWaitEvent(cx.copy_stream, first_, 0));   // whoever used this block before on the lane's stream is done first
+    uint64_t at = 0;
+    for (int i = 0; i < k; i++) {
+      const uint64_t gran = forced > 0 ? 0xFFFull : 0xFFFFFull;   // (forced: small test objects are cut too)
+      const uint64_t z = i + 1 == k ? len : std::min<uint64_t>(len, ((len / (uint64_t)k) * (uint64_t)(i + 1) + gran) & ~gran);
+      if (z > at) TF_HIP(hipMemcpyAsync((char *)dst + at, src + at, (size_t)(z - at), hipMemcpyHostToDevice, cx.copy_stream));
+      hipEvent_t e;
+      TF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      TF_HIP(hipEventRecord(e, cx.copy_stream));
+      ev.push_back(e); end.push_back(z);
+      at = z;
+    }
+  }
+  hipEvent_t first_ = nullptr;
+};
+// pages of one kind cut into runs by the piece their last byte arrives with: run i is launched behind piece i's event
+template <class T, class EndOf> static std::vector<std::pair<size_t, size_t>> by_piece(std::vector<T> &pages, const UploadPieces &up, EndOf end_of) {
+  std::vector<std::pair<size_t, size_t>> runs;
+  if (up.end.empty()) { runs.push_back({0, pages.size()}); return runs; }
+  std::stable_sort(pages.begin(), pages.end(), [&](const T &a, const T &b) { return end_of(a) < end_of(b); });
+  size_t at = 0;
+  for (size_t i = 0; i < up.end.size(); i++) {
+    size_t z = at;
+    while (z < pages.size() && (end_of(pages[z]) <= up.end[i] || i + 1 == up.end.size())) z++;
+    runs.push_back({at, z});
+    at = z;
+  }
+  return runs;
+}
+
+// What the tail (the bytes decoded beside the object: expanded dictionary indices, DELTA_BINARY_PACKED values, INT96 texts) can need at
+// most, from the footer alone: a chunk lists its encodings.
+static uint64_t tail_bound(const FileMeta &m, const std::vector<TopField> &fields, int64_t nrows) {
+  uint64_t bound = 64;
+  for (size_t k = 0; k < fields.size(); k++) {
+    if (fields[k].group) continue;
+    const SchemaEl &e = fields[k].el;
+    if (e.type == T_INT96) bound += (uint64_t)std::max<int64_t>(nrows, 1) * 32 + 16;
+    for (auto &g : m.groups) {
+      const ColChunk &c = g.cols[(size_t)fields[k].leaf];
+      if (c.enc_mask & ((1u << E_PLAIN_DICT) | (1u << E_RLE_DICT) | (e.type == T_BOOLEAN ? (1u << E_RLE) : 0u)))   // expanded indices: at most 4 bytes a value
+        bound += (uint64_t)std::max<int64_t>(c.num_values, 0) * 4 + 16 * (uint64_t)(std::max<int64_t>(c.num_values, 0) / 64 + 2);
+      if ((c.enc_mask >> E_DELTA_BINARY_PACKED) & 1u) bound += (uint64_t)std::max<int64_t>(c.num_values, 0) * 8 + 16 * (uint64_t)(std::max<int64_t>(c.num_values, 0) / 64 + 2);  // (every page's share is rounded up to 16 bytes)
+    }
+  }
+  return bound;
+}
+
+static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, bool force_arena, tfgpu_dbatch **out, Buf staged = nullptr) {
   PqClock clk;
   FileMeta m; std::string why;
   if (!parse_footer(f, len, m, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: " + why);
@@ -917,27 +1151,21 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   // chunk lists its encodings: DELTA_BINARY_PACKED values decode into the tail, an INT96 column's texts live there, a
   // DELTA_BYTE_ARRAY chunk sends the whole object through the arena instead).
   Buf file;
+  UploadPieces up;
   uint64_t tail_base = 0, tail_cap = 0;
   if (!inflate) {
-    uint64_t bound = 64;
-    for (size_t k = 0; k < fields.size(); k++) {
-      if (fields[k].group) continue;
-      const SchemaEl &e = fields[k].el;
-      if (e.type == T_INT96) bound += (uint64_t)std::max<int64_t>(nrows, 1) * 32 + 16;
-      for (auto &g : m.groups) {
-        const ColChunk &c = g.cols[(size_t)fields[k].leaf];
-        if (c.enc_mask & ((1u << E_PLAIN_DICT) | (1u << E_RLE_DICT) | (e.type == T_BOOLEAN ? (1u << E_RLE) : 0u)))   // expanded indices: at most 4 bytes a value
-          bound += (uint64_t)std::max<int64_t>(c.num_values, 0) * 4 + 16 * (uint64_t)(std::max<int64_t>(c.num_values, 0) / 64 + 2);
-        if ((c.enc_mask >> E_DELTA_BINARY_PACKED) & 1u) bound += (uint64_t)std::max<int64_t>(c.num_values, 0) * 8 + 16 * (uint64_t)(std::max<int64_t>(c.num_values, 0) / 64 + 2);  // (every page's share is rounded up to 16 bytes)
-      }
-    }
     tail_base = (len + 64 + 15) & ~15ull;
-    tail_cap = bound;
+    tail_cap = tail_bound(m, fields, nrows);
     if (tail_base + tail_cap + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the object and what is decoded beside it exceed 4 GiB: read it row group by row group");
-    file = dalloc((size_t)(tail_base + tail_cap) + 64);
-    h2d(file->p, f, (size_t)len);
+    if (staged) {  // the object is in HBM already (tfgpu_parquet_read_staged: somebody else's copy engine brought it), with room for the tail behind it
+      if (staged->bytes < (size_t)(tail_base + tail_cap) + 64) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read_staged: the staging buffer is smaller than tfgpu_parquet_staging_size asks for");
+      file = staged;
+    } else {
+      file = dalloc((size_t)(tail_base + tail_cap) + 64);
+      up.start(file->p, f, len);
+    }
     TF_HIP(hipMemsetAsync((char *)file->p + len, 0, (size_t)(tail_base - len), st));
-    clk.at("upload issued");
+    clk.at(staged ? "staged object taken" : "upload issued");
   }
 
   auto db = std::make_unique<tfgpu_dbatch>();
@@ -1217,24 +1445,48 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
       total += (size_t)P.ord;
     }
     arena_off = dalloc(std::max<size_t>(total, 1) * 4); arena_len = dalloc(std::max<size_t>(total, 1) * 4);
-    if (!all.empty() && nrows) {
-      Buf btp = upload_small(all.data(), all.size() * sizeof(TextPage));
-      keep.push_back(btp);
-      KernelTimer t("pq_walk_text");
-      pq_walk_text<<<(unsigned)all.size(), 256, 0, st>>>(dfile, (img_len + 64) & ~15ull, reinterpret_cast<const TextPage *>(btp->p), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
-    }
-    if (!hpages.empty() && nrows) {
-      Buf bh = upload_small(hpages.data(), hpages.size() * sizeof(HPage));
-      keep.push_back(bh);
-      KernelTimer t("pq_hybrid");
-      pq_hybrid<<<(unsigned)((hpages.size() * 64 + 255) / 256), 256, 0, st>>>(dfile, dtail, reinterpret_cast<const HPage *>(bh->p), (int32_t)hpages.size(), ptr<uint32_t>(derr));
-    }
+    // (an object that is going up in pieces: the pages of each kind in runs by the piece their last byte arrives with, a run queued
+    //  behind its piece's event; otherwise one run each)
+    const auto truns = by_piece(all, up, [](const TextPage &q) { return q.end; });
+    const auto hruns = by_piece(hpages, up, [](const HPage &q) { return q.end; });
+    const auto druns = by_piece(dpages, up, [](const DPage &q) { return q.mode == 1 ? q.data_end : ~0ull; });   // (a page of values reads its miniblocks wherever they lie: with the last piece)
+    Buf btp, bh, bm, bp;
+    if (!all.empty() && nrows) { btp = upload_small(all.data(), all.size() * sizeof(TextPage)); keep.push_back(btp); }
+    if (!hpages.empty() && nrows) { bh = upload_small(hpages.data(), hpages.size() * sizeof(HPage)); keep.push_back(bh); }
     if (!dpages.empty() && nrows) {
       DMini none{};
-      Buf bm = upload_small(minis.empty() ? &none : minis.data(), std::max<size_t>(minis.size(), 1) * sizeof(DMini)), bp = upload_small(dpages.data(), dpages.size() * sizeof(DPage));
+      bm = upload_small(minis.empty() ? &none : minis.data(), std::max<size_t>(minis.size(), 1) * sizeof(DMini)); bp = upload_small(dpages.data(), dpages.size() * sizeof(DPage));
       keep.push_back(bm); keep.push_back(bp);
-      KernelTimer t("pq_delta");
-      pq_delta<<<(unsigned)((dpages.size() * 64 + 255) / 256), 256, 0, st>>>(dfile, dtail, reinterpret_cast<const DMini *>(bm->p), reinterpret_cast<const DPage *>(bp->p), (int32_t)dpages.size(), ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
+    }
+    // TFGPU_PQ_WALK_SPEC=1: the windows by all 64 lanes of wave 0 (guessed slice entries, settled against the neighbours' exits).  OFF by default:
+    // measured on the MI355X (gpurun r11p-r11t, the 556 MB hits object, 721 pages of <= 69 windows) 88 % of the windows settle in 0.6 rounds
+    // and the kernel takes 3.77 ms against the one-lane walk's 3.73-4.02 — a lane's slice is walked three times (guess proofs, count, write)
+    // in lockstep with the slowest of 64 slices, every link two LDS reads behind an index computation; without any walk (=2, profiling
+    // only) the kernel is 0.075 ms: staging, barriers and the flush are not what it waits for
+    static const int walk_spec = [] { const char *e = std::getenv("TFGPU_PQ_WALK_SPEC"); return e ? std::atoi(e) : 0; }();   // A/B runs: 0 = the one-lane walk for every window
+    static const bool walk_debug = [] { const char *e = std::getenv("TFGPU_PQ_DEBUG"); return e && e[0] == '1'; }();
+    Buf wdbg = walk_debug ? dalloc_zero(32) : nullptr;
+    const size_t nruns = std::max<size_t>(up.end.size(), 1);
+    for (size_t g = 0; g < nruns; g++) {
+      up.wait((int)g);
+      if (btp && truns[g].second > truns[g].first) {
+        KernelTimer t("pq_walk_text");
+        pq_walk_text<<<(unsigned)(truns[g].second - truns[g].first), 256, 0, st>>>(dfile, (img_len + 64) & ~15ull, reinterpret_cast<const TextPage *>(btp->p) + truns[g].first, ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr), walk_spec, wdbg ? ptr<uint32_t>(wdbg) : nullptr);
+      }
+      if (bh && hruns[g].second > hruns[g].first) {
+        const size_t n = hruns[g].second - hruns[g].first;
+        KernelTimer t("pq_hybrid");
+        pq_hybrid<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(dfile, dtail, reinterpret_cast<const HPage *>(bh->p) + hruns[g].first, (int32_t)n, ptr<uint32_t>(derr));
+      }
+      if (bp && druns[g].second > druns[g].first) {
+        const size_t n = druns[g].second - druns[g].first;
+        KernelTimer t("pq_delta");
+        pq_delta<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(dfile, dtail, reinterpret_cast<const DMini *>(bm->p), reinterpret_cast<const DPage *>(bp->p) + druns[g].first, (int32_t)n, ptr<uint32_t>(arena_off), ptr<uint32_t>(arena_len), ptr<uint32_t>(derr));
+      }
+    }
+    if (wdbg) {
+      uint32_t h[8]; d2h(h, wdbg->p, 32); tf::sync();
+      std::fprintf(stderr, "tfgpu pq walk: %u windows, %u by the wave, %u did not settle, %u held a bad prefix, %u other; %.2f rounds a window; %u pages, the longest %u windows\n", h[0], h[1], h[2], h[3], h[4], h[0] ? (double)h[5] / h[0] : 0.0, h[7], h[6]);
     }
   }
   clk.at("text walks enqueued");
@@ -1335,7 +1587,11 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
       pq_pack_validity_all<<<dim3((unsigned)(((nrows + 7) / 8 + 255) / 256), (unsigned)ld.size()), 256, 0, st>>>(reinterpret_cast<const LevDesc *>(B + ld_at), nrows);
     }
     if (!fd.empty()) { KernelTimer t("pq_values"); pq_values_all<<<dim3(gx, (unsigned)fd.size()), 256, 0, st>>>(dfile, tail_base, reinterpret_cast<const FixedDesc *>(B + fd_at), nrows, ptr<uint32_t>(derr)); }
-    if (!td.empty()) { KernelTimer t("pq_text"); pq_text_cells_all<<<dim3(gx, (unsigned)td.size()), 256, 0, st>>>(dfile, tail_base, reinterpret_cast<const TextDesc *>(B + td_at), nrows, ptr<uint32_t>(derr)); }
+    if (!td.empty()) {
+      KernelTimer t("pq_text");
+      pq_text_cells_all<<<dim3((unsigned)((nrows + 256 * PQ_TEXT_RPT - 1) / (256 * PQ_TEXT_RPT)), (unsigned)td.size()), 256, 0, st>>>(dfile, tail_base, reinterpret_cast<const TextDesc *>(B + td_at), nrows, ptr<uint32_t>(derr));
+      sum_u32_segments_u64(ptr<uint32_t>(lens_all), nrows, (int)td.size(), lstride, reinterpret_cast<unsigned long long *>(tot64_all->p));   // (the text columns are the first segments)
+    }
     for (auto &q : int96_cols) {  // (rare: one launch per column)
       ColPlan &P = plans[q.oc];
       DColumn &d = P.d;
@@ -1351,26 +1607,39 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
     }
     if (nt) exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, (int)nt, lstride);
   }
-  std::vector<uint32_t> htot(totals.size() + 1);
-  std::vector<uint64_t> htot64(totals.size() + 1);
-  uint32_t herr[4] = {0, 0, 0, 0};
-  for (size_t k = 0; k < totals.size(); k++) d2h(&htot[k], ptr<uint32_t>(plans[totals[k]].d.offsets) + nrows, 4);
-  if (!totals.empty()) d2h(htot64.data(), tot64_all->p, totals.size() * 8);
-  d2h(herr, derr->p, 16);
+  // the text columns' sizes, their 64-bit sums and the error word: one gather launch, three read-backs into page-locked memory (a four-byte
+  // copy per column into a pageable vector was 22 us each)
+  const uint32_t *htot = nullptr, *htot64w = nullptr;
+  if (!totals.empty()) {
+    std::vector<const uint32_t *> at(totals.size());
+    for (size_t k = 0; k < totals.size(); k++) at[k] = ptr<uint32_t>(plans[totals[k]].d.offsets) + nrows;
+    Buf bat = upload_small(at.data(), at.size() * sizeof(at[0])), gathered = dalloc(totals.size() * 4);
+    pq_gather_words<<<1, 256, 0, st>>>(reinterpret_cast<const uint32_t *const *>(bat->p), (int)totals.size(), ptr<uint32_t>(gathered));
+    keep.push_back(bat); keep.push_back(gathered);
+    htot = d2h_u32(gathered->p, totals.size());
+    htot64w = d2h_u32(tot64_all->p, totals.size() * 2);
+  }
+  const uint32_t *herr = d2h_u32(derr->p, 4);
   clk.at("columns enqueued");
   tf::sync();  // ONE wait for the text columns' sizes (a dictionary-coded column can be far longer than its chunk), then the copies
   clk.at("first sync");
   if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
-  for (size_t k = 0; k < totals.size(); k++) if (htot64[k] >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + plans[totals[k]].d.name + " holds 4 GiB of text or more: read the object row group by row group");
-  for (size_t k = 0; k < totals.size(); k++) {
-    DColumn &d = plans[totals[k]].d;
-    d.data_len = htot[k];
-    d.data = dalloc((size_t)d.data_len + 16);
+  for (size_t k = 0; k < totals.size(); k++) if (((uint64_t)htot64w[2 * k] | (uint64_t)htot64w[2 * k + 1] << 32) >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + plans[totals[k]].d.name + " holds 4 GiB of text or more: read the object row group by row group");
+  if (!totals.empty()) {
+    std::vector<PackDesc> pd(totals.size());
+    for (size_t k = 0; k < totals.size(); k++) {
+      DColumn &d = plans[totals[k]].d;
+      d.data_len = htot[k];
+      d.data = dalloc((size_t)d.data_len + 16);
+      pd[k] = PackDesc{ptr<uint32_t>(d.offsets), ptr<uint8_t>(d.data), ptr<uint32_t>(soffs[k].second)};
+    }
+    Buf bpd = upload_small(pd.data(), pd.size() * sizeof(PackDesc));
     constexpr int RPT = 4;
     KernelTimer t("pq_pack_text");
-    pq_pack_text<RPT><<<(unsigned)((nrows + 256 * RPT - 1) / (256 * RPT)), 256, 0, st>>>(ptr<uint32_t>(d.offsets), nrows, dfile, ptr<uint8_t>(d.data), ptr<uint32_t>(soffs[k].second));
+    pq_pack_text_all<RPT><<<dim3((unsigned)((nrows + 256 * RPT - 1) / (256 * RPT)), (unsigned)totals.size()), 256, 0, st>>>(reinterpret_cast<const PackDesc *>(bpd->p), nrows, dfile);
+    keep.push_back(bpd);
   }
-  d2h(herr, derr->p, 16);
+  herr = d2h_u32(derr->p, 4);
   tf::sync();
   if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
   clk.at("second sync");
@@ -1386,6 +1655,33 @@ extern "C" int tfgpu_parquet_read_object(const void *bytes, uint64_t len, int me
   if (len >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: objects of 4 GiB and more: read them row group by row group");
   const uint8_t *f = static_cast<const uint8_t *>(bytes);
   try { return parquet_read_impl(f, len, schema, table_ns, table_name, file_name, false, out); }
+  catch (const NeedArena &) { return parquet_read_impl(f, len, schema, table_ns, table_name, file_name, true, out); }
+  TF_API_END
+}
+// The object brought into HBM by the caller (its own lane's copy engine, ahead of time): `bytes` stays the host copy the footer and the
+// page headers are walked in; `staged` holds the same `len` bytes at offset 0 and is at least tfgpu_parquet_staging_size long (the decoded
+// tail is written behind the object).  A compressed object's pages are inflated on the host: `staged` is then not used.
+extern "C" int tfgpu_parquet_staging_size(const void *bytes, uint64_t len, uint64_t *need) {
+  TF_API_BEGIN
+  if (!bytes || !need) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_staging_size: null argument");
+  FileMeta m; std::string why;
+  if (!parse_footer(static_cast<const uint8_t *>(bytes), len, m, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_staging_size: " + why);
+  std::vector<TopField> fields; int nleaves = 0;
+  if (!top_fields(m, fields, nleaves, why)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_staging_size: " + why);
+  for (auto &g : m.groups) if ((int)g.cols.size() != nleaves) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_staging_size: a row group does not hold every column");
+  int64_t nrows = 0;
+  for (auto &g : m.groups) nrows += g.num_rows;
+  *need = ((len + 64 + 15) & ~15ull) + tail_bound(m, fields, nrows) + 64;
+  return TFGPU_OK;
+  TF_API_END
+}
+extern "C" int tfgpu_parquet_read_staged(const void *bytes, uint64_t len, const tfgpu_dbuf *staged, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, tfgpu_dbatch **out) {
+  TF_API_BEGIN
+  if (!bytes || !out || !staged || !staged->mem) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read_staged: null argument");
+  if (len >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: objects of 4 GiB and more: read them row group by row group");
+  if (staged->size < len) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read_staged: the staging buffer is shorter than the object");
+  const uint8_t *f = static_cast<const uint8_t *>(bytes);
+  try { return parquet_read_impl(f, len, schema, table_ns, table_name, file_name, false, out, staged->mem); }
   catch (const NeedArena &) { return parquet_read_impl(f, len, schema, table_ns, table_name, file_name, true, out); }
   TF_API_END
 }

@@ -31,7 +31,7 @@ EXPORTS = [
     "tfgpu_apply", "tfgpu_transformation_create", "tfgpu_transformation_from_config", "tfgpu_transformation_size", "tfgpu_transformation_plan_type", "tfgpu_transformation_errors_output", "tfgpu_transformation_destroy", "tfgpu_transformation_table_plan", "tfgpu_transformation_push",
     "tfgpu_transformation_get_stats", "tfgpu_executor_start", "tfgpu_transformation_push_async", "tfgpu_wait", "tfgpu_collapse", "tfgpu_keys_changed", "tfgpu_dbatch_deepsizeof", "tfgpu_partition", "tfgpu_comm_unique_id", "tfgpu_comm_init", "tfgpu_comm_destroy", "tfgpu_comm_rank", "tfgpu_comm_world", "tfgpu_exchange", "tfgpu_csv_options_default", "tfgpu_csv_parse", "tfgpu_csv_split_rows", "tfgpu_json_parse", "tfgpu_json_result_schema", "tfgpu_sr_frames", "tfgpu_sr_json_parse", "tfgpu_sr_compile_schema", "tfgpu_sr_schema_info", "tfgpu_sr_schema_free", "tfgpu_sr_compile_proto", "tfgpu_pb_schema_info", "tfgpu_pb_schema_free", "tfgpu_sr_proto_parse", "tfgpu_debezium_unpack", "tfgpu_debezium_unpack_cached", "tfgpu_debezium_parse", "tfgpu_debezium_compile_schema", "tfgpu_dbz_schema_info", "tfgpu_dbz_schema_free", "tfgpu_dbz_receiver_create", "tfgpu_dbz_receiver_destroy", "tfgpu_dbz_receiver_known", "tfgpu_dbz_receive", "tfgpu_dbz_receive_group", "tfgpu_dbz_receive_group_meta", "tfgpu_debezium_compile_registry_schema", "tfgpu_dbz_receiver_add_registry_schema", "tfgpu_debezium_registry_frames", "tfgpu_dbz_receive_registry", "tfgpu_serialize", "tfgpu_serialize_ex", "tfgpu_serialize_batch", "tfgpu_ch_native_block", "tfgpu_queue_serialize", "tfgpu_queue_raw_column", "tfgpu_queue_mirror", "tfgpu_queue_part_groups", "tfgpu_kafka_hash_partition", "tfgpu_kafka_partitions", "tfgpu_debezium_emit", "tfgpu_dbuf_size", "tfgpu_dbuf_ptr",
     "tfgpu_dbuf_download", "tfgpu_dbuf_free", "tfgpu_dbuf_upload", "tfgpu_dbuf_alloc", "tfgpu_dbuf_write", "tfgpu_prof_enable", "tfgpu_prof_reset", "tfgpu_prof_count",
-    "tfgpu_prof_get", "tfgpu_prof_get_units", "tfgpu_parquet_read_object", "tfgpu_parquet_resolve_schema", "tfgpu_dbatch_nrows", "tfgpu_dbatch_dense",
+    "tfgpu_prof_get", "tfgpu_prof_get_units", "tfgpu_parquet_read_object", "tfgpu_parquet_staging_size", "tfgpu_parquet_read_staged", "tfgpu_parquet_resolve_schema", "tfgpu_dbatch_nrows", "tfgpu_dbatch_dense",
 ]
 
 
@@ -184,6 +184,30 @@ def parquet_read(data: bytes, schema: Optional[abi.Schema] = None, ns: str = "",
     L = load()
     L.tfgpu_parquet_read_object.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
     _check(L.tfgpu_parquet_read_object(C.c_void_p(buf.ctypes.data), C.c_uint64(len(buf)), abi.MEM_HOST, C.byref(cs) if cs is not None else None, ns.encode(), table.encode(),
+                                       file_name.encode() if file_name is not None else None, C.byref(out)))
+    return DeviceBatch(out)
+
+
+def parquet_staging_size(data) -> int:
+    """Bytes a staging buffer for tfgpu_parquet_read_staged must hold: the object, then room for what the reader decodes beside it."""
+    ptr_, n, _mem, keep = _bytes_arg(data)
+    need = C.c_uint64(0)
+    L = load()
+    L.tfgpu_parquet_staging_size.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    _check(L.tfgpu_parquet_staging_size(C.c_void_p(ptr_), C.c_uint64(n), C.byref(need)))
+    return int(need.value)
+
+
+def parquet_read_staged(data, staged: "DeviceBuffer", schema: Optional[abi.Schema] = None, ns: str = "", table: str = "", file_name: Optional[str] = None) -> "DeviceBatch":
+    """tfgpu_parquet_read_object for an object already in HBM: `data` = the host copy (bytes or a pinned HostBuffer), `staged` = a device
+    buffer of parquet_staging_size(data) bytes whose first len(data) bytes are the object."""
+    init()
+    ptr_, n, _mem, keep = _bytes_arg(data)
+    out = C.c_void_p()
+    cs = schema.to_c() if schema is not None else None
+    L = load()
+    L.tfgpu_parquet_read_staged.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    _check(L.tfgpu_parquet_read_staged(C.c_void_p(ptr_), C.c_uint64(n), staged._h, C.byref(cs) if cs is not None else None, ns.encode(), table.encode(),
                                        file_name.encode() if file_name is not None else None, C.byref(out)))
     return DeviceBatch(out)
 
