@@ -569,7 +569,15 @@ __global__ void __launch_bounds__(256) ser_chunk_layout(SerParams p, ChunkPlan c
     const uint32_t lo = __shfl_down((uint32_t)sum, d, 64), hi = __shfl_down((uint32_t)(sum >> 32), d, 64);
     if ((int)(threadIdx.x & 63) + d < 64) sum += ((unsigned long long)hi << 32) | lo;
   }
-  if ((threadIdx.x & 63) == 0) atomicAdd(p.total64, sum);
+  // … and one per workgroup: the waves' sums meet in LDS first (16 384 atomics on one word were still ~0.15 ms of a 2^20-row batch)
+  __shared__ unsigned long long wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (unsigned w = 0; w < (blockDim.x + 63) / 64; w++) t += wsum[w];
+    if (t) atomicAdd(p.total64, t);
+  }
 }
 // (4) the text
 template <int FMT>
