@@ -14,9 +14,28 @@ CSRC = os.path.join(ROOT, "transferia_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+_ASM = {}
+
+
+def _compile_all():
+    """Every source these tests look at, compiled side by side on first use (one hipcc run a file is 10-60 s; one after another they
+    were three minutes of the CPU suite)."""
+    if _ASM:
+        return
+    import concurrent.futures
+    srcs = sorted(set(re.findall(r'"(tf_[a-z_]+\.hip)"', open(os.path.abspath(__file__)).read())))   # every source a test names
+
+    def one(src):
+        return src, subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", "-", os.path.join(CSRC, src)],
+                                   capture_output=True, text=True, timeout=900)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        for src, r in ex.map(one, srcs):
+            _ASM[src] = r
+
+
 def kernel_table(src):
-    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", "-", os.path.join(CSRC, src)],
-                         capture_output=True, text=True, timeout=600)
+    _compile_all()
+    asm = _ASM[src]
     assert asm.returncode == 0, asm.stderr[-2000:]
     out = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", asm.stdout, re.S):
