@@ -130,6 +130,20 @@ typedef struct tfgpu_column {
   int32_t *nanos;     /* TFGPU_R_TIME only; NULL = all zero                   */
   uint8_t *validity;  /* bitmap, bit i (LSB first) = 1 if value i != nil;
                          NULL = no nil values                                 */
+  uint8_t *absent;    /* bitmap, bit i = 1: row i's ColumnNames do NOT list this
+                         column at all (an Update that leaves a TOASTed column
+                         out, pkg/abstract/changeitem/change_item_collapse.go:7-35;
+                         the Debezium receiver's `__debezium_unavailable_value`,
+                         pkg/debezium/receiver_engine.go:143-148) — a third cell
+                         state beside a value and nil.  An ABSENT cell also reads
+                         nil (its validity bit is 0).  NULL = every row lists the
+                         column (the uniform case).  A row's ColumnNames are the
+                         batch's columns it is not absent from, in batch order.
+                         Read by tfgpu_collapse, tfgpu_keys_changed,
+                         tfgpu_partition, view / download; every entry that
+                         computes on VALUES (transformers, serializers, the
+                         exchange) refuses such a batch by name
+                         (TFGPU_ERR_UNSUPPORTED).                               */
 } tfgpu_column;
 
 /* A batch = one contiguous same-table, same-schema run of ChangeItems, which
@@ -505,9 +519,13 @@ int tfgpu_wait(tfgpu_token *token, tfgpu_dbatch **transformed, tfgpu_dbatch **er
  * last change, then the deletes (the reference leaves those in map order; here: input order).  src_row of a surviving row
  * is the row whose Kind / OldKeys / LSN it keeps (the first of its chain); its values are the last writer's.
  * Batches with fewer than two rows, inserts only, or no key column come back unchanged.
- * Caller contract (the columnar batch cannot say more): every item shares the batch's ColumnNames — batches mixing
- * TOAST-style updates with fewer columns take the Go path (compareColumns, :7-35); SynchronizeKind items are uploaded as
- * TFGPU_K_SYNCHRONIZE (InsertsOnly, :37-44, treats that one as an insert).  Keys are filed by 128-bit hashes of their
+ * Items whose ColumnNames differ (TOAST-style Updates that leave columns out) say so through tfgpu_column.absent: the
+ * compareColumns merge (:7-35, :86-100) then runs on the device — a merged row lists the union of its chain's columns and
+ * takes every column's value from the LAST item of the chain that lists it.  The reference appends names a later item
+ * brings to the END of the merged row's ColumnNames; the columnar form keeps batch order, so a chain whose merged name
+ * order would differ from batch order (an earlier item lacks a column that a later item lists in FRONT of one the earlier
+ * item has) is refused by name — TFGPU_ERR_UNSUPPORTED, the Go path takes the batch.  SynchronizeKind items are uploaded
+ * as TFGPU_K_SYNCHRONIZE (InsertsOnly, :37-44, treats that one as an insert).  Keys are filed by 128-bit hashes of their
  * json.Marshal text and, hash for hash, compared as strings: two rows share a key exactly when the reference's map would
  * file them under one string.  TFGPU_ERR_UNSUPPORTED: NaN / Inf in a float key column, more than 2^29 rows.             */
 int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out);

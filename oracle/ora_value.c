@@ -166,11 +166,27 @@ ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema) {
     it->table = dups(cb->table_name ? cb->table_name : "");
     if (cb->part_id) { char pb[16]; snprintf(pb, sizeof pb, "%u", cb->part_id[r]); it->part_id = dups(pb); }  /* PartID = itoa (sharder.go:145) */
     else it->part_id = dups("");
-    it->names = nm; nm->refs++;
     it->schema = sch; sch->refs++;
-    it->nvalues = cb->ncols;
-    it->values = (ora_value *)calloc((size_t)(cb->ncols ? cb->ncols : 1), sizeof(ora_value));
-    for (int c = 0; c < cb->ncols; c++) it->values[c] = box(&cb->cols[c], r);
+    int listed = 0;  /* tfgpu_column.absent: the row's ColumnNames are the columns it is not absent from, in batch order */
+    for (int c = 0; c < cb->ncols; c++) if (!(cb->cols[c].absent && valid_at(cb->cols[c].absent, r))) listed++;
+    if (listed == cb->ncols) {
+      it->names = nm; nm->refs++;
+      it->nvalues = cb->ncols;
+      it->values = (ora_value *)calloc((size_t)(cb->ncols ? cb->ncols : 1), sizeof(ora_value));
+      for (int c = 0; c < cb->ncols; c++) it->values[c] = box(&cb->cols[c], r);
+    } else {
+      ora_names *own = (ora_names *)calloc(1, sizeof *own);
+      own->refs = 1; own->n = listed; own->names = (char **)calloc((size_t)(listed ? listed : 1), sizeof(char *));
+      it->names = own;
+      it->nvalues = listed;
+      it->values = (ora_value *)calloc((size_t)(listed ? listed : 1), sizeof(ora_value));
+      int k = 0;
+      for (int c = 0; c < cb->ncols; c++) {
+        if (cb->cols[c].absent && valid_at(cb->cols[c].absent, r)) continue;
+        own->names[k] = dups(cb->cols[c].name);
+        it->values[k++] = box(&cb->cols[c], r);
+      }
+    }
     it->src_row = cb->src_row ? cb->src_row[r] : r;
     if (onm && valid_at(cb->old_keys_present, r)) {
       it->old_names = onm; onm->refs++;

@@ -141,3 +141,96 @@ def rows_of(out):
         res.append((int(out.kind[i]) if out.kind is not None else 0, int(out.src_row[i]) if out.src_row is not None else i,
                     [abi.norm_value(c.pyvalue(i)) for c in out.cols], oldv))
     return res
+
+
+# ---- items whose ColumnNames differ (TOAST-style Updates): the ABSENT cell state of the columnar form -----------------------------
+def batch_from_items(items, ns="", table="t", names=None):
+    """(Batch, Schema) for row-wise items [{kind, keys, names, values, old_names?, old_values?}] whose ColumnNames may differ: the batch's
+    columns are the names in order of first appearance, a row that does not list a column is ABSENT there (Column.absent).  None when the
+    items cannot be one columnar batch (OldKeys under different KeyNames, one name under two Go types)."""
+    names = list(names or [])
+    for it in items:
+        for nm in it["names"]:
+            if nm not in names:
+                names.append(nm)
+    gotype = {}
+    for it in items:
+        for nm, v in zip(it["names"], it["values"]):
+            if v[0] != "nil" and gotype.setdefault(nm, v[0]) != v[0]:
+                return None
+    dt = {"int": "int64", "int64": "int64", "string": "utf8", "bytes": "string", "float64": "double"}
+    keys = items[0]["keys"]
+    knames = [k for k in keys if k not in names]  # a key column no item lists still belongs to the TableSchema
+    schema = abi.Schema([abi.ColSchema(nm, dt.get(gotype.get(nm, "string"), "utf8"), nm in keys, "", "") for nm in names + knames])
+    rows = [[dict(zip(it["names"], it["values"])).get(nm, ["nil", None]) for nm in names] for it in items]
+    b = abi.batch_from_rows(schema, names, rows, ns, table, [it["kind"] for it in items])
+    b.schema = schema
+    for c in b.cols:
+        ab = np.array([c.name not in it["names"] for it in items], bool)
+        if ab.any():
+            c.absent = ab
+            if c.validity is None:
+                c.validity = ~ab
+    onames = next((it["old_names"] for it in items if it.get("old_names")), None)
+    if onames:
+        if any(it.get("old_names") and it["old_names"] != onames for it in items):
+            return None
+        ogo = {}
+        for it in items:
+            for nm, v in zip(it.get("old_names") or [], it.get("old_values") or []):
+                if v[0] != "nil":
+                    ogo.setdefault(nm, v[0])
+        osch = abi.Schema([abi.ColSchema(nm, dt.get(ogo.get(nm, "string"), "utf8"), False, "", "") for nm in onames])
+        ob = abi.batch_from_rows(osch, onames, [it.get("old_values") or [["nil", None]] * len(onames) for it in items])
+        b.old_keys, b.old_present = ob.cols, np.array([bool(it.get("old_names")) for it in items])
+    return b, schema
+
+
+def items_of(out, keys=None):
+    """A batch (input or result) as the row-wise items the oracle's collapse_rows reports: a row lists the columns it is not ABSENT from."""
+    old = getattr(out, "old_keys", None) or []
+    pres = getattr(out, "old_present", None)
+    res = []
+    for i in range(out.nrows):
+        cols = [c for c in out.cols if getattr(c, "absent", None) is None or not c.absent[i]]
+        it = {"kind": KINDS[int(out.kind[i])] if out.kind is not None else "insert", "names": [c.name for c in cols],
+              "values": [list(abi.norm_value(c.pyvalue(i))) for c in cols],
+              "old": [[c.name, list(abi.norm_value(c.pyvalue(i)))] for c in old] if old and (pres is None or pres[i]) else [],
+              "src": int(out.src_row[i]) if out.src_row is not None else i}
+        res.append(it)
+    return res
+
+
+def norm_items(rows):
+    """the oracle's row-wise result in the same comparable form"""
+    return [{"kind": r["kind"], "names": list(r["names"]), "values": [list(abi.norm_value(v)) for v in r["values"]],
+             "old": [[n, list(abi.norm_value(v))] for n, v in r["old"]], "src": r["src"]} for r in rows]
+
+
+def random_toast_items(seed, n, ncols=5, domain=6, p_absent=0.35, weights=(3, 6, 1, 1), front_ok=False, toastable=None, p_nokey=0.3):
+    """Row-wise CDC items over columns id (key), c0..c{ncols-1}: an Update leaves each non-key column out with probability p_absent
+    (only the columns in `toastable`, when given; sometimes the key too, then it carries OldKeys); Inserts list everything unless front_ok (then they may leave columns out as well —
+    chains whose merged name order leaves batch order, which the device must refuse)."""
+    rng = np.random.default_rng(SEED0 + seed)
+    names = ["id"] + ["c%d" % j for j in range(ncols)]
+    items = []
+    for i in range(n):
+        kind = KINDS[int(rng.choice(4, p=np.array(weights) / sum(weights)))]
+        key = int(rng.integers(0, domain))
+        full = {"id": ["int64", key]}
+        for j in range(ncols):
+            full["c%d" % j] = ["string", "r%d.%d" % (i, j)] if j % 2 == 0 else (["int64", i * 10 + j] if rng.random() > 0.15 else ["nil", None])
+        listed = list(names)
+        if kind == "update" or (front_ok and kind == "insert"):
+            listed = ["id"] + [nm for j, nm in enumerate(names[1:]) if (toastable is not None and j not in toastable) or rng.random() >= p_absent]
+        it = {"kind": kind, "keys": ["id"], "names": listed, "values": [full[nm] for nm in listed]}
+        if kind in ("update", "delete") and rng.random() < 0.5:
+            okey = key if rng.random() < 0.6 else int(rng.integers(0, domain))
+            it["old_names"], it["old_values"] = ["id"], [["int64", okey]]
+            if kind == "update" and rng.random() < p_nokey:  # the key itself left out: the row is named by its OldKeys alone
+                it["names"] = it["names"][1:]
+                it["values"] = it["values"][1:]
+        if kind == "delete" and rng.random() < 0.5:
+            it["names"], it["values"] = ["id"], [full["id"]]
+        items.append(it)
+    return items

@@ -40,7 +40,7 @@ def test_enum_tables_match_header():
 
 def test_struct_sizes():
     # plain C structs, natural alignment on x86-64
-    assert C.sizeof(abi.CColumn) == 8 + 4 + 4 + 8 * 3 + 8 + 8 + 8
+    assert C.sizeof(abi.CColumn) == 8 + 4 + 4 + 8 * 3 + 8 + 8 + 8 + 8  # … validity, absent
     assert C.sizeof(abi.CRowError) == 24
     assert C.sizeof(abi.CColSchema) == 64
 

@@ -260,3 +260,117 @@ def test_keys_that_print_alike(tf, oracle):
     # 0xFF and 0xFE both print as the escape \\ufffd: one key; a real U+FFFD prints as its three bytes: another
     assert out.nrows == ref.nrows == 3
     assert sorted(int(x) for x in out.col("v").values) == sorted(int(x) for x in ref.col("v").values) == [2, 3, 4]
+
+
+# ---- compareColumns (change_item_collapse.go:7-35, :86-100): items whose ColumnNames differ, as ABSENT cells -----------------------
+def _collapse_items(tf, items, names=None):
+    from collapse_cases import batch_from_items, items_of
+    made = batch_from_items(items, names=names)
+    assert made is not None
+    b, schema = made
+    by_name = lambda its: [dict(it_, names=sorted(it_["names"]), values=[v for _, v in sorted(zip(it_["names"], it_["values"]))]) for it_ in its]
+    assert by_name(items_of(b)) == by_name([dict(it_, src=i) for i, it_ in enumerate(_as_out(items))])  # the columnar form says what the items say (names in batch order)
+    return items_of(tf.collapse(tf.DeviceBatch.upload(b)).download())
+
+
+def _as_out(items):
+    from transferia_amd import abi as _abi
+    return [{"kind": it["kind"], "names": list(it["names"]), "values": [list(_abi.norm_value(v)) for v in it["values"]],
+             "old": [[n, list(_abi.norm_value(v))] for n, v in zip(it.get("old_names") or [], it.get("old_values") or [])]} for it in items]
+
+
+def test_reference_cases_diff_column_names(tf, oracle):
+    """The TestCollapse runs whose items do NOT share one ColumnNames list (TOAST updates, deletes that list nothing): on the device,
+    the merged rows equal to the oracle's row-wise restatement of the Go loop — names, values, kinds, OldKeys, source rows."""
+    from collapse_cases import norm_items
+    ran = 0
+    for case in CASES:
+        items = case["items"]
+        if len({tuple(it["names"]) for it in items}) == 1:
+            continue
+        if any(v[0] == "json" for it in items for v in it["values"] + (it.get("old_values") or [])):
+            continue
+        want = norm_items(oracle.collapse_rows(items))
+        got = _collapse_items(tf, items)
+        assert got == want, case["name"]
+        assert len(got) == case["expect"]["len"]
+        for k, kind in case["expect"].get("kinds", {}).items():
+            assert got[int(k)]["kind"] == kind
+        ran += 1
+    assert ran >= 8
+
+
+@pytest.mark.parametrize("shape", [dict(n=2), dict(n=60, toastable=[4]), dict(n=400, domain=3), dict(n=400, domain=40, ncols=9), dict(n=300, p_absent=0.8, weights=(1, 8, 1, 0), toastable=[4]),
+                                   dict(n=300, domain=2, weights=(2, 10, 0, 1), ncols=3, toastable=[2]), dict(n=300, domain=2, weights=(2, 10, 0, 1), ncols=3),
+                                   dict(n=3000, domain=300, ncols=6, toastable=[5], p_absent=0.5, p_nokey=0.0)])
+def test_random_toast_batches(tf, oracle, shape):
+    """Random CDC streams whose Updates leave columns out: long merge chains, key changes, deletes that list only the key."""
+    from collapse_cases import random_toast_items, norm_items
+    names = ["id"] + ["c%d" % j for j in range(shape.get("ncols", 5))]
+    merged = compared = 0
+    for seed in range(8):
+        items = random_toast_items(100 + seed, **shape)
+        want = norm_items(oracle.collapse_rows(items))
+        if not all(r["names"] == [nm for nm in names if nm in r["names"]] for r in want):
+            # a chain that starts with a partial Update and later gains a column in front of one it has: merged names leave batch order
+            with pytest.raises(tf.TfgpuError, match="column order"):
+                _collapse_items(tf, items, names)
+            continue
+        got = _collapse_items(tf, items, names)
+        assert got == want, (shape, seed)
+        compared += 1
+        # a merged row mixes items: its cells ("r<item>.<column>" / item * 10 + column) name more than one
+        merged += sum(1 for r in want if len({v[1].split(b".")[0][1:] if v[0] == "string" else b"%d" % (v[1] // 10)
+                                              for nm, v in zip(r["names"], r["values"]) if nm != "id" and v[0] != "nil"}) > 1)
+    assert (compared or "toastable" not in shape) and (merged or shape["n"] < 10 or not compared), (compared, merged)
+
+
+def test_merged_names_out_of_batch_order_are_refused(tf, oracle):
+    """compareColumns APPENDS the names an Update brings; a chain whose merged ColumnNames are not in the batch's column order cannot be
+    said in the columnar form: refused by name (the Go path takes the batch), never answered in another order."""
+    from collapse_cases import norm_items
+    items = [{"kind": "update", "keys": ["id"], "names": ["id", "b"], "values": [["int64", 1], ["string", "b0"]]},
+             {"kind": "update", "keys": ["id"], "names": ["id", "a"], "values": [["int64", 1], ["string", "a1"]]}]
+    assert norm_items(oracle.collapse_rows(items))[0]["names"] == ["id", "b", "a"]
+    assert _collapse_items(tf, items, ["id", "b", "a"])[0]["names"] == ["id", "b", "a"]  # batch order = merged order: fine
+    with pytest.raises(tf.TfgpuError, match="column order"):
+        _collapse_items(tf, items, ["id", "a", "b"])
+    # random streams whose Inserts leave columns out too: every batch is either the oracle's rows or refused — and refused exactly when
+    # some merged row's names leave batch order
+    from collapse_cases import random_toast_items
+    names = ["id"] + ["c%d" % j for j in range(4)]
+    seen = {True: 0, False: 0}
+    for seed in range(24):
+        items = random_toast_items(900 + seed, 40, ncols=4, domain=5, front_ok=True)
+        want = norm_items(oracle.collapse_rows(items))
+        in_order = all(r["names"] == [nm for nm in names if nm in r["names"]] for r in want)
+        seen[in_order] += 1
+        if in_order:
+            assert _collapse_items(tf, items, names) == want, seed
+        else:
+            with pytest.raises(tf.TfgpuError, match="column order"):
+                _collapse_items(tf, items, names)
+    assert seen[True] and seen[False], seen
+
+
+def test_absent_cells_travel_and_value_entries_refuse(tf, oracle):
+    """ABSENT cells survive upload / view / download and tfgpu_partition; entries that compute on values say no by name."""
+    from collapse_cases import random_toast_items, batch_from_items, items_of
+    items = random_toast_items(7, 200)
+    b, schema = batch_from_items(items, names=["id"] + ["c%d" % j for j in range(5)])
+    db = tf.DeviceBatch.upload(b)
+    assert items_of(db.download()) == items_of(b)
+    grouped, counts = tf.partition(tf.Transformer("sharder_transformer", {"shardsCount": "3", "columns": {"includeColumns": ["^id$"]}}).apply(
+        tf.DeviceBatch.upload(_without_absent(b))).transformed, 3)
+    assert sum(counts) == 200
+    with pytest.raises(tf.TfgpuError, match="ABSENT"):
+        tf.Transformer("mask_field", {"columns": ["c0"], "maskFunctionHash": {"userDefinedSalt": "s"}}).apply(db)
+    # the changed-key flags read an absent key column as nil, like ChangeItem.KeysChanged reading ColumnValues by name
+    assert list(tf.keys_changed(db)) == list(oracle.keys_changed_rows(items))
+
+
+def _without_absent(b):
+    import dataclasses
+    c = abi.Batch([dataclasses.replace(col, absent=None) for col in b.cols], b.nrows, b.table_ns, b.table_name, b.kind, b.src_row, b.part_id)
+    c.schema = b.schema
+    return c

@@ -59,7 +59,7 @@ class CSchema(C.Structure):
 class CColumn(C.Structure):
     _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("repr", C.c_int32), ("values", C.c_void_p),
                 ("offsets", C.c_void_p), ("data", C.c_void_p), ("data_len", C.c_uint64), ("nanos", C.c_void_p),
-                ("validity", C.c_void_p)]
+                ("validity", C.c_void_p), ("absent", C.c_void_p)]
 
 
 class CBatch(C.Structure):
@@ -450,6 +450,7 @@ class Column:
     data: Optional[np.ndarray] = None     # uint8
     nanos: Optional[np.ndarray] = None    # int32
     validity: Optional[np.ndarray] = None  # bool[n] (python side), bitmap on the C side
+    absent: Optional[np.ndarray] = None    # bool[n]: rows whose ColumnNames leave this column out (tfgpu_column.absent); None = none
 
     def nrows(self) -> int:
         return int(len(self.offsets) - 1) if self.repr in VAR_REPRS else int(len(self.values))
@@ -534,6 +535,12 @@ class Batch:
                     bm = np.zeros(1, np.uint8)
                 keep.append(bm)
                 arr[i].validity = bm.ctypes.data
+            if getattr(c, "absent", None) is not None:  # rows whose ColumnNames leave this column out (tfgpu_column.absent)
+                ab = pack_validity(c.absent, self.nrows)
+                if len(ab) == 0:
+                    ab = np.zeros(1, np.uint8)
+                keep.append(ab)
+                arr[i].absent = ab.ctypes.data
         cb = CBatch()
         cb.nrows, cb.ncols, cb.cols = self.nrows, len(self.cols), arr
         ns, tn = _b(self.table_ns), _b(self.table_name)
@@ -597,6 +604,8 @@ def _column_from_c(c, n):
                 col.nanos = _np_from_ptr(c.nanos, n, np.int32)
         if c.validity:
             col.validity = unpack_validity(_np_from_ptr(c.validity, (n + 7) // 8, np.uint8), n)
+        if c.absent:
+            col.absent = unpack_validity(_np_from_ptr(c.absent, (n + 7) // 8, np.uint8), n)
         return col
 
 

@@ -203,7 +203,7 @@ int tfgpu_apply(tfgpu_plan *const *plans, int nplans, const tfgpu_dbatch *in, tf
 
 int tfgpu_partition(const tfgpu_dbatch *in, int nparts, tfgpu_dbatch **out, int64_t *counts) {
   TF_API_BEGIN
-  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(in, true);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!in || !out || !counts || nparts < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_partition: bad argument");
   std::lock_guard<std::mutex> lk(ctx().mu);
   *out = partition_rows(*in, nparts, counts).release();

@@ -19,9 +19,14 @@
 //   6. flags → one scan → three selection vectors → gathers: result = non-row items, rows by hashKToIdx, deletes.
 //
 // A collapsed row takes Kind / OldKeys / PartID / source position from its first item and ColumnValues from its last
-// writer; a Delete that follows an item with OldKeys inherits those OldKeys (change_item_collapse.go:111-118).  The
-// columnar batch has ONE ColumnNames list, so the compareColumns merge (:7-35, TOAST updates with fewer columns) is the
-// host's: the shim routes batches whose items differ in ColumnNames to the Go path.
+// writer; a Delete that follows an item with OldKeys inherits those OldKeys (change_item_collapse.go:111-118).
+//
+// The compareColumns merge (:7-35, :86-100; TOAST updates that leave columns out): the columnar batch has ONE column list, and a
+// row whose ColumnNames leave a column out marks the cell ABSENT (DColumn::absent).  The walk links every merged item to the item
+// it merged into (prev[]); a surviving row then takes each column from the LAST item of its chain that lists it
+// (collapse_merge_cols: one lane per (row, column that can be absent) walks the chain back), and lists the union.  The reference
+// APPENDS the names a later item brings (`total`), the columnar form keeps batch order: collapse_merge_order refuses — by name,
+// the Go path takes the batch — a chain whose merged name order is not batch order.
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -218,6 +223,12 @@ struct WalkParams {
   const uint8_t *kind;
   int32_t *rows_m, *rows_v, *k2idx, *del_i, *del_o;  // per key id
   uint32_t *ak;                  // per row: the key the row was filed under
+  int32_t *prev;                 // per row, only for batches with ABSENT cells: the item this Update merged into (-1: it starts a chain)
+  // only when a PRIMARY-KEY column can be absent: a merged row's current key is no longer its last writer's — an Update that lists
+  // none of the key columns leaves the chain's key as it was (TestCollapse "multiple PK, toast")
+  const uint8_t *keyform;        // per row: 0 = lists every key column, 1 = lists none, 2 = some (refused)
+  uint32_t *rows_kc;             // per key id: CurrentKeysString of the merged row filed there
+  uint32_t *bad;
 };
 __global__ void __launch_bounds__(256) collapse_walk(WalkParams p) {
   const int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,16 +244,28 @@ __global__ void __launch_bounds__(256) collapse_walk(WalkParams p) {
     if (kind == TFGPU_K_INSERT) {
       p.del_i[ko] = -1;
       p.rows_m[ko] = i; p.rows_v[ko] = i; p.k2idx[ko] = i; p.ak[i] = ko;
+      if (p.prev) p.prev[i] = -1;
+      if (p.rows_kc) p.rows_kc[ko] = kc;
     } else if (kind == TFGPU_K_UPDATE) {
       p.del_i[ko] = -1;
       const int32_t m = p.rows_m[ko];
       if (m < 0) {  // nothing to merge into: filed under its CURRENT key
         p.rows_m[kc] = i; p.rows_v[kc] = i; p.k2idx[kc] = i; p.ak[i] = kc;
+        if (p.prev) p.prev[i] = -1;
+        if (p.rows_kc) p.rows_kc[kc] = kc;
       } else {      // current.ColumnValues = c.ColumnValues; the row keeps the first item's Kind and OldKeys
+        if (p.prev) p.prev[i] = p.rows_v[ko];  // (compareColumns: columns this item leaves out keep the value of the chain before it)
         const uint32_t km = p.kind[m], krom = p.keyid[2 * (int64_t)m + 1];
-        const uint32_t newk = ((km == TFGPU_K_UPDATE || km == TFGPU_K_DELETE) && krom != NOKEY) ? krom : kc;
+        uint32_t cur = kc;  // CurrentKeysString of the merged row: the key columns come from the last item that lists them
+        if (p.rows_kc) {
+          const uint32_t form = p.keyform[i];
+          if (form == 1) cur = p.rows_kc[ko];
+          else if (form == 2) *p.bad = 1;
+        }
+        const uint32_t newk = ((km == TFGPU_K_UPDATE || km == TFGPU_K_DELETE) && krom != NOKEY) ? krom : cur;
         if (newk != ko) p.rows_m[ko] = -1;
         p.rows_m[newk] = m; p.rows_v[newk] = i; p.k2idx[newk] = i; p.ak[i] = newk;
+        if (p.rows_kc) p.rows_kc[newk] = cur;
       }
     } else if (kind == TFGPU_K_DELETE) {
       const int32_t m = p.rows_m[ko];
@@ -279,6 +302,63 @@ __global__ void __launch_bounds__(256) collapse_select(int64_t n, const uint8_t 
   if (c == 1) { const uint32_t k = ak[i]; m = rows_m[k]; v = rows_v[k]; o = m; }
   else if (c == 2) o = del_o[ak[i]];
   sel_meta[a] = m; sel_val[a] = v; sel_old[a] = o;
+}
+// which of its PRIMARY-KEY columns a row lists (only launched when one of them can be absent)
+__global__ void __launch_bounds__(256) collapse_keyform(int64_t n, int nk, const uint8_t *const *kabs, uint8_t *form) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int out = 0;
+  for (int k = 0; k < nk; k++) if (kabs[k] && ((kabs[k][r >> 3] >> (r & 7)) & 1u)) out++;
+  form[r] = out == 0 ? 0 : out == nk ? 1 : 2;
+}
+// ---- the compareColumns merge over ABSENT cells (change_item_collapse.go:7-35, :86-100) --------------------------
+// Output row k = the chain sel_meta[k] (first item) … sel_val[k] (last writer), linked backwards by prev[].  Column j of the row
+// comes from the last item of the chain that lists it: sel_col[j][k]; none does → the last writer's (absent) cell, and the row
+// does not list the column.  first_at[j][k] = how far behind the last writer the EARLIEST item listing the column sits (the
+// reference's `total` orders names by first appearance); NEVER for a column no item lists.
+struct MergeParams {
+  int64_t m, n;
+  const int32_t *sel_meta, *sel_val, *prev;
+  const uint8_t *const *absent;  // [na] bitmaps of the columns that can be absent
+  int32_t *sel_col;              // [na][m]
+  uint32_t *first_at;            // [na][m]
+};
+static constexpr uint32_t NEVER = 0xFFFFFFFFu;
+__global__ void __launch_bounds__(256) collapse_merge_cols(MergeParams p) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= p.m) return;
+  const int j = blockIdx.y;
+  const uint8_t *ab = p.absent[j];
+  const int32_t head = p.sel_meta[k], tail = p.sel_val[k];
+  int32_t r = tail, src = -1;
+  uint32_t d = 0, first = NEVER;
+  for (int64_t guard = 0; guard <= p.n; guard++) {
+    if (!((ab[r >> 3] >> (r & 7)) & 1u)) { if (src < 0) src = r; first = d; }
+    if (r == head) break;
+    const int32_t q = p.prev[r];
+    if (q < 0) break;
+    r = q; d++;
+  }
+  p.sel_col[(int64_t)j * p.m + k] = src < 0 ? tail : src;
+  p.first_at[(int64_t)j * p.m + k] = first;
+}
+// `total` = the first item's names, then what every later item brings, in that item's order: batch order exactly when, walking the
+// batch's columns, the first appearance never moves EARLIER in the chain (a column every row lists appears with the first item).
+__global__ void __launch_bounds__(256) collapse_merge_order(MergeParams p, const int32_t *__restrict__ acol /* [ncols]: index among the absent-capable columns or -1 */, int ncols, uint32_t *bad) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= p.m) return;
+  const int32_t head = p.sel_meta[k];
+  int32_t r = p.sel_val[k];
+  uint32_t len = 0;  // distance of the first item from the last writer
+  for (int64_t guard = 0; guard <= p.n && r != head; guard++) { const int32_t q = p.prev[r]; if (q < 0) break; r = q; len++; }
+  if (!len) return;  // one item: its own names
+  uint32_t last = len;
+  for (int c = 0; c < ncols; c++) {
+    const uint32_t f = acol[c] < 0 ? len : p.first_at[(int64_t)acol[c] * p.m + k];
+    if (f == NEVER) continue;
+    if (f > last) { *bad = 1; return; }
+    last = f;
+  }
 }
 __global__ void __launch_bounds__(256) collapse_any_non_insert(const uint8_t *kind, int64_t n, uint32_t *flag) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -392,10 +472,25 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   }
   timer.reset(); timer = std::make_unique<KernelTimer>("collapse_walk");
   Buf ak = dalloc((size_t)n * 4);
+  std::vector<size_t> acols;  // the columns some row leaves out of its ColumnNames
+  for (size_t c = 0; c < in.cols.size(); c++) if (in.cols[c].absent) acols.push_back(c);
+  Buf prev = acols.empty() ? nullptr : dalloc((size_t)n * 4);
   WalkParams wp{};
   wp.n = n; wp.sroot = ptr<uint32_t>(sroot); wp.sidx = ptr<uint32_t>(sidx); wp.keyid = ptr<uint32_t>(keyid); wp.kind = ptr<uint8_t>(in.kind);
   wp.rows_m = ptr<int32_t>(rows_m); wp.rows_v = ptr<int32_t>(rows_v); wp.k2idx = ptr<int32_t>(k2idx); wp.del_i = ptr<int32_t>(del_i); wp.del_o = ptr<int32_t>(del_o);
-  wp.ak = ptr<uint32_t>(ak);
+  wp.ak = ptr<uint32_t>(ak); wp.prev = ptr<int32_t>(prev);
+  Buf keyform, rows_kc, badform;
+  {
+    std::vector<const uint8_t *> kabs;  // the key columns the batch holds, with their absent bitmaps
+    bool any = false;
+    for (size_t k = 0; k < names.size(); k++) if (const DColumn *c = find_col(in.cols, names[k])) { kabs.push_back(ptr<uint8_t>(c->absent)); any |= (bool)c->absent; }
+    if (any) {
+      Buf bk = upload_small(kabs.data(), kabs.size() * sizeof(uint8_t *));
+      keyform = dalloc((size_t)n); rows_kc = dalloc((size_t)cap * 4); badform = dalloc_zero(4);
+      collapse_keyform<<<cgrid(n), 256, 0, st>>>(n, (int)kabs.size(), ptr<const uint8_t *>(bk), ptr<uint8_t>(keyform));
+      wp.keyform = ptr<uint8_t>(keyform); wp.rows_kc = ptr<uint32_t>(rows_kc); wp.bad = ptr<uint32_t>(badform);
+    }
+  }
   collapse_walk<<<cgrid(n), 256, 0, st>>>(wp);
   timer.reset(); timer = std::make_unique<KernelTimer>("collapse_select");
   Buf f = dalloc((size_t)(3 * n + 1) * 4 + 16);
@@ -403,8 +498,11 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   exclusive_scan_u32(ptr<uint32_t>(f), ptr<uint32_t>(f), 3 * n, true);
   const uint32_t *hm = d2h_u32(ptr<uint32_t>(f) + 3 * n);
   const uint32_t *hbad = d2h_u32(bad->p);
+  const uint32_t *hbadform = badform ? d2h_u32(badform->p) : nullptr;
   timer.reset();
   sync();
+  if (hbadform && *hbadform) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: an Update that merges into an earlier row lists some of the primary-key columns and leaves others out "
+                                                                "(the merged row's key would mix two items' values)");
   if (*hbad) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: NaN / Inf in a primary-key column (json.Marshal fails on the key; the reference files every such row under the empty key)");
   const int64_t m = *hm;
   Buf sel_meta = dalloc((size_t)m * 4 + 4), sel_val = dalloc((size_t)m * 4 + 4), sel_old = dalloc((size_t)m * 4 + 4);
@@ -416,7 +514,42 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   // for a Delete, from the row it removed)
   tfgpu_dbatch vals_in = in;
   vals_in.old_keys.clear(); vals_in.old_present = nullptr; vals_in.kind = nullptr; vals_in.part_id = nullptr; vals_in.src_row = nullptr;
-  auto out = gather_rows(vals_in, sel_val, m);
+  std::unique_ptr<tfgpu_dbatch> out;
+  if (acols.empty() || !m) out = gather_rows(vals_in, sel_val, m);
+  else {  // compareColumns: every column that can be absent through its own selection (the last item of the chain that lists it)
+    const size_t na = acols.size();
+    std::vector<const uint8_t *> abs(na);
+    std::vector<int32_t> acol(in.cols.size(), -1);
+    for (size_t a = 0; a < na; a++) { abs[a] = ptr<uint8_t>(in.cols[acols[a]].absent); acol[acols[a]] = (int32_t)a; }
+    Buf babs = upload_small(abs.data(), na * sizeof(uint8_t *)), bacol = upload_small(acol.data(), acol.size() * 4), border = dalloc_zero(4);
+    Buf sel_col = dalloc(na * (size_t)m * 4), first_at = dalloc(na * (size_t)m * 4);
+    MergeParams mp{};
+    mp.m = m; mp.n = n; mp.sel_meta = ptr<int32_t>(sel_meta); mp.sel_val = ptr<int32_t>(sel_val); mp.prev = ptr<int32_t>(prev);
+    mp.absent = ptr<const uint8_t *>(babs); mp.sel_col = ptr<int32_t>(sel_col); mp.first_at = ptr<uint32_t>(first_at);
+    {
+      KernelTimer tm("collapse_merge");
+      collapse_merge_cols<<<dim3(cgrid(m), (unsigned)na), 256, 0, st>>>(mp);
+      collapse_merge_order<<<cgrid(m), 256, 0, st>>>(mp, ptr<int32_t>(bacol), (int)acol.size(), ptr<uint32_t>(border));
+    }
+    const uint32_t *hbo = d2h_u32(border->p);
+    sync();
+    if (*hbo) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: an Update brings a column its row did not list, in front of one it did — the merged ColumnNames (compareColumns appends "
+                                                 "new names, change_item_collapse.go:24-33) are not in the batch's column order");
+    tfgpu_dbatch rest = vals_in;
+    rest.cols.clear();
+    for (size_t c = 0; c < in.cols.size(); c++) if (acol[c] < 0) rest.cols.push_back(in.cols[c]);
+    out = gather_rows(rest, sel_val, m);
+    std::vector<DColumn> merged(in.cols.size());
+    size_t ri = 0;
+    for (size_t c = 0; c < in.cols.size(); c++) {
+      if (acol[c] < 0) { merged[c] = std::move(out->cols[ri++]); continue; }
+      tfgpu_dbatch one;
+      one.nrows = n; one.cols.push_back(in.cols[c]);
+      auto g = gather_rows(one, subbuf(sel_col, (size_t)acol[c] * (size_t)m * 4, (size_t)m * 4), m);  // (its absent bitmap travels with it: still absent = no item listed it)
+      merged[c] = std::move(g->cols[0]);
+    }
+    out->cols = std::move(merged);
+  }
   tfgpu_dbatch meta_in;
   meta_in.nrows = n; meta_in.kind = in.kind; meta_in.part_id = in.part_id; meta_in.src_row = in.src_row;
   auto meta = gather_rows(meta_in, sel_meta, m);
@@ -471,7 +604,7 @@ int64_t keys_changed_rows(const tfgpu_dbatch &in, uint8_t *host_flags) {
 
 extern "C" int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed, int64_t *nchanged) {
   try {
-  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(in, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT cells are read here
     if (!in || !changed) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_keys_changed: null argument");
     std::lock_guard<std::mutex> lk(tf::ctx().mu);
     const int64_t c = tf::keys_changed_rows(*in, changed);
@@ -484,7 +617,7 @@ extern "C" int tfgpu_keys_changed(const tfgpu_dbatch *in, uint8_t *changed, int6
 
 extern "C" int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out) {
   try {
-  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(in, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT cells are read here
     if (!in || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_collapse: null argument");
     std::lock_guard<std::mutex> lk(tf::ctx().mu);
     *out = tf::collapse_rows(*in).release();

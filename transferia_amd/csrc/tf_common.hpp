@@ -191,6 +191,7 @@ struct DColumn {
   int dtype = TFGPU_T_INVALID;
   int repr = TFGPU_R_INVALID;
   Buf values, offsets, data, nanos, validity;
+  Buf absent;  // bitmap, bit r = 1: row r's ColumnNames do not list this column (tfgpu_column.absent); null = every row lists it
   uint64_t data_len = 0;
   std::shared_ptr<TextView> view;  // non-null while `data` may still be unpacked
   const Buf &payload() const { return (!data && view) ? view->packed : data; }
@@ -200,8 +201,11 @@ struct DColumn {
 void materialize(const struct ::tfgpu_dbatch &b, const std::vector<const DColumn *> *only = nullptr);
 // Gathers the rows of a batch whose rows are still a selection (tfgpu_dbatch::pending); no-op otherwise.  dense() takes the lane's
 // mutex itself (call it BEFORE locking); dense_locked() is for callers that hold it.
-void dense(const struct ::tfgpu_dbatch *b);
+// dense() also REFUSES (TFGPU_ERR_UNSUPPORTED, by name) a batch that holds ABSENT cells (DColumn::absent) unless the caller says it
+// reads them (collapse, keys_changed, view / download, the row movers): an entry that computes on values would read them as nil.
+void dense(const struct ::tfgpu_dbatch *b, bool absent_ok = false);
 void dense_locked(const struct ::tfgpu_dbatch &b);
+bool has_absent(const struct ::tfgpu_dbatch &b);
 // The library-owned HBM block that starts at `p` (a tfgpu_dbuf), or null for foreign pointers.
 Buf find_device_block(const void *p);
 void register_device_block(const Buf &b);

@@ -401,6 +401,7 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
       if (c.repr == TFGPU_R_TIME && c.nanos) d.nanos = upload(c.nanos, n * 4);
     }
     if (c.validity) d.validity = upload(c.validity, (n + 7) / 8);
+    if (c.absent && !is_old) d.absent = upload(c.absent, (n + 7) / 8);  // (OldKeys say which rows have them through old_keys_present)
     (is_old ? b->old_keys : b->cols).push_back(std::move(d));
   }
   if (h->n_old_keys && h->old_keys_present) b->old_present = upload(h->old_keys_present, (n + 7) / 8);
@@ -426,14 +427,14 @@ int64_t tfgpu_dbatch_nrows(const tfgpu_dbatch *b) { return b ? b->nrows : -1; }
 int tfgpu_dbatch_dense(const tfgpu_dbatch *b) {
   TF_API_BEGIN
   if (!b) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_dense: null argument");
-  tf::dense(b);
+  tf::dense(b, true);
   return TFGPU_OK;
   TF_API_END
 }
 
 int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   TF_API_BEGIN
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(b, true);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !v) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_view: null argument");
   { std::lock_guard<std::mutex> lk(ctx().mu); materialize(*b); }  // the view exposes packed payload pointers
   g_view.cols.assign(b->cols.size() + b->old_keys.size(), tfgpu_column{});
@@ -443,7 +444,7 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
     c.name = d.name.c_str(); c.dtype = d.dtype; c.repr = d.repr;
     c.values = d.values ? d.values->p : nullptr;
     c.offsets = ptr<uint32_t>(d.offsets); c.data = ptr<uint8_t>(d.payload()); c.data_len = d.data_len;
-    c.nanos = ptr<int32_t>(d.nanos); c.validity = ptr<uint8_t>(d.validity);
+    c.nanos = ptr<int32_t>(d.nanos); c.validity = ptr<uint8_t>(d.validity); c.absent = ptr<uint8_t>(d.absent);
   }
   v->nrows = b->nrows; v->ncols = (int32_t)b->cols.size(); v->cols = g_view.cols.data();
   v->table_ns = b->ns.c_str(); v->table_name = b->table.c_str();
@@ -469,7 +470,7 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
 
 int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
   TF_API_BEGIN
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(b, true);  // its rows may still be a selection (tfgpu_dbatch::pending)
   if (!b || !h) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: null argument");
   if (h->ncols != (int32_t)b->cols.size() || h->nrows != b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: shape mismatch");
   if (h->n_old_keys && h->n_old_keys != (int32_t)b->old_keys.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: old-key shape mismatch");
@@ -487,6 +488,7 @@ int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
       if (c.nanos && d.nanos) d2h(c.nanos, d.nanos->p, n * 4);
     }
     if (c.validity && d.validity) d2h(c.validity, d.validity->p, (n + 7) / 8);
+    if (c.absent && d.absent) d2h(c.absent, d.absent->p, (n + 7) / 8);
   }
   if (h->kind && b->kind) d2h(h->kind, b->kind->p, n);
   if (h->src_row && b->src_row) d2h(h->src_row, b->src_row->p, n * 4);

@@ -684,6 +684,7 @@ static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const 
       if (c.nanos) { o.nanos = dalloc((size_t)m * 4); fx.push_back(GFix{c.nanos->p, o.nanos->p, 4, 0}); }
     }
     if (c.validity) { o.validity = dalloc((size_t)(m + 7) / 8 + 1); bits.push_back(GBit{ptr<uint8_t>(c.validity), ptr<uint8_t>(o.validity)}); }
+    if (c.absent) { o.absent = dalloc((size_t)(m + 7) / 8 + 1); bits.push_back(GBit{ptr<uint8_t>(c.absent), ptr<uint8_t>(o.absent)}); }  // a moved row keeps its ColumnNames
     (ai < ncur ? out->cols : out->old_keys).push_back(std::move(o));
   }
   auto out_at = [&](size_t i) -> DColumn & { return i < ncur ? out->cols[i] : out->old_keys[i - ncur]; };
@@ -771,8 +772,19 @@ void dense_locked(const tfgpu_dbatch &b) {
   mb.replaced.clear();
   mb.pending.reset();
 }
-void dense(const tfgpu_dbatch *b) {
-  if (!b || !b->pending) return;
+bool has_absent(const tfgpu_dbatch &b) {
+  for (auto &c : (b.pending ? b.pending->src->cols : b.cols)) if (c.absent) return true;
+  return false;
+}
+void refuse_absent(const tfgpu_dbatch &b) {
+  if (has_absent(b))
+    throw Error(TFGPU_ERR_UNSUPPORTED, "the batch holds ABSENT cells (rows whose ColumnNames leave a column out: TOASTed updates, tfgpu_column.absent); this entry computes on values and "
+                                       "does not read them — tfgpu_collapse, tfgpu_keys_changed, tfgpu_partition, view / download do");
+}
+void dense(const tfgpu_dbatch *b, bool absent_ok) {
+  if (!b) return;
+  if (!absent_ok) refuse_absent(*b);
+  if (!b->pending) return;
   std::lock_guard<std::mutex> lk(ctx().mu);
   dense_locked(*b);
 }
@@ -1701,6 +1713,7 @@ std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &in, int nparts,
 }
 
 std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {
+  refuse_absent(in);  // transformers compute on values: an ABSENT cell is not a nil (the stock path takes the batch)
   if (in.pending && p.kind != PK_MASK) dense_locked(in);  // (the callers hold the lane's mutex) only mask_field reads through a selection
   switch (p.kind) {
     case PK_MASK: return apply_mask(p, in);

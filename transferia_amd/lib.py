@@ -381,6 +381,11 @@ class DeviceBatch:
                 keep.append(bm)
                 carr[i].validity = bm.ctypes.data
                 col._bm = bm
+            if c.absent:
+                ab = np.zeros((n + 7) // 8 + 1, np.uint8)
+                keep.append(ab)
+                carr[i].absent = ab.ctypes.data
+                col._ab = ab
             cols.append(col)
         hb = abi.CBatch()
         hb.nrows, hb.ncols, hb.cols, hb.mem = n, v.ncols, carr, abi.MEM_HOST
@@ -407,6 +412,8 @@ class DeviceBatch:
                     col.nanos = col.nanos[:n]
             if hasattr(col, "_bm"):
                 col.validity = abi.unpack_validity(col._bm, n)
+            if hasattr(col, "_ab"):
+                col.absent = abi.unpack_validity(col._ab, n)
         b = abi.Batch(cols[: v.ncols], n, (v.table_ns or b"").decode(), (v.table_name or b"").decode())
         if nold:
             b.old_keys = cols[v.ncols:]
