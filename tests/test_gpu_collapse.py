@@ -374,3 +374,41 @@ def _without_absent(b):
     c = abi.Batch([dataclasses.replace(col, absent=None) for col in b.cols], b.nrows, b.table_ns, b.table_name, b.kind, b.src_row, b.part_id)
     c.schema = b.schema
     return c
+
+
+def test_toast_rows_through_collapse_and_the_native_queue_format(tf, oracle):
+    """A TOAST stream → tfgpu_collapse → NativeSerializer on the device: every message byte for byte the oracle's ChangeItem.MarshalJSON
+    (change_item.go:568-616) of the same rows — each row writes its OWN columnnames, and columnvalues only when it lists a column."""
+    from collapse_cases import random_toast_items, batch_from_items, items_of
+    names = ["id"] + ["c%d" % j for j in range(5)]
+    done, seen = 0, set()
+    for seed in range(6):
+        items = random_toast_items(300 + seed, 120, toastable=[3, 4], p_absent=0.5, weights=(3, 6, 2, 0))
+        for it in items[::17]:                      # some rows list nothing at all (a Delete named by its OldKeys alone)
+            if it["kind"] == "delete":
+                it["names"], it["values"] = [], []
+                it.setdefault("old_names", ["id"]); it.setdefault("old_values", [["int64", 1]])
+        b, schema = batch_from_items(items, names=names)
+        N = b.nrows
+        meta = abi.row_meta(N, ids=np.arange(N) % 97, lsns=np.arange(N, dtype=np.uint64) + 5, commit_times=np.full(N, 1700000000000000000, np.uint64))
+        o = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 12, table_schema=schema)
+        db = tf.DeviceBatch.upload(b)
+        for dev in (db, None):                      # the stream as it came, then what Collapse leaves of it
+            if dev is None:
+                try:
+                    dev = tf.collapse(db)
+                except tf.TfgpuError as e:
+                    assert "column order" in str(e)
+                    continue
+            host = dev.download()
+            host.schema = schema
+            want = oracle.queue_serialize(o, host, schema, meta)
+            got = tf.queue_serialize(o, dev, meta).messages()
+            assert got == want and got, seed
+            seen.update(x for m in got for x in (b'"columnnames":["id","c0","c1","c2"]', b'"columnnames":["id","c0","c1","c2","c4"]', b'"columnnames":[],"table_schema"',
+                                                 b'"columnnames":["id","c0","c1","c2","c3","c4"]') if x in m)
+            done += 1
+    assert done >= 8 and len(seen) == 4, (done, seen)
+    # the JSON queue format computes on values: it says no, by name
+    with pytest.raises(tf.TfgpuError, match="ABSENT"):
+        tf.queue_serialize(abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=1 << 12), db, None)

@@ -104,7 +104,8 @@ def items_of(batch, cols, meta_lists=None):
     for r in range(batch.nrows):
         k = "insert" if batch.kind is None else kind_name.get(int(batch.kind[r]), "other")
         has = bool(old) and (pres is None or bool(pres[r]))
-        out.append(E.Item(k, batch.table_ns, batch.table_name, cols, [c.name for c in batch.cols], [tuple(c.pyvalue(r)) for c in batch.cols],
+        listed = [c for c in batch.cols if getattr(c, "absent", None) is None or not c.absent[r]]  # the row's own ColumnNames (tfgpu_column.absent)
+        out.append(E.Item(k, batch.table_ns, batch.table_name, cols, [c.name for c in listed], [tuple(c.pyvalue(r)) for c in listed],
                           [c.name for c in old] if has else [], [tuple(c.pyvalue(r)) for c in old] if has else [], ids[r], lsns[r], cts[r], txs[r]))
     return out
 
@@ -229,6 +230,29 @@ def test_parameter_variants(tf):
     # no rows, and rows of a non-row kind: no messages
     empty = abi.batch_from_rows(schema_of(table), [t[0] for t in table], [], "public", "crud")
     assert len(tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(table)), tf.DeviceBatch.upload(empty))) == 0
+
+
+def test_toasted_updates_write_the_placeholder_per_row(tf):
+    """Rows that leave columns out of their ColumnNames (tfgpu_column.absent: Updates with TOASTed columns unchanged) get the placeholder for exactly
+    those columns (buildKV, emitter_value_converter.go:311-323) — in `after` of the update and of the create event a key change fans out into; a
+    batch whose rows leave a KEY column out stays with the stock emitter, by name."""
+    for full_identity in (False, True):
+        table, b = crud_batch(300, 21 + full_identity, full_identity)
+        rng = np.random.default_rng(5)
+        upd = b.kind == abi.K_UPDATE
+        for c in b.cols[2:]:
+            ab = upd & (rng.random(b.nrows) < 0.5)
+            c.absent = ab
+            c.validity = (np.ones(b.nrows, bool) if c.validity is None else c.validity) & ~ab
+        n = b.nrows
+        meta = (list(range(n)), list(range(n)), [10 ** 18 + r for r in range(n)])
+        for params in ({}, {"unavailable.value.placeholder": "<toast \"q\">"}, {"dt.source.type": "mysql"}):
+            got, want, rows = emit_both(tf, b, table, dict(PARAMS, **params), meta)
+            assert_same(got, want, rows)
+        assert sum(b'"s":"__debezium_unavailable_value"' in v for _, v in got.messages() if v) > 20
+    b.cols[0].absent = upd
+    with pytest.raises(tf.TfgpuError, match="primary-key column id"):
+        tf.debezium_emit(abi.dbz_emit_options(PARAMS, schema_of(table)), tf.DeviceBatch.upload(b))
 
 
 def test_rows_moved_by_a_transformer_no_meta_and_keyless_tables(tf):

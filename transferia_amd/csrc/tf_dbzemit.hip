@@ -58,6 +58,8 @@ struct ECell {
   uint32_t from_old;          // the column is an OldKeys column: nil in rows without OldKeys
   uint32_t edk;               // DK_ARR_ELEM: the converter of one element
   DCol alt; uint32_t dk_alt, has_alt;  // … unless the row's own value stands in (a MySQL delete's `before`: ColumnValues under the OldKeys)
+  const uint8_t *absent;      // `after` members of a batch whose rows list different columns (DColumn::absent): a row that leaves the column out
+  uint32_t ph_off, ph_len;    // … writes the TOAST placeholder here (buildKV, emitter_value_converter.go:311-323), whatever the column's type
 };
 struct EParams {
   const ECell *cells; int32_t ncells;
@@ -737,6 +739,7 @@ template <class S> __device__ __forceinline__ int emit_cell(S &s, const EParams 
   if (ec.kind == EC_CONST) { put_bytes(s, p.blob + ec.pre_off, ec.pre_len); return 0; }
   if (ec.kind == EC_TAIL) { emit_tail(s, p, e, r); return 0; }
   put_bytes(s, p.blob + ec.pre_off, ec.pre_len);
+  if (ec.absent && ((ec.absent[r >> 3] >> (r & 7)) & 1u)) { put_bytes(s, p.blob + ec.ph_off, ec.ph_len); return 0; }  // TOASTed: not among the row's ColumnNames
   if (ec.from_old && !row_has_old(p, r)) {
     if (!ec.has_alt) { put_lit(s, "null"); return 0; }
     const CellBits b = load_cell(ec.alt, r);
@@ -1247,8 +1250,14 @@ static void push_object(CellList &L, uint32_t apply, std::vector<Member> ms) {
   if (ms.empty()) { L.push_const(apply, "{}"); return; }
   for (size_t i = 0; i < ms.size(); i++) {
     const std::string pre = std::string(i ? "," : "{") + jstr(ms[i].name) + ":";
-    if (ms[i].col) L.push_value(apply, pre, *ms[i].col, *ms[i].plan, ms[i].from_old, ms[i].alt);
-    else L.push_const(apply, pre + ms[i].constant);
+    if (ms[i].col) {
+      L.push_value(apply, pre, *ms[i].col, *ms[i].plan, ms[i].from_old, ms[i].alt);
+      if (!ms[i].constant.empty() && ms[i].col->absent) {  // rows that leave the column out write this constant instead (the TOAST placeholder)
+        ECell &c = L.cells.back();
+        c.absent = ptr<uint8_t>(ms[i].col->absent); c.ph_off = (uint32_t)L.blob->size(); c.ph_len = (uint32_t)ms[i].constant.size();
+        *L.blob += ms[i].constant;
+      }
+    } else L.push_const(apply, pre + ms[i].constant);
   }
   L.push_const(apply, "}");
 }
@@ -1347,7 +1356,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
                                    tfgpu_dbuf **values, uint64_t *val_start, uint8_t *val_null, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
   using namespace tf; using namespace tf::dbz;
   try {
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(b, true);  // its rows may still be a selection (tfgpu_dbatch::pending); rows that leave columns out (ABSENT cells) get the TOAST placeholder
     if (!o || !b || !keys || !values || !nmsg || !o->table_schema || (cap > 0 && (!key_start || !val_start || !val_null || !msg_row)))
       return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: null argument");
     if (o->nparams < 0 || (o->nparams > 0 && (!o->param_keys || !o->param_values))) return fail(TFGPU_ERR_INVALID, "tfgpu_debezium_emit: nparams without the key / value arrays");
@@ -1494,7 +1503,7 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
       V.push_const(EA_AFTER_NULL, "null");
       std::vector<Member> after;
       std::vector<char> in_batch((size_t)ts.ncols, 0);
-      for (auto &c : b->cols) { const int i = col_index(c.name); in_batch[(size_t)i] = 1; after.push_back({c.name, &c, &plans[(size_t)i], false, ""}); }
+      for (auto &c : b->cols) { const int i = col_index(c.name); in_batch[(size_t)i] = 1; after.push_back({c.name, &c, &plans[(size_t)i], false, c.absent ? jstr(P.get("unavailable.value.placeholder")) : std::string()}); }
       if (ts.ncols > (int)b->cols.size())  // TOAST (buildKV :311-323)
         for (int i = 0; i < ts.ncols; i++) if (!in_batch[(size_t)i]) after.push_back({ts.cols[i].name ? ts.cols[i].name : "", nullptr, nullptr, false, jstr(P.get("unavailable.value.placeholder"))});
       push_object(V, EA_AFTER, after);
@@ -1547,7 +1556,12 @@ extern "C" int tfgpu_debezium_emit(const tfgpu_dbz_emit_options *o, const tfgpu_
     if (!o->drop_keys) {
       if (key_schema) K.push_const(EA_KEY, "{\"payload\":");
       std::vector<Member> from_new, from_old;
-      for (auto &c : b->cols) { const int i = col_index(c.name); if (ts.cols[i].flags & TFGPU_COL_KEY) from_new.push_back({c.name, &c, &plans[(size_t)i], false, ""}); }
+      for (auto &c : b->cols) {
+        const int i = col_index(c.name);
+        if (!(ts.cols[i].flags & TFGPU_COL_KEY)) continue;
+        if (c.absent) return fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_debezium_emit: rows leave the primary-key column " + c.name + " out of their ColumnNames (the message key then has fewer members: the stock emitter takes the batch)");
+        from_new.push_back({c.name, &c, &plans[(size_t)i], false, ""});
+      }
       for (auto &c : b->old_keys) { const int i = col_index(c.name); if (ts.cols[i].flags & TFGPU_COL_KEY) from_old.push_back({c.name, &c, &plans[(size_t)i], true, ""}); }
       push_object(K, EA_KEY_NEW, from_new);
       if (has_old) push_object(K, EA_KEY_OLD, from_old);

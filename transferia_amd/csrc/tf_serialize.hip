@@ -27,10 +27,14 @@ struct SCol {
   uint32_t prec;              // DateTime64 precision
   uint32_t kind;              // queue formats: QC_*
   uint32_t apply;             // queue formats: QA_* (which rows hold this cell)
+  const uint8_t *absent;      // native queue format, QA_LISTED cells: the column's ABSENT bitmap (DColumn::absent) or null; `prec` = the column's index
 };
 // queue formats (tfgpu_queue_serialize): a row is a list of cells — header, constants, values, old-key values, trailer
-enum { QC_VALUE = 0, QC_HEADER = 1, QC_CONST = 2, QC_TRAILER = 3 };
-enum { QA_ALWAYS = 0, QA_NAMES = 1 /* names_form == 0 */, QA_OLD = 2 /* the row has OldKeys */, QA_ROW_EVENT = 3 /* kind != other */ };
+enum { QC_VALUE = 0, QC_HEADER = 1, QC_CONST = 2, QC_TRAILER = 3, QC_NAME = 4 /* `,"name"`: an entry of a row's own columnnames */ };
+enum { QA_ALWAYS = 0, QA_NAMES = 1 /* names_form == 0 */, QA_OLD = 2 /* the row has OldKeys */, QA_ROW_EVENT = 3 /* kind != other */,
+       // batches whose rows list different columns (tfgpu_column.absent): a cell of a column the row lists (the first listed one drops its
+       // leading comma), a constant of rows that list any column at all (`,"columnvalues":[` … `]`: len(c.ColumnValues) > 0, change_item.go:600)
+       QA_LISTED = 4, QA_ANY_LISTED = 5 };
 constexpr uint32_t QCONST_INLINE = 64;  // constants up to this many bytes are written by the cell's lane, longer ones by ser_fill_const
 
 struct QueueParams {
@@ -46,6 +50,7 @@ struct QueueParams {
   int32_t ngroups;               // group part ids: rows [gstart[g], gstart[g+1]) carry blob[gpart[g] .. gpart[g+1])
   const int64_t *gstart; const uint32_t *gpart;
   const uint8_t *msg_flags;      // [nrows]: bit 0 = first row of its message, bit 1 = last
+  const int32_t *first_listed;   // [nrows], batches with ABSENT cells: the first column the row lists, -1 = none
 };
 
 struct SerParams {
@@ -203,8 +208,12 @@ template <class S> __device__ __forceinline__ void emit_csv_field(S &s, const SC
 }
 
 // ---- queue formats: ChangeItem.MarshalJSON (change_item.go:568-616) as json.Marshal compacts it, and the queue JSON rows ----
-__device__ __forceinline__ bool q_applies(const SerParams &p, uint32_t apply, int64_t r) {
+__device__ __forceinline__ bool q_applies(const SerParams &p, uint32_t apply, int64_t r, const uint8_t *absent = nullptr) {
   switch (apply) {
+    case QA_LISTED: if (absent && ((absent[r >> 3] >> (r & 7)) & 1u)) return false;
+      return !p.q.m_form || p.q.m_form[p.q.src_row ? p.q.src_row[r] : r] == 0;
+    case QA_ANY_LISTED: if (p.q.first_listed[r] < 0) return false;
+      return !p.q.m_form || p.q.m_form[p.q.src_row ? p.q.src_row[r] : r] == 0;
     case QA_NAMES: return !p.q.m_form || p.q.m_form[p.q.src_row ? p.q.src_row[r] : r] == 0;
     case QA_OLD: return p.q.has_old && (!p.q.old_present || ((p.q.old_present[r >> 3] >> (r & 7)) & 1));
     case QA_ROW_EVENT: return !p.q.kind || p.q.kind[r] <= TFGPU_K_DELETE;
@@ -243,14 +252,16 @@ template <class S> __device__ __forceinline__ void emit_native_trailer(S &s, con
   s.put('}');
 }
 template <class S> __device__ __forceinline__ bool emit_queue_cell(S &s, const SerParams &p, const SCol &sc, int64_t r) {
-  if (!q_applies(p, sc.apply, r)) return false;
+  if (!q_applies(p, sc.apply, r, sc.absent)) return false;
   switch (sc.kind) {
     case QC_HEADER: emit_native_header(s, p, r); return true;
     case QC_TRAILER: emit_native_trailer(s, p, r); return true;
     case QC_CONST: put_bytes(s, p.blob + sc.pre_off, sc.pre_len); return true;
     default: break;
   }
-  put_bytes(s, p.blob + sc.pre_off, sc.pre_len);
+  const uint32_t lead = (sc.apply == QA_LISTED && p.q.first_listed[r] == (int32_t)sc.prec) ? 1u : 0u;  // the row's first listed column: no comma in front
+  put_bytes(s, p.blob + sc.pre_off + lead, sc.pre_len - lead);
+  if (sc.kind == QC_NAME) return true;
   if (p.q.qformat == TFGPU_QFMT_NATIVE) {  // encoding/json with escapeHTML on; a pre-marshalled `any` passes through compact()
     const DCol &c = sc.c;
     if (c.repr == TFGPU_R_JSON && is_valid(c, r)) put_html_compact(s, c.data + c.offsets[r], c.offsets[r + 1] - c.offsets[r]);
@@ -335,7 +346,7 @@ __global__ void __launch_bounds__(256) ser_cell_write(SerParams p) {
   if (r >= p.nrows) return;
   const int64_t it = (int64_t)ci * p.nrows + r;
   const SCol &sc = p.cols[ci];
-  if (p.q.qformat && ((sc.kind == QC_CONST && sc.pre_len > QCONST_INLINE) || !q_applies(p, sc.apply, r))) return;
+  if (p.q.qformat && ((sc.kind == QC_CONST && sc.pre_len > QCONST_INLINE) || !q_applies(p, sc.apply, r, sc.absent))) return;
   if (p.format == TFGPU_FMT_CH_JSON_EACH_ROW && !is_valid(sc.c, r)) return;
   uint64_t base = (uint64_t)p.row_len[r] + p.cell[it];
   if (p.ablate == 4) base = (uint64_t)(it % (int64_t)(p.row_len[p.nrows] / 24)) * 24;  // measurement: every cell at a lane-contiguous 24-byte slot
@@ -657,6 +668,14 @@ __global__ void __launch_bounds__(256) ser_queue_frame(SerParams p) {
   const uint32_t f = p.q.msg_flags[r];
   if (p.q.qformat == TFGPU_QFMT_NATIVE) { row[0] = (f & 1) ? '[' : ','; if (f & 2) row[len - 1] = ']'; }
   else if (!(f & 2)) row[len - 1] = '\n';
+}
+// batches whose rows list different columns: the first column every row lists (its name and value carry no leading comma), -1 = none
+__global__ void __launch_bounds__(256) queue_first_listed(const uint8_t *const *absent, int ncols, int64_t n, int32_t *first) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int32_t f = -1;
+  for (int j = 0; j < ncols; j++) if (!absent[j] || !((absent[j][r >> 3] >> (r & 7)) & 1u)) { f = j; break; }
+  first[r] = f;
 }
 // A long constant cell (column names, table schema) of every row: one workgroup per (row, 4 KiB chunk), 16 bytes per lane,
 // so a wave stores 1 KiB of consecutive bytes per step instead of one lane walking kilobytes.
@@ -1430,7 +1449,7 @@ static int queue_json_chunks(const tfgpu_queue_options *o, const tfgpu_dbatch *b
 extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_dbatch *b, const tfgpu_row_meta *meta, tfgpu_dbuf **values,
                                      uint64_t *msg_start, int64_t *msg_row, int64_t cap, int64_t *nmsg) {
   try {
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(b, o && o->format == TFGPU_QFMT_NATIVE);  // its rows may still be a selection (tfgpu_dbatch::pending); the native format writes every row's own ColumnNames (ABSENT cells)
     if (!o || !b || !values || !nmsg || (cap > 0 && (!msg_start || !msg_row))) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: null argument");
     if (o->format != TFGPU_QFMT_NATIVE && o->format != TFGPU_QFMT_JSON) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: unknown format");
     const bool native = o->format == TFGPU_QFMT_NATIVE;
@@ -1477,6 +1496,7 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
     if (!native && !has_nonrow && !cell_passes) return queue_json_chunks(o, b, gstart, values, msg_start, msg_row, cap, nmsg);
 
     // ---- the cell list ----
+    const bool ragged = native && has_absent(*b);
     std::string blob;
     std::vector<SCol> sc;
     auto add = [&](uint32_t kind, uint32_t apply, const std::string &pre, const DColumn *col) {
@@ -1493,9 +1513,22 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
     if (native) {
       add(QC_HEADER, QA_ALWAYS, "", nullptr);
       { std::string t = ",\"schema\":"; json_key(t, b->ns, true); t += ",\"table\":"; json_key(t, b->table, true); t += ",\"part\":"; q.hdr_off = (uint32_t)blob.size(); q.hdr_len = (uint32_t)t.size(); blob += t; }
-      { std::string t = ",\"columnnames\":"; std::vector<std::string> nm; for (auto &c : b->cols) nm.push_back(c.name); json_string_array(t, nm); if (ncols) t += ",\"columnvalues\":["; add(QC_CONST, QA_NAMES, t, nullptr); }
-      for (int j = 0; j < ncols; j++) add(QC_VALUE, QA_NAMES, j ? "," : "", &b->cols[(size_t)j]);
-      if (ncols) add(QC_CONST, QA_NAMES, "]", nullptr);
+      if (!ragged) {
+        { std::string t = ",\"columnnames\":"; std::vector<std::string> nm; for (auto &c : b->cols) nm.push_back(c.name); json_string_array(t, nm); if (ncols) t += ",\"columnvalues\":["; add(QC_CONST, QA_NAMES, t, nullptr); }
+        for (int j = 0; j < ncols; j++) add(QC_VALUE, QA_NAMES, j ? "," : "", &b->cols[(size_t)j]);
+        if (ncols) add(QC_CONST, QA_NAMES, "]", nullptr);
+      } else {  // rows list different columns (tfgpu_column.absent): every row writes its own columnnames, and columnvalues only when it lists any
+        auto listed = [&](uint32_t kind, const std::string &pre, int j) {
+          add(kind, QA_LISTED, pre, kind == QC_VALUE ? &b->cols[(size_t)j] : nullptr);
+          sc.back().absent = ptr<uint8_t>(b->cols[(size_t)j].absent); sc.back().prec = (uint32_t)j;
+        };
+        add(QC_CONST, QA_NAMES, ",\"columnnames\":[", nullptr);
+        for (int j = 0; j < ncols; j++) { std::string t = ","; json_key(t, b->cols[(size_t)j].name, true); listed(QC_NAME, t, j); }
+        add(QC_CONST, QA_NAMES, "]", nullptr);
+        add(QC_CONST, QA_ANY_LISTED, ",\"columnvalues\":[", nullptr);
+        for (int j = 0; j < ncols; j++) listed(QC_VALUE, ",", j);
+        add(QC_CONST, QA_ANY_LISTED, "]", nullptr);
+      }
       { std::string t; if (!o->omit_table_schema) { if (o->table_schema_json) { t += ",\"table_schema\":"; t += o->table_schema_json; } else table_schema_json(t, o, b); } t += ",\"oldkeys\":{"; add(QC_CONST, QA_ALWAYS, t, nullptr); }
       for (int k = 0; k < nold; k++) {
         std::string t;
@@ -1545,6 +1578,16 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
       q.gstart = ptr<int64_t>(a); q.gpart = ptr<uint32_t>(c);
     }
 
+    Buf first_listed;
+    if (ragged) {
+      std::vector<const uint8_t *> abs((size_t)ncols);
+      for (int j = 0; j < ncols; j++) abs[(size_t)j] = ptr<uint8_t>(b->cols[(size_t)j].absent);
+      Buf babs = upload_small(abs.data(), abs.size() * sizeof(uint8_t *));
+      keep.push_back(babs);
+      first_listed = dalloc((size_t)n * 4);
+      queue_first_listed<<<blocks(n), 256, 0, st>>>(ptr<const uint8_t *>(babs), ncols, n, ptr<int32_t>(first_listed));
+      q.first_listed = ptr<int32_t>(first_listed);
+    }
     Buf bsc = upload_const(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_const(blob.data(), blob.size());
     Buf cell = dalloc((size_t)ncell * (size_t)n * 4), row_len = dalloc((size_t)(n + 1) * 4 + 16), mflags = dalloc((size_t)n + 16);
     SerParams p{};
