@@ -427,6 +427,7 @@ static int receive_message(const unsigned char *p, size_t n, ora_batch *out, uin
       if (vals) for (int k = 0; k < vals->nk; k++) if (vals->klen[k] == strlen(f->field) && !memcmp(vals->keys[k], f->field, vals->klen[k])) val = vals->kids[k];
       if (!val) { rc = TFGPU_ROW_DBZ_FIELD; continue; }            /* "unable to get field %s from 'after'" */
       ora_value v;
+      if (f->optional && val->t == JV_STR && val->n == 28 && !memcmp(val->s, "__debezium_unavailable_value", 28)) continue;  /* isAbsent (receiver.go:98-105): the item does not list the column */
       int r = receive_value(f, o, val, &v);
       if (r) { rc = r == 1 ? TFGPU_ROW_DBZ_FIELD : TFGPU_ROW_HOST_FALLBACK; continue; }
       if (kind != TFGPU_K_DELETE) { it.names->names[it.names->n++] = strdup(f->field); it.values[it.nvalues++] = ora_value_clone(&v); }

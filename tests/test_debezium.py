@@ -203,8 +203,9 @@ def device_items(tf, parsed):
         if kind == "delete":
             assert not any(c.is_valid(r) for c in b.cols), "a Delete keeps ColumnValues nil"
             it["names"], it["values"] = [], []
-        else:
-            it["names"], it["values"] = names, [c.pyvalue(r) for c in b.cols]
+        else:  # a row lists the columns it is not ABSENT from (`__debezium_unavailable_value`, receiver.go:98-105)
+            listed = [c for c in b.cols if getattr(c, "absent", None) is None or not c.absent[r]]
+            it["names"], it["values"] = [c.name for c in listed], [c.pyvalue(r) for c in listed]
         pres = b.old_present is None or bool(b.old_present[r])
         it["old"] = [[k.name, k.pyvalue(r)] for k in (b.old_keys or [])] if pres and b.old_keys else []
         assert pres == (kind != "insert")

@@ -61,6 +61,7 @@ struct Params {
   uint32_t *keep;                              // [nmsg + 1]
   uint32_t *row_msg; int64_t nrows;
   uint32_t *nerr;
+  uint32_t *toast;                             // set when some optional field holds `__debezium_unavailable_value`: the row does not list that column
   unsigned long long *first_ok;                // lowest good message (atomicMin)
   const double *p10; const uint64_t *p128;
   // the fast path of dbz_unpack: messages that start with the bytes message `ref` holds in front of its payload value
@@ -570,6 +571,13 @@ __device__ int parse_message(const Params &p, int64_t m) {
     const int64_t i = (int64_t)j * p.nmsg + m;
     const uint32_t vtr = p.vtype[i];
     if ((vtr & VT_MASK) == VT_ABSENT) return TFGPU_ROW_DBZ_FIELD;  // "unable to get field %s from 'after'"
+    if ((vtr & VT_MASK) == VT_STR && p.vlen[i] >= 30 && p.fields[j].optional && is_unavailable(rd, p.vstart[i], p.vlen[i])) {
+      // receiveField's isAbsent (receiver_engine.go:143-148, receiver.go:98-105): the item does not list the column — an ABSENT cell
+      // (DColumn::absent); to the cell kernels it reads as a nil.  (Under a key field the OldKeys turn ragged too: check_value hands that to the host.)
+      p.vtype[i] = (uint8_t)(VT_NULL | VT_CANON);
+      *p.toast = 1u;
+      continue;
+    }
     const int rc = check_value(p, rd, p.fields[j], vtr, p.vstart[i], p.vlen[i]);
     if (rc != TFGPU_ROW_OK) return rc;
   }
@@ -930,6 +938,18 @@ __global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *col
   } else if (f.op == TFGPU_DBZ_BYTES) b64_decode(TextIter(rd, vt, vs, vl), [&](uint32_t b) { s.put(b); });
   else render_text(s, rd, f, vtr, vs, vl);
   s.flush();
+}
+// rows that do not list a column (see the walker's isAbsent note): one flag byte per (field, row) and a flag per field that has any
+__global__ void __launch_bounds__(256) dbz_absent_cells(Params p, int64_t nra, uint8_t *abs8, uint32_t *colflag) {
+  const int j = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool a = false;
+  if (r < p.nrows) {
+    const uint32_t m = p.row_msg[r];
+    const uint32_t v = p.vtype[(int64_t)j * p.nmsg + m];
+    a = v == (VT_NULL | VT_CANON) && p.kind[m] != TFGPU_K_DELETE;  // (a Delete lists nothing at all)
+    abs8[(int64_t)j * nra + r] = a ? 1 : 0;
+  }
+  if (__any(a) && (threadIdx.x & 63) == 0) atomicOr(&colflag[j], 1u);
 }
 struct PackJob { const uint8_t *bytes; uint8_t *bits; };
 // every byte-per-row flag array of a batch → its bitmap, in one launch (grid y = the array)
@@ -1302,7 +1322,7 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
   p.status = ptr<uint8_t>(status); p.kind = ptr<uint8_t>(kind); p.keep = ptr<uint32_t>(keep);
   p.lsn = ptr<uint64_t>(lsn); p.ts = ptr<uint64_t>(ts); p.tabhash = ptr<uint64_t>(tabhash); p.txid = ptr<uint32_t>(txid);
   p.tab_s = ptr<uint32_t>(tab_s); p.tab_n = ptr<uint32_t>(tab_n);
-  p.nerr = ptr<uint32_t>(misc); p.first_ok = ptr<unsigned long long>(misc) + 1;
+  p.nerr = ptr<uint32_t>(misc); p.first_ok = ptr<unsigned long long>(misc) + 1; p.toast = ptr<uint32_t>(misc) + 4;
   TF_HIP(hipMemsetAsync(p.first_ok, 0xFF, 8, st));
   p.p10 = pow10_table(); p.p128 = reinterpret_cast<const uint64_t *>(p.p10 + 632);
   Buf tabname = zview();
@@ -1382,13 +1402,14 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     dbz::dbz_table_name<<<1, 64, 0, st>>>(p, ptr<uint8_t>(tabname));
   }
   exclusive_scan_u32(p.keep, p.keep, nmsg, true);
-  const uint32_t *hrows = d2h_u32(p.keep + nmsg), *hnerr = d2h_u32(p.nerr);
+  const uint32_t *hrows = d2h_u32(p.keep + nmsg), *hnerr = d2h_u32(p.nerr, 5);  // [0] errors, [4] some row leaves a column out
   uint8_t htab[512];
   d2h(htab, tabname->p, 512);
   tf::sync();
   hc.mark("parse kernels + row count");
   const int64_t nrows = *hrows, nra = std::max<int64_t>(nrows, 1);
-  const uint32_t nerr_total = *hnerr;
+  const uint32_t nerr_total = hnerr[0];
+  const bool any_toast = hnerr[4] != 0;
   if (nrows > rows_cap && rows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_debezium_parse: more rows than `rows` holds");
 
   auto db = std::make_unique<tfgpu_dbatch>();
@@ -1519,6 +1540,19 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
   if (!db->old_keys.empty()) {
     db->old_present = zcarve((size_t)((nra + 7) / 8) + 8);
     jobs.push_back(dbz::PackJob{ptr<uint8_t>(old8), ptr<uint8_t>(db->old_present)});
+  }
+  Buf abs8;
+  if (any_toast && nrows && nf) {  // `__debezium_unavailable_value`: the columns those rows do not list (rare: its own launch and read-back)
+    abs8 = dalloc((size_t)nf * (size_t)nra);
+    Buf colflag = dalloc_zero((size_t)nf * 4);
+    dbz::dbz_absent_cells<<<dim3(dbz::nblk(nrows, 256), (unsigned)nf), 256, 0, st>>>(p, nra, ptr<uint8_t>(abs8), ptr<uint32_t>(colflag));
+    const uint32_t *hcf = d2h_u32(colflag->p, (size_t)nf);
+    tf::sync();
+    for (int j = 0; j < nf; j++) if (hcf[j]) {
+      DColumn &d = db->cols[(size_t)j];
+      d.absent = dalloc_zero((size_t)((nra + 7) / 8) + 8);
+      jobs.push_back(dbz::PackJob{ptr<uint8_t>(abs8) + (size_t)j * (size_t)nra, ptr<uint8_t>(d.absent)});
+    }
   }
   if (nrows && !jobs.empty()) {
     Buf bj = upload_small(jobs.data(), jobs.size() * sizeof(dbz::PackJob));
