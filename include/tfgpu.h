@@ -172,6 +172,14 @@ typedef struct tfgpu_batch {
                              Transformers that walk the SCHEMA and look values up
                              by name (sharder.go:134-143) need it when ColumnNames
                              and TableSchema differ.               */
+  uint16_t *col_order;     /* [nrows][ncols], row-major, or NULL = every row lists its columns in batch order.  Row r's
+                              ColumnNames are cols[col_order[r*ncols + 0]], cols[col_order[r*ncols + 1]], … for the columns it
+                              lists (tfgpu_column.absent), followed by the ones it does not (in no particular order): a full
+                              permutation of 0 .. ncols-1.  An OUTPUT of tfgpu_collapse only: compareColumns appends the names a
+                              later Update brings to the END of the merged row's list (change_item_collapse.go:24-33), which
+                              batch order cannot say.  Read by view / download (the fan-in rebuilds ColumnNames from it), the
+                              native queue format (names and values in that order) and the Debezium emitter (a map: order does
+                              not matter); everything else refuses such a batch by name; tfgpu_batch_upload refuses it too.   */
 } tfgpu_batch;
 
 /* Per-row failure, the C image of abstract.TransformerError
@@ -522,10 +530,11 @@ int tfgpu_wait(tfgpu_token *token, tfgpu_dbatch **transformed, tfgpu_dbatch **er
  * Items whose ColumnNames differ (TOAST-style Updates that leave columns out) say so through tfgpu_column.absent: the
  * compareColumns merge (:7-35, :86-100) then runs on the device — a merged row lists the union of its chain's columns and
  * takes every column's value from the LAST item of the chain that lists it.  The reference appends names a later item
- * brings to the END of the merged row's ColumnNames; the columnar form keeps batch order, so a chain whose merged name
- * order would differ from batch order (an earlier item lacks a column that a later item lists in FRONT of one the earlier
- * item has) is refused by name — TFGPU_ERR_UNSUPPORTED, the Go path takes the batch.  SynchronizeKind items are uploaded
- * as TFGPU_K_SYNCHRONIZE (InsertsOnly, :37-44, treats that one as an insert).  Keys are filed by 128-bit hashes of their
+ * brings to the END of the merged row's ColumnNames; where that differs from batch order (an earlier item lacks a column
+ * that a later item lists in FRONT of one the earlier item has) the result carries every row's own order
+ * (tfgpu_batch.col_order).  An Update that merges and lists only SOME of the primary-key columns is refused by name
+ * (TFGPU_ERR_UNSUPPORTED, the Go path takes the batch).  SynchronizeKind items are uploaded as TFGPU_K_SYNCHRONIZE
+ * (InsertsOnly, :37-44, treats that one as an insert).  Keys are filed by 128-bit hashes of their
  * json.Marshal text and, hash for hash, compared as strings: two rows share a key exactly when the reference's map would
  * file them under one string.  TFGPU_ERR_UNSUPPORTED: NaN / Inf in a float key column, more than 2^29 rows.             */
 int tfgpu_collapse(const tfgpu_dbatch *in, tfgpu_dbatch **out);

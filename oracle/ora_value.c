@@ -169,7 +169,7 @@ ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema) {
     it->schema = sch; sch->refs++;
     int listed = 0;  /* tfgpu_column.absent: the row's ColumnNames are the columns it is not absent from, in batch order */
     for (int c = 0; c < cb->ncols; c++) if (!(cb->cols[c].absent && valid_at(cb->cols[c].absent, r))) listed++;
-    if (listed == cb->ncols) {
+    if (listed == cb->ncols && !cb->col_order) {
       it->names = nm; nm->refs++;
       it->nvalues = cb->ncols;
       it->values = (ora_value *)calloc((size_t)(cb->ncols ? cb->ncols : 1), sizeof(ora_value));
@@ -181,7 +181,8 @@ ora_batch *ora_from_columns(const tfgpu_batch *cb, const tfgpu_schema *schema) {
       it->nvalues = listed;
       it->values = (ora_value *)calloc((size_t)(listed ? listed : 1), sizeof(ora_value));
       int k = 0;
-      for (int c = 0; c < cb->ncols; c++) {
+      for (int q = 0; q < cb->ncols; q++) {
+        const int c = cb->col_order ? cb->col_order[r * cb->ncols + q] : q;  /* tfgpu_batch.col_order: the row's own ColumnNames order */
         if (cb->cols[c].absent && valid_at(cb->cols[c].absent, r)) continue;
         own->names[k] = dups(cb->cols[c].name);
         it->values[k++] = box(&cb->cols[c], r);

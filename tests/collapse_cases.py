@@ -191,8 +191,10 @@ def items_of(out, keys=None):
     old = getattr(out, "old_keys", None) or []
     pres = getattr(out, "old_present", None)
     res = []
+    order = getattr(out, "col_order", None)
     for i in range(out.nrows):
-        cols = [c for c in out.cols if getattr(c, "absent", None) is None or not c.absent[i]]
+        seq = out.cols if order is None else [out.cols[int(j)] for j in order[i]]  # tfgpu_batch.col_order: the row's own ColumnNames order
+        cols = [c for c in seq if getattr(c, "absent", None) is None or not c.absent[i]]
         it = {"kind": KINDS[int(out.kind[i])] if out.kind is not None else "insert", "names": [c.name for c in cols],
               "values": [list(abi.norm_value(c.pyvalue(i))) for c in cols],
               "old": [[c.name, list(abi.norm_value(c.pyvalue(i)))] for c in old] if old and (pres is None or pres[i]) else [],

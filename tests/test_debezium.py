@@ -455,6 +455,73 @@ def test_gpu_stream_feeds_collapse_and_native_serializer(tf, oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_toasted_stream_stays_on_the_device(tf, oracle):
+    """A Postgres topic whose Updates carry `__debezium_unavailable_value` for unchanged TOASTed columns: the receiver leaves those columns out of
+    the row's ColumnNames (receiver.go:98-105) — ABSENT cells on the device, parsed (not handed to the host), equal to the oracle's items; the
+    rows then go through Collapse (compareColumns merges: the kept value of a left-out column is the chain's), the native queue format (every row
+    its own columnnames) and the Debezium emitter (the placeholder again), each against the oracle."""
+    import random
+    from transferia_amd import debezium
+    rng = random.Random(77 + SEED0)
+    schema = json.dumps(envelope_schema("events"), separators=(",", ":"))
+    msgs, marked = [], 0
+    for k, ps in cdc_payloads(rng, 900, "events", weird=False):
+        if '"op":"u"' in ps and k % 2:  # the update did not touch the TOASTed columns
+            after = ps.index('"after":')
+            for field, pat in (("name", '"name":'), ("blob", '"blob":'), ("amount", '"amount":')):
+                if rng.random() < 0.6:
+                    at = ps.index(pat, after)
+                    end = at + len(pat)
+                    stop = end
+                    if ps[end] == '"':
+                        stop = end + 1
+                        while ps[stop] != '"' or ps[stop - 1] == "\\":
+                            stop += 1
+                        stop += 1
+                    else:
+                        while ps[stop] not in ",}":
+                            stop += 1
+                    ps = ps[:end] + '"__debezium_unavailable_value"' + ps[stop:]
+                    marked += 1
+        msgs.append(('{"schema":%s,"payload":%s}' % (schema, ps)).encode("utf-8"))
+    assert marked > 100
+    data, m = abi.messages(msgs)
+    exp_items, codes = oracle.debezium_parse(data, m)
+    assert all(c == abi.ROW_OK for c in codes)
+    parsed, errors = debezium.Parser(tf).parse(data, m)
+    assert not errors and len(parsed) == 1
+    p = parsed[0]
+    got = device_items(tf, p)
+    ragged = 0
+    for it in exp_items:
+        assert_same_items(got[it["src"]], it, it["src"])
+        ragged += it["kind"] == "update" and len(it["names"]) < len(FIELDS)
+    assert ragged > 50
+    # Collapse: the device's rows equal the oracle's row-wise loop over the oracle's items
+    keys = [c.name for c in p.schema.cols if c.key]
+    rows_in = [{"kind": it["kind"], "keys": keys, "names": it["names"], "values": [list(v) if v[0] not in ("string", "bytes", "jsonnum") else [v[0], bytes(v[1]).decode("utf-8", "surrogateescape")] for v in it["values"]],
+                "old_names": [o[0] for o in it["old"]], "old_values": [list(o[1]) for o in it["old"]]} for it in exp_items]
+    col = tf.collapse(p.batch)
+    assert 0 < col.nrows < p.batch.nrows
+    a = col.download()
+    want = oracle.collapse_rows(rows_in)
+    from collapse_cases import items_of as rows_as_items
+    assert a.col_order is not None  # some chain starts with an Update that leaves `name` out and meets one that lists it: names out of batch order
+    assert [(r["kind"], r["src"], r["names"]) for r in want] == [(g["kind"], g["src"], [] if g["kind"] == "delete" else g["names"]) for g in rows_as_items(a)]
+    # the native queue format and the Debezium emitter over the collapsed rows, against the oracle reading the same (downloaded) rows
+    n = len(msgs)
+    ids, lsns, cts, nf = np.zeros(n, np.uint32), np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint8)
+    mm = p.rows["msg"]
+    ids[mm], lsns[mm], cts[mm], nf[mm] = p.rows["id"], p.rows["lsn"], p.rows["commit_time"], p.rows["names_form"]
+    meta = abi.row_meta(n, ids=ids, lsns=lsns, commit_times=cts, names_form=nf)
+    o = abi.queue_options(abi.QFMT_NATIVE, enabled=True, max_message_size=1 << 14, table_schema=p.schema, old_key_types=["int64"])
+    out = tf.queue_serialize(o, col, meta).messages()
+    a.schema = p.schema
+    assert out == oracle.queue_serialize(o, a, p.schema, meta) and len(out) > 3
+    assert any(b'"columnnames":["id","ver","flag","score","at"' in x for x in out) or any(b'"blob"' not in x.split(b'"columnvalues"')[0] for x in out)
+
+
+@pytest.mark.gpu
 def test_gpu_parse_refuses_foreign_frames(tf):
     """tfgpu_debezium_parse takes the frames back from the host: spans outside their message are refused before any lane runs."""
     from transferia_amd import debezium

@@ -307,49 +307,50 @@ def test_random_toast_batches(tf, oracle, shape):
     """Random CDC streams whose Updates leave columns out: long merge chains, key changes, deletes that list only the key."""
     from collapse_cases import random_toast_items, norm_items
     names = ["id"] + ["c%d" % j for j in range(shape.get("ncols", 5))]
-    merged = compared = 0
+    merged = compared = reordered = 0
     for seed in range(8):
         items = random_toast_items(100 + seed, **shape)
         want = norm_items(oracle.collapse_rows(items))
-        if not all(r["names"] == [nm for nm in names if nm in r["names"]] for r in want):
-            # a chain that starts with a partial Update and later gains a column in front of one it has: merged names leave batch order
-            with pytest.raises(tf.TfgpuError, match="column order"):
-                _collapse_items(tf, items, names)
-            continue
+        # (a chain that starts with a partial Update and later gains a column in front of one it has: the merged names leave batch order and the
+        #  result carries every row's own order, tfgpu_batch.col_order)
+        reordered += not all(r["names"] == [nm for nm in names if nm in r["names"]] for r in want)
         got = _collapse_items(tf, items, names)
         assert got == want, (shape, seed)
         compared += 1
         # a merged row mixes items: its cells ("r<item>.<column>" / item * 10 + column) name more than one
         merged += sum(1 for r in want if len({v[1].split(b".")[0][1:] if v[0] == "string" else b"%d" % (v[1] // 10)
                                               for nm, v in zip(r["names"], r["values"]) if nm != "id" and v[0] != "nil"}) > 1)
-    assert (compared or "toastable" not in shape) and (merged or shape["n"] < 10 or not compared), (compared, merged)
+    assert compared == 8 and (merged or shape["n"] < 10), (compared, merged)
+    assert reordered or "toastable" in shape or shape["n"] < 100, shape
 
 
-def test_merged_names_out_of_batch_order_are_refused(tf, oracle):
-    """compareColumns APPENDS the names an Update brings; a chain whose merged ColumnNames are not in the batch's column order cannot be
-    said in the columnar form: refused by name (the Go path takes the batch), never answered in another order."""
-    from collapse_cases import norm_items
+def test_merged_names_out_of_batch_order(tf, oracle):
+    """compareColumns APPENDS the names an Update brings; a chain whose merged ColumnNames are not in the batch's column order comes back with
+    every row's own order (tfgpu_batch.col_order) — the oracle's names, in the oracle's order; such a batch goes to download, the native queue
+    format and the Debezium emitter, and nowhere else."""
+    from collapse_cases import norm_items, batch_from_items
     items = [{"kind": "update", "keys": ["id"], "names": ["id", "b"], "values": [["int64", 1], ["string", "b0"]]},
              {"kind": "update", "keys": ["id"], "names": ["id", "a"], "values": [["int64", 1], ["string", "a1"]]}]
     assert norm_items(oracle.collapse_rows(items))[0]["names"] == ["id", "b", "a"]
-    assert _collapse_items(tf, items, ["id", "b", "a"])[0]["names"] == ["id", "b", "a"]  # batch order = merged order: fine
-    with pytest.raises(tf.TfgpuError, match="column order"):
-        _collapse_items(tf, items, ["id", "a", "b"])
-    # random streams whose Inserts leave columns out too: every batch is either the oracle's rows or refused — and refused exactly when
-    # some merged row's names leave batch order
+    assert _collapse_items(tf, items, ["id", "b", "a"])[0]["names"] == ["id", "b", "a"]  # batch order = merged order: no order array
+    b, _ = batch_from_items(items, names=["id", "a", "b"])
+    col = tf.collapse(tf.DeviceBatch.upload(b))
+    host = col.download()
+    assert host.col_order.tolist() == [[0, 2, 1]]
+    assert _collapse_items(tf, items, ["id", "a", "b"])[0]["names"] == ["id", "b", "a"]
+    for refuses in (lambda: tf.Transformer("mask_field", {"columns": ["a"], "maskFunctionHash": {"userDefinedSalt": "s"}}).apply(col), lambda: tf.DeviceBatch.upload(host),
+                    lambda: tf.queue_serialize(abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=1 << 12), col, None)):
+        with pytest.raises(tf.TfgpuError, match="order|ABSENT"):
+            refuses()
+    # random streams whose Inserts leave columns out too: the oracle's rows either way
     from collapse_cases import random_toast_items
     names = ["id"] + ["c%d" % j for j in range(4)]
     seen = {True: 0, False: 0}
     for seed in range(24):
         items = random_toast_items(900 + seed, 40, ncols=4, domain=5, front_ok=True)
         want = norm_items(oracle.collapse_rows(items))
-        in_order = all(r["names"] == [nm for nm in names if nm in r["names"]] for r in want)
-        seen[in_order] += 1
-        if in_order:
-            assert _collapse_items(tf, items, names) == want, seed
-        else:
-            with pytest.raises(tf.TfgpuError, match="column order"):
-                _collapse_items(tf, items, names)
+        seen[all(r["names"] == [nm for nm in names if nm in r["names"]] for r in want)] += 1
+        assert _collapse_items(tf, items, names) == want, seed
     assert seen[True] and seen[False], seen
 
 
@@ -395,11 +396,7 @@ def test_toast_rows_through_collapse_and_the_native_queue_format(tf, oracle):
         db = tf.DeviceBatch.upload(b)
         for dev in (db, None):                      # the stream as it came, then what Collapse leaves of it
             if dev is None:
-                try:
-                    dev = tf.collapse(db)
-                except tf.TfgpuError as e:
-                    assert "column order" in str(e)
-                    continue
+                dev = tf.collapse(db)
             host = dev.download()
             host.schema = schema
             want = oracle.queue_serialize(o, host, schema, meta)
@@ -408,7 +405,7 @@ def test_toast_rows_through_collapse_and_the_native_queue_format(tf, oracle):
             seen.update(x for m in got for x in (b'"columnnames":["id","c0","c1","c2"]', b'"columnnames":["id","c0","c1","c2","c4"]', b'"columnnames":[],"table_schema"',
                                                  b'"columnnames":["id","c0","c1","c2","c3","c4"]') if x in m)
             done += 1
-    assert done >= 8 and len(seen) == 4, (done, seen)
+    assert done == 12 and len(seen) == 4, (done, seen)
     # the JSON queue format computes on values: it says no, by name
     with pytest.raises(tf.TfgpuError, match="ABSENT"):
         tf.queue_serialize(abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=1 << 12), db, None)

@@ -66,7 +66,7 @@ class CBatch(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int32), ("cols", C.POINTER(CColumn)), ("table_ns", C.c_char_p),
                 ("table_name", C.c_char_p), ("kind", C.c_void_p), ("src_row", C.c_void_p), ("part_id", C.c_void_p),
                 ("mem", C.c_int32), ("n_old_keys", C.c_int32), ("old_keys", C.POINTER(CColumn)), ("old_keys_present", C.c_void_p),
-                ("schema", C.POINTER(CSchema))]
+                ("schema", C.POINTER(CSchema)), ("col_order", C.c_void_p)]
 
 
 class CRowError(C.Structure):
@@ -564,6 +564,10 @@ class Batch:
             cs = self.schema.to_c()
             keep.append(cs)
             cb.schema = C.pointer(cs)
+        if getattr(self, "col_order", None) is not None:  # every row's own ColumnNames order (an output of tfgpu_collapse; the oracle reads it, upload refuses it)
+            co = np.ascontiguousarray(self.col_order, dtype=np.uint16)
+            keep.append(co)
+            cb.col_order = co.ctypes.data if co.size else None
         if self.kind is not None:
             k = np.ascontiguousarray(self.kind, dtype=np.uint8)
             keep.append(k)

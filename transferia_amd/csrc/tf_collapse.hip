@@ -25,8 +25,8 @@
 // row whose ColumnNames leave a column out marks the cell ABSENT (DColumn::absent).  The walk links every merged item to the item
 // it merged into (prev[]); a surviving row then takes each column from the LAST item of its chain that lists it
 // (collapse_merge_cols: one lane per (row, column that can be absent) walks the chain back), and lists the union.  The reference
-// APPENDS the names a later item brings (`total`), the columnar form keeps batch order: collapse_merge_order refuses — by name,
-// the Go path takes the batch — a chain whose merged name order is not batch order.
+// APPENDS the names a later item brings (`total`): where some chain's merged name order is not batch order (collapse_merge_order
+// says so) the result carries every row's own order (collapse_merge_names → tfgpu_dbatch::col_order).
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -360,6 +360,28 @@ __global__ void __launch_bounds__(256) collapse_merge_order(MergeParams p, const
     last = f;
   }
 }
+// Every output row's ColumnNames as column indices: the columns it lists by first appearance in its chain (earliest item first, an
+// item's own columns in batch order — compareColumns' `total`, change_item_collapse.go:19-33), then the ones it does not list.
+__global__ void __launch_bounds__(256) collapse_merge_names(MergeParams p, const int32_t *__restrict__ acol, int ncols, uint16_t *__restrict__ order) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= p.m) return;
+  const int32_t head = p.sel_meta[k];
+  int32_t r = p.sel_val[k];
+  uint32_t len = 0;
+  for (int64_t guard = 0; guard <= p.n && r != head; guard++) { const int32_t q = p.prev[r]; if (q < 0) break; r = q; len++; }
+  auto first_of = [&](int c) { return acol[c] < 0 ? len : p.first_at[(int64_t)acol[c] * p.m + k]; };
+  uint16_t *o = order + k * ncols;
+  int pos = 0;
+  uint32_t cur = len + 1;  // first appearances still to place are < cur
+  while (pos < ncols) {
+    uint32_t next = NEVER; bool any = false;
+    for (int c = 0; c < ncols; c++) { const uint32_t f = first_of(c); if (f != NEVER && f < cur && (!any || f > next)) { next = f; any = true; } }
+    if (!any) break;
+    for (int c = 0; c < ncols; c++) if (first_of(c) == next) o[pos++] = (uint16_t)c;
+    cur = next;
+  }
+  for (int c = 0; c < ncols; c++) if (first_of(c) == NEVER) o[pos++] = (uint16_t)c;  // not listed: behind the listed ones
+}
 __global__ void __launch_bounds__(256) collapse_any_non_insert(const uint8_t *kind, int64_t n, uint32_t *flag) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && kind[i] != TFGPU_K_INSERT && kind[i] != TFGPU_K_SYNCHRONIZE) *flag = 1;  // InsertsOnly :37-44
@@ -422,6 +444,7 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   auto same = [&] { return std::make_unique<tfgpu_dbatch>(in); };
   if (n < 2 || !in.kind) return same();  // len(input) < 2; no Kind array = inserts only
   if (n >= (int64_t)1 << 29) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: more than 2^29 rows in one batch");
+  if (in.col_order) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: the batch's rows carry their own ColumnNames order (it is a collapsed batch already)");
   {  // InsertsOnly
     Buf flag = dalloc_zero(4);
     collapse_any_non_insert<<<cgrid(n), 256, 0, st>>>(ptr<uint8_t>(in.kind), n, ptr<uint32_t>(flag));
@@ -533,8 +556,12 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
     }
     const uint32_t *hbo = d2h_u32(border->p);
     sync();
-    if (*hbo) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: an Update brings a column its row did not list, in front of one it did — the merged ColumnNames (compareColumns appends "
-                                                 "new names, change_item_collapse.go:24-33) are not in the batch's column order");
+    Buf order;
+    if (*hbo) {  // an Update brought a column its row did not list, in front of one it did: the merged names are not in batch order
+      if (in.cols.size() > 0xFFFFu) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_collapse: merged ColumnNames out of batch order over more than 65535 columns");
+      order = dalloc((size_t)m * in.cols.size() * 2 + 16);
+      collapse_merge_names<<<cgrid(m), 256, 0, st>>>(mp, ptr<int32_t>(bacol), (int)acol.size(), ptr<uint16_t>(order));
+    }
     tfgpu_dbatch rest = vals_in;
     rest.cols.clear();
     for (size_t c = 0; c < in.cols.size(); c++) if (acol[c] < 0) rest.cols.push_back(in.cols[c]);
@@ -549,6 +576,7 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
       merged[c] = std::move(g->cols[0]);
     }
     out->cols = std::move(merged);
+    out->col_order = order;
   }
   tfgpu_dbatch meta_in;
   meta_in.nrows = n; meta_in.kind = in.kind; meta_in.part_id = in.part_id; meta_in.src_row = in.src_row;

@@ -235,6 +235,7 @@ struct tfgpu_dbatch {
   tf::Buf old_present;                              // bitmap: the row has OldKeys; null with old_keys = every row
   std::string ns, table;
   tf::Buf kind, src_row, part_id;
+  tf::Buf col_order;  // uint16 [nrows][ncols] or null: every row's own ColumnNames order (tfgpu_batch.col_order; tfgpu_collapse's merged rows)
 };
 
 struct tfgpu_dbuf {

@@ -374,6 +374,7 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
   TF_API_BEGIN
   if (!h || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_batch_upload: null argument");
   if (h->mem != TFGPU_MEM_HOST && h->mem != TFGPU_MEM_DEVICE) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_batch_upload: bad mem");
+  if (h->col_order) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_batch_upload: col_order is an output of tfgpu_collapse (rows whose ColumnNames are not in batch order stay with the Go path)");
   std::lock_guard<std::mutex> lk(ctx().mu);
   const bool from_dev = h->mem == TFGPU_MEM_DEVICE;
   struct Flag { Flag(bool v) { g_upload_from_device = v; } ~Flag() { g_upload_from_device = false; } } flag(from_dev);
@@ -464,6 +465,7 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *v) {
   v->n_old_keys = (int32_t)b->old_keys.size();
   v->old_keys = b->old_keys.empty() ? nullptr : g_view.cols.data() + b->cols.size();
   v->old_keys_present = ptr<uint8_t>(b->old_present);
+  v->col_order = ptr<uint16_t>(b->col_order);
   return TFGPU_OK;
   TF_API_END
 }
@@ -494,6 +496,7 @@ int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
   if (h->src_row && b->src_row) d2h(h->src_row, b->src_row->p, n * 4);
   if (h->part_id && b->part_id) d2h(h->part_id, b->part_id->p, n * 4);
   if (h->old_keys_present && b->old_present) d2h(h->old_keys_present, b->old_present->p, (n + 7) / 8);
+  if (h->col_order && b->col_order) d2h(h->col_order, b->col_order->p, n * b->cols.size() * 2);
   tf::sync();
   return TFGPU_OK;
   TF_API_END

@@ -51,6 +51,8 @@ struct QueueParams {
   const int64_t *gstart; const uint32_t *gpart;
   const uint8_t *msg_flags;      // [nrows]: bit 0 = first row of its message, bit 1 = last
   const int32_t *first_listed;   // [nrows], batches with ABSENT cells: the first column the row lists, -1 = none
+  const uint16_t *col_order;     // [nrows][ord_n] or null: the row's own order of its columns (tfgpu_dbatch::col_order): the name cells
+  int32_t ord_name0, ord_val0, ord_n;  // [ord_name0, + ord_n) and the value cells [ord_val0, + ord_n) are laid out in that order
 };
 
 struct SerParams {
@@ -318,6 +320,19 @@ __global__ void __launch_bounds__(256) ser_row_layout(SerParams p) {
   // load and a store to the same array in every step the compiler has to wait for each load in turn
   constexpr int U = 8;
   int32_t c = 0;
+  if (p.q.col_order) {  // the row's own column order (rare: a collapsed TOAST batch): the name and value cells are walked in it
+    const uint16_t *ord = p.q.col_order + r * p.q.ord_n;
+    for (; c < p.ncols; c++) {
+      int32_t ci = c;
+      if (c >= p.q.ord_name0 && c < p.q.ord_name0 + p.q.ord_n) ci = p.q.ord_name0 + ord[c - p.q.ord_name0];
+      else if (c >= p.q.ord_val0 && c < p.q.ord_val0 + p.q.ord_n) ci = p.q.ord_val0 + ord[c - p.q.ord_val0];
+      const uint32_t n = p.cell[(int64_t)ci * p.nrows + r];
+      p.cell[(int64_t)ci * p.nrows + r] = off;
+      off += n;
+    }
+    p.row_len[r] = off;
+    return;
+  }
   for (; c + U <= p.ncols; c += U) {
     uint32_t n[U];
 #pragma unroll
@@ -670,11 +685,14 @@ __global__ void __launch_bounds__(256) ser_queue_frame(SerParams p) {
   else if (!(f & 2)) row[len - 1] = '\n';
 }
 // batches whose rows list different columns: the first column every row lists (its name and value carry no leading comma), -1 = none
-__global__ void __launch_bounds__(256) queue_first_listed(const uint8_t *const *absent, int ncols, int64_t n, int32_t *first) {
+__global__ void __launch_bounds__(256) queue_first_listed(const uint8_t *const *absent, int ncols, int64_t n, const uint16_t *order, int32_t *first) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   int32_t f = -1;
-  for (int j = 0; j < ncols; j++) if (!absent[j] || !((absent[j][r >> 3] >> (r & 7)) & 1u)) { f = j; break; }
+  if (order) {  // the row's own order lists its columns first
+    const int j = ncols ? order[r * ncols] : -1;
+    if (j >= 0 && (!absent[j] || !((absent[j][r >> 3] >> (r & 7)) & 1u))) f = j;
+  } else for (int j = 0; j < ncols; j++) if (!absent[j] || !((absent[j][r >> 3] >> (r & 7)) & 1u)) { f = j; break; }
   first[r] = f;
 }
 // A long constant cell (column names, table schema) of every row: one workgroup per (row, 4 KiB chunk), 16 bytes per lane,
@@ -1497,6 +1515,7 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
 
     // ---- the cell list ----
     const bool ragged = native && has_absent(*b);
+    int ord_name0 = 0, ord_val0 = 0;
     std::string blob;
     std::vector<SCol> sc;
     auto add = [&](uint32_t kind, uint32_t apply, const std::string &pre, const DColumn *col) {
@@ -1523,9 +1542,11 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
           sc.back().absent = ptr<uint8_t>(b->cols[(size_t)j].absent); sc.back().prec = (uint32_t)j;
         };
         add(QC_CONST, QA_NAMES, ",\"columnnames\":[", nullptr);
+        ord_name0 = (int)sc.size();
         for (int j = 0; j < ncols; j++) { std::string t = ","; json_key(t, b->cols[(size_t)j].name, true); listed(QC_NAME, t, j); }
         add(QC_CONST, QA_NAMES, "]", nullptr);
         add(QC_CONST, QA_ANY_LISTED, ",\"columnvalues\":[", nullptr);
+        ord_val0 = (int)sc.size();
         for (int j = 0; j < ncols; j++) listed(QC_VALUE, ",", j);
         add(QC_CONST, QA_ANY_LISTED, "]", nullptr);
       }
@@ -1585,8 +1606,9 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
       Buf babs = upload_small(abs.data(), abs.size() * sizeof(uint8_t *));
       keep.push_back(babs);
       first_listed = dalloc((size_t)n * 4);
-      queue_first_listed<<<blocks(n), 256, 0, st>>>(ptr<const uint8_t *>(babs), ncols, n, ptr<int32_t>(first_listed));
+      queue_first_listed<<<blocks(n), 256, 0, st>>>(ptr<const uint8_t *>(babs), ncols, n, ptr<uint16_t>(b->col_order), ptr<int32_t>(first_listed));
       q.first_listed = ptr<int32_t>(first_listed);
+      if (b->col_order) { q.col_order = ptr<uint16_t>(b->col_order); q.ord_n = ncols; q.ord_name0 = ord_name0; q.ord_val0 = ord_val0; }
     }
     Buf bsc = upload_const(sc.data(), sc.size() * sizeof(SCol)), bblob = upload_const(blob.data(), blob.size());
     Buf cell = dalloc((size_t)ncell * (size_t)n * 4), row_len = dalloc((size_t)(n + 1) * 4 + 16), mflags = dalloc((size_t)n + 16);

@@ -628,6 +628,8 @@ __global__ void collect_totals(const uint32_t *lens_all, int64_t seg_stride, int
 // Gather all columns of `in` through `sel` (m output rows).
 static std::unique_ptr<tfgpu_dbatch> gather_batch(const tfgpu_dbatch &in, const Buf &sel, int64_t m, const std::vector<DColumn> *skip = nullptr) {
   // (skip: columns — by name — whose kept rows exist already: they are not gathered, their slot takes the given column)
+  if (in.col_order) throw Error(TFGPU_ERR_UNSUPPORTED, "the batch's rows carry their own ColumnNames order (tfgpu_batch.col_order: a collapsed TOAST batch); row-moving steps do not carry it — "
+                                                       "view / download, the native queue format and the Debezium emitter read it");
   auto out = std::make_unique<tfgpu_dbatch>();
   out->nrows = m; out->ns = in.ns; out->table = in.table; out->schema = in.schema;
   hipStream_t st = ctx().stream;
@@ -773,6 +775,7 @@ void dense_locked(const tfgpu_dbatch &b) {
   mb.pending.reset();
 }
 bool has_absent(const tfgpu_dbatch &b) {
+  if (b.col_order) return true;  // rows with their own ColumnNames order are ragged rows too
   for (auto &c : (b.pending ? b.pending->src->cols : b.cols)) if (c.absent) return true;
   return false;
 }

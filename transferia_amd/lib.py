@@ -402,6 +402,9 @@ class DeviceBatch:
             src = np.zeros(max(n, 1), np.int32); hb.src_row = src.ctypes.data
         if v.part_id:
             part = np.zeros(max(n, 1), np.uint32); hb.part_id = part.ctypes.data
+        order = None
+        if v.col_order:  # every row's own ColumnNames order (tfgpu_batch.col_order: a collapsed TOAST batch)
+            order = np.zeros(max(n * v.ncols, 1), np.uint16); hb.col_order = order.ctypes.data
         _check(load().tfgpu_dbatch_download(self._h, C.byref(hb)))
         for col in cols:
             if col.repr in abi.VAR_REPRS:
@@ -422,6 +425,8 @@ class DeviceBatch:
         # src_row NULL = identity (include/tfgpu.h): no row was dropped or reordered
         b.src_row = src[:n] if src is not None else np.arange(n, dtype=np.int32)
         b.part_id = part[:n] if part is not None else None
+        if order is not None:
+            b.col_order = order[: n * v.ncols].reshape(n, v.ncols)
         return b
 
     def free(self):
