@@ -139,11 +139,13 @@ typedef struct tfgpu_column {
                          nil (its validity bit is 0).  NULL = every row lists the
                          column (the uniform case).  A row's ColumnNames are the
                          batch's columns it is not absent from, in batch order.
-                         Read by tfgpu_collapse, tfgpu_keys_changed,
-                         tfgpu_partition, view / download; every entry that
-                         computes on VALUES (transformers, serializers, the
-                         exchange) refuses such a batch by name
-                         (TFGPU_ERR_UNSUPPORTED).                               */
+                         Written by tfgpu_batch_upload and the Debezium
+                         receiver (`__debezium_unavailable_value`); read by
+                         tfgpu_collapse, tfgpu_keys_changed, sharder_transformer,
+                         tfgpu_partition, tfgpu_exchange, view / download, the
+                         native queue format and the Debezium emitter; every
+                         other entry computes on VALUES and refuses such a batch
+                         by name (TFGPU_ERR_UNSUPPORTED).                       */
 } tfgpu_column;
 
 /* A batch = one contiguous same-table, same-schema run of ChangeItems, which

@@ -36,7 +36,7 @@ NAMES = ["id", "name", "ts", "opt"]
 
 def make(r):
     # rows of rank r as (host batch, python rows, kinds, old key values or None): deterministic, every rank can rebuild every other's
-    n = {"plain": 300 + 41 * r, "ragged": 300 + 41 * r, "empty_rank": 0 if r == 1 else 257, "mismatch": 50, "unnamed_old": 60}[case]
+    n = {"plain": 300 + 41 * r, "ragged": 300 + 41 * r, "toast": 300 + 41 * r, "empty_rank": 0 if r == 1 else 257, "mismatch": 50, "unnamed_old": 60}[case]
     lo = 1000 * r
     lean = case in ("ragged", "unnamed_old") and r == 1   # this rank has no nil anywhere, whole seconds only, no OldKeys, no kinds
     rows = []
@@ -61,6 +61,18 @@ def make(r):
                        abi.Column("ts", "timestamp", abi.R_TIME, values=z, nanos=np.zeros(0, np.int32)), abi.Column("opt", "int32", abi.R_INT32, values=np.zeros(0, np.int32))],
                       0, "db", "t", kind=np.zeros(0, np.uint8))
     b.schema = schema
+    if case == "toast" and r != 1:  # rows that do not list `opt` / `name` (tfgpu_column.absent): rank 1 has none, its peers do
+        for nm, mod in (("opt", 7), ("name", 5)):
+            c = b.col(nm)
+            ab = np.array([(lo + i) % mod == 3 for i in range(n)], bool)
+            c.absent = ab
+            c.validity = (np.ones(n, bool) if c.validity is None else c.validity) & ~ab
+            for i in np.nonzero(ab)[0]:
+                rows[int(i)][NAMES.index(nm)] = ["absent", None]
+        if b.col("name").data is not None:  # an absent text cell holds no bytes
+            nmcol = abi.batch_from_rows(schema, NAMES, [[v if v[0] != "absent" else ["nil", None] for v in row] for row in rows], "db", "t", kinds).col("name")
+            nmcol.absent, nmcol.validity = b.col("name").absent, b.col("name").validity
+            b.cols[NAMES.index("name")] = nmcol
     if lean:
         for c in b.cols:
             c.validity = None
@@ -121,6 +133,10 @@ for j, name in enumerate(NAMES):
     c = got.col(name)
     for i in range(got.nrows):
         g, e = c.pyvalue(i), exp_rows[i][j]
+        if e[0] == "absent":  # the row does not list the column: the bit travelled with it
+            assert c.absent is not None and c.absent[i] and g == ["nil", None], (name, i)
+            continue
+        assert c.absent is None or not c.absent[i], (name, i)
         if e[0] == "string":
             e = ["string", e[1].encode()]
         if e[0] == "time":
@@ -145,7 +161,7 @@ comm.close()
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("plain", 3), ("mismatch", 2), ("unnamed_old", 2)])
+@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("plain", 3), ("mismatch", 2), ("unnamed_old", 2), ("toast", 2), ("toast", 3)])
 def test_emulated_exchange_ranks(tmp_path, case, world):
     """tfgpu_exchange on world_size 2 / 3 without a GPU: one process per rank, the emulated kernels, RCCL replaced by the
     socket stand-in (tools/hipemu/fake_rccl.cpp) — the descriptor agreement, the grouped send/recv plan and the rebuild of
@@ -189,7 +205,7 @@ def _gpu_count():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: tfgpu_exchange between two processes over real RCCL / xGMI")
-@pytest.mark.parametrize("case", ["plain", "ragged", "empty_rank", "mismatch"])
+@pytest.mark.parametrize("case", ["plain", "ragged", "empty_rank", "mismatch", "toast"])
 def test_exchange_two_gpus(tmp_path, case):
     """The same worker as the emulated world_size-2 test, on two MI355X: one process per GPU, librccl, the rendezvous id through a
     file.  Runs only where two GPUs are visible (the build box has one)."""

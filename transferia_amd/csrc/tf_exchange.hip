@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) xc_iota_i32(int32_t *p, int64_t n) {
 }
 
 // descriptor flags
-enum : int64_t { CF_VALIDITY = 1, CF_NANOS = 2 };
+enum : int64_t { CF_VALIDITY = 1, CF_NANOS = 2, CF_ABSENT = 4 /* some row does not list the column (DColumn::absent) */ };
 enum : int64_t { BF_KIND = 1, BF_SRC_ROW = 2, BF_OLD_PRESENT = 4 };
 
 }  // namespace
@@ -191,7 +191,7 @@ std::unique_ptr<tfgpu_dbatch> exchange(tfgpu_comm &cm, const tfgpu_dbatch &in, c
     if (!c) { row[o_col + (size_t)j * 3] = -1; continue; }  // this rank has no OldKeys: it takes the others' description
     row[o_col + (size_t)j * 3] = c->repr;
     row[o_col + (size_t)j * 3 + 1] = c->dtype;
-    row[o_col + (size_t)j * 3 + 2] = (c->validity ? CF_VALIDITY : 0) | (c->nanos ? CF_NANOS : 0);
+    row[o_col + (size_t)j * 3 + 2] = (c->validity ? CF_VALIDITY : 0) | (c->nanos ? CF_NANOS : 0) | (c->absent ? CF_ABSENT : 0);
   }
   for (int d = 0; d < W; d++) row[o_rows + (size_t)d] = counts[d];
   Buf drow = upload_small(row.data(), L * 8), dbound = upload_small(bound.data(), bound.size() * 8);
@@ -209,7 +209,7 @@ std::unique_ptr<tfgpu_dbatch> exchange(tfgpu_comm &cm, const tfgpu_dbatch &in, c
   auto M = [&](int r, size_t k) -> int64_t { return mat[(size_t)r * L + k]; };
 
   // ---- the agreed description of every column, and what this rank receives
-  struct Desc { int repr = TFGPU_R_INVALID, dtype = TFGPU_T_INVALID; bool validity = false, nanos = false; };
+  struct Desc { int repr = TFGPU_R_INVALID, dtype = TFGPU_T_INVALID; bool validity = false, nanos = false, absent = false; };
   std::vector<Desc> desc((size_t)C);
   for (int64_t j = 0; j < C; j++) {
     Desc &d = desc[(size_t)j];
@@ -221,6 +221,7 @@ std::unique_ptr<tfgpu_dbatch> exchange(tfgpu_comm &cm, const tfgpu_dbatch &in, c
         throw Error(TFGPU_ERR_INVALID, "tfgpu_exchange: ranks disagree on the representation / type of column " + std::to_string(j));
       d.validity |= (M(r, o_col + (size_t)j * 3 + 2) & CF_VALIDITY) != 0;
       d.nanos |= (M(r, o_col + (size_t)j * 3 + 2) & CF_NANOS) != 0;
+      d.absent |= (M(r, o_col + (size_t)j * 3 + 2) & CF_ABSENT) != 0;
     }
   }
   // Every failure is evaluated for EVERY rank from what the two all-gathers brought (the same matrix on all ranks), so all
@@ -315,6 +316,7 @@ std::unique_ptr<tfgpu_dbatch> exchange(tfgpu_comm &cm, const tfgpu_dbatch &in, c
       }
     }
     if (d.validity) bitmap_move(c ? c->validity : Buf(), c ? 1 : 0, &o.validity);
+    if (d.absent) bitmap_move(c ? c->absent : Buf(), 0, &o.absent);  // a rank whose rows all list the column sends zeros
   };
   out->cols.resize((size_t)ncols);
   out->old_keys.resize((size_t)nold);
@@ -417,8 +419,9 @@ int tfgpu_comm_world(const tfgpu_comm *c) { return c ? c->world : 0; }
 
 int tfgpu_exchange(tfgpu_comm *c, const tfgpu_dbatch *in, const int64_t *counts, tfgpu_dbatch **out, int64_t *recv_counts) {
   TF_API_BEGIN
-  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(in, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT cells travel with their rows
   if (!c || !in || !counts || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_exchange: null argument");
+  if (in->col_order) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_exchange: the batch's rows carry their own ColumnNames order (a collapsed batch): the exchange runs in front of Collapse");
   std::lock_guard<std::mutex> lk(c->mu);       // a communicator carries one collective at a time
   std::lock_guard<std::mutex> lk2(ctx().mu);
   *out = exchange(*c, *in, counts, recv_counts).release();

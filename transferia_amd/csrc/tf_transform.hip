@@ -1716,7 +1716,9 @@ std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &in, int nparts,
 }
 
 std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {
-  refuse_absent(in);  // transformers compute on values: an ABSENT cell is not a nil (the stock path takes the batch)
+  // transformers compute on values: an ABSENT cell is not a nil (the stock path takes the batch) — but for the sharder, which reads its key
+  // columns through AsMap()[name] (sharder.go:134-143: a name the item does not list IS nil there) and passes every column on untouched
+  if (p.kind != PK_SHARDER) refuse_absent(in);
   if (in.pending && p.kind != PK_MASK) dense_locked(in);  // (the callers hold the lane's mutex) only mask_field reads through a selection
   switch (p.kind) {
     case PK_MASK: return apply_mask(p, in);
