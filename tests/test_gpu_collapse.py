@@ -409,3 +409,30 @@ def test_toast_rows_through_collapse_and_the_native_queue_format(tf, oracle):
     # the JSON queue format computes on values: it says no, by name
     with pytest.raises(tf.TfgpuError, match="ABSENT"):
         tf.queue_serialize(abi.queue_options(abi.QFMT_JSON, enabled=True, max_message_size=1 << 12), db, None)
+
+
+def test_toast_rows_through_the_bufferers_concat_and_the_measurer(tf, oracle):
+    """Size.Values of a TOAST batch (util.DeepSizeof(ColumnValues): a row's slice holds the columns it lists), then the Bufferer's flush — ONE
+    tfgpu_dbatch_concat of the buffered batches (some with ABSENT cells, some without) — and a cut back into shards: every row keeps its
+    ColumnNames, and Collapse over the merged batch is the oracle's over the concatenated items."""
+    from collapse_cases import random_toast_items, batch_from_items, items_of, norm_items
+    names = ["id"] + ["c%d" % j for j in range(5)]
+    parts, items_all = [], []
+    for k, (n, p_abs, w) in enumerate([(64, 0.4, (3, 6, 1, 0)), (40, 0.0, (3, 6, 0, 0)), (128, 0.6, (3, 6, 1, 0)), (8, 0.3, (3, 6, 1, 0))]):
+        items = random_toast_items(500 + k, n, p_absent=p_abs, weights=w, p_nokey=0.0)
+        assert p_abs or all(it["names"] == names for it in items)  # the second part lists everything: no bitmap of its own in the concat
+        b, schema = batch_from_items(items, names=names)
+        total, per = oracle.deepsizeof(b, schema)
+        db = tf.DeviceBatch.upload(b)
+        assert int(tf.deepsizeof(db)) == total
+        parts.append(db)
+        items_all += items
+    merged = tf.DeviceBatch.concat(parts)
+    whole, _ = batch_from_items(items_all, names=names)
+    assert items_of(merged.download()) == [dict(x, src=x["src"]) for x in items_of(whole)] or \
+        [dict(x, src=0) for x in items_of(merged.download())] == [dict(x, src=0) for x in items_of(whole)]
+    got = [dict(x, src=0) for x in items_of(tf.collapse(merged).download())]
+    want = [dict(x, src=0) for x in norm_items(oracle.collapse_rows(items_all))]
+    assert got == want
+    cut = merged.slice(64, 104)   # rows 64 .. 167: the all-listed part and the head of the third
+    assert [dict(x, src=0) for x in items_of(cut.download())] == [dict(x, src=0) for x in items_of(whole)[64:168]]

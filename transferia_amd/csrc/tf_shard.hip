@@ -84,11 +84,13 @@ static DColumn slice_column(const DColumn &c, int64_t r0, int64_t n, const VarCu
     if (c.nanos) { d.nanos = dalloc((size_t)n * 4); d2d(d.nanos->p, ptr<int32_t>(c.nanos) + r0, (size_t)n * 4); }
   }
   if (c.validity) { d.validity = dalloc((size_t)(n + 7) / 8); d2d(d.validity->p, ptr<uint8_t>(c.validity) + (r0 >> 3), (size_t)(n + 7) / 8); }
+  if (c.absent) { d.absent = dalloc((size_t)(n + 7) / 8); d2d(d.absent->p, ptr<uint8_t>(c.absent) + (r0 >> 3), (size_t)(n + 7) / 8); }  // rows keep their ColumnNames
   return d;
 }
 
 // rows [r0, r0 + n) of every cut (r0 multiples of 8), on the calling lane; ONE read-back for all var-width cut points
 static std::vector<std::unique_ptr<tfgpu_dbatch>> slice_many(const tfgpu_dbatch &b, const std::vector<int64_t> &cuts) {
+  if (b.col_order) throw Error(TFGPU_ERR_UNSUPPORTED, "the batch's rows carry their own ColumnNames order (a collapsed batch): it is not cut into shards");
   materialize(b);
   const size_t G = cuts.size() - 1;
   std::vector<const DColumn *> var;
@@ -130,6 +132,7 @@ static std::vector<std::unique_ptr<tfgpu_dbatch>> slice_many(const tfgpu_dbatch 
 // ---- re-homing ----------------------------------------------------------------------------------------------------------
 // `b` (made on the calling lane, or at least complete: the caller synchronised its lane) as a batch of lane `lane`
 static std::unique_ptr<tfgpu_dbatch> to_lane(const tfgpu_dbatch &b, int lane) {
+  if (b.col_order) throw Error(TFGPU_ERR_UNSUPPORTED, "the batch's rows carry their own ColumnNames order (a collapsed batch): it stays on its lane");
   materialize(b);
   auto r = std::make_unique<tfgpu_dbatch>();
   r->nrows = b.nrows; r->schema = b.schema; r->key_names = b.key_names; r->ns = b.ns; r->table = b.table;
@@ -153,6 +156,7 @@ static std::unique_ptr<tfgpu_dbatch> to_lane(const tfgpu_dbatch &b, int lane) {
     d.data = mv(c.payload(), (size_t)c.data_len);
     d.nanos = mv(c.nanos, n * 4);
     d.validity = mv(c.validity, (n + 7) / 8);
+    d.absent = mv(c.absent, (n + 7) / 8);
     return d;
   };
   for (auto &c : b.cols) r->cols.push_back(col(c));
@@ -180,6 +184,7 @@ static std::unique_ptr<tfgpu_dbatch> concat(const std::vector<const tfgpu_dbatch
     bool lazy_remote = false;
     for (auto &c : p->cols) if (c.view && !c.view->packed && !c.data && c.view->fstart && c.view->fstart->device != ctx().device) lazy_remote = true;
     if (lazy_remote) throw Error(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: a part on another device still holds unpacked text columns: move it with tfgpu_dbatch_to_lane (which packs) first");
+    if (p->col_order) throw Error(TFGPU_ERR_UNSUPPORTED, "tfgpu_dbatch_concat: a part's rows carry their own ColumnNames order (a collapsed batch)");
     materialize(*p);
   }
   hipStream_t st = ctx().stream;
@@ -196,13 +201,14 @@ static std::unique_ptr<tfgpu_dbatch> concat(const std::vector<const tfgpu_dbatch
     xcopy(d->p, m->p, bytes);
     return d;
   };
-  auto bitmap = [&](auto pick, bool any) -> Buf {  // pick(part) -> const Buf& ; a part without one = all ones
+  auto bitmap = [&](auto pick, bool any, bool null_means_ones = true) -> Buf {  // pick(part) -> const Buf& ; a part without one = all ones (validity) or all zeros (ABSENT)
     if (!any) return nullptr;
     Buf out = dalloc_zero((size_t)(n + 7) / 8 + 8);
     for (size_t g = 0; g < parts.size(); g++) {
       const int64_t k = parts[g]->nrows;
       if (!k) continue;
       Buf in = local(pick(*parts[g]), (size_t)(k + 7) / 8);
+      if (!in && !null_means_ones) continue;  // (the block starts zeroed)
       const int64_t nb = ((base[g] + k + 7) >> 3) - (base[g] >> 3);
       shard_splice_bits<<<blocks_of(nb), 256, 0, st>>>(ptr<uint8_t>(in), k, base[g], ptr<uint8_t>(out), in ? 0 : 1);
     }
@@ -247,6 +253,9 @@ static std::unique_ptr<tfgpu_dbatch> concat(const std::vector<const tfgpu_dbatch
     bool anyv = false;
     for (auto *p : parts) anyv = anyv || (bool)of(*p).validity;
     d.validity = bitmap([&](const tfgpu_dbatch &p) -> const Buf & { return of(p).validity; }, anyv);
+    bool anya = false;
+    for (auto *p : parts) anya = anya || (bool)of(*p).absent;
+    d.absent = bitmap([&](const tfgpu_dbatch &p) -> const Buf & { return of(p).absent; }, anya, false);  // the Bufferer's flush keeps every row's ColumnNames
     return d;
   };
   for (size_t i = 0; i < p0.cols.size(); i++) r->cols.push_back(col(i, false));
@@ -300,7 +309,7 @@ extern "C" {
 
 int tfgpu_dbatch_slice(const tfgpu_dbatch *b, int64_t row0, int64_t nrows, tfgpu_dbatch **out) {
   TF_API_BEGIN
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(b, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT bitmaps are cut / copied with the rows
   if (!b || !out || row0 < 0 || nrows < 0 || row0 + nrows > b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_slice: bad argument");
   if (row0 & 7) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_slice: row0 must be a multiple of 8 (bitmaps are cut at byte boundaries)");
   std::lock_guard<std::mutex> lk(ctx().mu);
@@ -313,7 +322,7 @@ int tfgpu_dbatch_slice(const tfgpu_dbatch *b, int64_t row0, int64_t nrows, tfgpu
 
 int tfgpu_dbatch_to_lane(const tfgpu_dbatch *b, int lane, tfgpu_dbatch **out) {
   TF_API_BEGIN
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(b, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT bitmaps are cut / copied with the rows
   if (!b || !out || lane < 0 || lane >= tfgpu_lane_count()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_to_lane: bad argument");
   { std::lock_guard<std::mutex> lk(ctx().mu); materialize(*b); tf::sync(); }  // everything enqueued for `b` on this lane has run
   *out = to_lane(*b, lane).release();
@@ -323,7 +332,7 @@ int tfgpu_dbatch_to_lane(const tfgpu_dbatch *b, int lane, tfgpu_dbatch **out) {
 
 int tfgpu_shard_rows(const tfgpu_dbatch *b, int nshards, const int *lanes, tfgpu_dbatch **out, int64_t *row0) {
   TF_API_BEGIN
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(b, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT bitmaps are cut / copied with the rows
   if (!b || !out || nshards < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_shard_rows: bad argument");
   for (int g = 0; lanes && g < nshards; g++) if (lanes[g] < 0 || lanes[g] >= tfgpu_lane_count()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_shard_rows: lane out of range");
   std::vector<int64_t> cuts((size_t)nshards + 1, 0);
@@ -352,7 +361,7 @@ int tfgpu_dbatch_concat(const tfgpu_dbatch *const *parts, int nparts, const int6
   if (!parts || !out || nparts < 1) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: bad argument");
   std::vector<const tfgpu_dbatch *> v;
   for (int g = 0; g < nparts; g++) { if (!parts[g]) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_concat: null part"); v.push_back(parts[g]); }
-  for (auto *b : v) tf::dense(b);  // rows that are still a selection (tfgpu_dbatch::pending)
+  for (auto *b : v) tf::dense(b, true);  // rows that are still a selection (tfgpu_dbatch::pending)
   std::lock_guard<std::mutex> lk(ctx().mu);
   *out = concat(v, row_base).release();
   return TFGPU_OK;

@@ -25,6 +25,7 @@ struct SzCol {
   const uint32_t *offsets;
   const uint8_t *data;      // R_JSON only
   const uint8_t *validity;
+  const uint8_t *absent;    // rows that do not list the column (DColumn::absent): no interface header either
   uint32_t fixed;           // size of a non-nil value without its payload bytes
   uint32_t var;             // 1: add the cell's byte length; 2: walk the JSON text
 };
@@ -94,6 +95,7 @@ __global__ void __launch_bounds__(256) deepsizeof_rows(const SzCol *cols, int nc
     s = 24 + 16ull * (uint64_t)ncols;
     for (int c = 0; c < ncols; c++) {
       const SzCol k = cols[c];
+      if (k.absent && ((k.absent[r >> 3] >> (r & 7)) & 1)) { s -= 16; continue; }  // ColumnValues is that much shorter
       if (k.validity && !((k.validity[r >> 3] >> (r & 7)) & 1)) continue;
       s += k.fixed;
       if (k.var == 1) s += k.offsets[r + 1] - k.offsets[r];
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(256) deepsizeof_rows(const SzCol *cols, int nc
 
 extern "C" int tfgpu_dbatch_deepsizeof(const tfgpu_dbatch *in, uint32_t flags, uint64_t *per_row, uint64_t *total) {
   TF_API_BEGIN
-  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(in, true);  // its rows may still be a selection (tfgpu_dbatch::pending); a row's ColumnValues hold the columns it lists
   if (!in || !total) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_deepsizeof: null argument");
   Context &cx = ctx();
   std::lock_guard<std::mutex> lk(cx.mu);
@@ -143,6 +145,7 @@ extern "C" int tfgpu_dbatch_deepsizeof(const tfgpu_dbatch *in, uint32_t flags, u
     k.offsets = ptr<uint32_t>(d.offsets);
     k.data = nullptr;
     k.validity = ptr<uint8_t>(d.validity);
+    k.absent = ptr<uint8_t>(d.absent);
     k.var = 0;
     switch (d.repr) {
       case TFGPU_R_STRING: case TFGPU_R_JSONNUM: k.fixed = 16; k.var = 1; break;
