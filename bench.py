@@ -1906,7 +1906,8 @@ class CollapseWorkload(Base):
 
     def setup(self):
         e, a = self.env, self.args
-        b, self.schema = e.workload.cdc_batch(a.rows)
+        self.toast = float(getattr(a, "toast", 0.0) or 0.0)
+        b, self.schema = e.workload.cdc_batch(a.rows, toast=self.toast)
         self.n = a.rows
         self.db = e.lib.DeviceBatch.upload(b)
 
@@ -1923,11 +1924,14 @@ class CollapseWorkload(Base):
         return {}
 
     def config(self):
-        return {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys, 60% of U/D with OldKeys, 15% of those change the PK) -> Collapse",
-                "rows_per_gpu_per_step": self.n, "rows_out_per_step": self.state["out_rows"]}
+        return {"workload": "CDC slice (35% insert / 45% update / 20% delete over rows/4 keys, 60% of U/D with OldKeys, 15% of those change the PK) -> Collapse"
+                            + (" — %.0f%% of the Updates leave the text column out (TOAST): compareColumns merges on the device" % (100 * self.toast) if self.toast else ""),
+                "rows_per_gpu_per_step": self.n, "rows_out_per_step": self.state["out_rows"], "toast": self.toast}
 
     def cpu(self):
         from oracle import oracle as ora
+        if self.toast:
+            return self.cpu_toast(ora)
         k = min(max(self.args.cpu_rows, 1 << 18), self.n)
         b2, s2 = self.env.workload.cdc_batch(k)
         r1 = ora.collapse(b2, s2)
@@ -1950,6 +1954,44 @@ class CollapseWorkload(Base):
             return _parity(k, "Collapse: surviving rows, their order, kinds, cells and OldKeys presence against the oracle", why, compared_output_rows=got.nrows)
         out["parity"] = _guard_parity(check)
         return out
+
+
+def _collapse_cpu_toast(self, ora):
+    """The TOAST stream through the oracle's ROW-WISE Collapse (items with their own ColumnNames, as the Go loop sees them) on a bounded slice,
+    and the device's rows for the same slice against it: names, their order, values, kinds, OldKeys, source rows."""
+    cc = _test_helpers("collapse_cases")
+    k = min(self.n, 1 << 16)
+    b2, s2 = self.env.workload.cdc_batch(k, toast=self.toast)
+    b2.schema = s2
+    items = [dict(it, keys=["id"], old_names=[o[0] for o in it["old"]], old_values=[o[1] for o in it["old"]]) for it in cc.items_of(b2)]
+    for it in items:
+        it["values"] = [[v[0], v[1].decode("latin-1") if isinstance(v[1], (bytes, bytearray)) else v[1]] for v in it["values"]]
+    t0 = time.perf_counter()
+    want = ora.collapse_rows(items)
+    sec = time.perf_counter() - t0
+    out = {"value": round(k / sec, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": f"a {k}-row slice of the same stream through the oracle's row-wise Collapse ({sec:.2f}s INCLUDING the JSON hand-over of the items to the C oracle), single thread",
+           "note": "a parity checker's timing, not a performance baseline (the items travel as JSON text)"}
+    out.update(host_info())
+
+    def check():
+        e = self.env
+        got = cc.items_of(e.lib.collapse(e.lib.DeviceBatch.upload(b2)).download())
+        exp = cc.norm_items(want)
+        why = None
+        if len(got) != len(exp):
+            why = "row count %d != %d" % (len(got), len(exp))
+        else:
+            for i, (g, w) in enumerate(zip(got, exp)):
+                if g != w:
+                    why = "row %d differs" % i
+                    break
+        return _parity(k, "Collapse over TOAST rows: every surviving row's ColumnNames (and their order), values, kind, OldKeys and source row against the oracle's row-wise Go loop", why, compared_output_rows=len(got))
+    out["parity"] = _guard_parity(check)
+    return out
+
+
+CollapseWorkload.cpu_toast = _collapse_cpu_toast
 
 
 class DebeziumWorkload(Base):
@@ -2207,6 +2249,7 @@ def main():
                     "(queue.DebeziumSerializer, key + value with inline schemas: tfgpu_debezium_emit)")
     ap.add_argument("--from-rows", action="store_true", help="configs0: also cross the boundary the way the reference would — boxed []interface{} rows fanned out into column buffers, "
                     "one crossing, fanned back in (tools/fanout/fanout_harness.cpp, INTEGRATION.md §2), timed per leg")
+    ap.add_argument("--toast", type=float, default=0.0, help="collapse workload: this share of the Updates leaves the text column out of its ColumnNames (TOAST): Collapse runs the compareColumns merge")
     ap.add_argument("--exchange", type=int, default=1, help="configs4 at 1 rank: 1 = every buffer still makes the RCCL round trip, 0 = skip the collective")
     args = ap.parse_args()
 

@@ -134,20 +134,28 @@ def hits_csv_options(header: bool = True) -> abi.CCsvOptions:
     return abi.csv_options(skip_rows=1 if header else 0)
 
 
-def cdc_batch(nrows: int, keys: int = 0, seed: int = SEED, p_old: float = 0.6, p_pk_change: float = 0.15):
+def cdc_batch(nrows: int, keys: int = 0, seed: int = SEED, p_old: float = 0.6, p_pk_change: float = 0.15, toast: float = 0.0):
     """A CDC stream slice for abstract.Collapse (BASELINE.json configs[4]: debezium stream → hash-partition → dedup):
     (Batch, Schema) of `nrows` row events over `keys` primary keys (default nrows / 4: chains of ~4 events per key),
     35 % inserts, 45 % updates, 20 % deletes; Update / Delete rows carry OldKeys with probability p_old and
-    p_pk_change of those change the primary key.  Columns: id int64 (PK), ver int64, payload utf8 (24 bytes), ts int64."""
+    p_pk_change of those change the primary key.  Columns: id int64 (PK), ver int64, payload utf8 (24 bytes), ts int64.
+    toast > 0: that share of the Updates leaves `payload` out of its ColumnNames (an unchanged TOASTed column: Column.absent),
+    so Collapse runs compareColumns' merge (change_item_collapse.go:7-35, :86-100)."""
     rng = np.random.default_rng(seed)
     keys = keys or max(nrows // 4, 1)
     schema = abi.Schema([abi.ColSchema("id", "int64", True, "", ""), abi.ColSchema("ver", "int64", False, "", ""),
                          abi.ColSchema("payload", "utf8", False, "", ""), abi.ColSchema("ts", "int64", False, "", "")])
     ids = rng.integers(0, keys, size=nrows, dtype=np.int64)
     kind = rng.choice(np.array([abi.K_INSERT, abi.K_UPDATE, abi.K_DELETE], dtype=np.uint8), size=nrows, p=[0.35, 0.45, 0.20])
-    pay = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)[rng.integers(0, 16, size=(nrows, 24))].reshape(-1)
-    cols = [abi.Column("id", "int64", abi.R_INT64, values=ids), abi.Column("ver", "int64", abi.R_INT64, values=np.arange(nrows, dtype=np.int64)),
-            abi.Column("payload", "utf8", abi.R_STRING, offsets=(np.arange(nrows + 1, dtype=np.uint32) * 24), data=np.ascontiguousarray(pay)),
+    pay = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)[rng.integers(0, 16, size=(nrows, 24))]
+    paycol = abi.Column("payload", "utf8", abi.R_STRING, offsets=(np.arange(nrows + 1, dtype=np.uint32) * 24), data=np.ascontiguousarray(pay.reshape(-1)))
+    if toast > 0:
+        ab = (kind == abi.K_UPDATE) & (np.random.default_rng(seed ^ 0x70A57).random(nrows) < toast)
+        lens = np.where(ab, 0, 24).astype(np.uint32)
+        off = np.zeros(nrows + 1, np.uint32)
+        np.cumsum(lens, out=off[1:])
+        paycol = abi.Column("payload", "utf8", abi.R_STRING, offsets=off, data=np.ascontiguousarray(pay[~ab].reshape(-1)), validity=~ab, absent=ab)
+    cols = [abi.Column("id", "int64", abi.R_INT64, values=ids), abi.Column("ver", "int64", abi.R_INT64, values=np.arange(nrows, dtype=np.int64)), paycol,
             abi.Column("ts", "int64", abi.R_INT64, values=1_700_000_000_000 + np.arange(nrows, dtype=np.int64))]
     b = abi.Batch(cols, nrows, "public", "events", kind=kind)
     b.schema = schema
