@@ -540,6 +540,43 @@ def test_gpu_parse_refuses_foreign_frames(tf):
 
 
 @pytest.mark.gpu
+def test_gpu_prefix_compare_at_every_alignment_and_edge(tf, oracle):
+    """dbz_prefix_same reads a message in its own 16-byte lines and the bytes in front of the first / behind the last line apart: messages that
+    start at every alignment, each with ONE byte of the shared head changed — the first, those around the first aligned line, one inside, those
+    around the last line, the last — must not inherit the reference's frame: their frames, and everything parsed from them, are the full walk's
+    (a changed field name shows in the item's ColumnNames, a changed brace in the message's fate)."""
+    from transferia_amd import debezium
+    base = cdc_messages(3, seed=SEED0 + 31, weird=False)[0]            # k % 3 == 0: {"schema":…,"payload":…}
+    head = base.index(b'"payload":') + len(b'"payload":')
+    at_name = base.index(b'"field":"ver"') + len(b'"field":"v')         # inside the schema: changes a column's name
+    spots = sorted({0, 1, 7, 8, 15, 16, 17, 31, 32, at_name, head // 2, head - 33, head - 17, head - 16, head - 15, head - 9, head - 8, head - 2, head - 1})
+    for shift in range(0, 16):
+        msgs = [base]
+        filler = b'{"schema":null,"payload":null}' + b" " * shift       # moves every later message's start by `shift` bytes
+        for sp in spots:
+            bad = bytearray(base)
+            bad[sp] = ord("#") if bad[sp] != ord("#") else ord("$")
+            msgs += [filler, bytes(bad), base]
+        msgs += [base] * 8                                              # 64 messages and more: the opening message becomes the batch's reference (dbz_prefix_same)
+        assert len(msgs) >= 64
+        data, m = abi.messages(msgs)
+        exp_items, codes = oracle.debezium_parse(data, m)
+        parsed, errors = debezium.Parser(tf).parse(data, m)
+        want = expected_errors(codes, exp_items, msgs)
+        # (a `before` struct that no longer spells the `after` struct's fields is the stock code's: the device hands such a message over where the
+        #  reference, for an insert, never looks at it)
+        assert {k: v for k, v in errors.items() if k in want} == want and all(v == abi.ROW_HOST_FALLBACK for k, v in errors.items() if k not in want), shift
+        got = {}
+        for p in parsed:
+            got.update(device_items(tf, p))
+        for it in exp_items:
+            if it["src"] not in errors:
+                assert_same_items(got[it["src"]], it, (shift, it["src"]))
+        assert len(got) >= len(spots)   # the untouched copies between them all parse
+        assert sum(1 for c in codes if c != abi.ROW_OK) >= len(spots) - 2   # nearly every changed byte breaks the message for the reference too
+
+
+@pytest.mark.gpu
 def test_gpu_unpack_with_a_cached_prefix_equals_the_full_walk(tf, oracle):
     """tfgpu_debezium_unpack_cached: the head of an earlier batch's message stands in for the per-batch reference walk; frames and
     everything downstream are the same, for messages that share the head and for those that do not."""

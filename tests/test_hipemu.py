@@ -161,7 +161,7 @@ comm.close()
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("plain", 3), ("mismatch", 2), ("unnamed_old", 2), ("toast", 2), ("toast", 3)])
+@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("mismatch", 2), ("unnamed_old", 2), ("toast", 2), ("toast", 3)])
 def test_emulated_exchange_ranks(tmp_path, case, world):
     """tfgpu_exchange on world_size 2 / 3 without a GPU: one process per rank, the emulated kernels, RCCL replaced by the
     socket stand-in (tools/hipemu/fake_rccl.cpp) — the descriptor agreement, the grouped send/recv plan and the rebuild of

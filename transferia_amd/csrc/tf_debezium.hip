@@ -205,10 +205,25 @@ __global__ void __launch_bounds__(256) dbz_prefix_same(Params p) {
   const uint64_t r = p.pref ? 0 : p.ms[p.ref];
   bool diff = (uint64_t)p.ms[m + 1] - a < (uint64_t)p.plen + 2;   // room for a value and the closing brace
   if (!diff) {
-    const uint32_t nw = p.plen >> 3;
-    for (uint32_t w = lane; w < nw; w += 64) diff |= read8u(p.data, a + 8ull * w) != read8u(rb, r + 8ull * w);
-    const uint32_t tail = p.plen & 7u;
-    if (lane == 0 && tail) { const uint64_t mask = (1ull << (8 * tail)) - 1; diff |= ((read8u(p.data, a + 8ull * nw) ^ read8u(rb, r + 8ull * nw)) & mask) != 0; }
+    // The MESSAGE is what streams from HBM: it is read in its own 16-byte lines (one aligned global_load_dwordx4 a lane, 1 KiB a wave
+    // step); the reference's bytes for the same positions sit at another alignment and come out of the cache (two shifted 8-byte reads
+    // each).  What lies in front of the first line and behind the last one (< 16 bytes each) is compared by lanes 0 and 1.
+    const uint64_t a1 = (a + 15) & ~15ull;
+    const uint32_t pre = min((uint32_t)(a1 - a), p.plen), nint = (p.plen - pre) >> 4;
+    for (uint32_t c = lane; c < nint; c += 64) {
+      const uint4 x = *reinterpret_cast<const uint4 *>(p.data + a1 + 16ull * c);
+      const uint64_t o = r + pre + 16ull * c;
+      diff |= ((uint64_t)x.x | ((uint64_t)x.y << 32)) != read8u(rb, o) || ((uint64_t)x.z | ((uint64_t)x.w << 32)) != read8u(rb, o + 8);
+    }
+    auto edge = [&](uint32_t at, uint32_t n) {  // n < 16 bytes at offset `at` of both
+      for (uint32_t k = 0; k < n; k += 8) {
+        const uint32_t nb = min(n - k, 8u);
+        const uint64_t mask = nb == 8 ? ~0ull : (1ull << (8 * nb)) - 1;
+        diff |= ((read8u(p.data, a + at + k) ^ read8u(rb, r + at + k)) & mask) != 0;
+      }
+    };
+    if (lane == 0) edge(0, pre);
+    if (lane == 1) edge(pre + 16u * nint, p.plen - pre - 16u * nint);
   }
   const bool any = __any(diff);
   if (lane == 0) p.same[m] = any ? 0 : 1;
