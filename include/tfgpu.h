@@ -457,7 +457,8 @@ int tfgpu_dbatch_view(const tfgpu_dbatch *b, tfgpu_batch *view);
 int64_t tfgpu_dbatch_nrows(const tfgpu_dbatch *b);
 /* Gathers the rows of a batch that are still a selection, now (a sink that is about to read every column anyway); no-op otherwise. */
 int tfgpu_dbatch_dense(const tfgpu_dbatch *b);
-/* Copy into caller-allocated host buffers sized from the view.              */
+/* Copy into caller-allocated host buffers sized from the view — including, where the view shows them, every column's `absent` bitmap and
+ * `col_order` (TFGPU_ERR_INVALID when the batch has them and host_out has no room: a row that does not list a column is not a row with a nil). */
 int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *host_out);
 void tfgpu_dbatch_free(tfgpu_dbatch *b);
 

@@ -436,3 +436,31 @@ def test_toast_rows_through_the_bufferers_concat_and_the_measurer(tf, oracle):
     assert got == want
     cut = merged.slice(64, 104)   # rows 64 .. 167: the all-listed part and the head of the third
     assert [dict(x, src=0) for x in items_of(cut.download())] == [dict(x, src=0) for x in items_of(whole)[64:168]]
+
+
+def test_download_without_room_for_the_absent_bits_is_refused(tf):
+    """A binding that knows nothing of tfgpu_column.absent must not read a TOAST batch as if its rows listed nils."""
+    import ctypes as C
+    from collapse_cases import random_toast_items, batch_from_items
+    b, _ = batch_from_items(random_toast_items(3, 50), names=["id"] + ["c%d" % j for j in range(5)])
+    db = tf.DeviceBatch.upload(b)
+    v = db.view()
+    n = int(v.nrows)
+    carr = (abi.CColumn * v.ncols)()
+    keep = []
+    for i in range(v.ncols):
+        c = v.cols[i]
+        carr[i].name, carr[i].dtype, carr[i].repr = c.name, c.dtype, c.repr
+        if c.repr in abi.VAR_REPRS:
+            off, dat = np.zeros(n + 1, np.uint32), np.zeros(max(int(c.data_len), 1), np.uint8)
+            keep += [off, dat]
+            carr[i].offsets, carr[i].data, carr[i].data_len = off.ctypes.data, dat.ctypes.data, c.data_len
+        else:
+            vals = np.zeros(max(n, 1), abi.REPR_NP[c.repr])
+            keep.append(vals)
+            carr[i].values = vals.ctypes.data
+    hb = abi.CBatch()
+    hb.nrows, hb.ncols, hb.cols, hb.mem = n, v.ncols, carr, abi.MEM_HOST
+    assert tf.load().tfgpu_dbatch_download(db._h, C.byref(hb)) != 0
+    assert b"absent" in (tf.load().tfgpu_last_error() or b"")
+    assert db.download().nrows == n   # the binding that brings the room gets the rows

@@ -476,6 +476,11 @@ int tfgpu_dbatch_download(const tfgpu_dbatch *b, tfgpu_batch *h) {
   if (!b || !h) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: null argument");
   if (h->ncols != (int32_t)b->cols.size() || h->nrows != b->nrows) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: shape mismatch");
   if (h->n_old_keys && h->n_old_keys != (int32_t)b->old_keys.size()) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: old-key shape mismatch");
+  // rows that do not list every column, or list them in their own order, cannot come down as if they did: a caller that brought no room for the
+  // bitmaps / the order (a binding older than tfgpu_column.absent) is told so instead of reading nils where the items had no column at all
+  for (size_t i = 0; i < b->cols.size(); i++)
+    if (b->cols[i].absent && !h->cols[i].absent) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: column " + b->cols[i].name + " holds ABSENT cells (see the view): host_out->cols[i].absent must point at (nrows + 7) / 8 bytes");
+  if (b->col_order && !h->col_order) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_dbatch_download: the rows carry their own ColumnNames order (see the view): host_out->col_order must point at nrows * ncols uint16");
   std::lock_guard<std::mutex> lk(ctx().mu);
   materialize(*b);
   size_t n = (size_t)b->nrows;
