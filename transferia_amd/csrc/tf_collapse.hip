@@ -76,6 +76,8 @@ struct HashParams {
   const uint8_t *old_present; int32_t has_old_keys;  // bitmap (null = every row) / the batch carries OldKeys at all
   uint64_t *h;        // [2n][2]: (h1 | 1, h2); h1 == 0: the row has no OldKeys
   uint32_t *badflag;  // a float key that json.Marshal refuses (NaN / Inf)
+  uint32_t *dbg;      // TFGPU_COLLAPSE_DEBUG=1 (measurement only): [0] the longest probe sequence, [1] all probes
+  uint32_t *defer_n, *defer_list;  // entries whose place only a compare of the key texts decides (collapse_intern_text)
   int32_t weak;
 };
 __device__ __forceinline__ bool float_bad(const DCol &c, int64_t r) {
@@ -138,7 +140,11 @@ __device__ bool key_text_equal(const HashParams &p, int64_t a, int64_t b) {
 // Same key string?  Equal raw values of every key ⇒ equal strings; a fixed-width value that differs ⇒ different strings
 // (integers, bools, times and finite floats print injectively); var-width values that differ may still print alike
 // (invalid UTF-8 → U+FFFD): only then are the texts themselves compared.
-__device__ bool keys_equal(const HashParams &p, int64_t a, int64_t b) {
+// TEXT = false (collapse_intern, the kernel every entry runs): 2 = "only the texts can tell" — the entry is put off to
+// collapse_intern_text.  The text compare renders both keys three times through the json.Marshal emitter: inlined into the kernel of
+// every entry it cost 248 VGPRs and 224 bytes of scratch a lane (two waves a SIMD for a kernel of dependent random reads: 175 us
+// whatever the batch); on its own it is paid by the entries that need it — hash twins whose raw values differ, once in a blue moon.
+template <bool TEXT> __device__ int keys_equal(const HashParams &p, int64_t a, int64_t b) {
   const int64_t ra = a >> 1, rb = b >> 1;
   bool need_text = false;
   for (int k = 0; k < p.nkeys; k++) {
@@ -156,26 +162,42 @@ __device__ bool keys_equal(const HashParams &p, int64_t a, int64_t b) {
     } else {
       const int w = repr_width_dev(x.repr);
       const uint8_t *va = (const uint8_t *)x.values + ra * w, *vb = (const uint8_t *)y.values + rb * w;
-      for (int i = 0; i < w; i++) if (va[i] != vb[i]) return false;
-      if (x.repr == TFGPU_R_TIME && (x.nanos ? x.nanos[ra] : 0) != (y.nanos ? y.nanos[rb] : 0)) return false;
+      for (int i = 0; i < w; i++) if (va[i] != vb[i]) return 0;
+      if (x.repr == TFGPU_R_TIME && (x.nanos ? x.nanos[ra] : 0) != (y.nanos ? y.nanos[rb] : 0)) return 0;
     }
   }
-  return need_text ? key_text_equal(p, a, b) : true;
+  if (!need_text) return 1;
+  if constexpr (TEXT) return key_text_equal(p, a, b) ? 1 : 0;
+  else return 2;
 }
-__global__ void __launch_bounds__(256) collapse_intern(HashParams p, int64_t n2, uint32_t *owner, uint32_t mask, uint32_t *__restrict__ keyid) {
+template <bool TEXT> __device__ __forceinline__ void intern_entry(const HashParams &p, int64_t j, uint32_t *owner, uint32_t mask, uint32_t *__restrict__ keyid) {
   const uint64_t *__restrict__ h = p.h;
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n2) return;
   const uint64_t a = h[2 * j], b = h[2 * j + 1];
   if (a == 0) { keyid[j] = NOKEY; return; }
   uint32_t slot = (uint32_t)(b ^ (a >> 17)) & mask;
+  uint32_t probes = 0;
   for (;;) {
+    probes++;
     uint32_t o = __hip_atomic_load(&owner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (o == NOKEY) o = atomicCAS(&owner[slot], NOKEY, (uint32_t)j);
-    if (o == NOKEY || o == (uint32_t)j) { keyid[j] = slot; return; }
-    if (h[2 * (int64_t)o] == a && h[2 * (int64_t)o + 1] == b && keys_equal(p, j, (int64_t)o)) { keyid[j] = slot; return; }
+    if (o == NOKEY || o == (uint32_t)j) { keyid[j] = slot; break; }
+    if (h[2 * (int64_t)o] == a && h[2 * (int64_t)o + 1] == b) {
+      const int eq = keys_equal<TEXT>(p, j, (int64_t)o);
+      if (eq == 1) { keyid[j] = slot; break; }
+      if (eq == 2) { p.defer_list[atomicAdd(p.defer_n, 1u)] = (uint32_t)j; break; }  // it owns nothing yet: collapse_intern_text files it as a late comer
+    }
     slot = (slot + 1) & mask;  // another key (or, once in 2^128, another string with this hash): probe on
   }
+  if (p.dbg) { atomicMax(&p.dbg[0], probes); atomicAdd(&p.dbg[1], probes); }
+}
+__global__ void __launch_bounds__(256) collapse_intern(HashParams p, int64_t n2, uint32_t *owner, uint32_t mask, uint32_t *__restrict__ keyid) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n2) intern_entry<false>(p, j, owner, mask, keyid);
+}
+// the entries only the key TEXTS can place (usually none: the launch finds an empty list and leaves)
+__global__ void __launch_bounds__(256) collapse_intern_text(HashParams p, uint32_t *owner, uint32_t mask, uint32_t *__restrict__ keyid) {
+  const uint32_t n = *p.defer_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) intern_entry<true>(p, (int64_t)p.defer_list[i], owner, mask, keyid);
 }
 
 // ---- 3. components -----------------------------------------------------------------------------------------------
@@ -481,8 +503,16 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
   hp.h = ptr<uint64_t>(hashes); hp.badflag = ptr<uint32_t>(bad);
   static const bool weak = [] { const char *e = std::getenv("TFGPU_COLLAPSE_WEAK_HASH"); return e && e[0] == '1'; }();
   hp.weak = weak ? 1 : 0;
+  static const bool dbg_on = [] { const char *e = std::getenv("TFGPU_COLLAPSE_DEBUG"); return e && e[0] == '1'; }();
+  Buf dbgb = dbg_on ? dalloc_zero(16) : nullptr;
+  hp.dbg = ptr<uint32_t>(dbgb);
   collapse_hash<<<cgrid(n2), 256, 0, st>>>(hp);
+  Buf defer = dalloc((size_t)(n2 + 1) * 4);
+  TF_HIP(hipMemsetAsync(defer->p, 0, 4, st));
+  hp.defer_n = ptr<uint32_t>(defer); hp.defer_list = ptr<uint32_t>(defer) + 1;
   collapse_intern<<<cgrid(n2), 256, 0, st>>>(hp, n2, ptr<uint32_t>(owner), (uint32_t)(cap - 1), ptr<uint32_t>(keyid));
+  collapse_intern_text<<<(unsigned)std::min<int64_t>(cgrid(n2), 256), 256, 0, st>>>(hp, ptr<uint32_t>(owner), (uint32_t)(cap - 1), ptr<uint32_t>(keyid));
+  if (dbg_on) { const uint32_t *hd = d2h_u32(dbgb->p, 2); sync(); std::fprintf(stderr, "tfgpu collapse: %lld entries, table 2^%d, longest probe sequence %u, probes %u\n", (long long)n2, bits, hd[0], hd[1]); }
   collapse_link<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), ptr<uint8_t>(in.kind), n, ptr<uint32_t>(parent));
   Buf root = dalloc((size_t)n * 4), idx = dalloc((size_t)n * 4), sroot = dalloc((size_t)n * 4), sidx = dalloc((size_t)n * 4);
   collapse_roots<<<cgrid(n), 256, 0, st>>>(ptr<uint32_t>(keyid), ptr<uint8_t>(in.kind), n, ptr<uint32_t>(parent), ptr<uint32_t>(root), ptr<uint32_t>(idx));
