@@ -82,6 +82,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; print('
     bench "configs0" "--from-rows"
     bench "configs2 configs3 configs4 configs4d json sr sr_proto collapse debezium debezium_sr"
     timeout 400 python bench.py --workload configs4 --sink debezium > "$OUT/bench_configs4_debezium.json" 2> "$OUT/bench_configs4_debezium.err"; echo "== configs4 --sink debezium rc=$?"; line "$OUT/bench_configs4_debezium.json"
+    timeout 400 python bench.py --workload collapse --toast 0.5 > "$OUT/bench_collapse_toast.json" 2> "$OUT/bench_collapse_toast.err"; echo "== collapse --toast 0.5 rc=$?"; line "$OUT/bench_collapse_toast.json"
     stats "csv configs2 configs3 json sr debezium debezium_sr configs4d"
     echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s" ;;
   *) echo "unknown mode $MODE"; exit 2 ;;
