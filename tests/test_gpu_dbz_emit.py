@@ -727,6 +727,46 @@ def test_the_references_crud_fixtures_cut_to_the_device_columns(tf, name):
         assert isinstance(json.loads(got.messages()[0][1])["payload"]["before"], dict)   # the old row, not null
 
 
+def test_the_references_crud_fixtures_as_one_batch_with_absent_cells(tf):
+    """The insert and the three updates of the reference's CRUD fixtures in ONE device batch over the table's 59 columns: the items that list fewer
+    columns (update1 / update2: unchanged TOASTed values left out by the source) say so through tfgpu_column.absent, and every message — the
+    `__debezium_unavailable_value` members of update1's and update2's values included — is the oracle's, which test_dbz_emitter_oracle.py pins
+    to the reference's own canon bytes (emitter_crud_test__debezium_update1val.txt, …update2val2.txt)."""
+    from test_dbz_emitter_oracle import read
+    items = [E.unmarshal_change_item(read(nm)) for nm in ("insert", "update0", "update1", "update2")]
+    cols = items[0].cols
+    assert all([c.name for c in it.cols] == [c.name for c in cols] for it in items) and all(device_resident(c.original_type) for c in cols)
+    table = [(c.name, c.dtype, c.key, c.original_type) for c in cols]
+    names = [c.name for c in cols]
+
+    def typed(v):
+        g, x = v
+        if g == "time":
+            return ["time", (x[0] + (x[2] if len(x) > 2 else 0), x[1])]
+        if g in ("string", "bytes", "jsonnum", "json"):
+            return [g, bytes(x)]
+        return [g, x]
+    rows = [[typed(dict(zip(it.names, it.values))[nm]) if nm in it.names else ["nil", None] for nm in names] for it in items]
+    b = abi.batch_from_rows(schema_of(table), names, rows, items[0].schema, items[0].table, kinds=[it.kind for it in items])
+    partial = 0
+    for c in b.cols:
+        ab = np.array([c.name not in it.names for it in items], bool)
+        if ab.any():
+            c.absent = ab
+            c.validity = (np.ones(len(items), bool) if c.validity is None else c.validity) & ~ab
+            partial += 1
+    assert partial >= 1 and [len(it.names) < len(names) for it in items] == [False, False, True, True]
+    onames = next(it.old_names for it in items if it.old_names)
+    assert all((not it.old_names) or it.old_names == onames for it in items)
+    ob = abi.batch_from_rows(schema_of(table), onames, [[typed(v) for v in it.old_values] if it.old_names else [["nil", None]] * len(onames) for it in items], items[0].schema, items[0].table)
+    b.old_keys, b.old_present = ob.cols, np.array([bool(it.old_names) for it in items])
+    meta = ([it.id for it in items], [it.lsn for it in items], [it.commit_time for it in items])
+    got, want, rws = emit_both(tf, b, table, PARAMS, meta)
+    assert_same(got, want, rws)
+    assert len(want) == 1 + 1 + 1 + 3
+    assert sum(b"__debezium_unavailable_value" in v for _k, v in got.messages() if v) >= 2
+
+
 def test_what_stays_with_the_stock_emitter_is_refused_by_name(tf):
     def call(table, rows, params=PARAMS, **kw):
         b = abi.batch_from_rows(schema_of(table), [t[0] for t in table], rows, "public", "t")
