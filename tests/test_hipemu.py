@@ -160,26 +160,50 @@ comm.close()
 """
 
 
-@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
-@pytest.mark.parametrize("case,world", [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("mismatch", 2), ("unnamed_old", 2), ("toast", 2), ("toast", 3)])
-def test_emulated_exchange_ranks(tmp_path, case, world):
-    """tfgpu_exchange on world_size 2 / 3 without a GPU: one process per rank, the emulated kernels, RCCL replaced by the
-    socket stand-in (tools/hipemu/fake_rccl.cpp) — the descriptor agreement, the grouped send/recv plan and the rebuild of
-    offsets / bitmaps / OldKeys are the product code.  Expected rows come from the oracle's sharder."""
-    import json
+EXCHANGE_CASES = [("plain", 2), ("ragged", 2), ("empty_rank", 2), ("mismatch", 2), ("unnamed_old", 2), ("toast", 2), ("toast", 3)]
+
+
+@pytest.fixture(scope="module")
+def exchange_runs(tmp_path_factory):
+    """Every case's ranks, all cases side by side (a rank is mostly start-up — the interpreter, numpy, the two libraries; one case after
+    another they were 150 s of the CPU suite): {(case, world): [(returncode, stdout, stderr) per rank]}."""
     sys.path.insert(0, os.path.join(ROOT, "tools", "hipemu"))
     import build as emu_build
     so = emu_build.build()
     fake = os.path.join(os.path.dirname(so), "libfakerccl.so")
-    script = tmp_path / "worker.py"
-    script.write_text(EXCHANGE_WORKER)
     env = dict(os.environ, TFGPU_TEST_EMU_LIB=so, TFGPU_RCCL_LIB=fake)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), case, str(tmp_path / "uid")], stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    procs = {}
+    for case, world in EXCHANGE_CASES:
+        d = tmp_path_factory.mktemp("xchg_%s_%d" % (case, world))
+        script = d / "worker.py"
+        script.write_text(EXCHANGE_WORKER)
+        procs[(case, world)] = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), case, str(d / "uid")], stdout=subprocess.PIPE,
+                                                 stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    out = {}
+    for key, ps in procs.items():
+        res = []
+        for p in ps:
+            try:
+                o, e = p.communicate(timeout=900)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, e = p.communicate()
+                e += "\n(timed out)"
+            res.append((p.returncode, o, e))
+        out[key] = res
+    return out
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+@pytest.mark.parametrize("case,world", EXCHANGE_CASES)
+def test_emulated_exchange_ranks(exchange_runs, case, world):
+    """tfgpu_exchange on world_size 2 / 3 without a GPU: one process per rank, the emulated kernels, RCCL replaced by the
+    socket stand-in (tools/hipemu/fake_rccl.cpp) — the descriptor agreement, the grouped send/recv plan and the rebuild of
+    offsets / bitmaps / OldKeys are the product code.  Expected rows come from the oracle's sharder."""
+    import json
     outs = []
-    for p in procs:
-        o, e = p.communicate(timeout=600)
-        assert p.returncode == 0, e[-3000:]
+    for rc, o, e in exchange_runs[(case, world)]:
+        assert rc == 0, e[-3000:]
         outs.append(json.loads(o.strip().splitlines()[-1]))
     outs.sort(key=lambda d: d["rank"])
     if case in ("mismatch", "unnamed_old"):
