@@ -31,13 +31,13 @@ if "-k" in args:
     i = args.index("-k")
     K = "(%s) and (%s)" % (K, args[i + 1])
     del args[i:i + 2]
-# four workers by file (pytest-xdist, when it is there): the pre-flight is most of the CPU suite's wall-clock; each worker is a
+# workers test by test (pytest-xdist, when it is there; TFGPU_EMU_DIST=loadfile: by file): the pre-flight is most of the CPU suite's wall-clock; each worker is a
 # process of its own with the same TFGPU_TEST_EMU_LIB, and the conftest points lib at it
 par = []
 if "-n" not in args and os.environ.get("TFGPU_EMU_WORKERS", str(min(8, os.cpu_count() or 4))) != "1":
     try:
         import xdist  # noqa: F401
-        par = ["-n", os.environ.get("TFGPU_EMU_WORKERS", str(min(8, os.cpu_count() or 4))), "--dist", "loadfile"]
+        par = ["-n", os.environ.get("TFGPU_EMU_WORKERS", str(min(8, os.cpu_count() or 4))), "--dist", os.environ.get("TFGPU_EMU_DIST", "load")]
     except ImportError:
         pass
 sys.exit(pytest.main(["-m", "gpu", "-q", "-p", "no:cacheprovider", *par, "-k", K, os.path.join(ROOT, "tests"), *args]))
