@@ -731,7 +731,8 @@ typedef struct tfgpu_sr_json_options {
   const tfgpu_sr_property *props; /* util.MapKeysInOrder(Properties): sorted by name, unique               */
   const char *table_ns;         /* BuildJSONTableID(tableNamePolicy, title) (table_name_policy.go:73-92)     */
   const char *table_name;
-  int32_t is_generate_updates;  /* absent optional fields leave ColumnNames: not columnar → TFGPU_ERR_UNSUPPORTED */
+  int32_t is_generate_updates;  /* isGenerateUpdates (format_json.go:44-47): every item is an Update and lists only the optional fields its
+                                   payload holds (utils_json.go:57-63) — the others are ABSENT cells (tfgpu_column.absent) */
   int32_t report_frame_errors;  /* also report the SR_SHORT / SR_MAGIC frames (set it in one call per batch) */
 } tfgpu_sr_json_options;
 /* makeChangeItemsFromMessageWithJSON + processPayload + convertTypes (format_json.go:15-67, utils_json.go:27-128) for

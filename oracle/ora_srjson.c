@@ -57,13 +57,15 @@ static int frame_item(ora_batch *out, const tfgpu_sr_json_options *o, ora_names 
   jv *m = decode_map(p, n, &is_null);
   if (!m && !is_null) return TFGPU_ROW_JSON_SYNTAX;  /* "Can't unmarshal data changes from message" */
   ora_value *vals = (ora_value *)calloc((size_t)(o->nprops ? o->nprops : 1), sizeof(ora_value));
+  char *listed = (char *)malloc((size_t)(o->nprops ? o->nprops : 1));
+  memset(listed, 1, (size_t)(o->nprops ? o->nprops : 1));
   int code = 0;
   for (int j = 0; j < o->nprops && !code; j++) {
     const tfgpu_sr_property *pr = &o->props[j];
     const jv *v = NULL;
     if (m) { size_t kl = strlen(pr->name); for (int i = 0; i < m->nk; i++) if (m->klen[i] == kl && !memcmp(m->keys[i], pr->name, kl)) v = m->kids[i]; }
     ora_value *dst = &vals[j];
-    if (!v) { if (pr->required) code = TFGPU_ROW_SR_REQUIRED; continue; }  /* absent optional field: nil (inserts carry every column) */
+    if (!v) { if (pr->required) code = TFGPU_ROW_SR_REQUIRED; else if (o->is_generate_updates) listed[j] = 0; continue; }  /* absent optional field: nil (inserts carry every column); isGenerateUpdates: not listed (utils_json.go:57-63) */
     if (v->t == JV_NULL && !pr->required) continue;                         /* in == nil && nullable */
     switch (pr->json_type) {
       case TFGPU_SRT_BOOLEAN: if (v->t == JV_TRUE || v->t == JV_FALSE) { dst->kind = OV_BOOL; dst->v.b = v->t == JV_TRUE; } else code = TFGPU_ROW_SR_TYPE; break;
@@ -79,13 +81,24 @@ static int frame_item(ora_batch *out, const tfgpu_sr_json_options *o, ora_names 
     }
   }
   jv_free(m);
-  if (code) { for (int j = 0; j < o->nprops; j++) ora_value_free(&vals[j]); free(vals); return code; }
+  if (code) { for (int j = 0; j < o->nprops; j++) ora_value_free(&vals[j]); free(vals); free(listed); return code; }
   ora_item *it = ora_batch_push(out);
-  it->kind = TFGPU_K_INSERT;
+  it->kind = o->is_generate_updates ? TFGPU_K_UPDATE : TFGPU_K_INSERT;  /* format_json.go:44-47 */
   it->ns = strdup(o->table_ns ? o->table_ns : ""); it->table = strdup(o->table_name ? o->table_name : ""); it->part_id = strdup("");
-  it->names = names; names->refs++;
   it->schema = sch; sch->refs++;
-  it->nvalues = o->nprops; it->values = vals;
+  int nl = 0;
+  for (int j = 0; j < o->nprops; j++) nl += listed[j];
+  if (nl == o->nprops) { it->names = names; names->refs++; it->nvalues = o->nprops; it->values = vals; }
+  else {  /* the item lists the fields its payload holds */
+    ora_names *own = (ora_names *)calloc(1, sizeof *own);
+    own->refs = 1; own->n = nl; own->names = (char **)calloc((size_t)(nl ? nl : 1), sizeof(char *));
+    ora_value *v2 = (ora_value *)calloc((size_t)(nl ? nl : 1), sizeof(ora_value));
+    int k = 0;
+    for (int j = 0; j < o->nprops; j++) if (listed[j]) { own->names[k] = strdup(o->props[j].name); v2[k++] = vals[j]; }
+    free(vals);
+    it->names = own; it->nvalues = nl; it->values = v2;
+  }
+  free(listed);
   it->src_row = ordinal;
   return 0;
 }

@@ -222,9 +222,10 @@ static size_t repr_width(int r) {
   return 0;
 }
 
-#define VAL(it) (old ? ((it)->n_old > c ? &(it)->old_values[c] : &NILV) : &(it)->values[c])
+/* idx (ColumnValues only): where item r holds this column, -1 = the item does not list it (an ABSENT cell: nil here, its bit in col->absent) */
+#define VAL(it) (old ? ((it)->n_old > c ? &(it)->old_values[c] : &NILV) : idx ? (idx[(it) - b->items] >= 0 ? &(it)->values[idx[(it) - b->items]] : &NILV) : &(it)->values[c])
 static const ora_value NILV = {0};
-static void fill_column(tfgpu_column *col, const ora_batch *b, const ora_item *f, const char *name, int c, int old) {
+static void fill_column(tfgpu_column *col, const ora_batch *b, const ora_item *f, const char *name, int c, int old, const int *idx) {
   {
     col->name = dups(name);
     /* dtype by name from the row's schema */
@@ -292,7 +293,52 @@ tfgpu_batch *ora_to_columns(const ora_batch *b) {
     const char *p = b->items[r].part_id;
     cb->part_id[r] = (p && *p >= '0' && *p <= '9') ? (uint32_t)strtoul(p, NULL, 10) : 0;
   }
-  for (int c = 0; c < cb->ncols; c++) fill_column(&cb->cols[c], b, f, f->names && c < f->names->n ? f->names->names[c] : "", c, 0);
+  /* items that list different columns (TOAST-style Updates, isGenerateUpdates, isAbsent): the batch's columns are the first item's TableSchema
+   * (when every listed name is in it) or the names in order of first appearance; an item that does not list a column is ABSENT there */
+  int ragged = 0;
+  for (int64_t r = 1; r < b->n && !ragged; r++) {
+    const ora_item *it = &b->items[r];
+    if (it->names == f->names) continue;
+    if (it->nvalues != f->nvalues) { ragged = 1; break; }
+    for (int c = 0; c < it->nvalues; c++) if (strcmp(it->names->names[c], f->names->names[c])) { ragged = 1; break; }
+  }
+  if (ragged) {
+    char **un = NULL; int nu = 0, capu = 0;
+    int covered = f->schema != NULL;
+    for (int64_t r = 0; r < b->n && covered; r++) for (int c = 0; c < b->items[r].nvalues && covered; c++) {
+      int hit = 0;
+      for (int k = 0; k < f->schema->ncols; k++) if (!strcmp(f->schema->cols[k].name, b->items[r].names->names[c])) { hit = 1; break; }
+      if (!hit) covered = 0;
+    }
+    if (covered) { nu = f->schema->ncols; un = (char **)calloc((size_t)(nu ? nu : 1), sizeof(char *)); for (int k = 0; k < nu; k++) un[k] = f->schema->cols[k].name; }
+    else for (int64_t r = 0; r < b->n; r++) for (int c = 0; c < b->items[r].nvalues; c++) {
+      const char *nm = b->items[r].names->names[c];
+      int hit = 0;
+      for (int k = 0; k < nu; k++) if (!strcmp(un[k], nm)) { hit = 1; break; }
+      if (hit) continue;
+      if (nu == capu) { capu = capu ? capu * 2 : 16; un = (char **)realloc(un, sizeof(char *) * (size_t)capu); }
+      un[nu++] = (char *)nm;
+    }
+    free(cb->cols);
+    cb->ncols = nu;
+    cb->cols = (tfgpu_column *)calloc((size_t)(nu ? nu : 1), sizeof(tfgpu_column));
+    int *idx = (int *)malloc(sizeof(int) * (size_t)b->n);
+    for (int k = 0; k < nu; k++) {
+      int any_absent = 0;
+      for (int64_t r = 0; r < b->n; r++) {
+        idx[r] = -1;
+        for (int c = 0; c < b->items[r].nvalues; c++) if (!strcmp(b->items[r].names->names[c], un[k])) idx[r] = c;  /* (a later duplicate wins, like AsMap) */
+        if (idx[r] < 0) any_absent = 1;
+      }
+      fill_column(&cb->cols[k], b, f, un[k], k, 0, idx);
+      if (any_absent) {
+        cb->cols[k].absent = (uint8_t *)calloc((size_t)((b->n + 7) / 8), 1);
+        for (int64_t r = 0; r < b->n; r++) if (idx[r] < 0) cb->cols[k].absent[r >> 3] |= (uint8_t)(1u << (r & 7));
+      }
+    }
+    free(idx); free(un);
+  } else
+  for (int c = 0; c < cb->ncols; c++) fill_column(&cb->cols[c], b, f, f->names && c < f->names->n ? f->names->names[c] : "", c, 0, NULL);
   /* OldKeys: columns by the KeyNames of the first row that has them */
   const ora_item *fo = NULL;
   for (int64_t r = 0; r < b->n && !fo; r++) if (b->items[r].n_old > 0) fo = &b->items[r];
@@ -301,7 +347,7 @@ tfgpu_batch *ora_to_columns(const ora_batch *b) {
     cb->old_keys = (tfgpu_column *)calloc((size_t)fo->n_old, sizeof(tfgpu_column));
     cb->old_keys_present = (uint8_t *)calloc((size_t)((b->n + 7) / 8), 1);
     for (int64_t r = 0; r < b->n; r++) if (b->items[r].n_old > 0) cb->old_keys_present[r >> 3] |= (uint8_t)(1u << (r & 7));
-    for (int c = 0; c < fo->n_old; c++) fill_column(&cb->old_keys[c], b, f, fo->old_names->names[c], c, 1);
+    for (int c = 0; c < fo->n_old; c++) fill_column(&cb->old_keys[c], b, f, fo->old_names->names[c], c, 1, NULL);
   }
   return cb;
 }
@@ -310,7 +356,7 @@ void ora_columns_free(tfgpu_batch *cb) {
   if (!cb) return;
   for (int c = 0; c < cb->ncols; c++) {
     tfgpu_column *col = &cb->cols[c];
-    free((void *)col->name); free(col->values); free(col->offsets); free(col->data); free(col->nanos); free(col->validity);
+    free((void *)col->name); free(col->values); free(col->offsets); free(col->data); free(col->nanos); free(col->validity); free(col->absent);
   }
   for (int c = 0; c < cb->n_old_keys; c++) {
     tfgpu_column *col = &cb->old_keys[c];

@@ -386,6 +386,38 @@ def _regular_payloads(rng, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("regular", [False, True])
+def test_gpu_is_generate_updates(tf, oracle, regular):
+    """isGenerateUpdates (format_json.go:44-47, utils_json.go:57-63): every item is an Update whose ColumnNames hold the optional fields its
+    payload holds — ABSENT cells (tfgpu_column.absent) for the others, where the insert form puts a nil.  Cells, kinds and which row lists
+    what against the oracle, over the random payloads (the per-frame walker) and the regular ones (the tile parser)."""
+    rng = np.random.default_rng(SEED0 + 4300 + regular)
+    schema, payloads = (_regular_payloads if regular else _random_payloads)(rng, 3000)
+    frames = [b"\0" + (5).to_bytes(4, "big") + p for p in payloads]
+    data, cm = abi.messages(frames, offsets=np.arange(len(frames)))
+    o = confluent_sr.sr_json_options(5, schema, is_generate_updates=True)
+    ref = oracle.sr_json_parse(o, data, cm)
+    got = tf.sr_json_parse(o, data, cm)
+    assert {e[0]: e[1] for e in got.errors} == {e[0]: e[1] for e in ref.errors}
+    gb, rb = got.batch, ref.batch
+    assert gb.nrows == rb.nrows > 1000 and np.array_equal(gb.src_row, rb.src_row)
+    assert gb.kind is not None and set(int(k) for k in gb.kind) == {abi.K_UPDATE} == set(int(k) for k in rb.kind)
+    assert [c.name for c in gb.cols] == [c.name for c in rb.cols]
+    some = 0
+    for g, r in zip(gb.cols, rb.cols):
+        ga = g.absent if g.absent is not None else np.zeros(gb.nrows, bool)
+        ra = r.absent if r.absent is not None else np.zeros(rb.nrows, bool)
+        assert np.array_equal(ga, ra), g.name
+        some += int(ga.sum())
+        assert (g.absent is None) == (not ra.any()), g.name   # a column every row lists carries no bitmap
+    assert some > 500
+    assert abi.batch_rows(gb) == abi.batch_rows(rb)
+    # the same bytes as inserts: every row lists every column, the fields that are not there are nils
+    ins = tf.sr_json_parse(confluent_sr.sr_json_options(5, schema), data, cm).batch
+    assert all(c.absent is None for c in ins.cols) and abi.batch_rows(ins) == abi.batch_rows(gb)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [40, 3000, 20000])
 def test_gpu_tile_path_matches_oracle(tf, oracle, n):
     rng = np.random.default_rng(SEED0 + (4100 + n))

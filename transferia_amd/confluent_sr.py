@@ -58,9 +58,9 @@ def build_json_table_id(title: str, policy: str = POLICY_DEBEZIUM_STYLE, manual_
 
 
 def sr_json_options(schema_id: int, schema_text: str, policy: str = POLICY_DEBEZIUM_STYLE, manual_table_name: str = "",
-                    report_frame_errors: bool = True) -> abi.CSrJsonOptions:
+                    report_frame_errors: bool = True, is_generate_updates: bool = False) -> abi.CSrJsonOptions:
     _title, rows, ns, table = _compile(schema_text, policy, manual_table_name)
-    return abi.sr_json_options(schema_id, rows, ns, table, report_frame_errors=report_frame_errors)
+    return abi.sr_json_options(schema_id, rows, ns, table, is_generate_updates=is_generate_updates, report_frame_errors=report_frame_errors)
 
 
 def table_schema(rows, ns: str = "", table: str = "") -> abi.Schema:
@@ -86,7 +86,8 @@ class ConfluentSrParser:
     nil rest); frames of a schema the registry does not know, or of a non-JSON schema, are the stock parser's business.
     """
 
-    def __init__(self, registry, policy: str = POLICY_DEBEZIUM_STYLE, manual_table_name: str = ""):
+    def __init__(self, registry, policy: str = POLICY_DEBEZIUM_STYLE, manual_table_name: str = "", is_generate_updates: bool = False):
+        self.is_generate_updates = bool(is_generate_updates)  # ParserConfig*.IsGenerateUpdates: JSON items become Updates listing the fields their payload holds
         self.registry, self.policy, self.manual = registry, policy, manual_table_name
         self._plans = {}
 
@@ -134,7 +135,7 @@ class ConfluentSrParser:
                     if f[4] == 0 and f[3] == sid:
                         fate[k] = {"fallback": True, "msg": f[0]}
                 continue
-            opts = sr_json_options(sid, text, self.policy, self.manual, report_frame_errors=first)
+            opts = sr_json_options(sid, text, self.policy, self.manual, report_frame_errors=first, is_generate_updates=self.is_generate_updates)
             first = False
             res = engine.sr_json_parse(opts, data, msgs)
             b = res.batch

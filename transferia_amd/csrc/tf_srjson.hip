@@ -660,6 +660,25 @@ __global__ void __launch_bounds__(256) sr_pack_validity(const OutCol *cols, int3
   cols[j].validity[b] = (uint8_t)v;
 }
 
+// isGenerateUpdates (format_json.go:44-47, utils_json.go:57-63): an optional field the payload does not hold is not among the item's ColumnNames —
+// the ABSENT bitmap of its column (DColumn::absent), one output byte a thread, and a flag per property that has any
+__global__ void __launch_bounds__(256) sr_pack_absent(Params p, const int32_t *opt, int nopt, uint8_t *const *bits, uint32_t *colflag) {
+  const int64_t nb = (p.nrows + 7) / 8;
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= (int64_t)nopt * nb) return;
+  const int k = (int)(it / nb); const int64_t b = it - (int64_t)k * nb;
+  const int j = opt[k];
+  uint32_t v = 0;
+  for (int q = 0; q < 8; q++) {
+    const int64_t r = b * 8 + q;
+    if (r >= p.nrows) break;
+    const uint64_t rec = p.vrec[(int64_t)j * p.nframes + p.row_frame[r]];
+    if (((uint32_t)(rec >> 56) & VT_MASK) == VT_ABSENT) v |= 1u << q;
+  }
+  bits[k][b] = (uint8_t)v;
+  if (v) atomicOr(&colflag[k], 1u);
+}
+
 static inline unsigned nblk(int64_t n, int t) { return (unsigned)std::max<int64_t>(1, (n + t - 1) / t); }
 
 // input bytes + message starts in HBM, frames counted and listed; returns the frame count
@@ -751,7 +770,6 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
                                    tfgpu_dbatch **out, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
   TF_API_BEGIN
   if (!o || !out || (len && !bytes) || (o->nprops && !o->props)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_sr_json_parse: null argument");
-  if (o->is_generate_updates) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR json: isGenerateUpdates drops absent fields from ColumnNames (rows of different shapes): not device-resident");
   const int np = o->nprops;
   std::string names;
   std::vector<sr::Prop> props((size_t)np);
@@ -875,6 +893,22 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     if (np) sr::sr_pack_validity<<<sr::nblk((int64_t)np * ((nrows + 7) / 8), 256), 256, 0, st>>>(ptr<sr::OutCol>(boc), np, nrows);
   }
   if (np == 0 && nrows) return tf::fail(TFGPU_ERR_UNSUPPORTED, "confluent SR json: a schema without properties");
+  // isGenerateUpdates: every item is an Update, and lists the optional fields its payload holds
+  std::vector<int32_t> optp;
+  std::vector<Buf> optbits;
+  const uint32_t *habs = nullptr;
+  if (o->is_generate_updates && nrows) {
+    db->kind = dalloc((size_t)nra);
+    TF_HIP(hipMemsetAsync(db->kind->p, TFGPU_K_UPDATE, (size_t)nra, st));
+    for (int j = 0; j < np; j++) if (!o->props[j].required) optp.push_back(j);
+    if (!optp.empty()) {
+      std::vector<uint8_t *> bp;
+      for (size_t k = 0; k < optp.size(); k++) { optbits.push_back(dalloc((size_t)((nra + 7) / 8) + 8)); bp.push_back(ptr<uint8_t>(optbits.back())); }
+      Buf bopt = upload_small(optp.data(), optp.size() * 4), bbp = upload_small(bp.data(), bp.size() * sizeof(uint8_t *)), colflag = dalloc_zero(optp.size() * 4);
+      sr::sr_pack_absent<<<sr::nblk((int64_t)optp.size() * ((nrows + 7) / 8), 256), 256, 0, st>>>(p, ptr<int32_t>(bopt), (int)optp.size(), ptr<uint8_t *>(bbp), ptr<uint32_t>(colflag));
+      habs = d2h_u32(colflag->p, optp.size());  // read at the next sync: a column no row leaves out carries no bitmap
+    }
+  }
   if (ntext) {
     exclusive_scan_u32_segments(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);  // offsets in place, the total at [nrows]
     const uint32_t *tot = segment_totals_to_host(ptr<uint32_t>(lens_all), nrows, ntext, seg_stride);
@@ -919,6 +953,7 @@ extern "C" int tfgpu_sr_json_parse(const tfgpu_sr_json_options *o, const void *b
     }
   }
   tf::sync();
+  for (size_t k = 0; habs && k < optp.size(); k++) if (habs[k]) db->cols[(size_t)optp[k]].absent = optbits[k];
   if (nerrs) *nerrs = ne;
   *out = db.release();
   return TFGPU_OK;
