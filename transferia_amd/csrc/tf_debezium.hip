@@ -852,8 +852,15 @@ struct OutCol {
 struct DbzRow { int64_t msg; uint64_t lsn, commit_time; uint32_t id; uint8_t names_form, pad[3]; };
 static_assert(sizeof(DbzRow) == sizeof(tfgpu_dbz_row), "row meta layout");
 
-__global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *cols, int32_t *src_row, uint8_t *kinds, uint8_t *old_present8, DbzRow *rows) {
-  const int j = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the field is the grid's y: a scalar)
+// Three kernels by what a field's receiver costs (the fields of a class are the grid's y, through `flist`): CLS 0 — booleans, integers,
+// strings, base64 lengths: a few registers; CLS 1 — float64 (the Eisel-Lemire parse and its 128-bit table); CLS 2 — the rendered logical
+// types (decimals as big integers, points, variable-scale decimals).  One kernel for all of them ran every integer cell at the rendered
+// types' 120 VGPRs and 160 bytes of scratch (four waves a SIMD for a kernel of dependent random reads).
+enum { DC_LIGHT = 0, DC_FLOAT = 1, DC_RENDER = 2 };
+__host__ __device__ inline int dbz_field_class(int op) { return op == TFGPU_DBZ_FLOAT64 ? DC_FLOAT : (op >= TFGPU_DBZ_BOOLEAN && op <= TFGPU_DBZ_BYTES) ? DC_LIGHT : DC_RENDER; }
+template <int CLS>
+__global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *cols, const int32_t *flist, int32_t *src_row, uint8_t *kinds, uint8_t *old_present8, DbzRow *rows) {
+  const int j = flist[blockIdx.y]; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the field is the grid's y: a scalar)
   if (r >= p.nrows) return;
   const uint32_t m = p.row_msg[r];
   const OutCol &c = cols[j];
@@ -869,6 +876,17 @@ __global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *c
   const bool nil = vt == VT_NULL;
   c.valid8[r] = (!nil && kind != TFGPU_K_DELETE) ? 1 : 0;         // a Delete keeps ColumnNames / ColumnValues nil
   if (c.old8) c.old8[r] = (!nil && kind != TFGPU_K_INSERT) ? 1 : 0;
+  if constexpr (CLS == DC_FLOAT) {
+    double d = 0;
+    if (!nil) { tf::Field fl{&rd, vs, vl}; parse_float_go(fl, 0, vl, p.p10, p.p128, &d); }
+    ((double *)c.values)[r] = d;
+    return;
+  } else if constexpr (CLS == DC_RENDER) {
+    CountSink s;
+    if (!nil) render_text(s, rd, f, vtr, vs, vl);
+    c.lens[r] = s.n;
+    return;
+  } else
   switch (f.op) {
     case TFGPU_DBZ_BOOLEAN: ((uint8_t *)c.values)[r] = vt == VT_TRUE; break;
     case TFGPU_DBZ_INT8: case TFGPU_DBZ_INT16: case TFGPU_DBZ_INT32: case TFGPU_DBZ_INT64: {
@@ -880,12 +898,6 @@ __global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *c
       else ((int64_t *)c.values)[r] = x;
       break;
     }
-    case TFGPU_DBZ_FLOAT64: {
-      double d = 0;
-      if (!nil) { tf::Field fl{&rd, vs, vl}; parse_float_go(fl, 0, vl, p.p10, p.p128, &d); }
-      ((double *)c.values)[r] = d;
-      break;
-    }
     case TFGPU_DBZ_STRING:
       if (nil) c.lens[r] = 0;
       else if (vt == VT_NUM) c.lens[r] = vl;
@@ -893,7 +905,7 @@ __global__ void __launch_bounds__(256) dbz_cell_values(Params p, const OutCol *c
       else { CountSink s; emit_unquoted(s, rd, vs, vl); c.lens[r] = s.n; }
       break;
     case TFGPU_DBZ_BYTES: { int n = 0; if (!nil) n = b64_decode(TextIter(rd, vt, vs, vl), [](uint32_t) {}); c.lens[r] = n > 0 ? (uint32_t)n : 0u; break; }
-    default: { CountSink s; if (!nil) render_text(s, rd, f, vtr, vs, vl); c.lens[r] = s.n; }
+    default: break;  // (a rendered type: CLS 2)
   }
 }
 // The text cells that are a plain byte range of the message (a string field's string without escapes, or its number token) go
@@ -928,6 +940,8 @@ __global__ void __launch_bounds__(256) dbz_copy_words(Params p, const OutCol *co
   auto so = [&](int64_t r) { return dbz_plain_src(p, j, r, nullptr); };
   segcopy_run<1>(c.lens, p.nrows, (int64_t)blockIdx.x * 256, p.data, c.data, so, doff, soff);
 }
+// RENDER == false: strings and base64 (the columns whose receiver is TFGPU_DBZ_STRING / _BYTES); true: the rendered logical types
+template <bool RENDER>
 __global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *cols, const int32_t *text_cols, int32_t ntext, int plain_done) {
   const int t = (int)blockIdx.y; const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.nrows) return;
@@ -946,12 +960,12 @@ __global__ void __launch_bounds__(256) dbz_cell_text(Params p, const OutCol *col
     for (; k + 8 <= n; k += 8) s.put_word(rd.word(a + k), 8);
     if (k < n) s.put_word(rd.word(a + k) & ((1ull << (8 * (n - k))) - 1), n - k);
   };
-  if (f.op == TFGPU_DBZ_STRING) {
+  if constexpr (RENDER) render_text(s, rd, f, vtr, vs, vl);
+  else if (f.op == TFGPU_DBZ_STRING) {
     if (vt == VT_NUM) copy_raw(vs, vl);
     else if (vtr & VT_PLAIN) copy_raw(vs + 1, vl - 2);
     else emit_unquoted(s, rd, vs, vl);
-  } else if (f.op == TFGPU_DBZ_BYTES) b64_decode(TextIter(rd, vt, vs, vl), [&](uint32_t b) { s.put(b); });
-  else render_text(s, rd, f, vtr, vs, vl);
+  } else b64_decode(TextIter(rd, vt, vs, vl), [&](uint32_t b) { s.put(b); });
   s.flush();
 }
 // rows that do not list a column (see the walker's isAbsent note): one flag byte per (field, row) and a flag per field that has any
@@ -1502,8 +1516,17 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     dbz::dbz_row_msgs<<<dbz::nblk(nmsg, 256), 256, 0, st>>>(p);
     if (nf) {
       KernelTimer t("dbz_cell_values");
-      dbz::dbz_cell_values<<<dim3(dbz::nblk(nrows, 256), (unsigned)nf), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(db->src_row), ptr<uint8_t>(db->kind), ptr<uint8_t>(old8),
+      std::vector<int32_t> fl[3];
+      for (int j = 0; j < nf; j++) fl[dbz::dbz_field_class(o->fields[j].op)].push_back(j);
+      auto launch = [&](auto kernel, const std::vector<int32_t> &l) {
+        if (l.empty()) return;
+        Buf bl = upload_small(l.data(), l.size() * 4);
+        kernel<<<dim3(dbz::nblk(nrows, 256), (unsigned)l.size()), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(bl), ptr<int32_t>(db->src_row), ptr<uint8_t>(db->kind), ptr<uint8_t>(old8),
                                                                                 reinterpret_cast<dbz::DbzRow *>(drows->p));
+      };
+      launch(dbz::dbz_cell_values<dbz::DC_LIGHT>, fl[0]);
+      launch(dbz::dbz_cell_values<dbz::DC_FLOAT>, fl[1]);
+      launch(dbz::dbz_cell_values<dbz::DC_RENDER>, fl[2]);
     }
   }
   hc.mark("columns + cell values");
@@ -1531,14 +1554,20 @@ extern "C" int tfgpu_debezium_parse(const tfgpu_dbz_options *o, const void *byte
     }
     boc = upload_small(oc.data(), oc.size() * sizeof(dbz::OutCol));
     Buf btc = upload_small(text_cols.data(), text_cols.size() * 4);
+    auto launch_text = [&](const std::vector<int32_t> &colsl, int plain_done) {  // the listed text columns, by receiver class
+      std::vector<int32_t> lt, hv;
+      for (int32_t j : colsl) (dbz::dbz_field_class(o->fields[j].op) == dbz::DC_RENDER ? hv : lt).push_back(j);
+      if (!lt.empty()) { Buf b = upload_small(lt.data(), lt.size() * 4); dbz::dbz_cell_text<false><<<dim3(dbz::nblk(nrows, 256), (unsigned)lt.size()), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(b), (int32_t)lt.size(), plain_done); }
+      if (!hv.empty()) { Buf b = upload_small(hv.data(), hv.size() * 4); dbz::dbz_cell_text<true><<<dim3(dbz::nblk(nrows, 256), (unsigned)hv.size()), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(b), (int32_t)hv.size(), plain_done); }
+    };
     if (nrows) {
       KernelTimer t("dbz_cell_text");
       if (words) {
         dbz::dbz_copy_words<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc));
         std::vector<int32_t> sp;
         for (int t2 = 0; t2 < ntext; t2++) if (hspec[t2]) sp.push_back(text_cols[(size_t)t2]);
-        if (!sp.empty()) { Buf bsp = upload_small(sp.data(), sp.size() * 4); dbz::dbz_cell_text<<<dim3(dbz::nblk(nrows, 256), (unsigned)sp.size()), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(bsp), (int32_t)sp.size(), 1); }
-      } else dbz::dbz_cell_text<<<dim3(dbz::nblk(nrows, 256), (unsigned)ntext), 256, 0, st>>>(p, ptr<dbz::OutCol>(boc), ptr<int32_t>(btc), ntext, 0);
+        launch_text(sp, 1);
+      } else launch_text(text_cols, 0);
     }
   }
   // bitmaps: ColumnValues validity per column; OldKeys = the key columns' buffers under their own validity
