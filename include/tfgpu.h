@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define TFGPU_ABI_VERSION 1
+/* 2: tfgpu_column gained `absent` (its size and array stride grew by one pointer) and tfgpu_batch gained `col_order` at its tail.
+ * A binding compiled against version 1's structs MUST NOT call this library: tfgpu_abi_version() is the first call a binding makes,
+ * and it refuses to go on when the number differs from the TFGPU_ABI_VERSION it was compiled with. */
+#define TFGPU_ABI_VERSION 2
 
 typedef enum tfgpu_status {
   TFGPU_OK = 0,

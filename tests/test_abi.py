@@ -25,7 +25,7 @@ def test_header_symbols_exported():
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(lib.EXPORTS) == syms
-    assert L.tfgpu_abi_version() == 1
+    assert L.tfgpu_abi_version() == 2  # 2: tfgpu_column.absent, tfgpu_batch.col_order (the struct layouts changed)
 
 
 def test_enum_tables_match_header():

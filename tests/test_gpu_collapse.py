@@ -370,6 +370,31 @@ def test_absent_cells_travel_and_value_entries_refuse(tf, oracle):
     assert list(tf.keys_changed(db)) == list(oracle.keys_changed_rows(items))
 
 
+def test_upload_makes_an_absent_cell_read_nil(tf, oracle):
+    """tfgpu_batch_upload establishes the invariant itself: an ABSENT cell's validity bit is cleared on the device even when
+    the caller sends validity = NULL ("no nils") or leaves the bit set — the key kernels (hash, compare, sharder, keys_changed) read
+    validity only, and an unlisted key must read nil like CurrentKeysString of a name the item does not list."""
+    import dataclasses
+    from collapse_cases import random_toast_items, batch_from_items, items_of
+    items = random_toast_items(11, 300, p_nokey=0.3)
+    names = ["id"] + ["c%d" % j for j in range(5)]
+    b, schema = batch_from_items(items, names=names)
+    assert any(c.absent is not None and c.absent.any() for c in b.cols)
+    for variant in ("null", "ones"):
+        cols = [dataclasses.replace(c, validity=None if variant == "null" else np.ones(b.nrows, bool)) if (c.absent is not None and c.validity is not None and not (~c.validity & ~c.absent).any()) else c
+                for c in b.cols]
+        sloppy = abi.Batch(cols, b.nrows, b.table_ns, b.table_name, b.kind, b.src_row, b.part_id)
+        sloppy.schema = b.schema
+        sloppy.old_keys, sloppy.old_present = getattr(b, "old_keys", None), getattr(b, "old_present", None)
+        db = tf.DeviceBatch.upload(sloppy)
+        got = db.download()
+        for c in got.cols:
+            if c.absent is not None and c.absent.any():
+                assert c.validity is not None and not (c.validity & c.absent).any(), (variant, c.name)
+        assert items_of(got) == items_of(b), variant
+        assert list(tf.keys_changed(db)) == list(oracle.keys_changed_rows(items)), variant
+
+
 def _without_absent(b):
     import dataclasses
     c = abi.Batch([dataclasses.replace(col, absent=None) for col in b.cols], b.nrows, b.table_ns, b.table_name, b.kind, b.src_row, b.part_id)

@@ -56,6 +56,9 @@ class CSchema(C.Structure):
     _fields_ = [("ncols", C.c_int32), ("cols", C.POINTER(CColSchema))]
 
 
+ABI_VERSION = 2  # include/tfgpu.h TFGPU_ABI_VERSION: the struct layouts below are this version's
+
+
 class CColumn(C.Structure):
     _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("repr", C.c_int32), ("values", C.c_void_p),
                 ("offsets", C.c_void_p), ("data", C.c_void_p), ("data_len", C.c_uint64), ("nanos", C.c_void_p),

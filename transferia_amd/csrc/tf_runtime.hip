@@ -245,6 +245,15 @@ Buf find_device_block(const void *p) {
   return b;
 }
 
+// An ABSENT cell reads nil: every kernel that reads key cells goes through the validity bitmap only, so the
+// invariant "absent bit set => validity bit clear" is established HERE, not trusted (a caller's NULL validity means "no nils").
+// One thread per bitmap byte; the bits past nrows of the last byte stay as the caller sent them (validity) or ones (no validity).
+__global__ void upload_validity_minus_absent(const uint8_t *validity_in, const uint8_t *absent, int64_t nbytes, uint8_t *validity_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbytes) return;
+  validity_out[i] = (uint8_t)((validity_in ? validity_in[i] : 0xFFu) & ~absent[i]);
+}
+
 }  // namespace tf
 
 using namespace tf;
@@ -402,7 +411,14 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
       if (c.repr == TFGPU_R_TIME && c.nanos) d.nanos = upload(c.nanos, n * 4);
     }
     if (c.validity) d.validity = upload(c.validity, (n + 7) / 8);
-    if (c.absent && !is_old) d.absent = upload(c.absent, (n + 7) / 8);  // (OldKeys say which rows have them through old_keys_present)
+    if (c.absent && !is_old && n) {  // (OldKeys say which rows have them through old_keys_present)
+      d.absent = upload(c.absent, (n + 7) / 8);
+      // validity = (validity or all-ones) & ~absent: an unlisted key must hash, compare and shard as nil (change_item.go CurrentKeysString)
+      Buf v = dalloc((n + 7) / 8);
+      const int64_t nb = (int64_t)((n + 7) / 8);
+      upload_validity_minus_absent<<<(unsigned)((nb + 255) / 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(d.validity), ptr<uint8_t>(d.absent), nb, ptr<uint8_t>(v));
+      d.validity = v;
+    }
     (is_old ? b->old_keys : b->cols).push_back(std::move(d));
   }
   if (h->n_old_keys && h->old_keys_present) b->old_present = upload(h->old_keys_present, (n + 7) / 8);

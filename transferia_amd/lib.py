@@ -53,6 +53,9 @@ def load():
         raise RuntimeError(f"{_LIBPATH} is missing: run `python -m transferia_amd.build` (hipcc, gfx950). "
                            "transferia_amd has no CPU implementation.")
     L = C.CDLL(_LIBPATH)
+    # the struct layouts of abi.py are version 2's: a library of another version would mis-stride tfgpu_column arrays (include/tfgpu.h)
+    if L.tfgpu_abi_version() != abi.ABI_VERSION:
+        raise RuntimeError("%s speaks ABI version %d, this binding version %d: rebuild one of them" % (_LIBPATH, L.tfgpu_abi_version(), abi.ABI_VERSION))
     P = C.c_void_p
     L.tfgpu_last_error.restype = C.c_char_p
     L.tfgpu_stream.restype = P
