@@ -678,7 +678,7 @@ def _row_values(L, bptr, row, ncols):
     return out
 
 
-def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data: bytes, msgs: abi.CMessages = None, want_rows: bool = True) -> JsonResult:
+def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data: bytes, msgs: abi.CMessages = None, want_rows: bool = True, want_batch: bool = False) -> JsonResult:
     """GenericParser{Format: "json"}.DoBatch over the oracle."""
     L = lib()
     cs = fields.to_c()
@@ -701,6 +701,10 @@ def json_parse(opts: abi.CJsonOptions, fields: abi.Schema, data: bytes, msgs: ab
     r.nrows = int(n)
     if want_rows:
         r.rows = [_row_values(L, bptr, i, len(r.schema.cols)) for i in range(n)]
+    if want_batch:  # the same rows as columns (ora_to_columns): what a 65 536-row comparison can afford
+        cb = L.ora_to_columns(bptr)
+        r.batch = abi.batch_from_c(cb.contents)
+        L.ora_columns_free(cb)
     L.ora_json_lines_free(lp)
     L.ora_batch_free(bptr)
     return r

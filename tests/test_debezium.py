@@ -189,12 +189,12 @@ def tf():
     return lib
 
 
-def device_items(tf, parsed):
-    """Rows of a debezium.Parsed as oracle-style items (message index → item)."""
+def device_items(tf, parsed, rows=None):
+    """Rows of a debezium.Parsed as oracle-style items (message index → item); `rows`: only the first so many (bench.py's parity legs)."""
     b = parsed.batch.download()
     out = {}
     names = [c.name for c in b.cols]
-    for r in range(b.nrows):
+    for r in range(b.nrows if rows is None else min(rows, b.nrows)):
         kind = ["insert", "update", "delete"][int(b.kind[r])]
         row = parsed.rows[r]
         it = {"kind": kind, "ns": b.table_ns, "table": b.table_name, "schema": parsed.schema, "id": int(row["id"]), "lsn": int(row["lsn"]),

@@ -31,6 +31,26 @@ for k in ("cpu_baseline","overlapped_lanes","pcie_inclusive","pull_push_concurre
     if d.get(k): print("  ", k, json.dumps(d[k])[:500])
 PY
 }
+keepjson() {  # a bench output file holds ONE JSON object: what a library printed to stdout in front of it (RCCL's banner in configs4) goes to FILE.log
+python - "$1" <<'PY'
+import json, sys
+p = sys.argv[1]
+try:
+    lines = [l for l in open(p).read().splitlines() if l.strip()]
+except OSError:
+    sys.exit(0)
+for i in range(len(lines) - 1, -1, -1):
+    try:
+        json.loads(lines[i])
+    except ValueError:
+        continue
+    rest = lines[:i] + lines[i + 1:]
+    if rest:
+        open(p + ".log", "w").write("\n".join(rest) + "\n")
+    open(p, "w").write(lines[i] + "\n")
+    break
+PY
+}
 tests() {
   timeout 1500 python -m pytest tests -m gpu -q --tb=short ${1:+-k "$1"} 2>&1 | tail -40 > "$OUT/pytest_gpu.log"; echo "== gpu tests"; tail -4 "$OUT/pytest_gpu.log"
   timeout 200 python __graft_entry__.py --smoke > "$OUT/smoke.log" 2>&1; echo "== smoke"; tail -1 "$OUT/smoke.log"
@@ -39,7 +59,7 @@ bench() {  # workloads, extra args
   for w in $1; do
     name=${w// /_}
     timeout 600 python bench.py --workload $w $2 > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"; echo "== bench $w rc=$?"; tail -c 200 "$OUT/bench_$name.err" | grep -v amdgpu.ids
-    line "$OUT/bench_$name.json"
+    keepjson "$OUT/bench_$name.json"; line "$OUT/bench_$name.json"
   done
 }
 stats() {
@@ -78,11 +98,11 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; print('
     date +%s > "$OUT/t0"
     tests
     traffic
-    timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_csv.json" 2> "$OUT/bench_csv.err"; echo "== csv (the driver's command line) rc=$?"; line "$OUT/bench_csv.json"
+    timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_csv.json" 2> "$OUT/bench_csv.err"; echo "== csv (the driver's command line) rc=$?"; keepjson "$OUT/bench_csv.json"; line "$OUT/bench_csv.json"
     bench "configs0" "--from-rows"
     bench "configs2 configs3 configs4 configs4d json sr sr_proto collapse debezium debezium_sr"
-    timeout 400 python bench.py --workload configs4 --sink debezium > "$OUT/bench_configs4_debezium.json" 2> "$OUT/bench_configs4_debezium.err"; echo "== configs4 --sink debezium rc=$?"; line "$OUT/bench_configs4_debezium.json"
-    timeout 400 python bench.py --workload collapse --toast 0.5 > "$OUT/bench_collapse_toast.json" 2> "$OUT/bench_collapse_toast.err"; echo "== collapse --toast 0.5 rc=$?"; line "$OUT/bench_collapse_toast.json"
+    timeout 400 python bench.py --workload configs4 --sink debezium > "$OUT/bench_configs4_debezium.json" 2> "$OUT/bench_configs4_debezium.err"; echo "== configs4 --sink debezium rc=$?"; keepjson "$OUT/bench_configs4_debezium.json"; line "$OUT/bench_configs4_debezium.json"
+    timeout 400 python bench.py --workload collapse --toast 0.5 > "$OUT/bench_collapse_toast.json" 2> "$OUT/bench_collapse_toast.err"; echo "== collapse --toast 0.5 rc=$?"; keepjson "$OUT/bench_collapse_toast.json"; line "$OUT/bench_collapse_toast.json"
     stats "csv configs2 configs3 json sr debezium debezium_sr configs4d"
     echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s" ;;
   *) echo "unknown mode $MODE"; exit 2 ;;
