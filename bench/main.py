@@ -43,6 +43,9 @@ def other_configs(args):
                 out[w] = {"baseline_config": which, "error": (r.stderr or r.stdout)[-300:]}
                 continue
             rf, par, cpu = d.get("roofline") or {}, d.get("parity") or {}, d.get("cpu_baseline") or {}
+            if not rf.get("kernel") and d.get("kernels"):  # a step of many small kernels none of which is priced in bytes (configs[4]): the longest is still named
+                kn, kv = max(d["kernels"].items(), key=lambda kv: kv[1].get("ms_per_step", 0))
+                rf = {"kernel": kn, "avg_launch_ms": kv.get("avg_ms"), "note": "not priced against the HBM peak (no algorithmic byte count for it)"}
             frac = rf.get("frac")
             ent = {"baseline_config": which, "workload": d["config"].get("workload", "")[:160], "value": d["value"], "unit": d["unit"], "ms_per_pass": round(d["ms_per_step"] / max(d.get("passes_per_step", 1), 1), 4),
                    "rows_per_pass": d["config"].get("rows_per_pass"), "dominant_kernel": rf.get("kernel"), "dominant_kernel_ms": rf.get("avg_launch_ms"), "frac": frac,

@@ -153,13 +153,13 @@ def pull_push(self, only_pipeline=False):
     # ---- the same work as a three-stage pipeline: ONE puller (H2D back to back on its own lane), transform lanes that take device-resident
     #      batches, ONE pusher (D2H back to back on its own lane), bounded queues of two batches between the stages — the double buffer of
     #      configs[2] spelled out: neither direction of the link ever waits for a lane to finish its other two legs ----
-    def run_pipe(ncomp, depth):
+    def run_pipe(ncomp, depth, npull=1, npush=1):
         try:
             import queue as _queue
             kk = max(a.pcie_steps, 2) * 6
-            hins = [lib.HostBuffer(self.data) for _ in range(depth)]
+            hins = [lib.HostBuffer(self.data) for _ in range(max(depth, 2 * npull))]
             houts = []
-            for _ in range(depth):
+            for _ in range(max(depth, 2 * npush)):
                 hb = lib.HostBuffer.__new__(lib.HostBuffer)
                 pp = ctypes_void()
                 lib._check(lib.load().tfgpu_host_alloc(cap, pp.ref))
@@ -167,20 +167,26 @@ def pull_push(self, only_pipeline=False):
                 houts.append(hb)
             q_in, q_out = _queue.Queue(maxsize=depth), _queue.Queue(maxsize=depth)
             errs = []
-            go = threading.Barrier(ncomp + 3)
-            tdone = {}
+            go = threading.Barrier(ncomp + npull + npush + 1)
+            tdone = {"n": 0, "t": 0.0, "pull_done": 0, "ends": 0}
+            lock = threading.Lock()
+            STOP = object()
 
-            def puller():
+            def puller(j):
                 try:
-                    lib.lane_use(ncomp + 1)
+                    lib.lane_use(ncomp + 1 + j)
                     go.wait()
-                    for i in range(kk):
+                    for i in range(j, kk, npull):
                         hd_ = ctypes.c_void_p()
-                        lib._check(lib.load().tfgpu_dbuf_upload(ctypes.c_void_p(hins[i % depth].ptr), hins[i % depth].size, ctypes.byref(hd_)))
+                        lib._check(lib.load().tfgpu_dbuf_upload(ctypes.c_void_p(hins[i % len(hins)].ptr), hins[i % len(hins)].size, ctypes.byref(hd_)))
                         lib.synchronize()   # the batch is in HBM: another lane may read it
                         q_in.put(lib.DeviceBuffer(hd_))
-                    for _ in range(ncomp):
-                        q_in.put(None)
+                    with lock:
+                        tdone["pull_done"] += 1
+                        last = tdone["pull_done"] == npull
+                    if last:
+                        for _ in range(ncomp):
+                            q_in.put(None)
                 except Exception as ex:  # noqa: BLE001
                     errs.append(ex); go.abort()
                     for _ in range(ncomp):
@@ -214,23 +220,33 @@ def pull_push(self, only_pipeline=False):
                 except Exception as ex:  # noqa: BLE001
                     errs.append(ex); go.abort(); q_out.put(None)
 
-            def pusher():
+            def pusher(j):
                 try:
-                    lib.lane_use(ncomp + 2)
+                    lib.lane_use(ncomp + 1 + npull + j)
                     go.wait()
-                    ends, i = 0, 0
-                    while ends < ncomp:
+                    i = 0
+                    while True:
                         out = q_out.get()
+                        if out is STOP:
+                            break
                         if out is None:
-                            ends += 1
+                            with lock:
+                                tdone["ends"] += 1
+                                fin = tdone["ends"] == ncomp
+                            if fin:
+                                for _ in range(npush - 1):
+                                    q_out.put(STOP)
+                                break
                             continue
-                        lib._check(lib.load().tfgpu_dbuf_download(out._h, houts[i % depth].ptr, out.size))   # returns when the text is in pinned memory
+                        hb = houts[(j + i * npush) % len(houts)]
+                        lib._check(lib.load().tfgpu_dbuf_download(out._h, hb.ptr, out.size))   # returns when the text is in pinned memory
                         out.free(); i += 1
-                    tdone["n"] = i
-                    tdone["t"] = time.perf_counter()
+                    with lock:
+                        tdone["n"] += i
+                        tdone["t"] = max(tdone["t"], time.perf_counter())
                 except Exception as ex:  # noqa: BLE001
                     errs.append(ex); go.abort()
-            ths = [threading.Thread(target=puller), threading.Thread(target=pusher)] + [threading.Thread(target=transformer, args=(k,)) for k in range(ncomp)]
+            ths = [threading.Thread(target=puller, args=(j,)) for j in range(npull)] + [threading.Thread(target=pusher, args=(j,)) for j in range(npush)] + [threading.Thread(target=transformer, args=(k,)) for k in range(ncomp)]
             for t in ths:
                 t.start()
             try:
@@ -250,7 +266,7 @@ def pull_push(self, only_pipeline=False):
                 step_ms = dt / kk * 1e3
                 ent = {"rows_per_s": round(self.n * kk / dt, 1), "ms_per_step": round(step_ms, 3), "transform_lanes": ncomp, "batches": kk,
                        "gb_per_s_h2d": round(len(self.data) * kk / dt / 1e9, 2), "gb_per_s_d2h": round(self.state["out_bytes"] * kk / dt / 1e9, 2),
-                       "note": "one puller, %d transform lanes, one pusher, queues of %d batches between them; the first batch's pull and the last batch's push are inside the time" % (ncomp, depth), "queue_depth": depth}
+                       "note": "%d puller lane(s), %d transform lanes, %d pusher lane(s), queues of %d batches between them; the first batch's pull and the last batch's push are inside the time" % (npull, ncomp, npush, depth), "queue_depth": depth, "pull_lanes": npull, "push_lanes": npush}
                 dup = res.get("copies_alone_concurrent") or {}
                 if dup.get("gb_per_s_h2d") and dup.get("gb_per_s_d2h"):
                     h2d_dup, d2h_dup = len(self.data) / dup["gb_per_s_h2d"] / 1e6, self.state["out_bytes"] / dup["gb_per_s_d2h"] / 1e6
@@ -264,6 +280,7 @@ def pull_push(self, only_pipeline=False):
     shapes = {"2_lanes_queue_2": run_pipe(2, 2)}
     if not only_pipeline or os.environ.get("TFGPU_BENCH_PIPE_3X3", "1") == "1":
         shapes["3_lanes_queue_3"] = run_pipe(3, 3)
+        shapes["2_pullers_2_lanes_2_pushers_queue_3"] = run_pipe(2, 3, 2, 2)   # a copy of each direction always queued behind the one in flight: no gap on the link between two batches
     good = {k: v for k, v in shapes.items() if "ms_per_step" in v}
     res["pipeline_3_stage"] = min(good.values(), key=lambda v: v["ms_per_step"]) if good else next(iter(shapes.values()))
     res["pipeline_shapes"] = {k: ({kk2: v[kk2] for kk2 in ("ms_per_step", "gb_per_s_h2d", "gb_per_s_d2h", "overlap_efficiency_vs_duplex_ceiling") if kk2 in v} if "ms_per_step" in v else v) for k, v in shapes.items()}

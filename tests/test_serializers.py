@@ -397,3 +397,32 @@ def test_gpu_rows_larger_than_the_lds_image(tf, oracle):
             ref = oracle.serialize(fmt, b, schema, _opts(o))
             assert ref is not None
             assert tf.serialize(fmt, tf.DeviceBatch.upload(b), _opts(o)).download() == ref, (fmt, o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{}, {"TFGPU_SLAB_RSHIFT": "2"}, {"TFGPU_SLAB_RSHIFT": "5", "TFGPU_SLAB_THREADS": "512"}, {"TFGPU_SLAB_IMAGE_BYTES": "1100"}, {"TFGPU_SLAB_IMAGE_BYTES": "3000", "TFGPU_SLAB_XCD": "0"}])
+def test_gpu_slab_form_of_the_text_serializers(tf, oracle, monkeypatch, knobs):
+    """The opt-in slab form (tf_serslab.inc: whole rows rendered into an LDS image, one contiguous run a workgroup) byte for byte against the
+    oracle, every format: random batches (nils, `any`, floats, escapes), the big-cell batch (rows longer than the image go straight to HBM),
+    and with the image clamped so that ordinary rows take the sub-run and the straight-to-HBM paths."""
+    import random
+    monkeypatch.setenv("TFGPU_SER_SLAB", "1")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for n in (1, 63, 1000):
+        rng = np.random.default_rng(SEED0 + (700 + n))
+        b, schema = _random_batch(rng, n)
+        db = tf.DeviceBatch.upload(b)
+        for fmt, o in ((abi.FMT_JSON, {}), (abi.FMT_JSON, {"add_closing_newline": True, "any_as_string": True}), (abi.FMT_CSV, {}), (abi.FMT_CH_JSON_EACH_ROW, {}),
+                       (abi.FMT_CH_JSON_EACH_ROW, {"ch_types": [[(1 << (i % 5)) if i % 3 else 0, i % 10] for i in range(len(b.cols))]})):
+            ref = oracle.serialize(fmt, b, schema, _opts(o))
+            assert ref is not None and tf.serialize(fmt, db, _opts(o)).download() == ref, (n, fmt, o)
+    prng = random.Random(SEED0 + 32)
+    schema = abi.Schema.of([["k", "int64", True], ["s", "utf8", False], ["t", "utf8", False], ["d", "double", False]])
+    rows = []
+    for k in range(200):
+        big = "x\"é\n" * prng.choice([0, 1, 3, 17500]) if k % 37 == 5 else "ab" * (k % 50)
+        rows.append([["int64", k * 1_000_003], ["string", big], ["nil", None] if k % 7 == 0 else ["string", "t%d" % k], ["float64", k / 3]])
+    b = abi.batch_from_rows(schema, ["k", "s", "t", "d"], rows, "", "t")
+    for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
+        assert tf.serialize(fmt, tf.DeviceBatch.upload(b), _opts({})).download() == oracle.serialize(fmt, b, schema, _opts({})), fmt

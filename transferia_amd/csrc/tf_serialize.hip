@@ -667,6 +667,8 @@ __global__ void __launch_bounds__(256) TF_SER_WRITE_ATTR ser_chunk_write(SerPara
   }
 }
 
+#include "tf_serslab.inc"
+
 // queue formats: the message frame once the cut plan is known.  Native: "[" before the first element of a message, ","
 // before the others, "]" after the last; JSON: "\n" after every element but the last of its message.
 __global__ void __launch_bounds__(256) ser_queue_tail_len(SerParams p) {
@@ -903,6 +905,77 @@ static ChunkSetup make_chunk_setup(const tfgpu_dbatch *b, int format, const std:
   return cs;
 }
 
+// The slab plan of the text formats (tf_serslab.inc): column records + 8-byte aligned key prefixes in ONE allocation (a workgroup stages
+// both with one loop), rows per workgroup from the estimated row text so that a group's rows fit the LDS image.
+struct SlabSetup { SlabPlan sp{}; Buf brecs; unsigned threads = 256; size_t lds_len = 0, lds_write = 0; };
+static int env_int(const char *name, int dflt) { const char *e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
+static SlabSetup make_slab_setup(const tfgpu_dbatch *b, int format, const std::vector<int> &order, const std::vector<SCol> &sc, const std::string &blob, int64_t n) {
+  SlabSetup ss;
+  const int ncols = (int)order.size();
+  std::vector<uint32_t> recs((size_t)ncols * SLAB_REC_WORDS, 0u);
+  std::vector<uint8_t> pblob;
+  double est_row = 4;
+  for (int j = 0; j < ncols; j++) {
+    const SCol &d = sc[(size_t)j];
+    const DColumn &c = b->cols[(size_t)order[(size_t)j]];
+    uint32_t *w = recs.data() + (size_t)j * SLAB_REC_WORDS;
+    auto put64 = [&](int k, const void *q) { const uint64_t v = reinterpret_cast<uintptr_t>(q); w[k] = (uint32_t)v; w[k + 1] = (uint32_t)(v >> 32); };
+    put64(SW_VALUES, d.c.values); put64(SW_OFFSETS, d.c.offsets); put64(SW_DATA, d.c.data); put64(SW_NANOS, d.c.nanos); put64(SW_VALIDITY, d.c.validity);
+    w[SW_REPR] = (uint32_t)d.c.repr; w[SW_DTYPE] = (uint32_t)d.c.dtype; w[SW_CH_FLAGS] = d.ch_flags; w[SW_PREC] = d.prec;
+    // the prefix without the chunk walks' leading placeholder byte (JSONEachRow: the slab cells put '{' or ',' themselves)
+    const uint32_t skip = format == TFGPU_FMT_CH_JSON_EACH_ROW ? 1u : 0u;
+    w[SW_PRE_OFF] = (uint32_t)pblob.size(); w[SW_PRE_LEN] = d.pre_len - skip;
+    pblob.insert(pblob.end(), blob.begin() + d.pre_off + skip, blob.begin() + d.pre_off + d.pre_len);
+    pblob.resize((pblob.size() + 7) & ~(size_t)7, 0);
+    double est = d.pre_len + 1.0;
+    switch (c.repr) {
+      case TFGPU_R_INT8: case TFGPU_R_UINT8: est += 3; break;
+      case TFGPU_R_INT16: case TFGPU_R_UINT16: est += 5; break;
+      case TFGPU_R_INT32: case TFGPU_R_UINT32: est += 10; break;
+      case TFGPU_R_INT64: case TFGPU_R_UINT64: case TFGPU_R_DURATION: est += 20; break;
+      case TFGPU_R_BOOL: est += 5; break;
+      case TFGPU_R_FLOAT32: case TFGPU_R_FLOAT64: est += 18; break;
+      case TFGPU_R_TIME: est += 32; break;
+      default: est += 2.0 + 1.1 * (double)c.data_len / (double)std::max<int64_t>(n, 1) * (format == TFGPU_FMT_JSON && c.repr == TFGPU_R_BYTES ? 1.34 : 1.0);
+    }
+    est_row += est;
+  }
+  pblob.resize((pblob.size() + 15) & ~(size_t)15, 0);
+  std::vector<uint8_t> both(recs.size() * 4 + pblob.size());
+  std::memcpy(both.data(), recs.data(), recs.size() * 4);
+  std::memcpy(both.data() + recs.size() * 4, pblob.data(), pblob.size());
+  ss.brecs = upload_const(both.data(), both.size());
+  SlabPlan &sp = ss.sp;
+  sp.recs = ptr<uint32_t>(ss.brecs);
+  sp.pblob = ptr<uint8_t>(ss.brecs) + recs.size() * 4;
+  sp.pblob_bytes = (uint32_t)pblob.size();
+  // rows per workgroup: the largest power of two whose estimated text fits the image budget
+  // (measurement and test knobs, read per call: the rows-per-workgroup budget, R itself, the workgroup size, a clamp on the image that forces the
+  //  sub-run and the straight-to-HBM paths on ordinary rows)
+  const int cap_kb = env_int("TFGPU_SLAB_CAP_KB", 24), force_r = env_int("TFGPU_SLAB_RSHIFT", -1), threads = env_int("TFGPU_SLAB_THREADS", 256), image_max = env_int("TFGPU_SLAB_IMAGE_BYTES", 0);
+  int rshift = 6;
+  while (rshift > 2 && (double)((size_t)1 << rshift) * est_row > (double)cap_kb * 1024.0) rshift--;
+  while (rshift > 2 && ((int64_t)1 << rshift) > std::max<int64_t>(n, 4)) rshift--;
+  if (force_r >= 2 && force_r <= 6) rshift = force_r;
+  ss.threads = (unsigned)std::min(512, std::max(64 << 0, threads));
+  while ((ss.threads >> rshift) == 0) rshift--;             // at least one thread a row
+  sp.rshift = rshift;
+  const size_t fixed = slab_lds_bytes(ncols, sp.pblob_bytes, rshift, 0);
+  size_t cap = (size_t)((double)((size_t)1 << rshift) * est_row * 1.15) + 256;
+  cap = std::max<size_t>(cap, (size_t)ss.threads * 4 + 64);
+  cap = std::min<size_t>(cap, 64 * 1024 - 64 - fixed);
+  if (image_max > 0) cap = std::max<size_t>((size_t)ss.threads * 4 + 64, std::min<size_t>(cap, (size_t)image_max));
+  sp.cap = (uint32_t)(cap & ~(size_t)15);
+  sp.ngroups = (n + ((int64_t)1 << rshift) - 1) >> rshift;
+  sp.xcd_order = env_int("TFGPU_SLAB_XCD", 1);
+  ss.lds_write = slab_lds_bytes(ncols, sp.pblob_bytes, rshift, sp.cap);
+  ss.lds_len = slab_lds_bytes(ncols, sp.pblob_bytes, rshift, ss.threads * 4 + 64);
+  return ss;
+}
+static inline unsigned slab_grid(const SlabPlan &sp) { return (unsigned)(sp.xcd_order ? ((sp.ngroups + 7) >> 3) << 3 : sp.ngroups); }
+// can the slab form take this batch?  (the fixed part — records, prefixes, one length per cell — must leave room for an image)
+static bool slab_fits(int ncols, size_t blob_bytes) { return ncols > 0 && (size_t)ncols * (SLAB_REC_WORDS * 4 + 16 + 4 * 4) + blob_bytes + 8192 < 60 * 1024; }
+
 extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out) {
   try {
   tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
@@ -981,11 +1054,25 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     const int64_t ncell = (int64_t)ncols * n;
     Buf cell, bcut, brecs;
     ChunkPlan cp{};
+    // the slab form (rows in LDS, one contiguous run a workgroup: tf_serslab.inc) is OPT-IN (TFGPU_SER_SLAB=1): it writes exactly the text's bytes, but on
+    // wide tables a workgroup's rows x ALL columns means 8-16 rows of 300 arrays per workgroup (32-byte reads, a TLB entry each) and 4-8 columns a wave —
+    // measured 3.3 + 10.2 ms against the chunk walks' 1.28 + 2.62 ms on configs[3] (profiles/r20d_tune_configs3.txt)
+    const bool slab_on = env_int("TFGPU_SER_SLAB", 0) != 0;
+    const bool slab = !scatter && slab_on && slab_fits(ncols, blob.size());
+    SlabSetup slabs;
     if (scatter) {
       cell = dalloc((size_t)std::max(ncols, 1) * (size_t)n * 4);
       p.cell = ptr<uint32_t>(cell);
       { KernelTimer t("ser_cell_len"); if (ncell) ser_cell_len<<<dim3(blocks(n), (unsigned)ncols), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_layout"); ser_row_layout<<<blocks(n), 256, 0, st>>>(p); }
+    } else if (slab) {
+      slabs = make_slab_setup(b, format, order, sc, blob, n);
+      SlabPlan lp = slabs.sp;
+      lp.cap = slabs.threads * 4 + 64;
+      KernelTimer t("ser_slab_len");
+      if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_slab_len<TFGPU_FMT_CH_JSON_EACH_ROW><<<slab_grid(lp), slabs.threads, slabs.lds_len, st>>>(p, lp);
+      else if (format == TFGPU_FMT_JSON) ser_slab_len<TFGPU_FMT_JSON><<<slab_grid(lp), slabs.threads, slabs.lds_len, st>>>(p, lp);
+      else ser_slab_len<TFGPU_FMT_CSV><<<slab_grid(lp), slabs.threads, slabs.lds_len, st>>>(p, lp);
     } else {
       ChunkSetup csu = make_chunk_setup(b, format, order, sc, blob, n);
       cp = csu.cp; bcut = csu.bcut; brecs = csu.brecs; cell = csu.cell;
@@ -1015,6 +1102,12 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
     if (scatter) {
       { KernelTimer t("ser_cell_write"); if (ncell) ser_cell_write<<<dim3(blocks(n), (unsigned)ncols), 256, 0, st>>>(p); }
       { KernelTimer t("ser_row_frame"); ser_row_frame<<<blocks(n), 256, 0, st>>>(p); }
+    } else if (slab) {
+      KernelTimer t("ser_slab_write");
+      const SlabPlan &sp = slabs.sp;
+      if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_slab_write<TFGPU_FMT_CH_JSON_EACH_ROW><<<slab_grid(sp), slabs.threads, slabs.lds_write, st>>>(p, sp);
+      else if (format == TFGPU_FMT_JSON) ser_slab_write<TFGPU_FMT_JSON><<<slab_grid(sp), slabs.threads, slabs.lds_write, st>>>(p, sp);
+      else ser_slab_write<TFGPU_FMT_CSV><<<slab_grid(sp), slabs.threads, slabs.lds_write, st>>>(p, sp);
     } else {
       const unsigned grid = ser_grid(cp);
       KernelTimer t("ser_chunk_write");
