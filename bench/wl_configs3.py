@@ -211,8 +211,82 @@ class Configs3Workload(Base):
                                 "the first object's pull and the last one's decode are inside the time"}
         except Exception as ex:  # noqa: BLE001
             pipe = {"error": str(ex)[:200]}
+        # ---- the same object as real writers leave it: SNAPPY pages (pyarrow's default codec; parquet-go inflates per page in its reader,
+        #      reader_parquet.go:137-283).  The compressed object crosses PCIe, pq_inflate (one wave a page) inflates the data pages on the device;
+        #      beside it the same read with every page inflated on the host (TFGPU_PQ_DEVICE_INFLATE=0: what rounds 4-5 did).  Rates are quoted in
+        #      UNCOMPRESSED bytes (the NONE object's size): what the decoder behind the codec sees. ----
+        compressed = {}
+        for codec in ("snappy", "lz4_raw"):
+            try:
+                bufc = io.BytesIO()
+                pq.write_table(pa.table(arrays, names=names), bufc, compression=codec if codec != "lz4_raw" else "LZ4_RAW", row_group_size=h.nrows)
+                datac = bufc.getvalue()
+                pinc = lib.HostBuffer(datac)
+
+                def onec(read_only=True, plans=None):
+                    out = C.c_void_p()
+                    lib._check(lib.load().tfgpu_parquet_read(C.c_void_p(pinc.ptr), C.c_uint64(len(datac)), abi.MEM_HOST, C.byref(cs), b"", b"hits", C.byref(out)))
+                    db = lib.DeviceBatch(out)
+                    if not read_only:
+                        tr = lib.apply_chain(plans if plans is not None else self.plans, db)
+                        o = lib.serialize(abi.FMT_CH_JSON_EACH_ROW, tr.transformed)
+                        o.free(); tr.transformed.free()
+                    db.free()
+                onec(); lib.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    onec()
+                lib.synchronize()
+                dtc = (time.perf_counter() - t0) / k
+                lib.prof_reset(); lib.prof_enable(True)
+                onec()
+                lib.prof_enable(False)
+                profc = {n: round(ms / max(l, 1), 4) for n, l, ms in lib.prof_get() if n.startswith("pq_")}
+                lib.prof_reset()
+                go3, done3, errs3 = threading.Barrier(nl + 1), threading.Barrier(nl + 1), []
+
+                def lane_c(j):
+                    try:
+                        lib.lane_use(j)
+                        onec(); lib.synchronize()
+                        go3.wait()
+                        for i in range(kk):
+                            if i % nl == j:
+                                onec()
+                        lib.synchronize()
+                        done3.wait()
+                    except Exception as ex:  # noqa: BLE001
+                        errs3.append(ex); go3.abort(); done3.abort()
+                thc = [threading.Thread(target=lane_c, args=(j,)) for j in range(nl)]
+                for t in thc:
+                    t.start()
+                try:
+                    go3.wait()
+                    t0 = time.perf_counter()
+                    done3.wait()
+                    dtc3 = (time.perf_counter() - t0) / kk
+                except threading.BrokenBarrierError:
+                    dtc3 = float("nan")
+                for t in thc:
+                    t.join()
+                lib.lane_use(0)
+                os.environ["TFGPU_PQ_DEVICE_INFLATE"] = "0"
+                try:
+                    onec(); lib.synchronize()
+                    t0 = time.perf_counter()
+                    onec(); lib.synchronize()
+                    dth = time.perf_counter() - t0
+                finally:
+                    os.environ.pop("TFGPU_PQ_DEVICE_INFLATE", None)
+                compressed[codec] = {"object_bytes": len(datac), "uncompressed_object_bytes": len(data), "read_only_ms": round(dtc * 1e3, 3),
+                                     "read_only_gb_per_s_uncompressed": round(len(data) / dtc / 1e9, 2), "read_only_gb_per_s_pcie": round(len(datac) / dtc / 1e9, 2),
+                                     "lanes_3": {"ms_per_object": round(dtc3 * 1e3, 3), "gb_per_s_uncompressed": round(len(data) / dtc3 / 1e9, 2)} if not errs3 else {"error": str(errs3[0])[:200]},
+                                     "host_inflate_read_only_ms": round(dth * 1e3, 3), "decode_kernels_avg_ms": profc}
+                pinc.free()
+            except Exception as ex:  # noqa: BLE001
+                compressed[codec] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
         pinned.free()
-        return {"parquet_source": {"object_bytes": len(data), "pipeline_pull_decode": pipe, "rows_per_s": round(h.nrows / dt, 1), "ms_per_step": round(dt * 1e3, 3), "gb_per_s_parquet_in": round(len(data) / dt / 1e9, 2),
+        return {"parquet_source": {"object_bytes": len(data), "compressed": compressed, "pipeline_pull_decode": pipe, "rows_per_s": round(h.nrows / dt, 1), "ms_per_step": round(dt * 1e3, 3), "gb_per_s_parquet_in": round(len(data) / dt / 1e9, 2),
                                    "read_only_ms": round(dt_read * 1e3, 3), "read_only_gb_per_s": round(len(data) / dt_read / 1e9, 2),
                                    "lanes_3": {"ms_per_step": round(dt3 * 1e3, 3), "gb_per_s_parquet_in": round(len(data) / dt3 / 1e9, 2), "rows_per_s": round(h.nrows / dt3, 1)} if not errs else {"error": str(errs[0])[:200]},
                                    "decode_kernels_avg_ms": prof,

@@ -371,7 +371,9 @@ void tfgpu_bufferer_destroy(tfgpu_bufferer *b);
  * footer and the page headers are walked in, `staged` (tfgpu_dbuf_alloc + tfgpu_dbuf_write, or tfgpu_dbuf_upload of a padded copy)
  * holds the same `len` bytes at offset 0 and is at least tfgpu_parquet_staging_size(bytes, len) long — the reader writes what it
  * decodes beside the object (expanded dictionary indices, DELTA_BINARY_PACKED values, INT96 texts) behind it.  The buffer stays the
- * caller's and may be freed when the call returns.  A compressed object's pages are inflated on the host: `staged` is not used. */
+ * caller's and may be freed when the call returns.  A compressed object does not use `staged`: its SNAPPY / LZ4_RAW data pages are
+ * inflated on the DEVICE (pq_inflate, one wave a page: the compressed object goes up as it is; the host inflates only what its walk reads
+ * at a page's front — definition levels, an index width — and dictionary / DELTA_* pages), GZIP / ZSTD pages on the host.          */
 int tfgpu_parquet_resolve_schema(const void *bytes, uint64_t len, int hide_system_cols, tfgpu_schema **out);
 int tfgpu_parquet_read_object(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, const char *file_name, tfgpu_dbatch **out);
 int tfgpu_parquet_read(const void *bytes, uint64_t len, int mem, const tfgpu_schema *schema, const char *table_ns, const char *table_name, tfgpu_dbatch **out);
@@ -386,9 +388,11 @@ int tfgpu_parquet_read_staged(const void *bytes, uint64_t len, const tfgpu_dbuf 
  * uncompressed).  Row groups are cut by row_group_max_rows, else by row_group_max_bytes over the PLAIN sizes (both 0: 128 MiB,
  * NewParquetBatchSerializer's default), at multiples of eight rows; one PLAIN v1 data page per column chunk.  *bytes is pinned
  * host memory of *len bytes: free it with tfgpu_host_free.  The batch's values must have the Go types Strictify gives them
- * (tfgpu_strictify first: that is NewStrictifyingBatchSerializer); a float64 VALUE (fmt's %v) is refused by name.  PARITY
- * UNPINNED: the byte layout is the writing library's (parquet-go) choice; the tests pin values, nulls, logical types and field
- * order to what pyarrow reads back.                                                                                          */
+ * (tfgpu_strictify first: that is NewStrictifyingBatchSerializer); a float64 VALUE (fmt's %v) is refused by name.  A nil in a
+ * Required field is written as the type's zero value, as parquet-go does.  PARITY: what the object SAYS — field order, physical and
+ * logical types, repetition, row count, every value — is pinned to the one Parquet object the reference holds
+ * (canondata/reference.reference.TestBatchSerializer_parquet_default/result, tests/test_parquet_write.py); its BYTE layout
+ * (encodings, page and footer bytes) is parquet-go's choice and stays unpinned.                                               */
 int tfgpu_parquet_write(const tfgpu_dbatch *b, const tfgpu_schema *schema, const char *codec, int64_t row_group_max_rows, uint64_t row_group_max_bytes, void **bytes, uint64_t *len);
 
 /* strictify.Strictify (pkg/abstract/changeitem/strictify/strictify.go:17-157) over a device batch — the first step of the

@@ -464,3 +464,77 @@ def test_damaged_objects_of_the_round_5_encodings(tf):
                     assert ex.code in (tf.ERR_INVALID, tf.ERR_UNSUPPORTED), str(ex)
                     errors += 1
         assert errors > 0 and reads > 0, (comp, errors, reads)
+
+
+def _kernels_of(tf, fn):
+    tf.prof_reset(); tf.prof_enable(True)
+    try:
+        out = fn()
+    finally:
+        names = {n for n, l, ms in tf.prof_get() if l}
+        tf.prof_enable(False)
+    return out, names
+
+
+def _inflate_cases(tf, codec, n, check_kws, big_kws, damage_step):
+    t = table(min(n, 5000) // 2, 33)
+    for kw in check_kws:
+        _, names = _kernels_of(tf, lambda: check(tf, t, compression=codec, **kw))
+        assert "pq_inflate" in names, (kw, names)
+    rng = np.random.default_rng(77)
+    words = ["alpha", "beta-gamma", "https://example.org/path/", "delta", "?q=", "epsilon_zeta", "0123456789"]
+    big = pa.table({
+        "text": pa.array(["".join(words[int(k)] for k in rng.integers(0, len(words), int(rng.integers(1, 9)))) for _ in range(n)]),      # one PLAIN page of n * 30 bytes: matches all over the ring
+        "noise": pa.array([bytes(rng.integers(0, 256, 24).astype(np.uint8)) for _ in range(n)], pa.binary()),                            # incompressible: literals of tens of KB
+        "zeros": pa.array([0] * n, pa.int64()),                                                                                           # period-1 copies, 64 bytes an element
+        "opt": pa.array([None if i % 5 == 0 else int(i) for i in range(n)], pa.int64()),                                                  # levels in front of the values
+        "flag": pa.array([bool(i & 4) for i in range(n)], pa.bool_()),
+    })
+    for kw in big_kws:
+        buf = io.BytesIO()
+        pq.write_table(big, buf, compression=codec, **kw)
+        data = buf.getvalue()
+        ref = pq.read_table(io.BytesIO(data))
+        dev, names = _kernels_of(tf, lambda: tf.parquet_read(data).download())
+        assert "pq_inflate" in names
+        for c in dev.cols:
+            want = ref.column(c.name).to_pylist()
+            valid = c.validity if c.validity is not None else np.ones(n, bool)
+            assert [bool(v) for v in valid] == [w is not None for w in want], c.name
+            if c.repr in abi.VAR_REPRS:
+                off = np.asarray(c.offsets, np.int64)
+                assert bytes(c.data[:int(off[-1])]) == b"".join((w.encode() if isinstance(w, str) else w) for w in want if w is not None), c.name
+            else:
+                got = np.asarray(c.values)
+                assert all(got[i] == w for i, w in enumerate(want) if w is not None), c.name
+    # a damaged page: a byte of the compressed body flipped — an element's operand (a copy from in front of the page, a literal past its end, a wrong
+    # stated length) fails the call; a flip inside literal bytes changes a value, not the structure.  Never an out-of-bounds access.
+    buf = io.BytesIO()
+    pq.write_table(pa.table({"s": pa.array(["abcdefgh" * 40 + str(i) for i in range(300)])}), buf, compression=codec, use_dictionary=False)
+    data = bytearray(buf.getvalue())
+    at = pq.ParquetFile(io.BytesIO(bytes(data))).metadata.row_group(0).column(0).data_page_offset
+    failed = 0
+    for delta in range(40, 400, damage_step):
+        bad = bytearray(data)
+        bad[at + delta] ^= 0xFF
+        try:
+            tf.parquet_read(bytes(bad)).download()
+        except tf.TfgpuError:
+            failed += 1
+    assert failed > 0
+
+
+@pytest.mark.parametrize("codec", ["SNAPPY", "LZ4_RAW"])
+def test_pages_inflated_on_the_device(tf, codec):
+    """pq_inflate (one wave a page; SNAPPY and LZ4_RAW): the shapes of `check` (dictionary pages + indices, PLAIN pages, v2 pages with their levels outside
+    the compressed part, optional columns whose levels the host inflates as a prefix), pages larger than the 64 KiB LDS ring (repetitive text whose
+    copies reach back over the ring, incompressible bytes = long literals, period-1 overlapping copies) and damaged pages — equal to pyarrow's reading."""
+    _inflate_cases(tf, codec, 2600, ({}, {"use_dictionary": False, "data_page_version": "2.0", "row_group_size": 1500}),
+                   ({"use_dictionary": False, "data_page_size": 1 << 24},), 11)
+
+
+@pytest.mark.parametrize("codec", ["SNAPPY", "LZ4_RAW"])
+def test_pages_inflated_on_the_device_fullsize(tf, codec):
+    """the same with pages of 1.8 MB (60 000 rows: the ring wraps 28 times), every page shape, a denser sweep of damaged bytes (MI355X only: minutes on the emulator)"""
+    _inflate_cases(tf, codec, 60000, ({}, {"use_dictionary": False, "data_page_size": 2048}, {"data_page_version": "2.0", "row_group_size": 1500}, {"use_dictionary": False, "data_page_size": 1 << 22}),
+                   ({"use_dictionary": False, "data_page_size": 1 << 24}, {"use_dictionary": False, "data_page_size": 100000, "data_page_version": "2.0"}, {}), 3)

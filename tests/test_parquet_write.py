@@ -1,5 +1,7 @@
 """tfgpu_parquet_write (tf_parquetw.hip) — pkg/serializer/parquet.go + parquet_format.go on the device — read back by an independent
-reader.  PARITY UNPINNED against the reference (the byte layout is parquet-go's choice, not in /root/reference): what is checked is
+reader.  PINNED to the one Parquet object the reference holds (TestBatchSerializer/parquet:default's canon `result`, a parquet-go file:
+test_the_reference_canon_object below — field order, physical and logical types, repetition, row count, every value of the same 118 items);
+the BYTE layout (encodings, page and footer bytes) is parquet-go's choice and stays unpinned.  Beyond the canon, what is checked is
 what the reference's schema builder and value conversion prescribe — fields in name order, the logical types of primitiveTypesMap,
 OPTIONAL unless Required, nil → null, float64 as its decimal text, `any` as JSON text, dates as days, times as nanoseconds — through
 pyarrow's reading of the object, for every codec CodecFromString names, and a round trip through tfgpu_parquet_read."""
@@ -137,9 +139,52 @@ def test_what_the_device_does_not_write_is_refused_by_name(tf):
         tf.parquet_write(db, schema)
     assert ei.value.code == tf.ERR_UNSUPPORTED and "Strictify" in str(ei.value)
     db.free()
-    schema = abi.Schema.of([["k", "int64", True, "", "", True]])   # a Required column with a nil
-    db = tf.DeviceBatch.upload(abi.batch_from_rows(schema, ["k"], [[["int64", 1]], [["nil", None]]], "db", "t"))
-    with pytest.raises(tf.TfgpuError) as ei:
-        tf.parquet_write(db, schema)
-    assert ei.value.code == tf.ERR_INVALID
+    # a Required column with a nil: parquet-go writes the type's zero value (pinned by the reference's canon object, below) — every physical type
+    schema = abi.Schema.of([["k", "int64", True, "", "", True], ["s", "utf8", False, "", "", True], ["b", "boolean", False, "", "", True], ["f", "float", False, "", "", True]])
+    db = tf.DeviceBatch.upload(abi.batch_from_rows(schema, ["k", "s", "b", "f"], [[["int64", 1], ["string", "x"], ["bool", True], ["float32", 1.5]], [["nil", None]] * 4,
+                                                                                [["int64", 3], ["nil", None], ["bool", True], ["nil", None]]], "db", "t"))
+    t = pq.read_table(io.BytesIO(tf.parquet_write(db, schema)))
+    assert t.to_pylist() == [{"b": True, "f": 1.5, "k": 1, "s": "x"}, {"b": False, "f": 0.0, "k": 0, "s": ""}, {"b": True, "f": 0.0, "k": 3, "s": ""}]
     db.free()
+
+
+
+def test_the_reference_canon_object(tf):
+    """pkg/serializer/reference/canondata/reference.reference.TestBatchSerializer_parquet_default/result (tests/golden/parquet_writer_canon.json is
+    pyarrow's reading of it, tools/extract_golden.py): the 118 items of ReadChangeItems(10) — 33 tables — written with the FIRST item's TableSchema,
+    every value looked up by field name in item.AsMap() (parquet_format.go:82-100).  The same rows through tfgpu_parquet_write must say the same:
+    fields in the same order with the same physical / logical types and repetition, 118 rows, every value — including the 0 a Required field
+    gets for a nil (the items of tables without `__primary_key`)."""
+    from util import golden
+    g = golden("parquet_writer_canon.json")
+    schema = abi.Schema.of([[n, t, k, "", "", req] for n, t, k, req in g["table_schema"]])
+    names = [c[0] for c in g["table_schema"]]
+    rows_in = []
+    for tb in golden("serializers_canon.json")["tables"]:
+        have = {n: i for i, n in enumerate(tb["common"]["names"])}
+        types = {c[0]: c[1] for c in tb["common"]["schema"]}
+        for r in tb["rows"]:
+            row = []
+            for n, t, _, _ in g["table_schema"]:
+                cell = r[have[n]] if n in have else ["nil", None]
+                assert cell[0] == "nil" or types[n] == t, (tb["name"], n)     # a same-named column of another DataType would be parquet-go's conversion: the corpus has none
+                row.append(cell)
+            rows_in.append(row)
+    assert len(rows_in) == g["num_rows"] == 118
+    db = tf.DeviceBatch.upload(abi.batch_from_rows(schema, names, rows_in, "public", "wtf_types"))
+    data = tf.parquet_write(db, schema, "")
+    f = pq.ParquetFile(io.BytesIO(data))
+    sch, md = f.schema, f.metadata
+    assert md.num_rows == 118 and md.num_row_groups == g["num_row_groups"] == 1
+    got_fields = [{"name": sch.column(i).name, "physical": sch.column(i).physical_type, "logical": str(sch.column(i).logical_type), "converted": str(sch.column(i).converted_type),
+                   "required": sch.column(i).max_definition_level == 0, "max_repetition_level": sch.column(i).max_repetition_level} for i in range(len(sch.names))]
+    assert got_fields == g["fields"]
+    rg = md.row_group(0)
+    assert [(rg.column(i).path_in_schema, rg.column(i).compression, rg.column(i).num_values) for i in range(rg.num_columns)] == [(c["name"], c["compression"], c["num_values"]) for c in g["chunks"]]
+    t = f.read()
+    got_rows = [[r[n] for n in sch.names] for r in t.to_pylist()]
+    # BYTE_ARRAY (JSON) values come back as bytes or str depending on the annotation pyarrow sees: compare as text
+    norm = lambda v: v.decode("utf-8") if isinstance(v, (bytes, bytearray)) else v  # noqa: E731
+    for i, (a, b) in enumerate(zip(got_rows, g["rows"])):
+        assert [norm(x) for x in a] == b, (i, a, b)
+    assert sum(1 for r in got_rows if r[0] == 0) == sum(1 for r in g["rows"] if r[0] == 0) > 0   # the Required nils

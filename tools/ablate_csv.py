@@ -12,6 +12,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from transferia_amd import lib, workload  # noqa: E402
 
+# the profiling branches are compiled out of the product: this script runs the ablate build of tf_csv.hip
+#   tools/build_variant.sh ablate tf_csv.hip -DTF_CSV_ABLATE_BUILD=1
+lib._LIBPATH = os.path.join(os.path.dirname(lib._LIBPATH), "variants", "libtfgpu_ablate.so")
+
 rows = int(os.environ.get("ROWS", 1 << 20))
 lib.init(0)
 dbuf, total, hs = bench.stage_shard(lib, workload, 0, rows)

@@ -1149,6 +1149,41 @@ def parquet_reader():
                                   "files": files}, compact=True)
 
 
+
+# ---------------------------------------------------------------------------
+# The ONE Parquet object the reference holds: TestBatchSerializer/parquet:default (reference_test.go:117-124) — the 118 items of
+# ReadChangeItems(10) written by parquetBatchSerializer with the FIRST item's TableSchema (parquet.go:69-84): every item's values are looked
+# up by field name in item.AsMap() (parquet_format.go:82-100), so the items of the other 31 tables contribute nils — and a nil in the
+# Required `__primary_key` comes out as 0.  The object is parquet-go's (not rebuildable here); what it SAYS — field order, physical /
+# logical types, repetition, row count, every value — is read with pyarrow and kept as data.
+# ---------------------------------------------------------------------------
+def parquet_writer_canon():
+    import glob
+    import pyarrow.parquet as pq
+    path = REF + "/pkg/serializer/reference/canondata/reference.reference.TestBatchSerializer_parquet_default/result"
+    f = pq.ParquetFile(path)
+    sch, md = f.schema, f.metadata
+    fields = []
+    for i in range(len(sch.names)):
+        c = sch.column(i)
+        fields.append({"name": c.name, "physical": c.physical_type, "logical": str(c.logical_type), "converted": str(c.converted_type), "required": c.max_definition_level == 0,
+                       "max_repetition_level": c.max_repetition_level})
+    rg = md.row_group(0)
+    chunks = [{"name": rg.column(i).path_in_schema, "compression": rg.column(i).compression, "num_values": rg.column(i).num_values} for i in range(rg.num_columns)]
+    t = f.read()
+    rows = [[r[n] for n in sch.names] for r in t.to_pylist()]
+    # the TableSchema the reference built its parquet.Schema from: items[0] of the corpus in the order ReadChangeItems gives (serializer_canon's order)
+    roots = ["tests/canon/clickhouse/canondata/*/extracted", "tests/canon/mysql/canondata/*/extracted", "tests/canon/postgres/gotest/canondata/*/extracted",
+             "tests/canon/ydb/canondata/*/extracted", "tests/canon/yt/canondata/*/extracted"]   # (serializer_canon's corpus)
+    first = sorted([p_ for g in roots for p_ in glob.glob(REF + "/" + g)], key=lambda p_: p_.split("/")[-2].split(".")[-1], reverse=True)[0]
+    with open(first) as fh:
+        it0 = json.load(fh)[0]
+    ts = [[c["name"], c["type"], bool(c["key"]), bool(c["required"])] for c in it0["TableSchema"]["value"]]
+    write("parquet_writer_canon.json", {"ref": path[len(REF) + 1:], "created_by": md.created_by, "num_rows": md.num_rows, "num_row_groups": md.num_row_groups, "root": "table",
+                                         "fields": fields, "chunks": chunks, "rows": rows, "table_schema": ts, "table_schema_from": first[len(REF) + 1:],
+                                         "items": "the 118 items of tests/golden/serializers_canon.json, in its order"})
+
+
 def hits_schema():
     with open(REF + "/pkg/providers/postgres/testdata/hits_data.json") as f:
         d = json.load(f)
@@ -1162,4 +1197,4 @@ def hits_schema():
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference tree not present: run this in the build container")
-    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium(); sr_format(); sr_protobuf(); parquet_reader()
+    mask(); sharder(); to_string(); to_datetime(); filter_rows(); csv_reader(); csv_splitter(); csv_typed(); serializers(); serializer_canon(); json_parser(); hits_schema(); collapse(); keys_changed(); queue_serializers(); confluent_sr(); debezium(); sr_format(); sr_protobuf(); parquet_reader(); parquet_writer_canon()

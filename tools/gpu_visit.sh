@@ -84,7 +84,8 @@ case $MODE in
   tests) tests "$1" ;;
   bench) bench "${1:-csv}" "$2" ;;
   ab) for w in $2; do for v in 1 0; do echo "== $w $1=$v"; env $1=$v timeout 300 python bench.py --workload $w --steps 5 --passes 1 --warmup 2 $QUIET > "$OUT/ab_${w}_$v.json" 2>/dev/null; line "$OUT/ab_${w}_$v.json"; done; done ;;
-  ablate) for a in $4; do env $1=$a timeout 120 python bench.py --workload $3 --steps 2 --passes 1 --warmup 1 --prof-steps 5 $QUIET 2>/dev/null | python -c "
+  ablate) V=""; [ "$1" = TFGPU_CSV_ABLATE ] && V="TFGPU_LIB_VARIANT=ablate"   # the CSV kernels' profiling branches exist only in the ablate build: tools/build_variant.sh ablate tf_csv.hip -DTF_CSV_ABLATE_BUILD=1 (before gpurun)
+    for a in $4; do env $V $1=$a timeout 120 python bench.py --workload $3 --steps 2 --passes 1 --warmup 1 --prof-steps 5 $QUIET 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; print('$1=$a', {n:round(k[n]['avg_ms'],4) for n in k if n=='$2'})" | tee -a "$OUT/ablate_$2.txt"; done ;;
   pmc) bash tools/gpu_pmc2.sh "$1" "$TAG/pmc_$1" "${2:-csv}" "${3:-2}" "$4"; cp "$OUT/pmc_$1/summary.txt" "$OUT/pmc_$1.txt" ;;

@@ -19,6 +19,7 @@
 // HBM-bound byte kernel: algorithmic traffic B_csv + B_bin per row.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <type_traits>
 
 #include "tf_devfmt.hpp"
@@ -32,6 +33,14 @@
 #include "tf_f64range.hpp"
 #include "tf_plan.hpp"
 
+// TFGPU_CSV_ABLATE=n (leave a kernel after phase n; results are NOT valid) is a profiling build only: the product's kernels carry none of
+// its branches (`if (t.ablate == 31)` sat in every integer cell of the one kernel that is instruction-bound).
+// tools/build_variant.sh ablate tf_csv.hip -DTF_CSV_ABLATE_BUILD=1 builds the variant tools/ablate_csv.py and gpu_visit.sh ablate load.
+#ifdef TF_CSV_ABLATE_BUILD
+#define CSV_ABL(x) ((x).ablate)
+#else
+#define CSV_ABL(x) 0
+#endif
 namespace tf {
 
 std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  // tf_transform.hip
@@ -1112,7 +1121,7 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
               const int bits = tc.width * 8;
               if (tc.kind == CK_INT) ok = ok && v <= (neg ? (1ull << (bits - 1)) : (1ull << (bits - 1)) - 1);
               else ok = ok && !(neg && v != 0) && (tc.width == 8 || v <= (1ull << bits) - 1);
-              if (ok && p.ablate != 5) {
+              if (ok && CSV_ABL(p) != 5) {
                 const int64_t sv = neg ? (int64_t)(0 - v) : (int64_t)v;
                 switch (tc.width) {
                   case 1: ((int8_t *)tc.p0)[r] = (int8_t)sv; break;
@@ -1322,7 +1331,7 @@ __device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint
 template <int KIND, int W, class T> __device__ __forceinline__ void reg_int_body(const RegTile &t, const RegCell &c, T *const out) {
   constexpr uint32_t FASTD = W < 4 ? 5u : 8u;  // digits the first tier takes (more cannot fit / need a second window)
   const uint32_t n = c.fend - c.fs;
-  if (t.ablate != 31 && wave_all(n - 1u < 4u || !c.on)) {
+  if (CSV_ABL(t) != 31 && wave_all(n - 1u < 4u || !c.on)) {
     // tier A: one to four characters, an unsigned canonical decimal — the common cell of a flag / small-integer column.  One
     // aligned LDS word pair holds the field's bytes [fend - 4, fend); masks come from shifts (an LDS table read costs the CU
     // as much as six VALU instructions), the leading-zero rule from the first character in byte 0.
@@ -1798,9 +1807,9 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
     if constexpr (COLS) {
       for (int ti = p.wave_task[wv]; ti < p.wave_task[wv + 1]; ti++) {
         const CsvTask k = p.tasks[ti];
-        if (p.ablate >= 10) {  // 10: no cells; 11: integer tasks only; 12: text; 13: date / timestamp
+        if (CSV_ABL(p) >= 10) {  // 10: no cells; 11: integer tasks only; 12: text; 13: date / timestamp
           const int grp = (k.kind == CK_INT || k.kind == CK_UINT) ? 11 : k.kind == CK_STR ? 12 : 13;
-          if (p.ablate != grp && !(p.ablate == 31 && grp == 11)) continue;
+          if (CSV_ABL(p) != grp && !(p.ablate == 31 && grp == 11)) continue;
         }
         switch (k.kind) {
           case CK_INT:
@@ -1822,9 +1831,9 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
       const CsvRun run = p.runs[ri];
       if (COLS && task_kind(run.kind)) continue;  // its cells ran as tasks
       const uint32_t items = (uint32_t)run.ncols * nr, nslots = (items + 63) >> 6;
-      if (p.ablate >= 10) {  // 10: no cells; 11: integer runs only; 12: text runs only; 13: date / timestamp runs only
+      if (CSV_ABL(p) >= 10) {  // 10: no cells; 11: integer runs only; 12: text runs only; 13: date / timestamp runs only
         const int grp = (run.kind == CK_INT || run.kind == CK_UINT) ? 11 : run.kind == CK_STR ? 12 : 13;
-        if (p.ablate != grp && !(p.ablate == 31 && grp == 11)) { sbase += nslots; continue; }
+        if (CSV_ABL(p) != grp && !(p.ablate == 31 && grp == 11)) { sbase += nslots; continue; }
       }
       switch (run.kind) {
         case CK_INT:
@@ -2580,7 +2589,11 @@ static int csv_parse_body(const tfgpu_csv_options *opts, const tfgpu_schema *sch
   for (auto &c : cols) if (c.kind == CK_F32) pp.o.p128 = reinterpret_cast<const uint64_t *>(pow10_table() + 632);
   pp.cols = ptr<CsvCol>(bcols); pp.ncols = ncols; pp.field_first = ptr<int32_t>(bff); pp.nfields_used = max_field + 1;
   pp.err = ptr<uint8_t>(err); pp.err_col = ptr<int32_t>(err_col); pp.nerr = ptr<uint32_t>(nerr);
+#ifdef TF_CSV_ABLATE_BUILD
   static const int ablate = [] { const char *e = std::getenv("TFGPU_CSV_ABLATE"); return e ? std::atoi(e) : 0; }();
+#else
+  static const int ablate = [] { const char *e = std::getenv("TFGPU_CSV_ABLATE"); if (e && std::atoi(e)) std::fprintf(stderr, "tfgpu: TFGPU_CSV_ABLATE needs the ablate build of tf_csv.hip (tools/build_variant.sh ablate tf_csv.hip -DTF_CSV_ABLATE_BUILD=1); ignored\n"); return 0; }();
+#endif
   pp.ablate = ablate;
   static const bool force_general = [] { const char *e = std::getenv("TFGPU_CSV_GENERAL"); return e && e[0] == '1'; }();
   pp.gen_n = ptr<uint32_t>(gen); pp.gen_tile = ptr<uint32_t>(gen) + 1; pp.force_general = force_general ? 1 : 0;

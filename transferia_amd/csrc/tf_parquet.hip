@@ -401,6 +401,72 @@ static bool lz4_raw_inflate(const uint8_t *p, const uint8_t *e, uint8_t *out, ui
   }
   return o == usize;
 }
+// The first `want` bytes of what [p, e) inflates to (the device inflates the page; the host's walk reads a page's definition levels and the
+// width byte of its dictionary indices, which sit at its front).  `cap` = the page's stated size (room behind `out`).  false: malformed so far.
+static bool snappy_inflate_prefix(const uint8_t *p, const uint8_t *e, uint8_t *out, uint64_t cap, uint64_t want) {
+  TReader r{p, e};
+  const uint64_t n = r.varint();
+  if (!r.ok || n != cap) return false;
+  p = r.p;
+  uint64_t o = 0;
+  want = std::min(want, cap);
+  while (p < e && o < want) {
+    const uint32_t tag = *p++;
+    uint64_t len, off;
+    switch (tag & 3) {
+      case 0: {
+        len = (tag >> 2) + 1;
+        if (len > 60) { const uint32_t nb = (uint32_t)len - 60; if ((uint64_t)(e - p) < nb) return false; len = 0; for (uint32_t i = 0; i < nb; i++) len |= (uint64_t)p[i] << (8 * i); len += 1; p += nb; }
+        if (len > (uint64_t)(e - p) || len > cap - o) return false;
+        const uint64_t take = std::min(len, want - o);   // (the rest of a long literal is the device's)
+        std::memcpy(out + o, p, (size_t)take); p += len; o += len;
+        continue;
+      }
+      case 1: if (p >= e) return false; len = ((tag >> 2) & 7) + 4; off = ((uint64_t)(tag >> 5) << 8) | *p++; break;
+      case 2: if (e - p < 2) return false; len = (tag >> 2) + 1; off = (uint64_t)p[0] | (uint64_t)p[1] << 8; p += 2; break;
+      default: if (e - p < 4) return false; len = (tag >> 2) + 1; off = (uint64_t)p[0] | (uint64_t)p[1] << 8 | (uint64_t)p[2] << 16 | (uint64_t)p[3] << 24; p += 4;
+    }
+    if (off == 0 || off > o || len > cap - o) return false;
+    for (uint64_t i = 0; i < len; i++) out[o + i] = out[o - off + i];
+    o += len;
+  }
+  return o >= want;
+}
+static bool lz4_raw_inflate_prefix(const uint8_t *p, const uint8_t *e, uint8_t *out, uint64_t cap, uint64_t want) {
+  uint64_t o = 0;
+  want = std::min(want, cap);
+  while (p < e && o < want) {
+    const uint32_t tok = *p++;
+    uint64_t lit = tok >> 4;
+    if (lit == 15) { uint8_t b; do { if (p >= e) return false; b = *p++; lit += b; } while (b == 255); }
+    if (lit > (uint64_t)(e - p) || lit > cap - o) return false;
+    std::memcpy(out + o, p, (size_t)std::min(lit, want - o)); p += lit; o += lit;
+    if (p == e || o >= want) break;
+    if (e - p < 2) return false;
+    const uint64_t off = (uint64_t)p[0] | (uint64_t)p[1] << 8; p += 2;
+    uint64_t ml = tok & 15;
+    if (ml == 15) { uint8_t b; do { if (p >= e) return false; b = *p++; ml += b; } while (b == 255); }
+    ml += 4;
+    if (off == 0 || off > o || ml > cap - o) return false;
+    for (uint64_t i = 0; i < ml; i++) out[o + i] = out[o - off + i];
+    o += ml;
+  }
+  return o >= want;
+}
+// bytes without a constructor run over them: the arena of a 556 MB object is not zero-filled page by page before it is overwritten
+struct RawVec {
+  uint8_t *p = nullptr; size_t n = 0, cap = 0;
+  RawVec() = default;
+  RawVec(const RawVec &) = delete;
+  RawVec &operator=(const RawVec &) = delete;
+  ~RawVec() { std::free(p); }
+  uint8_t *data() { return p; }
+  const uint8_t *data() const { return p; }
+  size_t size() const { return n; }
+  void reserve(size_t c) { if (c <= cap) return; uint8_t *q = (uint8_t *)std::realloc(p, c); if (!q) throw std::bad_alloc(); p = q; cap = c; }
+  void resize(size_t m) { if (m > cap) reserve(std::max(m, cap + cap / 2 + 4096)); n = m; }
+  void append(const uint8_t *b, const uint8_t *e) { const size_t at = n; resize(n + (size_t)(e - b)); if (e > b) std::memcpy(p + at, b, (size_t)(e - b)); }
+};
 enum { C_UNCOMPRESSED = 0, C_SNAPPY = 1, C_GZIP = 2, C_ZSTD = 6, C_LZ4_RAW = 7 };
 static bool page_inflate(int codec, const uint8_t *p, uint64_t n, uint8_t *out, uint64_t usize, std::string &why) {
   switch (codec) {
@@ -563,7 +629,7 @@ __device__ __forceinline__ uint32_t seg_value(const uint8_t *file, const Seg &s,
 enum : int32_t { CV_SAME = 0, CV_DATE = 1, CV_TS_MICROS = 2, CV_I32_I64 = 3, CV_I32_U64 = 4, CV_I64_U64 = 5, CV_F32_F64 = 6 };
 struct FixedOut { void *values; int32_t *nanos; int32_t in_width, out_width, conv; };
 // what the object's own numbers may not exceed, checked where the values are read (the error word is read back at the sync)
-enum : uint32_t { PQE_DICT_INDEX = 1, PQE_TEXT_LENGTH = 2, PQE_HYBRID = 3 };
+enum : uint32_t { PQE_DICT_INDEX = 1, PQE_TEXT_LENGTH = 2, PQE_HYBRID = 3, PQE_INFLATE = 4 };
 // DELTA_BINARY_PACKED / DELTA_LENGTH_BYTE_ARRAY pages: ONE WAVE per page walks its miniblocks in order; a miniblock's deltas are
 // unpacked one per lane (any width up to 64 bits), prefix-summed across the wave (wrapping 64-bit adds, as the format says) and carried
 // into the next one.  mode 0: value i → `width` bytes at tail[out_at + i * width] (the column's PLAIN values of this page);
@@ -631,6 +697,224 @@ __global__ void __launch_bounds__(256) pq_delta(const uint8_t *file, uint8_t *ta
   }
   if (bad && lane == 0) *err = PQE_TEXT_LENGTH;
 }
+// ---- page codecs on the device: SNAPPY and LZ4_RAW (round 6) --------------------------------------------------------------------
+// parquet-go inflates every page in its reader (reader_parquet.go:137-283); until round 6 so did this library — single-threaded, on the
+// host, inside the page walk: ~1 GB/s for an object whose uncompressed twin is decoded at 25 GB/s.  Pages are independent and both
+// formats are byte-oriented LZ77s (snappy format_description.txt: a varint length, then literal / copy elements with 1-, 2- or 4-byte
+// offsets; lz4_Block_format.md: token, literals, 2-byte offset, match), so ONE WAVE takes one page:
+//   * the compressed bytes ride in two 256-byte register windows (lane l holds dword l of each); an element's tag and operands are read
+//     with v_readlane at a wave-uniform index — the parse is a scalar chain without a memory round trip per element; the next window's
+//     load is in flight while the current one is parsed;
+//   * the last 64 KiB of OUTPUT live in an LDS ring: a copy reads its source bytes there, lane i byte i (an overlapping copy — offset <
+//     length — repeats its period: out[o + i] = out[o - off + i mod off]); snappy's compressor works on 64 KiB fragments and LZ4's
+//     offsets are 16 bits, so a source outside the ring (snappy's 4-byte offsets) is rare and is read back from the image;
+//   * the ring leaves for the image in 16 KiB pieces of aligned 16-byte stores (ring positions and image addresses are kept congruent
+//     mod 16).
+// Every length is checked against the page's own numbers (input and output ends, offsets that reach in front of the page): a page
+// that lies fails the call (PQE_INFLATE) — the kernels behind it bound-check whatever bytes they find anyway.
+struct InfPage { uint64_t src, src_end, dst; uint32_t usize, lead, codec, pad; };  // [src + lead, src_end) of the compressed object inflates to usize bytes at image[dst + lead]; the `lead` bytes (a v2 page's levels) are copied as they are
+constexpr uint32_t INF_RING = 64u * 1024u, INF_MASK = INF_RING - 1u, INF_PIECE = 16u * 1024u;
+TF_DYNAMIC_LDS(uint4, inf_ring4);
+struct InfWindow {
+  const uint8_t *base;   // 4-byte aligned address of window byte 0
+  uint32_t w0, w1;       // lane l: the dwords at base + 4 l and base + 256 + 4 l
+  __device__ __forceinline__ void load(const uint8_t *b, int lane) {
+    base = b;
+    w0 = *reinterpret_cast<const uint32_t *>(b + 4 * lane);
+    w1 = *reinterpret_cast<const uint32_t *>(b + 256 + 4 * lane);
+  }
+  __device__ __forceinline__ void shift(int lane) {  // the second window becomes the first; the next 256 bytes are requested
+    base += 256; w0 = w1;
+    w1 = *reinterpret_cast<const uint32_t *>(base + 256 + 4 * lane);
+  }
+  __device__ __forceinline__ uint32_t word(uint32_t d) const {  // dword d (0 .. 127) of the window, d wave-uniform
+    const int k = __builtin_amdgcn_readfirstlane((int)(d & 63u));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w0, k), b = (uint32_t)__builtin_amdgcn_readlane((int)w1, k);
+    return d < 64u ? a : b;
+  }
+  __device__ __forceinline__ uint64_t bytes8(uint32_t p) const {  // the eight bytes at window position p (p + 8 <= 508), p wave-uniform
+    const uint32_t d = p >> 2, sh = (p & 3u) * 8u;
+    const uint32_t x0 = word(d), x1 = word(d + 1), x2 = word(d + 2);
+    const uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32);
+    return sh ? (lo >> sh) | ((uint64_t)x2 << (64 - sh)) : lo;
+  }
+  __device__ __forceinline__ uint64_t bytes5(uint32_t p) const {  // at least five bytes at window position p: two dwords hold them ((p & 3) + 5 <= 8)
+    const uint32_t d = p >> 2, sh = (p & 3u) * 8u;
+    return ((uint64_t)word(d) | ((uint64_t)word(d + 1) << 32)) >> sh;
+  }
+  __device__ __forceinline__ uint32_t lane_byte(uint32_t p) const {  // the byte at window position p (< 512), p per lane
+    const uint32_t d = p >> 2;
+    const uint32_t a = (uint32_t)__shfl((int)w0, (int)(d & 63u), 64), b = (uint32_t)__shfl((int)w1, (int)(d & 63u), 64);
+    return ((d < 64u ? a : b) >> ((p & 3u) * 8u)) & 0xFFu;
+  }
+};
+template <int CODEC>
+__device__ __forceinline__ bool inflate_page(const uint8_t *cfile, uint8_t *image, const InfPage &pg, int lane) {
+  uint8_t *const ring = reinterpret_cast<uint8_t *>(inf_ring4);
+  const uint8_t *const in0 = cfile + pg.src + pg.lead;
+  const uint64_t in_len = pg.src_end - pg.src - pg.lead;
+  uint8_t *const out = image + pg.dst + pg.lead;
+  const uint32_t usize = pg.usize;
+  const uint32_t phase = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);   // ring position of output byte o = (o + phase) & INF_MASK
+  for (uint32_t i = (uint32_t)lane; i < pg.lead; i += 64) image[pg.dst + i] = cfile[pg.src + i];
+  InfWindow W;
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in0) & 3u);
+  W.load(in0 - mis, lane);
+  uint64_t ip = 0;          // input bytes consumed
+  uint32_t wp = mis;        // window position of input byte ip
+  uint32_t o = 0, flushed = 0;
+  // window position wp may have run past the first 256 bytes (or the whole window, after a long literal)
+  auto settle = [&]() {
+    if (wp >= 512u) { const uint32_t skip = wp & ~255u; W.load(W.base + skip, lane); wp -= skip; }
+    else if (wp >= 256u) { W.shift(lane); wp -= 256u; }
+  };
+  auto flush_to = [&](uint32_t upto, bool last) {  // output bytes [flushed, upto) → the image; whole 16-byte lines but for the page's two ends
+    if (upto <= flushed) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t a = flushed + phase, b = upto + phase;          // phased positions
+    const uint32_t a16 = (a + 15u) & ~15u, b16 = last ? (b & ~15u) : b;   // (not last: upto + phase is a multiple of 16 by construction)
+    for (uint32_t q = a + (uint32_t)lane; q < min(a16, b); q += 64) out[q - phase] = ring[q & INF_MASK];
+    if (b16 > a16) for (uint32_t q = a16 + 16u * (uint32_t)lane; q < b16; q += 16u * 64u)
+      *reinterpret_cast<uint4 *>(out + (q - phase)) = *reinterpret_cast<const uint4 *>(ring + (q & INF_MASK));
+    if (last) for (uint32_t q = max(b16, a16 > b ? b : a16) + (uint32_t)lane; q < b; q += 64) out[q - phase] = ring[q & INF_MASK];
+    flushed = upto;
+  };
+  auto maybe_flush = [&]() {  // keep less than a ring minus one piece unflushed
+    const uint32_t done = (o + phase) & ~(INF_PIECE - 1u);   // (a phased position: a multiple of 16)
+    if (done > phase + flushed) flush_to(done - phase, false);
+  };
+  auto literal = [&](uint32_t len) -> bool {
+    if ((uint64_t)len > in_len - ip || len > usize - o) return false;
+    uint32_t done = 0;
+    while (done < len) {  // pieces that never outrun the ring's unflushed room
+      const uint32_t n = min(len - done, INF_PIECE);
+      if (wp + n <= 512u) {
+        for (uint32_t i = (uint32_t)lane; i < ((n + 63u) & ~63u); i += 64) { const uint32_t v = W.lane_byte(min(wp + i, 511u)); if (i < n) ring[(o + i + phase) & INF_MASK] = (uint8_t)v; }
+      } else {
+        // a long literal (incompressible bytes come as literals of up to 64 KiB): 16 bytes a lane, four loads in flight — a byte a lane
+        // leaves 64 bytes a wave in flight and two waves a CU cannot cover the memory latency with that (measured: 6 GB/s a chip).
+        // Ring-ALIGNED 16-byte chunks (the source is read unaligned), the bytes in front of the first and behind the last one by one.
+        const uint8_t *src = in0 + ip;
+        const uint32_t rp = o + phase;                               // ring position of the literal's first byte (before masking)
+        const uint32_t head = min((16u - (rp & 15u)) & 15u, n);
+        if ((uint32_t)lane < head) ring[(rp + (uint32_t)lane) & INF_MASK] = src[lane];
+        const uint32_t chunks = (n - head) >> 4;
+        struct __attribute__((packed, aligned(1))) U64u { uint64_t v; };
+        for (uint32_t c0 = 0; c0 < chunks; c0 += 256) {
+          uint64_t lo[4], hi[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t c = c0 + 64u * (uint32_t)u + (uint32_t)lane;
+            lo[u] = 0; hi[u] = 0;
+            if (c < chunks) { const uint8_t *q = src + head + 16u * c; lo[u] = reinterpret_cast<const U64u *>(q)->v; hi[u] = reinterpret_cast<const U64u *>(q + 8)->v; }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t c = c0 + 64u * (uint32_t)u + (uint32_t)lane;
+            if (c < chunks) *reinterpret_cast<uint4 *>(ring + ((rp + head + 16u * c) & INF_MASK)) = make_uint4((uint32_t)lo[u], (uint32_t)(lo[u] >> 32), (uint32_t)hi[u], (uint32_t)(hi[u] >> 32));
+          }
+        }
+        const uint32_t done_b = head + 16u * chunks;
+        if (done_b + (uint32_t)lane < n) ring[(rp + done_b + (uint32_t)lane) & INF_MASK] = src[done_b + lane];
+      }
+      o += n; ip += n; wp += n; done += n;
+      maybe_flush();
+    }
+    settle();
+    return true;
+  };
+  auto match = [&](uint32_t len, uint32_t off) -> bool {
+    if (off == 0 || off > o || len > usize - o) return false;
+    uint32_t done = 0;
+    while (done < len) {
+      const uint32_t n = min(len - done, 64u);
+      if (off <= INF_RING - 128u) {
+        // (LDS is in order: the bytes earlier elements wrote are there)
+        const uint32_t i = (uint32_t)lane;
+        uint32_t k = i;
+        if (off < 64u) {                                // (uniform) the period of an overlapping copy: i mod off through a reciprocal, exact for i, off < 64
+          const uint32_t q = (uint32_t)(((uint32_t)i * (65536u / off + 1u)) >> 16);
+          k = i - q * off;
+        }
+        const uint8_t v = ring[(o - off + k + phase) & INF_MASK];
+        __builtin_amdgcn_wave_barrier();
+        if (i < n) ring[(o + i + phase) & INF_MASK] = v;
+      } else {
+        // a source the ring no longer holds: everything that far back has left for the image (pieces of 16 KiB)
+        flush_to(((o + phase) & ~15u) > phase ? ((o + phase) & ~15u) - phase : 0u, false);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        const uint32_t i = (uint32_t)lane;
+        uint8_t v = 0;
+        if (i < n) { const uint32_t s = o - off + i; v = s < flushed ? out[s] : ring[(s + phase) & INF_MASK]; }
+        __builtin_amdgcn_wave_barrier();
+        if (i < n) ring[(o + i + phase) & INF_MASK] = v;
+      }
+      o += n; done += n;
+      __builtin_amdgcn_wave_barrier();   // (the next piece of a long overlapping copy reads what this one wrote)
+      maybe_flush();
+    }
+    return true;
+  };
+  if (CODEC == 1) {  // SNAPPY: the uncompressed length first
+    uint64_t n = 0; uint32_t shb = 0;
+    for (;;) {
+      if (ip >= in_len || shb > 28) return false;
+      const uint32_t b = (uint32_t)(W.bytes8(wp) & 0xFFu);
+      ip++; wp++; settle();
+      n |= (uint64_t)(b & 0x7Fu) << shb; shb += 7;
+      if (!(b & 0x80u)) break;
+    }
+    if (n != usize) return false;
+    while (ip < in_len) {
+      const uint64_t w = W.bytes5(wp);
+      const uint32_t tag = (uint32_t)w & 0xFFu;
+      if ((tag & 3u) == 0u) {
+        uint32_t len = (tag >> 2) + 1u, hdr = 1u;
+        if (len > 60u) { const uint32_t nb = len - 60u; if (in_len - ip < 1u + nb) return false; len = (uint32_t)((w >> 8) & (nb == 4u ? 0xFFFFFFFFull : ((1ull << (8 * nb)) - 1ull))) + 1u; hdr += nb; if (len == 0u) return false; }
+        ip += hdr; wp += hdr; settle();
+        if (!literal(len)) return false;
+      } else {
+        uint32_t len, off, hdr;
+        if ((tag & 3u) == 1u) { len = ((tag >> 2) & 7u) + 4u; off = ((tag >> 5) << 8) | ((uint32_t)(w >> 8) & 0xFFu); hdr = 2u; }
+        else if ((tag & 3u) == 2u) { len = (tag >> 2) + 1u; off = (uint32_t)(w >> 8) & 0xFFFFu; hdr = 3u; }
+        else { len = (tag >> 2) + 1u; off = (uint32_t)(w >> 8); hdr = 5u; }
+        if (in_len - ip < hdr) return false;
+        ip += hdr; wp += hdr; settle();
+        if (!match(len, off)) return false;
+      }
+    }
+  } else {  // LZ4_RAW
+    while (ip < in_len) {
+      uint64_t w = W.bytes8(wp);
+      const uint32_t tok = (uint32_t)w & 0xFFu;
+      ip++; wp++; settle();
+      uint32_t lit = tok >> 4;
+      if (lit == 15u) for (;;) { if (ip >= in_len) return false; const uint32_t b = (uint32_t)(W.bytes8(wp) & 0xFFu); ip++; wp++; settle(); lit += b; if (lit > usize) return false; if (b != 255u) break; }
+      if (lit && !literal(lit)) return false;
+      if (ip == in_len) break;  // the last sequence is literals only
+      if (in_len - ip < 2u) return false;
+      w = W.bytes8(wp);
+      const uint32_t off = (uint32_t)w & 0xFFFFu;
+      ip += 2; wp += 2; settle();
+      uint32_t ml = tok & 15u;
+      if (ml == 15u) for (;;) { if (ip >= in_len) return false; const uint32_t b = (uint32_t)(W.bytes8(wp) & 0xFFu); ip++; wp++; settle(); ml += b; if (ml > usize) return false; if (b != 255u) break; }
+      if (!match(ml + 4u, off)) return false;
+    }
+  }
+  if (o != usize) return false;
+  flush_to(usize, true);
+  return true;
+}
+__global__ void __launch_bounds__(64) pq_inflate(const uint8_t *cfile, uint8_t *image, const InfPage *pages, int32_t npages, uint32_t *err) {
+  const int lane = threadIdx.x & 63;
+  const int32_t pi = (int32_t)blockIdx.x;
+  if (pi >= npages) return;
+  const InfPage pg = pages[pi];
+  const bool ok = pg.codec == 1u ? inflate_page<1>(cfile, image, pg, lane) : inflate_page<7>(cfile, image, pg, lane);
+  if (!ok && lane == 0) *err = PQE_INFLATE;
+}
+
 // The RLE / bit-packed hybrid stream of a page's dictionary indices (or RLE booleans) → one bw-byte word per value in the tail.  A
 // writer that alternates short literal groups and short repeats leaves a run header every few dozen values — a million and a half
 // of them in a 2^20-row object of a hundred dictionary-coded columns: walked on the host (a 32-byte segment each) they cost more than
@@ -1145,13 +1429,58 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   // (DELTA_BINARY_PACKED values, INT96 texts), sized by the walk.
   bool inflate = force_arena;
   for (auto &g : m.groups) for (auto &c : g.cols) if (c.codec != C_UNCOMPRESSED) inflate = true;
-  std::vector<uint8_t> arena;
-  if (inflate) arena.reserve((size_t)len * 2);
+  RawVec arena;
+  // Pages of the byte-oriented codecs (SNAPPY, LZ4_RAW) whose content the host's walk does not need — PLAIN values, dictionary indices,
+  // RLE booleans — are inflated ON THE DEVICE (pq_inflate, one wave a page): the compressed object goes up as it is, beside this walk,
+  // and the first `dev_region` bytes of the image are theirs (the arena keeps that room free and is uploaded from there on).  What the
+  // walk reads at a page's front (definition levels, the index width) the host inflates as a prefix.  Dictionary pages, DELTA_* pages
+  // and the other codecs (GZIP, ZSTD: entropy coders, a chain per bit) are the host's, as before.  TFGPU_PQ_DEVICE_INFLATE=0: all on the host (A/B).
+  const bool dev_inflate_on = [] { const char *e = std::getenv("TFGPU_PQ_DEVICE_INFLATE"); return !(e && e[0] == '0'); }();   // (read per call: bench.py and the tests A/B it in one process)
+  auto dev_page = [](const ColChunk &c, const PageHeader &h, int leaf_type) {
+    if (c.codec != C_SNAPPY && c.codec != C_LZ4_RAW) return false;
+    if (!(h.type == 0 || h.type == 3) || (h.type == 3 && !h.compressed_v2)) return false;
+    const bool enc_ok = h.enc == E_PLAIN || h.enc == E_RLE_DICT || h.enc == E_PLAIN_DICT || (h.enc == E_RLE && leaf_type == T_BOOLEAN);
+    const int64_t lead = h.type == 3 ? (int64_t)std::max(h.rep_len, 0) + (int64_t)std::max(h.def_len, 0) : 0;
+    return enc_ok && (int64_t)h.usize > lead && (int64_t)h.csize > lead;
+  };
+  uint64_t dev_region = 0, dev_cursor = 0;
+  std::vector<InfPage> infpages;
+  Buf cfile;
+  if (inflate && dev_inflate_on) {
+    // an upper bound of the region from the page headers alone (the walk below places the pages; a header that does not parse ends the
+    // count — the walk will say why)
+    uint64_t d = 0; bool any = false;
+    for (size_t k = 0; k < fields.size() && d < 0xF0000000ull; k++) {
+      if (fields[k].group) continue;
+      for (auto &g : m.groups) {
+        const ColChunk &c = g.cols[(size_t)fields[k].leaf];
+        if ((c.codec != C_SNAPPY && c.codec != C_LZ4_RAW) || c.data_off < 0 || c.total_comp < 0) continue;
+        uint64_t pos = (uint64_t)((c.dict_off > 0 && c.dict_off < c.data_off) ? c.dict_off : c.data_off);
+        const uint64_t end = pos + (uint64_t)c.total_comp;
+        if (end > len || end < pos) continue;
+        int64_t seen = 0;
+        while (pos < end && seen < c.num_values) {
+          TReader r{f + pos, f + end};
+          PageHeader h;
+          if (!parse_page_header(r, h) || h.csize < 0 || h.usize < 0 || h.nvalues < 0 || (uint64_t)h.csize > (uint64_t)(f + end - r.p)) break;
+          if (dev_page(c, h, fields[k].el.type)) { d = ((d + 15) & ~15ull) + (uint64_t)h.usize; any = true; }
+          if (h.type == 0 || h.type == 3) seen += h.nvalues;
+          pos = (uint64_t)(r.p - f) + (uint64_t)h.csize;
+        }
+      }
+    }
+    if (any && d < 0xF0000000ull) {
+      dev_region = (d + 15) & ~15ull;
+      cfile = dalloc((size_t)len + 1024);   // (the kernel's input windows read up to 512 bytes past a page's last byte)
+    }
+  }
+  UploadPieces up;
+  if (cfile) up.start(cfile->p, f, len);
+  if (inflate) { arena.reserve((size_t)dev_region + (size_t)len + (size_t)len / 2 + 4096); arena.resize((size_t)dev_region); }
   // An uncompressed object starts uploading NOW, beside the host's page walk: what the tail can need at most is in the footer (a
   // chunk lists its encodings: DELTA_BINARY_PACKED values decode into the tail, an INT96 column's texts live there, a
   // DELTA_BYTE_ARRAY chunk sends the whole object through the arena instead).
   Buf file;
-  UploadPieces up;
   uint64_t tail_base = 0, tail_cap = 0;
   if (!inflate) {
     tail_base = (len + 64 + 15) & ~15ull;
@@ -1285,6 +1614,28 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
           const int codec = (h.type == 3 && !h.compressed_v2) ? (int)C_UNCOMPRESSED : c.codec;
           if ((uint64_t)h.usize - lead > max_inflated(codec, (uint64_t)h.csize - lead))
             return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": a page states an uncompressed size its " + std::to_string(h.csize) + " bytes cannot inflate to");
+          const uint64_t dev_at = (dev_cursor + 15) & ~15ull;
+          if (dev_region && dev_page(c, h, leaf.type) && dev_at + (uint64_t)h.usize <= dev_region) {
+            // the device inflates this page into its place in front of the arena; the host reads only what the walk needs of its front
+            const size_t at0 = page_at0 = (size_t)dev_at;
+            dev_cursor = dev_at + (uint64_t)h.usize;
+            std::memcpy(arena.data() + at0, raw, (size_t)lead);
+            const uint8_t *cp = raw + lead, *ce = raw + h.csize;
+            uint8_t *dst = arena.data() + at0 + lead;
+            const uint64_t body = (uint64_t)h.usize - lead;
+            auto prefix = [&](uint64_t want) { return codec == C_SNAPPY ? snappy_inflate_prefix(cp, ce, dst, body, want) : lz4_raw_inflate_prefix(cp, ce, dst, body, want); };
+            const bool bad_page_msg = false; (void)bad_page_msg;
+            uint64_t want = 0;
+            if (leaf.rep == 1 && !h.v2) {  // v1: a 4-byte length, then the RLE levels
+              if (!prefix(4)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": malformed " + (codec == C_SNAPPY ? "SNAPPY" : "LZ4_RAW") + " page");
+              uint32_t L = 0; if (body >= 4) std::memcpy(&L, dst, 4);
+              want = 4 + (uint64_t)L;
+            }
+            want += (h.enc == E_RLE && leaf.type == T_BOOLEAN) ? 4 : (h.enc == E_PLAIN ? 0 : 1);
+            if (want && !prefix(want)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": malformed " + (codec == C_SNAPPY ? "SNAPPY" : "LZ4_RAW") + " page");
+            infpages.push_back(InfPage{(uint64_t)(raw - f), (uint64_t)(raw - f) + (uint64_t)h.csize, (uint64_t)at0, (uint32_t)body, (uint32_t)lead, (uint32_t)codec, 0u});
+            fb = arena.data(); pl = fb + at0; pe = pl + h.usize;
+          } else {
           const size_t at0 = page_at0 = (arena.size() + 15) & ~(size_t)15;
           if ((uint64_t)at0 + (uint64_t)h.usize + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the inflated pages of one object exceed 4 GiB: read it row group by row group");
           arena.resize(at0 + (size_t)h.usize);
@@ -1293,6 +1644,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
           if (!page_inflate(codec, raw + lead, (uint64_t)h.csize - lead, arena.data() + at0 + lead, (uint64_t)h.usize - lead, cw))
             return tf::fail(cw.find("need") != std::string::npos || cw.find("codec") != std::string::npos ? TFGPU_ERR_UNSUPPORTED : TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": " + cw);
           fb = arena.data(); pl = fb + at0; pe = pl + h.usize;
+          }
         } else if (c.codec != C_UNCOMPRESSED && (h.type == 0 || h.type == 2 || h.type == 3)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: internal: compressed page outside the inflating walk");
         if (h.type == 2) {  // dictionary page: PLAIN entries
           if (h.enc != E_PLAIN && h.enc != E_PLAIN_DICT) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: dictionary page encoding " + std::to_string(h.enc));
@@ -1400,7 +1752,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
             const size_t at0 = (arena.size() + 15) & ~(size_t)15;
             if ((uint64_t)at0 + exp.size() + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the inflated pages of one object exceed 4 GiB: read it row group by row group");
             arena.resize(at0);  // (fb may move: nothing below reads through it)
-            arena.insert(arena.end(), exp.begin(), exp.end());
+            arena.append(exp.data(), exp.data() + exp.size());
             if (is_flba) val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_FIXED_TEXT, P.width, (uint64_t)at0, 0, 0});
             else { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)at0, (uint64_t)(at0 + exp.size()), (uint32_t)ord, (uint32_t)present}); }
           } else return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": value encoding " + std::to_string(h.enc) + " (BYTE_STREAM_SPLIT, or a DELTA_* encoding over this type) is read by the stock reader");
@@ -1422,7 +1774,8 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
     tail_base = (img_len + 64 + 15) & ~15ull;
     if (tail_base + tail_need + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the object and what is decoded beside it exceed 4 GiB: read it row group by row group");
     file = dalloc((size_t)(tail_base + tail_need) + 64);
-    if (img_len) h2d(file->p, arena.data(), (size_t)img_len);
+    // (the first dev_region bytes are the device-inflated pages': not uploaded)
+    if (img_len > dev_region) h2d((char *)file->p + dev_region, arena.data() + dev_region, (size_t)(img_len - dev_region));
     TF_HIP(hipMemsetAsync((char *)file->p + img_len, 0, (size_t)(tail_base - img_len), st));
   } else if (tail_need > tail_cap) {
     // a chunk whose pages use an encoding its metadata does not list: the footer's bound does not hold — through the arena, sized by the walk
@@ -1431,6 +1784,16 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   const uint8_t *dfile = ptr<uint8_t>(file);
   uint8_t *dtail = ptr<uint8_t>(file) + tail_base;
   Buf derr = dalloc_zero(16);  // [0]: PQE_* raised by a kernel
+  if (!infpages.empty()) {
+    clk.at("device pages: walk done");
+    Buf bip = upload_small(infpages.data(), infpages.size() * sizeof(InfPage));
+    keep.push_back(bip); keep.push_back(cfile);
+    up.wait(0);   // the compressed object is in HBM
+    static const bool attr = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)INF_RING); return true; }();
+    (void)attr;
+    KernelTimer t("pq_inflate");
+    pq_inflate<<<(unsigned)infpages.size(), 64, INF_RING, st>>>(ptr<uint8_t>(cfile), ptr<uint8_t>(file), reinterpret_cast<const InfPage *>(bip->p), (int32_t)infpages.size(), ptr<uint32_t>(derr));
+  }
   // ---- (offset, length) of every PLAIN / DELTA_LENGTH byte-array value: the length-prefix walks of the PLAIN pages in one launch (the
   //      pages are independent; a page is a serial chain), the DELTA pages by prefix sums ----
   Buf arena_off, arena_len;
@@ -1623,7 +1986,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   clk.at("columns enqueued");
   tf::sync();  // ONE wait for the text columns' sizes (a dictionary-coded column can be far longer than its chunk), then the copies
   clk.at("first sync");
-  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
+  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_INFLATE ? "tfgpu_parquet_read: malformed SNAPPY / LZ4_RAW page (an element that runs past its page, or a copy from in front of it)" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
   for (size_t k = 0; k < totals.size(); k++) if (((uint64_t)htot64w[2 * k] | (uint64_t)htot64w[2 * k + 1] << 32) >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + plans[totals[k]].d.name + " holds 4 GiB of text or more: read the object row group by row group");
   if (!totals.empty()) {
     std::vector<PackDesc> pd(totals.size());
@@ -1641,7 +2004,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   }
   herr = d2h_u32(derr->p, 4);
   tf::sync();
-  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
+  if (herr[0]) return tf::fail(TFGPU_ERR_INVALID, herr[0] == PQE_DICT_INDEX ? "tfgpu_parquet_read: a dictionary index past its dictionary" : herr[0] == PQE_INFLATE ? "tfgpu_parquet_read: malformed SNAPPY / LZ4_RAW page (an element that runs past its page, or a copy from in front of it)" : herr[0] == PQE_HYBRID ? "tfgpu_parquet_read: malformed dictionary indices (an RLE / bit-packed run that ends outside its page)" : "tfgpu_parquet_read: a byte-array length that runs past its page");
   clk.at("second sync");
   for (auto &P : plans) db->cols.push_back(std::move(P.d));
   *out = db.release();

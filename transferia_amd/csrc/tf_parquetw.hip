@@ -306,7 +306,29 @@ extern "C" int tfgpu_parquet_write(const tfgpu_dbatch *b, const tfgpu_schema *sc
       std::string page;
       const size_t v0 = o.all_null ? 0 : o.rank[(size_t)r0], v1 = o.all_null ? 0 : o.rank[(size_t)r1];
       const size_t nv = v1 - v0;
-      if (l.required && nv != (size_t)gr) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_write: column " + l.name + " is Required and holds a nil");
+      // toParquetValue (parquet_format.go:43-52): a nil is parquet.ValueOf(nil) at definition level 0 whatever the field's repetition, and
+      // parquet-go writes a Required field's null as the type's ZERO value — pinned by the reference's own object
+      // (canondata/reference.reference.TestBatchSerializer_parquet_default/result: `__primary_key` is 0 in the rows of tables that have no
+      // such column; tests/test_parquet_write.py).  Rare: the page's values are expanded here, nils as zeros / empty byte arrays.
+      const bool fill_required = l.required && nv != (size_t)gr;
+      if (fill_required) {
+        auto is_valid = [&](int64_t r) { return !o.all_null && (o.valid.empty() || ((o.valid[(size_t)r >> 3] >> (r & 7)) & 1)); };
+        if (l.phys == T_BOOLEAN) {
+          size_t v = v0;
+          for (int64_t k = 0; k < gr; k += 8) { uint8_t byte = 0; for (int64_t j = 0; j < 8 && k + j < gr; j++) if (is_valid(r0 + k + j) && o.payload[v++]) byte |= (uint8_t)(1u << j); page.push_back((char)byte); }
+        } else if (l.phys == T_BYTE_ARRAY) {
+          for (int64_t r = r0; r < r1; r++) {
+            if (is_valid(r)) page.append((const char *)o.payload.data() + o.tdst[(size_t)r], (size_t)(o.tdst[(size_t)r + 1] - o.tdst[(size_t)r]));
+            else page.append(4, '\0');
+          }
+        } else {
+          size_t v = v0;
+          for (int64_t r = r0; r < r1; r++) {
+            if (is_valid(r)) { page.append((const char *)o.payload.data() + v * (size_t)l.width, (size_t)l.width); v++; }
+            else page.append((size_t)l.width, '\0');
+          }
+        }
+      }
       if (!l.required) {  // definition levels: RLE / bit-packed hybrid of 1-bit levels behind a 4-byte length
         std::string lv;
         auto hv = [&](uint64_t v) { while (v >= 0x80) { lv.push_back((char)(v | 0x80)); v >>= 7; } lv.push_back((char)v); };
@@ -316,7 +338,8 @@ extern "C" int tfgpu_parquet_write(const tfgpu_dbatch *b, const tfgpu_schema *sc
         const uint32_t L = (uint32_t)lv.size();
         page.append((const char *)&L, 4); page += lv;
       }
-      if (l.phys == T_BOOLEAN) { for (size_t k = 0; k < nv; k += 8) { uint8_t byte = 0; for (size_t j = 0; j < 8 && k + j < nv; j++) if (o.payload[v0 + k + j]) byte |= (uint8_t)(1u << j); page.push_back((char)byte); } }
+      if (fill_required) {}
+      else if (l.phys == T_BOOLEAN) { for (size_t k = 0; k < nv; k += 8) { uint8_t byte = 0; for (size_t j = 0; j < 8 && k + j < nv; j++) if (o.payload[v0 + k + j]) byte |= (uint8_t)(1u << j); page.push_back((char)byte); } }
       else if (l.phys == T_BYTE_ARRAY) { if (!o.all_null && !o.payload.empty()) page.append((const char *)o.payload.data() + o.tdst[(size_t)r0], (size_t)(o.tdst[(size_t)r1] - o.tdst[(size_t)r0])); }
       else if (nv) page.append((const char *)o.payload.data() + v0 * (size_t)l.width, nv * (size_t)l.width);
       std::string comp; const std::string *body = &page; std::string why;
