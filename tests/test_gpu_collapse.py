@@ -364,8 +364,10 @@ def test_absent_cells_travel_and_value_entries_refuse(tf, oracle):
     grouped, counts = tf.partition(tf.Transformer("sharder_transformer", {"shardsCount": "3", "columns": {"includeColumns": ["^id$"]}}).apply(
         tf.DeviceBatch.upload(_without_absent(b))).transformed, 3)
     assert sum(counts) == 200
+    with pytest.raises(tf.TfgpuError, match="ABSENT"):   # (mask_field and friends walk each row's own names since round 6: test_transformers_walk_each_rows_own_column_names)
+        tf.apply_chain([tf.Transformer("replace_primary_key", {"keys": ["id"], "tables": {}}), tf.Transformer("sql", {"tables": {"include_tables": [".*"]}, "query": "select * from table where id >= 0"})], db)
     with pytest.raises(tf.TfgpuError, match="ABSENT"):
-        tf.Transformer("mask_field", {"columns": ["c0"], "maskFunctionHash": {"userDefinedSalt": "s"}}).apply(db)
+        tf.serialize(abi.FMT_CSV, db)
     # the changed-key flags read an absent key column as nil, like ChangeItem.KeysChanged reading ColumnValues by name
     assert list(tf.keys_changed(db)) == list(oracle.keys_changed_rows(items))
 
@@ -489,3 +491,73 @@ def test_download_without_room_for_the_absent_bits_is_refused(tf):
     assert tf.load().tfgpu_dbatch_download(db._h, C.byref(hb)) != 0
     assert b"absent" in (tf.load().tfgpu_last_error() or b"")
     assert db.download().nrows == n   # the binding that brings the room gets the rows
+
+
+def test_toast_rows_through_collapse_and_clickhouse_jsoneachrow(tf, oracle):
+    """A Postgres-CDC batch with TOASTed Updates stays on the device all the way to the ClickHouse sink (round 6): the stream as it came and what
+    tfgpu_collapse leaves of it → ClickHouse JSONEachRow on the device, byte for byte the oracle's MarshalCItoJSON over the same rows — it walks each row's
+    OWN ColumnNames and skips nils (marshal.go:82-125), so a cell the row does not list prints like a nil one: nothing.  Rows that carry their own name
+    ORDER (col_order) are refused by name; json / csv (they type the i-th value by the schema's i-th column) keep refusing ragged rows."""
+    from collapse_cases import random_toast_items, batch_from_items
+    names = ["id"] + ["c%d" % j for j in range(5)]
+    done = refused = 0
+    for seed in range(8):
+        items = random_toast_items(1300 + seed, 160, toastable=[2, 3, 4], p_absent=0.5, weights=(3, 6, 0, 0), p_nokey=0.0)
+        b, schema = batch_from_items(items, names=names)
+        assert any(c.absent is not None and c.absent.any() for c in b.cols)
+        db = tf.DeviceBatch.upload(b)
+        for dev in (db, tf.collapse(db)):
+            host = dev.download()
+            host.schema = schema
+            if getattr(host, "col_order", None) is not None:
+                with pytest.raises(tf.TfgpuError, match="ABSENT"):
+                    tf.serialize(abi.FMT_CH_JSON_EACH_ROW, dev)
+                refused += 1
+                continue
+            want = oracle.serialize(abi.FMT_CH_JSON_EACH_ROW, host, schema)
+            got = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, dev).download()
+            assert want is not None and bytes(got) == bytes(want), seed
+            if any(c.absent is not None and c.absent.any() for c in host.cols):
+                done += 1
+                with pytest.raises(tf.TfgpuError, match="ABSENT"):
+                    tf.serialize(abi.FMT_JSON, dev)
+    assert done >= 8, (done, refused)
+
+
+def test_transformers_walk_each_rows_own_column_names(tf, oracle):
+    """mask_field / convert_to_string / convert_to_datetime leave a cell the row does not list as it is (hmac_hasher.go:56-63: the loop runs over
+    item.ColumnNames), filter_rows fails a row that does not list a filtered column ("Unable to find column", filter_rows.go:147-154) unless it lists
+    nothing at all, filter_columns / skip_events carry the bitmaps — the chain over Inserts that leave columns out, device against the oracle's row-wise
+    transformers: kept rows, names, values, row errors; then on to the ClickHouse sink."""
+    from collapse_cases import random_toast_items, batch_from_items, items_of
+    names = ["id"] + ["c%d" % j for j in range(5)]
+    chains = [
+        [("mask_field", {"maskFunctionHash": {"userDefinedSalt": "s"}, "columns": ["c0", "c3"]})],
+        [("convert_to_string", {"columns": {"includeColumns": ["^c1$", "^c3$"]}, "tables": {}})],
+        [("filter_rows", {"filter": "c1 > 50"})],
+        [("filter_rows", {"filters": ["c1 > 50", "c3 > 20"]}), ("mask_field", {"maskFunctionHash": {"userDefinedSalt": "s"}, "columns": ["c2"]})],
+        [("mask_field", {"maskFunctionHash": {"userDefinedSalt": "s"}, "columns": ["c0"]}), ("filter_columns", {"columns": {"excludeColumns": ["^c4$"]}, "tables": {}}),
+         ("convert_to_string", {"columns": {"includeColumns": ["^c1$"]}, "tables": {}})],
+    ]
+    checked = 0
+    for seed in range(4):
+        items = random_toast_items(1700 + seed, 200, p_absent=0.4, weights=(1, 0, 0, 0), front_ok=True)
+        if seed == 3:
+            items[5]["names"], items[5]["values"] = [], []          # a row that lists nothing: filter_rows' name loop never runs for it
+        b, schema = batch_from_items(items, names=names)
+        assert any(c.absent is not None and c.absent.any() for c in b.cols)
+        for chain in chains:
+            ref = oracle.apply_chain([oracle.Transformer(t, c) for t, c in chain], b, schema)
+            res = tf.apply_chain([tf.Transformer(t, c) for t, c in chain], tf.DeviceBatch.upload(b))
+            got = res.transformed.download()
+            assert items_of(got) == items_of(ref.batch), (seed, chain[0][0])
+            assert sorted((e[0], e[1]) for e in res.errors) == sorted((e[0], abi.ROWERR[e[1]]) for e in ref.errors), (seed, chain[0][0])
+            got.schema = ref.schema
+            want = oracle.serialize(abi.FMT_CH_JSON_EACH_ROW, ref.batch, ref.schema)
+            if want is not None and got.nrows:
+                assert bytes(tf.serialize(abi.FMT_CH_JSON_EACH_ROW, res.transformed).download()) == bytes(want), (seed, chain[0][0])
+            checked += 1
+    assert checked == 4 * len(chains)
+    with pytest.raises(tf.TfgpuError, match="ABSENT"):   # `sql` serializes whole rows for clickhouse-local: stock path
+        tf.apply_chain([tf.Transformer("replace_primary_key", {"keys": ["id"], "tables": {}}), tf.Transformer("sql", {"tables": {"include_tables": [".*"]}, "query": "select * from table where id >= 0"})],
+                       tf.DeviceBatch.upload(b))

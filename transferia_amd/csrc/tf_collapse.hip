@@ -404,6 +404,14 @@ __global__ void __launch_bounds__(256) collapse_merge_names(MergeParams p, const
   }
   for (int c = 0; c < ncols; c++) if (first_of(c) == NEVER) o[pos++] = (uint16_t)c;  // not listed: behind the listed ones
 }
+// does a bitmap of n bits hold a set one?  (bits past n in its last byte do not count)
+__global__ void __launch_bounds__(256) collapse_any_bit(const uint8_t *bits, int64_t n, uint32_t *flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nb = (n + 7) / 8;
+  if (i >= nb) return;
+  uint32_t v = bits[i];
+  if (i == nb - 1 && (n & 7)) v &= (1u << (n & 7)) - 1u;
+  if (v) *flag = 1u;
+}
 __global__ void __launch_bounds__(256) collapse_any_non_insert(const uint8_t *kind, int64_t n, uint32_t *flag) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && kind[i] != TFGPU_K_INSERT && kind[i] != TFGPU_K_SYNCHRONIZE) *flag = 1;  // InsertsOnly :37-44
@@ -607,6 +615,15 @@ std::unique_ptr<tfgpu_dbatch> collapse_rows(const tfgpu_dbatch &in) {
     }
     out->cols = std::move(merged);
     out->col_order = order;
+    // a merge that filled every cell of a column leaves a bitmap of zeros: dropped, so that a batch which is uniform AFTER the collapse is not
+    // taken for a ragged one by the entries that refuse those.  One flag word a column, read back together.
+    std::vector<std::pair<size_t, const uint32_t *>> chk;
+    for (size_t c = 0; c < out->cols.size(); c++) if (out->cols[c].absent && m > 0) {
+      Buf flag = dalloc_zero(4);
+      collapse_any_bit<<<cgrid((m + 7) / 8), 256, 0, st>>>(ptr<uint8_t>(out->cols[c].absent), m, ptr<uint32_t>(flag));
+      chk.push_back({c, d2h_u32(flag->p, 1)});
+    }
+    if (!chk.empty()) { sync(); for (auto &k : chk) if (!*k.second) out->cols[k.first].absent = nullptr; }
   }
   tfgpu_dbatch meta_in;
   meta_in.nrows = n; meta_in.kind = in.kind; meta_in.part_id = in.part_id; meta_in.src_row = in.src_row;

@@ -206,6 +206,8 @@ void materialize(const struct ::tfgpu_dbatch &b, const std::vector<const DColumn
 void dense(const struct ::tfgpu_dbatch *b, bool absent_ok = false);
 void dense_locked(const struct ::tfgpu_dbatch &b);
 bool has_absent(const struct ::tfgpu_dbatch &b);
+// a fresh bitmap: (validity, or all ones when null) with the bits of `absent` cleared — an ABSENT cell reads nil (tf_runtime.hip)
+Buf validity_minus_absent(const Buf &validity, const Buf &absent, int64_t nrows);
 // The library-owned HBM block that starts at `p` (a tfgpu_dbuf), or null for foreign pointers.
 Buf find_device_block(const void *p);
 void register_device_block(const Buf &b);

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) dbz_prefix_same(Params p) {
     // The MESSAGE is what streams from HBM: it is read in its own 16-byte lines (one aligned global_load_dwordx4 a lane, 1 KiB a wave
     // step); the reference's bytes for the same positions sit at another alignment and come out of the cache (two shifted 8-byte reads
     // each).  What lies in front of the first line and behind the last one (< 16 bytes each) is compared by lanes 0 and 1.
-    const uint64_t a1 = (a + 15) & ~15ull;
+    const uint64_t a1 = a + ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(p.data + a) & 15u)) & 15u);   // by ADDRESS: a caller's device buffer need not start on a 16-byte line
     const uint32_t pre = min((uint32_t)(a1 - a), p.plen), nint = (p.plen - pre) >> 4;
     for (uint32_t c = lane; c < nint; c += 64) {
       const uint4 x = *reinterpret_cast<const uint4 *>(p.data + a1 + 16ull * c);

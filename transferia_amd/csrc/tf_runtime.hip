@@ -254,6 +254,13 @@ __global__ void upload_validity_minus_absent(const uint8_t *validity_in, const u
   validity_out[i] = (uint8_t)((validity_in ? validity_in[i] : 0xFFu) & ~absent[i]);
 }
 
+Buf validity_minus_absent(const Buf &validity, const Buf &absent, int64_t nrows) {
+  const int64_t nb = (nrows + 7) / 8;
+  Buf v = dalloc((size_t)nb + 8);
+  if (nb) upload_validity_minus_absent<<<(unsigned)((nb + 255) / 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(validity), ptr<uint8_t>(absent), nb, ptr<uint8_t>(v));
+  return v;
+}
+
 }  // namespace tf
 
 using namespace tf;
@@ -414,10 +421,7 @@ int tfgpu_batch_upload(const tfgpu_batch *h, tfgpu_dbatch **out) {
     if (c.absent && !is_old && n) {  // (OldKeys say which rows have them through old_keys_present)
       d.absent = upload(c.absent, (n + 7) / 8);
       // validity = (validity or all-ones) & ~absent: an unlisted key must hash, compare and shard as nil (change_item.go CurrentKeysString)
-      Buf v = dalloc((n + 7) / 8);
-      const int64_t nb = (int64_t)((n + 7) / 8);
-      upload_validity_minus_absent<<<(unsigned)((nb + 255) / 256), 256, 0, ctx().stream>>>(ptr<uint8_t>(d.validity), ptr<uint8_t>(d.absent), nb, ptr<uint8_t>(v));
-      d.validity = v;
+      d.validity = validity_minus_absent(d.validity, d.absent, (int64_t)n);
     }
     (is_old ? b->old_keys : b->cols).push_back(std::move(d));
   }

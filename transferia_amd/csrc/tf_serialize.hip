@@ -978,7 +978,11 @@ static bool slab_fits(int ncols, size_t blob_bytes) { return ncols > 0 && (size_
 
 extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu_serialize_options *opts, tfgpu_dbuf **out) {
   try {
-  tf::dense(b);  // its rows may still be a selection (tfgpu_dbatch::pending)
+    // ClickHouse JSONEachRow walks the row's OWN ColumnNames by name and skips nils (MarshalCItoJSON, marshal.go:82-125): a cell the row does not
+    // list prints exactly like a nil one — nothing — and an ABSENT cell's validity bit is clear, so the walk needs no change.  The json / csv
+    // serializers type a row's i-th VALUE by the schema's i-th column (buildJsonKV / buildCsvCells: columns[i]) — a row that leaves a column out is
+    // typed by the wrong columns from there on: that quirk stays with the stock path, as do rows with their own name ORDER (col_order).
+    tf::dense(b, b && format == TFGPU_FMT_CH_JSON_EACH_ROW && !b->col_order);  // its rows may still be a selection (tfgpu_dbatch::pending)
     if (!b || !out) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_serialize: null argument");
     if (format == TFGPU_FMT_RAW) return serialize_raw(b, opts, out);
     if (format != TFGPU_FMT_CH_JSON_EACH_ROW && format != TFGPU_FMT_JSON && format != TFGPU_FMT_CSV)

@@ -291,7 +291,13 @@ static std::unique_ptr<tfgpu_dbatch> apply_mask(const tfgpu_plan &p, const tfgpu
     return o;
   };
   if (!in.pending) {
-    for (auto &c : out->cols) if (p.mask_has(c.name)) c = mask_one(c, nullptr);
+    for (auto &c : out->cols) if (p.mask_has(c.name)) {
+      // HmacHasher.Apply walks the item's OWN ColumnNames (hmac_hasher.go:56-63): a row that does not list the column is left as it is — the digest
+      // the kernel wrote for it is nobody's, the cell stays ABSENT (and reads nil)
+      const Buf ab = c.absent;
+      c = mask_one(c, nullptr);
+      if (ab) { c.absent = ab; c.validity = validity_minus_absent(nullptr, ab, n); }
+    }
     return out;
   }
   for (auto &c : from.cols) {
@@ -325,6 +331,7 @@ struct FilterParams {
   const uint8_t *str_data;
   const uint8_t *kind;
   int64_t nrows;
+  const uint8_t *const *absent;  // [ncols] ABSENT bitmaps (DColumn::absent) or null entries; null: every row lists every column
   uint32_t *keep;   // 0/1 per row
   uint8_t *err;     // tfgpu_rowerr per row
   int32_t *err_term;
@@ -498,6 +505,12 @@ __global__ void __launch_bounds__(256) filter_eval_kernel(FilterParams p) {
       for (int k = p.expr_start[e]; k < p.expr_start[e + 1] && ok && !err; k++) {  // matchExpression :145-178
         const DTerm &t = p.terms[k];
         if (p.ncols == 0) continue;  // a row without columns never enters the name loop
+        if (p.absent) {  // rows that list their own columns: the name loop runs over THIS row's ColumnNames (filter_rows.go:147-154)
+          bool any = false;
+          for (int c = 0; c < p.ncols && !any; c++) any = !(p.absent[c] && ((p.absent[c][r >> 3] >> (r & 7)) & 1));
+          if (!any) continue;
+          if (t.col >= 0 && p.absent[t.col] && ((p.absent[t.col][r >> 3] >> (r & 7)) & 1)) { err = TFGPU_ROW_COLUMN_NOT_FOUND; eterm = k; break; }
+        }
         if (t.col < 0) { err = TFGPU_ROW_COLUMN_NOT_FOUND; eterm = k; break; }
         int m = match_value(p, t, r);
         if (m < 0) { err = -m; eterm = k; } else if (!m) ok = false;
@@ -862,6 +875,14 @@ static std::unique_ptr<tfgpu_dbatch> run_filter(const std::vector<FExpr> &p_expr
   fp.cols = ptr<DCol>(bcols); fp.ncols = (int32_t)cols.size(); fp.terms = ptr<DTerm>(bterms); fp.expr_start = ptr<int32_t>(bexpr);
   fp.nexpr = table_applies ? (int32_t)p_exprs.size() : 0;
   fp.ints = ptr<int64_t>(bints); fp.floats = ptr<double>(bfl); fp.str_off = ptr<uint32_t>(bsoff); fp.str_data = ptr<uint8_t>(bsd);
+  fp.absent = nullptr;
+  Buf babs;
+  {
+    std::vector<const uint8_t *> abs;
+    bool any = false;
+    for (auto &c : in.cols) { abs.push_back(ptr<uint8_t>(c.absent)); any = any || c.absent; }
+    if (any) { babs = up(abs.data(), abs.size() * sizeof(const uint8_t *)); fp.absent = reinterpret_cast<const uint8_t *const *>(babs->p); }
+  }
   fp.kind = check_kinds ? ptr<uint8_t>(in.kind) : nullptr; fp.nrows = n; fp.keep = ptr<uint32_t>(keep); fp.err = ptr<uint8_t>(err); fp.err_term = ptr<int32_t>(eterm); fp.nerr = ptr<uint32_t>(nerr);
   if (!table_applies) {
     // only the kind check applies: emulate with zero expressions and keep-all for inserts
@@ -959,7 +980,9 @@ static std::unique_ptr<tfgpu_dbatch> apply_to_string(const tfgpu_plan &p, const 
     require_serializable(c, "convert_to_string");
     // already text with identical bytes: only the type tag changes
     if (repr_is_var(c.repr) && !c.validity) { c.dtype = p.to_bytes ? TFGPU_T_BYTES : TFGPU_T_UTF8; c.repr = p.to_bytes ? TFGPU_R_BYTES : TFGPU_R_STRING; continue; }
+    const Buf ab = c.absent;   // the transformer converts the values of the names a row LISTS (to_string.go: it walks item.ColumnNames): an ABSENT cell stays one
     c = column_to_string(c, in.nrows, p.to_bytes, 64);
+    if (ab) { c.absent = ab; c.validity = validity_minus_absent(nullptr, ab, in.nrows); }
   }
   return out;
 }
@@ -984,7 +1007,8 @@ static std::unique_ptr<tfgpu_dbatch> apply_to_datetime(const tfgpu_plan &p, cons
     KernelTimer t("to_datetime");
     if (n && c.dtype == TFGPU_T_INT32 && c.repr == TFGPU_R_INT32) todatetime_kernel<int32_t><<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<int32_t>(c.values), n, ptr<int64_t>(o.values));
     else if (n && c.dtype == TFGPU_T_UINT32 && c.repr == TFGPU_R_UINT32) todatetime_kernel<uint32_t><<<grid_for(n, 256), 256, 0, ctx().stream>>>(ptr<uint32_t>(c.values), n, ptr<int64_t>(o.values));
-    // nil values also become time.Unix(0,0): the value.(int32) assertion fails
+    // nil values also become time.Unix(0,0): the value.(int32) assertion fails — an ABSENT cell is no value at all (the loop walks item.ColumnNames): it stays one
+    if (c.absent) { o.absent = c.absent; o.validity = validity_minus_absent(nullptr, c.absent, n); }
     c = std::move(o);
   }
   return out;
@@ -1718,8 +1742,12 @@ std::unique_ptr<tfgpu_dbatch> partition_rows(const tfgpu_dbatch &in, int nparts,
 std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch &in, ApplyCtx &ax) {
   // transformers compute on values: an ABSENT cell is not a nil (the stock path takes the batch) — but for the sharder, which reads its key
   // columns through AsMap()[name] (sharder.go:134-143: a name the item does not list IS nil there) and passes every column on untouched
-  if (p.kind != PK_SHARDER) refuse_absent(in);
-  if (in.pending && p.kind != PK_MASK) dense_locked(in);  // (the callers hold the lane's mutex) only mask_field reads through a selection
+  // Since round 6 the transformers that walk an item's own ColumnNames do so here too: mask_field / convert_to_string / convert_to_datetime leave a
+  // cell the row does not list as it is (hmac_hasher.go:56-63), filter_rows fails such a row ("Unable to find column", filter_rows.go:147-154),
+  // the column droppers and the row filters carry the bitmaps.  `sql` (it serializes whole rows for clickhouse-local) and batches whose rows carry
+  // their own name ORDER (col_order indexes the column list these transformers change) stay with the stock path.
+  if (p.kind == PK_SQL || (in.col_order && p.kind != PK_SHARDER)) refuse_absent(in);
+  if (in.pending && (p.kind != PK_MASK || has_absent(in))) dense_locked(in);  // (the callers hold the lane's mutex) only mask_field reads through a selection
   switch (p.kind) {
     case PK_MASK: return apply_mask(p, in);
     case PK_RENAME: return apply_rename(p, in);

@@ -347,7 +347,7 @@ static void hand_over(PushOut &o, tfgpu_dbatch **transformed, tfgpu_dbatch **err
 int tfgpu_transformation_push(tfgpu_transformation *t, const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_dbatch **transformed, tfgpu_dbatch **error_batches,
                               int32_t *error_steps, int32_t batches_cap, int32_t *n_error_batches, tfgpu_row_error *errs, int64_t errs_cap, int64_t *nerrs) {
   TF_API_BEGIN
-  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(in, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT cells: the plans say which of them read such rows (apply_plan)
   if (!t || !in || !transformed) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_transformation_push: null argument");
   PushOut o;
   push_run(*t, *in, schema, o);
@@ -376,7 +376,7 @@ int tfgpu_executor_start(int workers) {
 
 int tfgpu_transformation_push_async(tfgpu_transformation *t, const tfgpu_dbatch *in, const tfgpu_schema *schema, tfgpu_token **token) {
   TF_API_BEGIN
-  tf::dense(in);  // its rows may still be a selection (tfgpu_dbatch::pending)
+  tf::dense(in, true);  // its rows may still be a selection (tfgpu_dbatch::pending); ABSENT cells: see tfgpu_transformation_push
   if (!t || !in || !token) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_transformation_push_async: null argument");
   if (g_exec.empty()) g_exec.start(2);
   auto tok = std::make_unique<tfgpu_token>();
