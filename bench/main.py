@@ -98,11 +98,17 @@ def main():
     rank, local_rank, world = tdist.env_rank()
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
+    # TEST INFRASTRUCTURE: tests/test_hipemu.py runs `bench.py --devices 0,1` end to end on the CPU emulator's fake devices (tools/hipemu, HIPEMU_DEVICES=2) so
+    # that the one-process-several-GPUs path cannot rot on one-GPU boxes; the numbers of such a run mean nothing and its line says so.
+    emu = os.environ.get("TFGPU_TEST_EMU_LIB")
+    if emu:
+        lib._LIBPATH = emu
+    else:
+        torch.cuda.set_device(local_rank)
     e = Env()
     e.rank, e.local_rank, e.world = rank, local_rank, world
-    e.device = torch.device("cuda", local_rank)
-    e.group = tdist.Group("nccl", e.device)  # RCCL: barrier + MAX of the wall time (+ the configs4 exchange)
+    e.device = torch.device("cpu") if emu else torch.device("cuda", local_rank)
+    e.group = tdist.Group("gloo" if emu else "nccl", e.device)  # RCCL: barrier + MAX of the wall time (+ the configs4 exchange)
     e.lib, e.abi, e.workload = lib, abi, workload
     e.devices = [int(x) for x in args.devices.split(",") if x.strip() != ""] if args.devices else None
     if e.devices:
@@ -116,7 +122,8 @@ def main():
     def sync_all():
         lib.synchronize()
         e.group.barrier()
-        torch.cuda.synchronize()
+        if not emu:
+            torch.cuda.synchronize()
     e.sync_all = sync_all
 
     W = WORKLOADS[args.workload](args, e)
@@ -200,7 +207,7 @@ def main():
     alg = W.alg()
     dom = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if kernels else None
     roofline = None
-    if dom and alg.get(dom):
+    if dom and alg.get(dom) and not emu:   # (the emulator's events carry no time)
         per_launch = alg[dom] / max(kernels[dom]["launches_per_step"], 1)
         # The kernels of a pass cannot take longer than the pass that contains them.  When the event pass says otherwise (another
         # clock state, a noisy box) the dominant kernel is bounded from the TIMED region instead: pass time minus the other kernels.
@@ -236,10 +243,10 @@ def main():
             extra = extra / max(kernels[dom]["launches_per_step"], 1)
             roofline["text_view_bytes_per_launch"] = int(extra)
             roofline["frac_with_text_views"] = round((per_launch + extra) / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-    int_roof = W.int_roofline(kernels)
+    int_roof = W.int_roofline(kernels) if not emu else None
     for k, v in kernels.items():
         b = alg.get(k)
-        if b:
+        if b and v["avg_ms"] > 0:
             v["alg_gb_s"] = round(b / max(v["launches_per_step"], 1) / (v["avg_ms"] * 1e-3) / 1e9, 2)
         v["avg_ms"], v["ms_per_step"] = round(v["avg_ms"], 4), round(v["ms_per_step"], 4)
 
@@ -265,6 +272,8 @@ def main():
                             "per_rank_rows_per_step": [int(x) for x in rank_rows],
                             "n1_equivalent": "every rank runs exactly the N=1 step over its own row-range shard (rows %d.. of the same synthetic table): value = sum of per_rank_rows_per_step x steps / max time" % (rows * (world - 1)),
                             "measured_beyond_one_gpu": "nothing beyond N=1 had been measured on hardware when this was written (README.md): at N>1 this line is the first evidence" if world > 1 else None}
+        if emu:
+            out["emulated"] = "tools/hipemu (CPU): a structural run of this command line, not a measurement"
         out["row_errors"] = W.state.get("errors", 0)
         out["roofline"] = roofline
         if int_roof:

@@ -253,3 +253,24 @@ def test_exchange_two_gpus(tmp_path, case):
         return
     for r, o in enumerate(outs):
         assert o["recv"] == [outs[s]["sent"][r] for s in range(2)]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_bench_devices_mode_runs_end_to_end_on_fake_devices():
+    """`bench.py --devices 0,1` — ONE process driving several GPUs, a lane and a row-range shard each (tfgpu_init_devices) — has never had two real
+    devices under it (the builder's and the driver's boxes hold one).  Here the whole command line runs on the emulator's two fake devices: argument
+    handling, the per-device staging threads, the timed region, the JSON line with its process_model block.  A structural test: the line says so."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools", "hipemu"))
+    import build as emu_build
+    so = emu_build.build()
+    env = dict(os.environ, TFGPU_TEST_EMU_LIB=so, HIPEMU_DEVICES="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--devices", "0,1", "--rows", "1536", "--steps", "2", "--passes", "1", "--warmup", "1", "--prof-steps", "1",
+                        "--cpu-rows", "0", "--other-configs", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["process_model"]["devices"] == [0, 1] and d["process_model"]["row_range_shards"] == 2
+    assert d["config"]["rows_per_pass"] == 1536 and d["value"] > 0 and "emulated" in d
+    assert d["kernels"].get("csv_parse_regular") or d["kernels"].get("csv_parse_tiles_general") or d["kernels"].get("csv_parse_listed")
