@@ -216,7 +216,7 @@ class Configs3Workload(Base):
         #      beside it the same read with every page inflated on the host (TFGPU_PQ_DEVICE_INFLATE=0: what rounds 4-5 did).  Rates are quoted in
         #      UNCOMPRESSED bytes (the NONE object's size): what the decoder behind the codec sees. ----
         compressed = {}
-        for codec in ("snappy", "lz4_raw"):
+        for codec in ("snappy", "lz4_raw", "zstd"):
             try:
                 bufc = io.BytesIO()
                 pq.write_table(pa.table(arrays, names=names), bufc, compression=codec if codec != "lz4_raw" else "LZ4_RAW", row_group_size=h.nrows)
@@ -270,18 +270,40 @@ class Configs3Workload(Base):
                 for t in thc:
                     t.join()
                 lib.lane_use(0)
+                # every page on the HOST: on all the cores this process may use (pages inflated side by side ahead of the walk), then on one thread
+                # (what rounds 4-5 did)
+                dth = dth1 = dtd = float("nan")
+                os.environ["TFGPU_PQ_DEVICE_INFLATE"] = "1"   # every eligible page on the device, whatever its shape
+                try:
+                    onec(); lib.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        onec()
+                    lib.synchronize()
+                    dtd = (time.perf_counter() - t0) / 2
+                finally:
+                    os.environ.pop("TFGPU_PQ_DEVICE_INFLATE", None)
                 os.environ["TFGPU_PQ_DEVICE_INFLATE"] = "0"
                 try:
                     onec(); lib.synchronize()
                     t0 = time.perf_counter()
+                    for _ in range(2):
+                        onec()
+                    lib.synchronize()
+                    dth = (time.perf_counter() - t0) / 2
+                    os.environ["TFGPU_PQ_INFLATE_THREADS"] = "1"
+                    t0 = time.perf_counter()
                     onec(); lib.synchronize()
-                    dth = time.perf_counter() - t0
+                    dth1 = time.perf_counter() - t0
                 finally:
-                    os.environ.pop("TFGPU_PQ_DEVICE_INFLATE", None)
+                    os.environ.pop("TFGPU_PQ_DEVICE_INFLATE", None); os.environ.pop("TFGPU_PQ_INFLATE_THREADS", None)
                 compressed[codec] = {"object_bytes": len(datac), "uncompressed_object_bytes": len(data), "read_only_ms": round(dtc * 1e3, 3),
                                      "read_only_gb_per_s_uncompressed": round(len(data) / dtc / 1e9, 2), "read_only_gb_per_s_pcie": round(len(datac) / dtc / 1e9, 2),
                                      "lanes_3": {"ms_per_object": round(dtc3 * 1e3, 3), "gb_per_s_uncompressed": round(len(data) / dtc3 / 1e9, 2)} if not errs3 else {"error": str(errs3[0])[:200]},
-                                     "host_inflate_read_only_ms": round(dth * 1e3, 3), "decode_kernels_avg_ms": profc}
+                                     "policy": "auto: small pages (<= 128 KiB inflated) and stored ones on the device, the others on the host's cores ahead of the walk",
+                                     "device_all_pages_read_only_ms": round(dtd * 1e3, 3), "host_inflate_all_cores_read_only_ms": round(dth * 1e3, 3), "host_inflate_all_cores_gb_per_s_uncompressed": round(len(data) / dth / 1e9, 2),
+                                     "host_inflate_one_thread_read_only_ms": round(dth1 * 1e3, 3), "usable_cores": usable_cores(),
+                                     "data_pages_inflated_on": "device (pq_inflate)" if "pq_inflate" in profc else "host", "decode_kernels_avg_ms": profc}
                 pinc.free()
             except Exception as ex:  # noqa: BLE001
                 compressed[codec] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}

@@ -476,11 +476,11 @@ def _kernels_of(tf, fn):
     return out, names
 
 
-def _inflate_cases(tf, codec, n, check_kws, big_kws, damage_step):
+def _inflate_cases(tf, codec, n, check_kws, big_kws, damage_step, forced=True):
     t = table(min(n, 5000) // 2, 33)
     for kw in check_kws:
         _, names = _kernels_of(tf, lambda: check(tf, t, compression=codec, **kw))
-        assert "pq_inflate" in names, (kw, names)
+        assert not forced or "pq_inflate" in names, (kw, names)
     rng = np.random.default_rng(77)
     words = ["alpha", "beta-gamma", "https://example.org/path/", "delta", "?q=", "epsilon_zeta", "0123456789"]
     big = pa.table({
@@ -524,17 +524,22 @@ def _inflate_cases(tf, codec, n, check_kws, big_kws, damage_step):
     assert failed > 0
 
 
+@pytest.mark.parametrize("mode", ["1", "auto"])
 @pytest.mark.parametrize("codec", ["SNAPPY", "LZ4_RAW"])
-def test_pages_inflated_on_the_device(tf, codec):
+def test_pages_inflated_on_the_device(tf, codec, mode, monkeypatch):
     """pq_inflate (one wave a page; SNAPPY and LZ4_RAW): the shapes of `check` (dictionary pages + indices, PLAIN pages, v2 pages with their levels outside
     the compressed part, optional columns whose levels the host inflates as a prefix), pages larger than the 64 KiB LDS ring (repetitive text whose
     copies reach back over the ring, incompressible bytes = long literals, period-1 overlapping copies) and damaged pages — equal to pyarrow's reading."""
+    # mode "1": every eligible page on the device (the kernel meets text, copies over the whole ring, damaged elements); "auto" (the default): pages that
+    # barely compress on the device — the noise column here — and the others on the host's cores, inflated side by side ahead of the walk
+    monkeypatch.setenv("TFGPU_PQ_DEVICE_INFLATE", mode)
     _inflate_cases(tf, codec, 2600, ({}, {"use_dictionary": False, "data_page_version": "2.0", "row_group_size": 1500}),
-                   ({"use_dictionary": False, "data_page_size": 1 << 24},), 11)
+                   ({"use_dictionary": False, "data_page_size": 1 << 24},), 11, forced=mode == "1")
 
 
 @pytest.mark.parametrize("codec", ["SNAPPY", "LZ4_RAW"])
-def test_pages_inflated_on_the_device_fullsize(tf, codec):
+def test_pages_inflated_on_the_device_fullsize(tf, codec, monkeypatch):
     """the same with pages of 1.8 MB (60 000 rows: the ring wraps 28 times), every page shape, a denser sweep of damaged bytes (MI355X only: minutes on the emulator)"""
+    monkeypatch.setenv("TFGPU_PQ_DEVICE_INFLATE", "1")
     _inflate_cases(tf, codec, 60000, ({}, {"use_dictionary": False, "data_page_size": 2048}, {"data_page_version": "2.0", "row_group_size": 1500}, {"use_dictionary": False, "data_page_size": 1 << 22}),
                    ({"use_dictionary": False, "data_page_size": 1 << 24}, {"use_dictionary": False, "data_page_size": 100000, "data_page_version": "2.0"}, {}), 3)

@@ -78,6 +78,8 @@ traffic() {  # HBM bytes per launch of the dominant kernels: FETCH_SIZE / WRITE_
   done
   bash tools/gpu_pmc2.sh "mask_hmac" $TAG/pmc_mask csv 1 "SQ_INSTS_VALU SQ_WAVES" > "$OUT/pmc_mask.log" 2>&1
   bash tools/gpu_pmc2.sh "csv_parse_regular" $TAG/pmc_csv_valu csv 1 "SQ_INSTS_VALU SQ_WAVES SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" > "$OUT/pmc_csv_valu.log" 2>&1
+  #  the busy side of the same kernel: active VALU, waits, thread-cycles — a second pass (eight SQ counters a pass)
+  bash tools/gpu_pmc2.sh "csv_parse_regular" $TAG/pmc_csv_busy csv 1 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" > "$OUT/pmc_csv_busy.log" 2>&1
   python tools/pmc_traffic.py "$OUT" && cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
 }
 case $MODE in

@@ -41,6 +41,11 @@
 #else
 #define CSV_ABL(x) 0
 #endif
+#if defined(TF_CSV_ABLATE_BUILD) || defined(TF_CSV_ABL_CELL_KEEP)
+#define CSV_ABL_CELL(x) ((x).ablate)
+#else
+#define CSV_ABL_CELL(x) 0
+#endif
 namespace tf {
 
 std::unique_ptr<tfgpu_dbatch> compact_rows(const tfgpu_dbatch &in, Buf keep);  // tf_transform.hip
@@ -1331,7 +1336,7 @@ __device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint
 template <int KIND, int W, class T> __device__ __forceinline__ void reg_int_body(const RegTile &t, const RegCell &c, T *const out) {
   constexpr uint32_t FASTD = W < 4 ? 5u : 8u;  // digits the first tier takes (more cannot fit / need a second window)
   const uint32_t n = c.fend - c.fs;
-  if (CSV_ABL(t) != 31 && wave_all(n - 1u < 4u || !c.on)) {
+  if (CSV_ABL_CELL(t) != 31 && wave_all(n - 1u < 4u || !c.on)) {
     // tier A: one to four characters, an unsigned canonical decimal — the common cell of a flag / small-integer column.  One
     // aligned LDS word pair holds the field's bytes [fend - 4, fend); masks come from shifts (an LDS table read costs the CU
     // as much as six VALU instructions), the leading-zero rule from the first character in byte 0.

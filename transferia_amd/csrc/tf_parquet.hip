@@ -36,6 +36,10 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <atomic>
+#include <thread>
+#include <unordered_map>
+#include <cstdio>
 
 #include "tf_common.hpp"
 #include "tf_segcopy.hpp"
@@ -453,20 +457,30 @@ static bool lz4_raw_inflate_prefix(const uint8_t *p, const uint8_t *e, uint8_t *
   }
   return o >= want;
 }
-// bytes without a constructor run over them: the arena of a 556 MB object is not zero-filled page by page before it is overwritten
+// The arena: bytes without a constructor run over them (a 556 MB object is not zero-filled page by page before it is overwritten), in PINNED host
+// memory (its upload is one DMA at the link's rate, not a staged copy out of pageable memory), and KEPT by the calling thread between calls — a
+// fresh half-gigabyte allocation is a hundred thousand page faults, more host time than the inflating itself once that runs on every core.
 struct RawVec {
   uint8_t *p = nullptr; size_t n = 0, cap = 0;
   RawVec() = default;
   RawVec(const RawVec &) = delete;
   RawVec &operator=(const RawVec &) = delete;
-  ~RawVec() { std::free(p); }
+  ~RawVec() { if (p) (void)hipHostFree(p); }
   uint8_t *data() { return p; }
   const uint8_t *data() const { return p; }
   size_t size() const { return n; }
-  void reserve(size_t c) { if (c <= cap) return; uint8_t *q = (uint8_t *)std::realloc(p, c); if (!q) throw std::bad_alloc(); p = q; cap = c; }
+  void reserve(size_t c) {
+    if (c <= cap) return;
+    void *q = nullptr;
+    if (hipHostMalloc(&q, c, hipHostMallocPortable) != hipSuccess || !q) throw std::bad_alloc();
+    if (n) std::memcpy(q, p, n);
+    if (p) (void)hipHostFree(p);
+    p = (uint8_t *)q; cap = c;
+  }
   void resize(size_t m) { if (m > cap) reserve(std::max(m, cap + cap / 2 + 4096)); n = m; }
   void append(const uint8_t *b, const uint8_t *e) { const size_t at = n; resize(n + (size_t)(e - b)); if (e > b) std::memcpy(p + at, b, (size_t)(e - b)); }
 };
+static RawVec &thread_arena() { static thread_local RawVec a; a.n = 0; return a; }
 enum { C_UNCOMPRESSED = 0, C_SNAPPY = 1, C_GZIP = 2, C_ZSTD = 6, C_LZ4_RAW = 7 };
 static bool page_inflate(int codec, const uint8_t *p, uint64_t n, uint8_t *out, uint64_t usize, std::string &why) {
   switch (codec) {
@@ -482,6 +496,18 @@ static bool page_inflate(int codec, const uint8_t *p, uint64_t n, uint8_t *out, 
 // arena is sized from it BEFORE a byte has been inflated — a few KB of headers each claiming 2 GiB must not make the host zero-fill
 // gigabytes.  Ratios of the formats: snappy copies 64 bytes per 3-byte element, LZ4 255 bytes per extra length byte, deflate 1032 : 1,
 // zstd an RLE block of 128 KiB from 4 bytes.
+// host threads for the pages the host inflates: the cores this process may use (the cgroup's CPU quota: a container on a 256-thread host is typically
+// given a handful), at most 32; TFGPU_PQ_INFLATE_THREADS overrides (1 = the walk's own thread, as before round 6)
+static size_t inflate_threads() {
+  if (const char *e = std::getenv("TFGPU_PQ_INFLATE_THREADS")) { const int v = std::atoi(e); if (v >= 1) return (size_t)std::min(v, 64); }
+  size_t n = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[32] = {0}; long period = 0;
+    if (std::fscanf(fq, "%31s %ld", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0) n = std::min<size_t>(n, (size_t)std::max(1L, std::atol(a) / period));
+    std::fclose(fq);
+  }
+  return std::min<size_t>(n, 32);
+}
 static uint64_t max_inflated(int codec, uint64_t csize) {
   switch (codec) {
     case C_UNCOMPRESSED: return csize;
@@ -713,7 +739,7 @@ __global__ void __launch_bounds__(256) pq_delta(const uint8_t *file, uint8_t *ta
 // Every length is checked against the page's own numbers (input and output ends, offsets that reach in front of the page): a page
 // that lies fails the call (PQE_INFLATE) — the kernels behind it bound-check whatever bytes they find anyway.
 struct InfPage { uint64_t src, src_end, dst; uint32_t usize, lead, codec, pad; };  // [src + lead, src_end) of the compressed object inflates to usize bytes at image[dst + lead]; the `lead` bytes (a v2 page's levels) are copied as they are
-constexpr uint32_t INF_RING = 64u * 1024u, INF_MASK = INF_RING - 1u, INF_PIECE = 16u * 1024u;
+constexpr uint32_t INF_RING_MAX = 64u * 1024u;   // the ring a workgroup asks for is a launch parameter (a power of two, 16 .. 64 KiB): the kernels are templates over it
 TF_DYNAMIC_LDS(uint4, inf_ring4);
 struct InfWindow {
   const uint8_t *base;   // 4-byte aligned address of window byte 0
@@ -748,8 +774,9 @@ struct InfWindow {
     return ((d < 64u ? a : b) >> ((p & 3u) * 8u)) & 0xFFu;
   }
 };
-template <int CODEC>
+template <int CODEC, uint32_t INF_RING>
 __device__ __forceinline__ bool inflate_page(const uint8_t *cfile, uint8_t *image, const InfPage &pg, int lane) {
+  constexpr uint32_t INF_MASK = INF_RING - 1u, INF_PIECE = INF_RING / 4u;
   uint8_t *const ring = reinterpret_cast<uint8_t *>(inf_ring4);
   const uint8_t *const in0 = cfile + pg.src + pg.lead;
   const uint64_t in_len = pg.src_end - pg.src - pg.lead;
@@ -841,8 +868,10 @@ __device__ __forceinline__ bool inflate_page(const uint8_t *cfile, uint8_t *imag
         __builtin_amdgcn_wave_barrier();
         if (i < n) ring[(o + i + phase) & INF_MASK] = v;
       } else {
-        // a source the ring no longer holds: everything that far back has left for the image (pieces of 16 KiB)
-        flush_to(((o + phase) & ~15u) > phase ? ((o + phase) & ~15u) - phase : 0u, false);
+        // a source the ring no longer holds: everything that far back has left for the image (the ring is flushed a quarter at a time, so what is
+        // more than three quarters of it behind `o` is in HBM; only a copy whose last bytes reach into the unflushed part — period-long copies
+        // over a far source do not exist, this is defensive — flushes first)
+        if (o - off + n > flushed) flush_to(((o + phase) & ~15u) > phase ? ((o + phase) & ~15u) - phase : 0u, false);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         const uint32_t i = (uint32_t)lane;
         uint8_t v = 0;
@@ -906,12 +935,13 @@ __device__ __forceinline__ bool inflate_page(const uint8_t *cfile, uint8_t *imag
   flush_to(usize, true);
   return true;
 }
+template <uint32_t RING>
 __global__ void __launch_bounds__(64) pq_inflate(const uint8_t *cfile, uint8_t *image, const InfPage *pages, int32_t npages, uint32_t *err) {
   const int lane = threadIdx.x & 63;
   const int32_t pi = (int32_t)blockIdx.x;
   if (pi >= npages) return;
   const InfPage pg = pages[pi];
-  const bool ok = pg.codec == 1u ? inflate_page<1>(cfile, image, pg, lane) : inflate_page<7>(cfile, image, pg, lane);
+  const bool ok = pg.codec == 1u ? inflate_page<1, RING>(cfile, image, pg, lane) : inflate_page<7, RING>(cfile, image, pg, lane);
   if (!ok && lane == 0) *err = PQE_INFLATE;
 }
 
@@ -1429,19 +1459,29 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   // (DELTA_BINARY_PACKED values, INT96 texts), sized by the walk.
   bool inflate = force_arena;
   for (auto &g : m.groups) for (auto &c : g.cols) if (c.codec != C_UNCOMPRESSED) inflate = true;
-  RawVec arena;
+  RawVec &arena = thread_arena();   // (empty again; its pinned block is the calling thread's from the last call)
   // Pages of the byte-oriented codecs (SNAPPY, LZ4_RAW) whose content the host's walk does not need — PLAIN values, dictionary indices,
   // RLE booleans — are inflated ON THE DEVICE (pq_inflate, one wave a page): the compressed object goes up as it is, beside this walk,
   // and the first `dev_region` bytes of the image are theirs (the arena keeps that room free and is uploaded from there on).  What the
   // walk reads at a page's front (definition levels, the index width) the host inflates as a prefix.  Dictionary pages, DELTA_* pages
   // and the other codecs (GZIP, ZSTD: entropy coders, a chain per bit) are the host's, as before.  TFGPU_PQ_DEVICE_INFLATE=0: all on the host (A/B).
-  const bool dev_inflate_on = [] { const char *e = std::getenv("TFGPU_PQ_DEVICE_INFLATE"); return !(e && e[0] == '0'); }();   // (read per call: bench.py and the tests A/B it in one process)
-  auto dev_page = [](const ColChunk &c, const PageHeader &h, int leaf_type) {
+  // Which pages: measured (profiles/r20j_pq_inflate_shapes.txt, one page a wave) the kernel copies stored LITERALS at 8-20 GB/s a page but parses a
+  // stream of short elements at ~6 M elements/s — 50 MB/s on text, and hardly more on values that "barely compress" (a 24-byte value with a repeated
+  // 4-byte length prefix is two elements) — and a wave's pages cannot be cut: the launch lasts as long as its LARGEST page (91 ms for the hits
+  // object's multi-megabyte text pages), while sixteen host cores inflate the same object's pages side by side in 46 ms.  So by default
+  // (TFGPU_PQ_DEVICE_INFLATE unset or "auto") the device takes the pages it is at least as good at — small ones (<= 128 KiB inflated: a few
+  // milliseconds each, hundreds in flight: objects of many small row groups or pages) and stored ones (compressed >= inflated: one long literal) —
+  // and the host's cores the rest; "1": every eligible page on the device; "0": none.  (Read per call: bench.py and the tests A/B it in one process.)
+  const int dev_inflate_mode = [] { const char *e = std::getenv("TFGPU_PQ_DEVICE_INFLATE"); return !e || !*e || *e == 'a' ? 2 : (*e == '0' ? 0 : 1); }();
+  const bool dev_inflate_on = dev_inflate_mode != 0;
+  auto dev_page = [dev_inflate_mode](const ColChunk &c, const PageHeader &h, int leaf_type) {
     if (c.codec != C_SNAPPY && c.codec != C_LZ4_RAW) return false;
     if (!(h.type == 0 || h.type == 3) || (h.type == 3 && !h.compressed_v2)) return false;
     const bool enc_ok = h.enc == E_PLAIN || h.enc == E_RLE_DICT || h.enc == E_PLAIN_DICT || (h.enc == E_RLE && leaf_type == T_BOOLEAN);
     const int64_t lead = h.type == 3 ? (int64_t)std::max(h.rep_len, 0) + (int64_t)std::max(h.def_len, 0) : 0;
-    return enc_ok && (int64_t)h.usize > lead && (int64_t)h.csize > lead;
+    if (!(enc_ok && (int64_t)h.usize > lead && (int64_t)h.csize > lead)) return false;
+    if (dev_inflate_mode == 2 && (int64_t)h.usize - lead > 128 * 1024 && (int64_t)h.csize < (int64_t)h.usize) return false;   // a large page of many elements: the host's cores
+    return true;
   };
   uint64_t dev_region = 0, dev_cursor = 0;
   std::vector<InfPage> infpages;
@@ -1517,6 +1557,75 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   } else for (size_t k = 0; k < fields.size(); k++) { want.push_back((int)k); outcols.push_back({fields[k].el.name, -1}); }
 
   std::vector<Buf> keep;  // tables the kernels read until the final sync
+  // ---- the pages the HOST inflates (GZIP / ZSTD everywhere; dictionary and DELTA_* pages of every codec; everything with the device codec
+  //      switched off) are inflated AHEAD of the walk, side by side on the host's cores: pages are independent, the reference's reader inflates them
+  //      one by one in its read loop (reader_parquet.go:137-283) and so did the walk below until round 6 (one thread, ~1 GB/s).  Each gets its
+  //      place in the arena here; the walk finds it by the page's file offset and reads it as if it had just inflated it. ----
+  std::unordered_map<uint64_t, size_t> preinflated;   // file offset of a page's payload → its offset in the arena
+  if (inflate) {
+    struct HostPage { const uint8_t *raw; uint64_t csize, usize, lead; int codec; size_t at0; };
+    std::vector<HostPage> hp;
+    size_t cur = arena.size();
+    bool fits = true;
+    for (size_t oc = 0; oc < want.size() && fits; oc++) {
+      if (want[oc] < 0) continue;
+      const TopField &fld = fields[(size_t)want[oc]];
+      if (fld.group || fld.el.logical == L_DECIMAL) continue;
+      for (auto &g : m.groups) {
+        const ColChunk &c = g.cols[(size_t)fld.leaf];
+        if (c.codec == C_UNCOMPRESSED || c.data_off < 0 || c.total_comp < 0) continue;
+        if (c.codec != C_SNAPPY && c.codec != C_GZIP && c.codec != C_ZSTD && c.codec != C_LZ4_RAW) continue;
+        uint64_t pos = (uint64_t)((c.dict_off > 0 && c.dict_off < c.data_off) ? c.dict_off : c.data_off);
+        const uint64_t end = pos + (uint64_t)c.total_comp;
+        if (end > len || end < pos) continue;
+        int64_t seen = 0;
+        while (pos < end && seen < c.num_values) {
+          TReader r{f + pos, f + end};
+          PageHeader h;
+          if (!parse_page_header(r, h) || h.csize < 0 || h.usize < 0 || h.nvalues < 0 || (uint64_t)h.csize > (uint64_t)(f + end - r.p)) break;
+          const uint8_t *raw = r.p;
+          if (h.type == 0 || h.type == 3) seen += h.nvalues;
+          pos = (uint64_t)(raw - f) + (uint64_t)h.csize;
+          if (!(h.type == 0 || h.type == 2 || h.type == 3)) continue;
+          const uint64_t lead = h.type == 3 ? (uint64_t)std::max(h.rep_len, 0) + (uint64_t)std::max(h.def_len, 0) : 0;
+          if (lead > (uint64_t)h.csize || lead > (uint64_t)h.usize) continue;   // (the walk reports it)
+          const int codec = (h.type == 3 && !h.compressed_v2) ? (int)C_UNCOMPRESSED : c.codec;
+          if (dev_region && dev_page(c, h, fld.el.type)) continue;               // the device's
+          if ((uint64_t)h.usize - lead > max_inflated(codec, (uint64_t)h.csize - lead)) continue;
+          const size_t at0 = (cur + 15) & ~(size_t)15;
+          if ((uint64_t)at0 + (uint64_t)h.usize + 64 >= 0xFFFFFFF0ull) { fits = false; break; }
+          hp.push_back(HostPage{raw, (uint64_t)h.csize, (uint64_t)h.usize, lead, codec, at0});
+          cur = at0 + (size_t)h.usize;
+        }
+        if (!fits) break;
+      }
+    }
+    if (fits && !hp.empty()) {
+      arena.resize(cur);
+      uint8_t *const base = arena.data();
+      std::atomic<size_t> next{0};
+      std::atomic<int> failed{-1};
+      std::vector<std::string> whys(hp.size());
+      auto work = [&]() {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= hp.size()) return;
+          const HostPage &q = hp[i];
+          std::memcpy(base + q.at0, q.raw, (size_t)q.lead);
+          if (!page_inflate(q.codec, q.raw + q.lead, q.csize - q.lead, base + q.at0 + q.lead, q.usize - q.lead, whys[i])) { int none = -1; failed.compare_exchange_strong(none, (int)i); }
+        }
+      };
+      const unsigned nthreads = (unsigned)std::min<size_t>(hp.size(), inflate_threads());
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(work);
+      work();
+      for (auto &t : pool) t.join();
+      if (failed.load() >= 0) {   // (the walk meets the page again and reports it with its column's name: it inflates it inline)
+        arena.resize((size_t)dev_region);
+      } else for (auto &q : hp) preinflated[(uint64_t)(q.raw - f)] = q.at0;
+      clk.at("host pages inflated");
+    }
+  }
   // ---- pass 1 (host): every column's segment tables ----
   struct ColPlan {
     DColumn d; bool nil = false, optional = false, is_text = false, is_int96 = false; uint32_t width = 0; int32_t conv = CV_SAME, out_width = 0;
@@ -1635,6 +1744,9 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
             if (want && !prefix(want)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": malformed " + (codec == C_SNAPPY ? "SNAPPY" : "LZ4_RAW") + " page");
             infpages.push_back(InfPage{(uint64_t)(raw - f), (uint64_t)(raw - f) + (uint64_t)h.csize, (uint64_t)at0, (uint32_t)body, (uint32_t)lead, (uint32_t)codec, 0u});
             fb = arena.data(); pl = fb + at0; pe = pl + h.usize;
+          } else if (auto pre = preinflated.find((uint64_t)(raw - f)); pre != preinflated.end()) {
+            page_at0 = pre->second;   // inflated ahead of the walk, beside the other host pages
+            fb = arena.data(); pl = fb + page_at0; pe = pl + h.usize;
           } else {
           const size_t at0 = page_at0 = (arena.size() + 15) & ~(size_t)15;
           if ((uint64_t)at0 + (uint64_t)h.usize + 64 >= 0xFFFFFFF0ull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: the inflated pages of one object exceed 4 GiB: read it row group by row group");
@@ -1789,10 +1901,14 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
     Buf bip = upload_small(infpages.data(), infpages.size() * sizeof(InfPage));
     keep.push_back(bip); keep.push_back(cfile);
     up.wait(0);   // the compressed object is in HBM
-    static const bool attr = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&pq_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)INF_RING); return true; }();
-    (void)attr;
+    // the ring: 64 KiB holds every source a snappy / LZ4 copy can name with a 16-bit offset (two waves a CU); a smaller ring lets more pages run side
+    // by side and sends the copies that reach further back to the image (TFGPU_PQ_RING_KB = 16 | 32 | 64, measurement: DESIGN 10)
+    const int ring_kb = [] { const char *e = std::getenv("TFGPU_PQ_RING_KB"); const int v = e ? std::atoi(e) : 64; return v == 16 || v == 32 ? v : 64; }();
     KernelTimer t("pq_inflate");
-    pq_inflate<<<(unsigned)infpages.size(), 64, INF_RING, st>>>(ptr<uint8_t>(cfile), ptr<uint8_t>(file), reinterpret_cast<const InfPage *>(bip->p), (int32_t)infpages.size(), ptr<uint32_t>(derr));
+    const InfPage *dp = reinterpret_cast<const InfPage *>(bip->p);
+    if (ring_kb == 16) pq_inflate<16384u><<<(unsigned)infpages.size(), 64, 16384, st>>>(ptr<uint8_t>(cfile), ptr<uint8_t>(file), dp, (int32_t)infpages.size(), ptr<uint32_t>(derr));
+    else if (ring_kb == 32) pq_inflate<32768u><<<(unsigned)infpages.size(), 64, 32768, st>>>(ptr<uint8_t>(cfile), ptr<uint8_t>(file), dp, (int32_t)infpages.size(), ptr<uint32_t>(derr));
+    else pq_inflate<65536u><<<(unsigned)infpages.size(), 64, 65536, st>>>(ptr<uint8_t>(cfile), ptr<uint8_t>(file), dp, (int32_t)infpages.size(), ptr<uint32_t>(derr));
   }
   // ---- (offset, length) of every PLAIN / DELTA_LENGTH byte-array value: the length-prefix walks of the PLAIN pages in one launch (the
   //      pages are independent; a page is a serial chain), the DELTA pages by prefix sums ----
