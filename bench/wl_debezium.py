@@ -33,7 +33,7 @@ def _replicas_diff(abi, batch, k0):
                 return "column %s: value of row %d" % (c.name, int(np.flatnonzero(x != x[0])[0]))
             if c.nanos is not None and not (np.asarray(c.nanos) == c.nanos[0]).all():
                 return "column %s: nanoseconds" % c.name
-    for name in ("kind", "part_id"):
+    for name in ("kind",):   # (src_row / part_id follow the message's index)
         arr = getattr(batch, name, None)
         if arr is not None and not (np.asarray(arr) == arr[0]).all():
             return name

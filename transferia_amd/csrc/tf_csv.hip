@@ -34,17 +34,12 @@
 #include "tf_plan.hpp"
 
 // TFGPU_CSV_ABLATE=n (leave a kernel after phase n; results are NOT valid) is a profiling build only: the product's kernels carry none of
-// its branches (`if (t.ablate == 31)` sat in every integer cell of the one kernel that is instruction-bound).
+// its branches (`if (CSV_ABL(t) == 31)` sat in every integer cell of the one kernel that is instruction-bound).
 // tools/build_variant.sh ablate tf_csv.hip -DTF_CSV_ABLATE_BUILD=1 builds the variant tools/ablate_csv.py and gpu_visit.sh ablate load.
 #ifdef TF_CSV_ABLATE_BUILD
 #define CSV_ABL(x) ((x).ablate)
 #else
 #define CSV_ABL(x) 0
-#endif
-#if defined(TF_CSV_ABLATE_BUILD) || defined(TF_CSV_ABL_CELL_KEEP)
-#define CSV_ABL_CELL(x) ((x).ablate)
-#else
-#define CSV_ABL_CELL(x) 0
 #endif
 namespace tf {
 
@@ -837,7 +832,7 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
   const bool cols_in_lds = p.ncols <= CT_LCOLS;
   if (cols_in_lds) for (int i = tid; i < p.ncols * 3; i += CT_THREADS) tcol_lds[i] = reinterpret_cast<const uint64_t *>(p.tcols)[i];
   __syncthreads();
-  if (p.ablate == 1) return;
+  if (CSV_ABL(p) == 1) return;
 
   // ---- classify: thread t walks bytes [96t, 96t+96) under both entry states ----
   const int base_chunk = tid * CT_CPT;
@@ -900,7 +895,7 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
       if (nl && cpos < CT_SPILL) last_lb_nl = cpos + 31 - __clz((int)nl);
     }
   }
-  if (p.ablate == 2) { if (st == 77u + fe01[0] + nlm[1]) p.err[0] = 1; return; }
+  if (CSV_ABL(p) == 2) { if (st == 77u + fe01[0] + nlm[1]) p.err[0] = 1; return; }
   // ---- block scan of the quote functions + max of the look-behind '\n' ----
   uint32_t inc = st;
 #pragma unroll
@@ -1023,7 +1018,7 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
     for (uint32_t i = tid; i < nr; i += CT_THREADS) slowf[i] = 0;
     __syncthreads();
     }
-    if (p.ablate == 3) { if (fpos[tid] == 0xFFFF && rowend[0] == 0xFFFF) p.err[0] = 1; return; }
+    if (CSV_ABL(p) == 3) { if (fpos[tid] == 0xFFFF && rowend[0] == 0xFFFF) p.err[0] = 1; return; }
 
     uint32_t next_bstart;
     if (skip_first) {
@@ -1085,7 +1080,7 @@ __device__ __forceinline__ void parse_tile_general(const CsvParams &p, const int
         const uint32_t fend = fpos[kr] & 0x7FFFu;
         if (nf == 1) fs = row_start + 1;  // no delimiter in the line: line[lastDelimPosition+1:] drops byte 0 (reader.go:263)
         const uint32_t n = fend - fs;
-        if (p.ablate == 6) { if (n == 0x7FFF) p.err[0] = 1; continue; }
+        if (CSV_ABL(p) == 6) { if (n == 0x7FFF) p.err[0] = 1; continue; }
         bool done = false;
         if (n == 0) {
           if (tc.kind == CK_STR) { ((uint32_t *)tc.p0)[r] = 0; ((uint32_t *)tc.p1)[r] = (uint32_t)(g0 + fs); done = true; }
@@ -1336,7 +1331,7 @@ __device__ __forceinline__ uint32_t quotes_in(const RegTile &t, uint32_t a, uint
 template <int KIND, int W, class T> __device__ __forceinline__ void reg_int_body(const RegTile &t, const RegCell &c, T *const out) {
   constexpr uint32_t FASTD = W < 4 ? 5u : 8u;  // digits the first tier takes (more cannot fit / need a second window)
   const uint32_t n = c.fend - c.fs;
-  if (CSV_ABL_CELL(t) != 31 && wave_all(n - 1u < 4u || !c.on)) {
+  if (CSV_ABL(t) != 31 && wave_all(n - 1u < 4u || !c.on)) {
     // tier A: one to four characters, an unsigned canonical decimal — the common cell of a flag / small-integer column.  One
     // aligned LDS word pair holds the field's bytes [fend - 4, fend); masks come from shifts (an LDS table read costs the CU
     // as much as six VALU instructions), the leading-zero rule from the first character in byte 0.
@@ -1358,7 +1353,7 @@ template <int KIND, int W, class T> __device__ __forceinline__ void reg_int_body
   bool bad;
   // first tier: no sign, no leading zero (a lone "0" is fine; a first byte above '9' fails the digit check), 1..FASTD digits
   const bool fast = (c0 >= '1' || n == 1u) && n - 1u < FASTD;
-  if (t.ablate == 31) { if (c.on && fast && wlo == 0x12345678u && whi == 77u) out[c.r] = 0; return; }  // (profiling: the slot's skeleton and reads only)
+  if (CSV_ABL(t) == 31) { if (c.on && fast && wlo == 0x12345678u && whi == 77u) out[c.r] = 0; return; }  // (profiling: the slot's skeleton and reads only)
   if (wave_all(fast || !c.on)) {
     const uint2 keep = t.keeptab[c.on ? n : 0u];  // the top n bytes of the window
     const uint32_t tlo = (wlo ^ 0x30303030u) & keep.x, thi = (whi ^ 0x30303030u) & keep.y;
@@ -1654,7 +1649,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
   for (int i = tid; i < (CR_FCAP + 32) / 32; i += CT_THREADS) nlbits[i] = 0;
   __syncthreads();
   phase(0);
-  if (p.ablate == 1) return;  // (TFGPU_CSV_ABLATE, profiling only: leave after phase n; results are not valid)
+  if (CSV_ABL(p) == 1) return;  // (TFGPU_CSV_ABLATE, profiling only: leave after phase n; results are not valid)
 
   // ---- pass 1: per-byte classes of this thread's 64 bytes, as 16-bit masks per 16-byte chunk ----
   const int base_chunk = tid * CT_CPT;
@@ -1702,7 +1697,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
   if (__any(bad != 0) && lane == 0) misc[1] = 1u;
   __syncthreads();
   phase(1);
-  if (p.ablate == 2) { if (par_in == 77u + qm[0] + dm[1] + nl[2] + qm[3] + dm[0] + nl[0]) p.err[0] = 1; return; }
+  if (CSV_ABL(p) == 2) { if (par_in == 77u + qm[0] + dm[1] + nl[2] + qm[3] + dm[0] + nl[0]) p.err[0] = 1; return; }
 
   // ---- pass 2: field ends = delimiters outside quotes, and every '\n' ----
   uint32_t s_in = par_in;
@@ -1747,7 +1742,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
     if (quit) return;
   } else if (misc[1] || nfe > (uint32_t)CR_FCAP || nr != nlines) { give_up(); return; }  // uniform: LDS flags were written before the barrier
   const uint32_t frs = misc[0];
-  if (p.ablate == 3) { if (fe[0] + fe[1] + fe[2] + fe[3] == 0xFFFFFFFFu) p.err[0] = 1; return; }
+  if (CSV_ABL(p) == 3) { if (fe[0] + fe[1] + fe[2] + fe[3] == 0xFFFFFFFFu) p.err[0] = 1; return; }
 
   // ---- index: one sweep over this thread's field ends, two chunks (32 bytes) per loop ----
   {
@@ -1789,7 +1784,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
   }
   __syncthreads();
   phase(3);
-  if (p.ablate == 4) return;
+  if (CSV_ABL(p) == 4) return;
   if (spec) {
     line0 = spec_sh[1]; line1 = line0 + nr;
     if (line1 > p.cap_lines) { if (tid == 0) p.spec[1] = 1u; return; }  // more lines than the buffers were sized for: the host parses the chunk again
@@ -1808,13 +1803,13 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
     RegTile t;
     t.sb = sb; t.fposx = fposx; t.qmask = qmask; t.qpre = qpre; t.keeptab = keeptab; t.slowf = slowf; t.colp0 = colp0; t.colp1 = colp1; t.colfield = colfield;
     t.nr = nr; t.NF = NF; t.step_q = 64u * CT_WAVES / nr; t.step_r = 64u * CT_WAVES - t.step_q * nr; t.inv_nr = __uint_as_float(__float_as_uint(1.0f / (float)nr) - 2u);  // a hair below 1 / nr: the quotient estimate never overshoots
-    t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0; t.ablate = p.ablate; t.col_mode = p.col_lanes;
+    t.row0 = (int32_t)((int64_t)line0 - p.skip_rows); t.g0 = (uint32_t)g0; t.quote = o.quote; t.double_quote = o.double_quote != 0; t.ablate = CSV_ABL(p); t.col_mode = p.col_lanes;
     if constexpr (COLS) {
       for (int ti = p.wave_task[wv]; ti < p.wave_task[wv + 1]; ti++) {
         const CsvTask k = p.tasks[ti];
         if (CSV_ABL(p) >= 10) {  // 10: no cells; 11: integer tasks only; 12: text; 13: date / timestamp
           const int grp = (k.kind == CK_INT || k.kind == CK_UINT) ? 11 : k.kind == CK_STR ? 12 : 13;
-          if (CSV_ABL(p) != grp && !(p.ablate == 31 && grp == 11)) continue;
+          if (CSV_ABL(p) != grp && !(CSV_ABL(p) == 31 && grp == 11)) continue;
         }
         switch (k.kind) {
           case CK_INT:
@@ -1838,7 +1833,7 @@ template <bool COLS> __device__ __forceinline__ void csv_parse_regular_body(cons
       const uint32_t items = (uint32_t)run.ncols * nr, nslots = (items + 63) >> 6;
       if (CSV_ABL(p) >= 10) {  // 10: no cells; 11: integer runs only; 12: text runs only; 13: date / timestamp runs only
         const int grp = (run.kind == CK_INT || run.kind == CK_UINT) ? 11 : run.kind == CK_STR ? 12 : 13;
-        if (CSV_ABL(p) != grp && !(p.ablate == 31 && grp == 11)) { sbase += nslots; continue; }
+        if (CSV_ABL(p) != grp && !(CSV_ABL(p) == 31 && grp == 11)) { sbase += nslots; continue; }
       }
       switch (run.kind) {
         case CK_INT:
