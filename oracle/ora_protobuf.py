@@ -164,11 +164,16 @@ class _P:
         label = ""
         if self.peek()[1] in ("optional", "required", "repeated"):
             label = self.next()[1]
-        if self.peek()[1] == "map":
-            raise HostOnly("map field")
         if self.peek()[1] == "group":
             raise HostOnly("group")
-        typ = self.ident()
+        map_key = None
+        if self.peek()[1] == "map" and self.i + 1 < len(self.t) and self.t[self.i + 1][1] == "<":   # map<K, V> name = N;
+            if label:
+                raise ProtoError("a map field takes no label")
+            self.next(); self.expect("<")
+            map_key = self.ident(); self.expect(","); typ = self.ident(); self.expect(">")
+        else:
+            typ = self.ident()
         name = self.ident()
         self.expect("=")
         k, num = self.next()
@@ -190,7 +195,7 @@ class _P:
                     if depth == 0:
                         break
         self.expect(";")
-        return {"name": name, "number": int(num, 0), "label": label, "type": typ, "default": has_default}
+        return {"name": name, "number": int(num, 0), "label": label, "type": typ, "default": has_default, "map_key": map_key}
 
 
 def _all_messages(msgs):
@@ -259,7 +264,7 @@ def compile_schema(text: str, policy: str = "debezium_style", manual_table_name:
             return list(BUILTIN[ref])
         out, seen2 = [], set()
         for f in ref.fields:
-            if f["label"] == "repeated" or f["default"] or f["label"] == "required" or (p.syntax != "proto3"):
+            if f["label"] == "repeated" or f.get("map_key") or f["default"] or f["label"] == "required" or (p.syntax != "proto3"):
                 raise HostOnly("a nested message the device does not walk")
             if f["number"] in seen2 or f["number"] <= 0 or f["number"] > 536870911:
                 raise ProtoError("field number")
@@ -284,16 +289,30 @@ def compile_schema(text: str, policy: str = "debezium_style", manual_table_name:
             raise ProtoError("field number")
         seen.add(f["number"])
         rep = f["label"] == "repeated"   # handleField: a repeated field is an `any` column
+        if f.get("map_key"):
+            # map<string, V>: the dynamic message holds a Go map; unpackRepeatedVal (types_protobuf.go:57-71) takes string keys only ("these types are not
+            # supported yet as a map key" otherwise) and runs every value through unpackNotRepeatedVal(v, TYPE_MESSAGE)'s default branch: json.Marshal +
+            # a UseNumber decode — the `any` text is json.Marshal of map[string]interface{}: keys in byte order.  Values: scalars / enums (a message value
+            # is one more level of nesting: stock path).
+            if f["map_key"] != "string":
+                raise HostOnly("map with a key type other than string")
+            if f["type"] in SCALARS:
+                vt = f["type"]
+            else:
+                k2, _r2 = _resolve(p, md.full, f["type"])
+                if k2 != "enum":
+                    raise HostOnly("map with message values")
+                vt = "enum"
+            fields.append((f["name"], f["number"], "map", "any", [("key", 1, "string"), ("value", 2, vt)], True))
+            continue
         if f["type"] in SCALARS:
             fields.append((f["name"], f["number"], f["type"], "any" if rep else SCALARS[f["type"]], None, rep))
             continue
         kind, ref = _resolve(p, md.full, f["type"])
         if kind == "enum":
             fields.append((f["name"], f["number"], "enum", "any" if rep else "utf8", None, rep))
-        elif rep:
-            raise HostOnly("repeated message field")
-        else:
-            fields.append((f["name"], f["number"], "message", "any", members_of(kind, ref, 1), False))
+        else:   # (repeated: the array of the elements' maps)
+            fields.append((f["name"], f["number"], "message", "any", members_of(kind, ref, 1), rep))
     if len({f[0] for f in fields}) != len(fields):
         raise ProtoError("a field name repeats")
     return {"record": record, "ns": ns, "table": table, "fields": fields}
@@ -355,6 +374,9 @@ _ZERO = {"int32": ("int32", 0), "enum": ("int32", 0), "int64": ("int64", 0), "ui
          "double": ("float64", 0.0), "string": ("string", b""), "bytes": ("bytes", b"")}
 
 
+MAP_MAX_ENTRIES = 32   # (the device's bound: tf_protobuf.hip)
+
+
 def _want_wt(ptype):
     return 0 if ptype in VARINT else 1 if ptype in FIX64 else 5 if ptype in FIX32 else 2
 
@@ -391,7 +413,14 @@ def decode_fields(b: bytes, fields):
             continue
         if len(f) > 5 and f[5]:   # repeated: every occurrence in wire order; numeric kinds also packed (length-delimited runs)
             elems = reps.setdefault(num, [])
-            if wt == _want_wt(f[2]):
+            if f[2] in ("message", "map"):
+                if wt != 2:
+                    raise HostOnly("wire type of a known field")
+                decode_fields(raw, [(n, k, t) for n, k, t in f[4]])   # the element / entry message unmarshals eagerly
+                elems.append(raw)
+                if f[2] == "map" and len(elems) > MAP_MAX_ENTRIES:
+                    raise HostOnly("a map field of more entries than the device orders")
+            elif wt == _want_wt(f[2]):
                 elems.append(raw)
             elif wt == 2 and _want_wt(f[2]) != 2:
                 j = 0
@@ -446,6 +475,29 @@ def unpack(schema, payload: bytes):
     vals = []
     for name, num, ptype, _yt, members, rep in schema["fields"]:
         raw = top.get(num)
+        if rep and ptype == "map":   # unpackRepeatedVal over map[interface{}]interface{}: map[string]interface{}; json.Marshal sorts the keys, a later entry of a key replaces the earlier
+            entries = {}
+            for r2 in top.get(("rep", num), []):
+                inner = decode_fields(r2, [(n, k, t) for n, k, t in members])
+                kraw, vraw = inner.get(1), inner.get(2)
+                vt = members[1][2]
+                v = _ZERO[vt] if vraw is None else ((("string", bytes(vraw)) if vt == "string" else ("bytes", bytes(vraw))) if vt in ("string", "bytes") else _scalar(vt, 0, vraw))
+                entries[bytes(kraw) if kraw is not None else b""] = _go_json(v)
+            from .dbz_emitter import go_json_string
+            vals.append(("json", b"{" + b",".join(go_json_string(k) + b":" + entries[k] for k in sorted(entries)) + b"}"))
+            continue
+        if rep and ptype == "message":   # unpackRepeatedVal over []interface{} of *dynamic.Message: the array of their maps
+            parts = []
+            for r2 in top.get(("rep", num), []):
+                inner = decode_fields(r2, [(n, k, t) for n, k, t in members])
+                mp = []
+                for mn, mk, mt in sorted(members):
+                    r3 = inner.get(mk)
+                    v = _ZERO[mt] if r3 is None else ((("string", bytes(r3)) if mt == "string" else ("bytes", bytes(r3))) if mt in ("string", "bytes") else _scalar(mt, 0, r3))
+                    mp.append(_json_key(mn) + b":" + _go_json(v))
+                parts.append(b"{" + b",".join(mp) + b"}")
+            vals.append(("json", b"[" + b",".join(parts) + b"]"))
+            continue
         if rep:   # unpackRepeatedVal: []interface{} of the elements' Go values; an absent field is the empty slice
             parts = []
             for r2 in top.get(("rep", num), []):

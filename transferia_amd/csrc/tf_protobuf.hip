@@ -50,6 +50,7 @@ struct Params {
   uint32_t *row_msg; int64_t nrows;
 };
 
+constexpr uint32_t MAP_MAX_ENTRIES = 32;   // a map field with more entries than this is the stock code's (TFGPU_ROW_HOST_FALLBACK): the emitter below is quadratic in them
 __device__ __forceinline__ int want_wt(int t) {
   switch (t) {
     case TFGPU_PB_DOUBLE: case TFGPU_PB_FIXED64: case TFGPU_PB_SFIXED64: return 1;
@@ -122,6 +123,19 @@ __global__ void __launch_bounds__(128) pb_decode(Params p) {
       const int64_t i = (int64_t)f * p.nmsg + m;
       if (fd.repeated) {  // every occurrence is an element; numeric kinds also arrive packed: a length-delimited run of them
         const int ew = want_wt(fd.ptype);
+        if (fd.ptype == TFGPU_PB_MESSAGE) {
+          // a repeated message field's element, or a map field's entry {key = 1, value = 2}: a nested message that unmarshals eagerly — its known members
+          // with their wire types (anything else: the stock code), a map's entries counted (the device orders them by key with a scan a key: small maps)
+          if (wt != 2) return 2;
+          const int r2 = walk(d, (uint32_t)raw, (uint32_t)raw + len, [&](uint32_t n2, uint32_t w2, uint64_t, uint32_t) {
+            for (int k = 0; k < fd.nmem; k++) if ((uint32_t)p.members[fd.mem_off + k].number == n2 && (int)w2 != want_wt(p.members[fd.mem_off + k].ptype)) return 2;
+            return 0;
+          });
+          if (r2) return r2;
+          if (fd.repeated == 2) { const uint64_t seen = p.present[i] ? p.rec[i] + 1 : 1; p.rec[i] = seen; if (seen > MAP_MAX_ENTRIES) return 2; }
+          p.present[i] = 1;
+          return 0;
+        }
         if ((int)wt != ew) {
           if (wt != 2) return 2;
           uint32_t q = (uint32_t)raw; const uint32_t qe = q + len;
@@ -228,6 +242,12 @@ template <class S> __device__ bool emit_array(S &s, const Params &p, const DFiel
   s.put('[');
   walk(rd, a, z, [&](uint32_t num, uint32_t wt, uint64_t raw, uint32_t len) {
     if (num != (uint32_t)fd.number) return 0;
+    if (fd.ptype == TFGPU_PB_MESSAGE) {  // an element message: its map, as a singular message field's (unpackRepeatedVal → unpackNotRepeatedVal over *dynamic.Message)
+      if (!first) s.put(',');
+      first = false;
+      if (!emit_message(s, p, fd, (uint32_t)raw, len)) ok = false;
+      return 0;
+    }
     auto one = [&](uint64_t r) { if (!first) s.put(','); first = false; if (!emit_member(s, d, fd.ptype, true, r)) ok = false; };
     if ((int)wt == ew) one(wt == 2 ? (raw | ((uint64_t)len << 32)) : raw);
     else {  // packed (pb_decode let nothing else through)
@@ -242,6 +262,49 @@ template <class S> __device__ bool emit_array(S &s, const Params &p, const DFiel
     return 0;
   });
   s.put(']');
+  return ok;
+}
+
+// a map<string, V> field's map[string]interface{} (types_protobuf.go:57-71) as json.Marshal writes it: keys in byte order, the LAST entry of a key
+// (protobuf's map semantics), an entry without a key / value member under "" / the zero value.  No scratch list of the entries: the smallest key
+// above the one just written is found by one scan of the field's occurrences a key (<= MAP_MAX_ENTRIES entries: pb_decode counted them).
+struct MapKey { uint32_t at, len; };
+__device__ __forceinline__ int key_cmp(const uint8_t *d, MapKey a, MapKey b) {
+  const uint32_t n = min(a.len, b.len);
+  for (uint32_t i = 0; i < n; i++) { const int x = (int)d[a.at + i] - (int)d[b.at + i]; if (x) return x; }
+  return (a.len > b.len) - (a.len < b.len);
+}
+template <class S> __device__ bool emit_map(S &s, const Params &p, const DField &fd, uint32_t a, uint32_t z) {
+  const uint8_t *d = p.data;
+  MemBytes rd(p.data);
+  const int vt = p.members[fd.mem_off + 1].ptype;
+  bool ok = true, have_prev = false, first = true;
+  MapKey prev{0, 0};
+  s.put('{');
+  for (uint32_t round = 0; round <= MAP_MAX_ENTRIES; round++) {
+    bool found = false; MapKey best{0, 0}; bool vpresent = false; uint64_t vraw = 0;
+    walk(rd, a, z, [&](uint32_t num, uint32_t wt, uint64_t raw, uint32_t len) {
+      if (num != (uint32_t)fd.number || wt != 2) return 0;
+      MapKey k{0, 0}; bool vp = false; uint64_t vr = 0;
+      walk(rd, (uint32_t)raw, (uint32_t)raw + len, [&](uint32_t n2, uint32_t w2, uint64_t r2, uint32_t l2) {
+        if (n2 == 1 && w2 == 2) k = MapKey{(uint32_t)r2, l2};
+        else if (n2 == 2) { vp = true; vr = w2 == 2 ? (r2 | ((uint64_t)l2 << 32)) : r2; }
+        return 0;
+      });
+      if (have_prev && key_cmp(d, k, prev) <= 0) return 0;          // written already (or a duplicate of one that was)
+      const int c = found ? key_cmp(d, k, best) : -1;
+      if (c <= 0) { found = true; best = k; vpresent = vp; vraw = vr; }  // a smaller key, or a LATER entry of the same one: the last one wins
+      return 0;
+    });
+    if (!found) break;
+    if (!first) s.put(',');
+    first = false;
+    emit_json_string(s, d + best.at, best.len, false);
+    s.put(':');
+    if (!emit_member(s, d, vt, vpresent, vraw)) ok = false;
+    prev = best; have_prev = true;
+  }
+  s.put('}');
   return ok;
 }
 
@@ -264,7 +327,7 @@ template <bool ANY> __global__ void __launch_bounds__(256) pb_cells(Params p, co
     if constexpr (ANY) {
       if (fd.repeated) {  // an absent repeated field is the empty slice: []
         CountSink s;
-        if (!emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1])) { host_rows[r] = 1; s.n = 0; }
+        if (!(fd.repeated == 2 ? emit_map(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]) : emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]))) { host_rows[r] = 1; s.n = 0; }   // (an absent map field is the empty map: {})
         c.lens[r] = s.n;
       } else if (!present) { c.lens[r] = 0; valid = false; }   // a nil *dynamic.Message: nil
       else {
@@ -308,7 +371,8 @@ __global__ void __launch_bounds__(256) pb_text_any(Params p, const OutCol *cols,
   const int64_t i = (int64_t)j * p.nmsg + m;
   if (c.lens[r + 1] == c.lens[r]) return;  // nil, or a row for the host: nothing was counted
   WriteSink s{c.data + c.lens[r]};
-  if (fd.repeated) emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
+  if (fd.repeated == 2) emit_map(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
+  else if (fd.repeated) emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
   else { const uint64_t raw = p.rec[i]; emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32)); }
   s.flush();
 }

@@ -8,8 +8,8 @@
 // The compiler itself (jhump/protoreflect protoparse) is a dependency of the reference, not part of it.  Restated here: the proto3
 // language subset whose messages the device takes — singular and repeated scalar / enum fields, and singular message fields whose own
 // fields are singular scalars / enums (the shape of both PROTOBUF schemas in the reference's parser test) — with protobuf's scoping rule for type
-// names.  Everything else is named and handed to the stock code (TFGPU_ROW_HOST_FALLBACK for every message of the schema): repeated
-// and map fields, oneof, proto2 (required / default / groups / extensions), services, imports other than confluent/meta.proto and
+// names; since round 6 also REPEATED one-level message fields and map<string, V> fields (V scalar / enum).  Everything else is named and handed
+// to the stock code (TFGPU_ROW_HOST_FALLBACK for every message of the schema): maps keyed by anything but a string or holding messages, oneof, proto2 (required / default / groups / extensions), services, imports other than confluent/meta.proto and
 // confluent/type/decimal.proto (whose Decimal message is built in).  A text that does not parse is TFGPU_ROW_SR_PROTO ("unable to
 // build MessageDescriptor": every message of the schema becomes `_unparsed`).
 #include <algorithm>
@@ -71,7 +71,7 @@ static std::vector<Tok> tokens(const std::string &t) {
   return out;
 }
 
-struct FieldDecl { std::string name, type, label; long long number = 0; bool has_default = false; };
+struct FieldDecl { std::string name, type, label, map_key; long long number = 0; bool has_default = false, is_map = false; };
 struct Msg { std::string name, full; std::vector<FieldDecl> fields; std::vector<std::unique_ptr<Msg>> messages; std::vector<std::string> enums; };
 
 struct Parser {
@@ -81,6 +81,7 @@ struct Parser {
   std::vector<std::unique_ptr<Msg>> messages;
   const Tok &peek() const { static const Tok eof{0, ""}; return i < t.size() ? t[i] : eof; }
   Tok next() { Tok k = peek(); i++; return k; }
+  Tok peek2() const { return i + 1 < t.size() ? t[i + 1] : Tok{0, ""}; }
   bool is_sym(const Tok &k, const char *s) const { return k.kind == 4 && k.s == s; }
   void expect(const char *s) { const Tok k = next(); if (k.s != s) throw SyntaxError{std::string("expected ") + s + ", got " + k.s}; }
   std::string ident() { const Tok k = next(); if (k.kind != 2) throw SyntaxError{"expected a name, got " + k.s}; return k.s; }
@@ -147,9 +148,13 @@ struct Parser {
   FieldDecl field() {
     FieldDecl f;
     if (peek().kind == 2 && (peek().s == "optional" || peek().s == "required" || peek().s == "repeated")) f.label = next().s;
-    if (peek().kind == 2 && peek().s == "map") throw HostOnly{"map field"};
     if (peek().kind == 2 && peek().s == "group") throw HostOnly{"group"};
-    f.type = ident();
+    if (peek().kind == 2 && peek().s == "map" && is_sym(peek2(), "<")) {  // map<K, V> name = N;  (language guide: no label; K an integral or string scalar, V anything but a map)
+      if (!f.label.empty()) throw SyntaxError{"a map field takes no label"};
+      next(); expect("<");
+      f.map_key = ident(); expect(","); f.type = ident(); expect(">");
+      f.is_map = true;
+    } else f.type = ident();
     f.name = ident();
     expect("=");
     const Tok num = next();
@@ -178,7 +183,7 @@ static const std::map<std::string, int> SCALAR = {
     {"sfixed64", TFGPU_PB_SFIXED64}, {"sint32", TFGPU_PB_SINT32}, {"sint64", TFGPU_PB_SINT64}};
 
 struct Member { std::string name; int32_t number, ptype; };
-struct Field { std::string name; int32_t number, ptype; std::vector<Member> members; bool repeated = false; };
+struct Field { std::string name; int32_t number, ptype; std::vector<Member> members; bool repeated = false, map = false; };
 
 static void collect(const std::vector<std::unique_ptr<Msg>> &ms, std::map<std::string, const Msg *> &msgs, std::vector<std::string> &enums) {
   for (auto &m : ms) { msgs[m->full] = m.get(); for (auto &e : m->enums) enums.push_back(e); collect(m->messages, msgs, enums); }
@@ -237,18 +242,31 @@ static Compiled compile(const std::string &text, const std::string &policy, cons
     if (f.number <= 0 || f.number > 536870911 || !seen.emplace(f.number, true).second) throw SyntaxError{"field number"};
     Field o;
     o.name = f.name; o.number = (int32_t)f.number; o.repeated = f.label == "repeated";
+    if (f.is_map) {
+      // map<string, V>: on the wire a repeated entry message {K key = 1; V value = 2;}; the dynamic message holds a Go map, unpackRepeatedVal
+      // (types_protobuf.go:57-71) takes string keys only and json.Marshal writes the map's keys in byte order — an `any` column
+      // {"k":v,…}.  Other key types are an error in the reference ("not supported yet as a map key"): stock path.  Message values: one more level: stock path.
+      if (f.map_key != "string") throw HostOnly{"map with a key type other than string"};
+      auto vs = SCALAR.find(f.type);
+      int vt;
+      if (vs != SCALAR.end()) vt = vs->second;
+      else { const Msg *r2 = nullptr; if (resolve(md->full, f.type, &r2) != 2) throw HostOnly{"map with message values"}; vt = TFGPU_PB_ENUM; }
+      o.ptype = TFGPU_PB_MESSAGE; o.map = true;
+      o.members = {{"key", 1, TFGPU_PB_STRING}, {"value", 2, vt}};
+      out.fields.push_back(std::move(o));
+      continue;
+    }
     auto sc = SCALAR.find(f.type);
     if (sc != SCALAR.end()) { o.ptype = sc->second; out.fields.push_back(std::move(o)); continue; }
     const Msg *ref = nullptr;
     const int kind = resolve(md->full, f.type, &ref);
     if (kind == 2) { o.ptype = TFGPU_PB_ENUM; out.fields.push_back(std::move(o)); continue; }
-    if (o.repeated) throw HostOnly{"repeated message field"};
-    o.ptype = TFGPU_PB_MESSAGE;
+    o.ptype = TFGPU_PB_MESSAGE;   // (a repeated message field: the array of its elements' maps, unpackRepeatedVal over *dynamic.Message elements)
     if (kind == 3) o.members = {{"value", 1, TFGPU_PB_BYTES}, {"precision", 2, TFGPU_PB_UINT32}, {"scale", 3, TFGPU_PB_INT32}};  // confluent/type/decimal.proto
     else {
       std::map<long long, bool> seen2;
       for (auto &g : ref->fields) {
-        if (g.label == "repeated" || g.has_default || g.label == "required") throw HostOnly{"a nested message the device does not walk"};
+        if (g.label == "repeated" || g.is_map || g.has_default || g.label == "required") throw HostOnly{"a nested message the device does not walk"};
         if (g.number <= 0 || g.number > 536870911 || !seen2.emplace(g.number, true).second) throw SyntaxError{"field number"};
         auto s2 = SCALAR.find(g.type);
         if (s2 != SCALAR.end()) { o.members.push_back({g.name, (int32_t)g.number, s2->second}); continue; }
@@ -282,7 +300,7 @@ struct tfgpu_pb_schema {
       for (auto &m : f.members) ms.push_back(tfgpu_pb_member{m.name.c_str(), m.number, m.ptype});
       cmembers.push_back(std::move(ms));
     }
-    for (size_t i = 0; i < c.fields.size(); i++) cfields.push_back(tfgpu_pb_field{c.fields[i].name.c_str(), c.fields[i].number, c.fields[i].ptype, (int32_t)cmembers[i].size(), cmembers[i].empty() ? nullptr : cmembers[i].data(), c.fields[i].repeated ? 1 : 0, 0});
+    for (size_t i = 0; i < c.fields.size(); i++) cfields.push_back(tfgpu_pb_field{c.fields[i].name.c_str(), c.fields[i].number, c.fields[i].ptype, (int32_t)cmembers[i].size(), cmembers[i].empty() ? nullptr : cmembers[i].data(), c.fields[i].map ? 2 : (c.fields[i].repeated ? 1 : 0), 0});
   }
 };
 
