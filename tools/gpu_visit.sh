@@ -10,6 +10,7 @@
 #   ablate   TAG ENVVAR KERNEL WORKLOAD "n1 n2 …"  KERNEL's time with ENVVAR=n (TFGPU_CSV_ABLATE / TFGPU_JT_ABLATE / TFGPU_SER_ABLATE)
 #   pmc      TAG KERNEL WORKLOAD NSETS ["C1 C2 …"]  rocprofv3 --pmc passes for one kernel (sets of tools/gpu_pmc2.sh, or one custom set)
 #   stats    TAG "w1 w2 …"                        rocprofv3 --kernel-trace --stats per workload (the timed region only, no side legs)
+#   traffic  TAG                                  the FETCH_SIZE / WRITE_SIZE / instruction-counter passes of the stamped kernels → gpurun_out/TAG/pmc_traffic.json
 #   timeline TAG WORKLOAD ANCHOR ["bench args" [pass]]  one pass of WORKLOAD as a timeline of dispatches (tools/timeline.py): offsets, durations, idle gaps
 #   evidence TAG                                  tests + smoke + HBM-traffic PMC (pmc_traffic.json) + every bench line + stats
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -92,6 +93,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']; print('$1=$a', {n:round(k[n]['avg_ms'],4) for n in k if n=='$2'})" | tee -a "$OUT/ablate_$2.txt"; done ;;
   pmc) bash tools/gpu_pmc2.sh "$1" "$TAG/pmc_$1" "${2:-csv}" "${3:-2}" "$4"; cp "$OUT/pmc_$1/summary.txt" "$OUT/pmc_$1.txt" ;;
   stats) stats "${1:-csv}" ;;
+  traffic) traffic ;;   # the PMC passes behind profiles/pmc_traffic.json alone (after a change to a stamped source file): copy gpurun_out/TAG/pmc_traffic.json to profiles/
   timeline)
     ( cd /tmp && timeout 300 rocprofv3 --kernel-trace -f csv -d "$GRAFT_REPO_ROOT/$OUT/tl_$1" -o trace -- python "$GRAFT_REPO_ROOT/bench.py" --workload $1 --steps 4 --passes 1 --warmup 2 --prof-steps 1 ${3:-$QUIET} > "$GRAFT_REPO_ROOT/$OUT/tl_$1.json" 2> "$GRAFT_REPO_ROOT/$OUT/tl_$1.err" )
     f=$(find "$OUT/tl_$1" -name '*kernel_trace.csv' | head -1)

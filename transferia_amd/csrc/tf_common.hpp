@@ -205,6 +205,7 @@ void materialize(const struct ::tfgpu_dbatch &b, const std::vector<const DColumn
 // reads them (collapse, keys_changed, view / download, the row movers): an entry that computes on values would read them as nil.
 void dense(const struct ::tfgpu_dbatch *b, bool absent_ok = false);
 void dense_locked(const struct ::tfgpu_dbatch &b);
+int lanes_created();   // lanes (stream + cache + pinned ring) this process has made so far (tf_runtime.hip)
 bool has_absent(const struct ::tfgpu_dbatch &b);
 // a fresh bitmap: (validity, or all ones when null) with the bits of `absent` cleared — an ABSENT cell reads nil (tf_runtime.hip)
 Buf validity_minus_absent(const Buf &validity, const Buf &absent, int64_t nrows);

@@ -103,7 +103,7 @@ struct TReader {
 };
 
 enum { T_BOOLEAN = 0, T_INT32 = 1, T_INT64 = 2, T_INT96 = 3, T_FLOAT = 4, T_DOUBLE = 5, T_BYTE_ARRAY = 6, T_FLBA = 7 };
-enum { E_PLAIN = 0, E_PLAIN_DICT = 2, E_RLE = 3, E_DELTA_BINARY_PACKED = 5, E_DELTA_LENGTH_BYTE_ARRAY = 6, E_DELTA_BYTE_ARRAY = 7, E_RLE_DICT = 8 };
+enum { E_PLAIN = 0, E_PLAIN_DICT = 2, E_RLE = 3, E_DELTA_BINARY_PACKED = 5, E_DELTA_LENGTH_BYTE_ARRAY = 6, E_DELTA_BYTE_ARRAY = 7, E_RLE_DICT = 8, E_BYTE_STREAM_SPLIT = 9 };
 // LogicalType's union members (parquet.thrift)
 enum { L_NONE = 0, L_STRING = 1, L_MAP = 2, L_LIST = 3, L_ENUM = 4, L_DECIMAL = 5, L_DATE = 6, L_TIME = 7, L_TIMESTAMP = 8, L_INTEGER = 10, L_UNKNOWN = 11, L_JSON = 12, L_BSON = 13, L_UUID = 14, L_FLOAT16 = 15 };
 
@@ -571,7 +571,8 @@ static bool delta_decode_host(const uint8_t *fb, const std::vector<DMini> &minis
 
 // ---- the segment table a column's rows / values look themselves up in ----------------------------------------------------
 enum : uint32_t { SG_RLE = 0, SG_PACKED = 1, SG_PLAIN = 2, SG_PLAIN_BOOL = 3, SG_PLAIN_TEXT = 4, SG_FIXED_TEXT = 5 /* FIXED_LEN_BYTE_ARRAY: value k at `at` + k * bw */,
-                      SG_INDEX = 6 /* a page's dictionary indices (or RLE booleans) expanded by pq_hybrid: value k = the bw-BYTE word at tail + at + k * bw */ };
+                      SG_INDEX = 6 /* a page's dictionary indices (or RLE booleans) expanded by pq_hybrid: value k = the bw-BYTE word at tail + at + k * bw */,
+                      SG_BSS = 7 /* BYTE_STREAM_SPLIT (Encodings.md: K = the type's width byte streams of `count` bytes each, back to back): byte j of value k at `at` + j * count + k */ };
 struct Seg {
   uint32_t start, count;   // first ordinal (levels: row of the column; values: ordinal among the present values) and length
   uint32_t kind, bw;       // SG_*; bit width of packed values
@@ -1278,6 +1279,7 @@ __device__ __forceinline__ void pq_fixed_row(const uint8_t *file, uint64_t tail_
     const uint32_t w = (uint32_t)o.in_width;
     if (s.kind == SG_PLAIN) v = load_unaligned(file, s.at + (s.in_tail ? tail_base : 0) + (uint64_t)(k - s.start) * w, w);
     else if (s.kind == SG_PLAIN_BOOL) v = (file[s.at + ((k - s.start) >> 3)] >> ((k - s.start) & 7)) & 1;
+    else if (s.kind == SG_BSS) { for (uint32_t j = 0; j < w; j++) v |= (uint64_t)file[s.at + (uint64_t)j * s.count + (k - s.start)] << (8 * j); }   // (a wave reads w runs of 64 consecutive bytes)
     else {
       const uint32_t idx = seg_value(file, s, k, tail_base);
       if (o.in_width == 1 && !dict_at) v = idx;  // (booleans under RLE are their own values)
@@ -1477,7 +1479,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
   auto dev_page = [dev_inflate_mode](const ColChunk &c, const PageHeader &h, int leaf_type) {
     if (c.codec != C_SNAPPY && c.codec != C_LZ4_RAW) return false;
     if (!(h.type == 0 || h.type == 3) || (h.type == 3 && !h.compressed_v2)) return false;
-    const bool enc_ok = h.enc == E_PLAIN || h.enc == E_RLE_DICT || h.enc == E_PLAIN_DICT || (h.enc == E_RLE && leaf_type == T_BOOLEAN);
+    const bool enc_ok = h.enc == E_PLAIN || h.enc == E_BYTE_STREAM_SPLIT || h.enc == E_RLE_DICT || h.enc == E_PLAIN_DICT || (h.enc == E_RLE && leaf_type == T_BOOLEAN);
     const int64_t lead = h.type == 3 ? (int64_t)std::max(h.rep_len, 0) + (int64_t)std::max(h.def_len, 0) : 0;
     if (!(enc_ok && (int64_t)h.usize > lead && (int64_t)h.csize > lead)) return false;
     if (dev_inflate_mode == 2 && (int64_t)h.usize - lead > 128 * 1024 && (int64_t)h.csize < (int64_t)h.usize) return false;   // a large page of many elements: the host's cores
@@ -1740,7 +1742,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
               uint32_t L = 0; if (body >= 4) std::memcpy(&L, dst, 4);
               want = 4 + (uint64_t)L;
             }
-            want += (h.enc == E_RLE && leaf.type == T_BOOLEAN) ? 4 : (h.enc == E_PLAIN ? 0 : 1);
+            want += (h.enc == E_RLE && leaf.type == T_BOOLEAN) ? 4 : ((h.enc == E_PLAIN || h.enc == E_BYTE_STREAM_SPLIT) ? 0 : 1);
             if (want && !prefix(want)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: column " + leaf.name + ": malformed " + (codec == C_SNAPPY ? "SNAPPY" : "LZ4_RAW") + " page");
             infpages.push_back(InfPage{(uint64_t)(raw - f), (uint64_t)(raw - f) + (uint64_t)h.csize, (uint64_t)at0, (uint32_t)body, (uint32_t)lead, (uint32_t)codec, 0u});
             fb = arena.data(); pl = fb + at0; pe = pl + h.usize;
@@ -1804,6 +1806,10 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
               if (need > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: the values of a PLAIN page of column " + leaf.name + " run past it");
               val.push_back(Seg{(uint32_t)ord, (uint32_t)present, leaf.type == T_BOOLEAN ? SG_PLAIN_BOOL : SG_PLAIN, 0, (uint64_t)(q - fb), 0, 0});
             }
+          } else if (h.enc == E_BYTE_STREAM_SPLIT && (leaf.type == T_FLOAT || leaf.type == T_DOUBLE || leaf.type == T_INT32 || leaf.type == T_INT64)) {
+            // the values' bytes transposed: stream j holds byte j of every value (floats compress better that way); read back per value on the device
+            if (present * P.width > (uint64_t)(pe - q)) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: the values of a BYTE_STREAM_SPLIT page of column " + leaf.name + " run past it");
+            val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_BSS, 0, (uint64_t)(q - fb), 0, 0});
           } else if (h.enc == E_RLE_DICT || h.enc == E_PLAIN_DICT) {
             if (q >= pe && present) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: truncated page");
             if (present && !have_dict) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: dictionary indices without a dictionary page in column " + leaf.name);
@@ -1867,7 +1873,7 @@ static int parquet_read_impl(const uint8_t *f, uint64_t len, const tfgpu_schema 
             arena.append(exp.data(), exp.data() + exp.size());
             if (is_flba) val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_FIXED_TEXT, P.width, (uint64_t)at0, 0, 0});
             else { val.push_back(Seg{(uint32_t)ord, (uint32_t)present, SG_PLAIN_TEXT, 0, 0, 0, 0}); tpages.push_back(TextPage{(uint64_t)at0, (uint64_t)(at0 + exp.size()), (uint32_t)ord, (uint32_t)present}); }
-          } else return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": value encoding " + std::to_string(h.enc) + " (BYTE_STREAM_SPLIT, or a DELTA_* encoding over this type) is read by the stock reader");
+          } else return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_parquet_read: column " + leaf.name + ": value encoding " + std::to_string(h.enc) + " (BYTE_STREAM_SPLIT over FIXED_LEN_BYTE_ARRAY, or a DELTA_* encoding over this type) is read by the stock reader");
           ord += present; seen += h.nvalues;
           if (ord > 0x7FFFFFF0ull) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_parquet_read: more values than rows in column " + leaf.name);
         }

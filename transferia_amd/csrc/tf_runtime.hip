@@ -254,6 +254,7 @@ __global__ void upload_validity_minus_absent(const uint8_t *validity_in, const u
   validity_out[i] = (uint8_t)((validity_in ? validity_in[i] : 0xFFu) & ~absent[i]);
 }
 
+int lanes_created() { int n = 0; for (auto &l : g_lanes) if (l) n++; return n; }
 Buf validity_minus_absent(const Buf &validity, const Buf &absent, int64_t nrows) {
   const int64_t nb = (nrows + 7) / 8;
   Buf v = dalloc((size_t)nb + 8);

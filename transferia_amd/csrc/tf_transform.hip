@@ -777,7 +777,13 @@ static std::unique_ptr<tfgpu_dbatch> compact(const tfgpu_dbatch &in, Buf keep /*
   return gather_batch(in, sel, m);
 }
 
+// The selection → dense transition mutates a handle its callers hold as const, and one handle can be reached from two threads on two lanes (the
+// Bufferer's collector concatenating a batch the pusher is serializing): the lane's mutex is the CALLING thread's, so the transition has a lock of
+// its own, and with more than one lane alive the gather is complete — not merely queued on the gathering lane's stream — when the lock is released
+// (the next reader may sit on another stream).  ADVICE r5.
+static std::mutex g_dense_mu;
 void dense_locked(const tfgpu_dbatch &b) {
+  std::lock_guard<std::mutex> dl(g_dense_mu);
   if (!b.pending) return;
   tfgpu_dbatch &mb = const_cast<tfgpu_dbatch &>(b);  // (the handle's observable value does not change: the same rows, now gathered)
   std::shared_ptr<PendingRows> pr = b.pending;
@@ -785,9 +791,11 @@ void dense_locked(const tfgpu_dbatch &b) {
   mb.cols = std::move(g->cols); mb.old_keys = std::move(g->old_keys); mb.old_present = g->old_present;
   mb.kind = g->kind; mb.src_row = g->src_row; mb.part_id = g->part_id;
   mb.replaced.clear();
+  if (lanes_created() > 1) sync();
   mb.pending.reset();
 }
 bool has_absent(const tfgpu_dbatch &b) {
+  std::lock_guard<std::mutex> dl(g_dense_mu);
   if (b.col_order) return true;  // rows with their own ColumnNames order are ragged rows too
   for (auto &c : (b.pending ? b.pending->src->cols : b.cols)) if (c.absent) return true;
   return false;
@@ -800,7 +808,7 @@ void refuse_absent(const tfgpu_dbatch &b) {
 void dense(const tfgpu_dbatch *b, bool absent_ok) {
   if (!b) return;
   if (!absent_ok) refuse_absent(*b);
-  if (!b->pending) return;
+  { std::lock_guard<std::mutex> dl(g_dense_mu); if (!b->pending) return; }
   std::lock_guard<std::mutex> lk(ctx().mu);
   dense_locked(*b);
 }
