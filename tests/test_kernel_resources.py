@@ -72,6 +72,10 @@ def test_serializer_and_sr_resources():
     # formatter's digit buffer on the JSON / CSV paths
     assert find(t, "ser_cell_write")["scratch"] <= 64 and find(t, "ser_cell_len")["scratch"] == 0
     walks = {k: v for k, v in t.items() if "ser_chunk_write" in k or "ser_chunk_len" in k}
+    lean = walks.pop(next(k for k in walks if "ser_chunk_len_fast" in k))
+    # the lean JSONEachRow length pass (round 6): no emitters, eight waves per SIMD, nothing spilled
+    assert lean["scratch"] == 0 and lean["vgpr"] <= 64 and lean["lds"] == 0, lean
+    assert find(t, "ser_text_flags")["scratch"] == 0
     assert len(walks) == 6 and min(v["scratch"] for v in walks.values()) == 0 and max(v["scratch"] for v in walks.values()) <= 64
     assert all(v["vgpr"] <= 128 for v in walks.values())  # four waves per SIMD (and four workgroups of 4 x 9 KiB LDS per CU): the walks are latency-bound
     assert find(t, "ser_fill_const")["vgpr"] <= 16

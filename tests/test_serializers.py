@@ -426,3 +426,61 @@ def test_gpu_slab_form_of_the_text_serializers(tf, oracle, monkeypatch, knobs):
     b = abi.batch_from_rows(schema, ["k", "s", "t", "d"], rows, "", "t")
     for fmt in (abi.FMT_JSON, abi.FMT_CSV, abi.FMT_CH_JSON_EACH_ROW):
         assert tf.serialize(fmt, tf.DeviceBatch.upload(b), _opts({})).download() == oracle.serialize(fmt, b, schema, _opts({})), fmt
+
+
+@pytest.mark.gpu
+def test_gpu_lean_length_pass_of_jsoneachrow(tf, oracle, monkeypatch):
+    """ser_chunk_len_fast (round 6): JSONEachRow lengths without the write pass's walk — digit counts, text as 2 + bytes unless ser_text_flags found a byte
+    that escapes in the COLUMN, dates as a constant unless the year leaves 0000-9999, DateTime64 / epoch seconds as digit counts.  Batches made ONLY of the
+    kinds it takes (so that it runs: the kernel list says so), every ClickHouse target kind the flags can name, nils, extremes, text with and without
+    escapes — byte for byte the oracle's MarshalCItoJSON and the same call with TFGPU_SER_LEN_FAST=0."""
+    rng = np.random.default_rng(SEED0 + 4242)
+    for n in (1, 65, 1500):
+        ext = np.array([0, 1, -1, 9, 10, 99, 100, -128, 127, 255, 32767, -32768, 65535, 99999999, 100000000, -99999999, -100000000, 2**31 - 1, -2**31, 2**32 - 1, 2**63 - 1, -2**63], dtype=object)
+        pick = lambda lo, hi: np.array([int(max(lo, min(hi, int(ext[i])))) if rng.random() < 0.5 else int(rng.integers(lo, hi)) for i in rng.integers(0, len(ext), n)], dtype=object)  # noqa: E731
+        cols = []
+        for name, dt, rp, npdt, lo, hi in (("i8", "int8", abi.R_INT8, np.int8, -128, 127), ("i16", "int16", abi.R_INT16, np.int16, -32768, 32767), ("i32", "int32", abi.R_INT32, np.int32, -2**31, 2**31 - 1),
+                                           ("i64", "int64", abi.R_INT64, np.int64, -2**63, 2**63 - 1), ("u8", "uint8", abi.R_UINT8, np.uint8, 0, 255), ("u16", "uint16", abi.R_UINT16, np.uint16, 0, 65535),
+                                           ("u32", "uint32", abi.R_UINT32, np.uint32, 0, 2**32 - 1), ("u64", "uint64", abi.R_UINT64, np.uint64, 0, 2**63 - 1), ("ianys", "any", abi.R_INT64, np.int64, -2**63, 2**63 - 1),
+                                           ("istr", "utf8", abi.R_INT32, np.int32, -2**31, 2**31 - 1)):
+            cols.append(abi.Column(name, dt, rp, values=np.array([int(x) for x in pick(lo, hi)], dtype=npdt), validity=rng.random(n) > 0.15))
+
+        def text(name, dt, rp, words):
+            p_ = [words[i] for i in rng.integers(0, len(words), n)]
+            off = np.concatenate([[0], np.cumsum([len(x) for x in p_])]).astype(np.uint32)
+            return abi.Column(name, dt, rp, offsets=off, data=np.frombuffer(b"".join(p_) or b"\0", np.uint8).copy(), validity=rng.random(n) > 0.1)
+        cols.append(text("plain", "utf8", abi.R_STRING, [b"", b"a", b"http://example.org/x?y=1", "café €".encode(), b"x" * 70]))
+        cols.append(text("esc", "utf8", abi.R_STRING, [b"", b"q\"q", b"back\\slash", b"line\nbreak\ttab", b"ctl\x01\x1f", b"plain words only"]))
+        cols.append(text("blob", "string", abi.R_BYTES, [b"", b"\x00\x01\xff", b"bytes \"quoted\"", b"raw"]))
+        cols.append(text("anytext", "any", abi.R_STRING, [b"v", b"\\", b"long " * 9]))
+        cols.append(text("dec", "utf8", abi.R_STRING, [b"1.50", b"-0.001", b"12345678901234567890.12"]))
+        cols.append(abi.Column("flag", "boolean", abi.R_BOOL, values=rng.integers(0, 2, n).astype(np.uint8), validity=rng.random(n) > 0.2))
+        cols.append(abi.Column("flagany", "any", abi.R_BOOL, values=rng.integers(0, 2, n).astype(np.uint8)))
+        secs = np.array([int(x) for x in rng.integers(-3 * 10**9, 5 * 10**9, n)], dtype=np.int64)
+        edge = [-62167219200, 253402300799, -62167219201, 253402300800, 0, -1, 86399]
+        secs[: min(n, len(edge))] = edge[: min(n, len(edge))]
+        for name, dt in (("day", "date"), ("at", "datetime"), ("ts", "timestamp"), ("ts3", "timestamp"), ("ts0", "timestamp"), ("tssec", "timestamp")):
+            cols.append(abi.Column(name, dt, abi.R_TIME, values=secs.copy(), nanos=rng.integers(0, 10**9, n).astype(np.int32), validity=rng.random(n) > 0.1))
+        b = abi.Batch(cols, n, "db", "tbl")
+        schema = abi.Schema.of([[c.name, c.dtype, False] for c in cols])
+        names = [c.name for c in cols]
+        base = [[0, 0] for _ in cols]
+        for nm, fl, prec in (("plain", 1, 0), ("esc", 1, 0), ("blob", 1, 0), ("anytext", 1, 0), ("dec", 8, 0), ("istr", 1, 0), ("day", 2, 0), ("at", 0, 0), ("ts", 4, 9), ("ts3", 4, 3), ("ts0", 4, 0), ("tssec", 0, 0)):
+            base[names.index(nm)] = [fl, prec]
+        quoted = [list(x) for x in base]
+        for nm in ("i8", "i64", "u64", "u16"):
+            quoted[names.index(nm)] = [1, 0]      # a numeric column under a String target: quoted digits
+        db = tf.DeviceBatch.upload(b)
+        for o in ({}, {"ch_types": base}, {"ch_types": quoted}, {"ch_types": base, "any_as_string": True}):
+            want = oracle.serialize(abi.FMT_CH_JSON_EACH_ROW, b, schema, _opts(o))
+            assert want is not None
+            tf.prof_reset(); tf.prof_enable(True)
+            got = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, db, _opts(o)).download()
+            kernels = {k for k, l, ms in tf.prof_get() if l}
+            tf.prof_enable(False)
+            assert "ser_text_flags" in kernels, kernels     # the lean pass ran
+            assert bytes(got) == bytes(want), (n, o.keys())
+            monkeypatch.setenv("TFGPU_SER_LEN_FAST", "0")
+            slow = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, db, _opts(o)).download()
+            monkeypatch.delenv("TFGPU_SER_LEN_FAST")
+            assert bytes(slow) == bytes(want)

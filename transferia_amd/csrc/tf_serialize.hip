@@ -667,6 +667,102 @@ __global__ void __launch_bounds__(256) TF_SER_WRITE_ATTR ser_chunk_write(SerPara
   }
 }
 
+// ---- the JSONEachRow length pass, lean form (round 6) -------------------------------------------------------------------------------
+// ser_chunk_len runs the write pass's own walk over a counting sink: the column records by v_readlane, the whole emitter family inlined (128
+// VGPRs: four waves a SIMD), every text cell's bytes read to count its escapes — 660 vector + 830 scalar instructions and three to five dependent
+// memory round trips a (64 rows x 5 cells) tile, 58 % of a wave's life waiting (profiles/r20b_pmc_ser_chunk.txt).  What a LENGTH needs is less:
+//   * integers: the digit count (the emitters' own CountSink path: the same code decides what the write pass will write);
+//   * text: 2 quotes + the cell's bytes — plus its escapes, and whether a COLUMN holds any byte that escapes at all ('"', '\', < 0x20) is one
+//     streaming pass over the column's bytes (ser_text_flags: all text columns in one launch).  A column without such a byte — nearly every column
+//     of nearly every batch — costs two offsets a cell and no byte; one with them is counted cell by cell as before;
+//   * dates / DateTime64 / epoch seconds: a constant or a digit count.
+// Column descriptors are 32-byte records read through the scalar unit at a wave-uniform index, the chunk's cells are loaded eight columns at a
+// time before the first is looked at, and the kernel needs a quarter of the registers: eight waves a SIMD hide what is left of the latency.
+// Same tiles, same (row, chunk) length table as ser_chunk_len: ser_chunk_layout and ser_chunk_write do not know the difference.  Batches with a
+// column outside the list (floats, `any`, []byte as arrays, times as strings) take ser_chunk_len as before.
+enum : uint32_t { LK_INT = 1, LK_TEXT = 2, LK_TEXT_RAW = 3, LK_BOOL = 4, LK_TIME_DATE = 5, LK_TIME_SEC = 6, LK_TIME_DT64 = 7 };
+struct LenCol {
+  const void *values;        // fixed-width values, or the text column's offsets
+  const uint8_t *validity;   // or null
+  const uint8_t *data;       // text bytes (only read when the column's flag says it holds bytes that escape)
+  uint32_t kind;             // LK_*
+  uint32_t add;              // prefix bytes (with the separator's) + what frames the value (quotes)
+  int32_t repr;              // LK_INT: the Go integer type; LK_TIME_DT64: the precision
+  uint32_t flag;             // LK_TEXT: index into the text flags
+};
+__global__ void __launch_bounds__(256) ser_text_flags(const LenCol *cols, const int32_t *text_cols, const uint64_t *text_bytes, uint32_t *flags) {
+  const int32_t j = (int32_t)blockIdx.y;
+  const LenCol c = cols[text_cols[j]];
+  const uint64_t n = text_bytes[j];
+  bool hit = false;
+  for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (uint64_t)gridDim.x * blockDim.x * 16) {
+    if (i + 16 <= n) {
+      const uint64_t a = load8(c.data + i), b = load8(c.data + i + 8);
+      hit |= (swar_has_less(a, 0x20) | swar_has(a, '"') | swar_has(a, '\\') | swar_has_less(b, 0x20) | swar_has(b, '"') | swar_has(b, '\\')) != 0;
+    } else for (uint64_t k = i; k < n; k++) { const uint32_t ch = c.data[k]; hit |= ch < 0x20 || ch == '"' || ch == '\\'; }
+  }
+  if (__any(hit) && (threadIdx.x & 63) == 0) flags[j] = 1u;
+}
+__device__ __forceinline__ uint32_t len_of_value(const LenCol &c, uint64_t v, int32_t ns, uint32_t t0, uint32_t t1, const uint32_t *flags) {
+  switch (c.kind) {
+    case LK_INT: { CountSink s; DCol d; d.repr = c.repr; CellBits b; b.v = v; b.ns = 0; b.valid = true; emit_int(s, d, b); return s.n; }
+    case LK_TEXT: {
+      const uint32_t n = t1 - t0;
+      if (!flags[c.flag]) return n;
+      CountSink s; emit_ch_quoted(s, c.data + t0, n); return s.n - 2u;   // (the quotes are in `add`)
+    }
+    case LK_TEXT_RAW: return t1 - t0;
+    case LK_BOOL: return (uint8_t)v ? 4u : 5u;
+    case LK_TIME_DATE: {
+      const int64_t sec = (int64_t)v;
+      if (sec >= -62167219200ll && sec <= 253402300799ll) return 10u;   // years 0000 .. 9999: "2006-01-02"
+      CountSink s; emit_date(s, sec); return s.n;
+    }
+    case LK_TIME_SEC: { CountSink s; emit_i64(s, (int64_t)v); return s.n; }
+    default: {  // LK_TIME_DT64
+      int64_t full = (int64_t)v * 1000000000LL + ns;
+      if (c.repr > 0 && c.repr < 9) full = full / pow10_i64(9 - c.repr);
+      CountSink s; emit_i64(s, full); return s.n;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) ser_chunk_len_fast(SerParams p, ChunkPlan cp, const LenCol *cols, const uint32_t *flags) {
+  const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int32_t k; int64_t r0;
+  tile_of(cp, tile, k, r0);
+  if (k >= cp.nchunks || r0 >= p.nrows) return;
+  const int32_t c0 = __builtin_amdgcn_readfirstlane(cp.cut[k]), c1 = __builtin_amdgcn_readfirstlane(cp.cut[k + 1]);
+  const int64_t rl = r0 + (threadIdx.x & 63);
+  if (rl >= p.nrows) return;
+  const int64_t r = rl;
+  uint32_t total = 0;
+  constexpr int G = 8;
+  for (int32_t cg = c0; cg < c1; cg += G) {
+    uint64_t v[G]; int32_t ns[G]; uint32_t ok = 0;   // (a text cell's two offsets ride in v: 26 registers of loads in flight, not 50)
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+      v[j] = 0; ns[j] = 0;
+      if (cg + j < c1) {
+        const LenCol &c = cols[cg + j];
+        if (!c.validity || ((c.validity[r >> 3] >> (r & 7)) & 1)) ok |= 1u << j;
+        if (c.kind == LK_TEXT || c.kind == LK_TEXT_RAW) { const uint32_t *o = (const uint32_t *)c.values; v[j] = o[r] | ((uint64_t)o[r + 1] << 32); }
+        else if (c.kind == LK_BOOL) v[j] = ((const uint8_t *)c.values)[r];
+        else if (c.kind == LK_INT) {
+          switch (c.repr) {
+            case TFGPU_R_INT8: case TFGPU_R_UINT8: v[j] = ((const uint8_t *)c.values)[r]; break;
+            case TFGPU_R_INT16: case TFGPU_R_UINT16: v[j] = ((const uint16_t *)c.values)[r]; break;
+            case TFGPU_R_INT32: case TFGPU_R_UINT32: v[j] = ((const uint32_t *)c.values)[r]; break;
+            default: v[j] = ((const uint64_t *)c.values)[r];
+          }
+        } else { v[j] = ((const uint64_t *)c.values)[r]; if (c.kind == LK_TIME_DT64 && c.data) ns[j] = ((const int32_t *)c.data)[r]; }   // (a time column's nanoseconds ride in `data`)
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G; j++) if (cg + j < c1 && ((ok >> j) & 1u)) { const LenCol &c = cols[cg + j]; total += c.add + len_of_value(c, v[j], ns[j], (uint32_t)v[j], (uint32_t)(v[j] >> 32), flags); }
+  }
+  cp.chunk[(int64_t)k * p.nrows + r] = total;
+}
+
 #include "tf_serslab.inc"
 
 // queue formats: the message frame once the cut plan is known.  Native: "[" before the first element of a message, ","
@@ -1081,7 +1177,51 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
       ChunkSetup csu = make_chunk_setup(b, format, order, sc, blob, n);
       cp = csu.cp; bcut = csu.bcut; brecs = csu.brecs; cell = csu.cell;
       const unsigned grid = ser_grid(cp);
-      {
+      // JSONEachRow over integers, text, booleans, dates / DateTime64 / epoch seconds: the lean length pass (ser_chunk_len_fast); anything else in the
+      // batch: the walk over a counting sink.  TFGPU_SER_LEN_FAST=0: always the walk (A/B).
+      std::vector<LenCol> lc;
+      std::vector<int32_t> tcols; std::vector<uint64_t> tbytes;
+      bool fast = format == TFGPU_FMT_CH_JSON_EACH_ROW && env_int("TFGPU_SER_LEN_FAST", 1) != 0 && p.ablate == 0;
+      for (int j = 0; j < ncols && fast; j++) {
+        const DColumn &c = b->cols[(size_t)order[(size_t)j]];
+        const SCol &q = sc[(size_t)j];
+        LenCol l{};
+        l.validity = q.c.validity; l.add = q.pre_len; l.repr = c.repr;
+        const uint32_t fl = q.ch_flags;
+        const bool numeric = (c.dtype >= TFGPU_T_INT8 && c.dtype <= TFGPU_T_FLOAT64) || c.dtype == TFGPU_T_INTERVAL;
+        const bool generic_quotes = c.dtype != TFGPU_T_ANY || any_as_string || (fl & TFGPU_CH_STRING);   // marshalGeneric's double marshal
+        if (c.repr >= TFGPU_R_INT8 && c.repr <= TFGPU_R_UINT64) {
+          l.kind = LK_INT; l.values = q.c.values;
+          if (numeric ? (fl & TFGPU_CH_STRING) != 0 : generic_quotes) l.add += 2;
+        } else if (c.repr == TFGPU_R_STRING || (c.repr == TFGPU_R_BYTES && !(fl & TFGPU_CH_ARRAY))) {
+          l.values = q.c.offsets; l.data = q.c.data;
+          if (fl & TFGPU_CH_DECIMAL) l.kind = LK_TEXT_RAW;
+          else { l.kind = LK_TEXT; l.add += 2; l.flag = (uint32_t)tcols.size(); tcols.push_back(j); tbytes.push_back(c.data_len); }
+        } else if (c.repr == TFGPU_R_BOOL) {
+          l.kind = LK_BOOL; l.values = q.c.values;
+          if (c.dtype != TFGPU_T_BOOLEAN && generic_quotes) l.add += 2;
+        } else if (c.repr == TFGPU_R_TIME && (c.dtype == TFGPU_T_DATE || c.dtype == TFGPU_T_DATETIME || c.dtype == TFGPU_T_TIMESTAMP) && !(fl & TFGPU_CH_STRING)) {
+          l.values = q.c.values;
+          if (fl & TFGPU_CH_DATETIME64) { l.kind = LK_TIME_DT64; l.repr = (int32_t)q.prec; l.data = reinterpret_cast<const uint8_t *>(q.c.nanos); }
+          else if (fl & TFGPU_CH_DATE) { l.kind = LK_TIME_DATE; l.add += 2; }
+          else l.kind = LK_TIME_SEC;
+        } else fast = false;
+        lc.push_back(l);
+      }
+      if (fast) {
+        Buf blc = upload_const(lc.data(), lc.size() * sizeof(LenCol));
+        Buf flags = dalloc_zero((tcols.size() + 1) * 4);
+        if (!tcols.empty()) {
+          Buf btc = upload_const(tcols.data(), tcols.size() * 4), btb = upload_const(tbytes.data(), tbytes.size() * 8);
+          uint64_t most = 0;
+          for (uint64_t x : tbytes) most = std::max(most, x);
+          const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((most + 4095) / 4096, 1), 2048);
+          KernelTimer t("ser_text_flags");
+          ser_text_flags<<<dim3(gx, (unsigned)tcols.size()), 256, 0, st>>>(ptr<LenCol>(blc), ptr<int32_t>(btc), ptr<uint64_t>(btb), ptr<uint32_t>(flags));
+        }
+        KernelTimer t("ser_chunk_len");
+        ser_chunk_len_fast<<<grid, 256, 0, st>>>(p, cp, ptr<LenCol>(blc), ptr<uint32_t>(flags));
+      } else {
         KernelTimer t("ser_chunk_len");
         if (format == TFGPU_FMT_CH_JSON_EACH_ROW) ser_chunk_len<TFGPU_FMT_CH_JSON_EACH_ROW><<<grid, 256, 0, st>>>(p, cp);
         else if (format == TFGPU_FMT_JSON) ser_chunk_len<TFGPU_FMT_JSON><<<grid, 256, 0, st>>>(p, cp);
