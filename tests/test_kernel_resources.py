@@ -129,3 +129,15 @@ def test_quick_tile_parsers_fit_three_workgroups_per_cu():
     for src, name in (("tf_json.hip", "json_parse_quick"), ("tf_srjson.hip", "sr_parse_quick"), ("tf_debezium.hip", "dbz_parse_quick")):
         k = find(kernel_table(src), name)
         assert k["scratch"] == 0 and k["vgpr"] <= 96 and k["lds"] * 3 <= 160 * 1024, (name, k)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_protobuf_any_kernels_do_not_carry_the_map_emitter():
+    """Round 6: map<string, V> and repeated-message support grew the `any` kernels from 124 VGPRs / no scratch to 180 / 184 bytes and cost 15 % of the
+    sr_proto line on a schema that has neither; the wide columns have their own instantiation now, and this is the guard."""
+    t = kernel_table("tf_protobuf.hip")
+    cells = find(t, "pb_cellsILb1ELb0EE")
+    assert cells["vgpr"] <= 128 and cells["scratch"] == 0, cells
+    text = find(t, "pb_text_anyILb0EE")
+    assert text["vgpr"] <= 128 and text["scratch"] <= 64, text
+    assert find(t, "pb_cellsILb0ELb0EE")["vgpr"] <= 16

@@ -234,7 +234,8 @@ template <class S> __device__ bool emit_message(S &s, const Params &p, const DFi
 }
 
 // a repeated field's []interface{}: the elements of every occurrence in wire order, packed runs unrolled.  false: a NaN / Inf element
-template <class S> __device__ bool emit_array(S &s, const Params &p, const DField &fd, uint32_t a, uint32_t z) {
+// MSG: the instantiation that takes element MESSAGES too (the wide kernels below)
+template <bool MSG, class S> __device__ bool emit_array(S &s, const Params &p, const DField &fd, uint32_t a, uint32_t z) {
   const uint8_t *d = p.data;
   MemBytes rd(p.data);
   const int ew = want_wt(fd.ptype);
@@ -242,7 +243,7 @@ template <class S> __device__ bool emit_array(S &s, const Params &p, const DFiel
   s.put('[');
   walk(rd, a, z, [&](uint32_t num, uint32_t wt, uint64_t raw, uint32_t len) {
     if (num != (uint32_t)fd.number) return 0;
-    if (fd.ptype == TFGPU_PB_MESSAGE) {  // an element message: its map, as a singular message field's (unpackRepeatedVal → unpackNotRepeatedVal over *dynamic.Message)
+    if constexpr (MSG) if (fd.ptype == TFGPU_PB_MESSAGE) {  // an element message: its map, as a singular message field's (unpackRepeatedVal → unpackNotRepeatedVal over *dynamic.Message)
       if (!first) s.put(',');
       first = false;
       if (!emit_message(s, p, fd, (uint32_t)raw, len)) ok = false;
@@ -310,8 +311,10 @@ template <class S> __device__ bool emit_map(S &s, const Params &p, const DField 
 
 // ANY = false: the columns whose cells are a few instructions each (fixed-width values, string / bytes lengths) — a kernel of a dozen
 // registers at full occupancy; ANY = true: the `any` columns, whose lengths come from the JSON emitter (float formatting, base64, the
-// string escaper: 120 VGPRs).  One kernel for both ran every cheap cell at the emitter's occupancy.
-template <bool ANY> __global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, const int32_t *list, int32_t *src_row, uint32_t *part_id, uint32_t *host_rows) {
+// string escaper: 120 VGPRs).  One kernel for both ran every cheap cell at the emitter's occupancy.  WIDE (with ANY): map fields and repeated
+// MESSAGE fields — the key-order scan and a message emitter inside the element walk took the `any` kernels from 124 VGPRs and no scratch to 180 and
+// 184 bytes (sr_proto 159 -> 136 M messages/s on a schema that holds neither: profiles/r25b_*); their columns have their own instantiation now.
+template <bool ANY, bool WIDE = false> __global__ void __launch_bounds__(256) pb_cells(Params p, const OutCol *cols, const int32_t *list, int32_t *src_row, uint32_t *part_id, uint32_t *host_rows) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int j = list[blockIdx.y];
   const bool in = r < p.nrows;
@@ -327,7 +330,10 @@ template <bool ANY> __global__ void __launch_bounds__(256) pb_cells(Params p, co
     if constexpr (ANY) {
       if (fd.repeated) {  // an absent repeated field is the empty slice: []
         CountSink s;
-        if (!(fd.repeated == 2 ? emit_map(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]) : emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]))) { host_rows[r] = 1; s.n = 0; }   // (an absent map field is the empty map: {})
+        bool ok;
+        if constexpr (WIDE) ok = fd.repeated == 2 ? emit_map(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]) : emit_array<true>(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);   // (an absent map field is the empty map: {})
+        else ok = emit_array<false>(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
+        if (!ok) { host_rows[r] = 1; s.n = 0; }
         c.lens[r] = s.n;
       } else if (!present) { c.lens[r] = 0; valid = false; }   // a nil *dynamic.Message: nil
       else {
@@ -361,7 +367,7 @@ __global__ void __launch_bounds__(256) pb_text_copy(Params p, const OutCol *cols
   s.flush();
 }
 // `any` cells: message fields and repeated fields marshalled
-__global__ void __launch_bounds__(256) pb_text_any(Params p, const OutCol *cols, const int32_t *list) {
+template <bool WIDE> __global__ void __launch_bounds__(256) pb_text_any(Params p, const OutCol *cols, const int32_t *list) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= p.nrows) return;
   const int j = list[blockIdx.y];
@@ -371,8 +377,8 @@ __global__ void __launch_bounds__(256) pb_text_any(Params p, const OutCol *cols,
   const int64_t i = (int64_t)j * p.nmsg + m;
   if (c.lens[r + 1] == c.lens[r]) return;  // nil, or a row for the host: nothing was counted
   WriteSink s{c.data + c.lens[r]};
-  if (fd.repeated == 2) emit_map(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
-  else if (fd.repeated) emit_array(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
+  if (WIDE && fd.repeated == 2) emit_map(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
+  else if (fd.repeated) emit_array<WIDE>(s, p, fd, p.ms[m] + 6u, p.ms[m + 1]);
   else { const uint64_t raw = p.rec[i]; emit_message(s, p, fd, (uint32_t)raw, (uint32_t)(raw >> 32)); }
   s.flush();
 }
@@ -521,8 +527,9 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
     db->schema.push_back({d.name, d.dtype});
     db->cols.push_back(std::move(d));
   }
-  std::vector<int32_t> light_cols, any_cols;
-  for (int j = 0; j < nf; j++) ((fl[j].repeated || fl[j].ptype == TFGPU_PB_MESSAGE) ? any_cols : light_cols).push_back(j);
+  std::vector<int32_t> light_cols, any_cols, wide_cols;
+  auto wide = [&](int j) { return fl[j].repeated == 2 || (fl[j].repeated && fl[j].ptype == TFGPU_PB_MESSAGE); };   // maps, repeated messages
+  for (int j = 0; j < nf; j++) (wide(j) ? wide_cols : (fl[j].repeated || fl[j].ptype == TFGPU_PB_MESSAGE) ? any_cols : light_cols).push_back(j);
   Buf boc = upload_small(oc.data(), oc.size() * sizeof(pbd::OutCol));
   if (nrows) {
     pbd::pb_row_msgs<<<pbd::nblk(nmsg, 256), 256, 0, st>>>(p);
@@ -532,6 +539,7 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
     if (!light_cols.empty()) pbd::pb_cells<false><<<dim3(pbd::nblk(nrows, 256), (unsigned)light_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bl), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id), ptr<uint32_t>(host_rows));
     else pbd::pb_src_rows<<<pbd::nblk(nrows, 256), 256, 0, st>>>(p, ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id));
     if (!any_cols.empty()) pbd::pb_cells<true><<<dim3(pbd::nblk(nrows, 256), (unsigned)any_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(ba), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id), ptr<uint32_t>(host_rows));
+    if (!wide_cols.empty()) { Buf bw = upload_small(wide_cols.data(), wide_cols.size() * 4); pbd::pb_cells<true, true><<<dim3(pbd::nblk(nrows, 256), (unsigned)wide_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bw), ptr<int32_t>(db->src_row), ptr<uint32_t>(db->part_id), ptr<uint32_t>(host_rows)); }
   }
   if (ntext) {
     // The `any` marshalling expands its input (absent members as "name":0, \u00XX, base64): a column's bytes are summed in 64 bits
@@ -554,10 +562,11 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
     boc = upload_small(oc.data(), oc.size() * sizeof(pbd::OutCol));
     if (nrows) {
       KernelTimer t("pb_text");
-      std::vector<int32_t> copy_cols, any_text;
-      for (int32_t j : text_cols) ((fl[j].repeated || fl[j].ptype == TFGPU_PB_MESSAGE) ? any_text : copy_cols).push_back(j);
+      std::vector<int32_t> copy_cols, any_text, wide_text;
+      for (int32_t j : text_cols) (wide(j) ? wide_text : (fl[j].repeated || fl[j].ptype == TFGPU_PB_MESSAGE) ? any_text : copy_cols).push_back(j);
       if (!copy_cols.empty()) { Buf bc = upload_small(copy_cols.data(), copy_cols.size() * 4); pbd::pb_text_copy<<<dim3(pbd::nblk(nrows, 256), (unsigned)copy_cols.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bc)); }
-      if (!any_text.empty()) { Buf bc = upload_small(any_text.data(), any_text.size() * 4); pbd::pb_text_any<<<dim3(pbd::nblk(nrows, 256), (unsigned)any_text.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bc)); }
+      if (!any_text.empty()) { Buf bc = upload_small(any_text.data(), any_text.size() * 4); pbd::pb_text_any<false><<<dim3(pbd::nblk(nrows, 256), (unsigned)any_text.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bc)); }
+      if (!wide_text.empty()) { Buf bc = upload_small(wide_text.data(), wide_text.size() * 4); pbd::pb_text_any<true><<<dim3(pbd::nblk(nrows, 256), (unsigned)wide_text.size()), 256, 0, st>>>(p, ptr<pbd::OutCol>(boc), ptr<int32_t>(bc)); }
     }
   }
   // rows whose `any` value holds a NaN / Inf: the reference keeps the Go float inside the map / slice, the column's JSON text cannot
