@@ -95,6 +95,7 @@ struct Context {
   struct Pending { int idx; hipEvent_t a, b; int64_t units = 0; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
+  hipEvent_t dense_event = nullptr;  // re-recorded behind every selection -> dense gather of this lane while other lanes are alive (tf::dense_locked)
   std::mutex mu;  // serialises API calls that enqueue on the stream
   int num_cus = 256;
   std::shared_ptr<struct DevMem> pow10tab;  // math.Pow10(n), n = -323..308 (tf_json.hip)
@@ -231,6 +232,8 @@ struct tfgpu_dbatch {
   int64_t nrows = 0;
   std::vector<tf::DColumn> cols;                    // EMPTY while `pending` is set
   std::shared_ptr<tf::PendingRows> pending;         // set: this batch is nrows selected rows of pending->src, not gathered yet
+  void *dense_done = nullptr;                       // the gathering lane's hipEvent_t (Context::dense_event, lives as long as the lane), recorded behind the gather that ended
+  int dense_lane = -1;                              //   `pending` while several lanes were alive: a reader on ANOTHER lane's stream waits for it (tf::dense)
   std::vector<tf::DColumn> replaced;                // with `pending`: columns already computed over the kept rows (dense, by name)
   std::vector<std::pair<std::string, int>> schema;  // TableSchema (name, DataType) in order; empty = same as cols
   std::vector<std::string> key_names;               // names of the PrimaryKey columns of that schema (MakeMapKeys)

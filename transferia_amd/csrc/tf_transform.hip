@@ -791,8 +791,19 @@ void dense_locked(const tfgpu_dbatch &b) {
   mb.cols = std::move(g->cols); mb.old_keys = std::move(g->old_keys); mb.old_present = g->old_present;
   mb.kind = g->kind; mb.src_row = g->src_row; mb.part_id = g->part_id;
   mb.replaced.clear();
-  if (lanes_created() > 1) sync();
+  if (lanes_created() > 1) {  // the gather is QUEUED on this lane's stream: leave an event behind it for readers on other streams (a host sync here cost configs[4] 0.2 ms a pass)
+    // ONE event a lane, recorded again at every transition: a reader that waits on a later record than its batch's waits for more than it must, never for less
+    Context &cx = ctx();
+    if (!cx.dense_event) TF_HIP(hipEventCreateWithFlags(&cx.dense_event, hipEventDisableTiming));
+    TF_HIP(hipEventRecord(cx.dense_event, cx.stream));
+    mb.dense_done = (void *)cx.dense_event;
+    mb.dense_lane = current_lane();
+  }
   mb.pending.reset();
+}
+// a batch another lane made dense: this lane's stream waits for that gather (no-op on the gathering lane, or once nobody else is alive)
+static void wait_dense_nolock(const tfgpu_dbatch &b) {
+  if (b.dense_done && b.dense_lane != current_lane()) TF_HIP(hipStreamWaitEvent(ctx().stream, (hipEvent_t)b.dense_done, 0));
 }
 bool has_absent(const tfgpu_dbatch &b) {
   std::lock_guard<std::mutex> dl(g_dense_mu);
@@ -808,7 +819,7 @@ void refuse_absent(const tfgpu_dbatch &b) {
 void dense(const tfgpu_dbatch *b, bool absent_ok) {
   if (!b) return;
   if (!absent_ok) refuse_absent(*b);
-  { std::lock_guard<std::mutex> dl(g_dense_mu); if (!b->pending) return; }
+  { std::lock_guard<std::mutex> dl(g_dense_mu); if (!b->pending) { wait_dense_nolock(*b); return; } }
   std::lock_guard<std::mutex> lk(ctx().mu);
   dense_locked(*b);
 }
@@ -1755,7 +1766,8 @@ std::unique_ptr<tfgpu_dbatch> apply_plan(const tfgpu_plan &p, const tfgpu_dbatch
   // the column droppers and the row filters carry the bitmaps.  `sql` (it serializes whole rows for clickhouse-local) and batches whose rows carry
   // their own name ORDER (col_order indexes the column list these transformers change) stay with the stock path.
   if (p.kind == PK_SQL || (in.col_order && p.kind != PK_SHARDER)) refuse_absent(in);
-  if (in.pending && (p.kind != PK_MASK || has_absent(in))) dense_locked(in);  // (the callers hold the lane's mutex) only mask_field reads through a selection
+  if (in.pending && (p.kind != PK_MASK || has_absent(in))) dense_locked(in);
+  else if (!in.pending) { std::lock_guard<std::mutex> dl(g_dense_mu); wait_dense_nolock(in); }  // (the callers hold the lane's mutex) only mask_field reads through a selection
   switch (p.kind) {
     case PK_MASK: return apply_mask(p, in);
     case PK_RENAME: return apply_rename(p, in);
