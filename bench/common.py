@@ -235,3 +235,53 @@ class Base:
     def int_roofline(self, kernels):
         return None
 
+    def overlapped_lanes(self, nl, steps):
+        """Never `value`: the same steps dealt round-robin to `nl` device lanes, each with its own copy of the workload (its own staged input, parser /
+        plan objects and host thread) — the parsequeue's shape (parse of batch N+1 beside the transform of batch N, parsequeue.go:118-154): what one lane
+        leaves idle between its kernels (read-backs, the host's share of a call) is filled by another lane's kernels."""
+        import threading
+        e = self.env
+        nl = max(1, min(nl, e.lib.lane_count()))
+        if nl < 2:
+            return None
+        go, done = threading.Barrier(nl + 1), threading.Barrier(nl + 1)
+        errs = []
+
+        def lane_main(k):
+            try:
+                e.lib.lane_use(k)
+                w = self
+                if k:
+                    w = type(self)(self.args, self.env)
+                    w.setup()
+                for _ in range(2):
+                    w.step()
+                e.lib.synchronize()
+                go.wait()
+                for i in range(steps):
+                    if i % nl == k:
+                        w.step()
+                e.lib.synchronize()
+                done.wait()
+            except Exception as ex:  # noqa: BLE001
+                errs.append(ex)
+                go.abort(); done.abort()
+        threads = [threading.Thread(target=lane_main, args=(k,)) for k in range(nl)]
+        for t in threads:
+            t.start()
+        try:
+            go.wait()
+            t0 = time.perf_counter()
+            done.wait()
+            dt = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            dt = None
+        for t in threads:
+            t.join()
+        e.lib.lane_use(0)
+        if errs or dt is None:
+            return {"error": str(errs[0])[:200] if errs else "a lane stopped"}
+        return {"lanes": nl, "steps": steps, "rows_per_s": round(self.rows() * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                "note": "the same steps dealt to several device lanes, each with its own host thread, staged input and parser / plan objects (the parsequeue's shape): "
+                        "one lane's read-backs and host work run beside another lane's kernels; never `value`"}
+

@@ -19,15 +19,15 @@ class Env:
 
 # BASELINE.json's other configurations (and the Debezium parser, the source half of configs[4]) on the default line: each runs as its OWN short bench
 # process after the headline's timed region — its own context, its own cpu_baseline / parity leg — and only a digest of its line is kept here.
-OTHER_CONFIGS = [("configs0", "configs[0]", []), ("configs2", "configs[2]", []), ("configs3", "configs[3]", []), ("configs4", "configs[4]", []), ("debezium", "configs[4] source format", [])]
+OTHER_CONFIGS = [("configs0", "configs[0]", []), ("configs2", "configs[2]", []), ("configs3", "configs[3]", []), ("configs4", "configs[4]", ["--overlap-lanes", "3"]), ("debezium", "configs[4] source format", ["--overlap-lanes", "3"])]
 
 
 def other_configs(args):
     import subprocess
     out = {}
     for w, which, extra in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--gpus", "1", "--steps", "8", "--warmup", "2", "--overlap-lanes", "0", "--pcie-steps", "0",
-               "--cpu-rows", str(1 << 16), "--cpu-all-rows", "0", "--parity-rows", str(args.parity_rows), "--other-configs", "0"] + extra
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--gpus", "1", "--steps", "8", "--warmup", "2", "--pcie-steps", "0",
+               "--cpu-rows", str(1 << 16), "--cpu-all-rows", "0", "--parity-rows", str(args.parity_rows), "--other-configs", "0"] + (extra or ["--overlap-lanes", "0"])
         t0 = time.perf_counter()
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -52,6 +52,9 @@ def other_configs(args):
                    "achieved_gb_s": rf.get("achieved"), "kernels_consistent_with_timed_region": rf.get("consistent"),
                    "parity": {"identical": bool(par.get("identical")), "checked": par.get("checked_input_rows", 0), "what": (par.get("checked") or par.get("error") or "")[:240]},
                    "cpu_port_rows_per_s": cpu.get("value"), "seconds": round(time.perf_counter() - t0, 1)}
+            ol = d.get("overlapped_lanes") or {}
+            if ol.get("rows_per_s"):  # never `value`: the same steps on three lanes (Base.overlapped_lanes) — what the one-lane figure leaves idle between its kernels, filled
+                ent["three_lanes_rows_per_s"] = ol["rows_per_s"]
             if frac is not None and frac > 1.0:
                 ent["frac"], ent["refused"] = None, "a fraction above 1 is not printed"
             out[w] = ent
@@ -202,6 +205,10 @@ def main():
     kernel_sum_ms = sum(v["ms_per_step"] for v in kernels.values())
 
     side = W.side_measurements() if hasattr(W, "side_measurements") else {}
+    if "overlapped_lanes" not in side and args.overlap_lanes > 1 and world == 1 and not getattr(e, "devices", None) and args.workload not in ("csv", "configs0", "configs2", "configs3"):
+        ol = W.overlapped_lanes(args.overlap_lanes, max(min(args.steps * passes, 60), 6))   # the message workloads: see Base.overlapped_lanes
+        if ol:
+            side = dict(side); side["overlapped_lanes"] = ol
 
     W.kernels = kernels
     alg = W.alg()
