@@ -484,3 +484,10 @@ def test_gpu_lean_length_pass_of_jsoneachrow(tf, oracle, monkeypatch):
             slow = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, db, _opts(o)).download()
             monkeypatch.delenv("TFGPU_SER_LEN_FAST")
             assert bytes(slow) == bytes(want)
+        if n >= 65:   # a slice: its text columns' offsets start above zero (ser_text_flags takes the byte range from the offsets themselves)
+            part = db.slice(16, n - 30)
+            whole = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, db, _opts({"ch_types": base})).download()
+            lines = bytes(whole).split(b"\n")
+            got = tf.serialize(abi.FMT_CH_JSON_EACH_ROW, part, _opts({"ch_types": base})).download()
+            assert bytes(got) == b"\n".join(lines[16:n - 14]) + b"\n"
+            part.free()

@@ -690,12 +690,14 @@ struct LenCol {
   int32_t repr;              // LK_INT: the Go integer type; LK_TIME_DT64: the precision
   uint32_t flag;             // LK_TEXT: index into the text flags
 };
-__global__ void __launch_bounds__(256) ser_text_flags(const LenCol *cols, const int32_t *text_cols, const uint64_t *text_bytes, uint32_t *flags) {
+__global__ void __launch_bounds__(256) ser_text_flags(const LenCol *cols, const int32_t *text_cols, int64_t nrows, uint32_t *flags) {
   const int32_t j = (int32_t)blockIdx.y;
   const LenCol c = cols[text_cols[j]];
-  const uint64_t n = text_bytes[j];
+  // the bytes the column's cells cover, from its own offsets (a sliced column starts above zero; the host's byte count only sizes the grid)
+  const uint32_t *off = (const uint32_t *)c.values;
+  const uint64_t n = off[nrows];
   bool hit = false;
-  for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (uint64_t)gridDim.x * blockDim.x * 16) {
+  for (uint64_t i = off[0] + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (uint64_t)gridDim.x * blockDim.x * 16) {
     if (i + 16 <= n) {
       const uint64_t a = load8(c.data + i), b = load8(c.data + i + 8);
       hit |= (swar_has_less(a, 0x20) | swar_has(a, '"') | swar_has(a, '\\') | swar_has_less(b, 0x20) | swar_has(b, '"') | swar_has(b, '\\')) != 0;
@@ -1212,12 +1214,12 @@ extern "C" int tfgpu_serialize_ex(int format, const tfgpu_dbatch *b, const tfgpu
         Buf blc = upload_const(lc.data(), lc.size() * sizeof(LenCol));
         Buf flags = dalloc_zero((tcols.size() + 1) * 4);
         if (!tcols.empty()) {
-          Buf btc = upload_const(tcols.data(), tcols.size() * 4), btb = upload_const(tbytes.data(), tbytes.size() * 8);
+          Buf btc = upload_const(tcols.data(), tcols.size() * 4);
           uint64_t most = 0;
           for (uint64_t x : tbytes) most = std::max(most, x);
           const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((most + 4095) / 4096, 1), 2048);
           KernelTimer t("ser_text_flags");
-          ser_text_flags<<<dim3(gx, (unsigned)tcols.size()), 256, 0, st>>>(ptr<LenCol>(blc), ptr<int32_t>(btc), ptr<uint64_t>(btb), ptr<uint32_t>(flags));
+          ser_text_flags<<<dim3(gx, (unsigned)tcols.size()), 256, 0, st>>>(ptr<LenCol>(blc), ptr<int32_t>(btc), n, ptr<uint32_t>(flags));
         }
         KernelTimer t("ser_chunk_len");
         ser_chunk_len_fast<<<grid, 256, 0, st>>>(p, cp, ptr<LenCol>(blc), ptr<uint32_t>(flags));
