@@ -768,7 +768,7 @@ int tfgpu_sr_json_parse(const tfgpu_sr_json_options *opts, const void *bytes, ui
  * scalars / enums, repeated scalars / enums (`any` columns: the array of their elements, packed or not, `[]` when absent), or singular
  * messages of singular scalar / enum fields (`any` columns: the map of ALL their fields, keys sorted; confluent.type.Decimal is built in).  tfgpu_pb_schema_info: code = TFGPU_ROW_OK and the fields, TFGPU_ROW_SR_PROTO (the text does
  * not compile / the record name does not split: every message of the schema is `_unparsed`) or TFGPU_ROW_HOST_FALLBACK with `why`
- * (oneof fields, maps with other than string keys or with message values, proto2, deeper nesting, other imports: the stock code).  policy: "debezium_style" (default) |
+ * (a oneof inside a NESTED message, maps with other than string keys or with message values, proto2, deeper nesting, other imports: the stock code; a top-level oneof's members are columns, tfgpu_pb_field.oneof).  policy: "debezium_style" (default) |
  * "message_name"; message_name: "" = the first message of the file (getRecordName).
  * tfgpu_sr_proto_parse: every Kafka message whose prefix carries schema_id.  *out: one row per good message (src_row = part_id =
  * message index); errs: row = step = message index, code = TFGPU_ROW_SR_PROTO (the bytes do not unmarshal), TFGPU_ROW_SR_SHORT /
@@ -782,7 +782,9 @@ enum { TFGPU_PB_DOUBLE = 1, TFGPU_PB_FLOAT, TFGPU_PB_INT64, TFGPU_PB_UINT64, TFG
 typedef struct tfgpu_pb_member { const char *name; int32_t number; int32_t ptype; } tfgpu_pb_member;
 typedef struct tfgpu_pb_field { const char *name; int32_t number; int32_t ptype; int32_t nmembers; const tfgpu_pb_member *members; /* of a MESSAGE field, sorted by name */
                                 int32_t repeated; /* 1: a repeated scalar / enum / one-level message field: an `any` column, the JSON array of its elements (a message element: its map);
-                                                     2: a map<string, V> field (V scalar / enum; members = {key, value}): an `any` column, {"key":value,...} with the keys in byte order */ int32_t reserved; } tfgpu_pb_field;
+                                                     2: a map<string, V> field (V scalar / enum; members = {key, value}): an `any` column, {"key":value,...} with the keys in byte order */
+                                int32_t oneof;    /* k > 0: a member of the message's k-th oneof — a column like any other; on the wire a member CLEARS the group's other members
+                                                     (the last one met is the one set; the others read their zero value / nil) */ } tfgpu_pb_field;
 typedef struct tfgpu_pb_schema tfgpu_pb_schema;
 int tfgpu_sr_compile_proto(const char *schema_text, uint64_t len, const char *policy, const char *manual_table_name, const char *message_name, tfgpu_pb_schema **out);
 int tfgpu_pb_schema_info(const tfgpu_pb_schema *s, int32_t *code, const tfgpu_pb_field **fields, int32_t *nfields, const char **table_ns, const char **table_name, const char **record, const char **why);

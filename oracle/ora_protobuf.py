@@ -52,7 +52,7 @@ def _tokens(text):
 
 class _Msg:
     def __init__(self, name, full):
-        self.name, self.full, self.fields, self.messages, self.enums = name, full, [], [], []
+        self.name, self.full, self.fields, self.messages, self.enums, self.noneof = name, full, [], [], [], 0
 
 
 class _P:
@@ -154,7 +154,28 @@ class _P:
             elif v in ("extensions", "extend", "group"):
                 raise HostOnly(v)
             elif v == "oneof":
-                raise HostOnly("oneof")   # (GetKnownFields order and the unset member's value are the dynamic message's business)
+                # oneof name { type member = N; … }: the members are fields of the message in declaration order (the descriptor's field list, which
+                # GetKnownFields walks: types_protobuf.go:103); no label, no map (language guide).  What a oneof adds is on the wire: decode_fields
+                self.next(); self.ident(); self.expect("{")
+                m.noneof += 1
+                while True:
+                    k2, v2 = self.peek()
+                    if v2 == "}" and k2 == "sym":
+                        self.next()
+                        break
+                    if k2 == "eof":
+                        raise ProtoError("unexpected end")
+                    if v2 == "option":
+                        self.skip_statement(); continue
+                    if v2 == ";":
+                        self.next(); continue
+                    if v2 == "group":
+                        raise HostOnly("group")
+                    f = self.field()
+                    if f["label"] or f["map_key"]:
+                        raise ProtoError("a oneof member takes no label and is no map")
+                    f["oneof"] = m.noneof
+                    m.fields.append(f)
             elif v == ";":
                 self.next()
             else:
@@ -195,7 +216,7 @@ class _P:
                     if depth == 0:
                         break
         self.expect(";")
-        return {"name": name, "number": int(num, 0), "label": label, "type": typ, "default": has_default, "map_key": map_key}
+        return {"name": name, "number": int(num, 0), "label": label, "type": typ, "default": has_default, "map_key": map_key, "oneof": 0}
 
 
 def _all_messages(msgs):
@@ -264,7 +285,7 @@ def compile_schema(text: str, policy: str = "debezium_style", manual_table_name:
             return list(BUILTIN[ref])
         out, seen2 = [], set()
         for f in ref.fields:
-            if f["label"] == "repeated" or f.get("map_key") or f["default"] or f["label"] == "required" or (p.syntax != "proto3"):
+            if f["label"] == "repeated" or f.get("map_key") or f["default"] or f["label"] == "required" or f.get("oneof") or (p.syntax != "proto3"):
                 raise HostOnly("a nested message the device does not walk")
             if f["number"] in seen2 or f["number"] <= 0 or f["number"] > 536870911:
                 raise ProtoError("field number")
@@ -303,16 +324,16 @@ def compile_schema(text: str, policy: str = "debezium_style", manual_table_name:
                 if k2 != "enum":
                     raise HostOnly("map with message values")
                 vt = "enum"
-            fields.append((f["name"], f["number"], "map", "any", [("key", 1, "string"), ("value", 2, vt)], True))
+            fields.append((f["name"], f["number"], "map", "any", [("key", 1, "string"), ("value", 2, vt)], True, 0))
             continue
         if f["type"] in SCALARS:
-            fields.append((f["name"], f["number"], f["type"], "any" if rep else SCALARS[f["type"]], None, rep))
+            fields.append((f["name"], f["number"], f["type"], "any" if rep else SCALARS[f["type"]], None, rep, f.get("oneof", 0)))
             continue
         kind, ref = _resolve(p, md.full, f["type"])
         if kind == "enum":
-            fields.append((f["name"], f["number"], "enum", "any" if rep else "utf8", None, rep))
+            fields.append((f["name"], f["number"], "enum", "any" if rep else "utf8", None, rep, f.get("oneof", 0)))
         else:   # (repeated: the array of the elements' maps)
-            fields.append((f["name"], f["number"], "message", "any", members_of(kind, ref, 1), rep))
+            fields.append((f["name"], f["number"], "message", "any", members_of(kind, ref, 1), rep, f.get("oneof", 0)))
     if len({f[0] for f in fields}) != len(fields):
         raise ProtoError("a field name repeats")
     return {"record": record, "ns": ns, "table": table, "fields": fields}
@@ -436,6 +457,10 @@ def decode_fields(b: bytes, fields):
             else:
                 raise HostOnly("wire type of a known field")
             continue
+        if len(f) > 6 and f[6]:   # a oneof member: setting it clears the group's other members (the dynamic message does while it unmarshals): the last one on the wire stays
+            for o in fields:
+                if o is not f and len(o) > 6 and o[6] == f[6]:
+                    out.pop(o[1], None)
         if wt != _want_wt(f[2]):
             raise HostOnly("wire type of a known field")
         if f[2] == "message":
@@ -473,7 +498,7 @@ def unpack(schema, payload: bytes):
     """unpackProtobufDynamicMessage: [(gotype, value)] in field order; nested messages as ("json", marshalled map, keys sorted)"""
     top = decode_fields(payload, schema["fields"])
     vals = []
-    for name, num, ptype, _yt, members, rep in schema["fields"]:
+    for name, num, ptype, _yt, members, rep, *_oneof in schema["fields"]:
         raw = top.get(num)
         if rep and ptype == "map":   # unpackRepeatedVal over map[interface{}]interface{}: map[string]interface{}; json.Marshal sorts the keys, a later entry of a key replaces the earlier
             entries = {}

@@ -167,6 +167,20 @@ def random_proto(rng, damage=False):
             used = saved
             nested.append("  message N%d {\n%s\n  }" % (i, "\n".join(members)))
             body.append("  %s%sN%d f%d = %d;" % (rng.choice(["", "", "repeated "]), rng.choice(["", "Value.", pkg + ".Value.", "." + pkg + ".Value."]), i, i, num()))   # protobuf's scoping: relative, partly and fully qualified; repeated: the array of the elements' maps
+    for g in range(rng.choice([0, 0, 1, 2])):   # oneof blocks: members are columns like any other; on the wire the last member met clears the others
+        mem = []
+        for k in range(rng.randrange(1, 5)):
+            if rng.random() < 0.2:
+                saved = used
+                used = set()
+                inner = ["    %s m%d = %d;" % (rng.choice(SCALAR_TYPES + ["Color"]), q, num()) for q in range(rng.choice([1, 2, 3]))]
+                used = saved
+                nested.append("  message O%d_%d {\n%s\n  }" % (g, k, "\n".join(inner)))
+                mem.append("    O%d_%d o%d_%d = %d;" % (g, k, g, k, num()))
+            else:
+                mem.append("    %s o%d_%d = %d;" % (rng.choice(SCALAR_TYPES + ["Color"]), g, k, num()))
+        block = "  oneof choice%d {\n%s\n  }" % (g, "\n".join(mem))
+        body.insert(rng.randrange(len(body) + 1), block)
     label = "intact"
     if damage:
         label = rng.choice(["repeated", "map", "oneof", "proto2", "default", "import", "unknown type", "deep", "syntax", "dup number", "reserved ok", "comment ok", "short name"])
@@ -176,8 +190,12 @@ def random_proto(rng, damage=False):
         elif label == "map":      # a key type the reference refuses ("not supported yet as a map key"), or message values
             nested.append("  message Rep { int32 x = 1; }")
             body.append(rng.choice(["  map<int32, string> mm = %d;", "  map<string, Rep> mm = %d;", "  map<bool, Color> mm = %d;"]) % num())
-        elif label == "oneof":
-            body.append("  oneof oo { int32 oa = %d; string ob = %d; }" % (num(), num()))
+        elif label == "oneof":   # a oneof inside a NESTED message (the device does not walk it), or a member with a label (a syntax error)
+            if rng.random() < 0.5:
+                nested.append("  message Rep { oneof oo { int32 oa = 1; string ob = 2; } }")
+                body.append("  Rep rr = %d;" % num())
+            else:
+                body.append("  oneof oo { repeated int32 oa = %d; string ob = %d; }" % (num(), num()))
         elif label == "proto2":
             lines[0] = 'syntax = "proto2";'
         elif label == "default":
@@ -208,14 +226,14 @@ def compile_both(text, policy="debezium_style", manual="", message_name=""):
     from transferia_amd import confluent_sr, lib
     try:
         o = P.compile_schema(text, policy, manual, message_name)
-        want = ("ok", o["record"], o["ns"], o["table"], [(f[0], f[1], PB[f[2]], sorted((m[0], m[1], PB[m[2]]) for m in (f[4] or [])), f[5]) for f in o["fields"]])
+        want = ("ok", o["record"], o["ns"], o["table"], [(f[0], f[1], PB[f[2]], sorted((m[0], m[1], PB[m[2]]) for m in (f[4] or [])), f[5]) for f in o["fields"]], [f[6] for f in o["fields"]])
     except P.ProtoError:
         want = ("proto",)
     except P.HostOnly:
         want = ("host",)
     s = confluent_sr.ProtoSchema(lib, text.encode(), policy, manual, message_name)
     if s.code == abi.ROW_OK:
-        got = ("ok", s.record, s.ns, s.table, [(n, k, t, sorted(m), rep) for n, k, t, m, rep in s.fields])
+        got = ("ok", s.record, s.ns, s.table, [(n, k, t, sorted(m), rep) for n, k, t, m, rep in s.fields], s.oneofs)
     else:
         got = ("proto",) if s.code == abi.ROW_SR_PROTO else ("host",)
     return got, want, s
@@ -282,7 +300,7 @@ def enc_field(num, ptype, rng):
 def random_message(rng, sch, weird):
     """a wire message for a compiled oracle schema; with `weird` also the shapes that do not unmarshal or go to the host"""
     parts = []
-    for name, num, ptype, _yt, members, rep in sch["fields"]:
+    for name, num, ptype, _yt, members, rep, *_oneof in sch["fields"]:
         if rng.random() < 0.2:
             continue
         if rep and ptype == "map":
@@ -706,3 +724,54 @@ def test_gpu_map_fields_and_repeated_messages(tf, oracle):
     for bad, why in ((b"map<int32, string> m = 2;", "key"), (b"map<string, P> m = 2; message P { int32 x = 1; }", "message values"), (b"repeated P m = 2; message P { repeated int32 x = 1; }", "nested")):
         s2 = confluent_sr.ProtoSchema(tf, b'syntax = "proto3"; package a.b.c; message V { int32 id = 1; ' + bad + b" }")
         assert s2.code == abi.ROW_HOST_FALLBACK and why in s2.why, (bad, s2.why)
+
+
+@pytest.mark.gpu
+def test_gpu_oneof_members_clear_each_other(tf, oracle):
+    """oneof (round 6): the members are columns like any other, in declaration order (the descriptor's field list GetKnownFields walks, types_protobuf.go:103);
+    what the oneof adds is on the wire — the dynamic message clears the group's other members when it sets one, so the LAST member met stays and the others read
+    their zero value (a message member: nil).  Device against the oracle and against literal expectations; a oneof inside a nested message and a labelled member
+    are named (stock path / a schema that does not parse).  Parity note: the reference holds no oneof vector — the semantics are protobuf's own (encoding guide:
+    "if multiple values for the same oneof are on the wire, only the last member seen is used")."""
+    from oracle import ora_protobuf as P
+    from transferia_amd import confluent_sr
+    text = (b'syntax = "proto3"; package a.b.c; message V { int32 id = 1; oneof pick { int32 a = 2; string b = 3; P c = 4; } int64 tail = 5; '
+            b'oneof other { bool x = 6; double y = 7; } message P { int32 u = 1; string w = 2; } }')
+    s = confluent_sr.ProtoSchema(tf, text)
+    assert s.code == abi.ROW_OK, s.why
+    assert [(f.name, f.dtype) for f in s.table_schema().cols] == [("id", "int32"), ("a", "int32"), ("b", "utf8"), ("c", "any"), ("tail", "int64"), ("x", "boolean"), ("y", "double")]
+    assert s.oneofs == [0, 1, 1, 1, 0, 2, 2]
+    fa = lambda v: varint(2 << 3) + varint(v)                                    # noqa: E731
+    fb = lambda t: varint(3 << 3 | 2) + varint(len(t)) + t                       # noqa: E731
+    fc = lambda u: varint(4 << 3 | 2) + varint(2) + varint(1 << 3) + varint(u)   # noqa: E731
+    ident = lambda k: varint(1 << 3) + varint(k)                                 # noqa: E731
+    bodies = [ident(0) + fa(7) + fb(b"txt"),                   # b last: a cleared
+              ident(1) + fb(b"txt") + fa(7),                   # a last: b cleared
+              ident(2) + fc(5) + fa(9) + fc(6),                # c, a, c: the second c is a NEW message (not merged with the first), a cleared
+              ident(3) + fb(b"keep") + fa(0),                  # an explicit zero still clears b
+              ident(4) + fa(3) + varint(6 << 3) + varint(1) + varint(7 << 3 | 1) + struct.pack("<d", 2.5) + varint(5 << 3) + varint(11),   # two groups do not touch each other; y last: x cleared
+              ident(5)]                                        # nothing set
+    msgs = [frame(9, m) for m in bodies]
+    want = P.parse_messages(msgs, {9: text})
+    data, m = abi.messages(msgs)
+    batch, errors = s.parse(9, data, m)
+    rows, b = device_rows(batch)
+    assert errors == {}
+    lit = [[0, 0, "txt", None, 0, False, 0.0], [1, 7, "", None, 0, False, 0.0], [2, 0, "", b'{"u":6,"w":""}', 0, False, 0.0], [3, 0, "", None, 0, False, 0.0],
+           [4, 3, "", None, 11, False, 2.5], [5, 0, "", None, 0, False, 0.0]]
+    for k in range(len(bodies)):
+        assert want[k][0] == "item"
+        for got, w in zip(rows[k], want[k][1]["values"]):
+            assert (bytes(got[1]) == w[1]) if w[0] == "json" else (abi.norm_value(got) == abi.norm_value(w)), (k, got, w)
+        for got, w in zip(rows[k], lit[k]):
+            if w is None:
+                assert got[0] == "nil", (k, got)
+            elif isinstance(w, bytes):
+                assert bytes(got[1]) == w, (k, got)
+            elif isinstance(w, str):
+                assert bytes(got[1]).decode() == w, (k, got)
+            else:
+                assert got[1] == w, (k, got, w)
+    for bad, code, why in ((b"P q = 2; message P { oneof o { int32 x = 1; string y = 2; } }", abi.ROW_HOST_FALLBACK, "nested"), (b"oneof o { repeated int32 x = 2; }", abi.ROW_SR_PROTO, "label")):
+        s2 = confluent_sr.ProtoSchema(tf, b'syntax = "proto3"; package a.b.c; message V { int32 id = 1; ' + bad + b" }")
+        assert s2.code == code and why in s2.why, (bad, s2.code, s2.why)

@@ -177,7 +177,7 @@ class _CPbMember(C.Structure):
 
 
 class _CPbField(C.Structure):
-    _fields_ = [("name", C.c_char_p), ("number", C.c_int32), ("ptype", C.c_int32), ("nmembers", C.c_int32), ("members", C.POINTER(_CPbMember)), ("repeated", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("name", C.c_char_p), ("number", C.c_int32), ("ptype", C.c_int32), ("nmembers", C.c_int32), ("members", C.POINTER(_CPbMember)), ("repeated", C.c_int32), ("oneof", C.c_int32)]
 
 
 class ProtoSchema:
@@ -200,6 +200,7 @@ class ProtoSchema:
         self.ns, self.table, self.record = (ns.value or b"").decode(), (table.value or b"").decode(), (record.value or b"").decode()
         self.fields = [(fp[i].name.decode(), int(fp[i].number), int(fp[i].ptype), [(fp[i].members[k].name.decode(), int(fp[i].members[k].number), int(fp[i].members[k].ptype)) for k in range(fp[i].nmembers)], bool(fp[i].repeated))
                        for i in range(nf.value)]
+        self.oneofs = [int(fp[i].oneof) for i in range(nf.value)]   # k > 0: the field is a member of the message's k-th oneof
 
     def __del__(self):
         try:

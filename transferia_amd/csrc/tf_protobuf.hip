@@ -36,7 +36,7 @@ namespace tf {
 namespace pbd {
 
 enum : uint8_t { ST_OK = 0, ST_SKIP = 250 };  // other values: TFGPU_ROW_* codes
-struct DField { int32_t number, ptype, mem_off, nmem; uint32_t name_off, name_len; int32_t repeated, pad; };  // members / names: offsets into the tables below
+struct DField { int32_t number, ptype, mem_off, nmem; uint32_t name_off, name_len; int32_t repeated, oneof; };  // members / names: offsets into the tables below
 struct DMember { int32_t number, ptype; uint32_t name_off, name_len; };
 
 struct Params {
@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(128) pb_decode(Params p) {
     if (f >= 0) {
       const DField &fd = p.fields[f];
       const int64_t i = (int64_t)f * p.nmsg + m;
+      if (fd.oneof) {  // a oneof member: setting it clears the others of its group (the dynamic message does so while it unmarshals): the LAST member on the wire stays
+        for (int k = 0; k < p.nfields; k++) if (k != f && p.fields[k].oneof == fd.oneof) p.present[(int64_t)k * p.nmsg + m] = 0;
+      }
       if (fd.repeated) {  // every occurrence is an element; numeric kinds also arrive packed: a length-delimited run of them
         const int ew = want_wt(fd.ptype);
         if (fd.ptype == TFGPU_PB_MESSAGE) {
@@ -449,7 +452,7 @@ extern "C" int tfgpu_sr_proto_parse(const tfgpu_pb_schema *sch, uint32_t schema_
   members.clear();
   for (int j = 0; j < nf; j++) {
     pbd::DField &d = fields[(size_t)j];
-    d.number = fl[j].number; d.ptype = fl[j].ptype; d.mem_off = (int32_t)members.size(); d.nmem = fl[j].nmembers; d.repeated = fl[j].repeated; d.pad = 0;
+    d.number = fl[j].number; d.ptype = fl[j].ptype; d.mem_off = (int32_t)members.size(); d.nmem = fl[j].nmembers; d.repeated = fl[j].repeated; d.oneof = fl[j].oneof;
     d.name_off = (uint32_t)names.size(); d.name_len = (uint32_t)std::strlen(fl[j].name); names += fl[j].name;
     for (int k = 0; k < fl[j].nmembers; k++) {
       const tfgpu_pb_member &mb = fl[j].members[k];

@@ -9,7 +9,7 @@
 // language subset whose messages the device takes — singular and repeated scalar / enum fields, and singular message fields whose own
 // fields are singular scalars / enums (the shape of both PROTOBUF schemas in the reference's parser test) — with protobuf's scoping rule for type
 // names; since round 6 also REPEATED one-level message fields and map<string, V> fields (V scalar / enum).  Everything else is named and handed
-// to the stock code (TFGPU_ROW_HOST_FALLBACK for every message of the schema): maps keyed by anything but a string or holding messages, oneof, proto2 (required / default / groups / extensions), services, imports other than confluent/meta.proto and
+// to the stock code (TFGPU_ROW_HOST_FALLBACK for every message of the schema): maps keyed by anything but a string or holding messages, a oneof inside a nested message, proto2 (required / default / groups / extensions), services, imports other than confluent/meta.proto and
 // confluent/type/decimal.proto (whose Decimal message is built in).  A text that does not parse is TFGPU_ROW_SR_PROTO ("unable to
 // build MessageDescriptor": every message of the schema becomes `_unparsed`).
 #include <algorithm>
@@ -71,8 +71,8 @@ static std::vector<Tok> tokens(const std::string &t) {
   return out;
 }
 
-struct FieldDecl { std::string name, type, label, map_key; long long number = 0; bool has_default = false, is_map = false; };
-struct Msg { std::string name, full; std::vector<FieldDecl> fields; std::vector<std::unique_ptr<Msg>> messages; std::vector<std::string> enums; };
+struct FieldDecl { std::string name, type, label, map_key; long long number = 0; bool has_default = false, is_map = false; int oneof = 0; /* k > 0: a member of the message's k-th oneof */ };
+struct Msg { std::string name, full; std::vector<FieldDecl> fields; std::vector<std::unique_ptr<Msg>> messages; std::vector<std::string> enums; int noneof = 0; };
 
 struct Parser {
   std::vector<Tok> t; size_t i = 0;
@@ -140,7 +140,25 @@ struct Parser {
       if (k.kind == 2 && k.s == "message") m->messages.push_back(message(m->full));
       else if (k.kind == 2 && k.s == "enum") { next(); const std::string n = ident(); skip_block(); m->enums.push_back(m->full + "." + n); }
       else if (k.kind == 2 && (k.s == "option" || k.s == "reserved")) skip_statement();
-      else if (k.kind == 2 && (k.s == "extensions" || k.s == "extend" || k.s == "group" || k.s == "oneof")) throw HostOnly{k.s};
+      else if (k.kind == 2 && (k.s == "extensions" || k.s == "extend" || k.s == "group")) throw HostOnly{k.s};
+      else if (k.kind == 2 && k.s == "oneof") {
+        // oneof name { type member = N; … }: its members are fields of the message like any other, in declaration order (the descriptor's field list; GetKnownFields,
+        // types_protobuf.go:103) — a member takes no label and is no map (language guide); what a oneof adds is on the wire: setting a member clears the others
+        next(); ident(); expect("{");
+        const int g = ++m->noneof;
+        for (;;) {
+          const Tok q = peek();
+          if (is_sym(q, "}")) { next(); break; }
+          if (q.kind == 0) throw SyntaxError{"unexpected end"};
+          if (q.kind == 2 && q.s == "option") { skip_statement(); continue; }
+          if (is_sym(q, ";")) { next(); continue; }
+          if (q.kind == 2 && q.s == "group") throw HostOnly{"group"};
+          FieldDecl f = field();
+          if (!f.label.empty() || f.is_map) throw SyntaxError{"a oneof member takes no label and is no map"};
+          f.oneof = g;
+          m->fields.push_back(std::move(f));
+        }
+      }
       else if (is_sym(k, ";")) next();
       else m->fields.push_back(field());
     }
@@ -183,7 +201,7 @@ static const std::map<std::string, int> SCALAR = {
     {"sfixed64", TFGPU_PB_SFIXED64}, {"sint32", TFGPU_PB_SINT32}, {"sint64", TFGPU_PB_SINT64}};
 
 struct Member { std::string name; int32_t number, ptype; };
-struct Field { std::string name; int32_t number, ptype; std::vector<Member> members; bool repeated = false, map = false; };
+struct Field { std::string name; int32_t number, ptype; std::vector<Member> members; bool repeated = false, map = false; int32_t oneof = 0; };
 
 static void collect(const std::vector<std::unique_ptr<Msg>> &ms, std::map<std::string, const Msg *> &msgs, std::vector<std::string> &enums) {
   for (auto &m : ms) { msgs[m->full] = m.get(); for (auto &e : m->enums) enums.push_back(e); collect(m->messages, msgs, enums); }
@@ -241,7 +259,7 @@ static Compiled compile(const std::string &text, const std::string &policy, cons
     if (f.has_default) throw HostOnly{"default option"};
     if (f.number <= 0 || f.number > 536870911 || !seen.emplace(f.number, true).second) throw SyntaxError{"field number"};
     Field o;
-    o.name = f.name; o.number = (int32_t)f.number; o.repeated = f.label == "repeated";
+    o.name = f.name; o.number = (int32_t)f.number; o.repeated = f.label == "repeated"; o.oneof = f.oneof;
     if (f.is_map) {
       // map<string, V>: on the wire a repeated entry message {K key = 1; V value = 2;}; the dynamic message holds a Go map, unpackRepeatedVal
       // (types_protobuf.go:57-71) takes string keys only and json.Marshal writes the map's keys in byte order — an `any` column
@@ -266,7 +284,7 @@ static Compiled compile(const std::string &text, const std::string &policy, cons
     else {
       std::map<long long, bool> seen2;
       for (auto &g : ref->fields) {
-        if (g.label == "repeated" || g.is_map || g.has_default || g.label == "required") throw HostOnly{"a nested message the device does not walk"};
+        if (g.label == "repeated" || g.is_map || g.has_default || g.label == "required" || g.oneof) throw HostOnly{"a nested message the device does not walk"};
         if (g.number <= 0 || g.number > 536870911 || !seen2.emplace(g.number, true).second) throw SyntaxError{"field number"};
         auto s2 = SCALAR.find(g.type);
         if (s2 != SCALAR.end()) { o.members.push_back({g.name, (int32_t)g.number, s2->second}); continue; }
@@ -300,7 +318,7 @@ struct tfgpu_pb_schema {
       for (auto &m : f.members) ms.push_back(tfgpu_pb_member{m.name.c_str(), m.number, m.ptype});
       cmembers.push_back(std::move(ms));
     }
-    for (size_t i = 0; i < c.fields.size(); i++) cfields.push_back(tfgpu_pb_field{c.fields[i].name.c_str(), c.fields[i].number, c.fields[i].ptype, (int32_t)cmembers[i].size(), cmembers[i].empty() ? nullptr : cmembers[i].data(), c.fields[i].map ? 2 : (c.fields[i].repeated ? 1 : 0), 0});
+    for (size_t i = 0; i < c.fields.size(); i++) cfields.push_back(tfgpu_pb_field{c.fields[i].name.c_str(), c.fields[i].number, c.fields[i].ptype, (int32_t)cmembers[i].size(), cmembers[i].empty() ? nullptr : cmembers[i].data(), c.fields[i].map ? 2 : (c.fields[i].repeated ? 1 : 0), c.fields[i].oneof});
   }
 };
 
