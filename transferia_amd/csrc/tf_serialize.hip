@@ -488,7 +488,8 @@ __device__ __forceinline__ DCol rec_dcol(uint32_t rec) {
 #ifndef TF_SER_LEN_ATTR
 #define TF_SER_LEN_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-// … and for the write pass (9 KiB of image per wave: 16 waves x 9 KiB per CU; measured 3.04 -> 2.8 ms with a lookahead of four)
+// … and for the write pass (9 KiB of image per wave: 16 waves x 9 KiB per CU; measured 3.04 -> 2.8 ms with a lookahead of four in round 3; on round 6's
+// kernels and 144-byte chunks a lookahead of 1 / 2 / 3 / 4 / 6 / 8 gives 2.71 / 2.39 / 2.42 / 2.45 / 2.50 / 2.56 ms: two, profiles/r28e_*, r28f_*)
 #ifndef TF_SER_WRITE_ATTR
 #define TF_SER_WRITE_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
@@ -496,7 +497,7 @@ __device__ __forceinline__ DCol rec_dcol(uint32_t rec) {
 #define TF_SER_LEN_AHEAD 8
 #endif
 #ifndef TF_SER_WRITE_AHEAD
-#define TF_SER_WRITE_AHEAD 4
+#define TF_SER_WRITE_AHEAD 2
 #endif
 constexpr int LEN_AHEAD = TF_SER_LEN_AHEAD, WRITE_AHEAD = TF_SER_WRITE_AHEAD;
 template <int FMT, class S> __device__ __forceinline__ void walk_cell(S &s, const SerParams &p, uint32_t rec, const CellBits &b, bool &first) {
@@ -959,8 +960,11 @@ static ChunkSetup make_chunk_setup(const tfgpu_dbatch *b, int format, const std:
   Buf &bcut = cs.bcut, &brecs = cs.brecs, &cell = cs.cell;
   const int ncols = (int)order.size();
   // the cuts: consecutive columns until the ESTIMATED text of a row's chunk passes the target (64 rows of a chunk share a 9 KiB
-  // image, i.e. 144 bytes per row; an estimate that is off only sends more tiles down the direct path)
-  static const uint32_t target = [] { const char *e = std::getenv("TFGPU_SER_CHUNK_BYTES"); return e ? (uint32_t)std::atoi(e) : 112u; }();
+  // image, i.e. 144 bytes per row; an estimate that is off only sends more tiles down the direct path).  The target IS the image's
+  // 144 bytes since round 6 (112 until then): swept again on the round's kernels — 112 / 128 / 136 / 144 / 152 / 160 / 192 give a write
+  // pass of 2.55 / 2.43 / 2.39 / 2.36 / 2.47 / 2.60 / 3.03 ms on configs[3] and 0.61 / 0.51 / - / 0.49 on configs[2] (profiles/r28c_*,
+  // r28d_*): fewer, fuller tiles win until the tiles that outgrow the image (and write straight to HBM) take over
+  static const uint32_t target = [] { const char *e = std::getenv("TFGPU_SER_CHUNK_BYTES"); return e ? (uint32_t)std::atoi(e) : 144u; }();
   std::vector<int32_t> cut{0};
   double acc = 0;
   for (int j = 0; j < ncols; j++) {
