@@ -729,7 +729,13 @@ __device__ __forceinline__ uint32_t len_of_value(const LenCol &c, uint64_t v, in
     }
   }
 }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) ser_chunk_len_fast(SerParams p, ChunkPlan cp, const LenCol *cols, const uint32_t *flags) {
+#ifndef TF_SER_LENFAST_ATTR
+#define TF_SER_LENFAST_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+#ifndef TF_SER_LENFAST_G
+#define TF_SER_LENFAST_G 8
+#endif
+__global__ void __launch_bounds__(256) TF_SER_LENFAST_ATTR ser_chunk_len_fast(SerParams p, ChunkPlan cp, const LenCol *cols, const uint32_t *flags) {
   const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   int32_t k; int64_t r0;
   tile_of(cp, tile, k, r0);
@@ -739,7 +745,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
   if (rl >= p.nrows) return;
   const int64_t r = rl;
   uint32_t total = 0;
-  constexpr int G = 8;
+  constexpr int G = TF_SER_LENFAST_G;
   for (int32_t cg = c0; cg < c1; cg += G) {
     uint64_t v[G]; int32_t ns[G]; uint32_t ok = 0;   // (a text cell's two offsets ride in v: 26 registers of loads in flight, not 50)
 #pragma unroll
