@@ -254,7 +254,7 @@ class Base:
                 if k:
                     w = type(self)(self.args, self.env)
                     w.setup()
-                for _ in range(2):
+                for _ in range(6):   # the lane's block cache has to have seen every size the step asks for: a hipMalloc inside the timed region stalls EVERY lane
                     w.step()
                 e.lib.synchronize()
                 go.wait()

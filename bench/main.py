@@ -206,8 +206,13 @@ def main():
 
     side = W.side_measurements() if hasattr(W, "side_measurements") else {}
     if "overlapped_lanes" not in side and args.overlap_lanes > 1 and world == 1 and not getattr(e, "devices", None) and args.workload not in ("csv", "configs0", "configs2", "configs3"):
-        ol = W.overlapped_lanes(args.overlap_lanes, max(min(args.steps * passes, 60), 6))   # the message workloads: see Base.overlapped_lanes
-        if ol:
+        ols = [W.overlapped_lanes(args.overlap_lanes, max(min(args.steps * passes, 60), 6)) for _ in range(int(os.environ.get("TFGPU_BENCH_OL_REPEAT", "3")))]   # the message workloads: see Base.overlapped_lanes
+        ols = [o for o in ols if o]
+        if ols:
+            good = sorted((o for o in ols if "rows_per_s" in o), key=lambda o: o["rows_per_s"])
+            ol = dict(good[len(good) // 2]) if good else ols[0]   # the median of the repeats; all of them listed
+            if good:
+                ol["repeats_rows_per_s"] = [o["rows_per_s"] for o in ols if "rows_per_s" in o]
             side = dict(side); side["overlapped_lanes"] = ol
 
     W.kernels = kernels
