@@ -10,21 +10,40 @@
 namespace tf {
 namespace dev {
 
+// decimal digits of v without a division: compares against the powers of ten (32-bit ones while v fits 32 bits)
+__device__ __forceinline__ int digits_u64(uint64_t v) {
+  if (!(v >> 32)) {
+    const uint32_t x = (uint32_t)v;
+    return 1 + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) + (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
+  }
+  return 10 + (v >= 10000000000ull) + (v >= 100000000000ull) + (v >= 1000000000000ull) + (v >= 10000000000000ull) + (v >= 100000000000000ull) +
+         (v >= 1000000000000000ull) + (v >= 10000000000000000ull) + (v >= 100000000000000000ull) + (v >= 1000000000000000000ull) + (v >= 10000000000000000000ull);
+}
+// strconv.FormatUint(v, 10): the digits are written from the back in 9-digit pieces of 32-bit arithmetic (a 64-bit `/ 10` a digit
+// and a reversed copy through a second local array is what this replaced: 147 us of sharder_crc32 per 2^20 int64 keys)
 __device__ __forceinline__ int fmt_u64(uint8_t *dst, uint64_t v) {
-  uint8_t tmp[20];
-  int n = 0;
-  do { tmp[n++] = (uint8_t)('0' + v % 10); v /= 10; } while (v);
-  for (int i = 0; i < n; i++) dst[i] = tmp[n - 1 - i];
+  const int n = digits_u64(v);
+  int i = n;
+  uint32_t top;
+  if (v >> 32) {
+    const uint64_t q = v / 1000000000ull;
+    uint32_t lo = (uint32_t)(v - q * 1000000000ull);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { dst[--i] = (uint8_t)('0' + lo % 10u); lo /= 10u; }
+    if (q >> 32) {
+      const uint32_t q2 = (uint32_t)(q / 1000000000ull);
+      uint32_t mid = (uint32_t)(q - (uint64_t)q2 * 1000000000ull);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { dst[--i] = (uint8_t)('0' + mid % 10u); mid /= 10u; }
+      top = q2;
+    } else top = (uint32_t)q;
+  } else top = (uint32_t)v;
+  do { dst[--i] = (uint8_t)('0' + top % 10u); top /= 10u; } while (top);
   return n;
 }
 __device__ __forceinline__ int fmt_i64(uint8_t *dst, int64_t v) {
   if (v < 0) { dst[0] = '-'; return 1 + fmt_u64(dst + 1, (uint64_t)(-(v + 1)) + 1u); }
   return fmt_u64(dst, (uint64_t)v);
-}
-__device__ __forceinline__ int digits_u64(uint64_t v) {
-  int n = 1;
-  while (v >= 10) { v /= 10; n++; }
-  return n;
 }
 
 __device__ __forceinline__ int64_t floordiv(int64_t a, int64_t b) {

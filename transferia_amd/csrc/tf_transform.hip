@@ -1058,6 +1058,60 @@ __global__ void __launch_bounds__(256) sharder_kernel(SharderParams p) {
   uint32_t crc = 0xFFFFFFFFu;
   for (int i = 0; i < p.ncols; i++) {
     if (i) crc = crc32_update(crc, '.', tab);
+    {  // an integer key (the usual one): its digits go from registers into the CRC, most significant first — no text buffer
+      const DCol &c = p.cols[i];
+      bool isint = true, neg = false;
+      uint64_t mag = 0;
+      if (c.repr == 0 || !is_valid(c, r)) isint = false;
+      else switch (c.repr) {
+        case TFGPU_R_INT8: { const int64_t v = ((const int8_t *)c.values)[r]; neg = v < 0; mag = neg ? (uint64_t)(-v) : (uint64_t)v; break; }
+        case TFGPU_R_INT16: { const int64_t v = ((const int16_t *)c.values)[r]; neg = v < 0; mag = neg ? (uint64_t)(-v) : (uint64_t)v; break; }
+        case TFGPU_R_INT32: { const int64_t v = ((const int32_t *)c.values)[r]; neg = v < 0; mag = neg ? (uint64_t)(-v) : (uint64_t)v; break; }
+        case TFGPU_R_INT64: { const int64_t v = ((const int64_t *)c.values)[r]; neg = v < 0; mag = neg ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v; break; }
+        case TFGPU_R_UINT8: mag = ((const uint8_t *)c.values)[r]; break;
+        case TFGPU_R_UINT16: mag = ((const uint16_t *)c.values)[r]; break;
+        case TFGPU_R_UINT32: mag = ((const uint32_t *)c.values)[r]; break;
+        case TFGPU_R_UINT64: mag = ((const uint64_t *)c.values)[r]; break;
+        default: isint = false;
+      }
+      if (isint) {
+        if (neg) crc = crc32_update(crc, '-', tab);
+        bool started = false;
+        auto piece = [&](uint32_t x, bool last) {  // nine digits of x < 10^9; leading zeros of the number are not part of its text
+          uint32_t pw = 100000000u;
+#pragma unroll
+          for (int k = 0; k < 9; k++) {
+            const uint32_t d = x / pw; x -= d * pw; pw /= 10u;
+            started = started || d != 0 || (last && k == 8);
+            if (started) crc = crc32_update(crc, (uint8_t)('0' + d), tab);
+          }
+        };
+        if (mag >> 32) {
+          const uint64_t q = mag / 1000000000ull;
+          const uint32_t lo = (uint32_t)(mag - q * 1000000000ull);
+          if (q >> 32) {
+            const uint32_t q2 = (uint32_t)(q / 1000000000ull);
+            const uint32_t d1 = q2 / 10u;  // q2 <= 18
+            if (d1) crc = crc32_update(crc, (uint8_t)('0' + d1), tab);
+            crc = crc32_update(crc, (uint8_t)('0' + (q2 - d1 * 10u)), tab);
+            started = true;
+            piece((uint32_t)(q - (uint64_t)q2 * 1000000000ull), false);
+          } else {
+            const uint32_t qq = (uint32_t)q;  // 1 .. 4 294 967 295: ten digits at most
+            const uint32_t d9 = qq / 1000000000u;
+            if (d9) { crc = crc32_update(crc, (uint8_t)('0' + d9), tab); started = true; }
+            piece(qq - d9 * 1000000000u, false);
+          }
+          piece(lo, true);
+        } else {
+          const uint32_t x = (uint32_t)mag;
+          const uint32_t d9 = x / 1000000000u;
+          if (d9) { crc = crc32_update(crc, (uint8_t)('0' + d9), tab); started = true; }
+          piece(x - d9 * 1000000000u, true);
+        }
+        continue;
+      }
+    }
     uint8_t buf[64]; const uint8_t *ext = nullptr; int len;
     if (p.cols[i].repr == 0) { buf[0] = '<'; buf[1] = 'n'; buf[2] = 'i'; buf[3] = 'l'; buf[4] = '>'; len = 5; }
     else len = serialize_small(p.cols[i], r, buf, &ext);
