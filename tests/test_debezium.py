@@ -506,7 +506,13 @@ def test_gpu_toasted_stream_stays_on_the_device(tf, oracle):
     a = col.download()
     want = oracle.collapse_rows(rows_in)
     from collapse_cases import items_of as rows_as_items
-    assert a.col_order is not None  # some chain starts with an Update that leaves `name` out and meets one that lists it: names out of batch order
+    # a chain that starts with an Update leaving a column out and meets one that lists it has its names out of batch order: the batch then
+    # carries every row's own order (the committed seed's stream holds such chains; a soak seed's may not — found by seed 603)
+    batch_names = [c.name for c in a.cols]
+    out_of_order = any(r["kind"] != "delete" and r["names"] != [x for x in batch_names if x in r["names"]] for r in want)
+    if out_of_order:
+        assert getattr(a, "col_order", None) is not None
+    assert out_of_order or SEED0 != 0
     assert [(r["kind"], r["src"], r["names"]) for r in want] == [(g["kind"], g["src"], [] if g["kind"] == "delete" else g["names"]) for g in rows_as_items(a)]
     # the native queue format and the Debezium emitter over the collapsed rows, against the oracle reading the same (downloaded) rows
     n = len(msgs)

@@ -182,6 +182,40 @@ def test_random_parity_mask_tostring_sharder(tf, oracle, n):
         assert len(errs) == len(ref.errors)
 
 
+def test_integer_digit_boundaries_through_tostring_and_sharder(tf, oracle):
+    """strconv.FormatInt / FormatUint on the device work in 9-digit pieces of 32-bit arithmetic, and the sharder feeds an integer key's
+    digits to the CRC straight from registers (to_string.go:145-178, sharder.go:130-145): every power of ten and of two around which a
+    piece or a digit count changes, both signs, every integer repr — against the oracle."""
+    pts = {0, 1, 9, 10, 11, 99, 100, 101}
+    for e in range(1, 20):
+        pts.update({10**e - 1, 10**e, 10**e + 1})
+    for e in (7, 8, 15, 16, 31, 32, 33, 62, 63, 64):
+        pts.update({2**e - 1, 2**e, 2**e + 1})
+    pts.update({4294967295999999999, 4294967296000000000, 999999999999999999, 1000000000000000000, 18446744073709551615, 9223372036854775807})
+    cols = []
+    for name, r, dt in [("i8", abi.R_INT8, "int8"), ("i16", abi.R_INT16, "int16"), ("i32", abi.R_INT32, "int32"), ("i64", abi.R_INT64, "int64"),
+                        ("u8", abi.R_UINT8, "uint8"), ("u16", abi.R_UINT16, "uint16"), ("u32", abi.R_UINT32, "uint32"), ("u64", abi.R_UINT64, "uint64")]:
+        info = np.iinfo(abi.REPR_NP[r])
+        vals = sorted({v for x in pts for v in (x, -x, -x - 1) if info.min <= v <= info.max} | {int(info.min), int(info.max)})
+        cols.append((name, dt, r, vals))
+    n = max(len(c[3]) for c in cols)
+    bcols = []
+    for name, dt, r, vals in cols:
+        a = np.array([vals[i % len(vals)] for i in range(n)], dtype=abi.REPR_NP[r])
+        bcols.append(abi.Column(name, dt, r, values=a, validity=(np.arange(n) % 17 != 5) if name == "i32" else None))
+    b = abi.Batch(bcols, n, "db", "tbl")
+    schema = abi.Schema.of([[c.name, c.dtype, c.name == "i64"] for c in bcols])
+    cases = [("convert_to_string", {})] + [("sharder_transformer", {"shardsCount": "1000003", "columns": {"includeColumns": ["^%s$" % c.name]}}) for c in bcols]
+    cases.append(("sharder_transformer", {"shardsCount": "65521"}))
+    for type_name, cfg in cases:
+        t, out, errs = run_gpu(tf, type_name, cfg, b)
+        ref = oracle.Transformer(type_name, cfg).apply(b, schema)
+        assert_batches_equal(out, ref.batch, f"{type_name} {cfg}")
+        if type_name == "sharder_transformer":
+            assert np.array_equal(out.part_id, ref.batch.part_id), cfg
+        assert len(errs) == len(ref.errors)
+
+
 @pytest.mark.parametrize("n", [1, 64, 4097, 50000])
 def test_random_parity_filter_rows(tf, oracle, n):
     rng = np.random.default_rng(SEED0 + (7 * n + 1))

@@ -78,7 +78,8 @@ def test_serializer_and_sr_resources():
     assert find(t, "ser_text_flags")["scratch"] == 0
     assert len(walks) == 6 and min(v["scratch"] for v in walks.values()) == 0 and max(v["scratch"] for v in walks.values()) <= 64
     assert all(v["vgpr"] <= 128 for v in walks.values())  # four waves per SIMD (and four workgroups of 4 x 9 KiB LDS per CU): the walks are latency-bound
-    assert find(t, "ser_fill_const")["vgpr"] <= 16
+    fc = find(t, "ser_fill_const")  # a wave per (row, 2 KiB piece): full occupancy, nothing spilled
+    assert fc["vgpr"] <= 32 and fc["scratch"] == 0
     t = kernel_table("tf_srjson.hip")
     # the parse kernel keeps per-depth key spans for the `any` order check in scratch (2 x 128 words) and nothing more
     assert find(t, "sr_parse_frames")["scratch"] <= 2048 and find(t, "sr_count_frames")["scratch"] == 0

@@ -802,21 +802,28 @@ __global__ void __launch_bounds__(256) queue_first_listed(const uint8_t *const *
   } else for (int j = 0; j < ncols; j++) if (!absent[j] || !((absent[j][r >> 3] >> (r & 7)) & 1u)) { f = j; break; }
   first[r] = f;
 }
-// A long constant cell (column names, table schema) of every row: one workgroup per (row, 4 KiB chunk), 16 bytes per lane,
-// so a wave stores 1 KiB of consecutive bytes per step instead of one lane walking kilobytes.
-__global__ void __launch_bounds__(256) ser_fill_const(SerParams p, int32_t ci, uint32_t chunks) {
-  const int64_t r = blockIdx.x / chunks; const uint32_t ch = blockIdx.x % chunks;
+// A long constant cell (column names, table schema) of every row: one WAVE per (row, 2 KiB piece) — a workgroup per (row, 4 KiB chunk)
+// left most of its 256 lanes without a byte to move for the few hundred bytes to a few KiB such a cell holds, and the launch was bound by
+// its 10^5..10^6 workgroups.  The destination's alignment decides the split: bytes up to its next 16-byte boundary, aligned 16-byte
+// stores, a byte tail; the source is a few cache-resident KiB of the blob wherever it sits.
+constexpr uint32_t QFILL_PIECE = 2048;
+__global__ void __launch_bounds__(256) ser_fill_const(SerParams p, int32_t ci, uint32_t pieces) {
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const int64_t r = item / pieces; const uint32_t piece = (uint32_t)(item % pieces);
+  if (r >= p.nrows) return;
   const SCol &sc = p.cols[ci];
   if (!q_applies(p, sc.apply, r)) return;
-  struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
   const uint8_t *src = p.blob + sc.pre_off;
   uint8_t *dst = p.out + (uint64_t)p.row_len[r] + p.cell[(int64_t)ci * p.nrows + r];
-  const uint32_t o = ch * 4096u + threadIdx.x * 16u;
-  if (o >= sc.pre_len) return;
-  if (o + 16u <= sc.pre_len) {
-    const uint64_t a = reinterpret_cast<const U64 *>(src + o)->v, b = reinterpret_cast<const U64 *>(src + o + 8)->v;
-    reinterpret_cast<U64 *>(dst + o)->v = a; reinterpret_cast<U64 *>(dst + o + 8)->v = b;
-  } else for (uint32_t i = o; i < sc.pre_len; i++) dst[i] = src[i];
+  const uint32_t a = piece * QFILL_PIECE, b = min(a + QFILL_PIECE, sc.pre_len);
+  const uint32_t head = min((uint32_t)((16 - ((uintptr_t)(dst + a) & 15)) & 15), b - a);
+  if (lane < head) dst[a + lane] = src[a + lane];
+  const uint32_t a16 = a + head, quads = (b - a16) / 16;
+  struct __attribute__((packed, aligned(1))) U128 { uint32_t x, y, z, w; };
+  for (uint32_t q = lane; q < quads; q += 64) { const U128 v = reinterpret_cast<const U128 *>(src + a16)[q]; reinterpret_cast<uint4 *>(dst + a16)[q] = make_uint4(v.x, v.y, v.z, v.w); }
+  const uint32_t t0 = a16 + quads * 16;
+  if (lane < b - t0) dst[t0 + lane] = src[t0 + lane];
 }
 // which row kinds occur (bit k = kind k), and whether every src_row indexes the row meta
 __global__ void queue_check_kernel(const uint8_t *kind, const int32_t *src_row, int64_t n, int64_t meta_n, uint32_t *flags) {
@@ -1895,9 +1902,11 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
     p.out = ptr<uint8_t>(res->mem);
     { KernelTimer t("ser_cell_write"); if (ncell && n) ser_cell_write<<<dim3(blocks(n), (unsigned)ncell), 256, 0, st>>>(p); }
     for (int ci = 0; ci < ncell; ci++) if (sc[(size_t)ci].kind == QC_CONST && sc[(size_t)ci].pre_len > QCONST_INLINE) {
-      const uint32_t chunks = (sc[(size_t)ci].pre_len + 4095u) / 4096u;
+      const uint32_t pieces = (sc[(size_t)ci].pre_len + QFILL_PIECE - 1) / QFILL_PIECE;
+      const uint64_t items = (uint64_t)n * pieces;
+      if (items > 0x1FFFFFFFFull) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: too many rows for one call");
       KernelTimer t("ser_fill_const");
-      ser_fill_const<<<(unsigned)(n * chunks), 256, 0, st>>>(p, ci, chunks);
+      ser_fill_const<<<(unsigned)((items + 3) / 4), 256, 0, st>>>(p, ci, pieces);
     }
     { KernelTimer t("ser_queue_frame"); ser_queue_frame<<<blocks(n), 256, 0, st>>>(p); }
     tf::sync();  // `keep` (row meta staging) is released on return
