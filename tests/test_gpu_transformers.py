@@ -35,11 +35,13 @@ def assert_batches_equal(a: abi.Batch, b: abi.Batch, ctx=""):
         return  # the oracle's row-to-column conversion has no columns to show for an empty result
     assert [c.name for c in a.cols] == [c.name for c in b.cols], ctx
     for ca, cb in zip(a.cols, b.cols):
-        assert ca.repr == cb.repr, (ctx, ca.name, ca.repr, cb.repr)
-        assert ca.dtype == cb.dtype, (ctx, ca.name, ca.dtype, cb.dtype)
         va = ca.validity if ca.validity is not None else np.ones(a.nrows, bool)
         vb = cb.validity if cb.validity is not None else np.ones(b.nrows, bool)
+        assert ca.dtype == cb.dtype, (ctx, ca.name, ca.dtype, cb.dtype)
         assert np.array_equal(va, vb), (ctx, ca.name, "validity")
+        if not vb.any() and cb.repr != ca.repr:
+            continue  # every cell nil: the oracle's row-to-column conversion has no value to take the column's repr from (found by soak seed 615: one row, nil)
+        assert ca.repr == cb.repr, (ctx, ca.name, ca.repr, cb.repr)
         if ca.repr in abi.VAR_REPRS:
             assert np.array_equal(ca.offsets, cb.offsets), (ctx, ca.name, "offsets")
             assert bytes(ca.data[: int(ca.offsets[-1])]) == bytes(cb.data[: int(cb.offsets[-1])]), (ctx, ca.name, "data")
