@@ -507,9 +507,11 @@ def unpack(schema, payload: bytes):
                 kraw, vraw = inner.get(1), inner.get(2)
                 vt = members[1][2]
                 v = _ZERO[vt] if vraw is None else ((("string", bytes(vraw)) if vt == "string" else ("bytes", bytes(vraw))) if vt in ("string", "bytes") else _scalar(vt, 0, vraw))
-                entries[bytes(kraw) if kraw is not None else b""] = _go_json(v)
+                entries[bytes(kraw) if kraw is not None else b""] = v
             from .dbz_emitter import go_json_string
-            vals.append(("json", b"{" + b",".join(go_json_string(k) + b":" + entries[k] for k in sorted(entries)) + b"}"))
+            # (json.Marshal sees the map as it stands at the end: a value that a later entry of its key replaced — a NaN, say — never reaches it;
+            #  soak seed 623 met an oracle that rendered every entry as it came)
+            vals.append(("json", b"{" + b",".join(go_json_string(k) + b":" + _go_json(entries[k]) for k in sorted(entries)) + b"}"))
             continue
         if rep and ptype == "message":   # unpackRepeatedVal over []interface{} of *dynamic.Message: the array of their maps
             parts = []

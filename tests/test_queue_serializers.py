@@ -214,6 +214,38 @@ def test_gpu_queue_matches_oracle(tf, oracle, n):
 
 
 @pytest.mark.gpu
+def test_gpu_queue_cut_plan_sweep(tf, oracle, monkeypatch):
+    """The cut plan finds a message's end by a galloping search over the element lengths' prefix sums instead of the batchers' running sum
+    (native_batcher.go:10-63, json_batcher.go:11-66): every limit from 'no element fits' to 'everything fits', with and without an item count,
+    over groups with an empty one in the middle — against the oracle's batchers, and (TFGPU_CUT_PLAN_CHECK=1) against the literal loop inside
+    the library."""
+    monkeypatch.setenv("TFGPU_CUT_PLAN_CHECK", "1")
+    n = 331
+    rng = np.random.default_rng(SEED0 + 4242)
+    b, schema, meta = _random_case(rng, n)
+    db = tf.DeviceBatch.upload(b)
+    groups = [n // 3, 0, 1, n - n // 3 - 1]
+    for fmt in (abi.QFMT_NATIVE, abi.QFMT_JSON):
+        if fmt == abi.QFMT_JSON:
+            b.kind = np.full(n, abi.K_INSERT, np.uint8)
+            db = tf.DeviceBatch.upload(b)
+        for size in (1, 2, 40, 150, 151, 152, 300, 301, 700, 1500, 4096, 20000, 1 << 22, 0):
+            for items in (0, 1, 2, 3, 17, 1000):
+                for gr in (None, groups):
+                    kw = dict(enabled=True, max_message_size=size, max_change_items=items)
+                    if gr:
+                        kw["group_rows"] = gr
+                    if fmt == abi.QFMT_NATIVE:
+                        kw["omit_table_schema"] = True
+                    o = abi.queue_options(fmt, **kw)
+                    ref = oracle.queue_serialize(o, b, schema, meta if fmt == abi.QFMT_NATIVE else None)
+                    assert ref is not None
+                    res = tf.queue_serialize(o, db, meta if fmt == abi.QFMT_NATIVE else None)
+                    assert res.messages() == ref, (fmt, size, items, bool(gr))
+                    assert list(res.msg_row) == oracle.queue_serialize.rows, (fmt, size, items, bool(gr))
+
+
+@pytest.mark.gpu
 def test_gpu_queue_canon_corpus(tf, oracle):
     """The all-databases corpus (tests/golden/serializers_canon.json: arrays, hstore, decimals as json.Number, FixedString, YT
     composite values) as input to the native and JSON queue serializers: device against the oracle."""

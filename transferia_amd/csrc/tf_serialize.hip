@@ -1631,6 +1631,69 @@ static void queue_cut_plan(const tfgpu_queue_options *o, const uint32_t *elem_le
   if (start != n) emit(start, n);
 }
 
+// The cut plan AND the messages' places in one sweep per MESSAGE instead of two loops per ELEMENT (the two loops were 0.25-0.3 ms of
+// host time per 3 x 10^5 rows: a fifth of a configs[4] pass, profiles/r31b_timeline_configs4.txt).  Q[i] = sum over j < i of (len_j + 1)
+// turns the batchers' running test  sum + (num_new - 1) + len + wrap > max  (native_batcher.go:10-63, json_batcher.go:11-66; queue_cut_plan
+// above is its literal restatement) into  Q[i + 1] - Q[start] + wrap - 1 > max, monotone in i: the first violating element of a message
+// is found by a galloping search from its start.  An element that opens a message is never tested alone by the batchers — but an
+// element too large for a message of its own violates again with the next one and is cut off as a message of one either way, so
+// restarting the search AT it emits the same ranges (len >= 0).  A message's place: the element lengths in front of it plus one byte per
+// message closed (native: ']' joins, ',' between elements is counted in the lengths) or per element not closing one (JSON: '\n').
+static int64_t queue_cut_and_place(const tfgpu_queue_options *o, const uint32_t *elen, int64_t n, const std::vector<int64_t> &gstart, uint32_t lead, bool native,
+                                   uint8_t *flags, uint64_t *msg_start, int64_t *msg_row, int64_t cap, uint64_t *total_out) {
+  static thread_local std::vector<uint64_t> qstore;
+  if (qstore.size() < (size_t)n + 1) qstore.resize((size_t)n + 1);
+  uint64_t *Q = qstore.data();
+  {
+    uint64_t q = 0;
+    Q[0] = 0;
+    for (int64_t i = 0; i < n; i++) { q += (uint64_t)(uint32_t)(elen[i] - lead) + 1u; Q[i + 1] = q; }
+  }
+  auto pe = [&](int64_t i) { return Q[i] + (uint64_t)i * lead - (uint64_t)i; };  // sum of elen[0 .. i)
+  int64_t nm = 0;
+  auto emit = [&](int64_t a, int64_t z) {
+    flags[a] |= 1; flags[z - 1] |= 2;
+    if (nm < cap) { msg_start[nm] = pe(a) + (native ? (uint64_t)nm : (uint64_t)(a - nm)); msg_row[nm] = a; }
+    nm++;
+  };
+  const uint64_t wrap = o->format == TFGPU_QFMT_NATIVE ? 2 : 0, maxsz = (uint64_t)o->max_message_size;
+  for (size_t g = 0; g + 1 < gstart.size(); g++) {
+    const int64_t g0 = gstart[g], g1 = gstart[g + 1];
+    if (g0 == g1) continue;
+    if (!o->batching_enabled) { for (int64_t i = g0; i < g1; i++) emit(i, i + 1); continue; }
+    int64_t start = g0;
+    while (start < g1) {
+      const uint64_t q0 = Q[start];
+      auto too_big = [&](int64_t i) { return Q[i + 1] - q0 + wrap - 1 > maxsz; };  // element i joins the message that starts at `start`
+      int64_t lim = g1;  // the first element the item count refuses
+      if (o->max_change_items != 0) lim = o->max_change_items > 0 ? std::min<int64_t>(g1, start + o->max_change_items) : start;
+      int64_t iv = lim;
+      if (maxsz != 0 && lim > start) {
+        if (too_big(start)) iv = start;
+        else {  // gallop: element lo fits, the first that does not lies in (lo, hi]
+          int64_t lo = start, step = 1, hi = -1;
+          while (lo + step < lim) { if (too_big(lo + step)) { hi = lo + step; break; } lo += step; step <<= 1; }
+          if (hi < 0) { if (lo + 1 < lim && too_big(lim - 1)) hi = lim - 1; else hi = lim; }
+          if (hi < lim) { while (hi - lo > 1) { const int64_t mid = lo + ((hi - lo) >> 1); if (too_big(mid)) hi = mid; else lo = mid; } }
+          iv = hi;
+        }
+      }
+      if (iv >= g1) { emit(start, g1); break; }
+      if (iv == start) { emit(start, start + 1); start = iv + 1; }
+      else { emit(start, iv); start = iv; }
+    }
+  }
+  *total_out = pe(n) + (native ? (uint64_t)nm : (uint64_t)(n - nm));
+  // TFGPU_CUT_PLAN_CHECK=1 (tests): the literal restatement of the batchers' loop must give the same flags
+  const char *chk = std::getenv("TFGPU_CUT_PLAN_CHECK");  // (read every call: a test switches it on in a process that has serialized before)
+  if (chk && chk[0] == '1') {
+    std::vector<uint8_t> f2((size_t)n, 0);
+    for (size_t g = 0; g + 1 < gstart.size(); g++) queue_cut_plan(o, elen + gstart[g], gstart[g + 1] - gstart[g], lead, f2.data() + gstart[g]);
+    if (n && std::memcmp(f2.data(), flags, (size_t)n) != 0) throw Error(TFGPU_ERR_DEVICE, "tfgpu_queue_serialize: internal: the galloping cut plan and the batchers' loop disagree");
+  }
+  return nm;
+}
+
 template <class T> static const T *meta_array(const tfgpu_row_meta *m, const T *p, size_t count, std::vector<Buf> &keep) {
   if (!p) return nullptr;
   if (m->mem == TFGPU_MEM_DEVICE) return p;
@@ -1699,12 +1762,8 @@ static int queue_json_chunks(const tfgpu_queue_options *o, const tfgpu_dbatch *b
   // ---- the cut plan (host: the batchers' sequential greedy loop over the element lengths) ----
   CutBuffers cb(p.row_len, n);
   const uint32_t *elen = cb.elen; uint8_t *hflags = cb.flags;
-  for (size_t g = 0; g + 1 < gstart.size(); g++) queue_cut_plan(o, elen + gstart[g], gstart[g + 1] - gstart[g], 0u, hflags + gstart[g]);
-  int64_t nm = 0; uint64_t total = 0;
-  for (int64_t r = 0; r < n; r++) {
-    if (hflags[(size_t)r] & 1) { if (nm < cap) { msg_start[nm] = total; msg_row[nm] = r; } nm++; }
-    total += elen[(size_t)r] + ((hflags[(size_t)r] & 2) ? 0u : 1u);
-  }
+  uint64_t total = 0;
+  const int64_t nm = queue_cut_and_place(o, elen, n, gstart, 0u, false, hflags, msg_start, msg_row, cap, &total);
   if (nm > cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: more messages than msg_start / msg_row hold");
   if (total >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: output exceeds 4 GiB; split the batch by rows");
   msg_start[nm] = total; msg_row[nm] = n;
@@ -1888,12 +1947,8 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
     CutBuffers cb(p.row_len, n);
     const uint32_t *elen = cb.elen; uint8_t *hflags = cb.flags;
     const uint32_t lead = native ? 1u : 0u;
-    for (size_t g = 0; g + 1 < gstart.size(); g++) queue_cut_plan(o, elen + gstart[g], gstart[g + 1] - gstart[g], lead, hflags + gstart[g]);
-    int64_t nm = 0; uint64_t total = 0;
-    for (int64_t r = 0; r < n; r++) {
-      if (hflags[(size_t)r] & 1) { if (nm < cap) { msg_start[nm] = total; msg_row[nm] = r; } nm++; }
-      total += elen[(size_t)r] + (native ? ((hflags[(size_t)r] & 2) ? 1u : 0u) : ((hflags[(size_t)r] & 2) ? 0u : 1u));
-    }
+    uint64_t total = 0;
+    const int64_t nm = queue_cut_and_place(o, elen, n, gstart, lead, native, hflags, msg_start, msg_row, cap, &total);
     if (nm > cap) return tf::fail(TFGPU_ERR_INVALID, "tfgpu_queue_serialize: more messages than msg_start / msg_row hold");
     if (total >> 32) return tf::fail(TFGPU_ERR_UNSUPPORTED, "tfgpu_queue_serialize: output exceeds 4 GiB; split the batch by rows");
     msg_start[nm] = total; msg_row[nm] = n;
