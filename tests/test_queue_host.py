@@ -168,3 +168,8 @@ def test_gpu_queue_random_against_the_checker(tf):
     pid = sharded.download().part_id
     o2, c2, i2 = queue.part_groups(np.asarray(pid), 2000)
     assert order.tolist() == o2.tolist() and counts == c2 and ids == i2
+    # … and behind one with a thousand shards (the groups are looked up through a map, the last row's group first)
+    res = tf.Transformer("sharder_transformer", {"columns": {"includeColumns": ["id"]}, "shardsCount": "997"}).apply(tf.DeviceBatch.upload(hb))
+    order, counts, ids = dq.part_groups(res.transformed)
+    o2, c2, i2 = queue.part_groups(np.asarray(res.transformed.download().part_id), 2000)
+    assert order.tolist() == o2.tolist() and counts == c2 and ids == i2 and len(ids) > 500
