@@ -300,6 +300,11 @@ def test_reference_cases_diff_column_names(tf, oracle):
     assert ran >= 8
 
 
+def _soak_seed():
+    import os
+    return int(os.environ.get("TFGPU_TEST_SEED", "0")) != 0
+
+
 @pytest.mark.parametrize("shape", [dict(n=2), dict(n=60, toastable=[4]), dict(n=400, domain=3), dict(n=400, domain=40, ncols=9), dict(n=300, p_absent=0.8, weights=(1, 8, 1, 0), toastable=[4]),
                                    dict(n=300, domain=2, weights=(2, 10, 0, 1), ncols=3, toastable=[2]), dict(n=300, domain=2, weights=(2, 10, 0, 1), ncols=3),
                                    dict(n=3000, domain=300, ncols=6, toastable=[5], p_absent=0.5, p_nokey=0.0)])
@@ -321,7 +326,7 @@ def test_random_toast_batches(tf, oracle, shape):
         merged += sum(1 for r in want if len({v[1].split(b".")[0][1:] if v[0] == "string" else b"%d" % (v[1] // 10)
                                               for nm, v in zip(r["names"], r["values"]) if nm != "id" and v[0] != "nil"}) > 1)
     assert compared == 8 and (merged or shape["n"] < 10), (compared, merged)
-    assert reordered or "toastable" in shape or shape["n"] < 100, shape
+    assert reordered or "toastable" in shape or shape["n"] < 100 or _soak_seed(), shape   # (the committed streams' shape, not the product: a soak seed's streams may hold no such chain — seed 633)
 
 
 def test_merged_names_out_of_batch_order(tf, oracle):
