@@ -827,19 +827,20 @@ __global__ void __launch_bounds__(256) ser_fill_const(SerParams p, int32_t ci, u
   const uint32_t t0 = a16 + quads * 16;
   if (lane < b - t0) dst[t0 + lane] = src[t0 + lane];
 }
-// which row kinds occur (bit k = kind k), and whether every src_row indexes the row meta
-__global__ void queue_check_kernel(const uint8_t *kind, const int32_t *src_row, int64_t n, int64_t meta_n, uint32_t *flags) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// which row kinds occur (bit k = kind k), and whether every src_row indexes the row meta.  A few hundred waves stride over the rows and
+// each adds ONE atomic: a wave per 64 rows was ~5 000 atomics on one word for 3 x 10^5 rows — they all read the word as zero before the
+// first lands, and the L2 takes them one after another: 47-56 us of a kernel that reads 1.5 MB (profiles/r31b, r35b timelines)
+constexpr unsigned QCHECK_BLOCKS = 128;
+__global__ void __launch_bounds__(256) queue_check_kernel(const uint8_t *kind, const int32_t *src_row, int64_t n, int64_t meta_n, uint32_t *flags) {
   uint32_t f = 0;
-  if (r < n) {
-    f = 1u << (kind ? (kind[r] & 3u) : 0u);
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    f |= 1u << (kind ? (kind[r] & 3u) : 0u);
     if (meta_n >= 0) { const int64_t k = src_row ? src_row[r] : r; if (k < 0 || k >= meta_n) f |= 16u; }
   }
-  // one look at the flag word per WAVE (a lane each was 47 us for 3 x 10^5 rows: every lane's load of the one word the atomics keep changing)
   uint32_t w = 0;
 #pragma unroll
   for (int b = 0; b < 5; b++) if (__ballot((f >> b) & 1u)) w |= 1u << b;
-  if ((threadIdx.x & 63) == 0 && w && (w & ~__atomic_load_n(flags, __ATOMIC_RELAXED)) != 0) atomicOr(flags, w);
+  if ((threadIdx.x & 63) == 0 && w) atomicOr(flags, w);
 }
 
 static inline unsigned blocks(int64_t n) { return (unsigned)std::max<int64_t>(1, (n + 255) / 256); }
@@ -1825,7 +1826,7 @@ extern "C" int tfgpu_queue_serialize(const tfgpu_queue_options *o, const tfgpu_d
 
     // ---- what must fail the call before any text exists: kinds, meta range, NaN / Inf ----
     Buf flags = dalloc_zero(8);
-    queue_check_kernel<<<blocks(n), 256, 0, st>>>(ptr<uint8_t>(b->kind), ptr<int32_t>(b->src_row), n, (native && meta) ? meta->n : -1, ptr<uint32_t>(flags));
+    queue_check_kernel<<<std::min(blocks(n), QCHECK_BLOCKS), 256, 0, st>>>(ptr<uint8_t>(b->kind), ptr<int32_t>(b->src_row), n, (native && meta) ? meta->n : -1, ptr<uint32_t>(flags));
     auto nonfinite = [&](const DColumn &c) {
       if (c.repr != TFGPU_R_FLOAT32 && c.repr != TFGPU_R_FLOAT64) return;
       float_nonfinite_kernel<<<blocks(n), 256, 0, st>>>(c.values->p, n, c.repr == TFGPU_R_FLOAT32, ptr<uint8_t>(c.validity), ptr<uint32_t>(flags) + 1);
