@@ -768,22 +768,35 @@ __global__ void __launch_bounds__(256) dbz_cell_len(EParams p) {
   }
   p.cell[(int64_t)ci * p.nev + e] = n;
 }
+// A stream's running total takes ONE atomic per workgroup: an atomic per wave was ~6 000 of them on one word per 4 x 10^5 events, and the L2 takes them one
+// after another at ~9 ns apiece — half of dbz_walk_len's duration.  Every thread of the workgroup calls it (256 threads).
+__device__ __forceinline__ void add_total64(unsigned long long *total, unsigned long long sum) {
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t lo = __shfl_down((uint32_t)sum, d, 64), hi = __shfl_down((uint32_t)(sum >> 32), d, 64);
+    if ((int)(threadIdx.x & 63) + d < 64) sum += ((unsigned long long)hi << 32) | lo;
+  }
+  __shared__ unsigned long long wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { const unsigned long long t = wsum[0] + wsum[1] + wsum[2] + wsum[3]; if (t) atomicAdd(total, t); }
+}
 __global__ void __launch_bounds__(256) dbz_event_layout(EParams p) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= p.nev) return;
   uint32_t off = 0;
-  constexpr int U = 8;
-  int32_t c = 0;
-  for (; c + U <= p.ncells; c += U) {
-    uint32_t n[U];
+  if (e < p.nev) {  // (no early return: every wave meets the one barrier inside add_total64 exactly once)
+    constexpr int U = 8;
+    int32_t c = 0;
+    for (; c + U <= p.ncells; c += U) {
+      uint32_t n[U];
 #pragma unroll
-    for (int q = 0; q < U; q++) n[q] = p.cell[(int64_t)(c + q) * p.nev + e];
+      for (int q = 0; q < U; q++) n[q] = p.cell[(int64_t)(c + q) * p.nev + e];
 #pragma unroll
-    for (int q = 0; q < U; q++) { p.cell[(int64_t)(c + q) * p.nev + e] = off; off += n[q]; }
+      for (int q = 0; q < U; q++) { p.cell[(int64_t)(c + q) * p.nev + e] = off; off += n[q]; }
+    }
+    for (; c < p.ncells; c++) { const uint32_t n = p.cell[(int64_t)c * p.nev + e]; p.cell[(int64_t)c * p.nev + e] = off; off += n; }
+    p.ev_len[e] = off;
   }
-  for (; c < p.ncells; c++) { const uint32_t n = p.cell[(int64_t)c * p.nev + e]; p.cell[(int64_t)c * p.nev + e] = off; off += n; }
-  p.ev_len[e] = off;
-  atomicAdd(p.total64, (unsigned long long)off);
+  add_total64(p.total64, (unsigned long long)off);
 }
 __global__ void __launch_bounds__(256) dbz_cell_write(EParams p) {
   const int32_t ci = (int32_t)blockIdx.y; const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -803,18 +816,19 @@ __global__ void __launch_bounds__(256) dbz_cell_write(EParams p) {
 // pass keeps one running count, the write pass one running pointer, and the place of a long constant is noted for dbz_fill_const as the walk passes it.
 __global__ void __launch_bounds__(256) dbz_walk_len(EParams p) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= p.nev) return;
-  const int64_t r = p.ev_row ? p.ev_row[e] : e;
   CountSink s;
-  for (int32_t ci = 0; ci < p.ncells; ci++) {
-    const ECell &ec = p.cells[ci];
-    if (!applies(p, ec.apply, e, r)) continue;
-    if (ec.kind == EC_CONST) { s.n += ec.pre_len; continue; }
-    const int rc = emit_cell(s, p, ec, e, r);
-    if (rc) atomicMin(&p.err[rc - 1], ((unsigned long long)e << 16) | (unsigned long long)ci);
+  if (e < p.nev) {  // (no early return: every wave meets the one barrier inside add_total64 exactly once)
+    const int64_t r = p.ev_row ? p.ev_row[e] : e;
+    for (int32_t ci = 0; ci < p.ncells; ci++) {
+      const ECell &ec = p.cells[ci];
+      if (!applies(p, ec.apply, e, r)) continue;
+      if (ec.kind == EC_CONST) { s.n += ec.pre_len; continue; }
+      const int rc = emit_cell(s, p, ec, e, r);
+      if (rc) atomicMin(&p.err[rc - 1], ((unsigned long long)e << 16) | (unsigned long long)ci);
+    }
+    p.ev_len[e] = s.n;
   }
-  p.ev_len[e] = s.n;
-  atomicAdd(p.total64, (unsigned long long)s.n);
+  add_total64(p.total64, (unsigned long long)s.n);
 }
 __global__ void __launch_bounds__(256) dbz_walk_write(EParams p, uint32_t *const_at /* [long constants][nev] */) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
